@@ -1,0 +1,575 @@
+"""Synthetic sliding-window inputs: street-canyon scene, trajectory, LiDAR scans,
+0.4 m voxel map, IMU pre-integrations, GNSS DD-pseudorange / Doppler measurements and a prior.
+
+Everything here is INPUT PREPARATION that the reference does on the host before the hot path
+(`Preintegration::push_back`, GLIO/include/factors/Preintegration.h:73-194; `downSampleCloud`,
+GLIO/src/Estimator.cpp:3618-3631; the GNSS weight matrix, Estimator.cpp:2350-2357).  Seeds follow
+SURVEY.md: base 20260925.
+"""
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import ctypes_types as T
+
+SEED_BASE = 20260925
+ANCHOR_ECEF = np.array([-2419233.42, 5385473.13, 2405341.30])       # config_urban_hk.yaml:29-31
+STATION_ECEF = np.array([-2414266.9200, 5386768.9870, 2407460.0310])  # yaml:40-42
+GRAVITY = 9.80511                                                   # yaml:11
+ACC_N, GYR_N, ACC_W, GYR_W = 3.9939570888238808e-03, 1.5636343949698187e-03, 6.4356659353532566e-05, 3.5640318696367613e-05
+LIGHT_SPEED = 2.99792458e8
+EARTH_OMG = 7.2921151467e-5
+L1_LAMBDA = LIGHT_SPEED / 1575.42e6
+
+
+# ------------------------------------------------------------------ quaternion helpers (w,x,y,z)
+def qmul(a, b):
+    w1, x1, y1, z1 = a
+    w2, x2, y2, z2 = b
+    return np.array([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                     w1 * y2 + y1 * w2 + z1 * x2 - x1 * z2, w1 * z2 + z1 * w2 + x1 * y2 - y1 * x2])
+
+
+def qconj(q):
+    return np.array([q[0], -q[1], -q[2], -q[3]])
+
+
+def q2R(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def R2q(R):
+    tr = np.trace(R)
+    if tr > 0:
+        s = math.sqrt(tr + 1.0) * 2
+        q = np.array([0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = math.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0) * 2
+        q = np.zeros(4)
+        q[0] = (R[k, j] - R[j, k]) / s
+        q[1 + i] = 0.25 * s
+        q[1 + j] = (R[j, i] + R[i, j]) / s
+        q[1 + k] = (R[k, i] + R[i, k]) / s
+    if q[0] < 0:
+        q = -q
+    return q / np.linalg.norm(q)
+
+
+def euler_R(yaw, pitch, roll):
+    cy, sy, cp, sp, cr, sr = math.cos(yaw), math.sin(yaw), math.cos(pitch), math.sin(pitch), math.cos(roll), math.sin(roll)
+    Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]])
+    Ry = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]])
+    Rx = np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]])
+    return Rz @ Ry @ Rx
+
+
+def rotvec_q(v):
+    n = np.linalg.norm(v)
+    if n < 1e-15:
+        return np.array([1.0, 0, 0, 0])
+    return np.r_[math.cos(n / 2), math.sin(n / 2) * v / n]
+
+
+def skew(v):
+    return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+
+
+# ------------------------------------------------------------------ scene
+@dataclass
+class Scene:
+    """Planar patches: centre c, two in-plane half-axes u,v (so the patch is c + a u + b v, |a|,|b|<=1)."""
+    c: np.ndarray
+    u: np.ndarray
+    v: np.ndarray
+
+    @property
+    def normals(self):
+        n = np.cross(self.u, self.v)
+        return n / np.linalg.norm(n, axis=1, keepdims=True)
+
+    @property
+    def areas(self):
+        return 4 * np.linalg.norm(np.cross(self.u, self.v), axis=1)
+
+
+def make_scene(length=200.0, width=20.0, height=15.0, n_boxes=20, seed=SEED_BASE):
+    rng = np.random.default_rng(seed)
+    c, u, v = [], [], []
+
+    def rect(cen, hu, hv):
+        c.append(cen); u.append(hu); v.append(hv)
+
+    L, Wd, H = length, width, height
+    rect([L / 2, 0, 0], [L / 2, 0, 0], [0, Wd / 2, 0])                    # ground z=0
+    rect([L / 2, Wd / 2, H / 2], [L / 2, 0, 0], [0, 0, H / 2])            # wall y=+w/2
+    rect([L / 2, -Wd / 2, H / 2], [L / 2, 0, 0], [0, 0, H / 2])           # wall y=-w/2
+    rect([0, 0, H / 2], [0, Wd / 2, 0], [0, 0, H / 2])                    # end walls
+    rect([L, 0, H / 2], [0, Wd / 2, 0], [0, 0, H / 2])
+    for _ in range(n_boxes):
+        bx = rng.uniform(5, L - 5)
+        side = rng.choice([-1.0, 1.0])
+        by = side * rng.uniform(3.5, Wd / 2 - 1.5)
+        sx, sy, sz = rng.uniform(1.0, 3.0), rng.uniform(0.8, 1.5), rng.uniform(1.5, 4.0)
+        rect([bx, by, sz], [sx / 2, 0, 0], [0, sy / 2, 0])                # top
+        for s in (-1, 1):
+            rect([bx, by + s * sy / 2, sz / 2], [sx / 2, 0, 0], [0, 0, sz / 2])
+            rect([bx + s * sx / 2, by, sz / 2], [0, sy / 2, 0], [0, 0, sz / 2])
+    return Scene(np.array(c, float), np.array(u, float), np.array(v, float))
+
+
+def sample_scene(scene, n, rng, centre=None, radius=None):
+    """n points uniform in area on the patches (restricted to a ball when centre/radius given);
+    returns points and patch ids."""
+    pts = np.zeros((0, 3))
+    ids = np.zeros(0, int)
+    p_area = scene.areas / scene.areas.sum()
+    while len(pts) < n:
+        m = int((n - len(pts)) * 1.6) + 64
+        pid = rng.choice(len(p_area), size=m, p=p_area)
+        a = rng.uniform(-1, 1, m)[:, None]
+        b = rng.uniform(-1, 1, m)[:, None]
+        p = scene.c[pid] + a * scene.u[pid] + b * scene.v[pid]
+        if centre is not None:
+            keep = np.linalg.norm(p - centre, axis=1) < radius
+            p, pid = p[keep], pid[keep]
+        pts = np.vstack([pts, p])
+        ids = np.r_[ids, pid]
+    return pts[:n], ids[:n]
+
+
+def voxel_average(pts, leaf):
+    """pcl::VoxelGrid restated for input prep: centroid of the points in each leaf-sized voxel
+    (downSampleCloud, Estimator.cpp:3618-3631; leaf 0.4 m at :854)."""
+    key = np.floor(pts / leaf).astype(np.int64)
+    key -= key.min(axis=0)
+    dims = key.max(axis=0) + 1
+    lin = (key[:, 0] * dims[1] + key[:, 1]) * dims[2] + key[:, 2]
+    order = np.argsort(lin, kind="stable")
+    lin_s = lin[order]
+    uniq, start, cnt = np.unique(lin_s, return_index=True, return_counts=True)
+    sums = np.add.reduceat(pts[order], start, axis=0)
+    return sums / cnt[:, None]
+
+
+# ------------------------------------------------------------------ trajectory
+class Trajectory:
+    """IMU-body pose in the local world frame: ~8 m/s along x, yaw +-5 deg."""
+
+    def __init__(self, t0=2.0, speed=8.0):
+        self.t0, self.speed = t0, speed
+
+    def pos(self, t):
+        return np.array([self.speed * t, 1.0 * math.sin(0.5 * t), 1.5 + 0.05 * math.sin(0.8 * t)])
+
+    def vel(self, t):
+        return np.array([self.speed, 0.5 * math.cos(0.5 * t), 0.04 * math.cos(0.8 * t)])
+
+    def acc(self, t):
+        return np.array([0.0, -0.25 * math.sin(0.5 * t), -0.032 * math.sin(0.8 * t)])
+
+    def R(self, t):
+        return euler_R(math.radians(5) * math.sin(0.7 * t), math.radians(1.0) * math.sin(0.9 * t), math.radians(1.5) * math.sin(1.1 * t))
+
+    def omega_body(self, t, h=1e-5):
+        dR = self.R(t - h).T @ self.R(t + h)
+        w = np.array([dR[2, 1] - dR[1, 2], dR[0, 2] - dR[2, 0], dR[1, 0] - dR[0, 1]]) / 2.0
+        return w / (2 * h)
+
+    def specific_force(self, t):
+        return self.R(t).T @ (self.acc(t) + np.array([0, 0, GRAVITY]))
+
+
+# ------------------------------------------------------------------ IMU pre-integration (host input prep)
+def preintegrate(acc, gyr, dts, ba, bg, noise=(ACC_N, GYR_N, ACC_W, GYR_W)):
+    """class Preintegration restated (Preintegration.h:29-194): constructed with the first sample,
+    then push_back(dt, acc, gyr) for the rest.  Returns a dict with the fields of glio_preint."""
+    acc_n, gyr_n, acc_w, gyr_w = noise
+    Nz = np.zeros((18, 18))
+    for k, s in zip((0, 3, 6, 9, 12, 15), (acc_n, gyr_n, acc_n, gyr_n, acc_w, gyr_w)):
+        Nz[k:k + 3, k:k + 3] = s * s * np.eye(3)
+    dp, dq, dv = np.zeros(3), np.array([1.0, 0, 0, 0]), np.zeros(3)
+    J = np.eye(15)
+    P = 0.001 * np.eye(15)                                   # Preintegration.h:56
+    acc0, gyr0 = acc[0].copy(), gyr[0].copy()
+    sum_dt = 0.0
+    I3 = np.eye(3)
+    for k in range(1, len(acc)):
+        dt, acc1, gyr1 = dts[k - 1], acc[k], gyr[k]
+        Rq = q2R(dq)
+        un_acc_0 = Rq @ (acc0 - ba)
+        un_gyr = 0.5 * (gyr0 + gyr1) - bg
+        rq = qmul(dq, np.r_[1.0, un_gyr * dt / 2])           # :108 (not normalised here)
+        Rr = q2R_unnormalised(rq)
+        un_acc_1 = Rr @ (acc1 - ba)
+        un_acc = 0.5 * (un_acc_0 + un_acc_1)
+        rp = dp + dv * dt + 0.5 * un_acc * dt * dt
+        rv = dv + un_acc * dt
+        w_x = 0.5 * (gyr0 + gyr1) - bg
+        R_w_x, R_a_0_x, R_a_1_x = skew(w_x), skew(acc0 - ba), skew(acc1 - ba)
+        Rr_m = q2R_eigen(rq)
+        F = np.zeros((15, 15))
+        F[0:3, 0:3] = I3
+        F[0:3, 3:6] = -0.25 * Rq @ R_a_0_x * dt * dt + -0.25 * Rr_m @ R_a_1_x @ (I3 - R_w_x * dt) * dt * dt
+        F[0:3, 6:9] = I3 * dt
+        F[0:3, 9:12] = -0.25 * (Rq + Rr_m) * dt * dt
+        F[0:3, 12:15] = -0.1667 * Rr_m @ R_a_1_x * dt * dt * -dt
+        F[3:6, 3:6] = I3 - R_w_x * dt
+        F[3:6, 12:15] = -I3 * dt
+        F[6:9, 3:6] = -0.5 * Rq @ R_a_0_x * dt + -0.5 * Rr_m @ R_a_1_x @ (I3 - R_w_x * dt) * dt
+        F[6:9, 6:9] = I3
+        F[6:9, 9:12] = -0.5 * (Rq + Rr_m) * dt
+        F[6:9, 12:15] = -0.5 * Rr_m @ R_a_1_x * dt * -dt
+        F[9:12, 9:12] = I3
+        F[12:15, 12:15] = I3
+        V = np.zeros((15, 18))
+        V[0:3, 0:3] = 0.5 * Rq * dt * dt
+        V[0:3, 3:6] = 0.25 * Rr_m @ R_a_1_x * dt * dt * 0.5 * dt
+        V[0:3, 6:9] = 0.5 * Rr_m * dt * dt
+        V[0:3, 9:12] = V[0:3, 3:6]
+        V[3:6, 3:6] = 0.5 * I3 * dt
+        V[3:6, 9:12] = 0.5 * I3 * dt
+        V[6:9, 0:3] = 0.5 * Rq * dt
+        V[6:9, 3:6] = 0.5 * -Rr_m @ R_a_1_x * dt * 0.5 * dt
+        V[6:9, 6:9] = 0.5 * Rr_m * dt
+        V[6:9, 9:12] = V[6:9, 3:6]
+        V[9:12, 12:15] = I3 * dt
+        V[12:15, 15:18] = I3 * dt
+        J = F @ J
+        P = F @ P @ F.T + V @ Nz @ V.T
+        dp, dv = rp, rv
+        dq = rq / np.linalg.norm(rq)                         # :190
+        sum_dt += dt
+        acc0, gyr0 = acc1, gyr1
+    return dict(delta_p=dp, delta_q=dq, delta_v=dv, linearized_ba=np.array(ba, float), linearized_bg=np.array(bg, float),
+                sum_dt=sum_dt, jacobian=J, covariance=P)
+
+
+def q2R_eigen(q):
+    """Eigen toRotationMatrix on a possibly non-unit quaternion (what Preintegration.h:135 evaluates)."""
+    w, x, y, z = q
+    tx, ty, tz = 2 * x, 2 * y, 2 * z
+    twx, twy, twz = tx * w, ty * w, tz * w
+    txx, txy, txz = tx * x, ty * x, tz * x
+    tyy, tyz, tzz = ty * y, tz * y, tz * z
+    return np.array([[1 - (tyy + tzz), txy - twz, txz + twy], [txy + twz, 1 - (txx + tzz), tyz - twx], [txz - twy, tyz + twx, 1 - (txx + tyy)]])
+
+
+def q2R_unnormalised(q):
+    """Eigen `q * v` (_transformVector) as a matrix, for a possibly non-unit q."""
+    w, u = q[0], q[1:]
+    S = skew(u)
+    return np.eye(3) + 2 * w * S + 2 * S @ S
+
+
+def fill_preint(dst, d):
+    for k in ("delta_p", "delta_q", "delta_v", "linearized_ba", "linearized_bg"):
+        getattr(dst, k)[:] = list(np.asarray(d[k], float))
+    dst.sum_dt = float(d["sum_dt"])
+    dst.jacobian[:] = list(np.asarray(d["jacobian"], float).ravel())
+    dst.covariance[:] = list(np.asarray(d["covariance"], float).ravel())
+
+
+# ------------------------------------------------------------------ GNSS
+def ecef2rotation(xyz):
+    """gnss_comm ecef2geo + geo2rotation (gnss_utility.cpp:347-390,738-748): R_ecef_enu."""
+    e2, a = 6.69437999014e-3, 6378137.0
+    a2 = a * a
+    b2 = a2 * (1 - e2)
+    b = math.sqrt(b2)
+    ep2 = (a2 - b2) / b2
+    p = math.hypot(xyz[0], xyz[1])
+    s1, s2 = xyz[2] * a, p * b
+    h = math.hypot(s1, s2)
+    st, ct = s1 / h, s2 / h
+    s1 = xyz[2] + ep2 * b * st ** 3
+    s2 = p - a * e2 * ct ** 3
+    lat = math.atan(s1 / s2)
+    lon = math.atan2(xyz[1], xyz[0])
+    sl, cl, so, co = math.sin(lat), math.cos(lat), math.sin(lon), math.cos(lon)
+    return np.array([[-so, -sl * co, cl * co], [co, -sl * so, cl * so], [0, cl, sl]])
+
+
+@dataclass
+class Window:
+    """All buffers of one sliding-window problem (what the reference holds as Estimator members)."""
+    opts: T.GlioOpts
+    W: int
+    gt: T.WindowState
+    init: T.WindowState
+    kf_times: np.ndarray
+    scans: list                      # per slot [N][4] float32 (LiDAR frame)
+    scan_plane_id: list
+    map_pts: np.ndarray              # [M][4] float32
+    scene: Scene
+    preints: list = field(default_factory=list)   # dicts
+    dd: list = field(default_factory=list)        # GlioDdPsr
+    dop: list = field(default_factory=list)       # GlioDoppler
+    frame: T.GlioGnssFrame = None
+    prior: dict = None
+
+
+def default_opts(W=5, pts=65536, map_pts=1 << 21, n_ddt=0):
+    o = T.GlioOpts()
+    o.window, o.max_iterations = W, 15
+    o.max_points_per_scan, o.max_map_points, o.max_ddt_epochs = pts, map_pts, n_ddt
+    o.jacobi_scaling = 1
+    o.huber_delta, o.doppler_huber_delta = 1.0, 1.0
+    o.q_lb[:] = [1.0, 0, 0, 0]
+    o.t_lb[:] = [0, 0, 0.28]
+    o.lidar_const, o.surf_dist_thres = 7.5, 0.18
+    o.kd_max_radius, o.weight_gate = 1.5, 0.3
+    o.gravity = GRAVITY
+    o.initial_trust_region_radius, o.max_trust_region_radius, o.min_trust_region_radius = 1e4, 1e16, 1e-32
+    o.min_relative_decrease, o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance = 1e-3, 1e-6, 1e-10, 1e-8
+    return o
+
+
+def make_window(W=5, pts_per_scan=2048, seed=SEED_BASE, with_gnss=False, with_prior=False, kf_dt=0.4,
+                map_density=12.0, scan_radius=60.0, scene=None, perturb=(0.10, 0.5, 0.1), imu_rate=100.0):
+    rng_state = np.random.default_rng(seed + 2)
+    scene = scene or make_scene(seed=seed)
+    traj = Trajectory()
+    t_lb = np.array([0, 0, 0.28])
+    kf_times = traj.t0 + kf_dt * np.arange(W)
+    gt = T.WindowState(W)
+    for s, t in enumerate(kf_times):
+        gt.trans[s] = traj.pos(t)
+        gt.quat[s] = R2q(traj.R(t))
+        gt.speed_bias[s, 0:3] = traj.vel(t)
+
+    # scans (LiDAR frame): p_lidar = q_lb * R^T (p_w - t) + t_lb, range noise 0.02 m along the ray
+    scans, pids = [], []
+    for s in range(W):
+        rng = np.random.default_rng(seed + 100 + s)
+        Rw, tw = q2R(gt.quat[s]), gt.trans[s]
+        sensor = tw + Rw @ (-t_lb)          # LiDAR origin in world (q_lb = I)
+        pw, pid = sample_scene(scene, pts_per_scan, rng, centre=sensor, radius=scan_radius)
+        ray = pw - sensor
+        rn = np.linalg.norm(ray, axis=1, keepdims=True)
+        pw = sensor + ray * (1 + rng.normal(0, 0.02, (len(pw), 1)) / np.maximum(rn, 1e-3))
+        pl = (pw - tw) @ Rw + t_lb
+        inten = rng.integers(0, 32, len(pl)) + 0.1 * rng.uniform(0, 1, len(pl))
+        scans.append(np.ascontiguousarray(np.c_[pl, inten].astype(np.float32)))
+        pids.append(pid)
+
+    # local map: scene sampled around the window, noisy, voxel-averaged at 0.4 m
+    rng = np.random.default_rng(seed + 7)
+    centre = gt.trans[W // 2]
+    reach = scan_radius + np.linalg.norm(gt.trans[-1] - gt.trans[0]) / 2 + 5
+    area = scene.areas.sum()
+    n_raw = int(min(area, math.pi * reach * reach * 1.6) * map_density)
+    mp, _ = sample_scene(scene, n_raw, rng, centre=centre, radius=reach)
+    mp = mp + rng.normal(0, 0.01, mp.shape)
+    mp = voxel_average(mp, 0.4)
+    map_pts = np.ascontiguousarray(np.c_[mp, np.zeros(len(mp))].astype(np.float32))
+
+    # initial state = perturbed ground truth
+    init = gt.copy()
+    sp, sr, sv = perturb
+    for s in range(W):
+        init.trans[s] += rng_state.normal(0, sp, 3)
+        dq = rotvec_q(rng_state.normal(0, math.radians(sr), 3))
+        q = qmul(dq, gt.quat[s])
+        init.quat[s] = q / np.linalg.norm(q)
+        init.speed_bias[s, 0:3] += rng_state.normal(0, sv, 3)
+
+    n_ddt = 0
+    win = Window(opts=None, W=W, gt=gt, init=init, kf_times=kf_times, scans=scans, scan_plane_id=pids,
+                 map_pts=map_pts, scene=scene)
+
+    # IMU pre-integrations between consecutive keyframes
+    rng_imu = np.random.default_rng(seed + 3)
+    for s in range(W - 1):
+        n = int(round(kf_dt * imu_rate))
+        ts = kf_times[s] + np.arange(n + 1) / imu_rate
+        acc = np.array([traj.specific_force(t) for t in ts]) + rng_imu.normal(0, ACC_N, (n + 1, 3))
+        gyr = np.array([traj.omega_body(t) for t in ts]) + rng_imu.normal(0, GYR_N, (n + 1, 3))
+        win.preints.append(preintegrate(acc, gyr, np.full(n, 1.0 / imu_rate), np.zeros(3), np.zeros(3)))
+
+    if with_gnss:
+        n_ddt = _make_gnss(win, traj, seed)
+    if with_prior:
+        win.prior = make_synthetic_prior(win, seed)
+    gt.n_ddt = init.n_ddt = n_ddt
+    gt.rcv_ddt = np.zeros(max(n_ddt, 1))
+    init.rcv_ddt = np.zeros(max(n_ddt, 1))
+    if with_gnss:
+        gt.rcv_ddt[:n_ddt] = win._ddt_true
+        init.rcv_ddt[:n_ddt] = 0.0
+    win.opts = default_opts(W, pts=max(pts_per_scan, 64), map_pts=max(len(map_pts), 64), n_ddt=n_ddt)
+    return win
+
+
+def _make_gnss(win, traj, seed, sats_per_sys=10, epoch_dt=0.1):
+    rng = np.random.default_rng(seed + 4)
+    Ree = ecef2rotation(ANCHOR_ECEF)
+    yaw = 0.0
+    Rel = np.array([[math.cos(yaw), -math.sin(yaw), 0], [math.sin(yaw), math.cos(yaw), 0], [0, 0, 1]])
+    Rloc = Ree @ Rel
+    win.frame = T.GlioGnssFrame()
+    win.frame.yaw_enu_local = yaw
+    win.frame.anc_ecef[:] = list(ANCHOR_ECEF)
+    up = ANCHOR_ECEF / np.linalg.norm(ANCHOR_ECEF)
+    east = Ree[:, 0]
+    north = Ree[:, 1]
+    sats = []
+    for _sys in range(2):
+        pos, vel = [], []
+        while len(pos) < sats_per_sys:
+            el = math.radians(rng.uniform(15, 85))
+            az = rng.uniform(0, 2 * math.pi)
+            d = math.cos(el) * (math.sin(az) * east + math.cos(az) * north) + math.sin(el) * up
+            # intersect the ray from the anchor with the 26 560 km shell
+            b = ANCHOR_ECEF @ d
+            c = ANCHOR_ECEF @ ANCHOR_ECEF - 26560e3 ** 2
+            lam = -b + math.sqrt(b * b - c)
+            p = ANCHOR_ECEF + lam * d
+            tang = np.cross(p, rng.normal(size=3))
+            tang /= np.linalg.norm(tang)
+            pos.append(p)
+            vel.append(3874.0 * tang)
+        sats.append((np.array(pos), np.array(vel)))
+    t0, t1 = win.kf_times[0], win.kf_times[-1]
+    epochs = np.arange(t0 + epoch_dt / 2, t1, epoch_dt)
+    clock_bias = 1234.5
+    ddt_true = []
+    for e, te in enumerate(epochs):
+        l = int(np.searchsorted(win.kf_times, te) - 1)
+        l = min(max(l, 0), win.W - 2)
+        lo, hi = win.kf_times[l], win.kf_times[l + 1]
+        ratio = (hi - te) / (hi - lo)                                   # Estimator.cpp:2280
+        p_true = traj.pos(te)
+        v_true = traj.vel(te)
+        Pe = Rloc @ p_true + ANCHOR_ECEF
+        Ve = Rloc @ v_true
+        ddt_e = 5.0 + 0.01 * e
+        ddt_true.append(ddt_e)
+        dts = te - t0
+        for sysid, (spos0, svel) in enumerate(sats):
+            spos = spos0 + svel * dts
+            f = T.GlioDdPsr()
+            f.slot_i, f.slot_j, f.n_sat = l, l + 1, sats_per_sys
+            el_best = int(np.argmax([(sp - ANCHOR_ECEF) @ up / np.linalg.norm(sp - ANCHOR_ECEF) for sp in spos]))
+            f.master = el_best
+            f.ratio, f.threshold = ratio, 10.0                           # DDpsr_threshold {10}, Estimator.cpp:2088
+            f.station[:] = list(STATION_ECEF)
+            snr = rng.uniform(30, 50, sats_per_sys)
+            for i in range(sats_per_sys):
+                f.user_sat_pos[i][:] = list(spos[i])
+                f.ref_sat_pos[i][:] = list(spos[i])
+                f.user_psr[i] = np.linalg.norm(spos[i] - Pe) + clock_bias + rng.normal(0, 1.0)
+                f.ref_psr[i] = np.linalg.norm(spos[i] - STATION_ECEF) + 77.0 + rng.normal(0, 0.3)
+            # weight matrix: (D Q^-1 D^T)^(o 1/2) inverse, Estimator.cpp:2350-2357, Q = diag(snr-based weights)
+            wdiag = (snr / 50.0) ** 2
+            D = np.zeros((sats_per_sys - 1, sats_per_sys))
+            r = 0
+            for i in range(sats_per_sys):
+                if i == f.master:
+                    continue
+                D[r, f.master] = 1
+                D[r, i] = -1
+                r += 1
+            Rm = D @ np.diag(1.0 / wdiag) @ D.T
+            Wm = np.linalg.inv(np.sqrt(Rm))
+            f.weight[:Wm.size] = list(Wm.ravel())
+            win.dd.append(f)
+            for i in range(sats_per_sys):
+                g = T.GlioDoppler()
+                g.slot_i, g.slot_j, g.epoch = l, l + 1, e
+                g.ratio, g.var = ratio, 0.2
+                g.sat_pos[:] = list(spos[i])
+                g.sat_vel[:] = list(svel[i])
+                g.sv_ddt = 1e-3 * rng.normal()
+                g.lamda = L1_LAMBDA
+                d = spos[i] - Pe
+                eh = d / np.linalg.norm(d)
+                sag = EARTH_OMG / LIGHT_SPEED * (svel[i][0] * Pe[1] + spos[i][0] * Ve[1] - svel[i][1] * Pe[0] - spos[i][1] * Ve[0])
+                est = (svel[i] - Ve) @ eh + sag + ddt_e - g.sv_ddt
+                g.doppler = (-est + rng.normal(0, 0.1)) / L1_LAMBDA
+                g.lever_arm[:] = [0, 0, 0]
+                g.R_ecef_local[:] = list(Rloc.ravel())
+                win.dop.append(g)
+    win._ddt_true = np.array(ddt_true)
+    return len(epochs)
+
+
+def make_synthetic_prior(win, seed):
+    """A synthetic marginalization prior with the reference's block structure (T,Q of slots 0..W-2 and
+    SpeedBias of slot 0 -- Estimator.cpp:2521-2534,2584-2600): J0 = chol(Lambda)^T of an SPD information
+    matrix, r0 = J0 * e for a small e, x0 = ground truth + small offsets."""
+    rng = np.random.default_rng(seed + 9)
+    W = win.W
+    blocks = []
+    idx = 0
+    for s in range(W - 1):
+        kinds = (T.BLK_TRANS, T.BLK_QUAT, T.BLK_SPEEDBIAS) if s == 0 else (T.BLK_TRANS, T.BLK_QUAT)
+        for k in kinds:
+            blocks.append((s, k, idx))
+            idx += 9 if k == T.BLK_SPEEDBIAS else 3
+    n = idx
+    A = rng.normal(0, 1.0, (n, n)) * 0.3
+    Lam = A @ A.T / n + np.diag(rng.uniform(20.0, 60.0, n))
+    J0 = np.linalg.cholesky(Lam).T
+    r0 = J0 @ rng.normal(0, 0.01, n)
+    x0 = np.zeros((len(blocks), 9))
+    for b, (s, k, _) in enumerate(blocks):
+        if k == T.BLK_TRANS:
+            x0[b, :3] = win.gt.trans[s] + rng.normal(0, 0.02, 3)
+        elif k == T.BLK_QUAT:
+            q = qmul(rotvec_q(rng.normal(0, 0.002, 3)), win.gt.quat[s])
+            x0[b, :4] = q / np.linalg.norm(q)
+        else:
+            x0[b, :9] = win.gt.speed_bias[s] + rng.normal(0, 0.02, 9)
+    return dict(n=n, lin_jac=np.ascontiguousarray(J0), lin_res=np.ascontiguousarray(r0),
+                blk_slot=np.array([b[0] for b in blocks], np.int32), blk_kind=np.array([b[1] for b in blocks], np.int32),
+                blk_idx=np.array([b[2] for b in blocks], np.int32), blk_x0=np.ascontiguousarray(x0))
+
+
+def prior_struct(prior):
+    """glio_prior view over the numpy arrays of a prior dict (keeps references alive via the dict)."""
+    p = T.GlioPrior()
+    if prior is None:
+        p.n = 0
+        p.n_blocks = 0
+        return p
+    p.n, p.n_blocks = int(prior["n"]), len(prior["blk_slot"])
+    p.lin_jac, p.lin_res = T.dptr(prior["lin_jac"]), T.dptr(prior["lin_res"])
+    p.blk_slot, p.blk_kind, p.blk_idx = T.iptr(prior["blk_slot"]), T.iptr(prior["blk_kind"]), T.iptr(prior["blk_idx"])
+    p.blk_x0 = T.dptr(prior["blk_x0"])
+    return p
+
+
+def analytic_correspondences(win, state=None):
+    """Plane correspondences built from the KNOWN scene planes instead of a 5-NN search, following the
+    gating / weighting arithmetic of findCorrespondingSurfFeatures (Estimator.cpp:3662-3692).  Used to
+    feed the solver at sizes where a CPU nearest-neighbour search would take minutes."""
+    state = state or win.init
+    o = win.opts
+    t_lb = np.array(o.t_lb)
+    normals = win.scene.normals
+    offs = -(normals * win.scene.c).sum(1)
+    flip = offs < 0                       # fitted planes have n.p + d = 0 with d = 1/|n'| > 0
+    normals = np.where(flip[:, None], -normals, normals)
+    offs = np.abs(offs)
+    offs = np.where(offs < 1e-9, 1e-9, offs)
+    out = []
+    for s in range(win.W):
+        sc = win.scans[s]
+        Rw, tw = q2R(state.quat[s]), state.trans[s]
+        pw = ((sc[:, :3].astype(np.float64) - t_lb) @ Rw.T + tw).astype(np.float32)
+        n = normals[win.scan_plane_id[s]]
+        d = offs[win.scan_plane_id[s]]
+        pd = (np.einsum("ij,ij->i", n, pw.astype(np.float64)) + d).astype(np.float32)
+        rr = np.sqrt(np.sqrt((pw * pw).sum(1, dtype=np.float32)).astype(np.float32)).astype(np.float32)
+        w = (1.0 - 0.9 * np.abs(pd).astype(np.float64) / rr.astype(np.float64)).astype(np.float32)
+        keep = w > o.weight_gate
+        planes = np.c_[(w[:, None].astype(np.float64) * n), w.astype(np.float64) * d].astype(np.float32)
+        scores = o.lidar_const * w.astype(np.float64)
+        out.append((np.ascontiguousarray(sc[keep]), np.ascontiguousarray(planes[keep]), np.ascontiguousarray(scores[keep])))
+    return out

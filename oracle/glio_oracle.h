@@ -1,0 +1,114 @@
+/*
+ * glio_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C, single-thread, fp64 restatement of the reference's sliding-window hot path
+ * (GLIO/src/Estimator.cpp:2046-2736 and the factor headers under GLIO/include/factors/), written the
+ * way the reference + Ceres 1.14 evaluate it: every factor returns residuals and GLOBAL Jacobians
+ * through the ceres::CostFunction::Evaluate convention, the loss corrector and the quaternion
+ * local parameterisation are applied afterwards, and the normal equations are summed densely.
+ *
+ * PARITY UNPINNED: the reference has no tests or golden vectors for this path (SURVEY.md section 4,
+ * 8c) and cannot be built here (needs ROS, PCL, Ceres, Eigen, GTSAM -- none installed, Ceres tarball
+ * stripped from the tree).  This restatement is pinned only by self-authored checks: central finite
+ * differences, an independent numpy transcription of the factors (tests/numpy_factors.py), and
+ * closed-form cases.  Every number produced with it must be labelled
+ * "reference-restatement (Ceres-1.14 semantics)", never "Ceres".
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or call this.
+ */
+#ifndef GLIO_ORACLE_H_
+#define GLIO_ORACLE_H_
+
+#include "../include/glio_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_problem {
+    glio_opts opts;
+    /* LiDAR plane correspondences, concatenated by window slot: slot s owns [off[s], off[s+1]) */
+    const int32_t* lidar_offset;   /* [W+1] */
+    const float* lidar_pts;        /* [N][4]  vec_surf_cur_pts (x,y,z,intensity), LiDAR frame */
+    const float* lidar_planes;     /* [N][4]  vec_surf_normal: (w*n, w*d) */
+    const double* lidar_scores;    /* [N]     vec_surf_scores = lidar_const*w */
+    /* IMU edges: edge k links slot imu_slot[k] and imu_slot[k]+1 */
+    int32_t n_imu;
+    const glio_preint* imu;
+    const int32_t* imu_slot;
+    glio_prior prior;
+    int32_t n_dd;
+    const glio_dd_psr* dd;
+    int32_t n_dop;
+    const glio_doppler* dop;
+    glio_gnss_frame frame;
+} orc_problem;
+
+void orc_opts_default(glio_opts* o);
+
+/* ---- single-factor evaluators, Ceres Evaluate() pointer convention (jacobians / jacobians[i] may be NULL) */
+/* LidarPlaneNormFactor (LidarKeyframeFactor.h:73-122): blocks t[3], q[4]; 1 residual */
+int orc_eval_lidar_plane(const glio_opts* o, const float cp[4], const float plane[4], double score,
+                         double const* const* parameters, double* residuals, double** jacobians);
+/* ImuFactor (ImuFactor.h:21-171): blocks Pi3 Qi4 SBi9 Pj3 Qj4 SBj9; 15 residuals */
+int orc_eval_imu(const glio_opts* o, const glio_preint* pre,
+                 double const* const* parameters, double* residuals, double** jacobians);
+/* sqrt_info = LLT(cov^-1).L^T  (ImuFactor.h:44-45); out 15x15 row-major */
+int orc_imu_sqrt_info(const double* covariance, double* sqrt_info);
+/* MarginalizationFactor::Evaluate (MarginalizationFactor.cpp:233-287): parameters[b] = block b */
+int orc_eval_marg(const glio_prior* p, double const* const* parameters, double* residuals, double** jacobians);
+/* dd_psr_factor_20::Evaluate (dd_psr_factor.hpp:25-171): blocks Pi3 Pj3 yaw1 anc3; 19 residuals */
+int orc_eval_dd_psr(const glio_dd_psr* f, double const* const* parameters, double* residuals, double** jacobians);
+/* tcdopplerFactor (dopp_factor.hpp:24-75): blocks Pi3 SBi9 Pj3 SBj9 ddt[n] yaw1 anc3; 1 residual.
+ * jacobians[4] (if non-NULL) receives only d r / d ddt[epoch] as a single double. */
+int orc_eval_doppler(const glio_doppler* f, double const* const* parameters, double* residuals, double** jacobians);
+/* ecef2rotation (gnss_comm/src/gnss_utility.cpp:347-390,738-753): R_ecef_enu row-major */
+void orc_ecef2rotation(const double ecef[3], double R[9]);
+
+/* ---- Ceres pieces */
+/* QuaternionParameterization::Plus (nnls_modeling.rst:1312-1327) */
+void orc_quat_plus(const double q[4], const double delta[3], double out[4]);
+/* x (+) delta over the whole window; delta has 15*W + n_ddt entries */
+void orc_state_plus(const glio_state* x, int W, const double* delta, glio_state* out);
+
+/* ---- window problem */
+/* local (tangent) dimension 15*W + n_ddt */
+int orc_local_dim(const orc_problem* p, const glio_state* x);
+/* One linearisation: dense H = J^T J (n x n row-major), g = J^T r, cost = 1/2 sum rho(|r|^2),
+ * all AFTER loss correction and local parameterisation, unscaled.  Any of H,g may be NULL. */
+int orc_linearize(const orc_problem* p, const glio_state* x, double* H, double* g, double* cost);
+/* Ceres-1.14 trust-region (traditional dogleg, dense normal Cholesky, Jacobi scaling) */
+int orc_solve(const orc_problem* p, glio_state* x, glio_summary* summary);
+
+/* ---- correspondence search (Estimator.cpp:3633-3708): brute-force exact 5-NN + plane fit.
+ * out arrays have capacity n_scan; returns the number of correspondences kept, in scan order. */
+int orc_associate(const glio_opts* o, const float* map_pts /*[M][4]*/, int M,
+                  const float* scan /*[n][4]*/, int n, const double q[4], const double t[3],
+                  float* out_pts /*[n][4]*/, float* out_planes /*[n][4]*/, double* out_scores,
+                  int32_t* out_src_index /* may be NULL */, int32_t* out_nn /* [n][5] may be NULL */);
+/* colPivHouseholderQr().solve for the 5x3 system A n = b  (Estimator.cpp:3661) */
+void orc_plane_qr_solve(const double A[15], const double b[5], double x[3]);
+
+/* ---- marginalization (MarginalizationFactor.cpp:87-221 + Estimator.cpp:2462-2607) */
+/* Builds the next prior from the CURRENT window (prior + IMU(0,1) + all LiDAR factors, slot 0
+ * dropped).  Output arrays sized for n = 6(W-1)+9: lin_jac [n*n], lin_res [n], blk_* [2(W-1)+1],
+ * blk_x0 [(2(W-1)+1)*9].  Slots in the output are ALREADY shifted (i -> i-1, Estimator.cpp:2584-2598).
+ * Returns n. */
+int orc_marginalize(const orc_problem* p, const glio_state* x, double* lin_jac, double* lin_res,
+                    int32_t* blk_slot, int32_t* blk_kind, int32_t* blk_idx, double* blk_x0);
+
+/* ---- batch stage (BinaryLidarPlaneNormFactor, LidarKeyframeFactor.h:124-164) */
+/* residual + global jacobians, blocks t1[3] q1[4] t2[3] q2[4] */
+int orc_eval_binary_plane(const float cp[4], const double norm_cent[6], double score,
+                          double const* const* parameters, double* residuals, double** jacobians);
+/* Banded normal equations of a batch of binary constraints.  Poses [K][7] = (t, q).  Constraint c:
+ * keyframes (ci[c], cj[c]).  Hband: [K][band+1][36] upper block band (block (k, k+d) at [k][d]),
+ * g: [K][6]. */
+int orc_batch_linearize(int K, int band, const double* poses, int64_t n_con, const int32_t* ci,
+                        const int32_t* cj, const float* cp /*[n][4]*/, const double* norm_cent /*[n][6]*/,
+                        const double* score, double* Hband, double* g, double* cost);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,126 @@
+/*
+ * orc_assoc.c -- CPU ORACLE (test infrastructure): Estimator::findCorrespondingSurfFeatures
+ * (GLIO/src/Estimator.cpp:3633-3708) with the PCL kd-tree replaced by a brute-force exact 5-NN.
+ *
+ * Precision per step follows the reference (quirk Q2): the transform is computed in double and
+ * stored as float (transformPoint, Estimator.cpp:1490-1498); nearest-neighbour squared distances are
+ * float sums dx*dx+dy*dy+dz*dz in that order (FLANN L2_Simple<float> as used by pcl::KdTreeFLANN);
+ * the 5x3 plane fit is double (colPivHouseholderQr, :3661); pd and weight are float (:3678-3679).
+ * Ties in distance are broken by the lower map index (FLANN's own tie order is unspecified).
+ * Compile with -ffp-contract=off so that no float multiply-add is fused.
+ * PARITY UNPINNED -- see glio_oracle.h.
+ */
+#include <float.h>
+#include "glio_oracle.h"
+#include "orc_math.h"
+
+/* Eigen::ColPivHouseholderQR<Matrix<double,5,3>>::solve restated (Eigen 3.3 ColPivHouseholderQR.h:
+ * column pivoting on the largest remaining column norm, Householder reflectors, solve through
+ * nonzeroPivots()).  Column norms are recomputed directly at every step instead of being
+ * down-dated, which can only change the pivot order on exact near-ties. */
+void orc_plane_qr_solve(const double Ain[15], const double bin[5], double x[3]) {
+    enum { M = 5, N = 3 };
+    double A[M][N], b[M];
+    int perm[N] = {0, 1, 2};
+    for (int i = 0; i < M; ++i) { b[i] = bin[i]; for (int j = 0; j < N; ++j) A[i][j] = Ain[i * N + j]; }
+    double maxnorm = 0;
+    for (int j = 0; j < N; ++j) { double s = 0; for (int i = 0; i < M; ++i) s += A[i][j] * A[i][j]; s = sqrt(s); if (s > maxnorm) maxnorm = s; }
+    const double thr_helper = (maxnorm * DBL_EPSILON) * (maxnorm * DBL_EPSILON) / (double)M;
+    int nonzero = N;
+    for (int k = 0; k < N; ++k) {
+        int best = k; double bestsq = -1;
+        for (int j = k; j < N; ++j) { double s = 0; for (int i = k; i < M; ++i) s += A[i][j] * A[i][j]; if (s > bestsq) { bestsq = s; best = j; } }
+        if (nonzero == N && bestsq < thr_helper * (double)(M - k)) nonzero = k;
+        if (best != k) {
+            for (int i = 0; i < M; ++i) { double t = A[i][k]; A[i][k] = A[i][best]; A[i][best] = t; }
+            int t = perm[k]; perm[k] = perm[best]; perm[best] = t;
+        }
+        /* makeHouseholderInPlace on A[k:,k] */
+        double tail = 0;
+        for (int i = k + 1; i < M; ++i) tail += A[i][k] * A[i][k];
+        double c0 = A[k][k], beta, tau, v[M];
+        if (tail <= DBL_MIN) { tau = 0; beta = c0; for (int i = k + 1; i < M; ++i) v[i] = 0; }
+        else {
+            beta = sqrt(c0 * c0 + tail);
+            if (c0 >= 0) beta = -beta;
+            for (int i = k + 1; i < M; ++i) v[i] = A[i][k] / (c0 - beta);
+            tau = (beta - c0) / beta;
+        }
+        v[k] = 1.0;
+        /* apply H = I - tau v v^T to remaining columns and to b */
+        for (int j = k + 1; j < N; ++j) {
+            double s = 0;
+            for (int i = k; i < M; ++i) s += v[i] * A[i][j];
+            s *= tau;
+            for (int i = k; i < M; ++i) A[i][j] -= s * v[i];
+        }
+        {
+            double s = 0;
+            for (int i = k; i < M; ++i) s += v[i] * b[i];
+            s *= tau;
+            for (int i = k; i < M; ++i) b[i] -= s * v[i];
+        }
+        A[k][k] = beta;
+        for (int i = k + 1; i < M; ++i) A[i][k] = 0;
+    }
+    double y[N] = {0, 0, 0};
+    for (int i = nonzero - 1; i >= 0; --i) {
+        double s = b[i];
+        for (int j = i + 1; j < nonzero; ++j) s -= A[i][j] * y[j];
+        y[i] = s / A[i][i];
+    }
+    for (int j = 0; j < N; ++j) x[perm[j]] = y[j];
+}
+
+int orc_associate(const glio_opts* o, const float* map, int M, const float* scan, int n,
+                  const double q[4], const double t[3], float* out_pts, float* out_planes,
+                  double* out_scores, int32_t* out_src, int32_t* out_nn) {
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) {
+        const float* pl = scan + 4 * (size_t)i;
+        /* transformPoint: double math, float store */
+        double pin[3] = {pl[0], pl[1], pl[2]}, pout[3];
+        q_rot(q, pin, pout);
+        const float px = (float)(pout[0] + t[0]), py = (float)(pout[1] + t[1]), pz = (float)(pout[2] + t[2]);
+        /* exact 5-NN, ascending (dist, index) */
+        float bd[5] = {FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX};
+        int bi[5] = {-1, -1, -1, -1, -1};
+        for (int m = 0; m < M; ++m) {
+            const float* mp = map + 4 * (size_t)m;
+            const float dx = px - mp[0], dy = py - mp[1], dz = pz - mp[2];
+            float d = dx * dx; d = d + dy * dy; d = d + dz * dz;
+            if (d < bd[4]) {
+                int k = 4;
+                while (k > 0 && d < bd[k - 1]) { bd[k] = bd[k - 1]; bi[k] = bi[k - 1]; --k; }
+                bd[k] = d; bi[k] = m;
+            }
+        }
+        if (out_nn) for (int k = 0; k < 5; ++k) out_nn[5 * (size_t)i + k] = bi[k];
+        if (!(bi[4] >= 0 && bd[4] < o->kd_max_radius)) continue;              /* :3651 */
+        double A[15], b[5] = {-1, -1, -1, -1, -1}, nrm[3];
+        for (int k = 0; k < 5; ++k) for (int c = 0; c < 3; ++c) A[k * 3 + c] = (double)map[4 * (size_t)bi[k] + c];
+        orc_plane_qr_solve(A, b, nrm);                                           /* :3661 */
+        const double nn = v3_norm(nrm);
+        const double normInverse = 1.0 / nn;                                     /* :3662 */
+        nrm[0] /= nn; nrm[1] /= nn; nrm[2] /= nn;                                /* :3663 */
+        int valid = 1;
+        for (int k = 0; k < 5; ++k)
+            if (fabs(nrm[0] * A[k * 3] + nrm[1] * A[k * 3 + 1] + nrm[2] * A[k * 3 + 2] + normInverse) > o->surf_dist_thres) { valid = 0; break; }
+        if (!valid) continue;                                                    /* :3667-3674 */
+        const float pd = (float)(nrm[0] * (double)px + nrm[1] * (double)py + nrm[2] * (double)pz + normInverse);  /* :3678 */
+        const float rr = sqrtf(sqrtf(px * px + py * py + pz * pz));              /* float sqrt(sqrt(.)) */
+        const float weight = (float)(1.0 - 0.9 * (double)fabsf(pd) / (double)rr);  /* :3679 */
+        if (!(weight > o->weight_gate)) continue;                                /* :3681 */
+        float* op = out_pts + 4 * (size_t)cnt;
+        float* on = out_planes + 4 * (size_t)cnt;
+        op[0] = pl[0]; op[1] = pl[1]; op[2] = pl[2]; op[3] = pl[3];              /* :3688 */
+        on[0] = (float)((double)weight * nrm[0]);                                /* :3683-3686 */
+        on[1] = (float)((double)weight * nrm[1]);
+        on[2] = (float)((double)weight * nrm[2]);
+        on[3] = (float)((double)weight * normInverse);
+        out_scores[cnt] = o->lidar_const * (double)weight;                       /* :3692 */
+        if (out_src) out_src[cnt] = i;
+        ++cnt;
+    }
+    return cnt;
+}

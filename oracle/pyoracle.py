@@ -1,0 +1,221 @@
+"""ctypes binding of the CPU ORACLE (oracle/_build/libglio_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+Nothing under glio_amd/ may import this module.  Numbers produced with it are
+"reference-restatement (Ceres-1.14 semantics)", parity unpinned (see oracle/glio_oracle.h).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from glio_amd import ctypes_types as T
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libglio_oracle.so")
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO):
+        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
+    return _SO
+
+
+class OrcProblem(C.Structure):
+    _fields_ = [("opts", T.GlioOpts), ("lidar_offset", T.c_int32_p), ("lidar_pts", T.c_float_p),
+                ("lidar_planes", T.c_float_p), ("lidar_scores", T.c_double_p),
+                ("n_imu", C.c_int32), ("imu", C.POINTER(T.GlioPreint)), ("imu_slot", T.c_int32_p),
+                ("prior", T.GlioPrior), ("n_dd", C.c_int32), ("dd", C.POINTER(T.GlioDdPsr)),
+                ("n_dop", C.c_int32), ("dop", C.POINTER(T.GlioDoppler)), ("frame", T.GlioGnssFrame)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_associate.restype = C.c_int
+        _lib.orc_marginalize.restype = C.c_int
+    return _lib
+
+
+def _pp(arrs):
+    """double const* const* from a list of numpy arrays (or None)."""
+    P = (T.c_double_p * len(arrs))()
+    for i, a in enumerate(arrs):
+        P[i] = T.dptr(a) if a is not None else None
+    return P
+
+
+class Problem:
+    """Owns the numpy buffers behind an orc_problem."""
+
+    def __init__(self, win, corr, use_gnss=True, use_prior=True, use_imu=True):
+        from glio_amd import synth
+        self.win = win
+        W = win.W
+        counts = [len(c[2]) for c in corr]
+        self.offset = np.zeros(W + 1, np.int32)
+        self.offset[1:] = np.cumsum(counts)
+        self.pts = np.ascontiguousarray(np.vstack([c[0] for c in corr]).astype(np.float32)) if sum(counts) else np.zeros((1, 4), np.float32)
+        self.planes = np.ascontiguousarray(np.vstack([c[1] for c in corr]).astype(np.float32)) if sum(counts) else np.zeros((1, 4), np.float32)
+        self.scores = np.ascontiguousarray(np.concatenate([c[2] for c in corr])) if sum(counts) else np.zeros(1)
+        n_imu = len(win.preints) if use_imu else 0
+        self.imu = T.preint_array(n_imu)
+        for k in range(n_imu):
+            synth.fill_preint(self.imu[k], win.preints[k])
+        self.imu_slot = np.arange(max(n_imu, 1), dtype=np.int32)
+        self.dd = (T.GlioDdPsr * max(len(win.dd), 1))(*win.dd) if (use_gnss and win.dd) else (T.GlioDdPsr * 1)()
+        self.dop = (T.GlioDoppler * max(len(win.dop), 1))(*win.dop) if (use_gnss and win.dop) else (T.GlioDoppler * 1)()
+        p = OrcProblem()
+        p.opts = win.opts
+        p.lidar_offset, p.lidar_pts, p.lidar_planes, p.lidar_scores = T.iptr(self.offset), T.fptr(self.pts), T.fptr(self.planes), T.dptr(self.scores)
+        p.n_imu, p.imu, p.imu_slot = n_imu, self.imu, T.iptr(self.imu_slot)
+        self.prior_dict = win.prior if use_prior else None
+        p.prior = synth.prior_struct(self.prior_dict)
+        p.n_dd = len(win.dd) if use_gnss else 0
+        p.dd = self.dd
+        p.n_dop = len(win.dop) if use_gnss else 0
+        p.dop = self.dop
+        if win.frame is not None:
+            p.frame = win.frame
+        self.c = p
+
+    def n(self, state):
+        return 15 * self.win.W + state.n_ddt
+
+    def linearize(self, state, want_H=True):
+        n = self.n(state)
+        H = np.zeros((n, n)) if want_H else None
+        g = np.zeros(n) if want_H else None
+        cost = C.c_double()
+        cs = state.c()
+        ok = lib().orc_linearize(C.byref(self.c), C.byref(cs), T.dptr(H) if want_H else None, T.dptr(g) if want_H else None, C.byref(cost))
+        assert ok
+        return H, g, cost.value
+
+    def solve(self, state):
+        s = state.copy()
+        cs = s.c()
+        summ = T.GlioSummary()
+        lib().orc_solve(C.byref(self.c), C.byref(cs), C.byref(summ))
+        return s, summ
+
+    def marginalize(self, state):
+        W = self.win.W
+        n = 6 * (W - 1) + 9
+        nb = 2 * (W - 1) + 1
+        out = dict(n=n, lin_jac=np.zeros((n, n)), lin_res=np.zeros(n), blk_slot=np.zeros(nb, np.int32),
+                   blk_kind=np.zeros(nb, np.int32), blk_idx=np.zeros(nb, np.int32), blk_x0=np.zeros((nb, 9)))
+        cs = state.c()
+        r = lib().orc_marginalize(C.byref(self.c), C.byref(cs), T.dptr(out["lin_jac"]), T.dptr(out["lin_res"]),
+                                  T.iptr(out["blk_slot"]), T.iptr(out["blk_kind"]), T.iptr(out["blk_idx"]), T.dptr(out["blk_x0"]))
+        assert r == n
+        return out
+
+
+def associate(opts, map_pts, scan, q, t, want_nn=False):
+    n = len(scan)
+    pts = np.zeros((n, 4), np.float32)
+    planes = np.zeros((n, 4), np.float32)
+    scores = np.zeros(n)
+    src = np.zeros(n, np.int32)
+    nn = np.zeros((n, 5), np.int32) if want_nn else None
+    q = np.ascontiguousarray(q, float)
+    t = np.ascontiguousarray(t, float)
+    cnt = lib().orc_associate(C.byref(opts), T.fptr(map_pts), len(map_pts), T.fptr(scan), n, T.dptr(q), T.dptr(t),
+                              T.fptr(pts), T.fptr(planes), T.dptr(scores), T.iptr(src), T.iptr(nn) if want_nn else None)
+    res = (pts[:cnt].copy(), planes[:cnt].copy(), scores[:cnt].copy(), src[:cnt].copy())
+    return res + ((nn,) if want_nn else ())
+
+
+def lidar_pose_for_association(opts, q, t):
+    """Q2 = Q * q_lb^-1, T2 = T - Q2 * t_lb  (Estimator.cpp:2216-2217)."""
+    from glio_amd import synth
+    qlb = np.array(opts.q_lb)
+    q2 = synth.qmul(np.asarray(q, float), synth.qconj(qlb) / (qlb @ qlb))
+    t2 = np.asarray(t, float) - synth.q2R(q2 / np.linalg.norm(q2)) @ np.array(opts.t_lb)
+    return q2, t2
+
+
+def eval_lidar_plane(opts, cp, plane, score, t, q, want_J=True):
+    r = np.zeros(1)
+    Jt, Jq = np.zeros(3), np.zeros(4)
+    cp = np.ascontiguousarray(cp, np.float32)
+    plane = np.ascontiguousarray(plane, np.float32)
+    lib().orc_eval_lidar_plane(C.byref(opts), T.fptr(cp), T.fptr(plane), C.c_double(score), _pp([np.ascontiguousarray(t, float), np.ascontiguousarray(q, float)]),
+                               T.dptr(r), _pp([Jt, Jq]) if want_J else None)
+    return r[0], Jt, Jq
+
+
+def eval_imu(opts, pre_struct, params, want_J=True):
+    r = np.zeros(15)
+    sizes = [3, 4, 9, 3, 4, 9]
+    J = [np.zeros((15, s)) for s in sizes]
+    params = [np.ascontiguousarray(p, float) for p in params]
+    ok = lib().orc_eval_imu(C.byref(opts), C.byref(pre_struct), _pp(params), T.dptr(r), _pp(J) if want_J else None)
+    assert ok
+    return r, J
+
+
+def eval_marg(prior_dict, params, want_J=True):
+    from glio_amd import synth
+    ps = synth.prior_struct(prior_dict)
+    n = prior_dict["n"]
+    r = np.zeros(n)
+    sizes = [3 if k == 0 else (4 if k == 1 else 9) for k in prior_dict["blk_kind"]]
+    J = [np.zeros((n, s)) for s in sizes]
+    params = [np.ascontiguousarray(p, float) for p in params]
+    lib().orc_eval_marg(C.byref(ps), _pp(params), T.dptr(r), _pp(J) if want_J else None)
+    return r, J
+
+
+def eval_dd_psr(f, Pi, Pj, yaw, anc, want_J=True):
+    r = np.zeros(19)
+    J = [np.zeros((19, 3)), np.zeros((19, 3)), None, None]
+    params = [np.ascontiguousarray(Pi, float), np.ascontiguousarray(Pj, float), np.array([yaw], float), np.ascontiguousarray(anc, float)]
+    lib().orc_eval_dd_psr(C.byref(f), _pp(params), T.dptr(r), _pp(J) if want_J else None)
+    return r, J[:2]
+
+
+def eval_doppler(f, Pi, SBi, Pj, SBj, ddt, yaw, anc, want_J=True):
+    r = np.zeros(1)
+    J = [np.zeros(3), np.zeros(9), np.zeros(3), np.zeros(9), np.zeros(1), None, None]
+    params = [np.ascontiguousarray(a, float) for a in (Pi, SBi, Pj, SBj, ddt)] + [np.array([yaw], float), np.ascontiguousarray(anc, float)]
+    lib().orc_eval_doppler(C.byref(f), _pp(params), T.dptr(r), _pp(J) if want_J else None)
+    return r[0], J[:5]
+
+
+def quat_plus(q, d):
+    out = np.zeros(4)
+    lib().orc_quat_plus(T.dptr(np.ascontiguousarray(q, float)), T.dptr(np.ascontiguousarray(d, float)), T.dptr(out))
+    return out
+
+
+def plane_qr_solve(A, b):
+    x = np.zeros(3)
+    lib().orc_plane_qr_solve(T.dptr(np.ascontiguousarray(A, float)), T.dptr(np.ascontiguousarray(b, float)), T.dptr(x))
+    return x
+
+
+def eval_binary_plane(cp, pnc, score, t1, q1, t2, q2):
+    r = np.zeros(1)
+    J = [np.zeros(3), np.zeros(4), np.zeros(3), np.zeros(4)]
+    cp = np.ascontiguousarray(cp, np.float32)
+    lib().orc_eval_binary_plane(T.fptr(cp), T.dptr(np.ascontiguousarray(pnc, float)), C.c_double(score),
+                                _pp([np.ascontiguousarray(a, float) for a in (t1, q1, t2, q2)]), T.dptr(r), _pp(J))
+    return r[0], J
+
+
+def batch_linearize(K, band, poses, ci, cj, cp, pnc, score):
+    H = np.zeros((K, band + 1, 36))
+    g = np.zeros((K, 6))
+    cost = C.c_double()
+    ok = lib().orc_batch_linearize(K, band, T.dptr(poses), C.c_int64(len(ci)), T.iptr(ci), T.iptr(cj), T.fptr(cp), T.dptr(pnc), T.dptr(score),
+                                   T.dptr(H), T.dptr(g), C.byref(cost))
+    assert ok
+    return H, g, cost.value
