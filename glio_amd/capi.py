@@ -1,0 +1,185 @@
+"""ctypes binding of libglio_hip.so (include/glio_hip.h) and the host-side mirror of the reference's
+sliding-window call sequence.  There is no CPU fallback: if the library or a HIP device is missing,
+construction raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import ctypes_types as T
+from . import synth
+
+_LIB = None
+LIB_PATH = os.environ.get("GLIO_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libglio_hip.so")
+
+KERNEL_LIDAR_LINEARIZE, KERNEL_FULL_LINEARIZE, KERNEL_TR_STEP, KERNEL_ASSOCIATE, KERNEL_MAP_BUILD = range(5)
+
+
+class GlioError(RuntimeError):
+    pass
+
+
+def load():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise GlioError(f"{LIB_PATH} is missing: build it with `python -m glio_amd.build` (hipcc, gfx950). "
+                            "There is no CPU fallback for the GLIO hot path.")
+        lib = C.CDLL(LIB_PATH)
+        lib.glio_last_error.restype = C.c_char_p
+        lib.glio_destroy.restype = None
+        lib.glio_opts_default.restype = None
+        _LIB = lib
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise GlioError(f"libglio_hip error {rc}: {load().glio_last_error().decode()}")
+
+
+def device_count():
+    return load().glio_device_count()
+
+
+class Context:
+    """One glio_ctx = the device-resident state of one sliding window (one HIP stream)."""
+
+    def __init__(self, opts, device=0):
+        lib = load()
+        if lib.glio_device_count() < 1:
+            raise GlioError("no HIP device visible: libglio_hip has no CPU fallback")
+        self.opts = opts
+        self.W = opts.window
+        self._h = C.c_void_p()
+        _check(lib.glio_create(device, C.byref(opts), C.byref(self._h)))
+        self._keep = []
+
+    def close(self):
+        if self._h:
+            load().glio_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- uploads
+    def set_map(self, map_pts):
+        _check(load().glio_set_map(self._h, T.fptr(map_pts), len(map_pts)))
+
+    def set_scan(self, slot, scan):
+        _check(load().glio_set_scan(self._h, slot, T.fptr(scan), len(scan)))
+
+    def associate(self, slot, scan, q, t):
+        cnt = C.c_int()
+        q = np.ascontiguousarray(q, float); t = np.ascontiguousarray(t, float)
+        _check(load().glio_associate(self._h, slot, T.fptr(scan), len(scan), T.dptr(q), T.dptr(t), C.byref(cnt)))
+        return cnt.value
+
+    def associate_resident(self, slot, q, t):
+        cnt = C.c_int()
+        q = np.ascontiguousarray(q, float); t = np.ascontiguousarray(t, float)
+        _check(load().glio_associate_resident(self._h, slot, T.dptr(q), T.dptr(t), C.byref(cnt)))
+        return cnt.value
+
+    def set_correspondences(self, slot, pts, planes, scores):
+        pts = np.ascontiguousarray(pts, np.float32); planes = np.ascontiguousarray(planes, np.float32)
+        scores = np.ascontiguousarray(scores, np.float64)
+        n = len(scores)
+        if n == 0:
+            pts = np.zeros((1, 4), np.float32); planes = np.zeros((1, 4), np.float32); scores = np.zeros(1)
+        _check(load().glio_set_correspondences(self._h, slot, T.fptr(pts), T.fptr(planes), T.dptr(scores), n))
+
+    def get_correspondences(self, slot):
+        cap = self.opts.max_points_per_scan
+        pts = np.zeros((cap, 4), np.float32); planes = np.zeros((cap, 4), np.float32); scores = np.zeros(cap)
+        cnt = C.c_int()
+        _check(load().glio_get_correspondences(self._h, slot, T.fptr(pts), T.fptr(planes), T.dptr(scores), cap, C.byref(cnt)))
+        n = cnt.value
+        return pts[:n].copy(), planes[:n].copy(), scores[:n].copy()
+
+    def set_imu(self, preints, slots=None):
+        n = len(preints)
+        arr = T.preint_array(n)
+        for k, p in enumerate(preints):
+            synth.fill_preint(arr[k], p)
+        slots = np.arange(max(n, 1), dtype=np.int32) if slots is None else np.ascontiguousarray(slots, np.int32)
+        _check(load().glio_set_imu(self._h, n, arr, T.iptr(slots)))
+
+    def set_prior(self, prior):
+        ps = synth.prior_struct(prior)
+        self._keep.append(prior)
+        _check(load().glio_set_prior(self._h, C.byref(ps)))
+
+    def set_gnss(self, frame, dd, dop):
+        dd_arr = (T.GlioDdPsr * max(len(dd), 1))(*dd)
+        dop_arr = (T.GlioDoppler * max(len(dop), 1))(*dop)
+        _check(load().glio_set_gnss(self._h, C.byref(frame) if frame is not None else None, len(dd), dd_arr, len(dop), dop_arr))
+
+    def load_window(self, win, corr=None, use_gnss=True, use_prior=True, use_imu=True):
+        """Upload a synth.Window: correspondences (pre-made, parity hook) + all small factors."""
+        if corr is not None:
+            for s in range(win.W):
+                self.set_correspondences(s, *corr[s])
+        self.set_imu(win.preints if use_imu else [])
+        self.set_prior(win.prior if use_prior else None)
+        if use_gnss and win.frame is not None:
+            self.set_gnss(win.frame, win.dd, win.dop)
+        else:
+            self.set_gnss(None, [], [])
+
+    # ---- compute
+    def linearize(self, state, want_H=True):
+        n = 15 * self.W + state.n_ddt
+        H = np.zeros((n, n)) if want_H else None
+        g = np.zeros(n) if want_H else None
+        cost = C.c_double()
+        cs = state.c()
+        _check(load().glio_linearize(self._h, C.byref(cs), T.dptr(H) if want_H else None, T.dptr(g) if want_H else None, C.byref(cost)))
+        return H, g, cost.value
+
+    def solve(self, state):
+        s = state.copy()
+        cs = s.c()
+        summ = T.GlioSummary()
+        _check(load().glio_solve(self._h, C.byref(cs), C.byref(summ)))
+        return s, summ
+
+    def time_kernel(self, which, reps=20):
+        ms = C.c_float()
+        _check(load().glio_time_kernel(self._h, which, reps, C.byref(ms)))
+        return ms.value
+
+    def time_solve(self, state, reps=5):
+        ms = C.c_float()
+        summ = T.GlioSummary()
+        cs = state.c()
+        _check(load().glio_time_solve(self._h, C.byref(cs), reps, C.byref(ms), C.byref(summ)))
+        return ms.value, summ
+
+    def set_stream(self, stream_ptr):
+        _check(load().glio_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    # ---- single-factor evaluators (Ceres Evaluate convention)
+    def eval_lidar_plane(self, cp, plane, score, t, q):
+        cp = np.ascontiguousarray(cp, np.float32); plane = np.ascontiguousarray(plane, np.float32)
+        r = np.zeros(1); Jt = np.zeros(3); Jq = np.zeros(4)
+        params = [np.ascontiguousarray(t, float), np.ascontiguousarray(q, float)]
+        P = (T.c_double_p * 2)(T.dptr(params[0]), T.dptr(params[1]))
+        J = (T.c_double_p * 2)(T.dptr(Jt), T.dptr(Jq))
+        _check(load().glio_eval_lidar_plane(self._h, T.fptr(cp), T.fptr(plane), C.c_double(score), P, T.dptr(r), J))
+        return r[0], Jt, Jq
+
+    def eval_imu(self, pre, params):
+        ps = T.GlioPreint()
+        synth.fill_preint(ps, pre)
+        params = [np.ascontiguousarray(p, float) for p in params]
+        P = (T.c_double_p * 6)(*[T.dptr(p) for p in params])
+        r = np.zeros(15)
+        Js = [np.zeros((15, s)) for s in (3, 4, 9, 3, 4, 9)]
+        J = (T.c_double_p * 6)(*[T.dptr(j) for j in Js])
+        _check(load().glio_eval_imu(self._h, C.byref(ps), P, T.dptr(r), J))
+        return r, Js

@@ -1,0 +1,602 @@
+// capi.hip -- the extern "C" boundary of libglio_hip.so (declared in include/glio_hip.h): context
+// management, uploads (with the host-side digestion the reference also does on the CPU before the hot
+// path: IMU sqrt-information, factor sorting), and the solve / linearise / evaluator orchestration.
+// There is NO CPU fallback in here: without a HIP device glio_create fails and every entry point
+// returns GLIO_E_HIP / GLIO_E_STATE.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "glio_device.h"
+
+void glio_launch_eval_imu(glio_ctx* c, const ImuEdgeDev* d_edge, const double* d_params, double* d_out);
+void glio_launch_eval_lidar(glio_ctx* c, const float cp[4], const float plane[4], double score, const double* d_params, double* d_out);
+void glio_launch_gram(glio_ctx* c, int np);
+void glio_tr_step_configure(size_t max_lds);
+
+static thread_local char g_err[512] = "";
+void glio_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+struct CtxExtra {
+    GnssDevExtra gx;
+    double* d_eval_params; double* d_eval_out; ImuEdgeDev* d_eval_edge;
+    double* h_eval;   // pinned
+};
+static std::vector<std::pair<glio_ctx*, CtxExtra*>> g_extras;
+static CtxExtra* extra_of(glio_ctx* c) {
+    for (auto& p : g_extras) if (p.first == c) return p.second;
+    return nullptr;
+}
+GnssDevExtra* glio_extra(glio_ctx* c) { return &extra_of(c)->gx; }
+
+extern "C" {
+
+int glio_abi_version(void) { return 1; }
+const char* glio_last_error(void) { return g_err; }
+int glio_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int glio_struct_sizes(int32_t* out, int n) {
+    const int32_t v[8] = {(int32_t)sizeof(glio_opts), (int32_t)sizeof(glio_state), (int32_t)sizeof(glio_preint), (int32_t)sizeof(glio_prior),
+                          (int32_t)sizeof(glio_dd_psr), (int32_t)sizeof(glio_doppler), (int32_t)sizeof(glio_gnss_frame), (int32_t)sizeof(glio_summary)};
+    for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
+    return 8;
+}
+
+void glio_opts_default(glio_opts* o) {
+    memset(o, 0, sizeof *o);
+    o->window = 5; o->max_iterations = 15; o->max_points_per_scan = 65536; o->max_map_points = 1 << 21;
+    o->max_ddt_epochs = 0; o->jacobi_scaling = 1;
+    o->huber_delta = 1.0; o->doppler_huber_delta = 1.0;
+    o->q_lb[0] = 1.0; o->t_lb[2] = 0.28;
+    o->lidar_const = 7.5; o->surf_dist_thres = 0.18; o->kd_max_radius = 1.5f; o->weight_gate = 0.3f;
+    o->gravity = 9.80511;
+    o->initial_trust_region_radius = 1e4; o->max_trust_region_radius = 1e16; o->min_trust_region_radius = 1e-32;
+    o->min_relative_decrease = 1e-3; o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
+}
+
+#define ALLOC(ptr, bytes) GLIO_HIP_CHECK(hipMalloc((void**)&(ptr), (bytes) > 0 ? (size_t)(bytes) : 16))
+
+int glio_create(int device, const glio_opts* opts, glio_ctx** out) {
+    if (!opts || !out) { glio_set_error("null argument"); return GLIO_E_ARG; }
+    if (glio_device_count() < 1) { glio_set_error("no HIP device visible: the GLIO hot path has no CPU fallback"); return GLIO_E_HIP; }
+    const int W = opts->window;
+    if (W < 1 || W > GLIO_MAX_WINDOW || opts->max_points_per_scan < 1) { glio_set_error("bad window / capacity"); return GLIO_E_ARG; }
+    const int n_max = 15 * W + std::max(0, opts->max_ddt_epochs);
+    if (glio_tr_step_lds_bytes(n_max) > 160 * 1024) { glio_set_error("15*W + ddt = %d unknowns exceed the single-CU solver (LDS)", n_max); return GLIO_E_ARG; }
+    GLIO_HIP_CHECK(hipSetDevice(device));
+    glio_ctx* c = new glio_ctx();
+    memset(c, 0, sizeof *c);
+    c->opts = *opts; c->device = device; c->W = W; c->cap = opts->max_points_per_scan;
+    c->n_ddt_max = std::max(0, opts->max_ddt_epochs); c->n_max = n_max;
+    GLIO_HIP_CHECK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    const size_t wc = (size_t)W * c->cap;
+    ALLOC(c->d_pts, wc * sizeof(float4)); ALLOC(c->d_planes, wc * sizeof(float4)); ALLOC(c->d_scores, wc * sizeof(double));
+    ALLOC(c->d_count, W * sizeof(int)); ALLOC(c->d_scan, wc * sizeof(float4));
+    GLIO_HIP_CHECK(hipMemset(c->d_count, 0, W * sizeof(int)));
+    ALLOC(c->d_imu, W * sizeof(ImuEdgeDev)); ALLOC(c->d_imu_blocks, 2 * W * sizeof(PairBlock));
+    ALLOC(c->d_gnss_blocks, 2 * (size_t)W * W * sizeof(PairBlock));
+    ALLOC(c->d_groups, (size_t)W * W * sizeof(GnssGroup));
+    const int ne = std::max(1, c->n_ddt_max);
+    ALLOC(c->d_ddt_blocks, 2 * (size_t)ne * sizeof(DdtBlock));
+    GLIO_HIP_CHECK(hipMemset(c->d_ddt_blocks, 0, 2 * (size_t)ne * sizeof(DdtBlock)));
+    const int npmax = 6 * W + 9;
+    ALLOC(c->d_prior_J0, (size_t)npmax * npmax * 8); ALLOC(c->d_prior_A0, (size_t)npmax * npmax * 8);
+    ALLOC(c->d_prior_r0, npmax * 8); ALLOC(c->d_prior_x0, (size_t)(2 * W + 1) * 9 * 8);
+    ALLOC(c->d_prior_slot, (2 * W + 1) * 4); ALLOC(c->d_prior_kind, (2 * W + 1) * 4); ALLOC(c->d_prior_idx, (2 * W + 1) * 4);
+    ALLOC(c->d_prior_index, 15 * W * 4);
+    ALLOC(c->d_prior_H, 2 * (size_t)npmax * npmax * 8); ALLOC(c->d_prior_g, 2 * npmax * 8); ALLOC(c->d_prior_cost, 2 * 8);
+    ALLOC(c->d_prior_work, (size_t)(3 * npmax + 9 * (2 * W + 1)) * 8);
+    const int nx = glio_x_size(W, c->n_ddt_max);
+    for (int k = 0; k < 2; ++k) {
+        ALLOC(c->d_x[k], nx * 8);
+        ALLOC(c->d_H[k], (size_t)n_max * n_max * 8);
+        ALLOC(c->d_g[k], n_max * 8);
+        ALLOC(c->d_cost[k], 8);
+    }
+    ALLOC(c->d_xout, nx * 8);
+    ALLOC(c->d_lidar_partials, (size_t)W * GLIO_K3_BLOCKS_PER_KF * GLIO_LIDAR_ACC * 8);
+    ALLOC(c->d_lidar_blocks, 2 * (size_t)W * GLIO_LIDAR_ACC * 8);
+    ALLOC(c->d_L, (size_t)(n_max + 1) * n_max * 8);
+    ALLOC(c->d_vec, (size_t)10 * n_max * 8);
+    ALLOC(c->d_status, sizeof(SolverStatus));
+    GLIO_HIP_CHECK(hipHostMalloc((void**)&c->h_status, sizeof(SolverStatus)));
+    GLIO_HIP_CHECK(hipHostMalloc((void**)&c->h_xbuf, (size_t)nx * 8));
+    GLIO_HIP_CHECK(hipEventCreate(&c->ev0)); GLIO_HIP_CHECK(hipEventCreate(&c->ev1));
+    CtxExtra* ex = new CtxExtra();
+    memset(ex, 0, sizeof *ex);
+    ALLOC(ex->gx.d_runs, (size_t)std::max(1, c->n_ddt_max) * sizeof(DopRun));
+    ALLOC(ex->gx.d_prior_colblk, npmax * 4);
+    ALLOC(ex->d_eval_params, 64 * 8); ALLOC(ex->d_eval_out, (15 + 15 * 32) * 8); ALLOC(ex->d_eval_edge, sizeof(ImuEdgeDev));
+    GLIO_HIP_CHECK(hipHostMalloc((void**)&ex->h_eval, (15 + 15 * 32) * 8));
+    g_extras.emplace_back(c, ex);
+    glio_tr_step_configure(160 * 1024);
+    if (glio_assoc_create(c) != GLIO_OK) return GLIO_E_HIP;
+    *out = c;
+    return GLIO_OK;
+}
+
+void glio_destroy(glio_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    glio_assoc_destroy(c);
+    void* ptrs[] = {c->d_pts, c->d_planes, c->d_scores, c->d_count, c->d_scan, c->d_imu, c->d_imu_blocks, c->d_gnss_blocks, c->d_groups,
+                    c->d_ddt_blocks, c->d_dd, c->d_dop, c->d_prior_J0, c->d_prior_A0, c->d_prior_r0, c->d_prior_x0, c->d_prior_slot,
+                    c->d_prior_kind, c->d_prior_idx, c->d_prior_index, c->d_prior_H, c->d_prior_g, c->d_prior_cost, c->d_prior_work,
+                    c->d_x[0], c->d_x[1], c->d_H[0], c->d_H[1], c->d_g[0], c->d_g[1], c->d_cost[0], c->d_cost[1], c->d_xout,
+                    c->d_lidar_partials, c->d_lidar_blocks, c->d_L, c->d_vec, c->d_status};
+    for (void* p : ptrs) if (p) hipFree(p);
+    hipHostFree(c->h_status); hipHostFree(c->h_xbuf);
+    hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
+    for (size_t i = 0; i < g_extras.size(); ++i)
+        if (g_extras[i].first == c) {
+            CtxExtra* ex = g_extras[i].second;
+            hipFree(ex->gx.d_runs); hipFree(ex->gx.d_prior_colblk); hipFree(ex->d_eval_params); hipFree(ex->d_eval_out); hipFree(ex->d_eval_edge);
+            hipHostFree(ex->h_eval);
+            delete ex;
+            g_extras.erase(g_extras.begin() + i);
+            break;
+        }
+    hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int glio_set_stream(glio_ctx* c, void* s) {
+    if (!c) return GLIO_E_ARG;
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return GLIO_OK;
+}
+int glio_synchronize(glio_ctx* c) {
+    if (!c) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return GLIO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- LiDAR
+int glio_set_correspondences(glio_ctx* c, int slot, const float* pts, const float* planes, const double* scores, int n) {
+    if (!c || slot < 0 || slot >= c->W || n < 0 || n > c->cap) { glio_set_error("bad slot / count %d (cap %d)", n, c ? c->cap : 0); return GLIO_E_ARG; }
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    const size_t off = (size_t)slot * c->cap;
+    if (n > 0) {
+        GLIO_HIP_CHECK(hipMemcpyAsync(c->d_pts + off, pts, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+        GLIO_HIP_CHECK(hipMemcpyAsync(c->d_planes + off, planes, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+        GLIO_HIP_CHECK(hipMemcpyAsync(c->d_scores + off, scores, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    c->h_count[slot] = n;
+    GLIO_HIP_CHECK(hipMemcpyAsync(c->d_count + slot, &c->h_count[slot], 4, hipMemcpyHostToDevice, c->stream));
+    GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->have_factors = 1;
+    return GLIO_OK;
+}
+
+int glio_get_correspondences(glio_ctx* c, int slot, float* pts, float* planes, double* scores, int capacity, int* out_count) {
+    if (!c || slot < 0 || slot >= c->W) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    const int n = c->h_count[slot];
+    if (out_count) *out_count = n;
+    if (n > capacity) { glio_set_error("capacity %d < count %d", capacity, n); return GLIO_E_ARG; }
+    const size_t off = (size_t)slot * c->cap;
+    if (n > 0) {
+        if (pts) GLIO_HIP_CHECK(hipMemcpyAsync(pts, c->d_pts + off, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
+        if (planes) GLIO_HIP_CHECK(hipMemcpyAsync(planes, c->d_planes + off, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
+        if (scores) GLIO_HIP_CHECK(hipMemcpyAsync(scores, c->d_scores + off, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return GLIO_OK;
+}
+
+int glio_set_map(glio_ctx* c, const float* map_xyzi, int n) {
+    if (!c || !map_xyzi || n < 0 || n > c->opts.max_map_points) { glio_set_error("bad map size"); return GLIO_E_ARG; }
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    return glio_assoc_build_map(c, map_xyzi, n);
+}
+int glio_set_scan(glio_ctx* c, int slot, const float* scan, int n) {
+    if (!c || slot < 0 || slot >= c->W || n < 0 || n > c->cap) { glio_set_error("bad slot / scan size"); return GLIO_E_ARG; }
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    if (n > 0) GLIO_HIP_CHECK(hipMemcpyAsync(c->d_scan + (size_t)slot * c->cap, scan, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->h_scan_count[slot] = n;
+    return GLIO_OK;
+}
+int glio_associate_resident(glio_ctx* c, int slot, const double q[4], const double t[3], int* out_count) {
+    if (!c || slot < 0 || slot >= c->W) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    const int rc = glio_assoc_run(c, slot, q, t, out_count);
+    if (rc == GLIO_OK) c->have_factors = 1;
+    return rc;
+}
+int glio_associate(glio_ctx* c, int slot, const float* scan, int n, const double q[4], const double t[3], int* out_count) {
+    const int rc = glio_set_scan(c, slot, scan, n);
+    if (rc != GLIO_OK) return rc;
+    return glio_associate_resident(c, slot, q, t, out_count);
+}
+
+// ---------------------------------------------------------------------------------------------- IMU
+static bool inv15(const double* A_in, double* Ainv) {
+    double A[225];
+    memcpy(A, A_in, sizeof A);
+    for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) Ainv[i * 15 + j] = i == j;
+    for (int c = 0; c < 15; ++c) {
+        int piv = c; double best = fabs(A[c * 15 + c]);
+        for (int r = c + 1; r < 15; ++r) if (fabs(A[r * 15 + c]) > best) { best = fabs(A[r * 15 + c]); piv = r; }
+        if (best == 0.0) return false;
+        if (piv != c) for (int j = 0; j < 15; ++j) { std::swap(A[c * 15 + j], A[piv * 15 + j]); std::swap(Ainv[c * 15 + j], Ainv[piv * 15 + j]); }
+        const double d = A[c * 15 + c];
+        for (int j = 0; j < 15; ++j) { A[c * 15 + j] /= d; Ainv[c * 15 + j] /= d; }
+        for (int r = 0; r < 15; ++r) {
+            if (r == c) continue;
+            const double f = A[r * 15 + c];
+            if (f == 0.0) continue;
+            for (int j = 0; j < 15; ++j) { A[r * 15 + j] -= f * A[c * 15 + j]; Ainv[r * 15 + j] -= f * Ainv[c * 15 + j]; }
+        }
+    }
+    return true;
+}
+// sqrt_info = LLT(cov^-1).matrixL().transpose()  (ImuFactor.h:44-45) -- the reference recomputes this on
+// the CPU in every Evaluate; it only depends on the pre-integration, so it is digested once at upload (Q5).
+static bool digest_edge(const glio_preint* p, int slot, ImuEdgeDev* e) {
+    memset(e, 0, sizeof *e);
+    memcpy(e->delta_p, p->delta_p, 24); memcpy(e->delta_q, p->delta_q, 32); memcpy(e->delta_v, p->delta_v, 24);
+    memcpy(e->lin_ba, p->linearized_ba, 24); memcpy(e->lin_bg, p->linearized_bg, 24);
+    e->sum_dt = p->sum_dt; e->slot_i = slot;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            e->dp_dba[r * 3 + c] = p->jacobian[(0 + r) * 15 + 9 + c];
+            e->dp_dbg[r * 3 + c] = p->jacobian[(0 + r) * 15 + 12 + c];
+            e->dq_dbg[r * 3 + c] = p->jacobian[(3 + r) * 15 + 12 + c];
+            e->dv_dba[r * 3 + c] = p->jacobian[(6 + r) * 15 + 9 + c];
+            e->dv_dbg[r * 3 + c] = p->jacobian[(6 + r) * 15 + 12 + c];
+        }
+    double I[225];
+    if (!inv15(p->covariance, I)) return false;
+    for (int j = 0; j < 15; ++j) {           // lower Cholesky of the (lower triangle of the) inverse
+        double d = I[j * 15 + j];
+        for (int k = 0; k < j; ++k) d -= I[j * 15 + k] * I[j * 15 + k];
+        if (!(d > 0.0)) return false;
+        d = sqrt(d);
+        I[j * 15 + j] = d;
+        for (int i = j + 1; i < 15; ++i) {
+            double s = I[i * 15 + j];
+            for (int k = 0; k < j; ++k) s -= I[i * 15 + k] * I[j * 15 + k];
+            I[i * 15 + j] = s / d;
+        }
+    }
+    for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) e->sqrt_info[i * 15 + j] = j >= i ? I[j * 15 + i] : 0.0;
+    return true;
+}
+
+int glio_set_imu(glio_ctx* c, int n_edges, const glio_preint* edges, const int32_t* slot_i) {
+    if (!c || n_edges < 0 || n_edges > c->W - 1 + (c->W == 1)) { glio_set_error("bad IMU edge count"); return GLIO_E_ARG; }
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    std::vector<ImuEdgeDev> h(std::max(1, n_edges));
+    for (int k = 0; k < n_edges; ++k) {
+        if (slot_i[k] < 0 || slot_i[k] + 1 >= c->W) { glio_set_error("IMU edge slot out of range"); return GLIO_E_ARG; }
+        if (!digest_edge(&edges[k], slot_i[k], &h[k])) { glio_set_error("IMU covariance not invertible / not SPD"); return GLIO_E_NUMERIC; }
+    }
+    if (n_edges) GLIO_HIP_CHECK(hipMemcpy(c->d_imu, h.data(), n_edges * sizeof(ImuEdgeDev), hipMemcpyHostToDevice));
+    c->n_imu = n_edges;
+    if (n_edges) c->have_factors = 1;
+    return GLIO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- prior
+int glio_set_prior(glio_ctx* c, const glio_prior* p) {
+    if (!c) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    if (!p || p->n <= 0) { c->prior_n = 0; c->prior_nb = 0; return GLIO_OK; }
+    const int np = p->n, nb = p->n_blocks, W = c->W;
+    if (np > 6 * W + 9 || nb > 2 * W + 1) { glio_set_error("prior too large for window"); return GLIO_E_ARG; }
+    std::vector<int> index(15 * W, -1), colblk(np, -1);
+    for (int b = 0; b < nb; ++b) {
+        const int s = p->blk_slot[b], k = p->blk_kind[b], idx = p->blk_idx[b];
+        const int ls = k == GLIO_BLK_SPEEDBIAS ? 9 : 3;
+        if (s < 0 || s >= W || idx < 0 || idx + ls > np) { glio_set_error("prior block out of range"); return GLIO_E_ARG; }
+        const int off = 15 * s + (k == GLIO_BLK_TRANS ? 0 : (k == GLIO_BLK_QUAT ? 3 : 6));
+        for (int j = 0; j < ls; ++j) { index[off + j] = idx + j; colblk[idx + j] = b; }
+    }
+    for (int j = 0; j < np; ++j) if (colblk[j] < 0) { glio_set_error("prior column %d not covered by a block", j); return GLIO_E_ARG; }
+    GnssDevExtra* ex = glio_extra(c);
+    GLIO_HIP_CHECK(hipMemcpy(c->d_prior_J0, p->lin_jac, (size_t)np * np * 8, hipMemcpyHostToDevice));
+    GLIO_HIP_CHECK(hipMemcpy(c->d_prior_r0, p->lin_res, np * 8, hipMemcpyHostToDevice));
+    GLIO_HIP_CHECK(hipMemcpy(c->d_prior_x0, p->blk_x0, (size_t)nb * 9 * 8, hipMemcpyHostToDevice));
+    GLIO_HIP_CHECK(hipMemcpy(c->d_prior_slot, p->blk_slot, nb * 4, hipMemcpyHostToDevice));
+    GLIO_HIP_CHECK(hipMemcpy(c->d_prior_kind, p->blk_kind, nb * 4, hipMemcpyHostToDevice));
+    GLIO_HIP_CHECK(hipMemcpy(c->d_prior_idx, p->blk_idx, nb * 4, hipMemcpyHostToDevice));
+    GLIO_HIP_CHECK(hipMemcpy(c->d_prior_index, index.data(), 15 * W * 4, hipMemcpyHostToDevice));
+    GLIO_HIP_CHECK(hipMemcpy(ex->d_prior_colblk, colblk.data(), np * 4, hipMemcpyHostToDevice));
+    c->prior_n = np; c->prior_nb = nb;
+    glio_launch_gram(c, np);
+    GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->have_factors = 1;
+    return GLIO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- GNSS
+static void ecef2rotation_host(const double xyz[3], double R[9]) {   // gnss_utility.cpp:347-390,738-748
+    const double e2 = 6.69437999014e-3, a = 6378137.0, R2D = 180.0 / M_PI, D2R = M_PI / 180.0;
+    const double a2 = a * a, b2 = a2 * (1 - e2), b = sqrt(b2), ep2 = (a2 - b2) / b2;
+    const double p = sqrt(xyz[0] * xyz[0] + xyz[1] * xyz[1]);
+    double s1 = xyz[2] * a, s2 = p * b, h = sqrt(s1 * s1 + s2 * s2);
+    const double st = s1 / h, ct = s2 / h;
+    s1 = xyz[2] + ep2 * b * pow(st, 3);
+    s2 = p - a * e2 * pow(ct, 3);
+    const double lat = (atan(s1 / s2) * R2D) * D2R, lon = (atan2(xyz[1], xyz[0]) * R2D) * D2R;
+    const double sl = sin(lat), cl = cos(lat), so = sin(lon), co = cos(lon);
+    R[0] = -so; R[1] = -sl * co; R[2] = cl * co;
+    R[3] = co;  R[4] = -sl * so; R[5] = cl * so;
+    R[6] = 0;   R[7] = cl;       R[8] = sl;
+}
+
+int glio_set_gnss(glio_ctx* c, const glio_gnss_frame* frame, int n_dd, const glio_dd_psr* dd, int n_dop, const glio_doppler* dop) {
+    if (!c || n_dd < 0 || n_dop < 0) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    const int W = c->W;
+    if (frame) {
+        c->frame = *frame;
+        double Ree[9];
+        ecef2rotation_host(frame->anc_ecef, Ree);
+        const double s = sin(frame->yaw_enu_local), co = cos(frame->yaw_enu_local);
+        const double Rel[9] = {co, -s, 0, s, co, 0, 0, 0, 1};
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+            double a = 0;
+            for (int k = 0; k < 3; ++k) a += Ree[i * 3 + k] * Rel[k * 3 + j];
+            c->R_ecef_local[i * 3 + j] = a;
+        }
+    } else if (n_dd + n_dop > 0) { glio_set_error("GNSS factors need a frame"); return GLIO_E_ARG; }
+    // sort by (slot_i, slot_j), Doppler additionally by epoch; group = one slot pair
+    std::vector<glio_dd_psr> sdd(dd, dd + n_dd);
+    std::vector<glio_doppler> sdop(dop, dop + n_dop);
+    for (auto& f : sdd) if (f.slot_i < 0 || f.slot_i >= W || f.slot_j < 0 || f.slot_j >= W || f.slot_i == f.slot_j || f.n_sat < 2 || f.n_sat > GLIO_DD_MAX_SAT || f.master < 0 || f.master >= f.n_sat) { glio_set_error("bad DD factor"); return GLIO_E_ARG; }
+    for (auto& f : sdop) if (f.slot_i < 0 || f.slot_i >= W || f.slot_j < 0 || f.slot_j >= W || f.slot_i == f.slot_j || f.epoch < 0 || f.epoch >= c->n_ddt_max) { glio_set_error("bad Doppler factor (epoch %d, max_ddt_epochs %d)", f.epoch, c->n_ddt_max); return GLIO_E_ARG; }
+    auto key = [W](int i, int j) { return i * W + j; };
+    std::stable_sort(sdd.begin(), sdd.end(), [&](const glio_dd_psr& a, const glio_dd_psr& b) { return key(a.slot_i, a.slot_j) < key(b.slot_i, b.slot_j); });
+    std::stable_sort(sdop.begin(), sdop.end(), [&](const glio_doppler& a, const glio_doppler& b) {
+        const int ka = key(a.slot_i, a.slot_j), kb = key(b.slot_i, b.slot_j);
+        return ka != kb ? ka < kb : a.epoch < b.epoch; });
+    std::vector<GnssGroup> groups;
+    std::vector<DopRun> runs;
+    size_t a = 0, b = 0;
+    while (a < sdd.size() || b < sdop.size()) {
+        int k = 1 << 30;
+        if (a < sdd.size()) k = std::min(k, key(sdd[a].slot_i, sdd[a].slot_j));
+        if (b < sdop.size()) k = std::min(k, key(sdop[b].slot_i, sdop[b].slot_j));
+        GnssGroup g;
+        g.slot_i = k / W; g.slot_j = k % W;
+        g.dd_begin = (int)a;
+        while (a < sdd.size() && key(sdd[a].slot_i, sdd[a].slot_j) == k) ++a;
+        g.dd_end = (int)a;
+        g.dop_begin = (int)b;
+        g.run_begin = (int)runs.size();
+        while (b < sdop.size() && key(sdop[b].slot_i, sdop[b].slot_j) == k) {
+            DopRun r;
+            r.begin = (int)b; r.epoch = sdop[b].epoch; r.group = (int)groups.size();
+            while (b < sdop.size() && key(sdop[b].slot_i, sdop[b].slot_j) == k && sdop[b].epoch == r.epoch) ++b;
+            r.end = (int)b;
+            runs.push_back(r);
+        }
+        g.dop_end = (int)b;
+        g.run_end = (int)runs.size();
+        groups.push_back(g);
+    }
+    // an epoch must belong to exactly one group (one clock-drift unknown per epoch, one bracketing pair)
+    { std::vector<int> seen(std::max(1, c->n_ddt_max), 0); for (auto& r : runs) if (seen[r.epoch]++) { glio_set_error("epoch %d appears under two keyframe pairs", r.epoch); return GLIO_E_ARG; } }
+    if ((int)groups.size() > W * W) return GLIO_E_ARG;
+    if (c->d_dd) { hipFree(c->d_dd); c->d_dd = nullptr; }
+    if (c->d_dop) { hipFree(c->d_dop); c->d_dop = nullptr; }
+    ALLOC(c->d_dd, sdd.size() * sizeof(glio_dd_psr)); ALLOC(c->d_dop, sdop.size() * sizeof(glio_doppler));
+    if (!sdd.empty()) GLIO_HIP_CHECK(hipMemcpy(c->d_dd, sdd.data(), sdd.size() * sizeof(glio_dd_psr), hipMemcpyHostToDevice));
+    if (!sdop.empty()) GLIO_HIP_CHECK(hipMemcpy(c->d_dop, sdop.data(), sdop.size() * sizeof(glio_doppler), hipMemcpyHostToDevice));
+    if (!groups.empty()) GLIO_HIP_CHECK(hipMemcpy(c->d_groups, groups.data(), groups.size() * sizeof(GnssGroup), hipMemcpyHostToDevice));
+    GnssDevExtra* ex = glio_extra(c);
+    if (!runs.empty()) GLIO_HIP_CHECK(hipMemcpy(ex->d_runs, runs.data(), runs.size() * sizeof(DopRun), hipMemcpyHostToDevice));
+    ex->n_runs = (int)runs.size();
+    GLIO_HIP_CHECK(hipMemset(c->d_ddt_blocks, 0, 2 * (size_t)std::max(1, c->n_ddt_max) * sizeof(DdtBlock)));
+    c->n_dd = (int)sdd.size(); c->n_dop = (int)sdop.size(); c->n_groups = (int)groups.size();
+    if (c->n_groups) c->have_factors = 1;
+    return GLIO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- solve
+static int check_state(glio_ctx* c, const glio_state* s) {
+    if (!c || !s || !s->trans || !s->quat || !s->speed_bias) { glio_set_error("null state"); return GLIO_E_ARG; }
+    if (s->n_ddt < 0 || s->n_ddt > c->n_ddt_max || (s->n_ddt > 0 && !s->rcv_ddt)) { glio_set_error("n_ddt %d exceeds max_ddt_epochs %d", s->n_ddt, c->n_ddt_max); return GLIO_E_ARG; }
+    if (!c->have_factors) { glio_set_error("no factors set"); return GLIO_E_STATE; }
+    return GLIO_OK;
+}
+static void pack_state(glio_ctx* c, const glio_state* s, double* h) {
+    const int W = c->W;
+    memcpy(h, s->trans, 3 * W * 8); memcpy(h + 3 * W, s->quat, 4 * W * 8); memcpy(h + 7 * W, s->speed_bias, 9 * W * 8);
+    if (s->n_ddt) memcpy(h + 16 * W, s->rcv_ddt, s->n_ddt * 8);
+}
+static void unpack_state(glio_ctx* c, const double* h, glio_state* s) {
+    const int W = c->W;
+    memcpy(s->trans, h, 3 * W * 8); memcpy(s->quat, h + 3 * W, 4 * W * 8); memcpy(s->speed_bias, h + 7 * W, 9 * W * 8);
+    if (s->n_ddt) memcpy(s->rcv_ddt, h + 16 * W, s->n_ddt * 8);
+}
+static void enqueue_linearize(glio_ctx* c, int use_status, int which, int n_ddt) {
+    glio_launch_lidar_linearize(c, use_status, which);
+    glio_launch_small_factors(c, use_status, which, n_ddt);
+    glio_launch_assemble(c, use_status, which, n_ddt);
+}
+// enqueue one complete solve from the packed state in h_xbuf; no host synchronisation inside
+static int enqueue_solve(glio_ctx* c, int n_ddt) {
+    const int nx = glio_x_size(c->W, n_ddt);
+    SolverStatus st;
+    memset(&st, 0, sizeof st);
+    st.cur = 1;                       // "candidate" buffer 0 holds the initial point
+    st.cand_pending = 1;
+    st.radius = c->opts.initial_trust_region_radius; st.mu = 1e-8; st.n_ddt = n_ddt;
+    *c->h_status = st;
+    GLIO_HIP_CHECK(hipMemcpyAsync(c->d_status, c->h_status, sizeof st, hipMemcpyHostToDevice, c->stream));
+    GLIO_HIP_CHECK(hipMemcpyAsync(c->d_x[0], c->h_xbuf, (size_t)nx * 8, hipMemcpyHostToDevice, c->stream));
+    for (int it = 0; it <= c->opts.max_iterations; ++it) {
+        enqueue_linearize(c, 1, 0, n_ddt);
+        glio_launch_tr_step(c, n_ddt);
+    }
+    GLIO_HIP_CHECK(hipGetLastError());
+    return GLIO_OK;
+}
+static void fill_summary(glio_ctx* c, glio_summary* sum) {
+    if (!sum) return;
+    const SolverStatus& st = *c->h_status;
+    memset(sum, 0, sizeof *sum);
+    sum->iterations = st.iteration; sum->successful_steps = st.successful; sum->termination = st.termination;
+    for (int k = 0; k < c->W; ++k) sum->n_lidar_residuals += c->h_count[k];
+    if (st.termination == GLIO_TERM_FAILURE) glio_set_error("trust-region solver failure (mu %g, iteration %d, invalid %d)", st.mu, st.iteration, st.invalid);
+    sum->initial_cost = st.initial_cost; sum->final_cost = st.cost; sum->final_radius = st.radius; sum->gradient_max_norm = st.grad_max_norm;
+}
+
+int glio_solve(glio_ctx* c, glio_state* s, glio_summary* sum) {
+    int rc = check_state(c, s);
+    if (rc) return rc;
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    const int n_ddt = s->n_ddt, nx = glio_x_size(c->W, n_ddt);
+    pack_state(c, s, c->h_xbuf);
+    rc = enqueue_solve(c, n_ddt);
+    if (rc) return rc;
+    GLIO_HIP_CHECK(hipMemcpyAsync(c->h_status, c->d_status, sizeof(SolverStatus), hipMemcpyDeviceToHost, c->stream));
+    GLIO_HIP_CHECK(hipMemcpyAsync(c->h_xbuf, c->d_xout, (size_t)nx * 8, hipMemcpyDeviceToHost, c->stream));
+    GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    fill_summary(c, sum);
+    if (!c->h_status->done) { glio_set_error("solver did not finish"); return GLIO_E_STATE; }
+    unpack_state(c, c->h_xbuf, s);
+    c->last_n_ddt = n_ddt;
+    if (c->h_status->termination == GLIO_TERM_FAILURE) return GLIO_E_NUMERIC;
+    return GLIO_OK;
+}
+
+int glio_linearize(glio_ctx* c, const glio_state* s, double* H, double* g, double* cost) {
+    int rc = check_state(c, s);
+    if (rc) return rc;
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    const int n_ddt = s->n_ddt, nx = glio_x_size(c->W, n_ddt), n = 15 * c->W + n_ddt;
+    pack_state(c, s, c->h_xbuf);
+    GLIO_HIP_CHECK(hipMemcpyAsync(c->d_x[0], c->h_xbuf, (size_t)nx * 8, hipMemcpyHostToDevice, c->stream));
+    enqueue_linearize(c, 0, 0, n_ddt);
+    GLIO_HIP_CHECK(hipGetLastError());
+    if (H) GLIO_HIP_CHECK(hipMemcpyAsync(H, c->d_H[0], (size_t)n * n * 8, hipMemcpyDeviceToHost, c->stream));
+    if (g) GLIO_HIP_CHECK(hipMemcpyAsync(g, c->d_g[0], (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    if (cost) GLIO_HIP_CHECK(hipMemcpyAsync(cost, c->d_cost[0], 8, hipMemcpyDeviceToHost, c->stream));
+    GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->last_n_ddt = n_ddt;
+    return GLIO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- evaluators
+int glio_eval_lidar_plane(glio_ctx* c, const float cp[4], const float plane[4], double score,
+                          double const* const* P, double* res, double** J) {
+    if (!c || !P || !res) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    CtxExtra* ex = extra_of(c);
+    double h[7];
+    memcpy(h, P[0], 24); memcpy(h + 3, P[1], 32);
+    GLIO_HIP_CHECK(hipMemcpyAsync(ex->d_eval_params, h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    glio_launch_eval_lidar(c, cp, plane, score, ex->d_eval_params, ex->d_eval_out);
+    GLIO_HIP_CHECK(hipMemcpyAsync(ex->h_eval, ex->d_eval_out, 8 * 8, hipMemcpyDeviceToHost, c->stream));
+    GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    res[0] = ex->h_eval[0];
+    if (J) {
+        if (J[0]) memcpy(J[0], ex->h_eval + 1, 24);
+        if (J[1]) memcpy(J[1], ex->h_eval + 4, 32);
+    }
+    return GLIO_OK;
+}
+
+int glio_eval_imu(glio_ctx* c, const glio_preint* pre, double const* const* P, double* res, double** J) {
+    if (!c || !pre || !P || !res) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    CtxExtra* ex = extra_of(c);
+    ImuEdgeDev e;
+    if (!digest_edge(pre, 0, &e)) { glio_set_error("IMU covariance not invertible / not SPD"); return GLIO_E_NUMERIC; }
+    double h[32];
+    const int sz[6] = {3, 4, 9, 3, 4, 9};
+    int off = 0;
+    for (int b = 0; b < 6; ++b) { memcpy(h + off, P[b], sz[b] * 8); off += sz[b]; }
+    GLIO_HIP_CHECK(hipMemcpyAsync(ex->d_eval_edge, &e, sizeof e, hipMemcpyHostToDevice, c->stream));
+    GLIO_HIP_CHECK(hipMemcpyAsync(ex->d_eval_params, h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));   // e and h live on the stack
+    glio_launch_eval_imu(c, ex->d_eval_edge, ex->d_eval_params, ex->d_eval_out);
+    GLIO_HIP_CHECK(hipMemcpyAsync(ex->h_eval, ex->d_eval_out, (15 + 15 * 32) * 8, hipMemcpyDeviceToHost, c->stream));
+    GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    memcpy(res, ex->h_eval, 15 * 8);
+    if (J) {
+        off = 0;
+        for (int b = 0; b < 6; ++b) {
+            if (J[b]) for (int r = 0; r < 15; ++r) for (int k = 0; k < sz[b]; ++k) J[b][r * sz[b] + k] = ex->h_eval[15 + r * 32 + off + k];
+            off += sz[b];
+        }
+    }
+    return GLIO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- timing hooks
+int glio_time_kernel(glio_ctx* c, int which, int reps, float* ms_out) {
+    if (!c || reps < 1 || !ms_out) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    if (which == GLIO_KERNEL_ASSOCIATE || which == GLIO_KERNEL_MAP_BUILD) { glio_assoc_time_hooks(c, which, reps, ms_out); return GLIO_OK; }
+    if (!c->have_factors) return GLIO_E_STATE;
+    const int n_ddt = c->last_n_ddt;
+    // warm-up launch, then `reps` timed launches on the context's stream
+    for (int pass = 0; pass < 2; ++pass) {
+        const int r = pass == 0 ? 1 : reps;
+        if (pass == 1) GLIO_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+        for (int k = 0; k < r; ++k) {
+            if (which == GLIO_KERNEL_LIDAR_LINEARIZE) glio_launch_lidar_linearize(c, 0, 0);
+            else if (which == GLIO_KERNEL_FULL_LINEARIZE) enqueue_linearize(c, 0, 0, n_ddt);
+            else if (which == GLIO_KERNEL_TR_STEP) {
+                // one first-iteration step computation (scale, Cauchy, Cholesky, dogleg) on H[0]
+                SolverStatus st;
+                memset(&st, 0, sizeof st);
+                st.cur = 1; st.cand_pending = 1; st.radius = c->opts.initial_trust_region_radius; st.mu = 1e-8; st.n_ddt = n_ddt;
+                *c->h_status = st;
+                GLIO_HIP_CHECK(hipMemcpyAsync(c->d_status, c->h_status, sizeof st, hipMemcpyHostToDevice, c->stream));
+                glio_launch_tr_step(c, n_ddt);
+            } else return GLIO_E_ARG;
+        }
+        if (pass == 1) GLIO_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
+        GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    float ms = 0;
+    GLIO_HIP_CHECK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *ms_out = ms / reps;
+    return GLIO_OK;
+}
+
+int glio_time_solve(glio_ctx* c, const glio_state* s, int reps, float* ms_out, glio_summary* last) {
+    int rc = check_state(c, s);
+    if (rc) return rc;
+    if (reps < 1 || !ms_out) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    const int n_ddt = s->n_ddt;
+    pack_state(c, s, c->h_xbuf);
+    GLIO_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+    for (int k = 0; k < reps; ++k) {
+        rc = enqueue_solve(c, n_ddt);
+        if (rc) return rc;
+        // h_status is re-read by the next enqueue's async H2D: wait for that copy, not for the solve
+        GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    GLIO_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
+    GLIO_HIP_CHECK(hipMemcpyAsync(c->h_status, c->d_status, sizeof(SolverStatus), hipMemcpyDeviceToHost, c->stream));
+    GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    GLIO_HIP_CHECK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *ms_out = ms / reps;
+    fill_summary(c, last);
+    c->last_n_ddt = n_ddt;
+    return GLIO_OK;
+}
+
+}  // extern "C"

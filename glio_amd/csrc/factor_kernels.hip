@@ -1,0 +1,784 @@
+// factor_kernels.hip -- K4/K5/K6 + assembly: the O(W) "small" factors of the sliding-window problem
+// and the gather that builds the dense normal equations H, g on device.
+//
+//   k_small_factors : one launch, workgroup roles
+//       [0, W)              reduce the K3 partials of keyframe b (fixed order)
+//       [W, W+n_imu)        ImuFactor::Evaluate          (reference GLIO/include/factors/ImuFactor.h:21-171,
+//                                                          Preintegration.h:196-235) -> 30x30 block
+//       [.., +n_groups)     dd_psr_factor_20::Evaluate   (dd_psr_factor.hpp:25-171) and
+//                           tcdopplerFactor              (dopp_factor.hpp:24-75, HuberLoss(1.0)) of one
+//                           (slot_i,slot_j) pair -> 30x30 block + per-epoch clock-drift coupling
+//       last                MarginalizationFactor::Evaluate (GLIO/src/MarginalizationFactor.cpp:233-287)
+//   k_assemble      : H[r][c] / g[r] gathered from those blocks (no atomics, deterministic)
+//
+// All Jacobians go through the same chain as Ceres: global Jacobian -> (loss corrector) ->
+// QuaternionParameterization Jacobian (left (+), GraphGNSSLibV1.1/docs/source/nnls_modeling.rst:1312-1327).
+// These factors are tiny (LDS/latency-bound, not roofline material); the point of having them on device
+// is that a whole trust-region solve runs without a host round trip.
+#include "glio_device.h"
+
+#define SF_THREADS 256
+
+struct SmallArgs {
+    int W, n_imu, n_groups, has_prior, n_ddt;
+    int lidar_blocks_per_kf;
+    const double* x0; const double* x1;
+    const SolverStatus* st; int use_status; int fixed_which;
+    const double* lidar_partials; double* lidar_blocks;     // [2][W][28]
+    const ImuEdgeDev* imu; PairBlock* imu_blocks;           // [2][W]
+    const glio_dd_psr* dd; const glio_doppler* dop; const GnssGroup* groups; const DopRun* runs; int n_runs;
+    PairBlock* gnss_blocks; DdtBlock* ddt_blocks; int gnss_stride; int ddt_stride;
+    double gravity, dop_huber;
+    double R_ecef_local[9]; double anc[3];
+    // prior
+    int np, npb;
+    const double* pJ0; const double* pA0; const double* pr0; const double* px0;
+    const int* pslot; const int* pkind; const int* pidx; const int* pcolblk;
+    double* pH; double* pg; double* pcost; double* pwork;
+};
+
+// ------------------------------------------------------------------------------------------------
+// IMU
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void qleft16(const double q[4], double M[16]) {
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    M[0] = w; M[1] = -x; M[2] = -y; M[3] = -z;
+    M[4] = x; M[5] = w; M[6] = -z; M[7] = y;
+    M[8] = y; M[9] = z; M[10] = w; M[11] = -x;
+    M[12] = z; M[13] = -y; M[14] = x; M[15] = w;
+}
+__device__ __forceinline__ void qright16(const double p[4], double M[16]) {
+    const double w = p[0], x = p[1], y = p[2], z = p[3];
+    M[0] = w; M[1] = -x; M[2] = -y; M[3] = -z;
+    M[4] = x; M[5] = w; M[6] = z; M[7] = -y;
+    M[8] = y; M[9] = -z; M[10] = w; M[11] = x;
+    M[12] = z; M[13] = y; M[14] = -x; M[15] = w;
+}
+
+// global column offsets of the six parameter blocks Pi3 Qi4 SBi9 Pj3 Qj4 SBj9
+#define IMU_GC 32
+// `eval_out` != NULL: single-factor evaluator mode (glio_eval_imu): write the whitened residual [15] and
+// the whitened GLOBAL Jacobians [15][32] (Pi3 Qi4 SBi9 Pj3 Qj4 SBj9) and return.
+__device__ void imu_block(const double gravity, const double* __restrict__ pPi, const double* __restrict__ pQi,
+                          const double* __restrict__ pSBi, const double* __restrict__ pPj, const double* __restrict__ pQj,
+                          const double* __restrict__ pSBj, const ImuEdgeDev& e, PairBlock* out, double* eval_out) {
+    __shared__ double Jg[15 * IMU_GC];
+    __shared__ double Jl[15 * 30];
+    __shared__ double WJ[15 * 30];
+    __shared__ double S[225];
+    __shared__ double r[15], wr[15];
+    const int tid = threadIdx.x;
+    const int i = e.slot_i, j = i + 1;
+    enum { O_P = 0, O_R = 3, O_V = 6, O_BA = 9, O_BG = 12 };
+
+    // ---- common quantities, computed redundantly by every lane (uniform control flow)
+    double Pi[3], Pj[3], Qi_raw[4], Qj_raw[4], Qi[4], Qj[4], Vi[3], Vj[3], Bai[3], Bgi[3], Baj[3], Bgj[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        Pi[k] = pPi[k]; Pj[k] = pPj[k];
+        Vi[k] = pSBi[k]; Bai[k] = pSBi[3 + k]; Bgi[k] = pSBi[6 + k];
+        Vj[k] = pSBj[k]; Baj[k] = pSBj[3 + k]; Bgj[k] = pSBj[6 + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { Qi_raw[k] = Qi[k] = pQi[k]; Qj_raw[k] = Qj[k] = pQj[k]; }
+    d_qnormalize(Qi); d_qnormalize(Qj);                       // ImuFactor.h:25,33
+    const double g[3] = {0.0, 0.0, -gravity};
+    const double dt = e.sum_dt;
+    double dba[3], dbg[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { dba[k] = Bai[k] - e.lin_ba[k]; dbg[k] = Bgi[k] - e.lin_bg[k]; }
+    double th[3], dq[4], cdq[4], cdv[3], cdp[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        th[k] = e.dq_dbg[3 * k] * dbg[0] + e.dq_dbg[3 * k + 1] * dbg[1] + e.dq_dbg[3 * k + 2] * dbg[2];
+        cdv[k] = e.delta_v[k] + (e.dv_dba[3 * k] * dba[0] + e.dv_dba[3 * k + 1] * dba[1] + e.dv_dba[3 * k + 2] * dba[2])
+                 + (e.dv_dbg[3 * k] * dbg[0] + e.dv_dbg[3 * k + 1] * dbg[1] + e.dv_dbg[3 * k + 2] * dbg[2]);
+        cdp[k] = e.delta_p[k] + (e.dp_dba[3 * k] * dba[0] + e.dp_dba[3 * k + 1] * dba[1] + e.dp_dba[3 * k + 2] * dba[2])
+                 + (e.dp_dbg[3 * k] * dbg[0] + e.dp_dbg[3 * k + 1] * dbg[1] + e.dp_dbg[3 * k + 2] * dbg[2]);
+    }
+    dq[0] = 1.0; dq[1] = th[0] / 2.0; dq[2] = th[1] / 2.0; dq[3] = th[2] / 2.0;   // deltaQ, not normalised (Q4)
+    d_qmul(e.delta_q, dq, cdq);
+    double Qi_inv[4], Qj_inv[4], cdq_inv[4], tmp[3], tmp1[3];
+    d_qinv(Qi, Qi_inv); d_qinv(Qj, Qj_inv); d_qinv(cdq, cdq_inv);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        tmp[k] = -0.5 * g[k] * dt * dt + Pj[k] - Pi[k] - Vi[k] * dt;
+        tmp1[k] = -g[k] * dt + Vj[k] - Vi[k];
+    }
+    double Ri_inv[9];
+    d_q2R(Qi_inv, Ri_inv);
+
+    // ---- residual (Preintegration.h:227-232) by lane 0; zero Jg by everyone
+    for (int k = tid; k < 15 * IMU_GC; k += SF_THREADS) Jg[k] = 0.0;
+    for (int k = tid; k < 225; k += SF_THREADS) S[k] = e.sqrt_info[k];
+    if (tid == 0) {
+        double rot[3], qij[4], qe[4];
+        d_qrot(Qi_inv, tmp, rot);
+        for (int k = 0; k < 3; ++k) r[O_P + k] = rot[k] - cdp[k];
+        d_qmul(Qi_inv, Qj, qij);
+        d_qmul(cdq_inv, qij, qe);
+        d_qnormalize(qe);
+        for (int k = 0; k < 3; ++k) r[O_R + k] = 2.0 * qe[1 + k];
+        d_qrot(Qi_inv, tmp1, rot);
+        for (int k = 0; k < 3; ++k) r[O_V + k] = rot[k] - cdv[k];
+        for (int k = 0; k < 3; ++k) { r[O_BA + k] = Baj[k] - Bai[k]; r[O_BG + k] = Bgj[k] - Bgi[k]; }
+    }
+    __syncthreads();
+
+    // ---- global Jacobians: lanes 0..5 fill one parameter block each (ImuFactor.h:63-167)
+    if (tid == 0) {            // Pi
+        for (int p = 0; p < 3; ++p) for (int c = 0; c < 3; ++c) Jg[(O_P + p) * IMU_GC + 0 + c] = -Ri_inv[p * 3 + c];
+    } else if (tid == 1) {     // Qi  (the P,V rows are the reference's as-written block, quirk Q15)
+        const double w = Qi[0];
+        const double* u = Qi + 1;
+        for (int sblk = 0; sblk < 2; ++sblk) {
+            const double* v = sblk == 0 ? tmp : tmp1;
+            const int row = sblk == 0 ? O_P : O_V;
+            double uxv[3];
+            d_cross(u, v, uxv);
+            const double udv = d_dot3(u, v);
+            const double Sv[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
+            for (int p = 0; p < 3; ++p) {
+                Jg[(row + p) * IMU_GC + 3] = 2 * (w * v[p] + uxv[p]);
+                for (int c = 0; c < 3; ++c)
+                    Jg[(row + p) * IMU_GC + 4 + c] = 2 * ((p == c ? udv : 0.0) + u[p] * v[c] - v[p] * u[c] - w * Sv[p * 3 + c]);
+            }
+        }
+        double L[16], Rm[16];
+        qleft16(Qj_inv, L); qright16(cdq, Rm);
+        for (int p = 0; p < 3; ++p)
+            for (int c = 0; c < 4; ++c) {
+                double s = 0;
+                for (int k = 0; k < 4; ++k) s += L[(1 + p) * 4 + k] * Rm[k * 4 + c];
+                Jg[(O_R + p) * IMU_GC + 3 + c] = -2 * s;
+            }
+    } else if (tid == 2) {     // SBi
+        double qa[4], qb[4];
+        d_qmul(Qj_inv, Qi, qa);
+        d_qmul(qa, cdq, qb);
+        const double TL[9] = {qb[0], -qb[3], qb[2], qb[3], qb[0], -qb[1], -qb[2], qb[1], qb[0]};   // w I + [vec]x
+        for (int p = 0; p < 3; ++p)
+            for (int c = 0; c < 3; ++c) {
+                Jg[(O_P + p) * IMU_GC + 7 + 0 + c] = -Ri_inv[p * 3 + c] * dt;
+                Jg[(O_P + p) * IMU_GC + 7 + 3 + c] = -e.dp_dba[p * 3 + c];
+                Jg[(O_P + p) * IMU_GC + 7 + 6 + c] = -e.dp_dbg[p * 3 + c];
+                Jg[(O_V + p) * IMU_GC + 7 + 0 + c] = -Ri_inv[p * 3 + c];
+                Jg[(O_V + p) * IMU_GC + 7 + 3 + c] = -e.dv_dba[p * 3 + c];
+                Jg[(O_V + p) * IMU_GC + 7 + 6 + c] = -e.dv_dbg[p * 3 + c];
+                double s = 0;
+                for (int k = 0; k < 3; ++k) s += TL[p * 3 + k] * e.dq_dbg[k * 3 + c];
+                Jg[(O_R + p) * IMU_GC + 7 + 6 + c] = -s;
+            }
+        for (int p = 0; p < 3; ++p) { Jg[(O_BA + p) * IMU_GC + 7 + 3 + p] = -1.0; Jg[(O_BG + p) * IMU_GC + 7 + 6 + p] = -1.0; }
+    } else if (tid == 3) {     // Pj
+        for (int p = 0; p < 3; ++p) for (int c = 0; c < 3; ++c) Jg[(O_P + p) * IMU_GC + 16 + c] = Ri_inv[p * 3 + c];
+    } else if (tid == 4) {     // Qj
+        double qa[4], L[16];
+        d_qmul(cdq_inv, Qi_inv, qa);
+        qleft16(qa, L);
+        for (int p = 0; p < 3; ++p) for (int c = 0; c < 4; ++c) Jg[(O_R + p) * IMU_GC + 19 + c] = 2 * L[(1 + p) * 4 + c];
+    } else if (tid == 5) {     // SBj
+        for (int p = 0; p < 3; ++p) for (int c = 0; c < 3; ++c) Jg[(O_V + p) * IMU_GC + 23 + c] = Ri_inv[p * 3 + c];
+        for (int p = 0; p < 3; ++p) { Jg[(O_BA + p) * IMU_GC + 23 + 3 + p] = 1.0; Jg[(O_BG + p) * IMU_GC + 23 + 6 + p] = 1.0; }
+    }
+    __syncthreads();
+
+    if (eval_out) {
+        for (int idx = tid; idx < 15 * IMU_GC; idx += SF_THREADS) {
+            const int rr = idx / IMU_GC, c = idx % IMU_GC;
+            double sacc = 0;
+            for (int k = 0; k < 15; ++k) sacc += S[rr * 15 + k] * Jg[k * IMU_GC + c];
+            eval_out[15 + idx] = sacc;
+        }
+        if (tid < 15) {
+            double sacc = 0;
+            for (int k = 0; k < 15; ++k) sacc += S[tid * 15 + k] * r[k];
+            eval_out[tid] = sacc;
+        }
+        return;
+    }
+    // ---- local parameterisation (Plus Jacobian at the RAW quaternion, as Ceres does)
+    double PJi[12], PJj[12];
+    d_plus_jac(Qi_raw, PJi); d_plus_jac(Qj_raw, PJj);
+    for (int idx = tid; idx < 450; idx += SF_THREADS) {
+        const int rr = idx / 30, c = idx % 30;
+        const double* row = Jg + rr * IMU_GC;
+        double v;
+        if (c < 3) v = row[c];
+        else if (c < 6) { const int cc = c - 3; v = row[3] * PJi[cc] + row[4] * PJi[3 + cc] + row[5] * PJi[6 + cc] + row[6] * PJi[9 + cc]; }
+        else if (c < 15) v = row[7 + (c - 6)];
+        else if (c < 18) v = row[16 + (c - 15)];
+        else if (c < 21) { const int cc = c - 18; v = row[19] * PJj[cc] + row[20] * PJj[3 + cc] + row[21] * PJj[6 + cc] + row[22] * PJj[9 + cc]; }
+        else v = row[23 + (c - 21)];
+        Jl[idx] = v;
+    }
+    __syncthreads();
+    // ---- whitening by sqrt_info (ImuFactor.h:47,69,97,...)
+    for (int idx = tid; idx < 450; idx += SF_THREADS) {
+        const int rr = idx / 30, c = idx % 30;
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 15; ++k) s += S[rr * 15 + k] * Jl[k * 30 + c];
+        WJ[idx] = s;
+    }
+    if (tid < 15) {
+        double s = 0;
+        for (int k = 0; k < 15; ++k) s += S[tid * 15 + k] * r[k];
+        wr[tid] = s;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 900; idx += SF_THREADS) {
+        const int p = idx / 30, c = idx % 30;
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 15; ++k) s += WJ[k * 30 + p] * WJ[k * 30 + c];
+        out->H[idx] = s;
+    }
+    if (tid < 30) {
+        double s = 0;
+        for (int k = 0; k < 15; ++k) s += WJ[k * 30 + tid] * wr[k];
+        out->g[tid] = s;
+    }
+    if (tid == 32) {
+        double s = 0;
+        for (int k = 0; k < 15; ++k) s += wr[k] * wr[k];
+        out->cost = 0.5 * s;
+        out->slot_a = i; out->slot_b = j;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GNSS group: DD pseudorange (no loss) + Doppler (Huber) of one (slot_i, slot_j) pair
+// ------------------------------------------------------------------------------------------------
+#define DOP_CHUNK 128
+__device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, const GnssGroup& gr, int gidx,
+                           PairBlock* out, DdtBlock* ddt_out) {
+    __shared__ double raw[19], Jri[19 * 3], Jrj[19 * 3];
+    __shared__ double wres[19], wJ[19 * 6];
+    __shared__ double dJ[DOP_CHUNK * 13], dr[DOP_CHUNK], drho[DOP_CHUNK];
+    __shared__ double s_ddt[16];   // c[12], h, g for the current run
+    const int tid = threadIdx.x;
+    const int W = a.W;
+    const int si = gr.slot_i, sj = gr.slot_j;
+    double Pi[3], Pj[3], Vi[3], Vj[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        Pi[k] = x[3 * si + k]; Pj[k] = x[3 * sj + k];
+        Vi[k] = x[7 * W + 9 * si + k]; Vj[k] = x[7 * W + 9 * sj + k];
+    }
+    const double* R = a.R_ecef_local;
+    // thread-private accumulators (thread p owns one entry), summed over factors in fixed order
+    double h6 = 0.0, g6 = 0.0, cost_dd = 0.0;       // DD: p<36 -> H6[p]; 36<=p<42 -> g6; p==42 cost
+    double h12 = 0.0, g12 = 0.0, cost_dop = 0.0;    // Doppler: p<144 -> H12[p]; 144<=p<156 -> g12; p==156 cost
+
+    // ---- DD pseudorange factors (dd_psr_factor.hpp:25-171)
+    for (int f = gr.dd_begin; f < gr.dd_end; ++f) {
+        const glio_dd_psr& F = a.dd[f];
+        const int ns = F.n_sat, m = F.master, nw = ns - 1;
+        double Pe[3];
+        {
+            double lp[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) lp[k] = F.ratio * Pi[k] + (1.0 - F.ratio) * Pj[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) Pe[k] = R[3 * k] * lp[0] + R[3 * k + 1] * lp[1] + R[3 * k + 2] * lp[2] + a.anc[k];
+        }
+        if (tid < ns && tid != m) {
+            const int i = tid, ri = i < m ? i : i - 1;
+            double d_ui[3], d_um[3], d_ri[3], d_rm[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                d_ui[k] = F.user_sat_pos[i][k] - Pe[k];
+                d_um[k] = F.user_sat_pos[m][k] - Pe[k];
+                d_ri[k] = F.ref_sat_pos[i][k] - F.station[k];
+                d_rm[k] = F.ref_sat_pos[m][k] - F.station[k];
+            }
+            const double r_ui = sqrt(d_dot3(d_ui, d_ui)), r_um = sqrt(d_dot3(d_um, d_um));
+            const double r_ri = sqrt(d_dot3(d_ri, d_ri)), r_rm = sqrt(d_dot3(d_rm, d_rm));
+            const double est = (r_ui - r_ri) - (r_um - r_rm);
+            const double obs = (F.user_psr[i] - F.ref_psr[i]) - (F.user_psr[m] - F.ref_psr[m]);
+            const double wgt = fabs(est - obs) > F.threshold ? 0.05 : 1.0;     // :99-102
+            raw[ri] = wgt * (est - obs);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double ei = (d_ui[0] * R[c] + d_ui[1] * R[3 + c] + d_ui[2] * R[6 + c]) / r_ui;
+                const double em = (d_um[0] * R[c] + d_um[1] * R[3 + c] + d_um[2] * R[6 + c]) / r_um;
+                Jri[ri * 3 + c] = (-ei * wgt * F.ratio) - (-em * wgt * F.ratio);
+                Jrj[ri * 3 + c] = (-ei * wgt * (1.0 - F.ratio)) - (-em * wgt * (1.0 - F.ratio));
+            }
+        }
+        __syncthreads();
+        if (tid < nw) {                       // residual = W r, J = W J  (:151-167)
+            double sr = 0, s6[6] = {0, 0, 0, 0, 0, 0};
+            for (int b = 0; b < nw; ++b) {
+                const double wv = F.weight[tid * nw + b];
+                sr += wv * raw[b];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { s6[k] += wv * Jri[b * 3 + k]; s6[3 + k] += wv * Jrj[b * 3 + k]; }
+            }
+            wres[tid] = sr;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) wJ[tid * 6 + k] = s6[k];
+        }
+        __syncthreads();
+        if (tid < 36) {
+            const int u = tid / 6, v = tid % 6;
+            double s = 0;
+            for (int r2 = 0; r2 < nw; ++r2) s += wJ[r2 * 6 + u] * wJ[r2 * 6 + v];
+            h6 += s;
+        } else if (tid < 42) {
+            const int u = tid - 36;
+            double s = 0;
+            for (int r2 = 0; r2 < nw; ++r2) s += wJ[r2 * 6 + u] * wres[r2];
+            g6 += s;
+        } else if (tid == 42) {
+            double s = 0;
+            for (int r2 = 0; r2 < nw; ++r2) s += wres[r2] * wres[r2];
+            cost_dd += 0.5 * s;
+        }
+        __syncthreads();
+    }
+
+    // ---- Doppler rows (dopp_factor.hpp:24-75 + HuberLoss(1.0), Estimator.cpp:2335), run = one epoch
+    const double OMG = 7.2921151467e-5, CLIGHT = 2.99792458e8;
+    for (int rn = gr.run_begin; rn < gr.run_end; ++rn) {
+        const DopRun run = a.runs[rn];
+        double c_acc = 0.0;          // tid<12: c[tid]; tid==12: h; tid==13: g
+        for (int c0 = run.begin; c0 < run.end; c0 += DOP_CHUNK) {
+            const int cnt = min(DOP_CHUNK, run.end - c0);
+            if (tid < cnt) {
+                const glio_doppler& F = a.dop[c0 + tid];
+                const double* Rf = F.R_ecef_local;
+                double lp[3], lv[3], Pe[3], Ve[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    lp[k] = F.ratio * Pi[k] + (1.0 - F.ratio) * Pj[k] + F.lever_arm[k];
+                    lv[k] = F.ratio * Vi[k] + (1.0 - F.ratio) * Vj[k];
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    Pe[k] = Rf[3 * k] * lp[0] + Rf[3 * k + 1] * lp[1] + Rf[3 * k + 2] * lp[2] + a.anc[k];
+                    Ve[k] = Rf[3 * k] * lv[0] + Rf[3 * k + 1] * lv[1] + Rf[3 * k + 2] * lv[2];
+                }
+                const double d[3] = {F.sat_pos[0] - Pe[0], F.sat_pos[1] - Pe[1], F.sat_pos[2] - Pe[2]};
+                const double rho = sqrt(d_dot3(d, d));
+                const double eh[3] = {d[0] / rho, d[1] / rho, d[2] / rho};
+                const double sag = OMG / CLIGHT * (F.sat_vel[0] * Pe[1] + F.sat_pos[0] * Ve[1] - F.sat_vel[1] * Pe[0] - F.sat_pos[1] * Ve[0]);
+                const double av[3] = {F.sat_vel[0] - Ve[0], F.sat_vel[1] - Ve[1], F.sat_vel[2] - Ve[2]};
+                const double ae = d_dot3(av, eh);
+                const double ddt = x[16 * W + F.epoch];
+                const double res = (ae + sag + ddt - F.sv_ddt + F.doppler * F.lamda) / F.var;
+                double gP[3], gV[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { gP[k] = -(av[k] - ae * eh[k]) / rho; gV[k] = -eh[k]; }
+                gP[0] += OMG / CLIGHT * (-F.sat_vel[1]); gP[1] += OMG / CLIGHT * F.sat_vel[0];
+                gV[0] += OMG / CLIGHT * (-F.sat_pos[1]); gV[1] += OMG / CLIGHT * F.sat_pos[0];
+                const double iv = 1.0 / F.var;
+                // Huber corrector for a scalar residual: sqrt(rho') on J and r, cost rho/2
+                const double ar = fabs(res), ah = a.dop_huber;
+                const bool inl = ar <= ah;
+                const double sw = inl ? 1.0 : sqrt(ah / ar);
+                drho[tid] = inl ? res * res : 2.0 * ah * ar - ah * ah;
+                dr[tid] = sw * res;
+                double* J = dJ + tid * 13;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double gPl = gP[0] * Rf[c] + gP[1] * Rf[3 + c] + gP[2] * Rf[6 + c];
+                    const double gVl = gV[0] * Rf[c] + gV[1] * Rf[3 + c] + gV[2] * Rf[6 + c];
+                    J[0 + c] = sw * F.ratio * gPl * iv;
+                    J[3 + c] = sw * F.ratio * gVl * iv;
+                    J[6 + c] = sw * (1.0 - F.ratio) * gPl * iv;
+                    J[9 + c] = sw * (1.0 - F.ratio) * gVl * iv;
+                }
+                J[12] = sw * iv;
+            }
+            __syncthreads();
+            if (tid < 144) {
+                const int u = tid / 12, v = tid % 12;
+                double s = 0;
+                for (int r2 = 0; r2 < cnt; ++r2) s += dJ[r2 * 13 + u] * dJ[r2 * 13 + v];
+                h12 += s;
+            } else if (tid < 156) {
+                const int u = tid - 144;
+                double s = 0;
+                for (int r2 = 0; r2 < cnt; ++r2) s += dJ[r2 * 13 + u] * dr[r2];
+                g12 += s;
+            } else if (tid == 156) {
+                double s = 0;
+                for (int r2 = 0; r2 < cnt; ++r2) s += drho[r2];
+                cost_dop += 0.5 * s;
+            } else if (tid >= 160 && tid < 174) {
+                const int u = tid - 160;     // 0..11: coupling, 12: h, 13: g
+                double s = 0;
+                if (u < 13) { for (int r2 = 0; r2 < cnt; ++r2) s += dJ[r2 * 13 + u] * dJ[r2 * 13 + 12]; }
+                else { for (int r2 = 0; r2 < cnt; ++r2) s += dJ[r2 * 13 + 12] * dr[r2]; }
+                c_acc += s;
+            }
+            __syncthreads();
+        }
+        if (tid >= 160 && tid < 174) s_ddt[tid - 160] = c_acc;
+        __syncthreads();
+        if (tid == 0) {
+            DdtBlock* D = ddt_out + run.epoch;
+            for (int k = 0; k < 12; ++k) D->c[k] = s_ddt[k];
+            D->h = s_ddt[12]; D->g = s_ddt[13];
+            D->group = gidx; D->used = 1;
+        }
+        __syncthreads();
+    }
+
+    // ---- scatter the thread-private accumulators into the dense pair block
+    for (int k = tid; k < GLIO_PAIR_DIM * GLIO_PAIR_DIM; k += SF_THREADS) out->H[k] = 0.0;
+    if (tid < GLIO_PAIR_DIM) out->g[tid] = 0.0;
+    __syncthreads();
+    __shared__ double s_cost[2];
+    const int map6[6] = {0, 1, 2, 15, 16, 17};
+    const int map12[12] = {0, 1, 2, 6, 7, 8, 15, 16, 17, 21, 22, 23};
+    if (tid == 42) s_cost[0] = cost_dd;
+    if (tid == 156) s_cost[1] = cost_dop;
+    // Doppler 12x12 first, DD 6x6 added on top (disjoint writers per entry -> two phases)
+    if (tid < 144) out->H[map12[tid / 12] * GLIO_PAIR_DIM + map12[tid % 12]] = h12;
+    else if (tid < 156) out->g[map12[tid - 144]] = g12;
+    __syncthreads();
+    if (tid < 36) out->H[map6[tid / 6] * GLIO_PAIR_DIM + map6[tid % 6]] += h6;
+    else if (tid < 42) out->g[map6[tid - 36]] += g6;
+    __syncthreads();
+    if (tid == 0) { out->cost = s_cost[0] + s_cost[1]; out->slot_a = si; out->slot_b = sj; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Marginalization prior (MarginalizationFactor.cpp:233-287)
+//   r = r0 + J0 dx ; local Jacobian = J0 * blockdiag(M_b), M_b = I or 2 s Qleft(q0^-1)[1:4,:] P(q)
+//   H = M^T (J0^T J0) M, g = M^T J0^T r, cost = |r|^2/2
+// ------------------------------------------------------------------------------------------------
+__device__ void prior_block(const SmallArgs& a, const double* __restrict__ x, double* H, double* gout, double* cost) {
+    const int tid = threadIdx.x, np = a.np, nb = a.npb, W = a.W;
+    double* dx = a.pwork;              // [np]
+    double* r = dx + np;               // [np]
+    double* v = r + np;                // [np]
+    double* Mb = v + np;               // [nb][9]
+    for (int b = tid; b < nb; b += SF_THREADS) {
+        const int s = a.pslot[b], kind = a.pkind[b], idx = a.pidx[b];
+        const double* x0 = a.px0 + 9 * b;
+        if (kind == GLIO_BLK_TRANS) {
+            for (int k = 0; k < 3; ++k) dx[idx + k] = x[3 * s + k] - x0[k];
+        } else if (kind == GLIO_BLK_SPEEDBIAS) {
+            for (int k = 0; k < 9; ++k) dx[idx + k] = x[7 * W + 9 * s + k] - x0[k];
+        } else {
+            double q[4], q0inv[4], dq[4];
+            for (int k = 0; k < 4; ++k) q[k] = x[3 * W + 4 * s + k];
+            d_qinv(x0, q0inv);
+            d_qmul(q0inv, q, dq);
+            const double sg = dq[0] >= 0 ? 2.0 : -2.0;           // :246-252, :276-281
+            d_qnormalize(dq);
+            for (int k = 0; k < 3; ++k) dx[idx + k] = sg * dq[1 + k];
+            double L[16], P[12];
+            qleft16(q0inv, L);
+            d_plus_jac(q, P);
+            for (int p = 0; p < 3; ++p)
+                for (int c = 0; c < 3; ++c) {
+                    double acc = 0;
+                    for (int k = 0; k < 4; ++k) acc += L[(1 + p) * 4 + k] * P[k * 3 + c];
+                    Mb[9 * b + p * 3 + c] = sg * acc;
+                }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < np; i += SF_THREADS) {
+        double s = a.pr0[i];
+        const double* row = a.pJ0 + (size_t)i * np;
+        for (int k = 0; k < np; ++k) s += row[k] * dx[k];
+        r[i] = s;
+    }
+    __syncthreads();
+    for (int j = tid; j < np; j += SF_THREADS) {
+        double s = 0;
+        for (int i = 0; i < np; ++i) s += a.pJ0[(size_t)i * np + j] * r[i];
+        v[j] = s;
+    }
+    __syncthreads();
+    for (int j = tid; j < np; j += SF_THREADS) {
+        const int b = a.pcolblk[j];
+        double s;
+        if (a.pkind[b] == GLIO_BLK_QUAT) {
+            const int idx = a.pidx[b], c = j - idx;
+            s = Mb[9 * b + 0 * 3 + c] * v[idx] + Mb[9 * b + 1 * 3 + c] * v[idx + 1] + Mb[9 * b + 2 * 3 + c] * v[idx + 2];
+        } else s = v[j];
+        gout[j] = s;
+    }
+    for (int e = tid; e < np * np; e += SF_THREADS) {
+        const int i = e / np, j = e % np;
+        const int bi = a.pcolblk[i], bj = a.pcolblk[j];
+        const bool qi = a.pkind[bi] == GLIO_BLK_QUAT, qj = a.pkind[bj] == GLIO_BLK_QUAT;
+        double s;
+        if (!qi && !qj) s = a.pA0[(size_t)i * np + j];
+        else if (qi && !qj) {
+            const int ii = a.pidx[bi], c = i - ii;
+            s = 0;
+            for (int k = 0; k < 3; ++k) s += Mb[9 * bi + k * 3 + c] * a.pA0[(size_t)(ii + k) * np + j];
+        } else if (!qi && qj) {
+            const int jj = a.pidx[bj], c = j - jj;
+            s = 0;
+            for (int l = 0; l < 3; ++l) s += a.pA0[(size_t)i * np + jj + l] * Mb[9 * bj + l * 3 + c];
+        } else {
+            const int ii = a.pidx[bi], ci = i - ii, jj = a.pidx[bj], cj = j - jj;
+            s = 0;
+            for (int k = 0; k < 3; ++k) {
+                double t = 0;
+                for (int l = 0; l < 3; ++l) t += a.pA0[(size_t)(ii + k) * np + jj + l] * Mb[9 * bj + l * 3 + cj];
+                s += Mb[9 * bi + k * 3 + ci] * t;
+            }
+        }
+        H[e] = s;
+    }
+    if (tid < 64) {
+        double s = 0;
+        for (int i = tid; i < np; i += 64) s += r[i] * r[i];
+        s = wave_sum(s);
+        if (tid == 0) *cost = 0.5 * s;
+    }
+}
+
+__global__ __launch_bounds__(SF_THREADS) void k_small_factors(const SmallArgs a) {
+    int which = a.fixed_which;
+    if (a.use_status) {
+        if (a.st->done || !a.st->cand_pending) return;
+        which = 1 - a.st->cur;
+    }
+    const double* x = which ? a.x1 : a.x0;
+    int b = blockIdx.x;
+    if (b < a.W) {            // fixed-order reduction of the K3 partials of keyframe b
+        if (threadIdx.x < GLIO_LIDAR_ACC) {
+            const double* p = a.lidar_partials + (size_t)b * a.lidar_blocks_per_kf * GLIO_LIDAR_ACC + threadIdx.x;
+            double s = 0;
+            for (int k = 0; k < a.lidar_blocks_per_kf; ++k) s += p[k * GLIO_LIDAR_ACC];
+            a.lidar_blocks[((size_t)which * a.W + b) * GLIO_LIDAR_ACC + threadIdx.x] = s;
+        }
+        return;
+    }
+    b -= a.W;
+    if (b < a.n_imu) {
+        const int si = a.imu[b].slot_i, sj = si + 1, W = a.W;
+        imu_block(a.gravity, x + 3 * si, x + 3 * W + 4 * si, x + 7 * W + 9 * si, x + 3 * sj, x + 3 * W + 4 * sj, x + 7 * W + 9 * sj,
+                  a.imu[b], a.imu_blocks + (size_t)which * a.W + b, nullptr);
+        return;
+    }
+    b -= a.n_imu;
+    if (b < a.n_groups) {
+        gnss_block(a, x, a.groups[b], b, a.gnss_blocks + (size_t)which * a.gnss_stride + b, a.ddt_blocks + (size_t)which * a.ddt_stride);
+        return;
+    }
+    if (a.has_prior) prior_block(a, x, a.pH + (size_t)which * a.np * a.np, a.pg + (size_t)which * a.np, a.pcost + which);
+}
+
+// ------------------------------------------------------------------------------------------------
+// assemble: gather every block into the dense normal equations (one thread per H entry)
+// ------------------------------------------------------------------------------------------------
+struct AsmArgs {
+    int W, n, n_ddt, n_imu, n_groups, has_prior, np;
+    const SolverStatus* st; int use_status; int fixed_which;
+    const double* lidar_blocks; const PairBlock* imu_blocks; const PairBlock* gnss_blocks; const DdtBlock* ddt_blocks;
+    int gnss_stride, ddt_stride;
+    const double* pH; const double* pg; const double* pcost; const int* prior_index;
+    double* H0; double* H1; double* g0; double* g1; double* c0; double* c1;
+};
+
+__device__ __forceinline__ int lidar_sym_index(int i, int j) {   // upper-triangle packed index, i<=j<6
+    return i * 6 - (i * (i - 1)) / 2 + (j - i);
+}
+__device__ __forceinline__ int dop_local12(int slot_is_j, int lc) {  // pose-local column -> 12-vector index or -1
+    int k;
+    if (lc < 3) k = lc; else if (lc >= 6 && lc < 9) k = 3 + (lc - 6); else return -1;
+    return slot_is_j ? 6 + k : k;
+}
+
+__global__ __launch_bounds__(256) void k_assemble(const AsmArgs a) {
+    int which = a.fixed_which;
+    if (a.use_status) {
+        if (a.st->done || !a.st->cand_pending) return;
+        which = 1 - a.st->cur;
+    }
+    double* H = which ? a.H1 : a.H0;
+    double* g = which ? a.g1 : a.g0;
+    const int n = a.n, W = a.W, np15 = 15 * W;
+    const PairBlock* imu = a.imu_blocks + (size_t)which * W;
+    const PairBlock* gn = a.gnss_blocks + (size_t)which * a.gnss_stride;
+    const DdtBlock* dd = a.ddt_blocks + (size_t)which * a.ddt_stride;
+    const double* lb = a.lidar_blocks + (size_t)which * W * GLIO_LIDAR_ACC;
+    const double* pH = a.pH + (size_t)which * a.np * a.np;
+    const double* pg = a.pg + (size_t)which * a.np;
+    const long total = (long)n * n;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total + n; e += (long)gridDim.x * blockDim.x) {
+        if (e >= total) {          // gradient entry
+            const int r = (int)(e - total);
+            double s = 0;
+            if (r < np15) {
+                const int sr = r / 15, lr = r % 15;
+                if (lr < 6) s += lb[sr * GLIO_LIDAR_ACC + 21 + lr];
+                for (int k = 0; k < a.n_imu; ++k) {
+                    if (imu[k].slot_a == sr) s += imu[k].g[lr];
+                    else if (imu[k].slot_b == sr) s += imu[k].g[15 + lr];
+                }
+                for (int k = 0; k < a.n_groups; ++k) {
+                    if (gn[k].slot_a == sr) s += gn[k].g[lr];
+                    else if (gn[k].slot_b == sr) s += gn[k].g[15 + lr];
+                }
+                if (a.has_prior) { const int pi = a.prior_index[r]; if (pi >= 0) s += pg[pi]; }
+            } else {
+                s = dd[r - np15].g;
+            }
+            g[r] = s;
+            continue;
+        }
+        const int r = (int)(e / n), c = (int)(e % n);
+        double s = 0;
+        if (r < np15 && c < np15) {
+            const int sr = r / 15, lr = r % 15, sc = c / 15, lc = c % 15;
+            if (sr == sc && lr < 6 && lc < 6) s += lb[sr * GLIO_LIDAR_ACC + (lr <= lc ? lidar_sym_index(lr, lc) : lidar_sym_index(lc, lr))];
+            for (int k = 0; k < a.n_imu; ++k) {
+                const int sa = imu[k].slot_a, sb = imu[k].slot_b;
+                if ((sr == sa || sr == sb) && (sc == sa || sc == sb))
+                    s += imu[k].H[((sr == sa ? 0 : 15) + lr) * GLIO_PAIR_DIM + (sc == sa ? 0 : 15) + lc];
+            }
+            for (int k = 0; k < a.n_groups; ++k) {
+                const int sa = gn[k].slot_a, sb = gn[k].slot_b;
+                if ((sr == sa || sr == sb) && (sc == sa || sc == sb))
+                    s += gn[k].H[((sr == sa ? 0 : 15) + lr) * GLIO_PAIR_DIM + (sc == sa ? 0 : 15) + lc];
+            }
+            if (a.has_prior) {
+                const int pi = a.prior_index[r], pj = a.prior_index[c];
+                if (pi >= 0 && pj >= 0) s += pH[(size_t)pi * a.np + pj];
+            }
+        } else if (r >= np15 && c >= np15) {
+            if (r == c) s = dd[r - np15].h;
+        } else {
+            const int ep = (r >= np15 ? r : c) - np15;
+            const int pc = r >= np15 ? c : r;
+            if (dd[ep].used) {
+                const int sc = pc / 15, lc = pc % 15;
+                const int gi = dd[ep].group;
+                const int sa = gn[gi].slot_a, sb = gn[gi].slot_b;
+                if (sc == sa || sc == sb) {
+                    const int k12 = dop_local12(sc == sb && sc != sa, lc);
+                    if (k12 >= 0) s = dd[ep].c[k12];
+                }
+            }
+        }
+        H[e] = s;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double cs = 0;
+        for (int k = 0; k < W; ++k) cs += lb[k * GLIO_LIDAR_ACC + 27];
+        for (int k = 0; k < a.n_imu; ++k) cs += imu[k].cost;
+        for (int k = 0; k < a.n_groups; ++k) cs += gn[k].cost;
+        if (a.has_prior) cs += a.pcost[which];
+        *(which ? a.c1 : a.c0) = cs;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// single-factor evaluators (Ceres Evaluate() convention, GLOBAL Jacobians) for the C-ABI shims
+// ------------------------------------------------------------------------------------------------
+// params: Pi3 Qi4 SBi9 Pj3 Qj4 SBj9 packed [32]; out: r[15] then J[15][32]
+__global__ __launch_bounds__(SF_THREADS) void k_eval_imu(const double gravity, const ImuEdgeDev* e, const double* params, double* out) {
+    imu_block(gravity, params + 0, params + 3, params + 7, params + 16, params + 19, params + 23, *e, nullptr, out);
+}
+
+// LidarPlaneNormFactor residual + global 1x3 / 1x4 Jacobians through Eigen's q*v formula
+// (LidarKeyframeFactor.h:87-103).  in: t3 q4 ; out: r, Jt[3], Jq[4]
+struct LidarEvalArgs { double qlb[4], tlb[3], cp[3], n[3], d, score; };
+__global__ void k_eval_lidar(const LidarEvalArgs a, const double* params, double* out) {
+    if (threadIdx.x != 0) return;
+    const double* t = params;
+    const double* q = params + 3;
+    double qlbi[4], c[3] = {a.cp[0] - a.tlb[0], a.cp[1] - a.tlb[1], a.cp[2] - a.tlb[2]}, pb[3], pw[3];
+    d_qinv(a.qlb, qlbi);
+    d_qrot(qlbi, c, pb);
+    d_qrot(q, pb, pw);
+    for (int k = 0; k < 3; ++k) pw[k] += t[k];
+    out[0] = a.score * (d_dot3(a.n, pw) + a.d);
+    for (int k = 0; k < 3; ++k) out[1 + k] = a.score * a.n[k];
+    const double w = q[0];
+    const double* u = q + 1;
+    double uv[3];
+    d_cross(u, pb, uv);
+    out[4] = a.score * 2.0 * d_dot3(a.n, uv);
+    const double Sv[9] = {0, -pb[2], pb[1], pb[2], 0, -pb[0], -pb[1], pb[0], 0};
+    const double Suv[9] = {0, -uv[2], uv[1], uv[2], 0, -uv[0], -uv[1], uv[0], 0};
+    const double Su[9] = {0, -u[2], u[1], u[2], 0, -u[0], -u[1], u[0], 0};
+    for (int k = 0; k < 3; ++k) {
+        double col[3];
+        for (int r = 0; r < 3; ++r) {
+            double susv = Su[r * 3] * Sv[k] + Su[r * 3 + 1] * Sv[3 + k] + Su[r * 3 + 2] * Sv[6 + k];
+            col[r] = -2 * w * Sv[r * 3 + k] - 2 * Suv[r * 3 + k] - 2 * susv;
+        }
+        out[5 + k] = a.score * d_dot3(a.n, col);
+    }
+}
+
+void glio_launch_eval_imu(glio_ctx* c, const ImuEdgeDev* d_edge, const double* d_params, double* d_out) {
+    hipLaunchKernelGGL(k_eval_imu, dim3(1), dim3(SF_THREADS), 0, c->stream, c->opts.gravity, d_edge, d_params, d_out);
+}
+void glio_launch_eval_lidar(glio_ctx* c, const float cp[4], const float plane[4], double score, const double* d_params, double* d_out) {
+    LidarEvalArgs a;
+    for (int k = 0; k < 4; ++k) a.qlb[k] = c->opts.q_lb[k];
+    for (int k = 0; k < 3; ++k) { a.tlb[k] = c->opts.t_lb[k]; a.cp[k] = (double)cp[k]; a.n[k] = (double)plane[k]; }
+    a.d = (double)plane[3]; a.score = score;
+    hipLaunchKernelGGL(k_eval_lidar, dim3(1), dim3(64), 0, c->stream, a, d_params, d_out);
+}
+
+// A0 = J0^T J0 of the prior (once per glio_set_prior)
+__global__ void k_gram(const double* __restrict__ J0, double* __restrict__ A0, int np) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)np * np) return;
+    const int i = (int)(e / np), j = (int)(e % np);
+    double s = 0;
+    for (int k = 0; k < np; ++k) s += J0[(size_t)k * np + i] * J0[(size_t)k * np + j];
+    A0[e] = s;
+}
+void glio_launch_gram(glio_ctx* c, int np) {
+    const long total = (long)np * np;
+    hipLaunchKernelGGL(k_gram, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_prior_J0, c->d_prior_A0, np);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side launchers
+// ------------------------------------------------------------------------------------------------
+GnssDevExtra* glio_extra(glio_ctx* c);   // defined in capi.hip
+
+void glio_launch_small_factors(glio_ctx* c, int use_status_cand, int which, int n_ddt) {
+    SmallArgs a;
+    GnssDevExtra* ex = glio_extra(c);
+    a.W = c->W; a.n_imu = c->n_imu; a.n_groups = c->n_groups; a.has_prior = c->prior_n > 0; a.n_ddt = n_ddt;
+    a.lidar_blocks_per_kf = GLIO_K3_BLOCKS_PER_KF;
+    a.x0 = c->d_x[0]; a.x1 = c->d_x[1];
+    a.st = c->d_status; a.use_status = use_status_cand; a.fixed_which = which;
+    a.lidar_partials = c->d_lidar_partials; a.lidar_blocks = c->d_lidar_blocks;
+    a.imu = c->d_imu; a.imu_blocks = c->d_imu_blocks;
+    a.dd = c->d_dd; a.dop = c->d_dop; a.groups = c->d_groups; a.runs = ex->d_runs; a.n_runs = ex->n_runs;
+    a.gnss_blocks = c->d_gnss_blocks; a.ddt_blocks = c->d_ddt_blocks; a.gnss_stride = c->W * c->W; a.ddt_stride = c->n_ddt_max > 0 ? c->n_ddt_max : 1;
+    a.gravity = c->opts.gravity; a.dop_huber = c->opts.doppler_huber_delta;
+    for (int k = 0; k < 9; ++k) a.R_ecef_local[k] = c->R_ecef_local[k];
+    for (int k = 0; k < 3; ++k) a.anc[k] = c->frame.anc_ecef[k];
+    a.np = c->prior_n; a.npb = c->prior_nb;
+    a.pJ0 = c->d_prior_J0; a.pA0 = c->d_prior_A0; a.pr0 = c->d_prior_r0; a.px0 = c->d_prior_x0;
+    a.pslot = c->d_prior_slot; a.pkind = c->d_prior_kind; a.pidx = c->d_prior_idx; a.pcolblk = ex->d_prior_colblk;
+    a.pH = c->d_prior_H; a.pg = c->d_prior_g; a.pcost = c->d_prior_cost; a.pwork = c->d_prior_work;
+    const int blocks = c->W + c->n_imu + c->n_groups + (a.has_prior ? 1 : 0);
+    hipLaunchKernelGGL(k_small_factors, dim3(blocks), dim3(SF_THREADS), 0, c->stream, a);
+}
+
+void glio_launch_assemble(glio_ctx* c, int use_status_cand, int which, int n_ddt) {
+    AsmArgs a;
+    a.W = c->W; a.n = 15 * c->W + n_ddt; a.n_ddt = n_ddt; a.n_imu = c->n_imu; a.n_groups = c->n_groups;
+    a.has_prior = c->prior_n > 0; a.np = c->prior_n;
+    a.st = c->d_status; a.use_status = use_status_cand; a.fixed_which = which;
+    a.lidar_blocks = c->d_lidar_blocks; a.imu_blocks = c->d_imu_blocks; a.gnss_blocks = c->d_gnss_blocks; a.ddt_blocks = c->d_ddt_blocks;
+    a.gnss_stride = c->W * c->W; a.ddt_stride = c->n_ddt_max > 0 ? c->n_ddt_max : 1;
+    a.pH = c->d_prior_H; a.pg = c->d_prior_g; a.pcost = c->d_prior_cost; a.prior_index = c->d_prior_index;
+    a.H0 = c->d_H[0]; a.H1 = c->d_H[1]; a.g0 = c->d_g[0]; a.g1 = c->d_g[1]; a.c0 = c->d_cost[0]; a.c1 = c->d_cost[1];
+    const long total = (long)a.n * a.n + a.n;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(256), 0, c->stream, a);
+}

@@ -1,0 +1,239 @@
+// glio_device.h -- shared declarations of the gfx950 implementation: context layout, device-side
+// small math, launch wrappers between translation units.  HIP only; never included by host callers
+// (they see include/glio_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/glio_hip.h"
+
+#define GLIO_WAVE 64
+
+// ------------------------------------------------------------------------------------------------
+// device-resident layouts
+// ------------------------------------------------------------------------------------------------
+// Per-keyframe LiDAR accumulator: 21 (upper triangle of the 6x6 J^T J) + 6 (J^T r) + 1 (cost)
+#define GLIO_LIDAR_ACC 28
+// K3 launch geometry: GLIO_K3_BLOCKS_PER_KF workgroups of GLIO_K3_THREADS per keyframe slot
+#define GLIO_K3_THREADS 256
+#define GLIO_K3_BLOCKS_PER_KF 32
+
+// IMU edge, device form (pre-digested on upload: sqrt_info is LLT(cov^-1).L^T, ImuFactor.h:44-45)
+struct ImuEdgeDev {
+    double delta_p[3], delta_q[4], delta_v[3], lin_ba[3], lin_bg[3];
+    double sum_dt;
+    double dp_dba[9], dp_dbg[9], dq_dbg[9], dv_dba[9], dv_dbg[9];
+    double sqrt_info[225];
+    int slot_i;
+    int pad_;
+};
+// dense local block of one IMU edge / GNSS group over [slot_a(15) | slot_b(15)]
+#define GLIO_PAIR_DIM 30
+struct PairBlock {
+    double H[GLIO_PAIR_DIM * GLIO_PAIR_DIM];
+    double g[GLIO_PAIR_DIM];
+    double cost;
+    int slot_a, slot_b;
+};
+// GNSS group = all DD / Doppler factors that share one (slot_i, slot_j) pair
+struct GnssGroup {
+    int slot_i, slot_j;
+    int dd_begin, dd_end;      // range in the sorted glio_dd_psr array
+    int dop_begin, dop_end;    // range in the sorted glio_doppler array (sorted by epoch inside)
+    int run_begin, run_end;    // range in the DopRun array
+};
+// Doppler rows of one epoch inside a group (contiguous in the sorted glio_doppler array)
+struct DopRun { int begin, end, epoch, group; };
+struct GnssDevExtra { DopRun* d_runs; int n_runs; int* d_prior_colblk; };
+// per-epoch Doppler coupling with the 12 pose variables (t_i v_i t_j v_j) of its group
+struct DdtBlock {
+    double c[12];
+    double h, g;
+    int group;
+    int used;
+};
+
+// Trust-region state machine, lives in device memory for the whole solve (no host round trips)
+struct SolverStatus {
+    int done;
+    int termination;
+    int iteration;
+    int successful;
+    int cur;              // index (0/1) of the buffers holding the current point x, H, g, cost
+    int phase;            // 0 = first evaluation pending, 1 = running
+    int reuse;
+    int invalid;
+    int n_ddt;
+    int cand_pending;     // 1 = the buffers 1-cur hold a point whose linearisation is wanted / available
+    double radius, mu;
+    double cost, model_cost_change;
+    double alpha, dogleg_step_norm;
+    double initial_cost, grad_max_norm;
+};
+
+struct glio_ctx {
+    glio_opts opts;
+    int device;
+    hipStream_t own_stream, stream;
+    int W, cap, n_max, n_ddt_max;
+    // ---- LiDAR correspondences [W][cap]
+    float4* d_pts;
+    float4* d_planes;
+    double* d_scores;
+    int* d_count;                 // [W]
+    int h_count[GLIO_MAX_WINDOW];
+    // ---- scans + map (association)
+    float4* d_scan;               // [W][cap]
+    int h_scan_count[GLIO_MAX_WINDOW];
+    float4* d_map_sorted;         // [max_map] sorted by cell, .w = original index bits
+    int map_n;
+    struct AssocWork* assoc;      // hash table etc. (assoc_kernels.hip)
+    // ---- small factors
+    ImuEdgeDev* d_imu; int n_imu;
+    PairBlock* d_imu_blocks;      // [2][W]
+    glio_dd_psr* d_dd; int n_dd;
+    glio_doppler* d_dop; int n_dop;
+    GnssGroup* d_groups; int n_groups;
+    PairBlock* d_gnss_blocks;     // [2][W*W] (n_groups used)
+    DdtBlock* d_ddt_blocks;       // [2][n_ddt_max]
+    glio_gnss_frame frame;
+    double R_ecef_local[9];       // R_ecef_enu(anchor) * Rz(yaw)
+    // prior
+    int prior_n, prior_nb;
+    double* d_prior_J0;           // [np][np]
+    double* d_prior_A0;           // J0^T J0
+    double* d_prior_r0;
+    double* d_prior_x0;           // [nb][9]
+    int* d_prior_slot; int* d_prior_kind; int* d_prior_idx;
+    int* d_prior_index;           // [15*W] state index -> prior column or -1
+    double* d_prior_H;            // [2][np*np]
+    double* d_prior_g;            // [2][np]
+    double* d_prior_cost;         // [2]
+    double* d_prior_work;         // dx, r, M blocks
+    // ---- state + normal equations, double buffered (cur / candidate)
+    double* d_x[2];               // layout: trans[3W] quat[4W] sb[9W] ddt[n_ddt_max]
+    double* d_xout;
+    double* d_lidar_partials;     // [W][BLOCKS_PER_KF][28]
+    double* d_lidar_blocks;       // [2][W][28]
+    double* d_H[2];
+    double* d_g[2];
+    double* d_cost[2];
+    // ---- solver workspace
+    double* d_L;                  // (n+1) x n factor workspace
+    double* d_vec;                // scale, diag, grad, gn, step, delta, tmp ... 10 x n_max
+    SolverStatus* d_status;
+    SolverStatus* h_status;       // pinned
+    double* h_xbuf;               // pinned staging for state upload/download
+    hipEvent_t ev0, ev1;
+    int have_factors;
+    int last_n_ddt;
+};
+
+static inline int glio_x_size(int W, int n_ddt) { return 16 * W + n_ddt; }
+
+// ------------------------------------------------------------------------------------------------
+// device math (quaternions are w,x,y,z)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void d_cross(const double a[3], const double b[3], double o[3]) {
+    const double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+__device__ __forceinline__ double d_dot3(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ void d_qmul(const double a[4], const double b[4], double o[4]) {
+    const double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    const double x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    const double y = a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3];
+    const double z = a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1];
+    o[0] = w; o[1] = x; o[2] = y; o[3] = z;
+}
+__device__ __forceinline__ void d_qinv(const double q[4], double o[4]) {
+    const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    o[0] = q[0] / n2; o[1] = -q[1] / n2; o[2] = -q[2] / n2; o[3] = -q[3] / n2;
+}
+__device__ __forceinline__ void d_qnormalize(double q[4]) {
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+// v + w 2(u x v) + u x 2(u x v)
+__device__ __forceinline__ void d_qrot(const double q[4], const double v[3], double o[3]) {
+    double uv[3], uuv[3];
+    d_cross(q + 1, v, uv);
+    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+    d_cross(q + 1, uv, uuv);
+    o[0] = v[0] + q[0] * uv[0] + uuv[0];
+    o[1] = v[1] + q[0] * uv[1] + uuv[1];
+    o[2] = v[2] + q[0] * uv[2] + uuv[2];
+}
+__device__ __forceinline__ void d_q2R(const double q[4], double R[9]) {
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x;
+    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+// Ceres QuaternionParameterization::Plus
+__device__ __forceinline__ void d_quat_plus(const double q[4], const double d[3], double o[4]) {
+    const double nrm = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    if (nrm > 0.0) {
+        const double s = sin(nrm) / nrm;
+        const double dq[4] = {cos(nrm), s * d[0], s * d[1], s * d[2]};
+        d_qmul(dq, q, o);
+    } else {
+        o[0] = q[0]; o[1] = q[1]; o[2] = q[2]; o[3] = q[3];
+    }
+}
+// d([1,delta] (x) q)/d delta, 4x3 row-major
+__device__ __forceinline__ void d_plus_jac(const double q[4], double P[12]) {
+    P[0] = -q[1]; P[1] = -q[2]; P[2] = -q[3];
+    P[3] = q[0];  P[4] = q[3];  P[5] = -q[2];
+    P[6] = -q[3]; P[7] = q[0];  P[8] = q[1];
+    P[9] = q[2];  P[10] = -q[1]; P[11] = q[0];
+}
+
+// broadcast lane `l` (compile-time constant) of a double through v_readlane_b32 (SALU path, no LDS)
+__device__ __forceinline__ double readlane_d(double v, int l) {
+#ifdef GLIO_NO_READLANE
+    return __shfl(v, l, 64);
+#endif
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers (one per translation unit)
+// ------------------------------------------------------------------------------------------------
+// lidar_kernels.hip
+void glio_launch_lidar_linearize(glio_ctx* c, int use_status_cand, int which);
+// factor_kernels.hip
+void glio_launch_small_factors(glio_ctx* c, int use_status_cand, int which, int n_ddt);
+void glio_launch_assemble(glio_ctx* c, int use_status_cand, int which, int n_ddt);
+// solver_kernels.hip
+void glio_launch_tr_step(glio_ctx* c, int n_ddt);
+size_t glio_tr_step_lds_bytes(int n);
+// assoc_kernels.hip
+int glio_assoc_create(glio_ctx* c);
+void glio_assoc_destroy(glio_ctx* c);
+int glio_assoc_build_map(glio_ctx* c, const float* map_xyzi, int n);
+int glio_assoc_run(glio_ctx* c, int slot, const double q[4], const double t[3], int* out_count);
+void glio_assoc_time_hooks(glio_ctx* c, int which, int reps, float* ms);
+
+void glio_set_error(const char* fmt, ...);
+#define GLIO_HIP_CHECK(expr)                                                              \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            glio_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return GLIO_E_HIP;                                                            \
+        }                                                                                 \
+    } while (0)

@@ -1,0 +1,147 @@
+// lidar_kernels.hip -- K3: LiDAR point-to-plane residual + 1x6 local Jacobian + Huber + per-keyframe
+// J^T J / J^T r / cost reduction, hand-written for gfx950.
+//
+// Replaces, per linearisation, the Ceres evaluation of every
+//   AutoDiffCostFunction<LidarPlaneNormFactor,1,3,4> + HuberLoss(1.0) + QuaternionParameterization
+// residual block (reference: GLIO/include/factors/LidarKeyframeFactor.h:87-103, created at
+// GLIO/src/Estimator.cpp:2226-2242) and the normal-equation build that follows inside ceres::Solve.
+//
+// Math (fused form of the chain global-Jacobian -> loss corrector -> local parameterisation):
+//   p_b = R_lb^T (cp - t_lb) ; rp = R(q) p_b ; p_w = rp + t
+//   r   = s (n^.p_w + d^)                               s = score, (n^,d^) = weighted plane
+//   J   = s [ n^ , 2 (rp x n^) ]                        (1x6: dt, dtheta under Ceres' left (+))
+//   rho'(r^2) = 1 (|r|<=a) or a/|r|  -> H += rho' J^T J, g += rho' J^T r, cost += rho/2
+//
+// Roofline: HBM-bound streaming reduction, 40 B per residual (float4 point + float4 plane + f64 score),
+// ~120 fp64 flop per residual (3 flop/B << fp64 ridge).  One wavefront touches exactly one keyframe
+// (arrays are keyframe-major), so the reduction is a pure 64-lane shuffle tree -> LDS across the 4
+// waves -> one 28-double partial per workgroup, summed in fixed order downstream (deterministic, no
+// atomics).
+#include "glio_device.h"
+
+struct LidarConst {
+    double RlbT[9];   // R(q_lb)^T
+    double tlb[3];
+    double huber;
+};
+
+__device__ __forceinline__ void lidar_accumulate(const float4 p, const float4 pl, const double s,
+                                                 const double M[9], const double t[3], const double tlb[3],
+                                                 const double a, double acc[GLIO_LIDAR_ACC]) {
+    const double cx = (double)p.x - tlb[0], cy = (double)p.y - tlb[1], cz = (double)p.z - tlb[2];
+    const double rx = M[0] * cx + M[1] * cy + M[2] * cz;
+    const double ry = M[3] * cx + M[4] * cy + M[5] * cz;
+    const double rz = M[6] * cx + M[7] * cy + M[8] * cz;
+    const double nx = (double)pl.x, ny = (double)pl.y, nz = (double)pl.z;
+    const double e = nx * (rx + t[0]) + ny * (ry + t[1]) + nz * (rz + t[2]) + (double)pl.w;
+    const double r = s * e;
+    double J[6];
+    J[0] = s * nx; J[1] = s * ny; J[2] = s * nz;
+    const double s2 = 2.0 * s;
+    J[3] = s2 * (ry * nz - rz * ny);
+    J[4] = s2 * (rz * nx - rx * nz);
+    J[5] = s2 * (rx * ny - ry * nx);
+    const double ar = fabs(r);
+    const bool inl = ar <= a;
+    const double w = inl ? 1.0 : a / ar;                  // rho'
+    const double rho = inl ? r * r : 2.0 * a * ar - a * a;
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double wi = w * J[i];
+#pragma unroll
+        for (int j = i; j < 6; ++j) acc[k++] += wi * J[j];
+        acc[21 + i] += wi * r;
+    }
+    acc[27] += 0.5 * rho;
+}
+
+template <int UNROLL>
+__global__ __launch_bounds__(GLIO_K3_THREADS) void k_lidar_linearize(
+    const float4* __restrict__ pts, const float4* __restrict__ planes, const double* __restrict__ scores,
+    const int* __restrict__ count, const int cap, const double* __restrict__ x0, const double* __restrict__ x1,
+    const SolverStatus* __restrict__ st, const int use_status, const int fixed_which, const int W,
+    const LidarConst lc, double* __restrict__ partials) {
+    int which = fixed_which;
+    if (use_status) {
+        if (st->done || !st->cand_pending) return;
+        which = 1 - st->cur;
+    }
+    const double* __restrict__ x = which ? x1 : x0;
+    const int kf = blockIdx.y;
+    const int nb = gridDim.x;
+    const int n = count[kf];
+
+    // per-keyframe constants: M = R(q) R_lb^T, t
+    double q[4], R[9], M[9], t[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t[k] = x[3 * kf + k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = x[3 * W + 4 * kf + k];
+    d_q2R(q, R);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            M[i * 3 + j] = R[i * 3 + 0] * lc.RlbT[0 * 3 + j] + R[i * 3 + 1] * lc.RlbT[1 * 3 + j] + R[i * 3 + 2] * lc.RlbT[2 * 3 + j];
+
+    double acc[GLIO_LIDAR_ACC];
+#pragma unroll
+    for (int k = 0; k < GLIO_LIDAR_ACC; ++k) acc[k] = 0.0;
+
+    const size_t base = (size_t)kf * cap;
+    const float4* __restrict__ P = pts + base;
+    const float4* __restrict__ Q = planes + base;
+    const double* __restrict__ S = scores + base;
+    const int stride = nb * GLIO_K3_THREADS;
+    int i = blockIdx.x * GLIO_K3_THREADS + threadIdx.x;
+    // main loop: UNROLL independent 16+16+8 B loads in flight per lane before any math
+    for (; i + (UNROLL - 1) * stride < n; i += UNROLL * stride) {
+        float4 p[UNROLL], pl[UNROLL];
+        double s[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            p[u] = P[i + u * stride];
+            pl[u] = Q[i + u * stride];
+            s[u] = S[i + u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) lidar_accumulate(p[u], pl[u], s[u], M, t, lc.tlb, lc.huber, acc);
+    }
+    for (; i < n; i += stride) lidar_accumulate(P[i], Q[i], S[i], M, t, lc.tlb, lc.huber, acc);
+
+    // wave shuffle tree -> LDS over the 4 waves -> one partial per workgroup
+    __shared__ double red[GLIO_K3_THREADS / GLIO_WAVE][GLIO_LIDAR_ACC];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < GLIO_LIDAR_ACC; ++k) {
+        const double v = wave_sum(acc[k]);
+        if (lane == 0) red[wv][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < GLIO_LIDAR_ACC) {
+        double v = red[0][threadIdx.x];
+#pragma unroll
+        for (int w2 = 1; w2 < GLIO_K3_THREADS / GLIO_WAVE; ++w2) v += red[w2][threadIdx.x];
+        partials[((size_t)kf * nb + blockIdx.x) * GLIO_LIDAR_ACC + threadIdx.x] = v;
+    }
+}
+
+void glio_launch_lidar_linearize(glio_ctx* c, int use_status_cand, int which) {
+    LidarConst lc;
+    // R(q_lb)^T via Eigen's inverse(): conj / |q|^2
+    const double* ql = c->opts.q_lb;
+    const double n2 = ql[0] * ql[0] + ql[1] * ql[1] + ql[2] * ql[2] + ql[3] * ql[3];
+    const double w = ql[0] / n2, x = -ql[1] / n2, y = -ql[2] / n2, z = -ql[3] / n2;
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    lc.RlbT[0] = 1 - (tyy + tzz); lc.RlbT[1] = txy - twz; lc.RlbT[2] = txz + twy;
+    lc.RlbT[3] = txy + twz; lc.RlbT[4] = 1 - (txx + tzz); lc.RlbT[5] = tyz - twx;
+    lc.RlbT[6] = txz - twy; lc.RlbT[7] = tyz + twx; lc.RlbT[8] = 1 - (txx + tyy);
+    for (int k = 0; k < 3; ++k) lc.tlb[k] = c->opts.t_lb[k];
+    lc.huber = c->opts.huber_delta;
+    dim3 grid(GLIO_K3_BLOCKS_PER_KF, c->W);
+    hipLaunchKernelGGL((k_lidar_linearize<4>), grid, dim3(GLIO_K3_THREADS), 0, c->stream,
+                       c->d_pts, c->d_planes, c->d_scores, c->d_count, c->cap, c->d_x[0], c->d_x[1],
+                       c->d_status, use_status_cand, which, c->W, lc, c->d_lidar_partials);
+}

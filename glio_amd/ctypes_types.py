@@ -111,7 +111,7 @@ class WindowState:
         s.trans[:] = self.trans
         s.quat[:] = self.quat
         s.speed_bias[:] = self.speed_bias
-        s.rcv_ddt[:] = self.rcv_ddt
+        s.rcv_ddt = self.rcv_ddt.copy()
         return s
 
     def c(self):

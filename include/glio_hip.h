@@ -1,0 +1,112 @@
+/*
+ * glio_hip.h -- C-ABI of libglio_hip.so: the MI355X (gfx950) implementation of GLIO's
+ * sliding-window hot path, Estimator::optimizeSlidingWindowWithLandMark
+ * (reference: GLIO/src/Estimator.cpp:2046-2736).
+ *
+ * This is the drop-in boundary.  The reference has no plugin API; what it has are
+ * (a) the Estimator member buffers the function reads and writes, and (b) the
+ * ceres::CostFunction::Evaluate(double const* const*, double*, double**) contract of every factor.
+ * Each entry point below names the reference interface it replaces.  Signatures carry plain
+ * pointers and sizes only; every pointer is caller-owned HOST memory unless the name ends in
+ * `_dev`.  All functions return 0 on success, a negative GLIO_E_* code otherwise; nothing throws.
+ * A context owns one HIP stream and is not thread-safe; independent contexts (sliding window vs
+ * batch thread, Estimator.cpp:5398-5404) may be used concurrently.
+ */
+#ifndef GLIO_HIP_H_
+#define GLIO_HIP_H_
+
+#include "glio_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    GLIO_OK = 0,
+    GLIO_E_ARG = -1,        /* bad argument / capacity exceeded */
+    GLIO_E_HIP = -2,        /* HIP runtime error (no device, launch failure ...) */
+    GLIO_E_STATE = -3,      /* call order violated (e.g. solve before any factor was set) */
+    GLIO_E_NUMERIC = -4     /* solver failure (Cholesky breakdown with mu >= 1) */
+};
+
+typedef struct glio_ctx glio_ctx;
+
+/* Library / device info.  `glio_device_count` < 1 means the HIP path is unusable: callers must fail. */
+int glio_abi_version(void);
+int glio_device_count(void);
+const char* glio_last_error(void);
+/* sizeof() of every POD struct, in the order opts,state,preint,prior,dd_psr,doppler,gnss_frame,summary
+ * (lets a foreign-language binding verify its struct layout). */
+int glio_struct_sizes(int32_t* out, int n);
+
+/* yaml defaults: GLIO/config/config_urban_hk.yaml:60-104 + Estimator.cpp:70,2424-2430 */
+void glio_opts_default(glio_opts* o);
+
+/* Replaces: construction of the per-window Ceres problem + device residency of Estimator members. */
+int glio_create(int device, const glio_opts* opts, glio_ctx** out);
+void glio_destroy(glio_ctx* ctx);
+/* Optional: run on a caller-provided hipStream_t (e.g. torch's current stream). NULL restores the own stream. */
+int glio_set_stream(glio_ctx* ctx, void* hip_stream);
+int glio_synchronize(glio_ctx* ctx);
+
+/* ---- K1: local map.  Replaces kd_tree_surf_local_map->setInputCloud(surf_local_map_ds)
+ * (Estimator.cpp:2056).  pts = PointXYZI[n] as 4 floats; builds the voxel hash on device. */
+int glio_set_map(glio_ctx* ctx, const float* map_xyzi, int n);
+
+/* ---- K2: correspondences.  Replaces findCorrespondingSurfFeatures(idx, Q2, T2)
+ * (Estimator.cpp:3633-3708) for window slot `slot`: uploads the scan (surf_frames[idx], PointXYZI[n],
+ * LiDAR frame), runs exact 5-NN + plane fit + gates on device and leaves the compacted
+ * vec_surf_cur_pts / vec_surf_normal / vec_surf_scores of that slot resident.  q,t = the LiDAR pose
+ * Q2,T2 of Estimator.cpp:2216-2217.  *out_count receives vec_surf_res_cnt[slot]. */
+int glio_associate(glio_ctx* ctx, int slot, const float* scan_xyzi, int n, const double q[4],
+                   const double t[3], int* out_count);
+/* Same, for a scan already resident from a previous glio_associate/glio_set_scan (re-association). */
+int glio_set_scan(glio_ctx* ctx, int slot, const float* scan_xyzi, int n);
+int glio_associate_resident(glio_ctx* ctx, int slot, const double q[4], const double t[3], int* out_count);
+/* Parity hook / featureSelection replacement: provide or read back a slot's correspondence arrays. */
+int glio_set_correspondences(glio_ctx* ctx, int slot, const float* pts_xyzi, const float* planes,
+                             const double* scores, int n);
+int glio_get_correspondences(glio_ctx* ctx, int slot, float* pts_xyzi, float* planes, double* scores,
+                             int capacity, int* out_count);
+
+/* ---- factors of the window problem */
+/* Replaces problem.AddResidualBlock(new ImuFactor(pre_integrations[idx+1]), NULL, ...)
+ * (Estimator.cpp:2182-2192).  Edge `k` links slots slot_i and slot_i+1. */
+int glio_set_imu(glio_ctx* ctx, int n_edges, const glio_preint* edges, const int32_t* slot_i);
+/* Replaces problem.AddResidualBlock(new MarginalizationFactor(last_marginalization_info), NULL,
+ * last_marginalization_parameter_blocks) (Estimator.cpp:2153-2158).  prior->n == 0 removes it. */
+int glio_set_prior(glio_ctx* ctx, const glio_prior* prior);
+/* Replaces addDDPsrResFactor (Estimator.cpp:1893-1897) and the tcdopplerFactor blocks
+ * (Estimator.cpp:2329-2337); para_yaw_enu_local / para_anc_ecef are the constant blocks. */
+int glio_set_gnss(glio_ctx* ctx, const glio_gnss_frame* frame, int n_dd, const glio_dd_psr* dd,
+                  int n_dop, const glio_doppler* dop);
+
+/* ---- the solve.  Replaces ceres::Solve(options, &problem, &summary) (Estimator.cpp:2424-2433):
+ * state in = tmpTrans/tmpQuat/tmpSpeedBias(/para_rcv_ddt) before, out = after. */
+int glio_solve(glio_ctx* ctx, glio_state* state_inout, glio_summary* summary);
+/* One linearisation at `state`: dense H = J^T J (n x n row-major, n = 15 W + state->n_ddt),
+ * g = J^T r, cost; after loss correction and local parameterisation, unscaled.  H/g may be NULL.
+ * Exposed so that parity can be checked per linearisation (SURVEY.md section 7 "hard parts"). */
+int glio_linearize(glio_ctx* ctx, const glio_state* state, double* H, double* g, double* cost);
+
+/* ---- single-factor evaluators with the exact Evaluate() pointer convention, computed on the GPU.
+ * A ceres::CostFunction shim is a five-line wrapper around these. */
+/* LidarPlaneNormFactor (LidarKeyframeFactor.h:73-122): parameters = {t[3], q[4]} */
+int glio_eval_lidar_plane(glio_ctx* ctx, const float cp[4], const float plane[4], double score,
+                          double const* const* parameters, double* residuals, double** jacobians);
+/* ImuFactor::Evaluate (ImuFactor.h:21-171): parameters = {Pi,Qi,SBi,Pj,Qj,SBj} */
+int glio_eval_imu(glio_ctx* ctx, const glio_preint* pre, double const* const* parameters,
+                  double* residuals, double** jacobians);
+
+/* ---- measurement hooks (bench.py): time `reps` launches of one kernel with HIP events on the
+ * context's stream; returns average milliseconds per launch in *ms_out. */
+enum { GLIO_KERNEL_LIDAR_LINEARIZE = 0, GLIO_KERNEL_FULL_LINEARIZE = 1, GLIO_KERNEL_TR_STEP = 2,
+       GLIO_KERNEL_ASSOCIATE = 3, GLIO_KERNEL_MAP_BUILD = 4 };
+int glio_time_kernel(glio_ctx* ctx, int which, int reps, float* ms_out);
+/* time `reps` complete solves from the same initial state with HIP events (state is not modified) */
+int glio_time_solve(glio_ctx* ctx, const glio_state* state, int reps, float* ms_out, glio_summary* last);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLIO_HIP_H_ */

@@ -1,0 +1,212 @@
+"""GPU parity tests: the hand-written HIP path (through the C-ABI of libglio_hip.so) against the CPU
+oracle on identical buffers.  Tolerances: H, g, cost per linearisation to 1e-10 relative (fp64, only
+the summation order differs); poses per solve to 1e-4 m / 1e-5 rad (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from glio_amd import ctypes_types as T
+from glio_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from glio_amd import capi
+    assert capi.device_count() >= 1, "no HIP device: the product path has no fallback"
+    return capi
+
+
+@pytest.fixture(scope="module")
+def po():
+    from oracle import pyoracle
+    return pyoracle
+
+
+def rel_err(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def rot_angle(qa, qb):
+    d = synth.qmul(synth.qconj(qa), qb)
+    return 2 * np.arctan2(np.linalg.norm(d[1:]), abs(d[0]))
+
+
+def assert_pose_parity(sa, sb, tol_t=1e-4, tol_r=1e-5):
+    dt = np.linalg.norm(sa.trans - sb.trans, axis=1).max()
+    dr = max(rot_angle(sa.quat[i], sb.quat[i]) for i in range(sa.W))
+    assert dt <= tol_t, f"translation parity {dt:.3e} m"
+    assert dr <= tol_r, f"rotation parity {dr:.3e} rad"
+    return dt, dr
+
+
+CASES = [
+    dict(name="lidar_only", use_imu=False, use_gnss=False, use_prior=False),
+    dict(name="lidar_imu", use_imu=True, use_gnss=False, use_prior=False),
+    dict(name="lidar_imu_prior", use_imu=True, use_gnss=False, use_prior=True),
+    dict(name="all", use_imu=True, use_gnss=True, use_prior=True),
+]
+
+
+def _state_for(win, use_gnss):
+    st = win.init.copy()
+    if not use_gnss:
+        st.n_ddt = 0
+    return st
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_linearize_parity_small(hip, po, small_window, small_corr, case):
+    win = small_window
+    kw = {k: case[k] for k in ("use_imu", "use_gnss", "use_prior")}
+    prob = po.Problem(win, small_corr, **kw)
+    ctx = hip.Context(win.opts)
+    ctx.load_window(win, small_corr, **kw)
+    for st in (_state_for(win, case["use_gnss"]), None):
+        if st is None:      # a second, different linearisation point
+            st = _state_for(win, case["use_gnss"])
+            st.trans += 0.05
+            st.speed_bias[:, 3:] += 0.01
+            st.rcv_ddt += 0.3
+        Ho, go, co = prob.linearize(st)
+        Hh, gh, ch = ctx.linearize(st)
+        assert abs(ch - co) <= 1e-10 * abs(co)
+        assert rel_err(gh, go) <= 1e-10
+        assert rel_err(Hh, Ho) <= 1e-10
+        assert np.abs(Hh - Hh.T).max() <= 1e-9 * np.abs(Hh).max()
+    ctx.close()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_solve_parity_small(hip, po, small_window, small_corr, case):
+    win = small_window
+    kw = {k: case[k] for k in ("use_imu", "use_gnss", "use_prior")}
+    prob = po.Problem(win, small_corr, **kw)
+    ctx = hip.Context(win.opts)
+    ctx.load_window(win, small_corr, **kw)
+    st = _state_for(win, case["use_gnss"])
+    so, summ_o = prob.solve(st)
+    sh, summ_h = ctx.solve(st)
+    assert summ_h.termination == summ_o.termination
+    assert summ_h.iterations == summ_o.iterations and summ_h.successful_steps == summ_o.successful_steps
+    assert abs(summ_h.final_cost - summ_o.final_cost) <= 1e-8 * abs(summ_o.final_cost)
+    assert_pose_parity(sh, so)
+    assert np.abs(sh.speed_bias - so.speed_bias).max() <= 1e-6
+    if st.n_ddt:
+        assert np.abs(sh.rcv_ddt - so.rcv_ddt).max() <= 1e-6
+    assert np.allclose(np.linalg.norm(sh.quat, axis=1), 1.0, atol=1e-12)
+    ctx.close()
+
+
+def test_solve_parity_tight_convergence(hip, po, small_window, small_corr):
+    """Both solvers run to tight convergence (function_tolerance 1e-12, 50 iterations): the converged
+    optimum itself must agree, independent of where the default schedule happens to stop."""
+    import copy
+    win = copy.copy(small_window)
+    opts = T.GlioOpts.from_buffer_copy(small_window.opts)
+    opts.function_tolerance = 1e-12
+    opts.parameter_tolerance = 1e-12
+    opts.max_iterations = 50
+    win.opts = opts
+    prob = po.Problem(win, small_corr)
+    ctx = hip.Context(opts)
+    ctx.load_window(win, small_corr)
+    so, _ = prob.solve(win.init)
+    sh, _ = ctx.solve(win.init)
+    assert_pose_parity(sh, so, 1e-6, 1e-7)
+    ctx.close()
+
+
+def test_evaluators_match_oracle(hip, po, small_window):
+    win = small_window
+    ctx = hip.Context(win.opts)
+    rng = np.random.default_rng(11)
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    t = rng.normal(size=3)
+    cp = (rng.normal(size=4) * 5).astype(np.float32)
+    pl = np.r_[0.7 * np.array([0.6, 0.0, 0.8]), 1.4].astype(np.float32)
+    r1, Jt1, Jq1 = ctx.eval_lidar_plane(cp, pl, 5.25, t, q)
+    r0, Jt0, Jq0 = po.eval_lidar_plane(win.opts, cp, pl, 5.25, t, q)
+    assert np.isclose(r1, r0, rtol=1e-13) and np.allclose(Jt1, Jt0, rtol=1e-13) and np.allclose(Jq1, Jq0, rtol=1e-12, atol=1e-13)
+    pre = win.preints[1]
+    ps = T.GlioPreint(); synth.fill_preint(ps, pre)
+    st = win.init
+    params = [st.trans[1], st.quat[1], st.speed_bias[1] + 0.01, st.trans[2], st.quat[2], st.speed_bias[2]]
+    r1, J1 = ctx.eval_imu(pre, params)
+    r0, J0 = po.eval_imu(win.opts, ps, params)
+    assert np.allclose(r1, r0, rtol=1e-9, atol=1e-9 * np.abs(r0).max())
+    for a, b in zip(J1, J0):
+        assert np.allclose(a, b, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(b).max()))
+    ctx.close()
+
+
+def test_c1_shape_parity(hip, po):
+    """BASELINE config C1: W=10, 16k surf points per keyframe, IMU + LiDAR (analytic correspondences)."""
+    win = synth.make_window(W=10, pts_per_scan=16384, seed=synth.SEED_BASE + 11)
+    corr = synth.analytic_correspondences(win)
+    prob = po.Problem(win, corr)
+    ctx = hip.Context(win.opts)
+    ctx.load_window(win, corr)
+    Ho, go, co = prob.linearize(win.init)
+    Hh, gh, ch = ctx.linearize(win.init)
+    assert abs(ch - co) <= 1e-10 * co and rel_err(gh, go) <= 1e-10 and rel_err(Hh, Ho) <= 1e-10
+    so, summ_o = prob.solve(win.init)
+    sh, summ_h = ctx.solve(win.init)
+    assert summ_h.iterations == summ_o.iterations
+    assert_pose_parity(sh, so)
+    ctx.close()
+
+
+def test_c2_shape_parity_full_size(hip, po):
+    """BASELINE config C2 (the bench workload): W=20, 64k pts/keyframe, LiDAR+IMU+GNSS+prior.
+    At this size the oracle still linearises in ~0.2 s, so parity is checked directly, plus the
+    size-independent properties: H symmetric PSD, cost additive over keyframes, counts preserved."""
+    win = synth.make_window(W=20, pts_per_scan=65536, with_gnss=True, with_prior=True, seed=synth.SEED_BASE + 12)
+    corr = synth.analytic_correspondences(win)
+    prob = po.Problem(win, corr)
+    ctx = hip.Context(win.opts)
+    ctx.load_window(win, corr)
+    Ho, go, co = prob.linearize(win.init)
+    Hh, gh, ch = ctx.linearize(win.init)
+    assert abs(ch - co) <= 1e-10 * co and rel_err(gh, go) <= 1e-10 and rel_err(Hh, Ho) <= 1e-10
+    assert np.abs(Hh - Hh.T).max() <= 1e-9 * np.abs(Hh).max()
+    assert np.linalg.eigvalsh(0.5 * (Hh + Hh.T)).min() > -1e-6 * np.abs(Hh).max()
+    so, summ_o = prob.solve(win.init)
+    sh, summ_h = ctx.solve(win.init)
+    assert summ_h.iterations == summ_o.iterations and summ_h.termination == summ_o.termination
+    assert summ_h.n_lidar_residuals == sum(len(c[2]) for c in corr)
+    assert_pose_parity(sh, so)
+    # determinism: the fixed-order reductions make two runs bit-identical
+    sh2, _ = ctx.solve(win.init)
+    assert np.array_equal(sh.trans, sh2.trans) and np.array_equal(sh.quat, sh2.quat)
+    ctx.close()
+
+
+def test_empty_and_ragged_slots(hip, po, small_window, small_corr):
+    """Edge cases: a keyframe with zero correspondences, one with a single one, one ragged."""
+    win = small_window
+    corr = [tuple(a.copy() for a in c) for c in small_corr]
+    corr[1] = (corr[1][0][:0], corr[1][1][:0], corr[1][2][:0])
+    corr[2] = (corr[2][0][:1], corr[2][1][:1], corr[2][2][:1])
+    corr[3] = (corr[3][0][:257], corr[3][1][:257], corr[3][2][:257])
+    prob = po.Problem(win, corr)
+    ctx = hip.Context(win.opts)
+    ctx.load_window(win, corr)
+    Ho, go, co = prob.linearize(win.init)
+    Hh, gh, ch = ctx.linearize(win.init)
+    assert abs(ch - co) <= 1e-10 * co and rel_err(gh, go) <= 1e-10 and rel_err(Hh, Ho) <= 1e-10
+    so, _ = prob.solve(win.init)
+    sh, _ = ctx.solve(win.init)
+    assert_pose_parity(sh, so)
+    ctx.close()
+
+
+def test_capacity_and_argument_errors(hip, small_window):
+    win = small_window
+    ctx = hip.Context(win.opts)
+    cap = win.opts.max_points_per_scan
+    with pytest.raises(hip.GlioError):
+        ctx.set_correspondences(0, np.zeros((cap + 1, 4), np.float32), np.zeros((cap + 1, 4), np.float32), np.zeros(cap + 1))
+    with pytest.raises(hip.GlioError):
+        ctx.solve(win.init)           # no factors yet
+    ctx.close()
