@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- sliding-window solves/sec on MI355X (BASELINE.json metric), one process per GPU.
+
+A "step" is one complete sliding-window solve through the C-ABI (`glio_solve`): state upload, up to 15
+device-resident trust-region iterations (K3 LiDAR linearise + small factors + assemble + dogleg/
+Cholesky), state download.  Workload = BASELINE config C2: 20-keyframe window, 64k surf points per
+keyframe, LiDAR + IMU + GNSS DD-pseudorange/Doppler + marginalization prior, synthetic data
+(glio_amd/synth.py, seed base 20260925) with the correspondence arrays already resident in HBM when
+the timed region starts.  The sliding window does not shard ("replicas only"), so with
+--gpus N every rank solves its own window and `value` is the aggregate (weak scaling).
+
+The line also carries: `roofline` for the dominant kernel (K3: 40 algorithmic bytes per LiDAR residual,
+timed with HIP events on the context's stream), `cpu_baseline` (the CPU oracle = a restatement of the
+reference's Ceres path, 1 thread, timed on this box on a bounded sample; N=1 only) and the per-stage
+timings of the correspondence search (BASELINE config C3) for information.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+BYTES_PER_RESIDUAL = 40        # float4 point + float4 plane + f64 score
+BYTES_PER_QUERY = 136          # 16 query + 5*16 neighbours + 40 output record
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--window", type=int, default=20)
+    ap.add_argument("--points", type=int, default=65536)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the GLIO hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from glio_amd import capi, synth
+    # every rank gets its own window (different seed): independent replicas
+    win = synth.make_window(W=args.window, pts_per_scan=args.points, with_gnss=True, with_prior=True,
+                            seed=synth.SEED_BASE + 12 + 1000 * rank)
+    corr = synth.analytic_correspondences(win)
+    n_res = int(sum(len(c[2]) for c in corr))
+    ctx = capi.Context(win.opts, device=local_rank)
+    ctx.load_window(win, corr)
+    state = win.init
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sol, summ = ctx.solve(state)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sol, summ = ctx.solve(state)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total_steps = args.steps * world
+    value = total_steps / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (K3), HIP events on the context stream
+    ctx.linearize(state, want_H=False)
+    k3_ms = ctx.time_kernel(capi.KERNEL_LIDAR_LINEARIZE, 50)
+    lin_ms = ctx.time_kernel(capi.KERNEL_FULL_LINEARIZE, 50)
+    trs_ms = ctx.time_kernel(capi.KERNEL_TR_STEP, 20)
+    achieved = n_res * BYTES_PER_RESIDUAL / (k3_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "k_lidar_linearize", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "bytes_per_launch": n_res * BYTES_PER_RESIDUAL, "avg_launch_us": round(k3_ms * 1e3, 2)}
+
+    # ---- correspondence search (config C3), informational
+    assoc = None
+    try:
+        actx = capi.Context(win.opts, device=local_rank)
+        t0 = time.perf_counter(); actx.set_map(win.map_pts); t_map = time.perf_counter() - t0
+        from glio_amd.capi import lidar_pose
+        cnts = []
+        for s in range(win.W):
+            actx.set_scan(s, win.scans[s])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(win.W):
+            q2, t2 = lidar_pose(win.opts, state.quat[s], state.trans[s])
+            cnts.append(actx.associate_resident(s, q2, t2))
+        t_assoc = time.perf_counter() - t0
+        k2_ms = actx.time_kernel(capi.KERNEL_ASSOCIATE, 10)
+        k1_ms = actx.time_kernel(capi.KERNEL_MAP_BUILD, 10)
+        nq = len(win.scans[0])
+        assoc = {"map_points": int(len(win.map_pts)), "queries_per_scan": nq, "map_build_us": round(k1_ms * 1e3, 1),
+                 "associate_scan_us": round(k2_ms * 1e3, 1), "window_associate_ms": round(t_assoc * 1e3, 3),
+                 "algorithmic_GBps": round(nq * BYTES_PER_QUERY / (k2_ms * 1e-3) / 1e9, 1), "kept": int(sum(cnts))}
+        actx.close()
+    except Exception as e:  # association is informational; never hide the headline
+        assoc = {"error": str(e)[:200]}
+
+    # ---- CPU baseline: the oracle (restatement of the reference's Ceres path), 1 thread, bounded sample
+    cpu = None
+    pose_err = None
+    if not args.no_cpu_baseline and world == 1:
+        try:
+            from oracle import pyoracle as po
+            prob = po.Problem(win, corr)
+            t0 = time.perf_counter()
+            n_cpu = 0
+            while True:
+                so, summ_o = prob.solve(state)
+                n_cpu += 1
+                if time.perf_counter() - t0 >= args.cpu_seconds or n_cpu >= 200:
+                    break
+            t_cpu = time.perf_counter() - t0
+            cpu = {"value": round(n_cpu / t_cpu, 4), "unit": "solves/s", "cores": 1, "kind": "port",
+                   "sample": f"{n_cpu} solves of the same C2 window ({summ_o.iterations} iterations each), "
+                             "oracle/ = CPU restatement (Ceres-1.14 semantics), not Ceres",
+                   "ms_per_solve": round(1e3 * t_cpu / n_cpu, 2), "cpu_model": _cpu_model(), "host_cores": os.cpu_count()}
+            d = synth.qmul
+            rot = max(2 * np.arctan2(np.linalg.norm(d(synth.qconj(so.quat[i]), sol.quat[i])[1:]), abs(d(synth.qconj(so.quat[i]), sol.quat[i])[0])) for i in range(win.W))
+            pose_err = {"max_trans_m": float(np.linalg.norm(sol.trans - so.trans, axis=1).max()), "max_rot_rad": float(rot),
+                        "iterations_gpu": int(summ.iterations), "iterations_cpu": int(summ_o.iterations)}
+        except Exception as e:
+            cpu = {"error": str(e)[:200]}
+
+    line = {
+        "metric": "sliding-window solves/sec (64k pts, 20 keyframes)", "value": round(value, 3), "unit": "solves/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"C2: {args.window}-keyframe window x {args.points} surf pts/keyframe, LiDAR+IMU+GNSS(DD-psr,Doppler)+prior, "
+                               "correspondences resident (pre-associated), Huber(1.0), dogleg, <=15 iterations",
+                   "lidar_residuals": n_res, "unknowns": 15 * win.W + state.n_ddt, "parallelism": f"replicas x{world}"},
+        "iterations": int(summ.iterations), "ms_per_iteration": round(ms_per_step / max(1, int(summ.iterations)), 4),
+        "termination": int(summ.termination),
+        "kernels_us": {"lidar_linearize": round(k3_ms * 1e3, 2), "full_linearize": round(lin_ms * 1e3, 2), "tr_step": round(trs_ms * 1e3, 2)},
+        "roofline": roofline, "cpu_baseline": cpu, "pose_vs_oracle": pose_err, "association": assoc,
+    }
+    if cpu and "value" in cpu:
+        line["speedup_vs_cpu_port"] = round(value / world / cpu["value"], 1)
+    print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+if __name__ == "__main__":
+    main()

@@ -183,3 +183,12 @@ class Context:
         J = (T.c_double_p * 6)(*[T.dptr(j) for j in Js])
         _check(load().glio_eval_imu(self._h, C.byref(ps), P, T.dptr(r), J))
         return r, Js
+
+
+def lidar_pose(opts, q, t):
+    """Q2 = Q * q_lb^-1, T2 = T - Q2 * t_lb: the LiDAR pose handed to findCorrespondingSurfFeatures
+    (reference GLIO/src/Estimator.cpp:2216-2217)."""
+    qlb = np.array(opts.q_lb)
+    q2 = synth.qmul(np.asarray(q, float), synth.qconj(qlb) / (qlb @ qlb))
+    t2 = np.asarray(t, float) - synth.q2R(q2 / np.linalg.norm(q2)) @ np.array(opts.t_lb)
+    return q2, t2

@@ -106,7 +106,9 @@ int glio_create(int device, const glio_opts* opts, glio_ctx** out) {
         ALLOC(c->d_cost[k], 8);
     }
     ALLOC(c->d_xout, nx * 8);
-    ALLOC(c->d_lidar_partials, (size_t)W * GLIO_K3_BLOCKS_PER_KF * GLIO_LIDAR_ACC * 8);
+    ALLOC(c->d_lidar_partials, (size_t)W * GLIO_K3_MAX_BLOCKS_PER_KF * GLIO_LIDAR_ACC * 8);
+    c->k3_bpk = GLIO_K3_BLOCKS_PER_KF; c->k3_unroll = 4;
+    { int per = 768 / W;   /* ~3 workgroups per CU measured best on MI355X (scripts/k3_sweep.py) */ if (per < 8) per = 8; if (per > GLIO_K3_MAX_BLOCKS_PER_KF) per = GLIO_K3_MAX_BLOCKS_PER_KF; c->k3_bpk = per; }
     ALLOC(c->d_lidar_blocks, 2 * (size_t)W * GLIO_LIDAR_ACC * 8);
     ALLOC(c->d_L, (size_t)(n_max + 1) * n_max * 8);
     ALLOC(c->d_vec, (size_t)10 * n_max * 8);
@@ -538,6 +540,12 @@ int glio_eval_imu(glio_ctx* c, const glio_preint* pre, double const* const* P, d
             off += sz[b];
         }
     }
+    return GLIO_OK;
+}
+
+int glio_debug_set_k3(glio_ctx* c, int bpk, int unroll) {
+    if (!c || bpk < 1 || bpk > GLIO_K3_MAX_BLOCKS_PER_KF || (unroll != 1 && unroll != 2 && unroll != 4 && unroll != 8)) return GLIO_E_ARG;
+    c->k3_bpk = bpk; c->k3_unroll = unroll;
     return GLIO_OK;
 }
 

@@ -750,7 +750,7 @@ void glio_launch_small_factors(glio_ctx* c, int use_status_cand, int which, int 
     SmallArgs a;
     GnssDevExtra* ex = glio_extra(c);
     a.W = c->W; a.n_imu = c->n_imu; a.n_groups = c->n_groups; a.has_prior = c->prior_n > 0; a.n_ddt = n_ddt;
-    a.lidar_blocks_per_kf = GLIO_K3_BLOCKS_PER_KF;
+    a.lidar_blocks_per_kf = c->k3_bpk;
     a.x0 = c->d_x[0]; a.x1 = c->d_x[1];
     a.st = c->d_status; a.use_status = use_status_cand; a.fixed_which = which;
     a.lidar_partials = c->d_lidar_partials; a.lidar_blocks = c->d_lidar_blocks;

@@ -17,7 +17,8 @@
 #define GLIO_LIDAR_ACC 28
 // K3 launch geometry: GLIO_K3_BLOCKS_PER_KF workgroups of GLIO_K3_THREADS per keyframe slot
 #define GLIO_K3_THREADS 256
-#define GLIO_K3_BLOCKS_PER_KF 32
+#define GLIO_K3_BLOCKS_PER_KF 32       /* default; ctx->k3_bpk is the live value */
+#define GLIO_K3_MAX_BLOCKS_PER_KF 256
 
 // IMU edge, device form (pre-digested on upload: sqrt_info is LLT(cov^-1).L^T, ImuFactor.h:44-45)
 struct ImuEdgeDev {
@@ -70,6 +71,7 @@ struct SolverStatus {
     double cost, model_cost_change;
     double alpha, dogleg_step_norm;
     double initial_cost, grad_max_norm;
+    double mu_used;       // mu of the factorisation behind the stored Gauss-Newton step
 };
 
 struct glio_ctx {
@@ -128,6 +130,7 @@ struct glio_ctx {
     hipEvent_t ev0, ev1;
     int have_factors;
     int last_n_ddt;
+    int k3_bpk, k3_unroll;        // K3 launch geometry (tunable, glio_debug_set_k3)
 };
 
 static inline int glio_x_size(int W, int n_ddt) { return 16 * W + n_ddt; }

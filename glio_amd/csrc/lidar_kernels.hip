@@ -14,7 +14,7 @@
 //
 // Roofline: HBM-bound streaming reduction, 40 B per residual (float4 point + float4 plane + f64 score),
 // ~120 fp64 flop per residual (3 flop/B << fp64 ridge).  One wavefront touches exactly one keyframe
-// (arrays are keyframe-major), so the reduction is a pure 64-lane shuffle tree -> LDS across the 4
+// (arrays are keyframe-major), so the reduction is a pure 64-lane shuffle butterfly -> LDS across the 4
 // waves -> one 28-double partial per workgroup, summed in fixed order downstream (deterministic, no
 // atomics).
 #include "glio_device.h"
@@ -110,13 +110,55 @@ __global__ __launch_bounds__(GLIO_K3_THREADS) void k_lidar_linearize(
     }
     for (; i < n; i += stride) lidar_accumulate(P[i], Q[i], S[i], M, t, lc.tlb, lc.huber, acc);
 
-    // wave shuffle tree -> LDS over the 4 waves -> one partial per workgroup
-    __shared__ double red[GLIO_K3_THREADS / GLIO_WAVE][GLIO_LIDAR_ACC];
+    // Wave reduction as a value-splitting butterfly: at every halving step a lane keeps one half of its
+    // values and ships the other half to its partner, so 32 (padded) accumulators need 16+8+4+2+1+1 = 32
+    // 64-bit shuffles instead of 28 x 6 = 168, in six dependent rounds.  After the xor-2 round lane L owns
+    // accumulator k = b5 + 2 b4 + 4 b3 + 8 b2 + 16 b1 (b_i = bit i of L); the xor-1 round completes the sum.
+    __shared__ double red[GLIO_K3_THREADS / GLIO_WAVE][32];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double v16[16], v8[8], v4[4], v2[2], v1;
+    {
+        const bool hi = (lane & 32) != 0;
 #pragma unroll
-    for (int k = 0; k < GLIO_LIDAR_ACC; ++k) {
-        const double v = wave_sum(acc[k]);
-        if (lane == 0) red[wv][k] = v;
+        for (int i = 0; i < 16; ++i) {
+            const double a = acc[2 * i], b = (2 * i + 1 < GLIO_LIDAR_ACC) ? acc[2 * i + 1] : 0.0;
+            const double keep = hi ? b : a, send = hi ? a : b;
+            v16[i] = keep + __shfl_xor(send, 32, 64);
+        }
+    }
+    {
+        const bool hi = (lane & 16) != 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double keep = hi ? v16[2 * i + 1] : v16[2 * i], send = hi ? v16[2 * i] : v16[2 * i + 1];
+            v8[i] = keep + __shfl_xor(send, 16, 64);
+        }
+    }
+    {
+        const bool hi = (lane & 8) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double keep = hi ? v8[2 * i + 1] : v8[2 * i], send = hi ? v8[2 * i] : v8[2 * i + 1];
+            v4[i] = keep + __shfl_xor(send, 8, 64);
+        }
+    }
+    {
+        const bool hi = (lane & 4) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const double keep = hi ? v4[2 * i + 1] : v4[2 * i], send = hi ? v4[2 * i] : v4[2 * i + 1];
+            v2[i] = keep + __shfl_xor(send, 4, 64);
+        }
+    }
+    {
+        const bool hi = (lane & 2) != 0;
+        const double keep = hi ? v2[1] : v2[0], send = hi ? v2[0] : v2[1];
+        v1 = keep + __shfl_xor(send, 2, 64);
+    }
+    v1 += __shfl_xor(v1, 1, 64);
+    if ((lane & 1) == 0) {
+        const int k = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 3) | (((lane >> 1) & 1) << 4);
+        red[wv][k] = v1;
     }
     __syncthreads();
     if (threadIdx.x < GLIO_LIDAR_ACC) {
@@ -140,8 +182,15 @@ void glio_launch_lidar_linearize(glio_ctx* c, int use_status_cand, int which) {
     lc.RlbT[6] = txz - twy; lc.RlbT[7] = tyz + twx; lc.RlbT[8] = 1 - (txx + tyy);
     for (int k = 0; k < 3; ++k) lc.tlb[k] = c->opts.t_lb[k];
     lc.huber = c->opts.huber_delta;
-    dim3 grid(GLIO_K3_BLOCKS_PER_KF, c->W);
-    hipLaunchKernelGGL((k_lidar_linearize<4>), grid, dim3(GLIO_K3_THREADS), 0, c->stream,
-                       c->d_pts, c->d_planes, c->d_scores, c->d_count, c->cap, c->d_x[0], c->d_x[1],
-                       c->d_status, use_status_cand, which, c->W, lc, c->d_lidar_partials);
+    dim3 grid(c->k3_bpk, c->W);
+#define K3_LAUNCH(U) hipLaunchKernelGGL((k_lidar_linearize<U>), grid, dim3(GLIO_K3_THREADS), 0, c->stream, \
+                       c->d_pts, c->d_planes, c->d_scores, c->d_count, c->cap, c->d_x[0], c->d_x[1], \
+                       c->d_status, use_status_cand, which, c->W, lc, c->d_lidar_partials)
+    switch (c->k3_unroll) {
+        case 1: K3_LAUNCH(1); break;
+        case 2: K3_LAUNCH(2); break;
+        case 8: K3_LAUNCH(8); break;
+        default: K3_LAUNCH(4); break;
+    }
+#undef K3_LAUNCH
 }

@@ -1,31 +1,39 @@
 // solver_kernels.hip -- K7: one trust-region iteration of ceres::Solve as configured by the reference
 // (GLIO/src/Estimator.cpp:2424-2433: SPARSE_NORMAL_CHOLESKY, DOGLEG, 15 iterations, monotonic steps),
-// restated on the dense device-resident normal equations and run entirely on the GPU:
+// restated on the dense device-resident normal equations and run entirely on the GPU.
 //
-//   three single-workgroup launches per iteration (512 lanes = 8 wavefronts on one CU), each reading and
-//   writing the SolverStatus record in device memory:
-//     k_tr_prepare  step evaluation of the candidate produced by the previous iteration: parameter /
-//                   function tolerance, relative decrease -> accept (swap the double-buffered H,g,x) or
-//                   reject, dogleg radius update (Ceres 1.14 TrustRegionMinimizer); loop-top checks
-//                   (max iterations, gradient tolerance, min radius); Jacobi scaling, D = sqrt(clamp(diag)),
-//                   Cauchy point
-//     k_tr_factor   Gauss-Newton step from an in-LDS-panel blocked right-looking Cholesky of
-//                   (S H S + mu D^2) with the right-hand side carried as an extra row; mu retry x10
-//     k_tr_dogleg   traditional dogleg interpolation, model cost change, candidate x (+) delta
-//                   (an invalid step, model cost change <= 0, consumes an iteration without a candidate)
-//   The host enqueues max_iterations+1 such groups interleaved with the linearisation kernels and never
-//   reads anything back until the end; kernels exit immediately once status.done is set, and the
-//   linearisation kernels also when no candidate is pending.
+// Four launches per iteration, all reading / writing the SolverStatus record in device memory:
+//   k_tr_prepare (1 workgroup)   step evaluation of the candidate produced by the previous iteration:
+//                 parameter / function tolerance, relative decrease -> accept (swap the double-buffered
+//                 H,g,x) or reject, dogleg radius update (Ceres 1.14 TrustRegionMinimizer); loop-top checks
+//                 (max iterations, gradient tolerance, min radius); Jacobi scaling, D = sqrt(clamp(diag)),
+//                 Cauchy direction u = S g~/D
+//   k_tr_scale   (n/4 workgroups, one wavefront per row)  t = H u  and  L = S H S + mu D^2 (lower triangle,
+//                 right-hand side S g carried as row n): the only O(n^2) streaming pass, spread over the chip
+//   k_tr_factor  (1 workgroup)   Cauchy step length; blocked LEFT-looking Cholesky of L: per 16-column panel
+//                 every wavefront owns 16x16 output tiles and runs one long v_mfma_f64_16x16x4_f64 chain
+//                 A_tile -= L[rows, 0:k0] L[k0:k0+16, 0:k0]^T (B operand = the 16 pivot rows staged in LDS,
+//                 A operand streamed from L2 as 16-byte loads), then the diagonal block is factored in
+//                 registers by wavefront 0 (v_readlane broadcasts) and the rows below are solved one lane
+//                 per row; back substitution; mu retry x10 on breakdown (DoglegStrategy)
+//   k_tr_dogleg  (1 workgroup)   traditional dogleg interpolation, model cost change (O(n): H S step follows
+//                 from the two products already known), candidate x (+) delta.  An invalid step (model cost
+//                 change <= 0) consumes an iteration without producing a candidate, as in Ceres.
+// The host enqueues max_iterations+1 such groups interleaved with the linearisation kernels and never
+// reads anything back until the end; kernels exit immediately once status.done is set, and the
+// linearisation kernels also when no candidate is pending.
 //
-// The Cholesky works on (n+1) x n doubles in L2-resident global memory with a 16-column panel staged
-// in LDS (<= 120 KB at n = 826); its trailing update is the one GEMM-shaped piece of the whole path and
-// runs on the matrix cores (v_mfma_f64_16x16x4_f64) -- latency/LDS-bound dense fp64, not roofline material.
+// The Cholesky is the one GEMM-shaped piece of the whole path and runs on the matrix cores; it is
+// latency/LDS-bound dense fp64 on a single CU (n <= ~1000 unknowns), not roofline material.
+//
+// NOTE: no __restrict__ on anything in this file: every buffer here is handed between lanes of the
+// workgroup across s_barrier.
 #include "glio_device.h"
 
 #define TR_THREADS 512
 #define TR_WAVES (TR_THREADS / 64)
 #define TR_NB 16
-#define TR_PS (TR_NB + 2)      // padded LDS row stride of the panel (conflict-free MFMA operand reads)
+#define TR_PS (TR_NB + 2)      // padded LDS row stride of the 16x16 diagonal block
 
 struct TrArgs {
     int W, n, n_ddt, max_iterations;
@@ -37,6 +45,16 @@ struct TrArgs {
     double* L; double* vec; int vstride;
     SolverStatus* status;
 };
+
+// workspace vectors (global, persist across the launches of one solve)
+#define V_SCALE(a) ((a).vec + 0 * (a).vstride)
+#define V_DIAG(a) ((a).vec + 1 * (a).vstride)
+#define V_GRAD(a) ((a).vec + 2 * (a).vstride)   /* g~ = S g / D                     */
+#define V_GN(a) ((a).vec + 3 * (a).vstride)     /* Gauss-Newton step in D-space      */
+#define V_Y(a) ((a).vec + 4 * (a).vstride)      /* y = (S H S + mu D^2)^-1 S g       */
+#define V_W(a) ((a).vec + 5 * (a).vstride)      /* scale * step = delta              */
+#define V_U(a) ((a).vec + 6 * (a).vstride)      /* u = S g~ / D (Cauchy direction)   */
+#define V_T(a) ((a).vec + 7 * (a).vstride)      /* t = H u                           */
 
 __device__ __forceinline__ double block_sum(double v, double* red) {
     v = wave_sum(v);
@@ -61,57 +79,84 @@ __device__ __forceinline__ double block_max(double v, double* red) {
     for (int k = 0; k < TR_WAVES; ++k) s = fmax(s, red[k]);
     return s;
 }
-// NOTE: no __restrict__ on anything in this file: every buffer here is handed between lanes of the
-// workgroup across s_barrier, and noalias lets LLVM move such loads above the barrier (observed: stale
-// sD / y reads in back_substitute, deterministic per binary).
-// y = H u, H n x n row-major in global memory; one wavefront per row, lanes across columns
-__device__ __forceinline__ void matvec(const double* H, const double* u, double* y, int n) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int r = 4 * wv; r < n; r += 4 * TR_WAVES) {       // 4 rows per wavefront pass: independent loads + reductions
-        double s[4] = {0, 0, 0, 0};
-        for (int c = lane; c < n; c += 64) {
-            const double uc = u[c];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) if (r + q < n) s[q] += H[(size_t)(r + q) * n + c] * uc;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) s[q] = wave_sum(s[q]);
-        if (lane == 0) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) if (r + q < n) y[r + q] = s[q];
-        }
-    }
-    __syncthreads();
-}
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef double v2f64 __attribute__((ext_vector_type(2)));
 
-// In-place blocked Cholesky of the leading n x n block of the (n+1) x n row-major matrix A (lower
-// triangle); row n is carried along (forward substitution of the right-hand side).  Returns false on
-// a non-positive / non-finite pivot.  lds: panel [(n+1 rounded to 16) x TR_PS], sD [TR_NB x TR_PS].
-//
-// Per 16-column panel:
-//   (1,2) the 16x16 diagonal block is factored by wavefront 0: lane i keeps row i in registers and the
-//         pivot column is broadcast with v_readlane (no LDS round trip, no s_barrier inside);
-//   (3)   the rows below are solved one lane per row (forward substitution against the LDS copy of
-//         L_kk, uniform-address LDS reads = broadcasts) and staged in the LDS panel P;
-//   (4)   the trailing update C -= P P^T runs on the matrix cores: one wavefront per 16x16 tile,
-//         4 x v_mfma_f64_16x16x4_f64 (A[i][k] = -P[I+i][k], B[k][j] = P[J+j][k]: both operands are the
-//         same "lane l -> row l&15, column l>>4" LDS read; TR_PS = 18 makes it bank-conflict free),
-//         accumulator initialised from the tile in L2 and written straight back.
-__device__ bool chol_augmented(double* A, const int n, double* panel, double* sD, int* flag) {
+extern __shared__ __attribute__((aligned(16))) unsigned char tr_lds[];
+
+// LDS carve of the factor kernel
+__device__ __host__ __forceinline__ int bp_stride(int n) { return ((n + 15) & ~15) + 2; }   // even -> 16-B aligned rows
+
+// ------------------------------------------------------------------------------------------------
+// Blocked left-looking Cholesky of the leading n x n block of the (n+1) x n row-major matrix A (lower
+// triangle), row n carried along (= forward substitution of the right-hand side).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool chol_left_looking(double* A, const int n, double* Bp, double* sD, int* flag) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int ld = n;
+    const int ld = n, SB = bp_stride(n);
+    const int li = lane & 15, lk = lane >> 4;
     if (tid == 0) *flag = 0;
     for (int k0 = 0; k0 < n; k0 += TR_NB) {
         const int nb = min(TR_NB, n - k0);
-        // (1) diagonal block -> LDS
+        const int m = n + 1 - k0;                 // rows of this panel (k0 .. n)
+        const int ntile = (m + 15) >> 4;
+        if (k0 > 0) {
+            // (0) the 16 pivot rows L[k0:k0+16, 0:k0] -> LDS (B operand of every tile of this panel)
+            for (int j = wv; j < TR_NB; j += TR_WAVES) {
+                const bool live = j < nb;
+                const double* src = A + (size_t)(k0 + (live ? j : 0)) * ld;
+                for (int c = lane; c < k0; c += 64) Bp[j * SB + c] = live ? src[c] : 0.0;
+            }
+            __syncthreads();
+            // (1) tile update on the matrix cores: acc(16x16) = A_tile - sum_c L[rows,c] L[k0+j,c]
+            for (int I = wv; I < ntile; I += TR_WAVES) {
+                const int R0 = k0 + 16 * I;
+                const int arow = R0 + li;                       // A-operand row of this lane
+                const bool arow_ok = arow <= n;
+                const double* ap = A + (size_t)(arow_ok ? arow : n) * ld + 2 * lk;
+                const double* bp = Bp + li * SB + 2 * lk;
+                v4f64 acc;
+                double* cbase = A + (size_t)(R0 + lk) * ld + k0 + li;   // C: lane l, reg r -> row (l>>4)+4r, col l&15
+                bool okr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    okr[r] = (R0 + lk + 4 * r) <= n && li < nb;
+                    acc[r] = okr[r] ? cbase[(size_t)(4 * r) * ld] : 0.0;
+                }
+                int c0 = 0;
+                for (; c0 + 32 <= k0; c0 += 32) {               // 4 x (16-byte A load + 16-byte LDS read) in flight
+                    v2f64 av[4], bv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        av[q] = *reinterpret_cast<const v2f64*>(ap + c0 + 8 * q);
+                        bv[q] = *reinterpret_cast<const v2f64*>(bp + c0 + 8 * q);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const double ax = arow_ok ? -av[q][0] : 0.0, ay = arow_ok ? -av[q][1] : 0.0;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, bv[q][0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, bv[q][1], acc, 0, 0, 0);
+                    }
+                }
+                for (; c0 < k0; c0 += 8) {
+                    const v2f64 av = *reinterpret_cast<const v2f64*>(ap + c0);
+                    const v2f64 bv = *reinterpret_cast<const v2f64*>(bp + c0);
+                    const double ax = arow_ok ? -av[0] : 0.0, ay = arow_ok ? -av[1] : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, bv[0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, bv[1], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (okr[r]) cbase[(size_t)(4 * r) * ld] = acc[r];
+            }
+            __syncthreads();
+        }
+        // (2) diagonal block -> LDS, factored by wavefront 0 (lane i keeps row i in registers)
         if (tid < TR_NB * TR_NB) {
             const int i = tid / TR_NB, j = tid % TR_NB;
             sD[i * TR_PS + j] = (i < nb && j <= i) ? A[(size_t)(k0 + i) * ld + k0 + j] : (i == j ? 1.0 : 0.0);
         }
         __syncthreads();
-        // (2) factor it in wavefront 0
         if (wv == 0) {
             double a[TR_NB];
 #pragma unroll
@@ -122,7 +167,9 @@ __device__ bool chol_augmented(double* A, const int n, double* panel, double* sD
                 double djj = readlane_d(a[j], j);
                 if (!(djj > 0.0) || !isfinite(djj)) { bad = true; djj = 1.0; }
                 const double d = sqrt(djj);
-                const double lij = (lane == j) ? d : a[j] / d;
+                const double rd = 1.0 / d;
+                const double lij = (lane == j) ? d : a[j] * rd;
+                if (lane == j) sD[TR_NB * TR_PS + j] = rd;        // reciprocal pivots for the row solves
                 a[j] = lij;
 #pragma unroll
                 for (int c = j + 1; c < TR_NB; ++c) {
@@ -145,76 +192,21 @@ __device__ bool chol_augmented(double* A, const int n, double* panel, double* sD
         if (*flag) return false;
         // (3) rows below (incl. the carried row n): X L_kk^T = A_panel, one lane per row
         const int r0 = k0 + nb;
-        const int m = n + 1 - r0;
-        const int mpad = (m + 15) & ~15;
-        for (int i = tid; i < mpad; i += TR_THREADS) {
+        const int mb = n + 1 - r0;
+        for (int i = tid; i < mb; i += TR_THREADS) {
+            double* row = A + (size_t)(r0 + i) * ld + k0;
             double xv[TR_NB];
-            if (i < m) {
-                double* row = A + (size_t)(r0 + i) * ld + k0;
 #pragma unroll
-                for (int j = 0; j < TR_NB; ++j) xv[j] = (j < nb) ? row[j] : 0.0;
+            for (int j = 0; j < TR_NB; ++j) xv[j] = (j < nb) ? row[j] : 0.0;
 #pragma unroll
-                for (int j = 0; j < TR_NB; ++j) {
-                    double s = xv[j];
+            for (int j = 0; j < TR_NB; ++j) {
+                double s = xv[j];
 #pragma unroll
-                    for (int k = 0; k < j; ++k) s -= xv[k] * sD[j * TR_PS + k];
-                    xv[j] = s / sD[j * TR_PS + j];
-                }
-#pragma unroll
-                for (int j = 0; j < TR_NB; ++j) if (j < nb) row[j] = xv[j];
-            } else {
-#pragma unroll
-                for (int j = 0; j < TR_NB; ++j) xv[j] = 0.0;
+                for (int k = 0; k < j; ++k) s -= xv[k] * sD[j * TR_PS + k];
+                xv[j] = s * sD[TR_NB * TR_PS + j];
             }
 #pragma unroll
-            for (int j = 0; j < TR_NB; ++j) panel[i * TR_PS + j] = (j < nb) ? xv[j] : 0.0;
-        }
-        __syncthreads();
-        // (4) trailing update on the matrix cores
-        const int mc = n - r0;                 // trailing columns (the carried row is not a column)
-        if (mc > 0) {
-            const int Tb = mpad >> 4;
-            const int ntiles = Tb * (Tb + 1) / 2;
-            const int li = lane & 15, lk = lane >> 4;
-            // SYRK_ILP independent tiles per wavefront iteration: their C loads and MFMA chains overlap
-            constexpr int SYRK_ILP = 3;
-            for (int id0 = wv; id0 < ntiles; id0 += TR_WAVES * SYRK_ILP) {
-                double av[SYRK_ILP][4], bv[SYRK_ILP][4];
-                v4f64 acc[SYRK_ILP];
-                double* cbase[SYRK_ILP];
-                bool okr[SYRK_ILP][4];
-#pragma unroll
-                for (int u = 0; u < SYRK_ILP; ++u) {
-                    const int id = id0 + u * TR_WAVES;
-                    const bool live = id < ntiles;
-                    const int idc = live ? id : 0;
-                    int ti = (int)((sqrtf(8.0f * (float)idc + 1.0f) - 1.0f) * 0.5f);
-                    while ((ti + 1) * (ti + 2) / 2 <= idc) ++ti;
-                    while (ti * (ti + 1) / 2 > idc) --ti;
-                    const int tj = idc - ti * (ti + 1) / 2;
-                    const double* pa = panel + (ti * 16 + li) * TR_PS + lk;
-                    const double* pb = panel + (tj * 16 + li) * TR_PS + lk;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { av[u][q] = -pa[4 * q]; bv[u][q] = pb[4 * q]; }
-                    // C tile: lane l, reg r -> row (l>>4) + 4 r, col l&15
-                    cbase[u] = A + (size_t)(r0 + ti * 16 + lk) * ld + r0 + tj * 16 + li;
-                    const int col = tj * 16 + li;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = ti * 16 + lk + 4 * r;
-                        okr[u][r] = live && row < m && col < mc && col <= row;
-                        acc[u][r] = okr[u][r] ? cbase[u][(size_t)(4 * r) * ld] : 0.0;
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int u = 0; u < SYRK_ILP; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][q], bv[u][q], acc[u], 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < SYRK_ILP; ++u)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (okr[u][r]) cbase[u][(size_t)(4 * r) * ld] = acc[u][r];
-            }
+            for (int j = 0; j < TR_NB; ++j) if (j < nb) row[j] = xv[j];
         }
         __syncthreads();
     }
@@ -222,7 +214,7 @@ __device__ bool chol_augmented(double* A, const int n, double* panel, double* sD
 }
 
 // Solve L^T z = y (L lower n x n in A, y in LDS, overwritten by z), blocked from the bottom up.
-__device__ void back_substitute(const double* A, const int n, double* y, double* sD) {
+__device__ __forceinline__ void back_substitute(const double* A, const int n, double* y, double* sD) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ld = n;
     const int nblk = (n + TR_NB - 1) / TR_NB;
@@ -235,9 +227,10 @@ __device__ void back_substitute(const double* A, const int n, double* y, double*
         __syncthreads();
         if (wv == 0) {        // lane i holds y_i; columns eliminated from the bottom with readlane broadcasts
             double yi = (lane < nb) ? y[k0 + lane] : 0.0;
+            const double rdiag = (lane < TR_NB) ? 1.0 / sD[lane * TR_PS + lane] : 1.0;
 #pragma unroll
             for (int k = TR_NB - 1; k >= 0; --k) {
-                const double zk = readlane_d(yi, k) / sD[k * TR_PS + k];
+                const double zk = readlane_d(yi, k) * readlane_d(rdiag, k);
                 if (lane == k) yi = zk;
                 else if (lane < k) yi -= sD[k * TR_PS + lane] * zk;
             }
@@ -257,24 +250,12 @@ __device__ void back_substitute(const double* A, const int n, double* y, double*
 __device__ __forceinline__ void finalize(const TrArgs& a, const SolverStatus& s) {
     const double* xc = s.cur ? a.x1 : a.x0;
     const int nx = 16 * a.W + a.n_ddt;
-    for (int k = threadIdx.x; k < nx; k += TR_THREADS) a.xout[k] = xc[k];
+    for (int k = threadIdx.x; k < nx; k += blockDim.x) a.xout[k] = xc[k];
     if (threadIdx.x == 0) *a.status = s;
 }
 
-extern __shared__ __attribute__((aligned(16))) unsigned char tr_lds[];
-
-// workspace vectors (global, persist across the launches of one solve)
-#define V_SCALE(a) ((a).vec + 0 * (a).vstride)
-#define V_DIAG(a) ((a).vec + 1 * (a).vstride)
-#define V_GRAD(a) ((a).vec + 2 * (a).vstride)   /* g~ = gs / D                      */
-#define V_GN(a) ((a).vec + 3 * (a).vstride)     /* Gauss-Newton step in D-space      */
-#define V_STEP(a) ((a).vec + 4 * (a).vstride)
-#define V_W(a) ((a).vec + 5 * (a).vstride)      /* scale * step = delta              */
-#define V_T1(a) ((a).vec + 6 * (a).vstride)
-#define V_T2(a) ((a).vec + 7 * (a).vstride)
-
 // ------------------------------------------------------------------------------------------------
-// K7a  k_tr_prepare: step evaluation of the pending candidate, loop-top checks, Cauchy point
+// K7a  k_tr_prepare
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TR_THREADS) void k_tr_prepare(const TrArgs a) {
     __shared__ double red[32];
@@ -284,7 +265,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_prepare(const TrArgs a) {
     if (tid == 0) s = *a.status;
     __syncthreads();
     if (s.done) return;
-    double* scale = V_SCALE(a); double* diag = V_DIAG(a); double* grad = V_GRAD(a); double* t1 = V_T1(a); double* t2 = V_T2(a);
+    double* scale = V_SCALE(a); double* diag = V_DIAG(a); double* grad = V_GRAD(a); double* u = V_U(a);
 
     if (s.cand_pending) {
         const int cand = 1 - s.cur;
@@ -368,55 +349,90 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_prepare(const TrArgs a) {
             diag[i] = dd;
             const double gs = scale[i] * g[i];
             grad[i] = gs / dd;
-            t1[i] = scale[i] * (gs / dd) / dd;          // u = S (g~ / D)
+            u[i] = scale[i] * (gs / dd) / dd;
         }
-        __syncthreads();
-        matvec(H, t1, t2, n);                            // H u
-        double p = 0, q2 = 0;
-        for (int i = tid; i < n; i += TR_THREADS) { p += t1[i] * t2[i]; q2 += grad[i] * grad[i]; }
-        p = block_sum(p, red);
-        q2 = block_sum(q2, red);
-        if (tid == 0) s.alpha = q2 / p;
     }
     __syncthreads();
     if (tid == 0) *a.status = s;
 }
 
 // ------------------------------------------------------------------------------------------------
-// K7b  k_tr_factor: Gauss-Newton step, (S H S + mu D^2) y = S g by the blocked MFMA Cholesky
+// K7b  k_tr_scale: one wavefront per row of H (multi-workgroup): t = H u, L = S H S + mu D^2, rhs row
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tr_scale(const TrArgs a) {
+    const SolverStatus* st = a.status;
+    if (st->done || st->reuse) return;
+    const int n = a.n;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i > n) return;
+    const double* H = st->cur ? a.H1 : a.H0;
+    const double* g = st->cur ? a.g1 : a.g0;
+    const double* scale = V_SCALE(a); const double* diag = V_DIAG(a); const double* u = V_U(a);
+    if (i == n) {                      // right-hand side S g as the carried row
+        for (int j = lane; j < n; j += 64) a.L[(size_t)n * n + j] = scale[j] * g[j];
+        return;
+    }
+    const double mu = st->mu, si = scale[i];
+    const double* hrow = H + (size_t)i * n;
+    double* lrow = a.L + (size_t)i * n;
+    double s = 0;
+    for (int j = lane; j < n; j += 64) {
+        const double h = hrow[j];
+        s += h * u[j];
+        if (j <= i) {
+            double v = si * h * scale[j];
+            if (i == j) v += mu * diag[i] * diag[i];
+            lrow[j] = v;
+        }
+    }
+    s = wave_sum(s);
+    if (lane == 0) V_T(a)[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7c  k_tr_factor
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TR_THREADS) void k_tr_factor(const TrArgs a) {
     const int tid = threadIdx.x;
     const int n = a.n;
-    double* panel = reinterpret_cast<double*>(tr_lds);                    // ((n+1) padded to 16) x TR_PS
-    double* sD = panel + (size_t)((n + 1 + 15) & ~15) * TR_PS;           // TR_NB x TR_PS
-    double* ylds = sD + TR_NB * TR_PS;                                    // n
+    double* Bp = reinterpret_cast<double*>(tr_lds);                       // 16 x bp_stride(n)
+    double* sD = Bp + TR_NB * bp_stride(n);                               // TR_NB x TR_PS
+    double* ylds = sD + (TR_NB + 1) * TR_PS;                              // n
     double* red = ylds + n + (n & 1);                                     // 32
     int* flag = reinterpret_cast<int*>(red + 32);
     double* smu = red + 40;
     if (a.status->done || a.status->reuse) return;
     const double* H = a.status->cur ? a.H1 : a.H0;
     const double* g = a.status->cur ? a.g1 : a.g0;
-    const double* scale = V_SCALE(a); const double* diag = V_DIAG(a); double* gn = V_GN(a);
-    if (tid == 0) *smu = a.status->mu;
+    const double* scale = V_SCALE(a); const double* diag = V_DIAG(a); const double* grad = V_GRAD(a);
+    const double* u = V_U(a); const double* t = V_T(a);
+    // Cauchy step length alpha = |g~|^2 / (u^T H u)
+    double p = 0, q2 = 0;
+    for (int i = tid; i < n; i += TR_THREADS) { p += u[i] * t[i]; q2 += grad[i] * grad[i]; }
+    p = block_sum(p, red);
+    q2 = block_sum(q2, red);
+    if (tid == 0) { a.status->alpha = q2 / p; *smu = a.status->mu; }
     __syncthreads();
     bool solved = false;
     for (int attempt = 0; attempt < 12; ++attempt) {
         const double mu = *smu;
         if (!(mu < 1.0)) break;
-        for (int i = tid >> 6; i < n; i += TR_WAVES) {
-            const double si = scale[i];
-            const double* hrow = H + (size_t)i * n;
-            double* lrow = a.L + (size_t)i * n;
-            for (int j = tid & 63; j <= i; j += 64) {
-                double v = si * hrow[j] * scale[j];
-                if (i == j) v += mu * diag[i] * diag[i];
-                lrow[j] = v;
+        if (attempt > 0) {             // breakdown: rebuild S H S + mu D^2 with the larger mu (rare)
+            for (int i = tid >> 6; i < n; i += TR_WAVES) {
+                const double si = scale[i];
+                const double* hrow = H + (size_t)i * n;
+                double* lrow = a.L + (size_t)i * n;
+                for (int j = tid & 63; j <= i; j += 64) {
+                    double v = si * hrow[j] * scale[j];
+                    if (i == j) v += mu * diag[i] * diag[i];
+                    lrow[j] = v;
+                }
             }
+            for (int j = tid; j < n; j += TR_THREADS) a.L[(size_t)n * n + j] = scale[j] * g[j];
+            __syncthreads();
         }
-        for (int j = tid; j < n; j += TR_THREADS) a.L[(size_t)n * n + j] = scale[j] * g[j];
-        __syncthreads();
-        const bool ok = chol_augmented(a.L, n, panel, sD, flag);
+        const bool ok = chol_left_looking(a.L, n, Bp, sD, flag);
         double bad = 1;
         if (ok) {
             for (int j = tid; j < n; j += TR_THREADS) ylds[j] = a.L[(size_t)n * n + j];
@@ -431,10 +447,13 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_factor(const TrArgs a) {
         if (tid == 0) *smu = mu * 10.0;
         __syncthreads();
     }
-    if (solved) for (int i = tid; i < n; i += TR_THREADS) gn[i] = -diag[i] * ylds[i];
+    if (solved) {
+        double* gn = V_GN(a); double* y = V_Y(a);
+        for (int i = tid; i < n; i += TR_THREADS) { y[i] = ylds[i]; gn[i] = -diag[i] * ylds[i]; }
+    }
     __syncthreads();
     if (tid == 0) {
-        if (solved) a.status->mu = fmax(1e-8, 2.0 * (*smu) / 10.0);
+        if (solved) { a.status->mu_used = *smu; a.status->mu = fmax(1e-8, 2.0 * (*smu) / 10.0); }
         else { a.status->mu = *smu; a.status->done = 1; a.status->termination = GLIO_TERM_FAILURE; }
     }
     if (!solved) {
@@ -444,7 +463,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_factor(const TrArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K7c  k_tr_dogleg: traditional dogleg interpolation, model cost change, candidate x (+) delta
+// K7d  k_tr_dogleg
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TR_THREADS) void k_tr_dogleg(const TrArgs a) {
     __shared__ double red[32];
@@ -454,15 +473,15 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_dogleg(const TrArgs a) {
     if (tid == 0) s = *a.status;
     __syncthreads();
     if (s.done) return;
-    const double* H = s.cur ? a.H1 : a.H0;
     const double* g = s.cur ? a.g1 : a.g0;
     const double* scale = V_SCALE(a); const double* diag = V_DIAG(a); const double* grad = V_GRAD(a); const double* gn = V_GN(a);
-    double* step = V_STEP(a); double* wvec = V_W(a); double* t2 = V_T2(a);
+    const double* y = V_Y(a); const double* t = V_T(a);
+    double* wvec = V_W(a);
     double gg = 0, nn = 0, gd = 0;
     for (int i = tid; i < n; i += TR_THREADS) { gg += grad[i] * grad[i]; nn += gn[i] * gn[i]; gd += grad[i] * gn[i]; }
     gg = block_sum(gg, red); nn = block_sum(nn, red); gd = block_sum(gd, red);
     const double gnorm = sqrt(gg), gnn = sqrt(nn), radius = s.radius, alpha = s.alpha;
-    double ca, cb, snorm;       // step = ca * grad + cb * gn
+    double ca, cb, snorm;       // step (D-space) = ca * grad + cb * gn
     if (gnn <= radius) { ca = 0.0; cb = 1.0; snorm = gnn; }
     else if (gnorm * alpha >= radius) { ca = -(radius / gnorm); cb = 0.0; snorm = radius; }
     else {
@@ -474,20 +493,23 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_dogleg(const TrArgs a) {
         const double beta = (c <= 0) ? (d - c) / b_minus_a_sq : (radius * radius - a_sq) / (d + c);
         ca = -alpha * (1.0 - beta); cb = beta; snorm = -1.0;
     }
-    double sn2 = 0;
+    // step_s = step / D = ca * (g~/D) + cb * (-y); w = S step_s.
+    // Hs step_s = ca * Hs (g~/D) - cb * Hs y, with Hs (g~/D) = S H u = S t and Hs y = S g - mu D^2 y
+    // -> model cost change = -(gs.step_s + step_s^T Hs step_s / 2) without another matrix pass.
+    const double mu = s.mu_used;
+    double sn2 = 0, lin = 0, quad = 0;
     for (int i = tid; i < n; i += TR_THREADS) {
         const double sv = ca * grad[i] + cb * gn[i];
         sn2 += sv * sv;
-        step[i] = sv / diag[i];
-        wvec[i] = scale[i] * step[i];
+        const double step_s = sv / diag[i];
+        wvec[i] = scale[i] * step_s;
+        const double gs = scale[i] * g[i];
+        const double hs_step = ca * (scale[i] * t[i]) - cb * (gs - mu * diag[i] * diag[i] * y[i]);
+        lin += gs * step_s;
+        quad += step_s * hs_step;
     }
-    sn2 = block_sum(sn2, red);
+    sn2 = block_sum(sn2, red); lin = block_sum(lin, red); quad = block_sum(quad, red);
     if (snorm < 0) snorm = sqrt(sn2);
-    // model cost change = -(g.w + w^T H w / 2), w = S step
-    matvec(H, wvec, t2, n);
-    double lin = 0, quad = 0;
-    for (int i = tid; i < n; i += TR_THREADS) { lin += g[i] * wvec[i]; quad += wvec[i] * t2[i]; }
-    lin = block_sum(lin, red); quad = block_sum(quad, red);
     const double mcc = -(lin + 0.5 * quad);
     const bool valid = mcc > 0.0;
     if (tid == 0) {
@@ -524,8 +546,8 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_dogleg(const TrArgs a) {
 }
 
 size_t glio_tr_step_lds_bytes(int n) {
-    size_t d = (size_t)((n + 1 + 15) & ~15) * TR_PS;
-    d += TR_NB * TR_PS;
+    size_t d = (size_t)TR_NB * bp_stride(n);
+    d += (TR_NB + 1) * TR_PS;
     d += n + (n & 1);
     d += 32 + 16;
     return d * sizeof(double);
@@ -543,17 +565,18 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
     a.L = c->d_L; a.vec = c->d_vec; a.vstride = c->n_max;
     a.status = c->d_status;
     hipLaunchKernelGGL(k_tr_prepare, dim3(1), dim3(TR_THREADS), 0, c->stream, a);
+    hipLaunchKernelGGL(k_tr_scale, dim3((a.n + 1 + 3) / 4), dim3(256), 0, c->stream, a);
     hipLaunchKernelGGL(k_tr_factor, dim3(1), dim3(TR_THREADS), glio_tr_step_lds_bytes(a.n), c->stream, a);
     hipLaunchKernelGGL(k_tr_dogleg, dim3(1), dim3(TR_THREADS), 0, c->stream, a);
 }
 
-// ---- test hook: solve (A + 0) x = b for a dense SPD n x n matrix with the in-kernel blocked Cholesky
+// ---- test hook: solve A x = b for a dense SPD n x n matrix with the in-kernel blocked Cholesky
 __global__ __launch_bounds__(TR_THREADS) void k_chol_test(double* L, int n, double* x, int* ok) {
-    double* panel = reinterpret_cast<double*>(tr_lds);
-    double* sD = panel + (size_t)((n + 1 + 15) & ~15) * TR_PS;
-    double* ylds = sD + TR_NB * TR_PS;
+    double* Bp = reinterpret_cast<double*>(tr_lds);
+    double* sD = Bp + TR_NB * bp_stride(n);
+    double* ylds = sD + (TR_NB + 1) * TR_PS;
     int* flag = reinterpret_cast<int*>(ylds + n + (n & 1) + 32);
-    const bool good = chol_augmented(L, n, panel, sD, flag);
+    const bool good = chol_left_looking(L, n, Bp, sD, flag);
     if (good) {
         for (int j = threadIdx.x; j < n; j += TR_THREADS) ylds[j] = L[(size_t)n * n + j];
         __syncthreads();
