@@ -8,7 +8,8 @@
 //       [.., +n_groups)     dd_psr_factor_20::Evaluate   (dd_psr_factor.hpp:25-171) and
 //                           tcdopplerFactor              (dopp_factor.hpp:24-75, HuberLoss(1.0)) of one
 //                           (slot_i,slot_j) pair -> 30x30 block + per-epoch clock-drift coupling
-//       last                MarginalizationFactor::Evaluate (GLIO/src/MarginalizationFactor.cpp:233-287)
+//       last 1+8            MarginalizationFactor::Evaluate (GLIO/src/MarginalizationFactor.cpp:233-287):
+//                           one workgroup for r, g, cost and eight sharing the rows of H
 //   k_assemble      : H[r][c] / g[r] gathered from those blocks (no atomics, deterministic)
 //
 // All Jacobians go through the same chain as Ceres: global Jacobian -> (loss corrector) ->
@@ -451,12 +452,11 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
 //   r = r0 + J0 dx ; local Jacobian = J0 * blockdiag(M_b), M_b = I or 2 s Qleft(q0^-1)[1:4,:] P(q)
 //   H = M^T (J0^T J0) M, g = M^T J0^T r, cost = |r|^2/2
 // ------------------------------------------------------------------------------------------------
-__device__ void prior_block(const SmallArgs& a, const double* __restrict__ x, double* H, double* gout, double* cost) {
-    const int tid = threadIdx.x, np = a.np, nb = a.npb, W = a.W;
-    double* dx = a.pwork;              // [np]
-    double* r = dx + np;               // [np]
-    double* v = r + np;                // [np]
-    double* Mb = v + np;               // [nb][9]
+#define PRIOR_H_BLOCKS 8      // workgroups that share the H = M^T A0 M entries; one more does r, g, cost
+
+// dx [np] and the 3x3 blocks M_b of the quaternion blocks, into LDS (every prior workgroup recomputes them)
+__device__ __forceinline__ void prior_dx_M(const SmallArgs& a, const double* __restrict__ x, double* dx, double* Mb) {
+    const int tid = threadIdx.x, nb = a.npb, W = a.W;
     for (int b = tid; b < nb; b += SF_THREADS) {
         const int s = a.pslot[b], kind = a.pkind[b], idx = a.pidx[b];
         const double* x0 = a.px0 + 9 * b;
@@ -484,11 +484,22 @@ __device__ void prior_block(const SmallArgs& a, const double* __restrict__ x, do
         }
     }
     __syncthreads();
-    for (int i = tid; i < np; i += SF_THREADS) {
-        double s = a.pr0[i];
+}
+
+#define PRIOR_MAX_NP (6 * GLIO_MAX_WINDOW + 9)
+#define PRIOR_MAX_NB (2 * GLIO_MAX_WINDOW + 1)
+
+// workgroup 0 of the prior: r = r0 + J0 dx (one wavefront per row, coalesced), v = J0^T r, g = M^T v, cost
+__device__ void prior_rg_block(const SmallArgs& a, const double* __restrict__ x, double* gout, double* cost) {
+    __shared__ double dx[PRIOR_MAX_NP], r[PRIOR_MAX_NP], v[PRIOR_MAX_NP], Mb[9 * PRIOR_MAX_NB];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, np = a.np;
+    prior_dx_M(a, x, dx, Mb);
+    for (int i = wv; i < np; i += SF_THREADS / 64) {
         const double* row = a.pJ0 + (size_t)i * np;
-        for (int k = 0; k < np; ++k) s += row[k] * dx[k];
-        r[i] = s;
+        double s = 0;
+        for (int k = lane; k < np; k += 64) s += row[k] * dx[k];
+        s = wave_sum(s);
+        if (lane == 0) r[i] = a.pr0[i] + s;
     }
     __syncthreads();
     for (int j = tid; j < np; j += SF_THREADS) {
@@ -506,36 +517,45 @@ __device__ void prior_block(const SmallArgs& a, const double* __restrict__ x, do
         } else s = v[j];
         gout[j] = s;
     }
-    for (int e = tid; e < np * np; e += SF_THREADS) {
-        const int i = e / np, j = e % np;
-        const int bi = a.pcolblk[i], bj = a.pcolblk[j];
-        const bool qi = a.pkind[bi] == GLIO_BLK_QUAT, qj = a.pkind[bj] == GLIO_BLK_QUAT;
-        double s;
-        if (!qi && !qj) s = a.pA0[(size_t)i * np + j];
-        else if (qi && !qj) {
-            const int ii = a.pidx[bi], c = i - ii;
-            s = 0;
-            for (int k = 0; k < 3; ++k) s += Mb[9 * bi + k * 3 + c] * a.pA0[(size_t)(ii + k) * np + j];
-        } else if (!qi && qj) {
-            const int jj = a.pidx[bj], c = j - jj;
-            s = 0;
-            for (int l = 0; l < 3; ++l) s += a.pA0[(size_t)i * np + jj + l] * Mb[9 * bj + l * 3 + c];
-        } else {
-            const int ii = a.pidx[bi], ci = i - ii, jj = a.pidx[bj], cj = j - jj;
-            s = 0;
-            for (int k = 0; k < 3; ++k) {
-                double t = 0;
-                for (int l = 0; l < 3; ++l) t += a.pA0[(size_t)(ii + k) * np + jj + l] * Mb[9 * bj + l * 3 + cj];
-                s += Mb[9 * bi + k * 3 + ci] * t;
-            }
-        }
-        H[e] = s;
-    }
     if (tid < 64) {
         double s = 0;
         for (int i = tid; i < np; i += 64) s += r[i] * r[i];
         s = wave_sum(s);
         if (tid == 0) *cost = 0.5 * s;
+    }
+}
+
+// workgroups 1..PRIOR_H_BLOCKS: rows i = part, part + PRIOR_H_BLOCKS, ... of H = M^T A0 M
+__device__ void prior_H_block(const SmallArgs& a, const double* __restrict__ x, double* H, int part) {
+    __shared__ double dx[PRIOR_MAX_NP], Mb[9 * PRIOR_MAX_NB];
+    const int tid = threadIdx.x, np = a.np;
+    prior_dx_M(a, x, dx, Mb);
+    for (int i = part; i < np; i += PRIOR_H_BLOCKS) {
+        const int bi = a.pcolblk[i];
+        const bool qi = a.pkind[bi] == GLIO_BLK_QUAT;
+        const int ii = a.pidx[bi], ci = i - ii;
+        for (int j = tid; j < np; j += SF_THREADS) {
+            const int bj = a.pcolblk[j];
+            const bool qj = a.pkind[bj] == GLIO_BLK_QUAT;
+            const int jj = a.pidx[bj], cj = j - jj;
+            double s;
+            if (!qi && !qj) s = a.pA0[(size_t)i * np + j];
+            else if (qi && !qj) {
+                s = 0;
+                for (int k = 0; k < 3; ++k) s += Mb[9 * bi + k * 3 + ci] * a.pA0[(size_t)(ii + k) * np + j];
+            } else if (!qi && qj) {
+                s = 0;
+                for (int l = 0; l < 3; ++l) s += a.pA0[(size_t)i * np + jj + l] * Mb[9 * bj + l * 3 + cj];
+            } else {
+                s = 0;
+                for (int k = 0; k < 3; ++k) {
+                    double t = 0;
+                    for (int l = 0; l < 3; ++l) t += a.pA0[(size_t)(ii + k) * np + jj + l] * Mb[9 * bj + l * 3 + cj];
+                    s += Mb[9 * bi + k * 3 + ci] * t;
+                }
+            }
+            H[(size_t)i * np + j] = s;
+        }
     }
 }
 
@@ -568,7 +588,11 @@ __global__ __launch_bounds__(SF_THREADS) void k_small_factors(const SmallArgs a)
         gnss_block(a, x, a.groups[b], b, a.gnss_blocks + (size_t)which * a.gnss_stride + b, a.ddt_blocks + (size_t)which * a.ddt_stride);
         return;
     }
-    if (a.has_prior) prior_block(a, x, a.pH + (size_t)which * a.np * a.np, a.pg + (size_t)which * a.np, a.pcost + which);
+    b -= a.n_groups;
+    if (a.has_prior) {
+        if (b == 0) prior_rg_block(a, x, a.pg + (size_t)which * a.np, a.pcost + which);
+        else prior_H_block(a, x, a.pH + (size_t)which * a.np * a.np, b - 1);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -607,64 +631,97 @@ __global__ __launch_bounds__(256) void k_assemble(const AsmArgs a) {
     const double* lb = a.lidar_blocks + (size_t)which * W * GLIO_LIDAR_ACC;
     const double* pH = a.pH + (size_t)which * a.np * a.np;
     const double* pg = a.pg + (size_t)which * a.np;
-    const long total = (long)n * n;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total + n; e += (long)gridDim.x * blockDim.x) {
-        if (e >= total) {          // gradient entry
-            const int r = (int)(e - total);
-            double s = 0;
-            if (r < np15) {
-                const int sr = r / 15, lr = r % 15;
-                if (lr < 6) s += lb[sr * GLIO_LIDAR_ACC + 21 + lr];
-                for (int k = 0; k < a.n_imu; ++k) {
-                    if (imu[k].slot_a == sr) s += imu[k].g[lr];
-                    else if (imu[k].slot_b == sr) s += imu[k].g[15 + lr];
-                }
-                for (int k = 0; k < a.n_groups; ++k) {
-                    if (gn[k].slot_a == sr) s += gn[k].g[lr];
-                    else if (gn[k].slot_b == sr) s += gn[k].g[15 + lr];
-                }
-                if (a.has_prior) { const int pi = a.prior_index[r]; if (pi >= 0) s += pg[pi]; }
-            } else {
-                s = dd[r - np15].g;
+    // O(1) lookup tables: IMU edge that starts at a slot, GNSS group of a slot pair
+    __shared__ short imap[GLIO_MAX_WINDOW];
+    __shared__ short gmap[GLIO_MAX_WINDOW * GLIO_MAX_WINDOW];
+    for (int k = threadIdx.x; k < W; k += blockDim.x) imap[k] = -1;
+    for (int k = threadIdx.x; k < W * W; k += blockDim.x) gmap[k] = -1;
+    __syncthreads();
+    for (int k = threadIdx.x; k < a.n_imu; k += blockDim.x) imap[imu[k].slot_a] = (short)k;
+    for (int k = threadIdx.x; k < a.n_groups; k += blockDim.x) {
+        gmap[gn[k].slot_a * W + gn[k].slot_b] = (short)k;
+        gmap[gn[k].slot_b * W + gn[k].slot_a] = (short)k;
+    }
+    __syncthreads();
+    // rows are dealt to workgroups, columns to lanes (coalesced stores, no integer division per entry)
+    for (int r = blockIdx.x; r <= n; r += gridDim.x) {
+        if (r == n) {          // gradient
+            for (int c = threadIdx.x; c < n; c += blockDim.x) {
+                double s = 0;
+                if (c < np15) {
+                    const int sc = c / 15, lc = c % 15;
+                    if (lc < 6) s += lb[sc * GLIO_LIDAR_ACC + 21 + lc];
+                    const int e0 = imap[sc], e1 = sc > 0 ? imap[sc - 1] : -1;
+                    if (e0 >= 0) s += imu[e0].g[lc];
+                    if (e1 >= 0 && imu[e1].slot_b == sc) s += imu[e1].g[15 + lc];
+                    for (int k = 0; k < a.n_groups; ++k) {
+                        if (gn[k].slot_a == sc) s += gn[k].g[lc];
+                        else if (gn[k].slot_b == sc) s += gn[k].g[15 + lc];
+                    }
+                    if (a.has_prior) { const int pi = a.prior_index[c]; if (pi >= 0) s += pg[pi]; }
+                } else s = dd[c - np15].g;
+                g[c] = s;
             }
-            g[r] = s;
             continue;
         }
-        const int r = (int)(e / n), c = (int)(e % n);
-        double s = 0;
-        if (r < np15 && c < np15) {
-            const int sr = r / 15, lr = r % 15, sc = c / 15, lc = c % 15;
-            if (sr == sc && lr < 6 && lc < 6) s += lb[sr * GLIO_LIDAR_ACC + (lr <= lc ? lidar_sym_index(lr, lc) : lidar_sym_index(lc, lr))];
-            for (int k = 0; k < a.n_imu; ++k) {
-                const int sa = imu[k].slot_a, sb = imu[k].slot_b;
-                if ((sr == sa || sr == sb) && (sc == sa || sc == sb))
-                    s += imu[k].H[((sr == sa ? 0 : 15) + lr) * GLIO_PAIR_DIM + (sc == sa ? 0 : 15) + lc];
-            }
-            for (int k = 0; k < a.n_groups; ++k) {
-                const int sa = gn[k].slot_a, sb = gn[k].slot_b;
-                if ((sr == sa || sr == sb) && (sc == sa || sc == sb))
-                    s += gn[k].H[((sr == sa ? 0 : 15) + lr) * GLIO_PAIR_DIM + (sc == sa ? 0 : 15) + lc];
-            }
-            if (a.has_prior) {
-                const int pi = a.prior_index[r], pj = a.prior_index[c];
-                if (pi >= 0 && pj >= 0) s += pH[(size_t)pi * a.np + pj];
-            }
-        } else if (r >= np15 && c >= np15) {
-            if (r == c) s = dd[r - np15].h;
-        } else {
-            const int ep = (r >= np15 ? r : c) - np15;
-            const int pc = r >= np15 ? c : r;
-            if (dd[ep].used) {
-                const int sc = pc / 15, lc = pc % 15;
-                const int gi = dd[ep].group;
-                const int sa = gn[gi].slot_a, sb = gn[gi].slot_b;
-                if (sc == sa || sc == sb) {
-                    const int k12 = dop_local12(sc == sb && sc != sa, lc);
-                    if (k12 >= 0) s = dd[ep].c[k12];
+        double* Hrow = H + (size_t)r * n;
+        if (r < np15) {
+            const int sr = r / 15, lr = r % 15;
+            const int pi = a.has_prior ? a.prior_index[r] : -1;
+            for (int c = threadIdx.x; c < n; c += blockDim.x) {
+                double s = 0;
+                if (c < np15) {
+                    const int sc = c / 15, lc = c % 15;
+                    if (sr == sc && lr < 6 && lc < 6) s += lb[sr * GLIO_LIDAR_ACC + (lr <= lc ? lidar_sym_index(lr, lc) : lidar_sym_index(lc, lr))];
+                    const int d = sc - sr;
+                    if (d >= -1 && d <= 1) {
+                        const int lo = sr < sc ? sr : sc;
+                        const int e0 = imap[lo];                               // edge (lo, lo+1)
+                        if (e0 >= 0 && (d != 0 || true)) {
+                            const int sa = imu[e0].slot_a, sb = imu[e0].slot_b;
+                            if ((sr == sa || sr == sb) && (sc == sa || sc == sb))
+                                s += imu[e0].H[((sr == sa ? 0 : 15) + lr) * GLIO_PAIR_DIM + (sc == sa ? 0 : 15) + lc];
+                        }
+                        if (d == 0 && sr > 0) {                                // edge (sr-1, sr) also covers (sr, sr)
+                            const int e1 = imap[sr - 1];
+                            if (e1 >= 0 && imu[e1].slot_b == sr) s += imu[e1].H[(15 + lr) * GLIO_PAIR_DIM + 15 + lc];
+                        }
+                    }
+                    if (sr != sc) {
+                        const int k = gmap[sr * W + sc];
+                        if (k >= 0) s += gn[k].H[((sr == gn[k].slot_a ? 0 : 15) + lr) * GLIO_PAIR_DIM + (sc == gn[k].slot_a ? 0 : 15) + lc];
+                    } else {
+                        for (int k = 0; k < a.n_groups; ++k) {                 // diagonal slot block: every group touching sr
+                            if (gn[k].slot_a == sr) s += gn[k].H[lr * GLIO_PAIR_DIM + lc];
+                            else if (gn[k].slot_b == sr) s += gn[k].H[(15 + lr) * GLIO_PAIR_DIM + 15 + lc];
+                        }
+                    }
+                    if (pi >= 0) { const int pj = a.prior_index[c]; if (pj >= 0) s += pH[(size_t)pi * a.np + pj]; }
+                } else {
+                    const int ep = c - np15;
+                    if (dd[ep].used) {
+                        const int gi = dd[ep].group;
+                        const int sa = gn[gi].slot_a, sb = gn[gi].slot_b;
+                        if (sr == sa || sr == sb) { const int k12 = dop_local12(sr == sb && sr != sa, lr); if (k12 >= 0) s = dd[ep].c[k12]; }
+                    }
                 }
+                Hrow[c] = s;
+            }
+        } else {
+            const int ep = r - np15;
+            const bool used = dd[ep].used != 0;
+            const int gi = used ? dd[ep].group : 0;
+            const int sa = used ? gn[gi].slot_a : -1, sb = used ? gn[gi].slot_b : -1;
+            for (int c = threadIdx.x; c < n; c += blockDim.x) {
+                double s = 0;
+                if (c >= np15) { if (c == r) s = dd[ep].h; }
+                else if (used) {
+                    const int sc = c / 15, lc = c % 15;
+                    if (sc == sa || sc == sb) { const int k12 = dop_local12(sc == sb && sc != sa, lc); if (k12 >= 0) s = dd[ep].c[k12]; }
+                }
+                Hrow[c] = s;
             }
         }
-        H[e] = s;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         double cs = 0;
@@ -764,7 +821,7 @@ void glio_launch_small_factors(glio_ctx* c, int use_status_cand, int which, int 
     a.pJ0 = c->d_prior_J0; a.pA0 = c->d_prior_A0; a.pr0 = c->d_prior_r0; a.px0 = c->d_prior_x0;
     a.pslot = c->d_prior_slot; a.pkind = c->d_prior_kind; a.pidx = c->d_prior_idx; a.pcolblk = ex->d_prior_colblk;
     a.pH = c->d_prior_H; a.pg = c->d_prior_g; a.pcost = c->d_prior_cost; a.pwork = c->d_prior_work;
-    const int blocks = c->W + c->n_imu + c->n_groups + (a.has_prior ? 1 : 0);
+    const int blocks = c->W + c->n_imu + c->n_groups + (a.has_prior ? 1 + PRIOR_H_BLOCKS : 0);
     hipLaunchKernelGGL(k_small_factors, dim3(blocks), dim3(SF_THREADS), 0, c->stream, a);
 }
 
@@ -777,8 +834,6 @@ void glio_launch_assemble(glio_ctx* c, int use_status_cand, int which, int n_ddt
     a.gnss_stride = c->W * c->W; a.ddt_stride = c->n_ddt_max > 0 ? c->n_ddt_max : 1;
     a.pH = c->d_prior_H; a.pg = c->d_prior_g; a.pcost = c->d_prior_cost; a.prior_index = c->d_prior_index;
     a.H0 = c->d_H[0]; a.H1 = c->d_H[1]; a.g0 = c->d_g[0]; a.g1 = c->d_g[1]; a.c0 = c->d_cost[0]; a.c1 = c->d_cost[1];
-    const long total = (long)a.n * a.n + a.n;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
+    const int blocks = a.n + 1;       // one workgroup per row of H (+ one for g)
     hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(256), 0, c->stream, a);
 }

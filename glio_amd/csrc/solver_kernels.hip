@@ -28,6 +28,8 @@
 //
 // NOTE: no __restrict__ on anything in this file: every buffer here is handed between lanes of the
 // workgroup across s_barrier.
+#include <vector>
+
 #include "glio_device.h"
 
 #define TR_THREADS 512
@@ -92,7 +94,7 @@ __device__ __host__ __forceinline__ int bp_stride(int n) { return ((n + 15) & ~1
 // Blocked left-looking Cholesky of the leading n x n block of the (n+1) x n row-major matrix A (lower
 // triangle), row n carried along (= forward substitution of the right-hand side).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool chol_left_looking(double* A, const int n, double* Bp, double* sD, int* flag) {
+__device__ __forceinline__ bool chol_left_looking(double* A, const int n, double* Bp, double* part, double* sD, int* flag, const int skip = 0) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ld = n, SB = bp_stride(n);
     const int li = lane & 15, lk = lane >> 4;
@@ -101,7 +103,7 @@ __device__ __forceinline__ bool chol_left_looking(double* A, const int n, double
         const int nb = min(TR_NB, n - k0);
         const int m = n + 1 - k0;                 // rows of this panel (k0 .. n)
         const int ntile = (m + 15) >> 4;
-        if (k0 > 0) {
+        if (k0 > 0 && !(skip & 1)) {
             // (0) the 16 pivot rows L[k0:k0+16, 0:k0] -> LDS (B operand of every tile of this panel)
             for (int j = wv; j < TR_NB; j += TR_WAVES) {
                 const bool live = j < nb;
@@ -109,8 +111,14 @@ __device__ __forceinline__ bool chol_left_looking(double* A, const int n, double
                 for (int c = lane; c < k0; c += 64) Bp[j * SB + c] = live ? src[c] : 0.0;
             }
             __syncthreads();
-            // (1) tile update on the matrix cores: acc(16x16) = A_tile - sum_c L[rows,c] L[k0+j,c]
-            for (int I = wv; I < ntile; I += TR_WAVES) {
+            // (1) tile update on the matrix cores: acc(16x16) = A_tile - sum_c L[rows,c] L[k0+j,c].
+            //     Work unit = (tile, k-split): late panels have few tiles and long chains, so the chain is cut
+            //     into KS pieces (<= 16 units in flight) and the partial accumulators are summed through LDS.
+            const int KS = ntile >= 9 ? 1 : min(8, 16 / ntile);
+            const int nk8 = k0 >> 3, ck8 = (nk8 + KS - 1) / KS;
+            for (int unit = wv; unit < ntile * KS; unit += TR_WAVES) {
+                const int I = unit / KS, ks = unit - I * KS;
+                const int cb = ks * ck8 * 8, ce = min(k0, cb + ck8 * 8);
                 const int R0 = k0 + 16 * I;
                 const int arow = R0 + li;                       // A-operand row of this lane
                 const bool arow_ok = arow <= n;
@@ -122,10 +130,10 @@ __device__ __forceinline__ bool chol_left_looking(double* A, const int n, double
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     okr[r] = (R0 + lk + 4 * r) <= n && li < nb;
-                    acc[r] = okr[r] ? cbase[(size_t)(4 * r) * ld] : 0.0;
+                    acc[r] = (okr[r] && ks == 0) ? cbase[(size_t)(4 * r) * ld] : 0.0;
                 }
-                int c0 = 0;
-                for (; c0 + 32 <= k0; c0 += 32) {               // 4 x (16-byte A load + 16-byte LDS read) in flight
+                int c0 = cb;
+                for (; c0 + 32 <= ce; c0 += 32) {               // 4 x (16-byte A load + 16-byte LDS read) in flight
                     v2f64 av[4], bv[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -139,17 +147,32 @@ __device__ __forceinline__ bool chol_left_looking(double* A, const int n, double
                         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, bv[q][1], acc, 0, 0, 0);
                     }
                 }
-                for (; c0 < k0; c0 += 8) {
-                    const v2f64 av = *reinterpret_cast<const v2f64*>(ap + c0);
-                    const v2f64 bv = *reinterpret_cast<const v2f64*>(bp + c0);
-                    const double ax = arow_ok ? -av[0] : 0.0, ay = arow_ok ? -av[1] : 0.0;
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, bv[0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, bv[1], acc, 0, 0, 0);
+                for (; c0 < ce; c0 += 8) {
+                    const v2f64 a1 = *reinterpret_cast<const v2f64*>(ap + c0);
+                    const v2f64 b1 = *reinterpret_cast<const v2f64*>(bp + c0);
+                    const double ax = arow_ok ? -a1[0] : 0.0, ay = arow_ok ? -a1[1] : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b1[0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, b1[1], acc, 0, 0, 0);
                 }
+                if (KS == 1) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (okr[r]) cbase[(size_t)(4 * r) * ld] = acc[r];
+                    for (int r = 0; r < 4; ++r) if (okr[r]) cbase[(size_t)(4 * r) * ld] = acc[r];
+                } else {
+                    *reinterpret_cast<v4f64*>(part + (size_t)unit * 256 + lane * 4) = acc;
+                }
             }
             __syncthreads();
+            if (KS > 1) {
+                for (int I = wv; I < ntile; I += TR_WAVES) {
+                    v4f64 acc = *reinterpret_cast<const v4f64*>(part + (size_t)(I * KS) * 256 + lane * 4);
+                    for (int ks = 1; ks < KS; ++ks) acc += *reinterpret_cast<const v4f64*>(part + (size_t)(I * KS + ks) * 256 + lane * 4);
+                    const int R0 = k0 + 16 * I;
+                    double* cbase = A + (size_t)(R0 + lk) * ld + k0 + li;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if ((R0 + lk + 4 * r) <= n && li < nb) cbase[(size_t)(4 * r) * ld] = acc[r];
+                }
+                __syncthreads();
+            }
         }
         // (2) diagonal block -> LDS, factored by wavefront 0 (lane i keeps row i in registers)
         if (tid < TR_NB * TR_NB) {
@@ -157,7 +180,7 @@ __device__ __forceinline__ bool chol_left_looking(double* A, const int n, double
             sD[i * TR_PS + j] = (i < nb && j <= i) ? A[(size_t)(k0 + i) * ld + k0 + j] : (i == j ? 1.0 : 0.0);
         }
         __syncthreads();
-        if (wv == 0) {
+        if (wv == 0 && !(skip & 2)) {
             double a[TR_NB];
 #pragma unroll
             for (int j = 0; j < TR_NB; ++j) a[j] = (lane < TR_NB) ? sD[lane * TR_PS + j] : 0.0;
@@ -166,8 +189,8 @@ __device__ __forceinline__ bool chol_left_looking(double* A, const int n, double
             for (int j = 0; j < TR_NB; ++j) {
                 double djj = readlane_d(a[j], j);
                 if (!(djj > 0.0) || !isfinite(djj)) { bad = true; djj = 1.0; }
-                const double d = sqrt(djj);
-                const double rd = 1.0 / d;
+                const double rd = rsqrt(djj);
+                const double d = djj * rd;
                 const double lij = (lane == j) ? d : a[j] * rd;
                 if (lane == j) sD[TR_NB * TR_PS + j] = rd;        // reciprocal pivots for the row solves
                 a[j] = lij;
@@ -190,23 +213,34 @@ __device__ __forceinline__ bool chol_left_looking(double* A, const int n, double
         }
         __syncthreads();
         if (*flag) return false;
-        // (3) rows below (incl. the carried row n): X L_kk^T = A_panel, one lane per row
+        // (3) rows below (incl. the carried row n): X L_kk^T = A_panel, one lane per row.  L_kk is NOT copied
+        //     per lane: every wavefront keeps it distributed (lane l holds row l&15) and the coefficient
+        //     L[j][k] reaches the FMA as a scalar through v_readlane -- no LDS traffic, 64 live VGPRs.
         const int r0 = k0 + nb;
         const int mb = n + 1 - r0;
-        for (int i = tid; i < mb; i += TR_THREADS) {
-            double* row = A + (size_t)(r0 + i) * ld + k0;
-            double xv[TR_NB];
+        if (!(skip & 4) && wv * 64 < ((mb + 63) & ~63)) {
+            double lr[TR_NB];
 #pragma unroll
-            for (int j = 0; j < TR_NB; ++j) xv[j] = (j < nb) ? row[j] : 0.0;
+            for (int k = 0; k < TR_NB; ++k) lr[k] = sD[(lane & 15) * TR_PS + k];
+            const double rdl = sD[TR_NB * TR_PS + (lane & 15)];
+            for (int i0 = wv * 64; i0 < mb; i0 += TR_THREADS) {
+                const int i = i0 + lane;
+                const bool live = i < mb;
+                double* row = A + (size_t)(r0 + (live ? i : 0)) * ld + k0;
+                double xv[TR_NB];
 #pragma unroll
-            for (int j = 0; j < TR_NB; ++j) {
-                double s = xv[j];
+                for (int j = 0; j < TR_NB; ++j) xv[j] = (live && j < nb) ? row[j] : 0.0;
 #pragma unroll
-                for (int k = 0; k < j; ++k) s -= xv[k] * sD[j * TR_PS + k];
-                xv[j] = s * sD[TR_NB * TR_PS + j];
+                for (int j = 0; j < TR_NB; ++j) {          // column-oriented: 15-j independent FMAs per step
+                    xv[j] *= readlane_d(rdl, j);
+#pragma unroll
+                    for (int k = j + 1; k < TR_NB; ++k) xv[k] -= xv[j] * readlane_d(lr[j], k);
+                }
+                if (live) {
+#pragma unroll
+                    for (int j = 0; j < TR_NB; ++j) if (j < nb) row[j] = xv[j];
+                }
             }
-#pragma unroll
-            for (int j = 0; j < TR_NB; ++j) if (j < nb) row[j] = xv[j];
         }
         __syncthreads();
     }
@@ -397,7 +431,8 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_factor(const TrArgs a) {
     const int tid = threadIdx.x;
     const int n = a.n;
     double* Bp = reinterpret_cast<double*>(tr_lds);                       // 16 x bp_stride(n)
-    double* sD = Bp + TR_NB * bp_stride(n);                               // TR_NB x TR_PS
+    double* part = Bp + TR_NB * bp_stride(n);                             // 16 units x 256 partial accumulators
+    double* sD = part + 16 * 256;                                         // (TR_NB + 1) x TR_PS
     double* ylds = sD + (TR_NB + 1) * TR_PS;                              // n
     double* red = ylds + n + (n & 1);                                     // 32
     int* flag = reinterpret_cast<int*>(red + 32);
@@ -432,7 +467,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_factor(const TrArgs a) {
             for (int j = tid; j < n; j += TR_THREADS) a.L[(size_t)n * n + j] = scale[j] * g[j];
             __syncthreads();
         }
-        const bool ok = chol_left_looking(a.L, n, Bp, sD, flag);
+        const bool ok = chol_left_looking(a.L, n, Bp, part, sD, flag);
         double bad = 1;
         if (ok) {
             for (int j = tid; j < n; j += TR_THREADS) ylds[j] = a.L[(size_t)n * n + j];
@@ -547,6 +582,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_dogleg(const TrArgs a) {
 
 size_t glio_tr_step_lds_bytes(int n) {
     size_t d = (size_t)TR_NB * bp_stride(n);
+    d += 16 * 256;
     d += (TR_NB + 1) * TR_PS;
     d += n + (n & 1);
     d += 32 + 16;
@@ -571,13 +607,14 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
 }
 
 // ---- test hook: solve A x = b for a dense SPD n x n matrix with the in-kernel blocked Cholesky
-__global__ __launch_bounds__(TR_THREADS) void k_chol_test(double* L, int n, double* x, int* ok) {
+__global__ __launch_bounds__(TR_THREADS) void k_chol_test(double* L, int n, double* x, int* ok, int skip) {
     double* Bp = reinterpret_cast<double*>(tr_lds);
-    double* sD = Bp + TR_NB * bp_stride(n);
+    double* part = Bp + TR_NB * bp_stride(n);
+    double* sD = part + 16 * 256;
     double* ylds = sD + (TR_NB + 1) * TR_PS;
     int* flag = reinterpret_cast<int*>(ylds + n + (n & 1) + 32);
-    const bool good = chol_left_looking(L, n, Bp, sD, flag);
-    if (good) {
+    const bool good = chol_left_looking(L, n, Bp, part, sD, flag, skip);
+    if (good && !(skip & 8)) {
         for (int j = threadIdx.x; j < n; j += TR_THREADS) ylds[j] = L[(size_t)n * n + j];
         __syncthreads();
         back_substitute(L, n, ylds, sD);
@@ -592,7 +629,7 @@ extern "C" int glio_debug_chol_solve(glio_ctx* c, int n, const double* A, const 
     GLIO_HIP_CHECK(hipMemcpy(c->d_L, A, (size_t)n * n * 8, hipMemcpyHostToDevice));
     GLIO_HIP_CHECK(hipMemcpy(c->d_L + (size_t)n * n, b, (size_t)n * 8, hipMemcpyHostToDevice));
     int* d_ok = reinterpret_cast<int*>(c->d_vec + 9 * (size_t)c->n_max);
-    hipLaunchKernelGGL(k_chol_test, dim3(1), dim3(TR_THREADS), glio_tr_step_lds_bytes(n), c->stream, c->d_L, n, c->d_vec, d_ok);
+    hipLaunchKernelGGL(k_chol_test, dim3(1), dim3(TR_THREADS), glio_tr_step_lds_bytes(n), c->stream, c->d_L, n, c->d_vec, d_ok, 0);
     GLIO_HIP_CHECK(hipGetLastError());
     int ok = 0;
     GLIO_HIP_CHECK(hipMemcpyAsync(x, c->d_vec, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
@@ -609,5 +646,33 @@ void glio_tr_step_configure(size_t max_lds) {
 extern "C" int glio_debug_read_vec(glio_ctx* c, int k, double* out, int n) {
     if (!c || k < 0 || k > 9 || n > c->n_max) return GLIO_E_ARG;
     GLIO_HIP_CHECK(hipMemcpy(out, c->d_vec + (size_t)k * c->n_max, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return GLIO_OK;
+}
+
+// timing hook: `reps` factorisations of an n x n identity-like matrix with selected phases skipped
+// (skip bits: 1 = MFMA update, 2 = diagonal-block factor, 4 = row solves, 8 = back substitution)
+extern "C" int glio_debug_chol_time(glio_ctx* c, int n, int reps, int skip, float* ms_out) {
+    if (!c || n < 1 || n > c->n_max) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    std::vector<double> A((size_t)(n + 1) * n, 0.0);
+    for (int i = 0; i < n; ++i) { A[(size_t)i * n + i] = 4.0 + i % 3; for (int j = 0; j < i; ++j) A[(size_t)i * n + j] = 1e-3 * ((i * 7 + j * 3) % 11); }
+    for (int j = 0; j < n; ++j) A[(size_t)n * n + j] = 1.0;
+    double* d_src = nullptr;
+    GLIO_HIP_CHECK(hipMalloc((void**)&d_src, A.size() * 8));
+    GLIO_HIP_CHECK(hipMemcpy(d_src, A.data(), A.size() * 8, hipMemcpyHostToDevice));
+    int* d_ok = reinterpret_cast<int*>(c->d_vec + 9 * (size_t)c->n_max);
+    float total = 0;
+    for (int r = 0; r < reps + 1; ++r) {
+        GLIO_HIP_CHECK(hipMemcpyAsync(c->d_L, d_src, A.size() * 8, hipMemcpyDeviceToDevice, c->stream));
+        GLIO_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+        hipLaunchKernelGGL(k_chol_test, dim3(1), dim3(TR_THREADS), glio_tr_step_lds_bytes(n), c->stream, c->d_L, n, c->d_vec, d_ok, skip);
+        GLIO_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
+        GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+        float ms = 0;
+        GLIO_HIP_CHECK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        if (r > 0) total += ms;
+    }
+    hipFree(d_src);
+    *ms_out = total / reps;
     return GLIO_OK;
 }
