@@ -24,6 +24,22 @@
 
 #include "glio_device.h"
 
+// Bit-exact contract with the reference arithmetic: no fused multiply-add anywhere in this file (the
+// float distances of FLANN and the double transform / plane fit of the reference are separate IEEE
+// operations; a fused product changes the last bit and with it the ranking of exact-tie neighbours).
+#pragma clang fp contract(off)
+
+// q * v through Eigen's _transformVector, compiled here so that it obeys the pragma above
+__device__ __forceinline__ void a_qrot(const double q[4], const double v[3], double o[3]) {
+    double uv[3], uuv[3];
+    uv[0] = q[2] * v[2] - q[3] * v[1]; uv[1] = q[3] * v[0] - q[1] * v[2]; uv[2] = q[1] * v[1] - q[2] * v[0];
+    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+    uuv[0] = q[2] * uv[2] - q[3] * uv[1]; uuv[1] = q[3] * uv[0] - q[1] * uv[2]; uuv[2] = q[1] * uv[1] - q[2] * uv[0];
+    o[0] = v[0] + q[0] * uv[0] + uuv[0];
+    o[1] = v[1] + q[0] * uv[1] + uuv[1];
+    o[2] = v[2] + q[0] * uv[2] + uuv[2];
+}
+
 struct AssocWork {
     float cell;                   // cell edge
     float inv_cell;
@@ -38,6 +54,7 @@ struct AssocWork {
     // per-query dense results (capacity = cap of a slot)
     float4* d_q_pt; float4* d_q_plane; double* d_q_score; int* d_q_flag; int* d_q_pos;
     int* d_nn;                    // optional [cap][5] neighbour indices (tests)
+    int* d_bcount; int* d_boff;   // per-workgroup kept counts and their exclusive scan
     int* d_count_tmp;
     int* h_count;                 // pinned
     float3 origin;
@@ -78,9 +95,22 @@ __global__ void k_hash_insert(const float4* __restrict__ pts, int n, float inv_c
     pt_slot[i] = (int)s;
 }
 
+// range allocation: one atomic per wavefront (wave-wide exclusive scan of the cell counts)
 __global__ void k_cell_alloc(const int* __restrict__ cnt, int* start, int cap, int* total) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < cap && cnt[i] > 0) start[i] = atomicAdd(total, cnt[i]);
+    const int lane = threadIdx.x & 63;
+    const int c = i < cap ? cnt[i] : 0;
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    const int wave_total = __shfl(incl, 63, 64);
+    int base = 0;
+    if (lane == 0 && wave_total > 0) base = atomicAdd(total, wave_total);
+    base = __shfl(base, 0, 64);
+    if (i < cap && c > 0) start[i] = base + incl - c;
 }
 
 __global__ void k_scatter(const float4* __restrict__ pts, int n, const int* __restrict__ pt_slot, const int* __restrict__ start,
@@ -190,101 +220,171 @@ struct AssocArgs {
     int n, table_cap;
 };
 
+// 16 lanes per query (4 queries per wavefront, 16 per workgroup): the lanes of a group probe the 27 cells
+// in two rounds, stride through the candidate points of each cell together, keep private top-5 lists and
+// merge them with shuffles; lane 0 of the group fits the plane.  This turns ~30 dependent L2 round trips
+// per query into a handful and gives the launch 16x the lanes to hide them with.
+#define AQ_LANES 16
+#define AQ_PER_BLOCK (256 / AQ_LANES)
+
+__device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src) {
+    const int lo = __shfl((int)(v & 0xffffffffull), src, 64), hi = __shfl((int)(v >> 32), src, 64);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
+    const int lo = __shfl_xor((int)(v & 0xffffffffull), m, 64), hi = __shfl_xor((int)(v >> 32), m, 64);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+
 __global__ __launch_bounds__(256) void k_associate(const AssocArgs a, const float4* __restrict__ scan,
                                                    const float4* __restrict__ map, const unsigned long long* __restrict__ keys,
                                                    const int* __restrict__ cstart, const int* __restrict__ ccount,
                                                    float4* __restrict__ o_pt, float4* __restrict__ o_plane, double* __restrict__ o_score,
-                                                   int* __restrict__ o_flag, int* __restrict__ o_nn) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
-    const float4 pl = scan[i];
+                                                   int* __restrict__ o_flag, int* __restrict__ o_lpos, int* __restrict__ o_bcount,
+                                                   int* __restrict__ o_nn) {
+    const int lane = threadIdx.x & 63, j = threadIdx.x & (AQ_LANES - 1), g = threadIdx.x / AQ_LANES;
+    const int gbase = lane & ~(AQ_LANES - 1);                 // first lane of this group inside the wavefront
+    const int i = blockIdx.x * AQ_PER_BLOCK + g;
+    const bool qlive = i < a.n;
+    const float4 pl = scan[qlive ? i : 0];
     // transformPoint: double math, float store
     const double pin[3] = {(double)pl.x, (double)pl.y, (double)pl.z};
     double po[3];
-    d_qrot(a.q, pin, po);
+    a_qrot(a.q, pin, po);
     const float px = (float)(po[0] + a.t[0]), py = (float)(po[1] + a.t[1]), pz = (float)(po[2] + a.t[2]);
+    const int cx = cell_of(px, a.inv_cell), cy = cell_of(py, a.inv_cell), cz = cell_of(pz, a.inv_cell);
+    // ---- probe: lane j looks up cells j and j+16 of the 27-neighbourhood
+    int cs[2] = {0, 0}, cc[2] = {0, 0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int c = j + 16 * h;
+        if (c < 27 && qlive) {
+            const int dx = c % 3 - 1, dy = (c / 3) % 3 - 1, dz = c / 9 - 1;
+            const unsigned long long key = pack_key(cx + dx, cy + dy, cz + dz);
+            unsigned s = hash_key(key) & (a.table_cap - 1);
+            for (;;) {
+                const unsigned long long k = keys[s];
+                if (k == key) { cs[h] = cstart[s]; cc[h] = ccount[s]; break; }
+                if (k == KEY_EMPTY) break;
+                s = (s + 1) & (a.table_cap - 1);
+            }
+        }
+    }
+    // ---- candidates: private top-5 per lane, ranked by (float distance, original index)
     float bd[5] = {FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX};
     int bi[5] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
     int bp[5] = {-1, -1, -1, -1, -1};          // position in the sorted map
-    const int cx = cell_of(px, a.inv_cell), cy = cell_of(py, a.inv_cell), cz = cell_of(pz, a.inv_cell);
-    for (int dz = -1; dz <= 1; ++dz)
-        for (int dy = -1; dy <= 1; ++dy)
-            for (int dx = -1; dx <= 1; ++dx) {
-                const unsigned long long key = pack_key(cx + dx, cy + dy, cz + dz);
-                unsigned s = hash_key(key) & (a.table_cap - 1);
-                int found = -1;
-                for (;;) {
-                    const unsigned long long k = keys[s];
-                    if (k == key) { found = (int)s; break; }
-                    if (k == KEY_EMPTY) break;
-                    s = (s + 1) & (a.table_cap - 1);
-                }
-                if (found < 0) continue;
-                const int beg = cstart[found], end = beg + ccount[found];
-                for (int m = beg; m < end; ++m) {
-                    const float4 mp = map[m];
-                    const float ex = __fsub_rn(px, mp.x), ey = __fsub_rn(py, mp.y), ez = __fsub_rn(pz, mp.z);
-                    float d = __fmul_rn(ex, ex);
-                    d = __fadd_rn(d, __fmul_rn(ey, ey));
-                    d = __fadd_rn(d, __fmul_rn(ez, ez));
-                    const int idx = __float_as_int(mp.w);
-                    if (d < bd[4] || (d == bd[4] && idx < bi[4])) {
-                        // insertion into the sorted top-5 (static indexing only)
-                        bd[4] = d; bi[4] = idx; bp[4] = m;
+    for (int c = 0; c < 27; ++c) {
+        const int src = gbase + (c & 15);
+        const int beg = __shfl(c < 16 ? cs[0] : cs[1], src, 64);
+        const int cnt = __shfl(c < 16 ? cc[0] : cc[1], src, 64);
+        for (int m = beg + j; m < beg + cnt; m += AQ_LANES) {
+            const float4 mp = map[m];
+            // plain operators, NOT the __f*_rn intrinsics: those are header functions compiled with
+            // contraction allowed and fuse after inlining; here the file-scope pragma keeps them separate
+            const float ex = px - mp.x, ey = py - mp.y, ez = pz - mp.z;
+            float d = ex * ex;
+            d = d + ey * ey;
+            d = d + ez * ez;
+            const int idx = __float_as_int(mp.w);
+            if (d < bd[4] || (d == bd[4] && idx < bi[4])) {
+                bd[4] = d; bi[4] = idx; bp[4] = m;
 #pragma unroll
-                        for (int k = 4; k > 0; --k) {
-                            const bool sw = bd[k] < bd[k - 1] || (bd[k] == bd[k - 1] && bi[k] < bi[k - 1]);
-                            if (sw) {
-                                const float td = bd[k]; bd[k] = bd[k - 1]; bd[k - 1] = td;
-                                const int ti = bi[k]; bi[k] = bi[k - 1]; bi[k - 1] = ti;
-                                const int tp = bp[k]; bp[k] = bp[k - 1]; bp[k - 1] = tp;
-                            }
-                        }
+                for (int k = 4; k > 0; --k) {
+                    const bool sw = bd[k] < bd[k - 1] || (bd[k] == bd[k - 1] && bi[k] < bi[k - 1]);
+                    if (sw) {
+                        const float td = bd[k]; bd[k] = bd[k - 1]; bd[k - 1] = td;
+                        const int ti = bi[k]; bi[k] = bi[k - 1]; bi[k - 1] = ti;
+                        const int tp = bp[k]; bp[k] = bp[k - 1]; bp[k - 1] = tp;
                     }
                 }
             }
-    if (o_nn) {
-#pragma unroll
-        for (int k = 0; k < 5; ++k) o_nn[5 * (size_t)i + k] = (bp[k] >= 0 && bd[k] < a.kd_max_radius) ? bi[k] : -1;
-    }
-    int valid = 0;
-    float4 oplane = make_float4(0, 0, 0, 0);
-    double oscore = 0;
-    if (bp[4] >= 0 && bd[4] < a.kd_max_radius) {                    // Estimator.cpp:3651
-        double A[5][3], A0[5][3], b[5], nrm[3];
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const float4 mp = map[bp[k]];
-            A[k][0] = A0[k][0] = (double)mp.x; A[k][1] = A0[k][1] = (double)mp.y; A[k][2] = A0[k][2] = (double)mp.z;
-            b[k] = -1.0;
         }
-        plane_qr_solve(A, b, nrm);
-        const double nn = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
-        const double normInverse = 1.0 / nn;
-        nrm[0] /= nn; nrm[1] /= nn; nrm[2] /= nn;
-        bool ok = true;
+    }
+    // ---- merge the 16 private lists: five rounds of group-wide argmin on the key (distance bits, index)
+    float md[5]; int mi[5], mp5[5];
 #pragma unroll
-        for (int k = 0; k < 5; ++k)
-            if (fabs(nrm[0] * A0[k][0] + nrm[1] * A0[k][1] + nrm[2] * A0[k][2] + normInverse) > a.surf_dist_thres) ok = false;
-        if (ok) {
-            const float pd = (float)(nrm[0] * (double)px + nrm[1] * (double)py + nrm[2] * (double)pz + normInverse);
-            float r2 = __fmul_rn(px, px);
-            r2 = __fadd_rn(r2, __fmul_rn(py, py));
-            r2 = __fadd_rn(r2, __fmul_rn(pz, pz));
-            const float rr = __fsqrt_rn(__fsqrt_rn(r2));
-            const float weight = (float)(1.0 - 0.9 * (double)fabsf(pd) / (double)rr);
-            if (weight > a.weight_gate) {
-                valid = 1;
-                oplane.x = (float)((double)weight * nrm[0]);
-                oplane.y = (float)((double)weight * nrm[1]);
-                oplane.z = (float)((double)weight * nrm[2]);
-                oplane.w = (float)((double)weight * normInverse);
-                oscore = a.lidar_const * (double)weight;
+    for (int r = 0; r < 5; ++r) {
+        const unsigned long long mykey = ((unsigned long long)__float_as_uint(bd[0]) << 32) | (unsigned)bi[0];
+        unsigned long long kmin = mykey;
+#pragma unroll
+        for (int off = AQ_LANES / 2; off > 0; off >>= 1) {
+            const unsigned long long o = shfl_xor_u64(kmin, off);
+            kmin = o < kmin ? o : kmin;
+        }
+        const bool win = mykey == kmin && bp[0] >= 0;
+        int pos = win ? bp[0] : -1;
+#pragma unroll
+        for (int off = AQ_LANES / 2; off > 0; off >>= 1) pos = max(pos, __shfl_xor(pos, off, 64));
+        md[r] = __uint_as_float((unsigned)(kmin >> 32)); mi[r] = (int)(kmin & 0xffffffffull); mp5[r] = pos;
+        if (win) {                                   // pop the head of the winner's list
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { bd[k] = bd[k + 1]; bi[k] = bi[k + 1]; bp[k] = bp[k + 1]; }
+            bd[4] = FLT_MAX; bi[4] = 0x7fffffff; bp[4] = -1;
+        }
+    }
+    // ---- plane fit + gates by lane 0 of the group
+    int valid = 0;
+    if (j == 0 && qlive) {
+        if (o_nn) {
+#ifdef GLIO_ASSOC_DEBUG_P
+            o_nn[5 * (size_t)i + 0] = __float_as_int(px); o_nn[5 * (size_t)i + 1] = __float_as_int(py); o_nn[5 * (size_t)i + 2] = __float_as_int(pz);
+            o_nn[5 * (size_t)i + 3] = __float_as_int(md[3]); o_nn[5 * (size_t)i + 4] = __float_as_int(md[4]);
+#else
+#pragma unroll
+            for (int k = 0; k < 5; ++k) o_nn[5 * (size_t)i + k] = (mp5[k] >= 0 && md[k] < a.kd_max_radius) ? mi[k] : -1;
+#endif
+        }
+        float4 oplane = make_float4(0, 0, 0, 0);
+        double oscore = 0;
+        if (mp5[4] >= 0 && md[4] < a.kd_max_radius) {                    // Estimator.cpp:3651
+            double A[5][3], A0[5][3], b[5], nrm[3];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const float4 mp = map[mp5[k]];
+                A[k][0] = A0[k][0] = (double)mp.x; A[k][1] = A0[k][1] = (double)mp.y; A[k][2] = A0[k][2] = (double)mp.z;
+                b[k] = -1.0;
+            }
+            plane_qr_solve(A, b, nrm);
+            const double nn = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+            const double normInverse = 1.0 / nn;
+            nrm[0] /= nn; nrm[1] /= nn; nrm[2] /= nn;
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+                if (fabs(nrm[0] * A0[k][0] + nrm[1] * A0[k][1] + nrm[2] * A0[k][2] + normInverse) > a.surf_dist_thres) ok = false;
+            if (ok) {
+                const float pd = (float)(nrm[0] * (double)px + nrm[1] * (double)py + nrm[2] * (double)pz + normInverse);
+                float r2 = px * px;
+                r2 = r2 + py * py;
+                r2 = r2 + pz * pz;
+                const float rr = sqrtf(sqrtf(r2));
+                const float weight = (float)(1.0 - 0.9 * (double)fabsf(pd) / (double)rr);
+                if (weight > a.weight_gate) {
+                    valid = 1;
+                    oplane.x = (float)((double)weight * nrm[0]);
+                    oplane.y = (float)((double)weight * nrm[1]);
+                    oplane.z = (float)((double)weight * nrm[2]);
+                    oplane.w = (float)((double)weight * normInverse);
+                    oscore = a.lidar_const * (double)weight;
+                }
             }
         }
+        o_flag[i] = valid;
+        if (valid) { o_pt[i] = pl; o_plane[i] = oplane; o_score[i] = oscore; }
     }
-    o_flag[i] = valid;
-    if (valid) { o_pt[i] = pl; o_plane[i] = oplane; o_score[i] = oscore; }
+    // ---- order-preserving positions inside the workgroup + workgroup count
+    __shared__ int wcount[4];
+    const unsigned long long bal = __ballot(valid);
+    const int wv = threadIdx.x >> 6;
+    if (lane == 0) wcount[wv] = __popcll(bal);
+    __syncthreads();
+    if (j == 0 && qlive) {
+        int before = __popcll(bal & ((1ull << lane) - 1ull));
+        for (int w2 = 0; w2 < wv; ++w2) before += wcount[w2];
+        o_lpos[i] = before;
+    }
+    if (threadIdx.x == 0) o_bcount[blockIdx.x] = wcount[0] + wcount[1] + wcount[2] + wcount[3];
 }
 
 // order-preserving compaction: single-workgroup exclusive scan of the flags, then scatter
@@ -308,12 +408,12 @@ __global__ __launch_bounds__(1024) void k_scan_flags(const int* __restrict__ fla
     if (tid == 1023) *total = sums[1023];
 }
 
-__global__ void k_compact(const int* __restrict__ flag, const int* __restrict__ pos, int n, const float4* __restrict__ q_pt,
-                          const float4* __restrict__ q_plane, const double* __restrict__ q_score, float4* __restrict__ o_pt,
-                          float4* __restrict__ o_plane, double* __restrict__ o_score) {
+__global__ void k_compact(const int* __restrict__ flag, const int* __restrict__ lpos, const int* __restrict__ boff, int n,
+                          const float4* __restrict__ q_pt, const float4* __restrict__ q_plane, const double* __restrict__ q_score,
+                          float4* __restrict__ o_pt, float4* __restrict__ o_plane, double* __restrict__ o_score) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !flag[i]) return;
-    const int p = pos[i];
+    const int p = boff[i / AQ_PER_BLOCK] + lpos[i];
     o_pt[p] = q_pt[i]; o_plane[p] = q_plane[i]; o_score[p] = q_score[i];
 }
 
@@ -336,6 +436,7 @@ int glio_assoc_create(glio_ctx* c) {
     AALLOC(w->d_total, 4); AALLOC(w->d_count_tmp, 4);
     AALLOC(w->d_q_pt, (size_t)cap * 16); AALLOC(w->d_q_plane, (size_t)cap * 16); AALLOC(w->d_q_score, (size_t)cap * 8);
     AALLOC(w->d_q_flag, (size_t)cap * 4); AALLOC(w->d_q_pos, (size_t)cap * 4); AALLOC(w->d_nn, (size_t)cap * 5 * 4);
+    AALLOC(w->d_bcount, (size_t)(cap / AQ_PER_BLOCK + 2) * 4); AALLOC(w->d_boff, (size_t)(cap / AQ_PER_BLOCK + 2) * 4);
     if (hipHostMalloc((void**)&w->h_count, 16) != hipSuccess) return GLIO_E_HIP;
     c->assoc = w;
     c->map_n = 0;
@@ -346,7 +447,7 @@ void glio_assoc_destroy(glio_ctx* c) {
     AssocWork* w = c->assoc;
     if (!w) return;
     void* ptrs[] = {w->d_keys, w->d_cell_count, w->d_cell_start, w->d_cell_fill, w->d_pt_slot, w->d_map_raw, c->d_map_sorted, w->d_total,
-                    w->d_count_tmp, w->d_q_pt, w->d_q_plane, w->d_q_score, w->d_q_flag, w->d_q_pos, w->d_nn};
+                    w->d_count_tmp, w->d_q_pt, w->d_q_plane, w->d_q_score, w->d_q_flag, w->d_q_pos, w->d_nn, w->d_bcount, w->d_boff};
     for (void* p : ptrs) if (p) hipFree(p);
     hipHostFree(w->h_count);
     delete w;
@@ -383,14 +484,16 @@ static void enqueue_assoc(glio_ctx* c, int slot, const double q[4], const double
     a.surf_dist_thres = c->opts.surf_dist_thres; a.lidar_const = c->opts.lidar_const;
     a.n = n; a.table_cap = w->table_cap;
     const size_t off = (size_t)slot * c->cap;
+    const int nblk = (n + AQ_PER_BLOCK - 1) / AQ_PER_BLOCK;
     if (n > 0) {
-        hipLaunchKernelGGL(k_associate, dim3((n + 255) / 256), dim3(256), 0, c->stream, a, c->d_scan + off, c->d_map_sorted, w->d_keys,
-                           w->d_cell_start, w->d_cell_count, w->d_q_pt, w->d_q_plane, w->d_q_score, w->d_q_flag, want_nn ? w->d_nn : nullptr);
+        hipLaunchKernelGGL(k_associate, dim3(nblk), dim3(256), 0, c->stream, a, c->d_scan + off, c->d_map_sorted, w->d_keys,
+                           w->d_cell_start, w->d_cell_count, w->d_q_pt, w->d_q_plane, w->d_q_score, w->d_q_flag, w->d_q_pos, w->d_bcount,
+                           want_nn ? w->d_nn : nullptr);
     }
-    hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(1024), 0, c->stream, w->d_q_flag, n, w->d_q_pos, c->d_count + slot);
+    hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(1024), 0, c->stream, w->d_bcount, nblk, w->d_boff, c->d_count + slot);
     if (n > 0) {
-        hipLaunchKernelGGL(k_compact, dim3((n + 255) / 256), dim3(256), 0, c->stream, w->d_q_flag, w->d_q_pos, n, w->d_q_pt, w->d_q_plane,
-                           w->d_q_score, c->d_pts + off, c->d_planes + off, c->d_scores + off);
+        hipLaunchKernelGGL(k_compact, dim3((n + 255) / 256), dim3(256), 0, c->stream, w->d_q_flag, w->d_q_pos, w->d_boff, n, w->d_q_pt,
+                           w->d_q_plane, w->d_q_score, c->d_pts + off, c->d_planes + off, c->d_scores + off);
     }
 }
 
