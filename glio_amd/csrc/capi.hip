@@ -84,13 +84,16 @@ int glio_create(int device, const glio_opts* opts, glio_ctx** out) {
     const size_t wc = (size_t)W * c->cap;
     ALLOC(c->d_pts, wc * sizeof(float4)); ALLOC(c->d_planes, wc * sizeof(float4)); ALLOC(c->d_scores, wc * sizeof(double));
     ALLOC(c->d_count, W * sizeof(int)); ALLOC(c->d_scan, wc * sizeof(float4));
-    GLIO_HIP_CHECK(hipMemset(c->d_count, 0, W * sizeof(int)));
+    // NB: every memset goes on the context's (non-blocking) stream: a null-stream hipMemset is asynchronous
+    // and unordered with it, and once raced with the first glio_set_correspondences count upload.
+    GLIO_HIP_CHECK(hipMemsetAsync(c->d_count, 0, W * sizeof(int), c->stream));
     ALLOC(c->d_imu, W * sizeof(ImuEdgeDev)); ALLOC(c->d_imu_blocks, 2 * W * sizeof(PairBlock));
     ALLOC(c->d_gnss_blocks, 2 * (size_t)W * W * sizeof(PairBlock));
     ALLOC(c->d_groups, (size_t)W * W * sizeof(GnssGroup));
     const int ne = std::max(1, c->n_ddt_max);
     ALLOC(c->d_ddt_blocks, 2 * (size_t)ne * sizeof(DdtBlock));
-    GLIO_HIP_CHECK(hipMemset(c->d_ddt_blocks, 0, 2 * (size_t)ne * sizeof(DdtBlock)));
+    GLIO_HIP_CHECK(hipMemsetAsync(c->d_ddt_blocks, 0, 2 * (size_t)ne * sizeof(DdtBlock), c->stream));
+    GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
     const int npmax = 6 * W + 9;
     ALLOC(c->d_prior_J0, (size_t)npmax * npmax * 8); ALLOC(c->d_prior_A0, (size_t)npmax * npmax * 8);
     ALLOC(c->d_prior_r0, npmax * 8); ALLOC(c->d_prior_x0, (size_t)(2 * W + 1) * 9 * 8);
@@ -404,7 +407,8 @@ int glio_set_gnss(glio_ctx* c, const glio_gnss_frame* frame, int n_dd, const gli
     GnssDevExtra* ex = glio_extra(c);
     if (!runs.empty()) GLIO_HIP_CHECK(hipMemcpy(ex->d_runs, runs.data(), runs.size() * sizeof(DopRun), hipMemcpyHostToDevice));
     ex->n_runs = (int)runs.size();
-    GLIO_HIP_CHECK(hipMemset(c->d_ddt_blocks, 0, 2 * (size_t)std::max(1, c->n_ddt_max) * sizeof(DdtBlock)));
+    GLIO_HIP_CHECK(hipMemsetAsync(c->d_ddt_blocks, 0, 2 * (size_t)std::max(1, c->n_ddt_max) * sizeof(DdtBlock), c->stream));
+    GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
     c->n_dd = (int)sdd.size(); c->n_dop = (int)sdop.size(); c->n_groups = (int)groups.size();
     if (c->n_groups) c->have_factors = 1;
     return GLIO_OK;

@@ -1,0 +1,114 @@
+"""GPU parity of K1/K2 (voxel-hash exact 5-NN + plane fit + gates + compaction) against the oracle's
+brute-force restatement of findCorrespondingSurfFeatures.  Bit-exact: same neighbour sets (ties broken by
+map index), identical float plane records and double scores, identical order."""
+import numpy as np
+import pytest
+
+from glio_amd import ctypes_types as T
+from glio_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from glio_amd import capi
+    assert capi.device_count() >= 1
+    return capi
+
+
+@pytest.fixture(scope="module")
+def po():
+    from oracle import pyoracle
+    return pyoracle
+
+
+def _check_slot(hip, po, ctx, win, s, scan, q2, t2):
+    pts, pl, sc, src, nn = po.associate(win.opts, win.map_pts, scan, q2, t2, want_nn=True)
+    cnt = ctx.associate(s, scan, q2, t2)
+    hp, hpl, hsc = ctx.get_correspondences(s)
+    assert cnt == len(sc)
+    assert np.array_equal(hp, pts)
+    assert np.array_equal(hpl.view(np.uint32), pl.view(np.uint32))
+    assert np.array_equal(hsc, sc)
+    hnn = np.zeros((len(scan), 5), np.int32)
+    hip.load().glio_debug_last_nn(ctx._h, T.iptr(hnn), len(hnn))
+    gate = hnn[:, 4] >= 0
+    assert np.array_equal(hnn[gate], nn[gate])
+    return cnt
+
+
+def test_association_bit_exact_small(hip, po):
+    win = synth.make_window(W=3, pts_per_scan=4000, seed=synth.SEED_BASE + 5)
+    ctx = hip.Context(win.opts)
+    ctx.set_map(win.map_pts)
+    for s in range(win.W):
+        q2, t2 = po.lidar_pose_for_association(win.opts, win.init.quat[s], win.init.trans[s])
+        cnt = _check_slot(hip, po, ctx, win, s, win.scans[s], q2, t2)
+        assert cnt > 0.9 * len(win.scans[s])
+    ctx.close()
+
+
+def test_association_edge_cases(hip, po):
+    """Ragged / degenerate inputs: a single query, queries far outside the map (5th neighbour gate fails),
+    a map smaller than five points (nothing can be accepted), re-association with a new pose."""
+    win = synth.make_window(W=2, pts_per_scan=777, seed=synth.SEED_BASE + 6)
+    ctx = hip.Context(win.opts)
+    ctx.set_map(win.map_pts)
+    q2, t2 = po.lidar_pose_for_association(win.opts, win.init.quat[0], win.init.trans[0])
+    _check_slot(hip, po, ctx, win, 0, win.scans[0][:1].copy(), q2, t2)
+    far = win.scans[0].copy()
+    far[:, :3] += 500.0
+    assert _check_slot(hip, po, ctx, win, 0, far, q2, t2) == 0
+    _check_slot(hip, po, ctx, win, 1, win.scans[1], q2, t2 + np.array([0.3, -0.2, 0.05]))   # a different pose
+    tiny = win.map_pts[:4].copy()
+    ctx2 = hip.Context(win.opts)
+    ctx2.set_map(tiny)
+    assert ctx2.associate(0, win.scans[0], q2, t2) == 0
+    ctx.close(); ctx2.close()
+
+
+def test_association_full_scan_properties(hip, po):
+    """BASELINE config C3 shape: a 131k-point scan against the local map.  Checked against the oracle on
+    a 4k-query sample (the brute-force oracle is O(N M)) and through size-independent properties on the
+    full scan: order preservation, kept records are a subsequence of the scan, weights inside (0.3, 1]."""
+    win = synth.make_window(W=1, pts_per_scan=131072, seed=synth.SEED_BASE + 7)
+    ctx = hip.Context(win.opts)
+    ctx.set_map(win.map_pts)
+    q2, t2 = po.lidar_pose_for_association(win.opts, win.init.quat[0], win.init.trans[0])
+    scan = win.scans[0]
+    cnt = ctx.associate(0, scan, q2, t2)
+    hp, hpl, hsc = ctx.get_correspondences(0)
+    assert cnt == len(hsc) and cnt > 0.5 * len(scan)
+    w = hsc / win.opts.lidar_const
+    assert w.min() > win.opts.weight_gate and w.max() <= 1.0
+    # kept points appear in scan order: match them greedily
+    pos = 0
+    view = scan.view(np.uint32).reshape(len(scan), 4)
+    hv = hp.view(np.uint32).reshape(len(hp), 4)
+    keys = {tuple(r): i for i, r in enumerate(map(tuple, view))}
+    idx = np.array([keys[tuple(r)] for r in hv[:2000]])
+    assert np.all(np.diff(idx) > 0)
+    sample = np.ascontiguousarray(scan[1000:5000])
+    _check_slot(hip, po, ctx, win, 0, sample, q2, t2)
+    ctx.close()
+
+
+def test_solve_from_gpu_association_matches_oracle(hip, po):
+    """End-to-end hot path: K1/K2 on the GPU feed K3..K7; the oracle runs on its own brute-force
+    association of the same buffers."""
+    win = synth.make_window(W=4, pts_per_scan=3000, with_gnss=True, with_prior=True, seed=synth.SEED_BASE + 8)
+    ctx = hip.Context(win.opts)
+    ctx.set_map(win.map_pts)
+    corr = []
+    for s in range(win.W):
+        q2, t2 = po.lidar_pose_for_association(win.opts, win.init.quat[s], win.init.trans[s])
+        ctx.associate(s, win.scans[s], q2, t2)
+        pts, pl, sc, _ = po.associate(win.opts, win.map_pts, win.scans[s], q2, t2)
+        corr.append((pts, pl, sc))
+    ctx.load_window(win, None)
+    sh, summ_h = ctx.solve(win.init)
+    so, summ_o = po.Problem(win, corr).solve(win.init)
+    assert summ_h.iterations == summ_o.iterations
+    assert np.linalg.norm(sh.trans - so.trans, axis=1).max() < 1e-9
+    ctx.close()
