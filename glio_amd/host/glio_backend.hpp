@@ -1,0 +1,152 @@
+// glio_backend.hpp -- host-side C++ mirror of the reference interface for the sliding-window hot path.
+//
+// Plain C++14, no HIP / torch / Ceres / Eigen headers: this is what a GLIO maintainer compiles into
+// GLIO/src/Estimator.cpp and links against libglio_hip.so.  Two layers:
+//   (1) factor shims with the exact ceres::CostFunction::Evaluate() signature (reference
+//       GLIO/include/factors/LidarKeyframeFactor.h:73-122, ImuFactor.h:12-175) -- derive them from
+//       ceres::SizedCostFunction<...> when Ceres is present;
+//   (2) SlidingWindowBackend: the buffers optimizeSlidingWindowWithLandMark() works on (tmpTrans/tmpQuat/
+//       tmpSpeedBias, Ps/Rs/Vs/Bas/Bgs, Estimator.cpp:345-348) and its call sequence (:2046-2736).
+#pragma once
+
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/glio_hip.h"
+
+namespace glio {
+
+struct Error : std::runtime_error {
+    explicit Error(const std::string& what) : std::runtime_error(what + ": " + glio_last_error()) {}
+};
+inline void check(int rc, const char* what) { if (rc != GLIO_OK) throw Error(what); }
+
+// ---- (1) factor shims ------------------------------------------------------------------------------
+// LidarPlaneNormFactor: residual 1, blocks {t[3], q[4]} (LidarKeyframeFactor.h:112-114)
+class LidarPlaneNormFactorHip {
+public:
+    LidarPlaneNormFactorHip(glio_ctx* ctx, const float cp[4], const float plane[4], double score) : ctx_(ctx), score_(score) {
+        for (int k = 0; k < 4; ++k) { cp_[k] = cp[k]; plane_[k] = plane[k]; }
+    }
+    bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const {
+        return glio_eval_lidar_plane(ctx_, cp_, plane_, score_, parameters, residuals, jacobians) == GLIO_OK;
+    }
+private:
+    glio_ctx* ctx_; float cp_[4], plane_[4]; double score_;
+};
+// ImuFactor: residual 15, blocks {Pi3,Qi4,SBi9,Pj3,Qj4,SBj9} (ImuFactor.h:12)
+class ImuFactorHip {
+public:
+    ImuFactorHip(glio_ctx* ctx, const glio_preint& pre) : ctx_(ctx), pre_(pre) {}
+    bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const {
+        return glio_eval_imu(ctx_, &pre_, parameters, residuals, jacobians) == GLIO_OK;
+    }
+private:
+    glio_ctx* ctx_; glio_preint pre_;
+};
+
+// ---- (2) the window ----------------------------------------------------------------------------------
+class SlidingWindowBackend {
+public:
+    explicit SlidingWindowBackend(const glio_opts& opts, int device = 0) : opts_(opts), W_(opts.window) {
+        check(glio_create(device, &opts_, &ctx_), "glio_create");
+        tmpTrans.assign(3 * W_, 0.0); tmpQuat.assign(4 * W_, 0.0); tmpSpeedBias.assign(9 * W_, 0.0);
+        for (int i = 0; i < W_; ++i) tmpQuat[4 * i] = 1.0;
+    }
+    ~SlidingWindowBackend() { glio_destroy(ctx_); }
+    SlidingWindowBackend(const SlidingWindowBackend&) = delete;
+    SlidingWindowBackend& operator=(const SlidingWindowBackend&) = delete;
+
+    glio_ctx* ctx() const { return ctx_; }
+    int window() const { return W_; }
+
+    // Estimator.cpp:2056  kd_tree_surf_local_map->setInputCloud(surf_local_map_ds)
+    void setLocalMap(const float* xyzi, int n) { check(glio_set_map(ctx_, xyzi, n), "glio_set_map"); }
+    // Estimator.cpp:2216-2222  Q2 = Q*q_lb^-1, T2 = T - Q2*t_lb, findCorrespondingSurfFeatures(idx-1, Q2, T2)
+    int findCorrespondingSurfFeatures(int slot, const float* scan_xyzi, int n) {
+        double q2[4], t2[3];
+        lidarPose(slot, q2, t2);
+        int cnt = 0;
+        check(glio_associate(ctx_, slot, scan_xyzi, n, q2, t2, &cnt), "glio_associate");
+        return cnt;
+    }
+    // Estimator.cpp:2182-2192 / 2153-2158 / 2329-2359
+    void setImuFactors(const std::vector<glio_preint>& pre) {
+        std::vector<int32_t> slots(pre.size());
+        for (size_t k = 0; k < pre.size(); ++k) slots[k] = (int32_t)k;
+        check(glio_set_imu(ctx_, (int)pre.size(), pre.data(), slots.data()), "glio_set_imu");
+    }
+    void setMarginalizationPrior(const glio_prior* prior) { check(glio_set_prior(ctx_, prior), "glio_set_prior"); }
+    void setGnss(const glio_gnss_frame* frame, const std::vector<glio_dd_psr>& dd, const std::vector<glio_doppler>& dop) {
+        check(glio_set_gnss(ctx_, frame, (int)dd.size(), dd.data(), (int)dop.size(), dop.data()), "glio_set_gnss");
+    }
+
+    // Estimator.cpp:2424-2433 ceres::Solve + :2439-2457 quaternion sign unification
+    glio_summary solve(std::vector<double>* rcv_ddt = nullptr) {
+        glio_state st;
+        st.trans = tmpTrans.data(); st.quat = tmpQuat.data(); st.speed_bias = tmpSpeedBias.data();
+        st.rcv_ddt = rcv_ddt && !rcv_ddt->empty() ? rcv_ddt->data() : nullptr;
+        st.n_ddt = rcv_ddt ? (int)rcv_ddt->size() : 0;
+        glio_summary sum;
+        check(glio_solve(ctx_, &st, &sum), "glio_solve");
+        for (int i = 0; i < W_; ++i)
+            if (tmpQuat[4 * i] < 0) for (int k = 0; k < 4; ++k) tmpQuat[4 * i + k] = -tmpQuat[4 * i + k];   // unifyQuaternion
+        return sum;
+    }
+
+    // Estimator.cpp:2611-2726 write-back with the reference's sanity gates.  Ps/Vs: [W][3]; Qs: [W][4] (w,x,y,z,
+    // the reference keeps Rs as matrices); para_speed_bias: [W][9].  Components failing their gate keep the old
+    // value (Q14).  The six bias gates are chained by dangling `else`s in the reference (the ROS_WARNs between
+    // them are commented out, :2689-2722), so only the FIRST bias component that passes is written (Q16).
+    void writeBack(double* Ps, double* Qs, double* Vs, double* para_speed_bias) const {
+        for (int i = 0; i < W_; ++i) {
+            const double* t = &tmpTrans[3 * i]; const double* q = &tmpQuat[4 * i]; const double* sb = &tmpSpeedBias[9 * i];
+            double dp = 0, dv = 0;
+            for (int k = 0; k < 3; ++k) { dp += (Ps[3 * i + k] - t[k]) * (Ps[3 * i + k] - t[k]); dv += (Vs[3 * i + k] - sb[k]) * (Vs[3 * i + k] - sb[k]); }
+            // dq = normalized(tmpQuat)^-1 * Rs ; qnorm = |dq.vec|
+            double qn = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+            const double a[4] = {q[0] / qn, -q[1] / qn, -q[2] / qn, -q[3] / qn};
+            const double* b = &Qs[4 * i];
+            const double vx = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+            const double vy = a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3];
+            const double vz = a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1];
+            const double qnorm = std::sqrt(vx * vx + vy * vy + vz * vz);
+            if (std::sqrt(dp) < 100) for (int k = 0; k < 3; ++k) Ps[3 * i + k] = t[k];
+            if (qnorm < 10) for (int k = 0; k < 4; ++k) Qs[4 * i + k] = q[k] / qn;
+            if (std::sqrt(dv) < 100) for (int k = 0; k < 3; ++k) { Vs[3 * i + k] = sb[k]; para_speed_bias[9 * i + k] = sb[k]; }
+            for (int k = 3; k < 9; ++k)
+                if (std::fabs(para_speed_bias[9 * i + k] - sb[k]) < 22) { para_speed_bias[9 * i + k] = sb[k]; break; }   // Q16
+        }
+    }
+
+    // state, laid out like the reference's double arrays
+    std::vector<double> tmpTrans, tmpQuat, tmpSpeedBias;
+
+private:
+    void lidarPose(int slot, double q2[4], double t2[3]) const {
+        const double* q = &tmpQuat[4 * slot]; const double* t = &tmpTrans[3 * slot];
+        const double* l = opts_.q_lb;
+        const double n2 = l[0] * l[0] + l[1] * l[1] + l[2] * l[2] + l[3] * l[3];
+        const double li[4] = {l[0] / n2, -l[1] / n2, -l[2] / n2, -l[3] / n2};
+        q2[0] = q[0] * li[0] - q[1] * li[1] - q[2] * li[2] - q[3] * li[3];
+        q2[1] = q[0] * li[1] + q[1] * li[0] + q[2] * li[3] - q[3] * li[2];
+        q2[2] = q[0] * li[2] + q[2] * li[0] + q[3] * li[1] - q[1] * li[3];
+        q2[3] = q[0] * li[3] + q[3] * li[0] + q[1] * li[2] - q[2] * li[1];
+        // T2 = T - Q2 * t_lb  (Eigen q*v)
+        const double* v = opts_.t_lb;
+        double uv[3] = {q2[2] * v[2] - q2[3] * v[1], q2[3] * v[0] - q2[1] * v[2], q2[1] * v[1] - q2[2] * v[0]};
+        for (double& x : uv) x += x;
+        const double uuv[3] = {q2[2] * uv[2] - q2[3] * uv[1], q2[3] * uv[0] - q2[1] * uv[2], q2[1] * uv[1] - q2[2] * uv[0]};
+        for (int k = 0; k < 3; ++k) t2[k] = t[k] - (v[k] + q2[0] * uv[k] + uuv[k]);
+    }
+    glio_opts opts_;
+    int W_;
+    glio_ctx* ctx_ = nullptr;
+};
+
+}  // namespace glio

@@ -1,0 +1,51 @@
+// host_demo.cpp -- the C++ call sequence of optimizeSlidingWindowWithLandMark() on the HIP backend, fed from
+// a flat binary window file written by tests (glio_amd/host/window_io.py).  Prints the solved state as text.
+// Build: g++ -std=c++14 -O2 host_demo.cpp -I../../include -L../lib -lglio_hip -Wl,-rpath,'$ORIGIN/../lib'
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "glio_backend.hpp"
+
+template <typename T> static void rd(FILE* f, T* p, size_t n) { if (fread(p, sizeof(T), n, f) != n) { fprintf(stderr, "short read\n"); exit(2); } }
+
+int main(int argc, char** argv) {
+    if (argc < 2) { fprintf(stderr, "usage: host_demo window.bin\n"); return 2; }
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) { perror("open"); return 2; }
+    glio_opts opts;
+    rd(f, &opts, 1);
+    int32_t hdr[4];   // n_map, n_imu, has_prior(0), reserved
+    rd(f, hdr, 4);
+    const int W = opts.window;
+    try {
+        glio::SlidingWindowBackend be(opts);
+        std::vector<float> map((size_t)hdr[0] * 4);
+        rd(f, map.data(), map.size());
+        be.setLocalMap(map.data(), hdr[0]);
+        rd(f, be.tmpTrans.data(), 3 * W); rd(f, be.tmpQuat.data(), 4 * W); rd(f, be.tmpSpeedBias.data(), 9 * W);
+        std::vector<glio_preint> pre(hdr[1]);
+        if (hdr[1]) rd(f, pre.data(), pre.size());
+        be.setImuFactors(pre);
+        long kept = 0;
+        for (int s = 0; s < W; ++s) {
+            int32_t n;
+            rd(f, &n, 1);
+            std::vector<float> scan((size_t)n * 4);
+            rd(f, scan.data(), scan.size());
+            kept += be.findCorrespondingSurfFeatures(s, scan.data(), n);
+        }
+        fclose(f);
+        std::vector<double> Ps = be.tmpTrans, Qs = be.tmpQuat, Vs(3 * W), psb = be.tmpSpeedBias;
+        for (int i = 0; i < W; ++i) for (int k = 0; k < 3; ++k) Vs[3 * i + k] = be.tmpSpeedBias[9 * i + k];
+        const glio_summary sum = be.solve();
+        be.writeBack(Ps.data(), Qs.data(), Vs.data(), psb.data());
+        printf("kept %ld iterations %d termination %d cost %.17g -> %.17g\n", kept, sum.iterations, sum.termination, sum.initial_cost, sum.final_cost);
+        for (int i = 0; i < W; ++i)
+            printf("kf %d %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", i, Ps[3 * i], Ps[3 * i + 1], Ps[3 * i + 2], Qs[4 * i], Qs[4 * i + 1], Qs[4 * i + 2], Qs[4 * i + 3]);
+    } catch (const std::exception& e) {
+        fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

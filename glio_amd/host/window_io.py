@@ -1,0 +1,45 @@
+"""Flat binary window file for glio_amd/host/host_demo (the C++ call sequence of the hot path)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from .. import ctypes_types as T
+from .. import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEMO = os.path.join(HERE, "host_demo")
+
+
+def build_demo(force=False):
+    src = [os.path.join(HERE, "host_demo.cpp"), os.path.join(HERE, "glio_backend.hpp")]
+    if force or not os.path.exists(DEMO) or any(os.path.getmtime(s) > os.path.getmtime(DEMO) for s in src):
+        subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", src[0], "-I" + os.path.join(HERE, "..", "..", "include"),
+                               "-L" + os.path.join(HERE, "..", "lib"), "-lglio_hip", "-Wl,-rpath,$ORIGIN/../lib", "-o", DEMO])
+    return DEMO
+
+
+def write_window(path, win):
+    """opts | n_map n_imu 0 0 | map | trans quat speed_bias | preints | per slot: n, scan"""
+    with open(path, "wb") as f:
+        f.write(bytes(win.opts))
+        f.write(np.array([len(win.map_pts), len(win.preints), 0, 0], np.int32).tobytes())
+        f.write(np.ascontiguousarray(win.map_pts, np.float32).tobytes())
+        f.write(win.init.trans.tobytes()); f.write(win.init.quat.tobytes()); f.write(win.init.speed_bias.tobytes())
+        arr = T.preint_array(len(win.preints))
+        for k, p in enumerate(win.preints):
+            synth.fill_preint(arr[k], p)
+        if win.preints:
+            f.write(bytes(arr)[:C.sizeof(T.GlioPreint) * len(win.preints)])
+        for s in range(win.W):
+            f.write(np.array([len(win.scans[s])], np.int32).tobytes())
+            f.write(np.ascontiguousarray(win.scans[s], np.float32).tobytes())
+
+
+def run_demo(path):
+    out = subprocess.run([build_demo(), path], capture_output=True, text=True, check=True).stdout.splitlines()
+    head = out[0].split()
+    info = dict(kept=int(head[1]), iterations=int(head[3]), termination=int(head[5]), initial_cost=float(head[7]), final_cost=float(head[9]))
+    rows = np.array([[float(x) for x in ln.split()[2:]] for ln in out[1:]])
+    return info, rows[:, :3], rows[:, 3:]
