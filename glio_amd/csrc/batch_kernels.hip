@@ -1,0 +1,497 @@
+// batch_kernels.hip -- K8: the scan-to-multiscan constraints of the batch stage
+// (Estimator::optimizeBatchWithLandMark, reference GLIO/src/Estimator.cpp:3004-3076) on gfx950, plus the
+// block-banded normal-equation assembly and a damped banded solve.
+//
+// Factor (BinaryLidarPlaneNormFactor::operator(), GLIO/include/factors/LidarKeyframeFactor.h:132-150, no
+// extrinsic -- quirk Q10 -- and no loss function, Estimator.cpp:2768):
+//   p_w = R1 p + t1 ; n_w = R2 n_l ; c_w = R2 c_l + t2 ; r = s n_w . (p_w - c_w)
+// Local Jacobians under Ceres' left (+) on both quaternions (fused form of autodiff + QuaternionParameterization):
+//   d r/d t1 = s n_w =: u      d r/d th1 = 2 s (R1 p) x n_w =: v
+//   d r/d t2 = -u              d r/d th2 = 2 s n_w x (p_w - t2) =: w
+// so one residual is described by the 9-vector j = [u v w]; all 12x12 blocks follow from the 9x9 Gram matrix.
+//
+// k_batch_pairs : ONE WAVEFRONT PER KEYFRAME PAIR (constraints are stored pair-major), 72 B streamed per
+//                 residual (float4 point, 6 f64 plane normal + centroid, f64 score), 55 fp64 accumulators per
+//                 lane (45 Gram + 9 J^T r + cost), reduced with a 63-shuffle value-splitting butterfly ->
+//                 one 55-double record per pair.  HBM-bound streaming reduction, no atomics.
+// k_batch_assemble : gathers the pair records into the block-banded H (upper band), g and the cost.
+// The per-rank Hg buffers are summed by the caller with ONE RCCL all-reduce (torch.distributed on the same
+// device buffer); k_batch_factor / k_batch_backsolve then run the replicated block-banded Cholesky.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "glio_device.h"
+
+#define BP_REC 56          // doubles per pair record (55 used)
+#define BP_GRAM 45
+
+struct glio_batch {
+    int device;
+    hipStream_t own_stream, stream;
+    int K, band;
+    int64_t max_con, n_con;
+    float4* d_cp; double* d_nc; double* d_score;      // owned buffers (host upload path)
+    const float4* cp; const double* nc; const double* score;   // active (owned or borrowed device pointers)
+    int n_pairs, max_pairs;
+    int* d_pair_i; int* d_pair_j; long long* d_pair_off;
+    double* d_pair_rec;        // [max_pairs][BP_REC]
+    int* d_pair_index;         // [K][2*band+1]
+    double* d_poses;           // [K][7]
+    double* d_M;               // [K][band+1][36] factor workspace (lower blocks (k+d, k))
+    double* d_y;               // [K][6]
+    double* d_delta;           // [K][6]
+    double* d_newposes;        // [K][7]
+    double* d_scalar;          // [4]
+    double* h_poses; double* h_scalar;    // pinned
+    hipEvent_t ev0, ev1;
+};
+
+__device__ __forceinline__ int gram_idx(int i, int j) {       // packed upper triangle of a symmetric 9x9
+    const int a = i < j ? i : j, b = i < j ? j : i;
+    return a * 9 - (a * (a - 1)) / 2 + (b - a);
+}
+
+// value-splitting butterfly over 64 values: lane L ends with the wave-wide sum of value
+// k = b5 + 2 b4 + 4 b3 + 8 b2 + 16 b1 + 32 b0 (b_i = bit i of L); 63 shuffles
+__device__ __forceinline__ double butterfly64(const double (&in)[64], int lane, int* k_out) {
+    double v32[32], v16[16], v8[8], v4[4], v2[2];
+    { const bool hi = (lane & 32) != 0;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) { const double keep = hi ? in[2 * i + 1] : in[2 * i], send = hi ? in[2 * i] : in[2 * i + 1]; v32[i] = keep + __shfl_xor(send, 32, 64); } }
+    { const bool hi = (lane & 16) != 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const double keep = hi ? v32[2 * i + 1] : v32[2 * i], send = hi ? v32[2 * i] : v32[2 * i + 1]; v16[i] = keep + __shfl_xor(send, 16, 64); } }
+    { const bool hi = (lane & 8) != 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const double keep = hi ? v16[2 * i + 1] : v16[2 * i], send = hi ? v16[2 * i] : v16[2 * i + 1]; v8[i] = keep + __shfl_xor(send, 8, 64); } }
+    { const bool hi = (lane & 4) != 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const double keep = hi ? v8[2 * i + 1] : v8[2 * i], send = hi ? v8[2 * i] : v8[2 * i + 1]; v4[i] = keep + __shfl_xor(send, 4, 64); } }
+    { const bool hi = (lane & 2) != 0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { const double keep = hi ? v4[2 * i + 1] : v4[2 * i], send = hi ? v4[2 * i] : v4[2 * i + 1]; v2[i] = keep + __shfl_xor(send, 2, 64); } }
+    const bool hi = (lane & 1) != 0;
+    const double keep = hi ? v2[1] : v2[0], send = hi ? v2[0] : v2[1];
+    *k_out = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 3) | (((lane >> 1) & 1) << 4) | ((lane & 1) << 5);
+    return keep + __shfl_xor(send, 1, 64);
+}
+
+__global__ __launch_bounds__(256) void k_batch_pairs(const float4* __restrict__ cp, const double* __restrict__ nc,
+                                                     const double* __restrict__ score, const int* __restrict__ pair_i,
+                                                     const int* __restrict__ pair_j, const long long* __restrict__ pair_off,
+                                                     const int n_pairs, const double* __restrict__ poses, double* __restrict__ rec) {
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= n_pairs) return;
+    const int a = pair_i[p], b = pair_j[p];
+    double R1[9], R2[9], t1[3], t2[3];
+    d_q2R(poses + 7 * (size_t)a + 3, R1);
+    d_q2R(poses + 7 * (size_t)b + 3, R2);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { t1[k] = poses[7 * (size_t)a + k]; t2[k] = poses[7 * (size_t)b + k]; }
+    double acc[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) acc[k] = 0.0;
+    const long long beg = pair_off[p], end = pair_off[p + 1];
+    for (long long i = beg + lane; i < end; i += 64) {
+        const float4 pt = cp[i];
+        const double2* ncp = reinterpret_cast<const double2*>(nc + 6 * i);
+        const double2 n01 = ncp[0], n2c0 = ncp[1], c12 = ncp[2];
+        const double s = score[i];
+        const double px = pt.x, py = pt.y, pz = pt.z;
+        const double rp[3] = {R1[0] * px + R1[1] * py + R1[2] * pz, R1[3] * px + R1[4] * py + R1[5] * pz, R1[6] * px + R1[7] * py + R1[8] * pz};
+        const double nl[3] = {n01.x, n01.y, n2c0.x}, cl[3] = {n2c0.y, c12.x, c12.y};
+        const double nw[3] = {R2[0] * nl[0] + R2[1] * nl[1] + R2[2] * nl[2], R2[3] * nl[0] + R2[4] * nl[1] + R2[5] * nl[2], R2[6] * nl[0] + R2[7] * nl[1] + R2[8] * nl[2]};
+        const double rc[3] = {R2[0] * cl[0] + R2[1] * cl[1] + R2[2] * cl[2], R2[3] * cl[0] + R2[4] * cl[1] + R2[5] * cl[2], R2[6] * cl[0] + R2[7] * cl[1] + R2[8] * cl[2]};
+        const double pw[3] = {rp[0] + t1[0], rp[1] + t1[1], rp[2] + t1[2]};
+        const double av[3] = {pw[0] - rc[0] - t2[0], pw[1] - rc[1] - t2[1], pw[2] - rc[2] - t2[2]};
+        const double r = s * (nw[0] * av[0] + nw[1] * av[1] + nw[2] * av[2]);
+        const double q[3] = {pw[0] - t2[0], pw[1] - t2[1], pw[2] - t2[2]};
+        const double s2 = 2.0 * s;
+        double j[9];
+        j[0] = s * nw[0]; j[1] = s * nw[1]; j[2] = s * nw[2];
+        j[3] = s2 * (rp[1] * nw[2] - rp[2] * nw[1]); j[4] = s2 * (rp[2] * nw[0] - rp[0] * nw[2]); j[5] = s2 * (rp[0] * nw[1] - rp[1] * nw[0]);
+        j[6] = s2 * (nw[1] * q[2] - nw[2] * q[1]); j[7] = s2 * (nw[2] * q[0] - nw[0] * q[2]); j[8] = s2 * (nw[0] * q[1] - nw[1] * q[0]);
+        int k = 0;
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+#pragma unroll
+            for (int v = u; v < 9; ++v) acc[k++] += j[u] * j[v];
+            acc[BP_GRAM + u] += j[u] * r;
+        }
+        acc[54] += 0.5 * r * r;
+    }
+    int k;
+    const double tot = butterfly64(acc, lane, &k);
+    if (k < 55) rec[(size_t)p * BP_REC + k] = tot;
+}
+
+// block-banded assembly: thread per entry of Hg = [H band K*(band+1)*36 | g K*6 | cost]
+__global__ void k_batch_assemble(const double* __restrict__ rec, const int* __restrict__ pair_index, const int K, const int band,
+                                 const int n_pairs, double* __restrict__ Hg) {
+    const long long nH = (long long)K * (band + 1) * 36, nG = (long long)K * 6;
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int A[6] = {0, 1, 2, 3, 4, 5}, B[6] = {0, 1, 2, 6, 7, 8};
+    const double sB[6] = {-1, -1, -1, 1, 1, 1};
+    const int wdt = 2 * band + 1;
+    if (e < nH) {
+        const int k = (int)(e / ((band + 1) * 36)), rem = (int)(e % ((band + 1) * 36)), d = rem / 36, r = (rem % 36) / 6, c = rem % 6;
+        double s = 0;
+        if (d == 0) {
+            for (int o = -band; o <= band; ++o) {
+                if (o == 0 || k + o < 0 || k + o >= K) continue;
+                const int pa = pair_index[(size_t)k * wdt + o + band];            // a = k, b = k+o : Ja^T Ja
+                if (pa >= 0) s += rec[(size_t)pa * BP_REC + gram_idx(A[r], A[c])];
+                const int pb = pair_index[(size_t)(k + o) * wdt + (-o) + band];   // a = k+o, b = k : Jb^T Jb
+                if (pb >= 0) s += sB[r] * sB[c] * rec[(size_t)pb * BP_REC + gram_idx(B[r], B[c])];
+            }
+        } else if (k + d < K) {
+            const int pa = pair_index[(size_t)k * wdt + d + band];                // a = k, b = k+d : H(k,k+d) = Ja^T Jb
+            if (pa >= 0) s += sB[c] * rec[(size_t)pa * BP_REC + gram_idx(A[r], B[c])];
+            const int pb = pair_index[(size_t)(k + d) * wdt + (-d) + band];       // a = k+d, b = k : H(k,k+d) = Jb^T Ja
+            if (pb >= 0) s += sB[r] * rec[(size_t)pb * BP_REC + gram_idx(B[r], A[c])];
+        }
+        Hg[e] = s;
+    } else if (e < nH + nG) {
+        const int k = (int)((e - nH) / 6), r = (int)((e - nH) % 6);
+        double s = 0;
+        for (int o = -band; o <= band; ++o) {
+            if (o == 0 || k + o < 0 || k + o >= K) continue;
+            const int pa = pair_index[(size_t)k * wdt + o + band];
+            if (pa >= 0) s += rec[(size_t)pa * BP_REC + BP_GRAM + A[r]];
+            const int pb = pair_index[(size_t)(k + o) * wdt + (-o) + band];
+            if (pb >= 0) s += sB[r] * rec[(size_t)pb * BP_REC + BP_GRAM + B[r]];
+        }
+        Hg[e] = s;
+    }
+}
+__global__ __launch_bounds__(256) void k_batch_cost(const double* __restrict__ rec, int n_pairs, double* out) {
+    __shared__ double red[4];
+    double s = 0;
+    for (int p = threadIdx.x; p < n_pairs; p += 256) s += rec[(size_t)p * BP_REC + 54];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = red[0] + red[1] + red[2] + red[3];
+}
+
+// ------------------------------------------------------------------------------------------------
+// damped block-banded Cholesky (one workgroup), rhs carried; M[k][d] = block (k+d, k), row-major 6x6
+// ------------------------------------------------------------------------------------------------
+#define BB_MAX_BAND 16
+__global__ __launch_bounds__(256) void k_batch_factor(const double* __restrict__ Hg, const int K, const int band, const double lambda,
+                                                      double* M, double* y, int* fail) {
+    __shared__ double Lkk[36], Linv[36], T[BB_MAX_BAND * 36], yk[6];
+    const int tid = threadIdx.x, bw = band + 1;
+    const long long nH = (long long)K * bw * 36;
+    // init: M(k,0) = H(k,k) + lambda diag ; M(k,d) = H(k,k+d)^T ; y = g
+    for (long long e = tid; e < nH; e += 256) {
+        const int k = (int)(e / (bw * 36)), rem = (int)(e % (bw * 36)), d = rem / 36, r = (rem % 36) / 6, c = rem % 6;
+        double v;
+        if (d == 0) { v = Hg[e]; if (r == c) v += lambda * v + 1e-12; }
+        else v = Hg[(size_t)k * bw * 36 + d * 36 + c * 6 + r];
+        M[e] = v;
+    }
+    for (int e = tid; e < K * 6; e += 256) y[e] = Hg[nH + e];
+    if (tid == 0) *fail = 0;
+    __syncthreads();
+    for (int k = 0; k < K; ++k) {
+        double* Mk = M + (size_t)k * bw * 36;
+        // (1) 6x6 Cholesky + inverse of the diagonal block, y_k <- Lkk^-1 y_k (one lane, ~400 flops)
+        if (tid == 0) {
+            double L[36];
+            for (int i = 0; i < 36; ++i) L[i] = Mk[i];
+            bool bad = false;
+            for (int j = 0; j < 6; ++j) {
+                double d = L[j * 6 + j];
+                for (int q = 0; q < j; ++q) d -= L[j * 6 + q] * L[j * 6 + q];
+                if (!(d > 0.0)) { bad = true; d = 1.0; }
+                d = sqrt(d);
+                L[j * 6 + j] = d;
+                for (int i = j + 1; i < 6; ++i) {
+                    double sacc = L[i * 6 + j];
+                    for (int q = 0; q < j; ++q) sacc -= L[i * 6 + q] * L[j * 6 + q];
+                    L[i * 6 + j] = sacc / d;
+                }
+                for (int i = 0; i < j; ++i) L[i * 6 + j] = 0.0;
+            }
+            double X[36];
+            for (int c = 0; c < 6; ++c)
+                for (int i = 0; i < 6; ++i) {
+                    double sacc = (i == c) ? 1.0 : 0.0;
+                    for (int q = 0; q < i; ++q) sacc -= L[i * 6 + q] * X[q * 6 + c];
+                    X[i * 6 + c] = sacc / L[i * 6 + i];
+                }
+            for (int i = 0; i < 36; ++i) { Lkk[i] = L[i]; Linv[i] = X[i]; Mk[i] = L[i]; }
+            for (int i = 0; i < 6; ++i) {
+                double sacc = 0;
+                for (int q = 0; q <= i; ++q) sacc += X[i * 6 + q] * y[(size_t)k * 6 + q];
+                yk[i] = sacc;
+            }
+            for (int i = 0; i < 6; ++i) y[(size_t)k * 6 + i] = yk[i];
+            if (bad) *fail = 1 + k;
+        }
+        __syncthreads();
+        const int nd = min(band, K - 1 - k);
+        // (2) T(d) = M(k,d) Lkk^-T for d = 1..nd  (into LDS)
+        for (int e = tid; e < nd * 36; e += 256) {
+            const int d = 1 + e / 36, r = (e % 36) / 6, c = e % 6;
+            const double* row = Mk + d * 36 + r * 6;
+            double sacc = 0;
+            for (int q = 0; q <= c; ++q) sacc += row[q] * Linv[c * 6 + q];
+            T[(d - 1) * 36 + r * 6 + c] = sacc;
+        }
+        __syncthreads();
+        // (3) store L(k+d,k), trailing update block (k+d1, k+d2) -= T(d1) T(d2)^T, y_{k+d} -= T(d) y_k
+        for (int e = tid; e < nd * 36; e += 256) Mk[36 + e] = T[e];
+        const int npair = nd * (nd + 1) / 2;
+        for (int e = tid; e < npair * 36; e += 256) {
+            int pr = e / 36, d1 = 1;
+            while (pr >= d1) { pr -= d1; ++d1; }       // pr = d2-1 in 0..d1-1
+            const int d2 = pr + 1, r = (e % 36) / 6, c = e % 6;
+            const double* t1 = T + (d1 - 1) * 36 + r * 6;
+            const double* t2 = T + (d2 - 1) * 36 + c * 6;
+            double sacc = 0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) sacc += t1[q] * t2[q];
+            M[((size_t)(k + d2) * bw + (d1 - d2)) * 36 + r * 6 + c] -= sacc;
+        }
+        for (int e = tid; e < nd * 6; e += 256) {
+            const int d = 1 + e / 6, r = e % 6;
+            double sacc = 0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) sacc += T[(d - 1) * 36 + r * 6 + q] * yk[q];
+            y[(size_t)(k + d) * 6 + r] -= sacc;
+        }
+        __syncthreads();
+    }
+}
+
+// back substitution L^T x = y by one wavefront; delta = -x
+__global__ __launch_bounds__(64) void k_batch_backsolve(const double* __restrict__ M, const double* __restrict__ y, const int K, const int band,
+                                                        double* delta) {
+    __shared__ double xr[(BB_MAX_BAND + 1) * 6];
+    __shared__ double rhs[6];
+    const int lane = threadIdx.x, bw = band + 1;
+    for (int k = K - 1; k >= 0; --k) {
+        const int nd = min(band, K - 1 - k);
+        const double* Mk = M + (size_t)k * bw * 36;
+        if (lane < 6) {
+            double sacc = y[(size_t)k * 6 + lane];
+            for (int d = 1; d <= nd; ++d) {
+                const double* xd = xr + ((k + d) % bw) * 6;
+                const double* blk = Mk + d * 36;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) sacc -= blk[r * 6 + lane] * xd[r];
+            }
+            rhs[lane] = sacc;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            double x[6];
+            for (int i = 5; i >= 0; --i) {
+                double sacc = rhs[i];
+                for (int q = i + 1; q < 6; ++q) sacc -= Mk[q * 6 + i] * x[q];
+                x[i] = sacc / Mk[i * 6 + i];
+            }
+            for (int i = 0; i < 6; ++i) { xr[(k % bw) * 6 + i] = x[i]; delta[(size_t)k * 6 + i] = -x[i]; }
+        }
+        __syncthreads();
+    }
+}
+
+// poses (+) delta, and the model decrease -(g.d + d^T H d / 2) from the band
+__global__ __launch_bounds__(256) void k_batch_apply(const double* __restrict__ Hg, const double* __restrict__ delta, const double* __restrict__ poses,
+                                                     const int K, const int band, double* newposes, double* model_dec) {
+    __shared__ double red[4];
+    const int bw = band + 1;
+    const double* g = Hg + (size_t)K * bw * 36;
+    double acc = 0;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
+        const double* dk = delta + (size_t)k * 6;
+        double Hd[6] = {0, 0, 0, 0, 0, 0};
+        for (int d = 0; d <= band && k + d < K; ++d) {
+            const double* blk = Hg + ((size_t)k * bw + d) * 36;
+            const double* dd = delta + (size_t)(k + d) * 6;
+            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) Hd[r] += blk[r * 6 + c] * dd[c];
+        }
+        for (int d = 1; d <= band && k - d >= 0; ++d) {
+            const double* blk = Hg + ((size_t)(k - d) * bw + d) * 36;     // H(k-d, k); need its transpose
+            const double* dd = delta + (size_t)(k - d) * 6;
+            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) Hd[r] += blk[c * 6 + r] * dd[c];
+        }
+        for (int r = 0; r < 6; ++r) acc += dk[r] * (g[(size_t)k * 6 + r] + 0.5 * Hd[r]);
+        const double* p = poses + (size_t)k * 7;
+        double* o = newposes + (size_t)k * 7;
+        for (int c = 0; c < 3; ++c) o[c] = p[c] + dk[c];
+        d_quat_plus(p + 3, dk + 3, o + 3);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(model_dec, -(red[0] + red[1] + red[2] + red[3]));
+}
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------------
+#define BALLOC(ptr, bytes) GLIO_HIP_CHECK(hipMalloc((void**)&(ptr), (size_t)(bytes) > 0 ? (size_t)(bytes) : 16))
+
+extern "C" {
+
+int64_t glio_batch_hg_size(int K, int band) { return (int64_t)K * (band + 1) * 36 + (int64_t)K * 6 + 1; }
+
+int glio_batch_create(int device, int K, int band, int64_t max_constraints, glio_batch** out) {
+    if (!out || K < 2 || band < 1 || band > BB_MAX_BAND || max_constraints < 1) { glio_set_error("bad batch shape"); return GLIO_E_ARG; }
+    if (glio_device_count() < 1) { glio_set_error("no HIP device visible: the batch stage has no CPU fallback"); return GLIO_E_HIP; }
+    GLIO_HIP_CHECK(hipSetDevice(device));
+    glio_batch* b = new glio_batch();
+    memset(b, 0, sizeof *b);
+    b->device = device; b->K = K; b->band = band; b->max_con = max_constraints;
+    b->max_pairs = K * 2 * band;
+    GLIO_HIP_CHECK(hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
+    b->stream = b->own_stream;
+    BALLOC(b->d_pair_i, b->max_pairs * 4); BALLOC(b->d_pair_j, b->max_pairs * 4); BALLOC(b->d_pair_off, (size_t)(b->max_pairs + 1) * 8);
+    BALLOC(b->d_pair_rec, (size_t)b->max_pairs * BP_REC * 8);
+    BALLOC(b->d_pair_index, (size_t)K * (2 * band + 1) * 4);
+    BALLOC(b->d_poses, (size_t)K * 7 * 8); BALLOC(b->d_newposes, (size_t)K * 7 * 8);
+    BALLOC(b->d_M, (size_t)K * (band + 1) * 36 * 8); BALLOC(b->d_y, (size_t)K * 6 * 8); BALLOC(b->d_delta, (size_t)K * 6 * 8);
+    BALLOC(b->d_scalar, 4 * 8);
+    GLIO_HIP_CHECK(hipHostMalloc((void**)&b->h_poses, (size_t)K * 7 * 8));
+    GLIO_HIP_CHECK(hipHostMalloc((void**)&b->h_scalar, 4 * 8));
+    GLIO_HIP_CHECK(hipEventCreate(&b->ev0)); GLIO_HIP_CHECK(hipEventCreate(&b->ev1));
+    *out = b;
+    return GLIO_OK;
+}
+
+void glio_batch_destroy(glio_batch* b) {
+    if (!b) return;
+    hipSetDevice(b->device);
+    hipStreamSynchronize(b->stream);
+    void* ptrs[] = {b->d_cp, b->d_nc, b->d_score, b->d_pair_i, b->d_pair_j, b->d_pair_off, b->d_pair_rec, b->d_pair_index, b->d_poses,
+                    b->d_newposes, b->d_M, b->d_y, b->d_delta, b->d_scalar};
+    for (void* p : ptrs) if (p) hipFree(p);
+    hipHostFree(b->h_poses); hipHostFree(b->h_scalar);
+    hipEventDestroy(b->ev0); hipEventDestroy(b->ev1);
+    hipStreamDestroy(b->own_stream);
+    delete b;
+}
+
+int glio_batch_set_stream(glio_batch* b, void* s) {
+    if (!b) return GLIO_E_ARG;
+    b->stream = s ? (hipStream_t)s : b->own_stream;
+    return GLIO_OK;
+}
+
+// pair segmentation from the (sorted) host index arrays
+static int build_pairs(glio_batch* b, int64_t n, const int32_t* ci, const int32_t* cj) {
+    const int K = b->K, band = b->band, wdt = 2 * band + 1;
+    std::vector<int> pi, pj, index((size_t)K * wdt, -1);
+    std::vector<long long> off;
+    for (int64_t i = 0; i < n; ++i) {
+        const int a = ci[i], c = cj[i];
+        if (a < 0 || a >= K || c < 0 || c >= K || a == c || std::abs(a - c) > band) { glio_set_error("constraint %lld: keyframes (%d,%d) outside band %d", (long long)i, a, c, band); return GLIO_E_ARG; }
+        if (pi.empty() || pi.back() != a || pj.back() != c) {
+            if (!pi.empty() && (a < pi.back() || (a == pi.back() && c < pj.back()))) { glio_set_error("constraints must be sorted by (ci, cj)"); return GLIO_E_ARG; }
+            if (index[(size_t)a * wdt + (c - a) + band] >= 0) { glio_set_error("constraints must be sorted by (ci, cj)"); return GLIO_E_ARG; }
+            index[(size_t)a * wdt + (c - a) + band] = (int)pi.size();
+            pi.push_back(a); pj.push_back(c); off.push_back(i);
+        }
+    }
+    off.push_back(n);
+    if ((int)pi.size() > b->max_pairs) return GLIO_E_ARG;
+    b->n_pairs = (int)pi.size();
+    if (b->n_pairs) {
+        GLIO_HIP_CHECK(hipMemcpy(b->d_pair_i, pi.data(), pi.size() * 4, hipMemcpyHostToDevice));
+        GLIO_HIP_CHECK(hipMemcpy(b->d_pair_j, pj.data(), pj.size() * 4, hipMemcpyHostToDevice));
+    }
+    GLIO_HIP_CHECK(hipMemcpy(b->d_pair_off, off.data(), off.size() * 8, hipMemcpyHostToDevice));
+    GLIO_HIP_CHECK(hipMemcpy(b->d_pair_index, index.data(), index.size() * 4, hipMemcpyHostToDevice));
+    b->n_con = n;
+    return GLIO_OK;
+}
+
+int glio_batch_set_constraints_dev(glio_batch* b, int64_t n, const int32_t* ci, const int32_t* cj, const float* cp_dev,
+                                   const double* nc_dev, const double* score_dev) {
+    if (!b || n < 0 || (n > 0 && (!ci || !cj || !cp_dev || !nc_dev || !score_dev))) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipSetDevice(b->device));
+    const int rc = build_pairs(b, n, ci, cj);
+    if (rc) return rc;
+    b->cp = reinterpret_cast<const float4*>(cp_dev); b->nc = nc_dev; b->score = score_dev;
+    return GLIO_OK;
+}
+
+int glio_batch_set_constraints(glio_batch* b, int64_t n, const int32_t* ci, const int32_t* cj, const float* cp,
+                               const double* nc, const double* score) {
+    if (!b || n < 0 || n > b->max_con) { glio_set_error("too many constraints"); return GLIO_E_ARG; }
+    GLIO_HIP_CHECK(hipSetDevice(b->device));
+    if (!b->d_cp) { BALLOC(b->d_cp, (size_t)b->max_con * 16); BALLOC(b->d_nc, (size_t)b->max_con * 48); BALLOC(b->d_score, (size_t)b->max_con * 8); }
+    if (n > 0) {
+        GLIO_HIP_CHECK(hipMemcpy(b->d_cp, cp, (size_t)n * 16, hipMemcpyHostToDevice));
+        GLIO_HIP_CHECK(hipMemcpy(b->d_nc, nc, (size_t)n * 48, hipMemcpyHostToDevice));
+        GLIO_HIP_CHECK(hipMemcpy(b->d_score, score, (size_t)n * 8, hipMemcpyHostToDevice));
+    }
+    return glio_batch_set_constraints_dev(b, n, ci, cj, reinterpret_cast<const float*>(b->d_cp), b->d_nc, b->d_score);
+}
+
+static void enqueue_batch_linearize(glio_batch* b, double* Hg_dev) {
+    const int K = b->K, band = b->band;
+    const long long nH = (long long)K * (band + 1) * 36, total = nH + (long long)K * 6;
+    if (b->n_pairs > 0)
+        hipLaunchKernelGGL(k_batch_pairs, dim3((b->n_pairs + 3) / 4), dim3(256), 0, b->stream, b->cp, b->nc, b->score, b->d_pair_i, b->d_pair_j,
+                           b->d_pair_off, b->n_pairs, b->d_poses, b->d_pair_rec);
+    hipLaunchKernelGGL(k_batch_assemble, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, b->stream, b->d_pair_rec, b->d_pair_index, K, band,
+                       b->n_pairs, Hg_dev);
+    hipLaunchKernelGGL(k_batch_cost, dim3(1), dim3(256), 0, b->stream, b->d_pair_rec, b->n_pairs, Hg_dev + total);
+}
+
+int glio_batch_linearize_dev(glio_batch* b, const double* poses, double* Hg_dev) {
+    if (!b || !poses || !Hg_dev) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipSetDevice(b->device));
+    memcpy(b->h_poses, poses, (size_t)b->K * 7 * 8);
+    GLIO_HIP_CHECK(hipMemcpyAsync(b->d_poses, b->h_poses, (size_t)b->K * 7 * 8, hipMemcpyHostToDevice, b->stream));
+    enqueue_batch_linearize(b, Hg_dev);
+    GLIO_HIP_CHECK(hipGetLastError());
+    GLIO_HIP_CHECK(hipStreamSynchronize(b->stream));
+    return GLIO_OK;
+}
+
+int glio_batch_time_linearize(glio_batch* b, const double* poses, double* Hg_dev, int reps, float* ms_out) {
+    if (!b || !poses || !Hg_dev || reps < 1 || !ms_out) return GLIO_E_ARG;
+    int rc = glio_batch_linearize_dev(b, poses, Hg_dev);      // warm-up + pose upload
+    if (rc) return rc;
+    GLIO_HIP_CHECK(hipEventRecord(b->ev0, b->stream));
+    for (int r = 0; r < reps; ++r) enqueue_batch_linearize(b, Hg_dev);
+    GLIO_HIP_CHECK(hipEventRecord(b->ev1, b->stream));
+    GLIO_HIP_CHECK(hipStreamSynchronize(b->stream));
+    float ms = 0;
+    GLIO_HIP_CHECK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+    *ms_out = ms / reps;
+    return GLIO_OK;
+}
+
+int glio_batch_step_dev(glio_batch* b, const double* Hg_dev, double lambda, const double* poses_in, double* poses_out, double* model_decrease) {
+    if (!b || !Hg_dev || !poses_in || !poses_out) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipSetDevice(b->device));
+    const int K = b->K, band = b->band;
+    memcpy(b->h_poses, poses_in, (size_t)K * 7 * 8);
+    GLIO_HIP_CHECK(hipMemcpyAsync(b->d_poses, b->h_poses, (size_t)K * 7 * 8, hipMemcpyHostToDevice, b->stream));
+    GLIO_HIP_CHECK(hipMemsetAsync(b->d_scalar, 0, 4 * 8, b->stream));
+    int* d_fail = reinterpret_cast<int*>(b->d_scalar + 2);
+    hipLaunchKernelGGL(k_batch_factor, dim3(1), dim3(256), 0, b->stream, Hg_dev, K, band, lambda, b->d_M, b->d_y, d_fail);
+    hipLaunchKernelGGL(k_batch_backsolve, dim3(1), dim3(64), 0, b->stream, b->d_M, b->d_y, K, band, b->d_delta);
+    hipLaunchKernelGGL(k_batch_apply, dim3((K + 255) / 256), dim3(256), 0, b->stream, Hg_dev, b->d_delta, b->d_poses, K, band, b->d_newposes, b->d_scalar);
+    GLIO_HIP_CHECK(hipGetLastError());
+    GLIO_HIP_CHECK(hipMemcpyAsync(b->h_poses, b->d_newposes, (size_t)K * 7 * 8, hipMemcpyDeviceToHost, b->stream));
+    GLIO_HIP_CHECK(hipMemcpyAsync(b->h_scalar, b->d_scalar, 4 * 8, hipMemcpyDeviceToHost, b->stream));
+    GLIO_HIP_CHECK(hipStreamSynchronize(b->stream));
+    int fail = 0;
+    memcpy(&fail, b->h_scalar + 2, 4);
+    if (fail) { glio_set_error("banded Cholesky breakdown at keyframe %d", fail - 1); return GLIO_E_NUMERIC; }
+    memcpy(poses_out, b->h_poses, (size_t)K * 7 * 8);
+    if (model_decrease) *model_decrease = b->h_scalar[0];
+    return GLIO_OK;
+}
+
+}  // extern "C"

@@ -106,6 +106,37 @@ int glio_time_kernel(glio_ctx* ctx, int which, int reps, float* ms_out);
 /* time `reps` complete solves from the same initial state with HIP events (state is not modified) */
 int glio_time_solve(glio_ctx* ctx, const glio_state* state, int reps, float* ms_out, glio_summary* last);
 
+
+/* ================================================================================================
+ * Batch stage (scan-to-multiscan), the one piece that shards over GPUs.
+ * Replaces, inside Estimator::optimizeBatchWithLandMark (Estimator.cpp:2739-3410), the evaluation of all
+ * BinaryLidarPlaneNormFactor residual blocks (LidarKeyframeFactor.h:124-164, built at Estimator.cpp:3004-3076,
+ * no loss function :2768) and their J^T J / J^T r build.  Unknowns: K keyframe poses (t, q), local size 6 K;
+ * H is block banded: block (k, k+d), d = 0..band, stored at Hg[(k*(band+1)+d)*36 ...] (row-major 6x6),
+ * followed by g [K][6] and the cost (1 double): Hg has glio_batch_hg_size(K, band) doubles.
+ * Each rank loads only ITS constraints; the ranks' Hg buffers are summed with one RCCL all-reduce (by the
+ * caller: torch.distributed / rccl on the device pointer), then every rank runs the same banded solve.
+ * Pointers named *_dev are DEVICE pointers (e.g. torch tensors); the others are host memory. */
+typedef struct glio_batch glio_batch;
+int64_t glio_batch_hg_size(int K, int band);
+int glio_batch_create(int device, int K, int band, int64_t max_constraints, glio_batch** out);
+void glio_batch_destroy(glio_batch* b);
+int glio_batch_set_stream(glio_batch* b, void* hip_stream);
+/* constraints sorted by (ci, cj); cp [n][4] float (point in frame ci), norm_cent [n][6] double (plane normal and
+ * centroid in frame cj), score [n]; |ci-cj| in 1..band */
+int glio_batch_set_constraints(glio_batch* b, int64_t n, const int32_t* ci, const int32_t* cj, const float* cp,
+                               const double* norm_cent, const double* score);
+int glio_batch_set_constraints_dev(glio_batch* b, int64_t n, const int32_t* ci_host, const int32_t* cj_host,
+                                   const float* cp_dev, const double* norm_cent_dev, const double* score_dev);
+/* poses [K][7] = (t, q) host; Hg_dev device buffer of glio_batch_hg_size doubles (overwritten) */
+int glio_batch_linearize_dev(glio_batch* b, const double* poses, double* Hg_dev);
+/* damped Gauss-Newton step from a (reduced) Hg: solves (H + lambda diag(H)) d = -g with a block-banded Cholesky on
+ * the device and returns poses (+) d; *model_decrease = -(g.d + d^T H d / 2).  poses_out may alias poses_in. */
+int glio_batch_step_dev(glio_batch* b, const double* Hg_dev, double lambda, const double* poses_in, double* poses_out,
+                        double* model_decrease);
+/* timing hook: average ms of `reps` linearisation launches (HIP events on the batch stream) */
+int glio_batch_time_linearize(glio_batch* b, const double* poses, double* Hg_dev, int reps, float* ms_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,111 @@
+"""GPU parity of the batch stage (K8 pair kernel + banded assembly + banded solve) against the oracle's
+BinaryLidarPlaneNormFactor restatement, and the sharding property the multi-GPU path relies on."""
+import numpy as np
+import pytest
+
+from glio_amd import batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def po():
+    from oracle import pyoracle
+    return pyoracle
+
+
+def _problem(K, band, per_kf, seed=3):
+    gt, init = batch.make_poses(K, seed=seed)
+    ci, cj, cp, nc, score = batch.make_constraints(gt, 0, K, per_kf, band, seed=seed, device="cuda:0")
+    return gt, init, ci, cj, cp, nc, score
+
+
+@pytest.mark.parametrize("K,band,per_kf", [(14, 3, 301), (40, 6, 500)])
+def test_batch_linearize_matches_oracle(po, K, band, per_kf):
+    gt, init, ci, cj, cp, nc, score = _problem(K, band, per_kf)
+    st = batch.BatchStage(K, band, len(ci))
+    st.set_constraints(ci, cj, cp, nc, score)
+    Hg = st.new_hg()
+    st.linearize(init, Hg)
+    Hb, g, cost = batch.unpack_hg(Hg.cpu().numpy(), K, band)
+    Ho, go, co = po.batch_linearize(K, band, np.ascontiguousarray(init), ci, cj, cp.cpu().numpy(), nc.cpu().numpy(), score.cpu().numpy())
+    assert abs(cost - co) <= 1e-11 * co
+    assert np.linalg.norm(g - go) <= 1e-11 * np.linalg.norm(go)
+    assert np.linalg.norm(Hb - Ho.reshape(Hb.shape)) <= 1e-11 * np.linalg.norm(Ho)
+    st.close()
+
+
+def test_batch_step_matches_dense_solve():
+    K, band = 30, 4
+    gt, init, ci, cj, cp, nc, score = _problem(K, band, 400, seed=5)
+    st = batch.BatchStage(K, band, len(ci))
+    st.set_constraints(ci, cj, cp, nc, score)
+    Hg = st.new_hg()
+    st.linearize(init, Hg)
+    lam = 1e-3
+    new, mdec = st.step(Hg, lam, init)
+    Hb, g, cost = batch.unpack_hg(Hg.cpu().numpy(), K, band)
+    H = batch.dense_from_band(Hb, K, band)
+    Hd = H + np.diag(lam * np.diag(H) + 1e-12)
+    d = np.linalg.solve(Hd, -g.ravel())
+    assert np.allclose(new[:, :3] - init[:, :3], d.reshape(K, 6)[:, :3], rtol=1e-8, atol=1e-10)
+    assert np.isclose(mdec, -(g.ravel() @ d + 0.5 * d @ H @ d), rtol=1e-8)
+    assert np.allclose(np.linalg.norm(new[:, 3:], axis=1), 1.0, atol=1e-12)
+    st.close()
+
+
+def test_shard_sum_equals_full_linearisation():
+    """What the RCCL all-reduce computes: the ranks' partial [H|g|cost] buffers add up to the full one."""
+    K, band, per_kf = 36, 6, 240
+    gt, init = batch.make_poses(K, seed=9)
+    full = batch.make_constraints(gt, 0, K, per_kf, band, seed=9, device="cuda:0")
+    st = batch.BatchStage(K, band, len(full[0]))
+    st.set_constraints(*full)
+    Hg_full = st.new_hg()
+    st.linearize(init, Hg_full)
+    for world in (2, 3, 8):
+        acc = st.new_hg()
+        for r in range(world):
+            lo, hi = batch.shard_range(K, r, world)
+            part = batch.make_constraints(gt, lo, hi, per_kf, band, seed=9, device="cuda:0")
+            sr = batch.BatchStage(K, band, max(1, len(part[0])))
+            sr.set_constraints(*part)
+            Hg = sr.new_hg()
+            sr.linearize(init, Hg)
+            acc += Hg
+            sr.close()
+        # same constraints? (the generator is seeded per source keyframe range start, so compare through costs of identical sets)
+        assert acc.shape == Hg_full.shape
+    # identical constraint sets split in two must add up exactly
+    ci, cj, cp, nc, score = full
+    cut = int(np.searchsorted(ci, K // 2))
+    acc = st.new_hg()
+    for sl in (slice(0, cut), slice(cut, len(ci))):
+        sr = batch.BatchStage(K, band, len(ci))
+        sr.set_constraints(ci[sl], cj[sl], cp[sl].contiguous(), nc[sl].contiguous(), score[sl].contiguous())
+        Hg = sr.new_hg()
+        sr.linearize(init, Hg)
+        acc += Hg
+        sr.close()
+    a, f = acc.cpu().numpy(), Hg_full.cpu().numpy()
+    assert np.linalg.norm(a - f) <= 1e-13 * np.linalg.norm(f)
+    st.close()
+
+
+def test_batch_lm_reduces_cost_and_recovers_relative_poses():
+    K, band = 60, 6
+    gt, init, ci, cj, cp, nc, score = _problem(K, band, 600, seed=11)
+    st = batch.BatchStage(K, band, len(ci))
+    st.set_constraints(ci, cj, cp, nc, score)
+    bufs = [st.new_hg(), st.new_hg()]
+    flip = [0]
+
+    def lin(p):
+        flip[0] ^= 1
+        st.linearize(p, bufs[flip[0]])
+        return bufs[flip[0]], float(bufs[flip[0]][-1].item())
+    poses, hist = batch.lm_solve(lin, st.step, init, iterations=8)
+    assert hist[-1] < 5e-2 * hist[0] and all(b <= a for a, b in zip(hist, hist[1:]))      # down to the 2 cm noise floor
+    rel = lambda P: np.linalg.norm(np.diff(P[:, :3], axis=0) - np.diff(gt[:, :3], axis=0), axis=1).max()
+    assert rel(poses) < 0.2 * rel(init)
+    st.close()
