@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--points", type=int, default=65536)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch-keyframes", type=int, default=2000)
+    ap.add_argument("--batch-per-kf", type=int, default=32768)
+    ap.add_argument("--no-batch", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -85,6 +88,13 @@ def main():
     total_steps = args.steps * world
     value = total_steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
+
+    batch_info = None
+    if not args.no_batch:
+        try:
+            batch_info = bench_batch_stage(args, rank, local_rank, world, dist, torch)
+        except Exception as e:  # informational section; never hide the headline
+            batch_info = {"error": str(e)[:300]}
 
     if rank != 0:
         if dist is not None:
@@ -163,7 +173,7 @@ def main():
         "iterations": int(summ.iterations), "ms_per_iteration": round(ms_per_step / max(1, int(summ.iterations)), 4),
         "termination": int(summ.termination),
         "kernels_us": {"lidar_linearize": round(k3_ms * 1e3, 2), "full_linearize": round(lin_ms * 1e3, 2), "tr_step": round(trs_ms * 1e3, 2)},
-        "roofline": roofline, "cpu_baseline": cpu, "pose_vs_oracle": pose_err, "association": assoc,
+        "roofline": roofline, "cpu_baseline": cpu, "pose_vs_oracle": pose_err, "association": assoc, "batch_stage": batch_info,
     }
     if cpu and "value" in cpu:
         line["speedup_vs_cpu_port"] = round(value / world / cpu["value"], 1)
@@ -171,6 +181,60 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_batch_stage(args, rank, local_rank, world, dist, torch):
+    """BASELINE config C4: optimizeBatch scan-to-multiscan, K keyframes x per_kf pre-associated binary plane
+    constraints, sharded by source-keyframe range; one RCCL all-reduce of the block-banded [H|g|cost] buffer per
+    linearisation.  STRONG scaling (the total work is fixed); reported next to the headline, not as `value`."""
+    import time as _t
+    from glio_amd import batch
+    K, band, per_kf = args.batch_keyframes, 6, args.batch_per_kf
+    gt, init = batch.make_poses(K)
+    lo, hi = batch.shard_range(K, rank, world)
+    dev = f"cuda:{local_rank}"
+    ci, cj, cp, nc, score = batch.make_constraints(gt, lo, hi, per_kf, band, device=dev)
+    st = batch.BatchStage(K, band, len(ci), device=local_rank)
+    st.set_constraints(ci, cj, cp, nc, score)
+    bufs = [st.new_hg(), st.new_hg()]
+    flip = [0]
+    t_ar = []
+
+    def lin(p):
+        flip[0] ^= 1
+        Hg = bufs[flip[0]]
+        st.linearize(p, Hg)
+        if dist is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); dist.all_reduce(Hg, op=dist.ReduceOp.SUM); e1.record(); torch.cuda.synchronize()
+            t_ar.append(e0.elapsed_time(e1))
+        return Hg, float(Hg[-1].item())
+    lin(init); lin(init)                                   # warm-up (RCCL communicator, caches)
+    t_ar.clear()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = _t.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        Hg, cost0 = lin(init)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t_lin_wall = (_t.perf_counter() - t0) / reps
+    k8_ms = st.time_linearize(init, bufs[0], 5)
+    lin(init)
+    t0 = _t.perf_counter()
+    poses, hist = batch.lm_solve(lin, st.step, init, iterations=3)
+    t_lm = (_t.perf_counter() - t0) / 3
+    info = {"workload": f"C4: {K} keyframes x {per_kf} binary plane constraints, band +-{band}, sharded by source keyframe over {world} GPU(s)",
+            "scaling": "strong", "constraints_total": int(K) * int(per_kf), "constraints_this_rank": int(len(ci)),
+            "linearize_kernels_ms": round(k8_ms, 4), "algorithmic_GBps_this_rank": round(len(ci) * 72 / (k8_ms * 1e-3) / 1e9, 1),
+            "allreduce_ms": round(float(np.mean(t_ar)), 4) if t_ar else 0.0, "allreduce_MB": round(batch.hg_size(K, band) * 8 / 1e6, 2),
+            "linearize_plus_allreduce_wall_ms": round(t_lin_wall * 1e3, 4), "lm_iteration_wall_ms": round(t_lm * 1e3, 3),
+            "cost_history": [round(h, 3) for h in hist]}
+    st.close()
+    return info
 
 
 def _cpu_model():
