@@ -148,6 +148,20 @@ class Context:
         _check(load().glio_solve(self._h, C.byref(cs), C.byref(summ)))
         return s, summ
 
+    def marginalize(self, state):
+        """Marginalize slot 0 at `state` (Estimator.cpp:2462-2607): returns the glio_prior fields of the next window."""
+        W = self.W
+        n = 6 * (W - 1) + 9
+        nb = 2 * (W - 1) + 1
+        out = dict(n=n, lin_jac=np.zeros((n, n)), lin_res=np.zeros(n), blk_slot=np.zeros(nb, np.int32),
+                   blk_kind=np.zeros(nb, np.int32), blk_idx=np.zeros(nb, np.int32), blk_x0=np.zeros((nb, 9)))
+        cs = state.c()
+        on, onb = C.c_int32(), C.c_int32()
+        _check(load().glio_marginalize(self._h, C.byref(cs), T.dptr(out["lin_jac"]), T.dptr(out["lin_res"]), T.iptr(out["blk_slot"]),
+                                       T.iptr(out["blk_kind"]), T.iptr(out["blk_idx"]), T.dptr(out["blk_x0"]), C.byref(on), C.byref(onb)))
+        assert on.value == n and onb.value == nb
+        return out
+
     def time_kernel(self, which, reps=20):
         ms = C.c_float()
         _check(load().glio_time_kernel(self._h, which, reps, C.byref(ms)))

@@ -29,6 +29,7 @@ struct CtxExtra {
     GnssDevExtra gx;
     double* d_eval_params; double* d_eval_out; ImuEdgeDev* d_eval_edge;
     double* h_eval;   // pinned
+    int imu_edge0;    // index of the IMU edge leaving slot 0 (-1: none)
 };
 static std::vector<std::pair<glio_ctx*, CtxExtra*>> g_extras;
 static CtxExtra* extra_of(glio_ctx* c) {
@@ -120,6 +121,7 @@ int glio_create(int device, const glio_opts* opts, glio_ctx** out) {
     GLIO_HIP_CHECK(hipHostMalloc((void**)&c->h_xbuf, (size_t)nx * 8));
     GLIO_HIP_CHECK(hipEventCreate(&c->ev0)); GLIO_HIP_CHECK(hipEventCreate(&c->ev1));
     CtxExtra* ex = new CtxExtra();
+    ex->imu_edge0 = -1;
     memset(ex, 0, sizeof *ex);
     ALLOC(ex->gx.d_runs, (size_t)std::max(1, c->n_ddt_max) * sizeof(DopRun));
     ALLOC(ex->gx.d_prior_colblk, npmax * 4);
@@ -292,6 +294,8 @@ int glio_set_imu(glio_ctx* c, int n_edges, const glio_preint* edges, const int32
     }
     if (n_edges) GLIO_HIP_CHECK(hipMemcpy(c->d_imu, h.data(), n_edges * sizeof(ImuEdgeDev), hipMemcpyHostToDevice));
     c->n_imu = n_edges;
+    extra_of(c)->imu_edge0 = -1;
+    for (int k = 0; k < n_edges; ++k) if (slot_i[k] == 0) extra_of(c)->imu_edge0 = k;
     if (n_edges) c->have_factors = 1;
     return GLIO_OK;
 }
@@ -497,6 +501,47 @@ int glio_linearize(glio_ctx* c, const glio_state* s, double* H, double* g, doubl
     if (cost) GLIO_HIP_CHECK(hipMemcpyAsync(cost, c->d_cost[0], 8, hipMemcpyDeviceToHost, c->stream));
     GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
     c->last_n_ddt = n_ddt;
+    return GLIO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- marginalization
+int glio_marginalize(glio_ctx* c, const glio_state* s, double* lin_jac, double* lin_res, int32_t* blk_slot, int32_t* blk_kind,
+                     int32_t* blk_idx, double* blk_x0, int32_t* out_n, int32_t* out_n_blocks) {
+    int rc = check_state(c, s);
+    if (rc) return rc;
+    if (!lin_jac || !lin_res || !blk_slot || !blk_kind || !blk_idx || !blk_x0) { glio_set_error("null output"); return GLIO_E_ARG; }
+    const int W = c->W;
+    if (W < 2) { glio_set_error("marginalization needs a window of at least 2 keyframes"); return GLIO_E_ARG; }
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    const int n_ddt = s->n_ddt, nx = glio_x_size(W, n_ddt), n = 6 * (W - 1) + 9;
+    pack_state(c, s, c->h_xbuf);
+    GLIO_HIP_CHECK(hipMemcpyAsync(c->d_x[0], c->h_xbuf, (size_t)nx * 8, hipMemcpyHostToDevice, c->stream));
+    glio_launch_lidar_linearize(c, 0, 0, 1);
+    glio_launch_small_factors(c, 0, 0, n_ddt, 1);
+    double *dJ, *dr; int* dok;
+    glio_launch_marginalize(c, extra_of(c)->imu_edge0, &dJ, &dr, &dok);
+    GLIO_HIP_CHECK(hipGetLastError());
+    int ok = 0;
+    GLIO_HIP_CHECK(hipMemcpyAsync(lin_jac, dJ, (size_t)n * n * 8, hipMemcpyDeviceToHost, c->stream));
+    GLIO_HIP_CHECK(hipMemcpyAsync(lin_res, dr, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    GLIO_HIP_CHECK(hipMemcpyAsync(&ok, dok, 4, hipMemcpyDeviceToHost, c->stream));
+    GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (!ok) { glio_set_error("marginalization: Schur complement is not positive definite (rank-deficient kept block)"); return GLIO_E_NUMERIC; }
+    // GetParameterBlocks with addr_shift slot s -> s-1 (Estimator.cpp:2584-2600)
+    int nb = 0;
+    for (int k = 1; k < W; ++k) {
+        const int kinds = k == 1 ? 3 : 2;
+        for (int kind = 0; kind < kinds; ++kind) {
+            blk_slot[nb] = k - 1; blk_kind[nb] = kind;
+            blk_idx[nb] = k == 1 ? (kind == 0 ? 0 : (kind == 1 ? 3 : 6)) : 15 + 6 * (k - 2) + 3 * kind;
+            const double* src = kind == 0 ? s->trans + 3 * k : (kind == 1 ? s->quat + 4 * k : s->speed_bias + 9 * k);
+            const int gs = kind == 0 ? 3 : (kind == 1 ? 4 : 9);
+            for (int j = 0; j < 9; ++j) blk_x0[9 * nb + j] = j < gs ? src[j] : 0.0;
+            ++nb;
+        }
+    }
+    if (out_n) *out_n = n;
+    if (out_n_blocks) *out_n_blocks = nb;
     return GLIO_OK;
 }
 

@@ -22,6 +22,7 @@
 
 struct SmallArgs {
     int W, n_imu, n_groups, has_prior, n_ddt;
+    int marg;                  // 1 = marginalization convention for quaternion blocks (global x,y,z columns, quirk Q8)
     int lidar_blocks_per_kf;
     const double* x0; const double* x1;
     const SolverStatus* st; int use_status; int fixed_which;
@@ -62,7 +63,7 @@ __device__ __forceinline__ void qright16(const double p[4], double M[16]) {
 // the whitened GLOBAL Jacobians [15][32] (Pi3 Qi4 SBi9 Pj3 Qj4 SBj9) and return.
 __device__ void imu_block(const double gravity, const double* __restrict__ pPi, const double* __restrict__ pQi,
                           const double* __restrict__ pSBi, const double* __restrict__ pPj, const double* __restrict__ pQj,
-                          const double* __restrict__ pSBj, const ImuEdgeDev& e, PairBlock* out, double* eval_out) {
+                          const double* __restrict__ pSBj, const ImuEdgeDev& e, PairBlock* out, double* eval_out, const int marg = 0) {
     __shared__ double Jg[15 * IMU_GC];
     __shared__ double Jl[15 * 30];
     __shared__ double WJ[15 * 30];
@@ -206,10 +207,10 @@ __device__ void imu_block(const double gravity, const double* __restrict__ pPi, 
         const double* row = Jg + rr * IMU_GC;
         double v;
         if (c < 3) v = row[c];
-        else if (c < 6) { const int cc = c - 3; v = row[3] * PJi[cc] + row[4] * PJi[3 + cc] + row[5] * PJi[6 + cc] + row[6] * PJi[9 + cc]; }
+        else if (c < 6) { const int cc = c - 3; v = marg ? row[4 + cc] : row[3] * PJi[cc] + row[4] * PJi[3 + cc] + row[5] * PJi[6 + cc] + row[6] * PJi[9 + cc]; }
         else if (c < 15) v = row[7 + (c - 6)];
         else if (c < 18) v = row[16 + (c - 15)];
-        else if (c < 21) { const int cc = c - 18; v = row[19] * PJj[cc] + row[20] * PJj[3 + cc] + row[21] * PJj[6 + cc] + row[22] * PJj[9 + cc]; }
+        else if (c < 21) { const int cc = c - 18; v = marg ? row[20 + cc] : row[19] * PJj[cc] + row[20] * PJj[3 + cc] + row[21] * PJj[6 + cc] + row[22] * PJj[9 + cc]; }
         else v = row[23 + (c - 21)];
         Jl[idx] = v;
     }
@@ -479,7 +480,7 @@ __device__ __forceinline__ void prior_dx_M(const SmallArgs& a, const double* __r
                 for (int c = 0; c < 3; ++c) {
                     double acc = 0;
                     for (int k = 0; k < 4; ++k) acc += L[(1 + p) * 4 + k] * P[k * 3 + c];
-                    Mb[9 * b + p * 3 + c] = sg * acc;
+                    Mb[9 * b + p * 3 + c] = a.marg ? sg * L[(1 + p) * 4 + 1 + c] : sg * acc;
                 }
         }
     }
@@ -580,7 +581,7 @@ __global__ __launch_bounds__(SF_THREADS) void k_small_factors(const SmallArgs a)
     if (b < a.n_imu) {
         const int si = a.imu[b].slot_i, sj = si + 1, W = a.W;
         imu_block(a.gravity, x + 3 * si, x + 3 * W + 4 * si, x + 7 * W + 9 * si, x + 3 * sj, x + 3 * W + 4 * sj, x + 7 * W + 9 * sj,
-                  a.imu[b], a.imu_blocks + (size_t)which * a.W + b, nullptr);
+                  a.imu[b], a.imu_blocks + (size_t)which * a.W + b, nullptr, a.marg);
         return;
     }
     b -= a.n_imu;
@@ -803,8 +804,9 @@ void glio_launch_gram(glio_ctx* c, int np) {
 // ------------------------------------------------------------------------------------------------
 GnssDevExtra* glio_extra(glio_ctx* c);   // defined in capi.hip
 
-void glio_launch_small_factors(glio_ctx* c, int use_status_cand, int which, int n_ddt) {
+void glio_launch_small_factors(glio_ctx* c, int use_status_cand, int which, int n_ddt, int marg) {
     SmallArgs a;
+    a.marg = marg;
     GnssDevExtra* ex = glio_extra(c);
     a.W = c->W; a.n_imu = c->n_imu; a.n_groups = c->n_groups; a.has_prior = c->prior_n > 0; a.n_ddt = n_ddt;
     a.lidar_blocks_per_kf = c->k3_bpk;

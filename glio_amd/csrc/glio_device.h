@@ -217,12 +217,14 @@ __device__ __forceinline__ double wave_sum(double v) {
 // launch wrappers (one per translation unit)
 // ------------------------------------------------------------------------------------------------
 // lidar_kernels.hip
-void glio_launch_lidar_linearize(glio_ctx* c, int use_status_cand, int which);
+void glio_launch_lidar_linearize(glio_ctx* c, int use_status_cand, int which, int marg = 0);
 // factor_kernels.hip
-void glio_launch_small_factors(glio_ctx* c, int use_status_cand, int which, int n_ddt);
+void glio_launch_small_factors(glio_ctx* c, int use_status_cand, int which, int n_ddt, int marg = 0);
 void glio_launch_assemble(glio_ctx* c, int use_status_cand, int which, int n_ddt);
 // solver_kernels.hip
 void glio_launch_tr_step(glio_ctx* c, int n_ddt);
+// marginalization of slot 0 from lidar_blocks/imu_blocks/prior H of buffer 0 (evaluated with marg = 1)
+int glio_launch_marginalize(glio_ctx* c, int imu_edge0, double** J0_dev, double** r0_dev, int** ok_dev);
 size_t glio_tr_step_lds_bytes(int n);
 // assoc_kernels.hip
 int glio_assoc_create(glio_ctx* c);

@@ -25,9 +25,15 @@ struct LidarConst {
     double huber;
 };
 
+// MARG = true: the marginalization's convention for the quaternion block (reference
+// GLIO/src/MarginalizationFactor.cpp:9-17, quirk Q8): the x,y,z columns of the GLOBAL 1x4 Jacobian that
+// autodiff produces through Eigen's q*v formula, i.e. s n^T (-2w[v]x - 2[u x v]x - 2[u]x[v]x) with
+// v = p_b, q = (w,u)  =  -2 s [ w (n x v) + n x (u x v) + (n x u) x v ].
+template <bool MARG>
 __device__ __forceinline__ void lidar_accumulate(const float4 p, const float4 pl, const double s,
                                                  const double M[9], const double t[3], const double tlb[3],
-                                                 const double a, double acc[GLIO_LIDAR_ACC]) {
+                                                 const double a, double acc[GLIO_LIDAR_ACC],
+                                                 const double RlbT[9], const double q[4]) {
     const double cx = (double)p.x - tlb[0], cy = (double)p.y - tlb[1], cz = (double)p.z - tlb[2];
     const double rx = M[0] * cx + M[1] * cy + M[2] * cz;
     const double ry = M[3] * cx + M[4] * cy + M[5] * cz;
@@ -38,9 +44,20 @@ __device__ __forceinline__ void lidar_accumulate(const float4 p, const float4 pl
     double J[6];
     J[0] = s * nx; J[1] = s * ny; J[2] = s * nz;
     const double s2 = 2.0 * s;
-    J[3] = s2 * (ry * nz - rz * ny);
-    J[4] = s2 * (rz * nx - rx * nz);
-    J[5] = s2 * (rx * ny - ry * nx);
+    if (!MARG) {
+        J[3] = s2 * (ry * nz - rz * ny);
+        J[4] = s2 * (rz * nx - rx * nz);
+        J[5] = s2 * (rx * ny - ry * nx);
+    } else {
+        const double vx = RlbT[0] * cx + RlbT[1] * cy + RlbT[2] * cz, vy = RlbT[3] * cx + RlbT[4] * cy + RlbT[5] * cz, vz = RlbT[6] * cx + RlbT[7] * cy + RlbT[8] * cz;
+        const double w = q[0], ux = q[1], uy = q[2], uz = q[3];
+        const double nvx = ny * vz - nz * vy, nvy = nz * vx - nx * vz, nvz = nx * vy - ny * vx;          // n x v
+        const double uvx = uy * vz - uz * vy, uvy = uz * vx - ux * vz, uvz = ux * vy - uy * vx;          // u x v
+        const double nux = ny * uz - nz * uy, nuy = nz * ux - nx * uz, nuz = nx * uy - ny * ux;          // n x u
+        J[3] = -s2 * (w * nvx + (ny * uvz - nz * uvy) + (nuy * vz - nuz * vy));
+        J[4] = -s2 * (w * nvy + (nz * uvx - nx * uvz) + (nuz * vx - nux * vz));
+        J[5] = -s2 * (w * nvz + (nx * uvy - ny * uvx) + (nux * vy - nuy * vx));
+    }
     const double ar = fabs(r);
     const bool inl = ar <= a;
     const double w = inl ? 1.0 : a / ar;                  // rho'
@@ -56,7 +73,7 @@ __device__ __forceinline__ void lidar_accumulate(const float4 p, const float4 pl
     acc[27] += 0.5 * rho;
 }
 
-template <int UNROLL>
+template <int UNROLL, bool MARG>
 __global__ __launch_bounds__(GLIO_K3_THREADS) void k_lidar_linearize(
     const float4* __restrict__ pts, const float4* __restrict__ planes, const double* __restrict__ scores,
     const int* __restrict__ count, const int cap, const double* __restrict__ x0, const double* __restrict__ x1,
@@ -106,9 +123,9 @@ __global__ __launch_bounds__(GLIO_K3_THREADS) void k_lidar_linearize(
             s[u] = S[i + u * stride];
         }
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) lidar_accumulate(p[u], pl[u], s[u], M, t, lc.tlb, lc.huber, acc);
+        for (int u = 0; u < UNROLL; ++u) lidar_accumulate<MARG>(p[u], pl[u], s[u], M, t, lc.tlb, lc.huber, acc, lc.RlbT, q);
     }
-    for (; i < n; i += stride) lidar_accumulate(P[i], Q[i], S[i], M, t, lc.tlb, lc.huber, acc);
+    for (; i < n; i += stride) lidar_accumulate<MARG>(P[i], Q[i], S[i], M, t, lc.tlb, lc.huber, acc, lc.RlbT, q);
 
     // Wave reduction as a value-splitting butterfly: at every halving step a lane keeps one half of its
     // values and ships the other half to its partner, so 32 (padded) accumulators need 16+8+4+2+1+1 = 32
@@ -169,7 +186,7 @@ __global__ __launch_bounds__(GLIO_K3_THREADS) void k_lidar_linearize(
     }
 }
 
-void glio_launch_lidar_linearize(glio_ctx* c, int use_status_cand, int which) {
+void glio_launch_lidar_linearize(glio_ctx* c, int use_status_cand, int which, int marg) {
     LidarConst lc;
     // R(q_lb)^T via Eigen's inverse(): conj / |q|^2
     const double* ql = c->opts.q_lb;
@@ -183,14 +200,15 @@ void glio_launch_lidar_linearize(glio_ctx* c, int use_status_cand, int which) {
     for (int k = 0; k < 3; ++k) lc.tlb[k] = c->opts.t_lb[k];
     lc.huber = c->opts.huber_delta;
     dim3 grid(c->k3_bpk, c->W);
-#define K3_LAUNCH(U) hipLaunchKernelGGL((k_lidar_linearize<U>), grid, dim3(GLIO_K3_THREADS), 0, c->stream, \
+#define K3_LAUNCH_(U, MG) hipLaunchKernelGGL((k_lidar_linearize<U, MG>), grid, dim3(GLIO_K3_THREADS), 0, c->stream, \
                        c->d_pts, c->d_planes, c->d_scores, c->d_count, c->cap, c->d_x[0], c->d_x[1], \
                        c->d_status, use_status_cand, which, c->W, lc, c->d_lidar_partials)
+    if (marg) { K3_LAUNCH_(4, true); return; }
     switch (c->k3_unroll) {
-        case 1: K3_LAUNCH(1); break;
-        case 2: K3_LAUNCH(2); break;
-        case 8: K3_LAUNCH(8); break;
-        default: K3_LAUNCH(4); break;
+        case 1: K3_LAUNCH_(1, false); break;
+        case 2: K3_LAUNCH_(2, false); break;
+        case 8: K3_LAUNCH_(8, false); break;
+        default: K3_LAUNCH_(4, false); break;
     }
-#undef K3_LAUNCH
+#undef K3_LAUNCH_
 }

@@ -94,7 +94,11 @@ __device__ __host__ __forceinline__ int bp_stride(int n) { return ((n + 15) & ~1
 // Blocked left-looking Cholesky of the leading n x n block of the (n+1) x n row-major matrix A (lower
 // triangle), row n carried along (= forward substitution of the right-hand side).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool chol_left_looking(double* A, const int n, double* Bp, double* part, double* sD, int* flag, const int skip = 0) {
+// SEMI = true (marginalization): `dtol[k]` is the threshold below which pivot k counts as zero; such a column of L
+// (and its entry of the carried row) is set to zero -- the Cholesky form of the reference's eigenvalue truncation.
+template <bool SEMI = false>
+__device__ __forceinline__ bool chol_left_looking(double* A, const int n, double* Bp, double* part, double* sD, int* flag, const int skip = 0,
+                                                  const double* dtol = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ld = n, SB = bp_stride(n);
     const int li = lane & 15, lk = lane >> 4;
@@ -185,11 +189,15 @@ __device__ __forceinline__ bool chol_left_looking(double* A, const int n, double
 #pragma unroll
             for (int j = 0; j < TR_NB; ++j) a[j] = (lane < TR_NB) ? sD[lane * TR_PS + j] : 0.0;
             bool bad = false;
+            double tolv = 0.0;
+            if (SEMI) tolv = (lane < nb) ? dtol[k0 + lane] : 0.0;
 #pragma unroll
             for (int j = 0; j < TR_NB; ++j) {
                 double djj = readlane_d(a[j], j);
-                if (!(djj > 0.0) || !isfinite(djj)) { bad = true; djj = 1.0; }
-                const double rd = rsqrt(djj);
+                bool null_pivot = false;
+                if (SEMI) null_pivot = j < nb && djj <= readlane_d(tolv, j);
+                if (!null_pivot && (!(djj > 0.0) || !isfinite(djj))) { bad = true; djj = 1.0; }
+                const double rd = null_pivot ? 0.0 : rsqrt(djj);
                 const double d = djj * rd;
                 const double lij = (lane == j) ? d : a[j] * rd;
                 if (lane == j) sD[TR_NB * TR_PS + j] = rd;        // reciprocal pivots for the row solves
@@ -606,6 +614,139 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
     hipLaunchKernelGGL(k_tr_dogleg, dim3(1), dim3(TR_THREADS), 0, c->stream, a);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Marginalization (MarginalizationInfo::Marginalize, reference GLIO/src/MarginalizationFactor.cpp:128-202):
+// A, b over [dropped m = 15 | kept n] -> Amm^+ by a 15x15 symmetric eigen-decomposition with the reference's
+// eps = 1e-8 -> Schur complement S = Arr - Arm Amm^+ Amr, bs = br - Arm Amm^+ bm -> S = L L^T with the blocked
+// MFMA Cholesky; J0 = L^T, r0 = L^-1 bs.  (The reference takes J0 = sqrt(Lambda) V^T from a second
+// eigen-decomposition; any J0 with J0^T J0 = S and J0^T r0 = bs is the same prior for its only consumer,
+// MarginalizationFactor::Evaluate.  A rank-deficient S -- where the reference would truncate -- is reported.)
+// ------------------------------------------------------------------------------------------------
+__device__ void sym_eig15(double* A, double* w, double* V) {          // cyclic Jacobi, one lane
+    const int n = 15;
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        double off = 0, dg = 0;
+        for (int i = 0; i < n; ++i) { dg += A[i * n + i] * A[i * n + i]; for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j]; }
+        if (off <= 1e-30 * (dg + 1e-300)) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[p * n + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < n; ++k) { const double akp = A[k * n + p], akq = A[k * n + q]; A[k * n + p] = c * akp - sn * akq; A[k * n + q] = sn * akp + c * akq; }
+                for (int k = 0; k < n; ++k) { const double apk = A[p * n + k], aqk = A[q * n + k]; A[p * n + k] = c * apk - sn * aqk; A[q * n + k] = sn * apk + c * aqk; }
+                for (int k = 0; k < n; ++k) { const double vkp = V[k * n + p], vkq = V[k * n + q]; V[k * n + p] = c * vkp - sn * vkq; V[k * n + q] = sn * vkp + c * vkq; }
+            }
+    }
+    for (int i = 0; i < n; ++i) w[i] = A[i * n + i];
+}
+
+// A: pos x pos row-major (pos = 15 + n), b: pos.  Out: J0 (n x n row-major), r0 (n), *ok.
+__global__ __launch_bounds__(TR_THREADS) void k_marg_schur(const double* A, const double* b, const int n, double* Lwork, double* Twork,
+                                                           double* J0, double* r0, int* ok) {
+    const int tid = threadIdx.x, m = 15, pos = m + n;
+    double* Bp = reinterpret_cast<double*>(tr_lds);
+    double* part = Bp + TR_NB * bp_stride(n);
+    double* sD = part + 16 * 256;
+    double* ylds = sD + (TR_NB + 1) * TR_PS;
+    double* red = ylds + n + (n & 1);
+    int* flag = reinterpret_cast<int*>(red + 32);
+    double *Amm = part, *Vm = part + 225, *Ainv = part + 450, *wm = part + 675;     // free until the factorisation starts
+    if (tid < 225) { const int i = tid / 15, j = tid % 15; Amm[tid] = 0.5 * (A[(size_t)i * pos + j] + A[(size_t)j * pos + i]); }
+    __syncthreads();
+    if (tid == 0) sym_eig15(Amm, wm, Vm);
+    __syncthreads();
+    if (tid < 225) {
+        const int i = tid / 15, j = tid % 15;
+        double sacc = 0;
+        for (int k = 0; k < 15; ++k) sacc += Vm[i * 15 + k] * (wm[k] > 1e-8 ? 1.0 / wm[k] : 0.0) * Vm[j * 15 + k];
+        Ainv[tid] = sacc;
+    }
+    __syncthreads();
+    for (int e = tid; e < n * 15; e += TR_THREADS) {          // T = Arm Amm^+
+        const int i = e / 15, j = e % 15;
+        double sacc = 0;
+        for (int k = 0; k < 15; ++k) sacc += A[(size_t)(m + i) * pos + k] * Ainv[k * 15 + j];
+        Twork[e] = sacc;
+    }
+    __syncthreads();
+    for (int i = tid >> 6; i <= n; i += TR_WAVES) {            // S (lower) and the carried right-hand side
+        for (int j = tid & 63; j < n; j += 64) {
+            if (i < n) {
+                if (j > i) continue;
+                double sacc = A[(size_t)(m + i) * pos + m + j];
+                for (int k = 0; k < 15; ++k) sacc -= Twork[i * 15 + k] * A[(size_t)k * pos + m + j];
+                Lwork[(size_t)i * n + j] = sacc;
+            } else {
+                double sacc = b[m + j];
+                for (int k = 0; k < 15; ++k) sacc -= Twork[j * 15 + k] * b[k];
+                Lwork[(size_t)n * n + j] = sacc;
+            }
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += TR_THREADS) ylds[j] = fmax(1e-8, 1e-9 * Lwork[(size_t)j * n + j]);
+    __syncthreads();
+    const bool good = chol_left_looking<true>(Lwork, n, Bp, part, sD, flag, 0, ylds);
+    if (good) {
+        for (int i = tid >> 6; i < n; i += TR_WAVES)
+            for (int j = tid & 63; j < n; j += 64) J0[(size_t)i * n + j] = (j >= i) ? Lwork[(size_t)j * n + i] : 0.0;
+        for (int j = tid; j < n; j += TR_THREADS) r0[j] = Lwork[(size_t)n * n + j];
+    }
+    if (tid == 0) *ok = good ? 1 : 0;
+}
+
+// marginalization ordering: [T0 Q0 SB0 | T1 Q1 SB1 | T2 Q2 | ... ] -> index in the window state vector (15 per slot)
+__device__ __forceinline__ int marg_state_index(int mi) { return mi < 30 ? mi : 15 * (2 + (mi - 30) / 6) + (mi - 30) % 6; }
+
+struct MargAsmArgs {
+    int W, pos, np, has_prior, imu_edge0;
+    const double* lidar_blocks; const PairBlock* imu_blocks; const double* pH; const double* pg; const int* prior_index;
+    double* A; double* b;
+};
+__global__ __launch_bounds__(256) void k_marg_assemble(const MargAsmArgs a) {
+    const int pos = a.pos;
+    for (int r = blockIdx.x; r <= pos; r += gridDim.x) {
+        for (int c = threadIdx.x; c < pos; c += blockDim.x) {
+            const int sc_i = marg_state_index(c), sc = sc_i / 15, lc = sc_i % 15;
+            double sacc = 0;
+            if (r == pos) {          // b
+                if (lc < 6) sacc += a.lidar_blocks[sc * GLIO_LIDAR_ACC + 21 + lc];
+                if (a.imu_edge0 >= 0 && sc <= 1) sacc += a.imu_blocks[a.imu_edge0].g[15 * sc + lc];
+                if (a.has_prior) { const int pi = a.prior_index[sc_i]; if (pi >= 0) sacc += a.pg[pi]; }
+                a.b[c] = sacc;
+                continue;
+            }
+            const int sr_i = marg_state_index(r), sr = sr_i / 15, lr = sr_i % 15;
+            if (sr == sc && lr < 6 && lc < 6) {
+                const int i = lr <= lc ? lr : lc, j = lr <= lc ? lc : lr;
+                sacc += a.lidar_blocks[sr * GLIO_LIDAR_ACC + i * 6 - (i * (i - 1)) / 2 + (j - i)];
+            }
+            if (a.imu_edge0 >= 0 && sr <= 1 && sc <= 1) sacc += a.imu_blocks[a.imu_edge0].H[(15 * sr + lr) * GLIO_PAIR_DIM + 15 * sc + lc];
+            if (a.has_prior) { const int pi = a.prior_index[sr_i], pj = a.prior_index[sc_i]; if (pi >= 0 && pj >= 0) sacc += a.pH[(size_t)pi * a.np + pj]; }
+            a.A[(size_t)r * pos + c] = sacc;
+        }
+    }
+}
+
+int glio_launch_marginalize(glio_ctx* c, int imu_edge0, double** J0_dev, double** r0_dev, int** ok_dev) {
+    const int W = c->W, n = 6 * (W - 1) + 9, pos = 15 + n;
+    MargAsmArgs a;
+    a.W = W; a.pos = pos; a.np = c->prior_n; a.has_prior = c->prior_n > 0; a.imu_edge0 = imu_edge0;
+    a.lidar_blocks = c->d_lidar_blocks; a.imu_blocks = c->d_imu_blocks; a.pH = c->d_prior_H; a.pg = c->d_prior_g; a.prior_index = c->d_prior_index;
+    a.A = c->d_H[0]; a.b = c->d_g[0];
+    hipLaunchKernelGGL(k_marg_assemble, dim3(pos + 1), dim3(256), 0, c->stream, a);
+    int* d_ok = reinterpret_cast<int*>(c->d_vec + 9 * (size_t)c->n_max);
+    double* Twork = c->d_vec;                    // n x 15 <= 10 n_max doubles? n*15 <= 15W*... checked by the caller
+    hipLaunchKernelGGL(k_marg_schur, dim3(1), dim3(TR_THREADS), glio_tr_step_lds_bytes(n), c->stream, c->d_H[0], c->d_g[0], n, c->d_L, Twork,
+                       c->d_H[1], c->d_g[1], d_ok);
+    *J0_dev = c->d_H[1]; *r0_dev = c->d_g[1]; *ok_dev = d_ok;
+    return 0;
+}
+
 // ---- test hook: solve A x = b for a dense SPD n x n matrix with the in-kernel blocked Cholesky
 __global__ __launch_bounds__(TR_THREADS) void k_chol_test(double* L, int n, double* x, int* ok, int skip) {
     double* Bp = reinterpret_cast<double*>(tr_lds);
@@ -641,6 +782,7 @@ extern "C" int glio_debug_chol_solve(glio_ctx* c, int n, const double* A, const 
 void glio_tr_step_configure(size_t max_lds) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_tr_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_test), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_marg_schur), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
 }
 
 extern "C" int glio_debug_read_vec(glio_ctx* c, int k, double* out, int n) {

@@ -89,6 +89,19 @@ int glio_solve(glio_ctx* ctx, glio_state* state_inout, glio_summary* summary);
  * Exposed so that parity can be checked per linearisation (SURVEY.md section 7 "hard parts"). */
 int glio_linearize(glio_ctx* ctx, const glio_state* state, double* H, double* g, double* cost);
 
+/* ---- marginalization of the oldest keyframe.  Replaces the MarginalizationInfo block of
+ * Estimator.cpp:2462-2607 (addResidualBlockInfo x {prior, IMU(0,1), every LidarPlaneNormFactor with Huber},
+ * preMarginalize, marginalize, getParameterBlocks(addr_shift)) on the factors currently set in the context,
+ * evaluated at `state` (the solution of glio_solve).  Outputs, caller-allocated for n = 6 (W-1) + 9 and
+ * nb = 2 (W-1) + 1: lin_jac [n][n] row-major, lin_res [n], blocks (slot already shifted s -> s-1, kind, first
+ * column, x0[9]) -- exactly the fields of glio_prior for the NEXT window.  lin_jac^T lin_jac and
+ * lin_jac^T lin_res equal the reference's (it factors the Schur complement by eigen-decomposition, this
+ * library by Cholesky: a different square root of the same matrix).  GLIO_E_NUMERIC if the Schur
+ * complement is not positive definite. */
+int glio_marginalize(glio_ctx* ctx, const glio_state* state, double* lin_jac, double* lin_res,
+                     int32_t* blk_slot, int32_t* blk_kind, int32_t* blk_idx, double* blk_x0,
+                     int32_t* out_n, int32_t* out_n_blocks);
+
 /* ---- single-factor evaluators with the exact Evaluate() pointer convention, computed on the GPU.
  * A ceres::CostFunction shim is a five-line wrapper around these. */
 /* LidarPlaneNormFactor (LidarKeyframeFactor.h:73-122): parameters = {t[3], q[4]} */
