@@ -26,6 +26,23 @@ struct Error : std::runtime_error {
 };
 inline void check(int rc, const char* what) { if (rc != GLIO_OK) throw Error(what); }
 
+// The marginalization result: last_marginalization_info (linearized_jacobians / residuals, keep_block_*) and
+// last_marginalization_parameter_blocks (MarginalizationFactor.h, Estimator.cpp:2584-2606) with blocks named by
+// (slot, kind) -- already shifted to the NEXT window's slots.
+struct MarginalizationPrior {
+    int n = 0;
+    std::vector<double> linearized_jacobians, linearized_residuals, keep_block_data;
+    std::vector<int32_t> keep_block_slot, keep_block_kind, keep_block_idx;
+    glio_prior view() const {
+        glio_prior p;
+        p.n = n; p.n_blocks = (int32_t)keep_block_slot.size();
+        p.lin_jac = linearized_jacobians.data(); p.lin_res = linearized_residuals.data();
+        p.blk_slot = keep_block_slot.data(); p.blk_kind = keep_block_kind.data(); p.blk_idx = keep_block_idx.data();
+        p.blk_x0 = keep_block_data.data();
+        return p;
+    }
+};
+
 // ---- (1) factor shims ------------------------------------------------------------------------------
 // LidarPlaneNormFactor: residual 1, blocks {t[3], q[4]} (LidarKeyframeFactor.h:112-114)
 class LidarPlaneNormFactorHip {
@@ -97,6 +114,22 @@ public:
         for (int i = 0; i < W_; ++i)
             if (tmpQuat[4 * i] < 0) for (int k = 0; k < 4; ++k) tmpQuat[4 * i + k] = -tmpQuat[4 * i + k];   // unifyQuaternion
         return sum;
+    }
+
+    // Estimator.cpp:2462-2607: marginalize the oldest keyframe at the solved state (call after solve()); the
+    // result is what setMarginalizationPrior() takes for the next window.
+    MarginalizationPrior marginalize() {
+        const int n = 6 * (W_ - 1) + 9, nb = 2 * (W_ - 1) + 1;
+        MarginalizationPrior m;
+        m.linearized_jacobians.assign((size_t)n * n, 0.0); m.linearized_residuals.assign(n, 0.0); m.keep_block_data.assign((size_t)nb * 9, 0.0);
+        m.keep_block_slot.assign(nb, 0); m.keep_block_kind.assign(nb, 0); m.keep_block_idx.assign(nb, 0);
+        glio_state st;
+        st.trans = tmpTrans.data(); st.quat = tmpQuat.data(); st.speed_bias = tmpSpeedBias.data(); st.rcv_ddt = nullptr; st.n_ddt = 0;
+        int32_t on = 0, onb = 0;
+        check(glio_marginalize(ctx_, &st, m.linearized_jacobians.data(), m.linearized_residuals.data(), m.keep_block_slot.data(),
+                               m.keep_block_kind.data(), m.keep_block_idx.data(), m.keep_block_data.data(), &on, &onb), "glio_marginalize");
+        m.n = on;
+        return m;
     }
 
     // Estimator.cpp:2611-2726 write-back with the reference's sanity gates.  Ps/Vs: [W][3]; Qs: [W][4] (w,x,y,z,

@@ -43,6 +43,11 @@ int main(int argc, char** argv) {
         printf("kept %ld iterations %d termination %d cost %.17g -> %.17g\n", kept, sum.iterations, sum.termination, sum.initial_cost, sum.final_cost);
         for (int i = 0; i < W; ++i)
             printf("kf %d %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", i, Ps[3 * i], Ps[3 * i + 1], Ps[3 * i + 2], Qs[4 * i], Qs[4 * i + 1], Qs[4 * i + 2], Qs[4 * i + 3]);
+        const glio::MarginalizationPrior m = be.marginalize();
+        double tr = 0, rr = 0;       // trace(J0^T J0) = |J0|_F^2 and |r0|^2: invariant under the choice of square root
+        for (double v : m.linearized_jacobians) tr += v * v;
+        for (double v : m.linearized_residuals) rr += v * v;
+        printf("prior %d %zu %.17g %.17g\n", m.n, m.keep_block_slot.size(), tr, rr);
     } catch (const std::exception& e) {
         fprintf(stderr, "error: %s\n", e.what());
         return 1;

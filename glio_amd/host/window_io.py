@@ -41,5 +41,9 @@ def run_demo(path):
     out = subprocess.run([build_demo(), path], capture_output=True, text=True, check=True).stdout.splitlines()
     head = out[0].split()
     info = dict(kept=int(head[1]), iterations=int(head[3]), termination=int(head[5]), initial_cost=float(head[7]), final_cost=float(head[9]))
-    rows = np.array([[float(x) for x in ln.split()[2:]] for ln in out[1:]])
+    rows = np.array([[float(x) for x in ln.split()[2:]] for ln in out[1:] if ln.startswith("kf ")])
+    for ln in out[1:]:
+        if ln.startswith("prior "):
+            p = ln.split()
+            info["prior"] = dict(n=int(p[1]), n_blocks=int(p[2]), jac_fro2=float(p[3]), res2=float(p[4]))
     return info, rows[:, :3], rows[:, 3:]

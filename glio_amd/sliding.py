@@ -1,0 +1,63 @@
+"""Streaming driver: the per-keyframe call sequence of `Estimator::optimizeSlidingWindowWithLandMark`
+(reference GLIO/src/Estimator.cpp:2046-2736) over a stream of keyframes, written against a backend with the
+methods of `capi.Context` (set_map / associate / set_imu / set_prior / set_gnss / solve / marginalize).
+
+Per window: local map -> (:2056), state arrays (:2100-2127), prior (:2153-2158), IMU edges (:2182-2192),
+correspondences per slot from the pre-solve poses (:2198-2248, once per solve: quirk Q3), solve (:2424-2433),
+quaternion sign unification (:2439-2457), marginalization of slot 0 with the kept blocks renamed s -> s-1
+(:2462-2607).  The window then slides by one keyframe; the newest slot starts from the caller's prediction
+(the reference takes it from IMU propagation, outside this path).
+"""
+import numpy as np
+
+from . import capi
+from . import ctypes_types as T
+
+
+def unify_quaternions(state):
+    """Estimator.cpp:2439-2457: q and -q are the same rotation; the reference keeps w >= 0."""
+    flip = state.quat[:, 0] < 0
+    state.quat[flip] *= -1.0
+    return state
+
+
+class SlidingWindowDriver:
+    def __init__(self, backend, opts, lidar_pose=capi.lidar_pose):
+        self.be, self.opts, self.W = backend, opts, opts.window
+        self.lidar_pose = lidar_pose
+        self.prior = None
+        self.state = None
+        self.first = 0                   # index (into the keyframe stream) of slot 0
+        self.history = []
+
+    def start(self, init_states):
+        """init_states: WindowState of the first full window."""
+        self.state = init_states.copy()
+        self.state.n_ddt = 0
+        self.first = 0
+
+    def step(self, map_pts, scans, preints):
+        """One optimizeSlidingWindowWithLandMark() call.  scans[s] / preints[s] are those of window slot s
+        (preints[s] links slots s and s+1).  Returns (solved state, summary, correspondence counts)."""
+        be, W = self.be, self.W
+        be.set_map(map_pts)
+        counts = []
+        for s in range(W):
+            q2, t2 = self.lidar_pose(self.opts, self.state.quat[s], self.state.trans[s])
+            counts.append(be.associate(s, scans[s], q2, t2))
+        be.set_imu(preints)
+        be.set_prior(self.prior)
+        be.set_gnss(None, [], [])
+        sol, summ = be.solve(self.state)
+        unify_quaternions(sol)
+        self.prior = be.marginalize(sol)
+        self.state = sol
+        self.history.append((self.first, sol.copy(), summ, counts))
+        return sol, summ, counts
+
+    def slide(self, new_trans, new_quat, new_speed_bias):
+        """Drop slot 0, shift the rest down, append the prediction of the new keyframe."""
+        st = self.state
+        st.trans[:-1] = st.trans[1:].copy(); st.quat[:-1] = st.quat[1:].copy(); st.speed_bias[:-1] = st.speed_bias[1:].copy()
+        st.trans[-1], st.quat[-1], st.speed_bias[-1] = new_trans, new_quat, new_speed_bias
+        self.first += 1

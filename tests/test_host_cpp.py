@@ -40,4 +40,9 @@ def test_cpp_sequence_matches_python_sequence(tmp_path):
     assert np.abs(trans - sol.trans).max() < 1e-12
     qs = sol.quat * np.where(sol.quat[:, :1] < 0, -1.0, 1.0)
     assert np.abs(quat - qs / np.linalg.norm(qs, axis=1, keepdims=True)).max() < 1e-12
+    st = sol.copy(); st.quat = qs
+    out = ctx.marginalize(st)
+    assert info["prior"]["n"] == out["n"] and info["prior"]["n_blocks"] == len(out["blk_slot"])
+    assert np.isclose(info["prior"]["jac_fro2"], (out["lin_jac"] ** 2).sum(), rtol=1e-9)
+    assert np.isclose(info["prior"]["res2"], out["lin_res"] @ out["lin_res"], rtol=1e-7, atol=1e-12)
     ctx.close()
