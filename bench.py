@@ -107,10 +107,22 @@ def main():
     k3_ms = ctx.time_kernel(capi.KERNEL_LIDAR_LINEARIZE, 50)
     lin_ms = ctx.time_kernel(capi.KERNEL_FULL_LINEARIZE, 50)
     trs_ms = ctx.time_kernel(capi.KERNEL_TR_STEP, 20)
+    marg_ms = ctx.time_kernel(capi.KERNEL_MARGINALIZE, 20)
+    t0 = time.perf_counter(); ctx.marginalize(sol); marg_call_ms = 1e3 * (time.perf_counter() - t0)
     achieved = n_res * BYTES_PER_RESIDUAL / (k3_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": "k_lidar_linearize", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
                 "bytes_per_launch": n_res * BYTES_PER_RESIDUAL, "avg_launch_us": round(k3_ms * 1e3, 2)}
+
+    # HBM traffic per launch from the committed PMC pass of this same command (rocprofv3 --pmc FETCH_SIZE, x2 gfx950
+    # correction; scripts/gpu_pmc.sh writes the file) -- only quoted when it was taken on the same workload
+    try:
+        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "k3_pmc.json")))
+        if int(pmc.get("lidar_residuals", -1)) == n_res:
+            roofline["traffic"] = pmc["k3_hbm_bytes_per_launch"]
+            roofline["traffic_source"] = pmc.get("source")
+    except (OSError, ValueError, KeyError):
+        pass
 
     # ---- correspondence search (config C3), informational
     assoc = None
@@ -172,7 +184,8 @@ def main():
                    "lidar_residuals": n_res, "unknowns": 15 * win.W + state.n_ddt, "parallelism": f"replicas x{world}"},
         "iterations": int(summ.iterations), "ms_per_iteration": round(ms_per_step / max(1, int(summ.iterations)), 4),
         "termination": int(summ.termination),
-        "kernels_us": {"lidar_linearize": round(k3_ms * 1e3, 2), "full_linearize": round(lin_ms * 1e3, 2), "tr_step": round(trs_ms * 1e3, 2)},
+        "kernels_us": {"lidar_linearize": round(k3_ms * 1e3, 2), "full_linearize": round(lin_ms * 1e3, 2), "tr_step": round(trs_ms * 1e3, 2),
+                       "marginalize": round(marg_ms * 1e3, 2), "marginalize_call_incl_readback": round(marg_call_ms * 1e3, 1)},
         "roofline": roofline, "cpu_baseline": cpu, "pose_vs_oracle": pose_err, "association": assoc, "batch_stage": batch_info,
     }
     if cpu and "value" in cpu:

@@ -111,7 +111,7 @@ int glio_create(int device, const glio_opts* opts, glio_ctx** out) {
     }
     ALLOC(c->d_xout, nx * 8);
     ALLOC(c->d_lidar_partials, (size_t)W * GLIO_K3_MAX_BLOCKS_PER_KF * GLIO_LIDAR_ACC * 8);
-    c->k3_bpk = GLIO_K3_BLOCKS_PER_KF; c->k3_unroll = 4;
+    c->k3_bpk = GLIO_K3_BLOCKS_PER_KF; c->k3_unroll = 14;   /* 4 loads in flight, non-temporal (streamed once per launch) */
     { int per = 768 / W;   /* ~3 workgroups per CU measured best on MI355X (scripts/k3_sweep.py) */ if (per < 8) per = 8; if (per > GLIO_K3_MAX_BLOCKS_PER_KF) per = GLIO_K3_MAX_BLOCKS_PER_KF; c->k3_bpk = per; }
     ALLOC(c->d_lidar_blocks, 2 * (size_t)W * GLIO_LIDAR_ACC * 8);
     ALLOC(c->d_L, (size_t)(n_max + 1) * n_max * 8);
@@ -593,7 +593,7 @@ int glio_eval_imu(glio_ctx* c, const glio_preint* pre, double const* const* P, d
 }
 
 int glio_debug_set_k3(glio_ctx* c, int bpk, int unroll) {
-    if (!c || bpk < 1 || bpk > GLIO_K3_MAX_BLOCKS_PER_KF || (unroll != 1 && unroll != 2 && unroll != 4 && unroll != 8)) return GLIO_E_ARG;
+    if (!c || bpk < 1 || bpk > GLIO_K3_MAX_BLOCKS_PER_KF || (unroll != 1 && unroll != 2 && unroll != 4 && unroll != 8 && unroll != 12 && unroll != 14 && unroll != 18)) return GLIO_E_ARG;
     c->k3_bpk = bpk; c->k3_unroll = unroll;
     return GLIO_OK;
 }
@@ -620,6 +620,12 @@ int glio_time_kernel(glio_ctx* c, int which, int reps, float* ms_out) {
                 *c->h_status = st;
                 GLIO_HIP_CHECK(hipMemcpyAsync(c->d_status, c->h_status, sizeof st, hipMemcpyHostToDevice, c->stream));
                 glio_launch_tr_step(c, n_ddt);
+            } else if (which == GLIO_KERNEL_MARGINALIZE) {
+                if (c->W < 2) return GLIO_E_ARG;
+                double *dJ, *dr; int* dok;
+                glio_launch_lidar_linearize(c, 0, 0, 1);
+                glio_launch_small_factors(c, 0, 0, n_ddt, 1);
+                glio_launch_marginalize(c, extra_of(c)->imu_edge0, &dJ, &dr, &dok);
             } else return GLIO_E_ARG;
         }
         if (pass == 1) GLIO_HIP_CHECK(hipEventRecord(c->ev1, c->stream));

@@ -73,7 +73,14 @@ __device__ __forceinline__ void lidar_accumulate(const float4 p, const float4 pl
     acc[27] += 0.5 * rho;
 }
 
-template <int UNROLL, bool MARG>
+typedef float k3_f4 __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ float4 k3_load4(const float4* p) {
+    if (NT) { const k3_f4 v = __builtin_nontemporal_load(reinterpret_cast<const k3_f4*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+    return *p;
+}
+template <bool NT> __device__ __forceinline__ double k3_load1(const double* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+
+template <int UNROLL, bool MARG, bool NT = false>
 __global__ __launch_bounds__(GLIO_K3_THREADS) void k_lidar_linearize(
     const float4* __restrict__ pts, const float4* __restrict__ planes, const double* __restrict__ scores,
     const int* __restrict__ count, const int cap, const double* __restrict__ x0, const double* __restrict__ x1,
@@ -118,9 +125,9 @@ __global__ __launch_bounds__(GLIO_K3_THREADS) void k_lidar_linearize(
         double s[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
-            p[u] = P[i + u * stride];
-            pl[u] = Q[i + u * stride];
-            s[u] = S[i + u * stride];
+            p[u] = k3_load4<NT>(P + i + u * stride);
+            pl[u] = k3_load4<NT>(Q + i + u * stride);
+            s[u] = k3_load1<NT>(S + i + u * stride);
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) lidar_accumulate<MARG>(p[u], pl[u], s[u], M, t, lc.tlb, lc.huber, acc, lc.RlbT, q);
@@ -200,7 +207,7 @@ void glio_launch_lidar_linearize(glio_ctx* c, int use_status_cand, int which, in
     for (int k = 0; k < 3; ++k) lc.tlb[k] = c->opts.t_lb[k];
     lc.huber = c->opts.huber_delta;
     dim3 grid(c->k3_bpk, c->W);
-#define K3_LAUNCH_(U, MG) hipLaunchKernelGGL((k_lidar_linearize<U, MG>), grid, dim3(GLIO_K3_THREADS), 0, c->stream, \
+#define K3_LAUNCH_(U, MG, ...) hipLaunchKernelGGL((k_lidar_linearize<U, MG, ##__VA_ARGS__>), grid, dim3(GLIO_K3_THREADS), 0, c->stream, \
                        c->d_pts, c->d_planes, c->d_scores, c->d_count, c->cap, c->d_x[0], c->d_x[1], \
                        c->d_status, use_status_cand, which, c->W, lc, c->d_lidar_partials)
     if (marg) { K3_LAUNCH_(4, true); return; }
@@ -208,6 +215,9 @@ void glio_launch_lidar_linearize(glio_ctx* c, int use_status_cand, int which, in
         case 1: K3_LAUNCH_(1, false); break;
         case 2: K3_LAUNCH_(2, false); break;
         case 8: K3_LAUNCH_(8, false); break;
+        case 12: K3_LAUNCH_(2, false, true); break;
+        case 14: K3_LAUNCH_(4, false, true); break;
+        case 18: K3_LAUNCH_(8, false, true); break;
         default: K3_LAUNCH_(4, false); break;
     }
 #undef K3_LAUNCH_

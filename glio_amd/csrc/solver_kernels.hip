@@ -622,26 +622,49 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
 // eigen-decomposition; any J0 with J0^T J0 = S and J0^T r0 = bs is the same prior for its only consumer,
 // MarginalizationFactor::Evaluate.  A rank-deficient S -- where the reference would truncate -- is reported.)
 // ------------------------------------------------------------------------------------------------
-__device__ void sym_eig15(double* A, double* w, double* V) {          // cyclic Jacobi, one lane
-    const int n = 15;
-    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 40; ++sweep) {
+// Symmetric eigen-decomposition of a 16 x 16 matrix (15 x 15 padded with a zero row/column) by ONE wavefront:
+// parallel cyclic Jacobi with the round-robin ordering -- every round applies 8 disjoint rotations at once,
+// A' = J^T A J and V' = V J, each lane producing 4 entries of A' and of V' from the previous buffers.
+// buf: 2 x (256 A + 256 V) doubles + 48 doubles of per-index rotation data.  Result: eigenvalues on the diagonal
+// of the returned A buffer, eigenvectors in the columns of the returned V buffer.
+__device__ __forceinline__ int jacobi16_wave(double* buf, const int lane) {
+    double* coef = buf + 1024;                     // alpha[16], beta[16]
+    int* partner = reinterpret_cast<int*>(coef + 32);
+    int cur = 0;
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        const double* A0 = buf + cur * 512;
         double off = 0, dg = 0;
-        for (int i = 0; i < n; ++i) { dg += A[i * n + i] * A[i * n + i]; for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j]; }
+        for (int e = lane; e < 256; e += 64) { const int i = e >> 4, j = e & 15; const double v = A0[e]; if (i == j) dg += v * v; else off += v * v; }
+        off = wave_sum(off); dg = wave_sum(dg);
         if (off <= 1e-30 * (dg + 1e-300)) break;
-        for (int p = 0; p < n - 1; ++p)
-            for (int q = p + 1; q < n; ++q) {
-                const double apq = A[p * n + q];
-                if (apq == 0.0) continue;
-                const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
-                for (int k = 0; k < n; ++k) { const double akp = A[k * n + p], akq = A[k * n + q]; A[k * n + p] = c * akp - sn * akq; A[k * n + q] = sn * akp + c * akq; }
-                for (int k = 0; k < n; ++k) { const double apk = A[p * n + k], aqk = A[q * n + k]; A[p * n + k] = c * apk - sn * aqk; A[q * n + k] = sn * apk + c * aqk; }
-                for (int k = 0; k < n; ++k) { const double vkp = V[k * n + p], vkq = V[k * n + q]; V[k * n + p] = c * vkp - sn * vkq; V[k * n + q] = sn * vkp + c * vkq; }
+        for (int r = 0; r < 15; ++r) {
+            double* A = buf + cur * 512; double* V = A + 256;
+            double* An = buf + (cur ^ 1) * 512; double* Vn = An + 256;
+            if (lane < 8) {
+                const int p0 = lane == 0 ? 15 : (r + lane) % 15, q0 = lane == 0 ? r : (r - lane + 15) % 15;
+                const int p = p0 < q0 ? p0 : q0, q = p0 < q0 ? q0 : p0;
+                const double apq = A[p * 16 + q];
+                double c = 1.0, sn = 0.0;
+                if (apq != 0.0) {
+                    const double theta = (A[q * 16 + q] - A[p * 16 + p]) / (2.0 * apq);
+                    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    c = 1.0 / sqrt(t * t + 1.0); sn = t * c;
+                }
+                coef[p] = c; coef[16 + p] = -sn; partner[p] = q;
+                coef[q] = c; coef[16 + q] = sn; partner[q] = p;
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int e = lane; e < 256; e += 64) {
+                const int i = e >> 4, j = e & 15, pi = partner[i], pj = partner[j];
+                const double ai = coef[i], bi = coef[16 + i], aj = coef[j], bj = coef[16 + j];
+                An[e] = ai * (aj * A[i * 16 + j] + bj * A[i * 16 + pj]) + bi * (aj * A[pi * 16 + j] + bj * A[pi * 16 + pj]);
+                Vn[e] = aj * V[i * 16 + j] + bj * V[i * 16 + pj];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            cur ^= 1;
+        }
     }
-    for (int i = 0; i < n; ++i) w[i] = A[i * n + i];
+    return cur;
 }
 
 // A: pos x pos row-major (pos = 15 + n), b: pos.  Out: J0 (n x n row-major), r0 (n), *ok.
@@ -654,15 +677,22 @@ __global__ __launch_bounds__(TR_THREADS) void k_marg_schur(const double* A, cons
     double* ylds = sD + (TR_NB + 1) * TR_PS;
     double* red = ylds + n + (n & 1);
     int* flag = reinterpret_cast<int*>(red + 32);
-    double *Amm = part, *Vm = part + 225, *Ainv = part + 450, *wm = part + 675;     // free until the factorisation starts
-    if (tid < 225) { const int i = tid / 15, j = tid % 15; Amm[tid] = 0.5 * (A[(size_t)i * pos + j] + A[(size_t)j * pos + i]); }
+    double* ebuf = part;                       // free until the factorisation starts: 2 x (A, V) 16 x 16 + rotation data
+    double* Ainv = part + 1100;
+    int& ecur = flag[2];
+    if (tid < 256) {
+        const int i = tid >> 4, j = tid & 15;
+        ebuf[tid] = (i < 15 && j < 15) ? 0.5 * (A[(size_t)i * pos + j] + A[(size_t)j * pos + i]) : 0.0;
+        ebuf[256 + tid] = (i == j) ? 1.0 : 0.0;
+    }
     __syncthreads();
-    if (tid == 0) sym_eig15(Amm, wm, Vm);
+    if (tid < 64) { const int cur = jacobi16_wave(ebuf, tid); if (tid == 0) ecur = cur; }
     __syncthreads();
     if (tid < 225) {
+        const double* Am = ebuf + ecur * 512; const double* Vm = Am + 256;
         const int i = tid / 15, j = tid % 15;
         double sacc = 0;
-        for (int k = 0; k < 15; ++k) sacc += Vm[i * 15 + k] * (wm[k] > 1e-8 ? 1.0 / wm[k] : 0.0) * Vm[j * 15 + k];
+        for (int k = 0; k < 16; ++k) { const double w = Am[k * 17]; sacc += Vm[i * 16 + k] * (w > 1e-8 ? 1.0 / w : 0.0) * Vm[j * 16 + k]; }
         Ainv[tid] = sacc;
     }
     __syncthreads();
