@@ -117,12 +117,24 @@ int glio_create(int device, const glio_opts* opts, glio_ctx** out) {
     ALLOC(c->d_L, (size_t)(n_max + 1) * n_max * 8);
     ALLOC(c->d_vec, (size_t)10 * n_max * 8);
     ALLOC(c->d_status, sizeof(SolverStatus));
+    {   // structured solver
+        ArrowDev& ar = c->arrow;
+        ar.mode = 1; ar.gnss_ok = 1; ar.prior_ok = 1; ar.max_epoch = -1;
+        ALLOC(ar.d_ep_slots, (size_t)ne * sizeof(int2)); ALLOC(ar.d_ep_off, (W + 1) * 4); ALLOC(ar.d_ep_list, 2 * (size_t)ne * 4);
+        GLIO_HIP_CHECK(hipMemsetAsync(ar.d_ep_slots, 0xff, (size_t)ne * sizeof(int2), c->stream));
+        GLIO_HIP_CHECK(hipMemsetAsync(ar.d_ep_off, 0, (W + 1) * 4, c->stream));
+        ALLOC(ar.d_Y, (size_t)(c->n_ddt_max + 9 * W) * (6 * W + 2) * 8);
+        ALLOC(ar.d_Lblk, (size_t)W * 190 * 8); ALLOC(ar.d_Sp, (size_t)(6 * W + 1) * 6 * W * 8);
+        ALLOC(ar.d_z, (size_t)n_max * 8); ALLOC(ar.d_flag, 4);
+        GLIO_HIP_CHECK(hipMemsetAsync(ar.d_flag, 0, 4, c->stream));
+        GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
     GLIO_HIP_CHECK(hipHostMalloc((void**)&c->h_status, sizeof(SolverStatus)));
     GLIO_HIP_CHECK(hipHostMalloc((void**)&c->h_xbuf, (size_t)nx * 8));
     GLIO_HIP_CHECK(hipEventCreate(&c->ev0)); GLIO_HIP_CHECK(hipEventCreate(&c->ev1));
     CtxExtra* ex = new CtxExtra();
-    ex->imu_edge0 = -1;
     memset(ex, 0, sizeof *ex);
+    ex->imu_edge0 = -1;
     ALLOC(ex->gx.d_runs, (size_t)std::max(1, c->n_ddt_max) * sizeof(DopRun));
     ALLOC(ex->gx.d_prior_colblk, npmax * 4);
     ALLOC(ex->d_eval_params, 64 * 8); ALLOC(ex->d_eval_out, (15 + 15 * 32) * 8); ALLOC(ex->d_eval_edge, sizeof(ImuEdgeDev));
@@ -143,7 +155,8 @@ void glio_destroy(glio_ctx* c) {
                     c->d_ddt_blocks, c->d_dd, c->d_dop, c->d_prior_J0, c->d_prior_A0, c->d_prior_r0, c->d_prior_x0, c->d_prior_slot,
                     c->d_prior_kind, c->d_prior_idx, c->d_prior_index, c->d_prior_H, c->d_prior_g, c->d_prior_cost, c->d_prior_work,
                     c->d_x[0], c->d_x[1], c->d_H[0], c->d_H[1], c->d_g[0], c->d_g[1], c->d_cost[0], c->d_cost[1], c->d_xout,
-                    c->d_lidar_partials, c->d_lidar_blocks, c->d_L, c->d_vec, c->d_status};
+                    c->d_lidar_partials, c->d_lidar_blocks, c->d_L, c->d_vec, c->d_status,
+                    c->arrow.d_ep_slots, c->arrow.d_ep_off, c->arrow.d_ep_list, c->arrow.d_Y, c->arrow.d_Lblk, c->arrow.d_Sp, c->arrow.d_z, c->arrow.d_flag};
     for (void* p : ptrs) if (p) hipFree(p);
     hipHostFree(c->h_status); hipHostFree(c->h_xbuf);
     hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
@@ -304,7 +317,7 @@ int glio_set_imu(glio_ctx* c, int n_edges, const glio_preint* edges, const int32
 int glio_set_prior(glio_ctx* c, const glio_prior* p) {
     if (!c) return GLIO_E_ARG;
     GLIO_HIP_CHECK(hipSetDevice(c->device));
-    if (!p || p->n <= 0) { c->prior_n = 0; c->prior_nb = 0; return GLIO_OK; }
+    if (!p || p->n <= 0) { c->prior_n = 0; c->prior_nb = 0; c->arrow.prior_ok = 1; return GLIO_OK; }
     const int np = p->n, nb = p->n_blocks, W = c->W;
     if (np > 6 * W + 9 || nb > 2 * W + 1) { glio_set_error("prior too large for window"); return GLIO_E_ARG; }
     std::vector<int> index(15 * W, -1), colblk(np, -1);
@@ -316,6 +329,7 @@ int glio_set_prior(glio_ctx* c, const glio_prior* p) {
         for (int j = 0; j < ls; ++j) { index[off + j] = idx + j; colblk[idx + j] = b; }
     }
     for (int j = 0; j < np; ++j) if (colblk[j] < 0) { glio_set_error("prior column %d not covered by a block", j); return GLIO_E_ARG; }
+    { int nsb = 0; for (int b = 0; b < nb; ++b) nsb += p->blk_kind[b] == GLIO_BLK_SPEEDBIAS; c->arrow.prior_ok = nsb <= 1; }   // two speed-bias blocks would couple the chain densely
     GnssDevExtra* ex = glio_extra(c);
     GLIO_HIP_CHECK(hipMemcpy(c->d_prior_J0, p->lin_jac, (size_t)np * np * 8, hipMemcpyHostToDevice));
     GLIO_HIP_CHECK(hipMemcpy(c->d_prior_r0, p->lin_res, np * 8, hipMemcpyHostToDevice));
@@ -408,6 +422,25 @@ int glio_set_gnss(glio_ctx* c, const glio_gnss_frame* frame, int n_dd, const gli
     if (!sdd.empty()) GLIO_HIP_CHECK(hipMemcpy(c->d_dd, sdd.data(), sdd.size() * sizeof(glio_dd_psr), hipMemcpyHostToDevice));
     if (!sdop.empty()) GLIO_HIP_CHECK(hipMemcpy(c->d_dop, sdop.data(), sdop.size() * sizeof(glio_doppler), hipMemcpyHostToDevice));
     if (!groups.empty()) GLIO_HIP_CHECK(hipMemcpy(c->d_groups, groups.data(), groups.size() * sizeof(GnssGroup), hipMemcpyHostToDevice));
+    {   // structure tables of the arrow solver: which keyframe slots each clock-drift epoch couples
+        const int ne = std::max(1, c->n_ddt_max);
+        std::vector<int2> es(ne, make_int2(-1, -1));
+        std::vector<std::vector<int>> per(W);
+        c->arrow.gnss_ok = 1; c->arrow.max_epoch = -1;
+        for (auto& r : runs) {
+            c->arrow.max_epoch = std::max(c->arrow.max_epoch, r.epoch);
+            const GnssGroup& g = groups[r.group];
+            const int lo = std::min(g.slot_i, g.slot_j), hi = std::max(g.slot_i, g.slot_j);
+            es[r.epoch] = make_int2(lo, hi);
+            per[lo].push_back(r.epoch); per[hi].push_back(r.epoch);
+            if (hi - lo != 1) c->arrow.gnss_ok = 0;       // velocity coupling between non-adjacent keyframes: chain is not tridiagonal
+        }
+        std::vector<int> off(W + 1, 0), list;
+        for (int i = 0; i < W; ++i) { off[i + 1] = off[i] + (int)per[i].size(); list.insert(list.end(), per[i].begin(), per[i].end()); }
+        GLIO_HIP_CHECK(hipMemcpy(c->arrow.d_ep_slots, es.data(), (size_t)ne * sizeof(int2), hipMemcpyHostToDevice));
+        GLIO_HIP_CHECK(hipMemcpy(c->arrow.d_ep_off, off.data(), (W + 1) * 4, hipMemcpyHostToDevice));
+        if (!list.empty()) GLIO_HIP_CHECK(hipMemcpy(c->arrow.d_ep_list, list.data(), list.size() * 4, hipMemcpyHostToDevice));
+    }
     GnssDevExtra* ex = glio_extra(c);
     if (!runs.empty()) GLIO_HIP_CHECK(hipMemcpy(ex->d_runs, runs.data(), runs.size() * sizeof(DopRun), hipMemcpyHostToDevice));
     ex->n_runs = (int)runs.size();
@@ -592,6 +625,12 @@ int glio_eval_imu(glio_ctx* c, const glio_preint* pre, double const* const* P, d
     return GLIO_OK;
 }
 
+// solver selection for tests: 0 = dense Cholesky only, 1 = structured (arrow) factorisation when the graph permits
+int glio_debug_set_solver(glio_ctx* c, int mode) {
+    if (!c || mode < 0 || mode > 1) return GLIO_E_ARG;
+    c->arrow.mode = mode;
+    return GLIO_OK;
+}
 int glio_debug_set_k3(glio_ctx* c, int bpk, int unroll) {
     if (!c || bpk < 1 || bpk > GLIO_K3_MAX_BLOCKS_PER_KF || (unroll != 1 && unroll != 2 && unroll != 4 && unroll != 8 && unroll != 12 && unroll != 14 && unroll != 18)) return GLIO_E_ARG;
     c->k3_bpk = bpk; c->k3_unroll = unroll;

@@ -74,6 +74,21 @@ struct SolverStatus {
     double mu_used;       // mu of the factorisation behind the stored Gauss-Newton step
 };
 
+// Structured ("arrow") linear solver of the trust-region step (solver_kernels.hip): buffers + structure tables
+struct ArrowDev {
+    int mode;                 // 1 = use when the structure permits (default), 0 = dense factorisation only
+    int gnss_ok, prior_ok;    // structure checks made when the factors are set
+    int max_epoch;            // largest clock-drift epoch referenced by a Doppler factor (-1: none)
+    int2* d_ep_slots;         // [n_ddt_max] keyframe slots (lo, hi) coupled by clock-drift epoch e, (-1,-1) if unused
+    int* d_ep_off;            // [W+1] CSR over slots: epochs touching slot i
+    int* d_ep_list;           // [2 n_ddt_max]
+    double* d_Y;              // (n_ddt + 9W) x (6W+2): L^-1 [M_ep | b_e]
+    double* d_Lblk;           // [W][190] factored speed-bias chain: L_ii (9x9), L_{i+1,i} (9x9), row stride 10, 9 reciprocal pivots
+    double* d_Sp;             // (6W+1) x 6W pose Schur complement + carried right-hand side
+    double* d_z;              // [n] solution in elimination order
+    int* d_flag;              // 0 running, 1 breakdown, 2 solved
+};
+
 struct glio_ctx {
     glio_opts opts;
     int device;
@@ -131,6 +146,7 @@ struct glio_ctx {
     int have_factors;
     int last_n_ddt;
     int k3_bpk, k3_unroll;        // K3 launch geometry (tunable, glio_debug_set_k3)
+    ArrowDev arrow;
 };
 
 static inline int glio_x_size(int W, int n_ddt) { return 16 * W + n_ddt; }

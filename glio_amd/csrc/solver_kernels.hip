@@ -46,6 +46,7 @@ struct TrArgs {
     const double* H0; const double* H1; const double* g0; const double* g1; const double* c0; const double* c1;
     double* L; double* vec; int vstride;
     SolverStatus* status;
+    int* arrow_flag; const double* arrow_z;      // structured solver result (null = dense only)
 };
 
 // workspace vectors (global, persist across the launches of one solve)
@@ -57,6 +58,15 @@ struct TrArgs {
 #define V_W(a) ((a).vec + 5 * (a).vstride)      /* scale * step = delta              */
 #define V_U(a) ((a).vec + 6 * (a).vstride)      /* u = S g~ / D (Cauchy direction)   */
 #define V_T(a) ((a).vec + 7 * (a).vstride)      /* t = H u                           */
+
+// Elimination ordering of the linear system: [clock-drift epochs (diagonal block) | speed-bias blocks, 9 per keyframe
+// (block tridiagonal: only an IMU / Doppler edge couples neighbours) | poses, 6 per keyframe (dense through the prior)].
+// Natural index (15 per keyframe: t q v ba bg, then the epochs) -> position in the factored matrix.
+__device__ __forceinline__ int tr_perm(const int i, const int W, const int nd) {
+    if (i >= 15 * W) return i - 15 * W;
+    const int sl = i / 15, l = i - 15 * sl;
+    return l < 6 ? nd + 9 * W + 6 * sl + l : nd + 9 * sl + (l - 6);
+}
 
 __device__ __forceinline__ double block_sum(double v, double* red) {
     v = wave_sum(v);
@@ -407,17 +417,19 @@ __global__ __launch_bounds__(256) void k_tr_scale(const TrArgs a) {
     const int n = a.n;
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (a.arrow_flag && blockIdx.x == 0 && threadIdx.x == 0) *a.arrow_flag = 0;
     if (i > n) return;
     const double* H = st->cur ? a.H1 : a.H0;
     const double* g = st->cur ? a.g1 : a.g0;
     const double* scale = V_SCALE(a); const double* diag = V_DIAG(a); const double* u = V_U(a);
+    const int W = a.W, nd = a.n_ddt;
     if (i == n) {                      // right-hand side S g as the carried row
-        for (int j = lane; j < n; j += 64) a.L[(size_t)n * n + j] = scale[j] * g[j];
+        for (int j = lane; j < n; j += 64) a.L[(size_t)n * n + tr_perm(j, W, nd)] = scale[j] * g[j];
         return;
     }
     const double mu = st->mu, si = scale[i];
     const double* hrow = H + (size_t)i * n;
-    double* lrow = a.L + (size_t)i * n;
+    const int pi = tr_perm(i, W, nd);
     double s = 0;
     for (int j = lane; j < n; j += 64) {
         const double h = hrow[j];
@@ -425,7 +437,8 @@ __global__ __launch_bounds__(256) void k_tr_scale(const TrArgs a) {
         if (j <= i) {
             double v = si * h * scale[j];
             if (i == j) v += mu * diag[i] * diag[i];
-            lrow[j] = v;
+            const int pj = tr_perm(j, W, nd);
+            a.L[(size_t)max(pi, pj) * n + min(pi, pj)] = v;
         }
     }
     s = wave_sum(s);
@@ -458,21 +471,27 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_factor(const TrArgs a) {
     if (tid == 0) { a.status->alpha = q2 / p; *smu = a.status->mu; }
     __syncthreads();
     bool solved = false;
-    for (int attempt = 0; attempt < 12; ++attempt) {
+    if (a.arrow_flag && *a.arrow_flag == 2) {          // the structured factorisation already solved this system
+        for (int j = tid; j < n; j += TR_THREADS) ylds[j] = a.arrow_z[j];
+        __syncthreads();
+        solved = true;
+    }
+    for (int attempt = 0; attempt < 12 && !solved; ++attempt) {
         const double mu = *smu;
         if (!(mu < 1.0)) break;
         if (attempt > 0) {             // breakdown: rebuild S H S + mu D^2 with the larger mu (rare)
             for (int i = tid >> 6; i < n; i += TR_WAVES) {
                 const double si = scale[i];
                 const double* hrow = H + (size_t)i * n;
-                double* lrow = a.L + (size_t)i * n;
+                const int pi = tr_perm(i, a.W, a.n_ddt);
                 for (int j = tid & 63; j <= i; j += 64) {
                     double v = si * hrow[j] * scale[j];
                     if (i == j) v += mu * diag[i] * diag[i];
-                    lrow[j] = v;
+                    const int pj = tr_perm(j, a.W, a.n_ddt);
+                    a.L[(size_t)max(pi, pj) * n + min(pi, pj)] = v;
                 }
             }
-            for (int j = tid; j < n; j += TR_THREADS) a.L[(size_t)n * n + j] = scale[j] * g[j];
+            for (int j = tid; j < n; j += TR_THREADS) a.L[(size_t)n * n + tr_perm(j, a.W, a.n_ddt)] = scale[j] * g[j];
             __syncthreads();
         }
         const bool ok = chol_left_looking(a.L, n, Bp, part, sD, flag);
@@ -492,7 +511,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_factor(const TrArgs a) {
     }
     if (solved) {
         double* gn = V_GN(a); double* y = V_Y(a);
-        for (int i = tid; i < n; i += TR_THREADS) { y[i] = ylds[i]; gn[i] = -diag[i] * ylds[i]; }
+        for (int i = tid; i < n; i += TR_THREADS) { const double yi = ylds[tr_perm(i, a.W, a.n_ddt)]; y[i] = yi; gn[i] = -diag[i] * yi; }
     }
     __syncthreads();
     if (tid == 0) {
@@ -588,6 +607,279 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_dogleg(const TrArgs a) {
     if (tid == 0) *a.status = s;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// K7c'  structured ("arrow") factorisation of M = S H S + mu D^2 in the elimination order of tr_perm():
+//   [ d: clock-drift epochs, diagonal | s: speed-bias blocks, block tridiagonal | p: poses, dense ]
+// Block Cholesky with the same pivots a dense Cholesky in this order would meet, but only the non-zero
+// structure is touched and the only long dense factorisation left is the 6W x 6W pose block:
+//   k_arrow_forward (one workgroup per 16 columns of [M_ep | b_e]):  L_dd = sqrt(diag); the speed-bias chain
+//       L_ii, L_{i+1,i} (9x9 blocks, wavefront 0, register/readlane factorisation of the 18x9 panel) and, one
+//       block behind it, Y = L_ee^-1 [M_ep | b_e] for the workgroup's columns (wavefront 1) -- the chain is
+//       recomputed by every workgroup (cheap) so that no grid synchronisation is needed;
+//   k_arrow_schur   (16x16 tiles):  S_pp = M_pp - Y^T Y, b_p' = b_p - Y^T y_e;
+//   k_arrow_solve   (one workgroup):  blocked MFMA Cholesky of S_pp (chol_left_looking), back substitution
+//       through p, the speed-bias chain and the epochs.
+// Any non-positive pivot raises the flag and k_tr_factor falls back to the dense factorisation (with its mu
+// retries), so the outcome is the dense one in every case.
+// ------------------------------------------------------------------------------------------------
+struct ArrowArgs {
+    int W, n, nd, np, K, ldY;
+    const double* A;
+    const int2* ep_slots; const int* ep_off; const int* ep_list;
+    double* Y; double* Lblk; double* Sp; double* z;
+    int* flag;
+    const SolverStatus* status;
+};
+#define AR_LB 190          /* one chain block in LDS / global: 18 rows x stride 10, then 9 reciprocal pivots (+1 pad) */
+#define AR_YS 17           /* row stride of the 16-column Y slices in LDS */
+
+__host__ __device__ __forceinline__ size_t arrow_forward_lds_doubles(int W, int nd) {
+    return (size_t)(nd + (nd & 1)) + (size_t)nd * AR_YS + (size_t)nd * 18 + (size_t)9 * W * AR_YS + 3 * AR_LB + 2;
+}
+
+__global__ __launch_bounds__(256) void k_arrow_forward(const ArrowArgs a) {
+    if (a.status->done || a.status->reuse) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int W = a.W, n = a.n, nd = a.nd, np = a.np;
+    const int c0 = blockIdx.x * 16, ncol = min(16, np + 1 - c0);
+    const double* A = a.A;
+    const double* rhs = A + (size_t)n * n;
+    double* rd = reinterpret_cast<double*>(tr_lds);
+    double* Yd = rd + nd + (nd & 1);
+    double* Vs = Yd + (size_t)nd * AR_YS;
+    double* Ys = Vs + (size_t)nd * 18;
+    double* Lb = Ys + (size_t)9 * W * AR_YS;
+    int* bad_lds = reinterpret_cast<int*>(Lb + 3 * AR_LB);
+    if (tid == 0) *bad_lds = 0;
+    __syncthreads();
+    // (1) epochs: pivots
+    for (int e = tid; e < nd; e += 256) {
+        const double m = A[(size_t)e * n + e];
+        if (!(m > 0.0) || !isfinite(m)) { *bad_lds = 1; rd[e] = 0.0; } else rd[e] = rsqrt(m);
+    }
+    __syncthreads();
+    // (2) epoch rows of Y for this workgroup's columns, and the epoch columns of the speed-bias rows
+    for (int idx = tid; idx < nd * 16; idx += 256) {
+        const int c = idx / nd, e = idx - c * nd, col = c0 + c;
+        double v = 0.0;
+        if (c < ncol) v = (col < np ? A[(size_t)(nd + 9 * W + col) * n + e] : rhs[e]) * rd[e];
+        Yd[e * AR_YS + c] = v;
+    }
+    for (int idx = tid; idx < nd * 18; idx += 256) {
+        const int e = idx / 18, q = idx - e * 18;
+        const int2 sl = a.ep_slots[e];
+        const int s1 = q < 9 ? sl.x : sl.y;
+        Vs[idx] = s1 >= 0 ? A[(size_t)(nd + 9 * s1 + (q < 9 ? q : q - 9)) * n + e] * rd[e] : 0.0;
+    }
+    __syncthreads();
+    // (3) speed-bias rows of [M_ep | b_e] minus the epoch contribution
+    for (int idx = tid; idx < 9 * W * 16; idx += 256) {
+        const int c = idx / (9 * W), k = idx - c * 9 * W, col = c0 + c;
+        double v = 0.0;
+        if (c < ncol) {
+            v = col < np ? A[(size_t)(nd + 9 * W + col) * n + nd + k] : rhs[nd + k];
+            const int sl = k / 9, q = k - 9 * sl;
+            for (int t = a.ep_off[sl]; t < a.ep_off[sl + 1]; ++t) {
+                const int e = a.ep_list[t];
+                v -= Vs[e * 18 + (a.ep_slots[e].x == sl ? 0 : 9) + q] * Yd[e * AR_YS + c];
+            }
+        }
+        Ys[k * AR_YS + c] = v;
+    }
+    __syncthreads();
+    // (4) the chain: wavefront 0 factors block `it`, wavefront 1 forward-substitutes block `it-1`
+    for (int it = 0; it <= W; ++it) {
+        if (wv == 0 && it < W) {
+            const int i = it, r = lane;
+            const bool rowD = r < 9, rowB = r >= 9 && r < 18 && i + 1 < W;
+            double av[9];
+            const size_t grow = rowD ? (size_t)(nd + 9 * i + r) : (size_t)(nd + 9 * (i + 1) + (r - 9));
+#pragma unroll
+            for (int j = 0; j < 9; ++j) av[j] = (rowD && j <= r) || rowB ? A[grow * n + nd + 9 * i + j] : 0.0;
+            for (int t = a.ep_off[i]; t < a.ep_off[i + 1]; ++t) {
+                const int e = a.ep_list[t];
+                const int2 sl = a.ep_slots[e];
+                const int side = sl.x == i ? 0 : 9, other = sl.x == i ? sl.y : sl.x;
+                double mine = 0.0;
+                if (rowD) mine = Vs[e * 18 + side + r];
+                else if (rowB && other == i + 1) mine = Vs[e * 18 + (9 - side) + (r - 9)];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) av[j] -= mine * Vs[e * 18 + side + j];
+            }
+            if (i > 0 && rowD) {
+                const double* Lp = Lb + ((i - 1) % 3) * AR_LB + 90;      // L_{i,i-1}: rows 9..17 of the previous block
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) sacc += Lp[r * 10 + k] * Lp[j * 10 + k];
+                    av[j] -= sacc;
+                }
+            }
+            bool bad = false;
+            double rpv = 0.0;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                double djj = readlane_d(av[j], j);
+                if (!(djj > 0.0) || !isfinite(djj)) { bad = true; djj = 1.0; }
+                const double rdj = rsqrt(djj);
+                const double lij = (lane == j) ? djj * rdj : av[j] * rdj;
+                if (lane == j) rpv = rdj;
+                av[j] = lij;
+#pragma unroll
+                for (int c = j + 1; c < 9; ++c) {
+                    const double lcj = readlane_d(lij, c);
+                    if (lane >= c) av[c] -= lij * lcj;
+                }
+            }
+            double* Lc = Lb + (i % 3) * AR_LB;
+            double* Lg = a.Lblk + (size_t)i * AR_LB;
+            if (r < 18) {
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    const double v = (rowD && j > r) || (!rowD && !rowB) ? 0.0 : av[j];
+                    Lc[r * 10 + j] = v;
+                    if (blockIdx.x == 0) Lg[r * 10 + j] = v;
+                }
+                if (r < 9) { Lc[180 + r] = rpv; if (blockIdx.x == 0) Lg[180 + r] = rpv; }
+            }
+            if (bad && lane == 0) *bad_lds = 1;
+        } else if (wv == 1 && it >= 1 && lane < 16) {
+            const int i = it - 1, c = lane;
+            double tv[9];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) tv[r] = Ys[(9 * i + r) * AR_YS + c];
+            if (i > 0) {
+                const double* Lp = Lb + ((i - 1) % 3) * AR_LB + 90;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const double yk = Ys[(9 * (i - 1) + k) * AR_YS + c];
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) tv[r] -= Lp[r * 10 + k] * yk;
+                }
+            }
+            const double* Lc = Lb + (i % 3) * AR_LB;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+#pragma unroll
+                for (int k = 0; k < r; ++k) tv[r] -= Lc[r * 10 + k] * tv[k];
+                tv[r] *= Lc[180 + r];
+            }
+#pragma unroll
+            for (int r = 0; r < 9; ++r) Ys[(9 * i + r) * AR_YS + c] = tv[r];
+        }
+        __syncthreads();
+    }
+    // (5) publish
+    for (int idx = tid; idx < a.K * 16; idx += 256) {
+        const int k = idx >> 4, c = idx & 15;
+        if (c < ncol) a.Y[(size_t)k * a.ldY + c0 + c] = k < nd ? Yd[k * AR_YS + c] : Ys[(k - nd) * AR_YS + c];
+    }
+    if (tid == 0 && *bad_lds) atomicOr(a.flag, 1);
+}
+
+__global__ __launch_bounds__(256) void k_arrow_schur(const ArrowArgs a) {
+    if (a.status->done || a.status->reuse) return;
+    const int T = (a.np + 1 + 15) / 16;
+    const int ta = blockIdx.x / T, tb = blockIdx.x % T;
+    if (tb > ta) return;
+    __shared__ double Ya[32][17], Yb[32][17];
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int np = a.np, K = a.K;
+    double acc = 0.0;
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        for (int idx = tid; idx < 512; idx += 256) {
+            const int rr = idx >> 4, cc = idx & 15, k = k0 + rr;
+            Ya[rr][cc] = (k < K && 16 * ta + cc <= np) ? a.Y[(size_t)k * a.ldY + 16 * ta + cc] : 0.0;
+            Yb[rr][cc] = (k < K && 16 * tb + cc <= np) ? a.Y[(size_t)k * a.ldY + 16 * tb + cc] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) acc += Ya[kk][ty] * Yb[kk][tx];
+        __syncthreads();
+    }
+    const int ai = 16 * ta + ty, bi = 16 * tb + tx;
+    if (ai <= np && bi < np && bi <= ai) {
+        const int o = a.nd + 9 * a.W;
+        const double base = ai < np ? a.A[(size_t)(o + ai) * a.n + o + bi] : a.A[(size_t)a.n * a.n + o + bi];
+        a.Sp[(size_t)ai * np + bi] = base - acc;
+    }
+}
+
+__host__ __device__ __forceinline__ size_t arrow_solve_extra_doubles(int W, int K) { return (size_t)K + (K & 1) + (size_t)W * AR_LB; }
+
+__global__ __launch_bounds__(TR_THREADS) void k_arrow_solve(const ArrowArgs a) {
+    if (a.status->done || a.status->reuse) return;
+    if (*a.flag & 1) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int W = a.W, n = a.n, nd = a.nd, np = a.np, K = a.K;
+    double* Bp = reinterpret_cast<double*>(tr_lds);
+    double* part = Bp + TR_NB * bp_stride(np);
+    double* sD = part + 16 * 256;
+    double* ylds = sD + (TR_NB + 1) * TR_PS;
+    double* red = ylds + np + (np & 1);
+    int* flag = reinterpret_cast<int*>(red + 32);
+    double* wb = red + 48;                        // [K] w, overwritten by z_d / z_s
+    double* Lb = wb + K + (K & 1);                // [W][AR_LB]
+    const bool good = chol_left_looking(a.Sp, np, Bp, part, sD, flag);
+    if (!good) { if (tid == 0) atomicOr(a.flag, 1); return; }
+    for (int j = tid; j < np; j += TR_THREADS) ylds[j] = a.Sp[(size_t)np * np + j];
+    for (int j = tid; j < W * AR_LB; j += TR_THREADS) Lb[j] = a.Lblk[j];
+    __syncthreads();
+    back_substitute(a.Sp, np, ylds, sD);          // ylds = z_p
+    // w = y_e - Y_p z_p  (one wavefront per row)
+    for (int k = wv; k < K; k += TR_WAVES) {
+        const double* yr = a.Y + (size_t)k * a.ldY;
+        double sacc = 0.0;
+        for (int c = lane; c < np; c += 64) sacc += yr[c] * ylds[c];
+        sacc = wave_sum(sacc);
+        if (lane == 0) wb[k] = yr[np] - sacc;
+    }
+    __syncthreads();
+    // speed-bias chain, bottom up: L_ii^T z_i = w_i - L_{i+1,i}^T z_{i+1}
+    if (wv == 0) {
+        for (int i = W - 1; i >= 0; --i) {
+            const double* Lc = Lb + i * AR_LB;
+            double v = lane < 9 ? wb[nd + 9 * i + lane] : 0.0;
+            if (i + 1 < W && lane < 9) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) v -= Lc[(9 + k) * 10 + lane] * wb[nd + 9 * (i + 1) + k];
+            }
+            const double rp = lane < 9 ? Lc[180 + lane] : 1.0;
+#pragma unroll
+            for (int k = 8; k >= 0; --k) {
+                const double zk = readlane_d(v, k) * readlane_d(rp, k);
+                if (lane == k) v = zk;
+                else if (lane < k) v -= Lc[k * 10 + lane] * zk;
+            }
+            if (lane < 9) wb[nd + 9 * i + lane] = v;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    __syncthreads();
+    // epochs: z_e = (w_e - sum_s L_se z_s) / L_ee
+    for (int e = tid; e < nd; e += TR_THREADS) {
+        const double m = a.A[(size_t)e * n + e];
+        const double rde = rsqrt(m);
+        const int2 sl = a.ep_slots[e];
+        double v = wb[e];
+        if (sl.x >= 0) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                v -= a.A[(size_t)(nd + 9 * sl.x + q) * n + e] * rde * wb[nd + 9 * sl.x + q];
+                v -= a.A[(size_t)(nd + 9 * sl.y + q) * n + e] * rde * wb[nd + 9 * sl.y + q];
+            }
+        }
+        a.z[e] = v * rde;
+    }
+    double bad = 0.0;
+    for (int k = tid; k < 9 * W; k += TR_THREADS) { const double v = wb[nd + k]; a.z[nd + k] = v; if (!isfinite(v)) bad = 1.0; }
+    for (int c = tid; c < np; c += TR_THREADS) { const double v = ylds[c]; a.z[K + c] = v; if (!isfinite(v)) bad = 1.0; }
+    bad = block_max(bad, red);
+    if (tid == 0) { if (bad == 0.0) *a.flag = 2; else atomicOr(a.flag, 1); }
+}
+
 size_t glio_tr_step_lds_bytes(int n) {
     size_t d = (size_t)TR_NB * bp_stride(n);
     d += 16 * 256;
@@ -608,8 +900,26 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
     a.H0 = c->d_H[0]; a.H1 = c->d_H[1]; a.g0 = c->d_g[0]; a.g1 = c->d_g[1]; a.c0 = c->d_cost[0]; a.c1 = c->d_cost[1];
     a.L = c->d_L; a.vec = c->d_vec; a.vstride = c->n_max;
     a.status = c->d_status;
+    // structured factorisation when the factor graph is a chain (IMU / Doppler edges between neighbours only, at most
+    // one speed-bias block in the prior) and its workspaces fit the LDS; the dense kernel stays as the fallback
+    const int np = 6 * c->W, K = a.n - np;
+    const size_t lds_fwd = arrow_forward_lds_doubles(c->W, n_ddt) * 8;
+    const size_t lds_slv = glio_tr_step_lds_bytes(np) + arrow_solve_extra_doubles(c->W, K) * 8;
+    const bool arrow = c->arrow.mode == 1 && c->arrow.gnss_ok && c->arrow.prior_ok && c->arrow.max_epoch < n_ddt && lds_fwd <= 160 * 1024 && lds_slv <= 160 * 1024;
+    a.arrow_flag = arrow ? c->arrow.d_flag : nullptr; a.arrow_z = c->arrow.d_z;
     hipLaunchKernelGGL(k_tr_prepare, dim3(1), dim3(TR_THREADS), 0, c->stream, a);
     hipLaunchKernelGGL(k_tr_scale, dim3((a.n + 1 + 3) / 4), dim3(256), 0, c->stream, a);
+    if (arrow) {
+        ArrowArgs r;
+        r.W = c->W; r.n = a.n; r.nd = n_ddt; r.np = np; r.K = K; r.ldY = np + 2;
+        r.A = c->d_L; r.ep_slots = c->arrow.d_ep_slots; r.ep_off = c->arrow.d_ep_off; r.ep_list = c->arrow.d_ep_list;
+        r.Y = c->arrow.d_Y; r.Lblk = c->arrow.d_Lblk; r.Sp = c->arrow.d_Sp; r.z = c->arrow.d_z; r.flag = c->arrow.d_flag;
+        r.status = c->d_status;
+        const int T = (np + 1 + 15) / 16;
+        hipLaunchKernelGGL(k_arrow_forward, dim3(T), dim3(256), lds_fwd, c->stream, r);
+        hipLaunchKernelGGL(k_arrow_schur, dim3(T * T), dim3(256), 0, c->stream, r);
+        hipLaunchKernelGGL(k_arrow_solve, dim3(1), dim3(TR_THREADS), lds_slv, c->stream, r);
+    }
     hipLaunchKernelGGL(k_tr_factor, dim3(1), dim3(TR_THREADS), glio_tr_step_lds_bytes(a.n), c->stream, a);
     hipLaunchKernelGGL(k_tr_dogleg, dim3(1), dim3(TR_THREADS), 0, c->stream, a);
 }
@@ -813,6 +1123,8 @@ void glio_tr_step_configure(size_t max_lds) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_tr_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_test), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_marg_schur), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_arrow_forward), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_arrow_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
 }
 
 extern "C" int glio_debug_read_vec(glio_ctx* c, int k, double* out, int n) {

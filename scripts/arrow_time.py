@@ -1,0 +1,16 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from glio_amd import synth, capi
+win = synth.make_window(W=20, pts_per_scan=65536, with_gnss=True, with_prior=True, seed=synth.SEED_BASE + 12)
+corr = synth.analytic_correspondences(win)
+for mode in (0, 1):
+    ctx = capi.Context(win.opts)
+    capi.load().glio_debug_set_solver(ctx._h, mode)
+    ctx.load_window(win, corr)
+    sol, summ = ctx.solve(win.init)
+    ms, s2 = ctx.time_solve(win.init, 10)
+    print(f"mode {mode}: iterations {summ.iterations} term {summ.termination} cost {summ.final_cost:.12g} solve {ms:.3f} ms  tr_step {ctx.time_kernel(2, 20)*1e3:.1f} us")
+    if mode == 0: ref = sol
+    else: print("max dtrans", np.abs(sol.trans - ref.trans).max(), "dsb", np.abs(sol.speed_bias - ref.speed_bias).max())
+    ctx.close()

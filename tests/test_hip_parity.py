@@ -210,3 +210,25 @@ def test_capacity_and_argument_errors(hip, small_window):
     with pytest.raises(hip.GlioError):
         ctx.solve(win.init)           # no factors yet
     ctx.close()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_structured_solver_equals_dense(hip, small_window, small_corr, case):
+    """The arrow factorisation (epochs | speed-bias chain | dense poses) and the dense Cholesky solve the same
+    linear systems: identical iteration history, solutions equal to rounding."""
+    win = small_window
+    kw = {k: case[k] for k in ("use_imu", "use_gnss", "use_prior")}
+    res = []
+    for mode in (0, 1):
+        ctx = hip.Context(win.opts)
+        assert hip.load().glio_debug_set_solver(ctx._h, mode) == 0
+        ctx.load_window(win, small_corr, **kw)
+        res.append(ctx.solve(_state_for(win, case["use_gnss"])))
+        ctx.close()
+    (sd, md), (sa, ma) = res
+    assert ma.iterations == md.iterations and ma.successful_steps == md.successful_steps and ma.termination == md.termination
+    assert abs(ma.final_cost - md.final_cost) <= 1e-12 * abs(md.final_cost)
+    assert np.abs(sa.trans - sd.trans).max() <= 1e-10 and np.abs(sa.quat - sd.quat).max() <= 1e-11
+    assert np.abs(sa.speed_bias - sd.speed_bias).max() <= 1e-9
+    if sd.n_ddt:
+        assert np.abs(sa.rcv_ddt - sd.rcv_ddt).max() <= 1e-9
