@@ -125,7 +125,7 @@ int glio_create(int device, const glio_opts* opts, glio_ctx** out) {
         GLIO_HIP_CHECK(hipMemsetAsync(ar.d_ep_off, 0, (W + 1) * 4, c->stream));
         ALLOC(ar.d_Y, (size_t)(c->n_ddt_max + 9 * W) * (6 * W + 2) * 8);
         ALLOC(ar.d_Lblk, (size_t)W * 190 * 8); ALLOC(ar.d_Sp, (size_t)(6 * W + 1) * 6 * W * 8);
-        ALLOC(ar.d_z, (size_t)n_max * 8); ALLOC(ar.d_flag, 4);
+        ALLOC(ar.d_z, (size_t)n_max * 8); ALLOC(ar.d_flag, 4); ALLOC(ar.d_dbg, 64 * 8);
         GLIO_HIP_CHECK(hipMemsetAsync(ar.d_flag, 0, 4, c->stream));
         GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
     }
@@ -156,7 +156,7 @@ void glio_destroy(glio_ctx* c) {
                     c->d_prior_kind, c->d_prior_idx, c->d_prior_index, c->d_prior_H, c->d_prior_g, c->d_prior_cost, c->d_prior_work,
                     c->d_x[0], c->d_x[1], c->d_H[0], c->d_H[1], c->d_g[0], c->d_g[1], c->d_cost[0], c->d_cost[1], c->d_xout,
                     c->d_lidar_partials, c->d_lidar_blocks, c->d_L, c->d_vec, c->d_status,
-                    c->arrow.d_ep_slots, c->arrow.d_ep_off, c->arrow.d_ep_list, c->arrow.d_Y, c->arrow.d_Lblk, c->arrow.d_Sp, c->arrow.d_z, c->arrow.d_flag};
+                    c->arrow.d_ep_slots, c->arrow.d_ep_off, c->arrow.d_ep_list, c->arrow.d_Y, c->arrow.d_Lblk, c->arrow.d_Sp, c->arrow.d_z, c->arrow.d_flag, c->arrow.d_dbg};
     for (void* p : ptrs) if (p) hipFree(p);
     hipHostFree(c->h_status); hipHostFree(c->h_xbuf);
     hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
@@ -629,6 +629,13 @@ int glio_eval_imu(glio_ctx* c, const glio_preint* pre, double const* const* P, d
 int glio_debug_set_solver(glio_ctx* c, int mode) {
     if (!c || mode < 0 || mode > 1) return GLIO_E_ARG;
     c->arrow.mode = mode;
+    return GLIO_OK;
+}
+int glio_debug_arrow_stamps(glio_ctx* c, long long* out64) {
+    if (!c || !out64) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    GLIO_HIP_CHECK(hipMemcpy(out64, c->arrow.d_dbg, 64 * 8, hipMemcpyDeviceToHost));
     return GLIO_OK;
 }
 int glio_debug_set_k3(glio_ctx* c, int bpk, int unroll) {

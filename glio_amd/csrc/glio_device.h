@@ -87,6 +87,7 @@ struct ArrowDev {
     double* d_Sp;             // (6W+1) x 6W pose Schur complement + carried right-hand side
     double* d_z;              // [n] solution in elimination order
     int* d_flag;              // 0 running, 1 breakdown, 2 solved
+    long long* d_dbg;         // [64] wall-clock stamps of the last launch (100 MHz), development aid
 };
 
 struct glio_ctx {

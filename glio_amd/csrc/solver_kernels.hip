@@ -630,12 +630,15 @@ struct ArrowArgs {
     double* Y; double* Lblk; double* Sp; double* z;
     int* flag;
     const SolverStatus* status;
+    long long* dbg;
 };
+#define AR_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) a.dbg[k] = wall_clock64(); } while (0)
 #define AR_LB 190          /* one chain block in LDS / global: 18 rows x stride 10, then 9 reciprocal pivots (+1 pad) */
 #define AR_YS 17           /* row stride of the 16-column Y slices in LDS */
 
 __host__ __device__ __forceinline__ size_t arrow_forward_lds_doubles(int W, int nd) {
-    return (size_t)(nd + (nd & 1)) + (size_t)nd * AR_YS + (size_t)nd * 18 + (size_t)9 * W * AR_YS + 3 * AR_LB + 2;
+    return (size_t)(nd + (nd & 1)) + (size_t)nd * AR_YS + (size_t)nd * 18 + (size_t)9 * W * AR_YS + 3 * AR_LB + (size_t)W * 180 +
+           (size_t)nd + 2 + (size_t)(W + 2) / 2 + 1 + (size_t)nd + 2;
 }
 
 __global__ __launch_bounds__(256) void k_arrow_forward(const ArrowArgs a) {
@@ -650,74 +653,111 @@ __global__ __launch_bounds__(256) void k_arrow_forward(const ArrowArgs a) {
     double* Vs = Yd + (size_t)nd * AR_YS;
     double* Ys = Vs + (size_t)nd * 18;
     double* Lb = Ys + (size_t)9 * W * AR_YS;
-    int* bad_lds = reinterpret_cast<int*>(Lb + 3 * AR_LB);
+    double* Blk = Lb + 3 * AR_LB;                            // [W][18][10]: rows 0-8 D_i, rows 9-17 B_i = M[s_{i+1}, s_i]
+    int2* eps = reinterpret_cast<int2*>(Blk + (size_t)W * 180);         // [nd]
+    int* eoff = reinterpret_cast<int*>(eps + nd + 2);                   // [W+1]
+    int* elist = eoff + ((W + 2) & ~1) + 2;                             // [2 nd]
+    int* bad_lds = elist + 2 * nd + 2;
     if (tid == 0) *bad_lds = 0;
+    AR_STAMP(0);
+    for (int e = tid; e < nd; e += 256) eps[e] = a.ep_slots[e];
+    for (int i = tid; i <= W; i += 256) eoff[i] = a.ep_off[i];
     __syncthreads();
+    for (int t = tid; t < eoff[W]; t += 256) elist[t] = a.ep_list[t];
     // (1) epochs: pivots
     for (int e = tid; e < nd; e += 256) {
         const double m = A[(size_t)e * n + e];
         if (!(m > 0.0) || !isfinite(m)) { *bad_lds = 1; rd[e] = 0.0; } else rd[e] = rsqrt(m);
     }
     __syncthreads();
-    // (2) epoch rows of Y for this workgroup's columns, and the epoch columns of the speed-bias rows
-    for (int idx = tid; idx < nd * 16; idx += 256) {
-        const int c = idx / nd, e = idx - c * nd, col = c0 + c;
-        double v = 0.0;
-        if (c < ncol) v = (col < np ? A[(size_t)(nd + 9 * W + col) * n + e] : rhs[e]) * rd[e];
-        Yd[e * AR_YS + c] = v;
+    AR_STAMP(1);
+    // (2) epoch rows of Y for this workgroup's columns, and the epoch columns of the speed-bias rows.
+    //     All global reads of this kernel are issued as batches of independent loads (16 per lane) before anything
+    //     is done with them: the kernel is latency-, not bandwidth-bound.
+    const size_t prow = (size_t)(nd + 9 * W);            // first pose row of A
+    for (int e = tid; e < nd; e += 256) {
+        double v[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { const int col = c0 + c; v[c] = c < ncol ? (col < np ? A[(prow + col) * n + e] : rhs[e]) : 0.0; }
+        const double re = rd[e];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) Yd[e * AR_YS + c] = v[c] * re;
     }
-    for (int idx = tid; idx < nd * 18; idx += 256) {
-        const int e = idx / 18, q = idx - e * 18;
-        const int2 sl = a.ep_slots[e];
-        const int s1 = q < 9 ? sl.x : sl.y;
-        Vs[idx] = s1 >= 0 ? A[(size_t)(nd + 9 * s1 + (q < 9 ? q : q - 9)) * n + e] * rd[e] : 0.0;
+    for (int e = tid; e < nd; e += 256) {
+        const int2 sl = eps[e];
+        double v[18];
+#pragma unroll
+        for (int q = 0; q < 18; ++q) { const int s1 = q < 9 ? sl.x : sl.y; v[q] = s1 >= 0 ? A[(size_t)(nd + 9 * s1 + (q < 9 ? q : q - 9)) * n + e] : 0.0; }
+        const double re = rd[e];
+#pragma unroll
+        for (int q = 0; q < 18; ++q) Vs[e * 18 + q] = v[q] * re;
+    }
+    AR_STAMP(2);
+    // (3) raw speed-bias rows of [M_ep | b_e] and raw chain blocks -> LDS
+    for (int k = tid; k < 9 * W; k += 256) {
+        double v[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { const int col = c0 + c; v[c] = c < ncol ? (col < np ? A[(prow + col) * n + nd + k] : rhs[nd + k]) : 0.0; }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) Ys[k * AR_YS + c] = v[c];
+    }
+    for (int q = tid; q < W * 18; q += 256) {            // one lane per row of a block: 9 contiguous doubles
+        const int i = q / 18, r = q - 18 * i;
+        const bool live = r < 9 || i + 1 < W;
+        const double* src = A + (size_t)(nd + 9 * i + r) * n + nd + 9 * i;      // r >= 9 runs into the rows of s_{i+1}
+        double v[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) v[j] = (live && (r >= 9 || j <= r)) ? src[j] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) Blk[i * 180 + r * 10 + j] = v[j];
     }
     __syncthreads();
-    // (3) speed-bias rows of [M_ep | b_e] minus the epoch contribution
-    for (int idx = tid; idx < 9 * W * 16; idx += 256) {
-        const int c = idx / (9 * W), k = idx - c * 9 * W, col = c0 + c;
-        double v = 0.0;
-        if (c < ncol) {
-            v = col < np ? A[(size_t)(nd + 9 * W + col) * n + nd + k] : rhs[nd + k];
-            const int sl = k / 9, q = k - 9 * sl;
-            for (int t = a.ep_off[sl]; t < a.ep_off[sl + 1]; ++t) {
-                const int e = a.ep_list[t];
-                v -= Vs[e * 18 + (a.ep_slots[e].x == sl ? 0 : 9) + q] * Yd[e * AR_YS + c];
-            }
+    //     ... minus the epoch contribution (LDS only)
+    for (int k = tid; k < 9 * W; k += 256) {
+        const int sl = k / 9, q = k - 9 * sl;
+        for (int t = eoff[sl]; t < eoff[sl + 1]; ++t) {
+            const int e = elist[t];
+            const double ve = Vs[e * 18 + (eps[e].x == sl ? 0 : 9) + q];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) Ys[k * AR_YS + c] -= ve * Yd[e * AR_YS + c];
         }
-        Ys[k * AR_YS + c] = v;
+    }
+    for (int q = tid; q < W * 18; q += 256) {
+        const int i = q / 18, r = q - 18 * i;
+        const bool rowD = r < 9;
+        if (!rowD && i + 1 >= W) continue;
+        for (int t = eoff[i]; t < eoff[i + 1]; ++t) {
+            const int e = elist[t];
+            const int2 sl = eps[e];
+            const int side = sl.x == i ? 0 : 9;
+            double mine;
+            if (rowD) mine = Vs[e * 18 + side + r];
+            else { if ((sl.x == i ? sl.y : sl.x) != i + 1) continue; mine = Vs[e * 18 + (9 - side) + (r - 9)]; }
+#pragma unroll
+            for (int j = 0; j < 9; ++j) if (!rowD || j <= r) Blk[i * 180 + r * 10 + j] -= mine * Vs[e * 18 + side + j];
+        }
     }
     __syncthreads();
-    // (4) the chain: wavefront 0 factors block `it`, wavefront 1 forward-substitutes block `it-1`
+    AR_STAMP(3);
+    // (4) the chain.  Wavefront 0: lanes 0-8 hold the rows of D_i, lanes 9-17 the rows of B_i; nine register steps
+    //     (v_readlane broadcasts) factor the 18 x 9 panel; the rank-9 update D_{i+1} -= L_{i+1,i} L_{i+1,i}^T is then
+    //     taken from the panel just stored to LDS (broadcast reads).  Wavefront 1 follows one block behind with the
+    //     forward substitution of this workgroup's 16 columns.
+    double av[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) av[j] = (wv == 0 && lane < 9) ? Blk[lane * 10 + j] : 0.0;
+    bool bad = false;
     for (int it = 0; it <= W; ++it) {
         if (wv == 0 && it < W) {
             const int i = it, r = lane;
-            const bool rowD = r < 9, rowB = r >= 9 && r < 18 && i + 1 < W;
-            double av[9];
-            const size_t grow = rowD ? (size_t)(nd + 9 * i + r) : (size_t)(nd + 9 * (i + 1) + (r - 9));
+            const bool more = i + 1 < W;
+            double nx[9];                           // next block's rows, fetched early: D_{i+1} (lanes 0-8)
 #pragma unroll
-            for (int j = 0; j < 9; ++j) av[j] = (rowD && j <= r) || rowB ? A[grow * n + nd + 9 * i + j] : 0.0;
-            for (int t = a.ep_off[i]; t < a.ep_off[i + 1]; ++t) {
-                const int e = a.ep_list[t];
-                const int2 sl = a.ep_slots[e];
-                const int side = sl.x == i ? 0 : 9, other = sl.x == i ? sl.y : sl.x;
-                double mine = 0.0;
-                if (rowD) mine = Vs[e * 18 + side + r];
-                else if (rowB && other == i + 1) mine = Vs[e * 18 + (9 - side) + (r - 9)];
+            for (int j = 0; j < 9; ++j) nx[j] = (more && r < 9) ? Blk[(i + 1) * 180 + r * 10 + j] : 0.0;
+            if (r >= 9 && r < 18) {
 #pragma unroll
-                for (int j = 0; j < 9; ++j) av[j] -= mine * Vs[e * 18 + side + j];
+                for (int j = 0; j < 9; ++j) av[j] = more ? Blk[i * 180 + r * 10 + j] : 0.0;
             }
-            if (i > 0 && rowD) {
-                const double* Lp = Lb + ((i - 1) % 3) * AR_LB + 90;      // L_{i,i-1}: rows 9..17 of the previous block
-#pragma unroll
-                for (int j = 0; j < 9; ++j) {
-                    double sacc = 0.0;
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) sacc += Lp[r * 10 + k] * Lp[j * 10 + k];
-                    av[j] -= sacc;
-                }
-            }
-            bool bad = false;
             double rpv = 0.0;
 #pragma unroll
             for (int j = 0; j < 9; ++j) {
@@ -738,13 +778,29 @@ __global__ __launch_bounds__(256) void k_arrow_forward(const ArrowArgs a) {
             if (r < 18) {
 #pragma unroll
                 for (int j = 0; j < 9; ++j) {
-                    const double v = (rowD && j > r) || (!rowD && !rowB) ? 0.0 : av[j];
+                    const double v = (r < 9 && j > r) ? 0.0 : av[j];
                     Lc[r * 10 + j] = v;
                     if (blockIdx.x == 0) Lg[r * 10 + j] = v;
                 }
                 if (r < 9) { Lc[180 + r] = rpv; if (blockIdx.x == 0) Lg[180 + r] = rpv; }
             }
-            if (bad && lane == 0) *bad_lds = 1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (more) {                             // D_{i+1}[r][j] -= X[r] . X[j],  X = L_{i+1,i} = rows 9..17 of Lc
+                const int rr = r < 9 ? r : 0;
+                const double* X = Lc + 90;
+                double xr[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) xr[k] = X[rr * 10 + k];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) sacc += xr[k] * X[j * 10 + k];
+                    nx[j] -= sacc;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 9; ++j) av[j] = (r < 9 && j <= r) ? nx[j] : 0.0;
         } else if (wv == 1 && it >= 1 && lane < 16) {
             const int i = it - 1, c = lane;
             double tv[9];
@@ -771,11 +827,15 @@ __global__ __launch_bounds__(256) void k_arrow_forward(const ArrowArgs a) {
         }
         __syncthreads();
     }
+    AR_STAMP(4);
+    if (wv == 0 && bad && lane == 0) *bad_lds = 1;
+    __syncthreads();
     // (5) publish
     for (int idx = tid; idx < a.K * 16; idx += 256) {
         const int k = idx >> 4, c = idx & 15;
         if (c < ncol) a.Y[(size_t)k * a.ldY + c0 + c] = k < nd ? Yd[k * AR_YS + c] : Ys[(k - nd) * AR_YS + c];
     }
+    AR_STAMP(5);
     if (tid == 0 && *bad_lds) atomicOr(a.flag, 1);
 }
 
@@ -822,21 +882,26 @@ __global__ __launch_bounds__(TR_THREADS) void k_arrow_solve(const ArrowArgs a) {
     int* flag = reinterpret_cast<int*>(red + 32);
     double* wb = red + 48;                        // [K] w, overwritten by z_d / z_s
     double* Lb = wb + K + (K & 1);                // [W][AR_LB]
+    AR_STAMP(8);
     const bool good = chol_left_looking(a.Sp, np, Bp, part, sD, flag);
     if (!good) { if (tid == 0) atomicOr(a.flag, 1); return; }
+    AR_STAMP(9);
     for (int j = tid; j < np; j += TR_THREADS) ylds[j] = a.Sp[(size_t)np * np + j];
     for (int j = tid; j < W * AR_LB; j += TR_THREADS) Lb[j] = a.Lblk[j];
     __syncthreads();
     back_substitute(a.Sp, np, ylds, sD);          // ylds = z_p
+    AR_STAMP(10);
     // w = y_e - Y_p z_p  (one wavefront per row)
-    for (int k = wv; k < K; k += TR_WAVES) {
+    for (int k = tid; k < K; k += TR_THREADS) {
         const double* yr = a.Y + (size_t)k * a.ldY;
-        double sacc = 0.0;
-        for (int c = lane; c < np; c += 64) sacc += yr[c] * ylds[c];
-        sacc = wave_sum(sacc);
-        if (lane == 0) wb[k] = yr[np] - sacc;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int c = 0;
+        for (; c + 4 <= np; c += 4) { s0 += yr[c] * ylds[c]; s1 += yr[c + 1] * ylds[c + 1]; s2 += yr[c + 2] * ylds[c + 2]; s3 += yr[c + 3] * ylds[c + 3]; }
+        for (; c < np; ++c) s0 += yr[c] * ylds[c];
+        wb[k] = yr[np] - ((s0 + s1) + (s2 + s3));
     }
     __syncthreads();
+    AR_STAMP(11);
     // speed-bias chain, bottom up: L_ii^T z_i = w_i - L_{i+1,i}^T z_{i+1}
     if (wv == 0) {
         for (int i = W - 1; i >= 0; --i) {
@@ -858,6 +923,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_arrow_solve(const ArrowArgs a) {
         }
     }
     __syncthreads();
+    AR_STAMP(12);
     // epochs: z_e = (w_e - sum_s L_se z_s) / L_ee
     for (int e = tid; e < nd; e += TR_THREADS) {
         const double m = a.A[(size_t)e * n + e];
@@ -877,6 +943,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_arrow_solve(const ArrowArgs a) {
     for (int k = tid; k < 9 * W; k += TR_THREADS) { const double v = wb[nd + k]; a.z[nd + k] = v; if (!isfinite(v)) bad = 1.0; }
     for (int c = tid; c < np; c += TR_THREADS) { const double v = ylds[c]; a.z[K + c] = v; if (!isfinite(v)) bad = 1.0; }
     bad = block_max(bad, red);
+    AR_STAMP(13);
     if (tid == 0) { if (bad == 0.0) *a.flag = 2; else atomicOr(a.flag, 1); }
 }
 
@@ -914,7 +981,7 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
         r.W = c->W; r.n = a.n; r.nd = n_ddt; r.np = np; r.K = K; r.ldY = np + 2;
         r.A = c->d_L; r.ep_slots = c->arrow.d_ep_slots; r.ep_off = c->arrow.d_ep_off; r.ep_list = c->arrow.d_ep_list;
         r.Y = c->arrow.d_Y; r.Lblk = c->arrow.d_Lblk; r.Sp = c->arrow.d_Sp; r.z = c->arrow.d_z; r.flag = c->arrow.d_flag;
-        r.status = c->d_status;
+        r.status = c->d_status; r.dbg = c->arrow.d_dbg;
         const int T = (np + 1 + 15) / 16;
         hipLaunchKernelGGL(k_arrow_forward, dim3(T), dim3(256), lds_fwd, c->stream, r);
         hipLaunchKernelGGL(k_arrow_schur, dim3(T * T), dim3(256), 0, c->stream, r);

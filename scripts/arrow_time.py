@@ -14,3 +14,13 @@ for mode in (0, 1):
     if mode == 0: ref = sol
     else: print("max dtrans", np.abs(sol.trans - ref.trans).max(), "dsb", np.abs(sol.speed_bias - ref.speed_bias).max())
     ctx.close()
+import ctypes as C
+ctx = capi.Context(win.opts)
+ctx.load_window(win, corr)
+ctx.linearize(win.init)
+ctx.time_kernel(2, 1)
+st = (C.c_longlong * 64)()
+capi.load().glio_debug_arrow_stamps(ctx._h, st)
+v = list(st)
+print("forward stamps (us):", [round((v[k + 1] - v[k]) / 100.0, 2) for k in range(0, 5)])
+print("solve stamps (us):", [round((v[k + 1] - v[k]) / 100.0, 2) for k in range(8, 13)])
