@@ -213,10 +213,8 @@ __device__ __forceinline__ bool chol_left_looking(double* A, const int n, double
                 if (lane == j) sD[TR_NB * TR_PS + j] = rd;        // reciprocal pivots for the row solves
                 a[j] = lij;
 #pragma unroll
-                for (int c = j + 1; c < TR_NB; ++c) {
-                    const double lcj = readlane_d(lij, c);
-                    if (lane >= c) a[c] -= lij * lcj;
-                }
+                for (int c = j + 1; c < TR_NB; ++c) a[c] -= lij * readlane_d(lij, c);   // unmasked: lanes < c only spoil entries above
+                                                                                        // the diagonal, which are never read or stored
             }
             if (lane < TR_NB) {
 #pragma unroll
@@ -294,6 +292,118 @@ __device__ __forceinline__ void back_substitute(const double* A, const int n, do
 #pragma unroll 4
             for (int k = 0; k < nb; ++k) s -= A[(size_t)(k0 + k) * ld + i] * y[k0 + k];
             y[i] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-resident variant for small systems (the 6W x 6W pose block of the arrow solver): the lower triangle is kept
+// PACKED in LDS (row i at i(i+1)/2, the carried right-hand side as row n), right-looking: per 16-column panel the
+// diagonal block is factored in the registers of wavefront 0, the rows below are solved one lane per row, and the
+// trailing triangle takes its rank-16 update on the matrix cores (one 16x16 tile per wavefront, operands read from
+// LDS).  No global-memory round trip between the phases.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int pk_off(const int i) { return (i * (i + 1)) >> 1; }
+__host__ __device__ __forceinline__ size_t pk_doubles(const int n) { const size_t d = (size_t)(n + 1) * (n + 2) / 2; return d + (d & 1); }
+
+__device__ __forceinline__ bool chol_packed_lds(double* P, const int n, double* sD, int* flag) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    for (int k0 = 0; k0 < n; k0 += TR_NB) {
+        const int nb = min(TR_NB, n - k0);
+        // (a+b) fused: every participating wavefront carries the diagonal block in lanes 0-15 (factored redundantly)
+        //       and 48 of the rows below in lanes 16-63; the 16 right-looking register steps then factor the block
+        //       AND solve those rows with the same v_readlane broadcasts -- no separate triangular-solve phase.
+        const int r0 = k0 + nb;
+        const int mb = n + 1 - r0;
+        if (wv == 0 || wv * 48 < mb) {
+            const bool isdiag = lane < TR_NB;
+            const int bi = wv * 48 + lane - TR_NB;
+            const bool live = isdiag ? lane < nb : bi < mb;
+            double* prow = P + pk_off(live ? (isdiag ? k0 + lane : r0 + bi) : 0) + k0;
+            double a[TR_NB];
+#pragma unroll
+            for (int j = 0; j < TR_NB; ++j) a[j] = (live && j < nb && (!isdiag || j <= lane)) ? prow[j] : ((isdiag && lane == j) ? 1.0 : 0.0);
+            bool bad = false;
+#pragma unroll
+            for (int j = 0; j < TR_NB; ++j) {
+                double djj = readlane_d(a[j], j);
+                if (!(djj > 0.0) || !isfinite(djj)) { bad = true; djj = 1.0; }
+                const double rd = rsqrt(djj);
+                const double lij = (lane == j) ? djj * rd : a[j] * rd;
+                a[j] = lij;
+#pragma unroll
+                for (int c = j + 1; c < TR_NB; ++c) a[c] -= lij * readlane_d(lij, c);
+            }
+            if (live && (wv == 0 || !isdiag)) {
+#pragma unroll
+                for (int j = 0; j < TR_NB; ++j) if (j < nb && (!isdiag || j <= lane)) prow[j] = a[j];
+            }
+            if (bad && wv == 0 && lane == 0) *flag = 1 + k0;
+        }
+        __syncthreads();
+        if (*flag) return false;
+        if (nb == TR_NB && r0 < n) {
+            const int T = (n + 1 - r0 + 15) >> 4;
+            const int ntiles = (T * (T + 1)) >> 1;
+            for (int t = wv; t < ntiles; t += TR_WAVES) {
+                int I = 0;
+                while (((I + 1) * (I + 2)) >> 1 <= t) ++I;
+                const int J = t - ((I * (I + 1)) >> 1);
+                const int ra = r0 + 16 * I + li, rb = r0 + 16 * J + li;
+                const bool oka = ra <= n, okb = rb < n;
+                const double* pa = P + pk_off(oka ? ra : n) + k0 + lk;
+                const double* pb = P + pk_off(okb ? rb : 0) + k0 + lk;
+                double ax[4], bx[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { ax[q] = pa[4 * q]; bx[q] = pb[4 * q]; }
+                v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(oka ? ax[q] : 0.0, okb ? bx[q] : 0.0, acc, 0, 0, 0);
+                const int colc = r0 + 16 * J + li;            // C: lane l, reg r -> row (l>>4)+4r, col l&15
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rowc = r0 + 16 * I + lk + 4 * r;
+                    if (rowc <= n && colc < n && colc <= rowc) P[pk_off(rowc) + colc] -= acc[r];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    return true;
+}
+
+// L^T z = y for the packed LDS factor; y (LDS) is overwritten by z
+__device__ __forceinline__ void backsub_packed_lds(const double* P, const int n, double* y, double* sD) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nblk = (n + TR_NB - 1) / TR_NB;
+    for (int b = nblk - 1; b >= 0; --b) {
+        const int k0 = b * TR_NB, nb = min(TR_NB, n - k0);
+        if (tid < TR_NB * TR_NB) {
+            const int i = tid / TR_NB, j = tid % TR_NB;
+            sD[i * TR_PS + j] = (i < nb && j <= i) ? P[pk_off(k0 + i) + k0 + j] : (i == j ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        if (wv == 0) {
+            double yi = (lane < nb) ? y[k0 + lane] : 0.0;
+            const double rdiag = (lane < TR_NB) ? 1.0 / sD[lane * TR_PS + lane] : 1.0;
+#pragma unroll
+            for (int k = TR_NB - 1; k >= 0; --k) {
+                const double zk = readlane_d(yi, k) * readlane_d(rdiag, k);
+                if (lane == k) yi = zk;
+                else if (lane < k) yi -= sD[k * TR_PS + lane] * zk;
+            }
+            if (lane < nb) y[k0 + lane] = yi;
+        }
+        __syncthreads();
+        for (int i = tid; i < k0; i += TR_THREADS) {
+            double sacc = y[i];
+#pragma unroll 4
+            for (int k = 0; k < nb; ++k) sacc -= P[pk_off(k0 + k) + i] * y[k0 + k];
+            y[i] = sacc;
         }
         __syncthreads();
     }
@@ -631,6 +741,7 @@ struct ArrowArgs {
     int* flag;
     const SolverStatus* status;
     long long* dbg;
+    int lds_chol;             // pose block factored in LDS (packed) instead of through global memory
 };
 #define AR_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) a.dbg[k] = wall_clock64(); } while (0)
 #define AR_LB 190          /* one chain block in LDS / global: 18 rows x stride 10, then 9 reciprocal pivots (+1 pad) */
@@ -638,7 +749,7 @@ struct ArrowArgs {
 
 __host__ __device__ __forceinline__ size_t arrow_forward_lds_doubles(int W, int nd) {
     return (size_t)(nd + (nd & 1)) + (size_t)nd * AR_YS + (size_t)nd * 18 + (size_t)9 * W * AR_YS + 3 * AR_LB + (size_t)W * 180 +
-           (size_t)nd + 2 + (size_t)(W + 2) / 2 + 1 + (size_t)nd + 2;
+           (size_t)nd + 2 + (size_t)(W + 2) / 2 + 1 + (size_t)nd + 2 + 2 + 92;      // ... + the 9x9 (stride 10) update scratch at the end
 }
 
 __global__ __launch_bounds__(256) void k_arrow_forward(const ArrowArgs a) {
@@ -658,6 +769,8 @@ __global__ __launch_bounds__(256) void k_arrow_forward(const ArrowArgs a) {
     int* eoff = reinterpret_cast<int*>(eps + nd + 2);                   // [W+1]
     int* elist = eoff + ((W + 2) & ~1) + 2;                             // [2 nd]
     int* bad_lds = elist + 2 * nd + 2;
+    double* Cs = Lb - 0;                 // set below
+    Cs = reinterpret_cast<double*>(tr_lds) + arrow_forward_lds_doubles(W, nd) - 92;
     if (tid == 0) *bad_lds = 0;
     AR_STAMP(0);
     for (int e = tid; e < nd; e += 256) eps[e] = a.ep_slots[e];
@@ -747,7 +860,11 @@ __global__ __launch_bounds__(256) void k_arrow_forward(const ArrowArgs a) {
 #pragma unroll
     for (int j = 0; j < 9; ++j) av[j] = (wv == 0 && lane < 9) ? Blk[lane * 10 + j] : 0.0;
     bool bad = false;
+    int pr = 0, pj = 0;                             // lane -> pair (pr, pj <= pr) of the rank-9 update, lanes 0..44
+    { int p = lane < 45 ? lane : 0; while ((pr + 1) * (pr + 2) / 2 <= p) ++pr; pj = p - pr * (pr + 1) / 2; }
+    long long busy = 0;
     for (int it = 0; it <= W; ++it) {
+        const long long tb0 = wall_clock64();
         if (wv == 0 && it < W) {
             const int i = it, r = lane;
             const bool more = i + 1 < W;
@@ -768,11 +885,8 @@ __global__ __launch_bounds__(256) void k_arrow_forward(const ArrowArgs a) {
                 if (lane == j) rpv = rdj;
                 av[j] = lij;
 #pragma unroll
-                for (int c = j + 1; c < 9; ++c) {
-                    const double lcj = readlane_d(lij, c);
-                    if (lane >= c) av[c] -= lij * lcj;
-                }
-            }
+                for (int c = j + 1; c < 9; ++c) av[c] -= lij * readlane_d(lij, c);      // lanes < c only touch entries above the
+            }                                                                            // diagonal, which nobody reads: no masking
             double* Lc = Lb + (i % 3) * AR_LB;
             double* Lg = a.Lblk + (size_t)i * AR_LB;
             if (r < 18) {
@@ -785,48 +899,61 @@ __global__ __launch_bounds__(256) void k_arrow_forward(const ArrowArgs a) {
                 if (r < 9) { Lc[180 + r] = rpv; if (blockIdx.x == 0) Lg[180 + r] = rpv; }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (more) {                             // D_{i+1}[r][j] -= X[r] . X[j],  X = L_{i+1,i} = rows 9..17 of Lc
-                const int rr = r < 9 ? r : 0;
-                const double* X = Lc + 90;
-                double xr[9];
+            if (more) {                             // D_{i+1}[r][j] -= X[r] . X[j],  X = L_{i+1,i} = rows 9..17 of Lc:
+                const double* X = Lc + 90;          // 45 lanes take one (r, j <= r) pair each, results pass through LDS
+                if (lane < 45) {
+                    double xa[9], xb[9];
 #pragma unroll
-                for (int k = 0; k < 9; ++k) xr[k] = X[rr * 10 + k];
-#pragma unroll
-                for (int j = 0; j < 9; ++j) {
+                    for (int k = 0; k < 9; ++k) { xa[k] = X[pr * 10 + k]; xb[k] = X[pj * 10 + k]; }
                     double sacc = 0.0;
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) sacc += xr[k] * X[j * 10 + k];
-                    nx[j] -= sacc;
+                    for (int k = 0; k < 9; ++k) sacc += xa[k] * xb[k];
+                    Cs[pr * 10 + pj] = sacc;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (r < 9) {
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) nx[j] -= Cs[r * 10 + j];
                 }
             }
 #pragma unroll
             for (int j = 0; j < 9; ++j) av[j] = (r < 9 && j <= r) ? nx[j] : 0.0;
-        } else if (wv == 1 && it >= 1 && lane < 16) {
-            const int i = it - 1, c = lane;
+        } else if (wv == 1 && it >= 1) {
+            // lane = (column c, k-group g): the 9x9 product is split over 4 groups of k and summed with two butterflies
+            const int i = it - 1, c = lane & 15, g = lane >> 4;
             double tv[9];
 #pragma unroll
-            for (int r = 0; r < 9; ++r) tv[r] = Ys[(9 * i + r) * AR_YS + c];
+            for (int r = 0; r < 9; ++r) tv[r] = g == 0 ? Ys[(9 * i + r) * AR_YS + c] : 0.0;
             if (i > 0) {
                 const double* Lp = Lb + ((i - 1) % 3) * AR_LB + 90;
 #pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    const double yk = Ys[(9 * (i - 1) + k) * AR_YS + c];
+                for (int kk = 0; kk < 3; ++kk) {
+                    const int k = g + 4 * kk;
+                    if (k < 9) {
+                        const double yk = Ys[(9 * (i - 1) + k) * AR_YS + c];
 #pragma unroll
-                    for (int r = 0; r < 9; ++r) tv[r] -= Lp[r * 10 + k] * yk;
+                        for (int r = 0; r < 9; ++r) tv[r] -= Lp[r * 10 + k] * yk;
+                    }
                 }
+#pragma unroll
+                for (int r = 0; r < 9; ++r) { tv[r] += __shfl_xor(tv[r], 16, 64); tv[r] += __shfl_xor(tv[r], 32, 64); }
             }
             const double* Lc = Lb + (i % 3) * AR_LB;
 #pragma unroll
-            for (int r = 0; r < 9; ++r) {
+            for (int k = 0; k < 9; ++k) {          // column-oriented forward substitution
+                tv[k] *= Lc[180 + k];
 #pragma unroll
-                for (int k = 0; k < r; ++k) tv[r] -= Lc[r * 10 + k] * tv[k];
-                tv[r] *= Lc[180 + r];
+                for (int r = k + 1; r < 9; ++r) tv[r] -= Lc[r * 10 + k] * tv[k];
             }
+            if (g == 0) {
 #pragma unroll
-            for (int r = 0; r < 9; ++r) Ys[(9 * i + r) * AR_YS + c] = tv[r];
+                for (int r = 0; r < 9; ++r) Ys[(9 * i + r) * AR_YS + c] = tv[r];
+            }
         }
+        busy += wall_clock64() - tb0;
         __syncthreads();
     }
+    if (blockIdx.x == 0 && lane == 0 && wv < 2) a.dbg[20 + wv] = busy;
     AR_STAMP(4);
     if (wv == 0 && bad && lane == 0) *bad_lds = 1;
     __syncthreads();
@@ -874,22 +1001,37 @@ __global__ __launch_bounds__(TR_THREADS) void k_arrow_solve(const ArrowArgs a) {
     if (*a.flag & 1) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int W = a.W, n = a.n, nd = a.nd, np = a.np, K = a.K;
-    double* Bp = reinterpret_cast<double*>(tr_lds);
-    double* part = Bp + TR_NB * bp_stride(np);
-    double* sD = part + 16 * 256;
+    double *Bp = nullptr, *part = nullptr, *Pk = nullptr, *sD;
+    if (a.lds_chol) { Pk = reinterpret_cast<double*>(tr_lds); sD = Pk + pk_doubles(np); }
+    else { Bp = reinterpret_cast<double*>(tr_lds); part = Bp + TR_NB * bp_stride(np); sD = part + 16 * 256; }
     double* ylds = sD + (TR_NB + 1) * TR_PS;
     double* red = ylds + np + (np & 1);
     int* flag = reinterpret_cast<int*>(red + 32);
     double* wb = red + 48;                        // [K] w, overwritten by z_d / z_s
     double* Lb = wb + K + (K & 1);                // [W][AR_LB]
     AR_STAMP(8);
-    const bool good = chol_left_looking(a.Sp, np, Bp, part, sD, flag);
-    if (!good) { if (tid == 0) atomicOr(a.flag, 1); return; }
-    AR_STAMP(9);
-    for (int j = tid; j < np; j += TR_THREADS) ylds[j] = a.Sp[(size_t)np * np + j];
     for (int j = tid; j < W * AR_LB; j += TR_THREADS) Lb[j] = a.Lblk[j];
-    __syncthreads();
-    back_substitute(a.Sp, np, ylds, sD);          // ylds = z_p
+    if (a.lds_chol) {
+        for (int i = wv; i <= np; i += TR_WAVES) {
+            const double* src = a.Sp + (size_t)i * np;
+            double* dst = Pk + pk_off(i);
+            for (int j = lane; j <= i && j < np; j += 64) dst[j] = src[j];
+        }
+        __syncthreads();
+        const bool good = chol_packed_lds(Pk, np, sD, flag);
+        if (!good) { if (tid == 0) atomicOr(a.flag, 1); return; }
+        AR_STAMP(9);
+        for (int j = tid; j < np; j += TR_THREADS) ylds[j] = Pk[pk_off(np) + j];
+        __syncthreads();
+        backsub_packed_lds(Pk, np, ylds, sD);     // ylds = z_p
+    } else {
+        const bool good = chol_left_looking(a.Sp, np, Bp, part, sD, flag);
+        if (!good) { if (tid == 0) atomicOr(a.flag, 1); return; }
+        AR_STAMP(9);
+        for (int j = tid; j < np; j += TR_THREADS) ylds[j] = a.Sp[(size_t)np * np + j];
+        __syncthreads();
+        back_substitute(a.Sp, np, ylds, sD);      // ylds = z_p
+    }
     AR_STAMP(10);
     // w = y_e - Y_p z_p  (one wavefront per row)
     for (int k = tid; k < K; k += TR_THREADS) {
@@ -971,7 +1113,10 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
     // one speed-bias block in the prior) and its workspaces fit the LDS; the dense kernel stays as the fallback
     const int np = 6 * c->W, K = a.n - np;
     const size_t lds_fwd = arrow_forward_lds_doubles(c->W, n_ddt) * 8;
-    const size_t lds_slv = glio_tr_step_lds_bytes(np) + arrow_solve_extra_doubles(c->W, K) * 8;
+    const size_t slv_tail = ((size_t)(TR_NB + 1) * TR_PS + np + (np & 1) + 48 + arrow_solve_extra_doubles(c->W, K)) * 8;
+    const size_t lds_pk = pk_doubles(np) * 8 + slv_tail;
+    const bool lds_chol = lds_pk <= 160 * 1024;
+    const size_t lds_slv = lds_chol ? lds_pk : glio_tr_step_lds_bytes(np) + arrow_solve_extra_doubles(c->W, K) * 8;
     const bool arrow = c->arrow.mode == 1 && c->arrow.gnss_ok && c->arrow.prior_ok && c->arrow.max_epoch < n_ddt && lds_fwd <= 160 * 1024 && lds_slv <= 160 * 1024;
     a.arrow_flag = arrow ? c->arrow.d_flag : nullptr; a.arrow_z = c->arrow.d_z;
     hipLaunchKernelGGL(k_tr_prepare, dim3(1), dim3(TR_THREADS), 0, c->stream, a);
@@ -981,7 +1126,7 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
         r.W = c->W; r.n = a.n; r.nd = n_ddt; r.np = np; r.K = K; r.ldY = np + 2;
         r.A = c->d_L; r.ep_slots = c->arrow.d_ep_slots; r.ep_off = c->arrow.d_ep_off; r.ep_list = c->arrow.d_ep_list;
         r.Y = c->arrow.d_Y; r.Lblk = c->arrow.d_Lblk; r.Sp = c->arrow.d_Sp; r.z = c->arrow.d_z; r.flag = c->arrow.d_flag;
-        r.status = c->d_status; r.dbg = c->arrow.d_dbg;
+        r.status = c->d_status; r.dbg = c->arrow.d_dbg; r.lds_chol = lds_chol ? 1 : 0;
         const int T = (np + 1 + 15) / 16;
         hipLaunchKernelGGL(k_arrow_forward, dim3(T), dim3(256), lds_fwd, c->stream, r);
         hipLaunchKernelGGL(k_arrow_schur, dim3(T * T), dim3(256), 0, c->stream, r);

@@ -24,3 +24,4 @@ capi.load().glio_debug_arrow_stamps(ctx._h, st)
 v = list(st)
 print("forward stamps (us):", [round((v[k + 1] - v[k]) / 100.0, 2) for k in range(0, 5)])
 print("solve stamps (us):", [round((v[k + 1] - v[k]) / 100.0, 2) for k in range(8, 13)])
+print("busy wave0/wave1 (us):", v[20] / 100.0, v[21] / 100.0)
