@@ -188,77 +188,45 @@ __device__ __forceinline__ bool chol_left_looking(double* A, const int n, double
                 __syncthreads();
             }
         }
-        // (2) diagonal block -> LDS, factored by wavefront 0 (lane i keeps row i in registers)
-        if (tid < TR_NB * TR_NB) {
-            const int i = tid / TR_NB, j = tid % TR_NB;
-            sD[i * TR_PS + j] = (i < nb && j <= i) ? A[(size_t)(k0 + i) * ld + k0 + j] : (i == j ? 1.0 : 0.0);
-        }
-        __syncthreads();
-        if (wv == 0 && !(skip & 2)) {
-            double a[TR_NB];
+        // (2+3) fused panel factorisation: every wavefront carries the diagonal block in lanes 0-15 (factored
+        //       redundantly, identical arithmetic) and 48 of the rows below (incl. the carried row n) in lanes 16-63.
+        //       The 16 right-looking register steps -- pivot and multipliers broadcast with v_readlane -- factor the
+        //       block AND solve X L_kk^T = A_panel for those rows: no separate triangular-solve phase, no LDS.
+        const int r0 = k0 + nb;
+        const int mb = n + 1 - r0;
+        if (!(skip & 2)) {
+            for (int base = wv * 48; base < mb; base += TR_WAVES * 48) {       // mb >= 1: wavefront 0 always runs
+                const bool isdiag = lane < TR_NB;
+                const int bi = base + lane - TR_NB;
+                const bool live = isdiag ? lane < nb : bi < mb;
+                double* prow = A + (size_t)(live ? (isdiag ? k0 + lane : r0 + bi) : 0) * ld + k0;
+                double a[TR_NB];
 #pragma unroll
-            for (int j = 0; j < TR_NB; ++j) a[j] = (lane < TR_NB) ? sD[lane * TR_PS + j] : 0.0;
-            bool bad = false;
-            double tolv = 0.0;
-            if (SEMI) tolv = (lane < nb) ? dtol[k0 + lane] : 0.0;
-#pragma unroll
-            for (int j = 0; j < TR_NB; ++j) {
-                double djj = readlane_d(a[j], j);
-                bool null_pivot = false;
-                if (SEMI) null_pivot = j < nb && djj <= readlane_d(tolv, j);
-                if (!null_pivot && (!(djj > 0.0) || !isfinite(djj))) { bad = true; djj = 1.0; }
-                const double rd = null_pivot ? 0.0 : rsqrt(djj);
-                const double d = djj * rd;
-                const double lij = (lane == j) ? d : a[j] * rd;
-                if (lane == j) sD[TR_NB * TR_PS + j] = rd;        // reciprocal pivots for the row solves
-                a[j] = lij;
-#pragma unroll
-                for (int c = j + 1; c < TR_NB; ++c) a[c] -= lij * readlane_d(lij, c);   // unmasked: lanes < c only spoil entries above
-                                                                                        // the diagonal, which are never read or stored
-            }
-            if (lane < TR_NB) {
+                for (int j = 0; j < TR_NB; ++j) a[j] = (live && j < nb && (!isdiag || j <= lane)) ? prow[j] : ((isdiag && lane == j) ? 1.0 : 0.0);
+                bool bad = false;
+                double tolv = 0.0;
+                if (SEMI) tolv = (lane < nb) ? dtol[k0 + lane] : 0.0;
 #pragma unroll
                 for (int j = 0; j < TR_NB; ++j) {
-                    if (j <= lane) {
-                        sD[lane * TR_PS + j] = a[j];
-                        if (lane < nb && j < nb) A[(size_t)(k0 + lane) * ld + k0 + j] = a[j];
-                    }
+                    double djj = readlane_d(a[j], j);
+                    bool null_pivot = false;
+                    if (SEMI) null_pivot = j < nb && djj <= readlane_d(tolv, j);
+                    if (!null_pivot && (!(djj > 0.0) || !isfinite(djj))) { bad = true; djj = 1.0; }
+                    const double rd = null_pivot ? 0.0 : rsqrt(djj);
+                    const double lij = (lane == j) ? djj * rd : a[j] * rd;
+                    a[j] = lij;
+#pragma unroll
+                    for (int c = j + 1; c < TR_NB; ++c) a[c] -= lij * readlane_d(lij, c);   // unmasked: entries above the diagonal
+                }                                                                           // are never read or stored
+                if (live && ((base == 0 && wv == 0) || !isdiag)) {
+#pragma unroll
+                    for (int j = 0; j < TR_NB; ++j) if (j < nb && (!isdiag || j <= lane)) prow[j] = a[j];
                 }
+                if (bad && wv == 0 && lane == 0) *flag = 1 + k0;
             }
-            if (bad && lane == 0) *flag = 1 + k0;
         }
         __syncthreads();
         if (*flag) return false;
-        // (3) rows below (incl. the carried row n): X L_kk^T = A_panel, one lane per row.  L_kk is NOT copied
-        //     per lane: every wavefront keeps it distributed (lane l holds row l&15) and the coefficient
-        //     L[j][k] reaches the FMA as a scalar through v_readlane -- no LDS traffic, 64 live VGPRs.
-        const int r0 = k0 + nb;
-        const int mb = n + 1 - r0;
-        if (!(skip & 4) && wv * 64 < ((mb + 63) & ~63)) {
-            double lr[TR_NB];
-#pragma unroll
-            for (int k = 0; k < TR_NB; ++k) lr[k] = sD[(lane & 15) * TR_PS + k];
-            const double rdl = sD[TR_NB * TR_PS + (lane & 15)];
-            for (int i0 = wv * 64; i0 < mb; i0 += TR_THREADS) {
-                const int i = i0 + lane;
-                const bool live = i < mb;
-                double* row = A + (size_t)(r0 + (live ? i : 0)) * ld + k0;
-                double xv[TR_NB];
-#pragma unroll
-                for (int j = 0; j < TR_NB; ++j) xv[j] = (live && j < nb) ? row[j] : 0.0;
-#pragma unroll
-                for (int j = 0; j < TR_NB; ++j) {          // column-oriented: 15-j independent FMAs per step
-                    xv[j] *= readlane_d(rdl, j);
-#pragma unroll
-                    for (int k = j + 1; k < TR_NB; ++k) xv[k] -= xv[j] * readlane_d(lr[j], k);
-                }
-                if (live) {
-#pragma unroll
-                    for (int j = 0; j < TR_NB; ++j) if (j < nb) row[j] = xv[j];
-                }
-            }
-        }
-        __syncthreads();
     }
     return true;
 }
