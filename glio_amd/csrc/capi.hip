@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <vector>
 
 #include "glio_device.h"
@@ -130,6 +131,9 @@ int glio_create(int device, const glio_opts* opts, glio_ctx** out) {
         GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
     }
     GLIO_HIP_CHECK(hipHostMalloc((void**)&c->h_status, sizeof(SolverStatus)));
+    GLIO_HIP_CHECK(hipHostMalloc((void**)&c->h_progress, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    GLIO_HIP_CHECK(hipHostGetDevicePointer((void**)&c->d_progress, (void*)c->h_progress, 0));
+    c->h_progress[0] = 0; c->h_progress[1] = 0; c->enqueue_lead = 1;
     GLIO_HIP_CHECK(hipHostMalloc((void**)&c->h_xbuf, (size_t)nx * 8));
     GLIO_HIP_CHECK(hipEventCreate(&c->ev0)); GLIO_HIP_CHECK(hipEventCreate(&c->ev1));
     CtxExtra* ex = new CtxExtra();
@@ -158,7 +162,7 @@ void glio_destroy(glio_ctx* c) {
                     c->d_lidar_partials, c->d_lidar_blocks, c->d_L, c->d_vec, c->d_status,
                     c->arrow.d_ep_slots, c->arrow.d_ep_off, c->arrow.d_ep_list, c->arrow.d_Y, c->arrow.d_Lblk, c->arrow.d_Sp, c->arrow.d_z, c->arrow.d_flag, c->arrow.d_dbg};
     for (void* p : ptrs) if (p) hipFree(p);
-    hipHostFree(c->h_status); hipHostFree(c->h_xbuf);
+    hipHostFree(c->h_status); hipHostFree(c->h_xbuf); hipHostFree((void*)c->h_progress);
     hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
     for (size_t i = 0; i < g_extras.size(); ++i)
         if (g_extras[i].first == c) {
@@ -484,9 +488,25 @@ static int enqueue_solve(glio_ctx* c, int n_ddt) {
     *c->h_status = st;
     GLIO_HIP_CHECK(hipMemcpyAsync(c->d_status, c->h_status, sizeof st, hipMemcpyHostToDevice, c->stream));
     GLIO_HIP_CHECK(hipMemcpyAsync(c->d_x[0], c->h_xbuf, (size_t)nx * 8, hipMemcpyHostToDevice, c->stream));
-    for (int it = 0; it <= c->opts.max_iterations; ++it) {
-        enqueue_linearize(c, 1, 0, n_ddt);
-        glio_launch_tr_step(c, n_ddt);
+    // The trust-region loop lives on the device (SolverStatus); the host only feeds it kernel groups
+    // [linearise, step].  Instead of queueing all max_iterations+1 groups blindly -- after convergence the rest are
+    // empty launches, ~2.5 us each -- it stays `enqueue_lead` groups ahead of the GPU, watching a progress word the
+    // first kernel of every group writes to mapped host memory, and stops as soon as `done` shows up.
+    c->h_progress[0] = 0; c->h_progress[1] = 0;
+    const int total = c->opts.max_iterations + 1;
+    const int lead = c->enqueue_lead < 1 ? total : c->enqueue_lead;
+    const auto t_start = std::chrono::steady_clock::now();
+    int enq = 0, spins = 0;
+    while (enq < total) {
+        if (c->h_progress[1]) break;
+        if (enq - c->h_progress[0] <= lead) {
+            enqueue_linearize(c, 1, 0, n_ddt);
+            glio_launch_tr_step(c, n_ddt);
+            ++enq;
+        } else if (((++spins) & 0xfff) == 0 && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(20)) {
+            glio_set_error("solver made no progress for 20 s (group %d of %d)", c->h_progress[0], total);
+            return GLIO_E_HIP;
+        }
     }
     GLIO_HIP_CHECK(hipGetLastError());
     return GLIO_OK;
@@ -636,6 +656,12 @@ int glio_debug_arrow_stamps(glio_ctx* c, long long* out64) {
     GLIO_HIP_CHECK(hipSetDevice(c->device));
     GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
     GLIO_HIP_CHECK(hipMemcpy(out64, c->arrow.d_dbg, 64 * 8, hipMemcpyDeviceToHost));
+    return GLIO_OK;
+}
+// kernel groups kept queued ahead of the GPU by glio_solve (0 = queue all max_iterations+1 groups up front)
+int glio_debug_set_enqueue_lead(glio_ctx* c, int lead) {
+    if (!c || lead < 0) return GLIO_E_ARG;
+    c->enqueue_lead = lead;
     return GLIO_OK;
 }
 int glio_debug_set_k3(glio_ctx* c, int bpk, int unroll) {

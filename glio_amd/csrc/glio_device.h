@@ -72,6 +72,8 @@ struct SolverStatus {
     double alpha, dogleg_step_norm;
     double initial_cost, grad_max_norm;
     double mu_used;       // mu of the factorisation behind the stored Gauss-Newton step
+    int group;            // number of trust-region kernel groups started (k_tr_prepare launches) in this solve
+    int pad_;
 };
 
 // Structured ("arrow") linear solver of the trust-region step (solver_kernels.hip): buffers + structure tables
@@ -142,6 +144,9 @@ struct glio_ctx {
     double* d_vec;                // scale, diag, grad, gn, step, delta, tmp ... 10 x n_max
     SolverStatus* d_status;
     SolverStatus* h_status;       // pinned
+    volatile int* h_progress;     // pinned + mapped: [0] groups started, [1] done -- written by the GPU, polled by the host
+    int* d_progress;              // device alias of h_progress
+    int enqueue_lead;             // kernel groups the host keeps queued ahead of the GPU
     double* h_xbuf;               // pinned staging for state upload/download
     hipEvent_t ev0, ev1;
     int have_factors;

@@ -47,6 +47,7 @@ struct TrArgs {
     double* L; double* vec; int vstride;
     SolverStatus* status;
     int* arrow_flag; const double* arrow_z;      // structured solver result (null = dense only)
+    int* progress;                               // host-mapped {groups started, done}
 };
 
 // workspace vectors (global, persist across the launches of one solve)
@@ -381,7 +382,7 @@ __device__ __forceinline__ void finalize(const TrArgs& a, const SolverStatus& s)
     const double* xc = s.cur ? a.x1 : a.x0;
     const int nx = 16 * a.W + a.n_ddt;
     for (int k = threadIdx.x; k < nx; k += blockDim.x) a.xout[k] = xc[k];
-    if (threadIdx.x == 0) *a.status = s;
+    if (threadIdx.x == 0) { *a.status = s; a.progress[1] = 1; __threadfence_system(); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -392,7 +393,14 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_prepare(const TrArgs a) {
     __shared__ SolverStatus s;
     const int tid = threadIdx.x;
     const int n = a.n, W = a.W, nx = 16 * W + a.n_ddt;
-    if (tid == 0) s = *a.status;
+    if (tid == 0) {
+        s = *a.status;
+        s.group += 1;
+        a.status->group = s.group;
+        a.progress[0] = s.group;                 // the host enqueues the next kernel group when it sees this one start
+        if (s.done) a.progress[1] = 1;
+        __threadfence_system();
+    }
     __syncthreads();
     if (s.done) return;
     double* scale = V_SCALE(a); double* diag = V_DIAG(a); double* grad = V_GRAD(a); double* u = V_U(a);
@@ -594,7 +602,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_factor(const TrArgs a) {
     __syncthreads();
     if (tid == 0) {
         if (solved) { a.status->mu_used = *smu; a.status->mu = fmax(1e-8, 2.0 * (*smu) / 10.0); }
-        else { a.status->mu = *smu; a.status->done = 1; a.status->termination = GLIO_TERM_FAILURE; }
+        else { a.status->mu = *smu; a.status->done = 1; a.status->termination = GLIO_TERM_FAILURE; a.progress[1] = 1; __threadfence_system(); }
     }
     if (!solved) {
         const double* xc = a.status->cur ? a.x1 : a.x0;
@@ -1076,7 +1084,7 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
     a.x0 = c->d_x[0]; a.x1 = c->d_x[1]; a.xout = c->d_xout;
     a.H0 = c->d_H[0]; a.H1 = c->d_H[1]; a.g0 = c->d_g[0]; a.g1 = c->d_g[1]; a.c0 = c->d_cost[0]; a.c1 = c->d_cost[1];
     a.L = c->d_L; a.vec = c->d_vec; a.vstride = c->n_max;
-    a.status = c->d_status;
+    a.status = c->d_status; a.progress = c->d_progress;
     // structured factorisation when the factor graph is a chain (IMU / Doppler edges between neighbours only, at most
     // one speed-bias block in the prior) and its workspaces fit the LDS; the dense kernel stays as the fallback
     const int np = 6 * c->W, K = a.n - np;
