@@ -126,7 +126,7 @@ int glio_create(int device, const glio_opts* opts, glio_ctx** out) {
         GLIO_HIP_CHECK(hipMemsetAsync(ar.d_ep_off, 0, (W + 1) * 4, c->stream));
         ALLOC(ar.d_Y, (size_t)(c->n_ddt_max + 9 * W) * (6 * W + 2) * 8);
         ALLOC(ar.d_Lblk, (size_t)W * 190 * 8); ALLOC(ar.d_Sp, (size_t)(6 * W + 1) * 6 * W * 8);
-        ALLOC(ar.d_z, (size_t)n_max * 8); ALLOC(ar.d_flag, 4); ALLOC(ar.d_dbg, 64 * 8);
+        ALLOC(ar.d_z, (size_t)n_max * 8); ALLOC(ar.d_flag, 4); ALLOC(ar.d_dbg, 320 * 8);
         GLIO_HIP_CHECK(hipMemsetAsync(ar.d_flag, 0, 4, c->stream));
         GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
     }
@@ -655,7 +655,7 @@ int glio_debug_arrow_stamps(glio_ctx* c, long long* out64) {
     if (!c || !out64) return GLIO_E_ARG;
     GLIO_HIP_CHECK(hipSetDevice(c->device));
     GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
-    GLIO_HIP_CHECK(hipMemcpy(out64, c->arrow.d_dbg, 64 * 8, hipMemcpyDeviceToHost));
+    GLIO_HIP_CHECK(hipMemcpy(out64, c->arrow.d_dbg, 320 * 8, hipMemcpyDeviceToHost));
     return GLIO_OK;
 }
 // kernel groups kept queued ahead of the GPU by glio_solve (0 = queue all max_iterations+1 groups up front)

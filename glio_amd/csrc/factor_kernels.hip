@@ -21,6 +21,7 @@
 #define SF_THREADS 256
 
 struct SmallArgs {
+    long long* dbg;           // per-workgroup duration (100 MHz ticks), development aid
     int W, n_imu, n_groups, has_prior, n_ddt;
     int marg;                  // 1 = marginalization convention for quaternion blocks (global x,y,z columns, quirk Q8)
     int lidar_blocks_per_kf;
@@ -560,7 +561,14 @@ __device__ void prior_H_block(const SmallArgs& a, const double* __restrict__ x, 
     }
 }
 
+__device__ void small_factors_body(const SmallArgs& a);
 __global__ __launch_bounds__(SF_THREADS) void k_small_factors(const SmallArgs a) {
+    const long long t0 = wall_clock64();
+    small_factors_body(a);
+    __syncthreads();
+    if (threadIdx.x == 0 && a.dbg && blockIdx.x < 250) a.dbg[blockIdx.x] = wall_clock64() - t0;
+}
+__device__ void small_factors_body(const SmallArgs& a) {
     int which = a.fixed_which;
     if (a.use_status) {
         if (a.st->done || !a.st->cand_pending) return;
@@ -807,6 +815,7 @@ GnssDevExtra* glio_extra(glio_ctx* c);   // defined in capi.hip
 void glio_launch_small_factors(glio_ctx* c, int use_status_cand, int which, int n_ddt, int marg) {
     SmallArgs a;
     a.marg = marg;
+    a.dbg = c->arrow.d_dbg + 64;
     GnssDevExtra* ex = glio_extra(c);
     a.W = c->W; a.n_imu = c->n_imu; a.n_groups = c->n_groups; a.has_prior = c->prior_n > 0; a.n_ddt = n_ddt;
     a.lidar_blocks_per_kf = c->k3_bpk;
