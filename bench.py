@@ -105,6 +105,8 @@ def main():
     # ---- roofline of the dominant kernel (K3), HIP events on the context stream
     ctx.linearize(state, want_H=False)
     k3_ms = ctx.time_kernel(capi.KERNEL_LIDAR_LINEARIZE, 50)
+    rd_ms = ctx.time_kernel(capi.KERNEL_STREAM_READ, 50)
+    ctx.linearize(state, want_H=False)
     lin_ms = ctx.time_kernel(capi.KERNEL_FULL_LINEARIZE, 50)
     trs_ms = ctx.time_kernel(capi.KERNEL_TR_STEP, 20)
     marg_ms = ctx.time_kernel(capi.KERNEL_MARGINALIZE, 20)
@@ -112,7 +114,9 @@ def main():
     achieved = n_res * BYTES_PER_RESIDUAL / (k3_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": "k_lidar_linearize", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
-                "bytes_per_launch": n_res * BYTES_PER_RESIDUAL, "avg_launch_us": round(k3_ms * 1e3, 2)}
+                "bytes_per_launch": n_res * BYTES_PER_RESIDUAL, "avg_launch_us": round(k3_ms * 1e3, 2),
+                "read_only_same_bytes_GBps": round(n_res * BYTES_PER_RESIDUAL / (rd_ms * 1e-3) / 1e9, 1),
+                "frac_of_read_only": round(rd_ms / k3_ms, 4)}
 
     # HBM traffic per launch from the committed PMC pass of this same command (rocprofv3 --pmc FETCH_SIZE, x2 gfx950
     # correction; scripts/gpu_pmc.sh writes the file) -- only quoted when it was taken on the same workload

@@ -12,7 +12,7 @@ from . import synth
 _LIB = None
 LIB_PATH = os.environ.get("GLIO_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libglio_hip.so")
 
-KERNEL_LIDAR_LINEARIZE, KERNEL_FULL_LINEARIZE, KERNEL_TR_STEP, KERNEL_ASSOCIATE, KERNEL_MAP_BUILD, KERNEL_MARGINALIZE = range(6)
+KERNEL_LIDAR_LINEARIZE, KERNEL_FULL_LINEARIZE, KERNEL_TR_STEP, KERNEL_ASSOCIATE, KERNEL_MAP_BUILD, KERNEL_MARGINALIZE, KERNEL_STREAM_READ = range(7)
 
 
 class GlioError(RuntimeError):

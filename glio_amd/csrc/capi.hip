@@ -112,7 +112,7 @@ int glio_create(int device, const glio_opts* opts, glio_ctx** out) {
     }
     ALLOC(c->d_xout, nx * 8);
     ALLOC(c->d_lidar_partials, (size_t)W * GLIO_K3_MAX_BLOCKS_PER_KF * GLIO_LIDAR_ACC * 8);
-    c->k3_bpk = GLIO_K3_BLOCKS_PER_KF; c->k3_unroll = 14;   /* 4 loads in flight, non-temporal (streamed once per launch) */
+    c->k3_bpk = GLIO_K3_BLOCKS_PER_KF; c->k3_unroll = 22;   /* 2-deep batches, non-temporal loads, next batch issued before the arithmetic of the current one */
     { int per = 768 / W;   /* ~3 workgroups per CU measured best on MI355X (scripts/k3_sweep.py) */ if (per < 8) per = 8; if (per > GLIO_K3_MAX_BLOCKS_PER_KF) per = GLIO_K3_MAX_BLOCKS_PER_KF; c->k3_bpk = per; }
     ALLOC(c->d_lidar_blocks, 2 * (size_t)W * GLIO_LIDAR_ACC * 8);
     ALLOC(c->d_L, (size_t)(n_max + 1) * n_max * 8);
@@ -665,7 +665,7 @@ int glio_debug_set_enqueue_lead(glio_ctx* c, int lead) {
     return GLIO_OK;
 }
 int glio_debug_set_k3(glio_ctx* c, int bpk, int unroll) {
-    if (!c || bpk < 1 || bpk > GLIO_K3_MAX_BLOCKS_PER_KF || (unroll != 1 && unroll != 2 && unroll != 4 && unroll != 8 && unroll != 12 && unroll != 14 && unroll != 18)) return GLIO_E_ARG;
+    if (!c || bpk < 1 || bpk > GLIO_K3_MAX_BLOCKS_PER_KF || (unroll != 1 && unroll != 2 && unroll != 4 && unroll != 8 && unroll != 12 && unroll != 14 && unroll != 18 && unroll != 21 && unroll != 22 && unroll != 24)) return GLIO_E_ARG;
     c->k3_bpk = bpk; c->k3_unroll = unroll;
     return GLIO_OK;
 }
@@ -683,6 +683,7 @@ int glio_time_kernel(glio_ctx* c, int which, int reps, float* ms_out) {
         if (pass == 1) GLIO_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
         for (int k = 0; k < r; ++k) {
             if (which == GLIO_KERNEL_LIDAR_LINEARIZE) glio_launch_lidar_linearize(c, 0, 0);
+            else if (which == GLIO_KERNEL_STREAM_READ) glio_launch_stream_read(c);
             else if (which == GLIO_KERNEL_FULL_LINEARIZE) enqueue_linearize(c, 0, 0, n_ddt);
             else if (which == GLIO_KERNEL_TR_STEP) {
                 // one first-iteration step computation (scale, Cauchy, Cholesky, dogleg) on H[0]

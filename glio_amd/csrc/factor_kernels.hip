@@ -254,12 +254,16 @@ __device__ void imu_block(const double gravity, const double* __restrict__ pPi, 
 // GNSS group: DD pseudorange (no loss) + Doppler (Huber) of one (slot_i, slot_j) pair
 // ------------------------------------------------------------------------------------------------
 #define DOP_CHUNK 128
+#define DD_CHUNK 8           /* DD factors evaluated side by side: 32 lanes each */
 __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, const GnssGroup& gr, int gidx,
                            PairBlock* out, DdtBlock* ddt_out) {
-    __shared__ double raw[19], Jri[19 * 3], Jrj[19 * 3];
-    __shared__ double wres[19], wJ[19 * 6];
+    // All factors of the pair are evaluated SIDE BY SIDE (DD factor f -> lanes 32 f' .. 32 f' + 31, Doppler row -> one
+    // lane): these are chains of dependent global loads (~1-2 us each on this part), so what counts is the number of
+    // latency rounds, not the arithmetic.  The sums keep the per-factor association of the sequential formulation.
+    __shared__ double raw[DD_CHUNK][19], Jri[DD_CHUNK][19 * 3], Jrj[DD_CHUNK][19 * 3];
+    __shared__ double wres[DD_CHUNK][19], wJ[DD_CHUNK][19 * 6];
+    __shared__ int s_nw[DD_CHUNK];
     __shared__ double dJ[DOP_CHUNK * 13], dr[DOP_CHUNK], drho[DOP_CHUNK];
-    __shared__ double s_ddt[16];   // c[12], h, g for the current run
     const int tid = threadIdx.x;
     const int W = a.W;
     const int si = gr.slot_i, sj = gr.slot_j;
@@ -274,158 +278,165 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
     double h6 = 0.0, g6 = 0.0, cost_dd = 0.0;       // DD: p<36 -> H6[p]; 36<=p<42 -> g6; p==42 cost
     double h12 = 0.0, g12 = 0.0, cost_dop = 0.0;    // Doppler: p<144 -> H12[p]; 144<=p<156 -> g12; p==156 cost
 
-    // ---- DD pseudorange factors (dd_psr_factor.hpp:25-171)
-    for (int f = gr.dd_begin; f < gr.dd_end; ++f) {
-        const glio_dd_psr& F = a.dd[f];
-        const int ns = F.n_sat, m = F.master, nw = ns - 1;
-        double Pe[3];
-        {
-            double lp[3];
+    // ---- DD pseudorange factors (dd_psr_factor.hpp:25-171), DD_CHUNK at a time
+    for (int f0 = gr.dd_begin; f0 < gr.dd_end; f0 += DD_CHUNK) {
+        const int nf = min(DD_CHUNK, gr.dd_end - f0);
+        const int fl = tid >> 5, i = tid & 31;
+        if (fl < nf) {
+            const glio_dd_psr& F = a.dd[f0 + fl];
+            const int ns = F.n_sat, m = F.master;
+            if (i == 0) s_nw[fl] = ns - 1;
+            if (i < ns && i != m) {
+                double Pe[3], lp[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) lp[k] = F.ratio * Pi[k] + (1.0 - F.ratio) * Pj[k];
+                for (int k = 0; k < 3; ++k) lp[k] = F.ratio * Pi[k] + (1.0 - F.ratio) * Pj[k];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) Pe[k] = R[3 * k] * lp[0] + R[3 * k + 1] * lp[1] + R[3 * k + 2] * lp[2] + a.anc[k];
-        }
-        if (tid < ns && tid != m) {
-            const int i = tid, ri = i < m ? i : i - 1;
-            double d_ui[3], d_um[3], d_ri[3], d_rm[3];
+                for (int k = 0; k < 3; ++k) Pe[k] = R[3 * k] * lp[0] + R[3 * k + 1] * lp[1] + R[3 * k + 2] * lp[2] + a.anc[k];
+                const int ri = i < m ? i : i - 1;
+                double d_ui[3], d_um[3], d_ri[3], d_rm[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                d_ui[k] = F.user_sat_pos[i][k] - Pe[k];
-                d_um[k] = F.user_sat_pos[m][k] - Pe[k];
-                d_ri[k] = F.ref_sat_pos[i][k] - F.station[k];
-                d_rm[k] = F.ref_sat_pos[m][k] - F.station[k];
-            }
-            const double r_ui = sqrt(d_dot3(d_ui, d_ui)), r_um = sqrt(d_dot3(d_um, d_um));
-            const double r_ri = sqrt(d_dot3(d_ri, d_ri)), r_rm = sqrt(d_dot3(d_rm, d_rm));
-            const double est = (r_ui - r_ri) - (r_um - r_rm);
-            const double obs = (F.user_psr[i] - F.ref_psr[i]) - (F.user_psr[m] - F.ref_psr[m]);
-            const double wgt = fabs(est - obs) > F.threshold ? 0.05 : 1.0;     // :99-102
-            raw[ri] = wgt * (est - obs);
+                for (int k = 0; k < 3; ++k) {
+                    d_ui[k] = F.user_sat_pos[i][k] - Pe[k];
+                    d_um[k] = F.user_sat_pos[m][k] - Pe[k];
+                    d_ri[k] = F.ref_sat_pos[i][k] - F.station[k];
+                    d_rm[k] = F.ref_sat_pos[m][k] - F.station[k];
+                }
+                const double r_ui = sqrt(d_dot3(d_ui, d_ui)), r_um = sqrt(d_dot3(d_um, d_um));
+                const double r_ri = sqrt(d_dot3(d_ri, d_ri)), r_rm = sqrt(d_dot3(d_rm, d_rm));
+                const double est = (r_ui - r_ri) - (r_um - r_rm);
+                const double obs = (F.user_psr[i] - F.ref_psr[i]) - (F.user_psr[m] - F.ref_psr[m]);
+                const double wgt = fabs(est - obs) > F.threshold ? 0.05 : 1.0;     // :99-102
+                raw[fl][ri] = wgt * (est - obs);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const double ei = (d_ui[0] * R[c] + d_ui[1] * R[3 + c] + d_ui[2] * R[6 + c]) / r_ui;
-                const double em = (d_um[0] * R[c] + d_um[1] * R[3 + c] + d_um[2] * R[6 + c]) / r_um;
-                Jri[ri * 3 + c] = (-ei * wgt * F.ratio) - (-em * wgt * F.ratio);
-                Jrj[ri * 3 + c] = (-ei * wgt * (1.0 - F.ratio)) - (-em * wgt * (1.0 - F.ratio));
+                for (int c = 0; c < 3; ++c) {
+                    const double ei = (d_ui[0] * R[c] + d_ui[1] * R[3 + c] + d_ui[2] * R[6 + c]) / r_ui;
+                    const double em = (d_um[0] * R[c] + d_um[1] * R[3 + c] + d_um[2] * R[6 + c]) / r_um;
+                    Jri[fl][ri * 3 + c] = (-ei * wgt * F.ratio) - (-em * wgt * F.ratio);
+                    Jrj[fl][ri * 3 + c] = (-ei * wgt * (1.0 - F.ratio)) - (-em * wgt * (1.0 - F.ratio));
+                }
             }
         }
         __syncthreads();
-        if (tid < nw) {                       // residual = W r, J = W J  (:151-167)
+        if (fl < nf && i < s_nw[fl]) {        // residual = W r, J = W J  (:151-167)
+            const glio_dd_psr& F = a.dd[f0 + fl];
+            const int nw = s_nw[fl];
             double sr = 0, s6[6] = {0, 0, 0, 0, 0, 0};
             for (int b = 0; b < nw; ++b) {
-                const double wv = F.weight[tid * nw + b];
-                sr += wv * raw[b];
+                const double wv = F.weight[i * nw + b];
+                sr += wv * raw[fl][b];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { s6[k] += wv * Jri[b * 3 + k]; s6[3 + k] += wv * Jrj[b * 3 + k]; }
+                for (int k = 0; k < 3; ++k) { s6[k] += wv * Jri[fl][b * 3 + k]; s6[3 + k] += wv * Jrj[fl][b * 3 + k]; }
             }
-            wres[tid] = sr;
+            wres[fl][i] = sr;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) wJ[tid * 6 + k] = s6[k];
+            for (int k = 0; k < 6; ++k) wJ[fl][i * 6 + k] = s6[k];
         }
         __syncthreads();
-        if (tid < 36) {
-            const int u = tid / 6, v = tid % 6;
-            double s = 0;
-            for (int r2 = 0; r2 < nw; ++r2) s += wJ[r2 * 6 + u] * wJ[r2 * 6 + v];
-            h6 += s;
-        } else if (tid < 42) {
-            const int u = tid - 36;
-            double s = 0;
-            for (int r2 = 0; r2 < nw; ++r2) s += wJ[r2 * 6 + u] * wres[r2];
-            g6 += s;
-        } else if (tid == 42) {
-            double s = 0;
-            for (int r2 = 0; r2 < nw; ++r2) s += wres[r2] * wres[r2];
-            cost_dd += 0.5 * s;
+        for (int q = 0; q < nf; ++q) {
+            const int nw = s_nw[q];
+            if (tid < 36) {
+                const int u = tid / 6, v = tid % 6;
+                double sacc = 0;
+                for (int r2 = 0; r2 < nw; ++r2) sacc += wJ[q][r2 * 6 + u] * wJ[q][r2 * 6 + v];
+                h6 += sacc;
+            } else if (tid < 42) {
+                const int u = tid - 36;
+                double sacc = 0;
+                for (int r2 = 0; r2 < nw; ++r2) sacc += wJ[q][r2 * 6 + u] * wres[q][r2];
+                g6 += sacc;
+            } else if (tid == 42) {
+                double sacc = 0;
+                for (int r2 = 0; r2 < nw; ++r2) sacc += wres[q][r2] * wres[q][r2];
+                cost_dd += 0.5 * sacc;
+            }
         }
         __syncthreads();
     }
 
-    // ---- Doppler rows (dopp_factor.hpp:24-75 + HuberLoss(1.0), Estimator.cpp:2335), run = one epoch
+    // ---- Doppler rows (dopp_factor.hpp:24-75 + HuberLoss(1.0), Estimator.cpp:2335): all epochs of the pair side by
+    //      side, one lane per row; sums are taken epoch by epoch (run = the rows of one epoch, contiguous)
     const double OMG = 7.2921151467e-5, CLIGHT = 2.99792458e8;
-    for (int rn = gr.run_begin; rn < gr.run_end; ++rn) {
-        const DopRun run = a.runs[rn];
-        double c_acc = 0.0;          // tid<12: c[tid]; tid==12: h; tid==13: g
-        for (int c0 = run.begin; c0 < run.end; c0 += DOP_CHUNK) {
-            const int cnt = min(DOP_CHUNK, run.end - c0);
-            if (tid < cnt) {
-                const glio_doppler& F = a.dop[c0 + tid];
-                const double* Rf = F.R_ecef_local;
-                double lp[3], lv[3], Pe[3], Ve[3];
+    double carry = 0.0;          // tid 160..173: partial c[tid-160] / h / g of an epoch that straddles a chunk boundary
+    int carry_run = -1;
+    for (int c0 = gr.dop_begin; c0 < gr.dop_end; c0 += DOP_CHUNK) {
+        const int cnt = min(DOP_CHUNK, gr.dop_end - c0);
+        if (tid < cnt) {
+            const glio_doppler& F = a.dop[c0 + tid];
+            const double* Rf = F.R_ecef_local;
+            double lp[3], lv[3], Pe[3], Ve[3];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    lp[k] = F.ratio * Pi[k] + (1.0 - F.ratio) * Pj[k] + F.lever_arm[k];
-                    lv[k] = F.ratio * Vi[k] + (1.0 - F.ratio) * Vj[k];
-                }
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    Pe[k] = Rf[3 * k] * lp[0] + Rf[3 * k + 1] * lp[1] + Rf[3 * k + 2] * lp[2] + a.anc[k];
-                    Ve[k] = Rf[3 * k] * lv[0] + Rf[3 * k + 1] * lv[1] + Rf[3 * k + 2] * lv[2];
-                }
-                const double d[3] = {F.sat_pos[0] - Pe[0], F.sat_pos[1] - Pe[1], F.sat_pos[2] - Pe[2]};
-                const double rho = sqrt(d_dot3(d, d));
-                const double eh[3] = {d[0] / rho, d[1] / rho, d[2] / rho};
-                const double sag = OMG / CLIGHT * (F.sat_vel[0] * Pe[1] + F.sat_pos[0] * Ve[1] - F.sat_vel[1] * Pe[0] - F.sat_pos[1] * Ve[0]);
-                const double av[3] = {F.sat_vel[0] - Ve[0], F.sat_vel[1] - Ve[1], F.sat_vel[2] - Ve[2]};
-                const double ae = d_dot3(av, eh);
-                const double ddt = x[16 * W + F.epoch];
-                const double res = (ae + sag + ddt - F.sv_ddt + F.doppler * F.lamda) / F.var;
-                double gP[3], gV[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { gP[k] = -(av[k] - ae * eh[k]) / rho; gV[k] = -eh[k]; }
-                gP[0] += OMG / CLIGHT * (-F.sat_vel[1]); gP[1] += OMG / CLIGHT * F.sat_vel[0];
-                gV[0] += OMG / CLIGHT * (-F.sat_pos[1]); gV[1] += OMG / CLIGHT * F.sat_pos[0];
-                const double iv = 1.0 / F.var;
-                // Huber corrector for a scalar residual: sqrt(rho') on J and r, cost rho/2
-                const double ar = fabs(res), ah = a.dop_huber;
-                const bool inl = ar <= ah;
-                const double sw = inl ? 1.0 : sqrt(ah / ar);
-                drho[tid] = inl ? res * res : 2.0 * ah * ar - ah * ah;
-                dr[tid] = sw * res;
-                double* J = dJ + tid * 13;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const double gPl = gP[0] * Rf[c] + gP[1] * Rf[3 + c] + gP[2] * Rf[6 + c];
-                    const double gVl = gV[0] * Rf[c] + gV[1] * Rf[3 + c] + gV[2] * Rf[6 + c];
-                    J[0 + c] = sw * F.ratio * gPl * iv;
-                    J[3 + c] = sw * F.ratio * gVl * iv;
-                    J[6 + c] = sw * (1.0 - F.ratio) * gPl * iv;
-                    J[9 + c] = sw * (1.0 - F.ratio) * gVl * iv;
-                }
-                J[12] = sw * iv;
+            for (int k = 0; k < 3; ++k) {
+                lp[k] = F.ratio * Pi[k] + (1.0 - F.ratio) * Pj[k] + F.lever_arm[k];
+                lv[k] = F.ratio * Vi[k] + (1.0 - F.ratio) * Vj[k];
             }
-            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                Pe[k] = Rf[3 * k] * lp[0] + Rf[3 * k + 1] * lp[1] + Rf[3 * k + 2] * lp[2] + a.anc[k];
+                Ve[k] = Rf[3 * k] * lv[0] + Rf[3 * k + 1] * lv[1] + Rf[3 * k + 2] * lv[2];
+            }
+            const double d[3] = {F.sat_pos[0] - Pe[0], F.sat_pos[1] - Pe[1], F.sat_pos[2] - Pe[2]};
+            const double rho = sqrt(d_dot3(d, d));
+            const double eh[3] = {d[0] / rho, d[1] / rho, d[2] / rho};
+            const double sag = OMG / CLIGHT * (F.sat_vel[0] * Pe[1] + F.sat_pos[0] * Ve[1] - F.sat_vel[1] * Pe[0] - F.sat_pos[1] * Ve[0]);
+            const double av[3] = {F.sat_vel[0] - Ve[0], F.sat_vel[1] - Ve[1], F.sat_vel[2] - Ve[2]};
+            const double ae = d_dot3(av, eh);
+            const double ddt = x[16 * W + F.epoch];
+            const double res = (ae + sag + ddt - F.sv_ddt + F.doppler * F.lamda) / F.var;
+            double gP[3], gV[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { gP[k] = -(av[k] - ae * eh[k]) / rho; gV[k] = -eh[k]; }
+            gP[0] += OMG / CLIGHT * (-F.sat_vel[1]); gP[1] += OMG / CLIGHT * F.sat_vel[0];
+            gV[0] += OMG / CLIGHT * (-F.sat_pos[1]); gV[1] += OMG / CLIGHT * F.sat_pos[0];
+            const double iv = 1.0 / F.var;
+            // Huber corrector for a scalar residual: sqrt(rho') on J and r, cost rho/2
+            const double ar = fabs(res), ah = a.dop_huber;
+            const bool inl = ar <= ah;
+            const double sw = inl ? 1.0 : sqrt(ah / ar);
+            drho[tid] = inl ? res * res : 2.0 * ah * ar - ah * ah;
+            dr[tid] = sw * res;
+            double* J = dJ + tid * 13;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double gPl = gP[0] * Rf[c] + gP[1] * Rf[3 + c] + gP[2] * Rf[6 + c];
+                const double gVl = gV[0] * Rf[c] + gV[1] * Rf[3 + c] + gV[2] * Rf[6 + c];
+                J[0 + c] = sw * F.ratio * gPl * iv;
+                J[3 + c] = sw * F.ratio * gVl * iv;
+                J[6 + c] = sw * (1.0 - F.ratio) * gPl * iv;
+                J[9 + c] = sw * (1.0 - F.ratio) * gVl * iv;
+            }
+            J[12] = sw * iv;
+        }
+        __syncthreads();
+        for (int rn = gr.run_begin; rn < gr.run_end; ++rn) {
+            const DopRun run = a.runs[rn];
+            const int rb = max(run.begin, c0) - c0, re = min(run.end, c0 + cnt) - c0;      // rows of this epoch in the chunk
+            if (rb >= re) continue;
             if (tid < 144) {
                 const int u = tid / 12, v = tid % 12;
-                double s = 0;
-                for (int r2 = 0; r2 < cnt; ++r2) s += dJ[r2 * 13 + u] * dJ[r2 * 13 + v];
-                h12 += s;
+                double sacc = 0;
+                for (int r2 = rb; r2 < re; ++r2) sacc += dJ[r2 * 13 + u] * dJ[r2 * 13 + v];
+                h12 += sacc;
             } else if (tid < 156) {
                 const int u = tid - 144;
-                double s = 0;
-                for (int r2 = 0; r2 < cnt; ++r2) s += dJ[r2 * 13 + u] * dr[r2];
-                g12 += s;
+                double sacc = 0;
+                for (int r2 = rb; r2 < re; ++r2) sacc += dJ[r2 * 13 + u] * dr[r2];
+                g12 += sacc;
             } else if (tid == 156) {
-                double s = 0;
-                for (int r2 = 0; r2 < cnt; ++r2) s += drho[r2];
-                cost_dop += 0.5 * s;
+                double sacc = 0;
+                for (int r2 = rb; r2 < re; ++r2) sacc += drho[r2];
+                cost_dop += 0.5 * sacc;
             } else if (tid >= 160 && tid < 174) {
                 const int u = tid - 160;     // 0..11: coupling, 12: h, 13: g
-                double s = 0;
-                if (u < 13) { for (int r2 = 0; r2 < cnt; ++r2) s += dJ[r2 * 13 + u] * dJ[r2 * 13 + 12]; }
-                else { for (int r2 = 0; r2 < cnt; ++r2) s += dJ[r2 * 13 + 12] * dr[r2]; }
-                c_acc += s;
+                double sacc = 0;
+                if (u < 13) { for (int r2 = rb; r2 < re; ++r2) sacc += dJ[r2 * 13 + u] * dJ[r2 * 13 + 12]; }
+                else { for (int r2 = rb; r2 < re; ++r2) sacc += dJ[r2 * 13 + 12] * dr[r2]; }
+                if (carry_run == rn) sacc = carry + sacc;
+                if (run.end <= c0 + cnt) {          // epoch complete: publish its clock-drift block
+                    DdtBlock* D = ddt_out + run.epoch;
+                    if (u < 12) D->c[u] = sacc; else if (u == 12) D->h = sacc; else D->g = sacc;
+                    if (u == 0) { D->group = gidx; D->used = 1; }
+                } else { carry = sacc; carry_run = rn; }
             }
-            __syncthreads();
-        }
-        if (tid >= 160 && tid < 174) s_ddt[tid - 160] = c_acc;
-        __syncthreads();
-        if (tid == 0) {
-            DdtBlock* D = ddt_out + run.epoch;
-            for (int k = 0; k < 12; ++k) D->c[k] = s_ddt[k];
-            D->h = s_ddt[12]; D->g = s_ddt[13];
-            D->group = gidx; D->used = 1;
         }
         __syncthreads();
     }

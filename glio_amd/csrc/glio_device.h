@@ -243,6 +243,7 @@ void glio_launch_lidar_linearize(glio_ctx* c, int use_status_cand, int which, in
 // factor_kernels.hip
 void glio_launch_small_factors(glio_ctx* c, int use_status_cand, int which, int n_ddt, int marg = 0);
 void glio_launch_assemble(glio_ctx* c, int use_status_cand, int which, int n_ddt);
+void glio_launch_stream_read(glio_ctx* c);
 // solver_kernels.hip
 void glio_launch_tr_step(glio_ctx* c, int n_ddt);
 // marginalization of slot 0 from lidar_blocks/imu_blocks/prior H of buffer 0 (evaluated with marg = 1)

@@ -80,7 +80,7 @@ template <bool NT> __device__ __forceinline__ float4 k3_load4(const float4* p) {
 }
 template <bool NT> __device__ __forceinline__ double k3_load1(const double* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
 
-template <int UNROLL, bool MARG, bool NT = false>
+template <int UNROLL, bool MARG, bool NT = false, bool PIPE = false>
 __global__ __launch_bounds__(GLIO_K3_THREADS) void k_lidar_linearize(
     const float4* __restrict__ pts, const float4* __restrict__ planes, const double* __restrict__ scores,
     const int* __restrict__ count, const int cap, const double* __restrict__ x0, const double* __restrict__ x1,
@@ -119,8 +119,36 @@ __global__ __launch_bounds__(GLIO_K3_THREADS) void k_lidar_linearize(
     const double* __restrict__ S = scores + base;
     const int stride = nb * GLIO_K3_THREADS;
     int i = blockIdx.x * GLIO_K3_THREADS + threadIdx.x;
+    if (PIPE) {
+        // software pipeline: the loads of batch k+1 are issued before the arithmetic of batch k, so that one resident
+        // wavefront overlaps its own ~2.3 us of fp64 work with the memory stream (few, long-running workgroups)
+        float4 p[UNROLL], pl[UNROLL];
+        double s[UNROLL];
+        bool have = i + (UNROLL - 1) * stride < n;
+        if (have) {
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) { p[u] = k3_load4<NT>(P + i + u * stride); pl[u] = k3_load4<NT>(Q + i + u * stride); s[u] = k3_load1<NT>(S + i + u * stride); }
+        }
+        while (have) {
+            const int inext = i + UNROLL * stride;
+            const bool more = inext + (UNROLL - 1) * stride < n;
+            float4 p2[UNROLL], pl2[UNROLL];
+            double s2[UNROLL];
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) { p2[u] = k3_load4<NT>(P + inext + u * stride); pl2[u] = k3_load4<NT>(Q + inext + u * stride); s2[u] = k3_load1<NT>(S + inext + u * stride); }
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) lidar_accumulate<MARG>(p[u], pl[u], s[u], M, t, lc.tlb, lc.huber, acc, lc.RlbT, q);
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) { p[u] = p2[u]; pl[u] = pl2[u]; s[u] = s2[u]; }
+            }
+            i = inext; have = more;
+        }
+    }
     // main loop: UNROLL independent 16+16+8 B loads in flight per lane before any math
-    for (; i + (UNROLL - 1) * stride < n; i += UNROLL * stride) {
+    for (; !PIPE && i + (UNROLL - 1) * stride < n; i += UNROLL * stride) {
         float4 p[UNROLL], pl[UNROLL];
         double s[UNROLL];
 #pragma unroll
@@ -193,6 +221,32 @@ __global__ __launch_bounds__(GLIO_K3_THREADS) void k_lidar_linearize(
     }
 }
 
+// Practical ceiling for K3: the same three streams (16 + 16 + 8 B per residual), same grid, same non-temporal loads,
+// but only a trivial sum -- what the memory system delivers for a launch of this size (bench.py reports it next to K3).
+__global__ __launch_bounds__(GLIO_K3_THREADS) void k_stream_read(const float4* __restrict__ pts, const float4* __restrict__ planes,
+                                                                 const double* __restrict__ scores, const int* __restrict__ count,
+                                                                 const int cap, double* __restrict__ out) {
+    const int kf = blockIdx.y, n = count[kf];
+    const size_t base = (size_t)kf * cap;
+    const int stride = gridDim.x * GLIO_K3_THREADS;
+    double acc = 0.0;
+    int i = blockIdx.x * GLIO_K3_THREADS + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        float4 p[4], q[4]; double s[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { p[u] = k3_load4<true>(pts + base + i + u * stride); q[u] = k3_load4<true>(planes + base + i + u * stride); s[u] = k3_load1<true>(scores + base + i + u * stride); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += (double)(p[u].x + p[u].y + p[u].z + p[u].w) + (double)(q[u].x + q[u].y + q[u].z + q[u].w) + s[u];
+    }
+    for (; i < n; i += stride) { const float4 p = pts[base + i], q = planes[base + i]; acc += (double)(p.x + p.y + p.z + p.w) + (double)(q.x + q.y + q.z + q.w) + scores[base + i]; }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) out[((size_t)kf * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)] = acc;
+}
+void glio_launch_stream_read(glio_ctx* c) {
+    hipLaunchKernelGGL(k_stream_read, dim3(c->k3_bpk, c->W), dim3(GLIO_K3_THREADS), 0, c->stream, c->d_pts, c->d_planes, c->d_scores, c->d_count,
+                       c->cap, c->d_lidar_partials);
+}
+
 void glio_launch_lidar_linearize(glio_ctx* c, int use_status_cand, int which, int marg) {
     LidarConst lc;
     // R(q_lb)^T via Eigen's inverse(): conj / |q|^2
@@ -218,6 +272,9 @@ void glio_launch_lidar_linearize(glio_ctx* c, int use_status_cand, int which, in
         case 12: K3_LAUNCH_(2, false, true); break;
         case 14: K3_LAUNCH_(4, false, true); break;
         case 18: K3_LAUNCH_(8, false, true); break;
+        case 21: K3_LAUNCH_(1, false, true, true); break;
+        case 22: K3_LAUNCH_(2, false, true, true); break;
+        case 24: K3_LAUNCH_(4, false, true, true); break;
         default: K3_LAUNCH_(4, false); break;
     }
 #undef K3_LAUNCH_

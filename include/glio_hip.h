@@ -114,7 +114,8 @@ int glio_eval_imu(glio_ctx* ctx, const glio_preint* pre, double const* const* pa
 /* ---- measurement hooks (bench.py): time `reps` launches of one kernel with HIP events on the
  * context's stream; returns average milliseconds per launch in *ms_out. */
 enum { GLIO_KERNEL_LIDAR_LINEARIZE = 0, GLIO_KERNEL_FULL_LINEARIZE = 1, GLIO_KERNEL_TR_STEP = 2,
-       GLIO_KERNEL_ASSOCIATE = 3, GLIO_KERNEL_MAP_BUILD = 4, GLIO_KERNEL_MARGINALIZE = 5 };
+       GLIO_KERNEL_ASSOCIATE = 3, GLIO_KERNEL_MAP_BUILD = 4, GLIO_KERNEL_MARGINALIZE = 5,
+       GLIO_KERNEL_STREAM_READ = 6 /* same bytes as LIDAR_LINEARIZE, no arithmetic: the practical ceiling */ };
 int glio_time_kernel(glio_ctx* ctx, int which, int reps, float* ms_out);
 /* time `reps` complete solves from the same initial state with HIP events (state is not modified) */
 int glio_time_solve(glio_ctx* ctx, const glio_state* state, int reps, float* ms_out, glio_summary* last);

@@ -13,14 +13,9 @@ st = (C.c_longlong * 320)()
 capi.load().glio_debug_arrow_stamps(ctx._h, st)
 v = np.array(list(st))[64:] / 100.0
 W = 20
-nu = 250 - W - 19 - 9
-import collections
 def stat(name, a):
     a = np.array(a)
     if len(a): print(f"{name:14s} n {len(a):4d} min {a.min():6.1f} mean {a.mean():6.1f} max {a.max():6.1f}")
-stat("lidar reduce", v[:W]); stat("imu", v[W:W + 19])
-# units: find count from context
-import ctypes as C2
-n_units = int(sum(1 for _ in win.dd)) + len(set((d.slot_i, d.slot_j, d.epoch) for d in win.dop))
-stat("gnss units", v[W + 19:W + 19 + n_units]); stat("prior", v[W + 19 + n_units:W + 19 + n_units + 9])
-print("n_units", n_units, "full_linearize", ctx.time_kernel(1, 30) * 1e3)
+stat("lidar reduce", v[:W]); stat("imu", v[W:W + 19]); stat("gnss", v[W + 19:W + 38]); stat("prior", v[W + 38:W + 47])
+print("prior blocks", v[W + 38:W + 47].round(1))
+print("full_linearize", ctx.time_kernel(1, 30) * 1e3, " stream_read", ctx.time_kernel(6, 50) * 1e3, " k3", ctx.time_kernel(0, 50) * 1e3)
