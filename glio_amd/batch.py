@@ -115,6 +115,87 @@ def make_constraints(gt, lo, hi, per_kf, band, seed=20260930, device="cpu"):
     return ci, cj, cp.contiguous(), nc, score.contiguous()
 
 
+# ------------------------------------------------------------------ batch association
+def search_window(idx, size, search_range, start_idx=0):
+    """First keyframe of the 2*search_range+1 window searched for keyframe `idx` (Estimator.cpp:3009-3017):
+    centred in the interior, clamped to the ends of the batch."""
+    if idx >= search_range + start_idx and idx < size - 1 - search_range:
+        return idx - search_range
+    if idx < search_range + start_idx:
+        return start_idx
+    return size - 2 * search_range - 1
+
+
+def pair_list(K, search_range):
+    """All (idx, search_idx) pairs of a batch in (ci, cj) order: the loop of Estimator.cpp:3004-3076 /
+    findGlobalCorrespondingSurfFeaturesAdd_Batch (:3814-3815)."""
+    ci, cj = [], []
+    for idx in range(K):
+        s0 = search_window(idx, K, search_range)
+        for j in range(s0, s0 + 2 * search_range + 1):
+            if j != idx and 0 <= j < K:
+                ci.append(idx); cj.append(j)
+    return np.asarray(ci, np.int32), np.asarray(cj, np.int32)
+
+
+class BatchAssociation:
+    """Device-resident findGlobalCorrespondingSurfFeaturesAdd_Batch: keyframe clouds stay on the GPU, `run` builds the
+    pair-major constraint arrays K8 consumes.  No CPU fallback."""
+
+    def __init__(self, K, max_points_per_frame, max_constraints, device=0):
+        lib = capi.load()
+        if lib.glio_device_count() < 1:
+            raise capi.GlioError("no HIP device visible: batch association has no CPU fallback")
+        lib.glio_bassoc_destroy.restype = None
+        self.K = K
+        self._h = C.c_void_p()
+        capi._check(lib.glio_bassoc_create(device, K, max_points_per_frame, C.c_int64(max_constraints), C.byref(self._h)))
+        self.pair_ci = self.pair_cj = self.pair_count = None
+        self.total = 0
+
+    def close(self):
+        if self._h:
+            capi.load().glio_bassoc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_frame(self, k, scan):
+        scan = np.ascontiguousarray(scan, np.float32)
+        capi._check(capi.load().glio_bassoc_set_frame(self._h, k, T.fptr(scan) if len(scan) else None, len(scan)))
+
+    def run(self, poses, pair_ci, pair_cj):
+        poses = np.ascontiguousarray(poses, np.float64)
+        self.pair_ci = np.ascontiguousarray(pair_ci, np.int32); self.pair_cj = np.ascontiguousarray(pair_cj, np.int32)
+        n = len(self.pair_ci)
+        self.pair_count = np.zeros(max(n, 1), np.int64)
+        tot = C.c_int64()
+        capi._check(capi.load().glio_bassoc_run(self._h, T.dptr(poses), n, T.iptr(self.pair_ci) if n else None, T.iptr(self.pair_cj) if n else None,
+                                                self.pair_count.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(tot)))
+        self.pair_count = self.pair_count[:n]
+        self.total = tot.value
+        return self.pair_count, self.total
+
+    def read(self, first=0, n=None):
+        n = self.total - first if n is None else n
+        cp = np.zeros((max(n, 1), 4), np.float32); nc = np.zeros((max(n, 1), 6)); sc = np.zeros(max(n, 1))
+        capi._check(capi.load().glio_bassoc_read(self._h, C.c_int64(first), C.c_int64(n), T.fptr(cp), T.dptr(nc), T.dptr(sc)))
+        return cp[:n], nc[:n], sc[:n]
+
+    def feed(self, stage):
+        """Hand the device arrays to a BatchStage (K8) without leaving the GPU."""
+        cp, nc, sc = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        lib = capi.load()
+        capi._check(lib.glio_bassoc_results_dev(self._h, C.byref(cp), C.byref(nc), C.byref(sc)))
+        stage._keep = self
+        capi._check(lib.glio_batch_set_constraints_pairs_dev(stage._h, len(self.pair_ci), T.iptr(self.pair_ci), T.iptr(self.pair_cj),
+                                                             self.pair_count.ctypes.data_as(C.POINTER(C.c_int64)), cp, nc, sc))
+
+
 # ------------------------------------------------------------------ the HIP stage
 class BatchStage:
     def __init__(self, K, band, max_constraints, device=0):

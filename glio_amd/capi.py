@@ -25,6 +25,14 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise GlioError(f"{LIB_PATH} is missing: build it with `python -m glio_amd.build` (hipcc, gfx950). "
                             "There is no CPU fallback for the GLIO hot path.")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 under the same SONAME as /opt/rocm's.
+        # Whichever is loaded first serves both; torch cannot start on the system one ("No HIP GPUs are available"), so
+        # when torch is installed it goes first.  (A C++ caller without torch simply uses /opt/rocm's.)
+        if os.environ.get("GLIO_NO_TORCH_PRELOAD") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         lib = C.CDLL(LIB_PATH)
         lib.glio_last_error.restype = C.c_char_p
         lib.glio_destroy.restype = None

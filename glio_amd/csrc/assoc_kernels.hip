@@ -21,6 +21,7 @@
 // (output record) = 136 B; the 27-cell candidate scan is served by L2.
 #include <cfloat>
 #include <cstring>
+#include <vector>
 
 #include "glio_device.h"
 
@@ -215,7 +216,8 @@ __device__ __forceinline__ void plane_qr_solve(double A[5][3], double b[5], doub
 
 struct AssocArgs {
     double q[4], t[3];
-    float inv_cell, kd_max_radius, weight_gate;
+    float inv_cell;
+    double kd_max_radius, weight_gate;      // doubles in the reference: float quantities are promoted for the comparison
     double surf_dist_thres, lidar_const;
     int n, table_cap;
 };
@@ -236,12 +238,17 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
     return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
 }
 
+// BATCH = true: findGlobalCorrespondingSurfFeaturesAdd_Batch (Estimator.cpp:3808-3892).  The "map" is ANOTHER keyframe's
+// cloud in the global frame (sorted by cell, original index in .w), `loc` the same cloud in that keyframe's own frame:
+// a second plane is fitted to the local coordinates of the same five neighbours and the record is
+// [unit local normal | local centroid] (6 doubles, o_nc) with score 2.5 w instead of the weighted global plane.
+template <bool BATCH>
 __global__ __launch_bounds__(256) void k_associate(const AssocArgs a, const float4* __restrict__ scan,
                                                    const float4* __restrict__ map, const unsigned long long* __restrict__ keys,
                                                    const int* __restrict__ cstart, const int* __restrict__ ccount,
                                                    float4* __restrict__ o_pt, float4* __restrict__ o_plane, double* __restrict__ o_score,
                                                    int* __restrict__ o_flag, int* __restrict__ o_lpos, int* __restrict__ o_bcount,
-                                                   int* __restrict__ o_nn) {
+                                                   int* __restrict__ o_nn, const float4* __restrict__ loc, double* __restrict__ o_nc) {
     const int lane = threadIdx.x & 63, j = threadIdx.x & (AQ_LANES - 1), g = threadIdx.x / AQ_LANES;
     const int gbase = lane & ~(AQ_LANES - 1);                 // first lane of this group inside the wavefront
     const int i = blockIdx.x * AQ_PER_BLOCK + g;
@@ -332,12 +339,12 @@ __global__ __launch_bounds__(256) void k_associate(const AssocArgs a, const floa
             o_nn[5 * (size_t)i + 3] = __float_as_int(md[3]); o_nn[5 * (size_t)i + 4] = __float_as_int(md[4]);
 #else
 #pragma unroll
-            for (int k = 0; k < 5; ++k) o_nn[5 * (size_t)i + k] = (mp5[k] >= 0 && md[k] < a.kd_max_radius) ? mi[k] : -1;
+            for (int k = 0; k < 5; ++k) o_nn[5 * (size_t)i + k] = (mp5[k] >= 0 && (double)md[k] < a.kd_max_radius) ? mi[k] : -1;
 #endif
         }
         float4 oplane = make_float4(0, 0, 0, 0);
         double oscore = 0;
-        if (mp5[4] >= 0 && md[4] < a.kd_max_radius) {                    // Estimator.cpp:3651
+        if (mp5[4] >= 0 && (double)md[4] < a.kd_max_radius) {                    // Estimator.cpp:3651
             double A[5][3], A0[5][3], b[5], nrm[3];
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
@@ -346,6 +353,20 @@ __global__ __launch_bounds__(256) void k_associate(const AssocArgs a, const floa
                 b[k] = -1.0;
             }
             plane_qr_solve(A, b, nrm);
+            double nloc[3] = {0, 0, 0}, cen[3] = {0, 0, 0};
+            if (BATCH) {                                                     // :3843-3859
+                double Al[5][3], bl[5];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const float4 lp = loc[mi[k]];
+                    Al[k][0] = (double)lp.x; Al[k][1] = (double)lp.y; Al[k][2] = (double)lp.z;
+                    cen[0] += Al[k][0]; cen[1] += Al[k][1]; cen[2] += Al[k][2];
+                    bl[k] = -1.0;
+                }
+                plane_qr_solve(Al, bl, nloc);
+                const double nln = sqrt(nloc[0] * nloc[0] + nloc[1] * nloc[1] + nloc[2] * nloc[2]);
+                nloc[0] /= nln; nloc[1] /= nln; nloc[2] /= nln;
+            }
             const double nn = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
             const double normInverse = 1.0 / nn;
             nrm[0] /= nn; nrm[1] /= nn; nrm[2] /= nn;
@@ -360,18 +381,23 @@ __global__ __launch_bounds__(256) void k_associate(const AssocArgs a, const floa
                 r2 = r2 + pz * pz;
                 const float rr = sqrtf(sqrtf(r2));
                 const float weight = (float)(1.0 - 0.9 * (double)fabsf(pd) / (double)rr);
-                if (weight > a.weight_gate) {
+                if ((double)weight > a.weight_gate) {
                     valid = 1;
                     oplane.x = (float)((double)weight * nrm[0]);
                     oplane.y = (float)((double)weight * nrm[1]);
                     oplane.z = (float)((double)weight * nrm[2]);
                     oplane.w = (float)((double)weight * normInverse);
                     oscore = a.lidar_const * (double)weight;
+                    if (BATCH) {
+                        double* nc = o_nc + 6 * (size_t)i;
+                        nc[0] = nloc[0]; nc[1] = nloc[1]; nc[2] = nloc[2];
+                        nc[3] = cen[0] / 5.; nc[4] = cen[1] / 5.; nc[5] = cen[2] / 5.;
+                    }
                 }
             }
         }
         o_flag[i] = valid;
-        if (valid) { o_pt[i] = pl; o_plane[i] = oplane; o_score[i] = oscore; }
+        if (valid) { o_pt[i] = pl; if (!BATCH) o_plane[i] = oplane; o_score[i] = oscore; }
     }
     // ---- order-preserving positions inside the workgroup + workgroup count
     __shared__ int wcount[4];
@@ -423,7 +449,7 @@ static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 int glio_assoc_create(glio_ctx* c) {
     AssocWork* w = new AssocWork();
     memset(w, 0, sizeof *w);
-    const float r = sqrtf(c->opts.kd_max_radius);
+    const float r = sqrtf((float)c->opts.kd_max_radius);
     w->cell = fmaxf(1.25f, r * 1.0001f);
     w->inv_cell = 1.0f / w->cell;
     const int mm = c->opts.max_map_points > 0 ? c->opts.max_map_points : 1;
@@ -486,9 +512,9 @@ static void enqueue_assoc(glio_ctx* c, int slot, const double q[4], const double
     const size_t off = (size_t)slot * c->cap;
     const int nblk = (n + AQ_PER_BLOCK - 1) / AQ_PER_BLOCK;
     if (n > 0) {
-        hipLaunchKernelGGL(k_associate, dim3(nblk), dim3(256), 0, c->stream, a, c->d_scan + off, c->d_map_sorted, w->d_keys,
+        hipLaunchKernelGGL(k_associate<false>, dim3(nblk), dim3(256), 0, c->stream, a, c->d_scan + off, c->d_map_sorted, w->d_keys,
                            w->d_cell_start, w->d_cell_count, w->d_q_pt, w->d_q_plane, w->d_q_score, w->d_q_flag, w->d_q_pos, w->d_bcount,
-                           want_nn ? w->d_nn : nullptr);
+                           want_nn ? w->d_nn : nullptr, nullptr, nullptr);
     }
     hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(1024), 0, c->stream, w->d_bcount, nblk, w->d_boff, c->d_count + slot);
     if (n > 0) {
@@ -543,3 +569,232 @@ void glio_assoc_time_hooks(glio_ctx* c, int which, int reps, float* ms) {
     hipEventElapsedTime(ms, c->ev0, c->ev1);
     *ms /= reps;
 }
+
+
+// ================================================================================================
+// Batch association: findGlobalCorrespondingSurfFeaturesAdd_Batch for a list of keyframe pairs.
+// Every keyframe gets its OWN voxel hash of its cloud in the global frame, built once per run and kept resident
+// (~1.9 MB per 32k-point keyframe: 2000 keyframes = 3.8 GB of the 288 GB); pair (ci, cj) then queries the points of ci
+// against hash[cj].  The kept records of consecutive pairs are appended at a device-side running offset (no host round
+// trip between pairs), which yields exactly the pair-major constraint arrays K8 (batch_kernels.hip) consumes.
+// ================================================================================================
+struct FrameHash {
+    int n, table_cap;
+    unsigned long long* d_keys; int* d_cell_count; int* d_cell_start; int* d_cell_fill; int* d_pt_slot;
+    float4* d_sorted;
+};
+struct glio_bassoc {
+    int device; hipStream_t stream;
+    int K, cap; long long max_con;
+    float inv_cell;
+    float4* d_local;                // [K][cap] keyframe-local clouds
+    float4* d_global;               // [cap] staging: one cloud in the global frame
+    int* h_n;                       // [K]
+    FrameHash* frames;              // [K]
+    int* d_total;                   // scratch of the hash build
+    // dense per-query results of the pair in flight
+    float4* d_q_cp; double* d_q_nc; double* d_q_score; int* d_q_flag; int* d_q_pos; int* d_bcount; int* d_boff;
+    // compacted output, pair major
+    float4* d_cp; double* d_nc; double* d_score;
+    long long* d_run;               // [1] running total
+    long long* d_pair_off; int max_pairs;     // [max_pairs + 1]
+    long long* h_pair_off;          // pinned
+    double* d_poses;                // [K][7]
+};
+
+__global__ void k_transform_cloud(const float4* __restrict__ in, int n, const double* __restrict__ pose, float4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // transformCloud, Estimator.cpp:1517-1546
+    if (i >= n) return;
+    const double t[3] = {pose[0], pose[1], pose[2]}, q[4] = {pose[3], pose[4], pose[5], pose[6]};
+    const float4 p = in[i];
+    const double pin[3] = {(double)p.x, (double)p.y, (double)p.z};
+    double po[3];
+    a_qrot(q, pin, po);
+    out[i] = make_float4((float)(po[0] + t[0]), (float)(po[1] + t[1]), (float)(po[2] + t[2]), p.w);
+}
+
+// exclusive scan of the per-workgroup kept counts + this pair's base offset taken from / added to the running total
+__global__ __launch_bounds__(1024) void k_scan_pair(const int* __restrict__ bcount, int nblk, int* __restrict__ boff, long long* run,
+                                                    long long* pair_off, long long max_con, int* overflow) {
+    __shared__ int sums[1024];
+    const int tid = threadIdx.x;
+    const int chunk = (nblk + 1023) / 1024;
+    const int beg = tid * chunk, end = min(nblk, beg + chunk);
+    int s = 0;
+    for (int i = beg; i < end; ++i) s += bcount[i];
+    sums[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = tid >= off ? sums[tid - off] : 0;
+        __syncthreads();
+        sums[tid] += v;
+        __syncthreads();
+    }
+    int r = sums[tid] - s;
+    for (int i = beg; i < end; ++i) { boff[i] = r; r += bcount[i]; }
+    if (tid == 1023) {
+        const long long base = *run;
+        long long tot = sums[1023];
+        if (base + tot > max_con) { *overflow = 1; tot = 0; }
+        pair_off[0] = base;
+        pair_off[1] = base + tot;        // overwritten by the next pair with the same value
+        *run = base + tot;
+    }
+}
+__global__ void k_compact_pair(const int* __restrict__ flag, const int* __restrict__ lpos, const int* __restrict__ boff, int n,
+                               const long long* __restrict__ pair_off, const float4* __restrict__ q_cp, const double* __restrict__ q_nc,
+                               const double* __restrict__ q_score, float4* __restrict__ o_cp, double* __restrict__ o_nc,
+                               double* __restrict__ o_score) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    if (pair_off[1] == pair_off[0]) return;                      // overflow: nothing is written for this pair
+    const long long p = pair_off[0] + boff[i / AQ_PER_BLOCK] + lpos[i];
+    o_cp[p] = q_cp[i]; o_score[p] = q_score[i];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o_nc[6 * p + k] = q_nc[6 * (size_t)i + k];
+}
+
+#define BA_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { glio_set_error("%s failed: %s", #expr, hipGetErrorString(e_)); return GLIO_E_HIP; } } while (0)
+
+extern "C" {
+
+int glio_bassoc_create(int device, int K, int max_points_per_frame, int64_t max_constraints, glio_bassoc** out) {
+    if (!out || K < 2 || max_points_per_frame < 1 || max_constraints < 1) return GLIO_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { glio_set_error("no HIP device %d", device); return GLIO_E_HIP; }
+    BA_CHECK(hipSetDevice(device));
+    glio_bassoc* b = new glio_bassoc();
+    memset(b, 0, sizeof *b);
+    b->device = device; b->K = K; b->cap = max_points_per_frame; b->max_con = max_constraints;
+    BA_CHECK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    b->inv_cell = 1.0f / fmaxf(1.25f, sqrtf(1.5f) * 1.0001f);
+    const size_t cap = (size_t)b->cap;
+    BA_CHECK(hipMalloc((void**)&b->d_local, (size_t)K * cap * 16)); BA_CHECK(hipMalloc((void**)&b->d_global, cap * 16));
+    b->h_n = new int[K]();
+    b->frames = new FrameHash[K]();
+    const int tc = next_pow2(2 * b->cap);
+    for (int k = 0; k < K; ++k) {
+        FrameHash& f = b->frames[k];
+        f.table_cap = tc;
+        BA_CHECK(hipMalloc((void**)&f.d_keys, (size_t)tc * 8)); BA_CHECK(hipMalloc((void**)&f.d_cell_count, (size_t)tc * 4));
+        BA_CHECK(hipMalloc((void**)&f.d_cell_start, (size_t)tc * 4)); BA_CHECK(hipMalloc((void**)&f.d_cell_fill, (size_t)tc * 4));
+        BA_CHECK(hipMalloc((void**)&f.d_pt_slot, cap * 4)); BA_CHECK(hipMalloc((void**)&f.d_sorted, cap * 16));
+    }
+    BA_CHECK(hipMalloc((void**)&b->d_total, 4));
+    BA_CHECK(hipMalloc((void**)&b->d_q_cp, cap * 16)); BA_CHECK(hipMalloc((void**)&b->d_q_nc, cap * 48)); BA_CHECK(hipMalloc((void**)&b->d_q_score, cap * 8));
+    BA_CHECK(hipMalloc((void**)&b->d_q_flag, cap * 4)); BA_CHECK(hipMalloc((void**)&b->d_q_pos, cap * 4));
+    BA_CHECK(hipMalloc((void**)&b->d_bcount, (cap / AQ_PER_BLOCK + 2) * 4)); BA_CHECK(hipMalloc((void**)&b->d_boff, (cap / AQ_PER_BLOCK + 2) * 4));
+    BA_CHECK(hipMalloc((void**)&b->d_cp, (size_t)max_constraints * 16)); BA_CHECK(hipMalloc((void**)&b->d_nc, (size_t)max_constraints * 48));
+    BA_CHECK(hipMalloc((void**)&b->d_score, (size_t)max_constraints * 8));
+    BA_CHECK(hipMalloc((void**)&b->d_run, 16)); BA_CHECK(hipMalloc((void**)&b->d_poses, (size_t)K * 7 * 8));
+    *out = b;
+    return GLIO_OK;
+}
+
+void glio_bassoc_destroy(glio_bassoc* b) {
+    if (!b) return;
+    hipSetDevice(b->device);
+    hipStreamSynchronize(b->stream);
+    for (int k = 0; k < b->K; ++k) {
+        FrameHash& f = b->frames[k];
+        void* p[] = {f.d_keys, f.d_cell_count, f.d_cell_start, f.d_cell_fill, f.d_pt_slot, f.d_sorted};
+        for (void* q : p) if (q) hipFree(q);
+    }
+    void* p[] = {b->d_local, b->d_global, b->d_total, b->d_q_cp, b->d_q_nc, b->d_q_score, b->d_q_flag, b->d_q_pos, b->d_bcount, b->d_boff,
+                 b->d_cp, b->d_nc, b->d_score, b->d_run, b->d_poses, b->d_pair_off};
+    for (void* q : p) if (q) hipFree(q);
+    if (b->h_pair_off) hipHostFree(b->h_pair_off);
+    delete[] b->h_n; delete[] b->frames;
+    hipStreamDestroy(b->stream);
+    delete b;
+}
+
+int glio_bassoc_set_frame(glio_bassoc* b, int k, const float* scan_xyzi, int n) {
+    if (!b || k < 0 || k >= b->K || n < 0 || n > b->cap || (n > 0 && !scan_xyzi)) { glio_set_error("bad keyframe cloud (k %d, n %d)", k, n); return GLIO_E_ARG; }
+    BA_CHECK(hipSetDevice(b->device));
+    if (n > 0) BA_CHECK(hipMemcpyAsync(b->d_local + (size_t)k * b->cap, scan_xyzi, (size_t)n * 16, hipMemcpyHostToDevice, b->stream));
+    BA_CHECK(hipStreamSynchronize(b->stream));
+    b->h_n[k] = n;
+    return GLIO_OK;
+}
+
+int glio_bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj,
+                    int64_t* pair_count_out, int64_t* total_out) {
+    if (!b || !poses || n_pairs < 0 || (n_pairs > 0 && (!pair_ci || !pair_cj))) return GLIO_E_ARG;
+    BA_CHECK(hipSetDevice(b->device));
+    for (int p = 0; p < n_pairs; ++p)
+        if (pair_ci[p] < 0 || pair_ci[p] >= b->K || pair_cj[p] < 0 || pair_cj[p] >= b->K || pair_ci[p] == pair_cj[p]) { glio_set_error("bad pair %d", p); return GLIO_E_ARG; }
+    if (n_pairs > b->max_pairs) {
+        if (b->d_pair_off) { hipFree(b->d_pair_off); hipHostFree(b->h_pair_off); b->d_pair_off = nullptr; b->h_pair_off = nullptr; }
+        b->max_pairs = n_pairs + 64;
+        BA_CHECK(hipMalloc((void**)&b->d_pair_off, (size_t)(b->max_pairs + 2) * 8));
+        BA_CHECK(hipHostMalloc((void**)&b->h_pair_off, (size_t)(b->max_pairs + 2) * 8));
+    }
+    BA_CHECK(hipMemcpyAsync(b->d_poses, poses, (size_t)b->K * 7 * 8, hipMemcpyHostToDevice, b->stream));
+    BA_CHECK(hipMemsetAsync(b->d_run, 0, 16, b->stream));
+    int* d_overflow = reinterpret_cast<int*>(b->d_run + 1);
+    // (1) every keyframe that occurs as a search frame: cloud -> global frame -> voxel hash
+    std::vector<char> need(b->K, 0);
+    for (int p = 0; p < n_pairs; ++p) need[pair_cj[p]] = 1;
+    for (int k = 0; k < b->K; ++k) {
+        if (!need[k]) continue;
+        FrameHash& f = b->frames[k];
+        const int n = b->h_n[k], tc = f.table_cap;
+        f.n = n;
+        hipLaunchKernelGGL(k_hash_clear, dim3((tc + 255) / 256), dim3(256), 0, b->stream, f.d_keys, f.d_cell_count, f.d_cell_fill, tc, b->d_total);
+        if (n == 0) continue;
+        hipLaunchKernelGGL(k_transform_cloud, dim3((n + 255) / 256), dim3(256), 0, b->stream, b->d_local + (size_t)k * b->cap, n, b->d_poses + 7 * k, b->d_global);
+        hipLaunchKernelGGL(k_hash_insert, dim3((n + 255) / 256), dim3(256), 0, b->stream, b->d_global, n, b->inv_cell, f.d_keys, f.d_cell_count, f.d_pt_slot, tc);
+        hipLaunchKernelGGL(k_cell_alloc, dim3((tc + 255) / 256), dim3(256), 0, b->stream, f.d_cell_count, f.d_cell_start, tc, b->d_total);
+        hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, b->stream, b->d_global, n, f.d_pt_slot, f.d_cell_start, f.d_cell_fill, f.d_sorted);
+    }
+    // (2) the pairs, in the caller's (ci, cj) order
+    for (int p = 0; p < n_pairs; ++p) {
+        const int ci = pair_ci[p], cj = pair_cj[p];
+        const int n = b->h_n[ci];
+        const FrameHash& f = b->frames[cj];
+        AssocArgs a;
+        for (int k = 0; k < 3; ++k) a.t[k] = poses[7 * ci + k];
+        for (int k = 0; k < 4; ++k) a.q[k] = poses[7 * ci + 3 + k];
+        a.inv_cell = b->inv_cell; a.kd_max_radius = 1.5; a.weight_gate = 0.3; a.surf_dist_thres = 0.18; a.lidar_const = 2.5;   // :3839,3874,3863,3885
+        a.n = n; a.table_cap = f.table_cap;
+        const int nblk = (n + AQ_PER_BLOCK - 1) / AQ_PER_BLOCK;
+        if (n > 0)
+            hipLaunchKernelGGL(k_associate<true>, dim3(nblk), dim3(256), 0, b->stream, a, b->d_local + (size_t)ci * b->cap, f.d_sorted, f.d_keys,
+                               f.d_cell_start, f.d_cell_count, b->d_q_cp, (float4*)nullptr, b->d_q_score, b->d_q_flag, b->d_q_pos, b->d_bcount,
+                               (int*)nullptr, b->d_local + (size_t)cj * b->cap, b->d_q_nc);
+        hipLaunchKernelGGL(k_scan_pair, dim3(1), dim3(1024), 0, b->stream, b->d_bcount, nblk, b->d_boff, b->d_run, b->d_pair_off + p, (long long)b->max_con, d_overflow);
+        if (n > 0)
+            hipLaunchKernelGGL(k_compact_pair, dim3((n + 255) / 256), dim3(256), 0, b->stream, b->d_q_flag, b->d_q_pos, b->d_boff, n, b->d_pair_off + p,
+                               b->d_q_cp, b->d_q_nc, b->d_q_score, b->d_cp, b->d_nc, b->d_score);
+    }
+    BA_CHECK(hipGetLastError());
+    long long tail[2] = {0, 0};
+    if (n_pairs > 0) BA_CHECK(hipMemcpyAsync(b->h_pair_off, b->d_pair_off, (size_t)(n_pairs + 1) * 8, hipMemcpyDeviceToHost, b->stream));
+    BA_CHECK(hipMemcpyAsync(tail, b->d_run, 16, hipMemcpyDeviceToHost, b->stream));
+    BA_CHECK(hipStreamSynchronize(b->stream));
+    if (*reinterpret_cast<int*>(&tail[1])) { glio_set_error("more constraints than max_constraints (%lld)", b->max_con); return GLIO_E_ARG; }
+    if (pair_count_out) for (int p = 0; p < n_pairs; ++p) pair_count_out[p] = b->h_pair_off[p + 1] - b->h_pair_off[p];
+    if (total_out) *total_out = tail[0];
+    return GLIO_OK;
+}
+
+int glio_bassoc_results_dev(glio_bassoc* b, const float** cp_dev, const double** nc_dev, const double** score_dev) {
+    if (!b) return GLIO_E_ARG;
+    if (cp_dev) *cp_dev = reinterpret_cast<const float*>(b->d_cp);
+    if (nc_dev) *nc_dev = b->d_nc;
+    if (score_dev) *score_dev = b->d_score;
+    return GLIO_OK;
+}
+
+int glio_bassoc_read(glio_bassoc* b, int64_t first, int64_t n, float* cp, double* norm_cent, double* score) {
+    if (!b || first < 0 || n < 0 || first + n > b->max_con) return GLIO_E_ARG;
+    BA_CHECK(hipSetDevice(b->device));
+    if (n == 0) return GLIO_OK;
+    if (cp) BA_CHECK(hipMemcpy(cp, b->d_cp + first, (size_t)n * 16, hipMemcpyDeviceToHost));
+    if (norm_cent) BA_CHECK(hipMemcpy(norm_cent, b->d_nc + 6 * first, (size_t)n * 48, hipMemcpyDeviceToHost));
+    if (score) BA_CHECK(hipMemcpy(score, b->d_score + first, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return GLIO_OK;
+}
+
+}  // extern "C"

@@ -422,6 +422,40 @@ int glio_batch_set_constraints_dev(glio_batch* b, int64_t n, const int32_t* ci, 
     return GLIO_OK;
 }
 
+// the same, from a pair list (what glio_bassoc_run produces): pair p = keyframes (pair_ci[p], pair_cj[p]) with
+// pair_count[p] consecutive records; pairs sorted by (ci, cj); empty pairs are skipped
+int glio_batch_set_constraints_pairs_dev(glio_batch* b, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj, const int64_t* pair_count,
+                                         const float* cp_dev, const double* nc_dev, const double* score_dev) {
+    if (!b || n_pairs < 0 || (n_pairs > 0 && (!pair_ci || !pair_cj || !pair_count || !cp_dev || !nc_dev || !score_dev))) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipSetDevice(b->device));
+    const int K = b->K, band = b->band, wdt = 2 * band + 1;
+    std::vector<int> pi, pj, index((size_t)K * wdt, -1);
+    std::vector<long long> off;
+    long long run = 0;
+    for (int p = 0; p < n_pairs; ++p) {
+        const int a = pair_ci[p], c = pair_cj[p];
+        if (a < 0 || a >= K || c < 0 || c >= K || a == c || std::abs(a - c) > band || pair_count[p] < 0) { glio_set_error("pair %d: keyframes (%d,%d) outside band %d", p, a, c, band); return GLIO_E_ARG; }
+        if (p > 0 && (a < pair_ci[p - 1] || (a == pair_ci[p - 1] && c <= pair_cj[p - 1]))) { glio_set_error("pairs must be sorted by (ci, cj)"); return GLIO_E_ARG; }
+        if (pair_count[p] > 0) {
+            index[(size_t)a * wdt + (c - a) + band] = (int)pi.size();
+            pi.push_back(a); pj.push_back(c); off.push_back(run);
+        }
+        run += pair_count[p];
+    }
+    off.push_back(run);
+    if ((int)pi.size() > b->max_pairs) return GLIO_E_ARG;
+    b->n_pairs = (int)pi.size();
+    if (b->n_pairs) {
+        GLIO_HIP_CHECK(hipMemcpy(b->d_pair_i, pi.data(), pi.size() * 4, hipMemcpyHostToDevice));
+        GLIO_HIP_CHECK(hipMemcpy(b->d_pair_j, pj.data(), pj.size() * 4, hipMemcpyHostToDevice));
+    }
+    GLIO_HIP_CHECK(hipMemcpy(b->d_pair_off, off.data(), off.size() * 8, hipMemcpyHostToDevice));
+    GLIO_HIP_CHECK(hipMemcpy(b->d_pair_index, index.data(), index.size() * 4, hipMemcpyHostToDevice));
+    b->n_con = run;
+    b->cp = reinterpret_cast<const float4*>(cp_dev); b->nc = nc_dev; b->score = score_dev;
+    return GLIO_OK;
+}
+
 int glio_batch_set_constraints(glio_batch* b, int64_t n, const int32_t* ci, const int32_t* cj, const float* cp,
                                const double* nc, const double* score) {
     if (!b || n < 0 || n > b->max_con) { glio_set_error("too many constraints"); return GLIO_E_ARG; }

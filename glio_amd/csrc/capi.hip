@@ -61,7 +61,7 @@ void glio_opts_default(glio_opts* o) {
     o->max_ddt_epochs = 0; o->jacobi_scaling = 1;
     o->huber_delta = 1.0; o->doppler_huber_delta = 1.0;
     o->q_lb[0] = 1.0; o->t_lb[2] = 0.28;
-    o->lidar_const = 7.5; o->surf_dist_thres = 0.18; o->kd_max_radius = 1.5f; o->weight_gate = 0.3f;
+    o->lidar_const = 7.5; o->surf_dist_thres = 0.18; o->kd_max_radius = 1.5; o->weight_gate = 0.3;
     o->gravity = 9.80511;
     o->initial_trust_region_radius = 1e4; o->max_trust_region_radius = 1e16; o->min_trust_region_radius = 1e-32;
     o->min_relative_decrease = 1e-3; o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;

@@ -25,7 +25,7 @@ class GlioOpts(C.Structure):
         ("huber_delta", C.c_double), ("doppler_huber_delta", C.c_double),
         ("q_lb", C.c_double * 4), ("t_lb", C.c_double * 3),
         ("lidar_const", C.c_double), ("surf_dist_thres", C.c_double),
-        ("kd_max_radius", C.c_float), ("weight_gate", C.c_float), ("gravity", C.c_double),
+        ("kd_max_radius", C.c_double), ("weight_gate", C.c_double), ("gravity", C.c_double),
         ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
         ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
         ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),

@@ -142,6 +142,11 @@ int glio_batch_set_constraints(glio_batch* b, int64_t n, const int32_t* ci, cons
                                const double* norm_cent, const double* score);
 int glio_batch_set_constraints_dev(glio_batch* b, int64_t n, const int32_t* ci_host, const int32_t* cj_host,
                                    const float* cp_dev, const double* norm_cent_dev, const double* score_dev);
+/* the same from a pair list (the output of glio_bassoc_run): pair p = (pair_ci[p], pair_cj[p]) owns pair_count[p]
+ * consecutive records of the device arrays; pairs sorted by (ci, cj) */
+int glio_batch_set_constraints_pairs_dev(glio_batch* b, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj,
+                                         const int64_t* pair_count, const float* cp_dev, const double* norm_cent_dev,
+                                         const double* score_dev);
 /* poses [K][7] = (t, q) host; Hg_dev device buffer of glio_batch_hg_size doubles (overwritten) */
 int glio_batch_linearize_dev(glio_batch* b, const double* poses, double* Hg_dev);
 /* damped Gauss-Newton step from a (reduced) Hg: solves (H + lambda diag(H)) d = -g with a block-banded Cholesky on
@@ -150,6 +155,27 @@ int glio_batch_step_dev(glio_batch* b, const double* Hg_dev, double lambda, cons
                         double* model_decrease);
 /* timing hook: average ms of `reps` linearisation launches (HIP events on the batch stream) */
 int glio_batch_time_linearize(glio_batch* b, const double* poses, double* Hg_dev, int reps, float* ms_out);
+
+
+/* ================================================================================================
+ * Batch association.  Replaces findGlobalCorrespondingSurfFeaturesAdd_Batch(idx, search_idx_start)
+ * (Estimator.cpp:3808-3892; its twin findGlobalCorrespondingSurfFeatures_Batch :3711-3806 is the same arithmetic)
+ * for a list of keyframe pairs: per pair (ci, cj) the points of surf_frames[ci] are matched against surf_frames[cj],
+ * both placed with pose_info_keyframe (poses [K][7] = t, q): exact 5-NN (sqd[4] < 1.5), plane fit in global and in
+ * cj-local coordinates, 0.18 validity, float pd / weight, weight > 0.3.  Output per kept point, appended pair after
+ * pair in the caller's order (device resident, the layout glio_batch_set_constraints_pairs_dev takes):
+ *   cp [4] float (the point in ci's frame), norm_cent [6] (unit normal and 5-point centroid in cj's frame),
+ *   score = 2.5 weight.   The caller applies the search-window rule of Estimator.cpp:3009-3017 to make the pair list
+ * (glio_amd/batch.py: search_window). */
+typedef struct glio_bassoc glio_bassoc;
+int glio_bassoc_create(int device, int K, int max_points_per_frame, int64_t max_constraints, glio_bassoc** out);
+void glio_bassoc_destroy(glio_bassoc* b);
+/* surf_frames[k]: PointXYZI[n] as 4 floats, keyframe-local; stays resident */
+int glio_bassoc_set_frame(glio_bassoc* b, int k, const float* scan_xyzi, int n);
+int glio_bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj,
+                    int64_t* pair_count_out, int64_t* total_out);
+int glio_bassoc_results_dev(glio_bassoc* b, const float** cp_dev, const double** norm_cent_dev, const double** score_dev);
+int glio_bassoc_read(glio_bassoc* b, int64_t first, int64_t n, float* cp, double* norm_cent, double* score);
 
 #ifdef __cplusplus
 }

@@ -43,8 +43,8 @@ typedef struct glio_opts {
     double t_lb[3];              /* LiDAR->IMU extrinsic translation, yaml:95-97 */
     double lidar_const;          /* yaml:70 */
     double surf_dist_thres;      /* yaml:71 (plane gate) */
-    float kd_max_radius;         /* yaml:72 -- compared with the SQUARED 5th-NN distance, Estimator.cpp:3651 */
-    float weight_gate;           /* 0.3, Estimator.cpp:3681 */
+    double kd_max_radius;        /* yaml:72 (a double, Estimator.cpp:364) -- compared with the SQUARED float 5th-NN distance, :3651 */
+    double weight_gate;          /* 0.3 -- `weight > 0.3` compares the float weight with a double literal, Estimator.cpp:3681 */
     double gravity;              /* IMU/gravity yaml:11 ; g_vec = (0,0,-gravity) Preintegration.h:58 */
     /* trust region (Ceres 1.14 defaults, nnls_solving.rst:1056-1188) */
     double initial_trust_region_radius; /* 1e4 */

@@ -97,6 +97,11 @@ void orc_plane_qr_solve(const double A[15], const double b[5], double x[3]);
 int orc_marginalize(const orc_problem* p, const glio_state* x, double* lin_jac, double* lin_res,
                     int32_t* blk_slot, int32_t* blk_kind, int32_t* blk_idx, double* blk_x0);
 
+/* findGlobalCorrespondingSurfFeaturesAdd_Batch for one keyframe pair (Estimator.cpp:3808-3892); returns the count */
+int orc_associate_pair(const float* scan_a, int na, const double qa[4], const double ta[3],
+                       const float* scan_b, int nb, const double qb[4], const double tb[3],
+                       float* out_cp, double* out_norm_cent, double* out_score, int32_t* out_src);
+
 /* ---- batch stage (BinaryLidarPlaneNormFactor, LidarKeyframeFactor.h:124-164) */
 /* residual + global jacobians, blocks t1[3] q1[4] t2[3] q2[4] */
 int orc_eval_binary_plane(const float cp[4], const double norm_cent[6], double score,

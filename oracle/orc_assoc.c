@@ -11,6 +11,7 @@
  * PARITY UNPINNED -- see glio_oracle.h.
  */
 #include <float.h>
+#include <stdlib.h>
 #include "glio_oracle.h"
 #include "orc_math.h"
 
@@ -96,7 +97,7 @@ int orc_associate(const glio_opts* o, const float* map, int M, const float* scan
             }
         }
         if (out_nn) for (int k = 0; k < 5; ++k) out_nn[5 * (size_t)i + k] = bi[k];
-        if (!(bi[4] >= 0 && bd[4] < o->kd_max_radius)) continue;              /* :3651 */
+        if (!(bi[4] >= 0 && (double)bd[4] < o->kd_max_radius)) continue;              /* :3651 */
         double A[15], b[5] = {-1, -1, -1, -1, -1}, nrm[3];
         for (int k = 0; k < 5; ++k) for (int c = 0; c < 3; ++c) A[k * 3 + c] = (double)map[4 * (size_t)bi[k] + c];
         orc_plane_qr_solve(A, b, nrm);                                           /* :3661 */
@@ -110,7 +111,7 @@ int orc_associate(const glio_opts* o, const float* map, int M, const float* scan
         const float pd = (float)(nrm[0] * (double)px + nrm[1] * (double)py + nrm[2] * (double)pz + normInverse);  /* :3678 */
         const float rr = sqrtf(sqrtf(px * px + py * py + pz * pz));              /* float sqrt(sqrt(.)) */
         const float weight = (float)(1.0 - 0.9 * (double)fabsf(pd) / (double)rr);  /* :3679 */
-        if (!(weight > o->weight_gate)) continue;                                /* :3681 */
+        if (!((double)weight > o->weight_gate)) continue;                                /* :3681 */
         float* op = out_pts + 4 * (size_t)cnt;
         float* on = out_planes + 4 * (size_t)cnt;
         op[0] = pl[0]; op[1] = pl[1]; op[2] = pl[2]; op[3] = pl[3];              /* :3688 */
@@ -122,5 +123,81 @@ int orc_associate(const glio_opts* o, const float* map, int M, const float* scan
         if (out_src) out_src[cnt] = i;
         ++cnt;
     }
+    return cnt;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * findGlobalCorrespondingSurfFeaturesAdd_Batch for ONE (idx, search_idx) pair
+ * (reference GLIO/src/Estimator.cpp:3808-3892; the _Batch twin at :3711-3806 is the same arithmetic).
+ * scan_a = surf_frames[idx], scan_b = surf_frames[search_idx] (PointXYZI as 4 floats, keyframe-local);
+ * (qa,ta) / (qb,tb) = pose_info_keyframe->points[idx / search_idx].  Both clouds go to the global frame with
+ * transformCloud (:1517-1546: double q*v + t, float store); 5-NN of every point of a in global b; gate
+ * sqd[4] < 1.5 (:3839); two 5x3 colPivHouseholderQr fits, global and keyframe-local coordinates of the same five
+ * neighbours (:3855-3859); validity with the global plane, 0.18 (:3861-3869); pd / weight in float (:3872-3873);
+ * kept if weight > 0.3 (:3874).  Output record (:3879-3887): the point of a in ITS local frame, score 2.5 w,
+ * [unit local normal of b | centroid of the five neighbours in b's local frame].
+ * ------------------------------------------------------------------------------------------------ */
+int orc_associate_pair(const float* scan_a, int na, const double qa[4], const double ta[3],
+                       const float* scan_b, int nb, const double qb[4], const double tb[3],
+                       float* out_cp, double* out_norm_cent, double* out_score, int32_t* out_src) {
+    float* gb = (float*)malloc(sizeof(float) * 3 * (size_t)(nb > 0 ? nb : 1));
+    for (int m = 0; m < nb; ++m) {
+        double pin[3] = {scan_b[4 * (size_t)m], scan_b[4 * (size_t)m + 1], scan_b[4 * (size_t)m + 2]}, po[3];
+        q_rot(qb, pin, po);
+        gb[3 * (size_t)m] = (float)(po[0] + tb[0]); gb[3 * (size_t)m + 1] = (float)(po[1] + tb[1]); gb[3 * (size_t)m + 2] = (float)(po[2] + tb[2]);
+    }
+    int cnt = 0;
+    for (int i = 0; i < na; ++i) {
+        const float* pl = scan_a + 4 * (size_t)i;
+        double pin[3] = {pl[0], pl[1], pl[2]}, pout[3];
+        q_rot(qa, pin, pout);
+        const float px = (float)(pout[0] + ta[0]), py = (float)(pout[1] + ta[1]), pz = (float)(pout[2] + ta[2]);
+        float bd[5] = {FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX};
+        int bi[5] = {-1, -1, -1, -1, -1};
+        for (int m = 0; m < nb; ++m) {
+            const float* mp = gb + 3 * (size_t)m;
+            const float dx = px - mp[0], dy = py - mp[1], dz = pz - mp[2];
+            float d = dx * dx; d = d + dy * dy; d = d + dz * dz;
+            if (d < bd[4]) {
+                int k = 4;
+                while (k > 0 && d < bd[k - 1]) { bd[k] = bd[k - 1]; bi[k] = bi[k - 1]; --k; }
+                bd[k] = d; bi[k] = m;
+            }
+        }
+        if (!(bi[4] >= 0 && (double)bd[4] < 1.5)) continue;                                  /* :3839 */
+        double A[15], Al[15], b[5] = {-1, -1, -1, -1, -1}, bl[5] = {-1, -1, -1, -1, -1}, nrm[3], nl[3];
+        double cx = 0, cy = 0, cz = 0;
+        for (int k = 0; k < 5; ++k) {
+            for (int c = 0; c < 3; ++c) {
+                A[k * 3 + c] = (double)gb[3 * (size_t)bi[k] + c];
+                Al[k * 3 + c] = (double)scan_b[4 * (size_t)bi[k] + c];
+            }
+            cx += Al[k * 3]; cy += Al[k * 3 + 1]; cz += Al[k * 3 + 2];                /* :3848-3850 */
+        }
+        orc_plane_qr_solve(A, b, nrm);                                                /* :3856 */
+        const double nn = v3_norm(nrm);
+        const double normInverse = 1.0 / nn;
+        nrm[0] /= nn; nrm[1] /= nn; nrm[2] /= nn;
+        orc_plane_qr_solve(Al, bl, nl);                                               /* :3858 */
+        const double nln = v3_norm(nl);
+        nl[0] /= nln; nl[1] /= nln; nl[2] /= nln;
+        int valid = 1;
+        for (int k = 0; k < 5; ++k)
+            if (fabs(nrm[0] * A[k * 3] + nrm[1] * A[k * 3 + 1] + nrm[2] * A[k * 3 + 2] + normInverse) > 0.18) { valid = 0; break; }
+        if (!valid) continue;
+        const float pd = (float)(nrm[0] * (double)px + nrm[1] * (double)py + nrm[2] * (double)pz + normInverse);
+        const float rr = sqrtf(sqrtf(px * px + py * py + pz * pz));
+        const float weight = (float)(1.0 - 0.9 * (double)fabsf(pd) / (double)rr);
+        if (!((double)weight > 0.3)) continue;                                        /* :3874, double comparison */
+        float* op = out_cp + 4 * (size_t)cnt;
+        op[0] = pl[0]; op[1] = pl[1]; op[2] = pl[2]; op[3] = pl[3];
+        double* nc = out_norm_cent + 6 * (size_t)cnt;
+        nc[0] = nl[0]; nc[1] = nl[1]; nc[2] = nl[2];
+        nc[3] = cx / 5.; nc[4] = cy / 5.; nc[5] = cz / 5.;
+        out_score[cnt] = 2.5 * (double)weight;                                        /* :3885 */
+        if (out_src) out_src[cnt] = i;
+        ++cnt;
+    }
+    free(gb);
     return cnt;
 }

@@ -21,8 +21,8 @@ void orc_opts_default(glio_opts* o) {
     o->t_lb[2] = 0.28;             /* yaml:95-97 */
     o->lidar_const = 7.5;          /* yaml:70 */
     o->surf_dist_thres = 0.18;     /* yaml:71 */
-    o->kd_max_radius = 1.5f;       /* yaml:72 */
-    o->weight_gate = 0.3f;         /* Estimator.cpp:3681 */
+    o->kd_max_radius = 1.5;       /* yaml:72 */
+    o->weight_gate = 0.3;         /* Estimator.cpp:3681 */
     o->gravity = 9.80511;          /* yaml:11 */
     o->initial_trust_region_radius = 1e4;
     o->max_trust_region_radius = 1e16;

@@ -133,6 +133,18 @@ def associate(opts, map_pts, scan, q, t, want_nn=False):
     return res + ((nn,) if want_nn else ())
 
 
+def associate_pair(scan_a, pose_a, scan_b, pose_b):
+    """findGlobalCorrespondingSurfFeaturesAdd_Batch for one pair; pose = (t[3], q[4])."""
+    na = len(scan_a)
+    cp = np.zeros((max(na, 1), 4), np.float32); nc = np.zeros((max(na, 1), 6)); sc = np.zeros(max(na, 1)); src = np.zeros(max(na, 1), np.int32)
+    pa = np.ascontiguousarray(pose_a, float); pb = np.ascontiguousarray(pose_b, float)
+    qa, ta, qb, tb = pa[3:].copy(), pa[:3].copy(), pb[3:].copy(), pb[:3].copy()
+    sa = np.ascontiguousarray(scan_a, np.float32); sb = np.ascontiguousarray(scan_b, np.float32)
+    cnt = lib().orc_associate_pair(T.fptr(sa), na, T.dptr(qa), T.dptr(ta), T.fptr(sb), len(sb), T.dptr(qb), T.dptr(tb),
+                                   T.fptr(cp), T.dptr(nc), T.dptr(sc), T.iptr(src))
+    return cp[:cnt].copy(), nc[:cnt].copy(), sc[:cnt].copy(), src[:cnt].copy()
+
+
 def lidar_pose_for_association(opts, q, t):
     """Q2 = Q * q_lb^-1, T2 = T - Q2 * t_lb  (Estimator.cpp:2216-2217)."""
     from glio_amd import synth

@@ -44,7 +44,7 @@ def test_defaults_are_the_reference_yaml(lib):
     lib.glio_opts_default(C.byref(o))
     assert (o.window, o.max_iterations, o.jacobi_scaling) == (5, 15, 1)
     assert (o.huber_delta, o.lidar_const, o.surf_dist_thres) == (1.0, 7.5, 0.18)
-    assert abs(o.kd_max_radius - 1.5) < 1e-7 and abs(o.weight_gate - 0.3) < 1e-7
+    assert o.kd_max_radius == 1.5 and o.weight_gate == 0.3
     assert list(o.t_lb) == [0.0, 0.0, 0.28] and list(o.q_lb) == [1.0, 0.0, 0.0, 0.0]
     assert o.gravity == 9.80511 and o.initial_trust_region_radius == 1e4 and o.function_tolerance == 1e-6
 

@@ -1,0 +1,90 @@
+"""GPU parity of the batch association: glio_bassoc_* vs the oracle's restatement of
+findGlobalCorrespondingSurfFeaturesAdd_Batch (reference GLIO/src/Estimator.cpp:3808-3892).  Bit-exact: the kept set,
+its order, the float point, the fp64 [local normal | centroid] record and the score are compared with ==."""
+import numpy as np
+import pytest
+
+from glio_amd import batch, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def frames():
+    """8 keyframes of the synthetic street scene with slightly wrong poses (as pose_info_keyframe would hold)."""
+    win = synth.make_window(W=8, pts_per_scan=4000, seed=synth.SEED_BASE + 51, perturb=(0.03, 0.2, 0.0), scan_radius=14.0, map_density=1.0)
+    o = win.opts
+    tlb = np.array(o.t_lb)
+    scans = []
+    for s in range(win.W):                       # the batch factor applies no extrinsic (quirk Q10): body-frame clouds
+        sc = win.scans[s].copy()
+        sc[:, :3] -= tlb.astype(np.float32)
+        scans.append(np.ascontiguousarray(sc))
+    poses = np.c_[win.init.trans, win.init.quat]
+    return scans, poses
+
+
+def test_pairs_match_oracle_bit_exact(frames):
+    from oracle import pyoracle as po
+    scans, poses = frames
+    K = len(scans)
+    ci, cj = batch.pair_list(K, 2)
+    ba = batch.BatchAssociation(K, 4096, 400000)
+    for k in range(K):
+        ba.set_frame(k, scans[k])
+    counts, total = ba.run(poses, ci, cj)
+    cp, nc, sc = ba.read()
+    assert total == counts.sum() and total > 2000, "the synthetic scene must produce constraints"
+    first = 0
+    for p in range(len(ci)):
+        ocp, onc, osc, _ = po.associate_pair(scans[ci[p]], poses[ci[p]], scans[cj[p]], poses[cj[p]])
+        n = counts[p]
+        assert n == len(osc), f"pair ({ci[p]},{cj[p]}): kept {n} vs oracle {len(osc)}"
+        assert np.array_equal(cp[first:first + n], ocp)
+        assert np.array_equal(nc[first:first + n], onc)
+        assert np.array_equal(sc[first:first + n], osc)
+        first += n
+    # records are what BinaryLidarPlaneNormFactor expects: unit normals, weights in (0.3, 1]
+    assert np.allclose(np.linalg.norm(nc[:, :3], axis=1), 1.0, atol=1e-12)
+    assert sc.min() > 2.5 * 0.3 and sc.max() <= 2.5
+    ba.close()
+
+
+def test_empty_frame_and_repeatability(frames):
+    scans, poses = frames
+    K = len(scans)
+    ci, cj = batch.pair_list(K, 1)
+    ba = batch.BatchAssociation(K, 4096, 200000)
+    for k in range(K):
+        ba.set_frame(k, scans[k] if k != 3 else scans[k][:0])
+    c1, t1 = ba.run(poses, ci, cj)
+    r1 = [a.copy() for a in ba.read()]
+    assert all(c1[p] == 0 for p in range(len(ci)) if ci[p] == 3 or cj[p] == 3)
+    c2, t2 = ba.run(poses, ci, cj)
+    r2 = ba.read()
+    assert t1 == t2 and np.array_equal(c1, c2) and all(np.array_equal(a, b) for a, b in zip(r1, r2))
+    ba.close()
+
+
+def test_association_feeds_batch_stage(frames):
+    """End to end on the device: associate -> K8 linearise; H, g, cost equal the oracle's on the oracle's constraints."""
+    from oracle import pyoracle as po
+    scans, poses = frames
+    K, rng = len(scans), 2
+    ci, cj = batch.pair_list(K, rng)
+    ba = batch.BatchAssociation(K, 4096, 400000)
+    for k in range(K):
+        ba.set_frame(k, scans[k])
+    counts, total = ba.run(poses, ci, cj)
+    st = batch.BatchStage(K, 2 * rng, total)
+    ba.feed(st)
+    Hg = st.new_hg()
+    st.linearize(poses, Hg)
+    Hb, g, cost = batch.unpack_hg(Hg.cpu().numpy(), K, 2 * rng)
+    cp, nc, sc = ba.read()
+    cci = np.repeat(ci, counts); ccj = np.repeat(cj, counts)
+    Ho, go, co = po.batch_linearize(K, 2 * rng, poses, cci, ccj, cp, nc, sc)
+    assert abs(cost - co) <= 1e-10 * abs(co)
+    assert np.linalg.norm(g - go) <= 1e-10 * np.linalg.norm(go)
+    assert np.linalg.norm(Hb - Ho) <= 1e-10 * np.linalg.norm(Ho)
+    st.close(); ba.close()
