@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--batch-keyframes", type=int, default=2000)
     ap.add_argument("--batch-per-kf", type=int, default=32768)
     ap.add_argument("--no-batch", action="store_true")
+    ap.add_argument("--no-bassoc", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -101,6 +102,13 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
+
+    bassoc_info = None
+    if not args.no_bassoc:
+        try:
+            bassoc_info = bench_batch_association(local_rank)
+        except Exception as e:
+            bassoc_info = {"error": str(e)[:300]}
 
     # ---- roofline of the dominant kernel (K3), HIP events on the context stream
     ctx.linearize(state, want_H=False)
@@ -190,7 +198,7 @@ def main():
         "termination": int(summ.termination),
         "kernels_us": {"lidar_linearize": round(k3_ms * 1e3, 2), "full_linearize": round(lin_ms * 1e3, 2), "tr_step": round(trs_ms * 1e3, 2),
                        "marginalize": round(marg_ms * 1e3, 2), "marginalize_call_incl_readback": round(marg_call_ms * 1e3, 1)},
-        "roofline": roofline, "cpu_baseline": cpu, "pose_vs_oracle": pose_err, "association": assoc, "batch_stage": batch_info,
+        "roofline": roofline, "cpu_baseline": cpu, "pose_vs_oracle": pose_err, "association": assoc, "batch_stage": batch_info, "batch_association": bassoc_info,
     }
     if cpu and "value" in cpu:
         line["speedup_vs_cpu_port"] = round(value / world / cpu["value"], 1)
@@ -198,6 +206,35 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_batch_association(local_rank, K=16, pts=32768, search_range=6):
+    """findGlobalCorrespondingSurfFeaturesAdd_Batch for every (keyframe, neighbour) pair of a short batch,
+    device resident; feeds K8 directly.  Informational (single GPU)."""
+    import time as _t
+    from glio_amd import batch, synth
+    win = synth.make_window(W=K, pts_per_scan=pts, seed=synth.SEED_BASE + 61, perturb=(0.03, 0.2, 0.0), scan_radius=25.0, map_density=0.5)
+    tlb = np.array(win.opts.t_lb, np.float32)
+    poses = np.c_[win.init.trans, win.init.quat]
+    ci, cj = batch.pair_list(K, search_range)
+    ba = batch.BatchAssociation(K, pts, int(len(ci)) * pts, device=local_rank)
+    for k in range(K):
+        sc = win.scans[k].copy(); sc[:, :3] -= tlb
+        ba.set_frame(k, sc)
+    ba.run(poses, ci, cj)                                   # warm-up
+    t0 = _t.perf_counter()
+    counts, total = ba.run(poses, ci, cj)
+    dt = _t.perf_counter() - t0
+    st = batch.BatchStage(K, 2 * search_range, max(int(total), 1), device=local_rank)
+    ba.feed(st)
+    Hg = st.new_hg()
+    k8_ms = st.time_linearize(poses, Hg, 5)
+    info = {"workload": f"{K} keyframes x {pts} surf points, search range {search_range}: {len(ci)} keyframe pairs",
+            "queries": int(len(ci)) * pts, "kept_constraints": int(total), "wall_ms": round(dt * 1e3, 2),
+            "Mqueries_per_s": round(len(ci) * pts / dt / 1e6, 1), "us_per_pair": round(dt * 1e6 / len(ci), 1),
+            "k8_linearize_on_result_ms": round(k8_ms, 4)}
+    st.close(); ba.close()
+    return info
 
 
 def bench_batch_stage(args, rank, local_rank, world, dist, torch):
