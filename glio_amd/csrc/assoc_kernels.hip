@@ -219,7 +219,7 @@ struct AssocArgs {
     float inv_cell;
     double kd_max_radius, weight_gate;      // doubles in the reference: float quantities are promoted for the comparison
     double surf_dist_thres, lidar_const;
-    int n, table_cap;
+    int n, table_cap, unit_scores;
 };
 
 // 16 lanes per query (4 queries per wavefront, 16 per workgroup): the lanes of a group probe the 27 cells
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void k_associate(const AssocArgs a, const floa
                     oplane.y = (float)((double)weight * nrm[1]);
                     oplane.z = (float)((double)weight * nrm[2]);
                     oplane.w = (float)((double)weight * normInverse);
-                    oscore = a.lidar_const * (double)weight;
+                    oscore = a.unit_scores ? 1.0 : a.lidar_const * (double)weight;
                     if (BATCH) {
                         double* nc = o_nc + 6 * (size_t)i;
                         nc[0] = nloc[0]; nc[1] = nloc[1]; nc[2] = nloc[2];
@@ -508,7 +508,7 @@ static void enqueue_assoc(glio_ctx* c, int slot, const double q[4], const double
     for (int k = 0; k < 3; ++k) a.t[k] = t[k];
     a.inv_cell = w->inv_cell; a.kd_max_radius = c->opts.kd_max_radius; a.weight_gate = c->opts.weight_gate;
     a.surf_dist_thres = c->opts.surf_dist_thres; a.lidar_const = c->opts.lidar_const;
-    a.n = n; a.table_cap = w->table_cap;
+    a.n = n; a.table_cap = w->table_cap; a.unit_scores = c->opts.unit_scores;
     const size_t off = (size_t)slot * c->cap;
     const int nblk = (n + AQ_PER_BLOCK - 1) / AQ_PER_BLOCK;
     if (n > 0) {
@@ -757,7 +757,7 @@ int glio_bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const int3
         for (int k = 0; k < 3; ++k) a.t[k] = poses[7 * ci + k];
         for (int k = 0; k < 4; ++k) a.q[k] = poses[7 * ci + 3 + k];
         a.inv_cell = b->inv_cell; a.kd_max_radius = 1.5; a.weight_gate = 0.3; a.surf_dist_thres = 0.18; a.lidar_const = 2.5;   // :3839,3874,3863,3885
-        a.n = n; a.table_cap = f.table_cap;
+        a.n = n; a.table_cap = f.table_cap; a.unit_scores = 0;
         const int nblk = (n + AQ_PER_BLOCK - 1) / AQ_PER_BLOCK;
         if (n > 0)
             hipLaunchKernelGGL(k_associate<true>, dim3(nblk), dim3(256), 0, b->stream, a, b->d_local + (size_t)ci * b->cap, f.d_sorted, f.d_keys,

@@ -61,7 +61,7 @@ void glio_opts_default(glio_opts* o) {
     o->max_ddt_epochs = 0; o->jacobi_scaling = 1;
     o->huber_delta = 1.0; o->doppler_huber_delta = 1.0;
     o->q_lb[0] = 1.0; o->t_lb[2] = 0.28;
-    o->lidar_const = 7.5; o->surf_dist_thres = 0.18; o->kd_max_radius = 1.5; o->weight_gate = 0.3;
+    o->lidar_const = 7.5; o->surf_dist_thres = 0.18; o->kd_max_radius = 1.5; o->weight_gate = 0.3; o->trust_region_strategy = GLIO_STRATEGY_DOGLEG; o->unit_scores = 0;
     o->gravity = 9.80511;
     o->initial_trust_region_radius = 1e4; o->max_trust_region_radius = 1e16; o->min_trust_region_radius = 1e-32;
     o->min_relative_decrease = 1e-3; o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
@@ -484,7 +484,7 @@ static int enqueue_solve(glio_ctx* c, int n_ddt) {
     memset(&st, 0, sizeof st);
     st.cur = 1;                       // "candidate" buffer 0 holds the initial point
     st.cand_pending = 1;
-    st.radius = c->opts.initial_trust_region_radius; st.mu = 1e-8; st.n_ddt = n_ddt;
+    st.radius = c->opts.initial_trust_region_radius; st.mu = 1e-8; st.n_ddt = n_ddt; st.decrease_factor = 2.0;
     *c->h_status = st;
     GLIO_HIP_CHECK(hipMemcpyAsync(c->d_status, c->h_status, sizeof st, hipMemcpyHostToDevice, c->stream));
     GLIO_HIP_CHECK(hipMemcpyAsync(c->d_x[0], c->h_xbuf, (size_t)nx * 8, hipMemcpyHostToDevice, c->stream));

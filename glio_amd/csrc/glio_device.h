@@ -73,7 +73,8 @@ struct SolverStatus {
     double initial_cost, grad_max_norm;
     double mu_used;       // mu of the factorisation behind the stored Gauss-Newton step
     int group;            // number of trust-region kernel groups started (k_tr_prepare launches) in this solve
-    int pad_;
+    int lin_fail;         // Levenberg-Marquardt: the linear solve of this iteration failed -> the step is invalid
+    double decrease_factor;   // LevenbergMarquardtStrategy::decrease_factor_
 };
 
 // Structured ("arrow") linear solver of the trust-region step (solver_kernels.hip): buffers + structure tables

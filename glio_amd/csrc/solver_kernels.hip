@@ -40,8 +40,9 @@
 struct TrArgs {
     int W, n, n_ddt, max_iterations;
     double min_relative_decrease, function_tolerance, gradient_tolerance, parameter_tolerance;
-    double min_radius, initial_radius;
+    double min_radius, initial_radius, max_radius;
     int jacobi_scaling;
+    int lm;                   // 1 = Levenberg-Marquardt strategy (mu = 1 / radius, no dogleg interpolation)
     double* x0; double* x1; double* xout;
     const double* H0; const double* H1; const double* g0; const double* g1; const double* c0; const double* c1;
     double* L; double* vec; int vstride;
@@ -435,10 +436,18 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_prepare(const TrArgs a) {
                     const double rel = (s.cost - ccost) / s.model_cost_change;
                     if (rel > a.min_relative_decrease) {
                         s.cur = cand; s.cost = ccost; s.successful += 1;
-                        if (rel < 0.25) s.radius *= 0.5;                                      // StepAccepted
-                        if (rel > 0.75) s.radius = fmax(s.radius, 3.0 * s.dogleg_step_norm);
-                        s.mu = fmax(1e-8, 2.0 * s.mu / 10.0);
+                        if (a.lm) {                                                           // LevenbergMarquardtStrategy::StepAccepted
+                            s.radius = s.radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3));
+                            s.radius = fmin(a.max_radius, s.radius);
+                            s.decrease_factor = 2.0;
+                        } else {
+                            if (rel < 0.25) s.radius *= 0.5;                                  // DoglegStrategy::StepAccepted
+                            if (rel > 0.75) s.radius = fmax(s.radius, 3.0 * s.dogleg_step_norm);
+                            s.mu = fmax(1e-8, 2.0 * s.mu / 10.0);
+                        }
                         s.reuse = 0;
+                    } else if (a.lm) {
+                        s.radius /= s.decrease_factor; s.decrease_factor *= 2.0; s.reuse = 0;   // StepRejected: new damping, refactor
                     } else {
                         s.radius *= 0.5; s.reuse = 1;                                         // StepRejected
                     }
@@ -478,6 +487,8 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_prepare(const TrArgs a) {
     }
     __syncthreads();
     if (s.done) { finalize(a, s); return; }
+    if (a.lm && tid == 0) s.mu = 1.0 / s.radius;      // (Hs + D^2 / radius) y = gs
+    __syncthreads();
 
     if (!s.reuse) {
         for (int i = tid; i < n; i += TR_THREADS) {
@@ -562,9 +573,9 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_factor(const TrArgs a) {
         __syncthreads();
         solved = true;
     }
-    for (int attempt = 0; attempt < 12 && !solved; ++attempt) {
+    for (int attempt = 0; attempt < (a.lm ? 1 : 12) && !solved; ++attempt) {
         const double mu = *smu;
-        if (!(mu < 1.0)) break;
+        if (!a.lm && !(mu < 1.0)) break;
         if (attempt > 0) {             // breakdown: rebuild S H S + mu D^2 with the larger mu (rare)
             for (int i = tid >> 6; i < n; i += TR_WAVES) {
                 const double si = scale[i];
@@ -601,10 +612,11 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_factor(const TrArgs a) {
     }
     __syncthreads();
     if (tid == 0) {
-        if (solved) { a.status->mu_used = *smu; a.status->mu = fmax(1e-8, 2.0 * (*smu) / 10.0); }
+        if (solved) { a.status->mu_used = *smu; if (!a.lm) a.status->mu = fmax(1e-8, 2.0 * (*smu) / 10.0); a.status->lin_fail = 0; }
+        else if (a.lm) { a.status->lin_fail = 1; }       // invalid step: k_tr_dogleg shrinks the radius
         else { a.status->mu = *smu; a.status->done = 1; a.status->termination = GLIO_TERM_FAILURE; a.progress[1] = 1; __threadfence_system(); }
     }
-    if (!solved) {
+    if (!solved && !a.lm) {
         const double* xc = a.status->cur ? a.x1 : a.x0;
         for (int k = tid; k < 16 * a.W + a.n_ddt; k += TR_THREADS) a.xout[k] = xc[k];
     }
@@ -630,7 +642,8 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_dogleg(const TrArgs a) {
     gg = block_sum(gg, red); nn = block_sum(nn, red); gd = block_sum(gd, red);
     const double gnorm = sqrt(gg), gnn = sqrt(nn), radius = s.radius, alpha = s.alpha;
     double ca, cb, snorm;       // step (D-space) = ca * grad + cb * gn
-    if (gnn <= radius) { ca = 0.0; cb = 1.0; snorm = gnn; }
+    if (a.lm) { ca = 0.0; cb = 1.0; snorm = gnn; }        // Levenberg-Marquardt: the damped step itself
+    else if (gnn <= radius) { ca = 0.0; cb = 1.0; snorm = gnn; }
     else if (gnorm * alpha >= radius) { ca = -(radius / gnorm); cb = 0.0; snorm = radius; }
     else {
         const double b_dot_a = -alpha * gd;
@@ -659,13 +672,15 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_dogleg(const TrArgs a) {
     sn2 = block_sum(sn2, red); lin = block_sum(lin, red); quad = block_sum(quad, red);
     if (snorm < 0) snorm = sqrt(sn2);
     const double mcc = -(lin + 0.5 * quad);
-    const bool valid = mcc > 0.0;
+    const bool valid = mcc > 0.0 && !(a.lm && s.lin_fail);
     if (tid == 0) {
         s.dogleg_step_norm = snorm;
         if (!valid) {
             s.invalid += 1;
             if (s.invalid >= 5) { s.done = 1; s.termination = GLIO_TERM_FAILURE; }
-            s.mu *= 10.0; s.reuse = 0;          // StepIsInvalid: consumes an iteration, no candidate
+            if (a.lm) { s.radius /= s.decrease_factor; s.decrease_factor *= 2.0; s.lin_fail = 0; }
+            else s.mu *= 10.0;
+            s.reuse = 0;                        // StepIsInvalid: consumes an iteration, no candidate
             s.cand_pending = 0;
         } else {
             s.invalid = 0;
@@ -1080,6 +1095,7 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
     a.min_relative_decrease = c->opts.min_relative_decrease; a.function_tolerance = c->opts.function_tolerance;
     a.gradient_tolerance = c->opts.gradient_tolerance; a.parameter_tolerance = c->opts.parameter_tolerance;
     a.min_radius = c->opts.min_trust_region_radius; a.initial_radius = c->opts.initial_trust_region_radius;
+    a.max_radius = c->opts.max_trust_region_radius; a.lm = c->opts.trust_region_strategy == GLIO_STRATEGY_LM;
     a.jacobi_scaling = c->opts.jacobi_scaling;
     a.x0 = c->d_x[0]; a.x1 = c->d_x[1]; a.xout = c->d_xout;
     a.H0 = c->d_H[0]; a.H1 = c->d_H[1]; a.g0 = c->d_g[0]; a.g1 = c->d_g[1]; a.c0 = c->d_cost[0]; a.c1 = c->d_cost[1];

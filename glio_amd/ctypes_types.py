@@ -30,6 +30,7 @@ class GlioOpts(C.Structure):
         ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
         ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
         ("parameter_tolerance", C.c_double),
+        ("trust_region_strategy", C.c_int32), ("unit_scores", C.c_int32),
     ]
 
 

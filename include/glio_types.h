@@ -27,6 +27,7 @@ extern "C" {
 #define GLIO_POSE_LOCAL 15      /* local (tangent) size of one keyframe: dt3 dtheta3 dv3 dba3 dbg3 */
 #define GLIO_DD_MAX_SAT 20      /* dd_psr_factor_20: psr_size_20, dd_psr_factor.hpp:12 */
 #define GLIO_MAX_WINDOW 64
+enum { GLIO_STRATEGY_DOGLEG = 0, GLIO_STRATEGY_LM = 1 };
 
 /* Options that shape the hot path.  Defaults (glio_opts_default) are the shipped yaml /
  * hard-coded values: GLIO/config/config_urban_hk.yaml:60-104, Estimator.cpp:70,2424-2430. */
@@ -54,6 +55,12 @@ typedef struct glio_opts {
     double function_tolerance;          /* 1e-6 */
     double gradient_tolerance;          /* 1e-10 */
     double parameter_tolerance;         /* 1e-8 */
+    /* 0 = DOGLEG (sliding window / batch, Estimator.cpp:2425), 1 = LEVENBERG_MARQUARDT (the Ceres default the
+     * front end runs with, LidarOdometry.cpp:521-530) */
+    int32_t trust_region_strategy;
+    /* 0 = vec_surf_scores = lidar_const * weight (Estimator.cpp:3692); 1 = unit scores: the front end's
+     * LidarPlaneNormIncreFactor carries no score (LidarKeyframeFactor.h:222-257) */
+    int32_t unit_scores;
 } glio_opts;
 
 /* Window state = the Ceres parameter blocks of the sliding-window problem.

@@ -119,7 +119,7 @@ int orc_associate(const glio_opts* o, const float* map, int M, const float* scan
         on[1] = (float)((double)weight * nrm[1]);
         on[2] = (float)((double)weight * nrm[2]);
         on[3] = (float)((double)weight * normInverse);
-        out_scores[cnt] = o->lidar_const * (double)weight;                       /* :3692 */
+        out_scores[cnt] = o->unit_scores ? 1.0 : o->lidar_const * (double)weight;  /* :3692 */
         if (out_src) out_src[cnt] = i;
         ++cnt;
     }

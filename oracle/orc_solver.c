@@ -337,6 +337,8 @@ int orc_solve(const orc_problem* p, glio_state* x, glio_summary* sum) {
     double* tmp2 = (double*)malloc(sizeof(double) * n);
     dogleg dl;
     dl.n = n; dl.radius = o->initial_trust_region_radius; dl.mu = 1e-8; dl.reuse = 0; dl.alpha = 0; dl.dogleg_step_norm = 0;
+    const int lm = o->trust_region_strategy == GLIO_STRATEGY_LM;
+    double decrease_factor = 2.0;        /* LevenbergMarquardtStrategy::decrease_factor_ */
     dl.diag = (double*)malloc(sizeof(double) * n);
     dl.grad = (double*)malloc(sizeof(double) * n);
     dl.gn = (double*)malloc(sizeof(double) * n);
@@ -368,7 +370,21 @@ int orc_solve(const orc_problem* p, glio_state* x, glio_summary* sum) {
         /* ---- DoglegStrategy::ComputeStep on the scaled system Hs = S H S, gs = S g */
         for (int i = 0; i < n; ++i) { gs[i] = scale[i] * g[i]; for (int j = 0; j < n; ++j) Hs[(size_t)i * n + j] = scale[i] * H[(size_t)i * n + j] * scale[j]; }
         int step_valid = 1;
-        if (!dl.reuse) {
+        if (lm) {
+            /* LevenbergMarquardtStrategy::ComputeStep (Ceres 1.14): D^2 = clamp(diag(J^T J)) / radius on the scaled
+             * system, (Hs + D^2) y = gs, step = -y */
+            for (int i = 0; i < n; ++i) {
+                double d = Hs[(size_t)i * n + i];
+                d = d < 1e-6 ? 1e-6 : (d > 1e32 ? 1e32 : d);
+                dl.diag[i] = sqrt(d);
+            }
+            memcpy(L, Hs, sizeof(double) * nn);
+            for (int i = 0; i < n; ++i) L[(size_t)i * n + i] += dl.diag[i] * dl.diag[i] / dl.radius;
+            if (chol_lower(L, n) == 0) {
+                chol_solve(L, n, gs, tmp);
+                for (int i = 0; i < n; ++i) { if (!isfinite(tmp[i])) step_valid = 0; step[i] = -tmp[i]; }
+            } else step_valid = 0;
+        } else if (!dl.reuse) {
             for (int i = 0; i < n; ++i) {
                 double d = Hs[(size_t)i * n + i];
                 d = d < 1e-6 ? 1e-6 : (d > 1e32 ? 1e32 : d);
@@ -397,7 +413,7 @@ int orc_solve(const orc_problem* p, glio_state* x, glio_summary* sum) {
             dl.mu = fmax(1e-8, 2.0 * dl.mu / 10.0);
             for (int i = 0; i < n; ++i) dl.gn[i] = -dl.diag[i] * tmp[i];
         }
-        {   /* ComputeTraditionalDoglegStep */
+        if (!lm) {   /* ComputeTraditionalDoglegStep */
             const double gnorm = sqrt(vdot(dl.grad, dl.grad, n));
             const double gnn = sqrt(vdot(dl.gn, dl.gn, n));
             if (gnn <= dl.radius) {
@@ -428,7 +444,8 @@ int orc_solve(const orc_problem* p, glio_state* x, glio_summary* sum) {
         if (!(mcc > 0.0)) step_valid = 0;
         if (!step_valid) {
             if (++invalid >= 5) { sum->termination = GLIO_TERM_FAILURE; break; }
-            dl.mu *= 10.0; dl.reuse = 0;          /* StepIsInvalid */
+            if (lm) { dl.radius /= decrease_factor; decrease_factor *= 2.0; }
+            else { dl.mu *= 10.0; dl.reuse = 0; }  /* StepIsInvalid */
             continue;
         }
         invalid = 0;
@@ -436,7 +453,7 @@ int orc_solve(const orc_problem* p, glio_state* x, glio_summary* sum) {
         orc_state_plus(x, W, delta, &cand);
         double ccost;
         int cok = orc_linearize(p, &cand, Hc, gc, &ccost);
-        if (!cok) { dl.radius *= 0.5; dl.reuse = 1; continue; }
+        if (!cok) { if (lm) { dl.radius /= decrease_factor; decrease_factor *= 2.0; } else { dl.radius *= 0.5; dl.reuse = 1; } continue; }
         /* ParameterToleranceReached */
         {
             const double step_norm = sqrt(state_diff_norm2(x, &cand, W, 0));
@@ -453,10 +470,18 @@ int orc_solve(const orc_problem* p, glio_state* x, glio_summary* sum) {
             memcpy(g, gc, sizeof(double) * n);
             ++sum->successful_steps;
             /* StepAccepted */
-            if (rel < 0.25) dl.radius *= 0.5;
-            if (rel > 0.75) dl.radius = fmax(dl.radius, 3.0 * dl.dogleg_step_norm);
-            dl.mu = fmax(1e-8, 2.0 * dl.mu / 10.0);
-            dl.reuse = 0;
+            if (lm) {
+                dl.radius = dl.radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3));
+                dl.radius = fmin(o->max_trust_region_radius, dl.radius);
+                decrease_factor = 2.0;
+            } else {
+                if (rel < 0.25) dl.radius *= 0.5;
+                if (rel > 0.75) dl.radius = fmax(dl.radius, 3.0 * dl.dogleg_step_norm);
+                dl.mu = fmax(1e-8, 2.0 * dl.mu / 10.0);
+                dl.reuse = 0;
+            }
+        } else if (lm) {
+            dl.radius /= decrease_factor; decrease_factor *= 2.0;      /* LM StepRejected */
         } else {
             dl.radius *= 0.5; dl.reuse = 1;       /* StepRejected */
         }
