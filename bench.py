@@ -103,6 +103,12 @@ def main():
             dist.destroy_process_group()
         return
 
+    localmap_info = None
+    try:
+        localmap_info = bench_local_map(local_rank, win)
+    except Exception as e:
+        localmap_info = {"error": str(e)[:300]}
+
     bassoc_info = None
     if not args.no_bassoc:
         try:
@@ -198,7 +204,7 @@ def main():
         "termination": int(summ.termination),
         "kernels_us": {"lidar_linearize": round(k3_ms * 1e3, 2), "full_linearize": round(lin_ms * 1e3, 2), "tr_step": round(trs_ms * 1e3, 2),
                        "marginalize": round(marg_ms * 1e3, 2), "marginalize_call_incl_readback": round(marg_call_ms * 1e3, 1)},
-        "roofline": roofline, "cpu_baseline": cpu, "pose_vs_oracle": pose_err, "association": assoc, "batch_stage": batch_info, "batch_association": bassoc_info,
+        "roofline": roofline, "cpu_baseline": cpu, "pose_vs_oracle": pose_err, "association": assoc, "batch_stage": batch_info, "batch_association": bassoc_info, "local_map": localmap_info,
     }
     if cpu and "value" in cpu:
         line["speedup_vs_cpu_port"] = round(value / world / cpu["value"], 1)
@@ -206,6 +212,32 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_local_map(local_rank, win, width=50):
+    """device-resident local map -- per keyframe one scan is pushed (PCIe) and the 50-keyframe ring is
+    voxel-averaged and hashed on the device, instead of uploading the down-sampled map.  Informational."""
+    import time as _t
+    from glio_amd import capi, synth
+    o = synth.default_opts(1, pts=65536, map_pts=1 << 21)
+    ctx = capi.Context(o, device=local_rank)
+    pts = len(win.scans[0])
+    ctx.localmap_config(width, 0.4, pts)
+    tlb = np.array(win.opts.t_lb, np.float32)
+    for k in range(width):
+        s = k % win.W
+        c = win.scans[s].copy(); c[:, :3] -= tlb
+        ctx.localmap_push(c, win.gt.quat[s], win.gt.trans[s] + np.array([0.4 * (k // win.W), 0, 0]))
+    ctx.localmap_build()
+    c = win.scans[0].copy()
+    t0 = _t.perf_counter(); ctx.localmap_push(c, win.gt.quat[0], win.gt.trans[0]); t_push = _t.perf_counter() - t0
+    t0 = _t.perf_counter(); nv = ctx.localmap_build(); t_build = _t.perf_counter() - t0
+    t0 = _t.perf_counter(); ctx.set_map(ctx.localmap_read()); t_upload = _t.perf_counter() - t0
+    info = {"workload": f"ring of {width} keyframes x {pts} points, leaf 0.4 m", "ring_points": width * pts, "map_points": int(nv),
+            "push_one_scan_ms": round(t_push * 1e3, 3), "voxelgrid_plus_hash_ms": round(t_build * 1e3, 3),
+            "host_map_upload_path_ms": round(t_upload * 1e3, 3)}
+    ctx.close()
+    return info
 
 
 def bench_batch_association(local_rank, K=16, pts=32768, search_range=6):

@@ -78,6 +78,27 @@ class Context:
     def set_map(self, map_pts):
         _check(load().glio_set_map(self._h, T.fptr(map_pts), len(map_pts)))
 
+    # ---- device-resident local map
+    def localmap_config(self, width, leaf, max_points_per_keyframe):
+        _check(load().glio_localmap_config(self._h, width, C.c_float(leaf), max_points_per_keyframe))
+
+    def localmap_push(self, cloud, q, t):
+        cloud = np.ascontiguousarray(cloud, np.float32)
+        q = np.ascontiguousarray(q, float); t = np.ascontiguousarray(t, float)
+        _check(load().glio_localmap_push(self._h, T.fptr(cloud) if len(cloud) else None, len(cloud), T.dptr(q), T.dptr(t)))
+
+    def localmap_build(self):
+        n = C.c_int()
+        _check(load().glio_localmap_build(self._h, C.byref(n)))
+        return n.value
+
+    def localmap_read(self):
+        n = C.c_int()
+        _check(load().glio_localmap_read(self._h, None, 0, C.byref(n)))
+        out = np.zeros((max(n.value, 1), 4), np.float32)
+        _check(load().glio_localmap_read(self._h, T.fptr(out), n.value, C.byref(n)))
+        return out[:n.value]
+
     def set_scan(self, slot, scan):
         _check(load().glio_set_scan(self._h, slot, T.fptr(scan), len(scan)))
 

@@ -501,6 +501,18 @@ int glio_assoc_build_map(glio_ctx* c, const float* map_xyzi, int n) {
     return GLIO_OK;
 }
 
+// K1 from points that are already on the device (the local map built by localmap_kernels.hip)
+int glio_assoc_build_map_dev(glio_ctx* c, const float4* d_pts, int n) {
+    AssocWork* w = c->assoc;
+    if (!w) return GLIO_E_STATE;
+    if (n > c->opts.max_map_points) { glio_set_error("local map has %d points, max_map_points is %d", n, c->opts.max_map_points); return GLIO_E_ARG; }
+    if (n > 0) GLIO_HIP_CHECK(hipMemcpyAsync(w->d_map_raw, d_pts, (size_t)n * 16, hipMemcpyDeviceToDevice, c->stream));
+    enqueue_build(c, n);
+    GLIO_HIP_CHECK(hipGetLastError());
+    c->map_n = n;
+    return GLIO_OK;
+}
+
 static void enqueue_assoc(glio_ctx* c, int slot, const double q[4], const double t[3], int n, int want_nn) {
     AssocWork* w = c->assoc;
     AssocArgs a;

@@ -155,6 +155,7 @@ void glio_destroy(glio_ctx* c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     glio_assoc_destroy(c);
+    glio_localmap_destroy(c);
     void* ptrs[] = {c->d_pts, c->d_planes, c->d_scores, c->d_count, c->d_scan, c->d_imu, c->d_imu_blocks, c->d_gnss_blocks, c->d_groups,
                     c->d_ddt_blocks, c->d_dd, c->d_dop, c->d_prior_J0, c->d_prior_A0, c->d_prior_r0, c->d_prior_x0, c->d_prior_slot,
                     c->d_prior_kind, c->d_prior_idx, c->d_prior_index, c->d_prior_H, c->d_prior_g, c->d_prior_cost, c->d_prior_work,

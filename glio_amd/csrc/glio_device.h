@@ -110,6 +110,7 @@ struct glio_ctx {
     float4* d_map_sorted;         // [max_map] sorted by cell, .w = original index bits
     int map_n;
     struct AssocWork* assoc;      // hash table etc. (assoc_kernels.hip)
+    struct LocalMap* localmap;    // device-resident keyframe ring + voxel grid (localmap_kernels.hip), created on demand
     // ---- small factors
     ImuEdgeDev* d_imu; int n_imu;
     PairBlock* d_imu_blocks;      // [2][W]
@@ -245,6 +246,8 @@ void glio_launch_lidar_linearize(glio_ctx* c, int use_status_cand, int which, in
 void glio_launch_small_factors(glio_ctx* c, int use_status_cand, int which, int n_ddt, int marg = 0);
 void glio_launch_assemble(glio_ctx* c, int use_status_cand, int which, int n_ddt);
 void glio_launch_stream_read(glio_ctx* c);
+int glio_assoc_build_map_dev(glio_ctx* c, const float4* d_pts, int n);
+void glio_localmap_destroy(glio_ctx* c);
 // solver_kernels.hip
 void glio_launch_tr_step(glio_ctx* c, int n_ddt);
 // marginalization of slot 0 from lidar_blocks/imu_blocks/prior H of buffer 0 (evaluated with marg = 1)

@@ -1,0 +1,249 @@
+// localmap_kernels.hip -- device-resident local surf map.
+//
+// Replaces, for the sliding-window path, buildLocalMapWithLandMark + downSampleCloud + the kd-tree input
+// (reference GLIO/src/Estimator.cpp:3529-3631, 2056): the last `local_map_width` keyframe clouds are kept ON THE
+// DEVICE in the map frame (transformCloud(surf_frames[idx], q_po * q_bl, q_po * t_bl + t_po), :3569-3574), so that per
+// keyframe only ONE new scan (16 B/point) crosses PCIe instead of the whole down-sampled map; the concatenation is
+// voxel-averaged on the device (pcl::VoxelGrid semantics: bounding box, floor(p * inv_leaf) - min_b, centroid per
+// voxel, output ordered by linear voxel index) and handed to K1 without leaving HBM.
+//
+// The ring holds width x cap x 16 B (50 x 64k points = 52 MB); a rebuild streams it once (~1.6 M points) -- far
+// cheaper than keeping incremental sums exact, and with no eviction arithmetic at all.  Voxel sums are accumulated in
+// 2^-20 m fixed point (int64 atomics): exact and order independent, hence bit-reproducible whatever the atomic order;
+// PCL's float accumulation (whose order std::sort leaves unspecified) is matched to ~1e-6 m, not bit for bit.
+#include <cfloat>
+#include <algorithm>
+#include <cstring>
+
+#include <hipcub/hipcub.hpp>
+
+#include "glio_device.h"
+
+// the transform must round like the reference's scalar code (and the oracle): no FMA contraction in this file
+#pragma clang fp contract(off)
+
+struct LocalMap {
+    int width, cap;                 // keyframes in the ring, points per keyframe
+    float leaf;
+    float4* d_ring;                 // [width][cap] clouds in the map frame
+    int* h_n;                       // [width] points per ring entry
+    int* d_n;                       // [width] the same, on the device (grid.y = ring slot)
+    int head, count;                // ring: entries [head, head+count) modulo width, oldest first
+    long long pushed;               // keyframes pushed so far
+    // voxel grid workspace
+    int table_cap;                  // power of two >= 2 * max voxels
+    unsigned long long* d_keys;     // voxel linear index or EMPTY
+    long long* d_sum;               // [table_cap][4] fixed-point sums x,y,z,intensity
+    int* d_cnt;                     // [table_cap]
+    int* d_bbox;                    // [6] ordered-int encoded min xyz / max xyz
+    int* d_nvox;                    // [1]
+    unsigned long long* d_vkey; unsigned long long* d_vkey_sorted; int* d_vslot; int* d_vslot_sorted;
+    void* d_sort_tmp; size_t sort_tmp_bytes;
+    float4* d_out;                  // [max voxels] down-sampled map, ordered by voxel index
+    int max_vox;
+    int* h_pin;                     // pinned scalar read-back
+};
+
+#define LM_EMPTY (~0ull)
+#define LM_FIX 1048576.0            /* 2^20: fixed-point scale of the voxel sums */
+
+__device__ __forceinline__ int f2ord(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+__device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+__global__ void k_lm_transform(const float4* __restrict__ in, int n, const double q0, const double q1, const double q2, const double q3,
+                               const double t0, const double t1, const double t2, float4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // transformCloud, Estimator.cpp:1517-1546 (double q*v + t, float store)
+    if (i >= n) return;
+    const float4 p = in[i];
+    const double v[3] = {(double)p.x, (double)p.y, (double)p.z};
+    // Eigen: v + w * (2 u x v) + u x (2 u x v), products kept separate (no contraction) as in assoc_kernels.hip
+    double uv[3] = {q2 * v[2] - q3 * v[1], q3 * v[0] - q1 * v[2], q1 * v[1] - q2 * v[0]};
+    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+    const double uuv[3] = {q2 * uv[2] - q3 * uv[1], q3 * uv[0] - q1 * uv[2], q1 * uv[1] - q2 * uv[0]};
+    out[i] = make_float4((float)((v[0] + q0 * uv[0] + uuv[0]) + t0), (float)((v[1] + q0 * uv[1] + uuv[1]) + t1),
+                         (float)((v[2] + q0 * uv[2] + uuv[2]) + t2), p.w);
+}
+
+__global__ void k_lm_clear(unsigned long long* keys, long long* sum, int* cnt, int cap, int* bbox, int* nvox) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap) { keys[i] = LM_EMPTY; cnt[i] = 0; sum[4 * (size_t)i] = 0; sum[4 * (size_t)i + 1] = 0; sum[4 * (size_t)i + 2] = 0; sum[4 * (size_t)i + 3] = 0; }
+    if (i < 3) bbox[i] = 0x7fffffff;
+    else if (i < 6) bbox[i] = (int)0x80000000;
+    if (i == 6) *nvox = 0;
+}
+__global__ void k_lm_bbox(const float4* __restrict__ ring, const int* __restrict__ ns, int cap, int* bbox) {
+    const float4* pts = ring + (size_t)blockIdx.y * cap;
+    const int n = ns[blockIdx.y];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+    for (; i < n; i += gridDim.x * blockDim.x) {
+        const float4 p = pts[i];
+        const int o[3] = {f2ord(p.x), f2ord(p.y), f2ord(p.z)};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { mn[c] = min(mn[c], o[c]); mx[c] = max(mx[c], o[c]); }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { mn[c] = min(mn[c], __shfl_xor(mn[c], off, 64)); mx[c] = max(mx[c], __shfl_xor(mx[c], off, 64)); }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { atomicMin(bbox + c, mn[c]); atomicMax(bbox + 3 + c, mx[c]); }
+    }
+}
+__device__ __forceinline__ unsigned lm_hash(unsigned long long k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return (unsigned)k;
+}
+__global__ void k_lm_accumulate(const float4* __restrict__ ring, const int* __restrict__ ns, int ring_cap, float inv_leaf,
+                                const int* __restrict__ bbox, unsigned long long* keys, long long* sum, int* cnt, int cap, int* nvox,
+                                unsigned long long* vkey, int* vslot, int max_vox) {
+    const float4* pts = ring + (size_t)blockIdx.y * ring_cap;
+    const int n = ns[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    int min_b[3], div_b[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { min_b[c] = (int)floorf(ord2f(bbox[c]) * inv_leaf); div_b[c] = (int)floorf(ord2f(bbox[3 + c]) * inv_leaf) - min_b[c] + 1; }
+    const int i0 = (int)(floorf(p.x * inv_leaf) - (float)min_b[0]);
+    const int i1 = (int)(floorf(p.y * inv_leaf) - (float)min_b[1]);
+    const int i2 = (int)(floorf(p.z * inv_leaf) - (float)min_b[2]);
+    const unsigned long long key = (unsigned long long)((long long)i0 + (long long)i1 * div_b[0] + (long long)i2 * div_b[0] * (long long)div_b[1]);
+    unsigned s = lm_hash(key) & (cap - 1);
+    for (;;) {
+        const unsigned long long k = atomicCAS(keys + s, LM_EMPTY, key);
+        if (k == LM_EMPTY) {                      // first point of this voxel: register it for the ordered output
+            const int v = atomicAdd(nvox, 1);
+            if (v < max_vox) { vkey[v] = key; vslot[v] = (int)s; }
+            break;
+        }
+        if (k == key) break;
+        s = (s + 1) & (cap - 1);
+    }
+    atomicAdd(reinterpret_cast<unsigned long long*>(sum + 4 * (size_t)s + 0), (unsigned long long)llrint((double)p.x * LM_FIX));
+    atomicAdd(reinterpret_cast<unsigned long long*>(sum + 4 * (size_t)s + 1), (unsigned long long)llrint((double)p.y * LM_FIX));
+    atomicAdd(reinterpret_cast<unsigned long long*>(sum + 4 * (size_t)s + 2), (unsigned long long)llrint((double)p.z * LM_FIX));
+    atomicAdd(reinterpret_cast<unsigned long long*>(sum + 4 * (size_t)s + 3), (unsigned long long)llrint((double)p.w * LM_FIX));
+    atomicAdd(cnt + s, 1);
+}
+__global__ void k_lm_emit(const int* __restrict__ vslot_sorted, int nv, const long long* __restrict__ sum, const int* __restrict__ cnt,
+                          float4* __restrict__ out) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv) return;
+    const int s = vslot_sorted[v];
+    const double c = (double)cnt[s];
+    out[v] = make_float4((float)((double)sum[4 * (size_t)s] / LM_FIX / c), (float)((double)sum[4 * (size_t)s + 1] / LM_FIX / c),
+                         (float)((double)sum[4 * (size_t)s + 2] / LM_FIX / c), (float)((double)sum[4 * (size_t)s + 3] / LM_FIX / c));
+}
+
+#define LM_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { glio_set_error("%s failed: %s", #expr, hipGetErrorString(e_)); return GLIO_E_HIP; } } while (0)
+static int lm_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+void glio_localmap_destroy(glio_ctx* c) {
+    LocalMap* m = c->localmap;
+    if (!m) return;
+    void* p[] = {m->d_n, m->d_ring, m->d_keys, m->d_sum, m->d_cnt, m->d_bbox, m->d_nvox, m->d_vkey, m->d_vkey_sorted, m->d_vslot, m->d_vslot_sorted, m->d_sort_tmp, m->d_out};
+    for (void* q : p) if (q) hipFree(q);
+    if (m->h_pin) hipHostFree(m->h_pin);
+    delete[] m->h_n;
+    delete m;
+    c->localmap = nullptr;
+}
+
+extern "C" {
+
+int glio_localmap_config(glio_ctx* c, int width, float leaf, int max_points_per_keyframe) {
+    if (!c || width < 1 || !(leaf > 0.f) || max_points_per_keyframe < 1) return GLIO_E_ARG;
+    LM_CHECK(hipSetDevice(c->device));
+    glio_localmap_destroy(c);
+    LocalMap* m = new LocalMap();
+    memset(m, 0, sizeof *m);
+    m->width = width; m->cap = max_points_per_keyframe; m->leaf = leaf;
+    m->max_vox = c->opts.max_map_points > 0 ? c->opts.max_map_points : 1;
+    m->table_cap = lm_pow2(2 * m->max_vox);
+    m->h_n = new int[width]();
+    LM_CHECK(hipMalloc((void**)&m->d_n, (size_t)width * 4));
+    LM_CHECK(hipMalloc((void**)&m->d_ring, (size_t)width * m->cap * 16));
+    LM_CHECK(hipMalloc((void**)&m->d_keys, (size_t)m->table_cap * 8)); LM_CHECK(hipMalloc((void**)&m->d_sum, (size_t)m->table_cap * 32));
+    LM_CHECK(hipMalloc((void**)&m->d_cnt, (size_t)m->table_cap * 4)); LM_CHECK(hipMalloc((void**)&m->d_bbox, 32)); LM_CHECK(hipMalloc((void**)&m->d_nvox, 4));
+    LM_CHECK(hipMalloc((void**)&m->d_vkey, (size_t)m->max_vox * 8)); LM_CHECK(hipMalloc((void**)&m->d_vkey_sorted, (size_t)m->max_vox * 8));
+    LM_CHECK(hipMalloc((void**)&m->d_vslot, (size_t)m->max_vox * 4)); LM_CHECK(hipMalloc((void**)&m->d_vslot_sorted, (size_t)m->max_vox * 4));
+    LM_CHECK(hipMalloc((void**)&m->d_out, (size_t)m->max_vox * 16));
+    m->sort_tmp_bytes = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, m->sort_tmp_bytes, m->d_vkey, m->d_vkey_sorted, m->d_vslot, m->d_vslot_sorted, m->max_vox, 0, 64, c->stream);
+    LM_CHECK(hipMalloc(&m->d_sort_tmp, m->sort_tmp_bytes + 16));
+    LM_CHECK(hipHostMalloc((void**)&m->h_pin, 64));
+    c->localmap = m;
+    return GLIO_OK;
+}
+
+int glio_localmap_push(glio_ctx* c, const float* cloud_xyzi, int n, const double q[4], const double t[3]) {
+    if (!c || !c->localmap) { glio_set_error("glio_localmap_config first"); return GLIO_E_STATE; }
+    LocalMap* m = c->localmap;
+    if (n < 0 || n > m->cap || (n > 0 && !cloud_xyzi) || !q || !t) return GLIO_E_ARG;
+    LM_CHECK(hipSetDevice(c->device));
+    int slot;
+    if (m->count < m->width) { slot = (m->head + m->count) % m->width; ++m->count; }
+    else { slot = m->head; m->head = (m->head + 1) % m->width; }                  // recent_surf_keyframes.pop_front() (:3585)
+    float4* dst = m->d_ring + (size_t)slot * m->cap;
+    if (n > 0) {
+        // stage the raw scan in the destination itself, transform in place
+        LM_CHECK(hipMemcpyAsync(dst, cloud_xyzi, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_lm_transform, dim3((n + 255) / 256), dim3(256), 0, c->stream, dst, n, q[0], q[1], q[2], q[3], t[0], t[1], t[2], dst);
+        LM_CHECK(hipGetLastError());
+        LM_CHECK(hipStreamSynchronize(c->stream));        // the caller's buffer may be reused after return
+    }
+    m->h_n[slot] = n;
+    ++m->pushed;
+    return GLIO_OK;
+}
+
+int glio_localmap_build(glio_ctx* c, int* out_points) {
+    if (!c || !c->localmap) { glio_set_error("glio_localmap_config first"); return GLIO_E_STATE; }
+    LocalMap* m = c->localmap;
+    LM_CHECK(hipSetDevice(c->device));
+    const float inv_leaf = 1.0f / m->leaf;
+    hipLaunchKernelGGL(k_lm_clear, dim3((m->table_cap + 255) / 256), dim3(256), 0, c->stream, m->d_keys, m->d_sum, m->d_cnt, m->table_cap, m->d_bbox, m->d_nvox);
+    // every ring slot in one launch (grid.y = slot; unused slots hold n = 0)
+    int nmax = 0;
+    for (int k = 0; k < m->width; ++k) nmax = std::max(nmax, m->h_n[k]);
+    LM_CHECK(hipMemcpyAsync(m->d_n, m->h_n, (size_t)m->width * 4, hipMemcpyHostToDevice, c->stream));
+    if (nmax > 0) {
+        hipLaunchKernelGGL(k_lm_bbox, dim3(std::min(64, (nmax + 255) / 256), m->width), dim3(256), 0, c->stream, m->d_ring, m->d_n, m->cap, m->d_bbox);
+        hipLaunchKernelGGL(k_lm_accumulate, dim3((nmax + 255) / 256, m->width), dim3(256), 0, c->stream, m->d_ring, m->d_n, m->cap, inv_leaf, m->d_bbox,
+                           m->d_keys, m->d_sum, m->d_cnt, m->table_cap, m->d_nvox, m->d_vkey, m->d_vslot, m->max_vox);
+    }
+    LM_CHECK(hipGetLastError());
+    LM_CHECK(hipMemcpyAsync(m->h_pin, m->d_nvox, 4, hipMemcpyDeviceToHost, c->stream));
+    LM_CHECK(hipStreamSynchronize(c->stream));
+    const int nv = m->h_pin[0];
+    if (nv > m->max_vox) { glio_set_error("local map has %d voxels, max_map_points is %d", nv, m->max_vox); return GLIO_E_ARG; }
+    if (nv > 0) {
+        size_t bytes = m->sort_tmp_bytes;
+        if (hipcub::DeviceRadixSort::SortPairs(m->d_sort_tmp, bytes, m->d_vkey, m->d_vkey_sorted, m->d_vslot, m->d_vslot_sorted, nv, 0, 64, c->stream) != hipSuccess) {
+            glio_set_error("voxel sort failed"); return GLIO_E_HIP;
+        }
+        hipLaunchKernelGGL(k_lm_emit, dim3((nv + 255) / 256), dim3(256), 0, c->stream, m->d_vslot_sorted, nv, m->d_sum, m->d_cnt, m->d_out);
+    }
+    const int rc = glio_assoc_build_map_dev(c, m->d_out, nv);          // K1: replaces setInputCloud(surf_local_map_ds) (:2056)
+    if (rc) return rc;
+    LM_CHECK(hipStreamSynchronize(c->stream));
+    if (out_points) *out_points = nv;
+    return GLIO_OK;
+}
+
+int glio_localmap_read(glio_ctx* c, float* out_xyzi, int capacity, int* out_n) {
+    if (!c || !c->localmap || !out_n) return GLIO_E_ARG;
+    LM_CHECK(hipSetDevice(c->device));
+    const int n = c->map_n;
+    *out_n = n;
+    if (out_xyzi && n > 0) {
+        if (capacity < n) return GLIO_E_ARG;
+        LM_CHECK(hipMemcpy(out_xyzi, c->localmap->d_out, (size_t)n * 16, hipMemcpyDeviceToHost));
+    }
+    return GLIO_OK;
+}
+
+}  // extern "C"

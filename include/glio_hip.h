@@ -53,6 +53,17 @@ int glio_synchronize(glio_ctx* ctx);
  * (Estimator.cpp:2056).  pts = PointXYZI[n] as 4 floats; builds the voxel hash on device. */
 int glio_set_map(glio_ctx* ctx, const float* map_xyzi, int n);
 
+/* ---- device-resident local map.  Replaces buildLocalMapWithLandMark + downSampleCloud + setInputCloud
+ * (Estimator.cpp:3529-3631, 2056) by a ring of the last `width` keyframe clouds kept on the device in the map frame:
+ * per keyframe ONE scan crosses PCIe (glio_localmap_push), the concatenation is voxel-averaged (pcl::VoxelGrid
+ * semantics, leaf = surf_ds_size) and hashed on the device (glio_localmap_build does what glio_set_map does).
+ *   width = local_map_width (yaml: 50); q,t = q_po * q_bl, q_po * t_bl + t_po (:3569-3570). */
+int glio_localmap_config(glio_ctx* ctx, int width, float leaf, int max_points_per_keyframe);
+int glio_localmap_push(glio_ctx* ctx, const float* cloud_xyzi, int n, const double q[4], const double t[3]);
+int glio_localmap_build(glio_ctx* ctx, int* out_points);
+/* test hook: the down-sampled map (surf_local_map_ds), ordered by voxel index */
+int glio_localmap_read(glio_ctx* ctx, float* out_xyzi, int capacity, int* out_n);
+
 /* ---- K2: correspondences.  Replaces findCorrespondingSurfFeatures(idx, Q2, T2)
  * (Estimator.cpp:3633-3708) for window slot `slot`: uploads the scan (surf_frames[idx], PointXYZI[n],
  * LiDAR frame), runs exact 5-NN + plane fit + gates on device and leaves the compacted

@@ -97,6 +97,10 @@ void orc_plane_qr_solve(const double A[15], const double b[5], double x[3]);
 int orc_marginalize(const orc_problem* p, const glio_state* x, double* lin_jac, double* lin_res,
                     int32_t* blk_slot, int32_t* blk_kind, int32_t* blk_idx, double* blk_x0);
 
+void orc_transform_cloud(const float* in, int n, const double q[4], const double t[3], float* out);
+/* pcl::VoxelGrid<PointXYZI> as used by downSampleCloud (Estimator.cpp:3618-3631); returns the voxel count */
+int orc_voxel_grid(const float* pts, int n, float leaf, float* out, int64_t* out_idx);
+
 /* findGlobalCorrespondingSurfFeaturesAdd_Batch for one keyframe pair (Estimator.cpp:3808-3892); returns the count */
 int orc_associate_pair(const float* scan_a, int na, const double qa[4], const double ta[3],
                        const float* scan_b, int nb, const double qb[4], const double tb[3],

@@ -201,3 +201,60 @@ int orc_associate_pair(const float* scan_a, int na, const double qa[4], const do
     free(gb);
     return cnt;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * pcl::VoxelGrid<PointXYZI>::applyFilter as used by downSampleCloud (Estimator.cpp:3618-3631,
+ * ds_filter_surf_map, leaf = surf_ds_size 0.4 m :854): PCL 1.8 semantics restated (PCL itself is an external
+ * dependency, not under /root/reference): bounding box -> min_b = floor(min * inv_leaf); voxel of a point =
+ * (int)(floor(x * inv_leaf) - (float)min_b) per axis, linear index i + j*div0 + k*div0*div1; points grouped by index,
+ * centroid of x,y,z,intensity accumulated in float; output ordered by voxel index.  PCL sorts with std::sort (order
+ * inside a voxel unspecified); here points of a voxel are accumulated in input order.
+ * Returns the number of voxels; out [n][4], out_idx [n] (optional) the linear voxel index of every output point.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct { int64_t idx; int src; } vg_item;
+static int vg_cmp(const void* a, const void* b) {
+    const vg_item* x = (const vg_item*)a; const vg_item* y = (const vg_item*)b;
+    if (x->idx != y->idx) return x->idx < y->idx ? -1 : 1;
+    return x->src < y->src ? -1 : (x->src > y->src);
+}
+int orc_voxel_grid(const float* pts, int n, float leaf, float* out, int64_t* out_idx) {
+    if (n <= 0) return 0;
+    const float inv = 1.0f / leaf;
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = 0; i < n; ++i) for (int c = 0; c < 3; ++c) { const float v = pts[4 * (size_t)i + c]; if (v < mn[c]) mn[c] = v; if (v > mx[c]) mx[c] = v; }
+    int min_b[3], div_b[3];
+    for (int c = 0; c < 3; ++c) { min_b[c] = (int)floorf(mn[c] * inv); div_b[c] = (int)floorf(mx[c] * inv) - min_b[c] + 1; }
+    vg_item* it = (vg_item*)malloc(sizeof(vg_item) * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const float* p = pts + 4 * (size_t)i;
+        const int i0 = (int)(floorf(p[0] * inv) - (float)min_b[0]);
+        const int i1 = (int)(floorf(p[1] * inv) - (float)min_b[1]);
+        const int i2 = (int)(floorf(p[2] * inv) - (float)min_b[2]);
+        it[i].idx = (int64_t)i0 + (int64_t)i1 * div_b[0] + (int64_t)i2 * div_b[0] * (int64_t)div_b[1];
+        it[i].src = i;
+    }
+    qsort(it, (size_t)n, sizeof(vg_item), vg_cmp);
+    int nv = 0;
+    for (int i = 0; i < n;) {
+        int j = i;
+        float acc[4] = {0, 0, 0, 0};
+        while (j < n && it[j].idx == it[i].idx) { const float* p = pts + 4 * (size_t)it[j].src; for (int c = 0; c < 4; ++c) acc[c] += p[c]; ++j; }
+        const float cnt = (float)(j - i);
+        for (int c = 0; c < 4; ++c) out[4 * (size_t)nv + c] = acc[c] / cnt;
+        if (out_idx) out_idx[nv] = it[i].idx;
+        ++nv;
+        i = j;
+    }
+    free(it);
+    return nv;
+}
+
+/* transformCloud (Estimator.cpp:1517-1546): double q*v + t, float store; intensity copied */
+void orc_transform_cloud(const float* in, int n, const double q[4], const double t[3], float* out) {
+    for (int i = 0; i < n; ++i) {
+        double pin[3] = {in[4 * (size_t)i], in[4 * (size_t)i + 1], in[4 * (size_t)i + 2]}, po[3];
+        q_rot(q, pin, po);
+        out[4 * (size_t)i] = (float)(po[0] + t[0]); out[4 * (size_t)i + 1] = (float)(po[1] + t[1]); out[4 * (size_t)i + 2] = (float)(po[2] + t[2]);
+        out[4 * (size_t)i + 3] = in[4 * (size_t)i + 3];
+    }
+}

@@ -133,6 +133,22 @@ def associate(opts, map_pts, scan, q, t, want_nn=False):
     return res + ((nn,) if want_nn else ())
 
 
+def transform_cloud(pts, q, t):
+    pts = np.ascontiguousarray(pts, np.float32)
+    out = np.zeros_like(pts)
+    q = np.ascontiguousarray(q, float); t = np.ascontiguousarray(t, float)
+    lib().orc_transform_cloud.restype = None
+    lib().orc_transform_cloud(T.fptr(pts), len(pts), T.dptr(q), T.dptr(t), T.fptr(out))
+    return out
+
+
+def voxel_grid(pts, leaf):
+    pts = np.ascontiguousarray(pts, np.float32)
+    out = np.zeros((max(len(pts), 1), 4), np.float32); idx = np.zeros(max(len(pts), 1), np.int64)
+    nv = lib().orc_voxel_grid(T.fptr(pts), len(pts), C.c_float(leaf), T.fptr(out), idx.ctypes.data_as(C.POINTER(C.c_int64)))
+    return out[:nv].copy(), idx[:nv].copy()
+
+
 def associate_pair(scan_a, pose_a, scan_b, pose_b):
     """findGlobalCorrespondingSurfFeaturesAdd_Batch for one pair; pose = (t[3], q[4])."""
     na = len(scan_a)
