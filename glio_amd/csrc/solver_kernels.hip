@@ -740,7 +740,107 @@ struct ArrowArgs {
 
 __host__ __device__ __forceinline__ size_t arrow_forward_lds_doubles(int W, int nd) {
     return (size_t)(nd + (nd & 1)) + (size_t)nd * AR_YS + (size_t)nd * 18 + (size_t)9 * W * AR_YS + 3 * AR_LB + (size_t)W * 180 +
-           (size_t)nd + 2 + (size_t)(W + 2) / 2 + 1 + (size_t)nd + 2 + 2 + 92;      // ... + the 9x9 (stride 10) update scratch at the end
+           (size_t)nd + 2 + (size_t)(W + 2) / 2 + 1 + (size_t)nd + 2 + 2 + 92 +      // ... + the 9x9 (stride 10) update scratch +
+           4 * AR_LB + 92;                                                      // the bottom chain's panels, the meeting block, its scratch
+}
+
+// One step of a speed-bias chain, executed by one wavefront.  On entry lanes 0-8 hold (in av) the rows of the current
+// diagonal block D_i, already corrected by the previous step.  Lanes 9-17 load the off-diagonal panel towards the NEXT
+// block of this chain: DOWN = false (top chain, i ascending): rows of B_i = M[s_{i+1}, s_i]; DOWN = true (bottom chain,
+// i descending): rows of B_{i-1}^T = M[s_{i-1}, s_i].  Nine register steps (pivot and multipliers by v_readlane) factor
+// the 18 x 9 panel; it is stored to Lc (rows 0-8 L_ii, rows 9-17 L_{nb,i}, then the reciprocal pivots) and, from
+// workgroup 0, to global memory for the back substitution.  The rank-9 correction C = L_{nb,i} L_{nb,i}^T of the next
+// diagonal block is computed by 45 lanes (one (r, j <= r) pair each) into Cs; on exit av = D_nb - C.
+template <bool DOWN>
+__device__ __forceinline__ void arrow_chain_step(const int i, const int nb, const bool has_nb, double (&av)[9], const double* Blk, double* Lc,
+                                                 double* Lg, double* Cs, const int lane, const int pr, const int pj, bool& bad) {
+    const int r = lane;
+    double nx[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) nx[j] = (has_nb && r < 9) ? Blk[nb * 180 + r * 10 + j] : 0.0;
+    if (r >= 9 && r < 18) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) av[j] = has_nb ? (DOWN ? Blk[nb * 180 + (9 + j) * 10 + (r - 9)] : Blk[i * 180 + r * 10 + j]) : 0.0;
+    }
+    double rpv = 0.0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        double djj = readlane_d(av[j], j);
+        if (!(djj > 0.0) || !isfinite(djj)) { bad = true; djj = 1.0; }
+        const double rdj = rsqrt(djj);
+        const double lij = (lane == j) ? djj * rdj : av[j] * rdj;
+        if (lane == j) rpv = rdj;
+        av[j] = lij;
+#pragma unroll
+        for (int c = j + 1; c < 9; ++c) av[c] -= lij * readlane_d(lij, c);      // lanes < c only touch entries above the
+    }                                                                            // diagonal, which nobody reads: no masking
+    if (r < 18) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const double v = (r < 9 && j > r) ? 0.0 : av[j];
+            Lc[r * 10 + j] = v;
+            if (Lg) Lg[r * 10 + j] = v;
+        }
+        if (r < 9) { Lc[180 + r] = rpv; if (Lg) Lg[180 + r] = rpv; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (has_nb) {
+        const double* X = Lc + 90;
+        if (lane < 45) {
+            double xa[9], xb[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { xa[k] = X[pr * 10 + k]; xb[k] = X[pj * 10 + k]; }
+            double sacc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) sacc += xa[k] * xb[k];
+            Cs[pr * 10 + pj] = sacc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (r < 9) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) nx[j] -= Cs[r * 10 + j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) av[j] = (r < 9 && j <= r) ? nx[j] : 0.0;
+}
+
+// Forward substitution of one chain block for 16 right-hand-side columns, by one wavefront: lane = (column c, k-group g);
+// Y_i = L_ii^-1 (R_i - sum over the (up to two) already eliminated neighbours nbr of L_{i,nbr} Y_nbr), L_{i,nbr} = rows 9-17
+// of the neighbour's stored panel.
+__device__ __forceinline__ void arrow_y_update(const int i, const int n_nbr, const int nbr0, const double* P0, const int nbr1, const double* P1,
+                                               const double* Lc, double* Ys, const int lane) {
+    const int c = lane & 15, g = lane >> 4;
+    double tv[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) tv[r] = g == 0 ? Ys[(9 * i + r) * AR_YS + c] : 0.0;
+    for (int q = 0; q < n_nbr; ++q) {
+        const int nbr = q == 0 ? nbr0 : nbr1;
+        const double* Lp = (q == 0 ? P0 : P1) + 90;
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+            const int k = g + 4 * kk;
+            if (k < 9) {
+                const double yk = Ys[(9 * nbr + k) * AR_YS + c];
+#pragma unroll
+                for (int r = 0; r < 9; ++r) tv[r] -= Lp[r * 10 + k] * yk;
+            }
+        }
+    }
+    if (n_nbr > 0) {
+#pragma unroll
+        for (int r = 0; r < 9; ++r) { tv[r] += __shfl_xor(tv[r], 16, 64); tv[r] += __shfl_xor(tv[r], 32, 64); }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {          // column-oriented forward substitution
+        tv[k] *= Lc[180 + k];
+#pragma unroll
+        for (int r = k + 1; r < 9; ++r) tv[r] -= Lc[r * 10 + k] * tv[k];
+    }
+    if (g == 0) {
+#pragma unroll
+        for (int r = 0; r < 9; ++r) Ys[(9 * i + r) * AR_YS + c] = tv[r];
+    }
 }
 
 __global__ __launch_bounds__(256) void k_arrow_forward(const ArrowArgs a) {
@@ -761,8 +861,9 @@ __global__ __launch_bounds__(256) void k_arrow_forward(const ArrowArgs a) {
     int* elist = eoff + ((W + 2) & ~1) + 2;                             // [2 nd]
     int* bad_lds = elist + 2 * nd + 2;
     double* Cs = Lb - 0;                 // set below
-    Cs = reinterpret_cast<double*>(tr_lds) + arrow_forward_lds_doubles(W, nd) - 92;
-    if (tid == 0) *bad_lds = 0;
+    Cs = reinterpret_cast<double*>(tr_lds) + arrow_forward_lds_doubles(W, nd) - 92 - (4 * AR_LB + 92);
+    int* vrows_lds = bad_lds + 1;        // 1 = some epoch couples to a non-velocity speed-bias row
+    if (tid == 0) { *bad_lds = 0; *vrows_lds = 0; }
     AR_STAMP(0);
     for (int e = tid; e < nd; e += 256) eps[e] = a.ep_slots[e];
     for (int i = tid; i <= W; i += 256) eoff[i] = a.ep_off[i];
@@ -794,7 +895,7 @@ __global__ __launch_bounds__(256) void k_arrow_forward(const ArrowArgs a) {
         for (int q = 0; q < 18; ++q) { const int s1 = q < 9 ? sl.x : sl.y; v[q] = s1 >= 0 ? A[(size_t)(nd + 9 * s1 + (q < 9 ? q : q - 9)) * n + e] : 0.0; }
         const double re = rd[e];
 #pragma unroll
-        for (int q = 0; q < 18; ++q) Vs[e * 18 + q] = v[q] * re;
+        for (int q = 0; q < 18; ++q) { Vs[e * 18 + q] = v[q] * re; if (v[q] != 0.0 && (q % 9) >= 3) *vrows_lds = 1; }
     }
     AR_STAMP(2);
     // (3) raw speed-bias rows of [M_ep | b_e] and raw chain blocks -> LDS
@@ -805,6 +906,7 @@ __global__ __launch_bounds__(256) void k_arrow_forward(const ArrowArgs a) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) Ys[k * AR_YS + c] = v[c];
     }
+    AR_STAMP(30);
     for (int q = tid; q < W * 18; q += 256) {            // one lane per row of a block: 9 contiguous doubles
         const int i = q / 18, r = q - 18 * i;
         const bool live = r < 9 || i + 1 < W;
@@ -815,138 +917,101 @@ __global__ __launch_bounds__(256) void k_arrow_forward(const ArrowArgs a) {
 #pragma unroll
         for (int j = 0; j < 9; ++j) Blk[i * 180 + r * 10 + j] = v[j];
     }
+    AR_STAMP(31);
     __syncthreads();
-    //     ... minus the epoch contribution (LDS only)
-    for (int k = tid; k < 9 * W; k += 256) {
-        const int sl = k / 9, q = k - 9 * sl;
+    AR_STAMP(32);
+    //     ... minus the epoch contribution (LDS only).  One work item per matrix entry, accumulated in a register over
+    //     the epochs of its keyframe in list order (fixed order -> reproducible).  A clock-drift epoch couples to the
+    //     velocity rows only (first 3 of the 9 speed-bias components): when phase (2) saw no other non-zero entry the
+    //     items are restricted to those rows.
+    const int qn = *vrows_lds ? 9 : 3;
+    for (int item = tid; item < W * qn * 16; item += 256) {
+        const int c = item & 15, kq = item >> 4, sl = kq / qn, q = kq - sl * qn, k = 9 * sl + q;
+        double v = Ys[k * AR_YS + c];
         for (int t = eoff[sl]; t < eoff[sl + 1]; ++t) {
             const int e = elist[t];
-            const double ve = Vs[e * 18 + (eps[e].x == sl ? 0 : 9) + q];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) Ys[k * AR_YS + c] -= ve * Yd[e * AR_YS + c];
+            v -= Vs[e * 18 + (eps[e].x == sl ? 0 : 9) + q] * Yd[e * AR_YS + c];
         }
+        Ys[k * AR_YS + c] = v;
     }
-    for (int q = tid; q < W * 18; q += 256) {
-        const int i = q / 18, r = q - 18 * i;
-        const bool rowD = r < 9;
-        if (!rowD && i + 1 >= W) continue;
+    AR_STAMP(33);
+    for (int item = tid; item < W * 2 * qn * qn; item += 256) {
+        const int i = item / (2 * qn * qn), w = item - i * 2 * qn * qn, half = w / (qn * qn), u = w - half * qn * qn, rr = u / qn, j = u - rr * qn;
+        const bool rowD = half == 0;
+        if ((rowD && j > rr) || (!rowD && i + 1 >= W)) continue;
+        double v = Blk[i * 180 + (rowD ? rr : 9 + rr) * 10 + j];
         for (int t = eoff[i]; t < eoff[i + 1]; ++t) {
             const int e = elist[t];
             const int2 sl = eps[e];
             const int side = sl.x == i ? 0 : 9;
-            double mine;
-            if (rowD) mine = Vs[e * 18 + side + r];
-            else { if ((sl.x == i ? sl.y : sl.x) != i + 1) continue; mine = Vs[e * 18 + (9 - side) + (r - 9)]; }
-#pragma unroll
-            for (int j = 0; j < 9; ++j) if (!rowD || j <= r) Blk[i * 180 + r * 10 + j] -= mine * Vs[e * 18 + side + j];
+            if (rowD) v -= Vs[e * 18 + side + rr] * Vs[e * 18 + side + j];
+            else if ((sl.x == i ? sl.y : sl.x) == i + 1) v -= Vs[e * 18 + (9 - side) + rr] * Vs[e * 18 + side + j];
         }
+        Blk[i * 180 + (rowD ? rr : 9 + rr) * 10 + j] = v;
     }
     __syncthreads();
     AR_STAMP(3);
-    // (4) the chain.  Wavefront 0: lanes 0-8 hold the rows of D_i, lanes 9-17 the rows of B_i; nine register steps
-    //     (v_readlane broadcasts) factor the 18 x 9 panel; the rank-9 update D_{i+1} -= L_{i+1,i} L_{i+1,i}^T is then
-    //     taken from the panel just stored to LDS (broadcast reads).  Wavefront 1 follows one block behind with the
-    //     forward substitution of this workgroup's 16 columns.
+    // (4) the chain, eliminated FROM BOTH ENDS (twisted factorisation): blocks 0 .. m-1 top-down by wavefront 0, blocks
+    //     W-1 .. m+1 bottom-up by wavefront 2, the meeting block m = W/2 last -- half the sequential depth.  Wavefronts 1
+    //     and 3 follow their chain one block behind with the forward substitution of this workgroup's 16 columns.
+    const int mid = W / 2, nT = mid, nB = W - 1 - mid, T = nT > nB ? nT : nB;
+    double* LbT = Lb;                               // 3 rotating panels of the top chain
+    double* LbB = Cs + 92;                          // 3 rotating panels of the bottom chain
+    double* Lm = LbB + 3 * AR_LB;                   // the meeting block
+    double* CsB = Lm + AR_LB;                       // correction of D_mid from the bottom chain (Cs: from the top chain)
     double av[9];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) av[j] = (wv == 0 && lane < 9) ? Blk[lane * 10 + j] : 0.0;
+    for (int j = 0; j < 9; ++j) av[j] = 0.0;
+    if (lane < 9) {
+        if (wv == 0 && nT > 0) { for (int j = 0; j < 9; ++j) av[j] = Blk[lane * 10 + j]; }
+        if (wv == 2 && nB > 0) { for (int j = 0; j < 9; ++j) av[j] = Blk[(W - 1) * 180 + lane * 10 + j]; }
+    }
     bool bad = false;
     int pr = 0, pj = 0;                             // lane -> pair (pr, pj <= pr) of the rank-9 update, lanes 0..44
     { int p = lane < 45 ? lane : 0; while ((pr + 1) * (pr + 2) / 2 <= p) ++pr; pj = p - pr * (pr + 1) / 2; }
-    long long busy = 0;
-    for (int it = 0; it <= W; ++it) {
-        const long long tb0 = wall_clock64();
-        if (wv == 0 && it < W) {
-            const int i = it, r = lane;
-            const bool more = i + 1 < W;
-            double nx[9];                           // next block's rows, fetched early: D_{i+1} (lanes 0-8)
+    for (int it = 0; it <= T + 1; ++it) {
+        if (wv == 0) {
+            if (it < nT) arrow_chain_step<false>(it, it + 1, true, av, Blk, LbT + (it % 3) * AR_LB, blockIdx.x == 0 ? a.Lblk + (size_t)it * AR_LB : nullptr,
+                                                 Cs, lane, pr, pj, bad);
+            else if (it == T) {                     // both chains are done: D_mid minus both corrections, factored alone
+                if (lane < 9) {
 #pragma unroll
-            for (int j = 0; j < 9; ++j) nx[j] = (more && r < 9) ? Blk[(i + 1) * 180 + r * 10 + j] : 0.0;
-            if (r >= 9 && r < 18) {
-#pragma unroll
-                for (int j = 0; j < 9; ++j) av[j] = more ? Blk[i * 180 + r * 10 + j] : 0.0;
-            }
-            double rpv = 0.0;
-#pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                double djj = readlane_d(av[j], j);
-                if (!(djj > 0.0) || !isfinite(djj)) { bad = true; djj = 1.0; }
-                const double rdj = rsqrt(djj);
-                const double lij = (lane == j) ? djj * rdj : av[j] * rdj;
-                if (lane == j) rpv = rdj;
-                av[j] = lij;
-#pragma unroll
-                for (int c = j + 1; c < 9; ++c) av[c] -= lij * readlane_d(lij, c);      // lanes < c only touch entries above the
-            }                                                                            // diagonal, which nobody reads: no masking
-            double* Lc = Lb + (i % 3) * AR_LB;
-            double* Lg = a.Lblk + (size_t)i * AR_LB;
-            if (r < 18) {
-#pragma unroll
-                for (int j = 0; j < 9; ++j) {
-                    const double v = (r < 9 && j > r) ? 0.0 : av[j];
-                    Lc[r * 10 + j] = v;
-                    if (blockIdx.x == 0) Lg[r * 10 + j] = v;
-                }
-                if (r < 9) { Lc[180 + r] = rpv; if (blockIdx.x == 0) Lg[180 + r] = rpv; }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (more) {                             // D_{i+1}[r][j] -= X[r] . X[j],  X = L_{i+1,i} = rows 9..17 of Lc:
-                const double* X = Lc + 90;          // 45 lanes take one (r, j <= r) pair each, results pass through LDS
-                if (lane < 45) {
-                    double xa[9], xb[9];
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) { xa[k] = X[pr * 10 + k]; xb[k] = X[pj * 10 + k]; }
-                    double sacc = 0.0;
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) sacc += xa[k] * xb[k];
-                    Cs[pr * 10 + pj] = sacc;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (r < 9) {
-#pragma unroll
-                    for (int j = 0; j < 9; ++j) nx[j] -= Cs[r * 10 + j];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 9; ++j) av[j] = (r < 9 && j <= r) ? nx[j] : 0.0;
-        } else if (wv == 1 && it >= 1) {
-            // lane = (column c, k-group g): the 9x9 product is split over 4 groups of k and summed with two butterflies
-            const int i = it - 1, c = lane & 15, g = lane >> 4;
-            double tv[9];
-#pragma unroll
-            for (int r = 0; r < 9; ++r) tv[r] = g == 0 ? Ys[(9 * i + r) * AR_YS + c] : 0.0;
-            if (i > 0) {
-                const double* Lp = Lb + ((i - 1) % 3) * AR_LB + 90;
-#pragma unroll
-                for (int kk = 0; kk < 3; ++kk) {
-                    const int k = g + 4 * kk;
-                    if (k < 9) {
-                        const double yk = Ys[(9 * (i - 1) + k) * AR_YS + c];
-#pragma unroll
-                        for (int r = 0; r < 9; ++r) tv[r] -= Lp[r * 10 + k] * yk;
+                    for (int j = 0; j < 9; ++j) {
+                        double v = j <= lane ? Blk[mid * 180 + lane * 10 + j] : 0.0;
+                        if (j <= lane && nT > 0) v -= Cs[lane * 10 + j];
+                        if (j <= lane && nB > 0) v -= CsB[lane * 10 + j];
+                        av[j] = v;
                     }
                 }
-#pragma unroll
-                for (int r = 0; r < 9; ++r) { tv[r] += __shfl_xor(tv[r], 16, 64); tv[r] += __shfl_xor(tv[r], 32, 64); }
+                arrow_chain_step<false>(mid, mid, false, av, Blk, Lm, blockIdx.x == 0 ? a.Lblk + (size_t)mid * AR_LB : nullptr, Cs, lane, pr, pj, bad);
             }
-            const double* Lc = Lb + (i % 3) * AR_LB;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {          // column-oriented forward substitution
-                tv[k] *= Lc[180 + k];
-#pragma unroll
-                for (int r = k + 1; r < 9; ++r) tv[r] -= Lc[r * 10 + k] * tv[k];
+        } else if (wv == 2) {
+            if (it < nB) {
+                const int i = W - 1 - it;
+                arrow_chain_step<true>(i, i - 1, true, av, Blk, LbB + (it % 3) * AR_LB, blockIdx.x == 0 ? a.Lblk + (size_t)i * AR_LB : nullptr, CsB, lane, pr, pj, bad);
             }
-            if (g == 0) {
-#pragma unroll
-                for (int r = 0; r < 9; ++r) Ys[(9 * i + r) * AR_YS + c] = tv[r];
+        } else if (wv == 1) {
+            if (it >= 1 && it <= nT) {
+                const int i = it - 1;
+                arrow_y_update(i, i > 0 ? 1 : 0, i - 1, LbT + ((i + 2) % 3) * AR_LB, 0, nullptr, LbT + (i % 3) * AR_LB, Ys, lane);
+            } else if (it == T + 1) {
+                const double* Pt = nT > 0 ? LbT + ((nT - 1) % 3) * AR_LB : nullptr;
+                const double* Pb = nB > 0 ? LbB + ((nB - 1) % 3) * AR_LB : nullptr;
+                if (nT > 0 && nB > 0) arrow_y_update(mid, 2, mid - 1, Pt, mid + 1, Pb, Lm, Ys, lane);
+                else if (nT > 0) arrow_y_update(mid, 1, mid - 1, Pt, 0, nullptr, Lm, Ys, lane);
+                else if (nB > 0) arrow_y_update(mid, 1, mid + 1, Pb, 0, nullptr, Lm, Ys, lane);
+                else arrow_y_update(mid, 0, 0, nullptr, 0, nullptr, Lm, Ys, lane);
+            }
+        } else {
+            if (it >= 1 && it <= nB) {
+                const int sB = it - 1, i = W - 1 - sB;
+                arrow_y_update(i, sB > 0 ? 1 : 0, i + 1, LbB + ((sB + 2) % 3) * AR_LB, 0, nullptr, LbB + (sB % 3) * AR_LB, Ys, lane);
             }
         }
-        busy += wall_clock64() - tb0;
         __syncthreads();
     }
-    if (blockIdx.x == 0 && lane == 0 && wv < 2) a.dbg[20 + wv] = busy;
+    if (bad && lane == 0) *bad_lds = 1;
     AR_STAMP(4);
-    if (wv == 0 && bad && lane == 0) *bad_lds = 1;
     __syncthreads();
     // (5) publish
     for (int idx = tid; idx < a.K * 16; idx += 256) {
@@ -1035,26 +1100,30 @@ __global__ __launch_bounds__(TR_THREADS) void k_arrow_solve(const ArrowArgs a) {
     }
     __syncthreads();
     AR_STAMP(11);
-    // speed-bias chain, bottom up: L_ii^T z_i = w_i - L_{i+1,i}^T z_{i+1}
-    if (wv == 0) {
-        for (int i = W - 1; i >= 0; --i) {
-            const double* Lc = Lb + i * AR_LB;
-            double v = lane < 9 ? wb[nd + 9 * i + lane] : 0.0;
-            if (i + 1 < W && lane < 9) {
+    // speed-bias chain in reverse elimination order: the meeting block first, then the two halves independently
+    // (wavefront 0: blocks mid-1 .. 0, wavefront 1: blocks mid+1 .. W-1):  L_ii^T z_i = w_i - L_{nbr,i}^T z_nbr
+    const int mid = W / 2;
+    auto chain_back = [&](const int i, const int nbr) {
+        const double* Lc = Lb + i * AR_LB;
+        double v = lane < 9 ? wb[nd + 9 * i + lane] : 0.0;
+        if (nbr >= 0 && lane < 9) {
 #pragma unroll
-                for (int k = 0; k < 9; ++k) v -= Lc[(9 + k) * 10 + lane] * wb[nd + 9 * (i + 1) + k];
-            }
-            const double rp = lane < 9 ? Lc[180 + lane] : 1.0;
-#pragma unroll
-            for (int k = 8; k >= 0; --k) {
-                const double zk = readlane_d(v, k) * readlane_d(rp, k);
-                if (lane == k) v = zk;
-                else if (lane < k) v -= Lc[k * 10 + lane] * zk;
-            }
-            if (lane < 9) wb[nd + 9 * i + lane] = v;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int k = 0; k < 9; ++k) v -= Lc[(9 + k) * 10 + lane] * wb[nd + 9 * nbr + k];
         }
-    }
+        const double rp = lane < 9 ? Lc[180 + lane] : 1.0;
+#pragma unroll
+        for (int k = 8; k >= 0; --k) {
+            const double zk = readlane_d(v, k) * readlane_d(rp, k);
+            if (lane == k) v = zk;
+            else if (lane < k) v -= Lc[k * 10 + lane] * zk;
+        }
+        if (lane < 9) wb[nd + 9 * i + lane] = v;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    if (wv == 0) chain_back(mid, -1);
+    __syncthreads();
+    if (wv == 0) { for (int i = mid - 1; i >= 0; --i) chain_back(i, i + 1); }
+    else if (wv == 1) { for (int i = mid + 1; i < W; ++i) chain_back(i, i - 1); }
     __syncthreads();
     AR_STAMP(12);
     // epochs: z_e = (w_e - sum_s L_se z_s) / L_ee

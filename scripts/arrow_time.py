@@ -25,3 +25,4 @@ v = list(st)
 print("forward stamps (us):", [round((v[k + 1] - v[k]) / 100.0, 2) for k in range(0, 5)])
 print("solve stamps (us):", [round((v[k + 1] - v[k]) / 100.0, 2) for k in range(8, 13)])
 print("busy wave0/wave1 (us):", v[20] / 100.0, v[21] / 100.0)
+print("phase3 detail (us): Ys raw", (v[30]-v[2])/100, "Blk raw", (v[31]-v[30])/100, "sync", (v[32]-v[31])/100, "Ys corr", (v[33]-v[32])/100, "Blk corr+sync", (v[3]-v[33])/100)
