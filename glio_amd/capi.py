@@ -114,6 +114,12 @@ class Context:
         _check(load().glio_associate_resident(self._h, slot, T.dptr(q), T.dptr(t), C.byref(cnt)))
         return cnt.value
 
+    def associate_window(self, quats, trans):
+        quats = np.ascontiguousarray(quats, float); trans = np.ascontiguousarray(trans, float)
+        cnt = np.zeros(self.W, np.int32)
+        _check(load().glio_associate_window(self._h, T.dptr(quats), T.dptr(trans), T.iptr(cnt)))
+        return cnt
+
     def set_correspondences(self, slot, pts, planes, scores):
         pts = np.ascontiguousarray(pts, np.float32); planes = np.ascontiguousarray(planes, np.float32)
         scores = np.ascontiguousarray(scores, np.float64)

@@ -549,6 +549,20 @@ int glio_assoc_run(glio_ctx* c, int slot, const double q[4], const double t[3], 
     return GLIO_OK;
 }
 
+// all W slots back to back on the stream, ONE host synchronisation: the per-slot sync of glio_assoc_run (count
+// read-back) costs as much as half a K2 launch
+int glio_assoc_run_window(glio_ctx* c, const double* quats, const double* trans, int32_t* out_counts) {
+    AssocWork* w = c->assoc;
+    if (!w) return GLIO_E_STATE;
+    if (c->map_n <= 0) { glio_set_error("no map set"); return GLIO_E_STATE; }
+    for (int s = 0; s < c->W; ++s) enqueue_assoc(c, s, quats + 4 * s, trans + 3 * s, c->h_scan_count[s], 0);
+    GLIO_HIP_CHECK(hipGetLastError());
+    GLIO_HIP_CHECK(hipMemcpyAsync(c->h_count, c->d_count, (size_t)c->W * 4, hipMemcpyDeviceToHost, c->stream));
+    GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (out_counts) for (int s = 0; s < c->W; ++s) out_counts[s] = c->h_count[s];
+    return GLIO_OK;
+}
+
 // test hook: neighbour indices of the last association (original map indices, -1 where the gate failed)
 extern "C" int glio_debug_last_nn(glio_ctx* c, int32_t* out, int n) {
     if (!c || !c->assoc) return GLIO_E_STATE;

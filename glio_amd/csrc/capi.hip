@@ -242,6 +242,13 @@ int glio_associate_resident(glio_ctx* c, int slot, const double q[4], const doub
     if (rc == GLIO_OK) c->have_factors = 1;
     return rc;
 }
+int glio_associate_window(glio_ctx* c, const double* quats, const double* trans, int32_t* out_counts) {
+    if (!c || !quats || !trans) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    const int rc = glio_assoc_run_window(c, quats, trans, out_counts);
+    if (rc == GLIO_OK) c->have_factors = 1;
+    return rc;
+}
 int glio_associate(glio_ctx* c, int slot, const float* scan, int n, const double q[4], const double t[3], int* out_count) {
     const int rc = glio_set_scan(c, slot, scan, n);
     if (rc != GLIO_OK) return rc;

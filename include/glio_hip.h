@@ -74,6 +74,9 @@ int glio_associate(glio_ctx* ctx, int slot, const float* scan_xyzi, int n, const
 /* Same, for a scan already resident from a previous glio_associate/glio_set_scan (re-association). */
 int glio_set_scan(glio_ctx* ctx, int slot, const float* scan_xyzi, int n);
 int glio_associate_resident(glio_ctx* ctx, int slot, const double q[4], const double t[3], int* out_count);
+/* The whole loop of Estimator.cpp:2198-2248 in one call: every slot's resident scan against the map with its own
+ * LiDAR pose (quats [W][4], trans [W][3] = Q2, T2 per slot), one host synchronisation; out_counts [W]. */
+int glio_associate_window(glio_ctx* ctx, const double* quats, const double* trans, int32_t* out_counts);
 /* Parity hook / featureSelection replacement: provide or read back a slot's correspondence arrays. */
 int glio_set_correspondences(glio_ctx* ctx, int slot, const float* pts_xyzi, const float* planes,
                              const double* scores, int n);

@@ -112,3 +112,20 @@ def test_solve_from_gpu_association_matches_oracle(hip, po):
     assert summ_h.iterations == summ_o.iterations
     assert np.linalg.norm(sh.trans - so.trans, axis=1).max() < 1e-9
     ctx.close()
+
+
+def test_window_association_equals_per_slot(hip, small_window):
+    """glio_associate_window (one call, one sync) leaves exactly what W glio_associate_resident calls leave."""
+    win = small_window
+    ctx = hip.Context(win.opts)
+    ctx.set_map(win.map_pts)
+    poses = [hip.lidar_pose(win.opts, win.init.quat[s], win.init.trans[s]) for s in range(win.W)]
+    per = []
+    for s in range(win.W):
+        n = ctx.associate(s, win.scans[s], *poses[s])
+        per.append((n,) + tuple(a.copy() for a in ctx.get_correspondences(s)))
+    cnt = ctx.associate_window(np.array([p[0] for p in poses]), np.array([p[1] for p in poses]))
+    for s in range(win.W):
+        got = ctx.get_correspondences(s)
+        assert cnt[s] == per[s][0] and all(np.array_equal(a, b) for a, b in zip(got, per[s][1:]))
+    ctx.close()
