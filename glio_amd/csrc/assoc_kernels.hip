@@ -55,6 +55,7 @@ struct AssocWork {
     // per-query dense results (capacity = cap of a slot)
     float4* d_q_pt; float4* d_q_plane; double* d_q_score; int* d_q_flag; int* d_q_pos;
     int* d_nn;                    // optional [cap][5] neighbour indices (tests)
+    int* d_nn5; float* d_d4;      // [cap][5] positions of the 5-NN in the sorted map, [cap] fifth distance (k_knn5 -> k_plane_fit)
     int* d_bcount; int* d_boff;   // per-workgroup kept counts and their exclusive scan
     int* d_count_tmp;
     int* h_count;                 // pinned
@@ -238,17 +239,20 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
     return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
 }
 
-// BATCH = true: findGlobalCorrespondingSurfFeaturesAdd_Batch (Estimator.cpp:3808-3892).  The "map" is ANOTHER keyframe's
-// cloud in the global frame (sorted by cell, original index in .w), `loc` the same cloud in that keyframe's own frame:
-// a second plane is fitted to the local coordinates of the same five neighbours and the record is
-// [unit local normal | local centroid] (6 doubles, o_nc) with score 2.5 w instead of the weighted global plane.
-template <bool BATCH>
-__global__ __launch_bounds__(256) void k_associate(const AssocArgs a, const float4* __restrict__ scan,
-                                                   const float4* __restrict__ map, const unsigned long long* __restrict__ keys,
-                                                   const int* __restrict__ cstart, const int* __restrict__ ccount,
-                                                   float4* __restrict__ o_pt, float4* __restrict__ o_plane, double* __restrict__ o_score,
-                                                   int* __restrict__ o_flag, int* __restrict__ o_lpos, int* __restrict__ o_bcount,
-                                                   int* __restrict__ o_nn, const float4* __restrict__ loc, double* __restrict__ o_nc) {
+// K2 runs as two kernels.
+// k_knn5: exact 5 nearest neighbours.  AQ_LANES lanes per query: the lanes of a group probe the 27 cells of the
+//   neighbourhood in rounds, stride through the candidate points of each cell together, keep private top-5 lists (ranked
+//   by float distance, then original map index) and merge them with shuffles.  Output per query: the positions of the
+//   five neighbours in the cell-sorted map and the fifth distance.
+// k_plane_fit<BATCH>: ONE lane per query (the 5x3 QR in double, the gates and the record need no cooperation, and inside
+//   k_knn5 they would run with 1 lane in AQ_LANES active).  BATCH = true: findGlobalCorrespondingSurfFeaturesAdd_Batch
+//   (Estimator.cpp:3808-3892): the "map" is ANOTHER keyframe's cloud in the global frame, `loc` the same cloud in that
+//   keyframe's own frame: a second plane is fitted to the local coordinates of the same five neighbours and the record is
+//   [unit local normal | local centroid] (6 doubles, o_nc) with score 2.5 w instead of the weighted global plane.
+#define AQ_ROUNDS ((27 + AQ_LANES - 1) / AQ_LANES)
+__global__ __launch_bounds__(256) void k_knn5(const AssocArgs a, const float4* __restrict__ scan, const float4* __restrict__ map,
+                                              const unsigned long long* __restrict__ keys, const int* __restrict__ cstart,
+                                              const int* __restrict__ ccount, int* __restrict__ o_nn5, float* __restrict__ o_d4) {
     const int lane = threadIdx.x & 63, j = threadIdx.x & (AQ_LANES - 1), g = threadIdx.x / AQ_LANES;
     const int gbase = lane & ~(AQ_LANES - 1);                 // first lane of this group inside the wavefront
     const int i = blockIdx.x * AQ_PER_BLOCK + g;
@@ -260,11 +264,12 @@ __global__ __launch_bounds__(256) void k_associate(const AssocArgs a, const floa
     a_qrot(a.q, pin, po);
     const float px = (float)(po[0] + a.t[0]), py = (float)(po[1] + a.t[1]), pz = (float)(po[2] + a.t[2]);
     const int cx = cell_of(px, a.inv_cell), cy = cell_of(py, a.inv_cell), cz = cell_of(pz, a.inv_cell);
-    // ---- probe: lane j looks up cells j and j+16 of the 27-neighbourhood
-    int cs[2] = {0, 0}, cc[2] = {0, 0};
+    // ---- probe: lane j looks up cells j, j + AQ_LANES, ... of the 27-neighbourhood
+    int cs[AQ_ROUNDS], cc[AQ_ROUNDS];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int c = j + 16 * h;
+    for (int h = 0; h < AQ_ROUNDS; ++h) {
+        cs[h] = 0; cc[h] = 0;
+        const int c = j + AQ_LANES * h;
         if (c < 27 && qlive) {
             const int dx = c % 3 - 1, dy = (c / 3) % 3 - 1, dz = c / 9 - 1;
             const unsigned long long key = pack_key(cx + dx, cy + dy, cz + dz);
@@ -282,9 +287,12 @@ __global__ __launch_bounds__(256) void k_associate(const AssocArgs a, const floa
     int bi[5] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
     int bp[5] = {-1, -1, -1, -1, -1};          // position in the sorted map
     for (int c = 0; c < 27; ++c) {
-        const int src = gbase + (c & 15);
-        const int beg = __shfl(c < 16 ? cs[0] : cs[1], src, 64);
-        const int cnt = __shfl(c < 16 ? cc[0] : cc[1], src, 64);
+        const int src = gbase + (c % AQ_LANES), h = c / AQ_LANES;
+        int csel = cs[0], nsel = cc[0];
+#pragma unroll
+        for (int q = 1; q < AQ_ROUNDS; ++q) if (h == q) { csel = cs[q]; nsel = cc[q]; }
+        const int beg = __shfl(csel, src, 64);
+        const int cnt = __shfl(nsel, src, 64);
         for (int m = beg + j; m < beg + cnt; m += AQ_LANES) {
             const float4 mp = map[m];
             // plain operators, NOT the __f*_rn intrinsics: those are header functions compiled with
@@ -308,7 +316,7 @@ __global__ __launch_bounds__(256) void k_associate(const AssocArgs a, const floa
             }
         }
     }
-    // ---- merge the 16 private lists: five rounds of group-wide argmin on the key (distance bits, index)
+    // ---- merge the private lists of the group: five rounds of group-wide argmin on the key (distance bits, index)
     float md[5]; int mi[5], mp5[5];
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
@@ -330,6 +338,53 @@ __global__ __launch_bounds__(256) void k_associate(const AssocArgs a, const floa
             bd[4] = FLT_MAX; bi[4] = 0x7fffffff; bp[4] = -1;
         }
     }
+    if (j == 0 && qlive) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) o_nn5[5 * (size_t)i + k] = mp5[k];
+        o_d4[i] = md[4];
+    }
+    (void)mi;
+}
+
+#define PF_BLOCK 256
+template <bool BATCH>
+__global__ __launch_bounds__(PF_BLOCK) void k_plane_fit(const AssocArgs a, const float4* __restrict__ scan, const float4* __restrict__ map,
+                                                        const int* __restrict__ nn5, const float* __restrict__ d4,
+                                                        float4* __restrict__ o_pt, float4* __restrict__ o_plane, double* __restrict__ o_score,
+                                                        int* __restrict__ o_flag, int* __restrict__ o_lpos, int* __restrict__ o_bcount,
+                                                        int* __restrict__ o_nn, const float4* __restrict__ loc, double* __restrict__ o_nc) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * PF_BLOCK + threadIdx.x;
+    const bool qlive = i < a.n;
+    const float4 pl = scan[qlive ? i : 0];
+    const double pin[3] = {(double)pl.x, (double)pl.y, (double)pl.z};
+    double po[3];
+    a_qrot(a.q, pin, po);
+    const float px = (float)(po[0] + a.t[0]), py = (float)(po[1] + a.t[1]), pz = (float)(po[2] + a.t[2]);
+    int mp5[5], mi[5];
+    float md4 = FLT_MAX;
+    float4 nbp[5];
+    if (qlive) {
+        md4 = d4[i];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) mp5[k] = nn5[5 * (size_t)i + k];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { nbp[k] = map[mp5[k] >= 0 ? mp5[k] : 0]; mi[k] = __float_as_int(nbp[k].w); }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { mp5[k] = -1; mi[k] = -1; nbp[k] = make_float4(0, 0, 0, 0); }
+    }
+    float md[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {               // same float expression as in k_knn5: identical bits
+        const float ex = px - nbp[k].x, ey = py - nbp[k].y, ez = pz - nbp[k].z;
+        float d = ex * ex;
+        d = d + ey * ey;
+        d = d + ez * ez;
+        md[k] = mp5[k] >= 0 ? d : FLT_MAX;
+    }
+    md[4] = md4;
+    const int j = 0;
     // ---- plane fit + gates by lane 0 of the group
     int valid = 0;
     if (j == 0 && qlive) {
@@ -348,7 +403,7 @@ __global__ __launch_bounds__(256) void k_associate(const AssocArgs a, const floa
             double A[5][3], A0[5][3], b[5], nrm[3];
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
-                const float4 mp = map[mp5[k]];
+                const float4 mp = nbp[k];
                 A[k][0] = A0[k][0] = (double)mp.x; A[k][1] = A0[k][1] = (double)mp.y; A[k][2] = A0[k][2] = (double)mp.z;
                 b[k] = -1.0;
             }
@@ -400,7 +455,7 @@ __global__ __launch_bounds__(256) void k_associate(const AssocArgs a, const floa
         if (valid) { o_pt[i] = pl; if (!BATCH) o_plane[i] = oplane; o_score[i] = oscore; }
     }
     // ---- order-preserving positions inside the workgroup + workgroup count
-    __shared__ int wcount[4];
+    __shared__ int wcount[PF_BLOCK / 64];
     const unsigned long long bal = __ballot(valid);
     const int wv = threadIdx.x >> 6;
     if (lane == 0) wcount[wv] = __popcll(bal);
@@ -410,7 +465,7 @@ __global__ __launch_bounds__(256) void k_associate(const AssocArgs a, const floa
         for (int w2 = 0; w2 < wv; ++w2) before += wcount[w2];
         o_lpos[i] = before;
     }
-    if (threadIdx.x == 0) o_bcount[blockIdx.x] = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    if (threadIdx.x == 0) { int tot = 0; for (int w2 = 0; w2 < PF_BLOCK / 64; ++w2) tot += wcount[w2]; o_bcount[blockIdx.x] = tot; }
 }
 
 // order-preserving compaction: single-workgroup exclusive scan of the flags, then scatter
@@ -439,7 +494,7 @@ __global__ void k_compact(const int* __restrict__ flag, const int* __restrict__ 
                           float4* __restrict__ o_pt, float4* __restrict__ o_plane, double* __restrict__ o_score) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !flag[i]) return;
-    const int p = boff[i / AQ_PER_BLOCK] + lpos[i];
+    const int p = boff[i / PF_BLOCK] + lpos[i];
     o_pt[p] = q_pt[i]; o_plane[p] = q_plane[i]; o_score[p] = q_score[i];
 }
 
@@ -462,6 +517,7 @@ int glio_assoc_create(glio_ctx* c) {
     AALLOC(w->d_total, 4); AALLOC(w->d_count_tmp, 4);
     AALLOC(w->d_q_pt, (size_t)cap * 16); AALLOC(w->d_q_plane, (size_t)cap * 16); AALLOC(w->d_q_score, (size_t)cap * 8);
     AALLOC(w->d_q_flag, (size_t)cap * 4); AALLOC(w->d_q_pos, (size_t)cap * 4); AALLOC(w->d_nn, (size_t)cap * 5 * 4);
+    AALLOC(w->d_nn5, (size_t)cap * 5 * 4); AALLOC(w->d_d4, (size_t)cap * 4);
     AALLOC(w->d_bcount, (size_t)(cap / AQ_PER_BLOCK + 2) * 4); AALLOC(w->d_boff, (size_t)(cap / AQ_PER_BLOCK + 2) * 4);
     if (hipHostMalloc((void**)&w->h_count, 16) != hipSuccess) return GLIO_E_HIP;
     c->assoc = w;
@@ -473,7 +529,7 @@ void glio_assoc_destroy(glio_ctx* c) {
     AssocWork* w = c->assoc;
     if (!w) return;
     void* ptrs[] = {w->d_keys, w->d_cell_count, w->d_cell_start, w->d_cell_fill, w->d_pt_slot, w->d_map_raw, c->d_map_sorted, w->d_total,
-                    w->d_count_tmp, w->d_q_pt, w->d_q_plane, w->d_q_score, w->d_q_flag, w->d_q_pos, w->d_nn, w->d_bcount, w->d_boff};
+                    w->d_count_tmp, w->d_q_pt, w->d_q_plane, w->d_q_score, w->d_q_flag, w->d_q_pos, w->d_nn, w->d_nn5, w->d_d4, w->d_bcount, w->d_boff};
     for (void* p : ptrs) if (p) hipFree(p);
     hipHostFree(w->h_count);
     delete w;
@@ -522,11 +578,13 @@ static void enqueue_assoc(glio_ctx* c, int slot, const double q[4], const double
     a.surf_dist_thres = c->opts.surf_dist_thres; a.lidar_const = c->opts.lidar_const;
     a.n = n; a.table_cap = w->table_cap; a.unit_scores = c->opts.unit_scores;
     const size_t off = (size_t)slot * c->cap;
-    const int nblk = (n + AQ_PER_BLOCK - 1) / AQ_PER_BLOCK;
+    const int nblk = (n + PF_BLOCK - 1) / PF_BLOCK;
     if (n > 0) {
-        hipLaunchKernelGGL(k_associate<false>, dim3(nblk), dim3(256), 0, c->stream, a, c->d_scan + off, c->d_map_sorted, w->d_keys,
-                           w->d_cell_start, w->d_cell_count, w->d_q_pt, w->d_q_plane, w->d_q_score, w->d_q_flag, w->d_q_pos, w->d_bcount,
-                           want_nn ? w->d_nn : nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL(k_knn5, dim3((n + AQ_PER_BLOCK - 1) / AQ_PER_BLOCK), dim3(256), 0, c->stream, a, c->d_scan + off, c->d_map_sorted, w->d_keys,
+                           w->d_cell_start, w->d_cell_count, w->d_nn5, w->d_d4);
+        hipLaunchKernelGGL(k_plane_fit<false>, dim3(nblk), dim3(PF_BLOCK), 0, c->stream, a, c->d_scan + off, c->d_map_sorted, w->d_nn5, w->d_d4,
+                           w->d_q_pt, w->d_q_plane, w->d_q_score, w->d_q_flag, w->d_q_pos, w->d_bcount, want_nn ? w->d_nn : nullptr,
+                           (const float4*)nullptr, (double*)nullptr);
     }
     hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(1024), 0, c->stream, w->d_bcount, nblk, w->d_boff, c->d_count + slot);
     if (n > 0) {
@@ -620,6 +678,7 @@ struct glio_bassoc {
     int* d_total;                   // scratch of the hash build
     // dense per-query results of the pair in flight
     float4* d_q_cp; double* d_q_nc; double* d_q_score; int* d_q_flag; int* d_q_pos; int* d_bcount; int* d_boff;
+    int* d_nn5; float* d_d4;
     // compacted output, pair major
     float4* d_cp; double* d_nc; double* d_score;
     long long* d_run;               // [1] running total
@@ -674,7 +733,7 @@ __global__ void k_compact_pair(const int* __restrict__ flag, const int* __restri
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !flag[i]) return;
     if (pair_off[1] == pair_off[0]) return;                      // overflow: nothing is written for this pair
-    const long long p = pair_off[0] + boff[i / AQ_PER_BLOCK] + lpos[i];
+    const long long p = pair_off[0] + boff[i / PF_BLOCK] + lpos[i];
     o_cp[p] = q_cp[i]; o_score[p] = q_score[i];
 #pragma unroll
     for (int k = 0; k < 6; ++k) o_nc[6 * p + k] = q_nc[6 * (size_t)i + k];
@@ -709,6 +768,7 @@ int glio_bassoc_create(int device, int K, int max_points_per_frame, int64_t max_
     BA_CHECK(hipMalloc((void**)&b->d_total, 4));
     BA_CHECK(hipMalloc((void**)&b->d_q_cp, cap * 16)); BA_CHECK(hipMalloc((void**)&b->d_q_nc, cap * 48)); BA_CHECK(hipMalloc((void**)&b->d_q_score, cap * 8));
     BA_CHECK(hipMalloc((void**)&b->d_q_flag, cap * 4)); BA_CHECK(hipMalloc((void**)&b->d_q_pos, cap * 4));
+    BA_CHECK(hipMalloc((void**)&b->d_nn5, cap * 20)); BA_CHECK(hipMalloc((void**)&b->d_d4, cap * 4));
     BA_CHECK(hipMalloc((void**)&b->d_bcount, (cap / AQ_PER_BLOCK + 2) * 4)); BA_CHECK(hipMalloc((void**)&b->d_boff, (cap / AQ_PER_BLOCK + 2) * 4));
     BA_CHECK(hipMalloc((void**)&b->d_cp, (size_t)max_constraints * 16)); BA_CHECK(hipMalloc((void**)&b->d_nc, (size_t)max_constraints * 48));
     BA_CHECK(hipMalloc((void**)&b->d_score, (size_t)max_constraints * 8));
@@ -726,7 +786,7 @@ void glio_bassoc_destroy(glio_bassoc* b) {
         void* p[] = {f.d_keys, f.d_cell_count, f.d_cell_start, f.d_cell_fill, f.d_pt_slot, f.d_sorted};
         for (void* q : p) if (q) hipFree(q);
     }
-    void* p[] = {b->d_local, b->d_global, b->d_total, b->d_q_cp, b->d_q_nc, b->d_q_score, b->d_q_flag, b->d_q_pos, b->d_bcount, b->d_boff,
+    void* p[] = {b->d_nn5, b->d_d4, b->d_local, b->d_global, b->d_total, b->d_q_cp, b->d_q_nc, b->d_q_score, b->d_q_flag, b->d_q_pos, b->d_bcount, b->d_boff,
                  b->d_cp, b->d_nc, b->d_score, b->d_run, b->d_poses, b->d_pair_off};
     for (void* q : p) if (q) hipFree(q);
     if (b->h_pair_off) hipHostFree(b->h_pair_off);
@@ -784,11 +844,14 @@ int glio_bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const int3
         for (int k = 0; k < 4; ++k) a.q[k] = poses[7 * ci + 3 + k];
         a.inv_cell = b->inv_cell; a.kd_max_radius = 1.5; a.weight_gate = 0.3; a.surf_dist_thres = 0.18; a.lidar_const = 2.5;   // :3839,3874,3863,3885
         a.n = n; a.table_cap = f.table_cap; a.unit_scores = 0;
-        const int nblk = (n + AQ_PER_BLOCK - 1) / AQ_PER_BLOCK;
-        if (n > 0)
-            hipLaunchKernelGGL(k_associate<true>, dim3(nblk), dim3(256), 0, b->stream, a, b->d_local + (size_t)ci * b->cap, f.d_sorted, f.d_keys,
-                               f.d_cell_start, f.d_cell_count, b->d_q_cp, (float4*)nullptr, b->d_q_score, b->d_q_flag, b->d_q_pos, b->d_bcount,
-                               (int*)nullptr, b->d_local + (size_t)cj * b->cap, b->d_q_nc);
+        const int nblk = (n + PF_BLOCK - 1) / PF_BLOCK;
+        if (n > 0) {
+            hipLaunchKernelGGL(k_knn5, dim3((n + AQ_PER_BLOCK - 1) / AQ_PER_BLOCK), dim3(256), 0, b->stream, a, b->d_local + (size_t)ci * b->cap, f.d_sorted,
+                               f.d_keys, f.d_cell_start, f.d_cell_count, b->d_nn5, b->d_d4);
+            hipLaunchKernelGGL(k_plane_fit<true>, dim3(nblk), dim3(PF_BLOCK), 0, b->stream, a, b->d_local + (size_t)ci * b->cap, f.d_sorted, b->d_nn5, b->d_d4,
+                               b->d_q_cp, (float4*)nullptr, b->d_q_score, b->d_q_flag, b->d_q_pos, b->d_bcount, (int*)nullptr,
+                               b->d_local + (size_t)cj * b->cap, b->d_q_nc);
+        }
         hipLaunchKernelGGL(k_scan_pair, dim3(1), dim3(1024), 0, b->stream, b->d_bcount, nblk, b->d_boff, b->d_run, b->d_pair_off + p, (long long)b->max_con, d_overflow);
         if (n > 0)
             hipLaunchKernelGGL(k_compact_pair, dim3((n + 255) / 256), dim3(256), 0, b->stream, b->d_q_flag, b->d_q_pos, b->d_boff, n, b->d_pair_off + p,
