@@ -574,10 +574,14 @@ __device__ void prior_H_block(const SmallArgs& a, const double* __restrict__ x, 
 
 __device__ void small_factors_body(const SmallArgs& a);
 __global__ __launch_bounds__(SF_THREADS) void k_small_factors(const SmallArgs a) {
+#ifdef GLIO_DEV_STAMPS
     const long long t0 = wall_clock64();
     small_factors_body(a);
     __syncthreads();
-    if (threadIdx.x == 0 && a.dbg && blockIdx.x < 250) a.dbg[blockIdx.x] = wall_clock64() - t0;
+    if (threadIdx.x == 0 && a.dbg && blockIdx.x < 250) a.dbg[blockIdx.x] = wall_clock64() - t0;     // scripts/small_time.py
+#else
+    small_factors_body(a);
+#endif
 }
 __device__ void small_factors_body(const SmallArgs& a) {
     int which = a.fixed_which;

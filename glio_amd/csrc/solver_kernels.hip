@@ -734,7 +734,12 @@ struct ArrowArgs {
     long long* dbg;
     int lds_chol;             // pose block factored in LDS (packed) instead of through global memory
 };
+// development aid: wall-clock stamps of the phases of the arrow kernels (build with GLIO_DEV_STAMPS=1, scripts/arrow_time.py)
+#ifdef GLIO_DEV_STAMPS
 #define AR_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) a.dbg[k] = wall_clock64(); } while (0)
+#else
+#define AR_STAMP(k) do { } while (0)
+#endif
 #define AR_LB 190          /* one chain block in LDS / global: 18 rows x stride 10, then 9 reciprocal pivots (+1 pad) */
 #define AR_YS 17           /* row stride of the 16-column Y slices in LDS */
 
