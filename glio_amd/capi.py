@@ -234,6 +234,45 @@ class Context:
         return r, Js
 
 
+def _ptrs(arrs):
+    return (T.c_double_p * len(arrs))(*[T.dptr(a) if a is not None else None for a in arrs])
+
+
+def _ctx_eval_methods():
+    def eval_dd_psr(self, f, Pi, Pj, yaw, anc):
+        params = [np.ascontiguousarray(Pi, float), np.ascontiguousarray(Pj, float), np.array([yaw], float), np.ascontiguousarray(anc, float)]
+        r = np.zeros(19); Js = [np.zeros((19, 3)), np.zeros((19, 3)), None, None]
+        _check(load().glio_eval_dd_psr(self._h, C.byref(f), _ptrs(params), T.dptr(r), _ptrs(Js)))
+        return r, Js[:2]
+
+    def eval_doppler(self, f, Pi, SBi, Pj, SBj, ddt, yaw, anc):
+        params = [np.ascontiguousarray(a, float) for a in (Pi, SBi, Pj, SBj, ddt)] + [np.array([yaw], float), np.ascontiguousarray(anc, float)]
+        r = np.zeros(1); Js = [np.zeros(3), np.zeros(9), np.zeros(3), np.zeros(9), np.zeros(1), None, None]
+        _check(load().glio_eval_doppler(self._h, C.byref(f), _ptrs(params), T.dptr(r), _ptrs(Js)))
+        return r[0], Js[:5]
+
+    def eval_marginalization(self, prior, params):
+        ps = synth.prior_struct(prior)
+        n = prior["n"]
+        sizes = [3 if k == 0 else (4 if k == 1 else 9) for k in prior["blk_kind"]]
+        params = [np.ascontiguousarray(p, float) for p in params]
+        r = np.zeros(n); Js = [np.zeros((n, s)) for s in sizes]
+        _check(load().glio_eval_marginalization(self._h, C.byref(ps), _ptrs(params), T.dptr(r), _ptrs(Js)))
+        return r, Js
+
+    def eval_binary_plane(self, cp, pnc, score, t1, q1, t2, q2):
+        cp = np.ascontiguousarray(cp, np.float32); pnc = np.ascontiguousarray(pnc, float)
+        params = [np.ascontiguousarray(a, float) for a in (t1, q1, t2, q2)]
+        r = np.zeros(1); Js = [np.zeros(3), np.zeros(4), np.zeros(3), np.zeros(4)]
+        _check(load().glio_eval_binary_plane(self._h, T.fptr(cp), T.dptr(pnc), C.c_double(score), _ptrs(params), T.dptr(r), _ptrs(Js)))
+        return r[0], Js
+    for fn in (eval_dd_psr, eval_doppler, eval_marginalization, eval_binary_plane):
+        setattr(Context, fn.__name__, fn)
+
+
+_ctx_eval_methods()
+
+
 def lidar_pose(opts, q, t):
     """Q2 = Q * q_lb^-1, T2 = T - Q2 * t_lb: the LiDAR pose handed to findCorrespondingSurfFeatures
     (reference GLIO/src/Estimator.cpp:2216-2217)."""

@@ -606,6 +606,20 @@ int glio_marginalize(glio_ctx* c, const glio_state* s, double* lin_jac, double* 
     return GLIO_OK;
 }
 
+}  // extern "C"
+// R_ecef_local = R_ecef_enu(anchor) * Rz(yaw)  (dd_psr_factor.hpp:33-45) -- shared with eval_kernels.hip
+void glio_host_ecef_local(const double anc[3], double yaw, double R[9]) {
+    double Ree[9];
+    ecef2rotation_host(anc, Ree);
+    const double s = sin(yaw), co = cos(yaw);
+    const double Rel[9] = {co, -s, 0, s, co, 0, 0, 0, 1};
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        double a = 0;
+        for (int k = 0; k < 3; ++k) a += Ree[i * 3 + k] * Rel[k * 3 + j];
+        R[i * 3 + j] = a;
+    }
+}
+extern "C" {
 // ---------------------------------------------------------------------------------------------- evaluators
 int glio_eval_lidar_plane(glio_ctx* c, const float cp[4], const float plane[4], double score,
                           double const* const* P, double* res, double** J) {

@@ -68,6 +68,52 @@ private:
 };
 
 // ---- (2) the window ----------------------------------------------------------------------------------
+// dd_psr_factor_20 (dd_psr_factor.hpp:15-171): 19 residuals, blocks {Pi3, Pj3, yaw1, anc3}
+class DdPsrFactorHip {
+public:
+    DdPsrFactorHip(glio_ctx* ctx, const glio_dd_psr& f) : ctx_(ctx), f_(f) {}
+    bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const {
+        return glio_eval_dd_psr(ctx_, &f_, parameters, residuals, jacobians) == GLIO_OK;
+    }
+private:
+    glio_ctx* ctx_; glio_dd_psr f_;
+};
+// tcdopplerFactor (dopp_factor.hpp:19-85): 1 residual, blocks {Pi3, SBi9, Pj3, SBj9, rcv_ddt[EPOCH_SIZE], yaw1, anc3};
+// jacobians[4], when requested, must point to EPOCH_SIZE doubles in Ceres: the shim a maintainer writes zero-fills it and
+// stores the single value glio_eval_doppler returns at [epoch]
+class DopplerFactorHip {
+public:
+    DopplerFactorHip(glio_ctx* ctx, const glio_doppler& f) : ctx_(ctx), f_(f) {}
+    bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const {
+        return glio_eval_doppler(ctx_, &f_, parameters, residuals, jacobians) == GLIO_OK;
+    }
+private:
+    glio_ctx* ctx_; glio_doppler f_;
+};
+// MarginalizationFactor (MarginalizationFactor.cpp:223-287): prior->n residuals, one block per kept parameter block
+class MarginalizationFactorHip {
+public:
+    MarginalizationFactorHip(glio_ctx* ctx, const glio_prior* prior) : ctx_(ctx), prior_(prior) {}
+    bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const {
+        return glio_eval_marginalization(ctx_, prior_, parameters, residuals, jacobians) == GLIO_OK;
+    }
+private:
+    glio_ctx* ctx_; const glio_prior* prior_;
+};
+// BinaryLidarPlaneNormFactor (LidarKeyframeFactor.h:124-164): 1 residual, blocks {t1 3, q1 4, t2 3, q2 4}
+class BinaryLidarPlaneNormFactorHip {
+public:
+    BinaryLidarPlaneNormFactorHip(glio_ctx* ctx, const float cp[4], const double norm_cent[6], double score) : ctx_(ctx), score_(score) {
+        for (int k = 0; k < 4; ++k) cp_[k] = cp[k];
+        for (int k = 0; k < 6; ++k) nc_[k] = norm_cent[k];
+    }
+    bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const {
+        return glio_eval_binary_plane(ctx_, cp_, nc_, score_, parameters, residuals, jacobians) == GLIO_OK;
+    }
+private:
+    glio_ctx* ctx_; float cp_[4]; double nc_[6]; double score_;
+};
+
 class SlidingWindowBackend {
 public:
     explicit SlidingWindowBackend(const glio_opts& opts, int device = 0) : opts_(opts), W_(opts.window) {

@@ -125,6 +125,22 @@ int glio_eval_lidar_plane(glio_ctx* ctx, const float cp[4], const float plane[4]
 int glio_eval_imu(glio_ctx* ctx, const glio_preint* pre, double const* const* parameters,
                   double* residuals, double** jacobians);
 
+/* dd_psr_factor_20::Evaluate (dd_psr_factor.hpp:25-171): parameters = {Pi[3], Pj[3], yaw[1], anc[3]}, 19 residuals
+ * (rows >= n_sat-1 zero), jacobians[0..1] 19x3 row-major; jacobians[2..3] are not written (the reference leaves them) */
+int glio_eval_dd_psr(glio_ctx* ctx, const glio_dd_psr* f, double const* const* parameters, double* residuals,
+                     double** jacobians);
+/* tcdopplerFactor (dopp_factor.hpp:24-75): parameters = {Pi[3], SBi[9], Pj[3], SBj[9], rcv_ddt[>epoch], yaw[1], anc[3]},
+ * 1 residual; jacobians[0..3] 1x3 / 1x9 / 1x3 / 1x9, jacobians[4] receives d r / d rcv_ddt[epoch] as ONE double */
+int glio_eval_doppler(glio_ctx* ctx, const glio_doppler* f, double const* const* parameters, double* residuals,
+                      double** jacobians);
+/* MarginalizationFactor::Evaluate (MarginalizationFactor.cpp:233-287): parameters[b] = kept block b (3, 4 or 9 doubles),
+ * prior->n residuals, jacobians[b] n x size_b row-major */
+int glio_eval_marginalization(glio_ctx* ctx, const glio_prior* prior, double const* const* parameters,
+                              double* residuals, double** jacobians);
+/* BinaryLidarPlaneNormFactor (LidarKeyframeFactor.h:124-164): parameters = {t1[3], q1[4], t2[3], q2[4]}, 1 residual */
+int glio_eval_binary_plane(glio_ctx* ctx, const float cp[4], const double norm_cent[6], double score,
+                           double const* const* parameters, double* residuals, double** jacobians);
+
 /* ---- measurement hooks (bench.py): time `reps` launches of one kernel with HIP events on the
  * context's stream; returns average milliseconds per launch in *ms_out. */
 enum { GLIO_KERNEL_LIDAR_LINEARIZE = 0, GLIO_KERNEL_FULL_LINEARIZE = 1, GLIO_KERNEL_TR_STEP = 2,

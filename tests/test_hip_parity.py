@@ -232,3 +232,54 @@ def test_structured_solver_equals_dense(hip, small_window, small_corr, case):
     assert np.abs(sa.speed_bias - sd.speed_bias).max() <= 1e-9
     if sd.n_ddt:
         assert np.abs(sa.rcv_ddt - sd.rcv_ddt).max() <= 1e-9
+
+
+def test_gnss_prior_batch_evaluators_match_oracle(hip, po, small_window):
+    """Every remaining factor type through the Evaluate() ABI on the GPU vs the oracle's evaluators."""
+    win = small_window
+    ctx = hip.Context(win.opts)
+    st = win.init
+    fr = win.frame
+    yaw, anc = fr.yaw_enu_local, np.array(fr.anc_ecef)
+    # DD pseudorange: ranges ~2e7 m, whitened residuals O(1..10)
+    for f in win.dd[:3]:
+        Pi, Pj = st.trans[f.slot_i], st.trans[f.slot_j]
+        ro, Jo = po.eval_dd_psr(f, Pi, Pj, yaw, anc)
+        rh, Jh = ctx.eval_dd_psr(f, Pi, Pj, yaw, anc)
+        assert np.abs(rh - ro).max() <= 1e-7 * max(1.0, np.abs(ro).max())
+        for a, b in zip(Jh, Jo):
+            assert np.abs(a - b).max() <= 1e-9
+        assert np.all(rh[f.n_sat - 1:] == 0)
+    # Doppler
+    ddt = np.linspace(0.1, 0.5, max(st.n_ddt, 1))
+    for f in win.dop[:4]:
+        args = (st.trans[f.slot_i], st.speed_bias[f.slot_i], st.trans[f.slot_j], st.speed_bias[f.slot_j], ddt, yaw, anc)
+        ro, Jo = po.eval_doppler(f, *args)
+        rh, Jh = ctx.eval_doppler(f, *args)
+        assert abs(rh - ro) <= 1e-8 * max(1.0, abs(ro))
+        for a, b in zip(Jh, Jo):
+            assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max())
+    # marginalization prior
+    pr = win.prior
+    params = []
+    for k in range(len(pr["blk_slot"])):
+        s, kind = pr["blk_slot"][k], pr["blk_kind"][k]
+        params.append([st.trans[s], st.quat[s], st.speed_bias[s]][kind])
+    ro, Jo = po.eval_marg(pr, params)
+    rh, Jh = ctx.eval_marginalization(pr, params)
+    assert rel_err(rh, ro) <= 1e-12
+    for a, b in zip(Jh, Jo):
+        assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max())
+    # binary plane
+    rng = np.random.default_rng(3)
+    for _ in range(3):
+        cp = rng.normal(0, 5, 4).astype(np.float32); pnc = np.r_[synth.rotvec_q(rng.normal(0, 1, 3))[1:], rng.normal(0, 5, 3)]
+        pnc[:3] /= np.linalg.norm(pnc[:3])
+        t1, t2 = rng.normal(0, 3, 3), rng.normal(0, 3, 3)
+        q1, q2 = synth.rotvec_q(rng.normal(0, 0.5, 3)), synth.rotvec_q(rng.normal(0, 0.5, 3))
+        ro, Jo = po.eval_binary_plane(cp, pnc, 2.1, t1, q1, t2, q2)
+        rh, Jh = ctx.eval_binary_plane(cp, pnc, 2.1, t1, q1, t2, q2)
+        assert abs(rh - ro) <= 1e-12 * max(1.0, abs(ro))
+        for a, b in zip(Jh, Jo):
+            assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max())
+    ctx.close()
