@@ -114,6 +114,10 @@ class Context:
         _check(load().glio_associate_resident(self._h, slot, T.dptr(q), T.dptr(t), C.byref(cnt)))
         return cnt.value
 
+    def select_correspondences(self, slot, indices):
+        idx = np.ascontiguousarray(indices, np.int32)
+        _check(load().glio_select_correspondences(self._h, slot, T.iptr(idx) if len(idx) else None, len(idx)))
+
     def associate_window(self, quats, trans):
         quats = np.ascontiguousarray(quats, float); trans = np.ascontiguousarray(trans, float)
         cnt = np.zeros(self.W, np.int32)

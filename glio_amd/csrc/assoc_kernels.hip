@@ -607,6 +607,36 @@ int glio_assoc_run(glio_ctx* c, int slot, const double q[4], const double t[3], 
     return GLIO_OK;
 }
 
+// featureSelection (Estimator.cpp:3894-3992) keeps a random subset of a slot's correspondences in draw order; the draws are
+// the caller's (host RNG), the device only gathers: record k <- record sel[k]
+__global__ void k_gather_corr(const int* __restrict__ sel, int n, const float4* __restrict__ pts, const float4* __restrict__ planes,
+                              const double* __restrict__ scores, float4* __restrict__ o_pts, float4* __restrict__ o_planes, double* __restrict__ o_scores) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int s = sel[k];
+    o_pts[k] = pts[s]; o_planes[k] = planes[s]; o_scores[k] = scores[s];
+}
+int glio_assoc_select(glio_ctx* c, int slot, const int32_t* indices, int n) {
+    AssocWork* w = c->assoc;
+    if (!w) return GLIO_E_STATE;
+    const int cur = c->h_count[slot];
+    if (n < 0 || n > cur) { glio_set_error("selection of %d out of %d correspondences", n, cur); return GLIO_E_ARG; }
+    for (int k = 0; k < n; ++k) if (indices[k] < 0 || indices[k] >= cur) { glio_set_error("selection index %d out of range", indices[k]); return GLIO_E_ARG; }
+    const size_t off = (size_t)slot * c->cap;
+    if (n > 0) {
+        GLIO_HIP_CHECK(hipMemcpyAsync(w->d_q_pos, indices, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_gather_corr, dim3((n + 255) / 256), dim3(256), 0, c->stream, w->d_q_pos, n, c->d_pts + off, c->d_planes + off, c->d_scores + off,
+                           w->d_q_pt, w->d_q_plane, w->d_q_score);
+        GLIO_HIP_CHECK(hipMemcpyAsync(c->d_pts + off, w->d_q_pt, (size_t)n * 16, hipMemcpyDeviceToDevice, c->stream));
+        GLIO_HIP_CHECK(hipMemcpyAsync(c->d_planes + off, w->d_q_plane, (size_t)n * 16, hipMemcpyDeviceToDevice, c->stream));
+        GLIO_HIP_CHECK(hipMemcpyAsync(c->d_scores + off, w->d_q_score, (size_t)n * 8, hipMemcpyDeviceToDevice, c->stream));
+    }
+    c->h_count[slot] = n;
+    GLIO_HIP_CHECK(hipMemcpyAsync(c->d_count + slot, &c->h_count[slot], 4, hipMemcpyHostToDevice, c->stream));
+    GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return GLIO_OK;
+}
+
 // all W slots back to back on the stream, ONE host synchronisation: the per-slot sync of glio_assoc_run (count
 // read-back) costs as much as half a K2 launch
 int glio_assoc_run_window(glio_ctx* c, const double* quats, const double* trans, int32_t* out_counts) {

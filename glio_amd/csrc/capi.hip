@@ -242,6 +242,11 @@ int glio_associate_resident(glio_ctx* c, int slot, const double q[4], const doub
     if (rc == GLIO_OK) c->have_factors = 1;
     return rc;
 }
+int glio_select_correspondences(glio_ctx* c, int slot, const int32_t* indices, int n) {
+    if (!c || slot < 0 || slot >= c->W || n < 0 || (n > 0 && !indices)) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    return glio_assoc_select(c, slot, indices, n);
+}
 int glio_associate_window(glio_ctx* c, const double* quats, const double* trans, int32_t* out_counts) {
     if (!c || !quats || !trans) return GLIO_E_ARG;
     GLIO_HIP_CHECK(hipSetDevice(c->device));

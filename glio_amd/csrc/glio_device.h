@@ -247,6 +247,7 @@ void glio_launch_small_factors(glio_ctx* c, int use_status_cand, int which, int 
 void glio_launch_assemble(glio_ctx* c, int use_status_cand, int which, int n_ddt);
 void glio_launch_stream_read(glio_ctx* c);
 int glio_assoc_build_map_dev(glio_ctx* c, const float4* d_pts, int n);
+int glio_assoc_select(glio_ctx* c, int slot, const int32_t* indices, int n);
 int glio_assoc_run_window(glio_ctx* c, const double* quats, const double* trans, int32_t* out_counts);
 void glio_localmap_destroy(glio_ctx* c);
 // solver_kernels.hip

@@ -21,6 +21,31 @@ def unify_quaternions(state):
     return state
 
 
+def feature_selection_draws(count, feature_res_num, rng, random_select=True):
+    """The index sequence `featureSelection` (Estimator.cpp:3894-3992) keeps, for `count` correspondences: nothing
+    changes when count - 1 < feature_res_num (early return :3906-3909, quirk Q9); otherwise feature_res_num draws, each
+    uniform over the records still left (the reference builds a no-repeat random array and takes its last element,
+    :3948-3957, then erases the record, :3964-3978); with random_select == false the set is emptied (:3945,3981-3987).
+    Returns None for "keep all", else the kept original indices in draw order."""
+    if count < 1 or count - 1 < feature_res_num:
+        return None
+    if not random_select:
+        return np.zeros(0, np.int32)
+    remaining = list(range(count))
+    out = []
+    while len(out) < feature_res_num:
+        out.append(remaining.pop(int(rng.integers(0, len(remaining)))))
+    return np.asarray(out, np.int32)
+
+
+def feature_selection(backend, slot, count, feature_res_num, rng, random_select=True):
+    sel = feature_selection_draws(count, feature_res_num, rng, random_select)
+    if sel is None:
+        return count
+    backend.select_correspondences(slot, sel)
+    return len(sel)
+
+
 class SlidingWindowDriver:
     def __init__(self, backend, opts, lidar_pose=capi.lidar_pose):
         self.be, self.opts, self.W = backend, opts, opts.window

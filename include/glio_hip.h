@@ -77,6 +77,11 @@ int glio_associate_resident(glio_ctx* ctx, int slot, const double q[4], const do
 /* The whole loop of Estimator.cpp:2198-2248 in one call: every slot's resident scan against the map with its own
  * LiDAR pose (quats [W][4], trans [W][3] = Q2, T2 per slot), one host synchronisation; out_counts [W]. */
 int glio_associate_window(glio_ctx* ctx, const double* quats, const double* trans, int32_t* out_counts);
+/* featureSelection (Estimator.cpp:3894-3992): keep records indices[0..n) of the slot, in that order (n = 0 empties the
+ * slot, the reference's random_select == false case :3945,3981-3987).  The random draws stay with the caller (the
+ * reference seeds from std::random_device, random_generator.hpp:58, so they are not reproducible anyway); the gather
+ * runs on the device, nothing is read back.  glio_amd/sliding.py::feature_selection restates the draw procedure. */
+int glio_select_correspondences(glio_ctx* ctx, int slot, const int32_t* indices, int n);
 /* Parity hook / featureSelection replacement: provide or read back a slot's correspondence arrays. */
 int glio_set_correspondences(glio_ctx* ctx, int slot, const float* pts_xyzi, const float* planes,
                              const double* scores, int n);

@@ -129,3 +129,24 @@ def test_window_association_equals_per_slot(hip, small_window):
         got = ctx.get_correspondences(s)
         assert cnt[s] == per[s][0] and all(np.array_equal(a, b) for a, b in zip(got, per[s][1:]))
     ctx.close()
+
+
+def test_feature_selection_gathers_on_device(hip, small_window):
+    """featureSelection (Estimator.cpp:3894-3992): seeded draws on the host, gather on the device."""
+    from glio_amd import sliding
+    win = small_window
+    ctx = hip.Context(win.opts)
+    ctx.set_map(win.map_pts)
+    q2, t2 = hip.lidar_pose(win.opts, win.init.quat[0], win.init.trans[0])
+    n = ctx.associate(0, win.scans[0], q2, t2)
+    full = [a.copy() for a in ctx.get_correspondences(0)]
+    assert sliding.feature_selection(ctx, 0, n, n + 5, np.random.default_rng(1)) == n          # too few candidates: early return, keep all
+    rng = np.random.default_rng(7)
+    sel = sliding.feature_selection_draws(n, 100, np.random.default_rng(7))
+    assert len(sel) == 100 and len(set(sel.tolist())) == 100
+    assert sliding.feature_selection(ctx, 0, n, 100, rng) == 100
+    got = ctx.get_correspondences(0)
+    assert all(np.array_equal(g, f[sel]) for g, f in zip(got, full))
+    assert sliding.feature_selection(ctx, 0, 100, 10, rng, random_select=False) == 0            # random_select false empties the set
+    assert len(ctx.get_correspondences(0)[2]) == 0
+    ctx.close()
