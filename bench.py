@@ -132,6 +132,13 @@ def main():
                 "read_only_same_bytes_GBps": round(n_res * BYTES_PER_RESIDUAL / (rd_ms * 1e-3) / 1e9, 1),
                 "frac_of_read_only": round(rd_ms / k3_ms, 4)}
 
+    # the same kernel on a launch that is large enough to leave the launch ramp/tail and the 256 MB Infinity Cache behind
+    # (BASELINE config C5 shape: 50 keyframes x 256k residuals = 524 MB per launch); informational, C2 stays the headline
+    try:
+        roofline["large_launch"] = bench_k3_large(local_rank)
+    except Exception as e:
+        roofline["large_launch"] = {"error": str(e)[:200]}
+
     # HBM traffic per launch from the committed PMC pass of this same command (rocprofv3 --pmc FETCH_SIZE, x2 gfx950
     # correction; scripts/gpu_pmc.sh writes the file) -- only quoted when it was taken on the same workload
     try:
@@ -217,6 +224,32 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_k3_large(local_rank, W=50, pts=262144):
+    from glio_amd import capi, synth
+    o = synth.default_opts(W, pts=pts, map_pts=64)
+    ctx = capi.Context(o, device=local_rank)
+    rng = np.random.default_rng(5)
+    p = np.zeros((pts, 4), np.float32); p[:, :3] = rng.uniform(-30, 30, (pts, 3))
+    n = rng.normal(0, 1, (pts, 3)); n /= np.linalg.norm(n, axis=1, keepdims=True)
+    pl = np.zeros((pts, 4), np.float32); pl[:, :3] = 0.8 * n; pl[:, 3] = rng.uniform(-5, 5, pts)
+    sc = rng.uniform(3, 7.5, pts)
+    for s in range(W):
+        ctx.set_correspondences(s, np.roll(p, s, axis=0), pl, sc)
+    ctx.set_imu([]); ctx.set_prior(None); ctx.set_gnss(None, [], [])
+    from glio_amd import ctypes_types as T
+    st = T.WindowState(W)
+    st.quat[:, 0] = 1.0
+    ctx.linearize(st, want_H=False)
+    k3 = min(ctx.time_kernel(capi.KERNEL_LIDAR_LINEARIZE, 20) for _ in range(3))
+    rd = min(ctx.time_kernel(capi.KERNEL_STREAM_READ, 20) for _ in range(3))
+    nres = W * pts
+    out = {"workload": f"C5 shape: {W} keyframes x {pts} residuals", "bytes_per_launch": nres * BYTES_PER_RESIDUAL, "avg_launch_us": round(k3 * 1e3, 2),
+           "achieved": round(nres * BYTES_PER_RESIDUAL / (k3 * 1e-3) / 1e9, 1), "frac": round(nres * BYTES_PER_RESIDUAL / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "read_only_same_bytes_GBps": round(nres * BYTES_PER_RESIDUAL / (rd * 1e-3) / 1e9, 1)}
+    ctx.close()
+    return out
 
 
 def bench_local_map(local_rank, win, width=50):
