@@ -120,7 +120,7 @@ int glio_create(int device, const glio_opts* opts, glio_ctx** out) {
     ALLOC(c->d_status, sizeof(SolverStatus));
     {   // structured solver
         ArrowDev& ar = c->arrow;
-        ar.mode = 1; ar.gnss_ok = 1; ar.prior_ok = 1; ar.max_epoch = -1;
+        ar.mode = 1; ar.gnss_ok = 1; ar.prior_ok = 1; ar.max_epoch = -1; ar.gnss_chain = 1; ar.prior_chain = 1;
         ALLOC(ar.d_ep_slots, (size_t)ne * sizeof(int2)); ALLOC(ar.d_ep_off, (W + 1) * 4); ALLOC(ar.d_ep_list, 2 * (size_t)ne * 4);
         GLIO_HIP_CHECK(hipMemsetAsync(ar.d_ep_slots, 0xff, (size_t)ne * sizeof(int2), c->stream));
         GLIO_HIP_CHECK(hipMemsetAsync(ar.d_ep_off, 0, (W + 1) * 4, c->stream));
@@ -334,7 +334,7 @@ int glio_set_imu(glio_ctx* c, int n_edges, const glio_preint* edges, const int32
 int glio_set_prior(glio_ctx* c, const glio_prior* p) {
     if (!c) return GLIO_E_ARG;
     GLIO_HIP_CHECK(hipSetDevice(c->device));
-    if (!p || p->n <= 0) { c->prior_n = 0; c->prior_nb = 0; c->arrow.prior_ok = 1; return GLIO_OK; }
+    if (!p || p->n <= 0) { c->prior_n = 0; c->prior_nb = 0; c->arrow.prior_ok = 1; c->arrow.prior_chain = 1; return GLIO_OK; }
     const int np = p->n, nb = p->n_blocks, W = c->W;
     if (np > 6 * W + 9 || nb > 2 * W + 1) { glio_set_error("prior too large for window"); return GLIO_E_ARG; }
     std::vector<int> index(15 * W, -1), colblk(np, -1);
@@ -347,6 +347,21 @@ int glio_set_prior(glio_ctx* c, const glio_prior* p) {
     }
     for (int j = 0; j < np; ++j) if (colblk[j] < 0) { glio_set_error("prior column %d not covered by a block", j); return GLIO_E_ARG; }
     { int nsb = 0; for (int b = 0; b < nb; ++b) nsb += p->blk_kind[b] == GLIO_BLK_SPEEDBIAS; c->arrow.prior_ok = nsb <= 1; }   // two speed-bias blocks would couple the chain densely
+    {   // Is J0^T J0 block diagonal by keyframe?  The reference's own marginalization always produces that (its LiDAR factors
+        // constrain every pose absolutely, quirk Q7, so eliminating the oldest keyframe never couples two kept ones); then
+        // the whole window is a keyframe chain and the solver needs no dense pose block.
+        std::vector<double> cn(np, 0.0);
+        for (int i = 0; i < np; ++i) for (int j = 0; j < np; ++j) cn[j] += p->lin_jac[(size_t)i * np + j] * p->lin_jac[(size_t)i * np + j];
+        bool chain = true;
+        for (int a = 0; a < np && chain; ++a)
+            for (int b2 = a + 1; b2 < np; ++b2) {
+                if (p->blk_slot[colblk[a]] == p->blk_slot[colblk[b2]]) continue;
+                double sab = 0;
+                for (int i = 0; i < np; ++i) sab += p->lin_jac[(size_t)i * np + a] * p->lin_jac[(size_t)i * np + b2];
+                if (fabs(sab) > 1e-13 * sqrt(cn[a] * cn[b2])) { chain = false; break; }
+            }
+        c->arrow.prior_chain = chain ? 1 : 0;
+    }
     GnssDevExtra* ex = glio_extra(c);
     GLIO_HIP_CHECK(hipMemcpy(c->d_prior_J0, p->lin_jac, (size_t)np * np * 8, hipMemcpyHostToDevice));
     GLIO_HIP_CHECK(hipMemcpy(c->d_prior_r0, p->lin_res, np * 8, hipMemcpyHostToDevice));
@@ -443,7 +458,8 @@ int glio_set_gnss(glio_ctx* c, const glio_gnss_frame* frame, int n_dd, const gli
         const int ne = std::max(1, c->n_ddt_max);
         std::vector<int2> es(ne, make_int2(-1, -1));
         std::vector<std::vector<int>> per(W);
-        c->arrow.gnss_ok = 1; c->arrow.max_epoch = -1;
+        c->arrow.gnss_ok = 1; c->arrow.max_epoch = -1; c->arrow.gnss_chain = 1;
+        for (auto& g : groups) if (std::abs(g.slot_i - g.slot_j) != 1) c->arrow.gnss_chain = 0;       // a DD pair that skips a keyframe breaks the chain
         for (auto& r : runs) {
             c->arrow.max_epoch = std::max(c->arrow.max_epoch, r.epoch);
             const GnssGroup& g = groups[r.group];
@@ -691,6 +707,7 @@ int glio_debug_set_enqueue_lead(glio_ctx* c, int lead) {
     c->enqueue_lead = lead;
     return GLIO_OK;
 }
+int glio_debug_solver_path(glio_ctx* c) { return c ? c->arrow.last_path : -1; }
 int glio_debug_set_k3(glio_ctx* c, int bpk, int unroll) {
     if (!c || bpk < 1 || bpk > GLIO_K3_MAX_BLOCKS_PER_KF || (unroll != 1 && unroll != 2 && unroll != 4 && unroll != 8 && unroll != 12 && unroll != 14 && unroll != 18 && unroll != 21 && unroll != 22 && unroll != 24)) return GLIO_E_ARG;
     c->k3_bpk = bpk; c->k3_unroll = unroll;

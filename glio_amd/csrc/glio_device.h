@@ -81,7 +81,9 @@ struct SolverStatus {
 struct ArrowDev {
     int mode;                 // 1 = use when the structure permits (default), 0 = dense factorisation only
     int gnss_ok, prior_ok;    // structure checks made when the factors are set
+    int gnss_chain, prior_chain;   // stronger: EVERY GNSS pair couples neighbouring keyframes / the prior is block diagonal by keyframe
     int max_epoch;            // largest clock-drift epoch referenced by a Doppler factor (-1: none)
+    int last_path;            // factorisation the last trust-region step was enqueued with: 0 dense, 1 arrow, 2 keyframe chain
     int2* d_ep_slots;         // [n_ddt_max] keyframe slots (lo, hi) coupled by clock-drift epoch e, (-1,-1) if unused
     int* d_ep_off;            // [W+1] CSR over slots: epochs touching slot i
     int* d_ep_list;           // [2 n_ddt_max]

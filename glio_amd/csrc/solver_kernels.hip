@@ -43,6 +43,7 @@ struct TrArgs {
     double min_radius, initial_radius, max_radius;
     int jacobi_scaling;
     int lm;                   // 1 = Levenberg-Marquardt strategy (mu = 1 / radius, no dogleg interpolation)
+    int perm_mode;            // elimination order written by k_tr_scale: 0 = [d | s | p] (arrow / dense), 1 = [d | keyframes] (chain)
     double* x0; double* x1; double* xout;
     const double* H0; const double* H1; const double* g0; const double* g1; const double* c0; const double* c1;
     double* L; double* vec; int vstride;
@@ -64,8 +65,10 @@ struct TrArgs {
 // Elimination ordering of the linear system: [clock-drift epochs (diagonal block) | speed-bias blocks, 9 per keyframe
 // (block tridiagonal: only an IMU / Doppler edge couples neighbours) | poses, 6 per keyframe (dense through the prior)].
 // Natural index (15 per keyframe: t q v ba bg, then the epochs) -> position in the factored matrix.
-__device__ __forceinline__ int tr_perm(const int i, const int W, const int nd) {
+// mode 1 (keyframe chain, prior block diagonal): [clock-drift epochs | keyframe blocks of 15 in natural order].
+__device__ __forceinline__ int tr_perm(const int i, const int W, const int nd, const int mode = 0) {
     if (i >= 15 * W) return i - 15 * W;
+    if (mode == 1) return nd + i;
     const int sl = i / 15, l = i - 15 * sl;
     return l < 6 ? nd + 9 * W + 6 * sl + l : nd + 9 * sl + (l - 6);
 }
@@ -521,12 +524,12 @@ __global__ __launch_bounds__(256) void k_tr_scale(const TrArgs a) {
     const double* scale = V_SCALE(a); const double* diag = V_DIAG(a); const double* u = V_U(a);
     const int W = a.W, nd = a.n_ddt;
     if (i == n) {                      // right-hand side S g as the carried row
-        for (int j = lane; j < n; j += 64) a.L[(size_t)n * n + tr_perm(j, W, nd)] = scale[j] * g[j];
+        for (int j = lane; j < n; j += 64) a.L[(size_t)n * n + tr_perm(j, W, nd, a.perm_mode)] = scale[j] * g[j];
         return;
     }
     const double mu = st->mu, si = scale[i];
     const double* hrow = H + (size_t)i * n;
-    const int pi = tr_perm(i, W, nd);
+    const int pi = tr_perm(i, W, nd, a.perm_mode);
     double s = 0;
     for (int j = lane; j < n; j += 64) {
         const double h = hrow[j];
@@ -534,7 +537,7 @@ __global__ __launch_bounds__(256) void k_tr_scale(const TrArgs a) {
         if (j <= i) {
             double v = si * h * scale[j];
             if (i == j) v += mu * diag[i] * diag[i];
-            const int pj = tr_perm(j, W, nd);
+            const int pj = tr_perm(j, W, nd, a.perm_mode);
             a.L[(size_t)max(pi, pj) * n + min(pi, pj)] = v;
         }
     }
@@ -580,15 +583,15 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_factor(const TrArgs a) {
             for (int i = tid >> 6; i < n; i += TR_WAVES) {
                 const double si = scale[i];
                 const double* hrow = H + (size_t)i * n;
-                const int pi = tr_perm(i, a.W, a.n_ddt);
+                const int pi = tr_perm(i, a.W, a.n_ddt, a.perm_mode);
                 for (int j = tid & 63; j <= i; j += 64) {
                     double v = si * hrow[j] * scale[j];
                     if (i == j) v += mu * diag[i] * diag[i];
-                    const int pj = tr_perm(j, a.W, a.n_ddt);
+                    const int pj = tr_perm(j, a.W, a.n_ddt, a.perm_mode);
                     a.L[(size_t)max(pi, pj) * n + min(pi, pj)] = v;
                 }
             }
-            for (int j = tid; j < n; j += TR_THREADS) a.L[(size_t)n * n + tr_perm(j, a.W, a.n_ddt)] = scale[j] * g[j];
+            for (int j = tid; j < n; j += TR_THREADS) a.L[(size_t)n * n + tr_perm(j, a.W, a.n_ddt, a.perm_mode)] = scale[j] * g[j];
             __syncthreads();
         }
         const bool ok = chol_left_looking(a.L, n, Bp, part, sD, flag);
@@ -608,7 +611,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_factor(const TrArgs a) {
     }
     if (solved) {
         double* gn = V_GN(a); double* y = V_Y(a);
-        for (int i = tid; i < n; i += TR_THREADS) { const double yi = ylds[tr_perm(i, a.W, a.n_ddt)]; y[i] = yi; gn[i] = -diag[i] * yi; }
+        for (int i = tid; i < n; i += TR_THREADS) { const double yi = ylds[tr_perm(i, a.W, a.n_ddt, a.perm_mode)]; y[i] = yi; gn[i] = -diag[i] * yi; }
     }
     __syncthreads();
     if (tid == 0) {
@@ -1154,6 +1157,281 @@ __global__ __launch_bounds__(TR_THREADS) void k_arrow_solve(const ArrowArgs a) {
     if (tid == 0) { if (bad == 0.0) *a.flag = 2; else atomicOr(a.flag, 1); }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// K7c''  keyframe-chain factorisation.  When the prior is block diagonal by keyframe (what the reference's own
+// marginalization produces, quirk Q7) and every IMU / GNSS factor couples neighbouring keyframes, M = S H S + mu D^2 in the
+// order [clock-drift epochs | keyframe 0 (15) | keyframe 1 | ...] is a diagonal block followed by a block-TRIDIAGONAL
+// chain of 15 x 15 blocks: no dense pose block at all.  ONE kernel, one workgroup: the blocks (minus the epoch
+// contribution) are staged in LDS; wavefront 0 eliminates keyframes 0 .. m-1, wavefront 2 keyframes W-1 .. m+1 (twisted
+// factorisation), the meeting keyframe m = W/2 last.  A chain step holds the 31 x 15 panel [D_i; B_i; rhs_i] one row per
+// lane, factors it in 15 register steps (v_readlane pivot / multipliers) -- the right-hand side rides along as row 30 --
+// and takes the rank-15 update of the next block from the stored panel (135 (row, column) pairs over the 64 lanes).
+// Back substitution runs the two half chains in parallel again.  The result goes where the arrow kernels put theirs
+// (a.z, flag 2); a non-positive pivot raises flag 1 and k_tr_factor falls back to the dense factorisation.
+// ------------------------------------------------------------------------------------------------
+#define KC_NB 15
+#define KC_RS 17                       /* row stride of a staged block: odd, so that the 31 row-lanes hit distinct LDS banks */
+#define KC_BLK (31 * KC_RS + 17)       /* 31 rows + 15 reciprocal pivots (+2) = 544 doubles per keyframe */
+#define KC_THREADS 512
+
+__host__ __device__ __forceinline__ size_t chain_lds_doubles(int W, int nd) {
+    return (size_t)(nd + (nd & 1)) * 2 + (size_t)nd * 30 + (size_t)W * KC_BLK + 2 * 288 + (size_t)15 * W + (W & 1) + (size_t)nd + 2 + (size_t)(W + 2) / 2 + 1 +
+           (size_t)nd + 2 + 2 * ((size_t)nd + 2) + 12;
+}
+
+template <bool DOWN>
+__device__ __forceinline__ void chain_step15(const int i, const int nb, const bool has_nb, double (&av)[KC_NB], double* Blk, double* Cs, const int lane, bool& bad,
+                                             const int (&pr2)[3], const int (&pj2)[3]) {
+    const int r = lane;
+    double* Bi = Blk + (size_t)i * KC_BLK;
+    double nx[KC_NB];
+    {
+        const double* Bn = Blk + (size_t)(has_nb ? nb : i) * KC_BLK;
+        const int row = r < KC_NB ? r : 30;
+#pragma unroll
+        for (int j = 0; j < KC_NB; ++j) nx[j] = (has_nb && (r < KC_NB || r == 30)) ? Bn[row * KC_RS + j] : 0.0;
+        if (r >= KC_NB && r < 30) {
+#pragma unroll
+            for (int j = 0; j < KC_NB; ++j) av[j] = has_nb ? (DOWN ? Bn[(KC_NB + j) * KC_RS + (r - KC_NB)] : Bi[r * KC_RS + j]) : 0.0;
+        }
+    }
+    double rpv = 0.0;
+#pragma unroll
+    for (int j = 0; j < KC_NB; ++j) {
+        double djj = readlane_d(av[j], j);
+        if (!(djj > 0.0) || !isfinite(djj)) { bad = true; djj = 1.0; }
+        const double rdj = rsqrt(djj);
+        const double lij = (lane == j) ? djj * rdj : av[j] * rdj;
+        if (lane == j) rpv = rdj;
+        av[j] = lij;
+#pragma unroll
+        for (int c = j + 1; c < KC_NB; ++c) av[c] -= lij * readlane_d(lij, c);
+    }
+    if (r < 31) {
+#pragma unroll
+        for (int j = 0; j < KC_NB; ++j) Bi[r * KC_RS + j] = (r < KC_NB && j > r) ? 0.0 : av[j];
+        if (r < KC_NB) Bi[31 * KC_RS + r] = rpv;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (has_nb) {
+        // C[r2][j2] = X[r2] . X[j2]: r2 = 0..14 rows of the next diagonal block (j2 <= r2), r2 = 15 the right-hand side
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int r2 = pr2[q], j2 = pj2[q];
+            if (r2 < 0) continue;
+            const double* xa = Bi + (r2 < 15 ? KC_NB + r2 : 30) * KC_RS;
+            const double* xb = Bi + (KC_NB + j2) * KC_RS;
+            double sacc = 0.0;
+#pragma unroll
+            for (int k = 0; k < KC_NB; ++k) sacc += xa[k] * xb[k];
+            Cs[r2 * KC_RS + j2] = sacc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (r < KC_NB || r == 30) {
+            const int row = r < KC_NB ? r : 15;
+#pragma unroll
+            for (int j = 0; j < KC_NB; ++j) if (r == 30 || j <= r) nx[j] -= Cs[row * KC_RS + j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KC_NB; ++j) av[j] = ((r < KC_NB && j <= r) || r == 30) ? nx[j] : 0.0;
+}
+
+struct ChainArgs {
+    int W, n, nd;
+    const double* A;
+    const int2* ep_slots; const int* ep_off; const int* ep_list;
+    double* z; int* flag;
+    const SolverStatus* status;
+    long long* dbg;
+};
+
+__global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a) {
+    if (a.status->done || a.status->reuse) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int W = a.W, n = a.n, nd = a.nd;
+    const double* A = a.A;
+    const double* rhs = A + (size_t)n * n;
+    double* rd = reinterpret_cast<double*>(tr_lds);
+    double* yd = rd + nd + (nd & 1);                       // forward-substituted right-hand side of the epochs
+    double* Vs = yd + nd + (nd & 1);                       // [nd][30]: epoch column restricted to its two keyframes, scaled
+    double* Blk = Vs + (size_t)nd * 30;                    // [W][KC_BLK]
+    double* CsT = Blk + (size_t)W * KC_BLK;
+    double* CsB = CsT + 288;
+    double* zb = CsB + 288;                                // [15 W]
+    int2* eps = reinterpret_cast<int2*>(zb + 15 * W + (W & 1));
+    int* eoff = reinterpret_cast<int*>(eps + nd + 2);
+    int* elist = eoff + ((W + 2) & ~1) + 2;
+    int* esd = elist + 2 * nd + 2;                         // [2 nd] per list entry: offset into Vs of this keyframe's rows
+    int* eoth = esd + 2 * nd + 2;                          // [2 nd] ... of the next keyframe's rows, or -1
+    int* misc = eoth + 2 * nd + 2;                         // [0] bad, [1] number of active local rows, [2..17] their indices
+    if (tid < 18) misc[tid] = 0;
+    AR_STAMP(40);
+    for (int e = tid; e < nd; e += KC_THREADS) eps[e] = a.ep_slots[e];
+    for (int i = tid; i <= W; i += KC_THREADS) eoff[i] = a.ep_off[i];
+    __syncthreads();
+    for (int t = tid; t < eoff[W]; t += KC_THREADS) elist[t] = a.ep_list[t];
+    for (int e = tid; e < nd; e += KC_THREADS) {
+        const double m = A[(size_t)e * n + e];
+        if (!(m > 0.0) || !isfinite(m)) { misc[0] = 1; rd[e] = 0.0; } else rd[e] = rsqrt(m);
+    }
+    __syncthreads();
+    AR_STAMP(41);
+    // epoch columns (scaled) and the raw blocks, every global read issued as a batch of independent loads
+    __shared__ int rowmask;
+    if (tid == 0) rowmask = 0;
+    for (int e = tid; e < nd; e += KC_THREADS) {
+        const int2 sl = eps[e];
+        double v[30];
+#pragma unroll
+        for (int q = 0; q < 30; ++q) { const int s1 = q < 15 ? sl.x : sl.y; v[q] = s1 >= 0 ? A[(size_t)(nd + 15 * s1 + (q < 15 ? q : q - 15)) * n + e] : 0.0; }
+        const double re = rd[e];
+        int mk = 0;
+#pragma unroll
+        for (int q = 0; q < 30; ++q) { Vs[e * 30 + q] = v[q] * re; if (v[q] != 0.0) mk |= 1 << (q % 15); }
+        if (mk) atomicOr(&rowmask, mk);
+        yd[e] = rhs[e] * re;
+    }
+    for (int q = tid; q < W * 31; q += KC_THREADS) {
+        const int i = q / 31, r = q - 31 * i;
+        double v[KC_NB];
+        if (r < 30) {
+            const bool live = r < KC_NB || i + 1 < W;
+            const double* src = A + (size_t)(nd + 15 * i + r) * n + nd + 15 * i;      // r >= 15 runs into the rows of keyframe i+1
+#pragma unroll
+            for (int j = 0; j < KC_NB; ++j) v[j] = (live && (r >= KC_NB || j <= r)) ? src[j] : 0.0;
+        } else {
+#pragma unroll
+            for (int j = 0; j < KC_NB; ++j) v[j] = rhs[nd + 15 * i + j];
+        }
+#pragma unroll
+        for (int j = 0; j < KC_NB; ++j) Blk[(size_t)i * KC_BLK + r * KC_RS + j] = v[j];
+    }
+    __syncthreads();
+    AR_STAMP(42);
+    if (tid == 0) { int na = 0; for (int q = 0; q < 15; ++q) if (rowmask >> q & 1) misc[2 + na++] = q; misc[1] = na; }
+    // per list entry (keyframe i, epoch e): offset of the epoch's rows of keyframe i in Vs, and of keyframe i+1 (or -1)
+    for (int i = wv; i < W; i += KC_THREADS / 64)
+        for (int t = eoff[i] + lane; t < eoff[i + 1]; t += 64) {
+            const int e = elist[t];
+            const int2 sl = eps[e];
+            const int side = sl.x == i ? 0 : 15;
+            esd[t] = e * 30 + side;
+            eoth[t] = (sl.x == i ? sl.y : sl.x) == i + 1 ? e * 30 + (15 - side) : -1;
+        }
+    __syncthreads();
+    // minus the epoch contribution: one item per touched entry, accumulated over the epochs of its keyframe in list order
+    {
+        const int na = misc[1];
+        const int per = 2 * na * na + na;            // D entries, B entries, rhs entries per keyframe
+        for (int item = tid; item < W * per; item += KC_THREADS) {
+            const int i = item / per, w = item - i * per;
+            int r, j, kindI;                          // kindI 0: D_i[r][j], 1: B_i[r][j] (rows of keyframe i+1), 2: rhs_i[j]
+            if (w < na * na) { kindI = 0; r = misc[2 + w / na]; j = misc[2 + w % na]; if (j > r) continue; }
+            else if (w < 2 * na * na) { kindI = 1; const int u = w - na * na; r = misc[2 + u / na]; j = misc[2 + u % na]; if (i + 1 >= W) continue; }
+            else { kindI = 2; r = 0; j = misc[2 + w - 2 * na * na]; }
+            double* dst = Blk + (size_t)i * KC_BLK + (kindI == 0 ? r : (kindI == 1 ? KC_NB + r : 30)) * KC_RS + j;
+            double v = *dst;
+            for (int t = eoff[i]; t < eoff[i + 1]; ++t) {
+                const int base = esd[t];
+                if (kindI == 0) v -= Vs[base + r] * Vs[base + j];
+                else if (kindI == 1) { const int ob = eoth[t]; if (ob >= 0) v -= Vs[ob + r] * Vs[base + j]; }
+                else v -= yd[elist[t]] * Vs[base + j];
+            }
+            *dst = v;
+        }
+    }
+    __syncthreads();
+    AR_STAMP(43);
+    // the chain from both ends
+    const int mid = W / 2, nT = mid, nB = W - 1 - mid, T = nT > nB ? nT : nB;
+    double av[KC_NB];
+#pragma unroll
+    for (int j = 0; j < KC_NB; ++j) av[j] = 0.0;
+    if (lane < KC_NB || lane == 30) {
+        const int row = lane < KC_NB ? lane : 30;
+        if (wv == 0 && nT > 0) { for (int j = 0; j < KC_NB; ++j) av[j] = Blk[row * KC_RS + j]; }
+        if (wv == 2 && nB > 0) { for (int j = 0; j < KC_NB; ++j) av[j] = Blk[(size_t)(W - 1) * KC_BLK + row * KC_RS + j]; }
+    }
+    bool bad = false;
+    int pr2[3], pj2[3];                          // the (row, column) pairs of the rank-15 update this lane computes
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int p = lane + 64 * q;
+        if (p < 120) { int r2 = 0; while (((r2 + 1) * (r2 + 2)) / 2 <= p) ++r2; pr2[q] = r2; pj2[q] = p - (r2 * (r2 + 1)) / 2; }
+        else if (p < 135) { pr2[q] = 15; pj2[q] = p - 120; }
+        else { pr2[q] = -1; pj2[q] = 0; }
+    }
+    for (int it = 0; it <= T; ++it) {
+        if (wv == 0) {
+            if (it < nT) chain_step15<false>(it, it + 1, true, av, Blk, CsT, lane, bad, pr2, pj2);
+            else if (it == T) {
+                if (lane < KC_NB || lane == 30) {
+                    const int row = lane < KC_NB ? lane : 30, crow = lane < KC_NB ? lane : 15;
+#pragma unroll
+                    for (int j = 0; j < KC_NB; ++j) {
+                        const bool use = lane == 30 || j <= lane;
+                        double v = use ? Blk[(size_t)mid * KC_BLK + row * KC_RS + j] : 0.0;
+                        if (use && nT > 0) v -= CsT[crow * KC_RS + j];
+                        if (use && nB > 0) v -= CsB[crow * KC_RS + j];
+                        av[j] = v;
+                    }
+                }
+                chain_step15<false>(mid, mid, false, av, Blk, CsT, lane, bad, pr2, pj2);
+            }
+        } else if (wv == 2) {
+            if (it < nB) { const int i = W - 1 - it; chain_step15<true>(i, i - 1, true, av, Blk, CsB, lane, bad, pr2, pj2); }
+        }
+        __syncthreads();
+    }
+    AR_STAMP(44);
+    if (bad && lane == 0) misc[0] = 1;
+    __syncthreads();
+    if (misc[0]) { if (tid == 0) atomicOr(a.flag, 1); return; }
+    // back substitution: meeting keyframe, then the two halves in parallel:  L_ii^T z_i = y_i - L_{nbr,i}^T z_nbr
+    auto back = [&](const int i, const int nbr) {
+        const double* Bi = Blk + (size_t)i * KC_BLK;
+        double v = lane < KC_NB ? Bi[30 * KC_RS + lane] : 0.0;
+        if (nbr >= 0 && lane < KC_NB) {
+#pragma unroll
+            for (int k = 0; k < KC_NB; ++k) v -= Bi[(KC_NB + k) * KC_RS + lane] * zb[15 * nbr + k];
+        }
+        const double rp = lane < KC_NB ? Bi[31 * KC_RS + lane] : 1.0;
+#pragma unroll
+        for (int k = KC_NB - 1; k >= 0; --k) {
+            const double zk = readlane_d(v, k) * readlane_d(rp, k);
+            if (lane == k) v = zk;
+            else if (lane < k) v -= Bi[k * KC_RS + lane] * zk;
+        }
+        if (lane < KC_NB) zb[15 * i + lane] = v;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    if (wv == 0) back(mid, -1);
+    __syncthreads();
+    if (wv == 0) { for (int i = mid - 1; i >= 0; --i) back(i, i + 1); }
+    else if (wv == 1) { for (int i = mid + 1; i < W; ++i) back(i, i - 1); }
+    __syncthreads();
+    AR_STAMP(45);
+    double bd2 = 0.0;
+    for (int e = tid; e < nd; e += KC_THREADS) {
+        const int2 sl = eps[e];
+        double v = yd[e];
+        if (sl.x >= 0) {
+#pragma unroll
+            for (int q = 0; q < 15; ++q) { v -= Vs[e * 30 + q] * zb[15 * sl.x + q]; v -= Vs[e * 30 + 15 + q] * zb[15 * sl.y + q]; }
+        }
+        v *= rd[e];
+        a.z[e] = v;
+        if (!isfinite(v)) bd2 = 1.0;
+    }
+    for (int k = tid; k < 15 * W; k += KC_THREADS) { const double v = zb[k]; a.z[nd + k] = v; if (!isfinite(v)) bd2 = 1.0; }
+    if (bd2 != 0.0) misc[0] = 1;
+    __syncthreads();
+    AR_STAMP(46);
+    if (tid == 0) { if (misc[0]) atomicOr(a.flag, 1); else *a.flag = 2; }
+}
+
 size_t glio_tr_step_lds_bytes(int n) {
     size_t d = (size_t)TR_NB * bp_stride(n);
     d += 16 * 256;
@@ -1184,10 +1462,19 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
     const bool lds_chol = lds_pk <= 160 * 1024;
     const size_t lds_slv = lds_chol ? lds_pk : glio_tr_step_lds_bytes(np) + arrow_solve_extra_doubles(c->W, K) * 8;
     const bool arrow = c->arrow.mode == 1 && c->arrow.gnss_ok && c->arrow.prior_ok && c->arrow.max_epoch < n_ddt && lds_fwd <= 160 * 1024 && lds_slv <= 160 * 1024;
-    a.arrow_flag = arrow ? c->arrow.d_flag : nullptr; a.arrow_z = c->arrow.d_z;
+    const size_t lds_chain = chain_lds_doubles(c->W, n_ddt) * 8;
+    const bool chain = c->arrow.mode == 1 && c->arrow.gnss_chain && c->arrow.prior_chain && c->arrow.max_epoch < n_ddt && lds_chain <= 150 * 1024;
+    a.perm_mode = chain ? 1 : 0;
+    c->arrow.last_path = chain ? 2 : (arrow ? 1 : 0);
+    a.arrow_flag = (arrow || chain) ? c->arrow.d_flag : nullptr; a.arrow_z = c->arrow.d_z;
     hipLaunchKernelGGL(k_tr_prepare, dim3(1), dim3(TR_THREADS), 0, c->stream, a);
     hipLaunchKernelGGL(k_tr_scale, dim3((a.n + 1 + 3) / 4), dim3(256), 0, c->stream, a);
-    if (arrow) {
+    if (chain) {
+        ChainArgs r;
+        r.W = c->W; r.n = a.n; r.nd = n_ddt; r.A = c->d_L; r.ep_slots = c->arrow.d_ep_slots; r.ep_off = c->arrow.d_ep_off; r.ep_list = c->arrow.d_ep_list;
+        r.z = c->arrow.d_z; r.flag = c->arrow.d_flag; r.status = c->d_status; r.dbg = c->arrow.d_dbg;
+        hipLaunchKernelGGL(k_chain_solve, dim3(1), dim3(KC_THREADS), lds_chain, c->stream, r);
+    } else if (arrow) {
         ArrowArgs r;
         r.W = c->W; r.n = a.n; r.nd = n_ddt; r.np = np; r.K = K; r.ldY = np + 2;
         r.A = c->d_L; r.ep_slots = c->arrow.d_ep_slots; r.ep_off = c->arrow.d_ep_off; r.ep_list = c->arrow.d_ep_list;
@@ -1403,6 +1690,7 @@ void glio_tr_step_configure(size_t max_lds) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_marg_schur), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_arrow_forward), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_arrow_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(max_lds - 1024));
 }
 
 extern "C" int glio_debug_read_vec(glio_ctx* c, int k, double* out, int n) {

@@ -406,6 +406,35 @@ def make_window(W=5, pts_per_scan=2048, seed=SEED_BASE, with_gnss=False, with_pr
     return win
 
 
+def sub_window(long, lo, W):
+    """Keyframes lo .. lo+W-1 of a longer synthetic window as a window of their own (slots and clock-drift epochs
+    renumbered from 0): what the sliding window looks like after `lo` slides.  The prior is left empty."""
+    gt, init = T.WindowState(W), T.WindowState(W)
+    for dst, src in ((gt, long.gt), (init, long.init)):
+        dst.trans[:], dst.quat[:], dst.speed_bias[:] = src.trans[lo:lo + W], src.quat[lo:lo + W], src.speed_bias[lo:lo + W]
+    dd, dop, emap = [], [], {}
+    for f in long.dd:
+        if lo <= f.slot_i < lo + W and lo <= f.slot_j < lo + W:
+            g = type(f).from_buffer_copy(f); g.slot_i -= lo; g.slot_j -= lo
+            dd.append(g)
+    for f in long.dop:
+        if lo <= f.slot_i < lo + W and lo <= f.slot_j < lo + W:
+            g = type(f).from_buffer_copy(f); g.slot_i -= lo; g.slot_j -= lo
+            g.epoch = emap.setdefault(f.epoch, len(emap))
+            dop.append(g)
+    n_ddt = len(emap)
+    for st, src in ((gt, long.gt), (init, long.init)):
+        st.n_ddt = n_ddt
+        st.rcv_ddt = np.zeros(max(n_ddt, 1))
+        for old, new in emap.items():
+            st.rcv_ddt[new] = src.rcv_ddt[old]
+    win = Window(opts=None, W=W, gt=gt, init=init, kf_times=long.kf_times[lo:lo + W], scans=long.scans[lo:lo + W],
+                 scan_plane_id=long.scan_plane_id[lo:lo + W], map_pts=long.map_pts, scene=long.scene,
+                 preints=long.preints[lo:lo + W - 1], dd=dd, dop=dop, frame=long.frame if (dd or dop) else None)
+    win.opts = default_opts(W, pts=max(max(len(sc) for sc in win.scans), 64), map_pts=max(len(long.map_pts), 64), n_ddt=n_ddt)
+    return win
+
+
 def _make_gnss(win, traj, seed, sats_per_sys=10, epoch_dt=0.1):
     rng = np.random.default_rng(seed + 4)
     Ree = ecef2rotation(ANCHOR_ECEF)

@@ -283,3 +283,42 @@ def test_gnss_prior_batch_evaluators_match_oracle(hip, po, small_window):
         for a, b in zip(Jh, Jo):
             assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max())
     ctx.close()
+
+
+@pytest.fixture(scope="module")
+def steady_window(po):
+    """A window whose prior IS a marginalization output (block diagonal by keyframe): keyframes 1..W of a
+    W+1 stream, prior from marginalizing keyframe 0 of the window before."""
+    W = 5
+    long = synth.make_window(W=W + 1, pts_per_scan=600, with_gnss=True, seed=synth.SEED_BASE + 91)
+    first = synth.sub_window(long, 0, W)
+    corr0 = synth.analytic_correspondences(first)
+    prob0 = po.Problem(first, corr0, use_gnss=False, use_prior=False)
+    st0 = first.init.copy(); st0.n_ddt = 0
+    sol0, _ = prob0.solve(st0)
+    prior = prob0.marginalize(sol0)
+    win = synth.sub_window(long, 1, W)
+    win.prior = prior
+    return win, synth.analytic_correspondences(win)
+
+
+@pytest.mark.parametrize("use_gnss", [False, True], ids=["imu_prior", "imu_gnss_prior"])
+def test_keyframe_chain_solver_equals_dense(hip, po, steady_window, use_gnss):
+    win, corr = steady_window
+    res = []
+    for mode in (0, 1):
+        ctx = hip.Context(win.opts)
+        hip.load().glio_debug_set_solver(ctx._h, mode)
+        ctx.load_window(win, corr, use_gnss=use_gnss)
+        st = _state_for(win, use_gnss)
+        res.append(ctx.solve(st) + (hip.load().glio_debug_solver_path(ctx._h),))
+        ctx.close()
+    (sd, md, pd_), (sc, mc, pc) = res
+    assert pd_ == 0 and pc == 2, "the marginalization prior must select the keyframe-chain factorisation"
+    assert mc.iterations == md.iterations and mc.successful_steps == md.successful_steps and mc.termination == md.termination
+    assert abs(mc.final_cost - md.final_cost) <= 1e-12 * abs(md.final_cost)
+    assert np.abs(sc.trans - sd.trans).max() <= 1e-10 and np.abs(sc.quat - sd.quat).max() <= 1e-11
+    assert np.abs(sc.speed_bias - sd.speed_bias).max() <= 1e-9
+    so, mo = po.Problem(win, corr, use_gnss=use_gnss).solve(_state_for(win, use_gnss))
+    assert mo.iterations == mc.iterations
+    assert_pose_parity(sc, so)
