@@ -255,15 +255,22 @@ __device__ void imu_block(const double gravity, const double* __restrict__ pPi, 
 // ------------------------------------------------------------------------------------------------
 #define DOP_CHUNK 128
 #define DD_CHUNK 8           /* DD factors evaluated side by side: 32 lanes each */
+#define GN_MAX_RUNS 32       /* Doppler epochs of one keyframe pair kept in LDS (more: read from global) */
 __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, const GnssGroup& gr, int gidx,
                            PairBlock* out, DdtBlock* ddt_out) {
     // All factors of the pair are evaluated SIDE BY SIDE (DD factor f -> lanes 32 f' .. 32 f' + 31, Doppler row -> one
-    // lane): these are chains of dependent global loads (~1-2 us each on this part), so what counts is the number of
-    // latency rounds, not the arithmetic.  The sums keep the per-factor association of the sequential formulation.
+    // lane).  These are chains of dependent global loads (~1-2 us each on this part), so what counts is the number of
+    // latency ROUNDS, not the arithmetic: everything a factor needs is fetched in one round (per-satellite quantities by
+    // the satellite's own lane, the master's reach the others through LDS; the whitening matrix cooperatively into LDS;
+    // the clock-drift unknowns and the epoch table of the pair too).  Sums keep the per-factor association of the
+    // sequential formulation.
     __shared__ double raw[DD_CHUNK][19], Jri[DD_CHUNK][19 * 3], Jrj[DD_CHUNK][19 * 3];
-    __shared__ double wres[DD_CHUNK][19], wJ[DD_CHUNK][19 * 6];
-    __shared__ int s_nw[DD_CHUNK];
-    __shared__ double dJ[DOP_CHUNK * 13], dr[DOP_CHUNK], drho[DOP_CHUNK];
+    __shared__ double wE[DD_CHUNK][19 * 8];          // whitened rows: 6 Jacobian entries, the residual, (pad)
+    __shared__ double sWt[DD_CHUNK][19 * 19];
+    __shared__ double sE[DD_CHUNK][20][3], sRu[DD_CHUNK][20], sRr[DD_CHUNK][20], sObs[DD_CHUNK][20];   // per satellite: e^T R, |d_u|, |d_r|, psr_u - psr_r
+    __shared__ int s_nw[DD_CHUNK], s_m[DD_CHUNK];
+    __shared__ double dE[DOP_CHUNK * 16];            // per row: 13 Jacobian entries, corrected residual, rho, 1
+    __shared__ DopRun s_runs[GN_MAX_RUNS];
     const int tid = threadIdx.x;
     const int W = a.W;
     const int si = gr.slot_i, sj = gr.slot_j;
@@ -273,6 +280,14 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
         Pi[k] = x[3 * si + k]; Pj[k] = x[3 * sj + k];
         Vi[k] = x[7 * W + 9 * si + k]; Vj[k] = x[7 * W + 9 * sj + k];
     }
+#ifdef GLIO_DEV_STAMPS
+#define GN_STAMP(k) do { if (gidx == 0 && tid == 0 && a.dbg) a.dbg[200 + (k)] = wall_clock64(); } while (0)
+#else
+#define GN_STAMP(k) do { } while (0)
+#endif
+    GN_STAMP(0);
+    const int n_runs = gr.run_end - gr.run_begin;
+    if (tid < n_runs && tid < GN_MAX_RUNS) s_runs[tid] = a.runs[gr.run_begin + tid];
     const double* R = a.R_ecef_local;
     // thread-private accumulators (thread p owns one entry), summed over factors in fixed order
     double h6 = 0.0, g6 = 0.0, cost_dd = 0.0;       // DD: p<36 -> H6[p]; 36<=p<42 -> g6; p==42 cost
@@ -282,77 +297,77 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
     for (int f0 = gr.dd_begin; f0 < gr.dd_end; f0 += DD_CHUNK) {
         const int nf = min(DD_CHUNK, gr.dd_end - f0);
         const int fl = tid >> 5, i = tid & 31;
+        double f_ratio = 0.0, f_thr = 0.0;
         if (fl < nf) {
             const glio_dd_psr& F = a.dd[f0 + fl];
-            const int ns = F.n_sat, m = F.master;
-            if (i == 0) s_nw[fl] = ns - 1;
-            if (i < ns && i != m) {
+            f_ratio = F.ratio; f_thr = F.threshold;
+            // the whitening matrix, cooperatively (independent of n_sat: the used part is the leading nw x nw block)
+            for (int k = i; k < 19 * 19; k += 32) sWt[fl][k] = F.weight[k];
+            if (i == 0) { s_nw[fl] = F.n_sat - 1; s_m[fl] = F.master; }
+            if (i < GLIO_DD_MAX_SAT) {
                 double Pe[3], lp[3];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) lp[k] = F.ratio * Pi[k] + (1.0 - F.ratio) * Pj[k];
+                for (int k = 0; k < 3; ++k) lp[k] = f_ratio * Pi[k] + (1.0 - f_ratio) * Pj[k];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) Pe[k] = R[3 * k] * lp[0] + R[3 * k + 1] * lp[1] + R[3 * k + 2] * lp[2] + a.anc[k];
-                const int ri = i < m ? i : i - 1;
-                double d_ui[3], d_um[3], d_ri[3], d_rm[3];
+                double d_u[3], d_r[3];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    d_ui[k] = F.user_sat_pos[i][k] - Pe[k];
-                    d_um[k] = F.user_sat_pos[m][k] - Pe[k];
-                    d_ri[k] = F.ref_sat_pos[i][k] - F.station[k];
-                    d_rm[k] = F.ref_sat_pos[m][k] - F.station[k];
-                }
-                const double r_ui = sqrt(d_dot3(d_ui, d_ui)), r_um = sqrt(d_dot3(d_um, d_um));
-                const double r_ri = sqrt(d_dot3(d_ri, d_ri)), r_rm = sqrt(d_dot3(d_rm, d_rm));
-                const double est = (r_ui - r_ri) - (r_um - r_rm);
-                const double obs = (F.user_psr[i] - F.ref_psr[i]) - (F.user_psr[m] - F.ref_psr[m]);
-                const double wgt = fabs(est - obs) > F.threshold ? 0.05 : 1.0;     // :99-102
+                for (int k = 0; k < 3; ++k) { d_u[k] = F.user_sat_pos[i][k] - Pe[k]; d_r[k] = F.ref_sat_pos[i][k] - F.station[k]; }
+                const double r_u = sqrt(d_dot3(d_u, d_u)), r_r = sqrt(d_dot3(d_r, d_r));
+                sRu[fl][i] = r_u; sRr[fl][i] = r_r; sObs[fl][i] = F.user_psr[i] - F.ref_psr[i];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) sE[fl][i][c] = (d_u[0] * R[c] + d_u[1] * R[3 + c] + d_u[2] * R[6 + c]) / r_u;
+            }
+        }
+        GN_STAMP(1);
+        __syncthreads();
+        GN_STAMP(2);
+        if (fl < nf) {
+            const int ns = s_nw[fl] + 1, m = s_m[fl];
+            if (i < ns && i != m) {
+                const int ri = i < m ? i : i - 1;
+                const double est = (sRu[fl][i] - sRr[fl][i]) - (sRu[fl][m] - sRr[fl][m]);
+                const double obs = sObs[fl][i] - sObs[fl][m];
+                const double wgt = fabs(est - obs) > f_thr ? 0.05 : 1.0;     // :99-102
                 raw[fl][ri] = wgt * (est - obs);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const double ei = (d_ui[0] * R[c] + d_ui[1] * R[3 + c] + d_ui[2] * R[6 + c]) / r_ui;
-                    const double em = (d_um[0] * R[c] + d_um[1] * R[3 + c] + d_um[2] * R[6 + c]) / r_um;
-                    Jri[fl][ri * 3 + c] = (-ei * wgt * F.ratio) - (-em * wgt * F.ratio);
-                    Jrj[fl][ri * 3 + c] = (-ei * wgt * (1.0 - F.ratio)) - (-em * wgt * (1.0 - F.ratio));
+                    const double ei = sE[fl][i][c], em = sE[fl][m][c];
+                    Jri[fl][ri * 3 + c] = (-ei * wgt * f_ratio) - (-em * wgt * f_ratio);
+                    Jrj[fl][ri * 3 + c] = (-ei * wgt * (1.0 - f_ratio)) - (-em * wgt * (1.0 - f_ratio));
                 }
             }
         }
         __syncthreads();
         if (fl < nf && i < s_nw[fl]) {        // residual = W r, J = W J  (:151-167)
-            const glio_dd_psr& F = a.dd[f0 + fl];
             const int nw = s_nw[fl];
             double sr = 0, s6[6] = {0, 0, 0, 0, 0, 0};
             for (int b = 0; b < nw; ++b) {
-                const double wv = F.weight[i * nw + b];
+                const double wv = sWt[fl][i * nw + b];
                 sr += wv * raw[fl][b];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { s6[k] += wv * Jri[fl][b * 3 + k]; s6[3 + k] += wv * Jrj[fl][b * 3 + k]; }
             }
-            wres[fl][i] = sr;
+            wE[fl][i * 8 + 6] = sr;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) wJ[fl][i * 6 + k] = s6[k];
+            for (int k = 0; k < 6; ++k) wE[fl][i * 8 + k] = s6[k];
         }
         __syncthreads();
-        for (int q = 0; q < nf; ++q) {
-            const int nw = s_nw[q];
-            if (tid < 36) {
-                const int u = tid / 6, v = tid % 6;
+        // every reducing lane runs the SAME loop, a dot product of two columns of the whitened rows (no divergence inside
+        // the wavefront): (u, v) -> H6, (u, residual) -> g6, (residual, residual) -> 2 cost
+        if (tid < 43) {
+            const int ua = tid < 36 ? tid / 6 : (tid < 42 ? tid - 36 : 6), ub = tid < 36 ? tid % 6 : 6;
+            for (int q = 0; q < nf; ++q) {
+                const int nw = s_nw[q];
                 double sacc = 0;
-                for (int r2 = 0; r2 < nw; ++r2) sacc += wJ[q][r2 * 6 + u] * wJ[q][r2 * 6 + v];
-                h6 += sacc;
-            } else if (tid < 42) {
-                const int u = tid - 36;
-                double sacc = 0;
-                for (int r2 = 0; r2 < nw; ++r2) sacc += wJ[q][r2 * 6 + u] * wres[q][r2];
-                g6 += sacc;
-            } else if (tid == 42) {
-                double sacc = 0;
-                for (int r2 = 0; r2 < nw; ++r2) sacc += wres[q][r2] * wres[q][r2];
-                cost_dd += 0.5 * sacc;
+                for (int r2 = 0; r2 < nw; ++r2) sacc += wE[q][r2 * 8 + ua] * wE[q][r2 * 8 + ub];
+                if (tid < 36) h6 += sacc; else if (tid < 42) g6 += sacc; else cost_dd += 0.5 * sacc;
             }
         }
         __syncthreads();
     }
 
+    GN_STAMP(3);
     // ---- Doppler rows (dopp_factor.hpp:24-75 + HuberLoss(1.0), Estimator.cpp:2335): all epochs of the pair side by
     //      side, one lane per row; sums are taken epoch by epoch (run = the rows of one epoch, contiguous)
     const double OMG = 7.2921151467e-5, CLIGHT = 2.99792458e8;
@@ -392,9 +407,10 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
             const double ar = fabs(res), ah = a.dop_huber;
             const bool inl = ar <= ah;
             const double sw = inl ? 1.0 : sqrt(ah / ar);
-            drho[tid] = inl ? res * res : 2.0 * ah * ar - ah * ah;
-            dr[tid] = sw * res;
-            double* J = dJ + tid * 13;
+            double* J = dE + tid * 16;
+            J[14] = inl ? res * res : 2.0 * ah * ar - ah * ah;
+            J[13] = sw * res;
+            J[15] = 1.0;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const double gPl = gP[0] * Rf[c] + gP[1] * Rf[3 + c] + gP[2] * Rf[6 + c];
@@ -406,41 +422,50 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
             }
             J[12] = sw * iv;
         }
+        GN_STAMP(4);
         __syncthreads();
-        for (int rn = gr.run_begin; rn < gr.run_end; ++rn) {
-            const DopRun run = a.runs[rn];
-            const int rb = max(run.begin, c0) - c0, re = min(run.end, c0 + cnt) - c0;      // rows of this epoch in the chunk
-            if (rb >= re) continue;
-            if (tid < 144) {
-                const int u = tid / 12, v = tid % 12;
-                double sacc = 0;
-                for (int r2 = rb; r2 < re; ++r2) sacc += dJ[r2 * 13 + u] * dJ[r2 * 13 + v];
-                h12 += sacc;
-            } else if (tid < 156) {
-                const int u = tid - 144;
-                double sacc = 0;
-                for (int r2 = rb; r2 < re; ++r2) sacc += dJ[r2 * 13 + u] * dr[r2];
-                g12 += sacc;
-            } else if (tid == 156) {
-                double sacc = 0;
-                for (int r2 = rb; r2 < re; ++r2) sacc += drho[r2];
-                cost_dop += 0.5 * sacc;
-            } else if (tid >= 160 && tid < 174) {
-                const int u = tid - 160;     // 0..11: coupling, 12: h, 13: g
-                double sacc = 0;
-                if (u < 13) { for (int r2 = rb; r2 < re; ++r2) sacc += dJ[r2 * 13 + u] * dJ[r2 * 13 + 12]; }
-                else { for (int r2 = rb; r2 < re; ++r2) sacc += dJ[r2 * 13 + 12] * dr[r2]; }
-                if (carry_run == rn) sacc = carry + sacc;
-                if (run.end <= c0 + cnt) {          // epoch complete: publish its clock-drift block
-                    DdtBlock* D = ddt_out + run.epoch;
-                    if (u < 12) D->c[u] = sacc; else if (u == 12) D->h = sacc; else D->g = sacc;
-                    if (u == 0) { D->group = gidx; D->used = 1; }
-                } else { carry = sacc; carry_run = rn; }
+        GN_STAMP(5);
+        {   // one loop form for every reducing lane: dot product of two columns of the row records over the rows of an epoch
+            //   tid < 144: (u, v) -> H12;  144..155: (u, residual) -> g12;  156: (rho, 1) -> 2 cost;
+            //   160..171: (u, ddt column) -> coupling c[u];  172: (ddt, ddt) -> h;  173: (ddt, residual) -> g
+            int ua = 0, ub = 0;
+            bool active = true;
+            if (tid < 144) { ua = tid / 12; ub = tid % 12; }
+            else if (tid < 156) { ua = tid - 144; ub = 13; }
+            else if (tid == 156) { ua = 14; ub = 15; }
+            else if (tid >= 160 && tid < 172) { ua = tid - 160; ub = 12; }
+            else if (tid == 172) { ua = 12; ub = 12; }
+            else if (tid == 173) { ua = 12; ub = 13; }
+            else active = false;
+            for (int rl = 0; rl < n_runs && active; ++rl) {
+                const int rn = gr.run_begin + rl;
+                DopRun run;
+                if (rl < GN_MAX_RUNS) run = s_runs[rl]; else run = a.runs[rn];
+                const int rb = max(run.begin, c0) - c0, re = min(run.end, c0 + cnt) - c0;      // rows of this epoch in the chunk
+                if (rb >= re) continue;
+                double s0 = 0, s1 = 0;
+                int r2 = rb;
+                for (; r2 + 2 <= re; r2 += 2) { s0 += dE[r2 * 16 + ua] * dE[r2 * 16 + ub]; s1 += dE[(r2 + 1) * 16 + ua] * dE[(r2 + 1) * 16 + ub]; }
+                if (r2 < re) s0 += dE[r2 * 16 + ua] * dE[r2 * 16 + ub];
+                double sacc = s0 + s1;
+                if (tid < 144) h12 += sacc;
+                else if (tid < 156) g12 += sacc;
+                else if (tid == 156) cost_dop += 0.5 * sacc;
+                else {
+                    const int u = tid - 160;     // 0..11: coupling, 12: h, 13: g
+                    if (carry_run == rn) sacc = carry + sacc;
+                    if (run.end <= c0 + cnt) {          // epoch complete: publish its clock-drift block
+                        DdtBlock* D = ddt_out + run.epoch;
+                        if (u < 12) D->c[u] = sacc; else if (u == 12) D->h = sacc; else D->g = sacc;
+                        if (u == 0) { D->group = gidx; D->used = 1; }
+                    } else { carry = sacc; carry_run = rn; }
+                }
             }
         }
         __syncthreads();
     }
 
+    GN_STAMP(6);
     // ---- scatter the thread-private accumulators into the dense pair block
     for (int k = tid; k < GLIO_PAIR_DIM * GLIO_PAIR_DIM; k += SF_THREADS) out->H[k] = 0.0;
     if (tid < GLIO_PAIR_DIM) out->g[tid] = 0.0;
@@ -458,6 +483,7 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
     else if (tid < 42) out->g[map6[tid - 36]] += g6;
     __syncthreads();
     if (tid == 0) { out->cost = s_cost[0] + s_cost[1]; out->slot_a = si; out->slot_b = sj; }
+    GN_STAMP(7);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -507,18 +533,27 @@ __device__ void prior_rg_block(const SmallArgs& a, const double* __restrict__ x,
     __shared__ double dx[PRIOR_MAX_NP], r[PRIOR_MAX_NP], v[PRIOR_MAX_NP], Mb[9 * PRIOR_MAX_NB];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, np = a.np;
     prior_dx_M(a, x, dx, Mb);
-    for (int i = wv; i < np; i += SF_THREADS / 64) {
+    // r = r0 + J0 dx: one lane per row, four independent accumulators -- the loads of a row do not depend on each other, so
+    // the whole product costs a few latency rounds instead of one wave-reduction round trip per row
+    for (int i = tid; i < np; i += SF_THREADS) {
         const double* row = a.pJ0 + (size_t)i * np;
-        double s = 0;
-        for (int k = lane; k < np; k += 64) s += row[k] * dx[k];
-        s = wave_sum(s);
-        if (lane == 0) r[i] = a.pr0[i] + s;
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        int k = 0;
+        for (; k + 4 <= np; k += 4) { s0 += row[k] * dx[k]; s1 += row[k + 1] * dx[k + 1]; s2 += row[k + 2] * dx[k + 2]; s3 += row[k + 3] * dx[k + 3]; }
+        for (; k < np; ++k) s0 += row[k] * dx[k];
+        r[i] = a.pr0[i] + ((s0 + s1) + (s2 + s3));
     }
+    (void)lane; (void)wv;
     __syncthreads();
     for (int j = tid; j < np; j += SF_THREADS) {
-        double s = 0;
-        for (int i = 0; i < np; ++i) s += a.pJ0[(size_t)i * np + j] * r[i];
-        v[j] = s;
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        int i = 0;
+        for (; i + 4 <= np; i += 4) {
+            s0 += a.pJ0[(size_t)i * np + j] * r[i]; s1 += a.pJ0[(size_t)(i + 1) * np + j] * r[i + 1];
+            s2 += a.pJ0[(size_t)(i + 2) * np + j] * r[i + 2]; s3 += a.pJ0[(size_t)(i + 3) * np + j] * r[i + 3];
+        }
+        for (; i < np; ++i) s0 += a.pJ0[(size_t)i * np + j] * r[i];
+        v[j] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
     for (int j = tid; j < np; j += SF_THREADS) {

@@ -19,3 +19,5 @@ def stat(name, a):
 stat("lidar reduce", v[:W]); stat("imu", v[W:W + 19]); stat("gnss", v[W + 19:W + 38]); stat("prior", v[W + 38:W + 47])
 print("prior blocks", v[W + 38:W + 47].round(1))
 print("full_linearize", ctx.time_kernel(1, 30) * 1e3, " stream_read", ctx.time_kernel(6, 50) * 1e3, " k3", ctx.time_kernel(0, 50) * 1e3)
+g = np.array(list(st))[264:272]
+print("gnss block 0 stamps (us): dd loads+compute, sync, dd rest, dop compute, sync, dop reduce, scatter:", [round((g[k + 1] - g[k]) / 100.0, 2) for k in range(7)])
