@@ -128,10 +128,14 @@ __device__ void imu_block(const double gravity, const double* __restrict__ pPi, 
     }
     __syncthreads();
 
-    // ---- global Jacobians: lanes 0..5 fill one parameter block each (ImuFactor.h:63-167)
-    if (tid == 0) {            // Pi
+    // ---- global Jacobians, one parameter block per role (ImuFactor.h:63-167).  The roles run different code, so they are
+    //      spread over the four wavefronts (lane 0 of each): inside one wavefront they would execute one after the other.
+    const int role_wave = tid >> 6;
+    const bool role_lane = (tid & 63) == 0;
+    if (role_lane && role_wave == 0) {            // Pi
         for (int p = 0; p < 3; ++p) for (int c = 0; c < 3; ++c) Jg[(O_P + p) * IMU_GC + 0 + c] = -Ri_inv[p * 3 + c];
-    } else if (tid == 1) {     // Qi  (the P,V rows are the reference's as-written block, quirk Q15)
+    }
+    if (role_lane && role_wave == 1) {     // Qi  (the P,V rows are the reference's as-written block, quirk Q15)
         const double w = Qi[0];
         const double* u = Qi + 1;
         for (int sblk = 0; sblk < 2; ++sblk) {
@@ -155,7 +159,8 @@ __device__ void imu_block(const double gravity, const double* __restrict__ pPi, 
                 for (int k = 0; k < 4; ++k) s += L[(1 + p) * 4 + k] * Rm[k * 4 + c];
                 Jg[(O_R + p) * IMU_GC + 3 + c] = -2 * s;
             }
-    } else if (tid == 2) {     // SBi
+    }
+    if (role_lane && role_wave == 2) {     // SBi
         double qa[4], qb[4];
         d_qmul(Qj_inv, Qi, qa);
         d_qmul(qa, cdq, qb);
@@ -173,14 +178,17 @@ __device__ void imu_block(const double gravity, const double* __restrict__ pPi, 
                 Jg[(O_R + p) * IMU_GC + 7 + 6 + c] = -s;
             }
         for (int p = 0; p < 3; ++p) { Jg[(O_BA + p) * IMU_GC + 7 + 3 + p] = -1.0; Jg[(O_BG + p) * IMU_GC + 7 + 6 + p] = -1.0; }
-    } else if (tid == 3) {     // Pj
+    }
+    if (role_lane && role_wave == 0) {     // Pj
         for (int p = 0; p < 3; ++p) for (int c = 0; c < 3; ++c) Jg[(O_P + p) * IMU_GC + 16 + c] = Ri_inv[p * 3 + c];
-    } else if (tid == 4) {     // Qj
+    }
+    if (role_lane && role_wave == 3) {     // Qj
         double qa[4], L[16];
         d_qmul(cdq_inv, Qi_inv, qa);
         qleft16(qa, L);
         for (int p = 0; p < 3; ++p) for (int c = 0; c < 4; ++c) Jg[(O_R + p) * IMU_GC + 19 + c] = 2 * L[(1 + p) * 4 + c];
-    } else if (tid == 5) {     // SBj
+    }
+    if (role_lane && role_wave == 0) {     // SBj
         for (int p = 0; p < 3; ++p) for (int c = 0; c < 3; ++c) Jg[(O_V + p) * IMU_GC + 23 + c] = Ri_inv[p * 3 + c];
         for (int p = 0; p < 3; ++p) { Jg[(O_BA + p) * IMU_GC + 23 + 3 + p] = 1.0; Jg[(O_BG + p) * IMU_GC + 23 + 6 + p] = 1.0; }
     }
@@ -491,7 +499,7 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
 //   r = r0 + J0 dx ; local Jacobian = J0 * blockdiag(M_b), M_b = I or 2 s Qleft(q0^-1)[1:4,:] P(q)
 //   H = M^T (J0^T J0) M, g = M^T J0^T r, cost = |r|^2/2
 // ------------------------------------------------------------------------------------------------
-#define PRIOR_H_BLOCKS 8      // workgroups that share the H = M^T A0 M entries; one more does r, g, cost
+#define PRIOR_H_BLOCKS 24     // workgroups that share the H = M^T A0 M entries; one more does r, g, cost
 
 // dx [np] and the 3x3 blocks M_b of the quaternion blocks, into LDS (every prior workgroup recomputes them)
 __device__ __forceinline__ void prior_dx_M(const SmallArgs& a, const double* __restrict__ x, double* dx, double* Mb) {

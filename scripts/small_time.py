@@ -16,7 +16,7 @@ W = 20
 def stat(name, a):
     a = np.array(a)
     if len(a): print(f"{name:14s} n {len(a):4d} min {a.min():6.1f} mean {a.mean():6.1f} max {a.max():6.1f}")
-stat("lidar reduce", v[:W]); stat("imu", v[W:W + 19]); stat("gnss", v[W + 19:W + 38]); stat("prior", v[W + 38:W + 47])
+stat("lidar reduce", v[:W]); stat("imu", v[W:W + 19]); stat("gnss", v[W + 19:W + 38]); stat("prior", v[W + 38:W + 38 + 25])
 print("prior blocks", v[W + 38:W + 47].round(1))
 print("full_linearize", ctx.time_kernel(1, 30) * 1e3, " stream_read", ctx.time_kernel(6, 50) * 1e3, " k3", ctx.time_kernel(0, 50) * 1e3)
 g = np.array(list(st))[264:272]
