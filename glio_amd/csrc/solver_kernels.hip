@@ -1392,17 +1392,23 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a) {
     // back substitution: meeting keyframe, then the two halves in parallel:  L_ii^T z_i = y_i - L_{nbr,i}^T z_nbr
     auto back = [&](const int i, const int nbr) {
         const double* Bi = Blk + (size_t)i * KC_BLK;
-        double v = lane < KC_NB ? Bi[30 * KC_RS + lane] : 0.0;
-        if (nbr >= 0 && lane < KC_NB) {
+        const int ln = lane < KC_NB ? lane : 0;
+        double lcol[KC_NB], bcol[KC_NB];             // column `lane` of L_ii and of L_{nbr,i}: fetched before the dependent chain starts
 #pragma unroll
-            for (int k = 0; k < KC_NB; ++k) v -= Bi[(KC_NB + k) * KC_RS + lane] * zb[15 * nbr + k];
-        }
+        for (int k = 0; k < KC_NB; ++k) { lcol[k] = Bi[k * KC_RS + ln]; bcol[k] = Bi[(KC_NB + k) * KC_RS + ln]; }
         const double rp = lane < KC_NB ? Bi[31 * KC_RS + lane] : 1.0;
+        double v = lane < KC_NB ? Bi[30 * KC_RS + lane] : 0.0;
+        if (nbr >= 0) {
+            double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+            for (int k = 0; k < KC_NB; k += 3) { s0 += bcol[k] * zb[15 * nbr + k]; s1 += bcol[k + 1] * zb[15 * nbr + k + 1]; s2 += bcol[k + 2] * zb[15 * nbr + k + 2]; }
+            v -= (s0 + s1) + s2;
+        }
 #pragma unroll
         for (int k = KC_NB - 1; k >= 0; --k) {
             const double zk = readlane_d(v, k) * readlane_d(rp, k);
             if (lane == k) v = zk;
-            else if (lane < k) v -= Bi[k * KC_RS + lane] * zk;
+            else if (lane < k) v -= lcol[k] * zk;
         }
         if (lane < KC_NB) zb[15 * i + lane] = v;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
