@@ -118,6 +118,9 @@ class Context:
         idx = np.ascontiguousarray(indices, np.int32)
         _check(load().glio_select_correspondences(self._h, slot, T.iptr(idx) if len(idx) else None, len(idx)))
 
+    def slide_window(self):
+        _check(load().glio_slide_window(self._h))
+
     def associate_window(self, quats, trans):
         quats = np.ascontiguousarray(quats, float); trans = np.ascontiguousarray(trans, float)
         cnt = np.zeros(self.W, np.int32)
@@ -200,6 +203,10 @@ class Context:
                                        T.iptr(out["blk_kind"]), T.iptr(out["blk_idx"]), T.dptr(out["blk_x0"]), C.byref(on), C.byref(onb)))
         assert on.value == n and onb.value == nb
         return out
+
+    def marginalize_keep(self, state):
+        cs = state.c()
+        _check(load().glio_marginalize_keep(self._h, C.byref(cs)))
 
     def time_kernel(self, which, reps=20):
         ms = C.c_float()

@@ -242,6 +242,20 @@ int glio_associate_resident(glio_ctx* c, int slot, const double q[4], const doub
     if (rc == GLIO_OK) c->have_factors = 1;
     return rc;
 }
+// slide the window by one keyframe on the device: the resident scan of slot s+1 becomes that of slot s (slot W-1 is left for
+// the next glio_set_scan); correspondences are not moved, the next glio_associate_window recomputes them (Q3: once per solve)
+int glio_slide_window(glio_ctx* c) {
+    if (!c) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    for (int s = 0; s + 1 < c->W; ++s) {
+        const int n = c->h_scan_count[s + 1];
+        if (n > 0) GLIO_HIP_CHECK(hipMemcpyAsync(c->d_scan + (size_t)s * c->cap, c->d_scan + (size_t)(s + 1) * c->cap, (size_t)n * 16, hipMemcpyDeviceToDevice, c->stream));
+        c->h_scan_count[s] = n;
+    }
+    c->h_scan_count[c->W - 1] = 0;
+    GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return GLIO_OK;
+}
 int glio_select_correspondences(glio_ctx* c, int slot, const int32_t* indices, int n) {
     if (!c || slot < 0 || slot >= c->W || n < 0 || (n > 0 && !indices)) return GLIO_E_ARG;
     GLIO_HIP_CHECK(hipSetDevice(c->device));
@@ -624,6 +638,62 @@ int glio_marginalize(glio_ctx* c, const glio_state* s, double* lin_jac, double* 
     }
     if (out_n) *out_n = n;
     if (out_n_blocks) *out_n_blocks = nb;
+    return GLIO_OK;
+}
+
+// Marginalize and KEEP: the result becomes this context's prior for the next window without leaving the device (J0, r0 are
+// copied device to device; only the small block tables are rebuilt on the host).  The caller slides its state arrays by one
+// keyframe afterwards.  Equivalent to glio_marginalize + glio_set_prior(result), minus two PCIe trips of the n x n matrix.
+int glio_marginalize_keep(glio_ctx* c, const glio_state* s) {
+    int rc = check_state(c, s);
+    if (rc) return rc;
+    const int W = c->W;
+    if (W < 2) { glio_set_error("marginalization needs a window of at least 2 keyframes"); return GLIO_E_ARG; }
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    const int n_ddt = s->n_ddt, nx = glio_x_size(W, n_ddt), n = 6 * (W - 1) + 9, nb = 2 * (W - 1) + 1;
+    pack_state(c, s, c->h_xbuf);
+    GLIO_HIP_CHECK(hipMemcpyAsync(c->d_x[0], c->h_xbuf, (size_t)nx * 8, hipMemcpyHostToDevice, c->stream));
+    glio_launch_lidar_linearize(c, 0, 0, 1);
+    glio_launch_small_factors(c, 0, 0, n_ddt, 1);
+    double *dJ, *dr; int* dok;
+    glio_launch_marginalize(c, extra_of(c)->imu_edge0, &dJ, &dr, &dok);
+    GLIO_HIP_CHECK(hipGetLastError());
+    int ok = 0;
+    GLIO_HIP_CHECK(hipMemcpyAsync(&ok, dok, 4, hipMemcpyDeviceToHost, c->stream));
+    GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (!ok) { glio_set_error("marginalization: Schur complement is not positive definite"); return GLIO_E_NUMERIC; }
+    // the new prior's block tables (slots already shifted s -> s-1, Estimator.cpp:2584-2600)
+    std::vector<int> slot(nb), kind(nb), idx(nb), index(15 * W, -1), colblk(n, -1);
+    std::vector<double> x0((size_t)nb * 9, 0.0);
+    int b = 0;
+    for (int k = 1; k < W; ++k) {
+        const int kinds = k == 1 ? 3 : 2;
+        for (int kd = 0; kd < kinds; ++kd, ++b) {
+            slot[b] = k - 1; kind[b] = kd;
+            idx[b] = k == 1 ? (kd == 0 ? 0 : (kd == 1 ? 3 : 6)) : 15 + 6 * (k - 2) + 3 * kd;
+            const double* src = kd == 0 ? s->trans + 3 * k : (kd == 1 ? s->quat + 4 * k : s->speed_bias + 9 * k);
+            const int gs = kd == 0 ? 3 : (kd == 1 ? 4 : 9), ls = kd == 2 ? 9 : 3;
+            for (int j = 0; j < gs; ++j) x0[9 * b + j] = src[j];
+            const int off = 15 * (k - 1) + (kd == 0 ? 0 : (kd == 1 ? 3 : 6));
+            for (int j = 0; j < ls; ++j) { index[off + j] = idx[b] + j; colblk[idx[b] + j] = b; }
+        }
+    }
+    GnssDevExtra* ex = glio_extra(c);
+    GLIO_HIP_CHECK(hipMemcpyAsync(c->d_prior_J0, dJ, (size_t)n * n * 8, hipMemcpyDeviceToDevice, c->stream));
+    GLIO_HIP_CHECK(hipMemcpyAsync(c->d_prior_r0, dr, (size_t)n * 8, hipMemcpyDeviceToDevice, c->stream));
+    GLIO_HIP_CHECK(hipMemcpyAsync(c->d_prior_x0, x0.data(), (size_t)nb * 9 * 8, hipMemcpyHostToDevice, c->stream));
+    GLIO_HIP_CHECK(hipMemcpyAsync(c->d_prior_slot, slot.data(), nb * 4, hipMemcpyHostToDevice, c->stream));
+    GLIO_HIP_CHECK(hipMemcpyAsync(c->d_prior_kind, kind.data(), nb * 4, hipMemcpyHostToDevice, c->stream));
+    GLIO_HIP_CHECK(hipMemcpyAsync(c->d_prior_idx, idx.data(), nb * 4, hipMemcpyHostToDevice, c->stream));
+    GLIO_HIP_CHECK(hipMemcpyAsync(c->d_prior_index, index.data(), 15 * W * 4, hipMemcpyHostToDevice, c->stream));
+    GLIO_HIP_CHECK(hipMemcpyAsync(ex->d_prior_colblk, colblk.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+    // a Schur complement of block-diagonal pieces (LiDAR blocks, the IMU edge of the dropped keyframe, a block-diagonal old
+    // prior) is block diagonal, and so is its Cholesky root: the chain property is inherited
+    const int chain = c->prior_n > 0 ? c->arrow.prior_chain : 1;
+    c->prior_n = n; c->prior_nb = nb;
+    c->arrow.prior_ok = 1; c->arrow.prior_chain = chain;
+    glio_launch_gram(c, n);
+    GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));        // the host vectors above go out of scope
     return GLIO_OK;
 }
 

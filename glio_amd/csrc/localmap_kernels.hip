@@ -7,10 +7,12 @@
 // voxel-averaged on the device (pcl::VoxelGrid semantics: bounding box, floor(p * inv_leaf) - min_b, centroid per
 // voxel, output ordered by linear voxel index) and handed to K1 without leaving HBM.
 //
-// The ring holds width x cap x 16 B (50 x 64k points = 52 MB); a rebuild streams it once (~1.6 M points) -- far
-// cheaper than keeping incremental sums exact, and with no eviction arithmetic at all.  Voxel sums are accumulated in
-// 2^-20 m fixed point (int64 atomics): exact and order independent, hence bit-reproducible whatever the atomic order;
-// PCL's float accumulation (whose order std::sort leaves unspecified) is matched to ~1e-6 m, not bit for bit.
+// The ring holds width x cap x 16 B (50 x 64k points = 52 MB).  The voxel table is PERSISTENT and keyed by absolute voxel
+// coordinates; sums are kept in 2^-20 m fixed point (int64 atomics), i.e. they are exact integers: pushing a keyframe adds
+// its points, evicting the oldest subtracts them again and the table is exactly what a rebuild from scratch would give
+// (bit for bit, whatever the atomic order) -- insert/evict costs two keyframes of traffic instead of re-streaming the
+// whole ring (3.3 M points).  Emptied voxels stay as tombstones (count 0) until they fill half the table, then the table
+// is rebuilt once.  PCL's float accumulation (whose order std::sort leaves unspecified) is matched to ~1e-6 m.
 #include <cfloat>
 #include <algorithm>
 #include <cstring>
@@ -35,7 +37,10 @@ struct LocalMap {
     unsigned long long* d_keys;     // voxel linear index or EMPTY
     long long* d_sum;               // [table_cap][4] fixed-point sums x,y,z,intensity
     int* d_cnt;                     // [table_cap]
-    int* d_bbox;                    // [6] ordered-int encoded min xyz / max xyz
+    int* d_bbox;                    // [6] ordered-int encoded min xyz / max xyz of the whole ring
+    int* d_slot_bbox;               // [width][6] the same per ring slot
+    int* d_nkeys;                   // [1] voxel keys ever claimed in the table (live + tombstones)
+    int nkeys_seen;                 // host copy after the last build
     int* d_nvox;                    // [1]
     unsigned long long* d_vkey; unsigned long long* d_vkey_sorted; int* d_vslot; int* d_vslot_sorted;
     void* d_sort_tmp; size_t sort_tmp_bytes;
@@ -64,16 +69,14 @@ __global__ void k_lm_transform(const float4* __restrict__ in, int n, const doubl
                          (float)((v[2] + q0 * uv[2] + uuv[2]) + t2), p.w);
 }
 
-__global__ void k_lm_clear(unsigned long long* keys, long long* sum, int* cnt, int cap, int* bbox, int* nvox) {
+__global__ void k_lm_clear(unsigned long long* keys, long long* sum, int* cnt, int cap, int* nkeys) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < cap) { keys[i] = LM_EMPTY; cnt[i] = 0; sum[4 * (size_t)i] = 0; sum[4 * (size_t)i + 1] = 0; sum[4 * (size_t)i + 2] = 0; sum[4 * (size_t)i + 3] = 0; }
-    if (i < 3) bbox[i] = 0x7fffffff;
-    else if (i < 6) bbox[i] = (int)0x80000000;
-    if (i == 6) *nvox = 0;
+    if (i == 0) *nkeys = 0;
 }
-__global__ void k_lm_bbox(const float4* __restrict__ ring, const int* __restrict__ ns, int cap, int* bbox) {
-    const float4* pts = ring + (size_t)blockIdx.y * cap;
-    const int n = ns[blockIdx.y];
+__global__ void k_lm_bbox_init(int* bbox) { const int i = threadIdx.x; if (i < 3) bbox[i] = 0x7fffffff; else if (i < 6) bbox[i] = (int)0x80000000; }
+// bounding box of one ring slot (ordered-int atomics)
+__global__ void k_lm_bbox(const float4* __restrict__ pts, int n, int* bbox) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
     for (; i < n; i += gridDim.x * blockDim.x) {
@@ -92,41 +95,55 @@ __global__ void k_lm_bbox(const float4* __restrict__ ring, const int* __restrict
         for (int c = 0; c < 3; ++c) { atomicMin(bbox + c, mn[c]); atomicMax(bbox + 3 + c, mx[c]); }
     }
 }
+// union of the slot boxes (slots with n = 0 are skipped)
+__global__ void k_lm_bbox_union(const int* __restrict__ slot_bbox, const int* __restrict__ ns, int width, int* bbox) {
+    const int c = threadIdx.x;
+    if (c >= 6) return;
+    int v = c < 3 ? 0x7fffffff : (int)0x80000000;
+    for (int k = 0; k < width; ++k) if (ns[k] > 0) v = c < 3 ? min(v, slot_bbox[6 * k + c]) : max(v, slot_bbox[6 * k + c]);
+    bbox[c] = v;
+}
 __device__ __forceinline__ unsigned lm_hash(unsigned long long k) {
     k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
     return (unsigned)k;
 }
-__global__ void k_lm_accumulate(const float4* __restrict__ ring, const int* __restrict__ ns, int ring_cap, float inv_leaf,
-                                const int* __restrict__ bbox, unsigned long long* keys, long long* sum, int* cnt, int cap, int* nvox,
-                                unsigned long long* vkey, int* vslot, int max_vox) {
-    const float4* pts = ring + (size_t)blockIdx.y * ring_cap;
-    const int n = ns[blockIdx.y];
+__device__ __forceinline__ unsigned long long lm_key(int ix, int iy, int iz) {        // absolute voxel coordinates, 21 bits each, biased
+    return ((unsigned long long)(unsigned)(ix + (1 << 20)) << 42) | ((unsigned long long)(unsigned)(iy + (1 << 20)) << 21) | (unsigned long long)(unsigned)(iz + (1 << 20));
+}
+// add (sign = +1) or remove (sign = -1) the points of one keyframe
+__global__ void k_lm_accumulate(const float4* __restrict__ pts, int n, float inv_leaf, int sign, unsigned long long* keys, long long* sum, int* cnt,
+                                int cap, int* nkeys) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 p = pts[i];
+    const unsigned long long key = lm_key((int)floorf(p.x * inv_leaf), (int)floorf(p.y * inv_leaf), (int)floorf(p.z * inv_leaf));
+    unsigned s = lm_hash(key) & (cap - 1);
+    int probes = 0;
+    for (;;) {
+        const unsigned long long k = sign > 0 ? atomicCAS(keys + s, LM_EMPTY, key) : keys[s];
+        if (k == LM_EMPTY) { if (sign > 0) atomicAdd(nkeys, 1); break; }       // (a removal always finds its key)
+        if (k == key) break;
+        s = (s + 1) & (cap - 1);
+        if (++probes >= cap) { atomicOr(nkeys, 0x40000000); return; }          // table full: reported by glio_localmap_build
+    }
+    const long long f[4] = {llrint((double)p.x * LM_FIX), llrint((double)p.y * LM_FIX), llrint((double)p.z * LM_FIX), llrint((double)p.w * LM_FIX)};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) atomicAdd(reinterpret_cast<unsigned long long*>(sum + 4 * (size_t)s + c), (unsigned long long)(sign > 0 ? f[c] : -f[c]));
+    atomicAdd(cnt + s, sign);
+}
+// list the live voxels with their pcl::VoxelGrid linear index (relative to the ring's bounding box) for the ordered output
+__global__ void k_lm_list(const unsigned long long* __restrict__ keys, const int* __restrict__ cnt, int cap, float inv_leaf, const int* __restrict__ bbox,
+                          int* nvox, unsigned long long* vkey, int* vslot, int max_vox) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= cap || cnt[s] <= 0) return;
     int min_b[3], div_b[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) { min_b[c] = (int)floorf(ord2f(bbox[c]) * inv_leaf); div_b[c] = (int)floorf(ord2f(bbox[3 + c]) * inv_leaf) - min_b[c] + 1; }
-    const int i0 = (int)(floorf(p.x * inv_leaf) - (float)min_b[0]);
-    const int i1 = (int)(floorf(p.y * inv_leaf) - (float)min_b[1]);
-    const int i2 = (int)(floorf(p.z * inv_leaf) - (float)min_b[2]);
-    const unsigned long long key = (unsigned long long)((long long)i0 + (long long)i1 * div_b[0] + (long long)i2 * div_b[0] * (long long)div_b[1]);
-    unsigned s = lm_hash(key) & (cap - 1);
-    for (;;) {
-        const unsigned long long k = atomicCAS(keys + s, LM_EMPTY, key);
-        if (k == LM_EMPTY) {                      // first point of this voxel: register it for the ordered output
-            const int v = atomicAdd(nvox, 1);
-            if (v < max_vox) { vkey[v] = key; vslot[v] = (int)s; }
-            break;
-        }
-        if (k == key) break;
-        s = (s + 1) & (cap - 1);
-    }
-    atomicAdd(reinterpret_cast<unsigned long long*>(sum + 4 * (size_t)s + 0), (unsigned long long)llrint((double)p.x * LM_FIX));
-    atomicAdd(reinterpret_cast<unsigned long long*>(sum + 4 * (size_t)s + 1), (unsigned long long)llrint((double)p.y * LM_FIX));
-    atomicAdd(reinterpret_cast<unsigned long long*>(sum + 4 * (size_t)s + 2), (unsigned long long)llrint((double)p.z * LM_FIX));
-    atomicAdd(reinterpret_cast<unsigned long long*>(sum + 4 * (size_t)s + 3), (unsigned long long)llrint((double)p.w * LM_FIX));
-    atomicAdd(cnt + s, 1);
+    const unsigned long long k = keys[s];
+    const int ix = (int)((k >> 42) & 0x1fffff) - (1 << 20), iy = (int)((k >> 21) & 0x1fffff) - (1 << 20), iz = (int)(k & 0x1fffff) - (1 << 20);
+    const unsigned long long lin = (unsigned long long)((long long)(ix - min_b[0]) + (long long)(iy - min_b[1]) * div_b[0] + (long long)(iz - min_b[2]) * div_b[0] * (long long)div_b[1]);
+    const int v = atomicAdd(nvox, 1);
+    if (v < max_vox) { vkey[v] = lin; vslot[v] = s; }
 }
 __global__ void k_lm_emit(const int* __restrict__ vslot_sorted, int nv, const long long* __restrict__ sum, const int* __restrict__ cnt,
                           float4* __restrict__ out) {
@@ -144,7 +161,7 @@ static int lm_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 void glio_localmap_destroy(glio_ctx* c) {
     LocalMap* m = c->localmap;
     if (!m) return;
-    void* p[] = {m->d_n, m->d_ring, m->d_keys, m->d_sum, m->d_cnt, m->d_bbox, m->d_nvox, m->d_vkey, m->d_vkey_sorted, m->d_vslot, m->d_vslot_sorted, m->d_sort_tmp, m->d_out};
+    void* p[] = {m->d_slot_bbox, m->d_nkeys, m->d_n, m->d_ring, m->d_keys, m->d_sum, m->d_cnt, m->d_bbox, m->d_nvox, m->d_vkey, m->d_vkey_sorted, m->d_vslot, m->d_vslot_sorted, m->d_sort_tmp, m->d_out};
     for (void* q : p) if (q) hipFree(q);
     if (m->h_pin) hipHostFree(m->h_pin);
     delete[] m->h_n;
@@ -168,6 +185,7 @@ int glio_localmap_config(glio_ctx* c, int width, float leaf, int max_points_per_
     LM_CHECK(hipMalloc((void**)&m->d_ring, (size_t)width * m->cap * 16));
     LM_CHECK(hipMalloc((void**)&m->d_keys, (size_t)m->table_cap * 8)); LM_CHECK(hipMalloc((void**)&m->d_sum, (size_t)m->table_cap * 32));
     LM_CHECK(hipMalloc((void**)&m->d_cnt, (size_t)m->table_cap * 4)); LM_CHECK(hipMalloc((void**)&m->d_bbox, 32)); LM_CHECK(hipMalloc((void**)&m->d_nvox, 4));
+    LM_CHECK(hipMalloc((void**)&m->d_slot_bbox, (size_t)width * 24)); LM_CHECK(hipMalloc((void**)&m->d_nkeys, 4));
     LM_CHECK(hipMalloc((void**)&m->d_vkey, (size_t)m->max_vox * 8)); LM_CHECK(hipMalloc((void**)&m->d_vkey_sorted, (size_t)m->max_vox * 8));
     LM_CHECK(hipMalloc((void**)&m->d_vslot, (size_t)m->max_vox * 4)); LM_CHECK(hipMalloc((void**)&m->d_vslot_sorted, (size_t)m->max_vox * 4));
     LM_CHECK(hipMalloc((void**)&m->d_out, (size_t)m->max_vox * 16));
@@ -175,6 +193,9 @@ int glio_localmap_config(glio_ctx* c, int width, float leaf, int max_points_per_
     hipcub::DeviceRadixSort::SortPairs(nullptr, m->sort_tmp_bytes, m->d_vkey, m->d_vkey_sorted, m->d_vslot, m->d_vslot_sorted, m->max_vox, 0, 64, c->stream);
     LM_CHECK(hipMalloc(&m->d_sort_tmp, m->sort_tmp_bytes + 16));
     LM_CHECK(hipHostMalloc((void**)&m->h_pin, 64));
+    hipLaunchKernelGGL(k_lm_clear, dim3((m->table_cap + 255) / 256), dim3(256), 0, c->stream, m->d_keys, m->d_sum, m->d_cnt, m->table_cap, m->d_nkeys);
+    LM_CHECK(hipMemsetAsync(m->d_n, 0, (size_t)width * 4, c->stream));
+    LM_CHECK(hipStreamSynchronize(c->stream));
     c->localmap = m;
     return GLIO_OK;
 }
@@ -184,17 +205,26 @@ int glio_localmap_push(glio_ctx* c, const float* cloud_xyzi, int n, const double
     LocalMap* m = c->localmap;
     if (n < 0 || n > m->cap || (n > 0 && !cloud_xyzi) || !q || !t) return GLIO_E_ARG;
     LM_CHECK(hipSetDevice(c->device));
+    const float inv_leaf = 1.0f / m->leaf;
     int slot;
     if (m->count < m->width) { slot = (m->head + m->count) % m->width; ++m->count; }
-    else { slot = m->head; m->head = (m->head + 1) % m->width; }                  // recent_surf_keyframes.pop_front() (:3585)
+    else {                                                                        // recent_surf_keyframes.pop_front() (:3585):
+        slot = m->head; m->head = (m->head + 1) % m->width;                       // take the oldest keyframe's points out of the table
+        const int no = m->h_n[slot];
+        if (no > 0) hipLaunchKernelGGL(k_lm_accumulate, dim3((no + 255) / 256), dim3(256), 0, c->stream, m->d_ring + (size_t)slot * m->cap, no, inv_leaf, -1,
+                                       m->d_keys, m->d_sum, m->d_cnt, m->table_cap, m->d_nkeys);
+    }
     float4* dst = m->d_ring + (size_t)slot * m->cap;
+    hipLaunchKernelGGL(k_lm_bbox_init, dim3(1), dim3(64), 0, c->stream, m->d_slot_bbox + 6 * slot);
     if (n > 0) {
-        // stage the raw scan in the destination itself, transform in place
+        // stage the raw scan in the destination itself, transform in place, then add it to the voxel table
         LM_CHECK(hipMemcpyAsync(dst, cloud_xyzi, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(k_lm_transform, dim3((n + 255) / 256), dim3(256), 0, c->stream, dst, n, q[0], q[1], q[2], q[3], t[0], t[1], t[2], dst);
-        LM_CHECK(hipGetLastError());
-        LM_CHECK(hipStreamSynchronize(c->stream));        // the caller's buffer may be reused after return
+        hipLaunchKernelGGL(k_lm_bbox, dim3(std::min(64, (n + 255) / 256)), dim3(256), 0, c->stream, dst, n, m->d_slot_bbox + 6 * slot);
+        hipLaunchKernelGGL(k_lm_accumulate, dim3((n + 255) / 256), dim3(256), 0, c->stream, dst, n, inv_leaf, +1, m->d_keys, m->d_sum, m->d_cnt, m->table_cap, m->d_nkeys);
     }
+    LM_CHECK(hipGetLastError());
+    LM_CHECK(hipStreamSynchronize(c->stream));            // the caller's buffer may be reused after return
     m->h_n[slot] = n;
     ++m->pushed;
     return GLIO_OK;
@@ -205,20 +235,26 @@ int glio_localmap_build(glio_ctx* c, int* out_points) {
     LocalMap* m = c->localmap;
     LM_CHECK(hipSetDevice(c->device));
     const float inv_leaf = 1.0f / m->leaf;
-    hipLaunchKernelGGL(k_lm_clear, dim3((m->table_cap + 255) / 256), dim3(256), 0, c->stream, m->d_keys, m->d_sum, m->d_cnt, m->table_cap, m->d_bbox, m->d_nvox);
-    // every ring slot in one launch (grid.y = slot; unused slots hold n = 0)
-    int nmax = 0;
-    for (int k = 0; k < m->width; ++k) nmax = std::max(nmax, m->h_n[k]);
     LM_CHECK(hipMemcpyAsync(m->d_n, m->h_n, (size_t)m->width * 4, hipMemcpyHostToDevice, c->stream));
-    if (nmax > 0) {
-        hipLaunchKernelGGL(k_lm_bbox, dim3(std::min(64, (nmax + 255) / 256), m->width), dim3(256), 0, c->stream, m->d_ring, m->d_n, m->cap, m->d_bbox);
-        hipLaunchKernelGGL(k_lm_accumulate, dim3((nmax + 255) / 256, m->width), dim3(256), 0, c->stream, m->d_ring, m->d_n, m->cap, inv_leaf, m->d_bbox,
-                           m->d_keys, m->d_sum, m->d_cnt, m->table_cap, m->d_nvox, m->d_vkey, m->d_vslot, m->max_vox);
+    if (m->nkeys_seen > m->table_cap / 2) {               // too many tombstones: rebuild the table from the ring once
+        hipLaunchKernelGGL(k_lm_clear, dim3((m->table_cap + 255) / 256), dim3(256), 0, c->stream, m->d_keys, m->d_sum, m->d_cnt, m->table_cap, m->d_nkeys);
+        for (int k = 0; k < m->count; ++k) {
+            const int slot = (m->head + k) % m->width, n = m->h_n[slot];
+            if (n > 0) hipLaunchKernelGGL(k_lm_accumulate, dim3((n + 255) / 256), dim3(256), 0, c->stream, m->d_ring + (size_t)slot * m->cap, n, inv_leaf, +1,
+                                          m->d_keys, m->d_sum, m->d_cnt, m->table_cap, m->d_nkeys);
+        }
     }
+    LM_CHECK(hipMemsetAsync(m->d_nvox, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_lm_bbox_union, dim3(1), dim3(64), 0, c->stream, m->d_slot_bbox, m->d_n, m->width, m->d_bbox);
+    hipLaunchKernelGGL(k_lm_list, dim3((m->table_cap + 255) / 256), dim3(256), 0, c->stream, m->d_keys, m->d_cnt, m->table_cap, inv_leaf, m->d_bbox,
+                       m->d_nvox, m->d_vkey, m->d_vslot, m->max_vox);
     LM_CHECK(hipGetLastError());
     LM_CHECK(hipMemcpyAsync(m->h_pin, m->d_nvox, 4, hipMemcpyDeviceToHost, c->stream));
+    LM_CHECK(hipMemcpyAsync(m->h_pin + 1, m->d_nkeys, 4, hipMemcpyDeviceToHost, c->stream));
     LM_CHECK(hipStreamSynchronize(c->stream));
     const int nv = m->h_pin[0];
+    if (m->h_pin[1] & 0x40000000) { glio_set_error("local map voxel table overflow (raise max_map_points)"); return GLIO_E_ARG; }
+    m->nkeys_seen = m->h_pin[1];
     if (nv > m->max_vox) { glio_set_error("local map has %d voxels, max_map_points is %d", nv, m->max_vox); return GLIO_E_ARG; }
     if (nv > 0) {
         size_t bytes = m->sort_tmp_bytes;

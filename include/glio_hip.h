@@ -74,6 +74,9 @@ int glio_associate(glio_ctx* ctx, int slot, const float* scan_xyzi, int n, const
 /* Same, for a scan already resident from a previous glio_associate/glio_set_scan (re-association). */
 int glio_set_scan(glio_ctx* ctx, int slot, const float* scan_xyzi, int n);
 int glio_associate_resident(glio_ctx* ctx, int slot, const double q[4], const double t[3], int* out_count);
+/* Slide the window by one keyframe: the resident scan of slot s+1 becomes that of slot s (device-to-device); slot W-1 is
+ * free for the new keyframe's glio_set_scan.  (surf_frames / keyframe_idx bookkeeping of Estimator.cpp:4240-4300.) */
+int glio_slide_window(glio_ctx* ctx);
 /* The whole loop of Estimator.cpp:2198-2248 in one call: every slot's resident scan against the map with its own
  * LiDAR pose (quats [W][4], trans [W][3] = Q2, T2 per slot), one host synchronisation; out_counts [W]. */
 int glio_associate_window(glio_ctx* ctx, const double* quats, const double* trans, int32_t* out_counts);
@@ -120,6 +123,11 @@ int glio_linearize(glio_ctx* ctx, const glio_state* state, double* H, double* g,
 int glio_marginalize(glio_ctx* ctx, const glio_state* state, double* lin_jac, double* lin_res,
                      int32_t* blk_slot, int32_t* blk_kind, int32_t* blk_idx, double* blk_x0,
                      int32_t* out_n, int32_t* out_n_blocks);
+
+/* The same, but the result is installed as THIS context's prior for the next window without leaving the device
+ * (= glio_marginalize + glio_set_prior of its output, minus the two PCIe trips of the n x n matrix).  The caller then
+ * slides its state arrays / scans / IMU edges by one keyframe as the reference does (Estimator.cpp:2584-2607, 4300ff). */
+int glio_marginalize_keep(glio_ctx* ctx, const glio_state* state);
 
 /* ---- single-factor evaluators with the exact Evaluate() pointer convention, computed on the GPU.
  * A ceres::CostFunction shim is a five-line wrapper around these. */

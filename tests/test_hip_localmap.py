@@ -43,6 +43,14 @@ def test_ring_voxelgrid_matches_oracle(stream):
         got = ctx.localmap_read()
         assert n == len(ref) == len(got), f"keyframe {s}: {n} voxels vs oracle {len(ref)}"
         assert np.abs(got - ref).max() <= 2e-5, "centroids (ordered by voxel index)"
+    # insert/evict is exact: a fresh context that only ever saw the last `width` keyframes holds the same map, bit for bit
+    fresh = capi.Context(o)
+    fresh.localmap_config(width, leaf, 8192)
+    for s2 in range(win.W - width, win.W):
+        fresh.localmap_push(clouds[s2], *poses[s2])
+    fresh.localmap_build()
+    assert np.array_equal(fresh.localmap_read(), ctx.localmap_read())
+    fresh.close()
     # rebuilding is reproducible bit for bit (exact fixed-point sums, sorted output)
     a = ctx.localmap_read().copy()
     ctx.localmap_build()

@@ -107,3 +107,24 @@ def test_marginalize_c2_shape(hip, po):
     sol, _ = ctx.solve(st)
     _check_root(ctx.marginalize(sol), prob.marginalize(sol))
     ctx.close()
+
+
+def test_marginalize_keep_equals_roundtrip(hip, small_window, small_corr):
+    """glio_marginalize_keep installs on the device exactly the prior that glio_marginalize + glio_set_prior would."""
+    win = small_window
+    st = win.init.copy(); st.n_ddt = 0
+    res = []
+    for keep in (False, True):
+        ctx = hip.Context(win.opts)
+        ctx.load_window(win, small_corr, use_gnss=False)
+        sol, _ = ctx.solve(st)
+        if keep:
+            ctx.marginalize_keep(sol)
+        else:
+            ctx.set_prior(ctx.marginalize(sol))
+        nxt = sol.copy(); nxt.trans += 0.02
+        res.append(ctx.linearize(nxt) + (ctx.solve(nxt),))
+        ctx.close()
+    (Ha, ga, ca, (sa, ma)), (Hb, gb, cb, (sb, mb)) = res
+    assert np.array_equal(Ha, Hb) and np.array_equal(ga, gb) and ca == cb
+    assert ma.iterations == mb.iterations and np.array_equal(sa.trans, sb.trans)
