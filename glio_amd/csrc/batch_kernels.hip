@@ -19,6 +19,7 @@
 // device buffer); k_batch_factor / k_batch_backsolve then run the replicated block-banded Cholesky.
 #include <algorithm>
 #include <cstring>
+#include <cstdlib>
 #include <vector>
 
 #include "glio_device.h"
@@ -180,124 +181,253 @@ __global__ __launch_bounds__(256) void k_batch_cost(const double* __restrict__ r
 // damped block-banded Cholesky (one workgroup), rhs carried; M[k][d] = block (k+d, k), row-major 6x6
 // ------------------------------------------------------------------------------------------------
 #define BB_MAX_BAND 16
-__global__ __launch_bounds__(256) void k_batch_factor(const double* __restrict__ Hg, const int K, const int band, const double lambda,
-                                                      double* M, double* y, int* fail) {
-    __shared__ double Lkk[36], Linv[36], T[BB_MAX_BAND * 36], yk[6];
-    const int tid = threadIdx.x, bw = band + 1;
-    const long long nH = (long long)K * bw * 36;
-    // init: M(k,0) = H(k,k) + lambda diag ; M(k,d) = H(k,k+d)^T ; y = g
-    for (long long e = tid; e < nH; e += 256) {
-        const int k = (int)(e / (bw * 36)), rem = (int)(e % (bw * 36)), d = rem / 36, r = (rem % 36) / 6, c = rem % 6;
-        double v;
-        if (d == 0) { v = Hg[e]; if (r == c) v += lambda * v + 1e-12; }
-        else v = Hg[(size_t)k * bw * 36 + d * 36 + c * 6 + r];
-        M[e] = v;
+// Block-banded Cholesky of H + lambda diag(H) (K block rows of 6, half band `band` blocks) by ONE wavefront, no workgroup
+// barriers.  Block column k = the (band+1) blocks A(k+d, k), d = 0..band, plus the right-hand side as one more row:
+// 6 (band+1) + 1 rows of 6 -- one row per lane (two row slots per lane when band > 9).  A ring of band+1 block columns
+// lives in LDS.  Step k: the panel is factored in six register steps (pivot and multipliers by v_readlane, as in the
+// window solver), written back (LDS for the update, global for the back substitution), the rank-6 update is applied to the
+// band+... following columns of the ring (entries strided over the lanes, operands read from LDS), and block column
+// k+band+1, whose global loads were issued at the top of the step, takes the freed ring slot.
+// M out: [K][band+1][36], block (k, d) = L(k+d, k) row-major;  y out: L^-1 g.
+#define BB_ROWS(band) (6 * ((band) + 1) + 1)
+__host__ __device__ __forceinline__ size_t batch_factor_lds_doubles(int band) {
+    size_t items = 0;
+    for (int j = 1; j <= band; ++j) items += (size_t)(6 * (band - j + 1) + 1) * 6;
+    return (size_t)(band + 2) * BB_ROWS(band) * 6 + 8 + items + 4;              // ring (band + 2 slots) + the packed (int2) item table
+}
+
+__device__ __forceinline__ void bb_load_column(const double* __restrict__ Hg, const long long nH, const int K, const int band, const double lambda,
+                                               const int k, const int lane, double (&r0)[6], double (&r1)[6]) {
+    // row rho of block column k: rho = 6 d + r -> A(k+d, k)[r][c] = H(k, k+d)[c][r]; the last row is the right-hand side g_k
+    const int bw = band + 1, R = 6 * bw;
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) {
+        const int rho = lane + 64 * slot;
+        double (&dst)[6] = slot == 0 ? r0 : r1;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) dst[c] = 0.0;
+        if (k >= K || rho > R) continue;
+        if (rho == R) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) dst[c] = Hg[nH + (size_t)k * 6 + c];
+        } else {
+            const int d = rho / 6, r = rho - 6 * d;
+            if (k + d < K) {
+                const double* blk = Hg + ((size_t)k * bw + d) * 36;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    double v = blk[c * 6 + r];
+                    if (d == 0 && r == c) v += lambda * v + 1e-12;
+                    dst[c] = (d == 0 && c > r) ? 0.0 : v;
+                }
+            }
+        }
     }
-    for (int e = tid; e < K * 6; e += 256) y[e] = Hg[nH + e];
+}
+
+#define BBF_THREADS 256
+// One workgroup, four wavefronts with fixed roles per step k (ring of band+2 block-column slots in LDS, so the column that
+// enters the band never shares a slot with one still in use):
+//   wavefront 0   factors the panel [A(k..k+band, k); rhs_k] held one row per lane (six register steps, v_readlane pivots)
+//   -- barrier --
+//   all           rank-6 update of the following columns / right-hand sides (tabulated item list, four items per lane at a
+//                 time: dot products first, read-modify-writes after)
+//   wavefront 1   also streams the factored panel to global memory (M, y) for the back substitution
+//   wavefront 3   also brings block column k+band+1 from global memory into the free slot (its loads were issued before
+//                 the first barrier, i.e. they overlap the factorisation)
+//   -- barrier --
+template <bool TWO>
+__global__ __launch_bounds__(BBF_THREADS) void k_batch_factor(const double* __restrict__ Hg, const int K, const int band, const double lambda,
+                                                              double* M, double* y, int* fail) {
+    extern __shared__ double bb_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, bw = band + 1, ns = bw + 1, R = 6 * bw, rows = R + 1;
+    const long long nH = (long long)K * bw * 36;
+    double* ring = bb_lds;                                   // [ns][rows][6]
     if (tid == 0) *fail = 0;
+    for (int k = wv; k < bw; k += BBF_THREADS / 64) {        // preload block columns 0 .. bw-1
+        double r0[6], r1[6];
+        bb_load_column(Hg, nH, K, band, lambda, k, lane, r0, r1);
+        double* col = ring + (size_t)(k % ns) * rows * 6;
+        if (lane < rows) { for (int c = 0; c < 6; ++c) col[lane * 6 + c] = r0[c]; }
+        if (TWO && lane + 64 < rows) { for (int c = 0; c < 6; ++c) col[(lane + 64) * 6 + c] = r1[c]; }
+    }
+    // item table of the trailing update for a full band, packed: offset of panel row 6 i + r (or the rhs row) | offset of panel
+    // row 6 j + c | target row * 6 + c (10 bits each); j | max(i, j) << 8
+    int2* desc = reinterpret_cast<int2*>(ring + (size_t)ns * rows * 6 + 2);
+    int n_items = 0;
+    for (int j = 1; j <= band; ++j) n_items += (6 * (band - j + 1) + 1) * 6;
+    {
+        int base = 0;
+        for (int j = 1; j <= band; ++j) {
+            const int nrow = 6 * (band - j + 1) + 1;
+            for (int e = tid; e < nrow * 6; e += BBF_THREADS) {
+                const int rr = e / 6, c = e - 6 * rr;
+                const bool is_rhs = rr == nrow - 1;
+                int w = is_rhs ? j : j + rr / 6;
+                if (!is_rhs && rr < 6 && c > rr) w = 255;                 // upper part of a diagonal block: never valid
+                int2 ds;                                                  // offsets < 1024: 10 bits each
+                ds.x = ((is_rhs ? R : 6 * j + rr) * 6) | (((6 * j + c) * 6) << 10) | ((((is_rhs ? R : rr) * 6 + c)) << 20);
+                ds.y = j | (w << 8);
+                desc[base + e] = ds;
+            }
+            base += nrow * 6;
+        }
+    }
     __syncthreads();
     for (int k = 0; k < K; ++k) {
-        double* Mk = M + (size_t)k * bw * 36;
-        // (1) 6x6 Cholesky + inverse of the diagonal block, y_k <- Lkk^-1 y_k (one lane, ~400 flops)
-        if (tid == 0) {
-            double L[36];
-            for (int i = 0; i < 36; ++i) L[i] = Mk[i];
-            bool bad = false;
-            for (int j = 0; j < 6; ++j) {
-                double d = L[j * 6 + j];
-                for (int q = 0; q < j; ++q) d -= L[j * 6 + q] * L[j * 6 + q];
-                if (!(d > 0.0)) { bad = true; d = 1.0; }
-                d = sqrt(d);
-                L[j * 6 + j] = d;
-                for (int i = j + 1; i < 6; ++i) {
-                    double sacc = L[i * 6 + j];
-                    for (int q = 0; q < j; ++q) sacc -= L[i * 6 + q] * L[j * 6 + q];
-                    L[i * 6 + j] = sacc / d;
-                }
-                for (int i = 0; i < j; ++i) L[i * 6 + j] = 0.0;
-            }
-            double X[36];
-            for (int c = 0; c < 6; ++c)
-                for (int i = 0; i < 6; ++i) {
-                    double sacc = (i == c) ? 1.0 : 0.0;
-                    for (int q = 0; q < i; ++q) sacc -= L[i * 6 + q] * X[q * 6 + c];
-                    X[i * 6 + c] = sacc / L[i * 6 + i];
-                }
-            for (int i = 0; i < 36; ++i) { Lkk[i] = L[i]; Linv[i] = X[i]; Mk[i] = L[i]; }
-            for (int i = 0; i < 6; ++i) {
-                double sacc = 0;
-                for (int q = 0; q <= i; ++q) sacc += X[i * 6 + q] * y[(size_t)k * 6 + q];
-                yk[i] = sacc;
-            }
-            for (int i = 0; i < 6; ++i) y[(size_t)k * 6 + i] = yk[i];
-            if (bad) *fail = 1 + k;
-        }
-        __syncthreads();
+        double* col = ring + (size_t)(k % ns) * rows * 6;
         const int nd = min(band, K - 1 - k);
-        // (2) T(d) = M(k,d) Lkk^-T for d = 1..nd  (into LDS)
-        for (int e = tid; e < nd * 36; e += 256) {
-            const int d = 1 + e / 36, r = (e % 36) / 6, c = e % 6;
-            const double* row = Mk + d * 36 + r * 6;
-            double sacc = 0;
-            for (int q = 0; q <= c; ++q) sacc += row[q] * Linv[c * 6 + q];
-            T[(d - 1) * 36 + r * 6 + c] = sacc;
+        double n0[6], n1[6];
+        if (wv == 3) bb_load_column(Hg, nH, K, band, lambda, k + bw, lane, n0, n1);        // consumed after the barrier
+        if (wv == 0) {
+            double a0[6], a1[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) { a0[c] = lane < rows ? col[lane * 6 + c] : 0.0; a1[c] = (TWO && lane + 64 < rows) ? col[(lane + 64) * 6 + c] : 0.0; }
+            bool bad = false;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                double djj = readlane_d(a0[j], j);
+                if (!(djj > 0.0) || !isfinite(djj)) { bad = true; djj = 1.0; }
+                const double rd = rsqrt(djj);
+                const double l0 = (lane == j) ? djj * rd : a0[j] * rd;
+                a0[j] = l0;
+                double l1 = 0.0;
+                if (TWO) { l1 = a1[j] * rd; a1[j] = l1; }
+#pragma unroll
+                for (int c = j + 1; c < 6; ++c) { const double m = readlane_d(l0, c); a0[c] -= l0 * m; if (TWO) a1[c] -= l1 * m; }
+            }
+            if (bad && lane == 0 && *fail == 0) *fail = 1 + k;
+            if (lane < rows) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) col[lane * 6 + c] = (lane < 6 && c > lane) ? 0.0 : a0[c];
+            }
+            if (TWO && lane + 64 < rows) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) col[(lane + 64) * 6 + c] = a1[c];
+            }
         }
         __syncthreads();
-        // (3) store L(k+d,k), trailing update block (k+d1, k+d2) -= T(d1) T(d2)^T, y_{k+d} -= T(d) y_k
-        for (int e = tid; e < nd * 36; e += 256) Mk[36 + e] = T[e];
-        const int npair = nd * (nd + 1) / 2;
-        for (int e = tid; e < npair * 36; e += 256) {
-            int pr = e / 36, d1 = 1;
-            while (pr >= d1) { pr -= d1; ++d1; }       // pr = d2-1 in 0..d1-1
-            const int d2 = pr + 1, r = (e % 36) / 6, c = e % 6;
-            const double* t1 = T + (d1 - 1) * 36 + r * 6;
-            const double* t2 = T + (d2 - 1) * 36 + c * 6;
-            double sacc = 0;
-#pragma unroll
-            for (int q = 0; q < 6; ++q) sacc += t1[q] * t2[q];
-            M[((size_t)(k + d2) * bw + (d1 - d2)) * 36 + r * 6 + c] -= sacc;
+        if (wv == 1) {                           // the factored panel -> global: L blocks of block column k, and y_k
+            const int nL = 36 * (nd + 1);
+            for (int e = lane; e < nL; e += 64) M[(size_t)k * bw * 36 + e] = col[e];
+            if (lane < 6) y[(size_t)k * 6 + lane] = col[R * 6 + lane];
         }
-        for (int e = tid; e < nd * 6; e += 256) {
-            const int d = 1 + e / 6, r = e % 6;
-            double sacc = 0;
+        for (int e0 = tid; e0 < n_items; e0 += BBF_THREADS * 4) {
+            double sacc[4];
+            int toff[4];
 #pragma unroll
-            for (int q = 0; q < 6; ++q) sacc += T[(d - 1) * 36 + r * 6 + q] * yk[q];
-            y[(size_t)(k + d) * 6 + r] -= sacc;
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + BBF_THREADS * u;
+                sacc[u] = 0.0; toff[u] = -1;
+                if (e < n_items) {
+                    const int2 ds = desc[e];
+                    if ((ds.y >> 8) <= nd) {                 // max(i, j): the block row exists for this (shorter) last band
+                        const double* xi = col + (ds.x & 1023);
+                        const double* xj = col + ((ds.x >> 10) & 1023);
+                        double v = 0.0;
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) v += xi[q] * xj[q];
+                        sacc[u] = v;
+                        toff[u] = ((k + (ds.y & 255)) % ns) * rows * 6 + ((ds.x >> 20) & 1023);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (toff[u] >= 0) ring[toff[u]] -= sacc[u];
+        }
+        if (wv == 3) {                           // block column k+bw enters the band through the free slot
+            double* dst = ring + (size_t)((k + bw) % ns) * rows * 6;
+            if (lane < rows) { for (int c = 0; c < 6; ++c) dst[lane * 6 + c] = n0[c]; }
+            if (TWO && lane + 64 < rows) { for (int c = 0; c < 6; ++c) dst[(lane + 64) * 6 + c] = n1[c]; }
         }
         __syncthreads();
     }
 }
 
-// back substitution L^T x = y by one wavefront; delta = -x
+// back substitution L^T x = y by one wavefront; delta = -x.  The L column of the next step is prefetched while the current
+// one is consumed; the last `band` solutions stay in LDS.
 __global__ __launch_bounds__(64) void k_batch_backsolve(const double* __restrict__ M, const double* __restrict__ y, const int K, const int band,
                                                         double* delta) {
     __shared__ double xr[(BB_MAX_BAND + 1) * 6];
-    __shared__ double rhs[6];
-    const int lane = threadIdx.x, bw = band + 1;
+    __shared__ double colL[(BB_MAX_BAND + 1) * 36];
+    const int lane = threadIdx.x, bw = band + 1, n36 = bw * 36;
+    if (band <= 8) {
+        // register path: lane c < 6 owns column c of every block of block column k -- L(k+d,k)[r][c], d = 0..band -- and
+        // fetches the values of step k-1 while step k computes: no staging, nothing but 6 lanes' own loads
+        const int c = lane < 6 ? lane : 0;
+        double cur[9 * 6], nxt[9 * 6];
+        double ycur = 0.0, ynxt = 0.0;
+#pragma unroll
+        for (int e = 0; e < 54; ++e) { const int d = e / 6, r = e % 6; nxt[e] = d <= band ? M[(size_t)(K - 1) * n36 + d * 36 + r * 6 + c] : 0.0; }
+        ynxt = y[(size_t)(K - 1) * 6 + c];
+        for (int k = K - 1; k >= 0; --k) {
+            const int nd = min(band, K - 1 - k);
+#pragma unroll
+            for (int e = 0; e < 54; ++e) cur[e] = nxt[e];
+            ycur = ynxt;
+            if (k > 0) {
+#pragma unroll
+                for (int e = 0; e < 54; ++e) { const int d = e / 6, r = e % 6; nxt[e] = d <= band ? M[(size_t)(k - 1) * n36 + d * 36 + r * 6 + c] : 0.0; }
+                ynxt = y[(size_t)(k - 1) * 6 + c];
+            }
+            double v = ycur;
+#pragma unroll
+            for (int d = 1; d <= 8; ++d) {
+                if (d <= nd) {
+                    const double* xd = xr + ((k + d) % bw) * 6;
+                    double s0 = 0, s1 = 0;
+#pragma unroll
+                    for (int r = 0; r < 6; r += 2) { s0 += cur[d * 6 + r] * xd[r]; s1 += cur[d * 6 + r + 1] * xd[r + 1]; }
+                    v -= s0 + s1;
+                }
+            }
+            // L_kk^T x = v: lane c holds x_c; cur[q] = L_kk[q][c]
+            double dg = 1.0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) if (lane == q) dg = cur[q];
+            const double rdiag = 1.0 / dg;
+#pragma unroll
+            for (int q = 5; q >= 0; --q) {
+                const double zq = readlane_d(v, q) * readlane_d(rdiag, q);
+                if (lane == q) v = zq;
+                else if (lane < q) v -= cur[q] * zq;
+            }
+            if (lane < 6) { xr[(k % bw) * 6 + lane] = v; delta[(size_t)k * 6 + lane] = -v; }
+            GLIO_WAVE_LDS_SYNC();
+        }
+        return;
+    }
+    double pf[((BB_MAX_BAND + 1) * 36 + 63) / 64];
+    const int npf = (n36 + 63) / 64;
+    for (int q = 0; q < npf; ++q) { const int e = lane + 64 * q; pf[q] = (e < n36) ? M[(size_t)(K - 1) * n36 + e] : 0.0; }
+    double ypf = lane < 6 ? y[(size_t)(K - 1) * 6 + lane] : 0.0;
     for (int k = K - 1; k >= 0; --k) {
         const int nd = min(band, K - 1 - k);
-        const double* Mk = M + (size_t)k * bw * 36;
+        for (int q = 0; q < npf; ++q) { const int e = lane + 64 * q; if (e < n36) colL[e] = pf[q]; }
+        if (k > 0) { for (int q = 0; q < npf; ++q) { const int e = lane + 64 * q; pf[q] = (e < n36) ? M[(size_t)(k - 1) * n36 + e] : 0.0; } }
+        const double yk = ypf;
+        if (k > 0) ypf = lane < 6 ? y[(size_t)(k - 1) * 6 + lane] : 0.0;
+        GLIO_WAVE_LDS_SYNC();
+        double v = yk;
         if (lane < 6) {
-            double sacc = y[(size_t)k * 6 + lane];
             for (int d = 1; d <= nd; ++d) {
                 const double* xd = xr + ((k + d) % bw) * 6;
-                const double* blk = Mk + d * 36;
+                const double* blk = colL + d * 36;
 #pragma unroll
-                for (int r = 0; r < 6; ++r) sacc -= blk[r * 6 + lane] * xd[r];
+                for (int r = 0; r < 6; ++r) v -= blk[r * 6 + lane] * xd[r];
             }
-            rhs[lane] = sacc;
         }
-        __syncthreads();
-        if (lane == 0) {
-            double x[6];
-            for (int i = 5; i >= 0; --i) {
-                double sacc = rhs[i];
-                for (int q = i + 1; q < 6; ++q) sacc -= Mk[q * 6 + i] * x[q];
-                x[i] = sacc / Mk[i * 6 + i];
-            }
-            for (int i = 0; i < 6; ++i) { xr[(k % bw) * 6 + i] = x[i]; delta[(size_t)k * 6 + i] = -x[i]; }
+        const double lc[6] = {colL[0 * 6 + (lane < 6 ? lane : 0)], colL[1 * 6 + (lane < 6 ? lane : 0)], colL[2 * 6 + (lane < 6 ? lane : 0)],
+                              colL[3 * 6 + (lane < 6 ? lane : 0)], colL[4 * 6 + (lane < 6 ? lane : 0)], colL[5 * 6 + (lane < 6 ? lane : 0)]};
+        const double rdg = lane < 6 ? 1.0 / colL[lane * 7] : 1.0;
+#pragma unroll
+        for (int q = 5; q >= 0; --q) {               // L_kk^T x = v: lane c holds x_c; column c of L_kk below the diagonal = lc[q], q > c
+            const double zq = readlane_d(v, q) * readlane_d(rdg, q);
+            if (lane == q) v = zq;
+            else if (lane < q) v -= lc[q] * zq;
         }
-        __syncthreads();
+        if (lane < 6) { xr[(k % bw) * 6 + lane] = v; delta[(size_t)k * 6 + lane] = -v; }
+        GLIO_WAVE_LDS_SYNC();
     }
 }
 
@@ -344,6 +474,8 @@ int64_t glio_batch_hg_size(int K, int band) { return (int64_t)K * (band + 1) * 3
 
 int glio_batch_create(int device, int K, int band, int64_t max_constraints, glio_batch** out) {
     if (!out || K < 2 || band < 1 || band > BB_MAX_BAND || max_constraints < 1) { glio_set_error("bad batch shape"); return GLIO_E_ARG; }
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_batch_factor<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(batch_factor_lds_doubles(BB_MAX_BAND) * 8));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_batch_factor<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(batch_factor_lds_doubles(9) * 8));
     if (glio_device_count() < 1) { glio_set_error("no HIP device visible: the batch stage has no CPU fallback"); return GLIO_E_HIP; }
     GLIO_HIP_CHECK(hipSetDevice(device));
     glio_batch* b = new glio_batch();
@@ -513,7 +645,10 @@ int glio_batch_step_dev(glio_batch* b, const double* Hg_dev, double lambda, cons
     GLIO_HIP_CHECK(hipMemcpyAsync(b->d_poses, b->h_poses, (size_t)K * 7 * 8, hipMemcpyHostToDevice, b->stream));
     GLIO_HIP_CHECK(hipMemsetAsync(b->d_scalar, 0, 4 * 8, b->stream));
     int* d_fail = reinterpret_cast<int*>(b->d_scalar + 2);
-    hipLaunchKernelGGL(k_batch_factor, dim3(1), dim3(256), 0, b->stream, Hg_dev, K, band, lambda, b->d_M, b->d_y, d_fail);
+    if (BB_ROWS(band) > 64)
+        hipLaunchKernelGGL(k_batch_factor<true>, dim3(1), dim3(BBF_THREADS), batch_factor_lds_doubles(band) * 8, b->stream, Hg_dev, K, band, lambda, b->d_M, b->d_y, d_fail);
+    else
+        hipLaunchKernelGGL(k_batch_factor<false>, dim3(1), dim3(BBF_THREADS), batch_factor_lds_doubles(band) * 8, b->stream, Hg_dev, K, band, lambda, b->d_M, b->d_y, d_fail);
     hipLaunchKernelGGL(k_batch_backsolve, dim3(1), dim3(64), 0, b->stream, b->d_M, b->d_y, K, band, b->d_delta);
     hipLaunchKernelGGL(k_batch_apply, dim3((K + 255) / 256), dim3(256), 0, b->stream, Hg_dev, b->d_delta, b->d_poses, K, band, b->d_newposes, b->d_scalar);
     GLIO_HIP_CHECK(hipGetLastError());

@@ -224,6 +224,13 @@ __device__ __forceinline__ void d_plus_jac(const double q[4], double P[12]) {
 }
 
 // broadcast lane `l` (compile-time constant) of a double through v_readlane_b32 (SALU path, no LDS)
+// Ordering point for LDS traffic between the lanes of ONE wavefront: earlier ds_writes are complete and visible, later
+// ds_reads are not hoisted above it.  Restricted to the LDS address space on purpose: a generic wavefront-scope fence also
+// drains every outstanding GLOBAL load/store (s_waitcnt vmcnt(0)), which would expose the latency of loads issued early
+// for prefetching.
+#define GLIO_WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local"); __builtin_amdgcn_wave_barrier(); \
+                                  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local"); } while (0)
+
 __device__ __forceinline__ double readlane_d(double v, int l) {
 #ifdef GLIO_NO_READLANE
     return __shfl(v, l, 64);

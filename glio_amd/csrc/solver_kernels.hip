@@ -791,7 +791,7 @@ __device__ __forceinline__ void arrow_chain_step(const int i, const int nb, cons
         }
         if (r < 9) { Lc[180 + r] = rpv; if (Lg) Lg[180 + r] = rpv; }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    GLIO_WAVE_LDS_SYNC();
     if (has_nb) {
         const double* X = Lc + 90;
         if (lane < 45) {
@@ -803,7 +803,7 @@ __device__ __forceinline__ void arrow_chain_step(const int i, const int nb, cons
             for (int k = 0; k < 9; ++k) sacc += xa[k] * xb[k];
             Cs[pr * 10 + pj] = sacc;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        GLIO_WAVE_LDS_SYNC();
         if (r < 9) {
 #pragma unroll
             for (int j = 0; j < 9; ++j) nx[j] -= Cs[r * 10 + j];
@@ -1126,7 +1126,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_arrow_solve(const ArrowArgs a) {
             else if (lane < k) v -= Lc[k * 10 + lane] * zk;
         }
         if (lane < 9) wb[nd + 9 * i + lane] = v;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        GLIO_WAVE_LDS_SYNC();
     };
     if (wv == 0) chain_back(mid, -1);
     __syncthreads();
@@ -1213,7 +1213,7 @@ __device__ __forceinline__ void chain_step15(const int i, const int nb, const bo
         for (int j = 0; j < KC_NB; ++j) Bi[r * KC_RS + j] = (r < KC_NB && j > r) ? 0.0 : av[j];
         if (r < KC_NB) Bi[31 * KC_RS + r] = rpv;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    GLIO_WAVE_LDS_SYNC();
     if (has_nb) {
         // C[r2][j2] = X[r2] . X[j2]: r2 = 0..14 rows of the next diagonal block (j2 <= r2), r2 = 15 the right-hand side
 #pragma unroll
@@ -1227,7 +1227,7 @@ __device__ __forceinline__ void chain_step15(const int i, const int nb, const bo
             for (int k = 0; k < KC_NB; ++k) sacc += xa[k] * xb[k];
             Cs[r2 * KC_RS + j2] = sacc;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        GLIO_WAVE_LDS_SYNC();
         if (r < KC_NB || r == 30) {
             const int row = r < KC_NB ? r : 15;
 #pragma unroll
@@ -1411,7 +1411,7 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a) {
             else if (lane < k) v -= lcol[k] * zk;
         }
         if (lane < KC_NB) zb[15 * i + lane] = v;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        GLIO_WAVE_LDS_SYNC();
     };
     if (wv == 0) back(mid, -1);
     __syncthreads();
@@ -1534,14 +1534,14 @@ __device__ __forceinline__ int jacobi16_wave(double* buf, const int lane) {
                 coef[p] = c; coef[16 + p] = -sn; partner[p] = q;
                 coef[q] = c; coef[16 + q] = sn; partner[q] = p;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            GLIO_WAVE_LDS_SYNC();
             for (int e = lane; e < 256; e += 64) {
                 const int i = e >> 4, j = e & 15, pi = partner[i], pj = partner[j];
                 const double ai = coef[i], bi = coef[16 + i], aj = coef[j], bj = coef[16 + j];
                 An[e] = ai * (aj * A[i * 16 + j] + bj * A[i * 16 + pj]) + bi * (aj * A[pi * 16 + j] + bj * A[pi * 16 + pj]);
                 Vn[e] = aj * V[i * 16 + j] + bj * V[i * 16 + pj];
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            GLIO_WAVE_LDS_SYNC();
             cur ^= 1;
         }
     }

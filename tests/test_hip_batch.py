@@ -35,8 +35,8 @@ def test_batch_linearize_matches_oracle(po, K, band, per_kf):
     st.close()
 
 
-def test_batch_step_matches_dense_solve():
-    K, band = 30, 4
+@pytest.mark.parametrize("K,band", [(30, 4), (60, 9), (64, 12), (50, 16)], ids=["band4", "band9", "band12_two_row_slots", "band16"])
+def test_batch_step_matches_dense_solve(K, band):
     gt, init, ci, cj, cp, nc, score = _problem(K, band, 400, seed=5)
     st = batch.BatchStage(K, band, len(ci))
     st.set_constraints(ci, cj, cp, nc, score)
