@@ -86,3 +86,47 @@ class SlidingWindowDriver:
         st.trans[:-1] = st.trans[1:].copy(); st.quat[:-1] = st.quat[1:].copy(); st.speed_bias[:-1] = st.speed_bias[1:].copy()
         st.trans[-1], st.quat[-1], st.speed_bias[-1] = new_trans, new_quat, new_speed_bias
         self.first += 1
+
+
+class ResidentSlidingWindow:
+    """The same per-keyframe sequence with everything kept on the device between keyframes (capi.Context only):
+    scans slide with `glio_slide_window`, only the NEW keyframe's scan is uploaded, all slots are associated in one call,
+    and the marginalization result stays resident as the next prior (`glio_marginalize_keep`)."""
+
+    def __init__(self, ctx, opts, lidar_pose=capi.lidar_pose):
+        self.ctx, self.opts, self.W = ctx, opts, opts.window
+        self.lidar_pose = lidar_pose
+        self.state = None
+        self.first = 0
+        self._have_scans = False
+
+    def start(self, init_states):
+        self.state = init_states.copy()
+        self.state.n_ddt = 0
+        self.ctx.set_prior(None)
+        self.ctx.set_gnss(None, [], [])
+
+    def step(self, map_pts, scans, preints):
+        ctx, W = self.ctx, self.W
+        ctx.set_map(map_pts)
+        if not self._have_scans:
+            for s in range(W):
+                ctx.set_scan(s, scans[s])
+            self._have_scans = True
+        else:
+            ctx.slide_window()
+            ctx.set_scan(W - 1, scans[W - 1])
+        poses = [self.lidar_pose(self.opts, self.state.quat[s], self.state.trans[s]) for s in range(W)]
+        counts = ctx.associate_window(np.array([p[0] for p in poses]), np.array([p[1] for p in poses]))
+        ctx.set_imu(preints)
+        sol, summ = ctx.solve(self.state)
+        unify_quaternions(sol)
+        ctx.marginalize_keep(sol)
+        self.state = sol
+        return sol, summ, [int(c) for c in counts]
+
+    def slide(self, new_trans, new_quat, new_speed_bias):
+        st = self.state
+        st.trans[:-1] = st.trans[1:].copy(); st.quat[:-1] = st.quat[1:].copy(); st.speed_bias[:-1] = st.speed_bias[1:].copy()
+        st.trans[-1], st.quat[-1], st.speed_bias[-1] = new_trans, new_quat, new_speed_bias
+        self.first += 1

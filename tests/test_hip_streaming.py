@@ -83,3 +83,28 @@ def test_streaming_windows_match_oracle():
                 d.slide(long.init.trans[k + W], long.init.quat[k + W], long.init.speed_bias[k + W])
     assert drivers[0].first == L - W
     ctx.close()
+
+
+def test_resident_stream_equals_roundtrip_stream():
+    """Keeping scans and prior on the device between keyframes (slide_window / associate_window / marginalize_keep)
+    reproduces the host-round-trip sequence bit for bit over five consecutive windows."""
+    from glio_amd import capi
+    from glio_amd import ctypes_types as T
+    W, L = 4, 8
+    long = synth.make_window(W=L, pts_per_scan=700, seed=synth.SEED_BASE + 41)
+    opts = synth.default_opts(W, pts=1024, map_pts=max(len(long.map_pts), 64))
+    first = T.WindowState(W)
+    first.trans[:], first.quat[:], first.speed_bias[:] = long.init.trans[:W], long.init.quat[:W], long.init.speed_bias[:W]
+    ca, cb = capi.Context(opts), capi.Context(opts)
+    da = sliding.SlidingWindowDriver(ca, opts)
+    db = sliding.ResidentSlidingWindow(cb, opts)
+    da.start(first); db.start(first)
+    for k in range(L - W + 1):
+        sa, ma, na = da.step(long.map_pts, long.scans[k:k + W], long.preints[k:k + W - 1])
+        sb, mb, nb = db.step(long.map_pts, long.scans[k:k + W], long.preints[k:k + W - 1])
+        assert na == nb and ma.iterations == mb.iterations
+        assert np.array_equal(sa.trans, sb.trans) and np.array_equal(sa.quat, sb.quat) and np.array_equal(sa.speed_bias, sb.speed_bias)
+        if k + W < L:
+            for d in (da, db):
+                d.slide(long.init.trans[k + W], long.init.quat[k + W], long.init.speed_bias[k + W])
+    ca.close(); cb.close()
