@@ -45,7 +45,9 @@ struct AssocWork {
     float cell;                   // cell edge
     float inv_cell;
     int table_cap;                // power of two
+    int cap_eff;                  // power of two <= table_cap sized for the current map (2 n points: load factor <= 0.5)
     unsigned long long* d_keys;   // [cap] EMPTY = ~0ull
+    int4* d_ent;                  // [cap] {key lo, key hi, first point, points}: what the queries read, one 16 B load per probe
     int* d_cell_count;            // [cap]
     int* d_cell_start;            // [cap]
     int* d_cell_fill;             // [cap]
@@ -59,6 +61,7 @@ struct AssocWork {
     int* d_bcount; int* d_boff;   // per-workgroup kept counts and their exclusive scan
     int* d_count_tmp;
     int* h_count;                 // pinned
+    double* d_win; double* h_win; // [W][7] poses + [W] counts of the window association (h_win pinned)
     float3 origin;
 };
 
@@ -74,10 +77,16 @@ __device__ __forceinline__ unsigned hash_key(unsigned long long k) {
     return (unsigned)k;
 }
 __device__ __forceinline__ int cell_of(float v, float inv_cell) { return (int)floorf(v * inv_cell); }
+// Home slot: the eight cells of a 2x2x2 block sit in eight consecutive 16 B entries (one 128 B line), so the 27 probes
+// of a query touch at most 8 lines of the table instead of 27; collisions continue linearly.
+__device__ __forceinline__ unsigned home_slot(int cx, int cy, int cz, int cap) {
+    const unsigned h = hash_key(pack_key(cx >> 1, cy >> 1, cz >> 1));
+    return ((h << 3) | (unsigned)((cx & 1) | ((cy & 1) << 1) | ((cz & 1) << 2))) & (unsigned)(cap - 1);
+}
 
-__global__ void k_hash_clear(unsigned long long* keys, int* cnt, int* fill, int cap, int* total) {
+__global__ void k_hash_clear(unsigned long long* keys, int* cnt, int* fill, int cap, int* total, int4* ent) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < cap) { keys[i] = KEY_EMPTY; cnt[i] = 0; fill[i] = 0; }
+    if (i < cap) { keys[i] = KEY_EMPTY; cnt[i] = 0; fill[i] = 0; ent[i] = make_int4(-1, -1, 0, 0); }
     if (i == 0) *total = 0;
 }
 
@@ -86,8 +95,9 @@ __global__ void k_hash_insert(const float4* __restrict__ pts, int n, float inv_c
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 p = pts[i];
-    const unsigned long long key = pack_key(cell_of(p.x, inv_cell), cell_of(p.y, inv_cell), cell_of(p.z, inv_cell));
-    unsigned s = hash_key(key) & (cap - 1);
+    const int cx = cell_of(p.x, inv_cell), cy = cell_of(p.y, inv_cell), cz = cell_of(p.z, inv_cell);
+    const unsigned long long key = pack_key(cx, cy, cz);
+    unsigned s = home_slot(cx, cy, cz, cap);
     for (;;) {
         const unsigned long long prev = atomicCAS(&keys[s], KEY_EMPTY, key);
         if (prev == KEY_EMPTY || prev == key) break;
@@ -98,7 +108,8 @@ __global__ void k_hash_insert(const float4* __restrict__ pts, int n, float inv_c
 }
 
 // range allocation: one atomic per wavefront (wave-wide exclusive scan of the cell counts)
-__global__ void k_cell_alloc(const int* __restrict__ cnt, int* start, int cap, int* total) {
+__global__ void k_cell_alloc(const int* __restrict__ cnt, int* start, int cap, int* total, const unsigned long long* __restrict__ keys,
+                             int4* __restrict__ ent) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int c = i < cap ? cnt[i] : 0;
@@ -113,6 +124,10 @@ __global__ void k_cell_alloc(const int* __restrict__ cnt, int* start, int cap, i
     if (lane == 0 && wave_total > 0) base = atomicAdd(total, wave_total);
     base = __shfl(base, 0, 64);
     if (i < cap && c > 0) start[i] = base + incl - c;
+    if (i < cap) {
+        const unsigned long long k = keys[i];
+        ent[i] = make_int4((int)(unsigned)(k & 0xffffffffull), (int)(unsigned)(k >> 32), base + incl - c, c);
+    }
 }
 
 __global__ void k_scatter(const float4* __restrict__ pts, int n, const int* __restrict__ pt_slot, const int* __restrict__ start,
@@ -221,7 +236,33 @@ struct AssocArgs {
     double kd_max_radius, weight_gate;      // doubles in the reference: float quantities are promoted for the comparison
     double surf_dist_thres, lidar_const;
     int n, table_cap, unit_scores;
+    // window mode (glio_assoc_run_window): blockIdx.y = keyframe slot; pose and query count of the slot come from device
+    // arrays, every per-query array is addressed at slot * stride.  nullptr / 0 for a single scan.
+    const double* win_poses;                // [W][7] = q (w, x, y, z), t
+    const int* win_counts;                  // [W]
+    int q_stride, w_stride, b_stride;       // scan + correspondence arrays, dense work arrays, per-workgroup counts
 };
+struct AssocSlot { double q[4], t[3]; int n; size_t qoff, woff, boff; };
+__device__ __forceinline__ AssocSlot assoc_slot(const AssocArgs& a) {
+    AssocSlot s;
+    if (a.win_poses) {
+        const int k = blockIdx.y;
+        const double* P = a.win_poses + 7 * k;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s.q[i] = P[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s.t[i] = P[4 + i];
+        s.n = a.win_counts[k];
+        s.qoff = (size_t)k * a.q_stride; s.woff = (size_t)k * a.w_stride; s.boff = (size_t)k * a.b_stride;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s.q[i] = a.q[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s.t[i] = a.t[i];
+        s.n = a.n; s.qoff = 0; s.woff = 0; s.boff = 0;
+    }
+    return s;
+}
 
 // 16 lanes per query (4 queries per wavefront, 16 per workgroup): the lanes of a group probe the 27 cells
 // in two rounds, stride through the candidate points of each cell together, keep private top-5 lists and
@@ -250,21 +291,48 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 //   keyframe's own frame: a second plane is fitted to the local coordinates of the same five neighbours and the record is
 //   [unit local normal | local centroid] (6 doubles, o_nc) with score 2.5 w instead of the weighted global plane.
 #define AQ_ROUNDS ((27 + AQ_LANES - 1) / AQ_LANES)
+__device__ __forceinline__ void knn5_insert(const float px, const float py, const float pz, const float4 mp, const int m,
+                                            float bd[5], int bi[5], int bp[5]) {
+    // plain operators, NOT the __f*_rn intrinsics: those are header functions compiled with
+    // contraction allowed and fuse after inlining; here the file-scope pragma keeps them separate
+    const float ex = px - mp.x, ey = py - mp.y, ez = pz - mp.z;
+    float d = ex * ex;
+    d = d + ey * ey;
+    d = d + ez * ez;
+    const int idx = __float_as_int(mp.w);
+    if (d < bd[4] || (d == bd[4] && idx < bi[4])) {
+        bd[4] = d; bi[4] = idx; bp[4] = m;
+#pragma unroll
+        for (int k = 4; k > 0; --k) {
+            const bool sw = bd[k] < bd[k - 1] || (bd[k] == bd[k - 1] && bi[k] < bi[k - 1]);
+            if (sw) {
+                const float td = bd[k]; bd[k] = bd[k - 1]; bd[k - 1] = td;
+                const int ti = bi[k]; bi[k] = bi[k - 1]; bi[k - 1] = ti;
+                const int tp = bp[k]; bp[k] = bp[k - 1]; bp[k - 1] = tp;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_knn5(const AssocArgs a, const float4* __restrict__ scan, const float4* __restrict__ map,
-                                              const unsigned long long* __restrict__ keys, const int* __restrict__ cstart,
-                                              const int* __restrict__ ccount, int* __restrict__ o_nn5, float* __restrict__ o_d4) {
+                                              const int4* __restrict__ ent, int* __restrict__ o_nn5, float* __restrict__ o_d4) {
+    // per query: the 27 cells as (exclusive prefix of candidate counts, first point); entries 27..31 hold the total
+    __shared__ int2 s_tab[AQ_PER_BLOCK][33];
     const int lane = threadIdx.x & 63, j = threadIdx.x & (AQ_LANES - 1), g = threadIdx.x / AQ_LANES;
     const int gbase = lane & ~(AQ_LANES - 1);                 // first lane of this group inside the wavefront
     const int i = blockIdx.x * AQ_PER_BLOCK + g;
-    const bool qlive = i < a.n;
+    const AssocSlot sl = assoc_slot(a);
+    if (blockIdx.x * AQ_PER_BLOCK >= sl.n) return;
+    scan += sl.qoff; o_nn5 += 5 * sl.woff; o_d4 += sl.woff;
+    const bool qlive = i < sl.n;
     const float4 pl = scan[qlive ? i : 0];
     // transformPoint: double math, float store
     const double pin[3] = {(double)pl.x, (double)pl.y, (double)pl.z};
     double po[3];
-    a_qrot(a.q, pin, po);
-    const float px = (float)(po[0] + a.t[0]), py = (float)(po[1] + a.t[1]), pz = (float)(po[2] + a.t[2]);
+    a_qrot(sl.q, pin, po);
+    const float px = (float)(po[0] + sl.t[0]), py = (float)(po[1] + sl.t[1]), pz = (float)(po[2] + sl.t[2]);
     const int cx = cell_of(px, a.inv_cell), cy = cell_of(py, a.inv_cell), cz = cell_of(pz, a.inv_cell);
-    // ---- probe: lane j looks up cells j, j + AQ_LANES, ... of the 27-neighbourhood
+    // ---- probe: lane j looks up cells j and j + AQ_LANES of the 27-neighbourhood (one 16 B entry per probe)
     int cs[AQ_ROUNDS], cc[AQ_ROUNDS];
 #pragma unroll
     for (int h = 0; h < AQ_ROUNDS; ++h) {
@@ -273,48 +341,48 @@ __global__ __launch_bounds__(256) void k_knn5(const AssocArgs a, const float4* _
         if (c < 27 && qlive) {
             const int dx = c % 3 - 1, dy = (c / 3) % 3 - 1, dz = c / 9 - 1;
             const unsigned long long key = pack_key(cx + dx, cy + dy, cz + dz);
-            unsigned s = hash_key(key) & (a.table_cap - 1);
+            const int klo = (int)(unsigned)(key & 0xffffffffull), khi = (int)(unsigned)(key >> 32);
+            unsigned s = home_slot(cx + dx, cy + dy, cz + dz, a.table_cap);
             for (;;) {
-                const unsigned long long k = keys[s];
-                if (k == key) { cs[h] = cstart[s]; cc[h] = ccount[s]; break; }
-                if (k == KEY_EMPTY) break;
+                const int4 e = ent[s];
+                if (e.x == klo && e.y == khi) { cs[h] = e.z; cc[h] = e.w; break; }
+                if ((e.x & e.y) == -1) break;                 // KEY_EMPTY
                 s = (s + 1) & (a.table_cap - 1);
             }
         }
     }
+    // ---- flatten: exclusive prefix of the counts in cell order (round 0 lanes 0..15, then round 1), so that the group
+    // walks ONE list of `tot` candidates with all its lanes busy instead of 27 mostly empty cells one after the other
+    int s0 = cc[0], s1 = cc[1];
+#pragma unroll
+    for (int off = 1; off < AQ_LANES; off <<= 1) {
+        const int t0 = __shfl_up(s0, off, AQ_LANES), t1 = __shfl_up(s1, off, AQ_LANES);
+        if (j >= off) { s0 += t0; s1 += t1; }
+    }
+    const int tot0 = __shfl(s0, gbase + AQ_LANES - 1, 64);
+    const int tot = tot0 + __shfl(s1, gbase + AQ_LANES - 1, 64);
+    s_tab[g][j] = make_int2(s0 - cc[0], cs[0]);
+    s_tab[g][AQ_LANES + j] = make_int2(tot0 + s1 - cc[1], cs[1]);           // cells >= 27 are empty: their prefix is `tot`
+    GLIO_WAVE_LDS_SYNC();
     // ---- candidates: private top-5 per lane, ranked by (float distance, original index)
     float bd[5] = {FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX};
     int bi[5] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
     int bp[5] = {-1, -1, -1, -1, -1};          // position in the sorted map
-    for (int c = 0; c < 27; ++c) {
-        const int src = gbase + (c % AQ_LANES), h = c / AQ_LANES;
-        int csel = cs[0], nsel = cc[0];
+    const int2* tab = s_tab[g];
+    auto locate = [&](const int f) {           // largest cell whose prefix is <= f holds candidate f
+        int c = 0;
 #pragma unroll
-        for (int q = 1; q < AQ_ROUNDS; ++q) if (h == q) { csel = cs[q]; nsel = cc[q]; }
-        const int beg = __shfl(csel, src, 64);
-        const int cnt = __shfl(nsel, src, 64);
-        for (int m = beg + j; m < beg + cnt; m += AQ_LANES) {
-            const float4 mp = map[m];
-            // plain operators, NOT the __f*_rn intrinsics: those are header functions compiled with
-            // contraction allowed and fuse after inlining; here the file-scope pragma keeps them separate
-            const float ex = px - mp.x, ey = py - mp.y, ez = pz - mp.z;
-            float d = ex * ex;
-            d = d + ey * ey;
-            d = d + ez * ez;
-            const int idx = __float_as_int(mp.w);
-            if (d < bd[4] || (d == bd[4] && idx < bi[4])) {
-                bd[4] = d; bi[4] = idx; bp[4] = m;
-#pragma unroll
-                for (int k = 4; k > 0; --k) {
-                    const bool sw = bd[k] < bd[k - 1] || (bd[k] == bd[k - 1] && bi[k] < bi[k - 1]);
-                    if (sw) {
-                        const float td = bd[k]; bd[k] = bd[k - 1]; bd[k - 1] = td;
-                        const int ti = bi[k]; bi[k] = bi[k - 1]; bi[k - 1] = ti;
-                        const int tp = bp[k]; bp[k] = bp[k - 1]; bp[k - 1] = tp;
-                    }
-                }
-            }
-        }
+        for (int step = 16; step > 0; step >>= 1) if (tab[c + step].x <= f) c += step;
+        const int2 e = tab[c];
+        return e.y + (f - e.x);
+    };
+    for (int f = j; f < tot; f += 2 * AQ_LANES) {
+        const int f2 = f + AQ_LANES;
+        const bool two = f2 < tot;
+        const int m1 = locate(f), m2 = two ? locate(f2) : m1;
+        const float4 p1 = map[m1], p2 = map[m2];
+        knn5_insert(px, py, pz, p1, m1, bd, bi, bp);
+        if (two) knn5_insert(px, py, pz, p2, m2, bd, bi, bp);
     }
     // ---- merge the private lists of the group: five rounds of group-wide argmin on the key (distance bits, index)
     float md[5]; int mi[5], mp5[5];
@@ -355,12 +423,16 @@ __global__ __launch_bounds__(PF_BLOCK) void k_plane_fit(const AssocArgs a, const
                                                         int* __restrict__ o_nn, const float4* __restrict__ loc, double* __restrict__ o_nc) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * PF_BLOCK + threadIdx.x;
-    const bool qlive = i < a.n;
+    const AssocSlot sl = assoc_slot(a);
+    if (blockIdx.x * PF_BLOCK >= sl.n) return;
+    scan += sl.qoff; nn5 += 5 * sl.woff; d4 += sl.woff;
+    o_pt += sl.woff; if (!BATCH) o_plane += sl.woff; o_score += sl.woff; o_flag += sl.woff; o_lpos += sl.woff; o_bcount += sl.boff;
+    const bool qlive = i < sl.n;
     const float4 pl = scan[qlive ? i : 0];
     const double pin[3] = {(double)pl.x, (double)pl.y, (double)pl.z};
     double po[3];
-    a_qrot(a.q, pin, po);
-    const float px = (float)(po[0] + a.t[0]), py = (float)(po[1] + a.t[1]), pz = (float)(po[2] + a.t[2]);
+    a_qrot(sl.q, pin, po);
+    const float px = (float)(po[0] + sl.t[0]), py = (float)(po[1] + sl.t[1]), pz = (float)(po[2] + sl.t[2]);
     int mp5[5], mi[5];
     float md4 = FLT_MAX;
     float4 nbp[5];
@@ -469,9 +541,15 @@ __global__ __launch_bounds__(PF_BLOCK) void k_plane_fit(const AssocArgs a, const
 }
 
 // order-preserving compaction: single-workgroup exclusive scan of the flags, then scatter
-__global__ __launch_bounds__(1024) void k_scan_flags(const int* __restrict__ flag, int n, int* __restrict__ pos, int* __restrict__ total) {
+__global__ __launch_bounds__(1024) void k_scan_flags(const int* __restrict__ flag, int n, int* __restrict__ pos, int* __restrict__ total,
+                                                     const int* __restrict__ win_counts, const int b_stride) {
     __shared__ int sums[1024];
     const int tid = threadIdx.x;
+    if (win_counts) {                      // window mode: one workgroup per keyframe slot
+        const int k = blockIdx.x;
+        n = (win_counts[k] + PF_BLOCK - 1) / PF_BLOCK;
+        flag += (size_t)k * b_stride; pos += (size_t)k * b_stride; total += k;
+    }
     const int chunk = (n + 1023) / 1024;
     const int beg = tid * chunk, end = min(n, beg + chunk);
     int s = 0;
@@ -491,8 +569,15 @@ __global__ __launch_bounds__(1024) void k_scan_flags(const int* __restrict__ fla
 
 __global__ void k_compact(const int* __restrict__ flag, const int* __restrict__ lpos, const int* __restrict__ boff, int n,
                           const float4* __restrict__ q_pt, const float4* __restrict__ q_plane, const double* __restrict__ q_score,
-                          float4* __restrict__ o_pt, float4* __restrict__ o_plane, double* __restrict__ o_score) {
+                          float4* __restrict__ o_pt, float4* __restrict__ o_plane, double* __restrict__ o_score,
+                          const int* __restrict__ win_counts, const int q_stride, const int w_stride, const int b_stride) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (win_counts) {
+        const size_t k = blockIdx.y;
+        n = win_counts[k];
+        flag += k * w_stride; lpos += k * w_stride; boff += k * b_stride; q_pt += k * w_stride; q_plane += k * w_stride; q_score += k * w_stride;
+        o_pt += k * q_stride; o_plane += k * q_stride; o_score += k * q_stride;
+    }
     if (i >= n || !flag[i]) return;
     const int p = boff[i / PF_BLOCK] + lpos[i];
     o_pt[p] = q_pt[i]; o_plane[p] = q_plane[i]; o_score[p] = q_score[i];
@@ -511,15 +596,20 @@ int glio_assoc_create(glio_ctx* c) {
     w->table_cap = next_pow2(2 * mm);
     const int cap = c->cap;
 #define AALLOC(ptr, bytes) do { if (hipMalloc((void**)&(ptr), (size_t)(bytes)) != hipSuccess) { glio_set_error("hipMalloc failed in assoc_create"); return GLIO_E_HIP; } } while (0)
-    AALLOC(w->d_keys, (size_t)w->table_cap * 8); AALLOC(w->d_cell_count, (size_t)w->table_cap * 4);
+    w->cap_eff = w->table_cap;
+    AALLOC(w->d_keys, (size_t)w->table_cap * 8); AALLOC(w->d_ent, (size_t)w->table_cap * 16); AALLOC(w->d_cell_count, (size_t)w->table_cap * 4);
     AALLOC(w->d_cell_start, (size_t)w->table_cap * 4); AALLOC(w->d_cell_fill, (size_t)w->table_cap * 4);
     AALLOC(w->d_pt_slot, (size_t)mm * 4); AALLOC(w->d_map_raw, (size_t)mm * 16); AALLOC(c->d_map_sorted, (size_t)mm * 16);
     AALLOC(w->d_total, 4); AALLOC(w->d_count_tmp, 4);
-    AALLOC(w->d_q_pt, (size_t)cap * 16); AALLOC(w->d_q_plane, (size_t)cap * 16); AALLOC(w->d_q_score, (size_t)cap * 8);
-    AALLOC(w->d_q_flag, (size_t)cap * 4); AALLOC(w->d_q_pos, (size_t)cap * 4); AALLOC(w->d_nn, (size_t)cap * 5 * 4);
-    AALLOC(w->d_nn5, (size_t)cap * 5 * 4); AALLOC(w->d_d4, (size_t)cap * 4);
-    AALLOC(w->d_bcount, (size_t)(cap / AQ_PER_BLOCK + 2) * 4); AALLOC(w->d_boff, (size_t)(cap / AQ_PER_BLOCK + 2) * 4);
+    // dense per-query work arrays for ALL W slots (72 B per query): the window association runs the slots in one launch
+    const size_t wc = (size_t)cap * c->W, wb = (size_t)(cap / AQ_PER_BLOCK + 2) * c->W;
+    AALLOC(w->d_q_pt, wc * 16); AALLOC(w->d_q_plane, wc * 16); AALLOC(w->d_q_score, wc * 8);
+    AALLOC(w->d_q_flag, wc * 4); AALLOC(w->d_q_pos, wc * 4); AALLOC(w->d_nn, (size_t)cap * 5 * 4);
+    AALLOC(w->d_nn5, wc * 5 * 4); AALLOC(w->d_d4, wc * 4);
+    AALLOC(w->d_bcount, wb * 4); AALLOC(w->d_boff, wb * 4);
+    AALLOC(w->d_win, (size_t)c->W * 64);
     if (hipHostMalloc((void**)&w->h_count, 16) != hipSuccess) return GLIO_E_HIP;
+    if (hipHostMalloc((void**)&w->h_win, (size_t)c->W * 64) != hipSuccess) return GLIO_E_HIP;
     c->assoc = w;
     c->map_n = 0;
     return GLIO_OK;
@@ -528,21 +618,24 @@ int glio_assoc_create(glio_ctx* c) {
 void glio_assoc_destroy(glio_ctx* c) {
     AssocWork* w = c->assoc;
     if (!w) return;
-    void* ptrs[] = {w->d_keys, w->d_cell_count, w->d_cell_start, w->d_cell_fill, w->d_pt_slot, w->d_map_raw, c->d_map_sorted, w->d_total,
-                    w->d_count_tmp, w->d_q_pt, w->d_q_plane, w->d_q_score, w->d_q_flag, w->d_q_pos, w->d_nn, w->d_nn5, w->d_d4, w->d_bcount, w->d_boff};
+    void* ptrs[] = {w->d_keys, w->d_ent, w->d_cell_count, w->d_cell_start, w->d_cell_fill, w->d_pt_slot, w->d_map_raw, c->d_map_sorted, w->d_total,
+                    w->d_count_tmp, w->d_q_pt, w->d_q_plane, w->d_q_score, w->d_q_flag, w->d_q_pos, w->d_nn, w->d_nn5, w->d_d4, w->d_bcount, w->d_boff, w->d_win};
     for (void* p : ptrs) if (p) hipFree(p);
     hipHostFree(w->h_count);
+    if (w->h_win) hipHostFree(w->h_win);
     delete w;
     c->assoc = nullptr;
 }
 
 static void enqueue_build(glio_ctx* c, int n) {
     AssocWork* w = c->assoc;
-    const int cap = w->table_cap;
-    hipLaunchKernelGGL(k_hash_clear, dim3((cap + 255) / 256), dim3(256), 0, c->stream, w->d_keys, w->d_cell_count, w->d_cell_fill, cap, w->d_total);
+    int cap = next_pow2(2 * (n > 512 ? n : 512));          // sized for THIS map: a smaller table stays in L2
+    if (cap > w->table_cap) cap = w->table_cap;
+    w->cap_eff = cap;
+    hipLaunchKernelGGL(k_hash_clear, dim3((cap + 255) / 256), dim3(256), 0, c->stream, w->d_keys, w->d_cell_count, w->d_cell_fill, cap, w->d_total, w->d_ent);
     if (n == 0) return;
     hipLaunchKernelGGL(k_hash_insert, dim3((n + 255) / 256), dim3(256), 0, c->stream, w->d_map_raw, n, w->inv_cell, w->d_keys, w->d_cell_count, w->d_pt_slot, cap);
-    hipLaunchKernelGGL(k_cell_alloc, dim3((cap + 255) / 256), dim3(256), 0, c->stream, w->d_cell_count, w->d_cell_start, cap, w->d_total);
+    hipLaunchKernelGGL(k_cell_alloc, dim3((cap + 255) / 256), dim3(256), 0, c->stream, w->d_cell_count, w->d_cell_start, cap, w->d_total, w->d_keys, w->d_ent);
     hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, c->stream, w->d_map_raw, n, w->d_pt_slot, w->d_cell_start, w->d_cell_fill, c->d_map_sorted);
 }
 
@@ -576,21 +669,55 @@ static void enqueue_assoc(glio_ctx* c, int slot, const double q[4], const double
     for (int k = 0; k < 3; ++k) a.t[k] = t[k];
     a.inv_cell = w->inv_cell; a.kd_max_radius = c->opts.kd_max_radius; a.weight_gate = c->opts.weight_gate;
     a.surf_dist_thres = c->opts.surf_dist_thres; a.lidar_const = c->opts.lidar_const;
-    a.n = n; a.table_cap = w->table_cap; a.unit_scores = c->opts.unit_scores;
+    a.n = n; a.table_cap = w->cap_eff; a.unit_scores = c->opts.unit_scores;
+    a.win_poses = nullptr; a.win_counts = nullptr; a.q_stride = a.w_stride = a.b_stride = 0;
     const size_t off = (size_t)slot * c->cap;
     const int nblk = (n + PF_BLOCK - 1) / PF_BLOCK;
     if (n > 0) {
-        hipLaunchKernelGGL(k_knn5, dim3((n + AQ_PER_BLOCK - 1) / AQ_PER_BLOCK), dim3(256), 0, c->stream, a, c->d_scan + off, c->d_map_sorted, w->d_keys,
-                           w->d_cell_start, w->d_cell_count, w->d_nn5, w->d_d4);
+        hipLaunchKernelGGL(k_knn5, dim3((n + AQ_PER_BLOCK - 1) / AQ_PER_BLOCK), dim3(256), 0, c->stream, a, c->d_scan + off, c->d_map_sorted, w->d_ent,
+                           w->d_nn5, w->d_d4);
         hipLaunchKernelGGL(k_plane_fit<false>, dim3(nblk), dim3(PF_BLOCK), 0, c->stream, a, c->d_scan + off, c->d_map_sorted, w->d_nn5, w->d_d4,
                            w->d_q_pt, w->d_q_plane, w->d_q_score, w->d_q_flag, w->d_q_pos, w->d_bcount, want_nn ? w->d_nn : nullptr,
                            (const float4*)nullptr, (double*)nullptr);
     }
-    hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(1024), 0, c->stream, w->d_bcount, nblk, w->d_boff, c->d_count + slot);
+    hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(1024), 0, c->stream, w->d_bcount, nblk, w->d_boff, c->d_count + slot, (const int*)nullptr, 0);
     if (n > 0) {
         hipLaunchKernelGGL(k_compact, dim3((n + 255) / 256), dim3(256), 0, c->stream, w->d_q_flag, w->d_q_pos, w->d_boff, n, w->d_q_pt,
-                           w->d_q_plane, w->d_q_score, c->d_pts + off, c->d_planes + off, c->d_scores + off);
+                           w->d_q_plane, w->d_q_score, c->d_pts + off, c->d_planes + off, c->d_scores + off, (const int*)nullptr, 0, 0, 0);
     }
+}
+
+// all W slots in four launches: blockIdx.y = slot
+static int enqueue_assoc_window(glio_ctx* c, const double* quats, const double* trans) {
+    AssocWork* w = c->assoc;
+    const int W = c->W;
+    int maxn = 0;
+    for (int s = 0; s < W; ++s) {
+        for (int k = 0; k < 4; ++k) w->h_win[7 * s + k] = quats[4 * s + k];
+        for (int k = 0; k < 3; ++k) w->h_win[7 * s + 4 + k] = trans[3 * s + k];
+        reinterpret_cast<int*>(w->h_win + 7 * W)[s] = c->h_scan_count[s];
+        if (c->h_scan_count[s] > maxn) maxn = c->h_scan_count[s];
+    }
+    GLIO_HIP_CHECK(hipMemcpyAsync(w->d_win, w->h_win, (size_t)W * 60, hipMemcpyHostToDevice, c->stream));
+    AssocArgs a;
+    memset(&a, 0, sizeof a);
+    a.inv_cell = w->inv_cell; a.kd_max_radius = c->opts.kd_max_radius; a.weight_gate = c->opts.weight_gate;
+    a.surf_dist_thres = c->opts.surf_dist_thres; a.lidar_const = c->opts.lidar_const;
+    a.n = 0; a.table_cap = w->cap_eff; a.unit_scores = c->opts.unit_scores;
+    a.win_poses = w->d_win; a.win_counts = reinterpret_cast<const int*>(w->d_win + 7 * W);
+    a.q_stride = c->cap; a.w_stride = c->cap; a.b_stride = c->cap / AQ_PER_BLOCK + 2;
+    if (maxn > 0) {
+        hipLaunchKernelGGL(k_knn5, dim3((maxn + AQ_PER_BLOCK - 1) / AQ_PER_BLOCK, W), dim3(256), 0, c->stream, a, c->d_scan, c->d_map_sorted, w->d_ent,
+                           w->d_nn5, w->d_d4);
+        hipLaunchKernelGGL(k_plane_fit<false>, dim3((maxn + PF_BLOCK - 1) / PF_BLOCK, W), dim3(PF_BLOCK), 0, c->stream, a, c->d_scan, c->d_map_sorted,
+                           w->d_nn5, w->d_d4, w->d_q_pt, w->d_q_plane, w->d_q_score, w->d_q_flag, w->d_q_pos, w->d_bcount, (int*)nullptr,
+                           (const float4*)nullptr, (double*)nullptr);
+    }
+    hipLaunchKernelGGL(k_scan_flags, dim3(W), dim3(1024), 0, c->stream, w->d_bcount, 0, w->d_boff, c->d_count, a.win_counts, a.b_stride);
+    if (maxn > 0)
+        hipLaunchKernelGGL(k_compact, dim3((maxn + 255) / 256, W), dim3(256), 0, c->stream, w->d_q_flag, w->d_q_pos, w->d_boff, 0, w->d_q_pt,
+                           w->d_q_plane, w->d_q_score, c->d_pts, c->d_planes, c->d_scores, a.win_counts, a.q_stride, a.w_stride, a.b_stride);
+    return GLIO_OK;
 }
 
 int glio_assoc_run(glio_ctx* c, int slot, const double q[4], const double t[3], int* out_count) {
@@ -643,7 +770,7 @@ int glio_assoc_run_window(glio_ctx* c, const double* quats, const double* trans,
     AssocWork* w = c->assoc;
     if (!w) return GLIO_E_STATE;
     if (c->map_n <= 0) { glio_set_error("no map set"); return GLIO_E_STATE; }
-    for (int s = 0; s < c->W; ++s) enqueue_assoc(c, s, quats + 4 * s, trans + 3 * s, c->h_scan_count[s], 0);
+    { const int rc = enqueue_assoc_window(c, quats, trans); if (rc != GLIO_OK) return rc; }
     GLIO_HIP_CHECK(hipGetLastError());
     GLIO_HIP_CHECK(hipMemcpyAsync(c->h_count, c->d_count, (size_t)c->W * 4, hipMemcpyDeviceToHost, c->stream));
     GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -693,8 +820,8 @@ void glio_assoc_time_hooks(glio_ctx* c, int which, int reps, float* ms) {
 // trip between pairs), which yields exactly the pair-major constraint arrays K8 (batch_kernels.hip) consumes.
 // ================================================================================================
 struct FrameHash {
-    int n, table_cap;
-    unsigned long long* d_keys; int* d_cell_count; int* d_cell_start; int* d_cell_fill; int* d_pt_slot;
+    int n, table_cap, cap_eff;
+    unsigned long long* d_keys; int4* d_ent; int* d_cell_count; int* d_cell_start; int* d_cell_fill; int* d_pt_slot;
     float4* d_sorted;
 };
 struct glio_bassoc {
@@ -791,7 +918,8 @@ int glio_bassoc_create(int device, int K, int max_points_per_frame, int64_t max_
     for (int k = 0; k < K; ++k) {
         FrameHash& f = b->frames[k];
         f.table_cap = tc;
-        BA_CHECK(hipMalloc((void**)&f.d_keys, (size_t)tc * 8)); BA_CHECK(hipMalloc((void**)&f.d_cell_count, (size_t)tc * 4));
+        BA_CHECK(hipMalloc((void**)&f.d_keys, (size_t)tc * 8)); BA_CHECK(hipMalloc((void**)&f.d_ent, (size_t)tc * 16));
+        BA_CHECK(hipMalloc((void**)&f.d_cell_count, (size_t)tc * 4));
         BA_CHECK(hipMalloc((void**)&f.d_cell_start, (size_t)tc * 4)); BA_CHECK(hipMalloc((void**)&f.d_cell_fill, (size_t)tc * 4));
         BA_CHECK(hipMalloc((void**)&f.d_pt_slot, cap * 4)); BA_CHECK(hipMalloc((void**)&f.d_sorted, cap * 16));
     }
@@ -813,7 +941,7 @@ void glio_bassoc_destroy(glio_bassoc* b) {
     hipStreamSynchronize(b->stream);
     for (int k = 0; k < b->K; ++k) {
         FrameHash& f = b->frames[k];
-        void* p[] = {f.d_keys, f.d_cell_count, f.d_cell_start, f.d_cell_fill, f.d_pt_slot, f.d_sorted};
+        void* p[] = {f.d_keys, f.d_ent, f.d_cell_count, f.d_cell_start, f.d_cell_fill, f.d_pt_slot, f.d_sorted};
         for (void* q : p) if (q) hipFree(q);
     }
     void* p[] = {b->d_nn5, b->d_d4, b->d_local, b->d_global, b->d_total, b->d_q_cp, b->d_q_nc, b->d_q_score, b->d_q_flag, b->d_q_pos, b->d_bcount, b->d_boff,
@@ -855,13 +983,15 @@ int glio_bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const int3
     for (int k = 0; k < b->K; ++k) {
         if (!need[k]) continue;
         FrameHash& f = b->frames[k];
-        const int n = b->h_n[k], tc = f.table_cap;
-        f.n = n;
-        hipLaunchKernelGGL(k_hash_clear, dim3((tc + 255) / 256), dim3(256), 0, b->stream, f.d_keys, f.d_cell_count, f.d_cell_fill, tc, b->d_total);
+        const int n = b->h_n[k];
+        int tc = next_pow2(2 * (n > 512 ? n : 512));
+        if (tc > f.table_cap) tc = f.table_cap;
+        f.n = n; f.cap_eff = tc;
+        hipLaunchKernelGGL(k_hash_clear, dim3((tc + 255) / 256), dim3(256), 0, b->stream, f.d_keys, f.d_cell_count, f.d_cell_fill, tc, b->d_total, f.d_ent);
         if (n == 0) continue;
         hipLaunchKernelGGL(k_transform_cloud, dim3((n + 255) / 256), dim3(256), 0, b->stream, b->d_local + (size_t)k * b->cap, n, b->d_poses + 7 * k, b->d_global);
         hipLaunchKernelGGL(k_hash_insert, dim3((n + 255) / 256), dim3(256), 0, b->stream, b->d_global, n, b->inv_cell, f.d_keys, f.d_cell_count, f.d_pt_slot, tc);
-        hipLaunchKernelGGL(k_cell_alloc, dim3((tc + 255) / 256), dim3(256), 0, b->stream, f.d_cell_count, f.d_cell_start, tc, b->d_total);
+        hipLaunchKernelGGL(k_cell_alloc, dim3((tc + 255) / 256), dim3(256), 0, b->stream, f.d_cell_count, f.d_cell_start, tc, b->d_total, f.d_keys, f.d_ent);
         hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, b->stream, b->d_global, n, f.d_pt_slot, f.d_cell_start, f.d_cell_fill, f.d_sorted);
     }
     // (2) the pairs, in the caller's (ci, cj) order
@@ -873,11 +1003,12 @@ int glio_bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const int3
         for (int k = 0; k < 3; ++k) a.t[k] = poses[7 * ci + k];
         for (int k = 0; k < 4; ++k) a.q[k] = poses[7 * ci + 3 + k];
         a.inv_cell = b->inv_cell; a.kd_max_radius = 1.5; a.weight_gate = 0.3; a.surf_dist_thres = 0.18; a.lidar_const = 2.5;   // :3839,3874,3863,3885
-        a.n = n; a.table_cap = f.table_cap; a.unit_scores = 0;
+        a.n = n; a.table_cap = f.cap_eff; a.unit_scores = 0;
+        a.win_poses = nullptr; a.win_counts = nullptr; a.q_stride = a.w_stride = a.b_stride = 0;
         const int nblk = (n + PF_BLOCK - 1) / PF_BLOCK;
         if (n > 0) {
             hipLaunchKernelGGL(k_knn5, dim3((n + AQ_PER_BLOCK - 1) / AQ_PER_BLOCK), dim3(256), 0, b->stream, a, b->d_local + (size_t)ci * b->cap, f.d_sorted,
-                               f.d_keys, f.d_cell_start, f.d_cell_count, b->d_nn5, b->d_d4);
+                               f.d_ent, b->d_nn5, b->d_d4);
             hipLaunchKernelGGL(k_plane_fit<true>, dim3(nblk), dim3(PF_BLOCK), 0, b->stream, a, b->d_local + (size_t)ci * b->cap, f.d_sorted, b->d_nn5, b->d_d4,
                                b->d_q_cp, (float4*)nullptr, b->d_q_score, b->d_q_flag, b->d_q_pos, b->d_bcount, (int*)nullptr,
                                b->d_local + (size_t)cj * b->cap, b->d_q_nc);

@@ -701,13 +701,16 @@ __global__ __launch_bounds__(256) void k_assemble(const AsmArgs a) {
     // O(1) lookup tables: IMU edge that starts at a slot, GNSS group of a slot pair
     __shared__ short imap[GLIO_MAX_WINDOW];
     __shared__ short gmap[GLIO_MAX_WINDOW * GLIO_MAX_WINDOW];
-    for (int k = threadIdx.x; k < W; k += blockDim.x) imap[k] = -1;
+    __shared__ short gsa[GLIO_MAX_WINDOW * GLIO_MAX_WINDOW], gsb[GLIO_MAX_WINDOW * GLIO_MAX_WINDOW];   // slots of every GNSS group: the loops
+    for (int k = threadIdx.x; k < W; k += blockDim.x) imap[k] = -1;                                       // below must not chase them in global memory
     for (int k = threadIdx.x; k < W * W; k += blockDim.x) gmap[k] = -1;
     __syncthreads();
     for (int k = threadIdx.x; k < a.n_imu; k += blockDim.x) imap[imu[k].slot_a] = (short)k;
     for (int k = threadIdx.x; k < a.n_groups; k += blockDim.x) {
-        gmap[gn[k].slot_a * W + gn[k].slot_b] = (short)k;
-        gmap[gn[k].slot_b * W + gn[k].slot_a] = (short)k;
+        const int sa = gn[k].slot_a, sb = gn[k].slot_b;
+        gsa[k] = (short)sa; gsb[k] = (short)sb;
+        gmap[sa * W + sb] = (short)k;
+        gmap[sb * W + sa] = (short)k;
     }
     __syncthreads();
     // rows are dealt to workgroups, columns to lanes (coalesced stores, no integer division per entry)
@@ -722,8 +725,8 @@ __global__ __launch_bounds__(256) void k_assemble(const AsmArgs a) {
                     if (e0 >= 0) s += imu[e0].g[lc];
                     if (e1 >= 0 && imu[e1].slot_b == sc) s += imu[e1].g[15 + lc];
                     for (int k = 0; k < a.n_groups; ++k) {
-                        if (gn[k].slot_a == sc) s += gn[k].g[lc];
-                        else if (gn[k].slot_b == sc) s += gn[k].g[15 + lc];
+                        if (gsa[k] == sc) s += gn[k].g[lc];
+                        else if (gsb[k] == sc) s += gn[k].g[15 + lc];
                     }
                     if (a.has_prior) { const int pi = a.prior_index[c]; if (pi >= 0) s += pg[pi]; }
                 } else s = dd[c - np15].g;
@@ -756,11 +759,11 @@ __global__ __launch_bounds__(256) void k_assemble(const AsmArgs a) {
                     }
                     if (sr != sc) {
                         const int k = gmap[sr * W + sc];
-                        if (k >= 0) s += gn[k].H[((sr == gn[k].slot_a ? 0 : 15) + lr) * GLIO_PAIR_DIM + (sc == gn[k].slot_a ? 0 : 15) + lc];
+                        if (k >= 0) s += gn[k].H[((sr == gsa[k] ? 0 : 15) + lr) * GLIO_PAIR_DIM + (sc == gsa[k] ? 0 : 15) + lc];
                     } else {
                         for (int k = 0; k < a.n_groups; ++k) {                 // diagonal slot block: every group touching sr
-                            if (gn[k].slot_a == sr) s += gn[k].H[lr * GLIO_PAIR_DIM + lc];
-                            else if (gn[k].slot_b == sr) s += gn[k].H[(15 + lr) * GLIO_PAIR_DIM + 15 + lc];
+                            if (gsa[k] == sr) s += gn[k].H[lr * GLIO_PAIR_DIM + lc];
+                            else if (gsb[k] == sr) s += gn[k].H[(15 + lr) * GLIO_PAIR_DIM + 15 + lc];
                         }
                     }
                     if (pi >= 0) { const int pj = a.prior_index[c]; if (pj >= 0) s += pH[(size_t)pi * a.np + pj]; }
@@ -768,7 +771,7 @@ __global__ __launch_bounds__(256) void k_assemble(const AsmArgs a) {
                     const int ep = c - np15;
                     if (dd[ep].used) {
                         const int gi = dd[ep].group;
-                        const int sa = gn[gi].slot_a, sb = gn[gi].slot_b;
+                        const int sa = gsa[gi], sb = gsb[gi];
                         if (sr == sa || sr == sb) { const int k12 = dop_local12(sr == sb && sr != sa, lr); if (k12 >= 0) s = dd[ep].c[k12]; }
                     }
                 }
@@ -778,7 +781,7 @@ __global__ __launch_bounds__(256) void k_assemble(const AsmArgs a) {
             const int ep = r - np15;
             const bool used = dd[ep].used != 0;
             const int gi = used ? dd[ep].group : 0;
-            const int sa = used ? gn[gi].slot_a : -1, sb = used ? gn[gi].slot_b : -1;
+            const int sa = used ? gsa[gi] : -1, sb = used ? gsb[gi] : -1;
             for (int c = threadIdx.x; c < n; c += blockDim.x) {
                 double s = 0;
                 if (c >= np15) { if (c == r) s = dd[ep].h; }
@@ -790,13 +793,15 @@ __global__ __launch_bounds__(256) void k_assemble(const AsmArgs a) {
             }
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blockIdx.x == 0 && threadIdx.x < 64) {       // total cost: every term fetched by its own lane, fixed-shape wave reduction
+        const int l = threadIdx.x;
         double cs = 0;
-        for (int k = 0; k < W; ++k) cs += lb[k * GLIO_LIDAR_ACC + 27];
-        for (int k = 0; k < a.n_imu; ++k) cs += imu[k].cost;
-        for (int k = 0; k < a.n_groups; ++k) cs += gn[k].cost;
-        if (a.has_prior) cs += a.pcost[which];
-        *(which ? a.c1 : a.c0) = cs;
+        for (int k = l; k < W; k += 64) cs += lb[k * GLIO_LIDAR_ACC + 27];
+        for (int k = l; k < a.n_imu; k += 64) cs += imu[k].cost;
+        for (int k = l; k < a.n_groups; k += 64) cs += gn[k].cost;
+        if (l == 0 && a.has_prior) cs += a.pcost[which];
+        cs = wave_sum(cs);
+        if (l == 0) *(which ? a.c1 : a.c0) = cs;
     }
 }
 
