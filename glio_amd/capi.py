@@ -143,13 +143,30 @@ class Context:
         n = cnt.value
         return pts[:n].copy(), planes[:n].copy(), scores[:n].copy()
 
-    def set_imu(self, preints, slots=None):
+    @staticmethod
+    def marshal_imu(preints, slots=None):
+        """The C arrays glio_set_imu takes (a C++ caller owns these natively; Python pays ~0.5 ms to build them)."""
         n = len(preints)
         arr = T.preint_array(n)
         for k, p in enumerate(preints):
             synth.fill_preint(arr[k], p)
         slots = np.arange(max(n, 1), dtype=np.int32) if slots is None else np.ascontiguousarray(slots, np.int32)
+        return n, arr, slots
+
+    @staticmethod
+    def marshal_gnss(frame, dd, dop):
+        return frame, len(dd), (T.GlioDdPsr * max(len(dd), 1))(*dd), len(dop), (T.GlioDoppler * max(len(dop), 1))(*dop)
+
+    def set_imu_marshalled(self, m):
+        n, arr, slots = m
         _check(load().glio_set_imu(self._h, n, arr, T.iptr(slots)))
+
+    def set_gnss_marshalled(self, m):
+        frame, ndd, dd_arr, ndop, dop_arr = m
+        _check(load().glio_set_gnss(self._h, C.byref(frame) if frame is not None else None, ndd, dd_arr, ndop, dop_arr))
+
+    def set_imu(self, preints, slots=None):
+        self.set_imu_marshalled(self.marshal_imu(preints, slots))
 
     def set_prior(self, prior):
         ps = synth.prior_struct(prior)
@@ -157,9 +174,7 @@ class Context:
         _check(load().glio_set_prior(self._h, C.byref(ps)))
 
     def set_gnss(self, frame, dd, dop):
-        dd_arr = (T.GlioDdPsr * max(len(dd), 1))(*dd)
-        dop_arr = (T.GlioDoppler * max(len(dop), 1))(*dop)
-        _check(load().glio_set_gnss(self._h, C.byref(frame) if frame is not None else None, len(dd), dd_arr, len(dop), dop_arr))
+        self.set_gnss_marshalled(self.marshal_gnss(frame, dd, dop))
 
     def load_window(self, win, corr=None, use_gnss=True, use_prior=True, use_imu=True):
         """Upload a synth.Window: correspondences (pre-made, parity hook) + all small factors."""

@@ -164,6 +164,7 @@ void glio_destroy(glio_ctx* c) {
                     c->arrow.d_ep_slots, c->arrow.d_ep_off, c->arrow.d_ep_list, c->arrow.d_Y, c->arrow.d_Lblk, c->arrow.d_Sp, c->arrow.d_z, c->arrow.d_flag, c->arrow.d_dbg};
     for (void* p : ptrs) if (p) hipFree(p);
     hipHostFree(c->h_status); hipHostFree(c->h_xbuf); hipHostFree((void*)c->h_progress);
+    if (c->h_stage) hipHostFree(c->h_stage);
     hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
     for (size_t i = 0; i < g_extras.size(); ++i)
         if (g_extras[i].first == c) {
@@ -328,6 +329,30 @@ static bool digest_edge(const glio_preint* p, int slot, ImuEdgeDev* e) {
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------- pinned upload arena
+// A set_* call stages every table in pinned memory and enqueues asynchronous copies; the caller synchronises once.
+static int stage_reserve(glio_ctx* c, size_t bytes) {
+    c->h_stage_used = 0;
+    if (bytes <= c->h_stage_cap) return GLIO_OK;
+    GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->h_stage) hipHostFree(c->h_stage);
+    c->h_stage = nullptr; c->h_stage_cap = 0;
+    const size_t cap = bytes * 2 + 4096;
+    GLIO_HIP_CHECK(hipHostMalloc((void**)&c->h_stage, cap));
+    c->h_stage_cap = cap;
+    return GLIO_OK;
+}
+static int stage_upload(glio_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return GLIO_OK;
+    const size_t off = (c->h_stage_used + 63) & ~(size_t)63;
+    if (off + bytes > c->h_stage_cap) { glio_set_error("upload arena overflow"); return GLIO_E_STATE; }
+    memcpy(c->h_stage + off, src, bytes);
+    c->h_stage_used = off + bytes;
+    GLIO_HIP_CHECK(hipMemcpyAsync(dst, c->h_stage + off, bytes, hipMemcpyHostToDevice, c->stream));
+    return GLIO_OK;
+}
+#define STAGE(dst, src, bytes) do { const int rc_ = stage_upload(c, (dst), (src), (bytes)); if (rc_ != GLIO_OK) return rc_; } while (0)
+
 int glio_set_imu(glio_ctx* c, int n_edges, const glio_preint* edges, const int32_t* slot_i) {
     if (!c || n_edges < 0 || n_edges > c->W - 1 + (c->W == 1)) { glio_set_error("bad IMU edge count"); return GLIO_E_ARG; }
     GLIO_HIP_CHECK(hipSetDevice(c->device));
@@ -336,7 +361,11 @@ int glio_set_imu(glio_ctx* c, int n_edges, const glio_preint* edges, const int32
         if (slot_i[k] < 0 || slot_i[k] + 1 >= c->W) { glio_set_error("IMU edge slot out of range"); return GLIO_E_ARG; }
         if (!digest_edge(&edges[k], slot_i[k], &h[k])) { glio_set_error("IMU covariance not invertible / not SPD"); return GLIO_E_NUMERIC; }
     }
-    if (n_edges) GLIO_HIP_CHECK(hipMemcpy(c->d_imu, h.data(), n_edges * sizeof(ImuEdgeDev), hipMemcpyHostToDevice));
+    if (n_edges) {
+        { const int rc = stage_reserve(c, n_edges * sizeof(ImuEdgeDev) + 64); if (rc != GLIO_OK) return rc; }
+        STAGE(c->d_imu, h.data(), n_edges * sizeof(ImuEdgeDev));
+        GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
     c->n_imu = n_edges;
     extra_of(c)->imu_edge0 = -1;
     for (int k = 0; k < n_edges; ++k) if (slot_i[k] == 0) extra_of(c)->imu_edge0 = k;
@@ -462,34 +491,48 @@ int glio_set_gnss(glio_ctx* c, const glio_gnss_frame* frame, int n_dd, const gli
     // an epoch must belong to exactly one group (one clock-drift unknown per epoch, one bracketing pair)
     { std::vector<int> seen(std::max(1, c->n_ddt_max), 0); for (auto& r : runs) if (seen[r.epoch]++) { glio_set_error("epoch %d appears under two keyframe pairs", r.epoch); return GLIO_E_ARG; } }
     if ((int)groups.size() > W * W) return GLIO_E_ARG;
-    if (c->d_dd) { hipFree(c->d_dd); c->d_dd = nullptr; }
-    if (c->d_dop) { hipFree(c->d_dop); c->d_dop = nullptr; }
-    ALLOC(c->d_dd, sdd.size() * sizeof(glio_dd_psr)); ALLOC(c->d_dop, sdop.size() * sizeof(glio_doppler));
-    if (!sdd.empty()) GLIO_HIP_CHECK(hipMemcpy(c->d_dd, sdd.data(), sdd.size() * sizeof(glio_dd_psr), hipMemcpyHostToDevice));
-    if (!sdop.empty()) GLIO_HIP_CHECK(hipMemcpy(c->d_dop, sdop.data(), sdop.size() * sizeof(glio_doppler), hipMemcpyHostToDevice));
-    if (!groups.empty()) GLIO_HIP_CHECK(hipMemcpy(c->d_groups, groups.data(), groups.size() * sizeof(GnssGroup), hipMemcpyHostToDevice));
-    {   // structure tables of the arrow solver: which keyframe slots each clock-drift epoch couples
-        const int ne = std::max(1, c->n_ddt_max);
-        std::vector<int2> es(ne, make_int2(-1, -1));
-        std::vector<std::vector<int>> per(W);
-        c->arrow.gnss_ok = 1; c->arrow.max_epoch = -1; c->arrow.gnss_chain = 1;
-        for (auto& g : groups) if (std::abs(g.slot_i - g.slot_j) != 1) c->arrow.gnss_chain = 0;       // a DD pair that skips a keyframe breaks the chain
-        for (auto& r : runs) {
-            c->arrow.max_epoch = std::max(c->arrow.max_epoch, r.epoch);
-            const GnssGroup& g = groups[r.group];
-            const int lo = std::min(g.slot_i, g.slot_j), hi = std::max(g.slot_i, g.slot_j);
-            es[r.epoch] = make_int2(lo, hi);
-            per[lo].push_back(r.epoch); per[hi].push_back(r.epoch);
-            if (hi - lo != 1) c->arrow.gnss_ok = 0;       // velocity coupling between non-adjacent keyframes: chain is not tridiagonal
-        }
-        std::vector<int> off(W + 1, 0), list;
-        for (int i = 0; i < W; ++i) { off[i + 1] = off[i] + (int)per[i].size(); list.insert(list.end(), per[i].begin(), per[i].end()); }
-        GLIO_HIP_CHECK(hipMemcpy(c->arrow.d_ep_slots, es.data(), (size_t)ne * sizeof(int2), hipMemcpyHostToDevice));
-        GLIO_HIP_CHECK(hipMemcpy(c->arrow.d_ep_off, off.data(), (W + 1) * 4, hipMemcpyHostToDevice));
-        if (!list.empty()) GLIO_HIP_CHECK(hipMemcpy(c->arrow.d_ep_list, list.data(), list.size() * 4, hipMemcpyHostToDevice));
+    if (sdd.size() > c->dd_cap || !c->d_dd) {
+        GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (c->d_dd) { hipFree(c->d_dd); c->d_dd = nullptr; }
+        c->dd_cap = sdd.size() + sdd.size() / 2 + 16;
+        ALLOC(c->d_dd, c->dd_cap * sizeof(glio_dd_psr));
     }
+    if (sdop.size() > c->dop_cap || !c->d_dop) {
+        GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (c->d_dop) { hipFree(c->d_dop); c->d_dop = nullptr; }
+        c->dop_cap = sdop.size() + sdop.size() / 2 + 16;
+        ALLOC(c->d_dop, c->dop_cap * sizeof(glio_doppler));
+    }
+    // structure tables of the arrow solver: which keyframe slots each clock-drift epoch couples
+    const int ne = std::max(1, c->n_ddt_max);
+    std::vector<int2> es(ne, make_int2(-1, -1));
+    std::vector<std::vector<int>> per(W);
+    c->arrow.gnss_ok = 1; c->arrow.max_epoch = -1; c->arrow.gnss_chain = 1;
+    for (auto& g : groups) if (std::abs(g.slot_i - g.slot_j) != 1) c->arrow.gnss_chain = 0;       // a DD pair that skips a keyframe breaks the chain
+    for (auto& r : runs) {
+        c->arrow.max_epoch = std::max(c->arrow.max_epoch, r.epoch);
+        const GnssGroup& g = groups[r.group];
+        const int lo = std::min(g.slot_i, g.slot_j), hi = std::max(g.slot_i, g.slot_j);
+        es[r.epoch] = make_int2(lo, hi);
+        per[lo].push_back(r.epoch); per[hi].push_back(r.epoch);
+        if (hi - lo != 1) c->arrow.gnss_ok = 0;       // velocity coupling between non-adjacent keyframes: chain is not tridiagonal
+    }
+    std::vector<int> off(W + 1, 0), list;
+    for (int i = 0; i < W; ++i) { off[i + 1] = off[i] + (int)per[i].size(); list.insert(list.end(), per[i].begin(), per[i].end()); }
     GnssDevExtra* ex = glio_extra(c);
-    if (!runs.empty()) GLIO_HIP_CHECK(hipMemcpy(ex->d_runs, runs.data(), runs.size() * sizeof(DopRun), hipMemcpyHostToDevice));
+    {
+        const size_t total = sdd.size() * sizeof(glio_dd_psr) + sdop.size() * sizeof(glio_doppler) + groups.size() * sizeof(GnssGroup) +
+                             (size_t)ne * sizeof(int2) + (W + 1) * 4 + list.size() * 4 + runs.size() * sizeof(DopRun) + 8 * 64;
+        const int rc = stage_reserve(c, total);
+        if (rc != GLIO_OK) return rc;
+    }
+    STAGE(c->d_dd, sdd.data(), sdd.size() * sizeof(glio_dd_psr));
+    STAGE(c->d_dop, sdop.data(), sdop.size() * sizeof(glio_doppler));
+    STAGE(c->d_groups, groups.data(), groups.size() * sizeof(GnssGroup));
+    STAGE(c->arrow.d_ep_slots, es.data(), (size_t)ne * sizeof(int2));
+    STAGE(c->arrow.d_ep_off, off.data(), (size_t)(W + 1) * 4);
+    STAGE(c->arrow.d_ep_list, list.data(), list.size() * 4);
+    STAGE(ex->d_runs, runs.data(), runs.size() * sizeof(DopRun));
     ex->n_runs = (int)runs.size();
     GLIO_HIP_CHECK(hipMemsetAsync(c->d_ddt_blocks, 0, 2 * (size_t)std::max(1, c->n_ddt_max) * sizeof(DdtBlock), c->stream));
     GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
