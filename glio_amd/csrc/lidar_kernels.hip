@@ -73,6 +73,66 @@ __device__ __forceinline__ void lidar_accumulate(const float4 p, const float4 pl
     acc[27] += 0.5 * rho;
 }
 
+__device__ __forceinline__ void k3_reduce_store(const double acc[GLIO_LIDAR_ACC], double* __restrict__ partials, const int kf, const int nb) {
+    // Wave reduction as a value-splitting butterfly: at every halving step a lane keeps one half of its
+    // values and ships the other half to its partner, so 32 (padded) accumulators need 16+8+4+2+1+1 = 32
+    // 64-bit shuffles instead of 28 x 6 = 168, in six dependent rounds.  After the xor-2 round lane L owns
+    // accumulator k = b5 + 2 b4 + 4 b3 + 8 b2 + 16 b1 (b_i = bit i of L); the xor-1 round completes the sum.
+    __shared__ double red[GLIO_K3_THREADS / GLIO_WAVE][32];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double v16[16], v8[8], v4[4], v2[2], v1;
+    {
+        const bool hi = (lane & 32) != 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const double a = acc[2 * i], b = (2 * i + 1 < GLIO_LIDAR_ACC) ? acc[2 * i + 1] : 0.0;
+            const double keep = hi ? b : a, send = hi ? a : b;
+            v16[i] = keep + __shfl_xor(send, 32, 64);
+        }
+    }
+    {
+        const bool hi = (lane & 16) != 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double keep = hi ? v16[2 * i + 1] : v16[2 * i], send = hi ? v16[2 * i] : v16[2 * i + 1];
+            v8[i] = keep + __shfl_xor(send, 16, 64);
+        }
+    }
+    {
+        const bool hi = (lane & 8) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double keep = hi ? v8[2 * i + 1] : v8[2 * i], send = hi ? v8[2 * i] : v8[2 * i + 1];
+            v4[i] = keep + __shfl_xor(send, 8, 64);
+        }
+    }
+    {
+        const bool hi = (lane & 4) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const double keep = hi ? v4[2 * i + 1] : v4[2 * i], send = hi ? v4[2 * i] : v4[2 * i + 1];
+            v2[i] = keep + __shfl_xor(send, 4, 64);
+        }
+    }
+    {
+        const bool hi = (lane & 2) != 0;
+        const double keep = hi ? v2[1] : v2[0], send = hi ? v2[0] : v2[1];
+        v1 = keep + __shfl_xor(send, 2, 64);
+    }
+    v1 += __shfl_xor(v1, 1, 64);
+    if ((lane & 1) == 0) {
+        const int k = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 3) | (((lane >> 1) & 1) << 4);
+        red[wv][k] = v1;
+    }
+    __syncthreads();
+    if (threadIdx.x < GLIO_LIDAR_ACC) {
+        double v = red[0][threadIdx.x];
+#pragma unroll
+        for (int w2 = 1; w2 < GLIO_K3_THREADS / GLIO_WAVE; ++w2) v += red[w2][threadIdx.x];
+        partials[((size_t)kf * nb + blockIdx.x) * GLIO_LIDAR_ACC + threadIdx.x] = v;
+    }
+}
+
 typedef float k3_f4 __attribute__((ext_vector_type(4)));
 template <bool NT> __device__ __forceinline__ float4 k3_load4(const float4* p) {
     if (NT) { const k3_f4 v = __builtin_nontemporal_load(reinterpret_cast<const k3_f4*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
@@ -162,63 +222,94 @@ __global__ __launch_bounds__(GLIO_K3_THREADS) void k_lidar_linearize(
     }
     for (; i < n; i += stride) lidar_accumulate<MARG>(P[i], Q[i], S[i], M, t, lc.tlb, lc.huber, acc, lc.RlbT, q);
 
-    // Wave reduction as a value-splitting butterfly: at every halving step a lane keeps one half of its
-    // values and ships the other half to its partner, so 32 (padded) accumulators need 16+8+4+2+1+1 = 32
-    // 64-bit shuffles instead of 28 x 6 = 168, in six dependent rounds.  After the xor-2 round lane L owns
-    // accumulator k = b5 + 2 b4 + 4 b3 + 8 b2 + 16 b1 (b_i = bit i of L); the xor-1 round completes the sum.
-    __shared__ double red[GLIO_K3_THREADS / GLIO_WAVE][32];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    double v16[16], v8[8], v4[4], v2[2], v1;
-    {
-        const bool hi = (lane & 32) != 0;
+    k3_reduce_store(acc, partials, kf, nb);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3, LDS-DMA form.  The three streams go global -> LDS with `global_load_lds_dwordx4` (no VGPR staging), each
+// wavefront owning a private ring of K3D_STAGES chunks of 64 residuals (1 KiB points + 1 KiB planes + 512 B scores),
+// so a CU keeps (waves x (stages - 1) x 2.5 KiB) of reads in flight regardless of register pressure while the fp64
+// arithmetic of the chunk that has landed runs.  Chunks are dealt round-robin to the waves of a keyframe.  The
+// counter discipline is manual: 3 VMEM operations per chunk, `s_waitcnt vmcnt(3 * chunks still in flight behind
+// this one)` before the ds_reads of a slot, and the slot is re-armed only after those reads have returned.
+// Needs cap % 64 == 0 (16 B aligned score rows, no clamping of the last chunk); other shapes take the register path.
+// ------------------------------------------------------------------------------------------------
+#define K3D_CHUNK_BYTES 2560
+typedef __attribute__((address_space(1))) const void* k3_gptr;
+typedef __attribute__((address_space(3))) void* k3_lptr;
+template <int N> __device__ __forceinline__ void k3_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int STAGES, bool DRAIN = false>
+__global__ __launch_bounds__(GLIO_K3_THREADS) void k_lidar_linearize_dma(
+    const float4* __restrict__ pts, const float4* __restrict__ planes, const double* __restrict__ scores,
+    const int* __restrict__ count, const int cap, const double* __restrict__ x0, const double* __restrict__ x1,
+    const SolverStatus* __restrict__ st, const int use_status, const int fixed_which, const int W,
+    const LidarConst lc, double* __restrict__ partials) {
+    __shared__ __attribute__((aligned(16))) char ring[GLIO_K3_THREADS / GLIO_WAVE][STAGES][K3D_CHUNK_BYTES];
+    int which = fixed_which;
+    if (use_status) {
+        if (st->done || !st->cand_pending) return;
+        which = 1 - st->cur;
+    }
+    const double* __restrict__ x = which ? x1 : x0;
+    const int kf = blockIdx.y, nb = gridDim.x, n = count[kf];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // scalar: the waits below branch on it
+    const int nwaves = nb * (GLIO_K3_THREADS / GLIO_WAVE), wid = blockIdx.x * (GLIO_K3_THREADS / GLIO_WAVE) + wv;
+    const int nchunks = (n + 63) >> 6;
+    const int mine = wid < nchunks ? (nchunks - wid + nwaves - 1) / nwaves : 0;     // chunks wid, wid + nwaves, ...
+    const size_t base = (size_t)kf * cap;
+    const float4* __restrict__ P = pts + base;
+    const float4* __restrict__ Q = planes + base;
+    const double* __restrict__ S = scores + base;
+    char* my = &ring[wv][0][0];
+    auto issue = [&](const int k) {           // chunk number k of this wave -> slot k % STAGES
+        const int c0 = (wid + k * nwaves) << 6;
+        char* dst = my + (k % STAGES) * K3D_CHUNK_BYTES;
+        __builtin_amdgcn_global_load_lds((k3_gptr)(P + c0 + lane), (k3_lptr)dst, 16, 0, 2);
+        __builtin_amdgcn_global_load_lds((k3_gptr)(Q + c0 + lane), (k3_lptr)(dst + 1024), 16, 0, 2);
+        if (lane < 32) __builtin_amdgcn_global_load_lds((k3_gptr)(S + c0 + 2 * lane), (k3_lptr)(dst + 2048), 16, 0, 2);
+    };
+    // per-keyframe constants: the pose loads go out first, the ring's prologue right behind them
+    double q[4], R[9], M[9], t[3];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const double a = acc[2 * i], b = (2 * i + 1 < GLIO_LIDAR_ACC) ? acc[2 * i + 1] : 0.0;
-            const double keep = hi ? b : a, send = hi ? a : b;
-            v16[i] = keep + __shfl_xor(send, 32, 64);
-        }
-    }
-    {
-        const bool hi = (lane & 16) != 0;
+    for (int k = 0; k < 3; ++k) t[k] = x[3 * kf + k];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const double keep = hi ? v16[2 * i + 1] : v16[2 * i], send = hi ? v16[2 * i] : v16[2 * i + 1];
-            v8[i] = keep + __shfl_xor(send, 16, 64);
-        }
-    }
-    {
-        const bool hi = (lane & 8) != 0;
+    for (int k = 0; k < 4; ++k) q[k] = x[3 * W + 4 * kf + k];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const double keep = hi ? v8[2 * i + 1] : v8[2 * i], send = hi ? v8[2 * i] : v8[2 * i + 1];
-            v4[i] = keep + __shfl_xor(send, 8, 64);
-        }
-    }
-    {
-        const bool hi = (lane & 4) != 0;
+    for (int k = 0; k < STAGES; ++k) if (k < mine) issue(k);
+    d_q2R(q, R);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const double keep = hi ? v4[2 * i + 1] : v4[2 * i], send = hi ? v4[2 * i] : v4[2 * i + 1];
-            v2[i] = keep + __shfl_xor(send, 4, 64);
-        }
-    }
-    {
-        const bool hi = (lane & 2) != 0;
-        const double keep = hi ? v2[1] : v2[0], send = hi ? v2[0] : v2[1];
-        v1 = keep + __shfl_xor(send, 2, 64);
-    }
-    v1 += __shfl_xor(v1, 1, 64);
-    if ((lane & 1) == 0) {
-        const int k = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 3) | (((lane >> 1) & 1) << 4);
-        red[wv][k] = v1;
-    }
-    __syncthreads();
-    if (threadIdx.x < GLIO_LIDAR_ACC) {
-        double v = red[0][threadIdx.x];
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int w2 = 1; w2 < GLIO_K3_THREADS / GLIO_WAVE; ++w2) v += red[w2][threadIdx.x];
-        partials[((size_t)kf * nb + blockIdx.x) * GLIO_LIDAR_ACC + threadIdx.x] = v;
+        for (int j = 0; j < 3; ++j)
+            M[i * 3 + j] = R[i * 3 + 0] * lc.RlbT[0 * 3 + j] + R[i * 3 + 1] * lc.RlbT[1 * 3 + j] + R[i * 3 + 2] * lc.RlbT[2 * 3 + j];
+    double acc[GLIO_LIDAR_ACC];
+#pragma unroll
+    for (int k = 0; k < GLIO_LIDAR_ACC; ++k) acc[k] = 0.0;
+
+    for (int k = 0; k < mine; ++k) {
+        const int behind = min(STAGES - 1, mine - 1 - k);        // chunks issued after this one and still in flight
+        if (DRAIN) k3_wait_vm<0>();
+        else if (behind >= 3 && STAGES > 3) k3_wait_vm<9>();
+        else if (behind == 2 && STAGES > 2) k3_wait_vm<6>();
+        else if (behind == 1) k3_wait_vm<3>();
+        else k3_wait_vm<0>();
+        // ds_reads as inline asm: for a C++ LDS load that may alias an LDS-DMA destination the compiler inserts
+        // s_waitcnt vmcnt(0) (it cannot count the ring), which would serialise the whole pipeline
+        const unsigned slot = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(my + (k % STAGES) * K3D_CHUNK_BYTES);
+        k3_f4 pv, plv;
+        double sc;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(pv) : "v"(slot + 16u * lane) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(plv) : "v"(slot + 16u * lane) : "memory");
+        asm volatile("ds_read_b64 %0, %1 offset:2048" : "=v"(sc) : "v"(slot + 8u * lane) : "memory");
+        // the wait names the three results as read-write operands: the compiler sees them live until here, so it can
+        // neither reuse a dead component (p.w) while the read is in flight nor hoist a conversion above the wait
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pv), "+v"(plv), "+v"(sc) : : "memory");   // slot is in registers: it may be re-armed
+        const float4 p = make_float4(pv.x, pv.y, pv.z, pv.w), pl = make_float4(plv.x, plv.y, plv.z, plv.w);
+        if (k + STAGES < mine) issue(k + STAGES);
+        if (((wid + k * nwaves) << 6) + lane < n) lidar_accumulate<false>(p, pl, sc, M, t, lc.tlb, lc.huber, acc, lc.RlbT, q);
     }
+    k3_reduce_store(acc, partials, kf, nb);
 }
 
 // Practical ceiling for K3: the same three streams (16 + 16 + 8 B per residual), same grid, same non-temporal loads,
@@ -265,7 +356,17 @@ void glio_launch_lidar_linearize(glio_ctx* c, int use_status_cand, int which, in
                        c->d_pts, c->d_planes, c->d_scores, c->d_count, c->cap, c->d_x[0], c->d_x[1], \
                        c->d_status, use_status_cand, which, c->W, lc, c->d_lidar_partials)
     if (marg) { K3_LAUNCH_(4, true); return; }
-    switch (c->k3_unroll) {
+#define K3_DMA_(...) hipLaunchKernelGGL((k_lidar_linearize_dma<__VA_ARGS__>), grid, dim3(GLIO_K3_THREADS), 0, c->stream, \
+                       c->d_pts, c->d_planes, c->d_scores, c->d_count, c->cap, c->d_x[0], c->d_x[1], \
+                       c->d_status, use_status_cand, which, c->W, lc, c->d_lidar_partials)
+    if ((c->cap & 63) == 0) {
+        if (c->k3_unroll == 32) { K3_DMA_(2); return; }
+        if (c->k3_unroll == 33) { K3_DMA_(3); return; }
+        if (c->k3_unroll == 34) { K3_DMA_(4); return; }
+        if (c->k3_unroll == 35) { K3_DMA_(3, true); return; }
+    }
+#undef K3_DMA_
+    switch (c->k3_unroll >= 32 && c->k3_unroll <= 35 ? 22 : c->k3_unroll) {
         case 1: K3_LAUNCH_(1, false); break;
         case 2: K3_LAUNCH_(2, false); break;
         case 8: K3_LAUNCH_(8, false); break;

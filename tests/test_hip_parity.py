@@ -77,6 +77,37 @@ def test_linearize_parity_small(hip, po, small_window, small_corr, case):
     ctx.close()
 
 
+@pytest.fixture(scope="module")
+def k3_window():
+    """1024-point scans (capacity a multiple of 64: the LDS-DMA form of K3 applies) with ragged per-keyframe counts."""
+    from glio_amd import synth
+    win = synth.make_window(W=3, pts_per_scan=1024, seed=synth.SEED_BASE + 31)
+    corr = synth.analytic_correspondences(win)
+    corr = [tuple(np.ascontiguousarray(a[: len(c[2]) - 37 * s - 5]) for a in c) for s, c in enumerate(corr)]
+    return win, corr
+
+
+@pytest.mark.parametrize("code", [1, 4, 12, 22, 24, 32, 33, 34])
+def test_lidar_kernel_variants(hip, po, k3_window, code):
+    """Every K3 code path (register batches, non-temporal, software pipelined, LDS-DMA rings of 2/3/4 chunks) against the
+    oracle; the last chunk of a keyframe is partial and the widest geometry leaves wavefronts without work."""
+    win, corr = k3_window
+    kw = dict(use_imu=False, use_gnss=False, use_prior=False)
+    prob = po.Problem(win, corr, **kw)
+    ctx = hip.Context(win.opts)
+    assert ctx.opts.max_points_per_scan % 64 == 0
+    ctx.load_window(win, corr, **kw)
+    st = _state_for(win, False)
+    Ho, go, co = prob.linearize(st)
+    for bpk in (1, 3, 8, 64):
+        assert hip.load().glio_debug_set_k3(ctx._h, bpk, code) == 0
+        Hh, gh, ch = ctx.linearize(st)
+        assert abs(ch - co) <= 1e-10 * abs(co)
+        assert rel_err(gh, go) <= 1e-10
+        assert rel_err(Hh, Ho) <= 1e-10
+    ctx.close()
+
+
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_solve_parity_small(hip, po, small_window, small_corr, case):
     win = small_window
