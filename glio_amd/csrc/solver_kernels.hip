@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256) void k_tr_scale(const TrArgs a) {
 // ------------------------------------------------------------------------------------------------
 // K7c  k_tr_factor
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TR_THREADS) void k_tr_factor(const TrArgs a) {
+__device__ __forceinline__ void tr_factor_body(const TrArgs& a) {
     const int tid = threadIdx.x;
     const int n = a.n;
     double* Bp = reinterpret_cast<double*>(tr_lds);                       // 16 x bp_stride(n)
@@ -628,9 +628,9 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_factor(const TrArgs a) {
 // ------------------------------------------------------------------------------------------------
 // K7d  k_tr_dogleg
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TR_THREADS) void k_tr_dogleg(const TrArgs a) {
-    __shared__ double red[32];
-    __shared__ SolverStatus s;
+__device__ __forceinline__ void tr_dogleg_body(const TrArgs& a) {
+    double* red = reinterpret_cast<double*>(tr_lds);                       // the factorisation's panel buffer is free again
+    SolverStatus& s = *reinterpret_cast<SolverStatus*>(red + 32);
     const int tid = threadIdx.x;
     const int n = a.n, W = a.W;
     if (tid == 0) s = *a.status;
@@ -711,6 +711,14 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_dogleg(const TrArgs a) {
     if (tid == 0) *a.status = s;
 }
 
+
+// K7c + K7d in one launch (one workgroup): the linear solve (or the structured solver's result) and the dogleg /
+// Levenberg-Marquardt step that consumes it
+__global__ __launch_bounds__(TR_THREADS) void k_tr_finish(const TrArgs a) {
+    tr_factor_body(a);
+    __syncthreads();
+    tr_dogleg_body(a);
+}
 
 // ------------------------------------------------------------------------------------------------
 // K7c'  structured ("arrow") factorisation of M = S H S + mu D^2 in the elimination order of tr_perm():
@@ -1491,8 +1499,7 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
         hipLaunchKernelGGL(k_arrow_schur, dim3(T * T), dim3(256), 0, c->stream, r);
         hipLaunchKernelGGL(k_arrow_solve, dim3(1), dim3(TR_THREADS), lds_slv, c->stream, r);
     }
-    hipLaunchKernelGGL(k_tr_factor, dim3(1), dim3(TR_THREADS), glio_tr_step_lds_bytes(a.n), c->stream, a);
-    hipLaunchKernelGGL(k_tr_dogleg, dim3(1), dim3(TR_THREADS), 0, c->stream, a);
+    hipLaunchKernelGGL(k_tr_finish, dim3(1), dim3(TR_THREADS), glio_tr_step_lds_bytes(a.n), c->stream, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1691,7 +1698,7 @@ extern "C" int glio_debug_chol_solve(glio_ctx* c, int n, const double* A, const 
 }
 
 void glio_tr_step_configure(size_t max_lds) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_tr_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_tr_finish), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_test), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_marg_schur), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_arrow_forward), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
