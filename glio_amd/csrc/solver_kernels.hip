@@ -1188,40 +1188,75 @@ __host__ __device__ __forceinline__ size_t chain_lds_doubles(int W, int nd) {
            (size_t)nd + 2 + 2 * ((size_t)nd + 2) + 12;
 }
 
+// 1 / sqrt(d) for a pivot already known to be positive, finite and far from the denormal range (it is a diagonal entry of
+// the Jacobi-scaled, mu-regularised matrix): the hardware estimate and one Newton step in a form that cancels to first
+// order, y = y0 + y0 (1 - d y0^2) / 2, without the library's class checks and rescaling (~5 dependent operations instead
+// of ~12 on the critical path of every pivot)
+__device__ __forceinline__ double pivot_rsqrt(const double d) {
+    const double y0 = __builtin_amdgcn_rsq(d);
+    const double e = fma(-d * y0, y0, 1.0);
+    const double y1 = fma(0.5 * y0, e, y0);
+    const double e1 = fma(-d * y1, y1, 1.0);
+    return fma(0.5 * y1, e1, y1);
+}
+
 template <bool DOWN>
 __device__ __forceinline__ void chain_step15(const int i, const int nb, const bool has_nb, double (&av)[KC_NB], double* Blk, double* Cs, const int lane, bool& bad,
-                                             const int (&pr2)[3], const int (&pj2)[3]) {
+                                             const int (&pr2)[3], const int (&pj2)[3], long long* ph = nullptr) {
+#ifdef GLIO_DEV_STAMPS
+#define CS_CLK(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define CS_PH(k) do { long long t_; CS_CLK(t_); if (ph) ph[k] += t_ - tprev; tprev = t_; } while (0)
+    long long tprev; CS_CLK(tprev);
+#else
+#define CS_PH(k) do { } while (0)
+#endif
     const int r = lane;
+    // lane-varying conditions as one integer limit per lane (j < lim): `a && b || c` on lane-varying operands compiles to
+    // exec-mask branches per element, which cost more than the arithmetic they guard
+    const int lim = r == 30 ? KC_NB : (r < KC_NB ? r + 1 : 0);         // columns of the next block this lane carries
+    const int tri = r < KC_NB ? r + 1 : KC_NB;                          // columns of its own row that are not above the diagonal
     double* Bi = Blk + (size_t)i * KC_BLK;
     double nx[KC_NB];
     {
         const double* Bn = Blk + (size_t)(has_nb ? nb : i) * KC_BLK;
+        // unconditional reads at clamped (always valid) addresses, selected afterwards: the 30 ds_reads go out back to back
         const int row = r < KC_NB ? r : 30;
+        const int rb = (r >= KC_NB && r < 30) ? r : KC_NB;
+        double ld[KC_NB];
 #pragma unroll
-        for (int j = 0; j < KC_NB; ++j) nx[j] = (has_nb && (r < KC_NB || r == 30)) ? Bn[row * KC_RS + j] : 0.0;
-        if (r >= KC_NB && r < 30) {
+        for (int j = 0; j < KC_NB; ++j) nx[j] = Bn[row * KC_RS + j];
 #pragma unroll
-            for (int j = 0; j < KC_NB; ++j) av[j] = has_nb ? (DOWN ? Bn[(KC_NB + j) * KC_RS + (r - KC_NB)] : Bi[r * KC_RS + j]) : 0.0;
-        }
+        for (int j = 0; j < KC_NB; ++j) ld[j] = DOWN ? Bn[(KC_NB + j) * KC_RS + (rb - KC_NB)] : Bi[rb * KC_RS + j];
+        const bool keep_nx = has_nb & (lim > 0);
+        const bool is_b = (r >= KC_NB) & (r < 30);
+#pragma unroll
+        for (int j = 0; j < KC_NB; ++j) nx[j] = keep_nx ? nx[j] : 0.0;
+#pragma unroll
+        for (int j = 0; j < KC_NB; ++j) av[j] = is_b ? (has_nb ? ld[j] : 0.0) : av[j];
     }
+    CS_PH(0);
     double rpv = 0.0;
 #pragma unroll
     for (int j = 0; j < KC_NB; ++j) {
         double djj = readlane_d(av[j], j);
-        if (!(djj > 0.0) || !isfinite(djj)) { bad = true; djj = 1.0; }
-        const double rdj = rsqrt(djj);
-        const double lij = (lane == j) ? djj * rdj : av[j] * rdj;
-        if (lane == j) rpv = rdj;
+        const bool okp = (djj > 0.0) & (djj < 1e300);               // also false for NaN
+        bad |= !okp;
+        djj = okp ? djj : 1.0;
+        const double rdj = pivot_rsqrt(djj);
+        const double lij = av[j] * rdj;                              // lane j: d / sqrt(d) = sqrt(d)
+        rpv = lane == j ? rdj : rpv;
         av[j] = lij;
 #pragma unroll
         for (int c = j + 1; c < KC_NB; ++c) av[c] -= lij * readlane_d(lij, c);
     }
+    CS_PH(1);
     if (r < 31) {
 #pragma unroll
-        for (int j = 0; j < KC_NB; ++j) Bi[r * KC_RS + j] = (r < KC_NB && j > r) ? 0.0 : av[j];
+        for (int j = 0; j < KC_NB; ++j) Bi[r * KC_RS + j] = j < tri ? av[j] : 0.0;
         if (r < KC_NB) Bi[31 * KC_RS + r] = rpv;
     }
     GLIO_WAVE_LDS_SYNC();
+    CS_PH(2);
     if (has_nb) {
         // C[r2][j2] = X[r2] . X[j2]: r2 = 0..14 rows of the next diagonal block (j2 <= r2), r2 = 15 the right-hand side
 #pragma unroll
@@ -1236,14 +1271,19 @@ __device__ __forceinline__ void chain_step15(const int i, const int nb, const bo
             Cs[r2 * KC_RS + j2] = sacc;
         }
         GLIO_WAVE_LDS_SYNC();
-        if (r < KC_NB || r == 30) {
-            const int row = r < KC_NB ? r : 15;
+        CS_PH(3);
+        {
+            const int row = r < KC_NB ? r : 15;              // lanes that hold nothing read row 15 too and discard it
+            double cv[KC_NB];
 #pragma unroll
-            for (int j = 0; j < KC_NB; ++j) if (r == 30 || j <= r) nx[j] -= Cs[row * KC_RS + j];
+            for (int j = 0; j < KC_NB; ++j) cv[j] = Cs[row * KC_RS + j];
+#pragma unroll
+            for (int j = 0; j < KC_NB; ++j) nx[j] -= j < lim ? cv[j] : 0.0;
         }
     }
 #pragma unroll
-    for (int j = 0; j < KC_NB; ++j) av[j] = ((r < KC_NB && j <= r) || r == 30) ? nx[j] : 0.0;
+    for (int j = 0; j < KC_NB; ++j) av[j] = j < lim ? nx[j] : 0.0;
+    CS_PH(4);
 }
 
 struct ChainArgs {
@@ -1341,11 +1381,28 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a) {
             else { kindI = 2; r = 0; j = misc[2 + w - 2 * na * na]; }
             double* dst = Blk + (size_t)i * KC_BLK + (kindI == 0 ? r : (kindI == 1 ? KC_NB + r : 30)) * KC_RS + j;
             double v = *dst;
-            for (int t = eoff[i]; t < eoff[i + 1]; ++t) {
-                const int base = esd[t];
-                if (kindI == 0) v -= Vs[base + r] * Vs[base + j];
-                else if (kindI == 1) { const int ob = eoth[t]; if (ob >= 0) v -= Vs[ob + r] * Vs[base + j]; }
-                else v -= yd[elist[t]] * Vs[base + j];
+            // four epochs per round: the index reads, then the operand reads, go out as independent batches (the
+            // subtractions stay in list order, so the result does not depend on the batching)
+            const int t1 = eoff[i + 1];
+            for (int t = eoff[i]; t < t1; t += 4) {
+                int base[4], ob[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int tt = t + q < t1 ? t + q : t1 - 1;
+                    base[q] = esd[tt];
+                    ob[q] = kindI == 1 ? eoth[tt] : (kindI == 2 ? elist[tt] : 0);
+                }
+                double xa[4], xb[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    xb[q] = Vs[base[q] + j];
+                    xa[q] = kindI == 0 ? Vs[base[q] + r] : (kindI == 1 ? Vs[(ob[q] >= 0 ? ob[q] : base[q]) + r] : yd[ob[q]]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool live = (t + q < t1) & !(kindI == 1 && ob[q] < 0);
+                    v -= live ? xa[q] * xb[q] : 0.0;
+                }
             }
             *dst = v;
         }
@@ -1371,19 +1428,23 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a) {
         else if (p < 135) { pr2[q] = 15; pj2[q] = p - 120; }
         else { pr2[q] = -1; pj2[q] = 0; }
     }
+    long long ph[5] = {0, 0, 0, 0, 0};
     for (int it = 0; it <= T; ++it) {
         if (wv == 0) {
-            if (it < nT) chain_step15<false>(it, it + 1, true, av, Blk, CsT, lane, bad, pr2, pj2);
+            if (it < nT) chain_step15<false>(it, it + 1, true, av, Blk, CsT, lane, bad, pr2, pj2, ph);
             else if (it == T) {
-                if (lane < KC_NB || lane == 30) {
+                {
                     const int row = lane < KC_NB ? lane : 30, crow = lane < KC_NB ? lane : 15;
+                    const int lim = lane == 30 ? KC_NB : (lane < KC_NB ? lane + 1 : 0);
+                    double b0[KC_NB], c0[KC_NB], c1[KC_NB];
+#pragma unroll
+                    for (int j = 0; j < KC_NB; ++j) { b0[j] = Blk[(size_t)mid * KC_BLK + row * KC_RS + j]; c0[j] = CsT[crow * KC_RS + j]; c1[j] = CsB[crow * KC_RS + j]; }
 #pragma unroll
                     for (int j = 0; j < KC_NB; ++j) {
-                        const bool use = lane == 30 || j <= lane;
-                        double v = use ? Blk[(size_t)mid * KC_BLK + row * KC_RS + j] : 0.0;
-                        if (use && nT > 0) v -= CsT[crow * KC_RS + j];
-                        if (use && nB > 0) v -= CsB[crow * KC_RS + j];
-                        av[j] = v;
+                        double v = b0[j];
+                        if (nT > 0) v -= c0[j];
+                        if (nB > 0) v -= c1[j];
+                        av[j] = j < lim ? v : 0.0;
                     }
                 }
                 chain_step15<false>(mid, mid, false, av, Blk, CsT, lane, bad, pr2, pj2);
@@ -1394,6 +1455,9 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a) {
         __syncthreads();
     }
     AR_STAMP(44);
+#ifdef GLIO_DEV_STAMPS
+    if (tid == 0) for (int k = 0; k < 5; ++k) a.dbg[60 + k] = ph[k];
+#endif
     if (bad && lane == 0) misc[0] = 1;
     __syncthreads();
     if (misc[0]) { if (tid == 0) atomicOr(a.flag, 1); return; }

@@ -19,3 +19,4 @@ st = (C.c_longlong * 320)()
 capi.load().glio_debug_arrow_stamps(ctx._h, st)
 v = list(st)
 print("chain stamps (us): setup, raw loads, corrections, chain, back, epilogue:", [round((v[k + 1] - v[k]) / 100.0, 2) for k in range(40, 46)])
+print("chain step phases, totals over the top half-chain (us): loads, 15 pivots, panel store, rank-15 update, correction:", [round(v[60 + k] / 100.0, 2) for k in range(5)])
