@@ -1258,17 +1258,22 @@ __device__ __forceinline__ void chain_step15(const int i, const int nb, const bo
     GLIO_WAVE_LDS_SYNC();
     CS_PH(2);
     if (has_nb) {
-        // C[r2][j2] = X[r2] . X[j2]: r2 = 0..14 rows of the next diagonal block (j2 <= r2), r2 = 15 the right-hand side
+        // C = X X^T on the matrix core: X = rows 15..30 of the factored panel (15 rows towards the next keyframe + the
+        // right-hand side row), 16 x 15.  v_mfma_f64_16x16x4 takes A[i][k] from lane (i + 16 k) and B[k][j] from lane
+        // (j + 16 k): for X X^T both are X[lane % 16][kb + lane / 16], so one LDS read per lane feeds both operands; four
+        // instructions cover k = 0..15 (k = 15 is padding: zero).  C: lane l, register q -> row (l >> 4) + 4 q, column l & 15.
+        {
+            const int xi = lane & 15, xg = lane >> 4;
+            const double* xrow = Bi + (KC_NB + xi) * KC_RS + xg;
+            double xv[4];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int r2 = pr2[q], j2 = pj2[q];
-            if (r2 < 0) continue;
-            const double* xa = Bi + (r2 < 15 ? KC_NB + r2 : 30) * KC_RS;
-            const double* xb = Bi + (KC_NB + j2) * KC_RS;
-            double sacc = 0.0;
+            for (int kb = 0; kb < 4; ++kb) xv[kb] = xrow[4 * kb];
+            xv[3] = xg == 3 ? 0.0 : xv[3];
+            v4f64 cacc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int k = 0; k < KC_NB; ++k) sacc += xa[k] * xb[k];
-            Cs[r2 * KC_RS + j2] = sacc;
+            for (int kb = 0; kb < 4; ++kb) cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[kb], xv[kb], cacc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Cs[(xg + 4 * q) * KC_RS + xi] = cacc[q];
         }
         GLIO_WAVE_LDS_SYNC();
         CS_PH(3);
