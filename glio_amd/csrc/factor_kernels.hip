@@ -683,7 +683,12 @@ __device__ __forceinline__ int dop_local12(int slot_is_j, int lc) {  // pose-loc
     return slot_is_j ? 6 + k : k;
 }
 
-__global__ __launch_bounds__(256) void k_assemble(const AsmArgs a) {
+// Every entry of H sums up to six block entries that live in different arrays.  All addresses come from LDS lookup tables
+// (built once per workgroup from one round of coalesced global reads) and every candidate is loaded UNCONDITIONALLY from a
+// clamped, always valid address and selected afterwards, so that a thread has all its global loads in flight together:
+// one memory round trip per entry instead of one per `if`.  The terms are added in a fixed order (LiDAR, IMU edge
+// (lo, lo+1), IMU edge (sr-1, sr), GNSS groups by ascending index, prior) whatever is present.
+__global__ __launch_bounds__(1024) void k_assemble(const AsmArgs a) {
     int which = a.fixed_which;
     if (a.use_status) {
         if (a.st->done || !a.st->cand_pending) return;
@@ -698,19 +703,30 @@ __global__ __launch_bounds__(256) void k_assemble(const AsmArgs a) {
     const double* lb = a.lidar_blocks + (size_t)which * W * GLIO_LIDAR_ACC;
     const double* pH = a.pH + (size_t)which * a.np * a.np;
     const double* pg = a.pg + (size_t)which * a.np;
-    // O(1) lookup tables: IMU edge that starts at a slot, GNSS group of a slot pair
-    __shared__ short imap[GLIO_MAX_WINDOW];
-    __shared__ short gmap[GLIO_MAX_WINDOW * GLIO_MAX_WINDOW];
-    __shared__ short gsa[GLIO_MAX_WINDOW * GLIO_MAX_WINDOW], gsb[GLIO_MAX_WINDOW * GLIO_MAX_WINDOW];   // slots of every GNSS group: the loops
-    for (int k = threadIdx.x; k < W; k += blockDim.x) imap[k] = -1;                                       // below must not chase them in global memory
+    __shared__ short imap[GLIO_MAX_WINDOW], isb[GLIO_MAX_WINDOW];                  // IMU edge that starts at a slot, its other slot
+    __shared__ short gmap[GLIO_MAX_WINDOW * GLIO_MAX_WINDOW];                      // GNSS group of a slot pair
+    __shared__ short gsa[GLIO_MAX_WINDOW * GLIO_MAX_WINDOW], gsb[GLIO_MAX_WINDOW * GLIO_MAX_WINDOW];   // slots of every GNSS group
+    __shared__ short gadj0[GLIO_MAX_WINDOW], gadj1[GLIO_MAX_WINDOW], gnext[GLIO_MAX_WINDOW];   // first two groups touching a slot; where a third may start
+    __shared__ short pidx[15 * GLIO_MAX_WINDOW];                                   // prior row of a pose parameter
+    for (int k = threadIdx.x; k < W; k += blockDim.x) { imap[k] = -1; isb[k] = -1; }
     for (int k = threadIdx.x; k < W * W; k += blockDim.x) gmap[k] = -1;
+    for (int k = threadIdx.x; k < np15; k += blockDim.x) pidx[k] = a.has_prior ? (short)a.prior_index[k] : (short)-1;
     __syncthreads();
-    for (int k = threadIdx.x; k < a.n_imu; k += blockDim.x) imap[imu[k].slot_a] = (short)k;
+    for (int k = threadIdx.x; k < a.n_imu; k += blockDim.x) { const int sa = imu[k].slot_a; imap[sa] = (short)k; isb[sa] = (short)imu[k].slot_b; }
     for (int k = threadIdx.x; k < a.n_groups; k += blockDim.x) {
         const int sa = gn[k].slot_a, sb = gn[k].slot_b;
         gsa[k] = (short)sa; gsb[k] = (short)sb;
         gmap[sa * W + sb] = (short)k;
         gmap[sb * W + sa] = (short)k;
+    }
+    __syncthreads();
+    for (int sl = threadIdx.x; sl < W; sl += blockDim.x) {
+        int k0 = -1, k1 = -1, nx = a.n_groups;
+        for (int k = 0; k < a.n_groups; ++k)
+            if (gsa[k] == sl || gsb[k] == sl) {
+                if (k0 < 0) k0 = k; else if (k1 < 0) k1 = k; else { nx = k; break; }
+            }
+        gadj0[sl] = (short)k0; gadj1[sl] = (short)k1; gnext[sl] = (short)nx;
     }
     __syncthreads();
     // rows are dealt to workgroups, columns to lanes (coalesced stores, no integer division per entry)
@@ -720,15 +736,26 @@ __global__ __launch_bounds__(256) void k_assemble(const AsmArgs a) {
                 double s = 0;
                 if (c < np15) {
                     const int sc = c / 15, lc = c % 15;
-                    if (lc < 6) s += lb[sc * GLIO_LIDAR_ACC + 21 + lc];
-                    const int e0 = imap[sc], e1 = sc > 0 ? imap[sc - 1] : -1;
-                    if (e0 >= 0) s += imu[e0].g[lc];
-                    if (e1 >= 0 && imu[e1].slot_b == sc) s += imu[e1].g[15 + lc];
-                    for (int k = 0; k < a.n_groups; ++k) {
+                    const bool lid = lc < 6;
+                    const int e0 = imap[sc], e1r = sc > 0 ? imap[sc - 1] : -1;
+                    const bool ok1 = e1r >= 0 && isb[sc - (sc > 0)] == sc;
+                    const int k0 = gadj0[sc], k1 = gadj1[sc], pi = pidx[c];
+                    const double vl = lb[sc * GLIO_LIDAR_ACC + 21 + (lid ? lc : 0)];
+                    const double v0 = imu[e0 >= 0 ? e0 : 0].g[lc];
+                    const double v1 = imu[ok1 ? e1r : 0].g[15 + lc];
+                    const double vg0 = gn[k0 >= 0 ? k0 : 0].g[(k0 >= 0 && gsa[k0] == sc ? 0 : 15) + lc];
+                    const double vg1 = gn[k1 >= 0 ? k1 : 0].g[(k1 >= 0 && gsa[k1] == sc ? 0 : 15) + lc];
+                    const double vp = pg[pi >= 0 ? pi : 0];
+                    s += lid ? vl : 0.0;
+                    s += e0 >= 0 ? v0 : 0.0;
+                    s += ok1 ? v1 : 0.0;
+                    s += k0 >= 0 ? vg0 : 0.0;
+                    s += k1 >= 0 ? vg1 : 0.0;
+                    for (int k = gnext[sc]; k < a.n_groups; ++k) {
                         if (gsa[k] == sc) s += gn[k].g[lc];
                         else if (gsb[k] == sc) s += gn[k].g[15 + lc];
                     }
-                    if (a.has_prior) { const int pi = a.prior_index[c]; if (pi >= 0) s += pg[pi]; }
+                    s += pi >= 0 ? vp : 0.0;
                 } else s = dd[c - np15].g;
                 g[c] = s;
             }
@@ -737,43 +764,63 @@ __global__ __launch_bounds__(256) void k_assemble(const AsmArgs a) {
         double* Hrow = H + (size_t)r * n;
         if (r < np15) {
             const int sr = r / 15, lr = r % 15;
-            const int pi = a.has_prior ? a.prior_index[r] : -1;
+            const int pi = pidx[r];
             for (int c = threadIdx.x; c < n; c += blockDim.x) {
                 double s = 0;
                 if (c < np15) {
                     const int sc = c / 15, lc = c % 15;
-                    if (sr == sc && lr < 6 && lc < 6) s += lb[sr * GLIO_LIDAR_ACC + (lr <= lc ? lidar_sym_index(lr, lc) : lidar_sym_index(lc, lr))];
                     const int d = sc - sr;
-                    if (d >= -1 && d <= 1) {
-                        const int lo = sr < sc ? sr : sc;
-                        const int e0 = imap[lo];                               // edge (lo, lo+1)
-                        if (e0 >= 0 && (d != 0 || true)) {
-                            const int sa = imu[e0].slot_a, sb = imu[e0].slot_b;
-                            if ((sr == sa || sr == sb) && (sc == sa || sc == sb))
-                                s += imu[e0].H[((sr == sa ? 0 : 15) + lr) * GLIO_PAIR_DIM + (sc == sa ? 0 : 15) + lc];
-                        }
-                        if (d == 0 && sr > 0) {                                // edge (sr-1, sr) also covers (sr, sr)
-                            const int e1 = imap[sr - 1];
-                            if (e1 >= 0 && imu[e1].slot_b == sr) s += imu[e1].H[(15 + lr) * GLIO_PAIR_DIM + 15 + lc];
-                        }
-                    }
-                    if (sr != sc) {
-                        const int k = gmap[sr * W + sc];
-                        if (k >= 0) s += gn[k].H[((sr == gsa[k] ? 0 : 15) + lr) * GLIO_PAIR_DIM + (sc == gsa[k] ? 0 : 15) + lc];
+                    // LiDAR: 6 x 6 pose block of the keyframe
+                    const bool lid = (d == 0) & (lr < 6) & (lc < 6);
+                    const int lix = lid ? (lr <= lc ? lidar_sym_index(lr, lc) : lidar_sym_index(lc, lr)) : 0;
+                    // IMU edge (lo, lo + 1) when both slots belong to it; edge (sr - 1, sr) also covers the block (sr, sr)
+                    const int lo = sr < sc ? sr : sc;
+                    const bool near = (d >= -1) & (d <= 1);
+                    const int e0 = near ? imap[lo] : -1;
+                    const int sb0 = near ? isb[lo] : -1;
+                    const bool ok0 = (e0 >= 0) & ((sr == lo) | (sr == sb0)) & ((sc == lo) | (sc == sb0));
+                    const int off0 = ((sr == lo ? 0 : 15) + lr) * GLIO_PAIR_DIM + (sc == lo ? 0 : 15) + lc;
+                    const int e1 = (d == 0 && sr > 0) ? imap[sr - 1] : -1;
+                    const bool ok1 = e1 >= 0 && isb[sr - 1] == sr;
+                    // GNSS: off-diagonal slot block = the group of the pair; diagonal slot block = every group touching sr
+                    int k0, k1, offg0, offg1 = 0;
+                    if (d != 0) {
+                        k0 = gmap[sr * W + sc]; k1 = -1;
+                        const int ga = k0 >= 0 ? gsa[k0] : -1;
+                        offg0 = ((sr == ga ? 0 : 15) + lr) * GLIO_PAIR_DIM + (sc == ga ? 0 : 15) + lc;
                     } else {
-                        for (int k = 0; k < a.n_groups; ++k) {                 // diagonal slot block: every group touching sr
+                        k0 = gadj0[sr]; k1 = gadj1[sr];
+                        offg0 = (k0 >= 0 && gsa[k0] == sr) ? lr * GLIO_PAIR_DIM + lc : (15 + lr) * GLIO_PAIR_DIM + 15 + lc;
+                        offg1 = (k1 >= 0 && gsa[k1] == sr) ? lr * GLIO_PAIR_DIM + lc : (15 + lr) * GLIO_PAIR_DIM + 15 + lc;
+                    }
+                    const int pj = pidx[c];
+                    const bool okp = (pi >= 0) & (pj >= 0);
+                    const double vl = lb[sr * GLIO_LIDAR_ACC + lix];
+                    const double v0 = imu[ok0 ? e0 : 0].H[ok0 ? off0 : 0];
+                    const double v1 = imu[ok1 ? e1 : 0].H[(15 + lr) * GLIO_PAIR_DIM + 15 + lc];
+                    const double vg0 = gn[k0 >= 0 ? k0 : 0].H[offg0];
+                    const double vg1 = gn[k1 >= 0 ? k1 : 0].H[offg1];
+                    const double vp = pH[okp ? (size_t)pi * a.np + pj : 0];
+                    s += lid ? vl : 0.0;
+                    s += ok0 ? v0 : 0.0;
+                    s += ok1 ? v1 : 0.0;
+                    s += k0 >= 0 ? vg0 : 0.0;
+                    s += k1 >= 0 ? vg1 : 0.0;
+                    if (d == 0)
+                        for (int k = gnext[sr]; k < a.n_groups; ++k) {                 // a slot with more than two GNSS groups (general graphs)
                             if (gsa[k] == sr) s += gn[k].H[lr * GLIO_PAIR_DIM + lc];
                             else if (gsb[k] == sr) s += gn[k].H[(15 + lr) * GLIO_PAIR_DIM + 15 + lc];
                         }
-                    }
-                    if (pi >= 0) { const int pj = a.prior_index[c]; if (pj >= 0) s += pH[(size_t)pi * a.np + pj]; }
+                    s += okp ? vp : 0.0;
                 } else {
                     const int ep = c - np15;
-                    if (dd[ep].used) {
-                        const int gi = dd[ep].group;
-                        const int sa = gsa[gi], sb = gsb[gi];
-                        if (sr == sa || sr == sb) { const int k12 = dop_local12(sr == sb && sr != sa, lr); if (k12 >= 0) s = dd[ep].c[k12]; }
-                    }
+                    const int used = dd[ep].used, gi0 = dd[ep].group;
+                    const int gi = used ? gi0 : 0;
+                    const int sa = gsa[gi], sb = gsb[gi];
+                    const int k12 = dop_local12(sr == sb && sr != sa, lr);
+                    const bool ok = (used != 0) & ((sr == sa) | (sr == sb)) & (k12 >= 0);
+                    const double v = dd[ep].c[ok ? k12 : 0];
+                    s = ok ? v : 0.0;
                 }
                 Hrow[c] = s;
             }
@@ -909,5 +956,6 @@ void glio_launch_assemble(glio_ctx* c, int use_status_cand, int which, int n_ddt
     a.pH = c->d_prior_H; a.pg = c->d_prior_g; a.pcost = c->d_prior_cost; a.prior_index = c->d_prior_index;
     a.H0 = c->d_H[0]; a.H1 = c->d_H[1]; a.g0 = c->d_g[0]; a.g1 = c->d_g[1]; a.c0 = c->d_cost[0]; a.c1 = c->d_cost[1];
     const int blocks = a.n + 1;       // one workgroup per row of H (+ one for g)
-    hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(256), 0, c->stream, a);
+    const int threads = a.n + 1 > 1024 ? 1024 : ((a.n + 1 + 63) / 64) * 64;    // one column per thread: a single round of loads per row
+    hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(threads), 0, c->stream, a);
 }
