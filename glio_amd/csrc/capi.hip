@@ -655,7 +655,7 @@ int glio_marginalize(glio_ctx* c, const glio_state* s, double* lin_jac, double* 
     const int n_ddt = s->n_ddt, nx = glio_x_size(W, n_ddt), n = 6 * (W - 1) + 9;
     pack_state(c, s, c->h_xbuf);
     GLIO_HIP_CHECK(hipMemcpyAsync(c->d_x[0], c->h_xbuf, (size_t)nx * 8, hipMemcpyHostToDevice, c->stream));
-    glio_launch_lidar_linearize(c, 0, 0, 1);
+    glio_launch_lidar_linearize(c, 0, 0, 1); glio_launch_lidar_reduce(c, 0);
     glio_launch_small_factors(c, 0, 0, n_ddt, 1);
     double *dJ, *dr; int* dok;
     glio_launch_marginalize(c, extra_of(c)->imu_edge0, &dJ, &dr, &dok);
@@ -696,7 +696,7 @@ int glio_marginalize_keep(glio_ctx* c, const glio_state* s) {
     const int n_ddt = s->n_ddt, nx = glio_x_size(W, n_ddt), n = 6 * (W - 1) + 9, nb = 2 * (W - 1) + 1;
     pack_state(c, s, c->h_xbuf);
     GLIO_HIP_CHECK(hipMemcpyAsync(c->d_x[0], c->h_xbuf, (size_t)nx * 8, hipMemcpyHostToDevice, c->stream));
-    glio_launch_lidar_linearize(c, 0, 0, 1);
+    glio_launch_lidar_linearize(c, 0, 0, 1); glio_launch_lidar_reduce(c, 0);
     glio_launch_small_factors(c, 0, 0, n_ddt, 1);
     double *dJ, *dr; int* dok;
     glio_launch_marginalize(c, extra_of(c)->imu_edge0, &dJ, &dr, &dok);
@@ -853,7 +853,7 @@ int glio_time_kernel(glio_ctx* c, int which, int reps, float* ms_out) {
             } else if (which == GLIO_KERNEL_MARGINALIZE) {
                 if (c->W < 2) return GLIO_E_ARG;
                 double *dJ, *dr; int* dok;
-                glio_launch_lidar_linearize(c, 0, 0, 1);
+                glio_launch_lidar_linearize(c, 0, 0, 1); glio_launch_lidar_reduce(c, 0);
                 glio_launch_small_factors(c, 0, 0, n_ddt, 1);
                 glio_launch_marginalize(c, extra_of(c)->imu_edge0, &dJ, &dr, &dok);
             } else return GLIO_E_ARG;

@@ -633,17 +633,7 @@ __device__ void small_factors_body(const SmallArgs& a) {
         which = 1 - a.st->cur;
     }
     const double* x = which ? a.x1 : a.x0;
-    int b = blockIdx.x;
-    if (b < a.W) {            // fixed-order reduction of the K3 partials of keyframe b
-        if (threadIdx.x < GLIO_LIDAR_ACC) {
-            const double* p = a.lidar_partials + (size_t)b * a.lidar_blocks_per_kf * GLIO_LIDAR_ACC + threadIdx.x;
-            double s = 0;
-            for (int k = 0; k < a.lidar_blocks_per_kf; ++k) s += p[k * GLIO_LIDAR_ACC];
-            a.lidar_blocks[((size_t)which * a.W + b) * GLIO_LIDAR_ACC + threadIdx.x] = s;
-        }
-        return;
-    }
-    b -= a.W;
+    int b = blockIdx.x;          // (the K3 partials are summed by their consumers, k_assemble / k_lidar_reduce: this kernel does not depend on K3)
     if (b < a.n_imu) {
         const int si = a.imu[b].slot_i, sj = si + 1, W = a.W;
         imu_block(a.gravity, x + 3 * si, x + 3 * W + 4 * si, x + 7 * W + 9 * si, x + 3 * sj, x + 3 * W + 4 * sj, x + 7 * W + 9 * sj,
@@ -662,13 +652,33 @@ __device__ void small_factors_body(const SmallArgs& a) {
     }
 }
 
+// fixed-order sum of the K3 partials of keyframe blockIdx.x into its 28-double block (consumers that want the blocks
+// themselves: the marginalization's assembly; k_assemble sums the partials on the fly instead)
+__global__ __launch_bounds__(64) void k_lidar_reduce(const double* __restrict__ partials, const int nb, double* __restrict__ blocks) {
+    if (threadIdx.x >= GLIO_LIDAR_ACC) return;
+    const double* p = partials + (size_t)blockIdx.x * nb * GLIO_LIDAR_ACC + threadIdx.x;
+    double s = 0;
+    for (int k0 = 0; k0 < nb; k0 += 8) {           // eight independent loads in flight, added in index order
+        double v8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v8[q] = p[(size_t)(k0 + q < nb ? k0 + q : k0) * GLIO_LIDAR_ACC];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += k0 + q < nb ? v8[q] : 0.0;
+    }
+    blocks[(size_t)blockIdx.x * GLIO_LIDAR_ACC + threadIdx.x] = s;
+}
+void glio_launch_lidar_reduce(glio_ctx* c, int which) {
+    hipLaunchKernelGGL(k_lidar_reduce, dim3(c->W), dim3(64), 0, c->stream, c->d_lidar_partials, c->k3_bpk,
+                       c->d_lidar_blocks + (size_t)which * c->W * GLIO_LIDAR_ACC);
+}
+
 // ------------------------------------------------------------------------------------------------
 // assemble: gather every block into the dense normal equations (one thread per H entry)
 // ------------------------------------------------------------------------------------------------
 struct AsmArgs {
     int W, n, n_ddt, n_imu, n_groups, has_prior, np;
     const SolverStatus* st; int use_status; int fixed_which;
-    const double* lidar_blocks; const PairBlock* imu_blocks; const PairBlock* gnss_blocks; const DdtBlock* ddt_blocks;
+    const double* lidar_partials; int lidar_nb; const PairBlock* imu_blocks; const PairBlock* gnss_blocks; const DdtBlock* ddt_blocks;
     int gnss_stride, ddt_stride;
     const double* pH; const double* pg; const double* pcost; const int* prior_index;
     double* H0; double* H1; double* g0; double* g1; double* c0; double* c1;
@@ -700,7 +710,24 @@ __global__ __launch_bounds__(1024) void k_assemble(const AsmArgs a) {
     const PairBlock* imu = a.imu_blocks + (size_t)which * W;
     const PairBlock* gn = a.gnss_blocks + (size_t)which * a.gnss_stride;
     const DdtBlock* dd = a.ddt_blocks + (size_t)which * a.ddt_stride;
-    const double* lb = a.lidar_blocks + (size_t)which * W * GLIO_LIDAR_ACC;
+    // LiDAR blocks: the fixed-order sum over the keyframe's K3 partials is taken right here, all nb loads of an entry in
+    // flight together (only the 6 x 6 pose entries and the 6 gradient entries of a keyframe have a LiDAR term)
+    const double* lp = a.lidar_partials;
+    const int lnb = a.lidar_nb;
+    auto lidar_term = [&](const int slot, const int idx, const bool live) {
+        double s = 0;
+        if (live) {
+            const double* p = lp + (size_t)slot * lnb * GLIO_LIDAR_ACC + idx;
+            for (int k0 = 0; k0 < lnb; k0 += 48) {          // 48 loads in flight per round (one round at the default geometry)
+                double vb[48];
+#pragma unroll
+                for (int q = 0; q < 48; ++q) vb[q] = p[(size_t)(k0 + q < lnb ? k0 + q : k0) * GLIO_LIDAR_ACC];
+#pragma unroll
+                for (int q = 0; q < 48; ++q) s += k0 + q < lnb ? vb[q] : 0.0;
+            }
+        }
+        return s;
+    };
     const double* pH = a.pH + (size_t)which * a.np * a.np;
     const double* pg = a.pg + (size_t)which * a.np;
     __shared__ short imap[GLIO_MAX_WINDOW], isb[GLIO_MAX_WINDOW];                  // IMU edge that starts at a slot, its other slot
@@ -740,12 +767,12 @@ __global__ __launch_bounds__(1024) void k_assemble(const AsmArgs a) {
                     const int e0 = imap[sc], e1r = sc > 0 ? imap[sc - 1] : -1;
                     const bool ok1 = e1r >= 0 && isb[sc - (sc > 0)] == sc;
                     const int k0 = gadj0[sc], k1 = gadj1[sc], pi = pidx[c];
-                    const double vl = lb[sc * GLIO_LIDAR_ACC + 21 + (lid ? lc : 0)];
                     const double v0 = imu[e0 >= 0 ? e0 : 0].g[lc];
                     const double v1 = imu[ok1 ? e1r : 0].g[15 + lc];
                     const double vg0 = gn[k0 >= 0 ? k0 : 0].g[(k0 >= 0 && gsa[k0] == sc ? 0 : 15) + lc];
                     const double vg1 = gn[k1 >= 0 ? k1 : 0].g[(k1 >= 0 && gsa[k1] == sc ? 0 : 15) + lc];
                     const double vp = pg[pi >= 0 ? pi : 0];
+                    const double vl = lidar_term(sc, 21 + (lid ? lc : 0), lid);
                     s += lid ? vl : 0.0;
                     s += e0 >= 0 ? v0 : 0.0;
                     s += ok1 ? v1 : 0.0;
@@ -795,12 +822,12 @@ __global__ __launch_bounds__(1024) void k_assemble(const AsmArgs a) {
                     }
                     const int pj = pidx[c];
                     const bool okp = (pi >= 0) & (pj >= 0);
-                    const double vl = lb[sr * GLIO_LIDAR_ACC + lix];
                     const double v0 = imu[ok0 ? e0 : 0].H[ok0 ? off0 : 0];
                     const double v1 = imu[ok1 ? e1 : 0].H[(15 + lr) * GLIO_PAIR_DIM + 15 + lc];
                     const double vg0 = gn[k0 >= 0 ? k0 : 0].H[offg0];
                     const double vg1 = gn[k1 >= 0 ? k1 : 0].H[offg1];
                     const double vp = pH[okp ? (size_t)pi * a.np + pj : 0];
+                    const double vl = lidar_term(sr, lix, lid);
                     s += lid ? vl : 0.0;
                     s += ok0 ? v0 : 0.0;
                     s += ok1 ? v1 : 0.0;
@@ -843,7 +870,7 @@ __global__ __launch_bounds__(1024) void k_assemble(const AsmArgs a) {
     if (blockIdx.x == 0 && threadIdx.x < 64) {       // total cost: every term fetched by its own lane, fixed-shape wave reduction
         const int l = threadIdx.x;
         double cs = 0;
-        for (int k = l; k < W; k += 64) cs += lb[k * GLIO_LIDAR_ACC + 27];
+        for (int k = l; k < W; k += 64) cs += lidar_term(k, 27, true);
         for (int k = l; k < a.n_imu; k += 64) cs += imu[k].cost;
         for (int k = l; k < a.n_groups; k += 64) cs += gn[k].cost;
         if (l == 0 && a.has_prior) cs += a.pcost[which];
@@ -942,7 +969,8 @@ void glio_launch_small_factors(glio_ctx* c, int use_status_cand, int which, int 
     a.pJ0 = c->d_prior_J0; a.pA0 = c->d_prior_A0; a.pr0 = c->d_prior_r0; a.px0 = c->d_prior_x0;
     a.pslot = c->d_prior_slot; a.pkind = c->d_prior_kind; a.pidx = c->d_prior_idx; a.pcolblk = ex->d_prior_colblk;
     a.pH = c->d_prior_H; a.pg = c->d_prior_g; a.pcost = c->d_prior_cost; a.pwork = c->d_prior_work;
-    const int blocks = c->W + c->n_imu + c->n_groups + (a.has_prior ? 1 + PRIOR_H_BLOCKS : 0);
+    const int blocks = c->n_imu + c->n_groups + (a.has_prior ? 1 + PRIOR_H_BLOCKS : 0);
+    if (blocks == 0) return;
     hipLaunchKernelGGL(k_small_factors, dim3(blocks), dim3(SF_THREADS), 0, c->stream, a);
 }
 
@@ -951,7 +979,7 @@ void glio_launch_assemble(glio_ctx* c, int use_status_cand, int which, int n_ddt
     a.W = c->W; a.n = 15 * c->W + n_ddt; a.n_ddt = n_ddt; a.n_imu = c->n_imu; a.n_groups = c->n_groups;
     a.has_prior = c->prior_n > 0; a.np = c->prior_n;
     a.st = c->d_status; a.use_status = use_status_cand; a.fixed_which = which;
-    a.lidar_blocks = c->d_lidar_blocks; a.imu_blocks = c->d_imu_blocks; a.gnss_blocks = c->d_gnss_blocks; a.ddt_blocks = c->d_ddt_blocks;
+    a.lidar_partials = c->d_lidar_partials; a.lidar_nb = c->k3_bpk; a.imu_blocks = c->d_imu_blocks; a.gnss_blocks = c->d_gnss_blocks; a.ddt_blocks = c->d_ddt_blocks;
     a.gnss_stride = c->W * c->W; a.ddt_stride = c->n_ddt_max > 0 ? c->n_ddt_max : 1;
     a.pH = c->d_prior_H; a.pg = c->d_prior_g; a.pcost = c->d_prior_cost; a.prior_index = c->d_prior_index;
     a.H0 = c->d_H[0]; a.H1 = c->d_H[1]; a.g0 = c->d_g[0]; a.g1 = c->d_g[1]; a.c0 = c->d_cost[0]; a.c1 = c->d_cost[1];

@@ -256,6 +256,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 void glio_launch_lidar_linearize(glio_ctx* c, int use_status_cand, int which, int marg = 0);
 // factor_kernels.hip
 void glio_launch_small_factors(glio_ctx* c, int use_status_cand, int which, int n_ddt, int marg = 0);
+void glio_launch_lidar_reduce(glio_ctx* c, int which);      // K3 partials -> d_lidar_blocks (the marginalization's assembly reads the blocks)
 void glio_launch_assemble(glio_ctx* c, int use_status_cand, int which, int n_ddt);
 void glio_launch_stream_read(glio_ctx* c);
 int glio_assoc_build_map_dev(glio_ctx* c, const float4* d_pts, int n);

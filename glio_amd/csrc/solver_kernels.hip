@@ -1236,13 +1236,19 @@ __device__ __forceinline__ void chain_step15(const int i, const int nb, const bo
     }
     CS_PH(0);
     double rpv = 0.0;
+    // The pivots form a scalar recurrence d_{j+1} = a_{j+1,j+1} - (a_{j+1,j} / sqrt(d_j))^2 that is carried in the uniform
+    // domain one step ahead of the vector update: the next 1/sqrt starts three dependent operations after the previous
+    // one instead of waiting for the column scaling, the rank-1 update and a v_readlane round trip.  A non-positive or
+    // non-finite pivot only raises `bad` (the dense fallback redoes the solve); it is not patched on the critical path.
+    double djj = readlane_d(av[0], 0);
 #pragma unroll
     for (int j = 0; j < KC_NB; ++j) {
-        double djj = readlane_d(av[j], j);
-        const bool okp = (djj > 0.0) & (djj < 1e300);               // also false for NaN
-        bad |= !okp;
-        djj = okp ? djj : 1.0;
+        bad |= !((djj > 0.0) & (djj < 1e300));                       // also true for NaN
         const double rdj = pivot_rsqrt(djj);
+        if (j + 1 < KC_NB) {
+            const double lnx = readlane_d(av[j], j + 1) * rdj;        // L[j+1][j]
+            djj = fma(-lnx, lnx, readlane_d(av[j + 1], j + 1));       // next pivot (both operands were final before this step)
+        }
         const double lij = av[j] * rdj;                              // lane j: d / sqrt(d) = sqrt(d)
         rpv = lane == j ? rdj : rpv;
         av[j] = lij;

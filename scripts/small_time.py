@@ -16,8 +16,8 @@ W = 20
 def stat(name, a):
     a = np.array(a)
     if len(a): print(f"{name:14s} n {len(a):4d} min {a.min():6.1f} mean {a.mean():6.1f} max {a.max():6.1f}")
-stat("lidar reduce", v[:W]); stat("imu", v[W:W + 19]); stat("gnss", v[W + 19:W + 38]); stat("prior", v[W + 38:W + 38 + 25])
-print("prior blocks", v[W + 38:W + 47].round(1))
+stat("imu", v[:19]); stat("gnss", v[19:38]); stat("prior", v[38:38 + 25])
+print("prior blocks", v[38:47].round(1))
 print("full_linearize", ctx.time_kernel(1, 30) * 1e3, " stream_read", ctx.time_kernel(6, 50) * 1e3, " k3", ctx.time_kernel(0, 50) * 1e3)
 g = np.array(list(st))[264:272]
 print("gnss block 0 stamps (us): dd loads+compute, sync, dd rest, dop compute, sync, dop reduce, scatter:", [round((g[k + 1] - g[k]) / 100.0, 2) for k in range(7)])
