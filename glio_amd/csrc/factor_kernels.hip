@@ -16,7 +16,7 @@
 // QuaternionParameterization Jacobian (left (+), GraphGNSSLibV1.1/docs/source/nnls_modeling.rst:1312-1327).
 // These factors are tiny (LDS/latency-bound, not roofline material); the point of having them on device
 // is that a whole trust-region solve runs without a host round trip.
-#include "glio_device.h"
+#include "k3_device.h"
 
 #define SF_THREADS 256
 
@@ -60,16 +60,16 @@ __device__ __forceinline__ void qright16(const double p[4], double M[16]) {
 
 // global column offsets of the six parameter blocks Pi3 Qi4 SBi9 Pj3 Qj4 SBj9
 #define IMU_GC 32
+struct ImuLds { double Jg[15 * IMU_GC], Jl[15 * 30], WJ[15 * 30], S[225], r[15], wr[15]; };
 // `eval_out` != NULL: single-factor evaluator mode (glio_eval_imu): write the whitened residual [15] and
 // the whitened GLOBAL Jacobians [15][32] (Pi3 Qi4 SBi9 Pj3 Qj4 SBj9) and return.
-__device__ void imu_block(const double gravity, const double* __restrict__ pPi, const double* __restrict__ pQi,
+__device__ __forceinline__ void imu_block(const double gravity, const double* __restrict__ pPi, const double* __restrict__ pQi,
                           const double* __restrict__ pSBi, const double* __restrict__ pPj, const double* __restrict__ pQj,
-                          const double* __restrict__ pSBj, const ImuEdgeDev& e, PairBlock* out, double* eval_out, const int marg = 0) {
-    __shared__ double Jg[15 * IMU_GC];
-    __shared__ double Jl[15 * 30];
-    __shared__ double WJ[15 * 30];
-    __shared__ double S[225];
-    __shared__ double r[15], wr[15];
+                          const double* __restrict__ pSBj, const ImuEdgeDev& e, PairBlock* out, double* eval_out, const int marg, unsigned char* pool) {
+    // LDS comes from the caller's pool: the roles of the small-factor kernel overlay one another (a workgroup has one role)
+    ImuLds& lds_ = *reinterpret_cast<ImuLds*>(pool);
+    double (&Jg)[15 * IMU_GC] = lds_.Jg; double (&Jl)[15 * 30] = lds_.Jl; double (&WJ)[15 * 30] = lds_.WJ;
+    double (&S)[225] = lds_.S; double (&r)[15] = lds_.r; double (&wr)[15] = lds_.wr;
     const int tid = threadIdx.x;
     const int i = e.slot_i, j = i + 1;
     enum { O_P = 0, O_R = 3, O_V = 6, O_BA = 9, O_BG = 12 };
@@ -264,21 +264,31 @@ __device__ void imu_block(const double gravity, const double* __restrict__ pPi, 
 #define DOP_CHUNK 128
 #define DD_CHUNK 8           /* DD factors evaluated side by side: 32 lanes each */
 #define GN_MAX_RUNS 32       /* Doppler epochs of one keyframe pair kept in LDS (more: read from global) */
+struct GnssLds {
+    double raw[DD_CHUNK][19], Jri[DD_CHUNK][19 * 3], Jrj[DD_CHUNK][19 * 3];
+    double wE[DD_CHUNK][19 * 8];          // whitened rows: 6 Jacobian entries, the residual, (pad)
+    double sWt[DD_CHUNK][19 * 19];
+    double sE[DD_CHUNK][20][3], sRu[DD_CHUNK][20], sRr[DD_CHUNK][20], sObs[DD_CHUNK][20];   // per satellite: e^T R, |d_u|, |d_r|, psr_u - psr_r
+    double dE[DOP_CHUNK * 16];            // per row: 13 Jacobian entries, corrected residual, rho, 1
+    double s_cost[2];
+    DopRun s_runs[GN_MAX_RUNS];
+    int s_nw[DD_CHUNK], s_m[DD_CHUNK];
+};
 __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, const GnssGroup& gr, int gidx,
-                           PairBlock* out, DdtBlock* ddt_out) {
+                           PairBlock* out, DdtBlock* ddt_out, unsigned char* pool) {
     // All factors of the pair are evaluated SIDE BY SIDE (DD factor f -> lanes 32 f' .. 32 f' + 31, Doppler row -> one
     // lane).  These are chains of dependent global loads (~1-2 us each on this part), so what counts is the number of
     // latency ROUNDS, not the arithmetic: everything a factor needs is fetched in one round (per-satellite quantities by
     // the satellite's own lane, the master's reach the others through LDS; the whitening matrix cooperatively into LDS;
     // the clock-drift unknowns and the epoch table of the pair too).  Sums keep the per-factor association of the
     // sequential formulation.
-    __shared__ double raw[DD_CHUNK][19], Jri[DD_CHUNK][19 * 3], Jrj[DD_CHUNK][19 * 3];
-    __shared__ double wE[DD_CHUNK][19 * 8];          // whitened rows: 6 Jacobian entries, the residual, (pad)
-    __shared__ double sWt[DD_CHUNK][19 * 19];
-    __shared__ double sE[DD_CHUNK][20][3], sRu[DD_CHUNK][20], sRr[DD_CHUNK][20], sObs[DD_CHUNK][20];   // per satellite: e^T R, |d_u|, |d_r|, psr_u - psr_r
-    __shared__ int s_nw[DD_CHUNK], s_m[DD_CHUNK];
-    __shared__ double dE[DOP_CHUNK * 16];            // per row: 13 Jacobian entries, corrected residual, rho, 1
-    __shared__ DopRun s_runs[GN_MAX_RUNS];
+    GnssLds& lds_ = *reinterpret_cast<GnssLds*>(pool);
+    double (&raw)[DD_CHUNK][19] = lds_.raw; double (&Jri)[DD_CHUNK][19 * 3] = lds_.Jri; double (&Jrj)[DD_CHUNK][19 * 3] = lds_.Jrj;
+    double (&wE)[DD_CHUNK][19 * 8] = lds_.wE; double (&sWt)[DD_CHUNK][19 * 19] = lds_.sWt;
+    double (&sE)[DD_CHUNK][20][3] = lds_.sE; double (&sRu)[DD_CHUNK][20] = lds_.sRu; double (&sRr)[DD_CHUNK][20] = lds_.sRr; double (&sObs)[DD_CHUNK][20] = lds_.sObs;
+    int (&s_nw)[DD_CHUNK] = lds_.s_nw; int (&s_m)[DD_CHUNK] = lds_.s_m;
+    double (&dE)[DOP_CHUNK * 16] = lds_.dE; DopRun (&s_runs)[GN_MAX_RUNS] = lds_.s_runs;
+    double (&s_cost)[2] = lds_.s_cost;
     const int tid = threadIdx.x;
     const int W = a.W;
     const int si = gr.slot_i, sj = gr.slot_j;
@@ -478,7 +488,6 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
     for (int k = tid; k < GLIO_PAIR_DIM * GLIO_PAIR_DIM; k += SF_THREADS) out->H[k] = 0.0;
     if (tid < GLIO_PAIR_DIM) out->g[tid] = 0.0;
     __syncthreads();
-    __shared__ double s_cost[2];
     const int map6[6] = {0, 1, 2, 15, 16, 17};
     const int map12[12] = {0, 1, 2, 6, 7, 8, 15, 16, 17, 21, 22, 23};
     if (tid == 42) s_cost[0] = cost_dd;
@@ -537,8 +546,11 @@ __device__ __forceinline__ void prior_dx_M(const SmallArgs& a, const double* __r
 #define PRIOR_MAX_NB (2 * GLIO_MAX_WINDOW + 1)
 
 // workgroup 0 of the prior: r = r0 + J0 dx (one wavefront per row, coalesced), v = J0^T r, g = M^T v, cost
-__device__ void prior_rg_block(const SmallArgs& a, const double* __restrict__ x, double* gout, double* cost) {
-    __shared__ double dx[PRIOR_MAX_NP], r[PRIOR_MAX_NP], v[PRIOR_MAX_NP], Mb[9 * PRIOR_MAX_NB];
+struct PriorLds { double dx[PRIOR_MAX_NP], r[PRIOR_MAX_NP], v[PRIOR_MAX_NP], Mb[9 * PRIOR_MAX_NB]; };
+union SmallLds { ImuLds imu; GnssLds gn; PriorLds pr; };
+__device__ void prior_rg_block(const SmallArgs& a, const double* __restrict__ x, double* gout, double* cost, unsigned char* pool) {
+    PriorLds& lds_ = *reinterpret_cast<PriorLds*>(pool);
+    double (&dx)[PRIOR_MAX_NP] = lds_.dx; double (&r)[PRIOR_MAX_NP] = lds_.r; double (&v)[PRIOR_MAX_NP] = lds_.v; double (&Mb)[9 * PRIOR_MAX_NB] = lds_.Mb;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, np = a.np;
     prior_dx_M(a, x, dx, Mb);
     // r = r0 + J0 dx: one lane per row, four independent accumulators -- the loads of a row do not depend on each other, so
@@ -582,8 +594,9 @@ __device__ void prior_rg_block(const SmallArgs& a, const double* __restrict__ x,
 }
 
 // workgroups 1..PRIOR_H_BLOCKS: rows i = part, part + PRIOR_H_BLOCKS, ... of H = M^T A0 M
-__device__ void prior_H_block(const SmallArgs& a, const double* __restrict__ x, double* H, int part) {
-    __shared__ double dx[PRIOR_MAX_NP], Mb[9 * PRIOR_MAX_NB];
+__device__ void prior_H_block(const SmallArgs& a, const double* __restrict__ x, double* H, int part, unsigned char* pool) {
+    PriorLds& lds_ = *reinterpret_cast<PriorLds*>(pool);
+    double (&dx)[PRIOR_MAX_NP] = lds_.dx; double (&Mb)[9 * PRIOR_MAX_NB] = lds_.Mb;
     const int tid = threadIdx.x, np = a.np;
     prior_dx_M(a, x, dx, Mb);
     for (int i = part; i < np; i += PRIOR_H_BLOCKS) {
@@ -627,6 +640,7 @@ __global__ __launch_bounds__(SF_THREADS) void k_small_factors(const SmallArgs a)
 #endif
 }
 __device__ void small_factors_body(const SmallArgs& a) {
+    __shared__ __attribute__((aligned(16))) unsigned char pool[sizeof(SmallLds)];
     int which = a.fixed_which;
     if (a.use_status) {
         if (a.st->done || !a.st->cand_pending) return;
@@ -637,19 +651,43 @@ __device__ void small_factors_body(const SmallArgs& a) {
     if (b < a.n_imu) {
         const int si = a.imu[b].slot_i, sj = si + 1, W = a.W;
         imu_block(a.gravity, x + 3 * si, x + 3 * W + 4 * si, x + 7 * W + 9 * si, x + 3 * sj, x + 3 * W + 4 * sj, x + 7 * W + 9 * sj,
-                  a.imu[b], a.imu_blocks + (size_t)which * a.W + b, nullptr, a.marg);
+                  a.imu[b], a.imu_blocks + (size_t)which * a.W + b, nullptr, a.marg, pool);
         return;
     }
     b -= a.n_imu;
     if (b < a.n_groups) {
-        gnss_block(a, x, a.groups[b], b, a.gnss_blocks + (size_t)which * a.gnss_stride + b, a.ddt_blocks + (size_t)which * a.ddt_stride);
+        gnss_block(a, x, a.groups[b], b, a.gnss_blocks + (size_t)which * a.gnss_stride + b, a.ddt_blocks + (size_t)which * a.ddt_stride, pool);
         return;
     }
     b -= a.n_groups;
     if (a.has_prior) {
-        if (b == 0) prior_rg_block(a, x, a.pg + (size_t)which * a.np, a.pcost + which);
-        else prior_H_block(a, x, a.pH + (size_t)which * a.np * a.np, b - 1);
+        if (b == 0) prior_rg_block(a, x, a.pg + (size_t)which * a.np, a.pcost + which, pool);
+        else prior_H_block(a, x, a.pH + (size_t)which * a.np * a.np, b - 1, pool);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_linearize_all: K3 and the small factors in ONE launch.  They only share their input (the candidate state), so the
+// workgroups of both run side by side: the first n_small workgroups take the small-factor roles (long, latency-bound
+// chains on few CUs), the rest are K3 workgroups streaming the correspondences on the others.  The launch lasts about as
+// long as the slower of the two instead of their sum.  (Two streams with fork/join events cost more than they save on
+// this runtime, and hipExtAnyOrderLaunch is ignored on gfx9; one heterogeneous launch needs neither.)
+// ------------------------------------------------------------------------------------------------
+struct K3Args {
+    const float4* pts; const float4* planes; const double* scores; const int* count; int cap;
+    LidarConst lc; double* partials; int n_small, nb;
+};
+__global__ __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_linearize_all(const SmallArgs a, const K3Args k) {
+    static_assert(SF_THREADS == GLIO_K3_THREADS, "one block size for both roles");
+    if ((int)blockIdx.x < k.n_small) { small_factors_body(a); return; }
+    int which = a.fixed_which;
+    if (a.use_status) {
+        if (a.st->done || !a.st->cand_pending) return;
+        which = 1 - a.st->cur;
+    }
+    const int b = (int)blockIdx.x - k.n_small;
+    const int kf = b / k.nb, bx = b - kf * k.nb;
+    k3_body<2, false, true, true>(k.pts, k.planes, k.scores, k.count, k.cap, which ? a.x1 : a.x0, a.W, k.lc, k.partials, kf, bx, k.nb);
 }
 
 // fixed-order sum of the K3 partials of keyframe blockIdx.x into its 28-double block (consumers that want the blocks
@@ -668,7 +706,7 @@ __global__ __launch_bounds__(64) void k_lidar_reduce(const double* __restrict__ 
     blocks[(size_t)blockIdx.x * GLIO_LIDAR_ACC + threadIdx.x] = s;
 }
 void glio_launch_lidar_reduce(glio_ctx* c, int which) {
-    hipLaunchKernelGGL(k_lidar_reduce, dim3(c->W), dim3(64), 0, c->stream, c->d_lidar_partials, c->k3_bpk,
+    hipLaunchKernelGGL(k_lidar_reduce, dim3(c->W), dim3(64), 0, c->stream, c->d_lidar_partials, c->last_k3_nb,
                        c->d_lidar_blocks + (size_t)which * c->W * GLIO_LIDAR_ACC);
 }
 
@@ -884,7 +922,8 @@ __global__ __launch_bounds__(1024) void k_assemble(const AsmArgs a) {
 // ------------------------------------------------------------------------------------------------
 // params: Pi3 Qi4 SBi9 Pj3 Qj4 SBj9 packed [32]; out: r[15] then J[15][32]
 __global__ __launch_bounds__(SF_THREADS) void k_eval_imu(const double gravity, const ImuEdgeDev* e, const double* params, double* out) {
-    imu_block(gravity, params + 0, params + 3, params + 7, params + 16, params + 19, params + 23, *e, nullptr, out);
+    __shared__ __attribute__((aligned(16))) unsigned char pool[sizeof(ImuLds)];
+    imu_block(gravity, params + 0, params + 3, params + 7, params + 16, params + 19, params + 23, *e, nullptr, out, 0, pool);
 }
 
 // LidarPlaneNormFactor residual + global 1x3 / 1x4 Jacobians through Eigen's q*v formula
@@ -949,8 +988,7 @@ void glio_launch_gram(glio_ctx* c, int np) {
 // ------------------------------------------------------------------------------------------------
 GnssDevExtra* glio_extra(glio_ctx* c);   // defined in capi.hip
 
-void glio_launch_small_factors(glio_ctx* c, int use_status_cand, int which, int n_ddt, int marg) {
-    SmallArgs a;
+static int fill_small_args(glio_ctx* c, int use_status_cand, int which, int n_ddt, int marg, SmallArgs& a) {
     a.marg = marg;
     a.dbg = c->arrow.d_dbg + 64;
     GnssDevExtra* ex = glio_extra(c);
@@ -969,9 +1007,29 @@ void glio_launch_small_factors(glio_ctx* c, int use_status_cand, int which, int 
     a.pJ0 = c->d_prior_J0; a.pA0 = c->d_prior_A0; a.pr0 = c->d_prior_r0; a.px0 = c->d_prior_x0;
     a.pslot = c->d_prior_slot; a.pkind = c->d_prior_kind; a.pidx = c->d_prior_idx; a.pcolblk = ex->d_prior_colblk;
     a.pH = c->d_prior_H; a.pg = c->d_prior_g; a.pcost = c->d_prior_cost; a.pwork = c->d_prior_work;
-    const int blocks = c->n_imu + c->n_groups + (a.has_prior ? 1 + PRIOR_H_BLOCKS : 0);
+    return c->n_imu + c->n_groups + (a.has_prior ? 1 + PRIOR_H_BLOCKS : 0);
+}
+void glio_launch_small_factors(glio_ctx* c, int use_status_cand, int which, int n_ddt, int marg) {
+    SmallArgs a;
+    const int blocks = fill_small_args(c, use_status_cand, which, n_ddt, marg, a);
     if (blocks == 0) return;
     hipLaunchKernelGGL(k_small_factors, dim3(blocks), dim3(SF_THREADS), 0, c->stream, a);
+}
+// K3 + small factors in one launch.  Two workgroups fit a CU (register file and LDS of the small-factor roles): the K3 share
+// of the grid is what is left of 2 x 256 slots after the small-factor workgroups, so that everything is resident at once.
+void glio_launch_linearize_all(glio_ctx* c, int use_status_cand, int which, int n_ddt) {
+    SmallArgs a;
+    const int n_small = fill_small_args(c, use_status_cand, which, n_ddt, 0, a);
+    if (n_small == 0) { glio_launch_lidar_linearize(c, use_status_cand, which); return; }
+    K3Args k;
+    k.pts = c->d_pts; k.planes = c->d_planes; k.scores = c->d_scores; k.count = c->d_count; k.cap = c->cap;
+    k.lc = glio_lidar_const(c); k.partials = c->d_lidar_partials; k.n_small = n_small;
+    int nb = (512 - n_small) / c->W;
+    if (nb < 4) nb = 4;
+    if (nb > c->k3_bpk) nb = c->k3_bpk;
+    k.nb = nb;
+    c->last_k3_nb = nb;
+    hipLaunchKernelGGL(k_linearize_all, dim3(n_small + c->W * nb), dim3(SF_THREADS), 0, c->stream, a, k);
 }
 
 void glio_launch_assemble(glio_ctx* c, int use_status_cand, int which, int n_ddt) {
@@ -979,7 +1037,7 @@ void glio_launch_assemble(glio_ctx* c, int use_status_cand, int which, int n_ddt
     a.W = c->W; a.n = 15 * c->W + n_ddt; a.n_ddt = n_ddt; a.n_imu = c->n_imu; a.n_groups = c->n_groups;
     a.has_prior = c->prior_n > 0; a.np = c->prior_n;
     a.st = c->d_status; a.use_status = use_status_cand; a.fixed_which = which;
-    a.lidar_partials = c->d_lidar_partials; a.lidar_nb = c->k3_bpk; a.imu_blocks = c->d_imu_blocks; a.gnss_blocks = c->d_gnss_blocks; a.ddt_blocks = c->d_ddt_blocks;
+    a.lidar_partials = c->d_lidar_partials; a.lidar_nb = c->last_k3_nb; a.imu_blocks = c->d_imu_blocks; a.gnss_blocks = c->d_gnss_blocks; a.ddt_blocks = c->d_ddt_blocks;
     a.gnss_stride = c->W * c->W; a.ddt_stride = c->n_ddt_max > 0 ? c->n_ddt_max : 1;
     a.pH = c->d_prior_H; a.pg = c->d_prior_g; a.pcost = c->d_prior_cost; a.prior_index = c->d_prior_index;
     a.H0 = c->d_H[0]; a.H1 = c->d_H[1]; a.g0 = c->d_g[0]; a.g1 = c->d_g[1]; a.c0 = c->d_cost[0]; a.c1 = c->d_cost[1];

@@ -159,6 +159,8 @@ struct glio_ctx {
     int have_factors;
     int last_n_ddt;
     int k3_bpk, k3_unroll;        // K3 launch geometry (tunable, glio_debug_set_k3)
+    int last_k3_nb;               // partials per keyframe written by the most recent K3 (its consumers sum that many)
+    int merged_linearize;         // K3 and the small factors in one launch (k_linearize_all)
     ArrowDev arrow;
 };
 
@@ -256,6 +258,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 void glio_launch_lidar_linearize(glio_ctx* c, int use_status_cand, int which, int marg = 0);
 // factor_kernels.hip
 void glio_launch_small_factors(glio_ctx* c, int use_status_cand, int which, int n_ddt, int marg = 0);
+void glio_launch_linearize_all(glio_ctx* c, int use_status_cand, int which, int n_ddt);   // K3 + small factors, one launch
 void glio_launch_lidar_reduce(glio_ctx* c, int which);      // K3 partials -> d_lidar_blocks (the marginalization's assembly reads the blocks)
 void glio_launch_assemble(glio_ctx* c, int use_status_cand, int which, int n_ddt);
 void glio_launch_stream_read(glio_ctx* c);
