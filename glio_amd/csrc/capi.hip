@@ -112,7 +112,7 @@ int glio_create(int device, const glio_opts* opts, glio_ctx** out) {
     }
     ALLOC(c->d_xout, nx * 8);
     ALLOC(c->d_lidar_partials, (size_t)W * GLIO_K3_MAX_BLOCKS_PER_KF * GLIO_LIDAR_ACC * 8);
-    c->k3_bpk = GLIO_K3_BLOCKS_PER_KF; c->last_k3_nb = c->k3_bpk; c->merged_linearize = 1; c->k3_unroll = 22;   /* 2-deep batches, non-temporal loads, next batch issued before the arithmetic of the current one */
+    c->k3_bpk = GLIO_K3_BLOCKS_PER_KF; c->last_k3_nb = c->k3_bpk; c->merged_linearize = 2; c->k3_unroll = 22;   /* 2-deep batches, non-temporal loads, next batch issued before the arithmetic of the current one */
     { int per = 768 / W;   /* ~3 workgroups per CU measured best on MI355X (scripts/k3_sweep.py) */ if (per < 8) per = 8; if (per > GLIO_K3_MAX_BLOCKS_PER_KF) per = GLIO_K3_MAX_BLOCKS_PER_KF; c->k3_bpk = per; }
     ALLOC(c->d_lidar_blocks, 2 * (size_t)W * GLIO_LIDAR_ACC * 8);
     ALLOC(c->d_L, (size_t)(n_max + 1) * n_max * 8);
@@ -819,7 +819,7 @@ int glio_debug_arrow_stamps(glio_ctx* c, long long* out64) {
     GLIO_HIP_CHECK(hipMemcpy(out64, c->arrow.d_dbg, 320 * 8, hipMemcpyDeviceToHost));
     return GLIO_OK;
 }
-int glio_debug_set_merged_linearize(glio_ctx* c, int on) { if (!c) return GLIO_E_ARG; c->merged_linearize = on ? 1 : 0; return GLIO_OK; }
+int glio_debug_set_merged_linearize(glio_ctx* c, int on) { if (!c) return GLIO_E_ARG; c->merged_linearize = on; return GLIO_OK; }
 // kernel groups kept queued ahead of the GPU by glio_solve (0 = queue all max_iterations+1 groups up front)
 int glio_debug_set_enqueue_lead(glio_ctx* c, int lead) {
     if (!c || lead < 0) return GLIO_E_ARG;

@@ -675,7 +675,7 @@ __device__ void small_factors_body(const SmallArgs& a) {
 // ------------------------------------------------------------------------------------------------
 struct K3Args {
     const float4* pts; const float4* planes; const double* scores; const int* count; int cap;
-    LidarConst lc; double* partials; int n_small, nb;
+    LidarConst lc; double* partials; int n_small, nb, skip_lo, skip_hi, n_k3;
 };
 __global__ __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_linearize_all(const SmallArgs a, const K3Args k) {
     static_assert(SF_THREADS == GLIO_K3_THREADS, "one block size for both roles");
@@ -685,7 +685,12 @@ __global__ __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         if (a.st->done || !a.st->cand_pending) return;
         which = 1 - a.st->cur;
     }
-    const int b = (int)blockIdx.x - k.n_small;
+    // workgroups [skip_lo, skip_hi) stay idle: in dispatch order they would land in the second slot of the CUs that run the
+    // small-factor workgroups and slow those (the launch's long pole) down
+    int b = (int)blockIdx.x;
+    if (b >= k.skip_lo && b < k.skip_hi) return;
+    b -= k.n_small + (b >= k.skip_hi ? k.skip_hi - k.skip_lo : 0);
+    if (b >= k.n_k3) return;
     const int kf = b / k.nb, bx = b - kf * k.nb;
     k3_body<2, false, true, true>(k.pts, k.planes, k.scores, k.count, k.cap, which ? a.x1 : a.x0, a.W, k.lc, k.partials, kf, bx, k.nb);
 }
@@ -1024,12 +1029,14 @@ void glio_launch_linearize_all(glio_ctx* c, int use_status_cand, int which, int 
     K3Args k;
     k.pts = c->d_pts; k.planes = c->d_planes; k.scores = c->d_scores; k.count = c->d_count; k.cap = c->cap;
     k.lc = glio_lidar_const(c); k.partials = c->d_lidar_partials; k.n_small = n_small;
-    int nb = (512 - n_small) / c->W;
+    const bool skip = c->merged_linearize == 2 && n_small <= 128;
+    int nb = (512 - (skip ? 2 : 1) * n_small) / c->W;
     if (nb < 4) nb = 4;
     if (nb > c->k3_bpk) nb = c->k3_bpk;
-    k.nb = nb;
+    k.nb = nb; k.n_k3 = c->W * nb;
+    k.skip_lo = skip ? 256 : 0; k.skip_hi = skip ? 256 + n_small : 0;
     c->last_k3_nb = nb;
-    hipLaunchKernelGGL(k_linearize_all, dim3(n_small + c->W * nb), dim3(SF_THREADS), 0, c->stream, a, k);
+    hipLaunchKernelGGL(k_linearize_all, dim3(n_small + k.n_k3 + (k.skip_hi - k.skip_lo)), dim3(SF_THREADS), 0, c->stream, a, k);
 }
 
 void glio_launch_assemble(glio_ctx* c, int use_status_cand, int which, int n_ddt) {

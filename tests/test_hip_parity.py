@@ -108,6 +108,26 @@ def test_lidar_kernel_variants(hip, po, k3_window, code):
     ctx.close()
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_linearize_launch_forms(hip, po, small_window, small_corr, mode):
+    """K3 and the small factors as separate launches (0), in one heterogeneous launch (1), and with the idle workgroups
+    behind the small-factor CUs (2, the default): the same normal equations, and the same solve, as the oracle's."""
+    win = small_window
+    prob = po.Problem(win, small_corr)
+    ctx = hip.Context(win.opts)
+    ctx.load_window(win, small_corr)
+    assert hip.load().glio_debug_set_merged_linearize(ctx._h, mode) == 0
+    st = _state_for(win, True)
+    Ho, go, co = prob.linearize(st)
+    Hh, gh, ch = ctx.linearize(st)
+    assert abs(ch - co) <= 1e-10 * abs(co) and rel_err(gh, go) <= 1e-10 and rel_err(Hh, Ho) <= 1e-10
+    so, summ_o = prob.solve(st)
+    sh, summ_h = ctx.solve(st)
+    assert summ_h.iterations == summ_o.iterations
+    assert np.abs(sh.trans - so.trans).max() <= 1e-8 and np.abs(sh.quat - so.quat).max() <= 1e-9
+    ctx.close()
+
+
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_solve_parity_small(hip, po, small_window, small_corr, case):
     win = small_window
