@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <chrono>
 #include <vector>
 
@@ -104,8 +105,14 @@ int glio_create(int device, const glio_opts* opts, glio_ctx** out) {
     ALLOC(c->d_prior_H, 2 * (size_t)npmax * npmax * 8); ALLOC(c->d_prior_g, 2 * npmax * 8); ALLOC(c->d_prior_cost, 2 * 8);
     ALLOC(c->d_prior_work, (size_t)(3 * npmax + 9 * (2 * W + 1)) * 8);
     const int nx = glio_x_size(W, c->n_ddt_max);
+    {   // [SolverStatus | pad to 512 B | x buffer 0] in one allocation (and one pinned mirror): a solve starts with ONE upload
+        unsigned char* up = nullptr;
+        ALLOC(up, 512 + (size_t)nx * 8);
+        c->d_status = reinterpret_cast<SolverStatus*>(up);
+        c->d_x[0] = reinterpret_cast<double*>(up + 512);
+    }
     for (int k = 0; k < 2; ++k) {
-        ALLOC(c->d_x[k], nx * 8);
+        if (k == 1) ALLOC(c->d_x[k], nx * 8);
         ALLOC(c->d_H[k], (size_t)n_max * n_max * 8);
         ALLOC(c->d_g[k], n_max * 8);
         ALLOC(c->d_cost[k], 8);
@@ -117,7 +124,6 @@ int glio_create(int device, const glio_opts* opts, glio_ctx** out) {
     ALLOC(c->d_lidar_blocks, 2 * (size_t)W * GLIO_LIDAR_ACC * 8);
     ALLOC(c->d_L, (size_t)(n_max + 1) * n_max * 8);
     ALLOC(c->d_vec, (size_t)10 * n_max * 8);
-    ALLOC(c->d_status, sizeof(SolverStatus));
     {   // structured solver
         ArrowDev& ar = c->arrow;
         ar.mode = 1; ar.gnss_ok = 1; ar.prior_ok = 1; ar.max_epoch = -1; ar.gnss_chain = 1; ar.prior_chain = 1;
@@ -130,11 +136,20 @@ int glio_create(int device, const glio_opts* opts, glio_ctx** out) {
         GLIO_HIP_CHECK(hipMemsetAsync(ar.d_flag, 0, 4, c->stream));
         GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
     }
-    GLIO_HIP_CHECK(hipHostMalloc((void**)&c->h_status, sizeof(SolverStatus)));
     GLIO_HIP_CHECK(hipHostMalloc((void**)&c->h_progress, 64, hipHostMallocMapped | hipHostMallocCoherent));
     GLIO_HIP_CHECK(hipHostGetDevicePointer((void**)&c->d_progress, (void*)c->h_progress, 0));
     c->h_progress[0] = 0; c->h_progress[1] = 0; c->enqueue_lead = 1;
-    GLIO_HIP_CHECK(hipHostMalloc((void**)&c->h_xbuf, (size_t)nx * 8));
+    static_assert(sizeof(SolverStatus) <= 512, "result layout");
+    GLIO_HIP_CHECK(hipHostMalloc((void**)&c->h_result, 512 + (size_t)nx * 8, hipHostMallocMapped | hipHostMallocCoherent));
+    GLIO_HIP_CHECK(hipHostGetDevicePointer((void**)&c->d_result, (void*)c->h_result, 0));
+    memset(c->h_result, 0, 512 + (size_t)nx * 8);
+    c->solve_id = 0;
+    {
+        unsigned char* hup = nullptr;
+        GLIO_HIP_CHECK(hipHostMalloc((void**)&hup, 512 + (size_t)nx * 8));
+        c->h_status = reinterpret_cast<SolverStatus*>(hup);
+        c->h_xbuf = reinterpret_cast<double*>(hup + 512);
+    }
     GLIO_HIP_CHECK(hipEventCreate(&c->ev0)); GLIO_HIP_CHECK(hipEventCreate(&c->ev1));
     CtxExtra* ex = new CtxExtra();
     memset(ex, 0, sizeof *ex);
@@ -159,11 +174,11 @@ void glio_destroy(glio_ctx* c) {
     void* ptrs[] = {c->d_pts, c->d_planes, c->d_scores, c->d_count, c->d_scan, c->d_imu, c->d_imu_blocks, c->d_gnss_blocks, c->d_groups,
                     c->d_ddt_blocks, c->d_dd, c->d_dop, c->d_prior_J0, c->d_prior_A0, c->d_prior_r0, c->d_prior_x0, c->d_prior_slot,
                     c->d_prior_kind, c->d_prior_idx, c->d_prior_index, c->d_prior_H, c->d_prior_g, c->d_prior_cost, c->d_prior_work,
-                    c->d_x[0], c->d_x[1], c->d_H[0], c->d_H[1], c->d_g[0], c->d_g[1], c->d_cost[0], c->d_cost[1], c->d_xout,
+                    /* d_x[0] lives inside d_status' allocation */ c->d_x[1], c->d_H[0], c->d_H[1], c->d_g[0], c->d_g[1], c->d_cost[0], c->d_cost[1], c->d_xout,
                     c->d_lidar_partials, c->d_lidar_blocks, c->d_L, c->d_vec, c->d_status,
                     c->arrow.d_ep_slots, c->arrow.d_ep_off, c->arrow.d_ep_list, c->arrow.d_Y, c->arrow.d_Lblk, c->arrow.d_Sp, c->arrow.d_z, c->arrow.d_flag, c->arrow.d_dbg};
     for (void* p : ptrs) if (p) hipFree(p);
-    hipHostFree(c->h_status); hipHostFree(c->h_xbuf); hipHostFree((void*)c->h_progress);
+    hipHostFree(c->h_status); /* h_xbuf lives inside it */ hipHostFree((void*)c->h_progress); hipHostFree(c->h_result);
     if (c->h_stage) hipHostFree(c->h_stage);
     hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
     for (size_t i = 0; i < g_extras.size(); ++i)
@@ -576,26 +591,28 @@ static int enqueue_solve(glio_ctx* c, int n_ddt) {
     st.cur = 1;                       // "candidate" buffer 0 holds the initial point
     st.cand_pending = 1;
     st.radius = c->opts.initial_trust_region_radius; st.mu = 1e-8; st.n_ddt = n_ddt; st.decrease_factor = 2.0;
+    c->solve_id = c->solve_id % 30000 + 1;          // kernels of the previous solve's look-ahead group may still be draining:
+    st.solve_id = c->solve_id;                      // their progress words carry the old tag and are ignored
     *c->h_status = st;
-    GLIO_HIP_CHECK(hipMemcpyAsync(c->d_status, c->h_status, sizeof st, hipMemcpyHostToDevice, c->stream));
-    GLIO_HIP_CHECK(hipMemcpyAsync(c->d_x[0], c->h_xbuf, (size_t)nx * 8, hipMemcpyHostToDevice, c->stream));
+    GLIO_HIP_CHECK(hipMemcpyAsync(c->d_status, c->h_status, 512 + (size_t)nx * 8, hipMemcpyHostToDevice, c->stream));   // status + state
     // The trust-region loop lives on the device (SolverStatus); the host only feeds it kernel groups
     // [linearise, step].  Instead of queueing all max_iterations+1 groups blindly -- after convergence the rest are
     // empty launches, ~2.5 us each -- it stays `enqueue_lead` groups ahead of the GPU, watching a progress word the
     // first kernel of every group writes to mapped host memory, and stops as soon as `done` shows up.
-    c->h_progress[0] = 0; c->h_progress[1] = 0;
+    const int id = c->solve_id;
+    auto started = [&]() { const int w = c->h_progress[0]; return (w >> 16) == id ? (w & 0xffff) : 0; };
     const int total = c->opts.max_iterations + 1;
     const int lead = c->enqueue_lead < 1 ? total : c->enqueue_lead;
     const auto t_start = std::chrono::steady_clock::now();
     int enq = 0, spins = 0;
     while (enq < total) {
-        if (c->h_progress[1]) break;
-        if (enq - c->h_progress[0] <= lead) {
+        if (c->h_progress[1] == id) break;
+        if (enq - started() <= lead) {
             enqueue_linearize(c, 1, 0, n_ddt);
             glio_launch_tr_step(c, n_ddt);
             ++enq;
         } else if (((++spins) & 0xfff) == 0 && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(20)) {
-            glio_set_error("solver made no progress for 20 s (group %d of %d)", c->h_progress[0], total);
+            glio_set_error("solver made no progress for 20 s (group %d of %d)", started(), total);
             return GLIO_E_HIP;
         }
     }
@@ -620,9 +637,26 @@ int glio_solve(glio_ctx* c, glio_state* s, glio_summary* sum) {
     pack_state(c, s, c->h_xbuf);
     rc = enqueue_solve(c, n_ddt);
     if (rc) return rc;
-    GLIO_HIP_CHECK(hipMemcpyAsync(c->h_status, c->d_status, sizeof(SolverStatus), hipMemcpyDeviceToHost, c->stream));
-    GLIO_HIP_CHECK(hipMemcpyAsync(c->h_xbuf, c->d_xout, (size_t)nx * 8, hipMemcpyDeviceToHost, c->stream));
-    GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    // The kernel that ends the solve publishes status + state in mapped host memory and then the solve's tag: no
+    // device-to-host copy, no stream synchronisation (the look-ahead group of empty launches drains behind our back; the
+    // next call on this stream queues behind it).  Fallback after 20 s without the tag: the classic copy + sync.
+    {
+        const auto t_wait = std::chrono::steady_clock::now();
+        int spins = 0;
+        bool seen = true;
+        while (c->h_progress[1] != c->solve_id) {
+            if (((++spins) & 0xfff) == 0 && std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(20)) { seen = false; break; }
+        }
+        if (seen) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            memcpy(c->h_status, c->h_result, sizeof(SolverStatus));
+            memcpy(c->h_xbuf, c->h_result + 512, (size_t)nx * 8);
+        } else {
+            GLIO_HIP_CHECK(hipMemcpyAsync(c->h_status, c->d_status, sizeof(SolverStatus), hipMemcpyDeviceToHost, c->stream));
+            GLIO_HIP_CHECK(hipMemcpyAsync(c->h_xbuf, c->d_xout, (size_t)nx * 8, hipMemcpyDeviceToHost, c->stream));
+            GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+        }
+    }
     fill_summary(c, sum);
     if (!c->h_status->done) { glio_set_error("solver did not finish"); return GLIO_E_STATE; }
     unpack_state(c, c->h_xbuf, s);

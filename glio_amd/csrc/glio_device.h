@@ -75,6 +75,8 @@ struct SolverStatus {
     int group;            // number of trust-region kernel groups started (k_tr_prepare launches) in this solve
     int lin_fail;         // Levenberg-Marquardt: the linear solve of this iteration failed -> the step is invalid
     double decrease_factor;   // LevenbergMarquardtStrategy::decrease_factor_
+    int solve_id;             // tag of this solve in the host-mapped progress words (kernels of an earlier solve may still be draining)
+    int pad_;
 };
 
 // Structured ("arrow") linear solver of the trust-region step (solver_kernels.hip): buffers + structure tables
@@ -151,7 +153,10 @@ struct glio_ctx {
     double* d_vec;                // scale, diag, grad, gn, step, delta, tmp ... 10 x n_max
     SolverStatus* d_status;
     SolverStatus* h_status;       // pinned
-    volatile int* h_progress;     // pinned + mapped: [0] groups started, [1] done -- written by the GPU, polled by the host
+    volatile int* h_progress;     // pinned + mapped: [0] (solve id << 16) | groups started, [1] id of the solve that is done -- written by the GPU, polled by the host
+    unsigned char* h_result; unsigned char* d_result;   // pinned + mapped: [SolverStatus | pad to 512 B | final state]: the last kernel of a solve
+                                                        // publishes its result here, glio_solve reads it without a copy or a stream sync
+    int solve_id;
     int* d_progress;              // device alias of h_progress
     int enqueue_lead;             // kernel groups the host keeps queued ahead of the GPU
     double* h_xbuf;               // pinned staging for state upload/download

@@ -49,7 +49,8 @@ struct TrArgs {
     double* L; double* vec; int vstride;
     SolverStatus* status;
     int* arrow_flag; const double* arrow_z;      // structured solver result (null = dense only)
-    int* progress;                               // host-mapped {groups started, done}
+    int* progress;                               // host-mapped {(solve id << 16) | groups started, id of the finished solve}
+    SolverStatus* status_host; double* xout_host; // host-mapped copy of the result (glio_solve reads it without a device-to-host copy)
 };
 
 // workspace vectors (global, persist across the launches of one solve)
@@ -385,8 +386,10 @@ __device__ __forceinline__ void backsub_packed_lds(const double* P, const int n,
 __device__ __forceinline__ void finalize(const TrArgs& a, const SolverStatus& s) {
     const double* xc = s.cur ? a.x1 : a.x0;
     const int nx = 16 * a.W + a.n_ddt;
-    for (int k = threadIdx.x; k < nx; k += blockDim.x) a.xout[k] = xc[k];
-    if (threadIdx.x == 0) { *a.status = s; a.progress[1] = 1; __threadfence_system(); }
+    for (int k = threadIdx.x; k < nx; k += blockDim.x) { const double v = xc[k]; a.xout[k] = v; a.xout_host[k] = v; }
+    __threadfence_system();                      // every thread's part of the host copy is out before the flag
+    __syncthreads();
+    if (threadIdx.x == 0) { *a.status = s; *a.status_host = s; __threadfence_system(); a.progress[1] = s.solve_id; __threadfence_system(); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -401,8 +404,8 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_prepare(const TrArgs a) {
         s = *a.status;
         s.group += 1;
         a.status->group = s.group;
-        a.progress[0] = s.group;                 // the host enqueues the next kernel group when it sees this one start
-        if (s.done) a.progress[1] = 1;
+        a.progress[0] = (s.solve_id << 16) | s.group;       // the host enqueues the next kernel group when it sees this one start
+        if (s.done) a.progress[1] = s.solve_id;
         __threadfence_system();
     }
     __syncthreads();
@@ -617,11 +620,14 @@ __device__ __forceinline__ void tr_factor_body(const TrArgs& a) {
     if (tid == 0) {
         if (solved) { a.status->mu_used = *smu; if (!a.lm) a.status->mu = fmax(1e-8, 2.0 * (*smu) / 10.0); a.status->lin_fail = 0; }
         else if (a.lm) { a.status->lin_fail = 1; }       // invalid step: k_tr_dogleg shrinks the radius
-        else { a.status->mu = *smu; a.status->done = 1; a.status->termination = GLIO_TERM_FAILURE; a.progress[1] = 1; __threadfence_system(); }
+        else { a.status->mu = *smu; a.status->done = 1; a.status->termination = GLIO_TERM_FAILURE; }
     }
-    if (!solved && !a.lm) {
+    if (!solved && !a.lm) {          // linear solver failure: publish the current point as the result
         const double* xc = a.status->cur ? a.x1 : a.x0;
-        for (int k = tid; k < 16 * a.W + a.n_ddt; k += TR_THREADS) a.xout[k] = xc[k];
+        for (int k = tid; k < 16 * a.W + a.n_ddt; k += TR_THREADS) { const double v = xc[k]; a.xout[k] = v; a.xout_host[k] = v; }
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) { *a.status_host = *a.status; __threadfence_system(); a.progress[1] = a.status->solve_id; __threadfence_system(); }
     }
 }
 
@@ -1542,6 +1548,7 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
     a.H0 = c->d_H[0]; a.H1 = c->d_H[1]; a.g0 = c->d_g[0]; a.g1 = c->d_g[1]; a.c0 = c->d_cost[0]; a.c1 = c->d_cost[1];
     a.L = c->d_L; a.vec = c->d_vec; a.vstride = c->n_max;
     a.status = c->d_status; a.progress = c->d_progress;
+    a.status_host = reinterpret_cast<SolverStatus*>(c->d_result); a.xout_host = reinterpret_cast<double*>(c->d_result + 512);
     // structured factorisation when the factor graph is a chain (IMU / Doppler edges between neighbours only, at most
     // one speed-bias block in the prior) and its workspaces fit the LDS; the dense kernel stays as the fallback
     const int np = 6 * c->W, K = a.n - np;
