@@ -1,16 +1,16 @@
 // factor_kernels.hip -- K4/K5/K6 + assembly: the O(W) "small" factors of the sliding-window problem
 // and the gather that builds the dense normal equations H, g on device.
 //
-//   k_small_factors : one launch, workgroup roles
-//       [0, W)              reduce the K3 partials of keyframe b (fixed order)
-//       [W, W+n_imu)        ImuFactor::Evaluate          (reference GLIO/include/factors/ImuFactor.h:21-171,
+//   k_small_factors : workgroup roles (inside glio_solve they are the first workgroups of k_linearize_all, which runs
+//                     the K3 workgroups beside them; the roles overlay one LDS pool)
+//       [0, n_imu)          ImuFactor::Evaluate          (reference GLIO/include/factors/ImuFactor.h:21-171,
 //                                                          Preintegration.h:196-235) -> 30x30 block
 //       [.., +n_groups)     dd_psr_factor_20::Evaluate   (dd_psr_factor.hpp:25-171) and
 //                           tcdopplerFactor              (dopp_factor.hpp:24-75, HuberLoss(1.0)) of one
 //                           (slot_i,slot_j) pair -> 30x30 block + per-epoch clock-drift coupling
-//       last 1+8            MarginalizationFactor::Evaluate (GLIO/src/MarginalizationFactor.cpp:233-287):
-//                           one workgroup for r, g, cost and eight sharing the rows of H
-//   k_assemble      : H[r][c] / g[r] gathered from those blocks (no atomics, deterministic)
+//       last 1+24           MarginalizationFactor::Evaluate (GLIO/src/MarginalizationFactor.cpp:233-287):
+//                           one workgroup for r, g, cost and 24 sharing the rows of H
+//   k_assemble      : H[r][c] / g[r] gathered from those blocks and from the K3 partials (no atomics, deterministic)
 //
 // All Jacobians go through the same chain as Ceres: global Jacobian -> (loss corrector) ->
 // QuaternionParameterization Jacobian (left (+), GraphGNSSLibV1.1/docs/source/nnls_modeling.rst:1312-1327).
@@ -24,10 +24,8 @@ struct SmallArgs {
     long long* dbg;           // per-workgroup duration (100 MHz ticks), development aid
     int W, n_imu, n_groups, has_prior, n_ddt;
     int marg;                  // 1 = marginalization convention for quaternion blocks (global x,y,z columns, quirk Q8)
-    int lidar_blocks_per_kf;
     const double* x0; const double* x1;
     const SolverStatus* st; int use_status; int fixed_which;
-    const double* lidar_partials; double* lidar_blocks;     // [2][W][28]
     const ImuEdgeDev* imu; PairBlock* imu_blocks;           // [2][W]
     const glio_dd_psr* dd; const glio_doppler* dop; const GnssGroup* groups; const DopRun* runs; int n_runs;
     PairBlock* gnss_blocks; DdtBlock* ddt_blocks; int gnss_stride; int ddt_stride;
@@ -998,10 +996,8 @@ static int fill_small_args(glio_ctx* c, int use_status_cand, int which, int n_dd
     a.dbg = c->arrow.d_dbg + 64;
     GnssDevExtra* ex = glio_extra(c);
     a.W = c->W; a.n_imu = c->n_imu; a.n_groups = c->n_groups; a.has_prior = c->prior_n > 0; a.n_ddt = n_ddt;
-    a.lidar_blocks_per_kf = c->k3_bpk;
     a.x0 = c->d_x[0]; a.x1 = c->d_x[1];
     a.st = c->d_status; a.use_status = use_status_cand; a.fixed_which = which;
-    a.lidar_partials = c->d_lidar_partials; a.lidar_blocks = c->d_lidar_blocks;
     a.imu = c->d_imu; a.imu_blocks = c->d_imu_blocks;
     a.dd = c->d_dd; a.dop = c->d_dop; a.groups = c->d_groups; a.runs = ex->d_runs; a.n_runs = ex->n_runs;
     a.gnss_blocks = c->d_gnss_blocks; a.ddt_blocks = c->d_ddt_blocks; a.gnss_stride = c->W * c->W; a.ddt_stride = c->n_ddt_max > 0 ? c->n_ddt_max : 1;

@@ -1179,8 +1179,9 @@ __global__ __launch_bounds__(TR_THREADS) void k_arrow_solve(const ArrowArgs a) {
 // chain of 15 x 15 blocks: no dense pose block at all.  ONE kernel, one workgroup: the blocks (minus the epoch
 // contribution) are staged in LDS; wavefront 0 eliminates keyframes 0 .. m-1, wavefront 2 keyframes W-1 .. m+1 (twisted
 // factorisation), the meeting keyframe m = W/2 last.  A chain step holds the 31 x 15 panel [D_i; B_i; rhs_i] one row per
-// lane, factors it in 15 register steps (v_readlane pivot / multipliers) -- the right-hand side rides along as row 30 --
-// and takes the rank-15 update of the next block from the stored panel (135 (row, column) pairs over the 64 lanes).
+// lane, factors it in 15 register steps (v_readlane multipliers, the pivots one step ahead as a scalar recurrence) -- the
+// right-hand side rides along as row 30 -- and takes the rank-15 update of the next block from the stored panel as
+// C = X X^T on the matrix core (4 x v_mfma_f64_16x16x4).
 // Back substitution runs the two half chains in parallel again.  The result goes where the arrow kernels put theirs
 // (a.z, flag 2); a non-positive pivot raises flag 1 and k_tr_factor falls back to the dense factorisation.
 // ------------------------------------------------------------------------------------------------
@@ -1208,7 +1209,7 @@ __device__ __forceinline__ double pivot_rsqrt(const double d) {
 
 template <bool DOWN>
 __device__ __forceinline__ void chain_step15(const int i, const int nb, const bool has_nb, double (&av)[KC_NB], double* Blk, double* Cs, const int lane, bool& bad,
-                                             const int (&pr2)[3], const int (&pj2)[3], long long* ph = nullptr) {
+                                             long long* ph = nullptr) {
 #ifdef GLIO_DEV_STAMPS
 #define CS_CLK(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define CS_PH(k) do { long long t_; CS_CLK(t_); if (ph) ph[k] += t_ - tprev; tprev = t_; } while (0)
@@ -1437,18 +1438,10 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a) {
         if (wv == 2 && nB > 0) { for (int j = 0; j < KC_NB; ++j) av[j] = Blk[(size_t)(W - 1) * KC_BLK + row * KC_RS + j]; }
     }
     bool bad = false;
-    int pr2[3], pj2[3];                          // the (row, column) pairs of the rank-15 update this lane computes
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const int p = lane + 64 * q;
-        if (p < 120) { int r2 = 0; while (((r2 + 1) * (r2 + 2)) / 2 <= p) ++r2; pr2[q] = r2; pj2[q] = p - (r2 * (r2 + 1)) / 2; }
-        else if (p < 135) { pr2[q] = 15; pj2[q] = p - 120; }
-        else { pr2[q] = -1; pj2[q] = 0; }
-    }
     long long ph[5] = {0, 0, 0, 0, 0};
     for (int it = 0; it <= T; ++it) {
         if (wv == 0) {
-            if (it < nT) chain_step15<false>(it, it + 1, true, av, Blk, CsT, lane, bad, pr2, pj2, ph);
+            if (it < nT) chain_step15<false>(it, it + 1, true, av, Blk, CsT, lane, bad, ph);
             else if (it == T) {
                 {
                     const int row = lane < KC_NB ? lane : 30, crow = lane < KC_NB ? lane : 15;
@@ -1464,10 +1457,10 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a) {
                         av[j] = j < lim ? v : 0.0;
                     }
                 }
-                chain_step15<false>(mid, mid, false, av, Blk, CsT, lane, bad, pr2, pj2);
+                chain_step15<false>(mid, mid, false, av, Blk, CsT, lane, bad);
             }
         } else if (wv == 2) {
-            if (it < nB) { const int i = W - 1 - it; chain_step15<true>(i, i - 1, true, av, Blk, CsB, lane, bad, pr2, pj2); }
+            if (it < nB) { const int i = W - 1 - it; chain_step15<true>(i, i - 1, true, av, Blk, CsB, lane, bad); }
         }
         __syncthreads();
     }
