@@ -268,7 +268,9 @@ __device__ __forceinline__ AssocSlot assoc_slot(const AssocArgs& a) {
 // in two rounds, stride through the candidate points of each cell together, keep private top-5 lists and
 // merge them with shuffles; lane 0 of the group fits the plane.  This turns ~30 dependent L2 round trips
 // per query into a handful and gives the launch 16x the lanes to hide them with.
-#define AQ_LANES 16
+#ifndef AQ_LANES
+#define AQ_LANES 16      /* 8 measured -7 % on the one-call window association but +23 % on the 32k-query pair launches */
+#endif
 #define AQ_PER_BLOCK (256 / AQ_LANES)
 
 __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src) {
@@ -317,6 +319,7 @@ __device__ __forceinline__ void knn5_insert(const float px, const float py, cons
 __global__ __launch_bounds__(256) void k_knn5(const AssocArgs a, const float4* __restrict__ scan, const float4* __restrict__ map,
                                               const int4* __restrict__ ent, int* __restrict__ o_nn5, float* __restrict__ o_d4) {
     // per query: the 27 cells as (exclusive prefix of candidate counts, first point); entries 27..31 hold the total
+    static_assert(AQ_ROUNDS * AQ_LANES <= 32 && AQ_LANES >= 2, "the cell table of a query has 32 entries");
     __shared__ int2 s_tab[AQ_PER_BLOCK][33];
     const int lane = threadIdx.x & 63, j = threadIdx.x & (AQ_LANES - 1), g = threadIdx.x / AQ_LANES;
     const int gbase = lane & ~(AQ_LANES - 1);                 // first lane of this group inside the wavefront
@@ -353,16 +356,19 @@ __global__ __launch_bounds__(256) void k_knn5(const AssocArgs a, const float4* _
     }
     // ---- flatten: exclusive prefix of the counts in cell order (round 0 lanes 0..15, then round 1), so that the group
     // walks ONE list of `tot` candidates with all its lanes busy instead of 27 mostly empty cells one after the other
-    int s0 = cc[0], s1 = cc[1];
+    int tot = 0;
 #pragma unroll
-    for (int off = 1; off < AQ_LANES; off <<= 1) {
-        const int t0 = __shfl_up(s0, off, AQ_LANES), t1 = __shfl_up(s1, off, AQ_LANES);
-        if (j >= off) { s0 += t0; s1 += t1; }
+    for (int h = 0; h < AQ_ROUNDS; ++h) {
+        int incl = cc[h];
+#pragma unroll
+        for (int off = 1; off < AQ_LANES; off <<= 1) {
+            const int t0 = __shfl_up(incl, off, AQ_LANES);
+            if (j >= off) incl += t0;
+        }
+        s_tab[g][h * AQ_LANES + j] = make_int2(tot + incl - cc[h], cs[h]);      // cells >= 27 are empty: their prefix is the total
+        tot += __shfl(incl, gbase + AQ_LANES - 1, 64);
     }
-    const int tot0 = __shfl(s0, gbase + AQ_LANES - 1, 64);
-    const int tot = tot0 + __shfl(s1, gbase + AQ_LANES - 1, 64);
-    s_tab[g][j] = make_int2(s0 - cc[0], cs[0]);
-    s_tab[g][AQ_LANES + j] = make_int2(tot0 + s1 - cc[1], cs[1]);           // cells >= 27 are empty: their prefix is `tot`
+    for (int c = AQ_ROUNDS * AQ_LANES + j; c < 32; c += AQ_LANES) s_tab[g][c] = make_int2(tot, 0);   // padding of the search table
     GLIO_WAVE_LDS_SYNC();
     // ---- candidates: private top-5 per lane, ranked by (float distance, original index)
     float bd[5] = {FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX};
