@@ -293,25 +293,30 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 //   keyframe's own frame: a second plane is fitted to the local coordinates of the same five neighbours and the record is
 //   [unit local normal | local centroid] (6 doubles, o_nc) with score 2.5 w instead of the weighted global plane.
 #define AQ_ROUNDS ((27 + AQ_LANES - 1) / AQ_LANES)
+// Candidate lists are kept as ONE 64-bit key per entry, (float distance bits << 32) | original map index: for non-negative
+// floats the unsigned order of the bits is the order of the values, so "smaller distance, then smaller index" is a single
+// u64 compare and a list entry moves as one register pair (the kernel is VALU-issue bound: ~1600 vector instructions per
+// wavefront of four queries, rocprofv3 SQ_INSTS_VALU).
 __device__ __forceinline__ void knn5_insert(const float px, const float py, const float pz, const float4 mp, const int m,
-                                            float bd[5], int bi[5], int bp[5]) {
+                                            unsigned long long bk[5], int bp[5]) {
     // plain operators, NOT the __f*_rn intrinsics: those are header functions compiled with
     // contraction allowed and fuse after inlining; here the file-scope pragma keeps them separate
     const float ex = px - mp.x, ey = py - mp.y, ez = pz - mp.z;
     float d = ex * ex;
     d = d + ey * ey;
     d = d + ez * ez;
-    const int idx = __float_as_int(mp.w);
-    if (d < bd[4] || (d == bd[4] && idx < bi[4])) {
-        bd[4] = d; bi[4] = idx; bp[4] = m;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(mp.w);
+    if (key < bk[4]) {
+        bk[4] = key; bp[4] = m;
 #pragma unroll
         for (int k = 4; k > 0; --k) {
-            const bool sw = bd[k] < bd[k - 1] || (bd[k] == bd[k - 1] && bi[k] < bi[k - 1]);
-            if (sw) {
-                const float td = bd[k]; bd[k] = bd[k - 1]; bd[k - 1] = td;
-                const int ti = bi[k]; bi[k] = bi[k - 1]; bi[k - 1] = ti;
-                const int tp = bp[k]; bp[k] = bp[k - 1]; bp[k - 1] = tp;
-            }
+            const bool sw = bk[k] < bk[k - 1];
+            const unsigned long long tk = sw ? bk[k - 1] : bk[k];
+            bk[k - 1] = sw ? bk[k] : bk[k - 1];
+            bk[k] = tk;
+            const int tp = sw ? bp[k - 1] : bp[k];
+            bp[k - 1] = sw ? bp[k] : bp[k - 1];
+            bp[k] = tp;
         }
     }
 }
@@ -371,8 +376,7 @@ __global__ __launch_bounds__(256) void k_knn5(const AssocArgs a, const float4* _
     for (int c = AQ_ROUNDS * AQ_LANES + j; c < 32; c += AQ_LANES) s_tab[g][c] = make_int2(tot, 0);   // padding of the search table
     GLIO_WAVE_LDS_SYNC();
     // ---- candidates: private top-5 per lane, ranked by (float distance, original index)
-    float bd[5] = {FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX};
-    int bi[5] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    unsigned long long bk[5] = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull};
     int bp[5] = {-1, -1, -1, -1, -1};          // position in the sorted map
     const int2* tab = s_tab[g];
     auto locate = [&](const int f) {           // largest cell whose prefix is <= f holds candidate f
@@ -387,14 +391,14 @@ __global__ __launch_bounds__(256) void k_knn5(const AssocArgs a, const float4* _
         const bool two = f2 < tot;
         const int m1 = locate(f), m2 = two ? locate(f2) : m1;
         const float4 p1 = map[m1], p2 = map[m2];
-        knn5_insert(px, py, pz, p1, m1, bd, bi, bp);
-        if (two) knn5_insert(px, py, pz, p2, m2, bd, bi, bp);
+        knn5_insert(px, py, pz, p1, m1, bk, bp);
+        if (two) knn5_insert(px, py, pz, p2, m2, bk, bp);
     }
     // ---- merge the private lists of the group: five rounds of group-wide argmin on the key (distance bits, index)
-    float md[5]; int mi[5], mp5[5];
+    float md4 = FLT_MAX; int mp5[5];
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
-        const unsigned long long mykey = ((unsigned long long)__float_as_uint(bd[0]) << 32) | (unsigned)bi[0];
+        const unsigned long long mykey = bk[0];
         unsigned long long kmin = mykey;
 #pragma unroll
         for (int off = AQ_LANES / 2; off > 0; off >>= 1) {
@@ -405,19 +409,19 @@ __global__ __launch_bounds__(256) void k_knn5(const AssocArgs a, const float4* _
         int pos = win ? bp[0] : -1;
 #pragma unroll
         for (int off = AQ_LANES / 2; off > 0; off >>= 1) pos = max(pos, __shfl_xor(pos, off, 64));
-        md[r] = __uint_as_float((unsigned)(kmin >> 32)); mi[r] = (int)(kmin & 0xffffffffull); mp5[r] = pos;
+        mp5[r] = pos;
+        if (r == 4) md4 = pos >= 0 ? __uint_as_float((unsigned)(kmin >> 32)) : FLT_MAX;
         if (win) {                                   // pop the head of the winner's list
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { bd[k] = bd[k + 1]; bi[k] = bi[k + 1]; bp[k] = bp[k + 1]; }
-            bd[4] = FLT_MAX; bi[4] = 0x7fffffff; bp[4] = -1;
+            for (int k = 0; k < 4; ++k) { bk[k] = bk[k + 1]; bp[k] = bp[k + 1]; }
+            bk[4] = ~0ull; bp[4] = -1;
         }
     }
     if (j == 0 && qlive) {
 #pragma unroll
         for (int k = 0; k < 5; ++k) o_nn5[5 * (size_t)i + k] = mp5[k];
-        o_d4[i] = md[4];
+        o_d4[i] = md4;
     }
-    (void)mi;
 }
 
 #define PF_BLOCK 256
