@@ -1,0 +1,68 @@
+"""Committed fixture tests/golden/window_small.npz (made by tests/golden/make_golden.py from the CPU oracle; NOT reference
+output -- the reference cannot be run here, parity stays unpinned): the oracle still reproduces it (no GPU needed), and the
+HIP path agrees with the frozen numbers (GPU)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden as mg      # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(HERE, "golden", "window_small.npz"))
+
+
+@pytest.fixture(scope="module")
+def case():
+    return mg.make_case()
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / max(1e-300, np.abs(np.asarray(b)).max())
+
+
+def test_inputs_and_oracle_reproduce_the_fixture(golden, case):
+    win, corr, counts, head = case
+    assert mg.input_digest(win) == str(golden["input_sha256"]), "the synthetic generator changed: inputs differ from the fixture's"
+    assert np.array_equal(counts, golden["assoc_counts"])
+    assert np.array_equal(head, golden["assoc_head"])                       # association is float/bit-exact work
+    out = mg.oracle_outputs(win, corr)
+    assert int(out["iterations"]) == int(golden["iterations"])
+    for k in ("H", "g", "cost", "final_cost", "marg_S", "marg_b", "marg_c"):
+        assert rel(out[k], golden[k]) <= 1e-11, k
+    for k in ("sol_trans", "sol_quat", "sol_speed_bias", "sol_rcv_ddt"):
+        assert np.abs(out[k] - golden[k]).max() <= 1e-10, k
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_the_fixture(golden, case):
+    from glio_amd import capi
+    from glio_amd.capi import lidar_pose
+    win, _, _, _ = case
+    ctx = capi.Context(win.opts)
+    ctx.set_map(win.map_pts)
+    ctx.set_imu(win.preints); ctx.set_prior(win.prior); ctx.set_gnss(win.frame, win.dd, win.dop)
+    head = []
+    for s in range(win.W):
+        q2, t2 = lidar_pose(win.opts, win.init.quat[s], win.init.trans[s])
+        n = ctx.associate(s, win.scans[s], q2, t2)
+        assert n == int(golden["assoc_counts"][s])
+        pts, pl, sc = ctx.get_correspondences(s)
+        head.append(np.concatenate([pts[:8].ravel(), pl[:8].ravel(), sc[:8]]))
+    assert np.array_equal(np.array(head), golden["assoc_head"])             # bit-exact
+    H, g, cost = ctx.linearize(win.init)
+    assert rel(H, golden["H"]) <= 1e-10 and rel(g, golden["g"]) <= 1e-10 and abs(cost - float(golden["cost"])) <= 1e-10 * abs(cost)
+    sol, summ = ctx.solve(win.init)
+    assert summ.iterations == int(golden["iterations"])
+    assert abs(summ.final_cost - float(golden["final_cost"])) <= 1e-9 * abs(summ.final_cost)
+    assert np.abs(sol.trans - golden["sol_trans"]).max() <= 1e-8 and np.abs(sol.quat - golden["sol_quat"]).max() <= 1e-9
+    assert np.abs(sol.speed_bias - golden["sol_speed_bias"]).max() <= 1e-7
+    m = ctx.marginalize(sol)
+    J0 = np.asarray(m["lin_jac"]); r0 = np.asarray(m["lin_res"])
+    assert rel(J0.T @ J0, golden["marg_S"]) <= 1e-7 and rel(J0.T @ r0, golden["marg_b"]) <= 1e-7
+    ctx.close()
