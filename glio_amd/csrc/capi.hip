@@ -597,8 +597,9 @@ static int enqueue_solve(glio_ctx* c, int n_ddt) {
     GLIO_HIP_CHECK(hipMemcpyAsync(c->d_status, c->h_status, 512 + (size_t)nx * 8, hipMemcpyHostToDevice, c->stream));   // status + state
     // The trust-region loop lives on the device (SolverStatus); the host only feeds it kernel groups
     // [linearise, step].  Instead of queueing all max_iterations+1 groups blindly -- after convergence the rest are
-    // empty launches, ~2.5 us each -- it stays `enqueue_lead` groups ahead of the GPU, watching a progress word the
-    // first kernel of every group writes to mapped host memory, and stops as soon as `done` shows up.
+    // empty launches, ~2.5 us each -- it enqueues group k + 1 when k_tr_prepare of group k reports (through a progress word in
+    // mapped host memory) that the solve goes on, i.e. while group k's step (~70 us) is still running, and stops as soon
+    // as the finished solve's tag shows up (`enqueue_lead` > 1 queues that many groups further ahead, < 1 all of them).
     const int id = c->solve_id;
     auto started = [&]() { const int w = c->h_progress[0]; return (w >> 16) == id ? (w & 0xffff) : 0; };
     const int total = c->opts.max_iterations + 1;
@@ -607,7 +608,7 @@ static int enqueue_solve(glio_ctx* c, int n_ddt) {
     int enq = 0, spins = 0;
     while (enq < total) {
         if (c->h_progress[1] == id) break;
-        if (enq - started() <= lead) {
+        if (enq - started() < lead) {
             enqueue_linearize(c, 1, 0, n_ddt);
             glio_launch_tr_step(c, n_ddt);
             ++enq;

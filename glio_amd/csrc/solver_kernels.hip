@@ -404,9 +404,6 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_prepare(const TrArgs a) {
         s = *a.status;
         s.group += 1;
         a.status->group = s.group;
-        a.progress[0] = (s.solve_id << 16) | s.group;       // the host enqueues the next kernel group when it sees this one start
-        if (s.done) a.progress[1] = s.solve_id;
-        __threadfence_system();
     }
     __syncthreads();
     if (s.done) return;
@@ -493,6 +490,10 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_prepare(const TrArgs a) {
     }
     __syncthreads();
     if (s.done) { finalize(a, s); return; }
+    // The solve goes on: only now is the host told to enqueue the next kernel group (it then has this whole step, ~70 us,
+    // to do so).  Announcing the group at its start instead made the host queue one group beyond the last useful one
+    // every time: ~9 empty launches (~20 us) between back-to-back solves.
+    if (tid == 0) { a.progress[0] = (s.solve_id << 16) | s.group; __threadfence_system(); }
     if (a.lm && tid == 0) s.mu = 1.0 / s.radius;      // (Hs + D^2 / radius) y = gs
     __syncthreads();
 
