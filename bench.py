@@ -127,6 +127,12 @@ def main():
     except Exception as e:
         pipeline_info = {"error": str(e)[:300]}
 
+    odometry_info = None
+    try:
+        odometry_info = bench_odometry(local_rank)
+    except Exception as e:  # noqa: BLE001 -- informational section, never fatal for the bench line
+        odometry_info = {"error": str(e)[:300]}
+
     bassoc_info = None
     if not args.no_bassoc:
         try:
@@ -259,7 +265,7 @@ def main():
         "dense_prior_variant": dense_variant,
         "kernels_us": {"lidar_linearize": round(k3_ms * 1e3, 2), "full_linearize": round(lin_ms * 1e3, 2), "tr_step": round(trs_ms * 1e3, 2),
                        "marginalize": round(marg_ms * 1e3, 2), "marginalize_call_incl_readback": round(marg_call_ms * 1e3, 1)},
-        "roofline": roofline, "cpu_baseline": cpu, "pose_vs_oracle": pose_err, "association": assoc, "batch_stage": batch_info, "batch_association": bassoc_info, "local_map": localmap_info, "keyframe_pipeline": pipeline_info,
+        "roofline": roofline, "cpu_baseline": cpu, "pose_vs_oracle": pose_err, "association": assoc, "batch_stage": batch_info, "batch_association": bassoc_info, "local_map": localmap_info, "front_end_odometry": odometry_info, "keyframe_pipeline": pipeline_info,
     }
     if cpu and "value" in cpu:
         line["speedup_vs_cpu_port"] = round(value / world / cpu["value"], 1)
@@ -318,6 +324,38 @@ def bench_keyframe_pipeline(local_rank, stream, W):
     info = {"workload": f"steady-state keyframe cycle, W = {W}, {pts} points per scan, 50-keyframe local map",
             "stages_ms": {k: round(v * 1e3, 3) for k, v in stages.items()}, "cycle_ms": round(total * 1e3, 3),
             "keyframes_per_s": round(1.0 / total, 1), "iterations": int(summ.iterations)}
+    ctx.close()
+    return info
+
+
+def bench_odometry(local_rank, pts=65536):
+    """front-end scan-to-map odometry (LidarOdometry::updateTransformationWithCeres): per scan the map hash is
+    rebuilt (kd_tree_surf_last->setInputCloud) and match_cnt = 2 rounds of [associate, Levenberg-Marquardt solve of the
+    one-keyframe problem] run through the same C-ABI.  Informational."""
+    import time as _t
+    from glio_amd import capi, odometry, synth
+    win = synth.make_window(W=1, pts_per_scan=pts, seed=synth.SEED_BASE + 71, perturb=(0.15, 0.8, 0.0), scan_radius=30.0)
+    scan = win.scans[0].copy()
+    scan[:, :3] -= np.array(win.opts.t_lb, np.float32)
+    pose0 = np.r_[win.init.quat[0], win.init.trans[0]]
+    o = odometry.frontend_opts(len(scan), len(win.map_pts))
+    ctx = capi.Context(o, device=local_rank)
+    odo = odometry.ScanToMapOdometry(ctx)
+    for _ in range(2):
+        odo.set_map(win.map_pts); pose, rounds = odo.update(scan, pose0, match_cnt=2)
+    reps = 10
+    t0 = _t.perf_counter()
+    for _ in range(reps):
+        odo.set_map(win.map_pts)
+    t_map = (_t.perf_counter() - t0) / reps
+    t0 = _t.perf_counter()
+    for _ in range(reps):
+        pose, rounds = odo.update(scan, pose0, match_cnt=2)
+    t_upd = (_t.perf_counter() - t0) / reps
+    err = float(np.abs(pose[4:] - win.gt.trans[0]).max())
+    info = {"workload": f"one {pts}-point surf scan vs a {len(win.map_pts)}-point local map, match_cnt 2, LM <= 12 iterations, Huber 0.1",
+            "set_map_ms": round(t_map * 1e3, 3), "update_ms": round(t_upd * 1e3, 3), "scans_per_s": round(1.0 / (t_map + t_upd), 1),
+            "lm_iterations": [int(r[0].iterations) for r in rounds], "kept": [int(r[1]) for r in rounds], "max_trans_err_vs_truth_m": round(err, 4)}
     ctx.close()
     return info
 
