@@ -241,11 +241,32 @@ struct AssocArgs {
     const double* win_poses;                // [W][7] = q (w, x, y, z), t
     const int* win_counts;                  // [W]
     int q_stride, w_stride, b_stride;       // scan + correspondence arrays, dense work arrays, per-workgroup counts
+    // pair mode (glio_bassoc_run): blockIdx.y = pair inside the chunk; pair (ci, cj) queries the cloud of keyframe ci
+    // (local frame, posed with poses[ci]) against the voxel hash of keyframe cj
+    const struct FrameDesc* frames;         // [K]
+    const int* pair_ci; const int* pair_cj; // [n_pairs]
+    const double* poses;                    // [K][7] = t, q (w, x, y, z)
+    int pair0;                              // first pair of this launch
 };
-struct AssocSlot { double q[4], t[3]; int n; size_t qoff, woff, boff; };
+struct FrameDesc { const int4* ent; const float4* sorted; int n, cap_eff; };
+struct AssocSlot { double q[4], t[3]; int n; size_t qoff, woff, boff; const int4* ent; const float4* map; size_t locoff; int table_cap; };
 __device__ __forceinline__ AssocSlot assoc_slot(const AssocArgs& a) {
     AssocSlot s;
-    if (a.win_poses) {
+    s.ent = nullptr; s.map = nullptr; s.locoff = 0; s.table_cap = a.table_cap;
+    if (a.frames) {
+        const int p = a.pair0 + blockIdx.y;
+        const int ci = a.pair_ci[p], cj = a.pair_cj[p];
+        const double* P = a.poses + 7 * ci;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s.t[i] = P[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s.q[i] = P[3 + i];
+        const FrameDesc fj = a.frames[cj];
+        s.n = a.frames[ci].n;
+        s.qoff = (size_t)ci * a.q_stride; s.woff = (size_t)blockIdx.y * a.w_stride; s.boff = (size_t)blockIdx.y * a.b_stride;
+        s.ent = fj.ent; s.map = fj.sorted; s.table_cap = fj.cap_eff;
+        s.locoff = (size_t)cj * a.q_stride;
+    } else if (a.win_poses) {
         const int k = blockIdx.y;
         const double* P = a.win_poses + 7 * k;
 #pragma unroll
@@ -332,6 +353,8 @@ __global__ __launch_bounds__(256) void k_knn5(const AssocArgs a, const float4* _
     const AssocSlot sl = assoc_slot(a);
     if (blockIdx.x * AQ_PER_BLOCK >= sl.n) return;
     scan += sl.qoff; o_nn5 += 5 * sl.woff; o_d4 += sl.woff;
+    if (sl.ent) { ent = sl.ent; map = sl.map; }
+    const int table_cap = sl.table_cap;
     const bool qlive = i < sl.n;
     const float4 pl = scan[qlive ? i : 0];
     // transformPoint: double math, float store
@@ -350,12 +373,12 @@ __global__ __launch_bounds__(256) void k_knn5(const AssocArgs a, const float4* _
             const int dx = c % 3 - 1, dy = (c / 3) % 3 - 1, dz = c / 9 - 1;
             const unsigned long long key = pack_key(cx + dx, cy + dy, cz + dz);
             const int klo = (int)(unsigned)(key & 0xffffffffull), khi = (int)(unsigned)(key >> 32);
-            unsigned s = home_slot(cx + dx, cy + dy, cz + dz, a.table_cap);
+            unsigned s = home_slot(cx + dx, cy + dy, cz + dz, table_cap);
             for (;;) {
                 const int4 e = ent[s];
                 if (e.x == klo && e.y == khi) { cs[h] = e.z; cc[h] = e.w; break; }
                 if ((e.x & e.y) == -1) break;                 // KEY_EMPTY
-                s = (s + 1) & (a.table_cap - 1);
+                s = (s + 1) & (table_cap - 1);
             }
         }
     }
@@ -437,6 +460,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_plane_fit(const AssocArgs a, const
     if (blockIdx.x * PF_BLOCK >= sl.n) return;
     scan += sl.qoff; nn5 += 5 * sl.woff; d4 += sl.woff;
     o_pt += sl.woff; if (!BATCH) o_plane += sl.woff; o_score += sl.woff; o_flag += sl.woff; o_lpos += sl.woff; o_bcount += sl.boff;
+    if (sl.map) { map = sl.map; loc += sl.locoff; o_nc += 6 * sl.woff; }
     const bool qlive = i < sl.n;
     const float4 pl = scan[qlive ? i : 0];
     const double pin[3] = {(double)pl.x, (double)pl.y, (double)pl.z};
@@ -675,6 +699,7 @@ int glio_assoc_build_map_dev(glio_ctx* c, const float4* d_pts, int n) {
 static void enqueue_assoc(glio_ctx* c, int slot, const double q[4], const double t[3], int n, int want_nn) {
     AssocWork* w = c->assoc;
     AssocArgs a;
+    memset(&a, 0, sizeof a);
     for (int k = 0; k < 4; ++k) a.q[k] = q[k];
     for (int k = 0; k < 3; ++k) a.t[k] = t[k];
     a.inv_cell = w->inv_cell; a.kd_max_radius = c->opts.kd_max_radius; a.weight_gate = c->opts.weight_gate;
@@ -825,9 +850,10 @@ void glio_assoc_time_hooks(glio_ctx* c, int which, int reps, float* ms) {
 // ================================================================================================
 // Batch association: findGlobalCorrespondingSurfFeaturesAdd_Batch for a list of keyframe pairs.
 // Every keyframe gets its OWN voxel hash of its cloud in the global frame, built once per run and kept resident
-// (~1.9 MB per 32k-point keyframe: 2000 keyframes = 3.8 GB of the 288 GB); pair (ci, cj) then queries the points of ci
-// against hash[cj].  The kept records of consecutive pairs are appended at a device-side running offset (no host round
-// trip between pairs), which yields exactly the pair-major constraint arrays K8 (batch_kernels.hip) consumes.
+// (~2.9 MB per 32k-point keyframe: 2000 keyframes = 5.8 GB of the 288 GB); pair (ci, cj) then queries the points of ci
+// against hash[cj], BA_CHUNK pairs per launch (blockIdx.y = pair of the chunk; frame descriptors, pair lists and poses
+// live in device tables).  The kept records of consecutive pairs are appended at a device-side running offset (no host
+// round trip between pairs), which yields exactly the pair-major constraint arrays K8 (batch_kernels.hip) consumes.
 // ================================================================================================
 struct FrameHash {
     int n, table_cap, cap_eff;
@@ -850,6 +876,8 @@ struct glio_bassoc {
     float4* d_cp; double* d_nc; double* d_score;
     long long* d_run;               // [1] running total
     long long* d_pair_off; int max_pairs;     // [max_pairs + 1]
+    FrameDesc* d_frames; int* d_pair_ci; int* d_pair_cj;      // [K], [max_pairs] x 2: what the chunked launches index by blockIdx.y
+    int b_stride;                             // per-pair stride of the per-workgroup count arrays
     long long* h_pair_off;          // pinned
     double* d_poses;                // [K][7]
 };
@@ -865,45 +893,57 @@ __global__ void k_transform_cloud(const float4* __restrict__ in, int n, const do
     out[i] = make_float4((float)(po[0] + t[0]), (float)(po[1] + t[1]), (float)(po[2] + t[2]), p.w);
 }
 
-// exclusive scan of the per-workgroup kept counts + this pair's base offset taken from / added to the running total
-__global__ __launch_bounds__(1024) void k_scan_pair(const int* __restrict__ bcount, int nblk, int* __restrict__ boff, long long* run,
-                                                    long long* pair_off, long long max_con, int* overflow) {
-    __shared__ int sums[1024];
-    const int tid = threadIdx.x;
-    const int chunk = (nblk + 1023) / 1024;
-    const int beg = tid * chunk, end = min(nblk, beg + chunk);
-    int s = 0;
-    for (int i = beg; i < end; ++i) s += bcount[i];
-    sums[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int v = tid >= off ? sums[tid - off] : 0;
-        __syncthreads();
-        sums[tid] += v;
-        __syncthreads();
+// Compaction of the kept records, pair major, for a CHUNK of pairs per launch (blockIdx.y / wavefront = pair of the chunk):
+// the per-workgroup kept counts of every pair are scanned by one wavefront, one thread then threads the running total
+// through the chunk in pair order, so the constraint arrays come out exactly as with one launch per pair.
+#define BA_CHUNK 32
+__global__ __launch_bounds__(1024) void k_scan_pairs(const int* __restrict__ bcount, const int b_stride, const FrameDesc* __restrict__ frames,
+                                                     const int* __restrict__ pair_ci, const int pair0, const int np, int* __restrict__ boff,
+                                                     long long* run, long long* pair_off, const long long max_con, int* overflow) {
+    __shared__ int tot[BA_CHUNK];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int q = wv; q < np; q += 16) {
+        const int n = frames[pair_ci[pair0 + q]].n, nblk = (n + PF_BLOCK - 1) / PF_BLOCK;
+        int carry = 0;
+        for (int i0 = 0; i0 < nblk; i0 += 64) {
+            const int i = i0 + lane;
+            const int v = i < nblk ? bcount[(size_t)q * b_stride + i] : 0;
+            int incl = v;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+            if (i < nblk) boff[(size_t)q * b_stride + i] = carry + incl - v;
+            carry += __shfl(incl, 63, 64);
+        }
+        if (lane == 0) tot[q] = carry;
     }
-    int r = sums[tid] - s;
-    for (int i = beg; i < end; ++i) { boff[i] = r; r += bcount[i]; }
-    if (tid == 1023) {
-        const long long base = *run;
-        long long tot = sums[1023];
-        if (base + tot > max_con) { *overflow = 1; tot = 0; }
-        pair_off[0] = base;
-        pair_off[1] = base + tot;        // overwritten by the next pair with the same value
-        *run = base + tot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long r = *run;
+        for (int q = 0; q < np; ++q) {
+            long long t = tot[q];
+            if (r + t > max_con) { *overflow = 1; t = 0; }
+            pair_off[pair0 + q] = r;
+            r += t;
+        }
+        pair_off[pair0 + np] = r;             // overwritten by the next chunk with the same value
+        *run = r;
     }
 }
-__global__ void k_compact_pair(const int* __restrict__ flag, const int* __restrict__ lpos, const int* __restrict__ boff, int n,
-                               const long long* __restrict__ pair_off, const float4* __restrict__ q_cp, const double* __restrict__ q_nc,
-                               const double* __restrict__ q_score, float4* __restrict__ o_cp, double* __restrict__ o_nc,
-                               double* __restrict__ o_score) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !flag[i]) return;
-    if (pair_off[1] == pair_off[0]) return;                      // overflow: nothing is written for this pair
-    const long long p = pair_off[0] + boff[i / PF_BLOCK] + lpos[i];
-    o_cp[p] = q_cp[i]; o_score[p] = q_score[i];
+__global__ void k_compact_pairs(const int* __restrict__ flag, const int* __restrict__ lpos, const int* __restrict__ boff, const int w_stride,
+                                const int b_stride, const FrameDesc* __restrict__ frames, const int* __restrict__ pair_ci, const int pair0,
+                                const long long* __restrict__ pair_off, const float4* __restrict__ q_cp, const double* __restrict__ q_nc,
+                                const double* __restrict__ q_score, float4* __restrict__ o_cp, double* __restrict__ o_nc,
+                                double* __restrict__ o_score) {
+    const int q = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = frames[pair_ci[pair0 + q]].n;
+    const size_t w = (size_t)q * w_stride + i;
+    if (i >= n || !flag[w]) return;
+    const long long p0 = pair_off[pair0 + q];
+    if (pair_off[pair0 + q + 1] == p0) return;                   // overflow: nothing is written for this pair
+    const long long p = p0 + boff[(size_t)q * b_stride + i / PF_BLOCK] + lpos[w];
+    o_cp[p] = q_cp[w]; o_score[p] = q_score[w];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) o_nc[6 * p + k] = q_nc[6 * (size_t)i + k];
+    for (int k = 0; k < 6; ++k) o_nc[6 * p + k] = q_nc[6 * w + k];
 }
 
 #define BA_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { glio_set_error("%s failed: %s", #expr, hipGetErrorString(e_)); return GLIO_E_HIP; } } while (0)
@@ -934,10 +974,14 @@ int glio_bassoc_create(int device, int K, int max_points_per_frame, int64_t max_
         BA_CHECK(hipMalloc((void**)&f.d_pt_slot, cap * 4)); BA_CHECK(hipMalloc((void**)&f.d_sorted, cap * 16));
     }
     BA_CHECK(hipMalloc((void**)&b->d_total, 4));
-    BA_CHECK(hipMalloc((void**)&b->d_q_cp, cap * 16)); BA_CHECK(hipMalloc((void**)&b->d_q_nc, cap * 48)); BA_CHECK(hipMalloc((void**)&b->d_q_score, cap * 8));
-    BA_CHECK(hipMalloc((void**)&b->d_q_flag, cap * 4)); BA_CHECK(hipMalloc((void**)&b->d_q_pos, cap * 4));
-    BA_CHECK(hipMalloc((void**)&b->d_nn5, cap * 20)); BA_CHECK(hipMalloc((void**)&b->d_d4, cap * 4));
-    BA_CHECK(hipMalloc((void**)&b->d_bcount, (cap / AQ_PER_BLOCK + 2) * 4)); BA_CHECK(hipMalloc((void**)&b->d_boff, (cap / AQ_PER_BLOCK + 2) * 4));
+    // dense per-query work arrays for a chunk of BA_CHUNK pairs (104 B per query and pair)
+    const size_t wc = cap * BA_CHUNK;
+    b->b_stride = (int)(cap / PF_BLOCK + 2);
+    BA_CHECK(hipMalloc((void**)&b->d_q_cp, wc * 16)); BA_CHECK(hipMalloc((void**)&b->d_q_nc, wc * 48)); BA_CHECK(hipMalloc((void**)&b->d_q_score, wc * 8));
+    BA_CHECK(hipMalloc((void**)&b->d_q_flag, wc * 4)); BA_CHECK(hipMalloc((void**)&b->d_q_pos, wc * 4));
+    BA_CHECK(hipMalloc((void**)&b->d_nn5, wc * 20)); BA_CHECK(hipMalloc((void**)&b->d_d4, wc * 4));
+    BA_CHECK(hipMalloc((void**)&b->d_bcount, (size_t)b->b_stride * BA_CHUNK * 4)); BA_CHECK(hipMalloc((void**)&b->d_boff, (size_t)b->b_stride * BA_CHUNK * 4));
+    BA_CHECK(hipMalloc((void**)&b->d_frames, (size_t)K * sizeof(FrameDesc)));
     BA_CHECK(hipMalloc((void**)&b->d_cp, (size_t)max_constraints * 16)); BA_CHECK(hipMalloc((void**)&b->d_nc, (size_t)max_constraints * 48));
     BA_CHECK(hipMalloc((void**)&b->d_score, (size_t)max_constraints * 8));
     BA_CHECK(hipMalloc((void**)&b->d_run, 16)); BA_CHECK(hipMalloc((void**)&b->d_poses, (size_t)K * 7 * 8));
@@ -955,7 +999,7 @@ void glio_bassoc_destroy(glio_bassoc* b) {
         for (void* q : p) if (q) hipFree(q);
     }
     void* p[] = {b->d_nn5, b->d_d4, b->d_local, b->d_global, b->d_total, b->d_q_cp, b->d_q_nc, b->d_q_score, b->d_q_flag, b->d_q_pos, b->d_bcount, b->d_boff,
-                 b->d_cp, b->d_nc, b->d_score, b->d_run, b->d_poses, b->d_pair_off};
+                 b->d_cp, b->d_nc, b->d_score, b->d_run, b->d_poses, b->d_pair_off, b->d_frames, b->d_pair_ci, b->d_pair_cj};
     for (void* q : p) if (q) hipFree(q);
     if (b->h_pair_off) hipHostFree(b->h_pair_off);
     delete[] b->h_n; delete[] b->frames;
@@ -979,9 +1023,10 @@ int glio_bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const int3
     for (int p = 0; p < n_pairs; ++p)
         if (pair_ci[p] < 0 || pair_ci[p] >= b->K || pair_cj[p] < 0 || pair_cj[p] >= b->K || pair_ci[p] == pair_cj[p]) { glio_set_error("bad pair %d", p); return GLIO_E_ARG; }
     if (n_pairs > b->max_pairs) {
-        if (b->d_pair_off) { hipFree(b->d_pair_off); hipHostFree(b->h_pair_off); b->d_pair_off = nullptr; b->h_pair_off = nullptr; }
+        if (b->d_pair_off) { hipFree(b->d_pair_off); hipHostFree(b->h_pair_off); hipFree(b->d_pair_ci); hipFree(b->d_pair_cj); b->d_pair_off = nullptr; b->h_pair_off = nullptr; }
         b->max_pairs = n_pairs + 64;
         BA_CHECK(hipMalloc((void**)&b->d_pair_off, (size_t)(b->max_pairs + 2) * 8));
+        BA_CHECK(hipMalloc((void**)&b->d_pair_ci, (size_t)b->max_pairs * 4)); BA_CHECK(hipMalloc((void**)&b->d_pair_cj, (size_t)b->max_pairs * 4));
         BA_CHECK(hipHostMalloc((void**)&b->h_pair_off, (size_t)(b->max_pairs + 2) * 8));
     }
     BA_CHECK(hipMemcpyAsync(b->d_poses, poses, (size_t)b->K * 7 * 8, hipMemcpyHostToDevice, b->stream));
@@ -1004,29 +1049,41 @@ int glio_bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const int3
         hipLaunchKernelGGL(k_cell_alloc, dim3((tc + 255) / 256), dim3(256), 0, b->stream, f.d_cell_count, f.d_cell_start, tc, b->d_total, f.d_keys, f.d_ent);
         hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, b->stream, b->d_global, n, f.d_pt_slot, f.d_cell_start, f.d_cell_fill, f.d_sorted);
     }
-    // (2) the pairs, in the caller's (ci, cj) order
-    for (int p = 0; p < n_pairs; ++p) {
-        const int ci = pair_ci[p], cj = pair_cj[p];
-        const int n = b->h_n[ci];
-        const FrameHash& f = b->frames[cj];
-        AssocArgs a;
-        for (int k = 0; k < 3; ++k) a.t[k] = poses[7 * ci + k];
-        for (int k = 0; k < 4; ++k) a.q[k] = poses[7 * ci + 3 + k];
-        a.inv_cell = b->inv_cell; a.kd_max_radius = 1.5; a.weight_gate = 0.3; a.surf_dist_thres = 0.18; a.lidar_const = 2.5;   // :3839,3874,3863,3885
-        a.n = n; a.table_cap = f.cap_eff; a.unit_scores = 0;
-        a.win_poses = nullptr; a.win_counts = nullptr; a.q_stride = a.w_stride = a.b_stride = 0;
-        const int nblk = (n + PF_BLOCK - 1) / PF_BLOCK;
-        if (n > 0) {
-            hipLaunchKernelGGL(k_knn5, dim3((n + AQ_PER_BLOCK - 1) / AQ_PER_BLOCK), dim3(256), 0, b->stream, a, b->d_local + (size_t)ci * b->cap, f.d_sorted,
-                               f.d_ent, b->d_nn5, b->d_d4);
-            hipLaunchKernelGGL(k_plane_fit<true>, dim3(nblk), dim3(PF_BLOCK), 0, b->stream, a, b->d_local + (size_t)ci * b->cap, f.d_sorted, b->d_nn5, b->d_d4,
-                               b->d_q_cp, (float4*)nullptr, b->d_q_score, b->d_q_flag, b->d_q_pos, b->d_bcount, (int*)nullptr,
-                               b->d_local + (size_t)cj * b->cap, b->d_q_nc);
+    // (2) the pairs, in the caller's (ci, cj) order, BA_CHUNK pairs per launch (blockIdx.y = pair of the chunk)
+    if (n_pairs > 0) {
+        std::vector<FrameDesc> fd(b->K);
+        int maxn = 0;
+        for (int k = 0; k < b->K; ++k) {
+            fd[k].ent = b->frames[k].d_ent; fd[k].sorted = b->frames[k].d_sorted; fd[k].n = b->h_n[k];
+            fd[k].cap_eff = need[k] ? b->frames[k].cap_eff : b->frames[k].table_cap;
+            if (b->h_n[k] > maxn) maxn = b->h_n[k];
         }
-        hipLaunchKernelGGL(k_scan_pair, dim3(1), dim3(1024), 0, b->stream, b->d_bcount, nblk, b->d_boff, b->d_run, b->d_pair_off + p, (long long)b->max_con, d_overflow);
-        if (n > 0)
-            hipLaunchKernelGGL(k_compact_pair, dim3((n + 255) / 256), dim3(256), 0, b->stream, b->d_q_flag, b->d_q_pos, b->d_boff, n, b->d_pair_off + p,
-                               b->d_q_cp, b->d_q_nc, b->d_q_score, b->d_cp, b->d_nc, b->d_score);
+        BA_CHECK(hipMemcpyAsync(b->d_frames, fd.data(), (size_t)b->K * sizeof(FrameDesc), hipMemcpyHostToDevice, b->stream));
+        BA_CHECK(hipMemcpyAsync(b->d_pair_ci, pair_ci, (size_t)n_pairs * 4, hipMemcpyHostToDevice, b->stream));
+        BA_CHECK(hipMemcpyAsync(b->d_pair_cj, pair_cj, (size_t)n_pairs * 4, hipMemcpyHostToDevice, b->stream));
+        BA_CHECK(hipStreamSynchronize(b->stream));                       // the three sources are pageable host memory
+        AssocArgs a;
+        memset(&a, 0, sizeof a);
+        a.inv_cell = b->inv_cell; a.kd_max_radius = 1.5; a.weight_gate = 0.3; a.surf_dist_thres = 0.18; a.lidar_const = 2.5;   // :3839,3874,3863,3885
+        a.unit_scores = 0;
+        a.q_stride = b->cap; a.w_stride = b->cap; a.b_stride = b->b_stride;
+        a.frames = b->d_frames; a.pair_ci = b->d_pair_ci; a.pair_cj = b->d_pair_cj; a.poses = b->d_poses;
+        for (int p0 = 0; p0 < n_pairs; p0 += BA_CHUNK) {
+            const int np = n_pairs - p0 < BA_CHUNK ? n_pairs - p0 : BA_CHUNK;
+            a.pair0 = p0;
+            if (maxn > 0) {
+                hipLaunchKernelGGL(k_knn5, dim3((maxn + AQ_PER_BLOCK - 1) / AQ_PER_BLOCK, np), dim3(256), 0, b->stream, a, b->d_local, (const float4*)nullptr,
+                                   (const int4*)nullptr, b->d_nn5, b->d_d4);
+                hipLaunchKernelGGL(k_plane_fit<true>, dim3((maxn + PF_BLOCK - 1) / PF_BLOCK, np), dim3(PF_BLOCK), 0, b->stream, a, b->d_local, (const float4*)nullptr,
+                                   b->d_nn5, b->d_d4, b->d_q_cp, (float4*)nullptr, b->d_q_score, b->d_q_flag, b->d_q_pos, b->d_bcount, (int*)nullptr,
+                                   b->d_local, b->d_q_nc);
+            }
+            hipLaunchKernelGGL(k_scan_pairs, dim3(1), dim3(1024), 0, b->stream, b->d_bcount, b->b_stride, b->d_frames, b->d_pair_ci, p0, np, b->d_boff,
+                               b->d_run, b->d_pair_off, (long long)b->max_con, d_overflow);
+            if (maxn > 0)
+                hipLaunchKernelGGL(k_compact_pairs, dim3((maxn + 255) / 256, np), dim3(256), 0, b->stream, b->d_q_flag, b->d_q_pos, b->d_boff, b->cap, b->b_stride,
+                                   b->d_frames, b->d_pair_ci, p0, b->d_pair_off, b->d_q_cp, b->d_q_nc, b->d_q_score, b->d_cp, b->d_nc, b->d_score);
+        }
     }
     BA_CHECK(hipGetLastError());
     long long tail[2] = {0, 0};
