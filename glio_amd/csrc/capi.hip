@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <atomic>
 #include <chrono>
@@ -68,7 +69,9 @@ void glio_opts_default(glio_opts* o) {
     o->min_relative_decrease = 1e-3; o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
 }
 
-#define ALLOC(ptr, bytes) GLIO_HIP_CHECK(hipMalloc((void**)&(ptr), (bytes) > 0 ? (size_t)(bytes) : 16))
+static int g_fill = getenv("GLIO_DEBUG_FILL") ? atoi(getenv("GLIO_DEBUG_FILL")) : -1;     // development aid: fill every allocation with this byte
+#define ALLOC(ptr, bytes) do { GLIO_HIP_CHECK(hipMalloc((void**)&(ptr), (bytes) > 0 ? (size_t)(bytes) : 16)); \
+                               if (g_fill >= 0) GLIO_HIP_CHECK(hipMemset((void*)(ptr), g_fill, (bytes) > 0 ? (size_t)(bytes) : 16)); } while (0)
 
 int glio_create(int device, const glio_opts* opts, glio_ctx** out) {
     if (!opts || !out) { glio_set_error("null argument"); return GLIO_E_ARG; }
@@ -843,8 +846,8 @@ int glio_eval_imu(glio_ctx* c, const glio_preint* pre, double const* const* P, d
 
 // solver selection for tests: 0 = dense Cholesky only, 1 = structured (arrow) factorisation when the graph permits
 int glio_debug_set_solver(glio_ctx* c, int mode) {
-    if (!c || mode < 0 || mode > 2) return GLIO_E_ARG;      // 0 dense only, 1 structured when possible, 2 = 1 + the chain kernel reports a
-    c->arrow.mode = mode;                                   // breakdown every time (test hook for its dense fallback)
+    if (!c || mode < 0 || mode > 1) return GLIO_E_ARG;
+    c->arrow.mode = mode;
     return GLIO_OK;
 }
 int glio_debug_arrow_stamps(glio_ctx* c, long long* out64) {
