@@ -126,7 +126,8 @@ int glio_create(int device, const glio_opts* opts, glio_ctx** out) {
     { int per = 768 / W;   /* ~3 workgroups per CU measured best on MI355X (scripts/k3_sweep.py) */ if (per < 8) per = 8; if (per > GLIO_K3_MAX_BLOCKS_PER_KF) per = GLIO_K3_MAX_BLOCKS_PER_KF; c->k3_bpk = per; }
     ALLOC(c->d_lidar_blocks, 2 * (size_t)W * GLIO_LIDAR_ACC * 8);
     ALLOC(c->d_L, (size_t)(n_max + 1) * n_max * 8);
-    ALLOC(c->d_vec, (size_t)10 * n_max * 8);
+    c->vstride = (n_max + 15) & ~15;
+    ALLOC(c->d_vec, (size_t)10 * c->vstride * 8);
     {   // structured solver
         ArrowDev& ar = c->arrow;
         ar.mode = 1; ar.gnss_ok = 1; ar.prior_ok = 1; ar.max_epoch = -1; ar.gnss_chain = 1; ar.prior_chain = 1;
@@ -576,7 +577,22 @@ static void unpack_state(glio_ctx* c, const double* h, glio_state* s) {
     memcpy(s->trans, h, 3 * W * 8); memcpy(s->quat, h + 3 * W, 4 * W * 8); memcpy(s->speed_bias, h + 7 * W, 9 * W * 8);
     if (s->n_ddt) memcpy(s->rcv_ddt, h + 16 * W, s->n_ddt * 8);
 }
+// Development aid (GLIO_DEBUG_LDS_POISON=1): LDS is not cleared between kernels, so a kernel that reads LDS it has not
+// written sees whatever ran on that CU before -- results that depend on the process history.  This fills the LDS of every
+// CU with NaNs before each kernel group, which turns such a read into a loud, reproducible failure.
+extern __shared__ double poison_lds[];
+__global__ void k_lds_poison(int n) {
+    for (int k = threadIdx.x; k < n; k += blockDim.x) poison_lds[k] = __longlong_as_double(0x7ff8dead00000000ll + k);
+}
+static int g_poison = getenv("GLIO_DEBUG_LDS_POISON") ? atoi(getenv("GLIO_DEBUG_LDS_POISON")) : 0;
+static void lds_poison(glio_ctx* c) {
+    if (!g_poison) return;
+    static bool configured = false;
+    if (!configured) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_lds_poison), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); configured = true; }
+    hipLaunchKernelGGL(k_lds_poison, dim3(1024), dim3(256), 160 * 1024, c->stream, 160 * 1024 / 8);
+}
 static void enqueue_linearize(glio_ctx* c, int use_status, int which, int n_ddt) {
+    lds_poison(c);
     if (c->merged_linearize) {
         glio_launch_linearize_all(c, use_status, which, n_ddt);
         glio_launch_assemble(c, use_status, which, n_ddt);
@@ -613,6 +629,7 @@ static int enqueue_solve(glio_ctx* c, int n_ddt) {
         if (c->h_progress[1] == id) break;
         if (enq - started() < lead) {
             enqueue_linearize(c, 1, 0, n_ddt);
+            lds_poison(c);
             glio_launch_tr_step(c, n_ddt);
             ++enq;
         } else if (((++spins) & 0xfff) == 0 && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(20)) {

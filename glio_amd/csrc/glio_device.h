@@ -150,7 +150,9 @@ struct glio_ctx {
     double* d_cost[2];
     // ---- solver workspace
     double* d_L;                  // (n+1) x n factor workspace
-    double* d_vec;                // scale, diag, grad, gn, step, delta, tmp ... 10 x n_max
+    double* d_vec;                // scale, diag, grad, gn, step, delta, tmp ... 10 x vstride
+    int vstride;                  // n_max rounded up to 16 doubles: the work vectors do not share 128 B lines (a line read for the tail of
+                                  // one vector would otherwise also cache the head of the next, which the same kernel may rewrite)
     SolverStatus* d_status;
     SolverStatus* h_status;       // pinned
     volatile int* h_progress;     // pinned + mapped: [0] (solve id << 16) | groups started, [1] id of the solve that is done -- written by the GPU, polled by the host

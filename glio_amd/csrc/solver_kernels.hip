@@ -1540,7 +1540,7 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
     a.jacobi_scaling = c->opts.jacobi_scaling;
     a.x0 = c->d_x[0]; a.x1 = c->d_x[1]; a.xout = c->d_xout;
     a.H0 = c->d_H[0]; a.H1 = c->d_H[1]; a.g0 = c->d_g[0]; a.g1 = c->d_g[1]; a.c0 = c->d_cost[0]; a.c1 = c->d_cost[1];
-    a.L = c->d_L; a.vec = c->d_vec; a.vstride = c->n_max;
+    a.L = c->d_L; a.vec = c->d_vec; a.vstride = c->vstride;
     a.status = c->d_status; a.progress = c->d_progress;
     a.status_host = reinterpret_cast<SolverStatus*>(c->d_result); a.xout_host = reinterpret_cast<double*>(c->d_result + 512);
     // structured factorisation when the factor graph is a chain (IMU / Doppler edges between neighbours only, at most
@@ -1784,7 +1784,7 @@ void glio_tr_step_configure(size_t max_lds) {
 
 extern "C" int glio_debug_read_vec(glio_ctx* c, int k, double* out, int n) {
     if (!c || k < 0 || k > 9 || n > c->n_max) return GLIO_E_ARG;
-    GLIO_HIP_CHECK(hipMemcpy(out, c->d_vec + (size_t)k * c->n_max, (size_t)n * 8, hipMemcpyDeviceToHost));
+    GLIO_HIP_CHECK(hipMemcpy(out, c->d_vec + (size_t)k * c->vstride, (size_t)n * 8, hipMemcpyDeviceToHost));
     return GLIO_OK;
 }
 
