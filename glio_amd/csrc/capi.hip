@@ -863,8 +863,8 @@ int glio_eval_imu(glio_ctx* c, const glio_preint* pre, double const* const* P, d
 
 // solver selection for tests: 0 = dense Cholesky only, 1 = structured (arrow) factorisation when the graph permits
 int glio_debug_set_solver(glio_ctx* c, int mode) {
-    if (!c || mode < 0 || mode > 1) return GLIO_E_ARG;
-    c->arrow.mode = mode;
+    if (!c || mode < 0 || mode > 2) return GLIO_E_ARG;      // 0 dense only, 1 structured when possible, 2 = 1 + the chain kernel reports a
+    c->arrow.mode = mode;                                   // breakdown every time (test hook for its dense fallback)
     return GLIO_OK;
 }
 int glio_debug_arrow_stamps(glio_ctx* c, long long* out64) {

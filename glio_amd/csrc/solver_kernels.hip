@@ -44,6 +44,8 @@ struct TrArgs {
     int jacobi_scaling;
     int lm;                   // 1 = Levenberg-Marquardt strategy (mu = 1 / radius, no dogleg interpolation)
     int perm_mode;            // elimination order written by k_tr_scale: 0 = [d | s | p] (arrow / dense), 1 = [d | keyframes] (chain)
+    int fused_chain;          // 1 = k_chain_solve did k_tr_prepare's and k_tr_scale's work itself: a.L is NOT filled (the dense
+                              // fallback rebuilds it), t = H u comes from the chain kernel
     double* x0; double* x1; double* xout;
     const double* H0; const double* H1; const double* g0; const double* g1; const double* c0; const double* c1;
     double* L; double* vec; int vstride;
@@ -395,7 +397,12 @@ __device__ __forceinline__ void finalize(const TrArgs& a, const SolverStatus& s)
 // ------------------------------------------------------------------------------------------------
 // K7a  k_tr_prepare
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TR_THREADS) void k_tr_prepare(const TrArgs a) {
+// returns true when a linear solve has to follow (status written, vectors ready), false when this group has nothing to do
+// (the solve is finished -- possibly just now -- or was finished before)
+struct TrDecision { int cur, reuse; double mu; };     // what a kernel that continues after tr_prepare_body needs of the new status: it
+                                                      // must not re-read *a.status -- the line it loaded at entry may still sit in this
+                                                      // CU's L1, which is not refreshed by the store that rewrote it
+__device__ __forceinline__ bool tr_prepare_body(const TrArgs& a, TrDecision* out = nullptr) {
     __shared__ double red[32];
     __shared__ SolverStatus s;
     const int tid = threadIdx.x;
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_prepare(const TrArgs a) {
         a.status->group = s.group;
     }
     __syncthreads();
-    if (s.done) return;
+    if (s.done) return false;
     double* scale = V_SCALE(a); double* diag = V_DIAG(a); double* grad = V_GRAD(a); double* u = V_U(a);
 
     if (s.cand_pending) {
@@ -461,7 +468,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_prepare(const TrArgs a) {
         if (tid == 0) s.cand_pending = 0;
         __syncthreads();
     }
-    if (s.done) { finalize(a, s); return; }
+    if (s.done) { finalize(a, s); return false; }
 
     const double* H = s.cur ? a.H1 : a.H0;
     const double* g = s.cur ? a.g1 : a.g0;
@@ -489,7 +496,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_prepare(const TrArgs a) {
         else s.iteration += 1;
     }
     __syncthreads();
-    if (s.done) { finalize(a, s); return; }
+    if (s.done) { finalize(a, s); return false; }
     // The solve goes on: only now is the host told to enqueue the next kernel group (it then has this whole step, ~70 us,
     // to do so).  Announcing the group at its start instead made the host queue one group beyond the last useful one
     // every time: ~9 empty launches (~20 us) between back-to-back solves.
@@ -510,7 +517,11 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_prepare(const TrArgs a) {
     }
     __syncthreads();
     if (tid == 0) *a.status = s;
+    if (out) { out->cur = s.cur; out->reuse = s.reuse; out->mu = s.mu; }
+    __syncthreads();
+    return true;
 }
+__global__ __launch_bounds__(TR_THREADS) void k_tr_prepare(const TrArgs a) { (void)tr_prepare_body(a); }
 
 // ------------------------------------------------------------------------------------------------
 // K7b  k_tr_scale: one wavefront per row of H (multi-workgroup): t = H u, L = S H S + mu D^2, rhs row
@@ -567,6 +578,19 @@ __device__ __forceinline__ void tr_factor_body(const TrArgs& a) {
     const double* g = a.status->cur ? a.g1 : a.g0;
     const double* scale = V_SCALE(a); const double* diag = V_DIAG(a); const double* grad = V_GRAD(a);
     const double* u = V_U(a); const double* t = V_T(a);
+    if (a.fused_chain && !(a.arrow_flag && *a.arrow_flag == 2)) {
+        // the chain kernel broke down (non-positive pivot): nobody has written t = H u or the scaled matrix; do k_tr_scale's
+        // work here (one wavefront per row), then the dense factorisation below takes over
+        double* tw = V_T(a);
+        for (int i = tid >> 6; i < n; i += TR_WAVES) {
+            const double* hrow = H + (size_t)i * n;
+            double sacc = 0;
+            for (int j = tid & 63; j < n; j += 64) sacc += hrow[j] * u[j];
+            sacc = wave_sum(sacc);
+            if ((tid & 63) == 0) tw[i] = sacc;
+        }
+        __syncthreads();
+    }
     // Cauchy step length alpha = |g~|^2 / (u^T H u)
     double p = 0, q2 = 0;
     for (int i = tid; i < n; i += TR_THREADS) { p += u[i] * t[i]; q2 += grad[i] * grad[i]; }
@@ -583,7 +607,7 @@ __device__ __forceinline__ void tr_factor_body(const TrArgs& a) {
     for (int attempt = 0; attempt < (a.lm ? 1 : 12) && !solved; ++attempt) {
         const double mu = *smu;
         if (!a.lm && !(mu < 1.0)) break;
-        if (attempt > 0) {             // breakdown: rebuild S H S + mu D^2 with the larger mu (rare)
+        if (attempt > 0 || a.fused_chain) {    // breakdown (or nobody built it yet): S H S + mu D^2 with the current mu (rare)
             for (int i = tid >> 6; i < n; i += TR_WAVES) {
                 const double si = scale[i];
                 const double* hrow = H + (size_t)i * n;
@@ -1193,7 +1217,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_arrow_solve(const ArrowArgs a) {
 
 __host__ __device__ __forceinline__ size_t chain_lds_doubles(int W, int nd) {
     return (size_t)(nd + (nd & 1)) * 2 + (size_t)nd * 30 + (size_t)W * KC_BLK + 2 * 288 + (size_t)15 * W + (W & 1) + (size_t)nd + 2 + (size_t)(W + 2) / 2 + 1 +
-           (size_t)nd + 2 + 2 * ((size_t)nd + 2) + 12;
+           (size_t)nd + 2 + 2 * ((size_t)nd + 2) + 12 + (size_t)nd + 2;
 }
 
 // 1 / sqrt(d) for a pivot already known to be positive, finite and far from the denormal range (it is a diagonal entry of
@@ -1307,19 +1331,38 @@ __device__ __forceinline__ void chain_step15(const int i, const int nb, const bo
 
 struct ChainArgs {
     int W, n, nd;
-    const double* A;
     const int2* ep_slots; const int* ep_off; const int* ep_list;
     double* z; int* flag;
     const SolverStatus* status;
     long long* dbg;
+    int force_fail;           // test hook: report a breakdown although there is none (exercises the dense fallback)
 };
 
-__global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a) {
-    if (a.status->done || a.status->reuse) return;
+// The kernel also does the work of k_tr_prepare (state machine, scaling vectors) and of k_tr_scale for this structure: it
+// reads H and g directly, forms M = S H S + mu D^2 and the right-hand side S g while staging them (same arithmetic, same
+// order of operations as k_tr_scale), and computes t = H u from the staged blocks -- two launches and a round trip of the
+// scaled matrix through global memory less per iteration.  The dense fallback (k_tr_finish on flag 1) rebuilds what it needs.
+__global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a, const TrArgs tr) {
+    static_assert(KC_THREADS == TR_THREADS, "tr_prepare_body runs with the chain kernel's workgroup");
+    TrDecision dec;
+    if (!tr_prepare_body(tr, &dec)) return;
+    if (dec.reuse) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int W = a.W, n = a.n, nd = a.nd;
-    const double* A = a.A;
-    const double* rhs = A + (size_t)n * n;
+    if (tid == 0) *a.flag = 0;
+    // chain order p = [epochs | keyframe 0 (15) | ...]  <->  natural order i = [keyframes | epochs]
+    const int np15 = 15 * W;
+    const double* __restrict__ Hn = dec.cur ? tr.H1 : tr.H0;
+    const double* __restrict__ gn = dec.cur ? tr.g1 : tr.g0;
+    // (scale, diag, u were written by tr_prepare_body above: safe to read back because the work vectors occupy whole 128 B
+    // lines -- glio_ctx::vstride -- so no line holding them was fetched before they were written)
+    const double* __restrict__ scv = V_SCALE(tr);
+    const double* __restrict__ dgv = V_DIAG(tr);
+    const double mu = dec.mu;
+    auto nat = [&](const int p) { return p < nd ? np15 + p : p - nd; };
+    // entries of S H S + mu D^2 as k_tr_scale forms them (same operations in the same order); everything is loaded
+    // unconditionally and selected afterwards, so that a thread's loads go out as one batch
+    auto Rld = [&](const int p) { const int i = nat(p); return scv[i] * gn[i]; };
     double* rd = reinterpret_cast<double*>(tr_lds);
     double* yd = rd + nd + (nd & 1);                       // forward-substituted right-hand side of the epochs
     double* Vs = yd + nd + (nd & 1);                       // [nd][30]: epoch column restricted to its two keyframes, scaled
@@ -1333,6 +1376,7 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a) {
     int* esd = elist + 2 * nd + 2;                         // [2 nd] per list entry: offset into Vs of this keyframe's rows
     int* eoth = esd + 2 * nd + 2;                          // [2 nd] ... of the next keyframe's rows, or -1
     int* misc = eoth + 2 * nd + 2;                         // [0] bad, [1] number of active local rows, [2..17] their indices
+    double* wd = reinterpret_cast<double*>(misc + 24);     // [nd] u / s of the epochs (for t = H u)
     __shared__ int rowmask;                            // cleared here, two barriers before the first atomicOr into it
     if (tid < 18) misc[tid] = 0;
     if (tid == 0) rowmask = 0;
@@ -1342,7 +1386,9 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a) {
     __syncthreads();
     for (int t = tid; t < eoff[W]; t += KC_THREADS) elist[t] = a.ep_list[t];
     for (int e = tid; e < nd; e += KC_THREADS) {
-        const double m = A[(size_t)e * n + e];
+        const int ie = np15 + e;
+        const double se = scv[ie], he = Hn[(size_t)ie * n + ie], de = dgv[ie];
+        const double m = se * he * se + mu * de * de;
         if (!(m > 0.0) || !isfinite(m)) { misc[0] = 1; rd[e] = 0.0; } else rd[e] = rsqrt(m);
     }
     __syncthreads();
@@ -1350,30 +1396,91 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a) {
     // epoch columns (scaled) and the raw blocks, every global read issued as a batch of independent loads
     for (int e = tid; e < nd; e += KC_THREADS) {
         const int2 sl = eps[e];
-        double v[30];
+        double v[30], sr[30];
+        const double sce = scv[np15 + e];
 #pragma unroll
-        for (int q = 0; q < 30; ++q) { const int s1 = q < 15 ? sl.x : sl.y; v[q] = s1 >= 0 ? A[(size_t)(nd + 15 * s1 + (q < 15 ? q : q - 15)) * n + e] : 0.0; }
+        for (int q = 0; q < 30; ++q) {
+            const int s1 = q < 15 ? sl.x : sl.y;
+            const int i = 15 * (s1 >= 0 ? s1 : 0) + (q < 15 ? q : q - 15);
+            v[q] = Hn[(size_t)i * n + np15 + e]; sr[q] = scv[i];
+        }
+#pragma unroll
+        for (int q = 0; q < 30; ++q) { const int s1 = q < 15 ? sl.x : sl.y; v[q] = s1 >= 0 ? sr[q] * v[q] * sce : 0.0; }
         const double re = rd[e];
         int mk = 0;
 #pragma unroll
         for (int q = 0; q < 30; ++q) { Vs[e * 30 + q] = v[q] * re; if (v[q] != 0.0) mk |= 1 << (q % 15); }
         if (mk) atomicOr(&rowmask, mk);
-        yd[e] = rhs[e] * re;
+        yd[e] = Rld(e) * re;
     }
     for (int q = tid; q < W * 31; q += KC_THREADS) {
         const int i = q / 31, r = q - 31 * i;
         double v[KC_NB];
         if (r < 30) {
             const bool live = r < KC_NB || i + 1 < W;
-            const double* src = A + (size_t)(nd + 15 * i + r) * n + nd + 15 * i;      // r >= 15 runs into the rows of keyframe i+1
+            const int irow = live ? 15 * i + r : 15 * i, icol = 15 * i;                // r >= 15 runs into the rows of keyframe i+1
+            const double si = scv[irow], di = dgv[irow];
+            double h[KC_NB], sj[KC_NB];
 #pragma unroll
-            for (int j = 0; j < KC_NB; ++j) v[j] = (live && (r >= KC_NB || j <= r)) ? src[j] : 0.0;
+            for (int j = 0; j < KC_NB; ++j) { h[j] = Hn[(size_t)irow * n + icol + j]; sj[j] = scv[icol + j]; }
+#pragma unroll
+            for (int j = 0; j < KC_NB; ++j) {
+                double w = si * h[j] * sj[j];
+                w += (irow == icol + j) ? mu * di * di : 0.0;
+                v[j] = (live && (r >= KC_NB || j <= r)) ? w : 0.0;
+            }
         } else {
 #pragma unroll
-            for (int j = 0; j < KC_NB; ++j) v[j] = rhs[nd + 15 * i + j];
+            for (int j = 0; j < KC_NB; ++j) v[j] = Rld(nd + 15 * i + j);
         }
 #pragma unroll
         for (int j = 0; j < KC_NB; ++j) Blk[(size_t)i * KC_BLK + r * KC_RS + j] = v[j];
+    }
+    // w = u / s, staged where the back substitution will put z later
+    {
+        const double* __restrict__ uv = V_U(tr);
+        for (int k = tid; k < np15; k += KC_THREADS) zb[k] = uv[k] / scv[k];
+        for (int e = tid; e < nd; e += KC_THREADS) wd[e] = uv[np15 + e] / scv[np15 + e];
+    }
+    __syncthreads();
+    // t = H u from the staged (scaled) blocks: t_i = (sum_j (S H S)_ij w_j) / s_i, one row per thread
+    for (int row = tid; row < np15 + nd; row += KC_THREADS) {
+        double acc = 0.0;
+        if (row < np15) {
+            const int i = row / 15, r = row - 15 * i;
+            const double* Bi = Blk + (size_t)i * KC_BLK;
+#pragma unroll
+            for (int j = 0; j < KC_NB; ++j) {
+                double v = j <= r ? Bi[r * KC_RS + j] : Bi[j * KC_RS + r];
+                if (j == r) v -= mu * dgv[row] * dgv[row];
+                acc += v * zb[15 * i + j];
+            }
+            if (i + 1 < W) {
+#pragma unroll
+                for (int j = 0; j < KC_NB; ++j) acc += Bi[(KC_NB + j) * KC_RS + r] * zb[15 * (i + 1) + j];
+            }
+            if (i > 0) {
+                const double* Bp = Blk + (size_t)(i - 1) * KC_BLK;
+#pragma unroll
+                for (int j = 0; j < KC_NB; ++j) acc += Bp[(KC_NB + r) * KC_RS + j] * zb[15 * (i - 1) + j];
+            }
+            for (int tt = eoff[i]; tt < eoff[i + 1]; ++tt) {
+                const int e = elist[tt];
+                const int side = eps[e].x == i ? 0 : 15;
+                acc += (Vs[e * 30 + side + r] / rd[e]) * wd[e];
+            }
+            V_T(tr)[row] = acc / scv[row];
+        } else {
+            const int e = row - np15;
+            const int2 sl = eps[e];
+            const double se = scv[row];
+            acc = se * Hn[(size_t)row * n + row] * se * wd[e];
+            if (sl.x >= 0) {
+#pragma unroll
+                for (int q = 0; q < 30; ++q) acc += (Vs[e * 30 + q] / rd[e]) * zb[15 * (q < 15 ? sl.x : sl.y) + (q < 15 ? q : q - 15)];
+            }
+            V_T(tr)[row] = acc / se;
+        }
     }
     __syncthreads();
     AR_STAMP(42);
@@ -1469,7 +1576,7 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a) {
 #ifdef GLIO_DEV_STAMPS
     if (tid == 0) for (int k = 0; k < 5; ++k) a.dbg[60 + k] = ph[k];
 #endif
-    if (bad && lane == 0) misc[0] = 1;
+    if ((bad || a.force_fail) && lane == 0) misc[0] = 1;
     __syncthreads();
     if (misc[0]) { if (tid == 0) atomicOr(a.flag, 1); return; }
     // back substitution: meeting keyframe, then the two halves in parallel:  L_ii^T z_i = y_i - L_{nbr,i}^T z_nbr
@@ -1551,19 +1658,22 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
     const size_t lds_pk = pk_doubles(np) * 8 + slv_tail;
     const bool lds_chol = lds_pk <= 160 * 1024;
     const size_t lds_slv = lds_chol ? lds_pk : glio_tr_step_lds_bytes(np) + arrow_solve_extra_doubles(c->W, K) * 8;
-    const bool arrow = c->arrow.mode == 1 && c->arrow.gnss_ok && c->arrow.prior_ok && c->arrow.max_epoch < n_ddt && lds_fwd <= 160 * 1024 && lds_slv <= 160 * 1024;
+    const bool arrow = c->arrow.mode >= 1 && c->arrow.gnss_ok && c->arrow.prior_ok && c->arrow.max_epoch < n_ddt && lds_fwd <= 160 * 1024 && lds_slv <= 160 * 1024;
     const size_t lds_chain = chain_lds_doubles(c->W, n_ddt) * 8;
-    const bool chain = c->arrow.mode == 1 && c->arrow.gnss_chain && c->arrow.prior_chain && c->arrow.max_epoch < n_ddt && lds_chain <= 150 * 1024;
+    const bool chain = c->arrow.mode >= 1 && c->arrow.gnss_chain && c->arrow.prior_chain && c->arrow.max_epoch < n_ddt && lds_chain <= 150 * 1024;
     a.perm_mode = chain ? 1 : 0;
     c->arrow.last_path = chain ? 2 : (arrow ? 1 : 0);
     a.arrow_flag = (arrow || chain) ? c->arrow.d_flag : nullptr; a.arrow_z = c->arrow.d_z;
-    hipLaunchKernelGGL(k_tr_prepare, dim3(1), dim3(TR_THREADS), 0, c->stream, a);
-    hipLaunchKernelGGL(k_tr_scale, dim3((a.n + 1 + 3) / 4), dim3(256), 0, c->stream, a);
+    a.fused_chain = chain ? 1 : 0;
+    if (!chain) {
+        hipLaunchKernelGGL(k_tr_prepare, dim3(1), dim3(TR_THREADS), 0, c->stream, a);
+        hipLaunchKernelGGL(k_tr_scale, dim3((a.n + 1 + 3) / 4), dim3(256), 0, c->stream, a);
+    }
     if (chain) {
         ChainArgs r;
-        r.W = c->W; r.n = a.n; r.nd = n_ddt; r.A = c->d_L; r.ep_slots = c->arrow.d_ep_slots; r.ep_off = c->arrow.d_ep_off; r.ep_list = c->arrow.d_ep_list;
-        r.z = c->arrow.d_z; r.flag = c->arrow.d_flag; r.status = c->d_status; r.dbg = c->arrow.d_dbg;
-        hipLaunchKernelGGL(k_chain_solve, dim3(1), dim3(KC_THREADS), lds_chain, c->stream, r);
+        r.W = c->W; r.n = a.n; r.nd = n_ddt; r.ep_slots = c->arrow.d_ep_slots; r.ep_off = c->arrow.d_ep_off; r.ep_list = c->arrow.d_ep_list;
+        r.z = c->arrow.d_z; r.flag = c->arrow.d_flag; r.status = c->d_status; r.dbg = c->arrow.d_dbg; r.force_fail = c->arrow.mode == 2;
+        hipLaunchKernelGGL(k_chain_solve, dim3(1), dim3(KC_THREADS), lds_chain, c->stream, r, a);
     } else if (arrow) {
         ArrowArgs r;
         r.W = c->W; r.n = a.n; r.nd = n_ddt; r.np = np; r.K = K; r.ldY = np + 2;

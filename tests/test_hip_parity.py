@@ -373,3 +373,13 @@ def test_keyframe_chain_solver_equals_dense(hip, po, steady_window, use_gnss):
     so, mo = po.Problem(win, corr, use_gnss=use_gnss).solve(_state_for(win, use_gnss))
     assert mo.iterations == mc.iterations
     assert_pose_parity(sc, so)
+    # the chain kernel's breakdown path: every step reports a non-positive pivot, k_tr_finish rebuilds the scaled matrix
+    # and t = H u itself and factors densely -- the iterates must be the dense solver's
+    ctx = hip.Context(win.opts)
+    hip.load().glio_debug_set_solver(ctx._h, 2)
+    ctx.load_window(win, corr, use_gnss=use_gnss)
+    sf, mf = ctx.solve(_state_for(win, use_gnss))
+    assert hip.load().glio_debug_solver_path(ctx._h) == 2
+    ctx.close()
+    assert mf.iterations == md.iterations and mf.termination == md.termination
+    assert np.abs(sf.trans - sd.trans).max() <= 1e-10 and np.abs(sf.quat - sd.quat).max() <= 1e-11
