@@ -1393,6 +1393,15 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a, c
     }
     __syncthreads();
     AR_STAMP(41);
+    // issued with the same batch of loads: w = u / s (staged where the back substitution will put z later) and the scalars
+    // of the row of t = H u this thread will compute
+    double pre_s = 1.0, pre_d = 0.0, pre_h = 0.0;
+    {
+        const double* __restrict__ uv = V_U(tr);
+        for (int k = tid; k < np15; k += KC_THREADS) zb[k] = uv[k] / scv[k];
+        for (int e = tid; e < nd; e += KC_THREADS) wd[e] = uv[np15 + e] / scv[np15 + e];
+        if (tid < np15 + nd) { pre_s = scv[tid]; pre_d = dgv[tid]; pre_h = tid >= np15 ? Hn[(size_t)tid * n + tid] : 0.0; }
+    }
     // epoch columns (scaled) and the raw blocks, every global read issued as a batch of independent loads
     for (int e = tid; e < nd; e += KC_THREADS) {
         const int2 sl = eps[e];
@@ -1436,23 +1445,20 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a, c
 #pragma unroll
         for (int j = 0; j < KC_NB; ++j) Blk[(size_t)i * KC_BLK + r * KC_RS + j] = v[j];
     }
-    // w = u / s, staged where the back substitution will put z later
-    {
-        const double* __restrict__ uv = V_U(tr);
-        for (int k = tid; k < np15; k += KC_THREADS) zb[k] = uv[k] / scv[k];
-        for (int e = tid; e < nd; e += KC_THREADS) wd[e] = uv[np15 + e] / scv[np15 + e];
-    }
     __syncthreads();
-    // t = H u from the staged (scaled) blocks: t_i = (sum_j (S H S)_ij w_j) / s_i, one row per thread
+    // t = H u from the staged (scaled) blocks: t_i = (sum_j (S H S)_ij w_j) / s_i, one row per thread (its scalars were
+    // fetched with the blocks, so this phase touches LDS only)
     for (int row = tid; row < np15 + nd; row += KC_THREADS) {
         double acc = 0.0;
+        const bool first = row == tid;
+        const double s_row = first ? pre_s : scv[row], d_row = first ? pre_d : dgv[row];
         if (row < np15) {
             const int i = row / 15, r = row - 15 * i;
             const double* Bi = Blk + (size_t)i * KC_BLK;
 #pragma unroll
             for (int j = 0; j < KC_NB; ++j) {
                 double v = j <= r ? Bi[r * KC_RS + j] : Bi[j * KC_RS + r];
-                if (j == r) v -= mu * dgv[row] * dgv[row];
+                if (j == r) v -= mu * d_row * d_row;
                 acc += v * zb[15 * i + j];
             }
             if (i + 1 < W) {
@@ -1469,12 +1475,12 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a, c
                 const int side = eps[e].x == i ? 0 : 15;
                 acc += (Vs[e * 30 + side + r] / rd[e]) * wd[e];
             }
-            V_T(tr)[row] = acc / scv[row];
+            V_T(tr)[row] = acc / s_row;
         } else {
             const int e = row - np15;
             const int2 sl = eps[e];
-            const double se = scv[row];
-            acc = se * Hn[(size_t)row * n + row] * se * wd[e];
+            const double se = s_row;
+            acc = se * (first ? pre_h : Hn[(size_t)row * n + row]) * se * wd[e];
             if (sl.x >= 0) {
 #pragma unroll
                 for (int q = 0; q < 30; ++q) acc += (Vs[e * 30 + q] / rd[e]) * zb[15 * (q < 15 ? sl.x : sl.y) + (q < 15 ? q : q - 15)];
