@@ -2,32 +2,37 @@
 // (GLIO/src/Estimator.cpp:2424-2433: SPARSE_NORMAL_CHOLESKY, DOGLEG, 15 iterations, monotonic steps),
 // restated on the dense device-resident normal equations and run entirely on the GPU.
 //
-// Four launches per iteration, all reading / writing the SolverStatus record in device memory:
-//   k_tr_prepare (1 workgroup)   step evaluation of the candidate produced by the previous iteration:
-//                 parameter / function tolerance, relative decrease -> accept (swap the double-buffered
-//                 H,g,x) or reject, dogleg radius update (Ceres 1.14 TrustRegionMinimizer); loop-top checks
-//                 (max iterations, gradient tolerance, min radius); Jacobi scaling, D = sqrt(clamp(diag)),
-//                 Cauchy direction u = S g~/D
+// The steps of one iteration, all reading / writing the SolverStatus record in device memory:
+//   prepare (tr_prepare_body; its own launch k_tr_prepare, or the prologue of k_chain_solve)   step evaluation of the
+//                 candidate produced by the previous iteration: parameter / function tolerance, relative decrease ->
+//                 accept (swap the double-buffered H,g,x) or reject, dogleg radius update (Ceres 1.14
+//                 TrustRegionMinimizer); loop-top checks (max iterations, gradient tolerance, min radius); Jacobi
+//                 scaling, D = sqrt(clamp(diag)), Cauchy direction u = S g~/D
 //   k_tr_scale   (n/4 workgroups, one wavefront per row)  t = H u  and  L = S H S + mu D^2 (lower triangle,
 //                 right-hand side S g carried as row n): the only O(n^2) streaming pass, spread over the chip
-//   k_tr_factor  (1 workgroup)   Cauchy step length; blocked LEFT-looking Cholesky of L: per 16-column panel
-//                 every wavefront owns 16x16 output tiles and runs one long v_mfma_f64_16x16x4_f64 chain
+//                 (not launched on the keyframe-chain path: k_chain_solve forms what it needs while staging)
+//   the structured factorisation when the graph permits: k_chain_solve (one launch, incl. prepare and scale) or
+//                 k_arrow_forward / k_arrow_schur / k_arrow_solve
+//   k_tr_finish  (1 workgroup) = tr_factor_body + tr_dogleg_body:
+//                 Cauchy step length; the structured solver's result, or the blocked LEFT-looking Cholesky of L: per
+//                 16-column panel every wavefront owns 16x16 output tiles and runs one long v_mfma_f64_16x16x4_f64 chain
 //                 A_tile -= L[rows, 0:k0] L[k0:k0+16, 0:k0]^T (B operand = the 16 pivot rows staged in LDS,
 //                 A operand streamed from L2 as 16-byte loads), then the diagonal block is factored in
 //                 registers by wavefront 0 (v_readlane broadcasts) and the rows below are solved one lane
-//                 per row; back substitution; mu retry x10 on breakdown (DoglegStrategy)
-//   k_tr_dogleg  (1 workgroup)   traditional dogleg interpolation, model cost change (O(n): H S step follows
+//                 per row; back substitution; mu retry x10 on breakdown (DoglegStrategy);
+//                 then the traditional dogleg interpolation, model cost change (O(n): H S step follows
 //                 from the two products already known), candidate x (+) delta.  An invalid step (model cost
 //                 change <= 0) consumes an iteration without producing a candidate, as in Ceres.
-// The host enqueues max_iterations+1 such groups interleaved with the linearisation kernels and never
-// reads anything back until the end; kernels exit immediately once status.done is set, and the
+// The host enqueues such groups interleaved with the linearisation kernels one at a time (capi.hip: enqueue_solve) and
+// takes the result from mapped host memory; kernels exit immediately once status.done is set, and the
 // linearisation kernels also when no candidate is pending.
 //
 // The Cholesky is the one GEMM-shaped piece of the whole path and runs on the matrix cores; it is
 // latency/LDS-bound dense fp64 on a single CU (n <= ~1000 unknowns), not roofline material.
 //
 // NOTE: no __restrict__ on anything in this file: every buffer here is handed between lanes of the
-// workgroup across s_barrier.
+// workgroup across s_barrier.  And a kernel here must not re-read global data it has itself rewritten unless the two
+// cannot share a 128 B line with anything it loaded earlier (see glio_ctx::vstride and DESIGN.md, "coherence trap").
 #include <vector>
 
 #include "glio_device.h"
@@ -1352,12 +1357,12 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a, c
     if (tid == 0) *a.flag = 0;
     // chain order p = [epochs | keyframe 0 (15) | ...]  <->  natural order i = [keyframes | epochs]
     const int np15 = 15 * W;
-    const double* __restrict__ Hn = dec.cur ? tr.H1 : tr.H0;
-    const double* __restrict__ gn = dec.cur ? tr.g1 : tr.g0;
+    const double* Hn = dec.cur ? tr.H1 : tr.H0;
+    const double* gn = dec.cur ? tr.g1 : tr.g0;
     // (scale, diag, u were written by tr_prepare_body above: safe to read back because the work vectors occupy whole 128 B
     // lines -- glio_ctx::vstride -- so no line holding them was fetched before they were written)
-    const double* __restrict__ scv = V_SCALE(tr);
-    const double* __restrict__ dgv = V_DIAG(tr);
+    const double* scv = V_SCALE(tr);
+    const double* dgv = V_DIAG(tr);
     const double mu = dec.mu;
     auto nat = [&](const int p) { return p < nd ? np15 + p : p - nd; };
     // entries of S H S + mu D^2 as k_tr_scale forms them (same operations in the same order); everything is loaded
@@ -1397,7 +1402,7 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a, c
     // of the row of t = H u this thread will compute
     double pre_s = 1.0, pre_d = 0.0, pre_h = 0.0;
     {
-        const double* __restrict__ uv = V_U(tr);
+        const double* uv = V_U(tr);
         for (int k = tid; k < np15; k += KC_THREADS) zb[k] = uv[k] / scv[k];
         for (int e = tid; e < nd; e += KC_THREADS) wd[e] = uv[np15 + e] / scv[np15 + e];
         if (tid < np15 + nd) { pre_s = scv[tid]; pre_d = dgv[tid]; pre_h = tid >= np15 ? Hn[(size_t)tid * n + tid] : 0.0; }
