@@ -66,3 +66,61 @@ def test_hip_path_matches_the_fixture(golden, case):
     J0 = np.asarray(m["lin_jac"]); r0 = np.asarray(m["lin_res"])
     assert rel(J0.T @ J0, golden["marg_S"]) <= 1e-7 and rel(J0.T @ r0, golden["marg_b"]) <= 1e-7
     ctx.close()
+
+
+# ---- the rows SURVEY 8f ranks next (f2 batch association, f3 front-end odometry, f4 local map) -----------------------
+import make_golden_next as mgn      # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def golden_next():
+    return np.load(os.path.join(HERE, "golden", "next_rows_small.npz"))
+
+
+@pytest.fixture(scope="module")
+def case_next():
+    return mgn.make_inputs()
+
+
+def test_next_rows_oracle_reproduces_the_fixture(golden_next, case_next):
+    win, body = case_next
+    assert mgn.digest(win, body) == str(golden_next["input_sha256"]), "the synthetic generator changed"
+    out = mgn.oracle_outputs(win, body)
+    assert int(out["pair_count"]) == int(golden_next["pair_count"]) and int(out["map_count"]) == int(golden_next["map_count"])
+    for k in ("pair_cp", "pair_nc", "pair_score", "odo_iterations", "odo_kept"):
+        assert np.array_equal(out[k], golden_next[k]), k                      # float / index work: exact
+    assert np.abs(out["odo_pose"] - golden_next["odo_pose"]).max() <= 1e-11
+    assert np.abs(out["map_head"] - golden_next["map_head"]).max() <= 1e-6
+
+
+@pytest.mark.gpu
+def test_next_rows_hip_matches_the_fixture(golden_next, case_next):
+    from glio_amd import batch, capi, odometry, synth
+    win, body = case_next
+    # f2: one keyframe pair, bit-exact records in the same order
+    ba = batch.BatchAssociation(2, 2048, 100000)
+    ba.set_frame(0, body[0]); ba.set_frame(1, body[1])
+    poses = np.c_[win.init.trans, win.init.quat][:2]
+    counts, total = ba.run(poses, np.array([0], np.int32), np.array([1], np.int32))
+    cp, nc, sc = ba.read()
+    assert total == int(golden_next["pair_count"])
+    assert np.array_equal(cp[:16], golden_next["pair_cp"]) and np.array_equal(nc[:16], golden_next["pair_nc"]) and np.array_equal(sc[:16], golden_next["pair_score"])
+    ba.close()
+    # f3: two matching rounds of the front end
+    o = odometry.frontend_opts(len(body[0]), len(win.map_pts))
+    ctx = capi.Context(o)
+    odo = odometry.ScanToMapOdometry(ctx)
+    odo.set_map(win.map_pts)
+    pose, rounds = odo.update(body[0], np.r_[win.init.quat[0], win.init.trans[0]], match_cnt=2)
+    assert [int(r[0].iterations) for r in rounds] == list(golden_next["odo_iterations"])
+    assert [int(r[1]) for r in rounds] == list(golden_next["odo_kept"])
+    assert np.abs(pose - golden_next["odo_pose"]).max() <= 1e-8
+    ctx.close()
+    # f4: voxel-grid local map of the three-keyframe ring
+    lm = capi.Context(synth.default_opts(1, pts=2048, map_pts=1 << 15))
+    lm.localmap_config(3, 0.4, 2048)
+    for s in range(3):
+        lm.localmap_push(body[s], win.gt.quat[s], win.gt.trans[s])
+    assert lm.localmap_build() == int(golden_next["map_count"])
+    assert np.abs(lm.localmap_read()[:32] - golden_next["map_head"]).max() <= 2e-5
+    lm.close()
