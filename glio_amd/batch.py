@@ -138,6 +138,15 @@ def pair_list(K, search_range):
     return np.asarray(ci, np.int32), np.asarray(cj, np.int32)
 
 
+def pair_shard(pair_ci, K, rank, world):
+    """Slice [first, last) of a ci-major pair list (pair_list) owned by `rank`: the pairs whose SOURCE keyframe lies in the
+    rank's keyframe range -- the same ownership rule as the constraints of the batch stage, so a rank associates exactly
+    the pairs whose constraints it will linearise and nothing crosses ranks before the one all-reduce."""
+    lo, hi = shard_range(K, rank, world)
+    ci = np.asarray(pair_ci)
+    return int(np.searchsorted(ci, lo, side="left")), int(np.searchsorted(ci, hi, side="left"))
+
+
 class BatchAssociation:
     """Device-resident findGlobalCorrespondingSurfFeaturesAdd_Batch: keyframe clouds stay on the GPU, `run` builds the
     pair-major constraint arrays K8 consumes.  No CPU fallback."""

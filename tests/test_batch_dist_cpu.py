@@ -59,3 +59,66 @@ def test_two_rank_allreduce_equals_single_rank(tmp_path):
     Hb, g, cost = po.batch_linearize(K, band, np.ascontiguousarray(init), ci, cj, cp, nc, sc)
     full = np.concatenate([Hb.ravel(), g.ravel(), [cost]])
     assert np.linalg.norm(reduced - full) <= 1e-12 * np.linalg.norm(full)
+
+
+# ---- association + linearisation of the batch stage, sharded by source keyframe (oracle standing in for the HIP kernels)
+def _frames(K=6, pts=500):
+    from glio_amd import synth
+    win = synth.make_window(W=K, pts_per_scan=pts, seed=synth.SEED_BASE + 61, perturb=(0.03, 0.2, 0.0), scan_radius=12.0, map_density=1.0)
+    tlb = np.array(win.opts.t_lb, np.float32)
+    scans = []
+    for s in range(K):
+        c = win.scans[s].copy(); c[:, :3] -= tlb
+        scans.append(np.ascontiguousarray(c))
+    return scans, np.ascontiguousarray(np.c_[win.init.trans, win.init.quat])
+
+
+def _associate_and_linearize(po, scans, poses, ci, cj, K, band):
+    cps, ncs, scs, cis, cjs = [], [], [], [], []
+    for a, b in zip(ci, cj):
+        cp, nc, sc, _ = po.associate_pair(scans[a], poses[a], scans[b], poses[b])
+        cps.append(cp); ncs.append(nc); scs.append(sc); cis.append(np.full(len(sc), a, np.int32)); cjs.append(np.full(len(sc), b, np.int32))
+    cat = lambda xs, shape: np.concatenate(xs) if xs else np.zeros(shape)
+    Hb, g, cost = po.batch_linearize(K, band, poses, cat(cis, 0).astype(np.int32), cat(cjs, 0).astype(np.int32),
+                                     cat(cps, (0, 4)).astype(np.float32), cat(ncs, (0, 6)), cat(scs, 0))
+    return np.concatenate([Hb.ravel(), g.ravel(), [cost]])
+
+
+def _assoc_worker(rank, world, port, K, rng, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle as po
+    scans, poses = _frames(K)
+    ci, cj = batch.pair_list(K, rng)
+    first, last = batch.pair_shard(ci, K, rank, world)
+    Hg = torch.from_numpy(_associate_and_linearize(po, scans, poses, ci[first:last], cj[first:last], K, 2 * rng))
+    dist.all_reduce(Hg, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        np.save(out_path, Hg.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pair_shards_partition_the_pair_list():
+    for K, rng in ((6, 1), (20, 3), (33, 6)):
+        ci, cj = batch.pair_list(K, rng)
+        for world in (1, 2, 3, 8):
+            cuts = [batch.pair_shard(ci, K, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == len(ci) and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+            for r, (f, l) in enumerate(cuts):
+                lo, hi = batch.shard_range(K, r, world)
+                assert np.all((ci[f:l] >= lo) & (ci[f:l] < hi))
+
+
+def test_two_rank_association_plus_linearisation_equals_single_rank(tmp_path):
+    from oracle import pyoracle as po
+    K, rng, world = 6, 1, 2
+    out = str(tmp_path / "hg_assoc.npy")
+    mp.spawn(_assoc_worker, args=(world, _free_port(), K, rng, out), nprocs=world, join=True)
+    reduced = np.load(out)
+    scans, poses = _frames(K)
+    ci, cj = batch.pair_list(K, rng)
+    full = _associate_and_linearize(po, scans, poses, ci, cj, K, 2 * rng)
+    assert full[-1] > 0, "the synthetic frames must produce constraints"
+    assert np.abs(reduced - full).max() <= 1e-9 * np.abs(full).max()
