@@ -178,6 +178,49 @@ public:
         return m;
     }
 
+    // ---- the same keyframe cycle with everything kept on the device between keyframes (what glio_amd/sliding.py's
+    // ResidentSlidingWindow does in Python): only the NEW keyframe's scan crosses PCIe, all W slots are associated in one
+    // call, the marginalization result stays on the device as the next window's prior.
+    // surf_frames bookkeeping of Estimator.cpp:4240-4300: slot s <- slot s+1 (scans and their correspondences)
+    void slideWindow() { check(glio_slide_window(ctx_), "glio_slide_window"); }
+    void setScan(int slot, const float* scan_xyzi, int n) { check(glio_set_scan(ctx_, slot, scan_xyzi, n), "glio_set_scan"); }
+    // the loop over idx of Estimator.cpp:2216-2222 for the whole window, with the poses held in tmpTrans / tmpQuat
+    std::vector<int32_t> findCorrespondingSurfFeaturesWindow() {
+        std::vector<double> q2(4 * W_), t2(3 * W_);
+        for (int s = 0; s < W_; ++s) lidarPose(s, &q2[4 * s], &t2[3 * s]);
+        std::vector<int32_t> counts(W_, 0);
+        check(glio_associate_window(ctx_, q2.data(), t2.data(), counts.data()), "glio_associate_window");
+        return counts;
+    }
+    // Estimator.cpp:2462-2607 with the result kept resident as the prior of the next window (no J0 read-back)
+    void marginalizeAndKeep() {
+        glio_state st;
+        st.trans = tmpTrans.data(); st.quat = tmpQuat.data(); st.speed_bias = tmpSpeedBias.data(); st.rcv_ddt = nullptr; st.n_ddt = 0;
+        check(glio_marginalize_keep(ctx_, &st), "glio_marginalize_keep");
+    }
+    // buildLocalMapWithLandMark + downSampleCloud (Estimator.cpp:3529-3631) on the device: push the new keyframe's cloud
+    // (body frame) with its pose, rebuild the voxel-averaged ring map and its search structure; returns the map size
+    void configureLocalMap(int width, float leaf, int max_points_per_keyframe) {
+        check(glio_localmap_config(ctx_, width, leaf, max_points_per_keyframe), "glio_localmap_config");
+    }
+    int pushKeyframeAndBuildLocalMap(const float* cloud_xyzi, int n, const double q[4], const double t[3]) {
+        check(glio_localmap_push(ctx_, cloud_xyzi, n, q, t), "glio_localmap_push");
+        int pts = 0;
+        check(glio_localmap_build(ctx_, &pts), "glio_localmap_build");
+        return pts;
+    }
+    // shift the host-side state like the reference's slideWindow(): the newest slot is initialised by the caller
+    void slideState(const double new_t[3], const double new_q[4], const double new_sb[9]) {
+        for (int i = 0; i + 1 < W_; ++i) {
+            for (int k = 0; k < 3; ++k) tmpTrans[3 * i + k] = tmpTrans[3 * (i + 1) + k];
+            for (int k = 0; k < 4; ++k) tmpQuat[4 * i + k] = tmpQuat[4 * (i + 1) + k];
+            for (int k = 0; k < 9; ++k) tmpSpeedBias[9 * i + k] = tmpSpeedBias[9 * (i + 1) + k];
+        }
+        for (int k = 0; k < 3; ++k) tmpTrans[3 * (W_ - 1) + k] = new_t[k];
+        for (int k = 0; k < 4; ++k) tmpQuat[4 * (W_ - 1) + k] = new_q[k];
+        for (int k = 0; k < 9; ++k) tmpSpeedBias[9 * (W_ - 1) + k] = new_sb[k];
+    }
+
     // Estimator.cpp:2611-2726 write-back with the reference's sanity gates.  Ps/Vs: [W][3]; Qs: [W][4] (w,x,y,z,
     // the reference keeps Rs as matrices); para_speed_bias: [W][9].  Components failing their gate keep the old
     // value (Q14).  The six bias gates are chained by dangling `else`s in the reference (the ROS_WARNs between

@@ -48,6 +48,15 @@ int main(int argc, char** argv) {
         for (double v : m.linearized_jacobians) tr += v * v;
         for (double v : m.linearized_residuals) rr += v * v;
         printf("prior %d %zu %.17g %.17g\n", m.n, m.keep_block_slot.size(), tr, rr);
+        // the device-resident form of the same cycle: the scans are already resident from the per-slot calls above, so one
+        // call re-associates the whole window at the solved poses; then marginalize-and-keep, and the kept prior is used by
+        // a second solve of the same window
+        const std::vector<int32_t> counts = be.findCorrespondingSurfFeaturesWindow();
+        long kept_window = 0;
+        for (int32_t c : counts) kept_window += c;
+        be.marginalizeAndKeep();
+        const glio_summary sum2 = be.solve();
+        printf("resident %ld %d %.17g\n", kept_window, sum2.iterations, sum2.final_cost);
     } catch (const std::exception& e) {
         fprintf(stderr, "error: %s\n", e.what());
         return 1;

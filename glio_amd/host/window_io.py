@@ -46,4 +46,7 @@ def run_demo(path):
         if ln.startswith("prior "):
             p = ln.split()
             info["prior"] = dict(n=int(p[1]), n_blocks=int(p[2]), jac_fro2=float(p[3]), res2=float(p[4]))
+        if ln.startswith("resident "):
+            p = ln.split()
+            info["resident"] = dict(kept=int(p[1]), iterations=int(p[2]), final_cost=float(p[3]))
     return info, rows[:, :3], rows[:, 3:]

@@ -45,4 +45,11 @@ def test_cpp_sequence_matches_python_sequence(tmp_path):
     assert info["prior"]["n"] == out["n"] and info["prior"]["n_blocks"] == len(out["blk_slot"])
     assert np.isclose(info["prior"]["jac_fro2"], (out["lin_jac"] ** 2).sum(), rtol=1e-9)
     assert np.isclose(info["prior"]["res2"], out["lin_res"] @ out["lin_res"], rtol=1e-7, atol=1e-12)
+    # the resident form (C++: findCorrespondingSurfFeaturesWindow / marginalizeAndKeep / solve) against the same calls here
+    poses = [capi.lidar_pose(win.opts, st.quat[s], st.trans[s]) for s in range(win.W)]
+    counts = ctx.associate_window(np.array([p[0] for p in poses]), np.array([p[1] for p in poses]))
+    ctx.marginalize_keep(st)
+    sol2, summ2 = ctx.solve(st)
+    assert info["resident"]["kept"] == int(np.sum(counts)) and info["resident"]["iterations"] == summ2.iterations
+    assert np.isclose(info["resident"]["final_cost"], summ2.final_cost, rtol=1e-12)
     ctx.close()
