@@ -12,7 +12,9 @@ from . import synth
 _LIB = None
 LIB_PATH = os.environ.get("GLIO_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libglio_hip.so")
 
-KERNEL_LIDAR_LINEARIZE, KERNEL_FULL_LINEARIZE, KERNEL_TR_STEP, KERNEL_ASSOCIATE, KERNEL_MAP_BUILD, KERNEL_MARGINALIZE, KERNEL_STREAM_READ = range(7)
+(KERNEL_LIDAR_LINEARIZE, KERNEL_FULL_LINEARIZE, KERNEL_TR_STEP, KERNEL_ASSOCIATE, KERNEL_MAP_BUILD, KERNEL_MARGINALIZE, KERNEL_STREAM_READ,
+ KERNEL_LINEARIZE_ALL) = range(8)
+LIDAR_F64, LIDAR_F32_MFMA = 0, 1
 
 
 class GlioError(RuntimeError):
@@ -170,7 +172,7 @@ class Context:
 
     def set_prior(self, prior):
         ps = synth.prior_struct(prior)
-        self._keep.append(prior)
+        self._keep = [prior]          # glio_set_prior copies synchronously; only the latest is held (for the caller's convenience)
         _check(load().glio_set_prior(self._h, C.byref(ps)))
 
     def set_gnss(self, frame, dd, dop):

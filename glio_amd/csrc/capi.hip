@@ -34,16 +34,14 @@ struct CtxExtra {
     double* h_eval;   // pinned
     int imu_edge0;    // index of the IMU edge leaving slot 0 (-1: none)
 };
-static std::vector<std::pair<glio_ctx*, CtxExtra*>> g_extras;
-static CtxExtra* extra_of(glio_ctx* c) {
-    for (auto& p : g_extras) if (p.first == c) return p.second;
-    return nullptr;
-}
+// the extras hang off the context itself (glio_ctx::extra): no process-global registry, so independent contexts can be
+// created, used and destroyed from different threads concurrently (Estimator.cpp:5398-5404)
+static CtxExtra* extra_of(glio_ctx* c) { return static_cast<CtxExtra*>(c->extra); }
 GnssDevExtra* glio_extra(glio_ctx* c) { return &extra_of(c)->gx; }
 
 extern "C" {
 
-int glio_abi_version(void) { return 1; }
+int glio_abi_version(void) { return 2; }
 const char* glio_last_error(void) { return g_err; }
 int glio_device_count(void) {
     int n = 0;
@@ -73,6 +71,7 @@ static int g_fill = getenv("GLIO_DEBUG_FILL") ? atoi(getenv("GLIO_DEBUG_FILL")) 
 #define ALLOC(ptr, bytes) do { GLIO_HIP_CHECK(hipMalloc((void**)&(ptr), (bytes) > 0 ? (size_t)(bytes) : 16)); \
                                if (g_fill >= 0) GLIO_HIP_CHECK(hipMemset((void*)(ptr), g_fill, (bytes) > 0 ? (size_t)(bytes) : 16)); } while (0)
 
+static int create_body(int device, const glio_opts* opts, glio_ctx* c);
 int glio_create(int device, const glio_opts* opts, glio_ctx** out) {
     if (!opts || !out) { glio_set_error("null argument"); return GLIO_E_ARG; }
     if (glio_device_count() < 1) { glio_set_error("no HIP device visible: the GLIO hot path has no CPU fallback"); return GLIO_E_HIP; }
@@ -83,6 +82,21 @@ int glio_create(int device, const glio_opts* opts, glio_ctx** out) {
     GLIO_HIP_CHECK(hipSetDevice(device));
     glio_ctx* c = new glio_ctx();
     memset(c, 0, sizeof *c);
+    c->device = device;
+    const int rc = create_body(device, opts, c);
+    if (rc != GLIO_OK) {                      // a failed allocation half way: release what was built (every pointer is null-checked)
+        char keep[sizeof g_err];
+        memcpy(keep, g_err, sizeof keep);
+        glio_destroy(c);
+        memcpy(g_err, keep, sizeof keep);
+        return rc;
+    }
+    *out = c;
+    return GLIO_OK;
+}
+static int create_body(int device, const glio_opts* opts, glio_ctx* c) {
+    const int W = opts->window;
+    const int n_max = 15 * W + std::max(0, opts->max_ddt_epochs);
     c->opts = *opts; c->device = device; c->W = W; c->cap = opts->max_points_per_scan;
     c->n_ddt_max = std::max(0, opts->max_ddt_epochs); c->n_max = n_max;
     GLIO_HIP_CHECK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -90,6 +104,8 @@ int glio_create(int device, const glio_opts* opts, glio_ctx** out) {
     const size_t wc = (size_t)W * c->cap;
     ALLOC(c->d_pts, wc * sizeof(float4)); ALLOC(c->d_planes, wc * sizeof(float4)); ALLOC(c->d_scores, wc * sizeof(double));
     ALLOC(c->d_count, W * sizeof(int)); ALLOC(c->d_scan, wc * sizeof(float4));
+    if (opts->lidar_precision == GLIO_LIDAR_F32_MFMA) { ALLOC(c->d_pts_s, wc * sizeof(float4)); c->f32_dirty = 1; }
+    else if (opts->lidar_precision != GLIO_LIDAR_F64) { glio_set_error("unknown lidar_precision %d", opts->lidar_precision); return GLIO_E_ARG; }
     // NB: every memset goes on the context's (non-blocking) stream: a null-stream hipMemset is asynchronous
     // and unordered with it, and once raced with the first glio_set_correspondences count upload.
     GLIO_HIP_CHECK(hipMemsetAsync(c->d_count, 0, W * sizeof(int), c->stream));
@@ -162,39 +178,42 @@ int glio_create(int device, const glio_opts* opts, glio_ctx** out) {
     ALLOC(ex->gx.d_prior_colblk, npmax * 4);
     ALLOC(ex->d_eval_params, 64 * 8); ALLOC(ex->d_eval_out, (15 + 15 * 32) * 8); ALLOC(ex->d_eval_edge, sizeof(ImuEdgeDev));
     GLIO_HIP_CHECK(hipHostMalloc((void**)&ex->h_eval, (15 + 15 * 32) * 8));
-    g_extras.emplace_back(c, ex);
+    c->extra = ex;
     glio_tr_step_configure(160 * 1024);
     if (glio_assoc_create(c) != GLIO_OK) return GLIO_E_HIP;
-    *out = c;
     return GLIO_OK;
 }
 
 void glio_destroy(glio_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    if (c->stream) hipStreamSynchronize(c->stream);
     glio_assoc_destroy(c);
     glio_localmap_destroy(c);
-    void* ptrs[] = {c->d_pts, c->d_planes, c->d_scores, c->d_count, c->d_scan, c->d_imu, c->d_imu_blocks, c->d_gnss_blocks, c->d_groups,
+    void* ptrs[] = {c->d_pts, c->d_planes, c->d_scores, c->d_pts_s, c->d_count, c->d_scan, c->d_imu, c->d_imu_blocks, c->d_gnss_blocks, c->d_groups,
                     c->d_ddt_blocks, c->d_dd, c->d_dop, c->d_prior_J0, c->d_prior_A0, c->d_prior_r0, c->d_prior_x0, c->d_prior_slot,
                     c->d_prior_kind, c->d_prior_idx, c->d_prior_index, c->d_prior_H, c->d_prior_g, c->d_prior_cost, c->d_prior_work,
                     /* d_x[0] lives inside d_status' allocation */ c->d_x[1], c->d_H[0], c->d_H[1], c->d_g[0], c->d_g[1], c->d_cost[0], c->d_cost[1], c->d_xout,
                     c->d_lidar_partials, c->d_lidar_blocks, c->d_L, c->d_vec, c->d_status,
                     c->arrow.d_ep_slots, c->arrow.d_ep_off, c->arrow.d_ep_list, c->arrow.d_Y, c->arrow.d_Lblk, c->arrow.d_Sp, c->arrow.d_z, c->arrow.d_flag, c->arrow.d_dbg};
     for (void* p : ptrs) if (p) hipFree(p);
-    hipHostFree(c->h_status); /* h_xbuf lives inside it */ hipHostFree((void*)c->h_progress); hipHostFree(c->h_result);
+    if (c->h_status) hipHostFree(c->h_status); /* h_xbuf lives inside it */
+    if (c->h_progress) hipHostFree((void*)c->h_progress);
+    if (c->h_result) hipHostFree(c->h_result);
     if (c->h_stage) hipHostFree(c->h_stage);
-    hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
-    for (size_t i = 0; i < g_extras.size(); ++i)
-        if (g_extras[i].first == c) {
-            CtxExtra* ex = g_extras[i].second;
-            hipFree(ex->gx.d_runs); hipFree(ex->gx.d_prior_colblk); hipFree(ex->d_eval_params); hipFree(ex->d_eval_out); hipFree(ex->d_eval_edge);
-            hipHostFree(ex->h_eval);
-            delete ex;
-            g_extras.erase(g_extras.begin() + i);
-            break;
-        }
-    hipStreamDestroy(c->own_stream);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (CtxExtra* ex = extra_of(c)) {
+        if (ex->gx.d_runs) hipFree(ex->gx.d_runs);
+        if (ex->gx.d_prior_colblk) hipFree(ex->gx.d_prior_colblk);
+        if (ex->d_eval_params) hipFree(ex->d_eval_params);
+        if (ex->d_eval_out) hipFree(ex->d_eval_out);
+        if (ex->d_eval_edge) hipFree(ex->d_eval_edge);
+        if (ex->h_eval) hipHostFree(ex->h_eval);
+        delete ex;
+        c->extra = nullptr;
+    }
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }
 
@@ -222,7 +241,7 @@ int glio_set_correspondences(glio_ctx* c, int slot, const float* pts, const floa
     c->h_count[slot] = n;
     GLIO_HIP_CHECK(hipMemcpyAsync(c->d_count + slot, &c->h_count[slot], 4, hipMemcpyHostToDevice, c->stream));
     GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
-    c->have_factors = 1;
+    c->have_factors = 1; c->f32_dirty = 1;
     return GLIO_OK;
 }
 
@@ -259,7 +278,7 @@ int glio_associate_resident(glio_ctx* c, int slot, const double q[4], const doub
     if (!c || slot < 0 || slot >= c->W) return GLIO_E_ARG;
     GLIO_HIP_CHECK(hipSetDevice(c->device));
     const int rc = glio_assoc_run(c, slot, q, t, out_count);
-    if (rc == GLIO_OK) c->have_factors = 1;
+    if (rc == GLIO_OK) { c->have_factors = 1; c->f32_dirty = 1; }
     return rc;
 }
 // slide the window by one keyframe on the device: the resident scan of slot s+1 becomes that of slot s (slot W-1 is left for
@@ -279,13 +298,14 @@ int glio_slide_window(glio_ctx* c) {
 int glio_select_correspondences(glio_ctx* c, int slot, const int32_t* indices, int n) {
     if (!c || slot < 0 || slot >= c->W || n < 0 || (n > 0 && !indices)) return GLIO_E_ARG;
     GLIO_HIP_CHECK(hipSetDevice(c->device));
+    c->f32_dirty = 1;
     return glio_assoc_select(c, slot, indices, n);
 }
 int glio_associate_window(glio_ctx* c, const double* quats, const double* trans, int32_t* out_counts) {
     if (!c || !quats || !trans) return GLIO_E_ARG;
     GLIO_HIP_CHECK(hipSetDevice(c->device));
     const int rc = glio_assoc_run_window(c, quats, trans, out_counts);
-    if (rc == GLIO_OK) c->have_factors = 1;
+    if (rc == GLIO_OK) { c->have_factors = 1; c->f32_dirty = 1; }
     return rc;
 }
 int glio_associate(glio_ctx* c, int slot, const float* scan, int n, const double q[4], const double t[3], int* out_count) {
@@ -402,10 +422,15 @@ int glio_set_prior(glio_ctx* c, const glio_prior* p) {
     std::vector<int> index(15 * W, -1), colblk(np, -1);
     for (int b = 0; b < nb; ++b) {
         const int s = p->blk_slot[b], k = p->blk_kind[b], idx = p->blk_idx[b];
+        if (k != GLIO_BLK_TRANS && k != GLIO_BLK_QUAT && k != GLIO_BLK_SPEEDBIAS) { glio_set_error("prior block %d: unknown kind %d", b, k); return GLIO_E_ARG; }
         const int ls = k == GLIO_BLK_SPEEDBIAS ? 9 : 3;
         if (s < 0 || s >= W || idx < 0 || idx + ls > np) { glio_set_error("prior block out of range"); return GLIO_E_ARG; }
         const int off = 15 * s + (k == GLIO_BLK_TRANS ? 0 : (k == GLIO_BLK_QUAT ? 3 : 6));
-        for (int j = 0; j < ls; ++j) { index[off + j] = idx + j; colblk[idx + j] = b; }
+        for (int j = 0; j < ls; ++j) {
+            if (index[off + j] >= 0) { glio_set_error("prior: two blocks for slot %d kind %d", s, k); return GLIO_E_ARG; }
+            if (colblk[idx + j] >= 0) { glio_set_error("prior: blocks %d and %d overlap at column %d", colblk[idx + j], b, idx + j); return GLIO_E_ARG; }
+            index[off + j] = idx + j; colblk[idx + j] = b;
+        }
     }
     for (int j = 0; j < np; ++j) if (colblk[j] < 0) { glio_set_error("prior column %d not covered by a block", j); return GLIO_E_ARG; }
     { int nsb = 0; for (int b = 0; b < nb; ++b) nsb += p->blk_kind[b] == GLIO_BLK_SPEEDBIAS; c->arrow.prior_ok = nsb <= 1; }   // two speed-bias blocks would couple the chain densely
@@ -565,6 +590,12 @@ static int check_state(glio_ctx* c, const glio_state* s) {
     if (!c || !s || !s->trans || !s->quat || !s->speed_bias) { glio_set_error("null state"); return GLIO_E_ARG; }
     if (s->n_ddt < 0 || s->n_ddt > c->n_ddt_max || (s->n_ddt > 0 && !s->rcv_ddt)) { glio_set_error("n_ddt %d exceeds max_ddt_epochs %d", s->n_ddt, c->n_ddt_max); return GLIO_E_ARG; }
     if (!c->have_factors) { glio_set_error("no factors set"); return GLIO_E_STATE; }
+    // every Doppler epoch is an unknown of the problem: a state that carries fewer clock-drift slots than the factors
+    // reference would leave x[16 W + epoch] unset and drop that epoch's column from H (silently wrong)
+    if (c->n_dop > 0 && c->arrow.max_epoch >= s->n_ddt) {
+        glio_set_error("Doppler factors reference clock-drift epoch %d but the state carries n_ddt = %d", c->arrow.max_epoch, s->n_ddt);
+        return GLIO_E_ARG;
+    }
     return GLIO_OK;
 }
 static void pack_state(glio_ctx* c, const glio_state* s, double* h) {
@@ -903,6 +934,7 @@ int glio_time_kernel(glio_ctx* c, int which, int reps, float* ms_out) {
             if (which == GLIO_KERNEL_LIDAR_LINEARIZE) glio_launch_lidar_linearize(c, 0, 0);
             else if (which == GLIO_KERNEL_STREAM_READ) glio_launch_stream_read(c);
             else if (which == GLIO_KERNEL_FULL_LINEARIZE) enqueue_linearize(c, 0, 0, n_ddt);
+            else if (which == GLIO_KERNEL_LINEARIZE_ALL) glio_launch_linearize_all(c, 0, 0, n_ddt);
             else if (which == GLIO_KERNEL_TR_STEP) {
                 // one first-iteration step computation (scale, Cauchy, Cholesky, dogleg) on H[0]
                 SolverStatus st;

@@ -675,8 +675,11 @@ struct K3Args {
     const float4* pts; const float4* planes; const double* scores; const int* count; int cap;
     LidarConst lc; double* partials; int n_small, nb, skip_lo, skip_hi, n_k3;
 };
+template <bool F32>
 __global__ __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_linearize_all(const SmallArgs a, const K3Args k) {
     static_assert(SF_THREADS == GLIO_K3_THREADS, "one block size for both roles");
+    __shared__ __attribute__((aligned(16))) float k3f_tile[F32 ? (GLIO_K3_THREADS / GLIO_WAVE) * K3F_TILE_FLOATS : 4];
+    __shared__ double k3f_red[F32 ? (GLIO_K3_THREADS / GLIO_WAVE) * 72 : 1];
     if ((int)blockIdx.x < k.n_small) { small_factors_body(a); return; }
     int which = a.fixed_which;
     if (a.use_status) {
@@ -690,7 +693,8 @@ __global__ __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     b -= k.n_small + (b >= k.skip_hi ? k.skip_hi - k.skip_lo : 0);
     if (b >= k.n_k3) return;
     const int kf = b / k.nb, bx = b - kf * k.nb;
-    k3_body<2, false, true, true>(k.pts, k.planes, k.scores, k.count, k.cap, which ? a.x1 : a.x0, a.W, k.lc, k.partials, kf, bx, k.nb);
+    if (F32) k3_body_f32<true>(k.pts, k.planes, k.count, k.cap, which ? a.x1 : a.x0, a.W, k.lc, k.partials, kf, bx, k.nb, k3f_tile, k3f_red);
+    else k3_body<2, false, true, true>(k.pts, k.planes, k.scores, k.count, k.cap, which ? a.x1 : a.x0, a.W, k.lc, k.partials, kf, bx, k.nb);
 }
 
 // fixed-order sum of the K3 partials of keyframe blockIdx.x into its 28-double block (consumers that want the blocks
@@ -1029,10 +1033,24 @@ void glio_launch_linearize_all(glio_ctx* c, int use_status_cand, int which, int 
     int nb = (512 - (skip ? 2 : 1) * n_small) / c->W;
     if (nb < 4) nb = 4;
     if (nb > c->k3_bpk) nb = c->k3_bpk;
+    {   // large keyframes (C5: 262 144 residuals each) get more workgroups than fit at once -- about 4 k residuals per
+        // workgroup; the small-factor workgroups are first in dispatch order and still start with the launch
+        int maxn = 0;
+        for (int s2 = 0; s2 < c->W; ++s2) if (c->h_count[s2] > maxn) maxn = c->h_count[s2];
+        int want = (maxn + 4095) / 4096;
+        if (want > GLIO_K3_MAX_BLOCKS_PER_KF) want = GLIO_K3_MAX_BLOCKS_PER_KF;
+        if (want > nb) nb = want;
+    }
     k.nb = nb; k.n_k3 = c->W * nb;
     k.skip_lo = skip ? 256 : 0; k.skip_hi = skip ? 256 + n_small : 0;
     c->last_k3_nb = nb;
-    hipLaunchKernelGGL(k_linearize_all, dim3(n_small + k.n_k3 + (k.skip_hi - k.skip_lo)), dim3(SF_THREADS), 0, c->stream, a, k);
+    if (c->opts.lidar_precision == GLIO_LIDAR_F32_MFMA) {
+        glio_lidar_pack_f32(c);
+        k.pts = c->d_pts_s;
+        hipLaunchKernelGGL(k_linearize_all<true>, dim3(n_small + k.n_k3 + (k.skip_hi - k.skip_lo)), dim3(SF_THREADS), 0, c->stream, a, k);
+        return;
+    }
+    hipLaunchKernelGGL(k_linearize_all<false>, dim3(n_small + k.n_k3 + (k.skip_hi - k.skip_lo)), dim3(SF_THREADS), 0, c->stream, a, k);
 }
 
 void glio_launch_assemble(glio_ctx* c, int use_status_cand, int which, int n_ddt) {

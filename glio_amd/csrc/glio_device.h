@@ -106,6 +106,8 @@ struct glio_ctx {
     float4* d_pts;
     float4* d_planes;
     double* d_scores;
+    float4* d_pts_s;              // [W][cap] points with the score as a float in .w (opts.lidar_precision = GLIO_LIDAR_F32_MFMA only)
+    int f32_dirty;                // the correspondences changed since d_pts_s was packed
     int* d_count;                 // [W]
     int h_count[GLIO_MAX_WINDOW];
     // ---- scans + map (association)
@@ -169,6 +171,7 @@ struct glio_ctx {
     int last_k3_nb;               // partials per keyframe written by the most recent K3 (its consumers sum that many)
     int merged_linearize;         // K3 and the small factors in one launch (k_linearize_all)
     ArrowDev arrow;
+    void* extra;                  // CtxExtra (capi.hip): evaluator scratch, GNSS run tables -- owned by the context
 };
 
 static inline int glio_x_size(int W, int n_ddt) { return 16 * W + n_ddt; }
@@ -263,6 +266,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 // ------------------------------------------------------------------------------------------------
 // lidar_kernels.hip
 void glio_launch_lidar_linearize(glio_ctx* c, int use_status_cand, int which, int marg = 0);
+void glio_lidar_pack_f32(glio_ctx* c);                      // no-op unless the f32 form is selected and the correspondences changed
 // factor_kernels.hip
 void glio_launch_small_factors(glio_ctx* c, int use_status_cand, int which, int n_ddt, int marg = 0);
 void glio_launch_linearize_all(glio_ctx* c, int use_status_cand, int which, int n_ddt);   // K3 + small factors, one launch

@@ -204,5 +204,130 @@ __device__ __forceinline__ void k3_body(
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// K3, fp32-Jacobian form with the J^T J contraction on the matrix core (BASELINE config C5; opts.lidar_precision =
+// GLIO_LIDAR_F32_MFMA).  32 B per residual: float4 point with the SCORE as a float in .w (k_pack_points_f32) + float4
+// plane.  Per residual the error e = n^.(M c + t) + d^ is still formed in double (world coordinates are ~100 m: a float
+// there costs ~1e-5 m, the size of the answers the gate is stated in), the 1x6 Jacobian and the loss weights in float.
+// A wavefront takes 64 consecutive residuals, writes the weighted row  a = sqrt(rho') [J0..J5, r, 0]  of each into an
+// LDS tile [8 columns][64 residuals] and reads it back transposed into the operand layout of v_mfma_f32_16x16x4_f32:
+//   A[i][k] = lane (i + 16 k), B[k][j] = lane (j + 16 k)  ->  for A^T A both operands are the SAME register,
+//   lane l = (column c = l & 7, residual group grp = (l >> 3) & 1, k = l >> 4): columns 0-7 of the 16 carry one set of
+//   four residuals, columns 8-15 another, so one instruction contracts 8 residuals and the two 8x8 diagonal blocks of
+//   the 16x16 result are two partial sums of [J^T J | J^T r] (the off-diagonal blocks are cross terms, discarded).
+// Eight instructions per chunk on two interleaved accumulators (the dependent latency is 40 cycles, the issue interval
+// 32); after every chunk the float accumulators (16 terms each) are added into double ones, so the float rounding does not
+// grow with the number of residuals.  The cost rho/2 is summed in double on the vector ALU.
+// The partial that leaves the workgroup has the same 28-double layout as the fp64 kernel's: the consumers do not change.
+// ------------------------------------------------------------------------------------------------
+typedef float k3_v4f32 __attribute__((ext_vector_type(4)));
+#define K3F_TILE_FLOATS 512     /* 8 columns x 64 residuals per wavefront */
+
+template <bool NT>
+__device__ __forceinline__ void k3_body_f32(
+    const float4* __restrict__ pts_s, const float4* __restrict__ planes, const int* __restrict__ count, const int cap,
+    const double* __restrict__ x, const int W, const LidarConst& lc, double* __restrict__ partials, const int kf, const int bx, const int nb,
+    float* tile /* [waves][K3F_TILE_FLOATS] */, double* red /* [waves][72] */) {
+    const int n = count[kf];
+    double q[4], R[9], M[9], t[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t[k] = x[3 * kf + k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = x[3 * W + 4 * kf + k];
+    d_q2R(q, R);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            M[i * 3 + j] = R[i * 3 + 0] * lc.RlbT[0 * 3 + j] + R[i * 3 + 1] * lc.RlbT[1 * 3 + j] + R[i * 3 + 2] * lc.RlbT[2 * 3 + j];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* T = tile + wv * K3F_TILE_FLOATS;
+    const int nwaves = nb * (GLIO_K3_THREADS / GLIO_WAVE), wid = bx * (GLIO_K3_THREADS / GLIO_WAVE) + wv;
+    const int nchunks = (n + 63) >> 6;
+    const size_t base = (size_t)kf * cap;
+    const float4* __restrict__ P = pts_s + base;
+    const float4* __restrict__ Q = planes + base;
+    // operand role of this lane: column c7 of the residuals 8 seg .. 8 seg + 7 of the chunk (seg = 2 k + grp)
+    const int c7 = lane & 7, seg = ((lane >> 4) << 1) | ((lane >> 3) & 1);
+    const float* rd = T + c7 * 64 + seg * 8;
+    T[7 * 64 + lane] = 0.0f;                               // padding column, never rewritten
+    double acc64[4] = {0.0, 0.0, 0.0, 0.0};
+    double cost = 0.0;
+    const double a = lc.huber;
+    const float af = (float)a;
+    int ch = wid;
+    bool have = ch < nchunks;
+    float4 p = make_float4(0, 0, 0, 0), pl = p;
+    if (have) { const int i0 = min(ch * 64 + lane, n - 1); p = k3_load4<NT>(P + i0); pl = k3_load4<NT>(Q + i0); }
+    while (have) {
+        const int chn = ch + nwaves;
+        const bool more = chn < nchunks;
+        float4 p2 = p, pl2 = pl;
+        if (more) { const int i1 = min(chn * 64 + lane, n - 1); p2 = k3_load4<NT>(P + i1); pl2 = k3_load4<NT>(Q + i1); }   // next chunk in flight during the arithmetic
+        const bool live = ch * 64 + lane < n;
+        // ---- residual in double
+        const double cx = (double)p.x - lc.tlb[0], cy = (double)p.y - lc.tlb[1], cz = (double)p.z - lc.tlb[2];
+        const double rx = M[0] * cx + M[1] * cy + M[2] * cz;
+        const double ry = M[3] * cx + M[4] * cy + M[5] * cz;
+        const double rz = M[6] * cx + M[7] * cy + M[8] * cz;
+        const double e = (double)pl.x * (rx + t[0]) + (double)pl.y * (ry + t[1]) + (double)pl.z * (rz + t[2]) + (double)pl.w;
+        const double r = (double)p.w * e;
+        const double ar = fabs(r);
+        const bool inl = ar <= a;
+        const double rho = inl ? r * r : 2.0 * a * ar - a * a;
+        cost += live ? 0.5 * rho : 0.0;
+        // ---- Jacobian and loss weight in float
+        const float sf = p.w, s2 = 2.0f * sf;
+        const float rxf = (float)rx, ryf = (float)ry, rzf = (float)rz, rf = (float)r, arf = (float)ar;
+        float sw = inl ? 1.0f : __builtin_amdgcn_sqrtf(af * __builtin_amdgcn_rcpf(arf));        // sqrt(rho')
+        sw = live ? sw : 0.0f;
+        const float ws = sw * sf, ws2 = sw * s2;
+        T[0 * 64 + lane] = ws * pl.x;
+        T[1 * 64 + lane] = ws * pl.y;
+        T[2 * 64 + lane] = ws * pl.z;
+        T[3 * 64 + lane] = ws2 * (ryf * pl.z - rzf * pl.y);
+        T[4 * 64 + lane] = ws2 * (rzf * pl.x - rxf * pl.z);
+        T[5 * 64 + lane] = ws2 * (rxf * pl.y - ryf * pl.x);
+        T[6 * 64 + lane] = sw * rf;
+        GLIO_WAVE_LDS_SYNC();
+        const k3_v4f32 a0 = *reinterpret_cast<const k3_v4f32*>(rd), a1 = *reinterpret_cast<const k3_v4f32*>(rd + 4);
+        k3_v4f32 c0 = {0.0f, 0.0f, 0.0f, 0.0f}, c1 = {0.0f, 0.0f, 0.0f, 0.0f};
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, a0.x, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, a0.y, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, a0.z, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, a0.w, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, a1.x, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, a1.y, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, a1.z, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, a1.w, c1, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc64[k] += (double)c0[k] + (double)c1[k];
+        GLIO_WAVE_LDS_SYNC();                              // the tile is in registers: the next chunk may overwrite it
+        ch = chn; p = p2; pl = pl2; have = more;
+    }
+    // ---- C layout: lane l, register k -> row 4 (l >> 4) + k, column l & 15.  Block 0 = rows, columns 0..7 (lanes with
+    // l >> 4 < 2, l & 15 < 8), block 1 = rows, columns 8..15 = the same entries 40 lanes further on.
+    double* myred = red + wv * 72;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double other = __shfl(acc64[k], (lane + 40) & 63, 64);
+        if ((lane >> 4) < 2 && (lane & 15) < 8) myred[(4 * (lane >> 4) + k) * 8 + (lane & 7)] = acc64[k] + other;
+    }
+    cost = wave_sum(cost);
+    if (lane == 0) myred[64] = cost;
+    __syncthreads();
+    if (threadIdx.x < GLIO_LIDAR_ACC) {
+        // packed upper triangle (i <= j < 6) -> (i, j); 21..26 -> row 6 (J^T r); 27 -> cost
+        const int ti[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
+        const int tj[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
+        const int k = threadIdx.x;
+        const int idx = k < 21 ? ti[k] * 8 + tj[k] : (k < 27 ? 6 * 8 + (k - 21) : 64);
+        double v = red[idx];
+#pragma unroll
+        for (int w2 = 1; w2 < GLIO_K3_THREADS / GLIO_WAVE; ++w2) v += red[w2 * 72 + idx];
+        partials[((size_t)kf * nb + bx) * GLIO_LIDAR_ACC + k] = v;
+    }
+}
+
 // host side: R(q_lb)^T, t_lb, Huber width of the context
 LidarConst glio_lidar_const(const glio_ctx* c);

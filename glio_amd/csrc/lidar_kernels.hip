@@ -120,6 +120,61 @@ __global__ __launch_bounds__(GLIO_K3_THREADS) void k_lidar_linearize_dma(
     k3_reduce_store(acc, partials, kf, blockIdx.x, nb);
 }
 
+// ------------------------------------------------------------------------------------------------
+// K3, fp32-Jacobian / MFMA form (k3_body_f32 in k3_device.h) as its own launch, and the packing of its 32 B/residual
+// input: point.w <- (float) score.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GLIO_K3_THREADS) void k_lidar_linearize_f32(
+    const float4* __restrict__ pts_s, const float4* __restrict__ planes, const int* __restrict__ count, const int cap,
+    const double* __restrict__ x0, const double* __restrict__ x1, const SolverStatus* __restrict__ st, const int use_status,
+    const int fixed_which, const int W, const LidarConst lc, double* __restrict__ partials) {
+    __shared__ __attribute__((aligned(16))) float tile[(GLIO_K3_THREADS / GLIO_WAVE) * K3F_TILE_FLOATS];
+    __shared__ double red[(GLIO_K3_THREADS / GLIO_WAVE) * 72];
+    int which = fixed_which;
+    if (use_status) {
+        if (st->done || !st->cand_pending) return;
+        which = 1 - st->cur;
+    }
+    k3_body_f32<true>(pts_s, planes, count, cap, which ? x1 : x0, W, lc, partials, blockIdx.y, blockIdx.x, gridDim.x, tile, red);
+}
+__global__ __launch_bounds__(256) void k_pack_points_f32(const float4* __restrict__ pts, const double* __restrict__ scores,
+                                                         const int* __restrict__ count, const int cap, float4* __restrict__ out) {
+    const int kf = blockIdx.y, n = count[kf];
+    const size_t base = (size_t)kf * cap;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float4 p = pts[base + i];
+        p.w = (float)scores[base + i];
+        out[base + i] = p;
+    }
+}
+// (re)build the packed points when the correspondences changed since the last linearisation
+void glio_lidar_pack_f32(glio_ctx* c) {
+    if (c->opts.lidar_precision != GLIO_LIDAR_F32_MFMA || !c->f32_dirty) return;
+    int blocks = (c->cap + 255) / 256;
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(k_pack_points_f32, dim3(blocks, c->W), dim3(256), 0, c->stream, c->d_pts, c->d_scores, c->d_count, c->cap, c->d_pts_s);
+    c->f32_dirty = 0;
+}
+// read-only ceiling of the 32 B/residual stream (same grid as the f32 kernel)
+__global__ __launch_bounds__(GLIO_K3_THREADS) void k_stream_read32(const float4* __restrict__ pts, const float4* __restrict__ planes,
+                                                                   const int* __restrict__ count, const int cap, double* __restrict__ out) {
+    const int kf = blockIdx.y, n = count[kf];
+    const size_t base = (size_t)kf * cap;
+    const int stride = gridDim.x * GLIO_K3_THREADS;
+    float acc = 0.0f;
+    int i = blockIdx.x * GLIO_K3_THREADS + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        float4 p[4], q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { p[u] = k3_load4<true>(pts + base + i + u * stride); q[u] = k3_load4<true>(planes + base + i + u * stride); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += (p[u].x + p[u].y + p[u].z + p[u].w) + (q[u].x + q[u].y + q[u].z + q[u].w);
+    }
+    for (; i < n; i += stride) { const float4 p = pts[base + i], q = planes[base + i]; acc += (p.x + p.y + p.z + p.w) + (q.x + q.y + q.z + q.w); }
+    double a = wave_sum((double)acc);
+    if ((threadIdx.x & 63) == 0) out[((size_t)kf * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)] = a;
+}
+
 // Practical ceiling for K3: the same three streams (16 + 16 + 8 B per residual), same grid, same non-temporal loads,
 // but only a trivial sum -- what the memory system delivers for a launch of this size (bench.py reports it next to K3).
 __global__ __launch_bounds__(GLIO_K3_THREADS) void k_stream_read(const float4* __restrict__ pts, const float4* __restrict__ planes,
@@ -142,6 +197,11 @@ __global__ __launch_bounds__(GLIO_K3_THREADS) void k_stream_read(const float4* _
     if ((threadIdx.x & 63) == 0) out[((size_t)kf * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)] = acc;
 }
 void glio_launch_stream_read(glio_ctx* c) {
+    if (c->opts.lidar_precision == GLIO_LIDAR_F32_MFMA) {
+        hipLaunchKernelGGL(k_stream_read32, dim3(c->k3_bpk, c->W), dim3(GLIO_K3_THREADS), 0, c->stream, c->d_pts_s, c->d_planes, c->d_count,
+                           c->cap, c->d_lidar_partials);
+        return;
+    }
     hipLaunchKernelGGL(k_stream_read, dim3(c->k3_bpk, c->W), dim3(GLIO_K3_THREADS), 0, c->stream, c->d_pts, c->d_planes, c->d_scores, c->d_count,
                        c->cap, c->d_lidar_partials);
 }
@@ -169,7 +229,13 @@ void glio_launch_lidar_linearize(glio_ctx* c, int use_status_cand, int which, in
 #define K3_LAUNCH_(U, MG, ...) hipLaunchKernelGGL((k_lidar_linearize<U, MG, ##__VA_ARGS__>), grid, dim3(GLIO_K3_THREADS), 0, c->stream, \
                        c->d_pts, c->d_planes, c->d_scores, c->d_count, c->cap, c->d_x[0], c->d_x[1], \
                        c->d_status, use_status_cand, which, c->W, lc, c->d_lidar_partials)
-    if (marg) { K3_LAUNCH_(4, true); return; }
+    if (marg) { K3_LAUNCH_(4, true); return; }          // the marginalization keeps the fp64 form (its Jacobian convention differs, Q8)
+    if (c->opts.lidar_precision == GLIO_LIDAR_F32_MFMA) {
+        glio_lidar_pack_f32(c);
+        hipLaunchKernelGGL(k_lidar_linearize_f32, grid, dim3(GLIO_K3_THREADS), 0, c->stream, c->d_pts_s, c->d_planes, c->d_count, c->cap,
+                           c->d_x[0], c->d_x[1], c->d_status, use_status_cand, which, c->W, lc, c->d_lidar_partials);
+        return;
+    }
 #define K3_DMA_(...) hipLaunchKernelGGL((k_lidar_linearize_dma<__VA_ARGS__>), grid, dim3(GLIO_K3_THREADS), 0, c->stream, \
                        c->d_pts, c->d_planes, c->d_scores, c->d_count, c->cap, c->d_x[0], c->d_x[1], \
                        c->d_status, use_status_cand, which, c->W, lc, c->d_lidar_partials)

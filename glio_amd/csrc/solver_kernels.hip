@@ -648,16 +648,11 @@ __device__ __forceinline__ void tr_factor_body(const TrArgs& a) {
     }
     __syncthreads();
     if (tid == 0) {
-        if (solved) { a.status->mu_used = *smu; if (!a.lm) a.status->mu = fmax(1e-8, 2.0 * (*smu) / 10.0); a.status->lin_fail = 0; }
-        else if (a.lm) { a.status->lin_fail = 1; }       // invalid step: k_tr_dogleg shrinks the radius
-        else { a.status->mu = *smu; a.status->done = 1; a.status->termination = GLIO_TERM_FAILURE; }
-    }
-    if (!solved && !a.lm) {          // linear solver failure: publish the current point as the result
-        const double* xc = a.status->cur ? a.x1 : a.x0;
-        for (int k = tid; k < 16 * a.W + a.n_ddt; k += TR_THREADS) { const double v = xc[k]; a.xout[k] = v; a.xout_host[k] = v; }
-        __threadfence_system();
-        __syncthreads();
-        if (tid == 0) { *a.status_host = *a.status; __threadfence_system(); a.progress[1] = a.status->solve_id; __threadfence_system(); }
+        // Ceres 1.14 DoglegStrategy::ComputeGaussNewtonStep only RAISES mu (the next solve starts from the last successful
+        // value; StepAccepted lowers it).  If every mu < max_mu failed, the strategy reports LINEAR_SOLVER_FAILURE and the
+        // minimizer counts an invalid step (tr_dogleg_body: StepIsInvalid, five in a row end the solve with FAILURE).
+        if (solved) { a.status->mu_used = *smu; if (!a.lm) a.status->mu = *smu; a.status->lin_fail = 0; }
+        else { if (!a.lm) a.status->mu = *smu; a.status->lin_fail = 1; }
     }
 }
 
@@ -711,14 +706,15 @@ __device__ __forceinline__ void tr_dogleg_body(const TrArgs& a) {
     sn2 = block_sum(sn2, red); lin = block_sum(lin, red); quad = block_sum(quad, red);
     if (snorm < 0) snorm = sqrt(sn2);
     const double mcc = -(lin + 0.5 * quad);
-    const bool valid = mcc > 0.0 && !(a.lm && s.lin_fail);
+    const bool valid = mcc > 0.0 && !s.lin_fail;
     if (tid == 0) {
         s.dogleg_step_norm = snorm;
         if (!valid) {
             s.invalid += 1;
             if (s.invalid >= 5) { s.done = 1; s.termination = GLIO_TERM_FAILURE; }
-            if (a.lm) { s.radius /= s.decrease_factor; s.decrease_factor *= 2.0; s.lin_fail = 0; }
+            if (a.lm) { s.radius /= s.decrease_factor; s.decrease_factor *= 2.0; }
             else s.mu *= 10.0;
+            s.lin_fail = 0;
             s.reuse = 0;                        // StepIsInvalid: consumes an iteration, no candidate
             s.cand_pending = 0;
         } else {

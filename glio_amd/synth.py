@@ -331,7 +331,7 @@ def default_opts(W=5, pts=65536, map_pts=1 << 21, n_ddt=0):
 
 
 def make_window(W=5, pts_per_scan=2048, seed=SEED_BASE, with_gnss=False, with_prior=False, kf_dt=0.4,
-                map_density=12.0, scan_radius=60.0, scene=None, perturb=(0.10, 0.5, 0.1), imu_rate=100.0):
+                map_density=12.0, scan_radius=60.0, scene=None, perturb=(0.10, 0.5, 0.1), imu_rate=100.0, gnss_epoch_dt=0.1):
     rng_state = np.random.default_rng(seed + 2)
     scene = scene or make_scene(seed=seed)
     traj = Trajectory()
@@ -393,7 +393,7 @@ def make_window(W=5, pts_per_scan=2048, seed=SEED_BASE, with_gnss=False, with_pr
         win.preints.append(preintegrate(acc, gyr, np.full(n, 1.0 / imu_rate), np.zeros(3), np.zeros(3)))
 
     if with_gnss:
-        n_ddt = _make_gnss(win, traj, seed)
+        n_ddt = _make_gnss(win, traj, seed, epoch_dt=gnss_epoch_dt)
     if with_prior:
         win.prior = make_synthetic_prior(win, seed)
     gt.n_ddt = init.n_ddt = n_ddt
@@ -404,6 +404,23 @@ def make_window(W=5, pts_per_scan=2048, seed=SEED_BASE, with_gnss=False, with_pr
         init.rcv_ddt[:n_ddt] = 0.0
     win.opts = default_opts(W, pts=max(pts_per_scan, 64), map_pts=max(len(map_pts), 64), n_ddt=n_ddt)
     return win
+
+
+def tiled_map(map_pts, tiles, pitch=40.0):
+    """BASELINE config C3 ("131k-pt raw scan against a map of 10^6-scale points"): the reference's map is voxel-filtered at
+    0.4 m (Estimator.cpp:854,3620), so a map of that size is a map of large EXTENT, not of higher density.  The street's
+    local map is replicated `tiles` times at a lateral pitch (parallel streets, further apart than the 1.22 m search
+    radius, so they never contribute a neighbour): per-query candidate density as in the reference, hash table and point
+    array tiles-times larger.  Tile 0 is the original (the scan's street); the tiles are interleaved point by point so that
+    the original points are spread over the whole index range."""
+    mp = np.asarray(map_pts, np.float32)
+    out = np.empty((len(mp) * tiles, 4), np.float32)
+    for k in range(tiles):
+        sh = mp.copy()
+        side = (k + 1) // 2 * (1 if k % 2 else -1)          # 0, +1, -1, +2, -2, ...
+        sh[:, 1] += np.float32(pitch * side)
+        out[k::tiles] = sh
+    return np.ascontiguousarray(out)
 
 
 def sub_window(long, lo, W):

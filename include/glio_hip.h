@@ -158,7 +158,8 @@ int glio_eval_binary_plane(glio_ctx* ctx, const float cp[4], const double norm_c
  * context's stream; returns average milliseconds per launch in *ms_out. */
 enum { GLIO_KERNEL_LIDAR_LINEARIZE = 0, GLIO_KERNEL_FULL_LINEARIZE = 1, GLIO_KERNEL_TR_STEP = 2,
        GLIO_KERNEL_ASSOCIATE = 3, GLIO_KERNEL_MAP_BUILD = 4, GLIO_KERNEL_MARGINALIZE = 5,
-       GLIO_KERNEL_STREAM_READ = 6 /* same bytes as LIDAR_LINEARIZE, no arithmetic: the practical ceiling */ };
+       GLIO_KERNEL_STREAM_READ = 6 /* same bytes as LIDAR_LINEARIZE, no arithmetic: the practical ceiling */,
+       GLIO_KERNEL_LINEARIZE_ALL = 7 /* the launch glio_solve uses: K3 workgroups beside the small-factor workgroups */ };
 int glio_time_kernel(glio_ctx* ctx, int which, int reps, float* ms_out);
 /* time `reps` complete solves from the same initial state with HIP events (state is not modified) */
 int glio_time_solve(glio_ctx* ctx, const glio_state* state, int reps, float* ms_out, glio_summary* last);

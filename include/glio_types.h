@@ -61,7 +61,15 @@ typedef struct glio_opts {
     /* 0 = vec_surf_scores = lidar_const * weight (Estimator.cpp:3692); 1 = unit scores: the front end's
      * LidarPlaneNormIncreFactor carries no score (LidarKeyframeFactor.h:222-257) */
     int32_t unit_scores;
+    /* arithmetic of the LiDAR plane linearisation (K3).  GLIO_LIDAR_F64 (default): everything in double, 40 B per residual
+     * (the reference's Jet<double,7> evaluation).  GLIO_LIDAR_F32_MFMA (BASELINE config C5, the W = 50 x 256 k stress
+     * shape): the score travels as a float in the point's 4th component (32 B per residual), the residual is still
+     * formed in double, the 1x6 Jacobian in float, and the per-keyframe J^T J / J^T r contraction of each 64-residual
+     * chunk runs on the matrix core (v_mfma_f32_16x16x4_f32) with double accumulation across chunks. */
+    int32_t lidar_precision;
+    int32_t reserved_;
 } glio_opts;
+enum { GLIO_LIDAR_F64 = 0, GLIO_LIDAR_F32_MFMA = 1 };
 
 /* Window state = the Ceres parameter blocks of the sliding-window problem.
  * Reference: tmpTrans/tmpQuat/tmpSpeedBias (Estimator.cpp:345-348), para_rcv_ddt (:309).

@@ -77,6 +77,9 @@ int orc_local_dim(const orc_problem* p, const glio_state* x);
 /* One linearisation: dense H = J^T J (n x n row-major), g = J^T r, cost = 1/2 sum rho(|r|^2),
  * all AFTER loss correction and local parameterisation, unscaled.  Any of H,g may be NULL. */
 int orc_linearize(const orc_problem* p, const glio_state* x, double* H, double* g, double* cost);
+/* bench.py's all-cores CPU baseline: OpenMP threads over the keyframes of the LiDAR factor loop (default 1 = the reference's
+ * options.num_threads = 1; parity tests never change it) */
+void orc_set_threads(int t);
 /* Ceres-1.14 trust-region (traditional dogleg, dense normal Cholesky, Jacobi scaling) */
 int orc_solve(const orc_problem* p, glio_state* x, glio_summary* summary);
 
@@ -86,6 +89,10 @@ int orc_associate(const glio_opts* o, const float* map_pts /*[M][4]*/, int M,
                   const float* scan /*[n][4]*/, int n, const double q[4], const double t[3],
                   float* out_pts /*[n][4]*/, float* out_planes /*[n][4]*/, double* out_scores,
                   int32_t* out_src_index /* may be NULL */, int32_t* out_nn /* [n][5] may be NULL */);
+/* identical output; the brute-force nearest-neighbour phase runs on `threads` OpenMP threads (full-size parity checks) */
+int orc_associate_mt(const glio_opts* o, const float* map_pts, int M, const float* scan, int n, const double q[4],
+                     const double t[3], float* out_pts, float* out_planes, double* out_scores,
+                     int32_t* out_src_index, int32_t* out_nn, int threads);
 /* colPivHouseholderQr().solve for the 5x3 system A n = b  (Estimator.cpp:3661) */
 void orc_plane_qr_solve(const double A[15], const double b[5], double x[3]);
 

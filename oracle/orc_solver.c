@@ -132,6 +132,39 @@ static void accumulate(const rblock* b, int use_loss, double loss_a, int n, doub
     free(Jl);
 }
 
+/* threads of the all-cores baseline variant (1 = the reference's options.num_threads = 1, Estimator.cpp:2426: the parity path) */
+static int g_orc_threads = 1;
+void orc_set_threads(int t) { g_orc_threads = t < 1 ? 1 : t; }
+
+/* the LidarPlaneNormFactor blocks of keyframe s (Estimator.cpp:2226-2242), cost added residual by residual into *cost */
+static void lidar_keyframe(const orc_problem* p, const glio_state* x, int s, int n, double* H, double* g, double* cost, int want_J) {
+    const double* P[2] = {x->trans + 3 * s, x->quat + 4 * s};
+    double Pq[12];
+    quat_plus_jacobian(P[1], Pq);
+    for (int i = p->lidar_offset[s]; i < p->lidar_offset[s + 1]; ++i) {
+        double r, Jt[3], Jq[4];
+        double* J[2] = {Jt, Jq};
+        orc_eval_lidar_plane(&p->opts, p->lidar_pts + 4 * (size_t)i, p->lidar_planes + 4 * (size_t)i,
+                             p->lidar_scores[i], P, &r, want_J ? J : NULL);
+        /* scalar residual: Huber has rho'' <= 0 so the corrector reduces to sqrt(rho') scaling */
+        double rho[3];
+        huber(p->opts.huber_delta, r * r, rho);
+        *cost += 0.5 * rho[0];
+        if (!want_J) continue;
+        const double sr = sqrt(rho[1]);
+        double Jl[6];
+        for (int k = 0; k < 3; ++k) Jl[k] = sr * Jt[k];
+        for (int k = 0; k < 3; ++k)
+            Jl[3 + k] = sr * (Jq[0] * Pq[k] + Jq[1] * Pq[3 + k] + Jq[2] * Pq[6 + k] + Jq[3] * Pq[9 + k]);
+        const double rc = sr * r;
+        const int o = 15 * s;
+        for (int a = 0; a < 6; ++a) {
+            if (g) g[o + a] += Jl[a] * rc;
+            if (H) for (int bb = 0; bb < 6; ++bb) H[(size_t)(o + a) * n + o + bb] += Jl[a] * Jl[bb];
+        }
+    }
+}
+
 int orc_linearize(const orc_problem* p, const glio_state* x, double* H, double* g, double* cost_out) {
     const int W = p->opts.window;
     const int n = 15 * W + x->n_ddt;
@@ -216,32 +249,16 @@ int orc_linearize(const orc_problem* p, const glio_state* x, double* H, double* 
     }
 
     /* 3. LiDAR plane factors with HuberLoss(lossKernel) (Estimator.cpp:2198-2248) */
-    for (int s = 0; s < W; ++s) {
-        const double* P[2] = {x->trans + 3 * s, x->quat + 4 * s};
-        double Pq[12];
-        quat_plus_jacobian(P[1], Pq);
-        for (int i = p->lidar_offset[s]; i < p->lidar_offset[s + 1]; ++i) {
-            double r, Jt[3], Jq[4];
-            double* J[2] = {Jt, Jq};
-            orc_eval_lidar_plane(&p->opts, p->lidar_pts + 4 * (size_t)i, p->lidar_planes + 4 * (size_t)i,
-                                 p->lidar_scores[i], P, &r, want_J ? J : NULL);
-            /* scalar residual: Huber has rho'' <= 0 so the corrector reduces to sqrt(rho') scaling */
-            double rho[3];
-            huber(p->opts.huber_delta, r * r, rho);
-            cost += 0.5 * rho[0];
-            if (!want_J) continue;
-            const double sr = sqrt(rho[1]);
-            double Jl[6];
-            for (int k = 0; k < 3; ++k) Jl[k] = sr * Jt[k];
-            for (int k = 0; k < 3; ++k)
-                Jl[3 + k] = sr * (Jq[0] * Pq[k] + Jq[1] * Pq[3 + k] + Jq[2] * Pq[6 + k] + Jq[3] * Pq[9 + k]);
-            const double rc = sr * r;
-            const int o = 15 * s;
-            for (int a = 0; a < 6; ++a) {
-                if (g) g[o + a] += Jl[a] * rc;
-                if (H) for (int bb = 0; bb < 6; ++bb) H[(size_t)(o + a) * n + o + bb] += Jl[a] * Jl[bb];
-            }
-        }
+    if (g_orc_threads > 1) {
+        /* all-cores CPU baseline (bench.py): keyframes are independent (disjoint blocks of H and g); the per-keyframe
+         * costs are added in keyframe order afterwards.  Not the parity path: the cost's summation order differs. */
+        double* cs = (double*)calloc((size_t)W, sizeof(double));
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_orc_threads)
+        for (int s = 0; s < W; ++s) lidar_keyframe(p, x, s, n, H, g, &cs[s], want_J);
+        for (int s = 0; s < W; ++s) cost += cs[s];
+        free(cs);
+    } else {
+        for (int s = 0; s < W; ++s) lidar_keyframe(p, x, s, n, H, g, &cost, want_J);
     }
 
     /* 4. Doppler factors with HuberLoss(1.0) (Estimator.cpp:2329-2337) */
@@ -341,7 +358,7 @@ int orc_solve(const orc_problem* p, glio_state* x, glio_summary* sum) {
     double decrease_factor = 2.0;        /* LevenbergMarquardtStrategy::decrease_factor_ */
     dl.diag = (double*)malloc(sizeof(double) * n);
     dl.grad = (double*)malloc(sizeof(double) * n);
-    dl.gn = (double*)malloc(sizeof(double) * n);
+    dl.gn = (double*)calloc(n, sizeof(double));
     glio_state cand;
     state_alloc(&cand, W, x->n_ddt);
 
@@ -409,9 +426,11 @@ int orc_solve(const orc_problem* p, glio_state* x, glio_summary* sum) {
                 }
                 dl.mu *= 10.0;
             }
-            if (!solved) { sum->termination = GLIO_TERM_FAILURE; break; }
-            dl.mu = fmax(1e-8, 2.0 * dl.mu / 10.0);
-            for (int i = 0; i < n; ++i) dl.gn[i] = -dl.diag[i] * tmp[i];
+            /* Ceres 1.14 DoglegStrategy::ComputeGaussNewtonStep: mu is only RAISED here ("next time ... the multiplier starts
+             * out from the last successful solve"); it is lowered in StepAccepted alone.  When every mu < max_mu fails the
+             * strategy returns LINEAR_SOLVER_FAILURE and the minimizer counts an invalid step (HandleInvalidStep). */
+            if (!solved) step_valid = 0;
+            else for (int i = 0; i < n; ++i) dl.gn[i] = -dl.diag[i] * tmp[i];
         }
         if (!lm) {   /* ComputeTraditionalDoglegStep */
             const double gnorm = sqrt(vdot(dl.grad, dl.grad, n));

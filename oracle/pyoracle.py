@@ -43,6 +43,12 @@ def lib():
     return _lib
 
 
+def set_threads(t):
+    """OpenMP threads of the LiDAR factor loop (bench.py's all-cores baseline; 1 = parity path)."""
+    lib().orc_set_threads.restype = None
+    lib().orc_set_threads(int(t))
+
+
 def _pp(arrs):
     """double const* const* from a list of numpy arrays (or None)."""
     P = (T.c_double_p * len(arrs))()
@@ -118,7 +124,8 @@ class Problem:
         return out
 
 
-def associate(opts, map_pts, scan, q, t, want_nn=False):
+def associate(opts, map_pts, scan, q, t, want_nn=False, threads=1):
+    """threads > 1: the brute-force nearest-neighbour phase on that many OpenMP threads (identical output)."""
     n = len(scan)
     pts = np.zeros((n, 4), np.float32)
     planes = np.zeros((n, 4), np.float32)
@@ -127,8 +134,9 @@ def associate(opts, map_pts, scan, q, t, want_nn=False):
     nn = np.zeros((n, 5), np.int32) if want_nn else None
     q = np.ascontiguousarray(q, float)
     t = np.ascontiguousarray(t, float)
-    cnt = lib().orc_associate(C.byref(opts), T.fptr(map_pts), len(map_pts), T.fptr(scan), n, T.dptr(q), T.dptr(t),
-                              T.fptr(pts), T.fptr(planes), T.dptr(scores), T.iptr(src), T.iptr(nn) if want_nn else None)
+    lib().orc_associate_mt.restype = C.c_int
+    cnt = lib().orc_associate_mt(C.byref(opts), T.fptr(map_pts), len(map_pts), T.fptr(scan), n, T.dptr(q), T.dptr(t),
+                                 T.fptr(pts), T.fptr(planes), T.dptr(scores), T.iptr(src), T.iptr(nn) if want_nn else None, int(threads))
     res = (pts[:cnt].copy(), planes[:cnt].copy(), scores[:cnt].copy(), src[:cnt].copy())
     return res + ((nn,) if want_nn else ())
 

@@ -1,0 +1,142 @@
+"""Soak and concurrency tests of the device-resident solver (the class of defect DESIGN.md calls the "coherence trap":
+results that depend on what ran before).
+
+* 300 back-to-back solves of one window on a reused context, and solves on a stream of fresh contexts, must be bit-identical
+  (state, iteration count, costs) -- also with every CU's LDS NaN-poisoned before each kernel group and every context
+  allocation filled with NaN bytes (GLIO_DEBUG_LDS_POISON / GLIO_DEBUG_FILL are read when the library loads, so that part
+  runs in a child process).
+* The reference drives the sliding-window problem and the batch problem from two threads at once
+  (GLIO/src/Estimator.cpp:5398-5404, no lock at :2751): a sliding-window context and a batch context hammered from two
+  threads, with a third creating and destroying contexts, must each produce what they produce alone."""
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from glio_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _window():
+    stream = synth.make_window(W=9, pts_per_scan=3000, with_gnss=True, with_prior=False, seed=synth.SEED_BASE + 41)
+    return stream
+
+
+def _digest(sol, summ):
+    return (sol.trans.tobytes(), sol.quat.tobytes(), sol.speed_bias.tobytes(), sol.rcv_ddt.tobytes(), int(summ.iterations),
+            int(summ.termination), float(summ.final_cost), float(summ.initial_cost))
+
+
+_SOAK_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from glio_amd import capi, synth
+from test_hip_soak import _window, _digest
+stream = _window()
+first = synth.sub_window(stream, 0, 8)
+ctx0 = capi.Context(first.opts); ctx0.load_window(first, synth.analytic_correspondences(first))
+sol0, _ = ctx0.solve(first.init)
+prior = ctx0.marginalize(sol0); ctx0.close()
+win = synth.sub_window(stream, 1, 8); win.prior = prior            # steady state: the keyframe-chain solver path
+corr = synth.analytic_correspondences(win)
+ref = None
+ctx = capi.Context(win.opts); ctx.load_window(win, corr)
+for k in range(%d):
+    d = _digest(*ctx.solve(win.init))
+    ref = ref or d
+    assert d == ref, f"reused context: solve {k} differs"
+path = capi.load().glio_debug_solver_path(ctx._h)
+ctx.close()
+for k in range(%d):
+    c = capi.Context(win.opts); c.load_window(win, corr)
+    for j in range(3):
+        assert _digest(*c.solve(win.init)) == ref, f"fresh context {k}, solve {j} differs"
+    c.close()
+print("SOAK_OK", path, ref[4])
+"""
+
+
+@pytest.mark.parametrize("poison", [False, True], ids=["plain", "lds_poison_nan_fill"])
+def test_repeated_solves_are_bit_identical(poison):
+    env = dict(os.environ)
+    if poison:
+        env["GLIO_DEBUG_LDS_POISON"] = "1"
+        env["GLIO_DEBUG_FILL"] = "255"
+    n_reuse, n_fresh = (300, 25) if not poison else (120, 10)
+    out = subprocess.run([sys.executable, "-c", _SOAK_SCRIPT % (ROOT, os.path.join(ROOT, "tests"), n_reuse, n_fresh)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "SOAK_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.stdout.split("SOAK_OK")[1].split()[0] == "2", "the steady-state window must take the keyframe-chain path"
+
+
+def test_sliding_window_and_batch_contexts_from_two_threads():
+    import torch  # noqa: F401  (the HIP runtime of this process)
+    from glio_amd import batch, capi
+    stream = _window()
+    win = synth.sub_window(stream, 0, 8)
+    corr = synth.analytic_correspondences(win)
+    ctx = capi.Context(win.opts); ctx.load_window(win, corr)
+    ref_sw = _digest(*ctx.solve(win.init))
+
+    K, band = 96, 6
+    gt, init = batch.make_poses(K)
+    ci, cj, cp, nc, score = batch.make_constraints(gt, 0, K, 512, band, device="cuda:0")
+    st = batch.BatchStage(K, band, len(ci)); st.set_constraints(ci, cj, cp, nc, score)
+    Hg = st.new_hg()
+    st.linearize(init, Hg)
+    ref_hg = Hg.cpu().numpy().copy()
+    ref_step, ref_md = st.step(Hg, 1e-4, init)
+
+    errors = []
+    stop = threading.Event()
+
+    def sw_thread():
+        try:
+            for _ in range(150):
+                if _digest(*ctx.solve(win.init)) != ref_sw:
+                    errors.append("sliding-window solve changed under concurrency"); return
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"sw: {e}")
+
+    def batch_thread():
+        try:
+            hg = st.new_hg()
+            for _ in range(150):
+                st.linearize(init, hg)
+                if not np.array_equal(hg.cpu().numpy(), ref_hg):
+                    errors.append("batch linearisation changed under concurrency"); return
+                out, md = st.step(hg, 1e-4, init)
+                if not np.array_equal(out, ref_step) or md != ref_md:
+                    errors.append("batch step changed under concurrency"); return
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"batch: {e}")
+
+    def churn_thread():
+        try:
+            small = synth.sub_window(stream, 2, 4)
+            sc = synth.analytic_correspondences(small)
+            ref = None
+            while not stop.is_set():
+                c = capi.Context(small.opts); c.load_window(small, sc)
+                d = _digest(*c.solve(small.init))
+                ref = ref or d
+                if d != ref:
+                    errors.append("churned context differs"); return
+                c.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"churn: {e}")
+
+    ts = [threading.Thread(target=f) for f in (sw_thread, batch_thread)]
+    tc = threading.Thread(target=churn_thread)
+    tc.start()
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    stop.set(); tc.join(timeout=120)
+    assert not errors, errors
+    ctx.close(); st.close()
