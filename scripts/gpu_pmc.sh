@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 for CNT in FETCH_SIZE WRITE_SIZE; do
   OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$CNT
   rm -rf $OUT; mkdir -p $OUT
-  rocprofv3 --pmc $CNT --output-format csv -d $OUT -o pmc -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-batch > gpurun_out/pmc_$CNT.log 2>&1
+  rocprofv3 --pmc $CNT --output-format csv -d $OUT -o pmc -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-batch --no-c5 --no-bassoc > gpurun_out/pmc_$CNT.log 2>&1
   f=$(find $OUT -name "*counter_collection.csv" | head -1)
   python - "$f" $CNT <<'PY' | tee -a gpurun_out/k3_pmc.txt
 import csv, sys, collections, json, os
@@ -43,13 +43,20 @@ alg = line["roofline"]["bytes_per_launch"] if line else None
 k3v = [x for k, v in raw["FETCH_SIZE"].items() if "k_lidar_linearize" in k for x in v if alg and 0.75 < 2.0 * x * 1024 / alg < 1.25]
 wrv = [x for k, v in raw.get("WRITE_SIZE", {}).items() if "k_lidar_linearize" in k for x in v if x * 1024 < 1e6]
 fetch = 2.0 * (sum(k3v) / len(k3v)) * 1024 if k3v else None          # KB -> B, x2: gfx950 reports half of a wide coalesced read
+# the launch the solve itself uses (K3 workgroups + small factors): k_linearize_all at the C2 size
+lav = [x for k, v in raw["FETCH_SIZE"].items() if "k_linearize_all" in k for x in v if alg and 0.75 < 2.0 * x * 1024 / alg < 1.6]
+law = [x for k, v in raw.get("WRITE_SIZE", {}).items() if "k_linearize_all" in k for x in v if x * 1024 < 4e6]
+la_fetch = 2.0 * (sum(lav) / len(lav)) * 1024 if lav else None
+la_write = (sum(law) / len(law)) * 1024 if law else 0.0
 wr = [sum(wrv) / len(wrv)] if wrv else []
 out = {"lidar_residuals": line["config"]["lidar_residuals"] if line else None, "launches_averaged": len(k3v),
        "k3_fetch_bytes_per_launch": fetch, "k3_write_bytes_per_launch": (wr[0] * 1024 if wr else None),
        "k3_hbm_bytes_per_launch": (fetch + (wr[0] * 1024 if wr else 0.0)) if fetch else None,
        "algorithmic_bytes_per_launch": line["roofline"]["bytes_per_launch"] if line else None,
+       "linearize_all_launches_averaged": len(lav), "linearize_all_fetch_bytes_per_launch": la_fetch,
+       "linearize_all_hbm_bytes_per_launch": (la_fetch + la_write) if la_fetch else None,
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 3 --warmup 1 "
-                 "--no-cpu-baseline --no-batch`; FETCH_SIZE x2 (gfx950 wide-read correction), KB -> bytes"}
+                 "--no-cpu-baseline --no-batch --no-c5 --no-bassoc`; FETCH_SIZE x2 (gfx950 wide-read correction), KB -> bytes"}
 json.dump(out, open("gpurun_out/k3_pmc.json", "w"), indent=1)
 print(json.dumps(out))
 PY

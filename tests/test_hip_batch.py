@@ -63,30 +63,36 @@ def test_shard_sum_equals_full_linearisation():
     st.set_constraints(*full)
     Hg_full = st.new_hg()
     st.linearize(init, Hg_full)
+    # the constraint set split by SOURCE keyframe range (batch.shard_range: the ownership rule of the sharded stage) into
+    # 2, 3 and 8 ranks: the ranks' buffers must add up to the full linearisation
+    ci, cj, cp, nc, score = full
+    f = Hg_full.cpu().numpy()
     for world in (2, 3, 8):
         acc = st.new_hg()
+        total = 0
         for r in range(world):
             lo, hi = batch.shard_range(K, r, world)
-            part = batch.make_constraints(gt, lo, hi, per_kf, band, seed=9, device="cuda:0")
-            sr = batch.BatchStage(K, band, max(1, len(part[0])))
-            sr.set_constraints(*part)
+            a0, a1 = int(np.searchsorted(ci, lo, side="left")), int(np.searchsorted(ci, hi, side="left"))
+            total += a1 - a0
+            sr = batch.BatchStage(K, band, max(1, a1 - a0))
+            sr.set_constraints(ci[a0:a1], cj[a0:a1], cp[a0:a1].contiguous(), nc[a0:a1].contiguous(), score[a0:a1].contiguous())
             Hg = sr.new_hg()
             sr.linearize(init, Hg)
             acc += Hg
             sr.close()
-        # same constraints? (the generator is seeded per source keyframe range start, so compare through costs of identical sets)
-        assert acc.shape == Hg_full.shape
-    # identical constraint sets split in two must add up exactly
-    ci, cj, cp, nc, score = full
-    cut = int(np.searchsorted(ci, K // 2))
-    acc = st.new_hg()
-    for sl in (slice(0, cut), slice(cut, len(ci))):
-        sr = batch.BatchStage(K, band, len(ci))
-        sr.set_constraints(ci[sl], cj[sl], cp[sl].contiguous(), nc[sl].contiguous(), score[sl].contiguous())
-        Hg = sr.new_hg()
-        sr.linearize(init, Hg)
-        acc += Hg
-        sr.close()
+        assert total == len(ci)
+        a = acc.cpu().numpy()
+        assert np.linalg.norm(a - f) <= 1e-13 * np.linalg.norm(f), f"{world} shards"
+        assert abs(a[-1] - f[-1]) <= 1e-13 * abs(f[-1])
+    # and the generator's own per-rank sets (what bench.py builds on every rank) cover every source keyframe exactly once
+    for world in (2, 3, 8):
+        n_tot = 0
+        for r in range(world):
+            lo, hi = batch.shard_range(K, r, world)
+            part = batch.make_constraints(gt, lo, hi, per_kf, band, seed=9, device="cuda:0")
+            assert len(part[0]) == (hi - lo) * per_kf and (part[0] >= lo).all() and (part[0] < hi).all()
+            n_tot += len(part[0])
+        assert n_tot == K * per_kf
     a, f = acc.cpu().numpy(), Hg_full.cpu().numpy()
     assert np.linalg.norm(a - f) <= 1e-13 * np.linalg.norm(f)
     st.close()
