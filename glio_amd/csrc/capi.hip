@@ -18,7 +18,7 @@
 void glio_launch_eval_imu(glio_ctx* c, const ImuEdgeDev* d_edge, const double* d_params, double* d_out);
 void glio_launch_eval_lidar(glio_ctx* c, const float cp[4], const float plane[4], double score, const double* d_params, double* d_out);
 void glio_launch_gram(glio_ctx* c, int np);
-void glio_tr_step_configure(size_t max_lds);
+int glio_tr_step_configure(size_t max_lds);
 
 static thread_local char g_err[512] = "";
 void glio_set_error(const char* fmt, ...) {
@@ -137,7 +137,16 @@ static int create_body(int device, const glio_opts* opts, glio_ctx* c) {
         ALLOC(c->d_cost[k], 8);
     }
     ALLOC(c->d_xout, nx * 8);
-    ALLOC(c->d_lidar_partials, (size_t)W * GLIO_K3_MAX_BLOCKS_PER_KF * GLIO_LIDAR_ACC * 8);
+    ALLOC(c->d_lidar_partials, 2 * (size_t)W * GLIO_K3_MAX_BLOCKS_PER_KF * GLIO_LIDAR_ACC * 8);
+    ALLOC(c->d_hdiag[0], n_max * 8); ALLOC(c->d_hdiag[1], n_max * 8);
+    ALLOC(c->d_chain_tabs, (size_t)(8 + 15) * W * sizeof(short));
+    ALLOC(c->d_chain_src, 2 * (size_t)W * GLIO_CS_SOURCES * GLIO_CS_STRIDE * 8);
+    GLIO_HIP_CHECK(hipMemsetAsync(c->d_chain_src, 0, 2 * (size_t)W * GLIO_CS_SOURCES * GLIO_CS_STRIDE * 8, c->stream));
+    GLIO_HIP_CHECK(hipHostMalloc((void**)&c->h_chain_tabs, (size_t)(8 + 15) * W * sizeof(short)));
+    c->h_groups = (GnssGroup*)calloc((size_t)W * W, sizeof(GnssGroup));
+    c->h_prior_index = (int*)malloc((size_t)15 * W * sizeof(int));
+    for (int k = 0; k < 15 * W; ++k) c->h_prior_index[k] = -1;
+    c->chain_tabs_dirty = 1;
     c->k3_bpk = GLIO_K3_BLOCKS_PER_KF; c->last_k3_nb = c->k3_bpk; c->merged_linearize = 2; c->k3_unroll = 22;   /* 2-deep batches, non-temporal loads, next batch issued before the arithmetic of the current one */
     { int per = 768 / W;   /* ~3 workgroups per CU measured best on MI355X (scripts/k3_sweep.py) */ if (per < 8) per = 8; if (per > GLIO_K3_MAX_BLOCKS_PER_KF) per = GLIO_K3_MAX_BLOCKS_PER_KF; c->k3_bpk = per; }
     ALLOC(c->d_lidar_blocks, 2 * (size_t)W * GLIO_LIDAR_ACC * 8);
@@ -179,7 +188,7 @@ static int create_body(int device, const glio_opts* opts, glio_ctx* c) {
     ALLOC(ex->d_eval_params, 64 * 8); ALLOC(ex->d_eval_out, (15 + 15 * 32) * 8); ALLOC(ex->d_eval_edge, sizeof(ImuEdgeDev));
     GLIO_HIP_CHECK(hipHostMalloc((void**)&ex->h_eval, (15 + 15 * 32) * 8));
     c->extra = ex;
-    glio_tr_step_configure(160 * 1024);
+    if (glio_tr_step_configure(160 * 1024) != GLIO_OK) return GLIO_E_HIP;
     if (glio_assoc_create(c) != GLIO_OK) return GLIO_E_HIP;
     return GLIO_OK;
 }
@@ -194,13 +203,15 @@ void glio_destroy(glio_ctx* c) {
                     c->d_ddt_blocks, c->d_dd, c->d_dop, c->d_prior_J0, c->d_prior_A0, c->d_prior_r0, c->d_prior_x0, c->d_prior_slot,
                     c->d_prior_kind, c->d_prior_idx, c->d_prior_index, c->d_prior_H, c->d_prior_g, c->d_prior_cost, c->d_prior_work,
                     /* d_x[0] lives inside d_status' allocation */ c->d_x[1], c->d_H[0], c->d_H[1], c->d_g[0], c->d_g[1], c->d_cost[0], c->d_cost[1], c->d_xout,
-                    c->d_lidar_partials, c->d_lidar_blocks, c->d_L, c->d_vec, c->d_status,
+                    c->d_lidar_partials, c->d_hdiag[0], c->d_hdiag[1], c->d_chain_tabs, c->d_chain_src, c->d_lidar_blocks, c->d_L, c->d_vec, c->d_status,
                     c->arrow.d_ep_slots, c->arrow.d_ep_off, c->arrow.d_ep_list, c->arrow.d_Y, c->arrow.d_Lblk, c->arrow.d_Sp, c->arrow.d_z, c->arrow.d_flag, c->arrow.d_dbg};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_status) hipHostFree(c->h_status); /* h_xbuf lives inside it */
     if (c->h_progress) hipHostFree((void*)c->h_progress);
     if (c->h_result) hipHostFree(c->h_result);
     if (c->h_stage) hipHostFree(c->h_stage);
+    if (c->h_chain_tabs) hipHostFree(c->h_chain_tabs);
+    free(c->h_groups); free(c->h_prior_index);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (CtxExtra* ex = extra_of(c)) {
@@ -406,6 +417,8 @@ int glio_set_imu(glio_ctx* c, int n_edges, const glio_preint* edges, const int32
         GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
     }
     c->n_imu = n_edges;
+    for (int k = 0; k < n_edges; ++k) c->h_imu_slot[k] = slot_i[k];
+    c->chain_tabs_dirty = 1;
     extra_of(c)->imu_edge0 = -1;
     for (int k = 0; k < n_edges; ++k) if (slot_i[k] == 0) extra_of(c)->imu_edge0 = k;
     if (n_edges) c->have_factors = 1;
@@ -416,7 +429,12 @@ int glio_set_imu(glio_ctx* c, int n_edges, const glio_preint* edges, const int32
 int glio_set_prior(glio_ctx* c, const glio_prior* p) {
     if (!c) return GLIO_E_ARG;
     GLIO_HIP_CHECK(hipSetDevice(c->device));
-    if (!p || p->n <= 0) { c->prior_n = 0; c->prior_nb = 0; c->arrow.prior_ok = 1; c->arrow.prior_chain = 1; return GLIO_OK; }
+    if (!p || p->n <= 0) {
+        c->prior_n = 0; c->prior_nb = 0; c->arrow.prior_ok = 1; c->arrow.prior_chain = 1;
+        for (int k = 0; k < 15 * c->W; ++k) c->h_prior_index[k] = -1;
+        c->chain_tabs_dirty = 1;
+        return GLIO_OK;
+    }
     const int np = p->n, nb = p->n_blocks, W = c->W;
     if (np > 6 * W + 9 || nb > 2 * W + 1) { glio_set_error("prior too large for window"); return GLIO_E_ARG; }
     std::vector<int> index(15 * W, -1), colblk(np, -1);
@@ -459,6 +477,8 @@ int glio_set_prior(glio_ctx* c, const glio_prior* p) {
     GLIO_HIP_CHECK(hipMemcpy(c->d_prior_index, index.data(), 15 * W * 4, hipMemcpyHostToDevice));
     GLIO_HIP_CHECK(hipMemcpy(ex->d_prior_colblk, colblk.data(), np * 4, hipMemcpyHostToDevice));
     c->prior_n = np; c->prior_nb = nb;
+    for (int k = 0; k < 15 * W; ++k) c->h_prior_index[k] = index[k];
+    c->chain_tabs_dirty = 1;
     glio_launch_gram(c, np);
     GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
     c->have_factors = 1;
@@ -552,7 +572,9 @@ int glio_set_gnss(glio_ctx* c, const glio_gnss_frame* frame, int n_dd, const gli
     std::vector<int2> es(ne, make_int2(-1, -1));
     std::vector<std::vector<int>> per(W);
     c->arrow.gnss_ok = 1; c->arrow.max_epoch = -1; c->arrow.gnss_chain = 1;
-    for (auto& g : groups) if (std::abs(g.slot_i - g.slot_j) != 1) c->arrow.gnss_chain = 0;       // a DD pair that skips a keyframe breaks the chain
+    for (auto& g : groups) if (g.slot_j - g.slot_i != 1) c->arrow.gnss_chain = 0;       // a pair that skips a keyframe (or is listed upper keyframe first) breaks the chain
+    for (size_t k = 0; k < groups.size(); ++k) c->h_groups[k] = groups[k];
+    c->chain_tabs_dirty = 1;
     for (auto& r : runs) {
         c->arrow.max_epoch = std::max(c->arrow.max_epoch, r.epoch);
         const GnssGroup& g = groups[r.group];
@@ -622,16 +644,19 @@ static void lds_poison(glio_ctx* c) {
     if (!configured) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_lds_poison), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); configured = true; }
     hipLaunchKernelGGL(k_lds_poison, dim3(1024), dim3(256), 160 * 1024, c->stream, 160 * 1024 / 8);
 }
-static void enqueue_linearize(glio_ctx* c, int use_status, int which, int n_ddt) {
+// `dense`: also gather the blocks into the dense H, g (k_assemble).  The solve on the keyframe-chain path does not need it
+// (k_chain_step reads the factor blocks); glio_linearize and the other solver paths do.
+static void enqueue_linearize(glio_ctx* c, int use_status, int which, int n_ddt, int dense = 1) {
+    if (c->chain_tabs_dirty) glio_chain_tabs_upload(c);      // gather tables + zeroed slices, ahead of the factor kernels that fill them
     lds_poison(c);
     if (c->merged_linearize) {
         glio_launch_linearize_all(c, use_status, which, n_ddt);
-        glio_launch_assemble(c, use_status, which, n_ddt);
+        if (dense) glio_launch_assemble(c, use_status, which, n_ddt);
         return;
     }
     glio_launch_lidar_linearize(c, use_status, which);
     glio_launch_small_factors(c, use_status, which, n_ddt);
-    glio_launch_assemble(c, use_status, which, n_ddt);
+    if (dense) glio_launch_assemble(c, use_status, which, n_ddt);
 }
 // enqueue one complete solve from the packed state in h_xbuf; no host synchronisation inside
 static int enqueue_solve(glio_ctx* c, int n_ddt) {
@@ -656,10 +681,11 @@ static int enqueue_solve(glio_ctx* c, int n_ddt) {
     const int lead = c->enqueue_lead < 1 ? total : c->enqueue_lead;
     const auto t_start = std::chrono::steady_clock::now();
     int enq = 0, spins = 0;
+    const int dense = glio_solver_needs_dense_H(c, n_ddt);
     while (enq < total) {
         if (c->h_progress[1] == id) break;
         if (enq - started() < lead) {
-            enqueue_linearize(c, 1, 0, n_ddt);
+            enqueue_linearize(c, 1, 0, n_ddt, dense);
             lds_poison(c);
             glio_launch_tr_step(c, n_ddt);
             ++enq;
@@ -825,6 +851,8 @@ int glio_marginalize_keep(glio_ctx* c, const glio_state* s) {
     // prior) is block diagonal, and so is its Cholesky root: the chain property is inherited
     const int chain = c->prior_n > 0 ? c->arrow.prior_chain : 1;
     c->prior_n = n; c->prior_nb = nb;
+    for (int k = 0; k < 15 * W; ++k) c->h_prior_index[k] = index[k];
+    c->chain_tabs_dirty = 1;
     c->arrow.prior_ok = 1; c->arrow.prior_chain = chain;
     glio_launch_gram(c, n);
     GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));        // the host vectors above go out of scope
@@ -894,8 +922,9 @@ int glio_eval_imu(glio_ctx* c, const glio_preint* pre, double const* const* P, d
 
 // solver selection for tests: 0 = dense Cholesky only, 1 = structured (arrow) factorisation when the graph permits
 int glio_debug_set_solver(glio_ctx* c, int mode) {
-    if (!c || mode < 0 || mode > 2) return GLIO_E_ARG;      // 0 dense only, 1 structured when possible, 2 = 1 + the chain kernel reports a
-    c->arrow.mode = mode;                                   // breakdown every time (test hook for its dense fallback)
+    if (!c || mode < 0 || mode > 3) return GLIO_E_ARG;      // 0 dense only, 1 structured when possible, 2 = 1 + the chain kernel reports a
+    c->arrow.mode = mode;                                   // breakdown every time (test hook for its dense fallback), 3 = 1 with the
+                                                            // legacy chain sequence (assemble + k_chain_solve + k_tr_finish) instead of k_chain_step
     return GLIO_OK;
 }
 int glio_debug_arrow_stamps(glio_ctx* c, long long* out64) {

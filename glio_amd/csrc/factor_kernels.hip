@@ -36,7 +36,12 @@ struct SmallArgs {
     const double* pJ0; const double* pA0; const double* pr0; const double* px0;
     const int* pslot; const int* pkind; const int* pidx; const int* pcolblk;
     double* pH; double* pg; double* pcost; double* pwork;
+    // chain-layout contributions (glio_device.h, GLIO_CS_*): written beside the pair blocks, consumed by k_chain_step
+    double* chain_src; const short* chain_tabs;
 };
+__device__ __forceinline__ double* chain_slice(const SmallArgs& a, const int which, const int slot, const int source) {
+    return a.chain_src + (((size_t)which * a.W + slot) * GLIO_CS_SOURCES + source) * GLIO_CS_STRIDE;
+}
 
 // ------------------------------------------------------------------------------------------------
 // IMU
@@ -63,7 +68,8 @@ struct ImuLds { double Jg[15 * IMU_GC], Jl[15 * 30], WJ[15 * 30], S[225], r[15],
 // the whitened GLOBAL Jacobians [15][32] (Pi3 Qi4 SBi9 Pj3 Qj4 SBj9) and return.
 __device__ __forceinline__ void imu_block(const double gravity, const double* __restrict__ pPi, const double* __restrict__ pQi,
                           const double* __restrict__ pSBi, const double* __restrict__ pPj, const double* __restrict__ pQj,
-                          const double* __restrict__ pSBj, const ImuEdgeDev& e, PairBlock* out, double* eval_out, const int marg, unsigned char* pool) {
+                          const double* __restrict__ pSBj, const ImuEdgeDev& e, PairBlock* out, double* eval_out, const int marg, unsigned char* pool,
+                          double* cs_a = nullptr, double* cs_b = nullptr) {
     // LDS comes from the caller's pool: the roles of the small-factor kernel overlay one another (a workgroup has one role)
     ImuLds& lds_ = *reinterpret_cast<ImuLds*>(pool);
     double (&Jg)[15 * IMU_GC] = lds_.Jg; double (&Jl)[15 * 30] = lds_.Jl; double (&WJ)[15 * 30] = lds_.WJ;
@@ -242,6 +248,11 @@ __device__ __forceinline__ void imu_block(const double gravity, const double* __
 #pragma unroll
         for (int k = 0; k < 15; ++k) s += WJ[k * 30 + p] * WJ[k * 30 + c];
         out->H[idx] = s;
+        if (cs_a) {          // the same entry in chain layout: aa -> D of slot_i, ba -> B of slot_i, bb -> D of slot_j
+            if (p < 15) { if (c <= p) cs_a[p * (p + 1) / 2 + c] = s; }
+            else if (c < 15) cs_a[120 + (p - 15) * 15 + c] = s;
+            else if (c <= p) cs_b[(p - 15) * (p - 14) / 2 + (c - 15)] = s;
+        }
     }
     if (tid < 30) {
         double s = 0;
@@ -269,11 +280,12 @@ struct GnssLds {
     double sE[DD_CHUNK][20][3], sRu[DD_CHUNK][20], sRr[DD_CHUNK][20], sObs[DD_CHUNK][20];   // per satellite: e^T R, |d_u|, |d_r|, psr_u - psr_r
     double dE[DOP_CHUNK * 16];            // per row: 13 Jacobian entries, corrected residual, rho, 1
     double s_cost[2];
+    double sH6[36];                       // the DD part of the pair block, for the chain-layout slices
     DopRun s_runs[GN_MAX_RUNS];
     int s_nw[DD_CHUNK], s_m[DD_CHUNK];
 };
 __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, const GnssGroup& gr, int gidx,
-                           PairBlock* out, DdtBlock* ddt_out, unsigned char* pool) {
+                           PairBlock* out, DdtBlock* ddt_out, unsigned char* pool, const int which) {
     // All factors of the pair are evaluated SIDE BY SIDE (DD factor f -> lanes 32 f' .. 32 f' + 31, Doppler row -> one
     // lane).  These are chains of dependent global loads (~1-2 us each on this part), so what counts is the number of
     // latency ROUNDS, not the arithmetic: everything a factor needs is fetched in one round (per-satellite quantities by
@@ -498,6 +510,25 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
     else if (tid < 42) out->g[map6[tid - 36]] += g6;
     __syncthreads();
     if (tid == 0) { out->cost = s_cost[0] + s_cost[1]; out->slot_a = si; out->slot_b = sj; }
+    // chain-layout slices of the two keyframes (only pairs (i, i + 1) take part in the keyframe chain).  Only the 12 x 12
+    // positions of (t v of i, t v of j) can be non-zero (the DD part lives on a subset of them); everything else in a GNSS
+    // slice was zeroed when the structure was set and is never written.  An entry is h12 (+ h6), as out->H was formed.
+    if (a.chain_src && !a.marg && sj == si + 1) {
+        if (tid < 36) lds_.sH6[tid] = h6;
+        __syncthreads();
+        if (tid < 144) {
+            const ChainKf* kd = reinterpret_cast<const ChainKf*>(a.chain_tabs);
+            const int ia = tid / 12, ib = tid - 12 * ia;
+            const int R = map12[ia], C = map12[ib];
+            // position inside the DD 6-vector (t of i, t of j) or -1
+            const int a6 = (ia % 6) < 3 ? (ia / 6) * 3 + ia % 6 : -1, b6 = (ib % 6) < 3 ? (ib / 6) * 3 + ib % 6 : -1;
+            double v = h12;
+            if (a6 >= 0 && b6 >= 0) v += lds_.sH6[a6 * 6 + b6];
+            if (R < 15) { if (C <= R) chain_slice(a, which, si, kd[si].k0 == gidx ? 2 : 3)[R * (R + 1) / 2 + C] = v; }                 // aa
+            else if (C < 15) chain_slice(a, which, si, kd[si].k0 == gidx ? 2 : 3)[120 + (R - 15) * 15 + C] = v;                       // ba
+            else if (C <= R) chain_slice(a, which, sj, kd[sj].k0 == gidx ? 2 : 3)[(R - 15) * (R - 14) / 2 + (C - 15)] = v;             // bb
+        }
+    }
     GN_STAMP(7);
 }
 
@@ -592,7 +623,7 @@ __device__ void prior_rg_block(const SmallArgs& a, const double* __restrict__ x,
 }
 
 // workgroups 1..PRIOR_H_BLOCKS: rows i = part, part + PRIOR_H_BLOCKS, ... of H = M^T A0 M
-__device__ void prior_H_block(const SmallArgs& a, const double* __restrict__ x, double* H, int part, unsigned char* pool) {
+__device__ void prior_H_block(const SmallArgs& a, const double* __restrict__ x, double* H, int part, unsigned char* pool, const int which) {
     PriorLds& lds_ = *reinterpret_cast<PriorLds*>(pool);
     double (&dx)[PRIOR_MAX_NP] = lds_.dx; double (&Mb)[9 * PRIOR_MAX_NB] = lds_.Mb;
     const int tid = threadIdx.x, np = a.np;
@@ -601,6 +632,7 @@ __device__ void prior_H_block(const SmallArgs& a, const double* __restrict__ x, 
         const int bi = a.pcolblk[i];
         const bool qi = a.pkind[bi] == GLIO_BLK_QUAT;
         const int ii = a.pidx[bi], ci = i - ii;
+        const int slot_i = a.pslot[bi];
         for (int j = tid; j < np; j += SF_THREADS) {
             const int bj = a.pcolblk[j];
             const bool qj = a.pkind[bj] == GLIO_BLK_QUAT;
@@ -622,6 +654,13 @@ __device__ void prior_H_block(const SmallArgs& a, const double* __restrict__ x, 
                 }
             }
             H[(size_t)i * np + j] = s;
+            if (a.chain_src && !a.marg) {        // chain layout: same-keyframe entries (lower triangle) and entries towards the keyframe below
+                const int sr = slot_i, sc = a.pslot[bj];
+                const int lr = (a.pkind[bi] == GLIO_BLK_TRANS ? 0 : (a.pkind[bi] == GLIO_BLK_QUAT ? 3 : 6)) + ci;
+                const int lc = (a.pkind[bj] == GLIO_BLK_TRANS ? 0 : (a.pkind[bj] == GLIO_BLK_QUAT ? 3 : 6)) + cj;
+                if (sr == sc) { if (lc <= lr) chain_slice(a, which, sr, 4)[lr * (lr + 1) / 2 + lc] = s; }
+                else if (sr == sc + 1) chain_slice(a, which, sc, 4)[120 + lr * 15 + lc] = s;
+            }
         }
     }
 }
@@ -649,18 +688,19 @@ __device__ void small_factors_body(const SmallArgs& a) {
     if (b < a.n_imu) {
         const int si = a.imu[b].slot_i, sj = si + 1, W = a.W;
         imu_block(a.gravity, x + 3 * si, x + 3 * W + 4 * si, x + 7 * W + 9 * si, x + 3 * sj, x + 3 * W + 4 * sj, x + 7 * W + 9 * sj,
-                  a.imu[b], a.imu_blocks + (size_t)which * a.W + b, nullptr, a.marg, pool);
+                  a.imu[b], a.imu_blocks + (size_t)which * a.W + b, nullptr, a.marg, pool,
+                  a.marg ? nullptr : chain_slice(a, which, si, 0), a.marg ? nullptr : chain_slice(a, which, sj, 1));
         return;
     }
     b -= a.n_imu;
     if (b < a.n_groups) {
-        gnss_block(a, x, a.groups[b], b, a.gnss_blocks + (size_t)which * a.gnss_stride + b, a.ddt_blocks + (size_t)which * a.ddt_stride, pool);
+        gnss_block(a, x, a.groups[b], b, a.gnss_blocks + (size_t)which * a.gnss_stride + b, a.ddt_blocks + (size_t)which * a.ddt_stride, pool, which);
         return;
     }
     b -= a.n_groups;
     if (a.has_prior) {
         if (b == 0) prior_rg_block(a, x, a.pg + (size_t)which * a.np, a.pcost + which, pool);
-        else prior_H_block(a, x, a.pH + (size_t)which * a.np * a.np, b - 1, pool);
+        else prior_H_block(a, x, a.pH + (size_t)which * a.np * a.np, b - 1, pool, which);
     }
 }
 
@@ -673,7 +713,7 @@ __device__ void small_factors_body(const SmallArgs& a) {
 // ------------------------------------------------------------------------------------------------
 struct K3Args {
     const float4* pts; const float4* planes; const double* scores; const int* count; int cap;
-    LidarConst lc; double* partials; int n_small, nb, skip_lo, skip_hi, n_k3;
+    LidarConst lc; double* partials; size_t pstride; int n_small, nb, skip_lo, skip_hi, n_k3;
 };
 template <bool F32>
 __global__ __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_linearize_all(const SmallArgs a, const K3Args k) {
@@ -693,8 +733,9 @@ __global__ __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     b -= k.n_small + (b >= k.skip_hi ? k.skip_hi - k.skip_lo : 0);
     if (b >= k.n_k3) return;
     const int kf = b / k.nb, bx = b - kf * k.nb;
-    if (F32) k3_body_f32<true>(k.pts, k.planes, k.count, k.cap, which ? a.x1 : a.x0, a.W, k.lc, k.partials, kf, bx, k.nb, k3f_tile, k3f_red);
-    else k3_body<2, false, true, true>(k.pts, k.planes, k.scores, k.count, k.cap, which ? a.x1 : a.x0, a.W, k.lc, k.partials, kf, bx, k.nb);
+    double* part = k.partials + (size_t)which * k.pstride;
+    if (F32) k3_body_f32<true>(k.pts, k.planes, k.count, k.cap, which ? a.x1 : a.x0, a.W, k.lc, part, kf, bx, k.nb, k3f_tile, k3f_red);
+    else k3_body<2, false, true, true>(k.pts, k.planes, k.scores, k.count, k.cap, which ? a.x1 : a.x0, a.W, k.lc, part, kf, bx, k.nb);
 }
 
 // fixed-order sum of the K3 partials of keyframe blockIdx.x into its 28-double block (consumers that want the blocks
@@ -713,7 +754,7 @@ __global__ __launch_bounds__(64) void k_lidar_reduce(const double* __restrict__ 
     blocks[(size_t)blockIdx.x * GLIO_LIDAR_ACC + threadIdx.x] = s;
 }
 void glio_launch_lidar_reduce(glio_ctx* c, int which) {
-    hipLaunchKernelGGL(k_lidar_reduce, dim3(c->W), dim3(64), 0, c->stream, c->d_lidar_partials, c->last_k3_nb,
+    hipLaunchKernelGGL(k_lidar_reduce, dim3(c->W), dim3(64), 0, c->stream, c->d_lidar_partials + (size_t)which * glio_partials_stride(c), c->last_k3_nb,
                        c->d_lidar_blocks + (size_t)which * c->W * GLIO_LIDAR_ACC);
 }
 
@@ -723,7 +764,7 @@ void glio_launch_lidar_reduce(glio_ctx* c, int which) {
 struct AsmArgs {
     int W, n, n_ddt, n_imu, n_groups, has_prior, np;
     const SolverStatus* st; int use_status; int fixed_which;
-    const double* lidar_partials; int lidar_nb; const PairBlock* imu_blocks; const PairBlock* gnss_blocks; const DdtBlock* ddt_blocks;
+    const double* lidar_partials; size_t lidar_pstride; int lidar_nb; const PairBlock* imu_blocks; const PairBlock* gnss_blocks; const DdtBlock* ddt_blocks;
     int gnss_stride, ddt_stride;
     const double* pH; const double* pg; const double* pcost; const int* prior_index;
     double* H0; double* H1; double* g0; double* g1; double* c0; double* c1;
@@ -757,7 +798,7 @@ __global__ __launch_bounds__(1024) void k_assemble(const AsmArgs a) {
     const DdtBlock* dd = a.ddt_blocks + (size_t)which * a.ddt_stride;
     // LiDAR blocks: the fixed-order sum over the keyframe's K3 partials is taken right here, all nb loads of an entry in
     // flight together (only the 6 x 6 pose entries and the 6 gradient entries of a keyframe have a LiDAR term)
-    const double* lp = a.lidar_partials;
+    const double* lp = a.lidar_partials + (size_t)which * a.lidar_pstride;
     const int lnb = a.lidar_nb;
     auto lidar_term = [&](const int slot, const int idx, const bool live) {
         double s = 0;
@@ -1012,6 +1053,7 @@ static int fill_small_args(glio_ctx* c, int use_status_cand, int which, int n_dd
     a.pJ0 = c->d_prior_J0; a.pA0 = c->d_prior_A0; a.pr0 = c->d_prior_r0; a.px0 = c->d_prior_x0;
     a.pslot = c->d_prior_slot; a.pkind = c->d_prior_kind; a.pidx = c->d_prior_idx; a.pcolblk = ex->d_prior_colblk;
     a.pH = c->d_prior_H; a.pg = c->d_prior_g; a.pcost = c->d_prior_cost; a.pwork = c->d_prior_work;
+    a.chain_src = c->d_chain_src; a.chain_tabs = c->d_chain_tabs;
     return c->n_imu + c->n_groups + (a.has_prior ? 1 + PRIOR_H_BLOCKS : 0);
 }
 void glio_launch_small_factors(glio_ctx* c, int use_status_cand, int which, int n_ddt, int marg) {
@@ -1028,7 +1070,7 @@ void glio_launch_linearize_all(glio_ctx* c, int use_status_cand, int which, int 
     if (n_small == 0) { glio_launch_lidar_linearize(c, use_status_cand, which); return; }
     K3Args k;
     k.pts = c->d_pts; k.planes = c->d_planes; k.scores = c->d_scores; k.count = c->d_count; k.cap = c->cap;
-    k.lc = glio_lidar_const(c); k.partials = c->d_lidar_partials; k.n_small = n_small;
+    k.lc = glio_lidar_const(c); k.partials = c->d_lidar_partials; k.pstride = glio_partials_stride(c); k.n_small = n_small;
     const bool skip = c->merged_linearize == 2 && n_small <= 128;
     int nb = (512 - (skip ? 2 : 1) * n_small) / c->W;
     if (nb < 4) nb = 4;
@@ -1058,7 +1100,7 @@ void glio_launch_assemble(glio_ctx* c, int use_status_cand, int which, int n_ddt
     a.W = c->W; a.n = 15 * c->W + n_ddt; a.n_ddt = n_ddt; a.n_imu = c->n_imu; a.n_groups = c->n_groups;
     a.has_prior = c->prior_n > 0; a.np = c->prior_n;
     a.st = c->d_status; a.use_status = use_status_cand; a.fixed_which = which;
-    a.lidar_partials = c->d_lidar_partials; a.lidar_nb = c->last_k3_nb; a.imu_blocks = c->d_imu_blocks; a.gnss_blocks = c->d_gnss_blocks; a.ddt_blocks = c->d_ddt_blocks;
+    a.lidar_partials = c->d_lidar_partials; a.lidar_pstride = glio_partials_stride(c); a.lidar_nb = c->last_k3_nb; a.imu_blocks = c->d_imu_blocks; a.gnss_blocks = c->d_gnss_blocks; a.ddt_blocks = c->d_ddt_blocks;
     a.gnss_stride = c->W * c->W; a.ddt_stride = c->n_ddt_max > 0 ? c->n_ddt_max : 1;
     a.pH = c->d_prior_H; a.pg = c->d_prior_g; a.pcost = c->d_prior_cost; a.prior_index = c->d_prior_index;
     a.H0 = c->d_H[0]; a.H1 = c->d_H[1]; a.g0 = c->d_g[0]; a.g1 = c->d_g[1]; a.c0 = c->d_cost[0]; a.c1 = c->d_cost[1];

@@ -97,6 +97,15 @@ struct ArrowDev {
     long long* d_dbg;         // [64] wall-clock stamps of the last launch (100 MHz), development aid
 };
 
+// Chain-layout contributions ("slices"): every factor role also writes what it contributes to the block-tridiagonal part of H
+// straight into the layout k_chain_step factors, one slice of GLIO_CS_STRIDE doubles per (keyframe i, source):
+//   entry w < 120: D_i[r][c], c <= r, w = r (r + 1) / 2 + c;  w >= 120: B_i[lr][c] = H[15 (i+1) + lr][15 i + c], w = 120 + 15 lr + c
+//   sources: 0 IMU edge (i, i+1) [aa -> D_i, ba -> B_i], 1 IMU edge (i-1, i) [bb -> D_i], 2 / 3 first / second GNSS group
+//   touching i (ascending group index), 4 prior.  Slices of absent sources stay zero (re-zeroed when the structure changes).
+#define GLIO_CS_STRIDE 352
+#define GLIO_CS_SOURCES 5
+struct ChainKf { short e0, e1, k0, k1, o0, o1, kp, pad_; };   // per keyframe: IMU edges, GNSS groups (+ whether i is their slot_a), group of (i, i+1)
+
 struct glio_ctx {
     glio_opts opts;
     int device;
@@ -145,7 +154,8 @@ struct glio_ctx {
     // ---- state + normal equations, double buffered (cur / candidate)
     double* d_x[2];               // layout: trans[3W] quat[4W] sb[9W] ddt[n_ddt_max]
     double* d_xout;
-    double* d_lidar_partials;     // [W][BLOCKS_PER_KF][28]
+    double* d_lidar_partials;     // [2][W][GLIO_K3_MAX_BLOCKS_PER_KF][28]: double buffered (current point / candidate) like every factor block
+    double* d_hdiag[2];           // [n_max] diag(H) of the current point / candidate (keyframe-chain path: no dense H is built)
     double* d_lidar_blocks;       // [2][W][28]
     double* d_H[2];
     double* d_g[2];
@@ -172,9 +182,17 @@ struct glio_ctx {
     int merged_linearize;         // K3 and the small factors in one launch (k_linearize_all)
     ArrowDev arrow;
     void* extra;                  // CtxExtra (capi.hip): evaluator scratch, GNSS run tables -- owned by the context
+    // ---- host mirrors of the factor graph's structure + the gather tables k_chain_step reads (built from them when dirty)
+    int h_imu_slot[GLIO_MAX_WINDOW];          // slot_i of IMU edge k
+    GnssGroup* h_groups;                      // [W*W] (n_groups used)
+    int* h_prior_index;                       // [15 W] state index -> prior column or -1
+    short* d_chain_tabs; short* h_chain_tabs; // [8 W + 15 W] ChainKf per keyframe, then the prior index (h_: pinned)
+    int chain_tabs_dirty;
+    double* d_chain_src;                      // [2][W][GLIO_CS_SOURCES][GLIO_CS_STRIDE] chain-layout contributions, double buffered
 };
 
 static inline int glio_x_size(int W, int n_ddt) { return 16 * W + n_ddt; }
+static inline size_t glio_partials_stride(const glio_ctx* c) { return (size_t)c->W * GLIO_K3_MAX_BLOCKS_PER_KF * GLIO_LIDAR_ACC; }
 
 // ------------------------------------------------------------------------------------------------
 // device math (quaternions are w,x,y,z)
@@ -279,6 +297,9 @@ int glio_assoc_run_window(glio_ctx* c, const double* quats, const double* trans,
 void glio_localmap_destroy(glio_ctx* c);
 // solver_kernels.hip
 void glio_launch_tr_step(glio_ctx* c, int n_ddt);
+void glio_chain_tabs_upload(glio_ctx* c);
+int glio_solver_path(const glio_ctx* c, int n_ddt);           // 2 keyframe chain, 1 arrow, 0 dense
+int glio_solver_needs_dense_H(const glio_ctx* c, int n_ddt);  // 0: the step (k_chain_step) gathers from the factor blocks itself
 // marginalization of slot 0 from lidar_blocks/imu_blocks/prior H of buffer 0 (evaluated with marg = 1)
 int glio_launch_marginalize(glio_ctx* c, int imu_edge0, double** J0_dev, double** r0_dev, int** ok_dev);
 size_t glio_tr_step_lds_bytes(int n);

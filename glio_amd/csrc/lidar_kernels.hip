@@ -24,13 +24,14 @@ __global__ __launch_bounds__(GLIO_K3_THREADS) void k_lidar_linearize(
     const float4* __restrict__ pts, const float4* __restrict__ planes, const double* __restrict__ scores,
     const int* __restrict__ count, const int cap, const double* __restrict__ x0, const double* __restrict__ x1,
     const SolverStatus* __restrict__ st, const int use_status, const int fixed_which, const int W,
-    const LidarConst lc, double* __restrict__ partials) {
+    const LidarConst lc, double* __restrict__ partials, const size_t pstride) {
     int which = fixed_which;
     if (use_status) {
         if (st->done || !st->cand_pending) return;
         which = 1 - st->cur;
     }
-    k3_body<UNROLL, MARG, NT, PIPE>(pts, planes, scores, count, cap, which ? x1 : x0, W, lc, partials, blockIdx.y, blockIdx.x, gridDim.x);
+    // the partials are double buffered like every other factor block: buffer `which` belongs to the point being linearised
+    k3_body<UNROLL, MARG, NT, PIPE>(pts, planes, scores, count, cap, which ? x1 : x0, W, lc, partials + (size_t)which * pstride, blockIdx.y, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(GLIO_K3_THREADS) void k_lidar_linearize_dma(
     const float4* __restrict__ pts, const float4* __restrict__ planes, const double* __restrict__ scores,
     const int* __restrict__ count, const int cap, const double* __restrict__ x0, const double* __restrict__ x1,
     const SolverStatus* __restrict__ st, const int use_status, const int fixed_which, const int W,
-    const LidarConst lc, double* __restrict__ partials) {
+    const LidarConst lc, double* __restrict__ partials_base, const size_t pstride) {
     __shared__ __attribute__((aligned(16))) char ring[GLIO_K3_THREADS / GLIO_WAVE][STAGES][K3D_CHUNK_BYTES];
     int which = fixed_which;
     if (use_status) {
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(GLIO_K3_THREADS) void k_lidar_linearize_dma(
         which = 1 - st->cur;
     }
     const double* __restrict__ x = which ? x1 : x0;
+    double* __restrict__ partials = partials_base + (size_t)which * pstride;
     const int kf = blockIdx.y, nb = gridDim.x, n = count[kf];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // scalar: the waits below branch on it
     const int nwaves = nb * (GLIO_K3_THREADS / GLIO_WAVE), wid = blockIdx.x * (GLIO_K3_THREADS / GLIO_WAVE) + wv;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(GLIO_K3_THREADS) void k_lidar_linearize_dma(
 __global__ __launch_bounds__(GLIO_K3_THREADS) void k_lidar_linearize_f32(
     const float4* __restrict__ pts_s, const float4* __restrict__ planes, const int* __restrict__ count, const int cap,
     const double* __restrict__ x0, const double* __restrict__ x1, const SolverStatus* __restrict__ st, const int use_status,
-    const int fixed_which, const int W, const LidarConst lc, double* __restrict__ partials) {
+    const int fixed_which, const int W, const LidarConst lc, double* __restrict__ partials, const size_t pstride) {
     __shared__ __attribute__((aligned(16))) float tile[(GLIO_K3_THREADS / GLIO_WAVE) * K3F_TILE_FLOATS];
     __shared__ double red[(GLIO_K3_THREADS / GLIO_WAVE) * 72];
     int which = fixed_which;
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(GLIO_K3_THREADS) void k_lidar_linearize_f32(
         if (st->done || !st->cand_pending) return;
         which = 1 - st->cur;
     }
-    k3_body_f32<true>(pts_s, planes, count, cap, which ? x1 : x0, W, lc, partials, blockIdx.y, blockIdx.x, gridDim.x, tile, red);
+    k3_body_f32<true>(pts_s, planes, count, cap, which ? x1 : x0, W, lc, partials + (size_t)which * pstride, blockIdx.y, blockIdx.x, gridDim.x, tile, red);
 }
 __global__ __launch_bounds__(256) void k_pack_points_f32(const float4* __restrict__ pts, const double* __restrict__ scores,
                                                          const int* __restrict__ count, const int cap, float4* __restrict__ out) {
@@ -228,17 +230,17 @@ void glio_launch_lidar_linearize(glio_ctx* c, int use_status_cand, int which, in
     dim3 grid(c->k3_bpk, c->W);
 #define K3_LAUNCH_(U, MG, ...) hipLaunchKernelGGL((k_lidar_linearize<U, MG, ##__VA_ARGS__>), grid, dim3(GLIO_K3_THREADS), 0, c->stream, \
                        c->d_pts, c->d_planes, c->d_scores, c->d_count, c->cap, c->d_x[0], c->d_x[1], \
-                       c->d_status, use_status_cand, which, c->W, lc, c->d_lidar_partials)
+                       c->d_status, use_status_cand, which, c->W, lc, c->d_lidar_partials, glio_partials_stride(c))
     if (marg) { K3_LAUNCH_(4, true); return; }          // the marginalization keeps the fp64 form (its Jacobian convention differs, Q8)
     if (c->opts.lidar_precision == GLIO_LIDAR_F32_MFMA) {
         glio_lidar_pack_f32(c);
         hipLaunchKernelGGL(k_lidar_linearize_f32, grid, dim3(GLIO_K3_THREADS), 0, c->stream, c->d_pts_s, c->d_planes, c->d_count, c->cap,
-                           c->d_x[0], c->d_x[1], c->d_status, use_status_cand, which, c->W, lc, c->d_lidar_partials);
+                           c->d_x[0], c->d_x[1], c->d_status, use_status_cand, which, c->W, lc, c->d_lidar_partials, glio_partials_stride(c));
         return;
     }
 #define K3_DMA_(...) hipLaunchKernelGGL((k_lidar_linearize_dma<__VA_ARGS__>), grid, dim3(GLIO_K3_THREADS), 0, c->stream, \
                        c->d_pts, c->d_planes, c->d_scores, c->d_count, c->cap, c->d_x[0], c->d_x[1], \
-                       c->d_status, use_status_cand, which, c->W, lc, c->d_lidar_partials)
+                       c->d_status, use_status_cand, which, c->W, lc, c->d_lidar_partials, glio_partials_stride(c))
     if ((c->cap & 63) == 0) {
         if (c->k3_unroll == 32) { K3_DMA_(2); return; }
         if (c->k3_unroll == 33) { K3_DMA_(3); return; }

@@ -56,6 +56,7 @@ struct TrArgs {
     double* L; double* vec; int vstride;
     SolverStatus* status;
     int* arrow_flag; const double* arrow_z;      // structured solver result (null = dense only)
+    const double* hd0; const double* hd1;        // diag(H) of buffers 0 / 1 when no dense H exists (k_chain_step), else null
     int* progress;                               // host-mapped {(solve id << 16) | groups started, id of the finished solve}
     SolverStatus* status_host; double* xout_host; // host-mapped copy of the result (glio_solve reads it without a device-to-host copy)
 };
@@ -79,6 +80,18 @@ __device__ __forceinline__ int tr_perm(const int i, const int W, const int nd, c
     if (mode == 1) return nd + i;
     const int sl = i / 15, l = i - 15 * sl;
     return l < 6 ? nd + 9 * W + 6 * sl + l : nd + 9 * sl + (l - 6);
+}
+
+// SolverStatus read through L2 (agent-scope loads bypass this CU's vector L1): for code that re-reads the record after the
+// same kernel rewrote it (k_chain_step runs the state machine, the factorisation and the dogleg step in one launch)
+__device__ __forceinline__ SolverStatus status_load_l2(const SolverStatus* p) {
+    static_assert(sizeof(SolverStatus) % 8 == 0, "SolverStatus is read as 64-bit words");
+    SolverStatus s;
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(p);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&s);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(SolverStatus) / 8); ++k) dst[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return s;
 }
 
 __device__ __forceinline__ double block_sum(double v, double* red) {
@@ -425,7 +438,8 @@ __device__ __forceinline__ bool tr_prepare_body(const TrArgs& a, TrDecision* out
         const int cand = 1 - s.cur;
         if (s.phase == 0) {
             const double* Hc = cand ? a.H1 : a.H0;
-            for (int i = tid; i < n; i += TR_THREADS) scale[i] = a.jacobi_scaling ? 1.0 / (1.0 + sqrt(Hc[(size_t)i * n + i])) : 1.0;
+            const double* hdc = cand ? a.hd1 : a.hd0;
+            for (int i = tid; i < n; i += TR_THREADS) scale[i] = a.jacobi_scaling ? 1.0 / (1.0 + sqrt(a.hd0 ? hdc[i] : Hc[(size_t)i * n + i])) : 1.0;
             __syncthreads();
             if (tid == 0) {
                 s.cur = cand;
@@ -476,6 +490,7 @@ __device__ __forceinline__ bool tr_prepare_body(const TrArgs& a, TrDecision* out
     if (s.done) { finalize(a, s); return false; }
 
     const double* H = s.cur ? a.H1 : a.H0;
+    const double* hdv = s.cur ? a.hd1 : a.hd0;
     const double* g = s.cur ? a.g1 : a.g0;
     const double* xc = s.cur ? a.x1 : a.x0;
     // gradient max norm = | x - Plus(x, -g) |_inf
@@ -511,7 +526,7 @@ __device__ __forceinline__ bool tr_prepare_body(const TrArgs& a, TrDecision* out
 
     if (!s.reuse) {
         for (int i = tid; i < n; i += TR_THREADS) {
-            double d = scale[i] * scale[i] * H[(size_t)i * n + i];
+            double d = scale[i] * scale[i] * (a.hd0 ? hdv[i] : H[(size_t)i * n + i]);
             d = d < 1e-6 ? 1e-6 : (d > 1e32 ? 1e32 : d);
             const double dd = sqrt(d);
             diag[i] = dd;
@@ -568,7 +583,12 @@ __global__ __launch_bounds__(256) void k_tr_scale(const TrArgs a) {
 // ------------------------------------------------------------------------------------------------
 // K7c  k_tr_factor
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void tr_factor_body(const TrArgs& a) {
+// `Builder`: how the scaled, regularised matrix S H S + mu D^2 (lower triangle in tr_perm order, right-hand side S g as
+// row n) is rebuilt in a.L when the structured factorisation broke down.  The default reads the dense H; k_chain_step, which
+// never builds a dense H, passes a builder that gathers the entries from the factor blocks.
+struct DenseBuilder { static constexpr bool kHasDenseH = true; __device__ void operator()(const TrArgs&, double) const {} };
+template <class Builder = DenseBuilder>
+__device__ __forceinline__ void tr_factor_body(const TrArgs& a, const Builder& builder = Builder()) {
     const int tid = threadIdx.x;
     const int n = a.n;
     double* Bp = reinterpret_cast<double*>(tr_lds);                       // 16 x bp_stride(n)
@@ -578,12 +598,18 @@ __device__ __forceinline__ void tr_factor_body(const TrArgs& a) {
     double* red = ylds + n + (n & 1);                                     // 32
     int* flag = reinterpret_cast<int*>(red + 32);
     double* smu = red + 40;
-    if (a.status->done || a.status->reuse) return;
-    const double* H = a.status->cur ? a.H1 : a.H0;
-    const double* g = a.status->cur ? a.g1 : a.g0;
+    // (in the dynamic carve: k_tr_finish may be given all 160 KB as dynamic LDS, a static variable would not fit beside it)
+    double& f_mu = red[41];
+    int* fi = reinterpret_cast<int*>(red + 42);
+    int &f_done = fi[0], &f_reuse = fi[1], &f_cur = fi[2];
+    if (tid == 0) { const SolverStatus st0 = status_load_l2(a.status); f_done = st0.done; f_reuse = st0.reuse; f_cur = st0.cur; f_mu = st0.mu; }
+    __syncthreads();
+    if (f_done || f_reuse) return;
+    const double* H = f_cur ? a.H1 : a.H0;
+    const double* g = f_cur ? a.g1 : a.g0;
     const double* scale = V_SCALE(a); const double* diag = V_DIAG(a); const double* grad = V_GRAD(a);
     const double* u = V_U(a); const double* t = V_T(a);
-    if (a.fused_chain && !(a.arrow_flag && *a.arrow_flag == 2)) {
+    if (Builder::kHasDenseH && a.fused_chain && !(a.arrow_flag && *a.arrow_flag == 2)) {
         // the chain kernel broke down (non-positive pivot): nobody has written t = H u or the scaled matrix; do k_tr_scale's
         // work here (one wavefront per row), then the dense factorisation below takes over
         double* tw = V_T(a);
@@ -601,7 +627,7 @@ __device__ __forceinline__ void tr_factor_body(const TrArgs& a) {
     for (int i = tid; i < n; i += TR_THREADS) { p += u[i] * t[i]; q2 += grad[i] * grad[i]; }
     p = block_sum(p, red);
     q2 = block_sum(q2, red);
-    if (tid == 0) { a.status->alpha = q2 / p; *smu = a.status->mu; }
+    if (tid == 0) { a.status->alpha = q2 / p; *smu = f_mu; }
     __syncthreads();
     bool solved = false;
     if (a.arrow_flag && *a.arrow_flag == 2) {          // the structured factorisation already solved this system
@@ -612,7 +638,8 @@ __device__ __forceinline__ void tr_factor_body(const TrArgs& a) {
     for (int attempt = 0; attempt < (a.lm ? 1 : 12) && !solved; ++attempt) {
         const double mu = *smu;
         if (!a.lm && !(mu < 1.0)) break;
-        if (attempt > 0 || a.fused_chain) {    // breakdown (or nobody built it yet): S H S + mu D^2 with the current mu (rare)
+        if (!Builder::kHasDenseH) { builder(a, mu); __syncthreads(); }
+        else if (attempt > 0 || a.fused_chain) {    // breakdown (or nobody built it yet): S H S + mu D^2 with the current mu (rare)
             for (int i = tid >> 6; i < n; i += TR_WAVES) {
                 const double si = scale[i];
                 const double* hrow = H + (size_t)i * n;
@@ -664,7 +691,7 @@ __device__ __forceinline__ void tr_dogleg_body(const TrArgs& a) {
     SolverStatus& s = *reinterpret_cast<SolverStatus*>(red + 32);
     const int tid = threadIdx.x;
     const int n = a.n, W = a.W;
-    if (tid == 0) s = *a.status;
+    if (tid == 0) s = status_load_l2(a.status);
     __syncthreads();
     if (s.done) return;
     const double* g = s.cur ? a.g1 : a.g0;
@@ -1635,14 +1662,570 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a, c
     if (tid == 0) { if (misc[0]) atomicOr(a.flag, 1); else *a.flag = 2; }
 }
 
-size_t glio_tr_step_lds_bytes(int n) {
+// ------------------------------------------------------------------------------------------------
+// k_chain_step: the WHOLE trust-region step of the keyframe-chain path in one launch (one workgroup) and without a dense
+// H.  It gathers what it needs straight from the factor blocks that k_linearize_all left (K3 partials, IMU / GNSS pair
+// blocks, clock-drift blocks, prior H) -- every entry as the same sum, in the same order, that k_assemble would have
+// written into the dense matrix, so the numbers downstream are bit-identical to the assemble + k_chain_solve + k_tr_finish
+// sequence it replaces -- and then runs, in this order: the state machine (tr_prepare_body, fed with diag(H), g and the
+// cost of the candidate), the scaling + epoch elimination + twisted chain factorisation + back substitution of
+// k_chain_solve, and the Cauchy / dogleg step + candidate of k_tr_finish.  A steady-state iteration is two launches:
+// [k_linearize_all, k_chain_step].  On a non-positive pivot the same workgroup rebuilds S H S + mu D^2 densely from the
+// blocks (ChainBuilder) and factors it with the generic blocked Cholesky and Ceres' mu retries -- the outcome is the dense
+// one in every case, as before.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ size_t tr_step_lds_doubles(int n) {
     size_t d = (size_t)TR_NB * bp_stride(n);
     d += 16 * 256;
     d += (TR_NB + 1) * TR_PS;
     d += n + (n & 1);
     d += 32 + 16;
-    return d * sizeof(double);
+    return d;
 }
+// byte offset of the gather tables inside k_chain_step's dynamic LDS: behind both carves that use the front of the array
+__host__ __device__ __forceinline__ size_t chain_step_tabs_offset(int W, int nd, int n) {
+    const size_t a = chain_lds_doubles(W, nd) * 8, b = tr_step_lds_doubles(n) * 8;
+    return ((a > b ? a : b) + 15) & ~(size_t)15;
+}
+__host__ __device__ __forceinline__ size_t chain_step_lds_bytes(int W, int nd, int n) {
+    return chain_step_tabs_offset(W, nd, n) + (size_t)W * GLIO_LIDAR_ACC * 8 + 2 * (size_t)(n + (n & 1)) * 8 + (size_t)nd * 128 + (size_t)(8 + 15) * W * 2 + 3 * 346 * 2 + 64;
+}
+struct GatherArgs {
+    const double* lidar_partials; size_t lidar_pstride; int lidar_nb;
+    const PairBlock* imu_blocks; const PairBlock* gnss_blocks; const DdtBlock* ddt_blocks;
+    int gnss_stride, ddt_stride, n_imu, n_groups, has_prior, np;
+    const double* pH; const double* pg; const double* pcost;
+    const short* tabs;            // [W] ChainKf, then [15 W] prior index: built on the host from the graph's structure (glio_chain_tabs_upload)
+    const double* chain_src;      // [2][W][GLIO_CS_SOURCES][GLIO_CS_STRIDE] chain-layout contributions written by the factor roles
+    double* hd0; double* hd1; double* g0; double* g1; double* c0; double* c1;
+};
+// where the blocks of keyframe i come from (the chain structure leaves at most these):
+//   e0 IMU edge (i, i+1) [its aa part feeds D_i, its ba part B_i], e1 IMU edge (i-1, i) [bb part feeds D_i],
+//   k0 / k1 the GNSS groups touching i in ascending index, o0 / o1 = 1 when i is the group's slot_a,
+//   kp the GNSS group of the pair (i, i+1) [ba part feeds B_i]
+struct GatherTabs {
+    const ChainKf* kd;                // [W]
+    const short* pidx;                // [15 W] prior row of a pose parameter or -1
+    double* lid;                      // [W][28] K3 partials of one buffer summed in index order
+};
+__device__ __forceinline__ int kc_lidar_sym_index(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
+__device__ __forceinline__ int kc_dop_local12(int slot_is_j, int lc) {
+    int k;
+    if (lc < 3) k = lc; else if (lc >= 6 && lc < 9) k = 3 + (lc - 6); else return -1;
+    return slot_is_j ? 6 + k : k;
+}
+// chain-layout index of an entry: r30 < 15 -> D_i[r30][j] (j <= r30), r30 >= 15 -> B_i[r30 - 15][j]
+__device__ __forceinline__ int kc_w(const int r30, const int j) { return r30 < 15 ? r30 * (r30 + 1) / 2 + j : 120 + (r30 - 15) * 15 + j; }
+// One entry of the block-tridiagonal H as the sum of the LiDAR block and the five chain-layout slices of keyframe i, added in
+// k_assemble's order (LiDAR, IMU edge (i, i+1), IMU edge (i-1, i), GNSS groups by ascending index, prior; a slice of an absent
+// source is zero), so the sum is bit-identical to the dense matrix' entry.
+__device__ __forceinline__ double kc_gather_entry(const GatherArgs& G, const GatherTabs& T, const int which, const int W, const int i, const int r30, const int j) {
+    const double* p = G.chain_src + (((size_t)which * W + i) * GLIO_CS_SOURCES) * GLIO_CS_STRIDE + kc_w(r30, j);
+    const double v0 = p[0], v1 = p[GLIO_CS_STRIDE], v2 = p[2 * GLIO_CS_STRIDE], v3 = p[3 * GLIO_CS_STRIDE], v4 = p[4 * GLIO_CS_STRIDE];
+    const bool lid = (r30 < 6) & (j < 6);
+    double s = 0;
+    s += lid ? T.lid[i * GLIO_LIDAR_ACC + kc_lidar_sym_index(j < r30 ? j : r30, j < r30 ? r30 : j)] : 0.0;
+    s += v0; s += v1; s += v2; s += v3; s += v4;
+    return s;
+}
+// gradient entry of pose parameter (sc, lc), k_assemble's order
+__device__ __forceinline__ double kc_gather_grad(const GatherArgs& G, const GatherTabs& T, const int which, const int W, const int sc, const int lc) {
+    const PairBlock* imu = G.imu_blocks + (size_t)which * W;
+    const PairBlock* gn = G.gnss_blocks + (size_t)which * G.gnss_stride;
+    const double* pg = G.pg + (size_t)which * G.np;
+    const ChainKf d = T.kd[sc];
+    const bool lid = lc < 6;
+    const int pi = T.pidx[15 * sc + lc];
+    const double v0 = imu[d.e0 >= 0 ? d.e0 : 0].g[lc];
+    const double v1 = imu[d.e1 >= 0 ? d.e1 : 0].g[15 + lc];
+    const double vg0 = gn[d.k0 >= 0 ? d.k0 : 0].g[(d.o0 ? 0 : 15) + lc];
+    const double vg1 = gn[d.k1 >= 0 ? d.k1 : 0].g[(d.o1 ? 0 : 15) + lc];
+    const double vp = pg[pi >= 0 ? pi : 0];
+    const double vl = T.lid[sc * GLIO_LIDAR_ACC + 21 + (lid ? lc : 0)];
+    double s = 0;
+    s += lid ? vl : 0.0;
+    s += d.e0 >= 0 ? v0 : 0.0;
+    s += d.e1 >= 0 ? v1 : 0.0;
+    s += d.k0 >= 0 ? vg0 : 0.0;
+    s += d.k1 >= 0 ? vg1 : 0.0;
+    s += pi >= 0 ? vp : 0.0;
+    return s;
+}
+// K3 partials of buffer `which` -> T.lid, each entry the sum of its nb partials in index order (what k_assemble adds up)
+__device__ __forceinline__ void kc_reduce_lidar(const GatherArgs& G, const GatherTabs& T, const int which, const int W) {
+    const double* lp = G.lidar_partials + (size_t)which * G.lidar_pstride;
+    const int lnb = G.lidar_nb;
+    for (int it = threadIdx.x; it < W * GLIO_LIDAR_ACC; it += blockDim.x) {
+        const int slot = it / GLIO_LIDAR_ACC, idx = it - slot * GLIO_LIDAR_ACC;
+        const double* p = lp + (size_t)slot * lnb * GLIO_LIDAR_ACC + idx;
+        double sacc = 0;
+        for (int k0 = 0; k0 < lnb; k0 += 24) {
+            double vb[24];
+#pragma unroll
+            for (int q = 0; q < 24; ++q) vb[q] = p[(size_t)(k0 + q < lnb ? k0 + q : k0) * GLIO_LIDAR_ACC];
+#pragma unroll
+            for (int q = 0; q < 24; ++q) sacc += k0 + q < lnb ? vb[q] : 0.0;
+        }
+        T.lid[it] = sacc;
+    }
+}
+
+// rebuilds S H S + mu D^2 (tr_perm order, mode 1) and the right-hand side row in a.L from the factor blocks: the dense
+// fallback of k_chain_step.  Entries outside the block-tridiagonal part and the epoch columns are zero by the chain property.
+struct ChainBuilder {
+    static constexpr bool kHasDenseH = false;
+    const GatherArgs* G; const GatherTabs* T; int cur;
+    __device__ void operator()(const TrArgs& a, const double mu) const {
+        const int n = a.n, W = a.W, nd = a.n_ddt, np15 = 15 * W, tid = threadIdx.x;
+        const double* scale = V_SCALE(a); const double* diag = V_DIAG(a);
+        const double* g = cur ? a.g1 : a.g0;
+        const DdtBlock* dd = G->ddt_blocks + (size_t)cur * G->ddt_stride;
+        for (size_t k = tid; k < (size_t)(n + 1) * n; k += TR_THREADS) a.L[k] = 0.0;
+        __syncthreads();
+        for (int q = tid; q < W * 30 * 15; q += TR_THREADS) {
+            const int i = q / 450, rem = q - 450 * i, r30 = rem / 15, j = rem - 15 * r30;
+            if (r30 >= 15 && i + 1 >= W) continue;
+            if (r30 < 15 && j > r30) continue;
+            const int irow = 15 * i + r30, icol = 15 * i + j;          // r30 >= 15 runs into keyframe i + 1
+            double v = scale[irow] * kc_gather_entry(*G, *T, cur, W, i, r30, j) * scale[icol];
+            if (irow == icol) v += mu * diag[irow] * diag[irow];
+            a.L[(size_t)(nd + irow) * n + nd + icol] = v;
+        }
+        // epoch columns (the pair (sa, sa + 1) of the epoch's group) and diagonal; epochs come first in the elimination order
+        for (int q = tid; q < nd * 31; q += TR_THREADS) {
+            const int e = q / 31, r = q - 31 * e;
+            const int ie = np15 + e;
+            if (r == 30) { a.L[(size_t)e * n + e] = scale[ie] * dd[e].h * scale[ie] + mu * diag[ie] * diag[ie]; continue; }
+            if (!dd[e].used) continue;
+            const int sa = G->gnss_blocks[(size_t)cur * G->gnss_stride + dd[e].group].slot_a;
+            const int k12 = kc_dop_local12(r >= 15, r < 15 ? r : r - 15);
+            if (k12 < 0) continue;
+            const int irow = 15 * sa + r;
+            a.L[(size_t)(nd + irow) * n + e] = scale[irow] * dd[e].c[k12] * scale[ie];
+        }
+        for (int j = tid; j < n; j += TR_THREADS) a.L[(size_t)n * n + tr_perm(j, W, nd, 1)] = scale[j] * g[j];
+    }
+};
+
+__global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, const TrArgs tr, const GatherArgs G) {
+    static_assert(KC_THREADS == TR_THREADS, "tr_prepare_body runs with the chain kernel's workgroup");
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int W = a.W, n = a.n, nd = a.nd;
+    const int np15 = 15 * W;
+    // ---- carve (dynamic LDS).  The gather tables sit BEHIND the region tr_factor_body / tr_dogleg_body overlay at the
+    // front of tr_lds: they are still needed by the dense fallback.
+    double* rd = reinterpret_cast<double*>(tr_lds);
+    double* yd = rd + nd + (nd & 1);
+    double* Vs = yd + nd + (nd & 1);
+    double* Blk = Vs + (size_t)nd * 30;
+    double* CsT = Blk + (size_t)W * KC_BLK;
+    double* CsB = CsT + 288;
+    double* zb = CsB + 288;
+    int2* eps = reinterpret_cast<int2*>(zb + 15 * W + (W & 1));
+    int* eoff = reinterpret_cast<int*>(eps + nd + 2);
+    int* elist = eoff + ((W + 2) & ~1) + 2;
+    int* esd = elist + 2 * nd + 2;
+    int* eoth = esd + 2 * nd + 2;
+    int* misc = eoth + 2 * nd + 2;
+    double* wd = reinterpret_cast<double*>(misc + 24);
+    double* gt_base = reinterpret_cast<double*>(tr_lds + chain_step_tabs_offset(W, nd, n));
+    double* lid = gt_base;                               // [W][28]
+    double* sS = lid + W * GLIO_LIDAR_ACC;               // [n] Jacobi scale       (staged copies of the work vectors)
+    double* sDg = sS + n + (n & 1);                      // [n] D = sqrt(clamp(diag))
+    double* dds = sDg + n + (n & 1);                     // [nd][15] clock-drift blocks: c[12], h, g, (group, used)
+    short* stab = reinterpret_cast<short*>(dds + (size_t)nd * 15 + (nd & 1));
+    short* wr30 = stab + (8 + 15) * W + ((8 + 15) * W & 1);      // [345] chain-layout index -> row (0..29), column, LiDAR packed index or -1
+    short* wj = wr30 + 346;
+    short* wlx = wj + 346;
+    GatherTabs T;
+    T.lid = lid; T.kd = reinterpret_cast<const ChainKf*>(stab); T.pidx = stab + 8 * W;
+    __shared__ int rowmask;
+    __shared__ int s_pending, s_cand, s_done;
+    AR_STAMP(40);
+    // ---- round 0: status, the host-built gather tables, the structure tables of the epochs
+    if (tid == 0) { const SolverStatus* st = tr.status; s_done = st->done; s_pending = st->cand_pending; s_cand = 1 - st->cur; }
+    for (int k = tid; k < (8 + 15) * W; k += KC_THREADS) stab[k] = G.tabs[k];
+    for (int w = tid; w < 345; w += KC_THREADS) {
+        int r30, j;
+        if (w < 120) { int r = 0; while ((r + 1) * (r + 2) / 2 <= w) ++r; r30 = r; j = w - r * (r + 1) / 2; }
+        else { r30 = 15 + (w - 120) / 15; j = (w - 120) % 15; }
+        wr30[w] = (short)r30; wj[w] = (short)j;
+        wlx[w] = (short)((r30 < 6 && j < 6) ? kc_lidar_sym_index(j, r30) : -1);      // j <= r30 in the lower triangle
+    }
+    for (int e = tid; e < nd; e += KC_THREADS) eps[e] = a.ep_slots[e];
+    for (int i = tid; i <= W; i += KC_THREADS) eoff[i] = a.ep_off[i];
+    __syncthreads();
+    if (s_done) return;
+    const int cand = s_cand;
+    AR_STAMP(41);
+    // ---- diag(H), g and the cost of the candidate, for the state machine
+    if (s_pending) {
+        kc_reduce_lidar(G, T, cand, W);
+        __syncthreads();
+        double* hd = cand ? G.hd1 : G.hd0;
+        double* gv = cand ? G.g1 : G.g0;
+        const DdtBlock* dd = G.ddt_blocks + (size_t)cand * G.ddt_stride;
+        for (int c = tid; c < n; c += KC_THREADS) {
+            if (c < np15) {
+                const int sc = c / 15, lc = c - 15 * sc;
+                hd[c] = kc_gather_entry(G, T, cand, W, sc, lc, lc);      // diagonal entry of D
+                gv[c] = kc_gather_grad(G, T, cand, W, sc, lc);
+            } else { hd[c] = dd[c - np15].h; gv[c] = dd[c - np15].g; }
+        }
+        if (tid < 64) {          // total cost: the same lane assignment and wave reduction as k_assemble
+            const PairBlock* imu = G.imu_blocks + (size_t)cand * W;
+            const PairBlock* gn = G.gnss_blocks + (size_t)cand * G.gnss_stride;
+            double cs = 0;
+            for (int k = tid; k < W; k += 64) cs += T.lid[k * GLIO_LIDAR_ACC + 27];
+            for (int k = tid; k < G.n_imu; k += 64) cs += imu[k].cost;
+            for (int k = tid; k < G.n_groups; k += 64) cs += gn[k].cost;
+            if (tid == 0 && G.has_prior) cs += G.pcost[cand];
+            cs = wave_sum(cs);
+            if (tid == 0) *(cand ? G.c1 : G.c0) = cs;
+        }
+        __threadfence();
+    }
+    __syncthreads();
+    AR_STAMP(42);
+    // ---- state machine (reads the vectors just written: nothing of them was loaded earlier in this kernel)
+    TrDecision dec;
+    if (!tr_prepare_body(tr, &dec)) return;
+    AR_STAMP(43);
+    if (!dec.reuse) {
+    if (tid == 0) *a.flag = 0;
+    if (!(s_pending && dec.cur == cand)) { kc_reduce_lidar(G, T, dec.cur, W); }      // (invalid step earlier: the current point's blocks again)
+    const double* gn = dec.cur ? tr.g1 : tr.g0;
+    const DdtBlock* ddg = G.ddt_blocks + (size_t)dec.cur * G.ddt_stride;
+    const double mu = dec.mu;
+    auto nat = [&](const int p) { return p < nd ? np15 + p : p - nd; };
+    if (tid < 18) misc[tid] = 0;
+    if (tid == 0) rowmask = 0;
+    // round 1: the work vectors, the clock-drift blocks (coalesced, 15 doubles each) and the epoch list into LDS
+    for (int k = tid; k < n; k += KC_THREADS) { sS[k] = V_SCALE(tr)[k]; sDg[k] = V_DIAG(tr)[k]; }
+    for (int k = tid; k < nd * 15; k += KC_THREADS) dds[k] = reinterpret_cast<const double*>(ddg)[k];
+    for (int t = tid; t < eoff[W]; t += KC_THREADS) elist[t] = a.ep_list[t];
+    {
+        const double* uv = V_U(tr);
+        for (int k = tid; k < np15; k += KC_THREADS) zb[k] = uv[k];
+        for (int e = tid; e < nd; e += KC_THREADS) wd[e] = uv[np15 + e];
+    }
+    static_assert(sizeof(DdtBlock) == 15 * sizeof(double), "DdtBlock staged as 15 doubles");
+    __syncthreads();
+    auto Rld = [&](const int p) { const int i = nat(p); return sS[i] * gn[i]; };
+    for (int k = tid; k < np15; k += KC_THREADS) zb[k] = zb[k] / sS[k];
+    for (int e = tid; e < nd; e += KC_THREADS) {
+        wd[e] = wd[e] / sS[np15 + e];
+        const int ie = np15 + e;
+        const double se = sS[ie], he = dds[e * 15 + 12], de = sDg[ie];
+        const double m = se * he * se + mu * de * de;
+        if (!(m > 0.0) || !isfinite(m)) { misc[0] = 1; rd[e] = 0.0; } else rd[e] = rsqrt(m);
+    }
+    __syncthreads();
+    int mk_rows = 0;
+    for (int it = tid; it < nd * 30; it += KC_THREADS) {       // one (epoch, row) pair per item
+        const int e = it / 30, q = it - 30 * e;
+        const int2 sl = eps[e];
+        const int used = reinterpret_cast<const int*>(dds + e * 15 + 14)[1];
+        const int s1 = q < 15 ? sl.x : sl.y;
+        const int k12 = kc_dop_local12(q >= 15, q < 15 ? q : q - 15);
+        const bool ok = (used != 0) & (s1 >= 0) & (k12 >= 0);
+        const double v = ok ? sS[15 * (s1 >= 0 ? s1 : 0) + (q < 15 ? q : q - 15)] * dds[e * 15 + (k12 >= 0 ? k12 : 0)] * sS[np15 + e] : 0.0;
+        Vs[it] = v * rd[e];
+        if (v != 0.0) mk_rows |= 1 << (q % 15);
+    }
+    {   // rows that carry an epoch coupling: one LDS atomic per wavefront
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mk_rows |= __shfl_xor(mk_rows, off, 64);
+        if (lane == 0 && mk_rows) atomicOr(&rowmask, mk_rows);
+    }
+    for (int e = tid; e < nd; e += KC_THREADS) yd[e] = Rld(e) * rd[e];
+    AR_STAMP(44);
+    // the keyframe blocks: 345 entries per keyframe (lower triangle of D_i, all of B_i): the LiDAR block + the five slices the
+    // factor roles wrote in this layout (coalesced, same index in every slice), seven items per thread in flight, scaled on the way in
+    {
+        const double* src = G.chain_src + (size_t)dec.cur * W * GLIO_CS_SOURCES * GLIO_CS_STRIDE;
+        const int total = W * 345;
+        constexpr int KB = 7;
+        for (int q0 = tid; q0 < total; q0 += KB * KC_THREADS) {
+            double v[KB][5];
+            int ii[KB], ww[KB];
+#pragma unroll
+            for (int u = 0; u < KB; ++u) {
+                const int q = q0 + u * KC_THREADS;
+                const int qq = q < total ? q : tid;
+                const int i = qq / 345, w = qq - 345 * i;
+                ii[u] = i; ww[u] = w;
+                const double* p = src + (size_t)i * GLIO_CS_SOURCES * GLIO_CS_STRIDE + w;
+#pragma unroll
+                for (int sidx = 0; sidx < 5; ++sidx) v[u][sidx] = p[sidx * GLIO_CS_STRIDE];
+            }
+#pragma unroll
+            for (int u = 0; u < KB; ++u) {
+                const int q = q0 + u * KC_THREADS;
+                if (q >= total) continue;
+                const int i = ii[u], w = ww[u];
+                const int r30 = wr30[w], j = wj[w], lix = wlx[w];
+                const bool live = r30 < 15 || i + 1 < W;
+                const int irow = 15 * i + r30, icol = 15 * i;
+                double h = 0;
+                h += lix >= 0 ? lid[i * GLIO_LIDAR_ACC + (lix >= 0 ? lix : 0)] : 0.0;
+                h += v[u][0]; h += v[u][1]; h += v[u][2]; h += v[u][3]; h += v[u][4];
+                double wv_ = (live ? sS[irow] : 0.0) * h * sS[icol + j];
+                wv_ += (irow == icol + j) ? mu * sDg[irow] * sDg[irow] : 0.0;
+                Blk[(size_t)i * KC_BLK + r30 * KC_RS + j] = live ? wv_ : 0.0;
+            }
+        }
+        // the strict upper triangle of D_i is read as zero by the chain steps
+        for (int q = tid; q < W * 105; q += KC_THREADS) {
+            const int i = q / 105, w = q - 105 * i;
+            const int r = wr30[w], c = wj[w];               // pair (r + 1, c) with c <= r  ->  entry [c][r + 1] above the diagonal
+            Blk[(size_t)i * KC_BLK + c * KC_RS + (r + 1)] = 0.0;
+        }
+    }
+    for (int q = tid; q < W * 15; q += KC_THREADS) { const int i = q / 15, j = q - 15 * i; Blk[(size_t)i * KC_BLK + 30 * KC_RS + j] = Rld(nd + 15 * i + j); }
+    __syncthreads();
+    AR_STAMP(45);
+    for (int row = tid; row < np15 + nd; row += KC_THREADS) {
+        double acc = 0.0;
+        const double s_row = sS[row], d_row = sDg[row];
+        if (row < np15) {
+            const int i = row / 15, r = row - 15 * i;
+            const double* Bi = Blk + (size_t)i * KC_BLK;
+#pragma unroll
+            for (int j = 0; j < KC_NB; ++j) {
+                double v = j <= r ? Bi[r * KC_RS + j] : Bi[j * KC_RS + r];
+                if (j == r) v -= mu * d_row * d_row;
+                acc += v * zb[15 * i + j];
+            }
+            if (i + 1 < W) {
+#pragma unroll
+                for (int j = 0; j < KC_NB; ++j) acc += Bi[(KC_NB + j) * KC_RS + r] * zb[15 * (i + 1) + j];
+            }
+            if (i > 0) {
+                const double* Bp = Blk + (size_t)(i - 1) * KC_BLK;
+#pragma unroll
+                for (int j = 0; j < KC_NB; ++j) acc += Bp[(KC_NB + r) * KC_RS + j] * zb[15 * (i - 1) + j];
+            }
+            for (int tt = eoff[i]; tt < eoff[i + 1]; ++tt) {
+                const int e = elist[tt];
+                const int side = eps[e].x == i ? 0 : 15;
+                acc += (Vs[e * 30 + side + r] / rd[e]) * wd[e];
+            }
+            V_T(tr)[row] = acc / s_row;
+        } else {
+            const int e = row - np15;
+            const int2 sl = eps[e];
+            const double se = s_row;
+            acc = se * dds[e * 15 + 12] * se * wd[e];
+            if (sl.x >= 0) {
+#pragma unroll
+                for (int q = 0; q < 30; ++q) acc += (Vs[e * 30 + q] / rd[e]) * zb[15 * (q < 15 ? sl.x : sl.y) + (q < 15 ? q : q - 15)];
+            }
+            V_T(tr)[row] = acc / se;
+        }
+    }
+    __syncthreads();
+    AR_STAMP(46);
+    if (tid == 0) { int na = 0; for (int q = 0; q < 15; ++q) if (rowmask >> q & 1) misc[2 + na++] = q; misc[1] = na; }
+    for (int i = wv; i < W; i += KC_THREADS / 64)
+        for (int t = eoff[i] + lane; t < eoff[i + 1]; t += 64) {
+            const int e = elist[t];
+            const int2 sl = eps[e];
+            const int side = sl.x == i ? 0 : 15;
+            esd[t] = e * 30 + side;
+            eoth[t] = (sl.x == i ? sl.y : sl.x) == i + 1 ? e * 30 + (15 - side) : -1;
+        }
+    __syncthreads();
+    {
+        const int na = misc[1];
+        const int per = 2 * na * na + na;
+        for (int item = tid; item < W * per; item += KC_THREADS) {
+            const int i = item / per, w = item - i * per;
+            int r, j, kindI;
+            if (w < na * na) { kindI = 0; r = misc[2 + w / na]; j = misc[2 + w % na]; if (j > r) continue; }
+            else if (w < 2 * na * na) { kindI = 1; const int u = w - na * na; r = misc[2 + u / na]; j = misc[2 + u % na]; if (i + 1 >= W) continue; }
+            else { kindI = 2; r = 0; j = misc[2 + w - 2 * na * na]; }
+            double* dst = Blk + (size_t)i * KC_BLK + (kindI == 0 ? r : (kindI == 1 ? KC_NB + r : 30)) * KC_RS + j;
+            double v = *dst;
+            const int t1 = eoff[i + 1];
+            for (int t = eoff[i]; t < t1; t += 4) {
+                int base[4], ob[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int tt = t + q < t1 ? t + q : t1 - 1;
+                    base[q] = esd[tt];
+                    ob[q] = kindI == 1 ? eoth[tt] : (kindI == 2 ? elist[tt] : 0);
+                }
+                double xa[4], xb[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    xb[q] = Vs[base[q] + j];
+                    xa[q] = kindI == 0 ? Vs[base[q] + r] : (kindI == 1 ? Vs[(ob[q] >= 0 ? ob[q] : base[q]) + r] : yd[ob[q]]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool live = (t + q < t1) & !(kindI == 1 && ob[q] < 0);
+                    v -= live ? xa[q] * xb[q] : 0.0;
+                }
+            }
+            *dst = v;
+        }
+    }
+    __syncthreads();
+    AR_STAMP(47);
+    // the chain from both ends
+    const int mid = W / 2, nT = mid, nB = W - 1 - mid, Tn = nT > nB ? nT : nB;
+    double av[KC_NB];
+#pragma unroll
+    for (int j = 0; j < KC_NB; ++j) av[j] = 0.0;
+    if (lane < KC_NB || lane == 30) {
+        const int row = lane < KC_NB ? lane : 30;
+        if (wv == 0 && nT > 0) { for (int j = 0; j < KC_NB; ++j) av[j] = Blk[row * KC_RS + j]; }
+        if (wv == 2 && nB > 0) { for (int j = 0; j < KC_NB; ++j) av[j] = Blk[(size_t)(W - 1) * KC_BLK + row * KC_RS + j]; }
+    }
+    bool bad = false;
+    long long ph[5] = {0, 0, 0, 0, 0};
+    for (int it = 0; it <= Tn; ++it) {
+        if (wv == 0) {
+            if (it < nT) chain_step15<false>(it, it + 1, true, av, Blk, CsT, lane, bad, ph);
+            else if (it == Tn) {
+                {
+                    const int row = lane < KC_NB ? lane : 30, crow = lane < KC_NB ? lane : 15;
+                    const int lim = lane == 30 ? KC_NB : (lane < KC_NB ? lane + 1 : 0);
+                    double b0[KC_NB], c0[KC_NB], c1[KC_NB];
+#pragma unroll
+                    for (int j = 0; j < KC_NB; ++j) { b0[j] = Blk[(size_t)mid * KC_BLK + row * KC_RS + j]; c0[j] = CsT[crow * KC_RS + j]; c1[j] = CsB[crow * KC_RS + j]; }
+#pragma unroll
+                    for (int j = 0; j < KC_NB; ++j) {
+                        double v = b0[j];
+                        if (nT > 0) v -= c0[j];
+                        if (nB > 0) v -= c1[j];
+                        av[j] = j < lim ? v : 0.0;
+                    }
+                }
+                chain_step15<false>(mid, mid, false, av, Blk, CsT, lane, bad);
+            }
+        } else if (wv == 2) {
+            if (it < nB) { const int i = W - 1 - it; chain_step15<true>(i, i - 1, true, av, Blk, CsB, lane, bad); }
+        }
+        __syncthreads();
+    }
+    AR_STAMP(48);
+#ifdef GLIO_DEV_STAMPS
+    if (tid == 0) for (int k = 0; k < 5; ++k) a.dbg[60 + k] = ph[k];
+#endif
+    if ((bad || a.force_fail) && lane == 0) misc[0] = 1;
+    __syncthreads();
+    if (!misc[0]) {
+        auto back = [&](const int i, const int nbr) {
+            const double* Bi = Blk + (size_t)i * KC_BLK;
+            const int ln = lane < KC_NB ? lane : 0;
+            double lcol[KC_NB], bcol[KC_NB];
+#pragma unroll
+            for (int k = 0; k < KC_NB; ++k) { lcol[k] = Bi[k * KC_RS + ln]; bcol[k] = Bi[(KC_NB + k) * KC_RS + ln]; }
+            const double rp = lane < KC_NB ? Bi[31 * KC_RS + lane] : 1.0;
+            double v = lane < KC_NB ? Bi[30 * KC_RS + lane] : 0.0;
+            if (nbr >= 0) {
+                double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+                for (int k = 0; k < KC_NB; k += 3) { s0 += bcol[k] * zb[15 * nbr + k]; s1 += bcol[k + 1] * zb[15 * nbr + k + 1]; s2 += bcol[k + 2] * zb[15 * nbr + k + 2]; }
+                v -= (s0 + s1) + s2;
+            }
+#pragma unroll
+            for (int k = KC_NB - 1; k >= 0; --k) {
+                const double zk = readlane_d(v, k) * readlane_d(rp, k);
+                if (lane == k) v = zk;
+                else if (lane < k) v -= lcol[k] * zk;
+            }
+            if (lane < KC_NB) zb[15 * i + lane] = v;
+            GLIO_WAVE_LDS_SYNC();
+        };
+        if (wv == 0) back(mid, -1);
+        __syncthreads();
+        if (wv == 0) { for (int i = mid - 1; i >= 0; --i) back(i, i + 1); }
+        else if (wv == 1) { for (int i = mid + 1; i < W; ++i) back(i, i - 1); }
+        __syncthreads();
+        double bd2 = 0.0;
+        for (int e = tid; e < nd; e += KC_THREADS) {
+            const int2 sl = eps[e];
+            double v = yd[e];
+            if (sl.x >= 0) {
+#pragma unroll
+                for (int q = 0; q < 15; ++q) { v -= Vs[e * 30 + q] * zb[15 * sl.x + q]; v -= Vs[e * 30 + 15 + q] * zb[15 * sl.y + q]; }
+            }
+            v *= rd[e];
+            a.z[e] = v;
+            if (!isfinite(v)) bd2 = 1.0;
+        }
+        for (int k = tid; k < 15 * W; k += KC_THREADS) { const double v = zb[k]; a.z[nd + k] = v; if (!isfinite(v)) bd2 = 1.0; }
+        if (bd2 != 0.0) misc[0] = 1;
+        __syncthreads();
+    }
+    if (tid == 0) { *a.flag = misc[0] ? 1 : 2; }
+    __threadfence();
+    __syncthreads();
+    AR_STAMP(49);
+    }   // !dec.reuse
+    // ---- the linear solve's result (or the dense fallback) and the dogleg step, as k_tr_finish
+    ChainBuilder cb;
+    cb.G = &G; cb.T = &T; cb.cur = dec.cur;
+    tr_factor_body(tr, cb);
+    __syncthreads();
+    AR_STAMP(50);
+    tr_dogleg_body(tr);
+    AR_STAMP(51);
+}
+
+size_t glio_tr_step_lds_bytes(int n) { return tr_step_lds_doubles(n) * sizeof(double); }
+
+// The gather tables of k_chain_step, from the host's mirror of the factor graph (IMU edge slots, GNSS groups, prior index):
+// per keyframe a ChainKf descriptor, then the prior index.  Rebuilt when a set_* call changed the structure; the copy is
+// asynchronous on the context's stream, ahead of the kernels that read it.
+void glio_chain_tabs_upload(glio_ctx* c) {
+    const int W = c->W;
+    hipStreamSynchronize(c->stream);                 // a copy out of the pinned buffer may still be queued (rare: only when dirty)
+    ChainKf* kd = reinterpret_cast<ChainKf*>(c->h_chain_tabs);
+    short* pidx = c->h_chain_tabs + 8 * W;
+    for (int i = 0; i < W; ++i) { ChainKf d; d.e0 = d.e1 = d.k0 = d.k1 = d.kp = -1; d.o0 = d.o1 = 0; d.pad_ = 0; kd[i] = d; }
+    for (int k = 0; k < c->n_imu; ++k) {
+        const int si = c->h_imu_slot[k];
+        if (si < 0 || si + 1 >= W) continue;
+        kd[si].e0 = (short)k; kd[si + 1].e1 = (short)k;
+    }
+    for (int k = 0; k < c->n_groups; ++k) {          // ascending group index: the order k_assemble adds the groups in
+        const int sa = c->h_groups[k].slot_i, sb = c->h_groups[k].slot_j;
+        for (int side = 0; side < 2; ++side) {
+            const int sl = side == 0 ? sa : sb;
+            if (sl < 0 || sl >= W) continue;
+            if (kd[sl].k0 < 0) { kd[sl].k0 = (short)k; kd[sl].o0 = side == 0; }
+            else if (kd[sl].k1 < 0) { kd[sl].k1 = (short)k; kd[sl].o1 = side == 0; }
+        }
+        if (sb == sa + 1 && sa >= 0 && sa < W) kd[sa].kp = (short)k;
+    }
+    for (int k = 0; k < 15 * W; ++k) pidx[k] = (short)c->h_prior_index[k];
+    hipMemcpyAsync(c->d_chain_tabs, c->h_chain_tabs, (size_t)(8 + 15) * W * sizeof(short), hipMemcpyHostToDevice, c->stream);
+    // the structure changed: slices of sources that no longer exist must read as zero
+    hipMemsetAsync(c->d_chain_src, 0, 2 * (size_t)W * GLIO_CS_SOURCES * GLIO_CS_STRIDE * 8, c->stream);
+    c->chain_tabs_dirty = 0;
+}
+
+// which factorisation the trust-region step of this context takes for a state with n_ddt clock-drift unknowns:
+// 2 = keyframe chain (k_chain_step, no dense H), 1 = arrow, 0 = dense
+int glio_solver_path(const glio_ctx* c, int n_ddt) {
+    const int n = 15 * c->W + n_ddt;
+    const int np = 6 * c->W, K = n - np;
+    const size_t lds_fwd = arrow_forward_lds_doubles(c->W, n_ddt) * 8;
+    const size_t slv_tail = ((size_t)(TR_NB + 1) * TR_PS + np + (np & 1) + 48 + arrow_solve_extra_doubles(c->W, K)) * 8;
+    const size_t lds_pk = pk_doubles(np) * 8 + slv_tail;
+    const bool lds_chol = lds_pk <= 160 * 1024;
+    const size_t lds_slv = lds_chol ? lds_pk : glio_tr_step_lds_bytes(np) + arrow_solve_extra_doubles(c->W, K) * 8;
+    const bool arrow = c->arrow.mode >= 1 && c->arrow.gnss_ok && c->arrow.prior_ok && c->arrow.max_epoch < n_ddt && lds_fwd <= 160 * 1024 && lds_slv <= 160 * 1024;
+    const size_t lds_chain = c->arrow.mode == 3 ? chain_lds_doubles(c->W, n_ddt) * 8 + 8 * 1024 : chain_step_lds_bytes(c->W, n_ddt, n) + 2 * 1024;
+    const bool chain = c->arrow.mode >= 1 && c->arrow.gnss_chain && c->arrow.prior_chain && c->arrow.max_epoch < n_ddt && lds_chain <= 158 * 1024;
+    return chain ? 2 : (arrow ? 1 : 0);
+}
+// the linearisation must also build the dense H (k_assemble) unless the step is k_chain_step
+int glio_solver_needs_dense_H(const glio_ctx* c, int n_ddt) { return !(glio_solver_path(c, n_ddt) == 2 && c->arrow.mode != 3); }
 
 void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
     TrArgs a;
@@ -1665,9 +2248,11 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
     const size_t lds_pk = pk_doubles(np) * 8 + slv_tail;
     const bool lds_chol = lds_pk <= 160 * 1024;
     const size_t lds_slv = lds_chol ? lds_pk : glio_tr_step_lds_bytes(np) + arrow_solve_extra_doubles(c->W, K) * 8;
-    const bool arrow = c->arrow.mode >= 1 && c->arrow.gnss_ok && c->arrow.prior_ok && c->arrow.max_epoch < n_ddt && lds_fwd <= 160 * 1024 && lds_slv <= 160 * 1024;
+    const int path = glio_solver_path(c, n_ddt);
+    const bool chain = path == 2, arrow = path >= 1;       // (arrow is only consulted when !chain)
+    const bool legacy_chain = chain && c->arrow.mode == 3;   // assemble + k_chain_solve + k_tr_finish (kept as the cross-check of k_chain_step)
     const size_t lds_chain = chain_lds_doubles(c->W, n_ddt) * 8;
-    const bool chain = c->arrow.mode >= 1 && c->arrow.gnss_chain && c->arrow.prior_chain && c->arrow.max_epoch < n_ddt && lds_chain <= 150 * 1024;
+    a.hd0 = nullptr; a.hd1 = nullptr;
     a.perm_mode = chain ? 1 : 0;
     c->arrow.last_path = chain ? 2 : (arrow ? 1 : 0);
     a.arrow_flag = (arrow || chain) ? c->arrow.d_flag : nullptr; a.arrow_z = c->arrow.d_z;
@@ -1680,6 +2265,20 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
         ChainArgs r;
         r.W = c->W; r.n = a.n; r.nd = n_ddt; r.ep_slots = c->arrow.d_ep_slots; r.ep_off = c->arrow.d_ep_off; r.ep_list = c->arrow.d_ep_list;
         r.z = c->arrow.d_z; r.flag = c->arrow.d_flag; r.status = c->d_status; r.dbg = c->arrow.d_dbg; r.force_fail = c->arrow.mode == 2;
+        if (!legacy_chain) {
+            GatherArgs G;
+            G.lidar_partials = c->d_lidar_partials; G.lidar_pstride = glio_partials_stride(c); G.lidar_nb = c->last_k3_nb;
+            G.imu_blocks = c->d_imu_blocks; G.gnss_blocks = c->d_gnss_blocks; G.ddt_blocks = c->d_ddt_blocks;
+            G.gnss_stride = c->W * c->W; G.ddt_stride = c->n_ddt_max > 0 ? c->n_ddt_max : 1;
+            G.n_imu = c->n_imu; G.n_groups = c->n_groups; G.has_prior = c->prior_n > 0; G.np = c->prior_n;
+            G.pH = c->d_prior_H; G.pg = c->d_prior_g; G.pcost = c->d_prior_cost;
+            G.tabs = c->d_chain_tabs; G.chain_src = c->d_chain_src;
+            G.hd0 = c->d_hdiag[0]; G.hd1 = c->d_hdiag[1]; G.g0 = c->d_g[0]; G.g1 = c->d_g[1]; G.c0 = c->d_cost[0]; G.c1 = c->d_cost[1];
+            a.hd0 = c->d_hdiag[0]; a.hd1 = c->d_hdiag[1];
+            a.fused_chain = 2;
+            hipLaunchKernelGGL(k_chain_step, dim3(1), dim3(KC_THREADS), chain_step_lds_bytes(c->W, n_ddt, a.n), c->stream, r, a, G);
+            return;                                   // the one launch is the whole step
+        }
         hipLaunchKernelGGL(k_chain_solve, dim3(1), dim3(KC_THREADS), lds_chain, c->stream, r, a);
     } else if (arrow) {
         ArrowArgs r;
@@ -1890,13 +2489,18 @@ extern "C" int glio_debug_chol_solve(glio_ctx* c, int n, const double* A, const 
     return ok ? GLIO_OK : GLIO_E_NUMERIC;
 }
 
-void glio_tr_step_configure(size_t max_lds) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_tr_finish), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_test), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_marg_schur), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_arrow_forward), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_arrow_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(max_lds - 1024));
+int glio_tr_step_configure(size_t max_lds) {
+#define TR_CONF_(kernel, bytes) do { const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+        if (e_ != hipSuccess) { (void)hipGetLastError(); glio_set_error("hipFuncSetAttribute(%s, %d B of dynamic LDS) failed: %s", #kernel, (int)(bytes), hipGetErrorString(e_)); return GLIO_E_HIP; } } while (0)
+    TR_CONF_(k_tr_finish, max_lds);
+    TR_CONF_(k_chol_test, max_lds);
+    TR_CONF_(k_marg_schur, max_lds);
+    TR_CONF_(k_arrow_forward, max_lds);
+    TR_CONF_(k_arrow_solve, max_lds);
+    TR_CONF_(k_chain_solve, max_lds - 1024);
+    TR_CONF_(k_chain_step, max_lds - 2048);
+#undef TR_CONF_
+    return GLIO_OK;
 }
 
 extern "C" int glio_debug_read_vec(glio_ctx* c, int k, double* out, int n) {

@@ -36,7 +36,7 @@ def load(path):
     return acc
 sq, fe, wr = load("gpurun_out/c5_sq.csv"), load("gpurun_out/c5_fetch.csv"), load("gpurun_out/c5_write.csv")
 out = {"source": "rocprofv3 --pmc (separate passes: SQ counters | FETCH_SIZE | WRITE_SIZE) and --kernel-trace --stats of `python scripts/c5_launch.py`; "
-                 "FETCH_SIZE x2 (gfx950 wide-read correction), KB -> bytes; MfmaUtil = sum(SQ_VALU_MFMA_BUSY_CYCLES) / (GRBM_GUI_ACTIVE x 1024 SIMDs)"}
+                 "FETCH_SIZE x2 (gfx950 wide-read correction), KB -> bytes; MfmaUtil = sum(SQ_VALU_MFMA_BUSY_CYCLES) / ((GRBM_GUI_ACTIVE / 8 XCDs) x 1024 SIMDs)"}
 for tag, key, bpr in (("f32_mfma", "k_lidar_linearize_f32", 32), ("f64", "k_lidar_linearize<", 40)):
     ks = [k for k in sq if key in k]
     if not ks:
@@ -47,7 +47,12 @@ for tag, key, bpr in (("f32_mfma", "k_lidar_linearize_f32", 32), ("f64", "k_lida
     for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_MFMA", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"):
         e[c] = mean(sq, c)
     if e.get("GRBM_GUI_ACTIVE"):
-        e["mfma_util_pct"] = 100.0 * (e["SQ_VALU_MFMA_BUSY_CYCLES"] or 0.0) / (e["GRBM_GUI_ACTIVE"] * 1024)
+        # rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs (1.59 M for an 84.6 us launch = 8 x 199 k cycles at
+        # 2.35 GHz); MFMA busy cycles are summed over the 1024 SIMDs
+        cyc = e["GRBM_GUI_ACTIVE"] / 8.0
+        e["gpu_cycles_per_launch"] = cyc
+        e["mfma_util_pct"] = 100.0 * (e["SQ_VALU_MFMA_BUSY_CYCLES"] or 0.0) / (cyc * 1024)
+        e["valu_insts_per_wave64_of_residuals"] = (e["SQ_INSTS_VALU"] or 0.0) / (50 * 262144 / 64.0)
         e["mfma_flop_from_counter"] = (e["SQ_INSTS_VALU_MFMA_MOPS_F32"] or 0.0) * 512
     f = mean(fe, "FETCH_SIZE"); w = mean(wr, "WRITE_SIZE")
     e["fetch_bytes_per_launch"] = 2.0 * f * 1024 if f else None

@@ -383,3 +383,29 @@ def test_keyframe_chain_solver_equals_dense(hip, po, steady_window, use_gnss):
     ctx.close()
     assert mf.iterations == md.iterations and mf.termination == md.termination
     assert np.abs(sf.trans - sd.trans).max() <= 1e-10 and np.abs(sf.quat - sd.quat).max() <= 1e-11
+
+
+@pytest.mark.parametrize("use_gnss", [True, False], ids=["gnss", "no_gnss"])
+def test_chain_step_is_bit_identical_to_the_assembled_sequence(hip, steady_window, use_gnss):
+    """k_chain_step gathers H, g and the cost from the factor blocks with the sums k_assemble would have formed, in the same
+    order, so the one-launch step must reproduce the legacy sequence [k_assemble, k_chain_solve, k_tr_finish] bit for bit:
+    states, iteration history, costs -- here over repeated solves and after a re-linearisation through glio_linearize."""
+    win, corr = steady_window
+    out = []
+    for mode in (3, 1):
+        ctx = hip.Context(win.opts)
+        hip.load().glio_debug_set_solver(ctx._h, mode)
+        ctx.load_window(win, corr, use_gnss=use_gnss)
+        st = _state_for(win, use_gnss)
+        runs = []
+        for k in range(3):
+            s, m = ctx.solve(st)
+            runs.append((s.trans.tobytes(), s.quat.tobytes(), s.speed_bias.tobytes(), s.rcv_ddt[:s.n_ddt].tobytes(), m.iterations, m.successful_steps,
+                         m.termination, m.initial_cost, m.final_cost, m.final_radius, m.gradient_max_norm))
+            if k == 0:
+                ctx.linearize(st)            # the dense assembly in between must not disturb the block-fed step
+        assert hip.load().glio_debug_solver_path(ctx._h) == 2
+        out.append(runs)
+        ctx.close()
+    assert out[0][0] == out[0][1] == out[0][2]
+    assert out[1] == out[0]
