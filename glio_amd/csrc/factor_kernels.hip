@@ -69,7 +69,13 @@ struct ImuLds { double Jg[15 * IMU_GC], Jl[15 * 30], WJ[15 * 30], S[225], r[15],
 __device__ __forceinline__ void imu_block(const double gravity, const double* __restrict__ pPi, const double* __restrict__ pQi,
                           const double* __restrict__ pSBi, const double* __restrict__ pPj, const double* __restrict__ pQj,
                           const double* __restrict__ pSBj, const ImuEdgeDev& e, PairBlock* out, double* eval_out, const int marg, unsigned char* pool,
-                          double* cs_a = nullptr, double* cs_b = nullptr) {
+                          double* cs_a = nullptr, double* cs_b = nullptr, long long* stamp_dbg = nullptr) {
+#ifdef GLIO_DEV_STAMPS
+#define IMU_STAMP(k) do { if (stamp_dbg && threadIdx.x == 0) stamp_dbg[k] = wall_clock64(); } while (0)
+#else
+#define IMU_STAMP(k) do { } while (0)
+#endif
+    IMU_STAMP(0);
     // LDS comes from the caller's pool: the roles of the small-factor kernel overlay one another (a workgroup has one role)
     ImuLds& lds_ = *reinterpret_cast<ImuLds*>(pool);
     double (&Jg)[15 * IMU_GC] = lds_.Jg; double (&Jl)[15 * 30] = lds_.Jl; double (&WJ)[15 * 30] = lds_.WJ;
@@ -131,6 +137,7 @@ __device__ __forceinline__ void imu_block(const double gravity, const double* __
         for (int k = 0; k < 3; ++k) { r[O_BA + k] = Baj[k] - Bai[k]; r[O_BG + k] = Bgj[k] - Bgi[k]; }
     }
     __syncthreads();
+    IMU_STAMP(1);
 
     // ---- global Jacobians, one parameter block per role (ImuFactor.h:63-167).  The roles run different code, so they are
     //      spread over the four wavefronts (lane 0 of each): inside one wavefront they would execute one after the other.
@@ -197,6 +204,7 @@ __device__ __forceinline__ void imu_block(const double gravity, const double* __
         for (int p = 0; p < 3; ++p) { Jg[(O_BA + p) * IMU_GC + 23 + 3 + p] = 1.0; Jg[(O_BG + p) * IMU_GC + 23 + 6 + p] = 1.0; }
     }
     __syncthreads();
+    IMU_STAMP(2);
 
     if (eval_out) {
         for (int idx = tid; idx < 15 * IMU_GC; idx += SF_THREADS) {
@@ -228,6 +236,7 @@ __device__ __forceinline__ void imu_block(const double gravity, const double* __
         Jl[idx] = v;
     }
     __syncthreads();
+    IMU_STAMP(3);
     // ---- whitening by sqrt_info (ImuFactor.h:47,69,97,...)
     for (int idx = tid; idx < 450; idx += SF_THREADS) {
         const int rr = idx / 30, c = idx % 30;
@@ -242,6 +251,7 @@ __device__ __forceinline__ void imu_block(const double gravity, const double* __
         wr[tid] = s;
     }
     __syncthreads();
+    IMU_STAMP(4);
     for (int idx = tid; idx < 900; idx += SF_THREADS) {
         const int p = idx / 30, c = idx % 30;
         double s = 0;
@@ -265,6 +275,7 @@ __device__ __forceinline__ void imu_block(const double gravity, const double* __
         out->cost = 0.5 * s;
         out->slot_a = i; out->slot_b = j;
     }
+    IMU_STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -281,6 +292,7 @@ struct GnssLds {
     double dE[DOP_CHUNK * 16];            // per row: 13 Jacobian entries, corrected residual, rho, 1
     double s_cost[2];
     double sH6[36];                       // the DD part of the pair block, for the chain-layout slices
+    double dpart[DD_CHUNK][44];           // per-factor parts of the DD reduction
     DopRun s_runs[GN_MAX_RUNS];
     int s_nw[DD_CHUNK], s_m[DD_CHUNK];
 };
@@ -383,12 +395,21 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
         __syncthreads();
         // every reducing lane runs the SAME loop, a dot product of two columns of the whitened rows (no divergence inside
         // the wavefront): (u, v) -> H6, (u, residual) -> g6, (residual, residual) -> 2 cost
+        // one lane per (factor, entry): 43 entries (36 of H6, 6 of g6, the cost) x up to DD_CHUNK factors, each a dot product of
+        // two columns of the factor's whitened rows; then 43 lanes add the factors' parts in factor order (the association of the
+        // sequential formulation: rows inside a factor first, factors after)
+        for (int p2 = tid; p2 < nf * 43; p2 += SF_THREADS) {
+            const int q = p2 / 43, cb = p2 - 43 * q;
+            const int ua = cb < 36 ? cb / 6 : (cb < 42 ? cb - 36 : 6), ub = cb < 36 ? cb % 6 : 6;
+            const int nw = s_nw[q];
+            double sacc = 0;
+            for (int r2 = 0; r2 < nw; ++r2) sacc += wE[q][r2 * 8 + ua] * wE[q][r2 * 8 + ub];
+            lds_.dpart[q][cb] = sacc;
+        }
+        __syncthreads();
         if (tid < 43) {
-            const int ua = tid < 36 ? tid / 6 : (tid < 42 ? tid - 36 : 6), ub = tid < 36 ? tid % 6 : 6;
             for (int q = 0; q < nf; ++q) {
-                const int nw = s_nw[q];
-                double sacc = 0;
-                for (int r2 = 0; r2 < nw; ++r2) sacc += wE[q][r2 * 8 + ua] * wE[q][r2 * 8 + ub];
+                const double sacc = lds_.dpart[q][tid];
                 if (tid < 36) h6 += sacc; else if (tid < 42) g6 += sacc; else cost_dd += 0.5 * sacc;
             }
         }
@@ -473,6 +494,13 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
                 if (rb >= re) continue;
                 double s0 = 0, s1 = 0;
                 int r2 = rb;
+                for (; r2 + 8 <= re; r2 += 8) {        // eight rows' reads in flight; the two partial sums keep their even / odd rows
+                    double xa[8], xb[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { xa[u] = dE[(r2 + u) * 16 + ua]; xb[u] = dE[(r2 + u) * 16 + ub]; }
+#pragma unroll
+                    for (int u = 0; u < 8; u += 2) { s0 += xa[u] * xb[u]; s1 += xa[u + 1] * xb[u + 1]; }
+                }
                 for (; r2 + 2 <= re; r2 += 2) { s0 += dE[r2 * 16 + ua] * dE[r2 * 16 + ub]; s1 += dE[(r2 + 1) * 16 + ua] * dE[(r2 + 1) * 16 + ub]; }
                 if (r2 < re) s0 += dE[r2 * 16 + ua] * dE[r2 * 16 + ub];
                 double sacc = s0 + s1;
@@ -689,7 +717,7 @@ __device__ void small_factors_body(const SmallArgs& a) {
         const int si = a.imu[b].slot_i, sj = si + 1, W = a.W;
         imu_block(a.gravity, x + 3 * si, x + 3 * W + 4 * si, x + 7 * W + 9 * si, x + 3 * sj, x + 3 * W + 4 * sj, x + 7 * W + 9 * sj,
                   a.imu[b], a.imu_blocks + (size_t)which * a.W + b, nullptr, a.marg, pool,
-                  a.marg ? nullptr : chain_slice(a, which, si, 0), a.marg ? nullptr : chain_slice(a, which, sj, 1));
+                  a.marg ? nullptr : chain_slice(a, which, si, 0), a.marg ? nullptr : chain_slice(a, which, sj, 1), (b == 0 && a.dbg) ? a.dbg + 190 : nullptr);
         return;
     }
     b -= a.n_imu;
@@ -720,7 +748,17 @@ __global__ __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     static_assert(SF_THREADS == GLIO_K3_THREADS, "one block size for both roles");
     __shared__ __attribute__((aligned(16))) float k3f_tile[F32 ? (GLIO_K3_THREADS / GLIO_WAVE) * K3F_TILE_FLOATS : 4];
     __shared__ double k3f_red[F32 ? (GLIO_K3_THREADS / GLIO_WAVE) * 72 : 1];
+#ifdef GLIO_DEV_STAMPS
+    if ((int)blockIdx.x < k.n_small) {          // per-workgroup duration of the small-factor roles (scripts/small_time.py)
+        const long long t0 = wall_clock64();
+        small_factors_body(a);
+        __syncthreads();
+        if (threadIdx.x == 0 && a.dbg && blockIdx.x < 190) a.dbg[blockIdx.x] = wall_clock64() - t0;
+        return;
+    }
+#else
     if ((int)blockIdx.x < k.n_small) { small_factors_body(a); return; }
+#endif
     int which = a.fixed_which;
     if (a.use_status) {
         if (a.st->done || !a.st->cand_pending) return;

@@ -105,6 +105,27 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
     for (int k = 0; k < TR_WAVES; ++k) s += red[k];
     return s;
 }
+// N sums through ONE pair of barriers: the same butterfly, the same inter-wave order per value as block_sum, so each result is
+// bit-identical to a separate block_sum call.  red needs N * TR_WAVES doubles.
+template <int N>
+__device__ __forceinline__ void block_sum_n(double (&v)[N], double* red) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = wave_sum(v[k]);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) red[k * TR_WAVES + wv] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double s = 0;
+#pragma unroll
+        for (int w = 0; w < TR_WAVES; ++w) s += red[k * TR_WAVES + w];
+        v[k] = s;
+    }
+}
 __device__ __forceinline__ double block_max(double v, double* red) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
@@ -452,8 +473,7 @@ __device__ __forceinline__ bool tr_prepare_body(const TrArgs& a, TrDecision* out
             const double* xn = cand ? a.x1 : a.x0;
             double d2 = 0, x2 = 0;
             for (int k = tid; k < nx; k += TR_THREADS) { const double d = xc[k] - xn[k]; d2 += d * d; x2 += xc[k] * xc[k]; }
-            d2 = block_sum(d2, red);
-            x2 = block_sum(x2, red);
+            { double v2[2] = {d2, x2}; block_sum_n<2>(v2, red); d2 = v2[0]; x2 = v2[1]; }
             if (tid == 0) {
                 const double ccost = *(cand ? a.c1 : a.c0);
                 const double step_norm = sqrt(d2), x_norm = sqrt(x2);
@@ -520,7 +540,9 @@ __device__ __forceinline__ bool tr_prepare_body(const TrArgs& a, TrDecision* out
     // The solve goes on: only now is the host told to enqueue the next kernel group (it then has this whole step, ~70 us,
     // to do so).  Announcing the group at its start instead made the host queue one group beyond the last useful one
     // every time: ~9 empty launches (~20 us) between back-to-back solves.
-    if (tid == 0) { a.progress[0] = (s.solve_id << 16) | s.group; __threadfence_system(); }
+    // (a plain store to host-coherent memory: it leaves the GPU at once; a system-scope fence here would only stall this workgroup
+    // ~1 us until the write is acknowledged across PCIe)
+    if (tid == 0) { *reinterpret_cast<volatile int*>(a.progress) = (s.solve_id << 16) | s.group; }
     if (a.lm && tid == 0) s.mu = 1.0 / s.radius;      // (Hs + D^2 / radius) y = gs
     __syncthreads();
 
@@ -625,8 +647,7 @@ __device__ __forceinline__ void tr_factor_body(const TrArgs& a, const Builder& b
     // Cauchy step length alpha = |g~|^2 / (u^T H u)
     double p = 0, q2 = 0;
     for (int i = tid; i < n; i += TR_THREADS) { p += u[i] * t[i]; q2 += grad[i] * grad[i]; }
-    p = block_sum(p, red);
-    q2 = block_sum(q2, red);
+    { double v2[2] = {p, q2}; block_sum_n<2>(v2, red); p = v2[0]; q2 = v2[1]; }
     if (tid == 0) { a.status->alpha = q2 / p; *smu = f_mu; }
     __syncthreads();
     bool solved = false;
@@ -700,7 +721,7 @@ __device__ __forceinline__ void tr_dogleg_body(const TrArgs& a) {
     double* wvec = V_W(a);
     double gg = 0, nn = 0, gd = 0;
     for (int i = tid; i < n; i += TR_THREADS) { gg += grad[i] * grad[i]; nn += gn[i] * gn[i]; gd += grad[i] * gn[i]; }
-    gg = block_sum(gg, red); nn = block_sum(nn, red); gd = block_sum(gd, red);
+    { double v3[3] = {gg, nn, gd}; block_sum_n<3>(v3, red); gg = v3[0]; nn = v3[1]; gd = v3[2]; }
     const double gnorm = sqrt(gg), gnn = sqrt(nn), radius = s.radius, alpha = s.alpha;
     double ca, cb, snorm;       // step (D-space) = ca * grad + cb * gn
     if (a.lm) { ca = 0.0; cb = 1.0; snorm = gnn; }        // Levenberg-Marquardt: the damped step itself
@@ -730,7 +751,7 @@ __device__ __forceinline__ void tr_dogleg_body(const TrArgs& a) {
         lin += gs * step_s;
         quad += step_s * hs_step;
     }
-    sn2 = block_sum(sn2, red); lin = block_sum(lin, red); quad = block_sum(quad, red);
+    { double v3[3] = {sn2, lin, quad}; block_sum_n<3>(v3, red); sn2 = v3[0]; lin = v3[1]; quad = v3[2]; }
     if (snorm < 0) snorm = sqrt(sn2);
     const double mcc = -(lin + 0.5 * quad);
     const bool valid = mcc > 0.0 && !s.lin_fail;

@@ -21,3 +21,6 @@ print("prior blocks", v[38:47].round(1))
 print("full_linearize", ctx.time_kernel(1, 30) * 1e3, " stream_read", ctx.time_kernel(6, 50) * 1e3, " k3", ctx.time_kernel(0, 50) * 1e3)
 g = np.array(list(st))[264:272]
 print("gnss block 0 stamps (us): dd loads+compute, sync, dd rest, dop compute, sync, dop reduce, scatter:", [round((g[k + 1] - g[k]) / 100.0, 2) for k in range(7)])
+im = np.array(list(st))[64 + 190:64 + 196]
+print("imu block 0 stamps (us): common + residual, global-Jacobian roles, local parameterisation, whitening, J^T J + stores:", [round((im[k + 1] - im[k]) / 100.0, 2) for k in range(5)])
+print("linearize_all", ctx.time_kernel(7, 30) * 1e3)
