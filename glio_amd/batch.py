@@ -258,6 +258,15 @@ class BatchStage:
         capi._check(capi.load().glio_batch_step_dev(self._h, C.c_void_p(Hg.data_ptr()), C.c_double(lam), T.dptr(poses), T.dptr(out), C.byref(md)))
         return out, md.value
 
+    def time_solve(self, Hg, lam=1e-4, reps=5):
+        ms = C.c_float()
+        capi._check(capi.load().glio_batch_time_solve(self._h, C.c_void_p(Hg.data_ptr()), C.c_double(lam), reps, C.byref(ms)))
+        return ms.value
+
+    def set_solver(self, mode):
+        """0 = sequential banded Cholesky (one workgroup), 1 = block cyclic reduction (default)."""
+        capi._check(capi.load().glio_batch_debug_set_solver(self._h, mode))
+
     def time_linearize(self, poses, Hg, reps=10):
         poses = np.ascontiguousarray(poses, np.float64)
         ms = C.c_float()

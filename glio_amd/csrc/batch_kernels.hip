@@ -44,9 +44,15 @@ struct glio_batch {
     double* d_delta;           // [K][6]
     double* d_newposes;        // [K][7]
     double* d_scalar;          // [4]
+    double* d_parts;           // per-workgroup parts of the model decrease (summed in fixed order)
     double* h_poses; double* h_scalar;    // pinned
     hipEvent_t ev0, ev1;
+    void* bcr;                 // block-cyclic-reduction solver (batch_solve_kernels.hip); null for bands it does not cover
+    int solver_mode;           // 1 = block cyclic reduction (default when available), 0 = the sequential banded kernels
 };
+void* glio_bcr_create(int K, int band);
+void glio_bcr_destroy(void* h);
+void glio_bcr_solve(void* h, const double* Hg, double lambda, double* delta, int** fail_dev, hipStream_t stream);
 
 __device__ __forceinline__ int gram_idx(int i, int j) {       // packed upper triangle of a symmetric 9x9
     const int a = i < j ? i : j, b = i < j ? j : i;
@@ -460,7 +466,13 @@ __global__ __launch_bounds__(256) void k_batch_apply(const double* __restrict__ 
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(model_dec, -(red[0] + red[1] + red[2] + red[3]));
+    if (threadIdx.x == 0) model_dec[blockIdx.x] = -(red[0] + red[1] + red[2] + red[3]);       // per-workgroup part; k_batch_apply_sum adds them in order
+}
+__global__ void k_batch_apply_sum(const double* __restrict__ parts, const int n, double* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0;
+    for (int k = 0; k < n; ++k) s += parts[k];
+    *out = s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -490,10 +502,20 @@ int glio_batch_create(int device, int K, int band, int64_t max_constraints, glio
     BALLOC(b->d_poses, (size_t)K * 7 * 8); BALLOC(b->d_newposes, (size_t)K * 7 * 8);
     BALLOC(b->d_M, (size_t)K * (band + 1) * 36 * 8); BALLOC(b->d_y, (size_t)K * 6 * 8); BALLOC(b->d_delta, (size_t)K * 6 * 8);
     BALLOC(b->d_scalar, 4 * 8);
+    BALLOC(b->d_parts, (size_t)((K + 255) / 256 + 1) * 8);
     GLIO_HIP_CHECK(hipHostMalloc((void**)&b->h_poses, (size_t)K * 7 * 8));
     GLIO_HIP_CHECK(hipHostMalloc((void**)&b->h_scalar, 4 * 8));
     GLIO_HIP_CHECK(hipEventCreate(&b->ev0)); GLIO_HIP_CHECK(hipEventCreate(&b->ev1));
+    b->bcr = glio_bcr_create(K, band);
+    b->solver_mode = b->bcr ? 1 : 0;
     *out = b;
+    return GLIO_OK;
+}
+
+// test / measurement hook: 0 = sequential banded Cholesky (one workgroup), 1 = block cyclic reduction
+int glio_batch_debug_set_solver(glio_batch* b, int mode) {
+    if (!b || mode < 0 || mode > 1 || (mode == 1 && !b->bcr)) return GLIO_E_ARG;
+    b->solver_mode = mode;
     return GLIO_OK;
 }
 
@@ -501,8 +523,9 @@ void glio_batch_destroy(glio_batch* b) {
     if (!b) return;
     hipSetDevice(b->device);
     hipStreamSynchronize(b->stream);
+    glio_bcr_destroy(b->bcr);
     void* ptrs[] = {b->d_cp, b->d_nc, b->d_score, b->d_pair_i, b->d_pair_j, b->d_pair_off, b->d_pair_rec, b->d_pair_index, b->d_poses,
-                    b->d_newposes, b->d_M, b->d_y, b->d_delta, b->d_scalar};
+                    b->d_newposes, b->d_M, b->d_y, b->d_delta, b->d_scalar, b->d_parts};
     for (void* p : ptrs) if (p) hipFree(p);
     hipHostFree(b->h_poses); hipHostFree(b->h_scalar);
     hipEventDestroy(b->ev0); hipEventDestroy(b->ev1);
@@ -637,6 +660,34 @@ int glio_batch_time_linearize(glio_batch* b, const double* poses, double* Hg_dev
     return GLIO_OK;
 }
 
+// timing hook: average ms of `reps` banded solves (H + lambda diag H) x = g with the selected solver (HIP events on the batch stream)
+int glio_batch_time_solve(glio_batch* b, const double* Hg_dev, double lambda, int reps, float* ms_out) {
+    if (!b || !Hg_dev || reps < 1 || !ms_out) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipSetDevice(b->device));
+    const int K = b->K, band = b->band;
+    int* d_fail = reinterpret_cast<int*>(b->d_scalar + 2);
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) GLIO_HIP_CHECK(hipEventRecord(b->ev0, b->stream));
+        for (int r = 0; r < (pass == 0 ? 1 : reps); ++r) {
+            int* d_fail_bcr = nullptr;
+            if (b->solver_mode == 1) glio_bcr_solve(b->bcr, Hg_dev, lambda, b->d_delta, &d_fail_bcr, b->stream);
+            else {
+                if (BB_ROWS(band) > 64)
+                    hipLaunchKernelGGL(k_batch_factor<true>, dim3(1), dim3(BBF_THREADS), batch_factor_lds_doubles(band) * 8, b->stream, Hg_dev, K, band, lambda, b->d_M, b->d_y, d_fail);
+                else
+                    hipLaunchKernelGGL(k_batch_factor<false>, dim3(1), dim3(BBF_THREADS), batch_factor_lds_doubles(band) * 8, b->stream, Hg_dev, K, band, lambda, b->d_M, b->d_y, d_fail);
+                hipLaunchKernelGGL(k_batch_backsolve, dim3(1), dim3(64), 0, b->stream, b->d_M, b->d_y, K, band, b->d_delta);
+            }
+        }
+        if (pass == 1) GLIO_HIP_CHECK(hipEventRecord(b->ev1, b->stream));
+        GLIO_HIP_CHECK(hipStreamSynchronize(b->stream));
+    }
+    float ms = 0;
+    GLIO_HIP_CHECK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+    *ms_out = ms / reps;
+    return GLIO_OK;
+}
+
 int glio_batch_step_dev(glio_batch* b, const double* Hg_dev, double lambda, const double* poses_in, double* poses_out, double* model_decrease) {
     if (!b || !Hg_dev || !poses_in || !poses_out) return GLIO_E_ARG;
     GLIO_HIP_CHECK(hipSetDevice(b->device));
@@ -645,19 +696,23 @@ int glio_batch_step_dev(glio_batch* b, const double* Hg_dev, double lambda, cons
     GLIO_HIP_CHECK(hipMemcpyAsync(b->d_poses, b->h_poses, (size_t)K * 7 * 8, hipMemcpyHostToDevice, b->stream));
     GLIO_HIP_CHECK(hipMemsetAsync(b->d_scalar, 0, 4 * 8, b->stream));
     int* d_fail = reinterpret_cast<int*>(b->d_scalar + 2);
-    if (BB_ROWS(band) > 64)
+    int* d_fail_bcr = nullptr;
+    if (b->solver_mode == 1) glio_bcr_solve(b->bcr, Hg_dev, lambda, b->d_delta, &d_fail_bcr, b->stream);
+    else if (BB_ROWS(band) > 64)
         hipLaunchKernelGGL(k_batch_factor<true>, dim3(1), dim3(BBF_THREADS), batch_factor_lds_doubles(band) * 8, b->stream, Hg_dev, K, band, lambda, b->d_M, b->d_y, d_fail);
     else
         hipLaunchKernelGGL(k_batch_factor<false>, dim3(1), dim3(BBF_THREADS), batch_factor_lds_doubles(band) * 8, b->stream, Hg_dev, K, band, lambda, b->d_M, b->d_y, d_fail);
-    hipLaunchKernelGGL(k_batch_backsolve, dim3(1), dim3(64), 0, b->stream, b->d_M, b->d_y, K, band, b->d_delta);
-    hipLaunchKernelGGL(k_batch_apply, dim3((K + 255) / 256), dim3(256), 0, b->stream, Hg_dev, b->d_delta, b->d_poses, K, band, b->d_newposes, b->d_scalar);
+    if (b->solver_mode != 1) hipLaunchKernelGGL(k_batch_backsolve, dim3(1), dim3(64), 0, b->stream, b->d_M, b->d_y, K, band, b->d_delta);
+    if (d_fail_bcr) GLIO_HIP_CHECK(hipMemcpyAsync(d_fail, d_fail_bcr, 4, hipMemcpyDeviceToDevice, b->stream));
+    hipLaunchKernelGGL(k_batch_apply, dim3((K + 255) / 256), dim3(256), 0, b->stream, Hg_dev, b->d_delta, b->d_poses, K, band, b->d_newposes, b->d_parts);
+    hipLaunchKernelGGL(k_batch_apply_sum, dim3(1), dim3(64), 0, b->stream, b->d_parts, (K + 255) / 256, b->d_scalar);
     GLIO_HIP_CHECK(hipGetLastError());
     GLIO_HIP_CHECK(hipMemcpyAsync(b->h_poses, b->d_newposes, (size_t)K * 7 * 8, hipMemcpyDeviceToHost, b->stream));
     GLIO_HIP_CHECK(hipMemcpyAsync(b->h_scalar, b->d_scalar, 4 * 8, hipMemcpyDeviceToHost, b->stream));
     GLIO_HIP_CHECK(hipStreamSynchronize(b->stream));
     int fail = 0;
     memcpy(&fail, b->h_scalar + 2, 4);
-    if (fail) { glio_set_error("banded Cholesky breakdown at keyframe %d", fail - 1); return GLIO_E_NUMERIC; }
+    if (fail) { glio_set_error("banded Cholesky breakdown (%s, code %d)", b->solver_mode == 1 ? "block cyclic reduction" : "sequential", fail); return GLIO_E_NUMERIC; }
     memcpy(poses_out, b->h_poses, (size_t)K * 7 * 8);
     if (model_decrease) *model_decrease = b->h_scalar[0];
     return GLIO_OK;

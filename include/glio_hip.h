@@ -197,6 +197,8 @@ int glio_batch_linearize_dev(glio_batch* b, const double* poses, double* Hg_dev)
  * the device and returns poses (+) d; *model_decrease = -(g.d + d^T H d / 2).  poses_out may alias poses_in. */
 int glio_batch_step_dev(glio_batch* b, const double* Hg_dev, double lambda, const double* poses_in, double* poses_out,
                         double* model_decrease);
+/* timing hook: average ms of `reps` banded solves (H + lambda diag H) x = g (HIP events on the batch stream) */
+int glio_batch_time_solve(glio_batch* b, const double* Hg_dev, double lambda, int reps, float* ms_out);
 /* timing hook: average ms of `reps` linearisation launches (HIP events on the batch stream) */
 int glio_batch_time_linearize(glio_batch* b, const double* poses, double* Hg_dev, int reps, float* ms_out);
 

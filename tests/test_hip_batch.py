@@ -115,3 +115,31 @@ def test_batch_lm_reduces_cost_and_recovers_relative_poses():
     rel = lambda P: np.linalg.norm(np.diff(P[:, :3], axis=0) - np.diff(gt[:, :3], axis=0), axis=1).max()
     assert rel(poses) < 0.2 * rel(init)
     st.close()
+
+
+@pytest.mark.parametrize("K,band", [(60, 6), (203, 6), (2000, 6), (50, 12), (301, 12), (37, 3)])
+def test_block_cyclic_reduction_equals_sequential_banded_solve(K, band):
+    """The damped banded solve by block cyclic reduction (batch_solve_kernels.hip: super-blocks of 6 or 12 keyframes, all
+    eliminations of a level in parallel) against the one-workgroup sequential banded Cholesky and, at small K, numpy."""
+    gt, init, ci, cj, cp, nc, score = _problem(K, band, 40 if K > 500 else 200, seed=21 + K)
+    st = batch.BatchStage(K, band, len(ci))
+    st.set_constraints(ci, cj, cp, nc, score)
+    Hg = st.new_hg()
+    st.linearize(init, Hg)
+    lam = 1e-4
+    st.set_solver(1)
+    new1, m1 = st.step(Hg, lam, init)
+    new1b, m1b = st.step(Hg, lam, init)
+    assert np.array_equal(new1, new1b) and m1 == m1b                       # fixed-order sums: bit-identical runs
+    st.set_solver(0)
+    new0, m0 = st.step(Hg, lam, init)
+    d1, d0 = new1[:, :3] - init[:, :3], new0[:, :3] - init[:, :3]
+    assert np.abs(d1 - d0).max() <= 1e-9 * max(1.0, np.abs(d0).max()), np.abs(d1 - d0).max()
+    assert np.abs(new1[:, 3:] - new0[:, 3:]).max() <= 1e-10
+    assert abs(m1 - m0) <= 1e-9 * abs(m0)
+    if K <= 300:
+        Hb, g, cost = batch.unpack_hg(Hg.cpu().numpy(), K, band)
+        H = batch.dense_from_band(Hb, K, band)
+        d = np.linalg.solve(H + np.diag(lam * np.diag(H) + 1e-12), -g.ravel())
+        assert np.allclose(d1, d.reshape(K, 6)[:, :3], rtol=1e-8, atol=1e-10)
+    st.close()
