@@ -649,6 +649,8 @@ def bench_batch_stage(args, rank, local_rank, world, dist, torch):
         dist.barrier()
     t_lin_wall = (_t.perf_counter() - t0) / reps
     k8_ms = st.time_linearize(init, bufs[0], 5)
+    solve_bcr_ms = min(st.time_solve(bufs[0], 1e-4, 5) for _ in range(2))
+    st.set_solver(0); solve_seq_ms = st.time_solve(bufs[0], 1e-4, 1); st.set_solver(1)
     lin(init)
     t0 = _t.perf_counter()
     poses, hist = batch.lm_solve(lin, st.step, init, iterations=3)
@@ -658,6 +660,9 @@ def bench_batch_stage(args, rank, local_rank, world, dist, torch):
             "linearize_kernels_ms": round(k8_ms, 4), "algorithmic_GBps_this_rank": round(len(ci) * 72 / (k8_ms * 1e-3) / 1e9, 1),
             "allreduce_ms": round(float(np.mean(t_ar)), 4) if t_ar else 0.0, "allreduce_MB": round(batch.hg_size(K, band) * 8 / 1e6, 2),
             "linearize_plus_allreduce_wall_ms": round(t_lin_wall * 1e3, 4), "lm_iteration_wall_ms": round(t_lm * 1e3, 3),
+            "banded_solve_ms": round(solve_bcr_ms, 4), "banded_solve": "block cyclic reduction over super-blocks of 6 keyframes (replicated on every rank)",
+            "banded_solve_sequential_one_workgroup_ms": round(solve_seq_ms, 3),
+            "collective": ("torch.distributed all_reduce (backend nccl = RCCL) on the device buffer" if dist is not None else "none (1 rank)"),
             "cost_history": [round(h, 3) for h in hist]}
     st.close()
     return info

@@ -660,6 +660,39 @@ int glio_batch_time_linearize(glio_batch* b, const double* poses, double* Hg_dev
     return GLIO_OK;
 }
 
+// ---- helpers for a host that never includes HIP headers (glio_amd/host/glio_batch_backend.hpp): the reduced buffer lives on
+// the device, the host hands its pointer and the batch stream to the collective (ncclAllReduce) between linearise and step
+int glio_batch_hg_alloc_dev(glio_batch* b, double** out) {
+    if (!b || !out) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipSetDevice(b->device));
+    GLIO_HIP_CHECK(hipMalloc((void**)out, (size_t)glio_batch_hg_size(b->K, b->band) * 8));
+    return GLIO_OK;
+}
+int glio_batch_hg_free_dev(glio_batch* b, double* p) {
+    if (!b) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipSetDevice(b->device));
+    if (p) GLIO_HIP_CHECK(hipFree(p));
+    return GLIO_OK;
+}
+int glio_batch_get_stream(glio_batch* b, void** out) {
+    if (!b || !out) return GLIO_E_ARG;
+    *out = (void*)b->stream;
+    return GLIO_OK;
+}
+int glio_batch_read_dev(glio_batch* b, const double* dev, int64_t first, int64_t n, double* out) {
+    if (!b || !dev || !out || first < 0 || n < 0) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipSetDevice(b->device));
+    GLIO_HIP_CHECK(hipMemcpyAsync(out, dev + first, (size_t)n * 8, hipMemcpyDeviceToHost, b->stream));
+    GLIO_HIP_CHECK(hipStreamSynchronize(b->stream));
+    return GLIO_OK;
+}
+int glio_batch_synchronize(glio_batch* b) {
+    if (!b) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipSetDevice(b->device));
+    GLIO_HIP_CHECK(hipStreamSynchronize(b->stream));
+    return GLIO_OK;
+}
+
 // timing hook: average ms of `reps` banded solves (H + lambda diag H) x = g with the selected solver (HIP events on the batch stream)
 int glio_batch_time_solve(glio_batch* b, const double* Hg_dev, double lambda, int reps, float* ms_out) {
     if (!b || !Hg_dev || reps < 1 || !ms_out) return GLIO_E_ARG;

@@ -50,3 +50,38 @@ def run_demo(path):
             p = ln.split()
             info["resident"] = dict(kept=int(p[1]), iterations=int(p[2]), final_cost=float(p[3]))
     return info, rows[:, :3], rows[:, 3:]
+
+
+DEMO_BATCH = os.path.join(HERE, "host_demo_batch")
+
+
+def build_demo_batch(force=False):
+    """The C++ sharded batch stage (links librccl: ncclAllReduce between linearise and step)."""
+    src = [os.path.join(HERE, "host_demo_batch.cpp"), os.path.join(HERE, "glio_batch_backend.hpp")]
+    if force or not os.path.exists(DEMO_BATCH) or any(os.path.getmtime(s) > os.path.getmtime(DEMO_BATCH) for s in src):
+        subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-D__HIP_PLATFORM_AMD__", src[0], "-I" + os.path.join(HERE, "..", "..", "include"),
+                               "-I/opt/rocm/include", "-L" + os.path.join(HERE, "..", "lib"), "-lglio_hip", "-L/opt/rocm/lib", "-lrccl", "-lamdhip64", "-lpthread",
+                               "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath,/opt/rocm/lib", "-o", DEMO_BATCH])
+    return DEMO_BATCH
+
+
+def write_batch_problem(path, K, band, iterations, poses, ci, cj, cp, nc, score):
+    with open(path, "wb") as f:
+        f.write(np.array([K, band, iterations, 0], np.int32).tobytes())
+        f.write(np.array([len(ci)], np.int64).tobytes())
+        f.write(np.ascontiguousarray(poses, np.float64).tobytes())
+        f.write(np.ascontiguousarray(ci, np.int32).tobytes()); f.write(np.ascontiguousarray(cj, np.int32).tobytes())
+        f.write(np.ascontiguousarray(cp, np.float32).tobytes()); f.write(np.ascontiguousarray(nc, np.float64).tobytes())
+        f.write(np.ascontiguousarray(score, np.float64).tobytes())
+
+
+def run_demo_batch(path, iterations=None, env=None):
+    cmd = [build_demo_batch(), path] + ([str(iterations)] if iterations is not None else [])
+    out = subprocess.run(cmd, capture_output=True, text=True, check=True, env=env).stdout.splitlines()
+    # (RCCL prints its own version banner on stdout: pick our lines by their first word)
+    head = next(ln for ln in out if ln.startswith("batch ")).split()
+    info = {head[i]: head[i + 1] for i in range(1, len(head) - 1, 2)}
+    hist = [float(x) for x in next(ln for ln in out if ln.startswith("cost ")).split()[1:]]
+    rows = np.array([[float(x) for x in ln.split()[2:]] for ln in out if ln.startswith("kf ")])
+    info["raw"] = [ln for ln in out if not ln.startswith("kf ")]
+    return info, hist, rows

@@ -197,6 +197,16 @@ int glio_batch_linearize_dev(glio_batch* b, const double* poses, double* Hg_dev)
  * the device and returns poses (+) d; *model_decrease = -(g.d + d^T H d / 2).  poses_out may alias poses_in. */
 int glio_batch_step_dev(glio_batch* b, const double* Hg_dev, double lambda, const double* poses_in, double* poses_out,
                         double* model_decrease);
+/* For a C++ host that never includes HIP headers (glio_amd/host/glio_batch_backend.hpp): the reduced buffer
+ * [H band | g | cost] as a device allocation, the batch stream to hand to ncclAllReduce between glio_batch_linearize_dev and
+ * glio_batch_step_dev, a read-back of a few of its doubles (the cost is the last one), a stream synchronisation. */
+int glio_batch_hg_alloc_dev(glio_batch* b, double** out_dev);
+int glio_batch_hg_free_dev(glio_batch* b, double* dev);
+int glio_batch_get_stream(glio_batch* b, void** out_hip_stream);
+int glio_batch_read_dev(glio_batch* b, const double* dev, int64_t first, int64_t n, double* out_host);
+int glio_batch_synchronize(glio_batch* b);
+/* 0 = the sequential banded Cholesky (one workgroup), 1 = block cyclic reduction (default where the band permits) */
+int glio_batch_debug_set_solver(glio_batch* b, int mode);
 /* timing hook: average ms of `reps` banded solves (H + lambda diag H) x = g (HIP events on the batch stream) */
 int glio_batch_time_solve(glio_batch* b, const double* Hg_dev, double lambda, int reps, float* ms_out);
 /* timing hook: average ms of `reps` linearisation launches (HIP events on the batch stream) */
