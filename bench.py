@@ -622,19 +622,15 @@ def bench_batch_stage(args, rank, local_rank, world, dist, torch):
     ci, cj, cp, nc, score = batch.make_constraints(gt, lo, hi, per_kf, band, device=dev)
     st = batch.BatchStage(K, band, len(ci), device=local_rank)
     st.set_constraints(ci, cj, cp, nc, score)
-    bufs = [st.new_hg(), st.new_hg()]
-    flip = [0]
     t_ar = []
 
-    def lin(p):
-        flip[0] ^= 1
-        Hg = bufs[flip[0]]
-        st.linearize(p, Hg)
-        if dist is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); dist.all_reduce(Hg, op=dist.ReduceOp.SUM); e1.record(); torch.cuda.synchronize()
-            t_ar.append(e0.elapsed_time(e1))
-        return Hg, float(Hg[-1].item())
+    def timed_allreduce(Hg):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); dist.all_reduce(Hg, op=dist.ReduceOp.SUM); e1.record(); torch.cuda.synchronize()
+        t_ar.append(e0.elapsed_time(e1))
+    drv = batch.ShardedBatchSolve(st, dist, on_allreduce=timed_allreduce if dist is not None else None)   # the driver the gloo tests exercise
+    lin = drv.linearize
+    bufs = drv._bufs
     lin(init); lin(init)                                   # warm-up (RCCL communicator, caches)
     t_ar.clear()
     torch.cuda.synchronize()

@@ -274,6 +274,35 @@ class BatchStage:
         return ms.value
 
 
+class ShardedBatchSolve:
+    """The driver of the sharded stage, the same object on one GPU, on 8 GPUs (RCCL) and in the CPU tests (gloo):
+    `stage` is this rank's lineariser / solver -- anything with new_hg(), linearize(poses, Hg) and step(Hg, lam, poses), i.e.
+    a BatchStage (HIP) or a stand-in -- holding only THIS rank's constraints; `dist` is torch.distributed (or None for one
+    rank).  One all_reduce(SUM) of the [H band | g | cost] buffer per linearisation makes every rank hold the global system,
+    then every rank takes the same step: no other collective."""
+
+    def __init__(self, stage, dist=None, on_allreduce=None):
+        self.stage, self.dist, self.on_allreduce = stage, dist, on_allreduce
+        self._bufs = [stage.new_hg(), stage.new_hg()]
+        self._flip = 0
+        self.allreduces = 0
+
+    def linearize(self, poses):
+        self._flip ^= 1
+        Hg = self._bufs[self._flip]
+        self.stage.linearize(poses, Hg)
+        if self.dist is not None:
+            if self.on_allreduce is not None:
+                self.on_allreduce(Hg)          # (bench.py times the collective here)
+            else:
+                self.dist.all_reduce(Hg, op=self.dist.ReduceOp.SUM)
+            self.allreduces += 1
+        return Hg, float(Hg[-1].item())
+
+    def solve(self, poses0, iterations=10, lam=1e-4):
+        return lm_solve(self.linearize, self.stage.step, poses0, iterations=iterations, lam=lam)
+
+
 def lm_solve(linearize_reduced, step, poses0, iterations=10, lam=1e-4):
     """Damped Gauss-Newton loop of the batch stage.  `linearize_reduced(poses) -> (Hg, cost)` must return the
     ALL-REDUCED buffer (every rank sees the same numbers, so every rank takes the same decisions)."""

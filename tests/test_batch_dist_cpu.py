@@ -122,3 +122,63 @@ def test_two_rank_association_plus_linearisation_equals_single_rank(tmp_path):
     full = _associate_and_linearize(po, scans, poses, ci, cj, K, 2 * rng)
     assert full[-1] > 0, "the synthetic frames must produce constraints"
     assert np.abs(reduced - full).max() <= 1e-9 * np.abs(full).max()
+
+
+# ---- the driver itself (glio_amd.batch.ShardedBatchSolve: the object bench.py runs on the GPUs) on two gloo ranks, with a CPU
+# stand-in for the HIP stage: same interface, lineariser = the oracle, step = a dense numpy solve of the band
+class _OracleStage:
+    def __init__(self, K, band, ci, cj, cp, nc, score):
+        self.K, self.band, self.c = K, band, (ci, cj, cp, nc, score)
+
+    def new_hg(self):
+        return torch.zeros(batch.hg_size(self.K, self.band), dtype=torch.float64)
+
+    def linearize(self, poses, Hg):
+        from oracle import pyoracle as po
+        ci, cj, cp, nc, score = self.c
+        Hb, g, cost = po.batch_linearize(self.K, self.band, np.ascontiguousarray(poses), ci, cj, cp, nc, score)
+        Hg.copy_(torch.from_numpy(np.concatenate([Hb.ravel(), g.ravel(), [cost]])))
+
+    def step(self, Hg, lam, poses):
+        from oracle import pyoracle as po
+        Hb, g, cost = batch.unpack_hg(Hg.numpy(), self.K, self.band)
+        H = batch.dense_from_band(Hb, self.K, self.band)
+        d = np.linalg.solve(H + np.diag(lam * np.diag(H) + 1e-12), -g.ravel()).reshape(self.K, 6)
+        out = poses.copy()
+        out[:, :3] += d[:, :3]
+        for k in range(self.K):
+            out[k, 3:] = po.quat_plus(poses[k, 3:], d[k, 3:])
+        return out, float(-(g.ravel() @ d.ravel() + 0.5 * d.ravel() @ H @ d.ravel()))
+
+
+def _driver_worker(rank, world, port, K, band, per_kf, iters, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gt, init = batch.make_poses(K, seed=6)
+    ci, cj, cp, nc, score = batch.make_constraints(gt, 0, K, per_kf, band, seed=6)       # the global set, cut by source keyframe
+    lo, hi = batch.shard_range(K, rank, world)
+    a0, a1 = int(np.searchsorted(ci, lo, side="left")), int(np.searchsorted(ci, hi, side="left"))
+    stage = _OracleStage(K, band, ci[a0:a1], cj[a0:a1], cp.numpy()[a0:a1], nc.numpy()[a0:a1], score.numpy()[a0:a1])
+    drv = batch.ShardedBatchSolve(stage, dist if world > 1 else None)
+    poses, hist = drv.solve(init, iterations=iters)
+    assert drv.allreduces == (iters + 1 if world > 1 else 0)
+    if rank == 0:
+        np.save(out_path, np.concatenate([poses.ravel(), hist]))
+    if world > 1:
+        dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_driver_two_ranks_equal_one_rank(tmp_path):
+    """ShardedBatchSolve end to end (linearise my shard, one all-reduce, identical step on every rank, accept/reject) on two
+    gloo ranks reproduces the one-rank solve of the same constraint set."""
+    K, band, per_kf, iters = 24, 4, 80, 3
+    outs = []
+    for world in (1, 2):
+        out = str(tmp_path / f"drv{world}.npy")
+        mp.spawn(_driver_worker, args=(world, _free_port(), K, band, per_kf, iters, out), nprocs=world, join=True)
+        outs.append(np.load(out))
+    assert np.abs(outs[0] - outs[1]).max() <= 1e-9 * max(1.0, np.abs(outs[0]).max())
+    hist = outs[0][-(iters + 1):]
+    assert hist[-1] < 0.2 * hist[0]
