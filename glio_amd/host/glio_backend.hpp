@@ -114,6 +114,46 @@ private:
     glio_ctx* ctx_; float cp_[4]; double nc_[6]; double score_;
 };
 
+// Estimator.cpp:2611-2726: copy the solution back into the estimator's members with the reference's sanity gates.
+//   tmpTrans [W][3], tmpQuat [W][4] (w,x,y,z), tmpSpeedBias [W][9], tmp_rcv_dt [W][3] (may be null): the solved blocks
+//   Ps / Vs [W][3], Qs [W][4] (the reference keeps Rs as matrices), para_speed_bias [W][9]                : in/out
+//   Bas / Bgs [W][3], abs_poses [W][7] (q w,x,y,z then t, :2651-2666), rcv_dt [W][3]                       : out, any may be null
+// A component failing its gate keeps its old value (Q14: |dp| < 100, |dq.vec| < 10, |dv| < 100, |db| < 22).  abs_poses takes the
+// RAW solved quaternion, Rs the normalised one (:2661-2669).  The six bias gates are chained by dangling `else`s (the
+// ROS_WARNs between them are commented out, :2689-2722), so only the FIRST bias component that passes is written (Q16).
+// rcv_dt is copied unconditionally (:2645-2647; the blocks carry no residuals, Q6).
+inline void writeBackState(int W, const double* tmpTrans, const double* tmpQuat, const double* tmpSpeedBias, const double* tmp_rcv_dt,
+                           double* Ps, double* Qs, double* Vs, double* para_speed_bias, double* Bas, double* Bgs, double* abs_poses,
+                           double* rcv_dt) {
+    for (int i = 0; i < W; ++i) {
+        const double* t = tmpTrans + 3 * i; const double* q = tmpQuat + 4 * i; const double* sb = tmpSpeedBias + 9 * i;
+        double dp = 0, dv = 0;
+        for (int k = 0; k < 3; ++k) { dp += (Ps[3 * i + k] - t[k]) * (Ps[3 * i + k] - t[k]); dv += (Vs[3 * i + k] - sb[k]) * (Vs[3 * i + k] - sb[k]); }
+        // dq = normalized(tmpQuat)^-1 * Rs ; qnorm = |dq.vec|
+        const double qn = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        const double a[4] = {q[0] / qn, -q[1] / qn, -q[2] / qn, -q[3] / qn};
+        const double* b = Qs + 4 * i;
+        const double vx = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+        const double vy = a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3];
+        const double vz = a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1];
+        const double qnorm = std::sqrt(vx * vx + vy * vy + vz * vz);
+        if (rcv_dt && tmp_rcv_dt) for (int k = 0; k < 3; ++k) rcv_dt[3 * i + k] = tmp_rcv_dt[3 * i + k];
+        if (std::sqrt(dp) < 100) {
+            for (int k = 0; k < 3; ++k) { Ps[3 * i + k] = t[k]; if (abs_poses) abs_poses[7 * i + 4 + k] = t[k]; }
+        }
+        if (qnorm < 10) {
+            for (int k = 0; k < 4; ++k) { Qs[4 * i + k] = q[k] / qn; if (abs_poses) abs_poses[7 * i + k] = q[k]; }
+        }
+        if (std::sqrt(dv) < 100) for (int k = 0; k < 3; ++k) { Vs[3 * i + k] = sb[k]; para_speed_bias[9 * i + k] = sb[k]; }
+        for (int k = 3; k < 9; ++k)
+            if (std::fabs(para_speed_bias[9 * i + k] - sb[k]) < 22) {          // Q16: the first component that passes, and only that one
+                para_speed_bias[9 * i + k] = sb[k];
+                if (k < 6) { if (Bas) Bas[3 * i + k - 3] = sb[k]; } else if (Bgs) Bgs[3 * i + k - 6] = sb[k];
+                break;
+            }
+    }
+}
+
 class SlidingWindowBackend {
 public:
     explicit SlidingWindowBackend(const glio_opts& opts, int device = 0) : opts_(opts), W_(opts.window) {
@@ -221,29 +261,10 @@ public:
         for (int k = 0; k < 9; ++k) tmpSpeedBias[9 * (W_ - 1) + k] = new_sb[k];
     }
 
-    // Estimator.cpp:2611-2726 write-back with the reference's sanity gates.  Ps/Vs: [W][3]; Qs: [W][4] (w,x,y,z,
-    // the reference keeps Rs as matrices); para_speed_bias: [W][9].  Components failing their gate keep the old
-    // value (Q14).  The six bias gates are chained by dangling `else`s in the reference (the ROS_WARNs between
-    // them are commented out, :2689-2722), so only the FIRST bias component that passes is written (Q16).
-    void writeBack(double* Ps, double* Qs, double* Vs, double* para_speed_bias) const {
-        for (int i = 0; i < W_; ++i) {
-            const double* t = &tmpTrans[3 * i]; const double* q = &tmpQuat[4 * i]; const double* sb = &tmpSpeedBias[9 * i];
-            double dp = 0, dv = 0;
-            for (int k = 0; k < 3; ++k) { dp += (Ps[3 * i + k] - t[k]) * (Ps[3 * i + k] - t[k]); dv += (Vs[3 * i + k] - sb[k]) * (Vs[3 * i + k] - sb[k]); }
-            // dq = normalized(tmpQuat)^-1 * Rs ; qnorm = |dq.vec|
-            double qn = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-            const double a[4] = {q[0] / qn, -q[1] / qn, -q[2] / qn, -q[3] / qn};
-            const double* b = &Qs[4 * i];
-            const double vx = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
-            const double vy = a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3];
-            const double vz = a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1];
-            const double qnorm = std::sqrt(vx * vx + vy * vy + vz * vz);
-            if (std::sqrt(dp) < 100) for (int k = 0; k < 3; ++k) Ps[3 * i + k] = t[k];
-            if (qnorm < 10) for (int k = 0; k < 4; ++k) Qs[4 * i + k] = q[k] / qn;
-            if (std::sqrt(dv) < 100) for (int k = 0; k < 3; ++k) { Vs[3 * i + k] = sb[k]; para_speed_bias[9 * i + k] = sb[k]; }
-            for (int k = 3; k < 9; ++k)
-                if (std::fabs(para_speed_bias[9 * i + k] - sb[k]) < 22) { para_speed_bias[9 * i + k] = sb[k]; break; }   // Q16
-        }
+    // Estimator.cpp:2611-2726 write-back with the reference's sanity gates (writeBackState below, on this backend's tmp arrays)
+    void writeBack(double* Ps, double* Qs, double* Vs, double* para_speed_bias, double* Bas = nullptr, double* Bgs = nullptr,
+                   double* abs_poses = nullptr, double* rcv_dt = nullptr, const double* tmp_rcv_dt = nullptr) const {
+        writeBackState(W_, tmpTrans.data(), tmpQuat.data(), tmpSpeedBias.data(), tmp_rcv_dt, Ps, Qs, Vs, para_speed_bias, Bas, Bgs, abs_poses, rcv_dt);
     }
 
     // state, laid out like the reference's double arrays

@@ -79,3 +79,46 @@ def test_streaming_driver_call_sequence():
     be.calls.clear()
     drv.step(None, [None] * W, [])
     assert [c for c in be.calls if not isinstance(c, str)][0][1] == {"n": 1}      # the marginalization result is the next prior
+
+
+def test_write_back_gates_cpp_against_transcription(tmp_path):
+    """glio::writeBackState (glio_amd/host/glio_backend.hpp, Estimator.cpp:2611-2726) compiled with plain g++ and driven with
+    states that trip each gate: |dp| >= 100 keeps Ps and abs_poses t, |dq.vec| >= 10 can never trip for unit quaternions (the
+    gate is vacuous, replicated anyway), |dv| >= 100 keeps Vs, and of the six bias components only the FIRST that passes its
+    |db| < 22 gate is written (dangling else chain, quirk Q16); rcv_dt is copied unconditionally."""
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "glio_amd", "host")
+    exe = str(tmp_path / "wb")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", os.path.join(here, "host_writeback_test.cpp"), "-I" + os.path.join(here, "..", "..", "include"), "-o", exe])
+    rng = np.random.default_rng(5)
+    W = 4
+    tT, tQ, tSB, tDt = rng.normal(size=(W, 3)), rng.normal(size=(W, 4)), rng.normal(size=(W, 9)), rng.normal(size=(W, 3))
+    Ps, Vs, psb = tT + rng.normal(size=(W, 3)), tSB[:, :3] + rng.normal(size=(W, 3)), tSB + rng.normal(size=(W, 9))
+    Qs = tQ / np.linalg.norm(tQ, axis=1, keepdims=True)
+    Ps[1] += 500.0                  # trips the position gate of keyframe 1
+    Vs[2] += 300.0                  # trips the velocity gate of keyframe 2
+    psb[3, 3] += 40.0               # ba_x of keyframe 3 fails -> ba_y is the first to pass and the only one written
+    psb[0, 3:] += 40.0              # every bias component of keyframe 0 fails: nothing written
+    Bas, Bgs, ap, dt = np.full((W, 3), -7.0), np.full((W, 3), -8.0), np.full((W, 7), -9.0), np.zeros((W, 3))
+    arrs = [tT, tQ, tSB, tDt, Ps, Qs, Vs, psb, Bas, Bgs, ap, dt]
+    txt = str(W) + "\n" + "\n".join(" ".join(repr(float(x)) for x in a.ravel()) for a in arrs)
+    out = subprocess.run([exe], input=txt, capture_output=True, text=True, check=True).stdout.splitlines()
+    got = {ln.split()[0]: np.array([float(x) for x in ln.split()[1:]]) for ln in out}
+    # transcription
+    ePs, eQs, eVs, epsb, eBas, eBgs, eap = Ps.copy(), Qs.copy(), Vs.copy(), psb.copy(), Bas.copy(), Bgs.copy(), ap.copy()
+    for i in range(W):
+        if np.linalg.norm(Ps[i] - tT[i]) < 100:
+            ePs[i] = tT[i]; eap[i, 4:] = tT[i]
+        eQs[i] = tQ[i] / np.linalg.norm(tQ[i]); eap[i, :4] = tQ[i]        # |dq.vec| <= 1 < 10 always
+        if np.linalg.norm(Vs[i] - tSB[i, :3]) < 100:
+            eVs[i] = tSB[i, :3]; epsb[i, :3] = tSB[i, :3]
+        for k in range(3, 9):
+            if abs(psb[i, k] - tSB[i, k]) < 22:
+                epsb[i, k] = tSB[i, k]
+                (eBas if k < 6 else eBgs)[i, (k - 3) % 3] = tSB[i, k]
+                break
+    for name, e in (("Ps", ePs), ("Qs", eQs), ("Vs", eVs), ("psb", epsb), ("Bas", eBas), ("Bgs", eBgs), ("abs", eap), ("dt", tDt)):
+        assert np.allclose(got[name], e.ravel(), rtol=1e-15, atol=0), name
+    assert np.array_equal(got["Ps"].reshape(W, 3)[1], Ps[1]) and np.array_equal(got["Vs"].reshape(W, 3)[2], Vs[2])
+    assert got["Bas"].reshape(W, 3)[3, 1] == tSB[3, 4] and got["Bas"].reshape(W, 3)[3, 0] == -7.0 and np.all(got["Bas"].reshape(W, 3)[0] == -7.0)
