@@ -147,6 +147,29 @@ def pair_shard(pair_ci, K, rank, world):
     return int(np.searchsorted(ci, lo, side="left")), int(np.searchsorted(ci, hi, side="left"))
 
 
+def batch_selection_draws(count, res_num, rng, ends=False, rand_set_num=400):
+    """The indices `globalFeatureSelectionAdd_Batch` (Estimator.cpp:4057-4116) keeps of a keyframe pair's `count` records:
+    all of them (None) when count <= batch_feature_res_num (:4077), otherwise the first res_num entries of
+    geneRandArrayNoRepeat(0, count - 1, res_num) -- a shuffle of the indices 0 .. count - 2, so the LAST record is never drawn
+    (random_generator.hpp:79-93: n = high - low values) -- in shuffle order.
+    ends = True: `globalFeatureSelection_Batch` (:3994-4055), used for the first / last search_range keyframes: nothing is
+    selected when count - 1 < res_num or count < 50 -- and there the reference RETURNS, i.e. skips the remaining neighbours
+    of that keyframe too (:4014-4017; the caller sees "stop" = the string 'return') --, the draw is the first res_num of a
+    no-repeat random set of min(rand_set_num, count - 1, count - res_num - 1) indices (the same distribution)."""
+    if not ends:
+        if count <= res_num:
+            return None
+        return rng.permutation(count - 1)[:res_num].astype(np.int64)
+    if count - 1 < res_num or count < 50:
+        return "return"
+    rs = rand_set_num
+    if count - 1 < rs:
+        rs = count - 1
+    if count - res_num < rs:
+        rs = count - res_num - 1
+    return rng.permutation(count - 1)[:min(res_num, max(rs, 0))].astype(np.int64)
+
+
 class BatchAssociation:
     """Device-resident findGlobalCorrespondingSurfFeaturesAdd_Batch: keyframe clouds stay on the GPU, `run` builds the
     pair-major constraint arrays K8 consumes.  No CPU fallback."""
@@ -188,6 +211,29 @@ class BatchAssociation:
         self.pair_count = self.pair_count[:n]
         self.total = tot.value
         return self.pair_count, self.total
+
+    def select(self, res_num, rng, ends_of=None, rand_set_num=400):
+        """Batch feature selection over the pairs of the last run (batch_feature_res_num records per pair at most), gathered on
+        the device.  ends_of: optional predicate idx -> bool marking the source keyframes that take the `_Batch` (ends) rule."""
+        offs = np.concatenate([[0], np.cumsum(self.pair_count)]).astype(np.int64)
+        keep, counts = [], np.zeros(len(self.pair_count), np.int64)
+        stopped = set()
+        for p in range(len(self.pair_count)):
+            c = int(self.pair_count[p])
+            idx = int(self.pair_ci[p])
+            ends = bool(ends_of(idx)) if ends_of is not None else False
+            if ends and idx in stopped:
+                d = None
+            else:
+                d = batch_selection_draws(c, res_num, rng, ends=ends, rand_set_num=rand_set_num)
+                if isinstance(d, str):
+                    stopped.add(idx); d = None
+            sel = np.arange(c, dtype=np.int64) if d is None else d
+            keep.append(offs[p] + sel); counts[p] = len(sel)
+        src = np.ascontiguousarray(np.concatenate(keep) if keep else np.zeros(0, np.int64), np.int64)
+        capi._check(capi.load().glio_bassoc_select(self._h, C.c_int64(len(src)), src.ctypes.data_as(C.POINTER(C.c_int64)) if len(src) else None, C.c_int64(self.total)))
+        self.pair_count, self.total = counts, int(len(src))
+        return src
 
     def read(self, first=0, n=None):
         n = self.total - first if n is None else n

@@ -885,6 +885,8 @@ struct glio_bassoc {
     int b_stride;                             // per-pair stride of the per-workgroup count arrays
     long long* h_pair_off;          // pinned
     double* d_poses;                // [K][7]
+    // feature selection scratch (grow-only): the gathered records and their source indices
+    float4* d_sel_cp; double* d_sel_nc; double* d_sel_score; long long* d_sel_idx; long long sel_cap;
 };
 
 __global__ void k_transform_cloud(const float4* __restrict__ in, int n, const double* __restrict__ pose, float4* __restrict__ out) {
@@ -1004,7 +1006,8 @@ void glio_bassoc_destroy(glio_bassoc* b) {
         for (void* q : p) if (q) hipFree(q);
     }
     void* p[] = {b->d_nn5, b->d_d4, b->d_local, b->d_global, b->d_total, b->d_q_cp, b->d_q_nc, b->d_q_score, b->d_q_flag, b->d_q_pos, b->d_bcount, b->d_boff,
-                 b->d_cp, b->d_nc, b->d_score, b->d_run, b->d_poses, b->d_pair_off, b->d_frames, b->d_pair_ci, b->d_pair_cj};
+                 b->d_cp, b->d_nc, b->d_score, b->d_run, b->d_poses, b->d_pair_off, b->d_frames, b->d_pair_ci, b->d_pair_cj,
+                 b->d_sel_cp, b->d_sel_nc, b->d_sel_score, b->d_sel_idx};
     for (void* q : p) if (q) hipFree(q);
     if (b->h_pair_off) hipHostFree(b->h_pair_off);
     delete[] b->h_n; delete[] b->frames;
@@ -1106,6 +1109,42 @@ int glio_bassoc_results_dev(glio_bassoc* b, const float** cp_dev, const double**
     if (cp_dev) *cp_dev = reinterpret_cast<const float*>(b->d_cp);
     if (nc_dev) *nc_dev = b->d_nc;
     if (score_dev) *score_dev = b->d_score;
+    return GLIO_OK;
+}
+
+// globalFeatureSelectionAdd_Batch / globalFeatureSelection_Batch (Estimator.cpp:4057-4116, 3994-4055): keep, per keyframe pair, the
+// records the caller drew (the reference seeds from std::random_device -- random_generator.hpp:58 -- so the draws stay with the
+// caller, glio_amd/batch.py::batch_selection_draws restates the rules); the gather runs on the device and the pair-major arrays
+// glio_batch_set_constraints_pairs_dev consumes are compacted in place.  src_index [n_keep]: indices into the CURRENT arrays,
+// in the order the kept records shall have (pair after pair).
+__global__ void k_bassoc_gather(const long long* __restrict__ idx, const long long n, const float4* __restrict__ cp, const double* __restrict__ nc,
+                                const double* __restrict__ score, float4* __restrict__ o_cp, double* __restrict__ o_nc, double* __restrict__ o_score) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const long long sidx = idx[k];
+    o_cp[k] = cp[sidx];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) o_nc[6 * k + c] = nc[6 * sidx + c];
+    o_score[k] = score[sidx];
+}
+int glio_bassoc_select(glio_bassoc* b, int64_t n_keep, const int64_t* src_index, int64_t n_current) {
+    if (!b || n_keep < 0 || n_current < 0 || n_current > b->max_con || n_keep > n_current || (n_keep > 0 && !src_index)) return GLIO_E_ARG;
+    BA_CHECK(hipSetDevice(b->device));
+    for (int64_t k = 0; k < n_keep; ++k) if (src_index[k] < 0 || src_index[k] >= n_current) { glio_set_error("selection index %lld out of range", (long long)src_index[k]); return GLIO_E_ARG; }
+    if (n_keep == 0) return GLIO_OK;
+    if (n_keep > b->sel_cap) {
+        if (b->d_sel_cp) { hipFree(b->d_sel_cp); hipFree(b->d_sel_nc); hipFree(b->d_sel_score); hipFree(b->d_sel_idx); }
+        b->sel_cap = n_keep + n_keep / 2 + 1024;
+        BA_CHECK(hipMalloc((void**)&b->d_sel_cp, (size_t)b->sel_cap * 16)); BA_CHECK(hipMalloc((void**)&b->d_sel_nc, (size_t)b->sel_cap * 48));
+        BA_CHECK(hipMalloc((void**)&b->d_sel_score, (size_t)b->sel_cap * 8)); BA_CHECK(hipMalloc((void**)&b->d_sel_idx, (size_t)b->sel_cap * 8));
+    }
+    BA_CHECK(hipMemcpyAsync(b->d_sel_idx, src_index, (size_t)n_keep * 8, hipMemcpyHostToDevice, b->stream));
+    hipLaunchKernelGGL(k_bassoc_gather, dim3((unsigned)((n_keep + 255) / 256)), dim3(256), 0, b->stream, b->d_sel_idx, (long long)n_keep, b->d_cp, b->d_nc, b->d_score,
+                       b->d_sel_cp, b->d_sel_nc, b->d_sel_score);
+    BA_CHECK(hipMemcpyAsync(b->d_cp, b->d_sel_cp, (size_t)n_keep * 16, hipMemcpyDeviceToDevice, b->stream));
+    BA_CHECK(hipMemcpyAsync(b->d_nc, b->d_sel_nc, (size_t)n_keep * 48, hipMemcpyDeviceToDevice, b->stream));
+    BA_CHECK(hipMemcpyAsync(b->d_score, b->d_sel_score, (size_t)n_keep * 8, hipMemcpyDeviceToDevice, b->stream));
+    BA_CHECK(hipStreamSynchronize(b->stream));
     return GLIO_OK;
 }
 

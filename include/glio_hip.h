@@ -231,6 +231,11 @@ int glio_bassoc_set_frame(glio_bassoc* b, int k, const float* scan_xyzi, int n);
 int glio_bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj,
                     int64_t* pair_count_out, int64_t* total_out);
 int glio_bassoc_results_dev(glio_bassoc* b, const float** cp_dev, const double** norm_cent_dev, const double** score_dev);
+/* globalFeatureSelectionAdd_Batch / globalFeatureSelection_Batch (Estimator.cpp:4057-4116, 3994-4055; batch_feature_res_num: 25):
+ * keep records src_index[0..n_keep) of the current n_current records, in that order (pair after pair; the caller updates its
+ * per-pair counts).  The random draws stay with the caller (the reference seeds from std::random_device); the gather runs on
+ * the device, in place.  glio_amd/batch.py::batch_selection_draws restates the draw rules. */
+int glio_bassoc_select(glio_bassoc* b, int64_t n_keep, const int64_t* src_index, int64_t n_current);
 int glio_bassoc_read(glio_bassoc* b, int64_t first, int64_t n, float* cp, double* norm_cent, double* score);
 
 #ifdef __cplusplus

@@ -88,3 +88,39 @@ def test_association_feeds_batch_stage(frames):
     assert np.linalg.norm(g - go) <= 1e-10 * np.linalg.norm(go)
     assert np.linalg.norm(Hb - Ho) <= 1e-10 * np.linalg.norm(Ho)
     st.close(); ba.close()
+
+
+def test_batch_feature_selection_gathers_on_device():
+    """globalFeatureSelectionAdd_Batch (Estimator.cpp:4057-4116): at most batch_feature_res_num = 25 records per keyframe pair,
+    drawn without repetition from all but the last record; the gather runs on the device and the compacted arrays feed K8."""
+    from glio_amd import batch, synth
+    K, pts, rng_s = 5, 900, 2
+    win = synth.make_window(W=K, pts_per_scan=pts, seed=synth.SEED_BASE + 61, perturb=(0.03, 0.2, 0.0), scan_radius=14.0, map_density=1.0)
+    tlb = np.array(win.opts.t_lb, np.float32)
+    poses = np.c_[win.init.trans, win.init.quat]
+    ci, cj = batch.pair_list(K, rng_s)
+    ba = batch.BatchAssociation(K, pts, len(ci) * pts)
+    for k in range(K):
+        sc = win.scans[k].copy(); sc[:, :3] -= tlb
+        ba.set_frame(k, sc)
+    counts, total = ba.run(poses, ci, cj)
+    counts = counts.copy()
+    assert total > 0 and counts.max() > 25
+    before = [a.copy() for a in ba.read()]
+    src = ba.select(25, np.random.default_rng(3))
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    assert all(c == min(25, n) if n > 25 else c == n for c, n in zip(ba.pair_count, counts))
+    after = ba.read()
+    assert all(np.array_equal(a, b[src]) for a, b in zip(after, before))
+    k0 = 0
+    for p, n in enumerate(counts):                              # per pair: distinct indices of that pair, never its last record when drawn
+        s = src[k0:k0 + ba.pair_count[p]] - offs[p]
+        k0 += ba.pair_count[p]
+        assert len(set(s.tolist())) == len(s) and (s >= 0).all() and (s < n).all()
+        if n > 25:
+            assert (s < n - 1).all()
+    st = batch.BatchStage(K, 2 * rng_s, max(ba.total, 1))
+    ba.feed(st)
+    Hg = st.new_hg(); st.linearize(poses, Hg)
+    assert float(Hg[-1].item()) > 0
+    st.close(); ba.close()

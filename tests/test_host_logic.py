@@ -122,3 +122,15 @@ def test_write_back_gates_cpp_against_transcription(tmp_path):
         assert np.allclose(got[name], e.ravel(), rtol=1e-15, atol=0), name
     assert np.array_equal(got["Ps"].reshape(W, 3)[1], Ps[1]) and np.array_equal(got["Vs"].reshape(W, 3)[2], Vs[2])
     assert got["Bas"].reshape(W, 3)[3, 1] == tSB[3, 4] and got["Bas"].reshape(W, 3)[3, 0] == -7.0 and np.all(got["Bas"].reshape(W, 3)[0] == -7.0)
+
+
+def test_batch_selection_draw_rules():
+    from glio_amd import batch
+    rng = np.random.default_rng(1)
+    assert batch.batch_selection_draws(25, 25, rng) is None and batch.batch_selection_draws(3, 25, rng) is None
+    d = batch.batch_selection_draws(40, 25, rng)
+    assert len(d) == 25 and len(set(d.tolist())) == 25 and d.max() <= 38              # the last record (39) is never drawn
+    assert batch.batch_selection_draws(49, 25, rng, ends=True) == "return" and batch.batch_selection_draws(25, 25, rng, ends=True) == "return"
+    d = batch.batch_selection_draws(60, 25, rng, ends=True)
+    assert len(d) == 25 and d.max() <= 58
+    assert len(batch.batch_selection_draws(50, 40, rng, ends=True, rand_set_num=400)) == 9       # rand set clamped to count - res_num - 1
