@@ -147,6 +147,88 @@ def pair_shard(pair_ci, K, rank, world):
     return int(np.searchsorted(ci, lo, side="left")), int(np.searchsorted(ci, hi, side="left"))
 
 
+def delta_q_pairs(odo, search_range, start_idx=0):
+    """The attitude-constraint pairs of optimizeBatch (Estimator.cpp:2831-2891) from the odometry keyframe poses `odo` [K][7]
+    (x y z qw qx qy qz): for every keyframe i, walk backward then forward adding (i, j, const_diff = q_i^-1 q_j) whenever the
+    distance to the last taken keyframe exceeds `5 / search_range` (an INTEGER division in the reference: 0 for search_range > 5).
+    The reference's quirks are kept: `factor_count` is reset only when it reaches search_range, so a backward walk that found
+    fewer leaves its count (and its `p_tmp`) to the forward walk; q_i is sign-unified (w >= 0), q_j is not."""
+    odo = np.asarray(odo, np.float64)
+    K = len(odo)
+    thr = float(5 // search_range)
+    di, dj, dc = [], [], []
+
+    def qmul(a, b):
+        w1, v1, w2, v2 = a[0], a[1:], b[0], b[1:]
+        return np.r_[w1 * w2 - v1 @ v2, w1 * v2 + w2 * v1 + np.cross(v1, v2)]
+
+    for i in range(start_idx, K):
+        qi = odo[i, 3:] * (-1.0 if odo[i, 3] < 0 else 1.0)
+        qi_inv = np.r_[qi[0], -qi[1:]] / (qi @ qi)
+        p_tmp = odo[i, :3]
+        count = 0
+        for walk in (range(i, start_idx - 1, -1), range(i, K)):
+            for j in walk:
+                if count == search_range:
+                    count = 0
+                    break
+                if j == i:
+                    continue
+                if np.linalg.norm(p_tmp - odo[j, :3]) > thr:
+                    p_tmp = odo[j, :3]
+                    di.append(i); dj.append(j); dc.append(qmul(qi_inv, odo[j, 3:]))
+                    count += 1
+    return np.array(di, np.int32), np.array(dj, np.int32), np.array(dc, np.float64).reshape(-1, 4)
+
+
+DDPSR_THRESHOLDS = (1e9, 10.0, 8.0, 6.0)      # Estimator.cpp:2764-2767: iteration_num = 4 rounds of the 7 listed values
+
+
+def make_batch_gnss(gt, seed=20260930, sats_per_sys=10, psr_sigma=1.0, outliers=0.05):
+    """Synthetic double-differenced pseudorange factors of the batch problem: one GNSS epoch between every pair of consecutive
+    keyframes (leftKey = k, rightKey = k + 1, ts_ratio as Estimator.cpp:3100-3130 derives it), two constellations, identity
+    weight and the station position (addDDPsrResFactor_gl, Estimator.cpp:1899-1911); a fraction of the user pseudoranges carries
+    a multipath-like outlier so that the {1e9, 10, 8, 6} threshold rounds have something to down-weight."""
+    from . import synth
+    rng = np.random.default_rng(seed + 9)
+    K = len(gt)
+    frame = T.GlioGnssFrame()
+    frame.yaw_enu_local = 0.0
+    frame.anc_ecef[:] = list(synth.ANCHOR_ECEF)
+    Ree = synth.ecef2rotation(synth.ANCHOR_ECEF)
+    up = synth.ANCHOR_ECEF / np.linalg.norm(synth.ANCHOR_ECEF)
+    east, north = Ree[:, 0], Ree[:, 1]
+    sats = []
+    for _sys in range(2):
+        pos = []
+        while len(pos) < sats_per_sys:
+            el, az = math.radians(rng.uniform(15, 85)), rng.uniform(0, 2 * math.pi)
+            d = math.cos(el) * (math.sin(az) * east + math.cos(az) * north) + math.sin(el) * up
+            b, c = synth.ANCHOR_ECEF @ d, synth.ANCHOR_ECEF @ synth.ANCHOR_ECEF - 26560e3 ** 2
+            pos.append(synth.ANCHOR_ECEF + (-b + math.sqrt(b * b - c)) * d)
+        sats.append(np.array(pos))
+    dd = []
+    for k in range(K - 1):
+        ratio = float(rng.uniform(0.05, 0.95))
+        Pe = Ree @ (ratio * gt[k, :3] + (1 - ratio) * gt[k + 1, :3]) + synth.ANCHOR_ECEF
+        clock = 1234.5 + 0.3 * k
+        for spos in sats:
+            f = T.GlioDdPsr()
+            f.slot_i, f.slot_j, f.n_sat = k, k + 1, sats_per_sys
+            f.master = int(np.argmax([(sp - synth.ANCHOR_ECEF) @ up / np.linalg.norm(sp - synth.ANCHOR_ECEF) for sp in spos]))
+            f.ratio, f.threshold = ratio, DDPSR_THRESHOLDS[0]
+            f.station[:] = list(synth.STATION_ECEF)
+            for i in range(sats_per_sys):
+                f.user_sat_pos[i][:] = list(spos[i]); f.ref_sat_pos[i][:] = list(spos[i])
+                bad = 25.0 * rng.uniform(0.5, 1.5) if (rng.uniform() < outliers and i != f.master) else 0.0
+                f.user_psr[i] = np.linalg.norm(spos[i] - Pe) + clock + rng.normal(0, psr_sigma) + bad
+                f.ref_psr[i] = np.linalg.norm(spos[i] - synth.STATION_ECEF) + 77.0 + rng.normal(0, 0.3)
+            W = np.eye(sats_per_sys - 1)
+            f.weight[:W.size] = list(W.ravel())
+            dd.append(f)
+    return dd, frame
+
+
 def batch_selection_draws(count, res_num, rng, ends=False, rand_set_num=400):
     """The indices `globalFeatureSelectionAdd_Batch` (Estimator.cpp:4057-4116) keeps of a keyframe pair's `count` records:
     all of them (None) when count <= batch_feature_res_num (:4077), otherwise the first res_num entries of
@@ -252,6 +334,9 @@ class BatchAssociation:
 
 
 # ------------------------------------------------------------------ the HIP stage
+ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
+
+
 class BatchStage:
     def __init__(self, K, band, max_constraints, device=0):
         lib = capi.load()
@@ -303,6 +388,51 @@ class BatchStage:
         md = C.c_double()
         capi._check(capi.load().glio_batch_step_dev(self._h, C.c_void_p(Hg.data_ptr()), C.c_double(lam), T.dptr(poses), T.dptr(out), C.byref(md)))
         return out, md.value
+
+    def set_small_factors(self, dq=None, dd=None, frame=None, threshold=None):
+        """The replicated small factors every rank adds after the all-reduce: dq = (i, j, const_diff [n][4]) attitude constraints
+        (delta_q_pairs), dd = list of GlioDdPsr between the bracketing keyframes, frame = GlioGnssFrame; `threshold` overrides
+        every DD factor's DDpsrThreshold (the outer round's value)."""
+        dq = dq if dq is not None else (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 4)))
+        di = np.ascontiguousarray(dq[0], np.int32); dj = np.ascontiguousarray(dq[1], np.int32); dc = np.ascontiguousarray(dq[2], np.float64)
+        dd = list(dd or [])
+        if threshold is not None:
+            for f in dd:
+                f.threshold = float(threshold)
+        arr = (T.GlioDdPsr * max(len(dd), 1))(*dd)
+        capi._check(capi.load().glio_batch_set_small_factors(self._h, C.byref(frame) if frame is not None else None, len(di), T.iptr(di) if len(di) else None,
+                                                             T.iptr(dj) if len(di) else None, T.dptr(dc) if len(di) else None, len(dd), arr if dd else None))
+
+    def add_small(self, poses, Hg):
+        poses = np.ascontiguousarray(poses, np.float64)
+        capi._check(capi.load().glio_batch_add_small_dev(self._h, T.dptr(poses), C.c_void_p(Hg.data_ptr())))
+
+    def solve_tr(self, poses, opts=None, dist=None, on_allreduce=None):
+        """ceres::Solve of the batch problem (Estimator.cpp:3275-3284) on the device.  With `dist` (torch.distributed, world > 1) the
+        library calls back once per linearisation with this rank's [H|g|cost] buffer; the hook all-reduces it in place."""
+        import torch
+        poses = np.ascontiguousarray(poses, np.float64).copy()
+        opts = opts or T.batch_tr_opts()
+        summ = T.GlioSummary()
+        dev = f"cuda:{self.device}"
+        calls = [0]
+
+        class _Dev:            # a device buffer of the library seen through the CUDA array interface
+            def __init__(self, ptr, n):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+        def hook(ptr, count, stream, user):
+            t = torch.as_tensor(_Dev(ptr, count), device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize(self.device)
+            calls[0] += 1
+            if on_allreduce:
+                on_allreduce(t)
+
+        cb = ALLREDUCE_FN(hook) if dist is not None else ALLREDUCE_FN()
+        capi._check(capi.load().glio_batch_solve_tr(self._h, T.dptr(poses), C.byref(opts), cb, None, C.byref(summ)))
+        self.allreduces = calls[0]
+        return poses, summ
 
     def time_solve(self, Hg, lam=1e-4, reps=5):
         ms = C.c_float()
@@ -364,4 +494,21 @@ def lm_solve(linearize_reduced, step, poses0, iterations=10, lam=1e-4):
         else:
             lam *= 4.0
         history.append(cost)
+    return poses, history
+
+
+def solve_batch_rounds(stage, poses0, odo, search_range, dd, frame, reassociate=None, opts=None, dist=None, thresholds=DDPSR_THRESHOLDS):
+    """The outer loop of optimizeBatch (Estimator.cpp:2764-3410): `iteration_num` rounds, each re-searching the LiDAR
+    correspondences at the current poses (`reassociate(poses)` must leave the new constraint set on `stage`; None keeps it),
+    rebuilding the small factors with this round's DDpsr_threshold, and running one trust-region solve.  The attitude constraints
+    are rebuilt every round from the ODOMETRY poses `odo` (pose_info_keyframe is not updated inside the loop)."""
+    poses = np.ascontiguousarray(poses0, np.float64).copy()
+    dq = delta_q_pairs(odo, search_range)
+    history = []
+    for thr in thresholds:
+        if reassociate is not None:
+            reassociate(poses)
+        stage.set_small_factors(dq, dd, frame, threshold=thr)
+        poses, summ = stage.solve_tr(poses, opts, dist)
+        history.append(summ.as_dict())
     return poses, history

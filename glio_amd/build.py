@@ -5,8 +5,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libglio_hip.so")
-SOURCES = ["lidar_kernels.hip", "factor_kernels.hip", "solver_kernels.hip", "assoc_kernels.hip", "batch_kernels.hip", "batch_solve_kernels.hip", "localmap_kernels.hip", "eval_kernels.hip", "capi.hip"]
-HEADERS = [os.path.join(CSRC, "glio_device.h"), os.path.join(CSRC, "k3_device.h"), os.path.join(HERE, "..", "include", "glio_hip.h"), os.path.join(HERE, "..", "include", "glio_types.h")]
+SOURCES = ["lidar_kernels.hip", "factor_kernels.hip", "solver_kernels.hip", "assoc_kernels.hip", "batch_kernels.hip", "batch_solve_kernels.hip", "batch_tr_kernels.hip", "localmap_kernels.hip", "eval_kernels.hip", "capi.hip"]
+HEADERS = [os.path.join(CSRC, "glio_device.h"), os.path.join(CSRC, "k3_device.h"), os.path.join(CSRC, "batch_device.h"), os.path.join(HERE, "..", "include", "glio_hip.h"), os.path.join(HERE, "..", "include", "glio_types.h")]
 
 
 def _stale():

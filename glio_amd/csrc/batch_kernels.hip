@@ -24,35 +24,7 @@
 
 #include "glio_device.h"
 
-#define BP_REC 56          // doubles per pair record (55 used)
-#define BP_GRAM 45
-
-struct glio_batch {
-    int device;
-    hipStream_t own_stream, stream;
-    int K, band;
-    int64_t max_con, n_con;
-    float4* d_cp; double* d_nc; double* d_score;      // owned buffers (host upload path)
-    const float4* cp; const double* nc; const double* score;   // active (owned or borrowed device pointers)
-    int n_pairs, max_pairs;
-    int* d_pair_i; int* d_pair_j; long long* d_pair_off;
-    double* d_pair_rec;        // [max_pairs][BP_REC]
-    int* d_pair_index;         // [K][2*band+1]
-    double* d_poses;           // [K][7]
-    double* d_M;               // [K][band+1][36] factor workspace (lower blocks (k+d, k))
-    double* d_y;               // [K][6]
-    double* d_delta;           // [K][6]
-    double* d_newposes;        // [K][7]
-    double* d_scalar;          // [4]
-    double* d_parts;           // per-workgroup parts of the model decrease (summed in fixed order)
-    double* h_poses; double* h_scalar;    // pinned
-    hipEvent_t ev0, ev1;
-    void* bcr;                 // block-cyclic-reduction solver (batch_solve_kernels.hip); null for bands it does not cover
-    int solver_mode;           // 1 = block cyclic reduction (default when available), 0 = the sequential banded kernels
-};
-void* glio_bcr_create(int K, int band);
-void glio_bcr_destroy(void* h);
-void glio_bcr_solve(void* h, const double* Hg, double lambda, double* delta, int** fail_dev, hipStream_t stream);
+#include "batch_device.h"
 
 __device__ __forceinline__ int gram_idx(int i, int j) {       // packed upper triangle of a symmetric 9x9
     const int a = i < j ? i : j, b = i < j ? j : i;
@@ -524,6 +496,7 @@ void glio_batch_destroy(glio_batch* b) {
     hipSetDevice(b->device);
     hipStreamSynchronize(b->stream);
     glio_bcr_destroy(b->bcr);
+    glio_batch_small_destroy(b);
     void* ptrs[] = {b->d_cp, b->d_nc, b->d_score, b->d_pair_i, b->d_pair_j, b->d_pair_off, b->d_pair_rec, b->d_pair_index, b->d_poses,
                     b->d_newposes, b->d_M, b->d_y, b->d_delta, b->d_scalar, b->d_parts};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -624,6 +597,8 @@ int glio_batch_set_constraints(glio_batch* b, int64_t n, const int32_t* ci, cons
     return glio_batch_set_constraints_dev(b, n, ci, cj, reinterpret_cast<const float*>(b->d_cp), b->d_nc, b->d_score);
 }
 
+static void enqueue_batch_linearize(glio_batch* b, double* Hg_dev);
+extern "C++" void glio_batch_enqueue_linearize(glio_batch* b, double* Hg_dev) { enqueue_batch_linearize(b, Hg_dev); }
 static void enqueue_batch_linearize(glio_batch* b, double* Hg_dev) {
     const int K = b->K, band = b->band;
     const long long nH = (long long)K * (band + 1) * 36, total = nH + (long long)K * 6;

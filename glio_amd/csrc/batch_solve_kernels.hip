@@ -43,8 +43,8 @@ struct BcrDev {
 
 // ------------------------------------------------------------------------------------------------ init
 __global__ __launch_bounds__(BCR_THREADS) void k_bcr_init(const double* __restrict__ Hg, const int K, const int band, const double lambda,
-                                                          const int M, const int sb, const int S, double* __restrict__ D, double* __restrict__ C,
-                                                          double* __restrict__ y) {
+                                                          const double* __restrict__ dadd, const int M, const int sb, const int S, double* __restrict__ D,
+                                                          double* __restrict__ C, double* __restrict__ y) {
     const int s = blockIdx.x, bw = band + 1;
     const long long nH = (long long)K * bw * 36;
     // H(ka, kb)[r][c] for |ka - kb| <= band from the upper band storage
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_init(const double* __restri
         const int i = e / M, j = e - M * i;
         const int ka = s * sb + i / 6, r = i % 6, kb = s * sb + j / 6, c = j % 6;
         double v = Hent(ka, r, kb, c);
-        if (i == j && ka < K) v += lambda * v + 1e-12;
+        if (i == j && ka < K) v += dadd ? dadd[(size_t)ka * 6 + r] : lambda * v + 1e-12;
         D[(size_t)s * M * M + e] = v;
         if (s + 1 < S) {        // C_s = A[s+1][s]: rows in super-block s+1, columns in s
             const int kr = (s + 1) * sb + i / 6;
@@ -295,10 +295,10 @@ void glio_bcr_destroy(void* h) {
 
 // (H + lambda diag H) x = g, delta = -x; everything enqueued on `stream`.  *fail_dev (int) is set non-zero on a non-positive pivot.
 template <int M>
-static void bcr_run(BcrDev* b, const double* Hg, double lambda, double* delta, hipStream_t stream) {
+static void bcr_run(BcrDev* b, const double* Hg, double lambda, const double* dadd, double* delta, hipStream_t stream) {
     const int S = b->S;
     hipMemsetAsync(b->fail, 0, 4, stream);
-    hipLaunchKernelGGL(k_bcr_init, dim3(S), dim3(BCR_THREADS), 0, stream, Hg, b->K, b->band, lambda, M, b->sb, S, b->D, b->C, b->y);
+    hipLaunchKernelGGL(k_bcr_init, dim3(S), dim3(BCR_THREADS), 0, stream, Hg, b->K, b->band, lambda, dadd, M, b->sb, S, b->D, b->C, b->y);
     const size_t lds_up = (size_t)(3 * M * (M + 1) + 2 * M) * 8, lds_back = (size_t)(M * (M + 1) + 3 * M) * 8;
     for (int l = 0; l < b->levels; ++l) {
         const int ne = b->h_elim_off[l + 1] - b->h_elim_off[l], nk = b->h_kept_off[l + 1] - b->h_kept_off[l];
@@ -311,9 +311,10 @@ static void bcr_run(BcrDev* b, const double* Hg, double lambda, double* delta, h
     }
     hipLaunchKernelGGL(k_bcr_delta, dim3((b->K * 6 + 255) / 256), dim3(256), 0, stream, b->z, b->K, M, b->sb, delta);
 }
-void glio_bcr_solve(void* h, const double* Hg, double lambda, double* delta, int** fail_dev, hipStream_t stream) {
+void glio_bcr_solve_shift(void* h, const double* Hg, double lambda, const double* dadd, double* delta, int** fail_dev, hipStream_t stream) {
     BcrDev* b = static_cast<BcrDev*>(h);
-    if (b->M == 36) bcr_run<36>(b, Hg, lambda, delta, stream); else bcr_run<72>(b, Hg, lambda, delta, stream);
+    if (b->M == 36) bcr_run<36>(b, Hg, lambda, dadd, delta, stream); else bcr_run<72>(b, Hg, lambda, dadd, delta, stream);
     *fail_dev = b->fail;
 }
+void glio_bcr_solve(void* h, const double* Hg, double lambda, double* delta, int** fail_dev, hipStream_t stream) { glio_bcr_solve_shift(h, Hg, lambda, nullptr, delta, fail_dev, stream); }
 int glio_bcr_levels(void* h) { return static_cast<BcrDev*>(h)->levels; }

@@ -35,6 +35,22 @@ class GlioOpts(C.Structure):
     ]
 
 
+class GlioBatchTrOpts(C.Structure):
+    _fields_ = [("max_iterations", C.c_int32), ("use_nonmonotonic_steps", C.c_int32), ("max_consecutive_nonmonotonic_steps", C.c_int32),
+                ("jacobi_scaling", C.c_int32), ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
+                ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double), ("function_tolerance", C.c_double),
+                ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double)]
+
+
+def batch_tr_opts(max_iterations=100):
+    """ceres::Solver::Options of the batch solve (Estimator.cpp:3275-3281, yaml max_num_iter: 100) + Ceres 1.14 defaults."""
+    o = GlioBatchTrOpts()
+    o.max_iterations, o.use_nonmonotonic_steps, o.max_consecutive_nonmonotonic_steps, o.jacobi_scaling = max_iterations, 1, 5, 1
+    o.initial_trust_region_radius, o.max_trust_region_radius, o.min_trust_region_radius = 1e4, 1e16, 1e-32
+    o.min_relative_decrease, o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance = 1e-3, 1e-6, 1e-10, 1e-8
+    return o
+
+
 class GlioState(C.Structure):
     _fields_ = [("trans", c_double_p), ("quat", c_double_p), ("speed_bias", c_double_p),
                 ("rcv_ddt", c_double_p), ("n_ddt", C.c_int32)]

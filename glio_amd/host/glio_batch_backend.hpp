@@ -7,6 +7,7 @@
 //   rank r owns the constraints whose source keyframe lies in shardRange(K, r, world)   (same rule as glio_amd/batch.py)
 //   iteration:  Hg_r = linearize(poses)  ->  allReduce(Hg)  ->  every rank: step(Hg, lambda)  (identical numbers on every rank)
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <functional>
 #include <stdexcept>
@@ -22,6 +23,53 @@ inline std::pair<int, int> shardRange(int K, int rank, int world) {
     const int base = K / world, rem = K % world;
     const int lo = rank * base + (rank < rem ? rank : rem);
     return {lo, lo + base + (rank < rem ? 1 : 0)};
+}
+
+// The attitude-constraint pairs of optimizeBatch (Estimator.cpp:2831-2891) from the odometry keyframe poses ([K][7] = x y z
+// qw qx qy qz): for keyframe i walk backward, then forward, taking (i, j, const_diff = q_i^-1 q_j) whenever the distance to the
+// last taken keyframe exceeds 5 / search_range -- an INTEGER division there.  factor_count is reset only when it reaches
+// search_range, so a short backward walk leaves its count (and its reference position) to the forward walk.
+struct DeltaQPairs { std::vector<int32_t> i, j; std::vector<double> const_diff; };
+inline DeltaQPairs deltaQPairs(const std::vector<double>& odo, int K, int search_range, int start_idx = 0) {
+    DeltaQPairs out;
+    const double thr = (double)(5 / search_range);
+    for (int i = start_idx; i < K; ++i) {
+        const double* pi = &odo[7 * (size_t)i];
+        const double sgn = pi[3] < 0 ? -1.0 : 1.0;                       // unifyQuaternion(qi)
+        const double qi[4] = {sgn * pi[3], sgn * pi[4], sgn * pi[5], sgn * pi[6]};
+        const double n2 = qi[0] * qi[0] + qi[1] * qi[1] + qi[2] * qi[2] + qi[3] * qi[3];
+        const double a[4] = {qi[0] / n2, -qi[1] / n2, -qi[2] / n2, -qi[3] / n2};
+        double p_tmp[3] = {pi[0], pi[1], pi[2]};
+        int count = 0;
+        for (int dir = -1; dir <= 1; dir += 2) {
+            for (int j = i; dir < 0 ? j >= start_idx : j < K; j += dir) {
+                if (count == search_range) { count = 0; break; }
+                if (j == i) continue;
+                const double* pj = &odo[7 * (size_t)j];
+                const double dx = p_tmp[0] - pj[0], dy = p_tmp[1] - pj[1], dz = p_tmp[2] - pj[2];
+                if (std::sqrt(dx * dx + dy * dy + dz * dz) > thr) {
+                    p_tmp[0] = pj[0]; p_tmp[1] = pj[1]; p_tmp[2] = pj[2];
+                    const double* b = pj + 3;
+                    out.i.push_back(i); out.j.push_back(j);
+                    out.const_diff.push_back(a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3]);
+                    out.const_diff.push_back(a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2]);
+                    out.const_diff.push_back(a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3]);
+                    out.const_diff.push_back(a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1]);
+                    ++count;
+                }
+            }
+        }
+    }
+    return out;
+}
+
+// ceres::Solver::Options of the batch solve (Estimator.cpp:3275-3281; yaml max_num_iter) + Ceres 1.14 defaults
+inline glio_batch_tr_opts batchTrOpts(int max_iterations = 100) {
+    glio_batch_tr_opts o;
+    o.max_iterations = max_iterations; o.use_nonmonotonic_steps = 1; o.max_consecutive_nonmonotonic_steps = 5; o.jacobi_scaling = 1;
+    o.initial_trust_region_radius = 1e4; o.max_trust_region_radius = 1e16; o.min_trust_region_radius = 1e-32;
+    o.min_relative_decrease = 1e-3; o.function_tolerance = 1e-6; o.gradient_tolerance = 1e-10; o.parameter_tolerance = 1e-8;
+    return o;
 }
 
 class BatchBackend {
@@ -78,10 +126,39 @@ public:
         }
         return poses;
     }
+    // ---- the full pose problem: small factors replicated on every rank + the trust-region solve inside the library
+    void setSmallFactors(const glio_gnss_frame* frame, const DeltaQPairs& dq, std::vector<glio_dd_psr>& dd, double dd_threshold) {
+        for (glio_dd_psr& f : dd) f.threshold = dd_threshold;
+        check(glio_batch_set_small_factors(h_, frame, (int)dq.i.size(), dq.i.data(), dq.j.data(), dq.const_diff.data(), (int)dd.size(), dd.data()),
+              "glio_batch_set_small_factors");
+    }
+    glio_summary solveTrustRegion(std::vector<double>& poses, const glio_batch_tr_opts& opts) {
+        glio_summary s;
+        check(glio_batch_solve_tr(h_, poses.data(), &opts, allreduce_ ? &BatchBackend::trampoline : nullptr, this, &s), "glio_batch_solve_tr");
+        return s;
+    }
+    // the outer loop of optimizeBatch (Estimator.cpp:2764-3410): iteration_num = 4 rounds with DDpsr_threshold {1e9, 10, 8, 6};
+    // `reassociate` (may be empty) re-searches the LiDAR correspondences at the current poses and calls setConstraints
+    std::vector<glio_summary> solveRounds(std::vector<double>& poses, const std::vector<double>& odo, int search_range, const glio_gnss_frame* frame,
+                                          std::vector<glio_dd_psr>& dd, const glio_batch_tr_opts& opts,
+                                          const std::function<void(const std::vector<double>&)>& reassociate = {}) {
+        static const double thresholds[4] = {1000000000, 10, 8, 6};
+        const DeltaQPairs dq = deltaQPairs(odo, K_, search_range);
+        std::vector<glio_summary> out;
+        for (double thr : thresholds) {
+            if (reassociate) reassociate(poses);
+            setSmallFactors(frame, dq, dd, thr);
+            out.push_back(solveTrustRegion(poses, opts));
+        }
+        return out;
+    }
     glio_batch* handle() { return h_; }
     void* stream() { return stream_; }
 
 private:
+    static void trampoline(double* dev, int64_t count, void* stream, void* user) {
+        static_cast<BatchBackend*>(user)->allreduce_(dev, (size_t)count, stream);
+    }
     static void check(int rc, const char* what) {
         if (rc != GLIO_OK) throw std::runtime_error(std::string(what) + ": " + glio_last_error());
     }

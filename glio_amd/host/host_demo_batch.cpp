@@ -6,6 +6,8 @@
 //   host_demo_batch problem.bin [iterations] [id_file]         RANK / WORLD_SIZE / LOCAL_RANK from the environment (default 0/1/0)
 // problem.bin: int32 K, band, iterations_hint, 0 | int64 n | poses [K][7] f64 | ci [n] i32 | cj [n] i32 | cp [n][4] f32 |
 //              norm_cent [n][6] f64 | score [n] f64      (all constraints; every rank keeps its own shard)
+//              with header word 3 = 1 the file continues: odo [K][7] f64 | int32 search_range, n_dd | glio_gnss_frame | glio_dd_psr [n_dd]
+//              and the program runs the full pose problem instead: 4 threshold rounds of the trust-region solve (BatchBackend::solveRounds)
 // Build: g++ -std=c++14 -O2 -D__HIP_PLATFORM_AMD__ host_demo_batch.cpp -I../../include -I/opt/rocm/include -L../lib -lglio_hip
 //        -L/opt/rocm/lib -lrccl -Wl,-rpath,'$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib
 #include <chrono>
@@ -38,6 +40,18 @@ int main(int argc, char** argv) {
     std::vector<float> cp((size_t)n * 4);
     rd(f, poses.data(), poses.size()); rd(f, ci.data(), ci.size()); rd(f, cj.data(), cj.size());
     rd(f, cp.data(), cp.size()); rd(f, nc.data(), nc.size()); rd(f, score.data(), score.size());
+    const bool full = hdr[3] == 1;
+    std::vector<double> odo;
+    std::vector<glio_dd_psr> dd;
+    glio_gnss_frame frame;
+    int32_t sr_ndd[2] = {0, 0};
+    memset(&frame, 0, sizeof frame);
+    if (full) {
+        odo.resize((size_t)K * 7);
+        rd(f, odo.data(), odo.size()); rd(f, sr_ndd, 2); rd(f, &frame, 1);
+        dd.resize((size_t)sr_ndd[1]);
+        rd(f, dd.data(), dd.size());
+    }
     fclose(f);
     // this rank's shard: constraints whose source keyframe is in [lo, hi) (they are sorted by (ci, cj))
     const std::pair<int, int> rg = glio::shardRange(K, rank, world);
@@ -74,19 +88,25 @@ int main(int argc, char** argv) {
             const auto t0 = std::chrono::steady_clock::now();
             const ncclResult_t r = ncclAllReduce(dev, dev, count, ncclDouble, ncclSum, comm, (hipStream_t)stream);
             if (r != ncclSuccess) throw std::runtime_error(std::string("ncclAllReduce: ") + ncclGetErrorString(r));
-            if (glio_batch_synchronize(be.handle()) != GLIO_OK) throw std::runtime_error("synchronize");
+            if (!full && glio_batch_synchronize(be.handle()) != GLIO_OK) throw std::runtime_error("synchronize");   // (timing only; the solve is stream-ordered)
             t_reduce += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             reduced_bytes += count * 8; ++n_reduce;
         });
         be.setConstraints(a1 - a0, ci.data() + a0, cj.data() + a0, cp.data() + 4 * a0, nc.data() + 6 * a0, score.data() + a0);
         std::vector<double> hist;
+        std::vector<glio_summary> rounds;
         const auto t0 = std::chrono::steady_clock::now();
-        const std::vector<double> sol = be.solve(poses, iterations, 1e-4, &hist);
+        std::vector<double> sol;
+        if (full) { sol = poses; rounds = be.solveRounds(sol, odo, sr_ndd[0], &frame, dd, glio::batchTrOpts(iterations)); }
+        else sol = be.solve(poses, iterations, 1e-4, &hist);
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (rank == 0) {
             printf("batch K %d band %d constraints %lld world %d iterations %d wall_ms %.3f allreduces %d allreduce_MB_each %.3f allreduce_ms_mean %.4f\n",
                    K, band, (long long)n, world, iterations, secs * 1e3, n_reduce, n_reduce ? reduced_bytes / 1e6 / n_reduce : 0.0,
                    n_reduce ? t_reduce * 1e3 / n_reduce : 0.0);
+            for (const glio_summary& r : rounds)
+                printf("round iterations %d successful %d termination %d initial_cost %.17g final_cost %.17g\n", r.iterations, r.successful_steps, r.termination,
+                       r.initial_cost, r.final_cost);
             printf("cost");
             for (double c : hist) printf(" %.17g", c);
             printf("\n");

@@ -65,14 +65,22 @@ def build_demo_batch(force=False):
     return DEMO_BATCH
 
 
-def write_batch_problem(path, K, band, iterations, poses, ci, cj, cp, nc, score):
+def write_batch_problem(path, K, band, iterations, poses, ci, cj, cp, nc, score, full=None):
+    """full = (odo [K][7], search_range, frame, dd list): appends the data of the full pose problem (see host_demo_batch.cpp)."""
     with open(path, "wb") as f:
-        f.write(np.array([K, band, iterations, 0], np.int32).tobytes())
+        f.write(np.array([K, band, iterations, 1 if full else 0], np.int32).tobytes())
         f.write(np.array([len(ci)], np.int64).tobytes())
         f.write(np.ascontiguousarray(poses, np.float64).tobytes())
         f.write(np.ascontiguousarray(ci, np.int32).tobytes()); f.write(np.ascontiguousarray(cj, np.int32).tobytes())
         f.write(np.ascontiguousarray(cp, np.float32).tobytes()); f.write(np.ascontiguousarray(nc, np.float64).tobytes())
         f.write(np.ascontiguousarray(score, np.float64).tobytes())
+        if full:
+            odo, search_range, frame, dd = full
+            f.write(np.ascontiguousarray(odo, np.float64).tobytes())
+            f.write(np.array([search_range, len(dd)], np.int32).tobytes())
+            f.write(bytes(frame))
+            for d in dd:
+                f.write(bytes(d))
 
 
 def run_demo_batch(path, iterations=None, env=None):
@@ -81,7 +89,12 @@ def run_demo_batch(path, iterations=None, env=None):
     # (RCCL prints its own version banner on stdout: pick our lines by their first word)
     head = next(ln for ln in out if ln.startswith("batch ")).split()
     info = {head[i]: head[i + 1] for i in range(1, len(head) - 1, 2)}
-    hist = [float(x) for x in next(ln for ln in out if ln.startswith("cost ")).split()[1:]]
+    hist = [float(x) for x in next(ln for ln in out if ln.split()[:1] == ["cost"]).split()[1:]]
     rows = np.array([[float(x) for x in ln.split()[2:]] for ln in out if ln.startswith("kf ")])
     info["raw"] = [ln for ln in out if not ln.startswith("kf ")]
+    info["rounds"] = []
+    for ln in out:
+        if ln.startswith("round "):
+            w = ln.split()
+            info["rounds"].append({w[i]: float(w[i + 1]) for i in range(1, len(w) - 1, 2)})
     return info, hist, rows

@@ -197,6 +197,22 @@ int glio_batch_linearize_dev(glio_batch* b, const double* poses, double* Hg_dev)
  * the device and returns poses (+) d; *model_decrease = -(g.d + d^T H d / 2).  poses_out may alias poses_in. */
 int glio_batch_step_dev(glio_batch* b, const double* Hg_dev, double lambda, const double* poses_in, double* poses_out,
                         double* model_decrease);
+/* ---- the rest of the batch problem on keyframe poses + its trust-region solve (Estimator.cpp:2739-3410 without the IMU chain).
+ * glio_batch_set_small_factors: delta_q_factor_auto attitude constraints (Estimator.cpp:2831-2891; dq_const [n_dq][4] = const_diff,
+ *   blocks q[dq_i], q[dq_j]) and dd_psr_factor_20 per GNSS epoch (Estimator.cpp:3197-3271; slot_i / slot_j = leftKey / rightKey,
+ *   identity weight and the station position as addDDPsrResFactor_gl passes them, :1899-1911; `threshold` = DDpsr_threshold of the
+ *   current outer round, :2764-2767).  They are small and identical on every rank: each rank adds them itself AFTER the all-reduce.
+ * glio_batch_add_small_dev: adds them, evaluated at `poses`, into a (reduced) buffer.
+ * glio_batch_solve_tr: ceres::Solve of Estimator.cpp:3275-3284 (DOGLEG, non-monotonic steps, max_num_iter) on the device; the
+ *   `allreduce` hook (NULL = one rank) is called with this rank's linearisation (device pointer, doubles, HIP stream, user) and
+ *   must leave the sum over the ranks in place -- ncclAllReduce on that stream in C++, torch.distributed.all_reduce in Python.
+ *   Traditional dogleg in place of SUBSPACE_DOGLEG (a stated deviation); poses [K][7] in/out. */
+typedef void (*glio_allreduce_fn)(double* dev, int64_t count, void* hip_stream, void* user);
+int glio_batch_set_small_factors(glio_batch* b, const glio_gnss_frame* frame, int n_dq, const int32_t* dq_i, const int32_t* dq_j,
+                                 const double* dq_const, int n_dd, const glio_dd_psr* dd);
+int glio_batch_add_small_dev(glio_batch* b, const double* poses, double* Hg_dev);
+int glio_batch_solve_tr(glio_batch* b, double* poses, const glio_batch_tr_opts* opts, glio_allreduce_fn allreduce, void* user, glio_summary* summary);
+
 /* For a C++ host that never includes HIP headers (glio_amd/host/glio_batch_backend.hpp): the reduced buffer
  * [H band | g | cost] as a device allocation, the batch stream to hand to ncclAllReduce between glio_batch_linearize_dev and
  * glio_batch_step_dev, a read-back of a few of its doubles (the cost is the last one), a stream synchronisation. */

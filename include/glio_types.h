@@ -172,6 +172,22 @@ enum {
     GLIO_TERM_FAILURE = 5
 };
 
+/* Trust-region options of the batch solve (ceres::Solver::Options as set at Estimator.cpp:3275-3281: DOGLEG, non-monotonic
+ * steps, max_num_iter from the yaml; the rest are Ceres 1.14 defaults).  Shared by libglio_hip (glio_batch_solve_tr) and the oracle. */
+typedef struct glio_batch_tr_opts {
+    int32_t max_iterations;                      /* options.max_num_iterations = max_num_iter (yaml:65: 100) */
+    int32_t use_nonmonotonic_steps;              /* true, Estimator.cpp:3281 */
+    int32_t max_consecutive_nonmonotonic_steps;  /* Ceres default 5 */
+    int32_t jacobi_scaling;                      /* Ceres default true */
+    double initial_trust_region_radius;          /* 1e4 */
+    double max_trust_region_radius;              /* 1e16 */
+    double min_trust_region_radius;              /* 1e-32 */
+    double min_relative_decrease;                /* 1e-3 */
+    double function_tolerance;                   /* 1e-6 */
+    double gradient_tolerance;                   /* 1e-10 */
+    double parameter_tolerance;                  /* 1e-8 */
+} glio_batch_tr_opts;
+
 /* One scan-to-multiscan constraint of the batch stage (BinaryLidarPlaneNormFactor,
  * LidarKeyframeFactor.h:124-164; built Estimator.cpp:3048,3071). */
 typedef struct glio_batch_opts {

@@ -124,6 +124,26 @@ int orc_batch_linearize(int K, int band, const double* poses, int64_t n_con, con
                         const int32_t* cj, const float* cp /*[n][4]*/, const double* norm_cent /*[n][6]*/,
                         const double* score, double* Hband, double* g, double* cost);
 
+/* ---- the batch problem on keyframe poses (Estimator::optimizeBatchWithLandMark, Estimator.cpp:2739-3410, sms_fusion_level 1
+ * without the IMU chain): BinaryLidarPlaneNormFactor blocks (:3004-3076), delta_q_factor_auto attitude constraints (:2831-2891,
+ * LidarKeyframeFactor.h:283-303), dd_psr_factor_20 per GNSS epoch between the bracketing keyframes with identity weight and the
+ * station position (:3197-3271, :1899-1911); no loss function (:2768). */
+typedef struct orc_batch_problem {
+    int32_t K, band;
+    int64_t n_con; const int32_t* ci; const int32_t* cj; const float* cp; const double* norm_cent; const double* score;
+    int32_t n_dq; const int32_t* dq_i; const int32_t* dq_j; const double* dq_const;      /* [n_dq][4] const_diff = qi^-1 qj at construction (w,x,y,z) */
+    int32_t n_dd; const glio_dd_psr* dd;                                                /* slot_i / slot_j = keyframe indices (leftKey, rightKey) */
+    glio_gnss_frame frame;
+} orc_batch_problem;
+/* delta_q_factor_auto (LidarKeyframeFactor.h:283-303): blocks qi[4], qj[4]; 3 residuals = 10000 (dq^-1 qi^-1 qj).vec; global Jacobians 3x4 */
+int orc_eval_delta_q(const double dq_const[4], double const* const* parameters, double* residuals, double** jacobians);
+/* banded normal equations of ALL factors (layout as orc_batch_linearize) */
+int orc_batch_linearize_full(const orc_batch_problem* p, const double* poses, double* Hband, double* g, double* cost);
+/* Ceres-1.14 trust region on the batch problem: Jacobi scaling, TRADITIONAL dogleg (the reference asks for SUBSPACE_DOGLEG: the
+ * same two-dimensional subspace, minimised exactly there and along the dogleg path here -- a stated deviation of the
+ * restatement), non-monotonic step acceptance (TrustRegionStepEvaluator), dense Cholesky.  poses [K][7] in/out. */
+int orc_batch_solve(const orc_batch_problem* p, const glio_batch_tr_opts* o, double* poses, glio_summary* summary);
+
 #ifdef __cplusplus
 }
 #endif

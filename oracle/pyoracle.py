@@ -255,3 +255,53 @@ def batch_linearize(K, band, poses, ci, cj, cp, pnc, score):
                                    T.dptr(H), T.dptr(g), C.byref(cost))
     assert ok
     return H, g, cost.value
+
+
+# ------------------------------------------------------------------ the batch problem on keyframe poses
+class OrcBatchProblem(C.Structure):
+    _fields_ = [("K", C.c_int32), ("band", C.c_int32), ("n_con", C.c_int64), ("ci", T.c_int32_p), ("cj", T.c_int32_p), ("cp", T.c_float_p),
+                ("norm_cent", T.c_double_p), ("score", T.c_double_p), ("n_dq", C.c_int32), ("dq_i", T.c_int32_p), ("dq_j", T.c_int32_p),
+                ("dq_const", T.c_double_p), ("n_dd", C.c_int32), ("dd", C.POINTER(T.GlioDdPsr)), ("frame", T.GlioGnssFrame)]
+
+
+def eval_delta_q(dq_const, qi, qj, want_J=True):
+    r = np.zeros(3)
+    J = [np.zeros((3, 4)), np.zeros((3, 4))]
+    lib().orc_eval_delta_q(T.dptr(np.ascontiguousarray(dq_const, float)), _pp([np.ascontiguousarray(qi, float), np.ascontiguousarray(qj, float)]),
+                           T.dptr(r), _pp(J) if want_J else None)
+    return r, J
+
+
+class BatchProblem:
+    """Owns the numpy buffers behind an orc_batch_problem: binary plane constraints, delta_q attitude constraints (i, j, const_diff),
+    DD pseudorange factors (slot_i / slot_j = keyframe indices)."""
+
+    def __init__(self, K, band, ci, cj, cp, nc, score, dq=None, dd=None, frame=None):
+        self.K, self.band = K, band
+        self.ci = np.ascontiguousarray(ci, np.int32); self.cj = np.ascontiguousarray(cj, np.int32)
+        self.cp = np.ascontiguousarray(cp, np.float32); self.nc = np.ascontiguousarray(nc, np.float64); self.score = np.ascontiguousarray(score, np.float64)
+        dq = dq or (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 4)))
+        self.dq_i = np.ascontiguousarray(dq[0], np.int32); self.dq_j = np.ascontiguousarray(dq[1], np.int32); self.dq_c = np.ascontiguousarray(dq[2], np.float64)
+        dd = dd or []
+        self.dd = (T.GlioDdPsr * max(len(dd), 1))(*dd)
+        p = OrcBatchProblem()
+        p.K, p.band, p.n_con = K, band, len(self.ci)
+        p.ci, p.cj, p.cp, p.norm_cent, p.score = T.iptr(self.ci), T.iptr(self.cj), T.fptr(self.cp), T.dptr(self.nc), T.dptr(self.score)
+        p.n_dq, p.dq_i, p.dq_j, p.dq_const = len(self.dq_i), T.iptr(self.dq_i), T.iptr(self.dq_j), T.dptr(self.dq_c)
+        p.n_dd, p.dd = len(dd), self.dd
+        if frame is not None:
+            p.frame = frame
+        self.c = p
+
+    def linearize(self, poses):
+        K, band = self.K, self.band
+        H = np.zeros((K, band + 1, 36)); g = np.zeros((K, 6)); cost = C.c_double()
+        ok = lib().orc_batch_linearize_full(C.byref(self.c), T.dptr(np.ascontiguousarray(poses, float)), T.dptr(H), T.dptr(g), C.byref(cost))
+        assert ok
+        return H, g, cost.value
+
+    def solve(self, poses, opts):
+        x = np.ascontiguousarray(poses, float).copy()
+        summ = T.GlioSummary()
+        lib().orc_batch_solve(C.byref(self.c), C.byref(opts), T.dptr(x), C.byref(summ))
+        return x, summ

@@ -93,3 +93,30 @@ def test_cpp_batch_stage_with_rccl_allreduce_matches_python(tmp_path):
     assert np.allclose(hist, hist_py, rtol=1e-13)
     assert np.abs(rows - poses).max() < 1e-12
     st.close()
+
+
+@pytest.mark.gpu
+def test_cpp_full_batch_problem_rounds_match_python(tmp_path):
+    """host_demo_batch on the full pose problem (plane constraints + delta_q + DD pseudoranges; BatchBackend::solveRounds: the 4
+    DDpsr_threshold rounds, glio_batch_solve_tr with ncclAllReduce as the hook) against glio_amd.batch.solve_batch_rounds."""
+    from glio_amd import batch
+    from glio_amd import ctypes_types as T
+    K, band, iters, sr = 48, 6, 12, 3
+    gt, init = batch.make_poses(K, seed=19, perturb=(0.08, 0.004))
+    ci, cj, cp, nc, score = batch.make_constraints(gt, 0, K, 200, band, seed=19)
+    odo = gt.copy(); odo[:, :3] += np.random.default_rng(19).normal(0, 0.02, (K, 3))
+    odo[5, 3:] *= -1.0                                        # a keyframe stored with w < 0: q_i is unified, q_j is not
+    dd, frame = batch.make_batch_gnss(gt, seed=19)
+    path = str(tmp_path / "full.bin")
+    window_io.write_batch_problem(path, K, band, iters, init, ci, cj, cp.numpy(), nc.numpy(), score.numpy(), full=(odo, sr, frame, dd))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    info, _, rows = window_io.run_demo_batch(path, iters, env=env)
+    st = batch.BatchStage(K, band, len(ci)); st.set_constraints(ci, cj, cp.numpy(), nc.numpy(), score.numpy())
+    poses, hist = batch.solve_batch_rounds(st, init, odo, sr, dd, frame, opts=T.batch_tr_opts(iters))
+    assert len(info["rounds"]) == 4
+    for a, b in zip(info["rounds"], hist):
+        assert int(a["iterations"]) == b["iterations"] and int(a["termination"]) == b["termination"]
+        assert np.isclose(a["final_cost"], b["final_cost"], rtol=1e-12)
+    assert int(info["allreduces"]) == sum(1 + h["iterations"] for h in hist) or int(info["allreduces"]) >= 4
+    assert np.abs(rows - poses).max() < 1e-12
+    st.close()

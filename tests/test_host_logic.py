@@ -134,3 +134,29 @@ def test_batch_selection_draw_rules():
     d = batch.batch_selection_draws(60, 25, rng, ends=True)
     assert len(d) == 25 and d.max() <= 58
     assert len(batch.batch_selection_draws(50, 40, rng, ends=True, rand_set_num=400)) == 9       # rand set clamped to count - res_num - 1
+
+
+def test_delta_q_pairs_follow_the_reference_walk():
+    """Estimator.cpp:2831-2891: backward then forward, factor_count shared between the two walks and reset only at search_range,
+    the distance gate an integer division (0 for search_range 6, 1 for search_range 3..5), q_i sign-unified."""
+    from glio_amd import batch
+    K = 8
+    odo = np.zeros((K, 7)); odo[:, 0] = np.arange(K) * 2.0; odo[:, 3] = 1.0
+    i, j, c = batch.delta_q_pairs(odo, 3)
+    pairs = list(zip(i.tolist(), j.tolist()))
+    assert [p for p in pairs if p[0] == 0] == [(0, 1), (0, 2), (0, 3)]
+    assert [p for p in pairs if p[0] == 1] == [(1, 0), (1, 2), (1, 3)]            # one backward, so only two forward before the count resets
+    assert [p for p in pairs if p[0] == 4] == [(4, 3), (4, 2), (4, 1), (4, 5), (4, 6), (4, 7)]
+    assert np.allclose(c, [1, 0, 0, 0])
+    # gate: spacing 0.5 m with search_range 4 -> threshold 1 m measured from the last TAKEN keyframe
+    odo2 = odo.copy(); odo2[:, 0] = np.arange(K) * 0.5
+    i2, j2, _ = batch.delta_q_pairs(odo2, 4)
+    assert [b for a, b in zip(i2, j2) if a == 0] == [3, 6]
+    # search_range 6 -> 5 / 6 == 0: every keyframe at a different position passes
+    i3, j3, _ = batch.delta_q_pairs(odo2, 6)
+    assert [b for a, b in zip(i3, j3) if a == 0] == [1, 2, 3, 4, 5, 6]
+    # sign unification of q_i only
+    odo4 = odo.copy(); odo4[2, 3] = -1.0
+    i4, j4, c4 = batch.delta_q_pairs(odo4, 3)
+    for a, b, d in zip(i4, j4, c4):
+        assert np.allclose(d, [-1 if b == 2 else 1, 0, 0, 0]), (a, b, d)

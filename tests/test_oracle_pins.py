@@ -220,3 +220,20 @@ def test_converged_optimum_matches_scipy_minimiser(small_window, small_corr):
             stp.speed_bias[s] += d[15 * s + 6:15 * s + 15]
         stp.rcv_ddt[:stp.n_ddt] += d[15 * win.W:]
         assert prob.linearize(stp, want_H=False)[2] >= c_end - 1e-9 * c_end
+
+
+def test_delta_q_functor_autograd():
+    """delta_q_factor_auto (LidarKeyframeFactor.h:283-303): residual 10000 (dq^-1 qi^-1 qj).vec with Eigen's inverse
+    (conjugate / squaredNorm); the oracle's hand-derived 3x4 global Jacobians against torch.autograd, also at non-unit qi."""
+    rng = np.random.default_rng(21)
+    for trial in range(5):
+        dq, qi, qj = rand_q(rng), rand_q(rng) * (1.0 + 0.02 * trial), rand_q(rng)
+        r, J = po.eval_delta_q(dq, qi, qj)
+        dqt = torch.tensor(dq)
+
+        def functor(a, b):
+            return 10000.0 * q_mul(q_mul(q_inverse(dqt), q_inverse(a)), b)[1:]
+        a, b = torch.tensor(qi, requires_grad=True), torch.tensor(qj, requires_grad=True)
+        Ja, Jb = torch.autograd.functional.jacobian(functor, (a, b))
+        assert np.allclose(r, functor(a, b).detach().numpy(), rtol=1e-13, atol=1e-9)
+        assert np.allclose(J[0], Ja.numpy(), rtol=1e-11, atol=1e-7) and np.allclose(J[1], Jb.numpy(), rtol=1e-11, atol=1e-7)
