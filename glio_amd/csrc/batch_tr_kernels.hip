@@ -9,8 +9,8 @@
 //     mu D^2 regularisation, dogleg combination, model cost change, candidate poses: all on the device; the host keeps only
 //     the scalar state machine and calls the caller's all-reduce hook between "linearise my shard" and everything else.
 //     Deviation, stated: TRADITIONAL dogleg in place of SUBSPACE_DOGLEG (the same two-dimensional subspace {gradient,
-//     Gauss-Newton}; Ceres minimises the model over the whole subspace, the dogleg path is a curve in it); the oracle
-//     (oracle/orc_batch.c) restates exactly this.
+//     Gauss-Newton}; Ceres minimises the model over the whole subspace, the dogleg path is a curve in it); the CPU
+//     checker used by the tests restates exactly this.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
