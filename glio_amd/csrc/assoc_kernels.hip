@@ -62,6 +62,8 @@ struct AssocWork {
     int* d_count_tmp;
     int* h_count;                 // pinned
     double* d_win; double* h_win; // [W][7] poses + [W] counts of the window association (h_win pinned)
+    struct KnnBinHost* kb;        // query binning buffers of the tiled search
+    float4* d_ps;                 // [W][cap] presorted copies of the resident scans (w = index in the scan)
     float3 origin;
     double last_pose0[7];         // (q, t) slot 0 was last associated with: the timing hook replays THAT association
     int have_pose0;
@@ -232,7 +234,19 @@ __device__ __forceinline__ void plane_qr_solve(double A[5][3], double b[5], doub
     }
 }
 
+// Query binning of the tiled neighbour search (k_qbin_* / k_knn5_tile): per launch row y (a scan, a window slot or a keyframe
+// pair) the queries are grouped by the voxel-hash cell they fall in; a UNIT is up to TK_LANES queries of one cell.
+struct KnnBin {
+    unsigned long long* keys; int* cnt; int* cstart;      // [Y][capq] open-addressing table of the occupied query cells (left EMPTY / 0 by k_qbin_alloc)
+    int* qslot; int* qrank;                               // [Y][w_stride] table slot and arrival rank of query i
+    float4* qtmp; float4* qs;                             // [Y][w_stride] transformed query (w = its index): in scan order, grouped by cell
+    int2* units;                                          // [Y][unit_stride] (first grouped position, queries)
+    int* counters;                                        // [Y][2] grouped queries, units (zeroed again by k_plane_fit)
+    int capq, unit_stride;
+};
+
 struct AssocArgs {
+    KnnBin kb;
     double q[4], t[3];
     float inv_cell;
     double kd_max_radius, weight_gate;      // doubles in the reference: float quantities are promoted for the comparison
@@ -320,15 +334,7 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 // floats the unsigned order of the bits is the order of the values, so "smaller distance, then smaller index" is a single
 // u64 compare and a list entry moves as one register pair (the kernel is VALU-issue bound: ~1600 vector instructions per
 // wavefront of four queries, rocprofv3 SQ_INSTS_VALU).
-__device__ __forceinline__ void knn5_insert(const float px, const float py, const float pz, const float4 mp, const int m,
-                                            unsigned long long bk[5], int bp[5]) {
-    // plain operators, NOT the __f*_rn intrinsics: those are header functions compiled with
-    // contraction allowed and fuse after inlining; here the file-scope pragma keeps them separate
-    const float ex = px - mp.x, ey = py - mp.y, ez = pz - mp.z;
-    float d = ex * ex;
-    d = d + ey * ey;
-    d = d + ez * ez;
-    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(mp.w);
+__device__ __forceinline__ void knn5_insert_key(const unsigned long long key, const int m, unsigned long long bk[5], int bp[5]) {
     if (key < bk[4]) {
         bk[4] = key; bp[4] = m;
 #pragma unroll
@@ -342,6 +348,16 @@ __device__ __forceinline__ void knn5_insert(const float px, const float py, cons
             bp[k] = tp;
         }
     }
+}
+__device__ __forceinline__ void knn5_insert(const float px, const float py, const float pz, const float4 mp, const int m,
+                                            unsigned long long bk[5], int bp[5]) {
+    // plain operators, NOT the __f*_rn intrinsics: those are header functions compiled with
+    // contraction allowed and fuse after inlining; here the file-scope pragma keeps them separate
+    const float ex = px - mp.x, ey = py - mp.y, ez = pz - mp.z;
+    float d = ex * ex;
+    d = d + ey * ey;
+    d = d + ez * ez;
+    knn5_insert_key(((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(mp.w), m, bk, bp);
 }
 
 __global__ __launch_bounds__(256) void k_knn5(const AssocArgs a, const float4* __restrict__ scan, const float4* __restrict__ map,
@@ -449,6 +465,287 @@ __global__ __launch_bounds__(256) void k_knn5(const AssocArgs a, const float4* _
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// K2, tiled.  k_knn5 above spends ~1600 vector instructions per wavefront of FOUR queries, most of them on per-query
+// overhead (27 hash probes, prefix, candidate location, a five-round shuffle merge); it is VALU-issue bound.  Queries that
+// fall in the same cell share their 27-cell candidate set, so the search runs per UNIT = up to 16 queries of one cell:
+//   presort (once per uploaded cloud: k_qbin_count / _alloc / _scatter in the cloud's OWN frame, 5 m blocks) makes every run of
+//           1024 consecutive points spatially compact, whatever order the caller's cloud came in;
+//   k_qbin_tile   per 1024 consecutive presorted points: transformPoint, cell, grouping by cell in an LDS hash table (LDS
+//                 atomics only; one global atomic per workgroup for its range of the unit list), grouped queries written out;
+//   k_knn5_tile   per unit, 32 lanes (16 queries x 2 halves of the candidate list): the 27 cells are probed ONCE, their points
+//                 staged in LDS, then every lane scans its half of the staged list for its own query: 8 VALU for the float
+//                 distance + 8 for a seven-deep sorted insertion on 32-bit keys (v_min_u32 + 6 v_med3_u32) per candidate.
+// The 32-bit key is (distance bits with the low 8 bits replaced by the LDS slot): unsigned order = distance order up to
+// 2^-15 relative.  The exact ranking rule of the reference-equivalent search -- float distance, then original map index --
+// is restored afterwards: the seven selected candidates are re-evaluated exactly (64-bit keys) and merged into the lane's
+// running top five; the selection provably contains the exact top five of what the lane scanned when the fifth exact distance
+// lies in a strictly lower truncation bucket than the seventh selected key (anything not selected has a key, hence a bucket, at
+// least as large).  When it does not (four near-ties inside 2^-15), the lane rescans with exact keys.  The two halves are merged
+// at the end.  The order of the queries inside a cell and of the units in memory is arbitrary; the results are not: every query
+// is independent and written at its own index.
+#define TK_Q 16
+#define TK_LANES 32
+#define TK_CAP 128
+#define TK_SEL 7
+#define TK_UNITS (256 / TK_LANES)
+#define TK_MASK 127u
+#define QT_THREADS 1024
+#define QT_SLOTS 2048
+#define PRESORT_CELL 5.0f
+
+__global__ __launch_bounds__(256) void k_qbin_count(const AssocArgs a, const float4* __restrict__ scan) {
+    const AssocSlot sl = assoc_slot(a);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= sl.n) return;
+    const float4 pl = scan[sl.qoff + i];
+    const double pin[3] = {(double)pl.x, (double)pl.y, (double)pl.z};
+    double po[3];
+    a_qrot(sl.q, pin, po);
+    const float px = (float)(po[0] + sl.t[0]), py = (float)(po[1] + sl.t[1]), pz = (float)(po[2] + sl.t[2]);
+    const int cx = cell_of(px, a.inv_cell), cy = cell_of(py, a.inv_cell), cz = cell_of(pz, a.inv_cell);
+    const int capq = a.kb.capq;
+    unsigned long long* keys = a.kb.keys + (size_t)blockIdx.y * capq;
+    const unsigned long long key = pack_key(cx, cy, cz);
+    unsigned s = home_slot(cx, cy, cz, capq);
+    for (;;) {
+        unsigned long long prev = keys[s];                         // a stale EMPTY only costs the CAS; a key, once seen, stays
+        if (prev != key) prev = atomicCAS(&keys[s], KEY_EMPTY, key);
+        if (prev == KEY_EMPTY || prev == key) break;
+        s = (s + 1) & (capq - 1);
+    }
+    const int rank = atomicAdd(&a.kb.cnt[(size_t)blockIdx.y * capq + s], 1);
+    a.kb.qslot[sl.woff + i] = (int)s;
+    a.kb.qrank[sl.woff + i] = rank;
+    a.kb.qtmp[sl.woff + i] = make_float4(px, py, pz, __int_as_float(i));
+}
+
+__global__ __launch_bounds__(1024) void k_qbin_alloc(const AssocArgs a) {
+    __shared__ int s_w[16], s_base;
+    const int capq = a.kb.capq;
+    const int s = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t row = (size_t)blockIdx.y * capq;
+    const int c = s < capq ? a.kb.cnt[row + s] : 0;
+    int ic = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(ic, off, 64);
+        if (lane >= off) ic += v;
+    }
+    if (lane == 63) s_w[wv] = ic;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int k = 0; k < 16; ++k) { const int v = s_w[k]; s_w[k] = t; t += v; }
+        s_base = t > 0 ? atomicAdd(&a.kb.counters[2 * blockIdx.y], t) : 0;
+    }
+    __syncthreads();
+    if (c > 0) {
+        a.kb.cstart[row + s] = s_base + s_w[wv] + ic - c;
+        a.kb.keys[row + s] = KEY_EMPTY;
+        a.kb.cnt[row + s] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_qbin_scatter(const AssocArgs a) {
+    const AssocSlot sl = assoc_slot(a);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= sl.n) return;
+    const int pos = a.kb.cstart[(size_t)blockIdx.y * a.kb.capq + a.kb.qslot[sl.woff + i]] + a.kb.qrank[sl.woff + i];
+    a.kb.qs[sl.woff + pos] = a.kb.qtmp[sl.woff + i];
+}
+
+// per launch row y and tile of 1024 consecutive presorted points: units + grouped world-frame queries (w = original index)
+__global__ __launch_bounds__(QT_THREADS) void k_qbin_tile(const AssocArgs a, const float4* __restrict__ ps) {
+    __shared__ unsigned long long s_key[QT_SLOTS];
+    __shared__ int s_cnt[QT_SLOTS], s_ust[QT_SLOTS];
+    __shared__ int s_wc[16], s_wu[16], s_ubase;
+    const AssocSlot sl = assoc_slot(a);
+    const int tile0 = blockIdx.x * QT_THREADS, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tile0 >= sl.n) return;
+    for (int s = tid; s < QT_SLOTS; s += QT_THREADS) { s_key[s] = KEY_EMPTY; s_cnt[s] = 0; }
+    __syncthreads();
+    const int i = tile0 + tid;
+    const bool live = i < sl.n;
+    float px = 0, py = 0, pz = 0, pw = 0;
+    int slot = 0, rank = 0;
+    if (live) {
+        const float4 pl = ps[sl.qoff + i];
+        const double pin[3] = {(double)pl.x, (double)pl.y, (double)pl.z};
+        double po[3];
+        a_qrot(sl.q, pin, po);
+        px = (float)(po[0] + sl.t[0]); py = (float)(po[1] + sl.t[1]); pz = (float)(po[2] + sl.t[2]); pw = pl.w;
+        const unsigned long long key = pack_key(cell_of(px, a.inv_cell), cell_of(py, a.inv_cell), cell_of(pz, a.inv_cell));
+        unsigned s = hash_key(key) & (QT_SLOTS - 1);
+        for (;;) {
+            const unsigned long long prev = atomicCAS(&s_key[s], KEY_EMPTY, key);
+            if (prev == KEY_EMPTY || prev == key) break;
+            s = (s + 1) & (QT_SLOTS - 1);
+        }
+        rank = atomicAdd(&s_cnt[s], 1);
+        slot = (int)s;
+    }
+    __syncthreads();
+    // exclusive scan of (queries, units) over the 2048 slots, two slots per thread
+    const int c0 = s_cnt[2 * tid], c1 = s_cnt[2 * tid + 1];
+    const int u0 = (c0 + TK_Q - 1) / TK_Q, u1 = (c1 + TK_Q - 1) / TK_Q;
+    int ic = c0 + c1, iu = u0 + u1;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(ic, off, 64), u = __shfl_up(iu, off, 64);
+        if (lane >= off) { ic += v; iu += u; }
+    }
+    if (lane == 63) { s_wc[wv] = ic; s_wu[wv] = iu; }
+    __syncthreads();
+    if (tid == 0) {
+        int tc = 0, tu = 0;
+        for (int k = 0; k < 16; ++k) { const int v = s_wc[k], u = s_wu[k]; s_wc[k] = tc; s_wu[k] = tu; tc += v; tu += u; }
+        s_ubase = atomicAdd(&a.kb.counters[2 * blockIdx.y + 1], tu);
+    }
+    __syncthreads();
+    const int st0 = s_wc[wv] + ic - (c0 + c1), ut0 = s_ubase + s_wu[wv] + iu - (u0 + u1);
+    s_cnt[2 * tid] = st0; s_cnt[2 * tid + 1] = st0 + c0;
+    int2* un = a.kb.units + (size_t)blockIdx.y * a.kb.unit_stride;
+    for (int u = 0; u < u0; ++u) un[ut0 + u] = make_int2(tile0 + st0 + TK_Q * u, min(TK_Q, c0 - TK_Q * u));
+    for (int u = 0; u < u1; ++u) un[ut0 + u0 + u] = make_int2(tile0 + st0 + c0 + TK_Q * u, min(TK_Q, c1 - TK_Q * u));
+    __syncthreads();
+    if (live) a.kb.qs[sl.woff + tile0 + s_cnt[slot] + rank] = make_float4(px, py, pz, pw);
+}
+
+// sorted insertion of `key` into t[0] <= ... <= t[6]: new t[k] = med3(t[k-1], key, t[k]) (from the OLD values), new t[0] = min
+__device__ __forceinline__ unsigned tk_med3(const unsigned a, const unsigned b, const unsigned c) {
+    return max(min(a, b), min(max(a, b), c));
+}
+__device__ __forceinline__ void tk_insert(unsigned t[TK_SEL], const unsigned key) {
+#pragma unroll
+    for (int k = TK_SEL - 1; k > 0; --k) t[k] = tk_med3(t[k - 1], key, t[k]);
+    t[0] = min(t[0], key);
+}
+
+__global__ __launch_bounds__(256) void k_knn5_tile(const AssocArgs a, const float4* __restrict__ map, const int4* __restrict__ ent,
+                                                   int* __restrict__ o_nn5, float* __restrict__ o_d4) {
+    __shared__ float4 s_pts[TK_UNITS][TK_CAP + 2];      // + 2: the two units of a wavefront broadcast from different banks
+    __shared__ int s_pos[TK_UNITS][TK_CAP];
+    __shared__ int2 s_tab[TK_UNITS][33];
+    const int lane = threadIdx.x & 63, l32 = threadIdx.x & 31, j = threadIdx.x & (TK_Q - 1), h = (threadIdx.x >> 4) & 1, g = threadIdx.x / TK_LANES;
+    const int gbase = lane & ~(TK_LANES - 1);
+    const AssocSlot sl = assoc_slot(a);
+    if (sl.n <= 0) return;
+    o_nn5 += 5 * sl.woff; o_d4 += sl.woff;
+    if (sl.ent) { ent = sl.ent; map = sl.map; }
+    const int table_cap = sl.table_cap;
+    const int n_units = a.kb.counters[2 * blockIdx.y + 1];
+    const int2* units = a.kb.units + (size_t)blockIdx.y * a.kb.unit_stride;
+    const float4* qs = a.kb.qs + sl.woff;
+    for (int u0 = blockIdx.x * TK_UNITS; u0 < n_units; u0 += gridDim.x * TK_UNITS) {
+        const int uid = u0 + g;
+        const bool ulive = uid < n_units;
+        const int2 un = ulive ? units[uid] : make_int2(0, 0);
+        const bool qlive = j < un.y;
+        const float4 qp = ulive ? qs[un.x + (qlive ? j : 0)] : make_float4(0, 0, 0, 0);
+        const float px = qp.x, py = qp.y, pz = qp.z;
+        const int qi = __float_as_int(qp.w);
+        const int cx = cell_of(px, a.inv_cell), cy = cell_of(py, a.inv_cell), cz = cell_of(pz, a.inv_cell);    // the same for the whole unit
+        // ---- probe the 27 cells once per unit: lane c < 27 takes cell c
+        int cs = 0, cc = 0;
+        if (l32 < 27 && ulive) {
+            const int dx = l32 % 3 - 1, dy = (l32 / 3) % 3 - 1, dz = l32 / 9 - 1;
+            const unsigned long long key = pack_key(cx + dx, cy + dy, cz + dz);
+            const int klo = (int)(unsigned)(key & 0xffffffffull), khi = (int)(unsigned)(key >> 32);
+            unsigned s = home_slot(cx + dx, cy + dy, cz + dz, table_cap);
+            for (;;) {
+                const int4 e = ent[s];
+                if (e.x == klo && e.y == khi) { cs = e.z; cc = e.w; break; }
+                if ((e.x & e.y) == -1) break;
+                s = (s + 1) & (table_cap - 1);
+            }
+        }
+        int incl = cc;
+#pragma unroll
+        for (int off = 1; off < TK_LANES; off <<= 1) {
+            const int t0 = __shfl_up(incl, off, TK_LANES);
+            if (l32 >= off) incl += t0;
+        }
+        s_tab[g][l32] = make_int2(incl - cc, cs);
+        const int tot = __shfl(incl, gbase + TK_LANES - 1, 64);
+        if (l32 == 0) s_tab[g][32] = make_int2(tot, 0);
+        const int tot_w = max(tot, __shfl_xor(tot, 32, 64));
+        GLIO_WAVE_LDS_SYNC();
+        const int2* tab = s_tab[g];
+        auto locate = [&](const int f) {
+            int c = 0;
+#pragma unroll
+            for (int step = 16; step > 0; step >>= 1) if (tab[c + step].x <= f) c += step;
+            const int2 e = tab[c];
+            return e.y + (f - e.x);
+        };
+        unsigned long long bk[5] = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull};
+        int bp[5] = {-1, -1, -1, -1, -1};
+        for (int base = 0; base < tot_w; base += TK_CAP) {
+            const int n_c = min(max(tot - base, 0), TK_CAP);                       // staged candidates of this unit
+            const int n_w = min(tot_w - base, TK_CAP), n_w8 = (n_w + 7) & ~7;       // scan length of the wavefront
+            // ---- stage: beyond the unit's own list a far point (never selected)
+            for (int f = l32; f < n_w8; f += TK_LANES) {
+                float4 pt = make_float4(3e18f, 3e18f, 3e18f, 0.f);
+                int pos = -1;
+                if (f < n_c) { pos = locate(base + f); pt = map[pos]; }
+                s_pts[g][f] = pt;
+                s_pos[g][f] = pos;
+            }
+            GLIO_WAVE_LDS_SYNC();
+            // ---- scan: every lane ranks its half (slots of parity h) of the staged list for its own query
+            unsigned tk[TK_SEL];
+#pragma unroll
+            for (int k = 0; k < TK_SEL; ++k) tk[k] = ~0u;
+            for (int f = h; f < n_w8; f += 8) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 mp = s_pts[g][f + 2 * u];
+                    const float ex = px - mp.x, ey = py - mp.y, ez = pz - mp.z;
+                    float d = ex * ex;
+                    d = d + ey * ey;
+                    d = d + ez * ez;
+                    tk_insert(tk, (__float_as_uint(d) & ~TK_MASK) | (unsigned)(f + 2 * u));
+                }
+            }
+            // ---- exact re-ranking of the selection, merged into the lane's running five
+            bool all_in = false;
+#pragma unroll
+            for (int k = 0; k < TK_SEL; ++k) {
+                const unsigned t = tk[k];
+                const int slot = (int)(t & TK_MASK);
+                const bool real = t != ~0u && slot < n_c;
+                if (real) knn5_insert(px, py, pz, s_pts[g][slot], s_pos[g][slot], bk, bp);
+                if (k == TK_SEL - 1) all_in = !real;                                // fewer than TK_SEL candidates: all of them were merged
+            }
+            const bool safe = all_in || ((unsigned)(bk[4] >> 32) & ~TK_MASK) < (tk[TK_SEL - 1] & ~TK_MASK);
+            if (__any(qlive && !safe)) {
+                if (qlive && !safe) {
+                    for (int f = h; f < n_c; f += 2) {
+                        bool dup = false;
+#pragma unroll
+                        for (int k = 0; k < TK_SEL; ++k) dup = dup || (tk[k] != ~0u && (int)(tk[k] & TK_MASK) == f);
+                        if (!dup) knn5_insert(px, py, pz, s_pts[g][f], s_pos[g][f], bk, bp);
+                    }
+                }
+            }
+            GLIO_WAVE_LDS_SYNC();
+        }
+        // ---- the other half's five
+        unsigned long long ok[5]; int op[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { ok[k] = shfl_xor_u64(bk[k], 16); op[k] = __shfl_xor(bp[k], 16, 64); }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) knn5_insert_key(ok[k], op[k], bk, bp);
+        if (qlive && h == 0) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) o_nn5[5 * (size_t)qi + k] = bp[k];
+            o_d4[qi] = bp[4] >= 0 ? __uint_as_float((unsigned)(bk[4] >> 32)) : FLT_MAX;
+        }
+    }
+}
+
 #define PF_BLOCK 256
 template <bool BATCH>
 __global__ __launch_bounds__(PF_BLOCK) void k_plane_fit(const AssocArgs a, const float4* __restrict__ scan, const float4* __restrict__ map,
@@ -458,6 +755,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_plane_fit(const AssocArgs a, const
                                                         int* __restrict__ o_nn, const float4* __restrict__ loc, double* __restrict__ o_nc) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (a.kb.counters && blockIdx.x == 0 && threadIdx.x == 0) { a.kb.counters[2 * blockIdx.y] = 0; a.kb.counters[2 * blockIdx.y + 1] = 0; }
     const AssocSlot sl = assoc_slot(a);
     if (blockIdx.x * PF_BLOCK >= sl.n) return;
     scan += sl.qoff; nn5 += 5 * sl.woff; d4 += sl.woff;
@@ -577,50 +875,97 @@ __global__ __launch_bounds__(PF_BLOCK) void k_plane_fit(const AssocArgs a, const
 }
 
 // order-preserving compaction: single-workgroup exclusive scan of the flags, then scatter
-__global__ __launch_bounds__(1024) void k_scan_flags(const int* __restrict__ flag, int n, int* __restrict__ pos, int* __restrict__ total,
-                                                     const int* __restrict__ win_counts, const int b_stride) {
-    __shared__ int sums[1024];
-    const int tid = threadIdx.x;
-    if (win_counts) {                      // window mode: one workgroup per keyframe slot
-        const int k = blockIdx.x;
-        n = (win_counts[k] + PF_BLOCK - 1) / PF_BLOCK;
-        flag += (size_t)k * b_stride; pos += (size_t)k * b_stride; total += k;
-    }
-    const int chunk = (n + 1023) / 1024;
-    const int beg = tid * chunk, end = min(n, beg + chunk);
-    int s = 0;
-    for (int i = beg; i < end; ++i) s += flag[i];
-    sums[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {       // Hillis-Steele inclusive scan
-        const int v = tid >= off ? sums[tid - off] : 0;
-        __syncthreads();
-        sums[tid] += v;
-        __syncthreads();
-    }
-    int run = sums[tid] - s;
-    for (int i = beg; i < end; ++i) { pos[i] = run; run += flag[i]; }
-    if (tid == 1023) *total = sums[1023];
-}
-
-__global__ void k_compact(const int* __restrict__ flag, const int* __restrict__ lpos, const int* __restrict__ boff, int n,
-                          const float4* __restrict__ q_pt, const float4* __restrict__ q_plane, const double* __restrict__ q_score,
-                          float4* __restrict__ o_pt, float4* __restrict__ o_plane, double* __restrict__ o_score,
-                          const int* __restrict__ win_counts, const int q_stride, const int w_stride, const int b_stride) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// order-preserving compaction: k_plane_fit left, per workgroup of PF_BLOCK queries, the kept count (bcount) and every kept
+// query's position inside the workgroup (lpos).  Each workgroup here sums the counts of the workgroups before it (a few
+// hundred integers) instead of waiting for a separate scan kernel; the last one writes the slot's total.
+__global__ __launch_bounds__(PF_BLOCK) void k_compact(const int* __restrict__ flag, const int* __restrict__ lpos, const int* __restrict__ bcount, int n,
+                                                      const float4* __restrict__ q_pt, const float4* __restrict__ q_plane, const double* __restrict__ q_score,
+                                                      float4* __restrict__ o_pt, float4* __restrict__ o_plane, double* __restrict__ o_score, int* __restrict__ total,
+                                                      const int* __restrict__ win_counts, const int q_stride, const int w_stride, const int b_stride) {
+    __shared__ int s_part[PF_BLOCK / 64], s_off;
+    const int i = blockIdx.x * PF_BLOCK + threadIdx.x;
     if (win_counts) {
         const size_t k = blockIdx.y;
         n = win_counts[k];
-        flag += k * w_stride; lpos += k * w_stride; boff += k * b_stride; q_pt += k * w_stride; q_plane += k * w_stride; q_score += k * w_stride;
-        o_pt += k * q_stride; o_plane += k * q_stride; o_score += k * q_stride;
+        flag += k * w_stride; lpos += k * w_stride; bcount += k * b_stride; q_pt += k * w_stride; q_plane += k * w_stride; q_score += k * w_stride;
+        o_pt += k * q_stride; o_plane += k * q_stride; o_score += k * q_stride; total += k;
+        if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) *total = 0;
     }
+    if (blockIdx.x * PF_BLOCK >= n) return;
+    int part = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += PF_BLOCK) part += bcount[b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int k = 0; k < PF_BLOCK / 64; ++k) t += s_part[k];
+        s_off = t;
+        if ((blockIdx.x + 1) * PF_BLOCK >= n) *total = t + bcount[blockIdx.x];
+    }
+    __syncthreads();
     if (i >= n || !flag[i]) return;
-    const int p = boff[i / PF_BLOCK] + lpos[i];
+    const int p = s_off + lpos[i];
     o_pt[p] = q_pt[i]; o_plane[p] = q_plane[i]; o_score[p] = q_score[i];
 }
 
 // ------------------------------------------------------------------------------------------------
 static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+struct KnnBinHost { KnnBin d; int rows, cap, capq_max; };
+static int g_knn_mode = 0;           // 0 = tiled search (k_qbin_* + k_knn5_tile), 1 = one 16-lane group per query (k_knn5); glio_debug_set_knn_mode
+static KnnBinHost* knn_bin_create(int rows, int cap) {
+    KnnBinHost* h = new KnnBinHost();
+    memset(h, 0, sizeof *h);
+    h->rows = rows; h->cap = cap; h->capq_max = next_pow2(2 * (cap > 512 ? cap : 512));
+    KnnBin& d = h->d;
+    d.unit_stride = cap / TK_Q + cap + 16;
+    const size_t tq = (size_t)rows * h->capq_max, wq = (size_t)rows * cap;
+    bool ok = hipMalloc((void**)&d.keys, tq * 8) == hipSuccess && hipMalloc((void**)&d.cnt, tq * 4) == hipSuccess && hipMalloc((void**)&d.cstart, tq * 4) == hipSuccess &&
+              hipMalloc((void**)&d.qslot, wq * 4) == hipSuccess && hipMalloc((void**)&d.qrank, wq * 4) == hipSuccess && hipMalloc((void**)&d.qtmp, wq * 16) == hipSuccess &&
+              hipMalloc((void**)&d.qs, wq * 16) == hipSuccess && hipMalloc((void**)&d.units, (size_t)rows * d.unit_stride * 8) == hipSuccess &&
+              hipMalloc((void**)&d.counters, (size_t)rows * 8) == hipSuccess;
+    ok = ok && hipMemset(d.keys, 0xff, tq * 8) == hipSuccess && hipMemset(d.cnt, 0, tq * 4) == hipSuccess && hipMemset(d.counters, 0, (size_t)rows * 8) == hipSuccess;
+    if (!ok) { glio_set_error("hipMalloc failed for the query binning buffers"); return nullptr; }
+    return h;
+}
+static void knn_bin_destroy(KnnBinHost* h) {
+    if (!h) return;
+    void* p[] = {h->d.keys, h->d.cnt, h->d.cstart, h->d.qslot, h->d.qrank, h->d.qtmp, h->d.qs, h->d.units, h->d.counters};
+    for (void* q : p) if (q) hipFree(q);
+    delete h;
+}
+// presort one cloud (n points at `cloud`, in its own frame) into `ps` (w = original index): the same binning kernels with the
+// identity pose and 5 m blocks, so that every run of 1024 consecutive points of `ps` is spatially compact
+static void enqueue_presort(hipStream_t stream, KnnBinHost* kb, const float4* cloud, int n, float4* ps) {
+    if (n <= 0) return;
+    AssocArgs a;
+    memset(&a, 0, sizeof a);
+    a.q[0] = 1.0; a.inv_cell = 1.0f / PRESORT_CELL; a.n = n;
+    a.kb = kb->d; a.kb.qs = ps;
+    a.kb.capq = next_pow2(2 * (n > 512 ? n : 512));
+    if (a.kb.capq > kb->capq_max) a.kb.capq = kb->capq_max;
+    hipLaunchKernelGGL(k_qbin_count, dim3((n + 255) / 256), dim3(256), 0, stream, a, cloud);
+    hipLaunchKernelGGL(k_qbin_alloc, dim3(a.kb.capq / 1024), dim3(1024), 0, stream, a);
+    hipLaunchKernelGGL(k_qbin_scatter, dim3((n + 255) / 256), dim3(256), 0, stream, a);
+    hipMemsetAsync(kb->d.counters, 0, 8, stream);
+}
+// exact 5-NN of every query of the launch rows [0, rows): the caller's AssocArgs select the row geometry (assoc_slot);
+// `scan` = the clouds as uploaded, `ps` = their presorted copies
+static void enqueue_knn(hipStream_t stream, AssocArgs& a, KnnBinHost* kb, int rows, int maxn, const float4* scan, const float4* ps, const float4* map,
+                        const int4* ent, int* nn5, float* d4) {
+    if (g_knn_mode == 1 || !kb) {
+        memset(&a.kb, 0, sizeof a.kb);
+        hipLaunchKernelGGL(k_knn5, dim3((maxn + AQ_PER_BLOCK - 1) / AQ_PER_BLOCK, rows), dim3(256), 0, stream, a, scan, map, ent, nn5, d4);
+        return;
+    }
+    a.kb = kb->d;
+    hipLaunchKernelGGL(k_qbin_tile, dim3((maxn + QT_THREADS - 1) / QT_THREADS, rows), dim3(QT_THREADS), 0, stream, a, ps);
+    int gx = (maxn + 63) / 64;
+    if (gx > 2048) gx = 2048;
+    hipLaunchKernelGGL(k_knn5_tile, dim3(gx, rows), dim3(256), 0, stream, a, map, ent, nn5, d4);
+}
 
 int glio_assoc_create(glio_ctx* c) {
     AssocWork* w = new AssocWork();
@@ -646,6 +991,9 @@ int glio_assoc_create(glio_ctx* c) {
     AALLOC(w->d_win, (size_t)c->W * 64);
     if (hipHostMalloc((void**)&w->h_count, 16) != hipSuccess) return GLIO_E_HIP;
     if (hipHostMalloc((void**)&w->h_win, (size_t)c->W * 64) != hipSuccess) return GLIO_E_HIP;
+    w->kb = knn_bin_create(c->W, cap);
+    if (!w->kb) return GLIO_E_HIP;
+    AALLOC(w->d_ps, wc * 16);
     c->assoc = w;
     c->map_n = 0;
     return GLIO_OK;
@@ -655,12 +1003,23 @@ void glio_assoc_destroy(glio_ctx* c) {
     AssocWork* w = c->assoc;
     if (!w) return;
     void* ptrs[] = {w->d_keys, w->d_ent, w->d_cell_count, w->d_cell_start, w->d_cell_fill, w->d_pt_slot, w->d_map_raw, c->d_map_sorted, w->d_total,
-                    w->d_count_tmp, w->d_q_pt, w->d_q_plane, w->d_q_score, w->d_q_flag, w->d_q_pos, w->d_nn, w->d_nn5, w->d_d4, w->d_bcount, w->d_boff, w->d_win};
+                    w->d_count_tmp, w->d_q_pt, w->d_q_plane, w->d_q_score, w->d_q_flag, w->d_q_pos, w->d_nn, w->d_nn5, w->d_d4, w->d_bcount, w->d_boff, w->d_win, w->d_ps};
     for (void* p : ptrs) if (p) hipFree(p);
+    knn_bin_destroy(w->kb);
     hipHostFree(w->h_count);
     if (w->h_win) hipHostFree(w->h_win);
     delete w;
     c->assoc = nullptr;
+}
+
+// a scan was uploaded to / moved between slots: keep its presorted copy in step (enqueued on the context stream)
+void glio_assoc_scan_uploaded(glio_ctx* c, int slot, int n) {
+    AssocWork* w = c->assoc;
+    if (w) enqueue_presort(c->stream, w->kb, c->d_scan + (size_t)slot * c->cap, n, w->d_ps + (size_t)slot * c->cap);
+}
+void glio_assoc_scan_moved(glio_ctx* c, int from, int to, int n) {
+    AssocWork* w = c->assoc;
+    if (w && n > 0) hipMemcpyAsync(w->d_ps + (size_t)to * c->cap, w->d_ps + (size_t)from * c->cap, (size_t)n * 16, hipMemcpyDeviceToDevice, c->stream);
 }
 
 static void enqueue_build(glio_ctx* c, int n) {
@@ -711,20 +1070,20 @@ static void enqueue_assoc(glio_ctx* c, int slot, const double q[4], const double
     const size_t off = (size_t)slot * c->cap;
     const int nblk = (n + PF_BLOCK - 1) / PF_BLOCK;
     if (n > 0) {
-        hipLaunchKernelGGL(k_knn5, dim3((n + AQ_PER_BLOCK - 1) / AQ_PER_BLOCK), dim3(256), 0, c->stream, a, c->d_scan + off, c->d_map_sorted, w->d_ent,
-                           w->d_nn5, w->d_d4);
+        enqueue_knn(c->stream, a, w->kb, 1, n, c->d_scan + off, w->d_ps + off, c->d_map_sorted, w->d_ent, w->d_nn5, w->d_d4);
         hipLaunchKernelGGL(k_plane_fit<false>, dim3(nblk), dim3(PF_BLOCK), 0, c->stream, a, c->d_scan + off, c->d_map_sorted, w->d_nn5, w->d_d4,
                            w->d_q_pt, w->d_q_plane, w->d_q_score, w->d_q_flag, w->d_q_pos, w->d_bcount, want_nn ? w->d_nn : nullptr,
                            (const float4*)nullptr, (double*)nullptr);
     }
-    hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(1024), 0, c->stream, w->d_bcount, nblk, w->d_boff, c->d_count + slot, (const int*)nullptr, 0);
     if (n > 0) {
-        hipLaunchKernelGGL(k_compact, dim3((n + 255) / 256), dim3(256), 0, c->stream, w->d_q_flag, w->d_q_pos, w->d_boff, n, w->d_q_pt,
-                           w->d_q_plane, w->d_q_score, c->d_pts + off, c->d_planes + off, c->d_scores + off, (const int*)nullptr, 0, 0, 0);
+        hipLaunchKernelGGL(k_compact, dim3((n + PF_BLOCK - 1) / PF_BLOCK), dim3(PF_BLOCK), 0, c->stream, w->d_q_flag, w->d_q_pos, w->d_bcount, n, w->d_q_pt,
+                           w->d_q_plane, w->d_q_score, c->d_pts + off, c->d_planes + off, c->d_scores + off, c->d_count + slot, (const int*)nullptr, 0, 0, 0);
+    } else {
+        hipMemsetAsync(c->d_count + slot, 0, 4, c->stream);
     }
 }
 
-// all W slots in four launches: blockIdx.y = slot
+// all W slots in four launches (tile binning, search, plane fit, compaction): blockIdx.y = slot
 static int enqueue_assoc_window(glio_ctx* c, const double* quats, const double* trans) {
     AssocWork* w = c->assoc;
     const int W = c->W;
@@ -744,16 +1103,13 @@ static int enqueue_assoc_window(glio_ctx* c, const double* quats, const double* 
     a.win_poses = w->d_win; a.win_counts = reinterpret_cast<const int*>(w->d_win + 7 * W);
     a.q_stride = c->cap; a.w_stride = c->cap; a.b_stride = c->cap / AQ_PER_BLOCK + 2;
     if (maxn > 0) {
-        hipLaunchKernelGGL(k_knn5, dim3((maxn + AQ_PER_BLOCK - 1) / AQ_PER_BLOCK, W), dim3(256), 0, c->stream, a, c->d_scan, c->d_map_sorted, w->d_ent,
-                           w->d_nn5, w->d_d4);
+        enqueue_knn(c->stream, a, w->kb, W, maxn, c->d_scan, w->d_ps, c->d_map_sorted, w->d_ent, w->d_nn5, w->d_d4);
         hipLaunchKernelGGL(k_plane_fit<false>, dim3((maxn + PF_BLOCK - 1) / PF_BLOCK, W), dim3(PF_BLOCK), 0, c->stream, a, c->d_scan, c->d_map_sorted,
                            w->d_nn5, w->d_d4, w->d_q_pt, w->d_q_plane, w->d_q_score, w->d_q_flag, w->d_q_pos, w->d_bcount, (int*)nullptr,
                            (const float4*)nullptr, (double*)nullptr);
     }
-    hipLaunchKernelGGL(k_scan_flags, dim3(W), dim3(1024), 0, c->stream, w->d_bcount, 0, w->d_boff, c->d_count, a.win_counts, a.b_stride);
-    if (maxn > 0)
-        hipLaunchKernelGGL(k_compact, dim3((maxn + 255) / 256, W), dim3(256), 0, c->stream, w->d_q_flag, w->d_q_pos, w->d_boff, 0, w->d_q_pt,
-                           w->d_q_plane, w->d_q_score, c->d_pts, c->d_planes, c->d_scores, a.win_counts, a.q_stride, a.w_stride, a.b_stride);
+    hipLaunchKernelGGL(k_compact, dim3(maxn > 0 ? (maxn + PF_BLOCK - 1) / PF_BLOCK : 1, W), dim3(PF_BLOCK), 0, c->stream, w->d_q_flag, w->d_q_pos, w->d_bcount, 0, w->d_q_pt,
+                       w->d_q_plane, w->d_q_score, c->d_pts, c->d_planes, c->d_scores, c->d_count, a.win_counts, a.q_stride, a.w_stride, a.b_stride);
     return GLIO_OK;
 }
 
@@ -870,6 +1226,7 @@ struct glio_bassoc {
     int K, cap; long long max_con;
     float inv_cell;
     float4* d_local;                // [K][cap] keyframe-local clouds
+    float4* d_local_ps;             // [K][cap] the same, presorted (w = index in the cloud)
     float4* d_global;               // [cap] staging: one cloud in the global frame
     int* h_n;                       // [K]
     FrameHash* frames;              // [K]
@@ -877,6 +1234,7 @@ struct glio_bassoc {
     // dense per-query results of the pair in flight
     float4* d_q_cp; double* d_q_nc; double* d_q_score; int* d_q_flag; int* d_q_pos; int* d_bcount; int* d_boff;
     int* d_nn5; float* d_d4;
+    KnnBinHost* kb;                 // query binning buffers of the tiled search, BA_CHUNK rows
     // compacted output, pair major
     float4* d_cp; double* d_nc; double* d_score;
     long long* d_run;               // [1] running total
@@ -957,6 +1315,12 @@ __global__ void k_compact_pairs(const int* __restrict__ flag, const int* __restr
 
 extern "C" {
 
+int glio_debug_set_knn_mode(int mode) {
+    if (mode != 0 && mode != 1) return GLIO_E_ARG;
+    g_knn_mode = mode;
+    return GLIO_OK;
+}
+
 int glio_bassoc_create(int device, int K, int max_points_per_frame, int64_t max_constraints, glio_bassoc** out) {
     if (!out || K < 2 || max_points_per_frame < 1 || max_constraints < 1) return GLIO_E_ARG;
     int ndev = 0;
@@ -969,6 +1333,7 @@ int glio_bassoc_create(int device, int K, int max_points_per_frame, int64_t max_
     b->inv_cell = 1.0f / fmaxf(1.25f, sqrtf(1.5f) * 1.0001f);
     const size_t cap = (size_t)b->cap;
     BA_CHECK(hipMalloc((void**)&b->d_local, (size_t)K * cap * 16)); BA_CHECK(hipMalloc((void**)&b->d_global, cap * 16));
+    BA_CHECK(hipMalloc((void**)&b->d_local_ps, (size_t)K * cap * 16));
     b->h_n = new int[K]();
     b->frames = new FrameHash[K]();
     const int tc = next_pow2(2 * b->cap);
@@ -992,6 +1357,8 @@ int glio_bassoc_create(int device, int K, int max_points_per_frame, int64_t max_
     BA_CHECK(hipMalloc((void**)&b->d_cp, (size_t)max_constraints * 16)); BA_CHECK(hipMalloc((void**)&b->d_nc, (size_t)max_constraints * 48));
     BA_CHECK(hipMalloc((void**)&b->d_score, (size_t)max_constraints * 8));
     BA_CHECK(hipMalloc((void**)&b->d_run, 16)); BA_CHECK(hipMalloc((void**)&b->d_poses, (size_t)K * 7 * 8));
+    b->kb = knn_bin_create(BA_CHUNK, b->cap);
+    if (!b->kb) return GLIO_E_HIP;
     *out = b;
     return GLIO_OK;
 }
@@ -1005,10 +1372,11 @@ void glio_bassoc_destroy(glio_bassoc* b) {
         void* p[] = {f.d_keys, f.d_ent, f.d_cell_count, f.d_cell_start, f.d_cell_fill, f.d_pt_slot, f.d_sorted};
         for (void* q : p) if (q) hipFree(q);
     }
-    void* p[] = {b->d_nn5, b->d_d4, b->d_local, b->d_global, b->d_total, b->d_q_cp, b->d_q_nc, b->d_q_score, b->d_q_flag, b->d_q_pos, b->d_bcount, b->d_boff,
+    void* p[] = {b->d_nn5, b->d_d4, b->d_local, b->d_local_ps, b->d_global, b->d_total, b->d_q_cp, b->d_q_nc, b->d_q_score, b->d_q_flag, b->d_q_pos, b->d_bcount, b->d_boff,
                  b->d_cp, b->d_nc, b->d_score, b->d_run, b->d_poses, b->d_pair_off, b->d_frames, b->d_pair_ci, b->d_pair_cj,
                  b->d_sel_cp, b->d_sel_nc, b->d_sel_score, b->d_sel_idx};
     for (void* q : p) if (q) hipFree(q);
+    knn_bin_destroy(b->kb);
     if (b->h_pair_off) hipHostFree(b->h_pair_off);
     delete[] b->h_n; delete[] b->frames;
     hipStreamDestroy(b->stream);
@@ -1019,6 +1387,8 @@ int glio_bassoc_set_frame(glio_bassoc* b, int k, const float* scan_xyzi, int n) 
     if (!b || k < 0 || k >= b->K || n < 0 || n > b->cap || (n > 0 && !scan_xyzi)) { glio_set_error("bad keyframe cloud (k %d, n %d)", k, n); return GLIO_E_ARG; }
     BA_CHECK(hipSetDevice(b->device));
     if (n > 0) BA_CHECK(hipMemcpyAsync(b->d_local + (size_t)k * b->cap, scan_xyzi, (size_t)n * 16, hipMemcpyHostToDevice, b->stream));
+    enqueue_presort(b->stream, b->kb, b->d_local + (size_t)k * b->cap, n, b->d_local_ps + (size_t)k * b->cap);
+    BA_CHECK(hipGetLastError());
     BA_CHECK(hipStreamSynchronize(b->stream));
     b->h_n[k] = n;
     return GLIO_OK;
@@ -1080,8 +1450,7 @@ int glio_bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const int3
             const int np = n_pairs - p0 < BA_CHUNK ? n_pairs - p0 : BA_CHUNK;
             a.pair0 = p0;
             if (maxn > 0) {
-                hipLaunchKernelGGL(k_knn5, dim3((maxn + AQ_PER_BLOCK - 1) / AQ_PER_BLOCK, np), dim3(256), 0, b->stream, a, b->d_local, (const float4*)nullptr,
-                                   (const int4*)nullptr, b->d_nn5, b->d_d4);
+                enqueue_knn(b->stream, a, b->kb, np, maxn, b->d_local, b->d_local_ps, (const float4*)nullptr, (const int4*)nullptr, b->d_nn5, b->d_d4);
                 hipLaunchKernelGGL(k_plane_fit<true>, dim3((maxn + PF_BLOCK - 1) / PF_BLOCK, np), dim3(PF_BLOCK), 0, b->stream, a, b->d_local, (const float4*)nullptr,
                                    b->d_nn5, b->d_d4, b->d_q_cp, (float4*)nullptr, b->d_q_score, b->d_q_flag, b->d_q_pos, b->d_bcount, (int*)nullptr,
                                    b->d_local, b->d_q_nc);

@@ -281,6 +281,8 @@ int glio_set_scan(glio_ctx* c, int slot, const float* scan, int n) {
     if (!c || slot < 0 || slot >= c->W || n < 0 || n > c->cap) { glio_set_error("bad slot / scan size"); return GLIO_E_ARG; }
     GLIO_HIP_CHECK(hipSetDevice(c->device));
     if (n > 0) GLIO_HIP_CHECK(hipMemcpyAsync(c->d_scan + (size_t)slot * c->cap, scan, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    glio_assoc_scan_uploaded(c, slot, n);
+    GLIO_HIP_CHECK(hipGetLastError());
     GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
     c->h_scan_count[slot] = n;
     return GLIO_OK;
@@ -300,6 +302,7 @@ int glio_slide_window(glio_ctx* c) {
     for (int s = 0; s + 1 < c->W; ++s) {
         const int n = c->h_scan_count[s + 1];
         if (n > 0) GLIO_HIP_CHECK(hipMemcpyAsync(c->d_scan + (size_t)s * c->cap, c->d_scan + (size_t)(s + 1) * c->cap, (size_t)n * 16, hipMemcpyDeviceToDevice, c->stream));
+        glio_assoc_scan_moved(c, s + 1, s, n);
         c->h_scan_count[s] = n;
     }
     c->h_scan_count[c->W - 1] = 0;

@@ -305,6 +305,9 @@ int glio_launch_marginalize(glio_ctx* c, int imu_edge0, double** J0_dev, double*
 size_t glio_tr_step_lds_bytes(int n);
 // assoc_kernels.hip
 int glio_assoc_create(glio_ctx* c);
+// the resident scan of a slot changed (uploaded / moved by the slide): keep the presorted copy the tiled search reads in step
+void glio_assoc_scan_uploaded(glio_ctx* c, int slot, int n);
+void glio_assoc_scan_moved(glio_ctx* c, int from, int to, int n);
 void glio_assoc_destroy(glio_ctx* c);
 int glio_assoc_build_map(glio_ctx* c, const float* map_xyzi, int n);
 int glio_assoc_run(glio_ctx* c, int slot, const double q[4], const double t[3], int* out_count);

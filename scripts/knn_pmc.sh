@@ -14,7 +14,13 @@ ctx.set_map(win.map_pts)
 for s in range(2): ctx.set_scan(s, win.scans[s])
 q, t = lidar_pose(win.opts, win.init.quat[0], win.init.trans[0])
 for _ in range(4): ctx.associate_resident(0, q, t)
+if os.environ.get("KNN_UNITS"):
+    R = synth.q2R(np.asarray(q)); p = (win.scans[0][:, :3].astype(np.float64) @ R.T + np.asarray(t)).astype(np.float32)
+    cell = np.floor(p * np.float32(1.0 / 1.25)).astype(np.int64)
+    _, cnt = np.unique(cell, axis=0, return_counts=True)
+    print("query cells", len(cnt), "units", int(np.sum((cnt + 15) // 16)), "mean fill", float(np.mean(cnt)), "median", float(np.median(cnt)), "max", int(cnt.max()))
 PY
+KNN_UNITS=1 python /tmp/knn_once.py | tail -1
 for GRP in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT"; do
   OUT=/tmp/knn_pmc; rm -rf $OUT; mkdir -p $OUT
   rocprofv3 --pmc $GRP --output-format csv -d $OUT -o pmc -- python /tmp/knn_once.py > /tmp/knn_pmc.log 2>&1
@@ -24,10 +30,11 @@ import csv, sys, collections
 acc = collections.defaultdict(list)
 try:
     for row in csv.DictReader(open(sys.argv[1])):
-        if "k_knn5" in row["Kernel_Name"]:
-            acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
-    for k, v in acc.items():
-        print(f"k_knn5 {k:32s} last launch {v[-1]:16.1f}  (launches {len(v)})")
+        kn = row["Kernel_Name"].split("(")[0]
+        if kn.startswith("k_knn5") or kn.startswith("k_qbin"):
+            acc[(kn, row["Counter_Name"])].append(float(row["Counter_Value"]))
+    for (kn, k), v in sorted(acc.items()):
+        print(f"{kn:16s} {k:32s} last launch {v[-1]:16.1f}  (launches {len(v)})")
     if not acc: print("no k_knn5 rows:", open("/tmp/knn_pmc.log").read()[-500:])
 except Exception as e:
     print("no data:", e); print(open("/tmp/knn_pmc.log").read()[-600:])

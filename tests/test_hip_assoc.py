@@ -150,3 +150,58 @@ def test_feature_selection_gathers_on_device(hip, small_window):
     assert sliding.feature_selection(ctx, 0, 100, 10, rng, random_select=False) == 0            # random_select false empties the set
     assert len(ctx.get_correspondences(0)[2]) == 0
     ctx.close()
+
+
+def test_tiled_search_exact_ties_and_dense_cells(hip, po):
+    """The tiled neighbour search ranks on truncated 32-bit keys and restores the exact (float distance, map index) order
+    afterwards.  Two inputs built to defeat a sloppy version of that: (a) a 0.25 m lattice map with queries ON lattice points
+    and cell centres -- dozens of exactly equal distances per query, so the selection's safety test fails and the exact rescan
+    must run; (b) 60 map points per voxel-hash cell (> 128 candidates per unit: several staging chunks)."""
+    win = synth.make_window(W=1, pts_per_scan=512, seed=synth.SEED_BASE + 9)
+    rng = np.random.default_rng(5)
+    g = np.arange(-16, 17) * 0.25
+    lat = np.stack(np.meshgrid(g + 10.0, g, [0.0, 0.25], indexing="ij"), -1).reshape(-1, 3)
+    lat_map = np.zeros((len(lat), 4), np.float32); lat_map[:, :3] = lat[rng.permutation(len(lat))]
+    qs = np.zeros((1500, 4), np.float32)
+    qs[:500, :3] = lat[rng.integers(0, len(lat), 500)]                       # on lattice points
+    qs[500:1000, :3] = lat[rng.integers(0, len(lat), 500)] + 0.125          # cell centres: 8 equidistant neighbours
+    qs[1000:, :3] = lat[rng.integers(0, len(lat), 500)] + rng.normal(0, 0.3, (500, 3))
+    ident_q, ident_t = np.array([1.0, 0, 0, 0]), np.zeros(3)
+    dense = np.zeros((40000, 4), np.float32)
+    dense[:, :3] = rng.uniform([5, -4, -0.05], [13, 4, 0.05], (40000, 3))   # a 8 x 8 m slab, 625 points per m^2
+    dq = np.zeros((3000, 4), np.float32); dq[:, :3] = rng.uniform([6, -3, -0.3], [12, 3, 0.3], (3000, 3))
+    lib = hip.load()
+    for mode in (0, 1):
+        lib.glio_debug_set_knn_mode(mode)
+        try:
+            for m, q in ((lat_map, qs), (dense, dq)):
+                o = synth.default_opts(1, pts=len(q), map_pts=len(m))
+                w2 = type("W", (), {"opts": o, "map_pts": m})
+                ctx = hip.Context(o)
+                ctx.set_map(m)
+                _check_slot(hip, po, ctx, w2, 0, q, ident_q, ident_t)
+                ctx.close()
+        finally:
+            lib.glio_debug_set_knn_mode(0)
+
+
+def test_both_search_modes_give_identical_records(hip):
+    """Tiled (default) and one-group-per-query searches on a full 64k scan: identical compacted records."""
+    win = synth.make_window(W=2, pts_per_scan=65536, seed=synth.SEED_BASE + 10)
+    lib = hip.load()
+    out = []
+    for mode in (0, 1):
+        lib.glio_debug_set_knn_mode(mode)
+        try:
+            ctx = hip.Context(win.opts)
+            ctx.set_map(win.map_pts)
+            q2, t2 = hip.lidar_pose(win.opts, win.init.quat[0], win.init.trans[0])
+            cnt = ctx.associate(0, win.scans[0], q2, t2)
+            hp, hpl, hsc = ctx.get_correspondences(0)
+            out.append((cnt, hp.copy(), hpl.copy(), hsc.copy()))
+            ctx.close()
+        finally:
+            lib.glio_debug_set_knn_mode(0)
+    assert out[0][0] == out[1][0] > 50000
+    for a, b in zip(out[0][1:], out[1][1:]):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
