@@ -24,7 +24,7 @@ def build(force=False, verbose=False):
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", "-Wno-unused-value",
-           ] + (["-DGLIO_DEV_STAMPS"] if os.environ.get("GLIO_DEV_STAMPS") == "1" else []) + srcs + ["-o", LIB]
+           ] + (["-DGLIO_DEV_STAMPS"] if os.environ.get("GLIO_DEV_STAMPS") == "1" else []) + os.environ.get("GLIO_EXTRA_DEFS", "").split() + srcs + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

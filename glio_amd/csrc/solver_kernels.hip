@@ -1378,6 +1378,35 @@ __device__ __forceinline__ void chain_step15(const int i, const int nb, const bo
     CS_PH(4);
 }
 
+// Preparation of a factored chain block for the back substitution, by a wavefront that has nothing else to do while the
+// two chain wavefronts work on the next keyframes: with L (rows 0..14), X = B L^-T (rows 15..29, row = neighbour's unknown)
+// and y = L^-1 r (row 30) in place, lane c < 15 solves L^T m = X[c][:] and lane 15 solves L^T m = y (15 sequential steps
+// each, L broadcast from LDS); rows 15..29 then hold M = L^-T X^T (row = OWN unknown) and row 30 holds w = L^-T y, so that
+// the back substitution of this keyframe is one matrix-vector product, z = w - M z_neighbour, instead of a 15-step
+// triangular solve on the critical path.
+__device__ __forceinline__ void chain_prepare_back(double* Bi, const int lane) {
+    const int c = lane < 16 ? lane : 0;
+    const double* xr = Bi + (c < KC_NB ? KC_NB + c : 30) * KC_RS;
+    double m[KC_NB];
+#pragma unroll
+    for (int k = 0; k < KC_NB; ++k) m[k] = xr[k];
+#pragma unroll
+    for (int k = KC_NB - 1; k >= 0; --k) {
+        double s0 = m[k], s1 = 0.0;
+#pragma unroll
+        for (int j = k + 1; j < KC_NB; ++j) { if ((j - k) & 1) s0 -= Bi[j * KC_RS + k] * m[j]; else s1 -= Bi[j * KC_RS + k] * m[j]; }
+        m[k] = (s0 + s1) * Bi[31 * KC_RS + k];
+    }
+    GLIO_WAVE_LDS_SYNC();                                  // every lane has read its right-hand side before anyone overwrites the rows
+    if (lane < KC_NB) {
+#pragma unroll
+        for (int r = 0; r < KC_NB; ++r) Bi[(KC_NB + r) * KC_RS + lane] = m[r];
+    } else if (lane == KC_NB) {
+#pragma unroll
+        for (int r = 0; r < KC_NB; ++r) Bi[30 * KC_RS + r] = m[r];
+    }
+}
+
 struct ChainArgs {
     int W, n, nd;
     const int2* ep_slots; const int* ep_off; const int* ep_list;
@@ -1624,6 +1653,10 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a, c
             }
         } else if (wv == 2) {
             if (it < nB) { const int i = W - 1 - it; chain_step15<true>(i, i - 1, true, av, Blk, CsB, lane, bad); }
+        } else if (wv == 1) {                       // (SIMD 1 and 3: not the SIMDs the two chain wavefronts issue on)
+            if (it >= 1 && it - 1 < nT) chain_prepare_back(Blk + (size_t)(it - 1) * KC_BLK, lane);
+        } else if (wv == 3) {
+            if (it >= 1 && it - 1 < nB) chain_prepare_back(Blk + (size_t)(W - it) * KC_BLK, lane);
         }
         __syncthreads();
     }
@@ -1658,10 +1691,23 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a, c
         if (lane < KC_NB) zb[15 * i + lane] = v;
         GLIO_WAVE_LDS_SYNC();
     };
+    auto back_mv = [&](const int i, const int nbr) {          // z_i = w_i - M_i z_neighbour (blocks transformed by chain_prepare_back)
+        const double* Bi = Blk + (size_t)i * KC_BLK;
+        if (lane < KC_NB) {
+            double mrow[KC_NB], zn[KC_NB];
+#pragma unroll
+            for (int k = 0; k < KC_NB; ++k) { mrow[k] = Bi[(KC_NB + lane) * KC_RS + k]; zn[k] = zb[15 * nbr + k]; }
+            double s0 = Bi[30 * KC_RS + lane], s1 = 0, s2 = 0;
+#pragma unroll
+            for (int k = 0; k < KC_NB; k += 3) { s0 -= mrow[k] * zn[k]; s1 -= mrow[k + 1] * zn[k + 1]; s2 -= mrow[k + 2] * zn[k + 2]; }
+            zb[15 * i + lane] = (s0 + s1) + s2;
+        }
+        GLIO_WAVE_LDS_SYNC();
+    };
     if (wv == 0) back(mid, -1);
     __syncthreads();
-    if (wv == 0) { for (int i = mid - 1; i >= 0; --i) back(i, i + 1); }
-    else if (wv == 1) { for (int i = mid + 1; i < W; ++i) back(i, i - 1); }
+    if (wv == 0) { for (int i = mid - 1; i >= 0; --i) back_mv(i, i + 1); }
+    else if (wv == 1) { for (int i = mid + 1; i < W; ++i) back_mv(i, i - 1); }
     __syncthreads();
     AR_STAMP(45);
     double bd2 = 0.0;
@@ -2128,6 +2174,10 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
             }
         } else if (wv == 2) {
             if (it < nB) { const int i = W - 1 - it; chain_step15<true>(i, i - 1, true, av, Blk, CsB, lane, bad); }
+        } else if (wv == 1) {                       // (SIMD 1 and 3: not the SIMDs the two chain wavefronts issue on)
+            if (it >= 1 && it - 1 < nT) chain_prepare_back(Blk + (size_t)(it - 1) * KC_BLK, lane);          // the block the top chain left last round
+        } else if (wv == 3) {
+            if (it >= 1 && it - 1 < nB) chain_prepare_back(Blk + (size_t)(W - it) * KC_BLK, lane);
         }
         __syncthreads();
     }
@@ -2161,10 +2211,24 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
             if (lane < KC_NB) zb[15 * i + lane] = v;
             GLIO_WAVE_LDS_SYNC();
         };
+        // z_i = w_i - M_i z_neighbour on the blocks chain_prepare_back transformed
+        auto back_mv = [&](const int i, const int nbr) {
+            const double* Bi = Blk + (size_t)i * KC_BLK;
+            if (lane < KC_NB) {
+                double mrow[KC_NB], zn[KC_NB];
+#pragma unroll
+                for (int k = 0; k < KC_NB; ++k) { mrow[k] = Bi[(KC_NB + lane) * KC_RS + k]; zn[k] = zb[15 * nbr + k]; }
+                double s0 = Bi[30 * KC_RS + lane], s1 = 0, s2 = 0;
+#pragma unroll
+                for (int k = 0; k < KC_NB; k += 3) { s0 -= mrow[k] * zn[k]; s1 -= mrow[k + 1] * zn[k + 1]; s2 -= mrow[k + 2] * zn[k + 2]; }
+                zb[15 * i + lane] = (s0 + s1) + s2;
+            }
+            GLIO_WAVE_LDS_SYNC();
+        };
         if (wv == 0) back(mid, -1);
         __syncthreads();
-        if (wv == 0) { for (int i = mid - 1; i >= 0; --i) back(i, i + 1); }
-        else if (wv == 1) { for (int i = mid + 1; i < W; ++i) back(i, i - 1); }
+        if (wv == 0) { for (int i = mid - 1; i >= 0; --i) back_mv(i, i + 1); }
+        else if (wv == 1) { for (int i = mid + 1; i < W; ++i) back_mv(i, i - 1); }
         __syncthreads();
         double bd2 = 0.0;
         for (int e = tid; e < nd; e += KC_THREADS) {
