@@ -403,6 +403,9 @@ class BatchStage:
         capi._check(capi.load().glio_batch_set_small_factors(self._h, C.byref(frame) if frame is not None else None, len(di), T.iptr(di) if len(di) else None,
                                                              T.iptr(dj) if len(di) else None, T.dptr(dc) if len(di) else None, len(dd), arr if dd else None))
 
+    def set_dd_threshold(self, threshold):
+        capi._check(capi.load().glio_batch_set_dd_threshold(self._h, C.c_double(threshold)))
+
     def add_small(self, poses, Hg):
         poses = np.ascontiguousarray(poses, np.float64)
         capi._check(capi.load().glio_batch_add_small_dev(self._h, T.dptr(poses), C.c_void_p(Hg.data_ptr())))
@@ -502,13 +505,18 @@ def solve_batch_rounds(stage, poses0, odo, search_range, dd, frame, reassociate=
     correspondences at the current poses (`reassociate(poses)` must leave the new constraint set on `stage`; None keeps it),
     rebuilding the small factors with this round's DDpsr_threshold, and running one trust-region solve.  The attitude constraints
     are rebuilt every round from the ODOMETRY poses `odo` (pose_info_keyframe is not updated inside the loop)."""
+    import time
     poses = np.ascontiguousarray(poses0, np.float64).copy()
     dq = delta_q_pairs(odo, search_range)
+    stage.set_small_factors(dq, dd, frame, threshold=thresholds[0])
     history = []
     for thr in thresholds:
         if reassociate is not None:
             reassociate(poses)
-        stage.set_small_factors(dq, dd, frame, threshold=thr)
+        stage.set_dd_threshold(thr)
+        t0 = time.perf_counter()
         poses, summ = stage.solve_tr(poses, opts, dist)
-        history.append(summ.as_dict())
+        h = summ.as_dict()
+        h["solve_ms"] = (time.perf_counter() - t0) * 1e3
+        history.append(h)
     return poses, history

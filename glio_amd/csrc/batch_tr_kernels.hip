@@ -204,11 +204,17 @@ __global__ void k_small_add(const int K, const int band, const int2* __restrict_
             for (int q = 0; q < pb.y; ++q) s += frec[(size_t)(pb.x + q) * SREC + 114 + r];
         }
         Hg[e] += s;
-    } else if (e == nH + nG) {
-        double s = 0;
-        for (int q = 0; q < n_fac; ++q) s += frec[(size_t)q * SREC + 120];
-        Hg[e] += s;
     }
+}
+// the cost of the small factors: fixed assignment of factors to threads and a fixed reduction tree (deterministic)
+__global__ __launch_bounds__(256) void k_small_cost(const double* __restrict__ frec, const int n_fac, double* __restrict__ cost) {
+    __shared__ double red[4];
+    double s = 0;
+    for (int q = threadIdx.x; q < n_fac; q += 256) s += frec[(size_t)q * SREC + 120];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *cost += (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // ------------------------------------------------------------------------------------------------ trust-region vector kernels
@@ -365,6 +371,7 @@ static void enqueue_small(glio_batch* b, const double* poses_dev, double* Hg_dev
                        s->d_rel, s->d_frec);
     const long long tot = glio_batch_hg_size(K, band);
     hipLaunchKernelGGL(k_small_add, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, b->stream, K, band, s->d_small_index, s->d_frec, s->n_fac, Hg_dev);
+    hipLaunchKernelGGL(k_small_cost, dim3(1), dim3(256), 0, b->stream, s->d_frec, s->n_fac, Hg_dev + tot - 1);
 }
 
 extern "C" {
@@ -422,6 +429,21 @@ int glio_batch_set_small_factors(glio_batch* b, const glio_gnss_frame* frame, in
         BT_CHECK(hipMemcpy(s->d_rel, rel, 96, hipMemcpyHostToDevice));
     }
     s->n_dq = n_dq; s->n_dd = n_dd; s->n_fac = nf;
+    return GLIO_OK;
+}
+
+__global__ void k_set_dd_threshold(glio_dd_psr* dd, const int n, const double thr) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < n) dd[f].threshold = thr;
+}
+// DDpsr_threshold of the next outer round (Estimator.cpp:2764-2767) for every DD factor already on the device
+int glio_batch_set_dd_threshold(glio_batch* b, double threshold) {
+    if (!b) return GLIO_E_ARG;
+    BT_CHECK(hipSetDevice(b->device));
+    BatchSmall* s = b->small;
+    if (!s || s->n_dd == 0) return GLIO_OK;
+    hipLaunchKernelGGL(k_set_dd_threshold, dim3((s->n_dd + 255) / 256), dim3(256), 0, b->stream, s->d_dd, s->n_dd, threshold);
+    BT_CHECK(hipGetLastError());
     return GLIO_OK;
 }
 

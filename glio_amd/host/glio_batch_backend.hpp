@@ -144,10 +144,11 @@ public:
                                           const std::function<void(const std::vector<double>&)>& reassociate = {}) {
         static const double thresholds[4] = {1000000000, 10, 8, 6};
         const DeltaQPairs dq = deltaQPairs(odo, K_, search_range);
+        setSmallFactors(frame, dq, dd, thresholds[0]);
         std::vector<glio_summary> out;
         for (double thr : thresholds) {
             if (reassociate) reassociate(poses);
-            setSmallFactors(frame, dq, dd, thr);
+            check(glio_batch_set_dd_threshold(h_, thr), "glio_batch_set_dd_threshold");
             out.push_back(solveTrustRegion(poses, opts));
         }
         return out;

@@ -210,6 +210,7 @@ int glio_batch_step_dev(glio_batch* b, const double* Hg_dev, double lambda, cons
 typedef void (*glio_allreduce_fn)(double* dev, int64_t count, void* hip_stream, void* user);
 int glio_batch_set_small_factors(glio_batch* b, const glio_gnss_frame* frame, int n_dq, const int32_t* dq_i, const int32_t* dq_j,
                                  const double* dq_const, int n_dd, const glio_dd_psr* dd);
+int glio_batch_set_dd_threshold(glio_batch* b, double threshold);   /* the next round's DDpsr_threshold, factors stay on the device */
 int glio_batch_add_small_dev(glio_batch* b, const double* poses, double* Hg_dev);
 int glio_batch_solve_tr(glio_batch* b, double* poses, const glio_batch_tr_opts* opts, glio_allreduce_fn allreduce, void* user, glio_summary* summary);
 
