@@ -147,7 +147,7 @@ static int create_body(int device, const glio_opts* opts, glio_ctx* c) {
     c->h_prior_index = (int*)malloc((size_t)15 * W * sizeof(int));
     for (int k = 0; k < 15 * W; ++k) c->h_prior_index[k] = -1;
     c->chain_tabs_dirty = 1;
-    c->k3_bpk = GLIO_K3_BLOCKS_PER_KF; c->last_k3_nb = c->k3_bpk; c->merged_linearize = 2; c->k3_unroll = 22;   /* 2-deep batches, non-temporal loads, next batch issued before the arithmetic of the current one */
+    c->k3_bpk = GLIO_K3_BLOCKS_PER_KF; c->last_k3_nb = c->k3_bpk; c->merged_linearize = 2; c->want_pair_H = 1; c->k3_unroll = 22;   /* 2-deep batches, non-temporal loads, next batch issued before the arithmetic of the current one */
     { int per = 768 / W;   /* ~3 workgroups per CU measured best on MI355X (scripts/k3_sweep.py) */ if (per < 8) per = 8; if (per > GLIO_K3_MAX_BLOCKS_PER_KF) per = GLIO_K3_MAX_BLOCKS_PER_KF; c->k3_bpk = per; }
     ALLOC(c->d_lidar_blocks, 2 * (size_t)W * GLIO_LIDAR_ACC * 8);
     ALLOC(c->d_L, (size_t)(n_max + 1) * n_max * 8);
@@ -651,6 +651,7 @@ static void lds_poison(glio_ctx* c) {
 // (k_chain_step reads the factor blocks); glio_linearize and the other solver paths do.
 static void enqueue_linearize(glio_ctx* c, int use_status, int which, int n_ddt, int dense = 1) {
     if (c->chain_tabs_dirty) glio_chain_tabs_upload(c);      // gather tables + zeroed slices, ahead of the factor kernels that fill them
+    c->want_pair_H = dense;
     lds_poison(c);
     if (c->merged_linearize) {
         glio_launch_linearize_all(c, use_status, which, n_ddt);
@@ -966,7 +967,7 @@ int glio_time_kernel(glio_ctx* c, int which, int reps, float* ms_out) {
             if (which == GLIO_KERNEL_LIDAR_LINEARIZE) glio_launch_lidar_linearize(c, 0, 0);
             else if (which == GLIO_KERNEL_STREAM_READ) glio_launch_stream_read(c);
             else if (which == GLIO_KERNEL_FULL_LINEARIZE) enqueue_linearize(c, 0, 0, n_ddt);
-            else if (which == GLIO_KERNEL_LINEARIZE_ALL) glio_launch_linearize_all(c, 0, 0, n_ddt);
+            else if (which == GLIO_KERNEL_LINEARIZE_ALL) { c->want_pair_H = glio_solver_needs_dense_H(c, n_ddt); glio_launch_linearize_all(c, 0, 0, n_ddt); }   // as launched inside the solve
             else if (which == GLIO_KERNEL_TR_STEP) {
                 // one first-iteration step computation (scale, Cauchy, Cholesky, dogleg) on H[0]
                 SolverStatus st;

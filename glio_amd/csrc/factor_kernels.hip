@@ -37,7 +37,7 @@ struct SmallArgs {
     const int* pslot; const int* pkind; const int* pidx; const int* pcolblk;
     double* pH; double* pg; double* pcost; double* pwork;
     // chain-layout contributions (glio_device.h, GLIO_CS_*): written beside the pair blocks, consumed by k_chain_step
-    double* chain_src; const short* chain_tabs;
+    double* chain_src; const short* chain_tabs; int pair_H;
 };
 __device__ __forceinline__ double* chain_slice(const SmallArgs& a, const int which, const int slot, const int source) {
     return a.chain_src + (((size_t)which * a.W + slot) * GLIO_CS_SOURCES + source) * GLIO_CS_STRIDE;
@@ -69,7 +69,7 @@ struct ImuLds { double Jg[15 * IMU_GC], Jl[15 * 30], WJ[15 * 30], S[225], r[15],
 __device__ __forceinline__ void imu_block(const double gravity, const double* __restrict__ pPi, const double* __restrict__ pQi,
                           const double* __restrict__ pSBi, const double* __restrict__ pPj, const double* __restrict__ pQj,
                           const double* __restrict__ pSBj, const ImuEdgeDev& e, PairBlock* out, double* eval_out, const int marg, unsigned char* pool,
-                          double* cs_a = nullptr, double* cs_b = nullptr, long long* stamp_dbg = nullptr) {
+                          double* cs_a = nullptr, double* cs_b = nullptr, long long* stamp_dbg = nullptr, const bool pair_H = true) {
 #ifdef GLIO_DEV_STAMPS
 #define IMU_STAMP(k) do { if (stamp_dbg && threadIdx.x == 0) stamp_dbg[k] = wall_clock64(); } while (0)
 #else
@@ -257,7 +257,7 @@ __device__ __forceinline__ void imu_block(const double gravity, const double* __
         double s = 0;
 #pragma unroll
         for (int k = 0; k < 15; ++k) s += WJ[k * 30 + p] * WJ[k * 30 + c];
-        out->H[idx] = s;
+        if (pair_H) out->H[idx] = s;
         if (cs_a) {          // the same entry in chain layout: aa -> D of slot_i, ba -> B of slot_i, bb -> D of slot_j
             if (p < 15) { if (c <= p) cs_a[p * (p + 1) / 2 + c] = s; }
             else if (c < 15) cs_a[120 + (p - 15) * 15 + c] = s;
@@ -332,6 +332,12 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
     // thread-private accumulators (thread p owns one entry), summed over factors in fixed order
     double h6 = 0.0, g6 = 0.0, cost_dd = 0.0;       // DD: p<36 -> H6[p]; 36<=p<42 -> g6; p==42 cost
     double h12 = 0.0, g12 = 0.0, cost_dop = 0.0;    // Doppler: p<144 -> H12[p]; 144<=p<156 -> g12; p==156 cost
+
+    // The first chunk of Doppler rows is fetched NOW (one record per lane, into registers): its load latency then runs under the
+    // DD section instead of after it.
+    glio_doppler dop0;
+    const bool have_dop0 = tid < min(DOP_CHUNK, gr.dop_end - gr.dop_begin);
+    if (have_dop0) dop0 = a.dop[gr.dop_begin + tid];
 
     // ---- DD pseudorange factors (dd_psr_factor.hpp:25-171), DD_CHUNK at a time
     for (int f0 = gr.dd_begin; f0 < gr.dd_end; f0 += DD_CHUNK) {
@@ -425,7 +431,9 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
     for (int c0 = gr.dop_begin; c0 < gr.dop_end; c0 += DOP_CHUNK) {
         const int cnt = min(DOP_CHUNK, gr.dop_end - c0);
         if (tid < cnt) {
-            const glio_doppler& F = a.dop[c0 + tid];
+            glio_doppler Fl;
+            if (c0 == gr.dop_begin) Fl = dop0; else Fl = a.dop[c0 + tid];
+            const glio_doppler& F = Fl;
             const double* Rf = F.R_ecef_local;
             double lp[3], lv[3], Pe[3], Ve[3];
 #pragma unroll
@@ -523,7 +531,8 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
 
     GN_STAMP(6);
     // ---- scatter the thread-private accumulators into the dense pair block
-    for (int k = tid; k < GLIO_PAIR_DIM * GLIO_PAIR_DIM; k += SF_THREADS) out->H[k] = 0.0;
+    const bool pair_H = a.pair_H != 0;           // (uniform) the dense 30 x 30 block is only written for consumers that read it
+    if (pair_H) for (int k = tid; k < GLIO_PAIR_DIM * GLIO_PAIR_DIM; k += SF_THREADS) out->H[k] = 0.0;
     if (tid < GLIO_PAIR_DIM) out->g[tid] = 0.0;
     __syncthreads();
     const int map6[6] = {0, 1, 2, 15, 16, 17};
@@ -531,10 +540,10 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
     if (tid == 42) s_cost[0] = cost_dd;
     if (tid == 156) s_cost[1] = cost_dop;
     // Doppler 12x12 first, DD 6x6 added on top (disjoint writers per entry -> two phases)
-    if (tid < 144) out->H[map12[tid / 12] * GLIO_PAIR_DIM + map12[tid % 12]] = h12;
+    if (tid < 144) { if (pair_H) out->H[map12[tid / 12] * GLIO_PAIR_DIM + map12[tid % 12]] = h12; }
     else if (tid < 156) out->g[map12[tid - 144]] = g12;
     __syncthreads();
-    if (tid < 36) out->H[map6[tid / 6] * GLIO_PAIR_DIM + map6[tid % 6]] += h6;
+    if (tid < 36) { if (pair_H) out->H[map6[tid / 6] * GLIO_PAIR_DIM + map6[tid % 6]] += h6; }
     else if (tid < 42) out->g[map6[tid - 36]] += g6;
     __syncthreads();
     if (tid == 0) { out->cost = s_cost[0] + s_cost[1]; out->slot_a = si; out->slot_b = sj; }
@@ -717,7 +726,7 @@ __device__ void small_factors_body(const SmallArgs& a) {
         const int si = a.imu[b].slot_i, sj = si + 1, W = a.W;
         imu_block(a.gravity, x + 3 * si, x + 3 * W + 4 * si, x + 7 * W + 9 * si, x + 3 * sj, x + 3 * W + 4 * sj, x + 7 * W + 9 * sj,
                   a.imu[b], a.imu_blocks + (size_t)which * a.W + b, nullptr, a.marg, pool,
-                  a.marg ? nullptr : chain_slice(a, which, si, 0), a.marg ? nullptr : chain_slice(a, which, sj, 1), (b == 0 && a.dbg) ? a.dbg + 190 : nullptr);
+                  a.marg ? nullptr : chain_slice(a, which, si, 0), a.marg ? nullptr : chain_slice(a, which, sj, 1), (b == 0 && a.dbg) ? a.dbg + 190 : nullptr, a.pair_H != 0);
         return;
     }
     b -= a.n_imu;
@@ -1091,7 +1100,7 @@ static int fill_small_args(glio_ctx* c, int use_status_cand, int which, int n_dd
     a.pJ0 = c->d_prior_J0; a.pA0 = c->d_prior_A0; a.pr0 = c->d_prior_r0; a.px0 = c->d_prior_x0;
     a.pslot = c->d_prior_slot; a.pkind = c->d_prior_kind; a.pidx = c->d_prior_idx; a.pcolblk = ex->d_prior_colblk;
     a.pH = c->d_prior_H; a.pg = c->d_prior_g; a.pcost = c->d_prior_cost; a.pwork = c->d_prior_work;
-    a.chain_src = c->d_chain_src; a.chain_tabs = c->d_chain_tabs;
+    a.chain_src = c->d_chain_src; a.chain_tabs = c->d_chain_tabs; a.pair_H = (marg || !c->d_chain_src) ? 1 : c->want_pair_H;
     return c->n_imu + c->n_groups + (a.has_prior ? 1 + PRIOR_H_BLOCKS : 0);
 }
 void glio_launch_small_factors(glio_ctx* c, int use_status_cand, int which, int n_ddt, int marg) {

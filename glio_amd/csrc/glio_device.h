@@ -188,6 +188,7 @@ struct glio_ctx {
     int* h_prior_index;                       // [15 W] state index -> prior column or -1
     short* d_chain_tabs; short* h_chain_tabs; // [8 W + 15 W] ChainKf per keyframe, then the prior index (h_: pinned)
     int chain_tabs_dirty;
+    int want_pair_H;              // 0: the linearisation in flight feeds k_chain_step only (chain slices, g, cost): the 30 x 30 pair blocks are not written
     double* d_chain_src;                      // [2][W][GLIO_CS_SOURCES][GLIO_CS_STRIDE] chain-layout contributions, double buffered
 };
 

@@ -1908,6 +1908,7 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
     T.lid = lid; T.kd = reinterpret_cast<const ChainKf*>(stab); T.pidx = stab + 8 * W;
     __shared__ int rowmask;
     __shared__ int s_pending, s_cand, s_done;
+    __shared__ int s_prog[2];
     AR_STAMP(40);
     // ---- round 0: status, the host-built gather tables, the structure tables of the epochs
     if (tid == 0) { const SolverStatus* st = tr.status; s_done = st->done; s_pending = st->cand_pending; s_cand = 1 - st->cur; }
@@ -2138,6 +2139,7 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
             *dst = v;
         }
     }
+    if (tid < 2) s_prog[tid] = 0;
     __syncthreads();
     AR_STAMP(47);
     // the chain from both ends
@@ -2152,35 +2154,50 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
     }
     bool bad = false;
     long long ph[5] = {0, 0, 0, 0, 0};
-    for (int it = 0; it <= Tn; ++it) {
-        if (wv == 0) {
-            if (it < nT) chain_step15<false>(it, it + 1, true, av, Blk, CsT, lane, bad, ph);
-            else if (it == Tn) {
-                {
-                    const int row = lane < KC_NB ? lane : 30, crow = lane < KC_NB ? lane : 15;
-                    const int lim = lane == 30 ? KC_NB : (lane < KC_NB ? lane + 1 : 0);
-                    double b0[KC_NB], c0[KC_NB], c1[KC_NB];
-#pragma unroll
-                    for (int j = 0; j < KC_NB; ++j) { b0[j] = Blk[(size_t)mid * KC_BLK + row * KC_RS + j]; c0[j] = CsT[crow * KC_RS + j]; c1[j] = CsB[crow * KC_RS + j]; }
-#pragma unroll
-                    for (int j = 0; j < KC_NB; ++j) {
-                        double v = b0[j];
-                        if (nT > 0) v -= c0[j];
-                        if (nB > 0) v -= c1[j];
-                        av[j] = j < lim ? v : 0.0;
-                    }
-                }
-                chain_step15<false>(mid, mid, false, av, Blk, CsT, lane, bad);
-            }
-        } else if (wv == 2) {
-            if (it < nB) { const int i = W - 1 - it; chain_step15<true>(i, i - 1, true, av, Blk, CsB, lane, bad); }
-        } else if (wv == 1) {                       // (SIMD 1 and 3: not the SIMDs the two chain wavefronts issue on)
-            if (it >= 1 && it - 1 < nT) chain_prepare_back(Blk + (size_t)(it - 1) * KC_BLK, lane);          // the block the top chain left last round
-        } else if (wv == 3) {
-            if (it >= 1 && it - 1 < nB) chain_prepare_back(Blk + (size_t)(W - it) * KC_BLK, lane);
+    // The two fronts run WITHOUT workgroup barriers between their steps (they meet only at the middle keyframe); each publishes
+    // its progress in LDS, and the wavefronts that prepare the factored blocks for the back substitution (on the two SIMDs the
+    // fronts do not issue on) follow it by polling.
+    if (wv == 0) {
+        for (int it = 0; it < nT; ++it) {
+            chain_step15<false>(it, it + 1, true, av, Blk, CsT, lane, bad, ph);
+            if (lane == 0) *reinterpret_cast<volatile int*>(&s_prog[0]) = it + 1;
         }
-        __syncthreads();
+    } else if (wv == 2) {
+        for (int it = 0; it < nB; ++it) {
+            const int i = W - 1 - it;
+            chain_step15<true>(i, i - 1, true, av, Blk, CsB, lane, bad);
+            if (lane == 0) *reinterpret_cast<volatile int*>(&s_prog[1]) = it + 1;
+        }
+    } else if (wv == 1) {
+        for (int k = 0; k < nT; ++k) {
+            while (*reinterpret_cast<volatile int*>(&s_prog[0]) < k + 1) __builtin_amdgcn_s_sleep(2);
+            chain_prepare_back(Blk + (size_t)k * KC_BLK, lane);
+        }
+    } else if (wv == 3) {
+        for (int k = 0; k < nB; ++k) {
+            while (*reinterpret_cast<volatile int*>(&s_prog[1]) < k + 1) __builtin_amdgcn_s_sleep(2);
+            chain_prepare_back(Blk + (size_t)(W - 1 - k) * KC_BLK, lane);
+        }
     }
+    __syncthreads();
+    if (wv == 0) {
+        {
+            const int row = lane < KC_NB ? lane : 30, crow = lane < KC_NB ? lane : 15;
+            const int lim = lane == 30 ? KC_NB : (lane < KC_NB ? lane + 1 : 0);
+            double b0[KC_NB], c0[KC_NB], c1[KC_NB];
+#pragma unroll
+            for (int j = 0; j < KC_NB; ++j) { b0[j] = Blk[(size_t)mid * KC_BLK + row * KC_RS + j]; c0[j] = CsT[crow * KC_RS + j]; c1[j] = CsB[crow * KC_RS + j]; }
+#pragma unroll
+            for (int j = 0; j < KC_NB; ++j) {
+                double v = b0[j];
+                if (nT > 0) v -= c0[j];
+                if (nB > 0) v -= c1[j];
+                av[j] = j < lim ? v : 0.0;
+            }
+        }
+        chain_step15<false>(mid, mid, false, av, Blk, CsT, lane, bad);
+    }
+    __syncthreads();
     AR_STAMP(48);
 #ifdef GLIO_DEV_STAMPS
     if (tid == 0) for (int k = 0; k < 5; ++k) a.dbg[60 + k] = ph[k];
