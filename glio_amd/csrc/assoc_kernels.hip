@@ -1029,6 +1029,26 @@ void glio_assoc_scan_moved(glio_ctx* c, int from, int to, int n) {
     AssocWork* w = c->assoc;
     if (w && n > 0) hipMemcpyAsync(w->d_ps + (size_t)to * c->cap, w->d_ps + (size_t)from * c->cap, (size_t)n * 16, hipMemcpyDeviceToDevice, c->stream);
 }
+// the slide of the window as ONE launch: thread e carries element e of the scan (and of its presorted copy) of slot s + 1 down to
+// slot s, for s = 0 .. W-2 in order -- every element is owned by one thread, so the overlapping moves need no staging
+// (2 (W - 1) hipMemcpyAsync calls cost ~0.19 ms of launch overhead at W = 20)
+struct SlideCounts { int n[GLIO_MAX_WINDOW]; };
+__global__ void k_slide_scans(float4* __restrict__ scan, float4* __restrict__ ps, const int cap, const int W, const SlideCounts cn) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int s = 0; s + 1 < W; ++s) {
+        if (e < cn.n[s + 1]) {
+            scan[(size_t)s * cap + e] = scan[(size_t)(s + 1) * cap + e];
+            if (ps) ps[(size_t)s * cap + e] = ps[(size_t)(s + 1) * cap + e];
+        }
+    }
+}
+void glio_assoc_slide_scans(glio_ctx* c) {
+    AssocWork* w = c->assoc;
+    SlideCounts cn;
+    int maxn = 0;
+    for (int s = 0; s < c->W; ++s) { cn.n[s] = c->h_scan_count[s]; if (s > 0 && cn.n[s] > maxn) maxn = cn.n[s]; }
+    if (maxn > 0) hipLaunchKernelGGL(k_slide_scans, dim3((maxn + 255) / 256), dim3(256), 0, c->stream, c->d_scan, w ? w->d_ps : nullptr, c->cap, c->W, cn);
+}
 
 static void enqueue_build(glio_ctx* c, int n) {
     AssocWork* w = c->assoc;

@@ -301,12 +301,9 @@ int glio_associate_resident(glio_ctx* c, int slot, const double q[4], const doub
 int glio_slide_window(glio_ctx* c) {
     if (!c) return GLIO_E_ARG;
     GLIO_HIP_CHECK(hipSetDevice(c->device));
-    for (int s = 0; s + 1 < c->W; ++s) {
-        const int n = c->h_scan_count[s + 1];
-        if (n > 0) GLIO_HIP_CHECK(hipMemcpyAsync(c->d_scan + (size_t)s * c->cap, c->d_scan + (size_t)(s + 1) * c->cap, (size_t)n * 16, hipMemcpyDeviceToDevice, c->stream));
-        glio_assoc_scan_moved(c, s + 1, s, n);
-        c->h_scan_count[s] = n;
-    }
+    glio_assoc_slide_scans(c);
+    GLIO_HIP_CHECK(hipGetLastError());
+    for (int s = 0; s + 1 < c->W; ++s) c->h_scan_count[s] = c->h_scan_count[s + 1];
     c->h_scan_count[c->W - 1] = 0;
     GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
     return GLIO_OK;

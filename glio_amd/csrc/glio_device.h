@@ -309,6 +309,7 @@ int glio_assoc_create(glio_ctx* c);
 // the resident scan of a slot changed (uploaded / moved by the slide): keep the presorted copy the tiled search reads in step
 void glio_assoc_scan_uploaded(glio_ctx* c, int slot, int n);
 void glio_assoc_scan_moved(glio_ctx* c, int from, int to, int n);
+void glio_assoc_slide_scans(glio_ctx* c);            // all resident scans (and their presorted copies) one slot down, one launch
 void glio_assoc_destroy(glio_ctx* c);
 int glio_assoc_build_map(glio_ctx* c, const float* map_xyzi, int n);
 int glio_assoc_run(glio_ctx* c, int slot, const double q[4], const double t[3], int* out_count);
