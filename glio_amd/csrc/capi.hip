@@ -44,7 +44,7 @@ GnssDevExtra* glio_extra(glio_ctx* c) { return &extra_of(c)->gx; }
 
 extern "C" {
 
-int glio_abi_version(void) { return 2; }
+int glio_abi_version(void) { return 3; }   // 3: glio_opts.lidar_precision, the batch pose problem (small factors, trust-region solve), 9 struct sizes
 const char* glio_last_error(void) { return g_err; }
 int glio_device_count(void) {
     int n = 0;
@@ -52,10 +52,11 @@ int glio_device_count(void) {
     return n;
 }
 int glio_struct_sizes(int32_t* out, int n) {
-    const int32_t v[8] = {(int32_t)sizeof(glio_opts), (int32_t)sizeof(glio_state), (int32_t)sizeof(glio_preint), (int32_t)sizeof(glio_prior),
-                          (int32_t)sizeof(glio_dd_psr), (int32_t)sizeof(glio_doppler), (int32_t)sizeof(glio_gnss_frame), (int32_t)sizeof(glio_summary)};
-    for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
-    return 8;
+    const int32_t v[9] = {(int32_t)sizeof(glio_opts), (int32_t)sizeof(glio_state), (int32_t)sizeof(glio_preint), (int32_t)sizeof(glio_prior),
+                          (int32_t)sizeof(glio_dd_psr), (int32_t)sizeof(glio_doppler), (int32_t)sizeof(glio_gnss_frame), (int32_t)sizeof(glio_summary),
+                          (int32_t)sizeof(glio_batch_tr_opts)};
+    for (int i = 0; i < n && i < 9; ++i) out[i] = v[i];
+    return 9;
 }
 
 void glio_opts_default(glio_opts* o) {

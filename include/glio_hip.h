@@ -35,8 +35,8 @@ typedef struct glio_ctx glio_ctx;
 int glio_abi_version(void);
 int glio_device_count(void);
 const char* glio_last_error(void);
-/* sizeof() of every POD struct, in the order opts,state,preint,prior,dd_psr,doppler,gnss_frame,summary
- * (lets a foreign-language binding verify its struct layout). */
+/* sizeof() of every POD struct, in the order opts,state,preint,prior,dd_psr,doppler,gnss_frame,summary,batch_tr_opts
+ * (lets a foreign-language binding verify its struct layout); returns how many there are. */
 int glio_struct_sizes(int32_t* out, int n);
 
 /* yaml defaults: GLIO/config/config_urban_hk.yaml:60-104 + Estimator.cpp:70,2424-2430 */

@@ -33,9 +33,9 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_struct_layouts_match(lib):
-    out = (C.c_int32 * 8)()
-    assert lib.glio_struct_sizes(out, 8) == 8
-    mine = [C.sizeof(x) for x in (T.GlioOpts, T.GlioState, T.GlioPreint, T.GlioPrior, T.GlioDdPsr, T.GlioDoppler, T.GlioGnssFrame, T.GlioSummary)]
+    out = (C.c_int32 * 9)()
+    assert lib.glio_struct_sizes(out, 9) == 9
+    mine = [C.sizeof(x) for x in (T.GlioOpts, T.GlioState, T.GlioPreint, T.GlioPrior, T.GlioDdPsr, T.GlioDoppler, T.GlioGnssFrame, T.GlioSummary, T.GlioBatchTrOpts)]
     assert list(out) == mine
 
 
