@@ -293,6 +293,7 @@ struct GnssLds {
     double s_cost[2];
     double sH6[36];                       // the DD part of the pair block, for the chain-layout slices
     double dpart[DD_CHUNK][44];           // per-factor parts of the DD reduction
+    double sG6[8];                        // DD gradient part (6), met with the Doppler part in the scatter
     DopRun s_runs[GN_MAX_RUNS];
     int s_nw[DD_CHUNK], s_m[DD_CHUNK];
 };
@@ -333,12 +334,6 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
     double h6 = 0.0, g6 = 0.0, cost_dd = 0.0;       // DD: p<36 -> H6[p]; 36<=p<42 -> g6; p==42 cost
     double h12 = 0.0, g12 = 0.0, cost_dop = 0.0;    // Doppler: p<144 -> H12[p]; 144<=p<156 -> g12; p==156 cost
 
-    // The first chunk of Doppler rows is fetched NOW (one record per lane, into registers): its load latency then runs under the
-    // DD section instead of after it.
-    glio_doppler dop0;
-    const bool have_dop0 = tid < min(DOP_CHUNK, gr.dop_end - gr.dop_begin);
-    if (have_dop0) dop0 = a.dop[gr.dop_begin + tid];
-
     // ---- DD pseudorange factors (dd_psr_factor.hpp:25-171), DD_CHUNK at a time
     for (int f0 = gr.dd_begin; f0 < gr.dd_end; f0 += DD_CHUNK) {
         const int nf = min(DD_CHUNK, gr.dd_end - f0);
@@ -366,7 +361,9 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
             }
         }
         GN_STAMP(1);
-        __syncthreads();
+        // From here to the per-factor parts everything a factor needs was produced by ITS OWN 32 lanes (one half of a wavefront):
+        // wavefront-level LDS synchronisation is enough, the workgroup barrier comes only before the factors are added up.
+        GLIO_WAVE_LDS_SYNC();
         GN_STAMP(2);
         if (fl < nf) {
             const int ns = s_nw[fl] + 1, m = s_m[fl];
@@ -384,7 +381,7 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
                 }
             }
         }
-        __syncthreads();
+        GLIO_WAVE_LDS_SYNC();
         if (fl < nf && i < s_nw[fl]) {        // residual = W r, J = W J  (:151-167)
             const int nw = s_nw[fl];
             double sr = 0, s6[6] = {0, 0, 0, 0, 0, 0};
@@ -398,19 +395,18 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
 #pragma unroll
             for (int k = 0; k < 6; ++k) wE[fl][i * 8 + k] = s6[k];
         }
-        __syncthreads();
-        // every reducing lane runs the SAME loop, a dot product of two columns of the whitened rows (no divergence inside
-        // the wavefront): (u, v) -> H6, (u, residual) -> g6, (residual, residual) -> 2 cost
-        // one lane per (factor, entry): 43 entries (36 of H6, 6 of g6, the cost) x up to DD_CHUNK factors, each a dot product of
-        // two columns of the factor's whitened rows; then 43 lanes add the factors' parts in factor order (the association of the
-        // sequential formulation: rows inside a factor first, factors after)
-        for (int p2 = tid; p2 < nf * 43; p2 += SF_THREADS) {
-            const int q = p2 / 43, cb = p2 - 43 * q;
-            const int ua = cb < 36 ? cb / 6 : (cb < 42 ? cb - 36 : 6), ub = cb < 36 ? cb % 6 : 6;
-            const int nw = s_nw[q];
-            double sacc = 0;
-            for (int r2 = 0; r2 < nw; ++r2) sacc += wE[q][r2 * 8 + ua] * wE[q][r2 * 8 + ub];
-            lds_.dpart[q][cb] = sacc;
+        GLIO_WAVE_LDS_SYNC();
+        // the factor's own 32 lanes take its 43 entries (36 of H6, 6 of g6, the cost): each a dot product of two columns of the factor's
+        // whitened rows; then 43 lanes add the factors' parts in factor order (the association of the sequential formulation: rows
+        // inside a factor first, factors after)
+        if (fl < nf) {
+            for (int cb = i; cb < 43; cb += 32) {
+                const int ua = cb < 36 ? cb / 6 : (cb < 42 ? cb - 36 : 6), ub = cb < 36 ? cb % 6 : 6;
+                const int nw = s_nw[fl];
+                double sacc = 0;
+                for (int r2 = 0; r2 < nw; ++r2) sacc += wE[fl][r2 * 8 + ua] * wE[fl][r2 * 8 + ub];
+                lds_.dpart[fl][cb] = sacc;
+            }
         }
         __syncthreads();
         if (tid < 43) {
@@ -426,14 +422,12 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
     // ---- Doppler rows (dopp_factor.hpp:24-75 + HuberLoss(1.0), Estimator.cpp:2335): all epochs of the pair side by
     //      side, one lane per row; sums are taken epoch by epoch (run = the rows of one epoch, contiguous)
     const double OMG = 7.2921151467e-5, CLIGHT = 2.99792458e8;
-    double carry = 0.0;          // tid 160..173: partial c[tid-160] / h / g of an epoch that straddles a chunk boundary
+    double carry = 0.0;          // tid 192..205: partial c / h / g of an epoch that straddles a chunk boundary
     int carry_run = -1;
     for (int c0 = gr.dop_begin; c0 < gr.dop_end; c0 += DOP_CHUNK) {
         const int cnt = min(DOP_CHUNK, gr.dop_end - c0);
         if (tid < cnt) {
-            glio_doppler Fl;
-            if (c0 == gr.dop_begin) Fl = dop0; else Fl = a.dop[c0 + tid];
-            const glio_doppler& F = Fl;
+            const glio_doppler& F = a.dop[c0 + tid];
             const double* Rf = F.R_ecef_local;
             double lp[3], lv[3], Pe[3], Ve[3];
 #pragma unroll
@@ -482,19 +476,31 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
         GN_STAMP(4);
         __syncthreads();
         GN_STAMP(5);
-        {   // one loop form for every reducing lane: dot product of two columns of the row records over the rows of an epoch
-            //   tid < 144: (u, v) -> H12;  144..155: (u, residual) -> g12;  156: (rho, 1) -> 2 cost;
-            //   160..171: (u, ddt column) -> coupling c[u];  172: (ddt, ddt) -> h;  173: (ddt, residual) -> g
-            int ua = 0, ub = 0;
-            bool active = true;
-            if (tid < 144) { ua = tid / 12; ub = tid % 12; }
-            else if (tid < 156) { ua = tid - 144; ub = 13; }
-            else if (tid == 156) { ua = 14; ub = 15; }
-            else if (tid >= 160 && tid < 172) { ua = tid - 160; ub = 12; }
-            else if (tid == 172) { ua = 12; ub = 12; }
-            else if (tid == 173) { ua = 12; ub = 13; }
-            else active = false;
-            for (int rl = 0; rl < n_runs && active; ++rl) {
+        // Reduction.  tid < 157 (wavefronts 0..2): dot product of two columns of the row records over ALL rows of the chunk --
+        //   tid < 144: (u, v) -> H12;  144..155: (u, residual) -> g12;  156: (rho, 1) -> 2 cost  -- these sums run over every epoch anyway.
+        // tid 192..205 (wavefront 3, concurrently): the same per EPOCH (run = the rows of one epoch, contiguous) --
+        //   192..203: (u, ddt column) -> coupling c[u];  204: (ddt, ddt) -> h;  205: (ddt, residual) -> g.
+        if (tid < 157) {
+            const int ua = tid < 144 ? tid / 12 : (tid < 156 ? tid - 144 : 14), ub = tid < 144 ? tid % 12 : (tid < 156 ? 13 : 15);
+            double s0 = 0, s1 = 0;
+            int r2 = 0;
+            for (; r2 + 8 <= cnt; r2 += 8) {        // eight rows' reads in flight; the two partial sums keep their even / odd rows
+                double xa[8], xb[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { xa[u] = dE[(r2 + u) * 16 + ua]; xb[u] = dE[(r2 + u) * 16 + ub]; }
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) { s0 += xa[u] * xb[u]; s1 += xa[u + 1] * xb[u + 1]; }
+            }
+            for (; r2 + 2 <= cnt; r2 += 2) { s0 += dE[r2 * 16 + ua] * dE[r2 * 16 + ub]; s1 += dE[(r2 + 1) * 16 + ua] * dE[(r2 + 1) * 16 + ub]; }
+            if (r2 < cnt) s0 += dE[r2 * 16 + ua] * dE[r2 * 16 + ub];
+            const double sacc = s0 + s1;
+            if (tid < 144) h12 += sacc;
+            else if (tid < 156) g12 += sacc;
+            else cost_dop += 0.5 * sacc;
+        } else if (tid >= 192 && tid < 206) {
+            const int u = tid - 192;     // 0..11: coupling, 12: h, 13: g
+            const int ua = u < 12 ? u : 12, ub = u < 13 ? 12 : 13;
+            for (int rl = 0; rl < n_runs; ++rl) {
                 const int rn = gr.run_begin + rl;
                 DopRun run;
                 if (rl < GN_MAX_RUNS) run = s_runs[rl]; else run = a.runs[rn];
@@ -502,28 +508,22 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
                 if (rb >= re) continue;
                 double s0 = 0, s1 = 0;
                 int r2 = rb;
-                for (; r2 + 8 <= re; r2 += 8) {        // eight rows' reads in flight; the two partial sums keep their even / odd rows
+                for (; r2 + 8 <= re; r2 += 8) {
                     double xa[8], xb[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { xa[u] = dE[(r2 + u) * 16 + ua]; xb[u] = dE[(r2 + u) * 16 + ub]; }
+                    for (int q = 0; q < 8; ++q) { xa[q] = dE[(r2 + q) * 16 + ua]; xb[q] = dE[(r2 + q) * 16 + ub]; }
 #pragma unroll
-                    for (int u = 0; u < 8; u += 2) { s0 += xa[u] * xb[u]; s1 += xa[u + 1] * xb[u + 1]; }
+                    for (int q = 0; q < 8; q += 2) { s0 += xa[q] * xb[q]; s1 += xa[q + 1] * xb[q + 1]; }
                 }
                 for (; r2 + 2 <= re; r2 += 2) { s0 += dE[r2 * 16 + ua] * dE[r2 * 16 + ub]; s1 += dE[(r2 + 1) * 16 + ua] * dE[(r2 + 1) * 16 + ub]; }
                 if (r2 < re) s0 += dE[r2 * 16 + ua] * dE[r2 * 16 + ub];
                 double sacc = s0 + s1;
-                if (tid < 144) h12 += sacc;
-                else if (tid < 156) g12 += sacc;
-                else if (tid == 156) cost_dop += 0.5 * sacc;
-                else {
-                    const int u = tid - 160;     // 0..11: coupling, 12: h, 13: g
-                    if (carry_run == rn) sacc = carry + sacc;
-                    if (run.end <= c0 + cnt) {          // epoch complete: publish its clock-drift block
-                        DdtBlock* D = ddt_out + run.epoch;
-                        if (u < 12) D->c[u] = sacc; else if (u == 12) D->h = sacc; else D->g = sacc;
-                        if (u == 0) { D->group = gidx; D->used = 1; }
-                    } else { carry = sacc; carry_run = rn; }
-                }
+                if (carry_run == rn) sacc = carry + sacc;
+                if (run.end <= c0 + cnt) {          // epoch complete: publish its clock-drift block
+                    DdtBlock* D = ddt_out + run.epoch;
+                    if (u < 12) D->c[u] = sacc; else if (u == 12) D->h = sacc; else D->g = sacc;
+                    if (u == 0) { D->group = gidx; D->used = 1; }
+                } else { carry = sacc; carry_run = rn; }
             }
         }
         __syncthreads();
@@ -532,40 +532,44 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
     GN_STAMP(6);
     // ---- scatter the thread-private accumulators into the dense pair block
     const bool pair_H = a.pair_H != 0;           // (uniform) the dense 30 x 30 block is only written for consumers that read it
-    if (pair_H) for (int k = tid; k < GLIO_PAIR_DIM * GLIO_PAIR_DIM; k += SF_THREADS) out->H[k] = 0.0;
-    if (tid < GLIO_PAIR_DIM) out->g[tid] = 0.0;
-    __syncthreads();
     const int map6[6] = {0, 1, 2, 15, 16, 17};
     const int map12[12] = {0, 1, 2, 6, 7, 8, 15, 16, 17, 21, 22, 23};
-    if (tid == 42) s_cost[0] = cost_dd;
+    const bool chain = a.chain_src && !a.marg && sj == si + 1;
+    // the DD parts (6 x 6, 6, cost) and the Doppler cost meet the Doppler parts through LDS: one barrier
+    if (tid < 36) lds_.sH6[tid] = h6;
+    else if (tid < 42) lds_.sG6[tid - 36] = g6;
+    else if (tid == 42) s_cost[0] = cost_dd;
     if (tid == 156) s_cost[1] = cost_dop;
-    // Doppler 12x12 first, DD 6x6 added on top (disjoint writers per entry -> two phases)
-    if (tid < 144) { if (pair_H) out->H[map12[tid / 12] * GLIO_PAIR_DIM + map12[tid % 12]] = h12; }
-    else if (tid < 156) out->g[map12[tid - 144]] = g12;
+    if (pair_H) for (int k = tid; k < GLIO_PAIR_DIM * GLIO_PAIR_DIM; k += SF_THREADS) out->H[k] = 0.0;
     __syncthreads();
-    if (tid < 36) { if (pair_H) out->H[map6[tid / 6] * GLIO_PAIR_DIM + map6[tid % 6]] += h6; }
-    else if (tid < 42) out->g[map6[tid - 36]] += g6;
-    __syncthreads();
-    if (tid == 0) { out->cost = s_cost[0] + s_cost[1]; out->slot_a = si; out->slot_b = sj; }
-    // chain-layout slices of the two keyframes (only pairs (i, i + 1) take part in the keyframe chain).  Only the 12 x 12
-    // positions of (t v of i, t v of j) can be non-zero (the DD part lives on a subset of them); everything else in a GNSS
-    // slice was zeroed when the structure was set and is never written.  An entry is h12 (+ h6), as out->H was formed.
-    if (a.chain_src && !a.marg && sj == si + 1) {
-        if (tid < 36) lds_.sH6[tid] = h6;
-        __syncthreads();
-        if (tid < 144) {
+    if (tid < 144) {
+        const int ia = tid / 12, ib = tid - 12 * ia;
+        const int R = map12[ia], C = map12[ib];
+        // position inside the DD 6-vector (t of i, t of j) or -1
+        const int a6 = (ia % 6) < 3 ? (ia / 6) * 3 + ia % 6 : -1, b6 = (ib % 6) < 3 ? (ib / 6) * 3 + ib % 6 : -1;
+        double v = h12;
+        if (a6 >= 0 && b6 >= 0) v += lds_.sH6[a6 * 6 + b6];          // Doppler 12 x 12 first, DD 6 x 6 added on top
+        if (pair_H) out->H[R * GLIO_PAIR_DIM + C] = v;
+        if (chain) {
+            // chain-layout slices of the two keyframes (only pairs (i, i + 1) take part in the keyframe chain).  Only the 12 x 12 positions
+            // of (t v of i, t v of j) can be non-zero; everything else in a GNSS slice was zeroed when the structure was set
             const ChainKf* kd = reinterpret_cast<const ChainKf*>(a.chain_tabs);
-            const int ia = tid / 12, ib = tid - 12 * ia;
-            const int R = map12[ia], C = map12[ib];
-            // position inside the DD 6-vector (t of i, t of j) or -1
-            const int a6 = (ia % 6) < 3 ? (ia / 6) * 3 + ia % 6 : -1, b6 = (ib % 6) < 3 ? (ib / 6) * 3 + ib % 6 : -1;
-            double v = h12;
-            if (a6 >= 0 && b6 >= 0) v += lds_.sH6[a6 * 6 + b6];
             if (R < 15) { if (C <= R) chain_slice(a, which, si, kd[si].k0 == gidx ? 2 : 3)[R * (R + 1) / 2 + C] = v; }                 // aa
             else if (C < 15) chain_slice(a, which, si, kd[si].k0 == gidx ? 2 : 3)[120 + (R - 15) * 15 + C] = v;                       // ba
             else if (C <= R) chain_slice(a, which, sj, kd[sj].k0 == gidx ? 2 : 3)[(R - 15) * (R - 14) / 2 + (C - 15)] = v;             // bb
         }
-    }
+    } else if (tid < 156) {
+        const int ia = tid - 144;
+        const int a6 = (ia % 6) < 3 ? (ia / 6) * 3 + ia % 6 : -1;
+        out->g[map12[ia]] = a6 >= 0 ? g12 + lds_.sG6[a6] : g12;
+    } else if (tid >= 160 && tid < 160 + GLIO_PAIR_DIM) {
+        const int k = tid - 160;                     // the 18 entries of g outside (t v of i, t v of j) are zero
+        bool in12 = false;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) in12 = in12 || map12[q] == k;
+        if (!in12) out->g[k] = 0.0;
+    } else if (tid == 200) { out->cost = s_cost[0] + s_cost[1]; out->slot_a = si; out->slot_b = sj; }
+    (void)map6;
     GN_STAMP(7);
 }
 
