@@ -422,7 +422,7 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
     // ---- Doppler rows (dopp_factor.hpp:24-75 + HuberLoss(1.0), Estimator.cpp:2335): all epochs of the pair side by
     //      side, one lane per row; sums are taken epoch by epoch (run = the rows of one epoch, contiguous)
     const double OMG = 7.2921151467e-5, CLIGHT = 2.99792458e8;
-    double carry = 0.0;          // tid 192..205: partial c / h / g of an epoch that straddles a chunk boundary
+    double carry = 0.0;          // tid 192..247: partial c / h / g of an epoch that straddles a chunk boundary
     int carry_run = -1;
     for (int c0 = gr.dop_begin; c0 < gr.dop_end; c0 += DOP_CHUNK) {
         const int cnt = min(DOP_CHUNK, gr.dop_end - c0);
@@ -478,8 +478,8 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
         GN_STAMP(5);
         // Reduction.  tid < 157 (wavefronts 0..2): dot product of two columns of the row records over ALL rows of the chunk --
         //   tid < 144: (u, v) -> H12;  144..155: (u, residual) -> g12;  156: (rho, 1) -> 2 cost  -- these sums run over every epoch anyway.
-        // tid 192..205 (wavefront 3, concurrently): the same per EPOCH (run = the rows of one epoch, contiguous) --
-        //   192..203: (u, ddt column) -> coupling c[u];  204: (ddt, ddt) -> h;  205: (ddt, residual) -> g.
+        // tid 192..247 (wavefront 3, concurrently): the same per EPOCH (run = the rows of one epoch, contiguous), 14 lanes per epoch --
+        //   (u, ddt column) -> coupling c[u], u < 12;  (ddt, ddt) -> h;  (ddt, residual) -> g.
         if (tid < 157) {
             const int ua = tid < 144 ? tid / 12 : (tid < 156 ? tid - 144 : 14), ub = tid < 144 ? tid % 12 : (tid < 156 ? 13 : 15);
             double s0 = 0, s1 = 0;
@@ -497,10 +497,12 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
             if (tid < 144) h12 += sacc;
             else if (tid < 156) g12 += sacc;
             else cost_dop += 0.5 * sacc;
-        } else if (tid >= 192 && tid < 206) {
-            const int u = tid - 192;     // 0..11: coupling, 12: h, 13: g
+        } else if (tid >= 192 && tid < 192 + 56) {
+            // four epochs side by side, 14 lanes each; an epoch keeps its lanes from chunk to chunk (rl is its index in the group), so a
+            // partial sum carried over a chunk boundary stays with the lane that continues it
+            const int slot = (tid - 192) / 14, u = (tid - 192) - 14 * slot;     // u 0..11: coupling, 12: h, 13: g
             const int ua = u < 12 ? u : 12, ub = u < 13 ? 12 : 13;
-            for (int rl = 0; rl < n_runs; ++rl) {
+            for (int rl = slot; rl < n_runs; rl += 4) {
                 const int rn = gr.run_begin + rl;
                 DopRun run;
                 if (rl < GN_MAX_RUNS) run = s_runs[rl]; else run = a.runs[rn];
