@@ -167,6 +167,7 @@ __global__ __launch_bounds__(64) void k_small_eval(const int n_fac, const int* _
             s *= 0.5;
         }
         rec[e] = s;
+        if (e == 120) frec[(size_t)n_fac * SREC + f] = s;          // costs once more, densely, behind the records: what k_small_cost sums
     }
 }
 
@@ -210,7 +211,7 @@ __global__ void k_small_add(const int K, const int band, const int2* __restrict_
 __global__ __launch_bounds__(256) void k_small_cost(const double* __restrict__ frec, const int n_fac, double* __restrict__ cost) {
     __shared__ double red[4];
     double s = 0;
-    for (int q = threadIdx.x; q < n_fac; q += 256) s += frec[(size_t)q * SREC + 120];
+    for (int q = threadIdx.x; q < n_fac; q += 256) s += frec[(size_t)n_fac * SREC + q];           // the dense copy of the records' cost entries (coalesced)
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -407,7 +408,7 @@ int glio_batch_set_small_factors(glio_batch* b, const glio_gnss_frame* frame, in
         s->cap_fac = (size_t)nf + nf / 2 + 16;
         BT_CHECK(hipMalloc((void**)&s->d_fa, s->cap_fac * 4)); BT_CHECK(hipMalloc((void**)&s->d_fb, s->cap_fac * 4));
         BT_CHECK(hipMalloc((void**)&s->d_ftype, s->cap_fac * 4)); BT_CHECK(hipMalloc((void**)&s->d_fidx, s->cap_fac * 4));
-        BT_CHECK(hipMalloc((void**)&s->d_dq_const, s->cap_fac * 32)); BT_CHECK(hipMalloc((void**)&s->d_frec, s->cap_fac * SREC * 8));
+        BT_CHECK(hipMalloc((void**)&s->d_dq_const, s->cap_fac * 32)); BT_CHECK(hipMalloc((void**)&s->d_frec, s->cap_fac * (SREC + 1) * 8));
     }
     if ((size_t)n_dd > s->cap_dd) {
         if (s->d_dd) hipFree(s->d_dd);
