@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256) void k_qbin_scatter(const AssocArgs a) {
 // per launch row y and tile of 1024 consecutive presorted points: units + grouped world-frame queries (w = original index)
 __global__ __launch_bounds__(QT_THREADS) void k_qbin_tile(const AssocArgs a, const float4* __restrict__ ps) {
     __shared__ unsigned long long s_key[QT_SLOTS];
-    __shared__ int s_cnt[QT_SLOTS], s_ust[QT_SLOTS];
+    __shared__ int s_cnt[QT_SLOTS];
     __shared__ int s_wc[16], s_wu[16], s_ubase;
     const AssocSlot sl = assoc_slot(a);
     const int tile0 = blockIdx.x * QT_THREADS, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -899,7 +899,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_compact(const int* __restrict__ fl
         o_pt += k * q_stride; o_plane += k * q_stride; o_score += k * q_stride; total += k;
         if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) *total = 0;
     }
-    if (blockIdx.x * PF_BLOCK >= n) return;
+    if ((int)(blockIdx.x * PF_BLOCK) >= n) return;
     int part = 0;
     for (int b = threadIdx.x; b < (int)blockIdx.x; b += PF_BLOCK) part += bcount[b];
 #pragma unroll
@@ -910,7 +910,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_compact(const int* __restrict__ fl
         int t = 0;
         for (int k = 0; k < PF_BLOCK / 64; ++k) t += s_part[k];
         s_off = t;
-        if ((blockIdx.x + 1) * PF_BLOCK >= n) *total = t + bcount[blockIdx.x];
+        if ((int)((blockIdx.x + 1) * PF_BLOCK) >= n) *total = t + bcount[blockIdx.x];
     }
     __syncthreads();
     if (i >= n || !flag[i]) return;

@@ -534,7 +534,6 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
     GN_STAMP(6);
     // ---- scatter the thread-private accumulators into the dense pair block
     const bool pair_H = a.pair_H != 0;           // (uniform) the dense 30 x 30 block is only written for consumers that read it
-    const int map6[6] = {0, 1, 2, 15, 16, 17};
     const int map12[12] = {0, 1, 2, 6, 7, 8, 15, 16, 17, 21, 22, 23};
     const bool chain = a.chain_src && !a.marg && sj == si + 1;
     // the DD parts (6 x 6, 6, cost) and the Doppler cost meet the Doppler parts through LDS: one barrier
@@ -571,7 +570,6 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
         for (int q = 0; q < 12; ++q) in12 = in12 || map12[q] == k;
         if (!in12) out->g[k] = 0.0;
     } else if (tid == 200) { out->cost = s_cost[0] + s_cost[1]; out->slot_a = si; out->slot_b = sj; }
-    (void)map6;
     GN_STAMP(7);
 }
 
