@@ -237,3 +237,83 @@ def test_delta_q_functor_autograd():
         Ja, Jb = torch.autograd.functional.jacobian(functor, (a, b))
         assert np.allclose(r, functor(a, b).detach().numpy(), rtol=1e-13, atol=1e-9)
         assert np.allclose(J[0], Ja.numpy(), rtol=1e-11, atol=1e-7) and np.allclose(J[1], Jb.numpy(), rtol=1e-11, atol=1e-7)
+
+
+def _torch_batch_cost(K, poses_t, con, dq, dd, frame):
+    """The whole batch pose problem's cost, 0.5 sum r^2, transcribed functor by functor in torch float64: BinaryLidarPlaneNormFactor
+    (LidarKeyframeFactor.h:134-148), delta_q_factor_auto (:283-303), dd_psr_factor_20 (dd_psr_factor.hpp:25-171, identity weight as
+    the batch stage builds it).  poses_t [K][7] = t, q (w x y z)."""
+    from glio_amd import synth
+    ci, cj, cp, nc, score = con
+    cost = torch.zeros((), dtype=torch.float64)
+    for k in range(len(ci)):
+        a, b = int(ci[k]), int(cj[k])
+        pw = q_rot(poses_t[a, 3:], torch.tensor(cp[k, :3].astype(np.float64))) + poses_t[a, :3]
+        n_o = q_rot(poses_t[b, 3:], torch.tensor(nc[k, :3]))
+        c_o = q_rot(poses_t[b, 3:], torch.tensor(nc[k, 3:])) + poses_t[b, :3]
+        r = float(score[k]) * n_o.dot(pw - c_o)
+        cost = cost + 0.5 * r * r
+    for k in range(len(dq[0])):
+        r = 10000.0 * q_mul(q_mul(q_inverse(torch.tensor(dq[2][k])), q_inverse(poses_t[int(dq[0][k]), 3:])), poses_t[int(dq[1][k]), 3:])[1:]
+        cost = cost + 0.5 * r.dot(r)
+    Ree = torch.tensor(synth.ecef2rotation(np.array(frame.anc_ecef)))
+    anc = torch.tensor(np.array(frame.anc_ecef))
+    for f in dd:
+        ns, m = f.n_sat, f.master
+        lp = f.ratio * poses_t[f.slot_i, :3] + (1.0 - f.ratio) * poses_t[f.slot_j, :3]
+        Pe = Ree @ lp + anc                                       # yaw_enu_local = 0 in the generator
+        st = torch.tensor(np.array(f.station))
+        def rng_(pos, to):
+            return torch.linalg.norm(torch.tensor(np.array(pos)) - to)
+        for i in range(ns):
+            if i == m:
+                continue
+            est = (rng_(f.user_sat_pos[i], Pe) - rng_(f.ref_sat_pos[i], st)) - (rng_(f.user_sat_pos[m], Pe) - rng_(f.ref_sat_pos[m], st))
+            obs = (f.user_psr[i] - f.ref_psr[i]) - (f.user_psr[m] - f.ref_psr[m])
+            w = 0.05 if abs(float(est.detach()) - obs) > f.threshold else 1.0
+            r = w * (est - obs)
+            cost = cost + 0.5 * r * r
+    return cost
+
+
+def test_batch_problem_cost_and_gradient_against_a_torch_transcription():
+    """orc_batch_linearize_full as a whole: the cost equals the torch transcription's, the gradient (in the local parameterisation:
+    translation additive, quaternion [cos|d|, sin|d| d/|d|] (x) q) equals autograd's through the same Plus, and the solved problem is
+    a stationary point whose cost random perturbations do not lower."""
+    from glio_amd import batch
+    K, band = 8, 4
+    gt, init = batch.make_poses(K, seed=51, perturb=(0.05, 0.003))
+    ci, cj, cp, nc, score = batch.make_constraints(gt, 0, K, 12, band, seed=51)
+    con = (ci, cj, cp.numpy(), nc.numpy(), score.numpy())
+    odo = gt.copy()
+    dq = batch.delta_q_pairs(odo, 2)
+    dd, frame = batch.make_batch_gnss(gt, seed=51, sats_per_sys=6)
+    for f in dd:
+        f.threshold = 1e9                                          # (no weight switching: the cost is smooth)
+    P = po.BatchProblem(K, band, *con, dq=dq, dd=dd, frame=frame)
+    H, g, cost = P.linearize(init)
+    x0 = torch.tensor(init)
+
+    def plus(d):
+        t = x0[:, :3] + d[:, :3]
+        nrm = torch.linalg.norm(d[:, 3:], dim=1, keepdim=True)
+        dqv = torch.cat([torch.cos(nrm), torch.sin(nrm) / nrm * d[:, 3:]], dim=1)
+        q = torch.stack([q_mul(dqv[k], x0[k, 3:]) for k in range(K)])
+        return torch.cat([t, q], dim=1)
+    d = torch.full((K, 6), 1e-30, dtype=torch.float64, requires_grad=True)      # (|d| -> 0 without the 0/0)
+    c_t = _torch_batch_cost(K, plus(d), con, dq, dd, frame)
+    (g_t,) = torch.autograd.grad(c_t, d)
+    assert abs(c_t.item() - cost) <= 1e-10 * cost
+    assert np.abs(g_t.numpy() - g).max() <= 1e-7 * np.abs(g).max()
+    # the converged solution: gradient ~ 0 and no nearby point with a lower cost
+    from glio_amd import ctypes_types as T
+    sol, summ = P.solve(init, T.batch_tr_opts(max_iterations=200))
+    Hs, gs, cs = P.linearize(sol)
+    assert np.abs(gs).max() <= 1e-5 * np.abs(g).max()
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        dlt = rng.normal(0, 1e-4, (K, 6))
+        pert = sol.copy(); pert[:, :3] += dlt[:, :3]
+        for k in range(K):
+            pert[k, 3:] = po.quat_plus(sol[k, 3:], dlt[k, 3:])
+        assert P.linearize(pert)[2] >= cs * (1 - 1e-12)
