@@ -245,9 +245,11 @@ __device__ __forceinline__ void plane_qr_solve(double A[5][3], double b[5], doub
 // Query binning of the tiled neighbour search (k_qbin_* / k_knn5_tile): per launch row y (a scan, a window slot or a keyframe
 // pair) the queries are grouped by the voxel-hash cell they fall in; a UNIT is up to TK_LANES queries of one cell.
 struct KnnBin {
-    unsigned long long* keys; int* cnt; int* cstart;      // [Y][capq] open-addressing table of the occupied query cells (left EMPTY / 0 by k_qbin_alloc)
-    int* qslot; int* qrank;                               // [Y][w_stride] table slot and arrival rank of query i
-    float4* qtmp; float4* qs;                             // [Y][w_stride] transformed query (w = its index): in scan order, grouped by cell
+    // presort of one uploaded cloud (k_qbin_count / _alloc / _scatter, launch row 0 only):
+    unsigned long long* keys; int* cnt; int* cstart;      // [capq] open-addressing table of the occupied cells (left EMPTY / 0 by k_qbin_alloc)
+    int* qslot; int* qrank; float4* qtmp;                 // [cap] table slot, arrival rank and transformed point (w = its index) of point i
+    // per-call grouping (k_qbin_tile) and search (k_knn5_tile), every launch row y:
+    float4* qs;                                           // [Y][w_stride] queries grouped by cell (world xyz, w = index in the scan); the presort's output pointer
     int2* units;                                          // [Y][unit_stride] (first grouped position, queries)
     int* counters;                                        // [Y][2] grouped queries, units (zeroed again by k_plane_fit)
     int capq, unit_stride;
@@ -929,9 +931,11 @@ static KnnBinHost* knn_bin_create(int rows, int cap) {
     h->rows = rows; h->cap = cap; h->capq_max = next_pow2(2 * (cap > 512 ? cap : 512));
     KnnBin& d = h->d;
     d.unit_stride = cap / TK_Q + cap + 16;
-    const size_t tq = (size_t)rows * h->capq_max, wq = (size_t)rows * cap;
+    // the global-atomic binning tables (keys .. qtmp) serve the presort of ONE uploaded cloud at a time: one row; the per-call grouping
+    // (k_qbin_tile) needs only the grouped queries, the unit list and the counters of every launch row
+    const size_t tq = (size_t)h->capq_max, wq1 = (size_t)cap, wq = (size_t)rows * cap;
     bool ok = hipMalloc((void**)&d.keys, tq * 8) == hipSuccess && hipMalloc((void**)&d.cnt, tq * 4) == hipSuccess && hipMalloc((void**)&d.cstart, tq * 4) == hipSuccess &&
-              hipMalloc((void**)&d.qslot, wq * 4) == hipSuccess && hipMalloc((void**)&d.qrank, wq * 4) == hipSuccess && hipMalloc((void**)&d.qtmp, wq * 16) == hipSuccess &&
+              hipMalloc((void**)&d.qslot, wq1 * 4) == hipSuccess && hipMalloc((void**)&d.qrank, wq1 * 4) == hipSuccess && hipMalloc((void**)&d.qtmp, wq1 * 16) == hipSuccess &&
               hipMalloc((void**)&d.qs, wq * 16) == hipSuccess && hipMalloc((void**)&d.units, (size_t)rows * d.unit_stride * 8) == hipSuccess &&
               hipMalloc((void**)&d.counters, (size_t)rows * 8) == hipSuccess;
     ok = ok && hipMemset(d.keys, 0xff, tq * 8) == hipSuccess && hipMemset(d.cnt, 0, tq * 4) == hipSuccess && hipMemset(d.counters, 0, (size_t)rows * 8) == hipSuccess;
