@@ -2502,7 +2502,69 @@ __global__ __launch_bounds__(TR_THREADS) void k_marg_schur(const double* A, cons
     __syncthreads();
     for (int j = tid; j < n; j += TR_THREADS) ylds[j] = fmax(1e-8, 1e-9 * Lwork[(size_t)j * n + j]);
     __syncthreads();
-    const bool good = chol_left_looking<true>(Lwork, n, Bp, part, sD, flag, 0, ylds);
+    // The Schur complement of block-diagonal pieces (LiDAR blocks of the dropped keyframe, its IMU edge, a prior that is block
+    // diagonal by keyframe -- what this marginalization itself produces, quirk Q7) is block diagonal in the kept order
+    // [T1 Q1 SB1 (15) | T2 Q2 (6) | T3 Q3 (6) | ...], with EXACT zeros between the blocks (sums of zeros).  Then its root is the
+    // roots of the blocks: one wavefront per block, the same register steps and the same null-pivot rule as the dense routine,
+    // instead of eight 16-column panels over the whole 123 x 123 matrix.  Any non-zero outside the blocks: dense routine.
+    int& bdiag = flag[3];
+    if (tid == 0) bdiag = (n >= 15 && (n - 15) % 6 == 0) ? 1 : 0;
+    __syncthreads();
+    {
+        int viol = 0;
+        for (int e = tid; e < n * n; e += TR_THREADS) {
+            const int i = e / n, j = e - n * i;
+            if (j >= i) continue;
+            const int bi = i < 15 ? 0 : 1 + (i - 15) / 6, bj = j < 15 ? 0 : 1 + (j - 15) / 6;
+            if (bi != bj && Lwork[e] != 0.0) viol = 1;
+        }
+        if (viol) bdiag = 0;
+    }
+    __syncthreads();
+    bool good;
+    if (bdiag) {
+        const int lane = tid & 63, wv = tid >> 6, nblk = 1 + (n - 15) / 6;
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        for (int bI = wv; bI < nblk; bI += TR_WAVES) {
+            const int o = bI == 0 ? 0 : 15 + 6 * (bI - 1), bs = bI == 0 ? 15 : 6;
+            const bool isrow = lane < bs, isrhs = lane == TR_NB;
+            double a[TR_NB];
+#pragma unroll
+            for (int j = 0; j < TR_NB; ++j) {
+                double v = (lane < TR_NB && lane == j) ? 1.0 : 0.0;                       // identity padding of the unused rows / columns
+                if (isrow && j < bs) v = j <= lane ? Lwork[(size_t)(o + lane) * n + o + j] : 0.0;
+                if (isrhs && j < bs) v = Lwork[(size_t)n * n + o + j];
+                a[j] = v;
+            }
+            const double tolv = isrow ? ylds[o + lane] : 0.0;
+            bool bad = false;
+#pragma unroll
+            for (int j = 0; j < TR_NB; ++j) {
+                double djj = readlane_d(a[j], j);
+                const bool null_pivot = j < bs && djj <= readlane_d(tolv, j);
+                if (!null_pivot && (!(djj > 0.0) || !isfinite(djj))) { bad = true; djj = 1.0; }
+                const double rd = null_pivot ? 0.0 : rsqrt(djj);
+                const double lij = (lane == j) ? djj * rd : a[j] * rd;
+                a[j] = lij;
+#pragma unroll
+                for (int c2 = j + 1; c2 < TR_NB; ++c2) a[c2] -= lij * readlane_d(lij, c2);
+            }
+            if (isrow) {
+#pragma unroll
+                for (int j = 0; j < TR_NB; ++j) if (j < bs && j <= lane) Lwork[(size_t)(o + lane) * n + o + j] = a[j];
+            } else if (isrhs) {
+#pragma unroll
+                for (int j = 0; j < TR_NB; ++j) if (j < bs) Lwork[(size_t)n * n + o + j] = a[j];
+            }
+            if (bad && lane == 0) *flag = 1 + o;
+        }
+        __threadfence_block();
+        __syncthreads();
+        good = *flag == 0;
+    } else {
+        good = chol_left_looking<true>(Lwork, n, Bp, part, sD, flag, 0, ylds);
+    }
     if (good) {
         for (int i = tid >> 6; i < n; i += TR_WAVES)
             for (int j = tid & 63; j < n; j += 64) J0[(size_t)i * n + j] = (j >= i) ? Lwork[(size_t)j * n + i] : 0.0;
