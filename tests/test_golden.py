@@ -124,3 +124,53 @@ def test_next_rows_hip_matches_the_fixture(golden_next, case_next):
     assert lm.localmap_build() == int(golden_next["map_count"])
     assert np.abs(lm.localmap_read()[:32] - golden_next["map_head"]).max() <= 2e-5
     lm.close()
+
+
+# ---- the batch pose problem (plane constraints + delta_q + DD pseudoranges, four threshold rounds) --------------------
+import make_golden_batch as mgb      # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def golden_batch():
+    return np.load(os.path.join(HERE, "golden", "batch_small.npz"))
+
+
+@pytest.fixture(scope="module")
+def case_batch():
+    return mgb.make_inputs()
+
+
+def test_batch_oracle_reproduces_the_fixture(golden_batch, case_batch):
+    assert mgb.digest(case_batch) == str(golden_batch["input_sha256"]), "the synthetic generator changed"
+    out = mgb.oracle_outputs(case_batch)
+    for k in ("dq_i", "dq_j", "round_iterations", "round_termination"):
+        assert np.array_equal(out[k], golden_batch[k]), k
+    assert np.abs(out["dq_const"] - golden_batch["dq_const"]).max() <= 1e-15
+    assert rel(out["lin_H"], golden_batch["lin_H"]) <= 1e-13 and rel(out["lin_g"], golden_batch["lin_g"]) <= 1e-13
+    assert abs(float(out["lin_cost"]) - float(golden_batch["lin_cost"])) <= 1e-13 * float(golden_batch["lin_cost"])
+    assert rel(out["round_costs"], golden_batch["round_costs"]) <= 1e-10
+    assert np.abs(out["poses"] - golden_batch["poses"]).max() <= 1e-9
+
+
+@pytest.mark.gpu
+def test_batch_hip_matches_the_fixture(golden_batch, case_batch):
+    from glio_amd import batch
+    from glio_amd import ctypes_types as T
+    c = case_batch
+    dq = batch.delta_q_pairs(c["odo"], mgb.SEARCH_RANGE)
+    assert np.array_equal(dq[0], golden_batch["dq_i"]) and np.array_equal(dq[1], golden_batch["dq_j"])
+    st = batch.BatchStage(mgb.K, mgb.BAND, len(c["con"][0]))
+    st.set_constraints(*c["con"])
+    st.set_small_factors(dq, c["dd"], c["frame"], threshold=batch.DDPSR_THRESHOLDS[0])
+    Hg = st.new_hg()
+    st.linearize(c["init"], Hg); st.add_small(c["init"], Hg)
+    got = Hg.cpu().numpy()
+    nH = mgb.K * (mgb.BAND + 1) * 36
+    assert rel(got[:nH], golden_batch["lin_H"].ravel()) <= 1e-12 and rel(got[nH:-1], golden_batch["lin_g"].ravel()) <= 1e-12
+    assert abs(got[-1] - float(golden_batch["lin_cost"])) <= 1e-12 * got[-1]
+    poses, hist = batch.solve_batch_rounds(st, c["init"], c["odo"], mgb.SEARCH_RANGE, c["dd"], c["frame"], opts=T.batch_tr_opts(mgb.MAX_ITER))
+    assert [h["iterations"] for h in hist] == list(golden_batch["round_iterations"])
+    assert [h["termination"] for h in hist] == list(golden_batch["round_termination"])
+    assert rel(np.array([[h["initial_cost"], h["final_cost"]] for h in hist]), golden_batch["round_costs"]) <= 1e-8
+    assert np.abs(poses - golden_batch["poses"]).max() <= 1e-7
+    st.close()
