@@ -2468,16 +2468,71 @@ __global__ __launch_bounds__(TR_THREADS) void k_marg_schur(const double* A, cons
         ebuf[256 + tid] = (i == j) ? 1.0 : 0.0;
     }
     __syncthreads();
-    if (tid < 64) { const int cur = jacobi16_wave(ebuf, tid); if (tid == 0) ecur = cur; }
-    __syncthreads();
-    if (tid < 225) {
-        const double* Am = ebuf + ecur * 512; const double* Vm = Am + 256;
-        const int i = tid / 15, j = tid % 15;
-        double sacc = 0;
-        for (int k = 0; k < 16; ++k) { const double w = Am[k * 17]; sacc += Vm[i * 16 + k] * (w > 1e-8 ? 1.0 / w : 0.0) * Vm[j * 16 + k]; }
-        Ainv[tid] = sacc;
+    // Amm^+ : the reference inverts the eigenvalues above 1e-8 and drops the rest (MarginalizationFactor.cpp:175-182).  When NO
+    // eigenvalue is dropped that is the plain inverse, and lambda_min = 1 / |Amm^-1|_2 >= 1 / |Amm^-1|_F can be certified from the
+    // inverse itself: one wavefront factors Amm = L L^T in registers and inverts L (3 us); if the factorisation is clean and
+    // 1 / |Amm^-1|_F > 1e-7 the result stands, otherwise (the first window of a stream is rank deficient by 3) the
+    // eigen-decomposition (16 x 16 parallel Jacobi, ~100 us) runs as before.
+    int& fast = flag[4];
+    double* Linv = ebuf + 512;                     // 16 x 16, free until the Jacobi sweeps start
+    if (tid < 64) {
+        const int lane = tid;
+        double a[16], x[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[j] = lane < 15 ? (j < 15 ? ebuf[lane * 16 + j] : 0.0) : ((lane == 15 && j == 15) ? 1.0 : 0.0);
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            double djj = readlane_d(a[j], j);
+            if (!(djj > 0.0) || !isfinite(djj)) { bad = true; djj = 1.0; }
+            const double rd = 1.0 / sqrt(djj);
+            const double lij = (lane == j) ? djj * rd : a[j] * rd;
+            a[j] = lij;
+#pragma unroll
+            for (int c2 = j + 1; c2 < 16; ++c2) a[c2] -= lij * readlane_d(lij, c2);
+        }
+        // lane c: column c of L^-1 (forward substitution of e_c); L[i][k] sits in lane i, register k
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            double sacc = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < i; ++k) sacc -= readlane_d(a[k], i) * x[k];
+            x[i] = sacc / readlane_d(a[i], i);
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) Linv[k * 16 + lane] = x[k];
+        }
+        if (lane == 0) fast = bad ? 0 : 1;
     }
     __syncthreads();
+    if (fast) {
+        if (tid < 225) {
+            const int i = tid / 15, j = tid % 15;
+            double sacc = 0;
+            for (int k = (i > j ? i : j); k < 15; ++k) sacc += Linv[k * 16 + i] * Linv[k * 16 + j];
+            Ainv[tid] = sacc;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double f2 = 0;
+            for (int k = 0; k < 225; ++k) f2 += Ainv[k] * Ainv[k];
+            if (!(f2 > 0.0) || !isfinite(f2) || !(1.0 / sqrt(f2) > 1e-7)) fast = 0;
+        }
+        __syncthreads();
+    }
+    if (!fast) {
+        if (tid < 64) { const int cur = jacobi16_wave(ebuf, tid); if (tid == 0) ecur = cur; }
+        __syncthreads();
+        if (tid < 225) {
+            const double* Am = ebuf + ecur * 512; const double* Vm = Am + 256;
+            const int i = tid / 15, j = tid % 15;
+            double sacc = 0;
+            for (int k = 0; k < 16; ++k) { const double w = Am[k * 17]; sacc += Vm[i * 16 + k] * (w > 1e-8 ? 1.0 / w : 0.0) * Vm[j * 16 + k]; }
+            Ainv[tid] = sacc;
+        }
+        __syncthreads();
+    }
     for (int e = tid; e < n * 15; e += TR_THREADS) {          // T = Arm Amm^+
         const int i = e / 15, j = e % 15;
         double sacc = 0;
