@@ -132,17 +132,30 @@ __global__ void k_lm_accumulate(const float4* __restrict__ pts, int n, float inv
     atomicAdd(cnt + s, sign);
 }
 // list the live voxels with their pcl::VoxelGrid linear index (relative to the ring's bounding box) for the ordered output
-__global__ void k_lm_list(const unsigned long long* __restrict__ keys, const int* __restrict__ cnt, int cap, float inv_leaf, const int* __restrict__ bbox,
-                          int* nvox, unsigned long long* vkey, int* vslot, int max_vox) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= cap || cnt[s] <= 0) return;
+__global__ __launch_bounds__(1024) void k_lm_list(const unsigned long long* __restrict__ keys, const int* __restrict__ cnt, int cap, float inv_leaf,
+                                                  const int* __restrict__ bbox, int* nvox, unsigned long long* vkey, int* vslot, int max_vox) {
+    // one list position per live voxel: positions come from a block-wide count (ballot per wavefront, 16 wavefront totals through LDS)
+    // and ONE atomic per 1024 slots -- an atomic per voxel (~1e5 on one address) made this kernel 100-500 us
+    __shared__ int s_w[16], s_base;
+    const int s = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool live = s < cap && cnt[s] > 0;
+    const unsigned long long bal = __ballot(live);
+    if (lane == 0) s_w[wv] = __popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int k = 0; k < 16; ++k) { const int v = s_w[k]; s_w[k] = t; t += v; }
+        s_base = t > 0 ? atomicAdd(nvox, t) : 0;
+    }
+    __syncthreads();
+    if (!live) return;
     int min_b[3], div_b[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) { min_b[c] = (int)floorf(ord2f(bbox[c]) * inv_leaf); div_b[c] = (int)floorf(ord2f(bbox[3 + c]) * inv_leaf) - min_b[c] + 1; }
     const unsigned long long k = keys[s];
     const int ix = (int)((k >> 42) & 0x1fffff) - (1 << 20), iy = (int)((k >> 21) & 0x1fffff) - (1 << 20), iz = (int)(k & 0x1fffff) - (1 << 20);
     const unsigned long long lin = (unsigned long long)((long long)(ix - min_b[0]) + (long long)(iy - min_b[1]) * div_b[0] + (long long)(iz - min_b[2]) * div_b[0] * (long long)div_b[1]);
-    const int v = atomicAdd(nvox, 1);
+    const int v = s_base + s_w[wv] + __popcll(bal & ((1ull << lane) - 1ull));
     if (v < max_vox) { vkey[v] = lin; vslot[v] = s; }
 }
 __global__ void k_lm_emit(const int* __restrict__ vslot_sorted, int nv, const long long* __restrict__ sum, const int* __restrict__ cnt,
@@ -246,7 +259,7 @@ int glio_localmap_build(glio_ctx* c, int* out_points) {
     }
     LM_CHECK(hipMemsetAsync(m->d_nvox, 0, 4, c->stream));
     hipLaunchKernelGGL(k_lm_bbox_union, dim3(1), dim3(64), 0, c->stream, m->d_slot_bbox, m->d_n, m->width, m->d_bbox);
-    hipLaunchKernelGGL(k_lm_list, dim3((m->table_cap + 255) / 256), dim3(256), 0, c->stream, m->d_keys, m->d_cnt, m->table_cap, inv_leaf, m->d_bbox,
+    hipLaunchKernelGGL(k_lm_list, dim3((m->table_cap + 1023) / 1024), dim3(1024), 0, c->stream, m->d_keys, m->d_cnt, m->table_cap, inv_leaf, m->d_bbox,
                        m->d_nvox, m->d_vkey, m->d_vslot, m->max_vox);
     LM_CHECK(hipGetLastError());
     LM_CHECK(hipMemcpyAsync(m->h_pin, m->d_nvox, 4, hipMemcpyDeviceToHost, c->stream));
