@@ -171,7 +171,7 @@ static int create_body(int device, const glio_opts* opts, glio_ctx* c) {
     }
     GLIO_HIP_CHECK(hipHostMalloc((void**)&c->h_progress, 64, hipHostMallocMapped | hipHostMallocCoherent));
     GLIO_HIP_CHECK(hipHostGetDevicePointer((void**)&c->d_progress, (void*)c->h_progress, 0));
-    c->h_progress[0] = 0; c->h_progress[1] = 0; c->enqueue_lead = 1;
+    c->h_progress[0] = 0; c->h_progress[1] = 0; c->h_progress[2] = 0; c->enqueue_lead = 1;
     static_assert(sizeof(SolverStatus) <= 512, "result layout");
     GLIO_HIP_CHECK(hipHostMalloc((void**)&c->h_result, 512 + (size_t)nx * 8, hipHostMallocMapped | hipHostMallocCoherent));
     GLIO_HIP_CHECK(hipHostGetDevicePointer((void**)&c->d_result, (void*)c->h_result, 0));
@@ -710,9 +710,19 @@ static int enqueue_solve(glio_ctx* c, int n_ddt) {
     const auto t_start = std::chrono::steady_clock::now();
     int enq = 0, spins = 0;
     const int dense = glio_solver_needs_dense_H(c, n_ddt);
+    // options.max_solver_time_in_seconds: when the budget is spent the host raises the stop word; the state machine of the next
+    // group sees it and ends the solve.  One more group is fed regardless of the look-ahead rule so that such a state machine runs.
+    const bool timed = c->opts.max_solver_time_s > 0.0;
+    const auto budget = std::chrono::duration<double>(timed ? c->opts.max_solver_time_s : 0.0);
+    bool stop_sent = false, extra_group = false;
     while (enq < total) {
         if (c->h_progress[1] == id) break;
-        if (enq - started() < lead) {
+        if (timed && !stop_sent && std::chrono::steady_clock::now() - t_start > budget) {
+            c->h_progress[2] = id;
+            stop_sent = true; extra_group = true;
+        }
+        if (enq - started() < lead || extra_group) {
+            extra_group = false;
             enqueue_linearize(c, 1, 0, n_ddt, dense);
             lds_poison(c);
             glio_launch_tr_step(c, n_ddt);

@@ -44,6 +44,7 @@
 
 struct TrArgs {
     int W, n, n_ddt, max_iterations;
+    const int* stop_word;        // mapped host word: equals the solve's id once the host's clock passed max_solver_time_s (nullptr: no limit)
     double min_relative_decrease, function_tolerance, gradient_tolerance, parameter_tolerance;
     double min_radius, initial_radius, max_radius;
     int jacobi_scaling;
@@ -530,7 +531,8 @@ __device__ __forceinline__ bool tr_prepare_body(const TrArgs& a, TrDecision* out
     gm = block_max(gm, red);
     if (tid == 0) {
         s.grad_max_norm = gm;
-        if (s.iteration >= a.max_iterations) { s.done = 1; s.termination = GLIO_TERM_NO_CONVERGENCE; }
+        const bool out_of_time = a.stop_word && *reinterpret_cast<const volatile int*>(a.stop_word) == s.solve_id;      // Ceres: MaxSolverTimeReached
+        if (s.iteration >= a.max_iterations || out_of_time) { s.done = 1; s.termination = GLIO_TERM_NO_CONVERGENCE; }
         else if (gm <= a.gradient_tolerance) { s.done = 1; s.termination = GLIO_TERM_GRADIENT_TOL; }
         else if (s.radius <= a.min_radius) { s.done = 1; s.termination = GLIO_TERM_MIN_RADIUS; }
         else s.iteration += 1;
@@ -2332,6 +2334,7 @@ int glio_solver_needs_dense_H(const glio_ctx* c, int n_ddt) { return !(glio_solv
 void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
     TrArgs a;
     a.W = c->W; a.n = 15 * c->W + n_ddt; a.n_ddt = n_ddt; a.max_iterations = c->opts.max_iterations;
+    a.stop_word = c->opts.max_solver_time_s > 0.0 ? c->d_progress + 2 : nullptr;
     a.min_relative_decrease = c->opts.min_relative_decrease; a.function_tolerance = c->opts.function_tolerance;
     a.gradient_tolerance = c->opts.gradient_tolerance; a.parameter_tolerance = c->opts.parameter_tolerance;
     a.min_radius = c->opts.min_trust_region_radius; a.initial_radius = c->opts.initial_trust_region_radius;

@@ -31,7 +31,7 @@ class GlioOpts(C.Structure):
         ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
         ("parameter_tolerance", C.c_double),
         ("trust_region_strategy", C.c_int32), ("unit_scores", C.c_int32),
-        ("lidar_precision", C.c_int32), ("reserved_", C.c_int32),
+        ("lidar_precision", C.c_int32), ("reserved_", C.c_int32), ("max_solver_time_s", C.c_double),
     ]
 
 

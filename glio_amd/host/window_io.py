@@ -10,10 +10,11 @@ from .. import synth
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 DEMO = os.path.join(HERE, "host_demo")
+_ABI_HEADERS = [os.path.join(HERE, "..", "..", "include", h) for h in ("glio_hip.h", "glio_types.h")]      # a changed struct must rebuild the demos
 
 
 def build_demo(force=False):
-    src = [os.path.join(HERE, "host_demo.cpp"), os.path.join(HERE, "glio_backend.hpp")]
+    src = [os.path.join(HERE, "host_demo.cpp"), os.path.join(HERE, "glio_backend.hpp")] + _ABI_HEADERS
     if force or not os.path.exists(DEMO) or any(os.path.getmtime(s) > os.path.getmtime(DEMO) for s in src):
         subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", src[0], "-I" + os.path.join(HERE, "..", "..", "include"),
                                "-L" + os.path.join(HERE, "..", "lib"), "-lglio_hip", "-Wl,-rpath,$ORIGIN/../lib", "-o", DEMO])
@@ -57,7 +58,7 @@ DEMO_BATCH = os.path.join(HERE, "host_demo_batch")
 
 def build_demo_batch(force=False):
     """The C++ sharded batch stage (links librccl: ncclAllReduce between linearise and step)."""
-    src = [os.path.join(HERE, "host_demo_batch.cpp"), os.path.join(HERE, "glio_batch_backend.hpp")]
+    src = [os.path.join(HERE, "host_demo_batch.cpp"), os.path.join(HERE, "glio_batch_backend.hpp")] + _ABI_HEADERS
     if force or not os.path.exists(DEMO_BATCH) or any(os.path.getmtime(s) > os.path.getmtime(DEMO_BATCH) for s in src):
         subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-D__HIP_PLATFORM_AMD__", src[0], "-I" + os.path.join(HERE, "..", "..", "include"),
                                "-I/opt/rocm/include", "-L" + os.path.join(HERE, "..", "lib"), "-lglio_hip", "-L/opt/rocm/lib", "-lrccl", "-lamdhip64", "-lpthread",

@@ -24,6 +24,7 @@ def frontend_opts(max_points, max_map_points, max_num_iter=12):
     o.t_lb[:] = [0, 0, 0]                           # LidarPlaneNormIncreFactor applies no extrinsic
     o.unit_scores = 1
     o.trust_region_strategy = 1                     # Ceres default LEVENBERG_MARQUARDT (solverOptions :521-527)
+    o.max_solver_time_s = 0.015                     # solverOptions.max_solver_time_in_seconds (:524)
     return o
 
 

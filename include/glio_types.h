@@ -68,6 +68,11 @@ typedef struct glio_opts {
      * chunk runs on the matrix core (v_mfma_f32_16x16x4_f32) with double accumulation across chunks. */
     int32_t lidar_precision;
     int32_t reserved_;
+    /* options.max_solver_time_in_seconds (the front end runs with 0.015, LidarOdometry.cpp:524; 0 = no limit, the sliding window's
+     * default).  Checked where Ceres checks it -- at the start of an iteration, after the tolerance tests of the previous one: the
+     * host's clock raises a flag in mapped memory, the device-resident loop reads it in its state machine and ends the solve with
+     * GLIO_TERM_NO_CONVERGENCE at the current (last accepted) point. */
+    double max_solver_time_s;
 } glio_opts;
 enum { GLIO_LIDAR_F64 = 0, GLIO_LIDAR_F32_MFMA = 1 };
 

@@ -17,8 +17,8 @@ _SO = os.path.join(_HERE, "_build", "libglio_oracle.so")
 
 
 def build(force=False):
-    if force or not os.path.exists(_SO):
-        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
+    """make decides what is stale (the Makefile lists the sources and ../include/glio_types.h: a changed struct must rebuild the checker)."""
+    subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
     return _SO
 
 

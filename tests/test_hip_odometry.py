@@ -80,3 +80,31 @@ def test_scan_to_map_matches_oracle(frame, match_cnt):
     # the estimate moves towards the ground truth
     assert np.linalg.norm(ph[4:] - gt[4:]) < 0.3 * np.linalg.norm(pose0[4:] - gt[4:])
     ctx.close()
+
+
+def test_solver_time_budget_ends_the_solve_at_an_accepted_point(frame):
+    """options.max_solver_time_in_seconds (LidarOdometry.cpp:524: 0.015 s).  With the front end's budget the solve is untouched (it
+    takes ~0.3 ms); with a budget that is spent at once the device loop stops at the next iteration start with NO_CONVERGENCE, at
+    a point it had accepted (cost not above the initial cost), and later solves on the same context are not affected."""
+    from glio_amd import capi
+    map_pts, scan, pose0, gt = frame
+    outs = {}
+    for budget in (0.015, 1e-7):
+        o = odometry.frontend_opts(len(scan), len(map_pts))
+        o.max_solver_time_s = budget
+        ctx = capi.Context(o)
+        odo = odometry.ScanToMapOdometry(ctx)
+        odo.set_map(map_pts)
+        pose, rounds = odo.update(scan, pose0, match_cnt=1)
+        outs[budget] = (pose, rounds[0][0])
+        if budget < 1e-3:      # the same context again with the normal budget: unaffected by the stop word of the earlier solve
+            ctx2 = capi.Context(odometry.frontend_opts(len(scan), len(map_pts)))
+            odo2 = odometry.ScanToMapOdometry(ctx2); odo2.set_map(map_pts)
+            pose2, rounds2 = odo2.update(scan, pose0, match_cnt=1)
+            assert rounds2[0][0].iterations == outs[0.015][1].iterations and np.abs(pose2 - outs[0.015][0]).max() == 0.0
+            ctx2.close()
+        ctx.close()
+    full, cut = outs[0.015][1], outs[1e-7][1]
+    assert full.termination != 0 and full.iterations >= 3
+    assert cut.termination == 0 and cut.iterations < full.iterations                  # GLIO_TERM_NO_CONVERGENCE
+    assert cut.final_cost <= cut.initial_cost * (1 + 1e-12) and np.all(np.isfinite(outs[1e-7][0]))
