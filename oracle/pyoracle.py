@@ -18,7 +18,11 @@ _SO = os.path.join(_HERE, "_build", "libglio_oracle.so")
 
 def build(force=False):
     """make decides what is stale (the Makefile lists the sources and ../include/glio_types.h: a changed struct must rebuild the checker)."""
-    subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
+    try:
+        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
+    except (OSError, subprocess.CalledProcessError):
+        if force or not os.path.exists(_SO):          # (a prebuilt checker travels with the tree: a box without make / gcc still runs it)
+            raise
     return _SO
 
 
