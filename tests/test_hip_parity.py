@@ -409,3 +409,26 @@ def test_chain_step_is_bit_identical_to_the_assembled_sequence(hip, steady_windo
         ctx.close()
     assert out[0][0] == out[0][1] == out[0][2]
     assert out[1] == out[0]
+
+
+def test_dense_gnss_pairs_cross_the_chunk_boundaries(hip, po):
+    """A keyframe pair with MORE factors than the GNSS role takes side by side: 25 epochs per pair (gnss_epoch_dt 0.016 s) = 50 DD
+    factors (7 chunks of 8) and 500 Doppler rows (4 chunks of 128, epochs straddling the chunk boundaries: the carried partial sums
+    of the per-epoch lanes).  Linearisation and solve against the oracle; the chain step (no dense H) against the dense path."""
+    from glio_amd import synth
+    win = synth.make_window(W=4, pts_per_scan=512, with_gnss=True, seed=synth.SEED_BASE + 77, gnss_epoch_dt=0.016)
+    corr = synth.analytic_correspondences(win)
+    assert len(win.dd) >= 3 * 40 and len(win.dop) >= 3 * 400
+    prob = po.Problem(win, corr, use_prior=False)
+    ctx = hip.Context(win.opts)
+    ctx.load_window(win, corr, use_prior=False)
+    st = _state_for(win, True)
+    Ho, go, co = prob.linearize(st)
+    Hh, gh, ch = ctx.linearize(st)
+    assert abs(ch - co) <= 1e-10 * abs(co) and rel_err(gh, go) <= 1e-10 and rel_err(Hh, Ho) <= 1e-10
+    so, mo = prob.solve(st)
+    sh, mh = ctx.solve(st)
+    assert mh.iterations == mo.iterations and mh.termination == mo.termination
+    assert np.abs(sh.trans - so.trans).max() < 1e-8 and np.abs(sh.rcv_ddt[:sh.n_ddt] - so.rcv_ddt[:so.n_ddt]).max() < 1e-6
+    assert hip.load().glio_debug_solver_path(ctx._h) == 2
+    ctx.close()
