@@ -170,11 +170,13 @@ def test_tiled_search_exact_ties_and_dense_cells(hip, po):
     dense = np.zeros((40000, 4), np.float32)
     dense[:, :3] = rng.uniform([5, -4, -0.05], [13, 4, 0.05], (40000, 3))   # a 8 x 8 m slab, 625 points per m^2
     dq = np.zeros((3000, 4), np.float32); dq[:, :3] = rng.uniform([6, -3, -0.3], [12, 3, 0.3], (3000, 3))
+    # (c) 5003 queries inside ONE voxel-hash cell (a tile of 1024 queries with a single key: 64 units of the same cell)
+    cl = np.zeros((5003, 4), np.float32); cl[:, :3] = rng.uniform([8.0, 0.1, -0.2], [8.9, 1.0, 0.2], (5003, 3))
     lib = hip.load()
     for mode in (0, 1):
         lib.glio_debug_set_knn_mode(mode)
         try:
-            for m, q in ((lat_map, qs), (dense, dq)):
+            for m, q in ((lat_map, qs), (dense, dq), (dense, cl)):
                 o = synth.default_opts(1, pts=len(q), map_pts=len(m))
                 w2 = type("W", (), {"opts": o, "map_pts": m})
                 ctx = hip.Context(o)
