@@ -17,8 +17,6 @@
 #include <algorithm>
 #include <cstring>
 
-#include <hipcub/hipcub.hpp>
-
 #include "glio_device.h"
 
 // the transform must round like the reference's scalar code (and the oracle): no FMA contraction in this file
@@ -54,6 +52,7 @@ struct LocalMap {
 
 __device__ __forceinline__ int f2ord(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
 __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+static inline float h_ord2f(int i) { const int u = i >= 0 ? i : i ^ 0x7fffffff; float f; memcpy(&f, &u, 4); return f; }     // the same on the host
 
 __global__ void k_lm_transform(const float4* __restrict__ in, int n, const double q0, const double q1, const double q2, const double q3,
                                const double t0, const double t1, const double t2, float4* __restrict__ out) {
@@ -158,6 +157,81 @@ __global__ __launch_bounds__(1024) void k_lm_list(const unsigned long long* __re
     const int v = s_base + s_w[wv] + __popcll(bal & ((1ull << lane) - 1ull));
     if (v < max_vox) { vkey[v] = lin; vslot[v] = s; }
 }
+// ------------------------------------------------------------------------------------------------
+// Ordered output: the live voxels sorted by their pcl::VoxelGrid linear index.  A least-significant-digit radix sort on 8-bit
+// digits, hand-written for this case: the keys are bounded by the ring's bounding box (typically < 2^24), so the host -- which
+// reads the voxel count back anyway -- asks for only ceil(bits / 8) passes (3 instead of the 8 a generic 64-bit sort runs).
+//   k_rs_hist     one wavefront per tile of 1024 pairs: 256-bin digit histogram (LDS atomics) -> hist[tile][digit]
+//   k_rs_scan     exclusive scan over (digit, tile) in that order: where each tile's run of each digit starts
+//   k_rs_scatter  the same wavefront per tile walks its 16 chunks of 64 in order; inside a chunk a pair's rank among the lanes
+//                 with the same digit comes from eight ballots (one per digit bit): stable, no LDS traffic for the ranking
+#define RS_TILE 1024
+__global__ __launch_bounds__(64) void k_rs_hist(const unsigned long long* __restrict__ key, const int n, const int shift, const int nt, int* __restrict__ hist) {
+    __shared__ int h[256];
+    const int lane = threadIdx.x, t0 = blockIdx.x * RS_TILE;
+    for (int d = lane; d < 256; d += 64) h[d] = 0;
+    GLIO_WAVE_LDS_SYNC();
+    unsigned long long kk[RS_TILE / 64];
+#pragma unroll
+    for (int q = 0; q < RS_TILE / 64; ++q) { const int e = t0 + 64 * q + lane; kk[q] = e < n ? key[e] : ~0ull; }
+#pragma unroll
+    for (int q = 0; q < RS_TILE / 64; ++q) if (t0 + 64 * q + lane < n) atomicAdd(&h[(int)((kk[q] >> shift) & 255ull)], 1);
+    GLIO_WAVE_LDS_SYNC();
+    for (int d = lane; d < 256; d += 64) hist[blockIdx.x * 256 + d] = h[d];           // [tile][digit]: coalesced here, in the scan and in the scatter
+}
+__global__ __launch_bounds__(1024) void k_rs_scan(int* __restrict__ hist, const int nt) {
+    // 256 digits x 4 quarters of the tiles: every thread sums its quarter (coalesced over the digits, loads independent of each
+    // other), the quarters and then the digits are chained through LDS, and the thread rewrites its quarter as running offsets
+    __shared__ int part[4][256], dbase[256];
+    const int d = threadIdx.x & 255, q = threadIdx.x >> 8;
+    const int per = (nt + 3) / 4, ta = min(nt, q * per), tb = min(nt, ta + per);
+    int s = 0;
+    for (int t = ta; t < tb; ++t) s += hist[t * 256 + d];
+    part[q][d] = s;
+    __syncthreads();
+    if (threadIdx.x < 256) dbase[d] = part[0][d] + part[1][d] + part[2][d] + part[3][d];
+    __syncthreads();
+    if (threadIdx.x == 0) { int run = 0; for (int k = 0; k < 256; ++k) { const int v = dbase[k]; dbase[k] = run; run += v; } }
+    __syncthreads();
+    int run = dbase[d];
+    for (int k = 0; k < q; ++k) run += part[k][d];
+    for (int t = ta; t < tb; ++t) { const int v = hist[t * 256 + d]; hist[t * 256 + d] = run; run += v; }
+}
+__global__ __launch_bounds__(64) void k_rs_scatter(const unsigned long long* __restrict__ key, const int* __restrict__ val, const int n, const int shift, const int nt,
+                                                   const int* __restrict__ hist, unsigned long long* __restrict__ okey, int* __restrict__ oval) {
+    __shared__ int base[256];
+    const int lane = threadIdx.x, t0 = blockIdx.x * RS_TILE;
+    for (int d = lane; d < 256; d += 64) base[d] = hist[blockIdx.x * 256 + d];
+    GLIO_WAVE_LDS_SYNC();
+    // all 16 chunks of the tile are fetched first (16 independent loads per lane in flight), then ranked chunk by chunk
+    unsigned long long kk[RS_TILE / 64]; int vv[RS_TILE / 64];
+#pragma unroll
+    for (int q = 0; q < RS_TILE / 64; ++q) {
+        const int e = t0 + 64 * q + lane;
+        kk[q] = e < n ? key[e] : 0ull;
+        vv[q] = e < n ? val[e] : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < RS_TILE / 64; ++q) {
+        const int e = t0 + 64 * q + lane;
+        const bool live = e < n;
+        const unsigned long long k = kk[q];
+        const int dg = (int)((k >> shift) & 255ull);
+        unsigned long long same = __ballot(live);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long bal = __ballot((dg >> b) & 1);
+            same &= ((dg >> b) & 1) ? bal : ~bal;
+        }
+        const int rank = __popcll(same & ((1ull << lane) - 1ull));
+        const int pos = live ? base[dg] + rank : 0;
+        GLIO_WAVE_LDS_SYNC();
+        if (live && rank == 0) base[dg] += __popcll(same);           // the first lane of every digit group advances its run
+        GLIO_WAVE_LDS_SYNC();
+        if (live) { okey[pos] = k; oval[pos] = vv[q]; }
+    }
+}
+
 __global__ void k_lm_emit(const int* __restrict__ vslot_sorted, int nv, const long long* __restrict__ sum, const int* __restrict__ cnt,
                           float4* __restrict__ out) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -202,8 +276,7 @@ int glio_localmap_config(glio_ctx* c, int width, float leaf, int max_points_per_
     LM_CHECK(hipMalloc((void**)&m->d_vkey, (size_t)m->max_vox * 8)); LM_CHECK(hipMalloc((void**)&m->d_vkey_sorted, (size_t)m->max_vox * 8));
     LM_CHECK(hipMalloc((void**)&m->d_vslot, (size_t)m->max_vox * 4)); LM_CHECK(hipMalloc((void**)&m->d_vslot_sorted, (size_t)m->max_vox * 4));
     LM_CHECK(hipMalloc((void**)&m->d_out, (size_t)m->max_vox * 16));
-    m->sort_tmp_bytes = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, m->sort_tmp_bytes, m->d_vkey, m->d_vkey_sorted, m->d_vslot, m->d_vslot_sorted, m->max_vox, 0, 64, c->stream);
+    m->sort_tmp_bytes = (size_t)256 * ((m->max_vox + RS_TILE - 1) / RS_TILE) * 4;          // digit histogram [256][tiles] of the radix sort
     LM_CHECK(hipMalloc(&m->d_sort_tmp, m->sort_tmp_bytes + 16));
     LM_CHECK(hipHostMalloc((void**)&m->h_pin, 64));
     hipLaunchKernelGGL(k_lm_clear, dim3((m->table_cap + 255) / 256), dim3(256), 0, c->stream, m->d_keys, m->d_sum, m->d_cnt, m->table_cap, m->d_nkeys);
@@ -264,17 +337,33 @@ int glio_localmap_build(glio_ctx* c, int* out_points) {
     LM_CHECK(hipGetLastError());
     LM_CHECK(hipMemcpyAsync(m->h_pin, m->d_nvox, 4, hipMemcpyDeviceToHost, c->stream));
     LM_CHECK(hipMemcpyAsync(m->h_pin + 1, m->d_nkeys, 4, hipMemcpyDeviceToHost, c->stream));
+    LM_CHECK(hipMemcpyAsync(m->h_pin + 2, m->d_bbox, 24, hipMemcpyDeviceToHost, c->stream));
     LM_CHECK(hipStreamSynchronize(c->stream));
     const int nv = m->h_pin[0];
     if (m->h_pin[1] & 0x40000000) { glio_set_error("local map voxel table overflow (raise max_map_points)"); return GLIO_E_ARG; }
     m->nkeys_seen = m->h_pin[1];
     if (nv > m->max_vox) { glio_set_error("local map has %d voxels, max_map_points is %d", nv, m->max_vox); return GLIO_E_ARG; }
     if (nv > 0) {
-        size_t bytes = m->sort_tmp_bytes;
-        if (hipcub::DeviceRadixSort::SortPairs(m->d_sort_tmp, bytes, m->d_vkey, m->d_vkey_sorted, m->d_vslot, m->d_vslot_sorted, nv, 0, 64, c->stream) != hipSuccess) {
-            glio_set_error("voxel sort failed"); return GLIO_E_HIP;
+        // number of key bits from the bounding box, exactly as k_lm_list forms the linear index
+        double span = 1.0;
+        for (int c3 = 0; c3 < 3; ++c3) {
+            const int lo = (int)floorf(h_ord2f(m->h_pin[2 + c3]) * inv_leaf), hi = (int)floorf(h_ord2f(m->h_pin[5 + c3]) * inv_leaf);
+            span *= (double)(hi - lo + 1);
         }
-        hipLaunchKernelGGL(k_lm_emit, dim3((nv + 255) / 256), dim3(256), 0, c->stream, m->d_vslot_sorted, nv, m->d_sum, m->d_cnt, m->d_out);
+        int bits = 1;
+        while (bits < 63 && (double)(1ull << bits) < span) ++bits;
+        const int passes = (bits + 7) / 8, nt = (nv + RS_TILE - 1) / RS_TILE;
+        unsigned long long* ka = m->d_vkey; unsigned long long* kb = m->d_vkey_sorted;
+        int* va = m->d_vslot; int* vb = m->d_vslot_sorted;
+        int* hist = reinterpret_cast<int*>(m->d_sort_tmp);
+        for (int p = 0; p < passes; ++p) {
+            hipLaunchKernelGGL(k_rs_hist, dim3(nt), dim3(64), 0, c->stream, ka, nv, 8 * p, nt, hist);
+            hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, c->stream, hist, nt);
+            hipLaunchKernelGGL(k_rs_scatter, dim3(nt), dim3(64), 0, c->stream, ka, va, nv, 8 * p, nt, hist, kb, vb);
+            std::swap(ka, kb); std::swap(va, vb);
+        }
+        LM_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(k_lm_emit, dim3((nv + 255) / 256), dim3(256), 0, c->stream, va, nv, m->d_sum, m->d_cnt, m->d_out);     // (va: the sorted side after the last swap)
     }
     const int rc = glio_assoc_build_map_dev(c, m->d_out, nv);          // K1: replaces setInputCloud(surf_local_map_ds) (:2056)
     if (rc) return rc;
