@@ -75,7 +75,8 @@ __global__ void k_lm_clear(unsigned long long* keys, long long* sum, int* cnt, i
 }
 __global__ void k_lm_bbox_init(int* bbox) { const int i = threadIdx.x; if (i < 3) bbox[i] = 0x7fffffff; else if (i < 6) bbox[i] = (int)0x80000000; }
 // bounding box of one ring slot (ordered-int atomics)
-__global__ void k_lm_bbox(const float4* __restrict__ pts, int n, int* bbox) {
+__global__ __launch_bounds__(1024) void k_lm_bbox(const float4* __restrict__ pts, int n, int* bbox) {
+    __shared__ int s_mn[16][3], s_mx[16][3];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
     for (; i < n; i += gridDim.x * blockDim.x) {
@@ -89,9 +90,17 @@ __global__ void k_lm_bbox(const float4* __restrict__ pts, int n, int* bbox) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { mn[c] = min(mn[c], __shfl_xor(mn[c], off, 64)); mx[c] = max(mx[c], __shfl_xor(mx[c], off, 64)); }
     }
+    // one set of six atomics per 1024-thread workgroup (they all hit the same six words)
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { atomicMin(bbox + c, mn[c]); atomicMax(bbox + 3 + c, mx[c]); }
+        for (int c = 0; c < 3; ++c) { s_mn[threadIdx.x >> 6][c] = mn[c]; s_mx[threadIdx.x >> 6][c] = mx[c]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int c = threadIdx.x % 3;
+        const int nw = (blockDim.x + 63) >> 6;
+        if (threadIdx.x < 3) { int v = 0x7fffffff; for (int w = 0; w < nw; ++w) v = min(v, s_mn[w][c]); atomicMin(bbox + c, v); }
+        else { int v = (int)0x80000000; for (int w = 0; w < nw; ++w) v = max(v, s_mx[w][c]); atomicMax(bbox + 3 + c, v); }
     }
 }
 // union of the slot boxes (slots with n = 0 are skipped)
@@ -306,7 +315,7 @@ int glio_localmap_push(glio_ctx* c, const float* cloud_xyzi, int n, const double
         // stage the raw scan in the destination itself, transform in place, then add it to the voxel table
         LM_CHECK(hipMemcpyAsync(dst, cloud_xyzi, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(k_lm_transform, dim3((n + 255) / 256), dim3(256), 0, c->stream, dst, n, q[0], q[1], q[2], q[3], t[0], t[1], t[2], dst);
-        hipLaunchKernelGGL(k_lm_bbox, dim3(std::min(64, (n + 255) / 256)), dim3(256), 0, c->stream, dst, n, m->d_slot_bbox + 6 * slot);
+        hipLaunchKernelGGL(k_lm_bbox, dim3(std::min(64, (n + 1023) / 1024)), dim3(1024), 0, c->stream, dst, n, m->d_slot_bbox + 6 * slot);
         hipLaunchKernelGGL(k_lm_accumulate, dim3((n + 255) / 256), dim3(256), 0, c->stream, dst, n, inv_leaf, +1, m->d_keys, m->d_sum, m->d_cnt, m->table_cap, m->d_nkeys);
     }
     LM_CHECK(hipGetLastError());
