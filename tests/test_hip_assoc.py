@@ -207,3 +207,37 @@ def test_both_search_modes_give_identical_records(hip):
     assert out[0][0] == out[1][0] > 50000
     for a, b in zip(out[0][1:], out[1][1:]):
         assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def test_window_association_ragged_slots_and_slide(hip, small_window):
+    """The one-call window association with slots of very different sizes -- an empty slot, a single point, 1025 points (one full
+    tile + one point of the query binning), a full scan -- and after glio_slide_window (the presorted copies move with the scans):
+    every slot equals its own single-slot association."""
+    win = small_window
+    W = win.W
+    sizes = [0, 1, 1025] + [len(win.scans[s]) for s in range(3, W)]
+    scans = [np.ascontiguousarray(win.scans[s][:sizes[s]]) for s in range(W)]
+    poses = [hip.lidar_pose(win.opts, win.init.quat[s], win.init.trans[s]) for s in range(W)]
+    ref = hip.Context(win.opts); ref.set_map(win.map_pts)
+    want = []
+    for s in range(W):
+        n = ref.associate(0, scans[s], *poses[s])
+        want.append((n,) + tuple(a.copy() for a in ref.get_correspondences(0)))
+    ref.close()
+    ctx = hip.Context(win.opts); ctx.set_map(win.map_pts)
+    for s in range(W):
+        ctx.set_scan(s, scans[s])
+    q2s, t2s = np.array([p[0] for p in poses]), np.array([p[1] for p in poses])
+    cnt = ctx.associate_window(q2s, t2s)
+    for s in range(W):
+        got = ctx.get_correspondences(s)
+        assert cnt[s] == want[s][0] and all(np.array_equal(a, b) for a, b in zip(got, want[s][1:])), s
+    # slide: slot s takes the scan of slot s + 1; associate with the poses shifted the same way
+    ctx.slide_window()
+    ctx.set_scan(W - 1, scans[0])
+    order = list(range(1, W)) + [0]
+    cnt2 = ctx.associate_window(np.array([poses[k][0] for k in order]), np.array([poses[k][1] for k in order]))
+    for s, k in enumerate(order):
+        got = ctx.get_correspondences(s)
+        assert cnt2[s] == want[k][0] and all(np.array_equal(a, b) for a, b in zip(got, want[k][1:])), (s, k)
+    ctx.close()
