@@ -15,11 +15,13 @@ from . import capi
 from . import ctypes_types as T
 
 
-def shard_range(K, rank, world):
-    """Contiguous keyframe range [lo, hi) owned by `rank` (source keyframe of a constraint decides)."""
-    base, rem = divmod(K, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+def shard_range(K, rank, world, band=6):
+    """Contiguous keyframe range [lo, hi) owned by `rank` (the source keyframe of a constraint decides): whole super-blocks of
+    the block cyclic reduction (6 keyframes, 12 for bands > 6), glio_batch_shard_range restated (tests/test_batch_dist_cpu.py
+    checks the two agree)."""
+    sbk = 6 if band <= 6 else 12
+    S = (K + sbk - 1) // sbk
+    return min(K, (S * rank // world) * sbk), min(K, (S * (rank + 1) // world) * sbk)
 
 
 def hg_size(K, band):
@@ -74,6 +76,50 @@ def make_poses(K, seed=20260930, perturb=(0.05, 0.003)):
         init[k, 3] = w1 * w2 - v1 @ v2
         init[k, 4:] = w1 * v2 + w2 * v1 + np.cross(v1, v2)
     return gt, init
+
+
+BATCH_KF_DT = 0.125          # seconds between batch keyframes (1 m spacing at 8 m/s)
+
+
+def make_batch_imu(K, seed=20260930, rate_per_kf=10, kf_dt=BATCH_KF_DT, perturb_v=0.05, noise=True):
+    """The IMU chain of the batch problem (Estimator.cpp:2990-3001): one pre-integration per pair of consecutive keyframes
+    of make_poses' track, from IMU samples of the analytic trajectory (position p(s), yaw(s), s = t / kf_dt), midpoint
+    pre-integrated on the host exactly as the window generator does (synth.preintegrate = class Preintegration restated).
+    Returns (preints [K - 1] dicts, speed_bias_gt [K][9], speed_bias_init [K][9]).  Edge k spans keyframes k .. k + 1
+    (the consistent interval; the reference's own indexing looks off by one there)."""
+    from . import synth
+    rng = np.random.default_rng(seed + 31)
+
+    def pos_d(s):       # first and second derivative of make_poses' position with respect to s
+        d1 = np.array([1.0, 3.0 / 40.0 * math.cos(s / 40.0), 0.2 / 25.0 * math.cos(s / 25.0)])
+        d2 = np.array([0.0, -3.0 / 1600.0 * math.sin(s / 40.0), -0.2 / 625.0 * math.sin(s / 25.0)])
+        return d1, d2
+
+    def Rz(s):
+        y = 0.075 * math.cos(s / 40.0)
+        c, sn = math.cos(y), math.sin(y)
+        return np.array([[c, -sn, 0], [sn, c, 0], [0, 0, 1.0]])
+
+    n = rate_per_kf
+    dts = np.full(n, kf_dt / n)
+    preints = []
+    for k in range(K - 1):
+        acc, gyr = np.zeros((n + 1, 3)), np.zeros((n + 1, 3))
+        for i in range(n + 1):
+            s = k + i / n
+            d1, d2 = pos_d(s)
+            a = d2 / (kf_dt * kf_dt)
+            acc[i] = Rz(s).T @ (a + np.array([0, 0, synth.GRAVITY]))
+            gyr[i] = [0.0, 0.0, -0.075 / 40.0 * math.sin(s / 40.0) / kf_dt]
+        if noise:
+            acc += rng.normal(0, synth.ACC_N, acc.shape); gyr += rng.normal(0, synth.GYR_N, gyr.shape)
+        preints.append(synth.preintegrate(acc, gyr, dts, np.zeros(3), np.zeros(3)))
+    sb_gt = np.zeros((K, 9))
+    for k in range(K):
+        sb_gt[k, :3] = pos_d(float(k))[0] / kf_dt
+    sb_init = sb_gt.copy()
+    sb_init[:, :3] += rng.normal(0, perturb_v, (K, 3))
+    return preints, sb_gt, sb_init
 
 
 def make_constraints(gt, lo, hi, per_kf, band, seed=20260930, device="cpu"):
@@ -406,19 +452,33 @@ class BatchStage:
     def set_dd_threshold(self, threshold):
         capi._check(capi.load().glio_batch_set_dd_threshold(self._h, C.c_double(threshold)))
 
-    def add_small(self, poses, Hg):
-        poses = np.ascontiguousarray(poses, np.float64)
-        capi._check(capi.load().glio_batch_add_small_dev(self._h, T.dptr(poses), C.c_void_p(Hg.data_ptr())))
+    def set_shard(self, rank, world):
+        """This stage is rank `rank` of `world` (before set_small_factors); returns its keyframe range."""
+        capi._check(capi.load().glio_batch_set_shard(self._h, rank, world))
+        self.rank, self.world = rank, world
+        return shard_range(self.K, rank, world, self.band)
 
-    def solve_tr(self, poses, opts=None, dist=None, on_allreduce=None):
-        """ceres::Solve of the batch problem (Estimator.cpp:3275-3284) on the device.  With `dist` (torch.distributed, world > 1) the
-        library calls back once per linearisation with this rank's [H|g|cost] buffer; the hook all-reduces it in place."""
+    def set_imu(self, preints, gravity=None):
+        """The ImuFactor chain (Estimator.cpp:2990-3001): K - 1 pre-integrations (dicts of synth.preintegrate or GlioPreint), [] removes it."""
+        from . import synth
+        preints = list(preints or [])
+        arr = (T.GlioPreint * max(len(preints), 1))()
+        for k, d in enumerate(preints):
+            if isinstance(d, T.GlioPreint):
+                arr[k] = d
+            else:
+                synth.fill_preint(arr[k], d)
+        capi._check(capi.load().glio_batch_set_imu(self._h, len(preints), arr if preints else None, C.c_double(synth.GRAVITY if gravity is None else gravity)))
+        self.n_imu = len(preints)
+
+    def _hook(self, dist, on_allreduce=None):
+        """The all-reduce hook of the library for torch.distributed: the collective is issued on the library's stream (made
+        torch's current stream for the call), so it is ordered with the kernels around it and the host does not wait."""
         import torch
-        poses = np.ascontiguousarray(poses, np.float64).copy()
-        opts = opts or T.batch_tr_opts()
-        summ = T.GlioSummary()
+        if dist is None:
+            return ALLREDUCE_FN(), None
         dev = f"cuda:{self.device}"
-        calls = [0]
+        calls = []
 
         class _Dev:            # a device buffer of the library seen through the CUDA array interface
             def __init__(self, ptr, n):
@@ -426,16 +486,50 @@ class BatchStage:
 
         def hook(ptr, count, stream, user):
             t = torch.as_tensor(_Dev(ptr, count), device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            torch.cuda.synchronize(self.device)
-            calls[0] += 1
-            if on_allreduce:
-                on_allreduce(t)
+            ext = torch.cuda.ExternalStream(stream, device=dev) if stream else torch.cuda.current_stream(dev)
+            with torch.cuda.stream(ext):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                if on_allreduce:
+                    on_allreduce(t)
+            calls.append(int(count))
 
-        cb = ALLREDUCE_FN(hook) if dist is not None else ALLREDUCE_FN()
-        capi._check(capi.load().glio_batch_solve_tr(self._h, T.dptr(poses), C.byref(opts), cb, None, C.byref(summ)))
-        self.allreduces = calls[0]
+        return ALLREDUCE_FN(hook), calls
+
+    def linearize_full(self, poses, speed_bias=None, dist=None):
+        """diag(H), g, cost of the whole problem through the solver's path (shard + hook + assembly); n = 6 K or 15 K."""
+        poses = np.ascontiguousarray(poses, np.float64)
+        B = 15 if getattr(self, "n_imu", 0) else 6
+        diag = np.zeros(B * self.K); g = np.zeros(B * self.K); cost = C.c_double()
+        sb = np.ascontiguousarray(speed_bias, np.float64) if speed_bias is not None else None
+        cb, _ = self._hook(dist)
+        capi._check(capi.load().glio_batch_linearize_full(self._h, T.dptr(poses), T.dptr(sb) if sb is not None else None, cb, None, T.dptr(diag), T.dptr(g), C.byref(cost)))
+        return diag, g, cost.value
+
+    def add_small(self, poses, Hg):
+        poses = np.ascontiguousarray(poses, np.float64)
+        capi._check(capi.load().glio_batch_add_small_dev(self._h, T.dptr(poses), C.c_void_p(Hg.data_ptr())))
+
+    def solve_tr(self, poses, opts=None, dist=None, on_allreduce=None, speed_bias=None):
+        """ceres::Solve of the batch problem (Estimator.cpp:3275-3284) on the device, device resident.  With `dist`
+        (torch.distributed or a stand-in with all_reduce, world > 1 set through set_shard) the library calls back five times per
+        trust-region iteration with a small device buffer; the hook all-reduces it in place on the library's stream.
+        Returns (poses, summary) or, with the IMU chain, (poses, speed_bias, summary)."""
+        poses = np.ascontiguousarray(poses, np.float64).copy()
+        opts = opts or T.batch_tr_opts()
+        summ = T.GlioSummary()
+        cb, calls = self._hook(dist, on_allreduce)
+        sb = np.ascontiguousarray(speed_bias, np.float64).copy() if speed_bias is not None else None
+        capi._check(capi.load().glio_batch_solve_tr2(self._h, T.dptr(poses), T.dptr(sb) if sb is not None else None, C.byref(opts), cb, None, C.byref(summ)))
+        self.allreduces = len(calls) if calls is not None else 0
+        self.allreduce_sizes = calls or []
+        if sb is not None:
+            return poses, sb, summ
         return poses, summ
+
+    def counters(self):
+        out = (C.c_int64 * 4)()
+        capi._check(capi.load().glio_batch_debug_counters(self._h, out))
+        return dict(hook_calls=out[0], hook_doubles=out[1], groups=out[2], bcr_levels=out[3])
 
     def time_solve(self, Hg, lam=1e-4, reps=5):
         ms = C.c_float()
@@ -500,13 +594,15 @@ def lm_solve(linearize_reduced, step, poses0, iterations=10, lam=1e-4):
     return poses, history
 
 
-def solve_batch_rounds(stage, poses0, odo, search_range, dd, frame, reassociate=None, opts=None, dist=None, thresholds=DDPSR_THRESHOLDS):
+def solve_batch_rounds(stage, poses0, odo, search_range, dd, frame, reassociate=None, opts=None, dist=None, thresholds=DDPSR_THRESHOLDS, speed_bias=None):
     """The outer loop of optimizeBatch (Estimator.cpp:2764-3410): `iteration_num` rounds, each re-searching the LiDAR
     correspondences at the current poses (`reassociate(poses)` must leave the new constraint set on `stage`; None keeps it),
     rebuilding the small factors with this round's DDpsr_threshold, and running one trust-region solve.  The attitude constraints
-    are rebuilt every round from the ODOMETRY poses `odo` (pose_info_keyframe is not updated inside the loop)."""
+    are rebuilt every round from the ODOMETRY poses `odo` (pose_info_keyframe is not updated inside the loop).  With the IMU chain
+    set on the stage, `speed_bias` [K][9] travels along and (poses, speed_bias, history) is returned."""
     import time
     poses = np.ascontiguousarray(poses0, np.float64).copy()
+    sb = None if speed_bias is None else np.ascontiguousarray(speed_bias, np.float64).copy()
     dq = delta_q_pairs(odo, search_range)
     stage.set_small_factors(dq, dd, frame, threshold=thresholds[0])
     history = []
@@ -515,8 +611,75 @@ def solve_batch_rounds(stage, poses0, odo, search_range, dd, frame, reassociate=
             reassociate(poses)
         stage.set_dd_threshold(thr)
         t0 = time.perf_counter()
-        poses, summ = stage.solve_tr(poses, opts, dist)
+        if sb is not None:
+            poses, sb, summ = stage.solve_tr(poses, opts, dist, speed_bias=sb)
+        else:
+            poses, summ = stage.solve_tr(poses, opts, dist)
         h = summ.as_dict()
         h["solve_ms"] = (time.perf_counter() - t0) * 1e3
         history.append(h)
+    if sb is not None:
+        return poses, sb, history
     return poses, history
+
+
+class ThreadRanks:
+    """N "virtual ranks" inside one process, one thread each, for exercising the sharded solve where only one GPU (or none: the
+    CPU stand-in) is available: all_reduce = device synchronise, barrier, rank 0 sums the buffers in rank order and writes the sum
+    back to every rank, barrier.  Same call sequence as torch.distributed; used by tests/ and by bench.py's projection."""
+
+    class ReduceOp:
+        SUM = "sum"
+
+    def __init__(self, world, sync=None):
+        import threading
+        self.world, self.sync = world, sync
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+        self.calls = [0] * world
+        self.errors = []
+
+    def view(self, rank):
+        outer = self
+
+        class _Rank:
+            ReduceOp = outer.ReduceOp
+
+            def all_reduce(self, t, op=None):
+                if outer.sync:
+                    outer.sync()
+                outer.slots[rank] = t
+                outer.barrier.wait()
+                if rank == 0:
+                    tot = outer.slots[0].clone()
+                    for q in outer.slots[1:]:
+                        tot += q
+                    for q in outer.slots:
+                        q.copy_(tot)
+                    if outer.sync:
+                        outer.sync()
+                outer.barrier.wait()
+                outer.calls[rank] += 1
+
+        return _Rank()
+
+    def run(self, fn):
+        """fn(rank, dist_view) in `world` threads; returns the list of results (exceptions are re-raised)."""
+        import threading
+        out = [None] * self.world
+
+        def work(r):
+            try:
+                out[r] = fn(r, self.view(r))
+            except BaseException as e:      # noqa: BLE001 -- re-raised below
+                self.errors.append(e)
+                self.barrier.abort()
+
+        th = [threading.Thread(target=work, args=(r,)) for r in range(self.world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if self.errors:
+            raise self.errors[0]
+        return out

@@ -18,18 +18,40 @@ def _stale():
 
 
 def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950: cross-compiles without a GPU (seconds per file)."""
+    """hipcc --offload-arch=gfx950: cross-compiles without a GPU.  Every source becomes its own object (recompiled only when
+    it or a header changed, all stale ones in parallel), then one link."""
     if not force and not _stale():
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", "-Wno-unused-value",
-           ] + (["-DGLIO_DEV_STAMPS"] if os.environ.get("GLIO_DEV_STAMPS") == "1" else []) + os.environ.get("GLIO_EXTRA_DEFS", "").split() + srcs + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    objdir = os.path.join(os.path.dirname(LIB), "obj")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value"] + \
+        (["-DGLIO_DEV_STAMPS"] if os.environ.get("GLIO_DEV_STAMPS") == "1" else []) + os.environ.get("GLIO_EXTRA_DEFS", "").split()
+    tag = os.path.join(objdir, "flags.txt")
+    flag_str = " ".join(flags)
+    if not os.path.exists(tag) or open(tag).read() != flag_str:
+        force = True
+    hdr_t = max(os.path.getmtime(h) for h in HEADERS)
+    jobs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        if not os.path.exists(src):
+            continue
+        obj = os.path.join(objdir, s.replace(".hip", ".o"))
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            jobs.append(["hipcc"] + flags + ["-c", src, "-o", obj])
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    open(tag, "w").write(flag_str)
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    print(build(force="--force" in __import__("sys").argv, verbose=True))

@@ -59,10 +59,12 @@ __device__ __forceinline__ double butterfly64(const double (&in)[64], int lane, 
 __global__ __launch_bounds__(256) void k_batch_pairs(const float4* __restrict__ cp, const double* __restrict__ nc,
                                                      const double* __restrict__ score, const int* __restrict__ pair_i,
                                                      const int* __restrict__ pair_j, const long long* __restrict__ pair_off,
-                                                     const int n_pairs, const double* __restrict__ poses, double* __restrict__ rec) {
+                                                     const int n_pairs, const double* __restrict__ poses0, double* __restrict__ rec,
+                                                     const BtSel sel, const double* __restrict__ poses1, double* __restrict__ cost_dense) {
     const int lane = threadIdx.x & 63;
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (p >= n_pairs) return;
+    if (p >= n_pairs || bt_skip(sel)) return;
+    const double* poses = bt_pick(sel) ? poses1 : poses0;
     const int a = pair_i[p], b = pair_j[p];
     double R1[9], R2[9], t1[3], t2[3];
     d_q2R(poses + 7 * (size_t)a + 3, R1);
@@ -104,13 +106,20 @@ __global__ __launch_bounds__(256) void k_batch_pairs(const float4* __restrict__ 
     int k;
     const double tot = butterfly64(acc, lane, &k);
     if (k < 55) rec[(size_t)p * BP_REC + k] = tot;
+    if (k == 54) cost_dense[p] = tot;          // the costs once more, densely: what k_batch_cost sums
 }
 
 // block-banded assembly: thread per entry of Hg = [H band K*(band+1)*36 | g K*6 | cost]
 __global__ void k_batch_assemble(const double* __restrict__ rec, const int* __restrict__ pair_index, const int K, const int band,
-                                 const int n_pairs, double* __restrict__ Hg) {
+                                 const int n_pairs, double* __restrict__ Hg0, const BtSel sel, double* __restrict__ Hg1, const int k0, const int k1) {
+    if (bt_skip(sel)) return;
+    double* Hg = bt_pick(sel) ? Hg1 : Hg0;
     const long long nH = (long long)K * (band + 1) * 36, nG = (long long)K * 6;
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // rows [k0, k1) only: thread t -> entry t of the rows' H part, then of their g part
+    const long long t_ = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nHr = (long long)(k1 - k0) * (band + 1) * 36, nGr = (long long)(k1 - k0) * 6;
+    if (t_ >= nHr + nGr) return;
+    const long long e = t_ < nHr ? (long long)k0 * (band + 1) * 36 + t_ : nH + (long long)k0 * 6 + (t_ - nHr);
     const int A[6] = {0, 1, 2, 3, 4, 5}, B[6] = {0, 1, 2, 6, 7, 8};
     const double sB[6] = {-1, -1, -1, 1, 1, 1};
     const int wdt = 2 * band + 1;
@@ -145,14 +154,16 @@ __global__ void k_batch_assemble(const double* __restrict__ rec, const int* __re
         Hg[e] = s;
     }
 }
-__global__ __launch_bounds__(256) void k_batch_cost(const double* __restrict__ rec, int n_pairs, double* out) {
-    __shared__ double red[4];
+__global__ __launch_bounds__(1024) void k_batch_cost(const double* __restrict__ cost_dense, int n_pairs, double* out0, const BtSel sel, double* out1) {
+    __shared__ double red[16];
+    if (bt_skip(sel)) return;
+    double* out = bt_pick(sel) ? out1 : out0;
     double s = 0;
-    for (int p = threadIdx.x; p < n_pairs; p += 256) s += rec[(size_t)p * BP_REC + 54];
+    for (int p = threadIdx.x; p < n_pairs; p += 1024) s += cost_dense[p];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) *out = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) { double t = 0; for (int w = 0; w < 16; ++w) t += red[w]; *out = t; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -469,7 +480,7 @@ int glio_batch_create(int device, int K, int band, int64_t max_constraints, glio
     GLIO_HIP_CHECK(hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
     b->stream = b->own_stream;
     BALLOC(b->d_pair_i, b->max_pairs * 4); BALLOC(b->d_pair_j, b->max_pairs * 4); BALLOC(b->d_pair_off, (size_t)(b->max_pairs + 1) * 8);
-    BALLOC(b->d_pair_rec, (size_t)b->max_pairs * BP_REC * 8);
+    BALLOC(b->d_pair_rec, (size_t)b->max_pairs * (BP_REC + 1) * 8);
     BALLOC(b->d_pair_index, (size_t)K * (2 * band + 1) * 4);
     BALLOC(b->d_poses, (size_t)K * 7 * 8); BALLOC(b->d_newposes, (size_t)K * 7 * 8);
     BALLOC(b->d_M, (size_t)K * (band + 1) * 36 * 8); BALLOC(b->d_y, (size_t)K * 6 * 8); BALLOC(b->d_delta, (size_t)K * 6 * 8);
@@ -599,15 +610,25 @@ int glio_batch_set_constraints(glio_batch* b, int64_t n, const int32_t* ci, cons
 
 static void enqueue_batch_linearize(glio_batch* b, double* Hg_dev);
 extern "C++" void glio_batch_enqueue_linearize(glio_batch* b, double* Hg_dev) { enqueue_batch_linearize(b, Hg_dev); }
-static void enqueue_batch_linearize(glio_batch* b, double* Hg_dev) {
+static void enqueue_batch_linearize_sel(glio_batch* b, const BtSel& sel, const double* poses0, const double* poses1, double* Hg0, double* Hg1, int k0, int k1) {
     const int K = b->K, band = b->band;
     const long long nH = (long long)K * (band + 1) * 36, total = nH + (long long)K * 6;
+    double* cost_dense = b->d_pair_rec + (size_t)b->max_pairs * BP_REC;
     if (b->n_pairs > 0)
         hipLaunchKernelGGL(k_batch_pairs, dim3((b->n_pairs + 3) / 4), dim3(256), 0, b->stream, b->cp, b->nc, b->score, b->d_pair_i, b->d_pair_j,
-                           b->d_pair_off, b->n_pairs, b->d_poses, b->d_pair_rec);
-    hipLaunchKernelGGL(k_batch_assemble, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, b->stream, b->d_pair_rec, b->d_pair_index, K, band,
-                       b->n_pairs, Hg_dev);
-    hipLaunchKernelGGL(k_batch_cost, dim3(1), dim3(256), 0, b->stream, b->d_pair_rec, b->n_pairs, Hg_dev + total);
+                           b->d_pair_off, b->n_pairs, poses0, b->d_pair_rec, sel, poses1, cost_dense);
+    const long long rows = (long long)(k1 - k0) * ((band + 1) * 36 + 6);
+    if (rows > 0)
+        hipLaunchKernelGGL(k_batch_assemble, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, b->stream, b->d_pair_rec, b->d_pair_index, K, band,
+                           b->n_pairs, Hg0, sel, Hg1, k0, k1);
+    hipLaunchKernelGGL(k_batch_cost, dim3(1), dim3(1024), 0, b->stream, cost_dense, b->n_pairs, Hg0 + total, sel, Hg1 ? Hg1 + total : nullptr);
+}
+extern "C++" void glio_batch_enqueue_linearize_sel(glio_batch* b, const BtSel& sel, const double* poses0, const double* poses1, double* Hg0, double* Hg1, int k0, int k1) {
+    enqueue_batch_linearize_sel(b, sel, poses0, poses1, Hg0, Hg1, k0, k1);
+}
+static void enqueue_batch_linearize(glio_batch* b, double* Hg_dev) {
+    BtSel sel; sel.cur = nullptr; sel.skip = nullptr; sel.want = 0;
+    enqueue_batch_linearize_sel(b, sel, b->d_poses, b->d_poses, Hg_dev, Hg_dev, 0, b->K);
 }
 
 int glio_batch_linearize_dev(glio_batch* b, const double* poses, double* Hg_dev) {

@@ -1,140 +1,158 @@
-// batch_solve_kernels.hip -- the damped block-banded solve of the batch stage by BLOCK CYCLIC REDUCTION, parallel over the
-// chip, replacing the one-workgroup sequential banded Cholesky (k_batch_factor + k_batch_backsolve, 6.5 ms at K = 2000)
-// on the critical path of every iteration of the sharded stage (Estimator::optimizeBatchWithLandMark's normal equations,
-// reference GLIO/src/Estimator.cpp:3004-3076,3275-3284: there Ceres' SPARSE_NORMAL_CHOLESKY).
+// batch_solve_kernels.hip -- the damped block-banded solve of the batch problem by BLOCK CYCLIC REDUCTION, parallel over the
+// chip and -- round 3 -- over the RANKS of the sharded stage (Estimator::optimizeBatchWithLandMark's normal equations,
+// reference GLIO/src/Estimator.cpp:3004-3076,3275-3284: there Ceres' SPARSE_NORMAL_CHOLESKY on one thread).
 //
-// The K keyframes (6 unknowns each, half band `band` keyframes) are grouped into S = ceil(K / sb) SUPER-BLOCKS of
-// sb = M / 6 >= band keyframes (M = 36 for band <= 6, 72 for band <= 12): in that blocking the matrix is block
-// TRIDIAGONAL with dense M x M blocks.  Odd-even (nested-dissection) elimination: a level eliminates every other active
-// node -- all of them at once, one workgroup each -- then the kept nodes take their Schur updates and become the next
-// level's chain; ceil(log2 S) + 1 levels.  It is an exact Cholesky in the nested-dissection order (no pivoting, SPD), so the
-// result equals the banded factorisation's up to rounding.
+// Unknowns: B per keyframe (6: pose only; 15: pose + speed/bias with the ImuFactor chain, Estimator.cpp:2809-2819,2990-3001).
+// The K keyframes are grouped into S = ceil(K / sbk) SUPER-BLOCKS of sbk >= band keyframes (M = sbk B unknowns: 36 / 72 for the
+// pose problem with band <= 6 / 12, 90 with the IMU chain): in that blocking the matrix is block TRIDIAGONAL with dense M x M
+// blocks.  Odd-even (nested-dissection) elimination: a level eliminates every other active node -- all at once, one workgroup
+// each -- then the kept nodes take their Schur updates; ceil(log2 S) + 1 levels.  Exact Cholesky in that order (SPD, no pivoting).
 //
-//   k_bcr_init    super-blocks D_s, couplings C_s = A[s+1][s] and right-hand sides from the band buffer [H | g] (+ damping)
+// Sharded (world > 1): rank r owns the super-blocks [S r / world, S (r+1) / world); its LAST super-block is a SEPARATOR (ranks
+// 0 .. world-2).  A rank eliminates its interior super-blocks with the separators at either end pinned: what remains are Schur
+// updates of the (at most two) adjacent separators and the coupling between them -- written into `sepbuf`, which the caller
+// all-reduces (every rank then holds the same (world-1)-node separator system, ~ 3 (world-1) M^2 doubles), every rank solves
+// that small chain redundantly (same kernels, "top" schedule) and substitutes back through its own levels.  One collective
+// per solve, no other exchange.  world = 1 is the same code with no separators and no collective.
+//
+//   k_bcr_init    super-blocks D_s, couplings A[s+1][s] and right-hand sides of the OWNED rows from the operator
+//                 S (H_pose_band + H_imu_chain) S + shift, S g    (scaling and shift applied on the fly, no scaled copy)
 //   k_bcr_elim    node p with active neighbours a < p < b: the (3M+1) x M panel [A_pp; A_ap; A_bp; y_p^T] one row per lane,
-//                 factored in M register steps (pivot and multipliers through LDS): L_p, U_a = A_ap L^-T, U_b = A_bp L^-T,
-//                 w = L^-1 y_p
-//   k_bcr_update  kept node q: A_qq -= U U^T of its eliminated neighbours, y_q -= U w, and the new coupling
-//                 A[b][a] = -U_b U_a^T of the node eliminated to its right
-//   k_bcr_back    z_p = L^-T (w - U_a^T z_a - U_b^T z_b), last level first
+//                 factored in M register steps with ONE workgroup barrier each (double-buffered column through LDS)
+//   k_bcr_update  kept node q: A_qq -= U U^T of its eliminated neighbours, y_q -= U w, new coupling A[b][a] = -U_b U_a^T
+//                 (3 x 3 register tiles over LDS-staged factors)
+//   k_bcr_back    z_p = L^-T (w - U_a^T z_a - U_b^T z_b): the triangular solve inside one wavefront (no barriers)
 // Every sum has a fixed order: two runs are bit-identical.
+#include <algorithm>
+#include <cstring>
 #include <vector>
 
-#include "glio_device.h"
+#include "batch_device.h"
 
-#define BCR_THREADS 256
-
-struct BcrElim { int node, a, b, ea, eb; };          // active neighbours (-1: none), edges A[node][a] (= C[ea], rows node) and A[b][node] (= C[eb])
-struct BcrKept { int node, pl, pr, enew, pad_; };    // eliminated neighbours to the left / right (-1: none), the new edge A[b(pr)][node] or -1
+struct BcrElim { int node, a, b, pad_; long long oD, oCa, oCb, oy; };   // blocks in the workspace; a / b: neighbour nodes (-1: none)
+struct BcrKept { int node, pl, pr, pad_; long long oD, oy, oCnew; };    // eliminated neighbours left / right (-1), new edge (-1: none)
+struct BcrInit { int sblock, pad_; long long oD, oy, oC; };             // global super-block; where D, y, A[sblock+1][sblock] go (-1: not wanted)
 
 struct BcrDev {
-    int M, sb, S, K, band, levels;
-    double* D;            // [S][M*M] row-major, symmetric (both triangles kept)
-    double* C;            // [2 S][M*M]  edge e: A[hi][lo], rows hi
-    double* y;            // [S][M]
-    double* z;            // [S][M]
-    double* L;            // [S][M*M] lower
-    double* Ua; double* Ub;   // [S][M*M] rows = unknowns of the neighbour
-    double* w;            // [S][M]
-    BcrElim* elim; BcrKept* kept;
-    std::vector<int> h_elim_off, h_kept_off;       // per level [levels + 1]
+    int M, sbk, S, K, band, B, rank, world;
+    int Slo, Shi, nint, NS, nnode;           // owned super-blocks, interior nodes, separators, nodes with factors (nint + NS)
+    int levels_loc, levels_top;
+    double* ws;              // D / C / y blocks of the interior nodes and local edges, then sepbuf
+    long long ws_doubles, sep_off, sep_doubles;   // sepbuf = [Dsep NS M^2 | Csep (NS-1) M^2 | ysep NS M | 16 extra scalars]
+    double* L; double* Ua; double* Ub;       // [nnode][M*M]
+    double* w; double* z;                    // [nnode][M]
+    BcrElim* elim; BcrKept* kept; BcrInit* init;
+    int n_init;
+    std::vector<int> h_elim_off, h_kept_off;       // per level [levels_loc + levels_top + 1]
+    std::vector<int> node_of_sblock;               // owned super-block (global index - Slo) -> node id
+    int* node_of_sblock_dev;
     int* fail;
 };
 
-// ------------------------------------------------------------------------------------------------ init
-__global__ __launch_bounds__(BCR_THREADS) void k_bcr_init(const double* __restrict__ Hg, const int K, const int band, const double lambda,
-                                                          const double* __restrict__ dadd, const int M, const int sb, const int S, double* __restrict__ D,
-                                                          double* __restrict__ C, double* __restrict__ y) {
-    const int s = blockIdx.x, bw = band + 1;
-    const long long nH = (long long)K * bw * 36;
-    // H(ka, kb)[r][c] for |ka - kb| <= band from the upper band storage
-    auto Hent = [&](const int ka, const int r, const int kb, const int c) -> double {
-        if (ka >= K || kb >= K) return (ka == kb && r == c) ? 1.0 : 0.0;          // padding keyframes of the last super-block: identity
-        const int d = kb - ka;
-        if (d > band || d < -band) return 0.0;
-        if (d >= 0) return Hg[((size_t)ka * bw + d) * 36 + r * 6 + c];
-        return Hg[((size_t)kb * bw + (-d)) * 36 + c * 6 + r];
-    };
-    for (int e = threadIdx.x; e < M * M; e += BCR_THREADS) {
+// ------------------------------------------------------------------------------------------------ the operator (HView / h_entry: batch_device.h)
+__device__ __forceinline__ HView bcr_view(const BcrOp& op, const int K, const int band, const int B) {
+    const int cur = op.cur ? *op.cur : 0;
+    HView v;
+    v.Hg = op.Hg[cur]; v.imu = op.imu[cur]; v.K = K; v.band = band; v.B = B;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_bcr_init(const BcrOp op, const BcrInit* __restrict__ tab, const int K, const int band, const int B, const int M,
+                                                  const int sbk, double* __restrict__ ws) {
+    if (op.skip && *op.skip) return;
+    const BcrInit t = tab[blockIdx.x];
+    const HView v = bcr_view(op, K, band, B);
+    const int cur = op.cur ? *op.cur : 0;
+    const double* gsrc = op.gfull[cur];
+    const int s = t.sblock;
+    for (int e = threadIdx.x; e < M * M; e += 256) {
         const int i = e / M, j = e - M * i;
-        const int ka = s * sb + i / 6, r = i % 6, kb = s * sb + j / 6, c = j % 6;
-        double v = Hent(ka, r, kb, c);
-        if (i == j && ka < K) v += dadd ? dadd[(size_t)ka * 6 + r] : lambda * v + 1e-12;
-        D[(size_t)s * M * M + e] = v;
-        if (s + 1 < S) {        // C_s = A[s+1][s]: rows in super-block s+1, columns in s
-            const int kr = (s + 1) * sb + i / 6;
-            C[(size_t)s * M * M + e] = (kr < K && kb < K) ? Hent(kr, r, kb, c) : 0.0;
+        const int ka = s * sbk + i / B, r = i % B, kb = s * sbk + j / B, c = j % B;
+        if (t.oD >= 0) {
+            double x = h_entry(v, ka, r, kb, c);
+            if (ka < K && kb < K && op.sc) x *= op.sc[(size_t)ka * B + r] * op.sc[(size_t)kb * B + c];
+            if (i == j && ka < K) x += op.dadd ? op.dadd[(size_t)ka * B + r] : op.lambda * x + 1e-12;
+            ws[t.oD + e] = x;
+        }
+        if (t.oC >= 0) {          // A[s+1][s]: rows in super-block s+1, columns in s
+            const int kr = (s + 1) * sbk + i / B;
+            double x = 0.0;
+            if (kr < K && kb < K) {
+                x = h_entry(v, kr, r, kb, c);
+                if (op.sc) x *= op.sc[(size_t)kr * B + r] * op.sc[(size_t)kb * B + c];
+            }
+            ws[t.oC + e] = x;
         }
     }
-    for (int i = threadIdx.x; i < M; i += BCR_THREADS) {
-        const int k = s * sb + i / 6;
-        y[(size_t)s * M + i] = k < K ? Hg[nH + (size_t)k * 6 + i % 6] : 0.0;
-    }
+    if (t.oy >= 0)
+        for (int i = threadIdx.x; i < M; i += 256) {
+            const int k = s * sbk + i / B, r = i % B;
+            double x = 0.0;
+            if (k < K) {
+                x = gsrc ? gsrc[(size_t)k * B + r] : v.Hg[(size_t)K * (band + 1) * 36 + (size_t)k * 6 + r];
+                if (op.sc) x *= op.sc[(size_t)k * B + r];
+            }
+            ws[t.oy + i] = x;
+        }
 }
 
 // ------------------------------------------------------------------------------------------------ elimination
+template <int M> struct BcrCfg { static constexpr int ROWS = 3 * M + 1; static constexpr int THREADS = ((ROWS + 63) / 64) * 64; };
+
 template <int M>
-__global__ __launch_bounds__(BCR_THREADS) void k_bcr_elim(const BcrElim* __restrict__ tab, const double* __restrict__ D, const double* __restrict__ C,
-                                                          const double* __restrict__ y, double* __restrict__ L, double* __restrict__ Ua,
-                                                          double* __restrict__ Ub, double* __restrict__ w, int* fail) {
-    __shared__ double colbuf[M];
-    __shared__ double s_rd;
+__global__ __launch_bounds__(BcrCfg<M>::THREADS) void k_bcr_elim(const int* skip, const BcrElim* __restrict__ tab, const double* __restrict__ ws,
+                                                                 double* __restrict__ L, double* __restrict__ Ua, double* __restrict__ Ub,
+                                                                 double* __restrict__ w, int* fail) {
+    if (skip && *skip) return;
+    __shared__ double col[2][M];
     __shared__ int s_bad;
     const BcrElim t = tab[blockIdx.x];
-    const int tid = threadIdx.x;
-    constexpr int ROWS = 3 * M + 1;
-    static_assert(ROWS <= BCR_THREADS, "one panel row per thread");
+    const int row = threadIdx.x;
     const size_t MM = (size_t)M * M;
-    // ---- the panel row of this thread
     double a[M];
-    const int row = tid;
-    if (tid == 0) s_bad = 0;
-    {
-        const bool hasA = t.a >= 0, hasB = t.b >= 0;
+    if (row == 0) s_bad = 0;
 #pragma unroll
-        for (int c = 0; c < M; ++c) a[c] = 0.0;
-        if (row < M) {
-            const double* src = D + (size_t)t.node * MM + (size_t)row * M;
+    for (int c = 0; c < M; ++c) a[c] = 0.0;
+    if (row < M) {
+        const double* src = ws + t.oD + (size_t)row * M;
 #pragma unroll
-            for (int c = 0; c < M; ++c) a[c] = src[c];
-        } else if (row < 2 * M) {             // row r of A[a][node] = column r of C[ea] (rows node, columns a)
-            if (hasA) {
-                const double* src = C + (size_t)t.ea * MM + (row - M);
+        for (int c = 0; c < M; ++c) a[c] = src[c];
+    } else if (row < 2 * M) {             // row r of A[a][node] = column r of A[node][a]
+        if (t.a >= 0) {
+            const double* src = ws + t.oCa + (row - M);
 #pragma unroll
-                for (int c = 0; c < M; ++c) a[c] = src[(size_t)c * M];
-            }
-        } else if (row < 3 * M) {             // row r of A[b][node] = row r of C[eb]
-            if (hasB) {
-                const double* src = C + (size_t)t.eb * MM + (size_t)(row - 2 * M) * M;
-#pragma unroll
-                for (int c = 0; c < M; ++c) a[c] = src[c];
-            }
-        } else if (row == 3 * M) {
-            const double* src = y + (size_t)t.node * M;
+            for (int c = 0; c < M; ++c) a[c] = src[(size_t)c * M];
+        }
+    } else if (row < 3 * M) {             // row r of A[b][node]
+        if (t.b >= 0) {
+            const double* src = ws + t.oCb + (size_t)(row - 2 * M) * M;
 #pragma unroll
             for (int c = 0; c < M; ++c) a[c] = src[c];
+        }
+    } else if (row == 3 * M) {
+        const double* src = ws + t.oy;
+#pragma unroll
+        for (int c = 0; c < M; ++c) a[c] = src[c];
+    }
+    // M register steps, one barrier each: the (unscaled) column j of the diagonal block goes through a double-buffered LDS row
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        if (row >= j && row < M) col[j & 1][row] = a[j];
+        __syncthreads();
+        const double piv = col[j & 1][j];
+        double rd;
+        if (!(piv > 0.0) || !isfinite(piv)) { rd = 1.0; if (row == j) s_bad = 1; } else rd = rsqrt(piv);
+        if (row >= j) {
+            const double lj = a[j] * rd;
+            a[j] = lj;
+            if (row > j) {
+#pragma unroll
+                for (int c = j + 1; c < M; ++c) a[c] -= lj * (col[j & 1][c] * rd);
+            }
         }
     }
     __syncthreads();
-    // ---- M register steps; the pivot's reciprocal root and the multipliers L[c][j] go through LDS
-#pragma unroll
-    for (int j = 0; j < M; ++j) {
-        if (row == j) {
-            const double piv = a[j];
-            if (!(piv > 0.0) || !isfinite(piv)) { s_bad = 1; s_rd = 1.0; } else s_rd = rsqrt(piv);
-        }
-        __syncthreads();
-        const double rd = s_rd;
-        a[j] = (row == j) ? a[j] * rd : a[j] * rd;          // L[row][j] (row j: sqrt(piv))
-        if (row > j && row < M) colbuf[row] = a[j];
-        __syncthreads();
-        if (row > j) {
-#pragma unroll
-            for (int c = j + 1; c < M; ++c) a[c] -= a[j] * colbuf[c];
-        }
-    }
-    if (tid == 0 && s_bad) atomicOr(fail, 1);
-    // ---- store: L (lower, zeros above), U_a, U_b row-major, w
+    if (row == 0 && s_bad) atomicOr(fail, 1);
     if (row < M) {
         double* dst = L + (size_t)t.node * MM + (size_t)row * M;
 #pragma unroll
@@ -155,48 +173,72 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_elim(const BcrElim* __restr
 }
 
 // ------------------------------------------------------------------------------------------------ Schur updates of the kept nodes
+#define BCR_UP_THREADS 256
+// C (MxM) (+)= sign * X Y^T with X, Y staged in LDS (row stride LD), 3 x 3 register tiles; acc(r, c, value) consumes the products
+template <int M, class F>
+__device__ __forceinline__ void bcr_xyT(const double* __restrict__ X, const double* __restrict__ Y, const int tid, F&& acc) {
+    constexpr int LD = M + 1, T = M / 3;
+    for (int tile = tid; tile < T * T; tile += BCR_UP_THREADS) {
+        const int r0 = (tile / T) * 3, c0 = (tile % T) * 3;
+        double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 6
+        for (int k = 0; k < M; ++k) {
+            const double x0 = X[r0 * LD + k], x1 = X[(r0 + 1) * LD + k], x2 = X[(r0 + 2) * LD + k];
+            const double y0 = Y[c0 * LD + k], y1 = Y[(c0 + 1) * LD + k], y2 = Y[(c0 + 2) * LD + k];
+            s[0] += x0 * y0; s[1] += x0 * y1; s[2] += x0 * y2;
+            s[3] += x1 * y0; s[4] += x1 * y1; s[5] += x1 * y2;
+            s[6] += x2 * y0; s[7] += x2 * y1; s[8] += x2 * y2;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc(r0 + i, c0 + j, s[i * 3 + j]);
+    }
+}
+
 template <int M>
-__global__ __launch_bounds__(BCR_THREADS) void k_bcr_update(const BcrKept* __restrict__ tab, double* __restrict__ D, double* __restrict__ C,
-                                                            double* __restrict__ y, const double* __restrict__ Ua, const double* __restrict__ Ub,
-                                                            const double* __restrict__ w) {
+__global__ __launch_bounds__(BCR_UP_THREADS) void k_bcr_update(const int* skip, const BcrKept* __restrict__ tab, double* __restrict__ ws,
+                                                               const double* __restrict__ Ua, const double* __restrict__ Ub, const double* __restrict__ w) {
+    if (skip && *skip) return;
+    static_assert(M % 3 == 0, "3 x 3 register tiles");
     extern __shared__ double bcr_lds[];
     constexpr int LD = M + 1;
-    double* X1 = bcr_lds;                 // U_b of the node eliminated to the left  (this node is its right neighbour)
-    double* X2 = X1 + M * LD;             // U_a of the node eliminated to the right (this node is its left neighbour)
-    double* X3 = X2 + M * LD;             // U_b of the node eliminated to the right (for the new coupling)
-    double* w1 = X3 + M * LD;
-    double* w2 = w1 + M;
+    double* XA = bcr_lds;                 // phase 1: U_b of the node eliminated to the left; phase 2: U_a of the node eliminated to the right
+    double* XB = XA + M * LD;             // phase 2: U_b of the node eliminated to the right (for the new coupling)
+    double* wv = XB + M * LD;
     const BcrKept t = tab[blockIdx.x];
     const int tid = threadIdx.x;
     const size_t MM = (size_t)M * M;
-    for (int e = tid; e < M * M; e += BCR_THREADS) {
-        const int r = e / M, c = e - M * r;
-        X1[r * LD + c] = t.pl >= 0 ? Ub[(size_t)t.pl * MM + e] : 0.0;
-        X2[r * LD + c] = t.pr >= 0 ? Ua[(size_t)t.pr * MM + e] : 0.0;
-        X3[r * LD + c] = (t.pr >= 0 && t.enew >= 0) ? Ub[(size_t)t.pr * MM + e] : 0.0;
+    double* Dq = ws + t.oD;
+    double* yq = ws + t.oy;
+    if (t.pl >= 0) {
+        for (int e = tid; e < M * M; e += BCR_UP_THREADS) { const int r = e / M, c = e - M * r; XA[r * LD + c] = Ub[(size_t)t.pl * MM + e]; }
+        for (int k = tid; k < M; k += BCR_UP_THREADS) wv[k] = w[(size_t)t.pl * M + k];
+        __syncthreads();
+        bcr_xyT<M>(XA, XA, tid, [&](int r, int c, double s) { Dq[r * M + c] -= s; });
+        for (int r = tid; r < M; r += BCR_UP_THREADS) { double s = 0; for (int k = 0; k < M; ++k) s += XA[r * LD + k] * wv[k]; yq[r] -= s; }
+        __syncthreads();
     }
-    for (int k = tid; k < M; k += BCR_THREADS) { w1[k] = t.pl >= 0 ? w[(size_t)t.pl * M + k] : 0.0; w2[k] = t.pr >= 0 ? w[(size_t)t.pr * M + k] : 0.0; }
-    __syncthreads();
-    double* Dq = D + (size_t)t.node * MM;
-    for (int e = tid; e < M * M; e += BCR_THREADS) {
-        const int r = e / M, c = e - M * r;
-        double s1 = 0, s2 = 0, s3 = 0;
-#pragma unroll 6
-        for (int k = 0; k < M; ++k) { s1 += X1[r * LD + k] * X1[c * LD + k]; s2 += X2[r * LD + k] * X2[c * LD + k]; s3 += X3[r * LD + k] * X2[c * LD + k]; }
-        Dq[e] = (Dq[e] - s1) - s2;
-        if (t.enew >= 0) C[(size_t)t.enew * MM + e] = -s3;          // A[b][a] = - U_b U_a^T  (rows b, columns a = this node)
-    }
-    for (int r = tid; r < M; r += BCR_THREADS) {
-        double s1 = 0, s2 = 0;
-        for (int k = 0; k < M; ++k) { s1 += X1[r * LD + k] * w1[k]; s2 += X2[r * LD + k] * w2[k]; }
-        y[(size_t)t.node * M + r] = (y[(size_t)t.node * M + r] - s1) - s2;
+    if (t.pr >= 0) {
+        for (int e = tid; e < M * M; e += BCR_UP_THREADS) {
+            const int r = e / M, c = e - M * r;
+            XA[r * LD + c] = Ua[(size_t)t.pr * MM + e];
+            if (t.oCnew >= 0) XB[r * LD + c] = Ub[(size_t)t.pr * MM + e];
+        }
+        for (int k = tid; k < M; k += BCR_UP_THREADS) wv[k] = w[(size_t)t.pr * M + k];
+        __syncthreads();
+        bcr_xyT<M>(XA, XA, tid, [&](int r, int c, double s) { Dq[r * M + c] -= s; });
+        if (t.oCnew >= 0) { double* Cn = ws + t.oCnew; bcr_xyT<M>(XB, XA, tid, [&](int r, int c, double s) { Cn[r * M + c] = -s; }); }   // A[b][a] = -U_b U_a^T
+        for (int r = tid; r < M; r += BCR_UP_THREADS) { double s = 0; for (int k = 0; k < M; ++k) s += XA[r * LD + k] * wv[k]; yq[r] -= s; }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ back substitution
 template <int M>
-__global__ __launch_bounds__(128) void k_bcr_back(const BcrElim* __restrict__ tab, const double* __restrict__ L, const double* __restrict__ Ua,
+__global__ __launch_bounds__(128) void k_bcr_back(const int* skip, const BcrElim* __restrict__ tab, const double* __restrict__ L, const double* __restrict__ Ua,
                                                   const double* __restrict__ Ub, const double* __restrict__ w, double* __restrict__ z) {
+    if (skip && *skip) return;
+    static_assert(M <= 128, "two rows per lane");
     extern __shared__ double bcr_lds[];
     constexpr int LD = M + 1;
     double* Ls = bcr_lds;            // [M][LD]
@@ -210,111 +252,265 @@ __global__ __launch_bounds__(128) void k_bcr_back(const BcrElim* __restrict__ ta
     for (int k = tid; k < M; k += 128) { za[k] = t.a >= 0 ? z[(size_t)t.a * M + k] : 0.0; zb[k] = t.b >= 0 ? z[(size_t)t.b * M + k] : 0.0; }
     __syncthreads();
     if (tid < M) {
-        double v = w[(size_t)t.node * M + tid];
+        const double v = w[(size_t)t.node * M + tid];
         double s1 = 0, s2 = 0;
         if (t.a >= 0) { const double* U = Ua + (size_t)t.node * MM + tid; for (int r = 0; r < M; ++r) s1 += U[(size_t)r * M] * za[r]; }
         if (t.b >= 0) { const double* U = Ub + (size_t)t.node * MM + tid; for (int r = 0; r < M; ++r) s2 += U[(size_t)r * M] * zb[r]; }
         tv[tid] = (v - s1) - s2;
     }
     __syncthreads();
-    // L^T z = t, last unknown first: z_r = t_r / L_rr, then t_k -= L[r][k] z_r for k < r
+    if (tid >= 64) return;
+    // L^T z = t inside wavefront 0, last unknown first; lane l holds t[l] and t[l + 64]; the solved entry travels by v_readlane
+    const int lane = tid;
+    double t0 = lane < M ? tv[lane] : 0.0, t1 = lane + 64 < M ? tv[lane + 64] : 0.0;
     for (int r = M - 1; r >= 0; --r) {
-        if (tid == r) tv[r] = tv[r] / Ls[r * LD + r];
-        __syncthreads();
-        if (tid < r) tv[tid] -= Ls[r * LD + tid] * tv[r];
-        __syncthreads();
+        const double diag = Ls[r * LD + r];
+        const double tr = r >= 64 ? __shfl(t1, r - 64, 64) : __shfl(t0, r, 64);
+        const double zr = tr / diag;
+        if (lane == (r & 63)) { if (r >= 64) t1 = zr; else t0 = zr; }
+        if (lane < r) t0 -= Ls[r * LD + lane] * zr;
+        if (lane + 64 < r) t1 -= Ls[r * LD + lane + 64] * zr;
     }
-    if (tid < M) z[(size_t)t.node * M + tid] = tv[tid];
+    if (lane < M) z[(size_t)t.node * M + lane] = t0;
+    if (lane + 64 < M) z[(size_t)t.node * M + lane + 64] = t1;
 }
 
-__global__ void k_bcr_delta(const double* __restrict__ z, const int K, const int M, const int sb, double* __restrict__ delta) {
+// delta = -z for the OWNED keyframes (the other entries of `delta` are left alone: the sharded caller zeroes them and all-reduces)
+__global__ void k_bcr_delta(const int* skip, const double* __restrict__ z, const int* __restrict__ node_of, const int k0, const int k1, const int Slo, const int B,
+                            const int M, const int sbk, double* __restrict__ delta, int* fail) {
+    if (skip && *skip) return;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= K * 6) return;
-    const int k = e / 6, r = e - 6 * k;
-    delta[e] = -z[(size_t)(k / sb) * M + (k % sb) * 6 + r];
+    if (e >= (k1 - k0) * B) return;
+    const int k = k0 + e / B, r = e % B;
+    const int s = k / sbk;
+    const double v = -z[(size_t)node_of[s - Slo] * M + (k % sbk) * B + r];
+    if (!isfinite(v)) atomicOr(fail, 2);
+    delta[(size_t)k * B + r] = v;
 }
 
-// ------------------------------------------------------------------------------------------------ host
-void* glio_bcr_create(int K, int band) {
-    if (band > 12) return nullptr;                         // wider bands keep the sequential banded kernels
-    BcrDev* b = new BcrDev();
-    b->K = K; b->band = band; b->M = band <= 6 ? 36 : 72; b->sb = b->M / 6; b->S = (K + b->sb - 1) / b->sb;
-    const int S = b->S, M = b->M;
-    const size_t MM = (size_t)M * M;
-    auto A = [](void** p, size_t bytes) { return hipMalloc(p, bytes > 0 ? bytes : 16) == hipSuccess; };
-    bool ok = A((void**)&b->D, S * MM * 8) && A((void**)&b->C, 2 * (size_t)S * MM * 8) && A((void**)&b->y, (size_t)S * M * 8) &&
-              A((void**)&b->z, (size_t)S * M * 8) && A((void**)&b->L, S * MM * 8) && A((void**)&b->Ua, S * MM * 8) && A((void**)&b->Ub, S * MM * 8) &&
-              A((void**)&b->w, (size_t)S * M * 8) && A((void**)&b->fail, 16);
-    // the elimination schedule: active list (chain order), edge between consecutive active nodes
-    std::vector<int> act(S), edge(S > 1 ? S - 1 : 0);
-    for (int s = 0; s < S; ++s) act[s] = s;
-    for (int s = 0; s + 1 < S; ++s) edge[s] = s;
-    int next_edge = S - 1;
-    std::vector<BcrElim> elim; std::vector<BcrKept> kept;
-    b->h_elim_off.push_back(0); b->h_kept_off.push_back(0);
-    while (!act.empty()) {
+// ------------------------------------------------------------------------------------------------ host: schedules
+static void bcr_build_schedule(std::vector<int> act, std::vector<char> pinned, std::vector<long long> edgeC /* between consecutive active nodes */,
+                               const std::vector<long long>& oD, const std::vector<long long>& oy, long long& next_edge_off, const long long MM,
+                               std::vector<BcrElim>& elim, std::vector<BcrKept>& kept, std::vector<int>& elim_off, std::vector<int>& kept_off,
+                               long long* final_edge /* the edge left between two pinned nodes, or -1 */) {
+    // oD / oy are indexed by node id; edgeC[p] = workspace offset of A[act[p+1]][act[p]]
+    for (;;) {
         const int n = (int)act.size();
-        std::vector<int> nact, nedge;
-        const int e0 = (int)elim.size();
-        for (int p = 0; p < n; p += 2) {                   // even positions are eliminated
+        int n_free = 0;
+        for (int p = 0; p < n; ++p) n_free += pinned[p] ? 0 : 1;
+        if (n_free == 0) break;
+        std::vector<char> el(n, 0);
+        { int idx = 0; for (int p = 0; p < n; ++p) if (!pinned[p]) { el[p] = (idx % 2 == 0); ++idx; } }
+        for (int p = 0; p < n; ++p) {
+            if (!el[p]) continue;
             BcrElim t;
-            t.node = act[p]; t.a = p > 0 ? act[p - 1] : -1; t.b = p + 1 < n ? act[p + 1] : -1;
-            t.ea = p > 0 ? edge[p - 1] : -1; t.eb = p + 1 < n ? edge[p] : -1;
+            t.node = act[p]; t.pad_ = 0;
+            t.a = p > 0 ? act[p - 1] : -1; t.b = p + 1 < n ? act[p + 1] : -1;
+            t.oD = oD[act[p]]; t.oy = oy[act[p]];
+            t.oCa = p > 0 ? edgeC[p - 1] : -1; t.oCb = p + 1 < n ? edgeC[p] : -1;
             elim.push_back(t);
         }
-        for (int p = 1; p < n; p += 2) {                   // odd positions are kept
+        std::vector<int> nact; std::vector<char> npin; std::vector<long long> nedge;
+        for (int p = 0; p < n; ++p) {
+            if (el[p]) continue;
             BcrKept t;
-            t.node = act[p]; t.pl = act[p - 1]; t.pr = p + 1 < n ? act[p + 1] : -1; t.pad_ = 0;
-            t.enew = (p + 2 < n) ? next_edge++ : -1;       // new coupling with the next kept node through the node eliminated between them
-            kept.push_back(t);
-            nact.push_back(act[p]);
-            if (t.enew >= 0) nedge.push_back(t.enew);
+            t.node = act[p]; t.pad_ = 0;
+            t.pl = (p > 0 && el[p - 1]) ? act[p - 1] : -1;
+            t.pr = (p + 1 < n && el[p + 1]) ? act[p + 1] : -1;
+            t.oD = oD[act[p]]; t.oy = oy[act[p]];
+            t.oCnew = -1;
+            // the edge to the next kept node
+            long long e_next = -2;        // -2: no next kept node
+            if (p + 1 < n && !el[p + 1]) e_next = edgeC[p];                                  // adjacent kept node: the edge stays
+            else if (p + 2 < n) { t.oCnew = next_edge_off; next_edge_off += MM; e_next = t.oCnew; }   // through the eliminated node between them
+            if (t.pl >= 0 || t.pr >= 0) kept.push_back(t);
+            nact.push_back(act[p]); npin.push_back(pinned[p]);
+            if (e_next != -2) nedge.push_back(e_next);
         }
-        (void)e0;
-        b->h_elim_off.push_back((int)elim.size()); b->h_kept_off.push_back((int)kept.size());
-        act.swap(nact); edge.swap(nedge);
+        elim_off.push_back((int)elim.size()); kept_off.push_back((int)kept.size());
+        act.swap(nact); pinned.swap(npin); edgeC.swap(nedge);
     }
-    b->levels = (int)b->h_elim_off.size() - 1;
-    ok = ok && A((void**)&b->elim, elim.size() * sizeof(BcrElim)) && A((void**)&b->kept, (kept.size() + 1) * sizeof(BcrKept));
+    if (final_edge) *final_edge = (act.size() == 2 && edgeC.size() == 1) ? edgeC[0] : -1;
+}
+
+void* glio_bcr_create2(int K, int band, int B, int rank, int world) {
+    if (band > 12 || (B != 6 && B != 15) || (B == 15 && band > 6) || world < 1 || rank < 0 || rank >= world) return nullptr;
+    BcrDev* b = new BcrDev();
+    b->K = K; b->band = band; b->B = B; b->rank = rank; b->world = world;
+    b->sbk = band <= 6 ? 6 : 12;
+    b->M = b->sbk * B;
+    b->S = (K + b->sbk - 1) / b->sbk;
+    if (b->S < world) { delete b; glio_set_error("batch solver: %d super-blocks cannot be spread over %d ranks", b->S, world); return nullptr; }
+    const int S = b->S, M = b->M;
+    const long long MM = (long long)M * M;
+    b->Slo = (int)((long long)S * rank / world); b->Shi = (int)((long long)S * (rank + 1) / world);
+    b->NS = world - 1;
+    const bool has_sep = rank < world - 1, has_left = rank > 0;
+    const int nown = b->Shi - b->Slo;
+    b->nint = nown - (has_sep ? 1 : 0);
+    b->nnode = b->nint + b->NS;
+    const int nint = b->nint, NS = b->NS;
+    // ---- workspace layout: [D int | y int | local edges ... | sepbuf]
+    std::vector<long long> oD(b->nnode), oy(b->nnode);
+    long long off = 0;
+    for (int i = 0; i < nint; ++i) { oD[i] = off; off += MM; }
+    for (int i = 0; i < nint; ++i) { oy[i] = off; off += M; }
+    // local edge slots: at most 2 per interior node over all levels, plus the original ones
+    const long long edge_base = off;
+    const long long edge_cap = (long long)(2 * nint + 4) * MM;
+    off += edge_cap;
+    b->sep_off = off;
+    const long long oDsep = off; off += (long long)NS * MM;
+    const long long oCsep = off; off += (long long)(NS > 1 ? NS - 1 : 0) * MM;
+    const long long oysep = off; off += (long long)NS * M;
+    off += 16;
+    b->sep_doubles = off - b->sep_off;
+    b->ws_doubles = off;
+    for (int s = 0; s < NS; ++s) { oD[nint + s] = oDsep + (long long)s * MM; oy[nint + s] = oysep + (long long)s * M; }
+    b->node_of_sblock.assign(nown, -1);
+    for (int i = 0; i < nint; ++i) b->node_of_sblock[i] = i;
+    if (has_sep) b->node_of_sblock[nown - 1] = nint + rank;
+    // ---- init tasks (owned super-blocks + the coupling to the left separator) and the local chain
+    std::vector<BcrInit> init;
+    std::vector<int> act; std::vector<char> pinned; std::vector<long long> edgeC;
+    long long next_edge = edge_base;
+    if (has_left) {
+        // A[Slo][Slo-1]: rows of my first super-block, columns of the left separator; where it goes depends on what my first block is
+        BcrInit t; t.sblock = b->Slo - 1; t.pad_ = 0; t.oD = -1; t.oy = -1;
+        if (nint > 0) { t.oC = next_edge; next_edge += MM; }
+        else t.oC = has_sep ? oCsep + (long long)(rank - 1) * MM : -1;          // no interior block: the separators couple directly
+        if (t.oC >= 0) init.push_back(t);
+        act.push_back(nint + rank - 1); pinned.push_back(1);
+        if (nint > 0) edgeC.push_back(t.oC);
+    }
+    for (int i = 0; i < nown; ++i) {
+        const int node = b->node_of_sblock[i];
+        BcrInit t; t.sblock = b->Slo + i; t.pad_ = 0; t.oD = oD[node]; t.oy = oy[node]; t.oC = -1;
+        if (i + 1 < nown) { t.oC = next_edge; next_edge += MM; }
+        init.push_back(t);
+        if (node < nint || has_sep) {
+            act.push_back(node); pinned.push_back(node >= nint ? 1 : 0);
+            if (i + 1 < nown) edgeC.push_back(t.oC);
+        }
+    }
+    b->n_init = (int)init.size();
+    std::vector<BcrElim> elim; std::vector<BcrKept> kept;
+    b->h_elim_off.push_back(0); b->h_kept_off.push_back(0);
+    long long final_edge = -1;
+    // the edge left between the two pinned separators must live in sepbuf (Csep[rank-1]): reserve by building with a scratch edge and
+    // redirecting: simplest is to run the schedule, then patch the kept entry that created it
+    bcr_build_schedule(act, pinned, edgeC, oD, oy, next_edge, MM, elim, kept, b->h_elim_off, b->h_kept_off, &final_edge);
+    b->levels_loc = (int)b->h_elim_off.size() - 1;
+    if (has_left && has_sep && final_edge >= 0 && nint > 0) {
+        const long long want = oCsep + (long long)(rank - 1) * MM;
+        for (BcrKept& t : kept) if (t.oCnew == final_edge) t.oCnew = want;
+        for (BcrElim& t : elim) { if (t.oCa == final_edge) t.oCa = want; if (t.oCb == final_edge) t.oCb = want; }
+    }
+    if (next_edge - edge_base > edge_cap) { delete b; glio_set_error("batch solver: edge workspace exceeded"); return nullptr; }
+    // ---- top schedule: the chain of separators
+    if (NS > 0) {
+        std::vector<int> tact(NS); std::vector<char> tpin(NS, 0); std::vector<long long> tedge;
+        for (int s = 0; s < NS; ++s) tact[s] = nint + s;
+        for (int s = 0; s + 1 < NS; ++s) tedge.push_back(oCsep + (long long)s * MM);
+        // new couplings of the top levels go to private edge slots behind the local ones
+        std::vector<BcrElim> e2; std::vector<BcrKept> k2;
+        long long top_edge = next_edge;
+        const long long need = (long long)(NS + 2) * MM;
+        (void)need;
+        bcr_build_schedule(tact, tpin, tedge, oD, oy, top_edge, MM, elim, kept, b->h_elim_off, b->h_kept_off, nullptr);
+        if (top_edge - edge_base > edge_cap) { delete b; glio_set_error("batch solver: edge workspace exceeded (top)"); return nullptr; }
+    }
+    b->levels_top = (int)b->h_elim_off.size() - 1 - b->levels_loc;
+    auto A = [](void** p, size_t bytes) { return hipMalloc(p, bytes > 0 ? bytes : 16) == hipSuccess; };
+    const size_t nn = (size_t)std::max(b->nnode, 1);
+    bool ok = A((void**)&b->ws, (size_t)b->ws_doubles * 8) && A((void**)&b->L, nn * MM * 8) && A((void**)&b->Ua, nn * MM * 8) && A((void**)&b->Ub, nn * MM * 8) &&
+              A((void**)&b->w, nn * M * 8) && A((void**)&b->z, nn * M * 8) && A((void**)&b->fail, 16) &&
+              A((void**)&b->elim, (elim.size() + 1) * sizeof(BcrElim)) && A((void**)&b->kept, (kept.size() + 1) * sizeof(BcrKept)) &&
+              A((void**)&b->init, (init.size() + 1) * sizeof(BcrInit)) && A((void**)&b->node_of_sblock_dev, (size_t)(nown + 1) * 4);
     if (!ok) { glio_set_error("batch solver: device allocation failed"); return nullptr; }
-    hipMemcpy(b->elim, elim.data(), elim.size() * sizeof(BcrElim), hipMemcpyHostToDevice);
+    hipMemset(b->ws, 0, (size_t)b->ws_doubles * 8);
+    if (!elim.empty()) hipMemcpy(b->elim, elim.data(), elim.size() * sizeof(BcrElim), hipMemcpyHostToDevice);
     if (!kept.empty()) hipMemcpy(b->kept, kept.data(), kept.size() * sizeof(BcrKept), hipMemcpyHostToDevice);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_update<72>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((3 * 72 * 73 + 2 * 72) * 8));
+    if (!init.empty()) hipMemcpy(b->init, init.data(), init.size() * sizeof(BcrInit), hipMemcpyHostToDevice);
+    hipMemcpy(b->node_of_sblock_dev, b->node_of_sblock.data(), (size_t)nown * 4, hipMemcpyHostToDevice);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_update<72>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((2 * 72 * 73 + 72) * 8));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_update<90>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((2 * 90 * 91 + 90) * 8));
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_back<72>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((72 * 73 + 3 * 72) * 8));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_back<90>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((90 * 91 + 3 * 90) * 8));
     (void)hipGetLastError();
     return b;
 }
+void* glio_bcr_create(int K, int band) { return glio_bcr_create2(K, band, 6, 0, 1); }
 
 void glio_bcr_destroy(void* h) {
     BcrDev* b = static_cast<BcrDev*>(h);
     if (!b) return;
-    void* ptrs[] = {b->D, b->C, b->y, b->z, b->L, b->Ua, b->Ub, b->w, b->elim, b->kept, b->fail};
+    void* ptrs[] = {b->ws, b->L, b->Ua, b->Ub, b->w, b->z, b->elim, b->kept, b->init, b->node_of_sblock_dev, b->fail};
     for (void* p : ptrs) if (p) hipFree(p);
     delete b;
 }
 
-// (H + lambda diag H) x = g, delta = -x; everything enqueued on `stream`.  *fail_dev (int) is set non-zero on a non-positive pivot.
-template <int M>
-static void bcr_run(BcrDev* b, const double* Hg, double lambda, const double* dadd, double* delta, hipStream_t stream) {
-    const int S = b->S;
-    hipMemsetAsync(b->fail, 0, 4, stream);
-    hipLaunchKernelGGL(k_bcr_init, dim3(S), dim3(BCR_THREADS), 0, stream, Hg, b->K, b->band, lambda, dadd, M, b->sb, S, b->D, b->C, b->y);
-    const size_t lds_up = (size_t)(3 * M * (M + 1) + 2 * M) * 8, lds_back = (size_t)(M * (M + 1) + 3 * M) * 8;
-    for (int l = 0; l < b->levels; ++l) {
-        const int ne = b->h_elim_off[l + 1] - b->h_elim_off[l], nk = b->h_kept_off[l + 1] - b->h_kept_off[l];
-        if (ne > 0) hipLaunchKernelGGL((k_bcr_elim<M>), dim3(ne), dim3(BCR_THREADS), 0, stream, b->elim + b->h_elim_off[l], b->D, b->C, b->y, b->L, b->Ua, b->Ub, b->w, b->fail);
-        if (nk > 0) hipLaunchKernelGGL((k_bcr_update<M>), dim3(nk), dim3(BCR_THREADS), lds_up, stream, b->kept + b->h_kept_off[l], b->D, b->C, b->y, b->Ua, b->Ub, b->w);
-    }
-    for (int l = b->levels - 1; l >= 0; --l) {
-        const int ne = b->h_elim_off[l + 1] - b->h_elim_off[l];
-        if (ne > 0) hipLaunchKernelGGL((k_bcr_back<M>), dim3(ne), dim3(128), lds_back, stream, b->elim + b->h_elim_off[l], b->L, b->Ua, b->Ub, b->w, b->z);
-    }
-    hipLaunchKernelGGL(k_bcr_delta, dim3((b->K * 6 + 255) / 256), dim3(256), 0, stream, b->z, b->K, M, b->sb, delta);
+void glio_bcr_owned_range(void* h, int* lo, int* hi) {
+    BcrDev* b = static_cast<BcrDev*>(h);
+    *lo = b->Slo * b->sbk; *hi = std::min(b->K, b->Shi * b->sbk);
 }
+double* glio_bcr_sepbuf(void* h, long long* count) {
+    BcrDev* b = static_cast<BcrDev*>(h);
+    *count = b->sep_doubles;
+    return b->ws + b->sep_off;
+}
+int* glio_bcr_fail_flag(void* h) { return static_cast<BcrDev*>(h)->fail; }
+
+template <int M>
+static void bcr_levels(BcrDev* b, const BcrOp& op, int l0, int l1, hipStream_t stream) {
+    const size_t lds_up = (size_t)(2 * M * (M + 1) + M) * 8;
+    for (int l = l0; l < l1; ++l) {
+        const int ne = b->h_elim_off[l + 1] - b->h_elim_off[l], nk = b->h_kept_off[l + 1] - b->h_kept_off[l];
+        if (ne > 0) hipLaunchKernelGGL((k_bcr_elim<M>), dim3(ne), dim3(BcrCfg<M>::THREADS), 0, stream, op.skip, b->elim + b->h_elim_off[l], b->ws, b->L, b->Ua, b->Ub, b->w, b->fail);
+        if (nk > 0) hipLaunchKernelGGL((k_bcr_update<M>), dim3(nk), dim3(BCR_UP_THREADS), lds_up, stream, op.skip, b->kept + b->h_kept_off[l], b->ws, b->Ua, b->Ub, b->w);
+    }
+}
+template <int M>
+static void bcr_back(BcrDev* b, const BcrOp& op, int l0, int l1, hipStream_t stream) {
+    const size_t lds_back = (size_t)(M * (M + 1) + 3 * M) * 8;
+    for (int l = l1 - 1; l >= l0; --l) {
+        const int ne = b->h_elim_off[l + 1] - b->h_elim_off[l];
+        if (ne > 0) hipLaunchKernelGGL((k_bcr_back<M>), dim3(ne), dim3(128), lds_back, stream, op.skip, b->elim + b->h_elim_off[l], b->L, b->Ua, b->Ub, b->w, b->z);
+    }
+}
+#define BCR_DISPATCH(fn, ...) do { if (b->M == 36) fn<36>(__VA_ARGS__); else if (b->M == 72) fn<72>(__VA_ARGS__); else fn<90>(__VA_ARGS__); } while (0)
+
+// phase 1: operator -> blocks, local elimination; afterwards sepbuf holds this rank's share of the separator system (all-reduce it)
+void glio_bcr_enqueue_local(void* h, const BcrOp& op, hipStream_t stream) {
+    BcrDev* b = static_cast<BcrDev*>(h);
+    hipMemsetAsync(b->fail, 0, 4, stream);
+    if (b->sep_doubles > 16) hipMemsetAsync(b->ws + b->sep_off, 0, (size_t)(b->sep_doubles - 16) * 8, stream);      // (the 16 extra scalars belong to the caller)
+    if (b->n_init > 0) hipLaunchKernelGGL(k_bcr_init, dim3(b->n_init), dim3(256), 0, stream, op, b->init, b->K, b->band, b->B, b->M, b->sbk, b->ws);
+    BCR_DISPATCH(bcr_levels, b, op, 0, b->levels_loc, stream);
+}
+// phase 2 (after the all-reduce of sepbuf): the separator chain, then back through the local levels; delta = -z for the owned keyframes
+void glio_bcr_enqueue_finish(void* h, const BcrOp& op, double* delta, hipStream_t stream) {
+    BcrDev* b = static_cast<BcrDev*>(h);
+    const int lt0 = b->levels_loc, lt1 = b->levels_loc + b->levels_top;
+    BCR_DISPATCH(bcr_levels, b, op, lt0, lt1, stream);
+    BCR_DISPATCH(bcr_back, b, op, lt0, lt1, stream);
+    BCR_DISPATCH(bcr_back, b, op, 0, b->levels_loc, stream);
+    int lo, hi;
+    glio_bcr_owned_range(b, &lo, &hi);
+    if (hi > lo) hipLaunchKernelGGL(k_bcr_delta, dim3(((hi - lo) * b->B + 255) / 256), dim3(256), 0, stream, op.skip, b->z, b->node_of_sblock_dev, lo, hi, b->Slo, b->B, b->M,
+                                    b->sbk, delta, b->fail);
+}
+
+// (H + lambda diag H) x = g (dadd: an explicit additive diagonal instead), delta = -x; the one-rank pose problem of the damped
+// Gauss-Newton path (glio_batch_step_dev).  *fail_dev (int) is set non-zero on a non-positive pivot.
 void glio_bcr_solve_shift(void* h, const double* Hg, double lambda, const double* dadd, double* delta, int** fail_dev, hipStream_t stream) {
     BcrDev* b = static_cast<BcrDev*>(h);
-    if (b->M == 36) bcr_run<36>(b, Hg, lambda, dadd, delta, stream); else bcr_run<72>(b, Hg, lambda, dadd, delta, stream);
+    BcrOp op;
+    memset(&op, 0, sizeof op);
+    op.Hg[0] = op.Hg[1] = Hg; op.lambda = lambda; op.dadd = dadd;
+    glio_bcr_enqueue_local(h, op, stream);
+    glio_bcr_enqueue_finish(h, op, delta, stream);
     *fail_dev = b->fail;
 }
 void glio_bcr_solve(void* h, const double* Hg, double lambda, double* delta, int** fail_dev, hipStream_t stream) { glio_bcr_solve_shift(h, Hg, lambda, nullptr, delta, fail_dev, stream); }
-int glio_bcr_levels(void* h) { return static_cast<BcrDev*>(h)->levels; }
+int glio_bcr_levels(void* h) { BcrDev* b = static_cast<BcrDev*>(h); return b->levels_loc + b->levels_top; }

@@ -1,17 +1,30 @@
-// batch_tr_kernels.hip -- the rest of the batch problem on keyframe poses and its trust-region solve, behind the C-ABI:
-//   * the "small" factors that every rank evaluates for itself and adds AFTER the all-reduce of the LiDAR band buffer
-//     (SURVEY 8e): delta_q_factor_auto attitude constraints (reference GLIO/src/Estimator.cpp:2831-2891,
-//     GLIO/include/factors/LidarKeyframeFactor.h:283-303) and dd_psr_factor_20 per GNSS epoch between the bracketing
-//     keyframes, identity weight, station position (:3197-3271, :1899-1911; dd_psr_factor.hpp:25-171) -- one wavefront per
-//     factor, a 121-double record each, summed into the band by a gather in fixed order (no atomics);
-//   * glio_batch_solve_tr: Ceres' trust-region loop as configured at Estimator.cpp:3275-3281 (DOGLEG, non-monotonic steps,
-//     max_num_iter) -- Jacobi scaling, Cauchy point, Gauss-Newton step from the block-cyclic-reduction solver with Ceres'
-//     mu D^2 regularisation, dogleg combination, model cost change, candidate poses: all on the device; the host keeps only
-//     the scalar state machine and calls the caller's all-reduce hook between "linearise my shard" and everything else.
-//     Deviation, stated: TRADITIONAL dogleg in place of SUBSPACE_DOGLEG (the same two-dimensional subspace {gradient,
-//     Gauss-Newton}; Ceres minimises the model over the whole subspace, the dogleg path is a curve in it); the CPU
-//     checker used by the tests restates exactly this.
+// batch_tr_kernels.hip -- the batch problem of Estimator::optimizeBatchWithLandMark beyond its scan-to-multiscan constraints, and its
+// trust-region solve, behind the C-ABI (reference GLIO/src/Estimator.cpp:2739-3410):
+//   * the "small" factors: delta_q_factor_auto attitude constraints (:2831-2891, LidarKeyframeFactor.h:283-303) and dd_psr_factor_20 per
+//     GNSS epoch between the bracketing keyframes (:3197-3271, :1899-1911; dd_psr_factor.hpp:25-171) -- one wavefront per factor, a
+//     121-double record each, summed into the band by a gather in fixed order (no atomics);
+//   * round 3: the IMU chain (:2990-3001, parameter blocks :2809-2819) -- an ImuFactor between consecutive keyframes, 15 unknowns per
+//     keyframe (pose 6 + speed/bias 9); the factor is the sliding window's device code (factor_kernels.hip), one workgroup per edge;
+//   * glio_batch_solve_tr2: ceres::Solve as configured at :3275-3284 -- DOGLEG, SUBSPACE_DOGLEG, non-monotonic steps, max_num_iter --
+//     DEVICE RESIDENT: the trust-region state machine (BtStatus) lives in device memory, every kernel of an iteration reads it and
+//     returns at once when it has nothing to do, the host only feeds kernel groups and watches a progress word in mapped memory
+//     (one stream synchronisation per solve).  Jacobi scaling, Cauchy point, Gauss-Newton step by block cyclic reduction with Ceres'
+//     mu D^2 regularisation, the two-dimensional subspace model (orthonormal basis of {gradient, Gauss-Newton}, B = U^T Hs U by two
+//     matrix-vector products, the quartic of the boundary problem solved by the Aberth iteration on one lane), Ceres' step
+//     evaluator, and the minimum-cost iterate as the result (Ceres copies x to the user's parameters only when its cost is below
+//     every earlier one).
+//   * SHARDED over ranks (glio_batch_set_shard): a rank owns a contiguous range of super-blocks of keyframes: its constraints
+//     (K8), its small factors, its IMU edges, the rows of every matrix-vector product and its part of the elimination tree.
+//     Per iteration the caller's all-reduce hook is called on FIVE small buffers (sizes at 2000 keyframes, 8 ranks, 15 states):
+//       A  the assembly buffer: the band rows within `band` keyframes of a range boundary + the diagonal, the gradient and the
+//          cost as partial sums (0.65 MB)       -- instead of the whole 4.1 MB band
+//       B  the separator system of the block cyclic reduction + the Cauchy curvature (0.85 MB)
+//       C  the Gauss-Newton step, every rank its own keyframes (0.24 MB)
+//       D  three curvature sums of the subspace model (64 B)         E  the model cost change's sums (64 B)
+//     and every rank takes identical decisions from identical numbers.  With one rank no hook is called at all.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -21,24 +34,28 @@
 #define SREC 124           // Haa 36 | Hbb 36 | Hab 36 | ga 6 | gb 6 | cost 1 | pad
 #define TRV_THREADS 256
 
-struct BatchSmall {
-    int n_dq, n_dd, n_fac;
-    int* d_fa; int* d_fb; int* d_ftype; int* d_fidx;      // sorted by ordered pair (a, b)
-    double* d_dq_const; glio_dd_psr* d_dd;
-    int2* d_small_index;       // [K][2 band + 1] (first, count) of the factors with (a = k, b = k + o)
-    double* d_frec;            // [n_fac][SREC]
-    size_t cap_fac, cap_dd;
-    double R_ecef_local[9], anc[3];
-    // trust region
-    double* d_vec;             // 12 vectors of 6 K
-    double* d_Hs;              // scaled copy of the band buffer
-    double* d_hg[2];           // linearisation of the current point / the candidate
-    double* d_x[2];            // poses of the current point / the candidate
-    double* d_red; double* h_red;   // reduction scratch (device, pinned host)
-    double* d_rel;             // R_ecef_local (9) and the anchor (3)
-    int have_scale;
+// Trust-region state machine of the batch solve, in device memory for the whole solve
+struct BtStatus {
+    int done, termination, iteration, successful;
+    int invalid, reuse, cur, first;
+    int skip_solve;            // done || the stored Gauss-Newton / Cauchy data are reused: the solve kernels of this group return
+    int step_pending;          // a candidate has been produced and linearised: the next state machine judges it
+    int solve_failed;          // the factorisation of this group broke down (or gave non-finite numbers)
+    int step_valid;            // the step of this group is usable (solve succeeded, model cost change > 0)
+    int one_dim, n_nonmono, solve_id, group;
+    int copy_min, retry, skip_step, pad1_;   // skip_step: done || this group has no usable step: the step kernels and the candidate's linearisation return
+    double radius, mu, alpha, dogleg_step_norm;
+    double cost, cand_cost, minimum_cost, reference_cost, candidate_cost, acc_ref, acc_cand, user_min_cost, initial_cost;
+    double gg, nn2, gd;        // |g~|^2, |gn|^2, g~ . gn
+    double puu;                // (g~/D)^T Hs (g~/D): the Cauchy curvature
+    double w2;                 // |w2|^2 of the second (unnormalised) basis vector
+    double p11, p12, p22;      // curvature of the subspace basis (u1, w2)
+    double c_g, c_n, c_1, c_2; // step (D-space) = c_g g~ + c_n gn + c_1 u1 + c_2 w2
+    double lin, quad, sd2;     // gs . s, s^T Hs s, |s_D|^2
+    double mcc;
+    double dx2, xn2, cand_grad_max, grad_max;
+    double pad_[4];
 };
-void glio_host_ecef_local(const double anc[3], double yaw, double R[9]);     // capi.hip
 
 // ------------------------------------------------------------------------------------------------ small factors
 __device__ __forceinline__ void bt_plus_jac(const double q[4], double P[12]) {
@@ -63,13 +80,15 @@ __device__ __forceinline__ void bt_qright(const double p[4], double M[16]) {
 }
 
 // one wavefront per factor: nr residuals with local Jacobians Ja, Jb (nr x 6, LDS) -> the record
-__global__ __launch_bounds__(64) void k_small_eval(const int n_fac, const int* __restrict__ fa, const int* __restrict__ fb, const int* __restrict__ ftype,
-                                                   const int* __restrict__ fidx, const double* __restrict__ poses, const double* __restrict__ dq_const,
+__global__ __launch_bounds__(64) void k_small_eval(const BtSel sel, const int n_fac, const int* __restrict__ fa, const int* __restrict__ fb, const int* __restrict__ ftype,
+                                                   const int* __restrict__ fidx, const double* __restrict__ poses0, const double* __restrict__ poses1,
+                                                   const double* __restrict__ dq_const,
                                                    const glio_dd_psr* __restrict__ dd, const double* __restrict__ Rel /* [9] R_ecef_local, [3] anchor */,
                                                    double* __restrict__ frec) {
     __shared__ double Ja[19 * 6], Jb[19 * 6], rr[19], raw[19], Jri[57], Jrj[57];
     const int f = blockIdx.x, lane = threadIdx.x;
-    if (f >= n_fac) return;
+    if (f >= n_fac || bt_skip(sel)) return;
+    const double* poses = bt_pick(sel) ? poses1 : poses0;
     const int a = fa[f], b = fb[f];
     const double* pa = poses + 7 * (size_t)a;
     const double* pb = poses + 7 * (size_t)b;
@@ -172,7 +191,10 @@ __global__ __launch_bounds__(64) void k_small_eval(const int n_fac, const int* _
 }
 
 // adds the factor records into the (reduced) band buffer: one thread per entry, factors in index order
-__global__ void k_small_add(const int K, const int band, const int2* __restrict__ sidx, const double* __restrict__ frec, const int n_fac, double* __restrict__ Hg) {
+__global__ void k_small_add(const BtSel sel, const int K, const int band, const int2* __restrict__ sidx, const double* __restrict__ frec, const int n_fac,
+                            double* __restrict__ Hg0, double* __restrict__ Hg1) {
+    if (bt_skip(sel)) return;
+    double* Hg = bt_pick(sel) ? Hg1 : Hg0;
     const long long nH = (long long)K * (band + 1) * 36, nG = (long long)K * 6;
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int wdt = 2 * band + 1;
@@ -208,8 +230,10 @@ __global__ void k_small_add(const int K, const int band, const int2* __restrict_
     }
 }
 // the cost of the small factors: fixed assignment of factors to threads and a fixed reduction tree (deterministic)
-__global__ __launch_bounds__(256) void k_small_cost(const double* __restrict__ frec, const int n_fac, double* __restrict__ cost) {
+__global__ __launch_bounds__(256) void k_small_cost(const BtSel sel, const double* __restrict__ frec, const int n_fac, double* __restrict__ cost0, double* __restrict__ cost1) {
     __shared__ double red[4];
+    if (bt_skip(sel)) return;
+    double* cost = bt_pick(sel) ? cost1 : cost0;
     double s = 0;
     for (int q = threadIdx.x; q < n_fac; q += 256) s += frec[(size_t)n_fac * SREC + q];           // the dense copy of the records' cost entries (coalesced)
     s = wave_sum(s);
@@ -218,164 +242,730 @@ __global__ __launch_bounds__(256) void k_small_cost(const double* __restrict__ f
     if (threadIdx.x == 0) *cost += (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// ------------------------------------------------------------------------------------------------ trust-region vector kernels
-// vector slots (6 K doubles each)
-enum { V_SC = 0, V_DG, V_GR, V_UU, V_TT, V_GS, V_GN, V_YY, V_ST, V_DL, V_DA, V_HS, V_COUNT };
-#define BV(b, k) ((b)->small->d_vec + (size_t)(k) * 6 * (b)->K)
 
-__device__ __forceinline__ double bt_diagH(const double* Hg, const int band, const int i) { return Hg[((size_t)(i / 6) * (band + 1)) * 36 + (i % 6) * 7]; }
+// ------------------------------------------------------------------------------------------------ trust-region vectors
+// vector slots (n = B K doubles each, every slot starts on its own 128 B line)
+enum { V_SC = 0, V_DG, V_GR, V_UU, V_GS, V_DA, V_GN, V_U1, V_W2, V_X1, V_X2, V_ST, V_SD, V_DL, V_T1, V_T2, V_COUNT };
 
-// scale (first call), D, g_s, g~, u, mu D^2
-__global__ void k_bt_prepare(const double* __restrict__ Hg, const int K, const int band, const int set_scale, const int jacobi, const double mu,
-                             double* __restrict__ sc, double* __restrict__ dg, double* __restrict__ gr, double* __restrict__ uu, double* __restrict__ gs,
-                             double* __restrict__ da) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, n = 6 * K;
-    if (i >= n) return;
-    const double h = bt_diagH(Hg, band, i);
-    if (set_scale) sc[i] = jacobi ? 1.0 / (1.0 + sqrt(h)) : 1.0;
-    const double s = sc[i];
-    double d = s * s * h;
-    d = d < 1e-6 ? 1e-6 : (d > 1e32 ? 1e32 : d);
-    const double D = sqrt(d);
-    const double g = Hg[(size_t)K * (band + 1) * 36 + i];
-    dg[i] = D; gs[i] = s * g; gr[i] = s * g / D; uu[i] = (s * g / D) / D;
-    da[i] = mu * D * D;
+struct BtOpts {        // glio_batch_tr_opts, by value
+    int max_iterations, max_nonmono, jacobi, dogleg_type;
+    double min_radius, min_rel, ftol, gtol, ptol;
+};
+struct BtBufs {        // what most kernels need
+    BtStatus* st;
+    int K, band, B, lo, hi;          // owned keyframes [lo, hi)
+    double* x[2]; double* s[2];      // poses [K][7], speed-bias [K][9] of the current / candidate point
+    double* xmin; double* smin;
+    double* hg[2];                   // pose band (local rows), g6, cost
+    PairBlock* rec[2];               // IMU edge records (null without the chain)
+    double* A[2];                    // replicated after the assembly all-reduce: diag [n] | g [n] | cost
+    double* vec; long long vstride;
+};
+#define BVEC(a, k) ((a).vec + (size_t)(k) * (a).vstride)
+
+__device__ __forceinline__ HView bt_view(const BtBufs& a, const int which) {
+    HView v; v.Hg = a.hg[which]; v.imu = a.rec[which]; v.K = a.K; v.band = a.band; v.B = a.B;
+    return v;
 }
-// Hs = S H S (band layout), rhs and cost copied
-__global__ void k_bt_scale_band(const double* __restrict__ Hg, const int K, const int band, const double* __restrict__ sc, double* __restrict__ Hs) {
-    const long long nH = (long long)K * (band + 1) * 36, tot = nH + 6LL * K + 1;
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= tot) return;
-    if (e < nH) {
-        const int k = (int)(e / ((band + 1) * 36)), rem = (int)(e % ((band + 1) * 36)), d = rem / 36, r = (rem % 36) / 6, c = rem % 6;
-        Hs[e] = (k + d < K) ? sc[6 * k + r] * Hg[e] * sc[6 * (k + d) + c] : 0.0;
-    } else if (e < nH + 6LL * K) { const int i = (int)(e - nH); Hs[e] = sc[i] * Hg[e]; }
-    else Hs[e] = Hg[e];
+
+// ---- assembly buffer: stage = [boundary rows NB x 2 band x (band+1) 36 | diag n | g n | cost | pad]
+struct BtAsm { int NB; int eo0, eo1; long long bnd_doubles; const int* bnd_kf; /* [NB] first keyframe of the next rank */ double* stage; int rank; };
+
+__global__ void k_bt_pack(const BtBufs a, const BtAsm m, const BtSel sel) {
+    if (bt_skip(sel)) return;
+    const int which = bt_pick(sel), K = a.K, band = a.band, B = a.B, n = B * K, bw = band + 1;
+    const double* Hg = a.hg[which];
+    const PairBlock* rec = a.rec[which];
+    const long long nH = (long long)K * bw * 36;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long row_d = (long long)bw * 36, per_b = 2LL * band * row_d;
+    if (t < m.bnd_doubles) {
+        const int j = (int)(t / per_b);
+        const long long r = t - (long long)j * per_b;
+        const int k = m.bnd_kf[j] - band + (int)(r / row_d);
+        m.stage[t] = (k >= 0 && k < K) ? Hg[(size_t)k * row_d + (r % row_d)] : 0.0;
+        return;
+    }
+    const long long i = t - m.bnd_doubles;
+    if (i >= 2LL * n) return;
+    const int isg = i >= n, idx = (int)(isg ? i - n : i), k = idx / B, r = idx % B;
+    double v = 0.0;
+    if (r < 6) v = isg ? Hg[nH + (size_t)k * 6 + r] : Hg[(size_t)k * row_d + r * 7];
+    if (rec) {          // my own IMU edges only: these are partial sums
+        if (k >= m.eo0 && k < m.eo1) v += isg ? rec[k].g[r] : rec[k].H[r * 30 + r];
+        if (k - 1 >= m.eo0 && k - 1 < m.eo1) v += isg ? rec[k - 1].g[15 + r] : rec[k - 1].H[(15 + r) * 30 + 15 + r];
+    }
+    m.stage[m.bnd_doubles + i] = v;
 }
-// y = Hband x (symmetric band, upper blocks stored): one thread per row
-__global__ void k_bt_matvec(const double* __restrict__ Hb, const int K, const int band, const double* __restrict__ x, double* __restrict__ y) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 6 * K) return;
-    const int k = i / 6, r = i % 6, bw = band + 1;
+// the cost of this rank: plane constraints + small factors (in Hg) + its IMU edges
+__global__ __launch_bounds__(256) void k_bt_pack_cost(const BtBufs a, const BtAsm m, const BtSel sel) {
+    __shared__ double red[4];
+    if (bt_skip(sel)) return;
+    const int which = bt_pick(sel), K = a.K, n = a.B * K;
+    const PairBlock* rec = a.rec[which];
     double s = 0;
-    for (int d = 0; d <= band && k + d < K; ++d) {
-        const double* blk = Hb + ((size_t)k * bw + d) * 36 + r * 6;
-        const double* xv = x + 6 * (size_t)(k + d);
-#pragma unroll
-        for (int c = 0; c < 6; ++c) s += blk[c] * xv[c];
-    }
-    for (int d = 1; d <= band && k - d >= 0; ++d) {
-        const double* blk = Hb + ((size_t)(k - d) * bw + d) * 36;          // H(k-d, k): transpose
-        const double* xv = x + 6 * (size_t)(k - d);
-#pragma unroll
-        for (int c = 0; c < 6; ++c) s += blk[c * 6 + r] * xv[c];
-    }
-    y[i] = s;
-}
-// up to four dot products a_k . b_k in one pass: per-workgroup parts, then k_bt_sum adds them in order (deterministic)
-struct DotArgs { const double* a[4]; const double* b[4]; int nd; };
-__global__ __launch_bounds__(TRV_THREADS) void k_bt_dots(const DotArgs da, const int n, double* __restrict__ parts) {
-    __shared__ double red[4][TRV_THREADS / 64];
-    double s[4] = {0, 0, 0, 0};
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) if (k < da.nd) s[k] += da.a[k][i] * da.b[k][i];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { s[k] = wave_sum(s[k]); if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s[k]; }
+    if (rec) for (int e = m.eo0 + threadIdx.x; e < m.eo1; e += 256) s += rec[e].cost;
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x < 4) { double t = 0; for (int w = 0; w < TRV_THREADS / 64; ++w) t += red[threadIdx.x][w]; parts[(size_t)blockIdx.x * 4 + threadIdx.x] = t; }
+    if (threadIdx.x == 0) m.stage[m.bnd_doubles + 2LL * n] = a.hg[which][(size_t)K * (a.band + 1) * 36 + (size_t)K * 6] + ((red[0] + red[1]) + (red[2] + red[3]));
 }
-__global__ void k_bt_sum(const double* __restrict__ parts, const int nb, double* __restrict__ out) {
-    if (threadIdx.x < 4) { double t = 0; for (int b = 0; b < nb; ++b) t += parts[(size_t)b * 4 + threadIdx.x]; out[threadIdx.x] = t; }
+// after the all-reduce: diag | g | cost become the replicated A[which]; the boundary rows next to this rank replace its local ones
+__global__ void k_bt_unpack(const BtBufs a, const BtAsm m, const BtSel sel) {
+    if (bt_skip(sel)) return;
+    const int which = bt_pick(sel), K = a.K, band = a.band, n = a.B * K, bw = band + 1;
+    double* Hg = a.hg[which];
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long row_d = (long long)bw * 36, per_b = 2LL * band * row_d;
+    if (t < m.bnd_doubles) {
+        const int j = (int)(t / per_b);
+        if (j != m.rank && j != m.rank - 1) return;
+        const long long r = t - (long long)j * per_b;
+        const int k = m.bnd_kf[j] - band + (int)(r / row_d);
+        if (k >= 0 && k < K) Hg[(size_t)k * row_d + (r % row_d)] = m.stage[t];
+        return;
+    }
+    const long long i = t - m.bnd_doubles;
+    if (i <= 2LL * n) a.A[which][i] = m.stage[m.bnd_doubles + i];
 }
-// gn = D v with v = -(Hs + mu D^2)^-1 gs as the banded solver returns it; step = ca g~ + cb gn (D-space); step_s = step / D; delta = S step_s
-__global__ void k_bt_gn(const double* __restrict__ dg, const double* __restrict__ v, double* __restrict__ gn, const int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) gn[i] = dg[i] * v[i];
-}
-__global__ void k_bt_step(const double ca, const double cb, const double* __restrict__ gr, const double* __restrict__ gn, const double* __restrict__ dg,
-                          const double* __restrict__ sc, double* __restrict__ st, double* __restrict__ stD, double* __restrict__ dl, const int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double sv = ca * gr[i] + cb * gn[i];
-    stD[i] = sv;                      // D-space step (its norm is the dogleg step norm)
-    st[i] = sv / dg[i];
-    dl[i] = sc[i] * (sv / dg[i]);
-}
-// candidate = x (+) delta;  parts: |x - cand|^2, |x|^2  and the gradient max norm needs | x - Plus(x, -g) |_inf (k_bt_gradmax)
-__global__ void k_bt_plus(const double* __restrict__ x, const double* __restrict__ dl, const int K, double* __restrict__ xo) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K) return;
-    for (int c = 0; c < 3; ++c) xo[7 * k + c] = x[7 * k + c] + dl[6 * k + c];
-    d_quat_plus(x + 7 * k + 3, dl + 6 * k + 3, xo + 7 * k + 3);
-}
-__global__ __launch_bounds__(TRV_THREADS) void k_bt_state_norms(const double* __restrict__ x, const double* __restrict__ xc, const double* __restrict__ g, const int K,
-                                                                double* __restrict__ out /* [0] |x - xc|^2 [1] |x|^2 [2] max |x - Plus(x, -g)| */) {
-    __shared__ double red[3][TRV_THREADS / 64];
+
+// |x - x_c|^2, |x|^2 (all parameter blocks) and the gradient max norm |x_c - Plus(x_c, -g_c)|_inf of the candidate; one workgroup
+__global__ __launch_bounds__(1024) void k_bt_norms(const BtBufs a, const BtSel sel) {
+    __shared__ double red[3][16];
+    if (bt_skip(sel)) return;
+    const int cur = a.st->cur & 1, cand = cur ^ 1, K = a.K, B = a.B, n = B * K;
+    const double* x = a.x[cur]; const double* xc = a.x[cand];
+    const double* s = a.s[cur]; const double* sc = a.s[cand];
+    const double* g = a.A[cand] + n;
     double d2 = 0, x2 = 0, gm = 0;
-    for (int k = threadIdx.x; k < K; k += TRV_THREADS) {
+    for (int k = threadIdx.x; k < K; k += 1024) {
         double nd[3], qn[4];
-        for (int c = 0; c < 7; ++c) { const double a = x[7 * k + c], d = a - xc[7 * k + c]; d2 += d * d; x2 += a * a; }
-        for (int c = 0; c < 3; ++c) { gm = fmax(gm, fabs(g[6 * k + c])); nd[c] = -g[6 * k + 3 + c]; }
-        d_quat_plus(x + 7 * k + 3, nd, qn);
-        for (int c = 0; c < 4; ++c) gm = fmax(gm, fabs(x[7 * k + 3 + c] - qn[c]));
+        for (int c = 0; c < 7; ++c) { const double v = x[7 * k + c], d = v - xc[7 * k + c]; d2 += d * d; x2 += v * v; }
+        for (int c = 0; c < 3; ++c) { gm = fmax(gm, fabs(g[B * k + c])); nd[c] = -g[B * k + 3 + c]; }
+        d_quat_plus(xc + 7 * k + 3, nd, qn);
+        for (int c = 0; c < 4; ++c) gm = fmax(gm, fabs(xc[7 * k + 3 + c] - qn[c]));
+        if (B == 15)
+            for (int c = 0; c < 9; ++c) { const double v = s[9 * k + c], d = v - sc[9 * k + c]; d2 += d * d; x2 += v * v; gm = fmax(gm, fabs(g[B * k + 6 + c])); }
     }
     d2 = wave_sum(d2); x2 = wave_sum(x2);
     for (int off = 32; off > 0; off >>= 1) gm = fmax(gm, __shfl_xor(gm, off, 64));
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = d2; red[1][threadIdx.x >> 6] = x2; red[2][threadIdx.x >> 6] = gm; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double a = 0, b = 0, c = 0;
-        for (int w = 0; w < TRV_THREADS / 64; ++w) { a += red[0][w]; b += red[1][w]; c = fmax(c, red[2][w]); }
-        out[0] = a; out[1] = b; out[2] = c;
+        double p = 0, q = 0, m = 0;
+        for (int w = 0; w < 16; ++w) { p += red[0][w]; q += red[1][w]; m = fmax(m, red[2][w]); }
+        a.st->dx2 = p; a.st->xn2 = q; a.st->cand_grad_max = m; a.st->cand_cost = a.A[cand][2 * n];
+        a.st->step_pending = 1;
     }
+}
+
+// ------------------------------------------------------------------------------------------------ the state machine
+struct BtHost { int* progress; BtStatus* result; };     // mapped host memory
+__global__ __launch_bounds__(256) void k_bt_state_machine(const BtBufs a, const BtOpts o, const BtHost h) {
+    __shared__ int sh_copy, sh_cur;
+    if (threadIdx.x == 0) {
+        BtStatus s = *a.st;
+        sh_copy = 0; sh_cur = s.cur & 1;
+        if (!s.done) {
+            bool retry = false;
+            if (s.first) {
+                s.first = 0; s.cur ^= 1;
+                s.cost = s.cand_cost; s.initial_cost = s.cost;
+                s.minimum_cost = s.reference_cost = s.candidate_cost = s.user_min_cost = s.cost;
+                s.acc_ref = s.acc_cand = 0; s.n_nonmono = 0;
+                s.grad_max = s.cand_grad_max;
+                sh_copy = 1;
+            } else if (s.solve_failed) {
+                s.mu *= 10.0;                                         // ComputeGaussNewtonStep: while (mu < max_mu) { ...; mu *= 10 }
+                if (s.mu < 1.0) retry = true;
+                else { if (++s.invalid >= 5) { s.done = 1; s.termination = GLIO_TERM_FAILURE; } else { s.mu *= 10.0; s.reuse = 0; } }
+            } else if (s.step_pending) {
+                const double ccost = s.cand_cost;
+                if (sqrt(s.dx2) <= o.ptol * (sqrt(s.xn2) + o.ptol)) { s.done = 1; s.termination = GLIO_TERM_PARAMETER_TOL; }
+                else if (fabs(s.cost - ccost) <= o.ftol * s.cost) { s.done = 1; s.termination = GLIO_TERM_FUNCTION_TOL; }
+                else {
+                    const double rel = (s.cost - ccost) / s.mcc, hist = (s.reference_cost - ccost) / (s.acc_ref + s.mcc);
+                    const double quality = o.max_nonmono > 0 ? fmax(rel, hist) : rel;
+                    if (quality > o.min_rel) {
+                        s.cur ^= 1; s.successful += 1;
+                        if (quality < 0.25) s.radius *= 0.5;
+                        if (quality > 0.75) s.radius = fmax(s.radius, 3.0 * s.dogleg_step_norm);
+                        s.mu = fmax(1e-8, 2.0 * s.mu / 10.0);
+                        s.reuse = 0;
+                        s.cost = ccost; s.grad_max = s.cand_grad_max;
+                        s.acc_cand += s.mcc; s.acc_ref += s.mcc;
+                        if (s.cost < s.minimum_cost) { s.minimum_cost = s.cost; s.n_nonmono = 0; s.candidate_cost = s.cost; s.acc_cand = 0; }
+                        else { ++s.n_nonmono; if (s.cost > s.candidate_cost) { s.candidate_cost = s.cost; s.acc_cand = 0; } }
+                        if (s.n_nonmono == o.max_nonmono) { s.reference_cost = s.candidate_cost; s.acc_ref = s.acc_cand; }
+                        if (s.cost < s.user_min_cost) { s.user_min_cost = s.cost; sh_copy = 1; }     // the user's parameters follow the best point only
+                    } else { s.radius *= 0.5; s.reuse = 1; }
+                }
+                s.invalid = 0;
+            } else {                                                  // the model cost change was not positive: an invalid step
+                if (++s.invalid >= 5) { s.done = 1; s.termination = GLIO_TERM_FAILURE; } else { s.mu *= 10.0; s.reuse = 0; }
+            }
+            // FinalizeIterationAndCheckIfMinimizerCanContinue, then the next iteration
+            while (!s.done && !retry) {
+                if (s.iteration >= o.max_iterations) { s.done = 1; s.termination = GLIO_TERM_NO_CONVERGENCE; break; }
+                if (s.grad_max <= o.gtol) { s.done = 1; s.termination = GLIO_TERM_GRADIENT_TOL; break; }
+                if (s.radius <= o.min_radius) { s.done = 1; s.termination = GLIO_TERM_MIN_RADIUS; break; }
+                ++s.iteration;
+                if (s.reuse || s.mu < 1.0) break;
+                // the linear solve cannot even be attempted (mu >= max_mu): this iteration's step is invalid at once
+                if (++s.invalid >= 5) { s.done = 1; s.termination = GLIO_TERM_FAILURE; break; }
+                s.mu *= 10.0; s.reuse = 0;
+            }
+            s.step_pending = 0; s.solve_failed = 0; s.retry = retry ? 1 : 0;
+            s.skip_solve = (s.done || s.reuse) ? 1 : 0;
+            s.step_valid = s.done ? 0 : 1; s.skip_step = s.done ? 1 : 0;
+            s.copy_min = sh_copy;
+            s.group += 1;
+            sh_cur = s.cur & 1;
+            *a.st = s;
+            if (s.done) { *h.result = s; __threadfence_system(); h.progress[1] = s.solve_id; }
+            else { __threadfence_system(); h.progress[0] = (s.solve_id << 16) | (s.group & 0xffff); }
+            __threadfence_system();
+        }
+    }
+    __syncthreads();
+    if (sh_copy) {
+        const double* x = a.x[sh_cur]; const double* sb = a.s[sh_cur];
+        for (int i = threadIdx.x; i < 7 * a.K; i += 256) a.xmin[i] = x[i];
+        if (a.B == 15) for (int i = threadIdx.x; i < 9 * a.K; i += 256) a.smin[i] = sb[i];
+    }
+}
+#define BT_SKIP_SOLVE(a) ((a).st->skip_solve != 0)
+#define BT_SKIP_STEP(a) ((a).st->step_valid == 0)
+
+// scale (first group), D, g_s, g~, u = g~ / D, mu D^2
+__global__ void k_bt_prepare(const BtBufs a, const int jacobi) {
+    if (BT_SKIP_SOLVE(a)) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, n = a.B * a.K;
+    if (i >= n) return;
+    const int cur = a.st->cur & 1;
+    const double h = a.A[cur][i], g = a.A[cur][n + i];
+    double* sc = BVEC(a, V_SC);
+    if (a.st->group == 1 && !a.st->retry) sc[i] = jacobi ? 1.0 / (1.0 + sqrt(h)) : 1.0;
+    const double s = sc[i];
+    double d = s * s * h;
+    d = d < 1e-6 ? 1e-6 : (d > 1e32 ? 1e32 : d);
+    const double D = sqrt(d);
+    BVEC(a, V_DG)[i] = D; BVEC(a, V_GS)[i] = s * g; BVEC(a, V_GR)[i] = s * g / D; BVEC(a, V_UU)[i] = (s * g / D) / D;
+    BVEC(a, V_DA)[i] = a.st->mu * D * D;
+}
+// y = Hs x for the OWNED rows (Hs = S H S on the fly) of up to two vectors; one thread per row
+__global__ void k_bt_matvec(const BtBufs a, const int solve_phase, const int vx0, const int vy0, const int vx1, const int vy1) {
+    if (solve_phase ? BT_SKIP_SOLVE(a) : BT_SKIP_STEP(a)) return;
+    const int B = a.B, K = a.K, band = a.band;
+    const int i = a.lo * B + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.hi * B) return;
+    const int k = i / B, r = i - B * k;
+    const HView v = bt_view(a, a.st->cur & 1);
+    const double* sc = BVEC(a, V_SC);
+    const double* x0 = BVEC(a, vx0);
+    const double* x1 = vx1 >= 0 ? BVEC(a, vx1) : x0;
+    double s0 = 0, s1 = 0;
+    const int kb0 = k - band < 0 ? 0 : k - band, kb1 = k + band >= K ? K - 1 : k + band;
+    for (int kb = kb0; kb <= kb1; ++kb) {
+        const int d = kb - k;
+        const bool near = d >= -1 && d <= 1 && B == 15;
+        if (r >= 6 && !near) continue;
+        const int cmax = near ? B : 6;
+        for (int c = 0; c < cmax; ++c) {
+            const double hv = h_entry(v, k, r, kb, c) * sc[(size_t)kb * B + c];
+            s0 += hv * x0[(size_t)kb * B + c];
+            s1 += hv * x1[(size_t)kb * B + c];
+        }
+    }
+    BVEC(a, vy0)[i] = sc[i] * s0;
+    if (vx1 >= 0) BVEC(a, vy1)[i] = sc[i] * s1;
+}
+// up to six dot products in one pass by ONE workgroup (fixed order: every rank gets the same bits from the same data)
+struct DotJobs { int n; int va[6], vb[6], owned[6]; double* out[6]; };
+__global__ __launch_bounds__(1024) void k_bt_dots(const BtBufs a, const int solve_phase, const DotJobs j) {
+    __shared__ double red[6][16];
+    if (solve_phase ? BT_SKIP_SOLVE(a) : BT_SKIP_STEP(a)) return;
+    const int n = a.B * a.K, o0 = a.lo * a.B, o1 = a.hi * a.B;
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const bool own = i >= o0 && i < o1;
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+            if (q < j.n && (own || !j.owned[q])) s[q] += BVEC(a, j.va[q])[i] * BVEC(a, j.vb[q])[i];
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { s[q] = wave_sum(s[q]); if ((threadIdx.x & 63) == 0) red[q][threadIdx.x >> 6] = s[q]; }
+    __syncthreads();
+    if (threadIdx.x < j.n) { double t = 0; for (int w = 0; w < 16; ++w) t += red[threadIdx.x][w]; *j.out[threadIdx.x] = t; }
+}
+// zero the step buffer outside the owned range and publish the factorisation's failure flag behind it (the buffer is all-reduced)
+__global__ void k_bt_dz_prepare(const BtBufs a, double* dz, const int* fail) {
+    if (BT_SKIP_SOLVE(a)) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, n = a.B * a.K;
+    if (i < n) { if (i < a.lo * a.B || i >= a.hi * a.B) dz[i] = 0.0; }
+    else if (i == n) dz[n] = *fail ? 1.0 : 0.0;
+}
+// gn = D v; a failed factorisation (on any rank) invalidates the group
+__global__ void k_bt_gn(const BtBufs a, const double* __restrict__ dz) {
+    if (BT_SKIP_SOLVE(a)) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, n = a.B * a.K;
+    const bool bad = dz[n] != 0.0;
+    if (i == 0 && bad) { a.st->solve_failed = 1; a.st->step_valid = 0; a.st->skip_step = 1; }
+    if (i < n) BVEC(a, V_GN)[i] = bad ? 0.0 : BVEC(a, V_DG)[i] * dz[i];
+}
+// DoglegStrategy::ComputeSubspaceModel, first half: u1 = the longer of {g~, gn} normalised, w2 = the other one minus its part along u1
+__global__ void k_bt_basis(const BtBufs a, const double* __restrict__ puu_sum) {
+    if (BT_SKIP_SOLVE(a)) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, n = a.B * a.K;
+    const double gg = a.st->gg, nn2 = a.st->nn2, gd = a.st->gd;
+    if (i == 0) { a.st->puu = *puu_sum; a.st->alpha = gg / *puu_sum; }
+    if (i >= n) return;
+    const bool swap = nn2 > gg;
+    const double c0 = swap ? BVEC(a, V_GN)[i] : BVEC(a, V_GR)[i], c1 = swap ? BVEC(a, V_GR)[i] : BVEC(a, V_GN)[i];
+    const double n0 = swap ? nn2 : gg;
+    const double u1 = c0 / sqrt(n0), w2 = c1 - (gd / n0) * c0;
+    const double D = BVEC(a, V_DG)[i];
+    BVEC(a, V_U1)[i] = u1; BVEC(a, V_W2)[i] = w2; BVEC(a, V_X1)[i] = u1 / D; BVEC(a, V_X2)[i] = w2 / D;
+}
+
+// ---- the boundary-constrained two-dimensional problem (DoglegStrategy::FindMinimumOnTrustRegionBoundary)
+struct cplx { double re, im; };
+__device__ __forceinline__ cplx c_mul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ cplx c_div(cplx a, cplx b) { const double d = b.re * b.re + b.im * b.im; return {(a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d}; }
+__device__ __forceinline__ double c_abs(cplx a) { return hypot(a.re, a.im); }
+// real parts of the four roots of c[0] y^4 + ... + c[4] (c[0] > 0) by the Aberth-Ehrlich iteration
+__device__ bool bt_quartic_roots_real(const double* c, double* re) {
+    double m[5];
+    for (int i = 0; i <= 4; ++i) { m[i] = c[i] / c[0]; if (!isfinite(m[i])) return false; }
+    double bound = 0, rad = 0;
+    for (int i = 1; i <= 4; ++i) { bound = fmax(bound, fabs(m[i])); rad = fmax(rad, pow(4.0 * fabs(m[i]), 1.0 / i)); }
+    bound += 1.0;
+    if (!(rad > 0)) { for (int i = 0; i < 4; ++i) re[i] = 0.0; return true; }
+    if (rad > bound) rad = bound;
+    cplx z[4];
+    for (int i = 0; i < 4; ++i) { double sn, cs; sincos(2.0 * M_PI * i / 4 + 0.4, &sn, &cs); z[i] = {rad * cs, rad * sn}; }
+    for (int it = 0; it < 500; ++it) {
+        double move = 0, size = 0;
+        for (int i = 0; i < 4; ++i) {
+            cplx pv = {1.0, 0.0}, dv = {0.0, 0.0};
+            for (int k = 1; k <= 4; ++k) { dv = c_mul(dv, z[i]); dv.re += pv.re; dv.im += pv.im; pv = c_mul(pv, z[i]); pv.re += m[k]; }
+            if (c_abs(pv) == 0.0) continue;
+            cplx s = {0.0, 0.0};
+            for (int j = 0; j < 4; ++j) if (j != i) { const cplx d = {z[i].re - z[j].re, z[i].im - z[j].im}; const cplx q = c_div({1.0, 0.0}, d); s.re += q.re; s.im += q.im; }
+            const cplx nw = c_div(pv, dv);
+            const cplx ns = c_mul(nw, s);
+            const cplx w = c_div(nw, {1.0 - ns.re, -ns.im});
+            if (!isfinite(w.re) || !isfinite(w.im)) continue;
+            z[i].re -= w.re; z[i].im -= w.im;
+            move = fmax(move, c_abs(w)); size = fmax(size, c_abs(z[i]));
+        }
+        if (move <= 1e-15 * size) break;
+    }
+    for (int i = 0; i < 4; ++i) { re[i] = z[i].re; if (!isfinite(re[i])) return false; }
+    return true;
+}
+__device__ bool bt_boundary_minimum(const double b00, const double b01, const double b11, const double g0, const double g1, const double radius, double* m0, double* m1) {
+    const double detB = b00 * b11 - b01 * b01, trB = b00 + b11, r2 = radius * radius;
+    const double ag0 = b11 * g0 - b01 * g1, ag1 = -b01 * g0 + b00 * g1;
+    double poly[5], roots[4];
+    poly[0] = r2;
+    poly[1] = 2.0 * r2 * trB;
+    poly[2] = r2 * (trB * trB + 2.0 * detB) - (g0 * g0 + g1 * g1);
+    poly[3] = -2.0 * ((g0 * ag0 + g1 * ag1) - r2 * detB * trB);
+    poly[4] = r2 * detB * detB - (ag0 * ag0 + ag1 * ag1);
+    if (!bt_quartic_roots_real(poly, roots)) return false;
+    double best = 1.7976931348623157e308;
+    bool found = false;
+    for (int i = 0; i < 4; ++i) {
+        // -(B + y I)^-1 g by a partially pivoted 2x2 LU
+        double a = b00 + roots[i], b = b01, c = b01, d = b11 + roots[i], r0 = g0, r1 = g1;
+        if (fabs(c) > fabs(a)) { double t = a; a = c; c = t; t = b; b = d; d = t; t = r0; r0 = r1; r1 = t; }
+        const double l = c / a, u11 = d - l * b, y1 = r1 - l * r0;
+        const double x1 = -(y1 / u11), x0 = -((r0 - b * (y1 / u11)) / a);
+        const double nx = sqrt(x0 * x0 + x1 * x1);
+        if (nx > 0) {
+            const double s0 = radius / nx * x0, s1 = radius / nx * x1;
+            const double f = 0.5 * (s0 * (b00 * s0 + b01 * s1) + s1 * (b01 * s0 + b11 * s1)) + g0 * s0 + g1 * s1;
+            found = true;
+            if (f < best) { best = f; *m0 = x0; *m1 = x1; }
+        }
+    }
+    return found;
+}
+// curvature of the basis from the all-reduced sums (stage D), then the step coefficients for the present radius
+__global__ void k_bt_dogleg(const BtBufs a, const double* __restrict__ stage_d, const int dogleg_type) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || BT_SKIP_STEP(a)) return;
+    BtStatus& s = *a.st;
+    if (!s.skip_solve) {          // fresh Gauss-Newton / Cauchy data: (re)build the subspace model
+        s.p11 = stage_d[0]; s.p12 = stage_d[1]; s.p22 = stage_d[2];
+        const double n0 = fmax(s.gg, s.nn2);
+        s.one_dim = sqrt(s.w2) <= sqrt(n0) * (2.220446049250313e-16 * 2.0) ? 1 : 0;
+    }
+    const double gg = s.gg, nn2 = s.nn2, gd = s.gd, radius = s.radius, alpha = s.alpha;
+    const double gnorm = sqrt(gg), gnn = sqrt(nn2);
+    double cg = 0, cn = 0, c1 = 0, c2 = 0, norm = -1.0;
+    bool traditional = dogleg_type != GLIO_DOGLEG_SUBSPACE;
+    if (!traditional) {
+        if (gnn <= radius) { cn = 1.0; norm = gnn; }
+        else if (s.one_dim) { cg = -(radius / gnorm); norm = radius; }
+        else {
+            const bool swap = nn2 > gg;
+            const double wn = sqrt(s.w2);
+            // g2 = U^T g~ ; w2 . g~ = (c1 - (gd / n0) c0) . g~
+            const double n0 = swap ? nn2 : gg;
+            const double g0 = (swap ? gd : gg) / sqrt(n0);
+            const double g1 = ((swap ? gg : gd) - (gd / n0) * (swap ? gd : gg)) / wn;
+            double m0 = 0, m1 = 0;
+            if (bt_boundary_minimum(s.p11, s.p12 / wn, s.p22 / s.w2, g0, g1, radius, &m0, &m1)) { c1 = m0; c2 = m1 / wn; norm = radius; }
+            else traditional = true;
+        }
+    }
+    if (traditional) {
+        if (gnn <= radius) { cg = 0; cn = 1.0; norm = gnn; }
+        else if (gnorm * alpha >= radius) { cg = -(radius / gnorm); cn = 0; norm = radius; }
+        else {
+            const double b_dot_a = -alpha * gd, a_sq = alpha * alpha * gg;
+            const double b_minus_a_sq = nn2 - 2 * b_dot_a + a_sq, c = b_dot_a - a_sq;
+            const double d = sqrt(c * c + b_minus_a_sq * (radius * radius - a_sq));
+            const double beta = (c <= 0) ? (d - c) / b_minus_a_sq : (radius * radius - a_sq) / (d + c);
+            cg = -alpha * (1.0 - beta); cn = beta; norm = -1.0;
+        }
+    }
+    s.c_g = cg; s.c_n = cn; s.c_1 = c1; s.c_2 = c2; s.dogleg_step_norm = norm;
+}
+// step in D-space, in the scaled variables, in the parameters; the candidate x (+) delta; one thread per keyframe
+__global__ void k_bt_step(const BtBufs a) {
+    if (BT_SKIP_STEP(a)) return;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, B = a.B;
+    if (k >= a.K) return;
+    const BtStatus& s = *a.st;
+    const int cur = s.cur & 1, cand = cur ^ 1;
+    double dl[15];
+    for (int r = 0; r < B; ++r) {
+        const size_t i = (size_t)k * B + r;
+        const double sD = s.c_g * BVEC(a, V_GR)[i] + s.c_n * BVEC(a, V_GN)[i] + s.c_1 * BVEC(a, V_U1)[i] + s.c_2 * BVEC(a, V_W2)[i];
+        const double st = sD / BVEC(a, V_DG)[i];
+        BVEC(a, V_SD)[i] = sD; BVEC(a, V_ST)[i] = st;
+        dl[r] = BVEC(a, V_SC)[i] * st;
+        BVEC(a, V_DL)[i] = dl[r];
+    }
+    const double* x = a.x[cur] + 7 * (size_t)k;
+    double* xo = a.x[cand] + 7 * (size_t)k;
+    for (int c = 0; c < 3; ++c) xo[c] = x[c] + dl[c];
+    d_quat_plus(x + 3, dl + 3, xo + 3);
+    if (B == 15) for (int c = 0; c < 9; ++c) a.s[cand][9 * (size_t)k + c] = a.s[cur][9 * (size_t)k + c] + dl[6 + c];
+}
+// model cost change = -(gs . s + s^T Hs s / 2) with the all-reduced quadratic term (stage E)
+__global__ void k_bt_mcc(const BtBufs a, const double* __restrict__ stage_e) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || BT_SKIP_STEP(a)) return;
+    BtStatus& s = *a.st;
+    s.quad = stage_e[0];
+    s.mcc = -(s.lin + 0.5 * s.quad);
+    if (s.dogleg_step_norm < 0) s.dogleg_step_norm = sqrt(s.sd2);
+    if (!(s.mcc > 0.0)) { s.step_valid = 0; s.skip_step = 1; }
 }
 
 // ------------------------------------------------------------------------------------------------ host
 #define BT_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { glio_set_error("%s failed: %s", #expr, hipGetErrorString(e_)); return GLIO_E_HIP; } } while (0)
+
+struct BatchSmall {
+    int n_dq, n_dd, n_fac;
+    int* d_fa; int* d_fb; int* d_ftype; int* d_fidx;      // sorted by ordered pair (a, b); only the factors this rank owns (a in [lo, hi))
+    double* d_dq_const; glio_dd_psr* d_dd;
+    int2* d_small_index;       // [K][2 band + 1] (first, count) of the factors with (a = k, b = k + o)
+    double* d_frec;            // [n_fac][SREC]
+    size_t cap_fac, cap_dd;
+    double R_ecef_local[9], anc[3];
+    double* d_rel;             // R_ecef_local (9) and the anchor (3)
+    // shard
+    int rank, world, lo, hi;
+    int* d_bnd_kf;
+    // IMU chain
+    int n_imu; ImuEdgeDev* d_imu; PairBlock* d_rec[2]; double gravity;
+    // trust region
+    int B;                     // unknowns per keyframe of the configured solve (6 / 15)
+    void* bcr; int bcr_B, bcr_rank, bcr_world;
+    double* d_vec; long long vstride;
+    double* d_hg[2]; double* d_A[2]; double* d_x[2]; double* d_s[2]; double* d_xmin; double* d_smin;
+    double* d_stage; long long stage_doubles, bnd_doubles;     // assembly all-reduce buffer
+    double* d_dz;              // [n + 2] Gauss-Newton step of the scaled system (all-reduced), then the failure flag
+    double* d_scal;            // [16] stage D (0..7) and stage E (8..15)
+    BtStatus* d_st;
+    int* h_prog; int* d_prog; BtStatus* h_res; BtStatus* d_res;     // mapped host memory
+    double* h_x;               // pinned [K][16]
+    int solve_id;
+    long long hook_calls, hook_doubles, groups;
+};
+void glio_host_ecef_local(const double anc[3], double yaw, double R[9]);     // capi.hip
+
+static void shard_range(int K, int band, int rank, int world, int* lo, int* hi) {
+    const int sbk = band <= 6 ? 6 : 12, S = (K + sbk - 1) / sbk;
+    const int Slo = (int)((long long)S * rank / world), Shi = (int)((long long)S * (rank + 1) / world);
+    *lo = std::min(K, Slo * sbk); *hi = std::min(K, Shi * sbk);
+}
 
 static int small_ensure(glio_batch* b) {
     if (b->small) return GLIO_OK;
     BatchSmall* s = new BatchSmall();
     memset(s, 0, sizeof *s);
     const int K = b->K, band = b->band;
-    const size_t hg = (size_t)glio_batch_hg_size(K, band);
+    s->rank = 0; s->world = 1; s->lo = 0; s->hi = K; s->B = 6;
     BT_CHECK(hipMalloc((void**)&s->d_small_index, (size_t)K * (2 * band + 1) * sizeof(int2)));
     BT_CHECK(hipMemset(s->d_small_index, 0, (size_t)K * (2 * band + 1) * sizeof(int2)));
-    BT_CHECK(hipMalloc((void**)&s->d_vec, (size_t)V_COUNT * 6 * K * 8));
-    BT_CHECK(hipMalloc((void**)&s->d_Hs, hg * 8));
-    for (int k = 0; k < 2; ++k) { BT_CHECK(hipMalloc((void**)&s->d_hg[k], hg * 8)); BT_CHECK(hipMalloc((void**)&s->d_x[k], (size_t)K * 7 * 8)); }
-    BT_CHECK(hipMalloc((void**)&s->d_red, (size_t)(4 * 256 + 16) * 8));
     BT_CHECK(hipMalloc((void**)&s->d_rel, 12 * 8));
     BT_CHECK(hipMemset(s->d_rel, 0, 12 * 8));
-    BT_CHECK(hipHostMalloc((void**)&s->h_red, 16 * 8));
+    BT_CHECK(hipMalloc((void**)&s->d_bnd_kf, 64 * 4));
     b->small = s;
     return GLIO_OK;
+}
+static void tr_free(BatchSmall* s) {
+    void* p[] = {s->d_vec, s->d_hg[0], s->d_hg[1], s->d_A[0], s->d_A[1], s->d_x[0], s->d_x[1], s->d_s[0], s->d_s[1], s->d_xmin, s->d_smin, s->d_stage, s->d_dz,
+                 s->d_scal, s->d_st};
+    for (void* q : p) if (q) hipFree(q);
+    if (s->h_prog) hipHostFree(s->h_prog);
+    if (s->h_res) hipHostFree(s->h_res);
+    if (s->h_x) hipHostFree(s->h_x);
+    s->d_vec = nullptr; s->d_hg[0] = s->d_hg[1] = s->d_A[0] = s->d_A[1] = s->d_x[0] = s->d_x[1] = s->d_s[0] = s->d_s[1] = s->d_xmin = s->d_smin = s->d_stage = s->d_dz = s->d_scal = nullptr;
+    s->d_st = nullptr; s->h_prog = nullptr; s->h_res = nullptr; s->h_x = nullptr;
+    if (s->bcr) { glio_bcr_destroy(s->bcr); s->bcr = nullptr; }
 }
 void glio_batch_small_destroy(glio_batch* b) {
     BatchSmall* s = b->small;
     if (!s) return;
-    void* p[] = {s->d_fa, s->d_fb, s->d_ftype, s->d_fidx, s->d_dq_const, s->d_dd, s->d_small_index, s->d_frec, s->d_vec, s->d_Hs, s->d_hg[0], s->d_hg[1],
-                 s->d_x[0], s->d_x[1], s->d_red, s->d_rel};
+    tr_free(s);
+    void* p[] = {s->d_fa, s->d_fb, s->d_ftype, s->d_fidx, s->d_dq_const, s->d_dd, s->d_small_index, s->d_frec, s->d_rel, s->d_bnd_kf, s->d_imu, s->d_rec[0], s->d_rec[1]};
     for (void* q : p) if (q) hipFree(q);
-    if (s->h_red) hipHostFree(s->h_red);
     delete s;
     b->small = nullptr;
 }
 
-// evaluate the small factors at the poses in `poses_dev` and add them into Hg_dev (call AFTER the all-reduce)
-static void enqueue_small(glio_batch* b, const double* poses_dev, double* Hg_dev) {
+// workspaces of the trust-region solve for the present (B, rank, world); (re)built when one of them changed
+static int tr_ensure(glio_batch* b) {
+    BatchSmall* s = b->small;
+    const int K = b->K, band = b->band, B = s->n_imu > 0 ? 15 : 6;
+    if (s->bcr && s->bcr_B == B && s->bcr_rank == s->rank && s->bcr_world == s->world) return GLIO_OK;
+    tr_free(s);
+    s->B = B;
+    s->bcr = glio_bcr_create2(K, band, B, s->rank, s->world);
+    if (!s->bcr) { if (B == 15 && band > 6) glio_set_error("the batch problem with the IMU chain is solved for band <= 6 (super-blocks of 6 keyframes x 15 states)"); return GLIO_E_ARG; }
+    s->bcr_B = B; s->bcr_rank = s->rank; s->bcr_world = s->world;
+    int lo, hi;
+    glio_bcr_owned_range(s->bcr, &lo, &hi);
+    if (lo != s->lo || hi != s->hi) { glio_set_error("shard range mismatch"); return GLIO_E_STATE; }
+    const long long n = (long long)B * K;
+    s->vstride = (n + 15) / 16 * 16;
+    const size_t hg = (size_t)glio_batch_hg_size(K, band);
+    const int NB = s->world - 1;
+    s->bnd_doubles = (long long)NB * 2 * band * (band + 1) * 36;
+    s->stage_doubles = s->bnd_doubles + 2 * n + 2;
+    BT_CHECK(hipMalloc((void**)&s->d_vec, (size_t)V_COUNT * s->vstride * 8));
+    BT_CHECK(hipMemset(s->d_vec, 0, (size_t)V_COUNT * s->vstride * 8));
+    for (int k = 0; k < 2; ++k) {
+        BT_CHECK(hipMalloc((void**)&s->d_hg[k], hg * 8)); BT_CHECK(hipMemset(s->d_hg[k], 0, hg * 8));
+        BT_CHECK(hipMalloc((void**)&s->d_A[k], (size_t)(2 * n + 2) * 8));
+        BT_CHECK(hipMalloc((void**)&s->d_x[k], (size_t)K * 7 * 8)); BT_CHECK(hipMalloc((void**)&s->d_s[k], (size_t)K * 9 * 8));
+        BT_CHECK(hipMemset(s->d_s[k], 0, (size_t)K * 9 * 8));
+    }
+    BT_CHECK(hipMalloc((void**)&s->d_xmin, (size_t)K * 7 * 8)); BT_CHECK(hipMalloc((void**)&s->d_smin, (size_t)K * 9 * 8));
+    BT_CHECK(hipMemset(s->d_smin, 0, (size_t)K * 9 * 8));
+    BT_CHECK(hipMalloc((void**)&s->d_stage, (size_t)s->stage_doubles * 8));
+    BT_CHECK(hipMalloc((void**)&s->d_dz, (size_t)(n + 2) * 8));
+    BT_CHECK(hipMalloc((void**)&s->d_scal, 16 * 8)); BT_CHECK(hipMemset(s->d_scal, 0, 16 * 8));
+    BT_CHECK(hipMalloc((void**)&s->d_st, sizeof(BtStatus)));
+    BT_CHECK(hipHostMalloc((void**)&s->h_prog, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    BT_CHECK(hipHostGetDevicePointer((void**)&s->d_prog, (void*)s->h_prog, 0));
+    BT_CHECK(hipHostMalloc((void**)&s->h_res, sizeof(BtStatus), hipHostMallocMapped | hipHostMallocCoherent));
+    BT_CHECK(hipHostGetDevicePointer((void**)&s->d_res, (void*)s->h_res, 0));
+    BT_CHECK(hipHostMalloc((void**)&s->h_x, (size_t)K * 16 * 8));
+    memset(s->h_prog, 0, 64);
+    std::vector<int> bnd(std::max(NB, 1), 0);
+    for (int j = 0; j < NB; ++j) { int l, h2; shard_range(K, band, j, s->world, &l, &h2); bnd[j] = h2; }
+    if (NB > 64) { glio_set_error("more than 65 ranks"); return GLIO_E_ARG; }
+    BT_CHECK(hipMemcpy(s->d_bnd_kf, bnd.data(), (size_t)std::max(NB, 1) * 4, hipMemcpyHostToDevice));
+    return GLIO_OK;
+}
+
+static BtBufs make_bufs(glio_batch* b) {
+    BatchSmall* s = b->small;
+    BtBufs a;
+    a.st = s->d_st; a.K = b->K; a.band = b->band; a.B = s->B; a.lo = s->lo; a.hi = s->hi;
+    for (int k = 0; k < 2; ++k) { a.x[k] = s->d_x[k]; a.s[k] = s->d_s[k]; a.hg[k] = s->d_hg[k]; a.rec[k] = s->n_imu > 0 ? s->d_rec[k] : nullptr; a.A[k] = s->d_A[k]; }
+    a.xmin = s->d_xmin; a.smin = s->d_smin; a.vec = s->d_vec; a.vstride = s->vstride;
+    return a;
+}
+static BtAsm make_asm(glio_batch* b) {
+    BatchSmall* s = b->small;
+    BtAsm m;
+    m.NB = s->world - 1; m.bnd_doubles = s->bnd_doubles; m.bnd_kf = s->d_bnd_kf; m.stage = s->d_stage; m.rank = s->rank;
+    m.eo0 = s->n_imu > 0 ? s->lo : 0; m.eo1 = s->n_imu > 0 ? std::min(s->hi, b->K - 1) : 0;
+    return m;
+}
+
+// small factors of this rank evaluated at the selected poses and added into the selected band buffer
+static void enqueue_small_sel(glio_batch* b, const BtSel& sel, const double* p0, const double* p1, double* Hg0, double* Hg1) {
     BatchSmall* s = b->small;
     if (!s || s->n_fac == 0) return;
     const int K = b->K, band = b->band;
-    hipLaunchKernelGGL(k_small_eval, dim3(s->n_fac), dim3(64), 0, b->stream, s->n_fac, s->d_fa, s->d_fb, s->d_ftype, s->d_fidx, poses_dev, s->d_dq_const, s->d_dd,
+    hipLaunchKernelGGL(k_small_eval, dim3(s->n_fac), dim3(64), 0, b->stream, sel, s->n_fac, s->d_fa, s->d_fb, s->d_ftype, s->d_fidx, p0, p1, s->d_dq_const, s->d_dd,
                        s->d_rel, s->d_frec);
     const long long tot = glio_batch_hg_size(K, band);
-    hipLaunchKernelGGL(k_small_add, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, b->stream, K, band, s->d_small_index, s->d_frec, s->n_fac, Hg_dev);
-    hipLaunchKernelGGL(k_small_cost, dim3(1), dim3(256), 0, b->stream, s->d_frec, s->n_fac, Hg_dev + tot - 1);
+    hipLaunchKernelGGL(k_small_add, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, b->stream, sel, K, band, s->d_small_index, s->d_frec, s->n_fac, Hg0, Hg1);
+    hipLaunchKernelGGL(k_small_cost, dim3(1), dim3(256), 0, b->stream, sel, s->d_frec, s->n_fac, Hg0 + tot - 1, Hg1 + tot - 1);
+}
+static void enqueue_small(glio_batch* b, const double* poses_dev, double* Hg_dev) {
+    BtSel sel; sel.cur = nullptr; sel.skip = nullptr; sel.want = 0;
+    enqueue_small_sel(b, sel, poses_dev, poses_dev, Hg_dev, Hg_dev);
+}
+
+typedef void (*bt_hook_fn)(double*, int64_t, void*, void*);
+struct BtRun { glio_batch* b; bt_hook_fn hook; void* user; };
+static void call_hook(const BtRun& r, double* dev, long long count) {
+    BatchSmall* s = r.b->small;
+    if (s->world <= 1 || !r.hook) return;
+    r.hook(dev, (int64_t)count, (void*)r.b->stream, r.user);
+    s->hook_calls += 1; s->hook_doubles += count;
+}
+
+// linearise the point selected by `want` (1: the candidate) -- K8 on this rank's constraints, its small factors, its IMU edges (plus
+// the one entering from the left neighbour, for complete diagonal blocks) -- then the assembly all-reduce and the candidate's norms
+static void enqueue_tr_linearize(const BtRun& r, int want, bool initial) {
+    glio_batch* b = r.b;
+    BatchSmall* s = b->small;
+    const BtBufs a = make_bufs(b);
+    const BtAsm m = make_asm(b);
+    hipStream_t st = b->stream;
+    BtSel sel; sel.cur = &s->d_st->cur; sel.skip = initial ? nullptr : &s->d_st->skip_step; sel.want = want;
+    const int K = b->K, band = b->band;
+    const int k0 = std::max(0, s->lo - band), k1 = std::min(K, s->hi + band);
+    glio_batch_enqueue_linearize_sel(b, sel, s->d_x[0], s->d_x[1], s->d_hg[0], s->d_hg[1], k0, k1);
+    enqueue_small_sel(b, sel, s->d_x[0], s->d_x[1], s->d_hg[0], s->d_hg[1]);
+    if (s->n_imu > 0) {
+        const int e0 = std::max(0, s->lo - 1), e1 = std::min(s->hi, K - 1);
+        glio_launch_batch_imu(st, sel, s->gravity, s->d_imu, e0, e1, s->d_x[0], s->d_x[1], s->d_s[0], s->d_s[1], s->d_rec[0], s->d_rec[1]);
+    }
+    const long long tot = s->bnd_doubles + 2LL * a.B * K;
+    hipLaunchKernelGGL(k_bt_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, a, m, sel);
+    hipLaunchKernelGGL(k_bt_pack_cost, dim3(1), dim3(256), 0, st, a, m, sel);
+    call_hook(r, s->d_stage, s->stage_doubles);
+    hipLaunchKernelGGL(k_bt_unpack, dim3((unsigned)((tot + 1 + 255) / 256)), dim3(256), 0, st, a, m, sel);
+    hipLaunchKernelGGL(k_bt_norms, dim3(1), dim3(1024), 0, st, a, sel);
+}
+
+// one trust-region group: state machine, (Cauchy + Gauss-Newton + subspace model), step, model cost change, the candidate's linearisation
+static void enqueue_tr_group(const BtRun& r, const BtOpts& o) {
+    glio_batch* b = r.b;
+    BatchSmall* s = b->small;
+    const BtBufs a = make_bufs(b);
+    hipStream_t st = b->stream;
+    const int K = b->K, B = s->B, n = B * K;
+    const int nbv = (n + TRV_THREADS - 1) / TRV_THREADS;
+    const int own = (s->hi - s->lo) * B, nbo = std::max(1, (own + TRV_THREADS - 1) / TRV_THREADS);
+    BtHost h; h.progress = s->d_prog; h.result = s->d_res;
+    hipLaunchKernelGGL(k_bt_state_machine, dim3(1), dim3(256), 0, st, a, o, h);
+    // ---- Cauchy point and Gauss-Newton step (skipped when the stored ones are reused)
+    hipLaunchKernelGGL(k_bt_prepare, dim3(nbv), dim3(TRV_THREADS), 0, st, a, o.jacobi);
+    hipLaunchKernelGGL(k_bt_matvec, dim3(nbo), dim3(TRV_THREADS), 0, st, a, 1, (int)V_UU, (int)V_T1, -1, -1);
+    long long sep_count = 0;
+    double* sep = glio_bcr_sepbuf(s->bcr, &sep_count);
+    double* extra = sep + sep_count - 16;
+    {
+        DotJobs j; memset(&j, 0, sizeof j);
+        j.n = 2;
+        j.va[0] = V_GR; j.vb[0] = V_GR; j.owned[0] = 0; j.out[0] = &s->d_st->gg;
+        j.va[1] = V_UU; j.vb[1] = V_T1; j.owned[1] = 1; j.out[1] = extra;          // the Cauchy curvature travels with the separator system
+        hipLaunchKernelGGL(k_bt_dots, dim3(1), dim3(1024), 0, st, a, 1, j);
+    }
+    BcrOp op; memset(&op, 0, sizeof op);
+    for (int k = 0; k < 2; ++k) { op.Hg[k] = s->d_hg[k]; op.imu[k] = s->n_imu > 0 ? s->d_rec[k] : nullptr; op.gfull[k] = s->d_A[k] + n; }
+    op.cur = &s->d_st->cur; op.sc = BVEC(a, V_SC); op.dadd = BVEC(a, V_DA); op.lambda = 0.0; op.skip = &s->d_st->skip_solve;
+    glio_bcr_enqueue_local(s->bcr, op, st);
+    call_hook(r, sep, sep_count);
+    glio_bcr_enqueue_finish(s->bcr, op, s->d_dz, st);
+    hipLaunchKernelGGL(k_bt_dz_prepare, dim3((n + 1 + 255) / 256), dim3(256), 0, st, a, s->d_dz, glio_bcr_fail_flag(s->bcr));
+    call_hook(r, s->d_dz, n + 2);
+    hipLaunchKernelGGL(k_bt_gn, dim3(nbv), dim3(TRV_THREADS), 0, st, a, s->d_dz);
+    {
+        DotJobs j; memset(&j, 0, sizeof j);
+        j.n = 2;
+        j.va[0] = V_GN; j.vb[0] = V_GN; j.out[0] = &s->d_st->nn2;
+        j.va[1] = V_GR; j.vb[1] = V_GN; j.out[1] = &s->d_st->gd;
+        hipLaunchKernelGGL(k_bt_dots, dim3(1), dim3(1024), 0, st, a, 1, j);
+    }
+    hipLaunchKernelGGL(k_bt_basis, dim3(nbv), dim3(TRV_THREADS), 0, st, a, extra);
+    hipLaunchKernelGGL(k_bt_matvec, dim3(nbo), dim3(TRV_THREADS), 0, st, a, 1, (int)V_X1, (int)V_T1, (int)V_X2, (int)V_T2);
+    {
+        DotJobs j; memset(&j, 0, sizeof j);
+        j.n = 4;
+        j.va[0] = V_X1; j.vb[0] = V_T1; j.owned[0] = 1; j.out[0] = s->d_scal + 0;
+        j.va[1] = V_X1; j.vb[1] = V_T2; j.owned[1] = 1; j.out[1] = s->d_scal + 1;
+        j.va[2] = V_X2; j.vb[2] = V_T2; j.owned[2] = 1; j.out[2] = s->d_scal + 2;
+        j.va[3] = V_W2; j.vb[3] = V_W2; j.owned[3] = 0; j.out[3] = &s->d_st->w2;
+        hipLaunchKernelGGL(k_bt_dots, dim3(1), dim3(1024), 0, st, a, 1, j);
+    }
+    call_hook(r, s->d_scal, 8);
+    // ---- the step for the present radius, its model cost change, the candidate
+    hipLaunchKernelGGL(k_bt_dogleg, dim3(1), dim3(64), 0, st, a, s->d_scal, o.dogleg_type);
+    hipLaunchKernelGGL(k_bt_step, dim3((K + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_bt_matvec, dim3(nbo), dim3(TRV_THREADS), 0, st, a, 0, (int)V_ST, (int)V_T1, -1, -1);
+    {
+        DotJobs j; memset(&j, 0, sizeof j);
+        j.n = 3;
+        j.va[0] = V_GS; j.vb[0] = V_ST; j.out[0] = &s->d_st->lin;
+        j.va[1] = V_ST; j.vb[1] = V_T1; j.owned[1] = 1; j.out[1] = s->d_scal + 8;
+        j.va[2] = V_SD; j.vb[2] = V_SD; j.out[2] = &s->d_st->sd2;
+        hipLaunchKernelGGL(k_bt_dots, dim3(1), dim3(1024), 0, st, a, 0, j);
+    }
+    call_hook(r, s->d_scal + 8, 8);
+    hipLaunchKernelGGL(k_bt_mcc, dim3(1), dim3(64), 0, st, a, s->d_scal + 8);
+    enqueue_tr_linearize(r, 1, false);          // the candidate's linearisation (returns at once when the group has no usable step)
+    s->groups += 1;
 }
 
 extern "C" {
+
+int glio_batch_shard_range(int K, int band, int rank, int world, int32_t* lo, int32_t* hi) {
+    if (K < 1 || band < 1 || world < 1 || rank < 0 || rank >= world || !lo || !hi) return GLIO_E_ARG;
+    int l, h;
+    shard_range(K, band, rank, world, &l, &h);
+    *lo = l; *hi = h;
+    return GLIO_OK;
+}
+// This object is rank `rank` of `world`: it owns the keyframes of glio_batch_shard_range -- the constraints given to
+// glio_batch_set_constraints* must have their source keyframe there; small factors and IMU edges are given whole, the library keeps its own.
+int glio_batch_set_shard(glio_batch* b, int rank, int world) {
+    if (!b || world < 1 || rank < 0 || rank >= world) return GLIO_E_ARG;
+    BT_CHECK(hipSetDevice(b->device));
+    { const int rc = small_ensure(b); if (rc) return rc; }
+    BatchSmall* s = b->small;
+    if (s->n_fac > 0 && (rank != s->rank || world != s->world)) { glio_set_error("glio_batch_set_shard must precede glio_batch_set_small_factors"); return GLIO_E_STATE; }
+    const int sbk = b->band <= 6 ? 6 : 12, S = (b->K + sbk - 1) / sbk;
+    if (S < world) { glio_set_error("%d keyframes are too few for %d ranks", b->K, world); return GLIO_E_ARG; }
+    s->rank = rank; s->world = world;
+    shard_range(b->K, b->band, rank, world, &s->lo, &s->hi);
+    return GLIO_OK;
+}
+
+// The ImuFactor chain (Estimator.cpp:2990-3001): edges[k] is the pre-integration between keyframes k and k + 1 (n_edges = K - 1), or
+// n_edges = 0 for the pose-only problem.  With the chain every keyframe has 15 unknowns and glio_batch_solve_tr2 takes the speed-bias blocks.
+int glio_batch_set_imu(glio_batch* b, int n_edges, const glio_preint* edges, double gravity) {
+    if (!b || (n_edges != 0 && n_edges != b->K - 1) || (n_edges > 0 && !edges)) return GLIO_E_ARG;
+    BT_CHECK(hipSetDevice(b->device));
+    { const int rc = small_ensure(b); if (rc) return rc; }
+    BatchSmall* s = b->small;
+    if (n_edges > 0 && b->band > 6) { glio_set_error("the batch problem with the IMU chain is solved for band <= 6"); return GLIO_E_ARG; }
+    if (n_edges > 0 && !s->d_imu) {
+        BT_CHECK(hipMalloc((void**)&s->d_imu, (size_t)(b->K - 1) * sizeof(ImuEdgeDev)));
+        for (int k = 0; k < 2; ++k) BT_CHECK(hipMalloc((void**)&s->d_rec[k], (size_t)(b->K - 1) * sizeof(PairBlock)));
+    }
+    if (n_edges > 0) {
+        std::vector<ImuEdgeDev> h((size_t)n_edges);
+        for (int k = 0; k < n_edges; ++k)
+            if (!glio_digest_imu_edge(&edges[k], k, &h[k])) { glio_set_error("IMU edge %d: covariance not invertible", k); return GLIO_E_ARG; }
+        BT_CHECK(hipMemcpy(s->d_imu, h.data(), (size_t)n_edges * sizeof(ImuEdgeDev), hipMemcpyHostToDevice));
+    }
+    s->n_imu = n_edges; s->gravity = gravity;
+    return GLIO_OK;
+}
 
 int glio_batch_set_small_factors(glio_batch* b, const glio_gnss_frame* frame, int n_dq, const int32_t* dq_i, const int32_t* dq_j, const double* dq_const,
                                  int n_dd, const glio_dd_psr* dd) {
@@ -383,16 +973,21 @@ int glio_batch_set_small_factors(glio_batch* b, const glio_gnss_frame* frame, in
     BT_CHECK(hipSetDevice(b->device));
     { const int rc = small_ensure(b); if (rc) return rc; }
     BatchSmall* s = b->small;
-    const int K = b->K, band = b->band, wdt = 2 * band + 1, nf = n_dq + n_dd;
+    const int K = b->K, band = b->band, wdt = 2 * band + 1;
     struct Fac { int a, b, type, idx; };
     std::vector<Fac> fac;
-    fac.reserve(nf);
+    fac.reserve((size_t)n_dq + n_dd);
     for (int f = 0; f < n_dq; ++f) fac.push_back({dq_i[f], dq_j[f], 0, f});
     for (int f = 0; f < n_dd; ++f) fac.push_back({dd[f].slot_i, dd[f].slot_j, 1, f});
     for (const Fac& f : fac) {
         if (f.a < 0 || f.a >= K || f.b < 0 || f.b >= K || f.a == f.b || std::abs(f.a - f.b) > band) { glio_set_error("small factor on keyframes (%d, %d) outside band %d", f.a, f.b, band); return GLIO_E_ARG; }
         if (f.type == 1 && (dd[f.idx].n_sat < 2 || dd[f.idx].n_sat > GLIO_DD_MAX_SAT || dd[f.idx].master < 0 || dd[f.idx].master >= dd[f.idx].n_sat)) { glio_set_error("bad DD factor"); return GLIO_E_ARG; }
     }
+    // sharded by the first keyframe of the factor: this rank keeps its own
+    std::vector<Fac> mine;
+    for (const Fac& f : fac) if (f.a >= s->lo && f.a < s->hi) mine.push_back(f);
+    fac.swap(mine);
+    const int nf = (int)fac.size();
     std::stable_sort(fac.begin(), fac.end(), [](const Fac& x, const Fac& y) { return x.a != y.a ? x.a < y.a : x.b < y.b; });
     std::vector<int2> index((size_t)K * wdt, make_int2(0, 0));
     std::vector<int> fa(std::max(nf, 1)), fb(std::max(nf, 1)), ft(std::max(nf, 1)), fi(std::max(nf, 1));
@@ -402,18 +997,23 @@ int glio_batch_set_small_factors(glio_batch* b, const glio_gnss_frame* frame, in
         if (e.y == 0) e.x = q;
         e.y += 1;
     }
-    if ((size_t)nf > s->cap_fac) {
-        void* p[] = {s->d_fa, s->d_fb, s->d_ftype, s->d_fidx, s->d_dq_const, s->d_frec};
-        for (void* q : p) if (q) hipFree(q);
-        s->cap_fac = (size_t)nf + nf / 2 + 16;
-        BT_CHECK(hipMalloc((void**)&s->d_fa, s->cap_fac * 4)); BT_CHECK(hipMalloc((void**)&s->d_fb, s->cap_fac * 4));
-        BT_CHECK(hipMalloc((void**)&s->d_ftype, s->cap_fac * 4)); BT_CHECK(hipMalloc((void**)&s->d_fidx, s->cap_fac * 4));
-        BT_CHECK(hipMalloc((void**)&s->d_dq_const, s->cap_fac * 32)); BT_CHECK(hipMalloc((void**)&s->d_frec, s->cap_fac * (SREC + 1) * 8));
+    const size_t need_fac = std::max((size_t)nf, (size_t)n_dq);
+    if (need_fac > s->cap_fac) {
+        void** p[] = {(void**)&s->d_fa, (void**)&s->d_fb, (void**)&s->d_ftype, (void**)&s->d_fidx, (void**)&s->d_dq_const, (void**)&s->d_frec};
+        for (void** q : p) { if (*q) hipFree(*q); *q = nullptr; }
+        s->cap_fac = 0; s->n_fac = 0;
+        const size_t cap = need_fac + need_fac / 2 + 16;
+        BT_CHECK(hipMalloc((void**)&s->d_fa, cap * 4)); BT_CHECK(hipMalloc((void**)&s->d_fb, cap * 4));
+        BT_CHECK(hipMalloc((void**)&s->d_ftype, cap * 4)); BT_CHECK(hipMalloc((void**)&s->d_fidx, cap * 4));
+        BT_CHECK(hipMalloc((void**)&s->d_dq_const, cap * 32)); BT_CHECK(hipMalloc((void**)&s->d_frec, cap * (SREC + 1) * 8));
+        s->cap_fac = cap;             // only after every allocation succeeded
     }
     if ((size_t)n_dd > s->cap_dd) {
-        if (s->d_dd) hipFree(s->d_dd);
-        s->cap_dd = (size_t)n_dd + n_dd / 2 + 16;
-        BT_CHECK(hipMalloc((void**)&s->d_dd, s->cap_dd * sizeof(glio_dd_psr)));
+        if (s->d_dd) { hipFree(s->d_dd); s->d_dd = nullptr; }
+        s->cap_dd = 0; s->n_dd = 0;
+        const size_t cap = (size_t)n_dd + n_dd / 2 + 16;
+        BT_CHECK(hipMalloc((void**)&s->d_dd, cap * sizeof(glio_dd_psr)));
+        s->cap_dd = cap;
     }
     if (nf) {
         BT_CHECK(hipMemcpy(s->d_fa, fa.data(), (size_t)nf * 4, hipMemcpyHostToDevice)); BT_CHECK(hipMemcpy(s->d_fb, fb.data(), (size_t)nf * 4, hipMemcpyHostToDevice));
@@ -448,7 +1048,7 @@ int glio_batch_set_dd_threshold(glio_batch* b, double threshold) {
     return GLIO_OK;
 }
 
-// adds the small factors evaluated at `poses` ([K][7], host) into the (reduced) buffer: the call that follows the all-reduce
+// adds the small factors evaluated at `poses` ([K][7], host) into a band buffer (the damped Gauss-Newton path; one rank)
 int glio_batch_add_small_dev(glio_batch* b, const double* poses, double* Hg_dev) {
     if (!b || !poses || !Hg_dev) return GLIO_E_ARG;
     BT_CHECK(hipSetDevice(b->device));
@@ -461,170 +1061,117 @@ int glio_batch_add_small_dev(glio_batch* b, const double* poses, double* Hg_dev)
     return GLIO_OK;
 }
 
-// The trust-region solve.  `allreduce` (may be NULL for one rank) is called with the device buffer of this rank's LiDAR
-// linearisation, its length in doubles, the HIP stream it was produced on and `user`; it must leave the SUM over the ranks in
-// place (e.g. ncclAllReduce on that stream, or torch.distributed.all_reduce).  Every rank then adds the replicated small
-// factors and takes identical decisions.
-int glio_batch_solve_tr(glio_batch* b, double* poses, const glio_batch_tr_opts* o, void (*allreduce)(double*, int64_t, void*, void*), void* user,
-                        glio_summary* sum) {
-    if (!b || !poses || !o || !sum) return GLIO_E_ARG;
-    if (!b->bcr) { glio_set_error("the trust-region batch solve needs the block-cyclic-reduction solver (band <= 12)"); return GLIO_E_ARG; }
+// One linearisation of the whole problem at (poses, speed_bias) through the solver's own path (shard, hook, assembly): the
+// replicated diagonal [n], gradient [n] and the cost, n = B K (parity checks; `allreduce` as in glio_batch_solve_tr2).
+int glio_batch_linearize_full(glio_batch* b, const double* poses, const double* speed_bias, glio_allreduce_fn allreduce, void* user, double* diag, double* grad,
+                              double* cost) {
+    if (!b || !poses) return GLIO_E_ARG;
     BT_CHECK(hipSetDevice(b->device));
     { const int rc = small_ensure(b); if (rc) return rc; }
+    { const int rc = tr_ensure(b); if (rc) return rc; }
     BatchSmall* s = b->small;
-    const int K = b->K, band = b->band, n = 6 * K;
-    const long long hg = glio_batch_hg_size(K, band);
-    const int nbv = (n + TRV_THREADS - 1) / TRV_THREADS, nbd = std::min(nbv, 256);
+    if (s->n_imu > 0 && !speed_bias) return GLIO_E_ARG;
+    const int K = b->K, n = s->B * K;
+    BtStatus st; memset(&st, 0, sizeof st);
+    st.cur = 1; st.first = 1;
+    BT_CHECK(hipMemcpyAsync(s->d_st, &st, sizeof st, hipMemcpyHostToDevice, b->stream));
+    BT_CHECK(hipMemcpyAsync(s->d_x[0], poses, (size_t)K * 7 * 8, hipMemcpyHostToDevice, b->stream));
+    if (s->n_imu > 0) BT_CHECK(hipMemcpyAsync(s->d_s[0], speed_bias, (size_t)K * 9 * 8, hipMemcpyHostToDevice, b->stream));
+    BT_CHECK(hipMemcpyAsync(s->d_x[1], s->d_x[0], (size_t)K * 7 * 8, hipMemcpyDeviceToDevice, b->stream));
+    BT_CHECK(hipMemcpyAsync(s->d_s[1], s->d_s[0], (size_t)K * 9 * 8, hipMemcpyDeviceToDevice, b->stream));
+    BtRun r; r.b = b; r.hook = allreduce; r.user = user;
+    enqueue_tr_linearize(r, 1, true);
+    BT_CHECK(hipGetLastError());
+    std::vector<double> h((size_t)2 * n + 1);
+    BT_CHECK(hipMemcpyAsync(h.data(), s->d_A[0], ((size_t)2 * n + 1) * 8, hipMemcpyDeviceToHost, b->stream));
+    BT_CHECK(hipStreamSynchronize(b->stream));
+    if (diag) memcpy(diag, h.data(), (size_t)n * 8);
+    if (grad) memcpy(grad, h.data() + n, (size_t)n * 8);
+    if (cost) *cost = h[(size_t)2 * n];
+    return GLIO_OK;
+}
+
+// The trust-region solve.  `allreduce` (NULL for one rank) is called with a device buffer, its length in doubles, the HIP stream the
+// buffer is produced and consumed on, and `user`; it must leave the SUM over the ranks in place, ORDERED ON THAT STREAM (ncclAllReduce on
+// it; torch.distributed.all_reduce with that stream current): the host does not wait for it.  Five calls per trust-region group (file
+// header), the same on every rank.  poses [K][7] in/out, speed_bias [K][9] in/out (with the IMU chain; else ignored, may be NULL).
+int glio_batch_solve_tr2(glio_batch* b, double* poses, double* speed_bias, const glio_batch_tr_opts* o, glio_allreduce_fn allreduce, void* user, glio_summary* sum) {
+    if (!b || !poses || !o || !sum) return GLIO_E_ARG;
+    BT_CHECK(hipSetDevice(b->device));
+    { const int rc = small_ensure(b); if (rc) return rc; }
+    { const int rc = tr_ensure(b); if (rc) return rc; }
+    BatchSmall* s = b->small;
+    if (s->n_imu > 0 && !speed_bias) { glio_set_error("the IMU chain is set: speed_bias [K][9] is needed"); return GLIO_E_ARG; }
+    if (s->world > 1 && !allreduce) { glio_set_error("rank %d of %d needs the all-reduce hook", s->rank, s->world); return GLIO_E_ARG; }
+    const int K = b->K;
     hipStream_t st = b->stream;
     memset(sum, 0, sizeof *sum);
-    s->have_scale = 0;
-    auto linearize = [&](int buf) -> int {        // poses in d_x[buf] -> d_hg[buf] (shard, reduce, small factors); returns through h_red[15] the cost
-        BT_CHECK(hipMemcpyAsync(b->d_poses, s->d_x[buf], (size_t)K * 7 * 8, hipMemcpyDeviceToDevice, st));
-        glio_batch_enqueue_linearize(b, s->d_hg[buf]);
-        if (allreduce) { BT_CHECK(hipStreamSynchronize(st)); allreduce(s->d_hg[buf], (int64_t)hg, (void*)st, user); }
-        enqueue_small(b, s->d_x[buf], s->d_hg[buf]);
-        BT_CHECK(hipMemcpyAsync(s->h_red + 15, s->d_hg[buf] + hg - 1, 8, hipMemcpyDeviceToHost, st));
-        BT_CHECK(hipStreamSynchronize(st));
-        return GLIO_OK;
-    };
-    auto dots = [&](int nd, const double* a0, const double* b0, const double* a1, const double* b1, const double* a2, const double* b2, const double* a3,
-                    const double* b3, double out[4]) -> int {
-        DotArgs da; da.nd = nd;
-        const double* A[4] = {a0, a1, a2, a3}; const double* B[4] = {b0, b1, b2, b3};
-        for (int k = 0; k < 4; ++k) { da.a[k] = A[k] ? A[k] : a0; da.b[k] = B[k] ? B[k] : b0; }
-        hipLaunchKernelGGL(k_bt_dots, dim3(nbd), dim3(TRV_THREADS), 0, st, da, n, s->d_red);
-        hipLaunchKernelGGL(k_bt_sum, dim3(1), dim3(64), 0, st, s->d_red, nbd, s->d_red + 4 * 256);
-        BT_CHECK(hipMemcpyAsync(s->h_red, s->d_red + 4 * 256, 4 * 8, hipMemcpyDeviceToHost, st));
-        BT_CHECK(hipStreamSynchronize(st));
-        for (int k = 0; k < 4; ++k) out[k] = s->h_red[k];
-        return GLIO_OK;
-    };
-    int cur = 0;
-    memcpy(b->h_poses, poses, (size_t)K * 7 * 8);
-    BT_CHECK(hipMemcpyAsync(s->d_x[cur], b->h_poses, (size_t)K * 7 * 8, hipMemcpyHostToDevice, st));
-    { const int rc = linearize(cur); if (rc) return rc; }
-    double cost = s->h_red[15];
-    sum->initial_cost = cost;
-    double radius = o->initial_trust_region_radius, mu = 1e-8, alpha = 0, dogleg_step_norm = 0;
-    int reuse = 0, iteration = 0, invalid = 0;
-    double minimum_cost = cost, current_cost = cost, reference_cost = cost, candidate_cost = cost, acc_ref = 0, acc_cand = 0;
-    int n_nonmono = 0;
-    const int max_nonmono = o->use_nonmonotonic_steps ? o->max_consecutive_nonmonotonic_steps : 0;
-    double gg = 0, nn2 = 0, gd = 0;         // |g~|^2, |gn|^2, g~.gn of the stored Gauss-Newton / Cauchy data
-    sum->termination = GLIO_TERM_NO_CONVERGENCE;
+    BtOpts bo;
+    bo.max_iterations = o->max_iterations; bo.max_nonmono = o->use_nonmonotonic_steps ? o->max_consecutive_nonmonotonic_steps : 0;
+    bo.jacobi = o->jacobi_scaling; bo.dogleg_type = o->dogleg_type;
+    bo.min_radius = o->min_trust_region_radius; bo.min_rel = o->min_relative_decrease; bo.ftol = o->function_tolerance; bo.gtol = o->gradient_tolerance;
+    bo.ptol = o->parameter_tolerance;
+    BtStatus init; memset(&init, 0, sizeof init);
+    init.cur = 1; init.first = 1; init.step_valid = 1;
+    init.radius = o->initial_trust_region_radius; init.mu = 1e-8;
+    s->solve_id = s->solve_id % 30000 + 1;
+    init.solve_id = s->solve_id;
+    const int id = s->solve_id;
+    memcpy(s->h_x, poses, (size_t)K * 7 * 8);
+    if (s->n_imu > 0) memcpy(s->h_x + (size_t)K * 7, speed_bias, (size_t)K * 9 * 8);
+    BT_CHECK(hipMemcpyAsync(s->d_st, &init, sizeof init, hipMemcpyHostToDevice, st));
+    BT_CHECK(hipMemcpyAsync(s->d_x[0], s->h_x, (size_t)K * 7 * 8, hipMemcpyHostToDevice, st));
+    if (s->n_imu > 0) BT_CHECK(hipMemcpyAsync(s->d_s[0], s->h_x + (size_t)K * 7, (size_t)K * 9 * 8, hipMemcpyHostToDevice, st));
+    BT_CHECK(hipMemcpyAsync(s->d_x[1], s->d_x[0], (size_t)K * 7 * 8, hipMemcpyDeviceToDevice, st));
+    BT_CHECK(hipMemcpyAsync(s->d_s[1], s->d_s[0], (size_t)K * 9 * 8, hipMemcpyDeviceToDevice, st));
+    BtRun r; r.b = b; r.hook = allreduce; r.user = user;
+    enqueue_tr_linearize(r, 1, true);            // the starting point is "the candidate" of a first group that accepts it unconditionally
+    // The loop lives on the device; the host feeds one group per decision of the state machine.  Group g + 1 is enqueued when the
+    // state machine of group g (its first kernel) has said "the solve goes on" -- i.e. while the rest of group g is still running
+    // -- so the queue never runs dry, and every rank enqueues exactly the same groups (the collectives inside them must match).
+    const int max_groups = o->max_iterations + 16 + 8 * 5;
+    const auto t0 = std::chrono::steady_clock::now();
     int rc = GLIO_OK;
-    for (;;) {
-        // gradient max norm and the loop-top checks
-        const double* gcur = s->d_hg[cur] + (size_t)K * (band + 1) * 36;
-        hipLaunchKernelGGL(k_bt_state_norms, dim3(1), dim3(TRV_THREADS), 0, st, s->d_x[cur], s->d_x[cur], gcur, K, s->d_red + 4 * 256 + 4);
-        BT_CHECK(hipMemcpyAsync(s->h_red + 4, s->d_red + 4 * 256 + 4, 3 * 8, hipMemcpyDeviceToHost, st));
-        BT_CHECK(hipStreamSynchronize(st));
-        sum->gradient_max_norm = s->h_red[6];
-        if (iteration >= o->max_iterations) { sum->termination = GLIO_TERM_NO_CONVERGENCE; break; }
-        if (sum->gradient_max_norm <= o->gradient_tolerance) { sum->termination = GLIO_TERM_GRADIENT_TOL; break; }
-        if (radius <= o->min_trust_region_radius) { sum->termination = GLIO_TERM_MIN_RADIUS; break; }
-        ++iteration;
-        bool step_valid = true;
-        if (!reuse) {
-            hipLaunchKernelGGL(k_bt_prepare, dim3(nbv), dim3(TRV_THREADS), 0, st, s->d_hg[cur], K, band, s->have_scale ? 0 : 1, o->jacobi_scaling, mu,
-                               BV(b, V_SC), BV(b, V_DG), BV(b, V_GR), BV(b, V_UU), BV(b, V_GS), BV(b, V_DA));
-            s->have_scale = 1;
-            hipLaunchKernelGGL(k_bt_scale_band, dim3((unsigned)((hg + 255) / 256)), dim3(256), 0, st, s->d_hg[cur], K, band, BV(b, V_SC), s->d_Hs);
-            // Cauchy: alpha = |g~|^2 / (w^T Hs w), w = g~ / D
-            hipLaunchKernelGGL(k_bt_matvec, dim3(nbv), dim3(TRV_THREADS), 0, st, s->d_Hs, K, band, BV(b, V_UU), BV(b, V_TT));
-            double d4[4];
-            rc = dots(2, BV(b, V_GR), BV(b, V_GR), BV(b, V_UU), BV(b, V_TT), nullptr, nullptr, nullptr, nullptr, d4);
-            if (rc) return rc;
-            gg = d4[0];
-            alpha = gg / d4[1];
-            bool solved = false;
-            while (mu < 1.0) {
-                int* fail_dev = nullptr;
-                glio_bcr_solve_shift(b->bcr, s->d_Hs, 0.0, BV(b, V_DA), BV(b, V_YY), &fail_dev, st);      // delta = -(Hs + mu D^2)^-1 gs
-                int fail = 0;
-                BT_CHECK(hipMemcpyAsync(s->h_red + 8, fail_dev, 4, hipMemcpyDeviceToHost, st));
-                BT_CHECK(hipStreamSynchronize(st));
-                memcpy(&fail, s->h_red + 8, 4);
-                if (!fail) { solved = true; break; }
-                mu *= 10.0;
-                hipLaunchKernelGGL(k_bt_prepare, dim3(nbv), dim3(TRV_THREADS), 0, st, s->d_hg[cur], K, band, 0, o->jacobi_scaling, mu,
-                                   BV(b, V_SC), BV(b, V_DG), BV(b, V_GR), BV(b, V_UU), BV(b, V_GS), BV(b, V_DA));
-            }
-            if (!solved) step_valid = false;
-            else {
-                hipLaunchKernelGGL(k_bt_gn, dim3(nbv), dim3(TRV_THREADS), 0, st, BV(b, V_DG), BV(b, V_YY), BV(b, V_GN), n);
-                double d3[4];
-                rc = dots(2, BV(b, V_GN), BV(b, V_GN), BV(b, V_GR), BV(b, V_GN), nullptr, nullptr, nullptr, nullptr, d3);
-                if (rc) return rc;
-                nn2 = d3[0]; gd = d3[1];
+    for (int g = 1; g <= max_groups; ++g) {
+        enqueue_tr_group(r, bo);
+        if (hipGetLastError() != hipSuccess) { glio_set_error("batch solve: launch failure in group %d", g); return GLIO_E_HIP; }
+        long long spins = 0;
+        bool finished = false;
+        for (;;) {
+            if (s->h_prog[1] == id) { finished = true; break; }
+            const int w = s->h_prog[0];
+            if ((w >> 16) == id && (w & 0xffff) >= (g & 0xffff)) break;
+            if (((++spins) & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+                glio_set_error("batch solve: no progress for 120 s (group %d)", g);
+                return GLIO_E_HIP;
             }
         }
-        double ca = 0, cb = 1, snorm = -1;
-        if (step_valid) {
-            const double gnorm = std::sqrt(gg), gnn = std::sqrt(nn2);
-            if (gnn <= radius) { ca = 0; cb = 1; snorm = gnn; }
-            else if (gnorm * alpha >= radius) { ca = -(radius / gnorm); cb = 0; snorm = radius; }
-            else {
-                const double b_dot_a = -alpha * gd, a_sq = alpha * alpha * gg;
-                const double b_minus_a_sq = nn2 - 2 * b_dot_a + a_sq, c = b_dot_a - a_sq;
-                const double d = std::sqrt(c * c + b_minus_a_sq * (radius * radius - a_sq));
-                const double beta = (c <= 0) ? (d - c) / b_minus_a_sq : (radius * radius - a_sq) / (d + c);
-                ca = -alpha * (1.0 - beta); cb = beta;
-            }
-            hipLaunchKernelGGL(k_bt_step, dim3(nbv), dim3(TRV_THREADS), 0, st, ca, cb, BV(b, V_GR), BV(b, V_GN), BV(b, V_DG), BV(b, V_SC),
-                               BV(b, V_ST), BV(b, V_HS), BV(b, V_DL), n);
-            // model cost change = -(gs . s + s^T Hs s / 2)
-            hipLaunchKernelGGL(k_bt_matvec, dim3(nbv), dim3(TRV_THREADS), 0, st, s->d_Hs, K, band, BV(b, V_ST), BV(b, V_TT));
-            double d4[4];
-            rc = dots(3, BV(b, V_GS), BV(b, V_ST), BV(b, V_ST), BV(b, V_TT), BV(b, V_HS), BV(b, V_HS), nullptr, nullptr, d4);
-            if (rc) return rc;
-            const double mcc = -(d4[0] + 0.5 * d4[1]);
-            if (snorm < 0) snorm = std::sqrt(d4[2]);
-            dogleg_step_norm = snorm;
-            if (!(mcc > 0.0)) step_valid = false;
-            else {
-                invalid = 0;
-                hipLaunchKernelGGL(k_bt_plus, dim3((K + 255) / 256), dim3(256), 0, st, s->d_x[cur], BV(b, V_DL), K, s->d_x[1 - cur]);
-                rc = linearize(1 - cur);
-                if (rc) return rc;
-                const double ccost = s->h_red[15];
-                hipLaunchKernelGGL(k_bt_state_norms, dim3(1), dim3(TRV_THREADS), 0, st, s->d_x[cur], s->d_x[1 - cur], gcur, K, s->d_red + 4 * 256 + 4);
-                BT_CHECK(hipMemcpyAsync(s->h_red + 4, s->d_red + 4 * 256 + 4, 3 * 8, hipMemcpyDeviceToHost, st));
-                BT_CHECK(hipStreamSynchronize(st));
-                const double step_norm = std::sqrt(s->h_red[4]), x_norm = std::sqrt(s->h_red[5]);
-                if (step_norm <= o->parameter_tolerance * (x_norm + o->parameter_tolerance)) { sum->termination = GLIO_TERM_PARAMETER_TOL; break; }
-                if (std::fabs(current_cost - ccost) <= o->function_tolerance * current_cost) { sum->termination = GLIO_TERM_FUNCTION_TOL; break; }
-                const double rel = (current_cost - ccost) / mcc;
-                const double hist = (reference_cost - ccost) / (acc_ref + mcc);
-                const double quality = max_nonmono > 0 ? std::max(rel, hist) : rel;
-                if (quality > o->min_relative_decrease) {
-                    cur = 1 - cur;
-                    sum->successful_steps += 1;
-                    if (quality < 0.25) radius *= 0.5;
-                    if (quality > 0.75) radius = std::max(radius, 3.0 * dogleg_step_norm);
-                    mu = std::max(1e-8, 2.0 * mu / 10.0);
-                    reuse = 0;
-                    current_cost = ccost;
-                    acc_cand += mcc; acc_ref += mcc;
-                    if (current_cost < minimum_cost) { minimum_cost = current_cost; n_nonmono = 0; candidate_cost = current_cost; acc_cand = 0; }
-                    else { ++n_nonmono; if (current_cost > candidate_cost) { candidate_cost = current_cost; acc_cand = 0; } }
-                    if (n_nonmono == max_nonmono) { reference_cost = candidate_cost; acc_ref = acc_cand; }
-                } else { radius *= 0.5; reuse = 1; }
-                continue;
-            }
-        }
-        // invalid step
-        if (++invalid >= 5) { sum->termination = GLIO_TERM_FAILURE; break; }
-        mu *= 10.0; reuse = 0;
+        if (finished) break;
     }
-    sum->iterations = iteration;
-    sum->final_cost = current_cost;
-    sum->final_radius = radius;
-    sum->n_lidar_residuals = (int32_t)std::min<int64_t>(b->n_con, 2147483647);
-    BT_CHECK(hipMemcpyAsync(b->h_poses, s->d_x[cur], (size_t)K * 7 * 8, hipMemcpyDeviceToHost, st));
+    std::atomic_thread_fence(std::memory_order_acquire);
+    BT_CHECK(hipMemcpyAsync(s->h_x, s->d_xmin, (size_t)K * 7 * 8, hipMemcpyDeviceToHost, st));
+    if (s->n_imu > 0) BT_CHECK(hipMemcpyAsync(s->h_x + (size_t)K * 7, s->d_smin, (size_t)K * 9 * 8, hipMemcpyDeviceToHost, st));
     BT_CHECK(hipStreamSynchronize(st));
-    memcpy(poses, b->h_poses, (size_t)K * 7 * 8);
-    if (sum->termination == GLIO_TERM_FAILURE) { glio_set_error("batch trust-region solver failure (mu %g, iteration %d)", mu, iteration); return GLIO_E_NUMERIC; }
+    const BtStatus res = *s->h_res;
+    if (!res.done || res.solve_id != id) { glio_set_error("batch solve did not finish"); return GLIO_E_STATE; }
+    memcpy(poses, s->h_x, (size_t)K * 7 * 8);
+    if (s->n_imu > 0) memcpy(speed_bias, s->h_x + (size_t)K * 7, (size_t)K * 9 * 8);
+    sum->iterations = res.iteration; sum->successful_steps = res.successful; sum->termination = res.termination;
+    sum->initial_cost = res.initial_cost; sum->final_cost = res.user_min_cost; sum->final_radius = res.radius; sum->gradient_max_norm = res.grad_max;
+    sum->n_lidar_residuals = (int32_t)std::min<int64_t>(b->n_con, 2147483647);
+    if (res.termination == GLIO_TERM_FAILURE) { glio_set_error("batch trust-region solver failure (mu %g, iteration %d)", res.mu, res.iteration); rc = GLIO_E_NUMERIC; }
+    return rc;
+}
+int glio_batch_solve_tr(glio_batch* b, double* poses, const glio_batch_tr_opts* o, glio_allreduce_fn allreduce, void* user, glio_summary* sum) {
+    if (b && b->small && b->small->n_imu > 0) { glio_set_error("the IMU chain is set: use glio_batch_solve_tr2"); return GLIO_E_STATE; }
+    return glio_batch_solve_tr2(b, poses, nullptr, o, allreduce, user, sum);
+}
+// counters of the last solves (bench / tests): hook calls, doubles handed to the hook, trust-region groups enqueued, BCR levels; reset on read
+int glio_batch_debug_counters(glio_batch* b, int64_t* out4) {
+    if (!b || !b->small || !out4) return GLIO_E_ARG;
+    BatchSmall* s = b->small;
+    out4[0] = s->hook_calls; out4[1] = s->hook_doubles; out4[2] = s->groups; out4[3] = s->bcr ? glio_bcr_levels(s->bcr) : 0;
+    s->hook_calls = s->hook_doubles = s->groups = 0;
     return GLIO_OK;
 }
 

@@ -44,7 +44,7 @@ GnssDevExtra* glio_extra(glio_ctx* c) { return &extra_of(c)->gx; }
 
 extern "C" {
 
-int glio_abi_version(void) { return 3; }   // 3: glio_opts.lidar_precision, the batch pose problem (small factors, trust-region solve), 9 struct sizes
+int glio_abi_version(void) { return 4; }   // 3: glio_opts.lidar_precision, the batch pose problem (small factors, trust-region solve), 9 struct sizes
 const char* glio_last_error(void) { return g_err; }
 int glio_device_count(void) {
     int n = 0;
@@ -351,6 +351,8 @@ static bool inv15(const double* A_in, double* Ainv) {
 }
 // sqrt_info = LLT(cov^-1).matrixL().transpose()  (ImuFactor.h:44-45) -- the reference recomputes this on
 // the CPU in every Evaluate; it only depends on the pre-integration, so it is digested once at upload (Q5).
+static bool digest_edge(const glio_preint* p, int slot, ImuEdgeDev* e);
+extern "C++" bool glio_digest_imu_edge(const glio_preint* p, int slot, ImuEdgeDev* e) { return digest_edge(p, slot, e); }
 static bool digest_edge(const glio_preint* p, int slot, ImuEdgeDev* e) {
     memset(e, 0, sizeof *e);
     memcpy(e->delta_p, p->delta_p, 24); memcpy(e->delta_q, p->delta_q, 32); memcpy(e->delta_v, p->delta_v, 24);

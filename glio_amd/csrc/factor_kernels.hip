@@ -17,6 +17,7 @@
 // These factors are tiny (LDS/latency-bound, not roofline material); the point of having them on device
 // is that a whole trust-region solve runs without a host round trip.
 #include "k3_device.h"
+#include "batch_device.h"
 
 #define SF_THREADS 256
 
@@ -1055,6 +1056,27 @@ __global__ void k_eval_lidar(const LidarEvalArgs a, const double* params, double
         }
         out[5 + k] = a.score * d_dot3(a.n, col);
     }
+}
+
+// The ImuFactor chain of the batch problem (Estimator.cpp:2990-3001; batch_tr_kernels.hip): one workgroup per edge e in
+// [e0, e1) between keyframes e and e + 1 of the poses [K][7] / speed-bias [K][9] arrays picked by `sel`; the 30 x 30 local
+// J^T J, J^T r and the cost go to rec[e] (the same device code as the sliding window's IMU role).
+__global__ __launch_bounds__(SF_THREADS) void k_batch_imu(const BtSel sel, const double gravity, const ImuEdgeDev* __restrict__ edges, const int e0,
+                                                          const double* __restrict__ poses0, const double* __restrict__ poses1,
+                                                          const double* __restrict__ sb0, const double* __restrict__ sb1, PairBlock* rec0, PairBlock* rec1) {
+    __shared__ __attribute__((aligned(16))) unsigned char pool[sizeof(ImuLds)];
+    if (bt_skip(sel)) return;
+    const int pick = bt_pick(sel), e = e0 + blockIdx.x;
+    const double* poses = pick ? poses1 : poses0;
+    const double* sb = pick ? sb1 : sb0;
+    PairBlock* rec = pick ? rec1 : rec0;
+    const double* pi = poses + 7 * (size_t)e;
+    const double* pj = poses + 7 * (size_t)(e + 1);
+    imu_block(gravity, pi, pi + 3, sb + 9 * (size_t)e, pj, pj + 3, sb + 9 * (size_t)(e + 1), edges[e], rec + e, nullptr, 0, pool);
+}
+void glio_launch_batch_imu(hipStream_t stream, const BtSel& sel, double gravity, const ImuEdgeDev* edges, int e0, int e1, const double* poses0, const double* poses1,
+                           const double* sb0, const double* sb1, PairBlock* rec0, PairBlock* rec1) {
+    if (e1 > e0) hipLaunchKernelGGL(k_batch_imu, dim3(e1 - e0), dim3(SF_THREADS), 0, stream, sel, gravity, edges, e0, poses0, poses1, sb0, sb1, rec0, rec1);
 }
 
 void glio_launch_eval_imu(glio_ctx* c, const ImuEdgeDev* d_edge, const double* d_params, double* d_out) {

@@ -39,12 +39,17 @@ class GlioBatchTrOpts(C.Structure):
     _fields_ = [("max_iterations", C.c_int32), ("use_nonmonotonic_steps", C.c_int32), ("max_consecutive_nonmonotonic_steps", C.c_int32),
                 ("jacobi_scaling", C.c_int32), ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
                 ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double), ("function_tolerance", C.c_double),
-                ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double)]
+                ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double), ("dogleg_type", C.c_int32), ("reserved_", C.c_int32)]
 
 
-def batch_tr_opts(max_iterations=100):
-    """ceres::Solver::Options of the batch solve (Estimator.cpp:3275-3281, yaml max_num_iter: 100) + Ceres 1.14 defaults."""
+DOGLEG_TRADITIONAL, DOGLEG_SUBSPACE = 0, 1
+
+
+def batch_tr_opts(max_iterations=100, dogleg=DOGLEG_SUBSPACE):
+    """ceres::Solver::Options of the batch solve (Estimator.cpp:3275-3281: DOGLEG, SUBSPACE_DOGLEG, non-monotonic steps; yaml
+    max_num_iter: 100) + Ceres 1.14 defaults."""
     o = GlioBatchTrOpts()
+    o.dogleg_type = dogleg
     o.max_iterations, o.use_nonmonotonic_steps, o.max_consecutive_nonmonotonic_steps, o.jacobi_scaling = max_iterations, 1, 5, 1
     o.initial_trust_region_radius, o.max_trust_region_radius, o.min_trust_region_radius = 1e4, 1e16, 1e-32
     o.min_relative_decrease, o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance = 1e-3, 1e-6, 1e-10, 1e-8

@@ -172,8 +172,9 @@ int glio_time_solve(glio_ctx* ctx, const glio_state* state, int reps, float* ms_
  * no loss function :2768) and their J^T J / J^T r build.  Unknowns: K keyframe poses (t, q), local size 6 K;
  * H is block banded: block (k, k+d), d = 0..band, stored at Hg[(k*(band+1)+d)*36 ...] (row-major 6x6),
  * followed by g [K][6] and the cost (1 double): Hg has glio_batch_hg_size(K, band) doubles.
- * Each rank loads only ITS constraints; the ranks' Hg buffers are summed with one RCCL all-reduce (by the
- * caller: torch.distributed / rccl on the device pointer), then every rank runs the same banded solve.
+ * Each rank loads only ITS constraints.  Damped Gauss-Newton path (glio_batch_linearize_dev / _step_dev): the ranks' Hg buffers are
+ * summed with one RCCL all-reduce by the caller, then every rank runs the same banded solve.  Trust-region path
+ * (glio_batch_solve_tr2, below): everything is sharded, see there.
  * Pointers named *_dev are DEVICE pointers (e.g. torch tensors); the others are host memory. */
 typedef struct glio_batch glio_batch;
 int64_t glio_batch_hg_size(int K, int band);
@@ -197,22 +198,42 @@ int glio_batch_linearize_dev(glio_batch* b, const double* poses, double* Hg_dev)
  * the device and returns poses (+) d; *model_decrease = -(g.d + d^T H d / 2).  poses_out may alias poses_in. */
 int glio_batch_step_dev(glio_batch* b, const double* Hg_dev, double lambda, const double* poses_in, double* poses_out,
                         double* model_decrease);
-/* ---- the rest of the batch problem on keyframe poses + its trust-region solve (Estimator.cpp:2739-3410 without the IMU chain).
+/* ---- the rest of the batch problem and its trust-region solve (Estimator.cpp:2739-3410, sms_fusion_level 1).
  * glio_batch_set_small_factors: delta_q_factor_auto attitude constraints (Estimator.cpp:2831-2891; dq_const [n_dq][4] = const_diff,
  *   blocks q[dq_i], q[dq_j]) and dd_psr_factor_20 per GNSS epoch (Estimator.cpp:3197-3271; slot_i / slot_j = leftKey / rightKey,
  *   identity weight and the station position as addDDPsrResFactor_gl passes them, :1899-1911; `threshold` = DDpsr_threshold of the
- *   current outer round, :2764-2767).  They are small and identical on every rank: each rank adds them itself AFTER the all-reduce.
- * glio_batch_add_small_dev: adds them, evaluated at `poses`, into a (reduced) buffer.
- * glio_batch_solve_tr: ceres::Solve of Estimator.cpp:3275-3284 (DOGLEG, non-monotonic steps, max_num_iter) on the device; the
- *   `allreduce` hook (NULL = one rank) is called with this rank's linearisation (device pointer, doubles, HIP stream, user) and
- *   must leave the sum over the ranks in place -- ncclAllReduce on that stream in C++, torch.distributed.all_reduce in Python.
- *   Traditional dogleg in place of SUBSPACE_DOGLEG (a stated deviation); poses [K][7] in/out. */
+ *   current outer round, :2764-2767).  Given whole on every rank; a rank keeps the factors whose first keyframe it owns.
+ * glio_batch_set_imu: the ImuFactor chain between consecutive keyframes (Estimator.cpp:2990-3001; gl_tmpSpeedBias blocks :2809-2819):
+ *   edges[k] = the pre-integration between keyframes k and k + 1 (the caller decides which interval that is),
+ *   n_edges = K - 1, or 0 for the pose-only problem.  With the chain every keyframe has 15 unknowns (band <= 6).
+ * glio_batch_set_shard / glio_batch_shard_range: this object is rank `rank` of `world`; it owns a contiguous range of whole
+ *   super-blocks of keyframes (6, or 12 for bands > 6).  The constraints handed to glio_batch_set_constraints* must have their source
+ *   keyframe (ci) in that range.  Call before glio_batch_set_small_factors.
+ * glio_batch_solve_tr2: ceres::Solve of Estimator.cpp:3275-3284 (DOGLEG, opts->dogleg_type = SUBSPACE_DOGLEG, non-monotonic steps,
+ *   max_num_iter), device resident -- the host feeds kernel groups and synchronises once per solve.  Returns, as Ceres does, the
+ *   iterate of least cost (poses [K][7] in/out, speed_bias [K][9] in/out with the IMU chain) and that cost as final_cost.
+ *   `allreduce` (NULL = one rank) is called with a device buffer, its length in doubles, the HIP stream it is produced and consumed on
+ *   and `user`; it must leave the sum over the ranks in place ORDERED ON THAT STREAM (ncclAllReduce on it in C++;
+ *   torch.distributed.all_reduce with that stream current in Python) -- the host does not wait for it.  Per trust-region iteration:
+ *   the assembly buffer (band rows next to the range boundaries + diagonal + gradient + cost), the separator system of the block
+ *   cyclic reduction, the Gauss-Newton step, and two 64-byte buffers of curvature sums; every rank the same sequence.
+ * glio_batch_linearize_full: one linearisation through the same path (parity hook): diag(H) [n], g [n], cost, n = (6 | 15) K. */
 typedef void (*glio_allreduce_fn)(double* dev, int64_t count, void* hip_stream, void* user);
+int glio_batch_shard_range(int K, int band, int rank, int world, int32_t* lo, int32_t* hi);
+int glio_batch_set_shard(glio_batch* b, int rank, int world);
 int glio_batch_set_small_factors(glio_batch* b, const glio_gnss_frame* frame, int n_dq, const int32_t* dq_i, const int32_t* dq_j,
                                  const double* dq_const, int n_dd, const glio_dd_psr* dd);
 int glio_batch_set_dd_threshold(glio_batch* b, double threshold);   /* the next round's DDpsr_threshold, factors stay on the device */
-int glio_batch_add_small_dev(glio_batch* b, const double* poses, double* Hg_dev);
+int glio_batch_set_imu(glio_batch* b, int n_edges, const glio_preint* edges, double gravity);
+int glio_batch_add_small_dev(glio_batch* b, const double* poses, double* Hg_dev);      /* damped Gauss-Newton path, one rank */
+int glio_batch_linearize_full(glio_batch* b, const double* poses, const double* speed_bias, glio_allreduce_fn allreduce, void* user,
+                              double* diag, double* grad, double* cost);
+int glio_batch_solve_tr2(glio_batch* b, double* poses, double* speed_bias, const glio_batch_tr_opts* opts, glio_allreduce_fn allreduce,
+                         void* user, glio_summary* summary);
+/* the pose-only problem (no IMU chain set) */
 int glio_batch_solve_tr(glio_batch* b, double* poses, const glio_batch_tr_opts* opts, glio_allreduce_fn allreduce, void* user, glio_summary* summary);
+/* hook calls, doubles handed to the hook, trust-region groups enqueued, elimination levels since the last call (reset on read) */
+int glio_batch_debug_counters(glio_batch* b, int64_t* out4);
 
 /* For a C++ host that never includes HIP headers (glio_amd/host/glio_batch_backend.hpp): the reduced buffer
  * [H band | g | cost] as a device allocation, the batch stream to hand to ncclAllReduce between glio_batch_linearize_dev and

@@ -191,7 +191,10 @@ typedef struct glio_batch_tr_opts {
     double function_tolerance;                   /* 1e-6 */
     double gradient_tolerance;                   /* 1e-10 */
     double parameter_tolerance;                  /* 1e-8 */
+    int32_t dogleg_type;                         /* GLIO_DOGLEG_SUBSPACE: options.dogleg_type = SUBSPACE_DOGLEG, Estimator.cpp:3278 */
+    int32_t reserved_;
 } glio_batch_tr_opts;
+enum { GLIO_DOGLEG_TRADITIONAL = 0, GLIO_DOGLEG_SUBSPACE = 1 };
 
 /* One scan-to-multiscan constraint of the batch stage (BinaryLidarPlaneNormFactor,
  * LidarKeyframeFactor.h:124-164; built Estimator.cpp:3048,3071). */

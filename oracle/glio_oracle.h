@@ -82,6 +82,8 @@ int orc_linearize(const orc_problem* p, const glio_state* x, double* H, double* 
 void orc_set_threads(int t);
 /* Ceres-1.14 trust-region (traditional dogleg, dense normal Cholesky, Jacobi scaling) */
 int orc_solve(const orc_problem* p, glio_state* x, glio_summary* summary);
+/* the same, recording per iteration (candidate cost, radius the step was computed with, |x - candidate|): history [max_iterations][3] */
+int orc_solve_history(const orc_problem* p, glio_state* x, glio_summary* summary, double* history);
 
 /* ---- correspondence search (Estimator.cpp:3633-3708): brute-force exact 5-NN + plane fit.
  * out arrays have capacity n_scan; returns the number of correspondences kept, in scan order. */
@@ -134,15 +136,29 @@ typedef struct orc_batch_problem {
     int32_t n_dq; const int32_t* dq_i; const int32_t* dq_j; const double* dq_const;      /* [n_dq][4] const_diff = qi^-1 qj at construction (w,x,y,z) */
     int32_t n_dd; const glio_dd_psr* dd;                                                /* slot_i / slot_j = keyframe indices (leftKey, rightKey) */
     glio_gnss_frame frame;
+    /* the IMU chain (Estimator.cpp:2990-3001): n_imu = 0 (pose-only problem, 6 unknowns per keyframe) or K - 1: imu[k] is the
+     * pre-integration of the ImuFactor between keyframes k and k + 1 (the caller decides which interval that is, quirk Q11);
+     * then every keyframe carries its speed-bias block (:2809-2819) and 15 unknowns */
+    int32_t n_imu; int32_t pad_; const glio_preint* imu; double gravity;
 } orc_batch_problem;
 /* delta_q_factor_auto (LidarKeyframeFactor.h:283-303): blocks qi[4], qj[4]; 3 residuals = 10000 (dq^-1 qi^-1 qj).vec; global Jacobians 3x4 */
 int orc_eval_delta_q(const double dq_const[4], double const* const* parameters, double* residuals, double** jacobians);
 /* banded normal equations of ALL factors (layout as orc_batch_linearize) */
 int orc_batch_linearize_full(const orc_batch_problem* p, const double* poses, double* Hband, double* g, double* cost);
-/* Ceres-1.14 trust region on the batch problem: Jacobi scaling, TRADITIONAL dogleg (the reference asks for SUBSPACE_DOGLEG: the
- * same two-dimensional subspace, minimised exactly there and along the dogleg path here -- a stated deviation of the
- * restatement), non-monotonic step acceptance (TrustRegionStepEvaluator), dense Cholesky.  poses [K][7] in/out. */
+/* Ceres-1.14 trust region on the batch problem (orc_batch2.c): Jacobi scaling, DOGLEG with o->dogleg_type (the reference:
+ * SUBSPACE_DOGLEG, Estimator.cpp:3278), non-monotonic step acceptance (TrustRegionStepEvaluator), the returned point is the one
+ * of least cost (Ceres copies x to the user's parameters only when x_cost < minimum_cost) and final_cost that minimum, dense
+ * Cholesky.  poses [K][7] in/out; speed_bias [K][9] in/out when p->n_imu > 0 (NULL otherwise).
+ * history (may be NULL): [max_iterations + 1][4] = candidate cost, radius, |x - candidate|, step quality per iteration (row 0: start). */
+int orc_batch2_dim(const orc_batch_problem* p);
+int orc_batch2_linearize(const orc_batch_problem* p, const double* poses, const double* speed_bias, double* H /*[n][n]*/, double* g, double* cost);
+int orc_batch2_solve(const orc_batch_problem* p, const glio_batch_tr_opts* o, double* poses, double* speed_bias, glio_summary* summary, double* history);
+/* the pose-only problem (p->n_imu must be 0) */
 int orc_batch_solve(const orc_batch_problem* p, const glio_batch_tr_opts* o, double* poses, glio_summary* summary);
+/* pieces of the subspace dogleg, exposed for the pins in tests/: real parts of all roots of a polynomial (leading coefficient
+ * first; Ceres' FindPolynomialRoots) and FindMinimumOnTrustRegionBoundary of the 2-D model (B row-major 2x2) */
+int orc_poly_roots_real(const double* coeffs, int degree, double* roots_real, int* n_roots);
+int orc_subspace_boundary_minimum(const double B[4], const double g[2], double radius, double out[2]);
 
 #ifdef __cplusplus
 }

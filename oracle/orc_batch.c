@@ -152,172 +152,8 @@ int orc_batch_linearize_full(const orc_batch_problem* p, const double* poses, do
     return 1;
 }
 
-/* ------------------------------------------------------------------------------------------------
- * Trust-region minimiser of the batch problem: Ceres 1.14 TrustRegionMinimizer + DoglegStrategy(TRADITIONAL_DOGLEG) +
- * TrustRegionStepEvaluator (non-monotonic steps), dense Cholesky of the 6K x 6K matrix built from the band.
- */
-static void batch_plus(const double* poses, int K, const double* delta, double* out) {
-    for (int k = 0; k < K; ++k) {
-        for (int c = 0; c < 3; ++c) out[7 * k + c] = poses[7 * k + c] + delta[6 * k + c];
-        orc_quat_plus(poses + 7 * k + 3, delta + 6 * k + 3, out + 7 * k + 3);
-    }
-}
-static void band_to_dense(const double* Hb, int K, int band, double* H) {
-    const int n = 6 * K;
-    memset(H, 0, sizeof(double) * (size_t)n * n);
-    for (int k = 0; k < K; ++k)
-        for (int d = 0; d <= band && k + d < K; ++d) {
-            const double* blk = Hb + ((size_t)k * (band + 1) + d) * 36;
-            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) {
-                H[(size_t)(6 * k + r) * n + 6 * (k + d) + c] = blk[r * 6 + c];
-                if (d) H[(size_t)(6 * (k + d) + c) * n + 6 * k + r] = blk[r * 6 + c];
-            }
-        }
-}
-
+/* The trust-region minimiser lives in orc_batch2.c (it also covers the IMU chain); the pose-only entry point: */
 int orc_batch_solve(const orc_batch_problem* p, const glio_batch_tr_opts* o, double* x, glio_summary* sum) {
-    const int K = p->K, band = p->band, n = 6 * K;
-    const size_t nn = (size_t)n * n, hb = (size_t)K * (band + 1) * 36;
-    double* Hb = (double*)malloc(sizeof(double) * hb);
-    double* H = (double*)malloc(sizeof(double) * nn);
-    double* Hs = (double*)malloc(sizeof(double) * nn);
-    double* L = (double*)malloc(sizeof(double) * nn);
-    double* g = (double*)malloc(sizeof(double) * n);
-    double* gc = (double*)malloc(sizeof(double) * n);
-    double* Hbc = (double*)malloc(sizeof(double) * hb);
-    double* gs = (double*)malloc(sizeof(double) * n);
-    double* scale = (double*)malloc(sizeof(double) * n);
-    double* diag = (double*)malloc(sizeof(double) * n);
-    double* grad = (double*)malloc(sizeof(double) * n);
-    double* gn = (double*)calloc(n, sizeof(double));
-    double* step = (double*)malloc(sizeof(double) * n);
-    double* delta = (double*)malloc(sizeof(double) * n);
-    double* tmp = (double*)malloc(sizeof(double) * n);
-    double* cand = (double*)malloc(sizeof(double) * 7 * K);
-    double* xn = (double*)malloc(sizeof(double) * 7 * K);
-    memset(sum, 0, sizeof *sum);
-    double cost;
-    int ok = orc_batch_linearize_full(p, x, Hb, g, &cost);
-    if (!ok) { sum->termination = GLIO_TERM_FAILURE; goto done; }
-    sum->initial_cost = cost;
-    for (int i = 0; i < n; ++i) { const int k = i / 6, r = i % 6; scale[i] = o->jacobi_scaling ? 1.0 / (1.0 + sqrt(Hb[((size_t)k * (band + 1)) * 36 + r * 7])) : 1.0; }
-    double radius = o->initial_trust_region_radius, mu = 1e-8, alpha = 0, dogleg_step_norm = 0;
-    int reuse = 0, iteration = 0, invalid = 0;
-    /* TrustRegionStepEvaluator */
-    double minimum_cost = cost, current_cost = cost, reference_cost = cost, candidate_cost = cost;
-    double acc_ref = 0, acc_cand = 0;
-    int n_nonmono = 0;
-    const int max_nonmono = o->use_nonmonotonic_steps ? o->max_consecutive_nonmonotonic_steps : 0;
-    sum->termination = GLIO_TERM_NO_CONVERGENCE;
-    for (;;) {
-        /* gradient max norm = | x - Plus(x, -g) |_inf */
-        for (int i = 0; i < n; ++i) tmp[i] = -g[i];
-        batch_plus(x, K, tmp, xn);
-        double gm = 0;
-        for (int i = 0; i < 7 * K; ++i) if (fabs(x[i] - xn[i]) > gm) gm = fabs(x[i] - xn[i]);
-        sum->gradient_max_norm = gm;
-        if (iteration >= o->max_iterations) { sum->termination = GLIO_TERM_NO_CONVERGENCE; break; }
-        if (gm <= o->gradient_tolerance) { sum->termination = GLIO_TERM_GRADIENT_TOL; break; }
-        if (radius <= o->min_trust_region_radius) { sum->termination = GLIO_TERM_MIN_RADIUS; break; }
-        ++iteration;
-        band_to_dense(Hb, K, band, H);
-        for (int i = 0; i < n; ++i) { gs[i] = scale[i] * g[i]; for (int j = 0; j < n; ++j) Hs[(size_t)i * n + j] = scale[i] * H[(size_t)i * n + j] * scale[j]; }
-        int step_valid = 1;
-        if (!reuse) {
-            for (int i = 0; i < n; ++i) {
-                double d = Hs[(size_t)i * n + i];
-                d = d < 1e-6 ? 1e-6 : (d > 1e32 ? 1e32 : d);
-                diag[i] = sqrt(d);
-                grad[i] = gs[i] / diag[i];
-            }
-            for (int i = 0; i < n; ++i) tmp[i] = grad[i] / diag[i];
-            double Jg2 = 0;
-            for (int i = 0; i < n; ++i) { double s = 0; for (int j = 0; j < n; ++j) s += Hs[(size_t)i * n + j] * tmp[j]; Jg2 += tmp[i] * s; }
-            double gg = 0;
-            for (int i = 0; i < n; ++i) gg += grad[i] * grad[i];
-            alpha = gg / Jg2;
-            int solved = 0;
-            while (mu < 1.0) {
-                memcpy(L, Hs, sizeof(double) * nn);
-                for (int i = 0; i < n; ++i) L[(size_t)i * n + i] += mu * diag[i] * diag[i];
-                if (chol_lower(L, n) == 0) {
-                    chol_solve(L, n, gs, tmp);
-                    int fin = 1;
-                    for (int i = 0; i < n; ++i) if (!isfinite(tmp[i])) fin = 0;
-                    if (fin) { solved = 1; break; }
-                }
-                mu *= 10.0;
-            }
-            if (!solved) step_valid = 0;
-            else for (int i = 0; i < n; ++i) gn[i] = -diag[i] * tmp[i];
-        }
-        {   /* ComputeTraditionalDoglegStep */
-            double gg = 0, nn2 = 0, gd = 0;
-            for (int i = 0; i < n; ++i) { gg += grad[i] * grad[i]; nn2 += gn[i] * gn[i]; gd += grad[i] * gn[i]; }
-            const double gnorm = sqrt(gg), gnn = sqrt(nn2);
-            if (gnn <= radius) { for (int i = 0; i < n; ++i) step[i] = gn[i]; dogleg_step_norm = gnn; }
-            else if (gnorm * alpha >= radius) { for (int i = 0; i < n; ++i) step[i] = -(radius / gnorm) * grad[i]; dogleg_step_norm = radius; }
-            else {
-                const double b_dot_a = -alpha * gd, a_sq = alpha * alpha * gg;
-                const double b_minus_a_sq = nn2 - 2 * b_dot_a + a_sq, c = b_dot_a - a_sq;
-                const double d = sqrt(c * c + b_minus_a_sq * (radius * radius - a_sq));
-                const double beta = (c <= 0) ? (d - c) / b_minus_a_sq : (radius * radius - a_sq) / (d + c);
-                double s2 = 0;
-                for (int i = 0; i < n; ++i) { step[i] = (-alpha * (1.0 - beta)) * grad[i] + beta * gn[i]; s2 += step[i] * step[i]; }
-                dogleg_step_norm = sqrt(s2);
-            }
-            for (int i = 0; i < n; ++i) step[i] /= diag[i];
-        }
-        double mcc;
-        {
-            double lin = 0, quad = 0;
-            for (int i = 0; i < n; ++i) { double s = 0; for (int j = 0; j < n; ++j) s += Hs[(size_t)i * n + j] * step[j]; quad += step[i] * s; lin += gs[i] * step[i]; }
-            mcc = -(lin + 0.5 * quad);
-        }
-        if (!(mcc > 0.0)) step_valid = 0;
-        if (!step_valid) {
-            if (++invalid >= 5) { sum->termination = GLIO_TERM_FAILURE; break; }
-            mu *= 10.0; reuse = 0;
-            continue;
-        }
-        invalid = 0;
-        for (int i = 0; i < n; ++i) delta[i] = step[i] * scale[i];
-        batch_plus(x, K, delta, cand);
-        double ccost;
-        if (!orc_batch_linearize_full(p, cand, Hbc, gc, &ccost)) { radius *= 0.5; reuse = 1; continue; }
-        {   /* ParameterToleranceReached */
-            double d2 = 0, x2 = 0;
-            for (int i = 0; i < 7 * K; ++i) { d2 += (x[i] - cand[i]) * (x[i] - cand[i]); x2 += x[i] * x[i]; }
-            if (sqrt(d2) <= o->parameter_tolerance * (sqrt(x2) + o->parameter_tolerance)) { sum->termination = GLIO_TERM_PARAMETER_TOL; break; }
-        }
-        if (fabs(current_cost - ccost) <= o->function_tolerance * current_cost) { sum->termination = GLIO_TERM_FUNCTION_TOL; break; }
-        /* TrustRegionStepEvaluator::StepQuality */
-        const double rel = (current_cost - ccost) / mcc;
-        const double hist = (reference_cost - ccost) / (acc_ref + mcc);
-        const double quality = max_nonmono > 0 ? (rel > hist ? rel : hist) : rel;
-        if (quality > o->min_relative_decrease) {
-            memcpy(x, cand, sizeof(double) * 7 * K);
-            memcpy(Hb, Hbc, sizeof(double) * hb);
-            memcpy(g, gc, sizeof(double) * n);
-            ++sum->successful_steps;
-            /* DoglegStrategy::StepAccepted(step_quality) */
-            if (quality < 0.25) radius *= 0.5;
-            if (quality > 0.75) radius = radius > 3.0 * dogleg_step_norm ? radius : 3.0 * dogleg_step_norm;
-            mu = mu * 2.0 / 10.0 > 1e-8 ? mu * 2.0 / 10.0 : 1e-8;
-            reuse = 0;
-            /* TrustRegionStepEvaluator::StepAccepted */
-            current_cost = ccost;
-            acc_cand += mcc; acc_ref += mcc;
-            if (current_cost < minimum_cost) { minimum_cost = current_cost; n_nonmono = 0; candidate_cost = current_cost; acc_cand = 0; }
-            else { ++n_nonmono; if (current_cost > candidate_cost) { candidate_cost = current_cost; acc_cand = 0; } }
-            if (n_nonmono == max_nonmono) { reference_cost = candidate_cost; acc_ref = acc_cand; }
-        } else { radius *= 0.5; reuse = 1; }
-    }
-    sum->iterations = iteration;
-    sum->final_cost = current_cost;
-    sum->final_radius = radius;
-done:
-    free(Hb); free(H); free(Hs); free(L); free(g); free(gc); free(Hbc); free(gs); free(scale); free(diag); free(grad); free(gn);
-    free(step); free(delta); free(tmp); free(cand); free(xn);
-    return sum->termination != GLIO_TERM_FAILURE;
+    if (p->n_imu != 0) return 0;
+    return orc_batch2_solve(p, o, x, NULL, sum, NULL);
 }

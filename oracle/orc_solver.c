@@ -336,7 +336,7 @@ static double state_diff_norm2(const glio_state* a, const glio_state* b, int W, 
     return acc;
 }
 
-int orc_solve(const orc_problem* p, glio_state* x, glio_summary* sum) {
+static int solve_impl(const orc_problem* p, glio_state* x, glio_summary* sum, double* history) {
     const glio_opts* o = &p->opts;
     const int W = o->window, n = 15 * W + x->n_ddt;
     const size_t nn = (size_t)n * n;
@@ -463,6 +463,7 @@ int orc_solve(const orc_problem* p, glio_state* x, glio_summary* sum) {
         if (!(mcc > 0.0)) step_valid = 0;
         if (!step_valid) {
             if (++invalid >= 5) { sum->termination = GLIO_TERM_FAILURE; break; }
+            if (history) { double* h = history + 3 * (iteration - 1); h[0] = cost; h[1] = dl.radius; h[2] = 0.0; }
             if (lm) { dl.radius /= decrease_factor; decrease_factor *= 2.0; }
             else { dl.mu *= 10.0; dl.reuse = 0; }  /* StepIsInvalid */
             continue;
@@ -477,6 +478,7 @@ int orc_solve(const orc_problem* p, glio_state* x, glio_summary* sum) {
         {
             const double step_norm = sqrt(state_diff_norm2(x, &cand, W, 0));
             const double x_norm = sqrt(state_norm2(x, W));
+            if (history) { double* h = history + 3 * (iteration - 1); h[0] = ccost; h[1] = dl.radius; h[2] = step_norm; }
             if (step_norm <= o->parameter_tolerance * (x_norm + o->parameter_tolerance)) { sum->termination = GLIO_TERM_PARAMETER_TOL; break; }
         }
         /* FunctionToleranceReached */
@@ -514,3 +516,7 @@ done:
     free(H); free(Hc); free(Hs); free(L); free(g); free(gc); free(gs); free(scale); free(step); free(delta); free(tmp); free(tmp2);
     return sum->termination != GLIO_TERM_FAILURE;
 }
+
+int orc_solve(const orc_problem* p, glio_state* x, glio_summary* sum) { return solve_impl(p, x, sum, NULL); }
+/* the same, recording per iteration (candidate cost, radius the step was computed with, |x - candidate|): history [max_iterations][3] */
+int orc_solve_history(const orc_problem* p, glio_state* x, glio_summary* sum, double* history) { return solve_impl(p, x, sum, history); }

@@ -115,6 +115,15 @@ class Problem:
         lib().orc_solve(C.byref(self.c), C.byref(cs), C.byref(summ))
         return s, summ
 
+    def solve_history(self, state):
+        """orc_solve_history: (state, summary, rows of (candidate cost, radius of the step, |x - candidate|) per iteration)"""
+        s = state.copy()
+        cs = s.c()
+        summ = T.GlioSummary()
+        hist = np.zeros((self.c.opts.max_iterations + 1, 3))
+        lib().orc_solve_history(C.byref(self.c), C.byref(cs), C.byref(summ), T.dptr(hist))
+        return s, summ, hist[:summ.iterations]
+
     def marginalize(self, state):
         W = self.win.W
         n = 6 * (W - 1) + 9
@@ -265,7 +274,8 @@ def batch_linearize(K, band, poses, ci, cj, cp, pnc, score):
 class OrcBatchProblem(C.Structure):
     _fields_ = [("K", C.c_int32), ("band", C.c_int32), ("n_con", C.c_int64), ("ci", T.c_int32_p), ("cj", T.c_int32_p), ("cp", T.c_float_p),
                 ("norm_cent", T.c_double_p), ("score", T.c_double_p), ("n_dq", C.c_int32), ("dq_i", T.c_int32_p), ("dq_j", T.c_int32_p),
-                ("dq_const", T.c_double_p), ("n_dd", C.c_int32), ("dd", C.POINTER(T.GlioDdPsr)), ("frame", T.GlioGnssFrame)]
+                ("dq_const", T.c_double_p), ("n_dd", C.c_int32), ("dd", C.POINTER(T.GlioDdPsr)), ("frame", T.GlioGnssFrame),
+                ("n_imu", C.c_int32), ("pad_", C.c_int32), ("imu", C.POINTER(T.GlioPreint)), ("gravity", C.c_double)]
 
 
 def eval_delta_q(dq_const, qi, qj, want_J=True):
@@ -280,7 +290,9 @@ class BatchProblem:
     """Owns the numpy buffers behind an orc_batch_problem: binary plane constraints, delta_q attitude constraints (i, j, const_diff),
     DD pseudorange factors (slot_i / slot_j = keyframe indices)."""
 
-    def __init__(self, K, band, ci, cj, cp, nc, score, dq=None, dd=None, frame=None):
+    def __init__(self, K, band, ci, cj, cp, nc, score, dq=None, dd=None, frame=None, imu=None, gravity=9.80511):
+        """imu: None (pose-only problem) or the K - 1 pre-integrations (dicts as synth.preintegrate returns, or GlioPreint) of the
+        ImuFactor chain (Estimator.cpp:2990-3001); then the unknowns are 15 per keyframe."""
         self.K, self.band = K, band
         self.ci = np.ascontiguousarray(ci, np.int32); self.cj = np.ascontiguousarray(cj, np.int32)
         self.cp = np.ascontiguousarray(cp, np.float32); self.nc = np.ascontiguousarray(nc, np.float64); self.score = np.ascontiguousarray(score, np.float64)
@@ -295,7 +307,42 @@ class BatchProblem:
         p.n_dd, p.dd = len(dd), self.dd
         if frame is not None:
             p.frame = frame
+        imu = list(imu) if imu is not None else []
+        assert len(imu) in (0, K - 1)
+        self.imu = (T.GlioPreint * max(len(imu), 1))()
+        for k, d in enumerate(imu):
+            if isinstance(d, T.GlioPreint):
+                self.imu[k] = d
+            else:
+                from glio_amd import synth
+                synth.fill_preint(self.imu[k], d)
+        p.n_imu, p.imu, p.gravity = len(imu), self.imu, gravity
+        self.n_imu = len(imu)
         self.c = p
+
+    @property
+    def dim(self):
+        return (15 if self.n_imu else 6) * self.K
+
+    def linearize_dense(self, poses, speed_bias=None):
+        """dense H, g, cost over [dt3 dtheta3 (dv3 dba3 dbg3)] per keyframe (orc_batch2_linearize)"""
+        n = self.dim
+        H = np.zeros((n, n)); g = np.zeros(n); cost = C.c_double()
+        sb = np.ascontiguousarray(speed_bias, float) if self.n_imu else None
+        ok = lib().orc_batch2_linearize(C.byref(self.c), T.dptr(np.ascontiguousarray(poses, float)), T.dptr(sb) if sb is not None else None, T.dptr(H), T.dptr(g), C.byref(cost))
+        assert ok
+        return H, g, cost.value
+
+    def solve2(self, poses, opts, speed_bias=None, want_history=False):
+        """orc_batch2_solve: returns (poses, speed_bias or None, summary[, history rows cost / radius / step norm / quality])"""
+        x = np.ascontiguousarray(poses, float).copy()
+        sb = np.ascontiguousarray(speed_bias, float).copy() if self.n_imu else None
+        summ = T.GlioSummary()
+        hist = np.zeros((opts.max_iterations + 1, 4))
+        lib().orc_batch2_solve(C.byref(self.c), C.byref(opts), T.dptr(x), T.dptr(sb) if sb is not None else None, C.byref(summ), T.dptr(hist) if want_history else None)
+        if want_history:
+            return x, sb, summ, hist[:summ.iterations]
+        return x, sb, summ
 
     def linearize(self, poses):
         K, band = self.K, self.band

@@ -38,12 +38,40 @@ def _worker(rank, world, port, K, band, per_kf, out_path):
 
 
 def test_shard_ranges_partition_the_keyframes():
-    for K in (7, 2000, 2001):
-        for world in (1, 2, 3, 8):
-            r = [batch.shard_range(K, k, world) for k in range(world)]
-            assert r[0][0] == 0 and r[-1][1] == K and all(a[1] == b[0] for a, b in zip(r, r[1:]))
-            sizes = [b - a for a, b in r]
-            assert max(sizes) - min(sizes) <= 1
+    """whole super-blocks of the block cyclic reduction (6 keyframes; 12 for bands > 6), spread as evenly as whole blocks allow;
+    the Python rule equals the library's (glio_batch_shard_range is host-only code: no GPU needed)"""
+    import ctypes as C
+    from glio_amd import capi
+    lib = capi.load()
+    for band in (4, 6, 12):
+        sbk = 6 if band <= 6 else 12
+        for K in (50, 2000, 2001):
+            for world in (1, 2, 3, 8):
+                if (K + sbk - 1) // sbk < world:
+                    continue
+                r = [batch.shard_range(K, k, world, band) for k in range(world)]
+                assert r[0][0] == 0 and r[-1][1] == K and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+                sizes = [b - a for a, b in r]
+                assert all(sz % sbk == 0 for sz in sizes[:-1]) and max(sizes) - min(sizes) <= 2 * sbk
+                for k in range(world):
+                    lo, hi = C.c_int32(), C.c_int32()
+                    assert lib.glio_batch_shard_range(K, band, k, world, C.byref(lo), C.byref(hi)) == 0
+                    assert (lo.value, hi.value) == r[k]
+
+
+def test_thread_ranks_harness_sums_in_rank_order():
+    """batch.ThreadRanks (the in-process stand-in for torch.distributed that the one-GPU tests of the sharded solve use)"""
+    world = 3
+    tr = batch.ThreadRanks(world)
+
+    def work(r, d):
+        t = torch.full((5,), float(r + 1), dtype=torch.float64)
+        d.all_reduce(t)
+        d.all_reduce(t)
+        return t
+
+    out = tr.run(work)
+    assert all(torch.equal(o, torch.full((5,), 18.0, dtype=torch.float64)) for o in out) and tr.calls == [2, 2, 2]
 
 
 def test_two_rank_allreduce_equals_single_rank(tmp_path):

@@ -49,28 +49,138 @@ def test_small_factors_added_after_the_reduce_match_the_oracle():
     st.close()
 
 
+def _stage(K, band, con, dq, dd, frame, imu=None, rank=0, world=1, threshold=None):
+    lo, hi = batch.shard_range(K, rank, world, band)
+    own = (con[0] >= lo) & (con[0] < hi)
+    mine = [c[own] for c in con]
+    st = batch.BatchStage(K, band, max(1, len(mine[0])))
+    if world > 1:
+        assert st.set_shard(rank, world) == (lo, hi)
+    st.set_constraints(*mine)
+    st.set_small_factors(dq, dd, frame, threshold=threshold)
+    if imu is not None:
+        st.set_imu(imu)
+    return st
+
+
 @pytest.mark.parametrize("with_small", [False, True])
-def test_trust_region_solve_follows_the_oracle(with_small):
+@pytest.mark.parametrize("dogleg", [T.DOGLEG_TRADITIONAL, T.DOGLEG_SUBSPACE])
+def test_trust_region_solve_follows_the_oracle(with_small, dogleg):
     K, band = 60, 6
     gt, init, con, dq, dd, frame = _problem(K, band, seed=35)
     if not with_small:
         dq, dd = None, []
     for f in dd:
         f.threshold = 10.0
-    st = batch.BatchStage(K, band, len(con[0]))
-    st.set_constraints(*con)
-    st.set_small_factors(dq, dd, frame)
-    opts = T.batch_tr_opts(max_iterations=30)
+    st = _stage(K, band, con, dq, dd, frame)
+    opts = T.batch_tr_opts(max_iterations=30, dogleg=dogleg)
     poses, summ = st.solve_tr(init, opts)
     want, wsum = _oracle(K, band, con, dq, dd, frame).solve(init, opts)
-    assert summ.iterations == wsum.iterations and summ.successful_steps == wsum.successful_steps and summ.termination == wsum.termination
+    assert summ.iterations == wsum.iterations and summ.successful_steps == wsum.successful_steps and summ.termination == wsum.termination, (summ.as_dict(), wsum.as_dict())
     assert np.isclose(summ.initial_cost, wsum.initial_cost, rtol=1e-12)
     assert np.isclose(summ.final_cost, wsum.final_cost, rtol=1e-9)
     assert np.abs(poses - want).max() < 1e-8
     assert summ.final_cost < 0.05 * summ.initial_cost
     if not with_small:
         assert np.abs(poses[:, :3] - gt[:, :3]).max() < 0.05
+    assert st.counters()["hook_calls"] == 0          # one rank: no collective at all
     st.close()
+
+
+def _imu_problem(K=48, band=6, per_kf=150, seed=51, perturb=(0.08, 0.004)):
+    gt, init = batch.make_poses(K, seed=seed, perturb=perturb)
+    ci, cj, cp, nc, score = batch.make_constraints(gt, 0, K, per_kf, band, seed=seed)
+    rng = np.random.default_rng(seed)
+    odo = gt.copy(); odo[:, :3] += rng.normal(0, 0.02, (K, 3))
+    dq = batch.delta_q_pairs(odo, 3)
+    dd, frame = batch.make_batch_gnss(gt, seed=seed)
+    for f in dd:
+        f.threshold = 10.0
+    imu, sb_gt, sb0 = batch.make_batch_imu(K, seed=seed)
+    return gt, init, (ci, cj, cp.numpy(), nc.numpy(), score.numpy()), dq, dd, frame, imu, sb0
+
+
+def test_linearisation_with_the_imu_chain_matches_the_oracle():
+    """diag(H), g and the cost of the 15-state problem (plane + delta_q + DD + ImuFactor chain) through the solver's own path"""
+    from oracle import pyoracle as po
+    K, band = 48, 6
+    gt, init, con, dq, dd, frame, imu, sb0 = _imu_problem(K, band)
+    st = _stage(K, band, con, dq, dd, frame, imu=imu)
+    diag, g, cost = st.linearize_full(init, sb0)
+    P = po.BatchProblem(K, band, *con, dq=dq, dd=dd, frame=frame, imu=imu)
+    H, gw, cw = P.linearize_dense(init, sb0)
+    assert abs(cost - cw) <= 1e-11 * cw
+    assert np.abs(diag - np.diag(H)).max() <= 1e-10 * np.diag(H).max()
+    assert np.abs(g - gw).max() <= 1e-10 * np.abs(gw).max()
+    st.close()
+
+
+@pytest.mark.parametrize("radius0", [1e4, 0.5])
+def test_trust_region_solve_with_the_imu_chain_follows_the_oracle(radius0):
+    """the complete batch problem: 15 unknowns per keyframe, SUBSPACE_DOGLEG, non-monotonic steps; the small initial radius makes
+    the first iterations boundary-constrained subspace steps (the quartic) and the run accepts cost-raising steps at the end"""
+    from oracle import pyoracle as po
+    K, band = 48, 6
+    gt, init, con, dq, dd, frame, imu, sb0 = _imu_problem(K, band, perturb=(0.3, 0.02) if radius0 < 1 else (0.08, 0.004))
+    st = _stage(K, band, con, dq, dd, frame, imu=imu)
+    opts = T.batch_tr_opts(max_iterations=16)
+    opts.initial_trust_region_radius = radius0
+    poses, sb, summ = st.solve_tr(init, opts, speed_bias=sb0)
+    P = po.BatchProblem(K, band, *con, dq=dq, dd=dd, frame=frame, imu=imu)
+    want, wsb, wsum = P.solve2(init, opts, sb0)
+    assert summ.iterations == wsum.iterations and summ.successful_steps == wsum.successful_steps and summ.termination == wsum.termination, (summ.as_dict(), wsum.as_dict())
+    assert np.isclose(summ.initial_cost, wsum.initial_cost, rtol=1e-12)
+    assert np.isclose(summ.final_cost, wsum.final_cost, rtol=1e-9)
+    assert np.abs(poses - want).max() < 1e-8 and np.abs(sb - wsb).max() < 1e-7
+    assert summ.final_cost < 0.01 * summ.initial_cost
+    st.close()
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("with_imu", [False, True])
+def test_sharded_solve_on_virtual_ranks_equals_one_rank(world, with_imu):
+    """`world` BatchStage objects in one process (one thread each, all on this GPU), each owning its keyframe range, its
+    constraints, its small factors and its IMU edges; the all-reduce hook sums the five small buffers per iteration across the
+    threads.  The sharded solve must take the same decisions as the one-rank solve and as the oracle."""
+    import torch
+    from oracle import pyoracle as po
+    K, band = 72, 6
+    gt, init, con, dq, dd, frame, imu, sb0 = _imu_problem(K, band, per_kf=90, seed=53)
+    if not with_imu:
+        imu, sb0 = None, None
+    opts = T.batch_tr_opts(max_iterations=12)
+    one = _stage(K, band, con, dq, dd, frame, imu=imu)
+    r1 = one.solve_tr(init, opts, speed_bias=sb0)
+    one.close()
+    ranks = batch.ThreadRanks(world, sync=torch.cuda.synchronize)
+    stages = [_stage(K, band, con, dq, dd, frame, imu=imu, rank=r, world=world) for r in range(world)]
+
+    def work(r, dist):
+        out = stages[r].solve_tr(init, opts, dist, speed_bias=sb0)
+        return out, stages[r].allreduce_sizes
+
+    res = ranks.run(work)
+    for st in stages:
+        st.close()
+    summ1 = r1[-1]
+    for (out, sizes) in res:
+        summ = out[-1]
+        assert summ.iterations == summ1.iterations and summ.termination == summ1.termination and summ.successful_steps == summ1.successful_steps
+        assert np.isclose(summ.final_cost, summ1.final_cost, rtol=1e-10)
+        assert np.abs(out[0] - r1[0]).max() < 1e-9
+        if with_imu:
+            assert np.abs(out[1] - r1[1]).max() < 1e-8
+        assert np.array_equal(out[0], res[0][0][0]), "every rank must hold the same result"
+        # five hook calls per trust-region group plus the initial assembly; the largest buffer is the separator system or the assembly
+        assert (len(sizes) - 1) % 5 == 0 and len(sizes) >= 1 + 5 * summ.iterations
+        B = 15 if with_imu else 6
+        assert max(sizes) < 0.5 * batch.hg_size(K, band) + 3 * (world - 1) * (6 * B) ** 2 + 3 * B * K
+    P = po.BatchProblem(K, band, *con, dq=dq, dd=dd, frame=frame, imu=imu)
+    if with_imu:
+        want, wsb, wsum = P.solve2(init, opts, sb0)
+    else:
+        want, wsum = P.solve(init, opts)
+    assert wsum.iterations == summ1.iterations and np.abs(res[0][0][0] - want).max() < 1e-8
 
 
 def test_threshold_rounds_downweight_the_pseudorange_outliers():
@@ -91,44 +201,3 @@ def test_threshold_rounds_downweight_the_pseudorange_outliers():
         ref, _ = po.BatchProblem(K, band, *con, dq=batch.delta_q_pairs(odo, 3), dd=dd, frame=frame).solve(ref, T.batch_tr_opts(max_iterations=30))
     assert np.abs(poses - ref).max() < 1e-7
     st.close()
-
-
-def test_allreduce_hook_sees_the_library_buffer_once_per_linearisation():
-    """The hook path of solve_tr with a stand-in for torch.distributed (one GPU here): the device buffer handed to the hook is the
-    [H | g | cost] of this rank BEFORE the small factors; summing it with itself (a 2-rank job whose ranks hold the same shard)
-    equals the solve with every plane constraint given twice."""
-    import torch
-    K, band = 30, 6
-    gt, init, con, dq, dd, frame = _problem(K, band, seed=39)
-
-    class FakeDist:
-        class ReduceOp:
-            SUM = "sum"
-
-        def __init__(self):
-            self.seen = []
-
-        def all_reduce(self, t, op=None):
-            assert t.is_cuda and t.dtype == torch.float64 and t.numel() == batch.hg_size(K, band)
-            self.seen.append(float(t[-1].item()))
-            t.mul_(2.0)
-
-    st = batch.BatchStage(K, band, len(con[0]))
-    st.set_constraints(*con)
-    st.set_small_factors(dq, dd, frame, threshold=10.0)
-    fd = FakeDist()
-    opts = T.batch_tr_opts(max_iterations=6)
-    poses, summ = st.solve_tr(init, opts, dist=fd)
-    assert st.allreduces == len(fd.seen) and len(fd.seen) >= 1 + summ.successful_steps
-    st.close()
-    twice = [np.concatenate([c, c]) for c in con]
-    order = np.lexsort((twice[1], twice[0]))
-    twice = [c[order] for c in twice]
-    st2 = batch.BatchStage(K, band, len(twice[0]))
-    st2.set_constraints(*twice)
-    st2.set_small_factors(dq, dd, frame, threshold=10.0)
-    want, wsum = st2.solve_tr(init, opts)
-    assert summ.iterations == wsum.iterations
-    assert np.isclose(summ.final_cost, wsum.final_cost, rtol=1e-10)
-    assert np.abs(poses - want).max() < 1e-9
-    st2.close()
