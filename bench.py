@@ -45,7 +45,14 @@ def main():
     ap.add_argument("--no-batch", action="store_true")
     ap.add_argument("--no-bassoc", action="store_true")
     ap.add_argument("--no-c5", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: the ranks only rendezvous (gloo) and rank 0 prints a line (CPU test of the launcher)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher around it: be the launcher (one process per GPU, RCCL rendezvous on 127.0.0.1)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
+    if args.dry_run:
+        return dry_run()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -169,7 +176,8 @@ def main():
     k3_ms = ctx.time_kernel(capi.KERNEL_LIDAR_LINEARIZE, 50)
     rd_ms = ctx.time_kernel(capi.KERNEL_STREAM_READ, 50)
     ctx.linearize(state, want_H=False)
-    la_ms = min(ctx.time_kernel(capi.KERNEL_LINEARIZE_ALL, 50) for _ in range(3))
+    la_runs = [ctx.time_kernel(capi.KERNEL_LINEARIZE_ALL, 50) for _ in range(3)]
+    la_ms = float(np.mean(la_runs))
     lin_ms = ctx.time_kernel(capi.KERNEL_FULL_LINEARIZE, 50)
     trs_ms = ctx.time_kernel(capi.KERNEL_TR_STEP, 20)
     marg_ms = ctx.time_kernel(capi.KERNEL_MARGINALIZE, 20)
@@ -181,7 +189,7 @@ def main():
     k3_alone = n_res * BYTES_PER_RESIDUAL / (k3_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": "k_linearize_all", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
-                "bytes_per_launch": n_res * BYTES_PER_RESIDUAL, "avg_launch_us": round(la_ms * 1e3, 2),
+                "bytes_per_launch": n_res * BYTES_PER_RESIDUAL, "avg_launch_us": round(la_ms * 1e3, 2), "min_of_3_averages_us": round(min(la_runs) * 1e3, 2),
                 "read_only_same_bytes_GBps": round(n_res * BYTES_PER_RESIDUAL / (rd_ms * 1e-3) / 1e9, 1),
                 "k3_standalone": {"kernel": "k_lidar_linearize", "avg_launch_us": round(k3_ms * 1e3, 2), "achieved": round(k3_alone, 1),
                                   "frac": round(k3_alone / HBM_PEAK_GBS, 4), "frac_of_read_only": round(rd_ms / k3_ms, 4)},
@@ -304,6 +312,45 @@ def main():
         dist.destroy_process_group()
 
 
+def launch_ranks(n):
+    """Spawn this script once per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (what torch.distributed.run would do);
+    rank 0's stdout is ours, so exactly one JSON line comes out.  Returns the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
+
+
+def dry_run():
+    """The launcher's CPU test: every rank joins a gloo group, an all-reduce proves they see each other, rank 0 prints a line."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "sliding-window solves/sec (64k pts, 20 keyframes)", "value": None, "n_gpus": world, "dry_run": True,
+                          "rank_sum": float(t.item())}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def bench_keyframe_pipeline(local_rank, stream, W):
     """One steady-state call of optimizeSlidingWindowWithLandMark with everything resident: slide the scans, upload ONE new
     scan, rebuild the local map on the device, associate all W slots (one call), solve, marginalize-and-keep.  The same
@@ -407,8 +454,8 @@ def bench_c3(local_rank, queries=131072, tiles=24):
     q2, t2 = lidar_pose(o, win.init.quat[0], win.init.trans[0])
     kept = ctx.associate(0, win.scans[0], q2, t2)
     t0 = _t.perf_counter(); ctx.associate_resident(0, q2, t2); t_call = _t.perf_counter() - t0
-    k2 = min(ctx.time_kernel(capi.KERNEL_ASSOCIATE, 10) for _ in range(3))
-    k1 = min(ctx.time_kernel(capi.KERNEL_MAP_BUILD, 5) for _ in range(2))
+    k2 = float(np.mean([ctx.time_kernel(capi.KERNEL_ASSOCIATE, 10) for _ in range(3)]))
+    k1 = float(np.mean([ctx.time_kernel(capi.KERNEL_MAP_BUILD, 5) for _ in range(2)]))
     info = {"workload": f"C3: {queries}-point scan vs a {len(big)}-point map (0.4 m voxel map of {tiles} parallel streets)",
             "queries": queries, "map_points": int(len(big)), "kept": int(kept), "associate_us": round(k2 * 1e3, 1),
             "associate_call_ms": round(t_call * 1e3, 3), "map_build_us": round(k1 * 1e3, 1), "set_map_call_incl_upload_ms": round(t_up * 1e3, 2),
@@ -442,9 +489,9 @@ def bench_c5(local_rank, W=50, pts=262144):
         ctx = capi.Context(o, device=local_rank)
         ctx.load_window(win, corr)
         ctx.linearize(win.init, want_H=False)
-        k3 = min(ctx.time_kernel(capi.KERNEL_LIDAR_LINEARIZE, 20) for _ in range(3))
-        rd = min(ctx.time_kernel(capi.KERNEL_STREAM_READ, 20) for _ in range(3))
-        la = min(ctx.time_kernel(capi.KERNEL_LINEARIZE_ALL, 20) for _ in range(3))
+        k3 = float(np.mean([ctx.time_kernel(capi.KERNEL_LIDAR_LINEARIZE, 20) for _ in range(3)]))
+        rd = float(np.mean([ctx.time_kernel(capi.KERNEL_STREAM_READ, 20) for _ in range(3)]))
+        la = float(np.mean([ctx.time_kernel(capi.KERNEL_LINEARIZE_ALL, 20) for _ in range(3)]))
         sol, summ = ctx.solve(win.init)
         reps = 5
         t0 = _t.perf_counter()
@@ -545,8 +592,8 @@ def bench_k3_large(local_rank, W=50, pts=262144):
     st = T.WindowState(W)
     st.quat[:, 0] = 1.0
     ctx.linearize(st, want_H=False)
-    k3 = min(ctx.time_kernel(capi.KERNEL_LIDAR_LINEARIZE, 20) for _ in range(3))
-    rd = min(ctx.time_kernel(capi.KERNEL_STREAM_READ, 20) for _ in range(3))
+    k3 = float(np.mean([ctx.time_kernel(capi.KERNEL_LIDAR_LINEARIZE, 20) for _ in range(3)]))
+    rd = float(np.mean([ctx.time_kernel(capi.KERNEL_STREAM_READ, 20) for _ in range(3)]))
     nres = W * pts
     out = {"workload": f"C5 shape: {W} keyframes x {pts} residuals", "bytes_per_launch": nres * BYTES_PER_RESIDUAL, "avg_launch_us": round(k3 * 1e3, 2),
            "achieved": round(nres * BYTES_PER_RESIDUAL / (k3 * 1e-3) / 1e9, 1), "frac": round(nres * BYTES_PER_RESIDUAL / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -611,90 +658,150 @@ def bench_batch_association(local_rank, K=16, pts=32768, search_range=6):
 
 
 def bench_batch_stage(args, rank, local_rank, world, dist, torch):
-    """BASELINE config C4: optimizeBatch scan-to-multiscan, K keyframes x per_kf pre-associated binary plane
-    constraints, sharded by source-keyframe range; one RCCL all-reduce of the block-banded [H|g|cost] buffer per
-    linearisation.  STRONG scaling (the total work is fixed); reported next to the headline, not as `value`."""
+    """BASELINE config C4: optimizeBatch, K keyframes x per_kf pre-associated binary plane constraints, sharded by source-keyframe
+    range (whole super-blocks of 6 keyframes).  STRONG scaling (the total work is fixed); reported next to the headline, not as
+    `value`.  Sections: the K8 linearisation kernel (72 B / constraint), the banded solve, the COMPLETE batch problem (plane +
+    delta_q + DD-pseudorange factors + the ImuFactor chain: 15 unknowns per keyframe) solved by the device-resident trust region
+    (SUBSPACE_DOGLEG, non-monotonic steps, four DDpsr_threshold rounds) with its five small collectives per iteration, the pose-only
+    variant, and -- on one GPU -- the per-rank time of an 8-rank job measured by replaying the recorded collective results."""
     import time as _t
     from glio_amd import batch
+    from glio_amd import ctypes_types as T
     K, band, per_kf = args.batch_keyframes, 6, args.batch_per_kf
     gt, init = batch.make_poses(K)
-    lo, hi = batch.shard_range(K, rank, world)
+    lo, hi = batch.shard_range(K, rank, world, band)
     dev = f"cuda:{local_rank}"
     ci, cj, cp, nc, score = batch.make_constraints(gt, lo, hi, per_kf, band, device=dev)
     st = batch.BatchStage(K, band, len(ci), device=local_rank)
+    if world > 1:
+        st.set_shard(rank, world)
     st.set_constraints(ci, cj, cp, nc, score)
-    t_ar = []
-
-    def timed_allreduce(Hg):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); dist.all_reduce(Hg, op=dist.ReduceOp.SUM); e1.record(); torch.cuda.synchronize()
-        t_ar.append(e0.elapsed_time(e1))
-    drv = batch.ShardedBatchSolve(st, dist, on_allreduce=timed_allreduce if dist is not None else None)   # the driver the gloo tests exercise
-    lin = drv.linearize
-    bufs = drv._bufs
-    lin(init); lin(init)                                   # warm-up (RCCL communicator, caches)
-    t_ar.clear()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = _t.perf_counter()
-    reps = 5
-    for _ in range(reps):
-        Hg, cost0 = lin(init)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t_lin_wall = (_t.perf_counter() - t0) / reps
-    k8_ms = st.time_linearize(init, bufs[0], 5)
-    solve_bcr_ms = min(st.time_solve(bufs[0], 1e-4, 5) for _ in range(2))
-    st.set_solver(0); solve_seq_ms = st.time_solve(bufs[0], 1e-4, 1); st.set_solver(1)
-    lin(init)
-    t0 = _t.perf_counter()
-    poses, hist = batch.lm_solve(lin, st.step, init, iterations=3)
-    t_lm = (_t.perf_counter() - t0) / 3
+    Hg = st.new_hg()
+    k8_ms = st.time_linearize(init, Hg, 5)
     info = {"workload": f"C4: {K} keyframes x {per_kf} binary plane constraints, band +-{band}, sharded by source keyframe over {world} GPU(s)",
-            "scaling": "strong", "constraints_total": int(K) * int(per_kf), "constraints_this_rank": int(len(ci)),
+            "scaling": "strong", "constraints_total": int(K) * int(per_kf), "constraints_this_rank": int(len(ci)), "keyframes_this_rank": [int(lo), int(hi)],
             "linearize_kernels_ms": round(k8_ms, 4), "algorithmic_GBps_this_rank": round(len(ci) * 72 / (k8_ms * 1e-3) / 1e9, 1),
-            "allreduce_ms": round(float(np.mean(t_ar)), 4) if t_ar else 0.0, "allreduce_MB": round(batch.hg_size(K, band) * 8 / 1e6, 2),
-            "linearize_plus_allreduce_wall_ms": round(t_lin_wall * 1e3, 4), "lm_iteration_wall_ms": round(t_lm * 1e3, 3),
-            "banded_solve_ms": round(solve_bcr_ms, 4), "banded_solve": "block cyclic reduction over super-blocks of 6 keyframes (replicated on every rank)",
-            "banded_solve_sequential_one_workgroup_ms": round(solve_seq_ms, 3),
-            "collective": ("torch.distributed all_reduce (backend nccl = RCCL) on the device buffer" if dist is not None else "none (1 rank)"),
-            "cost_history": [round(h, 3) for h in hist]}
-    # ---- the full pose problem of optimizeBatch: plane constraints (sharded) + delta_q attitude constraints + DD pseudoranges
-    # (replicated, added after the reduce), Ceres-style dogleg trust region inside the library (glio_batch_solve_tr), the four
-    # DDpsr_threshold rounds of Estimator.cpp:2764-2767.  The correspondences are kept (no re-association between the rounds here).
-    try:
-        from glio_amd import ctypes_types as T
-        sr = band // 2
-        odo = gt.copy(); odo[:, :3] += np.random.default_rng(11).normal(0, 0.02, (K, 3))
-        dd, frame = batch.make_batch_gnss(gt, seed=11)
-        opts = T.batch_tr_opts(max_iterations=args.batch_tr_iterations)
-        batch.solve_batch_rounds(st, init, odo, sr, dd, frame, opts=T.batch_tr_opts(max_iterations=2), dist=dist)        # warm-up
+            "collective": (f"torch.distributed all_reduce (backend nccl = RCCL), {world} ranks, on the library's stream" if dist is not None and world > 1 else "none (1 rank)")}
+    if world == 1:
+        st.linearize(init, Hg)
+        info["banded_solve_ms"] = round(float(np.mean([st.time_solve(Hg, 1e-4, 5) for _ in range(2)])), 4)
+        info["banded_solve"] = "block cyclic reduction over super-blocks of 6 keyframes (pose problem, 36 x 36 blocks)"
+    sr = band // 2
+    odo = gt.copy(); odo[:, :3] += np.random.default_rng(11).normal(0, 0.02, (K, 3))
+    dd, frame = batch.make_batch_gnss(gt, seed=11)
+    n_dq = len(batch.delta_q_pairs(odo, sr)[0])
+
+    def timed_rounds(stage, speed_bias, iters, label):
+        opts = T.batch_tr_opts(max_iterations=iters)
+        batch.solve_batch_rounds(stage, init, odo, sr, dd, frame, opts=T.batch_tr_opts(max_iterations=2), dist=dist if world > 1 else None, speed_bias=speed_bias)   # warm-up
+        stage.counters()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         t0 = _t.perf_counter()
-        poses_tr, rounds = batch.solve_batch_rounds(st, init, odo, sr, dd, frame, opts=opts, dist=dist)
+        out = batch.solve_batch_rounds(stage, init, odo, sr, dd, frame, opts=opts, dist=dist if world > 1 else None, speed_bias=speed_bias)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        t_tr = _t.perf_counter() - t0
+        wall = _t.perf_counter() - t0
+        rounds, poses_tr = out[-1], out[0]
+        cnt = stage.counters()
         its = sum(r["iterations"] for r in rounds)
-        lins = sum(r["iterations"] + 1 for r in rounds)
-        info["pose_problem_trust_region"] = {
-            "workload": f"{K} keyframes: {K * per_kf} plane constraints + {len(batch.delta_q_pairs(odo, sr)[0])} delta_q + {len(dd)} DD-pseudorange factors, "
-                        f"4 threshold rounds x <= {args.batch_tr_iterations} dogleg iterations",
-            "wall_ms_incl_python_factor_setup": round(t_tr * 1e3, 2), "solve_ms": round(sum(r["solve_ms"] for r in rounds), 3),
-            "trust_region_iterations": int(its), "linearisations": int(lins), "ms_per_linearisation_incl_step": round(sum(r["solve_ms"] for r in rounds) / max(lins, 1), 3),
-            "rounds": [{"iterations": r["iterations"], "termination": r["termination_name"], "initial_cost": round(r["initial_cost"], 3),
-                        "final_cost": round(r["final_cost"], 3)} for r in rounds],
-            "max_translation_error_vs_truth_m": round(float(np.abs(poses_tr[:, :3] - gt[:, :3]).max()), 4),
-            "note": "traditional dogleg in place of the reference's SUBSPACE_DOGLEG; IMU chain of the batch problem not included (DESIGN.md)"}
+        solve_ms = sum(r["solve_ms"] for r in rounds)
+        return {"problem": label, "wall_ms_incl_python_factor_setup": round(wall * 1e3, 2), "solve_ms": round(solve_ms, 3), "trust_region_iterations": int(its),
+                "kernel_groups": int(cnt["groups"]), "ms_per_group": round(solve_ms / max(cnt["groups"], 1), 3),
+                "allreduce_calls": int(cnt["hook_calls"]), "allreduce_MB_per_group": round(cnt["hook_doubles"] * 8 / 1e6 / max(cnt["groups"], 1), 3),
+                "elimination_levels": int(cnt["bcr_levels"]),
+                "rounds": [{"iterations": r["iterations"], "termination": r["termination_name"], "initial_cost": round(r["initial_cost"], 3), "final_cost": round(r["final_cost"], 3)} for r in rounds],
+                "max_translation_error_vs_truth_m": round(float(np.abs(poses_tr[:, :3] - gt[:, :3]).max()), 4)}
+    try:
+        info["pose_problem_trust_region"] = timed_rounds(st, None, args.batch_tr_iterations,
+                                                          f"{K} keyframes x 6 states: {K * per_kf} plane constraints + {n_dq} delta_q + {len(dd)} DD-pseudorange factors, SUBSPACE_DOGLEG, "
+                                                          f"4 threshold rounds x <= {args.batch_tr_iterations} iterations")
     except Exception as e:  # informational
         info["pose_problem_trust_region"] = {"error": str(e)[:300]}
+    try:
+        imu, sb_gt, sb0 = batch.make_batch_imu(K, seed=11)
+        st.set_imu(imu)
+        info["full_problem_trust_region"] = timed_rounds(st, sb0, args.batch_tr_iterations,
+                                                          f"{K} keyframes x 15 states: the same + {K - 1} ImuFactor edges (Estimator.cpp:2990-3001), SUBSPACE_DOGLEG, "
+                                                          f"4 threshold rounds x <= {args.batch_tr_iterations} iterations")
+    except Exception as e:
+        info["full_problem_trust_region"] = {"error": str(e)[:300]}
     st.close()
+    del cp, nc, score
+    if world == 1 and not os.environ.get("GLIO_BENCH_NO_PROJECTION"):
+        try:
+            info["projection_8_ranks"] = project_sharded(K, band, per_kf, gt, init, odo, sr, dd, frame, local_rank, torch, vworld=8)
+        except Exception as e:
+            info["projection_8_ranks"] = {"error": str(e)[:300]}
     return info
+
+
+def project_sharded(K, band, per_kf, gt, init, odo, sr, dd, frame, local_rank, torch, vworld=8, iters=6):
+    """What ONE rank of a `vworld`-rank job does per trust-region group, measured on this one GPU: the sharded solve is first run
+    with `vworld` virtual ranks (threads; the hook sums their buffers) while the all-reduced buffers are recorded, then a single
+    rank is run ALONE with a hook that replays the recorded sums (a device copy) -- same decisions, same kernels, no contention.
+    The collective itself is not on this box: its cost is added from the message sizes at an ASSUMED latency / bandwidth, stated."""
+    import time as _t
+    from glio_amd import batch
+    from glio_amd import ctypes_types as T
+    dev = f"cuda:{local_rank}"
+    imu, sb_gt, sb0 = batch.make_batch_imu(K, seed=11)
+    dq = batch.delta_q_pairs(odo, sr)
+    opts = T.batch_tr_opts(max_iterations=iters)
+    stages = []
+    for r in range(vworld):
+        lo, hi = batch.shard_range(K, r, vworld, band)
+        ci, cj, cp, nc, score = batch.make_constraints(gt, lo, hi, per_kf, band, device=dev)
+        s = batch.BatchStage(K, band, len(ci), device=local_rank)
+        s.set_shard(r, vworld)
+        s.set_constraints(ci, cj, cp, nc, score)
+        s.set_small_factors(dq, dd, frame, threshold=10.0)
+        s.set_imu(imu)
+        stages.append(s)
+    record = []
+    ranks = batch.ThreadRanks(vworld, sync=torch.cuda.synchronize)
+
+    def work(r, d):
+        return stages[r].solve_tr(init, opts, d, speed_bias=sb0, on_allreduce=(lambda t: record.append(t.clone())) if r == 0 else None)
+
+    res = ranks.run(work)
+    summ = res[0][-1]
+    who = vworld // 2                       # an interior rank: two boundaries
+
+    class Replay:
+        class ReduceOp:
+            SUM = "sum"
+
+        def __init__(self):
+            self.i = 0
+
+        def all_reduce(self, t, op=None):
+            t.copy_(record[self.i]); self.i += 1
+
+    rep = Replay()
+    stages[who].solve_tr(init, opts, rep, speed_bias=sb0)           # warm-up of the replay path
+    stages[who].counters()
+    rep.i = 0
+    torch.cuda.synchronize()
+    t0 = _t.perf_counter()
+    out = stages[who].solve_tr(init, opts, rep, speed_bias=sb0)
+    torch.cuda.synchronize()
+    wall = _t.perf_counter() - t0
+    cnt = stages[who].counters()
+    groups = max(cnt["groups"], 1)
+    sizes = stages[who].allreduce_sizes
+    per_group = sizes[1:6] if len(sizes) >= 6 else sizes
+    lat_us, bw_GBps = 25.0, 100.0           # ASSUMED: small-message all-reduce latency on 8 GPUs over xGMI; effective all-reduce bandwidth
+    comm_us = sum(lat_us + 8.0 * n / (bw_GBps * 1e3) for n in per_group)
+    for s in stages:
+        s.close()
+    return {"what": f"rank {who} of {vworld} run alone on this GPU with the recorded all-reduce results replayed ({summ.iterations} iterations, {groups} kernel groups); full problem, 15 states",
+            "compute_ms_per_group_this_rank": round(wall * 1e3 / groups, 3), "allreduce_doubles_per_group": [int(n) for n in per_group],
+            "assumed_collective": f"{lat_us} us latency + {bw_GBps} GB/s effective per all-reduce (NOT measured: one GPU here)",
+            "assumed_comm_ms_per_group": round(comm_us / 1e3, 3), "projected_ms_per_group": round(wall * 1e3 / groups + comm_us / 1e3, 3),
+            "same_result_as_virtual_run": bool(np.abs(out[0] - res[0][0]).max() < 1e-9)}
 
 
 def _cpu_model():

@@ -5,7 +5,8 @@
 // pointer and the batch stream -- see host_demo_batch.cpp for the complete multi-rank program.
 //
 //   rank r owns the constraints whose source keyframe lies in shardRange(K, r, world)   (same rule as glio_amd/batch.py)
-//   iteration:  Hg_r = linearize(poses)  ->  allReduce(Hg)  ->  every rank: step(Hg, lambda)  (identical numbers on every rank)
+//   damped Gauss-Newton path:  Hg_r = linearize(poses)  ->  allReduce(Hg)  ->  every rank: step(Hg, lambda)
+//   trust-region path (solveTrustRegion / solveRounds): everything sharded, five small all-reduces per iteration on stream()
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -19,10 +20,11 @@
 
 namespace glio {
 
-inline std::pair<int, int> shardRange(int K, int rank, int world) {
-    const int base = K / world, rem = K % world;
-    const int lo = rank * base + (rank < rem ? rank : rem);
-    return {lo, lo + base + (rank < rem ? 1 : 0)};
+// whole super-blocks of the solver's block cyclic reduction (6 keyframes; 12 for bands > 6): glio_batch_shard_range
+inline std::pair<int, int> shardRange(int K, int rank, int world, int band = 6) {
+    int32_t lo = 0, hi = K;
+    if (glio_batch_shard_range(K, band, rank, world, &lo, &hi) != GLIO_OK) throw std::runtime_error("glio_batch_shard_range");
+    return {lo, hi};
 }
 
 // The attitude-constraint pairs of optimizeBatch (Estimator.cpp:2831-2891) from the odometry keyframe poses ([K][7] = x y z
@@ -69,6 +71,7 @@ inline glio_batch_tr_opts batchTrOpts(int max_iterations = 100) {
     o.max_iterations = max_iterations; o.use_nonmonotonic_steps = 1; o.max_consecutive_nonmonotonic_steps = 5; o.jacobi_scaling = 1;
     o.initial_trust_region_radius = 1e4; o.max_trust_region_radius = 1e16; o.min_trust_region_radius = 1e-32;
     o.min_relative_decrease = 1e-3; o.function_tolerance = 1e-6; o.gradient_tolerance = 1e-10; o.parameter_tolerance = 1e-8;
+    o.dogleg_type = GLIO_DOGLEG_SUBSPACE; o.reserved_ = 0;        // options.dogleg_type = SUBSPACE_DOGLEG, Estimator.cpp:3278
     return o;
 }
 
@@ -132,16 +135,27 @@ public:
         check(glio_batch_set_small_factors(h_, frame, (int)dq.i.size(), dq.i.data(), dq.j.data(), dq.const_diff.data(), (int)dd.size(), dd.data()),
               "glio_batch_set_small_factors");
     }
-    glio_summary solveTrustRegion(std::vector<double>& poses, const glio_batch_tr_opts& opts) {
+    // this backend is rank `rank` of `world` (call before setSmallFactors): it owns the keyframes of shardRange(); the all-reduce set
+    // with setAllReduce is then called five times per trust-region iteration on small device buffers, ordered on stream()
+    void setShard(int rank, int world) { check(glio_batch_set_shard(h_, rank, world), "glio_batch_set_shard"); }
+    // the ImuFactor chain (Estimator.cpp:2990-3001): K - 1 pre-integrations, edges[k] between keyframes k and k + 1
+    void setImu(const std::vector<glio_preint>& edges, double gravity) {
+        check(glio_batch_set_imu(h_, (int)edges.size(), edges.empty() ? nullptr : edges.data(), gravity), "glio_batch_set_imu");
+        have_imu_ = !edges.empty();
+    }
+    // ceres::Solve of the batch problem (Estimator.cpp:3275-3284), device resident; speed_bias [K][9] travels with the IMU chain
+    glio_summary solveTrustRegion(std::vector<double>& poses, const glio_batch_tr_opts& opts, std::vector<double>* speed_bias = nullptr) {
         glio_summary s;
-        check(glio_batch_solve_tr(h_, poses.data(), &opts, allreduce_ ? &BatchBackend::trampoline : nullptr, this, &s), "glio_batch_solve_tr");
+        if (have_imu_ && (!speed_bias || speed_bias->size() != (size_t)K_ * 9)) throw std::runtime_error("solveTrustRegion: the IMU chain needs speed_bias [K][9]");
+        check(glio_batch_solve_tr2(h_, poses.data(), have_imu_ ? speed_bias->data() : nullptr, &opts, allreduce_ ? &BatchBackend::trampoline : nullptr, this, &s),
+              "glio_batch_solve_tr2");
         return s;
     }
     // the outer loop of optimizeBatch (Estimator.cpp:2764-3410): iteration_num = 4 rounds with DDpsr_threshold {1e9, 10, 8, 6};
     // `reassociate` (may be empty) re-searches the LiDAR correspondences at the current poses and calls setConstraints
     std::vector<glio_summary> solveRounds(std::vector<double>& poses, const std::vector<double>& odo, int search_range, const glio_gnss_frame* frame,
                                           std::vector<glio_dd_psr>& dd, const glio_batch_tr_opts& opts,
-                                          const std::function<void(const std::vector<double>&)>& reassociate = {}) {
+                                          const std::function<void(const std::vector<double>&)>& reassociate = {}, std::vector<double>* speed_bias = nullptr) {
         static const double thresholds[4] = {1000000000, 10, 8, 6};
         const DeltaQPairs dq = deltaQPairs(odo, K_, search_range);
         setSmallFactors(frame, dq, dd, thresholds[0]);
@@ -149,7 +163,7 @@ public:
         for (double thr : thresholds) {
             if (reassociate) reassociate(poses);
             check(glio_batch_set_dd_threshold(h_, thr), "glio_batch_set_dd_threshold");
-            out.push_back(solveTrustRegion(poses, opts));
+            out.push_back(solveTrustRegion(poses, opts, speed_bias));
         }
         return out;
     }
@@ -164,6 +178,7 @@ private:
         if (rc != GLIO_OK) throw std::runtime_error(std::string(what) + ": " + glio_last_error());
     }
     int K_, band_;
+    bool have_imu_ = false;
     glio_batch* h_ = nullptr;
     double* hg_[2] = {nullptr, nullptr};
     void* stream_ = nullptr;

@@ -54,7 +54,7 @@ int main(int argc, char** argv) {
     }
     fclose(f);
     // this rank's shard: constraints whose source keyframe is in [lo, hi) (they are sorted by (ci, cj))
-    const std::pair<int, int> rg = glio::shardRange(K, rank, world);
+    const std::pair<int, int> rg = glio::shardRange(K, rank, world, band);
     int64_t a0 = 0, a1 = n;
     while (a0 < n && ci[a0] < rg.first) ++a0;
     a1 = a0;
@@ -92,6 +92,7 @@ int main(int argc, char** argv) {
             t_reduce += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             reduced_bytes += count * 8; ++n_reduce;
         });
+        if (world > 1) be.setShard(rank, world);
         be.setConstraints(a1 - a0, ci.data() + a0, cj.data() + a0, cp.data() + 4 * a0, nc.data() + 6 * a0, score.data() + a0);
         std::vector<double> hist;
         std::vector<glio_summary> rounds;

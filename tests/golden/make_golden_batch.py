@@ -57,8 +57,46 @@ def oracle_outputs(case):
                 round_termination=np.array(terms), round_costs=np.array(costs), poses=poses)
 
 
+def imu_inputs():
+    """the same batch with the ImuFactor chain: pre-integrations of the analytic track + perturbed speed-bias blocks"""
+    from glio_amd import batch
+    imu, sb_gt, sb0 = batch.make_batch_imu(K, seed=20260931)
+    return imu, sb0
+
+
+def imu_digest(imu, sb0):
+    h = hashlib.sha256()
+    for d in imu:
+        for k in ("delta_p", "delta_q", "delta_v", "jacobian", "covariance"):
+            h.update(np.ascontiguousarray(d[k], np.float64).tobytes())
+    h.update(np.ascontiguousarray(sb0).tobytes())
+    return h.hexdigest()
+
+
+def oracle_outputs_imu(case, imu, sb0):
+    """15 unknowns per keyframe, SUBSPACE_DOGLEG, non-monotonic steps, one solve at threshold 10 from a small initial radius (so
+    that boundary-constrained subspace steps occur)"""
+    from glio_amd import batch
+    from glio_amd import ctypes_types as T
+    from oracle import pyoracle as po
+    dq = batch.delta_q_pairs(case["odo"], SEARCH_RANGE)
+    for f in case["dd"]:
+        f.threshold = 10.0
+    P = po.BatchProblem(K, BAND, *case["con"], dq=dq, dd=case["dd"], frame=case["frame"], imu=imu)
+    H, g, cost = P.linearize_dense(case["init"], sb0)
+    opts = T.batch_tr_opts(MAX_ITER)
+    opts.initial_trust_region_radius = 2.0
+    poses, sb, summ, hist = P.solve2(case["init"], opts, sb0, want_history=True)
+    return dict(imu_diag=np.diag(H).copy(), imu_g=g, imu_cost=np.float64(cost), imu_iterations=np.int64(summ.iterations), imu_successful=np.int64(summ.successful_steps),
+                imu_termination=np.int64(summ.termination), imu_costs=np.array([summ.initial_cost, summ.final_cost]), imu_history=hist, imu_poses=poses, imu_sb=sb)
+
+
 if __name__ == "__main__":
     case = make_inputs()
+    imu, sb0 = imu_inputs()
+    out_imu = oracle_outputs_imu(case, imu, sb0)
+    np.savez_compressed(os.path.join(HERE, "batch_imu_small.npz"), input_sha256=digest(case), imu_sha256=imu_digest(imu, sb0), **out_imu)
+    print("wrote batch_imu_small.npz: iterations", int(out_imu["imu_iterations"]), "termination", int(out_imu["imu_termination"]), "costs", out_imu["imu_costs"])
     out = oracle_outputs(case)
     np.savez_compressed(os.path.join(HERE, "batch_small.npz"), input_sha256=digest(case), **out)
     print("wrote batch_small.npz:", {k: np.shape(v) for k, v in out.items()}, "iterations", out["round_iterations"], "costs", out["round_costs"][:, 1])

@@ -174,3 +174,42 @@ def test_batch_hip_matches_the_fixture(golden_batch, case_batch):
     assert rel(np.array([[h["initial_cost"], h["final_cost"]] for h in hist]), golden_batch["round_costs"]) <= 1e-8
     assert np.abs(poses - golden_batch["poses"]).max() <= 1e-7
     st.close()
+
+
+# ---- the same batch with the ImuFactor chain (15 unknowns per keyframe, SUBSPACE_DOGLEG, minimum-cost iterate) --------------------
+@pytest.fixture(scope="module")
+def golden_batch_imu():
+    return np.load(os.path.join(HERE, "golden", "batch_imu_small.npz"))
+
+
+def test_batch_imu_oracle_reproduces_the_fixture(golden_batch_imu, case_batch):
+    imu, sb0 = mgb.imu_inputs()
+    assert mgb.digest(case_batch) == str(golden_batch_imu["input_sha256"]) and mgb.imu_digest(imu, sb0) == str(golden_batch_imu["imu_sha256"]), "the synthetic generator changed"
+    out = mgb.oracle_outputs_imu(case_batch, imu, sb0)
+    g = golden_batch_imu
+    assert int(out["imu_iterations"]) == int(g["imu_iterations"]) and int(out["imu_termination"]) == int(g["imu_termination"]) and int(out["imu_successful"]) == int(g["imu_successful"])
+    assert rel(out["imu_diag"], g["imu_diag"]) <= 1e-13 and rel(out["imu_g"], g["imu_g"]) <= 1e-12
+    assert rel(out["imu_costs"], g["imu_costs"]) <= 1e-10 and rel(out["imu_history"][:, :2], g["imu_history"][:, :2]) <= 1e-8
+    assert np.abs(out["imu_poses"] - g["imu_poses"]).max() <= 1e-9 and np.abs(out["imu_sb"] - g["imu_sb"]).max() <= 1e-8
+
+
+@pytest.mark.gpu
+def test_batch_imu_hip_matches_the_fixture(golden_batch_imu, case_batch):
+    from glio_amd import batch
+    from glio_amd import ctypes_types as T
+    c, g = case_batch, golden_batch_imu
+    imu, sb0 = mgb.imu_inputs()
+    dq = batch.delta_q_pairs(c["odo"], mgb.SEARCH_RANGE)
+    st = batch.BatchStage(mgb.K, mgb.BAND, len(c["con"][0]))
+    st.set_constraints(*c["con"])
+    st.set_small_factors(dq, c["dd"], c["frame"], threshold=10.0)
+    st.set_imu(imu)
+    diag, grad, cost = st.linearize_full(c["init"], sb0)
+    assert rel(diag, g["imu_diag"]) <= 1e-11 and rel(grad, g["imu_g"]) <= 1e-10 and abs(cost - float(g["imu_cost"])) <= 1e-11 * cost
+    opts = T.batch_tr_opts(mgb.MAX_ITER)
+    opts.initial_trust_region_radius = 2.0
+    poses, sb, summ = st.solve_tr(c["init"], opts, speed_bias=sb0)
+    assert summ.iterations == int(g["imu_iterations"]) and summ.termination == int(g["imu_termination"]) and summ.successful_steps == int(g["imu_successful"])
+    assert rel(np.array([summ.initial_cost, summ.final_cost]), g["imu_costs"]) <= 1e-8
+    assert np.abs(poses - g["imu_poses"]).max() <= 1e-7 and np.abs(sb - g["imu_sb"]).max() <= 1e-6
+    st.close()

@@ -166,7 +166,7 @@ def test_sharded_solve_on_virtual_ranks_equals_one_rank(world, with_imu):
     for (out, sizes) in res:
         summ = out[-1]
         assert summ.iterations == summ1.iterations and summ.termination == summ1.termination and summ.successful_steps == summ1.successful_steps
-        assert np.isclose(summ.final_cost, summ1.final_cost, rtol=1e-10)
+        assert np.isclose(summ.final_cost, summ1.final_cost, rtol=1e-9)
         assert np.abs(out[0] - r1[0]).max() < 1e-9
         if with_imu:
             assert np.abs(out[1] - r1[1]).max() < 1e-8
