@@ -20,7 +20,7 @@
 //   k_bcr_elim    node p with active neighbours a < p < b: the (3M+1) x M panel [A_pp; A_ap; A_bp; y_p^T] one row per lane,
 //                 factored in M register steps with ONE workgroup barrier each (double-buffered column through LDS)
 //   k_bcr_update  kept node q: A_qq -= U U^T of its eliminated neighbours, y_q -= U w, new coupling A[b][a] = -U_b U_a^T
-//                 (3 x 3 register tiles over LDS-staged factors)
+//                 (v_mfma_f64_16x16x4 tiles over LDS-staged factors)
 //   k_bcr_back    z_p = L^-T (w - U_a^T z_a - U_b^T z_b): the triangular solve inside one wavefront (no barriers)
 // Every sum has a fixed order: two runs are bit-identical.
 #include <algorithm>
@@ -174,25 +174,41 @@ __global__ __launch_bounds__(BcrCfg<M>::THREADS) void k_bcr_elim(const int* skip
 
 // ------------------------------------------------------------------------------------------------ Schur updates of the kept nodes
 #define BCR_UP_THREADS 256
-// C (MxM) (+)= sign * X Y^T with X, Y staged in LDS (row stride LD), 3 x 3 register tiles; acc(r, c, value) consumes the products
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+// The three M x M x M products of a kept node (U U^T twice, U_b U_a^T once) on the matrix core.  The factors are staged in LDS,
+// rows padded with zeros to MP = 16 ceil(M / 16), columns to KP = 4 ceil(M / 4), row stride LD (odd: the 16 lanes of an operand
+// column group hit distinct banks).  v_mfma_f64_16x16x4 takes A[i][k] from lane i + 16 k and B[k][j] from lane j + 16 k, so for
+// C = X Y^T lane l feeds X[16 I + l % 16][k0 + l / 16] and Y[16 J + l % 16][k0 + l / 16]: ONE 8-byte LDS read per operand per
+// 1024 multiply-adds (the 3 x 3 register tiles of the VALU form needed two reads per three).  C comes back with lane l,
+// register q = row (l >> 4) + 4 q, column l & 15.
+template <int M> struct BcrUp {
+    static constexpr int MP = ((M + 15) / 16) * 16, KP = ((M + 3) / 4) * 4, LD = KP | 1, T = MP / 16;
+    static constexpr size_t lds_bytes = (size_t)(2 * MP * LD + M) * 8;
+};
 template <int M, class F>
-__device__ __forceinline__ void bcr_xyT(const double* __restrict__ X, const double* __restrict__ Y, const int tid, F&& acc) {
-    constexpr int LD = M + 1, T = M / 3;
-    for (int tile = tid; tile < T * T; tile += BCR_UP_THREADS) {
-        const int r0 = (tile / T) * 3, c0 = (tile % T) * 3;
-        double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 6
-        for (int k = 0; k < M; ++k) {
-            const double x0 = X[r0 * LD + k], x1 = X[(r0 + 1) * LD + k], x2 = X[(r0 + 2) * LD + k];
-            const double y0 = Y[c0 * LD + k], y1 = Y[(c0 + 1) * LD + k], y2 = Y[(c0 + 2) * LD + k];
-            s[0] += x0 * y0; s[1] += x0 * y1; s[2] += x0 * y2;
-            s[3] += x1 * y0; s[4] += x1 * y1; s[5] += x1 * y2;
-            s[6] += x2 * y0; s[7] += x2 * y1; s[8] += x2 * y2;
+__device__ __forceinline__ void bcr_xyT_mfma(const double* __restrict__ X, const double* __restrict__ Y, const int tid, F&& acc) {
+    using C = BcrUp<M>;
+    const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    for (int tile = wave; tile < C::T * C::T; tile += BCR_UP_THREADS / 64) {
+        const int I = tile / C::T, J = tile - C::T * I;
+        const double* px = X + (16 * I + li) * C::LD + lk;
+        const double* py = Y + (16 * J + li) * C::LD + lk;
+        v4f64 c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+        for (int k0 = 0; k0 < C::KP; k0 += 4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(px[k0], py[k0], c, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = 16 * I + lk + 4 * q, col = 16 * J + li;
+            if (r < M && col < M) acc(r, col, c[q]);
         }
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) acc(r0 + i, c0 + j, s[i * 3 + j]);
+    }
+}
+template <int M>
+__device__ __forceinline__ void bcr_stage(double* __restrict__ dst, const double* __restrict__ src, const int tid) {
+    using C = BcrUp<M>;
+    for (int e = tid; e < C::MP * C::KP; e += BCR_UP_THREADS) {
+        const int r = e / C::KP, c = e - C::KP * r;
+        dst[r * C::LD + c] = (r < M && c < M) ? src[(size_t)r * M + c] : 0.0;
     }
 }
 
@@ -200,36 +216,32 @@ template <int M>
 __global__ __launch_bounds__(BCR_UP_THREADS) void k_bcr_update(const int* skip, const BcrKept* __restrict__ tab, double* __restrict__ ws,
                                                                const double* __restrict__ Ua, const double* __restrict__ Ub, const double* __restrict__ w) {
     if (skip && *skip) return;
-    static_assert(M % 3 == 0, "3 x 3 register tiles");
+    using C = BcrUp<M>;
     extern __shared__ double bcr_lds[];
-    constexpr int LD = M + 1;
     double* XA = bcr_lds;                 // phase 1: U_b of the node eliminated to the left; phase 2: U_a of the node eliminated to the right
-    double* XB = XA + M * LD;             // phase 2: U_b of the node eliminated to the right (for the new coupling)
-    double* wv = XB + M * LD;
+    double* XB = XA + C::MP * C::LD;      // phase 2: U_b of the node eliminated to the right (for the new coupling)
+    double* wv = XB + C::MP * C::LD;
     const BcrKept t = tab[blockIdx.x];
     const int tid = threadIdx.x;
     const size_t MM = (size_t)M * M;
     double* Dq = ws + t.oD;
     double* yq = ws + t.oy;
     if (t.pl >= 0) {
-        for (int e = tid; e < M * M; e += BCR_UP_THREADS) { const int r = e / M, c = e - M * r; XA[r * LD + c] = Ub[(size_t)t.pl * MM + e]; }
+        bcr_stage<M>(XA, Ub + (size_t)t.pl * MM, tid);
         for (int k = tid; k < M; k += BCR_UP_THREADS) wv[k] = w[(size_t)t.pl * M + k];
         __syncthreads();
-        bcr_xyT<M>(XA, XA, tid, [&](int r, int c, double s) { Dq[r * M + c] -= s; });
-        for (int r = tid; r < M; r += BCR_UP_THREADS) { double s = 0; for (int k = 0; k < M; ++k) s += XA[r * LD + k] * wv[k]; yq[r] -= s; }
+        bcr_xyT_mfma<M>(XA, XA, tid, [&](int r, int c, double s) { Dq[r * M + c] -= s; });
+        for (int r = tid; r < M; r += BCR_UP_THREADS) { double s = 0; for (int k = 0; k < M; ++k) s += XA[r * C::LD + k] * wv[k]; yq[r] -= s; }
         __syncthreads();
     }
     if (t.pr >= 0) {
-        for (int e = tid; e < M * M; e += BCR_UP_THREADS) {
-            const int r = e / M, c = e - M * r;
-            XA[r * LD + c] = Ua[(size_t)t.pr * MM + e];
-            if (t.oCnew >= 0) XB[r * LD + c] = Ub[(size_t)t.pr * MM + e];
-        }
+        bcr_stage<M>(XA, Ua + (size_t)t.pr * MM, tid);
+        if (t.oCnew >= 0) bcr_stage<M>(XB, Ub + (size_t)t.pr * MM, tid);
         for (int k = tid; k < M; k += BCR_UP_THREADS) wv[k] = w[(size_t)t.pr * M + k];
         __syncthreads();
-        bcr_xyT<M>(XA, XA, tid, [&](int r, int c, double s) { Dq[r * M + c] -= s; });
-        if (t.oCnew >= 0) { double* Cn = ws + t.oCnew; bcr_xyT<M>(XB, XA, tid, [&](int r, int c, double s) { Cn[r * M + c] = -s; }); }   // A[b][a] = -U_b U_a^T
-        for (int r = tid; r < M; r += BCR_UP_THREADS) { double s = 0; for (int k = 0; k < M; ++k) s += XA[r * LD + k] * wv[k]; yq[r] -= s; }
+        bcr_xyT_mfma<M>(XA, XA, tid, [&](int r, int c, double s) { Dq[r * M + c] -= s; });
+        if (t.oCnew >= 0) { double* Cn = ws + t.oCnew; bcr_xyT_mfma<M>(XB, XA, tid, [&](int r, int c, double s) { Cn[r * M + c] = -s; }); }   // A[b][a] = -U_b U_a^T
+        for (int r = tid; r < M; r += BCR_UP_THREADS) { double s = 0; for (int k = 0; k < M; ++k) s += XA[r * C::LD + k] * wv[k]; yq[r] -= s; }
     }
 }
 
@@ -433,8 +445,8 @@ void* glio_bcr_create2(int K, int band, int B, int rank, int world) {
     if (!kept.empty()) hipMemcpy(b->kept, kept.data(), kept.size() * sizeof(BcrKept), hipMemcpyHostToDevice);
     if (!init.empty()) hipMemcpy(b->init, init.data(), init.size() * sizeof(BcrInit), hipMemcpyHostToDevice);
     hipMemcpy(b->node_of_sblock_dev, b->node_of_sblock.data(), (size_t)nown * 4, hipMemcpyHostToDevice);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_update<72>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((2 * 72 * 73 + 72) * 8));
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_update<90>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((2 * 90 * 91 + 90) * 8));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_update<72>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BcrUp<72>::lds_bytes);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_update<90>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BcrUp<90>::lds_bytes);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_back<72>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((72 * 73 + 3 * 72) * 8));
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_back<90>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((90 * 91 + 3 * 90) * 8));
     (void)hipGetLastError();
@@ -463,7 +475,7 @@ int* glio_bcr_fail_flag(void* h) { return static_cast<BcrDev*>(h)->fail; }
 
 template <int M>
 static void bcr_levels(BcrDev* b, const BcrOp& op, int l0, int l1, hipStream_t stream) {
-    const size_t lds_up = (size_t)(2 * M * (M + 1) + M) * 8;
+    const size_t lds_up = BcrUp<M>::lds_bytes;
     for (int l = l0; l < l1; ++l) {
         const int ne = b->h_elim_off[l + 1] - b->h_elim_off[l], nk = b->h_kept_off[l + 1] - b->h_kept_off[l];
         if (ne > 0) hipLaunchKernelGGL((k_bcr_elim<M>), dim3(ne), dim3(BcrCfg<M>::THREADS), 0, stream, op.skip, b->elim + b->h_elim_off[l], b->ws, b->L, b->Ua, b->Ub, b->w, b->fail);

@@ -453,41 +453,54 @@ __global__ void k_bt_prepare(const BtBufs a, const int jacobi) {
     BVEC(a, V_DG)[i] = D; BVEC(a, V_GS)[i] = s * g; BVEC(a, V_GR)[i] = s * g / D; BVEC(a, V_UU)[i] = (s * g / D) / D;
     BVEC(a, V_DA)[i] = a.st->mu * D * D;
 }
-// y = Hs x for the OWNED rows (Hs = S H S on the fly) of up to two vectors; one thread per row
-__global__ void k_bt_matvec(const BtBufs a, const int solve_phase, const int vx0, const int vy0, const int vx1, const int vy1) {
+// y = Hs x for the OWNED rows (Hs = S H S on the fly) of up to two vectors.  One wavefront per owned keyframe: the scaled inputs of
+// the 2 band + 1 neighbouring keyframes go to LDS; lane (r, part) sums row r over every fourth neighbour, the four parts meet by
+// two shuffles.
+__global__ __launch_bounds__(64) void k_bt_matvec(const BtBufs a, const int solve_phase, const int vx0, const int vy0, const int vx1, const int vy1) {
+    __shared__ double xs[2][(2 * 16 + 1) * 15];
     if (solve_phase ? BT_SKIP_SOLVE(a) : BT_SKIP_STEP(a)) return;
-    const int B = a.B, K = a.K, band = a.band;
-    const int i = a.lo * B + blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.hi * B) return;
-    const int k = i / B, r = i - B * k;
+    const int B = a.B, K = a.K, band = a.band, k = a.lo + blockIdx.x, lane = threadIdx.x;
+    if (k >= a.hi) return;
     const HView v = bt_view(a, a.st->cur & 1);
     const double* sc = BVEC(a, V_SC);
     const double* x0 = BVEC(a, vx0);
     const double* x1 = vx1 >= 0 ? BVEC(a, vx1) : x0;
+    const int kb0 = k - band < 0 ? 0 : k - band, kb1 = k + band >= K ? K - 1 : k + band, nkb = kb1 - kb0 + 1;
+    for (int e = lane; e < nkb * B; e += 64) { const size_t i = (size_t)kb0 * B + e; const double sv = sc[i]; xs[0][e] = sv * x0[i]; xs[1][e] = sv * x1[i]; }
+    __syncthreads();
+    const int r = lane & 15, part = lane >> 4;
     double s0 = 0, s1 = 0;
-    const int kb0 = k - band < 0 ? 0 : k - band, kb1 = k + band >= K ? K - 1 : k + band;
-    for (int kb = kb0; kb <= kb1; ++kb) {
-        const int d = kb - k;
-        const bool near = d >= -1 && d <= 1 && B == 15;
-        if (r >= 6 && !near) continue;
-        const int cmax = near ? B : 6;
-        for (int c = 0; c < cmax; ++c) {
-            const double hv = h_entry(v, k, r, kb, c) * sc[(size_t)kb * B + c];
-            s0 += hv * x0[(size_t)kb * B + c];
-            s1 += hv * x1[(size_t)kb * B + c];
+    if (r < B)
+        for (int kbi = part; kbi < nkb; kbi += 4) {
+            const int kb = kb0 + kbi, d = kb - k;
+            const bool near = d >= -1 && d <= 1 && B == 15;
+            if (r >= 6 && !near) continue;
+            const int cmax = near ? B : 6;
+            for (int c = 0; c < cmax; ++c) {
+                const double hv = h_entry(v, k, r, kb, c);
+                s0 += hv * xs[0][kbi * B + c];
+                s1 += hv * xs[1][kbi * B + c];
+            }
         }
+    s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
+    s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+    if (lane < B) {
+        const size_t i = (size_t)k * B + lane;
+        BVEC(a, vy0)[i] = sc[i] * s0;
+        if (vx1 >= 0) BVEC(a, vy1)[i] = sc[i] * s1;
     }
-    BVEC(a, vy0)[i] = sc[i] * s0;
-    if (vx1 >= 0) BVEC(a, vy1)[i] = sc[i] * s1;
 }
-// up to six dot products in one pass by ONE workgroup (fixed order: every rank gets the same bits from the same data)
-struct DotJobs { int n; int va[6], vb[6], owned[6]; double* out[6]; };
-__global__ __launch_bounds__(1024) void k_bt_dots(const BtBufs a, const int solve_phase, const DotJobs j) {
-    __shared__ double red[6][16];
+// up to six dot products in one pass: BT_DOT_BLOCKS workgroups write their parts, the last one to finish adds them in block order
+// (fixed order: every rank gets the same bits from the same data)
+#define BT_DOT_BLOCKS 32
+struct DotJobs { int n; int va[6], vb[6], owned[6]; double* out[6]; double* parts; unsigned int* ticket; };
+__global__ __launch_bounds__(256) void k_bt_dots(const BtBufs a, const int solve_phase, const DotJobs j) {
+    __shared__ double red[6][4];
+    __shared__ int s_last;
     if (solve_phase ? BT_SKIP_SOLVE(a) : BT_SKIP_STEP(a)) return;
     const int n = a.B * a.K, o0 = a.lo * a.B, o1 = a.hi * a.B;
     double s[6] = {0, 0, 0, 0, 0, 0};
-    for (int i = threadIdx.x; i < n; i += 1024) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += BT_DOT_BLOCKS * 256) {
         const bool own = i >= o0 && i < o1;
 #pragma unroll
         for (int q = 0; q < 6; ++q)
@@ -496,7 +509,19 @@ __global__ __launch_bounds__(1024) void k_bt_dots(const BtBufs a, const int solv
 #pragma unroll
     for (int q = 0; q < 6; ++q) { s[q] = wave_sum(s[q]); if ((threadIdx.x & 63) == 0) red[q][threadIdx.x >> 6] = s[q]; }
     __syncthreads();
-    if (threadIdx.x < j.n) { double t = 0; for (int w = 0; w < 16; ++w) t += red[threadIdx.x][w]; *j.out[threadIdx.x] = t; }
+    if (threadIdx.x < 6) j.parts[blockIdx.x * 6 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(j.ticket, 1u) == BT_DOT_BLOCKS - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x < j.n) {
+        double t = 0;
+        for (int b2 = 0; b2 < BT_DOT_BLOCKS; ++b2) t += __builtin_nontemporal_load(&j.parts[b2 * 6 + threadIdx.x]);
+        *j.out[threadIdx.x] = t;
+    }
+    if (threadIdx.x == 0) *j.ticket = 0;
 }
 // zero the step buffer outside the owned range and publish the factorisation's failure flag behind it (the buffer is all-reduced)
 __global__ void k_bt_dz_prepare(const BtBufs a, double* dz, const int* fail) {
@@ -544,7 +569,7 @@ __device__ bool bt_quartic_roots_real(const double* c, double* re) {
     if (rad > bound) rad = bound;
     cplx z[4];
     for (int i = 0; i < 4; ++i) { double sn, cs; sincos(2.0 * M_PI * i / 4 + 0.4, &sn, &cs); z[i] = {rad * cs, rad * sn}; }
-    for (int it = 0; it < 500; ++it) {
+    for (int it = 0; it < 100; ++it) {
         double move = 0, size = 0;
         for (int i = 0; i < 4; ++i) {
             cplx pv = {1.0, 0.0}, dv = {0.0, 0.0};
@@ -559,7 +584,7 @@ __device__ bool bt_quartic_roots_real(const double* c, double* re) {
             z[i].re -= w.re; z[i].im -= w.im;
             move = fmax(move, c_abs(w)); size = fmax(size, c_abs(z[i]));
         }
-        if (move <= 1e-15 * size) break;
+        if (move <= 4e-15 * size) break;
     }
     for (int i = 0; i < 4; ++i) { re[i] = z[i].re; if (!isfinite(re[i])) return false; }
     return true;
@@ -690,6 +715,7 @@ struct BatchSmall {
     double* d_stage; long long stage_doubles, bnd_doubles;     // assembly all-reduce buffer
     double* d_dz;              // [n + 2] Gauss-Newton step of the scaled system (all-reduced), then the failure flag
     double* d_scal;            // [16] stage D (0..7) and stage E (8..15)
+    double* d_dot_parts; unsigned int* d_dot_ticket;      // k_bt_dots: per-workgroup parts and the arrival counter
     BtStatus* d_st;
     int* h_prog; int* d_prog; BtStatus* h_res; BtStatus* d_res;     // mapped host memory
     double* h_x;               // pinned [K][16]
@@ -720,12 +746,12 @@ static int small_ensure(glio_batch* b) {
 }
 static void tr_free(BatchSmall* s) {
     void* p[] = {s->d_vec, s->d_hg[0], s->d_hg[1], s->d_A[0], s->d_A[1], s->d_x[0], s->d_x[1], s->d_s[0], s->d_s[1], s->d_xmin, s->d_smin, s->d_stage, s->d_dz,
-                 s->d_scal, s->d_st};
+                 s->d_scal, s->d_st, s->d_dot_parts, s->d_dot_ticket};
     for (void* q : p) if (q) hipFree(q);
     if (s->h_prog) hipHostFree(s->h_prog);
     if (s->h_res) hipHostFree(s->h_res);
     if (s->h_x) hipHostFree(s->h_x);
-    s->d_vec = nullptr; s->d_hg[0] = s->d_hg[1] = s->d_A[0] = s->d_A[1] = s->d_x[0] = s->d_x[1] = s->d_s[0] = s->d_s[1] = s->d_xmin = s->d_smin = s->d_stage = s->d_dz = s->d_scal = nullptr;
+    s->d_vec = nullptr; s->d_hg[0] = s->d_hg[1] = s->d_A[0] = s->d_A[1] = s->d_x[0] = s->d_x[1] = s->d_s[0] = s->d_s[1] = s->d_xmin = s->d_smin = s->d_stage = s->d_dz = s->d_scal = nullptr; s->d_dot_parts = nullptr; s->d_dot_ticket = nullptr;
     s->d_st = nullptr; s->h_prog = nullptr; s->h_res = nullptr; s->h_x = nullptr;
     if (s->bcr) { glio_bcr_destroy(s->bcr); s->bcr = nullptr; }
 }
@@ -771,6 +797,7 @@ static int tr_ensure(glio_batch* b) {
     BT_CHECK(hipMalloc((void**)&s->d_stage, (size_t)s->stage_doubles * 8));
     BT_CHECK(hipMalloc((void**)&s->d_dz, (size_t)(n + 2) * 8));
     BT_CHECK(hipMalloc((void**)&s->d_scal, 16 * 8)); BT_CHECK(hipMemset(s->d_scal, 0, 16 * 8));
+    BT_CHECK(hipMalloc((void**)&s->d_dot_parts, BT_DOT_BLOCKS * 6 * 8)); BT_CHECK(hipMalloc((void**)&s->d_dot_ticket, 16)); BT_CHECK(hipMemset(s->d_dot_ticket, 0, 16));
     BT_CHECK(hipMalloc((void**)&s->d_st, sizeof(BtStatus)));
     BT_CHECK(hipHostMalloc((void**)&s->h_prog, 64, hipHostMallocMapped | hipHostMallocCoherent));
     BT_CHECK(hipHostGetDevicePointer((void**)&s->d_prog, (void*)s->h_prog, 0));
@@ -859,21 +886,21 @@ static void enqueue_tr_group(const BtRun& r, const BtOpts& o) {
     hipStream_t st = b->stream;
     const int K = b->K, B = s->B, n = B * K;
     const int nbv = (n + TRV_THREADS - 1) / TRV_THREADS;
-    const int own = (s->hi - s->lo) * B, nbo = std::max(1, (own + TRV_THREADS - 1) / TRV_THREADS);
+    const int nbo = std::max(1, s->hi - s->lo);
     BtHost h; h.progress = s->d_prog; h.result = s->d_res;
     hipLaunchKernelGGL(k_bt_state_machine, dim3(1), dim3(256), 0, st, a, o, h);
     // ---- Cauchy point and Gauss-Newton step (skipped when the stored ones are reused)
     hipLaunchKernelGGL(k_bt_prepare, dim3(nbv), dim3(TRV_THREADS), 0, st, a, o.jacobi);
-    hipLaunchKernelGGL(k_bt_matvec, dim3(nbo), dim3(TRV_THREADS), 0, st, a, 1, (int)V_UU, (int)V_T1, -1, -1);
+    hipLaunchKernelGGL(k_bt_matvec, dim3(nbo), dim3(64), 0, st, a, 1, (int)V_UU, (int)V_T1, -1, -1);
     long long sep_count = 0;
     double* sep = glio_bcr_sepbuf(s->bcr, &sep_count);
     double* extra = sep + sep_count - 16;
     {
-        DotJobs j; memset(&j, 0, sizeof j);
+        DotJobs j; memset(&j, 0, sizeof j); j.parts = s->d_dot_parts; j.ticket = s->d_dot_ticket;
         j.n = 2;
         j.va[0] = V_GR; j.vb[0] = V_GR; j.owned[0] = 0; j.out[0] = &s->d_st->gg;
         j.va[1] = V_UU; j.vb[1] = V_T1; j.owned[1] = 1; j.out[1] = extra;          // the Cauchy curvature travels with the separator system
-        hipLaunchKernelGGL(k_bt_dots, dim3(1), dim3(1024), 0, st, a, 1, j);
+        hipLaunchKernelGGL(k_bt_dots, dim3(BT_DOT_BLOCKS), dim3(256), 0, st, a, 1, j);
     }
     BcrOp op; memset(&op, 0, sizeof op);
     for (int k = 0; k < 2; ++k) { op.Hg[k] = s->d_hg[k]; op.imu[k] = s->n_imu > 0 ? s->d_rec[k] : nullptr; op.gfull[k] = s->d_A[k] + n; }
@@ -885,35 +912,35 @@ static void enqueue_tr_group(const BtRun& r, const BtOpts& o) {
     call_hook(r, s->d_dz, n + 2);
     hipLaunchKernelGGL(k_bt_gn, dim3(nbv), dim3(TRV_THREADS), 0, st, a, s->d_dz);
     {
-        DotJobs j; memset(&j, 0, sizeof j);
+        DotJobs j; memset(&j, 0, sizeof j); j.parts = s->d_dot_parts; j.ticket = s->d_dot_ticket;
         j.n = 2;
         j.va[0] = V_GN; j.vb[0] = V_GN; j.out[0] = &s->d_st->nn2;
         j.va[1] = V_GR; j.vb[1] = V_GN; j.out[1] = &s->d_st->gd;
-        hipLaunchKernelGGL(k_bt_dots, dim3(1), dim3(1024), 0, st, a, 1, j);
+        hipLaunchKernelGGL(k_bt_dots, dim3(BT_DOT_BLOCKS), dim3(256), 0, st, a, 1, j);
     }
     hipLaunchKernelGGL(k_bt_basis, dim3(nbv), dim3(TRV_THREADS), 0, st, a, extra);
-    hipLaunchKernelGGL(k_bt_matvec, dim3(nbo), dim3(TRV_THREADS), 0, st, a, 1, (int)V_X1, (int)V_T1, (int)V_X2, (int)V_T2);
+    hipLaunchKernelGGL(k_bt_matvec, dim3(nbo), dim3(64), 0, st, a, 1, (int)V_X1, (int)V_T1, (int)V_X2, (int)V_T2);
     {
-        DotJobs j; memset(&j, 0, sizeof j);
+        DotJobs j; memset(&j, 0, sizeof j); j.parts = s->d_dot_parts; j.ticket = s->d_dot_ticket;
         j.n = 4;
         j.va[0] = V_X1; j.vb[0] = V_T1; j.owned[0] = 1; j.out[0] = s->d_scal + 0;
         j.va[1] = V_X1; j.vb[1] = V_T2; j.owned[1] = 1; j.out[1] = s->d_scal + 1;
         j.va[2] = V_X2; j.vb[2] = V_T2; j.owned[2] = 1; j.out[2] = s->d_scal + 2;
         j.va[3] = V_W2; j.vb[3] = V_W2; j.owned[3] = 0; j.out[3] = &s->d_st->w2;
-        hipLaunchKernelGGL(k_bt_dots, dim3(1), dim3(1024), 0, st, a, 1, j);
+        hipLaunchKernelGGL(k_bt_dots, dim3(BT_DOT_BLOCKS), dim3(256), 0, st, a, 1, j);
     }
     call_hook(r, s->d_scal, 8);
     // ---- the step for the present radius, its model cost change, the candidate
     hipLaunchKernelGGL(k_bt_dogleg, dim3(1), dim3(64), 0, st, a, s->d_scal, o.dogleg_type);
     hipLaunchKernelGGL(k_bt_step, dim3((K + 255) / 256), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_bt_matvec, dim3(nbo), dim3(TRV_THREADS), 0, st, a, 0, (int)V_ST, (int)V_T1, -1, -1);
+    hipLaunchKernelGGL(k_bt_matvec, dim3(nbo), dim3(64), 0, st, a, 0, (int)V_ST, (int)V_T1, -1, -1);
     {
-        DotJobs j; memset(&j, 0, sizeof j);
+        DotJobs j; memset(&j, 0, sizeof j); j.parts = s->d_dot_parts; j.ticket = s->d_dot_ticket;
         j.n = 3;
         j.va[0] = V_GS; j.vb[0] = V_ST; j.out[0] = &s->d_st->lin;
         j.va[1] = V_ST; j.vb[1] = V_T1; j.owned[1] = 1; j.out[1] = s->d_scal + 8;
         j.va[2] = V_SD; j.vb[2] = V_SD; j.out[2] = &s->d_st->sd2;
-        hipLaunchKernelGGL(k_bt_dots, dim3(1), dim3(1024), 0, st, a, 0, j);
+        hipLaunchKernelGGL(k_bt_dots, dim3(BT_DOT_BLOCKS), dim3(256), 0, st, a, 0, j);
     }
     call_hook(r, s->d_scal + 8, 8);
     hipLaunchKernelGGL(k_bt_mcc, dim3(1), dim3(64), 0, st, a, s->d_scal + 8);

@@ -706,10 +706,12 @@ static int enqueue_solve(glio_ctx* c, int n_ddt) {
     // mapped host memory) that the solve goes on, i.e. while group k's step (~70 us) is still running, and stops as soon
     // as the finished solve's tag shows up (`enqueue_lead` > 1 queues that many groups further ahead, < 1 all of them).
     const int id = c->solve_id;
+    c->h_progress[2] = 0;            // a stop raised in an earlier solve must not outlive it (the ids wrap: a stale word would end the solve that reuses the id)
+    c->solve_t0 = std::chrono::steady_clock::now();
     auto started = [&]() { const int w = c->h_progress[0]; return (w >> 16) == id ? (w & 0xffff) : 0; };
     const int total = c->opts.max_iterations + 1;
     const int lead = c->enqueue_lead < 1 ? total : c->enqueue_lead;
-    const auto t_start = std::chrono::steady_clock::now();
+    const auto t_start = c->solve_t0;
     int enq = 0, spins = 0;
     const int dense = glio_solver_needs_dense_H(c, n_ddt);
     // options.max_solver_time_in_seconds: when the budget is spent the host raises the stop word; the state machine of the next
@@ -762,8 +764,15 @@ int glio_solve(glio_ctx* c, glio_state* s, glio_summary* sum) {
         const auto t_wait = std::chrono::steady_clock::now();
         int spins = 0;
         bool seen = true;
+        // max_solver_time_s is also watched here: with every group queued ahead the enqueue loop ends before the budget can elapse
+        const bool timed = c->opts.max_solver_time_s > 0.0;
+        const auto budget = std::chrono::duration<double>(timed ? c->opts.max_solver_time_s : 0.0);
         while (c->h_progress[1] != c->solve_id) {
-            if (((++spins) & 0xfff) == 0 && std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(20)) { seen = false; break; }
+            if (((++spins) & 0x3f) == 0) {
+                const auto now = std::chrono::steady_clock::now();
+                if (timed && c->h_progress[2] != c->solve_id && now - c->solve_t0 > budget) c->h_progress[2] = c->solve_id;
+                if (now - t_wait > std::chrono::seconds(20)) { seen = false; break; }
+            }
         }
         if (seen) {
             std::atomic_thread_fence(std::memory_order_acquire);

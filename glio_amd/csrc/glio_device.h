@@ -2,6 +2,7 @@
 // small math, launch wrappers between translation units.  HIP only; never included by host callers
 // (they see include/glio_hip.h).
 #pragma once
+#include <chrono>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -107,6 +108,7 @@ struct ArrowDev {
 struct ChainKf { short e0, e1, k0, k1, o0, o1, kp, pad_; };   // per keyframe: IMU edges, GNSS groups (+ whether i is their slot_a), group of (i, i+1)
 
 struct glio_ctx {
+    std::chrono::steady_clock::time_point solve_t0;   // start of the solve in flight (max_solver_time_s is watched in the enqueue and in the wait loop)
     glio_opts opts;
     int device;
     hipStream_t own_stream, stream;

@@ -121,7 +121,9 @@ private:
 // A component failing its gate keeps its old value (Q14: |dp| < 100, |dq.vec| < 10, |dv| < 100, |db| < 22).  abs_poses takes the
 // RAW solved quaternion, Rs the normalised one (:2661-2669).  The six bias gates are chained by dangling `else`s (the
 // ROS_WARNs between them are commented out, :2689-2722), so only the FIRST bias component that passes is written (Q16).
-// rcv_dt is copied unconditionally (:2645-2647; the blocks carry no residuals, Q6).
+// rcv_dt is copied unconditionally (:2645-2647; the blocks carry no residuals, Q6) -- and the reference writes it ONE KEYFRAME EARLIER than
+// the other arrays: rcv_dt[i-1] <- tmp_rcv_dt[slot of i] while Ps[i], Vs[i] ... take slot i.  Row s of every array here is window slot s,
+// so pass rcv_dt = &rcv_dt[first_idx - 1][0] where the others get &X[first_idx] (host_writeback_test.cpp does).
 inline void writeBackState(int W, const double* tmpTrans, const double* tmpQuat, const double* tmpSpeedBias, const double* tmp_rcv_dt,
                            double* Ps, double* Qs, double* Vs, double* para_speed_bias, double* Bas, double* Bgs, double* abs_poses,
                            double* rcv_dt) {
@@ -169,9 +171,17 @@ public:
     int window() const { return W_; }
 
     // Estimator.cpp:2056  kd_tree_surf_local_map->setInputCloud(surf_local_map_ds)
-    void setLocalMap(const float* xyzi, int n) { check(glio_set_map(ctx_, xyzi, n), "glio_set_map"); }
+    void setLocalMap(const float* xyzi, int n) { check(glio_set_map(ctx_, xyzi, n), "glio_set_map"); map_points_ = n; }
+    // `if (surf_local_map_ds->points.size() > 50)` (Estimator.cpp:2221,2244): with a smaller map the reference adds NO LiDAR factor
+    // for the keyframe ("Not enough feature points from the map")
+    bool mapLargeEnough() const { return map_points_ > 50; }
     // Estimator.cpp:2216-2222  Q2 = Q*q_lb^-1, T2 = T - Q2*t_lb, findCorrespondingSurfFeatures(idx-1, Q2, T2)
     int findCorrespondingSurfFeatures(int slot, const float* scan_xyzi, int n) {
+        if (!mapLargeEnough()) {
+            check(glio_set_scan(ctx_, slot, scan_xyzi, n), "glio_set_scan");
+            check(glio_select_correspondences(ctx_, slot, nullptr, 0), "glio_select_correspondences");    // the slot carries no residuals
+            return 0;
+        }
         double q2[4], t2[3];
         lidarPose(slot, q2, t2);
         int cnt = 0;
@@ -229,6 +239,10 @@ public:
         std::vector<double> q2(4 * W_), t2(3 * W_);
         for (int s = 0; s < W_; ++s) lidarPose(s, &q2[4 * s], &t2[3 * s]);
         std::vector<int32_t> counts(W_, 0);
+        if (!mapLargeEnough()) {                                    // Estimator.cpp:2221: no LiDAR factors from a map of <= 50 points
+            for (int s = 0; s < W_; ++s) check(glio_select_correspondences(ctx_, s, nullptr, 0), "glio_select_correspondences");
+            return counts;
+        }
         check(glio_associate_window(ctx_, q2.data(), t2.data(), counts.data()), "glio_associate_window");
         return counts;
     }
@@ -247,6 +261,7 @@ public:
         check(glio_localmap_push(ctx_, cloud_xyzi, n, q, t), "glio_localmap_push");
         int pts = 0;
         check(glio_localmap_build(ctx_, &pts), "glio_localmap_build");
+        map_points_ = pts;
         return pts;
     }
     // shift the host-side state like the reference's slideWindow(): the newest slot is initialised by the caller
@@ -289,6 +304,7 @@ private:
     }
     glio_opts opts_;
     int W_;
+    int map_points_ = 0;
     glio_ctx* ctx_ = nullptr;
 };
 

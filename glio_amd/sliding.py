@@ -46,6 +46,9 @@ def feature_selection(backend, slot, count, feature_res_num, rng, random_select=
     return len(sel)
 
 
+MIN_MAP_POINTS = 50        # `if (surf_local_map_ds->points.size() > 50)` guards the correspondence search, Estimator.cpp:2221,2244
+
+
 class SlidingWindowDriver:
     def __init__(self, backend, opts, lidar_pose=capi.lidar_pose):
         self.be, self.opts, self.W = backend, opts, opts.window
@@ -68,6 +71,10 @@ class SlidingWindowDriver:
         be.set_map(map_pts)
         counts = []
         for s in range(W):
+            if len(map_pts) <= MIN_MAP_POINTS:          # Estimator.cpp:2221: "Not enough feature points from the map" -- no LiDAR factors
+                be.set_correspondences(s, np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32), np.zeros(0))
+                counts.append(0)
+                continue
             q2, t2 = self.lidar_pose(self.opts, self.state.quat[s], self.state.trans[s])
             counts.append(be.associate(s, scans[s], q2, t2))
         be.set_imu(preints)
@@ -117,7 +124,12 @@ class ResidentSlidingWindow:
             ctx.slide_window()
             ctx.set_scan(W - 1, scans[W - 1])
         poses = [self.lidar_pose(self.opts, self.state.quat[s], self.state.trans[s]) for s in range(W)]
-        counts = ctx.associate_window(np.array([p[0] for p in poses]), np.array([p[1] for p in poses]))
+        if len(map_pts) <= MIN_MAP_POINTS:              # Estimator.cpp:2221
+            for s in range(W):
+                ctx.set_correspondences(s, np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32), np.zeros(0))
+            counts = [0] * W
+        else:
+            counts = ctx.associate_window(np.array([p[0] for p in poses]), np.array([p[1] for p in poses]))
         ctx.set_imu(preints)
         sol, summ = ctx.solve(self.state)
         unify_quaternions(sol)

@@ -137,7 +137,7 @@ static int poly_roots_real(const double* c_in, int deg_in, double* re, int* n_ou
     if (rad > bound) rad = bound;
     double complex z[8];
     for (int i = 0; i < deg; ++i) z[i] = rad * cexp(I * (2.0 * M_PI * i / deg + 0.4));
-    for (int it = 0; it < 500; ++it) {
+    for (int it = 0; it < 100; ++it) {
         double move = 0, size = 0;
         for (int i = 0; i < deg; ++i) {
             double complex pv = 1.0, dv = 0.0;                 /* Horner: p and p' */
@@ -152,7 +152,7 @@ static int poly_roots_real(const double* c_in, int deg_in, double* re, int* n_ou
             if (cabs(w) > move) move = cabs(w);
             if (cabs(z[i]) > size) size = cabs(z[i]);
         }
-        if (move <= 1e-15 * size) break;
+        if (move <= 4e-15 * size) break;
     }
     for (int i = 0; i < deg; ++i) { re[i] = creal(z[i]); if (!isfinite(re[i])) return 0; }
     return 1;

@@ -1,18 +1,43 @@
-"""Wall time of the batch pose problem's trust-region rounds (glio_batch_solve_tr) at C4 size on one GPU."""
-import sys, time
-sys.path.insert(0, ".")
+"""Times the trust-region solve of the batch problem (pose-only and with the IMU chain) at the C4 shape on one GPU and prints the
+per-group time; with rocprofv3 --kernel-trace --stats around it this gives the per-kernel breakdown of a group.
+    python scripts/batch_tr_time.py [K] [per_kf]"""
+import json
+import os
+import sys
+import time
+
 import numpy as np
-from glio_amd import batch, ctypes_types as T
-K, band, per_kf = int(sys.argv[1]) if len(sys.argv) > 1 else 2000, 6, int(sys.argv[2]) if len(sys.argv) > 2 else 32768
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch  # noqa: E402
+from glio_amd import batch  # noqa: E402
+from glio_amd import ctypes_types as T  # noqa: E402
+
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+per_kf = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
+band = 6
 gt, init = batch.make_poses(K)
 ci, cj, cp, nc, score = batch.make_constraints(gt, 0, K, per_kf, band, device="cuda:0")
-st = batch.BatchStage(K, band, len(ci)); st.set_constraints(ci, cj, cp, nc, score)
+st = batch.BatchStage(K, band, len(ci))
+st.set_constraints(ci, cj, cp, nc, score)
 odo = gt.copy(); odo[:, :3] += np.random.default_rng(11).normal(0, 0.02, (K, 3))
 dd, frame = batch.make_batch_gnss(gt, seed=11)
-for rep in range(2):
+st.set_small_factors(batch.delta_q_pairs(odo, 3), dd, frame, threshold=10.0)
+out = {}
+for label, with_imu in (("pose_6", False), ("full_15", True)):
+    sb0 = None
+    if with_imu:
+        imu, sb_gt, sb0 = batch.make_batch_imu(K, seed=11)
+        st.set_imu(imu)
+    opts = T.batch_tr_opts(max_iterations=8)
+    st.solve_tr(init, opts, speed_bias=sb0)
+    st.counters()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    poses, rounds = batch.solve_batch_rounds(st, init, odo, 3, dd, frame, opts=T.batch_tr_opts(10))
+    res = st.solve_tr(init, opts, speed_bias=sb0)
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    lins = sum(r["iterations"] + 1 for r in rounds)
-    print("wall ms", round(dt * 1e3, 1), "solve ms", [round(r["solve_ms"], 2) for r in rounds], "iterations", [r["iterations"] for r in rounds],
-          "ms per linearisation", round(sum(r["solve_ms"] for r in rounds) / lins, 3), "err", np.abs(poses[:, :3] - gt[:, :3]).max())
+    c = st.counters()
+    out[label] = {"solve_ms": round(dt * 1e3, 3), "groups": int(c["groups"]), "ms_per_group": round(dt * 1e3 / c["groups"], 3), "iterations": int(res[-1].iterations),
+                  "final_cost": float(res[-1].final_cost)}
+print(json.dumps(out))

@@ -117,6 +117,6 @@ def test_cpp_full_batch_problem_rounds_match_python(tmp_path):
     for a, b in zip(info["rounds"], hist):
         assert int(a["iterations"]) == b["iterations"] and int(a["termination"]) == b["termination"]
         assert np.isclose(a["final_cost"], b["final_cost"], rtol=1e-12)
-    assert int(info["allreduces"]) == sum(1 + h["iterations"] for h in hist) or int(info["allreduces"]) >= 4
+    assert int(info["allreduces"]) == 0          # one rank: the library calls no collective at all (the hook is for world > 1)
     assert np.abs(rows - poses).max() < 1e-12
     st.close()
