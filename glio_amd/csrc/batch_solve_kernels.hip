@@ -24,6 +24,7 @@
 //   k_bcr_back    z_p = L^-T (w - U_a^T z_a - U_b^T z_b): the triangular solve inside one wavefront (no barriers)
 // Every sum has a fixed order: two runs are bit-identical.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -172,9 +173,142 @@ __global__ __launch_bounds__(BcrCfg<M>::THREADS) void k_bcr_elim(const int* skip
     }
 }
 
+// ------------------------------------------------------------------------------------------------ elimination, blocked (round 3)
+// The same factorisation of the panel [A_pp; A_ap; y^T] and then [A_bp] against L, without a workgroup barrier per pivot:
+// 16-column panels; per panel every participating wavefront carries the 16 x 16 diagonal block in lanes 0-15 (factored
+// redundantly, pivots and multipliers by v_readlane) and 48 of the rows below in lanes 16-63, so the 16 register steps factor the
+// block AND solve those rows; the trailing part takes its rank-16 update as v_mfma_f64_16x16x4 tiles with operands read from LDS
+// (the scheme of the window solver's packed LDS Cholesky, solver_kernels.hip, extended by the coupling rows).  Two barriers per
+// PANEL instead of one per pivot.  LDS: the packed lower triangle of A_pp (rows at i (i + 1) / 2) + M + 1 full rows
+// (pass 1: A_ap and y; pass 2: A_bp, solved against the finished L).
+#define BCR_E2_THREADS 512
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+template <int M> struct BcrE2 {
+    static constexpr int XS = M | 1, TRI = M * (M + 1) / 2 + ((M * (M + 1) / 2) & 1);
+    static constexpr size_t lds_bytes = (size_t)(TRI + (M + 1) * XS + 8) * 8;
+};
+__device__ __forceinline__ int bcr_pk(const int i) { return (i * (i + 1)) >> 1; }
+
+// one pass over the panels.  FACTOR: the diagonal rows are factored as well (rows below = remaining diagonal rows, then the R extra
+// rows); otherwise L is final and only the R extra rows are solved against it.
+template <int M, bool FACTOR>
+__device__ __forceinline__ void bcr_panels(double* __restrict__ Lt, double* __restrict__ X, const int R, int* s_bad) {
+    using C = BcrE2<M>;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
+    for (int k0 = 0; k0 < M; k0 += 16) {
+        const int nb = M - k0 < 16 ? M - k0 : 16, r0 = k0 + nb;
+        const int nd = FACTOR ? M - r0 : 0;            // diagonal rows below the block
+        const int mb = nd + R;
+        if (wv == 0 || wv * 48 < mb) {
+            const bool isdiag = lane < 16;
+            const int bi = wv * 48 + lane - 16;
+            const bool live = isdiag ? lane < nb : bi < mb;
+            double* prow = isdiag ? Lt + bcr_pk(live ? k0 + lane : 0) + k0 : (bi < nd ? Lt + bcr_pk(live ? r0 + bi : 0) + k0 : X + (size_t)(live ? bi - nd : 0) * C::XS + k0);
+            double a[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a[j] = (live && j < nb && (!isdiag || j <= lane)) ? prow[j] : ((isdiag && lane == j) ? 1.0 : 0.0);
+            bool bad = false;
+            if (FACTOR) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    double djj = readlane_d(a[j], j);
+                    if (!(djj > 0.0) || !isfinite(djj)) { bad = true; djj = 1.0; }
+                    const double rd = rsqrt(djj);
+                    const double lij = (lane == j) ? djj * rd : a[j] * rd;
+                    a[j] = lij;
+#pragma unroll
+                    for (int c = j + 1; c < 16; ++c) a[c] -= lij * readlane_d(lij, c);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {      // lanes 0-15 hold the finished block L_kk: x_j = a_j / L_jj, a_c -= x_j L_cj
+                    const double ljj = readlane_d(a[j], j);
+                    const double xj = isdiag ? a[j] : a[j] / ljj;
+                    a[j] = xj;
+#pragma unroll
+                    for (int c = j + 1; c < 16; ++c) { const double lcj = readlane_d(xj, c); if (!isdiag) a[c] -= xj * lcj; }
+                }
+            }
+            if (live && ((FACTOR && wv == 0) || !isdiag)) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) if (j < nb && (!isdiag || j <= lane)) prow[j] = a[j];
+            }
+            if (bad && wv == 0 && lane == 0) *s_bad = 1;
+        }
+        __syncthreads();
+        if (nb == 16 && r0 < M) {
+            const int Tr = (mb + 15) >> 4, Tc = (M - r0 + 15) >> 4;
+            for (int t = wv; t < Tr * Tc; t += BCR_E2_THREADS / 64) {
+                const int I = t / Tc, J = t - Tc * I;
+                if (FACTOR && 16 * I + 15 < nd && J > I) continue;           // strictly above the diagonal of the triangle
+                const int ba = 16 * I + li, cb = r0 + 16 * J + li;
+                const bool oka = ba < mb, okb = cb < M;
+                const double* pa = (ba < nd ? Lt + bcr_pk(r0 + (oka ? ba : 0)) : X + (size_t)(oka ? ba - nd : 0) * C::XS) + k0 + lk;
+                const double* pb = Lt + bcr_pk(okb ? cb : r0) + k0 + lk;
+                double ax[4], bx[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { ax[q] = pa[4 * q]; bx[q] = pb[4 * q]; }
+                v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(oka ? ax[q] : 0.0, okb ? bx[q] : 0.0, acc, 0, 0, 0);
+                const int colc = r0 + 16 * J + li;                          // C: lane l, register q -> row (l >> 4) + 4 q, column l & 15
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int br = 16 * I + lk + 4 * q;
+                    if (br >= mb || colc >= M) continue;
+                    if (br < nd) { if (colc <= r0 + br) Lt[bcr_pk(r0 + br) + colc] -= acc[q]; }
+                    else X[(size_t)(br - nd) * C::XS + colc] -= acc[q];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int M>
+__global__ __launch_bounds__(BCR_E2_THREADS) void k_bcr_elim2(const int* skip, const BcrElim* __restrict__ tab, const double* __restrict__ ws,
+                                                              double* __restrict__ L, double* __restrict__ Ua, double* __restrict__ Ub,
+                                                              double* __restrict__ w, int* fail) {
+    if (skip && *skip) return;
+    using C = BcrE2<M>;
+    extern __shared__ double bcr_lds[];
+    double* Lt = bcr_lds;                  // packed lower triangle of A_pp -> L
+    double* X = Lt + C::TRI;               // [M + 1][XS]
+    __shared__ int s_bad;
+    const BcrElim t = tab[blockIdx.x];
+    const int tid = threadIdx.x;
+    const size_t MM = (size_t)M * M;
+    if (tid == 0) s_bad = 0;
+    for (int e = tid; e < M * M; e += BCR_E2_THREADS) {
+        const int i = e / M, j = e - M * i;
+        if (j <= i) Lt[bcr_pk(i) + j] = ws[t.oD + e];
+        // row r of A[a][node] = column r of A[node][a] (C[ea], rows node): X[r][c] = C[c][r]
+        X[(size_t)j * C::XS + i] = t.a >= 0 ? ws[t.oCa + e] : 0.0;
+    }
+    for (int c = tid; c < M; c += BCR_E2_THREADS) X[(size_t)M * C::XS + c] = ws[t.oy + c];
+    __syncthreads();
+    bcr_panels<M, true>(Lt, X, M + 1, &s_bad);
+    // L (zeros above the diagonal), U_a, w out; A[b][node] in
+    for (int e = tid; e < M * M; e += BCR_E2_THREADS) {
+        const int i = e / M, j = e - M * i;
+        L[(size_t)t.node * MM + e] = j <= i ? Lt[bcr_pk(i) + j] : 0.0;
+        Ua[(size_t)t.node * MM + e] = X[(size_t)i * C::XS + j];
+    }
+    for (int c = tid; c < M; c += BCR_E2_THREADS) w[(size_t)t.node * M + c] = X[(size_t)M * C::XS + c];
+    __syncthreads();
+    if (t.b >= 0) {
+        for (int e = tid; e < M * M; e += BCR_E2_THREADS) { const int i = e / M, j = e - M * i; X[(size_t)i * C::XS + j] = ws[t.oCb + e]; }
+        __syncthreads();
+        bcr_panels<M, false>(Lt, X, M, &s_bad);
+        for (int e = tid; e < M * M; e += BCR_E2_THREADS) { const int i = e / M, j = e - M * i; Ub[(size_t)t.node * MM + e] = X[(size_t)i * C::XS + j]; }
+    } else {
+        for (int e = tid; e < M * M; e += BCR_E2_THREADS) Ub[(size_t)t.node * MM + e] = 0.0;
+    }
+    if (tid == 0 && s_bad) atomicOr(fail, 1);
+}
+
 // ------------------------------------------------------------------------------------------------ Schur updates of the kept nodes
 #define BCR_UP_THREADS 256
-typedef double v4f64 __attribute__((ext_vector_type(4)));
 // The three M x M x M products of a kept node (U U^T twice, U_b U_a^T once) on the matrix core.  The factors are staged in LDS,
 // rows padded with zeros to MP = 16 ceil(M / 16), columns to KP = 4 ceil(M / 4), row stride LD (odd: the 16 lanes of an operand
 // column group hit distinct banks).  v_mfma_f64_16x16x4 takes A[i][k] from lane i + 16 k and B[k][j] from lane j + 16 k, so for
@@ -185,21 +319,36 @@ template <int M> struct BcrUp {
     static constexpr int MP = ((M + 15) / 16) * 16, KP = ((M + 3) / 4) * 4, LD = KP | 1, T = MP / 16;
     static constexpr size_t lds_bytes = (size_t)(2 * MP * LD + M) * 8;
 };
-template <int M, class F>
-__device__ __forceinline__ void bcr_xyT_mfma(const double* __restrict__ X, const double* __restrict__ Y, const int tid, F&& acc) {
+// dst (M x M, global, row-major) = (ACCUM ? dst : 0) - X Y^T.  The tile's old values are the accumulator's initial value and X is
+// fed negated, so the product lands as "old - X Y^T" without a read-modify-write behind the chain; the next tile's old values are
+// loaded while the current chain runs.
+template <int M, bool ACCUM>
+__device__ __forceinline__ void bcr_xyT_mfma(const double* __restrict__ X, const double* __restrict__ Y, const int tid, double* __restrict__ dst) {
     using C = BcrUp<M>;
     const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-    for (int tile = wave; tile < C::T * C::T; tile += BCR_UP_THREADS / 64) {
+    constexpr int NW = BCR_UP_THREADS / 64;
+    auto load_init = [&](const int tile, v4f64& c) {
         const int I = tile / C::T, J = tile - C::T * I;
-        const double* px = X + (16 * I + li) * C::LD + lk;
-        const double* py = Y + (16 * J + li) * C::LD + lk;
-        v4f64 c = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-        for (int k0 = 0; k0 < C::KP; k0 += 4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(px[k0], py[k0], c, 0, 0, 0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = 16 * I + lk + 4 * q, col = 16 * J + li;
-            if (r < M && col < M) acc(r, col, c[q]);
+            c[q] = (ACCUM && tile < C::T * C::T && r < M && col < M) ? dst[r * M + col] : 0.0;
+        }
+    };
+    v4f64 cnext = {0.0, 0.0, 0.0, 0.0};
+    load_init(wave, cnext);
+    for (int tile = wave; tile < C::T * C::T; tile += NW) {
+        const int I = tile / C::T, J = tile - C::T * I;
+        v4f64 c = cnext;
+        load_init(tile + NW, cnext);
+        const double* px = X + (16 * I + li) * C::LD + lk;
+        const double* py = Y + (16 * J + li) * C::LD + lk;
+#pragma unroll 4
+        for (int k0 = 0; k0 < C::KP; k0 += 4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-px[k0], py[k0], c, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = 16 * I + lk + 4 * q, col = 16 * J + li;
+            if (r < M && col < M) dst[r * M + col] = c[q];
         }
     }
 }
@@ -230,7 +379,7 @@ __global__ __launch_bounds__(BCR_UP_THREADS) void k_bcr_update(const int* skip, 
         bcr_stage<M>(XA, Ub + (size_t)t.pl * MM, tid);
         for (int k = tid; k < M; k += BCR_UP_THREADS) wv[k] = w[(size_t)t.pl * M + k];
         __syncthreads();
-        bcr_xyT_mfma<M>(XA, XA, tid, [&](int r, int c, double s) { Dq[r * M + c] -= s; });
+        bcr_xyT_mfma<M, true>(XA, XA, tid, Dq);
         for (int r = tid; r < M; r += BCR_UP_THREADS) { double s = 0; for (int k = 0; k < M; ++k) s += XA[r * C::LD + k] * wv[k]; yq[r] -= s; }
         __syncthreads();
     }
@@ -239,15 +388,15 @@ __global__ __launch_bounds__(BCR_UP_THREADS) void k_bcr_update(const int* skip, 
         if (t.oCnew >= 0) bcr_stage<M>(XB, Ub + (size_t)t.pr * MM, tid);
         for (int k = tid; k < M; k += BCR_UP_THREADS) wv[k] = w[(size_t)t.pr * M + k];
         __syncthreads();
-        bcr_xyT_mfma<M>(XA, XA, tid, [&](int r, int c, double s) { Dq[r * M + c] -= s; });
-        if (t.oCnew >= 0) { double* Cn = ws + t.oCnew; bcr_xyT_mfma<M>(XB, XA, tid, [&](int r, int c, double s) { Cn[r * M + c] = -s; }); }   // A[b][a] = -U_b U_a^T
+        bcr_xyT_mfma<M, true>(XA, XA, tid, Dq);
+        if (t.oCnew >= 0) bcr_xyT_mfma<M, false>(XB, XA, tid, ws + t.oCnew);          // A[b][a] = -U_b U_a^T
         for (int r = tid; r < M; r += BCR_UP_THREADS) { double s = 0; for (int k = 0; k < M; ++k) s += XA[r * C::LD + k] * wv[k]; yq[r] -= s; }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ back substitution
 template <int M>
-__global__ __launch_bounds__(128) void k_bcr_back(const int* skip, const BcrElim* __restrict__ tab, const double* __restrict__ L, const double* __restrict__ Ua,
+__global__ __launch_bounds__(256) void k_bcr_back(const int* skip, const BcrElim* __restrict__ tab, const double* __restrict__ L, const double* __restrict__ Ua,
                                                   const double* __restrict__ Ub, const double* __restrict__ w, double* __restrict__ z) {
     if (skip && *skip) return;
     static_assert(M <= 128, "two rows per lane");
@@ -257,24 +406,32 @@ __global__ __launch_bounds__(128) void k_bcr_back(const int* skip, const BcrElim
     double* tv = Ls + M * LD;        // [M]
     double* za = tv + M;
     double* zb = za + M;
+    double* ta = zb + M;
     const BcrElim t = tab[blockIdx.x];
     const int tid = threadIdx.x;
     const size_t MM = (size_t)M * M;
-    for (int e = tid; e < M * M; e += 128) { const int r = e / M, c = e - M * r; Ls[r * LD + c] = L[(size_t)t.node * MM + e]; }
-    for (int k = tid; k < M; k += 128) { za[k] = t.a >= 0 ? z[(size_t)t.a * M + k] : 0.0; zb[k] = t.b >= 0 ? z[(size_t)t.b * M + k] : 0.0; }
+    for (int k = tid; k < M; k += 256) { za[k] = t.a >= 0 ? z[(size_t)t.a * M + k] : 0.0; zb[k] = t.b >= 0 ? z[(size_t)t.b * M + k] : 0.0; tv[k] = 0.0; }
+    for (int e = tid; e < M * M; e += 256) { const int r = e / M, c = e - M * r; Ls[r * LD + c] = L[(size_t)t.node * MM + e]; }
     __syncthreads();
-    if (tid < M) {
-        const double v = w[(size_t)t.node * M + tid];
-        double s1 = 0, s2 = 0;
-        if (t.a >= 0) { const double* U = Ua + (size_t)t.node * MM + tid; for (int r = 0; r < M; ++r) s1 += U[(size_t)r * M] * za[r]; }
-        if (t.b >= 0) { const double* U = Ub + (size_t)t.node * MM + tid; for (int r = 0; r < M; ++r) s2 += U[(size_t)r * M] * zb[r]; }
-        tv[tid] = (v - s1) - s2;
+    // t = w - U_a^T z_a - U_b^T z_b: threads [0, 128) take U_a, [128, 256) U_b (columns coalesced across the threads)
+    {
+        const int c = tid & 127, half = tid >> 7;
+        const int nbr = half ? t.b : t.a;
+        double part = 0;
+        if (c < M && nbr >= 0) {
+            const double* U = (half ? Ub : Ua) + (size_t)t.node * MM + c;
+            const double* zz = half ? zb : za;
+#pragma unroll 6
+            for (int r = 0; r < M; ++r) part += U[(size_t)r * M] * zz[r];
+        }
+        if (c < M) (half ? tv : ta)[c] = part;
     }
     __syncthreads();
     if (tid >= 64) return;
-    // L^T z = t inside wavefront 0, last unknown first; lane l holds t[l] and t[l + 64]; the solved entry travels by v_readlane
+    // L^T z = t inside wavefront 0, last unknown first; lane l holds t[l] and t[l + 64]; the solved entry travels by a shuffle
     const int lane = tid;
-    double t0 = lane < M ? tv[lane] : 0.0, t1 = lane + 64 < M ? tv[lane + 64] : 0.0;
+    double t0 = lane < M ? (w[(size_t)t.node * M + lane] - ta[lane]) - tv[lane] : 0.0;
+    double t1 = lane + 64 < M ? (w[(size_t)t.node * M + lane + 64] - ta[lane + 64]) - tv[lane + 64] : 0.0;
     for (int r = M - 1; r >= 0; --r) {
         const double diag = Ls[r * LD + r];
         const double tr = r >= 64 ? __shfl(t1, r - 64, 64) : __shfl(t0, r, 64);
@@ -447,8 +604,10 @@ void* glio_bcr_create2(int K, int band, int B, int rank, int world) {
     hipMemcpy(b->node_of_sblock_dev, b->node_of_sblock.data(), (size_t)nown * 4, hipMemcpyHostToDevice);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_update<72>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BcrUp<72>::lds_bytes);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_update<90>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BcrUp<90>::lds_bytes);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_back<72>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((72 * 73 + 3 * 72) * 8));
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_back<90>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((90 * 91 + 3 * 90) * 8));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_elim2<72>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BcrE2<72>::lds_bytes);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_elim2<90>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BcrE2<90>::lds_bytes);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_back<72>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((72 * 73 + 4 * 72) * 8));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_back<90>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((90 * 91 + 4 * 90) * 8));
     (void)hipGetLastError();
     return b;
 }
@@ -473,21 +632,27 @@ double* glio_bcr_sepbuf(void* h, long long* count) {
 }
 int* glio_bcr_fail_flag(void* h) { return static_cast<BcrDev*>(h)->fail; }
 
+// 1 (default): the blocked elimination (k_bcr_elim2); 0: one register step per pivot with a workgroup barrier each (k_bcr_elim), kept as the cross-check
+static int g_bcr_elim_mode = getenv("GLIO_BCR_ELIM") ? atoi(getenv("GLIO_BCR_ELIM")) : 1;
+void glio_bcr_debug_set_elim(int mode) { g_bcr_elim_mode = mode; }
 template <int M>
 static void bcr_levels(BcrDev* b, const BcrOp& op, int l0, int l1, hipStream_t stream) {
     const size_t lds_up = BcrUp<M>::lds_bytes;
     for (int l = l0; l < l1; ++l) {
         const int ne = b->h_elim_off[l + 1] - b->h_elim_off[l], nk = b->h_kept_off[l + 1] - b->h_kept_off[l];
-        if (ne > 0) hipLaunchKernelGGL((k_bcr_elim<M>), dim3(ne), dim3(BcrCfg<M>::THREADS), 0, stream, op.skip, b->elim + b->h_elim_off[l], b->ws, b->L, b->Ua, b->Ub, b->w, b->fail);
+        if (ne > 0) {
+            if (g_bcr_elim_mode == 0) hipLaunchKernelGGL((k_bcr_elim<M>), dim3(ne), dim3(BcrCfg<M>::THREADS), 0, stream, op.skip, b->elim + b->h_elim_off[l], b->ws, b->L, b->Ua, b->Ub, b->w, b->fail);
+            else hipLaunchKernelGGL((k_bcr_elim2<M>), dim3(ne), dim3(BCR_E2_THREADS), BcrE2<M>::lds_bytes, stream, op.skip, b->elim + b->h_elim_off[l], b->ws, b->L, b->Ua, b->Ub, b->w, b->fail);
+        }
         if (nk > 0) hipLaunchKernelGGL((k_bcr_update<M>), dim3(nk), dim3(BCR_UP_THREADS), lds_up, stream, op.skip, b->kept + b->h_kept_off[l], b->ws, b->Ua, b->Ub, b->w);
     }
 }
 template <int M>
 static void bcr_back(BcrDev* b, const BcrOp& op, int l0, int l1, hipStream_t stream) {
-    const size_t lds_back = (size_t)(M * (M + 1) + 3 * M) * 8;
+    const size_t lds_back = (size_t)(M * (M + 1) + 4 * M) * 8;
     for (int l = l1 - 1; l >= l0; --l) {
         const int ne = b->h_elim_off[l + 1] - b->h_elim_off[l];
-        if (ne > 0) hipLaunchKernelGGL((k_bcr_back<M>), dim3(ne), dim3(128), lds_back, stream, op.skip, b->elim + b->h_elim_off[l], b->L, b->Ua, b->Ub, b->w, b->z);
+        if (ne > 0) hipLaunchKernelGGL((k_bcr_back<M>), dim3(ne), dim3(256), lds_back, stream, op.skip, b->elim + b->h_elim_off[l], b->L, b->Ua, b->Ub, b->w, b->z);
     }
 }
 #define BCR_DISPATCH(fn, ...) do { if (b->M == 36) fn<36>(__VA_ARGS__); else if (b->M == 72) fn<72>(__VA_ARGS__); else fn<90>(__VA_ARGS__); } while (0)
