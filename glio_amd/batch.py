@@ -379,6 +379,76 @@ class BatchAssociation:
                                                              self.pair_count.ctypes.data_as(C.POINTER(C.c_int64)), cp, nc, sc))
 
 
+class RoundsAssociation:
+    """The association schedule of optimizeBatchWithLandMark's rounds (Estimator.cpp:3004-3076): the INTERIOR keyframes use the
+    constraints stored when they left the sliding window (gl_vec_surf_*, filled by findGlobalCorrespondingSurfFeaturesAdd_Batch
+    after each window solve -- here: associated once, at the poses given to `start`), the first / last `search_range` keyframes
+    are re-searched in EVERY round at the current poses (findGlobalCorrespondingSurfFeatures_Batch, :3018-3030).  Three resident
+    BatchAssociation objects (front ends, interior, back ends: the pair list in (ci, cj) order splits into these three runs);
+    `__call__(poses)` re-runs the two end sets and hands the concatenated device arrays to the stage -- the `reassociate` hook of
+    solve_batch_rounds.  (The random globalFeatureSelection_Batch draw is left to the caller, as everywhere.)"""
+
+    def __init__(self, stage, scans, search_range, max_points_per_frame, device=0):
+        self.stage, self.K, self.sr = stage, len(scans), search_range
+        K = self.K
+        ci, cj = pair_list(K, search_range)
+        front = ci < search_range
+        back = ci > K - 1 - search_range
+        self.parts = []
+        for mask in (front, ~(front | back), back):
+            pci, pcj = ci[mask], cj[mask]
+            ba = BatchAssociation(K, max_points_per_frame, max(1, int(mask.sum())) * max_points_per_frame, device=device)
+            need = sorted(set(pci.tolist()) | set(pcj.tolist()))
+            for k in need:
+                ba.set_frame(k, scans[k])
+            self.parts.append((ba, pci, pcj))
+        self.device = device
+        self.runs = 0
+
+    def close(self):
+        for ba, _, _ in self.parts:
+            ba.close()
+
+    def _run(self, which, poses):
+        ba, pci, pcj = self.parts[which]
+        if len(pci):
+            ba.run(poses, pci, pcj)
+            self.runs += 1
+
+    def _feed(self):
+        import torch
+        dev = f"cuda:{self.device}"
+
+        class _Dev:
+            def __init__(self, ptr, shape, typestr):
+                self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
+
+        cps, ncs, scs, cis, cjs = [], [], [], [], []
+        lib = capi.load()
+        for ba, pci, pcj in self.parts:
+            if not len(pci) or ba.total == 0:
+                continue
+            cp, nc, sc = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            capi._check(lib.glio_bassoc_results_dev(ba._h, C.byref(cp), C.byref(nc), C.byref(sc)))
+            n = int(ba.total)
+            cps.append(torch.as_tensor(_Dev(cp.value, (n, 4), "<f4"), device=dev)); ncs.append(torch.as_tensor(_Dev(nc.value, (n, 6), "<f8"), device=dev))
+            scs.append(torch.as_tensor(_Dev(sc.value, (n,), "<f8"), device=dev))
+            cis.append(np.repeat(pci, ba.pair_count)); cjs.append(np.repeat(pcj, ba.pair_count))
+        ci = np.concatenate(cis).astype(np.int32); cj = np.concatenate(cjs).astype(np.int32)
+        self.stage.set_constraints(ci, cj, torch.cat(cps).contiguous(), torch.cat(ncs).contiguous(), torch.cat(scs).contiguous())
+        self.n_constraints = len(ci)
+
+    def start(self, poses):
+        """all three sets at `poses` (the stored interior constraints are made here)"""
+        for w in range(3):
+            self._run(w, poses)
+        self._feed()
+
+    def __call__(self, poses):
+        self._run(0, poses); self._run(2, poses)
+        self._feed()
+
+
 # ------------------------------------------------------------------ the HIP stage
 ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
 

@@ -66,23 +66,37 @@ __global__ __launch_bounds__(256) void k_bcr_init(const BcrOp op, const BcrInit*
     const int cur = op.cur ? *op.cur : 0;
     const double* gsrc = op.gfull[cur];
     const int s = t.sblock;
-    for (int e = threadIdx.x; e < M * M; e += 256) {
-        const int i = e / M, j = e - M * i;
-        const int ka = s * sbk + i / B, r = i % B, kb = s * sbk + j / B, c = j % B;
-        if (t.oD >= 0) {
-            double x = h_entry(v, ka, r, kb, c);
-            if (ka < K && kb < K && op.sc) x *= op.sc[(size_t)ka * B + r] * op.sc[(size_t)kb * B + c];
-            if (i == j && ka < K) x += op.dadd ? op.dadd[(size_t)ka * B + r] : op.lambda * x + 1e-12;
-            ws[t.oD + e] = x;
-        }
-        if (t.oC >= 0) {          // A[s+1][s]: rows in super-block s+1, columns in s
-            const int kr = (s + 1) * sbk + i / B;
-            double x = 0.0;
-            if (kr < K && kb < K) {
-                x = h_entry(v, kr, r, kb, c);
-                if (op.sc) x *= op.sc[(size_t)kr * B + r] * op.sc[(size_t)kb * B + c];
+    constexpr int U = 4;
+    for (int e0 = threadIdx.x; e0 < M * M; e0 += U * 256) {          // four entries of either block in flight per thread
+        double xd[U], xc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * 256;
+            const int ee = e < M * M ? e : 0;
+            const int i = ee / M, j = ee - M * i;
+            const int ka = s * sbk + i / B, r = i % B, kb = s * sbk + j / B, c = j % B;
+            xd[u] = 0.0; xc[u] = 0.0;
+            if (t.oD >= 0) {
+                double x = h_entry(v, ka, r, kb, c);
+                if (ka < K && kb < K && op.sc) x *= op.sc[(size_t)ka * B + r] * op.sc[(size_t)kb * B + c];
+                if (i == j && ka < K) x += op.dadd ? op.dadd[(size_t)ka * B + r] : op.lambda * x + 1e-12;
+                xd[u] = x;
             }
-            ws[t.oC + e] = x;
+            if (t.oC >= 0) {          // A[s+1][s]: rows in super-block s+1, columns in s
+                const int kr = (s + 1) * sbk + i / B;
+                if (kr < K && kb < K) {
+                    double x = h_entry(v, kr, r, kb, c);
+                    if (op.sc) x *= op.sc[(size_t)kr * B + r] * op.sc[(size_t)kb * B + c];
+                    xc[u] = x;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * 256;
+            if (e >= M * M) continue;
+            if (t.oD >= 0) ws[t.oD + e] = xd[u];
+            if (t.oC >= 0) ws[t.oC + e] = xc[u];
         }
     }
     if (t.oy >= 0)
@@ -279,11 +293,22 @@ __global__ __launch_bounds__(BCR_E2_THREADS) void k_bcr_elim2(const int* skip, c
     const int tid = threadIdx.x;
     const size_t MM = (size_t)M * M;
     if (tid == 0) s_bad = 0;
-    for (int e = tid; e < M * M; e += BCR_E2_THREADS) {
-        const int i = e / M, j = e - M * i;
-        if (j <= i) Lt[bcr_pk(i) + j] = ws[t.oD + e];
-        // row r of A[a][node] = column r of A[node][a] (C[ea], rows node): X[r][c] = C[c][r]
-        X[(size_t)j * C::XS + i] = t.a >= 0 ? ws[t.oCa + e] : 0.0;
+    constexpr int U = 8;
+    for (int e0 = tid; e0 < M * M; e0 += U * BCR_E2_THREADS) {       // eight entries of either block in flight per thread
+        double vd[U], vc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * BCR_E2_THREADS, i = e / M, j = e - M * i;
+            vd[u] = (e < M * M && j <= i) ? ws[t.oD + e] : 0.0;
+            vc[u] = (e < M * M && t.a >= 0) ? ws[t.oCa + e] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * BCR_E2_THREADS, i = e / M, j = e - M * i;
+            if (e >= M * M) continue;
+            if (j <= i) Lt[bcr_pk(i) + j] = vd[u];
+            X[(size_t)j * C::XS + i] = vc[u];          // row r of A[a][node] = column r of A[node][a] (rows node): X[r][c] = C[c][r]
+        }
     }
     for (int c = tid; c < M; c += BCR_E2_THREADS) X[(size_t)M * C::XS + c] = ws[t.oy + c];
     __syncthreads();
@@ -297,7 +322,13 @@ __global__ __launch_bounds__(BCR_E2_THREADS) void k_bcr_elim2(const int* skip, c
     for (int c = tid; c < M; c += BCR_E2_THREADS) w[(size_t)t.node * M + c] = X[(size_t)M * C::XS + c];
     __syncthreads();
     if (t.b >= 0) {
-        for (int e = tid; e < M * M; e += BCR_E2_THREADS) { const int i = e / M, j = e - M * i; X[(size_t)i * C::XS + j] = ws[t.oCb + e]; }
+        for (int e0 = tid; e0 < M * M; e0 += U * BCR_E2_THREADS) {
+            double vc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int e = e0 + u * BCR_E2_THREADS; vc[u] = e < M * M ? ws[t.oCb + e] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int e = e0 + u * BCR_E2_THREADS, i = e / M, j = e - M * i; if (e < M * M) X[(size_t)i * C::XS + j] = vc[u]; }
+        }
         __syncthreads();
         bcr_panels<M, false>(Lt, X, M, &s_bad);
         for (int e = tid; e < M * M; e += BCR_E2_THREADS) { const int i = e / M, j = e - M * i; Ub[(size_t)t.node * MM + e] = X[(size_t)i * C::XS + j]; }
@@ -355,9 +386,19 @@ __device__ __forceinline__ void bcr_xyT_mfma(const double* __restrict__ X, const
 template <int M>
 __device__ __forceinline__ void bcr_stage(double* __restrict__ dst, const double* __restrict__ src, const int tid) {
     using C = BcrUp<M>;
-    for (int e = tid; e < C::MP * C::KP; e += BCR_UP_THREADS) {
-        const int r = e / C::KP, c = e - C::KP * r;
-        dst[r * C::LD + c] = (r < M && c < M) ? src[(size_t)r * M + c] : 0.0;
+    constexpr int N = C::MP * C::KP, U = 8;
+    for (int e0 = tid; e0 < N; e0 += U * BCR_UP_THREADS) {          // eight loads in flight per thread
+        double v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * BCR_UP_THREADS, r = e / C::KP, c = e - C::KP * r;
+            v[u] = (e < N && r < M && c < M) ? src[(size_t)r * M + c] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * BCR_UP_THREADS, r = e / C::KP, c = e - C::KP * r;
+            if (e < N) dst[r * C::LD + c] = v[u];
+        }
     }
 }
 
@@ -411,7 +452,13 @@ __global__ __launch_bounds__(256) void k_bcr_back(const int* skip, const BcrElim
     const int tid = threadIdx.x;
     const size_t MM = (size_t)M * M;
     for (int k = tid; k < M; k += 256) { za[k] = t.a >= 0 ? z[(size_t)t.a * M + k] : 0.0; zb[k] = t.b >= 0 ? z[(size_t)t.b * M + k] : 0.0; tv[k] = 0.0; }
-    for (int e = tid; e < M * M; e += 256) { const int r = e / M, c = e - M * r; Ls[r * LD + c] = L[(size_t)t.node * MM + e]; }
+    for (int e0 = tid; e0 < M * M; e0 += 8 * 256) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = e0 + u * 256; v[u] = e < M * M ? L[(size_t)t.node * MM + e] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = e0 + u * 256, r = e / M, c = e - M * r; if (e < M * M) Ls[r * LD + c] = v[u]; }
+    }
     __syncthreads();
     // t = w - U_a^T z_a - U_b^T z_b: threads [0, 128) take U_a, [128, 256) U_b (columns coalesced across the threads)
     {
@@ -421,8 +468,13 @@ __global__ __launch_bounds__(256) void k_bcr_back(const int* skip, const BcrElim
         if (c < M && nbr >= 0) {
             const double* U = (half ? Ub : Ua) + (size_t)t.node * MM + c;
             const double* zz = half ? zb : za;
-#pragma unroll 6
-            for (int r = 0; r < M; ++r) part += U[(size_t)r * M] * zz[r];
+            double p2[6] = {0, 0, 0, 0, 0, 0};
+            static_assert(M % 6 == 0, "six independent partial sums");
+            for (int r = 0; r < M; r += 6) {
+#pragma unroll
+                for (int u = 0; u < 6; ++u) p2[u] += U[(size_t)(r + u) * M] * zz[r + u];
+            }
+            part = ((p2[0] + p2[1]) + (p2[2] + p2[3])) + (p2[4] + p2[5]);
         }
         if (c < M) (half ? tv : ta)[c] = part;
     }

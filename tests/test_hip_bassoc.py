@@ -124,3 +124,48 @@ def test_batch_feature_selection_gathers_on_device():
     Hg = st.new_hg(); st.linearize(poses, Hg)
     assert float(Hg[-1].item()) > 0
     st.close(); ba.close()
+
+
+def test_rounds_with_reassociation_follow_the_oracle(frames):
+    """The measured form of optimizeBatch's outer loop: the end keyframes are re-searched in every DDpsr_threshold round at the
+    current poses, the interior keeps its stored constraints (Estimator.cpp:3004-3076) -- device (RoundsAssociation + the
+    trust-region solve) against the oracle doing the same with associate_pair + orc_batch2_solve."""
+    from glio_amd import ctypes_types as T
+    from oracle import pyoracle as po
+    scans, poses0 = frames
+    K, sr = len(scans), 2
+    band = 2 * sr
+    rng = np.random.default_rng(7)
+    odo = poses0.copy(); odo[:, :3] += rng.normal(0, 0.01, (K, 3))
+    st = batch.BatchStage(K, band, 400000)
+    ra = batch.RoundsAssociation(st, scans, sr, 4096)
+    ra.start(poses0)
+    opts = T.batch_tr_opts(max_iterations=10)
+    thresholds = batch.DDPSR_THRESHOLDS[:3]
+    poses, hist = batch.solve_batch_rounds(st, poses0, odo, sr, [], None, reassociate=ra, opts=opts, thresholds=thresholds)
+    assert ra.runs == 3 + 2 * len(thresholds)
+    # ---- the oracle: interior pairs once at poses0, end pairs again at the start of every round
+    ci, cj = batch.pair_list(K, sr)
+    ends = (ci < sr) | (ci > K - 1 - sr)
+
+    def assoc(pairs, at):
+        out = {}
+        for a, b in pairs:
+            out[(a, b)] = po.associate_pair(scans[a], at[a], scans[b], at[b])[:3]
+        return out
+
+    stored = assoc([(a, b) for a, b, e in zip(ci, cj, ends) if not e], poses0)
+    ref = poses0.copy()
+    dq = batch.delta_q_pairs(odo, sr)
+    for _ in thresholds:
+        cur = dict(stored)
+        cur.update(assoc([(a, b) for a, b, e in zip(ci, cj, ends) if e], ref))
+        cis, cjs, cps, ncs, scs = [], [], [], [], []
+        for a, b in zip(ci, cj):
+            cp, nc, sc = cur[(a, b)]
+            cis.append(np.full(len(sc), a, np.int32)); cjs.append(np.full(len(sc), b, np.int32)); cps.append(cp); ncs.append(nc); scs.append(sc)
+        P = po.BatchProblem(K, band, np.concatenate(cis), np.concatenate(cjs), np.concatenate(cps), np.concatenate(ncs), np.concatenate(scs), dq=dq)
+        ref, summ = P.solve(ref, opts)
+    assert np.abs(poses - ref).max() < 1e-7
+    assert hist[-1]["final_cost"] <= hist[0]["initial_cost"]
+    ra.close(); st.close()
