@@ -684,8 +684,9 @@ double* glio_bcr_sepbuf(void* h, long long* count) {
 }
 int* glio_bcr_fail_flag(void* h) { return static_cast<BcrDev*>(h)->fail; }
 
-// 1 (default): the blocked elimination (k_bcr_elim2); 0: one register step per pivot with a workgroup barrier each (k_bcr_elim), kept as the cross-check
-static int g_bcr_elim_mode = getenv("GLIO_BCR_ELIM") ? atoi(getenv("GLIO_BCR_ELIM")) : 1;
+// -1 (default): by size -- the blocked elimination (k_bcr_elim2) for M >= 72, one register step per pivot with a workgroup barrier each
+// (k_bcr_elim) for M = 36, where it is the faster one (15 vs 19 us on MI355X); 1 / 0 force either (GLIO_BCR_ELIM, cross-checks)
+static int g_bcr_elim_mode = getenv("GLIO_BCR_ELIM") ? atoi(getenv("GLIO_BCR_ELIM")) : -1;
 void glio_bcr_debug_set_elim(int mode) { g_bcr_elim_mode = mode; }
 template <int M>
 static void bcr_levels(BcrDev* b, const BcrOp& op, int l0, int l1, hipStream_t stream) {
@@ -693,7 +694,7 @@ static void bcr_levels(BcrDev* b, const BcrOp& op, int l0, int l1, hipStream_t s
     for (int l = l0; l < l1; ++l) {
         const int ne = b->h_elim_off[l + 1] - b->h_elim_off[l], nk = b->h_kept_off[l + 1] - b->h_kept_off[l];
         if (ne > 0) {
-            if (g_bcr_elim_mode == 0) hipLaunchKernelGGL((k_bcr_elim<M>), dim3(ne), dim3(BcrCfg<M>::THREADS), 0, stream, op.skip, b->elim + b->h_elim_off[l], b->ws, b->L, b->Ua, b->Ub, b->w, b->fail);
+            if (g_bcr_elim_mode == 0 || (g_bcr_elim_mode < 0 && M < 72)) hipLaunchKernelGGL((k_bcr_elim<M>), dim3(ne), dim3(BcrCfg<M>::THREADS), 0, stream, op.skip, b->elim + b->h_elim_off[l], b->ws, b->L, b->Ua, b->Ub, b->w, b->fail);
             else hipLaunchKernelGGL((k_bcr_elim2<M>), dim3(ne), dim3(BCR_E2_THREADS), BcrE2<M>::lds_bytes, stream, op.skip, b->elim + b->h_elim_off[l], b->ws, b->L, b->Ua, b->Ub, b->w, b->fail);
         }
         if (nk > 0) hipLaunchKernelGGL((k_bcr_update<M>), dim3(nk), dim3(BCR_UP_THREADS), lds_up, stream, op.skip, b->kept + b->h_kept_off[l], b->ws, b->Ua, b->Ub, b->w);

@@ -95,6 +95,9 @@ int orc_associate(const glio_opts* o, const float* map_pts /*[M][4]*/, int M,
 int orc_associate_mt(const glio_opts* o, const float* map_pts, int M, const float* scan, int n, const double q[4],
                      const double t[3], float* out_pts, float* out_planes, double* out_scores,
                      int32_t* out_src_index, int32_t* out_nn, int threads);
+/* bench.py's CPU baseline only: 1 = the nearest-neighbour phase of orc_associate* uses a voxel grid of edge sqrt(kd_max_radius)
+ * instead of the brute force (identical records for every query that passes the radius gate); parity tests keep the default 0 */
+void orc_set_assoc_grid(int on);
 /* colPivHouseholderQr().solve for the 5x3 system A n = b  (Estimator.cpp:3661) */
 void orc_plane_qr_solve(const double A[15], const double b[5], double x[3]);
 

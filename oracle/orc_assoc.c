@@ -99,6 +99,68 @@ static void knn5_brute(const float* map, int M, float px, float py, float pz, fl
     }
 }
 
+/* ---- a grid index for the CPU baseline (bench.py): the same exact answer as the brute force for every query that passes the
+ * radius gate.  Cells of edge sqrt(kd_max_radius) (the gate compares the SQUARED 5th distance with kd_max_radius, quirk Q1), so
+ * every map point within the gate radius of a query lies in the 27 cells around the query's cell; candidates are ranked by
+ * (float distance, map index) exactly as knn5_brute ranks them.  A query whose fifth candidate fails the gate is rejected by
+ * the caller either way (with the brute force its true fifth neighbour is at least as far). */
+typedef struct { double edge; float lo[3]; int dim[3]; int* start; int* order; } orc_grid;
+static int grid_cell(const orc_grid* g, float x, float y, float z, int c[3]) {
+    const float p[3] = {x, y, z};
+    for (int k = 0; k < 3; ++k) { c[k] = (int)floor(((double)p[k] - (double)g->lo[k]) / g->edge); }
+    return c[0] >= -1 && c[0] <= g->dim[0] && c[1] >= -1 && c[1] <= g->dim[1] && c[2] >= -1 && c[2] <= g->dim[2];
+}
+static int grid_build(orc_grid* g, const float* map, int M, double edge) {
+    float hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    g->edge = edge; g->lo[0] = g->lo[1] = g->lo[2] = FLT_MAX; g->start = NULL; g->order = NULL;
+    for (int m = 0; m < M; ++m) for (int k = 0; k < 3; ++k) { const float v = map[4 * (size_t)m + k]; if (v < g->lo[k]) g->lo[k] = v; if (v > hi[k]) hi[k] = v; }
+    double cells = 1;
+    for (int k = 0; k < 3; ++k) { g->dim[k] = M > 0 ? (int)floor(((double)hi[k] - (double)g->lo[k]) / edge) + 1 : 1; cells *= g->dim[k]; }
+    if (M <= 0 || cells > 64e6) return 0;
+    const size_t nc = (size_t)cells;
+    g->start = (int*)calloc(nc + 1, sizeof(int));
+    g->order = (int*)malloc(sizeof(int) * (size_t)M);
+    int* cid = (int*)malloc(sizeof(int) * (size_t)M);
+    for (int m = 0; m < M; ++m) {
+        int c[3];
+        grid_cell(g, map[4 * (size_t)m], map[4 * (size_t)m + 1], map[4 * (size_t)m + 2], c);
+        for (int k = 0; k < 3; ++k) { if (c[k] < 0) c[k] = 0; if (c[k] >= g->dim[k]) c[k] = g->dim[k] - 1; }
+        cid[m] = (c[0] * g->dim[1] + c[1]) * g->dim[2] + c[2];
+        g->start[cid[m] + 1]++;
+    }
+    for (size_t c = 0; c < nc; ++c) g->start[c + 1] += g->start[c];
+    int* fill = (int*)malloc(sizeof(int) * nc);
+    memcpy(fill, g->start, sizeof(int) * nc);
+    for (int m = 0; m < M; ++m) g->order[fill[cid[m]]++] = m;          /* ascending map index inside a cell */
+    free(fill); free(cid);
+    return 1;
+}
+static void knn5_grid(const orc_grid* g, const float* map, float px, float py, float pz, float bd[5], int bi[5]) {
+    for (int k = 0; k < 5; ++k) { bd[k] = FLT_MAX; bi[k] = -1; }
+    int c[3];
+    if (!grid_cell(g, px, py, pz, c)) return;
+    for (int dx = -1; dx <= 1; ++dx) for (int dy = -1; dy <= 1; ++dy) for (int dz = -1; dz <= 1; ++dz) {
+        const int x = c[0] + dx, y = c[1] + dy, z = c[2] + dz;
+        if (x < 0 || y < 0 || z < 0 || x >= g->dim[0] || y >= g->dim[1] || z >= g->dim[2]) continue;
+        const int cell = (x * g->dim[1] + y) * g->dim[2] + z;
+        for (int s = g->start[cell]; s < g->start[cell + 1]; ++s) {
+            const int m = g->order[s];
+            const float* mp = map + 4 * (size_t)m;
+            const float ex = px - mp[0], ey = py - mp[1], ez = pz - mp[2];
+            float d = ex * ex; d = d + ey * ey; d = d + ez * ez;
+            if (d < bd[4] || (d == bd[4] && m < bi[4])) {
+                int k = 4;
+                while (k > 0 && (d < bd[k - 1] || (d == bd[k - 1] && m < bi[k - 1]))) { bd[k] = bd[k - 1]; bi[k] = bi[k - 1]; --k; }
+                bd[k] = d; bi[k] = m;
+            }
+        }
+    }
+}
+static int g_assoc_use_grid = 0;
+/* bench.py's CPU baseline: 1 = index the map with the grid above (same records as the brute force; falls back to it when the
+ * map's bounding box has more than 6.4e7 cells); parity tests keep 0 */
+void orc_set_assoc_grid(int on) { g_assoc_use_grid = on; }
+
 int orc_associate(const glio_opts* o, const float* map, int M, const float* scan, int n,
                   const double q[4], const double t[3], float* out_pts, float* out_planes,
                   double* out_scores, int32_t* out_src, int32_t* out_nn) {
@@ -113,6 +175,8 @@ int orc_associate_mt(const glio_opts* o, const float* map, int M, const float* s
                      double* out_scores, int32_t* out_src, int32_t* out_nn, int threads) {
     int cnt = 0;
     int* all_bi = NULL; float* all_bd = NULL;
+    orc_grid grid;
+    const int use_grid = g_assoc_use_grid && grid_build(&grid, map, M, sqrt(o->kd_max_radius));
     if (threads > 1) {
         all_bi = (int*)malloc(sizeof(int) * 5 * (size_t)(n > 0 ? n : 1));
         all_bd = (float*)malloc(sizeof(float) * 5 * (size_t)(n > 0 ? n : 1));
@@ -122,7 +186,8 @@ int orc_associate_mt(const glio_opts* o, const float* map, int M, const float* s
             double pin[3] = {pl[0], pl[1], pl[2]}, pout[3];
             q_rot(q, pin, pout);
             const float px = (float)(pout[0] + t[0]), py = (float)(pout[1] + t[1]), pz = (float)(pout[2] + t[2]);
-            knn5_brute(map, M, px, py, pz, all_bd + 5 * (size_t)i, all_bi + 5 * (size_t)i);
+            if (use_grid) knn5_grid(&grid, map, px, py, pz, all_bd + 5 * (size_t)i, all_bi + 5 * (size_t)i);
+            else knn5_brute(map, M, px, py, pz, all_bd + 5 * (size_t)i, all_bi + 5 * (size_t)i);
         }
     }
     for (int i = 0; i < n; ++i) {
@@ -135,6 +200,7 @@ int orc_associate_mt(const glio_opts* o, const float* map, int M, const float* s
         float bd[5];
         int bi[5];
         if (all_bi) { for (int k = 0; k < 5; ++k) { bd[k] = all_bd[5 * (size_t)i + k]; bi[k] = all_bi[5 * (size_t)i + k]; } }
+        else if (use_grid) knn5_grid(&grid, map, px, py, pz, bd, bi);
         else knn5_brute(map, M, px, py, pz, bd, bi);
         if (out_nn) for (int k = 0; k < 5; ++k) out_nn[5 * (size_t)i + k] = bi[k];
         if (!(bi[4] >= 0 && (double)bd[4] < o->kd_max_radius)) continue;              /* :3651 */
@@ -164,6 +230,7 @@ int orc_associate_mt(const glio_opts* o, const float* map, int M, const float* s
         ++cnt;
     }
     free(all_bi); free(all_bd);
+    if (use_grid) { free(grid.start); free(grid.order); }
     return cnt;
 }
 
