@@ -1428,6 +1428,7 @@ int glio_bassoc_set_frame(glio_bassoc* b, int k, const float* scan_xyzi, int n) 
 
 int glio_bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj,
                     int64_t* pair_count_out, int64_t* total_out) {
+    GLIO_TRACE("K2 glio_bassoc_run (batch association)");
     if (!b || !poses || n_pairs < 0 || (n_pairs > 0 && (!pair_ci || !pair_cj))) return GLIO_E_ARG;
     BA_CHECK(hipSetDevice(b->device));
     for (int p = 0; p < n_pairs; ++p)

@@ -632,6 +632,7 @@ static void enqueue_batch_linearize(glio_batch* b, double* Hg_dev) {
 }
 
 int glio_batch_linearize_dev(glio_batch* b, const double* poses, double* Hg_dev) {
+    GLIO_TRACE("K8 glio_batch_linearize_dev");
     if (!b || !poses || !Hg_dev) return GLIO_E_ARG;
     GLIO_HIP_CHECK(hipSetDevice(b->device));
     memcpy(b->h_poses, poses, (size_t)b->K * 7 * 8);
@@ -718,6 +719,7 @@ int glio_batch_time_solve(glio_batch* b, const double* Hg_dev, double lambda, in
 }
 
 int glio_batch_step_dev(glio_batch* b, const double* Hg_dev, double lambda, const double* poses_in, double* poses_out, double* model_decrease) {
+    GLIO_TRACE("glio_batch_step_dev (banded solve)");
     if (!b || !Hg_dev || !poses_in || !poses_out) return GLIO_E_ARG;
     GLIO_HIP_CHECK(hipSetDevice(b->device));
     const int K = b->K, band = b->band;

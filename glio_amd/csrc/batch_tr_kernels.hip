@@ -1123,6 +1123,7 @@ int glio_batch_linearize_full(glio_batch* b, const double* poses, const double* 
 // it; torch.distributed.all_reduce with that stream current): the host does not wait for it.  Five calls per trust-region group (file
 // header), the same on every rank.  poses [K][7] in/out, speed_bias [K][9] in/out (with the IMU chain; else ignored, may be NULL).
 int glio_batch_solve_tr2(glio_batch* b, double* poses, double* speed_bias, const glio_batch_tr_opts* o, glio_allreduce_fn allreduce, void* user, glio_summary* sum) {
+    GLIO_TRACE("K8 + trust region glio_batch_solve_tr2");
     if (!b || !poses || !o || !sum) return GLIO_E_ARG;
     BT_CHECK(hipSetDevice(b->device));
     { const int rc = small_ensure(b); if (rc) return rc; }

@@ -42,6 +42,28 @@ struct CtxExtra {
 static CtxExtra* extra_of(glio_ctx* c) { return static_cast<CtxExtra*>(c->extra); }
 GnssDevExtra* glio_extra(glio_ctx* c) { return &extra_of(c)->gx; }
 
+// ---- roctx ranges (GLIO_ROCTX=1)
+#include <dlfcn.h>
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char* e = getenv("GLIO_ROCTX");
+        if (!e || atoi(e) == 0) return;
+        void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) { push = nullptr; pop = nullptr; }
+    }
+};
+Roctx& roctx() { static Roctx r; return r; }
+}  // namespace
+GlioTraceRange::GlioTraceRange(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+GlioTraceRange::~GlioTraceRange() { if (on) roctx().pop(); }
+
 extern "C" {
 
 int glio_abi_version(void) { return 4; }   // 3: glio_opts.lidar_precision, the batch pose problem (small factors, trust-region solve), 9 struct sizes
@@ -276,6 +298,7 @@ int glio_get_correspondences(glio_ctx* c, int slot, float* pts, float* planes, d
 }
 
 int glio_set_map(glio_ctx* c, const float* map_xyzi, int n) {
+    GLIO_TRACE("K1 glio_set_map (voxel hash build)");
     if (!c || !map_xyzi || n < 0 || n > c->opts.max_map_points) { glio_set_error("bad map size"); return GLIO_E_ARG; }
     GLIO_HIP_CHECK(hipSetDevice(c->device));
     return glio_assoc_build_map(c, map_xyzi, n);
@@ -291,6 +314,7 @@ int glio_set_scan(glio_ctx* c, int slot, const float* scan, int n) {
     return GLIO_OK;
 }
 int glio_associate_resident(glio_ctx* c, int slot, const double q[4], const double t[3], int* out_count) {
+    GLIO_TRACE("K2 glio_associate_resident");
     if (!c || slot < 0 || slot >= c->W) return GLIO_E_ARG;
     GLIO_HIP_CHECK(hipSetDevice(c->device));
     const int rc = glio_assoc_run(c, slot, q, t, out_count);
@@ -316,6 +340,7 @@ int glio_select_correspondences(glio_ctx* c, int slot, const int32_t* indices, i
     return glio_assoc_select(c, slot, indices, n);
 }
 int glio_associate_window(glio_ctx* c, const double* quats, const double* trans, int32_t* out_counts) {
+    GLIO_TRACE("K2 glio_associate_window");
     if (!c || !quats || !trans) return GLIO_E_ARG;
     GLIO_HIP_CHECK(hipSetDevice(c->device));
     const int rc = glio_assoc_run_window(c, quats, trans, out_counts);
@@ -323,6 +348,7 @@ int glio_associate_window(glio_ctx* c, const double* quats, const double* trans,
     return rc;
 }
 int glio_associate(glio_ctx* c, int slot, const float* scan, int n, const double q[4], const double t[3], int* out_count) {
+    GLIO_TRACE("K2 glio_associate");
     const int rc = glio_set_scan(c, slot, scan, n);
     if (rc != GLIO_OK) return rc;
     return glio_associate_resident(c, slot, q, t, out_count);
@@ -750,6 +776,7 @@ static void fill_summary(glio_ctx* c, glio_summary* sum) {
 }
 
 int glio_solve(glio_ctx* c, glio_state* s, glio_summary* sum) {
+    GLIO_TRACE("K3-K7 glio_solve (linearise + trust region, device resident)");
     int rc = check_state(c, s);
     if (rc) return rc;
     GLIO_HIP_CHECK(hipSetDevice(c->device));
@@ -793,6 +820,7 @@ int glio_solve(glio_ctx* c, glio_state* s, glio_summary* sum) {
 }
 
 int glio_linearize(glio_ctx* c, const glio_state* s, double* H, double* g, double* cost) {
+    GLIO_TRACE("K3-K6 glio_linearize");
     int rc = check_state(c, s);
     if (rc) return rc;
     GLIO_HIP_CHECK(hipSetDevice(c->device));
@@ -812,6 +840,7 @@ int glio_linearize(glio_ctx* c, const glio_state* s, double* H, double* g, doubl
 // ---------------------------------------------------------------------------------------------- marginalization
 int glio_marginalize(glio_ctx* c, const glio_state* s, double* lin_jac, double* lin_res, int32_t* blk_slot, int32_t* blk_kind,
                      int32_t* blk_idx, double* blk_x0, int32_t* out_n, int32_t* out_n_blocks) {
+    GLIO_TRACE("glio_marginalize");
     int rc = check_state(c, s);
     if (rc) return rc;
     if (!lin_jac || !lin_res || !blk_slot || !blk_kind || !blk_idx || !blk_x0) { glio_set_error("null output"); return GLIO_E_ARG; }
@@ -854,6 +883,7 @@ int glio_marginalize(glio_ctx* c, const glio_state* s, double* lin_jac, double* 
 // copied device to device; only the small block tables are rebuilt on the host).  The caller slides its state arrays by one
 // keyframe afterwards.  Equivalent to glio_marginalize + glio_set_prior(result), minus two PCIe trips of the n x n matrix.
 int glio_marginalize_keep(glio_ctx* c, const glio_state* s) {
+    GLIO_TRACE("glio_marginalize_keep");
     int rc = check_state(c, s);
     if (rc) return rc;
     const int W = c->W;

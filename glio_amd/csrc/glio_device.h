@@ -318,6 +318,10 @@ int glio_assoc_run(glio_ctx* c, int slot, const double q[4], const double t[3], 
 void glio_assoc_time_hooks(glio_ctx* c, int which, int reps, float* ms);
 
 void glio_set_error(const char* fmt, ...);
+// roctx range around a C-ABI entry point (SURVEY section 5 "tracing"): visible in rocprofv3 --marker-trace when GLIO_ROCTX=1 (libroctx64 is
+// opened with dlopen: no link dependency, no cost when the switch is off)
+struct GlioTraceRange { explicit GlioTraceRange(const char* name); ~GlioTraceRange(); bool on; };
+#define GLIO_TRACE(name) GlioTraceRange glio_trace_range_(name)
 #define GLIO_HIP_CHECK(expr)                                                              \
     do {                                                                                  \
         hipError_t e_ = (expr);                                                           \

@@ -326,6 +326,7 @@ int glio_localmap_push(glio_ctx* c, const float* cloud_xyzi, int n, const double
 }
 
 int glio_localmap_build(glio_ctx* c, int* out_points) {
+    GLIO_TRACE("K1 glio_localmap_build (voxel grid + hash)");
     if (!c || !c->localmap) { glio_set_error("glio_localmap_config first"); return GLIO_E_STATE; }
     LocalMap* m = c->localmap;
     LM_CHECK(hipSetDevice(c->device));

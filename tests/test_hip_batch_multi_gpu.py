@@ -1,0 +1,74 @@
+"""The sharded batch solve over RCCL with one process per GPU.  Needs >= 2 visible devices: skipped on a one-GPU box (there the
+same sharding logic runs on virtual ranks, tests/test_hip_batch_tr.py::test_sharded_solve_on_virtual_ranks_equals_one_rank, and
+under gloo with a CPU stand-in, tests/test_batch_dist_cpu.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _problem(K=96, band=6, per_kf=120, seed=57):
+    from glio_amd import batch
+    gt, init = batch.make_poses(K, seed=seed, perturb=(0.08, 0.004))
+    ci, cj, cp, nc, score = batch.make_constraints(gt, 0, K, per_kf, band, seed=seed)
+    odo = gt.copy(); odo[:, :3] += np.random.default_rng(seed).normal(0, 0.02, (K, 3))
+    dq = batch.delta_q_pairs(odo, 3)
+    dd, frame = batch.make_batch_gnss(gt, seed=seed)
+    for f in dd:
+        f.threshold = 10.0
+    imu, sb_gt, sb0 = batch.make_batch_imu(K, seed=seed)
+    return K, band, init, (ci, cj, cp.numpy(), nc.numpy(), score.numpy()), dq, dd, frame, imu, sb0
+
+
+def _rank(rank, world, port, out_path):
+    import torch
+    import torch.distributed as dist
+    from glio_amd import batch
+    from glio_amd import ctypes_types as T
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    K, band, init, con, dq, dd, frame, imu, sb0 = _problem()
+    lo, hi = batch.shard_range(K, rank, world, band)
+    own = (con[0] >= lo) & (con[0] < hi)
+    st = batch.BatchStage(K, band, max(1, int(own.sum())), device=rank)
+    st.set_shard(rank, world)
+    st.set_constraints(*[c[own] for c in con])
+    st.set_small_factors(dq, dd, frame)
+    st.set_imu(imu)
+    poses, sb, summ = st.solve_tr(init, T.batch_tr_opts(max_iterations=12), dist, speed_bias=sb0)
+    if rank == 0:
+        np.savez(out_path, poses=poses, sb=sb, iterations=summ.iterations, termination=summ.termination, cost=summ.final_cost, calls=st.allreduces)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_gpus_over_rccl_equal_one_gpu(tmp_path):
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs (one process per GPU over RCCL)")
+    import torch.multiprocessing as mp
+    from glio_amd import batch
+    from glio_amd import ctypes_types as T
+    out = str(tmp_path / "two.npz")
+    mp.spawn(_rank, args=(2, _free_port(), out), nprocs=2, join=True)
+    two = np.load(out)
+    K, band, init, con, dq, dd, frame, imu, sb0 = _problem()
+    st = batch.BatchStage(K, band, len(con[0]))
+    st.set_constraints(*con); st.set_small_factors(dq, dd, frame); st.set_imu(imu)
+    poses, sb, summ = st.solve_tr(init, T.batch_tr_opts(max_iterations=12), speed_bias=sb0)
+    st.close()
+    assert int(two["iterations"]) == summ.iterations and int(two["termination"]) == summ.termination
+    assert np.isclose(float(two["cost"]), summ.final_cost, rtol=1e-9)
+    assert np.abs(two["poses"] - poses).max() < 1e-9 and np.abs(two["sb"] - sb).max() < 1e-8
+    assert int(two["calls"]) >= 1 + 5 * summ.iterations
