@@ -20,18 +20,17 @@ def _stale():
 def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950: cross-compiles without a GPU.  Every source becomes its own object (recompiled only when
     it or a header changed, all stale ones in parallel), then one link."""
-    if not force and not _stale():
-        return LIB
     from concurrent.futures import ThreadPoolExecutor
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
     objdir = os.path.join(os.path.dirname(LIB), "obj")
-    os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value"] + \
         (["-DGLIO_DEV_STAMPS"] if os.environ.get("GLIO_DEV_STAMPS") == "1" else []) + os.environ.get("GLIO_EXTRA_DEFS", "").split()
     tag = os.path.join(objdir, "flags.txt")
     flag_str = " ".join(flags)
-    if not os.path.exists(tag) or open(tag).read() != flag_str:
-        force = True
+    if os.path.exists(LIB) and os.path.exists(tag) and open(tag).read() != flag_str:
+        force = True                  # built with other defines (e.g. GLIO_DEV_STAMPS): everything again
+    if not force and not _stale():
+        return LIB
+    os.makedirs(objdir, exist_ok=True)
     hdr_t = max(os.path.getmtime(h) for h in HEADERS)
     jobs = []
     for s in SOURCES:

@@ -194,14 +194,25 @@ __global__ __launch_bounds__(BcrCfg<M>::THREADS) void k_bcr_elim(const int* skip
 // block AND solve those rows; the trailing part takes its rank-16 update as v_mfma_f64_16x16x4 tiles with operands read from LDS
 // (the scheme of the window solver's packed LDS Cholesky, solver_kernels.hip, extended by the coupling rows).  Two barriers per
 // PANEL instead of one per pivot.  LDS: the packed lower triangle of A_pp (rows at i (i + 1) / 2) + M + 1 full rows
-// (pass 1: A_ap and y; pass 2: A_bp, solved against the finished L).
+// (A_ap, y, A_bp: 2 M + 1 rows; at M = 90 that is 159.3 of the 160 KB).
 #define BCR_E2_THREADS 512
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 template <int M> struct BcrE2 {
-    static constexpr int XS = M | 1, TRI = M * (M + 1) / 2 + ((M * (M + 1) / 2) & 1);
-    static constexpr size_t lds_bytes = (size_t)(TRI + (M + 1) * XS + 8) * 8;
+    // row stride of the full rows: M itself when that keeps the 16 rows of an MFMA operand on distinct banks (M = 90: 180 banks apart
+    // mod 64 = 52), else M + 1; with stride 90 the whole panel of M = 90 -- triangle + 181 rows -- fits the 160 KB of LDS in ONE pass
+    static constexpr int XS = (M % 16 == 10 || M % 16 == 6) ? M : (M | 1), TRI = M * (M + 1) / 2 + ((M * (M + 1) / 2) & 1);
+    static constexpr size_t lds_bytes = (size_t)(TRI + (2 * M + 1) * XS) * 8;
 };
 __device__ __forceinline__ int bcr_pk(const int i) { return (i * (i + 1)) >> 1; }
+// 1 / sqrt(d) for a pivot already checked positive and finite: hardware estimate + two Newton steps, without the library's class
+// checks (the pivot's reciprocal root is on the critical path of every register step)
+__device__ __forceinline__ double bcr_rsqrt(const double d) {
+    const double y0 = __builtin_amdgcn_rsq(d);
+    const double e = fma(-d * y0, y0, 1.0);
+    const double y1 = fma(0.5 * y0, e, y0);
+    const double e1 = fma(-d * y1, y1, 1.0);
+    return fma(0.5 * y1, e1, y1);
+}
 
 // one pass over the panels.  FACTOR: the diagonal rows are factored as well (rows below = remaining diagonal rows, then the R extra
 // rows); otherwise L is final and only the R extra rows are solved against it.
@@ -226,8 +237,8 @@ __device__ __forceinline__ void bcr_panels(double* __restrict__ Lt, double* __re
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     double djj = readlane_d(a[j], j);
-                    if (!(djj > 0.0) || !isfinite(djj)) { bad = true; djj = 1.0; }
-                    const double rd = rsqrt(djj);
+                    if (!(djj > 1e-290) || !isfinite(djj)) { bad = true; djj = 1.0; }
+                    const double rd = bcr_rsqrt(djj);
                     const double lij = (lane == j) ? djj * rd : a[j] * rd;
                     a[j] = lij;
 #pragma unroll
@@ -287,7 +298,7 @@ __global__ __launch_bounds__(BCR_E2_THREADS) void k_bcr_elim2(const int* skip, c
     using C = BcrE2<M>;
     extern __shared__ double bcr_lds[];
     double* Lt = bcr_lds;                  // packed lower triangle of A_pp -> L
-    double* X = Lt + C::TRI;               // [M + 1][XS]
+    double* X = Lt + C::TRI;               // [2 M + 1][XS]: A_ap rows | y | A_bp rows
     __shared__ int s_bad;
     const BcrElim t = tab[blockIdx.x];
     const int tid = threadIdx.x;
@@ -311,35 +322,29 @@ __global__ __launch_bounds__(BCR_E2_THREADS) void k_bcr_elim2(const int* skip, c
         }
     }
     for (int c = tid; c < M; c += BCR_E2_THREADS) X[(size_t)M * C::XS + c] = ws[t.oy + c];
+    // rows M + 1 .. 2 M: A[b][node]
+    for (int e0 = tid; e0 < M * M; e0 += U * BCR_E2_THREADS) {
+        double vc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int e = e0 + u * BCR_E2_THREADS; vc[u] = (e < M * M && t.b >= 0) ? ws[t.oCb + e] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int e = e0 + u * BCR_E2_THREADS, i = e / M, j = e - M * i; if (e < M * M) X[(size_t)(M + 1 + i) * C::XS + j] = vc[u]; }
+    }
     __syncthreads();
-    bcr_panels<M, true>(Lt, X, M + 1, &s_bad);
-    // L (zeros above the diagonal), U_a, w out; A[b][node] in
+    bcr_panels<M, true>(Lt, X, 2 * M + 1, &s_bad);
+    // L (zeros above the diagonal), U_a, w, U_b out
     for (int e = tid; e < M * M; e += BCR_E2_THREADS) {
         const int i = e / M, j = e - M * i;
         L[(size_t)t.node * MM + e] = j <= i ? Lt[bcr_pk(i) + j] : 0.0;
         Ua[(size_t)t.node * MM + e] = X[(size_t)i * C::XS + j];
+        Ub[(size_t)t.node * MM + e] = X[(size_t)(M + 1 + i) * C::XS + j];
     }
     for (int c = tid; c < M; c += BCR_E2_THREADS) w[(size_t)t.node * M + c] = X[(size_t)M * C::XS + c];
-    __syncthreads();
-    if (t.b >= 0) {
-        for (int e0 = tid; e0 < M * M; e0 += U * BCR_E2_THREADS) {
-            double vc[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) { const int e = e0 + u * BCR_E2_THREADS; vc[u] = e < M * M ? ws[t.oCb + e] : 0.0; }
-#pragma unroll
-            for (int u = 0; u < U; ++u) { const int e = e0 + u * BCR_E2_THREADS, i = e / M, j = e - M * i; if (e < M * M) X[(size_t)i * C::XS + j] = vc[u]; }
-        }
-        __syncthreads();
-        bcr_panels<M, false>(Lt, X, M, &s_bad);
-        for (int e = tid; e < M * M; e += BCR_E2_THREADS) { const int i = e / M, j = e - M * i; Ub[(size_t)t.node * MM + e] = X[(size_t)i * C::XS + j]; }
-    } else {
-        for (int e = tid; e < M * M; e += BCR_E2_THREADS) Ub[(size_t)t.node * MM + e] = 0.0;
-    }
     if (tid == 0 && s_bad) atomicOr(fail, 1);
 }
 
 // ------------------------------------------------------------------------------------------------ Schur updates of the kept nodes
-#define BCR_UP_THREADS 256
+#define BCR_UP_THREADS 512
 // The three M x M x M products of a kept node (U U^T twice, U_b U_a^T once) on the matrix core.  The factors are staged in LDS,
 // rows padded with zeros to MP = 16 ceil(M / 16), columns to KP = 4 ceil(M / 4), row stride LD (odd: the 16 lanes of an operand
 // column group hit distinct banks).  v_mfma_f64_16x16x4 takes A[i][k] from lane i + 16 k and B[k][j] from lane j + 16 k, so for
@@ -437,53 +442,53 @@ __global__ __launch_bounds__(BCR_UP_THREADS) void k_bcr_update(const int* skip, 
 
 // ------------------------------------------------------------------------------------------------ back substitution
 template <int M>
-__global__ __launch_bounds__(256) void k_bcr_back(const int* skip, const BcrElim* __restrict__ tab, const double* __restrict__ L, const double* __restrict__ Ua,
+__global__ __launch_bounds__(512) void k_bcr_back(const int* skip, const BcrElim* __restrict__ tab, const double* __restrict__ L, const double* __restrict__ Ua,
                                                   const double* __restrict__ Ub, const double* __restrict__ w, double* __restrict__ z) {
     if (skip && *skip) return;
-    static_assert(M <= 128, "two rows per lane");
+    static_assert(M <= 128 && M % 6 == 0, "two rows per lane; the U^T z sums run in halves of M / 2 rows, three at a time");
     extern __shared__ double bcr_lds[];
-    constexpr int LD = M + 1;
+    constexpr int LD = M + 1, H = M / 2;
     double* Ls = bcr_lds;            // [M][LD]
-    double* tv = Ls + M * LD;        // [M]
-    double* za = tv + M;
+    double* za = Ls + M * LD;        // [M]
     double* zb = za + M;
-    double* ta = zb + M;
+    double* pt = zb + M;             // [4][128] partial sums: U_a rows [0, H), [H, M), U_b rows [0, H), [H, M)
     const BcrElim t = tab[blockIdx.x];
     const int tid = threadIdx.x;
     const size_t MM = (size_t)M * M;
-    for (int k = tid; k < M; k += 256) { za[k] = t.a >= 0 ? z[(size_t)t.a * M + k] : 0.0; zb[k] = t.b >= 0 ? z[(size_t)t.b * M + k] : 0.0; tv[k] = 0.0; }
-    for (int e0 = tid; e0 < M * M; e0 += 8 * 256) {
+    for (int k = tid; k < M; k += 512) { za[k] = t.a >= 0 ? z[(size_t)t.a * M + k] : 0.0; zb[k] = t.b >= 0 ? z[(size_t)t.b * M + k] : 0.0; }
+    for (int e0 = tid; e0 < M * M; e0 += 8 * 512) {
         double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int e = e0 + u * 256; v[u] = e < M * M ? L[(size_t)t.node * MM + e] : 0.0; }
+        for (int u = 0; u < 8; ++u) { const int e = e0 + u * 512; v[u] = e < M * M ? L[(size_t)t.node * MM + e] : 0.0; }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int e = e0 + u * 256, r = e / M, c = e - M * r; if (e < M * M) Ls[r * LD + c] = v[u]; }
+        for (int u = 0; u < 8; ++u) { const int e = e0 + u * 512, r = e / M, c = e - M * r; if (e < M * M) Ls[r * LD + c] = v[u]; }
     }
     __syncthreads();
-    // t = w - U_a^T z_a - U_b^T z_b: threads [0, 128) take U_a, [128, 256) U_b (columns coalesced across the threads)
+    // t = w - U_a^T z_a - U_b^T z_b: thread (part, c) sums half of the rows of one factor for column c (coalesced across c)
     {
-        const int c = tid & 127, half = tid >> 7;
+        const int c = tid & 127, part = tid >> 7, half = part >> 1, r0 = (part & 1) * H;
         const int nbr = half ? t.b : t.a;
-        double part = 0;
+        double acc = 0;
         if (c < M && nbr >= 0) {
-            const double* U = (half ? Ub : Ua) + (size_t)t.node * MM + c;
-            const double* zz = half ? zb : za;
-            double p2[6] = {0, 0, 0, 0, 0, 0};
-            static_assert(M % 6 == 0, "six independent partial sums");
-            for (int r = 0; r < M; r += 6) {
+            const double* U = (half ? Ub : Ua) + (size_t)t.node * MM + (size_t)r0 * M + c;
+            const double* zz = (half ? zb : za) + r0;
+            double p3[3] = {0, 0, 0};
 #pragma unroll
-                for (int u = 0; u < 6; ++u) p2[u] += U[(size_t)(r + u) * M] * zz[r + u];
+            for (int r = 0; r < H; r += 3) {
+#pragma unroll
+                for (int u = 0; u < 3; ++u) p3[u] += U[(size_t)(r + u) * M] * zz[r + u];
             }
-            part = ((p2[0] + p2[1]) + (p2[2] + p2[3])) + (p2[4] + p2[5]);
+            acc = (p3[0] + p3[1]) + p3[2];
         }
-        if (c < M) (half ? tv : ta)[c] = part;
+        pt[part * 128 + c] = acc;
     }
     __syncthreads();
     if (tid >= 64) return;
     // L^T z = t inside wavefront 0, last unknown first; lane l holds t[l] and t[l + 64]; the solved entry travels by a shuffle
     const int lane = tid;
-    double t0 = lane < M ? (w[(size_t)t.node * M + lane] - ta[lane]) - tv[lane] : 0.0;
-    double t1 = lane + 64 < M ? (w[(size_t)t.node * M + lane + 64] - ta[lane + 64]) - tv[lane + 64] : 0.0;
+    auto rhs = [&](const int i) { return (w[(size_t)t.node * M + i] - (pt[i] + pt[128 + i])) - (pt[256 + i] + pt[384 + i]); };
+    double t0 = lane < M ? rhs(lane) : 0.0;
+    double t1 = lane + 64 < M ? rhs(lane + 64) : 0.0;
     for (int r = M - 1; r >= 0; --r) {
         const double diag = Ls[r * LD + r];
         const double tr = r >= 64 ? __shfl(t1, r - 64, 64) : __shfl(t0, r, 64);
@@ -658,8 +663,8 @@ void* glio_bcr_create2(int K, int band, int B, int rank, int world) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_update<90>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BcrUp<90>::lds_bytes);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_elim2<72>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BcrE2<72>::lds_bytes);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_elim2<90>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BcrE2<90>::lds_bytes);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_back<72>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((72 * 73 + 4 * 72) * 8));
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_back<90>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((90 * 91 + 4 * 90) * 8));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_back<72>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((72 * 73 + 2 * 72 + 512) * 8));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_back<90>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((90 * 91 + 2 * 90 + 512) * 8));
     (void)hipGetLastError();
     return b;
 }
@@ -702,10 +707,10 @@ static void bcr_levels(BcrDev* b, const BcrOp& op, int l0, int l1, hipStream_t s
 }
 template <int M>
 static void bcr_back(BcrDev* b, const BcrOp& op, int l0, int l1, hipStream_t stream) {
-    const size_t lds_back = (size_t)(M * (M + 1) + 4 * M) * 8;
+    const size_t lds_back = (size_t)(M * (M + 1) + 2 * M + 4 * 128) * 8;
     for (int l = l1 - 1; l >= l0; --l) {
         const int ne = b->h_elim_off[l + 1] - b->h_elim_off[l];
-        if (ne > 0) hipLaunchKernelGGL((k_bcr_back<M>), dim3(ne), dim3(256), lds_back, stream, op.skip, b->elim + b->h_elim_off[l], b->L, b->Ua, b->Ub, b->w, b->z);
+        if (ne > 0) hipLaunchKernelGGL((k_bcr_back<M>), dim3(ne), dim3(512), lds_back, stream, op.skip, b->elim + b->h_elim_off[l], b->L, b->Ua, b->Ub, b->w, b->z);
     }
 }
 #define BCR_DISPATCH(fn, ...) do { if (b->M == 36) fn<36>(__VA_ARGS__); else if (b->M == 72) fn<72>(__VA_ARGS__); else fn<90>(__VA_ARGS__); } while (0)
