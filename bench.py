@@ -766,6 +766,34 @@ def bench_batch_association(local_rank, K=16, pts=32768, search_range=6):
             "Mqueries_per_s": round(len(ci) * pts / dt / 1e6, 1), "us_per_pair": round(dt * 1e6 / len(ci), 1),
             "k8_linearize_on_result_ms": round(k8_ms, 4)}
     st.close(); ba.close()
+    # ---- the rounds of optimizeBatch on REAL correspondences: the end keyframes re-searched in every DDpsr_threshold round
+    # (Estimator.cpp:3018-3030), the interior on its stored constraints, the trust-region solve between
+    try:
+        from glio_amd import ctypes_types as T
+        scans = []
+        for k in range(K):
+            sc = win.scans[k].copy(); sc[:, :3] -= tlb
+            scans.append(np.ascontiguousarray(sc))
+        st2 = batch.BatchStage(K, 2 * search_range, int(len(ci)) * pts, device=local_rank)
+        ra = batch.RoundsAssociation(st2, scans, search_range, pts, device=local_rank)
+        ra.start(poses)
+        odo = poses.copy()
+        t_re = []
+
+        def timed_reassociate(p):
+            t0 = _t.perf_counter(); ra(p); t_re.append(_t.perf_counter() - t0)
+        batch.solve_batch_rounds(st2, poses, odo, search_range, [], None, reassociate=timed_reassociate, opts=T.batch_tr_opts(max_iterations=10))   # warm-up
+        t_re.clear()
+        t0 = _t.perf_counter()
+        out_p, hist = batch.solve_batch_rounds(st2, poses, odo, search_range, [], None, reassociate=timed_reassociate, opts=T.batch_tr_opts(max_iterations=10))
+        dt2 = _t.perf_counter() - t0
+        info["rounds_with_reassociation"] = {"rounds": len(hist), "wall_ms": round(dt2 * 1e3, 2), "reassociation_ms_per_round": round(float(np.mean(t_re)) * 1e3, 3),
+                                             "solve_ms_per_round": round(float(np.mean([h["solve_ms"] for h in hist])), 3), "constraints": int(ra.n_constraints),
+                                             "iterations": [int(h["iterations"]) for h in hist],
+                                             "what": "end keyframes (first / last search_range) re-searched every round at the current poses, interior constraints stored; pose-only problem"}
+        ra.close(); st2.close()
+    except Exception as e:
+        info["rounds_with_reassociation"] = {"error": str(e)[:300]}
     return info
 
 

@@ -196,6 +196,14 @@ __global__ __launch_bounds__(BcrCfg<M>::THREADS) void k_bcr_elim(const int* skip
 // PANEL instead of one per pivot.  LDS: the packed lower triangle of A_pp (rows at i (i + 1) / 2) + M + 1 full rows
 // (A_ap, y, A_bp: 2 M + 1 rows; at M = 90 that is 159.3 of the 160 KB).
 #define BCR_E2_THREADS 512
+#ifdef GLIO_DEV_STAMPS
+__device__ long long g_bcr_stamps[8];      // elim2, workgroup 0: [0] load, [1] register steps, [2] MFMA updates, [3] store (100 MHz ticks, last launch)
+#define BCR_T(var) const long long var = wall_clock64()
+#define BCR_ACC(k, t1, t0) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_bcr_stamps[k] += (t1) - (t0); } while (0)
+#else
+#define BCR_T(var) do { } while (0)
+#define BCR_ACC(k, t1, t0) do { } while (0)
+#endif
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 template <int M> struct BcrE2 {
     // row stride of the full rows: M itself when that keeps the 16 rows of an MFMA operand on distinct banks (M = 90: 180 banks apart
@@ -224,6 +232,7 @@ __device__ __forceinline__ void bcr_panels(double* __restrict__ Lt, double* __re
         const int nb = M - k0 < 16 ? M - k0 : 16, r0 = k0 + nb;
         const int nd = FACTOR ? M - r0 : 0;            // diagonal rows below the block
         const int mb = nd + R;
+        BCR_T(tp0);
         if (wv == 0 || wv * 48 < mb) {
             const bool isdiag = lane < 16;
             const int bi = wv * 48 + lane - 16;
@@ -261,32 +270,47 @@ __device__ __forceinline__ void bcr_panels(double* __restrict__ Lt, double* __re
             if (bad && wv == 0 && lane == 0) *s_bad = 1;
         }
         __syncthreads();
+        BCR_T(tp1);
+        BCR_ACC(1, tp1, tp0);
         if (nb == 16 && r0 < M) {
+            // rank-16 update of everything right of the panel.  A wavefront owns ROW tiles (16 rows of the list "diagonal rows below the
+            // block, then the full rows"): the A operand and the four output-row pointers of a lane are set up once per row tile, the
+            // column tiles follow in a loop without divisions (measured: the index arithmetic of a flat tile loop cost as much as
+            // the MFMAs themselves).
             const int Tr = (mb + 15) >> 4, Tc = (M - r0 + 15) >> 4;
-            for (int t = wv; t < Tr * Tc; t += BCR_E2_THREADS / 64) {
-                const int I = t / Tc, J = t - Tc * I;
-                if (FACTOR && 16 * I + 15 < nd && J > I) continue;           // strictly above the diagonal of the triangle
-                const int ba = 16 * I + li, cb = r0 + 16 * J + li;
-                const bool oka = ba < mb, okb = cb < M;
+            constexpr int NW = BCR_E2_THREADS / 64;
+            for (int I = wv; I < Tr; I += NW) {
+                const int ba = 16 * I + li;
+                const bool oka = ba < mb;
                 const double* pa = (ba < nd ? Lt + bcr_pk(r0 + (oka ? ba : 0)) : X + (size_t)(oka ? ba - nd : 0) * C::XS) + k0 + lk;
-                const double* pb = Lt + bcr_pk(okb ? cb : r0) + k0 + lk;
-                double ax[4], bx[4];
+                double ax[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { ax[q] = pa[4 * q]; bx[q] = pb[4 * q]; }
-                v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(oka ? ax[q] : 0.0, okb ? bx[q] : 0.0, acc, 0, 0, 0);
-                const int colc = r0 + 16 * J + li;                          // C: lane l, register q -> row (l >> 4) + 4 q, column l & 15
+                for (int q = 0; q < 4; ++q) ax[q] = oka ? pa[4 * q] : 0.0;
+                double* orow[4];            // output rows of this lane: row (lane >> 4) + 4 q of the tile; null = outside
+                int olim[4];                // last column a diagonal row may take (its own index); M for the full rows
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int br = 16 * I + lk + 4 * q;
-                    if (br >= mb || colc >= M) continue;
-                    if (br < nd) { if (colc <= r0 + br) Lt[bcr_pk(r0 + br) + colc] -= acc[q]; }
-                    else X[(size_t)(br - nd) * C::XS + colc] -= acc[q];
+                    orow[q] = br >= mb ? nullptr : (br < nd ? Lt + bcr_pk(r0 + br) : X + (size_t)(br - nd) * C::XS);
+                    olim[q] = br < nd ? r0 + br : M;
+                }
+                const int Jn = (FACTOR && 16 * I + 15 < nd) ? (I + 1 < Tc ? I + 1 : Tc) : Tc;      // inside the triangle: tiles up to the diagonal
+                for (int J = 0; J < Jn; ++J) {
+                    const int cb = r0 + 16 * J + li;
+                    const bool okb = cb < M;
+                    const double* pb = Lt + bcr_pk(okb ? cb : r0) + k0 + lk;
+                    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[q], okb ? pb[4 * q] : 0.0, acc, 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (orow[q] && okb && cb <= olim[q]) orow[q][cb] -= acc[q];
                 }
             }
         }
         __syncthreads();
+        BCR_T(tp2);
+        BCR_ACC(2, tp2, tp1);
     }
 }
 
@@ -304,6 +328,10 @@ __global__ __launch_bounds__(BCR_E2_THREADS) void k_bcr_elim2(const int* skip, c
     const int tid = threadIdx.x;
     const size_t MM = (size_t)M * M;
     if (tid == 0) s_bad = 0;
+    BCR_T(ts0);
+#ifdef GLIO_DEV_STAMPS
+    if (blockIdx.x == 0 && tid == 0) { g_bcr_stamps[0] = g_bcr_stamps[1] = g_bcr_stamps[2] = g_bcr_stamps[3] = 0; }
+#endif
     constexpr int U = 8;
     for (int e0 = tid; e0 < M * M; e0 += U * BCR_E2_THREADS) {       // eight entries of either block in flight per thread
         double vd[U], vc[U];
@@ -331,7 +359,10 @@ __global__ __launch_bounds__(BCR_E2_THREADS) void k_bcr_elim2(const int* skip, c
         for (int u = 0; u < U; ++u) { const int e = e0 + u * BCR_E2_THREADS, i = e / M, j = e - M * i; if (e < M * M) X[(size_t)(M + 1 + i) * C::XS + j] = vc[u]; }
     }
     __syncthreads();
+    BCR_T(ts1);
+    BCR_ACC(0, ts1, ts0);
     bcr_panels<M, true>(Lt, X, 2 * M + 1, &s_bad);
+    BCR_T(ts2);
     // L (zeros above the diagonal), U_a, w, U_b out
     for (int e = tid; e < M * M; e += BCR_E2_THREADS) {
         const int i = e / M, j = e - M * i;
@@ -341,7 +372,14 @@ __global__ __launch_bounds__(BCR_E2_THREADS) void k_bcr_elim2(const int* skip, c
     }
     for (int c = tid; c < M; c += BCR_E2_THREADS) w[(size_t)t.node * M + c] = X[(size_t)M * C::XS + c];
     if (tid == 0 && s_bad) atomicOr(fail, 1);
+#ifdef GLIO_DEV_STAMPS
+    __syncthreads();
+    { BCR_T(ts3); BCR_ACC(3, ts3, ts2); }
+#endif
 }
+#ifdef GLIO_DEV_STAMPS
+extern "C" int glio_debug_bcr_stamps(long long* out8) { return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bcr_stamps), 64) == hipSuccess ? 0 : -2; }
+#endif
 
 // ------------------------------------------------------------------------------------------------ Schur updates of the kept nodes
 #define BCR_UP_THREADS 512

@@ -41,3 +41,11 @@ for label, with_imu in (("pose_6", False), ("full_15", True)):
     out[label] = {"solve_ms": round(dt * 1e3, 3), "groups": int(c["groups"]), "ms_per_group": round(dt * 1e3 / c["groups"], 3), "iterations": int(res[-1].iterations),
                   "final_cost": float(res[-1].final_cost)}
 print(json.dumps(out))
+try:
+    import ctypes as C
+    from glio_amd import capi
+    st8 = (C.c_longlong * 8)()
+    if capi.load().glio_debug_bcr_stamps(st8) == 0:
+        print("elim2 workgroup 0 of the last launch (us): load %.2f, register steps %.2f, MFMA updates %.2f, store %.2f" % tuple(v / 100.0 for v in list(st8)[:4]))
+except AttributeError:
+    pass
