@@ -391,34 +391,51 @@ extern "C" int glio_debug_bcr_stamps(long long* out8) { return hipMemcpyFromSymb
 // register q = row (l >> 4) + 4 q, column l & 15.
 template <int M> struct BcrUp {
     static constexpr int MP = ((M + 15) / 16) * 16, KP = ((M + 3) / 4) * 4, LD = KP | 1, T = MP / 16;
-    static constexpr size_t lds_bytes = (size_t)(2 * MP * LD + M) * 8;
+    static constexpr size_t lds_bytes = (size_t)(2 * MP * LD + 2 * M) * 8;
 };
-// dst (M x M, global, row-major) = (ACCUM ? dst : 0) - X Y^T.  The tile's old values are the accumulator's initial value and X is
-// fed negated, so the product lands as "old - X Y^T" without a read-modify-write behind the chain; the next tile's old values are
-// loaded while the current chain runs.
-template <int M, bool ACCUM>
-__device__ __forceinline__ void bcr_xyT_mfma(const double* __restrict__ X, const double* __restrict__ Y, const int tid, double* __restrict__ dst) {
+// dst (M x M, global, row-major) = (ACCUM ? dst : 0) - X1 Y1^T - X2 Y2^T (either product may be absent: null).  LOWER: only the tiles on and
+// below the diagonal (the consumers of a diagonal block read its lower triangle only).  The tile's old values are the accumulator's
+// initial value and X is fed negated, so the result lands as "old - X Y^T" without a read-modify-write behind the chain; the next
+// tile's old values are loaded while the current chain runs.  (On gfx950 the f64 MFMA has the VALU's throughput -- 78 TFLOP/s either
+// way -- so what it buys is operand traffic: one 8-byte LDS read per operand per 1024 multiply-adds.)
+template <int M, bool ACCUM, bool LOWER>
+__device__ __forceinline__ void bcr_xyT_mfma(const double* __restrict__ X1, const double* __restrict__ Y1, const double* __restrict__ X2,
+                                             const double* __restrict__ Y2, const int tid, double* __restrict__ dst) {
     using C = BcrUp<M>;
     const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-    constexpr int NW = BCR_UP_THREADS / 64;
+    constexpr int NW = BCR_UP_THREADS / 64, NT = LOWER ? C::T * (C::T + 1) / 2 : C::T * C::T;
+    auto decode = [&](const int tile, int& I, int& J) {
+        if (LOWER) { I = 0; while (((I + 1) * (I + 2)) >> 1 <= tile) ++I; J = tile - ((I * (I + 1)) >> 1); }
+        else { I = tile / C::T; J = tile - C::T * I; }
+    };
     auto load_init = [&](const int tile, v4f64& c) {
-        const int I = tile / C::T, J = tile - C::T * I;
+        int I = 0, J = 0;
+        if (tile < NT) decode(tile, I, J);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = 16 * I + lk + 4 * q, col = 16 * J + li;
-            c[q] = (ACCUM && tile < C::T * C::T && r < M && col < M) ? dst[r * M + col] : 0.0;
+            c[q] = (ACCUM && tile < NT && r < M && col < M) ? dst[r * M + col] : 0.0;
         }
     };
     v4f64 cnext = {0.0, 0.0, 0.0, 0.0};
     load_init(wave, cnext);
-    for (int tile = wave; tile < C::T * C::T; tile += NW) {
-        const int I = tile / C::T, J = tile - C::T * I;
+    for (int tile = wave; tile < NT; tile += NW) {
+        int I, J;
+        decode(tile, I, J);
         v4f64 c = cnext;
         load_init(tile + NW, cnext);
-        const double* px = X + (16 * I + li) * C::LD + lk;
-        const double* py = Y + (16 * J + li) * C::LD + lk;
+        if (X1) {
+            const double* px = X1 + (16 * I + li) * C::LD + lk;
+            const double* py = Y1 + (16 * J + li) * C::LD + lk;
 #pragma unroll 4
-        for (int k0 = 0; k0 < C::KP; k0 += 4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-px[k0], py[k0], c, 0, 0, 0);
+            for (int k0 = 0; k0 < C::KP; k0 += 4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-px[k0], py[k0], c, 0, 0, 0);
+        }
+        if (X2) {
+            const double* px = X2 + (16 * I + li) * C::LD + lk;
+            const double* py = Y2 + (16 * J + li) * C::LD + lk;
+#pragma unroll 4
+            for (int k0 = 0; k0 < C::KP; k0 += 4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-px[k0], py[k0], c, 0, 0, 0);
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = 16 * I + lk + 4 * q, col = 16 * J + li;
@@ -445,36 +462,41 @@ __device__ __forceinline__ void bcr_stage(double* __restrict__ dst, const double
     }
 }
 
+// Two workgroups per kept node: role 0 takes the diagonal block (A_qq -= U_b U_b^T of the node eliminated to the left, -= U_a U_a^T of
+// the one to the right: both factors staged side by side, lower tiles only) and the right-hand side; role 1 the new coupling
+// A[b][a] = -U_b U_a^T of the node eliminated to the right (all tiles).  The two roles cost about the same.
 template <int M>
 __global__ __launch_bounds__(BCR_UP_THREADS) void k_bcr_update(const int* skip, const BcrKept* __restrict__ tab, double* __restrict__ ws,
                                                                const double* __restrict__ Ua, const double* __restrict__ Ub, const double* __restrict__ w) {
     if (skip && *skip) return;
     using C = BcrUp<M>;
     extern __shared__ double bcr_lds[];
-    double* XA = bcr_lds;                 // phase 1: U_b of the node eliminated to the left; phase 2: U_a of the node eliminated to the right
-    double* XB = XA + C::MP * C::LD;      // phase 2: U_b of the node eliminated to the right (for the new coupling)
-    double* wv = XB + C::MP * C::LD;
-    const BcrKept t = tab[blockIdx.x];
-    const int tid = threadIdx.x;
+    double* XA = bcr_lds;
+    double* XB = XA + C::MP * C::LD;
+    double* wv = XB + C::MP * C::LD;          // [2][M]
+    const BcrKept t = tab[blockIdx.x >> 1];
+    const int role = blockIdx.x & 1, tid = threadIdx.x;
     const size_t MM = (size_t)M * M;
+    if (role == 1) {
+        if (t.pr < 0 || t.oCnew < 0) return;
+        bcr_stage<M>(XA, Ua + (size_t)t.pr * MM, tid);
+        bcr_stage<M>(XB, Ub + (size_t)t.pr * MM, tid);
+        __syncthreads();
+        bcr_xyT_mfma<M, false, false>(XB, XA, nullptr, nullptr, tid, ws + t.oCnew);          // rows b, columns a (= this node)
+        return;
+    }
     double* Dq = ws + t.oD;
     double* yq = ws + t.oy;
-    if (t.pl >= 0) {
-        bcr_stage<M>(XA, Ub + (size_t)t.pl * MM, tid);
-        for (int k = tid; k < M; k += BCR_UP_THREADS) wv[k] = w[(size_t)t.pl * M + k];
-        __syncthreads();
-        bcr_xyT_mfma<M, true>(XA, XA, tid, Dq);
-        for (int r = tid; r < M; r += BCR_UP_THREADS) { double s = 0; for (int k = 0; k < M; ++k) s += XA[r * C::LD + k] * wv[k]; yq[r] -= s; }
-        __syncthreads();
-    }
-    if (t.pr >= 0) {
-        bcr_stage<M>(XA, Ua + (size_t)t.pr * MM, tid);
-        if (t.oCnew >= 0) bcr_stage<M>(XB, Ub + (size_t)t.pr * MM, tid);
-        for (int k = tid; k < M; k += BCR_UP_THREADS) wv[k] = w[(size_t)t.pr * M + k];
-        __syncthreads();
-        bcr_xyT_mfma<M, true>(XA, XA, tid, Dq);
-        if (t.oCnew >= 0) bcr_xyT_mfma<M, false>(XB, XA, tid, ws + t.oCnew);          // A[b][a] = -U_b U_a^T
-        for (int r = tid; r < M; r += BCR_UP_THREADS) { double s = 0; for (int k = 0; k < M; ++k) s += XA[r * C::LD + k] * wv[k]; yq[r] -= s; }
+    if (t.pl >= 0) bcr_stage<M>(XA, Ub + (size_t)t.pl * MM, tid);
+    if (t.pr >= 0) bcr_stage<M>(XB, Ua + (size_t)t.pr * MM, tid);
+    for (int k = tid; k < M; k += BCR_UP_THREADS) { wv[k] = t.pl >= 0 ? w[(size_t)t.pl * M + k] : 0.0; wv[M + k] = t.pr >= 0 ? w[(size_t)t.pr * M + k] : 0.0; }
+    __syncthreads();
+    bcr_xyT_mfma<M, true, true>(t.pl >= 0 ? XA : nullptr, XA, t.pr >= 0 ? XB : nullptr, XB, tid, Dq);
+    for (int r = tid; r < M; r += BCR_UP_THREADS) {
+        double s1 = 0, s2 = 0;
+        if (t.pl >= 0) for (int k = 0; k < M; ++k) s1 += XA[r * C::LD + k] * wv[k];
+        if (t.pr >= 0) for (int k = 0; k < M; ++k) s2 += XB[r * C::LD + k] * wv[M + k];
+        yq[r] = (yq[r] - s1) - s2;
     }
 }
 
@@ -740,7 +762,7 @@ static void bcr_levels(BcrDev* b, const BcrOp& op, int l0, int l1, hipStream_t s
             if (g_bcr_elim_mode == 0 || (g_bcr_elim_mode < 0 && M < 72)) hipLaunchKernelGGL((k_bcr_elim<M>), dim3(ne), dim3(BcrCfg<M>::THREADS), 0, stream, op.skip, b->elim + b->h_elim_off[l], b->ws, b->L, b->Ua, b->Ub, b->w, b->fail);
             else hipLaunchKernelGGL((k_bcr_elim2<M>), dim3(ne), dim3(BCR_E2_THREADS), BcrE2<M>::lds_bytes, stream, op.skip, b->elim + b->h_elim_off[l], b->ws, b->L, b->Ua, b->Ub, b->w, b->fail);
         }
-        if (nk > 0) hipLaunchKernelGGL((k_bcr_update<M>), dim3(nk), dim3(BCR_UP_THREADS), lds_up, stream, op.skip, b->kept + b->h_kept_off[l], b->ws, b->Ua, b->Ub, b->w);
+        if (nk > 0) hipLaunchKernelGGL((k_bcr_update<M>), dim3(2 * nk), dim3(BCR_UP_THREADS), lds_up, stream, op.skip, b->kept + b->h_kept_off[l], b->ws, b->Ua, b->Ub, b->w);
     }
 }
 template <int M>
