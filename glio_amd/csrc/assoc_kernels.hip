@@ -1535,10 +1535,15 @@ int glio_bassoc_select(glio_bassoc* b, int64_t n_keep, const int64_t* src_index,
     for (int64_t k = 0; k < n_keep; ++k) if (src_index[k] < 0 || src_index[k] >= n_current) { glio_set_error("selection index %lld out of range", (long long)src_index[k]); return GLIO_E_ARG; }
     if (n_keep == 0) return GLIO_OK;
     if (n_keep > b->sel_cap) {
-        if (b->d_sel_cp) { hipFree(b->d_sel_cp); hipFree(b->d_sel_nc); hipFree(b->d_sel_score); hipFree(b->d_sel_idx); }
-        b->sel_cap = n_keep + n_keep / 2 + 1024;
-        BA_CHECK(hipMalloc((void**)&b->d_sel_cp, (size_t)b->sel_cap * 16)); BA_CHECK(hipMalloc((void**)&b->d_sel_nc, (size_t)b->sel_cap * 48));
-        BA_CHECK(hipMalloc((void**)&b->d_sel_score, (size_t)b->sel_cap * 8)); BA_CHECK(hipMalloc((void**)&b->d_sel_idx, (size_t)b->sel_cap * 8));
+        // (pointers nulled and the capacity reset before the new allocations: a failed hipMalloc must not leave dangling pointers
+        //  behind a capacity that claims room -- advisor finding of round 2)
+        void** old[] = {(void**)&b->d_sel_cp, (void**)&b->d_sel_nc, (void**)&b->d_sel_score, (void**)&b->d_sel_idx};
+        for (void** q : old) { if (*q) hipFree(*q); *q = nullptr; }
+        b->sel_cap = 0;
+        const int64_t cap = n_keep + n_keep / 2 + 1024;
+        BA_CHECK(hipMalloc((void**)&b->d_sel_cp, (size_t)cap * 16)); BA_CHECK(hipMalloc((void**)&b->d_sel_nc, (size_t)cap * 48));
+        BA_CHECK(hipMalloc((void**)&b->d_sel_score, (size_t)cap * 8)); BA_CHECK(hipMalloc((void**)&b->d_sel_idx, (size_t)cap * 8));
+        b->sel_cap = cap;
     }
     BA_CHECK(hipMemcpyAsync(b->d_sel_idx, src_index, (size_t)n_keep * 8, hipMemcpyHostToDevice, b->stream));
     hipLaunchKernelGGL(k_bassoc_gather, dim3((unsigned)((n_keep + 255) / 256)), dim3(256), 0, b->stream, b->d_sel_idx, (long long)n_keep, b->d_cp, b->d_nc, b->d_score,
