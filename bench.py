@@ -60,12 +60,21 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the GLIO hot path has no CPU fallback")
+    # GLIO_BENCH_SHARE_GPU=1: every rank on device 0 with gloo collectives staged through the host (RCCL refuses two ranks on one
+    # device).  It exists so that a ONE-GPU box can run the complete N-process path -- launcher, rendezvous, barriers, max over ranks,
+    # the sharded batch solve across processes; its timings are those of N processes contending for one GPU and say nothing about scaling.
+    share_gpu = os.environ.get("GLIO_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or os.environ.get("GLIO_BENCH_FORCE_DIST") == "1":     # the env switch lets a 1-GPU box exercise the RCCL path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from glio_amd import capi, synth
     # every rank gets its own window (different seed): independent replicas.  The workload is the STEADY STATE of the
@@ -104,7 +113,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if share_gpu else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     total_steps = args.steps * world
@@ -303,6 +312,8 @@ def main():
         "roofline": roofline, "cpu_baseline": cpu, "cpu_baselines_other_configs": cpu_more, "pose_vs_oracle": pose_err, "association": assoc,
         "association_c3": c3_info, "c5_stress": c5_info, "batch_stage": batch_info, "batch_association": bassoc_info, "local_map": localmap_info, "front_end_odometry": odometry_info, "keyframe_pipeline": pipeline_info,
     }
+    if share_gpu:
+        line["shared_gpu"] = f"{world} processes on ONE GPU, gloo through the host (GLIO_BENCH_SHARE_GPU=1): a test of the N-process path, not a scaling measurement"
     if c3_info:
         c3_info.pop("_cpu_sample", None)
     if cpu and "value" in cpu:
@@ -576,6 +587,17 @@ def bench_c3(local_rank, queries=131072, tiles=24):
             "Mqueries_per_s": round(queries / (k2 * 1e-3) / 1e6, 1)}
     info["_cpu_sample"] = (o, big, win.scans[0], q2, t2)
     ctx.close()
+    # the densest candidate set of a voxel-filtered planar map (synth.sheets_map: sheets inside each other's search radius)
+    dense, z = synth.sheets_map()
+    dscan = synth.sheets_scan(queries, z)
+    o2 = synth.default_opts(1, pts=queries, map_pts=len(dense))
+    ctx = capi.Context(o2, device=local_rank)
+    ctx.set_map(dense)
+    dk = ctx.associate(0, dscan, np.array([1.0, 0, 0, 0]), np.zeros(3))
+    d2 = float(np.mean([ctx.time_kernel(capi.KERNEL_ASSOCIATE, 10) for _ in range(3)]))
+    info["dense_candidate_set"] = {"workload": f"{queries} queries vs {len(dense)} points on 32 sheets 0.8 m apart (every query sees 4-5 sheets in its 27 cells)",
+                                   "kept": int(dk), "associate_us": round(d2 * 1e3, 1), "Mqueries_per_s": round(queries / (d2 * 1e-3) / 1e6, 1)}
+    ctx.close()
     return info
 
 
@@ -821,7 +843,9 @@ def bench_batch_stage(args, rank, local_rank, world, dist, torch):
     info = {"workload": f"C4: {K} keyframes x {per_kf} binary plane constraints, band +-{band}, sharded by source keyframe over {world} GPU(s)",
             "scaling": "strong", "constraints_total": int(K) * int(per_kf), "constraints_this_rank": int(len(ci)), "keyframes_this_rank": [int(lo), int(hi)],
             "linearize_kernels_ms": round(k8_ms, 4), "algorithmic_GBps_this_rank": round(len(ci) * 72 / (k8_ms * 1e-3) / 1e9, 1),
-            "collective": (f"torch.distributed all_reduce (backend nccl = RCCL), {world} ranks, on the library's stream" if dist is not None and world > 1 else "none (1 rank)")}
+            "collective": ((f"torch.distributed all_reduce (backend nccl = RCCL), {world} ranks, on the library's stream" if dist.get_backend() != "gloo" else
+                            f"gloo through host copies, {world} processes SHARING one GPU (GLIO_BENCH_SHARE_GPU=1: a protocol test, not a scaling measurement)")
+                           if dist is not None and world > 1 else "none (1 rank)")}
     if world == 1:
         st.linearize(init, Hg)
         info["banded_solve_ms"] = round(float(np.mean([st.time_solve(Hg, 1e-4, 5) for _ in range(2)])), 4)

@@ -554,11 +554,21 @@ class BatchStage:
             def __init__(self, ptr, n):
                 self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
 
+        # gloo (several processes sharing ONE GPU, where RCCL refuses duplicate devices: the hardware test of the multi-process
+        # protocol on a one-GPU box) sums through a host copy -- stream-synchronous, which the contract allows
+        staged = getattr(dist, "get_backend", None) is not None and getattr(dist, "is_initialized", lambda: False)() and dist.get_backend() == "gloo"
+
         def hook(ptr, count, stream, user):
             t = torch.as_tensor(_Dev(ptr, count), device=dev)
             ext = torch.cuda.ExternalStream(stream, device=dev) if stream else torch.cuda.current_stream(dev)
             with torch.cuda.stream(ext):
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                if staged:
+                    h = t.cpu()
+                    dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                    t.copy_(h)
+                    ext.synchronize()
+                else:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
                 if on_allreduce:
                     on_allreduce(t)
             calls.append(int(count))

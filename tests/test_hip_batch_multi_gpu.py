@@ -1,6 +1,11 @@
-"""The sharded batch solve over RCCL with one process per GPU.  Needs >= 2 visible devices: skipped on a one-GPU box (there the
-same sharding logic runs on virtual ranks, tests/test_hip_batch_tr.py::test_sharded_solve_on_virtual_ranks_equals_one_rank, and
-under gloo with a CPU stand-in, tests/test_batch_dist_cpu.py)."""
+"""The sharded batch solve across PROCESSES.
+* over RCCL with one process per GPU: needs >= 2 visible devices, skipped on a one-GPU box;
+* two and three processes SHARING one GPU, collectives through gloo (host copies -- RCCL refuses two ranks on one device): runs on a
+  one-GPU box and exercises everything but RCCL itself -- separate address spaces, the rendezvous, the deterministic collective
+  sequence of the device-resident loop (a rank that took a different decision would leave the others waiting: the test has a
+  timeout), the HIP stage on every rank.
+(The same sharding logic also runs on virtual ranks, tests/test_hip_batch_tr.py::test_sharded_solve_on_virtual_ranks_equals_one_rank,
+and under gloo with a CPU stand-in, tests/test_batch_dist_cpu.py.)"""
 import os
 import socket
 
@@ -29,19 +34,24 @@ def _problem(K=96, band=6, per_kf=120, seed=57):
     return K, band, init, (ci, cj, cp.numpy(), nc.numpy(), score.numpy()), dq, dd, frame, imu, sb0
 
 
-def _rank(rank, world, port, out_path):
+def _rank(rank, world, port, out_path, share_gpu=False):
+    import datetime
     import torch
     import torch.distributed as dist
     from glio_amd import batch
     from glio_amd import ctypes_types as T
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    device = 0 if share_gpu else rank
+    torch.cuda.set_device(device)
+    if share_gpu:
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
     K, band, init, con, dq, dd, frame, imu, sb0 = _problem()
     lo, hi = batch.shard_range(K, rank, world, band)
     own = (con[0] >= lo) & (con[0] < hi)
-    st = batch.BatchStage(K, band, max(1, int(own.sum())), device=rank)
+    st = batch.BatchStage(K, band, max(1, int(own.sum())), device=device)
     st.set_shard(rank, world)
     st.set_constraints(*[c[own] for c in con])
     st.set_small_factors(dq, dd, frame)
@@ -53,16 +63,9 @@ def _rank(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_two_gpus_over_rccl_equal_one_gpu(tmp_path):
-    import torch
-    if torch.cuda.device_count() < 2:
-        pytest.skip("needs two visible GPUs (one process per GPU over RCCL)")
-    import torch.multiprocessing as mp
+def _one_rank_and_compare(two):
     from glio_amd import batch
     from glio_amd import ctypes_types as T
-    out = str(tmp_path / "two.npz")
-    mp.spawn(_rank, args=(2, _free_port(), out), nprocs=2, join=True)
-    two = np.load(out)
     K, band, init, con, dq, dd, frame, imu, sb0 = _problem()
     st = batch.BatchStage(K, band, len(con[0]))
     st.set_constraints(*con); st.set_small_factors(dq, dd, frame); st.set_imu(imu)
@@ -72,3 +75,22 @@ def test_two_gpus_over_rccl_equal_one_gpu(tmp_path):
     assert np.isclose(float(two["cost"]), summ.final_cost, rtol=1e-9)
     assert np.abs(two["poses"] - poses).max() < 1e-9 and np.abs(two["sb"] - sb).max() < 1e-8
     assert int(two["calls"]) >= 1 + 5 * summ.iterations
+
+
+def test_two_gpus_over_rccl_equal_one_gpu(tmp_path):
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs (one process per GPU over RCCL)")
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "two.npz")
+    mp.spawn(_rank, args=(2, _free_port(), out), nprocs=2, join=True)
+    _one_rank_and_compare(np.load(out))
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 3])
+def test_processes_sharing_one_gpu_equal_one_rank(tmp_path, world):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "shared.npz")
+    mp.spawn(_rank, args=(world, _free_port(), out, True), nprocs=world, join=True)
+    _one_rank_and_compare(np.load(out))

@@ -89,3 +89,36 @@ def test_tiled_map_keeps_the_street(c3_case):
     a = capi.Context(o); a.set_map(big); na = a.associate(0, scan, q2, t2); ra = a.get_correspondences(0); a.close()
     b = capi.Context(o); b.set_map(win.map_pts); nb = b.associate(0, scan, q2, t2); rb = b.get_correspondences(0); b.close()
     assert na == nb and all(np.array_equal(x, y) for x, y in zip(ra, rb))
+
+
+def test_c3_dense_candidate_set_bit_exact():
+    """The same size of problem on the densest candidate set a voxel-filtered planar map offers (synth.sheets_map: sheets 0.8 m
+    apart, inside each other's search radius): 65 536 queries against 1 048 352 map points, the whole scan against the oracle's
+    brute-force association, bit for bit, neighbour indices included."""
+    from glio_amd import capi
+    from oracle import pyoracle as po
+    big, z = synth.sheets_map()
+    scan = synth.sheets_scan(65536, z)
+    o = synth.default_opts(1, pts=len(scan), map_pts=len(big))
+    q2, t2 = np.array([1.0, 0, 0, 0]), np.zeros(3)
+    ctx = capi.Context(o)
+    ctx.set_map(big)
+    cnt = ctx.associate(0, scan, q2, t2)
+    hp, hpl, hsc = ctx.get_correspondences(0)
+    hnn = np.zeros((len(scan), 5), np.int32)
+    capi.load().glio_debug_last_nn(ctx._h, T.iptr(hnn), len(hnn))
+    threads = min(128, len(os.sched_getaffinity(0)))
+    sel = np.arange(len(scan)) if len(scan) * len(big) / (threads * 5e8) <= 90.0 else np.arange(0, len(scan), 8)
+    pts, pl, sc, src, nn = po.associate(o, big, np.ascontiguousarray(scan[sel]), q2, t2, want_nn=True, threads=threads)
+    assert cnt > 0.8 * len(scan), cnt
+    if len(sel) == len(scan):
+        assert cnt == len(sc)
+        assert np.array_equal(hp, pts) and np.array_equal(hpl.view(np.uint32), pl.view(np.uint32)) and np.array_equal(hsc, sc)
+    gate = hnn[sel][:, 4] >= 0
+    assert gate.sum() > 0.8 * len(sel)
+    assert np.array_equal(hnn[sel][gate], nn[gate])
+    # a candidate set several sheets deep: the five neighbours of a query all lie on its own sheet although the sheets above and
+    # below are inside the search radius (the exact 5-NN is what keeps the plane fit meaningful here)
+    zq = scan[sel][gate][:, 2:3]
+    assert np.abs(big[nn[gate]][:, :, 2] - zq).max() < 0.2
+    ctx.close()
