@@ -75,11 +75,28 @@ __global__ __launch_bounds__(256) void k_batch_pairs(const float4* __restrict__ 
 #pragma unroll
     for (int k = 0; k < 64; ++k) acc[k] = 0.0;
     const long long beg = pair_off[p], end = pair_off[p + 1];
-    for (long long i = beg + lane; i < end; i += 64) {
-        const float4 pt = cp[i];
+    // software pipeline: the next constraint's 72 bytes are requested before the present one's ~160 multiply-adds are issued
+    long long i = beg + lane;
+    float4 pt_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    double2 n01_n = make_double2(0.0, 0.0), n2c0_n = n01_n, c12_n = n01_n;
+    double s_n = 0.0;
+    if (i < end) {
+        pt_n = cp[i];
         const double2* ncp = reinterpret_cast<const double2*>(nc + 6 * i);
-        const double2 n01 = ncp[0], n2c0 = ncp[1], c12 = ncp[2];
-        const double s = score[i];
+        n01_n = ncp[0]; n2c0_n = ncp[1]; c12_n = ncp[2];
+        s_n = score[i];
+    }
+    for (; i < end; i += 64) {
+        const float4 pt = pt_n;
+        const double2 n01 = n01_n, n2c0 = n2c0_n, c12 = c12_n;
+        const double s = s_n;
+        {
+            const long long in = i + 64 < end ? i + 64 : i;          // (the last iteration re-reads its own record: no branch in the loop body)
+            pt_n = cp[in];
+            const double2* ncp = reinterpret_cast<const double2*>(nc + 6 * in);
+            n01_n = ncp[0]; n2c0_n = ncp[1]; c12_n = ncp[2];
+            s_n = score[in];
+        }
         const double px = pt.x, py = pt.y, pz = pt.z;
         const double rp[3] = {R1[0] * px + R1[1] * py + R1[2] * pz, R1[3] * px + R1[4] * py + R1[5] * pz, R1[6] * px + R1[7] * py + R1[8] * pz};
         const double nl[3] = {n01.x, n01.y, n2c0.x}, cl[3] = {n2c0.y, c12.x, c12.y};

@@ -58,6 +58,7 @@ __device__ __forceinline__ HView bcr_view(const BcrOp& op, const int K, const in
     return v;
 }
 
+#define BCR_INIT_SPLIT 8
 __global__ __launch_bounds__(256) void k_bcr_init(const BcrOp op, const BcrInit* __restrict__ tab, const int K, const int band, const int B, const int M,
                                                   const int sbk, double* __restrict__ ws) {
     if (op.skip && *op.skip) return;
@@ -67,12 +68,15 @@ __global__ __launch_bounds__(256) void k_bcr_init(const BcrOp op, const BcrInit*
     const double* gsrc = op.gfull[cur];
     const int s = t.sblock;
     constexpr int U = 4;
-    for (int e0 = threadIdx.x; e0 < M * M; e0 += U * 256) {          // four entries of either block in flight per thread
+    // BCR_INIT_SPLIT workgroups per super-block (blockIdx.y), each a contiguous slice of the M x M entries: the kernel is a gather of
+    // dependent loads, so what it needs is wavefronts in flight, not bandwidth
+    const int per = (M * M + BCR_INIT_SPLIT - 1) / BCR_INIT_SPLIT, eb = blockIdx.y * per, ee_end = min(M * M, eb + per);
+    for (int e0 = eb + threadIdx.x; e0 < ee_end; e0 += U * 256) {          // four entries of either block in flight per thread
         double xd[U], xc[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int e = e0 + u * 256;
-            const int ee = e < M * M ? e : 0;
+            const int ee = e < ee_end ? e : 0;
             const int i = ee / M, j = ee - M * i;
             const int ka = s * sbk + i / B, r = i % B, kb = s * sbk + j / B, c = j % B;
             xd[u] = 0.0; xc[u] = 0.0;
@@ -94,12 +98,12 @@ __global__ __launch_bounds__(256) void k_bcr_init(const BcrOp op, const BcrInit*
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int e = e0 + u * 256;
-            if (e >= M * M) continue;
+            if (e >= ee_end) continue;
             if (t.oD >= 0) ws[t.oD + e] = xd[u];
             if (t.oC >= 0) ws[t.oC + e] = xc[u];
         }
     }
-    if (t.oy >= 0)
+    if (t.oy >= 0 && blockIdx.y == 0)
         for (int i = threadIdx.x; i < M; i += 256) {
             const int k = s * sbk + i / B, r = i % B;
             double x = 0.0;
@@ -780,7 +784,7 @@ void glio_bcr_enqueue_local(void* h, const BcrOp& op, hipStream_t stream) {
     BcrDev* b = static_cast<BcrDev*>(h);
     hipMemsetAsync(b->fail, 0, 4, stream);
     if (b->sep_doubles > 16) hipMemsetAsync(b->ws + b->sep_off, 0, (size_t)(b->sep_doubles - 16) * 8, stream);      // (the 16 extra scalars belong to the caller)
-    if (b->n_init > 0) hipLaunchKernelGGL(k_bcr_init, dim3(b->n_init), dim3(256), 0, stream, op, b->init, b->K, b->band, b->B, b->M, b->sbk, b->ws);
+    if (b->n_init > 0) hipLaunchKernelGGL(k_bcr_init, dim3(b->n_init, BCR_INIT_SPLIT), dim3(256), 0, stream, op, b->init, b->K, b->band, b->B, b->M, b->sbk, b->ws);
     BCR_DISPATCH(bcr_levels, b, op, 0, b->levels_loc, stream);
 }
 // phase 2 (after the all-reduce of sepbuf): the separator chain, then back through the local levels; delta = -z for the owned keyframes

@@ -329,39 +329,66 @@ __global__ void k_bt_unpack(const BtBufs a, const BtAsm m, const BtSel sel) {
     if (i <= 2LL * n) a.A[which][i] = m.stage[m.bnd_doubles + i];
 }
 
-// |x - x_c|^2, |x|^2 (all parameter blocks) and the gradient max norm |x_c - Plus(x_c, -g_c)|_inf of the candidate; one workgroup
-__global__ __launch_bounds__(1024) void k_bt_norms(const BtBufs a, const BtSel sel) {
-    __shared__ double red[3][16];
+// |x - x_c|^2, |x|^2 (all parameter blocks) and the gradient max norm |x_c - Plus(x_c, -g_c)|_inf of the candidate.  One lane per keyframe,
+// BT_NORM_THREADS per workgroup; the workgroups' parts are added by the last one to arrive, in workgroup order (the same bits on every rank).
+#define BT_NORM_THREADS 64
+struct NormParts { double* parts; unsigned int* ticket; };
+__global__ __launch_bounds__(BT_NORM_THREADS) void k_bt_norms(const BtBufs a, const BtSel sel, const NormParts np) {
+    __shared__ int s_last;
     if (bt_skip(sel)) return;
     const int cur = a.st->cur & 1, cand = cur ^ 1, K = a.K, B = a.B, n = B * K;
     const double* x = a.x[cur]; const double* xc = a.x[cand];
     const double* s = a.s[cur]; const double* sc = a.s[cand];
     const double* g = a.A[cand] + n;
     double d2 = 0, x2 = 0, gm = 0;
-    for (int k = threadIdx.x; k < K; k += 1024) {
+    const int k = blockIdx.x * BT_NORM_THREADS + threadIdx.x;
+    if (k < K) {
+        double xv[7], xcv[7], gv[15], sv[9], scv[9];
+#pragma unroll
+        for (int c = 0; c < 7; ++c) { xv[c] = x[7 * k + c]; xcv[c] = xc[7 * k + c]; }
+#pragma unroll
+        for (int c = 0; c < 15; ++c) gv[c] = c < B ? g[B * k + c] : 0.0;
+        if (B == 15) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) { sv[c] = s[9 * k + c]; scv[c] = sc[9 * k + c]; }
+        }
         double nd[3], qn[4];
-        for (int c = 0; c < 7; ++c) { const double v = x[7 * k + c], d = v - xc[7 * k + c]; d2 += d * d; x2 += v * v; }
-        for (int c = 0; c < 3; ++c) { gm = fmax(gm, fabs(g[B * k + c])); nd[c] = -g[B * k + 3 + c]; }
-        d_quat_plus(xc + 7 * k + 3, nd, qn);
-        for (int c = 0; c < 4; ++c) gm = fmax(gm, fabs(xc[7 * k + 3 + c] - qn[c]));
-        if (B == 15)
-            for (int c = 0; c < 9; ++c) { const double v = s[9 * k + c], d = v - sc[9 * k + c]; d2 += d * d; x2 += v * v; gm = fmax(gm, fabs(g[B * k + 6 + c])); }
+#pragma unroll
+        for (int c = 0; c < 7; ++c) { const double v = xv[c], d = v - xcv[c]; d2 += d * d; x2 += v * v; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { gm = fmax(gm, fabs(gv[c])); nd[c] = -gv[3 + c]; }
+        d_quat_plus(xcv + 3, nd, qn);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) gm = fmax(gm, fabs(xcv[3 + c] - qn[c]));
+        if (B == 15) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) { const double v = sv[c], d = v - scv[c]; d2 += d * d; x2 += v * v; gm = fmax(gm, fabs(gv[6 + c])); }
+        }
     }
+    // the lanes of a wavefront are added lane by lane in a fixed tree; workgroups in index order
     d2 = wave_sum(d2); x2 = wave_sum(x2);
     for (int off = 32; off > 0; off >>= 1) gm = fmax(gm, __shfl_xor(gm, off, 64));
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = d2; red[1][threadIdx.x >> 6] = x2; red[2][threadIdx.x >> 6] = gm; }
+    if (threadIdx.x == 0) { np.parts[3 * blockIdx.x] = d2; np.parts[3 * blockIdx.x + 1] = x2; np.parts[3 * blockIdx.x + 2] = gm; }
+    __threadfence();
+    if (threadIdx.x == 0) s_last = atomicAdd(np.ticket, 1u) == gridDim.x - 1;
     __syncthreads();
+    if (!s_last) return;
+    __threadfence();
     if (threadIdx.x == 0) {
         double p = 0, q = 0, m = 0;
-        for (int w = 0; w < 16; ++w) { p += red[0][w]; q += red[1][w]; m = fmax(m, red[2][w]); }
+        for (int w = 0; w < (int)gridDim.x; ++w) {
+            p += __builtin_nontemporal_load(&np.parts[3 * w]); q += __builtin_nontemporal_load(&np.parts[3 * w + 1]);
+            m = fmax(m, __builtin_nontemporal_load(&np.parts[3 * w + 2]));
+        }
         a.st->dx2 = p; a.st->xn2 = q; a.st->cand_grad_max = m; a.st->cand_cost = a.A[cand][2 * n];
         a.st->step_pending = 1;
+        *np.ticket = 0;
     }
 }
 
 // ------------------------------------------------------------------------------------------------ the state machine
 struct BtHost { int* progress; BtStatus* result; };     // mapped host memory
-__global__ __launch_bounds__(256) void k_bt_state_machine(const BtBufs a, const BtOpts o, const BtHost h) {
+__global__ __launch_bounds__(64) void k_bt_state_machine(const BtBufs a, const BtOpts o, const BtHost h) {
     __shared__ int sh_copy, sh_cur;
     if (threadIdx.x == 0) {
         BtStatus s = *a.st;
@@ -427,22 +454,21 @@ __global__ __launch_bounds__(256) void k_bt_state_machine(const BtBufs a, const 
             __threadfence_system();
         }
     }
-    __syncthreads();
-    if (sh_copy) {
-        const double* x = a.x[sh_cur]; const double* sb = a.s[sh_cur];
-        for (int i = threadIdx.x; i < 7 * a.K; i += 256) a.xmin[i] = x[i];
-        if (a.B == 15) for (int i = threadIdx.x; i < 9 * a.K; i += 256) a.smin[i] = sb[i];
-    }
+    // (the copy of the new best point into xmin / smin, flagged by copy_min, is done by k_bt_prepare, which follows with one thread per unknown)
 }
 #define BT_SKIP_SOLVE(a) ((a).st->skip_solve != 0)
 #define BT_SKIP_STEP(a) ((a).st->step_valid == 0)
 
 // scale (first group), D, g_s, g~, u = g~ / D, mu D^2
 __global__ void k_bt_prepare(const BtBufs a, const int jacobi) {
-    if (BT_SKIP_SOLVE(a)) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x, n = a.B * a.K;
     if (i >= n) return;
     const int cur = a.st->cur & 1;
+    if (a.st->copy_min) {            // the state machine accepted a point that is the best so far: the user's parameters follow it (two entries per thread)
+        const int nx = 7 * a.K, ns = a.B == 15 ? 9 * a.K : 0;
+        for (int e = i; e < nx + ns; e += n) { if (e < nx) a.xmin[e] = a.x[cur][e]; else a.smin[e - nx] = a.s[cur][e - nx]; }
+    }
+    if (BT_SKIP_SOLVE(a)) return;
     const double h = a.A[cur][i], g = a.A[cur][n + i];
     double* sc = BVEC(a, V_SC);
     if (a.st->group == 1 && !a.st->retry) sc[i] = jacobi ? 1.0 / (1.0 + sqrt(h)) : 1.0;
@@ -454,12 +480,18 @@ __global__ void k_bt_prepare(const BtBufs a, const int jacobi) {
     BVEC(a, V_DA)[i] = a.st->mu * D * D;
 }
 // y = Hs x for the OWNED rows (Hs = S H S on the fly) of up to two vectors.  One wavefront per owned keyframe: the scaled inputs of
-// the 2 band + 1 neighbouring keyframes go to LDS; lane (r, part) sums row r over every fourth neighbour, the four parts meet by
-// two shuffles.
+// the 2 band + 1 neighbouring keyframes go to LDS; then two passes whose loads are independent of each other (a lane's six or sixteen
+// matrix entries are fetched together):
+//   pose band   lane (r < 6, part of 8): row r of the 6 x 6 blocks (k, kb), kb = kb0 + part, + 8 -- from the stored block for kb >= k,
+//               from its transpose for kb < k;
+//   IMU chain   lane (r < 15, part of 4): row r of edge k's record against [x_k | x_k+1] and row 15 + r of edge k - 1's against
+//               [x_k-1 | x_k], every fourth of the 30 columns.
+// The parts meet by shuffles; the pose rows' sums travel through LDS to the lanes that write.
 __global__ __launch_bounds__(64) void k_bt_matvec(const BtBufs a, const int solve_phase, const int vx0, const int vy0, const int vx1, const int vy1) {
     __shared__ double xs[2][(2 * 16 + 1) * 15];
+    __shared__ double ys[2][8];
     if (solve_phase ? BT_SKIP_SOLVE(a) : BT_SKIP_STEP(a)) return;
-    const int B = a.B, K = a.K, band = a.band, k = a.lo + blockIdx.x, lane = threadIdx.x;
+    const int B = a.B, K = a.K, band = a.band, bw = band + 1, k = a.lo + blockIdx.x, lane = threadIdx.x;
     if (k >= a.hi) return;
     const HView v = bt_view(a, a.st->cur & 1);
     const double* sc = BVEC(a, V_SC);
@@ -468,26 +500,53 @@ __global__ __launch_bounds__(64) void k_bt_matvec(const BtBufs a, const int solv
     const int kb0 = k - band < 0 ? 0 : k - band, kb1 = k + band >= K ? K - 1 : k + band, nkb = kb1 - kb0 + 1;
     for (int e = lane; e < nkb * B; e += 64) { const size_t i = (size_t)kb0 * B + e; const double sv = sc[i]; xs[0][e] = sv * x0[i]; xs[1][e] = sv * x1[i]; }
     __syncthreads();
-    const int r = lane & 15, part = lane >> 4;
-    double s0 = 0, s1 = 0;
-    if (r < B)
-        for (int kbi = part; kbi < nkb; kbi += 4) {
-            const int kb = kb0 + kbi, d = kb - k;
-            const bool near = d >= -1 && d <= 1 && B == 15;
-            if (r >= 6 && !near) continue;
-            const int cmax = near ? B : 6;
-            for (int c = 0; c < cmax; ++c) {
-                const double hv = h_entry(v, k, r, kb, c);
-                s0 += hv * xs[0][kbi * B + c];
-                s1 += hv * xs[1][kbi * B + c];
+    {   // ---- pose band
+        const int r = lane & 7, part = lane >> 3;
+        double s0 = 0, s1 = 0;
+        if (r < 6) {
+            for (int kbi = part; kbi < nkb; kbi += 8) {
+                const int kb = kb0 + kbi, d = kb - k;
+                const double* p = d >= 0 ? v.Hg + ((size_t)k * bw + d) * 36 + r * 6 : v.Hg + ((size_t)kb * bw - d) * 36 + r;
+                const int stride = d >= 0 ? 1 : 6;
+                double hv[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) hv[c] = p[c * stride];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) { s0 += hv[c] * xs[0][kbi * B + c]; s1 += hv[c] * xs[1][kbi * B + c]; }
             }
         }
-    s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
-    s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+        s0 += __shfl_xor(s0, 8, 64); s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
+        s1 += __shfl_xor(s1, 8, 64); s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+        if (lane < 8) { ys[0][lane] = s0; ys[1][lane] = s1; }
+    }
+    double t0 = 0, t1 = 0;
+    if (B == 15 && v.imu) {   // ---- IMU chain
+        const int r = lane & 15, part = lane >> 4, kc = k - kb0;
+        if (r < 15) {
+            double ha[8], hb[8];
+            const bool ea = k < K - 1, eb = k > 0;
+            const double* pa = v.imu[ea ? k : 0].H + r * 30;
+            const double* pb = v.imu[eb ? k - 1 : 0].H + (15 + r) * 30;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int q = part + 4 * u; ha[u] = (ea && q < 30) ? pa[q] : 0.0; hb[u] = (eb && q < 30) ? pb[q] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = part + 4 * u;
+                if (q >= 30) continue;
+                const int ia = (q < 15 ? kc * B + q : (kc + 1) * B + q - 15), ib = (q < 15 ? (kc - 1) * B + q : kc * B + q - 15);
+                if (ea) { t0 += ha[u] * xs[0][ia]; t1 += ha[u] * xs[1][ia]; }
+                if (eb) { t0 += hb[u] * xs[0][ib]; t1 += hb[u] * xs[1][ib]; }
+            }
+        }
+        t0 += __shfl_xor(t0, 16, 64); t0 += __shfl_xor(t0, 32, 64);
+        t1 += __shfl_xor(t1, 16, 64); t1 += __shfl_xor(t1, 32, 64);
+    }
+    __syncthreads();
     if (lane < B) {
         const size_t i = (size_t)k * B + lane;
-        BVEC(a, vy0)[i] = sc[i] * s0;
-        if (vx1 >= 0) BVEC(a, vy1)[i] = sc[i] * s1;
+        const double p0 = lane < 6 ? ys[0][lane] : 0.0, p1 = lane < 6 ? ys[1][lane] : 0.0;
+        BVEC(a, vy0)[i] = sc[i] * (p0 + t0);
+        if (vx1 >= 0) BVEC(a, vy1)[i] = sc[i] * (p1 + t1);
     }
 }
 // up to six dot products in one pass: BT_DOT_BLOCKS workgroups write their parts, the last one to finish adds them in block order
@@ -659,26 +718,32 @@ __global__ void k_bt_dogleg(const BtBufs a, const double* __restrict__ stage_d, 
     s.c_g = cg; s.c_n = cn; s.c_1 = c1; s.c_2 = c2; s.dogleg_step_norm = norm;
 }
 // step in D-space, in the scaled variables, in the parameters; the candidate x (+) delta; one thread per keyframe
-__global__ void k_bt_step(const BtBufs a) {
+#define BT_STEP_KF 16
+__global__ __launch_bounds__(BT_STEP_KF * 15) void k_bt_step(const BtBufs a) {
+    __shared__ double sdl[BT_STEP_KF * 15];
     if (BT_SKIP_STEP(a)) return;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x, B = a.B;
-    if (k >= a.K) return;
+    const int B = a.B, tid = threadIdx.x;
+    const bool active = tid < BT_STEP_KF * B;
+    const int kl = tid / B, r = tid - B * kl, k = active ? blockIdx.x * BT_STEP_KF + kl : a.K;
     const BtStatus& s = *a.st;
     const int cur = s.cur & 1, cand = cur ^ 1;
-    double dl[15];
-    for (int r = 0; r < B; ++r) {
+    double dl = 0.0;
+    if (k < a.K) {
         const size_t i = (size_t)k * B + r;
         const double sD = s.c_g * BVEC(a, V_GR)[i] + s.c_n * BVEC(a, V_GN)[i] + s.c_1 * BVEC(a, V_U1)[i] + s.c_2 * BVEC(a, V_W2)[i];
         const double st = sD / BVEC(a, V_DG)[i];
         BVEC(a, V_SD)[i] = sD; BVEC(a, V_ST)[i] = st;
-        dl[r] = BVEC(a, V_SC)[i] * st;
-        BVEC(a, V_DL)[i] = dl[r];
+        dl = BVEC(a, V_SC)[i] * st;
+        BVEC(a, V_DL)[i] = dl;
     }
+    sdl[tid] = dl;
+    __syncthreads();
+    if (k >= a.K) return;
     const double* x = a.x[cur] + 7 * (size_t)k;
     double* xo = a.x[cand] + 7 * (size_t)k;
-    for (int c = 0; c < 3; ++c) xo[c] = x[c] + dl[c];
-    d_quat_plus(x + 3, dl + 3, xo + 3);
-    if (B == 15) for (int c = 0; c < 9; ++c) a.s[cand][9 * (size_t)k + c] = a.s[cur][9 * (size_t)k + c] + dl[6 + c];
+    if (r < 3) xo[r] = x[r] + dl;
+    else if (r == 3) d_quat_plus(x + 3, sdl + tid, xo + 3);
+    else if (r >= 6) a.s[cand][9 * (size_t)k + r - 6] = a.s[cur][9 * (size_t)k + r - 6] + dl;
 }
 // model cost change = -(gs . s + s^T Hs s / 2) with the all-reduced quadratic term (stage E)
 __global__ void k_bt_mcc(const BtBufs a, const double* __restrict__ stage_e) {
@@ -721,6 +786,9 @@ struct BatchSmall {
     double* h_x;               // pinned [K][16]
     int solve_id;
     long long hook_calls, hook_doubles, groups;
+    // the small factors and the IMU edges are evaluated on a second stream while K8 streams this rank's constraints (they are latency-bound
+    // launches of a few thousand wavefronts; K8 is bandwidth-bound): forked and joined with events inside enqueue_tr_linearize
+    hipStream_t side; hipEvent_t ev_fork, ev_join;
 };
 void glio_host_ecef_local(const double anc[3], double yaw, double R[9]);     // capi.hip
 
@@ -741,6 +809,9 @@ static int small_ensure(glio_batch* b) {
     BT_CHECK(hipMalloc((void**)&s->d_rel, 12 * 8));
     BT_CHECK(hipMemset(s->d_rel, 0, 12 * 8));
     BT_CHECK(hipMalloc((void**)&s->d_bnd_kf, 64 * 4));
+    BT_CHECK(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+    BT_CHECK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+    BT_CHECK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
     b->small = s;
     return GLIO_OK;
 }
@@ -761,6 +832,9 @@ void glio_batch_small_destroy(glio_batch* b) {
     tr_free(s);
     void* p[] = {s->d_fa, s->d_fb, s->d_ftype, s->d_fidx, s->d_dq_const, s->d_dd, s->d_small_index, s->d_frec, s->d_rel, s->d_bnd_kf, s->d_imu, s->d_rec[0], s->d_rec[1]};
     for (void* q : p) if (q) hipFree(q);
+    if (s->side) hipStreamDestroy(s->side);
+    if (s->ev_fork) hipEventDestroy(s->ev_fork);
+    if (s->ev_join) hipEventDestroy(s->ev_join);
     delete s;
     b->small = nullptr;
 }
@@ -797,7 +871,7 @@ static int tr_ensure(glio_batch* b) {
     BT_CHECK(hipMalloc((void**)&s->d_stage, (size_t)s->stage_doubles * 8));
     BT_CHECK(hipMalloc((void**)&s->d_dz, (size_t)(n + 2) * 8));
     BT_CHECK(hipMalloc((void**)&s->d_scal, 16 * 8)); BT_CHECK(hipMemset(s->d_scal, 0, 16 * 8));
-    BT_CHECK(hipMalloc((void**)&s->d_dot_parts, BT_DOT_BLOCKS * 6 * 8)); BT_CHECK(hipMalloc((void**)&s->d_dot_ticket, 16)); BT_CHECK(hipMemset(s->d_dot_ticket, 0, 16));
+    BT_CHECK(hipMalloc((void**)&s->d_dot_parts, (BT_DOT_BLOCKS * 6 + 3 * (size_t)((K + BT_NORM_THREADS - 1) / BT_NORM_THREADS)) * 8)); BT_CHECK(hipMalloc((void**)&s->d_dot_ticket, 16)); BT_CHECK(hipMemset(s->d_dot_ticket, 0, 16));
     BT_CHECK(hipMalloc((void**)&s->d_st, sizeof(BtStatus)));
     BT_CHECK(hipHostMalloc((void**)&s->h_prog, 64, hipHostMallocMapped | hipHostMallocCoherent));
     BT_CHECK(hipHostGetDevicePointer((void**)&s->d_prog, (void*)s->h_prog, 0));
@@ -829,19 +903,24 @@ static BtAsm make_asm(glio_batch* b) {
 }
 
 // small factors of this rank evaluated at the selected poses and added into the selected band buffer
-static void enqueue_small_sel(glio_batch* b, const BtSel& sel, const double* p0, const double* p1, double* Hg0, double* Hg1) {
+static void enqueue_small_eval(glio_batch* b, const BtSel& sel, const double* p0, const double* p1, hipStream_t st) {
+    BatchSmall* s = b->small;
+    if (!s || s->n_fac == 0) return;
+    hipLaunchKernelGGL(k_small_eval, dim3(s->n_fac), dim3(64), 0, st, sel, s->n_fac, s->d_fa, s->d_fb, s->d_ftype, s->d_fidx, p0, p1, s->d_dq_const, s->d_dd,
+                       s->d_rel, s->d_frec);
+}
+static void enqueue_small_accumulate(glio_batch* b, const BtSel& sel, double* Hg0, double* Hg1) {
     BatchSmall* s = b->small;
     if (!s || s->n_fac == 0) return;
     const int K = b->K, band = b->band;
-    hipLaunchKernelGGL(k_small_eval, dim3(s->n_fac), dim3(64), 0, b->stream, sel, s->n_fac, s->d_fa, s->d_fb, s->d_ftype, s->d_fidx, p0, p1, s->d_dq_const, s->d_dd,
-                       s->d_rel, s->d_frec);
     const long long tot = glio_batch_hg_size(K, band);
     hipLaunchKernelGGL(k_small_add, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, b->stream, sel, K, band, s->d_small_index, s->d_frec, s->n_fac, Hg0, Hg1);
     hipLaunchKernelGGL(k_small_cost, dim3(1), dim3(256), 0, b->stream, sel, s->d_frec, s->n_fac, Hg0 + tot - 1, Hg1 + tot - 1);
 }
 static void enqueue_small(glio_batch* b, const double* poses_dev, double* Hg_dev) {
     BtSel sel; sel.cur = nullptr; sel.skip = nullptr; sel.want = 0;
-    enqueue_small_sel(b, sel, poses_dev, poses_dev, Hg_dev, Hg_dev);
+    enqueue_small_eval(b, sel, poses_dev, poses_dev, b->stream);
+    enqueue_small_accumulate(b, sel, Hg_dev, Hg_dev);
 }
 
 typedef void (*bt_hook_fn)(double*, int64_t, void*, void*);
@@ -864,18 +943,27 @@ static void enqueue_tr_linearize(const BtRun& r, int want, bool initial) {
     BtSel sel; sel.cur = &s->d_st->cur; sel.skip = initial ? nullptr : &s->d_st->skip_step; sel.want = want;
     const int K = b->K, band = b->band;
     const int k0 = std::max(0, s->lo - band), k1 = std::min(K, s->hi + band);
-    glio_batch_enqueue_linearize_sel(b, sel, s->d_x[0], s->d_x[1], s->d_hg[0], s->d_hg[1], k0, k1);
-    enqueue_small_sel(b, sel, s->d_x[0], s->d_x[1], s->d_hg[0], s->d_hg[1]);
-    if (s->n_imu > 0) {
-        const int e0 = std::max(0, s->lo - 1), e1 = std::min(s->hi, K - 1);
-        glio_launch_batch_imu(st, sel, s->gravity, s->d_imu, e0, e1, s->d_x[0], s->d_x[1], s->d_s[0], s->d_s[1], s->d_rec[0], s->d_rec[1]);
+    const bool fork = s->n_fac > 0 || s->n_imu > 0;
+    if (fork) {                                    // small factors + IMU edges on the second stream, under K8
+        hipEventRecord(s->ev_fork, st);
+        hipStreamWaitEvent(s->side, s->ev_fork, 0);
+        enqueue_small_eval(b, sel, s->d_x[0], s->d_x[1], s->side);
+        if (s->n_imu > 0) {
+            const int e0 = std::max(0, s->lo - 1), e1 = std::min(s->hi, K - 1);
+            glio_launch_batch_imu(s->side, sel, s->gravity, s->d_imu, e0, e1, s->d_x[0], s->d_x[1], s->d_s[0], s->d_s[1], s->d_rec[0], s->d_rec[1]);
+        }
+        hipEventRecord(s->ev_join, s->side);
     }
+    glio_batch_enqueue_linearize_sel(b, sel, s->d_x[0], s->d_x[1], s->d_hg[0], s->d_hg[1], k0, k1);
+    if (fork) hipStreamWaitEvent(st, s->ev_join, 0);
+    enqueue_small_accumulate(b, sel, s->d_hg[0], s->d_hg[1]);
     const long long tot = s->bnd_doubles + 2LL * a.B * K;
     hipLaunchKernelGGL(k_bt_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, a, m, sel);
     hipLaunchKernelGGL(k_bt_pack_cost, dim3(1), dim3(256), 0, st, a, m, sel);
     call_hook(r, s->d_stage, s->stage_doubles);
     hipLaunchKernelGGL(k_bt_unpack, dim3((unsigned)((tot + 1 + 255) / 256)), dim3(256), 0, st, a, m, sel);
-    hipLaunchKernelGGL(k_bt_norms, dim3(1), dim3(1024), 0, st, a, sel);
+    NormParts np; np.parts = s->d_dot_parts + BT_DOT_BLOCKS * 6; np.ticket = s->d_dot_ticket + 1;
+    hipLaunchKernelGGL(k_bt_norms, dim3((K + BT_NORM_THREADS - 1) / BT_NORM_THREADS), dim3(BT_NORM_THREADS), 0, st, a, sel, np);
 }
 
 // one trust-region group: state machine, (Cauchy + Gauss-Newton + subspace model), step, model cost change, the candidate's linearisation
@@ -888,7 +976,7 @@ static void enqueue_tr_group(const BtRun& r, const BtOpts& o) {
     const int nbv = (n + TRV_THREADS - 1) / TRV_THREADS;
     const int nbo = std::max(1, s->hi - s->lo);
     BtHost h; h.progress = s->d_prog; h.result = s->d_res;
-    hipLaunchKernelGGL(k_bt_state_machine, dim3(1), dim3(256), 0, st, a, o, h);
+    hipLaunchKernelGGL(k_bt_state_machine, dim3(1), dim3(64), 0, st, a, o, h);
     // ---- Cauchy point and Gauss-Newton step (skipped when the stored ones are reused)
     hipLaunchKernelGGL(k_bt_prepare, dim3(nbv), dim3(TRV_THREADS), 0, st, a, o.jacobi);
     hipLaunchKernelGGL(k_bt_matvec, dim3(nbo), dim3(64), 0, st, a, 1, (int)V_UU, (int)V_T1, -1, -1);
@@ -932,7 +1020,7 @@ static void enqueue_tr_group(const BtRun& r, const BtOpts& o) {
     call_hook(r, s->d_scal, 8);
     // ---- the step for the present radius, its model cost change, the candidate
     hipLaunchKernelGGL(k_bt_dogleg, dim3(1), dim3(64), 0, st, a, s->d_scal, o.dogleg_type);
-    hipLaunchKernelGGL(k_bt_step, dim3((K + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_bt_step, dim3((K + BT_STEP_KF - 1) / BT_STEP_KF), dim3(BT_STEP_KF * 15), 0, st, a);
     hipLaunchKernelGGL(k_bt_matvec, dim3(nbo), dim3(64), 0, st, a, 0, (int)V_ST, (int)V_T1, -1, -1);
     {
         DotJobs j; memset(&j, 0, sizeof j); j.parts = s->d_dot_parts; j.ticket = s->d_dot_ticket;
