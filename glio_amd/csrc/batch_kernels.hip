@@ -56,6 +56,11 @@ __device__ __forceinline__ double butterfly64(const double (&in)[64], int lane, 
     return keep + __shfl_xor(send, 1, 64);
 }
 
+__device__ __forceinline__ double uniform_d(const double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __global__ __launch_bounds__(256) void k_batch_pairs(const float4* __restrict__ cp, const double* __restrict__ nc,
                                                      const double* __restrict__ score, const int* __restrict__ pair_i,
                                                      const int* __restrict__ pair_j, const long long* __restrict__ pair_off,
@@ -71,6 +76,12 @@ __global__ __launch_bounds__(256) void k_batch_pairs(const float4* __restrict__ 
     d_q2R(poses + 7 * (size_t)b + 3, R2);
 #pragma unroll
     for (int k = 0; k < 3; ++k) { t1[k] = poses[7 * (size_t)a + k]; t2[k] = poses[7 * (size_t)b + k]; }
+    // the two poses are the same for the whole wavefront: kept in scalar registers (24 doubles = 48 VGPRs less, which is what lets a
+    // third wavefront per SIMD in: the kernel alternates between waiting for 72-byte records and ~160 fp64 multiply-adds on each)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { R1[k] = uniform_d(R1[k]); R2[k] = uniform_d(R2[k]); }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { t1[k] = uniform_d(t1[k]); t2[k] = uniform_d(t2[k]); }
     double acc[64];
 #pragma unroll
     for (int k = 0; k < 64; ++k) acc[k] = 0.0;

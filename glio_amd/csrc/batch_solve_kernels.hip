@@ -509,13 +509,14 @@ template <int M>
 __global__ __launch_bounds__(512) void k_bcr_back(const int* skip, const BcrElim* __restrict__ tab, const double* __restrict__ L, const double* __restrict__ Ua,
                                                   const double* __restrict__ Ub, const double* __restrict__ w, double* __restrict__ z) {
     if (skip && *skip) return;
-    static_assert(M <= 128 && M % 6 == 0, "two rows per lane; the U^T z sums run in halves of M / 2 rows, three at a time");
+    static_assert(M <= 128 && M % 6 == 0, "two rows per lane; the U^T z sums run in halves of M / 2 rows, three chains");
     extern __shared__ double bcr_lds[];
     constexpr int LD = M + 1, H = M / 2;
     double* Ls = bcr_lds;            // [M][LD]
     double* za = Ls + M * LD;        // [M]
     double* zb = za + M;
     double* pt = zb + M;             // [4][128] partial sums: U_a rows [0, H), [H, M), U_b rows [0, H), [H, M)
+    double* rd = pt + 4 * 128;       // [M] reciprocal diagonal of L
     const BcrElim t = tab[blockIdx.x];
     const int tid = threadIdx.x;
     const size_t MM = (size_t)M * M;
@@ -536,16 +537,23 @@ __global__ __launch_bounds__(512) void k_bcr_back(const int* skip, const BcrElim
         if (c < M && nbr >= 0) {
             const double* U = (half ? Ub : Ua) + (size_t)t.node * MM + (size_t)r0 * M + c;
             const double* zz = (half ? zb : za) + r0;
+            // the factor's entries are independent global loads: fifteen at a time in flight (the sums keep three interleaved chains)
             double p3[3] = {0, 0, 0};
+            constexpr int CH = H % 15 == 0 ? 15 : 9;
+            static_assert(H % CH == 0, "chunk of the U^T z sums");
 #pragma unroll
-            for (int r = 0; r < H; r += 3) {
+            for (int r = 0; r < H; r += CH) {
+                double uv[CH];
 #pragma unroll
-                for (int u = 0; u < 3; ++u) p3[u] += U[(size_t)(r + u) * M] * zz[r + u];
+                for (int u = 0; u < CH; ++u) uv[u] = U[(size_t)(r + u) * M];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) p3[u % 3] += uv[u] * zz[r + u];
             }
             acc = (p3[0] + p3[1]) + p3[2];
         }
         pt[part * 128 + c] = acc;
     }
+    if (tid < M) rd[tid] = 1.0 / Ls[tid * LD + tid];
     __syncthreads();
     if (tid >= 64) return;
     // L^T z = t inside wavefront 0, last unknown first; lane l holds t[l] and t[l + 64]; the solved entry travels by a shuffle
@@ -553,13 +561,15 @@ __global__ __launch_bounds__(512) void k_bcr_back(const int* skip, const BcrElim
     auto rhs = [&](const int i) { return (w[(size_t)t.node * M + i] - (pt[i] + pt[128 + i])) - (pt[256 + i] + pt[384 + i]); };
     double t0 = lane < M ? rhs(lane) : 0.0;
     double t1 = lane + 64 < M ? rhs(lane + 64) : 0.0;
+    // fully unrolled: the pivot entry comes from its lane by v_readlane (a compile-time lane), the reciprocal diagonal and the row of L
+    // from LDS -- loads that depend on nothing solved so far, so the scheduler issues them ahead of the chain
+#pragma unroll
     for (int r = M - 1; r >= 0; --r) {
-        const double diag = Ls[r * LD + r];
-        const double tr = r >= 64 ? __shfl(t1, r - 64, 64) : __shfl(t0, r, 64);
-        const double zr = tr / diag;
+        const double tr = r >= 64 ? readlane_d(t1, r - 64) : readlane_d(t0, r);
+        const double zr = tr * rd[r];
         if (lane == (r & 63)) { if (r >= 64) t1 = zr; else t0 = zr; }
         if (lane < r) t0 -= Ls[r * LD + lane] * zr;
-        if (lane + 64 < r) t1 -= Ls[r * LD + lane + 64] * zr;
+        if (r > 64 && lane + 64 < r) t1 -= Ls[r * LD + lane + 64] * zr;
     }
     if (lane < M) z[(size_t)t.node * M + lane] = t0;
     if (lane + 64 < M) z[(size_t)t.node * M + lane + 64] = t1;
@@ -727,8 +737,8 @@ void* glio_bcr_create2(int K, int band, int B, int rank, int world) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_update<90>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BcrUp<90>::lds_bytes);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_elim2<72>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BcrE2<72>::lds_bytes);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_elim2<90>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BcrE2<90>::lds_bytes);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_back<72>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((72 * 73 + 2 * 72 + 512) * 8));
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_back<90>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((90 * 91 + 2 * 90 + 512) * 8));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_back<72>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((72 * 73 + 3 * 72 + 512) * 8));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_back<90>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((90 * 91 + 3 * 90 + 512) * 8));
     (void)hipGetLastError();
     return b;
 }
@@ -771,7 +781,7 @@ static void bcr_levels(BcrDev* b, const BcrOp& op, int l0, int l1, hipStream_t s
 }
 template <int M>
 static void bcr_back(BcrDev* b, const BcrOp& op, int l0, int l1, hipStream_t stream) {
-    const size_t lds_back = (size_t)(M * (M + 1) + 2 * M + 4 * 128) * 8;
+    const size_t lds_back = (size_t)(M * (M + 1) + 3 * M + 4 * 128) * 8;
     for (int l = l1 - 1; l >= l0; --l) {
         const int ne = b->h_elim_off[l + 1] - b->h_elim_off[l];
         if (ne > 0) hipLaunchKernelGGL((k_bcr_back<M>), dim3(ne), dim3(512), lds_back, stream, op.skip, b->elim + b->h_elim_off[l], b->L, b->Ua, b->Ub, b->w, b->z);
