@@ -48,6 +48,11 @@ struct BcrDev {
     std::vector<int> node_of_sblock;               // owned super-block (global index - Slo) -> node id
     int* node_of_sblock_dev;
     int* fail;
+    // with the IMU chain (B = 15): the speed-bias blocks of the four INNER keyframes of every super-block touch nothing outside their
+    // super-block, so they are eliminated before the reduction (k_bcr_pre) and recovered after it (k_bcr_post): the reduction then
+    // runs on 54 x 54 blocks (6 poses + the speed-bias blocks of the first and the last keyframe) instead of 90 x 90
+    bool pre;
+    double* preL; double* preU; double* prew;      // per owned super-block: L [36][36], U = A_ki L^-T [54][36], w = L^-1 y_i [36]
 };
 
 // ------------------------------------------------------------------------------------------------ the operator (HView / h_entry: batch_device.h)
@@ -113,6 +118,248 @@ __global__ __launch_bounds__(256) void k_bcr_init(const BcrOp op, const BcrInit*
             }
             ws[t.oy + i] = x;
         }
+}
+
+#ifdef GLIO_DEV_STAMPS
+__device__ long long g_bcr_stamps[8];      // elim2, workgroup 0: [0] load, [1] register steps, [2] MFMA updates, [3] store (100 MHz ticks, last launch)
+#define BCR_T(var) const long long var = wall_clock64()
+#define BCR_ACC(k, t1, t0) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_bcr_stamps[k] += (t1) - (t0); } while (0)
+#else
+#define BCR_T(var) do { } while (0)
+#define BCR_ACC(k, t1, t0) do { } while (0)
+#endif
+// ------------------------------------------------------------------------------------------------ pre-elimination of the inner speed-bias blocks
+// A super-block of 6 keyframes x 15 unknowns.  KEPT (54): keyframe 0 whole (15), the poses of keyframes 1..4 (4 x 6), keyframe 5 whole (15)
+// -- everything that couples to another super-block (the pose band reaches +-6 keyframes, the IMU edge 5 -> 0' the neighbour's first
+// keyframe).  INNER (36): the speed-bias blocks of keyframes 1..4, a 4-block chain coupled to the poses and speed-bias blocks of this
+// super-block only.  k_bcr_pre forms, from the operator, [A_ii; A_ki; y_i^T] (91 rows x 36), factors it in 36 register steps (one row
+// per lane, one barrier per pivot, as k_bcr_elim) and writes the Schur complement A_kk - U U^T, y_k - U w as the super-block's 54 x 54
+// node; k_bcr_post recovers z_i = L^-T (w - U^T z_k) and writes the step of the super-block's keyframes.
+#define PRE_NI 36
+#define PRE_NK 54
+#define PRE_ROWS (PRE_NI + PRE_NK + 1)
+__device__ __forceinline__ void pre_kept(const int i, int& kl, int& r) {
+    if (i < 15) { kl = 0; r = i; } else if (i < 39) { kl = 1 + (i - 15) / 6; r = (i - 15) % 6; } else { kl = 5; r = i - 39; }
+}
+__device__ __forceinline__ void pre_inner(const int p, int& kl, int& r) { kl = 1 + p / 9; r = 6 + p % 9; }
+// S (H_band + H_imu) S + shift, entry (r, c) of block (ka, kb) -- the value of h_entry (batch_device.h) with scale and shift, written WITHOUT
+// data-dependent branches: every load goes to a clamped address and is selected afterwards, so the entries a thread gathers are independent
+// loads the hardware overlaps (with the branches of h_entry each entry cost a full memory round trip: 1.3 us per entry per thread, measured)
+__device__ __forceinline__ double bcr_scaled_entry(const BcrOp& op, const HView& v, const int K, const int B, const int ka, const int r, const int kb, const int c) {
+    const bool in = ka < K && kb < K;
+    const int kac = ka < K ? ka : K - 1, kbc = kb < K ? kb : K - 1;
+    const int d = kbc - kac, bw = v.band + 1;
+    // pose band
+    const bool hasb = in && r < 6 && c < 6 && d <= v.band && d >= -v.band;
+    const int rb = r < 6 ? r : 0, cb = c < 6 ? c : 0, dd = d > v.band ? v.band : (d < -v.band ? -v.band : d);
+    const size_t ib = dd >= 0 ? ((size_t)kac * bw + dd) * 36 + rb * 6 + cb : ((size_t)kbc * bw + (-dd)) * 36 + cb * 6 + rb;
+    const double xb = v.Hg[ib];
+    // IMU chain: edge e1 holds (ka, kb) for |d| <= 1; the diagonal block takes a second share from the edge arriving at ka
+    double x1 = 0.0, x2 = 0.0;
+    bool has1 = false, has2 = false;
+    if (v.imu) {
+        const int e1 = d == -1 ? kbc : kac, e1c = e1 < K - 1 ? e1 : (K >= 2 ? K - 2 : 0);
+        const int o1 = d == 0 ? r * 30 + c : (d == 1 ? r * 30 + 15 + c : (15 + r) * 30 + c);
+        has1 = in && d >= -1 && d <= 1 && e1 < K - 1;
+        has2 = in && d == 0 && kac > 0;
+        const int e2c = kac > 0 ? kac - 1 : 0;
+        x1 = v.imu[e1c].H[o1];
+        x2 = v.imu[e2c < K - 1 ? e2c : 0].H[(15 + r) * 30 + 15 + c];
+    }
+    const double sa = op.sc ? op.sc[(size_t)kac * B + r] : 1.0, sb = op.sc ? op.sc[(size_t)kbc * B + c] : 1.0;
+    const double da = op.dadd ? op.dadd[(size_t)kac * B + r] : 0.0;
+    double x = (hasb ? xb : 0.0) + (has1 ? x1 : 0.0) + (has2 ? x2 : 0.0);
+    if (!in) return (ka == kb && r == c) ? 1.0 : 0.0;           // identity padding of the last super-block
+    x *= sa * sb;
+    if (ka == kb && r == c) x += op.dadd ? da : op.lambda * x + 1e-12;
+    return x;
+}
+__global__ __launch_bounds__(256) void k_bcr_pre(const BcrOp op, const BcrInit* __restrict__ tab, const int K, const int band, const int Slo, double* __restrict__ ws,
+                                                 double* __restrict__ preL, double* __restrict__ preU, double* __restrict__ prew, int* fail) {
+    if (op.skip && *op.skip) return;
+    constexpr int B = 15, NI = PRE_NI, NK = PRE_NK, LDP = NI + 1;
+    __shared__ double pan[PRE_ROWS * LDP];         // [A_ii; A_ki; y_i] rows of 36 (+1 pad), later U (rows 36..89) and w (row 90)
+    __shared__ double dk[NK * NK + NK];            // A_kk, y_k
+    __shared__ double col[2][NI];
+    __shared__ int s_bad;
+    const BcrInit t = tab[blockIdx.x];
+    const HView v = bcr_view(op, K, band, B);
+    const int cur = op.cur ? *op.cur : 0;
+    const double* gsrc = op.gfull[cur];
+    const int s = t.sblock, k0 = s * 6, tid = threadIdx.x;
+    constexpr int U = 8;
+    if (blockIdx.y > 0) {
+        // ---- the coupling A[s+1][s] between the KEPT unknowns (the inner blocks do not reach the neighbour): a gather, two workgroups
+        if (t.oC < 0) return;
+        const int half = (NK * NK + 1) / 2, eb = (blockIdx.y - 1) * half, ee = min(NK * NK, eb + half);
+        for (int e0 = eb + tid; e0 < ee; e0 += U * 256) {
+            double x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + u * 256, eo = e < ee ? e : eb;
+                int kli, ri, klj, cj;
+                pre_kept(eo / NK, kli, ri); pre_kept(eo % NK, klj, cj);
+                const int kr = k0 + 6 + kli, kb = k0 + klj;
+                x[u] = bcr_scaled_entry(op, v, K, B, kr, ri, kb, cj);          // (zero when either keyframe is padding: different blocks)
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int e = e0 + u * 256; if (e < ee) ws[t.oC + e] = x[u]; }
+        }
+        return;
+    }
+    if (t.oD < 0) return;
+    if (tid == 0) s_bad = 0;
+#ifdef GLIO_DEV_STAMPS
+    if (blockIdx.x == 0 && tid == 0) { g_bcr_stamps[4] = g_bcr_stamps[5] = g_bcr_stamps[6] = 0; }
+#endif
+    BCR_T(tq0);
+    // ---- gather: panel rows (91 x 36), A_kk (54 x 54), y_k -- eight entries in flight per thread
+    constexpr int NP = PRE_ROWS * NI, ND = NK * NK, NT = NP + ND + NK;
+    for (int e0 = tid; e0 < NT; e0 += U * 256) {
+        double x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // the entry's coordinates by selects only (no branch between the loads of different entries)
+            const int e = e0 + u * 256, ec = e < NT ? e : 0;
+            const bool inpan = ec < NP, indk = !inpan && ec < NP + ND;
+            const int prow = ec / NI, pc = ec - NI * prow;                  // panel: row, inner column
+            const int q = indk ? ec - NP : 0, di = q / NK, dj = q - NK * di;   // A_kk: kept row, kept column
+            const int yk = (!inpan && !indk) ? ec - NP - ND : 0;             // y_k: kept index
+            int kl_c, r_c, kl_r, r_r, kl_a, r_a, kl_b, r_b, kl_y, r_y;
+            pre_inner(pc, kl_c, r_c);
+            pre_inner(prow < NI ? prow : 0, kl_r, r_r);
+            pre_kept((prow >= NI && prow < NI + NK) ? prow - NI : 0, kl_a, r_a);
+            pre_kept(di, kl_b, r_b);
+            int kl_dj, r_dj;
+            pre_kept(dj, kl_dj, r_dj);
+            pre_kept(yk, kl_y, r_y);
+            const bool rhs = (inpan && prow == NI + NK) || (!inpan && !indk);
+            // matrix entry (ka, ra | kb, cb)
+            const int ka = k0 + (inpan ? (prow < NI ? kl_r : kl_a) : kl_b), ra = inpan ? (prow < NI ? r_r : r_a) : r_b;
+            const int kb = k0 + (inpan ? kl_c : kl_dj), cb = inpan ? r_c : r_dj;
+            const double val = bcr_scaled_entry(op, v, K, B, ka, ra, kb, cb);
+            // right-hand side entry (k, r)
+            const int kg = k0 + (inpan ? kl_c : kl_y), rg = inpan ? r_c : r_y, kgc = kg < K ? kg : K - 1;
+            const double gv = gsrc[(size_t)kgc * B + rg] * (op.sc ? op.sc[(size_t)kgc * B + rg] : 1.0);
+            x[u] = rhs ? (kg < K ? gv : 0.0) : val;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * 256;
+            if (e < NP) { const int row = e / NI, c = e - NI * row; pan[row * LDP + c] = x[u]; }
+            else if (e < NT) dk[e - NP] = x[u];
+        }
+    }
+    __syncthreads();
+    BCR_T(tq1);
+    BCR_ACC(4, tq1, tq0);
+    // ---- 36 register steps, one row per lane (rows 0..35 the inner block, 36..89 the kept rows, 90 the right-hand side)
+    const int row = tid;
+    double a[NI];
+#pragma unroll
+    for (int c = 0; c < NI; ++c) a[c] = row < PRE_ROWS ? pan[row * LDP + c] : 0.0;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        if (row >= j && row < NI) col[j & 1][row] = a[j];
+        __syncthreads();
+        const double piv = col[j & 1][j];
+        double rd;
+        if (!(piv > 0.0) || !isfinite(piv)) { rd = 1.0; if (row == j) s_bad = 1; } else rd = rsqrt(piv);
+        if (row >= j && row < PRE_ROWS) {
+            const double lj = a[j] * rd;
+            a[j] = lj;
+            if (row > j) {
+#pragma unroll
+                for (int c = j + 1; c < NI; ++c) a[c] -= lj * (col[j & 1][c] * rd);
+            }
+        }
+    }
+    __syncthreads();
+    BCR_T(tq2);
+    BCR_ACC(5, tq2, tq1);
+    const size_t sb = (size_t)(s - Slo);
+    if (row < PRE_ROWS) {
+#pragma unroll
+        for (int c = 0; c < NI; ++c) pan[row * LDP + c] = (row < NI && c > row) ? 0.0 : a[c];
+    }
+    if (tid == 0 && s_bad) atomicOr(fail, 1);
+    __syncthreads();
+    // factors out (coalesced), Schur complement and right-hand side of the kept unknowns
+    for (int e = tid; e < NI * NI; e += 256) preL[sb * NI * NI + e] = pan[(e / NI) * LDP + e % NI];
+    for (int e = tid; e < NK * NI; e += 256) preU[sb * NK * NI + e] = pan[(NI + e / NI) * LDP + e % NI];
+    if (tid < NI) prew[sb * NI + tid] = pan[(NI + NK) * LDP + tid];
+    for (int e = tid; e < NK * NK; e += 256) {
+        const int i = e / NK, j = e - NK * i;
+        const double* ui = pan + (NI + i) * LDP; const double* uj = pan + (NI + j) * LDP;
+        double s0 = 0, s1 = 0;
+#pragma unroll
+        for (int c = 0; c < NI; c += 2) { s0 += ui[c] * uj[c]; s1 += ui[c + 1] * uj[c + 1]; }
+        ws[t.oD + e] = dk[e] - (s0 + s1);
+    }
+    if (t.oy >= 0 && tid < NK) {
+        const double* ui = pan + (NI + tid) * LDP; const double* wv = pan + (NI + NK) * LDP;
+        double s0 = 0;
+#pragma unroll
+        for (int c = 0; c < NI; ++c) s0 += ui[c] * wv[c];
+        ws[t.oy + tid] = dk[NK * NK + tid] - s0;
+    }
+#ifdef GLIO_DEV_STAMPS
+    __syncthreads();
+    { BCR_T(tq3); BCR_ACC(6, tq3, tq2); }
+#endif
+}
+// z_i = L^-T (w - U^T z_k) of one owned super-block, then the step of its keyframes: delta = -z (kept unknowns from the node's solution)
+__global__ __launch_bounds__(64) void k_bcr_post(const int* skip, const double* __restrict__ z, const int* __restrict__ node_of, const int Slo, const int K,
+                                                 const double* __restrict__ preL, const double* __restrict__ preU, const double* __restrict__ prew,
+                                                 double* __restrict__ delta, int* fail) {
+    if (skip && *skip) return;
+    constexpr int B = 15, NI = PRE_NI, NK = PRE_NK, LDL = NI + 1;
+    __shared__ double Ls[NI * LDL], zk[NK], rd[NI], zi[NI];
+    const int sb = blockIdx.x, lane = threadIdx.x, s = Slo + sb, k0 = s * 6;
+    const int node = node_of[sb];
+    if (lane < NK) zk[lane] = z[(size_t)node * NK + lane];
+    for (int e0 = lane; e0 < NI * NI; e0 += 8 * 64) {
+        double v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = e0 + u * 64; v8[u] = e < NI * NI ? preL[(size_t)sb * NI * NI + e] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = e0 + u * 64; if (e < NI * NI) Ls[(e / NI) * LDL + e % NI] = v8[u]; }
+    }
+    __syncthreads();
+    double t = 0.0;
+    if (lane < NI) {
+        rd[lane] = 1.0 / Ls[lane * LDL + lane];
+        const double* Uc = preU + (size_t)sb * NK * NI + lane;
+        double p3[3] = {0, 0, 0};
+#pragma unroll
+        for (int i0 = 0; i0 < NK; i0 += 18) {
+            double uv[18];
+#pragma unroll
+            for (int u = 0; u < 18; ++u) uv[u] = Uc[(size_t)(i0 + u) * NI];
+#pragma unroll
+            for (int u = 0; u < 18; ++u) p3[u % 3] += uv[u] * zk[i0 + u];
+        }
+        t = prew[(size_t)sb * NI + lane] - ((p3[0] + p3[1]) + p3[2]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = NI - 1; r >= 0; --r) {
+        const double zr = readlane_d(t, r) * rd[r];
+        if (lane == r) t = zr;
+        if (lane < r) t -= Ls[r * LDL + lane] * zr;
+    }
+    if (lane < NI) zi[lane] = t;
+    __syncthreads();
+    for (int e = lane; e < 6 * B; e += 64) {
+        const int kl = e / B, r = e - B * kl, k = k0 + kl;
+        if (k >= K) continue;
+        double val;
+        if (r >= 6 && kl >= 1 && kl <= 4) val = zi[(kl - 1) * 9 + r - 6];
+        else val = zk[kl == 0 ? r : (kl == 5 ? 39 + r : 15 + (kl - 1) * 6 + r)];
+        val = -val;
+        if (!isfinite(val)) atomicOr(fail, 2);
+        delta[(size_t)k * B + r] = val;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ elimination
@@ -200,14 +447,6 @@ __global__ __launch_bounds__(BcrCfg<M>::THREADS) void k_bcr_elim(const int* skip
 // PANEL instead of one per pivot.  LDS: the packed lower triangle of A_pp (rows at i (i + 1) / 2) + M + 1 full rows
 // (A_ap, y, A_bp: 2 M + 1 rows; at M = 90 that is 159.3 of the 160 KB).
 #define BCR_E2_THREADS 512
-#ifdef GLIO_DEV_STAMPS
-__device__ long long g_bcr_stamps[8];      // elim2, workgroup 0: [0] load, [1] register steps, [2] MFMA updates, [3] store (100 MHz ticks, last launch)
-#define BCR_T(var) const long long var = wall_clock64()
-#define BCR_ACC(k, t1, t0) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_bcr_stamps[k] += (t1) - (t0); } while (0)
-#else
-#define BCR_T(var) do { } while (0)
-#define BCR_ACC(k, t1, t0) do { } while (0)
-#endif
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 template <int M> struct BcrE2 {
     // row stride of the full rows: M itself when that keeps the 16 rows of an MFMA operand on distinct banks (M = 90: 180 banks apart
@@ -638,7 +877,9 @@ void* glio_bcr_create2(int K, int band, int B, int rank, int world) {
     BcrDev* b = new BcrDev();
     b->K = K; b->band = band; b->B = B; b->rank = rank; b->world = world;
     b->sbk = band <= 6 ? 6 : 12;
-    b->M = b->sbk * B;
+    b->pre = B == 15;
+    b->M = b->pre ? PRE_NK : b->sbk * B;
+    b->preL = b->preU = b->prew = nullptr;
     b->S = (K + b->sbk - 1) / b->sbk;
     if (b->S < world) { delete b; glio_set_error("batch solver: %d super-blocks cannot be spread over %d ranks", b->S, world); return nullptr; }
     const int S = b->S, M = b->M;
@@ -727,12 +968,19 @@ void* glio_bcr_create2(int K, int band, int B, int rank, int world) {
               A((void**)&b->w, nn * M * 8) && A((void**)&b->z, nn * M * 8) && A((void**)&b->fail, 16) &&
               A((void**)&b->elim, (elim.size() + 1) * sizeof(BcrElim)) && A((void**)&b->kept, (kept.size() + 1) * sizeof(BcrKept)) &&
               A((void**)&b->init, (init.size() + 1) * sizeof(BcrInit)) && A((void**)&b->node_of_sblock_dev, (size_t)(nown + 1) * 4);
+    if (ok && b->pre) {
+        const size_t no = (size_t)std::max(nown, 1);
+        ok = A((void**)&b->preL, no * PRE_NI * PRE_NI * 8) && A((void**)&b->preU, no * PRE_NK * PRE_NI * 8) && A((void**)&b->prew, no * PRE_NI * 8);
+    }
     if (!ok) { glio_set_error("batch solver: device allocation failed"); return nullptr; }
     hipMemset(b->ws, 0, (size_t)b->ws_doubles * 8);
     if (!elim.empty()) hipMemcpy(b->elim, elim.data(), elim.size() * sizeof(BcrElim), hipMemcpyHostToDevice);
     if (!kept.empty()) hipMemcpy(b->kept, kept.data(), kept.size() * sizeof(BcrKept), hipMemcpyHostToDevice);
     if (!init.empty()) hipMemcpy(b->init, init.data(), init.size() * sizeof(BcrInit), hipMemcpyHostToDevice);
     hipMemcpy(b->node_of_sblock_dev, b->node_of_sblock.data(), (size_t)nown * 4, hipMemcpyHostToDevice);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_update<54>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BcrUp<54>::lds_bytes);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_elim2<54>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BcrE2<54>::lds_bytes);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_back<54>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((54 * 55 + 3 * 54 + 512) * 8));
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_update<72>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BcrUp<72>::lds_bytes);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_update<90>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BcrUp<90>::lds_bytes);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_elim2<72>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BcrE2<72>::lds_bytes);
@@ -747,7 +995,7 @@ void* glio_bcr_create(int K, int band) { return glio_bcr_create2(K, band, 6, 0, 
 void glio_bcr_destroy(void* h) {
     BcrDev* b = static_cast<BcrDev*>(h);
     if (!b) return;
-    void* ptrs[] = {b->ws, b->L, b->Ua, b->Ub, b->w, b->z, b->elim, b->kept, b->init, b->node_of_sblock_dev, b->fail};
+    void* ptrs[] = {b->ws, b->L, b->Ua, b->Ub, b->w, b->z, b->elim, b->kept, b->init, b->node_of_sblock_dev, b->fail, b->preL, b->preU, b->prew};
     for (void* p : ptrs) if (p) hipFree(p);
     delete b;
 }
@@ -763,7 +1011,7 @@ double* glio_bcr_sepbuf(void* h, long long* count) {
 }
 int* glio_bcr_fail_flag(void* h) { return static_cast<BcrDev*>(h)->fail; }
 
-// -1 (default): by size -- the blocked elimination (k_bcr_elim2) for M >= 72, one register step per pivot with a workgroup barrier each
+// -1 (default): by size -- the blocked elimination (k_bcr_elim2) for M >= 54, one register step per pivot with a workgroup barrier each
 // (k_bcr_elim) for M = 36, where it is the faster one (15 vs 19 us on MI355X); 1 / 0 force either (GLIO_BCR_ELIM, cross-checks)
 static int g_bcr_elim_mode = getenv("GLIO_BCR_ELIM") ? atoi(getenv("GLIO_BCR_ELIM")) : -1;
 void glio_bcr_debug_set_elim(int mode) { g_bcr_elim_mode = mode; }
@@ -773,7 +1021,7 @@ static void bcr_levels(BcrDev* b, const BcrOp& op, int l0, int l1, hipStream_t s
     for (int l = l0; l < l1; ++l) {
         const int ne = b->h_elim_off[l + 1] - b->h_elim_off[l], nk = b->h_kept_off[l + 1] - b->h_kept_off[l];
         if (ne > 0) {
-            if (g_bcr_elim_mode == 0 || (g_bcr_elim_mode < 0 && M < 72)) hipLaunchKernelGGL((k_bcr_elim<M>), dim3(ne), dim3(BcrCfg<M>::THREADS), 0, stream, op.skip, b->elim + b->h_elim_off[l], b->ws, b->L, b->Ua, b->Ub, b->w, b->fail);
+            if (g_bcr_elim_mode == 0 || (g_bcr_elim_mode < 0 && M < 54)) hipLaunchKernelGGL((k_bcr_elim<M>), dim3(ne), dim3(BcrCfg<M>::THREADS), 0, stream, op.skip, b->elim + b->h_elim_off[l], b->ws, b->L, b->Ua, b->Ub, b->w, b->fail);
             else hipLaunchKernelGGL((k_bcr_elim2<M>), dim3(ne), dim3(BCR_E2_THREADS), BcrE2<M>::lds_bytes, stream, op.skip, b->elim + b->h_elim_off[l], b->ws, b->L, b->Ua, b->Ub, b->w, b->fail);
         }
         if (nk > 0) hipLaunchKernelGGL((k_bcr_update<M>), dim3(2 * nk), dim3(BCR_UP_THREADS), lds_up, stream, op.skip, b->kept + b->h_kept_off[l], b->ws, b->Ua, b->Ub, b->w);
@@ -787,14 +1035,16 @@ static void bcr_back(BcrDev* b, const BcrOp& op, int l0, int l1, hipStream_t str
         if (ne > 0) hipLaunchKernelGGL((k_bcr_back<M>), dim3(ne), dim3(512), lds_back, stream, op.skip, b->elim + b->h_elim_off[l], b->L, b->Ua, b->Ub, b->w, b->z);
     }
 }
-#define BCR_DISPATCH(fn, ...) do { if (b->M == 36) fn<36>(__VA_ARGS__); else if (b->M == 72) fn<72>(__VA_ARGS__); else fn<90>(__VA_ARGS__); } while (0)
+#define BCR_DISPATCH(fn, ...) do { if (b->M == 36) fn<36>(__VA_ARGS__); else if (b->M == 54) fn<54>(__VA_ARGS__); else if (b->M == 72) fn<72>(__VA_ARGS__); else fn<90>(__VA_ARGS__); } while (0)
 
 // phase 1: operator -> blocks, local elimination; afterwards sepbuf holds this rank's share of the separator system (all-reduce it)
 void glio_bcr_enqueue_local(void* h, const BcrOp& op, hipStream_t stream) {
     BcrDev* b = static_cast<BcrDev*>(h);
     hipMemsetAsync(b->fail, 0, 4, stream);
     if (b->sep_doubles > 16) hipMemsetAsync(b->ws + b->sep_off, 0, (size_t)(b->sep_doubles - 16) * 8, stream);      // (the 16 extra scalars belong to the caller)
-    if (b->n_init > 0) hipLaunchKernelGGL(k_bcr_init, dim3(b->n_init, BCR_INIT_SPLIT), dim3(256), 0, stream, op, b->init, b->K, b->band, b->B, b->M, b->sbk, b->ws);
+    if (b->n_init > 0 && b->pre)
+        hipLaunchKernelGGL(k_bcr_pre, dim3(b->n_init, 3), dim3(256), 0, stream, op, b->init, b->K, b->band, b->Slo, b->ws, b->preL, b->preU, b->prew, b->fail);
+    else if (b->n_init > 0) hipLaunchKernelGGL(k_bcr_init, dim3(b->n_init, BCR_INIT_SPLIT), dim3(256), 0, stream, op, b->init, b->K, b->band, b->B, b->M, b->sbk, b->ws);
     BCR_DISPATCH(bcr_levels, b, op, 0, b->levels_loc, stream);
 }
 // phase 2 (after the all-reduce of sepbuf): the separator chain, then back through the local levels; delta = -z for the owned keyframes
@@ -806,7 +1056,9 @@ void glio_bcr_enqueue_finish(void* h, const BcrOp& op, double* delta, hipStream_
     BCR_DISPATCH(bcr_back, b, op, 0, b->levels_loc, stream);
     int lo, hi;
     glio_bcr_owned_range(b, &lo, &hi);
-    if (hi > lo) hipLaunchKernelGGL(k_bcr_delta, dim3(((hi - lo) * b->B + 255) / 256), dim3(256), 0, stream, op.skip, b->z, b->node_of_sblock_dev, lo, hi, b->Slo, b->B, b->M,
+    if (hi > lo && b->pre)
+        hipLaunchKernelGGL(k_bcr_post, dim3(b->Shi - b->Slo), dim3(64), 0, stream, op.skip, b->z, b->node_of_sblock_dev, b->Slo, b->K, b->preL, b->preU, b->prew, delta, b->fail);
+    else if (hi > lo) hipLaunchKernelGGL(k_bcr_delta, dim3(((hi - lo) * b->B + 255) / 256), dim3(256), 0, stream, op.skip, b->z, b->node_of_sblock_dev, lo, hi, b->Slo, b->B, b->M,
                                     b->sbk, delta, b->fail);
 }
 

@@ -47,5 +47,6 @@ try:
     st8 = (C.c_longlong * 8)()
     if capi.load().glio_debug_bcr_stamps(st8) == 0:
         print("elim2 workgroup 0 of the last launch (us): load %.2f, register steps %.2f, MFMA updates %.2f, store %.2f" % tuple(v / 100.0 for v in list(st8)[:4]))
+        print("k_bcr_pre workgroup 0 of the last launch (us): gather %.2f, 36 register steps %.2f, factors out + Schur complement %.2f" % tuple(v / 100.0 for v in list(st8)[4:7]))
 except AttributeError:
     pass
