@@ -136,6 +136,35 @@ def test_trust_region_solve_with_the_imu_chain_follows_the_oracle(radius0):
     st.close()
 
 
+@pytest.mark.parametrize("K,world", [(50, 1), (50, 2), (43, 3), (13, 1)])
+def test_ragged_last_super_block_with_the_imu_chain(K, world):
+    """K not a multiple of 6: the last super-block is padded with identity keyframes, whose inner speed-bias blocks go through the
+    pre-elimination like any other (k_bcr_pre / k_bcr_post); also on virtual ranks, where the ragged block is the last rank's."""
+    from oracle import pyoracle as po
+    import torch
+    band = 6
+    gt, init, con, dq, dd, frame, imu, sb0 = _imu_problem(K, band, per_kf=100, seed=59)
+    opts = T.batch_tr_opts(max_iterations=12)
+    P = po.BatchProblem(K, band, *con, dq=dq, dd=dd, frame=frame, imu=imu)
+    want, wsb, wsum = P.solve2(init, opts, sb0)
+    if world == 1:
+        st = _stage(K, band, con, dq, dd, frame, imu=imu)
+        poses, sb, summ = st.solve_tr(init, opts, speed_bias=sb0)
+        st.close()
+    else:
+        stages = [_stage(K, band, con, dq, dd, frame, imu=imu, rank=r, world=world) for r in range(world)]
+        ranks = batch.ThreadRanks(world, sync=torch.cuda.synchronize)
+        res = ranks.run(lambda r, d: stages[r].solve_tr(init, opts, d, speed_bias=sb0))
+        poses, sb, summ = res[0]
+        for other in res[1:]:
+            assert np.array_equal(other[0], poses) and np.array_equal(other[1], sb)
+        for s_ in stages:
+            s_.close()
+    assert summ.iterations == wsum.iterations and summ.termination == wsum.termination, (summ.as_dict(), wsum.as_dict())
+    assert np.isclose(summ.final_cost, wsum.final_cost, rtol=1e-8)
+    assert np.abs(poses - want).max() < 1e-7 and np.abs(sb - wsb).max() < 1e-6
+
+
 @pytest.mark.parametrize("world", [2, 3, 4])
 @pytest.mark.parametrize("with_imu", [False, True])
 def test_sharded_solve_on_virtual_ranks_equals_one_rank(world, with_imu):
