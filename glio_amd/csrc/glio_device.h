@@ -134,7 +134,7 @@ struct glio_ctx {
     glio_dd_psr* d_dd; int n_dd;
     glio_doppler* d_dop; int n_dop;
     size_t dd_cap, dop_cap;       // grow-only capacities (elements) of d_dd / d_dop
-    char* h_stage; size_t h_stage_cap, h_stage_used;   // pinned upload arena of the factor tables: every table of a set_* call
+    char* h_stage; size_t h_stage_cap, h_stage_used; char* d_stage; size_t h_stage_top; int n_stage_seg; struct { void* dst; const void* src; size_t bytes; } stage_seg[32];   // pinned upload arena of the factor tables: every table of a set_* call
                                                        // goes through it with asynchronous copies and ONE synchronisation
     GnssGroup* d_groups; int n_groups;
     PairBlock* d_gnss_blocks;     // [2][W*W] (n_groups used)
