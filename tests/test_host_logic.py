@@ -69,7 +69,8 @@ def test_streaming_driver_call_sequence():
     drv = sliding.SlidingWindowDriver(be, o)
     st = T.WindowState(W); st.quat[:, 0] = 1.0; st.quat[1] = [-1.0, 0, 0, 0]
     drv.start(st)
-    sol, summ, counts = drv.step(None, [None] * W, [])
+    the_map = np.zeros((sliding.MIN_MAP_POINTS + 1, 4), np.float32)               # one point more than the guard of Estimator.cpp:2221 asks for
+    sol, summ, counts = drv.step(the_map, [None] * W, [])
     assert counts == [7] * W and sol.quat[1, 0] == 1.0                            # unified sign
     names = [c if isinstance(c, str) else c[0] for c in be.calls]
     assert names == ["set_map", "associate0", "associate1", "associate2", "set_imu", "set_prior", "set_gnss", "solve", "marginalize"]
@@ -77,8 +78,31 @@ def test_streaming_driver_call_sequence():
     drv.slide(np.ones(3), np.array([1.0, 0, 0, 0]), np.zeros(9))
     assert drv.first == 1 and np.array_equal(drv.state.trans[-1], np.ones(3))
     be.calls.clear()
-    drv.step(None, [None] * W, [])
+    drv.step(the_map, [None] * W, [])
     assert [c for c in be.calls if not isinstance(c, str)][0][1] == {"n": 1}      # the marginalization result is the next prior
+
+
+def test_streaming_driver_skips_the_search_on_a_small_map():
+    """`if (surf_local_map_ds->points.size() > 50)` (Estimator.cpp:2221, 2244): with 50 map points or fewer no slot is associated -- the
+    window is solved on its IMU / GNSS / prior factors alone; 51 points are enough."""
+    W = 3
+    o = synth.default_opts(W)
+
+    class _Rec(_Recorder):
+        def set_correspondences(self, s, p, pl, sc): self.calls.append(f"empty{s}"); assert len(p) == 0 and len(pl) == 0 and len(sc) == 0
+
+    for n, searched in ((sliding.MIN_MAP_POINTS, False), (sliding.MIN_MAP_POINTS + 1, True)):
+        be = _Rec()
+        drv = sliding.SlidingWindowDriver(be, o)
+        st = T.WindowState(W); st.quat[:, 0] = 1.0
+        drv.start(st)
+        sol, summ, counts = drv.step(np.zeros((n, 4), np.float32), [None] * W, [])
+        names = [c for c in be.calls if isinstance(c, str)]
+        if searched:
+            assert counts == [7] * W and "associate0" in names and "empty0" not in names
+        else:
+            assert counts == [0] * W and names[:4] == ["set_map", "empty0", "empty1", "empty2"] and "associate0" not in names
+        assert "solve" in names and "marginalize" in names
 
 
 def test_write_back_gates_cpp_against_transcription(tmp_path):
