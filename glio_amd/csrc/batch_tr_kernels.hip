@@ -27,6 +27,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "batch_device.h"
@@ -1257,7 +1258,8 @@ int glio_batch_solve_tr2(glio_batch* b, double* poses, double* speed_bias, const
             if (s->h_prog[1] == id) { finished = true; break; }
             const int w = s->h_prog[0];
             if ((w >> 16) == id && (w & 0xffff) >= (g & 0xffff)) break;
-            if (((++spins) & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+            if (((++spins) & 0x3f) == 0) std::this_thread::yield();        // a group lasts a millisecond or more: polling does not need the whole core
+            if ((spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
                 glio_set_error("batch solve: no progress for 120 s (group %d)", g);
                 return GLIO_E_HIP;
             }

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <atomic>
 #include <chrono>
+#include <thread>
 #include <vector>
 
 #include "glio_device.h"
@@ -846,6 +847,7 @@ int glio_solve(glio_ctx* c, glio_state* s, glio_summary* sum) {
                 const auto now = std::chrono::steady_clock::now();
                 if (timed && c->h_progress[2] != c->solve_id && now - c->solve_t0 > budget) c->h_progress[2] = c->solve_id;
                 if (now - t_wait > std::chrono::seconds(20)) { seen = false; break; }
+                if (now - t_wait > std::chrono::milliseconds(2)) std::this_thread::yield();     // a long solve (C5-sized window): stop monopolising the core
             }
         }
         if (seen) {
