@@ -135,6 +135,7 @@ __device__ long long g_bcr_stamps[8];      // elim2, workgroup 0: [0] load, [1] 
 // super-block only.  k_bcr_pre forms, from the operator, [A_ii; A_ki; y_i^T] (91 rows x 36), factors it in 36 register steps (one row
 // per lane, one barrier per pivot, as k_bcr_elim) and writes the Schur complement A_kk - U U^T, y_k - U w as the super-block's 54 x 54
 // node; k_bcr_post recovers z_i = L^-T (w - U^T z_k) and writes the step of the super-block's keyframes.
+typedef double v4f64 __attribute__((ext_vector_type(4)));
 #define PRE_NI 36
 #define PRE_NK 54
 #define PRE_ROWS (PRE_NI + PRE_NK + 1)
@@ -153,7 +154,7 @@ __device__ __forceinline__ double bcr_scaled_entry(const BcrOp& op, const HView&
     const bool hasb = in && r < 6 && c < 6 && d <= v.band && d >= -v.band;
     const int rb = r < 6 ? r : 0, cb = c < 6 ? c : 0, dd = d > v.band ? v.band : (d < -v.band ? -v.band : d);
     const size_t ib = dd >= 0 ? ((size_t)kac * bw + dd) * 36 + rb * 6 + cb : ((size_t)kbc * bw + (-dd)) * 36 + cb * 6 + rb;
-    const double xb = v.Hg[ib];
+    const double xb = hasb ? v.Hg[ib] : 0.0;           // (lane-predicated: a masked lane issues no request -- most entries have no band part)
     // IMU chain: edge e1 holds (ka, kb) for |d| <= 1; the diagonal block takes a second share from the edge arriving at ka
     double x1 = 0.0, x2 = 0.0;
     bool has1 = false, has2 = false;
@@ -163,12 +164,12 @@ __device__ __forceinline__ double bcr_scaled_entry(const BcrOp& op, const HView&
         has1 = in && d >= -1 && d <= 1 && e1 < K - 1;
         has2 = in && d == 0 && kac > 0;
         const int e2c = kac > 0 ? kac - 1 : 0;
-        x1 = v.imu[e1c].H[o1];
-        x2 = v.imu[e2c < K - 1 ? e2c : 0].H[(15 + r) * 30 + 15 + c];
+        x1 = has1 ? v.imu[e1c].H[o1] : 0.0;
+        x2 = has2 ? v.imu[e2c < K - 1 ? e2c : 0].H[(15 + r) * 30 + 15 + c] : 0.0;
     }
     const double sa = op.sc ? op.sc[(size_t)kac * B + r] : 1.0, sb = op.sc ? op.sc[(size_t)kbc * B + c] : 1.0;
-    const double da = op.dadd ? op.dadd[(size_t)kac * B + r] : 0.0;
-    double x = (hasb ? xb : 0.0) + (has1 ? x1 : 0.0) + (has2 ? x2 : 0.0);
+    const double da = (op.dadd && in && ka == kb && r == c) ? op.dadd[(size_t)kac * B + r] : 0.0;
+    double x = xb + x1 + x2;
     if (!in) return (ka == kb && r == c) ? 1.0 : 0.0;           // identity padding of the last super-block
     x *= sa * sb;
     if (ka == kb && r == c) x += op.dadd ? da : op.lambda * x + 1e-12;
@@ -213,42 +214,115 @@ __global__ __launch_bounds__(256) void k_bcr_pre(const BcrOp op, const BcrInit* 
     if (blockIdx.x == 0 && tid == 0) { g_bcr_stamps[4] = g_bcr_stamps[5] = g_bcr_stamps[6] = 0; }
 #endif
     BCR_T(tq0);
-    // ---- gather: panel rows (91 x 36), A_kk (54 x 54), y_k -- eight entries in flight per thread
-    constexpr int NP = PRE_ROWS * NI, ND = NK * NK, NT = NP + ND + NK;
-    for (int e0 = tid; e0 < NT; e0 += U * 256) {
-        double x[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            // the entry's coordinates by selects only (no branch between the loads of different entries)
-            const int e = e0 + u * 256, ec = e < NT ? e : 0;
-            const bool inpan = ec < NP, indk = !inpan && ec < NP + ND;
-            const int prow = ec / NI, pc = ec - NI * prow;                  // panel: row, inner column
-            const int q = indk ? ec - NP : 0, di = q / NK, dj = q - NK * di;   // A_kk: kept row, kept column
-            const int yk = (!inpan && !indk) ? ec - NP - ND : 0;             // y_k: kept index
-            int kl_c, r_c, kl_r, r_r, kl_a, r_a, kl_b, r_b, kl_y, r_y;
-            pre_inner(pc, kl_c, r_c);
-            pre_inner(prow < NI ? prow : 0, kl_r, r_r);
-            pre_kept((prow >= NI && prow < NI + NK) ? prow - NI : 0, kl_a, r_a);
-            pre_kept(di, kl_b, r_b);
-            int kl_dj, r_dj;
-            pre_kept(dj, kl_dj, r_dj);
-            pre_kept(yk, kl_y, r_y);
-            const bool rhs = (inpan && prow == NI + NK) || (!inpan && !indk);
-            // matrix entry (ka, ra | kb, cb)
-            const int ka = k0 + (inpan ? (prow < NI ? kl_r : kl_a) : kl_b), ra = inpan ? (prow < NI ? r_r : r_a) : r_b;
-            const int kb = k0 + (inpan ? kl_c : kl_dj), cb = inpan ? r_c : r_dj;
-            const double val = bcr_scaled_entry(op, v, K, B, ka, ra, kb, cb);
-            // right-hand side entry (k, r)
-            const int kg = k0 + (inpan ? kl_c : kl_y), rg = inpan ? r_c : r_y, kgc = kg < K ? kg : K - 1;
-            const double gv = gsrc[(size_t)kgc * B + rg] * (op.sc ? op.sc[(size_t)kgc * B + rg] : 1.0);
-            x[u] = rhs ? (kg < K ? gv : 0.0) : val;
+    // ---- gather, SOURCE-major: the band rows of the super-block's six keyframes (1512 doubles) and its IMU edge records (900 each) are
+    // read as they lie in memory (coalesced: the entry-major form touched 21 cache lines per load instruction and was bound by the L1's
+    // address path) and scattered into the LDS panel.  An entry is band + own edge + previous edge, in that order (h_entry): the three
+    // sources are three passes with a barrier between them, each writing a cell at most once.  Mixed cells (kept row, inner column) exist
+    // once: they take the source entry of that orientation.  Scale, shift and the identity padding follow in a pass over the panel.
+    __shared__ double scl[90], dad[90], gsc[90];
+    {
+        for (int e = tid; e < PRE_ROWS * LDP; e += 256) pan[e] = 0.0;
+        for (int e = tid; e < NK * NK + NK; e += 256) dk[e] = 0.0;
+        if (tid < 90) {
+            const int k = k0 + tid / B, r = tid % B, kc = k < K ? k : K - 1;
+            const double sv = op.sc ? op.sc[(size_t)kc * B + r] : 1.0;
+            scl[tid] = k < K ? sv : 1.0;
+            dad[tid] = (op.dadd && k < K) ? op.dadd[(size_t)kc * B + r] : 0.0;
+            gsc[tid] = k < K ? gsrc[(size_t)kc * B + r] * sv : 0.0;
         }
+    }
+    __syncthreads();
+    auto cell = [&](const int u, const int vv) -> double* {          // the LDS cell of entry (row unknown u, column unknown vv), or null
+        const int klu = u / B, ru = u - B * klu, klv = vv / B, rv = vv - B * klv;
+        const bool iu = klu >= 1 && klu <= 4 && ru >= 6, iv = klv >= 1 && klv <= 4 && rv >= 6;
+        const int pu = (klu - 1) * 9 + ru - 6, pv = (klv - 1) * 9 + rv - 6;
+        const int ku = klu == 0 ? ru : (klu == 5 ? 39 + ru : 15 + (klu - 1) * 6 + ru), kv = klv == 0 ? rv : (klv == 5 ? 39 + rv : 15 + (klv - 1) * 6 + rv);
+        if (iv) return pan + (iu ? pu : NI + ku) * LDP + pv;          // inner column: panel row = inner or kept row
+        if (iu) return nullptr;                                        // (inner row, kept column): the cell of the other orientation
+        return dk + ku * NK + kv;
+    };
+    {   // pass 1: band.  t -> keyframe kl, block d, entry (r, c): H(k0 + kl, r | k0 + kl + d, c); both orientations for d > 0
+        const int bw = band + 1, per = bw * 36;
+        for (int t0 = tid; t0 < 6 * per; t0 += U * 256) {
+            double x[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int e = e0 + u * 256;
-            if (e < NP) { const int row = e / NI, c = e - NI * row; pan[row * LDP + c] = x[u]; }
-            else if (e < NT) dk[e - NP] = x[u];
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u * 256, kl = t / per, ka = k0 + kl, d = (t - per * kl) / 36;
+                x[u] = (t < 6 * per && ka < K && ka + d < K) ? v.Hg[(size_t)ka * per + (t - per * kl)] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u * 256;
+                if (t >= 6 * per) continue;
+                const int kl = t / per, q = t - per * kl, d = q / 36, r = (q % 36) / 6, c = q % 6;
+                if (kl + d > 5) continue;
+                *cell(kl * B + r, (kl + d) * B + c) = x[u];
+                if (d > 0) *cell((kl + d) * B + c, kl * B + r) = x[u];
+            }
         }
+    }
+    __syncthreads();
+    if (v.imu) {
+        // pass 2: edge (a, a + 1), a = k0 + kl: rows 0..14 of its record = [own diagonal part of a | block (a, a + 1)]; rows 15..29, columns
+        // 0..14 = block (a + 1, a).  (kl = 5: only the diagonal part lies in this super-block.)
+        for (int t0 = tid; t0 < 6 * 675; t0 += U * 256) {
+            double x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u * 256, kl = t / 675, q = t - 675 * kl, ka = k0 + kl;
+                // q < 450: row q / 30, column q % 30 of the record; q >= 450: row 15 + (q - 450) / 15, column (q - 450) % 15
+                const int o = q < 450 ? q : 450 + ((q - 450) / 15) * 30 + (q - 450) % 15;
+                x[u] = (t < 6 * 675 && ka < K - 1) ? v.imu[ka].H[o] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u * 256;
+                if (t >= 6 * 675) continue;
+                const int kl = t / 675, q = t - 675 * kl;
+                int ur, uc;
+                if (q < 450) { const int r = q / 30, c = q - 30 * r; ur = kl * B + r; uc = c < 15 ? kl * B + c : (kl + 1) * B + c - 15; }
+                else { const int r = (q - 450) / 15, c = (q - 450) - 15 * r; ur = (kl + 1) * B + r; uc = kl * B + c; }
+                if (ur >= 90 || uc >= 90) continue;                     // the part of edge 5 that belongs to the next super-block
+                double* cl = cell(ur, uc);
+                if (cl) *cl += x[u];
+            }
+        }
+        __syncthreads();
+        // pass 3: edge (a - 1, a), a = k0 + kl: rows 15..29, columns 15..29 of its record = the previous edge's share of a's diagonal block
+        for (int t0 = tid; t0 < 6 * 225; t0 += U * 256) {
+            double x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u * 256, kl = t / 225, q = t - 225 * kl, ka = k0 + kl;
+                x[u] = (t < 6 * 225 && ka >= 1 && ka < K) ? v.imu[ka - 1].H[(15 + q / 15) * 30 + 15 + q % 15] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u * 256;
+                if (t >= 6 * 225) continue;
+                const int kl = t / 225, q = t - 225 * kl;
+                double* cl = cell(kl * B + q / 15, kl * B + q % 15);
+                if (cl) *cl += x[u];
+            }
+        }
+    }
+    __syncthreads();
+    {   // pass 4: scale, shift, identity padding, right-hand sides
+        auto u_inner = [&](const int pp) { return (1 + pp / 9) * B + 6 + pp % 9; };
+        auto u_kept = [&](const int i) { int kl, r; pre_kept(i, kl, r); return kl * B + r; };
+        auto finish = [&](double& cellv, const int ur, const int uc) {
+            const bool pad = k0 + ur / B >= K || k0 + uc / B >= K;
+            double x = cellv * (scl[ur] * scl[uc]);
+            if (ur == uc) x += op.dadd ? dad[ur] : op.lambda * x + 1e-12;
+            cellv = pad ? (ur == uc ? 1.0 : 0.0) : x;
+        };
+        for (int e = tid; e < (NI + NK) * NI; e += 256) {
+            const int row = e / NI, c = e - NI * row;
+            finish(pan[row * LDP + c], row < NI ? u_inner(row) : u_kept(row - NI), u_inner(c));
+        }
+        for (int e = tid; e < NK * NK; e += 256) { const int i = e / NK, j = e - NK * i; finish(dk[e], u_kept(i), u_kept(j)); }
+        if (tid < NI) pan[(NI + NK) * LDP + tid] = gsc[u_inner(tid)];
+        if (tid >= 64 && tid < 64 + NK) dk[NK * NK + tid - 64] = gsc[u_kept(tid - 64)];
     }
     __syncthreads();
     BCR_T(tq1);
@@ -288,13 +362,21 @@ __global__ __launch_bounds__(256) void k_bcr_pre(const BcrOp op, const BcrInit* 
     for (int e = tid; e < NI * NI; e += 256) preL[sb * NI * NI + e] = pan[(e / NI) * LDP + e % NI];
     for (int e = tid; e < NK * NI; e += 256) preU[sb * NK * NI + e] = pan[(NI + e / NI) * LDP + e % NI];
     if (tid < NI) prew[sb * NI + tid] = pan[(NI + NK) * LDP + tid];
-    for (int e = tid; e < NK * NK; e += 256) {
-        const int i = e / NK, j = e - NK * i;
-        const double* ui = pan + (NI + i) * LDP; const double* uj = pan + (NI + j) * LDP;
-        double s0 = 0, s1 = 0;
+    {   // A_kk - U U^T on the matrix core: 4 x 4 tiles of 16 x 16 over the four wavefronts, the old block as the accumulator's initial value
+        const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+        for (int tile = wave; tile < 16; tile += 4) {
+            const int I = tile >> 2, J = tile & 3;
+            v4f64 c;
 #pragma unroll
-        for (int c = 0; c < NI; c += 2) { s0 += ui[c] * uj[c]; s1 += ui[c + 1] * uj[c + 1]; }
-        ws[t.oD + e] = dk[e] - (s0 + s1);
+            for (int q = 0; q < 4; ++q) { const int r = 16 * I + lk + 4 * q, cc = 16 * J + li; c[q] = (r < NK && cc < NK) ? dk[r * NK + cc] : 0.0; }
+            const int ra = 16 * I + li, rb = 16 * J + li;
+            const double* pa = pan + (NI + (ra < NK ? ra : 0)) * LDP + lk;
+            const double* pb = pan + (NI + (rb < NK ? rb : 0)) * LDP + lk;
+#pragma unroll
+            for (int kk = 0; kk < NI; kk += 4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(ra < NK ? -pa[kk] : 0.0, rb < NK ? pb[kk] : 0.0, c, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int r = 16 * I + lk + 4 * q, cc = 16 * J + li; if (r < NK && cc < NK) ws[t.oD + r * NK + cc] = c[q]; }
+        }
     }
     if (t.oy >= 0 && tid < NK) {
         const double* ui = pan + (NI + tid) * LDP; const double* wv = pan + (NI + NK) * LDP;
@@ -447,7 +529,6 @@ __global__ __launch_bounds__(BcrCfg<M>::THREADS) void k_bcr_elim(const int* skip
 // PANEL instead of one per pivot.  LDS: the packed lower triangle of A_pp (rows at i (i + 1) / 2) + M + 1 full rows
 // (A_ap, y, A_bp: 2 M + 1 rows; at M = 90 that is 159.3 of the 160 KB).
 #define BCR_E2_THREADS 512
-typedef double v4f64 __attribute__((ext_vector_type(4)));
 template <int M> struct BcrE2 {
     // row stride of the full rows: M itself when that keeps the 16 rows of an MFMA operand on distinct banks (M = 90: 180 banks apart
     // mod 64 = 52), else M + 1; with stride 90 the whole panel of M = 90 -- triangle + 181 rows -- fits the 160 KB of LDS in ONE pass
