@@ -94,3 +94,38 @@ def test_processes_sharing_one_gpu_equal_one_rank(tmp_path, world):
     out = str(tmp_path / "shared.npz")
     mp.spawn(_rank, args=(world, _free_port(), out, True), nprocs=world, join=True)
     _one_rank_and_compare(np.load(out))
+
+
+def _rccl_hook_rank(rank, world, port, out_path):
+    import torch
+    import torch.distributed as dist
+    from glio_amd import batch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    st = batch.BatchStage(12, 6, 16)
+    cb, calls = st._hook(dist)
+    side = torch.cuda.Stream()                                   # stands for the library's stream
+    buf = torch.arange(1000, dtype=torch.float64, device="cuda")
+    with torch.cuda.stream(side):
+        buf.mul_(2.0)                                            # work queued on that stream BEFORE the collective ...
+    cb(buf.data_ptr(), buf.numel(), side.cuda_stream, None)      # ... the hook as the library calls it: raw pointer, count, stream handle
+    with torch.cuda.stream(side):
+        buf.add_(1.0)                                            # ... and AFTER it
+    side.synchronize()
+    np.save(out_path, buf.cpu().numpy())
+    assert calls == [1000]
+    st.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_the_allreduce_hook_runs_rccl_on_the_library_stream(tmp_path):
+    """The hook the library calls five times per iteration, with the REAL backend (nccl = RCCL) in a one-rank group: a raw device pointer seen
+    through the CUDA array interface, the collective issued on the stream handle the library passes, ordered between the work queued on that
+    stream before and after it.  (World 1: the sum of one rank -- what is tested is that RCCL accepts the buffer and the external stream.)"""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "hook.npy")
+    mp.spawn(_rccl_hook_rank, args=(1, _free_port(), out), nprocs=1, join=True)
+    assert np.array_equal(np.load(out), 2.0 * np.arange(1000) + 1.0)
