@@ -9,6 +9,20 @@
 
 #include "../../include/glio_hip.h"
 
+// Debug allocator (GLIO_DEBUG_POISON_ALLOC=1): every device allocation of the library is filled with 0xFF bytes (NaN as a double, -1 as an
+// int) before it is handed out.  Fresh device memory of a process that runs alone is zero, so a kernel that READS a buffer it was never
+// given -- and silently relies on the zero -- passes every single-process test; with several processes on one GPU the pages may come back
+// with another process's data (found in round 3: `contention_repro.py`).  With the poison such a read fails loudly and reproducibly.
+#include <cstdlib>
+static inline hipError_t glio_dbg_malloc(void** p, size_t bytes) {
+    static const int poison = getenv("GLIO_DEBUG_POISON_ALLOC") ? atoi(getenv("GLIO_DEBUG_POISON_ALLOC")) : 0;
+    const hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess && poison && bytes > 0) { (void)hipMemset(*p, 0xFF, bytes); (void)hipDeviceSynchronize(); }
+    return e;
+}
+template <typename T> static inline hipError_t glio_dbg_malloc(T** p, size_t bytes) { return glio_dbg_malloc(reinterpret_cast<void**>(p), bytes); }
+#define hipMalloc(p, bytes) glio_dbg_malloc((p), (bytes))
+
 #define GLIO_WAVE 64
 
 // ------------------------------------------------------------------------------------------------
@@ -78,7 +92,18 @@ struct SolverStatus {
     double decrease_factor;   // LevenbergMarquardtStrategy::decrease_factor_
     int solve_id;             // tag of this solve in the host-mapped progress words (kernels of an earlier solve may still be draining)
     int pad_;
+    unsigned long long checksum;   // of the published result (status words + state), glio_result_mix: the host accepts the mapped copy only when it adds up
 };
+// Publication of the result in host-mapped memory.  The kernel that ends a solve writes [status | state] and then the solve's tag; the
+// host polls the tag.  Round 3 found (N processes sharing one GPU, scripts/contention_loop.py) that the tag can become visible BEFORE
+// parts of the payload -- whole keyframes of the state still zero, `done` still 0 -- although every writer executes a system-scope
+// fence before the tag is written: writes to host memory are not delivered in order under load.  (It only ever showed on the FIRST solve of
+// a context: later solves of the same window find the previous, identical result in the buffer.)  So the payload carries a checksum: every
+// 8-byte word enters with a position-dependent odd multiplier, the host recomputes it over what it read and keeps re-reading until it
+// adds up (a torn or stale payload passes with probability 2^-64); after 2 ms without a match it falls back to a stream-ordered copy.
+__host__ __device__ inline unsigned long long glio_result_mix(const unsigned long long word, const unsigned long long k) {
+    return (word + k) * (0x9E3779B97F4A7C15ull + 2ull * k);
+}
 
 // Structured ("arrow") linear solver of the trust-region step (solver_kernels.hip): buffers + structure tables
 struct ArrowDev {

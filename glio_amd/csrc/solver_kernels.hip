@@ -431,7 +431,27 @@ __device__ __forceinline__ void finalize(const TrArgs& a, const SolverStatus& s)
     for (int k = threadIdx.x; k < nx; k += blockDim.x) { const double v = xc[k]; a.xout[k] = v; a.xout_host[k] = v; }
     __threadfence_system();                      // every thread's part of the host copy is out before the flag
     __syncthreads();
-    if (threadIdx.x == 0) { *a.status = s; *a.status_host = s; __threadfence_system(); a.progress[1] = s.solve_id; __threadfence_system(); }
+    if (threadIdx.x < 64) {
+        // the checksum of the payload (glio_device.h), by the first wavefront alone (no LDS: some callers have none to spare)
+        unsigned long long part = 0;
+        for (int k = threadIdx.x; k < nx; k += 64) part += glio_result_mix((unsigned long long)__double_as_longlong(xc[k]), 64ull + (unsigned long long)k);
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned lo = __shfl_xor((unsigned)(part & 0xffffffffull), off, 64), hi = __shfl_xor((unsigned)(part >> 32), off, 64);
+            part += ((unsigned long long)hi << 32) | lo;
+        }
+        if (threadIdx.x == 0) {
+            SolverStatus t = s;
+            t.checksum = 0;
+            unsigned long long sum = part;
+            const unsigned long long* words = reinterpret_cast<const unsigned long long*>(&t);
+            for (int w = 0; w < (int)(sizeof(SolverStatus) / 8); ++w) sum += glio_result_mix(words[w], (unsigned long long)w);
+            t.checksum = sum;
+            *a.status = t; *a.status_host = t;
+            __threadfence_system();
+            a.progress[1] = s.solve_id;
+            __threadfence_system();
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

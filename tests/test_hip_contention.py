@@ -1,0 +1,24 @@
+"""Several PROCESSES sharing the GPU, each creating fresh contexts in a loop: solve twice, marginalize.  The first solve of a context
+reads its result from host-mapped memory that has never held a result before -- the case in which round 3 found the completion tag
+visible ahead of parts of the payload (whole keyframes of the returned state still zero, `done` still 0; ~10 % of the fresh contexts with
+12 processes on one MI355X, none with a single process).  The payload now carries a checksum that the host verifies (glio_device.h,
+SolverStatus::checksum); every iteration here must give the same result, and the first solve must equal the second."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(600)
+def test_fresh_contexts_under_contention_return_complete_results():
+    env = dict(os.environ, REPRO_TWICE="1", REPRO_PTS="16384")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "contention_loop.py"), "8", "10"], env=env, capture_output=True, text=True, timeout=540)
+    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(rows) == 8, out.stdout[-2000:] + out.stderr[-2000:]
+    for r in rows:
+        assert r["events"] == [] and r["distinct"] == 1, r
