@@ -22,3 +22,14 @@ def test_fresh_contexts_under_contention_return_complete_results():
     assert len(rows) == 8, out.stdout[-2000:] + out.stderr[-2000:]
     for r in rows:
         assert r["events"] == [] and r["distinct"] == 1, r
+
+
+@pytest.mark.timeout(600)
+def test_association_local_map_and_batch_solve_are_bit_stable_under_contention():
+    """The same load on the other entry points, fresh objects every iteration: K1 + K2 association records, the local map, the batch
+    problem's trust-region solve (IMU chain) -- hashes of the outputs must not change from iteration to iteration."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "contention_more.py"), "6", "6"], capture_output=True, text=True, timeout=540)
+    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(rows) == 6, out.stdout[-2000:] + out.stderr[-2000:]
+    for r in rows:
+        assert r["events"] == [] and r["distinct"] == 1, r
