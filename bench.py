@@ -843,6 +843,10 @@ def bench_batch_stage(args, rank, local_rank, world, dist, torch):
     info = {"workload": f"C4: {K} keyframes x {per_kf} binary plane constraints, band +-{band}, sharded by source keyframe over {world} GPU(s)",
             "scaling": "strong", "constraints_total": int(K) * int(per_kf), "constraints_this_rank": int(len(ci)), "keyframes_this_rank": [int(lo), int(hi)],
             "linearize_kernels_ms": round(k8_ms, 4), "algorithmic_GBps_this_rank": round(len(ci) * 72 / (k8_ms * 1e-3) / 1e9, 1),
+            "linearize_by_moments": {"what": "the residual is linear in (R_b^T R_a, R_b^T (t_a - t_b)): a solve streams the constraints ONCE (12-dimensional moments per keyframe pair, "
+                                             "centred at the first linearisation's poses) and evaluates them at every later linearisation; same sums, associated differently (1e-13)",
+                                     "moments_pass_plus_eval_ms": round(st.time_linearize_mode(init, Hg, 1, 5), 4),
+                                     "eval_ms": round(st.time_linearize_mode(init, Hg, 2, 20), 4)},
             "collective": ((f"torch.distributed all_reduce (backend nccl = RCCL), {world} ranks, on the library's stream" if dist.get_backend() != "gloo" else
                             f"gloo through host copies, {world} processes SHARING one GPU (GLIO_BENCH_SHARE_GPU=1: a protocol test, not a scaling measurement)")
                            if dist is not None and world > 1 else "none (1 rank)")}

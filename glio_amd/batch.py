@@ -620,6 +620,18 @@ class BatchStage:
         """0 = sequential banded Cholesky (one workgroup), 1 = block cyclic reduction (default)."""
         capi._check(capi.load().glio_batch_debug_set_solver(self._h, mode))
 
+    def linearize_mode(self, poses, Hg, mode):
+        """test hook: K8 by streaming (0), by moments taken at `poses` (1), by the moments stored earlier evaluated at `poses` (2)"""
+        poses = np.ascontiguousarray(poses, np.float64)
+        capi._check(capi.load().glio_debug_batch_linearize_mode(self._h, T.dptr(poses), C.c_void_p(Hg.data_ptr()), int(mode)))
+
+    def time_linearize_mode(self, poses, Hg, mode, reps=10):
+        """mode 1: the pairs' moments taken at `poses` + their evaluation; mode 2: the evaluation alone (k_batch_moment_eval + assembly + cost)"""
+        poses = np.ascontiguousarray(poses, np.float64)
+        ms = C.c_float()
+        capi._check(capi.load().glio_debug_batch_time_linearize_mode(self._h, T.dptr(poses), C.c_void_p(Hg.data_ptr()), int(mode), reps, C.byref(ms)))
+        return ms.value
+
     def time_linearize(self, poses, Hg, reps=10):
         poses = np.ascontiguousarray(poses, np.float64)
         ms = C.c_float()

@@ -29,6 +29,7 @@ struct glio_batch {
     struct BatchSmall* small;  // delta_q / DD-pseudorange factors of the batch problem + trust-region workspaces (batch_tr_kernels.hip)
     void* bcr;                 // block-cyclic-reduction solver (batch_solve_kernels.hip); null for bands it does not cover
     int solver_mode;           // 1 = block cyclic reduction (default when available), 0 = the sequential banded kernels
+    double* d_moments; int moments_pairs;      // per-pair moment records of K8 (batch_kernels.hip: k_batch_moments), sized for moments_pairs pairs
 };
 // which of a pair of buffers a kernel of the device-resident batch solve works on, and whether it runs at all:
 // buffer = cur ? (*cur ^ want) : want   (want 0: the current point's, 1: the candidate's);  *skip != 0: the kernel returns
@@ -83,7 +84,10 @@ void glio_bcr_solve_shift(void* h, const double* Hg, double lambda, const double
 // batch_kernels.hip: linearise this rank's shard into Hg_dev from the poses already on the device (b->d_poses)
 void glio_batch_enqueue_linearize(glio_batch* b, double* Hg_dev);
 // the same inside the device-resident solve: poses / output selected on the device (sel), rows [k0, k1) of the band only
-void glio_batch_enqueue_linearize_sel(glio_batch* b, const BtSel& sel, const double* poses0, const double* poses1, double* Hg0, double* Hg1, int k0, int k1);
+// mode 0: stream the constraints (k_batch_pairs); 1: take the pairs' moments at the selected poses, then evaluate them (the first linearisation of
+// a solve); 2: evaluate the stored moments only (every later one).  glio_batch_moments_ensure sizes the moment buffer for the present pairs.
+void glio_batch_enqueue_linearize_sel(glio_batch* b, const BtSel& sel, const double* poses0, const double* poses1, double* Hg0, double* Hg1, int k0, int k1, int mode = 0);
+int glio_batch_moments_ensure(glio_batch* b);
 // factor_kernels.hip: ImuFactor of the batch chain, one workgroup per edge e in [e0, e1): rec[sel][e]
 void glio_launch_batch_imu(hipStream_t stream, const BtSel& sel, double gravity, const ImuEdgeDev* edges, int e0, int e1, const double* poses0, const double* poses1,
                            const double* sb0, const double* sb1, PairBlock* rec0, PairBlock* rec1);

@@ -137,6 +137,191 @@ __global__ __launch_bounds__(256) void k_batch_pairs(const float4* __restrict__ 
     if (k == 54) cost_dense[p] = tot;          // the costs once more, densely: what k_batch_cost sums
 }
 
+// ------------------------------------------------------------------------------------------------ K8 by MOMENTS (round 3)
+// The residual of a binary plane constraint is LINEAR in theta = (M, tau) = (R_b^T R_a, R_b^T (t_a - t_b)):
+//     r_i = s_i n_i^T (M p_i + tau) - s_i n_i^T c_i = phi_i^T theta - d_i,    phi_i = s_i [n_i (x) p_i (9) | n_i (3)],  d_i = s_i n_i . c_i
+// (BinaryLidarPlaneNormFactor carries no loss function, LidarKeyframeFactor.h:124-164), so everything a pair contributes to the normal
+// equations at ANY pose follows from twelve-dimensional moments of its constraints, which do not depend on the poses:
+//     Phi = sum phi phi^T,   m = sum phi r0,   c0 = sum r0^2      with r0 = r(theta0) at the poses the moments were taken at;
+//     at theta = theta0 + delta:   sum r^2 = c0 + delta^T (m + gamma),  gamma = m + Phi delta = sum phi r,
+//     J_i = phi_i^T D  (D = d theta / d (t_a, rot_a, rot_b), 12 x 9, from the poses alone; d/d t_b = - d/d t_a)  =>
+//     J^T J = D^T Phi D,   J^T r = D^T gamma        -- the very sums k_batch_pairs forms constraint by constraint.
+// k_batch_moments streams the 72 bytes per constraint ONCE per constraint set (at the solve's first linearisation, centred there: the
+// quadratic in delta has no cancellation while the poses stay near theta0); every later linearisation of the solve is k_batch_moment_eval,
+// ~3000 multiply-adds per pair on 104 doubles instead of a pass over 4.7 GB (C4).  Same record layout as k_batch_pairs: the assembly does
+// not know the difference.  Exact (not an approximation); the sums are associated differently, which shows at the 1e-13 level.
+#define BM_REC 104          /* [0,78) Phi packed upper | [78,90) m | [90] c0 | [91,103) theta0 | pad */
+__host__ __device__ __forceinline__ int bm_idx(const int a, const int b) { return a * 12 - (a * (a - 1)) / 2 + (b - a); }      // a <= b
+__device__ __forceinline__ void bm_theta(const double R1[9], const double R2[9], const double t1[3], const double t2[3], double th[12]) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) th[3 * j + k] = R2[j] * R1[k] + R2[3 + j] * R1[3 + k] + R2[6 + j] * R1[6 + k];      // (R2^T R1)[j][k]
+        th[9 + j] = R2[j] * (t1[0] - t2[0]) + R2[3 + j] * (t1[1] - t2[1]) + R2[6 + j] * (t1[2] - t2[2]);
+    }
+}
+__global__ __launch_bounds__(256) void k_batch_moments(const float4* __restrict__ cp, const double* __restrict__ nc, const double* __restrict__ score,
+                                                       const int* __restrict__ pair_i, const int* __restrict__ pair_j, const long long* __restrict__ pair_off,
+                                                       const int n_pairs, const double* __restrict__ poses0, const BtSel sel, const double* __restrict__ poses1,
+                                                       double* __restrict__ mom) {
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= n_pairs || bt_skip(sel)) return;
+    const double* poses = bt_pick(sel) ? poses1 : poses0;
+    const int a = pair_i[p], b = pair_j[p];
+    double th0[12];
+    {
+        double R1[9], R2[9], t1[3], t2[3];
+        d_q2R(poses + 7 * (size_t)a + 3, R1);
+        d_q2R(poses + 7 * (size_t)b + 3, R2);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { t1[k] = poses[7 * (size_t)a + k]; t2[k] = poses[7 * (size_t)b + k]; }
+        bm_theta(R1, R2, t1, t2, th0);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) th0[k] = uniform_d(th0[k]);
+    }
+    double acc[128];
+#pragma unroll
+    for (int k = 0; k < 128; ++k) acc[k] = 0.0;
+    const long long beg = pair_off[p], end = pair_off[p + 1];
+    long long i = beg + lane;
+    float4 pt_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    double2 n01_n = make_double2(0.0, 0.0), n2c0_n = n01_n, c12_n = n01_n;
+    double s_n = 0.0;
+    if (i < end) {
+        pt_n = cp[i];
+        const double2* ncp = reinterpret_cast<const double2*>(nc + 6 * i);
+        n01_n = ncp[0]; n2c0_n = ncp[1]; c12_n = ncp[2];
+        s_n = score[i];
+    }
+    for (; i < end; i += 64) {
+        const float4 pt = pt_n;
+        const double2 n01 = n01_n, n2c0 = n2c0_n, c12 = c12_n;
+        const double s = s_n;
+        {
+            const long long in = i + 64 < end ? i + 64 : i;
+            pt_n = cp[in];
+            const double2* ncp = reinterpret_cast<const double2*>(nc + 6 * in);
+            n01_n = ncp[0]; n2c0_n = ncp[1]; c12_n = ncp[2];
+            s_n = score[in];
+        }
+        const double pv[3] = {(double)pt.x, (double)pt.y, (double)pt.z};
+        const double sn[3] = {s * n01.x, s * n01.y, s * n2c0.x};
+        double ph[12];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) ph[3 * j + k] = sn[j] * pv[k];
+            ph[9 + j] = sn[j];
+        }
+        double r0 = -(sn[0] * n2c0.y + sn[1] * c12.x + sn[2] * c12.y);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) r0 += ph[k] * th0[k];
+        int q = 0;
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+#pragma unroll
+            for (int v = u; v < 12; ++v) acc[q++] += ph[u] * ph[v];
+        }
+#pragma unroll
+        for (int u = 0; u < 12; ++u) acc[78 + u] += ph[u] * r0;
+        acc[90] += r0 * r0;
+    }
+    double lo[64], hi[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) { lo[k] = acc[k]; hi[k] = acc[64 + k]; }
+    int k1, k2;
+    const double t_lo = butterfly64(lo, lane, &k1);
+    const double t_hi = butterfly64(hi, lane, &k2);
+    double* out = mom + (size_t)p * BM_REC;
+    out[k1] = t_lo;
+    if (k2 < 27) out[64 + k2] = t_hi;
+    double tv = 0.0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) tv = lane == k ? th0[k] : tv;
+    if (lane < 12) out[91 + lane] = tv;
+}
+// the pair's record [9 x 9 Gram packed | J^T r (9) | cost] at the selected poses from its moments; one wavefront per pair
+__global__ __launch_bounds__(256) void k_batch_moment_eval(const double* __restrict__ mom, const int* __restrict__ pair_i, const int* __restrict__ pair_j, const int n_pairs,
+                                                           const double* __restrict__ poses0, double* __restrict__ rec, const BtSel sel, const double* __restrict__ poses1,
+                                                           double* __restrict__ cost_dense) {
+    __shared__ double sPhi[4][12 * 12 + 4], sD[4][12 * 9], sP[4][12 * 9], sV[4][48];      // sV: delta | m | gamma | (c0 ..)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int p = blockIdx.x * 4 + wv;
+    if (p >= n_pairs || bt_skip(sel)) return;
+    const double* poses = bt_pick(sel) ? poses1 : poses0;
+    const int a = pair_i[p], b = pair_j[p];
+    double R1[9], R2[9], t1[3], t2[3], th[12];
+    d_q2R(poses + 7 * (size_t)a + 3, R1);
+    d_q2R(poses + 7 * (size_t)b + 3, R2);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { t1[k] = poses[7 * (size_t)a + k]; t2[k] = poses[7 * (size_t)b + k]; }
+    bm_theta(R1, R2, t1, t2, th);
+    const double* M = mom + (size_t)p * BM_REC;
+    double* Phi = sPhi[wv]; double* D = sD[wv]; double* P = sP[wv]; double* V = sV[wv];
+    // Phi (full), m, delta
+    for (int e = lane; e < 144; e += 64) { const int r = e / 12, c = e - 12 * r; Phi[e] = M[r <= c ? bm_idx(r, c) : bm_idx(c, r)]; }
+    if (lane < 12) {
+        double tv = 0.0;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) tv = lane == k ? th[k] : tv;
+        V[lane] = tv - M[91 + lane];
+        V[12 + lane] = M[78 + lane];
+    }
+    // D = d theta / d (t_a | rot_a | rot_b), the local parameterisation of k_batch_pairs' Jacobian: J = [s n_w, 2 s (R1 p) x n_w, 2 s n_w x q]
+    for (int e = lane; e < 108; e += 64) {
+        const int ar = e / 9, u = e - 9 * ar;
+        double v = 0.0;
+        if (u < 3) { if (ar >= 9) v = R2[3 * u + (ar - 9)]; }
+        else {
+            const int k = u < 6 ? u - 3 : u - 6, l = (k + 1) % 3, m2 = (k + 2) % 3;
+            if (ar < 9) {
+                const int bj = ar / 3, aa = ar - 3 * bj;            // theta entry M[bj][aa] <-> phi = s n_bj p_aa
+                if (u < 6) v = 2.0 * (R1[3 * l + aa] * R2[3 * m2 + bj] - R1[3 * m2 + aa] * R2[3 * l + bj]);
+                else v = 2.0 * (R2[3 * l + bj] * R1[3 * m2 + aa] - R2[3 * m2 + bj] * R1[3 * l + aa]);
+            } else if (u >= 6) {
+                const int bj = ar - 9;
+                v = 2.0 * (R2[3 * l + bj] * (t1[m2] - t2[m2]) - R2[3 * m2 + bj] * (t1[l] - t2[l]));
+            }
+        }
+        D[e] = v;
+    }
+    GLIO_WAVE_LDS_SYNC();
+    if (lane < 12) {
+        double g = V[12 + lane];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) g += Phi[lane * 12 + k] * V[k];
+        V[24 + lane] = g;
+    }
+    for (int e = lane; e < 108; e += 64) {
+        const int ar = e / 9, u = e - 9 * ar;
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) v += Phi[ar * 12 + k] * D[k * 9 + u];
+        P[e] = v;
+    }
+    GLIO_WAVE_LDS_SYNC();
+    double outv = 0.0;
+    if (lane < 45) {
+        int u = 0, rem = lane;
+        while (rem >= 9 - u) { rem -= 9 - u; ++u; }
+        const int v2 = u + rem;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) outv += D[k * 9 + u] * P[k * 9 + v2];
+    } else if (lane < 54) {
+        const int u = lane - 45;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) outv += D[k * 9 + u] * V[24 + k];
+    } else if (lane == 54) {
+        double q = M[90];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) q += V[k] * (V[12 + k] + V[24 + k]);
+        outv = 0.5 * q;
+    }
+    if (lane < 55) rec[(size_t)p * BP_REC + lane] = outv;
+    if (lane == 54) cost_dense[p] = outv;
+}
+
 // block-banded assembly: thread per entry of Hg = [H band K*(band+1)*36 | g K*6 | cost]
 __global__ void k_batch_assemble(const double* __restrict__ rec, const int* __restrict__ pair_index, const int K, const int band,
                                  const int n_pairs, double* __restrict__ Hg0, const BtSel sel, double* __restrict__ Hg1, const int k0, const int k1) {
@@ -536,6 +721,7 @@ void glio_batch_destroy(glio_batch* b) {
     hipStreamSynchronize(b->stream);
     glio_bcr_destroy(b->bcr);
     glio_batch_small_destroy(b);
+    if (b->d_moments) hipFree(b->d_moments);
     void* ptrs[] = {b->d_cp, b->d_nc, b->d_score, b->d_pair_i, b->d_pair_j, b->d_pair_off, b->d_pair_rec, b->d_pair_index, b->d_poses,
                     b->d_newposes, b->d_M, b->d_y, b->d_delta, b->d_scalar, b->d_parts};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -638,21 +824,36 @@ int glio_batch_set_constraints(glio_batch* b, int64_t n, const int32_t* ci, cons
 
 static void enqueue_batch_linearize(glio_batch* b, double* Hg_dev);
 extern "C++" void glio_batch_enqueue_linearize(glio_batch* b, double* Hg_dev) { enqueue_batch_linearize(b, Hg_dev); }
-static void enqueue_batch_linearize_sel(glio_batch* b, const BtSel& sel, const double* poses0, const double* poses1, double* Hg0, double* Hg1, int k0, int k1) {
+static void enqueue_batch_linearize_sel(glio_batch* b, const BtSel& sel, const double* poses0, const double* poses1, double* Hg0, double* Hg1, int k0, int k1, int mode = 0) {
     const int K = b->K, band = b->band;
     const long long nH = (long long)K * (band + 1) * 36, total = nH + (long long)K * 6;
     double* cost_dense = b->d_pair_rec + (size_t)b->max_pairs * BP_REC;
-    if (b->n_pairs > 0)
+    if (mode != 0 && (!b->d_moments || b->moments_pairs < b->n_pairs)) mode = 0;          // (no moment buffer: stream)
+    if (b->n_pairs > 0 && mode == 0)
         hipLaunchKernelGGL(k_batch_pairs, dim3((b->n_pairs + 3) / 4), dim3(256), 0, b->stream, b->cp, b->nc, b->score, b->d_pair_i, b->d_pair_j,
                            b->d_pair_off, b->n_pairs, poses0, b->d_pair_rec, sel, poses1, cost_dense);
+    if (b->n_pairs > 0 && mode == 1)
+        hipLaunchKernelGGL(k_batch_moments, dim3((b->n_pairs + 3) / 4), dim3(256), 0, b->stream, b->cp, b->nc, b->score, b->d_pair_i, b->d_pair_j,
+                           b->d_pair_off, b->n_pairs, poses0, sel, poses1, b->d_moments);
+    if (b->n_pairs > 0 && mode != 0)
+        hipLaunchKernelGGL(k_batch_moment_eval, dim3((b->n_pairs + 3) / 4), dim3(256), 0, b->stream, b->d_moments, b->d_pair_i, b->d_pair_j, b->n_pairs,
+                           poses0, b->d_pair_rec, sel, poses1, cost_dense);
     const long long rows = (long long)(k1 - k0) * ((band + 1) * 36 + 6);
     if (rows > 0)
         hipLaunchKernelGGL(k_batch_assemble, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, b->stream, b->d_pair_rec, b->d_pair_index, K, band,
                            b->n_pairs, Hg0, sel, Hg1, k0, k1);
     hipLaunchKernelGGL(k_batch_cost, dim3(1), dim3(1024), 0, b->stream, cost_dense, b->n_pairs, Hg0 + total, sel, Hg1 ? Hg1 + total : nullptr);
 }
-extern "C++" void glio_batch_enqueue_linearize_sel(glio_batch* b, const BtSel& sel, const double* poses0, const double* poses1, double* Hg0, double* Hg1, int k0, int k1) {
-    enqueue_batch_linearize_sel(b, sel, poses0, poses1, Hg0, Hg1, k0, k1);
+extern "C++" void glio_batch_enqueue_linearize_sel(glio_batch* b, const BtSel& sel, const double* poses0, const double* poses1, double* Hg0, double* Hg1, int k0, int k1, int mode) {
+    enqueue_batch_linearize_sel(b, sel, poses0, poses1, Hg0, Hg1, k0, k1, mode);
+}
+extern "C++" int glio_batch_moments_ensure(glio_batch* b) {
+    if (b->d_moments && b->moments_pairs >= b->n_pairs) return GLIO_OK;
+    if (b->d_moments) { hipFree(b->d_moments); b->d_moments = nullptr; b->moments_pairs = 0; }
+    const int cap = b->n_pairs + b->n_pairs / 8 + 64;
+    GLIO_HIP_CHECK(hipMalloc((void**)&b->d_moments, (size_t)cap * BM_REC * 8));
+    b->moments_pairs = cap;
+    return GLIO_OK;
 }
 static void enqueue_batch_linearize(glio_batch* b, double* Hg_dev) {
     BtSel sel; sel.cur = nullptr; sel.skip = nullptr; sel.want = 0;
@@ -677,6 +878,40 @@ int glio_batch_time_linearize(glio_batch* b, const double* poses, double* Hg_dev
     if (rc) return rc;
     GLIO_HIP_CHECK(hipEventRecord(b->ev0, b->stream));
     for (int r = 0; r < reps; ++r) enqueue_batch_linearize(b, Hg_dev);
+    GLIO_HIP_CHECK(hipEventRecord(b->ev1, b->stream));
+    GLIO_HIP_CHECK(hipStreamSynchronize(b->stream));
+    float ms = 0;
+    GLIO_HIP_CHECK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+    *ms_out = ms / reps;
+    return GLIO_OK;
+}
+
+// test hook: one linearisation of the pose problem's plane constraints through the moment form (mode 1: take the moments at `poses`, then
+// evaluate; mode 2: evaluate the moments stored by an earlier mode-1 call at `poses`) or by streaming (mode 0)
+extern "C" int glio_debug_batch_linearize_mode(glio_batch* b, const double* poses, double* Hg_dev, int mode) {
+    if (!b || !poses || !Hg_dev || mode < 0 || mode > 2) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipSetDevice(b->device));
+    { const int rc = glio_batch_moments_ensure(b); if (rc) return rc; }
+    memcpy(b->h_poses, poses, (size_t)b->K * 7 * 8);
+    GLIO_HIP_CHECK(hipMemcpyAsync(b->d_poses, b->h_poses, (size_t)b->K * 7 * 8, hipMemcpyHostToDevice, b->stream));
+    BtSel sel; sel.cur = nullptr; sel.skip = nullptr; sel.want = 0;
+    enqueue_batch_linearize_sel(b, sel, b->d_poses, b->d_poses, Hg_dev, Hg_dev, 0, b->K, mode);
+    GLIO_HIP_CHECK(hipGetLastError());
+    GLIO_HIP_CHECK(hipStreamSynchronize(b->stream));
+    return GLIO_OK;
+}
+// measurement hook: the same with the linearisation taken through the pairs' moments -- mode 1: moments pass + evaluation (what the first
+// linearisation of a solve costs), mode 2: evaluation of the stored moments (every later one)
+extern "C" int glio_debug_batch_time_linearize_mode(glio_batch* b, const double* poses, double* Hg_dev, int mode, int reps, float* ms_out) {
+    if (!b || !poses || !Hg_dev || reps < 1 || !ms_out || mode < 0 || mode > 2) return GLIO_E_ARG;
+    int rc = glio_batch_linearize_dev(b, poses, Hg_dev);
+    if (rc) return rc;
+    rc = glio_batch_moments_ensure(b);
+    if (rc) return rc;
+    BtSel sel; sel.cur = nullptr; sel.skip = nullptr; sel.want = 0;
+    enqueue_batch_linearize_sel(b, sel, b->d_poses, b->d_poses, Hg_dev, Hg_dev, 0, b->K, 1);
+    GLIO_HIP_CHECK(hipEventRecord(b->ev0, b->stream));
+    for (int r = 0; r < reps; ++r) enqueue_batch_linearize_sel(b, sel, b->d_poses, b->d_poses, Hg_dev, Hg_dev, 0, b->K, mode);
     GLIO_HIP_CHECK(hipEventRecord(b->ev1, b->stream));
     GLIO_HIP_CHECK(hipStreamSynchronize(b->stream));
     float ms = 0;

@@ -924,6 +924,8 @@ static void enqueue_small(glio_batch* b, const double* poses_dev, double* Hg_dev
     enqueue_small_accumulate(b, sel, Hg_dev, Hg_dev);
 }
 
+// GLIO_BATCH_MOMENTS=0: every linearisation streams the constraints (k_batch_pairs), as before round 3's moment form -- kept for A/B runs and parity
+static int g_batch_moments = getenv("GLIO_BATCH_MOMENTS") ? atoi(getenv("GLIO_BATCH_MOMENTS")) : 1;
 typedef void (*bt_hook_fn)(double*, int64_t, void*, void*);
 struct BtRun { glio_batch* b; bt_hook_fn hook; void* user; };
 static void call_hook(const BtRun& r, double* dev, long long count) {
@@ -955,7 +957,8 @@ static void enqueue_tr_linearize(const BtRun& r, int want, bool initial) {
         }
         hipEventRecord(s->ev_join, s->side);
     }
-    glio_batch_enqueue_linearize_sel(b, sel, s->d_x[0], s->d_x[1], s->d_hg[0], s->d_hg[1], k0, k1);
+    // K8: the first linearisation of a solve takes the pairs' moments at its poses (one pass over the constraints), the later ones evaluate them
+    glio_batch_enqueue_linearize_sel(b, sel, s->d_x[0], s->d_x[1], s->d_hg[0], s->d_hg[1], k0, k1, g_batch_moments ? (initial ? 1 : 2) : 0);
     if (fork) hipStreamWaitEvent(st, s->ev_join, 0);
     enqueue_small_accumulate(b, sel, s->d_hg[0], s->d_hg[1]);
     const long long tot = s->bnd_doubles + 2LL * a.B * K;
@@ -1185,6 +1188,7 @@ int glio_batch_linearize_full(glio_batch* b, const double* poses, const double* 
     BT_CHECK(hipSetDevice(b->device));
     { const int rc = small_ensure(b); if (rc) return rc; }
     { const int rc = tr_ensure(b); if (rc) return rc; }
+    if (g_batch_moments) { const int rm = glio_batch_moments_ensure(b); if (rm) return rm; }
     BatchSmall* s = b->small;
     if (s->n_imu > 0 && !speed_bias) return GLIO_E_ARG;
     const int K = b->K, n = s->B * K;
@@ -1217,6 +1221,7 @@ int glio_batch_solve_tr2(glio_batch* b, double* poses, double* speed_bias, const
     BT_CHECK(hipSetDevice(b->device));
     { const int rc = small_ensure(b); if (rc) return rc; }
     { const int rc = tr_ensure(b); if (rc) return rc; }
+    if (g_batch_moments) { const int rm = glio_batch_moments_ensure(b); if (rm) return rm; }
     BatchSmall* s = b->small;
     if (s->n_imu > 0 && !speed_bias) { glio_set_error("the IMU chain is set: speed_bias [K][9] is needed"); return GLIO_E_ARG; }
     if (s->world > 1 && !allreduce) { glio_set_error("rank %d of %d needs the all-reduce hook", s->rank, s->world); return GLIO_E_ARG; }

@@ -143,3 +143,41 @@ def test_block_cyclic_reduction_equals_sequential_banded_solve(K, band):
         d = np.linalg.solve(H + np.diag(lam * np.diag(H) + 1e-12), -g.ravel())
         assert np.allclose(d1, d.reshape(K, 6)[:, :3], rtol=1e-8, atol=1e-10)
     st.close()
+
+
+def test_k8_by_moments_equals_the_streamed_linearisation_and_the_oracle():
+    """The plane constraints' residual is linear in (R_b^T R_a, R_b^T (t_a - t_b)): the pairs' moments, taken once at poses P0, give H, g
+    and the cost at ANY poses.  At P0 itself, and at poses 0.3 m / 2 degrees away from P0, the moment form must equal the streamed kernel
+    (k_batch_pairs) to rounding and the oracle to the tolerance the streamed kernel is held to."""
+    from oracle import pyoracle as po
+    K, band = 40, 6
+    gt, init = batch.make_poses(K, seed=91, perturb=(0.05, 0.003))
+    ci, cj, cp, nc, score = batch.make_constraints(gt, 0, K, 300, band, seed=91)
+    st = batch.BatchStage(K, band, len(ci))
+    cp, nc, score = cp.numpy(), nc.numpy(), score.numpy()
+    st.set_constraints(ci, cj, cp, nc, score)
+    rng = np.random.default_rng(91)
+    moved = init.copy()
+    moved[:, :3] += rng.normal(0, 0.3, (K, 3))
+    dq = rng.normal(0, 0.02, (K, 3))
+    for k in range(K):
+        w, x, y, z = moved[k, 3:]
+        d = np.concatenate([[1.0], 0.5 * dq[k]]); d /= np.linalg.norm(d)
+        moved[k, 3:] = [w * d[0] - x * d[1] - y * d[2] - z * d[3], w * d[1] + x * d[0] + y * d[3] - z * d[2],
+                        w * d[2] - x * d[3] + y * d[0] + z * d[1], w * d[3] + x * d[2] - y * d[1] + z * d[0]]
+    nH = K * (band + 1) * 36
+    for at, centre in ((init, init), (moved, init), (init, moved)):
+        streamed, mom = st.new_hg(), st.new_hg()
+        st.linearize_mode(at, streamed, 0)
+        st.linearize_mode(centre, mom, 1)                   # moments taken at `centre` ...
+        st.linearize_mode(at, mom, 2)                       # ... evaluated at `at`
+        a, b = streamed.cpu().numpy(), mom.cpu().numpy()
+        assert np.abs(a[:nH] - b[:nH]).max() <= 1e-12 * np.abs(a[:nH]).max()
+        assert np.abs(a[nH:-1] - b[nH:-1]).max() <= 1e-11 * np.abs(a[nH:-1]).max()
+        assert abs(a[-1] - b[-1]) <= 1e-11 * a[-1]
+        H, g, cost = po.BatchProblem(K, band, ci, cj, cp, nc, score).linearize(at)
+        want = np.concatenate([H.ravel(), g.ravel(), [cost]])
+        assert np.abs(b[:nH] - want[:nH]).max() <= 1e-11 * np.abs(want[:nH]).max()
+        assert np.abs(b[nH:-1] - want[nH:-1]).max() <= 1e-10 * np.abs(want[nH:-1]).max()
+        assert abs(b[-1] - want[-1]) <= 1e-10 * want[-1]
+    st.close()
