@@ -1,6 +1,6 @@
 #!/bin/bash
 # kernel timeline of ONE trust-region kernel group of the batch problem (full 15-state problem, C4 shape): rocprofv3 --kernel-trace around
-# scripts/batch_tr_time.py, then every kernel between two consecutive k_batch_pairs launches of the last solve with start offset / duration / gap
+# scripts/batch_tr_time.py, then every kernel between two consecutive k_bt_state_machine launches of the last solve with start offset / duration / gap
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/btl
@@ -12,8 +12,8 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 ts = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "")[:30]) for r in rows]
-pairs = [i for i, t in enumerate(ts) if t[2].startswith("k_batch_pairs")]
-a, b = pairs[-3], pairs[-2]          # a complete group in the middle of the last solve
+pairs = [i for i, t in enumerate(ts) if t[2].startswith("k_bt_state_machine")]
+a, b = pairs[-4], pairs[-3]          # a complete group in the middle of the last solve (from one state machine to the next)
 sel = ts[a:b]
 t0 = sel[0][0]
 prev_end = t0
