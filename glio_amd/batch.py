@@ -423,7 +423,7 @@ class RoundsAssociation:
             def __init__(self, ptr, shape, typestr):
                 self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
 
-        cps, ncs, scs, cis, cjs = [], [], [], [], []
+        cps, ncs, scs, cis, cjs, cnts = [], [], [], [], [], []
         lib = capi.load()
         for ba, pci, pcj in self.parts:
             if not len(pci) or ba.total == 0:
@@ -433,10 +433,15 @@ class RoundsAssociation:
             n = int(ba.total)
             cps.append(torch.as_tensor(_Dev(cp.value, (n, 4), "<f4"), device=dev)); ncs.append(torch.as_tensor(_Dev(nc.value, (n, 6), "<f8"), device=dev))
             scs.append(torch.as_tensor(_Dev(sc.value, (n,), "<f8"), device=dev))
-            cis.append(np.repeat(pci, ba.pair_count)); cjs.append(np.repeat(pcj, ba.pair_count))
-        ci = np.concatenate(cis).astype(np.int32); cj = np.concatenate(cjs).astype(np.int32)
-        self.stage.set_constraints(ci, cj, torch.cat(cps).contiguous(), torch.cat(ncs).contiguous(), torch.cat(scs).contiguous())
-        self.n_constraints = len(ci)
+            cis.append(np.asarray(pci, np.int32)); cjs.append(np.asarray(pcj, np.int32)); cnts.append(np.asarray(ba.pair_count, np.int64))
+        # the three runs are consecutive in (ci, cj) order: the stage takes the PAIR list (one entry per keyframe pair), not a keyframe index per
+        # constraint (building and scanning 4.4 M of those on the host cost ~8 ms per round)
+        pci = np.ascontiguousarray(np.concatenate(cis)); pcj = np.ascontiguousarray(np.concatenate(cjs)); pcount = np.ascontiguousarray(np.concatenate(cnts))
+        cp, nc, sc = torch.cat(cps).contiguous(), torch.cat(ncs).contiguous(), torch.cat(scs).contiguous()
+        self.stage._keep = (cp, nc, sc)
+        capi._check(lib.glio_batch_set_constraints_pairs_dev(self.stage._h, len(pci), T.iptr(pci), T.iptr(pcj), pcount.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                             C.c_void_p(cp.data_ptr()), C.c_void_p(nc.data_ptr()), C.c_void_p(sc.data_ptr())))
+        self.n_constraints = int(pcount.sum())
 
     def start(self, poses):
         """all three sets at `poses` (the stored interior constraints are made here)"""
