@@ -217,6 +217,10 @@ int glio_batch_step_dev(glio_batch* b, const double* Hg_dev, double lambda, cons
  *   torch.distributed.all_reduce with that stream current in Python) -- the host does not wait for it.  Per trust-region iteration:
  *   the assembly buffer (band rows next to the range boundaries + diagonal + gradient + cost), the separator system of the block
  *   cyclic reduction, the Gauss-Newton step, and two 64-byte buffers of curvature sums; every rank the same sequence.
+ *   The plane constraints are READ ONCE per call: BinaryLidarPlaneNormFactor's residual is linear in (R_b^T R_a, R_b^T (t_a - t_b)) and
+ *   carries no loss function, so the first linearisation takes 12-dimensional moments per keyframe pair (centred at the call's poses) and
+ *   every later one evaluates them -- the same sums, exact (GLIO_BATCH_MOMENTS=0 in the environment streams the constraints every time).
+ *   A caller that changes the constraint set calls again (every outer round of optimizeBatch does, Estimator.cpp:3018-3030).
  * glio_batch_linearize_full: one linearisation through the same path (parity hook): diag(H) [n], g [n], cost, n = (6 | 15) K. */
 typedef void (*glio_allreduce_fn)(double* dev, int64_t count, void* hip_stream, void* user);
 int glio_batch_shard_range(int K, int band, int rank, int world, int32_t* lo, int32_t* hi);
