@@ -878,7 +878,7 @@ static int tr_ensure(glio_batch* b) {
     BT_CHECK(hipHostGetDevicePointer((void**)&s->d_prog, (void*)s->h_prog, 0));
     BT_CHECK(hipHostMalloc((void**)&s->h_res, sizeof(BtStatus), hipHostMallocMapped | hipHostMallocCoherent));
     BT_CHECK(hipHostGetDevicePointer((void**)&s->d_res, (void*)s->h_res, 0));
-    BT_CHECK(hipHostMalloc((void**)&s->h_x, (size_t)K * 16 * 8));
+    BT_CHECK(hipHostMalloc((void**)&s->h_x, (size_t)K * 16 * 8 + sizeof(BtStatus) + 64));
     memset(s->h_prog, 0, 64);
     std::vector<int> bnd(std::max(NB, 1), 0);
     for (int j = 0; j < NB; ++j) { int l, h2; shard_range(K, band, j, s->world, &l, &h2); bnd[j] = h2; }
@@ -1274,8 +1274,12 @@ int glio_batch_solve_tr2(glio_batch* b, double* poses, double* speed_bias, const
     std::atomic_thread_fence(std::memory_order_acquire);
     BT_CHECK(hipMemcpyAsync(s->h_x, s->d_xmin, (size_t)K * 7 * 8, hipMemcpyDeviceToHost, st));
     if (s->n_imu > 0) BT_CHECK(hipMemcpyAsync(s->h_x + (size_t)K * 7, s->d_smin, (size_t)K * 9 * 8, hipMemcpyDeviceToHost, st));
+    // the final status by a stream-ordered copy of the device's own record (the mapped copy h_res only tells the loop above when to stop:
+    // host-mapped words are not a safe carrier for a payload, see SolverStatus::checksum in glio_device.h)
+    BtStatus* h_fin = reinterpret_cast<BtStatus*>(s->h_x + (size_t)K * 16);
+    BT_CHECK(hipMemcpyAsync(h_fin, s->d_st, sizeof(BtStatus), hipMemcpyDeviceToHost, st));
     BT_CHECK(hipStreamSynchronize(st));
-    const BtStatus res = *s->h_res;
+    const BtStatus res = *h_fin;
     if (!res.done || res.solve_id != id) { glio_set_error("batch solve did not finish"); return GLIO_E_STATE; }
     memcpy(poses, s->h_x, (size_t)K * 7 * 8);
     if (s->n_imu > 0) memcpy(speed_bias, s->h_x + (size_t)K * 7, (size_t)K * 9 * 8);
