@@ -417,7 +417,7 @@ class RoundsAssociation:
             ba.run(poses, pci, pcj)
             self.runs += 1
 
-    def _feed(self):
+    def _feed(self, changed=None):
         import torch
         dev = f"cuda:{self.device}"
 
@@ -425,9 +425,9 @@ class RoundsAssociation:
             def __init__(self, ptr, shape, typestr):
                 self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
 
-        cps, ncs, scs, cis, cjs, cnts = [], [], [], [], [], []
+        cps, ncs, scs, cis, cjs, cnts, chg = [], [], [], [], [], [], []
         lib = capi.load()
-        for ba, pci, pcj in self.parts:
+        for which, (ba, pci, pcj) in enumerate(self.parts):
             if not len(pci) or ba.total == 0:
                 continue
             cp, nc, sc = C.c_void_p(), C.c_void_p(), C.c_void_p()
@@ -436,13 +436,17 @@ class RoundsAssociation:
             cps.append(torch.as_tensor(_Dev(cp.value, (n, 4), "<f4"), device=dev)); ncs.append(torch.as_tensor(_Dev(nc.value, (n, 6), "<f8"), device=dev))
             scs.append(torch.as_tensor(_Dev(sc.value, (n,), "<f8"), device=dev))
             cis.append(np.asarray(pci, np.int32)); cjs.append(np.asarray(pcj, np.int32)); cnts.append(np.asarray(ba.pair_count, np.int64))
+            chg.append(np.full(len(pci), 1 if (changed is None or which in changed) else 0, np.uint8))
         # the three runs are consecutive in (ci, cj) order: the stage takes the PAIR list (one entry per keyframe pair), not a keyframe index per
         # constraint (building and scanning 4.4 M of those on the host cost ~8 ms per round)
         pci = np.ascontiguousarray(np.concatenate(cis)); pcj = np.ascontiguousarray(np.concatenate(cjs)); pcount = np.ascontiguousarray(np.concatenate(cnts))
         cp, nc, sc = torch.cat(cps).contiguous(), torch.cat(ncs).contiguous(), torch.cat(scs).contiguous()
         self.stage._keep = (cp, nc, sc)
-        capi._check(lib.glio_batch_set_constraints_pairs_dev(self.stage._h, len(pci), T.iptr(pci), T.iptr(pcj), pcount.ctypes.data_as(C.POINTER(C.c_int64)),
-                                                             C.c_void_p(cp.data_ptr()), C.c_void_p(nc.data_ptr()), C.c_void_p(sc.data_ptr())))
+        pchg = np.ascontiguousarray(np.concatenate(chg))
+        # only the re-searched runs are marked as replaced: the stage keeps the moment records of the interior pairs (Estimator.cpp:3018-3030)
+        capi._check(lib.glio_batch_update_constraints_pairs_dev(self.stage._h, len(pci), T.iptr(pci), T.iptr(pcj), pcount.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                                C.c_void_p(cp.data_ptr()), C.c_void_p(nc.data_ptr()), C.c_void_p(sc.data_ptr()),
+                                                                pchg.ctypes.data_as(C.POINTER(C.c_uint8)) if changed is not None else None))
         self.n_constraints = int(pcount.sum())
 
     def start(self, poses):
@@ -453,7 +457,7 @@ class RoundsAssociation:
 
     def __call__(self, poses):
         self._run(0, poses); self._run(2, poses)
-        self._feed()
+        self._feed(changed=(0, 2))
 
 
 # ------------------------------------------------------------------ the HIP stage
@@ -496,6 +500,18 @@ class BatchStage:
             cp = np.ascontiguousarray(cp, np.float32); nc = np.ascontiguousarray(nc, np.float64); score = np.ascontiguousarray(score, np.float64)
             capi._check(capi.load().glio_batch_set_constraints(self._h, C.c_int64(n), T.iptr(ci) if n else None, T.iptr(cj) if n else None,
                                                                 T.fptr(cp) if n else None, T.dptr(nc) if n else None, T.dptr(score) if n else None))
+
+    def set_constraints_pairs(self, pair_ci, pair_cj, pair_count, cp, nc, score, changed=None):
+        """The constraint set as a PAIR list (pair p = keyframes (pair_ci[p], pair_cj[p]) with pair_count[p] consecutive records in the torch
+        device tensors cp / nc / score, sorted by (ci, cj)).  `changed` (one flag per pair) marks the pairs whose records were replaced since the
+        previous call; the moment records of the others are kept (glio_batch_update_constraints_pairs_dev)."""
+        pci = np.ascontiguousarray(pair_ci, np.int32); pcj = np.ascontiguousarray(pair_cj, np.int32); cnt = np.ascontiguousarray(pair_count, np.int64)
+        assert cp.is_cuda and nc.is_contiguous() and cp.is_contiguous() and score.is_contiguous()
+        self._keep = (cp, nc, score)
+        chg = None if changed is None else np.ascontiguousarray(changed, np.uint8)
+        capi._check(capi.load().glio_batch_update_constraints_pairs_dev(self._h, len(pci), T.iptr(pci), T.iptr(pcj), cnt.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                                        C.c_void_p(cp.data_ptr()), C.c_void_p(nc.data_ptr()), C.c_void_p(score.data_ptr()),
+                                                                        chg.ctypes.data_as(C.POINTER(C.c_uint8)) if chg is not None else None))
 
     def new_hg(self):
         import torch

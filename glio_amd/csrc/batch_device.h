@@ -30,6 +30,10 @@ struct glio_batch {
     void* bcr;                 // block-cyclic-reduction solver (batch_solve_kernels.hip); null for bands it does not cover
     int solver_mode;           // 1 = block cyclic reduction (default when available), 0 = the sequential banded kernels
     double* d_moments; int moments_pairs;      // per-pair moment records of K8 (batch_kernels.hip: k_batch_moments), sized for moments_pairs pairs
+    int moments_valid;         // the records belong to the present constraint set (cleared by every glio_batch_set_constraints*)
+    int n_mom_changed;         // moments_valid: pairs whose constraints were replaced since (their slots in d_mom_slots), taken again at the next solve
+    int* d_mom_slots; int mom_slots_cap;
+    int* h_prev_pi; int* h_prev_pj; int h_prev_n;      // the pair list the records were taken for
 };
 // which of a pair of buffers a kernel of the device-resident batch solve works on, and whether it runs at all:
 // buffer = cur ? (*cur ^ want) : want   (want 0: the current point's, 1: the candidate's);  *skip != 0: the kernel returns

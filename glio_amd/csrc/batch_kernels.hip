@@ -163,10 +163,11 @@ __device__ __forceinline__ void bm_theta(const double R1[9], const double R2[9],
 __global__ __launch_bounds__(256) void k_batch_moments(const float4* __restrict__ cp, const double* __restrict__ nc, const double* __restrict__ score,
                                                        const int* __restrict__ pair_i, const int* __restrict__ pair_j, const long long* __restrict__ pair_off,
                                                        const int n_pairs, const double* __restrict__ poses0, const BtSel sel, const double* __restrict__ poses1,
-                                                       double* __restrict__ mom) {
+                                                       double* __restrict__ mom, const int* __restrict__ slots, const int n_slots) {
     const int lane = threadIdx.x & 63;
-    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (p >= n_pairs || bt_skip(sel)) return;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= (slots ? n_slots : n_pairs) || bt_skip(sel)) return;
+    const int p = slots ? slots[idx] : idx;          // (a list of pairs whose constraints were replaced, or all of them)
     const double* poses = bt_pick(sel) ? poses1 : poses0;
     const int a = pair_i[p], b = pair_j[p];
     double th0[12];
@@ -722,6 +723,8 @@ void glio_batch_destroy(glio_batch* b) {
     glio_bcr_destroy(b->bcr);
     glio_batch_small_destroy(b);
     if (b->d_moments) hipFree(b->d_moments);
+    if (b->d_mom_slots) hipFree(b->d_mom_slots);
+    free(b->h_prev_pi); free(b->h_prev_pj);
     void* ptrs[] = {b->d_cp, b->d_nc, b->d_score, b->d_pair_i, b->d_pair_j, b->d_pair_off, b->d_pair_rec, b->d_pair_index, b->d_poses,
                     b->d_newposes, b->d_M, b->d_y, b->d_delta, b->d_scalar, b->d_parts};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -772,6 +775,7 @@ int glio_batch_set_constraints_dev(glio_batch* b, int64_t n, const int32_t* ci, 
     const int rc = build_pairs(b, n, ci, cj);
     if (rc) return rc;
     b->cp = reinterpret_cast<const float4*>(cp_dev); b->nc = nc_dev; b->score = score_dev;
+    b->moments_valid = 0; b->h_prev_n = -1;
     return GLIO_OK;
 }
 
@@ -779,10 +783,18 @@ int glio_batch_set_constraints_dev(glio_batch* b, int64_t n, const int32_t* ci, 
 // pair_count[p] consecutive records; pairs sorted by (ci, cj); empty pairs are skipped
 int glio_batch_set_constraints_pairs_dev(glio_batch* b, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj, const int64_t* pair_count,
                                          const float* cp_dev, const double* nc_dev, const double* score_dev) {
+    return glio_batch_update_constraints_pairs_dev(b, n_pairs, pair_ci, pair_cj, pair_count, cp_dev, nc_dev, score_dev, nullptr);
+}
+// the same for a constraint set that differs from the previous one only in the pairs marked in `pair_changed` (one byte per input pair, non-zero =
+// its records were replaced; NULL = everything may have changed).  What the outer rounds of optimizeBatch do: the first / last search_range keyframes
+// are re-searched, the interior constraints are the stored ones (Estimator.cpp:3018-3030).  The next solve then takes the moments of the marked pairs
+// only.  Falls back to "everything changed" when the list of non-empty pairs is not the previous one.
+int glio_batch_update_constraints_pairs_dev(glio_batch* b, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj, const int64_t* pair_count,
+                                            const float* cp_dev, const double* nc_dev, const double* score_dev, const uint8_t* pair_changed) {
     if (!b || n_pairs < 0 || (n_pairs > 0 && (!pair_ci || !pair_cj || !pair_count || !cp_dev || !nc_dev || !score_dev))) return GLIO_E_ARG;
     GLIO_HIP_CHECK(hipSetDevice(b->device));
     const int K = b->K, band = b->band, wdt = 2 * band + 1;
-    std::vector<int> pi, pj, index((size_t)K * wdt, -1);
+    std::vector<int> pi, pj, index((size_t)K * wdt, -1), changed_slots;
     std::vector<long long> off;
     long long run = 0;
     for (int p = 0; p < n_pairs; ++p) {
@@ -791,12 +803,36 @@ int glio_batch_set_constraints_pairs_dev(glio_batch* b, int n_pairs, const int32
         if (p > 0 && (a < pair_ci[p - 1] || (a == pair_ci[p - 1] && c <= pair_cj[p - 1]))) { glio_set_error("pairs must be sorted by (ci, cj)"); return GLIO_E_ARG; }
         if (pair_count[p] > 0) {
             index[(size_t)a * wdt + (c - a) + band] = (int)pi.size();
+            if (!pair_changed || pair_changed[p]) changed_slots.push_back((int)pi.size());
             pi.push_back(a); pj.push_back(c); off.push_back(run);
         }
         run += pair_count[p];
     }
     off.push_back(run);
     if ((int)pi.size() > b->max_pairs) return GLIO_E_ARG;
+    {   // do the moment records of the unmarked pairs still stand?  only when the list of non-empty pairs is the one they were taken for
+        bool same = pair_changed && b->moments_valid && b->h_prev_n == (int)pi.size() && b->d_moments && b->moments_pairs >= (int)pi.size();
+        for (size_t q = 0; same && q < pi.size(); ++q) same = b->h_prev_pi[q] == pi[q] && b->h_prev_pj[q] == pj[q];
+        if (same) {
+            if ((int)changed_slots.size() > b->mom_slots_cap) {
+                if (b->d_mom_slots) hipFree(b->d_mom_slots);
+                b->d_mom_slots = nullptr; b->mom_slots_cap = 0;
+                const int cap = (int)changed_slots.size() + 256;
+                GLIO_HIP_CHECK(hipMalloc((void**)&b->d_mom_slots, (size_t)cap * 4));
+                b->mom_slots_cap = cap;
+            }
+            // (slots marked by an earlier update and not yet consumed by a solve stay marked: merge)
+            if (b->n_mom_changed > 0) { b->moments_valid = 0; }
+            else {
+                if (!changed_slots.empty()) GLIO_HIP_CHECK(hipMemcpy(b->d_mom_slots, changed_slots.data(), changed_slots.size() * 4, hipMemcpyHostToDevice));
+                b->n_mom_changed = (int)changed_slots.size();
+            }
+        } else b->moments_valid = 0;
+        free(b->h_prev_pi); free(b->h_prev_pj);
+        b->h_prev_pi = (int*)malloc((pi.size() + 1) * 4); b->h_prev_pj = (int*)malloc((pi.size() + 1) * 4);
+        if (!pi.empty()) { memcpy(b->h_prev_pi, pi.data(), pi.size() * 4); memcpy(b->h_prev_pj, pj.data(), pj.size() * 4); }
+        b->h_prev_n = (int)pi.size();
+    }
     b->n_pairs = (int)pi.size();
     if (b->n_pairs) {
         GLIO_HIP_CHECK(hipMemcpy(b->d_pair_i, pi.data(), pi.size() * 4, hipMemcpyHostToDevice));
@@ -832,9 +868,17 @@ static void enqueue_batch_linearize_sel(glio_batch* b, const BtSel& sel, const d
     if (b->n_pairs > 0 && mode == 0)
         hipLaunchKernelGGL(k_batch_pairs, dim3((b->n_pairs + 3) / 4), dim3(256), 0, b->stream, b->cp, b->nc, b->score, b->d_pair_i, b->d_pair_j,
                            b->d_pair_off, b->n_pairs, poses0, b->d_pair_rec, sel, poses1, cost_dense);
-    if (b->n_pairs > 0 && mode == 1)
-        hipLaunchKernelGGL(k_batch_moments, dim3((b->n_pairs + 3) / 4), dim3(256), 0, b->stream, b->cp, b->nc, b->score, b->d_pair_i, b->d_pair_j,
-                           b->d_pair_off, b->n_pairs, poses0, sel, poses1, b->d_moments);
+    if (b->n_pairs > 0 && mode == 1) {
+        // the records are a cache keyed by the constraint set: all pairs after glio_batch_set_constraints*, only the pairs the caller marked as
+        // replaced after glio_batch_update_constraints_pairs_dev (the end keyframes of a round, Estimator.cpp:3018-3030), none when nothing changed
+        if (!b->moments_valid)
+            hipLaunchKernelGGL(k_batch_moments, dim3((b->n_pairs + 3) / 4), dim3(256), 0, b->stream, b->cp, b->nc, b->score, b->d_pair_i, b->d_pair_j,
+                               b->d_pair_off, b->n_pairs, poses0, sel, poses1, b->d_moments, (const int*)nullptr, 0);
+        else if (b->n_mom_changed > 0)
+            hipLaunchKernelGGL(k_batch_moments, dim3((b->n_mom_changed + 3) / 4), dim3(256), 0, b->stream, b->cp, b->nc, b->score, b->d_pair_i, b->d_pair_j,
+                               b->d_pair_off, b->n_pairs, poses0, sel, poses1, b->d_moments, (const int*)b->d_mom_slots, b->n_mom_changed);
+        b->moments_valid = 1; b->n_mom_changed = 0;
+    }
     if (b->n_pairs > 0 && mode != 0)
         hipLaunchKernelGGL(k_batch_moment_eval, dim3((b->n_pairs + 3) / 4), dim3(256), 0, b->stream, b->d_moments, b->d_pair_i, b->d_pair_j, b->n_pairs,
                            poses0, b->d_pair_rec, sel, poses1, cost_dense);
@@ -850,6 +894,7 @@ extern "C++" void glio_batch_enqueue_linearize_sel(glio_batch* b, const BtSel& s
 extern "C++" int glio_batch_moments_ensure(glio_batch* b) {
     if (b->d_moments && b->moments_pairs >= b->n_pairs) return GLIO_OK;
     if (b->d_moments) { hipFree(b->d_moments); b->d_moments = nullptr; b->moments_pairs = 0; }
+    b->moments_valid = 0;
     const int cap = b->n_pairs + b->n_pairs / 8 + 64;
     GLIO_HIP_CHECK(hipMalloc((void**)&b->d_moments, (size_t)cap * BM_REC * 8));
     b->moments_pairs = cap;
@@ -898,6 +943,11 @@ extern "C" int glio_debug_batch_linearize_mode(glio_batch* b, const double* pose
     enqueue_batch_linearize_sel(b, sel, b->d_poses, b->d_poses, Hg_dev, Hg_dev, 0, b->K, mode);
     GLIO_HIP_CHECK(hipGetLastError());
     GLIO_HIP_CHECK(hipStreamSynchronize(b->stream));
+    return GLIO_OK;
+}
+extern "C" int glio_debug_batch_moment_state(glio_batch* b, int32_t out2[2]) {      // test hook: {records valid, pairs marked as replaced}
+    if (!b || !out2) return GLIO_E_ARG;
+    out2[0] = b->moments_valid; out2[1] = b->moments_valid ? b->n_mom_changed : -1;
     return GLIO_OK;
 }
 // measurement hook: the same with the linearisation taken through the pairs' moments -- mode 1: moments pass + evaluation (what the first

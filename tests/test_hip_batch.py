@@ -181,3 +181,59 @@ def test_k8_by_moments_equals_the_streamed_linearisation_and_the_oracle():
         assert np.abs(b[nH:-1] - want[nH:-1]).max() <= 1e-10 * np.abs(want[nH:-1]).max()
         assert abs(b[-1] - want[-1]) <= 1e-10 * want[-1]
     st.close()
+
+
+def test_moment_records_of_unchanged_pairs_are_kept_and_replaced_pairs_are_taken_again():
+    """A round of optimizeBatch replaces the constraints of the end keyframes only (Estimator.cpp:3018-3030).  The stage is told which pairs
+    changed; the next linearisation takes the moments of those pairs again and keeps the others.  Against the streamed kernel on the new set;
+    and the control: with the replaced pairs NOT marked the stale records must show."""
+    import torch
+    K, band, per_kf = 30, 6, 240
+    gt, init = batch.make_poses(K, seed=93, perturb=(0.05, 0.003))
+    ci, cj, cp, nc, score = batch.make_constraints(gt, 0, K, per_kf, band, seed=93, device="cuda:0")
+    ci2, cj2, cp2, nc2, score2 = batch.make_constraints(gt, 0, K, per_kf, band, seed=94, device="cuda:0")       # another draw, same pair structure
+    assert np.array_equal(ci, ci2) and np.array_equal(cj, cj2)
+    # the pair list: runs of equal (ci, cj)
+    key = ci.astype(np.int64) * K + cj
+    start = np.r_[0, np.flatnonzero(np.diff(key)) + 1]
+    pci, pcj, cnt = ci[start], cj[start], np.diff(np.r_[start, len(ci)])
+    ends = (pci < 3) | (pci >= K - 3)                                 # the "end keyframes" of this test
+    per_con = np.repeat(ends, cnt)
+    mask = torch.as_tensor(per_con, device="cuda:0")
+    cpn, ncn, scn = torch.where(mask[:, None], cp2, cp), torch.where(mask[:, None], nc2, nc), torch.where(mask, score2, score)
+    st = batch.BatchStage(K, band, len(ci))
+    st.set_constraints_pairs(pci, pcj, cnt, cp, nc, score)
+    first = st.new_hg(); st.linearize_mode(init, first, 1)             # moments of ALL pairs (first set)
+    nH = K * (band + 1) * 36
+    moved = init.copy(); moved[:, :3] += np.random.default_rng(93).normal(0, 0.05, (K, 3))
+
+    def close(a, b):
+        return (np.abs(a[:nH] - b[:nH]).max() <= 1e-12 * np.abs(a[:nH]).max() and np.abs(a[nH:-1] - b[nH:-1]).max() <= 1e-11 * np.abs(a[nH:-1]).max()
+                and abs(a[-1] - b[-1]) <= 1e-11 * a[-1])
+
+    st.set_constraints_pairs(pci, pcj, cnt, cpn, ncn, scn, changed=ends)
+    assert capi_counts(st) == (1, int(ends.sum()))
+    streamed, mom = st.new_hg(), st.new_hg()
+    st.linearize_mode(moved, streamed, 0)
+    st.linearize_mode(moved, mom, 1)                                   # takes the marked pairs only
+    assert capi_counts(st) == (1, 0)
+    assert close(streamed.cpu().numpy(), mom.cpu().numpy())
+    # control: back to the first set WITHOUT marking the ends -> their records are the second set's: visibly wrong
+    st.set_constraints_pairs(pci, pcj, cnt, cp, nc, score, changed=np.zeros(len(pci), np.uint8))
+    st.linearize_mode(moved, streamed, 0)
+    st.linearize_mode(moved, mom, 1)
+    assert not close(streamed.cpu().numpy(), mom.cpu().numpy())
+    # an unmarked call (changed = None) invalidates everything: right again
+    st.set_constraints_pairs(pci, pcj, cnt, cp, nc, score)
+    assert capi_counts(st)[0] == 0
+    st.linearize_mode(moved, mom, 1)
+    assert close(streamed.cpu().numpy(), mom.cpu().numpy())
+    st.close()
+
+
+def capi_counts(st):
+    import ctypes as C
+    from glio_amd import capi
+    v = (C.c_int * 2)()
+    capi._check(capi.load().glio_debug_batch_moment_state(st._h, v))
+    return int(v[0]), int(v[1])
