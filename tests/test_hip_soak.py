@@ -140,3 +140,46 @@ def test_sliding_window_and_batch_contexts_from_two_threads():
     stop.set(); tc.join(timeout=120)
     assert not errors, errors
     ctx.close(); st.close()
+
+
+def test_one_context_through_changing_factor_structures_equals_fresh_contexts():
+    """A context that is REUSED while the structure of its problem changes -- GNSS on / off, prior on / off (block structure changes with it), IMU
+    on / off, a slot without correspondences, another window of the stream -- must return, every time, exactly what a fresh context returns for
+    the same inputs: nothing of an earlier configuration (chain-layout slices, epoch tables, prior tables, look-ahead groups still draining) may
+    leak into a later one.  Each configuration is solved twice on the reused context (the second solve finds the first one's result in every
+    buffer; the first one does not) and marginalized."""
+    from glio_amd import capi
+    stream = _window()
+    wins = [synth.sub_window(stream, lo, 8) for lo in (0, 1)]
+    corr = [synth.analytic_correspondences(w) for w in wins]
+    empty = lambda c: (c[0][:0], c[1][:0], c[2][:0])
+    # a prior with real structure: the marginalization of window 0
+    c0 = capi.Context(wins[0].opts); c0.load_window(wins[0], corr[0])
+    s0, _ = c0.solve(wins[0].init); prior = c0.marginalize(s0); c0.close()
+    wins[1].prior = prior
+    configs = [
+        ("window 1: everything", 1, dict(), None),
+        ("window 0: no prior", 0, dict(), None),
+        ("window 1: no GNSS", 1, dict(use_gnss=False), None),
+        ("window 1: no prior, no IMU", 1, dict(use_prior=False, use_imu=False), None),
+        ("window 1: slot 3 without correspondences", 1, dict(), 3),
+        ("window 0: no GNSS, no prior", 0, dict(use_gnss=False), None),
+        ("window 1: everything again", 1, dict(), None),
+    ]
+    reused = capi.Context(wins[0].opts)
+    for name, wi, kw, drop in configs:
+        w, cr = wins[wi], list(corr[wi])
+        if drop is not None:
+            cr[drop] = empty(cr[drop])
+        fresh = capi.Context(w.opts); fresh.load_window(w, cr, **kw)
+        sol_f, sm_f = fresh.solve(w.init)
+        want = _digest(sol_f, sm_f)
+        marg_f = fresh.marginalize(sol_f)
+        fresh.close()
+        reused.load_window(w, cr, **kw)
+        for attempt in (1, 2):
+            sol_r, sm_r = reused.solve(w.init)
+            assert _digest(sol_r, sm_r) == want, f"{name}: solve {attempt} on the reused context differs from a fresh context"
+        marg_r = reused.marginalize(sol_r)
+        assert np.array_equal(marg_r["lin_jac"], marg_f["lin_jac"]) and np.array_equal(marg_r["lin_res"], marg_f["lin_res"]), f"{name}: marginalization differs"
+    reused.close()
