@@ -230,3 +230,42 @@ def test_threshold_rounds_downweight_the_pseudorange_outliers():
         ref, _ = po.BatchProblem(K, band, *con, dq=batch.delta_q_pairs(odo, 3), dd=dd, frame=frame).solve(ref, T.batch_tr_opts(max_iterations=30))
     assert np.abs(poses - ref).max() < 1e-7
     st.close()
+
+
+def test_one_stage_through_changing_problems_equals_fresh_stages():
+    """A BatchStage that is REUSED while its problem changes -- pose-only, then with the IMU chain, then another constraint set, then pose-only again,
+    then other small factors -- must return exactly what a fresh stage returns for the same inputs (moment records, elimination workspaces,
+    trust-region vectors, device status: nothing of an earlier problem may leak into a later one)."""
+    K, band = 42, 6
+    A = _imu_problem(K, band, per_kf=120, seed=61)
+    B = _imu_problem(K, band, per_kf=90, seed=62)
+    opts = T.batch_tr_opts(max_iterations=8)
+
+    def fresh(P, with_imu, with_small=True):
+        gt, init, con, dq, dd, frame, imu, sb0 = P
+        st = _stage(K, band, con, dq if with_small else None, dd if with_small else [], frame, imu=imu if with_imu else None)
+        out = st.solve_tr(init, opts, speed_bias=sb0 if with_imu else None)
+        st.close()
+        return out
+
+    def same(a, b):
+        return all(np.array_equal(x, y) for x, y in zip(a[:-1], b[:-1])) and a[-1].as_dict() == b[-1].as_dict()
+
+    gt, init, con, dq, dd, frame, imu, sb0 = A
+    st = _stage(K, band, con, dq, dd, frame)
+    steps = []
+    steps.append(("A pose-only", st.solve_tr(init, opts), fresh(A, False)))
+    st.set_imu(imu)
+    steps.append(("A with the IMU chain", st.solve_tr(init, opts, speed_bias=sb0), fresh(A, True)))
+    gtB, initB, conB, dqB, ddB, frameB, imuB, sb0B = B
+    st.set_constraints(*conB); st.set_small_factors(dqB, ddB, frameB); st.set_imu(imuB)
+    steps.append(("B with the IMU chain", st.solve_tr(initB, opts, speed_bias=sb0B), fresh(B, True)))
+    st.set_imu([])
+    steps.append(("B pose-only", st.solve_tr(initB, opts), fresh(B, False)))
+    st.set_small_factors(None, [], frameB)
+    steps.append(("B pose-only, plane constraints alone", st.solve_tr(initB, opts), fresh(B, False, with_small=False)))
+    st.set_constraints(*con); st.set_small_factors(dq, dd, frame); st.set_imu(imu)
+    steps.append(("A with the IMU chain, again", st.solve_tr(init, opts, speed_bias=sb0), fresh(A, True)))
+    st.close()
+    for name, got, want in steps:
+        assert same(got, want), name
