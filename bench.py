@@ -464,7 +464,7 @@ def bench_keyframe_stream(local_rank, W, pts, n_keyframes=8, cpu_keyframes=1, se
             nxt.trans[:-1], nxt.quat[:-1], nxt.speed_bias[:-1] = sol.trans[1:], sol.quat[1:], sol.speed_bias[1:]
             state = nxt
         t0 = _t.perf_counter(); ctx.slide_window(); ctx.set_scan(W - 1, long.scans[new])
-        t1 = _t.perf_counter(); ctx.localmap_push(body(new), long.gt.quat[new], long.gt.trans[new])
+        t1 = _t.perf_counter(); ctx.localmap_push_scan(W - 1, tlb, long.gt.quat[new], long.gt.trans[new])      # the scan just uploaded: no second copy of the same megabyte
         t1b = _t.perf_counter(); n_map = ctx.localmap_build()
         t2 = _t.perf_counter()
         if j > 0:

@@ -89,6 +89,11 @@ class Context:
         q = np.ascontiguousarray(q, float); t = np.ascontiguousarray(t, float)
         _check(load().glio_localmap_push(self._h, T.fptr(cloud) if len(cloud) else None, len(cloud), T.dptr(q), T.dptr(t)))
 
+    def localmap_push_scan(self, scan_slot, lidar_offset, q, t):
+        """push the scan that set_scan put into window slot `scan_slot` (no second upload): body point = scan point - lidar_offset (float)"""
+        off = np.ascontiguousarray(lidar_offset, np.float32); q = np.ascontiguousarray(q, np.float64); t = np.ascontiguousarray(t, np.float64)
+        _check(load().glio_localmap_push_scan(self._h, int(scan_slot), T.fptr(off), T.dptr(q), T.dptr(t)))
+
     def localmap_build(self):
         n = C.c_int()
         _check(load().glio_localmap_build(self._h, C.byref(n)))

@@ -68,6 +68,22 @@ __global__ void k_lm_transform(const float4* __restrict__ in, int n, const doubl
                          (float)((v[2] + q0 * uv[2] + uuv[2]) + t2), p.w);
 }
 
+// the same from a cloud that is already on the device in the LiDAR frame: p_body = p - off in FLOAT (what a caller's float cloud minus the
+// extrinsic translation gives), then transformCloud as above
+__global__ void k_lm_transform_off(const float4* __restrict__ in, int n, const float ox, const float oy, const float oz, const double q0, const double q1, const double q2,
+                                   const double q3, const double t0, const double t1, const double t2, float4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = in[i];
+    const float bx = p.x - ox, by = p.y - oy, bz = p.z - oz;
+    const double v[3] = {(double)bx, (double)by, (double)bz};
+    double uv[3] = {q2 * v[2] - q3 * v[1], q3 * v[0] - q1 * v[2], q1 * v[1] - q2 * v[0]};
+    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+    const double uuv[3] = {q2 * uv[2] - q3 * uv[1], q3 * uv[0] - q1 * uv[2], q1 * uv[1] - q2 * uv[0]};
+    out[i] = make_float4((float)((v[0] + q0 * uv[0] + uuv[0]) + t0), (float)((v[1] + q0 * uv[1] + uuv[1]) + t1),
+                         (float)((v[2] + q0 * uv[2] + uuv[2]) + t2), p.w);
+}
+
 __global__ void k_lm_clear(unsigned long long* keys, long long* sum, int* cnt, int cap, int* nkeys) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < cap) { keys[i] = LM_EMPTY; cnt[i] = 0; sum[4 * (size_t)i] = 0; sum[4 * (size_t)i + 1] = 0; sum[4 * (size_t)i + 2] = 0; sum[4 * (size_t)i + 3] = 0; }
@@ -320,6 +336,39 @@ int glio_localmap_push(glio_ctx* c, const float* cloud_xyzi, int n, const double
     }
     LM_CHECK(hipGetLastError());
     LM_CHECK(hipStreamSynchronize(c->stream));            // the caller's buffer may be reused after return
+    m->h_n[slot] = n;
+    ++m->pushed;
+    return GLIO_OK;
+}
+
+// The newest keyframe's cloud is usually on the device already -- glio_set_scan put it into window slot `slot` for the association.  This pushes THAT
+// copy (LiDAR frame) into the ring: body-frame point = scan point - lidar_offset (float, the extrinsic translation with R_lb = I as a caller's float
+// cloud would hold it), pose (q, t) of the body in the world.  No second upload of the same megabyte, no synchronisation.
+int glio_localmap_push_scan(glio_ctx* c, int scan_slot, const float lidar_offset[3], const double q[4], const double t[3]) {
+    if (!c || !c->localmap) { glio_set_error("glio_localmap_config first"); return GLIO_E_STATE; }
+    LocalMap* m = c->localmap;
+    if (scan_slot < 0 || scan_slot >= c->W || !lidar_offset || !q || !t) return GLIO_E_ARG;
+    const int n = c->h_scan_count[scan_slot];
+    if (n < 0 || n > m->cap) { glio_set_error("scan of slot %d has %d points, the ring takes %d", scan_slot, n, m->cap); return GLIO_E_ARG; }
+    LM_CHECK(hipSetDevice(c->device));
+    const float inv_leaf = 1.0f / m->leaf;
+    int slot;
+    if (m->count < m->width) { slot = (m->head + m->count) % m->width; ++m->count; }
+    else {
+        slot = m->head; m->head = (m->head + 1) % m->width;
+        const int no = m->h_n[slot];
+        if (no > 0) hipLaunchKernelGGL(k_lm_accumulate, dim3((no + 255) / 256), dim3(256), 0, c->stream, m->d_ring + (size_t)slot * m->cap, no, inv_leaf, -1,
+                                       m->d_keys, m->d_sum, m->d_cnt, m->table_cap, m->d_nkeys);
+    }
+    float4* dst = m->d_ring + (size_t)slot * m->cap;
+    hipLaunchKernelGGL(k_lm_bbox_init, dim3(1), dim3(64), 0, c->stream, m->d_slot_bbox + 6 * slot);
+    if (n > 0) {
+        hipLaunchKernelGGL(k_lm_transform_off, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_scan + (size_t)scan_slot * c->cap, n, lidar_offset[0], lidar_offset[1],
+                           lidar_offset[2], q[0], q[1], q[2], q[3], t[0], t[1], t[2], dst);
+        hipLaunchKernelGGL(k_lm_bbox, dim3(std::min(64, (n + 1023) / 1024)), dim3(1024), 0, c->stream, dst, n, m->d_slot_bbox + 6 * slot);
+        hipLaunchKernelGGL(k_lm_accumulate, dim3((n + 255) / 256), dim3(256), 0, c->stream, dst, n, inv_leaf, +1, m->d_keys, m->d_sum, m->d_cnt, m->table_cap, m->d_nkeys);
+    }
+    LM_CHECK(hipGetLastError());
     m->h_n[slot] = n;
     ++m->pushed;
     return GLIO_OK;

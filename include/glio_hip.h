@@ -60,6 +60,9 @@ int glio_set_map(glio_ctx* ctx, const float* map_xyzi, int n);
  *   width = local_map_width (yaml: 50); q,t = q_po * q_bl, q_po * t_bl + t_po (:3569-3570). */
 int glio_localmap_config(glio_ctx* ctx, int width, float leaf, int max_points_per_keyframe);
 int glio_localmap_push(glio_ctx* ctx, const float* cloud_xyzi, int n, const double q[4], const double t[3]);
+/* the same from the scan glio_set_scan already put into window slot `scan_slot` (LiDAR frame; body point = scan point - lidar_offset in float):
+ * the newest keyframe's cloud crosses PCIe once for both the association and the map */
+int glio_localmap_push_scan(glio_ctx* ctx, int scan_slot, const float lidar_offset[3], const double q[4], const double t[3]);
 int glio_localmap_build(glio_ctx* ctx, int* out_points);
 /* test hook: the down-sampled map (surf_local_map_ds), ordered by voxel index */
 int glio_localmap_read(glio_ctx* ctx, float* out_xyzi, int capacity, int* out_n);

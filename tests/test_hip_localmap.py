@@ -85,3 +85,27 @@ def test_association_on_device_built_map(stream):
     assert len(po_sc) == n_dev and np.array_equal(po_pl, pl_d)
     assert n_dev > 1000
     ctx.close(); ctx2.close()
+
+
+def test_push_of_the_resident_scan_gives_the_same_map(stream):
+    """The newest keyframe's cloud is on the device already (glio_set_scan, window slot W - 1); glio_localmap_push_scan pushes that copy
+    (body point = scan point - t_lb in float) instead of uploading it a second time: the ring and the map must be byte for byte what the
+    host-cloud push gives."""
+    from glio_amd import capi
+    win, clouds = stream
+    W = 3
+    o = synth.default_opts(W, pts=8192, map_pts=1 << 17)
+    tlb = np.array(win.opts.t_lb, np.float32)
+    a, b = capi.Context(o), capi.Context(o)
+    for c in (a, b):
+        c.localmap_config(4, 0.4, 8192)
+    for s in range(win.W):
+        q, t = win.gt.quat[s], win.gt.trans[s]
+        a.localmap_push(clouds[s], q, t)
+        if s > 0:
+            b.slide_window()
+        b.set_scan(W - 1, win.scans[s])
+        b.localmap_push_scan(W - 1, tlb, q, t)
+        na, nb = a.localmap_build(), b.localmap_build()
+        assert na == nb and np.array_equal(a.localmap_read(), b.localmap_read()), f"keyframe {s}"
+    a.close(); b.close()
