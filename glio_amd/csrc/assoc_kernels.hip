@@ -633,6 +633,15 @@ __device__ __forceinline__ void tk_insert(unsigned t[TK_SEL], const unsigned key
     t[0] = min(t[0], key);
 }
 
+#ifdef GLIO_DEV_STAMPS
+__device__ long long g_knn_stamps[8];      // workgroup 0, wavefront 0 of the last launch: [0] probe + prefix, [1] staging, [2] scan, [3] exact re-ranking, [4] merge + store, [5] units
+#define KN_T(var) const long long var = wall_clock64()
+#define KN_ACC(k, t1, t0) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_knn_stamps[k] += (t1) - (t0); } while (0)
+extern "C" int glio_debug_knn_stamps(long long* out8) { return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_knn_stamps), 64) == hipSuccess ? 0 : -2; }
+#else
+#define KN_T(var) do { } while (0)
+#define KN_ACC(k, t1, t0) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void k_knn5_tile(const AssocArgs a, const float4* __restrict__ map, const int4* __restrict__ ent,
                                                    int* __restrict__ o_nn5, float* __restrict__ o_d4) {
     __shared__ float4 s_pts[TK_UNITS][TK_CAP + 2];      // + 2: the two units of a wavefront broadcast from different banks
@@ -648,7 +657,11 @@ __global__ __launch_bounds__(256) void k_knn5_tile(const AssocArgs a, const floa
     const int n_units = a.kb.counters[2 * blockIdx.y + 1];
     const int2* units = a.kb.units + (size_t)blockIdx.y * a.kb.unit_stride;
     const float4* qs = a.kb.qs + sl.woff;
+#ifdef GLIO_DEV_STAMPS
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { for (int k = 0; k < 8; ++k) g_knn_stamps[k] = 0; }
+#endif
     for (int u0 = blockIdx.x * TK_UNITS; u0 < n_units; u0 += gridDim.x * TK_UNITS) {
+        KN_T(tk0);
         const int uid = u0 + g;
         const bool ulive = uid < n_units;
         const int2 un = ulive ? units[uid] : make_int2(0, 0);
@@ -692,7 +705,9 @@ __global__ __launch_bounds__(256) void k_knn5_tile(const AssocArgs a, const floa
         };
         unsigned long long bk[5] = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull};
         int bp[5] = {-1, -1, -1, -1, -1};
+        KN_T(tk1); KN_ACC(0, tk1, tk0); KN_ACC(5, 1, 0);
         for (int base = 0; base < tot_w; base += TK_CAP) {
+            KN_T(tc0);
             const int n_c = min(max(tot - base, 0), TK_CAP);                       // staged candidates of this unit
             const int n_w = min(tot_w - base, TK_CAP), n_w8 = (n_w + 7) & ~7;       // scan length of the wavefront
             // ---- stage: beyond the unit's own list a far point (never selected)
@@ -704,6 +719,7 @@ __global__ __launch_bounds__(256) void k_knn5_tile(const AssocArgs a, const floa
                 s_pos[g][f] = pos;
             }
             GLIO_WAVE_LDS_SYNC();
+            KN_T(tc1); KN_ACC(1, tc1, tc0);
             // ---- scan: every lane ranks its half (slots of parity h) of the staged list for its own query
             unsigned tk[TK_SEL];
 #pragma unroll
@@ -719,6 +735,7 @@ __global__ __launch_bounds__(256) void k_knn5_tile(const AssocArgs a, const floa
                     tk_insert(tk, (__float_as_uint(d) & ~TK_MASK) | (unsigned)(f + 2 * u));
                 }
             }
+            KN_T(tc2); KN_ACC(2, tc2, tc1);
             // ---- exact re-ranking of the selection, merged into the lane's running five
             bool all_in = false;
 #pragma unroll
@@ -741,7 +758,9 @@ __global__ __launch_bounds__(256) void k_knn5_tile(const AssocArgs a, const floa
                 }
             }
             GLIO_WAVE_LDS_SYNC();
+            KN_T(tc3); KN_ACC(3, tc3, tc2);
         }
+        KN_T(tk2);
         // ---- the other half's five
         unsigned long long ok[5]; int op[5];
 #pragma unroll
@@ -753,6 +772,7 @@ __global__ __launch_bounds__(256) void k_knn5_tile(const AssocArgs a, const floa
             for (int k = 0; k < 5; ++k) o_nn5[5 * (size_t)qi + k] = bp[k];
             o_d4[qi] = bp[4] >= 0 ? __uint_as_float((unsigned)(bk[4] >> 32)) : FLT_MAX;
         }
+        KN_T(tk3); KN_ACC(4, tk3, tk2);
     }
 }
 
