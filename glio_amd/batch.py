@@ -581,9 +581,16 @@ class BatchStage:
         # protocol on a one-GPU box) sums through a host copy -- stream-synchronous, which the contract allows
         staged = getattr(dist, "get_backend", None) is not None and getattr(dist, "is_initialized", lambda: False)() and dist.get_backend() == "gloo"
 
+        views, streams = {}, {}        # the library passes the same few buffers and the same stream every iteration: wrap each once (the hook sits
+                                       # on the host's enqueue path: ~5 calls per trust-region iteration)
+
         def hook(ptr, count, stream, user):
-            t = torch.as_tensor(_Dev(ptr, count), device=dev)
-            ext = torch.cuda.ExternalStream(stream, device=dev) if stream else torch.cuda.current_stream(dev)
+            t = views.get((ptr, count))
+            if t is None:
+                t = views[(ptr, count)] = torch.as_tensor(_Dev(ptr, count), device=dev)
+            ext = streams.get(stream)
+            if ext is None:
+                ext = streams[stream] = torch.cuda.ExternalStream(stream, device=dev) if stream else torch.cuda.current_stream(dev)
             with torch.cuda.stream(ext):
                 if staged:
                     h = t.cpu()
