@@ -101,7 +101,7 @@ __global__ __launch_bounds__(64) void k_small_eval(const BtSel sel, const int n_
     if (ftype[f] == 0) {
         // delta_q_factor_auto: r = 10000 (dq^-1 qi^-1 qj).vec; global 3x4 Jacobians, then Ceres' QuaternionParameterization
         nr = 3;
-        if (lane == 0) {
+        if (lane < 3) {            // lane k takes residual row k (the common quaternion products are cheap enough to be repeated by the three lanes)
             const double* dq = dq_const + 4 * (size_t)fidx[f];
             const double* qi = pa + 3;
             const double* qj = pb + 3;
@@ -114,14 +114,19 @@ __global__ __launch_bounds__(64) void k_small_eval(const BtSel sel, const int n_
             const double n2 = qi[0] * qi[0] + qi[1] * qi[1] + qi[2] * qi[2] + qi[3] * qi[3];
             const double Cq[4] = {qi[0], -qi[1], -qi[2], -qi[3]};
             bt_plus_jac(qi, Pa); bt_plus_jac(qj, Pb);
-            for (int k = 0; k < 3; ++k) {
-                rr[k] = 10000.0 * p[1 + k];
+            {
+                const int k = lane;
+                // row 1 + k of M and of LAu by selects (a run-time index into a register array would put the arrays into scratch memory)
+                double Mk[4], Lk[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { Mk[m] = k == 0 ? M[4 + m] : (k == 1 ? M[8 + m] : M[12 + m]); Lk[m] = k == 0 ? LAu[4 + m] : (k == 1 ? LAu[8 + m] : LAu[12 + m]); }
+                rr[k] = 10000.0 * (k == 0 ? p[1] : (k == 1 ? p[2] : p[3]));
                 double Jgi[4], Jgj[4];
                 for (int c = 0; c < 4; ++c) {
                     double s = 0;
-                    for (int m = 0; m < 4; ++m) s += M[(1 + k) * 4 + m] * (((m == c ? (m == 0 ? 1.0 : -1.0) : 0.0) - 2.0 * Cq[m] * qi[c] / n2) / n2);
+                    for (int m = 0; m < 4; ++m) s += Mk[m] * (((m == c ? (m == 0 ? 1.0 : -1.0) : 0.0) - 2.0 * Cq[m] * qi[c] / n2) / n2);
                     Jgi[c] = 10000.0 * s;
-                    Jgj[c] = 10000.0 * LAu[(1 + k) * 4 + c];
+                    Jgj[c] = 10000.0 * Lk[c];
                 }
                 for (int c = 0; c < 3; ++c) {
                     Ja[k * 6 + 3 + c] = Jgi[0] * Pa[c] + Jgi[1] * Pa[3 + c] + Jgi[2] * Pa[6 + c] + Jgi[3] * Pa[9 + c];
