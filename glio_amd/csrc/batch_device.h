@@ -99,4 +99,5 @@ void glio_launch_batch_imu(hipStream_t stream, const BtSel& sel, double gravity,
 bool glio_digest_imu_edge(const glio_preint* p, int slot, ImuEdgeDev* e);
 // batch_tr_kernels.hip
 void glio_batch_small_destroy(glio_batch* b);
-
+// capi.hip: GLIO_DEBUG_LDS_POISON=1 fills the LDS of every CU with NaNs (a kernel that reads LDS it never wrote then fails loudly); no-op otherwise
+void glio_lds_poison_stream(hipStream_t stream);

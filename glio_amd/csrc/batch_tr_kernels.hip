@@ -985,6 +985,7 @@ static void enqueue_tr_group(const BtRun& r, const BtOpts& o) {
     const int nbv = (n + TRV_THREADS - 1) / TRV_THREADS;
     const int nbo = std::max(1, s->hi - s->lo);
     BtHost h; h.progress = s->d_prog; h.result = s->d_res;
+    glio_lds_poison_stream(st);
     hipLaunchKernelGGL(k_bt_state_machine, dim3(1), dim3(64), 0, st, a, o, h);
     // ---- Cauchy point and Gauss-Newton step (skipped when the stored ones are reused)
     hipLaunchKernelGGL(k_bt_prepare, dim3(nbv), dim3(TRV_THREADS), 0, st, a, o.jacobi);
@@ -999,6 +1000,7 @@ static void enqueue_tr_group(const BtRun& r, const BtOpts& o) {
         j.va[1] = V_UU; j.vb[1] = V_T1; j.owned[1] = 1; j.out[1] = extra;          // the Cauchy curvature travels with the separator system
         hipLaunchKernelGGL(k_bt_dots, dim3(BT_DOT_BLOCKS), dim3(256), 0, st, a, 1, j);
     }
+    glio_lds_poison_stream(st);
     BcrOp op; memset(&op, 0, sizeof op);
     for (int k = 0; k < 2; ++k) { op.Hg[k] = s->d_hg[k]; op.imu[k] = s->n_imu > 0 ? s->d_rec[k] : nullptr; op.gfull[k] = s->d_A[k] + n; }
     op.cur = &s->d_st->cur; op.sc = BVEC(a, V_SC); op.dadd = BVEC(a, V_DA); op.lambda = 0.0; op.skip = &s->d_st->skip_solve;

@@ -741,12 +741,13 @@ __global__ void k_lds_poison(int n) {
     for (int k = threadIdx.x; k < n; k += blockDim.x) poison_lds[k] = __longlong_as_double(0x7ff8dead00000000ll + k);
 }
 static int g_poison = getenv("GLIO_DEBUG_LDS_POISON") ? atoi(getenv("GLIO_DEBUG_LDS_POISON")) : 0;
-static void lds_poison(glio_ctx* c) {
+extern "C++" void glio_lds_poison_stream(hipStream_t stream) {       // also called by the batch solve (batch_tr_kernels.hip)
     if (!g_poison) return;
     static bool configured = false;
     if (!configured) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_lds_poison), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); configured = true; }
-    hipLaunchKernelGGL(k_lds_poison, dim3(1024), dim3(256), 160 * 1024, c->stream, 160 * 1024 / 8);
+    hipLaunchKernelGGL(k_lds_poison, dim3(1024), dim3(256), 160 * 1024, stream, 160 * 1024 / 8);
 }
+static void lds_poison(glio_ctx* c) { glio_lds_poison_stream(c->stream); }
 // `dense`: also gather the blocks into the dense H, g (k_assemble).  The solve on the keyframe-chain path does not need it
 // (k_chain_step reads the factor blocks); glio_linearize and the other solver paths do.
 static void enqueue_linearize(glio_ctx* c, int use_status, int which, int n_ddt, int dense = 1) {
