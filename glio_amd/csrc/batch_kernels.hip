@@ -961,7 +961,10 @@ extern "C" int glio_debug_batch_time_linearize_mode(glio_batch* b, const double*
     BtSel sel; sel.cur = nullptr; sel.skip = nullptr; sel.want = 0;
     enqueue_batch_linearize_sel(b, sel, b->d_poses, b->d_poses, Hg_dev, Hg_dev, 0, b->K, 1);
     GLIO_HIP_CHECK(hipEventRecord(b->ev0, b->stream));
-    for (int r = 0; r < reps; ++r) enqueue_batch_linearize_sel(b, sel, b->d_poses, b->d_poses, Hg_dev, Hg_dev, 0, b->K, mode);
+    for (int r = 0; r < reps; ++r) {
+        if (mode == 1) b->moments_valid = 0;          // (the records are a cache: every repetition of the measurement takes them again)
+        enqueue_batch_linearize_sel(b, sel, b->d_poses, b->d_poses, Hg_dev, Hg_dev, 0, b->K, mode);
+    }
     GLIO_HIP_CHECK(hipEventRecord(b->ev1, b->stream));
     GLIO_HIP_CHECK(hipStreamSynchronize(b->stream));
     float ms = 0;

@@ -168,6 +168,7 @@ def test_k8_by_moments_equals_the_streamed_linearisation_and_the_oracle():
     nH = K * (band + 1) * 36
     for at, centre in ((init, init), (moved, init), (init, moved)):
         streamed, mom = st.new_hg(), st.new_hg()
+        st.set_constraints(ci, cj, cp, nc, score)           # (drops the moment records of the previous case: they are a cache keyed by the constraint set)
         st.linearize_mode(at, streamed, 0)
         st.linearize_mode(centre, mom, 1)                   # moments taken at `centre` ...
         st.linearize_mode(at, mom, 2)                       # ... evaluated at `at`
