@@ -269,3 +269,40 @@ def test_one_stage_through_changing_problems_equals_fresh_stages():
     st.close()
     for name, got, want in steps:
         assert same(got, want), name
+
+
+_MOMENTS_AB = r"""
+import sys, json
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+from glio_amd import batch
+from glio_amd import ctypes_types as T
+from test_hip_batch_tr import _imu_problem, _stage
+K, band = 48, 6
+gt, init, con, dq, dd, frame, imu, sb0 = _imu_problem(K, band, per_kf=200, seed=71, perturb=(1.0, 0.15))      # 1 m / ~9 degrees off
+st = _stage(K, band, con, dq, dd, frame, imu=imu)
+poses, sb, sm = st.solve_tr(init, T.batch_tr_opts(max_iterations=40), speed_bias=sb0)
+print("AB", json.dumps({"it": sm.iterations, "ok": sm.successful_steps, "term": sm.termination, "c0": sm.initial_cost, "c1": sm.final_cost, "poses": poses.tolist(), "sb": sb.tolist()}))
+"""
+
+
+def test_moment_form_follows_the_streamed_form_from_a_far_start():
+    """The moment records are centred at the solve's first poses; here the solve starts 1 m / 9 degrees away from the solution and the cost falls
+    by five orders of magnitude, so later linearisations evaluate the moments far from their centre.  The run with the streamed K8
+    (GLIO_BATCH_MOMENTS=0, read when the library loads: child processes) must take the same iterations and end at the same point."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("1", "0"):
+        env = dict(os.environ, GLIO_BATCH_MOMENTS=flag)
+        p = subprocess.run([sys.executable, "-c", _MOMENTS_AB % (root, os.path.join(root, "tests"))], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert p.returncode == 0 and "AB " in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+        outs.append(json.loads(p.stdout.split("AB ", 1)[1]))
+    a, b = outs
+    assert a["it"] == b["it"] and a["ok"] == b["ok"] and a["term"] == b["term"], (a["it"], b["it"], a["term"], b["term"])
+    assert a["c1"] < 1e-4 * a["c0"]
+    assert np.isclose(a["c0"], b["c0"], rtol=1e-11) and np.isclose(a["c1"], b["c1"], rtol=1e-8)
+    assert np.abs(np.array(a["poses"]) - np.array(b["poses"])).max() < 1e-8 and np.abs(np.array(a["sb"]) - np.array(b["sb"])).max() < 1e-7
