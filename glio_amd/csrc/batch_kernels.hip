@@ -323,8 +323,9 @@ __global__ __launch_bounds__(256) void k_batch_moment_eval(const double* __restr
     if (lane == 54) cost_dense[p] = outv;
 }
 
+#define BB_MAX_BAND 16
 // block-banded assembly: thread per entry of Hg = [H band K*(band+1)*36 | g K*6 | cost]
-__global__ void k_batch_assemble(const double* __restrict__ rec, const int* __restrict__ pair_index, const int K, const int band,
+__global__ __launch_bounds__(256) void k_batch_assemble(const double* __restrict__ rec, const int* __restrict__ pair_index, const int K, const int band,
                                  const int n_pairs, double* __restrict__ Hg0, const BtSel sel, double* __restrict__ Hg1, const int k0, const int k1) {
     if (bt_skip(sel)) return;
     double* Hg = bt_pick(sel) ? Hg1 : Hg0;
@@ -337,17 +338,37 @@ __global__ void k_batch_assemble(const double* __restrict__ rec, const int* __re
     const int A[6] = {0, 1, 2, 3, 4, 5}, B[6] = {0, 1, 2, 6, 7, 8};
     const double sB[6] = {-1, -1, -1, 1, 1, 1};
     const int wdt = 2 * band + 1;
+    // sum over the neighbours o = -band .. band (o != 0) of rec[pair (k, k+o)][ia] + sgn rec[pair (k+o, k)][ib], in that order.  The pair indices
+    // and then the record entries are fetched as two batches of independent loads (a loop of "index -> entry -> add" rounds paid two memory
+    // latencies per neighbour: 26 us for this kernel at C4)
+    auto sum_pairs = [&](const int k, const int ia, const int ib, const double sgn) {
+        int pa[2 * BB_MAX_BAND], pb[2 * BB_MAX_BAND];
+#pragma unroll
+        for (int q = 0; q < 2 * BB_MAX_BAND; ++q) {
+            const int o = q < BB_MAX_BAND ? q - BB_MAX_BAND : q - BB_MAX_BAND + 1;
+            const bool ok = o >= -band && o <= band && k + o >= 0 && k + o < K;
+            pa[q] = ok ? pair_index[(size_t)k * wdt + o + band] : -1;            // a = k, b = k+o
+            pb[q] = ok ? pair_index[(size_t)(k + o) * wdt + (-o) + band] : -1;   // a = k+o, b = k
+        }
+        double va[2 * BB_MAX_BAND], vb[2 * BB_MAX_BAND];
+#pragma unroll
+        for (int q = 0; q < 2 * BB_MAX_BAND; ++q) {
+            va[q] = pa[q] >= 0 ? rec[(size_t)pa[q] * BP_REC + ia] : 0.0;
+            vb[q] = pb[q] >= 0 ? rec[(size_t)pb[q] * BP_REC + ib] : 0.0;
+        }
+        double s = 0;
+#pragma unroll
+        for (int q = 0; q < 2 * BB_MAX_BAND; ++q) {
+            if (pa[q] >= 0) s += va[q];
+            if (pb[q] >= 0) s += sgn * vb[q];
+        }
+        return s;
+    };
     if (e < nH) {
         const int k = (int)(e / ((band + 1) * 36)), rem = (int)(e % ((band + 1) * 36)), d = rem / 36, r = (rem % 36) / 6, c = rem % 6;
         double s = 0;
         if (d == 0) {
-            for (int o = -band; o <= band; ++o) {
-                if (o == 0 || k + o < 0 || k + o >= K) continue;
-                const int pa = pair_index[(size_t)k * wdt + o + band];            // a = k, b = k+o : Ja^T Ja
-                if (pa >= 0) s += rec[(size_t)pa * BP_REC + gram_idx(A[r], A[c])];
-                const int pb = pair_index[(size_t)(k + o) * wdt + (-o) + band];   // a = k+o, b = k : Jb^T Jb
-                if (pb >= 0) s += sB[r] * sB[c] * rec[(size_t)pb * BP_REC + gram_idx(B[r], B[c])];
-            }
+            s = sum_pairs(k, gram_idx(A[r], A[c]), gram_idx(B[r], B[c]), sB[r] * sB[c]);      // Ja^T Ja of the pairs (k, .), Jb^T Jb of the pairs (., k)
         } else if (k + d < K) {
             const int pa = pair_index[(size_t)k * wdt + d + band];                // a = k, b = k+d : H(k,k+d) = Ja^T Jb
             if (pa >= 0) s += sB[c] * rec[(size_t)pa * BP_REC + gram_idx(A[r], B[c])];
@@ -357,15 +378,7 @@ __global__ void k_batch_assemble(const double* __restrict__ rec, const int* __re
         Hg[e] = s;
     } else if (e < nH + nG) {
         const int k = (int)((e - nH) / 6), r = (int)((e - nH) % 6);
-        double s = 0;
-        for (int o = -band; o <= band; ++o) {
-            if (o == 0 || k + o < 0 || k + o >= K) continue;
-            const int pa = pair_index[(size_t)k * wdt + o + band];
-            if (pa >= 0) s += rec[(size_t)pa * BP_REC + BP_GRAM + A[r]];
-            const int pb = pair_index[(size_t)(k + o) * wdt + (-o) + band];
-            if (pb >= 0) s += sB[r] * rec[(size_t)pb * BP_REC + BP_GRAM + B[r]];
-        }
-        Hg[e] = s;
+        Hg[e] = sum_pairs(k, BP_GRAM + A[r], BP_GRAM + B[r], sB[r]);
     }
 }
 __global__ __launch_bounds__(1024) void k_batch_cost(const double* __restrict__ cost_dense, int n_pairs, double* out0, const BtSel sel, double* out1) {
@@ -383,7 +396,6 @@ __global__ __launch_bounds__(1024) void k_batch_cost(const double* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // damped block-banded Cholesky (one workgroup), rhs carried; M[k][d] = block (k+d, k), row-major 6x6
 // ------------------------------------------------------------------------------------------------
-#define BB_MAX_BAND 16
 // Block-banded Cholesky of H + lambda diag(H) (K block rows of 6, half band `band` blocks) by ONE wavefront, no workgroup
 // barriers.  Block column k = the (band+1) blocks A(k+d, k), d = 0..band, plus the right-hand side as one more row:
 // 6 (band+1) + 1 rows of 6 -- one row per lane (two row slots per lane when band > 9).  A ring of band+1 block columns
