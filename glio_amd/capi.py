@@ -128,6 +128,16 @@ class Context:
     def slide_window(self):
         _check(load().glio_slide_window(self._h))
 
+    def associate_window_async(self, quats, trans):
+        """enqueue the association of all W slots and return at once (counts: associate_window_counts, or implicitly at the next solve)"""
+        q = np.ascontiguousarray(quats, np.float64); t = np.ascontiguousarray(trans, np.float64)
+        _check(load().glio_associate_window_async(self._h, T.dptr(q), T.dptr(t)))
+
+    def associate_window_counts(self):
+        out = np.zeros(self.W, np.int32)
+        _check(load().glio_associate_window_counts(self._h, T.iptr(out)))
+        return out
+
     def associate_window(self, quats, trans):
         quats = np.ascontiguousarray(quats, float); trans = np.ascontiguousarray(trans, float)
         cnt = np.zeros(self.W, np.int32)

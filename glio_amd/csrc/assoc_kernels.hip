@@ -61,6 +61,8 @@ struct AssocWork {
     int* d_bcount; int* d_boff;   // per-workgroup kept counts and their exclusive scan
     int* d_count_tmp;
     int* h_count;                 // pinned
+    int* h_counts_win;            // pinned [GLIO_MAX_WINDOW]: counts of an asynchronous window association, picked up by glio_assoc_finish_pending
+    int counts_pending;
     double* d_win; double* h_win; // [W][7] poses + [W] counts of the window association (h_win pinned)
     struct KnnBinHost* kb;        // query binning buffers of the tiled search
     float4* d_ps;                 // [W][cap] presorted copies of the resident scans (w = index in the scan)
@@ -1022,6 +1024,8 @@ int glio_assoc_create(glio_ctx* c) {
     AALLOC(w->d_bcount, wb * 4); AALLOC(w->d_boff, wb * 4);
     AALLOC(w->d_win, (size_t)c->W * 64);
     if (hipHostMalloc((void**)&w->h_count, 16) != hipSuccess) return GLIO_E_HIP;
+    if (hipHostMalloc((void**)&w->h_counts_win, GLIO_MAX_WINDOW * 4) != hipSuccess) return GLIO_E_HIP;
+    w->counts_pending = 0;
     if (hipHostMalloc((void**)&w->h_win, (size_t)c->W * 64) != hipSuccess) return GLIO_E_HIP;
     w->kb = knn_bin_create(c->W, cap);
     if (!w->kb) return GLIO_E_HIP;
@@ -1039,6 +1043,7 @@ void glio_assoc_destroy(glio_ctx* c) {
     for (void* p : ptrs) if (p) hipFree(p);
     knn_bin_destroy(w->kb);
     hipHostFree(w->h_count);
+    if (w->h_counts_win) hipHostFree(w->h_counts_win);
     if (w->h_win) hipHostFree(w->h_win);
     delete w;
     c->assoc = nullptr;
@@ -1224,6 +1229,31 @@ int glio_assoc_run_window(glio_ctx* c, const double* quats, const double* trans,
     GLIO_HIP_CHECK(hipMemcpyAsync(c->h_count, c->d_count, (size_t)c->W * 4, hipMemcpyDeviceToHost, c->stream));
     GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
     if (out_counts) for (int s = 0; s < c->W; ++s) out_counts[s] = c->h_count[s];
+    return GLIO_OK;
+}
+
+// The same without waiting: the searches are enqueued, the counts travel to pinned memory behind them, the call returns.  The host is free
+// for the window's factor tables (glio_set_imu / glio_set_gnss: their marshalling then runs while the GPU searches); glio_assoc_finish_pending --
+// called by glio_associate_window_counts and by every entry point that needs the correspondences -- waits and takes the counts over.
+int glio_assoc_run_window_async(glio_ctx* c, const double* quats, const double* trans) {
+    AssocWork* w = c->assoc;
+    if (!w) return GLIO_E_STATE;
+    if (c->map_n <= 0) { glio_set_error("no map set"); return GLIO_E_STATE; }
+    for (int k = 0; k < 4; ++k) w->last_pose0[k] = quats[k];
+    for (int k = 0; k < 3; ++k) w->last_pose0[4 + k] = trans[k];
+    w->have_pose0 = 1;
+    { const int rc = enqueue_assoc_window(c, quats, trans); if (rc != GLIO_OK) return rc; }
+    GLIO_HIP_CHECK(hipGetLastError());
+    GLIO_HIP_CHECK(hipMemcpyAsync(w->h_counts_win, c->d_count, (size_t)c->W * 4, hipMemcpyDeviceToHost, c->stream));
+    w->counts_pending = 1;
+    return GLIO_OK;
+}
+int glio_assoc_finish_pending(glio_ctx* c) {
+    AssocWork* w = c->assoc;
+    if (!w || !w->counts_pending) return GLIO_OK;
+    GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (int s = 0; s < c->W; ++s) c->h_count[s] = w->h_counts_win[s];
+    w->counts_pending = 0;
     return GLIO_OK;
 }
 

@@ -286,6 +286,7 @@ int glio_set_correspondences(glio_ctx* c, int slot, const float* pts, const floa
 int glio_get_correspondences(glio_ctx* c, int slot, float* pts, float* planes, double* scores, int capacity, int* out_count) {
     if (!c || slot < 0 || slot >= c->W) return GLIO_E_ARG;
     GLIO_HIP_CHECK(hipSetDevice(c->device));
+    { const int rp = glio_assoc_finish_pending(c); if (rp != GLIO_OK) return rp; }
     const int n = c->h_count[slot];
     if (out_count) *out_count = n;
     if (n > capacity) { glio_set_error("capacity %d < count %d", capacity, n); return GLIO_E_ARG; }
@@ -338,6 +339,7 @@ int glio_slide_window(glio_ctx* c) {
 int glio_select_correspondences(glio_ctx* c, int slot, const int32_t* indices, int n) {
     if (!c || slot < 0 || slot >= c->W || n < 0 || (n > 0 && !indices)) return GLIO_E_ARG;
     GLIO_HIP_CHECK(hipSetDevice(c->device));
+    { const int rp = glio_assoc_finish_pending(c); if (rp != GLIO_OK) return rp; }
     c->f32_dirty = 1;
     return glio_assoc_select(c, slot, indices, n);
 }
@@ -348,6 +350,22 @@ int glio_associate_window(glio_ctx* c, const double* quats, const double* trans,
     const int rc = glio_assoc_run_window(c, quats, trans, out_counts);
     if (rc == GLIO_OK) { c->have_factors = 1; c->f32_dirty = 1; }
     return rc;
+}
+int glio_associate_window_async(glio_ctx* c, const double* quats, const double* trans) {
+    GLIO_TRACE("K2 glio_associate_window_async");
+    if (!c || !quats || !trans) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    const int rc = glio_assoc_run_window_async(c, quats, trans);
+    if (rc == GLIO_OK) { c->have_factors = 1; c->f32_dirty = 1; }
+    return rc;
+}
+int glio_associate_window_counts(glio_ctx* c, int32_t* out_counts) {
+    if (!c) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    const int rc = glio_assoc_finish_pending(c);
+    if (rc != GLIO_OK) return rc;
+    if (out_counts) for (int s = 0; s < c->W; ++s) out_counts[s] = c->h_count[s];
+    return GLIO_OK;
 }
 int glio_associate(glio_ctx* c, int slot, const float* scan, int n, const double q[4], const double t[3], int* out_count) {
     GLIO_TRACE("K2 glio_associate");
@@ -828,6 +846,8 @@ int glio_solve(glio_ctx* c, glio_state* s, glio_summary* sum) {
     GLIO_TRACE("K3-K7 glio_solve (linearise + trust region, device resident)");
     int rc = check_state(c, s);
     if (rc) return rc;
+    rc = glio_assoc_finish_pending(c);
+    if (rc) return rc;
     GLIO_HIP_CHECK(hipSetDevice(c->device));
     const int n_ddt = s->n_ddt, nx = glio_x_size(c->W, n_ddt);
     pack_state(c, s, c->h_xbuf);
@@ -889,6 +909,8 @@ int glio_linearize(glio_ctx* c, const glio_state* s, double* H, double* g, doubl
     GLIO_TRACE("K3-K6 glio_linearize");
     int rc = check_state(c, s);
     if (rc) return rc;
+    rc = glio_assoc_finish_pending(c);
+    if (rc) return rc;
     GLIO_HIP_CHECK(hipSetDevice(c->device));
     const int n_ddt = s->n_ddt, nx = glio_x_size(c->W, n_ddt), n = 15 * c->W + n_ddt;
     pack_state(c, s, c->h_xbuf);
@@ -908,6 +930,8 @@ int glio_marginalize(glio_ctx* c, const glio_state* s, double* lin_jac, double* 
                      int32_t* blk_idx, double* blk_x0, int32_t* out_n, int32_t* out_n_blocks) {
     GLIO_TRACE("glio_marginalize");
     int rc = check_state(c, s);
+    if (rc) return rc;
+    rc = glio_assoc_finish_pending(c);
     if (rc) return rc;
     if (!lin_jac || !lin_res || !blk_slot || !blk_kind || !blk_idx || !blk_x0) { glio_set_error("null output"); return GLIO_E_ARG; }
     const int W = c->W;
@@ -954,6 +978,8 @@ int glio_marginalize(glio_ctx* c, const glio_state* s, double* lin_jac, double* 
 int glio_marginalize_keep(glio_ctx* c, const glio_state* s) {
     GLIO_TRACE("glio_marginalize_keep");
     int rc = check_state(c, s);
+    if (rc) return rc;
+    rc = glio_assoc_finish_pending(c);
     if (rc) return rc;
     const int W = c->W;
     if (W < 2) { glio_set_error("marginalization needs a window of at least 2 keyframes"); return GLIO_E_ARG; }

@@ -322,6 +322,8 @@ void glio_launch_stream_read(glio_ctx* c);
 int glio_assoc_build_map_dev(glio_ctx* c, const float4* d_pts, int n);
 int glio_assoc_select(glio_ctx* c, int slot, const int32_t* indices, int n);
 int glio_assoc_run_window(glio_ctx* c, const double* quats, const double* trans, int32_t* out_counts);
+int glio_assoc_run_window_async(glio_ctx* c, const double* quats, const double* trans);
+int glio_assoc_finish_pending(glio_ctx* c);
 void glio_localmap_destroy(glio_ctx* c);
 // solver_kernels.hip
 void glio_launch_tr_step(glio_ctx* c, int n_ddt);

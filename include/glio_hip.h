@@ -83,6 +83,10 @@ int glio_slide_window(glio_ctx* ctx);
 /* The whole loop of Estimator.cpp:2198-2248 in one call: every slot's resident scan against the map with its own
  * LiDAR pose (quats [W][4], trans [W][3] = Q2, T2 per slot), one host synchronisation; out_counts [W]. */
 int glio_associate_window(glio_ctx* ctx, const double* quats, const double* trans, int32_t* out_counts);
+/* the same in two halves: _async enqueues the searches and returns (the host is free for glio_set_imu / glio_set_gnss while the GPU searches);
+ * _counts waits and returns the per-slot counts (optional: every entry point that needs the correspondences waits by itself) */
+int glio_associate_window_async(glio_ctx* ctx, const double* quats, const double* trans);
+int glio_associate_window_counts(glio_ctx* ctx, int32_t* out_counts);
 /* featureSelection (Estimator.cpp:3894-3992): keep records indices[0..n) of the slot, in that order (n = 0 empties the
  * slot, the reference's random_select == false case :3945,3981-3987).  The random draws stay with the caller (the
  * reference seeds from std::random_device, random_generator.hpp:58, so they are not reproducible anyway); the gather

@@ -241,3 +241,31 @@ def test_window_association_ragged_slots_and_slide(hip, small_window):
         got = ctx.get_correspondences(s)
         assert cnt2[s] == want[k][0] and all(np.array_equal(a, b) for a, b in zip(got, want[k][1:])), (s, k)
     ctx.close()
+
+
+def test_asynchronous_window_association_gives_the_same_records():
+    """glio_associate_window_async + glio_associate_window_counts (the host stages the factor tables in between) against the synchronous call: counts
+    and every record identical; a solve right after the asynchronous call waits by itself."""
+    from glio_amd import capi
+    win = synth.make_window(W=4, pts_per_scan=6000, seed=synth.SEED_BASE + 23, with_gnss=True)
+    poses = [capi.lidar_pose(win.opts, win.init.quat[s], win.init.trans[s]) for s in range(win.W)]
+    q2s = np.array([p[0] for p in poses]); t2s = np.array([p[1] for p in poses])
+    a, b = capi.Context(win.opts), capi.Context(win.opts)
+    for c in (a, b):
+        c.set_map(win.map_pts)
+        for s in range(win.W):
+            c.set_scan(s, win.scans[s])
+    ca = a.associate_window(q2s, t2s)
+    b.associate_window_async(q2s, t2s)
+    b.set_imu(win.preints); b.set_gnss(win.frame, win.dd, win.dop)      # host work + uploads behind the searches
+    cb = b.associate_window_counts()
+    assert np.array_equal(ca, cb) and ca.sum() > 0
+    for s in range(win.W):
+        ra, rb = a.get_correspondences(s), b.get_correspondences(s)
+        assert all(np.array_equal(x, y) for x, y in zip(ra, rb))
+    # and without asking for the counts: the solve waits for the searches itself
+    a.set_imu(win.preints); a.set_gnss(win.frame, win.dd, win.dop); a.set_prior(None); b.set_prior(None)
+    b.associate_window_async(q2s, t2s)
+    sa, ma = a.solve(win.init); sb, mb = b.solve(win.init)
+    assert ma.iterations == mb.iterations and np.array_equal(sa.trans, sb.trans) and ma.n_lidar_residuals == mb.n_lidar_residuals
+    a.close(); b.close()
