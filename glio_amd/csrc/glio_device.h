@@ -22,6 +22,16 @@ static inline hipError_t glio_dbg_malloc(void** p, size_t bytes) {
 }
 template <typename T> static inline hipError_t glio_dbg_malloc(T** p, size_t bytes) { return glio_dbg_malloc(reinterpret_cast<void**>(p), bytes); }
 #define hipMalloc(p, bytes) glio_dbg_malloc((p), (bytes))
+// hipMemset (the synchronous-looking form) is enqueued on the NULL stream: asynchronous for the host and NOT ordered with this library's
+// non-blocking streams.  Every use here initialises a buffer at object creation that kernels on such a stream read soon after; with several
+// processes on the GPU the fill could still be pending when they ran (round 3, scripts/contention_more.py: 1 % of the first associations of a fresh
+// context lost a third of their queries -- the presort's hash table was cleared AFTER it had been filled).  The wrapper waits for the fill.
+static inline hipError_t glio_memset_done(void* p, int value, size_t bytes) {
+    const hipError_t e = hipMemset(p, value, bytes);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(nullptr);
+}
+#define hipMemset(p, value, bytes) glio_memset_done((p), (value), (bytes))
 
 #define GLIO_WAVE 64
 

@@ -27,9 +27,11 @@ def test_fresh_contexts_under_contention_return_complete_results():
 @pytest.mark.timeout(600)
 def test_association_local_map_and_batch_solve_are_bit_stable_under_contention():
     """The same load on the other entry points, fresh objects every iteration: K1 + K2 association records, the local map, the batch
-    problem's trust-region solve (IMU chain) -- hashes of the outputs must not change from iteration to iteration."""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "contention_more.py"), "6", "6"], capture_output=True, text=True, timeout=540)
+    problem's trust-region solve (IMU chain) -- hashes of the outputs must not change from iteration to iteration.  (Round 3: about 1 % of the
+    first associations of a fresh context kept a third fewer correspondences -- the query-binning table was initialised by a NULL-stream
+    hipMemset, which is not ordered with the library's non-blocking stream and, under load, ran after the table had been filled.)"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "contention_more.py"), "8", "12"], capture_output=True, text=True, timeout=540)
     rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(rows) == 6, out.stdout[-2000:] + out.stderr[-2000:]
+    assert len(rows) == 8, out.stdout[-2000:] + out.stderr[-2000:]
     for r in rows:
         assert r["events"] == [] and r["distinct"] == 1, r
