@@ -441,6 +441,7 @@ class RoundsAssociation:
         # constraint (building and scanning 4.4 M of those on the host cost ~8 ms per round)
         pci = np.ascontiguousarray(np.concatenate(cis)); pcj = np.ascontiguousarray(np.concatenate(cjs)); pcount = np.ascontiguousarray(np.concatenate(cnts))
         cp, nc, sc = torch.cat(cps).contiguous(), torch.cat(ncs).contiguous(), torch.cat(scs).contiguous()
+        _torch_done(cp)
         self.stage._keep = (cp, nc, sc)
         pchg = np.ascontiguousarray(np.concatenate(chg))
         # only the re-searched runs are marked as replaced: the stage keeps the moment records of the interior pairs (Estimator.cpp:3018-3030)
@@ -462,6 +463,16 @@ class RoundsAssociation:
 
 # ------------------------------------------------------------------ the HIP stage
 ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
+
+
+def _torch_done(*tensors):
+    """The library works on its OWN (non-blocking) streams, which are not ordered with torch's: a torch tensor handed to it must be complete first
+    (torch.zeros / torch.cat / a generator's kernels may still be queued when the Python call returns)."""
+    import torch
+    for t in tensors:
+        if hasattr(t, "is_cuda") and t.is_cuda:
+            torch.cuda.current_stream(t.device).synchronize()
+            return
 
 
 class BatchStage:
@@ -494,6 +505,7 @@ class BatchStage:
         if hasattr(cp, "data_ptr"):
             assert cp.is_cuda and cp.dtype.is_floating_point and nc.is_contiguous() and cp.is_contiguous() and score.is_contiguous()
             self._keep = (cp, nc, score)
+            _torch_done(cp)
             capi._check(capi.load().glio_batch_set_constraints_dev(self._h, C.c_int64(n), T.iptr(ci) if n else None, T.iptr(cj) if n else None,
                                                                     C.c_void_p(cp.data_ptr()), C.c_void_p(nc.data_ptr()), C.c_void_p(score.data_ptr())))
         else:
@@ -508,6 +520,7 @@ class BatchStage:
         pci = np.ascontiguousarray(pair_ci, np.int32); pcj = np.ascontiguousarray(pair_cj, np.int32); cnt = np.ascontiguousarray(pair_count, np.int64)
         assert cp.is_cuda and nc.is_contiguous() and cp.is_contiguous() and score.is_contiguous()
         self._keep = (cp, nc, score)
+        _torch_done(cp)
         chg = None if changed is None else np.ascontiguousarray(changed, np.uint8)
         capi._check(capi.load().glio_batch_update_constraints_pairs_dev(self._h, len(pci), T.iptr(pci), T.iptr(pcj), cnt.ctypes.data_as(C.POINTER(C.c_int64)),
                                                                         C.c_void_p(cp.data_ptr()), C.c_void_p(nc.data_ptr()), C.c_void_p(score.data_ptr()),
@@ -515,7 +528,9 @@ class BatchStage:
 
     def new_hg(self):
         import torch
-        return torch.zeros(hg_size(self.K, self.band), dtype=torch.float64, device=f"cuda:{self.device}")
+        out = torch.zeros(hg_size(self.K, self.band), dtype=torch.float64, device=f"cuda:{self.device}")
+        _torch_done(out)          # (the fill must not land after the library's first write into the buffer)
+        return out
 
     def linearize(self, poses, Hg):
         poses = np.ascontiguousarray(poses, np.float64)

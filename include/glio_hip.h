@@ -199,7 +199,9 @@ int glio_batch_set_constraints_dev(glio_batch* b, int64_t n, const int32_t* ci_h
 int glio_batch_set_constraints_pairs_dev(glio_batch* b, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj,
                                          const int64_t* pair_count, const float* cp_dev, const double* norm_cent_dev,
                                          const double* score_dev);
-/* the same for a constraint set that differs from the previous one only in the pairs marked in pair_changed (one byte per input pair; NULL = all):
+/* (every *_dev entry point BORROWS device buffers and reads them on the library's own non-blocking stream: the caller's stream must have finished
+ * producing them before the call)
+ * the same for a constraint set that differs from the previous one only in the pairs marked in pair_changed (one byte per input pair; NULL = all):
  * the outer rounds of optimizeBatch re-search the first / last search_range keyframes and keep the stored interior constraints
  * (Estimator.cpp:3018-3030); the next solve then reads the constraints of the marked pairs only (glio_batch_solve_tr2). */
 int glio_batch_update_constraints_pairs_dev(glio_batch* b, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj, const int64_t* pair_count,
