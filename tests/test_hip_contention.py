@@ -35,3 +35,15 @@ def test_association_local_map_and_batch_solve_are_bit_stable_under_contention()
     assert len(rows) == 8, out.stdout[-2000:] + out.stderr[-2000:]
     for r in rows:
         assert r["events"] == [] and r["distinct"] == 1, r
+
+
+@pytest.mark.timeout(600)
+def test_the_resident_keyframe_stream_is_deterministic_under_contention():
+    """The whole per-keyframe sequence on resident data (slide, new scan, local-map push of the resident scan, asynchronous association with the factor
+    tables staged meanwhile, solve, marginalize-and-keep) over six keyframes, run three times per process on fresh contexts with six processes on the
+    GPU: every run must reproduce the first bit for bit."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "contention_stream.py"), "6", "2"], capture_output=True, text=True, timeout=540)
+    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(rows) == 6, out.stdout[-2000:] + out.stderr[-2000:]
+    for r in rows:
+        assert r["events"] == [], r
