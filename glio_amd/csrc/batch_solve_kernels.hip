@@ -569,6 +569,7 @@ __device__ __forceinline__ void bcr_panels(double* __restrict__ Lt, double* __re
             if (FACTOR) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
+                    if (j >= nb) break;                  // the ragged last panel (6 columns at M = 54, 10 at M = 90): its padding steps are identities
                     double djj = readlane_d(a[j], j);
                     if (!(djj > 1e-290) || !isfinite(djj)) { bad = true; djj = 1.0; }
                     const double rd = bcr_rsqrt(djj);
@@ -580,6 +581,7 @@ __device__ __forceinline__ void bcr_panels(double* __restrict__ Lt, double* __re
             } else {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {      // lanes 0-15 hold the finished block L_kk: x_j = a_j / L_jj, a_c -= x_j L_cj
+                    if (j >= nb) break;
                     const double ljj = readlane_d(a[j], j);
                     const double xj = isdiag ? a[j] : a[j] / ljj;
                     a[j] = xj;
