@@ -1170,9 +1170,11 @@ static int enqueue_assoc_window(glio_ctx* c, const double* quats, const double* 
     return GLIO_OK;
 }
 
+int glio_assoc_finish_pending(glio_ctx* c);
 int glio_assoc_run(glio_ctx* c, int slot, const double q[4], const double t[3], int* out_count) {
     AssocWork* w = c->assoc;
     if (!w) return GLIO_E_STATE;
+    { const int rp = glio_assoc_finish_pending(c); if (rp != GLIO_OK) return rp; }
     if (c->map_n <= 0) { glio_set_error("no map set"); return GLIO_E_STATE; }
     const int n = c->h_scan_count[slot];
     if (slot == 0) { for (int k = 0; k < 4; ++k) w->last_pose0[k] = q[k]; for (int k = 0; k < 3; ++k) w->last_pose0[4 + k] = t[k]; w->have_pose0 = 1; }
@@ -1217,9 +1219,11 @@ int glio_assoc_select(glio_ctx* c, int slot, const int32_t* indices, int n) {
 
 // all W slots back to back on the stream, ONE host synchronisation: the per-slot sync of glio_assoc_run (count
 // read-back) costs as much as half a K2 launch
+int glio_assoc_finish_pending(glio_ctx* c);
 int glio_assoc_run_window(glio_ctx* c, const double* quats, const double* trans, int32_t* out_counts) {
     AssocWork* w = c->assoc;
     if (!w) return GLIO_E_STATE;
+    { const int rp = glio_assoc_finish_pending(c); if (rp != GLIO_OK) return rp; }      // (counts of an earlier asynchronous call must not overwrite this call's later)
     if (c->map_n <= 0) { glio_set_error("no map set"); return GLIO_E_STATE; }
     for (int k = 0; k < 4; ++k) w->last_pose0[k] = quats[k];
     for (int k = 0; k < 3; ++k) w->last_pose0[4 + k] = trans[k];

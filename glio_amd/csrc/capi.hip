@@ -270,6 +270,7 @@ int glio_synchronize(glio_ctx* c) {
 int glio_set_correspondences(glio_ctx* c, int slot, const float* pts, const float* planes, const double* scores, int n) {
     if (!c || slot < 0 || slot >= c->W || n < 0 || n > c->cap) { glio_set_error("bad slot / count %d (cap %d)", n, c ? c->cap : 0); return GLIO_E_ARG; }
     GLIO_HIP_CHECK(hipSetDevice(c->device));
+    { const int rp = glio_assoc_finish_pending(c); if (rp != GLIO_OK) return rp; }
     const size_t off = (size_t)slot * c->cap;
     if (n > 0) {
         GLIO_HIP_CHECK(hipMemcpyAsync(c->d_pts + off, pts, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));

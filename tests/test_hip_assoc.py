@@ -268,4 +268,10 @@ def test_asynchronous_window_association_gives_the_same_records():
     b.associate_window_async(q2s, t2s)
     sa, ma = a.solve(win.init); sb, mb = b.solve(win.init)
     assert ma.iterations == mb.iterations and np.array_equal(sa.trans, sb.trans) and ma.n_lidar_residuals == mb.n_lidar_residuals
+    # an asynchronous call followed by a synchronous one at OTHER poses: the later call's counts stand (the earlier one's must not come back)
+    t3s = t2s + np.array([0.4, -0.3, 0.0])
+    b.associate_window_async(q2s, t2s)
+    c_sync = b.associate_window(q2s, t3s)
+    assert np.array_equal(c_sync, a.associate_window(q2s, t3s)) and not np.array_equal(c_sync, ca)
+    assert np.array_equal(b.associate_window_counts(), c_sync)
     a.close(); b.close()
