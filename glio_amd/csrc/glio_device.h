@@ -279,8 +279,10 @@ __device__ __forceinline__ void d_q2R(const double q[4], double R[9]) {
 __device__ __forceinline__ void d_quat_plus(const double q[4], const double d[3], double o[4]) {
     const double nrm = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
     if (nrm > 0.0) {
-        const double s = sin(nrm) / nrm;
-        const double dq[4] = {cos(nrm), s * d[0], s * d[1], s * d[2]};
+        double sn, cs;
+        sincos(nrm, &sn, &cs);          // one argument reduction for both
+        const double s = sn / nrm;
+        const double dq[4] = {cs, s * d[0], s * d[1], s * d[2]};
         d_qmul(dq, q, o);
     } else {
         o[0] = q[0]; o[1] = q[1]; o[2] = q[2]; o[3] = q[3];
@@ -301,6 +303,13 @@ __device__ __forceinline__ void d_plus_jac(const double q[4], double P[12]) {
 // for prefetching.
 #define GLIO_WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local"); __builtin_amdgcn_wave_barrier(); \
                                   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local"); } while (0)
+
+// Workgroup barrier that orders LDS traffic ONLY: s_waitcnt lgkmcnt(0) + s_barrier.  __syncthreads() also drains every outstanding global
+// store of the wavefront (s_waitcnt vmcnt(0): on gfx9 stores count in vmcnt), i.e. it waits ~0.5 us for the write acknowledgements from L2 (more
+// for host-mapped memory) each time a phase has written results out.  For barriers between phases that hand data over through LDS and whose
+// global stores are only read by LATER launches.
+#define GLIO_BLOCK_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); \
+                                   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
 
 __device__ __forceinline__ double readlane_d(double v, int l) {
 #ifdef GLIO_NO_READLANE

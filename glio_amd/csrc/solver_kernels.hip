@@ -33,6 +33,7 @@
 // NOTE: no __restrict__ on anything in this file: every buffer here is handed between lanes of the
 // workgroup across s_barrier.  And a kernel here must not re-read global data it has itself rewritten unless the two
 // cannot share a 128 B line with anything it loaded earlier (see glio_ctx::vstride and DESIGN.md, "coherence trap").
+#include <type_traits>
 #include <vector>
 
 #include "glio_device.h"
@@ -108,17 +109,18 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 }
 // N sums through ONE pair of barriers: the same butterfly, the same inter-wave order per value as block_sum, so each result is
 // bit-identical to a separate block_sum call.  red needs N * TR_WAVES doubles.
-template <int N>
+// LB: LDS-only barriers (GLIO_BLOCK_LDS_SYNC) -- for callers whose global stores nobody reads back in this launch.
+template <int N, bool LB = false>
 __device__ __forceinline__ void block_sum_n(double (&v)[N], double* red) {
 #pragma unroll
     for (int k = 0; k < N; ++k) v[k] = wave_sum(v[k]);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __syncthreads();
+    if (LB) GLIO_BLOCK_LDS_SYNC(); else __syncthreads();
     if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < N; ++k) red[k * TR_WAVES + wv] = v[k];
     }
-    __syncthreads();
+    if (LB) GLIO_BLOCK_LDS_SYNC(); else __syncthreads();
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         double s = 0;
@@ -127,13 +129,14 @@ __device__ __forceinline__ void block_sum_n(double (&v)[N], double* red) {
         v[k] = s;
     }
 }
+template <bool LB = false>
 __device__ __forceinline__ double block_max(double v, double* red) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __syncthreads();
+    if (LB) GLIO_BLOCK_LDS_SYNC(); else __syncthreads();
     if (lane == 0) red[wv] = v;
-    __syncthreads();
+    if (LB) GLIO_BLOCK_LDS_SYNC(); else __syncthreads();
     double s = 0;
 #pragma unroll
     for (int k = 0; k < TR_WAVES; ++k) s = fmax(s, red[k]);
@@ -459,44 +462,78 @@ __device__ __forceinline__ void finalize(const TrArgs& a, const SolverStatus& s)
 // ------------------------------------------------------------------------------------------------
 // returns true when a linear solve has to follow (status written, vectors ready), false when this group has nothing to do
 // (the solve is finished -- possibly just now -- or was finished before)
-struct TrDecision { int cur, reuse; double mu; };     // what a kernel that continues after tr_prepare_body needs of the new status: it
-                                                      // must not re-read *a.status -- the line it loaded at entry may still sit in this
-                                                      // CU's L1, which is not refreshed by the store that rewrote it
-__device__ __forceinline__ bool tr_prepare_body(const TrArgs& a, TrDecision* out = nullptr) {
+struct TrDecision {            // what a kernel that continues after tr_prepare_body needs of the new status: it must not re-read
+    int cur, reuse; double mu; // *a.status -- the line it loaded at entry may still sit in this CU's L1, which is not refreshed by the
+    SolverStatus* full = nullptr;   // store that rewrote it.  full (optional, LDS): the whole record as written back.
+};
+// LDS mirrors that k_chain_step hands to the state machine (FAST): with them it has no global round trip of its own.  All of it concerns the
+// CANDIDATE (buffer 1 - st_in->cur), whose diag(H), g and cost the caller has just gathered; when the step is rejected the state machine
+// goes back to the global vectors of the current point.
+struct PrepMirror {
+    const SolverStatus* st_in;                                 // the record as loaded at kernel entry
+    const double* x0; const double* x1;                        // both state buffers
+    const double* hd; const double* g; const double* cost;     // diag(H), g, cost of the candidate
+    double* scale; double* diag; double* grad;                 // scale: the global vector on entry (phase > 0); all three are left filled for the caller
+    long long* dbg;                                            // stamped builds: device-clock marks of the state machine's sections (slots 80..)
+};
+#ifdef GLIO_DEV_STAMPS
+#define PM_STAMP(k) do { if (FAST && m->dbg && threadIdx.x == 0) m->dbg[k] = wall_clock64(); } while (0)
+#else
+#define PM_STAMP(k) do { } while (0)
+#endif
+template <bool FAST = false>
+__device__ __forceinline__ bool tr_prepare_body(const TrArgs& a, TrDecision* out = nullptr, const PrepMirror* m = nullptr) {
+    // FAST: every hand-over between threads goes through LDS and nothing this function stores to global memory is read back in the
+    // same launch, so its barriers do not wait for the stores' acknowledgements
+#define PB_SYNC() do { if (FAST) GLIO_BLOCK_LDS_SYNC(); else __syncthreads(); } while (0)
     __shared__ double red[32];
     __shared__ SolverStatus s;
     const int tid = threadIdx.x;
     const int n = a.n, W = a.W, nx = 16 * W + a.n_ddt;
     if (tid == 0) {
-        s = *a.status;
+        if (FAST) s = *m->st_in; else s = *a.status;
         s.group += 1;
         a.status->group = s.group;
     }
-    __syncthreads();
+    PB_SYNC();
     if (s.done) return false;
+    PM_STAMP(80);
     double* scale = V_SCALE(a); double* diag = V_DIAG(a); double* grad = V_GRAD(a); double* u = V_U(a);
+    const int cand0 = 1 - s.cur;                     // (FAST: the buffer the mirrors describe)
 
     if (s.cand_pending) {
         const int cand = 1 - s.cur;
         if (s.phase == 0) {
             const double* Hc = cand ? a.H1 : a.H0;
             const double* hdc = cand ? a.hd1 : a.hd0;
-            for (int i = tid; i < n; i += TR_THREADS) scale[i] = a.jacobi_scaling ? 1.0 / (1.0 + sqrt(a.hd0 ? hdc[i] : Hc[(size_t)i * n + i])) : 1.0;
-            __syncthreads();
+            for (int i = tid; i < n; i += TR_THREADS) {
+                const double h = FAST ? m->hd[i] : (a.hd0 ? hdc[i] : Hc[(size_t)i * n + i]);
+                const double sc = a.jacobi_scaling ? 1.0 / (1.0 + sqrt(h)) : 1.0;
+                scale[i] = sc;
+                if (FAST) m->scale[i] = sc;
+            }
+            PB_SYNC();
             if (tid == 0) {
                 s.cur = cand;
-                s.cost = *(cand ? a.c1 : a.c0);
+                s.cost = FAST ? *m->cost : *(cand ? a.c1 : a.c0);
                 s.initial_cost = s.cost;
                 s.phase = 1;
             }
         } else {
-            const double* xc = s.cur ? a.x1 : a.x0;
-            const double* xn = cand ? a.x1 : a.x0;
             double d2 = 0, x2 = 0;
-            for (int k = tid; k < nx; k += TR_THREADS) { const double d = xc[k] - xn[k]; d2 += d * d; x2 += xc[k] * xc[k]; }
-            { double v2[2] = {d2, x2}; block_sum_n<2>(v2, red); d2 = v2[0]; x2 = v2[1]; }
+            if (FAST) {
+                const double* xc = s.cur ? m->x1 : m->x0;
+                const double* xn = cand ? m->x1 : m->x0;
+                for (int k = tid; k < nx; k += TR_THREADS) { const double d = xc[k] - xn[k]; d2 += d * d; x2 += xc[k] * xc[k]; }
+            } else {
+                const double* xc = s.cur ? a.x1 : a.x0;
+                const double* xn = cand ? a.x1 : a.x0;
+                for (int k = tid; k < nx; k += TR_THREADS) { const double d = xc[k] - xn[k]; d2 += d * d; x2 += xc[k] * xc[k]; }
+            }
+            { double v2[2] = {d2, x2}; block_sum_n<2, FAST>(v2, red); d2 = v2[0]; x2 = v2[1]; }
+            PM_STAMP(81);
             if (tid == 0) {
-                const double ccost = *(cand ? a.c1 : a.c0);
+                const double ccost = FAST ? *m->cost : *(cand ? a.c1 : a.c0);
                 const double step_norm = sqrt(d2), x_norm = sqrt(x2);
                 if (step_norm <= a.parameter_tolerance * (x_norm + a.parameter_tolerance)) {
                     s.done = 1; s.termination = GLIO_TERM_PARAMETER_TOL;
@@ -524,31 +561,45 @@ __device__ __forceinline__ bool tr_prepare_body(const TrArgs& a, TrDecision* out
                 }
             }
         }
-        __syncthreads();
+        PB_SYNC();
         if (tid == 0) s.cand_pending = 0;
-        __syncthreads();
+        PB_SYNC();
     }
     if (s.done) { finalize(a, s); return false; }
+    PM_STAMP(82);
 
     const double* H = s.cur ? a.H1 : a.H0;
     const double* hdv = s.cur ? a.hd1 : a.hd0;
     const double* g = s.cur ? a.g1 : a.g0;
     const double* xc = s.cur ? a.x1 : a.x0;
+    const bool mirrored = FAST && s.cur == cand0;    // the current point is the one the mirrors describe (the candidate was accepted)
     // gradient max norm = | x - Plus(x, -g) |_inf
-    double gm = 0;
-    for (int k = tid; k < n; k += TR_THREADS) {
-        if (k < 15 * W && (k % 15) >= 3 && (k % 15) < 6) {
-            if ((k % 15) == 3) {
-                const int sl = k / 15;
-                const double d[3] = {-g[k], -g[k + 1], -g[k + 2]};
-                double q[4], qn[4];
-                for (int c = 0; c < 4; ++c) q[c] = xc[3 * W + 4 * sl + c];
-                d_quat_plus(q, d, qn);
-                for (int c = 0; c < 4; ++c) gm = fmax(gm, fabs(q[c] - qn[c]));
-            }
-        } else gm = fmax(gm, fabs(g[k]));
-    }
-    gm = block_max(gm, red);
+    // (FAST: the rotation entries -- a quaternion update with its sin / cos each -- are taken by the lanes of the last wavefront, which has
+    // no entry of its own when n <= 448, instead of by lanes scattered over all of them: a maximum does not care who contributes what)
+    auto grad_max = [&](const double* gv, const double* xv) {
+        double gmx = 0;
+        auto rot = [&](const int sl) {
+            const int k = 15 * sl + 3;
+            const double d[3] = {-gv[k], -gv[k + 1], -gv[k + 2]};
+            double q[4], qn[4];
+            for (int c = 0; c < 4; ++c) q[c] = xv[3 * W + 4 * sl + c];
+            d_quat_plus(q, d, qn);
+            for (int c = 0; c < 4; ++c) gmx = fmax(gmx, fabs(q[c] - qn[c]));
+        };
+        for (int k = tid; k < n; k += TR_THREADS) {
+            if (k < 15 * W && (k % 15) >= 3 && (k % 15) < 6) {
+                if (!FAST && (k % 15) == 3) rot(k / 15);
+            } else gmx = fmax(gmx, fabs(gv[k]));
+        }
+        if (FAST && tid >= TR_THREADS - 64) for (int sl = tid - (TR_THREADS - 64); sl < W; sl += 64) rot(sl);
+        return gmx;
+    };
+    double gm;
+    if (FAST) { const double* xl = s.cur ? m->x1 : m->x0; gm = mirrored ? grad_max(m->g, xl) : grad_max(g, xl); }
+    else gm = grad_max(g, xc);
+    PM_STAMP(83);
+    gm = block_max<FAST>(gm, red);
+    PM_STAMP(84);
     if (tid == 0) {
         s.grad_max_norm = gm;
         const bool out_of_time = a.stop_word && *reinterpret_cast<const volatile int*>(a.stop_word) == s.solve_id;      // Ceres: MaxSolverTimeReached
@@ -557,34 +608,55 @@ __device__ __forceinline__ bool tr_prepare_body(const TrArgs& a, TrDecision* out
         else if (s.radius <= a.min_radius) { s.done = 1; s.termination = GLIO_TERM_MIN_RADIUS; }
         else s.iteration += 1;
     }
-    __syncthreads();
+    PB_SYNC();
     if (s.done) { finalize(a, s); return false; }
     // The solve goes on: only now is the host told to enqueue the next kernel group (it then has this whole step, ~70 us,
     // to do so).  Announcing the group at its start instead made the host queue one group beyond the last useful one
     // every time: ~9 empty launches (~20 us) between back-to-back solves.
     // (a plain store to host-coherent memory: it leaves the GPU at once; a system-scope fence here would only stall this workgroup
     // ~1 us until the write is acknowledged across PCIe)
-    if (tid == 0) { *reinterpret_cast<volatile int*>(a.progress) = (s.solve_id << 16) | s.group; }
+    // (a relaxed system-scope atomic store, NOT a volatile one: the compiler follows a volatile store with s_waitcnt vmcnt(0), i.e. this
+    // wavefront would sit out the PCIe round trip, ~1 us, right here)
+    if (tid == 0) __hip_atomic_store(a.progress, (s.solve_id << 16) | s.group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (a.lm && tid == 0) s.mu = 1.0 / s.radius;      // (Hs + D^2 / radius) y = gs
-    __syncthreads();
+    PB_SYNC();
+    PM_STAMP(85);
 
     if (!s.reuse) {
-        for (int i = tid; i < n; i += TR_THREADS) {
-            double d = scale[i] * scale[i] * (a.hd0 ? hdv[i] : H[(size_t)i * n + i]);
-            d = d < 1e-6 ? 1e-6 : (d > 1e32 ? 1e32 : d);
-            const double dd = sqrt(d);
-            diag[i] = dd;
-            const double gs = scale[i] * g[i];
-            grad[i] = gs / dd;
-            u[i] = scale[i] * (gs / dd) / dd;
+        auto work_vectors = [&](const double* sv, const double* hv, const double* gv) {
+            for (int i = tid; i < n; i += TR_THREADS) {
+                double d = sv[i] * sv[i] * hv[i];
+                d = d < 1e-6 ? 1e-6 : (d > 1e32 ? 1e32 : d);
+                const double dd = sqrt(d);
+                diag[i] = dd;
+                const double gs = sv[i] * gv[i];
+                grad[i] = gs / dd;
+                u[i] = sv[i] * (gs / dd) / dd;
+                if (FAST) { m->diag[i] = dd; m->grad[i] = gs / dd; }
+            }
+        };
+        if (FAST) { if (mirrored) work_vectors(m->scale, m->hd, m->g); else work_vectors(m->scale, hdv, g); }
+        else if (a.hd0) work_vectors(scale, hdv, g);
+        else {
+            for (int i = tid; i < n; i += TR_THREADS) {
+                double d = scale[i] * scale[i] * H[(size_t)i * n + i];
+                d = d < 1e-6 ? 1e-6 : (d > 1e32 ? 1e32 : d);
+                const double dd = sqrt(d);
+                diag[i] = dd;
+                const double gs = scale[i] * g[i];
+                grad[i] = gs / dd;
+                u[i] = scale[i] * (gs / dd) / dd;
+            }
         }
     }
-    __syncthreads();
-    if (tid == 0) *a.status = s;
+    PB_SYNC();
+    PM_STAMP(86);
+    if (tid == 0) { *a.status = s; if (out && out->full) *out->full = s; }
     if (out) { out->cur = s.cur; out->reuse = s.reuse; out->mu = s.mu; }
-    __syncthreads();
+    PB_SYNC();
     return true;
 }
+#undef PB_SYNC
 __global__ __launch_bounds__(TR_THREADS) void k_tr_prepare(const TrArgs a) { (void)tr_prepare_body(a); }
 
 // ------------------------------------------------------------------------------------------------
@@ -1436,6 +1508,8 @@ struct ChainArgs {
     const SolverStatus* status;
     long long* dbg;
     int force_fail;           // test hook: report a breakdown although there is none (exercises the dense fallback)
+    int fast;                 // k_chain_step: bit 0 = the tail (Cauchy length, dogleg, candidate) from LDS, bit 1 = the front (candidate's diag/g/cost,
+                              // state machine) from LDS; 0 = the generic bodies that talk through the global work vectors (GLIO_CHAIN_FAST, default 3)
 };
 
 // The kernel also does the work of k_tr_prepare (state machine, scaling vectors) and of k_tr_scale for this structure: it
@@ -1477,6 +1551,7 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a, c
     int* eoth = esd + 2 * nd + 2;                          // [2 nd] ... of the next keyframe's rows, or -1
     int* misc = eoth + 2 * nd + 2;                         // [0] bad, [1] number of active local rows, [2..17] their indices
     double* wd = reinterpret_cast<double*>(misc + 24);     // [nd] u / s of the epochs (for t = H u)
+    double* wdr = reinterpret_cast<double*>(esd);          // [nd] (u / s) sqrt(m): lives where the index lists go AFTER t = H u
     __shared__ int rowmask;                            // cleared here, two barriers before the first atomicOr into it
     if (tid < 18) misc[tid] = 0;
     if (tid == 0) rowmask = 0;
@@ -1499,7 +1574,8 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a, c
     {
         const double* uv = V_U(tr);
         for (int k = tid; k < np15; k += KC_THREADS) zb[k] = uv[k] / scv[k];
-        for (int e = tid; e < nd; e += KC_THREADS) wd[e] = uv[np15 + e] / scv[np15 + e];
+        // wdr = w_e / r_e (r = 1 / sqrt(m)): the epoch term of t = H u un-scales the stored columns V = S c S r with it
+        for (int e = tid; e < nd; e += KC_THREADS) { const double we = uv[np15 + e] / scv[np15 + e]; wd[e] = we; wdr[e] = (1.0 / rd[e]) * we; }
         if (tid < np15 + nd) { pre_s = scv[tid]; pre_d = dgv[tid]; pre_h = tid >= np15 ? Hn[(size_t)tid * n + tid] : 0.0; }
     }
     // epoch columns (scaled) and the raw blocks, every global read issued as a batch of independent loads
@@ -1573,7 +1649,7 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a, c
             for (int tt = eoff[i]; tt < eoff[i + 1]; ++tt) {
                 const int e = elist[tt];
                 const int side = eps[e].x == i ? 0 : 15;
-                acc += (Vs[e * 30 + side + r] / rd[e]) * wd[e];
+                acc += Vs[e * 30 + side + r] * wdr[e];
             }
             V_T(tr)[row] = acc / s_row;
         } else {
@@ -1582,8 +1658,9 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a, c
             const double se = s_row;
             acc = se * (first ? pre_h : Hn[(size_t)row * n + row]) * se * wd[e];
             if (sl.x >= 0) {
+                const double ire = 1.0 / rd[e];             // one division per epoch, not one per entry
 #pragma unroll
-                for (int q = 0; q < 30; ++q) acc += (Vs[e * 30 + q] / rd[e]) * zb[15 * (q < 15 ? sl.x : sl.y) + (q < 15 ? q : q - 15)];
+                for (int q = 0; q < 30; ++q) acc += (Vs[e * 30 + q] * ire) * zb[15 * (q < 15 ? sl.x : sl.y) + (q < 15 ? q : q - 15)];
             }
             V_T(tr)[row] = acc / se;
         }
@@ -1777,7 +1854,8 @@ __host__ __device__ __forceinline__ size_t chain_step_tabs_offset(int W, int nd,
     return ((a > b ? a : b) + 15) & ~(size_t)15;
 }
 __host__ __device__ __forceinline__ size_t chain_step_lds_bytes(int W, int nd, int n) {
-    return chain_step_tabs_offset(W, nd, n) + (size_t)W * GLIO_LIDAR_ACC * 8 + 2 * (size_t)(n + (n & 1)) * 8 + (size_t)nd * 128 + (size_t)(8 + 15) * W * 2 + 3 * 346 * 2 + 64;
+    return chain_step_tabs_offset(W, nd, n) + (size_t)W * GLIO_LIDAR_ACC * 8 + 5 * (size_t)(n + (n & 1)) * 8 + (size_t)(n + W + ((n + W) & 1)) * 8 + (size_t)nd * 128 +
+           (size_t)(8 + 15) * W * 2 + 3 * 346 * 2 + 64;
 }
 struct GatherArgs {
     const double* lidar_partials; size_t lidar_pstride; int lidar_nb;
@@ -1844,6 +1922,32 @@ __device__ __forceinline__ double kc_gather_grad(const GatherArgs& G, const Gath
 __device__ __forceinline__ void kc_reduce_lidar(const GatherArgs& G, const GatherTabs& T, const int which, const int W) {
     const double* lp = G.lidar_partials + (size_t)which * G.lidar_pstride;
     const int lnb = G.lidar_nb;
+    const int total = W * GLIO_LIDAR_ACC;
+    if (lnb <= 24 && total <= 2 * (int)blockDim.x) {
+        // the usual geometry (560 entries, 512 threads, 24 partials each): a thread's two entries load together -- one round trip, not two
+        const int it0 = threadIdx.x, it1 = threadIdx.x + blockDim.x;
+        const bool h0 = it0 < total, h1 = it1 < total;
+        const int s0 = (h0 ? it0 : 0) / GLIO_LIDAR_ACC, s1 = (h1 ? it1 : 0) / GLIO_LIDAR_ACC;
+        const double* p0 = lp + (size_t)s0 * lnb * GLIO_LIDAR_ACC + ((h0 ? it0 : 0) - s0 * GLIO_LIDAR_ACC);
+        const double* p1 = lp + (size_t)s1 * lnb * GLIO_LIDAR_ACC + ((h1 ? it1 : 0) - s1 * GLIO_LIDAR_ACC);
+        double va[24], vb[24];
+#pragma unroll
+        for (int q = 0; q < 24; ++q) va[q] = p0[(size_t)(q < lnb ? q : 0) * GLIO_LIDAR_ACC];
+        if (h1) {
+#pragma unroll
+            for (int q = 0; q < 24; ++q) vb[q] = p1[(size_t)(q < lnb ? q : 0) * GLIO_LIDAR_ACC];
+        }
+        double sa = 0, sb = 0;
+#pragma unroll
+        for (int q = 0; q < 24; ++q) sa += q < lnb ? va[q] : 0.0;
+        if (h0) T.lid[it0] = sa;
+        if (h1) {
+#pragma unroll
+            for (int q = 0; q < 24; ++q) sb += q < lnb ? vb[q] : 0.0;
+            T.lid[it1] = sb;
+        }
+        return;
+    }
     for (int it = threadIdx.x; it < W * GLIO_LIDAR_ACC; it += blockDim.x) {
         const int slot = it / GLIO_LIDAR_ACC, idx = it - slot * GLIO_LIDAR_ACC;
         const double* p = lp + (size_t)slot * lnb * GLIO_LIDAR_ACC + idx;
@@ -1917,11 +2021,22 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
     int* eoth = esd + 2 * nd + 2;
     int* misc = eoth + 2 * nd + 2;
     double* wd = reinterpret_cast<double*>(misc + 24);
+    double* wdr = reinterpret_cast<double*>(esd);        // [nd] (u / s) sqrt(m) for t = H u: lives where the index lists go afterwards
     double* gt_base = reinterpret_cast<double*>(tr_lds + chain_step_tabs_offset(W, nd, n));
     double* lid = gt_base;                               // [W][28]
+    const int n2 = n + (n & 1), nx = n + W, nx2 = nx + (nx & 1);
     double* sS = lid + W * GLIO_LIDAR_ACC;               // [n] Jacobi scale       (staged copies of the work vectors)
-    double* sDg = sS + n + (n & 1);                      // [n] D = sqrt(clamp(diag))
-    double* dds = sDg + n + (n & 1);                     // [nd][15] clock-drift blocks: c[12], h, g, (group, used)
+    double* sDg = sS + n2;                               // [n] D = sqrt(clamp(diag))
+    double* sG = sDg + n2;                               // [n] g of the current point
+    double* sGr = sG + n2;                               // [n] g~ = S g / D
+    double* sT = sGr + n2;                               // [n] t = H u
+    double* sX = sT + n2;                                // [16 W + nd] the current point
+    double* dds = sX + nx2;                              // [nd][15] clock-drift blocks: c[12], h, g, (group, used)
+    // scratch of the front: state buffer 0 sits in sX, buffer 1 in [CsT, CsB) (free until the chain), the candidate's diag(H) in sDg (the
+    // state machine reads entry i before it overwrites it with D_i)
+    double* xm0 = sX; double* xm1 = CsT; double* sHd = sDg;
+    __shared__ double s_cost_lds;
+    double* sCost = &s_cost_lds;
     short* stab = reinterpret_cast<short*>(dds + (size_t)nd * 15 + (nd & 1));
     short* wr30 = stab + (8 + 15) * W + ((8 + 15) * W & 1);      // [345] chain-layout index -> row (0..29), column, LiDAR packed index or -1
     short* wj = wr30 + 346;
@@ -1931,9 +2046,17 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
     __shared__ int rowmask;
     __shared__ int s_pending, s_cand, s_done;
     __shared__ int s_prog[2];
+    __shared__ SolverStatus s_in, s_full;
     AR_STAMP(40);
     // ---- round 0: status, the host-built gather tables, the structure tables of the epochs
-    if (tid == 0) { const SolverStatus* st = tr.status; s_done = st->done; s_pending = st->cand_pending; s_cand = 1 - st->cur; }
+    if (tid == 0) { s_in = *tr.status; s_done = s_in.done; s_pending = s_in.cand_pending; s_cand = 1 - s_in.cur; }
+    if (tid < 18) misc[tid] = 0;            // [0] breakdown flag, [1] number of rows with an epoch coupling, [2..] their indices
+    if (tid == 0) rowmask = 0;
+    if ((a.fast & 2) && n <= KC_THREADS && nx2 <= 2 * 288) {        // what the state machine will want, in the same round trip: both state buffers and the Jacobi scale
+        for (int k = tid; k < nx; k += KC_THREADS) { xm0[k] = tr.x0[k]; xm1[k] = tr.x1[k]; }
+        for (int k = tid; k < n; k += KC_THREADS) sS[k] = V_SCALE(tr)[k];
+        for (int t = tid; t < 2 * nd; t += KC_THREADS) elist[t] = a.ep_list[t];
+    }
     for (int k = tid; k < (8 + 15) * W; k += KC_THREADS) stab[k] = G.tabs[k];
     for (int w = tid; w < 345; w += KC_THREADS) {
         int r30, j;
@@ -1944,12 +2067,116 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
     }
     for (int e = tid; e < nd; e += KC_THREADS) eps[e] = a.ep_slots[e];
     for (int i = tid; i <= W; i += KC_THREADS) eoff[i] = a.ep_off[i];
-    __syncthreads();
+    GLIO_BLOCK_LDS_SYNC();              // (LDS-only barriers wherever the hand-over is through LDS: see glio_device.h)
     if (s_done) return;
     const int cand = s_cand;
     AR_STAMP(41);
+    // The keyframe blocks: 345 entries per keyframe (lower triangle of D_i, all of B_i), each the LiDAR block + the five slices the factor
+    // roles wrote in this layout (coalesced, same index in every slice), seven items per thread in flight.  gather_load issues the loads of
+    // one batch, gather_store adds them up (k_assemble's order), scales (S H S + mu D^2) and stores.  (Measured without gain: gathering
+    // into LDS before the state machine and scaling afterwards; holding the first batch in registers across the state machine; skipping
+    // the slices that are zero by the graph's structure, ~45 % of the 276 KB -- the per-slice branches cost what the loads save.)
+    constexpr int KB = 7;
+    const int gtotal = W * 345;
+    auto gather_load = [&](const double* src, const int q0, double (&v)[KB][5]) {
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            const int q = q0 + u * KC_THREADS;
+            const int qq = q < gtotal ? q : tid;
+            const int i = qq / 345, w = qq - 345 * i;
+            const double* p = src + (size_t)i * GLIO_CS_SOURCES * GLIO_CS_STRIDE + w;
+#pragma unroll
+            for (int sidx = 0; sidx < 5; ++sidx) v[u][sidx] = p[sidx * GLIO_CS_STRIDE];
+        }
+    };
+    auto gather_store = [&](const int q0, const double (&v)[KB][5], const double mu_) {
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            const int q = q0 + u * KC_THREADS;
+            if (q >= gtotal) continue;
+            const int i = q / 345, w = q - 345 * i;
+            const int r30 = wr30[w], j = wj[w], lix = wlx[w];
+            const bool live = r30 < 15 || i + 1 < W;
+            const int irow = 15 * i + r30, icol = 15 * i;
+            double h = 0;
+            h += lix >= 0 ? lid[i * GLIO_LIDAR_ACC + (lix >= 0 ? lix : 0)] : 0.0;
+            h += v[u][0]; h += v[u][1]; h += v[u][2]; h += v[u][3]; h += v[u][4];
+            double wv_ = (live ? sS[irow] : 0.0) * h * sS[icol + j];
+            wv_ += (irow == icol + j) ? mu_ * sDg[irow] * sDg[irow] : 0.0;
+            Blk[(size_t)i * KC_BLK + r30 * KC_RS + j] = live ? wv_ : 0.0;
+        }
+    };
     // ---- diag(H), g and the cost of the candidate, for the state machine
-    if (s_pending) {
+    const bool ff = (a.fast & 2) && s_pending && n <= KC_THREADS && nx2 <= 2 * 288;      // the front from LDS (one item per thread; state buffer 1 fits [CsT, CsB))
+    if (ff) {
+        // every global load of this phase goes out before the first barrier: the slices' diagonal entries, the gradient parts, the costs
+        // and the clock-drift blocks travel together with the K3 partials instead of one round trip after the other
+        double* hd = cand ? G.hd1 : G.hd0;
+        double* gv = cand ? G.g1 : G.g0;
+        const DdtBlock* dd = G.ddt_blocks + (size_t)cand * G.ddt_stride;
+        const PairBlock* imu = G.imu_blocks + (size_t)cand * W;
+        const PairBlock* gnb = G.gnss_blocks + (size_t)cand * G.gnss_stride;
+        const int c = tid < n ? tid : 0;
+        const bool pose = c < np15;
+        const int sc = pose ? c / 15 : 0, lc = pose ? c - 15 * sc : 0, e = pose ? 0 : c - np15;
+        const ChainKf d = T.kd[sc];
+        const int pi = T.pidx[15 * sc + lc];
+        double e5[5], g5[5];
+        {
+            const double* p = G.chain_src + (((size_t)cand * W + sc) * GLIO_CS_SOURCES) * GLIO_CS_STRIDE + kc_w(lc, lc);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) e5[k] = p[k * GLIO_CS_STRIDE];
+            g5[0] = imu[d.e0 >= 0 ? d.e0 : 0].g[lc];
+            g5[1] = imu[d.e1 >= 0 ? d.e1 : 0].g[15 + lc];
+            g5[2] = gnb[d.k0 >= 0 ? d.k0 : 0].g[(d.o0 ? 0 : 15) + lc];
+            g5[3] = gnb[d.k1 >= 0 ? d.k1 : 0].g[(d.o1 ? 0 : 15) + lc];
+            g5[4] = (G.pg + (size_t)cand * G.np)[pi >= 0 ? pi : 0];
+        }
+        const double dh = nd > 0 ? dd[e].h : 0.0, dg = nd > 0 ? dd[e].g : 0.0;
+        double ci0 = 0, cg0 = 0, cp0 = 0;
+        if (wv == KC_THREADS / 64 - 1) {
+            ci0 = lane < G.n_imu ? imu[lane].cost : 0.0;
+            cg0 = lane < G.n_groups ? gnb[lane].cost : 0.0;
+            if (lane == 0 && G.has_prior) cp0 = G.pcost[cand];
+        }
+        for (int k = tid; k < nd * 15; k += KC_THREADS) dds[k] = reinterpret_cast<const double*>(dd)[k];
+        AR_STAMP(74);
+        kc_reduce_lidar(G, T, cand, W);
+        AR_STAMP(75);
+        GLIO_BLOCK_LDS_SYNC();
+        AR_STAMP(76);
+        if (tid < n) {
+            double hv, gg_;
+            if (pose) {
+                const bool lidp = lc < 6;
+                double sacc = 0;        // kc_gather_entry's order: LiDAR, the five slices
+                sacc += lidp ? T.lid[sc * GLIO_LIDAR_ACC + kc_lidar_sym_index(lidp ? lc : 0, lidp ? lc : 0)] : 0.0;
+                sacc += e5[0]; sacc += e5[1]; sacc += e5[2]; sacc += e5[3]; sacc += e5[4];
+                hv = sacc;
+                const double vl = T.lid[sc * GLIO_LIDAR_ACC + 21 + (lidp ? lc : 0)];
+                double gacc = 0;        // kc_gather_grad's order
+                gacc += lidp ? vl : 0.0;
+                gacc += d.e0 >= 0 ? g5[0] : 0.0;
+                gacc += d.e1 >= 0 ? g5[1] : 0.0;
+                gacc += d.k0 >= 0 ? g5[2] : 0.0;
+                gacc += d.k1 >= 0 ? g5[3] : 0.0;
+                gacc += pi >= 0 ? g5[4] : 0.0;
+                gg_ = gacc;
+            } else { hv = dh; gg_ = dg; }
+            hd[tid] = hv; gv[tid] = gg_;
+            sHd[tid] = hv; sG[tid] = gg_;
+        }
+        if (wv == KC_THREADS / 64 - 1) {          // total cost: the same lane assignment and wave reduction as k_assemble
+            double cs = 0;
+            for (int k = lane; k < W; k += 64) cs += T.lid[k * GLIO_LIDAR_ACC + 27];
+            for (int k = lane; k < G.n_imu; k += 64) cs += k == lane ? ci0 : imu[k].cost;
+            for (int k = lane; k < G.n_groups; k += 64) cs += k == lane ? cg0 : gnb[k].cost;
+            if (lane == 0 && G.has_prior) cs += cp0;
+            cs = wave_sum(cs);
+            if (lane == 0) { *(cand ? G.c1 : G.c0) = cs; *sCost = cs; }
+        }
+        // (no fence: nothing of this is read back from global memory in this launch)
+    } else if (s_pending) {
         kc_reduce_lidar(G, T, cand, W);
         __syncthreads();
         double* hd = cand ? G.hd1 : G.hd0;
@@ -1975,12 +2202,18 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
         }
         __threadfence();
     }
-    __syncthreads();
+    if (ff) GLIO_BLOCK_LDS_SYNC(); else __syncthreads();
     AR_STAMP(42);
     // ---- state machine (reads the vectors just written: nothing of them was loaded earlier in this kernel)
     TrDecision dec;
-    if (!tr_prepare_body(tr, &dec)) return;
+    dec.full = &s_full;
+    if (ff) {
+        PrepMirror pm;
+        pm.st_in = &s_in; pm.x0 = xm0; pm.x1 = xm1; pm.hd = sHd; pm.g = sG; pm.cost = sCost; pm.scale = sS; pm.diag = sDg; pm.grad = sGr; pm.dbg = a.dbg;
+        if (!tr_prepare_body<true>(tr, &dec, &pm)) return;
+    } else if (!tr_prepare_body(tr, &dec)) return;
     AR_STAMP(43);
+    bool fast_tail = false;
     if (!dec.reuse) {
     if (tid == 0) *a.flag = 0;
     if (!(s_pending && dec.cur == cand)) { kc_reduce_lidar(G, T, dec.cur, W); }      // (invalid step earlier: the current point's blocks again)
@@ -1988,29 +2221,42 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
     const DdtBlock* ddg = G.ddt_blocks + (size_t)dec.cur * G.ddt_stride;
     const double mu = dec.mu;
     auto nat = [&](const int p) { return p < nd ? np15 + p : p - nd; };
-    if (tid < 18) misc[tid] = 0;
-    if (tid == 0) rowmask = 0;
-    // round 1: the work vectors, the clock-drift blocks (coalesced, 15 doubles each) and the epoch list into LDS
-    for (int k = tid; k < n; k += KC_THREADS) { sS[k] = V_SCALE(tr)[k]; sDg[k] = V_DIAG(tr)[k]; }
-    for (int k = tid; k < nd * 15; k += KC_THREADS) dds[k] = reinterpret_cast<const double*>(ddg)[k];
-    for (int t = tid; t < eoff[W]; t += KC_THREADS) elist[t] = a.ep_list[t];
-    {
-        const double* uv = V_U(tr);
-        for (int k = tid; k < np15; k += KC_THREADS) zb[k] = uv[k];
-        for (int e = tid; e < nd; e += KC_THREADS) wd[e] = uv[np15 + e];
-    }
     static_assert(sizeof(DdtBlock) == 15 * sizeof(double), "DdtBlock staged as 15 doubles");
-    __syncthreads();
-    auto Rld = [&](const int p) { const int i = nat(p); return sS[i] * gn[i]; };
-    for (int k = tid; k < np15; k += KC_THREADS) zb[k] = zb[k] / sS[k];
-    for (int e = tid; e < nd; e += KC_THREADS) {
-        wd[e] = wd[e] / sS[np15 + e];
+    auto epoch_scalars = [&](const int e, const double we) {          // w_e = u / s, r_e = 1 / sqrt(m_e), w_e / r_e
+        wd[e] = we;
         const int ie = np15 + e;
         const double se = sS[ie], he = dds[e * 15 + 12], de = sDg[ie];
         const double m = se * he * se + mu * de * de;
-        if (!(m > 0.0) || !isfinite(m)) { misc[0] = 1; rd[e] = 0.0; } else rd[e] = rsqrt(m);
+        double re;
+        if (!(m > 0.0) || !isfinite(m)) { misc[0] = 1; re = 0.0; } else re = rsqrt(m);
+        rd[e] = re;
+        wdr[e] = (1.0 / re) * we;
+    };
+    if (ff && dec.cur == cand) {
+        // round 1 without a global load: scale, D, g~, g and the clock-drift blocks are in LDS already; u = S g~ / D as the state machine
+        // formed it, w = u / S and the epochs' scalars in the same pass (one barrier instead of two)
+        const double* xm = cand ? xm1 : xm0;
+        for (int k = tid; k < nx; k += KC_THREADS) sX[k] = xm[k];
+        for (int k = tid; k < np15; k += KC_THREADS) zb[k] = (sS[k] * sGr[k] / sDg[k]) / sS[k];
+        for (int e = tid; e < nd; e += KC_THREADS) epoch_scalars(e, (sS[np15 + e] * sGr[np15 + e] / sDg[np15 + e]) / sS[np15 + e]);
+    } else {
+        // round 1: the work vectors, the clock-drift blocks (coalesced, 15 doubles each) and the epoch list into LDS
+        const double* xg = dec.cur ? tr.x1 : tr.x0;
+        for (int k = tid; k < n; k += KC_THREADS) { sS[k] = V_SCALE(tr)[k]; sDg[k] = V_DIAG(tr)[k]; sGr[k] = V_GRAD(tr)[k]; sG[k] = gn[k]; }
+        for (int k = tid; k < nx; k += KC_THREADS) sX[k] = xg[k];
+        for (int k = tid; k < nd * 15; k += KC_THREADS) dds[k] = reinterpret_cast<const double*>(ddg)[k];
+        for (int t = tid; t < eoff[W]; t += KC_THREADS) elist[t] = a.ep_list[t];
+        const double* uv = V_U(tr);
+        for (int k = tid; k < np15; k += KC_THREADS) zb[k] = uv[k];
+        for (int e = tid; e < nd; e += KC_THREADS) wd[e] = uv[np15 + e];
+        GLIO_BLOCK_LDS_SYNC();
+        for (int k = tid; k < np15; k += KC_THREADS) zb[k] = zb[k] / sS[k];
+        for (int e = tid; e < nd; e += KC_THREADS) epoch_scalars(e, wd[e] / sS[np15 + e]);
     }
-    __syncthreads();
+    auto Rld = [&](const int p) { const int i = nat(p); return sS[i] * sG[i]; };
+    GLIO_BLOCK_LDS_SYNC();
+    AR_STAMP(90);
+    AR_STAMP(91);
     int mk_rows = 0;
     for (int it = tid; it < nd * 30; it += KC_THREADS) {       // one (epoch, row) pair per item
         const int e = it / 30, q = it - 30 * e;
@@ -2023,57 +2269,31 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
         Vs[it] = v * rd[e];
         if (v != 0.0) mk_rows |= 1 << (q % 15);
     }
+    AR_STAMP(92);
     {   // rows that carry an epoch coupling: one LDS atomic per wavefront
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) mk_rows |= __shfl_xor(mk_rows, off, 64);
         if (lane == 0 && mk_rows) atomicOr(&rowmask, mk_rows);
     }
+    AR_STAMP(93);
     for (int e = tid; e < nd; e += KC_THREADS) yd[e] = Rld(e) * rd[e];
     AR_STAMP(44);
-    // the keyframe blocks: 345 entries per keyframe (lower triangle of D_i, all of B_i): the LiDAR block + the five slices the
-    // factor roles wrote in this layout (coalesced, same index in every slice), seven items per thread in flight, scaled on the way in
     {
         const double* src = G.chain_src + (size_t)dec.cur * W * GLIO_CS_SOURCES * GLIO_CS_STRIDE;
-        const int total = W * 345;
-        constexpr int KB = 7;
-        for (int q0 = tid; q0 < total; q0 += KB * KC_THREADS) {
-            double v[KB][5];
-            int ii[KB], ww[KB];
-#pragma unroll
-            for (int u = 0; u < KB; ++u) {
-                const int q = q0 + u * KC_THREADS;
-                const int qq = q < total ? q : tid;
-                const int i = qq / 345, w = qq - 345 * i;
-                ii[u] = i; ww[u] = w;
-                const double* p = src + (size_t)i * GLIO_CS_SOURCES * GLIO_CS_STRIDE + w;
-#pragma unroll
-                for (int sidx = 0; sidx < 5; ++sidx) v[u][sidx] = p[sidx * GLIO_CS_STRIDE];
-            }
-#pragma unroll
-            for (int u = 0; u < KB; ++u) {
-                const int q = q0 + u * KC_THREADS;
-                if (q >= total) continue;
-                const int i = ii[u], w = ww[u];
-                const int r30 = wr30[w], j = wj[w], lix = wlx[w];
-                const bool live = r30 < 15 || i + 1 < W;
-                const int irow = 15 * i + r30, icol = 15 * i;
-                double h = 0;
-                h += lix >= 0 ? lid[i * GLIO_LIDAR_ACC + (lix >= 0 ? lix : 0)] : 0.0;
-                h += v[u][0]; h += v[u][1]; h += v[u][2]; h += v[u][3]; h += v[u][4];
-                double wv_ = (live ? sS[irow] : 0.0) * h * sS[icol + j];
-                wv_ += (irow == icol + j) ? mu * sDg[irow] * sDg[irow] : 0.0;
-                Blk[(size_t)i * KC_BLK + r30 * KC_RS + j] = live ? wv_ : 0.0;
-            }
-        }
-        // the strict upper triangle of D_i is read as zero by the chain steps
-        for (int q = tid; q < W * 105; q += KC_THREADS) {
-            const int i = q / 105, w = q - 105 * i;
-            const int r = wr30[w], c = wj[w];               // pair (r + 1, c) with c <= r  ->  entry [c][r + 1] above the diagonal
-            Blk[(size_t)i * KC_BLK + c * KC_RS + (r + 1)] = 0.0;
+        for (int q0 = tid; q0 < gtotal; q0 += KB * KC_THREADS) {
+            double gb[KB][5];
+            gather_load(src, q0, gb);
+            gather_store(q0, gb, mu);
         }
     }
+    // the strict upper triangle of D_i is read as zero by the chain steps
+    for (int q = tid; q < W * 105; q += KC_THREADS) {
+        const int i = q / 105, w = q - 105 * i;
+        const int r = wr30[w], c = wj[w];               // pair (r + 1, c) with c <= r  ->  entry [c][r + 1] above the diagonal
+        Blk[(size_t)i * KC_BLK + c * KC_RS + (r + 1)] = 0.0;
+    }
     for (int q = tid; q < W * 15; q += KC_THREADS) { const int i = q / 15, j = q - 15 * i; Blk[(size_t)i * KC_BLK + 30 * KC_RS + j] = Rld(nd + 15 * i + j); }
-    __syncthreads();
+    GLIO_BLOCK_LDS_SYNC();
     AR_STAMP(45);
     for (int row = tid; row < np15 + nd; row += KC_THREADS) {
         double acc = 0.0;
@@ -2099,24 +2319,27 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
             for (int tt = eoff[i]; tt < eoff[i + 1]; ++tt) {
                 const int e = elist[tt];
                 const int side = eps[e].x == i ? 0 : 15;
-                acc += (Vs[e * 30 + side + r] / rd[e]) * wd[e];
+                acc += Vs[e * 30 + side + r] * wdr[e];
             }
-            V_T(tr)[row] = acc / s_row;
+            { const double tv = acc / s_row; V_T(tr)[row] = tv; sT[row] = tv; }
         } else {
             const int e = row - np15;
             const int2 sl = eps[e];
             const double se = s_row;
             acc = se * dds[e * 15 + 12] * se * wd[e];
             if (sl.x >= 0) {
+                const double ire = 1.0 / rd[e];             // one division per epoch, not one per entry
 #pragma unroll
-                for (int q = 0; q < 30; ++q) acc += (Vs[e * 30 + q] / rd[e]) * zb[15 * (q < 15 ? sl.x : sl.y) + (q < 15 ? q : q - 15)];
+                for (int q = 0; q < 30; ++q) acc += (Vs[e * 30 + q] * ire) * zb[15 * (q < 15 ? sl.x : sl.y) + (q < 15 ? q : q - 15)];
             }
-            V_T(tr)[row] = acc / se;
+            { const double tv = acc / se; V_T(tr)[row] = tv; sT[row] = tv; }
         }
     }
-    __syncthreads();
+    AR_STAMP(94);
+    GLIO_BLOCK_LDS_SYNC();
     AR_STAMP(46);
     if (tid == 0) { int na = 0; for (int q = 0; q < 15; ++q) if (rowmask >> q & 1) misc[2 + na++] = q; misc[1] = na; }
+    AR_STAMP(95);
     for (int i = wv; i < W; i += KC_THREADS / 64)
         for (int t = eoff[i] + lane; t < eoff[i + 1]; t += 64) {
             const int e = elist[t];
@@ -2125,9 +2348,12 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
             esd[t] = e * 30 + side;
             eoth[t] = (sl.x == i ? sl.y : sl.x) == i + 1 ? e * 30 + (15 - side) : -1;
         }
-    __syncthreads();
-    {
-        const int na = misc[1];
+    GLIO_BLOCK_LDS_SYNC();
+    AR_STAMP(96);
+    // (the usual row set -- position and velocity, six rows -- as a compile-time constant: the index arithmetic of an item is five divisions
+    // by na and per, ~150 instructions with run-time divisors)
+    auto corrections = [&](const auto na_c) {
+        const int na = na_c;
         const int per = 2 * na * na + na;
         for (int item = tid; item < W * per; item += KC_THREADS) {
             const int i = item / per, w = item - i * per;
@@ -2160,9 +2386,10 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
             }
             *dst = v;
         }
-    }
+    };
+    if (misc[1] == 6) corrections(std::integral_constant<int, 6>{}); else corrections(misc[1]);
     if (tid < 2) s_prog[tid] = 0;
-    __syncthreads();
+    GLIO_BLOCK_LDS_SYNC();
     AR_STAMP(47);
     // the chain from both ends
     const int mid = W / 2, nT = mid, nB = W - 1 - mid, Tn = nT > nB ? nT : nB;
@@ -2176,33 +2403,47 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
     }
     bool bad = false;
     long long ph[5] = {0, 0, 0, 0, 0};
+    // back substitution of the middle keyframe (the one block whose triangular solve is on the critical path)
+    auto back = [&](const int i, const int nbr) {
+        const double* Bi = Blk + (size_t)i * KC_BLK;
+        const int ln = lane < KC_NB ? lane : 0;
+        double lcol[KC_NB], bcol[KC_NB];
+#pragma unroll
+        for (int k = 0; k < KC_NB; ++k) { lcol[k] = Bi[k * KC_RS + ln]; bcol[k] = Bi[(KC_NB + k) * KC_RS + ln]; }
+        const double rp = lane < KC_NB ? Bi[31 * KC_RS + lane] : 1.0;
+        double v = lane < KC_NB ? Bi[30 * KC_RS + lane] : 0.0;
+        if (nbr >= 0) {
+            double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+            for (int k = 0; k < KC_NB; k += 3) { s0 += bcol[k] * zb[15 * nbr + k]; s1 += bcol[k + 1] * zb[15 * nbr + k + 1]; s2 += bcol[k + 2] * zb[15 * nbr + k + 2]; }
+            v -= (s0 + s1) + s2;
+        }
+#pragma unroll
+        for (int k = KC_NB - 1; k >= 0; --k) {
+            const double zk = readlane_d(v, k) * readlane_d(rp, k);
+            if (lane == k) v = zk;
+            else if (lane < k) v -= lcol[k] * zk;
+        }
+        if (lane < KC_NB) zb[15 * i + lane] = v;
+        GLIO_WAVE_LDS_SYNC();
+    };
+
     // The two fronts run WITHOUT workgroup barriers between their steps (they meet only at the middle keyframe); each publishes
     // its progress in LDS, and the wavefronts that prepare the factored blocks for the back substitution (on the two SIMDs the
-    // fronts do not issue on) follow it by polling.
+    // fronts do not issue on) follow it by polling.  (Workgroup-scope atomics on the __shared__ words: ds_write / ds_read.  A cast to
+    // `volatile int*` drops the address space -- the accesses became FLAT, system scope, each followed by s_waitcnt vmcnt(0).)
     if (wv == 0) {
         for (int it = 0; it < nT; ++it) {
             chain_step15<false>(it, it + 1, true, av, Blk, CsT, lane, bad, ph);
-            if (lane == 0) *reinterpret_cast<volatile int*>(&s_prog[0]) = it + 1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            if (lane == 0) __hip_atomic_store(&s_prog[0], it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-    } else if (wv == 2) {
-        for (int it = 0; it < nB; ++it) {
-            const int i = W - 1 - it;
-            chain_step15<true>(i, i - 1, true, av, Blk, CsB, lane, bad);
-            if (lane == 0) *reinterpret_cast<volatile int*>(&s_prog[1]) = it + 1;
-        }
-    } else if (wv == 1) {
-        for (int k = 0; k < nT; ++k) {
-            while (*reinterpret_cast<volatile int*>(&s_prog[0]) < k + 1) __builtin_amdgcn_s_sleep(2);
-            chain_prepare_back(Blk + (size_t)k * KC_BLK, lane);
-        }
-    } else if (wv == 3) {
-        for (int k = 0; k < nB; ++k) {
-            while (*reinterpret_cast<volatile int*>(&s_prog[1]) < k + 1) __builtin_amdgcn_s_sleep(2);
-            chain_prepare_back(Blk + (size_t)(W - 1 - k) * KC_BLK, lane);
-        }
-    }
-    __syncthreads();
-    if (wv == 0) {
+        // the middle keyframe as soon as the other front has arrived (its last update sits in CsB): no workgroup barrier here, the wavefronts
+        // that prepare the back substitution finish their last blocks while this step runs
+        AR_STAMP(100);
+        while (__hip_atomic_load(&s_prog[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < nB) __builtin_amdgcn_s_sleep(1);
+        AR_STAMP(101);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         {
             const int row = lane < KC_NB ? lane : 30, crow = lane < KC_NB ? lane : 15;
             const int lim = lane == 30 ? KC_NB : (lane < KC_NB ? lane + 1 : 0);
@@ -2218,38 +2459,38 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
             }
         }
         chain_step15<false>(mid, mid, false, av, Blk, CsT, lane, bad);
+        AR_STAMP(102);
+        back(mid, -1);          // (garbage in, garbage out when a pivot broke down: nobody reads zb then)
+        AR_STAMP(103);
+    } else if (wv == 2) {
+        for (int it = 0; it < nB; ++it) {
+            const int i = W - 1 - it;
+            chain_step15<true>(i, i - 1, true, av, Blk, CsB, lane, bad);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            if (lane == 0) __hip_atomic_store(&s_prog[1], it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    } else if (wv == 1) {
+        for (int k = 0; k < nT; ++k) {
+            while (__hip_atomic_load(&s_prog[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < k + 1) __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            chain_prepare_back(Blk + (size_t)k * KC_BLK, lane);
+        }
+    } else if (wv == 3) {
+        for (int k = 0; k < nB; ++k) {
+            while (__hip_atomic_load(&s_prog[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < k + 1) __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            chain_prepare_back(Blk + (size_t)(W - 1 - k) * KC_BLK, lane);
+        }
     }
-    __syncthreads();
+    GLIO_BLOCK_LDS_SYNC();
     AR_STAMP(48);
 #ifdef GLIO_DEV_STAMPS
     if (tid == 0) for (int k = 0; k < 5; ++k) a.dbg[60 + k] = ph[k];
 #endif
     if ((bad || a.force_fail) && lane == 0) misc[0] = 1;
-    __syncthreads();
+    GLIO_BLOCK_LDS_SYNC();
+    AR_STAMP(97);
     if (!misc[0]) {
-        auto back = [&](const int i, const int nbr) {
-            const double* Bi = Blk + (size_t)i * KC_BLK;
-            const int ln = lane < KC_NB ? lane : 0;
-            double lcol[KC_NB], bcol[KC_NB];
-#pragma unroll
-            for (int k = 0; k < KC_NB; ++k) { lcol[k] = Bi[k * KC_RS + ln]; bcol[k] = Bi[(KC_NB + k) * KC_RS + ln]; }
-            const double rp = lane < KC_NB ? Bi[31 * KC_RS + lane] : 1.0;
-            double v = lane < KC_NB ? Bi[30 * KC_RS + lane] : 0.0;
-            if (nbr >= 0) {
-                double s0 = 0, s1 = 0, s2 = 0;
-#pragma unroll
-                for (int k = 0; k < KC_NB; k += 3) { s0 += bcol[k] * zb[15 * nbr + k]; s1 += bcol[k + 1] * zb[15 * nbr + k + 1]; s2 += bcol[k + 2] * zb[15 * nbr + k + 2]; }
-                v -= (s0 + s1) + s2;
-            }
-#pragma unroll
-            for (int k = KC_NB - 1; k >= 0; --k) {
-                const double zk = readlane_d(v, k) * readlane_d(rp, k);
-                if (lane == k) v = zk;
-                else if (lane < k) v -= lcol[k] * zk;
-            }
-            if (lane < KC_NB) zb[15 * i + lane] = v;
-            GLIO_WAVE_LDS_SYNC();
-        };
         // z_i = w_i - M_i z_neighbour on the blocks chain_prepare_back transformed
         auto back_mv = [&](const int i, const int nbr) {
             const double* Bi = Blk + (size_t)i * KC_BLK;
@@ -2264,11 +2505,11 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
             }
             GLIO_WAVE_LDS_SYNC();
         };
-        if (wv == 0) back(mid, -1);
-        __syncthreads();
         if (wv == 0) { for (int i = mid - 1; i >= 0; --i) back_mv(i, i + 1); }
         else if (wv == 1) { for (int i = mid + 1; i < W; ++i) back_mv(i, i - 1); }
-        __syncthreads();
+        AR_STAMP(98);
+        GLIO_BLOCK_LDS_SYNC();
+        AR_STAMP(99);
         double bd2 = 0.0;
         for (int e = tid; e < nd; e += KC_THREADS) {
             const int2 sl = eps[e];
@@ -2279,17 +2520,109 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
             }
             v *= rd[e];
             a.z[e] = v;
+            wd[e] = v;                  // (the fast tail reads the solution from LDS)
             if (!isfinite(v)) bd2 = 1.0;
         }
         for (int k = tid; k < 15 * W; k += KC_THREADS) { const double v = zb[k]; a.z[nd + k] = v; if (!isfinite(v)) bd2 = 1.0; }
         if (bd2 != 0.0) misc[0] = 1;
-        __syncthreads();
+        GLIO_BLOCK_LDS_SYNC();
     }
+    fast_tail = (a.fast & 1) && !misc[0];
     if (tid == 0) { *a.flag = misc[0] ? 1 : 2; }
-    __threadfence();
-    __syncthreads();
+    if (fast_tail) GLIO_BLOCK_LDS_SYNC(); else { __threadfence(); __syncthreads(); }      // (the generic tail reads t, z and the record back from global memory)
     AR_STAMP(49);
     }   // !dec.reuse
+    if (fast_tail) {
+        // ---- tr_factor_body (structured solve succeeded) + tr_dogleg_body on the LDS copies: the same arithmetic on the same numbers in the same
+        // order (thread i takes entry i, the sums go through block_sum_n), without the ~8 global round trips the generic bodies make through
+        // the work vectors.  The vectors and the status record are still WRITTEN to global memory (a rejected step re-enters through the
+        // generic dogleg body in the next launch), just not read back here.
+        double* red = CsT;                                     // 8 x 8 doubles
+        double* sW = Blk;                                      // the step (the chain blocks are dead)
+        const SolverStatus& s0 = s_full;
+        double p = 0, q2 = 0, gg = 0, nn = 0, gd = 0;
+        for (int i = tid; i < n; i += TR_THREADS) {
+            const double gr = sGr[i];
+            const double ui = sS[i] * gr / sDg[i];
+            p += ui * sT[i]; q2 += gr * gr;
+            const double yi = i < np15 ? zb[i] : wd[i - np15];
+            const double gni = -sDg[i] * yi;
+            V_Y(tr)[i] = yi; V_GN(tr)[i] = gni;
+            gg += gr * gr; nn += gni * gni; gd += gr * gni;
+        }
+        { double v5[5] = {p, q2, gg, nn, gd}; block_sum_n<5, true>(v5, red); p = v5[0]; q2 = v5[1]; gg = v5[2]; nn = v5[3]; gd = v5[4]; }
+        AR_STAMP(70);
+        const double alpha = q2 / p;
+        const double gnorm = sqrt(gg), gnn = sqrt(nn), radius = s0.radius;
+        double ca, cb, snorm;       // step (D-space) = ca * grad + cb * gn
+        if (tr.lm) { ca = 0.0; cb = 1.0; snorm = gnn; }
+        else if (gnn <= radius) { ca = 0.0; cb = 1.0; snorm = gnn; }
+        else if (gnorm * alpha >= radius) { ca = -(radius / gnorm); cb = 0.0; snorm = radius; }
+        else {
+            const double b_dot_a = -alpha * gd;
+            const double a_sq = alpha * alpha * gg;
+            const double b_minus_a_sq = nn - 2 * b_dot_a + a_sq;
+            const double c = b_dot_a - a_sq;
+            const double d = sqrt(c * c + b_minus_a_sq * (radius * radius - a_sq));
+            const double beta = (c <= 0) ? (d - c) / b_minus_a_sq : (radius * radius - a_sq) / (d + c);
+            ca = -alpha * (1.0 - beta); cb = beta; snorm = -1.0;
+        }
+        const double mu_u = s0.mu;                             // the factorisation succeeded with the record's mu: mu_used = mu
+        double sn2 = 0, lin = 0, quad = 0;
+        for (int i = tid; i < n; i += TR_THREADS) {
+            const double yi = i < np15 ? zb[i] : wd[i - np15];
+            const double gni = -sDg[i] * yi;
+            const double sv = ca * sGr[i] + cb * gni;
+            sn2 += sv * sv;
+            const double step_s = sv / sDg[i];
+            const double wi = sS[i] * step_s;
+            V_W(tr)[i] = wi; sW[i] = wi;
+            const double gs = sS[i] * sG[i];
+            const double hs_step = ca * (sS[i] * sT[i]) - cb * (gs - mu_u * sDg[i] * sDg[i] * yi);
+            lin += gs * step_s;
+            quad += step_s * hs_step;
+        }
+        AR_STAMP(71);
+        { double v3[3] = {sn2, lin, quad}; block_sum_n<3, true>(v3, red + 40); sn2 = v3[0]; lin = v3[1]; quad = v3[2]; }
+        AR_STAMP(72);
+        if (snorm < 0) snorm = sqrt(sn2);
+        const double mcc = -(lin + 0.5 * quad);
+        const bool valid = mcc > 0.0;                          // (lin_fail = 0: the linear solve succeeded)
+        bool ended = false;
+        SolverStatus sn = s0;                                  // registers; thread 0's copy is the one written back
+        sn.alpha = alpha; sn.mu_used = mu_u; sn.lin_fail = 0;
+        sn.dogleg_step_norm = snorm;
+        if (!valid) {
+            sn.invalid += 1;
+            if (sn.invalid >= 5) { sn.done = 1; sn.termination = GLIO_TERM_FAILURE; ended = true; }
+            if (tr.lm) { sn.radius /= sn.decrease_factor; sn.decrease_factor *= 2.0; }
+            else sn.mu *= 10.0;
+            sn.reuse = 0;
+            sn.cand_pending = 0;
+        } else {
+            sn.invalid = 0;
+            sn.model_cost_change = mcc;
+            sn.cand_pending = 1;
+        }
+        if (ended) { __syncthreads(); finalize(tr, sn); AR_STAMP(50); AR_STAMP(51); return; }
+        if (valid) {        // candidate = x (+) delta into the other buffer
+            double* xn = sn.cur ? tr.x0 : tr.x1;
+            for (int k = tid; k < 3 * W; k += TR_THREADS) { const int sl = k / 3, c = k % 3; xn[k] = sX[k] + sW[15 * sl + c]; }
+            if (tid >= TR_THREADS - 64) for (int sl = tid - (TR_THREADS - 64); sl < W; sl += 64) {      // (the last wavefront: beside the others' sums, not after them)
+                double q[4], qn[4];
+                const double d[3] = {sW[15 * sl + 3], sW[15 * sl + 4], sW[15 * sl + 5]};
+                for (int c = 0; c < 4; ++c) q[c] = sX[3 * W + 4 * sl + c];
+                d_quat_plus(q, d, qn);
+                for (int c = 0; c < 4; ++c) xn[3 * W + 4 * sl + c] = qn[c];
+            }
+            for (int k = tid; k < 9 * W; k += TR_THREADS) { const int sl = k / 9, c = k % 9; xn[7 * W + k] = sX[7 * W + k] + sW[15 * sl + 6 + c]; }
+            for (int k = tid; k < tr.n_ddt; k += TR_THREADS) xn[16 * W + k] = sX[16 * W + k] + sW[15 * W + k];
+        }
+        AR_STAMP(73);
+        if (tid == 0) *tr.status = sn;
+        AR_STAMP(50); AR_STAMP(51);
+        return;
+    }
     // ---- the linear solve's result (or the dense fallback) and the dogleg step, as k_tr_finish
     ChainBuilder cb;
     cb.G = &G; cb.T = &T; cb.cur = dec.cur;
@@ -2351,6 +2684,15 @@ int glio_solver_path(const glio_ctx* c, int n_ddt) {
 // the linearisation must also build the dense H (k_assemble) unless the step is k_chain_step
 int glio_solver_needs_dense_H(const glio_ctx* c, int n_ddt) { return !(glio_solver_path(c, n_ddt) == 2 && c->arrow.mode != 3); }
 
+// GLIO_CHAIN_FAST (bit 0: tail, bit 1: front of k_chain_step from LDS; default both).  0 = the generic bodies: the A/B switch of
+// scripts/chain_step_time.py and of test_chain_step_fast_paths_are_bit_identical.
+static int g_chain_fast = -1;
+extern "C" int glio_debug_chain_fast(int mask) { const int old = g_chain_fast; g_chain_fast = mask; return old; }
+static int chain_fast_mask() {
+    if (g_chain_fast < 0) { const char* e = getenv("GLIO_CHAIN_FAST"); g_chain_fast = e ? atoi(e) & 3 : 3; }
+    return g_chain_fast;
+}
+
 void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
     TrArgs a;
     a.W = c->W; a.n = 15 * c->W + n_ddt; a.n_ddt = n_ddt; a.max_iterations = c->opts.max_iterations;
@@ -2389,7 +2731,7 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
     if (chain) {
         ChainArgs r;
         r.W = c->W; r.n = a.n; r.nd = n_ddt; r.ep_slots = c->arrow.d_ep_slots; r.ep_off = c->arrow.d_ep_off; r.ep_list = c->arrow.d_ep_list;
-        r.z = c->arrow.d_z; r.flag = c->arrow.d_flag; r.status = c->d_status; r.dbg = c->arrow.d_dbg; r.force_fail = c->arrow.mode == 2;
+        r.z = c->arrow.d_z; r.flag = c->arrow.d_flag; r.status = c->d_status; r.dbg = c->arrow.d_dbg; r.force_fail = c->arrow.mode == 2; r.fast = chain_fast_mask();
         if (!legacy_chain) {
             GatherArgs G;
             G.lidar_partials = c->d_lidar_partials; G.lidar_pstride = glio_partials_stride(c); G.lidar_nb = c->last_k3_nb;

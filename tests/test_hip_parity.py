@@ -391,24 +391,49 @@ def test_chain_step_is_bit_identical_to_the_assembled_sequence(hip, steady_windo
     order, so the one-launch step must reproduce the legacy sequence [k_assemble, k_chain_solve, k_tr_finish] bit for bit:
     states, iteration history, costs -- here over repeated solves and after a re-linearisation through glio_linearize."""
     win, corr = steady_window
+    import copy
     out = []
-    for mode in (3, 1):
-        ctx = hip.Context(win.opts)
-        hip.load().glio_debug_set_solver(ctx._h, mode)
-        ctx.load_window(win, corr, use_gnss=use_gnss)
-        st = _state_for(win, use_gnss)
-        runs = []
-        for k in range(3):
-            s, m = ctx.solve(st)
-            runs.append((s.trans.tobytes(), s.quat.tobytes(), s.speed_bias.tobytes(), s.rcv_ddt[:s.n_ddt].tobytes(), m.iterations, m.successful_steps,
-                         m.termination, m.initial_cost, m.final_cost, m.final_radius, m.gradient_max_norm))
-            if k == 0:
-                ctx.linearize(st)            # the dense assembly in between must not disturb the block-fed step
-        assert hip.load().glio_debug_solver_path(ctx._h) == 2
-        out.append(runs)
-        ctx.close()
+    lib = hip.load()
+    # a second set of options under which most steps are REJECTED (the relative decrease of this nearly quadratic problem sits at 1): the
+    # rejected-step branches of the state machine, the stored Gauss-Newton / Cauchy vectors reused with the halved radius
+    opts2 = copy.copy(win.opts)
+    opts2.min_relative_decrease = 1.05 if use_gnss else 1.0
+    opts2.max_iterations = 30
+    far = _state_for(win, use_gnss)
+    far.trans = far.trans + np.random.default_rng(5).normal(0, 0.4, far.trans.shape)
+    far.speed_bias = far.speed_bias + np.random.default_rng(6).normal(0, 0.2, far.speed_bias.shape)
+    key = lambda s, m: (s.trans.tobytes(), s.quat.tobytes(), s.speed_bias.tobytes(), s.rcv_ddt[:s.n_ddt].tobytes(), m.iterations, m.successful_steps,
+                        m.termination, m.initial_cost, m.final_cost, m.final_radius, m.gradient_max_norm)
+    # (solver mode, GLIO_CHAIN_FAST mask): the legacy sequence, then k_chain_step with its generic bodies (0), with the tail (1), the front (2)
+    # and both (3, the default) running from the LDS copies instead of the global work vectors
+    try:
+        for mode, fast in ((3, 3), (1, 0), (1, 1), (1, 2), (1, 3)):
+            lib.glio_debug_chain_fast(fast)
+            ctx = hip.Context(win.opts)
+            lib.glio_debug_set_solver(ctx._h, mode)
+            ctx.load_window(win, corr, use_gnss=use_gnss)
+            st = _state_for(win, use_gnss)
+            runs = []
+            for k in range(3):
+                runs.append(key(*ctx.solve(st)))
+                if k == 0:
+                    ctx.linearize(st)            # the dense assembly in between must not disturb the block-fed step
+            assert lib.glio_debug_solver_path(ctx._h) == 2
+            ctx.close()
+            ctx = hip.Context(opts2)
+            lib.glio_debug_set_solver(ctx._h, mode)
+            ctx.load_window(win, corr, use_gnss=use_gnss)
+            s, m = ctx.solve(far)
+            assert lib.glio_debug_solver_path(ctx._h) == 2
+            assert m.iterations - m.successful_steps >= 10, "this run is meant to consist mostly of rejected steps"
+            runs.append(key(s, m))
+            ctx.close()
+            out.append(runs)
+    finally:
+        lib.glio_debug_chain_fast(3)
     assert out[0][0] == out[0][1] == out[0][2]
-    assert out[1] == out[0]
+    for k in range(1, len(out)):
+        assert out[k] == out[0], k
 
 
 def test_dense_gnss_pairs_cross_the_chunk_boundaries(hip, po):
