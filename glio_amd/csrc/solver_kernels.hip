@@ -2295,6 +2295,8 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
     for (int q = tid; q < W * 15; q += KC_THREADS) { const int i = q / 15, j = q - 15 * i; Blk[(size_t)i * KC_BLK + 30 * KC_RS + j] = Rld(nd + 15 * i + j); }
     GLIO_BLOCK_LDS_SYNC();
     AR_STAMP(45);
+    // (the list of rows with an epoch coupling, for the corrections below: by the last thread, which has no row of t when n < 512)
+    if (tid == KC_THREADS - 1) { int na = 0; for (int q = 0; q < 15; ++q) if (rowmask >> q & 1) misc[2 + na++] = q; misc[1] = na; }
     for (int row = tid; row < np15 + nd; row += KC_THREADS) {
         double acc = 0.0;
         const double s_row = sS[row], d_row = sDg[row];
@@ -2316,10 +2318,20 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
 #pragma unroll
                 for (int j = 0; j < KC_NB; ++j) acc += Bp[(KC_NB + r) * KC_RS + j] * zb[15 * (i - 1) + j];
             }
-            for (int tt = eoff[i]; tt < eoff[i + 1]; ++tt) {
-                const int e = elist[tt];
-                const int side = eps[e].x == i ? 0 : 15;
-                acc += Vs[e * 30 + side + r] * wdr[e];
+            // the epochs of this keyframe, eight at a time: the list entries, then their slot pairs, then the operands go out as three
+            // batches of independent LDS reads (one after the other they are three dependent round trips PER EPOCH); added in list order
+            const int t0e = eoff[i], t1e = eoff[i + 1];
+            for (int tb = t0e; tb < t1e; tb += 8) {
+                int ee[8], sd[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ee[q] = elist[tb + q < t1e ? tb + q : t1e - 1];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) sd[q] = eps[ee[q]].x == i ? 0 : 15;
+                double xv[8], xw[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { xv[q] = Vs[ee[q] * 30 + sd[q] + r]; xw[q] = wdr[ee[q]]; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc = tb + q < t1e ? acc + xv[q] * xw[q] : acc;
             }
             { const double tv = acc / s_row; V_T(tr)[row] = tv; sT[row] = tv; }
         } else {
@@ -2338,8 +2350,10 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
     AR_STAMP(94);
     GLIO_BLOCK_LDS_SYNC();
     AR_STAMP(46);
-    if (tid == 0) { int na = 0; for (int q = 0; q < 15; ++q) if (rowmask >> q & 1) misc[2 + na++] = q; misc[1] = na; }
     AR_STAMP(95);
+    // Minus the epochs' contribution D_i -= V V^T, B_i -= V' V^T, rhs_i -= y V over the epochs touching keyframe i, in list order.
+    // (Measured without gain: KC_THREADS / W threads per keyframe that read the keyframe's epoch list once into registers and then take
+    // their share of its entries -- the phase is bound by the ~1000 wavefront-level LDS reads of the operands, not by the index chains.)
     for (int i = wv; i < W; i += KC_THREADS / 64)
         for (int t = eoff[i] + lane; t < eoff[i + 1]; t += 64) {
             const int e = elist[t];
