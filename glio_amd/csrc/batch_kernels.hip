@@ -34,26 +34,25 @@ __device__ __forceinline__ int gram_idx(int i, int j) {       // packed upper tr
 // value-splitting butterfly over 64 values: lane L ends with the wave-wide sum of value
 // k = b5 + 2 b4 + 4 b3 + 8 b2 + 16 b1 + 32 b0 (b_i = bit i of L); 63 shuffles
 __device__ __forceinline__ double butterfly64(const double (&in)[64], int lane, int* k_out) {
+    // (exchanges through V_PERMLANE32/16_SWAP and DPP instead of ds_bpermute: glio_device.h, "Cross-lane exchange"; same sums)
     double v32[32], v16[16], v8[8], v4[4], v2[2];
-    { const bool hi = (lane & 32) != 0;
 #pragma unroll
-      for (int i = 0; i < 32; ++i) { const double keep = hi ? in[2 * i + 1] : in[2 * i], send = hi ? in[2 * i] : in[2 * i + 1]; v32[i] = keep + __shfl_xor(send, 32, 64); } }
-    { const bool hi = (lane & 16) != 0;
+    for (int i = 0; i < 32; ++i) { double x, y; lane_swap32(in[2 * i], in[2 * i + 1], x, y); v32[i] = x + y; }
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { const double keep = hi ? v32[2 * i + 1] : v32[2 * i], send = hi ? v32[2 * i] : v32[2 * i + 1]; v16[i] = keep + __shfl_xor(send, 16, 64); } }
+    for (int i = 0; i < 16; ++i) { double x, y; lane_swap16(v32[2 * i], v32[2 * i + 1], x, y); v16[i] = x + y; }
     { const bool hi = (lane & 8) != 0;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { const double keep = hi ? v16[2 * i + 1] : v16[2 * i], send = hi ? v16[2 * i] : v16[2 * i + 1]; v8[i] = keep + __shfl_xor(send, 8, 64); } }
+      for (int i = 0; i < 8; ++i) { const double keep = hi ? v16[2 * i + 1] : v16[2 * i], send = hi ? v16[2 * i] : v16[2 * i + 1]; v8[i] = keep + lane_xor_row_d<8>(send); } }
     { const bool hi = (lane & 4) != 0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const double keep = hi ? v8[2 * i + 1] : v8[2 * i], send = hi ? v8[2 * i] : v8[2 * i + 1]; v4[i] = keep + __shfl_xor(send, 4, 64); } }
+      for (int i = 0; i < 4; ++i) { const double keep = hi ? v8[2 * i + 1] : v8[2 * i], send = hi ? v8[2 * i] : v8[2 * i + 1]; v4[i] = keep + lane_xor_row_d<4>(send); } }
     { const bool hi = (lane & 2) != 0;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) { const double keep = hi ? v4[2 * i + 1] : v4[2 * i], send = hi ? v4[2 * i] : v4[2 * i + 1]; v2[i] = keep + __shfl_xor(send, 2, 64); } }
+      for (int i = 0; i < 2; ++i) { const double keep = hi ? v4[2 * i + 1] : v4[2 * i], send = hi ? v4[2 * i] : v4[2 * i + 1]; v2[i] = keep + lane_xor_row_d<2>(send); } }
     const bool hi = (lane & 1) != 0;
     const double keep = hi ? v2[1] : v2[0], send = hi ? v2[0] : v2[1];
     *k_out = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 3) | (((lane >> 1) & 1) << 4) | ((lane & 1) << 5);
-    return keep + __shfl_xor(send, 1, 64);
+    return keep + lane_xor_row_d<1>(send);
 }
 
 __device__ __forceinline__ double uniform_d(const double v) {

@@ -373,7 +373,7 @@ __global__ __launch_bounds__(BT_NORM_THREADS) void k_bt_norms(const BtBufs a, co
     }
     // the lanes of a wavefront are added lane by lane in a fixed tree; workgroups in index order
     d2 = wave_sum(d2); x2 = wave_sum(x2);
-    for (int off = 32; off > 0; off >>= 1) gm = fmax(gm, __shfl_xor(gm, off, 64));
+    gm = wave_max(gm);
     if (threadIdx.x == 0) { np.parts[3 * blockIdx.x] = d2; np.parts[3 * blockIdx.x + 1] = x2; np.parts[3 * blockIdx.x + 2] = gm; }
     __threadfence();
     if (threadIdx.x == 0) s_last = atomicAdd(np.ticket, 1u) == gridDim.x - 1;
@@ -521,8 +521,8 @@ __global__ __launch_bounds__(64) void k_bt_matvec(const BtBufs a, const int solv
                 for (int c = 0; c < 6; ++c) { s0 += hv[c] * xs[0][kbi * B + c]; s1 += hv[c] * xs[1][kbi * B + c]; }
             }
         }
-        s0 += __shfl_xor(s0, 8, 64); s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
-        s1 += __shfl_xor(s1, 8, 64); s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+        s0 = lane_xor_sum<8>(s0); s0 = lane_xor_sum<16>(s0); s0 = lane_xor_sum<32>(s0);
+        s1 = lane_xor_sum<8>(s1); s1 = lane_xor_sum<16>(s1); s1 = lane_xor_sum<32>(s1);
         if (lane < 8) { ys[0][lane] = s0; ys[1][lane] = s1; }
     }
     double t0 = 0, t1 = 0;
@@ -544,8 +544,8 @@ __global__ __launch_bounds__(64) void k_bt_matvec(const BtBufs a, const int solv
                 if (eb) { t0 += hb[u] * xs[0][ib]; t1 += hb[u] * xs[1][ib]; }
             }
         }
-        t0 += __shfl_xor(t0, 16, 64); t0 += __shfl_xor(t0, 32, 64);
-        t1 += __shfl_xor(t1, 16, 64); t1 += __shfl_xor(t1, 32, 64);
+        t0 = lane_xor_sum<16>(t0); t0 = lane_xor_sum<32>(t0);
+        t1 = lane_xor_sum<16>(t1); t1 = lane_xor_sum<32>(t1);
     }
     __syncthreads();
     if (lane < B) {

@@ -320,7 +320,63 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
+// ------------------------------------------------------------------------------------------------
+// Cross-lane exchange for the xor butterflies WITHOUT the LDS crossbar.  __shfl_xor compiles to ds_bpermute_b32 (two per double, ~100+
+// cycles of latency each, dependent from stage to stage): a six-stage butterfly costs ~0.4 us, and it ends every workgroup of the K3
+// linearisation and every block reduction of the single-workgroup solver kernels.  gfx950 has V_PERMLANE32_SWAP / V_PERMLANE16_SWAP for the
+// two stages that cross 16-lane rows, and DPP (row_ror:8, row_shl/shr:4 under bank masks, quad_perm) covers xor 8, 4, 2, 1 inside a row.
+// The values that meet are the same as with __shfl_xor, so every sum below is bit-identical to the shuffle form it replaces.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned glio_v2u __attribute__((ext_vector_type(2)));
+// One swap per 32-bit half: afterwards x holds, in lanes with bit 5 (resp. 4) CLEAR, a of the lane itself and, in lanes with it SET, b of
+// the partner lane; y holds a of the partner resp. b of the lane itself.  x + y is a whole reduce-scatter step of a value-splitting
+// butterfly (lanes with the bit clear end with a_own + a_partner, the others with b_partner + b_own) without a single select.
+__device__ __forceinline__ void lane_swap32(const double a, const double b, double& x, double& y) {
+    const glio_v2u lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const glio_v2u hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    x = __hiloint2double((int)hi.x, (int)lo.x); y = __hiloint2double((int)hi.y, (int)lo.y);
+}
+__device__ __forceinline__ void lane_swap16(const double a, const double b, double& x, double& y) {
+    const glio_v2u lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const glio_v2u hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    x = __hiloint2double((int)hi.x, (int)lo.x); y = __hiloint2double((int)hi.y, (int)lo.y);
+}
+// value of lane (i ^ OFF) for OFF = 8, 4, 2, 1 (inside a 16-lane row): DPP moves
+template <int OFF> __device__ __forceinline__ int lane_xor_row_i(const int v) {
+    static_assert(OFF == 8 || OFF == 4 || OFF == 2 || OFF == 1, "row-local xor distances");
+    if (OFF == 8) return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false);                 // row_ror:8
+    if (OFF == 4) {
+        const int p = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xF, 0x5, false);                    // row_shl:4 into lanes 0-3, 8-11 (from i + 4)
+        return __builtin_amdgcn_update_dpp(p, v, 0x114, 0xF, 0xA, false);                           // row_shr:4 into lanes 4-7, 12-15 (from i - 4)
+    }
+    if (OFF == 2) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);                  // quad_perm:[2,3,0,1]
+    return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);                                // quad_perm:[1,0,3,2]
+}
+template <int OFF> __device__ __forceinline__ double lane_xor_row_d(const double v) {
+    return __hiloint2double(lane_xor_row_i<OFF>(__double2hiint(v)), lane_xor_row_i<OFF>(__double2loint(v)));
+}
+// v of this lane + v of lane (i ^ OFF): one butterfly stage, any distance
+template <int OFF> __device__ __forceinline__ double lane_xor_sum(const double v) {
+    if (OFF == 32) { double x, y; lane_swap32(v, v, x, y); return x + y; }
+    else if (OFF == 16) { double x, y; lane_swap16(v, v, x, y); return x + y; }
+    else return v + lane_xor_row_d<(OFF == 32 || OFF == 16) ? 1 : OFF>(v);
+}
+// the six-stage xor butterfly (distances 32, 16, 8, 4, 2, 1 in this order) with an associative, commutative op: every lane ends with the
+// same value, the one the __shfl_xor loop `for (off = 32; off > 0; off >>= 1) v = op(v, __shfl_xor(v, off))` produces
+template <class Op> __device__ __forceinline__ double wave_butterfly_d(double v, const Op op) {
+    double x, y;
+    lane_swap32(v, v, x, y); v = op(x, y);
+    lane_swap16(v, v, x, y); v = op(x, y);
+    v = op(v, lane_xor_row_d<8>(v));
+    v = op(v, lane_xor_row_d<4>(v));
+    v = op(v, lane_xor_row_d<2>(v));
+    v = op(v, lane_xor_row_d<1>(v));
+    return v;
+}
+__device__ __forceinline__ double wave_sum(const double v) { return wave_butterfly_d(v, [](const double a, const double b) { return a + b; }); }
+__device__ __forceinline__ double wave_max(const double v) { return wave_butterfly_d(v, [](const double a, const double b) { return fmax(a, b); }); }
+// the shuffle forms, kept for the bit-for-bit check of the above (glio_debug_wave_reduce_check)
+__device__ __forceinline__ double wave_sum_shfl(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;

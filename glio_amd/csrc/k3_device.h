@@ -65,30 +65,28 @@ __device__ __forceinline__ void k3_reduce_store(const double acc[GLIO_LIDAR_ACC]
     // accumulator k = b5 + 2 b4 + 4 b3 + 8 b2 + 16 b1 (b_i = bit i of L); the xor-1 round completes the sum.
     __shared__ double red[GLIO_K3_THREADS / GLIO_WAVE][32];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // (the exchanges go through V_PERMLANE32/16_SWAP and DPP, not through ds_bpermute: glio_device.h, "Cross-lane exchange".  The two swap
+    // stages need no keep / send selects at all: swapping a's upper half with b's lower half IS the reduce-scatter step.)
     double v16[16], v8[8], v4[4], v2[2], v1;
-    {
-        const bool hi = (lane & 32) != 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const double a = acc[2 * i], b = (2 * i + 1 < GLIO_LIDAR_ACC) ? acc[2 * i + 1] : 0.0;
-            const double keep = hi ? b : a, send = hi ? a : b;
-            v16[i] = keep + __shfl_xor(send, 32, 64);
-        }
+    for (int i = 0; i < 16; ++i) {
+        const double a = acc[2 * i], b = (2 * i + 1 < GLIO_LIDAR_ACC) ? acc[2 * i + 1] : 0.0;
+        double x, y;
+        lane_swap32(a, b, x, y);
+        v16[i] = x + y;
     }
-    {
-        const bool hi = (lane & 16) != 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const double keep = hi ? v16[2 * i + 1] : v16[2 * i], send = hi ? v16[2 * i] : v16[2 * i + 1];
-            v8[i] = keep + __shfl_xor(send, 16, 64);
-        }
+    for (int i = 0; i < 8; ++i) {
+        double x, y;
+        lane_swap16(v16[2 * i], v16[2 * i + 1], x, y);
+        v8[i] = x + y;
     }
     {
         const bool hi = (lane & 8) != 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const double keep = hi ? v8[2 * i + 1] : v8[2 * i], send = hi ? v8[2 * i] : v8[2 * i + 1];
-            v4[i] = keep + __shfl_xor(send, 8, 64);
+            v4[i] = keep + lane_xor_row_d<8>(send);
         }
     }
     {
@@ -96,15 +94,15 @@ __device__ __forceinline__ void k3_reduce_store(const double acc[GLIO_LIDAR_ACC]
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const double keep = hi ? v4[2 * i + 1] : v4[2 * i], send = hi ? v4[2 * i] : v4[2 * i + 1];
-            v2[i] = keep + __shfl_xor(send, 4, 64);
+            v2[i] = keep + lane_xor_row_d<4>(send);
         }
     }
     {
         const bool hi = (lane & 2) != 0;
         const double keep = hi ? v2[1] : v2[0], send = hi ? v2[0] : v2[1];
-        v1 = keep + __shfl_xor(send, 2, 64);
+        v1 = keep + lane_xor_row_d<2>(send);
     }
-    v1 += __shfl_xor(v1, 1, 64);
+    v1 += lane_xor_row_d<1>(v1);
     if ((lane & 1) == 0) {
         const int k = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 3) | (((lane >> 1) & 1) << 4);
         red[wv][k] = v1;

@@ -131,8 +131,7 @@ __device__ __forceinline__ void block_sum_n(double (&v)[N], double* red) {
 }
 template <bool LB = false>
 __device__ __forceinline__ double block_max(double v, double* red) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    v = wave_max(v);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (LB) GLIO_BLOCK_LDS_SYNC(); else __syncthreads();
     if (lane == 0) red[wv] = v;
@@ -3132,5 +3131,49 @@ extern "C" int glio_debug_chol_time(glio_ctx* c, int n, int reps, int skip, floa
     }
     hipFree(d_src);
     *ms_out = total / reps;
+    return GLIO_OK;
+}
+
+// ---- test hook: the DPP / permlane-swap exchanges of glio_device.h against the __shfl_xor forms they replace, bit for bit.
+// One wavefront; in[64 * rounds]; returns the number of mismatching (lane, check) pairs.
+__global__ __launch_bounds__(64) void k_wave_reduce_check(const double* in, int rounds, int* bad) {
+    const int lane = threadIdx.x;
+    int nbad = 0;
+    auto same = [](const double a, const double b) { return __double_as_longlong(a) == __double_as_longlong(b); };
+    for (int r = 0; r < rounds; ++r) {
+        const double v = in[64 * r + lane], w = in[64 * ((r + 1) % rounds) + lane];
+        nbad += !same(wave_sum(v), wave_sum_shfl(v));
+        { double m = fabs(v); for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64)); nbad += !same(wave_max(fabs(v)), m); }
+        nbad += !same(lane_xor_sum<32>(v), v + __shfl_xor(v, 32, 64));
+        nbad += !same(lane_xor_sum<16>(v), v + __shfl_xor(v, 16, 64));
+        nbad += !same(lane_xor_sum<8>(v), v + __shfl_xor(v, 8, 64));
+        nbad += !same(lane_xor_sum<4>(v), v + __shfl_xor(v, 4, 64));
+        nbad += !same(lane_xor_sum<2>(v), v + __shfl_xor(v, 2, 64));
+        nbad += !same(lane_xor_sum<1>(v), v + __shfl_xor(v, 1, 64));
+        nbad += !same(lane_xor_row_d<8>(v), __shfl_xor(v, 8, 64)) + !same(lane_xor_row_d<4>(v), __shfl_xor(v, 4, 64));
+        nbad += !same(lane_xor_row_d<2>(v), __shfl_xor(v, 2, 64)) + !same(lane_xor_row_d<1>(v), __shfl_xor(v, 1, 64));
+        {   // the reduce-scatter step of the value-splitting butterflies (k3_reduce_store, butterfly64): keep + received
+            double x, y;
+            lane_swap32(v, w, x, y);
+            const bool hi = (lane & 32) != 0;
+            nbad += !same(x + y, (hi ? w : v) + __shfl_xor(hi ? v : w, 32, 64));
+            lane_swap16(v, w, x, y);
+            const bool hi16 = (lane & 16) != 0;
+            nbad += !same(x + y, (hi16 ? w : v) + __shfl_xor(hi16 ? v : w, 16, 64));
+        }
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+extern "C" int glio_debug_wave_reduce_check(glio_ctx* c, const double* values, int rounds, int* mismatches) {
+    if (!c || !values || rounds < 1 || rounds > 64 || !mismatches) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    double* d_in = c->d_L;                                     // scratch big enough for 64 * 64 doubles (n_max >= 15)
+    int* d_bad = reinterpret_cast<int*>(c->d_vec + 9 * (size_t)c->n_max);
+    GLIO_HIP_CHECK(hipMemcpyAsync(d_in, values, (size_t)64 * rounds * 8, hipMemcpyHostToDevice, c->stream));
+    GLIO_HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_wave_reduce_check, dim3(1), dim3(64), 0, c->stream, d_in, rounds, d_bad);
+    GLIO_HIP_CHECK(hipGetLastError());
+    GLIO_HIP_CHECK(hipMemcpyAsync(mismatches, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+    GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
     return GLIO_OK;
 }
