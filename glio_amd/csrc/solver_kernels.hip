@@ -428,11 +428,13 @@ __device__ __forceinline__ void backsub_packed_lds(const double* P, const int n,
 }
 
 __device__ __forceinline__ void finalize(const TrArgs& a, const SolverStatus& s) {
+    // Publication in host-mapped memory WITHOUT fences: [state | status with the checksum of both] and then the solve's tag, all as plain /
+    // relaxed stores.  The host accepts the payload only when its checksum adds up and re-reads until it does (capi.hip, glio_solve), so the
+    // order in which the pieces become visible does not matter for correctness -- three system-scope fences here (each a PCIe round trip that
+    // every wavefront of the workgroup sat out) only delayed the moment the host could see the tag.
     const double* xc = s.cur ? a.x1 : a.x0;
     const int nx = 16 * a.W + a.n_ddt;
     for (int k = threadIdx.x; k < nx; k += blockDim.x) { const double v = xc[k]; a.xout[k] = v; a.xout_host[k] = v; }
-    __threadfence_system();                      // every thread's part of the host copy is out before the flag
-    __syncthreads();
     if (threadIdx.x < 64) {
         // the checksum of the payload (glio_device.h), by the first wavefront alone (no LDS: some callers have none to spare)
         unsigned long long part = 0;
@@ -449,9 +451,7 @@ __device__ __forceinline__ void finalize(const TrArgs& a, const SolverStatus& s)
             for (int w = 0; w < (int)(sizeof(SolverStatus) / 8); ++w) sum += glio_result_mix(words[w], (unsigned long long)w);
             t.checksum = sum;
             *a.status = t; *a.status_host = t;
-            __threadfence_system();
-            a.progress[1] = s.solve_id;
-            __threadfence_system();
+            __hip_atomic_store(a.progress + 1, s.solve_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
