@@ -1500,6 +1500,137 @@ __device__ __forceinline__ void chain_prepare_back(double* Bi, const int lane) {
     }
 }
 
+// Minus the clock-drift epochs' contribution to the blocks of keyframe i (both chain kernels): with V_q the scaled column of epoch q restricted to
+// the rows of keyframe i that carry a coupling (Va, na rows), to those of keyframe i+1 when q couples (i, i+1) (Vb) and y_q its right-hand side,
+//   D_i -= Va Va^T,  B_i -= Vb Va^T,  rhs_i -= y Va^T  =  [Va; Vb; y] Va^T summed over the epochs touching i in list order:
+// a (2 na + 1) x L by L x na product per keyframe -- on the matrix core, four epochs per v_mfma_f64_16x16x4 with the entries themselves as the
+// accumulator (2 na + 1 <= 16).  One wavefront per keyframe: a lane derives the offsets of ITS epoch's rows once, reads one A and one B
+// operand per instruction and owns four entries of the result.  (As a flat list of entries, each re-reading the index lists and its 2 L
+// operands, this phase was ~1000 wavefront-level LDS reads and 5 us; the products are fused into the accumulation here, so the result
+// differs from that form in the last bits -- both chain kernels call this function, which keeps them bit-identical to each other.)
+__device__ __forceinline__ void chain_epoch_corrections_mfma(const int W, const int na, const int* misc_rows, const int* eoff, const int* elist, const int2* eps,
+                                                             const double* Vs, const double* yd, double* Blk, const int lane, const int wv, const int nwaves, long long* dbg = nullptr) {
+#ifdef GLIO_DEV_STAMPS
+#define EC_STAMP(k) do { if (dbg && threadIdx.x == 0) dbg[k] = wall_clock64(); } while (0)
+#else
+#define EC_STAMP(k) do { } while (0)
+#endif
+    EC_STAMP(104);
+    const int ci = lane & 15, ck = lane >> 4;                  // operand roles: row of A / column of B, and the epoch within the group of four
+    const int arow = ci < na ? misc_rows[ci] : (ci < 2 * na ? misc_rows[ci - na] : 0);
+    const int bcol = ci < na ? misc_rows[ci] : 0;
+    const bool colv = ci < na;
+    // the four entries of this lane inside a keyframe's block: column ci, rows ck + 4 q
+    int eoffs[4]; bool own0[4], isB[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rr = ck + 4 * q;
+        int rowoff; bool ok;
+        if (rr < na) { const int r = misc_rows[rr]; rowoff = r; ok = colv && bcol <= r; }                           // D_i, lower triangle
+        else if (rr < 2 * na) { rowoff = KC_NB + misc_rows[rr - na]; ok = colv; }                                    // B_i (rows of keyframe i + 1)
+        else { rowoff = 30; ok = colv && rr == 2 * na; }                                                           // right-hand side row
+        own0[q] = ok; isB[q] = rr >= na && rr < 2 * na;
+        eoffs[q] = rowoff * KC_RS + bcol;
+    }
+    // one group of four epochs of keyframe i: the operands of this lane (A negated: the accumulator loses the product)
+    auto operands = [&](const int i, const int t, const int t1, double& a, double& b) {
+        const bool live = t < t1;
+        const int e = live ? elist[t] : 0;
+        const int2 sl = eps[e];
+        const int side = sl.x == i ? 0 : 15;
+        const int base = e * 30 + side;
+        const int oth = (sl.x == i ? sl.y : sl.x) == i + 1 ? e * 30 + (15 - side) : -1;
+        const double va = Vs[base + arow], vo = Vs[(oth >= 0 ? oth : base) + arow], vy = yd[e], vb = Vs[base + bcol];
+        const double av = ci < na ? va : (ci < 2 * na ? (oth >= 0 ? vo : 0.0) : (ci == 2 * na ? vy : 0.0));
+        a = live ? -av : 0.0; b = (live && colv) ? vb : 0.0;
+    };
+    // Three keyframes of a wavefront in flight: every stage below is a batch of independent LDS reads (their dependent chain -- list entry,
+    // slot pair, operands -- is otherwise paid once per keyframe and group)
+    constexpr int NK = 3;
+    EC_STAMP(105);
+    for (int i0 = wv; i0 < W; i0 += NK * nwaves) {
+        int ii[NK], t0[NK], t1[NK];
+        bool two = true;
+#pragma unroll
+        for (int u = 0; u < NK; ++u) {
+            ii[u] = i0 + u * nwaves;
+            const bool act = ii[u] < W;
+            ii[u] = act ? ii[u] : 0;
+            t0[u] = eoff[ii[u]]; t1[u] = act ? eoff[ii[u] + 1] : t0[u];
+            two = two && (t1[u] - t0[u] <= 8);
+        }
+        v4f64 acc[NK]; double* blk[NK];
+#pragma unroll
+        for (int u = 0; u < NK; ++u) {
+            blk[u] = Blk + (size_t)ii[u] * KC_BLK;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[u][q] = (own0[q] && !(isB[q] && ii[u] + 1 >= W)) ? blk[u][eoffs[q]] : 0.0;
+        }
+        EC_STAMP(106);
+        if (two) {
+            // explicit stages over the six (keyframe, group) pairs: list entries, slot pairs, operands -- each a batch of independent reads
+            // (written per pair, with its conditional read of the list, the compiler walks the six dependent chains one after the other)
+            double a[NK][2], b[NK][2];
+            int ee[NK][2]; bool lv[NK][2];
+#pragma unroll
+            for (int u = 0; u < NK; ++u)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int t = t0[u] + 4 * c + ck;
+                    lv[u][c] = t < t1[u];
+                    ee[u][c] = elist[lv[u][c] ? t : 0];            // (entry 0 of the list is always allocated)
+                }
+            int2 sl[NK][2];
+#pragma unroll
+            for (int u = 0; u < NK; ++u)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) { ee[u][c] = lv[u][c] ? ee[u][c] : 0; sl[u][c] = eps[ee[u][c]]; }
+            double va[NK][2], vo[NK][2], vy[NK][2], vb[NK][2]; bool ho[NK][2];
+#pragma unroll
+            for (int u = 0; u < NK; ++u)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int e = ee[u][c], i = ii[u];
+                    const int side = sl[u][c].x == i ? 0 : 15;
+                    const int base = e * 30 + side;
+                    const int oth = (sl[u][c].x == i ? sl[u][c].y : sl[u][c].x) == i + 1 ? e * 30 + (15 - side) : -1;
+                    ho[u][c] = oth >= 0;
+                    va[u][c] = Vs[base + arow]; vo[u][c] = Vs[(oth >= 0 ? oth : base) + arow]; vy[u][c] = yd[e]; vb[u][c] = Vs[base + bcol];
+                }
+#pragma unroll
+            for (int u = 0; u < NK; ++u)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const double av = ci < na ? va[u][c] : (ci < 2 * na ? (ho[u][c] ? vo[u][c] : 0.0) : (ci == 2 * na ? vy[u][c] : 0.0));
+                    a[u][c] = lv[u][c] ? -av : 0.0; b[u][c] = (lv[u][c] && colv) ? vb[u][c] : 0.0;
+                }
+            EC_STAMP(107);
+#pragma unroll
+            for (int u = 0; u < NK; ++u) {
+                acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][0], b[u][0], acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][1], b[u][1], acc[u], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NK; ++u)
+                for (int tb = t0[u]; tb < t1[u]; tb += 4) {
+                    double a, b;
+                    operands(ii[u], tb + ck, t1[u], a, b);
+                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[u], 0, 0, 0);
+                }
+        }
+        EC_STAMP(108);
+#pragma unroll
+        for (int u = 0; u < NK; ++u) {
+            if (t1[u] <= t0[u]) continue;                  // (also the padding keyframes of the last round)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (own0[q] && !(isB[q] && ii[u] + 1 >= W)) blk[u][eoffs[q]] = acc[u][q];
+        }
+        EC_STAMP(109);
+    }
+#undef EC_STAMP
+}
+
 struct ChainArgs {
     int W, n, nd;
     const int2* ep_slots; const int* ep_off; const int* ep_list;
@@ -1667,6 +1798,9 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a, c
     __syncthreads();
     AR_STAMP(42);
     if (tid == 0) { int na = 0; for (int q = 0; q < 15; ++q) if (rowmask >> q & 1) misc[2 + na++] = q; misc[1] = na; }
+    __syncthreads();
+    if (2 * misc[1] + 1 <= 16) chain_epoch_corrections_mfma(W, misc[1], misc + 2, eoff, elist, eps, Vs, yd, Blk, lane, wv, KC_THREADS / 64);
+    else {
     // per list entry (keyframe i, epoch e): offset of the epoch's rows of keyframe i in Vs, and of keyframe i+1 (or -1)
     for (int i = wv; i < W; i += KC_THREADS / 64)
         for (int t = eoff[i] + lane; t < eoff[i + 1]; t += 64) {
@@ -1714,6 +1848,7 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a, c
             }
             *dst = v;
         }
+    }
     }
     __syncthreads();
     AR_STAMP(43);
@@ -2047,6 +2182,9 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
     __shared__ int s_prog[2];
     __shared__ SolverStatus s_in, s_full;
     AR_STAMP(40);
+#ifdef GLIO_DEV_STAMPS
+    if (tid == 0) a.dbg[120] = clock64();          // shader-clock counter beside the 100 MHz wall clock: the clock the workgroup actually runs at
+#endif
     // ---- round 0: status, the host-built gather tables, the structure tables of the epochs
     if (tid == 0) { s_in = *tr.status; s_done = s_in.done; s_pending = s_in.cand_pending; s_cand = 1 - s_in.cur; }
     if (tid < 18) misc[tid] = 0;            // [0] breakdown flag, [1] number of rows with an epoch coupling, [2..] their indices
@@ -2257,16 +2395,37 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
     AR_STAMP(90);
     AR_STAMP(91);
     int mk_rows = 0;
-    for (int it = tid; it < nd * 30; it += KC_THREADS) {       // one (epoch, row) pair per item
-        const int e = it / 30, q = it - 30 * e;
-        const int2 sl = eps[e];
-        const int used = reinterpret_cast<const int*>(dds + e * 15 + 14)[1];
-        const int s1 = q < 15 ? sl.x : sl.y;
-        const int k12 = kc_dop_local12(q >= 15, q < 15 ? q : q - 15);
-        const bool ok = (used != 0) & (s1 >= 0) & (k12 >= 0);
-        const double v = ok ? sS[15 * (s1 >= 0 ? s1 : 0) + (q < 15 ? q : q - 15)] * dds[e * 15 + (k12 >= 0 ? k12 : 0)] * sS[np15 + e] : 0.0;
-        Vs[it] = v * rd[e];
-        if (v != 0.0) mk_rows |= 1 << (q % 15);
+    // one (epoch, row) pair per item, five items of a thread at a time: what depends on (e, row) only goes out as one batch of LDS reads, the
+    // scale of the keyframe row (which needs the epoch's slot pair) as a second (item by item the compiler walks the chains one after the other)
+    for (int it0 = tid; it0 < nd * 30; it0 += 5 * KC_THREADS) {
+        int2 sl[5]; int used[5], k12[5], lc[5], ee[5]; double cv[5], se[5], re[5]; bool in[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int it = it0 + u * KC_THREADS;
+            in[u] = it < nd * 30;
+            const int itc = in[u] ? it : tid;
+            const int e = itc / 30, q = itc - 30 * e;
+            ee[u] = e; lc[u] = q < 15 ? q : q - 15;
+            k12[u] = kc_dop_local12(q >= 15, lc[u]);
+            sl[u] = eps[e];
+            used[u] = reinterpret_cast<const int*>(dds + e * 15 + 14)[1];
+            cv[u] = dds[e * 15 + (k12[u] >= 0 ? k12[u] : 0)]; se[u] = sS[np15 + e]; re[u] = rd[e];
+            lc[u] |= (q >= 15) << 8;                              // (bit 8: the row belongs to the epoch's second keyframe)
+        }
+        double sr[5]; bool ok[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int s1 = (lc[u] >> 8) ? sl[u].y : sl[u].x;
+            ok[u] = (used[u] != 0) & (s1 >= 0) & (k12[u] >= 0);
+            sr[u] = sS[15 * (s1 >= 0 ? s1 : 0) + (lc[u] & 255)];
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            if (!in[u]) continue;
+            const double v = ok[u] ? sr[u] * cv[u] * se[u] : 0.0;
+            Vs[it0 + u * KC_THREADS] = v * re[u];
+            if (v != 0.0) mk_rows |= 1 << ((lc[u] & 255) % 15);
+        }
     }
     AR_STAMP(92);
     {   // rows that carry an epoch coupling: one LDS atomic per wavefront
@@ -2286,10 +2445,17 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
         }
     }
     // the strict upper triangle of D_i is read as zero by the chain steps
-    for (int q = tid; q < W * 105; q += KC_THREADS) {
-        const int i = q / 105, w = q - 105 * i;
-        const int r = wr30[w], c = wj[w];               // pair (r + 1, c) with c <= r  ->  entry [c][r + 1] above the diagonal
-        Blk[(size_t)i * KC_BLK + c * KC_RS + (r + 1)] = 0.0;
+    for (int q0 = tid; q0 < W * 105; q0 += 5 * KC_THREADS) {             // (five items per round: their table reads as one batch)
+        int off[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int q = q0 + u * KC_THREADS < W * 105 ? q0 + u * KC_THREADS : q0;
+            const int i = q / 105, w = q - 105 * i;
+            const int r = wr30[w], c = wj[w];           // pair (r + 1, c) with c <= r  ->  entry [c][r + 1] above the diagonal
+            off[u] = i * KC_BLK + c * KC_RS + (r + 1);
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) Blk[off[u]] = 0.0;
     }
     for (int q = tid; q < W * 15; q += KC_THREADS) { const int i = q / 15, j = q - 15 * i; Blk[(size_t)i * KC_BLK + 30 * KC_RS + j] = Rld(nd + 15 * i + j); }
     GLIO_BLOCK_LDS_SYNC();
@@ -2350,9 +2516,15 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
     GLIO_BLOCK_LDS_SYNC();
     AR_STAMP(46);
     AR_STAMP(95);
-    // Minus the epochs' contribution D_i -= V V^T, B_i -= V' V^T, rhs_i -= y V over the epochs touching keyframe i, in list order.
-    // (Measured without gain: KC_THREADS / W threads per keyframe that read the keyframe's epoch list once into registers and then take
-    // their share of its entries -- the phase is bound by the ~1000 wavefront-level LDS reads of the operands, not by the index chains.)
+    // Minus the epochs' contribution D_i -= V V^T, B_i -= V' V^T, rhs_i -= y V over the epochs touching keyframe i, in list order: on the
+    // matrix core, one wavefront per keyframe (chain_epoch_corrections_mfma).  The flat entry list below stays for row sets that do not
+    // fit a 16-row tile.  (Measured without gain before that: threads that hold the keyframe's epoch list in registers and take a share of
+    // its entries -- the flat form is bound by its ~1000 wavefront-level LDS operand reads, not by the index chains.)
+    if (2 * misc[1] + 1 <= 16) {
+        AR_STAMP(96);
+        chain_epoch_corrections_mfma(W, misc[1], misc + 2, eoff, elist, eps, Vs, yd, Blk, lane, wv, KC_THREADS / 64, a.dbg);
+        AR_STAMP(110);
+    } else {
     for (int i = wv; i < W; i += KC_THREADS / 64)
         for (int t = eoff[i] + lane; t < eoff[i + 1]; t += 64) {
             const int e = elist[t];
@@ -2401,6 +2573,7 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
         }
     };
     if (misc[1] == 6) corrections(std::integral_constant<int, 6>{}); else corrections(misc[1]);
+    }
     if (tid < 2) s_prog[tid] = 0;
     GLIO_BLOCK_LDS_SYNC();
     AR_STAMP(47);
@@ -2632,6 +2805,9 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
             for (int k = tid; k < tr.n_ddt; k += TR_THREADS) xn[16 * W + k] = sX[16 * W + k] + sW[15 * W + k];
         }
         AR_STAMP(73);
+#ifdef GLIO_DEV_STAMPS
+        if (tid == 0) a.dbg[121] = clock64();
+#endif
         if (tid == 0) *tr.status = sn;
         AR_STAMP(50); AR_STAMP(51);
         return;
