@@ -1442,6 +1442,8 @@ __device__ __forceinline__ void chain_step15(const int i, const int nb, const bo
         // right-hand side row), 16 x 15.  v_mfma_f64_16x16x4 takes A[i][k] from lane (i + 16 k) and B[k][j] from lane
         // (j + 16 k): for X X^T both are X[lane % 16][kb + lane / 16], so one LDS read per lane feeds both operands; four
         // instructions cover k = 0..15 (k = 15 is padding: zero).  C: lane l, register q -> row (l >> 4) + 4 q, column l & 15.
+        // (Measured slower, round 3: pulling the operands straight out of the row-per-lane registers with 30 ds_bpermute instead of reading
+        // the stored panel back -- the pulls cost more than the store-wait-load round trip they avoid: 69.8 vs 68.0 us per step.)
         {
             const int xi = lane & 15, xg = lane >> 4;
             const double* xrow = Bi + (KC_NB + xi) * KC_RS + xg;
