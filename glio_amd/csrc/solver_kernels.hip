@@ -2060,27 +2060,21 @@ __device__ __forceinline__ void kc_reduce_lidar(const GatherArgs& G, const Gathe
     const int lnb = G.lidar_nb;
     const int total = W * GLIO_LIDAR_ACC;
     if (lnb <= 24 && total <= 2 * (int)blockDim.x) {
-        // the usual geometry (560 entries, 512 threads, 24 partials each): a thread's two entries load together -- one round trip, not two
-        const int it0 = threadIdx.x, it1 = threadIdx.x + blockDim.x;
-        const bool h0 = it0 < total, h1 = it1 < total;
-        const int s0 = (h0 ? it0 : 0) / GLIO_LIDAR_ACC, s1 = (h1 ? it1 : 0) / GLIO_LIDAR_ACC;
-        const double* p0 = lp + (size_t)s0 * lnb * GLIO_LIDAR_ACC + ((h0 ? it0 : 0) - s0 * GLIO_LIDAR_ACC);
-        const double* p1 = lp + (size_t)s1 * lnb * GLIO_LIDAR_ACC + ((h1 ? it1 : 0) - s1 * GLIO_LIDAR_ACC);
-        double va[24], vb[24];
+        // the usual geometry (560 entries, 24 partials each): a thread takes two ADJACENT entries and reads them as 16-byte loads -- 24 loads
+        // for the pair in one round (partial blocks are 28 doubles = 14 x 16 bytes apart, the pair starts at an even index)
+        static_assert(GLIO_LIDAR_ACC % 2 == 0, "pairs of entries stay inside a 28-double block");
+        const int pr = threadIdx.x;
+        if (2 * pr < total) {
+            const int it0 = 2 * pr;
+            const int s0 = it0 / GLIO_LIDAR_ACC;
+            const double* p0 = lp + (size_t)s0 * lnb * GLIO_LIDAR_ACC + (it0 - s0 * GLIO_LIDAR_ACC);
+            v2f64 va[24];
 #pragma unroll
-        for (int q = 0; q < 24; ++q) va[q] = p0[(size_t)(q < lnb ? q : 0) * GLIO_LIDAR_ACC];
-        if (h1) {
+            for (int q = 0; q < 24; ++q) va[q] = *reinterpret_cast<const v2f64*>(p0 + (size_t)(q < lnb ? q : 0) * GLIO_LIDAR_ACC);
+            double sa = 0, sb = 0;
 #pragma unroll
-            for (int q = 0; q < 24; ++q) vb[q] = p1[(size_t)(q < lnb ? q : 0) * GLIO_LIDAR_ACC];
-        }
-        double sa = 0, sb = 0;
-#pragma unroll
-        for (int q = 0; q < 24; ++q) sa += q < lnb ? va[q] : 0.0;
-        if (h0) T.lid[it0] = sa;
-        if (h1) {
-#pragma unroll
-            for (int q = 0; q < 24; ++q) sb += q < lnb ? vb[q] : 0.0;
-            T.lid[it1] = sb;
+            for (int q = 0; q < 24; ++q) { sa += q < lnb ? va[q][0] : 0.0; sb += q < lnb ? va[q][1] : 0.0; }
+            T.lid[it0] = sa; T.lid[it0 + 1] = sb;
         }
         return;
     }
@@ -2215,34 +2209,44 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
     // one batch, gather_store adds them up (k_assemble's order), scales (S H S + mu D^2) and stores.  (Measured without gain: gathering
     // into LDS before the state machine and scaling afterwards; holding the first batch in registers across the state machine; skipping
     // the slices that are zero by the graph's structure, ~45 % of the 276 KB -- the per-slice branches cost what the loads save.)
+    // An item is a PAIR of adjacent entries (w, w + 1) of a slice, read as one 16-byte load: 35 dwordx4 loads per thread in ONE round instead of
+    // 70 dwordx2 loads in two.  (Slices are 352 doubles apart and 16-byte aligned; entry 345, read with 344, is padding.)  The phase stays at
+    // ~6.5 us either way, and also with one packed table word and real branches in the store loop: it is neither the load instructions nor the
+    // LDS reads of the store loop -- what one CU can pull from the other XCDs' results (276 KB) sets it.
     constexpr int KB = 7;
-    const int gtotal = W * 345;
-    auto gather_load = [&](const double* src, const int q0, double (&v)[KB][5]) {
+    constexpr int GPAIRS = 173;                          // pairs per keyframe slice: entries 0..345
+    const int gtotal = W * GPAIRS;
+    auto gather_load = [&](const double* src, const int q0, v2f64 (&v)[KB][5]) {
 #pragma unroll
         for (int u = 0; u < KB; ++u) {
             const int q = q0 + u * KC_THREADS;
             const int qq = q < gtotal ? q : tid;
-            const int i = qq / 345, w = qq - 345 * i;
+            const int i = qq / GPAIRS, w = 2 * (qq - GPAIRS * i);
             const double* p = src + (size_t)i * GLIO_CS_SOURCES * GLIO_CS_STRIDE + w;
 #pragma unroll
-            for (int sidx = 0; sidx < 5; ++sidx) v[u][sidx] = p[sidx * GLIO_CS_STRIDE];
+            for (int sidx = 0; sidx < 5; ++sidx) v[u][sidx] = *reinterpret_cast<const v2f64*>(p + sidx * GLIO_CS_STRIDE);
         }
     };
-    auto gather_store = [&](const int q0, const double (&v)[KB][5], const double mu_) {
+    auto gather_store = [&](const int q0, const v2f64 (&v)[KB][5], const double mu_) {
 #pragma unroll
         for (int u = 0; u < KB; ++u) {
             const int q = q0 + u * KC_THREADS;
             if (q >= gtotal) continue;
-            const int i = q / 345, w = q - 345 * i;
-            const int r30 = wr30[w], j = wj[w], lix = wlx[w];
-            const bool live = r30 < 15 || i + 1 < W;
-            const int irow = 15 * i + r30, icol = 15 * i;
-            double h = 0;
-            h += lix >= 0 ? lid[i * GLIO_LIDAR_ACC + (lix >= 0 ? lix : 0)] : 0.0;
-            h += v[u][0]; h += v[u][1]; h += v[u][2]; h += v[u][3]; h += v[u][4];
-            double wv_ = (live ? sS[irow] : 0.0) * h * sS[icol + j];
-            wv_ += (irow == icol + j) ? mu_ * sDg[irow] * sDg[irow] : 0.0;
-            Blk[(size_t)i * KC_BLK + r30 * KC_RS + j] = live ? wv_ : 0.0;
+            const int i = q / GPAIRS, w0 = 2 * (q - GPAIRS * i);
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int w = w0 + h2;
+                if (w >= 345) continue;
+                const int r30 = wr30[w], j = wj[w], lix = wlx[w];
+                const bool live = r30 < 15 || i + 1 < W;
+                const int irow = 15 * i + r30, icol = 15 * i;
+                double h = 0;
+                h += lix >= 0 ? lid[i * GLIO_LIDAR_ACC + (lix >= 0 ? lix : 0)] : 0.0;
+                h += v[u][0][h2]; h += v[u][1][h2]; h += v[u][2][h2]; h += v[u][3][h2]; h += v[u][4][h2];
+                double wv_ = (live ? sS[irow] : 0.0) * h * sS[icol + j];
+                wv_ += (irow == icol + j) ? mu_ * sDg[irow] * sDg[irow] : 0.0;
+                Blk[(size_t)i * KC_BLK + r30 * KC_RS + j] = live ? wv_ : 0.0;
+            }
         }
     };
     // ---- diag(H), g and the cost of the candidate, for the state machine
@@ -2441,7 +2445,7 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
     {
         const double* src = G.chain_src + (size_t)dec.cur * W * GLIO_CS_SOURCES * GLIO_CS_STRIDE;
         for (int q0 = tid; q0 < gtotal; q0 += KB * KC_THREADS) {
-            double gb[KB][5];
+            v2f64 gb[KB][5];
             gather_load(src, q0, gb);
             gather_store(q0, gb, mu);
         }
