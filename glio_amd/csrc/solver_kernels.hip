@@ -1989,8 +1989,10 @@ __host__ __device__ __forceinline__ size_t chain_step_tabs_offset(int W, int nd,
     const size_t a = chain_lds_doubles(W, nd) * 8, b = tr_step_lds_doubles(n) * 8;
     return ((a > b ? a : b) + 15) & ~(size_t)15;
 }
-__host__ __device__ __forceinline__ size_t chain_step_lds_bytes(int W, int nd, int n) {
-    return chain_step_tabs_offset(W, nd, n) + (size_t)W * GLIO_LIDAR_ACC * 8 + 5 * (size_t)(n + (n & 1)) * 8 + (size_t)(n + W + ((n + W) & 1)) * 8 + (size_t)nd * 128 +
+// mirrors: the LDS copies of g, g~, t and the state that the LDS-resident front and tail (ChainArgs::fast) work on; a window whose blocks leave no
+// room for them still takes this kernel, with the generic bodies
+__host__ __device__ __forceinline__ size_t chain_step_lds_bytes(int W, int nd, int n, bool mirrors = true) {
+    return chain_step_tabs_offset(W, nd, n) + (size_t)W * GLIO_LIDAR_ACC * 8 + (mirrors ? 5 : 2) * (size_t)(n + (n & 1)) * 8 + (mirrors ? (size_t)(n + W + ((n + W) & 1)) * 8 : 0) + (size_t)nd * 128 +
            (size_t)(8 + 15) * W * 2 + 3 * 346 * 2 + 64;
 }
 struct GatherArgs {
@@ -2157,11 +2159,12 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
     const int n2 = n + (n & 1), nx = n + W, nx2 = nx + (nx & 1);
     double* sS = lid + W * GLIO_LIDAR_ACC;               // [n] Jacobi scale       (staged copies of the work vectors)
     double* sDg = sS + n2;                               // [n] D = sqrt(clamp(diag))
-    double* sG = sDg + n2;                               // [n] g of the current point
-    double* sGr = sG + n2;                               // [n] g~ = S g / D
-    double* sT = sGr + n2;                               // [n] t = H u
-    double* sX = sT + n2;                                // [16 W + nd] the current point
-    double* dds = sX + nx2;                              // [nd][15] clock-drift blocks: c[12], h, g, (group, used)
+    const bool mir = a.fast != 0;                        // (host: 0 when the mirrors below do not fit beside the blocks)
+    double* sG = sDg + n2;                               // [n] g of the current point            -+
+    double* sGr = sG + n2;                               // [n] g~ = S g / D                       | only with mir
+    double* sT = sGr + n2;                               // [n] t = H u                            |
+    double* sX = sT + n2;                                // [16 W + nd] the current point         -+
+    double* dds = mir ? sX + nx2 : sDg + n2;             // [nd][15] clock-drift blocks: c[12], h, g, (group, used)
     // scratch of the front: state buffer 0 sits in sX, buffer 1 in [CsT, CsB) (free until the chain), the candidate's diag(H) in sDg (the
     // state machine reads entry i before it overwrites it with D_i)
     double* xm0 = sX; double* xm1 = CsT; double* sHd = sDg;
@@ -2385,8 +2388,11 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
     } else {
         // round 1: the work vectors, the clock-drift blocks (coalesced, 15 doubles each) and the epoch list into LDS
         const double* xg = dec.cur ? tr.x1 : tr.x0;
-        for (int k = tid; k < n; k += KC_THREADS) { sS[k] = V_SCALE(tr)[k]; sDg[k] = V_DIAG(tr)[k]; sGr[k] = V_GRAD(tr)[k]; sG[k] = gn[k]; }
-        for (int k = tid; k < nx; k += KC_THREADS) sX[k] = xg[k];
+        for (int k = tid; k < n; k += KC_THREADS) { sS[k] = V_SCALE(tr)[k]; sDg[k] = V_DIAG(tr)[k]; }
+        if (mir) {
+            for (int k = tid; k < n; k += KC_THREADS) { sGr[k] = V_GRAD(tr)[k]; sG[k] = gn[k]; }
+            for (int k = tid; k < nx; k += KC_THREADS) sX[k] = xg[k];
+        }
         for (int k = tid; k < nd * 15; k += KC_THREADS) dds[k] = reinterpret_cast<const double*>(ddg)[k];
         for (int t = tid; t < eoff[W]; t += KC_THREADS) elist[t] = a.ep_list[t];
         const double* uv = V_U(tr);
@@ -2396,7 +2402,7 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
         for (int k = tid; k < np15; k += KC_THREADS) zb[k] = zb[k] / sS[k];
         for (int e = tid; e < nd; e += KC_THREADS) epoch_scalars(e, wd[e] / sS[np15 + e]);
     }
-    auto Rld = [&](const int p) { const int i = nat(p); return sS[i] * sG[i]; };
+    auto Rld = [&](const int p) { const int i = nat(p); return mir ? sS[i] * sG[i] : sS[i] * gn[i]; };
     GLIO_BLOCK_LDS_SYNC();
     AR_STAMP(90);
     AR_STAMP(91);
@@ -2504,7 +2510,7 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
 #pragma unroll
                 for (int q = 0; q < 8; ++q) acc = tb + q < t1e ? acc + xv[q] * xw[q] : acc;
             }
-            { const double tv = acc / s_row; V_T(tr)[row] = tv; sT[row] = tv; }
+            { const double tv = acc / s_row; V_T(tr)[row] = tv; if (mir) sT[row] = tv; }
         } else {
             const int e = row - np15;
             const int2 sl = eps[e];
@@ -2515,7 +2521,7 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
 #pragma unroll
                 for (int q = 0; q < 30; ++q) acc += (Vs[e * 30 + q] * ire) * zb[15 * (q < 15 ? sl.x : sl.y) + (q < 15 ? q : q - 15)];
             }
-            { const double tv = acc / se; V_T(tr)[row] = tv; sT[row] = tv; }
+            { const double tv = acc / se; V_T(tr)[row] = tv; if (mir) sT[row] = tv; }
         }
     }
     AR_STAMP(94);
@@ -2872,7 +2878,7 @@ int glio_solver_path(const glio_ctx* c, int n_ddt) {
     const bool lds_chol = lds_pk <= 160 * 1024;
     const size_t lds_slv = lds_chol ? lds_pk : glio_tr_step_lds_bytes(np) + arrow_solve_extra_doubles(c->W, K) * 8;
     const bool arrow = c->arrow.mode >= 1 && c->arrow.gnss_ok && c->arrow.prior_ok && c->arrow.max_epoch < n_ddt && lds_fwd <= 160 * 1024 && lds_slv <= 160 * 1024;
-    const size_t lds_chain = c->arrow.mode == 3 ? chain_lds_doubles(c->W, n_ddt) * 8 + 8 * 1024 : chain_step_lds_bytes(c->W, n_ddt, n) + 2 * 1024;
+    const size_t lds_chain = c->arrow.mode == 3 ? chain_lds_doubles(c->W, n_ddt) * 8 + 8 * 1024 : chain_step_lds_bytes(c->W, n_ddt, n, false) + 2 * 1024;
     const bool chain = c->arrow.mode >= 1 && c->arrow.gnss_chain && c->arrow.prior_chain && c->arrow.max_epoch < n_ddt && lds_chain <= 158 * 1024;
     return chain ? 2 : (arrow ? 1 : 0);
 }
@@ -2927,6 +2933,7 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
         ChainArgs r;
         r.W = c->W; r.n = a.n; r.nd = n_ddt; r.ep_slots = c->arrow.d_ep_slots; r.ep_off = c->arrow.d_ep_off; r.ep_list = c->arrow.d_ep_list;
         r.z = c->arrow.d_z; r.flag = c->arrow.d_flag; r.status = c->d_status; r.dbg = c->arrow.d_dbg; r.force_fail = c->arrow.mode == 2; r.fast = chain_fast_mask();
+        if (chain_step_lds_bytes(c->W, n_ddt, a.n, true) + 2 * 1024 > 158 * 1024) r.fast = 0;      // no room for the LDS mirrors: generic bodies
         if (!legacy_chain) {
             GatherArgs G;
             G.lidar_partials = c->d_lidar_partials; G.lidar_pstride = glio_partials_stride(c); G.lidar_nb = c->last_k3_nb;
@@ -2938,7 +2945,7 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
             G.hd0 = c->d_hdiag[0]; G.hd1 = c->d_hdiag[1]; G.g0 = c->d_g[0]; G.g1 = c->d_g[1]; G.c0 = c->d_cost[0]; G.c1 = c->d_cost[1];
             a.hd0 = c->d_hdiag[0]; a.hd1 = c->d_hdiag[1];
             a.fused_chain = 2;
-            hipLaunchKernelGGL(k_chain_step, dim3(1), dim3(KC_THREADS), chain_step_lds_bytes(c->W, n_ddt, a.n), c->stream, r, a, G);
+            hipLaunchKernelGGL(k_chain_step, dim3(1), dim3(KC_THREADS), chain_step_lds_bytes(c->W, n_ddt, a.n, r.fast != 0), c->stream, r, a, G);
             return;                                   // the one launch is the whole step
         }
         hipLaunchKernelGGL(k_chain_solve, dim3(1), dim3(KC_THREADS), lds_chain, c->stream, r, a);

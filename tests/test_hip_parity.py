@@ -436,6 +436,48 @@ def test_chain_step_is_bit_identical_to_the_assembled_sequence(hip, steady_windo
         assert out[k] == out[0], k
 
 
+def _steady_window_22(po):
+    W = 22
+    long = synth.make_window(W=W + 1, pts_per_scan=200, with_gnss=True, seed=synth.SEED_BASE + 93)
+    first = synth.sub_window(long, 0, W)
+    prob0 = po.Problem(first, synth.analytic_correspondences(first), use_gnss=False, use_prior=False)
+    st0 = first.init.copy(); st0.n_ddt = 0
+    sol0, _ = prob0.solve(st0)
+    win = synth.sub_window(long, 1, W)
+    win.prior = prob0.marginalize(sol0)
+    return win, synth.analytic_correspondences(win)
+
+
+def test_chain_step_on_a_window_too_large_for_its_lds_mirrors(hip, po):
+    """W = 22 with GNSS (n = 414): the keyframe blocks leave no room for the LDS copies the fast front / tail of k_chain_step work on, so the
+    host launches the kernel with its generic bodies (smaller carve) -- it must still be the chain path and agree with the oracle."""
+    win, corr = _steady_window_22(po)
+    so, mo = po.Problem(win, corr).solve(win.init.copy())
+    ctx = hip.Context(win.opts)
+    ctx.load_window(win, corr)
+    sc, mc = ctx.solve(win.init.copy())
+    assert hip.load().glio_debug_solver_path(ctx._h) == 2
+    ctx.close()
+    assert mc.iterations == mo.iterations and mc.termination == mo.termination
+    assert abs(mc.final_cost - mo.final_cost) <= 1e-9 * abs(mo.final_cost)
+    assert_pose_parity(sc, so, tol_t=1e-7, tol_r=1e-8)
+
+
+@pytest.mark.xfail(reason="open defect found at the end of round 3 (scripts/dense_vs_chain_sizes.py): the DENSE fallback (solver mode 0) is right up to n = 376 "
+                          "and runs into the iteration limit at n = 414, 1.6 mm off; the structured paths are not affected", strict=False)
+def test_dense_fallback_at_n_414(hip, po):
+    win, corr = _steady_window_22(po)
+    so, mo = po.Problem(win, corr).solve(win.init.copy())
+    ctx = hip.Context(win.opts)
+    hip.load().glio_debug_set_solver(ctx._h, 0)
+    ctx.load_window(win, corr)
+    sd, md = ctx.solve(win.init.copy())
+    assert hip.load().glio_debug_solver_path(ctx._h) == 0
+    ctx.close()
+    assert md.iterations == mo.iterations and md.termination == mo.termination
+    assert_pose_parity(sd, so)
+
+
 def test_dense_gnss_pairs_cross_the_chunk_boundaries(hip, po):
     """A keyframe pair with MORE factors than the GNSS role takes side by side: 25 epochs per pair (gnss_epoch_dt 0.016 s) = 50 DD
     factors (7 chunks of 8) and 500 Doppler rows (4 chunks of 128, epochs straddling the chunk boundaries: the carried partial sums
