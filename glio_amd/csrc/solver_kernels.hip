@@ -244,6 +244,13 @@ __device__ __forceinline__ bool chol_left_looking(double* A, const int n, double
         //       block AND solve X L_kk^T = A_panel for those rows: no separate triangular-solve phase, no LDS.
         const int r0 = k0 + nb;
         const int mb = n + 1 - r0;
+        // The factored diagonal block goes back to memory only AFTER the barrier below: with more than TR_WAVES * 48 = 384 rows under the panel
+        // the wavefronts come round a second time and load the diagonal block again -- it must still be the unfactored one.  (Until the end of
+        // round 3 wavefront 0 stored it at the end of its first round: every system with n >= 400 was factored wrongly, rel. error 3e-2; found
+        // with scripts/dense_probe_414.py, pinned by tests/test_hip_parity.py::test_blocked_cholesky_sizes.)
+        double adg[TR_NB];
+#pragma unroll
+        for (int j = 0; j < TR_NB; ++j) adg[j] = 0.0;
         if (!(skip & 2)) {
             for (int base = wv * 48; base < mb; base += TR_WAVES * 48) {       // mb >= 1: wavefront 0 always runs
                 const bool isdiag = lane < TR_NB;
@@ -268,15 +275,24 @@ __device__ __forceinline__ bool chol_left_looking(double* A, const int n, double
 #pragma unroll
                     for (int c = j + 1; c < TR_NB; ++c) a[c] -= lij * readlane_d(lij, c);   // unmasked: entries above the diagonal
                 }                                                                           // are never read or stored
-                if (live && ((base == 0 && wv == 0) || !isdiag)) {
+                if (live && !isdiag) {
 #pragma unroll
-                    for (int j = 0; j < TR_NB; ++j) if (j < nb && (!isdiag || j <= lane)) prow[j] = a[j];
+                    for (int j = 0; j < TR_NB; ++j) if (j < nb) prow[j] = a[j];
+                }
+                if (base == 0 && wv == 0) {
+#pragma unroll
+                    for (int j = 0; j < TR_NB; ++j) adg[j] = a[j];
                 }
                 if (bad && wv == 0 && lane == 0) *flag = 1 + k0;
             }
         }
         __syncthreads();
         if (*flag) return false;
+        if (!(skip & 2) && wv == 0 && lane < nb) {
+            double* prow = A + (size_t)(k0 + lane) * ld + k0;
+#pragma unroll
+            for (int j = 0; j < TR_NB; ++j) if (j < nb && j <= lane) prow[j] = adg[j];
+        }
     }
     return true;
 }

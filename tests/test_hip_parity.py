@@ -436,6 +436,26 @@ def test_chain_step_is_bit_identical_to_the_assembled_sequence(hip, steady_windo
         assert out[k] == out[0], k
 
 
+@pytest.mark.parametrize("n", [37, 160, 376, 399, 400, 414, 420])
+def test_blocked_cholesky_sizes(hip, n):
+    """The in-kernel blocked Cholesky + back substitution of the dense path (chol_left_looking, back_substitute) against numpy on random SPD
+    systems, on both sides of n = 400 (where a second round of the panel factorisation sets in)."""
+    import ctypes as C
+    win = synth.make_window(W=28, pts_per_scan=64, with_gnss=False)
+    ctx = hip.Context(win.opts)
+    rng = np.random.default_rng(n)
+    B = rng.normal(0, 1, (n, n))
+    A = B @ B.T / n + np.eye(n)
+    b = rng.normal(0, 1, n)
+    L = np.tril(A).copy()
+    x = np.zeros(n)
+    rc = hip.load().glio_debug_chol_solve(ctx._h, n, L.ctypes.data_as(C.POINTER(C.c_double)), b.ctypes.data_as(C.POINTER(C.c_double)), x.ctypes.data_as(C.POINTER(C.c_double)))
+    ctx.close()
+    assert rc == 0
+    xs = np.linalg.solve(A, b)
+    assert np.linalg.norm(x - xs) <= 1e-11 * np.linalg.norm(xs)
+
+
 def _steady_window_22(po):
     W = 22
     long = synth.make_window(W=W + 1, pts_per_scan=200, with_gnss=True, seed=synth.SEED_BASE + 93)
@@ -463,9 +483,9 @@ def test_chain_step_on_a_window_too_large_for_its_lds_mirrors(hip, po):
     assert_pose_parity(sc, so, tol_t=1e-7, tol_r=1e-8)
 
 
-@pytest.mark.xfail(reason="open defect found at the end of round 3 (scripts/dense_vs_chain_sizes.py): the DENSE fallback (solver mode 0) is right up to n = 376 "
-                          "and runs into the iteration limit at n = 414, 1.6 mm off; the structured paths are not affected", strict=False)
 def test_dense_fallback_at_n_414(hip, po):
+    """The dense fallback (solver mode 0) on a window with more than 384 rows under the first panel of its blocked Cholesky: until the end of
+    round 3 the wavefronts' second round re-read a diagonal block that wavefront 0 had already overwritten with its factor (n >= 400)."""
     win, corr = _steady_window_22(po)
     so, mo = po.Problem(win, corr).solve(win.init.copy())
     ctx = hip.Context(win.opts)
