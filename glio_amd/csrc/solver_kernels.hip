@@ -353,6 +353,9 @@ __device__ __forceinline__ bool chol_packed_lds(double* P, const int n, double* 
         //       AND solve those rows with the same v_readlane broadcasts -- no separate triangular-solve phase.
         const int r0 = k0 + nb;
         const int mb = n + 1 - r0;
+        double adg[TR_NB];                        // wavefront 0: the factored diagonal block, stored after the barrier (the other wavefronts
+#pragma unroll                                    // read the unfactored one at the start of their step; nothing orders that read before a store here)
+        for (int j = 0; j < TR_NB; ++j) adg[j] = 0.0;
         if (wv == 0 || wv * 48 < mb) {
             const bool isdiag = lane < TR_NB;
             const int bi = wv * 48 + lane - TR_NB;
@@ -372,14 +375,23 @@ __device__ __forceinline__ bool chol_packed_lds(double* P, const int n, double* 
 #pragma unroll
                 for (int c = j + 1; c < TR_NB; ++c) a[c] -= lij * readlane_d(lij, c);
             }
-            if (live && (wv == 0 || !isdiag)) {
+            if (live && !isdiag) {
 #pragma unroll
-                for (int j = 0; j < TR_NB; ++j) if (j < nb && (!isdiag || j <= lane)) prow[j] = a[j];
+                for (int j = 0; j < TR_NB; ++j) if (j < nb) prow[j] = a[j];
+            }
+            if (wv == 0) {
+#pragma unroll
+                for (int j = 0; j < TR_NB; ++j) adg[j] = a[j];
             }
             if (bad && wv == 0 && lane == 0) *flag = 1 + k0;
         }
         __syncthreads();
         if (*flag) return false;
+        if (wv == 0 && lane < nb) {
+            double* prow = P + pk_off(k0 + lane) + k0;
+#pragma unroll
+            for (int j = 0; j < TR_NB; ++j) if (j < nb && j <= lane) prow[j] = adg[j];
+        }
         if (nb == TR_NB && r0 < n) {
             const int T = (n + 1 - r0 + 15) >> 4;
             const int ntiles = (T * (T + 1)) >> 1;
