@@ -184,11 +184,13 @@ def pair_list(K, search_range):
     return np.asarray(ci, np.int32), np.asarray(cj, np.int32)
 
 
-def pair_shard(pair_ci, K, rank, world):
+def pair_shard(pair_ci, K, rank, world, band):
     """Slice [first, last) of a ci-major pair list (pair_list) owned by `rank`: the pairs whose SOURCE keyframe lies in the
     rank's keyframe range -- the same ownership rule as the constraints of the batch stage, so a rank associates exactly
-    the pairs whose constraints it will linearise and nothing crosses ranks before the one all-reduce."""
-    lo, hi = shard_range(K, rank, world)
+    the pairs whose constraints it will linearise and nothing crosses ranks before the one all-reduce.  `band` is the STAGE's
+    band (2 * search_range for pair_list(K, search_range): the end windows reach that far), because the ranges are cut on the
+    super-blocks of the solver, whose size depends on it (shard_range)."""
+    lo, hi = shard_range(K, rank, world, band)
     ci = np.asarray(pair_ci)
     return int(np.searchsorted(ci, lo, side="left")), int(np.searchsorted(ci, hi, side="left"))
 

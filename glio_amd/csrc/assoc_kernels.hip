@@ -1243,6 +1243,8 @@ int glio_assoc_run_window_async(glio_ctx* c, const double* quats, const double* 
     AssocWork* w = c->assoc;
     if (!w) return GLIO_E_STATE;
     if (c->map_n <= 0) { glio_set_error("no map set"); return GLIO_E_STATE; }
+    // an earlier asynchronous call may still be reading the pinned staging block (poses, scan counts) this one rewrites: take it over first
+    { const int rp = glio_assoc_finish_pending(c); if (rp != GLIO_OK) return rp; }
     for (int k = 0; k < 4; ++k) w->last_pose0[k] = quats[k];
     for (int k = 0; k < 3; ++k) w->last_pose0[4 + k] = trans[k];
     w->have_pose0 = 1;

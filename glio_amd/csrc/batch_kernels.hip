@@ -768,6 +768,7 @@ static int build_pairs(glio_batch* b, int64_t n, const int32_t* ci, const int32_
     }
     off.push_back(n);
     if ((int)pi.size() > b->max_pairs) return GLIO_E_ARG;
+    b->src_min = pi.empty() ? 0 : pi.front(); b->src_max = pi.empty() ? -1 : pi.back();      // (sorted by ci)
     b->n_pairs = (int)pi.size();
     if (b->n_pairs) {
         GLIO_HIP_CHECK(hipMemcpy(b->d_pair_i, pi.data(), pi.size() * 4, hipMemcpyHostToDevice));
@@ -821,6 +822,7 @@ int glio_batch_update_constraints_pairs_dev(glio_batch* b, int n_pairs, const in
     }
     off.push_back(run);
     if ((int)pi.size() > b->max_pairs) return GLIO_E_ARG;
+    b->src_min = pi.empty() ? 0 : pi.front(); b->src_max = pi.empty() ? -1 : pi.back();      // (sorted by ci)
     {   // do the moment records of the unmarked pairs still stand?  only when the list of non-empty pairs is the one they were taken for
         bool same = pair_changed && b->moments_valid && b->h_prev_n == (int)pi.size() && b->d_moments && b->moments_pairs >= (int)pi.size();
         for (size_t q = 0; same && q < pi.size(); ++q) same = b->h_prev_pi[q] == pi[q] && b->h_prev_pj[q] == pj[q];

@@ -846,15 +846,13 @@ void glio_batch_small_destroy(glio_batch* b) {
 }
 
 // workspaces of the trust-region solve for the present (B, rank, world); (re)built when one of them changed
-static int tr_ensure(glio_batch* b) {
+static int tr_build(glio_batch* b, const int B) {
     BatchSmall* s = b->small;
-    const int K = b->K, band = b->band, B = s->n_imu > 0 ? 15 : 6;
-    if (s->bcr && s->bcr_B == B && s->bcr_rank == s->rank && s->bcr_world == s->world) return GLIO_OK;
-    tr_free(s);
+    const int K = b->K, band = b->band;
+    if (s->world - 1 > 64) { glio_set_error("more than 65 ranks"); return GLIO_E_ARG; }
     s->B = B;
     s->bcr = glio_bcr_create2(K, band, B, s->rank, s->world);
     if (!s->bcr) { if (B == 15 && band > 6) glio_set_error("the batch problem with the IMU chain is solved for band <= 6 (super-blocks of 6 keyframes x 15 states)"); return GLIO_E_ARG; }
-    s->bcr_B = B; s->bcr_rank = s->rank; s->bcr_world = s->world;
     int lo, hi;
     glio_bcr_owned_range(s->bcr, &lo, &hi);
     if (lo != s->lo || hi != s->hi) { glio_set_error("shard range mismatch"); return GLIO_E_STATE; }
@@ -887,8 +885,17 @@ static int tr_ensure(glio_batch* b) {
     memset(s->h_prog, 0, 64);
     std::vector<int> bnd(std::max(NB, 1), 0);
     for (int j = 0; j < NB; ++j) { int l, h2; shard_range(K, band, j, s->world, &l, &h2); bnd[j] = h2; }
-    if (NB > 64) { glio_set_error("more than 65 ranks"); return GLIO_E_ARG; }
     BT_CHECK(hipMemcpy(s->d_bnd_kf, bnd.data(), (size_t)std::max(NB, 1) * 4, hipMemcpyHostToDevice));
+    return GLIO_OK;
+}
+static int tr_ensure(glio_batch* b) {
+    BatchSmall* s = b->small;
+    const int B = s->n_imu > 0 ? 15 : 6;
+    if (s->bcr && s->bcr_B == B && s->bcr_rank == s->rank && s->bcr_world == s->world) return GLIO_OK;
+    tr_free(s);
+    const int rc = tr_build(b, B);
+    if (rc != GLIO_OK) { tr_free(s); return rc; }     // a half-built set (an allocation failed midway) must not pass the check above next time
+    s->bcr_B = B; s->bcr_rank = s->rank; s->bcr_world = s->world;   // the cache keys only once every buffer exists
     return GLIO_OK;
 }
 
@@ -1232,6 +1239,13 @@ int glio_batch_solve_tr2(glio_batch* b, double* poses, double* speed_bias, const
     BatchSmall* s = b->small;
     if (s->n_imu > 0 && !speed_bias) { glio_set_error("the IMU chain is set: speed_bias [K][9] is needed"); return GLIO_E_ARG; }
     if (s->world > 1 && !allreduce) { glio_set_error("rank %d of %d needs the all-reduce hook", s->rank, s->world); return GLIO_E_ARG; }
+    // ownership: a sharded stage assembles the rows of keyframes lo - band .. hi + band only, so a constraint whose SOURCE keyframe another rank
+    // owns would be summed into rows this rank never hands to the all-reduce (silently wrong sums) -- refuse it instead
+    if (s->world > 1 && b->src_max >= b->src_min && (b->src_min < s->lo || b->src_max >= s->hi)) {
+        glio_set_error("rank %d of %d owns keyframes [%d, %d): constraint source keyframes %d..%d lie outside (shard the pairs with glio_batch_shard_range at THIS band)",
+                       s->rank, s->world, s->lo, s->hi, b->src_min, b->src_max);
+        return GLIO_E_ARG;
+    }
     const int K = b->K;
     hipStream_t st = b->stream;
     memset(sum, 0, sizeof *sum);
@@ -1267,8 +1281,9 @@ int glio_batch_solve_tr2(glio_batch* b, double* poses, double* speed_bias, const
         long long spins = 0;
         bool finished = false;
         for (;;) {
-            if (s->h_prog[1] == id) { finished = true; break; }
-            const int w = s->h_prog[0];
+            // GPU-written mapped words: every poll is a real load (acquire), never a value the compiler kept in a register
+            if (__atomic_load_n(&s->h_prog[1], __ATOMIC_ACQUIRE) == id) { finished = true; break; }
+            const int w = __atomic_load_n(&s->h_prog[0], __ATOMIC_ACQUIRE);
             if ((w >> 16) == id && (w & 0xffff) >= (g & 0xffff)) break;
             if (((++spins) & 0x3f) == 0) std::this_thread::yield();        // a group lasts a millisecond or more: polling does not need the whole core
             if ((spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {

@@ -293,6 +293,10 @@ __device__ __forceinline__ bool chol_left_looking(double* A, const int n, double
 #pragma unroll
             for (int j = 0; j < TR_NB; ++j) if (j < nb && j <= lane) prow[j] = adg[j];
         }
+        // Inside the loop nothing reads this diagonal block again (later panels touch rows >= k0 + 16 only), but after the LAST panel
+        // the caller does (the marginalization kernel copies L out with all eight wavefronts straight after the call): the store
+        // above must be ordered before the return by a barrier, not by timing.
+        if (k0 + TR_NB >= n) __syncthreads();
     }
     return true;
 }

@@ -119,7 +119,7 @@ def _assoc_worker(rank, world, port, K, rng, out_path):
     from oracle import pyoracle as po
     scans, poses = _frames(K)
     ci, cj = batch.pair_list(K, rng)
-    first, last = batch.pair_shard(ci, K, rank, world)
+    first, last = batch.pair_shard(ci, K, rank, world, 2 * rng)
     Hg = torch.from_numpy(_associate_and_linearize(po, scans, poses, ci[first:last], cj[first:last], K, 2 * rng))
     dist.all_reduce(Hg, op=dist.ReduceOp.SUM)
     if rank == 0:
@@ -132,10 +132,11 @@ def test_pair_shards_partition_the_pair_list():
     for K, rng in ((6, 1), (20, 3), (33, 6)):
         ci, cj = batch.pair_list(K, rng)
         for world in (1, 2, 3, 8):
-            cuts = [batch.pair_shard(ci, K, r, world) for r in range(world)]
+            band = 2 * rng          # the end windows of pair_list reach 2 * search_range: the band of the stage that takes these pairs
+            cuts = [batch.pair_shard(ci, K, r, world, band) for r in range(world)]
             assert cuts[0][0] == 0 and cuts[-1][1] == len(ci) and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
             for r, (f, l) in enumerate(cuts):
-                lo, hi = batch.shard_range(K, r, world)
+                lo, hi = batch.shard_range(K, r, world, band)       # (band 12 cuts on 12-keyframe super-blocks, not the default 6)
                 assert np.all((ci[f:l] >= lo) & (ci[f:l] < hi))
 
 

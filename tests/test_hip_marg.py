@@ -58,6 +58,26 @@ def test_marginalize_matches_oracle(hip, po, small_window, small_corr, use_prior
     ctx.close()
 
 
+@pytest.mark.parametrize("W", [3, 4], ids=["n21", "n27"])
+def test_marginalize_dense_schur_small(hip, po, W):
+    """A dense (not block-diagonal) prior sends the kernel through the blocked dense Cholesky (chol_left_looking<SEMI>) with
+    n = 21 / 27: two panels, the LAST diagonal block stored by wavefront 0 and read straight after the call by all eight
+    wavefronts for the J0 copy -- the hand-off that needs the barrier after the last panel."""
+    win = synth.make_window(W=W, pts_per_scan=500, with_prior=True, seed=synth.SEED_BASE + 41 + W)
+    assert np.count_nonzero(np.triu(win.prior["lin_jac"].T @ win.prior["lin_jac"], 16)) > 0      # dense information matrix
+    corr = synth.analytic_correspondences(win)
+    prob = po.Problem(win, corr, use_gnss=False)
+    for rep in range(3):                                   # (an ordering defect shows up as a flaky compare: repeat on fresh contexts)
+        ctx = hip.Context(win.opts)
+        ctx.load_window(win, corr, use_gnss=False)
+        st = win.init.copy(); st.n_ddt = 0
+        sol, _ = ctx.solve(st)
+        out_h = ctx.marginalize(sol)
+        assert out_h["n"] == 6 * (W - 1) + 9
+        _check_root(out_h, prob.marginalize(sol))
+        ctx.close()
+
+
 def test_marginalize_with_gnss_in_window(hip, po, small_window, small_corr):
     """GNSS factors are not part of the marginalization (Estimator.cpp:2462-2607 adds prior, IMU, LiDAR only)."""
     win = small_window
