@@ -146,6 +146,8 @@ typedef struct orc_batch_problem {
 } orc_batch_problem;
 /* delta_q_factor_auto (LidarKeyframeFactor.h:283-303): blocks qi[4], qj[4]; 3 residuals = 10000 (dq^-1 qi^-1 qj).vec; global Jacobians 3x4 */
 int orc_eval_delta_q(const double dq_const[4], double const* const* parameters, double* residuals, double** jacobians);
+/* LidarPoseFactorBatchRelativeAutoDiff (LidarPoseFactor.h:55-97): blocks P1[3] Q1[4] P2[3] Q2[4]; 6 residuals; global Jacobians 6 x {3,4,3,4} */
+int orc_eval_relative_pose(const double dq[4], const double dp[3], double const* const* parameters, double* residuals, double** jacobians);
 /* banded normal equations of ALL factors (layout as orc_batch_linearize) */
 int orc_batch_linearize_full(const orc_batch_problem* p, const double* poses, double* Hband, double* g, double* cost);
 /* Ceres-1.14 trust region on the batch problem (orc_batch2.c): Jacobi scaling, DOGLEG with o->dogleg_type (the reference:

@@ -91,6 +91,63 @@ int orc_eval_delta_q(const double dq_const[4], double const* const* P, double* r
     return 1;
 }
 
+/* LidarPoseFactorBatchRelativeAutoDiff (LidarPoseFactor.h:55-97; built at Estimator.cpp:2897-2955 for sms_fusion_level == 0, the shipped
+ * default config_urban_hk.yaml:63): blocks P1[3], Q1[4], P2[3], Q2[4]; 6 residuals
+ *   r[0:3] = 10 * 2 (dq^-1 * Q1^-1 * Q2).vec,   r[3:6] = 20 * (Q1^-1 * (P2 - P1) - dp)
+ * with Eigen's inverse() (conjugate / squared norm) and Eigen's q * v = v + 2 w (u x v) + 2 u x (u x v) on the NON-normalised Q1^-1 --
+ * exactly what the Jets differentiate.  Global Jacobians 6 x {3, 4, 3, 4}, row-major. */
+int orc_eval_relative_pose(const double dq[4], const double dp[3], double const* const* P, double* r, double** J) {
+    const double *p1 = P[0], *q1 = P[1], *p2 = P[2], *q2 = P[3];
+    double A[4], u[4], Au[4], p[4], v[3], rv[3];
+    q_inv(dq, A);
+    q_inv(q1, u);
+    q_mul(A, u, Au);
+    q_mul(Au, q2, p);
+    for (int k = 0; k < 3; ++k) { v[k] = p2[k] - p1[k]; r[k] = 10.0 * 2.0 * p[1 + k]; }
+    q_rot(u, v, rv);
+    for (int k = 0; k < 3; ++k) r[3 + k] = 20.0 * (rv[k] - dp[k]);
+    if (!J) return 1;
+    /* M(u) = d (u * v) / d v = I + 2 w [q]x + 2 [q]x [q]x */
+    double Sq[9], Sq2[9], M[9];
+    skew3(u + 1, Sq);
+    mat_mul(Sq, Sq, Sq2, 3, 3, 3);
+    for (int k = 0; k < 9; ++k) M[k] = ((k % 4 == 0) ? 1.0 : 0.0) + 2.0 * u[0] * Sq[k] + 2.0 * Sq2[k];
+    if (J[0]) { for (int k = 0; k < 9; ++k) J[0][k] = 0.0; for (int k = 0; k < 9; ++k) J[0][9 + k] = -20.0 * M[k]; }
+    if (J[2]) { for (int k = 0; k < 9; ++k) J[2][k] = 0.0; for (int k = 0; k < 9; ++k) J[2][9 + k] = 20.0 * M[k]; }
+    if (J[3]) {
+        double L[16];
+        q_left(Au, L);
+        for (int k = 0; k < 3; ++k) for (int c = 0; c < 4; ++c) { J[3][k * 4 + c] = 20.0 * L[(1 + k) * 4 + c]; J[3][(3 + k) * 4 + c] = 0.0; }
+    }
+    if (J[1]) {
+        /* d u / d q1, u = conj(q1) / |q1|^2 */
+        double dU[16];
+        const double n2 = q1[0] * q1[0] + q1[1] * q1[1] + q1[2] * q1[2] + q1[3] * q1[3];
+        const double Cq[4] = {q1[0], -q1[1], -q1[2], -q1[3]};
+        for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) dU[a * 4 + b] = ((a == b ? (a == 0 ? 1.0 : -1.0) : 0.0) - 2.0 * Cq[a] * q1[b] / n2) / n2;
+        /* rows 0..2: 20 [L(A) R(q2)]_(vec rows) dU */
+        double LA[16], Rv[16], Mq[16];
+        q_left(A, LA); q_right(q2, Rv);
+        for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) { double s = 0; for (int k = 0; k < 4; ++k) s += LA[a * 4 + k] * Rv[k * 4 + b]; Mq[a * 4 + b] = s; }
+        /* rows 3..5: 20 d(u * v)/d u dU;  d/dw = 2 (q x v),  d/dq = -2 w [v]x + 2 ((q.v) I + q v^T - 2 v q^T) */
+        double D[12], qxv[3], Sv[9];
+        v3_cross(u + 1, v, qxv);
+        skew3(v, Sv);
+        const double qv = v3_dot(u + 1, v);
+        for (int k = 0; k < 3; ++k) {
+            D[k * 4 + 0] = 2.0 * qxv[k];
+            for (int c = 0; c < 3; ++c)
+                D[k * 4 + 1 + c] = -2.0 * u[0] * Sv[k * 3 + c] + 2.0 * ((k == c ? qv : 0.0) + u[1 + k] * v[c] - 2.0 * v[k] * u[1 + c]);
+        }
+        for (int k = 0; k < 3; ++k) for (int c = 0; c < 4; ++c) {
+            double s0 = 0, s1 = 0;
+            for (int m = 0; m < 4; ++m) { s0 += Mq[(1 + k) * 4 + m] * dU[m * 4 + c]; s1 += D[k * 4 + m] * dU[m * 4 + c]; }
+            J[1][k * 4 + c] = 20.0 * s0; J[1][(3 + k) * 4 + c] = 20.0 * s1;
+        }
+    }
+    return 1;
+}
+
 /* adds J^T J / J^T r of one residual block with local Jacobians Ja (nr x 6, keyframe a) and Jb (nr x 6, keyframe b) */
 static void band_add(int band, double* Hband, double* g, int a, int b, int nr, const double* Ja, const double* Jb, const double* r) {
     double* Haa = Hband + ((size_t)a * (band + 1) + 0) * 36;

@@ -286,6 +286,14 @@ def eval_delta_q(dq_const, qi, qj, want_J=True):
     return r, J
 
 
+def eval_relative_pose(dq, dp, p1, q1, p2, q2, want_J=True):
+    r = np.zeros(6)
+    J = [np.zeros((6, 3)), np.zeros((6, 4)), np.zeros((6, 3)), np.zeros((6, 4))]
+    lib().orc_eval_relative_pose(T.dptr(np.ascontiguousarray(dq, float)), T.dptr(np.ascontiguousarray(dp, float)),
+                                 _pp([np.ascontiguousarray(a, float) for a in (p1, q1, p2, q2)]), T.dptr(r), _pp(J) if want_J else None)
+    return r, J
+
+
 class BatchProblem:
     """Owns the numpy buffers behind an orc_batch_problem: binary plane constraints, delta_q attitude constraints (i, j, const_diff),
     DD pseudorange factors (slot_i / slot_j = keyframe indices)."""

@@ -1,0 +1,2 @@
+// empty stand-in: the reference header utils/common.h includes <message_filters/subscriber.h>, the factor layer uses nothing of it (oracle/ref_shim, test infrastructure)
+#pragma once

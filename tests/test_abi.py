@@ -76,3 +76,15 @@ def test_product_package_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "pyoracle" not in txt and "glio_oracle" not in txt and "orc_" not in txt, f
+                # ... nor the reference's own factor code built for the checker (oracle/_ref, oracle/ref_shim, oracle/pyref.py)
+                assert "pyref" not in txt and "libglio_ref" not in txt and "ref_shim" not in txt and "ref_eval_" not in txt and "/root/reference" not in txt, f
+
+
+def test_product_library_does_not_link_the_checkers():
+    """libglio_hip.so and the C++ host demos need neither the oracle nor the reference build: no such DT_NEEDED entry, no such symbol"""
+    import subprocess
+    so = os.path.join(ROOT, "glio_amd", "lib", "libglio_hip.so")
+    dyn = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
+    assert "libglio_oracle" not in dyn and "libglio_ref" not in dyn
+    syms = subprocess.run(["nm", "-D", so], capture_output=True, text=True).stdout
+    assert " orc_" not in syms and " ref_eval_" not in syms and " ref_marginalize" not in syms

@@ -1,0 +1,211 @@
+"""Golden vectors of THE REFERENCE'S OWN factor code (tests/golden/ref_factors.npz, written by tests/golden/make_golden_ref.py from
+oracle/_ref/libglio_ref.so = the reference's headers compiled unmodified, oracle/ref_shim/Makefile) against
+  * the oracle (CPU, runs anywhere -- the GPU box has no /root/reference, the vectors are how the reference travels),
+  * the HIP evaluators of the C-ABI (glio_eval_*, glio_marginalize) on the GPU,
+  * and, where the reference tree exists, a fresh run of the generator (the committed file is reproducible).
+Tolerance 1e-12 relative to max(1, |reference|) for every factor; 1e-9 on the marginalization's Schur complement."""
+import os
+
+import numpy as np
+import pytest
+
+from glio_amd import ctypes_types as T
+from glio_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def G():
+    return dict(np.load(os.path.join(HERE, "golden", "ref_factors.npz")))
+
+
+@pytest.fixture(scope="module")
+def po():
+    from oracle import pyoracle
+    return pyoracle
+
+
+def close(a, b, tol=1e-12):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max())
+
+
+def _struct(cls, raw):
+    return cls.from_buffer_copy(raw.tobytes())
+
+
+def _imu_params(row):
+    return [row[0:3], row[3:7], row[7:16], row[16:19], row[19:23], row[23:32]]
+
+
+def _dop_args(row, nslot):
+    return [row[0:3], row[3:12], row[12:15], row[15:24], row[24:24 + nslot]]
+
+
+def _margf_params(pr, row):
+    out, o = [], 0
+    for k in pr["blk_kind"]:
+        sz = 3 if k == T.BLK_TRANS else (4 if k == T.BLK_QUAT else 9)
+        out.append(row[o:o + sz]); o += sz
+    return out
+
+
+def _canonical(out):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_ref", os.path.join(HERE, "golden", "make_golden_ref.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    return m.canonical_marg(out)
+
+
+# ------------------------------------------------------------------------------------------------ the oracle vs the reference's vectors (CPU)
+def test_committed_vectors_are_what_the_generator_writes(G):
+    from oracle import pyref
+    if not os.path.isdir(os.path.join(pyref.REFERENCE, "GLIO", "include", "factors")):
+        pytest.skip("no reference tree here: the committed vectors are used as they are")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_ref", os.path.join(HERE, "golden", "make_golden_ref.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    fresh = m.generate()
+    assert set(fresh) == set(G)
+    for k in G:
+        assert np.array_equal(np.asarray(fresh[k]), G[k]), k
+
+
+def test_oracle_lidar_plane(G, po):
+    o = synth.default_opts()
+    for k in range(len(G["lidar_r_out"])):
+        o.q_lb[:] = list(G["lidar_qlb_in"][k]); o.t_lb[:] = list(G["lidar_tlb_in"][k])
+        r, Jt, Jq = po.eval_lidar_plane(o, G["lidar_cp_in"][k], G["lidar_plane_in"][k], float(G["lidar_score_in"][k]), G["lidar_t_in"][k], G["lidar_q_in"][k])
+        assert close(r, G["lidar_r_out"][k]) and close(Jt, G["lidar_Jt_out"][k]) and close(Jq, G["lidar_Jq_out"][k]), k
+
+
+def test_oracle_binary_plane_delta_q_relative_pose(G, po):
+    for k in range(len(G["binary_r_out"])):
+        r, J = po.eval_binary_plane(G["binary_cp_in"][k], G["binary_pnc_in"][k], float(G["binary_score_in"][k]), G["binary_t1_in"][k], G["binary_q1_in"][k],
+                                    G["binary_t2_in"][k], G["binary_q2_in"][k])
+        assert close(r, G["binary_r_out"][k]) and all(close(J[b], G["binary_J%d_out" % b][k]) for b in range(4)), k
+        r, J = po.eval_delta_q(G["deltaq_dq_in"][k], G["deltaq_qi_in"][k], G["deltaq_qj_in"][k])
+        assert close(r, G["deltaq_r_out"][k]) and close(J[0], G["deltaq_J0_out"][k]) and close(J[1], G["deltaq_J1_out"][k]), k
+        r, J = po.eval_relative_pose(G["relpose_dq_in"][k], G["relpose_dp_in"][k], G["relpose_p1_in"][k], G["relpose_q1_in"][k], G["relpose_p2_in"][k], G["relpose_q2_in"][k])
+        assert close(r, G["relpose_r_out"][k]) and all(close(J[b], G["relpose_J%d_out" % b][k]) for b in range(4)), k
+
+
+def test_oracle_imu_and_preintegration(G, po):
+    o = synth.default_opts()
+    o.gravity = float(G["imu_gravity_in"])
+    for k in range(len(G["imu_r_out"])):
+        ps = _struct(T.GlioPreint, G["imu_preint_in"][k])
+        r, J = po.eval_imu(o, ps, _imu_params(G["imu_params_in"][k]))
+        assert close(r, G["imu_r_out"][k]) and all(close(J[b], G["imu_J%d_out" % b][k]) for b in range(6)), k
+    mine = synth.preintegrate(G["preint_acc_in"], G["preint_gyr_in"], G["preint_dt_in"], G["preint_ba_in"], G["preint_bg_in"])
+    want = _struct(T.GlioPreint, G["preint_out"])
+    assert close(mine["delta_p"], list(want.delta_p)) and close(mine["delta_q"], list(want.delta_q)) and close(mine["delta_v"], list(want.delta_v))
+    assert close(np.asarray(mine["jacobian"]).ravel(), list(want.jacobian), 1e-11) and close(np.asarray(mine["covariance"]).ravel(), list(want.covariance), 1e-11)
+
+
+def test_oracle_gnss(G, po):
+    for k in range(len(G["dd_r_out"])):
+        f = _struct(T.GlioDdPsr, G["dd_f_in"][k])
+        r, J = po.eval_dd_psr(f, G["dd_Pi_in"][k], G["dd_Pj_in"][k], float(G["dd_yaw_in"][k]), G["dd_anc_in"][k])
+        assert close(r, G["dd_r_out"][k], 1e-11) and close(J[0], G["dd_J0_out"][k]) and close(J[1], G["dd_J1_out"][k]), k
+    nslot = int(G["dop_nslot_in"])
+    for k in range(len(G["dop_r_out"])):
+        f = _struct(T.GlioDoppler, G["dop_f_in"][k])
+        r, J = po.eval_doppler(f, *_dop_args(G["dop_args_in"][k], nslot), float(G["dop_yaw_in"][k]), G["dop_anc_in"][k])
+        assert close(r, G["dop_r_out"][k], 1e-11) and all(close(J[b], G["dop_J%d_out" % b][k], 1e-11) for b in range(5)), k
+    for k in range(len(G["ecef_in"])):
+        R = np.zeros(9)
+        po.lib().orc_ecef2rotation(T.dptr(np.ascontiguousarray(G["ecef_in"][k])), T.dptr(R))
+        assert close(R.reshape(3, 3), G["ecef_R_out"][k], 1e-13)
+
+
+def test_oracle_marginalization_factor_and_step(G, po):
+    win = synth.make_window(W=4, pts_per_scan=32, with_prior=True, seed=int(G["margf_seed_in"]))
+    pr = win.prior
+    for k in range(len(G["margf_r_out"])):
+        r, J = po.eval_marg(pr, _margf_params(pr, G["margf_params_in"][k]))
+        assert close(r, G["margf_r_out"][k]) and close(np.concatenate([j.ravel() for j in J]), G["margf_J_out"][k]), k
+    winm = synth.make_window(W=4, pts_per_scan=300, with_prior=True, seed=int(G["marg_seed_in"]))
+    corr = synth.analytic_correspondences(winm)
+    prob = po.Problem(winm, corr, use_gnss=False, use_prior=True)
+    sol = winm.init.copy(); sol.n_ddt = 0
+    sol.trans[:], sol.quat[:], sol.speed_bias[:] = G["marg_trans_in"], G["marg_quat_in"], G["marg_sb_in"]
+    S, b, c, order, x0 = _canonical(prob.marginalize(sol))
+    assert np.array_equal(order, G["marg_order_out"]) and np.array_equal(x0, G["marg_x0_out"])
+    assert np.linalg.norm(S - G["marg_S_out"]) <= 1e-9 * np.linalg.norm(G["marg_S_out"])
+    assert np.linalg.norm(b - G["marg_b_out"]) <= 1e-8 * np.linalg.norm(G["marg_b_out"]) and abs(c - float(G["marg_c_out"])) <= 1e-7 * float(G["marg_c_out"])
+
+
+# ------------------------------------------------------------------------------------------------ the HIP evaluators vs the reference's vectors (GPU)
+@pytest.fixture(scope="module")
+def hip():
+    from glio_amd import capi
+    assert capi.device_count() >= 1, "no HIP device: the product path has no fallback"
+    return capi
+
+
+@pytest.mark.gpu
+def test_hip_lidar_and_binary_plane_vs_reference_vectors(G, hip):
+    ctxs = {}
+    for k in range(len(G["lidar_r_out"])):
+        key = tuple(G["lidar_qlb_in"][k]) + tuple(G["lidar_tlb_in"][k])
+        if key not in ctxs:
+            o = synth.default_opts(W=3, pts=1024, map_pts=4096)
+            o.q_lb[:] = list(G["lidar_qlb_in"][k]); o.t_lb[:] = list(G["lidar_tlb_in"][k])
+            ctxs[key] = hip.Context(o)
+        r, Jt, Jq = ctxs[key].eval_lidar_plane(G["lidar_cp_in"][k], G["lidar_plane_in"][k], float(G["lidar_score_in"][k]), G["lidar_t_in"][k], G["lidar_q_in"][k])
+        assert close(r, G["lidar_r_out"][k]) and close(Jt, G["lidar_Jt_out"][k]) and close(Jq, G["lidar_Jq_out"][k]), k
+    ctx = next(iter(ctxs.values()))
+    for k in range(len(G["binary_r_out"])):
+        r, J = ctx.eval_binary_plane(G["binary_cp_in"][k], G["binary_pnc_in"][k], float(G["binary_score_in"][k]), G["binary_t1_in"][k], G["binary_q1_in"][k],
+                                     G["binary_t2_in"][k], G["binary_q2_in"][k])
+        assert close(r, G["binary_r_out"][k]) and all(close(J[b], G["binary_J%d_out" % b][k]) for b in range(4)), k
+    for c in ctxs.values():
+        c.close()
+
+
+@pytest.mark.gpu
+def test_hip_imu_gnss_marg_factor_vs_reference_vectors(G, hip):
+    o = synth.default_opts(W=4, pts=1024, map_pts=4096, n_ddt=int(G["dop_nslot_in"]))
+    o.gravity = float(G["imu_gravity_in"])
+    ctx = hip.Context(o)
+    lib = hip.load()
+    import ctypes as C
+    for k in range(len(G["imu_r_out"])):
+        ps = _struct(T.GlioPreint, G["imu_preint_in"][k])
+        params = [np.ascontiguousarray(p, float) for p in _imu_params(G["imu_params_in"][k])]
+        r = np.zeros(15); Js = [np.zeros((15, s)) for s in (3, 4, 9, 3, 4, 9)]
+        hip._check(lib.glio_eval_imu(ctx._h, C.byref(ps), hip._ptrs(params), T.dptr(r), hip._ptrs(Js)))
+        assert close(r, G["imu_r_out"][k], 1e-11) and all(close(Js[b], G["imu_J%d_out" % b][k], 1e-11) for b in range(6)), k
+    for k in range(len(G["dd_r_out"])):
+        f = _struct(T.GlioDdPsr, G["dd_f_in"][k])
+        r, J = ctx.eval_dd_psr(f, G["dd_Pi_in"][k], G["dd_Pj_in"][k], float(G["dd_yaw_in"][k]), G["dd_anc_in"][k])
+        assert close(r, G["dd_r_out"][k], 1e-10) and close(J[0], G["dd_J0_out"][k], 1e-11) and close(J[1], G["dd_J1_out"][k], 1e-11), k
+    nslot = int(G["dop_nslot_in"])
+    for k in range(len(G["dop_r_out"])):
+        f = _struct(T.GlioDoppler, G["dop_f_in"][k])
+        r, J = ctx.eval_doppler(f, *_dop_args(G["dop_args_in"][k], nslot), float(G["dop_yaw_in"][k]), G["dop_anc_in"][k])
+        assert close(r, G["dop_r_out"][k], 1e-10) and all(close(J[b], G["dop_J%d_out" % b][k], 1e-10) for b in range(5)), k
+    win = synth.make_window(W=4, pts_per_scan=32, with_prior=True, seed=int(G["margf_seed_in"]))
+    pr = win.prior
+    for k in range(len(G["margf_r_out"])):
+        r, J = ctx.eval_marginalization(pr, _margf_params(pr, G["margf_params_in"][k]))
+        assert close(r, G["margf_r_out"][k], 1e-11) and close(np.concatenate([j.ravel() for j in J]), G["margf_J_out"][k], 1e-11), k
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_hip_marginalize_vs_reference_vectors(G, hip):
+    """glio_marginalize (K3 blocks + IMU edge + prior assembled and Schur-reduced on the device) vs MarginalizationInfo::Marginalize of the reference"""
+    winm = synth.make_window(W=4, pts_per_scan=300, with_prior=True, seed=int(G["marg_seed_in"]))
+    corr = synth.analytic_correspondences(winm)
+    ctx = hip.Context(winm.opts)
+    ctx.load_window(winm, corr, use_gnss=False, use_prior=True)
+    sol = winm.init.copy(); sol.n_ddt = 0
+    sol.trans[:], sol.quat[:], sol.speed_bias[:] = G["marg_trans_in"], G["marg_quat_in"], G["marg_sb_in"]
+    S, b, c, order, x0 = _canonical(ctx.marginalize(sol))
+    assert np.array_equal(order, G["marg_order_out"]) and np.array_equal(x0, G["marg_x0_out"])
+    assert np.linalg.norm(S - G["marg_S_out"]) <= 1e-8 * np.linalg.norm(G["marg_S_out"])
+    assert np.linalg.norm(b - G["marg_b_out"]) <= 1e-8 * np.linalg.norm(G["marg_b_out"]) and abs(c - float(G["marg_c_out"])) <= 1e-7 * float(G["marg_c_out"])
+    ctx.close()
