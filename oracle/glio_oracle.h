@@ -7,11 +7,13 @@
  * through the ceres::CostFunction::Evaluate convention, the loss corrector and the quaternion
  * local parameterisation are applied afterwards, and the normal equations are summed densely.
  *
- * PARITY UNPINNED: the reference has no tests or golden vectors for this path (SURVEY.md section 4,
- * 8c) and cannot be built here (needs ROS, PCL, Ceres, Eigen, GTSAM -- none installed, Ceres tarball
- * stripped from the tree).  This restatement is pinned only by self-authored checks: central finite
- * differences, an independent numpy transcription of the factors (tests/numpy_factors.py), and
- * closed-form cases.  Every number produced with it must be labelled
+ * PARITY: the FACTOR LAYER of this restatement (every orc_eval_*, the pre-integration inputs, the invariants of
+ * orc_marginalize) is pinned, since round 4, on the reference's own code: oracle/_ref/libglio_ref.so = the reference's
+ * factor headers + MarginalizationFactor.cpp + gnss_utility.cpp compiled unmodified from /root/reference against the
+ * stand-in headers of oracle/ref_shim/include (tests/test_oracle_ref.py: <= 1e-12 relative on 1000 random inputs per
+ * factor; tests/golden/ref_factors.npz carries the reference's outputs to the GPU box).  STILL UNPINNED: the Ceres solve
+ * loop (orc_solver.c, orc_batch2.c -- Ceres is not in the image nor under /root/reference), PCL's kd-tree / VoxelGrid and
+ * Eigen's colPivHouseholderQr (orc_assoc.c).  Numbers that pass through those must be labelled
  * "reference-restatement (Ceres-1.14 semantics)", never "Ceres".
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or call this.
@@ -157,6 +159,10 @@ int orc_batch_linearize_full(const orc_batch_problem* p, const double* poses, do
  * history (may be NULL): [max_iterations + 1][4] = candidate cost, radius, |x - candidate|, step quality per iteration (row 0: start). */
 int orc_batch2_dim(const orc_batch_problem* p);
 int orc_batch2_linearize(const orc_batch_problem* p, const double* poses, const double* speed_bias, double* H /*[n][n]*/, double* g, double* cost);
+/* the same matrix as a symmetric LOWER BAND (what the solve itself works on: C4's K = 2000 does not fit a dense n x n): Hband [n][hbw + 1],
+ * entry (i, j) with i - hbw <= j <= i at [i][j - i + hbw]; hbw = max(B * band + 5, 29 with the IMU chain) */
+int orc_batch2_half_bandwidth(const orc_batch_problem* p);
+int orc_batch2_linearize_banded(const orc_batch_problem* p, const double* poses, const double* speed_bias, double* Hband, double* g, double* cost);
 int orc_batch2_solve(const orc_batch_problem* p, const glio_batch_tr_opts* o, double* poses, double* speed_bias, glio_summary* summary, double* history);
 /* the pose-only problem (p->n_imu must be 0) */
 int orc_batch_solve(const orc_batch_problem* p, const glio_batch_tr_opts* o, double* poses, glio_summary* summary);

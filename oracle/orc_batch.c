@@ -3,7 +3,7 @@
  * scan-to-multiscan constraints (Estimator::optimizeBatchWithLandMark, GLIO/src/Estimator.cpp:
  * 3004-3076) -- BinaryLidarPlaneNormFactor (LidarKeyframeFactor.h:124-164), no loss function
  * (:2768), Ceres QuaternionParameterization on both quaternion blocks -- summed into the block-banded
- * normal equations that the multi-GPU path all-reduces.  PARITY UNPINNED -- see glio_oracle.h.
+ * normal equations that the multi-GPU path all-reduces.  Factor evaluators pinned on the reference's own code (oracle/_ref, tests/test_oracle_ref.py); see glio_oracle.h.
  */
 #include <stdlib.h>
 #include "glio_oracle.h"

@@ -35,8 +35,28 @@ static void plusJ2(const double q[4], double P[12]) {
 
 int orc_batch2_dim(const orc_batch_problem* p) { return (p->n_imu > 0 ? 15 : 6) * p->K; }
 
-/* dense H (n x n), g (n), cost of all factors at (poses, speed_bias) */
-int orc_batch2_linearize(const orc_batch_problem* p, const double* poses, const double* sb, double* H, double* g, double* cost_out) {
+/* ---- symmetric band storage of the normal matrix: the LOWER band, row i holds columns i - hbw .. i at a[i * (hbw + 1) + (j - i + hbw)].
+ * Half-bandwidth: pose blocks couple keyframes up to `band` apart (B * band + 5 scalar columns), the IMU edge couples all 15 states of
+ * neighbours (29).  K = 2000 with the IMU chain: 30 000 x 96 doubles = 23 MB where the dense matrix would be 7.2 GB.  Every sum below runs
+ * over the columns inside the band in ascending order, i.e. the dense loops minus their exact-zero terms: the banded solve returns the SAME
+ * bits as the dense one did (tests/golden/batch*_small.npz did not move). */
+typedef struct { int n, hbw; double* a; } bandm;
+int orc_batch2_half_bandwidth(const orc_batch_problem* p) {
+    const int B = p->n_imu > 0 ? 15 : 6, n = B * p->K;
+    int h = B * p->band + 5;
+    if (B == 15 && h < 29) h = 29;
+    if (h > n - 1) h = n - 1;
+    return h;
+}
+static inline double* bat(const bandm* m, int i, int j) { return m->a + (size_t)i * (m->hbw + 1) + (j - i + m->hbw); }      /* i >= j >= i - hbw */
+static inline double bget(const bandm* m, int i, int j) {
+    if (i < j) { const int t = i; i = j; j = t; }
+    return (i - j > m->hbw) ? 0.0 : *bat(m, i, j);
+}
+static int band_alloc(bandm* m, int n, int hbw) { m->n = n; m->hbw = hbw; m->a = (double*)calloc((size_t)n * (hbw + 1), sizeof(double)); return m->a != NULL; }
+
+/* banded H (lower band), g (n), cost of all factors at (poses, speed_bias) */
+static int batch2_linearize_band(const orc_batch_problem* p, const double* poses, const double* sb, bandm* H, double* g, double* cost_out) {
     const int K = p->K, band = p->band, B = p->n_imu > 0 ? 15 : 6, n = B * K;
     const size_t hb = (size_t)K * (band + 1) * 36;
     double* Hb = (double*)malloc(sizeof(double) * hb);
@@ -44,15 +64,15 @@ int orc_batch2_linearize(const orc_batch_problem* p, const double* poses, const 
     double cost = 0;
     int ok = orc_batch_linearize_full(p, poses, Hb, gb, &cost);
     if (ok) {
-        memset(H, 0, sizeof(double) * (size_t)n * n);
+        memset(H->a, 0, sizeof(double) * (size_t)n * (H->hbw + 1));
         memset(g, 0, sizeof(double) * n);
         for (int k = 0; k < K; ++k) {
             for (int r = 0; r < 6; ++r) g[B * k + r] = gb[6 * k + r];
             for (int d = 0; d <= band && k + d < K; ++d) {
                 const double* blk = Hb + ((size_t)k * (band + 1) + d) * 36;
                 for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) {
-                    H[(size_t)(B * k + r) * n + B * (k + d) + c] = blk[r * 6 + c];
-                    if (d) H[(size_t)(B * (k + d) + c) * n + B * k + r] = blk[r * 6 + c];
+                    const int row = B * k + r, col = B * (k + d) + c;         /* upper entry (row, col); the lower band holds (col, row) */
+                    if (col >= row) *bat(H, col, row) = blk[r * 6 + c];
                 }
             }
         }
@@ -84,10 +104,10 @@ int orc_batch2_linearize(const orc_batch_problem* p, const double* poses, const 
                 double gu = 0;
                 for (int i = 0; i < 15; ++i) gu += Jl[i * 30 + u] * r[i];
                 g[base + u] += gu;
-                for (int v = 0; v < 30; ++v) {
+                for (int v = 0; v <= u; ++v) {
                     double s = 0;
                     for (int i = 0; i < 15; ++i) s += Jl[i * 30 + u] * Jl[i * 30 + v];
-                    H[(size_t)(base + u) * n + base + v] += s;
+                    *bat(H, base + u, base + v) += s;
                 }
             }
         }
@@ -95,6 +115,67 @@ int orc_batch2_linearize(const orc_batch_problem* p, const double* poses, const 
     *cost_out = cost;
     free(Hb); free(gb);
     return ok;
+}
+/* the same with the lower band handed out: Hband [n][hbw + 1], hbw = orc_batch2_half_bandwidth (the K = 2000 checks of the GPU suite) */
+int orc_batch2_linearize_banded(const orc_batch_problem* p, const double* poses, const double* sb, double* Hband, double* g, double* cost_out) {
+    bandm H;
+    H.n = orc_batch2_dim(p); H.hbw = orc_batch2_half_bandwidth(p); H.a = Hband;
+    return batch2_linearize_band(p, poses, sb, &H, g, cost_out);
+}
+/* dense H (n x n), g (n), cost: the band expanded (small problems; tests) */
+int orc_batch2_linearize(const orc_batch_problem* p, const double* poses, const double* sb, double* H, double* g, double* cost_out) {
+    const int n = orc_batch2_dim(p);
+    bandm Hb;
+    if (!band_alloc(&Hb, n, orc_batch2_half_bandwidth(p))) return 0;
+    const int ok = batch2_linearize_band(p, poses, sb, &Hb, g, cost_out);
+    if (ok) for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) H[(size_t)i * n + j] = bget(&Hb, i, j);
+    free(Hb.a);
+    return ok;
+}
+
+/* scaled entry S H S of the band, evaluated exactly as the dense code did: (scale_i * H_ij) * scale_j */
+static inline double hs_at(const bandm* H, const double* scale, int i, int j) { return scale[i] * bget(H, i, j) * scale[j]; }
+/* y = (S H S) x */
+static void band_scaled_matvec(const bandm* H, const double* scale, const double* x, double* y) {
+    const int n = H->n, w = H->hbw;
+    for (int i = 0; i < n; ++i) {
+        const int j0 = i - w < 0 ? 0 : i - w, j1 = i + w > n - 1 ? n - 1 : i + w;
+        double s = 0;
+        for (int j = j0; j <= j1; ++j) s += hs_at(H, scale, i, j) * x[j];
+        y[i] = s;
+    }
+}
+/* banded Cholesky of the lower band in place (the dense chol_lower restricted to the band); 0 / -1 */
+static int band_chol(bandm* A) {
+    const int n = A->n, w = A->hbw;
+    for (int j = 0; j < n; ++j) {
+        double d = *bat(A, j, j);
+        for (int k = j - w < 0 ? 0 : j - w; k < j; ++k) d -= *bat(A, j, k) * *bat(A, j, k);
+        if (!(d > 0.0) || !isfinite(d)) return -1;
+        d = sqrt(d);
+        *bat(A, j, j) = d;
+        const int i1 = j + w > n - 1 ? n - 1 : j + w;
+        for (int i = j + 1; i <= i1; ++i) {
+            double s = *bat(A, i, j);
+            for (int k = i - w < 0 ? 0 : i - w; k < j; ++k) s -= *bat(A, i, k) * *bat(A, j, k);
+            *bat(A, i, j) = s / d;
+        }
+    }
+    return 0;
+}
+static void band_chol_solve(const bandm* L, const double* b, double* x) {
+    const int n = L->n, w = L->hbw;
+    for (int i = 0; i < n; ++i) {
+        double s = b[i];
+        for (int k = i - w < 0 ? 0 : i - w; k < i; ++k) s -= *bat(L, i, k) * x[k];
+        x[i] = s / *bat(L, i, i);
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double s = x[i];
+        const int k1 = i + w > n - 1 ? n - 1 : i + w;
+        for (int k = i + 1; k <= k1; ++k) s -= *bat(L, k, i) * x[k];
+        x[i] = s / *bat(L, i, i);
+    }
 }
 
 static void batch2_plus(const orc_batch_problem* p, const double* poses, const double* sb, const double* delta, double* poses_o, double* sb_o) {
@@ -179,8 +260,8 @@ typedef struct {
     double* basis;      /* [n][2] */
 } subspace_model;
 
-/* DoglegStrategy::ComputeSubspaceModel.  Hs = scaled H (n x n), gradient = D^-1 g_s, gn = scaled Gauss-Newton step, D = diagonal */
-static int compute_subspace_model(int n, const double* Hs, const double* diag, const double* gradient, const double* gn, subspace_model* M, double* work /* 4 n */) {
+/* DoglegStrategy::ComputeSubspaceModel.  S H S = the scaled normal matrix (band + scale vector), gradient = D^-1 g_s, gn = scaled Gauss-Newton step, D = diagonal */
+static int compute_subspace_model(int n, const bandm* H, const double* scale, const double* diag, const double* gradient, const double* gn, subspace_model* M, double* work /* 4 n */) {
     double* c0 = work; double* c1 = work + n; double* t0 = work + 2 * n; double* t1 = work + 3 * n;
     /* ColPivHouseholderQR of [gradient gn]: the column with the larger norm first */
     double n0 = 0, n1 = 0;
@@ -227,11 +308,8 @@ static int compute_subspace_model(int n, const double* Hs, const double* diag, c
     for (int i = 0; i < n; ++i) { M->g[0] += M->basis[2 * i] * gradient[i]; M->g[1] += M->basis[2 * i + 1] * gradient[i]; }
     /* B = (J D^-1 U)^T (J D^-1 U) = (D^-1 U)^T Hs (D^-1 U) */
     for (int i = 0; i < n; ++i) { c0[i] = M->basis[2 * i] / diag[i]; c1[i] = M->basis[2 * i + 1] / diag[i]; }
-    for (int i = 0; i < n; ++i) {
-        double s0 = 0, s1 = 0;
-        for (int j = 0; j < n; ++j) { s0 += Hs[(size_t)i * n + j] * c0[j]; s1 += Hs[(size_t)i * n + j] * c1[j]; }
-        t0[i] = s0; t1[i] = s1;
-    }
+    band_scaled_matvec(H, scale, c0, t0);
+    band_scaled_matvec(H, scale, c1, t1);
     double b00 = 0, b01 = 0, b11 = 0;
     for (int i = 0; i < n; ++i) { b00 += c0[i] * t0[i]; b01 += c0[i] * t1[i]; b11 += c1[i] * t1[i]; }
     M->B[0] = b00; M->B[1] = b01; M->B[2] = b01; M->B[3] = b11;
@@ -288,11 +366,10 @@ int orc_subspace_boundary_minimum(const double B[4], const double g[2], double r
 
 int orc_batch2_solve(const orc_batch_problem* p, const glio_batch_tr_opts* o, double* x_pose, double* x_sb, glio_summary* sum, double* history /* may be NULL: [max_iterations][4] per iteration: candidate cost, radius the step was computed with, |x - candidate|, step quality */) {
     const int K = p->K, B = p->n_imu > 0 ? 15 : 6, n = B * K, np = 7 * K, ns = B == 15 ? 9 * K : 0;
-    const size_t nn = (size_t)n * n;
-    double* H = (double*)malloc(sizeof(double) * nn);
-    double* Hc = (double*)malloc(sizeof(double) * nn);
-    double* Hs = (double*)malloc(sizeof(double) * nn);
-    double* L = (double*)malloc(sizeof(double) * nn);
+    const int hbw = orc_batch2_half_bandwidth(p);
+    bandm Hm, Hcm, Lm;                                  /* normal matrix at the current point, at the candidate, Cholesky work: lower bands */
+    band_alloc(&Hm, n, hbw); band_alloc(&Hcm, n, hbw); band_alloc(&Lm, n, hbw);
+    bandm* H = &Hm; bandm* Hc = &Hcm; bandm* L = &Lm;
     double* vec = (double*)calloc((size_t)16 * n, sizeof(double));
     double* g = vec, *gc = vec + n, *gs = vec + 2 * n, *scale = vec + 3 * n, *diag = vec + 4 * n, *grad = vec + 5 * n, *gn = vec + 6 * n,
           *step = vec + 7 * n, *delta = vec + 8 * n, *tmp = vec + 9 * n, *work = vec + 10 * n;      /* work: 4 n */
@@ -307,10 +384,10 @@ int orc_batch2_solve(const orc_batch_problem* p, const glio_batch_tr_opts* o, do
     memset(&SM, 0, sizeof SM);
     SM.basis = basis;
     double cost;
-    int ok = orc_batch2_linearize(p, xp, xs, H, g, &cost);
+    int ok = batch2_linearize_band(p, xp, xs, H, g, &cost);
     if (!ok) { sum->termination = GLIO_TERM_FAILURE; goto done; }
     sum->initial_cost = cost;
-    for (int i = 0; i < n; ++i) scale[i] = o->jacobi_scaling ? 1.0 / (1.0 + sqrt(H[(size_t)i * n + i])) : 1.0;
+    for (int i = 0; i < n; ++i) scale[i] = o->jacobi_scaling ? 1.0 / (1.0 + sqrt(*bat(H, i, i))) : 1.0;
     double radius = o->initial_trust_region_radius, mu = 1e-8, alpha = 0, dogleg_step_norm = 0;
     int reuse = 0, iteration = 0, invalid = 0;
     double minimum_cost = cost, current_cost = cost, reference_cost = cost, candidate_cost = cost;
@@ -330,25 +407,26 @@ int orc_batch2_solve(const orc_batch_problem* p, const glio_batch_tr_opts* o, do
         if (gm <= o->gradient_tolerance) { sum->termination = GLIO_TERM_GRADIENT_TOL; break; }
         if (radius <= o->min_trust_region_radius) { sum->termination = GLIO_TERM_MIN_RADIUS; break; }
         ++iteration;
-        for (int i = 0; i < n; ++i) { gs[i] = scale[i] * g[i]; for (int j = 0; j < n; ++j) Hs[(size_t)i * n + j] = scale[i] * H[(size_t)i * n + j] * scale[j]; }
+        for (int i = 0; i < n; ++i) gs[i] = scale[i] * g[i];            /* (S H S is evaluated entry by entry from the band: hs_at) */
         int step_valid = 1;
         if (!reuse) {
             for (int i = 0; i < n; ++i) {
-                double d = Hs[(size_t)i * n + i];
+                double d = hs_at(H, scale, i, i);
                 d = d < 1e-6 ? 1e-6 : (d > 1e32 ? 1e32 : d);
                 diag[i] = sqrt(d);
                 grad[i] = gs[i] / diag[i];
             }
             for (int i = 0; i < n; ++i) tmp[i] = grad[i] / diag[i];
             double Jg2 = 0, gg = 0;
-            for (int i = 0; i < n; ++i) { double s = 0; for (int j = 0; j < n; ++j) s += Hs[(size_t)i * n + j] * tmp[j]; Jg2 += tmp[i] * s; gg += grad[i] * grad[i]; }
+            band_scaled_matvec(H, scale, tmp, work);
+            for (int i = 0; i < n; ++i) { Jg2 += tmp[i] * work[i]; gg += grad[i] * grad[i]; }
             alpha = gg / Jg2;
             int solved = 0;
             while (mu < 1.0) {
-                memcpy(L, Hs, sizeof(double) * nn);
-                for (int i = 0; i < n; ++i) L[(size_t)i * n + i] += mu * diag[i] * diag[i];
-                if (chol_lower(L, n) == 0) {
-                    chol_solve(L, n, gs, tmp);
+                for (int i = 0; i < n; ++i) for (int j = i - hbw < 0 ? 0 : i - hbw; j <= i; ++j) *bat(L, i, j) = hs_at(H, scale, i, j);
+                for (int i = 0; i < n; ++i) *bat(L, i, i) += mu * diag[i] * diag[i];
+                if (band_chol(L) == 0) {
+                    band_chol_solve(L, gs, tmp);
                     int fin = 1;
                     for (int i = 0; i < n; ++i) if (!isfinite(tmp[i])) fin = 0;
                     if (fin) { solved = 1; break; }
@@ -358,7 +436,7 @@ int orc_batch2_solve(const orc_batch_problem* p, const glio_batch_tr_opts* o, do
             if (!solved) step_valid = 0;
             else {
                 for (int i = 0; i < n; ++i) gn[i] = -diag[i] * tmp[i];
-                if (o->dogleg_type == GLIO_DOGLEG_SUBSPACE && !compute_subspace_model(n, Hs, diag, grad, gn, &SM, work)) step_valid = 0;
+                if (o->dogleg_type == GLIO_DOGLEG_SUBSPACE && !compute_subspace_model(n, H, scale, diag, grad, gn, &SM, work)) step_valid = 0;
             }
         }
         if (step_valid) {
@@ -393,7 +471,8 @@ int orc_batch2_solve(const orc_batch_problem* p, const glio_batch_tr_opts* o, do
         double mcc = 0;
         if (step_valid) {
             double lin = 0, quad = 0;
-            for (int i = 0; i < n; ++i) { double s = 0; for (int j = 0; j < n; ++j) s += Hs[(size_t)i * n + j] * step[j]; quad += step[i] * s; lin += gs[i] * step[i]; }
+            band_scaled_matvec(H, scale, step, work);
+            for (int i = 0; i < n; ++i) { quad += step[i] * work[i]; lin += gs[i] * step[i]; }
             mcc = -(lin + 0.5 * quad);
             if (!(mcc > 0.0)) step_valid = 0;
         }
@@ -407,7 +486,7 @@ int orc_batch2_solve(const orc_batch_problem* p, const glio_batch_tr_opts* o, do
         for (int i = 0; i < n; ++i) delta[i] = step[i] * scale[i];
         batch2_plus(p, xp, xs, delta, cp, cs);
         double ccost;
-        if (!orc_batch2_linearize(p, cp, cs, Hc, gc, &ccost)) { radius *= 0.5; reuse = 1; continue; }
+        if (!batch2_linearize_band(p, cp, cs, Hc, gc, &ccost)) { radius *= 0.5; reuse = 1; continue; }
         {
             double d2 = 0, x2 = 0;
             for (int i = 0; i < np; ++i) { d2 += (xp[i] - cp[i]) * (xp[i] - cp[i]); x2 += xp[i] * xp[i]; }
@@ -423,7 +502,7 @@ int orc_batch2_solve(const orc_batch_problem* p, const glio_batch_tr_opts* o, do
         if (quality > o->min_relative_decrease) {
             memcpy(xp, cp, sizeof(double) * np);
             if (ns) memcpy(xs, cs, sizeof(double) * ns);
-            { double* t = H; H = Hc; Hc = t; }
+            { bandm* t = H; H = Hc; Hc = t; }
             memcpy(g, gc, sizeof(double) * n);
             ++sum->successful_steps;
             if (quality < 0.25) radius *= 0.5;
@@ -447,6 +526,6 @@ int orc_batch2_solve(const orc_batch_problem* p, const glio_batch_tr_opts* o, do
     sum->final_cost = user_min_cost;
     sum->final_radius = radius;
 done:
-    free(H); free(Hc); free(Hs); free(L); free(vec); free(xp); free(xs); free(cp); free(cs); free(np_); free(ns_);
+    free(Hm.a); free(Hcm.a); free(Lm.a); free(vec); free(xp); free(xs); free(cp); free(cs); free(np_); free(ns_);
     return sum->termination != GLIO_TERM_FAILURE;
 }

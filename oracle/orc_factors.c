@@ -1,7 +1,7 @@
 /*
  * orc_factors.c -- CPU ORACLE (test infrastructure): the reference's cost functions restated in
  * plain C with the ceres::CostFunction::Evaluate pointer convention (residuals + GLOBAL row-major
- * Jacobians; jacobians or jacobians[i] may be NULL).  See glio_oracle.h for the "parity unpinned"
+ * Jacobians; jacobians or jacobians[i] may be NULL).  See glio_oracle.h for the parity
  * statement.  Each function cites the reference lines it follows.
  */
 #include "glio_oracle.h"

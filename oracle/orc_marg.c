@@ -12,7 +12,7 @@
  * The reference orders blocks by unordered_map iteration (address keyed, unspecified); this
  * restatement fixes: dropped = [T0 Q0 SB0] (m = 15), kept = [T1 Q1 SB1 T2 Q2 ... T(W-1) Q(W-1)]
  * (n = 6(W-1)+9).  J0^T J0 and J0^T r0 are invariant to that choice and to eigenvector signs; compare
- * those, not J0 itself.  PARITY UNPINNED -- see glio_oracle.h.
+ * those, not J0 itself.  Pinned on the reference's own MarginalizationInfo (oracle/_ref, tests/test_oracle_ref.py) through these invariants; see glio_oracle.h.
  */
 #include <stdlib.h>
 #include "glio_oracle.h"

@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
 Nothing under glio_amd/ may import this module.  Numbers produced with it are
-"reference-restatement (Ceres-1.14 semantics)", parity unpinned (see oracle/glio_oracle.h).
+"reference-restatement (Ceres-1.14 semantics)", factor layer pinned on oracle/_ref, solve loop and association unpinned (see oracle/glio_oracle.h).
 """
 import ctypes as C
 import os
@@ -340,6 +340,17 @@ class BatchProblem:
         ok = lib().orc_batch2_linearize(C.byref(self.c), T.dptr(np.ascontiguousarray(poses, float)), T.dptr(sb) if sb is not None else None, T.dptr(H), T.dptr(g), C.byref(cost))
         assert ok
         return H, g, cost.value
+
+    def linearize_banded(self, poses, speed_bias=None):
+        """the same without the dense matrix (K = 2000): lower band [n][hbw + 1] (entry (i, j), i - hbw <= j <= i, at [i][j - i + hbw]), g, cost"""
+        n = self.dim
+        lib().orc_batch2_half_bandwidth.restype = C.c_int
+        hbw = lib().orc_batch2_half_bandwidth(C.byref(self.c))
+        Hb = np.zeros((n, hbw + 1)); g = np.zeros(n); cost = C.c_double()
+        sb = np.ascontiguousarray(speed_bias, float) if self.n_imu else None
+        ok = lib().orc_batch2_linearize_banded(C.byref(self.c), T.dptr(np.ascontiguousarray(poses, float)), T.dptr(sb) if sb is not None else None, T.dptr(Hb), T.dptr(g), C.byref(cost))
+        assert ok
+        return Hb, g, cost.value
 
     def solve2(self, poses, opts, speed_bias=None, want_history=False):
         """orc_batch2_solve: returns (poses, speed_bias or None, summary[, history rows cost / radius / step norm / quality])"""
