@@ -122,16 +122,23 @@ def make_batch_imu(K, seed=20260930, rate_per_kf=10, kf_dt=BATCH_KF_DT, perturb_
     return preints, sb_gt, sb_init
 
 
-def make_constraints(gt, lo, hi, per_kf, band, seed=20260930, device="cpu"):
+def make_constraints(gt, lo, hi, per_kf, band, seed=20260930, device="cpu", search_range=None):
     """Pre-associated binary plane constraints of the source keyframes [lo, hi): `per_kf` per keyframe spread over
     its up-to 2*band neighbours, sorted by (ci, cj).  Returns host index arrays and torch data tensors on `device`.
+    With `search_range` the neighbours are the reference's search windows instead (search_window: +-search_range in the interior, the
+    2 search_range + 1 keyframes at either end of the batch for the first / last search_range keyframes, Estimator.cpp:3009-3017) --
+    the structure whose END windows need band = 2 * search_range.
     Geometry follows the reference's construction (Estimator.cpp:3850-3857,3879-3884): point in frame ci,
     plane normal + 5-point centroid in the coordinates of frame cj, score = 2.5 * weight."""
     import torch
     K = len(gt)
     ci_list, cj_list = [], []
     for i in range(lo, hi):
-        nbr = [j for j in range(i - band, i + band + 1) if j != i and 0 <= j < K]
+        if search_range is None:
+            nbr = [j for j in range(i - band, i + band + 1) if j != i and 0 <= j < K]
+        else:
+            s0 = search_window(i, K, search_range)
+            nbr = [j for j in range(s0, s0 + 2 * search_range + 1) if j != i and 0 <= j < K and abs(j - i) <= band]
         share = [per_kf // len(nbr) + (1 if r < per_kf % len(nbr) else 0) for r in range(len(nbr))]
         for j, c in zip(nbr, share):
             ci_list.append(np.full(c, i, np.int32))

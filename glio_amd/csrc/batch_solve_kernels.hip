@@ -444,6 +444,186 @@ __global__ __launch_bounds__(64) void k_bcr_post(const int* skip, const double* 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ the same for bands 7..12 (round 4)
+// The reference gives the first and the last search_range keyframes of a batch a window of +-2 search_range (Estimator.cpp:3009-3017): with
+// the ImuFactor chain that is 15 unknowns per keyframe under a pose band of 12.  Super-blocks of 12 keyframes then (180 unknowns); KEPT (90):
+// keyframe 0 whole, the poses of keyframes 1..10, keyframe 11 whole -- all that reaches another super-block -- INNER (90): the speed-bias
+// blocks of keyframes 1..10.  The reduction runs on the same 90 x 90 nodes as the un-reduced band-6 problem would.  This is the rare shape
+// (two windows per batch want it): the panel is gathered entry by entry through bcr_scaled_entry and lives in LDS ([A_ii; A_ki; y_i^T],
+// 181 rows of 90 + 2 zero columns = 134.7 KB, dynamic), A_kk is read from the operator when the Schur complement is formed.
+#define PRE12_NI 90
+#define PRE12_NK 90
+#define PRE12_LDP 93
+#define PRE12_ROWS (PRE12_NI + PRE12_NK + 1)
+#define PRE12_LDS ((size_t)(PRE12_ROWS * PRE12_LDP + 2 * PRE12_NI) * 8 + 16)
+__device__ __forceinline__ void pre12_kept(const int i, int& kl, int& r) {
+    if (i < 15) { kl = 0; r = i; } else if (i < 75) { kl = 1 + (i - 15) / 6; r = (i - 15) % 6; } else { kl = 11; r = i - 75; }
+}
+__device__ __forceinline__ void pre12_inner(const int p, int& kl, int& r) { kl = 1 + p / 9; r = 6 + p % 9; }
+__global__ __launch_bounds__(256) void k_bcr_pre12(const BcrOp op, const BcrInit* __restrict__ tab, const int K, const int band, const int Slo, double* __restrict__ ws,
+                                                   double* __restrict__ preL, double* __restrict__ preU, double* __restrict__ prew, int* fail) {
+    if (op.skip && *op.skip) return;
+    constexpr int B = 15, NI = PRE12_NI, NK = PRE12_NK, LDP = PRE12_LDP, ROWS = PRE12_ROWS, SBK = 12;
+    extern __shared__ double pre12_lds[];
+    double* pan = pre12_lds;                              // [ROWS][LDP]
+    double (*col)[NI] = reinterpret_cast<double (*)[NI]>(pre12_lds + ROWS * LDP);       // [2][NI]
+    int* s_bad = reinterpret_cast<int*>(pre12_lds + ROWS * LDP + 2 * NI);
+    const BcrInit t = tab[blockIdx.x];
+    const HView v = bcr_view(op, K, band, B);
+    const int cur = op.cur ? *op.cur : 0;
+    const double* gsrc = op.gfull[cur];
+    const int s = t.sblock, k0 = s * SBK, tid = threadIdx.x;
+    constexpr int U = 8;
+    if (blockIdx.y > 0) {
+        // the coupling A[s+1][s] between the KEPT unknowns of neighbouring super-blocks (the inner blocks do not reach the neighbour)
+        if (t.oC < 0) return;
+        const int half = (NK * NK + 1) / 2, eb = (blockIdx.y - 1) * half, ee = min(NK * NK, eb + half);
+        for (int e0 = eb + tid; e0 < ee; e0 += U * 256) {
+            double x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + u * 256, eo = e < ee ? e : eb;
+                int kli, ri, klj, cj;
+                pre12_kept(eo / NK, kli, ri); pre12_kept(eo % NK, klj, cj);
+                x[u] = bcr_scaled_entry(op, v, K, B, k0 + SBK + kli, ri, k0 + klj, cj);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int e = e0 + u * 256; if (e < ee) ws[t.oC + e] = x[u]; }
+        }
+        return;
+    }
+    if (t.oD < 0) return;
+    if (tid == 0) *s_bad = 0;
+    auto unk_inner = [&](const int pp, int& k, int& r) { int kl; pre12_inner(pp, kl, r); k = k0 + kl; };
+    auto unk_kept = [&](const int i, int& k, int& r) { int kl; pre12_kept(i, kl, r); k = k0 + kl; };
+    auto rhs = [&](const int k, const int r) -> double {
+        if (k >= K) return 0.0;
+        return gsrc[(size_t)k * B + r] * (op.sc ? op.sc[(size_t)k * B + r] : 1.0);
+    };
+    // ---- the panel: rows 0..89 = A_ii, 90..179 = A_ki, 180 = y_i; columns 90..92 zero (the MFMA loop reads k in fours)
+    for (int e0 = tid; e0 < (NI + NK) * NI; e0 += U * 256) {
+        double x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * 256, eo = e < (NI + NK) * NI ? e : 0;
+            const int row = eo / NI, c = eo - NI * row;
+            int ka, ra, kb, cb;
+            if (row < NI) unk_inner(row, ka, ra); else unk_kept(row - NI, ka, ra);
+            unk_inner(c, kb, cb);
+            x[u] = bcr_scaled_entry(op, v, K, B, ka, ra, kb, cb);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int e = e0 + u * 256; if (e < (NI + NK) * NI) pan[(e / NI) * LDP + e % NI] = x[u]; }
+    }
+    if (tid < NI) { int k, r; unk_inner(tid, k, r); pan[(NI + NK) * LDP + tid] = rhs(k, r); }
+    for (int e = tid; e < ROWS * (LDP - NI); e += 256) pan[(e / (LDP - NI)) * LDP + NI + e % (LDP - NI)] = 0.0;
+    __syncthreads();
+    // ---- 90 register steps, one row per lane (rows 0..89 the inner block, 90..179 the kept rows, 180 the right-hand side)
+    const int row = tid;
+    double a[NI];
+#pragma unroll
+    for (int c = 0; c < NI; ++c) a[c] = row < ROWS ? pan[row * LDP + c] : 0.0;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        if (row >= j && row < NI) col[j & 1][row] = a[j];
+        __syncthreads();
+        const double piv = col[j & 1][j];
+        double rd;
+        if (!(piv > 0.0) || !isfinite(piv)) { rd = 1.0; if (row == j) *s_bad = 1; } else rd = rsqrt(piv);
+        if (row >= j && row < ROWS) {
+            const double lj = a[j] * rd;
+            a[j] = lj;
+            if (row > j) {
+#pragma unroll
+                for (int c = j + 1; c < NI; ++c) a[c] -= lj * (col[j & 1][c] * rd);
+            }
+        }
+    }
+    __syncthreads();
+    const size_t sb = (size_t)(s - Slo);
+    if (row < ROWS) {
+#pragma unroll
+        for (int c = 0; c < NI; ++c) pan[row * LDP + c] = (row < NI && c > row) ? 0.0 : a[c];
+    }
+    if (tid == 0 && *s_bad) atomicOr(fail, 1);
+    __syncthreads();
+    for (int e = tid; e < NI * NI; e += 256) preL[sb * NI * NI + e] = pan[(e / NI) * LDP + e % NI];
+    for (int e = tid; e < NK * NI; e += 256) preU[sb * NK * NI + e] = pan[(NI + e / NI) * LDP + e % NI];
+    if (tid < NI) prew[sb * NI + tid] = pan[(NI + NK) * LDP + tid];
+    {   // A_kk - U U^T on the matrix core: 6 x 6 tiles of 16 x 16 over the four wavefronts; A_kk from the operator as the accumulator's start
+        const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+        for (int tile = wave; tile < 36; tile += 4) {
+            const int I = tile / 6, J = tile - 6 * I;
+            v4f64 c;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 16 * I + lk + 4 * q, cc = 16 * J + li;
+                int ka, ra, kb, cb;
+                unk_kept(r < NK ? r : 0, ka, ra); unk_kept(cc < NK ? cc : 0, kb, cb);
+                c[q] = (r < NK && cc < NK) ? bcr_scaled_entry(op, v, K, B, ka, ra, kb, cb) : 0.0;
+            }
+            const int ra_ = 16 * I + li, rb_ = 16 * J + li;
+            const double* pa = pan + (NI + (ra_ < NK ? ra_ : 0)) * LDP + lk;
+            const double* pb = pan + (NI + (rb_ < NK ? rb_ : 0)) * LDP + lk;
+#pragma unroll
+            for (int kk = 0; kk < NI + 2; kk += 4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(ra_ < NK ? -pa[kk] : 0.0, rb_ < NK ? pb[kk] : 0.0, c, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int r = 16 * I + lk + 4 * q, cc = 16 * J + li; if (r < NK && cc < NK) ws[t.oD + r * NK + cc] = c[q]; }
+        }
+    }
+    if (t.oy >= 0 && tid < NK) {
+        const double* ui = pan + (NI + tid) * LDP; const double* wv = pan + (NI + NK) * LDP;
+        double s0 = 0;
+#pragma unroll 6
+        for (int c = 0; c < NI; ++c) s0 += ui[c] * wv[c];
+        int k, r; unk_kept(tid, k, r);
+        ws[t.oy + tid] = rhs(k, r) - s0;
+    }
+}
+// z_i = L^-T (w - U^T z_k) of one owned 12-keyframe super-block, then the step of its keyframes
+__global__ __launch_bounds__(128) void k_bcr_post12(const int* skip, const double* __restrict__ z, const int* __restrict__ node_of, const int Slo, const int K,
+                                                    const double* __restrict__ preL, const double* __restrict__ preU, const double* __restrict__ prew,
+                                                    double* __restrict__ delta, int* fail) {
+    if (skip && *skip) return;
+    constexpr int B = 15, NI = PRE12_NI, NK = PRE12_NK, LDL = NI + 1, SBK = 12;
+    extern __shared__ double post12_lds[];
+    double* Ls = post12_lds;                 // [NI][LDL]
+    double* zk = Ls + NI * LDL;              // [NK]
+    double* zi = zk + NK;                    // [NI]
+    const int sb = blockIdx.x, tid = threadIdx.x, s = Slo + sb, k0 = s * SBK;
+    const int node = node_of[sb];
+    if (tid < NK) zk[tid] = z[(size_t)node * NK + tid];
+    for (int e = tid; e < NI * NI; e += 128) Ls[(e / NI) * LDL + e % NI] = preL[(size_t)sb * NI * NI + e];
+    __syncthreads();
+    if (tid < NI) {
+        const double* Uc = preU + (size_t)sb * NK * NI + tid;
+        double p3[3] = {0, 0, 0};
+        for (int i0 = 0; i0 < NK; i0 += 18) {
+#pragma unroll
+            for (int u = 0; u < 18; ++u) p3[u % 3] += Uc[(size_t)(i0 + u) * NI] * zk[i0 + u];
+        }
+        zi[tid] = prew[(size_t)sb * NI + tid] - ((p3[0] + p3[1]) + p3[2]);
+    }
+    __syncthreads();
+    for (int r = NI - 1; r >= 0; --r) {              // back substitution L^T z = t, one column per step
+        if (tid == r) zi[r] = zi[r] / Ls[r * LDL + r];
+        __syncthreads();
+        if (tid < r) zi[tid] -= Ls[r * LDL + tid] * zi[r];
+        __syncthreads();
+    }
+    for (int e = tid; e < SBK * B; e += 128) {
+        const int kl = e / B, r = e - B * kl, k = k0 + kl;
+        if (k >= K) continue;
+        double val;
+        if (r >= 6 && kl >= 1 && kl <= 10) val = zi[(kl - 1) * 9 + r - 6];
+        else val = zk[kl == 0 ? r : (kl == 11 ? 75 + r : 15 + (kl - 1) * 6 + r)];
+        val = -val;
+        if (!isfinite(val)) atomicOr(fail, 2);
+        delta[(size_t)k * B + r] = val;
+    }
+}
+#define POST12_LDS ((size_t)(PRE12_NI * (PRE12_NI + 1) + PRE12_NK + PRE12_NI) * 8)
+
 // ------------------------------------------------------------------------------------------------ elimination
 template <int M> struct BcrCfg { static constexpr int ROWS = 3 * M + 1; static constexpr int THREADS = ((ROWS + 63) / 64) * 64; };
 
@@ -956,12 +1136,12 @@ static void bcr_build_schedule(std::vector<int> act, std::vector<char> pinned, s
 }
 
 void* glio_bcr_create2(int K, int band, int B, int rank, int world) {
-    if (band > 12 || (B != 6 && B != 15) || (B == 15 && band > 6) || world < 1 || rank < 0 || rank >= world) return nullptr;
+    if (band > 12 || (B != 6 && B != 15) || world < 1 || rank < 0 || rank >= world) return nullptr;
     BcrDev* b = new BcrDev();
     b->K = K; b->band = band; b->B = B; b->rank = rank; b->world = world;
     b->sbk = band <= 6 ? 6 : 12;
     b->pre = B == 15;
-    b->M = b->pre ? PRE_NK : b->sbk * B;
+    b->M = b->pre ? (b->sbk == 12 ? PRE12_NK : PRE_NK) : b->sbk * B;
     b->preL = b->preU = b->prew = nullptr;
     b->S = (K + b->sbk - 1) / b->sbk;
     if (b->S < world) { delete b; glio_set_error("batch solver: %d super-blocks cannot be spread over %d ranks", b->S, world); return nullptr; }
@@ -1053,7 +1233,8 @@ void* glio_bcr_create2(int K, int band, int B, int rank, int world) {
               A((void**)&b->init, (init.size() + 1) * sizeof(BcrInit)) && A((void**)&b->node_of_sblock_dev, (size_t)(nown + 1) * 4);
     if (ok && b->pre) {
         const size_t no = (size_t)std::max(nown, 1);
-        ok = A((void**)&b->preL, no * PRE_NI * PRE_NI * 8) && A((void**)&b->preU, no * PRE_NK * PRE_NI * 8) && A((void**)&b->prew, no * PRE_NI * 8);
+        const size_t ni = b->sbk == 12 ? PRE12_NI : PRE_NI, nk = b->sbk == 12 ? PRE12_NK : PRE_NK;
+        ok = A((void**)&b->preL, no * ni * ni * 8) && A((void**)&b->preU, no * nk * ni * 8) && A((void**)&b->prew, no * ni * 8);
     }
     if (!ok) { glio_set_error("batch solver: device allocation failed"); return nullptr; }
     hipMemset(b->ws, 0, (size_t)b->ws_doubles * 8);
@@ -1070,6 +1251,8 @@ void* glio_bcr_create2(int K, int band, int B, int rank, int world) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_elim2<90>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BcrE2<90>::lds_bytes);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_back<72>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((72 * 73 + 3 * 72 + 512) * 8));
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_back<90>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((90 * 91 + 3 * 90 + 512) * 8));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_pre12), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PRE12_LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_post12), hipFuncAttributeMaxDynamicSharedMemorySize, (int)POST12_LDS);
     (void)hipGetLastError();
     return b;
 }
@@ -1125,7 +1308,9 @@ void glio_bcr_enqueue_local(void* h, const BcrOp& op, hipStream_t stream) {
     BcrDev* b = static_cast<BcrDev*>(h);
     hipMemsetAsync(b->fail, 0, 4, stream);
     if (b->sep_doubles > 16) hipMemsetAsync(b->ws + b->sep_off, 0, (size_t)(b->sep_doubles - 16) * 8, stream);      // (the 16 extra scalars belong to the caller)
-    if (b->n_init > 0 && b->pre)
+    if (b->n_init > 0 && b->pre && b->sbk == 12)
+        hipLaunchKernelGGL(k_bcr_pre12, dim3(b->n_init, 3), dim3(256), PRE12_LDS, stream, op, b->init, b->K, b->band, b->Slo, b->ws, b->preL, b->preU, b->prew, b->fail);
+    else if (b->n_init > 0 && b->pre)
         hipLaunchKernelGGL(k_bcr_pre, dim3(b->n_init, 3), dim3(256), 0, stream, op, b->init, b->K, b->band, b->Slo, b->ws, b->preL, b->preU, b->prew, b->fail);
     else if (b->n_init > 0) hipLaunchKernelGGL(k_bcr_init, dim3(b->n_init, BCR_INIT_SPLIT), dim3(256), 0, stream, op, b->init, b->K, b->band, b->B, b->M, b->sbk, b->ws);
     BCR_DISPATCH(bcr_levels, b, op, 0, b->levels_loc, stream);
@@ -1139,7 +1324,9 @@ void glio_bcr_enqueue_finish(void* h, const BcrOp& op, double* delta, hipStream_
     BCR_DISPATCH(bcr_back, b, op, 0, b->levels_loc, stream);
     int lo, hi;
     glio_bcr_owned_range(b, &lo, &hi);
-    if (hi > lo && b->pre)
+    if (hi > lo && b->pre && b->sbk == 12)
+        hipLaunchKernelGGL(k_bcr_post12, dim3(b->Shi - b->Slo), dim3(128), POST12_LDS, stream, op.skip, b->z, b->node_of_sblock_dev, b->Slo, b->K, b->preL, b->preU, b->prew, delta, b->fail);
+    else if (hi > lo && b->pre)
         hipLaunchKernelGGL(k_bcr_post, dim3(b->Shi - b->Slo), dim3(64), 0, stream, op.skip, b->z, b->node_of_sblock_dev, b->Slo, b->K, b->preL, b->preU, b->prew, delta, b->fail);
     else if (hi > lo) hipLaunchKernelGGL(k_bcr_delta, dim3(((hi - lo) * b->B + 255) / 256), dim3(256), 0, stream, op.skip, b->z, b->node_of_sblock_dev, lo, hi, b->Slo, b->B, b->M,
                                     b->sbk, delta, b->fail);

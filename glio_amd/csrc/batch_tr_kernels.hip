@@ -852,7 +852,7 @@ static int tr_build(glio_batch* b, const int B) {
     if (s->world - 1 > 64) { glio_set_error("more than 65 ranks"); return GLIO_E_ARG; }
     s->B = B;
     s->bcr = glio_bcr_create2(K, band, B, s->rank, s->world);
-    if (!s->bcr) { if (B == 15 && band > 6) glio_set_error("the batch problem with the IMU chain is solved for band <= 6 (super-blocks of 6 keyframes x 15 states)"); return GLIO_E_ARG; }
+    if (!s->bcr) return GLIO_E_ARG;
     int lo, hi;
     glio_bcr_owned_range(s->bcr, &lo, &hi);
     if (lo != s->lo || hi != s->hi) { glio_set_error("shard range mismatch"); return GLIO_E_STATE; }
@@ -1085,7 +1085,6 @@ int glio_batch_set_imu(glio_batch* b, int n_edges, const glio_preint* edges, dou
     BT_CHECK(hipSetDevice(b->device));
     { const int rc = small_ensure(b); if (rc) return rc; }
     BatchSmall* s = b->small;
-    if (n_edges > 0 && b->band > 6) { glio_set_error("the batch problem with the IMU chain is solved for band <= 6"); return GLIO_E_ARG; }
     if (n_edges > 0 && !s->d_imu) {
         BT_CHECK(hipMalloc((void**)&s->d_imu, (size_t)(b->K - 1) * sizeof(ImuEdgeDev)));
         for (int k = 0; k < 2; ++k) BT_CHECK(hipMalloc((void**)&s->d_rec[k], (size_t)(b->K - 1) * sizeof(PairBlock)));

@@ -306,3 +306,49 @@ def test_moment_form_follows_the_streamed_form_from_a_far_start():
     assert a["c1"] < 1e-4 * a["c0"]
     assert np.isclose(a["c0"], b["c0"], rtol=1e-11) and np.isclose(a["c1"], b["c1"], rtol=1e-8)
     assert np.abs(np.array(a["poses"]) - np.array(b["poses"])).max() < 1e-8 and np.abs(np.array(a["sb"]) - np.array(b["sb"])).max() < 1e-7
+
+
+@pytest.mark.parametrize("K,world,windows", [(50, 1, True), (61, 1, True), (50, 2, True), (48, 1, False), (73, 3, False)])
+def test_imu_chain_under_the_references_end_windows_band_12(K, world, windows):
+    """The 15-state problem AS THE REFERENCE BUILDS IT: the first and the last search_range = 6 keyframes search a window of 13 keyframes
+    (Estimator.cpp:3009-3017), so the pose band is 12 there (6 in the interior) -- until round 4 glio_batch_set_imu refused band > 6.
+    Super-blocks of 12 keyframes, the speed-bias blocks of the ten inner keyframes pre-eliminated (k_bcr_pre12 / k_bcr_post12), 90 x 90 nodes.
+    `windows` False: every keyframe couples to +-12 (a full band-12 problem).  Against the banded oracle, on one rank and on virtual ranks."""
+    from oracle import pyoracle as po
+    import torch
+    band, sr = 12, 6
+    gt, init = batch.make_poses(K, seed=77 + K, perturb=(0.08, 0.004))
+    ci, cj, cp, nc, score = batch.make_constraints(gt, 0, K, 156, band, seed=77 + K, search_range=sr if windows else None)
+    if windows:
+        assert np.abs(ci - cj).max() == 12 and np.abs(ci - cj)[(ci >= 13) & (ci < K - 13)].max() == 6        # +-12 at the ends only
+    con = (ci, cj, cp.numpy(), nc.numpy(), score.numpy())
+    rng = np.random.default_rng(77 + K)
+    odo = gt.copy(); odo[:, :3] += rng.normal(0, 0.02, (K, 3))
+    dq = batch.delta_q_pairs(odo, sr)
+    dd, frame = batch.make_batch_gnss(gt, seed=77 + K)
+    for f in dd:
+        f.threshold = 10.0
+    imu, _, sb0 = batch.make_batch_imu(K, seed=77 + K)
+    opts = T.batch_tr_opts(max_iterations=12)
+    P = po.BatchProblem(K, band, *con, dq=dq, dd=dd, frame=frame, imu=imu)
+    want, wsb, wsum = P.solve2(init, opts, sb0)
+    if world == 1:
+        st = _stage(K, band, con, dq, dd, frame, imu=imu)
+        diag, g, cost = st.linearize_full(init, sb0)
+        Hb, gw, cw = P.linearize_banded(init, sb0)
+        assert abs(cost - cw) <= 1e-11 * cw and np.abs(diag - Hb[:, -1]).max() <= 1e-10 * Hb[:, -1].max() and np.abs(g - gw).max() <= 1e-10 * np.abs(gw).max()
+        poses, sb, summ = st.solve_tr(init, opts, speed_bias=sb0)
+        st.close()
+    else:
+        stages = [_stage(K, band, con, dq, dd, frame, imu=imu, rank=r, world=world) for r in range(world)]
+        ranks = batch.ThreadRanks(world, sync=torch.cuda.synchronize)
+        res = ranks.run(lambda r, d: stages[r].solve_tr(init, opts, d, speed_bias=sb0))
+        poses, sb, summ = res[0]
+        for other in res[1:]:
+            assert np.array_equal(other[0], poses) and np.array_equal(other[1], sb)
+        for s_ in stages:
+            s_.close()
+    assert summ.iterations == wsum.iterations and summ.successful_steps == wsum.successful_steps and summ.termination == wsum.termination, (summ.as_dict(), wsum.as_dict())
+    assert np.isclose(summ.final_cost, wsum.final_cost, rtol=1e-8)
+    assert np.abs(poses - want).max() < 1e-7 and np.abs(sb - wsb).max() < 1e-6
+    assert summ.final_cost < 0.01 * summ.initial_cost
