@@ -241,6 +241,34 @@ def delta_q_pairs(odo, search_range, start_idx=0):
 DDPSR_THRESHOLDS = (1e9, 10.0, 8.0, 6.0)      # Estimator.cpp:2764-2767: iteration_num = 4 rounds of the 7 listed values
 
 
+def relative_pose_pairs(odo, search_range, start_idx=0):
+    """The LidarPoseFactorBatchRelativeAutoDiff factors of optimizeBatch with sms_fusion_level == 0 (Estimator.cpp:2897-2955, the released default
+    config_urban_hk.yaml:63) from the odometry keyframe poses `odo` [K][7] (x y z qw qx qy qz): for idx in [start + sr, K) and ms_i in 1..sr-1 the
+    factor (idx - ms_i, idx), then for idx in [start, K - sr) and ms_i in 1..sr-1 the factor (idx, idx + ms_i) -- interior pairs appear in BOTH
+    loops and are added twice, as in the reference.  delta_q = q_a^-1 q_b, delta_p = q_a^-1 (p_b - p_a) with Eigen's inverse() and q * v.
+    Returns (i, j, const [n][7] = delta_q (w,x,y,z), delta_p)."""
+    odo = np.asarray(odo, np.float64)
+    K, sr = len(odo), search_range
+    ri, rj = [], []
+    for idx in range(start_idx + sr, K):
+        for ms in range(1, sr):
+            ri.append(idx - ms); rj.append(idx)
+    for idx in range(start_idx, K - sr):
+        for ms in range(1, sr):
+            ri.append(idx); rj.append(idx + ms)
+    ri = np.array(ri, np.int32); rj = np.array(rj, np.int32)
+    if len(ri) == 0:
+        return ri, rj, np.zeros((0, 7))
+    qa, qb = odo[ri, 3:], odo[rj, 3:]
+    qinv = np.concatenate([qa[:, :1], -qa[:, 1:]], axis=1) / np.sum(qa * qa, axis=1, keepdims=True)
+    w1, v1, w2, v2 = qinv[:, :1], qinv[:, 1:], qb[:, :1], qb[:, 1:]
+    dq = np.concatenate([w1 * w2 - np.sum(v1 * v2, axis=1, keepdims=True), w1 * v2 + w2 * v1 + np.cross(v1, v2)], axis=1)
+    d = odo[rj, :3] - odo[ri, :3]
+    uv = 2.0 * np.cross(v1, d)                                  # Eigen's _transformVector on the (non-normalised) inverse
+    dp = d + w1 * uv + np.cross(v1, uv)
+    return ri, rj, np.ascontiguousarray(np.concatenate([dq, dp], axis=1))
+
+
 def make_batch_gnss(gt, seed=20260930, sats_per_sys=10, psr_sigma=1.0, outliers=0.05):
     """Synthetic double-differenced pseudorange factors of the batch problem: one GNSS epoch between every pair of consecutive
     keyframes (leftKey = k, rightKey = k + 1, ts_ratio as Estimator.cpp:3100-3130 derives it), two constellations, identity
@@ -552,10 +580,15 @@ class BatchStage:
         capi._check(capi.load().glio_batch_step_dev(self._h, C.c_void_p(Hg.data_ptr()), C.c_double(lam), T.dptr(poses), T.dptr(out), C.byref(md)))
         return out, md.value
 
-    def set_small_factors(self, dq=None, dd=None, frame=None, threshold=None):
+    def set_small_factors(self, dq=None, dd=None, frame=None, threshold=None, rp=None):
         """The replicated small factors every rank adds after the all-reduce: dq = (i, j, const_diff [n][4]) attitude constraints
         (delta_q_pairs), dd = list of GlioDdPsr between the bracketing keyframes, frame = GlioGnssFrame; `threshold` overrides
-        every DD factor's DDpsrThreshold (the outer round's value)."""
+        every DD factor's DDpsrThreshold (the outer round's value); rp = (i, j, const [n][7]) relative-pose factors (relative_pose_pairs:
+        the scan-to-multiscan constraints of sms_fusion_level 0)."""
+        rp = rp if rp is not None else (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 7)))
+        ri = np.ascontiguousarray(rp[0], np.int32); rj = np.ascontiguousarray(rp[1], np.int32); rc = np.ascontiguousarray(rp[2], np.float64)
+        capi._check(capi.load().glio_batch_set_relative_pose_factors(self._h, len(ri), T.iptr(ri) if len(ri) else None, T.iptr(rj) if len(ri) else None,
+                                                                     T.dptr(rc) if len(ri) else None))
         dq = dq if dq is not None else (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 4)))
         di = np.ascontiguousarray(dq[0], np.int32); dj = np.ascontiguousarray(dq[1], np.int32); dc = np.ascontiguousarray(dq[2], np.float64)
         dd = list(dd or [])

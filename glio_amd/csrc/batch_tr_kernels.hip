@@ -83,7 +83,7 @@ __device__ __forceinline__ void bt_qright(const double p[4], double M[16]) {
 // one wavefront per factor: nr residuals with local Jacobians Ja, Jb (nr x 6, LDS) -> the record
 __global__ __launch_bounds__(64) void k_small_eval(const BtSel sel, const int n_fac, const int* __restrict__ fa, const int* __restrict__ fb, const int* __restrict__ ftype,
                                                    const int* __restrict__ fidx, const double* __restrict__ poses0, const double* __restrict__ poses1,
-                                                   const double* __restrict__ dq_const,
+                                                   const double* __restrict__ dq_const, const double* __restrict__ rp_const /* [n_rp][7]: delta_q (w,x,y,z), delta_p */,
                                                    const glio_dd_psr* __restrict__ dd, const double* __restrict__ Rel /* [9] R_ecef_local, [3] anchor */,
                                                    double* __restrict__ frec) {
     __shared__ double Ja[19 * 6], Jb[19 * 6], rr[19], raw[19], Jri[57], Jrj[57];
@@ -132,6 +132,77 @@ __global__ __launch_bounds__(64) void k_small_eval(const BtSel sel, const int n_
                     Ja[k * 6 + 3 + c] = Jgi[0] * Pa[c] + Jgi[1] * Pa[3 + c] + Jgi[2] * Pa[6 + c] + Jgi[3] * Pa[9 + c];
                     Jb[k * 6 + 3 + c] = Jgj[0] * Pb[c] + Jgj[1] * Pb[3 + c] + Jgj[2] * Pb[6 + c] + Jgj[3] * Pb[9 + c];
                 }
+            }
+        }
+    } else if (ftype[f] == 2) {
+        // LidarPoseFactorBatchRelativeAutoDiff (LidarPoseFactor.h:55-97; the scan-to-multiscan factor of sms_fusion_level 0, Estimator.cpp:2897-2955):
+        //   r[0:3] = 10 * 2 (dq^-1 q1^-1 q2).vec,  r[3:6] = 20 (q1^-1 (p2 - p1) - dp),  Eigen's inverse() = conjugate / |q|^2 and Eigen's q * v on the
+        //   NON-normalised inverse -- what the reference's Jets differentiate; global Jacobians, then Ceres' QuaternionParameterization.  Lane k = row k.
+        nr = 6;
+        if (lane < 6) {
+            const double* cst = rp_const + 7 * (size_t)fidx[f];
+            const double* q1 = pa + 3;
+            const double* q2 = pb + 3;
+            double A[4], u[4], Au[4], p[4], v[3];
+            d_qinv(cst, A); d_qinv(q1, u);
+            d_qmul(A, u, Au); d_qmul(Au, q2, p);
+            for (int k = 0; k < 3; ++k) v[k] = pb[k] - pa[k];
+            double Pa[12], Pb[12];
+            bt_plus_jac(q1, Pa); bt_plus_jac(q2, Pb);
+            const double n2 = q1[0] * q1[0] + q1[1] * q1[1] + q1[2] * q1[2] + q1[3] * q1[3];
+            const double Cq[4] = {q1[0], -q1[1], -q1[2], -q1[3]};
+            const int k = lane < 3 ? lane : lane - 3;
+            double Jg1[4], Jg2[4] = {0, 0, 0, 0}, Jp[3] = {0, 0, 0};        // this row's global Jacobians wrt q1, q2 and wrt p2 (= - wrt p1)
+            double G[4];                                                       // the row of d r / d u (u = q1^-1), before d u / d q1
+            double res;
+            if (lane < 3) {
+                double LA[16], Rv[16], LAu[16];
+                bt_qleft(A, LA); bt_qright(q2, Rv); bt_qleft(Au, LAu);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    double sM = 0;
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) sM += (k == 0 ? LA[4 + x] : (k == 1 ? LA[8 + x] : LA[12 + x])) * Rv[x * 4 + m];
+                    G[m] = sM;
+                    Jg2[m] = 20.0 * (k == 0 ? LAu[4 + m] : (k == 1 ? LAu[8 + m] : LAu[12 + m]));
+                }
+                res = 20.0 * (k == 0 ? p[1] : (k == 1 ? p[2] : p[3]));
+            } else {
+                // M(u) v = v + 2 w (q x v) + 2 q x (q x v);  d/dw = 2 (q x v),  d/dq = -2 w [v]x + 2 ((q.v) I + q v^T - 2 v q^T);  d/dv = M(u)
+                const double w = u[0], qx = u[1], qy = u[2], qz = u[3];
+                const double cx = qy * v[2] - qz * v[1], cy = qz * v[0] - qx * v[2], cz = qx * v[1] - qy * v[0];          // q x v
+                const double ccx = qy * cz - qz * cy, ccy = qz * cx - qx * cz, ccz = qx * cy - qy * cx;                  // q x (q x v)
+                const double rv = k == 0 ? v[0] + 2.0 * w * cx + 2.0 * ccx : (k == 1 ? v[1] + 2.0 * w * cy + 2.0 * ccy : v[2] + 2.0 * w * cz + 2.0 * ccz);
+                res = 20.0 * (rv - cst[4 + k]);
+                const double qv = qx * v[0] + qy * v[1] + qz * v[2];
+                const double qk = k == 0 ? qx : (k == 1 ? qy : qz), vk = k == 0 ? v[0] : (k == 1 ? v[1] : v[2]);
+                const double qq[3] = {qx, qy, qz};
+                // row k of [v]x: (0, -v2, v1), (v2, 0, -v0), (-v1, v0, 0)
+                const double sv[3] = {k == 0 ? 0.0 : (k == 1 ? v[2] : -v[1]), k == 0 ? -v[2] : (k == 1 ? 0.0 : v[0]), k == 0 ? v[1] : (k == 1 ? -v[0] : 0.0)};
+                // row k of [q]x and of [q]x [q]x = q q^T - (q.q) I
+                const double sq[3] = {k == 0 ? 0.0 : (k == 1 ? qz : -qy), k == 0 ? -qz : (k == 1 ? 0.0 : qx), k == 0 ? qy : (k == 1 ? -qx : 0.0)};
+                const double q2n = qx * qx + qy * qy + qz * qz;
+                G[0] = 2.0 * (k == 0 ? cx : (k == 1 ? cy : cz));
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    G[1 + c] = -2.0 * w * sv[c] + 2.0 * ((k == c ? qv : 0.0) + qk * v[c] - 2.0 * vk * qq[c]);
+                    Jp[c] = 20.0 * ((k == c ? 1.0 : 0.0) + 2.0 * w * sq[c] + 2.0 * (qk * qq[c] - (k == c ? q2n : 0.0)));
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                double sacc = 0;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) sacc += G[m] * (((m == c ? (m == 0 ? 1.0 : -1.0) : 0.0) - 2.0 * Cq[m] * q1[c] / n2) / n2);
+                Jg1[c] = 20.0 * sacc;
+            }
+            rr[lane] = res;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                Ja[lane * 6 + c] = -Jp[c];
+                Jb[lane * 6 + c] = Jp[c];
+                Ja[lane * 6 + 3 + c] = Jg1[0] * Pa[c] + Jg1[1] * Pa[3 + c] + Jg1[2] * Pa[6 + c] + Jg1[3] * Pa[9 + c];
+                Jb[lane * 6 + 3 + c] = Jg2[0] * Pb[c] + Jg2[1] * Pb[3 + c] + Jg2[2] * Pb[6 + c] + Jg2[3] * Pb[9 + c];
             }
         }
     } else {
@@ -768,6 +839,8 @@ struct BatchSmall {
     int n_dq, n_dd, n_fac;
     int* d_fa; int* d_fb; int* d_ftype; int* d_fidx;      // sorted by ordered pair (a, b); only the factors this rank owns (a in [lo, hi))
     double* d_dq_const; glio_dd_psr* d_dd;
+    // LidarPoseFactorBatchRelativeAutoDiff factors (glio_batch_set_relative_pose_factors): kept on the host until glio_batch_set_small_factors builds the table
+    int n_rp; int* h_rp_i; int* h_rp_j; double* h_rp_c; double* d_rp_const; size_t cap_rp;
     int2* d_small_index;       // [K][2 band + 1] (first, count) of the factors with (a = k, b = k + o)
     double* d_frec;            // [n_fac][SREC]
     size_t cap_fac, cap_dd;
@@ -836,8 +909,9 @@ void glio_batch_small_destroy(glio_batch* b) {
     BatchSmall* s = b->small;
     if (!s) return;
     tr_free(s);
-    void* p[] = {s->d_fa, s->d_fb, s->d_ftype, s->d_fidx, s->d_dq_const, s->d_dd, s->d_small_index, s->d_frec, s->d_rel, s->d_bnd_kf, s->d_imu, s->d_rec[0], s->d_rec[1]};
+    void* p[] = {s->d_fa, s->d_fb, s->d_ftype, s->d_fidx, s->d_dq_const, s->d_dd, s->d_small_index, s->d_frec, s->d_rel, s->d_bnd_kf, s->d_imu, s->d_rec[0], s->d_rec[1], s->d_rp_const};
     for (void* q : p) if (q) hipFree(q);
+    free(s->h_rp_i); free(s->h_rp_j); free(s->h_rp_c);
     if (s->side) hipStreamDestroy(s->side);
     if (s->ev_fork) hipEventDestroy(s->ev_fork);
     if (s->ev_join) hipEventDestroy(s->ev_join);
@@ -919,7 +993,7 @@ static BtAsm make_asm(glio_batch* b) {
 static void enqueue_small_eval(glio_batch* b, const BtSel& sel, const double* p0, const double* p1, hipStream_t st) {
     BatchSmall* s = b->small;
     if (!s || s->n_fac == 0) return;
-    hipLaunchKernelGGL(k_small_eval, dim3(s->n_fac), dim3(64), 0, st, sel, s->n_fac, s->d_fa, s->d_fb, s->d_ftype, s->d_fidx, p0, p1, s->d_dq_const, s->d_dd,
+    hipLaunchKernelGGL(k_small_eval, dim3(s->n_fac), dim3(64), 0, st, sel, s->n_fac, s->d_fa, s->d_fb, s->d_ftype, s->d_fidx, p0, p1, s->d_dq_const, s->d_rp_const, s->d_dd,
                        s->d_rel, s->d_frec);
 }
 static void enqueue_small_accumulate(glio_batch* b, const BtSel& sel, double* Hg0, double* Hg1) {
@@ -1108,9 +1182,10 @@ int glio_batch_set_small_factors(glio_batch* b, const glio_gnss_frame* frame, in
     const int K = b->K, band = b->band, wdt = 2 * band + 1;
     struct Fac { int a, b, type, idx; };
     std::vector<Fac> fac;
-    fac.reserve((size_t)n_dq + n_dd);
+    fac.reserve((size_t)n_dq + n_dd + s->n_rp);
     for (int f = 0; f < n_dq; ++f) fac.push_back({dq_i[f], dq_j[f], 0, f});
     for (int f = 0; f < n_dd; ++f) fac.push_back({dd[f].slot_i, dd[f].slot_j, 1, f});
+    for (int f = 0; f < s->n_rp; ++f) fac.push_back({s->h_rp_i[f], s->h_rp_j[f], 2, f});
     for (const Fac& f : fac) {
         if (f.a < 0 || f.a >= K || f.b < 0 || f.b >= K || f.a == f.b || std::abs(f.a - f.b) > band) { glio_set_error("small factor on keyframes (%d, %d) outside band %d", f.a, f.b, band); return GLIO_E_ARG; }
         if (f.type == 1 && (dd[f.idx].n_sat < 2 || dd[f.idx].n_sat > GLIO_DD_MAX_SAT || dd[f.idx].master < 0 || dd[f.idx].master >= dd[f.idx].n_sat)) { glio_set_error("bad DD factor"); return GLIO_E_ARG; }
@@ -1140,6 +1215,14 @@ int glio_batch_set_small_factors(glio_batch* b, const glio_gnss_frame* frame, in
         BT_CHECK(hipMalloc((void**)&s->d_dq_const, cap * 32)); BT_CHECK(hipMalloc((void**)&s->d_frec, cap * (SREC + 1) * 8));
         s->cap_fac = cap;             // only after every allocation succeeded
     }
+    if ((size_t)s->n_rp > s->cap_rp) {
+        if (s->d_rp_const) { hipFree(s->d_rp_const); s->d_rp_const = nullptr; }
+        s->cap_rp = 0;
+        const size_t cap = (size_t)s->n_rp + s->n_rp / 2 + 16;
+        BT_CHECK(hipMalloc((void**)&s->d_rp_const, cap * 56));
+        s->cap_rp = cap;
+    }
+    if (s->n_rp) BT_CHECK(hipMemcpy(s->d_rp_const, s->h_rp_c, (size_t)s->n_rp * 56, hipMemcpyHostToDevice));
     if ((size_t)n_dd > s->cap_dd) {
         if (s->d_dd) { hipFree(s->d_dd); s->d_dd = nullptr; }
         s->cap_dd = 0; s->n_dd = 0;
@@ -1162,6 +1245,26 @@ int glio_batch_set_small_factors(glio_batch* b, const glio_gnss_frame* frame, in
         BT_CHECK(hipMemcpy(s->d_rel, rel, 96, hipMemcpyHostToDevice));
     }
     s->n_dq = n_dq; s->n_dd = n_dd; s->n_fac = nf;
+    return GLIO_OK;
+}
+
+// LidarPoseFactorBatchRelativeAutoDiff factors between keyframes rp_i[f] and rp_j[f] (blocks P1 Q1 = keyframe rp_i, P2 Q2 = keyframe rp_j;
+// rp_const [n][7] = delta_q (w,x,y,z), delta_p as the estimator computes them from the odometry poses, Estimator.cpp:2901-2923): the scan-to-multiscan
+// factor of sms_fusion_level == 0, the released default (config_urban_hk.yaml:63).  Stored; the NEXT glio_batch_set_small_factors builds the factor
+// table with them (call this first; n_rp = 0 removes them).
+int glio_batch_set_relative_pose_factors(glio_batch* b, int n_rp, const int32_t* rp_i, const int32_t* rp_j, const double* rp_const) {
+    if (!b || n_rp < 0 || (n_rp > 0 && (!rp_i || !rp_j || !rp_const))) return GLIO_E_ARG;
+    BT_CHECK(hipSetDevice(b->device));
+    { const int rc = small_ensure(b); if (rc) return rc; }
+    BatchSmall* s = b->small;
+    free(s->h_rp_i); free(s->h_rp_j); free(s->h_rp_c);
+    s->h_rp_i = s->h_rp_j = nullptr; s->h_rp_c = nullptr; s->n_rp = 0;
+    if (n_rp > 0) {
+        s->h_rp_i = (int*)malloc((size_t)n_rp * 4); s->h_rp_j = (int*)malloc((size_t)n_rp * 4); s->h_rp_c = (double*)malloc((size_t)n_rp * 56);
+        if (!s->h_rp_i || !s->h_rp_j || !s->h_rp_c) return GLIO_E_ARG;
+        memcpy(s->h_rp_i, rp_i, (size_t)n_rp * 4); memcpy(s->h_rp_j, rp_j, (size_t)n_rp * 4); memcpy(s->h_rp_c, rp_const, (size_t)n_rp * 56);
+        s->n_rp = n_rp;
+    }
     return GLIO_OK;
 }
 

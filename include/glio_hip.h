@@ -219,7 +219,7 @@ int glio_batch_step_dev(glio_batch* b, const double* Hg_dev, double lambda, cons
  *   current outer round, :2764-2767).  Given whole on every rank; a rank keeps the factors whose first keyframe it owns.
  * glio_batch_set_imu: the ImuFactor chain between consecutive keyframes (Estimator.cpp:2990-3001; gl_tmpSpeedBias blocks :2809-2819):
  *   edges[k] = the pre-integration between keyframes k and k + 1 (the caller decides which interval that is),
- *   n_edges = K - 1, or 0 for the pose-only problem.  With the chain every keyframe has 15 unknowns (band <= 6).
+ *   n_edges = K - 1, or 0 for the pose-only problem.  With the chain every keyframe has 15 unknowns (band <= 12: the reference's +-12 end windows).
  * glio_batch_set_shard / glio_batch_shard_range: this object is rank `rank` of `world`; it owns a contiguous range of whole
  *   super-blocks of keyframes (6, or 12 for bands > 6).  The constraints handed to glio_batch_set_constraints* must have their source
  *   keyframe (ci) in that range.  Call before glio_batch_set_small_factors.
@@ -241,6 +241,11 @@ int glio_batch_shard_range(int K, int band, int rank, int world, int32_t* lo, in
 int glio_batch_set_shard(glio_batch* b, int rank, int world);
 int glio_batch_set_small_factors(glio_batch* b, const glio_gnss_frame* frame, int n_dq, const int32_t* dq_i, const int32_t* dq_j,
                                  const double* dq_const, int n_dd, const glio_dd_psr* dd);
+/* LidarPoseFactorBatchRelativeAutoDiff (GLIO/include/factors/LidarPoseFactor.h:55-97), the relative-pose factors that ARE the scan-to-multiscan
+ * constraints when sms_fusion_level == 0 (Estimator.cpp:2897-2955; the released default, config_urban_hk.yaml:63): blocks (P, Q) of keyframes rp_i[f]
+ * and rp_j[f], rp_const [n_rp][7] = (delta_q w,x,y,z, delta_p) from the odometry poses.  Call BEFORE glio_batch_set_small_factors, which builds the
+ * factor table (n_dq = n_dd = 0 is fine there). */
+int glio_batch_set_relative_pose_factors(glio_batch* b, int n_rp, const int32_t* rp_i, const int32_t* rp_j, const double* rp_const);
 int glio_batch_set_dd_threshold(glio_batch* b, double threshold);   /* the next round's DDpsr_threshold, factors stay on the device */
 int glio_batch_set_imu(glio_batch* b, int n_edges, const glio_preint* edges, double gravity);
 int glio_batch_add_small_dev(glio_batch* b, const double* poses, double* Hg_dev);      /* damped Gauss-Newton path, one rank */

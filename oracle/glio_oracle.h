@@ -145,6 +145,8 @@ typedef struct orc_batch_problem {
      * pre-integration of the ImuFactor between keyframes k and k + 1 (the caller decides which interval that is, quirk Q11);
      * then every keyframe carries its speed-bias block (:2809-2819) and 15 unknowns */
     int32_t n_imu; int32_t pad_; const glio_preint* imu; double gravity;
+    /* LidarPoseFactorBatchRelativeAutoDiff factors (sms_fusion_level 0, Estimator.cpp:2897-2955): keyframes (rp_i, rp_j), rp_const [n_rp][7] = delta_q (w,x,y,z), delta_p */
+    int32_t n_rp; int32_t pad2_; const int32_t* rp_i; const int32_t* rp_j; const double* rp_const;
 } orc_batch_problem;
 /* delta_q_factor_auto (LidarKeyframeFactor.h:283-303): blocks qi[4], qj[4]; 3 residuals = 10000 (dq^-1 qi^-1 qj).vec; global Jacobians 3x4 */
 int orc_eval_delta_q(const double dq_const[4], double const* const* parameters, double* residuals, double** jacobians);

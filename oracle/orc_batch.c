@@ -205,6 +205,25 @@ int orc_batch_linearize_full(const orc_batch_problem* p, const double* poses, do
         for (int i = 0; i < 19; ++i) cost += 0.5 * r[i] * r[i];
         band_add(band, Hband, g, a, b, 19, Ja, Jb, r);
     }
+    /* LidarPoseFactorBatchRelativeAutoDiff (sms_fusion_level 0, Estimator.cpp:2897-2955): blocks (t_i, q_i, t_j, q_j), all six local columns of either keyframe */
+    for (int f = 0; f < p->n_rp; ++f) {
+        const int a = p->rp_i[f], b = p->rp_j[f];
+        if (a == b || abs(a - b) > band) return 0;
+        const double* P[4] = {poses + 7 * (size_t)a, poses + 7 * (size_t)a + 3, poses + 7 * (size_t)b, poses + 7 * (size_t)b + 3};
+        double r[6], J0[18], J1[24], J2[18], J3[24];
+        double* J[4] = {J0, J1, J2, J3};
+        orc_eval_relative_pose(p->rp_const + 7 * (size_t)f, p->rp_const + 7 * (size_t)f + 4, P, r, J);
+        double Pa[12], Pb[12], Ja[36], Jb[36];
+        plusJ(P[1], Pa); plusJ(P[3], Pb);
+        for (int i = 0; i < 6; ++i)
+            for (int k = 0; k < 3; ++k) {
+                Ja[i * 6 + k] = J0[i * 3 + k]; Jb[i * 6 + k] = J2[i * 3 + k];
+                Ja[i * 6 + 3 + k] = J1[i * 4] * Pa[k] + J1[i * 4 + 1] * Pa[3 + k] + J1[i * 4 + 2] * Pa[6 + k] + J1[i * 4 + 3] * Pa[9 + k];
+                Jb[i * 6 + 3 + k] = J3[i * 4] * Pb[k] + J3[i * 4 + 1] * Pb[3 + k] + J3[i * 4 + 2] * Pb[6 + k] + J3[i * 4 + 3] * Pb[9 + k];
+            }
+        for (int i = 0; i < 6; ++i) cost += 0.5 * r[i] * r[i];
+        band_add(band, Hband, g, a, b, 6, Ja, Jb, r);
+    }
     *cost_out = cost;
     return 1;
 }

@@ -275,7 +275,8 @@ class OrcBatchProblem(C.Structure):
     _fields_ = [("K", C.c_int32), ("band", C.c_int32), ("n_con", C.c_int64), ("ci", T.c_int32_p), ("cj", T.c_int32_p), ("cp", T.c_float_p),
                 ("norm_cent", T.c_double_p), ("score", T.c_double_p), ("n_dq", C.c_int32), ("dq_i", T.c_int32_p), ("dq_j", T.c_int32_p),
                 ("dq_const", T.c_double_p), ("n_dd", C.c_int32), ("dd", C.POINTER(T.GlioDdPsr)), ("frame", T.GlioGnssFrame),
-                ("n_imu", C.c_int32), ("pad_", C.c_int32), ("imu", C.POINTER(T.GlioPreint)), ("gravity", C.c_double)]
+                ("n_imu", C.c_int32), ("pad_", C.c_int32), ("imu", C.POINTER(T.GlioPreint)), ("gravity", C.c_double),
+                ("n_rp", C.c_int32), ("pad2_", C.c_int32), ("rp_i", T.c_int32_p), ("rp_j", T.c_int32_p), ("rp_const", T.c_double_p)]
 
 
 def eval_delta_q(dq_const, qi, qj, want_J=True):
@@ -298,7 +299,7 @@ class BatchProblem:
     """Owns the numpy buffers behind an orc_batch_problem: binary plane constraints, delta_q attitude constraints (i, j, const_diff),
     DD pseudorange factors (slot_i / slot_j = keyframe indices)."""
 
-    def __init__(self, K, band, ci, cj, cp, nc, score, dq=None, dd=None, frame=None, imu=None, gravity=9.80511):
+    def __init__(self, K, band, ci, cj, cp, nc, score, dq=None, dd=None, frame=None, imu=None, gravity=9.80511, rp=None):
         """imu: None (pose-only problem) or the K - 1 pre-integrations (dicts as synth.preintegrate returns, or GlioPreint) of the
         ImuFactor chain (Estimator.cpp:2990-3001); then the unknowns are 15 per keyframe."""
         self.K, self.band = K, band
@@ -325,6 +326,12 @@ class BatchProblem:
                 from glio_amd import synth
                 synth.fill_preint(self.imu[k], d)
         p.n_imu, p.imu, p.gravity = len(imu), self.imu, gravity
+        # rp = (i, j, const [n][7]): LidarPoseFactorBatchRelativeAutoDiff factors (batch.relative_pose_pairs)
+        rp = rp or (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 7)))
+        self.rp_i = np.ascontiguousarray(rp[0], np.int32); self.rp_j = np.ascontiguousarray(rp[1], np.int32); self.rp_c = np.ascontiguousarray(rp[2], np.float64)
+        p.n_rp = len(self.rp_i)
+        if p.n_rp:
+            p.rp_i, p.rp_j, p.rp_const = T.iptr(self.rp_i), T.iptr(self.rp_j), T.dptr(self.rp_c)
         self.n_imu = len(imu)
         self.c = p
 

@@ -352,3 +352,66 @@ def test_imu_chain_under_the_references_end_windows_band_12(K, world, windows):
     assert np.isclose(summ.final_cost, wsum.final_cost, rtol=1e-8)
     assert np.abs(poses - want).max() < 1e-7 and np.abs(sb - wsb).max() < 1e-6
     assert summ.final_cost < 0.01 * summ.initial_cost
+
+
+@pytest.mark.parametrize("with_planes", [False, True], ids=["sms_fusion_level_0", "mixed"])
+@pytest.mark.parametrize("world", [1, 2])
+def test_relative_pose_factors_of_the_released_default(with_planes, world):
+    """sms_fusion_level == 0 (config_urban_hk.yaml:63, the SHIPPED default): the scan-to-multiscan constraints are LidarPoseFactorBatchRelativeAutoDiff
+    factors between keyframes up to search_range - 1 apart (Estimator.cpp:2897-2955), next to the delta_q and DD factors -- no plane constraints,
+    no IMU.  The factor is a role of the small-factor kernel (type 2); its oracle restatement is pinned on the reference's own Jets
+    (tests/test_oracle_ref.py::test_relative_pose_factor).  Linearisation and trust-region solve vs the oracle; `mixed` adds plane constraints."""
+    from oracle import pyoracle as po
+    import torch
+    K, band, sr = 60, 6, 6
+    gt, init = batch.make_poses(K, seed=88, perturb=(0.08, 0.004))
+    rng = np.random.default_rng(88)
+    odo = gt.copy(); odo[:, :3] += rng.normal(0, 0.02, (K, 3))
+    rp = batch.relative_pose_pairs(odo, sr)
+    assert len(rp[0]) == 2 * (K - sr) * (sr - 1) and np.abs(rp[0] - rp[1]).max() == sr - 1
+    dq = batch.delta_q_pairs(odo, sr)
+    dd, frame = batch.make_batch_gnss(gt, seed=88)
+    for f in dd:
+        f.threshold = 10.0
+    if with_planes:
+        ci, cj, cp, nc, score = batch.make_constraints(gt, 0, K, 120, band, seed=88)
+        con = (ci, cj, cp.numpy(), nc.numpy(), score.numpy())
+    else:
+        con = (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 4), np.float32), np.zeros((0, 6)), np.zeros(0))
+    P = po.BatchProblem(K, band, *con, dq=dq, dd=dd, frame=frame, rp=rp)
+    opts = T.batch_tr_opts(max_iterations=20)
+    want, wsum = P.solve(init, opts)
+
+    def stage(rank):
+        lo, hi = batch.shard_range(K, rank, world, band)
+        own = (con[0] >= lo) & (con[0] < hi)
+        st = batch.BatchStage(K, band, max(1, int(own.sum())))
+        if world > 1:
+            st.set_shard(rank, world)
+        st.set_constraints(*[c[own] for c in con])
+        st.set_small_factors(dq, dd, frame, rp=rp)
+        return st
+    if world == 1:
+        st = stage(0)
+        Hg = st.new_hg()
+        st.linearize(init, Hg); st.add_small(init, Hg)
+        got = Hg.cpu().numpy()
+        H, g, cost = P.linearize(init)
+        nH = K * (band + 1) * 36
+        assert np.abs(got[:nH] - H.ravel()).max() <= 1e-11 * np.abs(H).max()
+        assert np.abs(got[nH:-1] - g.ravel()).max() <= 1e-11 * np.abs(g).max() and abs(got[-1] - cost) <= 1e-12 * cost
+        poses, summ = st.solve_tr(init, opts)
+        st.close()
+    else:
+        stages = [stage(r) for r in range(world)]
+        ranks = batch.ThreadRanks(world, sync=torch.cuda.synchronize)
+        res = ranks.run(lambda r, d: stages[r].solve_tr(init, opts, d))
+        poses, summ = res[0]
+        assert np.array_equal(res[1][0], poses)
+        for s_ in stages:
+            s_.close()
+    assert summ.iterations == wsum.iterations and summ.successful_steps == wsum.successful_steps and summ.termination == wsum.termination, (summ.as_dict(), wsum.as_dict())
+    assert np.isclose(summ.final_cost, wsum.final_cost, rtol=1e-9) and np.abs(poses - want).max() < 1e-8
+    assert summ.final_cost < 0.05 * summ.initial_cost
+    rel = lambda X: np.linalg.norm(np.diff(X[:, :3], axis=0) - np.diff(odo[:, :3], axis=0), axis=1).max()
+    assert rel(poses) < 0.5 * rel(init)                      # the relative-pose factors pull the chain onto the odometry's increments
