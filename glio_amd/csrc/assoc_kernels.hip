@@ -252,7 +252,7 @@ struct KnnBin {
     int* qslot; int* qrank; float4* qtmp;                 // [cap] table slot, arrival rank and transformed point (w = its index) of point i
     // per-call grouping (k_qbin_tile) and search (k_knn5_tile), every launch row y:
     float4* qs;                                           // [Y][w_stride] queries grouped by cell (world xyz, w = index in the scan); the presort's output pointer
-    int2* units;                                          // [Y][unit_stride] (first grouped position, queries)
+    int4* units;                                          // [Y][unit_stride] (first grouped position, queries, cell key lo, hi): the search probes from the record alone
     int* counters;                                        // [Y][2] grouped queries, units (zeroed again by k_plane_fit)
     int capq, unit_stride;
 };
@@ -499,10 +499,15 @@ __global__ __launch_bounds__(256) void k_knn5(const AssocArgs a, const float4* _
 // is independent and written at its own index.
 #define TK_Q 16
 #define TK_LANES 32
-#define TK_CAP 128
-#define TK_SEL 7
-#define TK_UNITS (256 / TK_LANES)
-#define TK_MASK 127u
+#ifndef TK_CAP
+#define TK_CAP 256         /* staged candidates per chunk: the 27 cells of a C2 unit hold ~160 (p90 193, max 330): one chunk for nearly every unit (round 4; 128 before) */
+#endif
+#define TK_SEL 6           /* selection by truncated key; exact when the fifth exact distance lies in a lower bucket than the SIXTH selected key */
+#ifndef TK_THREADS
+#define TK_THREADS 64      /* ONE wavefront per workgroup (two units): a workgroup of four made every unit wait for the slowest of eight, and 43 KB of LDS per workgroup sent a quarter of the workgroups into a second round (r04 per-workgroup stamps) */
+#endif
+#define TK_UNITS (TK_THREADS / TK_LANES)
+#define TK_MASK ((unsigned)(TK_CAP - 1))
 #define QT_THREADS 1024
 #define QT_SLOTS 2048
 #define PRESORT_CELL 5.0f
@@ -618,9 +623,10 @@ __global__ __launch_bounds__(QT_THREADS) void k_qbin_tile(const AssocArgs a, con
     __syncthreads();
     const int st0 = s_wc[wv] + ic - (c0 + c1), ut0 = s_ubase + s_wu[wv] + iu - (u0 + u1);
     s_cnt[2 * tid] = st0; s_cnt[2 * tid + 1] = st0 + c0;
-    int2* un = a.kb.units + (size_t)blockIdx.y * a.kb.unit_stride;
-    for (int u = 0; u < u0; ++u) un[ut0 + u] = make_int2(tile0 + st0 + TK_Q * u, min(TK_Q, c0 - TK_Q * u));
-    for (int u = 0; u < u1; ++u) un[ut0 + u0 + u] = make_int2(tile0 + st0 + c0 + TK_Q * u, min(TK_Q, c1 - TK_Q * u));
+    int4* un = a.kb.units + (size_t)blockIdx.y * a.kb.unit_stride;
+    const unsigned long long k0 = s_key[2 * tid], k1 = s_key[2 * tid + 1];
+    for (int u = 0; u < u0; ++u) un[ut0 + u] = make_int4(tile0 + st0 + TK_Q * u, min(TK_Q, c0 - TK_Q * u), (int)(unsigned)(k0 & 0xffffffffull), (int)(unsigned)(k0 >> 32));
+    for (int u = 0; u < u1; ++u) un[ut0 + u0 + u] = make_int4(tile0 + st0 + c0 + TK_Q * u, min(TK_Q, c1 - TK_Q * u), (int)(unsigned)(k1 & 0xffffffffull), (int)(unsigned)(k1 >> 32));
     __syncthreads();
     if (live) a.kb.qs[sl.woff + tile0 + s_cnt[slot] + rank] = make_float4(px, py, pz, pw);
 }
@@ -640,14 +646,23 @@ __device__ long long g_knn_stamps[8];      // workgroup 0, wavefront 0 of the la
 #define KN_T(var) const long long var = wall_clock64()
 #define KN_ACC(k, t1, t0) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_knn_stamps[k] += (t1) - (t0); } while (0)
 extern "C" int glio_debug_knn_stamps(long long* out8) { return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_knn_stamps), 64) == hipSuccess ? 0 : -2; }
+// per workgroup (launch row 0) of the last launch: [start, end] device clock (100 MHz), candidates of its first unit, XCC / CU id
+__device__ long long g_knn_wg[4096][12];
+extern "C" int glio_debug_knn_wg(long long* out, int n) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_knn_wg), (size_t)n * 96) == hipSuccess ? 0 : -2; }
 #else
 #define KN_T(var) do { } while (0)
 #define KN_ACC(k, t1, t0) do { } while (0)
 #endif
-__global__ __launch_bounds__(256) void k_knn5_tile(const AssocArgs a, const float4* __restrict__ map, const int4* __restrict__ ent,
+typedef float tk_v2f __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(TK_THREADS) __attribute__((amdgpu_waves_per_eu(5))) void k_knn5_tile(const AssocArgs a, const float4* __restrict__ map, const int4* __restrict__ ent,
                                                    int* __restrict__ o_nn5, float* __restrict__ o_d4) {
-    __shared__ float4 s_pts[TK_UNITS][TK_CAP + 2];      // + 2: the two units of a wavefront broadcast from different banks
-    __shared__ int s_pos[TK_UNITS][TK_CAP];
+    // Candidates are staged in PAIRS, structure-of-arrays inside the pair: [x0 x1 | y0 y1 | z0 z1], so that a lane ranks two candidates with
+    // packed single-precision instructions (v_pk_add_f32 / v_pk_mul_f32: separate IEEE operations per half, no contraction -- the same bits as the
+    // scalar form) -- the search is VALU-issue bound (r04 counters: 8.8 M wavefront-VALU per 64 k scan = half the kernel's duration on 1024 SIMDs).
+    __shared__ tk_v2f s_xyz[TK_UNITS][TK_CAP / 2][3];
+    __shared__ int s_idx[TK_UNITS][TK_CAP];          // original map index (the tie-break of the ranking)
+    // (no array of map positions: the running five carry the candidate's ORDINAL in the unit's 27-cell list and the winners are located once at the
+    //  end -- a kilobyte of LDS per unit buys four more wavefronts per CU, and the search is bound by latency x occupancy, r04 counters)
     __shared__ int2 s_tab[TK_UNITS][33];
     const int lane = threadIdx.x & 63, l32 = threadIdx.x & 31, j = threadIdx.x & (TK_Q - 1), h = (threadIdx.x >> 4) & 1, g = threadIdx.x / TK_LANES;
     const int gbase = lane & ~(TK_LANES - 1);
@@ -657,21 +672,29 @@ __global__ __launch_bounds__(256) void k_knn5_tile(const AssocArgs a, const floa
     if (sl.ent) { ent = sl.ent; map = sl.map; }
     const int table_cap = sl.table_cap;
     const int n_units = a.kb.counters[2 * blockIdx.y + 1];
-    const int2* units = a.kb.units + (size_t)blockIdx.y * a.kb.unit_stride;
+    const int4* units = a.kb.units + (size_t)blockIdx.y * a.kb.unit_stride;
     const float4* qs = a.kb.qs + sl.woff;
 #ifdef GLIO_DEV_STAMPS
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { for (int k = 0; k < 8; ++k) g_knn_stamps[k] = 0; }
+    const long long wg_t0 = wall_clock64();
+    int wg_tot = 0, wg_chunks = 0, wg_unsafe = 0, wg_probe = 0;
+    long long wg_ph[5] = {0, 0, 0, 0, 0};
+#define WG_PH(k, t1, t0) wg_ph[k] += (t1) - (t0)
+#else
+#define WG_PH(k, t1, t0) do { } while (0)
 #endif
     for (int u0 = blockIdx.x * TK_UNITS; u0 < n_units; u0 += gridDim.x * TK_UNITS) {
         KN_T(tk0);
         const int uid = u0 + g;
         const bool ulive = uid < n_units;
-        const int2 un = ulive ? units[uid] : make_int2(0, 0);
+        const int4 un = ulive ? units[uid] : make_int4(0, 0, 0, 0);
         const bool qlive = j < un.y;
         const float4 qp = ulive ? qs[un.x + (qlive ? j : 0)] : make_float4(0, 0, 0, 0);
         const float px = qp.x, py = qp.y, pz = qp.z;
         const int qi = __float_as_int(qp.w);
-        const int cx = cell_of(px, a.inv_cell), cy = cell_of(py, a.inv_cell), cz = cell_of(pz, a.inv_cell);    // the same for the whole unit
+        // the unit's cell from its record (not from the query: the probe below then does not wait for the query's load)
+        const unsigned long long ukey = ((unsigned long long)(unsigned)un.w << 32) | (unsigned)un.z;
+        const int cx = (int)((ukey >> 42) & 0x1fffffu) - (1 << 20), cy = (int)((ukey >> 21) & 0x1fffffu) - (1 << 20), cz = (int)(ukey & 0x1fffffu) - (1 << 20);
         // ---- probe the 27 cells once per unit: lane c < 27 takes cell c
         int cs = 0, cc = 0;
         if (l32 < 27 && ulive) {
@@ -681,6 +704,9 @@ __global__ __launch_bounds__(256) void k_knn5_tile(const AssocArgs a, const floa
             unsigned s = home_slot(cx + dx, cy + dy, cz + dz, table_cap);
             for (;;) {
                 const int4 e = ent[s];
+#ifdef GLIO_DEV_STAMPS
+                ++wg_probe;
+#endif
                 if (e.x == klo && e.y == khi) { cs = e.z; cc = e.w; break; }
                 if ((e.x & e.y) == -1) break;
                 s = (s + 1) & (table_cap - 1);
@@ -705,39 +731,67 @@ __global__ __launch_bounds__(256) void k_knn5_tile(const AssocArgs a, const floa
             const int2 e = tab[c];
             return e.y + (f - e.x);
         };
+        auto staged = [&](const int slot) {            // the staged candidate `slot` as the float4 the exact ranking takes (w = original index)
+            const tk_v2f* pr = s_xyz[g][slot >> 1];
+            const int e = slot & 1;
+            return make_float4(e ? pr[0].y : pr[0].x, e ? pr[1].y : pr[1].x, e ? pr[2].y : pr[2].x, __int_as_float(s_idx[g][slot]));
+        };
         unsigned long long bk[5] = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull};
         int bp[5] = {-1, -1, -1, -1, -1};
-        KN_T(tk1); KN_ACC(0, tk1, tk0); KN_ACC(5, 1, 0);
+        const tk_v2f P0 = {px, px}, P1 = {py, py}, P2 = {pz, pz};
+        KN_T(tk1); KN_ACC(0, tk1, tk0); KN_ACC(5, 1, 0); WG_PH(0, tk1, tk0);
         for (int base = 0; base < tot_w; base += TK_CAP) {
             KN_T(tc0);
             const int n_c = min(max(tot - base, 0), TK_CAP);                       // staged candidates of this unit
             const int n_w = min(tot_w - base, TK_CAP), n_w8 = (n_w + 7) & ~7;       // scan length of the wavefront
-            // ---- stage: beyond the unit's own list a far point (never selected)
-            for (int f = l32; f < n_w8; f += TK_LANES) {
-                float4 pt = make_float4(3e18f, 3e18f, 3e18f, 0.f);
-                int pos = -1;
-                if (f < n_c) { pos = locate(base + f); pt = map[pos]; }
-                s_pts[g][f] = pt;
-                s_pos[g][f] = pos;
+            // ---- stage: beyond the unit's own list a far point (never selected).  All the loads of a lane are issued before the first LDS write.
+            for (int r0 = 0; r0 < TK_CAP / TK_LANES; r0 += 4) {          // four loads of a lane in flight (eight cost 16 more VGPRs = one wavefront per SIMD less)
+                if (TK_LANES * r0 >= n_w8) break;
+                float4 pt[4]; int ps[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = l32 + TK_LANES * (r0 + r);
+                    ps[r] = (f < n_c) ? locate(base + f) : -1;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pt[r] = ps[r] >= 0 ? map[ps[r]] : make_float4(3e18f, 3e18f, 3e18f, 0.f);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = l32 + TK_LANES * (r0 + r);
+                    if (f < n_w8) {
+                        float* pr = reinterpret_cast<float*>(s_xyz[g][f >> 1]);
+                        pr[f & 1] = pt[r].x; pr[2 + (f & 1)] = pt[r].y; pr[4 + (f & 1)] = pt[r].z;
+                        s_idx[g][f] = __float_as_int(pt[r].w);
+                    }
+                }
             }
             GLIO_WAVE_LDS_SYNC();
-            KN_T(tc1); KN_ACC(1, tc1, tc0);
-            // ---- scan: every lane ranks its half (slots of parity h) of the staged list for its own query
+            KN_T(tc1); KN_ACC(1, tc1, tc0); WG_PH(1, tc1, tc0);
+            // ---- scan: every lane ranks its half of the staged PAIRS (pairs of parity h) for its own query
             unsigned tk[TK_SEL];
 #pragma unroll
             for (int k = 0; k < TK_SEL; ++k) tk[k] = ~0u;
-            for (int f = h; f < n_w8; f += 8) {
+            for (int pp = h; pp < (n_w8 >> 1); pp += 4) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float4 mp = s_pts[g][f + 2 * u];
-                    const float ex = px - mp.x, ey = py - mp.y, ez = pz - mp.z;
-                    float d = ex * ex;
+                for (int u = 0; u < 2; ++u) {
+                    const tk_v2f* pr = s_xyz[g][pp + 2 * u];
+#ifdef TK_SCALAR_DIST
+                    const tk_v2f X = pr[0], Y = pr[1], Z = pr[2];
+                    tk_v2f d;
+                    { const float ex = px - X.x, ey = py - Y.x, ez = pz - Z.x; float t = ex * ex; t = t + ey * ey; t = t + ez * ez; d.x = t; }
+                    { const float ex = px - X.y, ey = py - Y.y, ez = pz - Z.y; float t = ex * ex; t = t + ey * ey; t = t + ez * ez; d.y = t; }
+#else
+                    const tk_v2f ex = P0 - pr[0], ey = P1 - pr[1], ez = P2 - pr[2];
+                    tk_v2f d = ex * ex;
                     d = d + ey * ey;
                     d = d + ez * ez;
-                    tk_insert(tk, (__float_as_uint(d) & ~TK_MASK) | (unsigned)(f + 2 * u));
+#endif
+                    const unsigned f0 = (unsigned)(2 * (pp + 2 * u));
+                    tk_insert(tk, (__float_as_uint(d.x) & ~TK_MASK) | f0);
+                    tk_insert(tk, (__float_as_uint(d.y) & ~TK_MASK) | (f0 + 1u));
                 }
             }
-            KN_T(tc2); KN_ACC(2, tc2, tc1);
+            KN_T(tc2); KN_ACC(2, tc2, tc1); WG_PH(2, tc2, tc1);
             // ---- exact re-ranking of the selection, merged into the lane's running five
             bool all_in = false;
 #pragma unroll
@@ -745,22 +799,42 @@ __global__ __launch_bounds__(256) void k_knn5_tile(const AssocArgs a, const floa
                 const unsigned t = tk[k];
                 const int slot = (int)(t & TK_MASK);
                 const bool real = t != ~0u && slot < n_c;
-                if (real) knn5_insert(px, py, pz, s_pts[g][slot], s_pos[g][slot], bk, bp);
+                if (real) knn5_insert(px, py, pz, staged(slot), base + slot, bk, bp);
                 if (k == TK_SEL - 1) all_in = !real;                                // fewer than TK_SEL candidates: all of them were merged
             }
             const bool safe = all_in || ((unsigned)(bk[4] >> 32) & ~TK_MASK) < (tk[TK_SEL - 1] & ~TK_MASK);
             if (__any(qlive && !safe)) {
+                // near-ties at the selection boundary: the candidates that can still belong to the exact five are those whose bucket is not above the
+                // last selected key's (everything else has a larger truncated, hence a larger exact, distance than all six selected).  A second pass
+                // over the lane's half with the cheap packed distances; the exact 64-bit insertion runs only for those few (round 3 re-ranked EVERY
+                // candidate of the half exactly: 12 us for the wavefronts that hit it -- the tail of the kernel, r04 per-workgroup stamps).
+                const unsigned edge = tk[TK_SEL - 1] & ~TK_MASK;
                 if (qlive && !safe) {
-                    for (int f = h; f < n_c; f += 2) {
-                        bool dup = false;
+                    for (int pp = h; pp < ((n_c + 1) >> 1); pp += 2) {
+                        const tk_v2f* pr = s_xyz[g][pp];
+                        const tk_v2f ex = P0 - pr[0], ey = P1 - pr[1], ez = P2 - pr[2];
+                        tk_v2f d = ex * ex;
+                        d = d + ey * ey;
+                        d = d + ez * ez;
+                        // (the common iteration is the packed distance and one compare: the selection's own slots are told apart inside the rare branch)
+                        if (min(__float_as_uint(d.x), __float_as_uint(d.y)) <= (edge | TK_MASK)) {
 #pragma unroll
-                        for (int k = 0; k < TK_SEL; ++k) dup = dup || (tk[k] != ~0u && (int)(tk[k] & TK_MASK) == f);
-                        if (!dup) knn5_insert(px, py, pz, s_pts[g][f], s_pos[g][f], bk, bp);
+                            for (int e = 0; e < 2; ++e) {
+                                const int f = 2 * pp + e;
+                                bool skip = f >= n_c || (__float_as_uint(e ? d.y : d.x) & ~TK_MASK) > edge;
+#pragma unroll
+                                for (int k = 0; k < TK_SEL; ++k) skip = skip || (tk[k] != ~0u && (int)(tk[k] & TK_MASK) == f);
+                                if (!skip) knn5_insert(px, py, pz, staged(f), base + f, bk, bp);
+                            }
+                        }
                     }
                 }
             }
             GLIO_WAVE_LDS_SYNC();
-            KN_T(tc3); KN_ACC(3, tc3, tc2);
+            KN_T(tc3); KN_ACC(3, tc3, tc2); WG_PH(3, tc3, tc2);
+#ifdef GLIO_DEV_STAMPS
+            ++wg_chunks; if (__any(qlive && !safe)) ++wg_unsafe;
+#endif
         }
         KN_T(tk2);
         // ---- the other half's five
@@ -771,11 +845,26 @@ __global__ __launch_bounds__(256) void k_knn5_tile(const AssocArgs a, const floa
         for (int k = 0; k < 5; ++k) knn5_insert_key(ok[k], op[k], bk, bp);
         if (qlive && h == 0) {
 #pragma unroll
-            for (int k = 0; k < 5; ++k) o_nn5[5 * (size_t)qi + k] = bp[k];
+            for (int k = 0; k < 5; ++k) o_nn5[5 * (size_t)qi + k] = bp[k] >= 0 ? locate(bp[k]) : -1;      // ordinal in the 27-cell list -> position in the sorted map
             o_d4[qi] = bp[4] >= 0 ? __uint_as_float((unsigned)(bk[4] >> 32)) : FLT_MAX;
         }
-        KN_T(tk3); KN_ACC(4, tk3, tk2);
+        GLIO_WAVE_LDS_SYNC();                        // (the next unit of this wavefront rewrites the cell table the winners were located with)
+        KN_T(tk3); KN_ACC(4, tk3, tk2); WG_PH(4, tk3, tk2);
+#ifdef GLIO_DEV_STAMPS
+        wg_tot = tot_w;
+#endif
     }
+#ifdef GLIO_DEV_STAMPS
+    if (blockIdx.y == 0 && blockIdx.x < 4096 && threadIdx.x == 0) {
+        unsigned xcc = 0, hwid = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        long long* rec = g_knn_wg[blockIdx.x];
+        rec[0] = wg_t0; rec[1] = wall_clock64(); rec[2] = wg_tot; rec[3] = ((long long)xcc << 32) | hwid;
+        rec[4] = wg_chunks; rec[5] = wg_unsafe; rec[6] = wg_probe;
+        for (int k = 0; k < 5; ++k) rec[7 + k] = wg_ph[k];
+    }
+#endif
 }
 
 #define PF_BLOCK 256
@@ -958,7 +1047,7 @@ static KnnBinHost* knn_bin_create(int rows, int cap) {
     const size_t tq = (size_t)h->capq_max, wq1 = (size_t)cap, wq = (size_t)rows * cap;
     bool ok = hipMalloc((void**)&d.keys, tq * 8) == hipSuccess && hipMalloc((void**)&d.cnt, tq * 4) == hipSuccess && hipMalloc((void**)&d.cstart, tq * 4) == hipSuccess &&
               hipMalloc((void**)&d.qslot, wq1 * 4) == hipSuccess && hipMalloc((void**)&d.qrank, wq1 * 4) == hipSuccess && hipMalloc((void**)&d.qtmp, wq1 * 16) == hipSuccess &&
-              hipMalloc((void**)&d.qs, wq * 16) == hipSuccess && hipMalloc((void**)&d.units, (size_t)rows * d.unit_stride * 8) == hipSuccess &&
+              hipMalloc((void**)&d.qs, wq * 16) == hipSuccess && hipMalloc((void**)&d.units, (size_t)rows * d.unit_stride * 16) == hipSuccess &&
               hipMalloc((void**)&d.counters, (size_t)rows * 8) == hipSuccess;
     ok = ok && hipMemset(d.keys, 0xff, tq * 8) == hipSuccess && hipMemset(d.cnt, 0, tq * 4) == hipSuccess && hipMemset(d.counters, 0, (size_t)rows * 8) == hipSuccess;
     if (!ok) { glio_set_error("hipMalloc failed for the query binning buffers"); return nullptr; }
@@ -996,9 +1085,13 @@ static void enqueue_knn(hipStream_t stream, AssocArgs& a, KnnBinHost* kb, int ro
     }
     a.kb = kb->d;
     hipLaunchKernelGGL(k_qbin_tile, dim3((maxn + QT_THREADS - 1) / QT_THREADS, rows), dim3(QT_THREADS), 0, stream, a, ps);
-    int gx = (maxn + 63) / 64;
-    if (gx > 2048) gx = 2048;
-    hipLaunchKernelGGL(k_knn5_tile, dim3(gx, rows), dim3(256), 0, stream, a, map, ent, nn5, d4);
+    // capacity for maxn / 8 units per row (k_qbin_tile makes at most n / 16 + cells): one wavefront-workgroup per unit pair up to 4096 per row, beyond
+    // that the workgroups stride
+    // (sizing the grid to what the chip holds at once -- ~4096 workgroups striding over the units -- measured 390 us instead of 303 us for the one-call
+    //  window association of 20 rows: the dispatcher is not the limit, and fresh workgroups overlap their probe / staging latencies better)
+    int gx = (maxn + 8 * TK_UNITS - 1) / (8 * TK_UNITS);
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(k_knn5_tile, dim3(gx, rows), dim3(TK_THREADS), 0, stream, a, map, ent, nn5, d4);
 }
 
 int glio_assoc_create(glio_ctx* c) {
