@@ -877,9 +877,16 @@ int glio_solve(glio_ctx* c, glio_state* s, glio_summary* sum) {
             // ahead of parts of the payload).  Re-read for up to 2 ms, then take the stream-ordered copy.
             const auto t_chk = std::chrono::steady_clock::now();
             for (;;) {
-                std::atomic_thread_fence(std::memory_order_acquire);
-                memcpy(c->h_status, c->h_result, sizeof(SolverStatus));
-                memcpy(c->h_xbuf, c->h_result + 512, (size_t)nx * 8);
+                // a PRIVATE copy, taken word by word with 8-byte atomic loads (the device writes naturally aligned 8-byte words; neither side can
+                // tear one), and only the private copy is validated and used: the happens-before argument is in DESIGN.md section 5
+                {
+                    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(c->h_result);
+                    unsigned long long* ds = reinterpret_cast<unsigned long long*>(c->h_status);
+                    for (size_t w = 0; w < sizeof(SolverStatus) / 8; ++w) ds[w] = __atomic_load_n(src + w, __ATOMIC_RELAXED);
+                    unsigned long long* dx = reinterpret_cast<unsigned long long*>(c->h_xbuf);
+                    for (int k = 0; k < nx; ++k) dx[k] = __atomic_load_n(src + 64 + k, __ATOMIC_RELAXED);
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                }
                 SolverStatus t = *c->h_status;
                 const unsigned long long want = t.checksum;
                 t.checksum = 0;
