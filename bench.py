@@ -143,6 +143,10 @@ def main():
     try:
         pipeline_info = bench_keyframe_stream(local_rank, args.window, args.points, cpu_keyframes=0 if (args.no_cpu_baseline or world > 1) else 1)
         pipeline_info["replay_of_one_keyframe"] = bench_keyframe_pipeline(local_rank, stream, args.window)
+        try:
+            pipeline_info["keyframe_pipeline_cpp"] = bench_keyframe_stream_cpp(local_rank, args.window, args.points, pipeline_info)
+        except Exception as e:  # noqa: BLE001 -- informational
+            pipeline_info["keyframe_pipeline_cpp"] = {"error": str(e)[:300]}
     except Exception as e:
         pipeline_info = {"error": str(e)[:300]}
 
@@ -570,6 +574,31 @@ def bench_keyframe_stream(local_rank, W, pts, n_keyframes=8, cpu_keyframes=1, se
         info["speedup_vs_cpu_port"] = round(cpu["ms"] / (total * 1e3), 1)
     ctx.close()
     return info
+
+
+def bench_keyframe_stream_cpp(local_rank, W, pts, py_info, n_keyframes=8, seed=None):
+    """The SAME moving stream driven from C++ (glio_amd/host/host_demo_stream.cpp over glio_backend.hpp, the host mirror a maintainer compiles into
+    Estimator.cpp -- `north_star`: host code stays C++): the stream is written to a flat file, the C++ program runs the keyframe cycle and times its
+    own stages with std::chrono.  Same library, same inputs: the iterations and the kept correspondences per keyframe must equal the Python driver's."""
+    import tempfile
+    from glio_amd import synth
+    from glio_amd.host import window_io
+    seed = synth.SEED_BASE + 12 if seed is None else seed
+    long = synth.make_window(W=W + n_keyframes, pts_per_scan=pts, with_gnss=True, with_prior=False, seed=seed)
+    wins = [synth.sub_window(long, j, W) for j in range(n_keyframes + 1)]
+    opts = wins[0].opts
+    opts.max_ddt_epochs = max(w.init.n_ddt for w in wins) + 8
+    opts.max_map_points = 1 << 18
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "stream.bin")
+        window_io.write_stream(path, long, wins, W, n_keyframes, pts)
+        runs = [window_io.run_demo_stream(path, device=local_rank) for _ in range(2)]
+    out = min(runs, key=lambda r: r["cycle_ms"])
+    out["host"] = "C++17 (g++ -O2), glio_backend.hpp over the C-ABI; stage times by std::chrono inside the program; best of 2 runs of 8 keyframes"
+    if py_info and "iterations" in py_info:
+        out["same_iterations_and_correspondences_as_the_python_driver"] = bool(out["iterations"] == py_info["iterations"] and out["correspondences_kept"] == py_info["correspondences_kept"])
+        out["python_cycle_ms"] = py_info.get("cycle_ms")
+    return out
 
 
 def cpu_keyframe(ctx, win, state, prior, poses, sol_gpu, summ_gpu, counts_gpu):

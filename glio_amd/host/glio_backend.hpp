@@ -246,10 +246,37 @@ public:
         check(glio_associate_window(ctx_, q2.data(), t2.data(), counts.data()), "glio_associate_window");
         return counts;
     }
+    // the same without waiting: the searches are enqueued and the call returns -- the caller fills the window's factor tables (setImuFactors, setGnss)
+    // while the GPU searches; windowCounts() (or the next solve) waits and returns the per-slot correspondence counts
+    void findCorrespondingSurfFeaturesWindowAsync() {
+        if (!mapLargeEnough()) {
+            for (int s = 0; s < W_; ++s) check(glio_select_correspondences(ctx_, s, nullptr, 0), "glio_select_correspondences");
+            return;
+        }
+        std::vector<double> q2(4 * W_), t2(3 * W_);
+        for (int s = 0; s < W_; ++s) lidarPose(s, &q2[4 * s], &t2[3 * s]);
+        check(glio_associate_window_async(ctx_, q2.data(), t2.data()), "glio_associate_window_async");
+    }
+    std::vector<int32_t> windowCounts() {
+        std::vector<int32_t> counts(W_, 0);
+        if (mapLargeEnough()) check(glio_associate_window_counts(ctx_, counts.data()), "glio_associate_window_counts");
+        return counts;
+    }
+    // the keyframe cloud that setScan() just put into window slot `scan_slot` goes into the local map from device memory (no second upload):
+    // body point = scan point - lidar_offset; then the ring map and its search structure are rebuilt
+    int pushScanAndBuildLocalMap(int scan_slot, const float lidar_offset[3], const double q[4], const double t[3]) {
+        check(glio_localmap_push_scan(ctx_, scan_slot, lidar_offset, q, t), "glio_localmap_push_scan");
+        int pts = 0;
+        check(glio_localmap_build(ctx_, &pts), "glio_localmap_build");
+        map_points_ = pts;
+        return pts;
+    }
     // Estimator.cpp:2462-2607 with the result kept resident as the prior of the next window (no J0 read-back)
-    void marginalizeAndKeep() {
+    // (rcv_ddt: the clock-drift slots of the solved state when the window carries Doppler factors -- the state handed over must be the solve's)
+    void marginalizeAndKeep(std::vector<double>* rcv_ddt = nullptr) {
         glio_state st;
-        st.trans = tmpTrans.data(); st.quat = tmpQuat.data(); st.speed_bias = tmpSpeedBias.data(); st.rcv_ddt = nullptr; st.n_ddt = 0;
+        st.trans = tmpTrans.data(); st.quat = tmpQuat.data(); st.speed_bias = tmpSpeedBias.data();
+        st.rcv_ddt = rcv_ddt && !rcv_ddt->empty() ? rcv_ddt->data() : nullptr; st.n_ddt = rcv_ddt ? (int)rcv_ddt->size() : 0;
         check(glio_marginalize_keep(ctx_, &st), "glio_marginalize_keep");
     }
     // buildLocalMapWithLandMark + downSampleCloud (Estimator.cpp:3529-3631) on the device: push the new keyframe's cloud

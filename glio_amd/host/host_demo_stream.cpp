@@ -1,0 +1,101 @@
+// host_demo_stream.cpp -- the MOVING-STREAM keyframe cycle of optimizeSlidingWindowWithLandMark() (Estimator.cpp:2046-2736, called per keyframe from
+// saveKeyFramesAndFactors, :4269) driven from C++ through glio_backend.hpp, and TIMED: slide the window + take the new keyframe's scan, update the
+// 50-keyframe local map on the device, associate all W slots (enqueued), fill the IMU / GNSS factor tables while the GPU searches, solve, marginalize the
+// oldest keyframe and keep the result as the next prior.  Input: a flat binary stream file written by glio_amd/host/window_io.py (write_stream); output:
+// one JSON line with the per-stage host times -- what bench.py reports as keyframe_pipeline_cpp next to the Python driver's figure.
+// Build: g++ -std=c++17 -O2 host_demo_stream.cpp -I../../include -L../lib -lglio_hip -Wl,-rpath,'$ORIGIN/../lib'
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "glio_backend.hpp"
+
+template <typename T> static void rd(FILE* f, T* p, size_t n) { if (n && fread(p, sizeof(T), n, f) != n) { fprintf(stderr, "short read\n"); exit(2); } }
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main(int argc, char** argv) {
+    if (argc < 2) { fprintf(stderr, "usage: host_demo_stream stream.bin [device]\n"); return 2; }
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) { perror("open"); return 2; }
+    const int device = argc > 2 ? atoi(argv[2]) : 0;
+    glio_opts opts;
+    rd(f, &opts, 1);
+    int32_t hdr[4];            // n_keyframes (timed; one more runs first as the warm-up), points per scan, local-map width, reserved
+    rd(f, hdr, 4);
+    float leaf, tlb[3];
+    rd(f, &leaf, 1); rd(f, tlb, 3);
+    const int W = opts.window, NK = hdr[0], pts = hdr[1], total_kf = W + NK;
+    std::vector<std::vector<float>> scans(total_kf, std::vector<float>((size_t)pts * 4));
+    std::vector<double> gtq((size_t)total_kf * 4), gtt((size_t)total_kf * 3);
+    for (int j = 0; j < total_kf; ++j) rd(f, scans[j].data(), scans[j].size());
+    rd(f, gtq.data(), gtq.size()); rd(f, gtt.data(), gtt.size());
+    struct Kf { std::vector<double> trans, quat, sb, ddt; std::vector<glio_preint> pre; glio_gnss_frame frame; std::vector<glio_dd_psr> dd; std::vector<glio_doppler> dop; };
+    std::vector<Kf> kf(NK + 1);
+    for (Kf& k : kf) {
+        int32_t n[4];          // n_ddt, n_preint, n_dd, n_dop
+        rd(f, n, 4);
+        k.trans.resize(3 * W); k.quat.resize(4 * W); k.sb.resize(9 * W); k.ddt.resize(n[0]); k.pre.resize(n[1]); k.dd.resize(n[2]); k.dop.resize(n[3]);
+        rd(f, k.trans.data(), k.trans.size()); rd(f, k.quat.data(), k.quat.size()); rd(f, k.sb.data(), k.sb.size()); rd(f, k.ddt.data(), k.ddt.size());
+        rd(f, k.pre.data(), k.pre.size()); rd(f, &k.frame, 1); rd(f, k.dd.data(), k.dd.size()); rd(f, k.dop.data(), k.dop.size());
+    }
+    fclose(f);
+    try {
+        glio::SlidingWindowBackend be(opts, device);
+        be.configureLocalMap(hdr[2], leaf, pts);
+        // the map before the first timed keyframe: the window's own earlier keyframes (body-frame clouds); slots 1..W-1 hold their scans
+        std::vector<float> body((size_t)pts * 4);
+        for (int j = 0; j < W - 1; ++j) {
+            body = scans[j];
+            for (int i = 0; i < pts; ++i) for (int c = 0; c < 3; ++c) body[4 * (size_t)i + c] -= tlb[c];
+            glio::check(glio_localmap_push(be.ctx(), body.data(), pts, &gtq[4 * j], &gtt[3 * j]), "glio_localmap_push");
+        }
+        for (int s = 0; s < W - 1; ++s) be.setScan(s + 1, scans[s].data(), pts);
+        { glio_prior none; memset(&none, 0, sizeof none); be.setMarginalizationPrior(&none); }      // the first window has no prior
+        double st[6] = {0, 0, 0, 0, 0, 0}, cyc = 0, cmin = 1e9, cmax = 0;
+        std::vector<int> iters; std::vector<long> kept;
+        double checksum = 0;
+        int map_pts = 0;
+        for (int j = 0; j <= NK; ++j) {
+            const Kf& k = kf[j];
+            const int nw = j + W - 1;                                   // the keyframe that enters the window
+            if (j == 0) { be.tmpTrans = k.trans; be.tmpQuat = k.quat; be.tmpSpeedBias = k.sb; }
+            else be.slideState(&k.trans[3 * (W - 1)], &k.quat[4 * (W - 1)], &k.sb[9 * (W - 1)]);      // previous solution shifted + the new keyframe's prediction
+            std::vector<double> ddt = k.ddt;
+            const double t0 = now_s();
+            be.slideWindow(); be.setScan(W - 1, scans[nw].data(), pts);
+            const double t1 = now_s();
+            map_pts = be.pushScanAndBuildLocalMap(W - 1, tlb, &gtq[4 * nw], &gtt[3 * nw]);
+            const double t2 = now_s();
+            be.findCorrespondingSurfFeaturesWindowAsync();
+            const double t3 = now_s();
+            be.setImuFactors(k.pre); be.setGnss(&k.frame, k.dd, k.dop);
+            const std::vector<int32_t> counts = be.windowCounts();
+            const double t4 = now_s();
+            const glio_summary sum = be.solve(&ddt);
+            const double t5 = now_s();
+            be.marginalizeAndKeep(&ddt);
+            const double t6 = now_s();
+            if (j == 0) continue;                                        // no prior yet, every first-touch cost: warm-up
+            const double d[6] = {t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5};
+            double c = 0;
+            for (int q = 0; q < 6; ++q) { st[q] += d[q] / NK; c += d[q]; }
+            cyc += c / NK; if (c < cmin) cmin = c; if (c > cmax) cmax = c;
+            iters.push_back(sum.iterations);
+            long kk = 0; for (int32_t v : counts) kk += v; kept.push_back(kk);
+            for (double v : be.tmpTrans) checksum += v;
+        }
+        printf("{\"stages_ms\": {\"slide_and_new_scan\": %.4f, \"local_map\": %.4f, \"associate_enqueue\": %.4f, \"factors_while_the_gpu_searches_then_wait\": %.4f, "
+               "\"solve\": %.4f, \"marginalize\": %.4f}, \"cycle_ms\": %.4f, \"cycle_ms_min_max\": [%.4f, %.4f], \"keyframes_per_s\": %.1f, \"map_points\": %d, \"iterations\": [",
+               st[0] * 1e3, st[1] * 1e3, st[2] * 1e3, st[3] * 1e3, st[4] * 1e3, st[5] * 1e3, cyc * 1e3, cmin * 1e3, cmax * 1e3, 1.0 / cyc, map_pts);
+        for (size_t i = 0; i < iters.size(); ++i) printf("%s%d", i ? ", " : "", iters[i]);
+        printf("], \"correspondences_kept\": [");
+        for (size_t i = 0; i < kept.size(); ++i) printf("%s%ld", i ? ", " : "", kept[i]);
+        printf("], \"trans_checksum\": %.17g}\n", checksum);
+    } catch (const std::exception& e) {
+        fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

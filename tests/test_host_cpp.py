@@ -120,3 +120,53 @@ def test_cpp_full_batch_problem_rounds_match_python(tmp_path):
     assert int(info["allreduces"]) == 0          # one rank: the library calls no collective at all (the hook is for world > 1)
     assert np.abs(rows - poses).max() < 1e-12
     st.close()
+
+
+@pytest.mark.gpu
+def test_cpp_keyframe_stream_equals_the_python_driver(tmp_path):
+    """host_demo_stream (C++17 over glio_backend.hpp): the moving-stream keyframe cycle -- slide, new scan, local map from the resident scan, asynchronous
+    window association, factor tables, solve, marginalize-and-keep -- gives the same iterations, the same kept correspondences and the same solved
+    translations as the Python driver of the same C entry points (same library, same inputs)."""
+    import numpy as np
+    from glio_amd import capi, synth
+    from glio_amd.capi import lidar_pose
+    from glio_amd.host import window_io
+    W, pts, NK = 5, 4096, 3
+    long = synth.make_window(W=W + NK, pts_per_scan=pts, with_gnss=True, with_prior=False, seed=synth.SEED_BASE + 21)
+    wins = [synth.sub_window(long, j, W) for j in range(NK + 1)]
+    opts = wins[0].opts
+    opts.max_ddt_epochs = max(w.init.n_ddt for w in wins) + 8
+    opts.max_map_points = 1 << 16
+    path = str(tmp_path / "stream.bin")
+    window_io.write_stream(path, long, wins, W, NK, pts)
+    got = window_io.run_demo_stream(path)
+    ctx = capi.Context(opts)
+    ctx.localmap_config(50, 0.4, pts)
+    tlb = np.array(opts.t_lb, np.float32)
+    for j in range(W - 1):
+        c = long.scans[j].copy(); c[:, :3] -= tlb
+        ctx.localmap_push(np.ascontiguousarray(c), long.gt.quat[j], long.gt.trans[j])
+    for s in range(W - 1):
+        ctx.set_scan(s + 1, long.scans[s])
+    ctx.set_prior(None)
+    iters, kept, checksum = [], [], 0.0
+    sol = None
+    for j in range(NK + 1):
+        win = wins[j]
+        state = win.init.copy()
+        if j > 0:
+            state.trans[:-1], state.quat[:-1], state.speed_bias[:-1] = sol.trans[1:], sol.quat[1:], sol.speed_bias[1:]
+        new = j + W - 1
+        ctx.slide_window(); ctx.set_scan(W - 1, long.scans[new])
+        ctx.localmap_push_scan(W - 1, tlb, long.gt.quat[new], long.gt.trans[new]); ctx.localmap_build()
+        poses = [lidar_pose(opts, state.quat[s], state.trans[s]) for s in range(W)]
+        ctx.associate_window_async(np.array([p[0] for p in poses]), np.array([p[1] for p in poses]))
+        ctx.set_imu(win.preints); ctx.set_gnss(win.frame, win.dd, win.dop)
+        counts = ctx.associate_window_counts()
+        sol, summ = ctx.solve(state)
+        ctx.marginalize_keep(sol)
+        if j > 0:
+            iters.append(int(summ.iterations)); kept.append(int(np.sum(counts))); checksum += float(np.sum(sol.trans))
+    ctx.close()
+    assert got["iterations"] == iters and got["correspondences_kept"] == kept
+    assert abs(got["trans_checksum"] - checksum) <= 1e-9 * abs(checksum)
