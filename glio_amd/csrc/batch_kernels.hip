@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_batch_pairs(const float4* __restrict__ 
     double acc[64];
 #pragma unroll
     for (int k = 0; k < 64; ++k) acc[k] = 0.0;
-    const long long beg = pair_off[p], end = pair_off[p + 1];
+    const long long beg = pair_off[2 * p], end = pair_off[2 * p + 1];      // [begin, end) of the pair's records: pairs need not be adjacent in memory
     // software pipeline: the next constraint's 72 bytes are requested before the present one's ~160 multiply-adds are issued
     long long i = beg + lane;
     float4 pt_n = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void k_batch_moments(const float4* __restrict_
     double acc[128];
 #pragma unroll
     for (int k = 0; k < 128; ++k) acc[k] = 0.0;
-    const long long beg = pair_off[p], end = pair_off[p + 1];
+    const long long beg = pair_off[2 * p], end = pair_off[2 * p + 1];      // [begin, end) of the pair's records: pairs need not be adjacent in memory
     long long i = beg + lane;
     float4 pt_n = make_float4(0.f, 0.f, 0.f, 0.f);
     double2 n01_n = make_double2(0.0, 0.0), n2c0_n = n01_n, c12_n = n01_n;
@@ -704,7 +704,7 @@ int glio_batch_create(int device, int K, int band, int64_t max_constraints, glio
     b->max_pairs = K * 2 * band;
     GLIO_HIP_CHECK(hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
     b->stream = b->own_stream;
-    BALLOC(b->d_pair_i, b->max_pairs * 4); BALLOC(b->d_pair_j, b->max_pairs * 4); BALLOC(b->d_pair_off, (size_t)(b->max_pairs + 1) * 8);
+    BALLOC(b->d_pair_i, b->max_pairs * 4); BALLOC(b->d_pair_j, b->max_pairs * 4); BALLOC(b->d_pair_off, (size_t)(b->max_pairs + 1) * 16);
     BALLOC(b->d_pair_rec, (size_t)b->max_pairs * (BP_REC + 1) * 8);
     BALLOC(b->d_pair_index, (size_t)K * (2 * band + 1) * 4);
     BALLOC(b->d_poses, (size_t)K * 7 * 8); BALLOC(b->d_newposes, (size_t)K * 7 * 8);
@@ -774,7 +774,9 @@ static int build_pairs(glio_batch* b, int64_t n, const int32_t* ci, const int32_
         GLIO_HIP_CHECK(hipMemcpy(b->d_pair_i, pi.data(), pi.size() * 4, hipMemcpyHostToDevice));
         GLIO_HIP_CHECK(hipMemcpy(b->d_pair_j, pj.data(), pj.size() * 4, hipMemcpyHostToDevice));
     }
-    GLIO_HIP_CHECK(hipMemcpy(b->d_pair_off, off.data(), off.size() * 8, hipMemcpyHostToDevice));
+    std::vector<long long> be(2 * pi.size() + 2, 0);
+    for (size_t q = 0; q < pi.size(); ++q) { be[2 * q] = off[q]; be[2 * q + 1] = off[q + 1]; }
+    GLIO_HIP_CHECK(hipMemcpy(b->d_pair_off, be.data(), be.size() * 8, hipMemcpyHostToDevice));
     GLIO_HIP_CHECK(hipMemcpy(b->d_pair_index, index.data(), index.size() * 4, hipMemcpyHostToDevice));
     b->n_con = n;
     return GLIO_OK;
@@ -803,6 +805,13 @@ int glio_batch_set_constraints_pairs_dev(glio_batch* b, int n_pairs, const int32
 // only.  Falls back to "everything changed" when the list of non-empty pairs is not the previous one.
 int glio_batch_update_constraints_pairs_dev(glio_batch* b, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj, const int64_t* pair_count,
                                             const float* cp_dev, const double* nc_dev, const double* score_dev, const uint8_t* pair_changed) {
+    return glio_batch_update_constraints_pairs_at_dev(b, n_pairs, pair_ci, pair_cj, pair_count, nullptr, cp_dev, nc_dev, score_dev, pair_changed);
+}
+// the same with the record range of every pair given explicitly: pair p's records are [pair_offset[p], pair_offset[p] + pair_count[p]) of the three
+// arrays (NULL: the pairs follow each other).  For a caller that keeps the stored interior constraints in place and rewrites only the regions of the
+// re-searched end keyframes (whose counts change from round to round) instead of re-packing tens of gigabytes every round.
+int glio_batch_update_constraints_pairs_at_dev(glio_batch* b, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj, const int64_t* pair_count,
+                                               const int64_t* pair_offset, const float* cp_dev, const double* nc_dev, const double* score_dev, const uint8_t* pair_changed) {
     if (!b || n_pairs < 0 || (n_pairs > 0 && (!pair_ci || !pair_cj || !pair_count || !cp_dev || !nc_dev || !score_dev))) return GLIO_E_ARG;
     GLIO_HIP_CHECK(hipSetDevice(b->device));
     const int K = b->K, band = b->band, wdt = 2 * band + 1;
@@ -813,14 +822,16 @@ int glio_batch_update_constraints_pairs_dev(glio_batch* b, int n_pairs, const in
         const int a = pair_ci[p], c = pair_cj[p];
         if (a < 0 || a >= K || c < 0 || c >= K || a == c || std::abs(a - c) > band || pair_count[p] < 0) { glio_set_error("pair %d: keyframes (%d,%d) outside band %d", p, a, c, band); return GLIO_E_ARG; }
         if (p > 0 && (a < pair_ci[p - 1] || (a == pair_ci[p - 1] && c <= pair_cj[p - 1]))) { glio_set_error("pairs must be sorted by (ci, cj)"); return GLIO_E_ARG; }
+        if (pair_offset && pair_offset[p] < 0) { glio_set_error("pair %d: negative record offset", p); return GLIO_E_ARG; }
         if (pair_count[p] > 0) {
             index[(size_t)a * wdt + (c - a) + band] = (int)pi.size();
             if (!pair_changed || pair_changed[p]) changed_slots.push_back((int)pi.size());
-            pi.push_back(a); pj.push_back(c); off.push_back(run);
+            pi.push_back(a); pj.push_back(c);
+            const long long beg = pair_offset ? (long long)pair_offset[p] : run;
+            off.push_back(beg); off.push_back(beg + (long long)pair_count[p]);
         }
         run += pair_count[p];
     }
-    off.push_back(run);
     if ((int)pi.size() > b->max_pairs) return GLIO_E_ARG;
     b->src_min = pi.empty() ? 0 : pi.front(); b->src_max = pi.empty() ? -1 : pi.back();      // (sorted by ci)
     {   // do the moment records of the unmarked pairs still stand?  only when the list of non-empty pairs is the one they were taken for
@@ -851,6 +862,7 @@ int glio_batch_update_constraints_pairs_dev(glio_batch* b, int n_pairs, const in
         GLIO_HIP_CHECK(hipMemcpy(b->d_pair_i, pi.data(), pi.size() * 4, hipMemcpyHostToDevice));
         GLIO_HIP_CHECK(hipMemcpy(b->d_pair_j, pj.data(), pj.size() * 4, hipMemcpyHostToDevice));
     }
+    off.push_back(0); off.push_back(0);
     GLIO_HIP_CHECK(hipMemcpy(b->d_pair_off, off.data(), off.size() * 8, hipMemcpyHostToDevice));
     GLIO_HIP_CHECK(hipMemcpy(b->d_pair_index, index.data(), index.size() * 4, hipMemcpyHostToDevice));
     b->n_con = run;

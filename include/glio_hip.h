@@ -206,6 +206,10 @@ int glio_batch_set_constraints_pairs_dev(glio_batch* b, int n_pairs, const int32
  * (Estimator.cpp:3018-3030); the next solve then reads the constraints of the marked pairs only (glio_batch_solve_tr2). */
 int glio_batch_update_constraints_pairs_dev(glio_batch* b, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj, const int64_t* pair_count,
                                             const float* cp_dev, const double* nc_dev, const double* score_dev, const uint8_t* pair_changed);
+/* the same with every pair's record range given explicitly: [pair_offset[p], pair_offset[p] + pair_count[p]) (NULL = the pairs follow each other).  The caller
+ * of the outer rounds keeps the stored interior constraints where they are and rewrites only the regions of the re-searched end keyframes. */
+int glio_batch_update_constraints_pairs_at_dev(glio_batch* b, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj, const int64_t* pair_count,
+                                               const int64_t* pair_offset, const float* cp_dev, const double* nc_dev, const double* score_dev, const uint8_t* pair_changed);
 /* poses [K][7] = (t, q) host; Hg_dev device buffer of glio_batch_hg_size doubles (overwritten) */
 int glio_batch_linearize_dev(glio_batch* b, const double* poses, double* Hg_dev);
 /* damped Gauss-Newton step from a (reduced) Hg: solves (H + lambda diag(H)) d = -g with a block-banded Cholesky on
