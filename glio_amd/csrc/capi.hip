@@ -175,7 +175,11 @@ static int create_body(int device, const glio_opts* opts, glio_ctx* c) {
     for (int k = 0; k < 15 * W; ++k) c->h_prior_index[k] = -1;
     c->chain_tabs_dirty = 1;
     c->k3_bpk = GLIO_K3_BLOCKS_PER_KF; c->last_k3_nb = c->k3_bpk; c->merged_linearize = 2; c->want_pair_H = 1; c->k3_unroll = 22;   /* 2-deep batches, non-temporal loads, next batch issued before the arithmetic of the current one */
-    { int per = 768 / W;   /* ~3 workgroups per CU measured best on MI355X (scripts/k3_sweep.py) */ if (per < 8) per = 8; if (per > GLIO_K3_MAX_BLOCKS_PER_KF) per = GLIO_K3_MAX_BLOCKS_PER_KF; c->k3_bpk = per; }
+    { int per = 768 / W;   /* ~3 workgroups per CU measured best on MI355X (scripts/k3_sweep.py) */
+      // the fp32 / MFMA form keeps two chunks (four 16-byte loads per lane) in flight per wavefront and wants ~8x as many of them resident: at the C5
+      // shape 120 workgroups per keyframe measured best (8 / 15 / 30 / 60 / 120 / 240: 96.7 / 91.8 / 88.8 / 82.1 / 76.8 / 80.2 us, scripts/c5_launch.py --sweep)
+      if (opts->lidar_precision == GLIO_LIDAR_F32_MFMA) per = 6000 / W;
+      if (per < 8) per = 8; if (per > GLIO_K3_MAX_BLOCKS_PER_KF) per = GLIO_K3_MAX_BLOCKS_PER_KF; c->k3_bpk = per; }
     ALLOC(c->d_lidar_blocks, 2 * (size_t)W * GLIO_LIDAR_ACC * 8);
     ALLOC(c->d_L, (size_t)(n_max + 1) * n_max * 8);
     c->vstride = (n_max + 15) & ~15;

@@ -253,16 +253,8 @@ __device__ __forceinline__ void k3_body_f32(
     double cost = 0.0;
     const double a = lc.huber;
     const float af = (float)a;
-    int ch = wid;
-    bool have = ch < nchunks;
-    float4 p = make_float4(0, 0, 0, 0), pl = p;
-    if (have) { const int i0 = min(ch * 64 + lane, n - 1); p = k3_load4<NT>(P + i0); pl = k3_load4<NT>(Q + i0); }
-    while (have) {
-        const int chn = ch + nwaves;
-        const bool more = chn < nchunks;
-        float4 p2 = p, pl2 = pl;
-        if (more) { const int i1 = min(chn * 64 + lane, n - 1); p2 = k3_load4<NT>(P + i1); pl2 = k3_load4<NT>(Q + i1); }   // next chunk in flight during the arithmetic
-        const bool live = ch * 64 + lane < n;
+    // One chunk: residual in double, Jacobian row in float, LDS transpose, eight MFMAs, float partials into the double accumulators.
+    auto chunk = [&](const float4 p, const float4 pl, const bool live) {
         // ---- residual in double
         const double cx = (double)p.x - lc.tlb[0], cy = (double)p.y - lc.tlb[1], cz = (double)p.z - lc.tlb[2];
         const double rx = M[0] * cx + M[1] * cy + M[2] * cz;
@@ -289,6 +281,7 @@ __device__ __forceinline__ void k3_body_f32(
         T[6 * 64 + lane] = sw * rf;
         GLIO_WAVE_LDS_SYNC();
         const k3_v4f32 a0 = *reinterpret_cast<const k3_v4f32*>(rd), a1 = *reinterpret_cast<const k3_v4f32*>(rd + 4);
+        GLIO_WAVE_LDS_SYNC();                              // the tile is in registers: the next chunk may overwrite it
         k3_v4f32 c0 = {0.0f, 0.0f, 0.0f, 0.0f}, c1 = {0.0f, 0.0f, 0.0f, 0.0f};
         c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, a0.x, c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, a0.y, c1, 0, 0, 0);
@@ -300,8 +293,24 @@ __device__ __forceinline__ void k3_body_f32(
         c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, a1.w, c1, 0, 0, 0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc64[k] += (double)c0[k] + (double)c1[k];
-        GLIO_WAVE_LDS_SYNC();                              // the tile is in registers: the next chunk may overwrite it
-        ch = chn; p = p2; pl = pl2; have = more;
+    };
+    // Two chunks per trip, and the loads of the NEXT two chunks (four 16-byte loads per lane) issued before this trip's arithmetic: with one chunk
+    // ahead a wavefront had 2 KB of the stream in flight, a CU ~57 KB -- a third of what the fp64 kernel keeps in flight, and the 32 B / residual
+    // form lost the bandwidth race it exists to win (r03: 101 us vs 90 us at the C5 shape).
+    int ch = wid;
+    float4 pA = make_float4(0, 0, 0, 0), plA = pA, pB = pA, plB = pA;
+    bool haveA = ch < nchunks, haveB = ch + nwaves < nchunks;
+    if (haveA) { const int i0 = min(ch * 64 + lane, n - 1); pA = k3_load4<NT>(P + i0); plA = k3_load4<NT>(Q + i0); }
+    if (haveB) { const int i0 = min((ch + nwaves) * 64 + lane, n - 1); pB = k3_load4<NT>(P + i0); plB = k3_load4<NT>(Q + i0); }
+    while (haveA) {
+        const int chA2 = ch + 2 * nwaves, chB2 = ch + 3 * nwaves;
+        const bool moreA = chA2 < nchunks, moreB = chB2 < nchunks;
+        float4 pA2 = pA, plA2 = plA, pB2 = pB, plB2 = plB;
+        if (moreA) { const int i1 = min(chA2 * 64 + lane, n - 1); pA2 = k3_load4<NT>(P + i1); plA2 = k3_load4<NT>(Q + i1); }
+        if (moreB) { const int i1 = min(chB2 * 64 + lane, n - 1); pB2 = k3_load4<NT>(P + i1); plB2 = k3_load4<NT>(Q + i1); }
+        chunk(pA, plA, ch * 64 + lane < n);
+        if (haveB) chunk(pB, plB, (ch + nwaves) * 64 + lane < n);
+        ch = chA2; pA = pA2; plA = plA2; pB = pB2; plB = plB2; haveA = moreA; haveB = moreB;
     }
     // ---- C layout: lane l, register k -> row 4 (l >> 4) + k, column l & 15.  Block 0 = rows, columns 0..7 (lanes with
     // l >> 4 < 2, l & 15 < 8), block 1 = rows, columns 8..15 = the same entries 40 lanes further on.
