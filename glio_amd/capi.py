@@ -94,6 +94,10 @@ class Context:
         off = np.ascontiguousarray(lidar_offset, np.float32); q = np.ascontiguousarray(q, np.float64); t = np.ascontiguousarray(t, np.float64)
         _check(load().glio_localmap_push_scan(self._h, int(scan_slot), T.fptr(off), T.dptr(q), T.dptr(t)))
 
+    def localmap_set_accumulation(self, mode):
+        """0: exact fixed-point voxel sums (default); 1: pcl::VoxelGrid's float sums in concatenation order (bit-identical to the oracle's map)"""
+        _check(load().glio_localmap_set_accumulation(self._h, int(mode)))
+
     def localmap_build(self):
         n = C.c_int()
         _check(load().glio_localmap_build(self._h, C.byref(n)))

@@ -45,6 +45,11 @@ struct LocalMap {
     float4* d_out;                  // [max voxels] down-sampled map, ordered by voxel index
     int max_vox;
     int* h_pin;                     // pinned scalar read-back
+    // accumulation = 1 (glio_localmap_set_accumulation): centroids as pcl::VoxelGrid forms them -- FLOAT sums over a voxel's points in the order of the
+    // concatenated cloud (keyframes oldest first, points in scan order: the order a stable sort by voxel index leaves, and what the oracle's restatement
+    // does) -- instead of the exact fixed-point sums.  Same voxels, same output order; the centroids then equal the oracle's bit for bit.
+    int accumulation;
+    int* d_fill; int* d_slot_start; int* d_plist;      // [table_cap], [table_cap], [width * cap]: per-voxel fill counters, list starts, point lists
 };
 
 #define LM_EMPTY (~0ull)
@@ -267,13 +272,66 @@ __global__ void k_lm_emit(const int* __restrict__ vslot_sorted, int nv, const lo
                          (float)((double)sum[4 * (size_t)s + 2] / LM_FIX / c), (float)((double)sum[4 * (size_t)s + 3] / LM_FIX / c));
 }
 
+// ---- float accumulation in concatenation order (accumulation = 1)
+// exclusive scan of the live voxels' counts in OUTPUT order -> where each voxel's point list starts (one workgroup: a contiguous chunk per thread)
+__global__ __launch_bounds__(1024) void k_lm_starts(const int* __restrict__ vslot_sorted, const int nv, const int* __restrict__ cnt, int* __restrict__ slot_start) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x, chunk = (nv + 1023) / 1024, v0 = tid * chunk, v1 = min(nv, v0 + chunk);
+    int sum = 0;
+    for (int v = v0; v < v1; ++v) sum += cnt[vslot_sorted[v]];
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int k = 0; k < 1024; ++k) { const int x = part[k]; part[k] = t; t += x; } }
+    __syncthreads();
+    int run = part[tid];
+    for (int v = v0; v < v1; ++v) { const int sl = vslot_sorted[v]; slot_start[sl] = run; run += cnt[sl]; }
+}
+// every ring point -> its voxel's list (arbitrary position; the entry is the point's index in the concatenated cloud: age * cap + j)
+__global__ void k_lm_scatter_idx(const float4* __restrict__ ring, const int* __restrict__ ns, const int cap, const int width, const int head, const int count,
+                                 const float inv_leaf, const unsigned long long* __restrict__ keys, const int table_cap, const int* __restrict__ slot_start,
+                                 int* __restrict__ fill, int* __restrict__ plist) {
+    const int slot = blockIdx.y, age = (slot - head + width) % width;
+    if (age >= count) return;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ns[slot]) return;
+    const float4 p = ring[(size_t)slot * cap + j];
+    const unsigned long long key = lm_key((int)floorf(p.x * inv_leaf), (int)floorf(p.y * inv_leaf), (int)floorf(p.z * inv_leaf));
+    unsigned s = lm_hash(key) & (table_cap - 1);
+    while (keys[s] != key) s = (s + 1) & (table_cap - 1);              // (every ring point's voxel is in the table)
+    const int pos = atomicAdd(fill + s, 1);
+    plist[slot_start[s] + pos] = age * cap + j;
+}
+// one thread per voxel: its list sorted by concatenated index (insertion sort in the thread's own segment: a voxel holds tens of points), then the
+// float sums in that order and the centroid = sum / (float) count, as pcl::VoxelGrid
+__global__ void k_lm_emit_float(const int* __restrict__ vslot_sorted, const int nv, const int* __restrict__ cnt, const int* __restrict__ slot_start,
+                                int* __restrict__ plist, const float4* __restrict__ ring, const int cap, const int width, const int head, float4* __restrict__ out) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv) return;
+    const int s = vslot_sorted[v], n = cnt[s];
+    int* L = plist + slot_start[s];
+    for (int a = 1; a < n; ++a) {
+        const int x = L[a];
+        int b = a - 1;
+        while (b >= 0 && L[b] > x) { L[b + 1] = L[b]; --b; }
+        L[b + 1] = x;
+    }
+    float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f;
+    for (int a = 0; a < n; ++a) {
+        const int idx = L[a], age = idx / cap, j = idx - age * cap;
+        const float4 p = ring[(size_t)((head + age) % width) * cap + j];
+        ax += p.x; ay += p.y; az += p.z; aw += p.w;
+    }
+    const float c = (float)n;
+    out[v] = make_float4(ax / c, ay / c, az / c, aw / c);
+}
+
 #define LM_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { glio_set_error("%s failed: %s", #expr, hipGetErrorString(e_)); return GLIO_E_HIP; } } while (0)
 static int lm_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 void glio_localmap_destroy(glio_ctx* c) {
     LocalMap* m = c->localmap;
     if (!m) return;
-    void* p[] = {m->d_slot_bbox, m->d_nkeys, m->d_n, m->d_ring, m->d_keys, m->d_sum, m->d_cnt, m->d_bbox, m->d_nvox, m->d_vkey, m->d_vkey_sorted, m->d_vslot, m->d_vslot_sorted, m->d_sort_tmp, m->d_out};
+    void* p[] = {m->d_slot_bbox, m->d_nkeys, m->d_n, m->d_ring, m->d_keys, m->d_sum, m->d_cnt, m->d_bbox, m->d_nvox, m->d_vkey, m->d_vkey_sorted, m->d_vslot, m->d_vslot_sorted, m->d_sort_tmp, m->d_out, m->d_fill, m->d_slot_start, m->d_plist};
     for (void* q : p) if (q) hipFree(q);
     if (m->h_pin) hipHostFree(m->h_pin);
     delete[] m->h_n;
@@ -422,12 +480,35 @@ int glio_localmap_build(glio_ctx* c, int* out_points) {
             std::swap(ka, kb); std::swap(va, vb);
         }
         LM_CHECK(hipGetLastError());
+        if (m->accumulation == 1) {
+            hipLaunchKernelGGL(k_lm_starts, dim3(1), dim3(1024), 0, c->stream, va, nv, m->d_cnt, m->d_slot_start);
+            LM_CHECK(hipMemsetAsync(m->d_fill, 0, (size_t)m->table_cap * 4, c->stream));
+            hipLaunchKernelGGL(k_lm_scatter_idx, dim3((m->cap + 255) / 256, m->width), dim3(256), 0, c->stream, m->d_ring, m->d_n, m->cap, m->width, m->head, m->count,
+                               inv_leaf, m->d_keys, m->table_cap, m->d_slot_start, m->d_fill, m->d_plist);
+            hipLaunchKernelGGL(k_lm_emit_float, dim3((nv + 255) / 256), dim3(256), 0, c->stream, va, nv, m->d_cnt, m->d_slot_start, m->d_plist, m->d_ring, m->cap, m->width,
+                               m->head, m->d_out);
+        } else
         hipLaunchKernelGGL(k_lm_emit, dim3((nv + 255) / 256), dim3(256), 0, c->stream, va, nv, m->d_sum, m->d_cnt, m->d_out);     // (va: the sorted side after the last swap)
     }
     const int rc = glio_assoc_build_map_dev(c, m->d_out, nv);          // K1: replaces setInputCloud(surf_local_map_ds) (:2056)
     if (rc) return rc;
     LM_CHECK(hipStreamSynchronize(c->stream));
     if (out_points) *out_points = nv;
+    return GLIO_OK;
+}
+
+// 0 (default): exact fixed-point voxel sums (insert / evict without re-streaming the ring, bit-reproducible whatever the atomic order);
+// 1: pcl::VoxelGrid's own arithmetic -- float sums over the voxel's points in the order of the concatenated cloud (the oracle's restatement): the centroids
+// then equal the oracle's BIT FOR BIT, at the price of one pass over the ring per build.  For A/B runs of the 1.5e-5 m difference between the two.
+int glio_localmap_set_accumulation(glio_ctx* c, int mode) {
+    if (!c || !c->localmap || (mode != 0 && mode != 1)) { glio_set_error("glio_localmap_config first; mode 0 or 1"); return GLIO_E_ARG; }
+    LocalMap* m = c->localmap;
+    LM_CHECK(hipSetDevice(c->device));
+    if (mode == 1 && !m->d_plist) {
+        LM_CHECK(hipMalloc((void**)&m->d_fill, (size_t)m->table_cap * 4)); LM_CHECK(hipMalloc((void**)&m->d_slot_start, (size_t)m->table_cap * 4));
+        LM_CHECK(hipMalloc((void**)&m->d_plist, (size_t)m->width * m->cap * 4));
+    }
+    m->accumulation = mode;
     return GLIO_OK;
 }
 

@@ -64,6 +64,9 @@ int glio_localmap_push(glio_ctx* ctx, const float* cloud_xyzi, int n, const doub
  * the newest keyframe's cloud crosses PCIe once for both the association and the map */
 int glio_localmap_push_scan(glio_ctx* ctx, int scan_slot, const float lidar_offset[3], const double q[4], const double t[3]);
 int glio_localmap_build(glio_ctx* ctx, int* out_points);
+/* centroid arithmetic of the voxel grid: 0 (default) exact fixed-point sums; 1 = pcl::VoxelGrid's float sums in the order of the concatenated cloud
+ * (Estimator.cpp:3618-3631 through PCL; the oracle's restatement): bit-identical to the oracle's map, one extra pass over the ring per build */
+int glio_localmap_set_accumulation(glio_ctx* ctx, int mode);
 /* test hook: the down-sampled map (surf_local_map_ds), ordered by voxel index */
 int glio_localmap_read(glio_ctx* ctx, float* out_xyzi, int capacity, int* out_n);
 
