@@ -2,7 +2,7 @@
 device's Cholesky root) change an association record with respect to the ORACLE-built state (PCL-style float voxel grid, eigen-root
 prior)?  On the same map the device association is bit-exact (tests/test_hip_assoc.py); here each side builds its own map and its
 own prior chain over a stream of keyframes, and the kept correspondences are compared record by record.
-    python scripts/knife_edge_count.py [keyframes] [points_per_scan] > profiles/r03_knife_edge.json"""
+    [GLIO_LOCALMAP_ACC=1] python scripts/knife_edge_count.py [keyframes] [points_per_scan] > profiles/r04_knife_edge[_float].json"""
 import json
 import os
 import sys
@@ -26,6 +26,8 @@ first = T.WindowState(W)
 first.trans[:], first.quat[:], first.speed_bias[:] = long.init.trans[:W], long.init.quat[:W], long.init.speed_bias[:W]
 ctx = capi.Context(opts)
 ctx.localmap_config(50, 0.4, pts)
+ACC = int(os.environ.get("GLIO_LOCALMAP_ACC", "0"))     # 1: pcl::VoxelGrid's float sums in concatenation order (glio_localmap_set_accumulation)
+ctx.localmap_set_accumulation(ACC)
 po.lib().orc_set_assoc_grid.restype = None
 po.lib().orc_set_assoc_grid(1)          # identical records to the brute force (tests/test_oracle_grid.py), just faster
 orc = OracleBackend(opts)
@@ -77,7 +79,7 @@ for k in range(L - W + 1):
             d.slide(long.init.trans[k + W], long.init.quat[k + W], long.init.speed_bias[k + W])
 po.lib().orc_set_assoc_grid(0)
 ctx.close()
-out = dict(what="device-built map + prior chain vs oracle-built, same stream; association records compared per keyframe", keyframes=len(rows), window=W, points_per_scan=pts,
+out = dict(what="device-built map + prior chain vs oracle-built, same stream; association records compared per keyframe", localmap_accumulation=ACC, keyframes=len(rows), window=W, points_per_scan=pts,
            totals=tot, fraction_of_records_in_one_side_only=(tot["only_dev"] + tot["only_orc"]) / max(1, tot["kept_dev"] + tot["kept_orc"]),
            fraction_of_common_records_with_different_bits=tot["common_differing_bits"] / max(1, tot["common"]),
            max_trans_diff_m=max(r["max_trans_diff_m"] for r in rows), per_keyframe=rows)
