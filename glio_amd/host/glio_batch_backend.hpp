@@ -135,6 +135,12 @@ public:
         check(glio_batch_set_small_factors(h_, frame, (int)dq.i.size(), dq.i.data(), dq.j.data(), dq.const_diff.data(), (int)dd.size(), dd.data()),
               "glio_batch_set_small_factors");
     }
+    // the LidarPoseFactorBatchRelativeAutoDiff blocks of sms_fusion_level == 0 (Estimator.cpp:2897-2955; the released default): keyframes (i[f], j[f]),
+    // const_[7 f ..] = (tmpQuat w,x,y,z, tmpTrans) of :2901-2921.  Call BEFORE setSmallFactors, which builds the factor table.
+    void setRelativePoseFactors(const std::vector<int32_t>& i, const std::vector<int32_t>& j, const std::vector<double>& const_) {
+        check(glio_batch_set_relative_pose_factors(h_, (int)i.size(), i.empty() ? nullptr : i.data(), j.empty() ? nullptr : j.data(), const_.empty() ? nullptr : const_.data()),
+              "glio_batch_set_relative_pose_factors");
+    }
     // this backend is rank `rank` of `world` (call before setSmallFactors): it owns the keyframes of shardRange(); the all-reduce set
     // with setAllReduce is then called five times per trust-region iteration on small device buffers, ordered on stream()
     void setShard(int rank, int world) { check(glio_batch_set_shard(h_, rank, world), "glio_batch_set_shard"); }
