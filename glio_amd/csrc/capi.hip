@@ -1139,6 +1139,7 @@ int glio_debug_set_enqueue_lead(glio_ctx* c, int lead) {
     return GLIO_OK;
 }
 int glio_debug_solver_path(glio_ctx* c) { return c ? c->arrow.last_path : -1; }
+int glio_debug_chain_fronts_used(glio_ctx* c) { return c ? c->arrow.last_fronts : -1; }
 int glio_debug_set_k3(glio_ctx* c, int bpk, int unroll) {
     if (!c || bpk < 1 || bpk > GLIO_K3_MAX_BLOCKS_PER_KF || (unroll != 1 && unroll != 2 && unroll != 4 && unroll != 8 && unroll != 12 && unroll != 14 && unroll != 18 && unroll != 21 && unroll != 22 && unroll != 24 && unroll != 32 && unroll != 33 && unroll != 34 && unroll != 35)) return GLIO_E_ARG;
     c->k3_bpk = bpk; c->k3_unroll = unroll;

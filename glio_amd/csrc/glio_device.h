@@ -122,6 +122,7 @@ struct ArrowDev {
     int gnss_chain, prior_chain;   // stronger: EVERY GNSS pair couples neighbouring keyframes / the prior is block diagonal by keyframe
     int max_epoch;            // largest clock-drift epoch referenced by a Doppler factor (-1: none)
     int last_path;            // factorisation the last trust-region step was enqueued with: 0 dense, 1 arrow, 2 keyframe chain
+    int last_fronts;          // elimination fronts of the last k_chain_step launch (2 or 4), 0 = none yet
     int2* d_ep_slots;         // [n_ddt_max] keyframe slots (lo, hi) coupled by clock-drift epoch e, (-1,-1) if unused
     int* d_ep_off;            // [W+1] CSR over slots: epochs touching slot i
     int* d_ep_list;           // [2 n_ddt_max]

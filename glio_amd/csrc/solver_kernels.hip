@@ -953,8 +953,10 @@ struct ArrowArgs {
 // development aid: wall-clock stamps of the phases of the arrow kernels (build with GLIO_DEV_STAMPS=1, scripts/arrow_time.py)
 #ifdef GLIO_DEV_STAMPS
 #define AR_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) a.dbg[k] = wall_clock64(); } while (0)
+#define WV_STAMP(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) a.dbg[k] = wall_clock64(); } while (0)      /* by the first lane of any wavefront */
 #else
 #define AR_STAMP(k) do { } while (0)
+#define WV_STAMP(k) do { } while (0)
 #endif
 #define AR_LB 190          /* one chain block in LDS / global: 18 rows x stride 10, then 9 reciprocal pivots (+1 pad) */
 #define AR_YS 17           /* row stride of the 16-column Y slices in LDS */
@@ -1408,7 +1410,7 @@ __device__ __forceinline__ double pivot_rsqrt(const double d) {
 
 template <bool DOWN>
 __device__ __forceinline__ void chain_step15(const int i, const int nb, const bool has_nb, double (&av)[KC_NB], double* Blk, double* Cs, const int lane, bool& bad,
-                                             long long* ph = nullptr) {
+                                             long long* ph = nullptr, const double* Nrows = nullptr) {
 #ifdef GLIO_DEV_STAMPS
 #define CS_CLK(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define CS_PH(k) do { long long t_; CS_CLK(t_); if (ph) ph[k] += t_ - tprev; tprev = t_; } while (0)
@@ -1432,7 +1434,7 @@ __device__ __forceinline__ void chain_step15(const int i, const int nb, const bo
 #pragma unroll
         for (int j = 0; j < KC_NB; ++j) nx[j] = Bn[row * KC_RS + j];
 #pragma unroll
-        for (int j = 0; j < KC_NB; ++j) ld[j] = DOWN ? Bn[(KC_NB + j) * KC_RS + (rb - KC_NB)] : Bi[rb * KC_RS + j];
+        for (int j = 0; j < KC_NB; ++j) ld[j] = DOWN ? Bn[(KC_NB + j) * KC_RS + (rb - KC_NB)] : (Nrows ? Nrows[(rb - KC_NB) * KC_RS + j] : Bi[rb * KC_RS + j]);
         const bool keep_nx = has_nb & (lim > 0);
         const bool is_b = (r >= KC_NB) & (r < 30);
 #pragma unroll
@@ -1531,6 +1533,149 @@ __device__ __forceinline__ void chain_prepare_back(double* Bi, const int lane) {
     } else if (lane == KC_NB) {
 #pragma unroll
         for (int r = 0; r < KC_NB; ++r) Bi[30 * KC_RS + r] = m[r];
+    }
+}
+
+// ---- four fronts (k_chain_step, W >= KC_F4_MIN_W).  The middle keyframe s = W / 2 is a separator: the chain falls into a left segment 0 .. s-1
+// and a right segment s+1 .. W-1, and each segment is eliminated from BOTH of its ends at once.  The outer fronts (A: 0 upwards, D: W-1
+// downwards) are the steps above.  The inner fronts start beside the separator (B: s-1 downwards, C: s+1 upwards); eliminating their blocks
+// fills in a coupling E_i = M[s, i] between the separator and the front's current block, which the front carries along as 15 more rows of
+// its panel (lanes 32..46): [D_i; N_i; rhs_i; E_i] is 46 x 15, still one row per lane, the same 15 pivots.  Its Schur complement
+//   [Xn; y; Xe] [Xn; y; Xe]^T  =  three 16 x 16 tiles:   C00 = [Xn; y][Xn; y]^T  -> D and rhs of the next block (as in chain_step15),
+//                                                        C10 = Xe [Xn; y]^T      -> minus the next block's E rows (columns 0..14) and the
+//                                                                                   separator's rhs (column 15, summed over the steps),
+//                                                        C11 = Xe Xe^T           -> the separator's diagonal block, summed over the steps in
+//                                                                                   the accumulator registers of the matrix core.
+// The two fronts of a segment meet at m (mL, mR): the outer wavefront eliminates it with the inner front's last E rows as its coupling
+// rows (chain_step15 with Nrows; its "next" block is the separator).  The separator is factored last, by wavefront 0.  Critical path for
+// W = 20: 5 steps + meeting block + separator instead of 10 steps + middle block.  Every hand-over is a release/acquire pair on an LDS word.
+#define KC_F4_MIN_W 12
+#define KC_ERS 15                      /* row stride of a slot of E rows (odd: the 15 row-lanes hit distinct banks) */
+#define KC_ES (15 * KC_ERS + 1)        /* one slot of E rows: 15 x 15 (+1: the matrix-core operand read of the padded k = 15 stays inside) */
+#define KC_TILE (16 * KC_RS)           /* one 16 x 16 tile of a Schur complement, row stride KC_RS */
+struct ChainSplit { int s, mL, mR, nA, nB, nC, nD; };
+__host__ __device__ __forceinline__ ChainSplit chain_f4_split(const int W) {
+    ChainSplit c;
+    c.s = W / 2;
+    c.nB = 4 * (c.s - 1) / 9;                 // inner fronts take a little less than half: their steps are the heavier ones
+    c.nC = 4 * (W - 1 - c.s - 1) / 9;
+    c.mL = c.s - 1 - c.nB; c.mR = c.s + 1 + c.nC;
+    c.nA = c.mL; c.nD = W - 1 - c.mR;
+    return c;
+}
+// One step of an inner front.  av: lanes 0..14 and 30 as in chain_step15, lanes 32..46 the E rows of block i.  Ei: where the factored E rows
+// (Xe) of block i go; Cs0 / Cs1: this wavefront's scratch tiles for C00 / C10; c11, racc: the separator's sums (see above).
+template <bool DOWN>
+__device__ __forceinline__ void chain_step15e(const int i, const int nb, double (&av)[KC_NB], double* Blk, double* Ei, double* Cs0, double* Cs1, const int cs1_stride,
+                                              const int lane, bool& bad, v4f64& c11, v4f64& racc) {
+    const int r = lane;
+    const int lim = r == 30 ? KC_NB : (r < KC_NB ? r + 1 : 0);
+    const int tri = r < KC_NB ? r + 1 : KC_NB;
+    const bool is_e = (r >= 32) & (r < 32 + KC_NB);
+    double* Bi = Blk + (size_t)i * KC_BLK;
+    double nx[KC_NB];
+    {
+        const double* Bn = Blk + (size_t)nb * KC_BLK;
+        const int row = r < KC_NB ? r : 30;
+        const int rb = (r >= KC_NB && r < 30) ? r : KC_NB;
+        double ld[KC_NB];
+#pragma unroll
+        for (int j = 0; j < KC_NB; ++j) nx[j] = Bn[row * KC_RS + j];
+#pragma unroll
+        for (int j = 0; j < KC_NB; ++j) ld[j] = DOWN ? Bn[(KC_NB + j) * KC_RS + (rb - KC_NB)] : Bi[rb * KC_RS + j];
+        const bool keep_nx = lim > 0;
+        const bool is_b = (r >= KC_NB) & (r < 30);
+#pragma unroll
+        for (int j = 0; j < KC_NB; ++j) nx[j] = keep_nx ? nx[j] : 0.0;
+#pragma unroll
+        for (int j = 0; j < KC_NB; ++j) av[j] = is_b ? ld[j] : av[j];
+    }
+    double rpv = 0.0;
+    double djj = readlane_d(av[0], 0);
+#pragma unroll
+    for (int j = 0; j < KC_NB; ++j) {
+        bad |= !((djj > 0.0) & (djj < 1e300));
+        const double rdj = pivot_rsqrt(djj);
+        if (j + 1 < KC_NB) {
+            const double lnx = readlane_d(av[j], j + 1) * rdj;
+            djj = fma(-lnx, lnx, readlane_d(av[j + 1], j + 1));
+        }
+        const double lij = av[j] * rdj;
+        rpv = lane == j ? rdj : rpv;
+        av[j] = lij;
+#pragma unroll
+        for (int c = j + 1; c < KC_NB; ++c) av[c] -= lij * readlane_d(lij, c);
+    }
+    if (r < 31) {
+#pragma unroll
+        for (int j = 0; j < KC_NB; ++j) Bi[r * KC_RS + j] = j < tri ? av[j] : 0.0;
+        if (r < KC_NB) Bi[31 * KC_RS + r] = rpv;
+    } else if (is_e) {
+#pragma unroll
+        for (int j = 0; j < KC_NB; ++j) Ei[(r - 32) * KC_ERS + j] = av[j];
+    }
+    GLIO_WAVE_LDS_SYNC();
+    {
+        const int xi = lane & 15, xg = lane >> 4;
+        const double* x0row = Bi + (KC_NB + xi) * KC_RS + xg;
+        const double* x1row = Ei + (xi < KC_NB ? xi : 0) * KC_ERS + xg;
+        double x0[4], x1[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) { x0[kb] = x0row[4 * kb]; x1[kb] = x1row[4 * kb]; }
+        x0[3] = xg == 3 ? 0.0 : x0[3];
+        x1[3] = xg == 3 ? 0.0 : x1[3];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) x1[kb] = xi == KC_NB ? 0.0 : x1[kb];
+        v4f64 c00 = {0.0, 0.0, 0.0, 0.0}, c10 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[kb], x0[kb], c00, 0, 0, 0);
+            c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[kb], x0[kb], c10, 0, 0, 0);
+            c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[kb], x1[kb], c11, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            Cs0[(xg + 4 * q) * KC_RS + xi] = c00[q];
+            if (xg + 4 * q < KC_NB && xi < KC_NB) Cs1[(xg + 4 * q) * cs1_stride + xi] = c10[q];       // (the scratch is the next block's E rows: 15 x 15 only)
+            racc[q] += xi == KC_NB ? c10[q] : 0.0;           // column 15 of C10 = Xe y^T: rows (xg + 4 q) of the separator's right-hand side
+        }
+    }
+    GLIO_WAVE_LDS_SYNC();
+    {
+        const double* cp = is_e ? Cs1 + (r - 32) * cs1_stride : Cs0 + (r < KC_NB ? r : 15) * KC_RS;
+        double cv[KC_NB];
+#pragma unroll
+        for (int j = 0; j < KC_NB; ++j) cv[j] = cp[j];
+#pragma unroll
+        for (int j = 0; j < KC_NB; ++j) av[j] = is_e ? -cv[j] : (j < lim ? nx[j] - cv[j] : 0.0);
+    }
+}
+
+// chain_prepare_back for a block of an inner front: lanes 16..30 transform its E rows the same way (Ei then holds Me = L^-T Xe^T, row = OWN
+// unknown), so that z_i = w_i - M_i z_neighbour - Me_i z_s
+__device__ __forceinline__ void chain_prepare_back_e(double* Bi, double* Ei, const int lane) {
+    const int c = lane < 31 ? lane : 15;
+    const double* xr = c < KC_NB ? Bi + (KC_NB + c) * KC_RS : (c == KC_NB ? Bi + 30 * KC_RS : Ei + (c - 16) * KC_ERS);
+    double m[KC_NB];
+#pragma unroll
+    for (int k = 0; k < KC_NB; ++k) m[k] = xr[k];
+#pragma unroll
+    for (int k = KC_NB - 1; k >= 0; --k) {
+        double s0 = m[k], s1 = 0.0;
+#pragma unroll
+        for (int j = k + 1; j < KC_NB; ++j) { if ((j - k) & 1) s0 -= Bi[j * KC_RS + k] * m[j]; else s1 -= Bi[j * KC_RS + k] * m[j]; }
+        m[k] = (s0 + s1) * Bi[31 * KC_RS + k];
+    }
+    GLIO_WAVE_LDS_SYNC();
+    if (lane < KC_NB) {
+#pragma unroll
+        for (int r = 0; r < KC_NB; ++r) Bi[(KC_NB + r) * KC_RS + lane] = m[r];
+    } else if (lane == KC_NB) {
+#pragma unroll
+        for (int r = 0; r < KC_NB; ++r) Bi[30 * KC_RS + r] = m[r];
+    } else if (lane < 31) {
+#pragma unroll
+        for (int r = 0; r < KC_NB; ++r) Ei[r * KC_ERS + (lane - 16)] = m[r];
     }
 }
 
@@ -1674,6 +1819,7 @@ struct ChainArgs {
     int force_fail;           // test hook: report a breakdown although there is none (exercises the dense fallback)
     int fast;                 // k_chain_step: bit 0 = the tail (Cauchy length, dogleg, candidate) from LDS, bit 1 = the front (candidate's diag/g/cost,
                               // state machine) from LDS; 0 = the generic bodies that talk through the global work vectors (GLIO_CHAIN_FAST, default 3)
+    int fronts4;              // k_chain_step: 1 = separator + four fronts (chain_f4_split; its LDS lies behind chain_step_lds_bytes), 0 = two fronts
 };
 
 // The kernel also does the work of k_tr_prepare (state machine, scaling vectors) and of k_tr_scale for this structure: it
@@ -2027,6 +2173,23 @@ __host__ __device__ __forceinline__ size_t chain_step_lds_bytes(int W, int nd, i
     return chain_step_tabs_offset(W, nd, n) + (size_t)W * GLIO_LIDAR_ACC * 8 + (mirrors ? 5 : 2) * (size_t)(n + (n & 1)) * 8 + (mirrors ? (size_t)(n + W + ((n + W) & 1)) * 8 : 0) + (size_t)nd * 128 +
            (size_t)(8 + 15) * W * 2 + 3 * 346 * 2 + 64;
 }
+// Where the four-front panels live (k_chain_step): nothing new is allocated for the E slots that fit into the LDS copy of the clock-drift blocks
+// (dds, dead once t = H u is formed); the rest and the inner fronts' two C00 tiles start at the gather index tables (wr30 / wj / wlx, dead after
+// the block gather) and run past the regular end of the carve.  The host sizes the launch with the same function.
+struct ChainF4Layout { size_t off_dds, off_r1, total; int k0; };
+__host__ __device__ __forceinline__ ChainF4Layout chain_f4_layout(const int W, const int nd, const int n, const bool mir) {
+    const size_t n2 = n + (n & 1), nx = n + W, nx2 = nx + (nx & 1);
+    ChainF4Layout L;
+    L.off_dds = chain_step_tabs_offset(W, nd, n) + (size_t)W * GLIO_LIDAR_ACC * 8 + (mir ? 5 : 2) * n2 * 8 + (mir ? nx2 * 8 : 0);
+    const size_t off_stab = L.off_dds + ((size_t)nd * 15 + (nd & 1)) * 8;
+    const size_t off_wr30 = off_stab + ((size_t)(8 + 15) * W + ((8 + 15) * W & 1)) * 2;
+    L.off_r1 = (off_wr30 + 15) & ~(size_t)15;
+    const ChainSplit c = chain_f4_split(W);
+    const int nE = c.nB + c.nC, fit = (int)(((size_t)nd * 15) / KC_ES);
+    L.k0 = fit < nE ? fit : nE;
+    L.total = L.off_r1 + ((size_t)(nE - L.k0) * KC_ES + 2 * KC_TILE) * 8;
+    return L;
+}
 struct GatherArgs {
     const double* lidar_partials; size_t lidar_pstride; int lidar_nb;
     const PairBlock* imu_blocks; const PairBlock* gnss_blocks; const DdtBlock* ddt_blocks;
@@ -2210,7 +2373,7 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
     T.lid = lid; T.kd = reinterpret_cast<const ChainKf*>(stab); T.pidx = stab + 8 * W;
     __shared__ int rowmask;
     __shared__ int s_pending, s_cand, s_done;
-    __shared__ int s_prog[2];
+    __shared__ int s_prog[4];
     __shared__ SolverStatus s_in, s_full;
     AR_STAMP(40);
 #ifdef GLIO_DEV_STAMPS
@@ -2618,9 +2781,17 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
     };
     if (misc[1] == 6) corrections(std::integral_constant<int, 6>{}); else corrections(misc[1]);
     }
-    if (tid < 2) s_prog[tid] = 0;
+    if (tid < 4) s_prog[tid] = 0;
     GLIO_BLOCK_LDS_SYNC();
     AR_STAMP(47);
+    // four fronts: the split and where its panels live (chain_f4_layout)
+    const bool f4 = a.fronts4 != 0;
+    const ChainSplit cs = chain_f4_split(W);
+    const ChainF4Layout f4l = chain_f4_layout(W, nd, n, mir);
+    double* f4r1 = reinterpret_cast<double*>(tr_lds + f4l.off_r1);
+    auto eslot = [&](const int k) -> double* { return k < f4l.k0 ? dds + (size_t)k * KC_ES : f4r1 + (size_t)(k - f4l.k0) * KC_ES; };
+    double* Cs1a = f4r1 + (size_t)(cs.nB + cs.nC - f4l.k0) * KC_ES;      // C00 of front B
+    double* Cs3a = Cs1a + KC_TILE;                                       // C00 of front C
     // the chain from both ends
     const int mid = W / 2, nT = mid, nB = W - 1 - mid, Tn = nT > nB ? nT : nB;
     double av[KC_NB];
@@ -2630,11 +2801,19 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
         const int row = lane < KC_NB ? lane : 30;
         if (wv == 0 && nT > 0) { for (int j = 0; j < KC_NB; ++j) av[j] = Blk[row * KC_RS + j]; }
         if (wv == 2 && nB > 0) { for (int j = 0; j < KC_NB; ++j) av[j] = Blk[(size_t)(W - 1) * KC_BLK + row * KC_RS + j]; }
+        if (f4 && wv == 1) { for (int j = 0; j < KC_NB; ++j) av[j] = Blk[(size_t)(cs.s - 1) * KC_BLK + row * KC_RS + j]; }
+        if (f4 && wv == 3) { for (int j = 0; j < KC_NB; ++j) av[j] = Blk[(size_t)(cs.s + 1) * KC_BLK + row * KC_RS + j]; }
+    } else if (f4 && lane >= 32 && lane < 32 + KC_NB) {
+        // the inner fronts' first E rows: the separator's own coupling to its neighbour.  B: E = B_{s-1} (rows = unknowns of s);
+        // C: E = B_s^T (B_s has the unknowns of s + 1 as rows)
+        const int e = lane - 32;
+        if (wv == 1) { for (int j = 0; j < KC_NB; ++j) av[j] = Blk[(size_t)(cs.s - 1) * KC_BLK + (KC_NB + e) * KC_RS + j]; }
+        if (wv == 3) { for (int j = 0; j < KC_NB; ++j) av[j] = Blk[(size_t)cs.s * KC_BLK + (KC_NB + j) * KC_RS + e]; }
     }
     bool bad = false;
     long long ph[5] = {0, 0, 0, 0, 0};
     // back substitution of the middle keyframe (the one block whose triangular solve is on the critical path)
-    auto back = [&](const int i, const int nbr) {
+    auto back = [&](const int i, const int nbr, double* zout = nullptr) {
         const double* Bi = Blk + (size_t)i * KC_BLK;
         const int ln = lane < KC_NB ? lane : 0;
         double lcol[KC_NB], bcol[KC_NB];
@@ -2654,7 +2833,7 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
             if (lane == k) v = zk;
             else if (lane < k) v -= lcol[k] * zk;
         }
-        if (lane < KC_NB) zb[15 * i + lane] = v;
+        if (lane < KC_NB) (zout ? zout : zb + 15 * i)[lane] = v;
         GLIO_WAVE_LDS_SYNC();
     };
 
@@ -2662,7 +2841,106 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
     // its progress in LDS, and the wavefronts that prepare the factored blocks for the back substitution (on the two SIMDs the
     // fronts do not issue on) follow it by polling.  (Workgroup-scope atomics on the __shared__ words: ds_write / ds_read.  A cast to
     // `volatile int*` drops the address space -- the accesses became FLAT, system scope, each followed by s_waitcnt vmcnt(0).)
-    if (wv == 0) {
+    auto publish = [&](const int f, const int v) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        if (lane == 0) __hip_atomic_store(&s_prog[f], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto await = [&](const int f, const int v, const int nap) {
+        while (__hip_atomic_load(&s_prog[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) { if (nap == 1) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(2); }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    };
+    if (f4) {
+        const int s = cs.s, mL = cs.mL, mR = cs.mR;
+        // the fronts are the critical path: on the SIMD they share with a wavefront that prepares blocks for the back substitution they issue first
+        if (wv < 4) __builtin_amdgcn_s_setprio(3);
+        const int lim = lane == 30 ? KC_NB : (lane < KC_NB ? lane + 1 : 0);
+        const int crow = lane < KC_NB ? lane : 15;
+        // av -= rows of a C00-shaped tile (rows 0..14: the next block's diagonal block, row 15: its right-hand side)
+        auto minus_c00 = [&](const double* tile) {
+            double c[KC_NB];
+#pragma unroll
+            for (int j = 0; j < KC_NB; ++j) c[j] = tile[crow * KC_RS + j];
+#pragma unroll
+            for (int j = 0; j < KC_NB; ++j) av[j] = j < lim ? av[j] - c[j] : 0.0;
+        };
+        // What an inner front leaves behind after its last step.  The meeting block's E rows go where the outer wavefront's step reads its
+        // coupling rows (left: rows 15..29 of block mL, the B_mL this front read in the step just finished; right: rows 15..29 of the separator's
+        // block, the B_s this front read before its first step) -- the last step had its C10 written there, here it is negated in place.  The
+        // separator's sums are subtracted from its staged block in place, front C first (front B waits for it): the left meeting step reads the
+        // separator's rows after both.
+        auto inner_done = [&](double* Em, const v4f64& c11, const v4f64& racc) {
+            if (lane >= 32 && lane < 32 + KC_NB) {
+#pragma unroll
+                for (int j = 0; j < KC_NB; ++j) Em[(lane - 32) * KC_RS + j] = av[j];
+            }
+            double* Bs = Blk + (size_t)s * KC_BLK;
+            const int xi = lane & 15, xg = lane >> 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = xg + 4 * q;
+                if (e < KC_NB && xi <= e) Bs[e * KC_RS + xi] -= c11[q];
+                else if (e < KC_NB && xi == KC_NB) Bs[30 * KC_RS + e] -= racc[q];
+            }
+        };
+        double* EmL = Blk + (size_t)mL * KC_BLK + KC_NB * KC_RS;
+        double* EmR = Blk + (size_t)s * KC_BLK + KC_NB * KC_RS;
+        if (wv == 0) {
+            for (int it = 0; it < cs.nA; ++it) { chain_step15<false>(it, it + 1, true, av, Blk, CsT, lane, bad, ph); publish(0, it + 1); }
+            AR_STAMP(100);
+            await(1, cs.nB, 1);
+            AR_STAMP(101);
+            minus_c00(Cs1a);
+            chain_step15<false>(mL, s, true, av, Blk, CsT, lane, bad);                   // (coupling rows: EmL; next block: the separator)
+            publish(0, cs.nA + 1);
+            AR_STAMP(111);
+            await(2, cs.nD + 1, 1);
+            AR_STAMP(112);
+            minus_c00(CsB);
+            chain_step15<false>(s, s, false, av, Blk, CsT, lane, bad);
+            AR_STAMP(102);
+            back(s, -1);
+            AR_STAMP(103);
+        } else if (wv == 2) {
+            for (int it = 0; it < cs.nD; ++it) { const int i = W - 1 - it; chain_step15<true>(i, i - 1, true, av, Blk, CsB, lane, bad); publish(2, it + 1); }
+            WV_STAMP(114);
+            await(3, cs.nC, 1);
+            minus_c00(Cs3a);
+            // (next block = itself: the rows a step prefetches for its successor are not used here -- wavefront 0 forms the separator's block -- and
+            //  the separator's staged rows are still being updated by front B)
+            chain_step15<false>(mR, mR, true, av, Blk, CsB, lane, bad, nullptr, EmR);
+            publish(2, cs.nD + 1);
+            WV_STAMP(115);
+        } else if (wv == 1) {
+            v4f64 c11 = {0.0, 0.0, 0.0, 0.0}, racc = {0.0, 0.0, 0.0, 0.0};
+            for (int it = 0; it < cs.nB; ++it) {
+                const int i = s - 1 - it;
+                const bool last = it == cs.nB - 1;
+                chain_step15e<true>(i, i - 1, av, Blk, eslot(it), Cs1a, last ? EmL : eslot(it + 1), last ? KC_RS : KC_ERS, lane, bad, c11, racc);
+                if (last) { await(3, cs.nC, 1); inner_done(EmL, c11, racc); }
+                publish(1, it + 1);
+            }
+            WV_STAMP(113);
+        } else if (wv == 3) {
+            v4f64 c11 = {0.0, 0.0, 0.0, 0.0}, racc = {0.0, 0.0, 0.0, 0.0};
+            for (int it = 0; it < cs.nC; ++it) {
+                const int i = s + 1 + it;
+                const bool last = it == cs.nC - 1;
+                chain_step15e<false>(i, i + 1, av, Blk, eslot(cs.nB + it), Cs3a, last ? EmR : eslot(cs.nB + it + 1), last ? KC_RS : KC_ERS, lane, bad, c11, racc);
+                if (last) inner_done(EmR, c11, racc);
+                publish(3, it + 1);
+            }
+            WV_STAMP(116);
+        } else if (wv == 4) {
+            for (int k = 0; k < cs.nA; ++k) { await(0, k + 1, 2); chain_prepare_back(Blk + (size_t)k * KC_BLK, lane); }
+        } else if (wv == 5) {
+            for (int k = 0; k < cs.nB; ++k) { await(1, k + 1, 2); chain_prepare_back_e(Blk + (size_t)(s - 1 - k) * KC_BLK, eslot(k), lane); }
+        } else if (wv == 6) {
+            for (int k = 0; k < cs.nD; ++k) { await(2, k + 1, 2); chain_prepare_back(Blk + (size_t)(W - 1 - k) * KC_BLK, lane); }
+        } else if (wv == 7) {
+            for (int k = 0; k < cs.nC; ++k) { await(3, k + 1, 2); chain_prepare_back_e(Blk + (size_t)(s + 1 + k) * KC_BLK, eslot(cs.nB + k), lane); }
+        }
+        if (wv < 4) __builtin_amdgcn_s_setprio(0);
+    } else if (wv == 0) {
         for (int it = 0; it < nT; ++it) {
             chain_step15<false>(it, it + 1, true, av, Blk, CsT, lane, bad, ph);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -2735,7 +3013,46 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
             }
             GLIO_WAVE_LDS_SYNC();
         };
-        if (wv == 0) { for (int i = mid - 1; i >= 0; --i) back_mv(i, i + 1); }
+        // four fronts: z_s is known; every wavefront starts from its segment's meeting block (the inner ones compute it privately).  The meeting
+        // blocks are solved by the triangular back substitution like the separator: preparing them as matrix-vector products would have to happen
+        // after the last elimination step, on the critical path
+        auto back_mv4 = [&](const int i, const double* znb, const double* Me, double* zout) {
+            const double* Bi = Blk + (size_t)i * KC_BLK;
+            const double* zs = zb + 15 * cs.s;
+            if (lane < KC_NB) {
+                double mrow[KC_NB], zn[KC_NB];
+#pragma unroll
+                for (int k = 0; k < KC_NB; ++k) { mrow[k] = Bi[(KC_NB + lane) * KC_RS + k]; zn[k] = znb[k]; }
+                double s0 = Bi[30 * KC_RS + lane], s1 = 0, s2 = 0;
+#pragma unroll
+                for (int k = 0; k < KC_NB; k += 3) { s0 -= mrow[k] * zn[k]; s1 -= mrow[k + 1] * zn[k + 1]; s2 -= mrow[k + 2] * zn[k + 2]; }
+                if (Me) {
+#pragma unroll
+                    for (int k = 0; k < KC_NB; ++k) { mrow[k] = Me[lane * KC_ERS + k]; zn[k] = zs[k]; }
+#pragma unroll
+                    for (int k = 0; k < KC_NB; k += 3) { s0 -= mrow[k] * zn[k]; s1 -= mrow[k + 1] * zn[k + 1]; s2 -= mrow[k + 2] * zn[k + 2]; }
+                }
+                zout[lane] = (s0 + s1) + s2;
+            }
+            GLIO_WAVE_LDS_SYNC();
+        };
+        if (f4) {
+            const int s = cs.s, mL = cs.mL, mR = cs.mR;
+            if (wv == 0) {
+                back(mL, s);
+                for (int i = mL - 1; i >= 0; --i) back_mv4(i, zb + 15 * (i + 1), nullptr, zb + 15 * i);
+            } else if (wv == 1) {
+                back(mL, s, Cs1a);
+                for (int i = mL + 1; i < s; ++i) back_mv4(i, i == mL + 1 ? Cs1a : zb + 15 * (i - 1), eslot(s - 1 - i), zb + 15 * i);
+            } else if (wv == 2) {
+                back(mR, s);
+                for (int i = mR + 1; i < W; ++i) back_mv4(i, zb + 15 * (i - 1), nullptr, zb + 15 * i);
+            } else if (wv == 3) {
+                back(mR, s, Cs3a);
+                for (int i = mR - 1; i > s; --i) back_mv4(i, i == mR - 1 ? Cs3a : zb + 15 * (i + 1), eslot(cs.nB + i - (s + 1)), zb + 15 * i);
+            }
+        }
+        else if (wv == 0) { for (int i = mid - 1; i >= 0; --i) back_mv(i, i + 1); }
         else if (wv == 1) { for (int i = mid + 1; i < W; ++i) back_mv(i, i - 1); }
         AR_STAMP(98);
         GLIO_BLOCK_LDS_SYNC();
@@ -2926,6 +3243,14 @@ static int chain_fast_mask() {
     return g_chain_fast;
 }
 
+// GLIO_CHAIN_FRONTS = 2: k_chain_step keeps the two-front elimination for every window (A/B switch and cross-check of the four-front order)
+static int g_chain_fronts = -1;
+extern "C" int glio_debug_chain_fronts(int fronts) { const int old = g_chain_fronts; g_chain_fronts = fronts; return old; }
+static int chain_fronts_mode() {
+    if (g_chain_fronts < 0) { const char* e = getenv("GLIO_CHAIN_FRONTS"); g_chain_fronts = e ? atoi(e) : 4; }
+    return g_chain_fronts;
+}
+
 void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
     TrArgs a;
     a.W = c->W; a.n = 15 * c->W + n_ddt; a.n_ddt = n_ddt; a.max_iterations = c->opts.max_iterations;
@@ -2966,6 +3291,14 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
         r.W = c->W; r.n = a.n; r.nd = n_ddt; r.ep_slots = c->arrow.d_ep_slots; r.ep_off = c->arrow.d_ep_off; r.ep_list = c->arrow.d_ep_list;
         r.z = c->arrow.d_z; r.flag = c->arrow.d_flag; r.status = c->d_status; r.dbg = c->arrow.d_dbg; r.force_fail = c->arrow.mode == 2; r.fast = chain_fast_mask();
         if (chain_step_lds_bytes(c->W, n_ddt, a.n, true) + 2 * 1024 > 158 * 1024) r.fast = 0;      // no room for the LDS mirrors: generic bodies
+        size_t lds_step = chain_step_lds_bytes(c->W, n_ddt, a.n, r.fast != 0);
+        {   // separator + four fronts when the window is long enough for it to pay and its panels fit (chain_f4_layout)
+            const ChainF4Layout L = chain_f4_layout(c->W, n_ddt, a.n, r.fast != 0);
+            const size_t with4 = L.total > lds_step ? L.total : lds_step;
+            r.fronts4 = (c->W >= KC_F4_MIN_W && chain_fronts_mode() != 2 && with4 + 2 * 1024 <= 158 * 1024) ? 1 : 0;
+            if (r.fronts4) lds_step = with4;
+            c->arrow.last_fronts = r.fronts4 ? 4 : 2;
+        }
         if (!legacy_chain) {
             GatherArgs G;
             G.lidar_partials = c->d_lidar_partials; G.lidar_pstride = glio_partials_stride(c); G.lidar_nb = c->last_k3_nb;
@@ -2977,7 +3310,7 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
             G.hd0 = c->d_hdiag[0]; G.hd1 = c->d_hdiag[1]; G.g0 = c->d_g[0]; G.g1 = c->d_g[1]; G.c0 = c->d_cost[0]; G.c1 = c->d_cost[1];
             a.hd0 = c->d_hdiag[0]; a.hd1 = c->d_hdiag[1];
             a.fused_chain = 2;
-            hipLaunchKernelGGL(k_chain_step, dim3(1), dim3(KC_THREADS), chain_step_lds_bytes(c->W, n_ddt, a.n, r.fast != 0), c->stream, r, a, G);
+            hipLaunchKernelGGL(k_chain_step, dim3(1), dim3(KC_THREADS), lds_step, c->stream, r, a, G);
             return;                                   // the one launch is the whole step
         }
         hipLaunchKernelGGL(k_chain_solve, dim3(1), dim3(KC_THREADS), lds_chain, c->stream, r, a);

@@ -39,6 +39,9 @@ print("epoch columns: round 1 + barrier", d(90, 43), "u / S, 1 / sqrt(m) + barri
 print("t = H u: rows", d(94, 45), "barrier", d(46, 94))
 print("epoch corrections: row list", d(95, 46), "index lists + barrier", d(96, 95), "rank-one corrections + barrier", d(47, 96))
 print("chain (wave 0): top front", d(100, 47), "wait for the bottom front", d(101, 100), "middle step", d(102, 101), "middle back substitution", d(103, 102), "barrier", d(48, 103))
+if os.environ.get("GLIO_CHAIN_FRONTS", "4") != "2" and v[111]:
+    print("four fronts, us after the start of the chain: front A done", d(100, 47), "B", d(113, 47), "C", d(116, 47), "D", d(114, 47), "| left meeting block done", d(111, 47),
+          "right", d(115, 47), "| separator factored", d(102, 47), "its back substitution", d(103, 47))
 print("back substitution: flag + barrier", d(97, 48), "half chains (wave 0)", d(98, 97), "barrier", d(99, 98), "epochs + z", d(49, 99))
 print("epoch corrections on the matrix core (wave 0): entry", d(104, 96), "lane roles", d(105, 104), "offsets + accumulators", d(106, 105), "operands", d(107, 106), "MFMA", d(108, 107), "stores", d(109, 108), "return", d(110, 109), "barrier", d(47, 110))
 print("shader clock over the step: %.0f MHz (clock64 ticks / wall-clock time between the first and the last stamp)" % ((v[121] - v[120]) / max(1, (v[73] - v[40])) * 100.0))

@@ -436,6 +436,64 @@ def test_chain_step_is_bit_identical_to_the_assembled_sequence(hip, steady_windo
         assert out[k] == out[0], k
 
 
+def _steady(hip, W, pts, seed):
+    """keyframes 1..W of a W+1 stream with the prior the DEVICE marginalization of keyframe 0 leaves (block diagonal by keyframe)"""
+    stream = synth.make_window(W=W + 1, pts_per_scan=pts, with_gnss=True, seed=synth.SEED_BASE + seed)
+    first = synth.sub_window(stream, 0, W)
+    c0 = hip.Context(first.opts)
+    c0.load_window(first, synth.analytic_correspondences(first))
+    s0, _ = c0.solve(first.init)
+    prior = c0.marginalize(s0)
+    c0.close()
+    win = synth.sub_window(stream, 1, W)
+    win.prior = prior
+    return win, synth.analytic_correspondences(win)
+
+
+@pytest.mark.parametrize("W,use_gnss", [(12, True), (13, False), (16, True), (17, True), (20, True), (20, False), (21, True), (24, False)])
+def test_four_front_elimination(hip, po, W, use_gnss):
+    """k_chain_step on windows of 12 keyframes and more: the middle keyframe as separator and four elimination fronts (chain_f4_split) instead of
+    two.  A different elimination order of the same positive definite system: the iterates must agree with the two-front order and with the dense
+    factorisation to rounding, iteration for iteration; the breakdown path (every step reports a bad pivot, the same workgroup rebuilds the system
+    densely from the factor blocks) must still find its tables intact behind the four-front panels.  W = 24 without GNSS / W = 21 with its epochs
+    are where the panels no longer fit beside the LDS mirrors -- whatever layout the launch picks, the numbers must not care."""
+    lib = hip.load()
+    win, corr = _steady(hip, W, 300, 300 + W)
+    far = _state_for(win, use_gnss)
+    far.trans = far.trans + np.random.default_rng(W).normal(0, 0.05, far.trans.shape)
+    res = {}
+    try:
+        for name, mode, fronts in (("dense", 0, 4), ("two", 1, 2), ("four", 1, 4), ("four_breakdown", 2, 4)):
+            lib.glio_debug_chain_fronts(fronts)
+            ctx = hip.Context(win.opts)
+            lib.glio_debug_set_solver(ctx._h, mode)
+            ctx.load_window(win, corr, use_gnss=use_gnss)
+            res[name] = ctx.solve(far) + (lib.glio_debug_solver_path(ctx._h),)
+            if name in ("two", "four"):
+                used = lib.glio_debug_chain_fronts_used(ctx._h)
+                assert used == (2 if name == "two" else 4) or (name == "four" and (W, use_gnss) in ((21, True), (24, False))), (name, used)
+            ctx.close()
+    finally:
+        lib.glio_debug_chain_fronts(4)
+    sd, md, pd_ = res["dense"]
+    assert pd_ == 0 and res["two"][2] == 2 and res["four"][2] == 2
+    for name in ("two", "four", "four_breakdown"):
+        s, m, _ = res[name]
+        assert m.iterations == md.iterations and m.successful_steps == md.successful_steps and m.termination == md.termination, name
+        assert abs(m.final_cost - md.final_cost) <= 1e-11 * abs(md.final_cost), name
+        assert np.abs(s.trans - sd.trans).max() <= 1e-9 and np.abs(s.quat - sd.quat).max() <= 1e-10 and np.abs(s.speed_bias - sd.speed_bias).max() <= 1e-8, name
+    s2, s4 = res["two"][0], res["four"][0]
+    assert np.abs(s4.trans - s2.trans).max() <= 1e-11 and np.abs(s4.quat - s2.quat).max() <= 1e-12 and np.abs(s4.speed_bias - s2.speed_bias).max() <= 1e-10
+    if W in (12, 20):
+        so, mo = po.Problem(win, corr, use_gnss=use_gnss).solve(_state_for_copy(far))
+        assert mo.iterations == res["four"][1].iterations
+        assert_pose_parity(s4, so, tol_t=1e-7, tol_r=1e-8)
+
+
+def _state_for_copy(st):
+    return st.copy()
+
+
 @pytest.mark.parametrize("n", [37, 160, 376, 399, 400, 414, 420])
 def test_blocked_cholesky_sizes(hip, n):
     """The in-kernel blocked Cholesky + back substitution of the dense path (chol_left_looking, back_substitute) against numpy on random SPD
