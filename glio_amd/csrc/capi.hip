@@ -206,7 +206,8 @@ static int create_body(int device, const glio_opts* opts, glio_ctx* c) {
     c->solve_id = 0;
     {
         unsigned char* hup = nullptr;
-        GLIO_HIP_CHECK(hipHostMalloc((void**)&hup, 512 + (size_t)nx * 8));
+        GLIO_HIP_CHECK(hipHostMalloc((void**)&hup, 512 + (size_t)nx * 8, hipHostMallocMapped));
+        GLIO_HIP_CHECK(hipHostGetDevicePointer(&c->d_h_status, (void*)hup, 0));
         c->h_status = reinterpret_cast<SolverStatus*>(hup);
         c->h_xbuf = reinterpret_cast<double*>(hup + 512);
     }
@@ -786,6 +787,11 @@ static void enqueue_linearize(glio_ctx* c, int use_status, int which, int n_ddt,
     glio_launch_small_factors(c, use_status, which, n_ddt);
     if (dense) glio_launch_assemble(c, use_status, which, n_ddt);
 }
+// status record + initial state, pinned host memory -> device, by a kernel of the solve's own queue: hipMemcpyAsync does the same with a blit kernel
+// (~4 us) and a barrier packet behind it (another ~4 us before the first linearisation starts); this is one ~2 us launch with nothing behind it
+__global__ __launch_bounds__(1024) void k_stage_in(unsigned long long* __restrict__ dst, const unsigned long long* __restrict__ src, const int nwords) {
+    for (int k = threadIdx.x; k < nwords; k += 1024) dst[k] = __builtin_nontemporal_load(src + k);      // (one round of reads over the link for the usual window)
+}
 // enqueue one complete solve from the packed state in h_xbuf; no host synchronisation inside
 static int enqueue_solve(glio_ctx* c, int n_ddt) {
     const int nx = glio_x_size(c->W, n_ddt);
@@ -797,7 +803,8 @@ static int enqueue_solve(glio_ctx* c, int n_ddt) {
     c->solve_id = c->solve_id % 30000 + 1;          // kernels of the previous solve's look-ahead group may still be draining:
     st.solve_id = c->solve_id;                      // their progress words carry the old tag and are ignored
     *c->h_status = st;
-    GLIO_HIP_CHECK(hipMemcpyAsync(c->d_status, c->h_status, 512 + (size_t)nx * 8, hipMemcpyHostToDevice, c->stream));   // status + state
+    hipLaunchKernelGGL(k_stage_in, dim3(1), dim3(1024), 0, c->stream, reinterpret_cast<unsigned long long*>(c->d_status),
+                       reinterpret_cast<const unsigned long long*>(c->d_h_status), 64 + nx);                              // status + state
     // The trust-region loop lives on the device (SolverStatus); the host only feeds it kernel groups
     // [linearise, step].  Instead of queueing all max_iterations+1 groups blindly -- after convergence the rest are
     // empty launches, ~2.5 us each -- it enqueues group k + 1 when k_tr_prepare of group k reports (through a progress word in

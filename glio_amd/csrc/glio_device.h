@@ -205,6 +205,7 @@ struct glio_ctx {
                                   // one vector would otherwise also cache the head of the next, which the same kernel may rewrite)
     SolverStatus* d_status;
     SolverStatus* h_status;       // pinned
+    void* d_h_status;             // its device address: k_stage_in pulls status + initial state from it (no blit, no barrier packet behind it)
     volatile int* h_progress;     // pinned + mapped: [0] (solve id << 16) | groups started, [1] id of the solve that is done -- written by the GPU, polled by the host; [2] written by the HOST, read by the GPU: id of the solve whose time budget is spent
     unsigned char* h_result; unsigned char* d_result;   // pinned + mapped: [SolverStatus | pad to 512 B | final state]: the last kernel of a solve
                                                         // publishes its result here, glio_solve reads it without a copy or a stream sync

@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/tl
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT -o tl -- python scripts/solve_once.py > gpurun_out/tl.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT -o tl -- python ${1:-scripts/solve_once.py} > gpurun_out/tl.log 2>&1
 f=$(find $OUT -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys
