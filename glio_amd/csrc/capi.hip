@@ -173,7 +173,7 @@ static int create_body(int device, const glio_opts* opts, glio_ctx* c) {
     c->h_groups = (GnssGroup*)calloc((size_t)W * W, sizeof(GnssGroup));
     c->h_prior_index = (int*)malloc((size_t)15 * W * sizeof(int));
     for (int k = 0; k < 15 * W; ++k) c->h_prior_index[k] = -1;
-    c->chain_tabs_dirty = 1;
+    c->chain_tabs_dirty = 1; c->h_band_clean = 0;
     c->k3_bpk = GLIO_K3_BLOCKS_PER_KF; c->last_k3_nb = c->k3_bpk; c->merged_linearize = 2; c->want_pair_H = 1; c->k3_unroll = 22;   /* 2-deep batches, non-temporal loads, next batch issued before the arithmetic of the current one */
     { int per = 768 / W;   /* ~3 workgroups per CU measured best on MI355X (scripts/k3_sweep.py) */
       // the fp32 / MFMA form keeps two chunks (four 16-byte loads per lane) in flight per wavefront and wants ~8x as many of them resident: at the C5
@@ -191,7 +191,7 @@ static int create_body(int device, const glio_opts* opts, glio_ctx* c) {
         GLIO_HIP_CHECK(hipMemsetAsync(ar.d_ep_slots, 0xff, (size_t)ne * sizeof(int2), c->stream));
         GLIO_HIP_CHECK(hipMemsetAsync(ar.d_ep_off, 0, (W + 1) * 4, c->stream));
         ALLOC(ar.d_Y, (size_t)(c->n_ddt_max + 9 * W) * (6 * W + 2) * 8);
-        ALLOC(ar.d_Lblk, (size_t)W * 190 * 8); ALLOC(ar.d_Sp, (size_t)(6 * W + 1) * 6 * W * 8);
+        ALLOC(ar.d_blk, (size_t)W * 544 * 8); ALLOC(ar.d_Lblk, (size_t)W * 190 * 8); ALLOC(ar.d_Sp, (size_t)(6 * W + 1) * 6 * W * 8);
         ALLOC(ar.d_z, (size_t)n_max * 8); ALLOC(ar.d_flag, 4); ALLOC(ar.d_dbg, 320 * 8);
         GLIO_HIP_CHECK(hipMemsetAsync(ar.d_flag, 0, 4, c->stream));
         GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -235,7 +235,7 @@ void glio_destroy(glio_ctx* c) {
                     c->d_prior_kind, c->d_prior_idx, c->d_prior_index, c->d_prior_H, c->d_prior_g, c->d_prior_cost, c->d_prior_work,
                     /* d_x[0] lives inside d_status' allocation */ c->d_x[1], c->d_H[0], c->d_H[1], c->d_g[0], c->d_g[1], c->d_cost[0], c->d_cost[1], c->d_xout,
                     c->d_lidar_partials, c->d_hdiag[0], c->d_hdiag[1], c->d_chain_tabs, c->d_chain_src, c->d_lidar_blocks, c->d_L, c->d_vec, c->d_status,
-                    c->arrow.d_ep_slots, c->arrow.d_ep_off, c->arrow.d_ep_list, c->arrow.d_Y, c->arrow.d_Lblk, c->arrow.d_Sp, c->arrow.d_z, c->arrow.d_flag, c->arrow.d_dbg};
+                    c->arrow.d_ep_slots, c->arrow.d_ep_off, c->arrow.d_ep_list, c->arrow.d_Y, c->arrow.d_blk, c->arrow.d_Lblk, c->arrow.d_Sp, c->arrow.d_z, c->arrow.d_flag, c->arrow.d_dbg};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_status) hipHostFree(c->h_status); /* h_xbuf lives inside it */
     if (c->h_progress) hipHostFree((void*)c->h_progress);
@@ -526,7 +526,7 @@ int glio_set_imu(glio_ctx* c, int n_edges, const glio_preint* edges, const int32
     }
     c->n_imu = n_edges;
     for (int k = 0; k < n_edges; ++k) c->h_imu_slot[k] = slot_i[k];
-    c->chain_tabs_dirty = 1;
+    c->chain_tabs_dirty = 1; c->h_band_clean = 0;
     extra_of(c)->imu_edge0 = -1;
     for (int k = 0; k < n_edges; ++k) if (slot_i[k] == 0) extra_of(c)->imu_edge0 = k;
     if (n_edges) c->have_factors = 1;
@@ -540,7 +540,7 @@ int glio_set_prior(glio_ctx* c, const glio_prior* p) {
     if (!p || p->n <= 0) {
         c->prior_n = 0; c->prior_nb = 0; c->arrow.prior_ok = 1; c->arrow.prior_chain = 1;
         for (int k = 0; k < 15 * c->W; ++k) c->h_prior_index[k] = -1;
-        c->chain_tabs_dirty = 1;
+        c->chain_tabs_dirty = 1; c->h_band_clean = 0;
         return GLIO_OK;
     }
     const int np = p->n, nb = p->n_blocks, W = c->W;
@@ -586,7 +586,7 @@ int glio_set_prior(glio_ctx* c, const glio_prior* p) {
     GLIO_HIP_CHECK(hipMemcpy(ex->d_prior_colblk, colblk.data(), np * 4, hipMemcpyHostToDevice));
     c->prior_n = np; c->prior_nb = nb;
     for (int k = 0; k < 15 * W; ++k) c->h_prior_index[k] = index[k];
-    c->chain_tabs_dirty = 1;
+    c->chain_tabs_dirty = 1; c->h_band_clean = 0;
     glio_launch_gram(c, np);
     GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
     c->have_factors = 1;
@@ -700,7 +700,7 @@ int glio_set_gnss(glio_ctx* c, const glio_gnss_frame* frame, int n_dd, const gli
     c->arrow.gnss_ok = 1; c->arrow.max_epoch = -1; c->arrow.gnss_chain = 1;
     for (auto& g : groups) if (g.slot_j - g.slot_i != 1) c->arrow.gnss_chain = 0;       // a pair that skips a keyframe (or is listed upper keyframe first) breaks the chain
     for (size_t k = 0; k < groups.size(); ++k) c->h_groups[k] = groups[k];
-    c->chain_tabs_dirty = 1;
+    c->chain_tabs_dirty = 1; c->h_band_clean = 0;
     for (auto& r : runs) {
         c->arrow.max_epoch = std::max(c->arrow.max_epoch, r.epoch);
         const GnssGroup& g = groups[r.group];
@@ -780,12 +780,12 @@ static void enqueue_linearize(glio_ctx* c, int use_status, int which, int n_ddt,
     lds_poison(c);
     if (c->merged_linearize) {
         glio_launch_linearize_all(c, use_status, which, n_ddt);
-        if (dense) glio_launch_assemble(c, use_status, which, n_ddt);
+        if (dense) glio_launch_assemble(c, use_status, which, n_ddt, dense == 2);
         return;
     }
     glio_launch_lidar_linearize(c, use_status, which);
     glio_launch_small_factors(c, use_status, which, n_ddt);
-    if (dense) glio_launch_assemble(c, use_status, which, n_ddt);
+    if (dense) glio_launch_assemble(c, use_status, which, n_ddt, dense == 2);
 }
 // status record + initial state, pinned host memory -> device, by a kernel of the solve's own queue: hipMemcpyAsync does the same with a blit kernel
 // (~4 us) and a barrier packet behind it (another ~4 us before the first linearisation starts); this is one ~2 us launch with nothing behind it
@@ -818,7 +818,7 @@ static int enqueue_solve(glio_ctx* c, int n_ddt) {
     const int lead = c->enqueue_lead < 1 ? total : c->enqueue_lead;
     const auto t_start = c->solve_t0;
     int enq = 0, spins = 0;
-    const int dense = glio_solver_needs_dense_H(c, n_ddt);
+    const int dense = glio_chain_kind(c, n_ddt) == 3 ? 2 : glio_solver_needs_dense_H(c, n_ddt);      // (2: the band k_chain_solve<true> reads is enough)
     // options.max_solver_time_in_seconds: when the budget is spent the host raises the stop word; the state machine of the next
     // group sees it and ends the solve.  One more group is fed regardless of the look-ahead rule so that such a state machine runs.
     const bool timed = c->opts.max_solver_time_s > 0.0;
@@ -1047,7 +1047,7 @@ int glio_marginalize_keep(glio_ctx* c, const glio_state* s) {
     const int chain = c->prior_n > 0 ? c->arrow.prior_chain : 1;
     c->prior_n = n; c->prior_nb = nb;
     for (int k = 0; k < 15 * W; ++k) c->h_prior_index[k] = index[k];
-    c->chain_tabs_dirty = 1;
+    c->chain_tabs_dirty = 1; c->h_band_clean = 0;
     c->arrow.prior_ok = 1; c->arrow.prior_chain = chain;
     glio_launch_gram(c, n);
     int* h_ok = reinterpret_cast<int*>(c->h_stage + ((c->h_stage_used + 63) & ~(size_t)63));      // (pinned; reserved above)
@@ -1056,7 +1056,7 @@ int glio_marginalize_keep(glio_ctx* c, const glio_state* s) {
     if (!*h_ok) {          // the installed tables describe a factor that does not exist: the context is left WITHOUT a prior
         c->prior_n = 0; c->prior_nb = 0; c->arrow.prior_ok = 1; c->arrow.prior_chain = 1;
         for (int k = 0; k < 15 * W; ++k) c->h_prior_index[k] = -1;
-        c->chain_tabs_dirty = 1;
+        c->chain_tabs_dirty = 1; c->h_band_clean = 0;
         glio_set_error("marginalization: Schur complement is not positive definite (the context now has no prior)");
         return GLIO_E_NUMERIC;
     }
@@ -1126,9 +1126,10 @@ int glio_eval_imu(glio_ctx* c, const glio_preint* pre, double const* const* P, d
 
 // solver selection for tests: 0 = dense Cholesky only, 1 = structured (arrow) factorisation when the graph permits
 int glio_debug_set_solver(glio_ctx* c, int mode) {
-    if (!c || mode < 0 || mode > 3) return GLIO_E_ARG;      // 0 dense only, 1 structured when possible, 2 = 1 + the chain kernel reports a
+    if (!c || mode < 0 || mode > 4) return GLIO_E_ARG;      // 0 dense only, 1 structured when possible, 2 = 1 + the chain kernel reports a
     c->arrow.mode = mode;                                   // breakdown every time (test hook for its dense fallback), 3 = 1 with the
-                                                            // legacy chain sequence (assemble + k_chain_solve + k_tr_finish) instead of k_chain_step
+                                                            // legacy chain sequence (assemble + k_chain_solve + k_tr_finish) instead of k_chain_step,
+                                                            // 4 = 1 without the chain kernels (the arrow factorisation although the graph is a chain)
     return GLIO_OK;
 }
 int glio_debug_arrow_stamps(glio_ctx* c, long long* out64) {

@@ -815,6 +815,7 @@ void glio_launch_lidar_reduce(glio_ctx* c, int which) {
 // ------------------------------------------------------------------------------------------------
 struct AsmArgs {
     int W, n, n_ddt, n_imu, n_groups, has_prior, np;
+    int band;                 // 1: pose rows are written in the block-tridiagonal band and the epoch columns only (k_chain_solve<true> reads nothing else)
     const SolverStatus* st; int use_status; int fixed_which;
     const double* lidar_partials; size_t lidar_pstride; int lidar_nb; const PairBlock* imu_blocks; const PairBlock* gnss_blocks; const DdtBlock* ddt_blocks;
     int gnss_stride, ddt_stride;
@@ -894,10 +895,13 @@ __global__ __launch_bounds__(1024) void k_assemble(const AsmArgs a) {
         gadj0[sl] = (short)k0; gadj1[sl] = (short)k1; gnext[sl] = (short)nx;
     }
     __syncthreads();
-    // rows are dealt to workgroups, columns to lanes (coalesced stores, no integer division per entry)
-    for (int r = blockIdx.x; r <= n; r += gridDim.x) {
+    // rows are dealt to workgroups, columns to lanes (coalesced stores, no integer division per entry).  Band mode: a row has ~45 + n_ddt live
+    // columns, so a workgroup of 1024 takes eight rows at a time, 128 lanes each.
+    const int r_first = a.band ? 8 * blockIdx.x + (threadIdx.x >> 7) : blockIdx.x, r_stride = a.band ? 8 * gridDim.x : gridDim.x;
+    const int c_first = a.band ? (threadIdx.x & 127) : threadIdx.x, c_stride = a.band ? 128 : blockDim.x;
+    for (int r = r_first; r <= n; r += r_stride) {
         if (r == n) {          // gradient
-            for (int c = threadIdx.x; c < n; c += blockDim.x) {
+            for (int c = c_first; c < n; c += c_stride) {
                 double s = 0;
                 if (c < np15) {
                     const int sc = c / 15, lc = c % 15;
@@ -930,8 +934,9 @@ __global__ __launch_bounds__(1024) void k_assemble(const AsmArgs a) {
         if (r < np15) {
             const int sr = r / 15, lr = r % 15;
             const int pi = pidx[r];
-            for (int c = threadIdx.x; c < n; c += blockDim.x) {
+            for (int c = c_first; c < n; c += c_stride) {
                 double s = 0;
+                if (a.band && c < np15 && (c < 15 * (sr - 1) || c >= 15 * (sr + 2))) continue;       // (zero by the chain structure; zeroed once by the host)
                 if (c < np15) {
                     const int sc = c / 15, lc = c % 15;
                     const int d = sc - sr;
@@ -994,7 +999,7 @@ __global__ __launch_bounds__(1024) void k_assemble(const AsmArgs a) {
             const bool used = dd[ep].used != 0;
             const int gi = used ? dd[ep].group : 0;
             const int sa = used ? gsa[gi] : -1, sb = used ? gsb[gi] : -1;
-            for (int c = threadIdx.x; c < n; c += blockDim.x) {
+            for (int c = c_first; c < n; c += c_stride) {
                 double s = 0;
                 if (c >= np15) { if (c == r) s = dd[ep].h; }
                 else if (used) {
@@ -1176,8 +1181,17 @@ void glio_launch_linearize_all(glio_ctx* c, int use_status_cand, int which, int 
     hipLaunchKernelGGL(k_linearize_all<false>, dim3(n_small + k.n_k3 + (k.skip_hi - k.skip_lo)), dim3(SF_THREADS), 0, c->stream, a, k);
 }
 
-void glio_launch_assemble(glio_ctx* c, int use_status_cand, int which, int n_ddt) {
+void glio_launch_assemble(glio_ctx* c, int use_status_cand, int which, int n_ddt, int band) {
     AsmArgs a;
+    a.band = band;
+    if (band && c->h_band_clean != 15 * c->W + n_ddt) {
+        // first band-only assembly since the structure changed / a full assembly ran: whatever the buffers hold outside the band goes
+        // (the dense fallback of the chain kernels reads the whole matrix).  No H of the solve being started exists yet.
+        const size_t nn = (size_t)(15 * c->W + n_ddt) * (15 * c->W + n_ddt) * sizeof(double);
+        hipMemsetAsync(c->d_H[0], 0, nn, c->stream); hipMemsetAsync(c->d_H[1], 0, nn, c->stream);
+        c->h_band_clean = 15 * c->W + n_ddt;               // (the row stride is part of it)
+    }
+    if (!band) c->h_band_clean = 0;
     a.W = c->W; a.n = 15 * c->W + n_ddt; a.n_ddt = n_ddt; a.n_imu = c->n_imu; a.n_groups = c->n_groups;
     a.has_prior = c->prior_n > 0; a.np = c->prior_n;
     a.st = c->d_status; a.use_status = use_status_cand; a.fixed_which = which;
@@ -1185,7 +1199,7 @@ void glio_launch_assemble(glio_ctx* c, int use_status_cand, int which, int n_ddt
     a.gnss_stride = c->W * c->W; a.ddt_stride = c->n_ddt_max > 0 ? c->n_ddt_max : 1;
     a.pH = c->d_prior_H; a.pg = c->d_prior_g; a.pcost = c->d_prior_cost; a.prior_index = c->d_prior_index;
     a.H0 = c->d_H[0]; a.H1 = c->d_H[1]; a.g0 = c->d_g[0]; a.g1 = c->d_g[1]; a.c0 = c->d_cost[0]; a.c1 = c->d_cost[1];
-    const int blocks = a.n + 1;       // one workgroup per row of H (+ one for g)
-    const int threads = a.n + 1 > 1024 ? 1024 : ((a.n + 1 + 63) / 64) * 64;    // one column per thread: a single round of loads per row
+    const int blocks = band ? (a.n + 1 + 7) / 8 : a.n + 1;       // one workgroup per row of H (+ one for g); band: eight rows each, side by side
+    const int threads = (band || a.n + 1 > 1024) ? 1024 : ((a.n + 1 + 63) / 64) * 64;    // one column per thread: a single round of loads per row
     hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(threads), 0, c->stream, a);
 }

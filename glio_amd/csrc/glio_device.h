@@ -127,6 +127,7 @@ struct ArrowDev {
     int* d_ep_off;            // [W+1] CSR over slots: epochs touching slot i
     int* d_ep_list;           // [2 n_ddt_max]
     double* d_Y;              // (n_ddt + 9W) x (6W+2): L^-1 [M_ep | b_e]
+    double* d_blk;            // [W][544] staged keyframe blocks of k_chain_solve<true> (windows whose blocks do not fit the LDS)
     double* d_Lblk;           // [W][190] factored speed-bias chain: L_ii (9x9), L_{i+1,i} (9x9), row stride 10, 9 reciprocal pivots
     double* d_Sp;             // (6W+1) x 6W pose Schur complement + carried right-hand side
     double* d_z;              // [n] solution in elimination order
@@ -227,6 +228,8 @@ struct glio_ctx {
     int* h_prior_index;                       // [15 W] state index -> prior column or -1
     short* d_chain_tabs; short* h_chain_tabs; // [8 W + 15 W] ChainKf per keyframe, then the prior index (h_: pinned)
     int chain_tabs_dirty;
+    int h_band_clean;             // n for which both dense H buffers are zero outside the band a band-only k_assemble writes, else 0 (reset by every full
+                                  // assembly and structure change)
     int want_pair_H;              // 0: the linearisation in flight feeds k_chain_step only (chain slices, g, cost): the 30 x 30 pair blocks are not written
     double* d_chain_src;                      // [2][W][GLIO_CS_SOURCES][GLIO_CS_STRIDE] chain-layout contributions, double buffered
 };
@@ -394,7 +397,8 @@ void glio_lidar_pack_f32(glio_ctx* c);                      // no-op unless the 
 void glio_launch_small_factors(glio_ctx* c, int use_status_cand, int which, int n_ddt, int marg = 0);
 void glio_launch_linearize_all(glio_ctx* c, int use_status_cand, int which, int n_ddt);   // K3 + small factors, one launch
 void glio_launch_lidar_reduce(glio_ctx* c, int which);      // K3 partials -> d_lidar_blocks (the marginalization's assembly reads the blocks)
-void glio_launch_assemble(glio_ctx* c, int use_status_cand, int which, int n_ddt);
+void glio_launch_assemble(glio_ctx* c, int use_status_cand, int which, int n_ddt, int band = 0);      // band: the block-tridiagonal part + epoch columns only
+int glio_chain_kind(const glio_ctx* c, int n_ddt);
 void glio_launch_stream_read(glio_ctx* c);
 int glio_assoc_build_map_dev(glio_ctx* c, const float4* d_pts, int n);
 int glio_assoc_select(glio_ctx* c, int slot, const int32_t* indices, int n);

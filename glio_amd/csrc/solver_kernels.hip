@@ -1396,6 +1396,9 @@ __host__ __device__ __forceinline__ size_t chain_lds_doubles(int W, int nd) {
            (size_t)nd + 2 + 2 * ((size_t)nd + 2) + 12 + (size_t)nd + 2;
 }
 
+// k_chain_solve<true>: the blocks live in global memory; the LDS holds everything else plus the four-front panels (all E slots, two C00 tiles)
+__host__ __device__ __forceinline__ size_t chain_lds_doubles_g(int W, int nd);
+
 // 1 / sqrt(d) for a pivot already known to be positive, finite and far from the denormal range (it is a diagonal entry of
 // the Jacobi-scaled, mu-regularised matrix): the hardware estimate and one Newton step in a form that cancels to first
 // order, y = y0 + y0 (1 - d y0^2) / 2, without the library's class checks and rescaling (~5 dependent operations instead
@@ -1408,7 +1411,17 @@ __device__ __forceinline__ double pivot_rsqrt(const double d) {
     return fma(0.5 * y1, e1, y1);
 }
 
-template <bool DOWN>
+// Ordering point between the lanes of one wavefront for what the chain functions hand over through the blocks.  G = false: the blocks live in LDS
+// (GLIO_WAVE_LDS_SYNC).  G = true: the blocks live in GLOBAL memory (windows whose blocks do not fit the LDS, k_chain_solve<true>): the stores must
+// have been acknowledged (s_waitcnt vmcnt(0)) before another lane reads them back through the compute unit's L1, which is what a workgroup-scope
+// release / acquire pair over all address spaces compiles to.
+template <bool G>
+__device__ __forceinline__ void chain_wave_sync() {
+    if (G) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+    else GLIO_WAVE_LDS_SYNC();
+}
+
+template <bool DOWN, bool G = false>
 __device__ __forceinline__ void chain_step15(const int i, const int nb, const bool has_nb, double (&av)[KC_NB], double* Blk, double* Cs, const int lane, bool& bad,
                                              long long* ph = nullptr, const double* Nrows = nullptr) {
 #ifdef GLIO_DEV_STAMPS
@@ -1469,7 +1482,7 @@ __device__ __forceinline__ void chain_step15(const int i, const int nb, const bo
         for (int j = 0; j < KC_NB; ++j) Bi[r * KC_RS + j] = j < tri ? av[j] : 0.0;
         if (r < KC_NB) Bi[31 * KC_RS + r] = rpv;
     }
-    GLIO_WAVE_LDS_SYNC();
+    chain_wave_sync<G>();
     CS_PH(2);
     if (has_nb) {
         // C = X X^T on the matrix core: X = rows 15..30 of the factored panel (15 rows towards the next keyframe + the
@@ -1513,6 +1526,7 @@ __device__ __forceinline__ void chain_step15(const int i, const int nb, const bo
 // each, L broadcast from LDS); rows 15..29 then hold M = L^-T X^T (row = OWN unknown) and row 30 holds w = L^-T y, so that
 // the back substitution of this keyframe is one matrix-vector product, z = w - M z_neighbour, instead of a 15-step
 // triangular solve on the critical path.
+template <bool G = false>
 __device__ __forceinline__ void chain_prepare_back(double* Bi, const int lane) {
     const int c = lane < 16 ? lane : 0;
     const double* xr = Bi + (c < KC_NB ? KC_NB + c : 30) * KC_RS;
@@ -1526,7 +1540,7 @@ __device__ __forceinline__ void chain_prepare_back(double* Bi, const int lane) {
         for (int j = k + 1; j < KC_NB; ++j) { if ((j - k) & 1) s0 -= Bi[j * KC_RS + k] * m[j]; else s1 -= Bi[j * KC_RS + k] * m[j]; }
         m[k] = (s0 + s1) * Bi[31 * KC_RS + k];
     }
-    GLIO_WAVE_LDS_SYNC();                                  // every lane has read its right-hand side before anyone overwrites the rows
+    chain_wave_sync<G>();                                  // every lane has read its right-hand side before anyone overwrites the rows
     if (lane < KC_NB) {
 #pragma unroll
         for (int r = 0; r < KC_NB; ++r) Bi[(KC_NB + r) * KC_RS + lane] = m[r];
@@ -1565,7 +1579,7 @@ __host__ __device__ __forceinline__ ChainSplit chain_f4_split(const int W) {
 }
 // One step of an inner front.  av: lanes 0..14 and 30 as in chain_step15, lanes 32..46 the E rows of block i.  Ei: where the factored E rows
 // (Xe) of block i go; Cs0 / Cs1: this wavefront's scratch tiles for C00 / C10; c11, racc: the separator's sums (see above).
-template <bool DOWN>
+template <bool DOWN, bool G = false>
 __device__ __forceinline__ void chain_step15e(const int i, const int nb, double (&av)[KC_NB], double* Blk, double* Ei, double* Cs0, double* Cs1, const int cs1_stride,
                                               const int lane, bool& bad, v4f64& c11, v4f64& racc) {
     const int r = lane;
@@ -1614,7 +1628,7 @@ __device__ __forceinline__ void chain_step15e(const int i, const int nb, double 
 #pragma unroll
         for (int j = 0; j < KC_NB; ++j) Ei[(r - 32) * KC_ERS + j] = av[j];
     }
-    GLIO_WAVE_LDS_SYNC();
+    chain_wave_sync<G>();
     {
         const int xi = lane & 15, xg = lane >> 4;
         const double* x0row = Bi + (KC_NB + xi) * KC_RS + xg;
@@ -1640,7 +1654,7 @@ __device__ __forceinline__ void chain_step15e(const int i, const int nb, double 
             racc[q] += xi == KC_NB ? c10[q] : 0.0;           // column 15 of C10 = Xe y^T: rows (xg + 4 q) of the separator's right-hand side
         }
     }
-    GLIO_WAVE_LDS_SYNC();
+    chain_wave_sync<G>();
     {
         const double* cp = is_e ? Cs1 + (r - 32) * cs1_stride : Cs0 + (r < KC_NB ? r : 15) * KC_RS;
         double cv[KC_NB];
@@ -1653,6 +1667,7 @@ __device__ __forceinline__ void chain_step15e(const int i, const int nb, double 
 
 // chain_prepare_back for a block of an inner front: lanes 16..30 transform its E rows the same way (Ei then holds Me = L^-T Xe^T, row = OWN
 // unknown), so that z_i = w_i - M_i z_neighbour - Me_i z_s
+template <bool G = false>
 __device__ __forceinline__ void chain_prepare_back_e(double* Bi, double* Ei, const int lane) {
     const int c = lane < 31 ? lane : 15;
     const double* xr = c < KC_NB ? Bi + (KC_NB + c) * KC_RS : (c == KC_NB ? Bi + 30 * KC_RS : Ei + (c - 16) * KC_ERS);
@@ -1666,7 +1681,7 @@ __device__ __forceinline__ void chain_prepare_back_e(double* Bi, double* Ei, con
         for (int j = k + 1; j < KC_NB; ++j) { if ((j - k) & 1) s0 -= Bi[j * KC_RS + k] * m[j]; else s1 -= Bi[j * KC_RS + k] * m[j]; }
         m[k] = (s0 + s1) * Bi[31 * KC_RS + k];
     }
-    GLIO_WAVE_LDS_SYNC();
+    chain_wave_sync<G>();
     if (lane < KC_NB) {
 #pragma unroll
         for (int r = 0; r < KC_NB; ++r) Bi[(KC_NB + r) * KC_RS + lane] = m[r];
@@ -1676,6 +1691,262 @@ __device__ __forceinline__ void chain_prepare_back_e(double* Bi, double* Ei, con
     } else if (lane < 31) {
 #pragma unroll
         for (int r = 0; r < KC_NB; ++r) Ei[r * KC_ERS + (lane - 16)] = m[r];
+    }
+}
+
+// Back substitution of one factored (NOT prepared) block by the triangular solve: L_ii^T z_i = y_i - X^T z_nbr (nbr < 0: no neighbour term).
+// zout: where z_i goes (default: its place in zb).
+template <bool G = false>
+__device__ __forceinline__ void chain_back_solve(const double* Blk, const int i, const int nbr, double* zb, double* zout, const int lane) {
+    const double* Bi = Blk + (size_t)i * KC_BLK;
+    const int ln = lane < KC_NB ? lane : 0;
+    double lcol[KC_NB], bcol[KC_NB];             // column `lane` of L_ii and of L_{nbr,i}: fetched before the dependent chain starts
+#pragma unroll
+    for (int k = 0; k < KC_NB; ++k) { lcol[k] = Bi[k * KC_RS + ln]; bcol[k] = Bi[(KC_NB + k) * KC_RS + ln]; }
+    const double rp = lane < KC_NB ? Bi[31 * KC_RS + lane] : 1.0;
+    double v = lane < KC_NB ? Bi[30 * KC_RS + lane] : 0.0;
+    if (nbr >= 0) {
+        double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+        for (int k = 0; k < KC_NB; k += 3) { s0 += bcol[k] * zb[15 * nbr + k]; s1 += bcol[k + 1] * zb[15 * nbr + k + 1]; s2 += bcol[k + 2] * zb[15 * nbr + k + 2]; }
+        v -= (s0 + s1) + s2;
+    }
+#pragma unroll
+    for (int k = KC_NB - 1; k >= 0; --k) {
+        const double zk = readlane_d(v, k) * readlane_d(rp, k);
+        if (lane == k) v = zk;
+        else if (lane < k) v -= lcol[k] * zk;
+    }
+    if (lane < KC_NB) (zout ? zout : zb + 15 * i)[lane] = v;
+    GLIO_WAVE_LDS_SYNC();
+}
+
+// LDS of the four-front elimination: the E slots (es0: the first k0 of them, es1: the rest) and the inner fronts' C00 tiles
+struct ChainF4Mem {
+    double* es0; double* es1; int k0; double* cs1a; double* cs3a;
+    __device__ __forceinline__ double* eslot(const int k) const { return k < k0 ? es0 + (size_t)k * KC_ES : es1 + (size_t)(k - k0) * KC_ES; }
+};
+
+// The four-front elimination itself (see above), by the eight wavefronts of the workgroup: fronts A, B, D, C on wavefronts 0, 1, 2, 3; wavefronts
+// 4..7 follow one front each and prepare its factored blocks for the back substitution.  NO workgroup barrier inside: every hand-over is a
+// release / acquire pair on a word of s_prog (zeroed by the caller, behind a barrier).  Ends with z of the separator in zb (wavefront 0); the
+// caller's barrier follows.  `bad` collects non-positive pivots per thread.
+template <bool G>
+__device__ __forceinline__ void chain_f4_factor(const int W, const ChainSplit& cs, double* Blk, double* CsT, double* CsB, const ChainF4Mem& M, double* zb, int* s_prog,
+                                                const int lane, const int wv, bool& bad, long long* ph, long long* dbg) {
+#ifdef GLIO_DEV_STAMPS
+#define F4_STAMP(k) do { if (dbg && blockIdx.x == 0 && lane == 0) dbg[k] = wall_clock64(); } while (0)
+#else
+#define F4_STAMP(k) do { } while (0)
+#endif
+    const int s = cs.s, mL = cs.mL, mR = cs.mR;
+    double av[KC_NB];
+#pragma unroll
+    for (int j = 0; j < KC_NB; ++j) av[j] = 0.0;
+    if (lane < KC_NB || lane == 30) {
+        const int row = lane < KC_NB ? lane : 30;
+        const int first = wv == 0 ? 0 : (wv == 1 ? s - 1 : (wv == 2 ? W - 1 : s + 1));
+        if (wv < 4) { for (int j = 0; j < KC_NB; ++j) av[j] = Blk[(size_t)first * KC_BLK + row * KC_RS + j]; }
+    } else if (lane >= 32 && lane < 32 + KC_NB) {
+        // the inner fronts' first E rows: the separator's own coupling to its neighbour.  B: E = B_{s-1} (rows = unknowns of s);
+        // C: E = B_s^T (B_s has the unknowns of s + 1 as rows)
+        const int e = lane - 32;
+        if (wv == 1) { for (int j = 0; j < KC_NB; ++j) av[j] = Blk[(size_t)(s - 1) * KC_BLK + (KC_NB + e) * KC_RS + j]; }
+        if (wv == 3) { for (int j = 0; j < KC_NB; ++j) av[j] = Blk[(size_t)s * KC_BLK + (KC_NB + j) * KC_RS + e]; }
+    }
+    // (Workgroup-scope atomics on the __shared__ words: ds_write / ds_read.  A cast to `volatile int*` drops the address space -- the accesses
+    //  became FLAT, system scope, each followed by s_waitcnt vmcnt(0).)  With the blocks in global memory the fences cover all address spaces.
+    auto publish = [&](const int f, const int v) {
+        if (G) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        if (lane == 0) __hip_atomic_store(&s_prog[f], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto await = [&](const int f, const int v, const int nap) {
+        while (__hip_atomic_load(&s_prog[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) { if (nap == 1) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(2); }
+        if (G) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    };
+    // the fronts are the critical path: on the SIMD they share with a wavefront that prepares blocks for the back substitution they issue first
+    if (wv < 4) __builtin_amdgcn_s_setprio(3);
+    const int lim = lane == 30 ? KC_NB : (lane < KC_NB ? lane + 1 : 0);
+    const int crow = lane < KC_NB ? lane : 15;
+    // av -= rows of a C00-shaped tile (rows 0..14: the next block's diagonal block, row 15: its right-hand side)
+    auto minus_c00 = [&](const double* tile) {
+        double c[KC_NB];
+#pragma unroll
+        for (int j = 0; j < KC_NB; ++j) c[j] = tile[crow * KC_RS + j];
+#pragma unroll
+        for (int j = 0; j < KC_NB; ++j) av[j] = j < lim ? av[j] - c[j] : 0.0;
+    };
+    // What an inner front leaves behind after its last step.  The meeting block's E rows go where the outer wavefront's step reads its
+    // coupling rows (left: rows 15..29 of block mL, the B_mL this front read in the step just finished; right: rows 15..29 of the separator's
+    // block, the B_s this front read before its first step) -- the last step had its C10 written there, here it is negated in place.  The
+    // separator's sums are subtracted from its staged block in place, front C first (front B waits for it): the left meeting step reads the
+    // separator's rows after both.
+    auto inner_done = [&](double* Em, const v4f64& c11, const v4f64& racc) {
+        if (lane >= 32 && lane < 32 + KC_NB) {
+#pragma unroll
+            for (int j = 0; j < KC_NB; ++j) Em[(lane - 32) * KC_RS + j] = av[j];
+        }
+        double* Bs = Blk + (size_t)s * KC_BLK;
+        const int xi = lane & 15, xg = lane >> 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = xg + 4 * q;
+            if (e < KC_NB && xi <= e) Bs[e * KC_RS + xi] -= c11[q];
+            else if (e < KC_NB && xi == KC_NB) Bs[30 * KC_RS + e] -= racc[q];
+        }
+    };
+    double* EmL = Blk + (size_t)mL * KC_BLK + KC_NB * KC_RS;
+    double* EmR = Blk + (size_t)s * KC_BLK + KC_NB * KC_RS;
+    if (wv == 0) {
+        for (int it = 0; it < cs.nA; ++it) { chain_step15<false, G>(it, it + 1, true, av, Blk, CsT, lane, bad, ph); publish(0, it + 1); }
+        F4_STAMP(100);
+        await(1, cs.nB, 1);
+        F4_STAMP(101);
+        minus_c00(M.cs1a);
+        chain_step15<false, G>(mL, s, true, av, Blk, CsT, lane, bad);                   // (coupling rows: EmL; next block: the separator)
+        publish(0, cs.nA + 1);
+        F4_STAMP(111);
+        await(2, cs.nD + 1, 1);
+        F4_STAMP(112);
+        minus_c00(CsB);
+        chain_step15<false, G>(s, s, false, av, Blk, CsT, lane, bad);
+        F4_STAMP(102);
+        chain_back_solve<G>(Blk, s, -1, zb, nullptr, lane);
+        F4_STAMP(103);
+    } else if (wv == 2) {
+        for (int it = 0; it < cs.nD; ++it) { const int i = W - 1 - it; chain_step15<true, G>(i, i - 1, true, av, Blk, CsB, lane, bad); publish(2, it + 1); }
+        F4_STAMP(114);
+        await(3, cs.nC, 1);
+        minus_c00(M.cs3a);
+        // (next block = itself: the rows a step prefetches for its successor are not used here -- wavefront 0 forms the separator's block -- and
+        //  the separator's staged rows are still being updated by front B)
+        chain_step15<false, G>(mR, mR, true, av, Blk, CsB, lane, bad, nullptr, EmR);
+        publish(2, cs.nD + 1);
+        F4_STAMP(115);
+    } else if (wv == 1) {
+        v4f64 c11 = {0.0, 0.0, 0.0, 0.0}, racc = {0.0, 0.0, 0.0, 0.0};
+        for (int it = 0; it < cs.nB; ++it) {
+            const int i = s - 1 - it;
+            const bool last = it == cs.nB - 1;
+            chain_step15e<true, G>(i, i - 1, av, Blk, M.eslot(it), M.cs1a, last ? EmL : M.eslot(it + 1), last ? KC_RS : KC_ERS, lane, bad, c11, racc);
+            if (last) { await(3, cs.nC, 1); inner_done(EmL, c11, racc); }
+            publish(1, it + 1);
+        }
+        F4_STAMP(113);
+    } else if (wv == 3) {
+        v4f64 c11 = {0.0, 0.0, 0.0, 0.0}, racc = {0.0, 0.0, 0.0, 0.0};
+        for (int it = 0; it < cs.nC; ++it) {
+            const int i = s + 1 + it;
+            const bool last = it == cs.nC - 1;
+            chain_step15e<false, G>(i, i + 1, av, Blk, M.eslot(cs.nB + it), M.cs3a, last ? EmR : M.eslot(cs.nB + it + 1), last ? KC_RS : KC_ERS, lane, bad, c11, racc);
+            if (last) inner_done(EmR, c11, racc);
+            publish(3, it + 1);
+        }
+        F4_STAMP(116);
+    } else if (wv == 4) {
+        for (int k = 0; k < cs.nA; ++k) { await(0, k + 1, 2); chain_prepare_back<G>(Blk + (size_t)k * KC_BLK, lane); }
+    } else if (wv == 5) {
+        for (int k = 0; k < cs.nB; ++k) { await(1, k + 1, 2); chain_prepare_back_e<G>(Blk + (size_t)(s - 1 - k) * KC_BLK, M.eslot(k), lane); }
+    } else if (wv == 6) {
+        for (int k = 0; k < cs.nD; ++k) { await(2, k + 1, 2); chain_prepare_back<G>(Blk + (size_t)(W - 1 - k) * KC_BLK, lane); }
+    } else if (wv == 7) {
+        for (int k = 0; k < cs.nC; ++k) { await(3, k + 1, 2); chain_prepare_back_e<G>(Blk + (size_t)(s + 1 + k) * KC_BLK, M.eslot(cs.nB + k), lane); }
+    }
+    if (wv < 4) __builtin_amdgcn_s_setprio(0);
+#undef F4_STAMP
+}
+
+// Back substitution behind chain_f4_factor (and the caller's barrier): z of the separator is known; every wavefront 0..3 starts from its segment's
+// meeting block (the inner ones compute it privately, into their dead C00 tile).  The meeting blocks are solved by the triangular back
+// substitution like the separator: preparing them as matrix-vector products would have to happen after the last elimination step, on the
+// critical path.  All other blocks: z_i = w_i - M_i z_neighbour - Me_i z_s on what chain_prepare_back(_e) left.
+template <bool G>
+__device__ __forceinline__ void chain_f4_backsub(const int W, const ChainSplit& cs, const double* Blk, const ChainF4Mem& M, double* zb, const int lane, const int wv) {
+    const int s = cs.s, mL = cs.mL, mR = cs.mR;
+    auto mv = [&](const int i, const double* znb, const double* Me, double* zout) {
+        const double* Bi = Blk + (size_t)i * KC_BLK;
+        const double* zs = zb + 15 * s;
+        if (lane < KC_NB) {
+            double mrow[KC_NB], zn[KC_NB];
+#pragma unroll
+            for (int k = 0; k < KC_NB; ++k) { mrow[k] = Bi[(KC_NB + lane) * KC_RS + k]; zn[k] = znb[k]; }
+            double s0 = Bi[30 * KC_RS + lane], s1 = 0, s2 = 0;
+#pragma unroll
+            for (int k = 0; k < KC_NB; k += 3) { s0 -= mrow[k] * zn[k]; s1 -= mrow[k + 1] * zn[k + 1]; s2 -= mrow[k + 2] * zn[k + 2]; }
+            if (Me) {
+#pragma unroll
+                for (int k = 0; k < KC_NB; ++k) { mrow[k] = Me[lane * KC_ERS + k]; zn[k] = zs[k]; }
+#pragma unroll
+                for (int k = 0; k < KC_NB; k += 3) { s0 -= mrow[k] * zn[k]; s1 -= mrow[k + 1] * zn[k + 1]; s2 -= mrow[k + 2] * zn[k + 2]; }
+            }
+            zout[lane] = (s0 + s1) + s2;
+        }
+        GLIO_WAVE_LDS_SYNC();
+    };
+    // one half chain: blocks i0, i0 + di, ... (cnt of them), each with its predecessor in the sequence as neighbour (the first one: zfirst)
+    auto run = [&](const int i0, const int di, const int cnt, const double* zfirst, const bool with_e, const int slot0, const int dslot) {
+        if (!G) {
+            for (int k = 0; k < cnt; ++k) {
+                const int i = i0 + k * di;
+                mv(i, k == 0 ? zfirst : zb + 15 * (i - di), with_e ? M.eslot(slot0 + k * dslot) : nullptr, zb + 15 * i);
+            }
+            return;
+        }
+        // blocks in global memory: the rows of M_i do not depend on z -- those of the next block are in flight while this one is multiplied
+        // (one global round trip per block on the critical path otherwise)
+        const int ln = lane < KC_NB ? lane : 0;
+        double cur[KC_NB + 1], nxt[KC_NB + 1];
+        auto fetch = [&](const int i, double (&m)[KC_NB + 1]) {
+            const double* Bi = Blk + (size_t)i * KC_BLK;
+#pragma unroll
+            for (int k = 0; k < KC_NB; ++k) m[k] = Bi[(KC_NB + ln) * KC_RS + k];
+            m[KC_NB] = Bi[30 * KC_RS + ln];
+        };
+        auto compute = [&](const int k, const double (&m)[KC_NB + 1]) {
+            const int i = i0 + k * di;
+            const double* znb = k == 0 ? zfirst : zb + 15 * (i - di);
+            const double* Me = with_e ? M.eslot(slot0 + k * dslot) : nullptr;
+            const double* zs = zb + 15 * s;
+            if (lane < KC_NB) {
+                double zn[KC_NB], mrow[KC_NB];
+#pragma unroll
+                for (int q = 0; q < KC_NB; ++q) zn[q] = znb[q];
+                double s0 = m[KC_NB], s1 = 0, s2 = 0;
+#pragma unroll
+                for (int q = 0; q < KC_NB; q += 3) { s0 -= m[q] * zn[q]; s1 -= m[q + 1] * zn[q + 1]; s2 -= m[q + 2] * zn[q + 2]; }
+                if (Me) {
+#pragma unroll
+                    for (int q = 0; q < KC_NB; ++q) { mrow[q] = Me[lane * KC_ERS + q]; zn[q] = zs[q]; }
+#pragma unroll
+                    for (int q = 0; q < KC_NB; q += 3) { s0 -= mrow[q] * zn[q]; s1 -= mrow[q + 1] * zn[q + 1]; s2 -= mrow[q + 2] * zn[q + 2]; }
+                }
+                zb[15 * i + lane] = (s0 + s1) + s2;
+            }
+            GLIO_WAVE_LDS_SYNC();
+        };
+        // (two buffers used alternately, the loop unrolled by hand: a copy `cur = nxt` at the end of an iteration would wait for the prefetch)
+        if (cnt > 0) fetch(i0, cur);
+        for (int k = 0; k < cnt; k += 2) {
+            if (k + 1 < cnt) fetch(i0 + (k + 1) * di, nxt);
+            compute(k, cur);
+            if (k + 1 < cnt) {
+                if (k + 2 < cnt) fetch(i0 + (k + 2) * di, cur);
+                compute(k + 1, nxt);
+            }
+        }
+    };
+    if (wv == 0) {
+        chain_back_solve<G>(Blk, mL, s, zb, nullptr, lane);
+        run(mL - 1, -1, mL, zb + 15 * mL, false, 0, 0);
+    } else if (wv == 1) {
+        chain_back_solve<G>(Blk, mL, s, zb, M.cs1a, lane);
+        run(mL + 1, 1, s - 1 - mL, M.cs1a, true, s - 2 - mL, -1);
+    } else if (wv == 2) {
+        chain_back_solve<G>(Blk, mR, s, zb, nullptr, lane);
+        run(mR + 1, 1, W - 1 - mR, zb + 15 * mR, false, 0, 0);
+    } else if (wv == 3) {
+        chain_back_solve<G>(Blk, mR, s, zb, M.cs3a, lane);
+        run(mR - 1, -1, mR - 1 - s, M.cs3a, true, cs.nB + mR - 2 - s, -1);
     }
 }
 
@@ -1819,13 +2090,17 @@ struct ChainArgs {
     int force_fail;           // test hook: report a breakdown although there is none (exercises the dense fallback)
     int fast;                 // k_chain_step: bit 0 = the tail (Cauchy length, dogleg, candidate) from LDS, bit 1 = the front (candidate's diag/g/cost,
                               // state machine) from LDS; 0 = the generic bodies that talk through the global work vectors (GLIO_CHAIN_FAST, default 3)
-    int fronts4;              // k_chain_step: 1 = separator + four fronts (chain_f4_split; its LDS lies behind chain_step_lds_bytes), 0 = two fronts
+    int fronts4;              // 1 = separator + four fronts (chain_f4_split), 0 = two fronts
+    double* blk;              // k_chain_solve<true>: [W][KC_BLK] the staged blocks in global memory (windows whose blocks do not fit the LDS)
 };
 
 // The kernel also does the work of k_tr_prepare (state machine, scaling vectors) and of k_tr_scale for this structure: it
 // reads H and g directly, forms M = S H S + mu D^2 and the right-hand side S g while staging them (same arithmetic, same
 // order of operations as k_tr_scale), and computes t = H u from the staged blocks -- two launches and a round trip of the
 // scaled matrix through global memory less per iteration.  The dense fallback (k_tr_finish on flag 1) rebuilds what it needs.
+// G = true: the staged blocks live in global memory (a.blk) instead of LDS -- windows of more keyframes than the LDS holds (C5: 50 keyframes).  Same
+// arithmetic; the elimination runs on four fronts when a.fronts4 is set (chain_f4_factor).
+template <bool G>
 __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a, const TrArgs tr) {
     static_assert(KC_THREADS == TR_THREADS, "tr_prepare_body runs with the chain kernel's workgroup");
     TrDecision dec;
@@ -1850,8 +2125,8 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a, c
     double* rd = reinterpret_cast<double*>(tr_lds);
     double* yd = rd + nd + (nd & 1);                       // forward-substituted right-hand side of the epochs
     double* Vs = yd + nd + (nd & 1);                       // [nd][30]: epoch column restricted to its two keyframes, scaled
-    double* Blk = Vs + (size_t)nd * 30;                    // [W][KC_BLK]
-    double* CsT = Blk + (size_t)W * KC_BLK;
+    double* Blk = G ? a.blk : Vs + (size_t)nd * 30;        // [W][KC_BLK]
+    double* CsT = G ? Vs + (size_t)nd * 30 : Blk + (size_t)W * KC_BLK;
     double* CsB = CsT + 288;
     double* zb = CsB + 288;                                // [15 W]
     int2* eps = reinterpret_cast<int2*>(zb + 15 * W + (W & 1));
@@ -1863,6 +2138,13 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a, c
     double* wd = reinterpret_cast<double*>(misc + 24);     // [nd] u / s of the epochs (for t = H u)
     double* wdr = reinterpret_cast<double*>(esd);          // [nd] (u / s) sqrt(m): lives where the index lists go AFTER t = H u
     __shared__ int rowmask;                            // cleared here, two barriers before the first atomicOr into it
+    __shared__ int s_prog[4];
+    const bool f4 = G && a.fronts4 != 0;
+    const ChainSplit cs = chain_f4_split(W);
+    ChainF4Mem f4m;
+    f4m.es0 = f4m.es1 = wd + nd + (nd & 1); f4m.k0 = 0;
+    f4m.cs1a = f4m.es1 + (size_t)(cs.nB + cs.nC) * KC_ES; f4m.cs3a = f4m.cs1a + KC_TILE;
+    if (tid < 4) s_prog[tid] = 0;
     if (tid < 18) misc[tid] = 0;
     if (tid == 0) rowmask = 0;
     AR_STAMP(40);
@@ -2044,9 +2326,11 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a, c
     }
     bool bad = false;
     long long ph[5] = {0, 0, 0, 0, 0};
+    if (f4) chain_f4_factor<G>(W, cs, Blk, CsT, CsB, f4m, zb, s_prog, lane, wv, bad, ph, a.dbg);
+    else
     for (int it = 0; it <= T; ++it) {
         if (wv == 0) {
-            if (it < nT) chain_step15<false>(it, it + 1, true, av, Blk, CsT, lane, bad, ph);
+            if (it < nT) chain_step15<false, G>(it, it + 1, true, av, Blk, CsT, lane, bad, ph);
             else if (it == T) {
                 {
                     const int row = lane < KC_NB ? lane : 30, crow = lane < KC_NB ? lane : 15;
@@ -2062,14 +2346,14 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a, c
                         av[j] = j < lim ? v : 0.0;
                     }
                 }
-                chain_step15<false>(mid, mid, false, av, Blk, CsT, lane, bad);
+                chain_step15<false, G>(mid, mid, false, av, Blk, CsT, lane, bad);
             }
         } else if (wv == 2) {
-            if (it < nB) { const int i = W - 1 - it; chain_step15<true>(i, i - 1, true, av, Blk, CsB, lane, bad); }
+            if (it < nB) { const int i = W - 1 - it; chain_step15<true, G>(i, i - 1, true, av, Blk, CsB, lane, bad); }
         } else if (wv == 1) {                       // (SIMD 1 and 3: not the SIMDs the two chain wavefronts issue on)
-            if (it >= 1 && it - 1 < nT) chain_prepare_back(Blk + (size_t)(it - 1) * KC_BLK, lane);
+            if (it >= 1 && it - 1 < nT) chain_prepare_back<G>(Blk + (size_t)(it - 1) * KC_BLK, lane);
         } else if (wv == 3) {
-            if (it >= 1 && it - 1 < nB) chain_prepare_back(Blk + (size_t)(W - it) * KC_BLK, lane);
+            if (it >= 1 && it - 1 < nB) chain_prepare_back<G>(Blk + (size_t)(W - it) * KC_BLK, lane);
         }
         __syncthreads();
     }
@@ -2117,10 +2401,15 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_solve(const ChainArgs a, c
         }
         GLIO_WAVE_LDS_SYNC();
     };
+    if (f4) {
+        __syncthreads();
+        chain_f4_backsub<G>(W, cs, Blk, f4m, zb, lane, wv);
+    } else {
     if (wv == 0) back(mid, -1);
     __syncthreads();
     if (wv == 0) { for (int i = mid - 1; i >= 0; --i) back_mv(i, i + 1); }
     else if (wv == 1) { for (int i = mid + 1; i < W; ++i) back_mv(i, i - 1); }
+    }
     __syncthreads();
     AR_STAMP(45);
     double bd2 = 0.0;
@@ -2172,6 +2461,10 @@ __host__ __device__ __forceinline__ size_t chain_step_tabs_offset(int W, int nd,
 __host__ __device__ __forceinline__ size_t chain_step_lds_bytes(int W, int nd, int n, bool mirrors = true) {
     return chain_step_tabs_offset(W, nd, n) + (size_t)W * GLIO_LIDAR_ACC * 8 + (mirrors ? 5 : 2) * (size_t)(n + (n & 1)) * 8 + (mirrors ? (size_t)(n + W + ((n + W) & 1)) * 8 : 0) + (size_t)nd * 128 +
            (size_t)(8 + 15) * W * 2 + 3 * 346 * 2 + 64;
+}
+__host__ __device__ __forceinline__ size_t chain_lds_doubles_g(int W, int nd) {
+    const ChainSplit c = chain_f4_split(W);
+    return chain_lds_doubles(W, nd) - (size_t)W * KC_BLK + (size_t)(nd + (nd & 1)) + (size_t)(c.nB + c.nC) * KC_ES + 2 * KC_TILE + 8;
 }
 // Where the four-front panels live (k_chain_step): nothing new is allocated for the E slots that fit into the LDS copy of the clock-drift blocks
 // (dds, dead once t = H u is formed); the rest and the inner fronts' two C00 tiles start at the gather index tables (wr30 / wj / wlx, dead after
@@ -2787,11 +3080,13 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
     // four fronts: the split and where its panels live (chain_f4_layout)
     const bool f4 = a.fronts4 != 0;
     const ChainSplit cs = chain_f4_split(W);
-    const ChainF4Layout f4l = chain_f4_layout(W, nd, n, mir);
-    double* f4r1 = reinterpret_cast<double*>(tr_lds + f4l.off_r1);
-    auto eslot = [&](const int k) -> double* { return k < f4l.k0 ? dds + (size_t)k * KC_ES : f4r1 + (size_t)(k - f4l.k0) * KC_ES; };
-    double* Cs1a = f4r1 + (size_t)(cs.nB + cs.nC - f4l.k0) * KC_ES;      // C00 of front B
-    double* Cs3a = Cs1a + KC_TILE;                                       // C00 of front C
+    ChainF4Mem f4m;
+    {
+        const ChainF4Layout f4l = chain_f4_layout(W, nd, n, mir);
+        f4m.es0 = dds; f4m.es1 = reinterpret_cast<double*>(tr_lds + f4l.off_r1); f4m.k0 = f4l.k0;
+        f4m.cs1a = f4m.es1 + (size_t)(cs.nB + cs.nC - f4l.k0) * KC_ES;      // C00 of front B
+        f4m.cs3a = f4m.cs1a + KC_TILE;                                      // C00 of front C
+    }
     // the chain from both ends
     const int mid = W / 2, nT = mid, nB = W - 1 - mid, Tn = nT > nB ? nT : nB;
     double av[KC_NB];
@@ -2801,145 +3096,18 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
         const int row = lane < KC_NB ? lane : 30;
         if (wv == 0 && nT > 0) { for (int j = 0; j < KC_NB; ++j) av[j] = Blk[row * KC_RS + j]; }
         if (wv == 2 && nB > 0) { for (int j = 0; j < KC_NB; ++j) av[j] = Blk[(size_t)(W - 1) * KC_BLK + row * KC_RS + j]; }
-        if (f4 && wv == 1) { for (int j = 0; j < KC_NB; ++j) av[j] = Blk[(size_t)(cs.s - 1) * KC_BLK + row * KC_RS + j]; }
-        if (f4 && wv == 3) { for (int j = 0; j < KC_NB; ++j) av[j] = Blk[(size_t)(cs.s + 1) * KC_BLK + row * KC_RS + j]; }
-    } else if (f4 && lane >= 32 && lane < 32 + KC_NB) {
-        // the inner fronts' first E rows: the separator's own coupling to its neighbour.  B: E = B_{s-1} (rows = unknowns of s);
-        // C: E = B_s^T (B_s has the unknowns of s + 1 as rows)
-        const int e = lane - 32;
-        if (wv == 1) { for (int j = 0; j < KC_NB; ++j) av[j] = Blk[(size_t)(cs.s - 1) * KC_BLK + (KC_NB + e) * KC_RS + j]; }
-        if (wv == 3) { for (int j = 0; j < KC_NB; ++j) av[j] = Blk[(size_t)cs.s * KC_BLK + (KC_NB + j) * KC_RS + e]; }
     }
     bool bad = false;
     long long ph[5] = {0, 0, 0, 0, 0};
     // back substitution of the middle keyframe (the one block whose triangular solve is on the critical path)
-    auto back = [&](const int i, const int nbr, double* zout = nullptr) {
-        const double* Bi = Blk + (size_t)i * KC_BLK;
-        const int ln = lane < KC_NB ? lane : 0;
-        double lcol[KC_NB], bcol[KC_NB];
-#pragma unroll
-        for (int k = 0; k < KC_NB; ++k) { lcol[k] = Bi[k * KC_RS + ln]; bcol[k] = Bi[(KC_NB + k) * KC_RS + ln]; }
-        const double rp = lane < KC_NB ? Bi[31 * KC_RS + lane] : 1.0;
-        double v = lane < KC_NB ? Bi[30 * KC_RS + lane] : 0.0;
-        if (nbr >= 0) {
-            double s0 = 0, s1 = 0, s2 = 0;
-#pragma unroll
-            for (int k = 0; k < KC_NB; k += 3) { s0 += bcol[k] * zb[15 * nbr + k]; s1 += bcol[k + 1] * zb[15 * nbr + k + 1]; s2 += bcol[k + 2] * zb[15 * nbr + k + 2]; }
-            v -= (s0 + s1) + s2;
-        }
-#pragma unroll
-        for (int k = KC_NB - 1; k >= 0; --k) {
-            const double zk = readlane_d(v, k) * readlane_d(rp, k);
-            if (lane == k) v = zk;
-            else if (lane < k) v -= lcol[k] * zk;
-        }
-        if (lane < KC_NB) (zout ? zout : zb + 15 * i)[lane] = v;
-        GLIO_WAVE_LDS_SYNC();
-    };
+    auto back = [&](const int i, const int nbr, double* zout = nullptr) { chain_back_solve<false>(Blk, i, nbr, zb, zout, lane); };
 
     // The two fronts run WITHOUT workgroup barriers between their steps (they meet only at the middle keyframe); each publishes
     // its progress in LDS, and the wavefronts that prepare the factored blocks for the back substitution (on the two SIMDs the
     // fronts do not issue on) follow it by polling.  (Workgroup-scope atomics on the __shared__ words: ds_write / ds_read.  A cast to
     // `volatile int*` drops the address space -- the accesses became FLAT, system scope, each followed by s_waitcnt vmcnt(0).)
-    auto publish = [&](const int f, const int v) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-        if (lane == 0) __hip_atomic_store(&s_prog[f], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    auto await = [&](const int f, const int v, const int nap) {
-        while (__hip_atomic_load(&s_prog[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) { if (nap == 1) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(2); }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-    };
     if (f4) {
-        const int s = cs.s, mL = cs.mL, mR = cs.mR;
-        // the fronts are the critical path: on the SIMD they share with a wavefront that prepares blocks for the back substitution they issue first
-        if (wv < 4) __builtin_amdgcn_s_setprio(3);
-        const int lim = lane == 30 ? KC_NB : (lane < KC_NB ? lane + 1 : 0);
-        const int crow = lane < KC_NB ? lane : 15;
-        // av -= rows of a C00-shaped tile (rows 0..14: the next block's diagonal block, row 15: its right-hand side)
-        auto minus_c00 = [&](const double* tile) {
-            double c[KC_NB];
-#pragma unroll
-            for (int j = 0; j < KC_NB; ++j) c[j] = tile[crow * KC_RS + j];
-#pragma unroll
-            for (int j = 0; j < KC_NB; ++j) av[j] = j < lim ? av[j] - c[j] : 0.0;
-        };
-        // What an inner front leaves behind after its last step.  The meeting block's E rows go where the outer wavefront's step reads its
-        // coupling rows (left: rows 15..29 of block mL, the B_mL this front read in the step just finished; right: rows 15..29 of the separator's
-        // block, the B_s this front read before its first step) -- the last step had its C10 written there, here it is negated in place.  The
-        // separator's sums are subtracted from its staged block in place, front C first (front B waits for it): the left meeting step reads the
-        // separator's rows after both.
-        auto inner_done = [&](double* Em, const v4f64& c11, const v4f64& racc) {
-            if (lane >= 32 && lane < 32 + KC_NB) {
-#pragma unroll
-                for (int j = 0; j < KC_NB; ++j) Em[(lane - 32) * KC_RS + j] = av[j];
-            }
-            double* Bs = Blk + (size_t)s * KC_BLK;
-            const int xi = lane & 15, xg = lane >> 4;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int e = xg + 4 * q;
-                if (e < KC_NB && xi <= e) Bs[e * KC_RS + xi] -= c11[q];
-                else if (e < KC_NB && xi == KC_NB) Bs[30 * KC_RS + e] -= racc[q];
-            }
-        };
-        double* EmL = Blk + (size_t)mL * KC_BLK + KC_NB * KC_RS;
-        double* EmR = Blk + (size_t)s * KC_BLK + KC_NB * KC_RS;
-        if (wv == 0) {
-            for (int it = 0; it < cs.nA; ++it) { chain_step15<false>(it, it + 1, true, av, Blk, CsT, lane, bad, ph); publish(0, it + 1); }
-            AR_STAMP(100);
-            await(1, cs.nB, 1);
-            AR_STAMP(101);
-            minus_c00(Cs1a);
-            chain_step15<false>(mL, s, true, av, Blk, CsT, lane, bad);                   // (coupling rows: EmL; next block: the separator)
-            publish(0, cs.nA + 1);
-            AR_STAMP(111);
-            await(2, cs.nD + 1, 1);
-            AR_STAMP(112);
-            minus_c00(CsB);
-            chain_step15<false>(s, s, false, av, Blk, CsT, lane, bad);
-            AR_STAMP(102);
-            back(s, -1);
-            AR_STAMP(103);
-        } else if (wv == 2) {
-            for (int it = 0; it < cs.nD; ++it) { const int i = W - 1 - it; chain_step15<true>(i, i - 1, true, av, Blk, CsB, lane, bad); publish(2, it + 1); }
-            WV_STAMP(114);
-            await(3, cs.nC, 1);
-            minus_c00(Cs3a);
-            // (next block = itself: the rows a step prefetches for its successor are not used here -- wavefront 0 forms the separator's block -- and
-            //  the separator's staged rows are still being updated by front B)
-            chain_step15<false>(mR, mR, true, av, Blk, CsB, lane, bad, nullptr, EmR);
-            publish(2, cs.nD + 1);
-            WV_STAMP(115);
-        } else if (wv == 1) {
-            v4f64 c11 = {0.0, 0.0, 0.0, 0.0}, racc = {0.0, 0.0, 0.0, 0.0};
-            for (int it = 0; it < cs.nB; ++it) {
-                const int i = s - 1 - it;
-                const bool last = it == cs.nB - 1;
-                chain_step15e<true>(i, i - 1, av, Blk, eslot(it), Cs1a, last ? EmL : eslot(it + 1), last ? KC_RS : KC_ERS, lane, bad, c11, racc);
-                if (last) { await(3, cs.nC, 1); inner_done(EmL, c11, racc); }
-                publish(1, it + 1);
-            }
-            WV_STAMP(113);
-        } else if (wv == 3) {
-            v4f64 c11 = {0.0, 0.0, 0.0, 0.0}, racc = {0.0, 0.0, 0.0, 0.0};
-            for (int it = 0; it < cs.nC; ++it) {
-                const int i = s + 1 + it;
-                const bool last = it == cs.nC - 1;
-                chain_step15e<false>(i, i + 1, av, Blk, eslot(cs.nB + it), Cs3a, last ? EmR : eslot(cs.nB + it + 1), last ? KC_RS : KC_ERS, lane, bad, c11, racc);
-                if (last) inner_done(EmR, c11, racc);
-                publish(3, it + 1);
-            }
-            WV_STAMP(116);
-        } else if (wv == 4) {
-            for (int k = 0; k < cs.nA; ++k) { await(0, k + 1, 2); chain_prepare_back(Blk + (size_t)k * KC_BLK, lane); }
-        } else if (wv == 5) {
-            for (int k = 0; k < cs.nB; ++k) { await(1, k + 1, 2); chain_prepare_back_e(Blk + (size_t)(s - 1 - k) * KC_BLK, eslot(k), lane); }
-        } else if (wv == 6) {
-            for (int k = 0; k < cs.nD; ++k) { await(2, k + 1, 2); chain_prepare_back(Blk + (size_t)(W - 1 - k) * KC_BLK, lane); }
-        } else if (wv == 7) {
-            for (int k = 0; k < cs.nC; ++k) { await(3, k + 1, 2); chain_prepare_back_e(Blk + (size_t)(s + 1 + k) * KC_BLK, eslot(cs.nB + k), lane); }
-        }
-        if (wv < 4) __builtin_amdgcn_s_setprio(0);
+        chain_f4_factor<false>(W, cs, Blk, CsT, CsB, f4m, zb, s_prog, lane, wv, bad, ph, a.dbg);
     } else if (wv == 0) {
         for (int it = 0; it < nT; ++it) {
             chain_step15<false>(it, it + 1, true, av, Blk, CsT, lane, bad, ph);
@@ -3013,45 +3181,7 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
             }
             GLIO_WAVE_LDS_SYNC();
         };
-        // four fronts: z_s is known; every wavefront starts from its segment's meeting block (the inner ones compute it privately).  The meeting
-        // blocks are solved by the triangular back substitution like the separator: preparing them as matrix-vector products would have to happen
-        // after the last elimination step, on the critical path
-        auto back_mv4 = [&](const int i, const double* znb, const double* Me, double* zout) {
-            const double* Bi = Blk + (size_t)i * KC_BLK;
-            const double* zs = zb + 15 * cs.s;
-            if (lane < KC_NB) {
-                double mrow[KC_NB], zn[KC_NB];
-#pragma unroll
-                for (int k = 0; k < KC_NB; ++k) { mrow[k] = Bi[(KC_NB + lane) * KC_RS + k]; zn[k] = znb[k]; }
-                double s0 = Bi[30 * KC_RS + lane], s1 = 0, s2 = 0;
-#pragma unroll
-                for (int k = 0; k < KC_NB; k += 3) { s0 -= mrow[k] * zn[k]; s1 -= mrow[k + 1] * zn[k + 1]; s2 -= mrow[k + 2] * zn[k + 2]; }
-                if (Me) {
-#pragma unroll
-                    for (int k = 0; k < KC_NB; ++k) { mrow[k] = Me[lane * KC_ERS + k]; zn[k] = zs[k]; }
-#pragma unroll
-                    for (int k = 0; k < KC_NB; k += 3) { s0 -= mrow[k] * zn[k]; s1 -= mrow[k + 1] * zn[k + 1]; s2 -= mrow[k + 2] * zn[k + 2]; }
-                }
-                zout[lane] = (s0 + s1) + s2;
-            }
-            GLIO_WAVE_LDS_SYNC();
-        };
-        if (f4) {
-            const int s = cs.s, mL = cs.mL, mR = cs.mR;
-            if (wv == 0) {
-                back(mL, s);
-                for (int i = mL - 1; i >= 0; --i) back_mv4(i, zb + 15 * (i + 1), nullptr, zb + 15 * i);
-            } else if (wv == 1) {
-                back(mL, s, Cs1a);
-                for (int i = mL + 1; i < s; ++i) back_mv4(i, i == mL + 1 ? Cs1a : zb + 15 * (i - 1), eslot(s - 1 - i), zb + 15 * i);
-            } else if (wv == 2) {
-                back(mR, s);
-                for (int i = mR + 1; i < W; ++i) back_mv4(i, zb + 15 * (i - 1), nullptr, zb + 15 * i);
-            } else if (wv == 3) {
-                back(mR, s, Cs3a);
-                for (int i = mR - 1; i > s; --i) back_mv4(i, i == mR - 1 ? Cs3a : zb + 15 * (i + 1), eslot(cs.nB + i - (s + 1)), zb + 15 * i);
-            }
-        }
+        if (f4) chain_f4_backsub<false>(W, cs, Blk, f4m, zb, lane, wv);
         else if (wv == 0) { for (int i = mid - 1; i >= 0; --i) back_mv(i, i + 1); }
         else if (wv == 1) { for (int i = mid + 1; i < W; ++i) back_mv(i, i - 1); }
         AR_STAMP(98);
@@ -3217,6 +3347,7 @@ void glio_chain_tabs_upload(glio_ctx* c) {
 }
 
 // which factorisation the trust-region step of this context takes for a state with n_ddt clock-drift unknowns:
+int glio_chain_kind(const glio_ctx* c, int n_ddt);
 // 2 = keyframe chain (k_chain_step, no dense H), 1 = arrow, 0 = dense
 int glio_solver_path(const glio_ctx* c, int n_ddt) {
     const int n = 15 * c->W + n_ddt;
@@ -3227,12 +3358,22 @@ int glio_solver_path(const glio_ctx* c, int n_ddt) {
     const bool lds_chol = lds_pk <= 160 * 1024;
     const size_t lds_slv = lds_chol ? lds_pk : glio_tr_step_lds_bytes(np) + arrow_solve_extra_doubles(c->W, K) * 8;
     const bool arrow = c->arrow.mode >= 1 && c->arrow.gnss_ok && c->arrow.prior_ok && c->arrow.max_epoch < n_ddt && lds_fwd <= 160 * 1024 && lds_slv <= 160 * 1024;
-    const size_t lds_chain = c->arrow.mode == 3 ? chain_lds_doubles(c->W, n_ddt) * 8 + 8 * 1024 : chain_step_lds_bytes(c->W, n_ddt, n, false) + 2 * 1024;
-    const bool chain = c->arrow.mode >= 1 && c->arrow.gnss_chain && c->arrow.prior_chain && c->arrow.max_epoch < n_ddt && lds_chain <= 158 * 1024;
-    return chain ? 2 : (arrow ? 1 : 0);
+    return glio_chain_kind(c, n_ddt) ? 2 : (arrow ? 1 : 0);
+}
+// which chain kernel: 0 none (graph not a chain / nothing fits), 1 = k_chain_step (one launch, blocks in LDS), 2 = the legacy sequence assemble +
+// k_chain_solve<false> + k_tr_finish (debug mode 3), 3 = the same sequence with k_chain_solve<true>: the blocks in global memory, for windows of
+// more keyframes than the LDS holds (C5: 50 keyframes, where the arrow factorisation costs ~420 us per step)
+int glio_chain_kind(const glio_ctx* c, int n_ddt) {
+    const int n = 15 * c->W + n_ddt;
+    if (!(c->arrow.mode >= 1 && c->arrow.gnss_chain && c->arrow.prior_chain && c->arrow.max_epoch < n_ddt)) return 0;
+    if (c->arrow.mode == 4) return 0;                          // (debug: the arrow factorisation although the graph is a chain)
+    if (c->arrow.mode == 3) return chain_lds_doubles(c->W, n_ddt) * 8 + 8 * 1024 <= 158 * 1024 ? 2 : 0;
+    if (chain_step_lds_bytes(c->W, n_ddt, n, false) + 2 * 1024 <= 158 * 1024) return 1;
+    if (c->W >= KC_F4_MIN_W && chain_lds_doubles_g(c->W, n_ddt) * 8 + 8 * 1024 <= 158 * 1024) return 3;
+    return 0;
 }
 // the linearisation must also build the dense H (k_assemble) unless the step is k_chain_step
-int glio_solver_needs_dense_H(const glio_ctx* c, int n_ddt) { return !(glio_solver_path(c, n_ddt) == 2 && c->arrow.mode != 3); }
+int glio_solver_needs_dense_H(const glio_ctx* c, int n_ddt) { return glio_chain_kind(c, n_ddt) != 1; }
 
 // GLIO_CHAIN_FAST (bit 0: tail, bit 1: front of k_chain_step from LDS; default both).  0 = the generic bodies: the A/B switch of
 // scripts/chain_step_time.py and of test_chain_step_fast_paths_are_bit_identical.
@@ -3275,8 +3416,9 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
     const size_t lds_slv = lds_chol ? lds_pk : glio_tr_step_lds_bytes(np) + arrow_solve_extra_doubles(c->W, K) * 8;
     const int path = glio_solver_path(c, n_ddt);
     const bool chain = path == 2, arrow = path >= 1;       // (arrow is only consulted when !chain)
-    const bool legacy_chain = chain && c->arrow.mode == 3;   // assemble + k_chain_solve + k_tr_finish (kept as the cross-check of k_chain_step)
-    const size_t lds_chain = chain_lds_doubles(c->W, n_ddt) * 8;
+    const int ckind = glio_chain_kind(c, n_ddt);
+    const bool legacy_chain = chain && ckind >= 2;   // assemble + k_chain_solve + k_tr_finish (cross-check of k_chain_step; with global blocks: long windows)
+    const size_t lds_chain = ckind == 3 ? chain_lds_doubles_g(c->W, n_ddt) * 8 : chain_lds_doubles(c->W, n_ddt) * 8;
     a.hd0 = nullptr; a.hd1 = nullptr;
     a.perm_mode = chain ? 1 : 0;
     c->arrow.last_path = chain ? 2 : (arrow ? 1 : 0);
@@ -3289,7 +3431,7 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
     if (chain) {
         ChainArgs r;
         r.W = c->W; r.n = a.n; r.nd = n_ddt; r.ep_slots = c->arrow.d_ep_slots; r.ep_off = c->arrow.d_ep_off; r.ep_list = c->arrow.d_ep_list;
-        r.z = c->arrow.d_z; r.flag = c->arrow.d_flag; r.status = c->d_status; r.dbg = c->arrow.d_dbg; r.force_fail = c->arrow.mode == 2; r.fast = chain_fast_mask();
+        r.z = c->arrow.d_z; r.flag = c->arrow.d_flag; r.status = c->d_status; r.dbg = c->arrow.d_dbg; r.force_fail = c->arrow.mode == 2; r.fast = chain_fast_mask(); r.blk = nullptr;
         if (chain_step_lds_bytes(c->W, n_ddt, a.n, true) + 2 * 1024 > 158 * 1024) r.fast = 0;      // no room for the LDS mirrors: generic bodies
         size_t lds_step = chain_step_lds_bytes(c->W, n_ddt, a.n, r.fast != 0);
         {   // separator + four fronts when the window is long enough for it to pay and its panels fit (chain_f4_layout)
@@ -3313,7 +3455,11 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
             hipLaunchKernelGGL(k_chain_step, dim3(1), dim3(KC_THREADS), lds_step, c->stream, r, a, G);
             return;                                   // the one launch is the whole step
         }
-        hipLaunchKernelGGL(k_chain_solve, dim3(1), dim3(KC_THREADS), lds_chain, c->stream, r, a);
+        if (ckind == 3) {
+            r.blk = c->arrow.d_blk; r.fronts4 = chain_fronts_mode() != 2 ? 1 : 0;
+            c->arrow.last_fronts = r.fronts4 ? 4 : 2;
+            hipLaunchKernelGGL(k_chain_solve<true>, dim3(1), dim3(KC_THREADS), lds_chain, c->stream, r, a);
+        } else hipLaunchKernelGGL(k_chain_solve<false>, dim3(1), dim3(KC_THREADS), lds_chain, c->stream, r, a);
     } else if (arrow) {
         ArrowArgs r;
         r.W = c->W; r.n = a.n; r.nd = n_ddt; r.np = np; r.K = K; r.ldY = np + 2;
@@ -3648,7 +3794,8 @@ int glio_tr_step_configure(size_t max_lds) {
     TR_CONF_(k_marg_schur, max_lds);
     TR_CONF_(k_arrow_forward, max_lds);
     TR_CONF_(k_arrow_solve, max_lds);
-    TR_CONF_(k_chain_solve, max_lds - 1024);
+    TR_CONF_(k_chain_solve<false>, max_lds - 1024);
+    TR_CONF_(k_chain_solve<true>, max_lds - 1024);
     TR_CONF_(k_chain_step, max_lds - 2048);
 #undef TR_CONF_
     return GLIO_OK;

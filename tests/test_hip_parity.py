@@ -450,13 +450,16 @@ def _steady(hip, W, pts, seed):
     return win, synth.analytic_correspondences(win)
 
 
-@pytest.mark.parametrize("W,use_gnss", [(12, True), (13, False), (16, True), (17, True), (20, True), (20, False), (21, True), (24, False)])
+@pytest.mark.parametrize("W,use_gnss", [(12, True), (13, False), (16, True), (17, True), (20, True), (20, False), (21, True), (24, False), (28, True), (41, False), (44, True)])
 def test_four_front_elimination(hip, po, W, use_gnss):
     """k_chain_step on windows of 12 keyframes and more: the middle keyframe as separator and four elimination fronts (chain_f4_split) instead of
     two.  A different elimination order of the same positive definite system: the iterates must agree with the two-front order and with the dense
     factorisation to rounding, iteration for iteration; the breakdown path (every step reports a bad pivot, the same workgroup rebuilds the system
     densely from the factor blocks) must still find its tables intact behind the four-front panels.  W = 24 without GNSS / W = 21 with its epochs
-    are where the panels no longer fit beside the LDS mirrors -- whatever layout the launch picks, the numbers must not care."""
+    are where the panels no longer fit beside the LDS mirrors -- whatever layout the launch picks, the numbers must not care.  From about 25
+    keyframes on the blocks themselves no longer fit the LDS: the sequence [band-only k_assemble, k_chain_solve<true>, k_tr_finish] keeps them in
+    global memory (same elimination, two or four fronts); its breakdown path reads the WHOLE dense matrix, i.e. relies on the zeros the host put
+    outside the band."""
     lib = hip.load()
     win, corr = _steady(hip, W, 300, 300 + W)
     far = _state_for(win, use_gnss)
