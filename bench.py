@@ -187,6 +187,26 @@ def main():
     except Exception as e:
         dense_variant = {"error": str(e)[:200]}
 
+    # ---- the steady-state solve at other window lengths (same construction as the headline, fewer points: the step does not depend on them).
+    # W = 22, 24: k_chain_step where the four-front panels / the LDS mirrors get tight; W = 30: the blocks no longer fit the LDS (k_chain_solve<true>)
+    window_sizes = {}
+    for Wx in (22, 24, 30):
+        try:
+            sx = synth.make_window(W=Wx + 1, pts_per_scan=8192, with_gnss=True, with_prior=False, seed=seed + Wx)
+            fx = synth.sub_window(sx, 0, Wx)
+            c0 = capi.Context(fx.opts, device=local_rank); c0.load_window(fx, synth.analytic_correspondences(fx))
+            s0x, _ = c0.solve(fx.init); px = c0.marginalize(s0x); c0.close()
+            wx = synth.sub_window(sx, 1, Wx); wx.prior = px
+            cx = capi.Context(wx.opts, device=local_rank); cx.load_window(wx, synth.analytic_correspondences(wx))
+            solx, smx = cx.solve(wx.init)
+            msx, _ = cx.time_solve(wx.init, 20)
+            window_sizes[f"W{Wx}"] = {"unknowns": 15 * Wx + int(wx.init.n_ddt), "points_per_keyframe": 8192, "ms_per_solve": round(msx, 4), "iterations": int(smx.iterations),
+                                      "tr_step_us": round(cx.time_kernel(capi.KERNEL_TR_STEP, 20) * 1e3, 2), "solver_path": int(capi.load().glio_debug_solver_path(cx._h)),
+                                      "chain_fronts": int(capi.load().glio_debug_chain_fronts_used(cx._h))}
+            cx.close()
+        except Exception as e:  # noqa: BLE001 -- informational
+            window_sizes[f"W{Wx}"] = {"error": str(e)[:200]}
+
     # ---- roofline of the dominant kernel (K3), HIP events on the context stream
     ctx.linearize(state, want_H=False)
     k3_ms = ctx.time_kernel(capi.KERNEL_LIDAR_LINEARIZE, 50)
@@ -354,6 +374,7 @@ def main():
         "iterations": int(summ.iterations), "ms_per_iteration": round(ms_per_step / max(1, int(summ.iterations)), 4),
         "termination": int(summ.termination), "solver_path": {0: "dense", 1: "arrow", 2: "keyframe chain"}.get(int(capi.load().glio_debug_solver_path(ctx._h)), "?"),
         "dense_prior_variant": dense_variant,
+        "window_sizes": window_sizes,
         "kernels_us": {"lidar_linearize": round(k3_ms * 1e3, 2), "full_linearize": round(lin_ms * 1e3, 2), "tr_step": round(trs_ms * 1e3, 2),
                        "marginalize": round(marg_ms * 1e3, 2), "marginalize_call_incl_readback": round(marg_call_ms * 1e3, 1)},
         "roofline": roofline, "cpu_baseline": cpu, "cpu_baselines_other_configs": cpu_more, "pose_vs_oracle": pose_err, "association": assoc,
@@ -741,7 +762,10 @@ def bench_c5(local_rank, W=50, pts=262144):
                      "read_only_same_bytes_GBps": round(n_res * bpr / (rd * 1e-3) / 1e9, 1), "linearize_all_us": round(la * 1e3, 2),
                      "residuals_per_s": round(n_res / (k3 * 1e-3) / 1e9, 2), "solves_per_s": round(1.0 / dt, 2), "ms_per_solve": round(dt * 1e3, 3),
                      "iterations": int(summ.iterations), "termination": int(summ.termination), "final_cost": float(summ.final_cost),
-                     "solver_path": int(capi.load().glio_debug_solver_path(ctx._h))}
+                     "solver_path": int(capi.load().glio_debug_solver_path(ctx._h)),
+                     "tr_step_us": round(ctx.time_kernel(capi.KERNEL_TR_STEP, 10) * 1e3, 2),
+                     "step_kernels": "band-only k_assemble + k_chain_solve<true> (keyframe chain, blocks in global memory, four fronts) + k_tr_finish"
+                                     if capi.load().glio_debug_solver_path(ctx._h) == 2 else "k_assemble + arrow / dense factorisation"}
         if prec == 1:
             sol32 = sol
             # useful MFMA work: 8 x v_mfma_f32_16x16x4_f32 (2048 flop each) per 64 residuals
