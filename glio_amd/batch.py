@@ -483,8 +483,13 @@ class RoundsAssociation:
             caps = [len(self.parts[0][1]) * self.maxpts, int(self.parts[1][0].total) if len(self.parts[1][1]) else 0, len(self.parts[2][1]) * self.maxpts]
             self._base = [0, caps[0], caps[0] + caps[1]]
             ntot = max(1, sum(caps))
-            self._buf = (torch.empty((ntot, 4), dtype=torch.float32, device=dev), torch.empty((ntot, 6), dtype=torch.float64, device=dev),
-                         torch.empty((ntot,), dtype=torch.float64, device=dev))
+            # (an existing set of arrays is reused when it is large enough: a fresh 44 GB allocation costs 1.3 s of page-table set-up at C4 size,
+            #  four times the association of all pairs itself -- scripts/batch_assoc_probe.py)
+            if getattr(self, "_buf", None) is None or self._buf[0].shape[0] < ntot:
+                self._buf = None
+                self.stage._keep = None
+                self._buf = (torch.empty((ntot, 4), dtype=torch.float32, device=dev), torch.empty((ntot, 6), dtype=torch.float64, device=dev),
+                             torch.empty((ntot,), dtype=torch.float64, device=dev))
         which_copy = (0, 1, 2) if first else tuple(changed)
         for w in which_copy:
             ba, pci, pcj = self.parts[w]
@@ -522,7 +527,6 @@ class RoundsAssociation:
         """all three sets at `poses` (the stored interior constraints are made here)"""
         for w in range(3):
             self._run(w, poses)
-        self._buf = None
         self._feed()
 
     def __call__(self, poses):
