@@ -56,6 +56,12 @@ def main():
     if args.dry_run:
         return dry_run()
 
+    # exactly ONE line on stdout: libraries print there too (RCCL's version banner when a communicator is created, from C stdio at exit), so the
+    # process's stdout descriptor points at stderr for the whole run and the JSON line goes to a private copy of the original descriptor
+    sys.stdout.flush()
+    out_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -386,7 +392,8 @@ def main():
         c3_info.pop("_cpu_sample", None)
     if cpu and "value" in cpu:
         line["speedup_vs_cpu_port"] = round(value / world / cpu["value"], 1)
-    print(json.dumps(line))
+    sys.stdout.flush()
+    os.write(out_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -1121,6 +1128,42 @@ def bench_batch_end_to_end(local_rank, torch, K, pts=32768, search_range=6, dist
     return info
 
 
+def measure_allreduce_calls(torch, local_rank, sizes, reps=20):
+    """What one stream-ordered all-reduce CALL of each of the given sizes (doubles) costs on the communicator at hand: the job's own when bench.py runs
+    on several ranks, else a ONE-rank RCCL communicator created for the purpose -- that one has no link to cross, so it measures the call itself
+    (launch, the RCCL kernel's set-up and its copy), the floor under any N-rank figure.  Device time by events around `reps` back-to-back calls."""
+    import torch.distributed as dist
+    own = False
+    if not dist.is_initialized():
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        own = True
+    try:
+        if dist.get_backend() != "nccl":
+            return None
+        out = []
+        for n in sizes:
+            t = torch.zeros(int(n), dtype=torch.float64, device=f"cuda:{local_rank}")
+            for _ in range(3):
+                dist.all_reduce(t)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record()
+            for _ in range(reps):
+                dist.all_reduce(t)
+            e1.record()
+            host = (time.perf_counter() - t0) / reps
+            torch.cuda.synchronize()
+            out.append({"doubles": int(n), "device_us_per_call": round(e0.elapsed_time(e1) * 1e3 / reps, 2), "host_us_per_call": round(host * 1e6, 2)})
+        return {"world": dist.get_world_size(), "calls": out}
+    finally:
+        if own:
+            dist.destroy_process_group()
+
+
 def project_sharded(K, band, per_kf, gt, init, odo, sr, dd, frame, local_rank, torch, vworld=8, iters=6):
     """What ONE rank of a `vworld`-rank job does per trust-region group, measured on this one GPU: the sharded solve is first run
     with `vworld` virtual ranks (threads; the hook sums their buffers) while the all-reduced buffers are recorded, then a single
@@ -1179,13 +1222,24 @@ def project_sharded(K, band, per_kf, gt, init, odo, sr, dd, frame, local_rank, t
     groups = max(cnt["groups"], 1)
     sizes = stages[who].allreduce_sizes
     per_group = sizes[1:6] if len(sizes) >= 6 else sizes
-    lat_us, bw_GBps = 25.0, 100.0           # ASSUMED: small-message all-reduce latency on 8 GPUs over xGMI; effective all-reduce bandwidth
-    comm_us = sum(lat_us + 8.0 * n / (bw_GBps * 1e3) for n in per_group)
     for s in stages:
         s.close()
+    # the collectives: the CALL is measured (one-rank RCCL communicator on this GPU: launch + the RCCL kernel with nothing to cross), the links are not --
+    # per all-reduce = measured call + ASSUMED ring latency over 8 GPUs + bytes at an ASSUMED effective all-reduce bandwidth
+    measured = None
+    try:
+        measured = measure_allreduce_calls(torch, local_rank, per_group)
+    except Exception as e:  # noqa: BLE001 -- informational
+        measured = {"error": str(e)[:200]}
+    ring_us, bw_GBps = 15.0, 100.0          # ASSUMED: 2 (N - 1) = 14 hops of ~1 us over xGMI; effective all-reduce bandwidth
+    call_us = [c["device_us_per_call"] for c in measured["calls"]] if measured and "calls" in measured else [25.0] * len(per_group)
+    lat_us = float(np.mean(call_us)) + ring_us
+    comm_us = sum(cu + ring_us + 8.0 * n / (bw_GBps * 1e3) for cu, n in zip(call_us, per_group))
     return {"what": f"rank {who} of {vworld} run alone on this GPU with the recorded all-reduce results replayed ({summ.iterations} iterations, {groups} kernel groups); full problem, 15 states",
             "compute_ms_per_group_this_rank": round(wall * 1e3 / groups, 3), "allreduce_doubles_per_group": [int(n) for n in per_group],
-            "assumed_collective": f"{lat_us} us latency + {bw_GBps} GB/s effective per all-reduce (NOT measured: one GPU here)",
+            "measured_allreduce_call_one_rank": measured,
+            "assumed_collective": f"measured one-rank call ({[round(c, 1) for c in call_us]} us by size) + {ring_us} us ring latency (ASSUMED) + {bw_GBps} GB/s effective (ASSUMED) per all-reduce; "
+                                  f"mean {lat_us:.1f} us + bytes / bandwidth -- the links are NOT measured: one GPU here",
             "assumed_comm_ms_per_group": round(comm_us / 1e3, 3), "projected_ms_per_group": round(wall * 1e3 / groups + comm_us / 1e3, 3),
             "same_result_as_virtual_run": bool(np.abs(out[0] - res[0][0]).max() < 1e-9)}
 
