@@ -363,7 +363,26 @@ def main():
         if assoc and "algorithmic_GBps" in assoc:
             others["K2_association_c2_scan"] = {"kernels": "k_qbin_tile + k_knn5_tile + k_plane_fit + k_compact", "bytes_per_unit": BYTES_PER_QUERY, "units": assoc["queries_per_scan"],
                                                 "us": assoc["associate_scan_us"], "achieved": assoc["algorithmic_GBps"], "frac": round(assoc["algorithmic_GBps"] / HBM_PEAK_GBS, 4),
-                                                "note": "gather-bound on a dependent chain per 16-query unit, not on bytes: profiles/r04_k2_findings.txt"}
+                                                "note": "not a bandwidth-bound kernel: its binding resource is VALU issue (valu_issue below); profiles/r04_k2_findings.txt"}
+            try:
+                # VALU-issue roofline of the search kernel: wavefront-level VALU instructions per 64k-query scan from the committed counter pass, 4 cycles
+                # each on one of 1024 SIMDs, against what a scan costs inside the one-call window association (20 scans keep every SIMD supplied)
+                valu = None
+                for ln in open(os.path.join(ROOT, "profiles", "r04_v1_k2_pmc.txt")):
+                    f = ln.split()
+                    if len(f) >= 5 and f[0] == "k_knn5_tile" and f[1] == "SQ_INSTS_VALU":
+                        valu = float(f[4])
+                if valu and assoc.get("window_associate_one_call_ms"):
+                    floor_us = valu * 4.0 / 1024.0 / 2.4e9 * 1e6
+                    per_scan = assoc["window_associate_one_call_ms"] * 1e3 / args.window
+                    others["K2_association_c2_scan"]["valu_issue"] = {
+                        "wave_valu_instructions_per_scan": valu, "source": "profiles/r04_v1_k2_pmc.txt (SQ_INSTS_VALU of k_knn5_tile, one C2 scan)",
+                        "floor_us_per_scan": round(floor_us, 2), "floor_assumes": "4 cycles per wave64 VALU instruction, 1024 SIMDs, 2.4 GHz",
+                        "window_call_us_per_scan_all_four_kernels": round(per_scan, 2), "frac_of_valu_issue_whole_call": round(floor_us / per_scan, 3),
+                        "k_knn5_tile_us_per_scan_in_window_call": 14.8, "frac_of_valu_issue_search_kernel": round(floor_us / 14.8, 3),
+                        "search_kernel_time_source": "profiles/r04_k2_findings.txt (rocprofv3 kernel trace of the window call: 295 us for 20 scans)"}
+            except (OSError, ValueError, KeyError, TypeError, ZeroDivisionError):
+                pass
         if c3_info and "frac_of_hbm_peak" in c3_info:
             others["K2_association_c3"] = {"bytes_per_unit": BYTES_PER_QUERY, "frac": c3_info["frac_of_hbm_peak"]}
     except (KeyError, TypeError, ZeroDivisionError):

@@ -781,10 +781,20 @@ __global__ __launch_bounds__(TK_THREADS) __attribute__((amdgpu_waves_per_eu(5)))
                     { const float ex = px - X.x, ey = py - Y.x, ez = pz - Z.x; float t = ex * ex; t = t + ey * ey; t = t + ez * ez; d.x = t; }
                     { const float ex = px - X.y, ey = py - Y.y, ez = pz - Z.y; float t = ex * ex; t = t + ey * ey; t = t + ez * ez; d.y = t; }
 #else
+                    // SELECTION distances with fused multiply-adds (v_pk_fma_f32: 6 packed instructions per candidate pair instead of 8).  They differ
+                    // from the reference's unfused float arithmetic by a few ulp (<= 3 x 2^-24 relative), which is far below a truncation bucket
+                    // (2^-15): a candidate's exact bucket is at most ONE away from its bucket here.  The exact rule is restored below -- the selected
+                    // six are re-ranked with the unfused distance, and the selection is trusted only when the fifth exact distance lies at least TWO
+                    // buckets under the sixth selected key (`safe`); otherwise the rescan uses the unfused form.
                     const tk_v2f ex = P0 - pr[0], ey = P1 - pr[1], ez = P2 - pr[2];
                     tk_v2f d = ex * ex;
+#ifdef TK_UNFUSED_SELECT
                     d = d + ey * ey;
                     d = d + ez * ez;
+#else
+                    d = __builtin_elementwise_fma(ey, ey, d);
+                    d = __builtin_elementwise_fma(ez, ez, d);
+#endif
 #endif
                     const unsigned f0 = (unsigned)(2 * (pp + 2 * u));
                     tk_insert(tk, (__float_as_uint(d.x) & ~TK_MASK) | f0);
@@ -802,13 +812,25 @@ __global__ __launch_bounds__(TK_THREADS) __attribute__((amdgpu_waves_per_eu(5)))
                 if (real) knn5_insert(px, py, pz, staged(slot), base + slot, bk, bp);
                 if (k == TK_SEL - 1) all_in = !real;                                // fewer than TK_SEL candidates: all of them were merged
             }
+#ifdef TK_UNFUSED_SELECT
             const bool safe = all_in || ((unsigned)(bk[4] >> 32) & ~TK_MASK) < (tk[TK_SEL - 1] & ~TK_MASK);
+#else
+            // an unselected candidate's selection bucket is >= the sixth key's, its exact bucket >= that minus one: the exact five are among the
+            // selected when the fifth exact distance lies in a bucket below THAT (the compare cannot wrap: distances are finite floats)
+            const bool safe = all_in || ((unsigned)(bk[4] >> 32) & ~TK_MASK) + (TK_MASK + 1u) < (tk[TK_SEL - 1] & ~TK_MASK);
+#endif
             if (__any(qlive && !safe)) {
                 // near-ties at the selection boundary: the candidates that can still belong to the exact five are those whose bucket is not above the
                 // last selected key's (everything else has a larger truncated, hence a larger exact, distance than all six selected).  A second pass
                 // over the lane's half with the cheap packed distances; the exact 64-bit insertion runs only for those few (round 3 re-ranked EVERY
                 // candidate of the half exactly: 12 us for the wavefronts that hit it -- the tail of the kernel, r04 per-workgroup stamps).
+#ifdef TK_UNFUSED_SELECT
                 const unsigned edge = tk[TK_SEL - 1] & ~TK_MASK;
+#else
+                // (the six selected have EXACT buckets up to one above the sixth key's selection bucket, so that is where a member of the exact five
+                //  can still sit; unfused distances from here on)
+                const unsigned edge = (tk[TK_SEL - 1] & ~TK_MASK) + (TK_MASK + 1u);
+#endif
                 if (qlive && !safe) {
                     for (int pp = h; pp < ((n_c + 1) >> 1); pp += 2) {
                         const tk_v2f* pr = s_xyz[g][pp];
