@@ -487,14 +487,17 @@ __global__ __launch_bounds__(256) void k_knn5(const AssocArgs a, const float4* _
 //   k_qbin_tile   per 1024 consecutive presorted points: transformPoint, cell, grouping by cell in an LDS hash table (LDS
 //                 atomics only; one global atomic per workgroup for its range of the unit list), grouped queries written out;
 //   k_knn5_tile   per unit, 32 lanes (16 queries x 2 halves of the candidate list): the 27 cells are probed ONCE, their points
-//                 staged in LDS, then every lane scans its half of the staged list for its own query: 8 VALU for the float
-//                 distance + 8 for a seven-deep sorted insertion on 32-bit keys (v_min_u32 + 6 v_med3_u32) per candidate.
+//                 staged in LDS (in pairs, structure of arrays), then every lane scans its half of the staged list for its own
+//                 query: 6 packed VALU per candidate PAIR for the two float distances (v_pk_add / v_pk_mul / v_pk_fma) + 2 x 7 for
+//                 the keys and a six-deep sorted insertion on 32-bit keys (v_and_or_b32, v_min_u32 + 5 v_med3_u32).
 // The 32-bit key is (distance bits with the low 8 bits replaced by the LDS slot): unsigned order = distance order up to
-// 2^-15 relative.  The exact ranking rule of the reference-equivalent search -- float distance, then original map index --
-// is restored afterwards: the seven selected candidates are re-evaluated exactly (64-bit keys) and merged into the lane's
-// running top five; the selection provably contains the exact top five of what the lane scanned when the fifth exact distance
-// lies in a strictly lower truncation bucket than the seventh selected key (anything not selected has a key, hence a bucket, at
-// least as large).  When it does not (four near-ties inside 2^-15), the lane rescans with exact keys.  The two halves are merged
+// 2^-15 relative.  The exact ranking rule of the reference-equivalent search -- float distance (UNFUSED, as FLANN's L2 computes it),
+// then original map index -- is restored afterwards: the six selected candidates are re-evaluated exactly (64-bit keys) and merged
+// into the lane's running top five.  The selection distances use fused multiply-adds (a few ulp off the unfused value: at most one
+// truncation bucket), so the selection provably contains the exact top five of what the lane scanned when the fifth exact distance
+// lies at least TWO buckets under the sixth selected key (anything not selected has a selection bucket at least as large as that
+// key's, hence an exact bucket at most one below it).  When it does not (near-ties inside 2^-14), the lane rescans with the unfused
+// distance and exact keys.  The two halves are merged
 // at the end.  The order of the queries inside a cell and of the units in memory is arbitrary; the results are not: every query
 // is independent and written at its own index.
 #define TK_Q 16
