@@ -22,8 +22,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _window():
-    stream = synth.make_window(W=9, pts_per_scan=3000, with_gnss=True, with_prior=False, seed=synth.SEED_BASE + 41)
+def _window(W=8):
+    stream = synth.make_window(W=W + 1, pts_per_scan=3000 if W <= 8 else 800, with_gnss=True, with_prior=False, seed=synth.SEED_BASE + 41)
     return stream
 
 
@@ -37,12 +37,13 @@ import sys, numpy as np
 sys.path.insert(0, %r); sys.path.insert(0, %r)
 from glio_amd import capi, synth
 from test_hip_soak import _window, _digest
-stream = _window()
-first = synth.sub_window(stream, 0, 8)
+W = %d
+stream = _window(W)
+first = synth.sub_window(stream, 0, W)
 ctx0 = capi.Context(first.opts); ctx0.load_window(first, synth.analytic_correspondences(first))
 sol0, _ = ctx0.solve(first.init)
 prior = ctx0.marginalize(sol0); ctx0.close()
-win = synth.sub_window(stream, 1, 8); win.prior = prior            # steady state: the keyframe-chain solver path
+win = synth.sub_window(stream, 1, W); win.prior = prior            # steady state: the keyframe-chain solver path
 corr = synth.analytic_correspondences(win)
 ref = None
 ctx = capi.Context(win.opts); ctx.load_window(win, corr)
@@ -51,26 +52,34 @@ for k in range(%d):
     ref = ref or d
     assert d == ref, f"reused context: solve {k} differs"
 path = capi.load().glio_debug_solver_path(ctx._h)
+fronts = capi.load().glio_debug_chain_fronts_used(ctx._h)
 ctx.close()
 for k in range(%d):
     c = capi.Context(win.opts); c.load_window(win, corr)
     for j in range(3):
         assert _digest(*c.solve(win.init)) == ref, f"fresh context {k}, solve {j} differs"
     c.close()
-print("SOAK_OK", path, ref[4])
+print("SOAK_OK", path, fronts, ref[4])
 """
 
 
-@pytest.mark.parametrize("poison", [False, True], ids=["plain", "lds_poison_nan_fill"])
-def test_repeated_solves_are_bit_identical(poison):
+@pytest.mark.parametrize("W,poison", [(8, False), (8, True), (20, False), (20, True), (28, False), (28, True)],
+                         ids=["plain", "lds_poison_nan_fill", "four_fronts", "four_fronts_lds_poison_nan_fill", "global_blocks", "global_blocks_lds_poison_nan_fill"])
+def test_repeated_solves_are_bit_identical(W, poison):
+    """W = 20: k_chain_step with the separator and four fronts -- its hand-overs are flags in LDS polled by eight wavefronts, so the interleaving differs
+    from run to run while every number must not; W = 28: the chain with its blocks in global memory (k_chain_solve<true>, band-only k_assemble)."""
     env = dict(os.environ)
     if poison:
         env["GLIO_DEBUG_LDS_POISON"] = "1"
         env["GLIO_DEBUG_FILL"] = "255"
     n_reuse, n_fresh = (300, 25) if not poison else (120, 10)
-    out = subprocess.run([sys.executable, "-c", _SOAK_SCRIPT % (ROOT, os.path.join(ROOT, "tests"), n_reuse, n_fresh)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    if W > 8:
+        n_reuse, n_fresh = n_reuse // 2, n_fresh // 2
+    out = subprocess.run([sys.executable, "-c", _SOAK_SCRIPT % (ROOT, os.path.join(ROOT, "tests"), W, n_reuse, n_fresh)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "SOAK_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
-    assert out.stdout.split("SOAK_OK")[1].split()[0] == "2", "the steady-state window must take the keyframe-chain path"
+    f = out.stdout.split("SOAK_OK")[1].split()
+    assert f[0] == "2", "the steady-state window must take the keyframe-chain path"
+    assert f[1] == ("2" if W == 8 else "4"), "elimination fronts"
 
 
 def test_sliding_window_and_batch_contexts_from_two_threads():
