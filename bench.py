@@ -774,6 +774,10 @@ def bench_c5(local_rank, W=50, pts=262144):
         ctx = capi.Context(o, device=local_rank)
         ctx.load_window(win, corr)
         ctx.linearize(win.init, want_H=False)
+        # warm-up: the first few hundred launches after the seconds of host-side set-up (window generation, uploads) run at ramping clocks -- whichever
+        # form is measured first lost 10-25 % to that (scripts/c5_window_vs_random.py: 85-101 us in the first round of a sweep, 75-77 us afterwards)
+        for _ in range(6):
+            ctx.time_kernel(capi.KERNEL_LIDAR_LINEARIZE, 50)
         k3 = float(np.mean([ctx.time_kernel(capi.KERNEL_LIDAR_LINEARIZE, 20) for _ in range(3)]))
         rd = float(np.mean([ctx.time_kernel(capi.KERNEL_STREAM_READ, 20) for _ in range(3)]))
         la = float(np.mean([ctx.time_kernel(capi.KERNEL_LINEARIZE_ALL, 20) for _ in range(3)]))
