@@ -132,6 +132,9 @@ struct ArrowDev {
     double* d_Sp;             // (6W+1) x 6W pose Schur complement + carried right-hand side
     double* d_z;              // [n] solution in elimination order
     int* d_flag;              // 0 running, 1 breakdown, 2 solved
+    double* d_chain_sum;      // [W][GLIO_CS_STRIDE] k_chain_step's helper workgroups: the candidate's block entries summed over their six sources
+    int* d_chain_done;        // [W] their completion words: 2 * sequence number + (produced ? 1 : 0)
+    int chain_seq;            // sequence number of the next k_chain_step launch (kernel argument)
     long long* d_dbg;         // [64] wall-clock stamps of the last launch (100 MHz), development aid
 };
 

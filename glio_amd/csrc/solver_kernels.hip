@@ -506,6 +506,9 @@ struct PrepMirror {
     const double* hd; const double* g; const double* cost;     // diag(H), g, cost of the candidate
     double* scale; double* diag; double* grad;                 // scale: the global vector on entry (phase > 0); all three are left filled for the caller
     long long* dbg;                                            // stamped builds: device-clock marks of the state machine's sections (slots 80..)
+    // k_chain_step's helper workgroups read the status record this function rewrites at its end: their completion words (2 * hseq + produced) are
+    // requested at entry and checked before that store; *hprod is cleared when one of them had nothing to produce
+    const int* hdone; int hseq; int helpers; int* hprod;
 };
 #ifdef GLIO_DEV_STAMPS
 #define PM_STAMP(k) do { if (FAST && m->dbg && threadIdx.x == 0) m->dbg[k] = wall_clock64(); } while (0)
@@ -526,6 +529,8 @@ __device__ __forceinline__ bool tr_prepare_body(const TrArgs& a, TrDecision* out
         s.group += 1;
         a.status->group = s.group;
     }
+    int hword = 0;
+    if (FAST && m->helpers && tid < m->helpers) hword = __hip_atomic_load(&m->hdone[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     PB_SYNC();
     if (s.done) return false;
     PM_STAMP(80);
@@ -679,6 +684,12 @@ __device__ __forceinline__ bool tr_prepare_body(const TrArgs& a, TrDecision* out
                 u[i] = scale[i] * (gs / dd) / dd;
             }
         }
+    }
+    if (FAST && m->helpers && tid < m->helpers) {
+        // (relaxed polling: the reader of the helpers' sums issues the acquire fence; the barrier below puts every helper's read of the record
+        //  before the store that replaces it)
+        while ((hword >> 1) != m->hseq) { __builtin_amdgcn_s_sleep(1); hword = __hip_atomic_load(&m->hdone[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        if (!(hword & 1)) *m->hprod = 0;
     }
     PB_SYNC();
     PM_STAMP(86);
@@ -2092,6 +2103,9 @@ struct ChainArgs {
                               // state machine) from LDS; 0 = the generic bodies that talk through the global work vectors (GLIO_CHAIN_FAST, default 3)
     int fronts4;              // 1 = separator + four fronts (chain_f4_split), 0 = two fronts
     double* blk;              // k_chain_solve<true>: [W][KC_BLK] the staged blocks in global memory (windows whose blocks do not fit the LDS)
+    // k_chain_step's helper workgroups (grid = 1 + helpers): workgroup 1 + i sums the candidate's block entries of keyframe i over their six sources
+    // while workgroup 0 runs the front and the state machine; hsum [W][GLIO_CS_STRIDE], hdone [W] = 2 * hseq + produced
+    int helpers; int hseq; double* hsum; int* hdone;
 };
 
 // The kernel also does the work of k_tr_prepare (state machine, scaling vectors) and of k_tr_scale for this structure: it
@@ -2620,8 +2634,68 @@ struct ChainBuilder {
     }
 };
 
+// Helper workgroup of k_chain_step for keyframe i (blockIdx.x = 1 + i).  The block gather of the step reads 276 KB that the factor roles left in six
+// places -- what ONE compute unit can pull in is what that phase costs (6.2 us).  The sums themselves depend on nothing the main workgroup decides
+// (only on which buffer holds the candidate: the status record as the previous kernel left it), so W otherwise idle compute units form them
+// while workgroup 0 gathers diag / g / cost and runs the state machine; it then reads 55 KB of sums.  Every entry is the same sum in the same
+// order as gather_store forms it (LiDAR partial sum first, then the five slices), so the step stays bit-identical.  (Measured: all helpers on
+// workgroup 0's XCD -- grid 1 + 8 W, seven of eight workgroups idle -- read back no faster and delayed the front by 12 us.)  The helper ALWAYS reports
+// (2 * hseq + produced): workgroup 0 waits for all of them before its state machine rewrites the status record they read.
+__device__ __forceinline__ void chain_step_helper(const ChainArgs& a, const TrArgs& tr, const GatherArgs& G, const int i) {
+    __shared__ double h_lid[GLIO_LIDAR_ACC];
+    __shared__ int h_go, h_cand;
+    const int tid = threadIdx.x, W = a.W;
+    if (tid == 0) {
+        const SolverStatus st = *tr.status;
+        h_go = (!st.done && st.cand_pending) ? 1 : 0;
+        h_cand = 1 - st.cur;
+    }
+    __syncthreads();
+    const int go = h_go, cand = h_cand;
+    if (go) {
+        if (tid < GLIO_LIDAR_ACC) {          // the keyframe's K3 partials, added in index order (kc_reduce_lidar)
+            const int lnb = G.lidar_nb;
+            const double* p = G.lidar_partials + (size_t)cand * G.lidar_pstride + (size_t)i * lnb * GLIO_LIDAR_ACC + tid;
+            double sacc = 0;
+            for (int k0 = 0; k0 < lnb; k0 += 24) {
+                double vb[24];
+#pragma unroll
+                for (int q = 0; q < 24; ++q) vb[q] = p[(size_t)(k0 + q < lnb ? k0 + q : k0) * GLIO_LIDAR_ACC];
+#pragma unroll
+                for (int q = 0; q < 24; ++q) sacc += k0 + q < lnb ? vb[q] : 0.0;
+            }
+            h_lid[tid] = sacc;
+        }
+        double v[5];
+        int lix = -1;
+        const int w = tid < 345 ? tid : 0;
+        {
+            int r30, j;
+            if (w < 120) { int r = 0; while ((r + 1) * (r + 2) / 2 <= w) ++r; r30 = r; j = w - r * (r + 1) / 2; }
+            else { r30 = 15 + (w - 120) / 15; j = (w - 120) % 15; }
+            lix = (r30 < 6 && j < 6) ? kc_lidar_sym_index(j, r30) : -1;
+            const double* p = G.chain_src + (((size_t)cand * W + i) * GLIO_CS_SOURCES) * GLIO_CS_STRIDE + w;
+#pragma unroll
+            for (int sidx = 0; sidx < 5; ++sidx) v[sidx] = p[sidx * GLIO_CS_STRIDE];
+        }
+        __syncthreads();
+        if (tid < 345) {
+            double h = 0;
+            h += lix >= 0 ? h_lid[lix] : 0.0;
+            h += v[0]; h += v[1]; h += v[2]; h += v[3]; h += v[4];
+            a.hsum[(size_t)i * GLIO_CS_STRIDE + tid] = h;
+        }
+    }
+    __threadfence();                                   // (agent scope: the sums leave this XCD's L2 before the completion word does)
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&a.hdone[i], 2 * a.hseq + go, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, const TrArgs tr, const GatherArgs G) {
     static_assert(KC_THREADS == TR_THREADS, "tr_prepare_body runs with the chain kernel's workgroup");
+    if (blockIdx.x > 0) {
+        chain_step_helper(a, tr, G, (int)blockIdx.x - 1); return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int W = a.W, n = a.n, nd = a.nd;
     const int np15 = 15 * W;
@@ -2837,6 +2911,22 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
         __threadfence();
     }
     if (ff) GLIO_BLOCK_LDS_SYNC(); else __syncthreads();
+    // ---- the helper workgroups: every one of them has read the status record (and left its sums) before the state machine rewrites that record.
+    // With the LDS-resident front the state machine checks their completion words itself, just before that store (PrepMirror); the generic body
+    // has no such hook: wait here.
+    __shared__ int s_hprod;
+    if (a.helpers) {
+        if (tid == 0) s_hprod = 1;
+        GLIO_BLOCK_LDS_SYNC();
+        if (!ff) {
+            if (tid < a.helpers) {
+                int v;
+                while (((v = __hip_atomic_load(&a.hdone[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 1) != a.hseq) __builtin_amdgcn_s_sleep(1);
+                if (!(v & 1)) s_hprod = 0;
+            }
+            GLIO_BLOCK_LDS_SYNC();
+        }
+    }
     AR_STAMP(42);
     // ---- state machine (reads the vectors just written: nothing of them was loaded earlier in this kernel)
     TrDecision dec;
@@ -2844,6 +2934,7 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
     if (ff) {
         PrepMirror pm;
         pm.st_in = &s_in; pm.x0 = xm0; pm.x1 = xm1; pm.hd = sHd; pm.g = sG; pm.cost = sCost; pm.scale = sS; pm.diag = sDg; pm.grad = sGr; pm.dbg = a.dbg;
+        pm.hdone = a.hdone; pm.hseq = a.hseq; pm.helpers = a.helpers; pm.hprod = &s_hprod;
         if (!tr_prepare_body<true>(tr, &dec, &pm)) return;
     } else if (!tr_prepare_body(tr, &dec)) return;
     AR_STAMP(43);
@@ -2936,7 +3027,41 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
     AR_STAMP(93);
     for (int e = tid; e < nd; e += KC_THREADS) yd[e] = Rld(e) * rd[e];
     AR_STAMP(44);
-    {
+    if (a.helpers && s_hprod && s_pending && dec.cur == cand) {
+        // the sums the helper workgroups left (same entries, same order of additions): 55 KB in one round of 16-byte loads instead of 276 KB.
+        // (Requesting them before the state machine and holding 36 registers across it was measured: the phases in between got slower by what this
+        //  one gained.)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // (every wavefront: the completion words were read by the first W threads only)
+        constexpr int KH = 7;
+        for (int q0 = tid; q0 < gtotal; q0 += KH * KC_THREADS) {
+            v2f64 hv[KH];
+#pragma unroll
+            for (int u = 0; u < KH; ++u) {
+                const int q = q0 + u * KC_THREADS;
+                const int qq = q < gtotal ? q : tid;
+                const int i = qq / GPAIRS, w = 2 * (qq - GPAIRS * i);
+                hv[u] = *reinterpret_cast<const v2f64*>(a.hsum + (size_t)i * GLIO_CS_STRIDE + w);
+            }
+#pragma unroll
+            for (int u = 0; u < KH; ++u) {
+                const int q = q0 + u * KC_THREADS;
+                if (q >= gtotal) continue;
+                const int i = q / GPAIRS, w0 = 2 * (q - GPAIRS * i);
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int w = w0 + h2;
+                    if (w >= 345) continue;
+                    const int r30 = wr30[w], j = wj[w];
+                    const bool live = r30 < 15 || i + 1 < W;
+                    const int irow = 15 * i + r30, icol = 15 * i;
+                    const double h = hv[u][h2];
+                    double wv_ = (live ? sS[irow] : 0.0) * h * sS[icol + j];
+                    wv_ += (irow == icol + j) ? mu * sDg[irow] * sDg[irow] : 0.0;
+                    Blk[(size_t)i * KC_BLK + r30 * KC_RS + j] = live ? wv_ : 0.0;
+                }
+            }
+        }
+    } else {
         const double* src = G.chain_src + (size_t)dec.cur * W * GLIO_CS_SOURCES * GLIO_CS_STRIDE;
         for (int q0 = tid; q0 < gtotal; q0 += KB * KC_THREADS) {
             v2f64 gb[KB][5];
@@ -3431,7 +3556,7 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
     if (chain) {
         ChainArgs r;
         r.W = c->W; r.n = a.n; r.nd = n_ddt; r.ep_slots = c->arrow.d_ep_slots; r.ep_off = c->arrow.d_ep_off; r.ep_list = c->arrow.d_ep_list;
-        r.z = c->arrow.d_z; r.flag = c->arrow.d_flag; r.status = c->d_status; r.dbg = c->arrow.d_dbg; r.force_fail = c->arrow.mode == 2; r.fast = chain_fast_mask(); r.blk = nullptr;
+        r.z = c->arrow.d_z; r.flag = c->arrow.d_flag; r.status = c->d_status; r.dbg = c->arrow.d_dbg; r.force_fail = c->arrow.mode == 2; r.fast = chain_fast_mask(); r.blk = nullptr; r.helpers = 0; r.hseq = 0; r.hsum = nullptr; r.hdone = nullptr;
         if (chain_step_lds_bytes(c->W, n_ddt, a.n, true) + 2 * 1024 > 158 * 1024) r.fast = 0;      // no room for the LDS mirrors: generic bodies
         size_t lds_step = chain_step_lds_bytes(c->W, n_ddt, a.n, r.fast != 0);
         {   // separator + four fronts when the window is long enough for it to pay and its panels fit (chain_f4_layout)
@@ -3452,7 +3577,11 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
             G.hd0 = c->d_hdiag[0]; G.hd1 = c->d_hdiag[1]; G.g0 = c->d_g[0]; G.g1 = c->d_g[1]; G.c0 = c->d_cost[0]; G.c1 = c->d_cost[1];
             a.hd0 = c->d_hdiag[0]; a.hd1 = c->d_hdiag[1];
             a.fused_chain = 2;
-            hipLaunchKernelGGL(k_chain_step, dim3(1), dim3(KC_THREADS), lds_step, c->stream, r, a, G);
+            // helper workgroups (one per keyframe) pre-sum the candidate's block entries: GLIO_CHAIN_HELPERS=0 switches them off (A/B)
+            static const bool helpers_off = getenv("GLIO_CHAIN_HELPERS") && atoi(getenv("GLIO_CHAIN_HELPERS")) == 0;
+            r.helpers = helpers_off ? 0 : c->W; r.hsum = c->arrow.d_chain_sum; r.hdone = c->arrow.d_chain_done;
+            r.hseq = c->arrow.chain_seq; c->arrow.chain_seq = c->arrow.chain_seq % (1 << 29) + 1;
+            hipLaunchKernelGGL(k_chain_step, dim3(1 + r.helpers), dim3(KC_THREADS), lds_step, c->stream, r, a, G);
             return;                                   // the one launch is the whole step
         }
         if (ckind == 3) {
