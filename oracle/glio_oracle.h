@@ -11,9 +11,13 @@
  * orc_marginalize) is pinned, since round 4, on the reference's own code: oracle/_ref/libglio_ref.so = the reference's
  * factor headers + MarginalizationFactor.cpp + gnss_utility.cpp compiled unmodified from /root/reference against the
  * stand-in headers of oracle/ref_shim/include (tests/test_oracle_ref.py: <= 1e-12 relative on 1000 random inputs per
- * factor; tests/golden/ref_factors.npz carries the reference's outputs to the GPU box).  STILL UNPINNED: the Ceres solve
- * loop (orc_solver.c, orc_batch2.c -- Ceres is not in the image nor under /root/reference), PCL's kd-tree / VoxelGrid and
- * Eigen's colPivHouseholderQr (orc_assoc.c).  Numbers that pass through those must be labelled
+ * factor; tests/golden/ref_factors.npz carries the reference's outputs to the GPU box).  The trust-region LOOP (orc_solver.c,
+ * orc_batch2.c; Ceres is neither in the image nor under /root/reference) is held, iteration by iteration, to tests/np_ceres.py
+ * (tests/test_oracle_tr_pins.py), and that restatement reproduces the progress tables the real library printed into its own
+ * documentation -- cost to 7 digits, gradient, step, tr_ratio, radius per iteration for helloworld and Powell's function, the
+ * radius column of curve_fitting's rejected and accepted steps (GraphGNSSLibV1.1/docs/source/nnls_tutorial.rst:139-143,378-394,
+ * 411-432,508-523; tests/test_ceres_docs_kat.py).  STILL UNPINNED: the dogleg step itself (no printed table uses it), PCL's kd-tree /
+ * VoxelGrid and Eigen's colPivHouseholderQr (orc_assoc.c).  Numbers that pass through those must be labelled
  * "reference-restatement (Ceres-1.14 semantics)", never "Ceres".
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or call this.

@@ -201,8 +201,10 @@ class LevenbergMarquardt:
     invalid = rejected
 
 
-def minimize(x0, evaluate, plus, flat, o):
-    """Returns (x_user, summary dict, history): history rows (candidate cost, radius at the step, |x - candidate|) per iteration."""
+def minimize(x0, evaluate, plus, flat, o, trace=None):
+    """Returns (x_user, summary dict, history): history rows (candidate cost, radius at the step, |x - candidate|) per iteration.
+    `trace` (a list): one dict per iteration with the columns of Ceres' progress table -- cost, cost_change, gradient max norm, step norm, tr_ratio
+    and the radius AFTER the iteration (tests/test_ceres_docs_kat.py holds them against the tables printed in the bundled Ceres documentation)."""
     x = x0
     ev = evaluate(x)
     if ev is None:
@@ -256,6 +258,7 @@ def minimize(x0, evaluate, plus, flat, o):
             term = FUNCTION_TOL
             break
         q = evalr.quality(ccost, mcc)
+        cost_before = evalr.current
         if q > o.min_relative_decrease:
             x, H, g = cand, Hc, gc
             ok_steps += 1
@@ -263,6 +266,11 @@ def minimize(x0, evaluate, plus, flat, o):
             evalr.accepted(ccost, mcc)
             if ccost < user_min:
                 user_min, x_user = ccost, x
+            if trace is not None:
+                trace.append(dict(cost=ccost, cost_change=cost_before - ccost, gradient=float(np.abs(flat(x) - flat(plus(x, -g))).max()), step=dx, ratio=q, radius=strat.radius,
+                                  x=np.array(flat(x), float).copy()))
         else:
             strat.rejected()
+            if trace is not None:
+                trace.append(dict(cost=cost_before, cost_change=cost_before - ccost, gradient=0.0, step=dx, ratio=q, radius=strat.radius))
     return x_user, dict(termination=term, iterations=it, successful_steps=ok_steps, initial_cost=initial, final_cost=user_min, final_radius=strat.radius), hist
