@@ -199,6 +199,25 @@ def main():
     except Exception as e:
         dense_variant = {"error": str(e)[:200]}
 
+    # ---- several windows at once on this GPU (informational; the headline stays ONE window, whose solve is latency-bound: its trust-region step is one
+    # workgroup).  Four PROCESSES, each with its own context and window of the headline shape, solving at the same time (scripts/stress_shared_solves.py;
+    # four threads of one process reach only ~60 % of this: the interpreter and the runtime's locks serialise their host sides).
+    concurrent = None
+    try:
+        import subprocess as _sp
+        NC, reps_c = 4, 600
+        env_c = dict(os.environ, STRESS_PTS=str(args.points), HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local_rank)))
+        outc = _sp.run([sys.executable, os.path.join(ROOT, "scripts", "stress_shared_solves.py"), str(NC), str(reps_c)], env=env_c, capture_output=True, text=True, timeout=300)
+        per = [float(ln.split("ms per solve under contention")[1]) for ln in outc.stdout.splitlines() if ln.startswith("OK rank")]
+        if len(per) == NC and outc.returncode == 0:
+            concurrent = {"windows_at_once": NC, "solves_each": reps_c, "ms_per_solve_each": [round(v, 4) for v in per], "aggregate_solves_per_s": round(sum(1e3 / v for v in per), 1),
+                          "what": "four independent windows of the headline shape (four processes, one context each) on ONE GPU, every solve checked bit for bit against the "
+                                  "process's first; not the headline -- one window's solve is latency-bound, the device has room for more of them"}
+        else:
+            concurrent = {"error": (outc.stdout[-200:] + outc.stderr[-200:])}
+    except Exception as e:  # noqa: BLE001 -- informational
+        concurrent = {"error": str(e)[:200]}
+
     # ---- the steady-state solve at other window lengths (same construction as the headline, fewer points: the step does not depend on them).
     # W = 22, 24: k_chain_step where the four-front panels / the LDS mirrors get tight; W = 30: the blocks no longer fit the LDS (k_chain_solve<true>)
     window_sizes = {}
@@ -405,7 +424,7 @@ def main():
         "iterations": int(summ.iterations), "ms_per_iteration": round(ms_per_step / max(1, int(summ.iterations)), 4),
         "termination": int(summ.termination), "solver_path": {0: "dense", 1: "arrow", 2: "keyframe chain"}.get(int(capi.load().glio_debug_solver_path(ctx._h)), "?"),
         "dense_prior_variant": dense_variant,
-        "window_sizes": window_sizes,
+        "window_sizes": window_sizes, "concurrent_windows_one_gpu": concurrent,
         "kernels_us": {"lidar_linearize": round(k3_ms * 1e3, 2), "full_linearize": round(lin_ms * 1e3, 2), "tr_step": round(trs_ms * 1e3, 2),
                        "marginalize": round(marg_ms * 1e3, 2), "marginalize_call_incl_readback": round(marg_call_ms * 1e3, 1)},
         "roofline": roofline, "cpu_baseline": cpu, "cpu_baselines_other_configs": cpu_more, "pose_vs_oracle": pose_err, "association": assoc,
