@@ -1436,7 +1436,8 @@ struct glio_bassoc {
     float4* d_global;               // [cap] staging: one cloud in the global frame
     int* h_n;                       // [K]
     FrameHash* frames;              // [K]
-    int* d_total;                   // scratch of the hash build
+    int* d_total;                   // scratch of the hash build: [BA_FB]
+    struct FrameBuild* d_fb; struct FrameBuild* h_fb;       // [K] build descriptors of the keyframes of a run, batch after batch (device / pinned)
     // dense per-query results of the pair in flight
     float4* d_q_cp; double* d_q_nc; double* d_q_score; int* d_q_flag; int* d_q_pos; int* d_bcount; int* d_boff;
     int* d_nn5; float* d_d4;
@@ -1462,6 +1463,87 @@ __global__ void k_transform_cloud(const float4* __restrict__ in, int n, const do
     double po[3];
     a_qrot(q, pin, po);
     out[i] = make_float4((float)(po[0] + t[0]), (float)(po[1] + t[1]), (float)(po[2] + t[2]), p.w);
+}
+
+// ---- the per-keyframe voxel hashes of the batch association, BA_FB keyframes per launch (blockIdx.y = keyframe of the batch).  One keyframe at a time
+// the five build kernels are launches of 128 workgroups that last 4-20 us each: 10 000 of them for 2000 keyframes, 80 of the 370 ms the association of
+// every pair of a C4-sized batch took.  Same device code as the single-frame kernels above, addressed through a descriptor per keyframe.
+#define BA_FB 64
+struct FrameBuild {
+    unsigned long long* keys; int4* ent; int* cnt; int* start; int* fill; int* pt_slot; float4* sorted;
+    const float4* local; float4* global; const double* pose; int* total; int n, tc;
+};
+__global__ void k_hash_clear_multi(const FrameBuild* __restrict__ fb) {
+    const FrameBuild f = fb[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < f.tc) { f.keys[i] = KEY_EMPTY; f.cnt[i] = 0; f.fill[i] = 0; f.ent[i] = make_int4(-1, -1, 0, 0); }
+    if (i == 0) *f.total = 0;
+}
+__global__ void k_transform_cloud_multi(const FrameBuild* __restrict__ fb) {
+    const FrameBuild f = fb[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // transformCloud, Estimator.cpp:1517-1546
+    if (i >= f.n) return;
+    const double t[3] = {f.pose[0], f.pose[1], f.pose[2]}, q[4] = {f.pose[3], f.pose[4], f.pose[5], f.pose[6]};
+    const float4 p = f.local[i];
+    const double pin[3] = {(double)p.x, (double)p.y, (double)p.z};
+    double po[3];
+    a_qrot(q, pin, po);
+    f.global[i] = make_float4((float)(po[0] + t[0]), (float)(po[1] + t[1]), (float)(po[2] + t[2]), p.w);
+}
+__global__ void k_hash_insert_multi(const FrameBuild* __restrict__ fb, const float inv_cell) {
+    const FrameBuild f = fb[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= f.n) return;
+    const float4 p = f.global[i];
+    const int cx = cell_of(p.x, inv_cell), cy = cell_of(p.y, inv_cell), cz = cell_of(p.z, inv_cell);
+    const unsigned long long key = pack_key(cx, cy, cz);
+    unsigned s = home_slot(cx, cy, cz, f.tc);
+    for (;;) {
+        unsigned long long prev = f.keys[s];
+        if (prev != key) prev = atomicCAS(&f.keys[s], KEY_EMPTY, key);
+        if (prev == KEY_EMPTY || prev == key) break;
+        s = (s + 1) & (f.tc - 1);
+    }
+    atomicAdd(&f.cnt[s], 1);
+    f.pt_slot[i] = (int)s;
+}
+__global__ __launch_bounds__(1024) void k_cell_alloc_multi(const FrameBuild* __restrict__ fb) {
+    __shared__ int s_w[16], s_base;
+    const FrameBuild f = fb[blockIdx.y];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    if (blockIdx.x * 1024 >= f.tc) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = i < f.tc ? f.cnt[i] : 0;
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int k = 0; k < 16; ++k) { const int v = s_w[k]; s_w[k] = t; t += v; }
+        s_base = t > 0 ? atomicAdd(f.total, t) : 0;
+    }
+    __syncthreads();
+    const int st = s_base + s_w[wv] + incl - c;
+    if (i < f.tc && c > 0) f.start[i] = st;
+    if (i < f.tc) {
+        const unsigned long long k = f.keys[i];
+        f.ent[i] = make_int4((int)(unsigned)(k & 0xffffffffull), (int)(unsigned)(k >> 32), st, c);
+    }
+}
+__global__ void k_scatter_multi(const FrameBuild* __restrict__ fb) {
+    const FrameBuild f = fb[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= f.n) return;
+    const int s = f.pt_slot[i];
+    const int pos = f.start[s] + atomicAdd(&f.fill[s], 1);
+    float4 p = f.global[i];
+    p.w = __int_as_float(i);
+    f.sorted[pos] = p;
 }
 
 // Compaction of the kept records, pair major, for a CHUNK of pairs per launch (blockIdx.y / wavefront = pair of the chunk):
@@ -1538,7 +1620,7 @@ int glio_bassoc_create(int device, int K, int max_points_per_frame, int64_t max_
     BA_CHECK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     b->inv_cell = 1.0f / fmaxf(1.25f, sqrtf(1.5f) * 1.0001f);
     const size_t cap = (size_t)b->cap;
-    BA_CHECK(hipMalloc((void**)&b->d_local, (size_t)K * cap * 16)); BA_CHECK(hipMalloc((void**)&b->d_global, cap * 16));
+    BA_CHECK(hipMalloc((void**)&b->d_local, (size_t)K * cap * 16)); BA_CHECK(hipMalloc((void**)&b->d_global, (size_t)BA_FB * cap * 16));
     BA_CHECK(hipMalloc((void**)&b->d_local_ps, (size_t)K * cap * 16));
     b->h_n = new int[K]();
     b->frames = new FrameHash[K]();
@@ -1551,7 +1633,8 @@ int glio_bassoc_create(int device, int K, int max_points_per_frame, int64_t max_
         BA_CHECK(hipMalloc((void**)&f.d_cell_start, (size_t)tc * 4)); BA_CHECK(hipMalloc((void**)&f.d_cell_fill, (size_t)tc * 4));
         BA_CHECK(hipMalloc((void**)&f.d_pt_slot, cap * 4)); BA_CHECK(hipMalloc((void**)&f.d_sorted, cap * 16));
     }
-    BA_CHECK(hipMalloc((void**)&b->d_total, 4));
+    BA_CHECK(hipMalloc((void**)&b->d_total, (size_t)BA_FB * 4));
+    BA_CHECK(hipMalloc((void**)&b->d_fb, (size_t)K * sizeof(FrameBuild))); BA_CHECK(hipHostMalloc((void**)&b->h_fb, (size_t)K * sizeof(FrameBuild)));
     // dense per-query work arrays for a chunk of BA_CHUNK pairs (104 B per query and pair)
     const size_t wc = cap * BA_CHUNK;
     b->b_stride = (int)(cap / PF_BLOCK + 2);
@@ -1583,6 +1666,8 @@ void glio_bassoc_destroy(glio_bassoc* b) {
                  b->d_sel_cp, b->d_sel_nc, b->d_sel_score, b->d_sel_idx};
     for (void* q : p) if (q) hipFree(q);
     knn_bin_destroy(b->kb);
+    if (b->d_fb) hipFree(b->d_fb);
+    if (b->h_fb) hipHostFree(b->h_fb);
     if (b->h_pair_off) hipHostFree(b->h_pair_off);
     delete[] b->h_n; delete[] b->frames;
     hipStreamDestroy(b->stream);
@@ -1620,19 +1705,34 @@ int glio_bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const int3
     // (1) every keyframe that occurs as a search frame: cloud -> global frame -> voxel hash
     std::vector<char> need(b->K, 0);
     for (int p = 0; p < n_pairs; ++p) need[pair_cj[p]] = 1;
-    for (int k = 0; k < b->K; ++k) {
-        if (!need[k]) continue;
-        FrameHash& f = b->frames[k];
-        const int n = b->h_n[k];
-        int tc = next_pow2(2 * (n > 512 ? n : 512));
-        if (tc > f.table_cap) tc = f.table_cap;
-        f.n = n; f.cap_eff = tc;
-        hipLaunchKernelGGL(k_hash_clear, dim3((tc + 255) / 256), dim3(256), 0, b->stream, f.d_keys, f.d_cell_count, f.d_cell_fill, tc, b->d_total, f.d_ent);
-        if (n == 0) continue;
-        hipLaunchKernelGGL(k_transform_cloud, dim3((n + 255) / 256), dim3(256), 0, b->stream, b->d_local + (size_t)k * b->cap, n, b->d_poses + 7 * k, b->d_global);
-        hipLaunchKernelGGL(k_hash_insert, dim3((n + 255) / 256), dim3(256), 0, b->stream, b->d_global, n, b->inv_cell, f.d_keys, f.d_cell_count, f.d_pt_slot, tc);
-        hipLaunchKernelGGL(k_cell_alloc, dim3((tc + 1023) / 1024), dim3(1024), 0, b->stream, f.d_cell_count, f.d_cell_start, tc, b->d_total, f.d_keys, f.d_ent);
-        hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, b->stream, b->d_global, n, f.d_pt_slot, f.d_cell_start, f.d_cell_fill, f.d_sorted);
+    {
+        std::vector<int> todo;
+        for (int k = 0; k < b->K; ++k) if (need[k]) todo.push_back(k);
+        for (size_t t0 = 0; t0 < todo.size(); t0 += BA_FB) {
+            const int nb = (int)std::min<size_t>(BA_FB, todo.size() - t0);
+            int max_tc = 0, max_n = 0;
+            for (int q = 0; q < nb; ++q) {
+                const int k = todo[t0 + q];
+                FrameHash& f = b->frames[k];
+                const int n = b->h_n[k];
+                int tc = next_pow2(2 * (n > 512 ? n : 512));
+                if (tc > f.table_cap) tc = f.table_cap;
+                f.n = n; f.cap_eff = tc;
+                FrameBuild& d = b->h_fb[t0 + q];
+                d.keys = f.d_keys; d.ent = f.d_ent; d.cnt = f.d_cell_count; d.start = f.d_cell_start; d.fill = f.d_cell_fill; d.pt_slot = f.d_pt_slot; d.sorted = f.d_sorted;
+                d.local = b->d_local + (size_t)k * b->cap; d.global = b->d_global + (size_t)q * b->cap; d.pose = b->d_poses + 7 * k; d.total = b->d_total + q; d.n = n; d.tc = tc;
+                if (tc > max_tc) max_tc = tc;
+                if (n > max_n) max_n = n;
+            }
+            const FrameBuild* dfb = b->d_fb + t0;
+            BA_CHECK(hipMemcpyAsync(b->d_fb + t0, b->h_fb + t0, (size_t)nb * sizeof(FrameBuild), hipMemcpyHostToDevice, b->stream));
+            hipLaunchKernelGGL(k_hash_clear_multi, dim3((max_tc + 255) / 256, nb), dim3(256), 0, b->stream, dfb);
+            if (max_n == 0) continue;
+            hipLaunchKernelGGL(k_transform_cloud_multi, dim3((max_n + 255) / 256, nb), dim3(256), 0, b->stream, dfb);
+            hipLaunchKernelGGL(k_hash_insert_multi, dim3((max_n + 255) / 256, nb), dim3(256), 0, b->stream, dfb, b->inv_cell);
+            hipLaunchKernelGGL(k_cell_alloc_multi, dim3((max_tc + 1023) / 1024, nb), dim3(1024), 0, b->stream, dfb);
+            hipLaunchKernelGGL(k_scatter_multi, dim3((max_n + 255) / 256, nb), dim3(256), 0, b->stream, dfb);
+        }
     }
     // (2) the pairs, in the caller's (ci, cj) order, BA_CHUNK pairs per launch (blockIdx.y = pair of the chunk)
     if (n_pairs > 0) {
