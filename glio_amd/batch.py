@@ -349,6 +349,7 @@ class BatchAssociation:
         self.K = K
         self._h = C.c_void_p()
         capi._check(lib.glio_bassoc_create(device, K, max_points_per_frame, C.c_int64(max_constraints), C.byref(self._h)))
+        self.capacity = int(max_constraints)
         self.pair_ci = self.pair_cj = self.pair_count = None
         self.total = 0
 
@@ -457,10 +458,11 @@ class RoundsAssociation:
             self.runs += 1
 
     def _feed(self, changed=None):
-        """Hand the three runs to the stage.  The records live in ONE set of device arrays laid out [front region | interior | back region]: the interior
-        (the stored constraints, tens of gigabytes at C4 size) is copied there once, at `start`; a round copies only the re-searched end runs into their
-        fixed-capacity regions and tells the stage every pair's record range (glio_batch_update_constraints_pairs_at_dev) -- concatenating the three
-        result sets anew every round cost 22 ms per round at K = 2000 (44 GB moved) against 2 ms for the re-search itself."""
+        """Hand the three runs to the stage.  The records live in ONE set of device arrays -- the interior association's own result arrays when they have
+        room behind the interior's records (the usual case: [interior | front region | back region], nothing of the interior is copied), else a separate
+        set [front region | interior | back region] filled once at `start`; a round copies only the re-searched end runs into their fixed-capacity regions
+        and tells the stage every pair's record range (glio_batch_update_constraints_pairs_at_dev) -- concatenating the three result sets anew every
+        round cost 22 ms per round at K = 2000 (44 GB moved) against 2 ms for the re-search itself."""
         import torch
         dev = f"cuda:{self.device}"
 
@@ -470,10 +472,10 @@ class RoundsAssociation:
 
         lib = capi.load()
 
-        def views(ba):
+        def views(ba, n=None):
             cp, nc, sc = C.c_void_p(), C.c_void_p(), C.c_void_p()
             capi._check(lib.glio_bassoc_results_dev(ba._h, C.byref(cp), C.byref(nc), C.byref(sc)))
-            n = int(ba.total)
+            n = int(ba.total) if n is None else int(n)
             if n == 0:
                 return None
             return (torch.as_tensor(_Dev(cp.value, (n, 4), "<f4"), device=dev), torch.as_tensor(_Dev(nc.value, (n, 6), "<f8"), device=dev),
@@ -481,19 +483,29 @@ class RoundsAssociation:
         first = changed is None or getattr(self, "_buf", None) is None
         if first:
             caps = [len(self.parts[0][1]) * self.maxpts, int(self.parts[1][0].total) if len(self.parts[1][1]) else 0, len(self.parts[2][1]) * self.maxpts]
-            self._base = [0, caps[0], caps[0] + caps[1]]
             ntot = max(1, sum(caps))
-            # (an existing set of arrays is reused when it is large enough: a fresh 44 GB allocation costs 1.3 s of page-table set-up at C4 size,
-            #  four times the association of all pairs itself -- scripts/batch_assoc_probe.py)
-            if getattr(self, "_buf", None) is None or self._buf[0].shape[0] < ntot:
-                self._buf = None
-                self.stage._keep = None
-                self._buf = (torch.empty((ntot, 4), dtype=torch.float32, device=dev), torch.empty((ntot, 6), dtype=torch.float64, device=dev),
-                             torch.empty((ntot,), dtype=torch.float64, device=dev))
+            inter = self.parts[1][0]
+            self._in_place = bool(len(self.parts[1][1])) and inter.capacity >= ntot
+            if self._in_place:
+                # The interior's records are tens of gigabytes at C4 size and they sit in the interior association's own result arrays, which have room
+                # behind them (capacity = pairs x points, kept records are fewer): those arrays ARE the stage's arrays, laid out [interior | front region |
+                # back region]; only the two small end runs are copied (20 ms per start for a 44 GB copy of the interior otherwise).
+                self._base = [caps[1], 0, caps[1] + caps[0]]
+                self._buf = views(inter, inter.capacity)
+            else:
+                self._base = [0, caps[0], caps[0] + caps[1]]
+                # (an existing set of arrays is reused when it is large enough: a fresh 44 GB allocation costs 1.3 s of page-table set-up at C4 size,
+                #  four times the association of all pairs itself -- scripts/batch_assoc_probe.py)
+                if getattr(self, "_buf", None) is None or self._buf[0].shape[0] < ntot or getattr(self, "_buf_is_view", False):
+                    self._buf = None
+                    self.stage._keep = None
+                    self._buf = (torch.empty((ntot, 4), dtype=torch.float32, device=dev), torch.empty((ntot, 6), dtype=torch.float64, device=dev),
+                                 torch.empty((ntot,), dtype=torch.float64, device=dev))
+            self._buf_is_view = self._in_place
         which_copy = (0, 1, 2) if first else tuple(changed)
         for w in which_copy:
             ba, pci, pcj = self.parts[w]
-            if not len(pci):
+            if not len(pci) or (w == 1 and self._in_place):
                 continue
             v = views(ba)
             if v is None:
