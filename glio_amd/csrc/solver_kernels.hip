@@ -3509,6 +3509,24 @@ static int chain_fast_mask() {
     return g_chain_fast;
 }
 
+// test hook (CPU-callable: host arithmetic only): where the four-front panels of k_chain_step would live for a window of W keyframes and nd clock-drift
+// epochs.  out = {regular dynamic LDS bytes, off_dds, bytes available at off_dds (the clock-drift copy), k0 (E slots placed there), off_r1, total bytes,
+// E slots in all, 1 if the launch would take four fronts}
+extern "C" int glio_debug_chain_f4_layout(int W, int nd, int mirrors, long long* out) {
+    if (W < 2 || nd < 0 || !out) return -1;
+    const int n = 15 * W + nd;
+    const bool mir = mirrors != 0;
+    const ChainF4Layout L = chain_f4_layout(W, nd, n, mir);
+    const ChainSplit c = chain_f4_split(W);
+    const size_t regular = chain_step_lds_bytes(W, nd, n, mir);
+    const size_t with4 = L.total > regular ? L.total : regular;
+    out[0] = (long long)regular; out[1] = (long long)L.off_dds; out[2] = (long long)nd * 15 * 8; out[3] = L.k0; out[4] = (long long)L.off_r1; out[5] = (long long)L.total;
+    out[6] = c.nB + c.nC; out[7] = (W >= KC_F4_MIN_W && with4 + 2 * 1024 <= 158 * 1024) ? 1 : 0;
+    out[8] = c.s; out[9] = c.mL; out[10] = c.mR; out[11] = c.nA; out[12] = c.nB; out[13] = c.nC; out[14] = c.nD;
+    out[15] = KC_ES * 8; out[16] = KC_TILE * 8;
+    return 0;
+}
+
 // GLIO_CHAIN_FRONTS = 2: k_chain_step keeps the two-front elimination for every window (A/B switch and cross-check of the four-front order)
 static int g_chain_fronts = -1;
 extern "C" int glio_debug_chain_fronts(int fronts) { const int old = g_chain_fronts; g_chain_fronts = fronts; return old; }

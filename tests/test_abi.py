@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_debug_hooks_the_gpu_tests_rely_on_are_exported(lib):
     """Undeclared test hooks (not part of the boundary): a stale library without them should fail here, on the CPU, not in the GPU suite."""
-    for n in ("glio_debug_set_solver", "glio_debug_solver_path", "glio_debug_chain_fast", "glio_debug_chain_fronts", "glio_debug_chain_fronts_used", "glio_debug_wave_reduce_check", "glio_debug_chol_solve",
+    for n in ("glio_debug_set_solver", "glio_debug_solver_path", "glio_debug_chain_fast", "glio_debug_chain_fronts", "glio_debug_chain_fronts_used", "glio_debug_chain_f4_layout", "glio_debug_wave_reduce_check", "glio_debug_chol_solve",
               "glio_debug_arrow_stamps", "glio_debug_read_vec"):
         assert hasattr(lib, n), n
 
