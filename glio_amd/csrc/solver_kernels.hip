@@ -3521,7 +3521,7 @@ extern "C" int glio_debug_chain_f4_layout(int W, int nd, int mirrors, long long*
     const size_t regular = chain_step_lds_bytes(W, nd, n, mir);
     const size_t with4 = L.total > regular ? L.total : regular;
     out[0] = (long long)regular; out[1] = (long long)L.off_dds; out[2] = (long long)nd * 15 * 8; out[3] = L.k0; out[4] = (long long)L.off_r1; out[5] = (long long)L.total;
-    out[6] = c.nB + c.nC; out[7] = (W >= KC_F4_MIN_W && with4 + 2 * 1024 <= 158 * 1024) ? 1 : 0;
+    out[6] = c.nB + c.nC; out[7] = (W >= KC_F4_MIN_W && with4 + 256 <= 158 * 1024) ? 1 : 0;
     out[8] = c.s; out[9] = c.mL; out[10] = c.mR; out[11] = c.nA; out[12] = c.nB; out[13] = c.nC; out[14] = c.nD;
     out[15] = KC_ES * 8; out[16] = KC_TILE * 8;
     return 0;
@@ -3580,7 +3580,8 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
         {   // separator + four fronts when the window is long enough for it to pay and its panels fit (chain_f4_layout)
             const ChainF4Layout L = chain_f4_layout(c->W, n_ddt, a.n, r.fast != 0);
             const size_t with4 = L.total > lds_step ? L.total : lds_step;
-            r.fronts4 = (c->W >= KC_F4_MIN_W && chain_fronts_mode() != 2 && with4 + 2 * 1024 <= 158 * 1024) ? 1 : 0;
+            // (158 KB is what hipFuncSetAttribute grants this kernel as dynamic LDS: 160 KB less 2 KB for its 1.4 KB of static LDS)
+            r.fronts4 = (c->W >= KC_F4_MIN_W && chain_fronts_mode() != 2 && with4 + 256 <= 158 * 1024) ? 1 : 0;
             if (r.fronts4) lds_step = with4;
             c->arrow.last_fronts = r.fronts4 ? 4 : 2;
         }
