@@ -48,10 +48,10 @@ struct AssocWork {
     int cap_eff;                  // power of two <= table_cap sized for the current map (2 n points: load factor <= 0.5)
     unsigned long long* d_keys;   // [cap] EMPTY = ~0ull
     int4* d_ent;                  // [cap] {key lo, key hi, first point, points}: what the queries read, one 16 B load per probe
-    int* d_cell_count;            // [cap]
-    int* d_cell_start;            // [cap]
-    int* d_cell_fill;             // [cap]
-    int* d_pt_slot;               // [max_map]
+    unsigned* d_cnt8;             // [cap][8] points per (cell, octant)
+    uint4* d_sub;                 // [cap] exclusive prefix of the octant counts, 8 x u16
+    int* d_pt_slot;               // [max_map] 8 * table slot + octant of point i
+    int* d_pt_rank;               // [max_map] its arrival rank inside that octant
     float4* d_map_raw;            // [max_map] upload staging
     int* d_total;                 // [1]
     // per-query dense results (capacity = cap of a slot)
@@ -90,17 +90,26 @@ __device__ __forceinline__ unsigned home_slot(int cx, int cy, int cz, int cap) {
     return ((h << 3) | (unsigned)((cx & 1) | ((cy & 1) << 1) | ((cz & 1) << 2))) & (unsigned)(cap - 1);
 }
 
-__global__ void k_hash_clear(unsigned long long* keys, int* cnt, int* fill, int cap, int* total, int4* ent) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < cap) { keys[i] = KEY_EMPTY; cnt[i] = 0; fill[i] = 0; ent[i] = make_int4(-1, -1, 0, 0); }
+// K1 orders the points of a cell by OCTANT (which half of the cell along x, y, z): oct = (hx & 1) | (hy & 1) << 1 | (hz & 1) << 2 with
+// h* = floor(v * 2 inv_cell) -- consistent with the cell (floor(2 y) >> 1 == floor(y), and 2 inv_cell scales exactly in binary floating point).
+// The near-block search (k_knn5_near) stages only the octants that touch the query cell.  cnt8 [cap][8]: per-octant counts; the atomic that
+// counts a point also hands it its rank inside its octant, so the scatter needs no second atomic.  sub [cap]: the exclusive prefix of the eight
+// octant counts as 8 x u16 (all ones when the cell holds more than SUB_MAX points: such cells are searched by the 27-cell kernel only).
+#define SUB_MAX 60000
+__device__ __forceinline__ int oct_of(const float4 p, const float inv_cell) {
+    const float ih = inv_cell * 2.0f;
+    return ((int)floorf(p.x * ih) & 1) | (((int)floorf(p.y * ih) & 1) << 1) | (((int)floorf(p.z * ih) & 1) << 2);
+}
+__device__ __forceinline__ void hash_clear_slot(const int i, const int cap, unsigned long long* keys, unsigned* cnt8, int* total, int4* ent, uint4* sub) {
+    if (i < cap) {
+        keys[i] = KEY_EMPTY;
+        reinterpret_cast<uint4*>(cnt8)[2 * (size_t)i] = make_uint4(0, 0, 0, 0); reinterpret_cast<uint4*>(cnt8)[2 * (size_t)i + 1] = make_uint4(0, 0, 0, 0);
+        ent[i] = make_int4(-1, -1, 0, 0); sub[i] = make_uint4(0, 0, 0, 0);
+    }
     if (i == 0) *total = 0;
 }
-
-__global__ void k_hash_insert(const float4* __restrict__ pts, int n, float inv_cell, unsigned long long* keys, int* cnt,
-                              int* pt_slot, int cap) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 p = pts[i];
+__device__ __forceinline__ void hash_insert_point(const float4 p, const int i, const float inv_cell, unsigned long long* keys, unsigned* cnt8, int* pt_slot, int* pt_rank,
+                                                  const int cap) {
     const int cx = cell_of(p.x, inv_cell), cy = cell_of(p.y, inv_cell), cz = cell_of(p.z, inv_cell);
     const unsigned long long key = pack_key(cx, cy, cz);
     unsigned s = home_slot(cx, cy, cz, cap);
@@ -110,18 +119,25 @@ __global__ void k_hash_insert(const float4* __restrict__ pts, int n, float inv_c
         if (prev == KEY_EMPTY || prev == key) break;
         s = (s + 1) & (cap - 1);
     }
-    atomicAdd(&cnt[s], 1);
-    pt_slot[i] = (int)s;
+    const int so = (int)(s * 8u) + oct_of(p, inv_cell);
+    pt_rank[i] = (int)atomicAdd(&cnt8[so], 1u);
+    pt_slot[i] = so;
 }
-
 // range allocation: one atomic per 1024-slot workgroup (block-wide exclusive scan of the cell counts; same-address atomics
 // execute one after the other at the memory side, a wavefront-granular version spent 14 us on 2048 of them)
-__global__ __launch_bounds__(1024) void k_cell_alloc(const int* __restrict__ cnt, int* start, int cap, int* total, const unsigned long long* __restrict__ keys,
-                                                     int4* __restrict__ ent) {
-    __shared__ int s_w[16], s_base;
-    const int i = blockIdx.x * 1024 + threadIdx.x;
+__device__ __forceinline__ void cell_alloc_slot(const int i, const int cap, const unsigned* __restrict__ cnt8, int* total, const unsigned long long* __restrict__ keys,
+                                                int4* __restrict__ ent, uint4* __restrict__ sub, int* s_w, int* s_base) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int c = i < cap ? cnt[i] : 0;
+    unsigned o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (i < cap) {
+        const uint4 a = reinterpret_cast<const uint4*>(cnt8)[2 * (size_t)i], b = reinterpret_cast<const uint4*>(cnt8)[2 * (size_t)i + 1];
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    }
+    unsigned pre[8];
+    unsigned cs = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { pre[k] = cs; cs += o[k]; }
+    const int c = (int)cs;
     int incl = c;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -133,26 +149,45 @@ __global__ __launch_bounds__(1024) void k_cell_alloc(const int* __restrict__ cnt
     if (threadIdx.x == 0) {
         int t = 0;
         for (int k = 0; k < 16; ++k) { const int v = s_w[k]; s_w[k] = t; t += v; }
-        s_base = t > 0 ? atomicAdd(total, t) : 0;
+        *s_base = t > 0 ? atomicAdd(total, t) : 0;
     }
     __syncthreads();
-    const int st = s_base + s_w[wv] + incl - c;
-    if (i < cap && c > 0) start[i] = st;
+    const int st = *s_base + s_w[wv] + incl - c;
     if (i < cap) {
         const unsigned long long k = keys[i];
         ent[i] = make_int4((int)(unsigned)(k & 0xffffffffull), (int)(unsigned)(k >> 32), st, c);
+        sub[i] = c > SUB_MAX ? make_uint4(~0u, ~0u, ~0u, ~0u)
+                             : make_uint4(pre[0] | (pre[1] << 16), pre[2] | (pre[3] << 16), pre[4] | (pre[5] << 16), pre[6] | (pre[7] << 16));
     }
 }
-
-__global__ void k_scatter(const float4* __restrict__ pts, int n, const int* __restrict__ pt_slot, const int* __restrict__ start,
-                          int* fill, float4* __restrict__ sorted) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int s = pt_slot[i];
-    const int pos = start[s] + atomicAdd(&fill[s], 1);
-    float4 p = pts[i];
+__device__ __forceinline__ void scatter_point(float4 p, const int i, const int* __restrict__ pt_slot, const int* __restrict__ pt_rank, const unsigned* __restrict__ cnt8,
+                                              const int4* __restrict__ ent, float4* __restrict__ sorted) {
+    const int so = pt_slot[i], s = so >> 3, oc = so & 7;
+    const uint4 a = reinterpret_cast<const uint4*>(cnt8)[2 * (size_t)s], b = reinterpret_cast<const uint4*>(cnt8)[2 * (size_t)s + 1];
+    const unsigned o[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    unsigned pre = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) pre += k < oc ? o[k] : 0u;
     p.w = __int_as_float(i);          // original index rides in .w (map intensity is not used by the path)
-    sorted[pos] = p;
+    sorted[ent[s].z + (int)pre + pt_rank[i]] = p;
+}
+
+__global__ void k_hash_clear(unsigned long long* keys, unsigned* cnt8, int cap, int* total, int4* ent, uint4* sub) {
+    hash_clear_slot(blockIdx.x * blockDim.x + threadIdx.x, cap, keys, cnt8, total, ent, sub);
+}
+__global__ void k_hash_insert(const float4* __restrict__ pts, int n, float inv_cell, unsigned long long* keys, unsigned* cnt8, int* pt_slot, int* pt_rank, int cap) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) hash_insert_point(pts[i], i, inv_cell, keys, cnt8, pt_slot, pt_rank, cap);
+}
+__global__ __launch_bounds__(1024) void k_cell_alloc(const unsigned* __restrict__ cnt8, int cap, int* total, const unsigned long long* __restrict__ keys,
+                                                     int4* __restrict__ ent, uint4* __restrict__ sub) {
+    __shared__ int s_w[16], s_base;
+    cell_alloc_slot(blockIdx.x * 1024 + threadIdx.x, cap, cnt8, total, keys, ent, sub, s_w, &s_base);
+}
+__global__ void k_scatter(const float4* __restrict__ pts, int n, const int* __restrict__ pt_slot, const int* __restrict__ pt_rank, const unsigned* __restrict__ cnt8,
+                          const int4* __restrict__ ent, float4* __restrict__ sorted) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) scatter_point(pts[i], i, pt_slot, pt_rank, cnt8, ent, sorted);
 }
 
 // ---- 5x3 column-pivoted Householder least squares, all indices compile-time (stays in registers)
@@ -253,14 +288,16 @@ struct KnnBin {
     // per-call grouping (k_qbin_tile) and search (k_knn5_tile), every launch row y:
     float4* qs;                                           // [Y][w_stride] queries grouped by cell (world xyz, w = index in the scan); the presort's output pointer
     int4* units;                                          // [Y][unit_stride] (first grouped position, queries, cell key lo, hi): the search probes from the record alone
-    int* counters;                                        // [Y][2] grouped queries, units (zeroed again by k_plane_fit)
+    int* counters;                                        // [Y][4] grouped queries, units, units the near-block search handed on (zeroed again by k_plane_fit)
+    int2* fails;                                          // [Y][unit_stride] (unit, mask of its queries) the near-block search (k_knn5_near) could not certify
+    int use_fails;                                        // k_knn5_tile: 1 = run over `fails` instead of every unit
     int capq, unit_stride;
 };
 
 struct AssocArgs {
     KnnBin kb;
     double q[4], t[3];
-    float inv_cell;
+    float inv_cell, cell;
     double kd_max_radius, weight_gate;      // doubles in the reference: float quantities are promoted for the comparison
     double surf_dist_thres, lidar_const;
     int n, table_cap, unit_scores;
@@ -276,11 +313,11 @@ struct AssocArgs {
     const double* poses;                    // [K][7] = t, q (w, x, y, z)
     int pair0;                              // first pair of this launch
 };
-struct FrameDesc { const int4* ent; const float4* sorted; int n, cap_eff; };
-struct AssocSlot { double q[4], t[3]; int n; size_t qoff, woff, boff; const int4* ent; const float4* map; size_t locoff; int table_cap; };
+struct FrameDesc { const int4* ent; const uint4* sub; const float4* sorted; int n, cap_eff; };
+struct AssocSlot { double q[4], t[3]; int n; size_t qoff, woff, boff; const int4* ent; const uint4* sub; const float4* map; size_t locoff; int table_cap; };
 __device__ __forceinline__ AssocSlot assoc_slot(const AssocArgs& a) {
     AssocSlot s;
-    s.ent = nullptr; s.map = nullptr; s.locoff = 0; s.table_cap = a.table_cap;
+    s.ent = nullptr; s.sub = nullptr; s.map = nullptr; s.locoff = 0; s.table_cap = a.table_cap;
     if (a.frames) {
         const int p = a.pair0 + blockIdx.y;
         const int ci = a.pair_ci[p], cj = a.pair_cj[p];
@@ -292,7 +329,7 @@ __device__ __forceinline__ AssocSlot assoc_slot(const AssocArgs& a) {
         const FrameDesc fj = a.frames[cj];
         s.n = a.frames[ci].n;
         s.qoff = (size_t)ci * a.q_stride; s.woff = (size_t)blockIdx.y * a.w_stride; s.boff = (size_t)blockIdx.y * a.b_stride;
-        s.ent = fj.ent; s.map = fj.sorted; s.table_cap = fj.cap_eff;
+        s.ent = fj.ent; s.sub = fj.sub; s.map = fj.sorted; s.table_cap = fj.cap_eff;
         s.locoff = (size_t)cj * a.q_stride;
     } else if (a.win_poses) {
         const int k = blockIdx.y;
@@ -558,7 +595,7 @@ __global__ __launch_bounds__(1024) void k_qbin_alloc(const AssocArgs a) {
     if (threadIdx.x == 0) {
         int t = 0;
         for (int k = 0; k < 16; ++k) { const int v = s_w[k]; s_w[k] = t; t += v; }
-        s_base = t > 0 ? atomicAdd(&a.kb.counters[2 * blockIdx.y], t) : 0;
+        s_base = t > 0 ? atomicAdd(&a.kb.counters[4 * blockIdx.y], t) : 0;
     }
     __syncthreads();
     if (c > 0) {
@@ -621,7 +658,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_qbin_tile(const AssocArgs a, con
     if (tid == 0) {
         int tc = 0, tu = 0;
         for (int k = 0; k < 16; ++k) { const int v = s_wc[k], u = s_wu[k]; s_wc[k] = tc; s_wu[k] = tu; tc += v; tu += u; }
-        s_ubase = atomicAdd(&a.kb.counters[2 * blockIdx.y + 1], tu);
+        s_ubase = atomicAdd(&a.kb.counters[4 * blockIdx.y + 1], tu);
     }
     __syncthreads();
     const int st0 = s_wc[wv] + ic - (c0 + c1), ut0 = s_ubase + s_wu[wv] + iu - (u0 + u1);
@@ -674,8 +711,11 @@ __global__ __launch_bounds__(TK_THREADS) __attribute__((amdgpu_waves_per_eu(5)))
     o_nn5 += 5 * sl.woff; o_d4 += sl.woff;
     if (sl.ent) { ent = sl.ent; map = sl.map; }
     const int table_cap = sl.table_cap;
-    const int n_units = a.kb.counters[2 * blockIdx.y + 1];
+    // use_fails: the launch ranks only what the near-block search (k_knn5_near) handed on -- entries (unit, mask of its queries); else every unit, every query
+    const bool by_list = a.kb.use_fails != 0;
+    const int n_units = a.kb.counters[4 * blockIdx.y + (by_list ? 2 : 1)];
     const int4* units = a.kb.units + (size_t)blockIdx.y * a.kb.unit_stride;
+    const int2* fails = a.kb.fails + (size_t)blockIdx.y * a.kb.unit_stride;
     const float4* qs = a.kb.qs + sl.woff;
 #ifdef GLIO_DEV_STAMPS
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { for (int k = 0; k < 8; ++k) g_knn_stamps[k] = 0; }
@@ -688,10 +728,11 @@ __global__ __launch_bounds__(TK_THREADS) __attribute__((amdgpu_waves_per_eu(5)))
 #endif
     for (int u0 = blockIdx.x * TK_UNITS; u0 < n_units; u0 += gridDim.x * TK_UNITS) {
         KN_T(tk0);
-        const int uid = u0 + g;
+        int uid = u0 + g, fmask = 0xffff;
         const bool ulive = uid < n_units;
+        if (by_list && ulive) { const int2 fe = fails[uid]; uid = fe.x; fmask = fe.y; }
         const int4 un = ulive ? units[uid] : make_int4(0, 0, 0, 0);
-        const bool qlive = j < un.y;
+        const bool qlive = j < un.y && ((fmask >> j) & 1);
         const float4 qp = ulive ? qs[un.x + (qlive ? j : 0)] : make_float4(0, 0, 0, 0);
         const float px = qp.x, py = qp.y, pz = qp.z;
         const int qi = __float_as_int(qp.w);
@@ -892,6 +933,262 @@ __global__ __launch_bounds__(TK_THREADS) __attribute__((amdgpu_waves_per_eu(5)))
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// K2, near block first (round 5).  k_knn5_tile ranks every query against all the points of 27 cells of edge 1.25 m -- 130-160 candidates, 84 % of
+// them outside the search radius (r04 counters: 10.6 M pairs per 64 k scan, 44 lane-operations each), although on a 0.4 m voxel map the fifth
+// neighbour lies 0.4-0.6 m away.  K1 now orders the points of every cell by octant, so a unit (<= 16 queries of ONE cell) can stage just the
+// NEAR BLOCK = the 4 x 4 x 4 half-cells centred on its cell (its own eight octants + the ring of octants that touch it: ~57 candidates on the C2
+// map) and rank it with ONE lane per query (no half lists, no merge).  A result is accepted only with a certificate of exactness:
+//     every map point outside the block is farther from the query than b = half + (distance of the query to the nearest face of its cell),
+//     so when the fifth distance found inside the block is < (b - margin)^2 the five found ARE the global five (ranked by float distance, then
+//     original index, exactly as k_knn5_tile ranks them), and sqd[4] < kd_max_radius is decided as well (b <= 1.25 m: b^2 can exceed 1.5 only
+//     for a query in the very centre of its cell; the gate itself is applied downstream on the exact distance either way).
+// Queries without a certificate (sparse surroundings: 0.1-3 % on the C2 stream), units whose block does not fit the staging area (dense maps) and
+// cells above SUB_MAX points are handed on -- (unit, query mask) in `fails` -- to k_knn5_tile, which ranks them over the full 27 cells as before.
+// Both kernels produce the same bytes for any query either can answer; tests/test_hip_assoc.py compares the three search modes.
+// margin: the cell of a point is floor(fl(v * inv_cell)); the products are off by <= 2^-24 relative, so cell faces sit within 3 ulp(|v|) of where
+// the arithmetic below puts them: 1e-6 |v| + 1e-5 m covers that four times over.
+#define NK_Q 16
+#define NK_UNITS 4
+#ifndef NK_CAP
+#define NK_CAP 128         /* staged candidates per unit (C2: mean 57, p99 97, max 115) */
+#endif
+#define NK_MASK ((unsigned)(NK_CAP - 1))
+#define NK_PER (NK_CAP / NK_Q)
+__device__ __forceinline__ void nk_insert(unsigned t[6], const unsigned key) {
+#pragma unroll
+    for (int k = 5; k > 0; --k) t[k] = tk_med3(t[k - 1], key, t[k]);
+    t[0] = min(t[0], key);
+}
+__device__ __forceinline__ void nk_cex(unsigned long long& x, unsigned long long& y) {
+    const bool sw = y < x;
+    const unsigned long long lo = sw ? y : x, hi = sw ? x : y;
+    x = lo; y = hi;
+}
+__device__ __forceinline__ unsigned nk_pref(const uint4 sb, const int cc, const int o) {      // exclusive prefix of octant o (o = 8: the cell's count)
+    const unsigned w = (o >> 1) == 0 ? sb.x : (o >> 1) == 1 ? sb.y : (o >> 1) == 2 ? sb.z : sb.w;
+    return o >= 8 ? (unsigned)cc : ((w >> (16 * (o & 1))) & 0xffffu);
+}
+__global__ __launch_bounds__(64) void k_knn5_near(const AssocArgs a, const float4* __restrict__ map, const int4* __restrict__ ent, const uint4* __restrict__ sub,
+                                                  int* __restrict__ o_nn5, float* __restrict__ o_d4) {
+    // candidates staged in QUADS, structure of arrays: [x0 x1 x2 x3][y0..y3][z0..z3] -- three 16 B LDS reads (broadcast inside a unit) feed four
+    // distance evaluations done two at a time with packed fp32 instructions
+    __shared__ float4 s_q4[NK_UNITS][NK_CAP / 4][3];
+    __shared__ int s_idx[NK_UNITS][NK_CAP];           // run << 24 | original map index (the tie-break); before the staging: the run marks
+    __shared__ int s_delta[NK_UNITS][64];             // per run: map position - staged slot
+    const int lane = threadIdx.x, j = lane & (NK_Q - 1), g = lane >> 4, gbase = lane & ~(NK_Q - 1);
+    const AssocSlot sl = assoc_slot(a);
+    if (sl.n <= 0) return;
+    o_nn5 += 5 * sl.woff; o_d4 += sl.woff;
+    if (sl.ent) { ent = sl.ent; sub = sl.sub; map = sl.map; }
+    const int table_cap = sl.table_cap;
+    const int n_units = a.kb.counters[4 * blockIdx.y + 1];
+    const int4* units = a.kb.units + (size_t)blockIdx.y * a.kb.unit_stride;
+    int2* fails = a.kb.fails + (size_t)blockIdx.y * a.kb.unit_stride;
+    const float4* qs = a.kb.qs + sl.woff;
+    const float cell = a.cell, half = 0.5f * a.cell;
+    for (int u0 = blockIdx.x * NK_UNITS; u0 < n_units; u0 += gridDim.x * NK_UNITS) {
+        const int uid = u0 + g;
+        const bool ulive = uid < n_units;
+        const int4 un = ulive ? units[uid] : make_int4(0, 0, 0, 0);
+        const bool qlive = j < un.y;
+        const float4 qp = ulive ? qs[un.x + (qlive ? j : 0)] : make_float4(0, 0, 0, 0);
+        const float px = qp.x, py = qp.y, pz = qp.z;
+        const int qi = __float_as_int(qp.w);
+        const unsigned long long ukey = ((unsigned long long)(unsigned)un.w << 32) | (unsigned)un.z;
+        const int cx = (int)((ukey >> 42) & 0x1fffffu) - (1 << 20), cy = (int)((ukey >> 21) & 0x1fffffu) - (1 << 20), cz = (int)(ukey & 0x1fffffu) - (1 << 20);
+        // ---- probe the 27 cells once per unit (lane j: cells j and j + 16); the record of a cell = (first point, points, octant prefix)
+        int* cellw = reinterpret_cast<int*>(&s_q4[g][0][0]);      // [27][6], dead before the staging writes the quads
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int c = j + NK_Q * hh;
+            if (c < 27) {
+                int cs = 0, cc = 0;
+                uint4 sb = make_uint4(0, 0, 0, 0);
+                if (ulive) {
+                    const int dx = c % 3 - 1, dy = (c / 3) % 3 - 1, dz = c / 9 - 1;
+                    const unsigned long long key = pack_key(cx + dx, cy + dy, cz + dz);
+                    const int klo = (int)(unsigned)(key & 0xffffffffull), khi = (int)(unsigned)(key >> 32);
+                    unsigned s = home_slot(cx + dx, cy + dy, cz + dz, table_cap);
+                    for (;;) {
+                        const int4 e = ent[s];
+                        const uint4 sv = sub[s];                  // (issued with the entry: one round trip per probe step)
+                        if (e.x == klo && e.y == khi) { cs = e.z; cc = e.w; sb = sv; break; }
+                        if ((e.x & e.y) == -1) break;
+                        s = (s + 1) & (table_cap - 1);
+                    }
+                }
+                int2* cw = reinterpret_cast<int2*>(cellw + 6 * c);
+                cw[0] = make_int2(cs, cc); cw[1] = make_int2((int)sb.x, (int)sb.y); cw[2] = make_int2((int)sb.z, (int)sb.w);
+            }
+        }
+        {   // own staging slots: no run starts here yet
+            int4* mk = reinterpret_cast<int4*>(&s_idx[g][NK_PER * j]);
+#pragma unroll
+            for (int i = 0; i < NK_PER / 4; ++i) mk[i] = make_int4(0, 0, 0, 0);
+        }
+        GLIO_WAVE_LDS_SYNC();
+        // ---- runs: lane j owns the row (y, z) = (j & 3, j >> 2) of the 4 x 4 x 4 half-cell block; along x the row crosses three cells:
+        // [upper half of cell -1][both halves of cell 0: contiguous][lower half of cell +1] = three runs of the octant-ordered map
+        int rst[3], rcn[3];
+        bool big = false;
+        {
+            const int hb = (j & 3) + 1, hc = (j >> 2) + 1;
+            const int rowc = 3 * (hb >> 1) + 9 * (hc >> 1), ob = ((hb & 1) << 1) | ((hc & 1) << 2);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int2* cw = reinterpret_cast<const int2*>(cellw + 6 * (rowc + k));
+                const int2 r0 = cw[0], r1 = cw[1], r2 = cw[2];
+                const uint4 sb = make_uint4((unsigned)r1.x, (unsigned)r1.y, (unsigned)r2.x, (unsigned)r2.y);
+                big = big || (sb.x == ~0u);
+                const int o0 = ob | (k == 0 ? 1 : 0), o1 = ob + (k == 2 ? 1 : 2);
+                const unsigned p0 = nk_pref(sb, r0.y, o0), p1 = nk_pref(sb, r0.y, o1);
+                rst[k] = r0.x + (int)p0; rcn[k] = (int)(p1 - p0);
+            }
+        }
+        const int mine = rcn[0] + rcn[1] + rcn[2];
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < NK_Q; off <<= 1) {
+            const int t0 = __shfl_up(incl, off, NK_Q);
+            if (j >= off) incl += t0;
+        }
+        const int tot = __shfl(incl, gbase + NK_Q - 1, 64);
+        const unsigned long long bigb = __ballot(big);
+        const bool over = tot > NK_CAP || ((bigb >> gbase) & 0xffffull) != 0;
+        const int tot_e = (over || !ulive) ? 0 : tot;
+        if (tot_e > 0) {
+            int pf = incl - mine;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (rcn[k] > 0) s_idx[g][pf] = 3 * j + k + 1;
+                s_delta[g][3 * j + k] = rst[k] - pf;
+                pf += rcn[k];
+            }
+        }
+        GLIO_WAVE_LDS_SYNC();
+        // ---- stage: lane j fills the slots [8 j, 8 j + 8): the run of a slot = the last mark at or before it (max-scan; marks grow with the slot)
+        {
+            int rn[NK_PER];
+            {
+                const int4* mk = reinterpret_cast<const int4*>(&s_idx[g][NK_PER * j]);
+                int run = 0;
+#pragma unroll
+                for (int i = 0; i < NK_PER / 4; ++i) {
+                    const int4 m = mk[i];
+                    run = max(run, m.x); rn[4 * i] = run; run = max(run, m.y); rn[4 * i + 1] = run;
+                    run = max(run, m.z); rn[4 * i + 2] = run; run = max(run, m.w); rn[4 * i + 3] = run;
+                }
+                int inc = run;
+#pragma unroll
+                for (int off = 1; off < NK_Q; off <<= 1) {
+                    const int t0 = __shfl_up(inc, off, NK_Q);
+                    if (j >= off) inc = max(inc, t0);
+                }
+                int carry = __shfl_up(inc, 1, NK_Q);
+                if (j == 0) carry = 0;
+#pragma unroll
+                for (int i = 0; i < NK_PER; ++i) rn[i] = max(rn[i], carry) - 1;
+            }
+            float4 pt[NK_PER];
+#pragma unroll
+            for (int i = 0; i < NK_PER; ++i) {
+                const int f = NK_PER * j + i;
+                pt[i] = make_float4(3e18f, 3e18f, 3e18f, 0.f);
+                if (f < tot_e) pt[i] = map[f + s_delta[g][rn[i]]];
+            }
+#pragma unroll
+            for (int i = 0; i < NK_PER / 4; ++i) {
+                float4* qd = s_q4[g][(NK_PER / 4) * j + i];
+                qd[0] = make_float4(pt[4 * i].x, pt[4 * i + 1].x, pt[4 * i + 2].x, pt[4 * i + 3].x);
+                qd[1] = make_float4(pt[4 * i].y, pt[4 * i + 1].y, pt[4 * i + 2].y, pt[4 * i + 3].y);
+                qd[2] = make_float4(pt[4 * i].z, pt[4 * i + 1].z, pt[4 * i + 2].z, pt[4 * i + 3].z);
+                reinterpret_cast<int4*>(&s_idx[g][NK_PER * j])[i] =
+                    make_int4((rn[4 * i] << 24) | (__float_as_int(pt[4 * i].w) & 0xffffff), (rn[4 * i + 1] << 24) | (__float_as_int(pt[4 * i + 1].w) & 0xffffff),
+                              (rn[4 * i + 2] << 24) | (__float_as_int(pt[4 * i + 2].w) & 0xffffff), (rn[4 * i + 3] << 24) | (__float_as_int(pt[4 * i + 3].w) & 0xffffff));
+            }
+        }
+        GLIO_WAVE_LDS_SYNC();
+        // ---- scan: every lane ranks the staged block for its own query; selection by truncated key (distance bits, low 7 = slot) with fused distances
+        int tot_w = tot_e;
+#pragma unroll
+        for (int off = 16; off < 64; off <<= 1) tot_w = max(tot_w, __shfl_xor(tot_w, off, 64));
+        const int n_q = (tot_w + 3) >> 2;
+        unsigned tk[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) tk[k] = ~0u;
+        const tk_v2f P0 = {px, px}, P1 = {py, py}, P2 = {pz, pz};
+        for (int qd = 0; qd < n_q; ++qd) {
+            const float4 X = s_q4[g][qd][0], Y = s_q4[g][qd][1], Z = s_q4[g][qd][2];
+            const tk_v2f xa = {X.x, X.y}, xb = {X.z, X.w}, ya = {Y.x, Y.y}, yb = {Y.z, Y.w}, za = {Z.x, Z.y}, zb = {Z.z, Z.w};
+            const tk_v2f exa = P0 - xa, eya = P1 - ya, eza = P2 - za, exb = P0 - xb, eyb = P1 - yb, ezb = P2 - zb;
+            tk_v2f da = exa * exa, db = exb * exb;
+            da = __builtin_elementwise_fma(eya, eya, da); db = __builtin_elementwise_fma(eyb, eyb, db);
+            da = __builtin_elementwise_fma(eza, eza, da); db = __builtin_elementwise_fma(ezb, ezb, db);
+            const unsigned f0 = (unsigned)(4 * qd);
+            nk_insert(tk, (__float_as_uint(da.x) & ~NK_MASK) | f0);
+            nk_insert(tk, (__float_as_uint(da.y) & ~NK_MASK) | (f0 + 1u));
+            nk_insert(tk, (__float_as_uint(db.x) & ~NK_MASK) | (f0 + 2u));
+            nk_insert(tk, (__float_as_uint(db.y) & ~NK_MASK) | (f0 + 3u));
+        }
+        // ---- exact re-ranking of the six selected: unfused float distance (FLANN's L2), then original index; the slot rides in the low byte (indices
+        // are unique, so it never decides)
+        unsigned long long K[6];
+        const float* flat = reinterpret_cast<const float*>(&s_q4[g][0][0]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const unsigned t = tk[k];
+            const int slot = (int)(t & NK_MASK);
+            const bool real = t != ~0u && slot < tot_e;
+            const int fo = 12 * (slot >> 2) + (slot & 3);
+            const float ex = px - flat[fo], ey = py - flat[fo + 4], ez = pz - flat[fo + 8];
+            float d = ex * ex;
+            d = d + ey * ey;
+            d = d + ez * ez;
+            const unsigned lo = ((unsigned)(s_idx[g][slot] & 0xffffff) << 8) | (unsigned)slot;
+            K[k] = real ? (((unsigned long long)__float_as_uint(d) << 32) | lo) : ~0ull;
+        }
+        nk_cex(K[0], K[5]); nk_cex(K[1], K[3]); nk_cex(K[2], K[4]);
+        nk_cex(K[1], K[2]); nk_cex(K[3], K[4]);
+        nk_cex(K[0], K[3]); nk_cex(K[2], K[5]);
+        nk_cex(K[0], K[1]); nk_cex(K[2], K[3]); nk_cex(K[4], K[5]);
+        nk_cex(K[1], K[2]); nk_cex(K[3], K[4]);
+        const bool has5 = K[4] != ~0ull;
+        // the selection distances are fused (a few ulp off): a candidate's exact bucket is at most ONE away from its selection bucket, so nothing
+        // unselected can precede the fifth exact key when that lies at least two buckets under the sixth selected key
+        const bool all_in = tk[5] == ~0u || (int)(tk[5] & NK_MASK) >= tot_e;
+        const bool safe = all_in || ((unsigned)(K[4] >> 32) & ~NK_MASK) + (NK_MASK + 1u) < (tk[5] & ~NK_MASK);
+        // ---- certificate: distance from the query to the boundary of the staged block
+        const float ox = (float)cx * cell, oy = (float)cy * cell, oz = (float)cz * cell;
+        float b = fminf(px - ox, (ox + cell) - px);
+        b = fminf(b, fminf(py - oy, (oy + cell) - py));
+        b = fminf(b, fminf(pz - oz, (oz + cell) - pz));
+        const float bm = (b + half) - (1e-5f + 1e-6f * fmaxf(fabsf(px), fmaxf(fabsf(py), fabsf(pz))));
+        const float d5 = __uint_as_float((unsigned)(K[4] >> 32));
+        const bool cert = qlive && has5 && safe && bm > 0.f && d5 < bm * bm * 0.99999f;
+        if (cert) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int slot = (int)((unsigned)K[k] & NK_MASK);
+                o_nn5[5 * (size_t)qi + k] = slot + s_delta[g][s_idx[g][slot] >> 24];
+            }
+            o_d4[qi] = d5;
+        }
+        // ---- hand the rest on: one entry per unit with uncertified queries, one atomic per wavefront
+        const unsigned long long fb = __ballot(qlive && !cert);
+        const int m16 = (int)((fb >> gbase) & 0xffffull);
+        const unsigned long long ub = __ballot(j == 0 && m16 != 0);
+        if (ub) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&a.kb.counters[4 * blockIdx.y + 2], __popcll(ub));
+            base = __shfl(base, 0, 64);
+            if (j == 0 && m16 != 0) fails[base + __popcll(ub & ((1ull << lane) - 1ull))] = make_int2(uid, m16);
+        }
+        GLIO_WAVE_LDS_SYNC();
+    }
+}
+
 #define PF_BLOCK 256
 template <bool BATCH>
 __global__ __launch_bounds__(PF_BLOCK) void k_plane_fit(const AssocArgs a, const float4* __restrict__ scan, const float4* __restrict__ map,
@@ -901,7 +1198,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_plane_fit(const AssocArgs a, const
                                                         int* __restrict__ o_nn, const float4* __restrict__ loc, double* __restrict__ o_nc) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * PF_BLOCK + threadIdx.x;
-    if (a.kb.counters && blockIdx.x == 0 && threadIdx.x == 0) { a.kb.counters[2 * blockIdx.y] = 0; a.kb.counters[2 * blockIdx.y + 1] = 0; }
+    if (a.kb.counters && blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<int4*>(a.kb.counters + 4 * blockIdx.y) = make_int4(0, 0, 0, 0);
     const AssocSlot sl = assoc_slot(a);
     if (blockIdx.x * PF_BLOCK >= sl.n) return;
     scan += sl.qoff; nn5 += 5 * sl.woff; d4 += sl.woff;
@@ -1060,7 +1357,8 @@ __global__ __launch_bounds__(PF_BLOCK) void k_compact(const int* __restrict__ fl
 static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 struct KnnBinHost { KnnBin d; int rows, cap, capq_max; };
-static int g_knn_mode = 0;           // 0 = tiled search (k_qbin_* + k_knn5_tile), 1 = one 16-lane group per query (k_knn5); glio_debug_set_knn_mode
+static int g_knn_mode = 0;           // 0 = near block first (k_knn5_near), the rest by the 27-cell tiled search (k_knn5_tile); 1 = one 16-lane group per query (k_knn5);
+                                     // 2 = every query by the 27-cell tiled search (the round-4 path); glio_debug_set_knn_mode
 static KnnBinHost* knn_bin_create(int rows, int cap) {
     KnnBinHost* h = new KnnBinHost();
     memset(h, 0, sizeof *h);
@@ -1073,14 +1371,14 @@ static KnnBinHost* knn_bin_create(int rows, int cap) {
     bool ok = hipMalloc((void**)&d.keys, tq * 8) == hipSuccess && hipMalloc((void**)&d.cnt, tq * 4) == hipSuccess && hipMalloc((void**)&d.cstart, tq * 4) == hipSuccess &&
               hipMalloc((void**)&d.qslot, wq1 * 4) == hipSuccess && hipMalloc((void**)&d.qrank, wq1 * 4) == hipSuccess && hipMalloc((void**)&d.qtmp, wq1 * 16) == hipSuccess &&
               hipMalloc((void**)&d.qs, wq * 16) == hipSuccess && hipMalloc((void**)&d.units, (size_t)rows * d.unit_stride * 16) == hipSuccess &&
-              hipMalloc((void**)&d.counters, (size_t)rows * 8) == hipSuccess;
-    ok = ok && hipMemset(d.keys, 0xff, tq * 8) == hipSuccess && hipMemset(d.cnt, 0, tq * 4) == hipSuccess && hipMemset(d.counters, 0, (size_t)rows * 8) == hipSuccess;
+              hipMalloc((void**)&d.counters, (size_t)rows * 16) == hipSuccess && hipMalloc((void**)&d.fails, (size_t)rows * d.unit_stride * 8) == hipSuccess;
+    ok = ok && hipMemset(d.keys, 0xff, tq * 8) == hipSuccess && hipMemset(d.cnt, 0, tq * 4) == hipSuccess && hipMemset(d.counters, 0, (size_t)rows * 16) == hipSuccess;
     if (!ok) { glio_set_error("hipMalloc failed for the query binning buffers"); return nullptr; }
     return h;
 }
 static void knn_bin_destroy(KnnBinHost* h) {
     if (!h) return;
-    void* p[] = {h->d.keys, h->d.cnt, h->d.cstart, h->d.qslot, h->d.qrank, h->d.qtmp, h->d.qs, h->d.units, h->d.counters};
+    void* p[] = {h->d.keys, h->d.cnt, h->d.cstart, h->d.qslot, h->d.qrank, h->d.qtmp, h->d.qs, h->d.units, h->d.counters, h->d.fails};
     for (void* q : p) if (q) hipFree(q);
     delete h;
 }
@@ -1097,12 +1395,12 @@ static void enqueue_presort(hipStream_t stream, KnnBinHost* kb, const float4* cl
     hipLaunchKernelGGL(k_qbin_count, dim3((n + 255) / 256), dim3(256), 0, stream, a, cloud);
     hipLaunchKernelGGL(k_qbin_alloc, dim3(a.kb.capq / 1024), dim3(1024), 0, stream, a);
     hipLaunchKernelGGL(k_qbin_scatter, dim3((n + 255) / 256), dim3(256), 0, stream, a);
-    hipMemsetAsync(kb->d.counters, 0, 8, stream);
+    hipMemsetAsync(kb->d.counters, 0, 16, stream);
 }
 // exact 5-NN of every query of the launch rows [0, rows): the caller's AssocArgs select the row geometry (assoc_slot);
 // `scan` = the clouds as uploaded, `ps` = their presorted copies
 static void enqueue_knn(hipStream_t stream, AssocArgs& a, KnnBinHost* kb, int rows, int maxn, const float4* scan, const float4* ps, const float4* map,
-                        const int4* ent, int* nn5, float* d4) {
+                        const int4* ent, const uint4* sub, int map_n_max, int* nn5, float* d4) {
     if (g_knn_mode == 1 || !kb) {
         memset(&a.kb, 0, sizeof a.kb);
         hipLaunchKernelGGL(k_knn5, dim3((maxn + AQ_PER_BLOCK - 1) / AQ_PER_BLOCK, rows), dim3(256), 0, stream, a, scan, map, ent, nn5, d4);
@@ -1116,7 +1414,16 @@ static void enqueue_knn(hipStream_t stream, AssocArgs& a, KnnBinHost* kb, int ro
     //  window association of 20 rows: the dispatcher is not the limit, and fresh workgroups overlap their probe / staging latencies better)
     int gx = (maxn + 8 * TK_UNITS - 1) / (8 * TK_UNITS);
     if (gx > 4096) gx = 4096;
+    // (the tie-break index rides in 24 bits of the near-block search's exact key: maps beyond 2^24 points take the 27-cell search alone)
+    if (g_knn_mode == 0 && map_n_max <= (1 << 24)) {
+        int gn = (maxn + 8 * NK_UNITS - 1) / (8 * NK_UNITS);
+        if (gn > 4096) gn = 4096;
+        hipLaunchKernelGGL(k_knn5_near, dim3(gn, rows), dim3(64), 0, stream, a, map, ent, sub, nn5, d4);
+        a.kb.use_fails = 1;
+        if (gx > 512) gx = 512;                                  // the list is short (0.1-3 % of the queries on the C2 stream): striding workgroups
+    }
     hipLaunchKernelGGL(k_knn5_tile, dim3(gx, rows), dim3(TK_THREADS), 0, stream, a, map, ent, nn5, d4);
+    a.kb.use_fails = 0;
 }
 
 int glio_assoc_create(glio_ctx* c) {
@@ -1130,9 +1437,9 @@ int glio_assoc_create(glio_ctx* c) {
     const int cap = c->cap;
 #define AALLOC(ptr, bytes) do { if (hipMalloc((void**)&(ptr), (size_t)(bytes)) != hipSuccess) { glio_set_error("hipMalloc failed in assoc_create"); return GLIO_E_HIP; } } while (0)
     w->cap_eff = w->table_cap;
-    AALLOC(w->d_keys, (size_t)w->table_cap * 8); AALLOC(w->d_ent, (size_t)w->table_cap * 16); AALLOC(w->d_cell_count, (size_t)w->table_cap * 4);
-    AALLOC(w->d_cell_start, (size_t)w->table_cap * 4); AALLOC(w->d_cell_fill, (size_t)w->table_cap * 4);
-    AALLOC(w->d_pt_slot, (size_t)mm * 4); AALLOC(w->d_map_raw, (size_t)mm * 16); AALLOC(c->d_map_sorted, (size_t)mm * 16);
+    AALLOC(w->d_keys, (size_t)w->table_cap * 8); AALLOC(w->d_ent, (size_t)w->table_cap * 16); AALLOC(w->d_cnt8, (size_t)w->table_cap * 32);
+    AALLOC(w->d_sub, (size_t)w->table_cap * 16);
+    AALLOC(w->d_pt_slot, (size_t)mm * 4); AALLOC(w->d_pt_rank, (size_t)mm * 4); AALLOC(w->d_map_raw, (size_t)mm * 16); AALLOC(c->d_map_sorted, (size_t)mm * 16);
     AALLOC(w->d_total, 4); AALLOC(w->d_count_tmp, 4);
     // dense per-query work arrays for ALL W slots (72 B per query): the window association runs the slots in one launch
     const size_t wc = (size_t)cap * c->W, wb = (size_t)(cap / AQ_PER_BLOCK + 2) * c->W;
@@ -1156,7 +1463,7 @@ int glio_assoc_create(glio_ctx* c) {
 void glio_assoc_destroy(glio_ctx* c) {
     AssocWork* w = c->assoc;
     if (!w) return;
-    void* ptrs[] = {w->d_keys, w->d_ent, w->d_cell_count, w->d_cell_start, w->d_cell_fill, w->d_pt_slot, w->d_map_raw, c->d_map_sorted, w->d_total,
+    void* ptrs[] = {w->d_keys, w->d_ent, w->d_cnt8, w->d_sub, w->d_pt_slot, w->d_pt_rank, w->d_map_raw, c->d_map_sorted, w->d_total,
                     w->d_count_tmp, w->d_q_pt, w->d_q_plane, w->d_q_score, w->d_q_flag, w->d_q_pos, w->d_nn, w->d_nn5, w->d_d4, w->d_bcount, w->d_boff, w->d_win, w->d_ps};
     for (void* p : ptrs) if (p) hipFree(p);
     knn_bin_destroy(w->kb);
@@ -1202,11 +1509,11 @@ static void enqueue_build(glio_ctx* c, int n) {
     int cap = next_pow2(2 * (n > 512 ? n : 512));          // sized for THIS map: a smaller table stays in L2
     if (cap > w->table_cap) cap = w->table_cap;
     w->cap_eff = cap;
-    hipLaunchKernelGGL(k_hash_clear, dim3((cap + 255) / 256), dim3(256), 0, c->stream, w->d_keys, w->d_cell_count, w->d_cell_fill, cap, w->d_total, w->d_ent);
+    hipLaunchKernelGGL(k_hash_clear, dim3((cap + 255) / 256), dim3(256), 0, c->stream, w->d_keys, w->d_cnt8, cap, w->d_total, w->d_ent, w->d_sub);
     if (n == 0) return;
-    hipLaunchKernelGGL(k_hash_insert, dim3((n + 255) / 256), dim3(256), 0, c->stream, w->d_map_raw, n, w->inv_cell, w->d_keys, w->d_cell_count, w->d_pt_slot, cap);
-    hipLaunchKernelGGL(k_cell_alloc, dim3((cap + 1023) / 1024), dim3(1024), 0, c->stream, w->d_cell_count, w->d_cell_start, cap, w->d_total, w->d_keys, w->d_ent);
-    hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, c->stream, w->d_map_raw, n, w->d_pt_slot, w->d_cell_start, w->d_cell_fill, c->d_map_sorted);
+    hipLaunchKernelGGL(k_hash_insert, dim3((n + 255) / 256), dim3(256), 0, c->stream, w->d_map_raw, n, w->inv_cell, w->d_keys, w->d_cnt8, w->d_pt_slot, w->d_pt_rank, cap);
+    hipLaunchKernelGGL(k_cell_alloc, dim3((cap + 1023) / 1024), dim3(1024), 0, c->stream, w->d_cnt8, cap, w->d_total, w->d_keys, w->d_ent, w->d_sub);
+    hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, c->stream, w->d_map_raw, n, w->d_pt_slot, w->d_pt_rank, w->d_cnt8, w->d_ent, c->d_map_sorted);
 }
 
 int glio_assoc_build_map(glio_ctx* c, const float* map_xyzi, int n) {
@@ -1238,14 +1545,14 @@ static void enqueue_assoc(glio_ctx* c, int slot, const double q[4], const double
     memset(&a, 0, sizeof a);
     for (int k = 0; k < 4; ++k) a.q[k] = q[k];
     for (int k = 0; k < 3; ++k) a.t[k] = t[k];
-    a.inv_cell = w->inv_cell; a.kd_max_radius = c->opts.kd_max_radius; a.weight_gate = c->opts.weight_gate;
+    a.inv_cell = w->inv_cell; a.cell = w->cell; a.kd_max_radius = c->opts.kd_max_radius; a.weight_gate = c->opts.weight_gate;
     a.surf_dist_thres = c->opts.surf_dist_thres; a.lidar_const = c->opts.lidar_const;
     a.n = n; a.table_cap = w->cap_eff; a.unit_scores = c->opts.unit_scores;
     a.win_poses = nullptr; a.win_counts = nullptr; a.q_stride = a.w_stride = a.b_stride = 0;
     const size_t off = (size_t)slot * c->cap;
     const int nblk = (n + PF_BLOCK - 1) / PF_BLOCK;
     if (n > 0) {
-        enqueue_knn(c->stream, a, w->kb, 1, n, c->d_scan + off, w->d_ps + off, c->d_map_sorted, w->d_ent, w->d_nn5, w->d_d4);
+        enqueue_knn(c->stream, a, w->kb, 1, n, c->d_scan + off, w->d_ps + off, c->d_map_sorted, w->d_ent, w->d_sub, c->map_n, w->d_nn5, w->d_d4);
         hipLaunchKernelGGL(k_plane_fit<false>, dim3(nblk), dim3(PF_BLOCK), 0, c->stream, a, c->d_scan + off, c->d_map_sorted, w->d_nn5, w->d_d4,
                            w->d_q_pt, w->d_q_plane, w->d_q_score, w->d_q_flag, w->d_q_pos, w->d_bcount, want_nn ? w->d_nn : nullptr,
                            (const float4*)nullptr, (double*)nullptr);
@@ -1272,13 +1579,13 @@ static int enqueue_assoc_window(glio_ctx* c, const double* quats, const double* 
     GLIO_HIP_CHECK(hipMemcpyAsync(w->d_win, w->h_win, (size_t)W * 60, hipMemcpyHostToDevice, c->stream));
     AssocArgs a;
     memset(&a, 0, sizeof a);
-    a.inv_cell = w->inv_cell; a.kd_max_radius = c->opts.kd_max_radius; a.weight_gate = c->opts.weight_gate;
+    a.inv_cell = w->inv_cell; a.cell = w->cell; a.kd_max_radius = c->opts.kd_max_radius; a.weight_gate = c->opts.weight_gate;
     a.surf_dist_thres = c->opts.surf_dist_thres; a.lidar_const = c->opts.lidar_const;
     a.n = 0; a.table_cap = w->cap_eff; a.unit_scores = c->opts.unit_scores;
     a.win_poses = w->d_win; a.win_counts = reinterpret_cast<const int*>(w->d_win + 7 * W);
     a.q_stride = c->cap; a.w_stride = c->cap; a.b_stride = c->cap / AQ_PER_BLOCK + 2;
     if (maxn > 0) {
-        enqueue_knn(c->stream, a, w->kb, W, maxn, c->d_scan, w->d_ps, c->d_map_sorted, w->d_ent, w->d_nn5, w->d_d4);
+        enqueue_knn(c->stream, a, w->kb, W, maxn, c->d_scan, w->d_ps, c->d_map_sorted, w->d_ent, w->d_sub, c->map_n, w->d_nn5, w->d_d4);
         hipLaunchKernelGGL(k_plane_fit<false>, dim3((maxn + PF_BLOCK - 1) / PF_BLOCK, W), dim3(PF_BLOCK), 0, c->stream, a, c->d_scan, c->d_map_sorted,
                            w->d_nn5, w->d_d4, w->d_q_pt, w->d_q_plane, w->d_q_score, w->d_q_flag, w->d_q_pos, w->d_bcount, (int*)nullptr,
                            (const float4*)nullptr, (double*)nullptr);
@@ -1424,19 +1731,20 @@ void glio_assoc_time_hooks(glio_ctx* c, int which, int reps, float* ms) {
 // ================================================================================================
 struct FrameHash {
     int n, table_cap, cap_eff;
-    unsigned long long* d_keys; int4* d_ent; int* d_cell_count; int* d_cell_start; int* d_cell_fill; int* d_pt_slot;
+    int4* d_ent; uint4* d_sub;        // resident: what the pair searches read
     float4* d_sorted;
 };
 struct glio_bassoc {
     int device; hipStream_t stream;
     int K, cap; long long max_con;
-    float inv_cell;
+    float inv_cell, cell;
     float4* d_local;                // [K][cap] keyframe-local clouds
     float4* d_local_ps;             // [K][cap] the same, presorted (w = index in the cloud)
     float4* d_global;               // [cap] staging: one cloud in the global frame
     int* h_n;                       // [K]
     FrameHash* frames;              // [K]
     int* d_total;                   // scratch of the hash build: [BA_FB]
+    unsigned long long* d_bkeys; unsigned* d_bcnt8; int* d_bslot; int* d_brank;      // build scratch of one batch of BA_FB keyframes: [BA_FB][tc], [BA_FB][tc][8], [BA_FB][cap] x 2
     struct FrameBuild* d_fb; struct FrameBuild* h_fb;       // [K] build descriptors of the keyframes of a run, batch after batch (device / pinned)
     // dense per-query results of the pair in flight
     float4* d_q_cp; double* d_q_nc; double* d_q_score; int* d_q_flag; int* d_q_pos; int* d_bcount; int* d_boff;
@@ -1470,14 +1778,12 @@ __global__ void k_transform_cloud(const float4* __restrict__ in, int n, const do
 // every pair of a C4-sized batch took.  Same device code as the single-frame kernels above, addressed through a descriptor per keyframe.
 #define BA_FB 64
 struct FrameBuild {
-    unsigned long long* keys; int4* ent; int* cnt; int* start; int* fill; int* pt_slot; float4* sorted;
+    unsigned long long* keys; int4* ent; uint4* sub; unsigned* cnt8; int* pt_slot; int* pt_rank; float4* sorted;
     const float4* local; float4* global; const double* pose; int* total; int n, tc;
 };
 __global__ void k_hash_clear_multi(const FrameBuild* __restrict__ fb) {
     const FrameBuild f = fb[blockIdx.y];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < f.tc) { f.keys[i] = KEY_EMPTY; f.cnt[i] = 0; f.fill[i] = 0; f.ent[i] = make_int4(-1, -1, 0, 0); }
-    if (i == 0) *f.total = 0;
+    hash_clear_slot(blockIdx.x * blockDim.x + threadIdx.x, f.tc, f.keys, f.cnt8, f.total, f.ent, f.sub);
 }
 __global__ void k_transform_cloud_multi(const FrameBuild* __restrict__ fb) {
     const FrameBuild f = fb[blockIdx.y];
@@ -1493,57 +1799,18 @@ __global__ void k_transform_cloud_multi(const FrameBuild* __restrict__ fb) {
 __global__ void k_hash_insert_multi(const FrameBuild* __restrict__ fb, const float inv_cell) {
     const FrameBuild f = fb[blockIdx.y];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= f.n) return;
-    const float4 p = f.global[i];
-    const int cx = cell_of(p.x, inv_cell), cy = cell_of(p.y, inv_cell), cz = cell_of(p.z, inv_cell);
-    const unsigned long long key = pack_key(cx, cy, cz);
-    unsigned s = home_slot(cx, cy, cz, f.tc);
-    for (;;) {
-        unsigned long long prev = f.keys[s];
-        if (prev != key) prev = atomicCAS(&f.keys[s], KEY_EMPTY, key);
-        if (prev == KEY_EMPTY || prev == key) break;
-        s = (s + 1) & (f.tc - 1);
-    }
-    atomicAdd(&f.cnt[s], 1);
-    f.pt_slot[i] = (int)s;
+    if (i < f.n) hash_insert_point(f.global[i], i, inv_cell, f.keys, f.cnt8, f.pt_slot, f.pt_rank, f.tc);
 }
 __global__ __launch_bounds__(1024) void k_cell_alloc_multi(const FrameBuild* __restrict__ fb) {
     __shared__ int s_w[16], s_base;
     const FrameBuild f = fb[blockIdx.y];
-    const int i = blockIdx.x * 1024 + threadIdx.x;
     if (blockIdx.x * 1024 >= f.tc) return;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int c = i < f.tc ? f.cnt[i] : 0;
-    int incl = c;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
-    }
-    if (lane == 63) s_w[wv] = incl;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int t = 0;
-        for (int k = 0; k < 16; ++k) { const int v = s_w[k]; s_w[k] = t; t += v; }
-        s_base = t > 0 ? atomicAdd(f.total, t) : 0;
-    }
-    __syncthreads();
-    const int st = s_base + s_w[wv] + incl - c;
-    if (i < f.tc && c > 0) f.start[i] = st;
-    if (i < f.tc) {
-        const unsigned long long k = f.keys[i];
-        f.ent[i] = make_int4((int)(unsigned)(k & 0xffffffffull), (int)(unsigned)(k >> 32), st, c);
-    }
+    cell_alloc_slot(blockIdx.x * 1024 + threadIdx.x, f.tc, f.cnt8, f.total, f.keys, f.ent, f.sub, s_w, &s_base);
 }
 __global__ void k_scatter_multi(const FrameBuild* __restrict__ fb) {
     const FrameBuild f = fb[blockIdx.y];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= f.n) return;
-    const int s = f.pt_slot[i];
-    const int pos = f.start[s] + atomicAdd(&f.fill[s], 1);
-    float4 p = f.global[i];
-    p.w = __int_as_float(i);
-    f.sorted[pos] = p;
+    if (i < f.n) scatter_point(f.global[i], i, f.pt_slot, f.pt_rank, f.cnt8, f.ent, f.sorted);
 }
 
 // Compaction of the kept records, pair major, for a CHUNK of pairs per launch (blockIdx.y / wavefront = pair of the chunk):
@@ -1606,7 +1873,7 @@ __global__ void k_compact_pairs(const int* __restrict__ flag, const int* __restr
 extern "C" {
 
 int glio_debug_set_knn_mode(int mode) {
-    if (mode != 0 && mode != 1) return GLIO_E_ARG;
+    if (mode < 0 || mode > 2) return GLIO_E_ARG;
     g_knn_mode = mode;
     return GLIO_OK;
 }
@@ -1620,7 +1887,8 @@ int glio_bassoc_create(int device, int K, int max_points_per_frame, int64_t max_
     memset(b, 0, sizeof *b);
     b->device = device; b->K = K; b->cap = max_points_per_frame; b->max_con = max_constraints;
     BA_CHECK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-    b->inv_cell = 1.0f / fmaxf(1.25f, sqrtf(1.5f) * 1.0001f);
+    b->cell = fmaxf(1.25f, sqrtf(1.5f) * 1.0001f);
+    b->inv_cell = 1.0f / b->cell;
     const size_t cap = (size_t)b->cap;
     BA_CHECK(hipMalloc((void**)&b->d_local, (size_t)K * cap * 16)); BA_CHECK(hipMalloc((void**)&b->d_global, (size_t)BA_FB * cap * 16));
     BA_CHECK(hipMalloc((void**)&b->d_local_ps, (size_t)K * cap * 16));
@@ -1630,12 +1898,13 @@ int glio_bassoc_create(int device, int K, int max_points_per_frame, int64_t max_
     for (int k = 0; k < K; ++k) {
         FrameHash& f = b->frames[k];
         f.table_cap = tc;
-        BA_CHECK(hipMalloc((void**)&f.d_keys, (size_t)tc * 8)); BA_CHECK(hipMalloc((void**)&f.d_ent, (size_t)tc * 16));
-        BA_CHECK(hipMalloc((void**)&f.d_cell_count, (size_t)tc * 4));
-        BA_CHECK(hipMalloc((void**)&f.d_cell_start, (size_t)tc * 4)); BA_CHECK(hipMalloc((void**)&f.d_cell_fill, (size_t)tc * 4));
-        BA_CHECK(hipMalloc((void**)&f.d_pt_slot, cap * 4)); BA_CHECK(hipMalloc((void**)&f.d_sorted, cap * 16));
+        BA_CHECK(hipMalloc((void**)&f.d_ent, (size_t)tc * 16)); BA_CHECK(hipMalloc((void**)&f.d_sub, (size_t)tc * 16)); BA_CHECK(hipMalloc((void**)&f.d_sorted, cap * 16));
+        // (a keyframe that never serves as a search frame keeps an EMPTY table: the probes of a stray pair end at once)
+        BA_CHECK(hipMemsetAsync(f.d_ent, 0xff, (size_t)tc * 16, b->stream));
     }
     BA_CHECK(hipMalloc((void**)&b->d_total, (size_t)BA_FB * 4));
+    BA_CHECK(hipMalloc((void**)&b->d_bkeys, (size_t)BA_FB * tc * 8)); BA_CHECK(hipMalloc((void**)&b->d_bcnt8, (size_t)BA_FB * tc * 32));
+    BA_CHECK(hipMalloc((void**)&b->d_bslot, (size_t)BA_FB * cap * 4)); BA_CHECK(hipMalloc((void**)&b->d_brank, (size_t)BA_FB * cap * 4));
     BA_CHECK(hipMalloc((void**)&b->d_fb, (size_t)K * sizeof(FrameBuild))); BA_CHECK(hipHostMalloc((void**)&b->h_fb, (size_t)K * sizeof(FrameBuild)));
     // dense per-query work arrays for a chunk of BA_CHUNK pairs (104 B per query and pair)
     const size_t wc = cap * BA_CHUNK;
@@ -1660,10 +1929,10 @@ void glio_bassoc_destroy(glio_bassoc* b) {
     hipStreamSynchronize(b->stream);
     for (int k = 0; k < b->K; ++k) {
         FrameHash& f = b->frames[k];
-        void* p[] = {f.d_keys, f.d_ent, f.d_cell_count, f.d_cell_start, f.d_cell_fill, f.d_pt_slot, f.d_sorted};
+        void* p[] = {f.d_ent, f.d_sub, f.d_sorted};
         for (void* q : p) if (q) hipFree(q);
     }
-    void* p[] = {b->d_nn5, b->d_d4, b->d_local, b->d_local_ps, b->d_global, b->d_total, b->d_q_cp, b->d_q_nc, b->d_q_score, b->d_q_flag, b->d_q_pos, b->d_bcount, b->d_boff,
+    void* p[] = {b->d_bkeys, b->d_bcnt8, b->d_bslot, b->d_brank, b->d_nn5, b->d_d4, b->d_local, b->d_local_ps, b->d_global, b->d_total, b->d_q_cp, b->d_q_nc, b->d_q_score, b->d_q_flag, b->d_q_pos, b->d_bcount, b->d_boff,
                  b->d_cp, b->d_nc, b->d_score, b->d_run, b->d_poses, b->d_pair_off, b->d_frames, b->d_pair_ci, b->d_pair_cj,
                  b->d_sel_cp, b->d_sel_nc, b->d_sel_score, b->d_sel_idx};
     for (void* q : p) if (q) hipFree(q);
@@ -1721,7 +1990,9 @@ int glio_bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const int3
                 if (tc > f.table_cap) tc = f.table_cap;
                 f.n = n; f.cap_eff = tc;
                 FrameBuild& d = b->h_fb[t0 + q];
-                d.keys = f.d_keys; d.ent = f.d_ent; d.cnt = f.d_cell_count; d.start = f.d_cell_start; d.fill = f.d_cell_fill; d.pt_slot = f.d_pt_slot; d.sorted = f.d_sorted;
+                d.keys = b->d_bkeys + (size_t)q * f.table_cap; d.cnt8 = b->d_bcnt8 + (size_t)q * f.table_cap * 8;
+                d.pt_slot = b->d_bslot + (size_t)q * b->cap; d.pt_rank = b->d_brank + (size_t)q * b->cap;
+                d.ent = f.d_ent; d.sub = f.d_sub; d.sorted = f.d_sorted;
                 d.local = b->d_local + (size_t)k * b->cap; d.global = b->d_global + (size_t)q * b->cap; d.pose = b->d_poses + 7 * k; d.total = b->d_total + q; d.n = n; d.tc = tc;
                 if (tc > max_tc) max_tc = tc;
                 if (n > max_n) max_n = n;
@@ -1741,7 +2012,7 @@ int glio_bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const int3
         std::vector<FrameDesc> fd(b->K);
         int maxn = 0;
         for (int k = 0; k < b->K; ++k) {
-            fd[k].ent = b->frames[k].d_ent; fd[k].sorted = b->frames[k].d_sorted; fd[k].n = b->h_n[k];
+            fd[k].ent = b->frames[k].d_ent; fd[k].sub = b->frames[k].d_sub; fd[k].sorted = b->frames[k].d_sorted; fd[k].n = b->h_n[k];
             fd[k].cap_eff = need[k] ? b->frames[k].cap_eff : b->frames[k].table_cap;
             if (b->h_n[k] > maxn) maxn = b->h_n[k];
         }
@@ -1751,7 +2022,7 @@ int glio_bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const int3
         BA_CHECK(hipStreamSynchronize(b->stream));                       // the three sources are pageable host memory
         AssocArgs a;
         memset(&a, 0, sizeof a);
-        a.inv_cell = b->inv_cell; a.kd_max_radius = 1.5; a.weight_gate = 0.3; a.surf_dist_thres = 0.18; a.lidar_const = 2.5;   // :3839,3874,3863,3885
+        a.inv_cell = b->inv_cell; a.cell = b->cell; a.kd_max_radius = 1.5; a.weight_gate = 0.3; a.surf_dist_thres = 0.18; a.lidar_const = 2.5;   // :3839,3874,3863,3885
         a.unit_scores = 0;
         a.q_stride = b->cap; a.w_stride = b->cap; a.b_stride = b->b_stride;
         a.frames = b->d_frames; a.pair_ci = b->d_pair_ci; a.pair_cj = b->d_pair_cj; a.poses = b->d_poses;
@@ -1759,7 +2030,7 @@ int glio_bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const int3
             const int np = n_pairs - p0 < BA_CHUNK ? n_pairs - p0 : BA_CHUNK;
             a.pair0 = p0;
             if (maxn > 0) {
-                enqueue_knn(b->stream, a, b->kb, np, maxn, b->d_local, b->d_local_ps, (const float4*)nullptr, (const int4*)nullptr, b->d_nn5, b->d_d4);
+                enqueue_knn(b->stream, a, b->kb, np, maxn, b->d_local, b->d_local_ps, (const float4*)nullptr, (const int4*)nullptr, (const uint4*)nullptr, b->cap, b->d_nn5, b->d_d4);
                 hipLaunchKernelGGL(k_plane_fit<true>, dim3((maxn + PF_BLOCK - 1) / PF_BLOCK, np), dim3(PF_BLOCK), 0, b->stream, a, b->d_local, (const float4*)nullptr,
                                    b->d_nn5, b->d_d4, b->d_q_cp, (float4*)nullptr, b->d_q_score, b->d_q_flag, b->d_q_pos, b->d_bcount, (int*)nullptr,
                                    b->d_local, b->d_q_nc);

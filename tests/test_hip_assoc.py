@@ -173,7 +173,7 @@ def test_tiled_search_exact_ties_and_dense_cells(hip, po):
     # (c) 5003 queries inside ONE voxel-hash cell (a tile of 1024 queries with a single key: 64 units of the same cell)
     cl = np.zeros((5003, 4), np.float32); cl[:, :3] = rng.uniform([8.0, 0.1, -0.2], [8.9, 1.0, 0.2], (5003, 3))
     lib = hip.load()
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         lib.glio_debug_set_knn_mode(mode)
         try:
             for m, q in ((lat_map, qs), (dense, dq), (dense, cl)):
@@ -192,7 +192,7 @@ def test_both_search_modes_give_identical_records(hip):
     win = synth.make_window(W=2, pts_per_scan=65536, seed=synth.SEED_BASE + 10)
     lib = hip.load()
     out = []
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         lib.glio_debug_set_knn_mode(mode)
         try:
             ctx = hip.Context(win.opts)
