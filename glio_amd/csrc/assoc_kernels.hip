@@ -20,6 +20,7 @@
 // Roofline: gather-bound.  Algorithmic bytes per query = 16 (query) + 5*16 (true neighbours) + 40
 // (output record) = 136 B; the 27-cell candidate scan is served by L2.
 #include <cfloat>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -57,7 +58,7 @@ struct AssocWork {
     // per-query dense results (capacity = cap of a slot)
     float4* d_q_pt; float4* d_q_plane; double* d_q_score; int* d_q_flag; int* d_q_pos;
     int* d_nn;                    // optional [cap][5] neighbour indices (tests)
-    int* d_nn5; float* d_d4;      // [cap][5] positions of the 5-NN in the sorted map, [cap] fifth distance (k_knn5 -> k_plane_fit)
+    int* d_nn5;                   // [cap][8] per query: positions of the 5-NN in the sorted map, the fifth distance (bits), 2 pad (searches -> k_plane_fit)
     int* d_bcount; int* d_boff;   // per-workgroup kept counts and their exclusive scan
     int* d_count_tmp;
     int* h_count;                 // pinned
@@ -281,6 +282,7 @@ __device__ __forceinline__ void plane_qr_solve(double A[5][3], double b[5], doub
 
 // Query binning of the tiled neighbour search (k_qbin_* / k_knn5_tile): per launch row y (a scan, a window slot or a keyframe
 // pair) the queries are grouped by the voxel-hash cell they fall in; a UNIT is up to TK_LANES queries of one cell.
+#define NK_ROW_SHIFT 26    /* merged window: w of a grouped query = launch row << 26 | index in the scan */
 struct KnnBin {
     // presort of one uploaded cloud (k_qbin_count / _alloc / _scatter, launch row 0 only):
     unsigned long long* keys; int* cnt; int* cstart;      // [capq] open-addressing table of the occupied cells (left EMPTY / 0 by k_qbin_alloc)
@@ -289,9 +291,21 @@ struct KnnBin {
     float4* qs;                                           // [Y][w_stride] queries grouped by cell (world xyz, w = index in the scan); the presort's output pointer
     int4* units;                                          // [Y][unit_stride] (first grouped position, queries, cell key lo, hi): the search probes from the record alone
     int* counters;                                        // [Y][4] grouped queries, units, units the near-block search handed on (zeroed again by k_plane_fit)
-    int2* fails;                                          // [Y][unit_stride] (unit, mask of its queries) the near-block search (k_knn5_near) could not certify
+    int4* fails;                                          // [Y][unit_stride] (first grouped query, queries | mask << 16, cell key lo, hi): up to 16 queries of a cell the near-block
+                                                          // search (k_knn5_near) hands on to the 27-cell tiled search
+    int* failq;                                           // [Y][w_stride_q] grouped positions of single uncertified queries (searched by k_knn5<true>, one 16-lane group each)
     int use_fails;                                        // k_knn5_tile: 1 = run over `fails` instead of every unit
+    unsigned long long* dbg;                              // nullptr, or [8] statistics of the near-block search (glio_debug_knn_stats)
     int capq, unit_stride;
+    // merged-window mode (glob = 1): the queries of ALL launch rows grouped by cell together.  k_qbin_tile emits (tile, cell) segments and counts them per
+    // cell in a global table, k_gbin_alloc lays the cells out and cuts them into units of <= 64 queries, k_gbin_scatter copies the segments into qs2; the
+    // searches then run as ONE launch row over `units` / `fails` / `failq` used flat and the counter block gctr (same layout as a row of `counters`).
+    int glob;
+    float4* qs2;                                          // [Y * w_stride] queries grouped by cell across the rows (w = row << 26 | index in the scan)
+    unsigned long long* gkeys; int* gcnt; int* gstart;    // [gcap] cell table (left EMPTY / 0 by k_gbin_alloc), first position of the cell in qs2
+    int4* segs;                                           // [Y * w_stride] (table slot or -1, offset inside the cell or absolute position, position in qs incl. row offset, queries)
+    int* gctr;                                            // [8] queries laid out, units, handed-on units, handed-on queries, segments, cells, orphan queries, -
+    int gcap, qcap_total;
 };
 
 struct AssocArgs {
@@ -306,6 +320,7 @@ struct AssocArgs {
     const double* win_poses;                // [W][7] = q (w, x, y, z), t
     const int* win_counts;                  // [W]
     int q_stride, w_stride, b_stride;       // scan + correspondence arrays, dense work arrays, per-workgroup counts
+    int w_stride_q;                         // row stride of kb.failq (= the binning capacity per row)
     // pair mode (glio_bassoc_run): blockIdx.y = pair inside the chunk; pair (ci, cj) queries the cloud of keyframe ci
     // (local frame, posed with poses[ci]) against the voxel hash of keyframe cj
     const struct FrameDesc* frames;         // [K]
@@ -409,26 +424,43 @@ __device__ __forceinline__ void knn5_insert(const float px, const float py, cons
     knn5_insert_key(((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(mp.w), m, bk, bp);
 }
 
-__global__ __launch_bounds__(256) void k_knn5(const AssocArgs a, const float4* __restrict__ scan, const float4* __restrict__ map,
-                                              const int4* __restrict__ ent, int* __restrict__ o_nn5, float* __restrict__ o_d4) {
+// LIST = false: query i of the launch row = point i of the scan (transformed here).  LIST = true: the queries the near-block search could not
+// certify -- `failq` holds their positions in the grouped query array (world frame already, w = index in the scan); the workgroups stride over the list.
+// (bx of gdx workgroups of blockDim.x threads work on the launch row blockIdx.y; s_tab: one 33-entry cell table per group of the workgroup)
+template <bool LIST>
+__device__ __forceinline__ void knn5_group_body(const AssocArgs& a, const float4* __restrict__ scan, const float4* __restrict__ map, const int4* __restrict__ ent,
+                                                int* __restrict__ o_nn5, const int bx, const int gdx, int2 (*s_tab)[33]) {
     // per query: the 27 cells as (exclusive prefix of candidate counts, first point); entries 27..31 hold the total
     static_assert(AQ_ROUNDS * AQ_LANES <= 32 && AQ_LANES >= 2, "the cell table of a query has 32 entries");
-    __shared__ int2 s_tab[AQ_PER_BLOCK][33];
     const int lane = threadIdx.x & 63, j = threadIdx.x & (AQ_LANES - 1), g = threadIdx.x / AQ_LANES;
     const int gbase = lane & ~(AQ_LANES - 1);                 // first lane of this group inside the wavefront
-    const int i = blockIdx.x * AQ_PER_BLOCK + g;
+    const int per_block = blockDim.x / AQ_LANES;
     const AssocSlot sl = assoc_slot(a);
-    if (blockIdx.x * AQ_PER_BLOCK >= sl.n) return;
-    scan += sl.qoff; o_nn5 += 5 * sl.woff; o_d4 += sl.woff;
+    const int n_q = LIST ? a.kb.counters[4 * blockIdx.y + 3] : sl.n;
+    if (bx * per_block >= n_q) return;
+    const bool glob = LIST && a.kb.glob != 0;
+    scan += sl.qoff;
+    if (!glob) { o_nn5 += 8 * sl.woff; }
     if (sl.ent) { ent = sl.ent; map = sl.map; }
     const int table_cap = sl.table_cap;
-    const bool qlive = i < sl.n;
-    const float4 pl = scan[qlive ? i : 0];
-    // transformPoint: double math, float store
-    const double pin[3] = {(double)pl.x, (double)pl.y, (double)pl.z};
-    double po[3];
-    a_qrot(sl.q, pin, po);
-    const float px = (float)(po[0] + sl.t[0]), py = (float)(po[1] + sl.t[1]), pz = (float)(po[2] + sl.t[2]);
+  for (int i0 = bx * per_block; i0 < n_q; i0 += gdx * per_block) {
+    size_t i = (size_t)(i0 + g);
+    const bool qlive = i0 + g < n_q;
+    float px, py, pz;
+    if (LIST) {
+        const int fq = qlive ? a.kb.failq[(size_t)blockIdx.y * a.w_stride_q + i] : 0;
+        const float4 qp = glob ? a.kb.qs2[fq] : a.kb.qs[sl.woff + fq];
+        const int qw = __float_as_int(qp.w);
+        px = qp.x; py = qp.y; pz = qp.z;
+        i = glob ? (size_t)((unsigned)qw >> NK_ROW_SHIFT) * a.w_stride + (qw & ((1 << NK_ROW_SHIFT) - 1)) : (size_t)qw;
+    } else {
+        const float4 pl = scan[qlive ? i : 0];
+        // transformPoint: double math, float store
+        const double pin[3] = {(double)pl.x, (double)pl.y, (double)pl.z};
+        double po[3];
+        a_qrot(sl.q, pin, po);
+        px = (float)(po[0] + sl.t[0]); py = (float)(po[1] + sl.t[1]); pz = (float)(po[2] + sl.t[2]);
+    }
     const int cx = cell_of(px, a.inv_cell), cy = cell_of(py, a.inv_cell), cz = cell_of(pz, a.inv_cell);
     // ---- probe: lane j looks up cells j and j + AQ_LANES of the 27-neighbourhood (one 16 B entry per probe)
     int cs[AQ_ROUNDS], cc[AQ_ROUNDS];
@@ -508,10 +540,17 @@ __global__ __launch_bounds__(256) void k_knn5(const AssocArgs a, const float4* _
         }
     }
     if (j == 0 && qlive) {
-#pragma unroll
-        for (int k = 0; k < 5; ++k) o_nn5[5 * (size_t)i + k] = mp5[k];
-        o_d4[i] = md4;
+        int4* rec = reinterpret_cast<int4*>(o_nn5 + 8 * i);         // one 32 B record per query: five positions, the fifth distance
+        rec[0] = make_int4(mp5[0], mp5[1], mp5[2], mp5[3]); rec[1] = make_int4(mp5[4], __float_as_int(md4), 0, 0);
     }
+    if (!LIST) break;
+    GLIO_WAVE_LDS_SYNC();                       // (the next query of this group rewrites its cell table)
+  }
+}
+__global__ __launch_bounds__(256) void k_knn5(const AssocArgs a, const float4* __restrict__ scan, const float4* __restrict__ map,
+                                              const int4* __restrict__ ent, int* __restrict__ o_nn5) {
+    __shared__ int2 s_tab[AQ_PER_BLOCK][33];
+    knn5_group_body<false>(a, scan, map, ent, o_nn5, blockIdx.x, gridDim.x, s_tab);
 }
 
 
@@ -613,6 +652,75 @@ __global__ __launch_bounds__(256) void k_qbin_scatter(const AssocArgs a) {
     a.kb.qs[sl.woff + pos] = a.kb.qtmp[sl.woff + i];
 }
 
+
+// ---- merged-window grouping (KnnBin::glob): the (tile, cell) segments k_qbin_tile found, counted per cell in a global table.
+#define GB_UNIT 64         /* queries per unit of the merged window (k_knn5_near<64>) */
+// One segment = `count` queries of cell `key` at qs[qs_pos ..].  The cell gets a table slot (bounded probe: 32 steps) and the segment an offset inside the
+// cell's run; a segment that finds no slot (more distinct cells than the table was sized for) is laid out by itself from the END of qs2 downwards and
+// becomes its own unit(s) -- slower, never wrong.  (No fill counter: every same-address atomic is executed one after the other at the memory side,
+// ~5 ns each -- a counter bumped per cell and read per segment made this kernel 284 us instead of 25.)
+__device__ __forceinline__ void gbin_segment(const KnnBin& kb, const int seg, const unsigned long long key, const int count, const int qs_pos) {
+    const unsigned mask = (unsigned)(kb.gcap - 1);
+    unsigned s = hash_key(key) & mask;
+    int slot = -1;
+    for (int tries = 0; tries < 32; ++tries) {
+        unsigned long long prev = kb.gkeys[s];
+        if (prev == KEY_EMPTY) {
+            prev = atomicCAS(&kb.gkeys[s], KEY_EMPTY, key);
+            if (prev == KEY_EMPTY) prev = key;
+        }
+        if (prev == key) { slot = (int)s; break; }
+        s = (s + 1) & mask;
+    }
+    int off;
+    if (slot >= 0) off = atomicAdd(&kb.gcnt[slot], count);
+    else {
+        off = kb.qcap_total - atomicAdd(&kb.gctr[6], count) - count;
+        const int nu = (count + GB_UNIT - 1) / GB_UNIT, ub = atomicAdd(&kb.gctr[1], nu);
+        for (int u = 0; u < nu; ++u)
+            kb.units[ub + u] = make_int4(off + GB_UNIT * u, min(GB_UNIT, count - GB_UNIT * u), (int)(unsigned)(key & 0xffffffffull), (int)(unsigned)(key >> 32));
+    }
+    kb.segs[seg] = make_int4(slot, off, qs_pos, count);
+}
+// the cells in table order: first position in qs2 (exclusive scan of the counts), units of <= 64 queries; the table is left EMPTY / 0 for the next call
+__global__ __launch_bounds__(1024) void k_gbin_alloc(const KnnBin kb) {
+    __shared__ int s_wc[16], s_wu[16], s_pb, s_ub;
+    const int s = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = s < kb.gcap ? kb.gcnt[s] : 0, nu = (c + GB_UNIT - 1) / GB_UNIT;
+    int ic = c, iu = nu;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(ic, off, 64), u = __shfl_up(iu, off, 64);
+        if (lane >= off) { ic += v; iu += u; }
+    }
+    if (lane == 63) { s_wc[wv] = ic; s_wu[wv] = iu; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tc = 0, tu = 0;
+        for (int k = 0; k < 16; ++k) { const int v = s_wc[k], u = s_wu[k]; s_wc[k] = tc; s_wu[k] = tu; tc += v; tu += u; }
+        s_pb = tc > 0 ? atomicAdd(&kb.gctr[0], tc) : 0;
+        s_ub = tu > 0 ? atomicAdd(&kb.gctr[1], tu) : 0;
+    }
+    __syncthreads();
+    if (c > 0) {
+        const int pb = s_pb + s_wc[wv] + ic - c, ub = s_ub + s_wu[wv] + iu - nu;
+        const unsigned long long key = kb.gkeys[s];
+        kb.gstart[s] = pb;
+        for (int u = 0; u < nu; ++u)
+            kb.units[ub + u] = make_int4(pb + GB_UNIT * u, min(GB_UNIT, c - GB_UNIT * u), (int)(unsigned)(key & 0xffffffffull), (int)(unsigned)(key >> 32));
+        kb.gkeys[s] = KEY_EMPTY; kb.gcnt[s] = 0;
+    }
+}
+// segment after segment (32 lanes each) from the tile-grouped rows into the cell-major array
+__global__ __launch_bounds__(256) void k_gbin_scatter(const KnnBin kb) {
+    const int n_segs = kb.gctr[4], l32 = threadIdx.x & 31;
+    for (int i = blockIdx.x * 8 + (threadIdx.x >> 5); i < n_segs; i += gridDim.x * 8) {
+        const int4 sg = kb.segs[i];
+        const int dst = sg.x >= 0 ? kb.gstart[sg.x] + sg.y : sg.y;
+        for (int l = l32; l < sg.w; l += 32) kb.qs2[dst + l] = kb.qs[sg.z + l];
+    }
+}
+
 // per launch row y and tile of 1024 consecutive presorted points: units + grouped world-frame queries (w = original index)
 __global__ __launch_bounds__(QT_THREADS) void k_qbin_tile(const AssocArgs a, const float4* __restrict__ ps) {
     __shared__ unsigned long long s_key[QT_SLOTS];
@@ -645,8 +753,9 @@ __global__ __launch_bounds__(QT_THREADS) void k_qbin_tile(const AssocArgs a, con
     }
     __syncthreads();
     // exclusive scan of (queries, units) over the 2048 slots, two slots per thread
+    const bool glob = a.kb.glob != 0;
     const int c0 = s_cnt[2 * tid], c1 = s_cnt[2 * tid + 1];
-    const int u0 = (c0 + TK_Q - 1) / TK_Q, u1 = (c1 + TK_Q - 1) / TK_Q;
+    const int u0 = glob ? (c0 > 0) : (c0 + TK_Q - 1) / TK_Q, u1 = glob ? (c1 > 0) : (c1 + TK_Q - 1) / TK_Q;      // units of this row, or segments of the merged window
     int ic = c0 + c1, iu = u0 + u1;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -658,15 +767,21 @@ __global__ __launch_bounds__(QT_THREADS) void k_qbin_tile(const AssocArgs a, con
     if (tid == 0) {
         int tc = 0, tu = 0;
         for (int k = 0; k < 16; ++k) { const int v = s_wc[k], u = s_wu[k]; s_wc[k] = tc; s_wu[k] = tu; tc += v; tu += u; }
-        s_ubase = atomicAdd(&a.kb.counters[4 * blockIdx.y + 1], tu);
+        s_ubase = glob ? atomicAdd(&a.kb.gctr[4], tu) : atomicAdd(&a.kb.counters[4 * blockIdx.y + 1], tu);
     }
     __syncthreads();
     const int st0 = s_wc[wv] + ic - (c0 + c1), ut0 = s_ubase + s_wu[wv] + iu - (u0 + u1);
     s_cnt[2 * tid] = st0; s_cnt[2 * tid + 1] = st0 + c0;
     int4* un = a.kb.units + (size_t)blockIdx.y * a.kb.unit_stride;
     const unsigned long long k0 = s_key[2 * tid], k1 = s_key[2 * tid + 1];
-    for (int u = 0; u < u0; ++u) un[ut0 + u] = make_int4(tile0 + st0 + TK_Q * u, min(TK_Q, c0 - TK_Q * u), (int)(unsigned)(k0 & 0xffffffffull), (int)(unsigned)(k0 >> 32));
-    for (int u = 0; u < u1; ++u) un[ut0 + u0 + u] = make_int4(tile0 + st0 + c0 + TK_Q * u, min(TK_Q, c1 - TK_Q * u), (int)(unsigned)(k1 & 0xffffffffull), (int)(unsigned)(k1 >> 32));
+    if (glob) {
+        if (c0 > 0) gbin_segment(a.kb, ut0, k0, c0, (int)(sl.woff + tile0 + st0));
+        if (c1 > 0) gbin_segment(a.kb, ut0 + u0, k1, c1, (int)(sl.woff + tile0 + st0 + c0));
+        pw = __int_as_float((int)((unsigned)blockIdx.y << NK_ROW_SHIFT) | __float_as_int(pw));      // the row travels with the query
+    } else {
+        for (int u = 0; u < u0; ++u) un[ut0 + u] = make_int4(tile0 + st0 + TK_Q * u, min(TK_Q, c0 - TK_Q * u), (int)(unsigned)(k0 & 0xffffffffull), (int)(unsigned)(k0 >> 32));
+        for (int u = 0; u < u1; ++u) un[ut0 + u0 + u] = make_int4(tile0 + st0 + c0 + TK_Q * u, min(TK_Q, c1 - TK_Q * u), (int)(unsigned)(k1 & 0xffffffffull), (int)(unsigned)(k1 >> 32));
+    }
     __syncthreads();
     if (live) a.kb.qs[sl.woff + tile0 + s_cnt[slot] + rank] = make_float4(px, py, pz, pw);
 }
@@ -694,8 +809,8 @@ extern "C" int glio_debug_knn_wg(long long* out, int n) { return hipMemcpyFromSy
 #define KN_ACC(k, t1, t0) do { } while (0)
 #endif
 typedef float tk_v2f __attribute__((ext_vector_type(2)));
-__global__ __launch_bounds__(TK_THREADS) __attribute__((amdgpu_waves_per_eu(5))) void k_knn5_tile(const AssocArgs a, const float4* __restrict__ map, const int4* __restrict__ ent,
-                                                   int* __restrict__ o_nn5, float* __restrict__ o_d4) {
+__device__ __forceinline__ void knn5_tile_body(const AssocArgs& a, const float4* __restrict__ map, const int4* __restrict__ ent,
+                                               int* __restrict__ o_nn5, const int bx, const int gdx) {
     // Candidates are staged in PAIRS, structure-of-arrays inside the pair: [x0 x1 | y0 y1 | z0 z1], so that a lane ranks two candidates with
     // packed single-precision instructions (v_pk_add_f32 / v_pk_mul_f32: separate IEEE operations per half, no contraction -- the same bits as the
     // scalar form) -- the search is VALU-issue bound (r04 counters: 8.8 M wavefront-VALU per 64 k scan = half the kernel's duration on 1024 SIMDs).
@@ -707,16 +822,19 @@ __global__ __launch_bounds__(TK_THREADS) __attribute__((amdgpu_waves_per_eu(5)))
     const int lane = threadIdx.x & 63, l32 = threadIdx.x & 31, j = threadIdx.x & (TK_Q - 1), h = (threadIdx.x >> 4) & 1, g = threadIdx.x / TK_LANES;
     const int gbase = lane & ~(TK_LANES - 1);
     const AssocSlot sl = assoc_slot(a);
-    if (sl.n <= 0) return;
-    o_nn5 += 5 * sl.woff; o_d4 += sl.woff;
+    if (a.kb.glob == 0) {
+        if (sl.n <= 0) return;
+        o_nn5 += 8 * sl.woff;
+    }
     if (sl.ent) { ent = sl.ent; map = sl.map; }
     const int table_cap = sl.table_cap;
     // use_fails: the launch ranks only what the near-block search (k_knn5_near) handed on -- entries (unit, mask of its queries); else every unit, every query
     const bool by_list = a.kb.use_fails != 0;
     const int n_units = a.kb.counters[4 * blockIdx.y + (by_list ? 2 : 1)];
     const int4* units = a.kb.units + (size_t)blockIdx.y * a.kb.unit_stride;
-    const int2* fails = a.kb.fails + (size_t)blockIdx.y * a.kb.unit_stride;
-    const float4* qs = a.kb.qs + sl.woff;
+    const int4* fails = a.kb.fails + (size_t)blockIdx.y * a.kb.unit_stride;
+    const bool glob = a.kb.glob != 0;
+    const float4* qs = glob ? a.kb.qs2 : a.kb.qs + sl.woff;
 #ifdef GLIO_DEV_STAMPS
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { for (int k = 0; k < 8; ++k) g_knn_stamps[k] = 0; }
     const long long wg_t0 = wall_clock64();
@@ -726,16 +844,18 @@ __global__ __launch_bounds__(TK_THREADS) __attribute__((amdgpu_waves_per_eu(5)))
 #else
 #define WG_PH(k, t1, t0) do { } while (0)
 #endif
-    for (int u0 = blockIdx.x * TK_UNITS; u0 < n_units; u0 += gridDim.x * TK_UNITS) {
+    for (int u0 = bx * TK_UNITS; u0 < n_units; u0 += gdx * TK_UNITS) {
         KN_T(tk0);
-        int uid = u0 + g, fmask = 0xffff;
+        const int uid = u0 + g;
+        int fmask = 0xffff;
         const bool ulive = uid < n_units;
-        if (by_list && ulive) { const int2 fe = fails[uid]; uid = fe.x; fmask = fe.y; }
-        const int4 un = ulive ? units[uid] : make_int4(0, 0, 0, 0);
+        int4 un = ulive ? (by_list ? fails[uid] : units[uid]) : make_int4(0, 0, 0, 0);
+        if (by_list) { fmask = (int)((unsigned)un.y >> 16); un.y &= 0xffff; }
         const bool qlive = j < un.y && ((fmask >> j) & 1);
         const float4 qp = ulive ? qs[un.x + (qlive ? j : 0)] : make_float4(0, 0, 0, 0);
         const float px = qp.x, py = qp.y, pz = qp.z;
-        const int qi = __float_as_int(qp.w);
+        const int qw = __float_as_int(qp.w);
+        const size_t qi = glob ? (size_t)((unsigned)qw >> NK_ROW_SHIFT) * a.w_stride + (qw & ((1 << NK_ROW_SHIFT) - 1)) : (size_t)qw;
         // the unit's cell from its record (not from the query: the probe below then does not wait for the query's load)
         const unsigned long long ukey = ((unsigned long long)(unsigned)un.w << 32) | (unsigned)un.z;
         const int cx = (int)((ukey >> 42) & 0x1fffffu) - (1 << 20), cy = (int)((ukey >> 21) & 0x1fffffu) - (1 << 20), cz = (int)(ukey & 0x1fffffu) - (1 << 20);
@@ -910,9 +1030,12 @@ __global__ __launch_bounds__(TK_THREADS) __attribute__((amdgpu_waves_per_eu(5)))
 #pragma unroll
         for (int k = 0; k < 5; ++k) knn5_insert_key(ok[k], op[k], bk, bp);
         if (qlive && h == 0) {
+            int ps5[5];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) o_nn5[5 * (size_t)qi + k] = bp[k] >= 0 ? locate(bp[k]) : -1;      // ordinal in the 27-cell list -> position in the sorted map
-            o_d4[qi] = bp[4] >= 0 ? __uint_as_float((unsigned)(bk[4] >> 32)) : FLT_MAX;
+            for (int k = 0; k < 5; ++k) ps5[k] = bp[k] >= 0 ? locate(bp[k]) : -1;      // ordinal in the 27-cell list -> position in the sorted map
+            int4* rec = reinterpret_cast<int4*>(o_nn5 + 8 * qi);
+            rec[0] = make_int4(ps5[0], ps5[1], ps5[2], ps5[3]);
+            rec[1] = make_int4(ps5[4], __float_as_int(bp[4] >= 0 ? __uint_as_float((unsigned)(bk[4] >> 32)) : FLT_MAX), 0, 0);
         }
         GLIO_WAVE_LDS_SYNC();                        // (the next unit of this wavefront rewrites the cell table the winners were located with)
         KN_T(tk3); KN_ACC(4, tk3, tk2); WG_PH(4, tk3, tk2);
@@ -932,6 +1055,19 @@ __global__ __launch_bounds__(TK_THREADS) __attribute__((amdgpu_waves_per_eu(5)))
     }
 #endif
 }
+__global__ __launch_bounds__(TK_THREADS) __attribute__((amdgpu_waves_per_eu(5))) void k_knn5_tile(const AssocArgs a, const float4* __restrict__ map, const int4* __restrict__ ent,
+                                                   int* __restrict__ o_nn5) {
+    knn5_tile_body(a, map, ent, o_nn5, blockIdx.x, gridDim.x);
+}
+// What the near-block search (k_knn5_near) handed on, in ONE launch (both lists are short and each of their wavefronts is a chain of dependent
+// round trips: two launches one after the other cost two such chains): workgroups [0, gq) take the single queries (one 16-lane group per query,
+// four per wavefront), the rest the units (27-cell tiled search, query mask).
+__global__ __launch_bounds__(64) void k_knn5_rest(const AssocArgs a, const int gq, const float4* __restrict__ scan, const float4* __restrict__ map, const int4* __restrict__ ent,
+                                                  int* __restrict__ o_nn5) {
+    __shared__ int2 s_tab[64 / AQ_LANES][33];
+    if ((int)blockIdx.x < gq) knn5_group_body<true>(a, scan, map, ent, o_nn5, blockIdx.x, gq, s_tab);
+    else knn5_tile_body(a, map, ent, o_nn5, (int)blockIdx.x - gq, (int)gridDim.x - gq);
+}
 
 
 // ------------------------------------------------------------------------------------------------
@@ -949,13 +1085,10 @@ __global__ __launch_bounds__(TK_THREADS) __attribute__((amdgpu_waves_per_eu(5)))
 // Both kernels produce the same bytes for any query either can answer; tests/test_hip_assoc.py compares the three search modes.
 // margin: the cell of a point is floor(fl(v * inv_cell)); the products are off by <= 2^-24 relative, so cell faces sit within 3 ulp(|v|) of where
 // the arithmetic below puts them: 1e-6 |v| + 1e-5 m covers that four times over.
-#define NK_Q 16
-#define NK_UNITS 4
-#ifndef NK_CAP
-#define NK_CAP 128         /* staged candidates per unit (C2: mean 57, p99 97, max 115) */
+#define NK_Q 16            /* lanes that own the 16 rows of the block (three runs each) */
+#ifndef NK_UNIT_FAILS
+#define NK_UNIT_FAILS 6    /* uncertified queries (of 16) from which they are re-searched together by the tiled kernel */
 #endif
-#define NK_MASK ((unsigned)(NK_CAP - 1))
-#define NK_PER (NK_CAP / NK_Q)
 __device__ __forceinline__ void nk_insert(unsigned t[6], const unsigned key) {
 #pragma unroll
     for (int k = 5; k > 0; --k) t[k] = tk_med3(t[k - 1], key, t[k]);
@@ -970,39 +1103,79 @@ __device__ __forceinline__ unsigned nk_pref(const uint4 sb, const int cc, const 
     const unsigned w = (o >> 1) == 0 ? sb.x : (o >> 1) == 1 ? sb.y : (o >> 1) == 2 ? sb.z : sb.w;
     return o >= 8 ? (unsigned)cc : ((w >> (16 * (o & 1))) & 0xffffu);
 }
-__global__ __launch_bounds__(64) void k_knn5_near(const AssocArgs a, const float4* __restrict__ map, const int4* __restrict__ ent, const uint4* __restrict__ sub,
-                                                  int* __restrict__ o_nn5, float* __restrict__ o_d4) {
+#ifdef GLIO_DEV_STAMPS
+#define NK_STAMP_WAVES 65536
+__device__ long long g_near_stamps[NK_STAMP_WAVES][8];   // per workgroup of the LAST launch (no atomics: same-address atomics queue at the memory side and distort what they measure):
+                                                        // [0] probe, [1] runs + marks, [2] staging, [3] scan, [4] re-ranking .. hand-on, [5] iterations, [6] start, [7] end (100 MHz)
+extern "C" int glio_debug_near_stamps(long long* out, int n_waves) {
+    if (n_waves > NK_STAMP_WAVES) n_waves = NK_STAMP_WAVES;
+    return (hipDeviceSynchronize() == hipSuccess && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_near_stamps), (size_t)n_waves * 64) == hipSuccess) ? 0 : -2;
+}
+#define NK_T(var) const long long var = wall_clock64()
+#define NK_ACC(k, t1, t0) nk_ph[k] += (t1) - (t0)
+#else
+#define NK_T(var) do { } while (0)
+#define NK_ACC(k, t1, t0) do { } while (0)
+#endif
+// UL = lanes (= queries) per unit: 16 -> four units of <= 16 queries per wavefront, 128 staging slots each (a scan or a keyframe pair alone: ~10-20
+// queries fall in a cell); 64 -> ONE unit of <= 64 queries per wavefront, 256 slots (the merged window association: the queries of all W scans are
+// grouped by cell together, ~350 per cell at C2, so the probes, the run table and the staging of a cell are paid once per 64 queries and every lane of
+// the scan works).
+#ifndef NK_ATTR
+#define NK_ATTR
+#endif
+#ifndef NK_WPB
+#define NK_WPB 4           /* independent wavefronts per workgroup (no workgroup barrier): one-wavefront workgroups left the SIMDs at 3.6 resident wavefronts of the 6 the registers allow */
+#endif
+template <int UL>
+__global__ __launch_bounds__(64 * NK_WPB) NK_ATTR void k_knn5_near(const AssocArgs a, const float4* __restrict__ map, const int4* __restrict__ ent, const uint4* __restrict__ sub,
+                                                  int* __restrict__ o_nn5) {
+    constexpr int NU = 64 / UL, CAP = UL == 64 ? 256 : 128, PER = CAP / UL;
+    constexpr unsigned MASK = (unsigned)(CAP - 1);
+    static_assert(UL == 16 || UL == 64, "units of 16 or 64 lanes");
     // candidates staged in QUADS, structure of arrays: [x0 x1 x2 x3][y0..y3][z0..z3] -- three 16 B LDS reads (broadcast inside a unit) feed four
     // distance evaluations done two at a time with packed fp32 instructions
-    __shared__ float4 s_q4[NK_UNITS][NK_CAP / 4][3];
-    __shared__ int s_idx[NK_UNITS][NK_CAP];           // run << 24 | original map index (the tie-break); before the staging: the run marks
-    __shared__ int s_delta[NK_UNITS][64];             // per run: map position - staged slot
-    const int lane = threadIdx.x, j = lane & (NK_Q - 1), g = lane >> 4, gbase = lane & ~(NK_Q - 1);
+    __shared__ float4 s_q4w[NK_WPB][NU][CAP / 4][3];
+    __shared__ int s_idxw[NK_WPB][NU][CAP];           // run << 24 | original map index (the tie-break); before the staging: the run marks
+    __shared__ int s_deltaw[NK_WPB][NU][64];          // per run: map position - staged slot
+    const int wv = threadIdx.x >> 6;
+    float4 (*s_q4)[CAP / 4][3] = s_q4w[wv];
+    int (*s_idx)[CAP] = s_idxw[wv];
+    int (*s_delta)[64] = s_deltaw[wv];
+    const int lane = threadIdx.x & 63, j = lane & (UL - 1), g = lane / UL, gbase = lane & ~(UL - 1);
+    const bool glob = a.kb.glob != 0;
     const AssocSlot sl = assoc_slot(a);
-    if (sl.n <= 0) return;
-    o_nn5 += 5 * sl.woff; o_d4 += sl.woff;
+    if (!glob && sl.n <= 0) return;
+    if (!glob) { o_nn5 += 8 * sl.woff; }
     if (sl.ent) { ent = sl.ent; sub = sl.sub; map = sl.map; }
     const int table_cap = sl.table_cap;
-    const int n_units = a.kb.counters[4 * blockIdx.y + 1];
+    int* ctr = a.kb.counters + 4 * blockIdx.y;
+    const int n_units = ctr[1];
     const int4* units = a.kb.units + (size_t)blockIdx.y * a.kb.unit_stride;
-    int2* fails = a.kb.fails + (size_t)blockIdx.y * a.kb.unit_stride;
-    const float4* qs = a.kb.qs + sl.woff;
+    int4* fails = a.kb.fails + (size_t)blockIdx.y * a.kb.unit_stride;
+    int* failq = a.kb.failq + (size_t)blockIdx.y * a.w_stride_q;
+    const float4* qs = glob ? a.kb.qs2 : a.kb.qs + sl.woff;
     const float cell = a.cell, half = 0.5f * a.cell;
-    for (int u0 = blockIdx.x * NK_UNITS; u0 < n_units; u0 += gridDim.x * NK_UNITS) {
+#ifdef GLIO_DEV_STAMPS
+    long long nk_ph[8] = {0, 0, 0, 0, 0, 0, wall_clock64(), 0};
+#endif
+    for (int u0 = (blockIdx.x * NK_WPB + wv) * NU; u0 < n_units; u0 += gridDim.x * NK_WPB * NU) {
+        NK_T(nt0);
         const int uid = u0 + g;
         const bool ulive = uid < n_units;
         const int4 un = ulive ? units[uid] : make_int4(0, 0, 0, 0);
         const bool qlive = j < un.y;
         const float4 qp = ulive ? qs[un.x + (qlive ? j : 0)] : make_float4(0, 0, 0, 0);
         const float px = qp.x, py = qp.y, pz = qp.z;
-        const int qi = __float_as_int(qp.w);
+        const int qw = __float_as_int(qp.w);
+        const size_t qi = glob ? (size_t)((unsigned)qw >> NK_ROW_SHIFT) * a.w_stride + (qw & ((1 << NK_ROW_SHIFT) - 1)) : (size_t)qw;
         const unsigned long long ukey = ((unsigned long long)(unsigned)un.w << 32) | (unsigned)un.z;
         const int cx = (int)((ukey >> 42) & 0x1fffffu) - (1 << 20), cy = (int)((ukey >> 21) & 0x1fffffu) - (1 << 20), cz = (int)(ukey & 0x1fffffu) - (1 << 20);
-        // ---- probe the 27 cells once per unit (lane j: cells j and j + 16); the record of a cell = (first point, points, octant prefix)
+        // ---- probe the 27 cells once per unit; the record of a cell = (first point, points, octant prefix)
         int* cellw = reinterpret_cast<int*>(&s_q4[g][0][0]);      // [27][6], dead before the staging writes the quads
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int c = j + NK_Q * hh;
+        for (int hh = 0; hh < (27 + UL - 1) / UL; ++hh) {
+            const int c = j + UL * hh;
             if (c < 27) {
                 int cs = 0, cc = 0;
                 uint4 sb = make_uint4(0, 0, 0, 0);
@@ -1024,16 +1197,17 @@ __global__ __launch_bounds__(64) void k_knn5_near(const AssocArgs a, const float
             }
         }
         {   // own staging slots: no run starts here yet
-            int4* mk = reinterpret_cast<int4*>(&s_idx[g][NK_PER * j]);
+            int4* mk = reinterpret_cast<int4*>(&s_idx[g][PER * j]);
 #pragma unroll
-            for (int i = 0; i < NK_PER / 4; ++i) mk[i] = make_int4(0, 0, 0, 0);
+            for (int i = 0; i < PER / 4; ++i) mk[i] = make_int4(0, 0, 0, 0);
         }
         GLIO_WAVE_LDS_SYNC();
-        // ---- runs: lane j owns the row (y, z) = (j & 3, j >> 2) of the 4 x 4 x 4 half-cell block; along x the row crosses three cells:
+        NK_T(nt1); NK_ACC(0, nt1, nt0); NK_ACC(5, 1, 0);
+        // ---- runs: lane j < 16 owns the row (y, z) = (j & 3, j >> 2) of the 4 x 4 x 4 half-cell block; along x the row crosses three cells:
         // [upper half of cell -1][both halves of cell 0: contiguous][lower half of cell +1] = three runs of the octant-ordered map
-        int rst[3], rcn[3];
+        int rst[3] = {0, 0, 0}, rcn[3] = {0, 0, 0};
         bool big = false;
-        {
+        if (j < NK_Q) {
             const int hb = (j & 3) + 1, hc = (j >> 2) + 1;
             const int rowc = 3 * (hb >> 1) + 9 * (hc >> 1), ob = ((hb & 1) << 1) | ((hc & 1) << 2);
 #pragma unroll
@@ -1052,13 +1226,13 @@ __global__ __launch_bounds__(64) void k_knn5_near(const AssocArgs a, const float
 #pragma unroll
         for (int off = 1; off < NK_Q; off <<= 1) {
             const int t0 = __shfl_up(incl, off, NK_Q);
-            if (j >= off) incl += t0;
+            if ((j & (NK_Q - 1)) >= off) incl += t0;
         }
         const int tot = __shfl(incl, gbase + NK_Q - 1, 64);
         const unsigned long long bigb = __ballot(big);
-        const bool over = tot > NK_CAP || ((bigb >> gbase) & 0xffffull) != 0;
+        const bool over = tot > CAP || ((bigb >> gbase) & (UL == 64 ? ~0ull : 0xffffull)) != 0;
         const int tot_e = (over || !ulive) ? 0 : tot;
-        if (tot_e > 0) {
+        if (tot_e > 0 && j < NK_Q) {
             int pf = incl - mine;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -1068,70 +1242,76 @@ __global__ __launch_bounds__(64) void k_knn5_near(const AssocArgs a, const float
             }
         }
         GLIO_WAVE_LDS_SYNC();
-        // ---- stage: lane j fills the slots [8 j, 8 j + 8): the run of a slot = the last mark at or before it (max-scan; marks grow with the slot)
+        NK_T(nt2); NK_ACC(1, nt2, nt1);
+        // ---- stage: lane j fills the slots [PER j, PER j + PER): the run of a slot = the last mark at or before it (max-scan; marks grow with the slot)
         {
-            int rn[NK_PER];
+            int rn[PER];
             {
-                const int4* mk = reinterpret_cast<const int4*>(&s_idx[g][NK_PER * j]);
+                const int4* mk = reinterpret_cast<const int4*>(&s_idx[g][PER * j]);
                 int run = 0;
 #pragma unroll
-                for (int i = 0; i < NK_PER / 4; ++i) {
+                for (int i = 0; i < PER / 4; ++i) {
                     const int4 m = mk[i];
                     run = max(run, m.x); rn[4 * i] = run; run = max(run, m.y); rn[4 * i + 1] = run;
                     run = max(run, m.z); rn[4 * i + 2] = run; run = max(run, m.w); rn[4 * i + 3] = run;
                 }
                 int inc = run;
 #pragma unroll
-                for (int off = 1; off < NK_Q; off <<= 1) {
-                    const int t0 = __shfl_up(inc, off, NK_Q);
+                for (int off = 1; off < UL; off <<= 1) {
+                    const int t0 = __shfl_up(inc, off, UL);
                     if (j >= off) inc = max(inc, t0);
                 }
-                int carry = __shfl_up(inc, 1, NK_Q);
+                int carry = __shfl_up(inc, 1, UL);
                 if (j == 0) carry = 0;
 #pragma unroll
-                for (int i = 0; i < NK_PER; ++i) rn[i] = max(rn[i], carry) - 1;
+                for (int i = 0; i < PER; ++i) rn[i] = max(rn[i], carry) - 1;
             }
-            float4 pt[NK_PER];
+            float4 pt[PER];
 #pragma unroll
-            for (int i = 0; i < NK_PER; ++i) {
-                const int f = NK_PER * j + i;
+            for (int i = 0; i < PER; ++i) {
+                const int f = PER * j + i;
                 pt[i] = make_float4(3e18f, 3e18f, 3e18f, 0.f);
                 if (f < tot_e) pt[i] = map[f + s_delta[g][rn[i]]];
             }
 #pragma unroll
-            for (int i = 0; i < NK_PER / 4; ++i) {
-                float4* qd = s_q4[g][(NK_PER / 4) * j + i];
+            for (int i = 0; i < PER / 4; ++i) {
+                float4* qd = s_q4[g][(PER / 4) * j + i];
                 qd[0] = make_float4(pt[4 * i].x, pt[4 * i + 1].x, pt[4 * i + 2].x, pt[4 * i + 3].x);
                 qd[1] = make_float4(pt[4 * i].y, pt[4 * i + 1].y, pt[4 * i + 2].y, pt[4 * i + 3].y);
                 qd[2] = make_float4(pt[4 * i].z, pt[4 * i + 1].z, pt[4 * i + 2].z, pt[4 * i + 3].z);
-                reinterpret_cast<int4*>(&s_idx[g][NK_PER * j])[i] =
+                reinterpret_cast<int4*>(&s_idx[g][PER * j])[i] =
                     make_int4((rn[4 * i] << 24) | (__float_as_int(pt[4 * i].w) & 0xffffff), (rn[4 * i + 1] << 24) | (__float_as_int(pt[4 * i + 1].w) & 0xffffff),
                               (rn[4 * i + 2] << 24) | (__float_as_int(pt[4 * i + 2].w) & 0xffffff), (rn[4 * i + 3] << 24) | (__float_as_int(pt[4 * i + 3].w) & 0xffffff));
             }
         }
         GLIO_WAVE_LDS_SYNC();
-        // ---- scan: every lane ranks the staged block for its own query; selection by truncated key (distance bits, low 7 = slot) with fused distances
+        NK_T(nt3); NK_ACC(2, nt3, nt2);
+        // ---- scan: every lane ranks the staged block for its own query; selection by truncated key (distance bits, low bits = slot) with fused distances
         int tot_w = tot_e;
 #pragma unroll
-        for (int off = 16; off < 64; off <<= 1) tot_w = max(tot_w, __shfl_xor(tot_w, off, 64));
+        for (int off = UL; off < 64; off <<= 1) tot_w = max(tot_w, __shfl_xor(tot_w, off, 64));
         const int n_q = (tot_w + 3) >> 2;
         unsigned tk[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) tk[k] = ~0u;
         const tk_v2f P0 = {px, px}, P1 = {py, py}, P2 = {pz, pz};
+        // (the next quad is read while this one is ranked: the three 16 B LDS reads of an iteration otherwise sit in front of its 47 vector instructions)
+        float4 Xn = s_q4[g][0][0], Yn = s_q4[g][0][1], Zn = s_q4[g][0][2];
         for (int qd = 0; qd < n_q; ++qd) {
-            const float4 X = s_q4[g][qd][0], Y = s_q4[g][qd][1], Z = s_q4[g][qd][2];
+            const float4 X = Xn, Y = Yn, Z = Zn;
+            { const int nx = min(qd + 1, CAP / 4 - 1); Xn = s_q4[g][nx][0]; Yn = s_q4[g][nx][1]; Zn = s_q4[g][nx][2]; }
             const tk_v2f xa = {X.x, X.y}, xb = {X.z, X.w}, ya = {Y.x, Y.y}, yb = {Y.z, Y.w}, za = {Z.x, Z.y}, zb = {Z.z, Z.w};
             const tk_v2f exa = P0 - xa, eya = P1 - ya, eza = P2 - za, exb = P0 - xb, eyb = P1 - yb, ezb = P2 - zb;
             tk_v2f da = exa * exa, db = exb * exb;
             da = __builtin_elementwise_fma(eya, eya, da); db = __builtin_elementwise_fma(eyb, eyb, db);
             da = __builtin_elementwise_fma(eza, eza, da); db = __builtin_elementwise_fma(ezb, ezb, db);
             const unsigned f0 = (unsigned)(4 * qd);
-            nk_insert(tk, (__float_as_uint(da.x) & ~NK_MASK) | f0);
-            nk_insert(tk, (__float_as_uint(da.y) & ~NK_MASK) | (f0 + 1u));
-            nk_insert(tk, (__float_as_uint(db.x) & ~NK_MASK) | (f0 + 2u));
-            nk_insert(tk, (__float_as_uint(db.y) & ~NK_MASK) | (f0 + 3u));
+            nk_insert(tk, (__float_as_uint(da.x) & ~MASK) | f0);
+            nk_insert(tk, (__float_as_uint(da.y) & ~MASK) | (f0 + 1u));
+            nk_insert(tk, (__float_as_uint(db.x) & ~MASK) | (f0 + 2u));
+            nk_insert(tk, (__float_as_uint(db.y) & ~MASK) | (f0 + 3u));
         }
+        NK_T(nt4); NK_ACC(3, nt4, nt3);
         // ---- exact re-ranking of the six selected: unfused float distance (FLANN's L2), then original index; the slot rides in the low byte (indices
         // are unique, so it never decides)
         unsigned long long K[6];
@@ -1139,7 +1319,7 @@ __global__ __launch_bounds__(64) void k_knn5_near(const AssocArgs a, const float
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             const unsigned t = tk[k];
-            const int slot = (int)(t & NK_MASK);
+            const int slot = (int)(t & MASK);
             const bool real = t != ~0u && slot < tot_e;
             const int fo = 12 * (slot >> 2) + (slot & 3);
             const float ex = px - flat[fo], ey = py - flat[fo + 4], ez = pz - flat[fo + 8];
@@ -1157,8 +1337,8 @@ __global__ __launch_bounds__(64) void k_knn5_near(const AssocArgs a, const float
         const bool has5 = K[4] != ~0ull;
         // the selection distances are fused (a few ulp off): a candidate's exact bucket is at most ONE away from its selection bucket, so nothing
         // unselected can precede the fifth exact key when that lies at least two buckets under the sixth selected key
-        const bool all_in = tk[5] == ~0u || (int)(tk[5] & NK_MASK) >= tot_e;
-        const bool safe = all_in || ((unsigned)(K[4] >> 32) & ~NK_MASK) + (NK_MASK + 1u) < (tk[5] & ~NK_MASK);
+        const bool all_in = tk[5] == ~0u || (int)(tk[5] & MASK) >= tot_e;
+        const bool safe = all_in || ((unsigned)(K[4] >> 32) & ~MASK) + (MASK + 1u) < (tk[5] & ~MASK);
         // ---- certificate: distance from the query to the boundary of the staged block
         const float ox = (float)cx * cell, oy = (float)cy * cell, oz = (float)cz * cell;
         float b = fminf(px - ox, (ox + cell) - px);
@@ -1168,40 +1348,74 @@ __global__ __launch_bounds__(64) void k_knn5_near(const AssocArgs a, const float
         const float d5 = __uint_as_float((unsigned)(K[4] >> 32));
         const bool cert = qlive && has5 && safe && bm > 0.f && d5 < bm * bm * 0.99999f;
         if (cert) {
+            int ps5[5];
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
-                const int slot = (int)((unsigned)K[k] & NK_MASK);
-                o_nn5[5 * (size_t)qi + k] = slot + s_delta[g][s_idx[g][slot] >> 24];
+                const int slot = (int)((unsigned)K[k] & MASK);
+                ps5[k] = slot + s_delta[g][s_idx[g][slot] >> 24];
             }
-            o_d4[qi] = d5;
+            int4* rec = reinterpret_cast<int4*>(o_nn5 + 8 * qi);            // one 32 B record per query (two 16 B stores into one line; six dword stores into three before)
+            rec[0] = make_int4(ps5[0], ps5[1], ps5[2], ps5[3]); rec[1] = make_int4(ps5[4], __float_as_int(d5), 0, 0);
         }
-        // ---- hand the rest on: one entry per unit with uncertified queries, one atomic per wavefront
+        // ---- hand the rest on, one atomic per wavefront and list.  Per 16 queries: all of them when the block did not fit, or many uncertified -> the
+        // 27-cell tiled search as (first grouped query, queries | mask << 16, cell key); single queries -> the one-group-per-query search (a tiled unit
+        // costs the same for 1 or 16 queries)
         const unsigned long long fb = __ballot(qlive && !cert);
-        const int m16 = (int)((fb >> gbase) & 0xffffull);
-        const unsigned long long ub = __ballot(j == 0 && m16 != 0);
+        const int m16 = (int)((fb >> (lane & ~15)) & 0xffffull);
+        const bool by_unit = over || __popc(m16) >= NK_UNIT_FAILS;
+        const unsigned long long ub = __ballot((lane & 15) == 0 && m16 != 0 && by_unit);
         if (ub) {
             int base = 0;
-            if (lane == 0) base = atomicAdd(&a.kb.counters[4 * blockIdx.y + 2], __popcll(ub));
+            if (lane == 0) base = atomicAdd(&ctr[2], __popcll(ub));
             base = __shfl(base, 0, 64);
-            if (j == 0 && m16 != 0) fails[base + __popcll(ub & ((1ull << lane) - 1ull))] = make_int2(uid, m16);
+            if ((lane & 15) == 0 && m16 != 0 && by_unit)
+                fails[base + __popcll(ub & ((1ull << lane) - 1ull))] = make_int4(un.x + j, min(16, un.y - j) | (m16 << 16), un.z, un.w);
+        }
+        if (a.kb.dbg) {
+            const unsigned long long lb = __ballot(qlive), cb = __ballot(cert), ob = __ballot(j == 0 && ulive && over), ul = __ballot(j == 0 && ulive);
+            int st = j == 0 ? tot_e : 0;
+#pragma unroll
+            for (int off = UL; off < 64; off <<= 1) st += __shfl_xor(st, off, 64);
+            if (lane == 0) {
+                atomicAdd(&a.kb.dbg[0], (unsigned long long)__popcll(ul)); atomicAdd(&a.kb.dbg[1], (unsigned long long)__popcll(ob));
+                atomicAdd(&a.kb.dbg[2], (unsigned long long)__popcll(ub)); atomicAdd(&a.kb.dbg[3], (unsigned long long)__popcll(fb));
+                atomicAdd(&a.kb.dbg[4], (unsigned long long)__popcll(lb)); atomicAdd(&a.kb.dbg[5], (unsigned long long)__popcll(cb));
+                atomicAdd(&a.kb.dbg[6], (unsigned long long)st); atomicAdd(&a.kb.dbg[7], (unsigned long long)n_q);
+            }
+        }
+        const unsigned long long qb = __ballot(qlive && !cert && !by_unit);
+        if (qb) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&ctr[3], __popcll(qb));
+            base = __shfl(base, 0, 64);
+            if (qlive && !cert && !by_unit) failq[base + __popcll(qb & ((1ull << lane) - 1ull))] = un.x + j;
         }
         GLIO_WAVE_LDS_SYNC();
+        NK_T(nt5); NK_ACC(4, nt5, nt4);
     }
+#ifdef GLIO_DEV_STAMPS
+    {
+        const unsigned w = (blockIdx.y * gridDim.x + blockIdx.x) * NK_WPB + wv;
+        nk_ph[7] = wall_clock64();
+        if (lane == 0 && w < NK_STAMP_WAVES) { for (int k = 0; k < 8; ++k) g_near_stamps[w][k] = nk_ph[k]; }
+    }
+#endif
 }
 
 #define PF_BLOCK 256
 template <bool BATCH>
 __global__ __launch_bounds__(PF_BLOCK) void k_plane_fit(const AssocArgs a, const float4* __restrict__ scan, const float4* __restrict__ map,
-                                                        const int* __restrict__ nn5, const float* __restrict__ d4,
+                                                        const int* __restrict__ nn5,
                                                         float4* __restrict__ o_pt, float4* __restrict__ o_plane, double* __restrict__ o_score,
                                                         int* __restrict__ o_flag, int* __restrict__ o_lpos, int* __restrict__ o_bcount,
                                                         int* __restrict__ o_nn, const float4* __restrict__ loc, double* __restrict__ o_nc) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * PF_BLOCK + threadIdx.x;
     if (a.kb.counters && blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<int4*>(a.kb.counters + 4 * blockIdx.y) = make_int4(0, 0, 0, 0);
+    if (a.kb.counters && a.kb.gctr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 8) a.kb.gctr[threadIdx.x] = 0;
     const AssocSlot sl = assoc_slot(a);
     if (blockIdx.x * PF_BLOCK >= sl.n) return;
-    scan += sl.qoff; nn5 += 5 * sl.woff; d4 += sl.woff;
+    scan += sl.qoff; nn5 += 8 * sl.woff;
     o_pt += sl.woff; if (!BATCH) o_plane += sl.woff; o_score += sl.woff; o_flag += sl.woff; o_lpos += sl.woff; o_bcount += sl.boff;
     if (sl.map) { map = sl.map; loc += sl.locoff; o_nc += 6 * sl.woff; }
     const bool qlive = i < sl.n;
@@ -1214,9 +1428,8 @@ __global__ __launch_bounds__(PF_BLOCK) void k_plane_fit(const AssocArgs a, const
     float md4 = FLT_MAX;
     float4 nbp[5];
     if (qlive) {
-        md4 = d4[i];
-#pragma unroll
-        for (int k = 0; k < 5; ++k) mp5[k] = nn5[5 * (size_t)i + k];
+        const int4 r0 = reinterpret_cast<const int4*>(nn5 + 8 * (size_t)i)[0], r1 = reinterpret_cast<const int4*>(nn5 + 8 * (size_t)i)[1];
+        mp5[0] = r0.x; mp5[1] = r0.y; mp5[2] = r0.z; mp5[3] = r0.w; mp5[4] = r1.x; md4 = __int_as_float(r1.y);
 #pragma unroll
         for (int k = 0; k < 5; ++k) { nbp[k] = map[mp5[k] >= 0 ? mp5[k] : 0]; mi[k] = __float_as_int(nbp[k].w); }
     } else {
@@ -1357,9 +1570,14 @@ __global__ __launch_bounds__(PF_BLOCK) void k_compact(const int* __restrict__ fl
 static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 struct KnnBinHost { KnnBin d; int rows, cap, capq_max; };
-static int g_knn_mode = 0;           // 0 = near block first (k_knn5_near), the rest by the 27-cell tiled search (k_knn5_tile); 1 = one 16-lane group per query (k_knn5);
-                                     // 2 = every query by the 27-cell tiled search (the round-4 path); glio_debug_set_knn_mode
-static KnnBinHost* knn_bin_create(int rows, int cap) {
+static unsigned long long* g_knn_dbg = nullptr;      // statistics of the near-block search (glio_debug_knn_stats)
+static int g_gbin_cap = 0;            // test knob (glio_debug_set_gbin_cap): cell-table size of the merged-window grouping, 0 = from the map
+static int g_knn_mode = 0;           // 0 = window calls: the queries of all slots grouped by cell together, near block first (k_knn5_near<64>), the rest by
+                                     //     k_knn5_rest; single rows: the 27-cell tiled search (k_knn5_tile);  1 = one 16-lane group per query (k_knn5);
+                                     // 2 = every query by the 27-cell tiled search (the round-4 path);  3 = near block first (k_knn5_near<16>), every launch
+                                     //     row by itself; glio_debug_set_knn_mode
+// gcells > 0: also the buffers of the merged-window grouping, its cell table sized for gcells cells (0: rows are always searched one by one)
+static KnnBinHost* knn_bin_create(int rows, int cap, int gcells = 0) {
     KnnBinHost* h = new KnnBinHost();
     memset(h, 0, sizeof *h);
     h->rows = rows; h->cap = cap; h->capq_max = next_pow2(2 * (cap > 512 ? cap : 512));
@@ -1371,14 +1589,25 @@ static KnnBinHost* knn_bin_create(int rows, int cap) {
     bool ok = hipMalloc((void**)&d.keys, tq * 8) == hipSuccess && hipMalloc((void**)&d.cnt, tq * 4) == hipSuccess && hipMalloc((void**)&d.cstart, tq * 4) == hipSuccess &&
               hipMalloc((void**)&d.qslot, wq1 * 4) == hipSuccess && hipMalloc((void**)&d.qrank, wq1 * 4) == hipSuccess && hipMalloc((void**)&d.qtmp, wq1 * 16) == hipSuccess &&
               hipMalloc((void**)&d.qs, wq * 16) == hipSuccess && hipMalloc((void**)&d.units, (size_t)rows * d.unit_stride * 16) == hipSuccess &&
-              hipMalloc((void**)&d.counters, (size_t)rows * 16) == hipSuccess && hipMalloc((void**)&d.fails, (size_t)rows * d.unit_stride * 8) == hipSuccess;
+              hipMalloc((void**)&d.counters, (size_t)rows * 16) == hipSuccess && hipMalloc((void**)&d.fails, (size_t)rows * d.unit_stride * 16) == hipSuccess &&
+              hipMalloc((void**)&d.failq, wq * 4) == hipSuccess;
     ok = ok && hipMemset(d.keys, 0xff, tq * 8) == hipSuccess && hipMemset(d.cnt, 0, tq * 4) == hipSuccess && hipMemset(d.counters, 0, (size_t)rows * 16) == hipSuccess;
+    if (ok && gcells > 0 && rows > 1 && rows < 64 && cap <= (1 << NK_ROW_SHIFT) && wq < (1ull << 31)) {
+        int gc = next_pow2(gcells > 4096 ? gcells : 4096);
+        const int gmax = next_pow2((int)(2 * wq > (1u << 30) ? (1u << 30) : 2 * wq));
+        if (gc > gmax) gc = gmax;
+        d.gcap = gc; d.qcap_total = (int)wq;
+        ok = hipMalloc((void**)&d.qs2, wq * 16) == hipSuccess && hipMalloc((void**)&d.segs, wq * 16) == hipSuccess && hipMalloc((void**)&d.gkeys, (size_t)gc * 8) == hipSuccess &&
+             hipMalloc((void**)&d.gcnt, (size_t)gc * 4) == hipSuccess && hipMalloc((void**)&d.gstart, (size_t)gc * 4) == hipSuccess && hipMalloc((void**)&d.gctr, 32) == hipSuccess;
+        ok = ok && hipMemset(d.gkeys, 0xff, (size_t)gc * 8) == hipSuccess && hipMemset(d.gcnt, 0, (size_t)gc * 4) == hipSuccess && hipMemset(d.gctr, 0, 32) == hipSuccess;
+    }
     if (!ok) { glio_set_error("hipMalloc failed for the query binning buffers"); return nullptr; }
     return h;
 }
 static void knn_bin_destroy(KnnBinHost* h) {
     if (!h) return;
-    void* p[] = {h->d.keys, h->d.cnt, h->d.cstart, h->d.qslot, h->d.qrank, h->d.qtmp, h->d.qs, h->d.units, h->d.counters, h->d.fails};
+    void* p[] = {h->d.keys, h->d.cnt, h->d.cstart, h->d.qslot, h->d.qrank, h->d.qtmp, h->d.qs, h->d.units, h->d.counters, h->d.fails, h->d.failq,
+                 h->d.qs2, h->d.segs, h->d.gkeys, h->d.gcnt, h->d.gstart, h->d.gctr};
     for (void* q : p) if (q) hipFree(q);
     delete h;
 }
@@ -1400,13 +1629,33 @@ static void enqueue_presort(hipStream_t stream, KnnBinHost* kb, const float4* cl
 // exact 5-NN of every query of the launch rows [0, rows): the caller's AssocArgs select the row geometry (assoc_slot);
 // `scan` = the clouds as uploaded, `ps` = their presorted copies
 static void enqueue_knn(hipStream_t stream, AssocArgs& a, KnnBinHost* kb, int rows, int maxn, const float4* scan, const float4* ps, const float4* map,
-                        const int4* ent, const uint4* sub, int map_n_max, int* nn5, float* d4) {
+                        const int4* ent, const uint4* sub, int map_n_max, int* nn5) {
     if (g_knn_mode == 1 || !kb) {
         memset(&a.kb, 0, sizeof a.kb);
-        hipLaunchKernelGGL(k_knn5, dim3((maxn + AQ_PER_BLOCK - 1) / AQ_PER_BLOCK, rows), dim3(256), 0, stream, a, scan, map, ent, nn5, d4);
+        hipLaunchKernelGGL(k_knn5, dim3((maxn + AQ_PER_BLOCK - 1) / AQ_PER_BLOCK, rows), dim3(256), 0, stream, a, scan, map, ent, nn5);
         return;
     }
-    a.kb = kb->d;
+    a.kb = kb->d; a.w_stride_q = kb->cap; a.kb.dbg = g_knn_dbg;
+    // merged window (mode 0, launch rows that share one map): the queries of all rows grouped by cell together, units of 64
+    if (g_knn_mode == 0 && map_n_max <= (1 << 24) && rows > 1 && map && kb->d.qs2 && !a.frames) {
+        int ge = g_gbin_cap > 0 ? next_pow2(g_gbin_cap) : next_pow2(map_n_max > 4096 ? map_n_max : 4096);      // (queried cells of the C2 window: ~10 k against a 70 k-point map)
+        if (ge > kb->d.gcap) ge = kb->d.gcap;
+        a.kb.glob = 1; a.kb.gcap = ge;
+        hipLaunchKernelGGL(k_qbin_tile, dim3((maxn + QT_THREADS - 1) / QT_THREADS, rows), dim3(QT_THREADS), 0, stream, a, ps);
+        hipLaunchKernelGGL(k_gbin_alloc, dim3((ge + 1023) / 1024), dim3(1024), 0, stream, a.kb);
+        const long long tot = (long long)rows * maxn;
+        hipLaunchKernelGGL(k_gbin_scatter, dim3((unsigned)((tot / 512 > 4096 ? 4096 : tot / 512) + 1)), dim3(256), 0, stream, a.kb);
+        a.kb.counters = kb->d.gctr;                                // one launch row: the counter block of the merged window
+        long long gn = tot / 32 + 64;                               // units of 64 at half fill; beyond that the workgroups stride
+        if (gn > 65536) gn = 65536;
+        hipLaunchKernelGGL(k_knn5_near<64>, dim3((unsigned)((gn + NK_WPB - 1) / NK_WPB), 1), dim3(64 * NK_WPB), 0, stream, a, map, ent, sub, nn5);
+        long long gq = tot / 64 + 64;                               // (one pass for up to 1/16 of the queries, 4 per workgroup; 2048 x 2 handed-on units)
+        if (gq > 16384) gq = 16384;
+        a.kb.use_fails = 1;
+        hipLaunchKernelGGL(k_knn5_rest, dim3((unsigned)gq + 2048, 1), dim3(64), 0, stream, a, (int)gq, scan, map, ent, nn5);
+        a.kb.use_fails = 0; a.kb.glob = 0; a.kb.counters = kb->d.counters; a.kb.gcap = kb->d.gcap;
+        return;
+    }
     hipLaunchKernelGGL(k_qbin_tile, dim3((maxn + QT_THREADS - 1) / QT_THREADS, rows), dim3(QT_THREADS), 0, stream, a, ps);
     // capacity for maxn / 8 units per row (k_qbin_tile makes at most n / 16 + cells): one wavefront-workgroup per unit pair up to 4096 per row, beyond
     // that the workgroups stride
@@ -1415,15 +1664,24 @@ static void enqueue_knn(hipStream_t stream, AssocArgs& a, KnnBinHost* kb, int ro
     int gx = (maxn + 8 * TK_UNITS - 1) / (8 * TK_UNITS);
     if (gx > 4096) gx = 4096;
     // (the tie-break index rides in 24 bits of the near-block search's exact key: maps beyond 2^24 points take the 27-cell search alone)
-    if (g_knn_mode == 0 && map_n_max <= (1 << 24)) {
-        int gn = (maxn + 8 * NK_UNITS - 1) / (8 * NK_UNITS);
+    // A launch row by itself (a lone scan, C3, the keyframe pairs of the batch association): ~10-20 queries fall in a cell, the near-block kernel then
+    // carries four quarter-filled units per wavefront and needs a second launch for what it hands on -- measured equal or slower than the 27-cell
+    // tiled search alone (C2 scan 46 vs 40 us, C3 57-63 vs 57, 192 pairs 2.3-2.5 vs 2.33 ms), so mode 0 keeps the tiled search there; mode 3 forces
+    // the near-block path row by row (tests: the same bytes).
+    if (g_knn_mode == 3 && map_n_max <= (1 << 24)) {
+        int gn = (maxn + 31) / 32;
         if (gn > 4096) gn = 4096;
-        hipLaunchKernelGGL(k_knn5_near, dim3(gn, rows), dim3(64), 0, stream, a, map, ent, sub, nn5, d4);
+        hipLaunchKernelGGL(k_knn5_near<16>, dim3((gn + NK_WPB - 1) / NK_WPB, rows), dim3(64 * NK_WPB), 0, stream, a, map, ent, sub, nn5);
+        // the lists are short (0.1-4 % of the queries on the C2 stream): striding workgroups
+        int gq = (maxn + 15) / 16, gt = gx;
+        if (gq > 1024) gq = 1024;
+        if (gt > 256) gt = 256;
         a.kb.use_fails = 1;
-        if (gx > 512) gx = 512;                                  // the list is short (0.1-3 % of the queries on the C2 stream): striding workgroups
+        hipLaunchKernelGGL(k_knn5_rest, dim3(gq + gt, rows), dim3(64), 0, stream, a, gq, scan, map, ent, nn5);
+        a.kb.use_fails = 0;
+        return;
     }
-    hipLaunchKernelGGL(k_knn5_tile, dim3(gx, rows), dim3(TK_THREADS), 0, stream, a, map, ent, nn5, d4);
-    a.kb.use_fails = 0;
+    hipLaunchKernelGGL(k_knn5_tile, dim3(gx, rows), dim3(TK_THREADS), 0, stream, a, map, ent, nn5);
 }
 
 int glio_assoc_create(glio_ctx* c) {
@@ -1445,14 +1703,14 @@ int glio_assoc_create(glio_ctx* c) {
     const size_t wc = (size_t)cap * c->W, wb = (size_t)(cap / AQ_PER_BLOCK + 2) * c->W;
     AALLOC(w->d_q_pt, wc * 16); AALLOC(w->d_q_plane, wc * 16); AALLOC(w->d_q_score, wc * 8);
     AALLOC(w->d_q_flag, wc * 4); AALLOC(w->d_q_pos, wc * 4); AALLOC(w->d_nn, (size_t)cap * 5 * 4);
-    AALLOC(w->d_nn5, wc * 5 * 4); AALLOC(w->d_d4, wc * 4);
+    AALLOC(w->d_nn5, wc * 32);
     AALLOC(w->d_bcount, wb * 4); AALLOC(w->d_boff, wb * 4);
     AALLOC(w->d_win, (size_t)c->W * 64);
     if (hipHostMalloc((void**)&w->h_count, 16) != hipSuccess) return GLIO_E_HIP;
     if (hipHostMalloc((void**)&w->h_counts_win, GLIO_MAX_WINDOW * 4) != hipSuccess) return GLIO_E_HIP;
     w->counts_pending = 0;
     if (hipHostMalloc((void**)&w->h_win, (size_t)c->W * 64) != hipSuccess) return GLIO_E_HIP;
-    w->kb = knn_bin_create(c->W, cap);
+    w->kb = knn_bin_create(c->W, cap, 4 * mm);
     if (!w->kb) return GLIO_E_HIP;
     AALLOC(w->d_ps, wc * 16);
     c->assoc = w;
@@ -1464,7 +1722,7 @@ void glio_assoc_destroy(glio_ctx* c) {
     AssocWork* w = c->assoc;
     if (!w) return;
     void* ptrs[] = {w->d_keys, w->d_ent, w->d_cnt8, w->d_sub, w->d_pt_slot, w->d_pt_rank, w->d_map_raw, c->d_map_sorted, w->d_total,
-                    w->d_count_tmp, w->d_q_pt, w->d_q_plane, w->d_q_score, w->d_q_flag, w->d_q_pos, w->d_nn, w->d_nn5, w->d_d4, w->d_bcount, w->d_boff, w->d_win, w->d_ps};
+                    w->d_count_tmp, w->d_q_pt, w->d_q_plane, w->d_q_score, w->d_q_flag, w->d_q_pos, w->d_nn, w->d_nn5, w->d_bcount, w->d_boff, w->d_win, w->d_ps};
     for (void* p : ptrs) if (p) hipFree(p);
     knn_bin_destroy(w->kb);
     hipHostFree(w->h_count);
@@ -1552,8 +1810,8 @@ static void enqueue_assoc(glio_ctx* c, int slot, const double q[4], const double
     const size_t off = (size_t)slot * c->cap;
     const int nblk = (n + PF_BLOCK - 1) / PF_BLOCK;
     if (n > 0) {
-        enqueue_knn(c->stream, a, w->kb, 1, n, c->d_scan + off, w->d_ps + off, c->d_map_sorted, w->d_ent, w->d_sub, c->map_n, w->d_nn5, w->d_d4);
-        hipLaunchKernelGGL(k_plane_fit<false>, dim3(nblk), dim3(PF_BLOCK), 0, c->stream, a, c->d_scan + off, c->d_map_sorted, w->d_nn5, w->d_d4,
+        enqueue_knn(c->stream, a, w->kb, 1, n, c->d_scan + off, w->d_ps + off, c->d_map_sorted, w->d_ent, w->d_sub, c->map_n, w->d_nn5);
+        hipLaunchKernelGGL(k_plane_fit<false>, dim3(nblk), dim3(PF_BLOCK), 0, c->stream, a, c->d_scan + off, c->d_map_sorted, w->d_nn5,
                            w->d_q_pt, w->d_q_plane, w->d_q_score, w->d_q_flag, w->d_q_pos, w->d_bcount, want_nn ? w->d_nn : nullptr,
                            (const float4*)nullptr, (double*)nullptr);
     }
@@ -1585,9 +1843,9 @@ static int enqueue_assoc_window(glio_ctx* c, const double* quats, const double* 
     a.win_poses = w->d_win; a.win_counts = reinterpret_cast<const int*>(w->d_win + 7 * W);
     a.q_stride = c->cap; a.w_stride = c->cap; a.b_stride = c->cap / AQ_PER_BLOCK + 2;
     if (maxn > 0) {
-        enqueue_knn(c->stream, a, w->kb, W, maxn, c->d_scan, w->d_ps, c->d_map_sorted, w->d_ent, w->d_sub, c->map_n, w->d_nn5, w->d_d4);
+        enqueue_knn(c->stream, a, w->kb, W, maxn, c->d_scan, w->d_ps, c->d_map_sorted, w->d_ent, w->d_sub, c->map_n, w->d_nn5);
         hipLaunchKernelGGL(k_plane_fit<false>, dim3((maxn + PF_BLOCK - 1) / PF_BLOCK, W), dim3(PF_BLOCK), 0, c->stream, a, c->d_scan, c->d_map_sorted,
-                           w->d_nn5, w->d_d4, w->d_q_pt, w->d_q_plane, w->d_q_score, w->d_q_flag, w->d_q_pos, w->d_bcount, (int*)nullptr,
+                           w->d_nn5, w->d_q_pt, w->d_q_plane, w->d_q_score, w->d_q_flag, w->d_q_pos, w->d_bcount, (int*)nullptr,
                            (const float4*)nullptr, (double*)nullptr);
     }
     hipLaunchKernelGGL(k_compact, dim3(maxn > 0 ? (maxn + PF_BLOCK - 1) / PF_BLOCK : 1, W), dim3(PF_BLOCK), 0, c->stream, w->d_q_flag, w->d_q_pos, w->d_bcount, 0, w->d_q_pt,
@@ -1748,7 +2006,7 @@ struct glio_bassoc {
     struct FrameBuild* d_fb; struct FrameBuild* h_fb;       // [K] build descriptors of the keyframes of a run, batch after batch (device / pinned)
     // dense per-query results of the pair in flight
     float4* d_q_cp; double* d_q_nc; double* d_q_score; int* d_q_flag; int* d_q_pos; int* d_bcount; int* d_boff;
-    int* d_nn5; float* d_d4;
+    int* d_nn5;
     KnnBinHost* kb;                 // query binning buffers of the tiled search, BA_CHUNK rows
     // compacted output, pair major
     float4* d_cp; double* d_nc; double* d_score;
@@ -1872,8 +2130,23 @@ __global__ void k_compact_pairs(const int* __restrict__ flag, const int* __restr
 
 extern "C" {
 
+// statistics of the near-block search since the last call (test / profiling hook): out[8] = units, units whose block did not fit, units handed on as units,
+// uncertified queries, queries, certified queries, staged candidates, scan quads (per wavefront); enable = 1 starts counting, 0 stops
+int glio_debug_knn_stats(int enable, unsigned long long* out8) {
+    if (out8) {
+        if (!g_knn_dbg) { memset(out8, 0, 64); }
+        else { if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out8, g_knn_dbg, 64, hipMemcpyDeviceToHost) != hipSuccess) return GLIO_E_HIP; }
+    }
+    if (enable && !g_knn_dbg) { if (hipMalloc((void**)&g_knn_dbg, 64) != hipSuccess) return GLIO_E_HIP; }
+    if (g_knn_dbg) hipMemset(g_knn_dbg, 0, 64);
+    if (!enable && g_knn_dbg) { hipFree(g_knn_dbg); g_knn_dbg = nullptr; }
+    return GLIO_OK;
+}
+
+// test knob: size of the cell table of the merged-window grouping (0 = sized from the map); a tiny table forces the orphan path
+int glio_debug_set_gbin_cap(int cap) { g_gbin_cap = cap < 0 ? 0 : cap; return GLIO_OK; }
 int glio_debug_set_knn_mode(int mode) {
-    if (mode < 0 || mode > 2) return GLIO_E_ARG;
+    if (mode < 0 || mode > 3) return GLIO_E_ARG;
     g_knn_mode = mode;
     return GLIO_OK;
 }
@@ -1911,7 +2184,7 @@ int glio_bassoc_create(int device, int K, int max_points_per_frame, int64_t max_
     b->b_stride = (int)(cap / PF_BLOCK + 2);
     BA_CHECK(hipMalloc((void**)&b->d_q_cp, wc * 16)); BA_CHECK(hipMalloc((void**)&b->d_q_nc, wc * 48)); BA_CHECK(hipMalloc((void**)&b->d_q_score, wc * 8));
     BA_CHECK(hipMalloc((void**)&b->d_q_flag, wc * 4)); BA_CHECK(hipMalloc((void**)&b->d_q_pos, wc * 4));
-    BA_CHECK(hipMalloc((void**)&b->d_nn5, wc * 20)); BA_CHECK(hipMalloc((void**)&b->d_d4, wc * 4));
+    BA_CHECK(hipMalloc((void**)&b->d_nn5, wc * 32));
     BA_CHECK(hipMalloc((void**)&b->d_bcount, (size_t)b->b_stride * BA_CHUNK * 4)); BA_CHECK(hipMalloc((void**)&b->d_boff, (size_t)b->b_stride * BA_CHUNK * 4));
     BA_CHECK(hipMalloc((void**)&b->d_frames, (size_t)K * sizeof(FrameDesc)));
     BA_CHECK(hipMalloc((void**)&b->d_cp, (size_t)max_constraints * 16)); BA_CHECK(hipMalloc((void**)&b->d_nc, (size_t)max_constraints * 48));
@@ -1932,7 +2205,7 @@ void glio_bassoc_destroy(glio_bassoc* b) {
         void* p[] = {f.d_ent, f.d_sub, f.d_sorted};
         for (void* q : p) if (q) hipFree(q);
     }
-    void* p[] = {b->d_bkeys, b->d_bcnt8, b->d_bslot, b->d_brank, b->d_nn5, b->d_d4, b->d_local, b->d_local_ps, b->d_global, b->d_total, b->d_q_cp, b->d_q_nc, b->d_q_score, b->d_q_flag, b->d_q_pos, b->d_bcount, b->d_boff,
+    void* p[] = {b->d_bkeys, b->d_bcnt8, b->d_bslot, b->d_brank, b->d_nn5, b->d_local, b->d_local_ps, b->d_global, b->d_total, b->d_q_cp, b->d_q_nc, b->d_q_score, b->d_q_flag, b->d_q_pos, b->d_bcount, b->d_boff,
                  b->d_cp, b->d_nc, b->d_score, b->d_run, b->d_poses, b->d_pair_off, b->d_frames, b->d_pair_ci, b->d_pair_cj,
                  b->d_sel_cp, b->d_sel_nc, b->d_sel_score, b->d_sel_idx};
     for (void* q : p) if (q) hipFree(q);
@@ -2030,9 +2303,9 @@ int glio_bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const int3
             const int np = n_pairs - p0 < BA_CHUNK ? n_pairs - p0 : BA_CHUNK;
             a.pair0 = p0;
             if (maxn > 0) {
-                enqueue_knn(b->stream, a, b->kb, np, maxn, b->d_local, b->d_local_ps, (const float4*)nullptr, (const int4*)nullptr, (const uint4*)nullptr, b->cap, b->d_nn5, b->d_d4);
+                enqueue_knn(b->stream, a, b->kb, np, maxn, b->d_local, b->d_local_ps, (const float4*)nullptr, (const int4*)nullptr, (const uint4*)nullptr, b->cap, b->d_nn5);
                 hipLaunchKernelGGL(k_plane_fit<true>, dim3((maxn + PF_BLOCK - 1) / PF_BLOCK, np), dim3(PF_BLOCK), 0, b->stream, a, b->d_local, (const float4*)nullptr,
-                                   b->d_nn5, b->d_d4, b->d_q_cp, (float4*)nullptr, b->d_q_score, b->d_q_flag, b->d_q_pos, b->d_bcount, (int*)nullptr,
+                                   b->d_nn5, b->d_q_cp, (float4*)nullptr, b->d_q_score, b->d_q_flag, b->d_q_pos, b->d_bcount, (int*)nullptr,
                                    b->d_local, b->d_q_nc);
             }
             hipLaunchKernelGGL(k_scan_pairs, dim3(1), dim3(1024), 0, b->stream, b->d_bcount, b->b_stride, b->d_frames, b->d_pair_ci, p0, np, b->d_boff,

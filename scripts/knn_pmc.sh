@@ -8,12 +8,18 @@ sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
 import numpy as np
 from glio_amd import synth, capi
 from glio_amd.capi import lidar_pose
-win = synth.make_window(W=2, pts_per_scan=65536, seed=synth.SEED_BASE + 12)
+WIN = bool(os.environ.get("KNN_WINDOW"))
+win = synth.make_window(W=20 if WIN else 2, pts_per_scan=65536, seed=synth.SEED_BASE if WIN else synth.SEED_BASE + 12)
 ctx = capi.Context(win.opts)
 ctx.set_map(win.map_pts)
-for s in range(2): ctx.set_scan(s, win.scans[s])
+for s in range(win.W): ctx.set_scan(s, win.scans[s])
 q, t = lidar_pose(win.opts, win.init.quat[0], win.init.trans[0])
-for _ in range(4): ctx.associate_resident(0, q, t)
+if WIN:
+    poses = [lidar_pose(win.opts, win.init.quat[s], win.init.trans[s]) for s in range(win.W)]
+    q2s = np.array([p[0] for p in poses]); t2s = np.array([p[1] for p in poses])
+    for _ in range(3): ctx.associate_window(q2s, t2s)
+else:
+    for _ in range(4): ctx.associate_resident(0, q, t)
 if os.environ.get("KNN_UNITS"):
     R = synth.q2R(np.asarray(q)); p = (win.scans[0][:, :3].astype(np.float64) @ R.T + np.asarray(t)).astype(np.float32)
     cell = np.floor(p * np.float32(1.0 / 1.25)).astype(np.int64)
@@ -31,7 +37,7 @@ acc = collections.defaultdict(list)
 try:
     for row in csv.DictReader(open(sys.argv[1])):
         kn = row["Kernel_Name"].split("(")[0]
-        if kn.startswith("k_knn5") or kn.startswith("k_qbin"):
+        if "k_knn5" in kn or "k_qbin" in kn or "k_gbin" in kn or "k_plane" in kn:
             acc[(kn, row["Counter_Name"])].append(float(row["Counter_Value"]))
     for (kn, k), v in sorted(acc.items()):
         print(f"{kn:16s} {k:32s} last launch {v[-1]:16.1f}  (launches {len(v)})")

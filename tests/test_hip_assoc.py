@@ -173,7 +173,7 @@ def test_tiled_search_exact_ties_and_dense_cells(hip, po):
     # (c) 5003 queries inside ONE voxel-hash cell (a tile of 1024 queries with a single key: 64 units of the same cell)
     cl = np.zeros((5003, 4), np.float32); cl[:, :3] = rng.uniform([8.0, 0.1, -0.2], [8.9, 1.0, 0.2], (5003, 3))
     lib = hip.load()
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         lib.glio_debug_set_knn_mode(mode)
         try:
             for m, q in ((lat_map, qs), (dense, dq), (dense, cl)):
@@ -192,7 +192,7 @@ def test_both_search_modes_give_identical_records(hip):
     win = synth.make_window(W=2, pts_per_scan=65536, seed=synth.SEED_BASE + 10)
     lib = hip.load()
     out = []
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         lib.glio_debug_set_knn_mode(mode)
         try:
             ctx = hip.Context(win.opts)
@@ -241,6 +241,35 @@ def test_window_association_ragged_slots_and_slide(hip, small_window):
         got = ctx.get_correspondences(s)
         assert cnt2[s] == want[k][0] and all(np.array_equal(a, b) for a, b in zip(got, want[k][1:])), (s, k)
     ctx.close()
+
+
+def test_merged_window_grouping_orphan_segments(hip, small_window):
+    """The one-call window association groups the queries of all slots by cell in a global table sized from the map.  With the table forced tiny
+    (16 slots, kept under 3/4 full) nearly every (tile, cell) segment finds no slot and is laid out by itself from the end of the array: every slot
+    must still equal the row-by-row search (mode 3), bit for bit."""
+    win = small_window
+    W = win.W
+    lib = hip.load()
+    poses = [hip.lidar_pose(win.opts, win.init.quat[s], win.init.trans[s]) for s in range(W)]
+    q2s, t2s = np.array([p[0] for p in poses]), np.array([p[1] for p in poses])
+    out = []
+    for mode, gcap in ((3, 0), (0, 16), (0, 0)):
+        lib.glio_debug_set_knn_mode(mode); lib.glio_debug_set_gbin_cap(gcap)
+        try:
+            ctx = hip.Context(win.opts); ctx.set_map(win.map_pts)
+            for s in range(W):
+                ctx.set_scan(s, win.scans[s])
+            cnt = ctx.associate_window(q2s, t2s)
+            out.append((list(cnt), [tuple(a.copy() for a in ctx.get_correspondences(s)) for s in range(W)]))
+            cnt2 = ctx.associate_window(q2s, t2s)                 # the tables are left clean: a second call gives the same
+            assert list(cnt2) == list(cnt)
+            ctx.close()
+        finally:
+            lib.glio_debug_set_knn_mode(0); lib.glio_debug_set_gbin_cap(0)
+    for k in (1, 2):
+        assert out[k][0] == out[0][0] and sum(out[0][0]) > 0
+        for s in range(W):
+            assert all(np.array_equal(a.view(np.uint8), b.view(np.uint8)) for a, b in zip(out[k][1][s], out[0][1][s])), (k, s)
 
 
 def test_asynchronous_window_association_gives_the_same_records():
