@@ -380,6 +380,45 @@ class BatchAssociation:
         self.total = tot.value
         return self.pair_count, self.total
 
+    # ---- batchFeatureAssociation (Estimator.cpp:3413-3432): the records of one keyframe's pairs ADDED behind what the object holds
+    def reset(self):
+        capi._check(capi.load().glio_bassoc_reset(self._h))
+        self.total = 0
+
+    def set_frame_from_scan(self, k, ctx, slot, lidar_offset):
+        """surf_frames[k] <- the scan resident in window slot `slot` of a capi.Context (device copy, minus the LiDAR offset)."""
+        off = np.ascontiguousarray(lidar_offset, np.float32)
+        capi._check(capi.load().glio_bassoc_set_frame_from_scan(self._h, k, ctx._h, slot, T.fptr(off)))
+
+    def run_append(self, poses, pair_ci, pair_cj, wait=True):
+        """Append the records of the given pairs; wait = False only enqueues (finish() returns the counts)."""
+        poses = np.ascontiguousarray(poses, np.float64)
+        ci = np.ascontiguousarray(pair_ci, np.int32); cj = np.ascontiguousarray(pair_cj, np.int32)
+        n = len(ci)
+        self._pending_n = n
+        lib = capi.load()
+        if not wait:
+            capi._check(lib.glio_bassoc_run_append_async(self._h, T.dptr(poses), n, T.iptr(ci) if n else None, T.iptr(cj) if n else None))
+            return None
+        cnt = np.zeros(max(n, 1), np.int64); tot = C.c_int64()
+        capi._check(lib.glio_bassoc_run_append(self._h, T.dptr(poses), n, T.iptr(ci) if n else None, T.iptr(cj) if n else None,
+                                               cnt.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(tot)))
+        self.total = tot.value
+        return cnt[:n], self.total
+
+    def finish(self):
+        n = getattr(self, "_pending_n", 0)
+        cnt = np.zeros(max(n, 1), np.int64); tot = C.c_int64()
+        capi._check(capi.load().glio_bassoc_finish(self._h, cnt.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(tot)))
+        self.total = tot.value
+        return cnt[:n], self.total
+
+    def select_range(self, first, src, n_current):
+        src = np.ascontiguousarray(src, np.int64)
+        capi._check(capi.load().glio_bassoc_select_range(self._h, C.c_int64(first), C.c_int64(len(src)), src.ctypes.data_as(C.POINTER(C.c_int64)) if len(src) else None,
+                                                         C.c_int64(n_current)))
+        self.total = first + len(src)
+
     def select(self, res_num, rng, ends_of=None, rand_set_num=400):
         """Batch feature selection over the pairs of the last run (batch_feature_res_num records per pair at most), gathered on
         the device.  ends_of: optional predicate idx -> bool marking the source keyframes that take the `_Batch` (ends) rule."""

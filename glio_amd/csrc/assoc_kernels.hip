@@ -321,6 +321,7 @@ struct AssocArgs {
     const int* win_counts;                  // [W]
     int q_stride, w_stride, b_stride;       // scan + correspondence arrays, dense work arrays, per-workgroup counts
     int w_stride_q;                         // row stride of kb.failq (= the binning capacity per row)
+    int ring_base, ring_W;                  // window mode: slot k reads the scan row (ring_base + k) % ring_W
     // pair mode (glio_bassoc_run): blockIdx.y = pair inside the chunk; pair (ci, cj) queries the cloud of keyframe ci
     // (local frame, posed with poses[ci]) against the voxel hash of keyframe cj
     const struct FrameDesc* frames;         // [K]
@@ -354,7 +355,7 @@ __device__ __forceinline__ AssocSlot assoc_slot(const AssocArgs& a) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) s.t[i] = P[4 + i];
         s.n = a.win_counts[k];
-        s.qoff = (size_t)k * a.q_stride; s.woff = (size_t)k * a.w_stride; s.boff = (size_t)k * a.b_stride;
+        s.qoff = (size_t)((k + a.ring_base) % a.ring_W) * a.q_stride; s.woff = (size_t)k * a.w_stride; s.boff = (size_t)k * a.b_stride;      // scans: ring rows
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) s.q[i] = a.q[i];
@@ -1735,33 +1736,8 @@ void glio_assoc_destroy(glio_ctx* c) {
 // a scan was uploaded to / moved between slots: keep its presorted copy in step (enqueued on the context stream)
 void glio_assoc_scan_uploaded(glio_ctx* c, int slot, int n) {
     AssocWork* w = c->assoc;
-    if (w) enqueue_presort(c->stream, w->kb, c->d_scan + (size_t)slot * c->cap, n, w->d_ps + (size_t)slot * c->cap);
+    if (w) { const size_t row = (size_t)glio_scan_row(c, slot) * c->cap; enqueue_presort(c->stream, w->kb, c->d_scan + row, n, w->d_ps + row); }
 }
-void glio_assoc_scan_moved(glio_ctx* c, int from, int to, int n) {
-    AssocWork* w = c->assoc;
-    if (w && n > 0) hipMemcpyAsync(w->d_ps + (size_t)to * c->cap, w->d_ps + (size_t)from * c->cap, (size_t)n * 16, hipMemcpyDeviceToDevice, c->stream);
-}
-// the slide of the window as ONE launch: thread e carries element e of the scan (and of its presorted copy) of slot s + 1 down to
-// slot s, for s = 0 .. W-2 in order -- every element is owned by one thread, so the overlapping moves need no staging
-// (2 (W - 1) hipMemcpyAsync calls cost ~0.19 ms of launch overhead at W = 20)
-struct SlideCounts { int n[GLIO_MAX_WINDOW]; };
-__global__ void k_slide_scans(float4* __restrict__ scan, float4* __restrict__ ps, const int cap, const int W, const SlideCounts cn) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    for (int s = 0; s + 1 < W; ++s) {
-        if (e < cn.n[s + 1]) {
-            scan[(size_t)s * cap + e] = scan[(size_t)(s + 1) * cap + e];
-            if (ps) ps[(size_t)s * cap + e] = ps[(size_t)(s + 1) * cap + e];
-        }
-    }
-}
-void glio_assoc_slide_scans(glio_ctx* c) {
-    AssocWork* w = c->assoc;
-    SlideCounts cn;
-    int maxn = 0;
-    for (int s = 0; s < c->W; ++s) { cn.n[s] = c->h_scan_count[s]; if (s > 0 && cn.n[s] > maxn) maxn = cn.n[s]; }
-    if (maxn > 0) hipLaunchKernelGGL(k_slide_scans, dim3((maxn + 255) / 256), dim3(256), 0, c->stream, c->d_scan, w ? w->d_ps : nullptr, c->cap, c->W, cn);
-}
-
 static void enqueue_build(glio_ctx* c, int n) {
     AssocWork* w = c->assoc;
     int cap = next_pow2(2 * (n > 512 ? n : 512));          // sized for THIS map: a smaller table stays in L2
@@ -1807,11 +1783,11 @@ static void enqueue_assoc(glio_ctx* c, int slot, const double q[4], const double
     a.surf_dist_thres = c->opts.surf_dist_thres; a.lidar_const = c->opts.lidar_const;
     a.n = n; a.table_cap = w->cap_eff; a.unit_scores = c->opts.unit_scores;
     a.win_poses = nullptr; a.win_counts = nullptr; a.q_stride = a.w_stride = a.b_stride = 0;
-    const size_t off = (size_t)slot * c->cap;
+    const size_t off = (size_t)slot * c->cap, row = (size_t)glio_scan_row(c, slot) * c->cap;      // correspondences by window slot, scans by ring row
     const int nblk = (n + PF_BLOCK - 1) / PF_BLOCK;
     if (n > 0) {
-        enqueue_knn(c->stream, a, w->kb, 1, n, c->d_scan + off, w->d_ps + off, c->d_map_sorted, w->d_ent, w->d_sub, c->map_n, w->d_nn5);
-        hipLaunchKernelGGL(k_plane_fit<false>, dim3(nblk), dim3(PF_BLOCK), 0, c->stream, a, c->d_scan + off, c->d_map_sorted, w->d_nn5,
+        enqueue_knn(c->stream, a, w->kb, 1, n, c->d_scan + row, w->d_ps + row, c->d_map_sorted, w->d_ent, w->d_sub, c->map_n, w->d_nn5);
+        hipLaunchKernelGGL(k_plane_fit<false>, dim3(nblk), dim3(PF_BLOCK), 0, c->stream, a, c->d_scan + row, c->d_map_sorted, w->d_nn5,
                            w->d_q_pt, w->d_q_plane, w->d_q_score, w->d_q_flag, w->d_q_pos, w->d_bcount, want_nn ? w->d_nn : nullptr,
                            (const float4*)nullptr, (double*)nullptr);
     }
@@ -1842,6 +1818,7 @@ static int enqueue_assoc_window(glio_ctx* c, const double* quats, const double* 
     a.n = 0; a.table_cap = w->cap_eff; a.unit_scores = c->opts.unit_scores;
     a.win_poses = w->d_win; a.win_counts = reinterpret_cast<const int*>(w->d_win + 7 * W);
     a.q_stride = c->cap; a.w_stride = c->cap; a.b_stride = c->cap / AQ_PER_BLOCK + 2;
+    a.ring_base = c->scan_base; a.ring_W = W;
     if (maxn > 0) {
         enqueue_knn(c->stream, a, w->kb, W, maxn, c->d_scan, w->d_ps, c->d_map_sorted, w->d_ent, w->d_sub, c->map_n, w->d_nn5);
         hipLaunchKernelGGL(k_plane_fit<false>, dim3((maxn + PF_BLOCK - 1) / PF_BLOCK, W), dim3(PF_BLOCK), 0, c->stream, a, c->d_scan, c->d_map_sorted,
@@ -2015,6 +1992,9 @@ struct glio_bassoc {
     FrameDesc* d_frames; int* d_pair_ci; int* d_pair_cj;      // [K], [max_pairs] x 2: what the chunked launches index by blockIdx.y
     int b_stride;                             // per-pair stride of the per-workgroup count arrays
     long long* h_pair_off;          // pinned
+    long long* h_tail;              // pinned [2]: running total, overflow flag of the last run
+    double* h_poses; int32_t* h_pairs; FrameDesc* h_fd;      // pinned staging of a run's inputs ([K][7], [2][max_pairs], [K]): the asynchronous run returns before they are read
+    int pending_pairs;              // pairs of an asynchronous run whose counts were not picked up yet (-1: none)
     double* d_poses;                // [K][7]
     // feature selection scratch (grow-only): the gathered records and their source indices
     float4* d_sel_cp; double* d_sel_nc; double* d_sel_score; long long* d_sel_idx; long long sel_cap;
@@ -2192,6 +2172,10 @@ int glio_bassoc_create(int device, int K, int max_points_per_frame, int64_t max_
     BA_CHECK(hipMalloc((void**)&b->d_run, 16)); BA_CHECK(hipMalloc((void**)&b->d_poses, (size_t)K * 7 * 8));
     b->kb = knn_bin_create(BA_CHUNK, b->cap);
     if (!b->kb) return GLIO_E_HIP;
+    BA_CHECK(hipHostMalloc((void**)&b->h_tail, 16)); BA_CHECK(hipHostMalloc((void**)&b->h_poses, (size_t)K * 7 * 8)); BA_CHECK(hipHostMalloc((void**)&b->h_fd, (size_t)K * sizeof(FrameDesc)));
+    b->h_tail[0] = b->h_tail[1] = 0; b->pending_pairs = -1;
+    BA_CHECK(hipMemsetAsync(b->d_run, 0, 16, b->stream));
+    BA_CHECK(hipStreamSynchronize(b->stream));
     *out = b;
     return GLIO_OK;
 }
@@ -2213,6 +2197,10 @@ void glio_bassoc_destroy(glio_bassoc* b) {
     if (b->d_fb) hipFree(b->d_fb);
     if (b->h_fb) hipHostFree(b->h_fb);
     if (b->h_pair_off) hipHostFree(b->h_pair_off);
+    if (b->h_pairs) hipHostFree(b->h_pairs);
+    if (b->h_tail) hipHostFree(b->h_tail);
+    if (b->h_poses) hipHostFree(b->h_poses);
+    if (b->h_fd) hipHostFree(b->h_fd);
     delete[] b->h_n; delete[] b->frames;
     hipStreamDestroy(b->stream);
     delete b;
@@ -2221,6 +2209,7 @@ void glio_bassoc_destroy(glio_bassoc* b) {
 int glio_bassoc_set_frame(glio_bassoc* b, int k, const float* scan_xyzi, int n) {
     if (!b || k < 0 || k >= b->K || n < 0 || n > b->cap || (n > 0 && !scan_xyzi)) { glio_set_error("bad keyframe cloud (k %d, n %d)", k, n); return GLIO_E_ARG; }
     BA_CHECK(hipSetDevice(b->device));
+    { const int rf = glio_bassoc_finish(b, nullptr, nullptr); if (rf != GLIO_OK) return rf; }      // (an asynchronous run may still read the clouds)
     if (n > 0) BA_CHECK(hipMemcpyAsync(b->d_local + (size_t)k * b->cap, scan_xyzi, (size_t)n * 16, hipMemcpyHostToDevice, b->stream));
     enqueue_presort(b->stream, b->kb, b->d_local + (size_t)k * b->cap, n, b->d_local_ps + (size_t)k * b->cap);
     BA_CHECK(hipGetLastError());
@@ -2229,22 +2218,39 @@ int glio_bassoc_set_frame(glio_bassoc* b, int k, const float* scan_xyzi, int n) 
     return GLIO_OK;
 }
 
-int glio_bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj,
-                    int64_t* pair_count_out, int64_t* total_out) {
+// one association run: hashes of every search frame at the given poses, then the pairs in the caller's order.  append: the records go behind what the
+// object already holds (the per-keyframe calls of batchFeatureAssociation, Estimator.cpp:3413-3432, accumulate gl_vec_surf_* this way); wait = 0: everything
+// is enqueued on the object's stream and the call returns (inputs are staged in pinned memory first) -- glio_bassoc_finish picks the counts up.
+static int bassoc_finish(glio_bassoc* b, int64_t* pair_count_out, int64_t* total_out) {
+    if (b->pending_pairs < 0) return GLIO_OK;
+    const int n_pairs = b->pending_pairs;
+    BA_CHECK(hipStreamSynchronize(b->stream));
+    b->pending_pairs = -1;
+    if (*reinterpret_cast<int*>(&b->h_tail[1])) { glio_set_error("more constraints than max_constraints (%lld)", b->max_con); return GLIO_E_ARG; }
+    if (pair_count_out) for (int p = 0; p < n_pairs; ++p) pair_count_out[p] = b->h_pair_off[p + 1] - b->h_pair_off[p];
+    if (total_out) *total_out = b->h_tail[0];
+    return GLIO_OK;
+}
+static int bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj, bool append, bool wait,
+                      int64_t* pair_count_out, int64_t* total_out) {
     GLIO_TRACE("K2 glio_bassoc_run (batch association)");
     if (!b || !poses || n_pairs < 0 || (n_pairs > 0 && (!pair_ci || !pair_cj))) return GLIO_E_ARG;
     BA_CHECK(hipSetDevice(b->device));
+    { const int rf = bassoc_finish(b, nullptr, nullptr); if (rf != GLIO_OK) return rf; }          // (an earlier asynchronous run still reads the staging buffers)
     for (int p = 0; p < n_pairs; ++p)
         if (pair_ci[p] < 0 || pair_ci[p] >= b->K || pair_cj[p] < 0 || pair_cj[p] >= b->K || pair_ci[p] == pair_cj[p]) { glio_set_error("bad pair %d", p); return GLIO_E_ARG; }
     if (n_pairs > b->max_pairs) {
-        if (b->d_pair_off) { hipFree(b->d_pair_off); hipHostFree(b->h_pair_off); hipFree(b->d_pair_ci); hipFree(b->d_pair_cj); b->d_pair_off = nullptr; b->h_pair_off = nullptr; }
+        if (b->d_pair_off) { hipFree(b->d_pair_off); hipHostFree(b->h_pair_off); hipFree(b->d_pair_ci); hipFree(b->d_pair_cj); hipHostFree(b->h_pairs); b->d_pair_off = nullptr; b->h_pair_off = nullptr; b->h_pairs = nullptr; }
         b->max_pairs = n_pairs + 64;
         BA_CHECK(hipMalloc((void**)&b->d_pair_off, (size_t)(b->max_pairs + 2) * 8));
         BA_CHECK(hipMalloc((void**)&b->d_pair_ci, (size_t)b->max_pairs * 4)); BA_CHECK(hipMalloc((void**)&b->d_pair_cj, (size_t)b->max_pairs * 4));
         BA_CHECK(hipHostMalloc((void**)&b->h_pair_off, (size_t)(b->max_pairs + 2) * 8));
+        BA_CHECK(hipHostMalloc((void**)&b->h_pairs, (size_t)b->max_pairs * 8));
     }
-    BA_CHECK(hipMemcpyAsync(b->d_poses, poses, (size_t)b->K * 7 * 8, hipMemcpyHostToDevice, b->stream));
-    BA_CHECK(hipMemsetAsync(b->d_run, 0, 16, b->stream));
+    memcpy(b->h_poses, poses, (size_t)b->K * 7 * 8);
+    BA_CHECK(hipMemcpyAsync(b->d_poses, b->h_poses, (size_t)b->K * 7 * 8, hipMemcpyHostToDevice, b->stream));
+    if (append) BA_CHECK(hipMemsetAsync(b->d_run + 1, 0, 8, b->stream));
+    else BA_CHECK(hipMemsetAsync(b->d_run, 0, 16, b->stream));
     int* d_overflow = reinterpret_cast<int*>(b->d_run + 1);
     // (1) every keyframe that occurs as a search frame: cloud -> global frame -> voxel hash
     std::vector<char> need(b->K, 0);
@@ -2282,17 +2288,16 @@ int glio_bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const int3
     }
     // (2) the pairs, in the caller's (ci, cj) order, BA_CHUNK pairs per launch (blockIdx.y = pair of the chunk)
     if (n_pairs > 0) {
-        std::vector<FrameDesc> fd(b->K);
         int maxn = 0;
         for (int k = 0; k < b->K; ++k) {
-            fd[k].ent = b->frames[k].d_ent; fd[k].sub = b->frames[k].d_sub; fd[k].sorted = b->frames[k].d_sorted; fd[k].n = b->h_n[k];
-            fd[k].cap_eff = need[k] ? b->frames[k].cap_eff : b->frames[k].table_cap;
-            if (b->h_n[k] > maxn) maxn = b->h_n[k];
+            FrameDesc& fd = b->h_fd[k];
+            fd.ent = b->frames[k].d_ent; fd.sub = b->frames[k].d_sub; fd.sorted = b->frames[k].d_sorted; fd.n = b->h_n[k];
+            fd.cap_eff = need[k] ? b->frames[k].cap_eff : b->frames[k].table_cap;
         }
-        BA_CHECK(hipMemcpyAsync(b->d_frames, fd.data(), (size_t)b->K * sizeof(FrameDesc), hipMemcpyHostToDevice, b->stream));
-        BA_CHECK(hipMemcpyAsync(b->d_pair_ci, pair_ci, (size_t)n_pairs * 4, hipMemcpyHostToDevice, b->stream));
-        BA_CHECK(hipMemcpyAsync(b->d_pair_cj, pair_cj, (size_t)n_pairs * 4, hipMemcpyHostToDevice, b->stream));
-        BA_CHECK(hipStreamSynchronize(b->stream));                       // the three sources are pageable host memory
+        for (int p = 0; p < n_pairs; ++p) { b->h_pairs[p] = pair_ci[p]; b->h_pairs[b->max_pairs + p] = pair_cj[p]; if (b->h_n[pair_ci[p]] > maxn) maxn = b->h_n[pair_ci[p]]; }
+        BA_CHECK(hipMemcpyAsync(b->d_frames, b->h_fd, (size_t)b->K * sizeof(FrameDesc), hipMemcpyHostToDevice, b->stream));
+        BA_CHECK(hipMemcpyAsync(b->d_pair_ci, b->h_pairs, (size_t)n_pairs * 4, hipMemcpyHostToDevice, b->stream));
+        BA_CHECK(hipMemcpyAsync(b->d_pair_cj, b->h_pairs + b->max_pairs, (size_t)n_pairs * 4, hipMemcpyHostToDevice, b->stream));
         AssocArgs a;
         memset(&a, 0, sizeof a);
         a.inv_cell = b->inv_cell; a.cell = b->cell; a.kd_max_radius = 1.5; a.weight_gate = 0.3; a.surf_dist_thres = 0.18; a.lidar_const = 2.5;   // :3839,3874,3863,3885
@@ -2316,13 +2321,51 @@ int glio_bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const int3
         }
     }
     BA_CHECK(hipGetLastError());
-    long long tail[2] = {0, 0};
     if (n_pairs > 0) BA_CHECK(hipMemcpyAsync(b->h_pair_off, b->d_pair_off, (size_t)(n_pairs + 1) * 8, hipMemcpyDeviceToHost, b->stream));
-    BA_CHECK(hipMemcpyAsync(tail, b->d_run, 16, hipMemcpyDeviceToHost, b->stream));
-    BA_CHECK(hipStreamSynchronize(b->stream));
-    if (*reinterpret_cast<int*>(&tail[1])) { glio_set_error("more constraints than max_constraints (%lld)", b->max_con); return GLIO_E_ARG; }
-    if (pair_count_out) for (int p = 0; p < n_pairs; ++p) pair_count_out[p] = b->h_pair_off[p + 1] - b->h_pair_off[p];
-    if (total_out) *total_out = tail[0];
+    BA_CHECK(hipMemcpyAsync(b->h_tail, b->d_run, 16, hipMemcpyDeviceToHost, b->stream));
+    b->pending_pairs = n_pairs;
+    return wait ? bassoc_finish(b, pair_count_out, total_out) : GLIO_OK;
+}
+int glio_bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj, int64_t* pair_count_out, int64_t* total_out) {
+    return bassoc_run(b, poses, n_pairs, pair_ci, pair_cj, false, true, pair_count_out, total_out);
+}
+int glio_bassoc_run_append(glio_bassoc* b, const double* poses, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj, int64_t* pair_count_out, int64_t* total_out) {
+    return bassoc_run(b, poses, n_pairs, pair_ci, pair_cj, true, true, pair_count_out, total_out);
+}
+int glio_bassoc_run_append_async(glio_bassoc* b, const double* poses, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj) {
+    return bassoc_run(b, poses, n_pairs, pair_ci, pair_cj, true, false, nullptr, nullptr);
+}
+int glio_bassoc_finish(glio_bassoc* b, int64_t* pair_count_out, int64_t* total_out) {
+    if (!b) return GLIO_E_ARG;
+    BA_CHECK(hipSetDevice(b->device));
+    if (b->pending_pairs < 0) { if (total_out) *total_out = b->h_tail[0]; return GLIO_OK; }
+    return bassoc_finish(b, pair_count_out, total_out);
+}
+int glio_bassoc_reset(glio_bassoc* b) {
+    if (!b) return GLIO_E_ARG;
+    BA_CHECK(hipSetDevice(b->device));
+    { const int rf = bassoc_finish(b, nullptr, nullptr); if (rf != GLIO_OK) return rf; }
+    BA_CHECK(hipMemsetAsync(b->d_run, 0, 16, b->stream));
+    b->h_tail[0] = b->h_tail[1] = 0;
+    return GLIO_OK;
+}
+// surf_frames[k] from a scan that is already resident in a sliding-window context (slot of its ring), minus the LiDAR offset: no second upload
+__global__ void k_copy_offset(const float4* __restrict__ in, int n, float ox, float oy, float oz, float4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const float4 p = in[i]; out[i] = make_float4(p.x - ox, p.y - oy, p.z - oz, p.w); }
+}
+int glio_bassoc_set_frame_from_scan(glio_bassoc* b, int k, glio_ctx* c, int slot, const float lidar_offset[3]) {
+    if (!b || !c || !lidar_offset || k < 0 || k >= b->K || slot < 0 || slot >= c->W || c->device != b->device) return GLIO_E_ARG;
+    const int n = c->h_scan_count[slot];
+    if (n > b->cap) { glio_set_error("scan of %d points, the batch association holds %d per keyframe", n, b->cap); return GLIO_E_ARG; }
+    BA_CHECK(hipSetDevice(b->device));
+    { const int rf = bassoc_finish(b, nullptr, nullptr); if (rf != GLIO_OK) return rf; }
+    BA_CHECK(hipStreamSynchronize(c->stream));                       // (the upload of the scan ran on the context's stream)
+    if (n > 0) hipLaunchKernelGGL(k_copy_offset, dim3((n + 255) / 256), dim3(256), 0, b->stream, c->d_scan + (size_t)glio_scan_row(c, slot) * c->cap, n,
+                                  lidar_offset[0], lidar_offset[1], lidar_offset[2], b->d_local + (size_t)k * b->cap);
+    enqueue_presort(b->stream, b->kb, b->d_local + (size_t)k * b->cap, n, b->d_local_ps + (size_t)k * b->cap);
+    BA_CHECK(hipGetLastError());
+    b->h_n[k] = n;
     return GLIO_OK;
 }
 
@@ -2349,11 +2392,17 @@ __global__ void k_bassoc_gather(const long long* __restrict__ idx, const long lo
     for (int c = 0; c < 6; ++c) o_nc[6 * k + c] = nc[6 * sidx + c];
     o_score[k] = score[sidx];
 }
-int glio_bassoc_select(glio_bassoc* b, int64_t n_keep, const int64_t* src_index, int64_t n_current) {
-    if (!b || n_keep < 0 || n_current < 0 || n_current > b->max_con || n_keep > n_current || (n_keep > 0 && !src_index)) return GLIO_E_ARG;
+int glio_bassoc_select(glio_bassoc* b, int64_t n_keep, const int64_t* src_index, int64_t n_current) { return glio_bassoc_select_range(b, 0, n_keep, src_index, n_current); }
+// the same over the TAIL [first, n_current) only (the records one keyframe's batchFeatureAssociation appended): they are replaced by the n_keep records
+// src_index names (absolute indices >= first); the object then holds first + n_keep records
+int glio_bassoc_select_range(glio_bassoc* b, int64_t first, int64_t n_keep, const int64_t* src_index, int64_t n_current) {
+    if (!b || first < 0 || n_keep < 0 || n_current < first || n_current > b->max_con || n_keep > n_current - first || (n_keep > 0 && !src_index)) return GLIO_E_ARG;
     BA_CHECK(hipSetDevice(b->device));
-    for (int64_t k = 0; k < n_keep; ++k) if (src_index[k] < 0 || src_index[k] >= n_current) { glio_set_error("selection index %lld out of range", (long long)src_index[k]); return GLIO_E_ARG; }
-    if (n_keep == 0) return GLIO_OK;
+    { const int rf = bassoc_finish(b, nullptr, nullptr); if (rf != GLIO_OK) return rf; }
+    for (int64_t k = 0; k < n_keep; ++k) if (src_index[k] < first || src_index[k] >= n_current) { glio_set_error("selection index %lld out of range", (long long)src_index[k]); return GLIO_E_ARG; }
+    b->h_tail[0] = first + n_keep;
+    BA_CHECK(hipMemcpyAsync(b->d_run, b->h_tail, 8, hipMemcpyHostToDevice, b->stream));
+    if (n_keep == 0) { BA_CHECK(hipStreamSynchronize(b->stream)); return GLIO_OK; }
     if (n_keep > b->sel_cap) {
         // (pointers nulled and the capacity reset before the new allocations: a failed hipMalloc must not leave dangling pointers
         //  behind a capacity that claims room -- advisor finding of round 2)
@@ -2368,9 +2417,9 @@ int glio_bassoc_select(glio_bassoc* b, int64_t n_keep, const int64_t* src_index,
     BA_CHECK(hipMemcpyAsync(b->d_sel_idx, src_index, (size_t)n_keep * 8, hipMemcpyHostToDevice, b->stream));
     hipLaunchKernelGGL(k_bassoc_gather, dim3((unsigned)((n_keep + 255) / 256)), dim3(256), 0, b->stream, b->d_sel_idx, (long long)n_keep, b->d_cp, b->d_nc, b->d_score,
                        b->d_sel_cp, b->d_sel_nc, b->d_sel_score);
-    BA_CHECK(hipMemcpyAsync(b->d_cp, b->d_sel_cp, (size_t)n_keep * 16, hipMemcpyDeviceToDevice, b->stream));
-    BA_CHECK(hipMemcpyAsync(b->d_nc, b->d_sel_nc, (size_t)n_keep * 48, hipMemcpyDeviceToDevice, b->stream));
-    BA_CHECK(hipMemcpyAsync(b->d_score, b->d_sel_score, (size_t)n_keep * 8, hipMemcpyDeviceToDevice, b->stream));
+    BA_CHECK(hipMemcpyAsync(b->d_cp + first, b->d_sel_cp, (size_t)n_keep * 16, hipMemcpyDeviceToDevice, b->stream));
+    BA_CHECK(hipMemcpyAsync(b->d_nc + 6 * first, b->d_sel_nc, (size_t)n_keep * 48, hipMemcpyDeviceToDevice, b->stream));
+    BA_CHECK(hipMemcpyAsync(b->d_score + first, b->d_sel_score, (size_t)n_keep * 8, hipMemcpyDeviceToDevice, b->stream));
     BA_CHECK(hipStreamSynchronize(b->stream));
     return GLIO_OK;
 }
@@ -2378,6 +2427,7 @@ int glio_bassoc_select(glio_bassoc* b, int64_t n_keep, const int64_t* src_index,
 int glio_bassoc_read(glio_bassoc* b, int64_t first, int64_t n, float* cp, double* norm_cent, double* score) {
     if (!b || first < 0 || n < 0 || first + n > b->max_con) return GLIO_E_ARG;
     BA_CHECK(hipSetDevice(b->device));
+    { const int rf = glio_bassoc_finish(b, nullptr, nullptr); if (rf != GLIO_OK) return rf; }
     if (n == 0) return GLIO_OK;
     if (cp) BA_CHECK(hipMemcpy(cp, b->d_cp + first, (size_t)n * 16, hipMemcpyDeviceToHost));
     if (norm_cent) BA_CHECK(hipMemcpy(norm_cent, b->d_nc + 6 * first, (size_t)n * 48, hipMemcpyDeviceToHost));

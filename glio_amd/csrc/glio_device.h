@@ -162,7 +162,8 @@ struct glio_ctx {
     int* d_count;                 // [W]
     int h_count[GLIO_MAX_WINDOW];
     // ---- scans + map (association)
-    float4* d_scan;               // [W][cap]
+    float4* d_scan;               // [W][cap] resident scans, a RING: window slot s lives in row (scan_base + s) % W (glio_slide_window advances scan_base)
+    int scan_base;
     int h_scan_count[GLIO_MAX_WINDOW];
     float4* d_map_sorted;         // [max_map] sorted by cell, .w = original index bits
     int map_n;
@@ -309,6 +310,7 @@ __device__ __forceinline__ void d_plus_jac(const double q[4], double P[12]) {
 // ds_reads are not hoisted above it.  Restricted to the LDS address space on purpose: a generic wavefront-scope fence also
 // drains every outstanding GLOBAL load/store (s_waitcnt vmcnt(0)), which would expose the latency of loads issued early
 // for prefetching.
+static inline int glio_scan_row(const glio_ctx* c, int slot) { return (c->scan_base + slot) % c->W; }
 #define GLIO_WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local"); __builtin_amdgcn_wave_barrier(); \
                                   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local"); } while (0)
 
@@ -421,8 +423,6 @@ size_t glio_tr_step_lds_bytes(int n);
 int glio_assoc_create(glio_ctx* c);
 // the resident scan of a slot changed (uploaded / moved by the slide): keep the presorted copy the tiled search reads in step
 void glio_assoc_scan_uploaded(glio_ctx* c, int slot, int n);
-void glio_assoc_scan_moved(glio_ctx* c, int from, int to, int n);
-void glio_assoc_slide_scans(glio_ctx* c);            // all resident scans (and their presorted copies) one slot down, one launch
 void glio_assoc_destroy(glio_ctx* c);
 int glio_assoc_build_map(glio_ctx* c, const float* map_xyzi, int n);
 int glio_assoc_run(glio_ctx* c, int slot, const double q[4], const double t[3], int* out_count);

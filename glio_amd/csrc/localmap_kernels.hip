@@ -421,7 +421,7 @@ int glio_localmap_push_scan(glio_ctx* c, int scan_slot, const float lidar_offset
     float4* dst = m->d_ring + (size_t)slot * m->cap;
     hipLaunchKernelGGL(k_lm_bbox_init, dim3(1), dim3(64), 0, c->stream, m->d_slot_bbox + 6 * slot);
     if (n > 0) {
-        hipLaunchKernelGGL(k_lm_transform_off, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_scan + (size_t)scan_slot * c->cap, n, lidar_offset[0], lidar_offset[1],
+        hipLaunchKernelGGL(k_lm_transform_off, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_scan + (size_t)glio_scan_row(c, scan_slot) * c->cap, n, lidar_offset[0], lidar_offset[1],
                            lidar_offset[2], q[0], q[1], q[2], q[3], t[0], t[1], t[2], dst);
         hipLaunchKernelGGL(k_lm_bbox, dim3(std::min(64, (n + 1023) / 1024)), dim3(1024), 0, c->stream, dst, n, m->d_slot_bbox + 6 * slot);
         hipLaunchKernelGGL(k_lm_accumulate, dim3((n + 255) / 256), dim3(256), 0, c->stream, dst, n, inv_leaf, +1, m->d_keys, m->d_sum, m->d_cnt, m->table_cap, m->d_nkeys);

@@ -142,3 +142,63 @@ class ResidentSlidingWindow:
         st.trans[:-1] = st.trans[1:].copy(); st.quat[:-1] = st.quat[1:].copy(); st.speed_bias[:-1] = st.speed_bias[1:].copy()
         st.trans[-1], st.quat[-1], st.speed_bias[-1] = new_trans, new_quat, new_speed_bias
         self.first += 1
+
+
+class KeyframeBatchAssociation:
+    """batchFeatureAssociation() (Estimator.cpp:3413-3432), the call that ends every optimizeSlidingWindowWithLandMark (:2733): once the stream holds
+    2 search_range keyframes, the keyframe idx = size - search_range - 1 is matched against its 2 search_range neighbours at the CURRENT poses
+    (findGlobalCorrespondingSurfFeaturesAdd_Batch :3808-3892: 12 hash builds + 12 pair searches on the device) and -- with a generator --
+    globalFeatureSelectionAdd_Batch (:4057-4116) keeps batch_feature_res_num records per pair.  The records accumulate in `ba` (a batch.BatchAssociation
+    sized for the stream), pair major, exactly what BatchAssociation.run over the same pairs and poses gives; `pairs` / `counts` list them in call order."""
+
+    def __init__(self, ba, search_range=6, feature_res_num=None, rng=None):
+        self.ba, self.sr, self.res_num, self.rng = ba, search_range, feature_res_num, rng
+        self.pair_ci, self.pair_cj, self.counts = [], [], []
+        self._enq = None
+
+    @staticmethod
+    def pairs_of(size, search_range):
+        """(idx, [j ...]) of the call made when the stream holds `size` keyframes, or None (Estimator.cpp:3414-3416)."""
+        idx = size - search_range - 1
+        if size < 2 * search_range or idx < search_range:
+            return None
+        return idx, [j for j in range(idx - search_range, idx + search_range + 1) if j != idx]
+
+    def enqueue(self, size, poses):
+        """poses [K][7] = t, q of every keyframe slot of `ba`.  Enqueues the searches on the association's own stream and returns."""
+        pr = self.pairs_of(size, self.sr)
+        if pr is None:
+            self._enq = None
+            return 0
+        idx, js = pr
+        ci, cj = np.full(len(js), idx, np.int32), np.asarray(js, np.int32)
+        self._first = self.ba.total
+        self.ba.run_append(poses, ci, cj, wait=False)
+        self._enq = (ci, cj)
+        return len(js)
+
+    def finish(self):
+        """Waits for the enqueued call, applies the selection, books the pairs.  Returns this call's per-pair counts."""
+        if self._enq is None:
+            return np.zeros(0, np.int64)
+        ci, cj = self._enq
+        self._enq = None
+        cnt, total = self.ba.finish()
+        if self.res_num is not None and self.rng is not None:
+            from .batch import batch_selection_draws
+            offs = self._first + np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+            keep, kept = [], cnt.copy()
+            for p in range(len(cnt)):
+                d = batch_selection_draws(int(cnt[p]), self.res_num, self.rng)
+                sel = np.arange(int(cnt[p]), dtype=np.int64) if d is None else d
+                keep.append(offs[p] + sel); kept[p] = len(sel)
+            src = np.concatenate(keep) if keep else np.zeros(0, np.int64)
+            if len(src) != total - self._first:
+                self.ba.select_range(self._first, src, total)
+            cnt = kept
+        self.pair_ci += ci.tolist(); self.pair_cj += cj.tolist(); self.counts += [int(c) for c in cnt]
+        return cnt
+
+    def step(self, size, poses):
+        self.enqueue(size, poses)
+        return self.finish()

@@ -298,12 +298,27 @@ void glio_bassoc_destroy(glio_bassoc* b);
 int glio_bassoc_set_frame(glio_bassoc* b, int k, const float* scan_xyzi, int n);
 int glio_bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj,
                     int64_t* pair_count_out, int64_t* total_out);
+/* batchFeatureAssociation() (Estimator.cpp:3413-3432), the call that ENDS every optimizeSlidingWindowWithLandMark (:2733): the keyframe
+ * idx = size - search_range - 1 is matched against its 2 search_range neighbours and the records are ADDED to gl_vec_surf_* -- here: appended behind
+ * what the object already holds (pair_count_out: the pairs of this call; total_out: everything held).  _async enqueues on the object's stream and
+ * returns (the inputs are staged in pinned memory); glio_bassoc_finish waits and hands the counts over.  glio_bassoc_reset forgets the records. */
+int glio_bassoc_run_append(glio_bassoc* b, const double* poses, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj,
+                           int64_t* pair_count_out, int64_t* total_out);
+int glio_bassoc_run_append_async(glio_bassoc* b, const double* poses, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj);
+int glio_bassoc_finish(glio_bassoc* b, int64_t* pair_count_out, int64_t* total_out);
+int glio_bassoc_reset(glio_bassoc* b);
+/* surf_frames[k] <- the scan resident in window slot `slot` of a sliding-window context on the same device, minus the LiDAR offset (a device copy:
+ * the keyframe that just entered the window is not uploaded a second time) */
+int glio_bassoc_set_frame_from_scan(glio_bassoc* b, int k, glio_ctx* ctx, int slot, const float lidar_offset[3]);
 int glio_bassoc_results_dev(glio_bassoc* b, const float** cp_dev, const double** norm_cent_dev, const double** score_dev);
 /* globalFeatureSelectionAdd_Batch / globalFeatureSelection_Batch (Estimator.cpp:4057-4116, 3994-4055; batch_feature_res_num: 25):
  * keep records src_index[0..n_keep) of the current n_current records, in that order (pair after pair; the caller updates its
  * per-pair counts).  The random draws stay with the caller (the reference seeds from std::random_device); the gather runs on
  * the device, in place.  glio_amd/batch.py::batch_selection_draws restates the draw rules. */
 int glio_bassoc_select(glio_bassoc* b, int64_t n_keep, const int64_t* src_index, int64_t n_current);
+/* the same over the tail [first, n_current) only -- what one keyframe's batchFeatureAssociation appended: src_index holds absolute indices >= first;
+ * afterwards the object holds first + n_keep records */
+int glio_bassoc_select_range(glio_bassoc* b, int64_t first, int64_t n_keep, const int64_t* src_index, int64_t n_current);
 int glio_bassoc_read(glio_bassoc* b, int64_t first, int64_t n, float* cp, double* norm_cent, double* score);
 
 #ifdef __cplusplus

@@ -169,3 +169,47 @@ def test_rounds_with_reassociation_follow_the_oracle(frames):
     assert np.abs(poses - ref).max() < 1e-7
     assert hist[-1]["final_cost"] <= hist[0]["initial_cost"]
     ra.close(); st.close()
+
+
+def test_keyframe_by_keyframe_accumulation_equals_one_run(frames):
+    """batchFeatureAssociation (Estimator.cpp:3413-3432) is called once per keyframe and ADDS the 2 search_range pairs of keyframe size - search_range - 1 to
+    gl_vec_surf_*: the records accumulated call after call (sliding.KeyframeBatchAssociation: asynchronous runs appended behind the resident set, the
+    frame taken from a sliding-window context's resident scan) are, bit for bit, the records of ONE glio_bassoc_run over the same pairs and poses."""
+    from glio_amd import capi, sliding
+    scans, poses = frames
+    K, sr = len(scans), 2
+    ba = batch.BatchAssociation(K, 4096, 400000)
+    kba = sliding.KeyframeBatchAssociation(ba, search_range=sr)
+    o = synth.default_opts(2, pts=4096, map_pts=64)
+    ctx = capi.Context(o)
+    zero = np.zeros(3, np.float32)
+    for size in range(1, K + 1):
+        k = size - 1
+        if k % 2:                                  # every other keyframe comes from a context's resident scan (ring slot), the rest from the host
+            ctx.slide_window(); ctx.set_scan(1, scans[k])
+            ba.set_frame_from_scan(k, ctx, 1, zero)
+        else:
+            ba.set_frame(k, scans[k])
+        want = sliding.KeyframeBatchAssociation.pairs_of(size, sr)
+        cnt = kba.step(size, poses)
+        assert (want is None) == (len(cnt) == 0)
+    assert len(kba.pair_ci) == 2 * sr * (K - 2 * sr) and ba.total == sum(kba.counts) > 1000
+    got = [a.copy() for a in ba.read(0, ba.total)]
+    ref = batch.BatchAssociation(K, 4096, 400000)
+    for k in range(K):
+        ref.set_frame(k, scans[k])
+    counts, total = ref.run(poses, np.array(kba.pair_ci, np.int32), np.array(kba.pair_cj, np.int32))
+    assert total == ba.total and counts.tolist() == kba.counts
+    for a, b in zip(got, ref.read()):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    # globalFeatureSelectionAdd_Batch on the tail only: earlier keyframes' records stay, each new pair keeps res_num draws (never its last record)
+    ba.reset()
+    ksel = sliding.KeyframeBatchAssociation(ba, search_range=sr, feature_res_num=25, rng=np.random.default_rng(3))
+    for size in range(2 * sr, K + 1):
+        ksel.step(size, poses)
+    assert all(c == 25 for c in ksel.counts) and ba.total == 25 * len(ksel.counts)
+    cp, nc, sc = ba.read(0, ba.total)
+    full_cp = got[0]
+    fs = {r.tobytes() for r in full_cp}
+    assert all(r.tobytes() in fs for r in cp)
+    ctx.close(); ba.close(); ref.close()
