@@ -191,4 +191,188 @@ private:
     AllReduce allreduce_;
 };
 
+// ================================================================================================
+// Batch association from C++ (glio_bassoc_* of the C-ABI): findGlobalCorrespondingSurfFeaturesAdd_Batch / _Batch (Estimator.cpp:3808-3892, 3711-3806),
+// the search-window rule of optimizeBatchWithLandMark (:3009-3017), batchFeatureAssociation (:3413-3432) and the two selection rules (:4057-4116,
+// 3994-4055).  Same rules as glio_amd/batch.py (search_window, pair_list, pair_shard, batch_selection_draws); tests/test_host_cpp.py holds the two
+// hosts to the same records.
+// ================================================================================================
+// first keyframe of the 2 search_range + 1 window searched for keyframe idx: centred in the interior, clamped at the ends of the batch (:3009-3017)
+inline int searchWindow(int idx, int size, int search_range, int start_idx = 0) {
+    if (idx >= search_range + start_idx && idx < size - 1 - search_range) return idx - search_range;
+    if (idx < search_range + start_idx) return start_idx;
+    return size - 2 * search_range - 1;
+}
+struct PairList { std::vector<int32_t> ci, cj; size_t size() const { return ci.size(); } };
+// every (idx, search_idx) pair of a batch of K keyframes, ci-major (the loop of :3004-3076)
+inline PairList pairList(int K, int search_range) {
+    PairList p;
+    for (int idx = 0; idx < K; ++idx) {
+        const int s0 = searchWindow(idx, K, search_range);
+        for (int j = s0; j <= s0 + 2 * search_range; ++j)
+            if (j != idx && j >= 0 && j < K) { p.ci.push_back(idx); p.cj.push_back(j); }
+    }
+    return p;
+}
+// the pairs a rank owns: those whose SOURCE keyframe lies in its keyframe range (the ownership rule of the constraints)
+inline PairList pairShard(const PairList& all, int K, int rank, int world, int band) {
+    const std::pair<int, int> rg = shardRange(K, rank, world, band);
+    PairList p;
+    for (size_t q = 0; q < all.size(); ++q)
+        if (all.ci[q] >= rg.first && all.ci[q] < rg.second) { p.ci.push_back(all.ci[q]); p.cj.push_back(all.cj[q]); }
+    return p;
+}
+// globalFeatureSelectionAdd_Batch keeps, of a pair's `count` records, all when count <= res_num, else the first res_num of a shuffle of 0 .. count - 2
+// (geneRandArrayNoRepeat(0, count - 1, n): n = high - low values, the LAST record is never drawn; random_generator.hpp:79-93).  `rand_below(n)` returns
+// a uniform integer in [0, n): the reference seeds from std::random_device, so the generator is the caller's.  Returns false = keep all.
+template <typename RandBelow>
+inline bool batchSelectionDraws(int64_t count, int res_num, RandBelow&& rand_below, std::vector<int64_t>& out) {
+    out.clear();
+    if (count <= res_num) return false;
+    std::vector<int64_t> idx((size_t)count - 1);
+    for (int64_t i = 0; i < count - 1; ++i) idx[(size_t)i] = i;
+    for (int64_t i = 0; i < res_num && i < count - 1; ++i) {            // partial Fisher-Yates: the first res_num of a uniform shuffle
+        const int64_t j = i + (int64_t)rand_below((uint64_t)(count - 1 - i));
+        std::swap(idx[(size_t)i], idx[(size_t)j]);
+        out.push_back(idx[(size_t)i]);
+    }
+    return true;
+}
+
+class BatchAssociationBackend {
+public:
+    BatchAssociationBackend(int K, int max_points_per_frame, int64_t max_constraints, int device = 0) : K_(K), cap_(max_constraints) {
+        check(glio_bassoc_create(device, K, max_points_per_frame, max_constraints, &h_), "glio_bassoc_create");
+    }
+    ~BatchAssociationBackend() { if (h_) glio_bassoc_destroy(h_); }
+    BatchAssociationBackend(const BatchAssociationBackend&) = delete;
+    BatchAssociationBackend& operator=(const BatchAssociationBackend&) = delete;
+
+    // surf_frames[k]: PointXYZI as 4 floats, keyframe-local (the batch factor applies no LiDAR-IMU extrinsic, quirk Q10: body-frame clouds)
+    void setFrame(int k, const float* xyzi, int n) { check(glio_bassoc_set_frame(h_, k, xyzi, n), "glio_bassoc_set_frame"); }
+    // the same from the scan resident in window slot `slot` of a sliding-window context (device copy, minus the LiDAR offset)
+    void setFrameFromScan(int k, glio_ctx* ctx, int slot, const float lidar_offset[3]) {
+        check(glio_bassoc_set_frame_from_scan(h_, k, ctx, slot, lidar_offset), "glio_bassoc_set_frame_from_scan");
+    }
+    // poses [K][7] = t, q (pose_info_keyframe).  run: the records of `pairs` replace what the object holds; runAppend: they are added behind it
+    std::vector<int64_t> run(const std::vector<double>& poses, const PairList& pairs) { return runImpl(poses, pairs, false); }
+    std::vector<int64_t> runAppend(const std::vector<double>& poses, const PairList& pairs) { return runImpl(poses, pairs, true); }
+    void runAppendAsync(const std::vector<double>& poses, const PairList& pairs) {
+        needPoses(poses);
+        check(glio_bassoc_run_append_async(h_, poses.data(), (int)pairs.size(), pairs.ci.data(), pairs.cj.data()), "glio_bassoc_run_append_async");
+        pending_ = (int)pairs.size();
+    }
+    std::vector<int64_t> finish() {
+        std::vector<int64_t> cnt((size_t)(pending_ > 0 ? pending_ : 1));
+        check(glio_bassoc_finish(h_, cnt.data(), &total_), "glio_bassoc_finish");
+        cnt.resize((size_t)(pending_ > 0 ? pending_ : 0)); pending_ = 0;
+        return cnt;
+    }
+    void reset() { check(glio_bassoc_reset(h_), "glio_bassoc_reset"); total_ = 0; }
+    // forget the records behind `total` (the outer rounds re-search the end keyframes: their regions are rewritten, Estimator.cpp:3018-3030)
+    void truncate(int64_t total) { check(glio_bassoc_select_range(h_, total, 0, nullptr, total_), "glio_bassoc_select_range"); total_ = total; }
+    // keep src (absolute record indices >= first) of the tail [first, total()): globalFeatureSelection*_Batch
+    void selectRange(int64_t first, const std::vector<int64_t>& src) {
+        check(glio_bassoc_select_range(h_, first, (int64_t)src.size(), src.empty() ? nullptr : src.data(), total_), "glio_bassoc_select_range");
+        total_ = first + (int64_t)src.size();
+    }
+    int64_t total() const { return total_; }
+    int64_t capacity() const { return cap_; }
+    void read(int64_t first, int64_t n, float* cp, double* norm_cent, double* score) { check(glio_bassoc_read(h_, first, n, cp, norm_cent, score), "glio_bassoc_read"); }
+    // the device-resident records to a batch stage: pair p owns [offset[p], offset[p] + count[p]) (offset empty: the pairs follow each other from 0)
+    void feed(BatchBackend& stage, const PairList& pairs, const std::vector<int64_t>& count, const std::vector<int64_t>& offset = {}, const std::vector<uint8_t>& changed = {}) {
+        const float* cp; const double* nc; const double* sc;
+        check(glio_bassoc_results_dev(h_, &cp, &nc, &sc), "glio_bassoc_results_dev");
+        check(glio_batch_update_constraints_pairs_at_dev(stage.handle(), (int)pairs.size(), pairs.ci.data(), pairs.cj.data(), count.data(), offset.empty() ? nullptr : offset.data(),
+                                                         cp, nc, sc, changed.empty() ? nullptr : changed.data()), "glio_batch_update_constraints_pairs_at_dev");
+    }
+    // batchFeatureAssociation() (Estimator.cpp:3413-3432): false when the stream is still too short, else the 2 search_range pairs of keyframe size - search_range - 1
+    static bool keyframePairs(int size, int search_range, PairList& out) {
+        out.ci.clear(); out.cj.clear();
+        const int idx = size - search_range - 1;
+        if (size < 2 * search_range || idx < search_range) return false;
+        for (int j = idx - search_range; j <= idx + search_range; ++j) if (j != idx) { out.ci.push_back(idx); out.cj.push_back(j); }
+        return true;
+    }
+    glio_bassoc* handle() { return h_; }
+
+private:
+    void needPoses(const std::vector<double>& poses) const { if (poses.size() != (size_t)K_ * 7) throw std::runtime_error("batch association: poses must be [K][7]"); }
+    std::vector<int64_t> runImpl(const std::vector<double>& poses, const PairList& pairs, bool append) {
+        needPoses(poses);
+        std::vector<int64_t> cnt(pairs.size() ? pairs.size() : 1);
+        check((append ? glio_bassoc_run_append : glio_bassoc_run)(h_, poses.data(), (int)pairs.size(), pairs.ci.data(), pairs.cj.data(), cnt.data(), &total_),
+              append ? "glio_bassoc_run_append" : "glio_bassoc_run");
+        cnt.resize(pairs.size());
+        return cnt;
+    }
+    static void check(int rc, const char* what) {
+        if (rc != GLIO_OK) throw std::runtime_error(std::string(what) + ": " + glio_last_error());
+    }
+    int K_;
+    int64_t cap_, total_ = 0;
+    int pending_ = 0;
+    glio_bassoc* h_ = nullptr;
+};
+
+// The association schedule of optimizeBatchWithLandMark's rounds (Estimator.cpp:3004-3076): the INTERIOR keyframes use the constraints stored when they
+// left the sliding window (gl_vec_surf_*: here associated once, at the poses given to start()), the first / last search_range keyframes are re-searched in
+// EVERY round at the current poses (findGlobalCorrespondingSurfFeatures_Batch, :3018-3030).  One resident association object: its record arrays are laid
+// out [interior | front ends | back ends]; a round truncates them to the interior and appends the two end runs again -- nothing is copied, the stage is
+// told every pair's record range and which pairs changed.  operator() is the `reassociate` hook of BatchBackend::solveRounds.  (The random
+// globalFeatureSelection_Batch draw is left to the caller, as everywhere.)
+class RoundsAssociation {
+public:
+    // `pairs` = this rank's pairs, ci-major (pairList or pairShard); K = keyframes of the batch
+    RoundsAssociation(BatchBackend& stage, BatchAssociationBackend& ba, const PairList& pairs, int K, int search_range) : stage_(stage), ba_(ba) {
+        for (size_t q = 0; q < pairs.size(); ++q) {
+            PairList& dst = pairs.ci[q] < search_range ? front_ : pairs.ci[q] > K - 1 - search_range ? back_ : inner_;
+            dst.ci.push_back(pairs.ci[q]); dst.cj.push_back(pairs.cj[q]);
+        }
+    }
+    void start(const std::vector<double>& poses) {
+        cnt_inner_ = ba_.run(poses, inner_);
+        inner_total_ = ba_.total();
+        ends(poses);
+        feed(false);
+    }
+    void operator()(const std::vector<double>& poses) {
+        ba_.truncate(inner_total_);
+        ends(poses);
+        feed(true);
+        ++runs_;
+    }
+    int64_t constraints() const { return ba_.total(); }
+    int rounds() const { return runs_; }
+
+private:
+    void ends(const std::vector<double>& poses) {
+        cnt_front_ = ba_.runAppend(poses, front_);
+        cnt_back_ = ba_.runAppend(poses, back_);
+    }
+    void feed(bool only_ends) {
+        PairList all;
+        std::vector<int64_t> cnt, off;
+        std::vector<uint8_t> chg;
+        int64_t o_front = inner_total_, o_inner = 0, o_back = inner_total_;
+        for (int64_t c : cnt_front_) o_back += c;
+        const PairList* parts[3] = {&front_, &inner_, &back_};
+        const std::vector<int64_t>* counts[3] = {&cnt_front_, &cnt_inner_, &cnt_back_};
+        int64_t base[3] = {o_front, o_inner, o_back};
+        for (int w = 0; w < 3; ++w)
+            for (size_t q = 0; q < parts[w]->size(); ++q) {
+                all.ci.push_back(parts[w]->ci[q]); all.cj.push_back(parts[w]->cj[q]);
+                cnt.push_back((*counts[w])[q]); off.push_back(base[w]); base[w] += (*counts[w])[q];
+                chg.push_back((uint8_t)(!only_ends || w != 1));
+            }
+        ba_.feed(stage_, all, cnt, off, only_ends ? chg : std::vector<uint8_t>());
+    }
+    BatchBackend& stage_;
+    BatchAssociationBackend& ba_;
+    PairList front_, inner_, back_;
+    std::vector<int64_t> cnt_front_, cnt_inner_, cnt_back_;
+    int64_t inner_total_ = 0;
+    int runs_ = 0;
+};
+
 }  // namespace glio

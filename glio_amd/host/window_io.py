@@ -84,6 +84,22 @@ def write_batch_problem(path, K, band, iterations, poses, ci, cj, cp, nc, score,
                 f.write(bytes(d))
 
 
+def write_batch_assoc_problem(path, K, band, iterations, poses, odo, search_range, frame, dd, clouds, max_points):
+    """The association mode of host_demo_batch.cpp (header word 3 = 2): no constraints, the keyframe clouds instead."""
+    with open(path, "wb") as f:
+        f.write(np.array([K, band, iterations, 2], np.int32).tobytes())
+        f.write(np.array([0], np.int64).tobytes())
+        f.write(np.ascontiguousarray(poses, np.float64).tobytes())
+        f.write(np.ascontiguousarray(odo, np.float64).tobytes())
+        f.write(np.array([search_range, len(dd), max_points, 0], np.int32).tobytes())
+        f.write(bytes(frame))
+        for d in dd:
+            f.write(bytes(d))
+        for c in clouds:
+            c = np.ascontiguousarray(c, np.float32)
+            f.write(np.array([len(c)], np.int32).tobytes()); f.write(c.tobytes())
+
+
 def run_demo_batch(path, iterations=None, env=None):
     cmd = [build_demo_batch(), path] + ([str(iterations)] if iterations is not None else [])
     out = subprocess.run(cmd, capture_output=True, text=True, check=True, env=env).stdout.splitlines()
@@ -93,6 +109,10 @@ def run_demo_batch(path, iterations=None, env=None):
     hist = [float(x) for x in next(ln for ln in out if ln.split()[:1] == ["cost"]).split()[1:]]
     rows = np.array([[float(x) for x in ln.split()[2:]] for ln in out if ln.startswith("kf ")])
     info["raw"] = [ln for ln in out if not ln.startswith("kf ")]
+    for ln in out:
+        if ln.startswith("assoc "):
+            w = ln.split()
+            info["assoc"] = {w[i]: float(w[i + 1]) for i in range(1, len(w) - 1, 2)}
     info["rounds"] = []
     for ln in out:
         if ln.startswith("round "):

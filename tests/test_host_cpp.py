@@ -170,3 +170,41 @@ def test_cpp_keyframe_stream_equals_the_python_driver(tmp_path):
     ctx.close()
     assert got["iterations"] == iters and got["correspondences_kept"] == kept
     assert abs(got["trans_checksum"] - checksum) <= 1e-9 * abs(checksum)
+
+
+@pytest.mark.gpu
+def test_cpp_batch_association_and_rounds_match_python(tmp_path):
+    """host_demo_batch in association mode: glio::BatchAssociationBackend + glio::RoundsAssociation (one resident association object, its arrays laid out
+    [interior | front ends | back ends], the ends truncated and re-searched every round) as the `reassociate` hook of BatchBackend::solveRounds, against the
+    Python driver (batch.RoundsAssociation: three association objects + device copies, batch.solve_batch_rounds): the same constraint count, the same
+    rounds (iterations, termination, costs), the same poses."""
+    from glio_amd import batch, synth
+    from glio_amd import ctypes_types as T
+    K, sr, pts, iters = 12, 2, 3000, 10
+    band = 2 * sr
+    win = synth.make_window(W=K, pts_per_scan=pts, seed=synth.SEED_BASE + 53, perturb=(0.03, 0.2, 0.0), scan_radius=14.0, map_density=1.0)
+    tlb = np.array(win.opts.t_lb, np.float32)
+    clouds = []
+    for s in range(K):
+        c = win.scans[s].copy(); c[:, :3] -= tlb
+        clouds.append(np.ascontiguousarray(c))
+    gt = np.c_[win.gt.trans, win.gt.quat]
+    init = np.c_[win.init.trans, win.init.quat]
+    odo = gt.copy(); odo[:, :3] += np.random.default_rng(53).normal(0, 0.02, (K, 3))
+    dd, frame = batch.make_batch_gnss(gt, seed=53)
+    path = str(tmp_path / "assoc.bin")
+    window_io.write_batch_assoc_problem(path, K, band, iters, init, odo, sr, frame, dd, clouds, 4096)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    info, _, rows = window_io.run_demo_batch(path, iters, env=env)
+    ci, _ = batch.pair_list(K, sr)
+    st = batch.BatchStage(K, band, len(ci) * 4096)
+    ra = batch.RoundsAssociation(st, clouds, sr, 4096)
+    ra.start(init)
+    poses, hist = batch.solve_batch_rounds(st, init, odo, sr, dd, frame, reassociate=ra, opts=T.batch_tr_opts(iters))
+    assert int(info["assoc"]["pairs"]) == len(ci) and int(info["assoc"]["constraints"]) == ra.n_constraints > 10000
+    assert len(info["rounds"]) == 4
+    for a, b in zip(info["rounds"], hist):
+        assert int(a["iterations"]) == b["iterations"] and int(a["termination"]) == b["termination"]
+        assert np.isclose(a["final_cost"], b["final_cost"], rtol=1e-8)      # (the two hosts lay the end regions out at different offsets: other summation order)
+    assert np.abs(rows - poses).max() < 1e-8
+    ra.close(); st.close()
