@@ -601,9 +601,19 @@ def bench_keyframe_stream(local_rank, W, pts, n_keyframes=8, cpu_keyframes=1, se
     for s in range(W - 1):
         ctx.set_scan(s + 1, long.scans[s])          # slots 1..W-1: the first slide moves them to 0..W-2
     ctx.set_prior(None)
+    # batchFeatureAssociation() (Estimator.cpp:3413-3432) ends every call of the function: every keyframe's cloud stays resident in a batch-association object
+    # (body frame), the keyframe search_range back is matched against its 12 neighbours at the solved poses; batch_feature_res_num 25 (config_urban_hk.yaml:102)
+    from glio_amd import batch as _batch, sliding as _sliding
+    total_kf = W + n_keyframes
+    ba = _batch.BatchAssociation(total_kf, pts, (n_keyframes + 2) * 12 * pts, device=local_rank)
+    kba = _sliding.KeyframeBatchAssociation(ba, search_range=6, feature_res_num=25, rng=np.random.default_rng(20260925))
+    kf_poses = np.c_[long.gt.trans, long.gt.quat][:total_kf].copy()
+    for j in range(W - 1):
+        ba.set_frame(j, body(j))
     state = wins[0].init.copy()
-    stages = dict(slide_and_new_scan=0.0, local_map=0.0, associate_enqueue=0.0, factors_while_the_gpu_searches_then_wait=0.0, solve=0.0, marginalize=0.0)
-    per_kf, iters, kept = [], [], []
+    stages = dict(slide_and_new_scan=0.0, local_map=0.0, associate_enqueue=0.0, factors_while_the_gpu_searches_then_wait=0.0, solve=0.0, marginalize=0.0,
+                  batch_feature_association_enqueue_and_wait=0.0)
+    per_kf, iters, kept, bfound = [], [], [], []
     lm_push = 0.0
     cpu = None
     prior_for_cpu = None
@@ -631,23 +641,42 @@ def bench_keyframe_stream(local_rank, W, pts, n_keyframes=8, cpu_keyframes=1, se
         t5 = _t.perf_counter()
         want_cpu = cpu is None and j >= 1 and j >= n_keyframes - cpu_keyframes + 1 and prior_for_cpu is not None
         if want_cpu:
-            cpu = cpu_keyframe(ctx, win, state, prior_for_cpu, poses, sol, summ, counts)
+            pr = _sliding.KeyframeBatchAssociation.pairs_of(new + 1, 6)
+            kp = kf_poses.copy(); kp[j:j + W, :3] = sol.trans; kp[j:j + W, 3:] = sol.quat
+            bp = None if pr is None else ([body(k) for k in range(total_kf)], kp, [pr[0]] * len(pr[1]), pr[1])
+            cpu = cpu_keyframe(ctx, win, state, prior_for_cpu, poses, sol, summ, counts, batch_pairs=bp)
         if j >= n_keyframes - cpu_keyframes and cpu is None:
             prior_for_cpu = ctx.marginalize(sol)     # (read back for the CPU side of the NEXT keyframe; untimed duplicate of the resident result)
+        # updatePose (:2730) + batchFeatureAssociation, enqueued on the association's own stream (it needs only the solved poses), picked up after the marginalization
+        t5c = _t.perf_counter()
+        from glio_amd.sliding import unify_quaternions
+        usol = unify_quaternions(sol.copy())
+        kf_poses[j:j + W, :3] = usol.trans; kf_poses[j:j + W, 3:] = usol.quat
+        ba.set_frame_from_scan(new, ctx, W - 1, tlb)
+        kba.enqueue(new + 1, kf_poses)
+        t5d = _t.perf_counter()
         t6 = _t.perf_counter(); ctx.marginalize_keep(sol)
         t7 = _t.perf_counter()
+        n_before = len(kba.counts)
+        found = kba.finish()
+        t8 = _t.perf_counter()
         if j == 0:
             continue                                 # the first keyframe has no prior and pays every first-touch cost: warm-up
-        for k, v in zip(stages, (t1 - t0, t2 - t1, t3 - t2b, t4 - t3, t5 - t4, t7 - t6)):
+        for k, v in zip(stages, (t1 - t0, t2 - t1, t3 - t2b, t4 - t3, t5 - t4, t7 - t6, (t5d - t5c) + (t8 - t7))):
             stages[k] += v / n_keyframes
-        per_kf.append((t2 - t0) + (t5 - t2b) + (t7 - t6)); iters.append(int(summ.iterations)); kept.append(int(np.sum(counts)))
+        per_kf.append((t2 - t0) + (t5 - t2b) + (t7 - t6) + (t5d - t5c) + (t8 - t7)); iters.append(int(summ.iterations)); kept.append(int(np.sum(counts)))
+        bfound.append(int(np.sum(found)))
+        if cpu is not None and cpu.get("batch_records_found") is not None and "batch_same_count" not in cpu:
+            cpu["batch_same_count"] = bool(cpu["batch_records_found"] == int(np.sum(found))) if want_cpu else None
     total = float(np.mean(per_kf))
     info = {"workload": f"moving stream: {n_keyframes} consecutive keyframes, W = {W}, {pts} points per scan, LiDAR+IMU+GNSS, local map of the last <= 50 keyframes "
                         f"({int(n_map)} points), prior = the previous keyframe's device marginalization",
             "stages_ms": {k: round(v * 1e3, 3) for k, v in stages.items()}, "local_map_push_ms": round(lm_push * 1e3, 3), "cycle_ms": round(total * 1e3, 3), "cycle_ms_min_max": [round(min(per_kf) * 1e3, 3), round(max(per_kf) * 1e3, 3)],
-            "keyframes_per_s": round(1.0 / total, 1), "iterations": iters, "correspondences_kept": kept, "cpu_same_keyframe": cpu}
+            "keyframes_per_s": round(1.0 / total, 1), "iterations": iters, "correspondences_kept": kept, "batch_records_found": bfound,
+            "batch_records_held": int(ba.total), "batch_feature_res_num": 25, "cpu_same_keyframe": cpu}
     if cpu and "ms" in cpu:
         info["speedup_vs_cpu_port"] = round(cpu["ms"] / (total * 1e3), 1)
+    ba.close()
     ctx.close()
     return info
 
@@ -672,12 +701,13 @@ def bench_keyframe_stream_cpp(local_rank, W, pts, py_info, n_keyframes=8, seed=N
     out = min(runs, key=lambda r: r["cycle_ms"])
     out["host"] = "C++17 (g++ -O2), glio_backend.hpp over the C-ABI; stage times by std::chrono inside the program; best of 2 runs of 8 keyframes"
     if py_info and "iterations" in py_info:
-        out["same_iterations_and_correspondences_as_the_python_driver"] = bool(out["iterations"] == py_info["iterations"] and out["correspondences_kept"] == py_info["correspondences_kept"])
+        out["same_iterations_and_correspondences_as_the_python_driver"] = bool(out["iterations"] == py_info["iterations"] and out["correspondences_kept"] == py_info["correspondences_kept"]
+                                                                               and out.get("batch_records_found") == py_info.get("batch_records_found"))
         out["python_cycle_ms"] = py_info.get("cycle_ms")
     return out
 
 
-def cpu_keyframe(ctx, win, state, prior, poses, sol_gpu, summ_gpu, counts_gpu):
+def cpu_keyframe(ctx, win, state, prior, poses, sol_gpu, summ_gpu, counts_gpu, batch_pairs=None):
     """One keyframe of the same function on the CPU oracle: the device-built map read back (both sides search the same map),
     association of the W slots through the grid index, solve, marginalization.  1 thread."""
     import time as _t
@@ -698,8 +728,20 @@ def cpu_keyframe(ctx, win, state, prior, poses, sol_gpu, summ_gpu, counts_gpu):
     t2 = _t.perf_counter()
     prob.marginalize(so)
     t3 = _t.perf_counter()
+    # batchFeatureAssociation of the same keyframe: 12 pair searches (grid index) at the poses the GPU side used; batch_pairs = (clouds, poses [K][7], ci, cj)
+    bfound = None
+    if batch_pairs is not None:
+        clouds, kposes, ci, cj = batch_pairs
+        po.lib().orc_set_assoc_grid(1)
+        try:
+            bfound = sum(len(po.associate_pair(clouds[a], kposes[a], clouds[b], kposes[b])[2]) for a, b in zip(ci, cj))
+        finally:
+            po.lib().orc_set_assoc_grid(0)
+    t4 = _t.perf_counter()
     same = [len(c[2]) for c in corr] == [int(c) for c in counts_gpu]
-    return {"ms": round((t3 - t0) * 1e3, 1), "stages_ms": {"associate_grid_index": round((t1 - t0) * 1e3, 1), "solve": round((t2 - t1) * 1e3, 1), "marginalize": round((t3 - t2) * 1e3, 1)},
+    return {"ms": round((t4 - t0) * 1e3, 1), "stages_ms": {"associate_grid_index": round((t1 - t0) * 1e3, 1), "solve": round((t2 - t1) * 1e3, 1), "marginalize": round((t3 - t2) * 1e3, 1),
+                                                           "batch_feature_association_12_pairs": round((t4 - t3) * 1e3, 1)},
+            "batch_records_found": bfound,
             "cores": 1, "kind": "port", "iterations": int(summ_o.iterations), "iterations_gpu": int(summ_gpu.iterations), "same_correspondence_counts": bool(same),
             "max_trans_diff_vs_gpu_m": float(np.linalg.norm(sol_gpu.trans - so.trans, axis=1).max()),
             "note": "oracle/ = CPU restatement (Ceres-1.14 semantics), not Ceres; map and prior are the device's own (read back), so both sides solve the same keyframe"}

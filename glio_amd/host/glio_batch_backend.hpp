@@ -375,4 +375,53 @@ private:
     int runs_ = 0;
 };
 
+// batchFeatureAssociation() per keyframe (Estimator.cpp:3413-3432; it ENDS every optimizeSlidingWindowWithLandMark, :2733): once the stream holds 2 search_range
+// keyframes, keyframe idx = size - search_range - 1 is matched against its 2 search_range neighbours at the current poses and the records are ADDED to
+// gl_vec_surf_* -- here appended behind what the association object holds; globalFeatureSelectionAdd_Batch (:4057-4116) then keeps batch_feature_res_num
+// records per pair.  enqueue() returns at once (own stream: the searches overlap the marginalization of the same keyframe), finish() waits, selects, books.
+class KeyframeBatchAssociation {
+public:
+    explicit KeyframeBatchAssociation(BatchAssociationBackend& ba, int search_range = 6, int feature_res_num = -1) : ba_(ba), sr_(search_range), res_num_(feature_res_num) {}
+    // poses [K][7] = t, q of every keyframe slot of the association object (pose_info_keyframe); size = keyframes in the stream so far
+    int enqueue(int size, const std::vector<double>& poses) {
+        have_ = BatchAssociationBackend::keyframePairs(size, sr_, cur_);
+        if (!have_) return 0;
+        first_ = ba_.total();
+        ba_.runAppendAsync(poses, cur_);
+        return (int)cur_.size();
+    }
+    // rand_below(n): uniform integer in [0, n) -- the reference seeds from std::random_device, the generator is the caller's.  Returns the pair counts FOUND
+    // (before the selection); `counts` books what was kept.
+    template <typename RandBelow>
+    std::vector<int64_t> finish(RandBelow&& rand_below) {
+        if (!have_) return {};
+        have_ = false;
+        const std::vector<int64_t> found = ba_.finish();
+        std::vector<int64_t> kept = found;
+        if (res_num_ >= 0) {
+            std::vector<int64_t> src, draw;
+            int64_t off = first_;
+            bool any = false;
+            for (size_t p = 0; p < found.size(); ++p) {
+                if (batchSelectionDraws(found[p], res_num_, rand_below, draw)) { any = true; for (int64_t d : draw) src.push_back(off + d); kept[p] = (int64_t)draw.size(); }
+                else for (int64_t d = 0; d < found[p]; ++d) src.push_back(off + d);
+                off += found[p];
+            }
+            if (any) ba_.selectRange(first_, src);
+        }
+        for (size_t p = 0; p < cur_.size(); ++p) { pairs.ci.push_back(cur_.ci[p]); pairs.cj.push_back(cur_.cj[p]); counts.push_back(kept[p]); }
+        return found;
+    }
+    std::vector<int64_t> finish() { return finish([](uint64_t) -> uint64_t { return 0; }); }      // (no selection configured: the generator is never called)
+    PairList pairs;                    // every pair booked so far, in call order = the order of the records
+    std::vector<int64_t> counts;
+
+private:
+    BatchAssociationBackend& ba_;
+    int sr_, res_num_;
+    PairList cur_;
+    int64_t first_ = 0;
+    bool have_ = false;
+};
+
 }  // namespace glio

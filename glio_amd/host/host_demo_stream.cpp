@@ -1,7 +1,9 @@
 // host_demo_stream.cpp -- the MOVING-STREAM keyframe cycle of optimizeSlidingWindowWithLandMark() (Estimator.cpp:2046-2736, called per keyframe from
 // saveKeyFramesAndFactors, :4269) driven from C++ through glio_backend.hpp, and TIMED: slide the window + take the new keyframe's scan, update the
 // 50-keyframe local map on the device, associate all W slots (enqueued), fill the IMU / GNSS factor tables while the GPU searches, solve, marginalize the
-// oldest keyframe and keep the result as the next prior.  Input: a flat binary stream file written by glio_amd/host/window_io.py (write_stream); output:
+// oldest keyframe and keep the result as the next prior, and -- what ends the reference function, :2733 -- batchFeatureAssociation() (:3413-3432): the keyframe
+// search_range back is matched against its 2 search_range neighbours at the solved poses (12 hash builds + 12 pair searches on the device, enqueued
+// right after the solve on the association's own stream so that they overlap the marginalization), globalFeatureSelectionAdd_Batch keeps 25 per pair.  Input: a flat binary stream file written by glio_amd/host/window_io.py (write_stream); output:
 // one JSON line with the per-stage host times -- what bench.py reports as keyframe_pipeline_cpp next to the Python driver's figure.
 // Build: g++ -std=c++17 -O2 host_demo_stream.cpp -I../../include -L../lib -lglio_hip -Wl,-rpath,'$ORIGIN/../lib'
 #include <chrono>
@@ -10,13 +12,16 @@
 #include <cstring>
 #include <vector>
 
+#include <random>
+
 #include "glio_backend.hpp"
+#include "glio_batch_backend.hpp"
 
 template <typename T> static void rd(FILE* f, T* p, size_t n) { if (n && fread(p, sizeof(T), n, f) != n) { fprintf(stderr, "short read\n"); exit(2); } }
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int main(int argc, char** argv) {
-    if (argc < 2) { fprintf(stderr, "usage: host_demo_stream stream.bin [device]\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: host_demo_stream stream.bin [device] [search_range]\n"); return 2; }
     FILE* f = fopen(argv[1], "rb");
     if (!f) { perror("open"); return 2; }
     const int device = argc > 2 ? atoi(argv[2]) : 0;
@@ -53,8 +58,21 @@ int main(int argc, char** argv) {
         }
         for (int s = 0; s < W - 1; ++s) be.setScan(s + 1, scans[s].data(), pts);
         { glio_prior none; memset(&none, 0, sizeof none); be.setMarginalizationPrior(&none); }      // the first window has no prior
-        double st[6] = {0, 0, 0, 0, 0, 0}, cyc = 0, cmin = 1e9, cmax = 0;
-        std::vector<int> iters; std::vector<long> kept;
+        // batchFeatureAssociation: every keyframe of the stream keeps its cloud (body frame) resident; search_range 6, batch_feature_res_num 25 (config_urban_hk.yaml:64,102)
+        const int SR = argc > 3 ? atoi(argv[3]) : 6, RES = hdr[3] > 0 ? hdr[3] : 25;
+        glio::BatchAssociationBackend ba(total_kf, pts, (int64_t)(NK + 2) * 2 * SR * pts, device);
+        glio::KeyframeBatchAssociation kba(ba, SR, RES);
+        std::mt19937_64 rng(20260925);
+        auto rand_below = [&](uint64_t n) -> uint64_t { return std::uniform_int_distribution<uint64_t>(0, n - 1)(rng); };
+        std::vector<double> kf_poses((size_t)total_kf * 7, 0.0);          // pose_info_keyframe: t, q of every keyframe (ground truth until a window solve moves it)
+        for (int j = 0; j < total_kf; ++j) { for (int c = 0; c < 3; ++c) kf_poses[7 * (size_t)j + c] = gtt[3 * (size_t)j + c]; for (int c = 0; c < 4; ++c) kf_poses[7 * (size_t)j + 3 + c] = gtq[4 * (size_t)j + c]; }
+        for (int j = 0; j < W - 1; ++j) {                                 // the clouds of the keyframes already in the window
+            body = scans[j];
+            for (int i = 0; i < pts; ++i) for (int c = 0; c < 3; ++c) body[4 * (size_t)i + c] -= tlb[c];
+            ba.setFrame(j, body.data(), pts);
+        }
+        double st[7] = {0, 0, 0, 0, 0, 0, 0}, cyc = 0, cmin = 1e9, cmax = 0;
+        std::vector<int> iters; std::vector<long> kept; std::vector<long> bfound; std::vector<long> bkept;
         double checksum = 0;
         int map_pts = 0;
         for (int j = 0; j <= NK; ++j) {
@@ -75,24 +93,40 @@ int main(int argc, char** argv) {
             const double t4 = now_s();
             const glio_summary sum = be.solve(&ddt);
             const double t5 = now_s();
+            // updatePose (:2730): the window's solved poses become pose_info_keyframe; then batchFeatureAssociation, enqueued (it needs only the poses)
+            for (int s = 0; s < W; ++s) {
+                const int g = j + s;
+                for (int c = 0; c < 3; ++c) kf_poses[7 * (size_t)g + c] = be.tmpTrans[3 * s + c];
+                for (int c = 0; c < 4; ++c) kf_poses[7 * (size_t)g + 3 + c] = be.tmpQuat[4 * s + c];
+            }
+            ba.setFrameFromScan(nw, be.ctx(), W - 1, tlb);
+            kba.enqueue(nw + 1, kf_poses);
+            const double t5b = now_s();
             be.marginalizeAndKeep(&ddt);
             const double t6 = now_s();
+            const std::vector<int64_t> found = kba.finish(rand_below);
+            const double t7 = now_s();
             if (j == 0) continue;                                        // no prior yet, every first-touch cost: warm-up
-            const double d[6] = {t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5};
+            const double d[7] = {t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5b, (t5b - t5) + (t7 - t6)};
             double c = 0;
-            for (int q = 0; q < 6; ++q) { st[q] += d[q] / NK; c += d[q]; }
+            for (int q = 0; q < 7; ++q) { st[q] += d[q] / NK; c += d[q]; }
+            { long f = 0; for (int64_t v : found) f += (long)v; bfound.push_back(f); bkept.push_back((long)ba.total()); }
             cyc += c / NK; if (c < cmin) cmin = c; if (c > cmax) cmax = c;
             iters.push_back(sum.iterations);
             long kk = 0; for (int32_t v : counts) kk += v; kept.push_back(kk);
             for (double v : be.tmpTrans) checksum += v;
         }
         printf("{\"stages_ms\": {\"slide_and_new_scan\": %.4f, \"local_map\": %.4f, \"associate_enqueue\": %.4f, \"factors_while_the_gpu_searches_then_wait\": %.4f, "
-               "\"solve\": %.4f, \"marginalize\": %.4f}, \"cycle_ms\": %.4f, \"cycle_ms_min_max\": [%.4f, %.4f], \"keyframes_per_s\": %.1f, \"map_points\": %d, \"iterations\": [",
-               st[0] * 1e3, st[1] * 1e3, st[2] * 1e3, st[3] * 1e3, st[4] * 1e3, st[5] * 1e3, cyc * 1e3, cmin * 1e3, cmax * 1e3, 1.0 / cyc, map_pts);
+               "\"solve\": %.4f, \"marginalize\": %.4f, \"batch_feature_association_enqueue_and_wait\": %.4f}, \"cycle_ms\": %.4f, \"cycle_ms_min_max\": [%.4f, %.4f], \"keyframes_per_s\": %.1f, \"map_points\": %d, \"iterations\": [",
+               st[0] * 1e3, st[1] * 1e3, st[2] * 1e3, st[3] * 1e3, st[4] * 1e3, st[5] * 1e3, st[6] * 1e3, cyc * 1e3, cmin * 1e3, cmax * 1e3, 1.0 / cyc, map_pts);
         for (size_t i = 0; i < iters.size(); ++i) printf("%s%d", i ? ", " : "", iters[i]);
         printf("], \"correspondences_kept\": [");
         for (size_t i = 0; i < kept.size(); ++i) printf("%s%ld", i ? ", " : "", kept[i]);
-        printf("], \"trans_checksum\": %.17g}\n", checksum);
+        printf("], \"batch_records_found\": [");
+        for (size_t i = 0; i < bfound.size(); ++i) printf("%s%ld", i ? ", " : "", bfound[i]);
+        printf("], \"batch_records_held\": [");
+        for (size_t i = 0; i < bkept.size(); ++i) printf("%s%ld", i ? ", " : "", bkept[i]);
+        printf("], \"batch_feature_res_num\": %d, \"trans_checksum\": %.17g}\n", RES, checksum);
     } catch (const std::exception& e) {
         fprintf(stderr, "error: %s\n", e.what());
         return 1;

@@ -126,21 +126,21 @@ DEMO_STREAM = os.path.join(HERE, "host_demo_stream")
 
 def build_demo_stream(force=False):
     """The C++ moving-stream keyframe cycle (host_demo_stream.cpp): what bench.py times as keyframe_pipeline_cpp."""
-    src = [os.path.join(HERE, "host_demo_stream.cpp"), os.path.join(HERE, "glio_backend.hpp")] + _ABI_HEADERS
+    src = [os.path.join(HERE, "host_demo_stream.cpp"), os.path.join(HERE, "glio_backend.hpp"), os.path.join(HERE, "glio_batch_backend.hpp")] + _ABI_HEADERS
     if force or not os.path.exists(DEMO_STREAM) or any(os.path.getmtime(s) > os.path.getmtime(DEMO_STREAM) for s in src):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", src[0], "-I" + os.path.join(HERE, "..", "..", "include"),
                                "-L" + os.path.join(HERE, "..", "lib"), "-lglio_hip", "-Wl,-rpath,$ORIGIN/../lib", "-o", DEMO_STREAM])
     return DEMO_STREAM
 
 
-def write_stream(path, long, wins, W, n_keyframes, pts, lm_width=50, leaf=0.4):
+def write_stream(path, long, wins, W, n_keyframes, pts, lm_width=50, leaf=0.4, batch_res_num=0):
     """The moving stream of bench.py's keyframe_stream as a flat file: opts | n_keyframes pts lm_width 0 | leaf tlb[3] | the W + n_keyframes scans |
     ground-truth q [.][4], t [.][3] (the poses the local map is pushed with) | per window j = 0..n_keyframes: n_ddt n_preint n_dd n_dop, init trans quat
     speed_bias rcv_ddt, preints, GNSS frame, DD factors, Doppler factors."""
     opts = wins[0].opts
     with open(path, "wb") as f:
         f.write(bytes(opts))
-        f.write(np.array([n_keyframes, pts, lm_width, 0], np.int32).tobytes())
+        f.write(np.array([n_keyframes, pts, lm_width, batch_res_num], np.int32).tobytes())      # (batch_feature_res_num of the per-keyframe batch association; 0 = the yaml's 25)
         f.write(np.array([leaf] + list(opts.t_lb), np.float32).tobytes())
         for j in range(W + n_keyframes):
             f.write(np.ascontiguousarray(long.scans[j], np.float32).tobytes())
@@ -163,9 +163,9 @@ def write_stream(path, long, wins, W, n_keyframes, pts, lm_width=50, leaf=0.4):
                 f.write(bytes(d))
 
 
-def run_demo_stream(path, device=0, env=None):
+def run_demo_stream(path, device=0, env=None, search_range=6):
     import json
-    r = subprocess.run([build_demo_stream(), path, str(device)], capture_output=True, text=True, env=env)
+    r = subprocess.run([build_demo_stream(), path, str(device), str(search_range)], capture_output=True, text=True, env=env)
     if r.returncode != 0:
         raise RuntimeError("host_demo_stream failed (%d): %s" % (r.returncode, (r.stderr or r.stdout)[-600:]))
     return json.loads(next(ln for ln in r.stdout.splitlines() if ln.startswith("{")))

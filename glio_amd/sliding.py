@@ -178,12 +178,13 @@ class KeyframeBatchAssociation:
         return len(js)
 
     def finish(self):
-        """Waits for the enqueued call, applies the selection, books the pairs.  Returns this call's per-pair counts."""
+        """Waits for the enqueued call, applies the selection, books the pairs (`counts`: what was kept).  Returns the per-pair counts FOUND."""
         if self._enq is None:
             return np.zeros(0, np.int64)
         ci, cj = self._enq
         self._enq = None
         cnt, total = self.ba.finish()
+        found = cnt.copy()
         if self.res_num is not None and self.rng is not None:
             from .batch import batch_selection_draws
             offs = self._first + np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
@@ -197,7 +198,7 @@ class KeyframeBatchAssociation:
                 self.ba.select_range(self._first, src, total)
             cnt = kept
         self.pair_ci += ci.tolist(); self.pair_cj += cj.tolist(); self.counts += [int(c) for c in cnt]
-        return cnt
+        return found
 
     def step(self, size, poses):
         self.enqueue(size, poses)

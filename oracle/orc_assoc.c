@@ -248,12 +248,15 @@ int orc_associate_mt(const glio_opts* o, const float* map, int M, const float* s
 int orc_associate_pair(const float* scan_a, int na, const double qa[4], const double ta[3],
                        const float* scan_b, int nb, const double qb[4], const double tb[3],
                        float* out_cp, double* out_norm_cent, double* out_score, int32_t* out_src) {
-    float* gb = (float*)malloc(sizeof(float) * 3 * (size_t)(nb > 0 ? nb : 1));
+    float* gb = (float*)malloc(sizeof(float) * 4 * (size_t)(nb > 0 ? nb : 1));
     for (int m = 0; m < nb; ++m) {
         double pin[3] = {scan_b[4 * (size_t)m], scan_b[4 * (size_t)m + 1], scan_b[4 * (size_t)m + 2]}, po[3];
         q_rot(qb, pin, po);
-        gb[3 * (size_t)m] = (float)(po[0] + tb[0]); gb[3 * (size_t)m + 1] = (float)(po[1] + tb[1]); gb[3 * (size_t)m + 2] = (float)(po[2] + tb[2]);
+        gb[4 * (size_t)m] = (float)(po[0] + tb[0]); gb[4 * (size_t)m + 1] = (float)(po[1] + tb[1]); gb[4 * (size_t)m + 2] = (float)(po[2] + tb[2]); gb[4 * (size_t)m + 3] = 0.f;
     }
+    /* (bench.py's CPU baseline indexes the search cloud with the grid above: the same records as the scan over every point, see orc_set_assoc_grid) */
+    orc_grid grid;
+    const int use_grid = g_assoc_use_grid && grid_build(&grid, gb, nb, sqrt(1.5));
     int cnt = 0;
     for (int i = 0; i < na; ++i) {
         const float* pl = scan_a + 4 * (size_t)i;
@@ -262,8 +265,9 @@ int orc_associate_pair(const float* scan_a, int na, const double qa[4], const do
         const float px = (float)(pout[0] + ta[0]), py = (float)(pout[1] + ta[1]), pz = (float)(pout[2] + ta[2]);
         float bd[5] = {FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX};
         int bi[5] = {-1, -1, -1, -1, -1};
-        for (int m = 0; m < nb; ++m) {
-            const float* mp = gb + 3 * (size_t)m;
+        if (use_grid) knn5_grid(&grid, gb, px, py, pz, bd, bi);
+        else for (int m = 0; m < nb; ++m) {
+            const float* mp = gb + 4 * (size_t)m;
             const float dx = px - mp[0], dy = py - mp[1], dz = pz - mp[2];
             float d = dx * dx; d = d + dy * dy; d = d + dz * dz;
             if (d < bd[4]) {
@@ -277,7 +281,7 @@ int orc_associate_pair(const float* scan_a, int na, const double qa[4], const do
         double cx = 0, cy = 0, cz = 0;
         for (int k = 0; k < 5; ++k) {
             for (int c = 0; c < 3; ++c) {
-                A[k * 3 + c] = (double)gb[3 * (size_t)bi[k] + c];
+                A[k * 3 + c] = (double)gb[4 * (size_t)bi[k] + c];
                 Al[k * 3 + c] = (double)scan_b[4 * (size_t)bi[k] + c];
             }
             cx += Al[k * 3]; cy += Al[k * 3 + 1]; cz += Al[k * 3 + 2];                /* :3848-3850 */
@@ -307,6 +311,7 @@ int orc_associate_pair(const float* scan_a, int na, const double qa[4], const do
         ++cnt;
     }
     free(gb);
+    if (use_grid) { free(grid.start); free(grid.order); }
     return cnt;
 }
 

@@ -139,7 +139,7 @@ def test_cpp_keyframe_stream_equals_the_python_driver(tmp_path):
     opts.max_map_points = 1 << 16
     path = str(tmp_path / "stream.bin")
     window_io.write_stream(path, long, wins, W, NK, pts)
-    got = window_io.run_demo_stream(path)
+    got = window_io.run_demo_stream(path, search_range=2)
     ctx = capi.Context(opts)
     ctx.localmap_config(50, 0.4, pts)
     tlb = np.array(opts.t_lb, np.float32)
@@ -151,6 +151,15 @@ def test_cpp_keyframe_stream_equals_the_python_driver(tmp_path):
     ctx.set_prior(None)
     iters, kept, checksum = [], [], 0.0
     sol = None
+    # batchFeatureAssociation at the end of every keyframe call (search_range 2 here so that the 8-keyframe stream reaches it; selection 25 per pair)
+    from glio_amd import batch, sliding
+    ba = batch.BatchAssociation(W + NK, pts, (NK + 2) * 4 * pts)
+    kba = sliding.KeyframeBatchAssociation(ba, search_range=2, feature_res_num=25, rng=np.random.default_rng(1))
+    kf_poses = np.c_[long.gt.trans, long.gt.quat][:W + NK].copy()
+    for j in range(W - 1):
+        c = long.scans[j].copy(); c[:, :3] -= tlb
+        ba.set_frame(j, np.ascontiguousarray(c))
+    bfound, bheld = [], []
     for j in range(NK + 1):
         win = wins[j]
         state = win.init.copy()
@@ -164,12 +173,20 @@ def test_cpp_keyframe_stream_equals_the_python_driver(tmp_path):
         ctx.set_imu(win.preints); ctx.set_gnss(win.frame, win.dd, win.dop)
         counts = ctx.associate_window_counts()
         sol, summ = ctx.solve(state)
+        usol = sliding.unify_quaternions(sol.copy())
+        kf_poses[j:j + W, :3] = usol.trans; kf_poses[j:j + W, 3:] = usol.quat
+        ba.set_frame_from_scan(new, ctx, W - 1, tlb)
+        kba.enqueue(new + 1, kf_poses)
         ctx.marginalize_keep(sol)
+        found = kba.finish()
         if j > 0:
             iters.append(int(summ.iterations)); kept.append(int(np.sum(counts))); checksum += float(np.sum(sol.trans))
-    ctx.close()
+            bfound.append(int(np.sum(found))); bheld.append(int(ba.total))
+    ctx.close(); ba.close()
     assert got["iterations"] == iters and got["correspondences_kept"] == kept
     assert abs(got["trans_checksum"] - checksum) <= 1e-9 * abs(checksum)
+    # the pair searches find the same records in both hosts (the 25 kept per pair are each host's own random draws: same counts)
+    assert got["batch_records_found"] == bfound and sum(bfound) > 4 * 1000 and got["batch_records_held"] == bheld and bheld[-1] == 25 * len(kba.counts)
 
 
 @pytest.mark.gpu
