@@ -326,7 +326,7 @@ def batch_selection_draws(count, res_num, rng, ends=False, rand_set_num=400):
     if not ends:
         if count <= res_num:
             return None
-        return rng.permutation(count - 1)[:res_num].astype(np.int64)
+        return rng.choice(count - 1, size=res_num, replace=False).astype(np.int64)      # (the first res_num of a uniform shuffle, without shuffling 60 000 indices)
     if count - 1 < res_num or count < 50:
         return "return"
     rs = rand_set_num
@@ -367,6 +367,11 @@ class BatchAssociation:
     def set_frame(self, k, scan):
         scan = np.ascontiguousarray(scan, np.float32)
         capi._check(capi.load().glio_bassoc_set_frame(self._h, k, T.fptr(scan) if len(scan) else None, len(scan)))
+
+    def set_frame_strided(self, k, points, ioff):
+        """surf_frames[k] from records of points.dtype.itemsize bytes (capi.PCL_XYZI: 32, intensity at 16)"""
+        pts = np.ascontiguousarray(points)
+        capi._check(capi.load().glio_bassoc_set_frame_strided(self._h, k, pts.ctypes.data_as(C.c_void_p) if len(pts) else None, len(pts), pts.dtype.itemsize, ioff))
 
     def run(self, poses, pair_ci, pair_cj):
         poses = np.ascontiguousarray(poses, np.float64)

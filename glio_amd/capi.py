@@ -52,6 +52,19 @@ def device_count():
     return load().glio_device_count()
 
 
+# pcl::PointXYZI as numpy sees it (GLIO/include/utils/common.h: PointType): 32-byte records, x y z at 0, intensity at byte 16
+PCL_XYZI = np.dtype({"names": ["x", "y", "z", "intensity"], "formats": ["<f4", "<f4", "<f4", "<f4"], "offsets": [0, 4, 8, 16], "itemsize": 32})
+PCL_XYZI_INTENSITY_OFFSET = 16
+
+
+def to_pcl_xyzi(xyzi):
+    """[n][4] float32 -> the 32-byte records a pcl::PointCloud<pcl::PointXYZI> holds (padding filled with garbage on purpose: it must not matter)"""
+    xyzi = np.asarray(xyzi, np.float32)
+    out = np.frombuffer(np.random.default_rng(7).integers(0, 255, len(xyzi) * 32, dtype=np.uint8).tobytes(), dtype=PCL_XYZI).copy()
+    out["x"], out["y"], out["z"], out["intensity"] = xyzi[:, 0], xyzi[:, 1], xyzi[:, 2], xyzi[:, 3]
+    return out
+
+
 class Context:
     """One glio_ctx = the device-resident state of one sliding window (one HIP stream)."""
 
@@ -79,6 +92,25 @@ class Context:
     # ---- uploads
     def set_map(self, map_pts):
         _check(load().glio_set_map(self._h, T.fptr(map_pts), len(map_pts)))
+
+    # ---- strided point input: clouds as records of `stride` bytes (x y z floats at 0, intensity float at `ioff`); pcl::PointXYZI = PCL_XYZI
+    @staticmethod
+    def _raw(points):
+        pts = np.ascontiguousarray(points)
+        return pts, pts.ctypes.data_as(C.c_void_p), len(pts), pts.dtype.itemsize
+
+    def set_map_strided(self, points, ioff):
+        pts, ptr, n, stride = self._raw(points)
+        _check(load().glio_set_map_strided(self._h, ptr, n, stride, ioff))
+
+    def set_scan_strided(self, slot, points, ioff):
+        pts, ptr, n, stride = self._raw(points)
+        _check(load().glio_set_scan_strided(self._h, slot, ptr, n, stride, ioff))
+
+    def localmap_push_strided(self, points, ioff, q, t):
+        pts, ptr, n, stride = self._raw(points)
+        q = np.ascontiguousarray(q, float); t = np.ascontiguousarray(t, float)
+        _check(load().glio_localmap_push_strided(self._h, ptr if n else None, n, stride, ioff, T.dptr(q), T.dptr(t)))
 
     # ---- device-resident local map
     def localmap_config(self, width, leaf, max_points_per_keyframe):

@@ -1750,10 +1750,10 @@ static void enqueue_build(glio_ctx* c, int n) {
     hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, c->stream, w->d_map_raw, n, w->d_pt_slot, w->d_pt_rank, w->d_cnt8, w->d_ent, c->d_map_sorted);
 }
 
-int glio_assoc_build_map(glio_ctx* c, const float* map_xyzi, int n) {
+int glio_assoc_build_map(glio_ctx* c, const void* map_points, int n, int stride, int ioff) {
     AssocWork* w = c->assoc;
     if (!w) return GLIO_E_STATE;
-    if (n > 0) GLIO_HIP_CHECK(hipMemcpyAsync(w->d_map_raw, map_xyzi, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    { const int ru = glio_upload_points(c->stream, &c->raw_stage, map_points, n, stride, ioff, w->d_map_raw); if (ru != GLIO_OK) return ru; }
     enqueue_build(c, n);
     GLIO_HIP_CHECK(hipGetLastError());
     GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -1994,6 +1994,7 @@ struct glio_bassoc {
     long long* h_pair_off;          // pinned
     long long* h_tail;              // pinned [2]: running total, overflow flag of the last run
     double* h_poses; int32_t* h_pairs; FrameDesc* h_fd;      // pinned staging of a run's inputs ([K][7], [2][max_pairs], [K]): the asynchronous run returns before they are read
+    GlioRawStage raw_stage;         // staging of strided clouds (glio_bassoc_set_frame_strided)
     int pending_pairs;              // pairs of an asynchronous run whose counts were not picked up yet (-1: none)
     double* d_poses;                // [K][7]
     // feature selection scratch (grow-only): the gathered records and their source indices
@@ -2201,16 +2202,19 @@ void glio_bassoc_destroy(glio_bassoc* b) {
     if (b->h_tail) hipHostFree(b->h_tail);
     if (b->h_poses) hipHostFree(b->h_poses);
     if (b->h_fd) hipHostFree(b->h_fd);
+    if (b->raw_stage.d) hipFree(b->raw_stage.d);
     delete[] b->h_n; delete[] b->frames;
     hipStreamDestroy(b->stream);
     delete b;
 }
 
-int glio_bassoc_set_frame(glio_bassoc* b, int k, const float* scan_xyzi, int n) {
-    if (!b || k < 0 || k >= b->K || n < 0 || n > b->cap || (n > 0 && !scan_xyzi)) { glio_set_error("bad keyframe cloud (k %d, n %d)", k, n); return GLIO_E_ARG; }
+int glio_bassoc_set_frame(glio_bassoc* b, int k, const float* scan_xyzi, int n) { return glio_bassoc_set_frame_strided(b, k, scan_xyzi, n, 16, 12); }
+int glio_bassoc_set_frame_strided(glio_bassoc* b, int k, const void* scan, int n, int stride_bytes, int intensity_offset) {
+    if (!b || k < 0 || k >= b->K || n < 0 || n > b->cap || (n > 0 && !scan)) { glio_set_error("bad keyframe cloud (k %d, n %d)", k, n); return GLIO_E_ARG; }
+    if (!glio_point_layout_ok(stride_bytes, intensity_offset)) { glio_set_error("bad point layout (stride %d, intensity at %d)", stride_bytes, intensity_offset); return GLIO_E_ARG; }
     BA_CHECK(hipSetDevice(b->device));
     { const int rf = glio_bassoc_finish(b, nullptr, nullptr); if (rf != GLIO_OK) return rf; }      // (an asynchronous run may still read the clouds)
-    if (n > 0) BA_CHECK(hipMemcpyAsync(b->d_local + (size_t)k * b->cap, scan_xyzi, (size_t)n * 16, hipMemcpyHostToDevice, b->stream));
+    { const int ru = glio_upload_points(b->stream, &b->raw_stage, scan, n, stride_bytes, intensity_offset, b->d_local + (size_t)k * b->cap); if (ru != GLIO_OK) return ru; }
     enqueue_presort(b->stream, b->kb, b->d_local + (size_t)k * b->cap, n, b->d_local_ps + (size_t)k * b->cap);
     BA_CHECK(hipGetLastError());
     BA_CHECK(hipStreamSynchronize(b->stream));

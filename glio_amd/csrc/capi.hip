@@ -244,6 +244,7 @@ void glio_destroy(glio_ctx* c) {
     if (c->h_result) hipHostFree(c->h_result);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->d_stage) hipFree(c->d_stage);
+    if (c->raw_stage.d) { hipFree(c->raw_stage.d); c->raw_stage.d = nullptr; c->raw_stage.cap = 0; }
     if (c->h_chain_tabs) hipHostFree(c->h_chain_tabs);
     free(c->h_groups); free(c->h_prior_index);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -308,16 +309,46 @@ int glio_get_correspondences(glio_ctx* c, int slot, float* pts, float* planes, d
     return GLIO_OK;
 }
 
-int glio_set_map(glio_ctx* c, const float* map_xyzi, int n) {
-    GLIO_TRACE("K1 glio_set_map (voxel hash build)");
-    if (!c || !map_xyzi || n < 0 || n > c->opts.max_map_points) { glio_set_error("bad map size"); return GLIO_E_ARG; }
-    GLIO_HIP_CHECK(hipSetDevice(c->device));
-    return glio_assoc_build_map(c, map_xyzi, n);
+// ---- strided point input: the clouds as the caller holds them (pcl::PointCloud<pcl::PointXYZI>::points.data(): 32 B records, intensity at byte 16,
+// GLIO/include/utils/common.h: PointType) -- one upload of the raw records + an unpack kernel, no host-side packing pass (Estimator.cpp:3529-3631 hands such
+// clouds around)
+__global__ void k_unpack_points(const unsigned char* __restrict__ raw, const int n, const int stride, const int ioff, float4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned char* r = raw + (size_t)i * stride;
+    const float* p = reinterpret_cast<const float*>(r);
+    out[i] = make_float4(p[0], p[1], p[2], *reinterpret_cast<const float*>(r + ioff));
 }
-int glio_set_scan(glio_ctx* c, int slot, const float* scan, int n) {
-    if (!c || slot < 0 || slot >= c->W || n < 0 || n > c->cap) { glio_set_error("bad slot / scan size"); return GLIO_E_ARG; }
+int glio_point_layout_ok(int stride, int ioff) { return stride >= 16 && (stride & 3) == 0 && (ioff & 3) == 0 && ioff >= 12 && ioff + 4 <= stride; }
+int glio_upload_points(hipStream_t stream, GlioRawStage* st, const void* host, int n, int stride, int ioff, float4* d_out) {
+    if (n <= 0) return GLIO_OK;
+    if (stride == 16 && ioff == 12) { GLIO_HIP_CHECK(hipMemcpyAsync(d_out, host, (size_t)n * 16, hipMemcpyHostToDevice, stream)); return GLIO_OK; }
+    const size_t bytes = (size_t)n * stride;
+    if (bytes > st->cap) {
+        GLIO_HIP_CHECK(hipStreamSynchronize(stream));               // (an earlier unpack may still read the old buffer)
+        if (st->d) hipFree(st->d);
+        st->d = nullptr; st->cap = 0;
+        GLIO_HIP_CHECK(hipMalloc(&st->d, bytes + bytes / 4));
+        st->cap = bytes + bytes / 4;
+    }
+    GLIO_HIP_CHECK(hipMemcpyAsync(st->d, host, bytes, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_unpack_points, dim3((n + 255) / 256), dim3(256), 0, stream, static_cast<const unsigned char*>(st->d), n, stride, ioff, d_out);
+    return GLIO_OK;
+}
+int glio_set_map_strided(glio_ctx* c, const void* map_points, int n, int stride_bytes, int intensity_offset) {
+    GLIO_TRACE("K1 glio_set_map (voxel hash build)");
+    if (!c || !map_points || n < 0 || n > c->opts.max_map_points) { glio_set_error("bad map size"); return GLIO_E_ARG; }
+    if (!glio_point_layout_ok(stride_bytes, intensity_offset)) { glio_set_error("bad point layout (stride %d, intensity at %d)", stride_bytes, intensity_offset); return GLIO_E_ARG; }
     GLIO_HIP_CHECK(hipSetDevice(c->device));
-    if (n > 0) GLIO_HIP_CHECK(hipMemcpyAsync(c->d_scan + (size_t)glio_scan_row(c, slot) * c->cap, scan, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    return glio_assoc_build_map(c, map_points, n, stride_bytes, intensity_offset);
+}
+int glio_set_map(glio_ctx* c, const float* map_xyzi, int n) { return glio_set_map_strided(c, map_xyzi, n, 16, 12); }
+int glio_set_scan(glio_ctx* c, int slot, const float* scan, int n) { return glio_set_scan_strided(c, slot, scan, n, 16, 12); }
+int glio_set_scan_strided(glio_ctx* c, int slot, const void* scan, int n, int stride_bytes, int intensity_offset) {
+    if (!c || slot < 0 || slot >= c->W || n < 0 || n > c->cap || (n > 0 && !scan)) { glio_set_error("bad slot / scan size"); return GLIO_E_ARG; }
+    if (!glio_point_layout_ok(stride_bytes, intensity_offset)) { glio_set_error("bad point layout (stride %d, intensity at %d)", stride_bytes, intensity_offset); return GLIO_E_ARG; }
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    { const int ru = glio_upload_points(c->stream, &c->raw_stage, scan, n, stride_bytes, intensity_offset, c->d_scan + (size_t)glio_scan_row(c, slot) * c->cap); if (ru != GLIO_OK) return ru; }
     glio_assoc_scan_uploaded(c, slot, n);
     GLIO_HIP_CHECK(hipGetLastError());
     GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));

@@ -147,7 +147,15 @@ struct ArrowDev {
 #define GLIO_CS_SOURCES 5
 struct ChainKf { short e0, e1, k0, k1, o0, o1, kp, pad_; };   // per keyframe: IMU edges, GNSS groups (+ whether i is their slot_a), group of (i, i+1)
 
+// A host cloud whose points are records of `stride` bytes: x, y, z as three floats at offset 0, the intensity as a float at `ioff` (pcl::PointXYZI: 32 / 16).
+// The raw records are uploaded in ONE copy into a grow-only staging buffer and unpacked to float4 on the device (glio_upload_points, capi.hip).
+struct GlioRawStage { void* d; size_t cap; };
+extern "C" {       // (defined inside capi.hip's extern "C" block; internal: not part of include/glio_hip.h)
+int glio_point_layout_ok(int stride, int ioff);
+int glio_upload_points(hipStream_t stream, GlioRawStage* st, const void* host, int n, int stride, int ioff, float4* d_out);
+}
 struct glio_ctx {
+    GlioRawStage raw_stage;       // staging of strided point input (glio_set_scan_strided, glio_set_map_strided, glio_localmap_push_strided)
     std::chrono::steady_clock::time_point solve_t0;   // start of the solve in flight (max_solver_time_s is watched in the enqueue and in the wait loop)
     glio_opts opts;
     int device;
@@ -424,7 +432,7 @@ int glio_assoc_create(glio_ctx* c);
 // the resident scan of a slot changed (uploaded / moved by the slide): keep the presorted copy the tiled search reads in step
 void glio_assoc_scan_uploaded(glio_ctx* c, int slot, int n);
 void glio_assoc_destroy(glio_ctx* c);
-int glio_assoc_build_map(glio_ctx* c, const float* map_xyzi, int n);
+int glio_assoc_build_map(glio_ctx* c, const void* map_points, int n, int stride, int ioff);
 int glio_assoc_run(glio_ctx* c, int slot, const double q[4], const double t[3], int* out_count);
 void glio_assoc_time_hooks(glio_ctx* c, int which, int reps, float* ms);
 

@@ -369,10 +369,12 @@ int glio_localmap_config(glio_ctx* c, int width, float leaf, int max_points_per_
     return GLIO_OK;
 }
 
-int glio_localmap_push(glio_ctx* c, const float* cloud_xyzi, int n, const double q[4], const double t[3]) {
+int glio_localmap_push(glio_ctx* c, const float* cloud_xyzi, int n, const double q[4], const double t[3]) { return glio_localmap_push_strided(c, cloud_xyzi, n, 16, 12, q, t); }
+int glio_localmap_push_strided(glio_ctx* c, const void* cloud_xyzi, int n, int stride_bytes, int intensity_offset, const double q[4], const double t[3]) {
     if (!c || !c->localmap) { glio_set_error("glio_localmap_config first"); return GLIO_E_STATE; }
     LocalMap* m = c->localmap;
     if (n < 0 || n > m->cap || (n > 0 && !cloud_xyzi) || !q || !t) return GLIO_E_ARG;
+    if (!glio_point_layout_ok(stride_bytes, intensity_offset)) { glio_set_error("bad point layout (stride %d, intensity at %d)", stride_bytes, intensity_offset); return GLIO_E_ARG; }
     LM_CHECK(hipSetDevice(c->device));
     const float inv_leaf = 1.0f / m->leaf;
     int slot;
@@ -387,7 +389,7 @@ int glio_localmap_push(glio_ctx* c, const float* cloud_xyzi, int n, const double
     hipLaunchKernelGGL(k_lm_bbox_init, dim3(1), dim3(64), 0, c->stream, m->d_slot_bbox + 6 * slot);
     if (n > 0) {
         // stage the raw scan in the destination itself, transform in place, then add it to the voxel table
-        LM_CHECK(hipMemcpyAsync(dst, cloud_xyzi, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+        { const int ru = glio_upload_points(c->stream, &c->raw_stage, cloud_xyzi, n, stride_bytes, intensity_offset, dst); if (ru != GLIO_OK) return ru; }
         hipLaunchKernelGGL(k_lm_transform, dim3((n + 255) / 256), dim3(256), 0, c->stream, dst, n, q[0], q[1], q[2], q[3], t[0], t[1], t[2], dst);
         hipLaunchKernelGGL(k_lm_bbox, dim3(std::min(64, (n + 1023) / 1024)), dim3(1024), 0, c->stream, dst, n, m->d_slot_bbox + 6 * slot);
         hipLaunchKernelGGL(k_lm_accumulate, dim3((n + 255) / 256), dim3(256), 0, c->stream, dst, n, inv_leaf, +1, m->d_keys, m->d_sum, m->d_cnt, m->table_cap, m->d_nkeys);

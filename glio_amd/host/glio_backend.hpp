@@ -156,6 +156,13 @@ inline void writeBackState(int W, const double* tmpTrans, const double* tmpQuat,
     }
 }
 
+// how the caller's clouds lie in memory: records of stride_bytes, x y z as floats at offset 0, the intensity as a float at intensity_offset
+struct PointLayout {
+    int stride_bytes, intensity_offset;
+    static PointLayout packed() { return {16, 12}; }
+    static PointLayout pclXYZI() { return {32, 16}; }        // pcl::PointXYZI, the reference's PointType (GLIO/include/utils/common.h)
+};
+
 class SlidingWindowBackend {
 public:
     explicit SlidingWindowBackend(const glio_opts& opts, int device = 0) : opts_(opts), W_(opts.window) {
@@ -172,6 +179,8 @@ public:
 
     // Estimator.cpp:2056  kd_tree_surf_local_map->setInputCloud(surf_local_map_ds)
     void setLocalMap(const float* xyzi, int n) { check(glio_set_map(ctx_, xyzi, n), "glio_set_map"); map_points_ = n; }
+    // the same straight from cloud->points.data() of a pcl::PointCloud<pcl::PointXYZI> (32-byte records, intensity at byte 16): PointLayout::pclXYZI()
+    void setLocalMap(const void* points, int n, PointLayout l) { check(glio_set_map_strided(ctx_, points, n, l.stride_bytes, l.intensity_offset), "glio_set_map_strided"); map_points_ = n; }
     // `if (surf_local_map_ds->points.size() > 50)` (Estimator.cpp:2221,2244): with a smaller map the reference adds NO LiDAR factor
     // for the keyframe ("Not enough feature points from the map")
     bool mapLargeEnough() const { return map_points_ > 50; }
@@ -234,6 +243,7 @@ public:
     // surf_frames bookkeeping of Estimator.cpp:4240-4300: slot s <- slot s+1 (scans and their correspondences)
     void slideWindow() { check(glio_slide_window(ctx_), "glio_slide_window"); }
     void setScan(int slot, const float* scan_xyzi, int n) { check(glio_set_scan(ctx_, slot, scan_xyzi, n), "glio_set_scan"); }
+    void setScan(int slot, const void* points, int n, PointLayout l) { check(glio_set_scan_strided(ctx_, slot, points, n, l.stride_bytes, l.intensity_offset), "glio_set_scan_strided"); }
     // the loop over idx of Estimator.cpp:2216-2222 for the whole window, with the poses held in tmpTrans / tmpQuat
     std::vector<int32_t> findCorrespondingSurfFeaturesWindow() {
         std::vector<double> q2(4 * W_), t2(3 * W_);
@@ -283,6 +293,13 @@ public:
     // (body frame) with its pose, rebuild the voxel-averaged ring map and its search structure; returns the map size
     void configureLocalMap(int width, float leaf, int max_points_per_keyframe) {
         check(glio_localmap_config(ctx_, width, leaf, max_points_per_keyframe), "glio_localmap_config");
+    }
+    int pushKeyframeAndBuildLocalMap(const void* points, int n, PointLayout l, const double q[4], const double t[3]) {
+        check(glio_localmap_push_strided(ctx_, points, n, l.stride_bytes, l.intensity_offset, q, t), "glio_localmap_push_strided");
+        int pts = 0;
+        check(glio_localmap_build(ctx_, &pts), "glio_localmap_build");
+        map_points_ = pts;
+        return pts;
     }
     int pushKeyframeAndBuildLocalMap(const float* cloud_xyzi, int n, const double q[4], const double t[3]) {
         check(glio_localmap_push(ctx_, cloud_xyzi, n, q, t), "glio_localmap_push");

@@ -250,6 +250,10 @@ public:
 
     // surf_frames[k]: PointXYZI as 4 floats, keyframe-local (the batch factor applies no LiDAR-IMU extrinsic, quirk Q10: body-frame clouds)
     void setFrame(int k, const float* xyzi, int n) { check(glio_bassoc_set_frame(h_, k, xyzi, n), "glio_bassoc_set_frame"); }
+    // the same straight from a pcl::PointCloud<pcl::PointXYZI>'s points.data(): stride 32, intensity at byte 16
+    void setFrame(int k, const void* points, int n, int stride_bytes, int intensity_offset) {
+        check(glio_bassoc_set_frame_strided(h_, k, points, n, stride_bytes, intensity_offset), "glio_bassoc_set_frame_strided");
+    }
     // the same from the scan resident in window slot `slot` of a sliding-window context (device copy, minus the LiDAR offset)
     void setFrameFromScan(int k, glio_ctx* ctx, int slot, const float lidar_offset[3]) {
         check(glio_bassoc_set_frame_from_scan(h_, k, ctx, slot, lidar_offset), "glio_bassoc_set_frame_from_scan");

@@ -52,6 +52,12 @@ int glio_synchronize(glio_ctx* ctx);
 /* ---- K1: local map.  Replaces kd_tree_surf_local_map->setInputCloud(surf_local_map_ds)
  * (Estimator.cpp:2056).  pts = PointXYZI[n] as 4 floats; builds the voxel hash on device. */
 int glio_set_map(glio_ctx* ctx, const float* map_xyzi, int n);
+/* ---- strided point input.  The reference hands its clouds around as pcl::PointCloud<PointType>, PointType = pcl::PointXYZI (GLIO/include/utils/common.h):
+ * records of 32 bytes, x y z as floats at bytes 0-11, the intensity at byte 16.  Every cloud-taking entry point has a *_strided twin that takes
+ * cloud->points.data() as it is: stride_bytes per record (>= 16, a multiple of 4), x y z at offset 0, intensity_offset in [12, stride - 4].  The raw
+ * records travel in ONE copy and are unpacked on the device -- no packing pass over the scan / the map on the host.  (stride 16, offset 12 = the packed
+ * float4 form the plain entry points take.)  Replaces the cloud hand-over of Estimator.cpp:2056 (map), :2198-2248 (scans), :3529-3631 (local map). */
+int glio_set_map_strided(glio_ctx* ctx, const void* map_points, int n, int stride_bytes, int intensity_offset);
 
 /* ---- device-resident local map.  Replaces buildLocalMapWithLandMark + downSampleCloud + setInputCloud
  * (Estimator.cpp:3529-3631, 2056) by a ring of the last `width` keyframe clouds kept on the device in the map frame:
@@ -60,6 +66,7 @@ int glio_set_map(glio_ctx* ctx, const float* map_xyzi, int n);
  *   width = local_map_width (yaml: 50); q,t = q_po * q_bl, q_po * t_bl + t_po (:3569-3570). */
 int glio_localmap_config(glio_ctx* ctx, int width, float leaf, int max_points_per_keyframe);
 int glio_localmap_push(glio_ctx* ctx, const float* cloud_xyzi, int n, const double q[4], const double t[3]);
+int glio_localmap_push_strided(glio_ctx* ctx, const void* cloud_points, int n, int stride_bytes, int intensity_offset, const double q[4], const double t[3]);
 /* the same from the scan glio_set_scan already put into window slot `scan_slot` (LiDAR frame; body point = scan point - lidar_offset in float):
  * the newest keyframe's cloud crosses PCIe once for both the association and the map */
 int glio_localmap_push_scan(glio_ctx* ctx, int scan_slot, const float lidar_offset[3], const double q[4], const double t[3]);
@@ -79,6 +86,7 @@ int glio_associate(glio_ctx* ctx, int slot, const float* scan_xyzi, int n, const
                    const double t[3], int* out_count);
 /* Same, for a scan already resident from a previous glio_associate/glio_set_scan (re-association). */
 int glio_set_scan(glio_ctx* ctx, int slot, const float* scan_xyzi, int n);
+int glio_set_scan_strided(glio_ctx* ctx, int slot, const void* scan_points, int n, int stride_bytes, int intensity_offset);
 int glio_associate_resident(glio_ctx* ctx, int slot, const double q[4], const double t[3], int* out_count);
 /* Slide the window by one keyframe: the resident scan of slot s+1 becomes that of slot s (device-to-device); slot W-1 is
  * free for the new keyframe's glio_set_scan.  (surf_frames / keyframe_idx bookkeeping of Estimator.cpp:4240-4300.) */
@@ -296,6 +304,7 @@ int glio_bassoc_create(int device, int K, int max_points_per_frame, int64_t max_
 void glio_bassoc_destroy(glio_bassoc* b);
 /* surf_frames[k]: PointXYZI[n] as 4 floats, keyframe-local; stays resident */
 int glio_bassoc_set_frame(glio_bassoc* b, int k, const float* scan_xyzi, int n);
+int glio_bassoc_set_frame_strided(glio_bassoc* b, int k, const void* scan_points, int n, int stride_bytes, int intensity_offset);
 int glio_bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj,
                     int64_t* pair_count_out, int64_t* total_out);
 /* batchFeatureAssociation() (Estimator.cpp:3413-3432), the call that ENDS every optimizeSlidingWindowWithLandMark (:2733): the keyframe
