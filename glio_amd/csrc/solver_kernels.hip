@@ -3893,6 +3893,9 @@ int glio_launch_marginalize(glio_ctx* c, int imu_edge0, double** J0_dev, double*
     a.W = W; a.pos = pos; a.np = c->prior_n; a.has_prior = c->prior_n > 0; a.imu_edge0 = imu_edge0;
     a.lidar_blocks = c->d_lidar_blocks; a.imu_blocks = c->d_imu_blocks; a.pH = c->d_prior_H; a.pg = c->d_prior_g; a.prior_index = c->d_prior_index;
     a.A = c->d_H[0]; a.b = c->d_g[0];
+    // (both dense H buffers are overwritten below -- the pos x pos A in d_H[0], J0 in d_H[1]: whatever a band-only assembly assumed about zeros outside
+    //  the band no longer holds, for EVERY caller: glio_marginalize, glio_marginalize_keep, the timing hook)
+    c->h_band_clean = 0;
     hipLaunchKernelGGL(k_marg_assemble, dim3(pos + 1), dim3(256), 0, c->stream, a);
     int* d_ok = reinterpret_cast<int*>(c->d_vec + 9 * (size_t)c->n_max);
     double* Twork = c->d_vec;                    // n x 15 <= 10 n_max doubles? n*15 <= 15W*... checked by the caller

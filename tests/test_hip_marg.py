@@ -148,3 +148,44 @@ def test_marginalize_keep_equals_roundtrip(hip, small_window, small_corr):
     (Ha, ga, ca, (sa, ma)), (Hb, gb, cb, (sb, mb)) = res
     assert np.array_equal(Ha, Hb) and np.array_equal(ga, gb) and ca == cb
     assert ma.iterations == mb.iterations and np.array_equal(sa.trans, sb.trans)
+
+
+def test_marginalize_then_band_only_solve_with_dense_fallback(hip):
+    """Advisor finding (round 4): the long-window chain path (chain kind 3: band-only assembly, k_chain_solve<true>) keeps both dense H buffers zero
+    outside the block-tridiagonal band and remembers that in h_band_clean; glio_marginalize overwrites those buffers (its pos x pos A, its J0).  A
+    solve AFTER a plain glio_marginalize -- prior untouched, so nothing else resets the flag -- whose chain kernel breaks down (debug mode 2: every step)
+    falls back to the dense factorisation of the whole matrix: it must see zeros off the band, i.e. give the iterates of the dense solver."""
+    W = 50
+    long = synth.make_window(W=W + 1, pts_per_scan=1024, seed=synth.SEED_BASE + 33)
+    first = synth.sub_window(long, 0, W)
+    win = synth.sub_window(long, 1, W)
+    corr0, corr = synth.analytic_correspondences(first), synth.analytic_correspondences(win)
+    st0 = first.init.copy(); st0.n_ddt = 0
+    st = win.init.copy(); st.n_ddt = 0
+    lib = hip.load()
+
+    def with_chain_prior(mode):
+        """a context holding window 1 with the device marginalization of window 0 as its prior (block diagonal by keyframe: the chain path applies)"""
+        ctx = hip.Context(win.opts)
+        lib.glio_debug_set_solver(ctx._h, mode)
+        ctx.load_window(first, corr0, use_gnss=False)
+        s, _ = ctx.solve(st0)
+        ctx.marginalize_keep(s)
+        for k in range(W):                                  # window 1's factors; the resident prior stays
+            ctx.set_correspondences(k, *corr[k])
+        ctx.set_imu(win.preints)
+        return ctx
+
+    ref = with_chain_prior(0)
+    s0, m0 = ref.solve(st)
+    ref.close()
+    ctx = with_chain_prior(1)
+    s1, m1 = ctx.solve(st)                                   # band-only assemblies: the buffers are declared clean for this n
+    assert lib.glio_debug_solver_path(ctx._h) == 2
+    ctx.marginalize(s1)                                      # ... and overwritten here
+    lib.glio_debug_set_solver(ctx._h, 2)                     # every chain step reports a breakdown: dense fallback on the assembled matrix
+    s2, m2 = ctx.solve(st)
+    ctx.close()
+    assert m1.iterations == m0.iterations
+    assert m2.iterations == m0.iterations and m2.termination == m0.termination
+    assert np.abs(s2.trans - s0.trans).max() <= 1e-9 and np.abs(s2.quat - s0.quat).max() <= 1e-10
