@@ -34,6 +34,7 @@ struct glio_batch {
     int n_mom_changed;         // moments_valid: pairs whose constraints were replaced since (their slots in d_mom_slots), taken again at the next solve
     int* d_mom_slots; int mom_slots_cap;
     int* h_prev_pi; int* h_prev_pj; int h_prev_n;      // the pair list the records were taken for
+    long long* h_prev_off;                             // [2 h_prev_n] and each pair's record range then: a pair whose range moved counts as replaced
     int src_min, src_max;      // smallest / largest SOURCE keyframe (ci) of the present constraint set (src_max < src_min: empty); a sharded solve checks them against its range
 };
 // which of a pair of buffers a kernel of the device-resident batch solve works on, and whether it runs at all:

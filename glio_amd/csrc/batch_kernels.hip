@@ -735,7 +735,7 @@ void glio_batch_destroy(glio_batch* b) {
     glio_batch_small_destroy(b);
     if (b->d_moments) hipFree(b->d_moments);
     if (b->d_mom_slots) hipFree(b->d_mom_slots);
-    free(b->h_prev_pi); free(b->h_prev_pj);
+    free(b->h_prev_pi); free(b->h_prev_pj); free(b->h_prev_off);
     void* ptrs[] = {b->d_cp, b->d_nc, b->d_score, b->d_pair_i, b->d_pair_j, b->d_pair_off, b->d_pair_rec, b->d_pair_index, b->d_poses,
                     b->d_newposes, b->d_M, b->d_y, b->d_delta, b->d_scalar, b->d_parts};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -833,10 +833,23 @@ int glio_batch_update_constraints_pairs_at_dev(glio_batch* b, int n_pairs, const
         run += pair_count[p];
     }
     if ((int)pi.size() > b->max_pairs) return GLIO_E_ARG;
+    if (pair_offset && pi.size() > 1) {            // explicit ranges must not overlap (they are borrowed memory: their upper end is the caller's to keep inside its arrays)
+        std::vector<std::pair<long long, long long>> rg(pi.size());
+        for (size_t q = 0; q < pi.size(); ++q) rg[q] = {off[2 * q], off[2 * q + 1]};
+        std::sort(rg.begin(), rg.end());
+        for (size_t q = 1; q < rg.size(); ++q) if (rg[q].first < rg[q - 1].second) { glio_set_error("record ranges of two pairs overlap ([%lld, %lld) and [%lld, %lld))", rg[q - 1].first, rg[q - 1].second, rg[q].first, rg[q].second); return GLIO_E_ARG; }
+    }
     b->src_min = pi.empty() ? 0 : pi.front(); b->src_max = pi.empty() ? -1 : pi.back();      // (sorted by ci)
     {   // do the moment records of the unmarked pairs still stand?  only when the list of non-empty pairs is the one they were taken for
         bool same = pair_changed && b->moments_valid && b->h_prev_n == (int)pi.size() && b->d_moments && b->moments_pairs >= (int)pi.size();
         for (size_t q = 0; same && q < pi.size(); ++q) same = b->h_prev_pi[q] == pi[q] && b->h_prev_pj[q] == pj[q];
+        if (same && b->h_prev_off) {                // an unmarked pair whose record range moved or changed length is a replaced pair all the same (advisor, round 4)
+            std::vector<char> marked(pi.size(), 0);
+            for (int sl : changed_slots) marked[(size_t)sl] = 1;
+            for (size_t q = 0; q < pi.size(); ++q)
+                if (!marked[q] && (b->h_prev_off[2 * q] != off[2 * q] || b->h_prev_off[2 * q + 1] != off[2 * q + 1])) { marked[q] = 1; changed_slots.push_back((int)q); }
+            std::sort(changed_slots.begin(), changed_slots.end());
+        }
         if (same) {
             if ((int)changed_slots.size() > b->mom_slots_cap) {
                 if (b->d_mom_slots) hipFree(b->d_mom_slots);
@@ -852,9 +865,9 @@ int glio_batch_update_constraints_pairs_at_dev(glio_batch* b, int n_pairs, const
                 b->n_mom_changed = (int)changed_slots.size();
             }
         } else b->moments_valid = 0;
-        free(b->h_prev_pi); free(b->h_prev_pj);
-        b->h_prev_pi = (int*)malloc((pi.size() + 1) * 4); b->h_prev_pj = (int*)malloc((pi.size() + 1) * 4);
-        if (!pi.empty()) { memcpy(b->h_prev_pi, pi.data(), pi.size() * 4); memcpy(b->h_prev_pj, pj.data(), pj.size() * 4); }
+        free(b->h_prev_pi); free(b->h_prev_pj); free(b->h_prev_off);
+        b->h_prev_pi = (int*)malloc((pi.size() + 1) * 4); b->h_prev_pj = (int*)malloc((pi.size() + 1) * 4); b->h_prev_off = (long long*)malloc((2 * pi.size() + 2) * 8);
+        if (!pi.empty()) { memcpy(b->h_prev_pi, pi.data(), pi.size() * 4); memcpy(b->h_prev_pj, pj.data(), pj.size() * 4); memcpy(b->h_prev_off, off.data(), 2 * pi.size() * 8); }
         b->h_prev_n = (int)pi.size();
     }
     b->n_pairs = (int)pi.size();

@@ -344,6 +344,7 @@ extern "C" {
 int glio_localmap_config(glio_ctx* c, int width, float leaf, int max_points_per_keyframe) {
     if (!c || width < 1 || !(leaf > 0.f) || max_points_per_keyframe < 1) return GLIO_E_ARG;
     LM_CHECK(hipSetDevice(c->device));
+    const int keep_accumulation = c->localmap ? c->localmap->accumulation : 0;      // (the centroid arithmetic is a property of the context, not of one ring)
     glio_localmap_destroy(c);
     LocalMap* m = new LocalMap();
     memset(m, 0, sizeof *m);
@@ -366,6 +367,7 @@ int glio_localmap_config(glio_ctx* c, int width, float leaf, int max_points_per_
     LM_CHECK(hipMemsetAsync(m->d_n, 0, (size_t)width * 4, c->stream));
     LM_CHECK(hipStreamSynchronize(c->stream));
     c->localmap = m;
+    if (keep_accumulation) return glio_localmap_set_accumulation(c, keep_accumulation);
     return GLIO_OK;
 }
 

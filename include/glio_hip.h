@@ -71,8 +71,10 @@ int glio_localmap_push_strided(glio_ctx* ctx, const void* cloud_points, int n, i
  * the newest keyframe's cloud crosses PCIe once for both the association and the map */
 int glio_localmap_push_scan(glio_ctx* ctx, int scan_slot, const float lidar_offset[3], const double q[4], const double t[3]);
 int glio_localmap_build(glio_ctx* ctx, int* out_points);
-/* centroid arithmetic of the voxel grid: 0 (default) exact fixed-point sums; 1 = pcl::VoxelGrid's float sums in the order of the concatenated cloud
- * (Estimator.cpp:3618-3631 through PCL; the oracle's restatement): bit-identical to the oracle's map, one extra pass over the ring per build */
+/* centroid arithmetic of the voxel grid: 0 (default) exact fixed-point sums; 1 = float sums in the order of the concatenated cloud, as the oracle's
+ * restatement of pcl::VoxelGrid forms them (Estimator.cpp:3618-3631 through PCL): bit-identical to the ORACLE's map (stable order inside a voxel).  PCL itself
+ * orders its point / voxel index vector with an unstable sort, so against a real PCL build the float sums may differ by an ulp -- the order inside a voxel is
+ * not specified by PCL.  One extra pass over the ring per build.  The mode survives glio_localmap_config (re-applied to the new ring). */
 int glio_localmap_set_accumulation(glio_ctx* ctx, int mode);
 /* test hook: the down-sampled map (surf_local_map_ds), ordered by voxel index */
 int glio_localmap_read(glio_ctx* ctx, float* out_xyzi, int capacity, int* out_n);
