@@ -32,6 +32,12 @@ def build(force=False):
     return _SO
 
 
+def build_probe():
+    """oracle/_ref/libme_probe.so: the Eigen stand-in behind a C interface (tests/test_mini_eigen.py); needs no reference tree"""
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "ref_shim"), "probe"], stdout=subprocess.DEVNULL)
+    return os.path.join(_HERE, "_ref", "libme_probe.so")
+
+
 _lib = None
 
 
