@@ -388,27 +388,42 @@ def main():
                 k8m = batch_info["constraints_this_rank"] * 72 / (mm * 1e-3) / 1e9
                 others["K8_batch_linearize_moments_pass"] = {"kernels": "k_batch_moments + evaluation", "bytes_per_unit": 72, "ms": mm, "achieved": round(k8m, 1), "frac": round(k8m / HBM_PEAK_GBS, 4)}
         if assoc and "algorithmic_GBps" in assoc:
-            others["K2_association_c2_scan"] = {"kernels": "k_qbin_tile + k_knn5_tile + k_plane_fit + k_compact", "bytes_per_unit": BYTES_PER_QUERY, "units": assoc["queries_per_scan"],
-                                                "us": assoc["associate_scan_us"], "achieved": assoc["algorithmic_GBps"], "frac": round(assoc["algorithmic_GBps"] / HBM_PEAK_GBS, 4),
-                                                "note": "not a bandwidth-bound kernel: its binding resource is VALU issue (valu_issue below); profiles/r04_k2_findings.txt"}
+            others["K2_association_c2_scan"] = {"kernels": "k_qbin_tile + k_knn5_tile + k_plane_fit + k_compact (a lone scan keeps the 27-cell tiled search)", "bytes_per_unit": BYTES_PER_QUERY,
+                                                "units": assoc["queries_per_scan"], "us": assoc["associate_scan_us"], "achieved": assoc["algorithmic_GBps"],
+                                                "frac": round(assoc["algorithmic_GBps"] / HBM_PEAK_GBS, 4),
+                                                "note": "not a bandwidth-bound path: its binding resource is VALU issue + dependent round trips; see K2_association_window"}
             try:
-                # VALU-issue roofline of the search kernel: wavefront-level VALU instructions per 64k-query scan from the committed counter pass, 4 cycles
-                # each on one of 1024 SIMDs, against what a scan costs inside the one-call window association (20 scans keep every SIMD supplied)
-                valu = None
-                for ln in open(os.path.join(ROOT, "profiles", "r04_v1_k2_pmc.txt")):
-                    f = ln.split()
-                    if len(f) >= 5 and f[0] == "k_knn5_tile" and f[1] == "SQ_INSTS_VALU":
-                        valu = float(f[4])
-                if valu and assoc.get("window_associate_one_call_ms"):
-                    floor_us = valu * 4.0 / 1024.0 / 2.4e9 * 1e6
-                    per_scan = assoc["window_associate_one_call_ms"] * 1e3 / args.window
-                    others["K2_association_c2_scan"]["valu_issue"] = {
-                        "wave_valu_instructions_per_scan": valu, "source": "profiles/r04_v1_k2_pmc.txt (SQ_INSTS_VALU of k_knn5_tile, one C2 scan)",
-                        "floor_us_per_scan": round(floor_us, 2), "floor_assumes": "4 cycles per wave64 VALU instruction, 1024 SIMDs, 2.4 GHz",
-                        "window_call_us_per_scan_all_four_kernels": round(per_scan, 2), "frac_of_valu_issue_whole_call": round(floor_us / per_scan, 3),
-                        "k_knn5_tile_us_per_scan_in_window_call": 14.8, "frac_of_valu_issue_search_kernel": round(floor_us / 14.8, 3),
-                        "search_kernel_time_source": "profiles/r04_k2_findings.txt (rocprofv3 kernel trace of the window call: 295 us for 20 scans)"}
-            except (OSError, ValueError, KeyError, TypeError, ZeroDivisionError):
+                # The window call (the path the keyframe function uses): the queries of all W scans grouped by cell together, near block first (k_knn5_near<64>),
+                # the rest by k_knn5_rest.  Kernel times and wavefront-VALU counts come from the NEWEST committed profiles of that workload (scripts/knn_prof_window.py
+                # under rocprofv3 --kernel-trace --stats, and scripts/knn_pmc.sh with KNN_WINDOW=1), not from constants in this file.
+                pdir = os.path.join(ROOT, "profiles")
+                kst = os.path.join(pdir, _latest_profile(pdir, "_k2_window_kernel_stats.csv"))
+                pmc = os.path.join(pdir, _latest_profile(pdir, "_k2_window_pmc.txt"))
+                kern = {}
+                for nm in ("k_qbin_tile", "k_gbin_alloc", "k_gbin_scatter", "k_knn5_near<64>", "k_knn5_rest", "k_plane_fit<false>", "k_compact"):
+                    v = _kernel_avg_ns(kst, nm)
+                    if v is not None:
+                        kern[nm] = round(v / 1e3, 1)
+                valu = {}
+                for ln in open(pmc):
+                    f = ln.replace("void ", "").split()
+                    if len(f) >= 5 and "SQ_INSTS_VALU" in f and f[0].startswith("k_knn5"):
+                        valu[f[0]] = float(f[f.index("launch") + 1])
+                per_call = assoc.get("window_associate_one_call_ms")
+                w = {"kernels_us_per_window_call": kern, "kernel_time_source": os.path.basename(kst), "window_call_ms_this_run": per_call,
+                     "bytes_per_unit": BYTES_PER_QUERY, "units": assoc["queries_per_scan"] * args.window}
+                if per_call:
+                    gb = BYTES_PER_QUERY * assoc["queries_per_scan"] * args.window / (per_call * 1e-3) / 1e9
+                    w["achieved"] = round(gb, 1); w["frac"] = round(gb / HBM_PEAK_GBS, 4)
+                if valu and kern.get("k_knn5_near<64>"):
+                    tot = sum(valu.values())
+                    floor_us = tot * 4.0 / 1024.0 / 2.4e9 * 1e6
+                    search_us = kern.get("k_knn5_near<64>", 0.0) + kern.get("k_knn5_rest", 0.0)
+                    w["valu_issue"] = {"wave_valu_instructions_per_window_call": valu, "source": os.path.basename(pmc), "floor_us": round(floor_us, 1),
+                                       "floor_assumes": "4 cycles per wave64 VALU instruction, 1024 SIMDs, 2.4 GHz", "search_kernels_us": round(search_us, 1),
+                                       "frac_of_valu_issue_search_kernels": round(floor_us / search_us, 3) if search_us else None}
+                others["K2_association_window"] = w
+            except (OSError, ValueError, KeyError, TypeError, ZeroDivisionError, AttributeError):
                 pass
         if c3_info and "frac_of_hbm_peak" in c3_info:
             others["K2_association_c3"] = {"bytes_per_unit": BYTES_PER_QUERY, "frac": c3_info["frac_of_hbm_peak"]}
@@ -432,6 +447,18 @@ def main():
         "roofline": roofline, "cpu_baseline": cpu, "cpu_baselines_other_configs": cpu_more, "pose_vs_oracle": pose_err, "association": assoc,
         "association_c3": c3_info, "c5_stress": c5_info, "batch_stage": batch_info, "batch_association": bassoc_info, "local_map": localmap_info, "front_end_odometry": odometry_info, "keyframe_pipeline": pipeline_info,
     }
+    # The whole reference function per keyframe (optimizeSlidingWindowWithLandMark from the new scan to the end of batchFeatureAssociation), driven from C++:
+    # the figure to hold next to `value`, which times the solve of a pre-associated window only (BASELINE config 2)
+    try:
+        cppk = (pipeline_info or {}).get("keyframe_pipeline_cpp") or {}
+        if "cycle_ms" in cppk:
+            line["whole_function_per_keyframe"] = {
+                "keyframes_per_s": cppk["keyframes_per_s"], "cycle_ms": cppk["cycle_ms"], "stages_ms": cppk["stages_ms"], "host": "C++ (glio_backend.hpp + glio_batch_backend.hpp)",
+                "what": "slide + new scan, device local map, association of all W slots, factor tables, solve, marginalization, batchFeatureAssociation (12 keyframe pairs + selection)",
+                "cpu_port_same_keyframe_ms": ((pipeline_info or {}).get("cpu_same_keyframe") or {}).get("ms"),
+                "solve_only_share_of_the_cycle": round(ms_per_step / cppk["cycle_ms"], 3)}
+    except (KeyError, TypeError, ZeroDivisionError):
+        pass
     if share_gpu:
         line["shared_gpu"] = f"{world} processes on ONE GPU, gloo through the host (GLIO_BENCH_SHARE_GPU=1): a test of the N-process path, not a scaling measurement"
     if c3_info:

@@ -864,6 +864,7 @@ struct BatchSmall {
     int* h_prog; int* d_prog; BtStatus* h_res; BtStatus* d_res;     // mapped host memory
     double* h_x;               // pinned [K][16]
     int solve_id;
+    int enqueue_lead;          // trust-region groups kept in flight by glio_batch_solve_tr2 (0 = default 2; 1 = wait for every group's decision)
     long long hook_calls, hook_doubles, groups;
     // the small factors and the IMU edges are evaluated on a second stream while K8 streams this rank's constraints (they are latency-bound
     // launches of a few thousand wavefronts; K8 is bandwidth-bound): forked and joined with events inside enqueue_tr_linearize
@@ -1371,29 +1372,43 @@ int glio_batch_solve_tr2(glio_batch* b, double* poses, double* speed_bias, const
     BT_CHECK(hipMemcpyAsync(s->d_s[1], s->d_s[0], (size_t)K * 9 * 8, hipMemcpyDeviceToDevice, st));
     BtRun r; r.b = b; r.hook = allreduce; r.user = user;
     enqueue_tr_linearize(r, 1, true);            // the starting point is "the candidate" of a first group that accepts it unconditionally
-    // The loop lives on the device; the host feeds one group per decision of the state machine.  Group g + 1 is enqueued when the
-    // state machine of group g (its first kernel) has said "the solve goes on" -- i.e. while the rest of group g is still running
-    // -- so the queue never runs dry, and every rank enqueues exactly the same groups (the collectives inside them must match).
-    const int max_groups = o->max_iterations + 16 + 8 * 5;
+    // The loop lives on the device; the host only keeps the queue fed.  Up to `lead` groups are in flight: group g is enqueued as soon as the state machine of
+    // group g - lead (its first kernel) has said "the solve goes on"; every kernel of a group enqueued behind the deciding one exits at once on the done flag
+    // (and its collectives run on stale buffers: harmless, and every rank calls them alike).  The number of groups a rank enqueues is a function of the device's
+    // decisions alone -- f + lead - 1 when group f decides to stop -- never of host timing: a group is enqueued whenever the progress word allows it, and the
+    // finished flag only ends the loop when it does not (progress is written before finished, and read again after finished was seen), so the collective
+    // sequences of the ranks match.  lead = 1 is the round-4 loop (wait for group g before enqueuing g + 1).
+    const int lead = s->enqueue_lead > 0 ? s->enqueue_lead : 2;
+    const int max_groups = o->max_iterations + 16 + 8 * 5 + lead;
     const auto t0 = std::chrono::steady_clock::now();
     int rc = GLIO_OK;
+    auto progress_allows = [&](int g) {          // group g - lead has reported "goes on" (groups 1 .. lead need nobody's word)
+        if (g <= lead) return true;
+        const int w = __atomic_load_n(&s->h_prog[0], __ATOMIC_ACQUIRE);      // GPU-written mapped words: every poll is a real load
+        return (w >> 16) == id && (w & 0xffff) >= ((g - lead) & 0xffff);
+    };
     for (int g = 1; g <= max_groups; ++g) {
-        enqueue_tr_group(r, bo);
-        if (hipGetLastError() != hipSuccess) { glio_set_error("batch solve: launch failure in group %d", g); return GLIO_E_HIP; }
         long long spins = 0;
-        bool finished = false;
+        bool go = false;
         for (;;) {
-            // GPU-written mapped words: every poll is a real load (acquire), never a value the compiler kept in a register
-            if (__atomic_load_n(&s->h_prog[1], __ATOMIC_ACQUIRE) == id) { finished = true; break; }
-            const int w = __atomic_load_n(&s->h_prog[0], __ATOMIC_ACQUIRE);
-            if ((w >> 16) == id && (w & 0xffff) >= (g & 0xffff)) break;
+            if (progress_allows(g)) { go = true; break; }
+            if (__atomic_load_n(&s->h_prog[1], __ATOMIC_ACQUIRE) == id) { go = progress_allows(g); break; }
             if (((++spins) & 0x3f) == 0) std::this_thread::yield();        // a group lasts a millisecond or more: polling does not need the whole core
             if ((spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
                 glio_set_error("batch solve: no progress for 120 s (group %d)", g);
                 return GLIO_E_HIP;
             }
         }
-        if (finished) break;
+        if (!go) break;
+        enqueue_tr_group(r, bo);
+        if (hipGetLastError() != hipSuccess) { glio_set_error("batch solve: launch failure in group %d", g); return GLIO_E_HIP; }
+    }
+    {   // the groups in flight end with the one that decided to stop
+        long long spins = 0;
+        while (__atomic_load_n(&s->h_prog[1], __ATOMIC_ACQUIRE) != id) {
+            if (((++spins) & 0x3f) == 0) std::this_thread::yield();
+            if ((spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) { glio_set_error("batch solve: no progress for 120 s"); return GLIO_E_HIP; }
+        }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     BT_CHECK(hipMemcpyAsync(s->h_x, s->d_xmin, (size_t)K * 7 * 8, hipMemcpyDeviceToHost, st));
@@ -1416,6 +1431,13 @@ int glio_batch_solve_tr2(glio_batch* b, double* poses, double* speed_bias, const
 int glio_batch_solve_tr(glio_batch* b, double* poses, const glio_batch_tr_opts* o, glio_allreduce_fn allreduce, void* user, glio_summary* sum) {
     if (b && b->small && b->small->n_imu > 0) { glio_set_error("the IMU chain is set: use glio_batch_solve_tr2"); return GLIO_E_STATE; }
     return glio_batch_solve_tr2(b, poses, nullptr, o, allreduce, user, sum);
+}
+// trust-region groups the host keeps in flight (1 = the round-4 loop: wait for group g's decision before enqueuing g + 1; default 2)
+int glio_batch_debug_set_enqueue_lead(glio_batch* b, int lead) {
+    if (!b || lead < 0 || lead > 8) return GLIO_E_ARG;
+    { const int rc = small_ensure(b); if (rc) return rc; }
+    b->small->enqueue_lead = lead;
+    return GLIO_OK;
 }
 // counters of the last solves (bench / tests): hook calls, doubles handed to the hook, trust-region groups enqueued, BCR levels; reset on read
 int glio_batch_debug_counters(glio_batch* b, int64_t* out4) {

@@ -274,6 +274,10 @@ int glio_batch_solve_tr2(glio_batch* b, double* poses, double* speed_bias, const
 int glio_batch_solve_tr(glio_batch* b, double* poses, const glio_batch_tr_opts* opts, glio_allreduce_fn allreduce, void* user, glio_summary* summary);
 /* hook calls, doubles handed to the hook, trust-region groups enqueued, elimination levels since the last call (reset on read) */
 int glio_batch_debug_counters(glio_batch* b, int64_t* out4);
+/* trust-region groups glio_batch_solve_tr2 keeps in flight: group g is enqueued when group g - lead has decided that the solve goes on; the groups behind the
+ * deciding one exit at once on the device.  Every rank enqueues the same number of groups (a function of the device's decisions, not of host timing), so
+ * the collective sequences match.  1 = wait for every group's decision before enqueuing the next (the round-4 loop); 0 = default (2). */
+int glio_batch_debug_set_enqueue_lead(glio_batch* b, int lead);
 
 /* For a C++ host that never includes HIP headers (glio_amd/host/glio_batch_backend.hpp): the reduced buffer
  * [H band | g | cost] as a device allocation, the batch stream to hand to ncclAllReduce between glio_batch_linearize_dev and

@@ -415,3 +415,39 @@ def test_relative_pose_factors_of_the_released_default(with_planes, world):
     assert summ.final_cost < 0.05 * summ.initial_cost
     rel = lambda X: np.linalg.norm(np.diff(X[:, :3], axis=0) - np.diff(odo[:, :3], axis=0), axis=1).max()
     assert rel(poses) < 0.5 * rel(init)                      # the relative-pose factors pull the chain onto the odometry's increments
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_groups_in_flight_do_not_change_the_solve_or_the_collective_count(world):
+    """glio_batch_solve_tr2 keeps `lead` trust-region groups in flight (group g is enqueued when group g - lead has decided that the solve goes on; the groups
+    behind the deciding one exit at once on the device).  lead 1 (wait for every decision: the round-4 loop), 2 (default) and 4 give the same iterates bit
+    for bit, and the number of groups -- hence of collective calls, which must match across ranks -- is a function of the decisions alone: groups(lead) =
+    groups(1) + lead - 1 on EVERY rank."""
+    import torch
+    from glio_amd import capi
+    K, band = 60, 6
+    gt, init, con, dq, dd, frame, imu, sb0 = _imu_problem(K, band, per_kf=80, seed=57)
+    opts = T.batch_tr_opts(max_iterations=10)
+    lib = capi.load()
+    runs = {}
+    for lead in (1, 2, 4):
+        stages = [_stage(K, band, con, dq, dd, frame, imu=imu, rank=r, world=world) for r in range(world)]
+        for st in stages:
+            assert lib.glio_batch_debug_set_enqueue_lead(st._h, lead) == 0
+            st.counters()
+        if world == 1:
+            res = [(stages[0].solve_tr(init, opts, speed_bias=sb0), stages[0].counters())]
+        else:
+            ranks = batch.ThreadRanks(world, sync=torch.cuda.synchronize)
+            res = ranks.run(lambda r, dist: (stages[r].solve_tr(init, opts, dist, speed_bias=sb0), stages[r].counters()))
+        for st in stages:
+            st.close()
+        runs[lead] = res
+    base = runs[1]
+    g1 = base[0][1]["groups"]
+    for lead, res in runs.items():
+        for (out, cnt), (out1, cnt1) in zip(res, base):
+            assert np.array_equal(out[0], out1[0]) and np.array_equal(out[1], out1[1]) and out[2].iterations == out1[2].iterations and out[2].final_cost == out1[2].final_cost
+            assert cnt["groups"] == g1 + lead - 1, (lead, cnt, g1)
+            if world > 1:
+                assert cnt["hook_calls"] == cnt1["hook_calls"] + 5 * (lead - 1)
