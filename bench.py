@@ -392,39 +392,9 @@ def main():
                                                 "units": assoc["queries_per_scan"], "us": assoc["associate_scan_us"], "achieved": assoc["algorithmic_GBps"],
                                                 "frac": round(assoc["algorithmic_GBps"] / HBM_PEAK_GBS, 4),
                                                 "note": "not a bandwidth-bound path: its binding resource is VALU issue + dependent round trips; see K2_association_window"}
-            try:
-                # The window call (the path the keyframe function uses): the queries of all W scans grouped by cell together, near block first (k_knn5_near<64>),
-                # the rest by k_knn5_rest.  Kernel times and wavefront-VALU counts come from the NEWEST committed profiles of that workload (scripts/knn_prof_window.py
-                # under rocprofv3 --kernel-trace --stats, and scripts/knn_pmc.sh with KNN_WINDOW=1), not from constants in this file.
-                pdir = os.path.join(ROOT, "profiles")
-                kst = os.path.join(pdir, _latest_profile(pdir, "_k2_window_kernel_stats.csv"))
-                pmc = os.path.join(pdir, _latest_profile(pdir, "_k2_window_pmc.txt"))
-                kern = {}
-                for nm in ("k_qbin_tile", "k_gbin_alloc", "k_gbin_scatter", "k_knn5_near<64>", "k_knn5_rest", "k_plane_fit<false>", "k_compact"):
-                    v = _kernel_avg_ns(kst, nm)
-                    if v is not None:
-                        kern[nm] = round(v / 1e3, 1)
-                valu = {}
-                for ln in open(pmc):
-                    f = ln.replace("void ", "").split()
-                    if len(f) >= 5 and "SQ_INSTS_VALU" in f and f[0].startswith("k_knn5"):
-                        valu[f[0]] = float(f[f.index("launch") + 1])
-                per_call = assoc.get("window_associate_one_call_ms")
-                w = {"kernels_us_per_window_call": kern, "kernel_time_source": os.path.basename(kst), "window_call_ms_this_run": per_call,
-                     "bytes_per_unit": BYTES_PER_QUERY, "units": assoc["queries_per_scan"] * args.window}
-                if per_call:
-                    gb = BYTES_PER_QUERY * assoc["queries_per_scan"] * args.window / (per_call * 1e-3) / 1e9
-                    w["achieved"] = round(gb, 1); w["frac"] = round(gb / HBM_PEAK_GBS, 4)
-                if valu and kern.get("k_knn5_near<64>"):
-                    tot = sum(valu.values())
-                    floor_us = tot * 4.0 / 1024.0 / 2.4e9 * 1e6
-                    search_us = kern.get("k_knn5_near<64>", 0.0) + kern.get("k_knn5_rest", 0.0)
-                    w["valu_issue"] = {"wave_valu_instructions_per_window_call": valu, "source": os.path.basename(pmc), "floor_us": round(floor_us, 1),
-                                       "floor_assumes": "4 cycles per wave64 VALU instruction, 1024 SIMDs, 2.4 GHz", "search_kernels_us": round(search_us, 1),
-                                       "frac_of_valu_issue_search_kernels": round(floor_us / search_us, 3) if search_us else None}
+            w = k2_window_block(assoc, args.window)
+            if w:
                 others["K2_association_window"] = w
-            except (OSError, ValueError, KeyError, TypeError, ZeroDivisionError, AttributeError):
-                pass
         if c3_info and "frac_of_hbm_peak" in c3_info:
             others["K2_association_c3"] = {"bytes_per_unit": BYTES_PER_QUERY, "frac": c3_info["frac_of_hbm_peak"]}
     except (KeyError, TypeError, ZeroDivisionError):
@@ -479,6 +449,43 @@ def _git_commit_of(relpath):
         out = subprocess.run(["git", "log", "-n", "1", "--format=%h", "--", relpath], cwd=ROOT, capture_output=True, text=True, timeout=10).stdout.strip()
         return out or None
     except (OSError, subprocess.SubprocessError):
+        return None
+
+
+def k2_window_block(assoc, window):
+    """`roofline.others.K2_association_window`: the one-call window association (the path the keyframe function uses: the queries of all W scans grouped by
+    cell together, near block first -- k_knn5_near<64> --, the rest by k_knn5_rest).  Kernel times and wavefront-VALU counts come from the NEWEST committed
+    profiles of that workload (scripts/knn_prof_window.py under rocprofv3 --kernel-trace --stats; scripts/knn_pmc.sh with KNN_WINDOW=1), never from constants
+    in this file; None when the profiles are absent."""
+    try:
+        pdir = os.path.join(ROOT, "profiles")
+        kst = os.path.join(pdir, _latest_profile(pdir, "_k2_window_kernel_stats.csv"))
+        pmc = os.path.join(pdir, _latest_profile(pdir, "_k2_window_pmc.txt"))
+        kern = {}
+        for nm in ("k_qbin_tile", "k_gbin_alloc", "k_gbin_scatter", "k_knn5_near<64>", "k_knn5_rest", "k_plane_fit<false>", "k_compact"):
+            v = _kernel_avg_ns(kst, nm)
+            if v is not None:
+                kern[nm] = round(v / 1e3, 1)
+        valu = {}
+        for ln in open(pmc):
+            f = ln.replace("void ", "").split()
+            if len(f) >= 5 and "SQ_INSTS_VALU" in f and f[0].startswith("k_knn5") and "launch" in f:
+                valu[f[0]] = float(f[f.index("launch") + 1])
+        per_call = assoc.get("window_associate_one_call_ms")
+        w = {"kernels_us_per_window_call": kern, "kernel_time_source": os.path.basename(kst), "window_call_ms_this_run": per_call,
+             "bytes_per_unit": BYTES_PER_QUERY, "units": assoc["queries_per_scan"] * window}
+        if per_call:
+            gb = BYTES_PER_QUERY * assoc["queries_per_scan"] * window / (per_call * 1e-3) / 1e9
+            w["achieved"] = round(gb, 1); w["frac"] = round(gb / HBM_PEAK_GBS, 4)
+        if valu and kern.get("k_knn5_near<64>"):
+            tot = sum(valu.values())
+            floor_us = tot * 4.0 / 1024.0 / 2.4e9 * 1e6
+            search_us = kern.get("k_knn5_near<64>", 0.0) + kern.get("k_knn5_rest", 0.0)
+            w["valu_issue"] = {"wave_valu_instructions_per_window_call": valu, "source": os.path.basename(pmc), "floor_us": round(floor_us, 1),
+                               "floor_assumes": "4 cycles per wave64 VALU instruction, 1024 SIMDs, 2.4 GHz", "search_kernels_us": round(search_us, 1),
+                               "frac_of_valu_issue_search_kernels": round(floor_us / search_us, 3) if search_us else None}
+        return w
+    except (OSError, ValueError, KeyError, TypeError, ZeroDivisionError, AttributeError):
         return None
 
 

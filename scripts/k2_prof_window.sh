@@ -7,6 +7,7 @@ for v in "$@"; do
   OUT=/tmp/knnprofw_$v; rm -rf $OUT; mkdir -p $OUT
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o trace -- python scripts/knn_prof_window.py > /tmp/k2w.log 2>&1
   f=$(find $OUT -name "*kernel_stats.csv" | head -1)
+  mkdir -p $GRAFT_REPO_ROOT/gpurun_out; cp $f $GRAFT_REPO_ROOT/gpurun_out/k2_window_kernel_stats_$v.csv      # (copy into profiles/rNN_k2_window_kernel_stats.csv: bench.py reads the newest)
   echo "== $v"; python - "$f" <<'PY'
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):

@@ -18,7 +18,7 @@ big = synth.tiled_map(synth.make_window(W=1, pts_per_scan=131072, seed=synth.SEE
 w3 = synth.make_window(W=1, pts_per_scan=131072, seed=synth.SEED_BASE + 7)
 K, pts, sr = 16, 32768, 6
 wb = synth.make_window(W=K, pts_per_scan=pts, seed=synth.SEED_BASE + 61, perturb=(0.03, 0.2, 0.0), scan_radius=25.0, map_density=0.5)
-for mode in (2, 0, 2, 0):
+for mode in (2, 3, 0, 2, 3, 0):
     lib.glio_debug_set_knn_mode(mode)
     r = {}
     ctx = capi.Context(win.opts)

@@ -49,3 +49,20 @@ def test_under_torch_distributed_run_the_ranks_come_from_the_environment():
     assert len(lines) == 1, p.stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["rank_sum"] == 3.0
+
+
+def test_k2_window_block_reads_the_newest_committed_profiles():
+    """bench.py's K2 roofline block takes its kernel times and VALU counts from profiles/rNN_k2_window_* (advisor, round 4: no constants of an old
+    profile in the bench line): the helper finds the newest pair and derives the VALU-issue floor from it."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    w = b.k2_window_block({"window_associate_one_call_ms": 0.32, "queries_per_scan": 65536}, 20)
+    assert w is not None and w["kernel_time_source"].endswith("_k2_window_kernel_stats.csv")
+    k = w["kernels_us_per_window_call"]
+    assert k["k_knn5_near<64>"] > 10 and k["k_plane_fit<false>"] > 5 and 0.0 < w["frac"] < 1.0
+    v = w["valu_issue"]
+    assert v["wave_valu_instructions_per_window_call"]["k_knn5_near<64>"] > 1e6 and 0.0 < v["frac_of_valu_issue_search_kernels"] <= 1.0
