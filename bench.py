@@ -732,7 +732,13 @@ def bench_keyframe_stream_cpp(local_rank, W, pts, py_info, n_keyframes=8, seed=N
         path = os.path.join(d, "stream.bin")
         window_io.write_stream(path, long, wins, W, n_keyframes, pts)
         runs = [window_io.run_demo_stream(path, device=local_rank) for _ in range(2)]
+        deferred = [window_io.run_demo_stream(path, device=local_rank, defer=True) for _ in range(2)]
     out = min(runs, key=lambda r: r["cycle_ms"])
+    dfr = min(deferred, key=lambda r: r["cycle_ms"])
+    out["batch_association_deferred_variant"] = {"cycle_ms": dfr["cycle_ms"], "keyframes_per_s": dfr["keyframes_per_s"], "stages_ms": dfr["stages_ms"],
+                                                 "same_results": bool(dfr["iterations"] == out["iterations"] and dfr["correspondences_kept"] == out["correspondences_kept"]),
+                                                 "what": "the batch association of keyframe j enqueued in call j (own stream), collected in call j + 1 before that call's enqueue: its searches run "
+                                                         "beside the next keyframe's work; the records arrive one keyframe later than in the reference (option, not the headline)"}
     out["host"] = "C++17 (g++ -O2), glio_backend.hpp over the C-ABI; stage times by std::chrono inside the program; best of 2 runs of 8 keyframes"
     if py_info and "iterations" in py_info:
         out["same_iterations_and_correspondences_as_the_python_driver"] = bool(out["iterations"] == py_info["iterations"] and out["correspondences_kept"] == py_info["correspondences_kept"]

@@ -314,6 +314,65 @@ def make_batch_gnss(gt, seed=20260930, sats_per_sys=10, psr_sigma=1.0, outliers=
     return dd, frame
 
 
+def select_batch_gnss_epochs(obs_local_ts, keyframe_time, first_idx, n_poses, trans):
+    """Which GNSS epochs enter the batch problem and between which keyframes (Estimator.cpp:3086-3126 with getGlobalLowerUpperIdx :1635-1663): rows
+    (epoch, left_key, right_key, ts_ratio).  Same rules as glio::selectBatchGnssEpochs (glio_batch_backend.hpp), which documents them."""
+    kt = np.asarray(keyframe_time, float)
+    out, padd = [], np.zeros(3)
+    if len(kt) == 0:
+        return out
+    for e, T in enumerate(np.asarray(obs_local_ts, float)):
+        if T > kt[-1] or T < kt[0]:
+            continue
+        lower, upper, diff = -1, 10000000, 10000000.0
+        for i in range(first_idx, n_poses):
+            t = kt[i - 1]
+            if abs(t - T) < diff and t < T:
+                lower, diff = i, abs(t - T)
+        diff = 10000000.0
+        for i in range(first_idx, n_poses):
+            t = kt[i - 1]
+            if abs(t - T) < diff and t > T:
+                upper, diff = i, abs(t - T)
+        if not (0 <= lower < n_poses and 0 <= upper < n_poses):
+            continue
+        tl, tu = kt[lower - 1], kt[upper - 1]
+        pj = np.asarray(trans[upper - 1], float)
+        if np.linalg.norm(pj - padd) < 1.0:
+            continue
+        padd = pj.copy()
+        out.append((e, lower - 1, upper - 1, (tu - T) / (tu - tl)))
+    return out
+
+
+def prn_system(prn):
+    """gnss_tools.h:1116-1168: 0 GPS, 1 BeiDou, 2 GLONASS, 3 Galileo, -1 none"""
+    if prn <= 32 or prn == 84:
+        return 0
+    if 87 <= prn <= 121:
+        return 1
+    if 32 < prn <= 56:
+        return 2
+    if 56 < prn < 87:
+        return 3
+    return -1
+
+
+def dd_group(system, user_prn, user_psr, user_ele, ref_prn):
+    """prepare<SYS>DDPsrData (Estimator.cpp:1702-1860): (rover indices, station indices, master) of one constellation; the master is chosen against a
+    running maximum that is updated with the SIGNED elevation (quirk, replicated)."""
+    user, ref = [], []
+    for i, p in enumerate(user_prn):
+        for j, q in enumerate(ref_prn):
+            if p == q and prn_system(p) == system and user_psr[i] > 1000:
+                user.append(i); ref.append(j)
+    master, max_ele = -1, 0.0
+    for m, i in enumerate(user):
+        if abs(user_ele[i]) > max_ele:
+            max_ele, master = user_ele[i], m
+    return user, ref, master
+
+
 def batch_selection_draws(count, res_num, rng, ends=False, rand_set_num=400):
     """The indices `globalFeatureSelectionAdd_Batch` (Estimator.cpp:4057-4116) keeps of a keyframe pair's `count` records:
     all of them (None) when count <= batch_feature_res_num (:4077), otherwise the first res_num entries of

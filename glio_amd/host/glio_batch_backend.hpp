@@ -428,4 +428,69 @@ private:
     bool have_ = false;
 };
 
+// ================================================================================================
+// Which GNSS epochs enter the batch problem, between which keyframes, and which satellites form a double-difference factor: the host rules of
+// optimizeBatchWithLandMark (Estimator.cpp:3086-3272) and prepare{GPS,BDS,GLO,GAL}DDPsrData (:1702-1860).  Pure host arithmetic; the factors
+// themselves are glio_dd_psr records evaluated on the device.  glio_amd/batch.py::select_batch_gnss_epochs / dd_group are the Python twins;
+// tests/test_host_logic.py holds the two to each other on random streams.
+// ================================================================================================
+struct GnssEpochSlot { int epoch, left_key, right_key; double ts_ratio; };
+// obs_local_ts[i] = time of epoch i minus timeshift_IMUtoGNSS (:3093); keyframe_time[k] as the reference holds it (pose index i is 1-based: its time is
+// keyframe_time[i - 1]); first_idx = keyframe_idx[0]; n_poses = pose_info_keyframe_batch->points.size(); trans = gl_tmpTrans [K][3] (0-based keys).
+// Per epoch: skipped outside [keyframe_time.front(), keyframe_time.back()] (:3100); lower / upper = the pose strictly before / after the epoch that is
+// closest in time, searched over [first_idx, n_poses) with strict "<" on the distance (getGlobalLowerUpperIdx, :1635-1663: the FIRST of equally close
+// ones wins; -1 / 10000000 when none); skipped unless both lie in [0, n_poses) (:3104-3105); ts_ratio = (t_upper - t) / (t_upper - t_lower) (:3109);
+// keys = idx - 1; skipped when the right keyframe lies less than 1 m from the right keyframe of the last ACCEPTED epoch (:3121-3126; the reference
+// point starts at the origin, so an epoch whose right keyframe is within 1 m of (0, 0, 0) is skipped too).
+inline std::vector<GnssEpochSlot> selectBatchGnssEpochs(const std::vector<double>& obs_local_ts, const std::vector<double>& keyframe_time, int first_idx, int n_poses,
+                                                        const std::vector<double>& trans) {
+    std::vector<GnssEpochSlot> out;
+    if (keyframe_time.empty()) return out;
+    double padd[3] = {0.0, 0.0, 0.0};
+    for (size_t e = 0; e < obs_local_ts.size(); ++e) {
+        const double T = obs_local_ts[e];
+        if (T > keyframe_time.back() || T < keyframe_time.front()) continue;
+        int lower = -1, upper = 10000000;
+        double diff = 10000000;
+        for (int i = first_idx; i < n_poses; ++i) { const double t = keyframe_time[(size_t)i - 1], d = std::fabs(t - T); if (d < diff && t < T) { lower = i; diff = d; } }
+        diff = 10000000;
+        for (int i = first_idx; i < n_poses; ++i) { const double t = keyframe_time[(size_t)i - 1], d = std::fabs(t - T); if (d < diff && t > T) { upper = i; diff = d; } }
+        if (lower < 0 || lower >= n_poses || upper < 0 || upper >= n_poses) continue;
+        const double tl = keyframe_time[(size_t)lower - 1], tu = keyframe_time[(size_t)upper - 1];
+        const int lk = lower - 1, rk = upper - 1;
+        const double* pj = &trans[3 * (size_t)rk];
+        const double dx = pj[0] - padd[0], dy = pj[1] - padd[1], dz = pj[2] - padd[2];
+        if (std::sqrt(dx * dx + dy * dy + dz * dz) < 1.0) continue;
+        padd[0] = pj[0]; padd[1] = pj[1]; padd[2] = pj[2];
+        out.push_back({(int)e, lk, rk, (tu - T) / (tu - tl)});
+    }
+    return out;
+}
+// constellation of a PRN as gnss_tools.h:1116-1168 numbers them: 0 GPS (<= 32 or 84), 1 BeiDou (87..121), 2 GLONASS (33..56), 3 Galileo (57..86), -1 none
+inline int prnSystem(int prn) {
+    if (prn <= 32 || prn == 84) return 0;
+    if (prn >= 87 && prn <= 121) return 1;
+    if (prn > 32 && prn <= 56) return 2;
+    if (prn > 56 && prn < 87) return 3;
+    return -1;
+}
+// prepare<SYS>DDPsrData (:1702-1860): the (rover, station) observation pairs of one constellation -- rover order outside, station order inside, rover
+// pseudorange > 1000 -- and the master = the LAST pair whose |elevation| exceeds the running maximum, which the reference updates with the SIGNED
+// elevation (maxEle = ele, not fabs(ele): replicated).  master stays -1 for an empty group; the caller adds the factor when the group holds more than 2
+// pairs (:3202).  The reference walks the systems in the order GPS, BDS, GLO, GAL (:3198-3271).
+struct DdGroup { std::vector<int> user, ref; int master = -1; };
+inline DdGroup ddGroup(int system, const std::vector<int>& user_prn, const std::vector<double>& user_psr, const std::vector<double>& user_ele,
+                       const std::vector<int>& ref_prn) {
+    DdGroup g;
+    for (size_t i = 0; i < user_prn.size(); ++i)
+        for (size_t j = 0; j < ref_prn.size(); ++j)
+            if (user_prn[i] == ref_prn[j] && prnSystem(user_prn[i]) == system && user_psr[i] > 1000) { g.user.push_back((int)i); g.ref.push_back((int)j); }
+    double max_ele = 0;
+    for (size_t m = 0; m < g.user.size(); ++m) {
+        const double ele = user_ele[(size_t)g.user[m]];
+        if (std::fabs(ele) > max_ele) { max_ele = ele; g.master = (int)m; }
+    }
+    return g;
+}
+
 }  // namespace glio

@@ -21,7 +21,7 @@ template <typename T> static void rd(FILE* f, T* p, size_t n) { if (n && fread(p
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int main(int argc, char** argv) {
-    if (argc < 2) { fprintf(stderr, "usage: host_demo_stream stream.bin [device] [search_range]\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: host_demo_stream stream.bin [device] [search_range] [defer]\n"); return 2; }
     FILE* f = fopen(argv[1], "rb");
     if (!f) { perror("open"); return 2; }
     const int device = argc > 2 ? atoi(argv[2]) : 0;
@@ -60,6 +60,10 @@ int main(int argc, char** argv) {
         { glio_prior none; memset(&none, 0, sizeof none); be.setMarginalizationPrior(&none); }      // the first window has no prior
         // batchFeatureAssociation: every keyframe of the stream keeps its cloud (body frame) resident; search_range 6, batch_feature_res_num 25 (config_urban_hk.yaml:64,102)
         const int SR = argc > 3 ? atoi(argv[3]) : 6, RES = hdr[3] > 0 ? hdr[3] : 25;
+        // defer = 1: the batch association of keyframe j is only ENQUEUED inside call j (own stream) and collected inside call j + 1, right before that call's
+        // own enqueue -- its searches then run beside the next keyframe's solve (one CU busy) instead of beside nothing.  The records reach gl_vec_surf_* one
+        // keyframe later than in the reference, which only the batch thread could notice; the default (0) returns from the call with them in place.
+        const bool defer = argc > 4 && atoi(argv[4]) != 0;
         glio::BatchAssociationBackend ba(total_kf, pts, (int64_t)(NK + 2) * 2 * SR * pts, device);
         glio::KeyframeBatchAssociation kba(ba, SR, RES);
         std::mt19937_64 rng(20260925);
@@ -99,12 +103,14 @@ int main(int argc, char** argv) {
                 for (int c = 0; c < 3; ++c) kf_poses[7 * (size_t)g + c] = be.tmpTrans[3 * s + c];
                 for (int c = 0; c < 4; ++c) kf_poses[7 * (size_t)g + 3 + c] = be.tmpQuat[4 * s + c];
             }
+            std::vector<int64_t> found;
+            if (defer) found = kba.finish(rand_below);                  // the previous keyframe's pairs: they had a whole cycle
             ba.setFrameFromScan(nw, be.ctx(), W - 1, tlb);
             kba.enqueue(nw + 1, kf_poses);
             const double t5b = now_s();
             be.marginalizeAndKeep(&ddt);
             const double t6 = now_s();
-            const std::vector<int64_t> found = kba.finish(rand_below);
+            if (!defer) found = kba.finish(rand_below);
             const double t7 = now_s();
             if (j == 0) continue;                                        // no prior yet, every first-touch cost: warm-up
             const double d[7] = {t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5b, (t5b - t5) + (t7 - t6)};
@@ -116,9 +122,10 @@ int main(int argc, char** argv) {
             long kk = 0; for (int32_t v : counts) kk += v; kept.push_back(kk);
             for (double v : be.tmpTrans) checksum += v;
         }
-        printf("{\"stages_ms\": {\"slide_and_new_scan\": %.4f, \"local_map\": %.4f, \"associate_enqueue\": %.4f, \"factors_while_the_gpu_searches_then_wait\": %.4f, "
+        if (defer) kba.finish(rand_below);                               // the last keyframe's pairs
+        printf("{\"batch_association_deferred\": %s, \"stages_ms\": {\"slide_and_new_scan\": %.4f, \"local_map\": %.4f, \"associate_enqueue\": %.4f, \"factors_while_the_gpu_searches_then_wait\": %.4f, "
                "\"solve\": %.4f, \"marginalize\": %.4f, \"batch_feature_association_enqueue_and_wait\": %.4f}, \"cycle_ms\": %.4f, \"cycle_ms_min_max\": [%.4f, %.4f], \"keyframes_per_s\": %.1f, \"map_points\": %d, \"iterations\": [",
-               st[0] * 1e3, st[1] * 1e3, st[2] * 1e3, st[3] * 1e3, st[4] * 1e3, st[5] * 1e3, st[6] * 1e3, cyc * 1e3, cmin * 1e3, cmax * 1e3, 1.0 / cyc, map_pts);
+               defer ? "true" : "false", st[0] * 1e3, st[1] * 1e3, st[2] * 1e3, st[3] * 1e3, st[4] * 1e3, st[5] * 1e3, st[6] * 1e3, cyc * 1e3, cmin * 1e3, cmax * 1e3, 1.0 / cyc, map_pts);
         for (size_t i = 0; i < iters.size(); ++i) printf("%s%d", i ? ", " : "", iters[i]);
         printf("], \"correspondences_kept\": [");
         for (size_t i = 0; i < kept.size(); ++i) printf("%s%ld", i ? ", " : "", kept[i]);

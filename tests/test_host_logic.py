@@ -184,3 +184,59 @@ def test_delta_q_pairs_follow_the_reference_walk():
     i4, j4, c4 = batch.delta_q_pairs(odo4, 3)
     for a, b, d in zip(i4, j4, c4):
         assert np.allclose(d, [-1 if b == 2 else 1, 0, 0, 0]), (a, b, d)
+
+
+def test_batch_gnss_epoch_selection_cpp_equals_python(tmp_path):
+    """glio::selectBatchGnssEpochs / glio::ddGroup (the host rules of optimizeBatchWithLandMark, Estimator.cpp:3086-3126 with getGlobalLowerUpperIdx :1635-1663,
+    and prepare<SYS>DDPsrData :1702-1860) against their Python twins on random streams, plus the rules themselves on hand-made cases: bracketing by the
+    closest keyframe strictly before / after, epochs outside the keyframe span or at a keyframe time without a neighbour dropped, the 1 m spacing gate
+    measured from the last ACCEPTED right keyframe (starting at the origin), the master satellite chosen with the signed-elevation quirk."""
+    import os
+    import subprocess
+    from glio_amd import batch
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "glio_amd", "host")
+    exe = str(tmp_path / "gsel")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", os.path.join(here, "host_gnss_select_test.cpp"), "-I" + os.path.join(here, "..", "..", "include"), "-o", exe])
+
+    def run(obs, kt, first_idx, n_poses, tr, sats=None):
+        parts = [f"{len(obs)} {len(kt)} {first_idx} {n_poses} {len(tr)}", " ".join(repr(float(x)) for x in obs), " ".join(repr(float(x)) for x in kt),
+                 " ".join(repr(float(x)) for x in np.asarray(tr).ravel())]
+        if sats is not None:
+            up, psr, ele, rp = sats
+            parts += [f"{len(up)} {len(rp)}", " ".join(str(int(x)) for x in up), " ".join(repr(float(x)) for x in psr), " ".join(repr(float(x)) for x in ele),
+                      " ".join(str(int(x)) for x in rp)]
+        out = subprocess.run([exe], input="\n".join(parts) + "\n", capture_output=True, text=True, check=True).stdout.splitlines()
+        ep = [(int(w[1]), int(w[2]), int(w[3]), float(w[4])) for w in (ln.split() for ln in out) if w[0] == "epoch"]
+        gr = {int(w[1]): (int(w[3]), [tuple(int(v) for v in t.split(":")) for t in w[5:]]) for w in (ln.split() for ln in out) if w[0] == "group"}
+        return ep, gr
+
+    rng = np.random.default_rng(11)
+    for trial in range(20):
+        K = int(rng.integers(5, 40))
+        kt = np.cumsum(rng.uniform(0.2, 0.6, K)) + 100.0
+        tr = np.cumsum(rng.normal(0, 1.2, (K, 3)), axis=0) + (0.0 if trial % 3 else 50.0)
+        obs = np.sort(rng.uniform(kt[0] - 1.0, kt[-1] + 1.0, int(rng.integers(1, 60))))
+        if trial % 4 == 0:
+            obs[::5] = kt[rng.integers(0, K, len(obs[::5]))]          # epochs exactly at keyframe times
+        first_idx, n_poses = int(rng.integers(1, 3)), K + int(rng.integers(0, 2))
+        got, _ = run(obs, kt, first_idx, min(n_poses, K + 1), tr)
+        want = batch.select_batch_gnss_epochs(obs, kt, first_idx, min(n_poses, K + 1), tr)
+        assert len(got) == len(want) and all(g[:3] == w[:3] and g[3] == w[3] for g, w in zip(got, want)), trial
+        for (e, lk, rk, ratio) in want:
+            assert lk < rk and kt[lk] < obs[e] < kt[rk] and 0.0 < ratio < 1.0
+    # hand-made: keyframes 1 s apart moving 0.6 m per keyframe along x from x = 10: epochs at 0.5 (before the first), 1.25, 1.5, 2.25, 3.0 (at a keyframe), 9.9 (after the last)
+    kt = np.arange(1.0, 6.0); tr = np.c_[10.0 + 0.6 * np.arange(5), np.zeros(5), np.zeros(5)]
+    got, _ = run([0.5, 1.25, 1.5, 2.25, 3.0, 4.5, 9.9], kt, 1, 5, tr)
+    # pose indices are 1-based and the search runs over [1, 5): keyframe_time[0..3]; 1.25 -> (1, 2) right keyframe x = 10.6: accepted (10.6 m from the origin);
+    # 1.5 -> the same right keyframe: 0 m from the last accepted: dropped; 2.25 -> right keyframe x = 11.2, 0.6 m: dropped; 3.0 -> (2, 4): strictly before / after,
+    # right keyframe x = 11.8, 1.2 m: accepted with ratio (4 - 3) / (4 - 2); 4.5 -> no pose after it inside [1, 5): dropped
+    assert got == [(1, 0, 1, 0.75), (4, 1, 3, 0.5)]
+    # double-difference groups: GPS 5, 12, 30 (+ 84), BeiDou 90, GLONASS 40, Galileo 60; PRN 12 has no station observation, PRN 30 a bad pseudorange
+    up, psr, ele = [5, 12, 30, 84, 90, 40, 60, 7], [2e7, 2e7, 500.0, 2e7, 2e7, 2e7, 2e7, 2e7], [30.0, 80.0, 70.0, -45.0, 10.0, 20.0, 15.0, 40.0]
+    rp = [7, 84, 5, 90, 60, 40, 30]
+    _, gr = run([1.5], [1.0, 2.0], 1, 2, [[5, 0, 0], [9, 0, 0]], sats=(up, psr, ele, rp))
+    for sysid in range(4):
+        u, r, m = batch.dd_group(sysid, up, psr, ele, rp)
+        assert gr[sysid] == (m, list(zip(u, r)))
+    # GPS pairs in rover order: (5 -> station 2), (84 -> 1), (7 -> 0); master: 30 deg sets max 30; |-45| > 30 sets max to -45 (signed!); |40| > -45 -> the LAST pair
+    assert gr[0] == (2, [(0, 2), (3, 1), (7, 0)]) and gr[1] == (0, [(4, 3)]) and gr[2] == (0, [(5, 5)]) and gr[3] == (0, [(6, 4)])
