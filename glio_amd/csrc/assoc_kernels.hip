@@ -19,6 +19,17 @@
 //
 // Roofline: gather-bound.  Algorithmic bytes per query = 16 (query) + 5*16 (true neighbours) + 40
 // (output record) = 136 B; the 27-cell candidate scan is served by L2.
+//
+// The kernels of this file, in the order a call uses them:
+//   K1   k_hash_clear / k_hash_insert / k_cell_alloc / k_scatter (+ the _multi forms: 64 keyframe hashes per launch): points ordered by (cell, octant)
+//   bin  k_qbin_count / _alloc / _scatter: presort of an uploaded cloud into 5 m blocks (once per cloud); k_qbin_tile: per call, queries grouped by cell
+//        inside tiles of 1024 presorted points -> units of <= 16 queries of one cell (a single launch row) or (tile, cell) segments (merged window);
+//        k_gbin_alloc / k_gbin_scatter: the segments of ALL rows laid out cell-major, units of <= 64 queries
+//   5-NN k_knn5_near<64> (merged window: near block + certificate, one unit per wavefront), k_knn5_rest (what it hands on: single queries by 16-lane
+//        groups, sixteen-query groups by the 27-cell tiled search); k_knn5_tile (single rows: the 27-cell tiled search of round 4);
+//        k_knn5 (debug mode 1: one 16-lane group per query, no binning), k_knn5_near<16> (debug mode 3: near block row by row)
+//   fit  k_plane_fit<BATCH>: one lane per query, gates, record, per-workgroup kept counts; k_compact / k_scan_pairs + k_compact_pairs: order-preserving
+//   batch association (glio_bassoc_*): resident per-keyframe hashes, pair-major records appended on the device
 #include <cfloat>
 #include <cstdlib>
 #include <cstring>
