@@ -3598,7 +3598,14 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
             a.fused_chain = 2;
             // helper workgroups (one per keyframe) pre-sum the candidate's block entries: GLIO_CHAIN_HELPERS=0 switches them off (A/B)
             static const bool helpers_off = getenv("GLIO_CHAIN_HELPERS") && atoi(getenv("GLIO_CHAIN_HELPERS")) == 0;
-            r.helpers = helpers_off ? 0 : c->W; r.hsum = c->arrow.d_chain_sum; r.hdone = c->arrow.d_chain_done;
+            // Workgroup 0 WAITS for the helpers' completion words inside the launch, and every workgroup of this launch reserves the whole dynamic LDS
+            // grant, i.e. a CU of its own: the hand-over needs 1 + W CUs that the launch can actually get.  HIP promises no forward progress between
+            // workgroups, so the helpers are used only when the device has room to spare (>= 2 (1 + W) CUs); a deployment that masks CUs or partitions the
+            // device below that must set GLIO_CHAIN_HELPERS=0 (the step then sums the blocks itself: 4 us slower, no cross-workgroup wait).  INTEGRATION.md section 5.
+            static int n_cu = -1;
+            if (n_cu < 0) { hipDeviceProp_t prop; n_cu = hipGetDeviceProperties(&prop, c->device) == hipSuccess ? prop.multiProcessorCount : 0; }
+            const bool room = n_cu >= 2 * (1 + c->W);
+            r.helpers = (helpers_off || !room) ? 0 : c->W; r.hsum = c->arrow.d_chain_sum; r.hdone = c->arrow.d_chain_done;
             r.hseq = c->arrow.chain_seq; c->arrow.chain_seq = c->arrow.chain_seq % (1 << 29) + 1;
             hipLaunchKernelGGL(k_chain_step, dim3(1 + r.helpers), dim3(KC_THREADS), lds_step, c->stream, r, a, G);
             return;                                   // the one launch is the whole step
