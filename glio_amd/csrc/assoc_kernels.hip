@@ -112,11 +112,12 @@ __device__ __forceinline__ int oct_of(const float4 p, const float inv_cell) {
     const float ih = inv_cell * 2.0f;
     return ((int)floorf(p.x * ih) & 1) | (((int)floorf(p.y * ih) & 1) << 1) | (((int)floorf(p.z * ih) & 1) << 2);
 }
-__device__ __forceinline__ void hash_clear_slot(const int i, const int cap, unsigned long long* keys, unsigned* cnt8, int* total, int4* ent, uint4* sub) {
+// (with_ent = 0 when a range allocation follows: k_cell_alloc writes ent and sub of EVERY slot from the keys, clearing them first only moved 32 of 72 B per slot)
+__device__ __forceinline__ void hash_clear_slot(const int i, const int cap, unsigned long long* keys, unsigned* cnt8, int* total, int4* ent, uint4* sub, const int with_ent) {
     if (i < cap) {
         keys[i] = KEY_EMPTY;
         reinterpret_cast<uint4*>(cnt8)[2 * (size_t)i] = make_uint4(0, 0, 0, 0); reinterpret_cast<uint4*>(cnt8)[2 * (size_t)i + 1] = make_uint4(0, 0, 0, 0);
-        ent[i] = make_int4(-1, -1, 0, 0); sub[i] = make_uint4(0, 0, 0, 0);
+        if (with_ent) { ent[i] = make_int4(-1, -1, 0, 0); sub[i] = make_uint4(0, 0, 0, 0); }
     }
     if (i == 0) *total = 0;
 }
@@ -134,6 +135,57 @@ __device__ __forceinline__ void hash_insert_point(const float4 p, const int i, c
     const int so = (int)(s * 8u) + oct_of(p, inv_cell);
     pt_rank[i] = (int)atomicAdd(&cnt8[so], 1u);
     pt_slot[i] = so;
+}
+// The same per TILE of HI_THREADS consecutive points, aggregated in LDS first (round 5).  Every returning device-scope atomic is a round trip to the memory side and
+// they pass at ~4 per ns whatever the launch: the per-point form spent 187 us inserting the 12 x 64 k points of one keyframe's batch association.  A tile groups
+// its points by cell in an LDS table (LDS atomics), then issues ONE global key insertion per distinct cell and ONE counting atomic per distinct (cell, octant);
+// the points take their ranks from the LDS counts.  Clouds that arrive spatially ordered (the presorted keyframe clouds, the voxel-sorted local map) put ~10-25
+// points into a cell of a tile; a cloud in random order gains nothing and loses nothing.
+#define HI_THREADS 512
+#define HI_SLOTS 1024
+struct HashInsertLds { unsigned long long key[HI_SLOTS]; unsigned cnt[HI_SLOTS][8]; unsigned base[HI_SLOTS][8]; int gslot[HI_SLOTS]; };
+__device__ __forceinline__ void hash_insert_tile(HashInsertLds& L, const float4* __restrict__ pts, const int n, const int tile0, const float inv_cell, unsigned long long* keys,
+                                                 unsigned* cnt8, int* pt_slot, int* pt_rank, const int cap) {
+    const int tid = threadIdx.x;
+    for (int q = tid; q < HI_SLOTS; q += HI_THREADS) {
+        L.key[q] = KEY_EMPTY;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) L.cnt[q][o] = 0;
+    }
+    __syncthreads();
+    const int i = tile0 + tid;
+    int ls = 0, oc = 0;
+    unsigned lrank = 0;
+    if (i < n) {
+        const float4 p = pts[i];
+        const unsigned long long key = pack_key(cell_of(p.x, inv_cell), cell_of(p.y, inv_cell), cell_of(p.z, inv_cell));
+        unsigned q = hash_key(key) & (HI_SLOTS - 1);
+        for (;;) {
+            const unsigned long long prev = atomicCAS(&L.key[q], KEY_EMPTY, key);
+            if (prev == KEY_EMPTY || prev == key) break;
+            q = (q + 1) & (HI_SLOTS - 1);
+        }
+        ls = (int)q; oc = oct_of(p, inv_cell);
+        lrank = atomicAdd(&L.cnt[q][oc], 1u);
+    }
+    __syncthreads();
+    for (int q = tid; q < HI_SLOTS; q += HI_THREADS) {
+        const unsigned long long key = L.key[q];
+        if (key == KEY_EMPTY) continue;
+        const int cx = (int)((key >> 42) & 0x1fffffu) - (1 << 20), cy = (int)((key >> 21) & 0x1fffffu) - (1 << 20), cz = (int)(key & 0x1fffffu) - (1 << 20);
+        unsigned g = home_slot(cx, cy, cz, cap);
+        for (;;) {
+            unsigned long long prev = keys[g];                         // a stale EMPTY only costs the CAS; a key, once seen, stays
+            if (prev != key) prev = atomicCAS(&keys[g], KEY_EMPTY, key);
+            if (prev == KEY_EMPTY || prev == key) break;
+            g = (g + 1) & (cap - 1);
+        }
+        L.gslot[q] = (int)g;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) { const unsigned c = L.cnt[q][o]; if (c) L.base[q][o] = atomicAdd(&cnt8[g * 8u + o], c); }
+    }
+    __syncthreads();
+    if (i < n) { pt_slot[i] = L.gslot[ls] * 8 + oc; pt_rank[i] = (int)(L.base[ls][oc] + lrank); }
 }
 // range allocation: one atomic per 1024-slot workgroup (block-wide exclusive scan of the cell counts; same-address atomics
 // execute one after the other at the memory side, a wavefront-granular version spent 14 us on 2048 of them)
@@ -172,24 +224,25 @@ __device__ __forceinline__ void cell_alloc_slot(const int i, const int cap, cons
                              : make_uint4(pre[0] | (pre[1] << 16), pre[2] | (pre[3] << 16), pre[4] | (pre[5] << 16), pre[6] | (pre[7] << 16));
     }
 }
+// (orig = the index the point has in the caller's cloud: i itself, or what a presorted cloud carries in .w)
 __device__ __forceinline__ void scatter_point(float4 p, const int i, const int* __restrict__ pt_slot, const int* __restrict__ pt_rank, const unsigned* __restrict__ cnt8,
-                                              const int4* __restrict__ ent, float4* __restrict__ sorted) {
+                                              const int4* __restrict__ ent, float4* __restrict__ sorted, const int orig) {
     const int so = pt_slot[i], s = so >> 3, oc = so & 7;
     const uint4 a = reinterpret_cast<const uint4*>(cnt8)[2 * (size_t)s], b = reinterpret_cast<const uint4*>(cnt8)[2 * (size_t)s + 1];
     const unsigned o[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     unsigned pre = 0;
 #pragma unroll
     for (int k = 0; k < 7; ++k) pre += k < oc ? o[k] : 0u;
-    p.w = __int_as_float(i);          // original index rides in .w (map intensity is not used by the path)
+    p.w = __int_as_float(orig);       // original index rides in .w (map intensity is not used by the path)
     sorted[ent[s].z + (int)pre + pt_rank[i]] = p;
 }
 
-__global__ void k_hash_clear(unsigned long long* keys, unsigned* cnt8, int cap, int* total, int4* ent, uint4* sub) {
-    hash_clear_slot(blockIdx.x * blockDim.x + threadIdx.x, cap, keys, cnt8, total, ent, sub);
+__global__ void k_hash_clear(unsigned long long* keys, unsigned* cnt8, int cap, int* total, int4* ent, uint4* sub, int with_ent) {
+    hash_clear_slot(blockIdx.x * blockDim.x + threadIdx.x, cap, keys, cnt8, total, ent, sub, with_ent);
 }
-__global__ void k_hash_insert(const float4* __restrict__ pts, int n, float inv_cell, unsigned long long* keys, unsigned* cnt8, int* pt_slot, int* pt_rank, int cap) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) hash_insert_point(pts[i], i, inv_cell, keys, cnt8, pt_slot, pt_rank, cap);
+__global__ __launch_bounds__(HI_THREADS) void k_hash_insert(const float4* __restrict__ pts, int n, float inv_cell, unsigned long long* keys, unsigned* cnt8, int* pt_slot, int* pt_rank, int cap) {
+    __shared__ HashInsertLds L;
+    hash_insert_tile(L, pts, n, blockIdx.x * HI_THREADS, inv_cell, keys, cnt8, pt_slot, pt_rank, cap);
 }
 __global__ __launch_bounds__(1024) void k_cell_alloc(const unsigned* __restrict__ cnt8, int cap, int* total, const unsigned long long* __restrict__ keys,
                                                      int4* __restrict__ ent, uint4* __restrict__ sub) {
@@ -199,7 +252,7 @@ __global__ __launch_bounds__(1024) void k_cell_alloc(const unsigned* __restrict_
 __global__ void k_scatter(const float4* __restrict__ pts, int n, const int* __restrict__ pt_slot, const int* __restrict__ pt_rank, const unsigned* __restrict__ cnt8,
                           const int4* __restrict__ ent, float4* __restrict__ sorted) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) scatter_point(pts[i], i, pt_slot, pt_rank, cnt8, ent, sorted);
+    if (i < n) scatter_point(pts[i], i, pt_slot, pt_rank, cnt8, ent, sorted, i);
 }
 
 // ---- 5x3 column-pivoted Householder least squares, all indices compile-time (stays in registers)
@@ -603,30 +656,60 @@ __global__ __launch_bounds__(256) void k_knn5(const AssocArgs a, const float4* _
 #define QT_SLOTS 2048
 #define PRESORT_CELL 5.0f
 
-__global__ __launch_bounds__(256) void k_qbin_count(const AssocArgs a, const float4* __restrict__ scan) {
+// (per tile of QC_THREADS points the blocks are grouped in LDS first -- one global key insertion and ONE returning counting atomic per distinct block of the
+//  tile instead of two per point: returning device-scope atomics pass at ~4 per ns, this kernel took 20 us for 64 k points; a LiDAR scan in ring order puts
+//  most of a tile into a handful of blocks)
+#define QC_THREADS 512
+#define QC_SLOTS 1024
+__global__ __launch_bounds__(QC_THREADS) void k_qbin_count(const AssocArgs a, const float4* __restrict__ scan) {
+    __shared__ unsigned long long s_key[QC_SLOTS];
+    __shared__ int s_cnt[QC_SLOTS], s_base[QC_SLOTS], s_g[QC_SLOTS];
     const AssocSlot sl = assoc_slot(a);
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= sl.n) return;
-    const float4 pl = scan[sl.qoff + i];
-    const double pin[3] = {(double)pl.x, (double)pl.y, (double)pl.z};
-    double po[3];
-    a_qrot(sl.q, pin, po);
-    const float px = (float)(po[0] + sl.t[0]), py = (float)(po[1] + sl.t[1]), pz = (float)(po[2] + sl.t[2]);
-    const int cx = cell_of(px, a.inv_cell), cy = cell_of(py, a.inv_cell), cz = cell_of(pz, a.inv_cell);
+    const int tid = threadIdx.x, i = blockIdx.x * QC_THREADS + tid;
+    if ((int)(blockIdx.x * QC_THREADS) >= sl.n) return;
+    for (int q = tid; q < QC_SLOTS; q += QC_THREADS) { s_key[q] = KEY_EMPTY; s_cnt[q] = 0; }
+    __syncthreads();
     const int capq = a.kb.capq;
     unsigned long long* keys = a.kb.keys + (size_t)blockIdx.y * capq;
-    const unsigned long long key = pack_key(cx, cy, cz);
-    unsigned s = home_slot(cx, cy, cz, capq);
-    for (;;) {
-        unsigned long long prev = keys[s];                         // a stale EMPTY only costs the CAS; a key, once seen, stays
-        if (prev != key) prev = atomicCAS(&keys[s], KEY_EMPTY, key);
-        if (prev == KEY_EMPTY || prev == key) break;
-        s = (s + 1) & (capq - 1);
+    float px = 0, py = 0, pz = 0;
+    int ls = 0, lrank = 0;
+    if (i < sl.n) {
+        const float4 pl = scan[sl.qoff + i];
+        const double pin[3] = {(double)pl.x, (double)pl.y, (double)pl.z};
+        double po[3];
+        a_qrot(sl.q, pin, po);
+        px = (float)(po[0] + sl.t[0]); py = (float)(po[1] + sl.t[1]); pz = (float)(po[2] + sl.t[2]);
+        const unsigned long long key = pack_key(cell_of(px, a.inv_cell), cell_of(py, a.inv_cell), cell_of(pz, a.inv_cell));
+        unsigned q = hash_key(key) & (QC_SLOTS - 1);
+        for (;;) {
+            const unsigned long long prev = atomicCAS(&s_key[q], KEY_EMPTY, key);
+            if (prev == KEY_EMPTY || prev == key) break;
+            q = (q + 1) & (QC_SLOTS - 1);
+        }
+        ls = (int)q;
+        lrank = atomicAdd(&s_cnt[q], 1);
     }
-    const int rank = atomicAdd(&a.kb.cnt[(size_t)blockIdx.y * capq + s], 1);
-    a.kb.qslot[sl.woff + i] = (int)s;
-    a.kb.qrank[sl.woff + i] = rank;
-    a.kb.qtmp[sl.woff + i] = make_float4(px, py, pz, __int_as_float(i));
+    __syncthreads();
+    for (int q = tid; q < QC_SLOTS; q += QC_THREADS) {
+        const unsigned long long key = s_key[q];
+        if (key == KEY_EMPTY) continue;
+        const int cx = (int)((key >> 42) & 0x1fffffu) - (1 << 20), cy = (int)((key >> 21) & 0x1fffffu) - (1 << 20), cz = (int)(key & 0x1fffffu) - (1 << 20);
+        unsigned s = home_slot(cx, cy, cz, capq);
+        for (;;) {
+            unsigned long long prev = keys[s];                         // a stale EMPTY only costs the CAS; a key, once seen, stays
+            if (prev != key) prev = atomicCAS(&keys[s], KEY_EMPTY, key);
+            if (prev == KEY_EMPTY || prev == key) break;
+            s = (s + 1) & (capq - 1);
+        }
+        s_g[q] = (int)s;
+        s_base[q] = atomicAdd(&a.kb.cnt[(size_t)blockIdx.y * capq + s], s_cnt[q]);
+    }
+    __syncthreads();
+    if (i < sl.n) {
+        a.kb.qslot[sl.woff + i] = s_g[ls];
+        a.kb.qrank[sl.woff + i] = s_base[ls] + lrank;
+        a.kb.qtmp[sl.woff + i] = make_float4(px, py, pz, __int_as_float(i));
+    }
 }
 
 __global__ __launch_bounds__(1024) void k_qbin_alloc(const AssocArgs a) {
@@ -1633,7 +1716,7 @@ static void enqueue_presort(hipStream_t stream, KnnBinHost* kb, const float4* cl
     a.kb = kb->d; a.kb.qs = ps;
     a.kb.capq = next_pow2(2 * (n > 512 ? n : 512));
     if (a.kb.capq > kb->capq_max) a.kb.capq = kb->capq_max;
-    hipLaunchKernelGGL(k_qbin_count, dim3((n + 255) / 256), dim3(256), 0, stream, a, cloud);
+    hipLaunchKernelGGL(k_qbin_count, dim3((n + QC_THREADS - 1) / QC_THREADS), dim3(QC_THREADS), 0, stream, a, cloud);
     hipLaunchKernelGGL(k_qbin_alloc, dim3(a.kb.capq / 1024), dim3(1024), 0, stream, a);
     hipLaunchKernelGGL(k_qbin_scatter, dim3((n + 255) / 256), dim3(256), 0, stream, a);
     hipMemsetAsync(kb->d.counters, 0, 16, stream);
@@ -1754,9 +1837,9 @@ static void enqueue_build(glio_ctx* c, int n) {
     int cap = next_pow2(2 * (n > 512 ? n : 512));          // sized for THIS map: a smaller table stays in L2
     if (cap > w->table_cap) cap = w->table_cap;
     w->cap_eff = cap;
-    hipLaunchKernelGGL(k_hash_clear, dim3((cap + 255) / 256), dim3(256), 0, c->stream, w->d_keys, w->d_cnt8, cap, w->d_total, w->d_ent, w->d_sub);
+    hipLaunchKernelGGL(k_hash_clear, dim3((cap + 255) / 256), dim3(256), 0, c->stream, w->d_keys, w->d_cnt8, cap, w->d_total, w->d_ent, w->d_sub, n == 0 ? 1 : 0);
     if (n == 0) return;
-    hipLaunchKernelGGL(k_hash_insert, dim3((n + 255) / 256), dim3(256), 0, c->stream, w->d_map_raw, n, w->inv_cell, w->d_keys, w->d_cnt8, w->d_pt_slot, w->d_pt_rank, cap);
+    hipLaunchKernelGGL(k_hash_insert, dim3((n + HI_THREADS - 1) / HI_THREADS), dim3(HI_THREADS), 0, c->stream, w->d_map_raw, n, w->inv_cell, w->d_keys, w->d_cnt8, w->d_pt_slot, w->d_pt_rank, cap);
     hipLaunchKernelGGL(k_cell_alloc, dim3((cap + 1023) / 1024), dim3(1024), 0, c->stream, w->d_cnt8, cap, w->d_total, w->d_keys, w->d_ent, w->d_sub);
     hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, c->stream, w->d_map_raw, n, w->d_pt_slot, w->d_pt_rank, w->d_cnt8, w->d_ent, c->d_map_sorted);
 }
@@ -2033,23 +2116,24 @@ struct FrameBuild {
 };
 __global__ void k_hash_clear_multi(const FrameBuild* __restrict__ fb) {
     const FrameBuild f = fb[blockIdx.y];
-    hash_clear_slot(blockIdx.x * blockDim.x + threadIdx.x, f.tc, f.keys, f.cnt8, f.total, f.ent, f.sub);
+    hash_clear_slot(blockIdx.x * blockDim.x + threadIdx.x, f.tc, f.keys, f.cnt8, f.total, f.ent, f.sub, f.n == 0 ? 1 : 0);
 }
 __global__ void k_transform_cloud_multi(const FrameBuild* __restrict__ fb) {
     const FrameBuild f = fb[blockIdx.y];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;          // transformCloud, Estimator.cpp:1517-1546
     if (i >= f.n) return;
     const double t[3] = {f.pose[0], f.pose[1], f.pose[2]}, q[4] = {f.pose[3], f.pose[4], f.pose[5], f.pose[6]};
-    const float4 p = f.local[i];
-    const double pin[3] = {(double)p.x, (double)p.y, (double)p.z};
+    const float4 p = f.local[i];                                  // (the PRESORTED copy of the keyframe cloud: w = index in the cloud; consecutive points are neighbours,
+    const double pin[3] = {(double)p.x, (double)p.y, (double)p.z};    //  which is what lets the tile insert below aggregate its atomics)
     double po[3];
     a_qrot(q, pin, po);
     f.global[i] = make_float4((float)(po[0] + t[0]), (float)(po[1] + t[1]), (float)(po[2] + t[2]), p.w);
 }
-__global__ void k_hash_insert_multi(const FrameBuild* __restrict__ fb, const float inv_cell) {
+__global__ __launch_bounds__(HI_THREADS) void k_hash_insert_multi(const FrameBuild* __restrict__ fb, const float inv_cell) {
+    __shared__ HashInsertLds L;
     const FrameBuild f = fb[blockIdx.y];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < f.n) hash_insert_point(f.global[i], i, inv_cell, f.keys, f.cnt8, f.pt_slot, f.pt_rank, f.tc);
+    if ((int)(blockIdx.x * HI_THREADS) >= f.n) return;
+    hash_insert_tile(L, f.global, f.n, blockIdx.x * HI_THREADS, inv_cell, f.keys, f.cnt8, f.pt_slot, f.pt_rank, f.tc);
 }
 __global__ __launch_bounds__(1024) void k_cell_alloc_multi(const FrameBuild* __restrict__ fb) {
     __shared__ int s_w[16], s_base;
@@ -2060,7 +2144,7 @@ __global__ __launch_bounds__(1024) void k_cell_alloc_multi(const FrameBuild* __r
 __global__ void k_scatter_multi(const FrameBuild* __restrict__ fb) {
     const FrameBuild f = fb[blockIdx.y];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < f.n) scatter_point(f.global[i], i, f.pt_slot, f.pt_rank, f.cnt8, f.ent, f.sorted);
+    if (i < f.n) scatter_point(f.global[i], i, f.pt_slot, f.pt_rank, f.cnt8, f.ent, f.sorted, __float_as_int(f.global[i].w));
 }
 
 // Compaction of the kept records, pair major, for a CHUNK of pairs per launch (blockIdx.y / wavefront = pair of the chunk):
@@ -2151,7 +2235,14 @@ int glio_bassoc_create(int device, int K, int max_points_per_frame, int64_t max_
     glio_bassoc* b = new glio_bassoc();
     memset(b, 0, sizeof *b);
     b->device = device; b->K = K; b->cap = max_points_per_frame; b->max_con = max_constraints;
-    BA_CHECK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    {   // LOW priority: the pair searches are wide, throughput-bound launches that a keyframe call enqueues beside its own latency-bound kernels (marginalization,
+        // local map, the solve's one-CU steps on the context's stream) -- those must get their CUs first (GLIO_BASSOC_PRIORITY=0: default priority, for A/B)
+        int least = 0, greatest = 0;
+        const char* e = getenv("GLIO_BASSOC_PRIORITY");
+        if ((!e || atoi(e) != 0) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+            BA_CHECK(hipStreamCreateWithPriority(&b->stream, hipStreamNonBlocking, least));
+        else BA_CHECK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    }
     b->cell = fmaxf(1.25f, sqrtf(1.5f) * 1.0001f);
     b->inv_cell = 1.0f / b->cell;
     const size_t cap = (size_t)b->cap;
@@ -2287,7 +2378,7 @@ static int bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const in
                 d.keys = b->d_bkeys + (size_t)q * f.table_cap; d.cnt8 = b->d_bcnt8 + (size_t)q * f.table_cap * 8;
                 d.pt_slot = b->d_bslot + (size_t)q * b->cap; d.pt_rank = b->d_brank + (size_t)q * b->cap;
                 d.ent = f.d_ent; d.sub = f.d_sub; d.sorted = f.d_sorted;
-                d.local = b->d_local + (size_t)k * b->cap; d.global = b->d_global + (size_t)q * b->cap; d.pose = b->d_poses + 7 * k; d.total = b->d_total + q; d.n = n; d.tc = tc;
+                d.local = b->d_local_ps + (size_t)k * b->cap; d.global = b->d_global + (size_t)q * b->cap; d.pose = b->d_poses + 7 * k; d.total = b->d_total + q; d.n = n; d.tc = tc;
                 if (tc > max_tc) max_tc = tc;
                 if (n > max_n) max_n = n;
             }
@@ -2296,7 +2387,7 @@ static int bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const in
             hipLaunchKernelGGL(k_hash_clear_multi, dim3((max_tc + 255) / 256, nb), dim3(256), 0, b->stream, dfb);
             if (max_n == 0) continue;
             hipLaunchKernelGGL(k_transform_cloud_multi, dim3((max_n + 255) / 256, nb), dim3(256), 0, b->stream, dfb);
-            hipLaunchKernelGGL(k_hash_insert_multi, dim3((max_n + 255) / 256, nb), dim3(256), 0, b->stream, dfb, b->inv_cell);
+            hipLaunchKernelGGL(k_hash_insert_multi, dim3((max_n + HI_THREADS - 1) / HI_THREADS, nb), dim3(HI_THREADS), 0, b->stream, dfb, b->inv_cell);
             hipLaunchKernelGGL(k_cell_alloc_multi, dim3((max_tc + 1023) / 1024, nb), dim3(1024), 0, b->stream, dfb);
             hipLaunchKernelGGL(k_scatter_multi, dim3((max_n + 255) / 256, nb), dim3(256), 0, b->stream, dfb);
         }
@@ -2376,9 +2467,17 @@ int glio_bassoc_set_frame_from_scan(glio_bassoc* b, int k, glio_ctx* c, int slot
     BA_CHECK(hipSetDevice(b->device));
     { const int rf = bassoc_finish(b, nullptr, nullptr); if (rf != GLIO_OK) return rf; }
     BA_CHECK(hipStreamSynchronize(c->stream));                       // (the upload of the scan ran on the context's stream)
-    if (n > 0) hipLaunchKernelGGL(k_copy_offset, dim3((n + 255) / 256), dim3(256), 0, b->stream, c->d_scan + (size_t)glio_scan_row(c, slot) * c->cap, n,
-                                  lidar_offset[0], lidar_offset[1], lidar_offset[2], b->d_local + (size_t)k * b->cap);
-    enqueue_presort(b->stream, b->kb, b->d_local + (size_t)k * b->cap, n, b->d_local_ps + (size_t)k * b->cap);
+    // the context presorted this scan when it was uploaded: its presorted copy (same points, w = index in the scan) is taken over with the same offset instead
+    // of presorting the cloud a second time (any spatially compact order serves: results are written at the original indices)
+    if (n > 0) {
+        const size_t row = (size_t)glio_scan_row(c, slot) * c->cap;
+        hipLaunchKernelGGL(k_copy_offset, dim3((n + 255) / 256), dim3(256), 0, b->stream, c->d_scan + row, n, lidar_offset[0], lidar_offset[1], lidar_offset[2],
+                           b->d_local + (size_t)k * b->cap);
+        if (c->assoc && c->assoc->d_ps)
+            hipLaunchKernelGGL(k_copy_offset, dim3((n + 255) / 256), dim3(256), 0, b->stream, c->assoc->d_ps + row, n, lidar_offset[0], lidar_offset[1], lidar_offset[2],
+                               b->d_local_ps + (size_t)k * b->cap);
+        else enqueue_presort(b->stream, b->kb, b->d_local + (size_t)k * b->cap, n, b->d_local_ps + (size_t)k * b->cap);
+    }
     BA_CHECK(hipGetLastError());
     b->h_n[k] = n;
     return GLIO_OK;

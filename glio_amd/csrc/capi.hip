@@ -126,7 +126,14 @@ static int create_body(int device, const glio_opts* opts, glio_ctx* c) {
     const int n_max = 15 * W + std::max(0, opts->max_ddt_epochs);
     c->opts = *opts; c->device = device; c->W = W; c->cap = opts->max_points_per_scan;
     c->n_ddt_max = std::max(0, opts->max_ddt_epochs); c->n_max = n_max;
-    GLIO_HIP_CHECK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    {   // the window's kernels are short and latency-bound (one-CU trust-region steps, marginalization, local map): highest priority, so that wide launches of
+        // other streams (the batch association of the same keyframe) do not sit in front of them
+        int least = 0, greatest = 0;
+        const char* e = getenv("GLIO_CTX_PRIORITY");
+        if ((!e || atoi(e) != 0) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+            GLIO_HIP_CHECK(hipStreamCreateWithPriority(&c->own_stream, hipStreamNonBlocking, greatest));
+        else GLIO_HIP_CHECK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    }
     c->stream = c->own_stream;
     const size_t wc = (size_t)W * c->cap;
     ALLOC(c->d_pts, wc * sizeof(float4)); ALLOC(c->d_planes, wc * sizeof(float4)); ALLOC(c->d_scores, wc * sizeof(double));

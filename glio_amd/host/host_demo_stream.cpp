@@ -63,7 +63,9 @@ int main(int argc, char** argv) {
         // defer = 1: the batch association of keyframe j is only ENQUEUED inside call j (own stream) and collected inside call j + 1, right before that call's
         // own enqueue -- its searches then run beside the next keyframe's solve (one CU busy) instead of beside nothing.  The records reach gl_vec_surf_* one
         // keyframe later than in the reference, which only the batch thread could notice; the default (0) returns from the call with them in place.
-        const bool defer = argc > 4 && atoi(argv[4]) != 0;
+        const bool defer = argc > 4 && atoi(argv[4]) == 1;
+        // 2 = the batch association enqueued AFTER the marginalization (nothing of the call overlaps it) -- A/B of the default order
+        const bool after_marg = argc > 4 && atoi(argv[4]) == 2;
         glio::BatchAssociationBackend ba(total_kf, pts, (int64_t)(NK + 2) * 2 * SR * pts, device);
         glio::KeyframeBatchAssociation kba(ba, SR, RES);
         std::mt19937_64 rng(20260925);
@@ -105,11 +107,11 @@ int main(int argc, char** argv) {
             }
             std::vector<int64_t> found;
             if (defer) found = kba.finish(rand_below);                  // the previous keyframe's pairs: they had a whole cycle
-            ba.setFrameFromScan(nw, be.ctx(), W - 1, tlb);
-            kba.enqueue(nw + 1, kf_poses);
+            if (!after_marg) { ba.setFrameFromScan(nw, be.ctx(), W - 1, tlb); kba.enqueue(nw + 1, kf_poses); }
             const double t5b = now_s();
             be.marginalizeAndKeep(&ddt);
             const double t6 = now_s();
+            if (after_marg) { ba.setFrameFromScan(nw, be.ctx(), W - 1, tlb); kba.enqueue(nw + 1, kf_poses); }
             if (!defer) found = kba.finish(rand_below);
             const double t7 = now_s();
             if (j == 0) continue;                                        // no prior yet, every first-touch cost: warm-up

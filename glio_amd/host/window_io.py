@@ -165,7 +165,7 @@ def write_stream(path, long, wins, W, n_keyframes, pts, lm_width=50, leaf=0.4, b
 
 def run_demo_stream(path, device=0, env=None, search_range=6, defer=False):
     import json
-    r = subprocess.run([build_demo_stream(), path, str(device), str(search_range), "1" if defer else "0"], capture_output=True, text=True, env=env)
+    r = subprocess.run([build_demo_stream(), path, str(device), str(search_range), str(int(defer))], capture_output=True, text=True, env=env)
     if r.returncode != 0:
         raise RuntimeError("host_demo_stream failed (%d): %s" % (r.returncode, (r.stderr or r.stdout)[-600:]))
     return json.loads(next(ln for ln in r.stdout.splitlines() if ln.startswith("{")))
