@@ -1667,7 +1667,8 @@ static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 struct KnnBinHost { KnnBin d; int rows, cap, capq_max; };
 static unsigned long long* g_knn_dbg = nullptr;      // statistics of the near-block search (glio_debug_knn_stats)
 static int g_gbin_cap = 0;            // test knob (glio_debug_set_gbin_cap): cell-table size of the merged-window grouping, 0 = from the map
-static int g_knn_mode = 0;           // 0 = window calls: the queries of all slots grouped by cell together, near block first (k_knn5_near<64>), the rest by
+static int knn_mode_from_env() { const char* e = getenv("GLIO_KNN_MODE"); const int m = e ? atoi(e) : 0; return m >= 0 && m <= 3 ? m : 0; }      // (A/B of whole programs, e.g. host_demo_stream)
+static int g_knn_mode = knn_mode_from_env();           // 0 = window calls: the queries of all slots grouped by cell together, near block first (k_knn5_near<64>), the rest by
                                      //     k_knn5_rest; single rows: the 27-cell tiled search (k_knn5_tile);  1 = one 16-lane group per query (k_knn5);
                                      // 2 = every query by the 27-cell tiled search (the round-4 path);  3 = near block first (k_knn5_near<16>), every launch
                                      //     row by itself; glio_debug_set_knn_mode
