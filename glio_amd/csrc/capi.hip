@@ -37,6 +37,11 @@ struct CtxExtra {
     // the pre-integrations of the last glio_set_imu and what was derived from them (inverse covariance root, 15^3 flops each): after a
     // slide W - 2 of the W - 1 edges are the same pre-integrations one slot lower, and only the new one is digested again
     std::vector<glio_preint> imu_raw; std::vector<ImuEdgeDev> imu_dig;
+    // early uploads (glio_set_imu, glio_set_gnss): a stream of their own and two pinned blocks with device mirrors, see stage_begin_early
+    hipStream_t up_stream = nullptr; hipEvent_t ev_up = nullptr;
+    struct UpArena { char* h = nullptr; char* d = nullptr; size_t cap = 0; hipEvent_t ev_free = nullptr; bool pending = false; } up[2];
+    int up_next = 0, up_cur = -1, up_mode = -1;
+    char* sv_h = nullptr; char* sv_d = nullptr; size_t sv_cap = 0;
 };
 // the extras hang off the context itself (glio_ctx::extra): no process-global registry, so independent contexts can be
 // created, used and destroyed from different threads concurrently (Estimator.cpp:5398-5404)
@@ -257,6 +262,10 @@ void glio_destroy(glio_ctx* c) {
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (CtxExtra* ex = extra_of(c)) {
+        if (ex->up_stream) hipStreamSynchronize(ex->up_stream);
+        for (auto& a : ex->up) { if (a.h) hipHostFree(a.h); if (a.d) hipFree(a.d); if (a.ev_free) hipEventDestroy(a.ev_free); }
+        if (ex->ev_up) hipEventDestroy(ex->ev_up);
+        if (ex->up_stream) hipStreamDestroy(ex->up_stream);
         if (ex->gx.d_runs) hipFree(ex->gx.d_runs);
         if (ex->gx.d_prior_colblk) hipFree(ex->gx.d_prior_colblk);
         if (ex->d_eval_params) hipFree(ex->d_eval_params);
@@ -488,8 +497,18 @@ __global__ __launch_bounds__(256) void k_unstage(const StageSegDev* __restrict__
     const size_t words = sg.bytes >> 2;          // every table is made of 4- or 8-byte items
     const unsigned int* __restrict__ src = static_cast<const unsigned int*>(sg.src);
     unsigned int* __restrict__ dst = static_cast<unsigned int*>(sg.dst);
-    for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < words; i += (size_t)gridDim.y * 256) dst[i] = src[i];
+    const size_t t = (size_t)blockIdx.y * 256 + threadIdx.x, nt = (size_t)gridDim.y * 256;
+    size_t done = 0;
+    if ((((size_t)sg.src | (size_t)sg.dst) & 15) == 0) {          // 16 bytes per thread and pass where both ends allow it, the tail by words
+        const size_t quads = words >> 2;
+        const uint4* __restrict__ s4 = static_cast<const uint4*>(sg.src);
+        uint4* __restrict__ d4 = static_cast<uint4*>(sg.dst);
+        for (size_t i = t; i < quads; i += nt) d4[i] = s4[i];
+        done = quads << 2;
+    }
+    for (size_t i = done + t; i < words; i += nt) dst[i] = src[i];
 }
+#define UNSTAGE_GY 32
 static int stage_reserve(glio_ctx* c, size_t bytes) {
     c->h_stage_used = STAGE_HEADER; c->n_stage_seg = 0;
     bytes += STAGE_HEADER + 64 * 34;
@@ -505,9 +524,56 @@ static int stage_reserve(glio_ctx* c, size_t bytes) {
     c->h_stage_cap = cap; c->h_stage_top = cap & ~(size_t)63;
     return GLIO_OK;
 }
+// EARLY uploads.  glio_set_imu / glio_set_gnss are called while the window's searches are still running on the context's stream
+// (findCorrespondingSurfFeaturesWindowAsync, then the factor tables): a copy enqueued on that stream would sit behind the searches, and the
+// synchronisation that releases the pinned block would wait for all of them (0.1 ms of every keyframe cycle, the GPU idle behind the
+// searches while the host then staged the GNSS tables).  So the block travels on a stream of its own into a device MIRROR that no kernel but
+// k_unstage reads, the host waits for that copy alone, and k_unstage -- the only writer of the tables -- stays on the context's stream, behind the
+// searches and every earlier reader of the tables, and waits for the copy through an event.  Two blocks take turns; a block is sent again only
+// after the k_unstage that read its mirror (event ev_free, waited for by the upload stream).  GLIO_EARLY_UPLOAD=0: the in-stream path (A/B).
+static bool stage_early_enabled(CtxExtra* ex) {
+    if (ex->up_mode < 0) { const char* e = getenv("GLIO_EARLY_UPLOAD"); ex->up_mode = (!e || atoi(e) != 0) ? 1 : 0; }
+    return ex->up_mode == 1;
+}
+static int stage_begin_early(glio_ctx* c, size_t bytes) {
+    CtxExtra* ex = extra_of(c);
+    if (!ex->up_stream) {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) GLIO_HIP_CHECK(hipStreamCreateWithPriority(&ex->up_stream, hipStreamNonBlocking, greatest));
+        else GLIO_HIP_CHECK(hipStreamCreateWithFlags(&ex->up_stream, hipStreamNonBlocking));
+        GLIO_HIP_CHECK(hipEventCreateWithFlags(&ex->ev_up, hipEventDisableTiming));
+    }
+    const int k = ex->up_next;
+    CtxExtra::UpArena& a = ex->up[k];
+    bytes += STAGE_HEADER + 64 * 34;
+    if (bytes > a.cap) {
+        if (a.pending) { GLIO_HIP_CHECK(hipEventSynchronize(a.ev_free)); a.pending = false; }
+        if (a.h) hipHostFree(a.h);
+        if (a.d) hipFree(a.d);
+        a.h = nullptr; a.d = nullptr; a.cap = 0;
+        const size_t cap = bytes * 2 + 4096;
+        GLIO_HIP_CHECK(hipHostMalloc((void**)&a.h, cap));
+        GLIO_HIP_CHECK(hipMalloc((void**)&a.d, cap));
+        a.cap = cap;
+        if (!a.ev_free) GLIO_HIP_CHECK(hipEventCreateWithFlags(&a.ev_free, hipEventDisableTiming));
+    }
+    // the staging functions work on the context's arena fields: point them at this block until stage_flush
+    ex->sv_h = c->h_stage; ex->sv_d = c->d_stage; ex->sv_cap = c->h_stage_cap;
+    c->h_stage = a.h; c->d_stage = a.d; c->h_stage_cap = a.cap;
+    c->h_stage_used = STAGE_HEADER; c->n_stage_seg = 0; c->h_stage_top = a.cap & ~(size_t)63;
+    ex->up_cur = k; ex->up_next = k ^ 1;
+    return GLIO_OK;
+}
+static void stage_end_early(glio_ctx* c) {
+    CtxExtra* ex = extra_of(c);
+    if (ex->up_cur < 0) return;
+    c->h_stage = ex->sv_h; c->d_stage = ex->sv_d; c->h_stage_cap = ex->sv_cap;
+    c->h_stage_used = STAGE_HEADER; c->n_stage_seg = 0; c->h_stage_top = c->h_stage_cap & ~(size_t)63;
+    ex->up_cur = -1;
+}
 static int stage_upload(glio_ctx* c, void* dst, const void* src, size_t bytes) {
     if (bytes == 0) return GLIO_OK;
-    if (bytes > STAGE_DIRECT_BYTES) {          // a large table goes straight to its destination (the copy engine beats a second pass over it);
+    if (bytes > STAGE_DIRECT_BYTES && extra_of(c)->up_cur < 0) {          // a large table goes straight to its destination (the copy engine beats a second pass over it);
         const size_t need = (bytes + 63) & ~(size_t)63;      // its pinned copy is taken from the TOP of the arena, outside the block stage_flush sends
         if (c->h_stage_top < need || c->h_stage_top - need < c->h_stage_used) { glio_set_error("upload arena overflow"); return GLIO_E_STATE; }
         c->h_stage_top -= need;
@@ -533,15 +599,33 @@ static int stage_d2d(glio_ctx* c, void* dst, const void* src, size_t bytes) {
 }
 static int stage_flush(glio_ctx* c) {
     const int n = c->n_stage_seg;
-    if (n == 0) return GLIO_OK;
+    CtxExtra* ex = extra_of(c);
+    if (n == 0) { stage_end_early(c); return GLIO_OK; }
     static_assert(sizeof(StageSegDev) * 32 <= STAGE_HEADER, "descriptor header");
     memcpy(c->h_stage, c->stage_seg, sizeof(StageSegDev) * (size_t)n);
+    if (ex->up_cur >= 0) {
+        CtxExtra::UpArena& a = ex->up[ex->up_cur];
+        hipError_t e = hipSuccess;
+        if (a.pending) e = hipStreamWaitEvent(ex->up_stream, a.ev_free, 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(a.d, a.h, c->h_stage_used, hipMemcpyHostToDevice, ex->up_stream);
+        if (e == hipSuccess) e = hipEventRecord(ex->ev_up, ex->up_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, ex->ev_up, 0);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_unstage, dim3(n, UNSTAGE_GY), dim3(256), 0, c->stream, reinterpret_cast<const StageSegDev*>(a.d));
+            e = hipEventRecord(a.ev_free, c->stream);
+            a.pending = true;
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ex->up_stream);          // the copy alone: the pinned block may be written again
+        stage_end_early(c);
+        if (e != hipSuccess) { glio_set_error("early upload: %s", hipGetErrorString(e)); return GLIO_E_HIP; }
+        return GLIO_OK;
+    }
     GLIO_HIP_CHECK(hipMemcpyAsync(c->d_stage, c->h_stage, c->h_stage_used, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_unstage, dim3(n, 8), dim3(256), 0, c->stream, reinterpret_cast<const StageSegDev*>(c->d_stage));
+    hipLaunchKernelGGL(k_unstage, dim3(n, UNSTAGE_GY), dim3(256), 0, c->stream, reinterpret_cast<const StageSegDev*>(c->d_stage));
     c->n_stage_seg = 0;
     return GLIO_OK;
 }
-#define STAGE(dst, src, bytes) do { const int rc_ = stage_upload(c, (dst), (src), (bytes)); if (rc_ != GLIO_OK) return rc_; } while (0)
+#define STAGE(dst, src, bytes) do { const int rc_ = stage_upload(c, (dst), (src), (bytes)); if (rc_ != GLIO_OK) { stage_end_early(c); return rc_; } } while (0)
 
 int glio_set_imu(glio_ctx* c, int n_edges, const glio_preint* edges, const int32_t* slot_i) {
     if (!c || n_edges < 0 || n_edges > c->W - 1 + (c->W == 1)) { glio_set_error("bad IMU edge count"); return GLIO_E_ARG; }
@@ -558,10 +642,11 @@ int glio_set_imu(glio_ctx* c, int n_edges, const glio_preint* edges, const int32
     }
     { CtxExtra* ex = extra_of(c); ex->imu_raw.assign(edges, edges + n_edges); ex->imu_dig.assign(h.begin(), h.begin() + n_edges); }
     if (n_edges) {
-        { const int rc = stage_reserve(c, n_edges * sizeof(ImuEdgeDev) + 64); if (rc != GLIO_OK) return rc; }
+        const bool early = stage_early_enabled(extra_of(c));
+        { const int rc = early ? stage_begin_early(c, n_edges * sizeof(ImuEdgeDev) + 64) : stage_reserve(c, n_edges * sizeof(ImuEdgeDev) + 64); if (rc != GLIO_OK) return rc; }
         STAGE(c->d_imu, h.data(), n_edges * sizeof(ImuEdgeDev));
         { const int rf = stage_flush(c); if (rf != GLIO_OK) return rf; }
-        GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (!early) GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
     }
     c->n_imu = n_edges;
     for (int k = 0; k < n_edges; ++k) c->h_imu_slot[k] = slot_i[k];
@@ -751,10 +836,11 @@ int glio_set_gnss(glio_ctx* c, const glio_gnss_frame* frame, int n_dd, const gli
     std::vector<int> off(W + 1, 0), list;
     for (int i = 0; i < W; ++i) { off[i + 1] = off[i] + (int)per[i].size(); list.insert(list.end(), per[i].begin(), per[i].end()); }
     GnssDevExtra* ex = glio_extra(c);
+    const bool early = stage_early_enabled(extra_of(c));
     {
         const size_t total = sdd.size() * sizeof(glio_dd_psr) + sdop.size() * sizeof(glio_doppler) + groups.size() * sizeof(GnssGroup) +
                              (size_t)ne * sizeof(int2) + (W + 1) * 4 + list.size() * 4 + runs.size() * sizeof(DopRun) + 8 * 64;
-        const int rc = stage_reserve(c, total);
+        const int rc = early ? stage_begin_early(c, total) : stage_reserve(c, total);
         if (rc != GLIO_OK) return rc;
     }
     STAGE(c->d_dd, sdd.data(), sdd.size() * sizeof(glio_dd_psr));
@@ -767,7 +853,7 @@ int glio_set_gnss(glio_ctx* c, const glio_gnss_frame* frame, int n_dd, const gli
     ex->n_runs = (int)runs.size();
     { const int rf = stage_flush(c); if (rf != GLIO_OK) return rf; }
     GLIO_HIP_CHECK(hipMemsetAsync(c->d_ddt_blocks, 0, 2 * (size_t)std::max(1, c->n_ddt_max) * sizeof(DdtBlock), c->stream));
-    GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (!early) GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
     c->n_dd = (int)sdd.size(); c->n_dop = (int)sdop.size(); c->n_groups = (int)groups.size();
     if (c->n_groups) c->have_factors = 1;
     return GLIO_OK;

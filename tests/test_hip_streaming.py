@@ -108,3 +108,39 @@ def test_resident_stream_equals_roundtrip_stream():
             for d in (da, db):
                 d.slide(long.init.trans[k + W], long.init.quat[k + W], long.init.speed_bias[k + W])
     ca.close(); cb.close()
+
+
+def test_early_factor_uploads_equal_in_stream_uploads(monkeypatch):
+    """glio_set_imu / glio_set_gnss while the window's searches run: by default the tables travel on a stream of their own into a device mirror and
+    k_unstage (on the context's stream) installs them; GLIO_EARLY_UPLOAD=0 copies on the context's stream and waits.  Same solve, bit for bit --
+    also when the calls come four in a row behind one search (another window's tables first: both upload blocks are sent again while the k_unstage
+    that reads their mirrors is still queued behind the searches), and over three keyframes of a stream (marginalize, slide, set again)."""
+    from glio_amd import capi
+    long = synth.make_window(W=7, pts_per_scan=5000, seed=synth.SEED_BASE + 31, with_gnss=True)
+    other = synth.make_window(W=4, pts_per_scan=64, seed=synth.SEED_BASE + 32, with_gnss=True)
+    wins = [synth.sub_window(long, j, 4) for j in range(3)]
+    out = []
+    for early in ("0", "1"):
+        monkeypatch.setenv("GLIO_EARLY_UPLOAD", early)
+        o = wins[0].opts
+        o.max_ddt_epochs = max(max(w.init.n_ddt for w in wins), other.init.n_ddt) + 4
+        c = capi.Context(o)
+        c.set_map(long.map_pts)
+        c.set_prior(None)
+        res = []
+        for j, win in enumerate(wins):
+            for s in range(win.W):
+                c.set_scan(s, win.scans[s])
+            poses = [capi.lidar_pose(win.opts, win.init.quat[s], win.init.trans[s]) for s in range(win.W)]
+            c.associate_window_async(np.array([p[0] for p in poses]), np.array([p[1] for p in poses]))
+            c.set_imu(other.preints); c.set_gnss(other.frame, other.dd, other.dop)
+            c.set_imu(win.preints); c.set_gnss(win.frame, win.dd, win.dop)
+            sol, summ = c.solve(win.init)
+            res.append((summ.iterations, sol.trans.copy(), sol.quat.copy(), sol.speed_bias.copy(), summ.final_cost))
+            c.marginalize_keep(sol)
+        out.append(res)
+        c.close()
+    for a, b in zip(*out):
+        assert a[0] == b[0] and a[4] == b[4]
+        for x, y in zip(a[1:4], b[1:4]):
+            assert np.array_equal(x, y)
