@@ -181,7 +181,7 @@ static int create_body(int device, const glio_opts* opts, glio_ctx* c) {
     ALLOC(c->d_chain_tabs, (size_t)(8 + 15) * W * sizeof(short));
     ALLOC(c->d_chain_src, 2 * (size_t)W * GLIO_CS_SOURCES * GLIO_CS_STRIDE * 8);
     GLIO_HIP_CHECK(hipMemsetAsync(c->d_chain_src, 0, 2 * (size_t)W * GLIO_CS_SOURCES * GLIO_CS_STRIDE * 8, c->stream));
-    GLIO_HIP_CHECK(hipHostMalloc((void**)&c->h_chain_tabs, (size_t)(8 + 15) * W * sizeof(short)));
+    GLIO_HIP_CHECK(hipHostMalloc((void**)&c->h_chain_tabs, 2 * (size_t)(8 + 15) * W * sizeof(short)));      // two copies, used in turn (glio_chain_tabs_upload)
     c->h_groups = (GnssGroup*)calloc((size_t)W * W, sizeof(GnssGroup));
     c->h_prior_index = (int*)malloc((size_t)15 * W * sizeof(int));
     for (int k = 0; k < 15 * W; ++k) c->h_prior_index[k] = -1;
@@ -258,6 +258,7 @@ void glio_destroy(glio_ctx* c) {
     if (c->d_stage) hipFree(c->d_stage);
     if (c->raw_stage.d) { hipFree(c->raw_stage.d); c->raw_stage.d = nullptr; c->raw_stage.cap = 0; }
     if (c->h_chain_tabs) hipHostFree(c->h_chain_tabs);
+    for (hipEvent_t& e : c->ev_tabs) if (e) { hipEventDestroy(e); e = nullptr; }
     free(c->h_groups); free(c->h_prior_index);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -416,6 +417,9 @@ int glio_associate_window_async(glio_ctx* c, const double* quats, const double* 
 int glio_associate_window_counts(glio_ctx* c, int32_t* out_counts) {
     if (!c) return GLIO_E_ARG;
     GLIO_HIP_CHECK(hipSetDevice(c->device));
+    // the caller has set this window's factor tables while the searches ran (the keyframe cycle's order): the solve's gather tables and the zeroed slices go
+    // out now, behind the searches, instead of at the head of the solve with the GPU idle
+    if (c->chain_tabs_dirty && c->have_factors) glio_chain_tabs_upload(c);
     const int rc = glio_assoc_finish_pending(c);
     if (rc != GLIO_OK) return rc;
     if (out_counts) for (int s = 0; s < c->W; ++s) out_counts[s] = c->h_count[s];

@@ -239,7 +239,7 @@ struct glio_ctx {
     GnssGroup* h_groups;                      // [W*W] (n_groups used)
     int* h_prior_index;                       // [15 W] state index -> prior column or -1
     short* d_chain_tabs; short* h_chain_tabs; // [8 W + 15 W] ChainKf per keyframe, then the prior index (h_: pinned)
-    int chain_tabs_dirty;
+    int chain_tabs_dirty; int chain_tabs_half, chain_tabs_on_device; hipEvent_t ev_tabs[2];      // (h_chain_tabs holds two copies used in turn, each with the event of its last upload)
     int h_band_clean;             // n for which both dense H buffers are zero outside the band a band-only k_assemble writes, else 0 (reset by every full
                                   // assembly and structure change)
     int want_pair_H;              // 0: the linearisation in flight feeds k_chain_step only (chain slices, g, cost): the 30 x 30 pair blocks are not written

@@ -33,6 +33,7 @@
 // NOTE: no __restrict__ on anything in this file: every buffer here is handed between lanes of the
 // workgroup across s_barrier.  And a kernel here must not re-read global data it has itself rewritten unless the two
 // cannot share a 128 B line with anything it loaded earlier (see glio_ctx::vstride and DESIGN.md, "coherence trap").
+#include <cstring>
 #include <type_traits>
 #include <vector>
 
@@ -3445,9 +3446,17 @@ size_t glio_tr_step_lds_bytes(int n) { return tr_step_lds_doubles(n) * sizeof(do
 // asynchronous on the context's stream, ahead of the kernels that read it.
 void glio_chain_tabs_upload(glio_ctx* c) {
     const int W = c->W;
-    hipStreamSynchronize(c->stream);                 // a copy out of the pinned buffer may still be queued (rare: only when dirty)
-    ChainKf* kd = reinterpret_cast<ChainKf*>(c->h_chain_tabs);
-    short* pidx = c->h_chain_tabs + 8 * W;
+    // Two pinned copies used in turn, each with the event of its last copy: the tables are rebuilt once or twice per keyframe (every set_* call and the
+    // marginalization change the structure), and waiting for the STREAM here meant waiting for whatever was queued on it (the window's searches, the
+    // status upload of the solve) with the host and then the GPU idle.  The copy two uploads back has long left its buffer; the wait below is a formality.
+    static_assert(sizeof(ChainKf) == 8 * sizeof(short), "ChainKf is eight shorts");
+    const int half = c->chain_tabs_half & 1;
+    c->chain_tabs_half ^= 1;
+    if (!c->ev_tabs[half]) hipEventCreateWithFlags(&c->ev_tabs[half], hipEventDisableTiming);
+    else hipEventSynchronize(c->ev_tabs[half]);
+    short* hbuf = c->h_chain_tabs + (size_t)half * (8 + 15) * W;
+    ChainKf* kd = reinterpret_cast<ChainKf*>(hbuf);
+    short* pidx = hbuf + 8 * W;
     for (int i = 0; i < W; ++i) { ChainKf d; d.e0 = d.e1 = d.k0 = d.k1 = d.kp = -1; d.o0 = d.o1 = 0; d.pad_ = 0; kd[i] = d; }
     for (int k = 0; k < c->n_imu; ++k) {
         const int si = c->h_imu_slot[k];
@@ -3465,7 +3474,13 @@ void glio_chain_tabs_upload(glio_ctx* c) {
         if (sb == sa + 1 && sa >= 0 && sa < W) kd[sa].kp = (short)k;
     }
     for (int k = 0; k < 15 * W; ++k) pidx[k] = (short)c->h_prior_index[k];
-    hipMemcpyAsync(c->d_chain_tabs, c->h_chain_tabs, (size_t)(8 + 15) * W * sizeof(short), hipMemcpyHostToDevice, c->stream);
+    // a stream of keyframes rebuilds the SAME tables call after call (IMU edge on every pair, the GNSS groups of the same pairs, the prior on the same
+    // blocks): then the device copy and the zeroed slices already are what this upload would leave
+    const short* prev = c->h_chain_tabs + (size_t)(half ^ 1) * (8 + 15) * W;
+    if (c->chain_tabs_on_device && memcmp(prev, hbuf, (size_t)(8 + 15) * W * sizeof(short)) == 0) { c->chain_tabs_dirty = 0; return; }
+    c->chain_tabs_on_device = 1;
+    hipMemcpyAsync(c->d_chain_tabs, hbuf, (size_t)(8 + 15) * W * sizeof(short), hipMemcpyHostToDevice, c->stream);
+    hipEventRecord(c->ev_tabs[half], c->stream);
     // the structure changed: slices of sources that no longer exist must read as zero
     hipMemsetAsync(c->d_chain_src, 0, 2 * (size_t)W * GLIO_CS_SOURCES * GLIO_CS_STRIDE * 8, c->stream);
     c->chain_tabs_dirty = 0;

@@ -77,7 +77,7 @@ int main(int argc, char** argv) {
             for (int i = 0; i < pts; ++i) for (int c = 0; c < 3; ++c) body[4 * (size_t)i + c] -= tlb[c];
             ba.setFrame(j, body.data(), pts);
         }
-        double st[7] = {0, 0, 0, 0, 0, 0, 0}, cyc = 0, cmin = 1e9, cmax = 0;
+        double st[7] = {0, 0, 0, 0, 0, 0, 0}, cyc = 0, cmin = 1e9, cmax = 0, fd[3] = {0, 0, 0};
         std::vector<int> iters; std::vector<long> kept; std::vector<long> bfound; std::vector<long> bkept;
         double checksum = 0;
         int map_pts = 0;
@@ -94,7 +94,10 @@ int main(int argc, char** argv) {
             const double t2 = now_s();
             be.findCorrespondingSurfFeaturesWindowAsync();
             const double t3 = now_s();
-            be.setImuFactors(k.pre); be.setGnss(&k.frame, k.dd, k.dop);
+            be.setImuFactors(k.pre);
+            const double t3a = now_s();
+            be.setGnss(&k.frame, k.dd, k.dop);
+            const double t3b = now_s();
             const std::vector<int32_t> counts = be.windowCounts();
             const double t4 = now_s();
             const glio_summary sum = be.solve(&ddt);
@@ -118,6 +121,7 @@ int main(int argc, char** argv) {
             const double d[7] = {t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5b, (t5b - t5) + (t7 - t6)};
             double c = 0;
             for (int q = 0; q < 7; ++q) { st[q] += d[q] / NK; c += d[q]; }
+            fd[0] += (t3a - t3) / NK; fd[1] += (t3b - t3a) / NK; fd[2] += (t4 - t3b) / NK;
             { long f = 0; for (int64_t v : found) f += (long)v; bfound.push_back(f); bkept.push_back((long)ba.total()); }
             cyc += c / NK; if (c < cmin) cmin = c; if (c > cmax) cmax = c;
             iters.push_back(sum.iterations);
@@ -135,7 +139,8 @@ int main(int argc, char** argv) {
         for (size_t i = 0; i < bfound.size(); ++i) printf("%s%ld", i ? ", " : "", bfound[i]);
         printf("], \"batch_records_held\": [");
         for (size_t i = 0; i < bkept.size(); ++i) printf("%s%ld", i ? ", " : "", bkept[i]);
-        printf("], \"batch_feature_res_num\": %d, \"trans_checksum\": %.17g}\n", RES, checksum);
+        printf("], \"factors_stage_ms\": {\"set_imu_host\": %.4f, \"set_gnss_host\": %.4f, \"wait_for_the_searches\": %.4f}", fd[0] * 1e3, fd[1] * 1e3, fd[2] * 1e3);
+        printf(", \"batch_feature_res_num\": %d, \"trans_checksum\": %.17g}\n", RES, checksum);
     } catch (const std::exception& e) {
         fprintf(stderr, "error: %s\n", e.what());
         return 1;

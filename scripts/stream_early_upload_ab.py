@@ -18,4 +18,4 @@ with tempfile.TemporaryDirectory() as d:
             env = dict(os.environ, GLIO_EARLY_UPLOAD=early)
             for mode in (0, 1):
                 r = min((window_io.run_demo_stream(path, env=env, defer=mode) for _ in range(2)), key=lambda x: x["cycle_ms"])
-                print("early", early, "deferred" if mode else "default ", "cycle_ms", r["cycle_ms"], {k: round(v, 3) for k, v in r["stages_ms"].items()}, "checksum", r["trans_checksum"], flush=True)
+                print("early", early, "deferred" if mode else "default ", "cycle_ms", r["cycle_ms"], {k: round(v, 3) for k, v in r["stages_ms"].items()}, r.get("factors_stage_ms"), "checksum", r["trans_checksum"], flush=True)
