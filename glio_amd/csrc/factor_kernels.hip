@@ -768,8 +768,12 @@ __global__ __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         small_factors_body(a);
         __syncthreads();
         if (threadIdx.x == 0 && a.dbg && blockIdx.x < 190) a.dbg[blockIdx.x] = wall_clock64() - t0;
+        if (threadIdx.x == 0 && a.dbg && blockIdx.x == 0) a.dbg[197] = t0;
         return;
     }
+    // (end of the K3 workgroups: plain stores into 32 slots by workgroup index -- the last writers are the last to finish; no atomics, which would
+    //  serialise at the memory side and lengthen what they measure)
+    struct K3End { long long* d; __device__ ~K3End() { __syncthreads(); if (threadIdx.x == 0 && d) d[208 + (blockIdx.x & 31)] = wall_clock64(); } } k3end{a.dbg};
 #else
     if ((int)blockIdx.x < k.n_small) { small_factors_body(a); return; }
 #endif

@@ -24,3 +24,8 @@ print("gnss block 0 stamps (us): dd loads+compute, sync, dd rest, dop compute, s
 im = np.array(list(st))[64 + 190:64 + 196]
 print("imu block 0 stamps (us): common + residual, global-Jacobian roles, local parameterisation, whitening, J^T J + stores:", [round((im[k + 1] - im[k]) / 100.0, 2) for k in range(5)])
 print("linearize_all", ctx.time_kernel(7, 30) * 1e3)
+capi.load().glio_debug_arrow_stamps(ctx._h, st)
+raw = list(st)
+t0 = raw[64 + 197]
+k3 = [(raw[64 + 208 + k] - t0) / 100.0 for k in range(32)]
+print("inside k_linearize_all, us after workgroup 0 started: small-factor workgroups done (max of the per-workgroup durations above); K3 workgroups: last done %.2f, slots %s" % (max(k3), [round(x, 1) for x in sorted(k3)[-6:]]))
