@@ -2066,6 +2066,7 @@ struct FrameHash {
 };
 struct glio_bassoc {
     int device; hipStream_t stream;
+    hipEvent_t ev_scan;             // glio_bassoc_set_frame_from_scan: the point of the context's stream the copy of its scan waits for (no host wait)
     int K, cap; long long max_con;
     float inv_cell, cell;
     float4* d_local;                // [K][cap] keyframe-local clouds
@@ -2307,6 +2308,7 @@ void glio_bassoc_destroy(glio_bassoc* b) {
     if (b->h_fd) hipHostFree(b->h_fd);
     if (b->raw_stage.d) hipFree(b->raw_stage.d);
     delete[] b->h_n; delete[] b->frames;
+    if (b->ev_scan) hipEventDestroy(b->ev_scan);
     hipStreamDestroy(b->stream);
     delete b;
 }
@@ -2467,7 +2469,10 @@ int glio_bassoc_set_frame_from_scan(glio_bassoc* b, int k, glio_ctx* c, int slot
     if (n > b->cap) { glio_set_error("scan of %d points, the batch association holds %d per keyframe", n, b->cap); return GLIO_E_ARG; }
     BA_CHECK(hipSetDevice(b->device));
     { const int rf = bassoc_finish(b, nullptr, nullptr); if (rf != GLIO_OK) return rf; }
-    BA_CHECK(hipStreamSynchronize(c->stream));                       // (the upload of the scan ran on the context's stream)
+    // the upload of the scan (and its presort) ran on the context's stream: this stream waits for that point, the host does not
+    if (!b->ev_scan) BA_CHECK(hipEventCreateWithFlags(&b->ev_scan, hipEventDisableTiming));
+    BA_CHECK(hipEventRecord(b->ev_scan, c->stream));
+    BA_CHECK(hipStreamWaitEvent(b->stream, b->ev_scan, 0));
     // the context presorted this scan when it was uploaded: its presorted copy (same points, w = index in the scan) is taken over with the same offset instead
     // of presorting the cloud a second time (any spatially compact order serves: results are written at the original indices)
     if (n > 0) {

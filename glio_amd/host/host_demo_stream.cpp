@@ -89,6 +89,9 @@ int main(int argc, char** argv) {
             std::vector<double> ddt = k.ddt;
             const double t0 = now_s();
             be.slideWindow(); be.setScan(W - 1, scans[nw].data(), pts);
+            // the keyframe's cloud goes to the batch association's store as soon as it is on the device (body frame: nothing of it depends on the solve); with the
+            // deferred variant the previous keyframe's searches are still in flight on that store's stream, and the copy is made once they were collected
+            if (!defer) ba.setFrameFromScan(nw, be.ctx(), W - 1, tlb);
             const double t1 = now_s();
             map_pts = be.pushScanAndBuildLocalMap(W - 1, tlb, &gtq[4 * nw], &gtt[3 * nw]);
             const double t2 = now_s();
@@ -110,11 +113,12 @@ int main(int argc, char** argv) {
             }
             std::vector<int64_t> found;
             if (defer) found = kba.finish(rand_below);                  // the previous keyframe's pairs: they had a whole cycle
-            if (!after_marg) { ba.setFrameFromScan(nw, be.ctx(), W - 1, tlb); kba.enqueue(nw + 1, kf_poses); }
+            if (defer) ba.setFrameFromScan(nw, be.ctx(), W - 1, tlb);
+            if (!after_marg) kba.enqueue(nw + 1, kf_poses);
             const double t5b = now_s();
             be.marginalizeAndKeep(&ddt);
             const double t6 = now_s();
-            if (after_marg) { ba.setFrameFromScan(nw, be.ctx(), W - 1, tlb); kba.enqueue(nw + 1, kf_poses); }
+            if (after_marg) kba.enqueue(nw + 1, kf_poses);
             if (!defer) found = kba.finish(rand_below);
             const double t7 = now_s();
             if (j == 0) continue;                                        // no prior yet, every first-touch cost: warm-up
