@@ -2094,7 +2094,8 @@ struct glio_bassoc {
     int pending_pairs;              // pairs of an asynchronous run whose counts were not picked up yet (-1: none)
     double* d_poses;                // [K][7]
     // feature selection scratch (grow-only): the gathered records and their source indices
-    float4* d_sel_cp; double* d_sel_nc; double* d_sel_score; long long* d_sel_idx; long long sel_cap;
+    float4* d_sel_cp; double* d_sel_nc; double* d_sel_score; long long* d_sel_idx; long long sel_cap;      // (d_sel_idx: [1 + cap], word 0 = the new running total)
+    long long* h_sel; long long h_sel_cap; hipEvent_t ev_sel; int sel_in_flight;                           // pinned copy of the same block; the event of its last upload
 };
 
 __global__ void k_transform_cloud(const float4* __restrict__ in, int n, const double* __restrict__ pose, float4* __restrict__ out) {
@@ -2309,6 +2310,8 @@ void glio_bassoc_destroy(glio_bassoc* b) {
     if (b->raw_stage.d) hipFree(b->raw_stage.d);
     delete[] b->h_n; delete[] b->frames;
     if (b->ev_scan) hipEventDestroy(b->ev_scan);
+    if (b->ev_sel) hipEventDestroy(b->ev_sel);
+    if (b->h_sel) hipHostFree(b->h_sel);
     hipStreamDestroy(b->stream);
     delete b;
 }
@@ -2491,6 +2494,8 @@ int glio_bassoc_set_frame_from_scan(glio_bassoc* b, int k, glio_ctx* c, int slot
 
 int glio_bassoc_results_dev(glio_bassoc* b, const float** cp_dev, const double** nc_dev, const double** score_dev) {
     if (!b) return GLIO_E_ARG;
+    // the hand-over to another stream's consumer (glio_batch_set_constraints_pairs_dev): whatever this stream still does to the arrays is waited for here
+    if (hipSetDevice(b->device) != hipSuccess || hipStreamSynchronize(b->stream) != hipSuccess) { glio_set_error("glio_bassoc_results_dev: stream"); return GLIO_E_HIP; }
     if (cp_dev) *cp_dev = reinterpret_cast<const float*>(b->d_cp);
     if (nc_dev) *nc_dev = b->d_nc;
     if (score_dev) *score_dev = b->d_score;
@@ -2515,32 +2520,59 @@ __global__ void k_bassoc_gather(const long long* __restrict__ idx, const long lo
 int glio_bassoc_select(glio_bassoc* b, int64_t n_keep, const int64_t* src_index, int64_t n_current) { return glio_bassoc_select_range(b, 0, n_keep, src_index, n_current); }
 // the same over the TAIL [first, n_current) only (the records one keyframe's batchFeatureAssociation appended): they are replaced by the n_keep records
 // src_index names (absolute indices >= first); the object then holds first + n_keep records
+// the gathered records back to [first, first + n) of the arrays, and the running total (word 0 of the uploaded block) to its place
+__global__ void k_bassoc_put(const long long first, const long long n, const float4* __restrict__ s_cp, const double* __restrict__ s_nc, const double* __restrict__ s_score,
+                             float4* __restrict__ cp, double* __restrict__ nc, double* __restrict__ score, const long long* __restrict__ blk, long long* __restrict__ run) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0) run[0] = blk[0];
+    if (k >= n) return;
+    cp[first + k] = s_cp[k];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) nc[6 * (first + k) + c] = s_nc[6 * k + c];
+    score[first + k] = s_score[k];
+}
+
 int glio_bassoc_select_range(glio_bassoc* b, int64_t first, int64_t n_keep, const int64_t* src_index, int64_t n_current) {
     if (!b || first < 0 || n_keep < 0 || n_current < first || n_current > b->max_con || n_keep > n_current - first || (n_keep > 0 && !src_index)) return GLIO_E_ARG;
     BA_CHECK(hipSetDevice(b->device));
     { const int rf = bassoc_finish(b, nullptr, nullptr); if (rf != GLIO_OK) return rf; }
     for (int64_t k = 0; k < n_keep; ++k) if (src_index[k] < first || src_index[k] >= n_current) { glio_set_error("selection index %lld out of range", (long long)src_index[k]); return GLIO_E_ARG; }
-    b->h_tail[0] = first + n_keep;
-    BA_CHECK(hipMemcpyAsync(b->d_run, b->h_tail, 8, hipMemcpyHostToDevice, b->stream));
-    if (n_keep == 0) { BA_CHECK(hipStreamSynchronize(b->stream)); return GLIO_OK; }
-    if (n_keep > b->sel_cap) {
+    // ONE pinned block [new running total | the indices] -> one copy, the gather into the staging arrays, one kernel that puts the records (and the total) in
+    // place; nothing is waited for: every later consumer is on this stream or synchronises it (glio_bassoc_read, glio_bassoc_results_dev).  (It used to be
+    // two pageable copies, the gather, three device copies and a synchronisation: ~60 us at the end of every keyframe call.)
+    if (n_keep > b->sel_cap || !b->d_sel_idx) {
         // (pointers nulled and the capacity reset before the new allocations: a failed hipMalloc must not leave dangling pointers
         //  behind a capacity that claims room -- advisor finding of round 2)
+        BA_CHECK(hipStreamSynchronize(b->stream));
         void** old[] = {(void**)&b->d_sel_cp, (void**)&b->d_sel_nc, (void**)&b->d_sel_score, (void**)&b->d_sel_idx};
         for (void** q : old) { if (*q) hipFree(*q); *q = nullptr; }
         b->sel_cap = 0;
         const int64_t cap = n_keep + n_keep / 2 + 1024;
         BA_CHECK(hipMalloc((void**)&b->d_sel_cp, (size_t)cap * 16)); BA_CHECK(hipMalloc((void**)&b->d_sel_nc, (size_t)cap * 48));
-        BA_CHECK(hipMalloc((void**)&b->d_sel_score, (size_t)cap * 8)); BA_CHECK(hipMalloc((void**)&b->d_sel_idx, (size_t)cap * 8));
+        BA_CHECK(hipMalloc((void**)&b->d_sel_score, (size_t)cap * 8)); BA_CHECK(hipMalloc((void**)&b->d_sel_idx, (size_t)(cap + 1) * 8));
         b->sel_cap = cap;
     }
-    BA_CHECK(hipMemcpyAsync(b->d_sel_idx, src_index, (size_t)n_keep * 8, hipMemcpyHostToDevice, b->stream));
-    hipLaunchKernelGGL(k_bassoc_gather, dim3((unsigned)((n_keep + 255) / 256)), dim3(256), 0, b->stream, b->d_sel_idx, (long long)n_keep, b->d_cp, b->d_nc, b->d_score,
-                       b->d_sel_cp, b->d_sel_nc, b->d_sel_score);
-    BA_CHECK(hipMemcpyAsync(b->d_cp + first, b->d_sel_cp, (size_t)n_keep * 16, hipMemcpyDeviceToDevice, b->stream));
-    BA_CHECK(hipMemcpyAsync(b->d_nc + 6 * first, b->d_sel_nc, (size_t)n_keep * 48, hipMemcpyDeviceToDevice, b->stream));
-    BA_CHECK(hipMemcpyAsync(b->d_score + first, b->d_sel_score, (size_t)n_keep * 8, hipMemcpyDeviceToDevice, b->stream));
-    BA_CHECK(hipStreamSynchronize(b->stream));
+    if (b->sel_in_flight) { BA_CHECK(hipEventSynchronize(b->ev_sel)); b->sel_in_flight = 0; }      // (the previous selection's block has left the pinned copy)
+    if (n_keep + 1 > b->h_sel_cap) {
+        if (b->h_sel) hipHostFree(b->h_sel);
+        b->h_sel = nullptr; b->h_sel_cap = 0;
+        const int64_t cap = n_keep + n_keep / 2 + 1024;
+        BA_CHECK(hipHostMalloc((void**)&b->h_sel, (size_t)cap * 8));
+        b->h_sel_cap = cap;
+    }
+    if (!b->ev_sel) BA_CHECK(hipEventCreateWithFlags(&b->ev_sel, hipEventDisableTiming));
+    b->h_tail[0] = first + n_keep;
+    b->h_sel[0] = first + n_keep;
+    if (n_keep > 0) memcpy(b->h_sel + 1, src_index, (size_t)n_keep * 8);
+    BA_CHECK(hipMemcpyAsync(b->d_sel_idx, b->h_sel, (size_t)(n_keep + 1) * 8, hipMemcpyHostToDevice, b->stream));
+    BA_CHECK(hipEventRecord(b->ev_sel, b->stream));
+    b->sel_in_flight = 1;
+    if (n_keep > 0)
+        hipLaunchKernelGGL(k_bassoc_gather, dim3((unsigned)((n_keep + 255) / 256)), dim3(256), 0, b->stream, b->d_sel_idx + 1, (long long)n_keep, b->d_cp, b->d_nc, b->d_score,
+                           b->d_sel_cp, b->d_sel_nc, b->d_sel_score);
+    hipLaunchKernelGGL(k_bassoc_put, dim3((unsigned)((std::max<int64_t>(n_keep, 1) + 255) / 256)), dim3(256), 0, b->stream, (long long)first, (long long)n_keep, b->d_sel_cp, b->d_sel_nc,
+                       b->d_sel_score, b->d_cp, b->d_nc, b->d_score, b->d_sel_idx, b->d_run);
+    BA_CHECK(hipGetLastError());
     return GLIO_OK;
 }
 
@@ -2548,6 +2580,7 @@ int glio_bassoc_read(glio_bassoc* b, int64_t first, int64_t n, float* cp, double
     if (!b || first < 0 || n < 0 || first + n > b->max_con) return GLIO_E_ARG;
     BA_CHECK(hipSetDevice(b->device));
     { const int rf = glio_bassoc_finish(b, nullptr, nullptr); if (rf != GLIO_OK) return rf; }
+    BA_CHECK(hipStreamSynchronize(b->stream));                       // (a selection may still be compacting the arrays)
     if (n == 0) return GLIO_OK;
     if (cp) BA_CHECK(hipMemcpy(cp, b->d_cp + first, (size_t)n * 16, hipMemcpyDeviceToHost));
     if (norm_cent) BA_CHECK(hipMemcpy(norm_cent, b->d_nc + 6 * first, (size_t)n * 48, hipMemcpyDeviceToHost));
