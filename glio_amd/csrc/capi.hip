@@ -38,6 +38,7 @@ struct CtxExtra {
     // slide W - 2 of the W - 1 edges are the same pre-integrations one slot lower, and only the new one is digested again
     std::vector<glio_preint> imu_raw; std::vector<ImuEdgeDev> imu_dig;
     // early uploads (glio_set_imu, glio_set_gnss): a stream of their own and two pinned blocks with device mirrors, see stage_begin_early
+    hipEvent_t ev_copy = nullptr;          // glio_set_scan: the end of the scan's copy (what the call waits for; the presort behind it is not waited for)
     hipStream_t up_stream = nullptr; hipEvent_t ev_up = nullptr;
     struct UpArena { char* h = nullptr; char* d = nullptr; size_t cap = 0; hipEvent_t ev_free = nullptr; bool pending = false; } up[2];
     int up_next = 0, up_cur = -1, up_mode = -1;
@@ -263,6 +264,7 @@ void glio_destroy(glio_ctx* c) {
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (CtxExtra* ex = extra_of(c)) {
+        if (ex->ev_copy) hipEventDestroy(ex->ev_copy);
         if (ex->up_stream) hipStreamSynchronize(ex->up_stream);
         for (auto& a : ex->up) { if (a.h) hipHostFree(a.h); if (a.d) hipFree(a.d); if (a.ev_free) hipEventDestroy(a.ev_free); }
         if (ex->ev_up) hipEventDestroy(ex->ev_up);
@@ -366,9 +368,14 @@ int glio_set_scan_strided(glio_ctx* c, int slot, const void* scan, int n, int st
     if (!glio_point_layout_ok(stride_bytes, intensity_offset)) { glio_set_error("bad point layout (stride %d, intensity at %d)", stride_bytes, intensity_offset); return GLIO_E_ARG; }
     GLIO_HIP_CHECK(hipSetDevice(c->device));
     { const int ru = glio_upload_points(c->stream, &c->raw_stage, scan, n, stride_bytes, intensity_offset, c->d_scan + (size_t)glio_scan_row(c, slot) * c->cap); if (ru != GLIO_OK) return ru; }
+    // the caller's buffer must have been read when the call returns: that is the copy, not the presort enqueued behind it (0.03 ms that the next call's
+    // launches now overlap)
+    CtxExtra* ex = extra_of(c);
+    if (!ex->ev_copy) GLIO_HIP_CHECK(hipEventCreateWithFlags(&ex->ev_copy, hipEventDisableTiming));
+    GLIO_HIP_CHECK(hipEventRecord(ex->ev_copy, c->stream));
     glio_assoc_scan_uploaded(c, slot, n);
     GLIO_HIP_CHECK(hipGetLastError());
-    GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    GLIO_HIP_CHECK(hipEventSynchronize(ex->ev_copy));
     c->h_scan_count[slot] = n;
     return GLIO_OK;
 }
