@@ -2518,8 +2518,6 @@ __global__ void k_bassoc_gather(const long long* __restrict__ idx, const long lo
     o_score[k] = score[sidx];
 }
 int glio_bassoc_select(glio_bassoc* b, int64_t n_keep, const int64_t* src_index, int64_t n_current) { return glio_bassoc_select_range(b, 0, n_keep, src_index, n_current); }
-// the same over the TAIL [first, n_current) only (the records one keyframe's batchFeatureAssociation appended): they are replaced by the n_keep records
-// src_index names (absolute indices >= first); the object then holds first + n_keep records
 // the gathered records back to [first, first + n) of the arrays, and the running total (word 0 of the uploaded block) to its place
 __global__ void k_bassoc_put(const long long first, const long long n, const float4* __restrict__ s_cp, const double* __restrict__ s_nc, const double* __restrict__ s_score,
                              float4* __restrict__ cp, double* __restrict__ nc, double* __restrict__ score, const long long* __restrict__ blk, long long* __restrict__ run) {
@@ -2532,6 +2530,8 @@ __global__ void k_bassoc_put(const long long first, const long long n, const flo
     score[first + k] = s_score[k];
 }
 
+// the same over the TAIL [first, n_current) only (the records one keyframe's batchFeatureAssociation appended): they are replaced by the n_keep records
+// src_index names (absolute indices >= first); the object then holds first + n_keep records
 int glio_bassoc_select_range(glio_bassoc* b, int64_t first, int64_t n_keep, const int64_t* src_index, int64_t n_current) {
     if (!b || first < 0 || n_keep < 0 || n_current < first || n_current > b->max_con || n_keep > n_current - first || (n_keep > 0 && !src_index)) return GLIO_E_ARG;
     BA_CHECK(hipSetDevice(b->device));

@@ -86,12 +86,14 @@ int glio_localmap_read(glio_ctx* ctx, float* out_xyzi, int capacity, int* out_n)
  * Q2,T2 of Estimator.cpp:2216-2217.  *out_count receives vec_surf_res_cnt[slot]. */
 int glio_associate(glio_ctx* ctx, int slot, const float* scan_xyzi, int n, const double q[4],
                    const double t[3], int* out_count);
-/* Same, for a scan already resident from a previous glio_associate/glio_set_scan (re-association). */
+/* Same, for a scan already resident from a previous glio_associate/glio_set_scan (re-association).
+ * glio_set_scan returns when the caller's buffer has been read; the presort of the scan is enqueued behind the copy and not waited for. */
 int glio_set_scan(glio_ctx* ctx, int slot, const float* scan_xyzi, int n);
 int glio_set_scan_strided(glio_ctx* ctx, int slot, const void* scan_points, int n, int stride_bytes, int intensity_offset);
 int glio_associate_resident(glio_ctx* ctx, int slot, const double q[4], const double t[3], int* out_count);
-/* Slide the window by one keyframe: the resident scan of slot s+1 becomes that of slot s (device-to-device); slot W-1 is
- * free for the new keyframe's glio_set_scan.  (surf_frames / keyframe_idx bookkeeping of Estimator.cpp:4240-4300.) */
+/* Slide the window by one keyframe: the resident scan of slot s+1 becomes that of slot s (the scans are a ring on the device: nothing is
+ * copied, nothing waited for); slot W-1 is free for the new keyframe's glio_set_scan.  (surf_frames / keyframe_idx bookkeeping of
+ * Estimator.cpp:4240-4300.) */
 int glio_slide_window(glio_ctx* ctx);
 /* The whole loop of Estimator.cpp:2198-2248 in one call: every slot's resident scan against the map with its own
  * LiDAR pose (quats [W][4], trans [W][3] = Q2, T2 per slot), one host synchronisation; out_counts [W]. */
@@ -111,7 +113,11 @@ int glio_set_correspondences(glio_ctx* ctx, int slot, const float* pts_xyzi, con
 int glio_get_correspondences(glio_ctx* ctx, int slot, float* pts_xyzi, float* planes, double* scores,
                              int capacity, int* out_count);
 
-/* ---- factors of the window problem */
+/* ---- factors of the window problem
+ * glio_set_imu / glio_set_gnss may be called while the window's searches run (glio_associate_window_async): their tables travel as one pinned block
+ * on a stream of the library's own into a device mirror, the call waits for that copy alone, and the kernel that installs the tables is enqueued on
+ * the context's stream behind everything that still reads the old ones.  (GLIO_EARLY_UPLOAD=0 in the environment: copy and wait on the context's
+ * stream, for A/B runs.) */
 /* Replaces problem.AddResidualBlock(new ImuFactor(pre_integrations[idx+1]), NULL, ...)
  * (Estimator.cpp:2182-2192).  Edge `k` links slots slot_i and slot_i+1. */
 int glio_set_imu(glio_ctx* ctx, int n_edges, const glio_preint* edges, const int32_t* slot_i);
@@ -332,7 +338,8 @@ int glio_bassoc_results_dev(glio_bassoc* b, const float** cp_dev, const double**
  * the device, in place.  glio_amd/batch.py::batch_selection_draws restates the draw rules. */
 int glio_bassoc_select(glio_bassoc* b, int64_t n_keep, const int64_t* src_index, int64_t n_current);
 /* the same over the tail [first, n_current) only -- what one keyframe's batchFeatureAssociation appended: src_index holds absolute indices >= first;
- * afterwards the object holds first + n_keep records */
+ * afterwards the object holds first + n_keep records.  Both calls copy src_index before they return and ENQUEUE the gather (no host wait);
+ * glio_bassoc_read and glio_bassoc_results_dev wait for it, later runs and selections are ordered behind it. */
 int glio_bassoc_select_range(glio_bassoc* b, int64_t first, int64_t n_keep, const int64_t* src_index, int64_t n_current);
 int glio_bassoc_read(glio_bassoc* b, int64_t first, int64_t n, float* cp, double* norm_cent, double* score);
 
