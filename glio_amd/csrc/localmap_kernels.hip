@@ -496,7 +496,8 @@ int glio_localmap_build(glio_ctx* c, int* out_points) {
     }
     const int rc = glio_assoc_build_map_dev(c, m->d_out, nv);          // K1: replaces setInputCloud(surf_local_map_ds) (:2056)
     if (rc) return rc;
-    LM_CHECK(hipStreamSynchronize(c->stream));
+    // (no wait here: the map's size is known since the synchronisation above, and everything that reads the map -- the searches, glio_localmap_read --
+    //  is ordered behind the build on this stream or waits for it)
     if (out_points) *out_points = nv;
     return GLIO_OK;
 }
@@ -523,6 +524,7 @@ int glio_localmap_read(glio_ctx* c, float* out_xyzi, int capacity, int* out_n) {
     *out_n = n;
     if (out_xyzi && n > 0) {
         if (capacity < n) return GLIO_E_ARG;
+        LM_CHECK(hipStreamSynchronize(c->stream));
         LM_CHECK(hipMemcpy(out_xyzi, c->localmap->d_out, (size_t)n * 16, hipMemcpyDeviceToHost));
     }
     return GLIO_OK;
