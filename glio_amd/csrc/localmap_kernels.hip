@@ -16,6 +16,7 @@
 #include <cfloat>
 #include <algorithm>
 #include <cstring>
+#include <chrono>
 
 #include "glio_device.h"
 
@@ -45,6 +46,7 @@ struct LocalMap {
     float4* d_out;                  // [max voxels] down-sampled map, ordered by voxel index
     int max_vox;
     int* h_pin;                     // pinned scalar read-back
+    unsigned long long* h_pub; unsigned long long* d_h_pub; unsigned pub_seq;      // the same three scalars published by a kernel into mapped host memory (k_lm_publish)
     // accumulation = 1 (glio_localmap_set_accumulation): centroids as pcl::VoxelGrid forms them -- FLOAT sums over a voxel's points in the order of the
     // concatenated cloud (keyframes oldest first, points in scan order: the order a stable sort by voxel index leaves, and what the oracle's restatement
     // does) -- instead of the exact fixed-point sums.  Same voxels, same output order; the centroids then equal the oracle's bit for bit.
@@ -334,6 +336,7 @@ void glio_localmap_destroy(glio_ctx* c) {
     void* p[] = {m->d_slot_bbox, m->d_nkeys, m->d_n, m->d_ring, m->d_keys, m->d_sum, m->d_cnt, m->d_bbox, m->d_nvox, m->d_vkey, m->d_vkey_sorted, m->d_vslot, m->d_vslot_sorted, m->d_sort_tmp, m->d_out, m->d_fill, m->d_slot_start, m->d_plist};
     for (void* q : p) if (q) hipFree(q);
     if (m->h_pin) hipHostFree(m->h_pin);
+    if (m->h_pub) hipHostFree(m->h_pub);
     delete[] m->h_n;
     delete m;
     c->localmap = nullptr;
@@ -363,6 +366,9 @@ int glio_localmap_config(glio_ctx* c, int width, float leaf, int max_points_per_
     m->sort_tmp_bytes = (size_t)256 * ((m->max_vox + RS_TILE - 1) / RS_TILE) * 4;          // digit histogram [256][tiles] of the radix sort
     LM_CHECK(hipMalloc(&m->d_sort_tmp, m->sort_tmp_bytes + 16));
     LM_CHECK(hipHostMalloc((void**)&m->h_pin, 64));
+    LM_CHECK(hipHostMalloc((void**)&m->h_pub, 64));
+    memset(m->h_pub, 0, 64);
+    LM_CHECK(hipHostGetDevicePointer((void**)&m->d_h_pub, m->h_pub, 0));
     hipLaunchKernelGGL(k_lm_clear, dim3((m->table_cap + 255) / 256), dim3(256), 0, c->stream, m->d_keys, m->d_sum, m->d_cnt, m->table_cap, m->d_nkeys);
     LM_CHECK(hipMemsetAsync(m->d_n, 0, (size_t)width * 4, c->stream));
     LM_CHECK(hipStreamSynchronize(c->stream));
@@ -436,6 +442,42 @@ int glio_localmap_push_scan(glio_ctx* c, int scan_slot, const float lidar_offset
     return GLIO_OK;
 }
 
+// The build needs three scalars on the host in its middle (voxel count, table fill, bounding box: the sort's geometry).  Three device-to-host copies and
+// a stream synchronisation cost ~40 us of idle GPU there; one thread writing them into MAPPED host memory -- four 8-byte words, then a tag that carries the
+// build's sequence number and a checksum of the words (writes to host memory have been seen out of order under load: glio_device.h, glio_result_mix) --
+// and the host polling the tag cost ~10.  No match within 2 ms: the copies and the synchronisation, as before.
+__global__ void k_lm_publish(const int* __restrict__ nvox, const int* __restrict__ nkeys, const int* __restrict__ bbox, unsigned long long* out, const unsigned seq) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned long long w[4];
+    w[0] = (unsigned long long)(unsigned)nvox[0] | ((unsigned long long)(unsigned)nkeys[0] << 32);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) w[1 + k] = (unsigned long long)(unsigned)bbox[2 * k] | ((unsigned long long)(unsigned)bbox[2 * k + 1] << 32);
+    unsigned long long cs = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cs += glio_result_mix(w[k], (unsigned long long)k);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) __hip_atomic_store(out + k, w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __hip_atomic_store(out + 4, (cs & 0xffffffff00000000ull) | seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+static bool lm_wait_published(LocalMap* m, int* out8) {
+    const unsigned seq = m->pub_seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 1;; ++spins) {
+        const unsigned long long tag = __atomic_load_n(m->h_pub + 4, __ATOMIC_ACQUIRE);
+        if ((unsigned)(tag & 0xffffffffull) == seq) {
+            unsigned long long w[4], cs = 0;
+            for (int k = 0; k < 4; ++k) { w[k] = __atomic_load_n(m->h_pub + k, __ATOMIC_RELAXED); cs += glio_result_mix(w[k], (unsigned long long)k); }
+            if ((cs & 0xffffffff00000000ull) == (tag & 0xffffffff00000000ull)) {
+                out8[0] = (int)(unsigned)(w[0] & 0xffffffffull); out8[1] = (int)(unsigned)(w[0] >> 32);
+                for (int k = 0; k < 3; ++k) { out8[2 + 2 * k] = (int)(unsigned)(w[1 + k] & 0xffffffffull); out8[3 + 2 * k] = (int)(unsigned)(w[1 + k] >> 32); }
+                return true;
+            }
+        }
+        if ((spins & 0xff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) return false;
+    }
+}
+
 int glio_localmap_build(glio_ctx* c, int* out_points) {
     GLIO_TRACE("K1 glio_localmap_build (voxel grid + hash)");
     if (!c || !c->localmap) { glio_set_error("glio_localmap_config first"); return GLIO_E_STATE; }
@@ -456,10 +498,15 @@ int glio_localmap_build(glio_ctx* c, int* out_points) {
     hipLaunchKernelGGL(k_lm_list, dim3((m->table_cap + 1023) / 1024), dim3(1024), 0, c->stream, m->d_keys, m->d_cnt, m->table_cap, inv_leaf, m->d_bbox,
                        m->d_nvox, m->d_vkey, m->d_vslot, m->max_vox);
     LM_CHECK(hipGetLastError());
-    LM_CHECK(hipMemcpyAsync(m->h_pin, m->d_nvox, 4, hipMemcpyDeviceToHost, c->stream));
-    LM_CHECK(hipMemcpyAsync(m->h_pin + 1, m->d_nkeys, 4, hipMemcpyDeviceToHost, c->stream));
-    LM_CHECK(hipMemcpyAsync(m->h_pin + 2, m->d_bbox, 24, hipMemcpyDeviceToHost, c->stream));
-    LM_CHECK(hipStreamSynchronize(c->stream));
+    m->pub_seq = m->pub_seq == 0xffffffffu ? 1u : m->pub_seq + 1u;
+    hipLaunchKernelGGL(k_lm_publish, dim3(1), dim3(64), 0, c->stream, m->d_nvox, m->d_nkeys, m->d_bbox, m->d_h_pub, m->pub_seq);
+    LM_CHECK(hipGetLastError());
+    if (!lm_wait_published(m, m->h_pin)) {
+        LM_CHECK(hipMemcpyAsync(m->h_pin, m->d_nvox, 4, hipMemcpyDeviceToHost, c->stream));
+        LM_CHECK(hipMemcpyAsync(m->h_pin + 1, m->d_nkeys, 4, hipMemcpyDeviceToHost, c->stream));
+        LM_CHECK(hipMemcpyAsync(m->h_pin + 2, m->d_bbox, 24, hipMemcpyDeviceToHost, c->stream));
+        LM_CHECK(hipStreamSynchronize(c->stream));
+    }
     const int nv = m->h_pin[0];
     if (m->h_pin[1] & 0x40000000) { glio_set_error("local map voxel table overflow (raise max_map_points)"); return GLIO_E_ARG; }
     m->nkeys_seen = m->h_pin[1];
