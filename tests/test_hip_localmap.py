@@ -136,3 +136,42 @@ def test_push_of_the_resident_scan_gives_the_same_map(stream):
         na, nb = a.localmap_build(), b.localmap_build()
         assert na == nb and np.array_equal(a.localmap_read(), b.localmap_read()), f"keyframe {s}"
     a.close(); b.close()
+
+
+def test_ordered_output_by_bitmap_rank_and_by_radix_sort(stream):
+    """The ordered voxel list comes from the rank of a voxel's bit in an occupancy bitmap of the bounding box (<= 2^27 cells) or, for larger boxes, from the
+    radix sort.  One context goes through: a normal map (bitmap), a map with two far-away outliers that blow the box up to 8e9 cells (radix sort; the bits
+    that fitted must be cleared again), the normal map once more (bitmap, must equal the first build bit for bit) -- every build against the oracle's voxel
+    grid; and the whole sequence equals a context forced onto the radix sort (GLIO_LM_SORT=1)."""
+    import os
+    from glio_amd import capi
+    from oracle import pyoracle as po
+    win, clouds = stream
+    o = synth.default_opts(1, pts=8192, map_pts=1 << 17)
+    leaf, width = 0.4, 1
+    ident = (np.array([1.0, 0, 0, 0]), np.zeros(3))
+    far = clouds[1].copy()
+    far[0, :3] = [700.0, -650.0, 90.0]; far[1, :3] = [-720.0, 610.0, -95.0]          # (1420 x 1260 x 185 m) / 0.4 m: 8.2e9 cells
+    seq = [clouds[0], far, clouds[0], clouds[2]]
+    results = []
+    for force in ("0", "1"):
+        os.environ["GLIO_LM_SORT"] = force
+        try:
+            ctx = capi.Context(o)
+            ctx.localmap_config(width, leaf, 8192)
+        finally:
+            os.environ.pop("GLIO_LM_SORT", None)
+        maps = []
+        for cl in seq:
+            ctx.localmap_push(cl, *ident)
+            n = ctx.localmap_build()
+            got = ctx.localmap_read().copy()
+            ref, _ = po.voxel_grid(cl, leaf)
+            assert n == len(ref) == len(got)
+            assert np.abs(got - ref).max() <= 2e-5
+            maps.append(got)
+        assert np.array_equal(maps[0], maps[2])
+        results.append(maps)
+        ctx.close()
+    for a, b in zip(*results):
+        assert np.array_equal(a, b)
