@@ -74,6 +74,7 @@ struct AssocWork {
     int* d_count_tmp;
     int* h_count;                 // pinned
     int* h_counts_win;            // pinned [GLIO_MAX_WINDOW]: counts of an asynchronous window association, picked up by glio_assoc_finish_pending
+    hipEvent_t ev_counts;         // ... which waits for THIS point of the stream (the counts' copy), not for what the caller enqueued behind the searches since
     int counts_pending;
     double* d_win; double* h_win; // [W][7] poses + [W] counts of the window association (h_win pinned)
     struct KnnBinHost* kb;        // query binning buffers of the tiled search
@@ -1824,6 +1825,7 @@ void glio_assoc_destroy(glio_ctx* c) {
     hipHostFree(w->h_count);
     if (w->h_counts_win) hipHostFree(w->h_counts_win);
     if (w->h_win) hipHostFree(w->h_win);
+    if (w->ev_counts) hipEventDestroy(w->ev_counts);
     delete w;
     c->assoc = nullptr;
 }
@@ -2006,13 +2008,17 @@ int glio_assoc_run_window_async(glio_ctx* c, const double* quats, const double* 
     { const int rc = enqueue_assoc_window(c, quats, trans); if (rc != GLIO_OK) return rc; }
     GLIO_HIP_CHECK(hipGetLastError());
     GLIO_HIP_CHECK(hipMemcpyAsync(w->h_counts_win, c->d_count, (size_t)c->W * 4, hipMemcpyDeviceToHost, c->stream));
+    if (!w->ev_counts) GLIO_HIP_CHECK(hipEventCreateWithFlags(&w->ev_counts, hipEventDisableTiming));
+    GLIO_HIP_CHECK(hipEventRecord(w->ev_counts, c->stream));
     w->counts_pending = 1;
     return GLIO_OK;
 }
 int glio_assoc_finish_pending(glio_ctx* c) {
     AssocWork* w = c->assoc;
     if (!w || !w->counts_pending) return GLIO_OK;
-    GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    // the counts' copy, not the whole stream: the factor tables the caller has set meanwhile (k_unstage, the clock-drift blocks' memset) are still being
+    // installed behind the searches, and the solve's first launches can be enqueued while they are (0.03 ms of idle GPU per keyframe otherwise)
+    GLIO_HIP_CHECK(hipEventSynchronize(w->ev_counts));
     for (int s = 0; s < c->W; ++s) c->h_count[s] = w->h_counts_win[s];
     w->counts_pending = 0;
     return GLIO_OK;
