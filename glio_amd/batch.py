@@ -449,6 +449,11 @@ class BatchAssociation:
         capi._check(capi.load().glio_bassoc_reset(self._h))
         self.total = 0
 
+    def prepare(self, pair_ci, pair_cj):
+        """Optional, ahead of a run whose pairs are known before its poses: build descriptors sent, hash tables of the search frames cleared."""
+        ci = np.ascontiguousarray(pair_ci, np.int32); cj = np.ascontiguousarray(pair_cj, np.int32)
+        capi._check(capi.load().glio_bassoc_prepare_async(self._h, len(ci), T.iptr(ci) if len(ci) else None, T.iptr(cj) if len(cj) else None))
+
     def set_frame_from_scan(self, k, ctx, slot, lidar_offset):
         """surf_frames[k] <- the scan resident in window slot `slot` of a capi.Context (device copy, minus the LiDAR offset)."""
         off = np.ascontiguousarray(lidar_offset, np.float32)

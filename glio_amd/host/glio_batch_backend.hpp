@@ -265,6 +265,9 @@ public:
     // poses [K][7] = t, q (pose_info_keyframe).  run: the records of `pairs` replace what the object holds; runAppend: they are added behind it
     std::vector<int64_t> run(const std::vector<double>& poses, const PairList& pairs) { return runImpl(poses, pairs, false); }
     std::vector<int64_t> runAppend(const std::vector<double>& poses, const PairList& pairs) { return runImpl(poses, pairs, true); }
+    void prepareAsync(const PairList& pairs) {
+        check(glio_bassoc_prepare_async(h_, (int)pairs.size(), pairs.ci.data(), pairs.cj.data()), "glio_bassoc_prepare_async");
+    }
     void runAppendAsync(const std::vector<double>& poses, const PairList& pairs) {
         needPoses(poses);
         check(glio_bassoc_run_append_async(h_, poses.data(), (int)pairs.size(), pairs.ci.data(), pairs.cj.data()), "glio_bassoc_run_append_async");
@@ -391,6 +394,12 @@ class KeyframeBatchAssociation {
 public:
     explicit KeyframeBatchAssociation(BatchAssociationBackend& ba, int search_range = 6, int feature_res_num = -1) : ba_(ba), sr_(search_range), res_num_(feature_res_num) {}
     // poses [K][7] = t, q of every keyframe slot of the association object (pose_info_keyframe); size = keyframes in the stream so far
+    // optional, before the poses exist (i.e. before the solve of the same keyframe call): the pairs of `size` keyframes are formed and their search frames'
+    // tables cleared on the device; enqueue(size, poses) then starts with the transform of the clouds
+    void prepare(int size) {
+        PairList pl;
+        if (BatchAssociationBackend::keyframePairs(size, sr_, pl)) ba_.prepareAsync(pl);
+    }
     int enqueue(int size, const std::vector<double>& poses) {
         have_ = BatchAssociationBackend::keyframePairs(size, sr_, cur_);
         if (!have_) return 0;

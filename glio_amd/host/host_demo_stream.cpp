@@ -102,6 +102,7 @@ int main(int argc, char** argv) {
             be.setGnss(&k.frame, k.dd, k.dop);
             const double t3b = now_s();
             const std::vector<int32_t> counts = be.windowCounts();
+            if (!defer && !after_marg) kba.prepare(nw + 1);          // (the pairs are known; their search frames' tables are cleared while the solve runs)
             const double t4 = now_s();
             const glio_summary sum = be.solve(&ddt);
             const double t5 = now_s();

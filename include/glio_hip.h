@@ -328,6 +328,10 @@ int glio_bassoc_run_append(glio_bassoc* b, const double* poses, int n_pairs, con
 int glio_bassoc_run_append_async(glio_bassoc* b, const double* poses, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj);
 int glio_bassoc_finish(glio_bassoc* b, int64_t* pair_count_out, int64_t* total_out);
 int glio_bassoc_reset(glio_bassoc* b);
+/* Optional, ahead of a run whose pairs are known before its poses (batchFeatureAssociation inside a keyframe call: the pairs follow from the keyframe count,
+ * the poses from the solve): sends the build descriptors of the run's search frames and clears their hash tables now; the run that follows with the same
+ * search frames skips both.  Anything else in between only makes the run do them itself. */
+int glio_bassoc_prepare_async(glio_bassoc* b, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj);
 /* surf_frames[k] <- the scan resident in window slot `slot` of a sliding-window context on the same device, minus the LiDAR offset (a device copy:
  * the keyframe that just entered the window is not uploaded a second time) */
 int glio_bassoc_set_frame_from_scan(glio_bassoc* b, int k, glio_ctx* ctx, int slot, const float lidar_offset[3]);

@@ -213,3 +213,42 @@ def test_keyframe_by_keyframe_accumulation_equals_one_run(frames):
     fs = {r.tobytes() for r in full_cp}
     assert all(r.tobytes() in fs for r in cp)
     ctx.close(); ba.close(); ref.close()
+
+
+def test_prepared_run_equals_plain_run(frames):
+    """glio_bassoc_prepare_async (descriptors sent, tables cleared before the poses exist) followed by a run over the same pairs; by a run over OTHER pairs
+    (the preparation does not apply: the run clears for itself); a preparation that is never used; a cloud replaced between preparation and run (same size:
+    still applies; other size: does not) -- the records always equal those of a fresh object's plain run, bit for bit."""
+    scans, poses = frames
+    K = len(scans)
+    pa = (np.array([2, 2, 3, 3], np.int32), np.array([0, 1, 1, 4], np.int32))
+    pb = (np.array([1, 4, 4], np.int32), np.array([3, 2, 5], np.int32))
+
+    def plain(pairs, sc):
+        ref = batch.BatchAssociation(K, 4096, 400000)
+        for k in range(K):
+            ref.set_frame(k, sc[k])
+        counts, total = ref.run(poses, *pairs)
+        out = [a.copy() for a in ref.read()]
+        return counts.tolist(), total, out
+
+    ba = batch.BatchAssociation(K, 4096, 400000)
+    for k in range(K):
+        ba.set_frame(k, scans[k])
+    alt = [s.copy() for s in scans]
+    alt[1] = scans[1][::-1].copy()                         # the same points in another order: same size
+    short = [s.copy() for s in scans]
+    short[1] = scans[1][: len(scans[1]) // 2].copy()      # another size
+    cases = [(pa, pa, scans, None), (pa, pb, scans, None), (pb, pa, scans, None), (pa, pa, alt, 1), (pa, pa, short, 1)]
+    for prep, run, sc, replaced in cases:
+        for k in range(K):
+            ba.set_frame(k, scans[k])
+        ba.prepare(*prep)
+        if replaced is not None:
+            ba.set_frame(replaced, sc[replaced])
+        counts, total = ba.run(poses, *run)
+        want = plain(run, sc)
+        assert counts.tolist() == want[0] and total == want[1] and total > 100
+        for a, b in zip(ba.read(), want[2]):
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    ba.prepare(*pa)                                        # prepared, never run: nothing to clean up
