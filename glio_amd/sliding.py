@@ -164,6 +164,14 @@ class KeyframeBatchAssociation:
             return None
         return idx, [j for j in range(idx - search_range, idx + search_range + 1) if j != idx]
 
+    def prepare(self, size):
+        """Optional, before the poses exist (before the solve of the same keyframe call): the pairs follow from the keyframe count alone; their search frames'
+        build descriptors go to the device and their hash tables are cleared now (glio_bassoc_prepare_async), enqueue() then starts with the clouds' transform."""
+        pr = self.pairs_of(size, self.sr)
+        if pr is not None:
+            idx, js = pr
+            self.ba.prepare(np.full(len(js), idx, np.int32), np.asarray(js, np.int32))
+
     def enqueue(self, size, poses):
         """poses [K][7] = t, q of every keyframe slot of `ba`.  Enqueues the searches on the association's own stream and returns."""
         pr = self.pairs_of(size, self.sr)
