@@ -33,6 +33,7 @@
 #include <cfloat>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <vector>
 
 #include "glio_device.h"
@@ -2072,7 +2073,7 @@ struct FrameHash {
 };
 struct glio_bassoc {
     int device; hipStream_t stream;
-    int prep_nb, prep_todo[64], prep_n[64], prep_tc[64];      // glio_bassoc_prepare_async: the first batch of search frames whose descriptors are on the device and whose tables are cleared
+    int prep_nb, prep_todo[64], prep_n[64], prep_tc[64]; long long prep_ns;      // glio_bassoc_prepare_async: the first batch of search frames whose descriptors are on the device and whose tables are cleared
     hipEvent_t ev_scan;             // glio_bassoc_set_frame_from_scan: the point of the context's stream the copy of its scan waits for (no host wait)
     int K, cap; long long max_con;
     float inv_cell, cell;
@@ -2392,6 +2393,7 @@ extern "C" int glio_bassoc_prepare_async(glio_bassoc* b, int n_pairs, const int3
     BA_CHECK(hipGetLastError());
     for (int q = 0; q < nb; ++q) { b->prep_todo[q] = todo[q]; b->prep_n[q] = b->h_n[todo[q]]; b->prep_tc[q] = b->h_fb[q].tc; }
     b->prep_nb = nb;
+    b->prep_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
     return GLIO_OK;
 }
 
@@ -2428,7 +2430,9 @@ static int bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const in
             bassoc_fill_batch(b, todo.data() + t0, t0, nb, &max_tc, &max_n);
             const FrameBuild* dfb = b->d_fb + t0;
             // glio_bassoc_prepare_async has sent this batch's descriptors and cleared its tables already (same keyframes, same sizes, nothing run since)?
-            bool prepared = t0 == 0 && b->prep_nb == nb;
+            // (... and recently: a preparation is meant to bridge one solve, ~0.4 ms; one older than 20 ms is simply not used)
+            bool prepared = t0 == 0 && b->prep_nb == nb &&
+                            std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() - b->prep_ns < 20000000ll;
             for (int q = 0; prepared && q < nb; ++q) prepared = b->prep_todo[q] == todo[q] && b->prep_n[q] == b->h_n[todo[q]] && b->prep_tc[q] == b->h_fb[q].tc;
             b->prep_nb = 0;
             if (!prepared) {
