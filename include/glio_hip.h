@@ -70,6 +70,8 @@ int glio_localmap_push_strided(glio_ctx* ctx, const void* cloud_points, int n, i
 /* the same from the scan glio_set_scan already put into window slot `scan_slot` (LiDAR frame; body point = scan point - lidar_offset in float):
  * the newest keyframe's cloud crosses PCIe once for both the association and the map */
 int glio_localmap_push_scan(glio_ctx* ctx, int scan_slot, const float lidar_offset[3], const double q[4], const double t[3]);
+/* Voxel grid + hash of the ring's content; *out_points = the map's size.  The call waits ONCE in its middle (the voxel count sizes the rest) and returns with
+ * the ordered output and the hash build still running on the context's stream: the searches are ordered behind them, glio_localmap_read waits. */
 int glio_localmap_build(glio_ctx* ctx, int* out_points);
 /* centroid arithmetic of the voxel grid: 0 (default) exact fixed-point sums; 1 = float sums in the order of the concatenated cloud, as the oracle's
  * restatement of pcl::VoxelGrid forms them (Estimator.cpp:3618-3631 through PCL): bit-identical to the ORACLE's map (stable order inside a voxel).  PCL itself
