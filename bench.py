@@ -528,7 +528,7 @@ def compact_line(line, full_path=None):
         optional.append(("batch_stage", batch_stage_summary(bs, 1)))
     fe = line.get("front_end_odometry")
     if isinstance(fe, dict):
-        optional.append(("front_end_odometry", _pick(fe, ("ms_per_scan", "cpp_ms_per_scan", "iterations", "error"))))
+        optional.append(("front_end_odometry", _pick(fe, ("update_ms", "scans_per_s", "lm_iterations", "cpp_update_ms", "error"))))
     if full_path:
         optional.append(("full_record", full_path))
     for k, v in optional:
