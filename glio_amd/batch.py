@@ -319,6 +319,9 @@ def select_batch_gnss_epochs(obs_local_ts, keyframe_time, first_idx, n_poses, tr
     (epoch, left_key, right_key, ts_ratio).  Same rules as glio::selectBatchGnssEpochs (glio_batch_backend.hpp), which documents them."""
     kt = np.asarray(keyframe_time, float)
     out, padd = [], np.zeros(3)
+    # (pose index i reads kt[i - 1] and trans[i - 1]: first_idx = 0 would wrap to the LAST keyframe here and read out of bounds in the C++ twin)
+    if first_idx < 1 or n_poses < first_idx or max(n_poses - 1, 0) > len(kt) or max(n_poses - 1, 0) > len(trans):
+        raise ValueError("select_batch_gnss_epochs: need first_idx >= 1 and n_poses - 1 <= len(keyframe_time), len(trans)")
     if len(kt) == 0:
         return out
     for e, T in enumerate(np.asarray(obs_local_ts, float)):

@@ -2073,7 +2073,7 @@ struct FrameHash {
 };
 struct glio_bassoc {
     int device; hipStream_t stream;
-    int prep_nb, prep_todo[64], prep_n[64], prep_tc[64]; long long prep_ns;      // glio_bassoc_prepare_async: the first batch of search frames whose descriptors are on the device and whose tables are cleared
+    int prep_nb, prep_todo[64], prep_n[64], prep_tc[64];      // glio_bassoc_prepare_async: the first batch of search frames whose descriptors are on the device and whose tables are cleared
     hipEvent_t ev_scan;             // glio_bassoc_set_frame_from_scan: the point of the context's stream the copy of its scan waits for (no host wait)
     int K, cap; long long max_con;
     float inv_cell, cell;
@@ -2099,7 +2099,10 @@ struct glio_bassoc {
     long long* h_tail;              // pinned [2]: running total, overflow flag of the last run
     double* h_poses; int32_t* h_pairs; FrameDesc* h_fd;      // pinned staging of a run's inputs ([K][7], [2][max_pairs], [K]): the asynchronous run returns before they are read
     GlioRawStage raw_stage;         // staging of strided clouds (glio_bassoc_set_frame_strided)
-    int pending_pairs;              // pairs of an asynchronous run whose counts were not picked up yet (-1: none)
+    int pending_pairs;              // pairs of an asynchronous run that is still on the stream (-1: none)
+    int done_pairs, done_overflow;  // ... of a run the stream was waited for (by any entry point) but whose counts glio_bassoc_finish has not fetched yet (-1: none):
+                                    // they stay in h_pair_off / h_tail until it does (or until the next run replaces them)
+    hipEvent_t ev_fb; int fb_in_flight;   // the last upload of build descriptors from the pinned h_fb (rewritten only behind it)
     double* d_poses;                // [K][7]
     // feature selection scratch (grow-only): the gathered records and their source indices
     float4* d_sel_cp; double* d_sel_nc; double* d_sel_score; long long* d_sel_idx; long long sel_cap;      // (d_sel_idx: [1 + cap], word 0 = the new running total)
@@ -2287,7 +2290,7 @@ int glio_bassoc_create(int device, int K, int max_points_per_frame, int64_t max_
     b->kb = knn_bin_create(BA_CHUNK, b->cap);
     if (!b->kb) return GLIO_E_HIP;
     BA_CHECK(hipHostMalloc((void**)&b->h_tail, 16)); BA_CHECK(hipHostMalloc((void**)&b->h_poses, (size_t)K * 7 * 8)); BA_CHECK(hipHostMalloc((void**)&b->h_fd, (size_t)K * sizeof(FrameDesc)));
-    b->h_tail[0] = b->h_tail[1] = 0; b->pending_pairs = -1;
+    b->h_tail[0] = b->h_tail[1] = 0; b->pending_pairs = -1; b->done_pairs = -1; b->done_overflow = 0;
     BA_CHECK(hipMemsetAsync(b->d_run, 0, 16, b->stream));
     BA_CHECK(hipStreamSynchronize(b->stream));
     *out = b;
@@ -2319,17 +2322,19 @@ void glio_bassoc_destroy(glio_bassoc* b) {
     delete[] b->h_n; delete[] b->frames;
     if (b->ev_scan) hipEventDestroy(b->ev_scan);
     if (b->ev_sel) hipEventDestroy(b->ev_sel);
+    if (b->ev_fb) hipEventDestroy(b->ev_fb);
     if (b->h_sel) hipHostFree(b->h_sel);
     hipStreamDestroy(b->stream);
     delete b;
 }
 
+static int bassoc_drain(glio_bassoc* b);
 int glio_bassoc_set_frame(glio_bassoc* b, int k, const float* scan_xyzi, int n) { return glio_bassoc_set_frame_strided(b, k, scan_xyzi, n, 16, 12); }
 int glio_bassoc_set_frame_strided(glio_bassoc* b, int k, const void* scan, int n, int stride_bytes, int intensity_offset) {
     if (!b || k < 0 || k >= b->K || n < 0 || n > b->cap || (n > 0 && !scan)) { glio_set_error("bad keyframe cloud (k %d, n %d)", k, n); return GLIO_E_ARG; }
     if (!glio_point_layout_ok(stride_bytes, intensity_offset)) { glio_set_error("bad point layout (stride %d, intensity at %d)", stride_bytes, intensity_offset); return GLIO_E_ARG; }
     BA_CHECK(hipSetDevice(b->device));
-    { const int rf = glio_bassoc_finish(b, nullptr, nullptr); if (rf != GLIO_OK) return rf; }      // (an asynchronous run may still read the clouds)
+    { const int rf = bassoc_drain(b); if (rf != GLIO_OK) return rf; }      // (an asynchronous run may still read the clouds)
     { const int ru = glio_upload_points(b->stream, &b->raw_stage, scan, n, stride_bytes, intensity_offset, b->d_local + (size_t)k * b->cap); if (ru != GLIO_OK) return ru; }
     enqueue_presort(b->stream, b->kb, b->d_local + (size_t)k * b->cap, n, b->d_local_ps + (size_t)k * b->cap);
     BA_CHECK(hipGetLastError());
@@ -2341,12 +2346,24 @@ int glio_bassoc_set_frame_strided(glio_bassoc* b, int k, const void* scan, int n
 // one association run: hashes of every search frame at the given poses, then the pairs in the caller's order.  append: the records go behind what the
 // object already holds (the per-keyframe calls of batchFeatureAssociation, Estimator.cpp:3413-3432, accumulate gl_vec_surf_* this way); wait = 0: everything
 // is enqueued on the object's stream and the call returns (inputs are staged in pinned memory first) -- glio_bassoc_finish picks the counts up.
-static int bassoc_finish(glio_bassoc* b, int64_t* pair_count_out, int64_t* total_out) {
+// An asynchronous run has two states behind it.  DRAINED: the stream was waited for (every entry point that touches what the run reads or writes does that
+// first) -- the run's counts and its overflow flag then lie in the pinned h_pair_off / h_tail.  COLLECTED: glio_bassoc_finish handed them to the caller.
+// bassoc_drain only moves a run from "on the stream" to "drained": the counts of a run are reported to glio_bassoc_finish and to nobody else, and its overflow
+// is reported there too (advisor finding of round 5: side calls used to consume both).
+static int bassoc_drain(glio_bassoc* b) {
     if (b->pending_pairs < 0) return GLIO_OK;
-    const int n_pairs = b->pending_pairs;
     BA_CHECK(hipStreamSynchronize(b->stream));
+    b->done_pairs = b->pending_pairs;
+    b->done_overflow = *reinterpret_cast<int*>(&b->h_tail[1]) != 0;
     b->pending_pairs = -1;
-    if (*reinterpret_cast<int*>(&b->h_tail[1])) { glio_set_error("more constraints than max_constraints (%lld)", b->max_con); return GLIO_E_ARG; }
+    return GLIO_OK;
+}
+static int bassoc_finish(glio_bassoc* b, int64_t* pair_count_out, int64_t* total_out) {
+    { const int rd = bassoc_drain(b); if (rd != GLIO_OK) return rd; }
+    if (b->done_pairs < 0) { if (total_out) *total_out = b->h_tail[0]; return GLIO_OK; }
+    const int n_pairs = b->done_pairs;
+    b->done_pairs = -1;
+    if (b->done_overflow) { b->done_overflow = 0; glio_set_error("more constraints than max_constraints (%lld)", b->max_con); return GLIO_E_ARG; }
     if (pair_count_out) for (int p = 0; p < n_pairs; ++p) pair_count_out[p] = b->h_pair_off[p + 1] - b->h_pair_off[p];
     if (total_out) *total_out = b->h_tail[0];
     return GLIO_OK;
@@ -2371,7 +2388,17 @@ static void bassoc_fill_batch(glio_bassoc* b, const int* todo, const size_t t0, 
     }
     *max_tc_out = max_tc; *max_n_out = max_n;
 }
-static int bassoc_finish(glio_bassoc* b, int64_t* pair_count_out, int64_t* total_out);
+// the pinned descriptor block h_fb is the source of asynchronous copies: it is rewritten only after the last of them has left it
+static int bassoc_fb_reusable(glio_bassoc* b) {
+    if (b->fb_in_flight) { BA_CHECK(hipEventSynchronize(b->ev_fb)); b->fb_in_flight = 0; }
+    return GLIO_OK;
+}
+static int bassoc_fb_uploaded(glio_bassoc* b) {
+    if (!b->ev_fb) BA_CHECK(hipEventCreateWithFlags(&b->ev_fb, hipEventDisableTiming));
+    BA_CHECK(hipEventRecord(b->ev_fb, b->stream));
+    b->fb_in_flight = 1;
+    return GLIO_OK;
+}
 // What a run does before it needs the poses: the build descriptors of its (first batch of) search frames go to the device and their hash tables are
 // cleared.  A caller that knows its pairs before it knows its poses (batchFeatureAssociation of a keyframe call: the pairs follow from the keyframe
 // count, the poses from the solve) calls this first; the run that follows with the same search frames skips both (0.02 ms off the start of the
@@ -2379,7 +2406,7 @@ static int bassoc_finish(glio_bassoc* b, int64_t* pair_count_out, int64_t* total
 extern "C" int glio_bassoc_prepare_async(glio_bassoc* b, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj) {
     if (!b || n_pairs < 0 || (n_pairs > 0 && (!pair_ci || !pair_cj))) return GLIO_E_ARG;
     BA_CHECK(hipSetDevice(b->device));
-    { const int rf = bassoc_finish(b, nullptr, nullptr); if (rf != GLIO_OK) return rf; }          // (an earlier asynchronous run still uses the build scratch)
+    { const int rf = bassoc_drain(b); if (rf != GLIO_OK) return rf; }          // (an earlier asynchronous run still uses the build scratch)
     b->prep_nb = 0;
     std::vector<char> need(b->K, 0);
     for (int p = 0; p < n_pairs; ++p) { if (pair_cj[p] < 0 || pair_cj[p] >= b->K) { glio_set_error("bad pair %d", p); return GLIO_E_ARG; } need[pair_cj[p]] = 1; }
@@ -2387,13 +2414,14 @@ extern "C" int glio_bassoc_prepare_async(glio_bassoc* b, int n_pairs, const int3
     for (int k = 0; k < b->K && nb < BA_FB; ++k) if (need[k]) todo[nb++] = k;
     if (nb == 0) return GLIO_OK;
     int max_tc = 0, max_n = 0;
+    { const int rw = bassoc_fb_reusable(b); if (rw != GLIO_OK) return rw; }
     bassoc_fill_batch(b, todo, 0, nb, &max_tc, &max_n);
     BA_CHECK(hipMemcpyAsync(b->d_fb, b->h_fb, (size_t)nb * sizeof(FrameBuild), hipMemcpyHostToDevice, b->stream));
+    { const int rw = bassoc_fb_uploaded(b); if (rw != GLIO_OK) return rw; }
     hipLaunchKernelGGL(k_hash_clear_multi, dim3((max_tc + 255) / 256, nb), dim3(256), 0, b->stream, static_cast<const FrameBuild*>(b->d_fb));
     BA_CHECK(hipGetLastError());
     for (int q = 0; q < nb; ++q) { b->prep_todo[q] = todo[q]; b->prep_n[q] = b->h_n[todo[q]]; b->prep_tc[q] = b->h_fb[q].tc; }
     b->prep_nb = nb;
-    b->prep_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
     return GLIO_OK;
 }
 
@@ -2402,7 +2430,13 @@ static int bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const in
     GLIO_TRACE("K2 glio_bassoc_run (batch association)");
     if (!b || !poses || n_pairs < 0 || (n_pairs > 0 && (!pair_ci || !pair_cj))) return GLIO_E_ARG;
     BA_CHECK(hipSetDevice(b->device));
-    { const int rf = bassoc_finish(b, nullptr, nullptr); if (rf != GLIO_OK) return rf; }          // (an earlier asynchronous run still reads the staging buffers)
+    { const int rf = bassoc_drain(b); if (rf != GLIO_OK) return rf; }          // (an earlier asynchronous run still reads the staging buffers)
+    // a drained run nobody collected: this run replaces its counts in the pinned buffers -- but its overflow must not get lost with them
+    if (b->done_pairs >= 0) {
+        const int ov = b->done_overflow;
+        b->done_pairs = -1; b->done_overflow = 0;
+        if (ov) { glio_set_error("more constraints than max_constraints (%lld) in the previous asynchronous run", b->max_con); return GLIO_E_ARG; }
+    }
     for (int p = 0; p < n_pairs; ++p)
         if (pair_ci[p] < 0 || pair_ci[p] >= b->K || pair_cj[p] < 0 || pair_cj[p] >= b->K || pair_ci[p] == pair_cj[p]) { glio_set_error("bad pair %d", p); return GLIO_E_ARG; }
     if (n_pairs > b->max_pairs) {
@@ -2424,19 +2458,29 @@ static int bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const in
     {
         std::vector<int> todo;
         for (int k = 0; k < b->K; ++k) if (need[k]) todo.push_back(k);
+        bool fb_checked = false, fb_written = false;
         for (size_t t0 = 0; t0 < todo.size(); t0 += BA_FB) {
             const int nb = (int)std::min<size_t>(BA_FB, todo.size() - t0);
             int max_tc = 0, max_n = 0;
-            bassoc_fill_batch(b, todo.data() + t0, t0, nb, &max_tc, &max_n);
-            const FrameBuild* dfb = b->d_fb + t0;
-            // glio_bassoc_prepare_async has sent this batch's descriptors and cleared its tables already (same keyframes, same sizes, nothing run since)?
-            // (... and recently: a preparation is meant to bridge one solve, ~0.4 ms; one older than 20 ms is simply not used)
-            bool prepared = t0 == 0 && b->prep_nb == nb &&
-                            std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() - b->prep_ns < 20000000ll;
-            for (int q = 0; prepared && q < nb; ++q) prepared = b->prep_todo[q] == todo[q] && b->prep_n[q] == b->h_n[todo[q]] && b->prep_tc[q] == b->h_fb[q].tc;
+            // glio_bassoc_prepare_async has sent this batch's descriptors and cleared its tables already (same keyframes, same sizes, nothing run since)?  The
+            // answer follows from what was prepared alone -- never from how long ago (advisor finding of round 5: a wall-clock test made the kernel sequence
+            // depend on host timing).  A prepared batch's descriptors are NOT rebuilt: they are on the device as the preparation wrote them.
+            bool prepared = t0 == 0 && b->prep_nb == nb;
+            for (int q = 0; prepared && q < nb; ++q) {
+                const int k = todo[q], n = b->h_n[k];
+                int tc = next_pow2(2 * (n > 512 ? n : 512));
+                if (tc > b->frames[k].table_cap) tc = b->frames[k].table_cap;
+                prepared = b->prep_todo[q] == k && b->prep_n[q] == n && b->prep_tc[q] == tc;
+            }
             b->prep_nb = 0;
-            if (!prepared) {
+            const FrameBuild* dfb = b->d_fb + t0;
+            if (prepared) {
+                for (int q = 0; q < nb; ++q) { if (b->prep_tc[q] > max_tc) max_tc = b->prep_tc[q]; if (b->prep_n[q] > max_n) max_n = b->prep_n[q]; }
+            } else {
+                if (!fb_checked) { const int rw = bassoc_fb_reusable(b); if (rw != GLIO_OK) return rw; fb_checked = true; }   // (once per run: its batches write distinct parts of h_fb)
+                bassoc_fill_batch(b, todo.data() + t0, t0, nb, &max_tc, &max_n);
                 BA_CHECK(hipMemcpyAsync(b->d_fb + t0, b->h_fb + t0, (size_t)nb * sizeof(FrameBuild), hipMemcpyHostToDevice, b->stream));
+                fb_written = true;
                 hipLaunchKernelGGL(k_hash_clear_multi, dim3((max_tc + 255) / 256, nb), dim3(256), 0, b->stream, dfb);
             }
             if (max_n == 0) continue;
@@ -2445,6 +2489,7 @@ static int bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const in
             hipLaunchKernelGGL(k_cell_alloc_multi, dim3((max_tc + 1023) / 1024, nb), dim3(1024), 0, b->stream, dfb);
             hipLaunchKernelGGL(k_scatter_multi, dim3((max_n + 255) / 256, nb), dim3(256), 0, b->stream, dfb);
         }
+        if (fb_written) { const int rw = bassoc_fb_uploaded(b); if (rw != GLIO_OK) return rw; }
     }
     // (2) the pairs, in the caller's (ci, cj) order, BA_CHUNK pairs per launch (blockIdx.y = pair of the chunk)
     if (n_pairs > 0) {
@@ -2498,13 +2543,13 @@ int glio_bassoc_run_append_async(glio_bassoc* b, const double* poses, int n_pair
 int glio_bassoc_finish(glio_bassoc* b, int64_t* pair_count_out, int64_t* total_out) {
     if (!b) return GLIO_E_ARG;
     BA_CHECK(hipSetDevice(b->device));
-    if (b->pending_pairs < 0) { if (total_out) *total_out = b->h_tail[0]; return GLIO_OK; }
     return bassoc_finish(b, pair_count_out, total_out);
 }
 int glio_bassoc_reset(glio_bassoc* b) {
     if (!b) return GLIO_E_ARG;
     BA_CHECK(hipSetDevice(b->device));
-    { const int rf = bassoc_finish(b, nullptr, nullptr); if (rf != GLIO_OK) return rf; }
+    { const int rf = bassoc_drain(b); if (rf != GLIO_OK) return rf; }
+    b->done_pairs = -1; b->done_overflow = 0;              // (a reset drops the records, and with them what an uncollected run had to say)
     BA_CHECK(hipMemsetAsync(b->d_run, 0, 16, b->stream));
     b->h_tail[0] = b->h_tail[1] = 0;
     return GLIO_OK;
@@ -2519,7 +2564,7 @@ int glio_bassoc_set_frame_from_scan(glio_bassoc* b, int k, glio_ctx* c, int slot
     const int n = c->h_scan_count[slot];
     if (n > b->cap) { glio_set_error("scan of %d points, the batch association holds %d per keyframe", n, b->cap); return GLIO_E_ARG; }
     BA_CHECK(hipSetDevice(b->device));
-    { const int rf = bassoc_finish(b, nullptr, nullptr); if (rf != GLIO_OK) return rf; }
+    { const int rf = bassoc_drain(b); if (rf != GLIO_OK) return rf; }
     // the upload of the scan (and its presort) ran on the context's stream: this stream waits for that point, the host does not
     if (!b->ev_scan) BA_CHECK(hipEventCreateWithFlags(&b->ev_scan, hipEventDisableTiming));
     BA_CHECK(hipEventRecord(b->ev_scan, c->stream));
@@ -2534,6 +2579,10 @@ int glio_bassoc_set_frame_from_scan(glio_bassoc* b, int k, glio_ctx* c, int slot
             hipLaunchKernelGGL(k_copy_offset, dim3((n + 255) / 256), dim3(256), 0, b->stream, c->assoc->d_ps + row, n, lidar_offset[0], lidar_offset[1], lidar_offset[2],
                                b->d_local_ps + (size_t)k * b->cap);
         else enqueue_presort(b->stream, b->kb, b->d_local + (size_t)k * b->cap, n, b->d_local_ps + (size_t)k * b->cap);
+        // ... and the context must not overwrite the row (glio_set_scan after W slides of the ring), nor be destroyed, before these copies have read it
+        if (!c->ev_ext_read) BA_CHECK(hipEventCreateWithFlags(&c->ev_ext_read, hipEventDisableTiming));
+        BA_CHECK(hipEventRecord(c->ev_ext_read, b->stream));
+        c->ext_read_pending = 1;
     }
     BA_CHECK(hipGetLastError());
     b->h_n[k] = n;
@@ -2583,7 +2632,7 @@ __global__ void k_bassoc_put(const long long first, const long long n, const flo
 int glio_bassoc_select_range(glio_bassoc* b, int64_t first, int64_t n_keep, const int64_t* src_index, int64_t n_current) {
     if (!b || first < 0 || n_keep < 0 || n_current < first || n_current > b->max_con || n_keep > n_current - first || (n_keep > 0 && !src_index)) return GLIO_E_ARG;
     BA_CHECK(hipSetDevice(b->device));
-    { const int rf = bassoc_finish(b, nullptr, nullptr); if (rf != GLIO_OK) return rf; }
+    { const int rf = bassoc_drain(b); if (rf != GLIO_OK) return rf; }
     for (int64_t k = 0; k < n_keep; ++k) if (src_index[k] < first || src_index[k] >= n_current) { glio_set_error("selection index %lld out of range", (long long)src_index[k]); return GLIO_E_ARG; }
     // ONE pinned block [new running total | the indices] -> one copy, the gather into the staging arrays, one kernel that puts the records (and the total) in
     // place; nothing is waited for: every later consumer is on this stream or synchronises it (glio_bassoc_read, glio_bassoc_results_dev).  (It used to be
@@ -2627,7 +2676,7 @@ int glio_bassoc_select_range(glio_bassoc* b, int64_t first, int64_t n_keep, cons
 int glio_bassoc_read(glio_bassoc* b, int64_t first, int64_t n, float* cp, double* norm_cent, double* score) {
     if (!b || first < 0 || n < 0 || first + n > b->max_con) return GLIO_E_ARG;
     BA_CHECK(hipSetDevice(b->device));
-    { const int rf = glio_bassoc_finish(b, nullptr, nullptr); if (rf != GLIO_OK) return rf; }
+    { const int rf = bassoc_drain(b); if (rf != GLIO_OK) return rf; }
     BA_CHECK(hipStreamSynchronize(b->stream));                       // (a selection may still be compacting the arrays)
     if (n == 0) return GLIO_OK;
     if (cp) BA_CHECK(hipMemcpy(cp, b->d_cp + first, (size_t)n * 16, hipMemcpyDeviceToHost));

@@ -206,7 +206,9 @@ __global__ __launch_bounds__(64) void k_small_eval(const BtSel sel, const int n_
             }
         }
     } else {
+#pragma clang fp contract(off)
         // dd_psr_factor_20::Evaluate (dd_psr_factor.hpp:25-171): one lane per satellite, then W r / W J by one lane per row
+        // (no FMA contraction: double differences of ~2.6e7 m ranges round like the reference's scalar build)
         nr = 19;
         const glio_dd_psr& F = dd[fidx[f]];
         const int ns = F.n_sat, m = F.master, nw = ns - 1, i = lane;
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(64) void k_small_eval(const BtSel sel, const int n_
                 d_ui[k] = F.user_sat_pos[i][k] - Pe[k]; d_um[k] = F.user_sat_pos[m][k] - Pe[k];
                 d_ri[k] = F.ref_sat_pos[i][k] - F.station[k]; d_rm[k] = F.ref_sat_pos[m][k] - F.station[k];
             }
-            const double r_ui = sqrt(d_dot3(d_ui, d_ui)), r_um = sqrt(d_dot3(d_um, d_um)), r_ri = sqrt(d_dot3(d_ri, d_ri)), r_rm = sqrt(d_dot3(d_rm, d_rm));
+            const double r_ui = sqrt(d_dot3_nc(d_ui, d_ui)), r_um = sqrt(d_dot3_nc(d_um, d_um)), r_ri = sqrt(d_dot3_nc(d_ri, d_ri)), r_rm = sqrt(d_dot3_nc(d_rm, d_rm));
             const double est = (r_ui - r_ri) - (r_um - r_rm);
             const double obs = (F.user_psr[i] - F.ref_psr[i]) - (F.user_psr[m] - F.ref_psr[m]);
             const double wgt = fabs(est - obs) > F.threshold ? 0.05 : 1.0;

@@ -141,6 +141,7 @@ static int create_body(int device, const glio_opts* opts, glio_ctx* c) {
         else GLIO_HIP_CHECK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     }
     c->stream = c->own_stream;
+    { hipDeviceProp_t prop; c->n_cu = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 0; }
     const size_t wc = (size_t)W * c->cap;
     ALLOC(c->d_pts, wc * sizeof(float4)); ALLOC(c->d_planes, wc * sizeof(float4)); ALLOC(c->d_scores, wc * sizeof(double));
     ALLOC(c->d_count, W * sizeof(int)); ALLOC(c->d_scan, wc * sizeof(float4));
@@ -243,6 +244,7 @@ void glio_destroy(glio_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->ev_ext_read) { if (c->ext_read_pending) hipEventSynchronize(c->ev_ext_read); hipEventDestroy(c->ev_ext_read); c->ev_ext_read = nullptr; }
     glio_assoc_destroy(c);
     glio_localmap_destroy(c);
     void* ptrs[] = {c->d_pts, c->d_planes, c->d_scores, c->d_pts_s, c->d_count, c->d_scan, c->d_imu, c->d_imu_blocks, c->d_gnss_blocks, c->d_groups,
@@ -367,6 +369,8 @@ int glio_set_scan_strided(glio_ctx* c, int slot, const void* scan, int n, int st
     if (!c || slot < 0 || slot >= c->W || n < 0 || n > c->cap || (n > 0 && !scan)) { glio_set_error("bad slot / scan size"); return GLIO_E_ARG; }
     if (!glio_point_layout_ok(stride_bytes, intensity_offset)) { glio_set_error("bad point layout (stride %d, intensity at %d)", stride_bytes, intensity_offset); return GLIO_E_ARG; }
     GLIO_HIP_CHECK(hipSetDevice(c->device));
+    // (a copy of a resident scan on another stream -- glio_bassoc_set_frame_from_scan -- may still be reading the row this call overwrites)
+    if (c->ext_read_pending) { GLIO_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_ext_read, 0)); c->ext_read_pending = 0; }
     { const int ru = glio_upload_points(c->stream, &c->raw_stage, scan, n, stride_bytes, intensity_offset, c->d_scan + (size_t)glio_scan_row(c, slot) * c->cap); if (ru != GLIO_OK) return ru; }
     // the caller's buffer must have been read when the call returns: that is the copy, not the presort enqueued behind it (0.03 ms that the next call's
     // launches now overlap)

@@ -17,6 +17,7 @@
 
 // out: res[19] | J_Pi[19][3] | J_Pj[19][3]
 __global__ __launch_bounds__(64) void k_eval_dd(const glio_dd_psr* __restrict__ Fp, const double* __restrict__ prm /* Pi3 Pj3 R9 anc3 */, double* out) {
+#pragma clang fp contract(off)
     __shared__ double raw[19], Ji[57], Jj[57];
     const glio_dd_psr& F = *Fp;
     const int i = threadIdx.x, ns = F.n_sat, m = F.master, nw = ns - 1;
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(64) void k_eval_dd(const glio_dd_psr* __restrict__ 
             d_ui[k] = F.user_sat_pos[i][k] - Pe[k]; d_um[k] = F.user_sat_pos[m][k] - Pe[k];
             d_ri[k] = F.ref_sat_pos[i][k] - F.station[k]; d_rm[k] = F.ref_sat_pos[m][k] - F.station[k];
         }
-        const double r_ui = sqrt(d_dot3(d_ui, d_ui)), r_um = sqrt(d_dot3(d_um, d_um)), r_ri = sqrt(d_dot3(d_ri, d_ri)), r_rm = sqrt(d_dot3(d_rm, d_rm));
+        const double r_ui = sqrt(d_dot3_nc(d_ui, d_ui)), r_um = sqrt(d_dot3_nc(d_um, d_um)), r_ri = sqrt(d_dot3_nc(d_ri, d_ri)), r_rm = sqrt(d_dot3_nc(d_rm, d_rm));
         const double est = (r_ui - r_ri) - (r_um - r_rm);
         const double obs = (F.user_psr[i] - F.ref_psr[i]) - (F.user_psr[m] - F.ref_psr[m]);
         const double wgt = fabs(est - obs) > F.threshold ? 0.05 : 1.0;
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(64) void k_eval_dd(const glio_dd_psr* __restrict__ 
 
 // out: res | J_Pi[3] | J_Vi[3] | J_Pj[3] | J_Vj[3] | d/d ddt
 __global__ void k_eval_doppler(const glio_doppler* __restrict__ Fp, const double* __restrict__ prm /* Pi3 Vi3 Pj3 Vj3 ddt anc3 */, double* out) {
+#pragma clang fp contract(off)
     if (threadIdx.x != 0) return;
     const glio_doppler& F = *Fp;
     const double OMG = 7.2921151467e-5, CLIGHT = 2.99792458e8;
@@ -75,11 +77,11 @@ __global__ void k_eval_doppler(const glio_doppler* __restrict__ Fp, const double
         Ve[k] = Rf[3 * k] * lv[0] + Rf[3 * k + 1] * lv[1] + Rf[3 * k + 2] * lv[2];
     }
     const double d[3] = {F.sat_pos[0] - Pe[0], F.sat_pos[1] - Pe[1], F.sat_pos[2] - Pe[2]};
-    const double rho = sqrt(d_dot3(d, d));
+    const double rho = sqrt(d_dot3_nc(d, d));
     const double eh[3] = {d[0] / rho, d[1] / rho, d[2] / rho};
     const double sag = OMG / CLIGHT * (F.sat_vel[0] * Pe[1] + F.sat_pos[0] * Ve[1] - F.sat_vel[1] * Pe[0] - F.sat_pos[1] * Ve[0]);
     const double av[3] = {F.sat_vel[0] - Ve[0], F.sat_vel[1] - Ve[1], F.sat_vel[2] - Ve[2]};
-    const double ae = d_dot3(av, eh);
+    const double ae = d_dot3_nc(av, eh);
     out[0] = (ae + sag + ddt - F.sv_ddt + F.doppler * F.lamda) / F.var;
     double gP[3], gV[3];
     for (int k = 0; k < 3; ++k) { gP[k] = -(av[k] - ae * eh[k]) / rho; gV[k] = -eh[k]; }

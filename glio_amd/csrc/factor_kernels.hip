@@ -300,6 +300,9 @@ struct GnssLds {
 };
 __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, const GnssGroup& gr, int gidx,
                            PairBlock* out, DdtBlock* ddt_out, unsigned char* pool, const int which) {
+    // rounds like the reference's scalar build: no FMA contraction anywhere in the GNSS role (double differences of ~2.6e7 m ranges; O(10^2) rows,
+    // no measurable cost) -- tests/test_golden_ref.py holds its residuals to the reference's vectors at 1e-11
+#pragma clang fp contract(off)
     // All factors of the pair are evaluated SIDE BY SIDE (DD factor f -> lanes 32 f' .. 32 f' + 31, Doppler row -> one
     // lane).  These are chains of dependent global loads (~1-2 us each on this part), so what counts is the number of
     // latency ROUNDS, not the arithmetic: everything a factor needs is fetched in one round (per-satellite quantities by
@@ -355,7 +358,7 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
                 double d_u[3], d_r[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { d_u[k] = F.user_sat_pos[i][k] - Pe[k]; d_r[k] = F.ref_sat_pos[i][k] - F.station[k]; }
-                const double r_u = sqrt(d_dot3(d_u, d_u)), r_r = sqrt(d_dot3(d_r, d_r));
+                const double r_u = sqrt(d_dot3_nc(d_u, d_u)), r_r = sqrt(d_dot3_nc(d_r, d_r));
                 sRu[fl][i] = r_u; sRr[fl][i] = r_r; sObs[fl][i] = F.user_psr[i] - F.ref_psr[i];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) sE[fl][i][c] = (d_u[0] * R[c] + d_u[1] * R[3 + c] + d_u[2] * R[6 + c]) / r_u;
@@ -442,11 +445,11 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
                 Ve[k] = Rf[3 * k] * lv[0] + Rf[3 * k + 1] * lv[1] + Rf[3 * k + 2] * lv[2];
             }
             const double d[3] = {F.sat_pos[0] - Pe[0], F.sat_pos[1] - Pe[1], F.sat_pos[2] - Pe[2]};
-            const double rho = sqrt(d_dot3(d, d));
+            const double rho = sqrt(d_dot3_nc(d, d));
             const double eh[3] = {d[0] / rho, d[1] / rho, d[2] / rho};
             const double sag = OMG / CLIGHT * (F.sat_vel[0] * Pe[1] + F.sat_pos[0] * Ve[1] - F.sat_vel[1] * Pe[0] - F.sat_pos[1] * Ve[0]);
             const double av[3] = {F.sat_vel[0] - Ve[0], F.sat_vel[1] - Ve[1], F.sat_vel[2] - Ve[2]};
-            const double ae = d_dot3(av, eh);
+            const double ae = d_dot3_nc(av, eh);
             const double ddt = x[16 * W + F.epoch];
             const double res = (ae + sag + ddt - F.sv_ddt + F.doppler * F.lamda) / F.var;
             double gP[3], gV[3];

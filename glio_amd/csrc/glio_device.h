@@ -244,6 +244,9 @@ struct glio_ctx {
                                   // assembly and structure change)
     int want_pair_H;              // 0: the linearisation in flight feeds k_chain_step only (chain slices, g, cost): the 30 x 30 pair blocks are not written
     double* d_chain_src;                      // [2][W][GLIO_CS_SOURCES][GLIO_CS_STRIDE] chain-layout contributions, double buffered
+    hipEvent_t ev_ext_read; int ext_read_pending;   // another object's stream is still READING the resident scans (glio_bassoc_set_frame_from_scan copies one on the
+                                                    // batch association's stream): the next write to a scan row, and glio_destroy, come behind this event
+    int n_cu;                                 // compute units of THIS context's device (the helper workgroups of k_chain_step need 2 (1 + W) of them)
 };
 
 static inline int glio_x_size(int W, int n_ddt) { return 16 * W + n_ddt; }
@@ -257,6 +260,12 @@ __device__ __forceinline__ void d_cross(const double a[3], const double b[3], do
     o[0] = x; o[1] = y; o[2] = z;
 }
 __device__ __forceinline__ double d_dot3(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+// the same with every product rounded before it is added (no FMA contraction): the GNSS roles difference ranges of ~2.6e7 m, where the
+// reference's build (scalar x86, no FMA) and a contracted sum differ by ulps of the RANGE -- orders above the residual's own rounding
+__device__ __forceinline__ double d_dot3_nc(const double a[3], const double b[3]) {
+#pragma clang fp contract(off)
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
 __device__ __forceinline__ void d_qmul(const double a[4], const double b[4], double o[4]) {
     const double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
     const double x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];

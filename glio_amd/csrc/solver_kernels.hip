@@ -509,7 +509,7 @@ struct PrepMirror {
     long long* dbg;                                            // stamped builds: device-clock marks of the state machine's sections (slots 80..)
     // k_chain_step's helper workgroups read the status record this function rewrites at its end: their completion words (2 * hseq + produced) are
     // requested at entry and checked before that store; *hprod is cleared when one of them had nothing to produce
-    const int* hdone; int hseq; int helpers; int* hprod;
+    const int* hdone; int hseq; int helpers; int* hprod; int hpolls;
 };
 #ifdef GLIO_DEV_STAMPS
 #define PM_STAMP(k) do { if (FAST && m->dbg && threadIdx.x == 0) m->dbg[k] = wall_clock64(); } while (0)
@@ -689,8 +689,12 @@ __device__ __forceinline__ bool tr_prepare_body(const TrArgs& a, TrDecision* out
     if (FAST && m->helpers && tid < m->helpers) {
         // (relaxed polling: the reader of the helpers' sums issues the acquire fence; the barrier below puts every helper's read of the record
         //  before the store that replaces it)
-        while ((hword >> 1) != m->hseq) { __builtin_amdgcn_s_sleep(1); hword = __hip_atomic_load(&m->hdone[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-        if (!(hword & 1)) *m->hprod = 0;
+        // BOUNDED: HIP promises no forward progress between the workgroups of a launch -- on a device with fewer free CUs than the host assumed (CU masks,
+        // partitions, a co-tenant) a helper may not even have started.  After hpolls polls the step stops waiting and sums the blocks itself (*hprod = 0);
+        // a helper that starts late reads the rewritten record, leaves sums nobody reads and ends -- the next launch cannot start before it has.
+        int polls = 0;
+        while ((hword >> 1) != m->hseq && polls < m->hpolls) { ++polls; __builtin_amdgcn_s_sleep(1); hword = __hip_atomic_load(&m->hdone[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        if ((hword >> 1) != m->hseq || !(hword & 1)) *m->hprod = 0;
     }
     PB_SYNC();
     PM_STAMP(86);
@@ -2106,7 +2110,7 @@ struct ChainArgs {
     double* blk;              // k_chain_solve<true>: [W][KC_BLK] the staged blocks in global memory (windows whose blocks do not fit the LDS)
     // k_chain_step's helper workgroups (grid = 1 + helpers): workgroup 1 + i sums the candidate's block entries of keyframe i over their six sources
     // while workgroup 0 runs the front and the state machine; hsum [W][GLIO_CS_STRIDE], hdone [W] = 2 * hseq + produced
-    int helpers; int hseq; double* hsum; int* hdone;
+    int helpers; int hseq; double* hsum; int* hdone; int hpolls;      // hpolls: how often workgroup 0 polls a completion word before it gives the helpers up
 };
 
 // The kernel also does the work of k_tr_prepare (state machine, scaling vectors) and of k_tr_scale for this structure: it
@@ -2921,9 +2925,9 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
         GLIO_BLOCK_LDS_SYNC();
         if (!ff) {
             if (tid < a.helpers) {
-                int v;
-                while (((v = __hip_atomic_load(&a.hdone[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 1) != a.hseq) __builtin_amdgcn_s_sleep(1);
-                if (!(v & 1)) s_hprod = 0;
+                int v, polls = 0;          // (bounded like the state machine's wait: see tr_prepare_body)
+                while (((v = __hip_atomic_load(&a.hdone[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 1) != a.hseq && polls < a.hpolls) { ++polls; __builtin_amdgcn_s_sleep(1); }
+                if ((v >> 1) != a.hseq || !(v & 1)) s_hprod = 0;
             }
             GLIO_BLOCK_LDS_SYNC();
         }
@@ -2935,7 +2939,7 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
     if (ff) {
         PrepMirror pm;
         pm.st_in = &s_in; pm.x0 = xm0; pm.x1 = xm1; pm.hd = sHd; pm.g = sG; pm.cost = sCost; pm.scale = sS; pm.diag = sDg; pm.grad = sGr; pm.dbg = a.dbg;
-        pm.hdone = a.hdone; pm.hseq = a.hseq; pm.helpers = a.helpers; pm.hprod = &s_hprod;
+        pm.hdone = a.hdone; pm.hseq = a.hseq; pm.helpers = a.helpers; pm.hprod = &s_hprod; pm.hpolls = a.hpolls;
         if (!tr_prepare_body<true>(tr, &dec, &pm)) return;
     } else if (!tr_prepare_body(tr, &dec)) return;
     AR_STAMP(43);
@@ -3589,7 +3593,7 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
     if (chain) {
         ChainArgs r;
         r.W = c->W; r.n = a.n; r.nd = n_ddt; r.ep_slots = c->arrow.d_ep_slots; r.ep_off = c->arrow.d_ep_off; r.ep_list = c->arrow.d_ep_list;
-        r.z = c->arrow.d_z; r.flag = c->arrow.d_flag; r.status = c->d_status; r.dbg = c->arrow.d_dbg; r.force_fail = c->arrow.mode == 2; r.fast = chain_fast_mask(); r.blk = nullptr; r.helpers = 0; r.hseq = 0; r.hsum = nullptr; r.hdone = nullptr;
+        r.z = c->arrow.d_z; r.flag = c->arrow.d_flag; r.status = c->d_status; r.dbg = c->arrow.d_dbg; r.force_fail = c->arrow.mode == 2; r.fast = chain_fast_mask(); r.blk = nullptr; r.helpers = 0; r.hseq = 0; r.hsum = nullptr; r.hdone = nullptr; r.hpolls = 0;
         if (chain_step_lds_bytes(c->W, n_ddt, a.n, true) + 2 * 1024 > 158 * 1024) r.fast = 0;      // no room for the LDS mirrors: generic bodies
         size_t lds_step = chain_step_lds_bytes(c->W, n_ddt, a.n, r.fast != 0);
         {   // separator + four fronts when the window is long enough for it to pay and its panels fit (chain_f4_layout)
@@ -3615,13 +3619,16 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
             static const bool helpers_off = getenv("GLIO_CHAIN_HELPERS") && atoi(getenv("GLIO_CHAIN_HELPERS")) == 0;
             // Workgroup 0 WAITS for the helpers' completion words inside the launch, and every workgroup of this launch reserves the whole dynamic LDS
             // grant, i.e. a CU of its own: the hand-over needs 1 + W CUs that the launch can actually get.  HIP promises no forward progress between
-            // workgroups, so the helpers are used only when the device has room to spare (>= 2 (1 + W) CUs); a deployment that masks CUs or partitions the
-            // device below that must set GLIO_CHAIN_HELPERS=0 (the step then sums the blocks itself: 4 us slower, no cross-workgroup wait).  INTEGRATION.md section 5.
-            static int n_cu = -1;
-            if (n_cu < 0) { hipDeviceProp_t prop; n_cu = hipGetDeviceProperties(&prop, c->device) == hipSuccess ? prop.multiProcessorCount : 0; }
-            const bool room = n_cu >= 2 * (1 + c->W);
+            // workgroups, so the helpers are used only when the device has room to spare (>= 2 (1 + W) CUs) AND the wait is bounded (hpolls below): a
+            // deployment that masks CUs or partitions the device cannot hang the step, it only loses the helpers' 4 us (GLIO_CHAIN_HELPERS=0 skips the
+            // attempt).  INTEGRATION.md section 5.
+            const bool room = c->n_cu >= 2 * (1 + c->W);          // (the context's own device: queried at glio_create, not a process-wide value)
             r.helpers = (helpers_off || !room) ? 0 : c->W; r.hsum = c->arrow.d_chain_sum; r.hdone = c->arrow.d_chain_done;
             r.hseq = c->arrow.chain_seq; c->arrow.chain_seq = c->arrow.chain_seq % (1 << 29) + 1;
+            // the wait for the helpers is bounded (a poll is a device-scope load + s_sleep: ~0.5-1 us; the helpers report ~5 us into the launch): ~0.2 ms at
+            // most, then the step sums the blocks itself.  GLIO_CHAIN_HELPER_POLLS=0 gives them up at once (test: same bits out)
+            static const int hpolls = getenv("GLIO_CHAIN_HELPER_POLLS") ? atoi(getenv("GLIO_CHAIN_HELPER_POLLS")) : 256;
+            r.hpolls = hpolls;
             hipLaunchKernelGGL(k_chain_step, dim3(1 + r.helpers), dim3(KC_THREADS), lds_step, c->stream, r, a, G);
             return;                                   // the one launch is the whole step
         }

@@ -458,6 +458,10 @@ struct GnssEpochSlot { int epoch, left_key, right_key; double ts_ratio; };
 inline std::vector<GnssEpochSlot> selectBatchGnssEpochs(const std::vector<double>& obs_local_ts, const std::vector<double>& keyframe_time, int first_idx, int n_poses,
                                                         const std::vector<double>& trans) {
     std::vector<GnssEpochSlot> out;
+    // pose index i reads keyframe_time[i - 1] and trans[i - 1]: first_idx = 0 would index element -1 (the reference's keyframe_idx starts at 1), and the search
+    // runs up to pose n_poses - 1.  Refused here rather than read out of bounds (advisor finding of round 5); select_batch_gnss_epochs raises the same way.
+    if (first_idx < 1 || n_poses < first_idx || (size_t)(n_poses > 0 ? n_poses - 1 : 0) > keyframe_time.size() || 3 * (size_t)(n_poses > 0 ? n_poses - 1 : 0) > trans.size())
+        throw std::invalid_argument("selectBatchGnssEpochs: need first_idx >= 1 and n_poses - 1 <= keyframe_time.size(), trans.size() / 3");
     if (keyframe_time.empty()) return out;
     double padd[3] = {0.0, 0.0, 0.0};
     for (size_t e = 0; e < obs_local_ts.size(); ++e) {

@@ -12,7 +12,9 @@ int main() {
     for (double& x : obs) if (scanf("%lf", &x) != 1) return 2;
     for (double& x : kt) if (scanf("%lf", &x) != 1) return 2;
     for (double& x : tr) if (scanf("%lf", &x) != 1) return 2;
-    for (const glio::GnssEpochSlot& s : glio::selectBatchGnssEpochs(obs, kt, first_idx, n_poses, tr)) printf("epoch %d %d %d %.17g\n", s.epoch, s.left_key, s.right_key, s.ts_ratio);
+    try {
+        for (const glio::GnssEpochSlot& s : glio::selectBatchGnssEpochs(obs, kt, first_idx, n_poses, tr)) printf("epoch %d %d %d %.17g\n", s.epoch, s.left_key, s.right_key, s.ts_ratio);
+    } catch (const std::invalid_argument& e) { printf("refused %s\n", e.what()); return 0; }
     int nu = 0, nr = 0;
     if (scanf("%d %d", &nu, &nr) != 2) return 0;
     std::vector<int> up(nu), rp(nr);

@@ -324,7 +324,10 @@ int glio_bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const int3
 /* batchFeatureAssociation() (Estimator.cpp:3413-3432), the call that ENDS every optimizeSlidingWindowWithLandMark (:2733): the keyframe
  * idx = size - search_range - 1 is matched against its 2 search_range neighbours and the records are ADDED to gl_vec_surf_* -- here: appended behind
  * what the object already holds (pair_count_out: the pairs of this call; total_out: everything held).  _async enqueues on the object's stream and
- * returns (the inputs are staged in pinned memory); glio_bassoc_finish waits and hands the counts over.  glio_bassoc_reset forgets the records. */
+ * returns (the inputs are staged in pinned memory); glio_bassoc_finish waits and hands the counts over.  glio_bassoc_reset forgets the records.
+ * Any other entry point of the object may be called in between (each waits for the run as far as it must): the run's counts -- and its
+ * overflow error, if it produced more than max_constraints records -- are kept for glio_bassoc_finish and reported there ONCE; a second run
+ * started before glio_bassoc_finish replaces the first run's counts, but returns its overflow error instead of starting. */
 int glio_bassoc_run_append(glio_bassoc* b, const double* poses, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj,
                            int64_t* pair_count_out, int64_t* total_out);
 int glio_bassoc_run_append_async(glio_bassoc* b, const double* poses, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj);
@@ -332,10 +335,12 @@ int glio_bassoc_finish(glio_bassoc* b, int64_t* pair_count_out, int64_t* total_o
 int glio_bassoc_reset(glio_bassoc* b);
 /* Optional, ahead of a run whose pairs are known before its poses (batchFeatureAssociation inside a keyframe call: the pairs follow from the keyframe count,
  * the poses from the solve): sends the build descriptors of the run's search frames and clears their hash tables now; the run that follows with the same
- * search frames skips both.  Anything else in between only makes the run do them itself. */
+ * search frames skips both.  Anything else in between only makes the run do them itself.  Whether a preparation applies follows from what was prepared
+ * (same search frames, same cloud sizes) and from nothing else -- not from how long ago it was made. */
 int glio_bassoc_prepare_async(glio_bassoc* b, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj);
 /* surf_frames[k] <- the scan resident in window slot `slot` of a sliding-window context on the same device, minus the LiDAR offset (a device copy:
- * the keyframe that just entered the window is not uploaded a second time) */
+ * the keyframe that just entered the window is not uploaded a second time).  The copy runs on the association's stream; the context's next
+ * glio_set_scan and glio_destroy are ordered behind it on the device (no host wait). */
 int glio_bassoc_set_frame_from_scan(glio_bassoc* b, int k, glio_ctx* ctx, int slot, const float lidar_offset[3]);
 int glio_bassoc_results_dev(glio_bassoc* b, const float** cp_dev, const double** norm_cent_dev, const double** score_dev);
 /* globalFeatureSelectionAdd_Batch / globalFeatureSelection_Batch (Estimator.cpp:4057-4116, 3994-4055; batch_feature_res_num: 25):

@@ -186,9 +186,9 @@ def test_hip_imu_gnss_marg_factor_vs_reference_vectors(G, hip):
     for k in range(len(G["dd_r_out"])):
         f = _struct(T.GlioDdPsr, G["dd_f_in"][k])
         r, J = ctx.eval_dd_psr(f, G["dd_Pi_in"][k], G["dd_Pj_in"][k], float(G["dd_yaw_in"][k]), G["dd_anc_in"][k])
-        # (a double-difference of four ~2.6e7 m ranges: one ulp of a range is 3.7e-9 m, the device contracts a*b+c into FMAs where the
-        #  reference build does not -- a few ulps of the RANGE is the floor for the residual, 5e-9 of a ~10-40 m residual)
-        assert close(r, G["dd_r_out"][k], 5e-9) and close(J[0], G["dd_J0_out"][k], 1e-11) and close(J[1], G["dd_J1_out"][k], 1e-11), k
+        # (a double-difference of four ~2.6e7 m ranges: one ulp of a range is 3.7e-9 m.  The GNSS roles are compiled without FMA contraction --
+        #  every product rounded as in the reference's scalar build -- so the residual is held like everything else here)
+        assert close(r, G["dd_r_out"][k], 1e-11) and close(J[0], G["dd_J0_out"][k], 1e-11) and close(J[1], G["dd_J1_out"][k], 1e-11), k
     nslot = int(G["dop_nslot_in"])
     for k in range(len(G["dop_r_out"])):
         f = _struct(T.GlioDoppler, G["dop_f_in"][k])

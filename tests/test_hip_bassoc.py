@@ -252,3 +252,45 @@ def test_prepared_run_equals_plain_run(frames):
         for a, b in zip(ba.read(), want[2]):
             assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
     ba.prepare(*pa)                                        # prepared, never run: nothing to clean up
+
+
+def test_an_asynchronous_runs_counts_survive_side_calls(frames):
+    """Advisor finding of round 5: every side entry point (set_frame*, prepare, select_range, read ...) used to CONSUME a pending asynchronous run -- its
+    per-pair counts were dropped and a later glio_bassoc_finish returned zeros; its overflow surfaced from the unrelated call.  Now side calls only wait
+    for the stream: the counts and the overflow of a run go to glio_bassoc_finish and to nobody else."""
+    from glio_amd import capi
+    scans, poses = frames
+    K = len(scans)
+    pairs = (np.array([2, 2, 3], np.int32), np.array([0, 1, 4], np.int32))
+    ref = batch.BatchAssociation(K, 4096, 400000)
+    for k in range(K):
+        ref.set_frame(k, scans[k])
+    want, want_total = ref.run(poses, *pairs)
+    ba = batch.BatchAssociation(K, 4096, 400000)
+    for k in range(K):
+        ba.set_frame(k, scans[k])
+    ba.reset()
+    assert ba.run_append(poses, *pairs, wait=False) is None
+    ba.set_frame(7, scans[7])                              # side calls between the run and its collection: a frame no pair uses ...
+    ba.prepare(np.array([5], np.int32), np.array([6], np.int32))      # ... a preparation ...
+    ba.read(0, 10)                                         # ... and a read-back
+    cnt, total = ba.finish()
+    assert cnt.tolist() == want.tolist() and total == want_total and total > 100
+    cnt2, total2 = ba.finish()                             # collected once: a second finish reports the total and no counts
+    assert total2 == want_total
+    # overflow: an object too small for the pairs; the error belongs to finish(), not to the side call in between
+    small = batch.BatchAssociation(K, 4096, 50)
+    for k in range(K):
+        small.set_frame(k, scans[k])
+    small.reset()
+    small.run_append(poses, *pairs, wait=False)
+    small.set_frame(7, scans[7])                           # must not raise
+    with pytest.raises(capi.GlioError):
+        small.finish()
+    small.finish()                                         # reported once
+    # ... and an uncollected overflow is not lost when the next run replaces the counts
+    small.reset()
+    small.run_append(poses, *pairs, wait=False)
+    with pytest.raises(capi.GlioError):
+        small.run_append(poses, *pairs, wait=False)
+    ba.close(); ref.close(); small.close()

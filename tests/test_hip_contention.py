@@ -47,3 +47,21 @@ def test_the_resident_keyframe_stream_is_deterministic_under_contention():
     assert len(rows) == 6, out.stdout[-2000:] + out.stderr[-2000:]
     for r in rows:
         assert r["events"] == [], r
+
+
+@pytest.mark.timeout(600)
+def test_chain_step_does_not_depend_on_its_helpers():
+    """k_chain_step's workgroup 0 waits INSIDE the launch for W helper workgroups -- a wait HIP does not promise to be satisfiable.  It is bounded: after
+    `hpolls` polls the step sums the blocks itself.  Same bits out (a) plainly, (b) with the helpers given up at once (GLIO_CHAIN_HELPER_POLLS=0), (c) on
+    a device that offers the launch only 2 compute units (HSA_CU_MASK: 21 workgroups, each a CU's worth of LDS), (d) both -- and none of them hangs."""
+    def run(extra):
+        env = dict(os.environ, **extra)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "chain_helpers_bound.py")], env=env, capture_output=True, text=True, timeout=240)
+        rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(rows) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+        return rows[0]
+    ref = run({})
+    assert ref["path"] == 2 and len(set(ref["hashes"])) == 1, ref
+    for extra in ({"GLIO_CHAIN_HELPER_POLLS": "0"}, {"HSA_CU_MASK": "0:0-1"}, {"HSA_CU_MASK": "0:0-1", "GLIO_CHAIN_HELPER_POLLS": "3"}):
+        got = run(extra)
+        assert got["path"] == 2 and got["hashes"] == ref["hashes"] and got["iterations"] == ref["iterations"], (extra, got, ref)

@@ -231,6 +231,14 @@ def test_batch_gnss_epoch_selection_cpp_equals_python(tmp_path):
     # 1.5 -> the same right keyframe: 0 m from the last accepted: dropped; 2.25 -> right keyframe x = 11.2, 0.6 m: dropped; 3.0 -> (2, 4): strictly before / after,
     # right keyframe x = 11.8, 1.2 m: accepted with ratio (4 - 3) / (4 - 2); 4.5 -> no pose after it inside [1, 5): dropped
     assert got == [(1, 0, 1, 0.75), (4, 1, 3, 0.5)]
+    # arguments that would index outside the arrays are refused by both twins: first_idx = 0 (pose indices are 1-based), more poses than keyframe times / positions
+    import pytest
+    for bad in ((0, 5), (1, 7), (6, 5)):
+        exe_out = subprocess.run([exe], input=f"1 5 {bad[0]} {bad[1]} 5\n2.5\n" + " ".join(map(str, kt)) + "\n" + " ".join(repr(float(x)) for x in tr.ravel()) + "\n",
+                                 capture_output=True, text=True, check=True).stdout
+        assert exe_out.startswith("refused"), (bad, exe_out)
+        with pytest.raises(ValueError):
+            batch.select_batch_gnss_epochs([2.5], kt, bad[0], bad[1], tr)
     # double-difference groups: GPS 5, 12, 30 (+ 84), BeiDou 90, GLONASS 40, Galileo 60; PRN 12 has no station observation, PRN 30 a bad pseudorange
     up, psr, ele = [5, 12, 30, 84, 90, 40, 60, 7], [2e7, 2e7, 500.0, 2e7, 2e7, 2e7, 2e7, 2e7], [30.0, 80.0, 70.0, -45.0, 10.0, 20.0, 15.0, 40.0]
     rp = [7, 84, 5, 90, 60, 40, 30]
