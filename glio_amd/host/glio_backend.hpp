@@ -11,6 +11,7 @@
 
 #include <array>
 #include <cmath>
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <stdexcept>
@@ -156,6 +157,32 @@ inline void writeBackState(int W, const double* tmpTrans, const double* tmpQuat,
     }
 }
 
+// featureSelection (Estimator.cpp:3894-3992), the draws only: which of `count` correspondences of a slot stay.  Returns false when nothing changes
+// (count - 1 < feature_res_num: the early return at :3906-3909, quirk Q9 -- the set is kept WHOLE, not cut to feature_res_num); otherwise `kept` holds
+// the original indices in draw order: feature_res_num draws, each uniform over the records still left (the reference builds a no-repeat random array
+// over the remaining records and takes its LAST element, :3948-3957, then erases that record, :3964-3978 -- i.e. one uniform draw per kept record,
+// whatever rand_set_num is); random_select == false empties the slot (:3945 never enters the loop, :3981-3987 install the empty sets).
+// rand_below(n): uniform integer in [0, n) -- the reference seeds from std::random_device (random_generator.hpp:58), so the generator is the caller's.
+// The Python twin is glio_amd/sliding.py::feature_selection_draws: same generator in, same indices out (tests/test_host_cpp.py).
+template <typename RandBelow>
+inline bool featureSelectionDraws(int64_t count, int feature_res_num, RandBelow&& rand_below, bool random_select, std::vector<int32_t>& kept) {
+    kept.clear();
+    if (count < 1 || count - 1 < (int64_t)feature_res_num) return false;
+    if (!random_select) return true;
+    // the d-th draw picks the k-th record STILL LEFT (k uniform below count - d): its original index is k advanced past every removed index <= it.
+    // `gone` stays sorted: O(feature_res_num^2) whatever the count (erasing from a 64k-element list per draw would be O(count) each)
+    std::vector<int32_t> gone;
+    gone.reserve((size_t)feature_res_num);
+    for (int d = 0; d < feature_res_num; ++d) {
+        int64_t v = (int64_t)rand_below((uint64_t)(count - d));
+        size_t pos = 0;
+        while (pos < gone.size() && (int64_t)gone[pos] <= v) { ++v; ++pos; }
+        gone.insert(gone.begin() + (std::ptrdiff_t)pos, (int32_t)v);
+        kept.push_back((int32_t)v);
+    }
+    return true;
+}
+
 // how the caller's clouds lie in memory: records of stride_bytes, x y z as floats at offset 0, the intensity as a float at intensity_offset
 struct PointLayout {
     int stride_bytes, intensity_offset;
@@ -196,6 +223,14 @@ public:
         int cnt = 0;
         check(glio_associate(ctx_, slot, scan_xyzi, n, q2, t2, &cnt), "glio_associate");
         return cnt;
+    }
+    // Estimator.cpp:2223  featureSelection(idx-1, Q2_, T2_), right behind the slot's findCorrespondingSurfFeatures: `count` = what the search kept for the
+    // slot (findCorrespondingSurfFeatures' return value / windowCounts()[slot]); the gather runs on the device.  Returns the slot's residual count.
+    template <typename RandBelow>
+    int featureSelection(int slot, int count, int feature_res_num, RandBelow&& rand_below, bool random_select = true) {
+        if (!featureSelectionDraws(count, feature_res_num, rand_below, random_select, sel_)) return count;
+        check(glio_select_correspondences(ctx_, slot, sel_.empty() ? nullptr : sel_.data(), (int)sel_.size()), "glio_select_correspondences");
+        return (int)sel_.size();
     }
     // Estimator.cpp:2182-2192 / 2153-2158 / 2329-2359
     void setImuFactors(const std::vector<glio_preint>& pre) {
@@ -348,8 +383,153 @@ private:
     }
     glio_opts opts_;
     int W_;
+    std::vector<int32_t> sel_;
     int map_points_ = 0;
     glio_ctx* ctx_ = nullptr;
+};
+
+// ---- (3) the front end -------------------------------------------------------------------------------
+// LidarOdometry (GLIO/src/LidarOdometry.cpp): scan-to-map odometry on the same C-ABI with a one-keyframe window.  Per scan, run() (:661-699):
+//   poseInitialization (:405-432)  abs_pose <- abs_pose o rel_pose
+//   buildLocalMap (:268-292)       the map = the LAST 20 frames' downsampled surf clouds at their solved poses (recent_surf_frames; frame 0 never enters:
+//                                  while fewer than 2 poses exist the map is the current scan itself, :271-275) -- here the device-resident ring
+//                                  (glio_localmap_config(20, 0.2): one cloud crosses PCIe per scan)
+//   downSampleCloud (:306-314)     VoxelGrid 0.2 m over the map (glio_localmap_build); the scan arrives downsampled (surf_last_ds: the caller's filter)
+//   updateTransformationWithCeres (:474-581)  match_cnt rounds (8 while fewer than 2 poses exist, else scan_match_cnt, :492-497) of
+//                                  [findCorrespondingSurfFeatures at the current abs_pose (:343-404: gates 1.0 / 0.06 / 0.4), one problem of
+//                                  LidarPlaneNormIncreFactor under HuberLoss(0.1), Levenberg-Marquardt, max_num_iter, 15 ms budget, unifyQuaternion]
+//   savePoses (:316-341), computeRelative (:434-471)  rel_pose <- pose[previous]^-1 o abs_pose
+// update() is the solve alone against a map the caller set (kd_tree_surf_last->setInputCloud(surf_from_map_ds), :482).
+// The Python twin is glio_amd/odometry.py::ScanToMapOdometry (tests/test_host_cpp.py holds the two to each other bit for bit).
+class ScanToMapOdometry {
+public:
+    struct Round { glio_summary summary; int kept; };
+    // glio_opts of the front end: the yaml's `lidar_odometry` block + the constants of LidarOdometry.cpp (odometry.frontend_opts)
+    static glio_opts frontendOpts(int max_points, int max_map_points, int max_num_iter = 12) {
+        glio_opts o;
+        glio_opts_default(&o);
+        o.window = 1; o.max_iterations = max_num_iter;                              // config_urban_hk.yaml:19
+        o.max_points_per_scan = max_points > 64 ? max_points : 64; o.max_map_points = max_map_points > 64 ? max_map_points : 64; o.max_ddt_epochs = 0;
+        o.jacobi_scaling = 1;
+        o.kd_max_radius = 1.0; o.surf_dist_thres = 0.06; o.weight_gate = 0.4;       // LidarOdometry.cpp:356,379,392
+        o.huber_delta = 0.1; o.doppler_huber_delta = 1.0;                           // :499
+        o.q_lb[0] = 1.0; o.q_lb[1] = o.q_lb[2] = o.q_lb[3] = 0.0;
+        o.t_lb[0] = o.t_lb[1] = o.t_lb[2] = 0.0;                                    // LidarPlaneNormIncreFactor applies no extrinsic
+        o.lidar_const = 7.5;
+        o.unit_scores = 1;                                                          // ... and carries no score (LidarKeyframeFactor.h:222-257)
+        o.trust_region_strategy = 1;                                                // Ceres default LEVENBERG_MARQUARDT (solverOptions :521-527)
+        o.max_solver_time_s = 0.015;                                                // :524
+        return o;
+    }
+    explicit ScanToMapOdometry(const glio_opts& opts, int device = 0, int scan_match_cnt = 1, int local_map_width = 20, float leaf = 0.2f)
+        : opts_(opts), scan_match_cnt_(scan_match_cnt) {
+        if (opts.window != 1) throw std::invalid_argument("ScanToMapOdometry: the front end is a one-keyframe window");
+        check(glio_create(device, &opts_, &ctx_), "glio_create");
+        check(glio_localmap_config(ctx_, local_map_width, leaf, opts_.max_points_per_scan), "glio_localmap_config");
+        // the window never carries another factor
+        check(glio_set_imu(ctx_, 0, nullptr, nullptr), "glio_set_imu");
+        check(glio_set_prior(ctx_, nullptr), "glio_set_prior");
+        check(glio_set_gnss(ctx_, nullptr, 0, nullptr, 0, nullptr), "glio_set_gnss");
+        abs_pose = {{1, 0, 0, 0, 0, 0, 0}}; rel_pose = {{1, 0, 0, 0, 0, 0, 0}};
+    }
+    ~ScanToMapOdometry() { glio_destroy(ctx_); }
+    ScanToMapOdometry(const ScanToMapOdometry&) = delete;
+    ScanToMapOdometry& operator=(const ScanToMapOdometry&) = delete;
+    glio_ctx* ctx() const { return ctx_; }
+
+    // kd_tree_surf_last->setInputCloud(surf_from_map_ds) (:482) with a map the caller built
+    void setMap(const float* xyzi, int n) { check(glio_set_map(ctx_, xyzi, n), "glio_set_map"); map_points_ = n; }
+    void setMap(const void* points, int n, PointLayout l) { check(glio_set_map_strided(ctx_, points, n, l.stride_bytes, l.intensity_offset), "glio_set_map_strided"); map_points_ = n; }
+
+    // updateTransformationWithCeres (:474-581) from the given pose (q w,x,y,z then t, the reference's abs_pose[7]); returns the new pose
+    std::array<double, 7> update(const float* surf_last_ds, int n, const std::array<double, 7>& pose, int match_cnt, std::vector<Round>* rounds = nullptr) {
+        std::array<double, 7> p = pose;
+        if (rounds) rounds->clear();
+        if (map_points_ < 10) return p;                                             // "Not enough feature points from the map" (:477-480)
+        check(glio_set_scan(ctx_, 0, surf_last_ds, n), "glio_set_scan");
+        double sb[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int it = 0; it < match_cnt; ++it) {
+            int kept = 0;
+            check(glio_associate_resident(ctx_, 0, &p[0], &p[4], &kept), "glio_associate_resident");
+            glio_state st;
+            st.trans = &p[4]; st.quat = &p[0]; st.speed_bias = sb; st.rcv_ddt = nullptr; st.n_ddt = 0;
+            glio_summary sum;
+            check(glio_solve(ctx_, &st, &sum), "glio_solve");
+            if (p[0] < 0) for (int k = 0; k < 4; ++k) p[k] = -p[k];                 // unifyQuaternion (:532-542)
+            if (rounds) rounds->push_back({sum, kept});
+        }
+        return p;
+    }
+
+    // LidarOdometry::run() (:661-699) for one scan; surf_last_ds = the scan after the caller's 0.2 m filter (down_size_filter_surf, :312-313).  Returns abs_pose.
+    std::array<double, 7> run(const float* surf_last_ds, int n, std::vector<Round>* rounds = nullptr) {
+        if (rounds) rounds->clear();
+        if (poses_ == 0) {                                                          // !system_initialized: savePoses(), nothing else (:671-675)
+            savePoses(surf_last_ds, n);
+            return abs_pose;
+        }
+        // poseInitialization: t0 = q0 * dt + t0, q0 = q0 * dq
+        {
+            double t[3], q[4];
+            rotate(&abs_pose[0], &rel_pose[4], t);
+            for (int k = 0; k < 3; ++k) t[k] += abs_pose[4 + k];
+            qmul(&abs_pose[0], &rel_pose[0], q);
+            for (int k = 0; k < 4; ++k) abs_pose[k] = q[k];
+            for (int k = 0; k < 3; ++k) abs_pose[4 + k] = t[k];
+        }
+        // buildLocalMap + downSampleCloud
+        if (poses_ <= 1) setMap(surf_last_ds, n);                                   // the current scan is its own map (:271-275; the two filters see the same cloud)
+        else {
+            check(glio_localmap_push(ctx_, last_cloud_.data(), (int)(last_cloud_.size() / 4), &last_pose_[0], &last_pose_[4]), "glio_localmap_push");
+            int pts = 0;
+            check(glio_localmap_build(ctx_, &pts), "glio_localmap_build");
+            map_points_ = pts;
+        }
+        abs_pose = update(surf_last_ds, n, abs_pose, poses_ < 2 ? 8 : scan_match_cnt_, rounds);
+        const std::array<double, 7> prev = last_pose_;
+        savePoses(surf_last_ds, n);
+        // computeRelative: rel = prev^-1 o abs
+        {
+            const double qi[4] = {prev[0], -prev[1], -prev[2], -prev[3]};           // (unit quaternions: the inverse is the conjugate, as Eigen's inverse() of a normalised one)
+            const double n2 = prev[0] * prev[0] + prev[1] * prev[1] + prev[2] * prev[2] + prev[3] * prev[3];
+            const double qin[4] = {qi[0] / n2, qi[1] / n2, qi[2] / n2, qi[3] / n2};
+            double q[4], d[3] = {abs_pose[4] - prev[4], abs_pose[5] - prev[5], abs_pose[6] - prev[6]}, t[3];
+            qmul(qin, &abs_pose[0], q);
+            rotate(qin, d, t);
+            for (int k = 0; k < 4; ++k) rel_pose[k] = q[k];
+            for (int k = 0; k < 3; ++k) rel_pose[4 + k] = t[k];
+        }
+        return abs_pose;
+    }
+    int frames() const { return poses_; }
+    int mapPoints() const { return map_points_; }
+
+    std::array<double, 7> abs_pose, rel_pose;          // q (w,x,y,z), t -- the reference's abs_pose[7] / rel_pose[7]
+
+private:
+    void savePoses(const float* cloud, int n) {
+        last_pose_ = abs_pose;
+        last_cloud_.assign(cloud, cloud + 4 * (size_t)n);
+        ++poses_;
+    }
+    static void qmul(const double a[4], const double b[4], double o[4]) {
+        o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+        o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+        o[2] = a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3];
+        o[3] = a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1];
+    }
+    static void rotate(const double q[4], const double v[3], double o[3]) {        // Eigen's q * v: v + 2 w (u x v) + 2 u x (u x v)
+        double uv[3] = {q[2] * v[2] - q[3] * v[1], q[3] * v[0] - q[1] * v[2], q[1] * v[1] - q[2] * v[0]};
+        for (double& x : uv) x += x;
+        const double uuv[3] = {q[2] * uv[2] - q[3] * uv[1], q[3] * uv[0] - q[1] * uv[2], q[1] * uv[1] - q[2] * uv[0]};
+        for (int k = 0; k < 3; ++k) o[k] = v[k] + q[0] * uv[k] + uuv[k];
+    }
+    glio_opts opts_;
+    int scan_match_cnt_;
+    glio_ctx* ctx_ = nullptr;
+    int poses_ = 0, map_points_ = 0;
+    std::array<double, 7> last_pose_{{1, 0, 0, 0, 0, 0, 0}};
+    std::vector<float> last_cloud_;
 };
 
 }  // namespace glio

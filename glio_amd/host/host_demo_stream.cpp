@@ -21,7 +21,7 @@ template <typename T> static void rd(FILE* f, T* p, size_t n) { if (n && fread(p
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int main(int argc, char** argv) {
-    if (argc < 2) { fprintf(stderr, "usage: host_demo_stream stream.bin [device] [search_range] [defer]\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: host_demo_stream stream.bin [device] [search_range] [defer] [res=N] [draws=FILE] [timed=N]\n"); return 2; }
     FILE* f = fopen(argv[1], "rb");
     if (!f) { perror("open"); return 2; }
     const int device = argc > 2 ? atoi(argv[2]) : 0;
@@ -68,8 +68,28 @@ int main(int argc, char** argv) {
         const bool after_marg = argc > 4 && atoi(argv[4]) == 2;
         glio::BatchAssociationBackend ba(total_kf, pts, (int64_t)(NK + 2) * 2 * SR * pts, device);
         glio::KeyframeBatchAssociation kba(ba, SR, RES);
+        // named arguments behind the positional ones: res=N (feature_res_num of featureSelection, Estimator.cpp:2223; 0 = no selection, the BASELINE workloads),
+        // draws=FILE (a table of 64-bit numbers: rand_below(n) = table[k++] mod n -- the generator a test shares with the Python host), timed=N (only the last N
+        // keyframes enter the averages: the released configuration fills its 50-keyframe local map first)
+        int feature_res = 0, timed_last = NK;
+        std::vector<uint64_t> table;
+        size_t table_k = 0;
+        for (int a = 5; a < argc; ++a) {
+            if (!strncmp(argv[a], "res=", 4)) feature_res = atoi(argv[a] + 4);
+            else if (!strncmp(argv[a], "timed=", 6)) timed_last = atoi(argv[a] + 6);
+            else if (!strncmp(argv[a], "draws=", 6)) {
+                FILE* df = fopen(argv[a] + 6, "rb");
+                if (!df) { perror("draws"); return 2; }
+                fseek(df, 0, SEEK_END); const long bytes = ftell(df); fseek(df, 0, SEEK_SET);
+                table.resize((size_t)bytes / 8); rd(df, table.data(), table.size()); fclose(df);
+            } else { fprintf(stderr, "unknown argument %s\n", argv[a]); return 2; }
+        }
+        if (timed_last < 1 || timed_last > NK) timed_last = NK;
         std::mt19937_64 rng(20260925);
-        auto rand_below = [&](uint64_t n) -> uint64_t { return std::uniform_int_distribution<uint64_t>(0, n - 1)(rng); };
+        auto rand_below = [&](uint64_t n) -> uint64_t {
+            if (!table.empty()) return table[table_k++ % table.size()] % n;
+            return std::uniform_int_distribution<uint64_t>(0, n - 1)(rng);
+        };
         std::vector<double> kf_poses((size_t)total_kf * 7, 0.0);          // pose_info_keyframe: t, q of every keyframe (ground truth until a window solve moves it)
         for (int j = 0; j < total_kf; ++j) { for (int c = 0; c < 3; ++c) kf_poses[7 * (size_t)j + c] = gtt[3 * (size_t)j + c]; for (int c = 0; c < 4; ++c) kf_poses[7 * (size_t)j + 3 + c] = gtq[4 * (size_t)j + c]; }
         for (int j = 0; j < W - 1; ++j) {                                 // the clouds of the keyframes already in the window
@@ -80,6 +100,7 @@ int main(int argc, char** argv) {
         double st[7] = {0, 0, 0, 0, 0, 0, 0}, cyc = 0, cmin = 1e9, cmax = 0, fd[3] = {0, 0, 0};
         std::vector<int> iters; std::vector<long> kept; std::vector<long> bfound; std::vector<long> bkept;
         double checksum = 0;
+        std::vector<double> last_trans, last_quat;
         int map_pts = 0;
         for (int j = 0; j <= NK; ++j) {
             const Kf& k = kf[j];
@@ -101,7 +122,9 @@ int main(int argc, char** argv) {
             const double t3a = now_s();
             be.setGnss(&k.frame, k.dd, k.dop);
             const double t3b = now_s();
-            const std::vector<int32_t> counts = be.windowCounts();
+            std::vector<int32_t> counts = be.windowCounts();
+            // featureSelection (Estimator.cpp:2223): right behind each slot's search, feature_res_num draws per slot (config_urban_hk.yaml:100: 100)
+            if (feature_res > 0) for (int s = 0; s < W; ++s) counts[s] = be.featureSelection(s, counts[s], feature_res, rand_below);
             if (!defer && !after_marg) kba.prepare(nw + 1);          // (the pairs are known; their search frames' tables are cleared while the solve runs)
             const double t4 = now_s();
             const glio_summary sum = be.solve(&ddt);
@@ -123,15 +146,17 @@ int main(int argc, char** argv) {
             if (!defer) found = kba.finish(rand_below);
             const double t7 = now_s();
             if (j == 0) continue;                                        // no prior yet, every first-touch cost: warm-up
+            { long f = 0; for (int64_t v : found) f += (long)v; bfound.push_back(f); bkept.push_back((long)ba.total()); }
+            iters.push_back(sum.iterations);
+            { long kk = 0; for (int32_t v : counts) kk += v; kept.push_back(kk); }
+            for (double v : be.tmpTrans) checksum += v;
+            last_trans = be.tmpTrans; last_quat = be.tmpQuat;
+            if (j <= NK - timed_last) continue;                          // (results are booked for every keyframe, times for the last timed_last)
             const double d[7] = {t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5b, (t5b - t5) + (t7 - t6)};
             double c = 0;
-            for (int q = 0; q < 7; ++q) { st[q] += d[q] / NK; c += d[q]; }
-            fd[0] += (t3a - t3) / NK; fd[1] += (t3b - t3a) / NK; fd[2] += (t4 - t3b) / NK;
-            { long f = 0; for (int64_t v : found) f += (long)v; bfound.push_back(f); bkept.push_back((long)ba.total()); }
-            cyc += c / NK; if (c < cmin) cmin = c; if (c > cmax) cmax = c;
-            iters.push_back(sum.iterations);
-            long kk = 0; for (int32_t v : counts) kk += v; kept.push_back(kk);
-            for (double v : be.tmpTrans) checksum += v;
+            for (int q = 0; q < 7; ++q) { st[q] += d[q] / timed_last; c += d[q]; }
+            fd[0] += (t3a - t3) / timed_last; fd[1] += (t3b - t3a) / timed_last; fd[2] += (t4 - t3b) / timed_last;
+            cyc += c / timed_last; if (c < cmin) cmin = c; if (c > cmax) cmax = c;
         }
         if (defer) kba.finish(rand_below);                               // the last keyframe's pairs
         printf("{\"batch_association_deferred\": %s, \"stages_ms\": {\"slide_and_new_scan\": %.4f, \"local_map\": %.4f, \"associate_enqueue\": %.4f, \"factors_while_the_gpu_searches_then_wait\": %.4f, "
@@ -145,7 +170,11 @@ int main(int argc, char** argv) {
         printf("], \"batch_records_held\": [");
         for (size_t i = 0; i < bkept.size(); ++i) printf("%s%ld", i ? ", " : "", bkept[i]);
         printf("], \"factors_stage_ms\": {\"set_imu_host\": %.4f, \"set_gnss_host\": %.4f, \"wait_for_the_searches\": %.4f}", fd[0] * 1e3, fd[1] * 1e3, fd[2] * 1e3);
-        printf(", \"batch_feature_res_num\": %d, \"trans_checksum\": %.17g}\n", RES, checksum);
+        printf(", \"batch_feature_res_num\": %d, \"feature_res_num\": %d, \"timed_keyframes\": %d, \"last_trans\": [", RES, feature_res, timed_last);
+        for (size_t i = 0; i < last_trans.size(); ++i) printf("%s%.17g", i ? ", " : "", last_trans[i]);
+        printf("], \"last_quat\": [");
+        for (size_t i = 0; i < last_quat.size(); ++i) printf("%s%.17g", i ? ", " : "", last_quat[i]);
+        printf("], \"trans_checksum\": %.17g}\n", checksum);
     } catch (const std::exception& e) {
         fprintf(stderr, "error: %s\n", e.what());
         return 1;

@@ -163,9 +163,56 @@ def write_stream(path, long, wins, W, n_keyframes, pts, lm_width=50, leaf=0.4, b
                 f.write(bytes(d))
 
 
-def run_demo_stream(path, device=0, env=None, search_range=6, defer=False):
+def run_demo_stream(path, device=0, env=None, search_range=6, defer=False, feature_res_num=0, draws=None, timed=None):
+    """feature_res_num > 0: featureSelection behind every slot's search (Estimator.cpp:2223); draws: file of uint64 both hosts draw from (sliding.TableRng);
+    timed: only the last `timed` keyframes enter the time averages"""
     import json
-    r = subprocess.run([build_demo_stream(), path, str(device), str(search_range), str(int(defer))], capture_output=True, text=True, env=env)
+    cmd = [build_demo_stream(), path, str(device), str(search_range), str(int(defer))]
+    if feature_res_num:
+        cmd.append(f"res={int(feature_res_num)}")
+    if draws:
+        cmd.append(f"draws={draws}")
+    if timed:
+        cmd.append(f"timed={int(timed)}")
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
     if r.returncode != 0:
         raise RuntimeError("host_demo_stream failed (%d): %s" % (r.returncode, (r.stderr or r.stdout)[-600:]))
     return json.loads(next(ln for ln in r.stdout.splitlines() if ln.startswith("{")))
+
+
+DEMO_ODOMETRY = os.path.join(HERE, "host_demo_odometry")
+
+
+def build_demo_odometry(force=False):
+    """The C++ front end (host_demo_odometry.cpp over glio::ScanToMapOdometry)."""
+    src = [os.path.join(HERE, "host_demo_odometry.cpp"), os.path.join(HERE, "glio_backend.hpp")] + _ABI_HEADERS
+    if force or not os.path.exists(DEMO_ODOMETRY) or any(os.path.getmtime(s) > os.path.getmtime(DEMO_ODOMETRY) for s in src):
+        subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", src[0], "-I" + os.path.join(HERE, "..", "..", "include"),
+                               "-L" + os.path.join(HERE, "..", "lib"), "-lglio_hip", "-Wl,-rpath,$ORIGIN/../lib", "-o", DEMO_ODOMETRY])
+    return DEMO_ODOMETRY
+
+
+def write_odometry_stream(path, opts, scans, scan_match_cnt=1):
+    """opts | n_scans scan_match_cnt 0 0 | per scan: n, points xyzi (the downsampled surf cloud of each LiDAR frame, body frame)"""
+    with open(path, "wb") as f:
+        f.write(bytes(opts))
+        f.write(np.array([len(scans), scan_match_cnt, 0, 0], np.int32).tobytes())
+        for sc in scans:
+            sc = np.ascontiguousarray(sc, np.float32)
+            f.write(np.array([len(sc)], np.int32).tobytes()); f.write(sc.tobytes())
+
+
+def run_demo_odometry(path, device=0, env=None):
+    """-> (poses [n][7] q then t, per-scan dicts, {"ms_per_scan": ...})"""
+    import json
+    r = subprocess.run([build_demo_odometry(), path, str(device)], capture_output=True, text=True, env=env)
+    if r.returncode != 0:
+        raise RuntimeError("host_demo_odometry failed (%d): %s" % (r.returncode, (r.stderr or r.stdout)[-600:]))
+    poses, rows = [], []
+    for ln in r.stdout.splitlines():
+        if ln.startswith("pose "):
+            w = ln.split()
+            poses.append([float(x) for x in w[2:9]])
+            rows.append({"rounds": int(w[9]), "kept": int(w[10]), "iterations": int(w[11]), "final_cost": float(w[12]), "map_points": int(w[13])})
+    info = json.loads(next(ln for ln in r.stdout.splitlines() if ln.startswith("{")))
+    return np.array(poses), rows, info

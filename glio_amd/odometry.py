@@ -28,12 +28,68 @@ def frontend_opts(max_points, max_map_points, max_num_iter=12):
     return o
 
 
-class ScanToMapOdometry:
-    """`backend`: capi.Context (or a test double with the same methods) created with `frontend_opts`."""
+LOCAL_MAP_WIDTH = 20          # `if (recent_surf_frames.size() < 20)`, LidarOdometry.cpp:278
+LOCAL_MAP_LEAF = 0.2          # down_size_filter_surf_map.setLeafSize(0.2, 0.2, 0.2), :158
 
-    def __init__(self, backend):
+
+def _qmul(a, b):
+    return np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                     a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3], a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1]])
+
+
+def _rotate(q, v):
+    """Eigen's q * v (v + 2 w (u x v) + 2 u x (u x v)), in the operation order of glio::ScanToMapOdometry::rotate: the two hosts agree bit for bit"""
+    uv = np.array([q[2] * v[2] - q[3] * v[1], q[3] * v[0] - q[1] * v[2], q[1] * v[1] - q[2] * v[0]])
+    uv = uv + uv
+    uuv = np.array([q[2] * uv[2] - q[3] * uv[1], q[3] * uv[0] - q[1] * uv[2], q[1] * uv[1] - q[2] * uv[0]])
+    return np.array([v[k] + q[0] * uv[k] + uuv[k] for k in range(3)])
+
+
+class ScanToMapOdometry:
+    """`backend`: capi.Context (or a test double with the same methods) created with `frontend_opts`.  update() is updateTransformationWithCeres
+    against a map the caller set; run() is LidarOdometry::run() (:661-699) per scan with the 20-frame / 0.2 m local map resident on the device --
+    glio::ScanToMapOdometry (glio_backend.hpp) is the same class in C++ and documents the sequence."""
+
+    def __init__(self, backend, scan_match_cnt=1):
         self.be = backend
         self.last = None
+        self.scan_match_cnt = scan_match_cnt
+        self.abs_pose = np.array([1.0, 0, 0, 0, 0, 0, 0])
+        self.rel_pose = np.array([1.0, 0, 0, 0, 0, 0, 0])
+        self.poses = 0
+        self.map_points = None
+        self._last_pose, self._last_cloud = None, None
+        self._ring = False
+
+    def _save(self, cloud):
+        self._last_pose, self._last_cloud = self.abs_pose.copy(), np.ascontiguousarray(cloud, np.float32)
+        self.poses += 1
+
+    def run(self, surf_last_ds, max_points=None):
+        """One scan (already downsampled: down_size_filter_surf, :312-313).  Returns (abs_pose, rounds)."""
+        if not self._ring:
+            self.be.localmap_config(LOCAL_MAP_WIDTH, LOCAL_MAP_LEAF, max_points or len(surf_last_ds))
+            self._ring = True
+        if self.poses == 0:                               # !system_initialized (:671-675)
+            self._save(surf_last_ds)
+            return self.abs_pose.copy(), []
+        a, r = self.abs_pose, self.rel_pose               # poseInitialization (:405-432)
+        t = _rotate(a[:4], r[4:]) + a[4:]
+        self.abs_pose = np.r_[_qmul(a[:4], r[:4]), t]
+        if self.poses <= 1:                               # buildLocalMap (:268-292) + downSampleCloud (:306-314)
+            self.be.set_map(surf_last_ds); self.map_points = len(surf_last_ds)
+        else:
+            self.be.localmap_push(self._last_cloud, self._last_pose[:4], self._last_pose[4:])
+            self.map_points = self.be.localmap_build()
+        rounds = []
+        if self.map_points >= 10:                         # (:477-480)
+            self.abs_pose, rounds = self.update(surf_last_ds, self.abs_pose, match_cnt=8 if self.poses < 2 else self.scan_match_cnt)
+        prev = self._last_pose
+        self._save(surf_last_ds)
+        n2 = float(prev[0] * prev[0] + prev[1] * prev[1] + prev[2] * prev[2] + prev[3] * prev[3])      # computeRelative (:434-471)
+        qin = np.array([prev[0], -prev[1], -prev[2], -prev[3]]) / n2
+        self.rel_pose = np.r_[_qmul(qin, self.abs_pose[:4]), _rotate(qin, self.abs_pose[4:] - prev[4:])]
+        return self.abs_pose.copy(), rounds
 
     def set_map(self, surf_from_map_ds):
         self.be.set_map(surf_from_map_ds)           # kd_tree_surf_last->setInputCloud (:482)

@@ -31,11 +31,30 @@ def feature_selection_draws(count, feature_res_num, rng, random_select=True):
         return None
     if not random_select:
         return np.zeros(0, np.int32)
-    remaining = list(range(count))
-    out = []
-    while len(out) < feature_res_num:
-        out.append(remaining.pop(int(rng.integers(0, len(remaining)))))
+    # the d-th draw picks the k-th record STILL LEFT, k uniform below count - d; its original index is k advanced past every removed index <= it
+    # (the same as popping from the list of remaining records, without building a list of `count` entries per slot; glio::featureSelectionDraws
+    # in glio_backend.hpp is this loop in C++: same generator in, same indices out)
+    gone, out = [], []
+    for d in range(feature_res_num):
+        v = int(rng.integers(0, count - d))
+        pos = 0
+        while pos < len(gone) and gone[pos] <= v:
+            v += 1; pos += 1
+        gone.insert(pos, v)
+        out.append(v)
     return np.asarray(out, np.int32)
+
+
+class TableRng:
+    """A generator that both hosts can share: integers(lo, hi) = lo + table[k++] mod (hi - lo) over a table of 63-bit numbers (written to a file for
+    host_demo_stream's `draws=`).  Not a statistical generator -- the means by which a test makes the C++ and the Python host draw the same records."""
+
+    def __init__(self, table):
+        self.table, self.k = np.ascontiguousarray(table, np.uint64), 0
+
+    def integers(self, lo, hi):
+        v = int(self.table[self.k % len(self.table)]); self.k += 1
+        return lo + v % (hi - lo)
 
 
 def feature_selection(backend, slot, count, feature_res_num, rng, random_select=True):

@@ -108,3 +108,78 @@ def test_solver_time_budget_ends_the_solve_at_an_accepted_point(frame):
     assert full.termination != 0 and full.iterations >= 3
     assert cut.termination == 0 and cut.iterations < full.iterations                  # GLIO_TERM_NO_CONVERGENCE
     assert cut.final_cost <= cut.initial_cost * (1 + 1e-12) and np.all(np.isfinite(outs[1e-7][0]))
+
+
+def _scan_stream(n_scans=8, pts=3000, seed=synth.SEED_BASE + 73):
+    """consecutive LiDAR frames of one drive (body frame, as surf_last_ds), expressed relative to the FIRST frame's pose: the front end starts at identity"""
+    win = synth.make_window(W=n_scans, pts_per_scan=pts, seed=seed, scan_radius=30.0, kf_dt=0.1)
+    tlb = np.array(win.opts.t_lb, np.float32)
+    scans = []
+    for s in range(n_scans):
+        c = win.scans[s].copy(); c[:, :3] -= tlb
+        scans.append(np.ascontiguousarray(c))
+    return win, scans
+
+
+class OracleRingBackend(OracleBackend):
+    """OracleBackend + the 20-frame local map: clouds at their poses (orc_transform_cloud), concatenated in ring order, pcl::VoxelGrid (orc_voxel_grid)"""
+
+    def localmap_config(self, width, leaf, cap):
+        self.width, self.leaf, self.ring = width, leaf, []
+
+    def localmap_push(self, cloud, q, t):
+        self.ring.append(self.po.transform_cloud(cloud, q, t))
+        self.ring = self.ring[-self.width:]
+
+    def localmap_build(self):
+        self.map, _ = self.po.voxel_grid(np.vstack(self.ring), self.leaf)
+        return len(self.map)
+
+
+def test_front_end_run_follows_the_oracle_over_a_stream():
+    """LidarOdometry::run() per scan (LidarOdometry.cpp:661-699: poseInitialization, buildLocalMap with the 20-frame ring, downSampleCloud at 0.2 m,
+    updateTransformationWithCeres, savePoses, computeRelative) on the device-resident local map (pcl's float accumulation: bit-identical maps) against the same
+    loop on the oracle: the same rounds, kept counts and iterations scan after scan, poses to 1e-9 although every scan starts from the previous result."""
+    from glio_amd import capi
+    win, scans = _scan_stream()
+    o = odometry.frontend_opts(max(len(s) for s in scans), 1 << 16)
+    ctx = capi.Context(o)
+    od_h, od_o = odometry.ScanToMapOdometry(ctx), odometry.ScanToMapOdometry(OracleRingBackend(o))
+    for k, sc in enumerate(scans):
+        if k == 1:
+            ctx.localmap_set_accumulation(1)              # (the ring exists from the first run() on)
+        ph, rh = od_h.run(sc, max_points=o.max_points_per_scan)
+        po_, ro = od_o.run(sc, max_points=o.max_points_per_scan)
+        assert len(rh) == len(ro) == (0 if k == 0 else (8 if k == 1 else 1)), k
+        for (sh, kh), (so, ko) in zip(rh, ro):
+            assert kh == ko and sh.iterations == so.iterations and sh.termination == so.termination, k
+        assert np.abs(ph - po_).max() <= 1e-9, (k, np.abs(ph - po_).max())
+        assert od_h.map_points == od_o.map_points
+        assert np.abs(od_h.rel_pose - od_o.rel_pose).max() <= 1e-9
+    # the drive moves ~1 m per scan (synthetic 10 m/s at 10 Hz); the estimate follows it: relative motion of the last step vs the ground truth's
+    gt_rel = np.linalg.norm(win.gt.trans[-1] - win.gt.trans[-2])
+    assert abs(np.linalg.norm(od_h.rel_pose[4:]) - gt_rel) < 0.1 * gt_rel + 0.05
+    ctx.close()
+
+
+def test_cpp_front_end_equals_the_python_twin(tmp_path):
+    """glio::ScanToMapOdometry (glio_backend.hpp, driven by host_demo_odometry) against glio_amd/odometry.py on the same scans through the same C entry
+    points: bit-identical poses, the same rounds / kept / iterations / map sizes per scan."""
+    from glio_amd import capi
+    from glio_amd.host import window_io
+    win, scans = _scan_stream(n_scans=7, pts=2500, seed=synth.SEED_BASE + 74)
+    o = odometry.frontend_opts(max(len(s) for s in scans), 1 << 16)
+    path = str(tmp_path / "odo.bin")
+    window_io.write_odometry_stream(path, o, scans, scan_match_cnt=2)
+    poses, rows, info = window_io.run_demo_odometry(path)
+    ctx = capi.Context(o)
+    od = odometry.ScanToMapOdometry(ctx, scan_match_cnt=2)
+    for k, sc in enumerate(scans):
+        p, rounds = od.run(sc, max_points=o.max_points_per_scan)
+        assert np.array_equal(p, poses[k]), (k, np.abs(p - poses[k]).max())
+        assert rows[k]["rounds"] == len(rounds) == (0 if k == 0 else (8 if k == 1 else 2))
+        assert rows[k]["kept"] == sum(kk for _, kk in rounds) and rows[k]["iterations"] == sum(int(s.iterations) for s, _ in rounds)
+        if k >= 1:
+            assert rows[k]["map_points"] == od.map_points
+    assert info["scans"] == len(scans) and info["ms_per_scan"] > 0
+    ctx.close()

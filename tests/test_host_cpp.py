@@ -9,6 +9,8 @@ import pytest
 from glio_amd import synth
 from glio_amd.host import window_io
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def test_host_mirror_builds_without_hip_headers():
     demo = window_io.build_demo(force=True)
@@ -225,3 +227,96 @@ def test_cpp_batch_association_and_rounds_match_python(tmp_path):
         assert np.isclose(a["final_cost"], b["final_cost"], rtol=1e-8)      # (the two hosts lay the end regions out at different offsets: other summation order)
     assert np.abs(rows - poses).max() < 1e-8
     ra.close(); st.close()
+
+
+@pytest.mark.gpu
+def test_released_configuration_cpp_equals_python_equals_oracle(tmp_path):
+    """The configuration the reference ships (config_urban_hk.yaml:60-104: slide_window_width 5, feature_res_num 100, random_select) replayed from C++:
+    glio::SlidingWindowBackend::featureSelection behind every slot's search (Estimator.cpp:2222-2223) with the draws of a generator both hosts share
+    (sliding.TableRng / host_demo_stream draws=) -- same iterations, same residual counts (100 per slot), same solved poses as the Python driver; and the
+    last keyframe's solve, on the correspondences the selection left and the prior the device's marginalization produced, equals the oracle's."""
+    import numpy as np
+    from glio_amd import capi, sliding, synth
+    from glio_amd.capi import lidar_pose
+    from glio_amd.host import window_io
+    from oracle import pyoracle as po
+    W, pts, NK, RES = 5, 4096, 3, 100
+    long = synth.make_window(W=W + NK, pts_per_scan=pts, with_gnss=False, with_prior=False, seed=synth.SEED_BASE + 23)
+    wins = [synth.sub_window(long, j, W) for j in range(NK + 1)]
+    opts = wins[0].opts
+    opts.max_map_points = 1 << 16
+    path, dpath = str(tmp_path / "stream.bin"), str(tmp_path / "draws.bin")
+    window_io.write_stream(path, long, wins, W, NK, pts)
+    table = np.random.default_rng(5).integers(0, 2 ** 62, 4096, dtype=np.uint64)
+    table.tofile(dpath)
+    got = window_io.run_demo_stream(path, search_range=6, feature_res_num=RES, draws=dpath)      # (search_range 6: the 8-keyframe stream never reaches the batch association)
+    rng = sliding.TableRng(table)
+    ctx = capi.Context(opts)
+    ctx.localmap_config(50, 0.4, pts)
+    tlb = np.array(opts.t_lb, np.float32)
+    for j in range(W - 1):
+        c = long.scans[j].copy(); c[:, :3] -= tlb
+        ctx.localmap_push(np.ascontiguousarray(c), long.gt.quat[j], long.gt.trans[j])
+    for s in range(W - 1):
+        ctx.set_scan(s + 1, long.scans[s])
+    ctx.set_prior(None)
+    iters, kept, checksum, sol, prior = [], [], 0.0, None, None
+    for j in range(NK + 1):
+        win = wins[j]
+        state = win.init.copy()
+        if j > 0:
+            state.trans[:-1], state.quat[:-1], state.speed_bias[:-1] = sol.trans[1:], sol.quat[1:], sol.speed_bias[1:]
+        new = j + W - 1
+        ctx.slide_window(); ctx.set_scan(W - 1, long.scans[new])
+        ctx.localmap_push_scan(W - 1, tlb, long.gt.quat[new], long.gt.trans[new]); ctx.localmap_build()
+        poses = [lidar_pose(opts, state.quat[s], state.trans[s]) for s in range(W)]
+        ctx.associate_window_async(np.array([p[0] for p in poses]), np.array([p[1] for p in poses]))
+        ctx.set_imu(win.preints); ctx.set_gnss(win.frame, win.dd, win.dop)
+        counts = list(ctx.associate_window_counts())
+        assert min(counts) > 10 * RES                                   # the selection has something to select from
+        for s in range(W):
+            counts[s] = sliding.feature_selection(ctx, s, counts[s], RES, rng)
+        assert counts == [RES] * W
+        corr = [ctx.get_correspondences(s) for s in range(W)]
+        sol, summ = ctx.solve(state)
+        if j == NK:                                                     # the oracle on the same buffers: selected correspondences, the device's prior
+            ow = synth.sub_window(long, j, W); ow.prior = prior
+            so, summ_o = po.Problem(ow, corr).solve(state)
+            assert summ_o.iterations == summ.iterations
+            assert np.linalg.norm(sol.trans - so.trans, axis=1).max() < 1e-9 and np.abs(sol.quat - so.quat).max() < 1e-10
+        prior = ctx.marginalize(sol) if j == NK - 1 else None          # (read back for the oracle's side of the last keyframe)
+        usol = sliding.unify_quaternions(sol.copy())
+        ctx.marginalize_keep(sol)
+        if j > 0:
+            iters.append(int(summ.iterations)); kept.append(int(np.sum(counts))); checksum += float(np.sum(sol.trans))
+    ctx.close()
+    assert got["feature_res_num"] == RES and got["iterations"] == iters and got["correspondences_kept"] == kept == [RES * W] * NK
+    assert abs(got["trans_checksum"] - checksum) <= 1e-12 * abs(checksum)
+    assert np.array_equal(np.array(got["last_trans"]).reshape(W, 3), sol.trans)          # same library, same inputs, same draws: the same bits
+    assert np.array_equal(np.array(got["last_quat"]).reshape(W, 4), usol.quat)
+
+
+def test_feature_selection_draws_cpp_equals_python(tmp_path):
+    """glio::featureSelectionDraws against sliding.feature_selection_draws on a shared table of numbers: the early return (count - 1 < feature_res_num keeps the
+    set whole, quirk Q9), random_select = false (empties the slot), and draws without repetition in the order drawn."""
+    import subprocess
+    import numpy as np
+    from glio_amd import sliding
+    here = os.path.join(ROOT, "glio_amd", "host")
+    src = tmp_path / "fs.cpp"
+    src.write_text('#include "glio_backend.hpp"\n#include <cstdio>\n#include <cstdlib>\n'
+                   'int main(int argc, char** argv) { const long count = atol(argv[1]); const int res = atoi(argv[2]); const bool rs = atoi(argv[3]) != 0; unsigned long long k = 0;\n'
+                   '  std::vector<unsigned long long> t; for (int a = 4; a < argc; ++a) t.push_back(strtoull(argv[a], nullptr, 10));\n'
+                   '  std::vector<int32_t> kept; const bool changed = glio::featureSelectionDraws(count, res, [&](uint64_t n) -> uint64_t { return t[k++ % t.size()] % n; }, rs, kept);\n'
+                   '  printf("%d", changed ? 1 : 0); for (int32_t v : kept) printf(" %d", v); printf("\\n"); return 0; }\n')
+    exe = str(tmp_path / "fs")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", str(src), "-I" + here, "-I" + os.path.join(ROOT, "include"), "-o", exe])
+    table = np.random.default_rng(9).integers(0, 2 ** 62, 300, dtype=np.uint64)
+    for count, res, rs in ((5000, 100, 1), (101, 100, 1), (100, 100, 1), (0, 100, 1), (102, 100, 1), (4096, 25, 1), (4096, 100, 0), (60, 100, 0)):
+        out = subprocess.run([exe, str(count), str(res), str(rs)] + [str(int(v)) for v in table], capture_output=True, text=True, check=True).stdout.split()
+        want = sliding.feature_selection_draws(count, res, sliding.TableRng(table), random_select=bool(rs))
+        if want is None:
+            assert out == ["0"], (count, res, rs, out)
+        else:
+            assert out[0] == "1" and [int(v) for v in out[1:]] == want.tolist(), (count, res, rs)
+            assert len(set(want.tolist())) == len(want) and (len(want) == 0 or (0 <= want.min() and want.max() < count))
