@@ -157,6 +157,17 @@ class Context:
         _check(load().glio_associate_resident(self._h, slot, T.dptr(q), T.dptr(t), C.byref(cnt)))
         return cnt.value
 
+    def select_correspondences_window(self, per_slot):
+        """per_slot[s]: None (slot untouched) or the indices slot s keeps, in order -- featureSelection of the whole window in one call"""
+        W = self.W
+        offs = np.zeros(W + 1, np.int32); changed = np.zeros(W, np.uint8); parts = []
+        for s in range(W):
+            if per_slot[s] is not None:
+                changed[s] = 1; parts.append(np.ascontiguousarray(per_slot[s], np.int32))
+            offs[s + 1] = offs[s] + (len(per_slot[s]) if per_slot[s] is not None else 0)
+        idx = np.concatenate(parts).astype(np.int32) if parts else np.zeros(0, np.int32)
+        _check(load().glio_select_correspondences_window(self._h, T.iptr(offs), T.iptr(idx) if len(idx) else None, changed.ctypes.data_as(C.POINTER(C.c_uint8))))
+
     def select_correspondences(self, slot, indices):
         idx = np.ascontiguousarray(indices, np.int32)
         _check(load().glio_select_correspondences(self._h, slot, T.iptr(idx) if len(idx) else None, len(idx)))

@@ -76,6 +76,7 @@ struct AssocWork {
     int* h_count;                 // pinned
     int* h_counts_win;            // pinned [GLIO_MAX_WINDOW]: counts of an asynchronous window association, picked up by glio_assoc_finish_pending
     hipEvent_t ev_counts;         // ... which waits for THIS point of the stream (the counts' copy), not for what the caller enqueued behind the searches since
+    int* h_sel; int* d_sel; size_t sel_cap; hipEvent_t ev_sel; int sel_in_flight;      // glio_assoc_select_window: its pinned block [offsets | changed | indices], the device copy, the event of the last upload
     int counts_pending;
     double* d_win; double* h_win; // [W][7] poses + [W] counts of the window association (h_win pinned)
     struct KnnBinHost* kb;        // query binning buffers of the tiled search
@@ -1827,6 +1828,9 @@ void glio_assoc_destroy(glio_ctx* c) {
     if (w->h_counts_win) hipHostFree(w->h_counts_win);
     if (w->h_win) hipHostFree(w->h_win);
     if (w->ev_counts) hipEventDestroy(w->ev_counts);
+    if (w->ev_sel) hipEventDestroy(w->ev_sel);
+    if (w->h_sel) hipHostFree(w->h_sel);
+    if (w->d_sel) hipFree(w->d_sel);
     delete w;
     c->assoc = nullptr;
 }
@@ -1972,6 +1976,72 @@ int glio_assoc_select(glio_ctx* c, int slot, const int32_t* indices, int n) {
     c->h_count[slot] = n;
     GLIO_HIP_CHECK(hipMemcpyAsync(c->d_count + slot, &c->h_count[slot], 4, hipMemcpyHostToDevice, c->stream));
     GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return GLIO_OK;
+}
+
+// featureSelection for the WHOLE window in one call (the released configuration selects in every slot of every keyframe call, Estimator.cpp:2222-2223: five
+// glio_assoc_select calls = five pageable uploads, fifteen device copies and five stream synchronisations, ~0.2 ms of a 0.95 ms call).  One pinned block
+// [offsets W + 1 | changed W | indices] -> one copy, a gather of every changed slot into the dense work arrays, a put-back that also installs the counts;
+// nothing is waited for: the solve is ordered behind it on the stream.
+__global__ void k_gather_corr_win(const int* __restrict__ blk, const int W, const int cap, const float4* __restrict__ pts, const float4* __restrict__ planes,
+                                  const double* __restrict__ scores, float4* __restrict__ o_pts, float4* __restrict__ o_planes, double* __restrict__ o_scores) {
+    const int s = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int o0 = blk[s], n = blk[s + 1] - o0;
+    if (!blk[W + 1 + s] || k >= n) return;
+    const size_t off = (size_t)s * cap;
+    const int src = blk[2 * W + 1 + o0 + k];
+    o_pts[off + k] = pts[off + src]; o_planes[off + k] = planes[off + src]; o_scores[off + k] = scores[off + src];
+}
+__global__ void k_put_corr_win(const int* __restrict__ blk, const int W, const int cap, const float4* __restrict__ s_pts, const float4* __restrict__ s_planes,
+                               const double* __restrict__ s_scores, float4* __restrict__ pts, float4* __restrict__ planes, double* __restrict__ scores, int* __restrict__ count) {
+    const int s = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = blk[s + 1] - blk[s];
+    if (!blk[W + 1 + s]) return;
+    if (k == 0) count[s] = n;
+    if (k >= n) return;
+    const size_t off = (size_t)s * cap;
+    pts[off + k] = s_pts[off + k]; planes[off + k] = s_planes[off + k]; scores[off + k] = s_scores[off + k];
+}
+int glio_assoc_select_window(glio_ctx* c, const int32_t* offsets, const int32_t* indices, const uint8_t* changed) {
+    AssocWork* w = c->assoc;
+    if (!w) return GLIO_E_STATE;
+    const int W = c->W;
+    if (offsets[0] != 0) { glio_set_error("offsets[0] must be 0"); return GLIO_E_ARG; }
+    int maxn = 0, any = 0;
+    for (int s = 0; s < W; ++s) {
+        const int n = offsets[s + 1] - offsets[s], cur = c->h_count[s];
+        if (n < 0) { glio_set_error("offsets not ascending at slot %d", s); return GLIO_E_ARG; }
+        if (changed && !changed[s]) continue;
+        if (n > cur) { glio_set_error("selection of %d out of %d correspondences (slot %d)", n, cur, s); return GLIO_E_ARG; }
+        for (int k = offsets[s]; k < offsets[s + 1]; ++k) if (indices[k] < 0 || indices[k] >= cur) { glio_set_error("selection index %d out of range (slot %d)", indices[k], s); return GLIO_E_ARG; }
+        if (n > maxn) maxn = n;
+        any = 1;
+    }
+    if (!any) return GLIO_OK;
+    const size_t words = (size_t)2 * W + 1 + (size_t)offsets[W];
+    if (words > w->sel_cap) {
+        if (w->sel_in_flight) { GLIO_HIP_CHECK(hipEventSynchronize(w->ev_sel)); w->sel_in_flight = 0; }
+        if (w->h_sel) hipHostFree(w->h_sel);
+        if (w->d_sel) hipFree(w->d_sel);
+        w->h_sel = nullptr; w->d_sel = nullptr; w->sel_cap = 0;
+        const size_t cap = words + words / 2 + 1024;
+        GLIO_HIP_CHECK(hipHostMalloc((void**)&w->h_sel, cap * 4)); GLIO_HIP_CHECK(hipMalloc((void**)&w->d_sel, cap * 4));
+        w->sel_cap = cap;
+    }
+    if (!w->ev_sel) GLIO_HIP_CHECK(hipEventCreateWithFlags(&w->ev_sel, hipEventDisableTiming));
+    if (w->sel_in_flight) { GLIO_HIP_CHECK(hipEventSynchronize(w->ev_sel)); w->sel_in_flight = 0; }     // (the previous call's block has left the pinned copy)
+    for (int s = 0; s <= W; ++s) w->h_sel[s] = offsets[s];
+    for (int s = 0; s < W; ++s) w->h_sel[W + 1 + s] = changed ? (changed[s] ? 1 : 0) : 1;
+    if (offsets[W] > 0) memcpy(w->h_sel + 2 * W + 1, indices, (size_t)offsets[W] * 4);
+    GLIO_HIP_CHECK(hipMemcpyAsync(w->d_sel, w->h_sel, words * 4, hipMemcpyHostToDevice, c->stream));
+    GLIO_HIP_CHECK(hipEventRecord(w->ev_sel, c->stream));
+    w->sel_in_flight = 1;
+    const dim3 grid((unsigned)((std::max(maxn, 1) + 255) / 256), (unsigned)W);
+    if (maxn > 0)
+        hipLaunchKernelGGL(k_gather_corr_win, grid, dim3(256), 0, c->stream, w->d_sel, W, c->cap, c->d_pts, c->d_planes, c->d_scores, w->d_q_pt, w->d_q_plane, w->d_q_score);
+    hipLaunchKernelGGL(k_put_corr_win, grid, dim3(256), 0, c->stream, w->d_sel, W, c->cap, w->d_q_pt, w->d_q_plane, w->d_q_score, c->d_pts, c->d_planes, c->d_scores, c->d_count);
+    GLIO_HIP_CHECK(hipGetLastError());
+    for (int s = 0; s < W; ++s) if (!changed || changed[s]) c->h_count[s] = offsets[s + 1] - offsets[s];
     return GLIO_OK;
 }
 

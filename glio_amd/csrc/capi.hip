@@ -409,6 +409,13 @@ int glio_select_correspondences(glio_ctx* c, int slot, const int32_t* indices, i
     c->f32_dirty = 1;
     return glio_assoc_select(c, slot, indices, n);
 }
+int glio_select_correspondences_window(glio_ctx* c, const int32_t* offsets, const int32_t* indices, const uint8_t* changed) {
+    if (!c || !offsets || (offsets[c->W] > 0 && !indices)) return GLIO_E_ARG;
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    { const int rp = glio_assoc_finish_pending(c); if (rp != GLIO_OK) return rp; }
+    c->f32_dirty = 1;
+    return glio_assoc_select_window(c, offsets, indices, changed);
+}
 int glio_associate_window(glio_ctx* c, const double* quats, const double* trans, int32_t* out_counts) {
     GLIO_TRACE("K2 glio_associate_window");
     if (!c || !quats || !trans) return GLIO_E_ARG;

@@ -424,6 +424,7 @@ int glio_chain_kind(const glio_ctx* c, int n_ddt);
 void glio_launch_stream_read(glio_ctx* c);
 int glio_assoc_build_map_dev(glio_ctx* c, const float4* d_pts, int n);
 int glio_assoc_select(glio_ctx* c, int slot, const int32_t* indices, int n);
+int glio_assoc_select_window(glio_ctx* c, const int32_t* offsets, const int32_t* indices, const uint8_t* changed);
 int glio_assoc_run_window(glio_ctx* c, const double* quats, const double* trans, int32_t* out_counts);
 int glio_assoc_run_window_async(glio_ctx* c, const double* quats, const double* trans);
 int glio_assoc_finish_pending(glio_ctx* c);

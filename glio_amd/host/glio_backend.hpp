@@ -232,6 +232,19 @@ public:
         check(glio_select_correspondences(ctx_, slot, sel_.empty() ? nullptr : sel_.data(), (int)sel_.size()), "glio_select_correspondences");
         return (int)sel_.size();
     }
+    // ... for all W slots of the window at once (the loop of :2198-2248 calls it slot after slot; the draws are made in slot order, exactly as W calls of
+    // featureSelection() would make them -- same generator in, same records kept): one upload and two launches instead of W synchronising calls.
+    // counts: in = what the searches kept (windowCounts()), out = the residual counts.
+    template <typename RandBelow>
+    void featureSelectionWindow(std::vector<int32_t>& counts, int feature_res_num, RandBelow&& rand_below, bool random_select = true) {
+        std::vector<int32_t> offsets((size_t)W_ + 1, 0), idx;
+        std::vector<uint8_t> changed((size_t)W_, 0);
+        for (int s = 0; s < W_; ++s) {
+            if (featureSelectionDraws(counts[s], feature_res_num, rand_below, random_select, sel_)) { changed[s] = 1; idx.insert(idx.end(), sel_.begin(), sel_.end()); counts[s] = (int32_t)sel_.size(); }
+            offsets[s + 1] = (int32_t)idx.size();
+        }
+        check(glio_select_correspondences_window(ctx_, offsets.data(), idx.empty() ? nullptr : idx.data(), changed.data()), "glio_select_correspondences_window");
+    }
     // Estimator.cpp:2182-2192 / 2153-2158 / 2329-2359
     void setImuFactors(const std::vector<glio_preint>& pre) {
         std::vector<int32_t> slots(pre.size());

@@ -72,11 +72,13 @@ int main(int argc, char** argv) {
         // draws=FILE (a table of 64-bit numbers: rand_below(n) = table[k++] mod n -- the generator a test shares with the Python host), timed=N (only the last N
         // keyframes enter the averages: the released configuration fills its 50-keyframe local map first)
         int feature_res = 0, timed_last = NK;
+        bool per_slot = false;
         std::vector<uint64_t> table;
         size_t table_k = 0;
         for (int a = 5; a < argc; ++a) {
             if (!strncmp(argv[a], "res=", 4)) feature_res = atoi(argv[a] + 4);
             else if (!strncmp(argv[a], "timed=", 6)) timed_last = atoi(argv[a] + 6);
+            else if (!strncmp(argv[a], "per_slot=", 9)) per_slot = atoi(argv[a] + 9) != 0;
             else if (!strncmp(argv[a], "draws=", 6)) {
                 FILE* df = fopen(argv[a] + 6, "rb");
                 if (!df) { perror("draws"); return 2; }
@@ -124,7 +126,9 @@ int main(int argc, char** argv) {
             const double t3b = now_s();
             std::vector<int32_t> counts = be.windowCounts();
             // featureSelection (Estimator.cpp:2223): right behind each slot's search, feature_res_num draws per slot (config_urban_hk.yaml:100: 100)
-            if (feature_res > 0) for (int s = 0; s < W; ++s) counts[s] = be.featureSelection(s, counts[s], feature_res, rand_below);
+            // (per_slot=1: W calls of featureSelection() instead of the one window call -- same draws, same records; A/B of the call overhead)
+            if (feature_res > 0 && per_slot) for (int s = 0; s < W; ++s) counts[s] = be.featureSelection(s, counts[s], feature_res, rand_below);
+            else if (feature_res > 0) be.featureSelectionWindow(counts, feature_res, rand_below);
             if (!defer && !after_marg) kba.prepare(nw + 1);          // (the pairs are known; their search frames' tables are cleared while the solve runs)
             const double t4 = now_s();
             const glio_summary sum = be.solve(&ddt);

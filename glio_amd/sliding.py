@@ -36,7 +36,7 @@ def feature_selection_draws(count, feature_res_num, rng, random_select=True):
     # in glio_backend.hpp is this loop in C++: same generator in, same indices out)
     gone, out = [], []
     for d in range(feature_res_num):
-        v = int(rng.integers(0, count - d))
+        v = int(rng.integers(0, int(count) - d))
         pos = 0
         while pos < len(gone) and gone[pos] <= v:
             v += 1; pos += 1
@@ -54,6 +54,7 @@ class TableRng:
 
     def integers(self, lo, hi):
         v = int(self.table[self.k % len(self.table)]); self.k += 1
+        lo, hi = int(lo), int(hi)
         return lo + v % (hi - lo)
 
 
@@ -63,6 +64,15 @@ def feature_selection(backend, slot, count, feature_res_num, rng, random_select=
         return count
     backend.select_correspondences(slot, sel)
     return len(sel)
+
+
+def feature_selection_window(backend, counts, feature_res_num, rng, random_select=True):
+    """featureSelection for every slot of the window, the draws in slot order (as W calls of feature_selection would make them), ONE device call.
+    Returns the residual counts."""
+    sels = [feature_selection_draws(int(c), feature_res_num, rng, random_select) for c in counts]
+    if any(sel is not None for sel in sels):
+        backend.select_correspondences_window(sels)
+    return [int(c) if sel is None else len(sel) for c, sel in zip(counts, sels)]
 
 
 MIN_MAP_POINTS = 50        # `if (surf_local_map_ds->points.size() > 50)` guards the correspondence search, Estimator.cpp:2221,2244

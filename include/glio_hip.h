@@ -109,6 +109,11 @@ int glio_associate_window_counts(glio_ctx* ctx, int32_t* out_counts);
  * reference seeds from std::random_device, random_generator.hpp:58, so they are not reproducible anyway); the gather
  * runs on the device, nothing is read back.  glio_amd/sliding.py::feature_selection restates the draw procedure. */
 int glio_select_correspondences(glio_ctx* ctx, int slot, const int32_t* indices, int n);
+/* The same for every slot of the window in ONE call -- what the released configuration does in every keyframe call (featureSelection behind each slot's
+ * search, Estimator.cpp:2222-2223; feature_res_num 100 of ~4 k records per slot): slot s keeps records indices[offsets[s] .. offsets[s+1]) of its own set, in
+ * that order (offsets[0] = 0, W + 1 entries); changed[s] == 0 leaves slot s untouched (the early return of :3906-3909), changed == NULL changes all.  One
+ * upload, two launches, no host wait: the solve that follows on the context is ordered behind it. */
+int glio_select_correspondences_window(glio_ctx* ctx, const int32_t* offsets, const int32_t* indices, const uint8_t* changed);
 /* Parity hook / featureSelection replacement: provide or read back a slot's correspondence arrays. */
 int glio_set_correspondences(glio_ctx* ctx, int slot, const float* pts_xyzi, const float* planes,
                              const double* scores, int n);

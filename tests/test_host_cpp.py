@@ -250,6 +250,9 @@ def test_released_configuration_cpp_equals_python_equals_oracle(tmp_path):
     table = np.random.default_rng(5).integers(0, 2 ** 62, 4096, dtype=np.uint64)
     table.tofile(dpath)
     got = window_io.run_demo_stream(path, search_range=6, feature_res_num=RES, draws=dpath)      # (search_range 6: the 8-keyframe stream never reaches the batch association)
+    # the C++ host selects the whole window in one call (glio_select_correspondences_window); W per-slot calls keep the same records
+    got_ps = window_io.run_demo_stream(path, search_range=6, feature_res_num=RES, draws=dpath, per_slot=True)
+    assert got_ps["last_trans"] == got["last_trans"] and got_ps["last_quat"] == got["last_quat"] and got_ps["iterations"] == got["iterations"]
     rng = sliding.TableRng(table)
     ctx = capi.Context(opts)
     ctx.localmap_config(50, 0.4, pts)
@@ -274,8 +277,11 @@ def test_released_configuration_cpp_equals_python_equals_oracle(tmp_path):
         ctx.set_imu(win.preints); ctx.set_gnss(win.frame, win.dd, win.dop)
         counts = list(ctx.associate_window_counts())
         assert min(counts) > 10 * RES                                   # the selection has something to select from
-        for s in range(W):
-            counts[s] = sliding.feature_selection(ctx, s, counts[s], RES, rng)
+        if j % 2:                                                       # the Python host alternates between the two forms
+            counts = sliding.feature_selection_window(ctx, counts, RES, rng)
+        else:
+            for s in range(W):
+                counts[s] = sliding.feature_selection(ctx, s, counts[s], RES, rng)
         assert counts == [RES] * W
         corr = [ctx.get_correspondences(s) for s in range(W)]
         sol, summ = ctx.solve(state)
