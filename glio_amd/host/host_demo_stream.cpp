@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include <random>
@@ -73,12 +74,18 @@ int main(int argc, char** argv) {
         // keyframes enter the averages: the released configuration fills its 50-keyframe local map first)
         int feature_res = 0, timed_last = NK;
         bool per_slot = false;
+        // sleep_ms=N: the host sleeps N ms inside every keyframe call (a 10 Hz caller leaves the GPU idle for ~100 ms between calls; the sleep is not part of
+        // any stage time).  sleep_at: 0 = between the batch association's preparation and the solve, 1 = before the call's first entry point, 2 = between the solve and
+        // the batch association's enqueue
+        int sleep_ms = 0, sleep_at = 0;
         std::vector<uint64_t> table;
         size_t table_k = 0;
         for (int a = 5; a < argc; ++a) {
             if (!strncmp(argv[a], "res=", 4)) feature_res = atoi(argv[a] + 4);
             else if (!strncmp(argv[a], "timed=", 6)) timed_last = atoi(argv[a] + 6);
             else if (!strncmp(argv[a], "per_slot=", 9)) per_slot = atoi(argv[a] + 9) != 0;
+            else if (!strncmp(argv[a], "sleep_ms=", 9)) sleep_ms = atoi(argv[a] + 9);
+            else if (!strncmp(argv[a], "sleep_at=", 9)) sleep_at = atoi(argv[a] + 9);
             else if (!strncmp(argv[a], "draws=", 6)) {
                 FILE* df = fopen(argv[a] + 6, "rb");
                 if (!df) { perror("draws"); return 2; }
@@ -99,6 +106,7 @@ int main(int argc, char** argv) {
             for (int i = 0; i < pts; ++i) for (int c = 0; c < 3; ++c) body[4 * (size_t)i + c] -= tlb[c];
             ba.setFrame(j, body.data(), pts);
         }
+        double stmax[7] = {0, 0, 0, 0, 0, 0, 0};
         double st[7] = {0, 0, 0, 0, 0, 0, 0}, cyc = 0, cmin = 1e9, cmax = 0, fd[3] = {0, 0, 0};
         std::vector<int> iters; std::vector<long> kept; std::vector<long> bfound; std::vector<long> bkept;
         double checksum = 0;
@@ -110,6 +118,7 @@ int main(int argc, char** argv) {
             if (j == 0) { be.tmpTrans = k.trans; be.tmpQuat = k.quat; be.tmpSpeedBias = k.sb; }
             else be.slideState(&k.trans[3 * (W - 1)], &k.quat[4 * (W - 1)], &k.sb[9 * (W - 1)]);      // previous solution shifted + the new keyframe's prediction
             std::vector<double> ddt = k.ddt;
+            if (sleep_ms > 0 && sleep_at == 1) std::this_thread::sleep_for(std::chrono::milliseconds(sleep_ms));
             const double t0 = now_s();
             be.slideWindow(); be.setScan(W - 1, scans[nw].data(), pts);
             // the keyframe's cloud goes to the batch association's store as soon as it is on the device (body frame: nothing of it depends on the solve); with the
@@ -130,6 +139,7 @@ int main(int argc, char** argv) {
             if (feature_res > 0 && per_slot) for (int s = 0; s < W; ++s) counts[s] = be.featureSelection(s, counts[s], feature_res, rand_below);
             else if (feature_res > 0) be.featureSelectionWindow(counts, feature_res, rand_below);
             if (!defer && !after_marg) kba.prepare(nw + 1);          // (the pairs are known; their search frames' tables are cleared while the solve runs)
+            if (sleep_ms > 0 && sleep_at == 0) std::this_thread::sleep_for(std::chrono::milliseconds(sleep_ms));
             const double t4 = now_s();
             const glio_summary sum = be.solve(&ddt);
             const double t5 = now_s();
@@ -140,6 +150,8 @@ int main(int argc, char** argv) {
                 for (int c = 0; c < 4; ++c) kf_poses[7 * (size_t)g + 3 + c] = be.tmpQuat[4 * s + c];
             }
             std::vector<int64_t> found;
+            double slept2 = 0;
+            if (sleep_ms > 0 && sleep_at == 2) { const double ts = now_s(); std::this_thread::sleep_for(std::chrono::milliseconds(sleep_ms)); slept2 = now_s() - ts; }
             if (defer) found = kba.finish(rand_below);                  // the previous keyframe's pairs: they had a whole cycle
             if (defer) ba.setFrameFromScan(nw, be.ctx(), W - 1, tlb);
             if (!after_marg) kba.enqueue(nw + 1, kf_poses);
@@ -156,7 +168,8 @@ int main(int argc, char** argv) {
             for (double v : be.tmpTrans) checksum += v;
             last_trans = be.tmpTrans; last_quat = be.tmpQuat;
             if (j <= NK - timed_last) continue;                          // (results are booked for every keyframe, times for the last timed_last)
-            const double d[7] = {t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5b, (t5b - t5) + (t7 - t6)};
+            const double d[7] = {t1 - t0, t2 - t1, t3 - t2, t4 - t3 - (sleep_at == 0 ? sleep_ms * 1e-3 : 0.0), t5 - t4, t6 - t5b, (t5b - t5 - slept2) + (t7 - t6)};
+            for (int q = 0; q < 7; ++q) if (d[q] > stmax[q]) stmax[q] = d[q];
             double c = 0;
             for (int q = 0; q < 7; ++q) { st[q] += d[q] / timed_last; c += d[q]; }
             fd[0] += (t3a - t3) / timed_last; fd[1] += (t3b - t3a) / timed_last; fd[2] += (t4 - t3b) / timed_last;
@@ -174,6 +187,8 @@ int main(int argc, char** argv) {
         printf("], \"batch_records_held\": [");
         for (size_t i = 0; i < bkept.size(); ++i) printf("%s%ld", i ? ", " : "", bkept[i]);
         printf("], \"factors_stage_ms\": {\"set_imu_host\": %.4f, \"set_gnss_host\": %.4f, \"wait_for_the_searches\": %.4f}", fd[0] * 1e3, fd[1] * 1e3, fd[2] * 1e3);
+        printf(", \"stage_max_ms\": [%.4f, %.4f, %.4f, %.4f, %.4f, %.4f, %.4f], \"sleep_ms\": %d, \"sleep_at\": %d", stmax[0] * 1e3, stmax[1] * 1e3, stmax[2] * 1e3, stmax[3] * 1e3, stmax[4] * 1e3,
+               stmax[5] * 1e3, stmax[6] * 1e3, sleep_ms, sleep_at);
         printf(", \"batch_feature_res_num\": %d, \"feature_res_num\": %d, \"timed_keyframes\": %d, \"last_trans\": [", RES, feature_res, timed_last);
         for (size_t i = 0; i < last_trans.size(); ++i) printf("%s%.17g", i ? ", " : "", last_trans[i]);
         printf("], \"last_quat\": [");
