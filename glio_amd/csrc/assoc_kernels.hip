@@ -395,14 +395,25 @@ struct AssocArgs {
     const int* pair_ci; const int* pair_cj; // [n_pairs]
     const double* poses;                    // [K][7] = t, q (w, x, y, z)
     int pair0;                              // first pair of this launch
+    // pair mode, shared query binning: the pairs of a chunk that query the SAME keyframe cloud (the 2 search_range pairs of a keyframe call; 12 consecutive pairs
+    // of batch.pair_list) have the same queries at the same pose -- they are grouped by cell ONCE.  A bin row = one distinct ci of the chunk:
+    const int* pair_row;                    // [n_pairs] bin row (inside its chunk) of a pair, or nullptr: every launch row bins for itself
+    const int* row_pair;                    // [n_pairs] at pair0 + r: a pair (absolute index) that queries bin row r's cloud
+    int bin_pass;                           // 1: the launch is the binning of the chunk's bin rows (blockIdx.y = bin row), 0: blockIdx.y = pair of the chunk
 };
 struct FrameDesc { const int4* ent; const uint4* sub; const float4* sorted; int n, cap_eff; };
-struct AssocSlot { double q[4], t[3]; int n; size_t qoff, woff, boff; const int4* ent; const uint4* sub; const float4* map; size_t locoff; int table_cap; };
+struct AssocSlot { double q[4], t[3]; int n; size_t qoff, woff, boff; const int4* ent; const uint4* sub; const float4* map; size_t locoff; int table_cap;
+                   int brow; };      // brow: the launch row whose grouped queries / units this row searches (itself, unless pairs share their binning)
 __device__ __forceinline__ AssocSlot assoc_slot(const AssocArgs& a) {
     AssocSlot s;
     s.ent = nullptr; s.sub = nullptr; s.map = nullptr; s.locoff = 0; s.table_cap = a.table_cap;
+    s.brow = blockIdx.y;
     if (a.frames) {
-        const int p = a.pair0 + blockIdx.y;
+        int p = a.pair0 + blockIdx.y;
+        if (a.pair_row) {
+            if (a.bin_pass) p = a.row_pair[p];          // the binning of bin row blockIdx.y: any pair that queries its cloud (same cloud, same pose)
+            else s.brow = a.pair_row[p];
+        }
         const int ci = a.pair_ci[p], cj = a.pair_cj[p];
         const double* P = a.poses + 7 * ci;
 #pragma unroll
@@ -517,7 +528,7 @@ __device__ __forceinline__ void knn5_group_body(const AssocArgs& a, const float4
     float px, py, pz;
     if (LIST) {
         const int fq = qlive ? a.kb.failq[(size_t)blockIdx.y * a.w_stride_q + i] : 0;
-        const float4 qp = glob ? a.kb.qs2[fq] : a.kb.qs[sl.woff + fq];
+        const float4 qp = glob ? a.kb.qs2[fq] : a.kb.qs[(size_t)sl.brow * a.w_stride + fq];
         const int qw = __float_as_int(qp.w);
         px = qp.x; py = qp.y; pz = qp.z;
         i = glob ? (size_t)((unsigned)qw >> NK_ROW_SHIFT) * a.w_stride + (qw & ((1 << NK_ROW_SHIFT) - 1)) : (size_t)qw;
@@ -928,11 +939,12 @@ __device__ __forceinline__ void knn5_tile_body(const AssocArgs& a, const float4*
     const int table_cap = sl.table_cap;
     // use_fails: the launch ranks only what the near-block search (k_knn5_near) handed on -- entries (unit, mask of its queries); else every unit, every query
     const bool by_list = a.kb.use_fails != 0;
-    const int n_units = a.kb.counters[4 * blockIdx.y + (by_list ? 2 : 1)];
-    const int4* units = a.kb.units + (size_t)blockIdx.y * a.kb.unit_stride;
+    // (units and grouped queries: the bin row's; the handed-on lists and their counts: this launch row's own)
+    const int n_units = by_list ? a.kb.counters[4 * blockIdx.y + 2] : a.kb.counters[4 * sl.brow + 1];
+    const int4* units = a.kb.units + (size_t)sl.brow * a.kb.unit_stride;
     const int4* fails = a.kb.fails + (size_t)blockIdx.y * a.kb.unit_stride;
     const bool glob = a.kb.glob != 0;
-    const float4* qs = glob ? a.kb.qs2 : a.kb.qs + sl.woff;
+    const float4* qs = glob ? a.kb.qs2 : a.kb.qs + (size_t)sl.brow * a.w_stride;
 #ifdef GLIO_DEV_STAMPS
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { for (int k = 0; k < 8; ++k) g_knn_stamps[k] = 0; }
     const long long wg_t0 = wall_clock64();
@@ -1248,11 +1260,11 @@ __global__ __launch_bounds__(64 * NK_WPB) NK_ATTR void k_knn5_near(const AssocAr
     if (sl.ent) { ent = sl.ent; sub = sl.sub; map = sl.map; }
     const int table_cap = sl.table_cap;
     int* ctr = a.kb.counters + 4 * blockIdx.y;
-    const int n_units = ctr[1];
-    const int4* units = a.kb.units + (size_t)blockIdx.y * a.kb.unit_stride;
+    const int n_units = a.kb.counters[4 * sl.brow + 1];
+    const int4* units = a.kb.units + (size_t)sl.brow * a.kb.unit_stride;
     int4* fails = a.kb.fails + (size_t)blockIdx.y * a.kb.unit_stride;
     int* failq = a.kb.failq + (size_t)blockIdx.y * a.w_stride_q;
-    const float4* qs = glob ? a.kb.qs2 : a.kb.qs + sl.woff;
+    const float4* qs = glob ? a.kb.qs2 : a.kb.qs + (size_t)sl.brow * a.w_stride;
     const float cell = a.cell, half = 0.5f * a.cell;
 #ifdef GLIO_DEV_STAMPS
     long long nk_ph[8] = {0, 0, 0, 0, 0, 0, wall_clock64(), 0};
@@ -1728,7 +1740,10 @@ static void enqueue_presort(hipStream_t stream, KnnBinHost* kb, const float4* cl
 // exact 5-NN of every query of the launch rows [0, rows): the caller's AssocArgs select the row geometry (assoc_slot);
 // `scan` = the clouds as uploaded, `ps` = their presorted copies
 static void enqueue_knn(hipStream_t stream, AssocArgs& a, KnnBinHost* kb, int rows, int maxn, const float4* scan, const float4* ps, const float4* map,
-                        const int4* ent, const uint4* sub, int map_n_max, int* nn5) {
+                        const int4* ent, const uint4* sub, int map_n_max, int* nn5, int bin_rows = 0) {
+    // bin_rows > 0 (pair mode, a.pair_row / a.row_pair set): only that many launch rows are grouped by cell; every pair searches its bin row's units
+    if (bin_rows <= 0 || !a.pair_row) { bin_rows = rows; a.pair_row = nullptr; a.row_pair = nullptr; }
+    a.bin_pass = 0;
     if (g_knn_mode == 1 || !kb) {
         memset(&a.kb, 0, sizeof a.kb);
         hipLaunchKernelGGL(k_knn5, dim3((maxn + AQ_PER_BLOCK - 1) / AQ_PER_BLOCK, rows), dim3(256), 0, stream, a, scan, map, ent, nn5);
@@ -1755,7 +1770,9 @@ static void enqueue_knn(hipStream_t stream, AssocArgs& a, KnnBinHost* kb, int ro
         a.kb.use_fails = 0; a.kb.glob = 0; a.kb.counters = kb->d.counters; a.kb.gcap = kb->d.gcap;
         return;
     }
-    hipLaunchKernelGGL(k_qbin_tile, dim3((maxn + QT_THREADS - 1) / QT_THREADS, rows), dim3(QT_THREADS), 0, stream, a, ps);
+    a.bin_pass = a.pair_row ? 1 : 0;
+    hipLaunchKernelGGL(k_qbin_tile, dim3((maxn + QT_THREADS - 1) / QT_THREADS, bin_rows), dim3(QT_THREADS), 0, stream, a, ps);
+    a.bin_pass = 0;
     // capacity for maxn / 8 units per row (k_qbin_tile makes at most n / 16 + cells): one wavefront-workgroup per unit pair up to 4096 per row, beyond
     // that the workgroups stride
     // (sizing the grid to what the chip holds at once -- ~4096 workgroups striding over the units -- measured 390 us instead of 303 us for the one-call
@@ -2164,6 +2181,7 @@ struct glio_bassoc {
     long long* d_run;               // [1] running total
     long long* d_pair_off; int max_pairs;     // [max_pairs + 1]
     FrameDesc* d_frames; int* d_pair_ci; int* d_pair_cj;      // [K], [max_pairs] x 2: what the chunked launches index by blockIdx.y
+    int* d_pair_row; int* d_row_pair;                          // [max_pairs] x 2: shared query binning (AssocArgs::pair_row / row_pair)
     int b_stride;                             // per-pair stride of the per-workgroup count arrays
     long long* h_pair_off;          // pinned
     long long* h_tail;              // pinned [2]: running total, overflow flag of the last run
@@ -2377,7 +2395,7 @@ void glio_bassoc_destroy(glio_bassoc* b) {
         for (void* q : p) if (q) hipFree(q);
     }
     void* p[] = {b->d_bkeys, b->d_bcnt8, b->d_bslot, b->d_brank, b->d_nn5, b->d_local, b->d_local_ps, b->d_global, b->d_total, b->d_q_cp, b->d_q_nc, b->d_q_score, b->d_q_flag, b->d_q_pos, b->d_bcount, b->d_boff,
-                 b->d_cp, b->d_nc, b->d_score, b->d_run, b->d_poses, b->d_pair_off, b->d_frames, b->d_pair_ci, b->d_pair_cj,
+                 b->d_cp, b->d_nc, b->d_score, b->d_run, b->d_poses, b->d_pair_off, b->d_frames, b->d_pair_ci, b->d_pair_cj, b->d_pair_row, b->d_row_pair,
                  b->d_sel_cp, b->d_sel_nc, b->d_sel_score, b->d_sel_idx};
     for (void* q : p) if (q) hipFree(q);
     knn_bin_destroy(b->kb);
@@ -2510,12 +2528,14 @@ static int bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const in
     for (int p = 0; p < n_pairs; ++p)
         if (pair_ci[p] < 0 || pair_ci[p] >= b->K || pair_cj[p] < 0 || pair_cj[p] >= b->K || pair_ci[p] == pair_cj[p]) { glio_set_error("bad pair %d", p); return GLIO_E_ARG; }
     if (n_pairs > b->max_pairs) {
-        if (b->d_pair_off) { hipFree(b->d_pair_off); hipHostFree(b->h_pair_off); hipFree(b->d_pair_ci); hipFree(b->d_pair_cj); hipHostFree(b->h_pairs); b->d_pair_off = nullptr; b->h_pair_off = nullptr; b->h_pairs = nullptr; }
+        if (b->d_pair_off) { hipFree(b->d_pair_off); hipHostFree(b->h_pair_off); hipFree(b->d_pair_ci); hipFree(b->d_pair_cj); hipFree(b->d_pair_row); hipFree(b->d_row_pair); hipHostFree(b->h_pairs);
+                             b->d_pair_off = nullptr; b->h_pair_off = nullptr; b->h_pairs = nullptr; b->d_pair_ci = b->d_pair_cj = b->d_pair_row = b->d_row_pair = nullptr; }
         b->max_pairs = n_pairs + 64;
         BA_CHECK(hipMalloc((void**)&b->d_pair_off, (size_t)(b->max_pairs + 2) * 8));
         BA_CHECK(hipMalloc((void**)&b->d_pair_ci, (size_t)b->max_pairs * 4)); BA_CHECK(hipMalloc((void**)&b->d_pair_cj, (size_t)b->max_pairs * 4));
+        BA_CHECK(hipMalloc((void**)&b->d_pair_row, (size_t)b->max_pairs * 4)); BA_CHECK(hipMalloc((void**)&b->d_row_pair, (size_t)b->max_pairs * 4));
         BA_CHECK(hipHostMalloc((void**)&b->h_pair_off, (size_t)(b->max_pairs + 2) * 8));
-        BA_CHECK(hipHostMalloc((void**)&b->h_pairs, (size_t)b->max_pairs * 8));
+        BA_CHECK(hipHostMalloc((void**)&b->h_pairs, (size_t)b->max_pairs * 16));
     }
     memcpy(b->h_poses, poses, (size_t)b->K * 7 * 8);
     BA_CHECK(hipMemcpyAsync(b->d_poses, b->h_poses, (size_t)b->K * 7 * 8, hipMemcpyHostToDevice, b->stream));
@@ -2570,9 +2590,31 @@ static int bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const in
             fd.cap_eff = need[k] ? b->frames[k].cap_eff : b->frames[k].table_cap;
         }
         for (int p = 0; p < n_pairs; ++p) { b->h_pairs[p] = pair_ci[p]; b->h_pairs[b->max_pairs + p] = pair_cj[p]; if (b->h_n[pair_ci[p]] > maxn) maxn = b->h_n[pair_ci[p]]; }
+        // shared query binning: per chunk, the distinct source keyframes in order of first appearance (their pairs usually follow each other: a linear look-back
+        // over the chunk's rows, at most BA_CHUNK of them)
+        std::vector<int> chunk_rows((size_t)(n_pairs + BA_CHUNK - 1) / BA_CHUNK, 0);
+        {
+            int32_t* h_row = b->h_pairs + 2 * (size_t)b->max_pairs; int32_t* h_rp = b->h_pairs + 3 * (size_t)b->max_pairs;
+            for (int p0 = 0; p0 < n_pairs; p0 += BA_CHUNK) {
+                const int np = n_pairs - p0 < BA_CHUNK ? n_pairs - p0 : BA_CHUNK;
+                int nr = 0;
+                for (int q = 0; q < np; ++q) {
+                    const int ci = pair_ci[p0 + q];
+                    int r = nr - 1;
+                    while (r >= 0 && pair_ci[h_rp[p0 + r]] != ci) --r;
+                    if (r < 0) { r = nr++; h_rp[p0 + r] = p0 + q; }
+                    h_row[p0 + q] = r;
+                }
+                for (int r = nr; r < np; ++r) h_rp[p0 + r] = p0;
+                chunk_rows[(size_t)p0 / BA_CHUNK] = nr;
+            }
+        }
+        static const bool share_bins = !(getenv("GLIO_BASSOC_SHARED_BINS") && atoi(getenv("GLIO_BASSOC_SHARED_BINS")) == 0);      // (0: every pair bins for itself -- A/B and tests)
         BA_CHECK(hipMemcpyAsync(b->d_frames, b->h_fd, (size_t)b->K * sizeof(FrameDesc), hipMemcpyHostToDevice, b->stream));
         BA_CHECK(hipMemcpyAsync(b->d_pair_ci, b->h_pairs, (size_t)n_pairs * 4, hipMemcpyHostToDevice, b->stream));
         BA_CHECK(hipMemcpyAsync(b->d_pair_cj, b->h_pairs + b->max_pairs, (size_t)n_pairs * 4, hipMemcpyHostToDevice, b->stream));
+        BA_CHECK(hipMemcpyAsync(b->d_pair_row, b->h_pairs + 2 * (size_t)b->max_pairs, (size_t)n_pairs * 4, hipMemcpyHostToDevice, b->stream));
+        BA_CHECK(hipMemcpyAsync(b->d_row_pair, b->h_pairs + 3 * (size_t)b->max_pairs, (size_t)n_pairs * 4, hipMemcpyHostToDevice, b->stream));
         AssocArgs a;
         memset(&a, 0, sizeof a);
         a.inv_cell = b->inv_cell; a.cell = b->cell; a.kd_max_radius = 1.5; a.weight_gate = 0.3; a.surf_dist_thres = 0.18; a.lidar_const = 2.5;   // :3839,3874,3863,3885
@@ -2583,7 +2625,10 @@ static int bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const in
             const int np = n_pairs - p0 < BA_CHUNK ? n_pairs - p0 : BA_CHUNK;
             a.pair0 = p0;
             if (maxn > 0) {
-                enqueue_knn(b->stream, a, b->kb, np, maxn, b->d_local, b->d_local_ps, (const float4*)nullptr, (const int4*)nullptr, (const uint4*)nullptr, b->cap, b->d_nn5);
+                a.pair_row = share_bins ? b->d_pair_row : nullptr; a.row_pair = share_bins ? b->d_row_pair : nullptr;
+                enqueue_knn(b->stream, a, b->kb, np, maxn, b->d_local, b->d_local_ps, (const float4*)nullptr, (const int4*)nullptr, (const uint4*)nullptr, b->cap, b->d_nn5,
+                            share_bins ? chunk_rows[(size_t)p0 / BA_CHUNK] : 0);
+                a.pair_row = nullptr; a.row_pair = nullptr;          // (the fit below addresses everything by the pair)
                 hipLaunchKernelGGL(k_plane_fit<true>, dim3((maxn + PF_BLOCK - 1) / PF_BLOCK, np), dim3(PF_BLOCK), 0, b->stream, a, b->d_local, (const float4*)nullptr,
                                    b->d_nn5, b->d_q_cp, (float4*)nullptr, b->d_q_score, b->d_q_flag, b->d_q_pos, b->d_bcount, (int*)nullptr,
                                    b->d_local, b->d_q_nc);
