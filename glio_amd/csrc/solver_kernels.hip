@@ -3883,6 +3883,190 @@ __global__ __launch_bounds__(TR_THREADS) void k_marg_schur(const double* A, cons
     if (tid == 0) *ok = good ? 1 : 0;
 }
 
+// ---- the same in three launches (round 6).  k_marg_schur runs everything in ONE workgroup over matrices that live in global memory: the n x n Schur
+// complement alone is n^2 / 2 entries of 15 dependent global reads each for 512 threads -- 90 us for n = 123 where the arithmetic is a few microseconds.
+// Split: (1) k_marg_inv, one workgroup: Amm^+ (fast inverse or the Jacobi eigen-decomposition) -> 225 doubles in global memory;
+//        (2) k_marg_rows, n + 1 workgroups: row i of T = Arm Amm^+ in LDS, row i of S (and the carried right-hand side as row n), the null-pivot tolerance
+//            of its diagonal entry, and a flag when a non-zero lies outside the block-diagonal pattern -- the same sums in the same order as above;
+//        (3) k_marg_root, one workgroup: the root of S (per diagonal block by one wavefront each, or the dense blocked Cholesky), J0, r0.
+// Same bits out (tests/test_hip_marg.py runs both forms).
+__global__ __launch_bounds__(TR_THREADS) void k_marg_inv(const double* A, const int n, double* Ainv_out, int* viol_out) {
+    const int tid = threadIdx.x, m = 15, pos = m + n;
+    double* part = reinterpret_cast<double*>(tr_lds);
+    double* ebuf = part;
+    double* Ainv = part + 1100;
+    __shared__ int s_fast, s_ecur;
+    if (tid == 0) *viol_out = 0;
+    if (tid < 256) {
+        const int i = tid >> 4, j = tid & 15;
+        ebuf[tid] = (i < 15 && j < 15) ? 0.5 * (A[(size_t)i * pos + j] + A[(size_t)j * pos + i]) : 0.0;
+        ebuf[256 + tid] = (i == j) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    double* Linv = ebuf + 512;
+    if (tid < 64) {
+        const int lane = tid;
+        double a[16], x[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[j] = lane < 15 ? (j < 15 ? ebuf[lane * 16 + j] : 0.0) : ((lane == 15 && j == 15) ? 1.0 : 0.0);
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            double djj = readlane_d(a[j], j);
+            if (!(djj > 0.0) || !isfinite(djj)) { bad = true; djj = 1.0; }
+            const double rd = 1.0 / sqrt(djj);
+            const double lij = (lane == j) ? djj * rd : a[j] * rd;
+            a[j] = lij;
+#pragma unroll
+            for (int c2 = j + 1; c2 < 16; ++c2) a[c2] -= lij * readlane_d(lij, c2);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            double sacc = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < i; ++k) sacc -= readlane_d(a[k], i) * x[k];
+            x[i] = sacc / readlane_d(a[i], i);
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) Linv[k * 16 + lane] = x[k];
+        }
+        if (lane == 0) s_fast = bad ? 0 : 1;
+    }
+    __syncthreads();
+    if (s_fast) {
+        if (tid < 225) {
+            const int i = tid / 15, j = tid % 15;
+            double sacc = 0;
+            for (int k = (i > j ? i : j); k < 15; ++k) sacc += Linv[k * 16 + i] * Linv[k * 16 + j];
+            Ainv[tid] = sacc;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double f2 = 0;
+            for (int k = 0; k < 225; ++k) f2 += Ainv[k] * Ainv[k];
+            if (!(f2 > 0.0) || !isfinite(f2) || !(1.0 / sqrt(f2) > 1e-7)) s_fast = 0;
+        }
+        __syncthreads();
+    }
+    if (!s_fast) {
+        if (tid < 64) { const int cur = jacobi16_wave(ebuf, tid); if (tid == 0) s_ecur = cur; }
+        __syncthreads();
+        if (tid < 225) {
+            const double* Am = ebuf + s_ecur * 512; const double* Vm = Am + 256;
+            const int i = tid / 15, j = tid % 15;
+            double sacc = 0;
+            for (int k = 0; k < 16; ++k) { const double w = Am[k * 17]; sacc += Vm[i * 16 + k] * (w > 1e-8 ? 1.0 / w : 0.0) * Vm[j * 16 + k]; }
+            Ainv[tid] = sacc;
+        }
+        __syncthreads();
+    }
+    if (tid < 225) Ainv_out[tid] = Ainv[tid];
+}
+// blockIdx.x = i < n: row i of S (lower part) ; blockIdx.x = n: the carried right-hand side.  128 threads.
+__global__ __launch_bounds__(128) void k_marg_rows(const double* __restrict__ A, const double* __restrict__ b, const int n, const double* __restrict__ Ainv,
+                                                   double* __restrict__ Twork, double* __restrict__ Lwork, double* __restrict__ tol, int* __restrict__ viol) {
+    __shared__ double sA[225], sT[15], sArow[15];
+    const int tid = threadIdx.x, m = 15, pos = m + n, i = blockIdx.x;
+    for (int k = tid; k < 225; k += 128) sA[k] = Ainv[k];
+    if (i < n && tid < 15) sArow[tid] = A[(size_t)(m + i) * pos + tid];
+    __syncthreads();
+    if (i < n) {
+        if (tid < 15) {                                      // T[i][j] = sum_k A[m + i][k] Ainv[k][j], k ascending
+            double sacc = 0;
+            for (int k = 0; k < 15; ++k) sacc += sArow[k] * sA[k * 15 + tid];
+            sT[tid] = sacc;
+            Twork[i * 15 + tid] = sacc;
+        }
+        __syncthreads();
+        int bad = 0;
+        for (int j = tid; j <= i; j += 128) {
+            double sacc = A[(size_t)(m + i) * pos + m + j];
+            for (int k = 0; k < 15; ++k) sacc -= sT[k] * A[(size_t)k * pos + m + j];
+            Lwork[(size_t)i * n + j] = sacc;
+            if (j == i) tol[i] = fmax(1e-8, 1e-9 * sacc);
+            else {
+                const int bi = i < 15 ? 0 : 1 + (i - 15) / 6, bj = j < 15 ? 0 : 1 + (j - 15) / 6;
+                if (bi != bj && sacc != 0.0) bad = 1;
+            }
+        }
+        if (bad) atomicOr(viol, 1);
+    } else {
+        // bs[j] = b[m + j] - sum_k T[j][k] b[k]: T of row j recomputed here (this workgroup does not wait for the others)
+        for (int j = tid; j < n; j += 128) {
+            double sacc = b[m + j];
+            for (int k = 0; k < 15; ++k) {
+                double tj = 0;
+                for (int l = 0; l < 15; ++l) tj += A[(size_t)(m + j) * pos + l] * sA[l * 15 + k];
+                sacc -= tj * b[k];
+            }
+            Lwork[(size_t)n * n + j] = sacc;
+        }
+    }
+}
+__global__ __launch_bounds__(TR_THREADS) void k_marg_root(const int n, double* Lwork, const double* __restrict__ tol, const int* __restrict__ viol, double* J0, double* r0, int* ok) {
+    const int tid = threadIdx.x;
+    double* Bp = reinterpret_cast<double*>(tr_lds);
+    double* part = Bp + TR_NB * bp_stride(n);
+    double* sD = part + 16 * 256;
+    double* ylds = sD + (TR_NB + 1) * TR_PS;
+    double* red = ylds + n + (n & 1);
+    int* flag = reinterpret_cast<int*>(red + 32);
+    for (int j = tid; j < n; j += TR_THREADS) ylds[j] = tol[j];
+    const bool bdiag = (n >= 15 && (n - 15) % 6 == 0) && *viol == 0;
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    bool good;
+    if (bdiag) {
+        const int lane = tid & 63, wv = tid >> 6, nblk = 1 + (n - 15) / 6;
+        for (int bI = wv; bI < nblk; bI += TR_WAVES) {
+            const int o = bI == 0 ? 0 : 15 + 6 * (bI - 1), bs = bI == 0 ? 15 : 6;
+            const bool isrow = lane < bs, isrhs = lane == TR_NB;
+            double a[TR_NB];
+#pragma unroll
+            for (int j = 0; j < TR_NB; ++j) {
+                double v = (lane < TR_NB && lane == j) ? 1.0 : 0.0;
+                if (isrow && j < bs) v = j <= lane ? Lwork[(size_t)(o + lane) * n + o + j] : 0.0;
+                if (isrhs && j < bs) v = Lwork[(size_t)n * n + o + j];
+                a[j] = v;
+            }
+            const double tolv = isrow ? ylds[o + lane] : 0.0;
+            bool bad = false;
+#pragma unroll
+            for (int j = 0; j < TR_NB; ++j) {
+                double djj = readlane_d(a[j], j);
+                const bool null_pivot = j < bs && djj <= readlane_d(tolv, j);
+                if (!null_pivot && (!(djj > 0.0) || !isfinite(djj))) { bad = true; djj = 1.0; }
+                const double rd = null_pivot ? 0.0 : rsqrt(djj);
+                const double lij = (lane == j) ? djj * rd : a[j] * rd;
+                a[j] = lij;
+#pragma unroll
+                for (int c2 = j + 1; c2 < TR_NB; ++c2) a[c2] -= lij * readlane_d(lij, c2);
+            }
+            // J0 = L^T and r0 straight from the registers: J0[j][o + lane] = L[o + lane][j] (the rest of J0 is zero: written below)
+            if (isrow) {
+#pragma unroll
+                for (int j = 0; j < TR_NB; ++j) if (j < bs && j <= lane) Lwork[(size_t)(o + lane) * n + o + j] = a[j];
+            } else if (isrhs) {
+#pragma unroll
+                for (int j = 0; j < TR_NB; ++j) if (j < bs) Lwork[(size_t)n * n + o + j] = a[j];
+            }
+            if (bad && lane == 0) *flag = 1 + o;
+        }
+        __threadfence_block();
+        __syncthreads();
+        good = *flag == 0;
+    } else {
+        good = chol_left_looking<true>(Lwork, n, Bp, part, sD, flag, 0, ylds);
+    }
+    if (good) {
+        for (int i = tid >> 6; i < n; i += TR_WAVES)
+            for (int j = tid & 63; j < n; j += 64) J0[(size_t)i * n + j] = (j >= i) ? Lwork[(size_t)j * n + i] : 0.0;
+        for (int j = tid; j < n; j += TR_THREADS) r0[j] = Lwork[(size_t)n * n + j];
+    }
+    if (tid == 0) *ok = good ? 1 : 0;
+}
+
 // marginalization ordering: [T0 Q0 SB0 | T1 Q1 SB1 | T2 Q2 | ... ] -> index in the window state vector (15 per slot)
 __device__ __forceinline__ int marg_state_index(int mi) { return mi < 30 ? mi : 15 * (2 + (mi - 30) / 6) + (mi - 30) % 6; }
 
@@ -3928,6 +4112,17 @@ int glio_launch_marginalize(glio_ctx* c, int imu_edge0, double** J0_dev, double*
     hipLaunchKernelGGL(k_marg_assemble, dim3(pos + 1), dim3(256), 0, c->stream, a);
     int* d_ok = reinterpret_cast<int*>(c->d_vec + 9 * (size_t)c->n_max);
     double* Twork = c->d_vec;                    // n x 15 <= 10 n_max doubles? n*15 <= 15W*... checked by the caller
+    static const bool split = !(getenv("GLIO_MARG_SPLIT") && atoi(getenv("GLIO_MARG_SPLIT")) == 0);      // (0: the one-workgroup form, for A/B and tests)
+    // scratch of the split form: Ainv (225), the tolerances (n), the pattern flag -- behind the (n + 1) x n work matrix in d_L, when it fits there
+    const size_t lwork = (size_t)(n + 1) * n + 2, need = 226 + (size_t)n + 2, have = (size_t)(c->n_max + 1) * c->n_max;
+    if (split && lwork + need <= have) {
+        double* Ainv = c->d_L + ((lwork + 1) & ~(size_t)1);
+        double* tol = Ainv + 226;
+        int* viol = reinterpret_cast<int*>(tol + n + 1);
+        hipLaunchKernelGGL(k_marg_inv, dim3(1), dim3(TR_THREADS), 16 * 1024, c->stream, c->d_H[0], n, Ainv, viol);
+        hipLaunchKernelGGL(k_marg_rows, dim3(n + 1), dim3(128), 0, c->stream, c->d_H[0], c->d_g[0], n, Ainv, Twork, c->d_L, tol, viol);
+        hipLaunchKernelGGL(k_marg_root, dim3(1), dim3(TR_THREADS), glio_tr_step_lds_bytes(n), c->stream, n, c->d_L, tol, viol, c->d_H[1], c->d_g[1], d_ok);
+    } else
     hipLaunchKernelGGL(k_marg_schur, dim3(1), dim3(TR_THREADS), glio_tr_step_lds_bytes(n), c->stream, c->d_H[0], c->d_g[0], n, c->d_L, Twork,
                        c->d_H[1], c->d_g[1], d_ok);
     *J0_dev = c->d_H[1]; *r0_dev = c->d_g[1]; *ok_dev = d_ok;
@@ -3972,6 +4167,7 @@ int glio_tr_step_configure(size_t max_lds) {
     TR_CONF_(k_tr_finish, max_lds);
     TR_CONF_(k_chol_test, max_lds);
     TR_CONF_(k_marg_schur, max_lds);
+    TR_CONF_(k_marg_root, max_lds);
     TR_CONF_(k_arrow_forward, max_lds);
     TR_CONF_(k_arrow_solve, max_lds);
     TR_CONF_(k_chain_solve<false>, max_lds - 1024);

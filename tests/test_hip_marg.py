@@ -189,3 +189,21 @@ def test_marginalize_then_band_only_solve_with_dense_fallback(hip):
     assert m1.iterations == m0.iterations
     assert m2.iterations == m0.iterations and m2.termination == m0.termination
     assert np.abs(s2.trans - s0.trans).max() <= 1e-9 and np.abs(s2.quat - s0.quat).max() <= 1e-10
+
+
+def test_three_launch_marginalization_equals_the_one_workgroup_form():
+    """Round 6 splits k_marg_schur (everything in one workgroup over global-memory matrices: 90 us for n = 123) into k_marg_inv / k_marg_rows (n + 1
+    workgroups) / k_marg_root: the same sums in the same order -- the prior is the same bit for bit, for a first window (rank-deficient Amm: Jacobi
+    eigen-decomposition) and a steady-state window (fast inverse), at W = 20 and at W = 3 (smallest scratch)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for W in ("20", "3"):
+        rows = []
+        for split in ("1", "0"):
+            env = dict(os.environ, GLIO_MARG_SPLIT=split, MS_W=W, MS_PTS="2048")
+            out = subprocess.run([sys.executable, os.path.join(root, "scripts", "marg_split_ab.py")], env=env, capture_output=True, text=True, timeout=300)
+            rows.append(json.loads(next(ln for ln in out.stdout.splitlines() if ln.startswith("{"))))
+        assert rows[0]["first_window"] == rows[1]["first_window"] and rows[0]["steady_window"] == rows[1]["steady_window"], rows
