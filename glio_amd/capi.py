@@ -13,7 +13,7 @@ _LIB = None
 LIB_PATH = os.environ.get("GLIO_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libglio_hip.so")
 
 (KERNEL_LIDAR_LINEARIZE, KERNEL_FULL_LINEARIZE, KERNEL_TR_STEP, KERNEL_ASSOCIATE, KERNEL_MAP_BUILD, KERNEL_MARGINALIZE, KERNEL_STREAM_READ,
- KERNEL_LINEARIZE_ALL) = range(8)
+ KERNEL_LINEARIZE_ALL, KERNEL_TR_STEP_STEADY) = range(9)
 LIDAR_F64, LIDAR_F32_MFMA = 0, 1
 
 

@@ -208,6 +208,7 @@ static int create_body(int device, const glio_opts* opts, glio_ctx* c) {
         ALLOC(ar.d_blk, (size_t)W * 544 * 8); ALLOC(ar.d_Lblk, (size_t)W * 190 * 8); ALLOC(ar.d_Sp, (size_t)(6 * W + 1) * 6 * W * 8);
         ALLOC(ar.d_z, (size_t)n_max * 8); ALLOC(ar.d_flag, 4); ALLOC(ar.d_dbg, 320 * 8);
         ALLOC(ar.d_chain_sum, (size_t)W * GLIO_CS_STRIDE * 8); ALLOC(ar.d_chain_done, (size_t)W * 4); ar.chain_seq = 1;
+        ALLOC(ar.d_fat_ep, (size_t)ne * 34 * 8);
         GLIO_HIP_CHECK(hipMemsetAsync(ar.d_chain_done, 0, (size_t)W * 4, c->stream));
         GLIO_HIP_CHECK(hipMemsetAsync(ar.d_flag, 0, 4, c->stream));
         GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -252,7 +253,7 @@ void glio_destroy(glio_ctx* c) {
                     c->d_prior_kind, c->d_prior_idx, c->d_prior_index, c->d_prior_H, c->d_prior_g, c->d_prior_cost, c->d_prior_work,
                     /* d_x[0] lives inside d_status' allocation */ c->d_x[1], c->d_H[0], c->d_H[1], c->d_g[0], c->d_g[1], c->d_cost[0], c->d_cost[1], c->d_xout,
                     c->d_lidar_partials, c->d_hdiag[0], c->d_hdiag[1], c->d_chain_tabs, c->d_chain_src, c->d_lidar_blocks, c->d_L, c->d_vec, c->d_status,
-                    c->arrow.d_ep_slots, c->arrow.d_ep_off, c->arrow.d_ep_list, c->arrow.d_Y, c->arrow.d_blk, c->arrow.d_Lblk, c->arrow.d_Sp, c->arrow.d_z, c->arrow.d_flag, c->arrow.d_dbg, c->arrow.d_chain_sum, c->arrow.d_chain_done};
+                    c->arrow.d_ep_slots, c->arrow.d_ep_off, c->arrow.d_ep_list, c->arrow.d_Y, c->arrow.d_blk, c->arrow.d_Lblk, c->arrow.d_Sp, c->arrow.d_z, c->arrow.d_flag, c->arrow.d_dbg, c->arrow.d_chain_sum, c->arrow.d_chain_done, c->arrow.d_fat_ep};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_status) hipHostFree(c->h_status); /* h_xbuf lives inside it */
     if (c->h_progress) hipHostFree((void*)c->h_progress);
@@ -1322,6 +1323,16 @@ int glio_time_kernel(glio_ctx* c, int which, int reps, float* ms_out) {
                 SolverStatus st;
                 memset(&st, 0, sizeof st);
                 st.cur = 1; st.cand_pending = 1; st.radius = c->opts.initial_trust_region_radius; st.mu = 1e-8; st.n_ddt = n_ddt;
+                *c->h_status = st;
+                GLIO_HIP_CHECK(hipMemcpyAsync(c->d_status, c->h_status, sizeof st, hipMemcpyHostToDevice, c->stream));
+                glio_launch_tr_step(c, n_ddt);
+            } else if (which == GLIO_KERNEL_TR_STEP_STEADY) {
+                // a later step: the candidate in buffer 0 is pending and will be ACCEPTED (a cost far above it, a positive model change), the Jacobi scale of the
+                // last solve is in place, mu at its floor -- the step the helpers' speculative build applies to
+                SolverStatus st;
+                memset(&st, 0, sizeof st);
+                st.cur = 1; st.cand_pending = 1; st.phase = 1; st.iteration = 1; st.radius = c->opts.initial_trust_region_radius; st.mu = 1e-8; st.n_ddt = n_ddt;
+                st.cost = 1e30; st.initial_cost = 1e30; st.model_cost_change = 1.0; st.dogleg_step_norm = 1.0;
                 *c->h_status = st;
                 GLIO_HIP_CHECK(hipMemcpyAsync(c->d_status, c->h_status, sizeof st, hipMemcpyHostToDevice, c->stream));
                 glio_launch_tr_step(c, n_ddt);

@@ -135,6 +135,7 @@ struct ArrowDev {
     double* d_chain_sum;      // [W][GLIO_CS_STRIDE] k_chain_step's helper workgroups: the candidate's block entries summed over their six sources
     int* d_chain_done;        // [W] their completion words: 2 * sequence number + (produced ? 1 : 0)
     int chain_seq;            // sequence number of the next k_chain_step launch (kernel argument)
+    double* d_fat_ep;         // [n_ddt_max][34] the fat helpers' epoch products (eliminated column V, 1 / sqrt(m), y, t); their blocks go to d_blk
     long long* d_dbg;         // [64] wall-clock stamps of the last launch (100 MHz), development aid
 };
 

@@ -507,9 +507,10 @@ struct PrepMirror {
     const double* hd; const double* g; const double* cost;     // diag(H), g, cost of the candidate
     double* scale; double* diag; double* grad;                 // scale: the global vector on entry (phase > 0); all three are left filled for the caller
     long long* dbg;                                            // stamped builds: device-clock marks of the state machine's sections (slots 80..)
-    // k_chain_step's helper workgroups read the status record this function rewrites at its end: their completion words (2 * hseq + produced) are
+    // k_chain_step's helper workgroups read the status record this function rewrites at its end: their completion words (4 * hseq + 2 * fat + produced) are
     // requested at entry and checked before that store; *hprod is cleared when one of them had nothing to produce
     const int* hdone; int hseq; int helpers; int* hprod; int hpolls;
+    int* hfat;                                                 // cleared when a helper did not deliver the fat products (bit 1 of its word)
 };
 #ifdef GLIO_DEV_STAMPS
 #define PM_STAMP(k) do { if (FAST && m->dbg && threadIdx.x == 0) m->dbg[k] = wall_clock64(); } while (0)
@@ -693,8 +694,9 @@ __device__ __forceinline__ bool tr_prepare_body(const TrArgs& a, TrDecision* out
         // partitions, a co-tenant) a helper may not even have started.  After hpolls polls the step stops waiting and sums the blocks itself (*hprod = 0);
         // a helper that starts late reads the rewritten record, leaves sums nobody reads and ends -- the next launch cannot start before it has.
         int polls = 0;
-        while ((hword >> 1) != m->hseq && polls < m->hpolls) { ++polls; __builtin_amdgcn_s_sleep(1); hword = __hip_atomic_load(&m->hdone[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-        if ((hword >> 1) != m->hseq || !(hword & 1)) *m->hprod = 0;
+        while ((hword >> 2) != m->hseq && polls < m->hpolls) { ++polls; __builtin_amdgcn_s_sleep(1); hword = __hip_atomic_load(&m->hdone[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        if ((hword >> 2) != m->hseq || !(hword & 1)) *m->hprod = 0;
+        if ((hword >> 2) != m->hseq || !(hword & 2)) *m->hfat = 0;
     }
     PB_SYNC();
     PM_STAMP(86);
@@ -2021,7 +2023,7 @@ __device__ __forceinline__ void chain_epoch_corrections_mfma(const int W, const 
         for (int u = 0; u < NK; ++u) {
             ii[u] = i0 + u * nwaves;
             const bool act = ii[u] < W;
-            ii[u] = act ? ii[u] : 0;
+            ii[u] = act ? ii[u] : i0;               // (an inactive one aliases the first: nothing of it is stored, every address stays inside the caller's blocks)
             t0[u] = eoff[ii[u]]; t1[u] = act ? eoff[ii[u] + 1] : t0[u];
             two = two && (t1[u] - t0[u] <= 8);
         }
@@ -2097,6 +2099,11 @@ __device__ __forceinline__ void chain_epoch_corrections_mfma(const int W, const 
 #undef EC_STAMP
 }
 
+// dynamic LDS a fat helper carves (chain_step_fat_helper), in bytes: the launch's grant must cover it
+__host__ __device__ __forceinline__ size_t chain_fat_helper_lds_bytes(int W, int nd) {
+    return (size_t)(352 * 2 + 84 + 48 * 6 + 2 * KC_BLK + 16 * KC_RS + (size_t)nd * 30 + 4 * (nd + 2) + (size_t)nd * 15 + (nd & 1) + 3 * (nd + 2) + 16) * 8 +
+           (size_t)(nd + 2) * 8 + (size_t)(((W + 2) & ~1) + 2 + 2 * nd + 2 + 24) * 4 + 80 * 2 + 64;
+}
 struct ChainArgs {
     int W, n, nd;
     const int2* ep_slots; const int* ep_off; const int* ep_list;
@@ -2109,9 +2116,16 @@ struct ChainArgs {
     int fronts4;              // 1 = separator + four fronts (chain_f4_split), 0 = two fronts
     double* blk;              // k_chain_solve<true>: [W][KC_BLK] the staged blocks in global memory (windows whose blocks do not fit the LDS)
     // k_chain_step's helper workgroups (grid = 1 + helpers): workgroup 1 + i sums the candidate's block entries of keyframe i over their six sources
-    // while workgroup 0 runs the front and the state machine; hsum [W][GLIO_CS_STRIDE], hdone [W] = 2 * hseq + produced
+    // while workgroup 0 runs the front and the state machine; hsum [W][GLIO_CS_STRIDE], hdone [W] = 4 * hseq + 2 * fat + produced
     int helpers; int hseq; double* hsum; int* hdone; int hpolls;      // hpolls: how often workgroup 0 polls a completion word before it gives the helpers up
+    // "fat" helpers (round 6): helper i also forms, ASSUMING the pending candidate is accepted, everything of keyframe i that the step builds between its
+    // state machine and the chain -- the scaled, regularised and epoch-corrected block, its right-hand side row, its rows of t = H u, and for the
+    // clock-drift epochs whose first keyframe is i the eliminated column V, 1 / sqrt(m), y and t.  Workgroup 0 checks the assumptions (accepted, the mu
+    // an acceptance leaves, every helper delivered) and then only LOADS: fat_blk [W][KC_BLK] (360 entries + 15 rows of t used), fat_ep [nd][34].
+    int fat; double* fat_blk; double* fat_ep;
 };
+#define KC_FAT_ENT 360                 /* per keyframe: 345 chain-layout entries + 15 right-hand side entries; the 15 rows of t follow at 360 */
+#define KC_FAT_EP 34                   /* per epoch: V (30), 1 / sqrt(m), y, t, pad */
 
 // The kernel also does the work of k_tr_prepare (state machine, scaling vectors) and of k_tr_scale for this structure: it
 // reads H and g directly, forms M = S H S + mu D^2 and the right-hand side S g while staging them (same arithmetic, same
@@ -2645,7 +2659,7 @@ struct ChainBuilder {
 // while workgroup 0 gathers diag / g / cost and runs the state machine; it then reads 55 KB of sums.  Every entry is the same sum in the same
 // order as gather_store forms it (LiDAR partial sum first, then the five slices), so the step stays bit-identical.  (Measured: all helpers on
 // workgroup 0's XCD -- grid 1 + 8 W, seven of eight workgroups idle -- read back no faster and delayed the front by 12 us.)  The helper ALWAYS reports
-// (2 * hseq + produced): workgroup 0 waits for all of them before its state machine rewrites the status record they read.
+// (4 * hseq + 2 * fat + produced): workgroup 0 waits for all of them before its state machine rewrites the status record they read.
 __device__ __forceinline__ void chain_step_helper(const ChainArgs& a, const TrArgs& tr, const GatherArgs& G, const int i) {
     __shared__ double h_lid[GLIO_LIDAR_ACC];
     __shared__ int h_go, h_cand;
@@ -2691,15 +2705,330 @@ __device__ __forceinline__ void chain_step_helper(const ChainArgs& a, const TrAr
             a.hsum[(size_t)i * GLIO_CS_STRIDE + tid] = h;
         }
     }
-    __threadfence();                                   // (agent scope: the sums leave this XCD's L2 before the completion word does)
+    __syncthreads();                                   // (one agent-scope release, by the store below: see chain_step_fat_helper)
+    if (tid == 0) __hip_atomic_store(&a.hdone[i], 4 * a.hseq + go, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The FAT helper of keyframe i (ChainArgs::fat): besides the sums of chain_step_helper it forms what workgroup 0 would build from them between its state
+// machine and the chain -- under the assumption that the pending candidate is ACCEPTED (then the current point is the candidate and, with the dogleg
+// strategy, mu becomes max(1e-8, mu / 5): DoglegStrategy::StepAccepted).  Every quantity is the SAME expression on the same operands in the same order as in
+// workgroup 0's own phases (work_vectors of the state machine; "round 1", the epoch columns, the block store, t = H u and the epoch corrections of
+// k_chain_step), restricted to keyframe i -- so the step's numbers do not depend on who formed them.  It needs keyframes i - 1 and i + 1 as far as they
+// enter: their scale / diagonal / gradient rows (u of the neighbours), the coupling block B_{i-1}, the clock-drift epochs that touch keyframe i.
+// Everything lives in this workgroup's own dynamic LDS.  Not taken (fat = 0 in the completion word, workgroup 0 builds as before): first step of a solve
+// (no scale yet), Levenberg-Marquardt (mu follows the radius), an epoch without keyframes, a non-positive epoch pivot.
+__device__ __forceinline__ void chain_step_fat_helper(const ChainArgs& a, const TrArgs& tr, const GatherArgs& G, const int i) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, W = a.W, nd = a.nd, np15 = 15 * W;
+#ifdef GLIO_DEV_STAMPS
+#define FH_STAMP(k) do { if (a.dbg && i == W / 2 && tid == 0) a.dbg[304 + (k)] = wall_clock64(); } while (0)
+#else
+#define FH_STAMP(k) do { } while (0)
+#endif
+    double* L = reinterpret_cast<double*>(tr_lds);
+    double* f_h = L;                       // [352] block entries of keyframe i summed over their six sources (= hsum)
+    double* f_hp = f_h + 352;              // [352] the same of keyframe i - 1
+    double* f_lid = f_hp + 352;            // [3][28] K3 partial sums of keyframes i - 1, i, i + 1
+    double* f_S = f_lid + 84;              // [3][16] Jacobi scale of their rows
+    double* f_D = f_S + 48;                // D = sqrt(clamp(S^2 H_rr))
+    double* f_gr = f_D + 48;               // g~ = S g / D
+    double* f_G = f_gr + 48;               // g
+    double* f_zb = f_G + 48;               // u / S with u = S g~ / D
+    double* f_hd = f_zb + 48;              // H_rr
+    double* f_blk = f_hd + 48;             // [KC_BLK] the block of keyframe i as the chain takes it
+    double* f_blk2 = f_blk + KC_BLK;       // the same before the epochs' corrections: what t = H u is formed from, while wavefront 0 corrects f_blk
+    double* f_bp = f_blk2 + KC_BLK;        // [15][KC_RS] rows 15..29 of block i - 1 (B_{i-1})
+    double* f_Vs = f_bp + 16 * KC_RS;      // [nd][30]
+    double* f_rd = f_Vs + (size_t)nd * 30; // [nd] each: 1 / sqrt(m), y, u / S, (u / S) sqrt(m), scale, D, g~ of the epoch unknowns
+    double* f_yd = f_rd + nd + 2;
+    double* f_wd = f_yd + nd + 2;
+    double* f_wdr = f_wd + nd + 2;
+    double* f_dds = f_wdr + nd + 2;        // [nd][15] clock-drift blocks (only the epochs touching keyframe i are filled)
+    double* f_Se = f_dds + (size_t)nd * 15 + (nd & 1);
+    double* f_De = f_Se + nd + 2;
+    double* f_gre = f_De + nd + 2;
+    double* f_t = f_gre + nd + 2;          // [16] rows of t of keyframe i
+    int2* f_eps = reinterpret_cast<int2*>(f_t + 16);
+    int* f_eoff = reinterpret_cast<int*>(f_eps + nd + 2);
+    int* f_elist = f_eoff + ((W + 2) & ~1) + 2;
+    int* f_misc = f_elist + 2 * nd + 2;    // [0] failure, [1] rows with an epoch coupling, [2..] their indices, [20] row mask
+    short* f_tab = reinterpret_cast<short*>(f_misc + 24);     // ChainKf of i - 1, i, i + 1 (24 shorts), then pidx of their 45 rows
+    __shared__ int h_go, h_cand, h_fat, h_ph0;
+    __shared__ double h_mu;
+    const short* gtab = G.tabs;
+    if (tid == 0) {
+        const SolverStatus st = *tr.status;
+        h_go = (!st.done && st.cand_pending) ? 1 : 0;
+        h_cand = 1 - st.cur;
+        h_fat = (h_go && !tr.lm && (a.fast & 3) == 3) ? 1 : 0;
+        h_ph0 = st.phase == 0 ? 1 : 0;
+        // mu as the state machine will leave it: the first step of a solve keeps the record's (and takes the point whatever it is, forming the Jacobi
+        // scale from its diagonal); a later one is assumed accepted: DoglegStrategy::StepAccepted, tr_prepare_body
+        h_mu = st.phase == 0 ? st.mu : fmax(1e-8, 2.0 * st.mu / 10.0);
+    }
+    // the structure tables travel with the status: descriptors of the three keyframes, the prior index of their rows, the epoch tables
+    if (tid < 24) { const int k = tid >> 3, kk = i - 1 + k; f_tab[tid] = (kk >= 0 && kk < W) ? gtab[8 * kk + (tid & 7)] : (short)-1; }
+    if (tid >= 64 && tid < 64 + 45) { const int q = tid - 64, k = q / 15, kk = i - 1 + k; f_tab[24 + q] = (kk >= 0 && kk < W) ? gtab[8 * W + 15 * kk + (q - 15 * k)] : (short)-1; }
+    for (int e = tid; e < nd; e += KC_THREADS) f_eps[e] = a.ep_slots[e];
+    for (int k = tid; k <= W; k += KC_THREADS) f_eoff[k] = a.ep_off[k];
+    for (int t = tid; t < 2 * nd; t += KC_THREADS) f_elist[t] = a.ep_list[t];
+    if (tid < 24) f_misc[tid] = 0;
+    for (int k = tid; k < 2 * KC_BLK; k += KC_THREADS) f_blk[k] = 0.0;       // the block and its copy for t = H u (f_blk2): zero above the diagonal, pivots row unused
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(&a.hdone[i], 2 * a.hseq + go, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    FH_STAMP(1);
+    const int go = h_go, cand = h_cand;
+    bool fat = h_fat != 0;
+    const bool ph0 = h_ph0 != 0;
+    const double mu = h_mu;
+    if (go) {
+        // ---- one round of loads: K3 partials of three keyframes, the slices of keyframes i and i - 1, the diagonal slices of i + 1, gradients, scale, epochs
+        const int lnb = G.lidar_nb;
+        double lsum = 0;
+        if (tid < 84) {
+            const int k = tid / GLIO_LIDAR_ACC, kk = i - 1 + k, ent = tid - GLIO_LIDAR_ACC * k;
+            if (kk >= 0 && kk < W) {
+                const double* p = G.lidar_partials + (size_t)cand * G.lidar_pstride + (size_t)kk * lnb * GLIO_LIDAR_ACC + ent;
+                for (int k0 = 0; k0 < lnb; k0 += 24) {
+                    double vb[24];
+#pragma unroll
+                    for (int q = 0; q < 24; ++q) vb[q] = p[(size_t)(k0 + q < lnb ? k0 + q : k0) * GLIO_LIDAR_ACC];
+#pragma unroll
+                    for (int q = 0; q < 24; ++q) lsum += k0 + q < lnb ? vb[q] : 0.0;
+                }
+            }
+        }
+        double v[5], vp[5];
+        int lix = -1;
+        const int w = tid < 345 ? tid : 0;
+        {
+            int r30, j;
+            if (w < 120) { int r = 0; while ((r + 1) * (r + 2) / 2 <= w) ++r; r30 = r; j = w - r * (r + 1) / 2; }
+            else { r30 = 15 + (w - 120) / 15; j = (w - 120) % 15; }
+            lix = (r30 < 6 && j < 6) ? kc_lidar_sym_index(j, r30) : -1;
+            const double* p = G.chain_src + (((size_t)cand * W + i) * GLIO_CS_SOURCES) * GLIO_CS_STRIDE + w;
+            const double* pp = G.chain_src + (((size_t)cand * W + (i > 0 ? i - 1 : 0)) * GLIO_CS_SOURCES) * GLIO_CS_STRIDE + w;
+#pragma unroll
+            for (int sidx = 0; sidx < 5; ++sidx) { v[sidx] = p[sidx * GLIO_CS_STRIDE]; vp[sidx] = pp[sidx * GLIO_CS_STRIDE]; }
+        }
+        // rows of the three keyframes (thread q of the second wavefront pair: 45 rows): scale, gradient parts, the diagonal slices of keyframe i + 1
+        double rs = 0, g5[5] = {0, 0, 0, 0, 0}, dn[5] = {0, 0, 0, 0, 0};
+        int rk = 0, rlc = 0, rkk = -1, rpi = -1;
+        ChainKf rd_; rd_.e0 = rd_.e1 = rd_.k0 = rd_.k1 = rd_.kp = -1; rd_.o0 = rd_.o1 = 0; rd_.pad_ = 0;
+        if (tid >= 384 && tid < 384 + 45) {
+            const int q = tid - 384;
+            rk = q / 15; rlc = q - 15 * rk; rkk = i - 1 + rk;
+            if (rkk >= 0 && rkk < W) {
+                rd_ = reinterpret_cast<const ChainKf*>(f_tab)[rk];
+                rpi = f_tab[24 + q];
+                const PairBlock* imu = G.imu_blocks + (size_t)cand * W;
+                const PairBlock* gnb = G.gnss_blocks + (size_t)cand * G.gnss_stride;
+                rs = V_SCALE(tr)[15 * rkk + rlc];
+                g5[0] = imu[rd_.e0 >= 0 ? rd_.e0 : 0].g[rlc];
+                g5[1] = imu[rd_.e1 >= 0 ? rd_.e1 : 0].g[15 + rlc];
+                g5[2] = gnb[rd_.k0 >= 0 ? rd_.k0 : 0].g[(rd_.o0 ? 0 : 15) + rlc];
+                g5[3] = gnb[rd_.k1 >= 0 ? rd_.k1 : 0].g[(rd_.o1 ? 0 : 15) + rlc];
+                g5[4] = (G.pg + (size_t)cand * G.np)[rpi >= 0 ? rpi : 0];
+                if (rk == 2) {
+                    const double* p = G.chain_src + (((size_t)cand * W + rkk) * GLIO_CS_SOURCES) * GLIO_CS_STRIDE + kc_w(rlc, rlc);
+#pragma unroll
+                    for (int sidx = 0; sidx < 5; ++sidx) dn[sidx] = p[sidx * GLIO_CS_STRIDE];
+                }
+            }
+        }
+        // the epochs that touch keyframe i: their blocks and the scale of their unknown
+        const int t0e = f_eoff[i], t1e = f_eoff[i + 1];
+        const DdtBlock* dd = G.ddt_blocks + (size_t)cand * G.ddt_stride;
+        for (int q = tid; q < (t1e - t0e) * 15; q += KC_THREADS) {
+            const int e = f_elist[t0e + q / 15], c15 = q % 15;
+            f_dds[e * 15 + c15] = reinterpret_cast<const double*>(dd + e)[c15];
+            if (c15 == 0) f_Se[e] = V_SCALE(tr)[np15 + e];
+        }
+        if (tid < 84) f_lid[tid] = lsum;
+        __syncthreads();
+    FH_STAMP(2);
+        // ---- the sums of keyframe i (what chain_step_helper leaves in hsum) and of keyframe i - 1
+        if (tid < 345) {
+            double h = 0;
+            h += lix >= 0 ? f_lid[GLIO_LIDAR_ACC + lix] : 0.0;
+            h += v[0]; h += v[1]; h += v[2]; h += v[3]; h += v[4];
+            f_h[tid] = h;
+            a.hsum[(size_t)i * GLIO_CS_STRIDE + tid] = h;
+            double hp = 0;
+            hp += lix >= 0 ? f_lid[lix] : 0.0;
+            hp += vp[0]; hp += vp[1]; hp += vp[2]; hp += vp[3]; hp += vp[4];
+            f_hp[tid] = hp;
+        }
+        __syncthreads();
+    FH_STAMP(3);
+        if (fat) {
+            // ---- diag(H) and g of the 45 rows (the front of k_chain_step), then the state machine's work vectors and "round 1"
+            if (tid >= 384 && tid < 384 + 45) {
+                const int q = tid - 384;
+                double hv = 0, gg = 0;
+                if (rkk >= 0 && rkk < W) {
+                    const bool lidp = rlc < 6;
+                    if (rk == 2) {
+                        double sacc = 0;
+                        sacc += lidp ? f_lid[2 * GLIO_LIDAR_ACC + kc_lidar_sym_index(lidp ? rlc : 0, lidp ? rlc : 0)] : 0.0;
+                        sacc += dn[0]; sacc += dn[1]; sacc += dn[2]; sacc += dn[3]; sacc += dn[4];
+                        hv = sacc;
+                    } else hv = (rk == 1 ? f_h : f_hp)[kc_w(rlc, rlc)];
+                    const double vl = f_lid[rk * GLIO_LIDAR_ACC + 21 + (lidp ? rlc : 0)];
+                    double gacc = 0;
+                    gacc += lidp ? vl : 0.0;
+                    gacc += rd_.e0 >= 0 ? g5[0] : 0.0;
+                    gacc += rd_.e1 >= 0 ? g5[1] : 0.0;
+                    gacc += rd_.k0 >= 0 ? g5[2] : 0.0;
+                    gacc += rd_.k1 >= 0 ? g5[3] : 0.0;
+                    gacc += rpi >= 0 ? g5[4] : 0.0;
+                    gg = gacc;
+                    if (ph0) rs = tr.jacobi_scaling ? 1.0 / (1.0 + sqrt(hv)) : 1.0;          // (the first step forms the scale: tr_prepare_body, phase 0)
+                    double d = rs * rs * hv;
+                    d = d < 1e-6 ? 1e-6 : (d > 1e32 ? 1e32 : d);
+                    const double dd_ = sqrt(d);
+                    const double gs = rs * gg;
+                    const double grd = gs / dd_;
+                    f_S[16 * rk + rlc] = rs; f_D[16 * rk + rlc] = dd_; f_gr[16 * rk + rlc] = grd; f_G[16 * rk + rlc] = gg; f_hd[16 * rk + rlc] = hv;
+                    f_zb[16 * rk + rlc] = (rs * grd / dd_) / rs;
+                } else { f_S[16 * rk + rlc] = 0.0; f_D[16 * rk + rlc] = 1.0; f_gr[16 * rk + rlc] = 0.0; f_G[16 * rk + rlc] = 0.0; f_hd[16 * rk + rlc] = 0.0; f_zb[16 * rk + rlc] = 0.0; }
+                (void)q;
+            }
+            // the epoch unknowns: work vectors, then epoch_scalars
+            for (int t = t0e + tid; t < t1e; t += KC_THREADS) {
+                const int e = f_elist[t];
+                const double he = f_dds[e * 15 + 12], ge = f_dds[e * 15 + 13];
+                const double se = ph0 ? (tr.jacobi_scaling ? 1.0 / (1.0 + sqrt(he)) : 1.0) : f_Se[e];
+                f_Se[e] = se;
+                double d = se * se * he;
+                d = d < 1e-6 ? 1e-6 : (d > 1e32 ? 1e32 : d);
+                const double de = sqrt(d);
+                const double gs = se * ge;
+                const double grd = gs / de;
+                f_De[e] = de; f_gre[e] = grd;
+                const double we = (se * grd / de) / se;
+                f_wd[e] = we;
+                const double m = se * he * se + mu * de * de;
+                double re;
+                if (!(m > 0.0) || !isfinite(m)) { f_misc[0] = 1; re = 0.0; } else re = rsqrt(m);
+                f_rd[e] = re;
+                f_wdr[e] = (1.0 / re) * we;
+                f_yd[e] = (se * ge) * re;
+                if (f_eps[e].x < 0) f_misc[0] = 1;
+            }
+            if (i == 0) for (int e = tid; e < nd; e += KC_THREADS) if (f_eps[e].x < 0 || f_eps[e].y != f_eps[e].x + 1) f_misc[0] = 1;      // (an epoch nobody owns)
+            __syncthreads();
+    FH_STAMP(4);
+            // ---- the epoch columns V = S c S / sqrt(m) of the epochs touching keyframe i (all 30 rows: the neighbour's rows feed B)
+            for (int it = tid; it < (t1e - t0e) * 30; it += KC_THREADS) {
+                const int e = f_elist[t0e + it / 30], q = it % 30;
+                const int lc = q < 15 ? q : q - 15;
+                const int k12 = kc_dop_local12(q >= 15, lc);
+                const int2 sl = f_eps[e];
+                const int used = reinterpret_cast<const int*>(f_dds + e * 15 + 14)[1];
+                const int s1 = q >= 15 ? sl.y : sl.x;
+                const bool ok = (used != 0) & (s1 >= 0) & (k12 >= 0);
+                const int kx = s1 - (i - 1);                                    // which of the three keyframes the row belongs to
+                const double sr = (kx >= 0 && kx < 3) ? f_S[16 * kx + lc] : 0.0;
+                const double cv = f_dds[e * 15 + (k12 >= 0 ? k12 : 0)];
+                const double vv = ok ? sr * cv * f_Se[e] : 0.0;
+                f_Vs[e * 30 + q] = vv * f_rd[e];
+            }
+            // ---- the block of keyframe i: S H S + mu D^2, zeros above the diagonal of D_i, the right-hand side row; rows 15..29 of block i - 1
+            // (independent of the epoch columns above: no barrier between the two)
+            if (tid < 345) {
+                int r30, j;
+                if (tid < 120) { int r = 0; while ((r + 1) * (r + 2) / 2 <= tid) ++r; r30 = r; j = tid - r * (r + 1) / 2; }
+                else { r30 = 15 + (tid - 120) / 15; j = (tid - 120) % 15; }
+                const bool live = r30 < 15 || i + 1 < W;
+                const double srow = r30 < 15 ? f_S[16 + r30] : f_S[32 + r30 - 15];
+                double wv_ = (live ? srow : 0.0) * f_h[tid] * f_S[16 + j];
+                wv_ += (r30 == j) ? mu * f_D[16 + r30] * f_D[16 + r30] : 0.0;
+                f_blk[r30 * KC_RS + j] = live ? wv_ : 0.0;
+                f_blk2[r30 * KC_RS + j] = live ? wv_ : 0.0;
+                if (tid >= 120 && i > 0) {                 // B_{i-1}: rows of keyframe i, columns of keyframe i - 1
+                    const int r = r30 - 15;
+                    double wp = f_S[16 + r] * f_hp[tid] * f_S[j];
+                    f_bp[r * KC_RS + j] = wp;
+                }
+            }
+            if (tid >= 448 && tid < 448 + 15) { const int j = tid - 448; f_blk[30 * KC_RS + j] = f_S[16 + j] * f_G[16 + j]; }
+            // the rows that can carry an epoch coupling are the position and velocity rows (kc_dop_local12): the corrections run over that fixed set -- a row
+            // whose V is zero for every epoch of this keyframe receives a sum of zeros, as in workgroup 0's data-derived set
+            if (tid == 0) { const int rows6[6] = {0, 1, 2, 6, 7, 8}; for (int q = 0; q < 6; ++q) f_misc[2 + q] = rows6[q]; f_misc[1] = 6; }
+            __syncthreads();
+    FH_STAMP(5);
+            // ---- three things at once: wavefront 0 takes the epochs' contribution off f_blk (matrix core, as in workgroup 0); wavefront 1 forms the rows of
+            // t = H u of keyframe i from the uncorrected copy; wavefront 2 the rows of t of the epochs whose first keyframe is i
+            if (wv == 0 && t1e > t0e) chain_epoch_corrections_mfma(W, f_misc[1], f_misc + 2, f_eoff, f_elist, f_eps, f_Vs, f_yd, f_blk - (size_t)i * KC_BLK, lane, i, W);
+            if (tid >= 64 && tid < 64 + 15) {
+                const int r = tid - 64;
+                double acc = 0.0;
+                const double s_row = f_S[16 + r], d_row = f_D[16 + r];
+#pragma unroll
+                for (int j = 0; j < KC_NB; ++j) {
+                    double vv = j <= r ? f_blk2[r * KC_RS + j] : f_blk2[j * KC_RS + r];
+                    if (j == r) vv -= mu * d_row * d_row;
+                    acc += vv * f_zb[16 + j];
+                }
+                if (i + 1 < W) {
+#pragma unroll
+                    for (int j = 0; j < KC_NB; ++j) acc += f_blk2[(KC_NB + j) * KC_RS + r] * f_zb[32 + j];
+                }
+                if (i > 0) {
+#pragma unroll
+                    for (int j = 0; j < KC_NB; ++j) acc += f_bp[r * KC_RS + j] * f_zb[j];
+                }
+                for (int t = t0e; t < t1e; ++t) {
+                    const int e = f_elist[t];
+                    const int sd = f_eps[e].x == i ? 0 : 15;
+                    acc = acc + f_Vs[e * 30 + sd + r] * f_wdr[e];
+                }
+                f_t[r] = acc / s_row;
+            }
+            if (tid >= 128 && tid < 128 + (t1e - t0e)) {
+                const int e = f_elist[t0e + tid - 128];
+                const int2 sl = f_eps[e];
+                if (sl.x == i) {
+                    const double se = f_Se[e];
+                    double acc = se * f_dds[e * 15 + 12] * se * f_wd[e];
+                    const double ire = 1.0 / f_rd[e];
+#pragma unroll
+                    for (int q = 0; q < 30; ++q) acc += (f_Vs[e * 30 + q] * ire) * f_zb[16 * ((q < 15 ? sl.x : sl.y) - (i - 1)) + (q < 15 ? q : q - 15)];
+                    a.fat_ep[(size_t)e * KC_FAT_EP + 32] = acc / se;
+                }
+            }
+            __syncthreads();
+    FH_STAMP(6);
+            if (f_misc[0]) fat = false;
+            if (fat) {
+                double* ob = a.fat_blk + (size_t)i * KC_BLK;
+                if (tid < 345) {
+                    int r30, j;
+                    if (tid < 120) { int r = 0; while ((r + 1) * (r + 2) / 2 <= tid) ++r; r30 = r; j = tid - r * (r + 1) / 2; }
+                    else { r30 = 15 + (tid - 120) / 15; j = (tid - 120) % 15; }
+                    ob[tid] = f_blk[r30 * KC_RS + j];
+                } else if (tid < 360) ob[tid] = f_blk[30 * KC_RS + (tid - 345)];
+                else if (tid < 375) ob[tid] = f_t[tid - 360];
+                for (int it = tid; it < (t1e - t0e) * 32; it += KC_THREADS) {
+                    const int e = f_elist[t0e + it / 32], q = it % 32;
+                    if (f_eps[e].x != i) continue;
+                    a.fat_ep[(size_t)e * KC_FAT_EP + q] = q < 30 ? f_Vs[e * 30 + q] : (q == 30 ? f_rd[e] : f_yd[e]);
+                }
+            }
+        }
+    } else fat = false;
+    // ONE agent-scope release: the barrier puts every wavefront's stores before thread 0's release store, whose write-back of this XCD's L2 carries them all
+    // (a __threadfence() by every wavefront in front of the barrier and the release store behind it were two write-backs: 1.5 us each, measured)
+    __syncthreads();
+    FH_STAMP(7);
+    if (tid == 0) __hip_atomic_store(&a.hdone[i], 4 * a.hseq + (fat ? 2 : 0) + go, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#undef FH_STAMP
 }
 
 __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, const TrArgs tr, const GatherArgs G) {
     static_assert(KC_THREADS == TR_THREADS, "tr_prepare_body runs with the chain kernel's workgroup");
     if (blockIdx.x > 0) {
-        chain_step_helper(a, tr, G, (int)blockIdx.x - 1); return;
+        if (a.fat) chain_step_fat_helper(a, tr, G, (int)blockIdx.x - 1); else chain_step_helper(a, tr, G, (int)blockIdx.x - 1);
+        return;
     }
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int W = a.W, n = a.n, nd = a.nd;
@@ -2919,15 +3248,16 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
     // ---- the helper workgroups: every one of them has read the status record (and left its sums) before the state machine rewrites that record.
     // With the LDS-resident front the state machine checks their completion words itself, just before that store (PrepMirror); the generic body
     // has no such hook: wait here.
-    __shared__ int s_hprod;
+    __shared__ int s_hprod, s_hfat;
+    if (tid == 0) s_hfat = 0;
     if (a.helpers) {
-        if (tid == 0) s_hprod = 1;
+        if (tid == 0) { s_hprod = 1; s_hfat = (a.fat && ff) ? 1 : 0; }
         GLIO_BLOCK_LDS_SYNC();
         if (!ff) {
             if (tid < a.helpers) {
                 int v, polls = 0;          // (bounded like the state machine's wait: see tr_prepare_body)
-                while (((v = __hip_atomic_load(&a.hdone[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 1) != a.hseq && polls < a.hpolls) { ++polls; __builtin_amdgcn_s_sleep(1); }
-                if ((v >> 1) != a.hseq || !(v & 1)) s_hprod = 0;
+                while (((v = __hip_atomic_load(&a.hdone[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 2) != a.hseq && polls < a.hpolls) { ++polls; __builtin_amdgcn_s_sleep(1); }
+                if ((v >> 2) != a.hseq || !(v & 1)) s_hprod = 0;
             }
             GLIO_BLOCK_LDS_SYNC();
         }
@@ -2939,7 +3269,7 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
     if (ff) {
         PrepMirror pm;
         pm.st_in = &s_in; pm.x0 = xm0; pm.x1 = xm1; pm.hd = sHd; pm.g = sG; pm.cost = sCost; pm.scale = sS; pm.diag = sDg; pm.grad = sGr; pm.dbg = a.dbg;
-        pm.hdone = a.hdone; pm.hseq = a.hseq; pm.helpers = a.helpers; pm.hprod = &s_hprod; pm.hpolls = a.hpolls;
+        pm.hdone = a.hdone; pm.hseq = a.hseq; pm.helpers = a.helpers; pm.hprod = &s_hprod; pm.hpolls = a.hpolls; pm.hfat = &s_hfat;
         if (!tr_prepare_body<true>(tr, &dec, &pm)) return;
     } else if (!tr_prepare_body(tr, &dec)) return;
     AR_STAMP(43);
@@ -2950,6 +3280,101 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
     const double* gn = dec.cur ? tr.g1 : tr.g0;
     const DdtBlock* ddg = G.ddt_blocks + (size_t)dec.cur * G.ddt_stride;
     const double mu = dec.mu;
+    // ---- fat helpers delivered and their assumptions hold (the candidate was accepted, mu is what an acceptance leaves): the blocks, the epoch columns and
+    // t = H u are LOADED -- 60 KB of finished numbers instead of four LDS phases (epoch columns, block store, t = H u, epoch corrections: ~15 us)
+    const bool fat_path = a.fat && a.helpers && s_hprod && s_hfat && ff && s_pending && dec.cur == cand && !tr.lm &&
+                          __double_as_longlong(mu) == __double_as_longlong(s_in.phase == 0 ? s_in.mu : fmax(1e-8, 2.0 * s_in.mu / 10.0));
+    if (fat_path) {
+        if (tid == 0 && a.dbg) a.dbg[300] += 1;            // (steps that took the fat helpers' products: glio_debug_arrow_stamps, slot 300)
+        const double* xm = cand ? xm1 : xm0;
+        for (int k = tid; k < nx; k += KC_THREADS) sX[k] = xm[k];
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        constexpr int FP = KC_FAT_ENT / 2;                   // pairs per keyframe
+        constexpr int KF = 8, KE = 5;
+        // ONE round of loads (blocks, rows of t, epoch products: every load is issued before the first LDS store), for windows that fit the batch; else loops
+        if (W * FP <= KF * KC_THREADS && np15 + nd <= KC_THREADS && nd * 32 <= KE * KC_THREADS) {
+            v2f64 hv[KF]; double tvv, ev[KE];
+#pragma unroll
+            for (int u = 0; u < KF; ++u) {
+                const int q = tid + u * KC_THREADS;
+                const int qq = q < W * FP ? q : tid;
+                const int i = qq / FP, w = 2 * (qq - FP * i);
+                hv[u] = *reinterpret_cast<const v2f64*>(a.fat_blk + (size_t)i * KC_BLK + w);
+            }
+            {
+                const int row = tid < np15 + nd ? tid : 0;
+                if (row < np15) { const int i = row / 15; tvv = a.fat_blk[(size_t)i * KC_BLK + KC_FAT_ENT + (row - 15 * i)]; }
+                else tvv = a.fat_ep[(size_t)(row - np15) * KC_FAT_EP + 32];
+            }
+#pragma unroll
+            for (int u = 0; u < KE; ++u) {
+                const int it = tid + u * KC_THREADS;
+                const int itc = it < nd * 32 ? it : 0;
+                ev[u] = nd > 0 ? a.fat_ep[(size_t)(itc >> 5) * KC_FAT_EP + (itc & 31)] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < KF; ++u) {
+                const int q = tid + u * KC_THREADS;
+                if (q >= W * FP) continue;
+                const int i = q / FP, w0 = 2 * (q - FP * i);
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int w = w0 + h2;
+                    const int off = w < 345 ? wr30[w] * KC_RS + wj[w] : 30 * KC_RS + (w - 345);
+                    Blk[(size_t)i * KC_BLK + off] = hv[u][h2];
+                }
+            }
+            if (tid < np15 + nd) { V_T(tr)[tid] = tvv; if (mir) sT[tid] = tvv; }
+#pragma unroll
+            for (int u = 0; u < KE; ++u) {
+                const int it = tid + u * KC_THREADS;
+                if (it >= nd * 32) continue;
+                const int e = it >> 5, q = it & 31;
+                if (q < 30) Vs[e * 30 + q] = ev[u]; else if (q == 30) rd[e] = ev[u]; else yd[e] = ev[u];
+            }
+        } else {
+        for (int q0 = tid; q0 < W * FP; q0 += KF * KC_THREADS) {
+            v2f64 hv[KF];
+#pragma unroll
+            for (int u = 0; u < KF; ++u) {
+                const int q = q0 + u * KC_THREADS;
+                const int qq = q < W * FP ? q : tid;
+                const int i = qq / FP, w = 2 * (qq - FP * i);
+                hv[u] = *reinterpret_cast<const v2f64*>(a.fat_blk + (size_t)i * KC_BLK + w);
+            }
+#pragma unroll
+            for (int u = 0; u < KF; ++u) {
+                const int q = q0 + u * KC_THREADS;
+                if (q >= W * FP) continue;
+                const int i = q / FP, w0 = 2 * (q - FP * i);
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int w = w0 + h2;
+                    const int off = w < 345 ? wr30[w] * KC_RS + wj[w] : 30 * KC_RS + (w - 345);
+                    Blk[(size_t)i * KC_BLK + off] = hv[u][h2];
+                }
+            }
+        }
+        for (int row = tid; row < np15 + nd; row += KC_THREADS) {
+            double tv;
+            if (row < np15) { const int i = row / 15; tv = a.fat_blk[(size_t)i * KC_BLK + KC_FAT_ENT + (row - 15 * i)]; }
+            else tv = a.fat_ep[(size_t)(row - np15) * KC_FAT_EP + 32];
+            V_T(tr)[row] = tv; if (mir) sT[row] = tv;
+        }
+        for (int it = tid; it < nd * 32; it += KC_THREADS) {
+            const int e = it >> 5, q = it & 31;
+            const double vv = a.fat_ep[(size_t)e * KC_FAT_EP + q];
+            if (q < 30) Vs[e * 30 + q] = vv; else if (q == 30) rd[e] = vv; else yd[e] = vv;
+        }
+        }
+        // the strict upper triangle of D_i is read as zero by the chain steps
+        for (int q0 = tid; q0 < W * 105; q0 += KC_THREADS) {
+            const int i = q0 / 105, w = q0 - 105 * i;
+            const int r = wr30[w], c = wj[w];
+            Blk[i * KC_BLK + c * KC_RS + (r + 1)] = 0.0;
+        }
+        GLIO_BLOCK_LDS_SYNC();
+    } else {
     auto nat = [&](const int p) { return p < nd ? np15 + p : p - nd; };
     static_assert(sizeof(DdtBlock) == 15 * sizeof(double), "DdtBlock staged as 15 doubles");
     auto epoch_scalars = [&](const int e, const double we) {          // w_e = u / s, r_e = 1 / sqrt(m_e), w_e / r_e
@@ -3204,6 +3629,7 @@ __global__ __launch_bounds__(KC_THREADS) void k_chain_step(const ChainArgs a, co
     };
     if (misc[1] == 6) corrections(std::integral_constant<int, 6>{}); else corrections(misc[1]);
     }
+    }   // !fat_path
     if (tid < 4) s_prog[tid] = 0;
     GLIO_BLOCK_LDS_SYNC();
     AR_STAMP(47);
@@ -3593,7 +4019,7 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
     if (chain) {
         ChainArgs r;
         r.W = c->W; r.n = a.n; r.nd = n_ddt; r.ep_slots = c->arrow.d_ep_slots; r.ep_off = c->arrow.d_ep_off; r.ep_list = c->arrow.d_ep_list;
-        r.z = c->arrow.d_z; r.flag = c->arrow.d_flag; r.status = c->d_status; r.dbg = c->arrow.d_dbg; r.force_fail = c->arrow.mode == 2; r.fast = chain_fast_mask(); r.blk = nullptr; r.helpers = 0; r.hseq = 0; r.hsum = nullptr; r.hdone = nullptr; r.hpolls = 0;
+        r.z = c->arrow.d_z; r.flag = c->arrow.d_flag; r.status = c->d_status; r.dbg = c->arrow.d_dbg; r.force_fail = c->arrow.mode == 2; r.fast = chain_fast_mask(); r.blk = nullptr; r.helpers = 0; r.hseq = 0; r.hsum = nullptr; r.hdone = nullptr; r.hpolls = 0; r.fat = 0; r.fat_blk = nullptr; r.fat_ep = nullptr;
         if (chain_step_lds_bytes(c->W, n_ddt, a.n, true) + 2 * 1024 > 158 * 1024) r.fast = 0;      // no room for the LDS mirrors: generic bodies
         size_t lds_step = chain_step_lds_bytes(c->W, n_ddt, a.n, r.fast != 0);
         {   // separator + four fronts when the window is long enough for it to pay and its panels fit (chain_f4_layout)
@@ -3624,11 +4050,14 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
             // attempt).  INTEGRATION.md section 5.
             const bool room = c->n_cu >= 2 * (1 + c->W);          // (the context's own device: queried at glio_create, not a process-wide value)
             r.helpers = (helpers_off || !room) ? 0 : c->W; r.hsum = c->arrow.d_chain_sum; r.hdone = c->arrow.d_chain_done;
-            r.hseq = c->arrow.chain_seq; c->arrow.chain_seq = c->arrow.chain_seq % (1 << 29) + 1;
+            r.hseq = c->arrow.chain_seq; c->arrow.chain_seq = c->arrow.chain_seq % (1 << 28) + 1;
             // the wait for the helpers is bounded (a poll is a device-scope load + s_sleep: ~0.5-1 us; the helpers report ~5 us into the launch): ~0.2 ms at
             // most, then the step sums the blocks itself.  GLIO_CHAIN_HELPER_POLLS=0 gives them up at once (test: same bits out)
             static const int hpolls = getenv("GLIO_CHAIN_HELPER_POLLS") ? atoi(getenv("GLIO_CHAIN_HELPER_POLLS")) : 256;
             r.hpolls = hpolls;
+            // fat helpers (GLIO_CHAIN_FAT=0: the helpers only sum): the speculative build of every keyframe's block, its rows of t and its epochs' columns
+            static const bool fat_on = !(getenv("GLIO_CHAIN_FAT") && atoi(getenv("GLIO_CHAIN_FAT")) == 0);
+            r.fat = (fat_on && r.helpers && chain_fat_helper_lds_bytes(c->W, n_ddt) <= lds_step) ? 1 : 0; r.fat_blk = c->arrow.d_blk; r.fat_ep = c->arrow.d_fat_ep;
             hipLaunchKernelGGL(k_chain_step, dim3(1 + r.helpers), dim3(KC_THREADS), lds_step, c->stream, r, a, G);
             return;                                   // the one launch is the whole step
         }

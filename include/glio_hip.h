@@ -192,7 +192,9 @@ int glio_eval_binary_plane(glio_ctx* ctx, const float cp[4], const double norm_c
 enum { GLIO_KERNEL_LIDAR_LINEARIZE = 0, GLIO_KERNEL_FULL_LINEARIZE = 1, GLIO_KERNEL_TR_STEP = 2,
        GLIO_KERNEL_ASSOCIATE = 3, GLIO_KERNEL_MAP_BUILD = 4, GLIO_KERNEL_MARGINALIZE = 5,
        GLIO_KERNEL_STREAM_READ = 6 /* same bytes as LIDAR_LINEARIZE, no arithmetic: the practical ceiling */,
-       GLIO_KERNEL_LINEARIZE_ALL = 7 /* the launch glio_solve uses: K3 workgroups beside the small-factor workgroups */ };
+       GLIO_KERNEL_LINEARIZE_ALL = 7 /* the launch glio_solve uses: K3 workgroups beside the small-factor workgroups */,
+       GLIO_KERNEL_TR_STEP_STEADY = 8 /* a LATER step of a solve (an accepted candidate pending, scale in place: call after a solve): what iterations 2.. cost;
+                                         GLIO_KERNEL_TR_STEP is the first step of a solve (no candidate yet, the helpers' speculative build does not apply) */ };
 int glio_time_kernel(glio_ctx* ctx, int which, int reps, float* ms_out);
 /* time `reps` complete solves from the same initial state with HIP events (state is not modified) */
 int glio_time_solve(glio_ctx* ctx, const glio_state* state, int reps, float* ms_out, glio_summary* last);

@@ -23,5 +23,11 @@ for _ in range(3):
     for a in (sol.trans, sol.quat, sol.speed_bias, sol.rcv_ddt):
         h.update(a.tobytes())
     hashes.append(h.hexdigest()[:16]); its.append(int(summ.iterations))
-print(json.dumps({"path": int(capi.load().glio_debug_solver_path(ctx._h)), "iterations": its, "hashes": hashes, "seconds": round(time.perf_counter() - t0, 3),
+import ctypes as C
+st = (C.c_longlong * 320)()
+capi.load().glio_debug_arrow_stamps(ctx._h, st)
+fat_steps = int(st[300])
+tr_us = round(ctx.time_kernel(capi.KERNEL_TR_STEP, 20) * 1e3, 2)
+ms, _ = ctx.time_solve(win.init, 20)
+print(json.dumps({"fat": os.environ.get("GLIO_CHAIN_FAT"), "fat_steps": fat_steps, "tr_step_us": tr_us, "solve_ms": round(ms, 4), "path": int(capi.load().glio_debug_solver_path(ctx._h)), "iterations": its, "hashes": hashes, "seconds": round(time.perf_counter() - t0, 3),
                   "polls": os.environ.get("GLIO_CHAIN_HELPER_POLLS"), "cu_mask": os.environ.get("HSA_CU_MASK")}))

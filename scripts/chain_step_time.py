@@ -18,7 +18,10 @@ for mask in (0, 1, 2, 3, 0, 3):
     ms, _ = ctx.time_solve(win.init, 20)
     print("fast mask", mask, "path", capi.load().glio_debug_solver_path(ctx._h), "iterations", summ.iterations, "solve ms", round(ms, 4), "tr_step us",
           round(ctx.time_kernel(2, 40) * 1e3, 2), "linearize_all us", round(ctx.time_kernel(7, 20) * 1e3, 2), "trans checksum", float(sol.trans.sum()))
-ctx.time_kernel(2, 1)
+steady = os.environ.get("CST_STEADY", "0") == "1"      # phases of a LATER step (accepted candidate pending: the helpers' speculative build applies)
+if steady:
+    print("steady step us", round(ctx.time_kernel(8, 40) * 1e3, 2), "first step us", round(ctx.time_kernel(2, 40) * 1e3, 2))
+ctx.time_kernel(8 if steady else 2, 1)
 st = (C.c_longlong * 320)()
 capi.load().glio_debug_arrow_stamps(ctx._h, st)
 v = list(st)
@@ -45,3 +48,6 @@ if os.environ.get("GLIO_CHAIN_FRONTS", "4") != "2" and v[111]:
 print("back substitution: flag + barrier", d(97, 48), "half chains (wave 0)", d(98, 97), "barrier", d(99, 98), "epochs + z", d(49, 99))
 print("epoch corrections on the matrix core (wave 0): entry", d(104, 96), "lane roles", d(105, 104), "offsets + accumulators", d(106, 105), "operands", d(107, 106), "MFMA", d(108, 107), "stores", d(109, 108), "return", d(110, 109), "barrier", d(47, 110))
 print("shader clock over the step: %.0f MHz (clock64 ticks / wall-clock time between the first and the last stamp)" % ((v[121] - v[120]) / max(1, (v[73] - v[40])) * 100.0))
+
+if steady:
+    print("fat helper W/2 (us after the main workgroup's first stamp): start", d(304, 40), "barriers", [d(304 + k, 40) for k in range(1, 9)], "end", d(319, 40))
