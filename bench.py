@@ -255,6 +255,7 @@ def main():
     la_ms = float(np.mean(la_runs))
     lin_ms = ctx.time_kernel(capi.KERNEL_FULL_LINEARIZE, 50)
     trs_ms = ctx.time_kernel(capi.KERNEL_TR_STEP, 20)
+    trs_steady_ms = ctx.time_kernel(capi.KERNEL_TR_STEP_STEADY, 20)
     marg_ms = ctx.time_kernel(capi.KERNEL_MARGINALIZE, 20)
     t0 = time.perf_counter(); ctx.marginalize(sol); marg_call_ms = 1e3 * (time.perf_counter() - t0)
     # the dominant kernel is the one glio_solve launches: k_linearize_all (K3 workgroups beside the small-factor
@@ -418,7 +419,7 @@ def main():
         "termination": int(summ.termination), "solver_path": {0: "dense", 1: "arrow", 2: "keyframe chain"}.get(int(capi.load().glio_debug_solver_path(ctx._h)), "?"),
         "dense_prior_variant": dense_variant,
         "window_sizes": window_sizes, "concurrent_windows_one_gpu": concurrent,
-        "kernels_us": {"lidar_linearize": round(k3_ms * 1e3, 2), "full_linearize": round(lin_ms * 1e3, 2), "tr_step": round(trs_ms * 1e3, 2),
+        "kernels_us": {"lidar_linearize": round(k3_ms * 1e3, 2), "full_linearize": round(lin_ms * 1e3, 2), "tr_step": round(trs_ms * 1e3, 2), "tr_step_later_iterations": round(trs_steady_ms * 1e3, 2),
                        "marginalize": round(marg_ms * 1e3, 2), "marginalize_call_incl_readback": round(marg_call_ms * 1e3, 1)},
         "roofline": roofline, "cpu_baseline": cpu, "cpu_baselines_other_configs": cpu_more, "pose_vs_oracle": pose_err, "association": assoc,
         "association_c3": c3_info, "c5_stress": c5_info, "batch_stage": batch_info, "batch_association": bassoc_info, "local_map": localmap_info, "front_end_odometry": odometry_info, "keyframe_pipeline": pipeline_info,
