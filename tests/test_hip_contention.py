@@ -62,9 +62,15 @@ def test_chain_step_does_not_depend_on_its_helpers():
         return rows[0]
     ref = run({})
     assert ref["path"] == 2 and len(set(ref["hashes"])) == 1, ref
-    for extra in ({"GLIO_CHAIN_HELPER_POLLS": "0"}, {"HSA_CU_MASK": "0:0-1"}, {"HSA_CU_MASK": "0:0-1", "GLIO_CHAIN_HELPER_POLLS": "3"}):
+    # (round 6: the helpers are "fat" -- they build every keyframe's block, rows of t and epoch columns speculatively; every step of these solves takes
+    #  their products, 4 per solve; with GLIO_CHAIN_FAT=0 they only sum, with the waits given up workgroup 0 builds everything itself: the same bits)
+    assert ref["fat_steps"] == sum(ref["iterations"]), ref
+    for extra in ({"GLIO_CHAIN_FAT": "0"}, {"GLIO_CHAIN_HELPERS": "0"}, {"GLIO_CHAIN_HELPER_POLLS": "0"}, {"HSA_CU_MASK": "0:0-1"},
+                  {"HSA_CU_MASK": "0:0-1", "GLIO_CHAIN_HELPER_POLLS": "3"}):
         got = run(extra)
         assert got["path"] == 2 and got["hashes"] == ref["hashes"] and got["iterations"] == ref["iterations"], (extra, got, ref)
+        if "GLIO_CHAIN_FAT" in extra or "GLIO_CHAIN_HELPERS" in extra or extra.get("GLIO_CHAIN_HELPER_POLLS") == "0":
+            assert got["fat_steps"] == 0, (extra, got)
 
 
 @pytest.mark.timeout(600)
