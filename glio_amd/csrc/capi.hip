@@ -211,6 +211,7 @@ static int create_body(int device, const glio_opts* opts, glio_ctx* c) {
         ALLOC(ar.d_fat_ep, (size_t)ne * 34 * 8);
         GLIO_HIP_CHECK(hipMemsetAsync(ar.d_chain_done, 0, (size_t)W * 4, c->stream));
         GLIO_HIP_CHECK(hipMemsetAsync(ar.d_flag, 0, 4, c->stream));
+        GLIO_HIP_CHECK(hipMemsetAsync(ar.d_dbg, 0, 320 * 8, c->stream));          // (slot 300 counts the steps that took the fat helpers' products)
         GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
     }
     GLIO_HIP_CHECK(hipHostMalloc((void**)&c->h_progress, 64, hipHostMallocMapped | hipHostMallocCoherent));
