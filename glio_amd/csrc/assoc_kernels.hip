@@ -66,6 +66,7 @@ struct AssocWork {
     int* d_pt_slot;               // [max_map] 8 * table slot + octant of point i
     int* d_pt_rank;               // [max_map] its arrival rank inside that octant
     float4* d_map_raw;            // [max_map] upload staging
+    const float4* last_src;       // the points the current map was built from (d_map_raw, or the local map's own output array)
     int* d_total;                 // [1]
     // per-query dense results (capacity = cap of a slot)
     float4* d_q_pt; float4* d_q_plane; double* d_q_score; int* d_q_flag; int* d_q_pos;
@@ -1857,16 +1858,18 @@ void glio_assoc_scan_uploaded(glio_ctx* c, int slot, int n) {
     AssocWork* w = c->assoc;
     if (w) { const size_t row = (size_t)glio_scan_row(c, slot) * c->cap; enqueue_presort(c->stream, w->kb, c->d_scan + row, n, w->d_ps + row); }
 }
-static void enqueue_build(glio_ctx* c, int n) {
+static void enqueue_build(glio_ctx* c, int n, const float4* src = nullptr) {
     AssocWork* w = c->assoc;
+    if (!src) src = w->d_map_raw;                          // (src: the map's points as they lie on the device -- the local map's output needs no copy into d_map_raw)
+    w->last_src = src;                                     // (what a re-build of the same map -- the timing hook -- reads)
     int cap = next_pow2(2 * (n > 512 ? n : 512));          // sized for THIS map: a smaller table stays in L2
     if (cap > w->table_cap) cap = w->table_cap;
     w->cap_eff = cap;
     hipLaunchKernelGGL(k_hash_clear, dim3((cap + 255) / 256), dim3(256), 0, c->stream, w->d_keys, w->d_cnt8, cap, w->d_total, w->d_ent, w->d_sub, n == 0 ? 1 : 0);
     if (n == 0) return;
-    hipLaunchKernelGGL(k_hash_insert, dim3((n + HI_THREADS - 1) / HI_THREADS), dim3(HI_THREADS), 0, c->stream, w->d_map_raw, n, w->inv_cell, w->d_keys, w->d_cnt8, w->d_pt_slot, w->d_pt_rank, cap);
+    hipLaunchKernelGGL(k_hash_insert, dim3((n + HI_THREADS - 1) / HI_THREADS), dim3(HI_THREADS), 0, c->stream, src, n, w->inv_cell, w->d_keys, w->d_cnt8, w->d_pt_slot, w->d_pt_rank, cap);
     hipLaunchKernelGGL(k_cell_alloc, dim3((cap + 1023) / 1024), dim3(1024), 0, c->stream, w->d_cnt8, cap, w->d_total, w->d_keys, w->d_ent, w->d_sub);
-    hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, c->stream, w->d_map_raw, n, w->d_pt_slot, w->d_pt_rank, w->d_cnt8, w->d_ent, c->d_map_sorted);
+    hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, c->stream, src, n, w->d_pt_slot, w->d_pt_rank, w->d_cnt8, w->d_ent, c->d_map_sorted);
 }
 
 int glio_assoc_build_map(glio_ctx* c, const void* map_points, int n, int stride, int ioff) {
@@ -1885,8 +1888,7 @@ int glio_assoc_build_map_dev(glio_ctx* c, const float4* d_pts, int n) {
     AssocWork* w = c->assoc;
     if (!w) return GLIO_E_STATE;
     if (n > c->opts.max_map_points) { glio_set_error("local map has %d points, max_map_points is %d", n, c->opts.max_map_points); return GLIO_E_ARG; }
-    if (n > 0) GLIO_HIP_CHECK(hipMemcpyAsync(w->d_map_raw, d_pts, (size_t)n * 16, hipMemcpyDeviceToDevice, c->stream));
-    enqueue_build(c, n);
+    enqueue_build(c, n, d_pts);          // (straight from the caller's device array: it stays untouched until the next local-map build, which this stream orders behind)
     GLIO_HIP_CHECK(hipGetLastError());
     c->map_n = n;
     return GLIO_OK;
@@ -2131,7 +2133,7 @@ void glio_assoc_time_hooks(glio_ctx* c, int which, int reps, float* ms) {
         const int r = pass == 0 ? 1 : reps;
         if (pass == 1) hipEventRecord(c->ev0, c->stream);
         for (int k = 0; k < r; ++k) {
-            if (which == GLIO_KERNEL_MAP_BUILD) enqueue_build(c, c->map_n);
+            if (which == GLIO_KERNEL_MAP_BUILD) enqueue_build(c, c->map_n, w->last_src);
             else {
                 // it overwrites slot 0's correspondences with the same result
                 enqueue_assoc(c, 0, q, t, c->h_scan_count[0], 0);

@@ -97,7 +97,12 @@ __global__ void k_lm_clear(unsigned long long* keys, long long* sum, int* cnt, i
     if (i < cap) { keys[i] = LM_EMPTY; cnt[i] = 0; sum[4 * (size_t)i] = 0; sum[4 * (size_t)i + 1] = 0; sum[4 * (size_t)i + 2] = 0; sum[4 * (size_t)i + 3] = 0; }
     if (i == 0) *nkeys = 0;
 }
-__global__ void k_lm_bbox_init(int* bbox) { const int i = threadIdx.x; if (i < 3) bbox[i] = 0x7fffffff; else if (i < 6) bbox[i] = (int)0x80000000; }
+// (also records the slot's point count on the device: the build used to upload all `width` counts from pageable memory -- an API call of ~8 us in a
+//  chain of launches that is bound by the host's launch rate)
+__global__ void k_lm_bbox_init(int* bbox, int* n_slot, const int n) {
+    const int i = threadIdx.x;
+    if (i < 3) bbox[i] = 0x7fffffff; else if (i < 6) bbox[i] = (int)0x80000000; else if (i == 6) *n_slot = n;
+}
 // bounding box of one ring slot (ordered-int atomics)
 __global__ __launch_bounds__(1024) void k_lm_bbox(const float4* __restrict__ pts, int n, int* bbox) {
     __shared__ int s_mn[16][3], s_mx[16][3];
@@ -128,9 +133,10 @@ __global__ __launch_bounds__(1024) void k_lm_bbox(const float4* __restrict__ pts
     }
 }
 // union of the slot boxes (slots with n = 0 are skipped)
-__global__ void k_lm_bbox_union(const int* __restrict__ slot_bbox, const int* __restrict__ ns, int width, int* bbox, int* bm_over) {
+__global__ void k_lm_bbox_union(const int* __restrict__ slot_bbox, const int* __restrict__ ns, int width, int* bbox, int* bm_over, int* nvox) {
     const int c = threadIdx.x;
     if (c == 6) *bm_over = 0;
+    if (c == 7) *nvox = 0;                 // (k_lm_list counts the voxels from zero: was a hipMemsetAsync of its own)
     if (c >= 6) return;
     int v = c < 3 ? 0x7fffffff : (int)0x80000000;
     for (int k = 0; k < width; ++k) if (ns[k] > 0) v = c < 3 ? min(v, slot_bbox[6 * k + c]) : max(v, slot_bbox[6 * k + c]);
@@ -504,7 +510,7 @@ int glio_localmap_push_strided(glio_ctx* c, const void* cloud_xyzi, int n, int s
                                        m->d_keys, m->d_sum, m->d_cnt, m->table_cap, m->d_nkeys);
     }
     float4* dst = m->d_ring + (size_t)slot * m->cap;
-    hipLaunchKernelGGL(k_lm_bbox_init, dim3(1), dim3(64), 0, c->stream, m->d_slot_bbox + 6 * slot);
+    hipLaunchKernelGGL(k_lm_bbox_init, dim3(1), dim3(64), 0, c->stream, m->d_slot_bbox + 6 * slot, m->d_n + slot, n);
     if (n > 0) {
         // stage the raw scan in the destination itself, transform in place, then add it to the voxel table
         { const int ru = glio_upload_points(c->stream, &c->raw_stage, cloud_xyzi, n, stride_bytes, intensity_offset, dst); if (ru != GLIO_OK) return ru; }
@@ -539,7 +545,7 @@ int glio_localmap_push_scan(glio_ctx* c, int scan_slot, const float lidar_offset
                                        m->d_keys, m->d_sum, m->d_cnt, m->table_cap, m->d_nkeys);
     }
     float4* dst = m->d_ring + (size_t)slot * m->cap;
-    hipLaunchKernelGGL(k_lm_bbox_init, dim3(1), dim3(64), 0, c->stream, m->d_slot_bbox + 6 * slot);
+    hipLaunchKernelGGL(k_lm_bbox_init, dim3(1), dim3(64), 0, c->stream, m->d_slot_bbox + 6 * slot, m->d_n + slot, n);
     if (n > 0) {
         hipLaunchKernelGGL(k_lm_transform_off, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_scan + (size_t)glio_scan_row(c, scan_slot) * c->cap, n, lidar_offset[0], lidar_offset[1],
                            lidar_offset[2], q[0], q[1], q[2], q[3], t[0], t[1], t[2], dst);
@@ -596,7 +602,7 @@ int glio_localmap_build(glio_ctx* c, int* out_points) {
     LocalMap* m = c->localmap;
     LM_CHECK(hipSetDevice(c->device));
     const float inv_leaf = 1.0f / m->leaf;
-    LM_CHECK(hipMemcpyAsync(m->d_n, m->h_n, (size_t)m->width * 4, hipMemcpyHostToDevice, c->stream));
+    // (the slots' point counts are on the device already: every push records its own, k_lm_bbox_init)
     if (m->nkeys_seen > m->table_cap / 2) {               // too many tombstones: rebuild the table from the ring once
         hipLaunchKernelGGL(k_lm_clear, dim3((m->table_cap + 255) / 256), dim3(256), 0, c->stream, m->d_keys, m->d_sum, m->d_cnt, m->table_cap, m->d_nkeys);
         for (int k = 0; k < m->count; ++k) {
@@ -605,12 +611,11 @@ int glio_localmap_build(glio_ctx* c, int* out_points) {
                                           m->d_keys, m->d_sum, m->d_cnt, m->table_cap, m->d_nkeys);
         }
     }
-    LM_CHECK(hipMemsetAsync(m->d_nvox, 0, 4, c->stream));
     if (m->d_bm && m->bm_dirty) {          // a build that ended between k_lm_list and its emit kernel (an error return) left bits behind
         LM_CHECK(hipMemsetAsync(m->d_bm, 0, (size_t)(BM_MAX_BITS / 32) * 4, c->stream));
         m->bm_dirty = 0;
     }
-    hipLaunchKernelGGL(k_lm_bbox_union, dim3(1), dim3(64), 0, c->stream, m->d_slot_bbox, m->d_n, m->width, m->d_bbox, m->d_bm_over);
+    hipLaunchKernelGGL(k_lm_bbox_union, dim3(1), dim3(64), 0, c->stream, m->d_slot_bbox, m->d_n, m->width, m->d_bbox, m->d_bm_over, m->d_nvox);
     hipLaunchKernelGGL(k_lm_list, dim3((m->table_cap + 1023) / 1024), dim3(1024), 0, c->stream, m->d_keys, m->d_cnt, m->table_cap, inv_leaf, m->d_bbox,
                        m->d_nvox, m->d_vkey, m->d_vslot, m->max_vox, m->d_bm, (unsigned long long)BM_MAX_BITS, m->d_bm_over);
     LM_CHECK(hipGetLastError());
