@@ -30,6 +30,9 @@ print("k_chain_step phases (us):")
 for k, nm in enumerate(names):
     print(f"  {nm:22s} {(v[41 + k] - v[40 + k]) / 100.0:7.2f}")
 print(f"  total                  {(v[51] - v[40]) / 100.0:7.2f}")
+if steady and v[300]:
+    print(f"  (this step took the fat helpers' products: the four phases between the state machine and the chain are ONE load phase of {(v[47] - v[43]) / 100.0:.2f} us;")
+    print("   their own lines above and the sub-phase lines of epoch columns / t = H u / epoch corrections below mix stamps of earlier launches)")
 print("chain step phases, totals over the top half-chain of 10 steps (us): loads, 15 pivots, panel store, rank-15 update, correction:", [round(v[60 + k] / 100.0, 2) for k in range(5)])
 
 def d(a, b):
