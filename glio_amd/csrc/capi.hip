@@ -722,6 +722,7 @@ int glio_set_prior(glio_ctx* c, const glio_prior* p) {
                 if (fabs(sab) > 1e-13 * sqrt(cn[a] * cn[b2])) { chain = false; break; }
             }
         c->arrow.prior_chain = chain ? 1 : 0;
+        c->prior_device_made = 0;
     }
     GnssDevExtra* ex = glio_extra(c);
     GLIO_HIP_CHECK(hipMemcpy(c->d_prior_J0, p->lin_jac, (size_t)np * np * 8, hipMemcpyHostToDevice));
@@ -1198,6 +1199,7 @@ int glio_marginalize_keep(glio_ctx* c, const glio_state* s) {
     for (int k = 0; k < 15 * W; ++k) c->h_prior_index[k] = index[k];
     c->chain_tabs_dirty = 1; c->h_band_clean = 0;
     c->arrow.prior_ok = 1; c->arrow.prior_chain = chain;
+    c->prior_device_made = 1;
     glio_launch_gram(c, n);
     int* h_ok = reinterpret_cast<int*>(c->h_stage + ((c->h_stage_used + 63) & ~(size_t)63));      // (pinned; reserved above)
     GLIO_HIP_CHECK(hipMemcpyAsync(h_ok, dok, 4, hipMemcpyDeviceToHost, c->stream));

@@ -712,6 +712,7 @@ __device__ void prior_H_block(const SmallArgs& a, const double* __restrict__ x, 
 
 __device__ void small_factors_body(const SmallArgs& a);
 __global__ __launch_bounds__(SF_THREADS) void k_small_factors(const SmallArgs a) {
+    __builtin_amdgcn_s_setprio(3);      // (O(W) latency-bound workgroups; in the keyframe call they run beside the batch association's wide launches)
 #ifdef GLIO_DEV_STAMPS
     const long long t0 = wall_clock64();
     small_factors_body(a);
@@ -1104,6 +1105,7 @@ void glio_launch_eval_lidar(glio_ctx* c, const float cp[4], const float plane[4]
 
 // A0 = J0^T J0 of the prior (once per glio_set_prior)
 __global__ void k_gram(const double* __restrict__ J0, double* __restrict__ A0, int np) {
+    __builtin_amdgcn_s_setprio(3);      // (see k_marg_inv)
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (long)np * np) return;
     const int i = (int)(e / np), j = (int)(e % np);

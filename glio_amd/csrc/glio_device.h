@@ -247,6 +247,7 @@ struct glio_ctx {
     double* d_chain_src;                      // [2][W][GLIO_CS_SOURCES][GLIO_CS_STRIDE] chain-layout contributions, double buffered
     hipEvent_t ev_ext_read; int ext_read_pending;   // another object's stream is still READING the resident scans (glio_bassoc_set_frame_from_scan copies one on the
                                                     // batch association's stream): the next write to a scan row, and glio_destroy, come behind this event
+    int prior_device_made;                    // the installed prior is glio_marginalize_keep's own product: block diagonal with EXACT zeros (a caller's prior is only held to a tolerance)
     int n_cu;                                 // compute units of THIS context's device (the helper workgroups of k_chain_step need 2 (1 + W) of them)
 };
 

@@ -4093,6 +4093,7 @@ void glio_launch_tr_step(glio_ctx* c, int n_ddt) {
 // A' = J^T A J and V' = V J, each lane producing 4 entries of A' and of V' from the previous buffers.
 // buf: 2 x (256 A + 256 V) doubles + 48 doubles of per-index rotation data.  Result: eigenvalues on the diagonal
 // of the returned A buffer, eigenvectors in the columns of the returned V buffer.
+template <bool G = false>            // G: the buffer lives in GLOBAL memory (k_marg_inv keeps its LDS under 6 KB; this path runs once per stream)
 __device__ __forceinline__ int jacobi16_wave(double* buf, const int lane) {
     double* coef = buf + 1024;                     // alpha[16], beta[16]
     int* partner = reinterpret_cast<int*>(coef + 32);
@@ -4119,14 +4120,14 @@ __device__ __forceinline__ int jacobi16_wave(double* buf, const int lane) {
                 coef[p] = c; coef[16 + p] = -sn; partner[p] = q;
                 coef[q] = c; coef[16 + q] = sn; partner[q] = p;
             }
-            GLIO_WAVE_LDS_SYNC();
+            chain_wave_sync<G>();
             for (int e = lane; e < 256; e += 64) {
                 const int i = e >> 4, j = e & 15, pi = partner[i], pj = partner[j];
                 const double ai = coef[i], bi = coef[16 + i], aj = coef[j], bj = coef[16 + j];
                 An[e] = ai * (aj * A[i * 16 + j] + bj * A[i * 16 + pj]) + bi * (aj * A[pi * 16 + j] + bj * A[pi * 16 + pj]);
                 Vn[e] = aj * V[i * 16 + j] + bj * V[i * 16 + pj];
             }
-            GLIO_WAVE_LDS_SYNC();
+            chain_wave_sync<G>();
             cur ^= 1;
         }
     }
@@ -4136,6 +4137,7 @@ __device__ __forceinline__ int jacobi16_wave(double* buf, const int lane) {
 // A: pos x pos row-major (pos = 15 + n), b: pos.  Out: J0 (n x n row-major), r0 (n), *ok.
 __global__ __launch_bounds__(TR_THREADS) void k_marg_schur(const double* A, const double* b, const int n, double* Lwork, double* Twork,
                                                            double* J0, double* r0, int* ok) {
+    __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, m = 15, pos = m + n;
     double* Bp = reinterpret_cast<double*>(tr_lds);
     double* part = Bp + TR_NB * bp_stride(n);
@@ -4319,25 +4321,24 @@ __global__ __launch_bounds__(TR_THREADS) void k_marg_schur(const double* A, cons
 //            of its diagonal entry, and a flag when a non-zero lies outside the block-diagonal pattern -- the same sums in the same order as above;
 //        (3) k_marg_root, one workgroup: the root of S (per diagonal block by one wavefront each, or the dense blocked Cholesky), J0, r0.
 // Same bits out (tests/test_hip_marg.py runs both forms).
-__global__ __launch_bounds__(TR_THREADS) void k_marg_inv(const double* A, const int n, double* Ainv_out, int* viol_out) {
-    const int tid = threadIdx.x, m = 15, pos = m + n;
-    double* part = reinterpret_cast<double*>(tr_lds);
-    double* ebuf = part;
-    double* Ainv = part + 1100;
-    __shared__ int s_fast, s_ecur;
-    if (tid == 0) *viol_out = 0;
-    if (tid < 256) {
-        const int i = tid >> 4, j = tid & 15;
-        ebuf[tid] = (i < 15 && j < 15) ? 0.5 * (A[(size_t)i * pos + j] + A[(size_t)j * pos + i]) : 0.0;
-        ebuf[256 + tid] = (i == j) ? 1.0 : 0.0;
+__global__ __launch_bounds__(64) void k_marg_inv(const double* A, const int n, double* Ainv_out, int* viol_out, double* jbuf) {
+    __builtin_amdgcn_s_setprio(3);      // (a short latency-bound kernel that shares its compute unit with the batch association's wide launches: its wavefronts issue first)
+    // ONE wavefront and 6 KB of static LDS: in a keyframe call this kernel is launched while the batch association's searches hold every compute unit's LDS
+    // but a few kilobytes -- with 16 KB of its own it waited for them to END (0.22 ms in profiles/r06_stream_cpp_timeline.txt).  The Jacobi eigen-decomposition
+    // (rank-deficient Amm: the first window of a stream) works in global memory instead (jbuf: 1100 doubles).
+    __shared__ double sA[256], sLinv[256], sAinv[232];
+    __shared__ int s_fast;
+    const int lane = threadIdx.x, m = 15, pos = m + n;
+    if (lane == 0) *viol_out = 0;
+    for (int e = lane; e < 256; e += 64) {
+        const int i = e >> 4, j = e & 15;
+        sA[e] = (i < 15 && j < 15) ? 0.5 * (A[(size_t)i * pos + j] + A[(size_t)j * pos + i]) : 0.0;
     }
-    __syncthreads();
-    double* Linv = ebuf + 512;
-    if (tid < 64) {
-        const int lane = tid;
+    GLIO_WAVE_LDS_SYNC();
+    {
         double a[16], x[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) a[j] = lane < 15 ? (j < 15 ? ebuf[lane * 16 + j] : 0.0) : ((lane == 15 && j == 15) ? 1.0 : 0.0);
+        for (int j = 0; j < 16; ++j) a[j] = lane < 15 ? (j < 15 ? sA[lane * 16 + j] : 0.0) : ((lane == 15 && j == 15) ? 1.0 : 0.0);
         bool bad = false;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -4358,43 +4359,45 @@ __global__ __launch_bounds__(TR_THREADS) void k_marg_inv(const double* A, const 
         }
         if (lane < 16) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) Linv[k * 16 + lane] = x[k];
+            for (int k = 0; k < 16; ++k) sLinv[k * 16 + lane] = x[k];
         }
         if (lane == 0) s_fast = bad ? 0 : 1;
     }
-    __syncthreads();
+    GLIO_WAVE_LDS_SYNC();
     if (s_fast) {
-        if (tid < 225) {
-            const int i = tid / 15, j = tid % 15;
+        for (int t = lane; t < 225; t += 64) {
+            const int i = t / 15, j = t % 15;
             double sacc = 0;
-            for (int k = (i > j ? i : j); k < 15; ++k) sacc += Linv[k * 16 + i] * Linv[k * 16 + j];
-            Ainv[tid] = sacc;
+            for (int k = (i > j ? i : j); k < 15; ++k) sacc += sLinv[k * 16 + i] * sLinv[k * 16 + j];
+            sAinv[t] = sacc;
         }
-        __syncthreads();
-        if (tid == 0) {
+        GLIO_WAVE_LDS_SYNC();
+        if (lane == 0) {
             double f2 = 0;
-            for (int k = 0; k < 225; ++k) f2 += Ainv[k] * Ainv[k];
+            for (int k = 0; k < 225; ++k) f2 += sAinv[k] * sAinv[k];
             if (!(f2 > 0.0) || !isfinite(f2) || !(1.0 / sqrt(f2) > 1e-7)) s_fast = 0;
         }
-        __syncthreads();
+        GLIO_WAVE_LDS_SYNC();
     }
     if (!s_fast) {
-        if (tid < 64) { const int cur = jacobi16_wave(ebuf, tid); if (tid == 0) s_ecur = cur; }
-        __syncthreads();
-        if (tid < 225) {
-            const double* Am = ebuf + s_ecur * 512; const double* Vm = Am + 256;
-            const int i = tid / 15, j = tid % 15;
+        for (int e = lane; e < 256; e += 64) { jbuf[e] = sA[e]; jbuf[256 + e] = ((e >> 4) == (e & 15)) ? 1.0 : 0.0; }
+        chain_wave_sync<true>();
+        const int cur = jacobi16_wave<true>(jbuf, lane);
+        const double* Am = jbuf + cur * 512; const double* Vm = Am + 256;
+        for (int t = lane; t < 225; t += 64) {
+            const int i = t / 15, j = t % 15;
             double sacc = 0;
             for (int k = 0; k < 16; ++k) { const double w = Am[k * 17]; sacc += Vm[i * 16 + k] * (w > 1e-8 ? 1.0 / w : 0.0) * Vm[j * 16 + k]; }
-            Ainv[tid] = sacc;
+            sAinv[t] = sacc;
         }
-        __syncthreads();
+        GLIO_WAVE_LDS_SYNC();
     }
-    if (tid < 225) Ainv_out[tid] = Ainv[tid];
+    for (int t = lane; t < 225; t += 64) Ainv_out[t] = sAinv[t];
 }
 // blockIdx.x = i < n: row i of S (lower part) ; blockIdx.x = n: the carried right-hand side.  128 threads.
 __global__ __launch_bounds__(128) void k_marg_rows(const double* __restrict__ A, const double* __restrict__ b, const int n, const double* __restrict__ Ainv,
                                                    double* __restrict__ Twork, double* __restrict__ Lwork, double* __restrict__ tol, int* __restrict__ viol) {
+    __builtin_amdgcn_s_setprio(3);
     __shared__ double sA[225], sT[15], sArow[15];
     const int tid = threadIdx.x, m = 15, pos = m + n, i = blockIdx.x;
     for (int k = tid; k < 225; k += 128) sA[k] = Ainv[k];
@@ -4433,18 +4436,27 @@ __global__ __launch_bounds__(128) void k_marg_rows(const double* __restrict__ A,
         }
     }
 }
+// SMALL: the host knows the Schur complement to be block diagonal (no prior, or a prior that is block diagonal by keyframe: LiDAR blocks, the dropped
+// keyframe's IMU edge and such a prior produce EXACT zeros between the blocks) -- the kernel then needs 3 KB of static LDS instead of the dense routine's
+// panels (~100 KB: a request that, beside the batch association's searches, waits for a compute unit to EMPTY).  Should the pattern check of k_marg_rows
+// have found a non-zero after all, it reports failure (ok = 0: the caller is left without a prior, as for a rank-deficient complement).
+template <bool SMALL>
 __global__ __launch_bounds__(TR_THREADS) void k_marg_root(const int n, double* Lwork, const double* __restrict__ tol, const int* __restrict__ viol, double* J0, double* r0, int* ok) {
+    __builtin_amdgcn_s_setprio(3);      // (a short latency-bound kernel that shares its compute unit with the batch association's wide launches: its wavefronts issue first)
     const int tid = threadIdx.x;
-    double* Bp = reinterpret_cast<double*>(tr_lds);
-    double* part = Bp + TR_NB * bp_stride(n);
-    double* sD = part + 16 * 256;
-    double* ylds = sD + (TR_NB + 1) * TR_PS;
-    double* red = ylds + n + (n & 1);
-    int* flag = reinterpret_cast<int*>(red + 32);
+    __shared__ double s_tol[SMALL ? 6 * GLIO_MAX_WINDOW + 16 : 2];
+    __shared__ int s_flag[8];
+    double* Bp = SMALL ? nullptr : reinterpret_cast<double*>(tr_lds);
+    double* part = SMALL ? nullptr : Bp + TR_NB * bp_stride(n);
+    double* sD = SMALL ? nullptr : part + 16 * 256;
+    double* ylds = SMALL ? s_tol : sD + (TR_NB + 1) * TR_PS;
+    double* red = SMALL ? nullptr : ylds + n + (n & 1);
+    int* flag = SMALL ? s_flag : reinterpret_cast<int*>(red + 32);
     for (int j = tid; j < n; j += TR_THREADS) ylds[j] = tol[j];
     const bool bdiag = (n >= 15 && (n - 15) % 6 == 0) && *viol == 0;
     if (tid == 0) *flag = 0;
     __syncthreads();
+    if (SMALL && !bdiag) { if (tid == 0) *ok = 0; return; }
     bool good;
     if (bdiag) {
         const int lane = tid & 63, wv = tid >> 6, nblk = 1 + (n - 15) / 6;
@@ -4486,7 +4498,8 @@ __global__ __launch_bounds__(TR_THREADS) void k_marg_root(const int n, double* L
         __syncthreads();
         good = *flag == 0;
     } else {
-        good = chol_left_looking<true>(Lwork, n, Bp, part, sD, flag, 0, ylds);
+        if (SMALL) good = false;
+        else good = chol_left_looking<true>(Lwork, n, Bp, part, sD, flag, 0, ylds);
     }
     if (good) {
         for (int i = tid >> 6; i < n; i += TR_WAVES)
@@ -4505,6 +4518,7 @@ struct MargAsmArgs {
     double* A; double* b;
 };
 __global__ __launch_bounds__(256) void k_marg_assemble(const MargAsmArgs a) {
+    __builtin_amdgcn_s_setprio(3);      // (a short latency-bound kernel that shares its compute unit with the batch association's wide launches: its wavefronts issue first)
     const int pos = a.pos;
     for (int r = blockIdx.x; r <= pos; r += gridDim.x) {
         for (int c = threadIdx.x; c < pos; c += blockDim.x) {
@@ -4543,14 +4557,19 @@ int glio_launch_marginalize(glio_ctx* c, int imu_edge0, double** J0_dev, double*
     double* Twork = c->d_vec;                    // n x 15 <= 10 n_max doubles? n*15 <= 15W*... checked by the caller
     static const bool split = !(getenv("GLIO_MARG_SPLIT") && atoi(getenv("GLIO_MARG_SPLIT")) == 0);      // (0: the one-workgroup form, for A/B and tests)
     // scratch of the split form: Ainv (225), the tolerances (n), the pattern flag -- behind the (n + 1) x n work matrix in d_L, when it fits there
-    const size_t lwork = (size_t)(n + 1) * n + 2, need = 226 + (size_t)n + 2, have = (size_t)(c->n_max + 1) * c->n_max;
+    const size_t lwork = (size_t)(n + 1) * n + 2, need = 226 + (size_t)n + 2 + 1100, have = (size_t)(c->n_max + 1) * c->n_max;
     if (split && lwork + need <= have) {
         double* Ainv = c->d_L + ((lwork + 1) & ~(size_t)1);
         double* tol = Ainv + 226;
         int* viol = reinterpret_cast<int*>(tol + n + 1);
-        hipLaunchKernelGGL(k_marg_inv, dim3(1), dim3(TR_THREADS), 16 * 1024, c->stream, c->d_H[0], n, Ainv, viol);
+        double* jbuf = tol + n + 2;                  // the Jacobi fallback's working matrices (global memory: k_marg_inv)
+        // the complement is block diagonal by construction when the old prior is (or there is none): the root then needs no panels
+        // (a prior the CALLER handed over is block diagonal only to glio_set_prior's tolerance: its complement takes the general root)
+        const bool bd = (c->prior_n == 0 || (c->arrow.prior_chain && c->prior_device_made)) && n >= 15 && (n - 15) % 6 == 0;
+        hipLaunchKernelGGL(k_marg_inv, dim3(1), dim3(64), 0, c->stream, c->d_H[0], n, Ainv, viol, jbuf);
         hipLaunchKernelGGL(k_marg_rows, dim3(n + 1), dim3(128), 0, c->stream, c->d_H[0], c->d_g[0], n, Ainv, Twork, c->d_L, tol, viol);
-        hipLaunchKernelGGL(k_marg_root, dim3(1), dim3(TR_THREADS), glio_tr_step_lds_bytes(n), c->stream, n, c->d_L, tol, viol, c->d_H[1], c->d_g[1], d_ok);
+        if (bd) hipLaunchKernelGGL(k_marg_root<true>, dim3(1), dim3(TR_THREADS), 0, c->stream, n, c->d_L, tol, viol, c->d_H[1], c->d_g[1], d_ok);
+        else hipLaunchKernelGGL(k_marg_root<false>, dim3(1), dim3(TR_THREADS), glio_tr_step_lds_bytes(n), c->stream, n, c->d_L, tol, viol, c->d_H[1], c->d_g[1], d_ok);
     } else
     hipLaunchKernelGGL(k_marg_schur, dim3(1), dim3(TR_THREADS), glio_tr_step_lds_bytes(n), c->stream, c->d_H[0], c->d_g[0], n, c->d_L, Twork,
                        c->d_H[1], c->d_g[1], d_ok);
@@ -4596,7 +4615,7 @@ int glio_tr_step_configure(size_t max_lds) {
     TR_CONF_(k_tr_finish, max_lds);
     TR_CONF_(k_chol_test, max_lds);
     TR_CONF_(k_marg_schur, max_lds);
-    TR_CONF_(k_marg_root, max_lds);
+    TR_CONF_(k_marg_root<false>, max_lds);
     TR_CONF_(k_arrow_forward, max_lds);
     TR_CONF_(k_arrow_solve, max_lds);
     TR_CONF_(k_chain_solve<false>, max_lds - 1024);
