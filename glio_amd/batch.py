@@ -478,6 +478,11 @@ class BatchAssociation:
         self.total = tot.value
         return cnt[:n], self.total
 
+    def select_tail_draws(self, res_num, raws):
+        """globalFeatureSelectionAdd_Batch for the asynchronous run in flight, on its stream (glio_bassoc_select_tail_draws_async): raws = res_num uint64 per pair."""
+        raws = np.ascontiguousarray(raws, np.uint64)
+        capi._check(capi.load().glio_bassoc_select_tail_draws_async(self._h, int(res_num), raws.ctypes.data_as(C.POINTER(C.c_uint64))))
+
     def finish(self):
         n = getattr(self, "_pending_n", 0)
         cnt = np.zeros(max(n, 1), np.int64); tot = C.c_int64()

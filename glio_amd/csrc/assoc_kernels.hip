@@ -2193,6 +2193,11 @@ struct glio_bassoc {
     int done_pairs, done_overflow;  // ... of a run the stream was waited for (by any entry point) but whose counts glio_bassoc_finish has not fetched yet (-1: none):
                                     // they stay in h_pair_off / h_tail until it does (or until the next run replaces them)
     hipEvent_t ev_fb; int fb_in_flight;   // the last upload of build descriptors from the pinned h_fb (rewritten only behind it)
+    // glio_bassoc_select_tail_draws_async: the caller's raw draws (pinned + device, [n_pairs * res_num] 64-bit numbers), the new offsets of the pairs
+    unsigned long long* h_raws; unsigned long long* d_raws; long long raws_cap; hipEvent_t ev_raws; int raws_in_flight;
+    long long* d_sel_off;             // [max_pairs + 1] where every pair's kept records go (absolute), last = the new running total
+    long long pending_first;          // records held when the pending asynchronous run was enqueued (the tail starts here)
+    int pending_selected;             // the pending run's pairs already went through the on-stream selection with this many records per pair at most (0: not)
     double* d_poses;                // [K][7]
     // feature selection scratch (grow-only): the gathered records and their source indices
     float4* d_sel_cp; double* d_sel_nc; double* d_sel_score; long long* d_sel_idx; long long sel_cap;      // (d_sel_idx: [1 + cap], word 0 = the new running total)
@@ -2413,6 +2418,10 @@ void glio_bassoc_destroy(glio_bassoc* b) {
     if (b->ev_scan) hipEventDestroy(b->ev_scan);
     if (b->ev_sel) hipEventDestroy(b->ev_sel);
     if (b->ev_fb) hipEventDestroy(b->ev_fb);
+    if (b->ev_raws) hipEventDestroy(b->ev_raws);
+    if (b->h_raws) hipHostFree(b->h_raws);
+    if (b->d_raws) hipFree(b->d_raws);
+    if (b->d_sel_off) hipFree(b->d_sel_off);
     if (b->h_sel) hipHostFree(b->h_sel);
     hipStreamDestroy(b->stream);
     delete b;
@@ -2539,6 +2548,7 @@ static int bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const in
         BA_CHECK(hipHostMalloc((void**)&b->h_pair_off, (size_t)(b->max_pairs + 2) * 8));
         BA_CHECK(hipHostMalloc((void**)&b->h_pairs, (size_t)b->max_pairs * 16));
     }
+    const long long first_before = append ? b->h_tail[0] : 0;      // the records held before this run (every earlier run was drained above: h_tail is settled)
     memcpy(b->h_poses, poses, (size_t)b->K * 7 * 8);
     BA_CHECK(hipMemcpyAsync(b->d_poses, b->h_poses, (size_t)b->K * 7 * 8, hipMemcpyHostToDevice, b->stream));
     if (append) BA_CHECK(hipMemsetAsync(b->d_run + 1, 0, 8, b->stream));
@@ -2646,6 +2656,8 @@ static int bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const in
     if (n_pairs > 0) BA_CHECK(hipMemcpyAsync(b->h_pair_off, b->d_pair_off, (size_t)(n_pairs + 1) * 8, hipMemcpyDeviceToHost, b->stream));
     BA_CHECK(hipMemcpyAsync(b->h_tail, b->d_run, 16, hipMemcpyDeviceToHost, b->stream));
     b->pending_pairs = n_pairs;
+    b->pending_first = first_before;
+    b->pending_selected = 0;
     return wait ? bassoc_finish(b, pair_count_out, total_out) : GLIO_OK;
 }
 int glio_bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj, int64_t* pair_count_out, int64_t* total_out) {
@@ -2703,6 +2715,121 @@ int glio_bassoc_set_frame_from_scan(glio_bassoc* b, int k, glio_ctx* c, int slot
     }
     BA_CHECK(hipGetLastError());
     b->h_n[k] = n;
+    return GLIO_OK;
+}
+
+// globalFeatureSelectionAdd_Batch (Estimator.cpp:4057-4116) ON THE STREAM, right behind the searches of an asynchronous run: no host round trip between
+// the searches and the selection (waiting for the counts, drawing, uploading the indices: ~50 us at the end of every keyframe call).  The draws are still
+// the caller's: `raws` holds res_num 64-bit numbers per pair, drawn before the counts are known; pair p keeps all of its `count` records when
+// count <= res_num, else the first res_num of a uniform shuffle of 0 .. count - 2 (the LAST record is never drawn, random_generator.hpp:79-93): step i swaps
+// position i with position i + raws[p * res_num + i] mod (count - 1 - i) -- glio::batchSelectionDraws with rand_below(n) = raw mod n.
+// k_bassoc_draw: one thread per pair forms the kept source indices (absolute) and the kept count; k_bassoc_draw_off: their prefix;
+// gather into the staging arrays, put back (the kernels of glio_bassoc_select_range).
+__global__ __launch_bounds__(64) void k_bassoc_draw(const long long* __restrict__ pair_off, const int n_pairs, const int res_num, const unsigned long long* __restrict__ raws,
+                                                    long long* __restrict__ src /* [n_pairs][res_num] */, int* __restrict__ kept) {
+    // one wavefront per pair: the pair's raw draws come in as one batch of loads, the shuffle's map lives in LDS (a thread-private array indexed at run time
+    // would live in scratch memory: a dependent global round trip per look-up -- the first version of this kernel took ~80 us for 12 pairs)
+    __shared__ unsigned long long s_raw[64];
+    __shared__ long long s_mk[64], s_mv[64], s_out[64];
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const long long o0 = pair_off[p], count = pair_off[p + 1] - o0;
+    long long* out = src + (size_t)p * res_num;
+    if (count <= res_num) { for (long long k = lane; k < count; k += 64) out[k] = o0 + k; if (lane == 0) kept[p] = (int)count; return; }
+    if (lane < res_num) s_raw[lane] = raws[(size_t)p * res_num + lane];
+    GLIO_WAVE_LDS_SYNC();
+    if (lane == 0) {
+        // partial Fisher-Yates without the index array: a small map of the positions whose content differs from their index (<= res_num entries)
+        int nm = 0, nk = 0;
+        for (int i = 0; i < res_num && i < count - 1; ++i) {
+            const long long j = i + (long long)(s_raw[i] % (unsigned long long)(count - 1 - i));
+            long long vi = i, vj = j;
+            for (int q = 0; q < nm; ++q) { const long long k = s_mk[q], v = s_mv[q]; if (k == i) vi = v; if (k == j) vj = v; }
+            bool found = false;
+            for (int q = 0; q < nm; ++q) if (s_mk[q] == j) { s_mv[q] = vi; found = true; }
+            if (!found) { s_mk[nm] = j; s_mv[nm] = vi; ++nm; }
+            s_out[nk++] = o0 + vj;
+        }
+        kept[p] = nk;
+        s_mk[63] = nk;
+    }
+    GLIO_WAVE_LDS_SYNC();
+    const int nk = (int)s_mk[63];
+    if (lane < nk) out[lane] = s_out[lane];
+}
+__global__ void k_bassoc_draw_off(const int* __restrict__ kept, const int n_pairs, const long long first, long long* __restrict__ sel_off, long long* __restrict__ run) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    long long r = first;
+    for (int p = 0; p < n_pairs; ++p) { sel_off[p] = r; r += kept[p]; }
+    sel_off[n_pairs] = r;
+    run[0] = r;
+}
+__global__ void k_bassoc_draw_gather(const long long* __restrict__ src, const int* __restrict__ kept, const long long* __restrict__ sel_off, const int res_num, const long long first,
+                                     const float4* __restrict__ cp, const double* __restrict__ nc, const double* __restrict__ score,
+                                     float4* __restrict__ o_cp, double* __restrict__ o_nc, double* __restrict__ o_score) {
+    const int p = blockIdx.x, k = threadIdx.x;
+    if (k >= kept[p]) return;
+    const long long sidx = src[(size_t)p * res_num + k], d = sel_off[p] - first + k;
+    o_cp[d] = cp[sidx];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) o_nc[6 * d + c] = nc[6 * sidx + c];
+    o_score[d] = score[sidx];
+}
+__global__ void k_bassoc_draw_put(const long long* __restrict__ sel_off, const int n_pairs, const long long first, const float4* __restrict__ s_cp, const double* __restrict__ s_nc,
+                                  const double* __restrict__ s_score, float4* __restrict__ cp, double* __restrict__ nc, double* __restrict__ score) {
+    const long long n = sel_off[n_pairs] - first, k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    cp[first + k] = s_cp[k];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) nc[6 * (first + k) + c] = s_nc[6 * k + c];
+    score[first + k] = s_score[k];
+}
+int glio_bassoc_select_tail_draws_async(glio_bassoc* b, int res_num, const uint64_t* raws) {
+    if (!b || res_num < 1 || res_num > 64 || !raws) return GLIO_E_ARG;
+    if (b->pending_pairs < 0) { glio_set_error("glio_bassoc_select_tail_draws_async: no asynchronous run is pending"); return GLIO_E_STATE; }
+    BA_CHECK(hipSetDevice(b->device));
+    const int n_pairs = b->pending_pairs;
+    if (n_pairs == 0) return GLIO_OK;
+    const long long need = (long long)n_pairs * res_num;
+    if (need > b->raws_cap) {
+        if (b->raws_in_flight) { BA_CHECK(hipEventSynchronize(b->ev_raws)); b->raws_in_flight = 0; }
+        if (b->h_raws) hipHostFree(b->h_raws);
+        if (b->d_raws) hipFree(b->d_raws);
+        if (b->d_sel_off) hipFree(b->d_sel_off);
+        b->h_raws = nullptr; b->d_raws = nullptr; b->d_sel_off = nullptr; b->raws_cap = 0;
+        const long long cap = need + need / 2 + 1024;
+        BA_CHECK(hipHostMalloc((void**)&b->h_raws, (size_t)cap * 8)); BA_CHECK(hipMalloc((void**)&b->d_raws, (size_t)cap * 16));      // (device: the raws, then the source indices)
+        BA_CHECK(hipMalloc((void**)&b->d_sel_off, (size_t)(cap + 2) * 8 + (size_t)cap * 4));                                            // (the offsets, then the kept counts)
+        b->raws_cap = cap;
+    }
+    // the staging arrays of the selection (grow-only, shared with glio_bassoc_select_range)
+    if (need > b->sel_cap || !b->d_sel_idx) {
+        BA_CHECK(hipStreamSynchronize(b->stream));
+        void** old[] = {(void**)&b->d_sel_cp, (void**)&b->d_sel_nc, (void**)&b->d_sel_score, (void**)&b->d_sel_idx};
+        for (void** q : old) { if (*q) hipFree(*q); *q = nullptr; }
+        b->sel_cap = 0;
+        const int64_t cap = need + need / 2 + 1024;
+        BA_CHECK(hipMalloc((void**)&b->d_sel_cp, (size_t)cap * 16)); BA_CHECK(hipMalloc((void**)&b->d_sel_nc, (size_t)cap * 48));
+        BA_CHECK(hipMalloc((void**)&b->d_sel_score, (size_t)cap * 8)); BA_CHECK(hipMalloc((void**)&b->d_sel_idx, (size_t)(cap + 1) * 8));
+        b->sel_cap = cap;
+    }
+    if (!b->ev_raws) BA_CHECK(hipEventCreateWithFlags(&b->ev_raws, hipEventDisableTiming));
+    if (b->raws_in_flight) { BA_CHECK(hipEventSynchronize(b->ev_raws)); b->raws_in_flight = 0; }
+    memcpy(b->h_raws, raws, (size_t)need * 8);
+    BA_CHECK(hipMemcpyAsync(b->d_raws, b->h_raws, (size_t)need * 8, hipMemcpyHostToDevice, b->stream));
+    BA_CHECK(hipEventRecord(b->ev_raws, b->stream));
+    b->raws_in_flight = 1;
+    long long* d_src = reinterpret_cast<long long*>(b->d_raws + b->raws_cap);
+    int* d_kept = reinterpret_cast<int*>(b->d_sel_off + b->raws_cap + 2);
+    hipLaunchKernelGGL(k_bassoc_draw, dim3(n_pairs), dim3(64), 0, b->stream, b->d_pair_off, n_pairs, res_num, b->d_raws, d_src, d_kept);
+    hipLaunchKernelGGL(k_bassoc_draw_off, dim3(1), dim3(64), 0, b->stream, d_kept, n_pairs, b->pending_first, b->d_sel_off, b->d_run);
+    hipLaunchKernelGGL(k_bassoc_draw_gather, dim3(n_pairs), dim3(64), 0, b->stream, d_src, d_kept, b->d_sel_off, res_num, b->pending_first, b->d_cp, b->d_nc, b->d_score,
+                       b->d_sel_cp, b->d_sel_nc, b->d_sel_score);
+    hipLaunchKernelGGL(k_bassoc_draw_put, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, b->stream, b->d_sel_off, n_pairs, b->pending_first, b->d_sel_cp, b->d_sel_nc, b->d_sel_score,
+                       b->d_cp, b->d_nc, b->d_score);
+    BA_CHECK(hipGetLastError());
+    // the running total as the selection left it (the copy the run enqueued carried the total BEFORE the selection; the pair counts stay the FOUND ones)
+    BA_CHECK(hipMemcpyAsync(b->h_tail, b->d_run, 8, hipMemcpyDeviceToHost, b->stream));
+    b->pending_selected = res_num;
     return GLIO_OK;
 }
 

@@ -8,6 +8,7 @@
 //   damped Gauss-Newton path:  Hg_r = linearize(poses)  ->  allReduce(Hg)  ->  every rank: step(Hg, lambda)
 //   trust-region path (solveTrustRegion / solveRounds): everything sharded, five small all-reduces per iteration on stream()
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <functional>
@@ -273,6 +274,10 @@ public:
         check(glio_bassoc_run_append_async(h_, poses.data(), (int)pairs.size(), pairs.ci.data(), pairs.cj.data()), "glio_bassoc_run_append_async");
         pending_ = (int)pairs.size();
     }
+    // the selection of the run in flight on its own stream (raws: res_num numbers per pair, drawn before the counts exist); finish() then returns the counts FOUND
+    void selectTailDrawsAsync(int res_num, const std::vector<uint64_t>& raws) {
+        check(glio_bassoc_select_tail_draws_async(h_, res_num, raws.data()), "glio_bassoc_select_tail_draws_async");
+    }
     std::vector<int64_t> finish() {
         std::vector<int64_t> cnt((size_t)(pending_ > 0 ? pending_ : 1));
         check(glio_bassoc_finish(h_, cnt.data(), &total_), "glio_bassoc_finish");
@@ -402,10 +407,23 @@ public:
     }
     int enqueue(int size, const std::vector<double>& poses) {
         have_ = BatchAssociationBackend::keyframePairs(size, sr_, cur_);
+        on_stream_ = false;
         if (!have_) return 0;
         first_ = ba_.total();
         ba_.runAppendAsync(poses, cur_);
         return (int)cur_.size();
+    }
+    // the same with the selection enqueued behind the searches on the association's stream: rand_u64() returns the caller's raw 64-bit draws (res_num per
+    // pair, made now: a draw does not need the counts, only its reduction does); finish() then has nothing to select and nothing to upload
+    template <typename RandU64>
+    int enqueueWithDraws(int size, const std::vector<double>& poses, RandU64&& rand_u64) {
+        const int n = enqueue(size, poses);
+        if (n == 0 || res_num_ < 1 || res_num_ > 64) return n;
+        std::vector<uint64_t> raws((size_t)n * (size_t)res_num_);
+        for (uint64_t& r : raws) r = rand_u64();
+        ba_.selectTailDrawsAsync(res_num_, raws);
+        on_stream_ = true;
+        return n;
     }
     // rand_below(n): uniform integer in [0, n) -- the reference seeds from std::random_device, the generator is the caller's.  Returns the pair counts FOUND
     // (before the selection); `counts` books what was kept.
@@ -415,7 +433,9 @@ public:
         have_ = false;
         const std::vector<int64_t> found = ba_.finish();
         std::vector<int64_t> kept = found;
-        if (res_num_ >= 0) {
+        if (on_stream_) {          // the device applied the rule: all of a pair's records when it has at most res_num, else res_num (never the last record)
+            for (size_t p = 0; p < found.size(); ++p) kept[p] = found[p] <= res_num_ ? found[p] : std::min<int64_t>(res_num_, found[p] - 1);
+        } else if (res_num_ >= 0) {
             std::vector<int64_t> src, draw;
             int64_t off = first_;
             bool any = false;
@@ -438,7 +458,7 @@ private:
     int sr_, res_num_;
     PairList cur_;
     int64_t first_ = 0;
-    bool have_ = false;
+    bool have_ = false, on_stream_ = false;
 };
 
 // ================================================================================================

@@ -74,6 +74,10 @@ int main(int argc, char** argv) {
         // keyframes enter the averages: the released configuration fills its 50-keyframe local map first)
         int feature_res = 0, timed_last = NK;
         bool per_slot = false;
+        // stream_draws=1: the selection's raw draws travel with the enqueue and globalFeatureSelectionAdd_Batch runs on the association's stream behind the
+        // searches (glio_bassoc_select_tail_draws_async).  Default: the host waits for the pair counts, draws, uploads the kept indices and does NOT wait for
+        // the gather -- measured faster (1.37 vs 1.40 ms per keyframe: the on-stream form puts a copy and four dependent launches in front of finish()'s wait)
+        bool host_draws = true;
         // sleep_ms=N: the host sleeps N ms inside every keyframe call (a 10 Hz caller leaves the GPU idle for ~100 ms between calls; the sleep is not part of
         // any stage time).  sleep_at: 0 = between the batch association's preparation and the solve, 1 = before the call's first entry point, 2 = between the solve and
         // the batch association's enqueue
@@ -84,6 +88,7 @@ int main(int argc, char** argv) {
             if (!strncmp(argv[a], "res=", 4)) feature_res = atoi(argv[a] + 4);
             else if (!strncmp(argv[a], "timed=", 6)) timed_last = atoi(argv[a] + 6);
             else if (!strncmp(argv[a], "per_slot=", 9)) per_slot = atoi(argv[a] + 9) != 0;
+            else if (!strncmp(argv[a], "stream_draws=", 13)) host_draws = atoi(argv[a] + 13) == 0;
             else if (!strncmp(argv[a], "sleep_ms=", 9)) sleep_ms = atoi(argv[a] + 9);
             else if (!strncmp(argv[a], "sleep_at=", 9)) sleep_at = atoi(argv[a] + 9);
             else if (!strncmp(argv[a], "draws=", 6)) {
@@ -95,6 +100,7 @@ int main(int argc, char** argv) {
         }
         if (timed_last < 1 || timed_last > NK) timed_last = NK;
         std::mt19937_64 rng(20260925);
+        auto rand_u64 = [&]() -> uint64_t { return table.empty() ? (uint64_t)rng() : table[table_k++ % table.size()]; };
         auto rand_below = [&](uint64_t n) -> uint64_t {
             if (!table.empty()) return table[table_k++ % table.size()] % n;
             return std::uniform_int_distribution<uint64_t>(0, n - 1)(rng);
@@ -154,11 +160,11 @@ int main(int argc, char** argv) {
             if (sleep_ms > 0 && sleep_at == 2) { const double ts = now_s(); std::this_thread::sleep_for(std::chrono::milliseconds(sleep_ms)); slept2 = now_s() - ts; }
             if (defer) found = kba.finish(rand_below);                  // the previous keyframe's pairs: they had a whole cycle
             if (defer) ba.setFrameFromScan(nw, be.ctx(), W - 1, tlb);
-            if (!after_marg) kba.enqueue(nw + 1, kf_poses);
+            if (!after_marg) { if (host_draws) kba.enqueue(nw + 1, kf_poses); else kba.enqueueWithDraws(nw + 1, kf_poses, rand_u64); }
             const double t5b = now_s();
             be.marginalizeAndKeep(&ddt);
             const double t6 = now_s();
-            if (after_marg) kba.enqueue(nw + 1, kf_poses);
+            if (after_marg) { if (host_draws) kba.enqueue(nw + 1, kf_poses); else kba.enqueueWithDraws(nw + 1, kf_poses, rand_u64); }
             if (!defer) found = kba.finish(rand_below);
             const double t7 = now_s();
             if (j == 0) continue;                                        // no prior yet, every first-touch cost: warm-up

@@ -180,8 +180,12 @@ class KeyframeBatchAssociation:
     globalFeatureSelectionAdd_Batch (:4057-4116) keeps batch_feature_res_num records per pair.  The records accumulate in `ba` (a batch.BatchAssociation
     sized for the stream), pair major, exactly what BatchAssociation.run over the same pairs and poses gives; `pairs` / `counts` list them in call order."""
 
-    def __init__(self, ba, search_range=6, feature_res_num=None, rng=None):
+    def __init__(self, ba, search_range=6, feature_res_num=None, rng=None, device_draws=False):
+        """device_draws: the selection's raw draws (res_num uint64 per pair, from `rng`) travel with the enqueue and the selection runs on the association's stream
+        behind the searches (glio_bassoc_select_tail_draws_async) instead of after a host round trip at finish()."""
         self.ba, self.sr, self.res_num, self.rng = ba, search_range, feature_res_num, rng
+        self.device_draws = bool(device_draws) and feature_res_num is not None and rng is not None and 1 <= feature_res_num <= 64
+        self._on_stream = False
         self.pair_ci, self.pair_cj, self.counts = [], [], []
         self._enq = None
 
@@ -212,6 +216,11 @@ class KeyframeBatchAssociation:
         self._first = self.ba.total
         self.ba.run_append(poses, ci, cj, wait=False)
         self._enq = (ci, cj)
+        self._on_stream = False
+        if self.device_draws:
+            raws = np.array([int(self.rng.integers(0, 2 ** 62)) for _ in range(len(js) * self.res_num)], np.uint64)
+            self.ba.select_tail_draws(self.res_num, raws)
+            self._on_stream = True
         return len(js)
 
     def finish(self):
@@ -222,7 +231,9 @@ class KeyframeBatchAssociation:
         self._enq = None
         cnt, total = self.ba.finish()
         found = cnt.copy()
-        if self.res_num is not None and self.rng is not None:
+        if self._on_stream:            # the device applied the rule: everything of a pair with at most res_num records, else res_num (never the last record)
+            cnt = np.array([c if c <= self.res_num else min(self.res_num, c - 1) for c in found.tolist()], np.int64)
+        elif self.res_num is not None and self.rng is not None:
             from .batch import batch_selection_draws
             offs = self._first + np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
             keep, kept = [], cnt.copy()

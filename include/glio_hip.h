@@ -340,6 +340,12 @@ int glio_bassoc_run_append(glio_bassoc* b, const double* poses, int n_pairs, con
 int glio_bassoc_run_append_async(glio_bassoc* b, const double* poses, int n_pairs, const int32_t* pair_ci, const int32_t* pair_cj);
 int glio_bassoc_finish(glio_bassoc* b, int64_t* pair_count_out, int64_t* total_out);
 int glio_bassoc_reset(glio_bassoc* b);
+/* globalFeatureSelectionAdd_Batch (Estimator.cpp:4057-4116) for the pairs of the asynchronous run in flight, ON ITS STREAM (call it right after
+ * glio_bassoc_run_append_async, before glio_bassoc_finish): no host round trip between the searches and the selection.  The draws stay the caller's:
+ * raws = res_num (<= 64) 64-bit numbers per pair of that run, drawn before the counts exist.  A pair with at most res_num records keeps them all; else it
+ * keeps the first res_num of a uniform shuffle of its records but the last (random_generator.hpp:79-93 never draws it): step i swaps position i with
+ * position i + raws[p * res_num + i] mod (count - 1 - i).  glio_bassoc_finish then reports the per-pair counts FOUND and the total HELD after the selection. */
+int glio_bassoc_select_tail_draws_async(glio_bassoc* b, int res_num, const uint64_t* raws);
 /* Optional, ahead of a run whose pairs are known before its poses (batchFeatureAssociation inside a keyframe call: the pairs follow from the keyframe count,
  * the poses from the solve): sends the build descriptors of the run's search frames and clears their hash tables now; the run that follows with the same
  * search frames skips both.  Anything else in between only makes the run do them itself.  Whether a preparation applies follows from what was prepared

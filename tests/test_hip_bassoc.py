@@ -294,3 +294,70 @@ def test_an_asynchronous_runs_counts_survive_side_calls(frames):
     with pytest.raises(capi.GlioError):
         small.run_append(poses, *pairs, wait=False)
     ba.close(); ref.close(); small.close()
+
+
+def test_on_stream_selection_equals_the_host_rule(frames):
+    """glio_bassoc_select_tail_draws_async: globalFeatureSelectionAdd_Batch on the association's stream, behind the searches of an asynchronous run, from raw
+    64-bit draws the caller made before the counts existed.  The records it leaves equal what the host rule (glio::batchSelectionDraws /
+    batch.batch_selection_draws with rand_below(n) = raw mod n, applied to the read-back records) leaves, bit for bit: pairs with at most res_num records keep
+    everything, the others the first res_num of a shuffle that never draws the last record; earlier records of the object stay; the total is updated."""
+    scans, poses = frames
+    K = len(scans)
+    pairs1 = (np.array([2, 2], np.int32), np.array([0, 1], np.int32))
+    pairs2 = (np.array([3, 3, 4, 5], np.int32), np.array([1, 4, 2, 7], np.int32))
+    res = 25
+    rng = np.random.default_rng(77)
+    raws = rng.integers(0, 2 ** 62, len(pairs2[0]) * res, dtype=np.uint64)
+    raws[res:2 * res] = 0                                   # a pair whose every draw is "position i itself"
+    # reference: plain runs, read back, the rule in numpy
+    ref = batch.BatchAssociation(K, 4096, 400000)
+    for k in range(K):
+        ref.set_frame(k, scans[k])
+    ref.reset()
+    c1, t1 = ref.run_append(poses, *pairs1)
+    c2, t2 = ref.run_append(poses, *pairs2)
+    cp, nc, sc = [a.copy() for a in ref.read(0, t2)]
+    keep = list(range(t1))
+    off = t1
+    want_kept = []
+    for p, cnt in enumerate(c2.tolist()):
+        if cnt <= res:
+            sel = list(range(cnt))
+        else:
+            pos = {}
+            sel = []
+            for i in range(min(res, cnt - 1)):
+                j = i + int(raws[p * res + i]) % (cnt - 1 - i)
+                vi, vj = pos.get(i, i), pos.get(j, j)
+                pos[j] = vi
+                sel.append(vj)
+        keep += [off + v for v in sel]; want_kept.append(len(sel)); off += cnt
+    keep = np.array(keep, np.int64)
+    assert min(c2) > res + 1                                # the rule has something to cut
+    # the object under test: the second run asynchronous, the selection behind it on the stream
+    ba = batch.BatchAssociation(K, 4096, 400000)
+    for k in range(K):
+        ba.set_frame(k, scans[k])
+    ba.reset()
+    ba.run_append(poses, *pairs1)
+    assert ba.run_append(poses, *pairs2, wait=False) is None
+    ba.select_tail_draws(res, raws)
+    found, total = ba.finish()
+    assert found.tolist() == c2.tolist() and total == t1 + sum(want_kept) == len(keep)
+    got = ba.read(0, total)
+    for a, b in zip(got, (cp[keep], nc[keep], sc[keep])):
+        assert np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
+    # a pair that holds fewer than res_num records keeps them all: res_num above every count
+    ba.reset()
+    ba.run_append(poses, *pairs2, wait=False)
+    ba.select_tail_draws(64, rng.integers(0, 2 ** 62, len(pairs2[0]) * 64, dtype=np.uint64))
+    found2, total2 = ba.finish()
+    assert found2.tolist() == c2.tolist() and total2 == sum(min(64, c - 1) if c > 64 else c for c in c2.tolist())
+    # the keyframe driver with device draws books res_num per pair and holds exactly that
+    from glio_amd import sliding
+    ba.reset()
+    kd = sliding.KeyframeBatchAssociation(ba, search_range=2, feature_res_num=res, rng=np.random.default_rng(5), device_draws=True)
+    for size in range(4, K + 1):
+        kd.step(size, poses)
+    assert all(c == res for c in kd.counts) and ba.total == res * len(kd.counts) > 0
+    ba.close(); ref.close()

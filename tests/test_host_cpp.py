@@ -142,6 +142,9 @@ def test_cpp_keyframe_stream_equals_the_python_driver(tmp_path):
     path = str(tmp_path / "stream.bin")
     window_io.write_stream(path, long, wins, W, NK, pts)
     got = window_io.run_demo_stream(path, search_range=2)
+    # (the selection on the association's stream from raw draws made before the counts exist: the same pairs found, the same 25 held per pair)
+    got_sd = window_io.run_demo_stream(path, search_range=2, stream_draws=True)
+    assert got_sd["batch_records_found"] == got["batch_records_found"] and got_sd["batch_records_held"] == got["batch_records_held"] and got_sd["iterations"] == got["iterations"]
     ctx = capi.Context(opts)
     ctx.localmap_config(50, 0.4, pts)
     tlb = np.array(opts.t_lb, np.float32)
