@@ -77,7 +77,7 @@ int main(int argc, char** argv) {
         // stream_draws=1: the selection's raw draws travel with the enqueue and globalFeatureSelectionAdd_Batch runs on the association's stream behind the
         // searches (glio_bassoc_select_tail_draws_async).  Default: the host waits for the pair counts, draws, uploads the kept indices and does NOT wait for
         // the gather -- measured faster (1.37 vs 1.40 ms per keyframe: the on-stream form puts a copy and four dependent launches in front of finish()'s wait)
-        bool host_draws = true;
+        bool host_draws = true, prepare_early = true;
         // sleep_ms=N: the host sleeps N ms inside every keyframe call (a 10 Hz caller leaves the GPU idle for ~100 ms between calls; the sleep is not part of
         // any stage time).  sleep_at: 0 = between the batch association's preparation and the solve, 1 = before the call's first entry point, 2 = between the solve and
         // the batch association's enqueue
@@ -89,6 +89,7 @@ int main(int argc, char** argv) {
             else if (!strncmp(argv[a], "timed=", 6)) timed_last = atoi(argv[a] + 6);
             else if (!strncmp(argv[a], "per_slot=", 9)) per_slot = atoi(argv[a] + 9) != 0;
             else if (!strncmp(argv[a], "stream_draws=", 13)) host_draws = atoi(argv[a] + 13) == 0;
+            else if (!strncmp(argv[a], "prepare_early=", 14)) prepare_early = atoi(argv[a] + 14) != 0;
             else if (!strncmp(argv[a], "sleep_ms=", 9)) sleep_ms = atoi(argv[a] + 9);
             else if (!strncmp(argv[a], "sleep_at=", 9)) sleep_at = atoi(argv[a] + 9);
             else if (!strncmp(argv[a], "draws=", 6)) {
@@ -138,13 +139,16 @@ int main(int argc, char** argv) {
             be.setImuFactors(k.pre);
             const double t3a = now_s();
             be.setGnss(&k.frame, k.dd, k.dop);
+            // (the batch association's pairs are known: their search frames' tables are cleared NOW, while the GPU searches and the host would only wait --
+            //  between the counts and the solve the same call cost 15 us of an idle GPU)
+            if (!defer && !after_marg && prepare_early) kba.prepare(nw + 1);
             const double t3b = now_s();
             std::vector<int32_t> counts = be.windowCounts();
             // featureSelection (Estimator.cpp:2223): right behind each slot's search, feature_res_num draws per slot (config_urban_hk.yaml:100: 100)
             // (per_slot=1: W calls of featureSelection() instead of the one window call -- same draws, same records; A/B of the call overhead)
             if (feature_res > 0 && per_slot) for (int s = 0; s < W; ++s) counts[s] = be.featureSelection(s, counts[s], feature_res, rand_below);
             else if (feature_res > 0) be.featureSelectionWindow(counts, feature_res, rand_below);
-            if (!defer && !after_marg) kba.prepare(nw + 1);          // (the pairs are known; their search frames' tables are cleared while the solve runs)
+            if (!defer && !after_marg && !prepare_early) kba.prepare(nw + 1);          // (round 5's place: between the counts and the solve)
             if (sleep_ms > 0 && sleep_at == 0) std::this_thread::sleep_for(std::chrono::milliseconds(sleep_ms));
             const double t4 = now_s();
             const glio_summary sum = be.solve(&ddt);

@@ -15,5 +15,5 @@ with tempfile.TemporaryDirectory() as td:
     window_io.run_demo_stream(path)
     for rep in range(int(os.environ.get("SCM_REPS", "3"))):
         for defer in (False, True):
-            g = window_io.run_demo_stream(path, defer=defer)
+            g = window_io.run_demo_stream(path, defer=defer, prepare_early=os.environ.get('SCM_PREP_EARLY', '1') == '1')
             print(json.dumps({"deferred": defer, "cycle_ms": g["cycle_ms"], "stages": {k: round(v, 3) for k, v in g["stages_ms"].items()}}))
