@@ -2733,8 +2733,7 @@ __device__ __forceinline__ void chain_step_fat_helper(const ChainArgs& a, const 
     double* f_gr = f_D + 48;               // g~ = S g / D
     double* f_G = f_gr + 48;               // g
     double* f_zb = f_G + 48;               // u / S with u = S g~ / D
-    double* f_hd = f_zb + 48;              // H_rr
-    double* f_blk = f_hd + 48;             // [KC_BLK] the block of keyframe i as the chain takes it
+    double* f_blk = f_zb + 48 + 48;        // [KC_BLK] the block of keyframe i as the chain takes it
     double* f_blk2 = f_blk + KC_BLK;       // the same before the epochs' corrections: what t = H u is formed from, while wavefront 0 corrects f_blk
     double* f_bp = f_blk2 + KC_BLK;        // [15][KC_RS] rows 15..29 of block i - 1 (B_{i-1})
     double* f_Vs = f_bp + 16 * KC_RS;      // [nd][30]
@@ -2862,7 +2861,6 @@ __device__ __forceinline__ void chain_step_fat_helper(const ChainArgs& a, const 
         if (fat) {
             // ---- diag(H) and g of the 45 rows (the front of k_chain_step), then the state machine's work vectors and "round 1"
             if (tid >= 384 && tid < 384 + 45) {
-                const int q = tid - 384;
                 double hv = 0, gg = 0;
                 if (rkk >= 0 && rkk < W) {
                     const bool lidp = rlc < 6;
@@ -2887,10 +2885,9 @@ __device__ __forceinline__ void chain_step_fat_helper(const ChainArgs& a, const 
                     const double dd_ = sqrt(d);
                     const double gs = rs * gg;
                     const double grd = gs / dd_;
-                    f_S[16 * rk + rlc] = rs; f_D[16 * rk + rlc] = dd_; f_gr[16 * rk + rlc] = grd; f_G[16 * rk + rlc] = gg; f_hd[16 * rk + rlc] = hv;
+                    f_S[16 * rk + rlc] = rs; f_D[16 * rk + rlc] = dd_; f_gr[16 * rk + rlc] = grd; f_G[16 * rk + rlc] = gg;
                     f_zb[16 * rk + rlc] = (rs * grd / dd_) / rs;
-                } else { f_S[16 * rk + rlc] = 0.0; f_D[16 * rk + rlc] = 1.0; f_gr[16 * rk + rlc] = 0.0; f_G[16 * rk + rlc] = 0.0; f_hd[16 * rk + rlc] = 0.0; f_zb[16 * rk + rlc] = 0.0; }
-                (void)q;
+                } else { f_S[16 * rk + rlc] = 0.0; f_D[16 * rk + rlc] = 1.0; f_gr[16 * rk + rlc] = 0.0; f_G[16 * rk + rlc] = 0.0; f_zb[16 * rk + rlc] = 0.0; }
             }
             // the epoch unknowns: work vectors, then epoch_scalars
             for (int t = t0e + tid; t < t1e; t += KC_THREADS) {
