@@ -40,8 +40,8 @@ struct CtxExtra {
     // early uploads (glio_set_imu, glio_set_gnss): a stream of their own and two pinned blocks with device mirrors, see stage_begin_early
     hipEvent_t ev_copy = nullptr;          // glio_set_scan: the end of the scan's copy (what the call waits for; the presort behind it is not waited for)
     hipStream_t up_stream = nullptr; hipEvent_t ev_up = nullptr;
-    struct UpArena { char* h = nullptr; char* d = nullptr; size_t cap = 0; hipEvent_t ev_free = nullptr; bool pending = false; } up[2];
-    int up_next = 0, up_cur = -1, up_mode = -1;
+    struct UpArena { char* h = nullptr; char* d = nullptr; size_t cap = 0; hipEvent_t ev_free = nullptr; bool pending = false; hipEvent_t ev_copied = nullptr; bool copying = false; } up[2];
+    int up_next = 0, up_cur = -1, up_mode = -1, up_wait = -1;
     char* sv_h = nullptr; char* sv_d = nullptr; size_t sv_cap = 0;
 };
 // the extras hang off the context itself (glio_ctx::extra): no process-global registry, so independent contexts can be
@@ -270,7 +270,7 @@ void glio_destroy(glio_ctx* c) {
     if (CtxExtra* ex = extra_of(c)) {
         if (ex->ev_copy) hipEventDestroy(ex->ev_copy);
         if (ex->up_stream) hipStreamSynchronize(ex->up_stream);
-        for (auto& a : ex->up) { if (a.h) hipHostFree(a.h); if (a.d) hipFree(a.d); if (a.ev_free) hipEventDestroy(a.ev_free); }
+        for (auto& a : ex->up) { if (a.h) hipHostFree(a.h); if (a.d) hipFree(a.d); if (a.ev_free) hipEventDestroy(a.ev_free); if (a.ev_copied) hipEventDestroy(a.ev_copied); }
         if (ex->ev_up) hipEventDestroy(ex->ev_up);
         if (ex->up_stream) hipStreamDestroy(ex->up_stream);
         if (ex->gx.d_runs) hipFree(ex->gx.d_runs);
@@ -570,6 +570,9 @@ static int stage_begin_early(glio_ctx* c, size_t bytes) {
     const int k = ex->up_next;
     CtxExtra::UpArena& a = ex->up[k];
     bytes += STAGE_HEADER + 64 * 34;
+    // the pinned block is written again: its last copy (two uploads ago) has to be through -- it has been for a long time; nothing else is waited for
+    if (a.copying) { GLIO_HIP_CHECK(hipEventSynchronize(a.ev_copied)); a.copying = false; }
+    if (!a.ev_copied) GLIO_HIP_CHECK(hipEventCreateWithFlags(&a.ev_copied, hipEventDisableTiming));
     if (bytes > a.cap) {
         if (a.pending) { GLIO_HIP_CHECK(hipEventSynchronize(a.ev_free)); a.pending = false; }
         if (a.h) hipHostFree(a.h);
@@ -639,7 +642,13 @@ static int stage_flush(glio_ctx* c) {
             e = hipEventRecord(a.ev_free, c->stream);
             a.pending = true;
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(ex->up_stream);          // the copy alone: the pinned block may be written again
+        // the pinned block is this arena's until its next turn (stage_begin_early waits for the copy then): the call does not wait for the copy
+        // (it did, with hipStreamSynchronize on the upload stream: 10-40 us of host time per call while a search kernel fills the chip; GLIO_EARLY_UPLOAD_WAIT=1)
+        if (ex->up_wait < 0) { const char* w = getenv("GLIO_EARLY_UPLOAD_WAIT"); ex->up_wait = (w && atoi(w) != 0) ? 1 : 0; }
+        if (e == hipSuccess) {
+            if (ex->up_wait) e = hipStreamSynchronize(ex->up_stream);
+            else { e = hipEventRecord(a.ev_copied, ex->up_stream); a.copying = true; }
+        }
         stage_end_early(c);
         if (e != hipSuccess) { glio_set_error("early upload: %s", hipGetErrorString(e)); return GLIO_E_HIP; }
         return GLIO_OK;
