@@ -295,6 +295,7 @@ struct GnssLds {
     double sH6[36];                       // the DD part of the pair block, for the chain-layout slices
     double dpart[DD_CHUNK][44];           // per-factor parts of the DD reduction
     double sG6[8];                        // DD gradient part (6), met with the Doppler part in the scatter
+    double sU[92];                        // Doppler sums by UNIQUE entry (78 of the symmetric 12 x 12, 12 of g, the cost), met with their readers in the scatter
     DopRun s_runs[GN_MAX_RUNS];
     int s_nw[DD_CHUNK], s_m[DD_CHUNK];
 };
@@ -336,8 +337,24 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
     const double* R = a.R_ecef_local;
     // thread-private accumulators (thread p owns one entry), summed over factors in fixed order
     double h6 = 0.0, g6 = 0.0, cost_dd = 0.0;       // DD: p<36 -> H6[p]; 36<=p<42 -> g6; p==42 cost
-    double h12 = 0.0, g12 = 0.0, cost_dop = 0.0;    // Doppler: p<144 -> H12[p]; 144<=p<156 -> g12; p==156 cost
+    double dq = 0.0;                                // Doppler: lane 2 e owns unique entry e (78 of H12's upper triangle row by row, 12 of g12, the cost)
 
+    // The Doppler rows of the first chunk are asked for NOW, in the round trip of the DD factors' data: they depend on nothing computed here, and asked for
+    // behind the DD part they were one more round trip (~1.5 us) of the longest role of the launch.  (Scalars only: a copy of the record itself lived in scratch.)
+    struct DopRow { double ratio, var, p0, p1, p2, v0, v1, v2, sv_ddt, doppler, lamda, l0, l1, l2, R0, R1, R2, R3, R4, R5, R6, R7, R8; int epoch; };
+    auto load_row = [&](const glio_doppler& F) {
+        DopRow r;
+        r.ratio = F.ratio; r.var = F.var; r.p0 = F.sat_pos[0]; r.p1 = F.sat_pos[1]; r.p2 = F.sat_pos[2]; r.v0 = F.sat_vel[0]; r.v1 = F.sat_vel[1]; r.v2 = F.sat_vel[2];
+        r.sv_ddt = F.sv_ddt; r.doppler = F.doppler; r.lamda = F.lamda; r.l0 = F.lever_arm[0]; r.l1 = F.lever_arm[1]; r.l2 = F.lever_arm[2];
+        r.R0 = F.R_ecef_local[0]; r.R1 = F.R_ecef_local[1]; r.R2 = F.R_ecef_local[2]; r.R3 = F.R_ecef_local[3]; r.R4 = F.R_ecef_local[4];
+        r.R5 = F.R_ecef_local[5]; r.R6 = F.R_ecef_local[6]; r.R7 = F.R_ecef_local[7]; r.R8 = F.R_ecef_local[8]; r.epoch = F.epoch;
+        return r;
+    };
+    const int dop_cnt0 = min(DOP_CHUNK, gr.dop_end - gr.dop_begin);
+    DopRow rowp = {};
+    if (tid < dop_cnt0) rowp = load_row(a.dop[gr.dop_begin + tid]);
+    double ddt_p = 0.0;          // x[16 W + epoch of the row]: needs the row; asked for behind the DD part's first stage
+    bool ddt_have = false;
     // ---- DD pseudorange factors (dd_psr_factor.hpp:25-171), DD_CHUNK at a time
     for (int f0 = gr.dd_begin; f0 < gr.dd_end; f0 += DD_CHUNK) {
         const int nf = min(DD_CHUNK, gr.dd_end - f0);
@@ -369,6 +386,7 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
         // wavefront-level LDS synchronisation is enough, the workgroup barrier comes only before the factors are added up.
         GLIO_WAVE_LDS_SYNC();
         GN_STAMP(2);
+        if (!ddt_have) { if (tid < dop_cnt0) ddt_p = x[16 * W + rowp.epoch]; ddt_have = true; }
         if (fl < nf) {
             const int ns = s_nw[fl] + 1, m = s_m[fl];
             if (i < ns && i != m) {
@@ -403,19 +421,26 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
         // the factor's own 32 lanes take its 43 entries (36 of H6, 6 of g6, the cost): each a dot product of two columns of the factor's
         // whitened rows; then 43 lanes add the factors' parts in factor order (the association of the sequential formulation: rows
         // inside a factor first, factors after)
-        if (fl < nf) {
-            for (int cb = i; cb < 43; cb += 32) {
-                const int ua = cb < 36 ? cb / 6 : (cb < 42 ? cb - 36 : 6), ub = cb < 36 ? cb % 6 : 6;
-                const int nw = s_nw[fl];
-                double sacc = 0;
-                for (int r2 = 0; r2 < nw; ++r2) sacc += wE[fl][r2 * 8 + ua] * wE[fl][r2 * 8 + ub];
-                lds_.dpart[fl][cb] = sacc;
-            }
+        // (H6 is symmetric and its two halves are the same products added in the same order: 21 + 6 + 1 = 28 UNIQUE entries, one per lane -- 43 entries
+        //  over 32 lanes were two rounds of the row loop)
+        if (fl < nf && i < 28) {
+            int ua, ub;
+            if (i < 21) { ua = 0; int rem = i; while (rem >= 6 - ua) { rem -= 6 - ua; ++ua; } ub = ua + rem; }      // upper triangle, row by row
+            else if (i < 27) { ua = i - 21; ub = 6; }
+            else { ua = 6; ub = 6; }
+            const int nw = s_nw[fl];
+            double sacc = 0;
+            for (int r2 = 0; r2 < nw; ++r2) sacc += wE[fl][r2 * 8 + ua] * wE[fl][r2 * 8 + ub];
+            lds_.dpart[fl][i] = sacc;
         }
         __syncthreads();
         if (tid < 43) {
+            int e;
+            if (tid < 36) { const int r = tid / 6, c2 = tid - 6 * r, lo = min(r, c2), hi = max(r, c2); e = lo * 6 - lo * (lo - 1) / 2 + (hi - lo); }
+            else if (tid < 42) e = 21 + (tid - 36);
+            else e = 27;
             for (int q = 0; q < nf; ++q) {
-                const double sacc = lds_.dpart[q][tid];
+                const double sacc = lds_.dpart[q][e];
                 if (tid < 36) h6 += sacc; else if (tid < 42) g6 += sacc; else cost_dd += 0.5 * sacc;
             }
         }
@@ -431,8 +456,11 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
     for (int c0 = gr.dop_begin; c0 < gr.dop_end; c0 += DOP_CHUNK) {
         const int cnt = min(DOP_CHUNK, gr.dop_end - c0);
         if (tid < cnt) {
-            const glio_doppler& F = a.dop[c0 + tid];
-            const double* Rf = F.R_ecef_local;
+            const bool first = c0 == gr.dop_begin;
+            const DopRow rw = first ? rowp : load_row(a.dop[c0 + tid]);
+            const struct { double ratio, var, sv_ddt, doppler, lamda; double sat_pos[3], sat_vel[3], lever_arm[3]; int epoch; } F =
+                {rw.ratio, rw.var, rw.sv_ddt, rw.doppler, rw.lamda, {rw.p0, rw.p1, rw.p2}, {rw.v0, rw.v1, rw.v2}, {rw.l0, rw.l1, rw.l2}, rw.epoch};
+            const double Rf[9] = {rw.R0, rw.R1, rw.R2, rw.R3, rw.R4, rw.R5, rw.R6, rw.R7, rw.R8};
             double lp[3], lv[3], Pe[3], Ve[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -450,7 +478,7 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
             const double sag = OMG / CLIGHT * (F.sat_vel[0] * Pe[1] + F.sat_pos[0] * Ve[1] - F.sat_vel[1] * Pe[0] - F.sat_pos[1] * Ve[0]);
             const double av[3] = {F.sat_vel[0] - Ve[0], F.sat_vel[1] - Ve[1], F.sat_vel[2] - Ve[2]};
             const double ae = d_dot3_nc(av, eh);
-            const double ddt = x[16 * W + F.epoch];
+            const double ddt = (first && ddt_have) ? ddt_p : x[16 * W + F.epoch];
             const double res = (ae + sag + ddt - F.sv_ddt + F.doppler * F.lamda) / F.var;
             double gP[3], gV[3];
 #pragma unroll
@@ -480,30 +508,35 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
         GN_STAMP(4);
         __syncthreads();
         GN_STAMP(5);
-        // Reduction.  tid < 157 (wavefronts 0..2): dot product of two columns of the row records over ALL rows of the chunk --
-        //   tid < 144: (u, v) -> H12;  144..155: (u, residual) -> g12;  156: (rho, 1) -> 2 cost  -- these sums run over every epoch anyway.
+        // Reduction.  tid < 182: dot products of two columns of the row records over ALL rows of the chunk --
+        //   (u, v) -> H12;  (u, residual) -> g12;  (rho, 1) -> 2 cost  -- these sums run over every epoch anyway.
         // tid 192..247 (wavefront 3, concurrently): the same per EPOCH (run = the rows of one epoch, contiguous), 14 lanes per epoch --
         //   (u, ddt column) -> coupling c[u], u < 12;  (ddt, ddt) -> h;  (ddt, residual) -> g.
-        if (tid < 157) {
-            const int ua = tid < 144 ? tid / 12 : (tid < 156 ? tid - 144 : 14), ub = tid < 144 ? tid % 12 : (tid < 156 ? 13 : 15);
-            double s0 = 0, s1 = 0;
-            int r2 = 0;
-            for (; r2 + 8 <= cnt; r2 += 8) {        // eight rows' reads in flight; the two partial sums keep their even / odd rows
-                double xa[8], xb[8];
+        if (tid < 182) {
+            // 91 UNIQUE entries (78 of the symmetric H12 -- (u, v) and (v, u) are the same products in the same order --, 12 of g12, the cost), two lanes
+            // each: the sums always were two partial sums over the even and the odd rows added at the end; the even lane takes the even rows, its
+            // neighbour the odd ones (157 entries by one lane each read every row twice as long)
+            const int e = tid >> 1, half = tid & 1;
+            int ua, ub;
+            if (e < 78) { ua = 0; int rem = e; while (rem >= 12 - ua) { rem -= 12 - ua; ++ua; } ub = ua + rem; }
+            else if (e < 90) { ua = e - 78; ub = 13; }
+            else { ua = 14; ub = 15; }
+            double sh = 0;
+            int r2 = half;
+            for (; r2 + 6 < cnt; r2 += 8) {         // four rows' reads in flight
+                double xa[4], xb[4];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { xa[u] = dE[(r2 + u) * 16 + ua]; xb[u] = dE[(r2 + u) * 16 + ub]; }
+                for (int u = 0; u < 4; ++u) { xa[u] = dE[(r2 + 2 * u) * 16 + ua]; xb[u] = dE[(r2 + 2 * u) * 16 + ub]; }
 #pragma unroll
-                for (int u = 0; u < 8; u += 2) { s0 += xa[u] * xb[u]; s1 += xa[u + 1] * xb[u + 1]; }
+                for (int u = 0; u < 4; ++u) sh += xa[u] * xb[u];
             }
-            for (; r2 + 2 <= cnt; r2 += 2) { s0 += dE[r2 * 16 + ua] * dE[r2 * 16 + ub]; s1 += dE[(r2 + 1) * 16 + ua] * dE[(r2 + 1) * 16 + ub]; }
-            if (r2 < cnt) s0 += dE[r2 * 16 + ua] * dE[r2 * 16 + ub];
-            const double sacc = s0 + s1;
-            if (tid < 144) h12 += sacc;
-            else if (tid < 156) g12 += sacc;
-            else cost_dop += 0.5 * sacc;
+            for (; r2 < cnt; r2 += 2) sh += dE[r2 * 16 + ua] * dE[r2 * 16 + ub];
+            const double so = __shfl_xor(sh, 1, 64);
+            if (half == 0) { const double sacc = sh + so; dq += e < 90 ? sacc : 0.5 * sacc; }
         } else if (tid >= 192 && tid < 192 + 56) {
             // four epochs side by side, 14 lanes each; an epoch keeps its lanes from chunk to chunk (rl is its index in the group), so a
             // partial sum carried over a chunk boundary stays with the lane that continues it
+            // (five epochs on lanes 182..251: slower -- wavefront 2 then walks both branches)
             const int slot = (tid - 192) / 14, u = (tid - 192) - 14 * slot;     // u 0..11: coupling, 12: h, 13: g
             const int ua = u < 12 ? u : 12, ub = u < 13 ? 12 : 13;
             for (int rl = slot; rl < n_runs; rl += 4) {
@@ -544,7 +577,7 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
     if (tid < 36) lds_.sH6[tid] = h6;
     else if (tid < 42) lds_.sG6[tid - 36] = g6;
     else if (tid == 42) s_cost[0] = cost_dd;
-    if (tid == 156) s_cost[1] = cost_dop;
+    if (tid < 182 && !(tid & 1)) { if ((tid >> 1) < 90) lds_.sU[tid >> 1] = dq; else s_cost[1] = dq; }
     if (pair_H) for (int k = tid; k < GLIO_PAIR_DIM * GLIO_PAIR_DIM; k += SF_THREADS) out->H[k] = 0.0;
     __syncthreads();
     if (tid < 144) {
@@ -552,7 +585,8 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
         const int R = map12[ia], C = map12[ib];
         // position inside the DD 6-vector (t of i, t of j) or -1
         const int a6 = (ia % 6) < 3 ? (ia / 6) * 3 + ia % 6 : -1, b6 = (ib % 6) < 3 ? (ib / 6) * 3 + ib % 6 : -1;
-        double v = h12;
+        const int lo = min(ia, ib), hi = max(ia, ib);
+        double v = lds_.sU[lo * 12 - lo * (lo - 1) / 2 + (hi - lo)];
         if (a6 >= 0 && b6 >= 0) v += lds_.sH6[a6 * 6 + b6];          // Doppler 12 x 12 first, DD 6 x 6 added on top
         if (pair_H) out->H[R * GLIO_PAIR_DIM + C] = v;
         if (chain) {
@@ -566,6 +600,7 @@ __device__ void gnss_block(const SmallArgs& a, const double* __restrict__ x, con
     } else if (tid < 156) {
         const int ia = tid - 144;
         const int a6 = (ia % 6) < 3 ? (ia / 6) * 3 + ia % 6 : -1;
+        const double g12 = lds_.sU[78 + ia];
         out->g[map12[ia]] = a6 >= 0 ? g12 + lds_.sG6[a6] : g12;
     } else if (tid >= 160 && tid < 160 + GLIO_PAIR_DIM) {
         const int k = tid - 160;                     // the 18 entries of g outside (t v of i, t v of j) are zero
@@ -710,19 +745,19 @@ __device__ void prior_H_block(const SmallArgs& a, const double* __restrict__ x, 
     }
 }
 
-__device__ void small_factors_body(const SmallArgs& a);
+__device__ void small_factors_body(const SmallArgs& a, int role);
 __global__ __launch_bounds__(SF_THREADS) void k_small_factors(const SmallArgs a) {
     __builtin_amdgcn_s_setprio(3);      // (O(W) latency-bound workgroups; in the keyframe call they run beside the batch association's wide launches)
 #ifdef GLIO_DEV_STAMPS
     const long long t0 = wall_clock64();
-    small_factors_body(a);
+    small_factors_body(a, (int)blockIdx.x);
     __syncthreads();
     if (threadIdx.x == 0 && a.dbg && blockIdx.x < 250) a.dbg[blockIdx.x] = wall_clock64() - t0;     // scripts/small_time.py
 #else
-    small_factors_body(a);
+    small_factors_body(a, (int)blockIdx.x);
 #endif
 }
-__device__ void small_factors_body(const SmallArgs& a) {
+__device__ void small_factors_body(const SmallArgs& a, const int role) {
     __shared__ __attribute__((aligned(16))) unsigned char pool[sizeof(SmallLds)];
     int which = a.fixed_which;
     if (a.use_status) {
@@ -730,7 +765,7 @@ __device__ void small_factors_body(const SmallArgs& a) {
         which = 1 - a.st->cur;
     }
     const double* x = which ? a.x1 : a.x0;
-    int b = blockIdx.x;          // (the K3 partials are summed by their consumers, k_assemble / k_lidar_reduce: this kernel does not depend on K3)
+    int b = role;                // (the K3 partials are summed by their consumers, k_assemble / k_lidar_reduce: this kernel does not depend on K3)
     if (b < a.n_imu) {
         const int si = a.imu[b].slot_i, sj = si + 1, W = a.W;
         imu_block(a.gravity, x + 3 * si, x + 3 * W + 4 * si, x + 7 * W + 9 * si, x + 3 * sj, x + 3 * W + 4 * sj, x + 7 * W + 9 * sj,
@@ -766,20 +801,22 @@ __global__ __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     static_assert(SF_THREADS == GLIO_K3_THREADS, "one block size for both roles");
     __shared__ __attribute__((aligned(16))) float k3f_tile[F32 ? (GLIO_K3_THREADS / GLIO_WAVE) * K3F_TILE_FLOATS : 4];
     __shared__ double k3f_red[F32 ? (GLIO_K3_THREADS / GLIO_WAVE) * 72 : 1];
+    int b = (int)blockIdx.x;
+    const int role = b < k.n_small ? b : -1;
 #ifdef GLIO_DEV_STAMPS
-    if ((int)blockIdx.x < k.n_small) {          // per-workgroup duration of the small-factor roles (scripts/small_time.py)
+    if (role >= 0) {          // per-workgroup duration of the small-factor roles (scripts/small_time.py)
         const long long t0 = wall_clock64();
-        small_factors_body(a);
+        small_factors_body(a, role);
         __syncthreads();
-        if (threadIdx.x == 0 && a.dbg && blockIdx.x < 190) a.dbg[blockIdx.x] = wall_clock64() - t0;
-        if (threadIdx.x == 0 && a.dbg && blockIdx.x == 0) a.dbg[197] = t0;
+        if (threadIdx.x == 0 && a.dbg && role < 190) a.dbg[role] = wall_clock64() - t0;
+        if (threadIdx.x == 0 && a.dbg && role == 0) a.dbg[197] = t0;
         return;
     }
     // (end of the K3 workgroups: plain stores into 32 slots by workgroup index -- the last writers are the last to finish; no atomics, which would
     //  serialise at the memory side and lengthen what they measure)
     struct K3End { long long* d; __device__ ~K3End() { __syncthreads(); if (threadIdx.x == 0 && d) d[208 + (blockIdx.x & 31)] = wall_clock64(); } } k3end{a.dbg};
 #else
-    if ((int)blockIdx.x < k.n_small) { small_factors_body(a); return; }
+    if (role >= 0) { small_factors_body(a, role); return; }
 #endif
     int which = a.fixed_which;
     if (a.use_status) {
@@ -788,7 +825,8 @@ __global__ __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     // workgroups [skip_lo, skip_hi) stay idle: in dispatch order they would land in the second slot of the CUs that run the
     // small-factor workgroups and slow those (the launch's long pole) down
-    int b = (int)blockIdx.x;
+    // (the small-factor workgroups two to a CU, [0, n/2) and [256, 256 + n/2), and every other slot for K3 -- 22 instead of 19 workgroups per keyframe:
+    //  16.2 us against 12.9; with K3 workgroups in those slots 15.7.  A small-factor workgroup wants its CU alone.)
     if (b >= k.skip_lo && b < k.skip_hi) return;
     b -= k.n_small + (b >= k.skip_hi ? k.skip_hi - k.skip_lo : 0);
     if (b >= k.n_k3) return;
