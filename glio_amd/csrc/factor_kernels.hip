@@ -1216,6 +1216,9 @@ void glio_launch_linearize_all(glio_ctx* c, int use_status_cand, int which, int 
         if (want > GLIO_K3_MAX_BLOCKS_PER_KF) want = GLIO_K3_MAX_BLOCKS_PER_KF;
         if (want > nb) nb = want;
     }
+    // (the launch now lasts as long as K3 on the CUs the small-factor workgroups leave it -- 193 of 256: with the small-factor roles left out altogether it
+    //  takes the same 12.5 us, and K3 alone on the whole chip 9.8.  More K3 workgroups than free slots do not help: from 20 per keyframe on the late ones land
+    //  beside the small-factor workgroups and the launch takes 15.3-15.9 us; 17 per keyframe 13.5.)
     k.nb = nb; k.n_k3 = c->W * nb;
     k.skip_lo = skip ? 256 : 0; k.skip_hi = skip ? 256 + n_small : 0;
     c->last_k3_nb = nb;
