@@ -21,6 +21,7 @@
 template <typename T> static void rd(FILE* f, T* p, size_t n) { if (n && fread(p, sizeof(T), n, f) != n) { fprintf(stderr, "short read\n"); exit(2); } }
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+extern "C" int glio_debug_arrow_stamps(glio_ctx* c, long long* out320);      // debug export of the library (scripts/chain_step_time.py reads the same)
 int main(int argc, char** argv) {
     if (argc < 2) { fprintf(stderr, "usage: host_demo_stream stream.bin [device] [search_range] [defer] [res=N] [draws=FILE] [timed=N]\n"); return 2; }
     FILE* f = fopen(argv[1], "rb");
@@ -203,7 +204,12 @@ int main(int argc, char** argv) {
         for (size_t i = 0; i < last_trans.size(); ++i) printf("%s%.17g", i ? ", " : "", last_trans[i]);
         printf("], \"last_quat\": [");
         for (size_t i = 0; i < last_quat.size(); ++i) printf("%s%.17g", i ? ", " : "", last_quat[i]);
-        printf("], \"trans_checksum\": %.17g}\n", checksum);
+        long long stamps[320] = {0};
+        glio_debug_arrow_stamps(be.ctx(), stamps);
+        long total_iters = 0; for (int v : iters) total_iters += v;
+        // (of the solver steps of the booked keyframes, how many took the helper workgroups' speculative build: slot 300 counts since the context was made,
+        //  the warm-up keyframe included)
+        printf("], \"steps_with_the_helpers_build\": %lld, \"iterations_booked\": %ld, \"trans_checksum\": %.17g}\n", stamps[300], total_iters, checksum);
     } catch (const std::exception& e) {
         fprintf(stderr, "error: %s\n", e.what());
         return 1;
