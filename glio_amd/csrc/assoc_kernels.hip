@@ -401,14 +401,20 @@ struct AssocArgs {
     const int* pair_row;                    // [n_pairs] bin row (inside its chunk) of a pair, or nullptr: every launch row bins for itself
     const int* row_pair;                    // [n_pairs] at pair0 + r: a pair (absolute index) that queries bin row r's cloud
     int bin_pass;                           // 1: the launch is the binning of the chunk's bin rows (blockIdx.y = bin row), 0: blockIdx.y = pair of the chunk
+    // pair mode, tables in the search frames' OWN frames (bassoc local mode): the voxel hash of keyframe cj was built once from its local cloud; its points are
+    // re-posed every run (FrameDesc::sorted, global frame, in the table's order).  Only the GROUPING of the queries changes: a query's cell is the cell of its
+    // position in cj's frame; distances, ranking, the gate and the fit work on the same global-frame floats as ever.
+    int local_tables;
 };
 struct FrameDesc { const int4* ent; const uint4* sub; const float4* sorted; int n, cap_eff; };
 struct AssocSlot { double q[4], t[3]; int n; size_t qoff, woff, boff; const int4* ent; const uint4* sub; const float4* map; size_t locoff; int table_cap;
-                   int brow; };      // brow: the launch row whose grouped queries / units this row searches (itself, unless pairs share their binning)
+                   int brow;         // brow: the launch row whose grouped queries / units this row searches (itself, unless pairs share their binning)
+                   double lq[4], lt[3]; int local; };      // local tables: the search frame's pose (the queries are grouped by their cell in ITS frame)
 __device__ __forceinline__ AssocSlot assoc_slot(const AssocArgs& a) {
     AssocSlot s;
     s.ent = nullptr; s.sub = nullptr; s.map = nullptr; s.locoff = 0; s.table_cap = a.table_cap;
     s.brow = blockIdx.y;
+    s.local = 0;
     if (a.frames) {
         int p = a.pair0 + blockIdx.y;
         if (a.pair_row) {
@@ -426,6 +432,14 @@ __device__ __forceinline__ AssocSlot assoc_slot(const AssocArgs& a) {
         s.qoff = (size_t)ci * a.q_stride; s.woff = (size_t)blockIdx.y * a.w_stride; s.boff = (size_t)blockIdx.y * a.b_stride;
         s.ent = fj.ent; s.sub = fj.sub; s.map = fj.sorted; s.table_cap = fj.cap_eff;
         s.locoff = (size_t)cj * a.q_stride;
+        if (a.local_tables) {
+            const double* Pj = a.poses + 7 * cj;
+            s.local = 1;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) s.lt[i] = Pj[i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s.lq[i] = Pj[3 + i];
+        }
     } else if (a.win_poses) {
         const int k = blockIdx.y;
         const double* P = a.win_poses + 7 * k;
@@ -851,7 +865,17 @@ __global__ __launch_bounds__(QT_THREADS) void k_qbin_tile(const AssocArgs a, con
         double po[3];
         a_qrot(sl.q, pin, po);
         px = (float)(po[0] + sl.t[0]); py = (float)(po[1] + sl.t[1]); pz = (float)(po[2] + sl.t[2]); pw = pl.w;
-        const unsigned long long key = pack_key(cell_of(px, a.inv_cell), cell_of(py, a.inv_cell), cell_of(pz, a.inv_cell));
+        float kx = px, ky = py, kz = pz;            // the position the query is grouped by
+        if (sl.local) {
+            // in the search frame's own frame (its table was built there): R_j^T (p_world - t_j).  Only the grouping depends on it -- a cell edge exceeds
+            // the search radius by 2.5 cm, rounding here is ~1e-6 m
+            const double dw[3] = {(po[0] + sl.t[0]) - sl.lt[0], (po[1] + sl.t[1]) - sl.lt[1], (po[2] + sl.t[2]) - sl.lt[2]};
+            const double qc[4] = {sl.lq[0], -sl.lq[1], -sl.lq[2], -sl.lq[3]};
+            double pl2[3];
+            a_qrot(qc, dw, pl2);
+            kx = (float)pl2[0]; ky = (float)pl2[1]; kz = (float)pl2[2];
+        }
+        const unsigned long long key = pack_key(cell_of(kx, a.inv_cell), cell_of(ky, a.inv_cell), cell_of(kz, a.inv_cell));
         unsigned s = hash_key(key) & (QT_SLOTS - 1);
         for (;;) {
             const unsigned long long prev = atomicCAS(&s_key[s], KEY_EMPTY, key);
@@ -1682,6 +1706,7 @@ static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 struct KnnBinHost { KnnBin d; int rows, cap, capq_max; };
 static unsigned long long* g_knn_dbg = nullptr;      // statistics of the near-block search (glio_debug_knn_stats)
+static int g_bassoc_local = -1;       // batch association, tables in the search frames' own frames: -1 = GLIO_BASSOC_LOCAL_TABLES (default on), test knob glio_debug_set_bassoc_local
 static int g_gbin_cap = 0;            // test knob (glio_debug_set_gbin_cap): cell-table size of the merged-window grouping, 0 = from the map
 static int knn_mode_from_env() { const char* e = getenv("GLIO_KNN_MODE"); const int m = e ? atoi(e) : 0; return m >= 0 && m <= 3 ? m : 0; }      // (A/B of whole programs, e.g. host_demo_stream)
 static int g_knn_mode = knn_mode_from_env();           // 0 = window calls: the queries of all slots grouped by cell together, near block first (k_knn5_near<64>), the rest by
@@ -2158,7 +2183,10 @@ void glio_assoc_time_hooks(glio_ctx* c, int which, int reps, float* ms) {
 struct FrameHash {
     int n, table_cap, cap_eff;
     int4* d_ent; uint4* d_sub;        // resident: what the pair searches read
-    float4* d_sorted;
+    float4* d_sorted;                 // the cloud in the table's order, GLOBAL frame (poses of the last run)
+    // local mode: the table was built from the keyframe's LOCAL cloud (once per cloud, valid whatever the poses do); d_sorted_local is the cloud in that
+    // table's order, d_sorted its re-posed copy of the run
+    float4* d_sorted_local; int local_valid;
 };
 struct glio_bassoc {
     int device; hipStream_t stream;
@@ -2173,7 +2201,8 @@ struct glio_bassoc {
     FrameHash* frames;              // [K]
     int* d_total;                   // scratch of the hash build: [BA_FB]
     unsigned long long* d_bkeys; unsigned* d_bcnt8; int* d_bslot; int* d_brank;      // build scratch of one batch of BA_FB keyframes: [BA_FB][tc], [BA_FB][tc][8], [BA_FB][cap] x 2
-    struct FrameBuild* d_fb; struct FrameBuild* h_fb;       // [K] build descriptors of the keyframes of a run, batch after batch (device / pinned)
+    struct FrameBuild* d_fb; struct FrameBuild* h_fb;       // [2 K] build descriptors of the keyframes of a run, batch after batch (device / pinned); local mode: [0, K) re-posing, [K, 2 K) builds
+    float4* d_sorted_local;         // [K][cap] slab behind FrameHash::d_sorted_local
     // dense per-query results of the pair in flight
     float4* d_q_cp; double* d_q_nc; double* d_q_score; int* d_q_flag; int* d_q_pos; int* d_bcount; int* d_boff;
     int* d_nn5;
@@ -2330,6 +2359,8 @@ int glio_debug_knn_stats(int enable, unsigned long long* out8) {
 
 // test knob: size of the cell table of the merged-window grouping (0 = sized from the map); a tiny table forces the orphan path
 int glio_debug_set_gbin_cap(int cap) { g_gbin_cap = cap < 0 ? 0 : cap; return GLIO_OK; }
+// test knob: 0 = every run hashes its search frames at their poses (the only mode before round 6), 1 = tables in the frames' own frames where the rule allows
+int glio_debug_set_bassoc_local(int on) { g_bassoc_local = on ? 1 : 0; return GLIO_OK; }
 int glio_debug_set_knn_mode(int mode) {
     if (mode < 0 || mode > 3) return GLIO_E_ARG;
     g_knn_mode = mode;
@@ -2357,12 +2388,14 @@ int glio_bassoc_create(int device, int K, int max_points_per_frame, int64_t max_
     const size_t cap = (size_t)b->cap;
     BA_CHECK(hipMalloc((void**)&b->d_local, (size_t)K * cap * 16)); BA_CHECK(hipMalloc((void**)&b->d_global, (size_t)BA_FB * cap * 16));
     BA_CHECK(hipMalloc((void**)&b->d_local_ps, (size_t)K * cap * 16));
+    BA_CHECK(hipMalloc((void**)&b->d_sorted_local, (size_t)K * cap * 16));
     b->h_n = new int[K]();
     b->frames = new FrameHash[K]();
     const int tc = next_pow2(2 * b->cap);
     for (int k = 0; k < K; ++k) {
         FrameHash& f = b->frames[k];
         f.table_cap = tc;
+        f.d_sorted_local = b->d_sorted_local + (size_t)k * cap; f.local_valid = 0;
         BA_CHECK(hipMalloc((void**)&f.d_ent, (size_t)tc * 16)); BA_CHECK(hipMalloc((void**)&f.d_sub, (size_t)tc * 16)); BA_CHECK(hipMalloc((void**)&f.d_sorted, cap * 16));
         // (a keyframe that never serves as a search frame keeps an EMPTY table: the probes of a stray pair end at once)
         BA_CHECK(hipMemsetAsync(f.d_ent, 0xff, (size_t)tc * 16, b->stream));
@@ -2370,7 +2403,7 @@ int glio_bassoc_create(int device, int K, int max_points_per_frame, int64_t max_
     BA_CHECK(hipMalloc((void**)&b->d_total, (size_t)BA_FB * 4));
     BA_CHECK(hipMalloc((void**)&b->d_bkeys, (size_t)BA_FB * tc * 8)); BA_CHECK(hipMalloc((void**)&b->d_bcnt8, (size_t)BA_FB * tc * 32));
     BA_CHECK(hipMalloc((void**)&b->d_bslot, (size_t)BA_FB * cap * 4)); BA_CHECK(hipMalloc((void**)&b->d_brank, (size_t)BA_FB * cap * 4));
-    BA_CHECK(hipMalloc((void**)&b->d_fb, (size_t)K * sizeof(FrameBuild))); BA_CHECK(hipHostMalloc((void**)&b->h_fb, (size_t)K * sizeof(FrameBuild)));
+    BA_CHECK(hipMalloc((void**)&b->d_fb, (size_t)2 * K * sizeof(FrameBuild))); BA_CHECK(hipHostMalloc((void**)&b->h_fb, (size_t)2 * K * sizeof(FrameBuild)));
     // dense per-query work arrays for a chunk of BA_CHUNK pairs (104 B per query and pair)
     const size_t wc = cap * BA_CHUNK;
     b->b_stride = (int)(cap / PF_BLOCK + 2);
@@ -2401,7 +2434,7 @@ void glio_bassoc_destroy(glio_bassoc* b) {
         void* p[] = {f.d_ent, f.d_sub, f.d_sorted};
         for (void* q : p) if (q) hipFree(q);
     }
-    void* p[] = {b->d_bkeys, b->d_bcnt8, b->d_bslot, b->d_brank, b->d_nn5, b->d_local, b->d_local_ps, b->d_global, b->d_total, b->d_q_cp, b->d_q_nc, b->d_q_score, b->d_q_flag, b->d_q_pos, b->d_bcount, b->d_boff,
+    void* p[] = {b->d_bkeys, b->d_bcnt8, b->d_bslot, b->d_brank, b->d_nn5, b->d_local, b->d_local_ps, b->d_sorted_local, b->d_global, b->d_total, b->d_q_cp, b->d_q_nc, b->d_q_score, b->d_q_flag, b->d_q_pos, b->d_bcount, b->d_boff,
                  b->d_cp, b->d_nc, b->d_score, b->d_run, b->d_poses, b->d_pair_off, b->d_frames, b->d_pair_ci, b->d_pair_cj, b->d_pair_row, b->d_row_pair,
                  b->d_sel_cp, b->d_sel_nc, b->d_sel_score, b->d_sel_idx};
     for (void* q : p) if (q) hipFree(q);
@@ -2439,6 +2472,7 @@ int glio_bassoc_set_frame_strided(glio_bassoc* b, int k, const void* scan, int n
     BA_CHECK(hipGetLastError());
     BA_CHECK(hipStreamSynchronize(b->stream));
     b->h_n[k] = n;
+    b->frames[k].local_valid = 0;
     return GLIO_OK;
 }
 
@@ -2498,6 +2532,50 @@ static int bassoc_fb_uploaded(glio_bassoc* b) {
     b->fb_in_flight = 1;
     return GLIO_OK;
 }
+// ---- LOCAL mode.  A run hashes every search frame at its pose of the run: 12 builds (clear, tile insert, cell allocation, scatter: 127 us of the 490 us chain)
+// in every keyframe call, for clouds that never change.  In local mode a keyframe's table is built ONCE, from its local cloud; a run re-poses the table's
+// points (one streaming launch for all search frames) and groups every pair's queries by their cell in the search frame's own frame (k_qbin_tile,
+// AssocArgs::local_tables) -- the pairs of a keyframe can then no longer share one grouping, which is why runs with many pairs per search frame (the batch
+// stage's pair list: 12 per keyframe, each table built once per run anyway) stay in the global mode.  Same records, bit for bit: the candidates of a query
+// are the 27 cells around its cell in either frame, both cover the ball of the search radius, and distances, ranking and gate read the same global floats.
+static bool bassoc_local_mode(const glio_bassoc* b, const int n_pairs, const int n_need, const double* poses, const std::vector<char>& need) {
+    if (g_bassoc_local < 0) g_bassoc_local = (getenv("GLIO_BASSOC_LOCAL_TABLES") && atoi(getenv("GLIO_BASSOC_LOCAL_TABLES")) == 0) ? 0 : 1;
+    if (!g_bassoc_local || g_knn_mode != 0 || n_need == 0 || n_pairs >= 4 * n_need) return false;
+    if (poses)       // (the grouping inverts the pose with the conjugate: unit quaternions only; anything else takes the global mode)
+        for (int k = 0; k < b->K; ++k) if (need[k]) {
+            const double* q = poses + 7 * k + 3;
+            const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+            if (!(fabs(n2 - 1.0) < 1e-9)) return false;
+        }
+    return true;
+}
+// the local tables that are missing among `need`: descriptors h_fb[K + ..] (the caller has made the pinned block reusable), upload, build.  *wrote: the block was written
+static int bassoc_build_local(glio_bassoc* b, const std::vector<char>& need, bool* wrote) {
+    std::vector<int> todo;
+    for (int k = 0; k < b->K; ++k) if (need[k] && !b->frames[k].local_valid) todo.push_back(k);
+    for (size_t t0 = 0; t0 < todo.size(); t0 += BA_FB) {
+        const int nb = (int)std::min<size_t>(BA_FB, todo.size() - t0);
+        int max_tc = 0, max_n = 0;
+        bassoc_fill_batch(b, todo.data() + t0, (size_t)b->K + t0, nb, &max_tc, &max_n);
+        for (int q = 0; q < nb; ++q) {
+            FrameBuild& d = b->h_fb[(size_t)b->K + t0 + q];
+            const int k = todo[t0 + q];
+            d.global = b->d_local_ps + (size_t)k * b->cap;            // (what is hashed: the presorted LOCAL cloud itself; nothing is transformed)
+            d.sorted = b->frames[k].d_sorted_local;
+        }
+        const FrameBuild* dfb = b->d_fb + b->K + t0;
+        BA_CHECK(hipMemcpyAsync(b->d_fb + b->K + t0, b->h_fb + b->K + t0, (size_t)nb * sizeof(FrameBuild), hipMemcpyHostToDevice, b->stream));
+        *wrote = true;
+        hipLaunchKernelGGL(k_hash_clear_multi, dim3((max_tc + 255) / 256, nb), dim3(256), 0, b->stream, dfb);
+        if (max_n > 0) {
+            hipLaunchKernelGGL(k_hash_insert_multi, dim3((max_n + HI_THREADS - 1) / HI_THREADS, nb), dim3(HI_THREADS), 0, b->stream, dfb, b->inv_cell);
+            hipLaunchKernelGGL(k_cell_alloc_multi, dim3((max_tc + 1023) / 1024, nb), dim3(1024), 0, b->stream, dfb);
+            hipLaunchKernelGGL(k_scatter_multi, dim3((max_n + 255) / 256, nb), dim3(256), 0, b->stream, dfb);
+        }
+        for (int q = 0; q < nb; ++q) b->frames[todo[t0 + q]].local_valid = 1;
+    }
+    return GLIO_OK;
+}
 // What a run does before it needs the poses: the build descriptors of its (first batch of) search frames go to the device and their hash tables are
 // cleared.  A caller that knows its pairs before it knows its poses (batchFeatureAssociation of a keyframe call: the pairs follow from the keyframe
 // count, the poses from the solve) calls this first; the run that follows with the same search frames skips both (0.02 ms off the start of the
@@ -2509,17 +2587,25 @@ extern "C" int glio_bassoc_prepare_async(glio_bassoc* b, int n_pairs, const int3
     b->prep_nb = 0;
     std::vector<char> need(b->K, 0);
     for (int p = 0; p < n_pairs; ++p) { if (pair_cj[p] < 0 || pair_cj[p] >= b->K) { glio_set_error("bad pair %d", p); return GLIO_E_ARG; } need[pair_cj[p]] = 1; }
-    int todo[BA_FB], nb = 0;
-    for (int k = 0; k < b->K && nb < BA_FB; ++k) if (need[k]) todo[nb++] = k;
+    int todo[BA_FB], nb = 0, n_need = 0;
+    for (int k = 0; k < b->K; ++k) if (need[k]) { if (nb < BA_FB) todo[nb++] = k; ++n_need; }
     if (nb == 0) return GLIO_OK;
     int max_tc = 0, max_n = 0;
     { const int rw = bassoc_fb_reusable(b); if (rw != GLIO_OK) return rw; }
+    if (bassoc_local_mode(b, n_pairs, n_need, nullptr, need)) {
+        // local mode: nothing of a run's tables depends on the poses -- the missing ones (the newest keyframe's) are BUILT now, the run only re-poses
+        bool wrote = false;
+        { const int rb = bassoc_build_local(b, need, &wrote); if (rb != GLIO_OK) return rb; }
+        if (wrote) { const int rw = bassoc_fb_uploaded(b); if (rw != GLIO_OK) return rw; }
+        BA_CHECK(hipGetLastError());
+        return GLIO_OK;
+    }
     bassoc_fill_batch(b, todo, 0, nb, &max_tc, &max_n);
     BA_CHECK(hipMemcpyAsync(b->d_fb, b->h_fb, (size_t)nb * sizeof(FrameBuild), hipMemcpyHostToDevice, b->stream));
     { const int rw = bassoc_fb_uploaded(b); if (rw != GLIO_OK) return rw; }
     hipLaunchKernelGGL(k_hash_clear_multi, dim3((max_tc + 255) / 256, nb), dim3(256), 0, b->stream, static_cast<const FrameBuild*>(b->d_fb));
     BA_CHECK(hipGetLastError());
-    for (int q = 0; q < nb; ++q) { b->prep_todo[q] = todo[q]; b->prep_n[q] = b->h_n[todo[q]]; b->prep_tc[q] = b->h_fb[q].tc; }
+    for (int q = 0; q < nb; ++q) { b->prep_todo[q] = todo[q]; b->prep_n[q] = b->h_n[todo[q]]; b->prep_tc[q] = b->h_fb[q].tc; b->frames[todo[q]].local_valid = 0; }
     b->prep_nb = nb;
     return GLIO_OK;
 }
@@ -2557,9 +2643,28 @@ static int bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const in
     // (1) every keyframe that occurs as a search frame: cloud -> global frame -> voxel hash
     std::vector<char> need(b->K, 0);
     for (int p = 0; p < n_pairs; ++p) need[pair_cj[p]] = 1;
-    {
+    int n_need = 0;
+    for (int k = 0; k < b->K; ++k) n_need += need[k] ? 1 : 0;
+    const bool local = bassoc_local_mode(b, n_pairs, n_need, poses, need);
+    if (local) {
+        b->prep_nb = 0;
+        { const int rw = bassoc_fb_reusable(b); if (rw != GLIO_OK) return rw; }
+        bool wrote = false;
+        { const int rb = bassoc_build_local(b, need, &wrote); if (rb != GLIO_OK) return rb; }
+        // every search frame's points at its pose of this run, in its table's order: one launch (k_transform_cloud_multi reads .local, writes .global)
+        int nt = 0, max_n = 0;
+        for (int k = 0; k < b->K; ++k) if (need[k]) {
+            FrameBuild& d = b->h_fb[nt++];
+            memset(&d, 0, sizeof d);
+            d.local = b->frames[k].d_sorted_local; d.global = b->frames[k].d_sorted; d.pose = b->d_poses + 7 * k; d.n = b->h_n[k];
+            if (d.n > max_n) max_n = d.n;
+        }
+        BA_CHECK(hipMemcpyAsync(b->d_fb, b->h_fb, (size_t)nt * sizeof(FrameBuild), hipMemcpyHostToDevice, b->stream));
+        { const int rw = bassoc_fb_uploaded(b); if (rw != GLIO_OK) return rw; }
+        if (max_n > 0) hipLaunchKernelGGL(k_transform_cloud_multi, dim3((max_n + 255) / 256, nt), dim3(256), 0, b->stream, static_cast<const FrameBuild*>(b->d_fb));
+    } else {
         std::vector<int> todo;
-        for (int k = 0; k < b->K; ++k) if (need[k]) todo.push_back(k);
+        for (int k = 0; k < b->K; ++k) if (need[k]) { todo.push_back(k); b->frames[k].local_valid = 0; }      // (the global build overwrites the table)
         bool fb_checked = false, fb_written = false;
         for (size_t t0 = 0; t0 < todo.size(); t0 += BA_FB) {
             const int nb = (int)std::min<size_t>(BA_FB, todo.size() - t0);
@@ -2621,7 +2726,8 @@ static int bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const in
                 chunk_rows[(size_t)p0 / BA_CHUNK] = nr;
             }
         }
-        static const bool share_bins = !(getenv("GLIO_BASSOC_SHARED_BINS") && atoi(getenv("GLIO_BASSOC_SHARED_BINS")) == 0);      // (0: every pair bins for itself -- A/B and tests)
+        static const bool share_env = !(getenv("GLIO_BASSOC_SHARED_BINS") && atoi(getenv("GLIO_BASSOC_SHARED_BINS")) == 0);      // (0: every pair bins for itself -- A/B and tests)
+        const bool share_bins = share_env && !local;       // (local tables: a pair's queries are grouped by their cell in ITS search frame)
         BA_CHECK(hipMemcpyAsync(b->d_frames, b->h_fd, (size_t)b->K * sizeof(FrameDesc), hipMemcpyHostToDevice, b->stream));
         BA_CHECK(hipMemcpyAsync(b->d_pair_ci, b->h_pairs, (size_t)n_pairs * 4, hipMemcpyHostToDevice, b->stream));
         BA_CHECK(hipMemcpyAsync(b->d_pair_cj, b->h_pairs + b->max_pairs, (size_t)n_pairs * 4, hipMemcpyHostToDevice, b->stream));
@@ -2633,6 +2739,7 @@ static int bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const in
         a.unit_scores = 0;
         a.q_stride = b->cap; a.w_stride = b->cap; a.b_stride = b->b_stride;
         a.frames = b->d_frames; a.pair_ci = b->d_pair_ci; a.pair_cj = b->d_pair_cj; a.poses = b->d_poses;
+        a.local_tables = local ? 1 : 0;
         for (int p0 = 0; p0 < n_pairs; p0 += BA_CHUNK) {
             const int np = n_pairs - p0 < BA_CHUNK ? n_pairs - p0 : BA_CHUNK;
             a.pair0 = p0;
@@ -2715,6 +2822,7 @@ int glio_bassoc_set_frame_from_scan(glio_bassoc* b, int k, glio_ctx* c, int slot
     }
     BA_CHECK(hipGetLastError());
     b->h_n[k] = n;
+    b->frames[k].local_valid = 0;
     return GLIO_OK;
 }
 

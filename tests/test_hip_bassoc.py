@@ -361,3 +361,57 @@ def test_on_stream_selection_equals_the_host_rule(frames):
         kd.step(size, poses)
     assert all(c == res for c in kd.counts) and ba.total == res * len(kd.counts) > 0
     ba.close(); ref.close()
+
+
+def test_tables_in_the_frames_own_frames_give_the_same_records(frames):
+    """Local mode (runs with few pairs per search frame: a keyframe call's 2 search_range pairs): a keyframe's voxel hash is built once from its LOCAL cloud, a run
+    re-poses the table's points and groups each pair's queries by their cell in the search frame's own frame.  Against the global mode (every run hashes its
+    search frames at their poses), bit for bit: the same pairs at three sets of poses one after the other (the tables survive, the points are re-posed), a cloud
+    replaced in between (its table is rebuilt), a search frame with an empty cloud, a quaternion that is not of unit length (the run takes the global mode by itself)."""
+    from glio_amd import capi
+    scans, poses = frames
+    K = len(scans)
+    lib = capi.load()
+    ci = np.array([5, 5, 5, 5, 6, 6, 6], np.int32); cj = np.array([1, 2, 3, 4, 2, 3, 7], np.int32)      # 7 pairs over 6 search frames: local where allowed
+    rng = np.random.default_rng(11)
+
+    def jitter(p, s):
+        q = p.copy()
+        q[:, :3] += rng.normal(0, s, (K, 3))
+        dq = np.c_[np.ones(K), rng.normal(0, s * 0.2, (K, 3))]
+        w0, v0 = q[:, 3:4].copy(), q[:, 4:7].copy()
+        w1, v1 = dq[:, 0:1], dq[:, 1:4]
+        qq = np.c_[w0 * w1 - (v0 * v1).sum(1, keepdims=True), w0 * v1 + w1 * v0 + np.cross(v0, v1)]
+        q[:, 3:7] = qq / np.linalg.norm(qq, axis=1, keepdims=True)
+        return q
+
+    pose_sets = [poses, jitter(poses, 0.05), jitter(poses, 0.3)]
+    scaled = poses.copy(); scaled[2, 3:7] *= 1.0005                           # not a unit quaternion: the conjugate does not invert it
+    alt = scans[3][::-1].copy()
+    out = {}
+    try:
+        for mode in (0, 1):
+            lib.glio_debug_set_bassoc_local(mode)
+            ba = batch.BatchAssociation(K, 4096, 400000)
+            for k in range(K):
+                ba.set_frame(k, scans[k])
+            got = []
+            for P in pose_sets:
+                counts, total = ba.run(P, ci, cj)
+                got.append((counts.tolist(), [a.copy() for a in ba.read()]))
+            ba.set_frame(3, alt)                                               # another cloud (same points, another order) in a search frame
+            counts, total = ba.run(pose_sets[1], ci, cj); got.append((counts.tolist(), [a.copy() for a in ba.read()]))
+            ba.set_frame(2, scans[2][:0])                                      # an empty search frame
+            counts, total = ba.run(pose_sets[1], ci, cj); got.append((counts.tolist(), [a.copy() for a in ba.read()]))
+            ba.set_frame(2, scans[2])
+            counts, total = ba.run(scaled, ci, cj); got.append((counts.tolist(), [a.copy() for a in ba.read()]))
+            counts, total = ba.run(poses, ci, cj); got.append((counts.tolist(), [a.copy() for a in ba.read()]))
+            out[mode] = got
+            ba.close()
+    finally:
+        lib.glio_debug_set_bassoc_local(1)
+    assert sum(out[0][0][0]) > 500 and out[0][0][0] != out[0][2][0]            # the poses matter
+    for step, (g0, g1) in enumerate(zip(out[0], out[1])):
+        assert g0[0] == g1[0], step
+        for a, b in zip(g0[1], g1[1]):
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), step
