@@ -2203,6 +2203,9 @@ struct glio_bassoc {
     unsigned long long* d_bkeys; unsigned* d_bcnt8; int* d_bslot; int* d_brank;      // build scratch of one batch of BA_FB keyframes: [BA_FB][tc], [BA_FB][tc][8], [BA_FB][cap] x 2
     struct FrameBuild* d_fb; struct FrameBuild* h_fb;       // [2 K] build descriptors of the keyframes of a run, batch after batch (device / pinned); local mode: [0, K) re-posing, [K, 2 K) builds
     float4* d_sorted_local;         // [K][cap] slab behind FrameHash::d_sorted_local
+    // local mode: everything a run sends ahead of its kernels -- poses [K][7], re-posing descriptors [K], frame descriptors [K], four pair arrays [4 K] each --
+    // as ONE pinned block and ONE copy (they were eight copies of a few hundred bytes, ~9 us of stream time each, in front of the searches of every keyframe call)
+    char* h_inbox; char* d_inbox; size_t inbox_bytes;
     // dense per-query results of the pair in flight
     float4* d_q_cp; double* d_q_nc; double* d_q_score; int* d_q_flag; int* d_q_pos; int* d_bcount; int* d_boff;
     int* d_nn5;
@@ -2389,6 +2392,8 @@ int glio_bassoc_create(int device, int K, int max_points_per_frame, int64_t max_
     BA_CHECK(hipMalloc((void**)&b->d_local, (size_t)K * cap * 16)); BA_CHECK(hipMalloc((void**)&b->d_global, (size_t)BA_FB * cap * 16));
     BA_CHECK(hipMalloc((void**)&b->d_local_ps, (size_t)K * cap * 16));
     BA_CHECK(hipMalloc((void**)&b->d_sorted_local, (size_t)K * cap * 16));
+    b->inbox_bytes = (size_t)K * (7 * 8 + sizeof(FrameBuild) + sizeof(FrameDesc)) + (size_t)4 * 4 * K * 4 + 64;
+    BA_CHECK(hipMalloc((void**)&b->d_inbox, b->inbox_bytes)); BA_CHECK(hipHostMalloc((void**)&b->h_inbox, b->inbox_bytes));
     b->h_n = new int[K]();
     b->frames = new FrameHash[K]();
     const int tc = next_pow2(2 * b->cap);
@@ -2441,6 +2446,8 @@ void glio_bassoc_destroy(glio_bassoc* b) {
     knn_bin_destroy(b->kb);
     if (b->d_fb) hipFree(b->d_fb);
     if (b->h_fb) hipHostFree(b->h_fb);
+    if (b->d_inbox) hipFree(b->d_inbox);
+    if (b->h_inbox) hipHostFree(b->h_inbox);
     if (b->h_pair_off) hipHostFree(b->h_pair_off);
     if (b->h_pairs) hipHostFree(b->h_pairs);
     if (b->h_tail) hipHostFree(b->h_tail);
@@ -2635,34 +2642,57 @@ static int bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const in
         BA_CHECK(hipHostMalloc((void**)&b->h_pairs, (size_t)b->max_pairs * 16));
     }
     const long long first_before = append ? b->h_tail[0] : 0;      // the records held before this run (every earlier run was drained above: h_tail is settled)
-    memcpy(b->h_poses, poses, (size_t)b->K * 7 * 8);
-    BA_CHECK(hipMemcpyAsync(b->d_poses, b->h_poses, (size_t)b->K * 7 * 8, hipMemcpyHostToDevice, b->stream));
-    if (append) BA_CHECK(hipMemsetAsync(b->d_run + 1, 0, 8, b->stream));
-    else BA_CHECK(hipMemsetAsync(b->d_run, 0, 16, b->stream));
-    int* d_overflow = reinterpret_cast<int*>(b->d_run + 1);
     // (1) every keyframe that occurs as a search frame: cloud -> global frame -> voxel hash
     std::vector<char> need(b->K, 0);
     for (int p = 0; p < n_pairs; ++p) need[pair_cj[p]] = 1;
     int n_need = 0;
     for (int k = 0; k < b->K; ++k) n_need += need[k] ? 1 : 0;
     const bool local = bassoc_local_mode(b, n_pairs, n_need, poses, need);
+    // what the kernels of this run index: the object's tables, or (local mode) the run's one block
+    const double* d_poses_run = b->d_poses;
+    const FrameDesc* d_frames_run = b->d_frames;
+    const int* d_ci_run = b->d_pair_ci; const int* d_cj_run = b->d_pair_cj;
     if (local) {
+        // [poses K x 7 | re-posing descriptors K | frame descriptors K | pair_ci | pair_cj]: filled, sent once (the previous run was drained above: the pinned
+        // block is free)
+        const size_t o_fb = (size_t)b->K * 56, o_fd = o_fb + (size_t)b->K * sizeof(FrameBuild), o_ci = o_fd + (size_t)b->K * sizeof(FrameDesc), o_cj = o_ci + (size_t)n_pairs * 4;
+        const size_t used = o_cj + (size_t)n_pairs * 4;
+        if (used > b->inbox_bytes) { glio_set_error("batch association: run block too small"); return GLIO_E_STATE; }
+        double* hp = reinterpret_cast<double*>(b->h_inbox);
+        FrameBuild* hfb = reinterpret_cast<FrameBuild*>(b->h_inbox + o_fb);
+        FrameDesc* hfd = reinterpret_cast<FrameDesc*>(b->h_inbox + o_fd);
+        int32_t* hci = reinterpret_cast<int32_t*>(b->h_inbox + o_ci); int32_t* hcj = reinterpret_cast<int32_t*>(b->h_inbox + o_cj);
+        d_poses_run = reinterpret_cast<const double*>(b->d_inbox);
+        d_frames_run = reinterpret_cast<const FrameDesc*>(b->d_inbox + o_fd);
+        d_ci_run = reinterpret_cast<const int*>(b->d_inbox + o_ci); d_cj_run = reinterpret_cast<const int*>(b->d_inbox + o_cj);
         b->prep_nb = 0;
         { const int rw = bassoc_fb_reusable(b); if (rw != GLIO_OK) return rw; }
         bool wrote = false;
-        { const int rb = bassoc_build_local(b, need, &wrote); if (rb != GLIO_OK) return rb; }
+        { const int rb = bassoc_build_local(b, need, &wrote); if (rb != GLIO_OK) return rb; }      // (only what glio_bassoc_prepare_async has not built already)
+        if (wrote) { const int rw = bassoc_fb_uploaded(b); if (rw != GLIO_OK) return rw; }
+        memcpy(hp, poses, (size_t)b->K * 56);
         // every search frame's points at its pose of this run, in its table's order: one launch (k_transform_cloud_multi reads .local, writes .global)
         int nt = 0, max_n = 0;
-        for (int k = 0; k < b->K; ++k) if (need[k]) {
-            FrameBuild& d = b->h_fb[nt++];
+        for (int k = 0; k < b->K; ++k) {
+            FrameDesc& fd = hfd[k];
+            fd.ent = b->frames[k].d_ent; fd.sub = b->frames[k].d_sub; fd.sorted = b->frames[k].d_sorted; fd.n = b->h_n[k];
+            fd.cap_eff = need[k] ? b->frames[k].cap_eff : b->frames[k].table_cap;
+            if (!need[k]) continue;
+            FrameBuild& d = hfb[nt++];
             memset(&d, 0, sizeof d);
-            d.local = b->frames[k].d_sorted_local; d.global = b->frames[k].d_sorted; d.pose = b->d_poses + 7 * k; d.n = b->h_n[k];
+            d.local = b->frames[k].d_sorted_local; d.global = b->frames[k].d_sorted; d.pose = d_poses_run + 7 * k; d.n = b->h_n[k];
             if (d.n > max_n) max_n = d.n;
         }
-        BA_CHECK(hipMemcpyAsync(b->d_fb, b->h_fb, (size_t)nt * sizeof(FrameBuild), hipMemcpyHostToDevice, b->stream));
-        { const int rw = bassoc_fb_uploaded(b); if (rw != GLIO_OK) return rw; }
-        if (max_n > 0) hipLaunchKernelGGL(k_transform_cloud_multi, dim3((max_n + 255) / 256, nt), dim3(256), 0, b->stream, static_cast<const FrameBuild*>(b->d_fb));
+        for (int p = 0; p < n_pairs; ++p) { hci[p] = pair_ci[p]; hcj[p] = pair_cj[p]; }
+        BA_CHECK(hipMemcpyAsync(b->d_inbox, b->h_inbox, used, hipMemcpyHostToDevice, b->stream));
+        if (append) BA_CHECK(hipMemsetAsync(b->d_run + 1, 0, 8, b->stream));
+        else BA_CHECK(hipMemsetAsync(b->d_run, 0, 16, b->stream));
+        if (max_n > 0) hipLaunchKernelGGL(k_transform_cloud_multi, dim3((max_n + 255) / 256, nt), dim3(256), 0, b->stream, reinterpret_cast<const FrameBuild*>(b->d_inbox + o_fb));
     } else {
+        memcpy(b->h_poses, poses, (size_t)b->K * 7 * 8);
+        BA_CHECK(hipMemcpyAsync(b->d_poses, b->h_poses, (size_t)b->K * 7 * 8, hipMemcpyHostToDevice, b->stream));
+        if (append) BA_CHECK(hipMemsetAsync(b->d_run + 1, 0, 8, b->stream));
+        else BA_CHECK(hipMemsetAsync(b->d_run, 0, 16, b->stream));
         std::vector<int> todo;
         for (int k = 0; k < b->K; ++k) if (need[k]) { todo.push_back(k); b->frames[k].local_valid = 0; }      // (the global build overwrites the table)
         bool fb_checked = false, fb_written = false;
@@ -2699,14 +2729,18 @@ static int bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const in
         if (fb_written) { const int rw = bassoc_fb_uploaded(b); if (rw != GLIO_OK) return rw; }
     }
     // (2) the pairs, in the caller's (ci, cj) order, BA_CHUNK pairs per launch (blockIdx.y = pair of the chunk)
+    int* d_overflow = reinterpret_cast<int*>(b->d_run + 1);
     if (n_pairs > 0) {
         int maxn = 0;
+        for (int p = 0; p < n_pairs; ++p) if (b->h_n[pair_ci[p]] > maxn) maxn = b->h_n[pair_ci[p]];
+        if (!local) {
         for (int k = 0; k < b->K; ++k) {
             FrameDesc& fd = b->h_fd[k];
             fd.ent = b->frames[k].d_ent; fd.sub = b->frames[k].d_sub; fd.sorted = b->frames[k].d_sorted; fd.n = b->h_n[k];
             fd.cap_eff = need[k] ? b->frames[k].cap_eff : b->frames[k].table_cap;
         }
-        for (int p = 0; p < n_pairs; ++p) { b->h_pairs[p] = pair_ci[p]; b->h_pairs[b->max_pairs + p] = pair_cj[p]; if (b->h_n[pair_ci[p]] > maxn) maxn = b->h_n[pair_ci[p]]; }
+        for (int p = 0; p < n_pairs; ++p) { b->h_pairs[p] = pair_ci[p]; b->h_pairs[b->max_pairs + p] = pair_cj[p]; }
+        }
         // shared query binning: per chunk, the distinct source keyframes in order of first appearance (their pairs usually follow each other: a linear look-back
         // over the chunk's rows, at most BA_CHUNK of them)
         std::vector<int> chunk_rows((size_t)(n_pairs + BA_CHUNK - 1) / BA_CHUNK, 0);
@@ -2728,17 +2762,19 @@ static int bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const in
         }
         static const bool share_env = !(getenv("GLIO_BASSOC_SHARED_BINS") && atoi(getenv("GLIO_BASSOC_SHARED_BINS")) == 0);      // (0: every pair bins for itself -- A/B and tests)
         const bool share_bins = share_env && !local;       // (local tables: a pair's queries are grouped by their cell in ITS search frame)
+        if (!local) {
         BA_CHECK(hipMemcpyAsync(b->d_frames, b->h_fd, (size_t)b->K * sizeof(FrameDesc), hipMemcpyHostToDevice, b->stream));
         BA_CHECK(hipMemcpyAsync(b->d_pair_ci, b->h_pairs, (size_t)n_pairs * 4, hipMemcpyHostToDevice, b->stream));
         BA_CHECK(hipMemcpyAsync(b->d_pair_cj, b->h_pairs + b->max_pairs, (size_t)n_pairs * 4, hipMemcpyHostToDevice, b->stream));
         BA_CHECK(hipMemcpyAsync(b->d_pair_row, b->h_pairs + 2 * (size_t)b->max_pairs, (size_t)n_pairs * 4, hipMemcpyHostToDevice, b->stream));
         BA_CHECK(hipMemcpyAsync(b->d_row_pair, b->h_pairs + 3 * (size_t)b->max_pairs, (size_t)n_pairs * 4, hipMemcpyHostToDevice, b->stream));
+        }
         AssocArgs a;
         memset(&a, 0, sizeof a);
         a.inv_cell = b->inv_cell; a.cell = b->cell; a.kd_max_radius = 1.5; a.weight_gate = 0.3; a.surf_dist_thres = 0.18; a.lidar_const = 2.5;   // :3839,3874,3863,3885
         a.unit_scores = 0;
         a.q_stride = b->cap; a.w_stride = b->cap; a.b_stride = b->b_stride;
-        a.frames = b->d_frames; a.pair_ci = b->d_pair_ci; a.pair_cj = b->d_pair_cj; a.poses = b->d_poses;
+        a.frames = d_frames_run; a.pair_ci = d_ci_run; a.pair_cj = d_cj_run; a.poses = d_poses_run;
         a.local_tables = local ? 1 : 0;
         for (int p0 = 0; p0 < n_pairs; p0 += BA_CHUNK) {
             const int np = n_pairs - p0 < BA_CHUNK ? n_pairs - p0 : BA_CHUNK;
@@ -2752,11 +2788,11 @@ static int bassoc_run(glio_bassoc* b, const double* poses, int n_pairs, const in
                                    b->d_nn5, b->d_q_cp, (float4*)nullptr, b->d_q_score, b->d_q_flag, b->d_q_pos, b->d_bcount, (int*)nullptr,
                                    b->d_local, b->d_q_nc);
             }
-            hipLaunchKernelGGL(k_scan_pairs, dim3(1), dim3(1024), 0, b->stream, b->d_bcount, b->b_stride, b->d_frames, b->d_pair_ci, p0, np, b->d_boff,
+            hipLaunchKernelGGL(k_scan_pairs, dim3(1), dim3(1024), 0, b->stream, b->d_bcount, b->b_stride, d_frames_run, d_ci_run, p0, np, b->d_boff,
                                b->d_run, b->d_pair_off, (long long)b->max_con, d_overflow);
             if (maxn > 0)
                 hipLaunchKernelGGL(k_compact_pairs, dim3((maxn + 255) / 256, np), dim3(256), 0, b->stream, b->d_q_flag, b->d_q_pos, b->d_boff, b->cap, b->b_stride,
-                                   b->d_frames, b->d_pair_ci, p0, b->d_pair_off, b->d_q_cp, b->d_q_nc, b->d_q_score, b->d_cp, b->d_nc, b->d_score);
+                                   d_frames_run, d_ci_run, p0, b->d_pair_off, b->d_q_cp, b->d_q_nc, b->d_q_score, b->d_cp, b->d_nc, b->d_score);
         }
     }
     BA_CHECK(hipGetLastError());
