@@ -75,10 +75,11 @@ int main(int argc, char** argv) {
         // keyframes enter the averages: the released configuration fills its 50-keyframe local map first)
         int feature_res = 0, timed_last = NK;
         bool per_slot = false;
-        // stream_draws=1: the selection's raw draws travel with the enqueue and globalFeatureSelectionAdd_Batch runs on the association's stream behind the
-        // searches (glio_bassoc_select_tail_draws_async).  Default: the host waits for the pair counts, draws, uploads the kept indices and does NOT wait for
-        // the gather -- measured faster (1.37 vs 1.40 ms per keyframe: the on-stream form puts a copy and four dependent launches in front of finish()'s wait)
-        bool host_draws = true, prepare_early = true;
+        // stream_draws=1 (default): the selection's raw draws travel with the enqueue and globalFeatureSelectionAdd_Batch runs on the association's stream behind the
+        // searches (glio_bassoc_select_tail_draws_async).  stream_draws=0: the host waits for the pair counts, draws, uploads the kept indices and does not wait for
+        // the gather.  (With twelve hash builds in the association's chain the host form measured faster, 1.37 vs 1.40 ms per keyframe; with the tables in the
+        // keyframes' own frames the chain is 165 us shorter, the host round trip at its end counts, and the on-stream form wins: 1.22 vs 1.27 ms, 10 runs each.)
+        bool host_draws = false, prepare_early = true;
         // sleep_ms=N: the host sleeps N ms inside every keyframe call (a 10 Hz caller leaves the GPU idle for ~100 ms between calls; the sleep is not part of
         // any stage time).  sleep_at: 0 = between the batch association's preparation and the solve, 1 = before the call's first entry point, 2 = between the solve and
         // the batch association's enqueue
