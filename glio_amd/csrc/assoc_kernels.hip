@@ -2871,34 +2871,32 @@ int glio_bassoc_set_frame_from_scan(glio_bassoc* b, int k, glio_ctx* c, int slot
 // gather into the staging arrays, put back (the kernels of glio_bassoc_select_range).
 __global__ __launch_bounds__(64) void k_bassoc_draw(const long long* __restrict__ pair_off, const int n_pairs, const int res_num, const unsigned long long* __restrict__ raws,
                                                     long long* __restrict__ src /* [n_pairs][res_num] */, int* __restrict__ kept) {
-    // one wavefront per pair: the pair's raw draws come in as one batch of loads, the shuffle's map lives in LDS (a thread-private array indexed at run time
-    // would live in scratch memory: a dependent global round trip per look-up -- the first version of this kernel took ~80 us for 12 pairs)
-    __shared__ unsigned long long s_raw[64];
-    __shared__ long long s_mk[64], s_mv[64], s_out[64];
+    // one wavefront per pair (a thread-private map indexed at run time would live in scratch memory: a dependent global round trip per look-up -- the first
+    // version of this kernel took ~80 us for 12 pairs)
     const int p = blockIdx.x, lane = threadIdx.x;
     const long long o0 = pair_off[p], count = pair_off[p + 1] - o0;
     long long* out = src + (size_t)p * res_num;
     if (count <= res_num) { for (long long k = lane; k < count; k += 64) out[k] = o0 + k; if (lane == 0) kept[p] = (int)count; return; }
-    if (lane < res_num) s_raw[lane] = raws[(size_t)p * res_num + lane];
-    GLIO_WAVE_LDS_SYNC();
-    if (lane == 0) {
-        // partial Fisher-Yates without the index array: a small map of the positions whose content differs from their index (<= res_num entries)
-        int nm = 0, nk = 0;
-        for (int i = 0; i < res_num && i < count - 1; ++i) {
-            const long long j = i + (long long)(s_raw[i] % (unsigned long long)(count - 1 - i));
-            long long vi = i, vj = j;
-            for (int q = 0; q < nm; ++q) { const long long k = s_mk[q], v = s_mv[q]; if (k == i) vi = v; if (k == j) vj = v; }
-            bool found = false;
-            for (int q = 0; q < nm; ++q) if (s_mk[q] == j) { s_mv[q] = vi; found = true; }
-            if (!found) { s_mk[nm] = j; s_mv[nm] = vi; ++nm; }
-            s_out[nk++] = o0 + vj;
-        }
-        kept[p] = nk;
-        s_mk[63] = nk;
+    // partial Fisher-Yates without the index array: a small map of the positions whose content differs from their index (<= res_num entries), ONE ENTRY PER
+    // LANE; a look-up is a ballot and a shuffle.  The 64-bit remainders (the slow part: ~150 instructions each) do not depend on the shuffle's state: lane i
+    // takes draw i's.  (One lane doing all of it -- remainders and linear searches of an LDS map -- took 37 us for 12 pairs at the end of every keyframe call.)
+    const int niter = (int)(res_num < count - 1 ? res_num : count - 1);
+    long long jmine = 0;
+    if (lane < niter) jmine = lane + (long long)(raws[(size_t)p * res_num + lane] % (unsigned long long)(count - 1 - lane));
+    long long mk = -1, mv = 0, outv = 0;
+    int nm = 0;
+    for (int i = 0; i < niter; ++i) {
+        const long long j = (long long)shfl_u64((unsigned long long)jmine, i);
+        const unsigned long long bi = __ballot(lane < nm && mk == i), bj = __ballot(lane < nm && mk == j);
+        long long vi = i, vj = j;
+        if (bi) vi = (long long)shfl_u64((unsigned long long)mv, __ffsll((long long)bi) - 1);
+        if (bj) vj = (long long)shfl_u64((unsigned long long)mv, __ffsll((long long)bj) - 1);
+        if (bj) { if (lane == __ffsll((long long)bj) - 1) mv = vi; }
+        else { if (lane == nm) { mk = j; mv = vi; } ++nm; }
+        if (lane == i) outv = o0 + vj;
     }
-    GLIO_WAVE_LDS_SYNC();
-    const int nk = (int)s_mk[63];
-    if (lane < nk) out[lane] = s_out[lane];
+    if (lane == 0) kept[p] = niter;
+    if (lane < niter) out[lane] = outv;
 }
 __global__ void k_bassoc_draw_off(const int* __restrict__ kept, const int n_pairs, const long long first, long long* __restrict__ sel_off, long long* __restrict__ run) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
