@@ -41,7 +41,7 @@ struct CtxExtra {
     hipEvent_t ev_copy = nullptr;          // glio_set_scan: the end of the scan's copy (what the call waits for; the presort behind it is not waited for)
     hipStream_t up_stream = nullptr; hipEvent_t ev_up = nullptr;
     struct UpArena { char* h = nullptr; char* d = nullptr; size_t cap = 0; hipEvent_t ev_free = nullptr; bool pending = false; hipEvent_t ev_copied = nullptr; bool copying = false; } up[2];
-    int up_next = 0, up_cur = -1, up_mode = -1, up_wait = -1;
+    int up_next = 0, up_cur = -1, up_mode = -1, up_wait = -1, unstage_up = -1;
     char* sv_h = nullptr; char* sv_d = nullptr; size_t sv_cap = 0;
 };
 // the extras hang off the context itself (glio_ctx::extra): no process-global registry, so independent contexts can be
@@ -635,12 +635,28 @@ static int stage_flush(glio_ctx* c) {
         hipError_t e = hipSuccess;
         if (a.pending) e = hipStreamWaitEvent(ex->up_stream, a.ev_free, 0);
         if (e == hipSuccess) e = hipMemcpyAsync(a.d, a.h, c->h_stage_used, hipMemcpyHostToDevice, ex->up_stream);
+        // k_unstage -- the only writer of the factor tables -- ON THE UPLOAD STREAM too, right behind its copy: every reader of those tables is an entry point
+        // that has returned by the time glio_set_imu / glio_set_gnss can be called (solve, marginalization, linearisation and the evaluation calls all end with
+        // a wait; what may still be in flight on the context's stream -- the window's searches, the local map, a presort -- reads none of them), and the next
+        // reader on the context's stream waits for the event below.  Behind the searches on the context's stream instead (GLIO_UNSTAGE_IN_STREAM=1) the two
+        // installs sat between the searches and the solve: 2 x (4 us + a 10 us cross-stream hand-over) of every keyframe call.
+        if (ex->unstage_up < 0) { const char* w = getenv("GLIO_UNSTAGE_IN_STREAM"); ex->unstage_up = (w && atoi(w) != 0) ? 0 : 1; }
+        if (ex->unstage_up) {
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_unstage, dim3(n, UNSTAGE_GY), dim3(256), 0, ex->up_stream, reinterpret_cast<const StageSegDev*>(a.d));
+                e = hipEventRecord(a.ev_free, ex->up_stream);
+                a.pending = true;
+            }
+            if (e == hipSuccess) e = hipEventRecord(ex->ev_up, ex->up_stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, ex->ev_up, 0);
+        } else {
         if (e == hipSuccess) e = hipEventRecord(ex->ev_up, ex->up_stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, ex->ev_up, 0);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_unstage, dim3(n, UNSTAGE_GY), dim3(256), 0, c->stream, reinterpret_cast<const StageSegDev*>(a.d));
             e = hipEventRecord(a.ev_free, c->stream);
             a.pending = true;
+        }
         }
         // the pinned block is this arena's until its next turn (stage_begin_early waits for the copy then): the call does not wait for the copy
         // (it did, with hipStreamSynchronize on the upload stream: 10-40 us of host time per call while a search kernel fills the chip; GLIO_EARLY_UPLOAD_WAIT=1)
