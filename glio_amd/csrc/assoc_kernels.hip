@@ -2392,7 +2392,7 @@ int glio_bassoc_create(int device, int K, int max_points_per_frame, int64_t max_
     BA_CHECK(hipMalloc((void**)&b->d_local, (size_t)K * cap * 16)); BA_CHECK(hipMalloc((void**)&b->d_global, (size_t)BA_FB * cap * 16));
     BA_CHECK(hipMalloc((void**)&b->d_local_ps, (size_t)K * cap * 16));
     BA_CHECK(hipMalloc((void**)&b->d_sorted_local, (size_t)K * cap * 16));
-    b->inbox_bytes = (size_t)K * (7 * 8 + sizeof(FrameBuild) + sizeof(FrameDesc)) + (size_t)4 * 4 * K * 4 + 64;
+    b->inbox_bytes = (size_t)K * (7 * 8 + sizeof(FrameBuild) + sizeof(FrameDesc)) + (size_t)2 * 4 * 16 * K + 64;      // (pair arrays: 2 x up to 16 K pairs)
     BA_CHECK(hipMalloc((void**)&b->d_inbox, b->inbox_bytes)); BA_CHECK(hipHostMalloc((void**)&b->h_inbox, b->inbox_bytes));
     b->h_n = new int[K]();
     b->frames = new FrameHash[K]();
@@ -2542,12 +2542,15 @@ static int bassoc_fb_uploaded(glio_bassoc* b) {
 // ---- LOCAL mode.  A run hashes every search frame at its pose of the run: 12 builds (clear, tile insert, cell allocation, scatter: 127 us of the 490 us chain)
 // in every keyframe call, for clouds that never change.  In local mode a keyframe's table is built ONCE, from its local cloud; a run re-poses the table's
 // points (one streaming launch for all search frames) and groups every pair's queries by their cell in the search frame's own frame (k_qbin_tile,
-// AssocArgs::local_tables) -- the pairs of a keyframe can then no longer share one grouping, which is why runs with many pairs per search frame (the batch
-// stage's pair list: 12 per keyframe, each table built once per run anyway) stay in the global mode.  Same records, bit for bit: the candidates of a query
+// AssocArgs::local_tables) -- the pairs of a keyframe can then no longer share one grouping.  Used for runs with fewer than 16 pairs per search frame
+// (GLIO_BASSOC_LOCAL_RATIO), which covers a keyframe call's 2 x search_range pairs AND the batch stage's pair list (12 per keyframe: its first run builds each
+// table once in either mode and measured equal, 50.9 against 51.2 ms for 4656 pairs of 32 k points; every later run over the same clouds -- the rounds'
+// re-association -- skips the builds: 48.0 against 50.0 ms).  Same records, bit for bit: the candidates of a query
 // are the 27 cells around its cell in either frame, both cover the ball of the search radius, and distances, ranking and gate read the same global floats.
 static bool bassoc_local_mode(const glio_bassoc* b, const int n_pairs, const int n_need, const double* poses, const std::vector<char>& need) {
     if (g_bassoc_local < 0) g_bassoc_local = (getenv("GLIO_BASSOC_LOCAL_TABLES") && atoi(getenv("GLIO_BASSOC_LOCAL_TABLES")) == 0) ? 0 : 1;
-    if (!g_bassoc_local || g_knn_mode != 0 || n_need == 0 || n_pairs >= 4 * n_need) return false;
+    static const int ratio = getenv("GLIO_BASSOC_LOCAL_RATIO") ? atoi(getenv("GLIO_BASSOC_LOCAL_RATIO")) : 16;
+    if (!g_bassoc_local || g_knn_mode != 0 || n_need == 0 || n_pairs >= ratio * n_need) return false;
     if (poses)       // (the grouping inverts the pose with the conjugate: unit quaternions only; anything else takes the global mode)
         for (int k = 0; k < b->K; ++k) if (need[k]) {
             const double* q = poses + 7 * k + 3;
