@@ -2901,6 +2901,65 @@ __global__ __launch_bounds__(64) void k_bassoc_draw(const long long* __restrict_
     if (lane == 0) kept[p] = niter;
     if (lane < niter) out[lane] = outv;
 }
+// the four kernels of the on-stream selection as ONE workgroup (a keyframe call's 2 x search_range pairs: <= 16, one wavefront each): draws, the prefix of the kept
+// counts, the kept records into registers, a barrier (every source has been read), the records to their places.  Same draws as k_bassoc_draw, same places as
+// k_bassoc_draw_off / _gather / _put (6 + 6 + 5 + 5 us of launches at the end of every keyframe call's association).
+__global__ __launch_bounds__(1024) void k_bassoc_draw_all(const long long* __restrict__ pair_off, const int n_pairs, const int res_num, const unsigned long long* __restrict__ raws,
+                                                          const long long first, long long* __restrict__ sel_off, long long* __restrict__ run,
+                                                          float4* __restrict__ cp, double* __restrict__ nc, double* __restrict__ score) {
+    __shared__ int s_kept[16];
+    __shared__ long long s_off[17];
+    const int p = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    long long sidx = -1;
+    int mine = 0;
+    if (p < n_pairs) {
+        const long long o0 = pair_off[p], count = pair_off[p + 1] - o0;
+        if (count <= res_num) { mine = (int)count; if (lane < count) sidx = o0 + lane; }
+        else {
+            const int niter = (int)(res_num < count - 1 ? res_num : count - 1);
+            long long jmine = 0;
+            if (lane < niter) jmine = lane + (long long)(raws[(size_t)p * res_num + lane] % (unsigned long long)(count - 1 - lane));
+            long long mk = -1, mv = 0;
+            int nm = 0;
+            for (int i = 0; i < niter; ++i) {
+                const long long j = (long long)shfl_u64((unsigned long long)jmine, i);
+                const unsigned long long bi = __ballot(lane < nm && mk == i), bj = __ballot(lane < nm && mk == j);
+                long long vi = i, vj = j;
+                if (bi) vi = (long long)shfl_u64((unsigned long long)mv, __ffsll((long long)bi) - 1);
+                if (bj) vj = (long long)shfl_u64((unsigned long long)mv, __ffsll((long long)bj) - 1);
+                if (bj) { if (lane == __ffsll((long long)bj) - 1) mv = vi; }
+                else { if (lane == nm) { mk = j; mv = vi; } ++nm; }
+                if (lane == i) sidx = o0 + vj;
+            }
+            mine = niter;
+        }
+        if (lane == 0) s_kept[p] = mine;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long r = first;
+        for (int q = 0; q < n_pairs; ++q) { s_off[q] = r; sel_off[q] = r; r += s_kept[q]; }
+        s_off[n_pairs] = r; sel_off[n_pairs] = r;
+        run[0] = r;
+    }
+    float4 rc = make_float4(0, 0, 0, 0);
+    double rn[6] = {0, 0, 0, 0, 0, 0}, rs = 0;
+    const bool live = p < n_pairs && lane < mine;
+    if (live) {
+        rc = cp[sidx];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) rn[c] = nc[6 * sidx + c];
+        rs = score[sidx];
+    }
+    __syncthreads();            // every kept record is in registers (the places written below may be another pair's sources), the offsets are known
+    if (live) {
+        const long long d = s_off[p] + lane;
+        cp[d] = rc;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) nc[6 * d + c] = rn[c];
+        score[d] = rs;
+    }
+}
 __global__ void k_bassoc_draw_off(const int* __restrict__ kept, const int n_pairs, const long long first, long long* __restrict__ sel_off, long long* __restrict__ run) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     long long r = first;
@@ -2965,12 +3024,17 @@ int glio_bassoc_select_tail_draws_async(glio_bassoc* b, int res_num, const uint6
     b->raws_in_flight = 1;
     long long* d_src = reinterpret_cast<long long*>(b->d_raws + b->raws_cap);
     int* d_kept = reinterpret_cast<int*>(b->d_sel_off + b->raws_cap + 2);
+    if (n_pairs <= 16) {
+        hipLaunchKernelGGL(k_bassoc_draw_all, dim3(1), dim3(64 * n_pairs), 0, b->stream, b->d_pair_off, n_pairs, res_num, b->d_raws, b->pending_first, b->d_sel_off, b->d_run,
+                           b->d_cp, b->d_nc, b->d_score);
+    } else {
     hipLaunchKernelGGL(k_bassoc_draw, dim3(n_pairs), dim3(64), 0, b->stream, b->d_pair_off, n_pairs, res_num, b->d_raws, d_src, d_kept);
     hipLaunchKernelGGL(k_bassoc_draw_off, dim3(1), dim3(64), 0, b->stream, d_kept, n_pairs, b->pending_first, b->d_sel_off, b->d_run);
     hipLaunchKernelGGL(k_bassoc_draw_gather, dim3(n_pairs), dim3(64), 0, b->stream, d_src, d_kept, b->d_sel_off, res_num, b->pending_first, b->d_cp, b->d_nc, b->d_score,
                        b->d_sel_cp, b->d_sel_nc, b->d_sel_score);
     hipLaunchKernelGGL(k_bassoc_draw_put, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, b->stream, b->d_sel_off, n_pairs, b->pending_first, b->d_sel_cp, b->d_sel_nc, b->d_sel_score,
                        b->d_cp, b->d_nc, b->d_score);
+    }
     BA_CHECK(hipGetLastError());
     // the running total as the selection left it (the copy the run enqueued carried the total BEFORE the selection; the pair counts stay the FOUND ones)
     BA_CHECK(hipMemcpyAsync(b->h_tail, b->d_run, 8, hipMemcpyDeviceToHost, b->stream));
