@@ -145,6 +145,10 @@ class Context:
     def set_scan(self, slot, scan):
         _check(load().glio_set_scan(self._h, slot, T.fptr(scan), len(scan)))
 
+    def set_scan_ahead(self, scan):
+        """the NEXT keyframe's scan into the ring row that is slot W - 1 after the next slide_window() (the current slot 0's scan is gone afterwards)"""
+        _check(load().glio_set_scan_ahead(self._h, T.fptr(scan), len(scan)))
+
     def associate(self, slot, scan, q, t):
         cnt = C.c_int()
         q = np.ascontiguousarray(q, float); t = np.ascontiguousarray(t, float)
@@ -286,6 +290,14 @@ class Context:
     def marginalize_keep(self, state):
         cs = state.c()
         _check(load().glio_marginalize_keep(self._h, C.byref(cs)))
+
+    def marginalize_keep_async(self, state):
+        """enqueue the marginalization and return; marginalize_keep_finish() (or the next entry point that reads the prior) waits"""
+        cs = state.c()
+        _check(load().glio_marginalize_keep_async(self._h, C.byref(cs)))
+
+    def marginalize_keep_finish(self):
+        _check(load().glio_marginalize_keep_finish(self._h))
 
     def time_kernel(self, which, reps=20):
         ms = C.c_float()

@@ -1879,6 +1879,10 @@ void glio_assoc_destroy(glio_ctx* c) {
 }
 
 // a scan was uploaded to / moved between slots: keep its presorted copy in step (enqueued on the context stream)
+void glio_assoc_presort_row(glio_ctx* c, hipStream_t stream, size_t row_offset, int n) {      // glio_set_scan_ahead: the presort of a ring row on a stream of the caller's
+    AssocWork* w = c->assoc;
+    if (w) enqueue_presort(stream, w->kb, c->d_scan + row_offset, n, w->d_ps + row_offset);
+}
 void glio_assoc_scan_uploaded(glio_ctx* c, int slot, int n) {
     AssocWork* w = c->assoc;
     if (w) { const size_t row = (size_t)glio_scan_row(c, slot) * c->cap; enqueue_presort(c->stream, w->kb, c->d_scan + row, n, w->d_ps + row); }

@@ -42,12 +42,15 @@ struct CtxExtra {
     hipStream_t up_stream = nullptr; hipEvent_t ev_up = nullptr;
     struct UpArena { char* h = nullptr; char* d = nullptr; size_t cap = 0; hipEvent_t ev_free = nullptr; bool pending = false; hipEvent_t ev_copied = nullptr; bool copying = false; } up[2];
     int up_next = 0, up_cur = -1, up_mode = -1, up_wait = -1, unstage_up = -1;
+    int* marg_h_ok = nullptr;              // glio_marginalize_keep_async: the pinned "positive definite" flag its finish looks at
+    hipEvent_t ev_ahead = nullptr; int ahead_valid = 0, ahead_n = 0;      // glio_set_scan_ahead: the upload + presort of the NEXT keyframe's scan on the upload stream
     char* sv_h = nullptr; char* sv_d = nullptr; size_t sv_cap = 0;
 };
 // the extras hang off the context itself (glio_ctx::extra): no process-global registry, so independent contexts can be
 // created, used and destroyed from different threads concurrently (Estimator.cpp:5398-5404)
 static CtxExtra* extra_of(glio_ctx* c) { return static_cast<CtxExtra*>(c->extra); }
 GnssDevExtra* glio_extra(glio_ctx* c) { return &extra_of(c)->gx; }
+static int marg_pending_done(glio_ctx* c);
 
 // ---- roctx ranges (GLIO_ROCTX=1)
 #include <dlfcn.h>
@@ -247,6 +250,8 @@ void glio_destroy(glio_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->ev_ext_read) { if (c->ext_read_pending) hipEventSynchronize(c->ev_ext_read); hipEventDestroy(c->ev_ext_read); c->ev_ext_read = nullptr; }
+    if (c->extra && extra_of(c)->up_stream) hipStreamSynchronize(extra_of(c)->up_stream);       // (a scan sent ahead may still be on its way)
+    if (c->extra && extra_of(c)->ev_ahead) { hipEventDestroy(extra_of(c)->ev_ahead); extra_of(c)->ev_ahead = nullptr; }
     glio_assoc_destroy(c);
     glio_localmap_destroy(c);
     void* ptrs[] = {c->d_pts, c->d_planes, c->d_scores, c->d_pts_s, c->d_count, c->d_scan, c->d_imu, c->d_imu_blocks, c->d_gnss_blocks, c->d_groups,
@@ -385,6 +390,37 @@ int glio_set_scan_strided(glio_ctx* c, int slot, const void* scan, int n, int st
     c->h_scan_count[slot] = n;
     return GLIO_OK;
 }
+// The NEXT keyframe's scan, sent while this keyframe's call is still running: into the ring row that becomes slot W - 1 with the next glio_slide_window -- the row of
+// the current slot 0, whose scan nothing reads any more once the window's association is through (the call fetches its counts first) -- on the upload stream, the
+// presort behind it there.  The next call's glio_slide_window takes it over (count, an event the context's stream waits for) and needs no glio_set_scan.
+int glio_set_scan_ahead(glio_ctx* c, const float* scan, int n) { return glio_set_scan_ahead_strided(c, scan, n, 16, 12); }
+int glio_set_scan_ahead_strided(glio_ctx* c, const void* scan, int n, int stride_bytes, int intensity_offset) {
+    if (!c || c->W < 2 || n < 0 || n > c->cap || (n > 0 && !scan)) { glio_set_error("bad scan size"); return GLIO_E_ARG; }
+    if (!glio_point_layout_ok(stride_bytes, intensity_offset)) { glio_set_error("bad point layout (stride %d, intensity at %d)", stride_bytes, intensity_offset); return GLIO_E_ARG; }
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    { const int rp = glio_assoc_finish_pending(c); if (rp != GLIO_OK) return rp; }              // every search that reads slot 0's scan has ended
+    CtxExtra* ex = extra_of(c);
+    if (!ex->up_stream) {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) GLIO_HIP_CHECK(hipStreamCreateWithPriority(&ex->up_stream, hipStreamNonBlocking, greatest));
+        else GLIO_HIP_CHECK(hipStreamCreateWithFlags(&ex->up_stream, hipStreamNonBlocking));
+        GLIO_HIP_CHECK(hipEventCreateWithFlags(&ex->ev_up, hipEventDisableTiming));
+    }
+    if (!ex->ev_ahead) GLIO_HIP_CHECK(hipEventCreateWithFlags(&ex->ev_ahead, hipEventDisableTiming));
+    if (!ex->ev_copy) GLIO_HIP_CHECK(hipEventCreateWithFlags(&ex->ev_copy, hipEventDisableTiming));
+    // (another object's stream may still be reading a resident scan -- never slot 0's: glio_bassoc_set_frame_from_scan copies the newest -- but the event is cheap)
+    if (c->ext_read_pending) { GLIO_HIP_CHECK(hipStreamWaitEvent(ex->up_stream, c->ev_ext_read, 0)); }
+    const size_t row = (size_t)glio_scan_row(c, 0) * c->cap;
+    { const int ru = glio_upload_points(ex->up_stream, &c->raw_stage, scan, n, stride_bytes, intensity_offset, c->d_scan + row); if (ru != GLIO_OK) return ru; }
+    GLIO_HIP_CHECK(hipEventRecord(ex->ev_copy, ex->up_stream));
+    glio_assoc_presort_row(c, ex->up_stream, row, n);
+    GLIO_HIP_CHECK(hipEventRecord(ex->ev_ahead, ex->up_stream));
+    GLIO_HIP_CHECK(hipGetLastError());
+    GLIO_HIP_CHECK(hipEventSynchronize(ex->ev_copy));       // the caller's buffer has been read
+    ex->ahead_valid = 1; ex->ahead_n = n;
+    c->h_scan_count[0] = 0;                                  // (slot 0's scan is gone)
+    return GLIO_OK;
+}
 int glio_associate_resident(glio_ctx* c, int slot, const double q[4], const double t[3], int* out_count) {
     GLIO_TRACE("K2 glio_associate_resident");
     if (!c || slot < 0 || slot >= c->W) return GLIO_E_ARG;
@@ -402,6 +438,12 @@ int glio_slide_window(glio_ctx* c) {
     c->scan_base = (c->scan_base + 1) % c->W;
     for (int s = 0; s + 1 < c->W; ++s) c->h_scan_count[s] = c->h_scan_count[s + 1];
     c->h_scan_count[c->W - 1] = 0;
+    CtxExtra* ex = extra_of(c);
+    if (ex->ahead_valid) {          // glio_set_scan_ahead: the row that is slot W - 1 now already holds the new keyframe's scan (presorted) -- or will, behind this event
+        GLIO_HIP_CHECK(hipStreamWaitEvent(c->stream, ex->ev_ahead, 0));
+        c->h_scan_count[c->W - 1] = ex->ahead_n;
+        ex->ahead_valid = 0;
+    }
     return GLIO_OK;
 }
 int glio_select_correspondences(glio_ctx* c, int slot, const int32_t* indices, int n) {
@@ -678,6 +720,7 @@ static int stage_flush(glio_ctx* c) {
 
 int glio_set_imu(glio_ctx* c, int n_edges, const glio_preint* edges, const int32_t* slot_i) {
     if (!c || n_edges < 0 || n_edges > c->W - 1 + (c->W == 1)) { glio_set_error("bad IMU edge count"); return GLIO_E_ARG; }
+    { const int rp = marg_pending_done(c); if (rp) return rp; }
     GLIO_HIP_CHECK(hipSetDevice(c->device));
     std::vector<ImuEdgeDev> h(std::max(1, n_edges));
     for (int k = 0; k < n_edges; ++k) {
@@ -709,6 +752,7 @@ int glio_set_imu(glio_ctx* c, int n_edges, const glio_preint* edges, const int32
 // ---------------------------------------------------------------------------------------------- prior
 int glio_set_prior(glio_ctx* c, const glio_prior* p) {
     if (!c) return GLIO_E_ARG;
+    { const int rp = marg_pending_done(c); if (rp) return rp; }
     GLIO_HIP_CHECK(hipSetDevice(c->device));
     if (!p || p->n <= 0) {
         c->prior_n = 0; c->prior_nb = 0; c->arrow.prior_ok = 1; c->arrow.prior_chain = 1;
@@ -786,6 +830,7 @@ static void ecef2rotation_host(const double xyz[3], double R[9]) {   // gnss_uti
 int glio_set_gnss(glio_ctx* c, const glio_gnss_frame* frame, int n_dd, const glio_dd_psr* dd, int n_dop, const glio_doppler* dop) {
     if (!c || n_dd < 0 || n_dop < 0) return GLIO_E_ARG;
     GLIO_HIP_CHECK(hipSetDevice(c->device));
+    { const int rp = marg_pending_done(c); if (rp) return rp; }
     const int W = c->W;
     if (frame) {
         c->frame = *frame;
@@ -1033,6 +1078,8 @@ int glio_solve(glio_ctx* c, glio_state* s, glio_summary* sum) {
     GLIO_TRACE("K3-K7 glio_solve (linearise + trust region, device resident)");
     int rc = check_state(c, s);
     if (rc) return rc;
+    rc = marg_pending_done(c);
+    if (rc) return rc;
     rc = glio_assoc_finish_pending(c);
     if (rc) return rc;
     GLIO_HIP_CHECK(hipSetDevice(c->device));
@@ -1103,6 +1150,8 @@ int glio_linearize(glio_ctx* c, const glio_state* s, double* H, double* g, doubl
     GLIO_TRACE("K3-K6 glio_linearize");
     int rc = check_state(c, s);
     if (rc) return rc;
+    rc = marg_pending_done(c);
+    if (rc) return rc;
     rc = glio_assoc_finish_pending(c);
     if (rc) return rc;
     GLIO_HIP_CHECK(hipSetDevice(c->device));
@@ -1123,6 +1172,7 @@ int glio_linearize(glio_ctx* c, const glio_state* s, double* H, double* g, doubl
 int glio_marginalize(glio_ctx* c, const glio_state* s, double* lin_jac, double* lin_res, int32_t* blk_slot, int32_t* blk_kind,
                      int32_t* blk_idx, double* blk_x0, int32_t* out_n, int32_t* out_n_blocks) {
     GLIO_TRACE("glio_marginalize");
+    { const int rp = marg_pending_done(c); if (rp) return rp; }
     int rc = check_state(c, s);
     if (rc) return rc;
     rc = glio_assoc_finish_pending(c);
@@ -1169,9 +1219,24 @@ int glio_marginalize(glio_ctx* c, const glio_state* s, double* lin_jac, double* 
 // Marginalize and KEEP: the result becomes this context's prior for the next window without leaving the device (J0, r0 are
 // copied device to device; only the small block tables are rebuilt on the host).  The caller slides its state arrays by one
 // keyframe afterwards.  Equivalent to glio_marginalize + glio_set_prior(result), minus two PCIe trips of the n x n matrix.
+static int marginalize_keep_wait(glio_ctx* c);
+// an asynchronous marginalization nobody finished: every entry point that reads the prior, or writes the pinned arena its flag lives in, finishes it first
+static int marg_pending_done(glio_ctx* c) { return (c && extra_of(c)->marg_h_ok) ? marginalize_keep_wait(c) : GLIO_OK; }
 int glio_marginalize_keep(glio_ctx* c, const glio_state* s) {
+    const int rc = glio_marginalize_keep_async(c, s);
+    return rc != GLIO_OK ? rc : glio_marginalize_keep_finish(c);
+}
+int glio_marginalize_keep_finish(glio_ctx* c) {
+    if (!c) return GLIO_E_ARG;
+    if (!extra_of(c)->marg_h_ok) return GLIO_OK;            // nothing pending
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    return marginalize_keep_wait(c);
+}
+int glio_marginalize_keep_async(glio_ctx* c, const glio_state* s) {
     GLIO_TRACE("glio_marginalize_keep");
     int rc = check_state(c, s);
+    if (rc) return rc;
+    rc = marg_pending_done(c);
     if (rc) return rc;
     rc = glio_assoc_finish_pending(c);
     if (rc) return rc;
@@ -1228,6 +1293,13 @@ int glio_marginalize_keep(glio_ctx* c, const glio_state* s) {
     glio_launch_gram(c, n);
     int* h_ok = reinterpret_cast<int*>(c->h_stage + ((c->h_stage_used + 63) & ~(size_t)63));      // (pinned; reserved above)
     GLIO_HIP_CHECK(hipMemcpyAsync(h_ok, dok, 4, hipMemcpyDeviceToHost, c->stream));
+    extra_of(c)->marg_h_ok = h_ok;                         // glio_marginalize_keep_finish (or the entry points that use the prior) waits and looks at it
+    return GLIO_OK;
+}
+static int marginalize_keep_wait(glio_ctx* c) {
+    const int W = c->W;
+    int* h_ok = extra_of(c)->marg_h_ok;
+    extra_of(c)->marg_h_ok = nullptr;
     GLIO_HIP_CHECK(hipStreamSynchronize(c->stream));
     if (!*h_ok) {          // the installed tables describe a factor that does not exist: the context is left WITHOUT a prior
         c->prior_n = 0; c->prior_nb = 0; c->arrow.prior_ok = 1; c->arrow.prior_chain = 1;

@@ -443,6 +443,7 @@ size_t glio_tr_step_lds_bytes(int n);
 int glio_assoc_create(glio_ctx* c);
 // the resident scan of a slot changed (uploaded / moved by the slide): keep the presorted copy the tiled search reads in step
 void glio_assoc_scan_uploaded(glio_ctx* c, int slot, int n);
+void glio_assoc_presort_row(glio_ctx* c, hipStream_t stream, size_t row_offset, int n);
 void glio_assoc_destroy(glio_ctx* c);
 int glio_assoc_build_map(glio_ctx* c, const void* map_points, int n, int stride, int ioff);
 int glio_assoc_run(glio_ctx* c, int slot, const double q[4], const double t[3], int* out_count);

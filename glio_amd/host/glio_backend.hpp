@@ -337,6 +337,17 @@ public:
         st.rcv_ddt = rcv_ddt && !rcv_ddt->empty() ? rcv_ddt->data() : nullptr; st.n_ddt = rcv_ddt ? (int)rcv_ddt->size() : 0;
         check(glio_marginalize_keep(ctx_, &st), "glio_marginalize_keep");
     }
+    // the same in two halves: the marginalization enqueued (the host is free: setScanAhead() of the next keyframe's cloud, say), then waited for
+    void marginalizeAndKeepAsync(std::vector<double>* rcv_ddt = nullptr) {
+        glio_state st;
+        st.trans = tmpTrans.data(); st.quat = tmpQuat.data(); st.speed_bias = tmpSpeedBias.data();
+        st.rcv_ddt = rcv_ddt && !rcv_ddt->empty() ? rcv_ddt->data() : nullptr; st.n_ddt = rcv_ddt ? (int)rcv_ddt->size() : 0;
+        check(glio_marginalize_keep_async(ctx_, &st), "glio_marginalize_keep_async");
+    }
+    void marginalizeFinish() { check(glio_marginalize_keep_finish(ctx_), "glio_marginalize_keep_finish"); }
+    // the NEXT keyframe's cloud, sent during this keyframe's call (after the solve): the next call's slideWindow() finds it in slot W - 1 and makes no setScan()
+    void setScanAhead(const float* scan_xyzi, int n) { check(glio_set_scan_ahead(ctx_, scan_xyzi, n), "glio_set_scan_ahead"); }
+    void setScanAhead(const void* points, int n, PointLayout l) { check(glio_set_scan_ahead_strided(ctx_, points, n, l.stride_bytes, l.intensity_offset), "glio_set_scan_ahead_strided"); }
     // buildLocalMapWithLandMark + downSampleCloud (Estimator.cpp:3529-3631) on the device: push the new keyframe's cloud
     // (body frame) with its pose, rebuild the voxel-averaged ring map and its search structure; returns the map size
     void configureLocalMap(int width, float leaf, int max_points_per_keyframe) {

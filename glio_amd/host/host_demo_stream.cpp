@@ -80,6 +80,10 @@ int main(int argc, char** argv) {
         // the gather.  (With twelve hash builds in the association's chain the host form measured faster, 1.37 vs 1.40 ms per keyframe; with the tables in the
         // keyframes' own frames the chain is 165 us shorter, the host round trip at its end counts, and the on-stream form wins: 1.22 vs 1.27 ms, 10 runs each.)
         bool host_draws = false, prepare_early = true;
+        // ahead=1: the NEXT keyframe's cloud goes to the device during this keyframe's call, beside the marginalization (glio_set_scan_ahead: the front end has
+        // the cloud before the back end is called, Estimator.cpp:5372ff); the next call's slide finds it in slot W - 1.  ahead=0: every call uploads its own.
+        bool ahead = false;
+        bool have_ahead = false;
         // sleep_ms=N: the host sleeps N ms inside every keyframe call (a 10 Hz caller leaves the GPU idle for ~100 ms between calls; the sleep is not part of
         // any stage time).  sleep_at: 0 = between the batch association's preparation and the solve, 1 = before the call's first entry point, 2 = between the solve and
         // the batch association's enqueue
@@ -92,6 +96,7 @@ int main(int argc, char** argv) {
             else if (!strncmp(argv[a], "per_slot=", 9)) per_slot = atoi(argv[a] + 9) != 0;
             else if (!strncmp(argv[a], "stream_draws=", 13)) host_draws = atoi(argv[a] + 13) == 0;
             else if (!strncmp(argv[a], "prepare_early=", 14)) prepare_early = atoi(argv[a] + 14) != 0;
+            else if (!strncmp(argv[a], "ahead=", 6)) ahead = atoi(argv[a] + 6) != 0;
             else if (!strncmp(argv[a], "sleep_ms=", 9)) sleep_ms = atoi(argv[a] + 9);
             else if (!strncmp(argv[a], "sleep_at=", 9)) sleep_at = atoi(argv[a] + 9);
             else if (!strncmp(argv[a], "draws=", 6)) {
@@ -129,7 +134,9 @@ int main(int argc, char** argv) {
             std::vector<double> ddt = k.ddt;
             if (sleep_ms > 0 && sleep_at == 1) std::this_thread::sleep_for(std::chrono::milliseconds(sleep_ms));
             const double t0 = now_s();
-            be.slideWindow(); be.setScan(W - 1, scans[nw].data(), pts);
+            be.slideWindow();
+            if (!have_ahead) be.setScan(W - 1, scans[nw].data(), pts);
+            have_ahead = false;
             // the keyframe's cloud goes to the batch association's store as soon as it is on the device (body frame: nothing of it depends on the solve); with the
             // deferred variant the previous keyframe's searches are still in flight on that store's stream, and the copy is made once they were collected
             if (!defer) ba.setFrameFromScan(nw, be.ctx(), W - 1, tlb);
@@ -168,7 +175,12 @@ int main(int argc, char** argv) {
             if (defer) ba.setFrameFromScan(nw, be.ctx(), W - 1, tlb);
             if (!after_marg) { if (host_draws) kba.enqueue(nw + 1, kf_poses); else kba.enqueueWithDraws(nw + 1, kf_poses, rand_u64); }
             const double t5b = now_s();
-            be.marginalizeAndKeep(&ddt);
+            if (ahead && j < NK) {
+                be.marginalizeAndKeepAsync(&ddt);
+                be.setScanAhead(scans[nw + 1].data(), pts);             // (the host would only wait for the marginalization here)
+                have_ahead = true;
+                be.marginalizeFinish();
+            } else be.marginalizeAndKeep(&ddt);
             const double t6 = now_s();
             if (after_marg) { if (host_draws) kba.enqueue(nw + 1, kf_poses); else kba.enqueueWithDraws(nw + 1, kf_poses, rand_u64); }
             if (!defer) found = kba.finish(rand_below);

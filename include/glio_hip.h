@@ -92,6 +92,13 @@ int glio_associate(glio_ctx* ctx, int slot, const float* scan_xyzi, int n, const
  * glio_set_scan returns when the caller's buffer has been read; the presort of the scan is enqueued behind the copy and not waited for. */
 int glio_set_scan(glio_ctx* ctx, int slot, const float* scan_xyzi, int n);
 int glio_set_scan_strided(glio_ctx* ctx, int slot, const void* scan_points, int n, int stride_bytes, int intensity_offset);
+/* The NEXT keyframe's scan, sent while the current keyframe's call is still running (the reference hands surf_frames over from the front end before
+ * optimizeSlidingWindowWithLandMark runs, Estimator.cpp:5372ff): it goes into the ring row that becomes slot W - 1 with the next glio_slide_window -- the row of
+ * the CURRENT slot 0, whose scan is gone afterwards (no re-association of slot 0) -- on a stream of its own, beside the call's kernels, the presort behind it.
+ * To be called once the window's association is through (after glio_associate_window_counts / the solve).  The next glio_slide_window takes the scan over; that
+ * call then makes no glio_set_scan for slot W - 1.  Returns when the caller's buffer has been read. */
+int glio_set_scan_ahead(glio_ctx* ctx, const float* scan_xyzi, int n);
+int glio_set_scan_ahead_strided(glio_ctx* ctx, const void* scan_points, int n, int stride_bytes, int intensity_offset);
 int glio_associate_resident(glio_ctx* ctx, int slot, const double q[4], const double t[3], int* out_count);
 /* Slide the window by one keyframe: the resident scan of slot s+1 becomes that of slot s (the scans are a ring on the device: nothing is
  * copied, nothing waited for); slot W-1 is free for the new keyframe's glio_set_scan.  (surf_frames / keyframe_idx bookkeeping of
@@ -161,6 +168,11 @@ int glio_marginalize(glio_ctx* ctx, const glio_state* state, double* lin_jac, do
  * (= glio_marginalize + glio_set_prior of its output, minus the two PCIe trips of the n x n matrix).  The caller then
  * slides its state arrays / scans / IMU edges by one keyframe as the reference does (Estimator.cpp:2584-2607, 4300ff). */
 int glio_marginalize_keep(glio_ctx* ctx, const glio_state* state);
+/* the same in two halves: _async enqueues everything and returns (the host is free, e.g. for glio_set_scan_ahead, while the GPU marginalizes); _finish waits and
+ * reports GLIO_E_NUMERIC if the Schur complement was not positive definite (the context is then left without a prior).  Every entry point that reads the prior
+ * finishes a pending marginalization by itself. */
+int glio_marginalize_keep_async(glio_ctx* ctx, const glio_state* state);
+int glio_marginalize_keep_finish(glio_ctx* ctx);
 
 /* ---- single-factor evaluators with the exact Evaluate() pointer convention, computed on the GPU.
  * A ceres::CostFunction shim is a five-line wrapper around these. */

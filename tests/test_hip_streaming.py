@@ -144,3 +144,47 @@ def test_early_factor_uploads_equal_in_stream_uploads(monkeypatch):
         assert a[0] == b[0] and a[4] == b[4]
         for x, y in zip(a[1:4], b[1:4]):
             assert np.array_equal(x, y)
+
+
+@pytest.mark.gpu
+def test_scan_sent_ahead_and_asynchronous_marginalization_change_nothing():
+    """glio_set_scan_ahead (the next keyframe's scan into the ring row the next slide exposes, on the upload stream) and glio_marginalize_keep_async / _finish against
+    the plain calls: two contexts walk the same three keyframes -- same counts, same correspondences, same solved states, same priors in effect."""
+    import numpy as np
+    from glio_amd import capi, synth
+    W, NK = 4, 3
+    long = synth.make_window(W=W + NK, pts_per_scan=3000, with_gnss=False, with_prior=False, seed=synth.SEED_BASE + 33)
+    wins = [synth.sub_window(long, j, W) for j in range(NK + 1)]
+    a, b = capi.Context(wins[0].opts), capi.Context(wins[0].opts)
+    for c in (a, b):
+        c.set_map(wins[0].map_pts)
+        for s in range(W):
+            c.set_scan(s, wins[0].scans[s])
+        c.set_prior(None)
+    sent = False
+    for j in range(NK + 1):
+        win = wins[j]
+        poses = [capi.lidar_pose(win.opts, win.init.quat[s], win.init.trans[s]) for s in range(W)]
+        q2s = np.array([p[0] for p in poses]); t2s = np.array([p[1] for p in poses])
+        if j > 0:
+            a.slide_window(); a.set_scan(W - 1, win.scans[W - 1])
+            b.slide_window()
+            if not sent:
+                b.set_scan(W - 1, win.scans[W - 1])
+        ca = a.associate_window(q2s, t2s)
+        b.associate_window_async(q2s, t2s); cb = b.associate_window_counts()
+        assert np.array_equal(ca, cb) and ca.sum() > 0, j
+        for s in range(W):
+            assert all(np.array_equal(x, y) for x, y in zip(a.get_correspondences(s), b.get_correspondences(s))), (j, s)
+        for c in (a, b):
+            c.set_imu(win.preints)
+        sa, ma = a.solve(win.init); sb, mb = b.solve(win.init)
+        assert ma.iterations == mb.iterations and np.array_equal(sa.trans, sb.trans) and np.array_equal(sa.quat, sb.quat), j
+        a.marginalize_keep(sa)
+        b.marginalize_keep_async(sb)
+        sent = j < NK
+        if sent:
+            b.set_scan_ahead(wins[j + 1].scans[W - 1])
+        if j % 2:
+            b.marginalize_keep_finish()          # (else: the next solve finishes it by itself)
+    a.close(); b.close()

@@ -145,6 +145,11 @@ def test_cpp_keyframe_stream_equals_the_python_driver(tmp_path):
     # (the selection on the association's stream from raw draws made before the counts exist: the same pairs found, the same 25 held per pair)
     got_sd = window_io.run_demo_stream(path, search_range=2, stream_draws=True)
     assert got_sd["batch_records_found"] == got["batch_records_found"] and got_sd["batch_records_held"] == got["batch_records_held"] and got_sd["iterations"] == got["iterations"]
+    # (the next keyframe's cloud sent during the call, beside an asynchronous marginalization -- glio_set_scan_ahead, glio_marginalize_keep_async / _finish: the
+    #  same stream, the same numbers)
+    got_ah = window_io.run_demo_stream(path, search_range=2, ahead=True)
+    for key in ("iterations", "correspondences_kept", "batch_records_found", "batch_records_held", "last_trans", "last_quat", "trans_checksum"):
+        assert got_ah[key] == got_sd[key], key
     ctx = capi.Context(opts)
     ctx.localmap_config(50, 0.4, pts)
     tlb = np.array(opts.t_lb, np.float32)
