@@ -1,6 +1,6 @@
 #!/bin/bash
 # kernel timeline of the LAST keyframe cycle of the C++ stream demo (host_demo_stream, mode $1: 0 default / 1 deferred / 2 batch association after the
-# marginalization): every kernel and copy with start offset, duration and gap; GPU-busy time of the cycle
+# marginalization; further arguments go to the program, e.g. ahead=1): every kernel and copy with start offset, duration and gap; GPU-busy time of the cycle
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 MODE=${1:-2}
@@ -19,7 +19,7 @@ window_io.write_stream("/tmp/stream_tl.bin", long, wins, W, NK, pts)
 window_io.build_demo_stream()
 PY
 OUT=/tmp/stl_cpp; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT -o tl -- glio_amd/host/host_demo_stream /tmp/stream_tl.bin 0 6 $MODE > /tmp/stl_cpp.log 2>&1
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT -o tl -- glio_amd/host/host_demo_stream /tmp/stream_tl.bin 0 6 $MODE "${@:2}" > /tmp/stl_cpp.log 2>&1
 f=$(find $OUT -name "*kernel_trace.csv" | head -1)
 m=$(find $OUT -name "*memory_copy_trace.csv" | head -1)
 python - "$f" "$m" <<'PY'
