@@ -433,7 +433,8 @@ def main():
             line["whole_function_per_keyframe"] = {
                 "keyframes_per_s": cppk["keyframes_per_s"], "cycle_ms": cppk["cycle_ms"], "stages_ms": cppk["stages_ms"], "host": "C++ (glio_backend.hpp + glio_batch_backend.hpp)",
                 "what": "slide + new scan, device local map, association of all W slots, factor tables, solve, marginalization, batchFeatureAssociation (12 keyframe pairs + selection); "
-                        "back-to-back calls, the next keyframe's cloud sent to the device during the call's tail (cycle_ms_each_call_uploads_its_own_scan: without)",
+                        "back-to-back calls, the next keyframe's cloud sent to the device and the next call's local map built during the call's tail "
+                        "(cycle_ms_each_call_uploads_its_own_scan: without)",
                 "cycle_ms_each_call_uploads_its_own_scan": (cppk.get("each_call_uploads_its_own_scan") or {}).get("cycle_ms"),
                 "cpu_port_same_keyframe_ms": ((pipeline_info or {}).get("cpu_same_keyframe") or {}).get("ms"),
                 "solve_only_share_of_the_cycle": round(ms_per_step / cppk["cycle_ms"], 3)}
@@ -905,15 +906,17 @@ def bench_keyframe_stream_cpp(local_rank, W, pts, py_info, n_keyframes=8, seed=N
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "stream.bin")
         window_io.write_stream(path, long, wins, W, n_keyframes, pts)
-        # the headline: back-to-back keyframe calls with the NEXT keyframe's cloud sent to the device during the call's tail (glio_set_scan_ahead beside the
-        # asynchronous marginalization: GLIO's front end holds the cloud before the back end is called); `each_call_uploads_its_own_scan`: without that
-        runs = [window_io.run_demo_stream(path, device=local_rank, ahead=True) for _ in range(2)]
+        # the headline: back-to-back keyframe calls with the NEXT keyframe's cloud sent to the device and the next call's local map built during the call's tail
+        # (glio_set_scan_ahead + glio_localmap_push_scan_ahead_and_build beside the asynchronous marginalization: GLIO's front end holds the cloud, and the new
+        # keyframe's initial pose follows from this call's solve, before the back end is called again); `each_call_uploads_its_own_scan`: without any of that
+        runs = [window_io.run_demo_stream(path, device=local_rank, ahead=True, map_ahead=True) for _ in range(2)]
         plain = [window_io.run_demo_stream(path, device=local_rank) for _ in range(2)]
         deferred = [window_io.run_demo_stream(path, device=local_rank, defer=True) for _ in range(2)]
     out = min(runs, key=lambda r: r["cycle_ms"])
     pln = min(plain, key=lambda r: r["cycle_ms"])
     dfr = min(deferred, key=lambda r: r["cycle_ms"])
     out["next_scan_sent_ahead"] = True
+    out["next_local_map_built_ahead"] = True
     out["each_call_uploads_its_own_scan"] = {"cycle_ms": pln["cycle_ms"], "keyframes_per_s": pln["keyframes_per_s"], "stages_ms": pln["stages_ms"],
                                              "same_results": bool(pln["iterations"] == out["iterations"] and pln["correspondences_kept"] == out["correspondences_kept"]
                                                                   and pln["trans_checksum"] == out["trans_checksum"])}
@@ -949,13 +952,16 @@ def bench_released_config(local_rank, n_fill=50, timed=8, pts=4096, seed=None):
         path = os.path.join(td, "released.bin")
         window_io.write_stream(path, long, wins, W, NK, pts, lm_width=50, leaf=0.4)
         env = dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local_rank)))
-        window_io.run_demo_stream(path, device=0, env=env, search_range=6, feature_res_num=100, timed=timed, ahead=True)     # clocks and first touches
-        got = window_io.run_demo_stream(path, device=0, env=env, search_range=6, feature_res_num=100, timed=timed, ahead=True)
-        got["next_scan_sent_ahead"] = True
+        window_io.run_demo_stream(path, device=0, env=env, search_range=6, feature_res_num=100, timed=timed, ahead=True, map_ahead=True)     # clocks and first touches
+        got = window_io.run_demo_stream(path, device=0, env=env, search_range=6, feature_res_num=100, timed=timed, ahead=True, map_ahead=True)
+        got["next_scan_sent_ahead"] = True; got["next_local_map_built_ahead"] = True
+        plain = window_io.run_demo_stream(path, device=0, env=env, search_range=6, feature_res_num=100, timed=timed)
+        got["each_call_uploads_its_own_scan_cycle_ms"] = plain["cycle_ms"]
     return {"workload": f"config_urban_hk.yaml: W = 5, feature_res_num 100 (random_select), {pts} surf points per scan, local map of 50 keyframes at 0.4 m "
                         f"({got['map_points']} points), search_range 6, batch_feature_res_num 25, no GNSS; {n_fill} keyframes fill the map, the last {timed} are timed",
             "host": "C++ (host_demo_stream res=100)", "window": W, "cycle_ms": got["cycle_ms"], "cycle_ms_min_max": got["cycle_ms_min_max"], "solve_ms": got["stages_ms"]["solve"],
             "stages_ms": got["stages_ms"], "keyframes_per_s": got["keyframes_per_s"], "iterations": got["iterations"][-timed:],
+            "next_scan_and_local_map_sent_ahead": True, "cycle_ms_each_call_uploads_its_own_scan": got["each_call_uploads_its_own_scan_cycle_ms"],
             "lidar_residuals_per_solve": got["correspondences_kept"][-timed:], "batch_records_held": got["batch_records_held"][-1] if got["batch_records_held"] else 0,
             "paper_first_stage_ms_unstated_pc": 30.0,
             "paper_note": "BASELINE.md: ~30 ms per frame for the first (sliding-window) stage, paper p.9, hardware unstated -- context only"}

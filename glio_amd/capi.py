@@ -145,6 +145,13 @@ class Context:
     def set_scan(self, slot, scan):
         _check(load().glio_set_scan(self._h, slot, T.fptr(scan), len(scan)))
 
+    def localmap_push_scan_ahead_and_build(self, lidar_offset, q, t):
+        """behind set_scan_ahead: the next call's local map (the cloud just sent, at the new keyframe's pose) on the upload stream; returns the map size"""
+        off = np.ascontiguousarray(lidar_offset, np.float32); q = np.ascontiguousarray(q, float); t = np.ascontiguousarray(t, float)
+        n = C.c_int()
+        _check(load().glio_localmap_push_scan_ahead_and_build(self._h, T.fptr(off), T.dptr(q), T.dptr(t), C.byref(n)))
+        return n.value
+
     def set_scan_ahead(self, scan):
         """the NEXT keyframe's scan into the ring row that is slot W - 1 after the next slide_window() (the current slot 0's scan is gone afterwards)"""
         _check(load().glio_set_scan_ahead(self._h, T.fptr(scan), len(scan)))

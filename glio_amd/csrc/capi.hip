@@ -421,6 +421,27 @@ int glio_set_scan_ahead_strided(glio_ctx* c, const void* scan, int n, int stride
     c->h_scan_count[0] = 0;                                  // (slot 0's scan is gone)
     return GLIO_OK;
 }
+// ... and the local map of the next keyframe's call, built during this one's tail too: the cloud glio_set_scan_ahead has just sent, pushed at the pose the caller
+// has for the new keyframe (its initial pose follows from this call's solve and the odometry: known once the solve has returned), voxel grid, K1 -- all on the
+// upload stream, beside the marginalization and the batch association (none of them reads the map).  The next call then makes no glio_localmap_push_scan /
+// glio_localmap_build: its glio_slide_window waits for the event and the association finds the map.
+int glio_localmap_push_scan_ahead_and_build(glio_ctx* c, const float lidar_offset[3], const double q[4], const double t[3], int* out_points) {
+    if (!c) return GLIO_E_ARG;
+    CtxExtra* ex = extra_of(c);
+    if (!ex->ahead_valid || !ex->up_stream) { glio_set_error("glio_set_scan_ahead first"); return GLIO_E_STATE; }
+    GLIO_HIP_CHECK(hipSetDevice(c->device));
+    // the local map's and K1's launches go where c->stream points: for the length of this call that is the upload stream; slot 0's row holds the new scan
+    hipStream_t own = c->stream;
+    const int n0 = c->h_scan_count[0];
+    c->stream = ex->up_stream; c->h_scan_count[0] = ex->ahead_n;
+    int rc = glio_localmap_push_scan(c, 0, lidar_offset, q, t);
+    if (rc == GLIO_OK) rc = glio_localmap_build(c, out_points);
+    hipError_t e = hipEventRecord(ex->ev_ahead, ex->up_stream);          // (replaces the scan's own event: the next slide waits for scan, presort, map and K1)
+    c->stream = own; c->h_scan_count[0] = n0;
+    if (rc != GLIO_OK) return rc;
+    GLIO_HIP_CHECK(e);
+    return GLIO_OK;
+}
 int glio_associate_resident(glio_ctx* c, int slot, const double q[4], const double t[3], int* out_count) {
     GLIO_TRACE("K2 glio_associate_resident");
     if (!c || slot < 0 || slot >= c->W) return GLIO_E_ARG;

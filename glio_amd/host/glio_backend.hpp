@@ -348,6 +348,14 @@ public:
     // the NEXT keyframe's cloud, sent during this keyframe's call (after the solve): the next call's slideWindow() finds it in slot W - 1 and makes no setScan()
     void setScanAhead(const float* scan_xyzi, int n) { check(glio_set_scan_ahead(ctx_, scan_xyzi, n), "glio_set_scan_ahead"); }
     void setScanAhead(const void* points, int n, PointLayout l) { check(glio_set_scan_ahead_strided(ctx_, points, n, l.stride_bytes, l.intensity_offset), "glio_set_scan_ahead_strided"); }
+    // ... and the next call's local map behind it (the cloud just sent ahead pushed at the new keyframe's pose, the ring map and its search structure rebuilt): the
+    // next call makes no pushScanAndBuildLocalMap()
+    int pushScanAheadAndBuildLocalMap(const float lidar_offset[3], const double q[4], const double t[3]) {
+        int pts = 0;
+        check(glio_localmap_push_scan_ahead_and_build(ctx_, lidar_offset, q, t, &pts), "glio_localmap_push_scan_ahead_and_build");
+        map_points_ = pts;
+        return pts;
+    }
     // buildLocalMapWithLandMark + downSampleCloud (Estimator.cpp:3529-3631) on the device: push the new keyframe's cloud
     // (body frame) with its pose, rebuild the voxel-averaged ring map and its search structure; returns the map size
     void configureLocalMap(int width, float leaf, int max_points_per_keyframe) {

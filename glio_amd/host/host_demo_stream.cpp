@@ -83,7 +83,9 @@ int main(int argc, char** argv) {
         // ahead=1: the NEXT keyframe's cloud goes to the device during this keyframe's call, beside the marginalization (glio_set_scan_ahead: the front end has
         // the cloud before the back end is called, Estimator.cpp:5372ff); the next call's slide finds it in slot W - 1.  ahead=0: every call uploads its own.
         bool ahead = false;
-        bool have_ahead = false;
+        bool have_ahead = false, have_map_ahead = false;
+        // map_ahead=1 (with ahead=1): the next call's local map is built during this call's tail too (glio_localmap_push_scan_ahead_and_build)
+        bool map_ahead = false;
         // sleep_ms=N: the host sleeps N ms inside every keyframe call (a 10 Hz caller leaves the GPU idle for ~100 ms between calls; the sleep is not part of
         // any stage time).  sleep_at: 0 = between the batch association's preparation and the solve, 1 = before the call's first entry point, 2 = between the solve and
         // the batch association's enqueue
@@ -97,6 +99,7 @@ int main(int argc, char** argv) {
             else if (!strncmp(argv[a], "stream_draws=", 13)) host_draws = atoi(argv[a] + 13) == 0;
             else if (!strncmp(argv[a], "prepare_early=", 14)) prepare_early = atoi(argv[a] + 14) != 0;
             else if (!strncmp(argv[a], "ahead=", 6)) ahead = atoi(argv[a] + 6) != 0;
+            else if (!strncmp(argv[a], "map_ahead=", 10)) map_ahead = atoi(argv[a] + 10) != 0;
             else if (!strncmp(argv[a], "sleep_ms=", 9)) sleep_ms = atoi(argv[a] + 9);
             else if (!strncmp(argv[a], "sleep_at=", 9)) sleep_at = atoi(argv[a] + 9);
             else if (!strncmp(argv[a], "draws=", 6)) {
@@ -141,7 +144,8 @@ int main(int argc, char** argv) {
             // deferred variant the previous keyframe's searches are still in flight on that store's stream, and the copy is made once they were collected
             if (!defer) ba.setFrameFromScan(nw, be.ctx(), W - 1, tlb);
             const double t1 = now_s();
-            map_pts = be.pushScanAndBuildLocalMap(W - 1, tlb, &gtq[4 * nw], &gtt[3 * nw]);
+            if (!have_map_ahead) map_pts = be.pushScanAndBuildLocalMap(W - 1, tlb, &gtq[4 * nw], &gtt[3 * nw]);
+            have_map_ahead = false;
             const double t2 = now_s();
             be.findCorrespondingSurfFeaturesWindowAsync();
             const double t3 = now_s();
@@ -179,6 +183,7 @@ int main(int argc, char** argv) {
                 be.marginalizeAndKeepAsync(&ddt);
                 be.setScanAhead(scans[nw + 1].data(), pts);             // (the host would only wait for the marginalization here)
                 have_ahead = true;
+                if (map_ahead) { map_pts = be.pushScanAheadAndBuildLocalMap(tlb, &gtq[4 * (nw + 1)], &gtt[3 * (nw + 1)]); have_map_ahead = true; }
                 be.marginalizeFinish();
             } else be.marginalizeAndKeep(&ddt);
             const double t6 = now_s();

@@ -163,7 +163,7 @@ def write_stream(path, long, wins, W, n_keyframes, pts, lm_width=50, leaf=0.4, b
                 f.write(bytes(d))
 
 
-def run_demo_stream(path, device=0, env=None, search_range=6, defer=False, feature_res_num=0, draws=None, timed=None, per_slot=False, sleep_ms=0, sleep_at=0, stream_draws=True, prepare_early=True, ahead=False):
+def run_demo_stream(path, device=0, env=None, search_range=6, defer=False, feature_res_num=0, draws=None, timed=None, per_slot=False, sleep_ms=0, sleep_at=0, stream_draws=True, prepare_early=True, ahead=False, map_ahead=False):
     """feature_res_num > 0: featureSelection behind every slot's search (Estimator.cpp:2223); draws: file of uint64 both hosts draw from (sliding.TableRng);
     timed: only the last `timed` keyframes enter the time averages"""
     import json
@@ -183,6 +183,8 @@ def run_demo_stream(path, device=0, env=None, search_range=6, defer=False, featu
         cmd.append("prepare_early=0")
     if ahead:
         cmd.append("ahead=1")
+    if map_ahead:
+        cmd.append("map_ahead=1")
     r = subprocess.run(cmd, capture_output=True, text=True, env=env)
     if r.returncode != 0:
         raise RuntimeError("host_demo_stream failed (%d): %s" % (r.returncode, (r.stderr or r.stdout)[-600:]))

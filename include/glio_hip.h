@@ -99,6 +99,10 @@ int glio_set_scan_strided(glio_ctx* ctx, int slot, const void* scan_points, int 
  * call then makes no glio_set_scan for slot W - 1.  Returns when the caller's buffer has been read. */
 int glio_set_scan_ahead(glio_ctx* ctx, const float* scan_xyzi, int n);
 int glio_set_scan_ahead_strided(glio_ctx* ctx, const void* scan_points, int n, int stride_bytes, int intensity_offset);
+/* ... and, behind it, the next call's local map: glio_localmap_push_scan of the cloud just sent ahead at the new keyframe's pose + glio_localmap_build, on the same
+ * stream beside the call's tail (the new keyframe's initial pose follows from this call's solve and the odometry: buildLocalMapWithLandMark pushes each keyframe
+ * once, at the pose it has when it arrives, Estimator.cpp:3585-3616).  The next call then makes neither call; its glio_slide_window waits for the event. */
+int glio_localmap_push_scan_ahead_and_build(glio_ctx* ctx, const float lidar_offset[3], const double q[4], const double t[3], int* out_points);
 int glio_associate_resident(glio_ctx* ctx, int slot, const double q[4], const double t[3], int* out_count);
 /* Slide the window by one keyframe: the resident scan of slot s+1 becomes that of slot s (the scans are a ring on the device: nothing is
  * copied, nothing waited for); slot W-1 is free for the new keyframe's glio_set_scan.  (surf_frames / keyframe_idx bookkeeping of

@@ -175,3 +175,35 @@ def test_ordered_output_by_bitmap_rank_and_by_radix_sort(stream):
         ctx.close()
     for a, b in zip(*results):
         assert np.array_equal(a, b)
+
+
+def test_map_built_ahead_on_the_upload_stream_is_the_same_map(stream):
+    """glio_set_scan_ahead + glio_localmap_push_scan_ahead_and_build (the next keyframe's cloud and the next call's local map during this call's tail, on the upload
+    stream; the next glio_slide_window takes both over) against the plain order (slide, glio_set_scan, glio_localmap_push_scan, glio_localmap_build): the same map,
+    byte for byte, keyframe after keyframe, and the same association against it."""
+    from glio_amd import capi
+    win, clouds = stream
+    W = 3
+    o = synth.default_opts(W, pts=8192, map_pts=1 << 17)
+    tlb = np.array(win.opts.t_lb, np.float32)
+    a, b = capi.Context(o), capi.Context(o)
+    for c in (a, b):
+        c.localmap_config(4, 0.4, 8192)
+    for s in range(win.W):
+        q, t = win.gt.quat[s], win.gt.trans[s]
+        if s > 0:
+            a.slide_window(); b.slide_window()            # (b: takes the scan and the map sent ahead)
+        a.set_scan(W - 1, win.scans[s])
+        a.localmap_push_scan(W - 1, tlb, q, t)
+        na = a.localmap_build()
+        if s == 0:
+            b.set_scan(W - 1, win.scans[s]); b.localmap_push_scan(W - 1, tlb, q, t); nb = b.localmap_build()
+        assert na == nb and np.array_equal(a.localmap_read(), b.localmap_read()), f"keyframe {s}"
+        pose = capi.lidar_pose(win.opts, q, t)
+        ca, cb = a.associate_resident(W - 1, *pose), b.associate_resident(W - 1, *pose)
+        assert ca == cb and ca > 100
+        assert all(np.array_equal(x, y) for x, y in zip(a.get_correspondences(W - 1), b.get_correspondences(W - 1)))
+        if s + 1 < win.W:                                  # during "the tail": the next keyframe's scan, then its map
+            b.set_scan_ahead(win.scans[s + 1])
+            nb = b.localmap_push_scan_ahead_and_build(tlb, win.gt.quat[s + 1], win.gt.trans[s + 1])
+    a.close(); b.close()

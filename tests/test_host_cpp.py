@@ -148,8 +148,10 @@ def test_cpp_keyframe_stream_equals_the_python_driver(tmp_path):
     # (the next keyframe's cloud sent during the call, beside an asynchronous marginalization -- glio_set_scan_ahead, glio_marginalize_keep_async / _finish: the
     #  same stream, the same numbers)
     got_ah = window_io.run_demo_stream(path, search_range=2, ahead=True)
-    for key in ("iterations", "correspondences_kept", "batch_records_found", "batch_records_held", "last_trans", "last_quat", "trans_checksum"):
+    got_ma = window_io.run_demo_stream(path, search_range=2, ahead=True, map_ahead=True)      # ... and the next call's local map built during the tail too
+    for key in ("iterations", "correspondences_kept", "batch_records_found", "batch_records_held", "last_trans", "last_quat", "trans_checksum", "map_points"):
         assert got_ah[key] == got_sd[key], key
+        assert got_ma[key] == got_sd[key], key
     ctx = capi.Context(opts)
     ctx.localmap_config(50, 0.4, pts)
     tlb = np.array(opts.t_lb, np.float32)
