@@ -1,4 +1,4 @@
-"""host_demo_stream on the C2 stream, N runs of one mode (SCO_MODE = default | host_draws | deferred): cycle and the slowest instance of every stage (stage_max_ms)."""
+"""host_demo_stream on the C2 stream, N runs of one mode (SCO_MODE = default | host_draws | deferred | ahead | map_ahead): cycle and the slowest instance of every stage (stage_max_ms)."""
 import json, os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from glio_amd import synth
@@ -10,7 +10,7 @@ opts = wins[0].opts
 opts.max_ddt_epochs = max(w.init.n_ddt for w in wins) + 8
 opts.max_map_points = 1 << 18
 mode = os.environ.get("SCO_MODE", "default")
-kw = {"default": {}, "host_draws": {"stream_draws": False}, "deferred": {"defer": True}}[mode]
+kw = {"default": {}, "host_draws": {"stream_draws": False}, "deferred": {"defer": True}, "ahead": {"ahead": True}, "map_ahead": {"ahead": True, "map_ahead": True}}[mode]
 with tempfile.TemporaryDirectory() as td:
     path = os.path.join(td, "s.bin")
     window_io.write_stream(path, long, wins, W, NK, pts)

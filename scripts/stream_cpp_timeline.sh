@@ -9,7 +9,7 @@ import os, sys
 sys.path.insert(0, ".")
 from glio_amd import synth
 from glio_amd.host import window_io
-W, pts, NK = 20, 65536, 4
+W, pts, NK = 20, 65536, 6
 long = synth.make_window(W=W + NK, pts_per_scan=pts, with_gnss=True, with_prior=False, seed=synth.SEED_BASE + 12)
 wins = [synth.sub_window(long, j, W) for j in range(NK + 1)]
 opts = wins[0].opts
